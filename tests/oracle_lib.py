@@ -1,0 +1,272 @@
+"""ctypes binding of the CPU oracle (oracle/libcanvas_oracle.so).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by canvas_amd/."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "libcanvas_oracle.so")
+
+CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD, CLEAN_LOESS = 1, 2, 4, 8, 16
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    lib.orc_bin_rate.restype = C.c_double
+    lib.orc_bin_chromosome.restype = C.c_int64
+    lib.orc_clean.restype = C.c_int64
+    lib.orc_median_f32.restype = C.c_float
+    lib.orc_golden_section_square.restype = C.c_double
+    lib.orc_golden_section_square.argtypes = [C.c_double, C.c_double]
+    lib.orc_tailp.restype = C.c_double
+    lib.orc_tailp.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
+    lib.orc_htmaxp.restype = C.c_double
+    lib.orc_tmaxp.restype = C.c_double
+    lib.orc_phyper.restype = C.c_double
+    lib.orc_phyper.argtypes = [C.c_double] * 4
+    lib.orc_trimmed_variance.restype = C.c_double
+    return lib
+
+
+lib = _load()
+
+
+def _p(a, t=None):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _pp(arrs):
+    """array of pointers to numpy arrays"""
+    T = C.c_void_p * len(arrs)
+    return T(*[a.ctypes.data for a in arrs])
+
+
+def bin_rate(hits, mask):
+    return lib.orc_bin_rate(_p(hits), _p(mask), C.c_int64(len(hits)))
+
+
+def bin_size(rates, counts_per_bin):
+    r = np.ascontiguousarray(rates, dtype=np.float64)
+    return lib.orc_bin_size(_p(r), len(r), counts_per_bin)
+
+
+def bin_chromosome(bases, mask, hits, bin_size, mode=3):
+    L = len(bases)
+    cap = L // max(1, bin_size) + 2
+    out = [np.zeros(cap, np.int32) for _ in range(4)]
+    n = lib.orc_bin_chromosome(_p(bases), _p(mask), _p(hits), C.c_int64(L), bin_size, mode, C.c_int64(cap), *[_p(o) for o in out])
+    return [o[:n].copy() for o in out]
+
+
+def bin_genome(bases, masks, hits, bin_size, mode=3, threads=1):
+    nchr = len(bases)
+    lens = np.array([len(b) for b in bases], np.int64)
+    caps = lens // max(1, bin_size) + 2
+    outs = [[np.zeros(int(c), np.int32) for c in caps] for _ in range(4)]
+    nb = np.zeros(nchr, np.int64)
+    lib.orc_bin_genome(nchr, _pp(bases), _pp(masks), _pp(hits), _p(lens), bin_size, mode, _p(caps),
+                       _pp(outs[0]), _pp(outs[1]), _pp(outs[2]), _pp(outs[3]), _p(nb), threads)
+    return [[outs[k][c][:nb[c]] for c in range(nchr)] for k in range(4)]
+
+
+def bin_rates_genome(masks, hits, threads=1):
+    nchr = len(masks)
+    lens = np.array([len(h) for h in hits], np.int64)
+    rates = np.zeros(nchr, np.float64)
+    lib.orc_bin_rates_genome(nchr, _pp(masks), _pp(hits), _p(lens), _p(rates), threads)
+    return rates
+
+
+def clean(chr_id, start, stop, count, gc, is_auto, is_y, flags, min_bins_weighted=100):
+    chr_id, start, stop, gc = [np.array(a, np.int32) for a in (chr_id, start, stop, gc)]
+    count = np.array(count, np.float32)
+    is_auto = np.ascontiguousarray(is_auto, np.uint8)
+    is_y = np.ascontiguousarray(is_y, np.uint8)
+    local_sd = C.c_double(-1.0)
+    stages = np.zeros(8, np.int32)
+    n = lib.orc_clean(C.c_int64(len(chr_id)), _p(chr_id), _p(start), _p(stop), _p(count), _p(gc), len(is_auto), _p(is_auto), _p(is_y),
+                      C.c_uint32(flags), min_bins_weighted, C.byref(local_sd), _p(stages))
+    return dict(chr=chr_id[:n], start=start[:n], stop=stop[:n], count=count[:n], gc=gc[:n], local_sd=local_sd.value, stages=stages)
+
+
+def _fmt(fn, v):
+    buf = C.create_string_buffer(64)
+    fn(v, buf, 64)
+    return buf.value.decode()
+
+
+def format_f2(v):
+    return _fmt(lib.orc_format_f2, C.c_float(v))
+
+
+def format_g15(v):
+    return _fmt(lib.orc_format_g15, C.c_double(v))
+
+
+def format_g7(v):
+    return _fmt(lib.orc_format_g7, C.c_float(v))
+
+
+def quartiles(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(3, np.float32)
+    lib.orc_quartiles(_p(x), len(x), _p(out))
+    return out
+
+
+def median_f32(x):
+    x = np.ascontiguousarray(x, np.float32)
+    return lib.orc_median_f32(_p(x), len(x))
+
+
+def loess_fit(x, y, bandwidth, rob_iters, x_step):
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    fitted = np.zeros_like(x); pred = np.zeros_like(x)
+    lib.orc_loess_fit(_p(x), _p(y), len(x), C.c_double(bandwidth), rob_iters, C.c_double(x_step), _p(fitted), _p(pred))
+    return fitted, pred
+
+
+def negbin(mean, variance, max_value):
+    out = np.zeros(max_value, np.float64)
+    lib.orc_negbin(C.c_double(mean), C.c_double(variance), max_value, _p(out))
+    return out
+
+
+def genotype_combos(n_states, cur):
+    out = np.zeros(4096, np.int32)
+    n = lib.orc_genotype_combos(n_states, cur, _p(out), 4096)
+    w = min(n_states, 4)
+    return out[: n * w].reshape(n, w).tolist()
+
+
+def hmm_global_params(cov):
+    n = np.array([len(c) for c in cov], np.int64)
+    med = C.c_double(); pv = C.c_double()
+    lib.orc_hmm_global_params(len(cov), _pp(cov), _p(n), C.byref(med), C.byref(pv))
+    return med.value, pv.value
+
+
+def hmm_chromosome(cov_samples, per_sample, medians=None, pvs=None):
+    S = len(cov_samples); T = len(cov_samples[0])
+    path = np.full(T, -9, np.int32)
+    m = np.ascontiguousarray(medians if medians is not None else np.zeros(S), np.float64)
+    v = np.ascontiguousarray(pvs if pvs is not None else np.zeros(S), np.float64)
+    ran = lib.orc_hmm_chromosome(S, int(per_sample), _pp(cov_samples), T, _p(m) if medians is not None else None,
+                                 _p(v) if pvs is not None else None, _p(path))
+    return ran, path
+
+
+def hmm_genome_per_sample(cov, threads=1):
+    n = np.array([len(c) for c in cov], np.int64)
+    paths = [np.full(len(c), -9, np.int32) for c in cov]
+    ran = np.zeros(len(cov), np.int32)
+    lib.orc_hmm_genome_per_sample(len(cov), _pp(cov), _p(n), _pp(paths), _p(ran), threads)
+    return paths, ran
+
+
+def segments_from_path(path, ran, start, end):
+    T = len(path)
+    ss = np.zeros(T + 1, np.uint32); se = np.zeros(T + 1, np.uint32)
+    n = lib.orc_segments_from_path(_p(path), T, int(ran), _p(start), _p(end), _p(ss), _p(se))
+    return ss[:n].copy(), se[:n].copy()
+
+
+def split_overlapping(starts, ends):
+    S = len(starts)
+    nseg = np.array([len(s) for s in starts], np.int32)
+    cap = 2 * int(nseg.sum()) + 2
+    os_ = np.zeros(cap, np.uint32); oe = np.zeros(cap, np.uint32)
+    n = lib.orc_split_overlapping(S, _pp(starts), _pp(ends), _p(nseg), _p(os_), _p(oe), cap)
+    return os_[:n].copy(), oe[:n].copy()
+
+
+def postprocess(bin_start, bin_end, seg_start, excl=None, max_inter_bin_dist=1000000):
+    nchr = len(bin_start)
+    nb = np.array([len(b) for b in bin_start], np.int64)
+    nseg = np.array([len(s) for s in seg_start], np.int32)
+    seg_id = [np.zeros(len(b), np.int32) for b in bin_start]
+    if excl is None:
+        last = lib.orc_postprocess(nchr, _p(nb), _pp(bin_start), _pp(bin_end), _p(nseg), _pp(seg_start), None, None, None,
+                                   max_inter_bin_dist, _pp(seg_id))
+    else:
+        es = [np.ascontiguousarray(e[0], np.int32) for e in excl]; ee = [np.ascontiguousarray(e[1], np.int32) for e in excl]
+        ne = np.array([len(e) for e in es], np.int32)
+        last = lib.orc_postprocess(nchr, _p(nb), _pp(bin_start), _pp(bin_end), _p(nseg), _pp(seg_start), _p(ne), _pp(es), _pp(ee),
+                                   max_inter_bin_dist, _pp(seg_id))
+    return seg_id, last
+
+
+_SBDRY = {}
+
+
+def cbs_boundary(n_perm=10000, alpha=0.01, eta=0.05):
+    key = (n_perm, alpha, eta)
+    if key not in _SBDRY:
+        cap = 8192 * 8
+        out = np.zeros(cap, np.uint32)
+        n = lib.orc_cbs_boundary(C.c_uint32(n_perm), C.c_double(alpha), C.c_double(eta), _p(out), cap)
+        _SBDRY[key] = out[:n].copy()
+    return _SBDRY[key]
+
+
+def tmaxo(x, al0=2):
+    x = np.ascontiguousarray(x, np.float64)
+    tss = float(np.sum(x * x))
+    sx = np.zeros_like(x); iseg = np.zeros(2, np.int32); ostat = C.c_double()
+    lib.orc_tmaxo(_p(x), len(x), C.c_double(tss), _p(sx), _p(iseg), C.byref(ostat), al0)
+    return ostat.value, iseg, sx
+
+
+def htmaxp(px, tss, k=25, al0=2):
+    px = np.ascontiguousarray(px, np.float64); sx = np.zeros_like(px)
+    return lib.orc_htmaxp(k, C.c_double(tss), _p(px), len(px), _p(sx), al0)
+
+
+def tmaxp(px, tss, al0=2):
+    px = np.ascontiguousarray(px, np.float64); sx = np.zeros_like(px)
+    return lib.orc_tmaxp(C.c_double(tss), _p(px), len(px), _p(sx), al0)
+
+
+def mt_u32(seed, n):
+    out = np.zeros(n, np.uint32)
+    lib.orc_mt_u32(C.c_uint32(seed), n, _p(out))
+    return out
+
+
+def cbs_seeds(nchr):
+    s = np.zeros(nchr, np.int32)
+    lib.orc_cbs_seeds(nchr, _p(s))
+    return s
+
+
+def xperm(x, seed, skip=0):
+    x = np.ascontiguousarray(x, np.float64); px = np.zeros_like(x)
+    lib.orc_xperm(_p(x), _p(px), len(x), C.c_uint32(seed & 0xFFFFFFFF), skip)
+    return px
+
+
+def cbs_chromosome(x, seed, sbdry=None, alpha=0.01, n_perm=10000, undo=0, trimmed_sd=1.0):
+    x = np.ascontiguousarray(x, np.float64)
+    sb = cbs_boundary(n_perm, alpha) if sbdry is None else sbdry
+    cap = len(x) + 1
+    ls = np.zeros(cap, np.int32); stats = np.zeros(7, np.int64)
+    n = lib.orc_cbs_chromosome(_p(x), len(x), C.c_int32(int(seed)), _p(sb), len(sb), C.c_double(alpha), C.c_uint32(n_perm), undo,
+                               C.c_double(trimmed_sd), _p(ls), cap, _p(stats))
+    return ls[:n].copy(), stats
+
+
+def cbs_genome(xs, alpha=0.01, n_perm=10000, threads=1):
+    sb = cbs_boundary(n_perm, alpha)
+    n = np.array([len(x) for x in xs], np.int64)
+    caps = np.array([len(x) + 1 for x in xs], np.int32)
+    ls = [np.zeros(int(c), np.int32) for c in caps]
+    nseg = np.zeros(len(xs), np.int32); stats = np.zeros(7, np.int64)
+    lib.orc_cbs_genome(len(xs), _pp(xs), _p(n), _p(sb), len(sb), C.c_double(alpha), C.c_uint32(n_perm), _pp(ls), _p(caps), _p(nseg), _p(stats), threads)
+    return [l[:k].copy() for l, k in zip(ls, nseg)], stats

@@ -1,0 +1,126 @@
+"""Pins the CPU oracle against every known-answer vector the reference's own tests hold for the hot path
+(SURVEY.md §8c).  Fixtures under tests/golden/ are data extracted by tests/golden/make_golden.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_loess_matches_r_vectors():
+    # CanvasTest/TestLoessInterpolator.cs:13-81: sum |fitted - R loess| < 0.31 for 0 and 2 robustness iterations
+    d = json.load(open(os.path.join(G, "loess_r_vectors.json")))
+    fitted, pred = O.loess_fit(d["x"], d["y"], 0.3, 0, 0.01)
+    assert np.abs(np.array(d["fittedR"]) - fitted).sum() < d["tolerance_sum_abs"]
+    assert np.abs(np.array(d["fittedR"]) - pred).sum() < d["tolerance_sum_abs"]
+    # SURVEY §8c scratch value for this reading of the algorithm
+    assert abs(np.abs(np.array(d["fittedR"]) - fitted).sum() - 0.3047) < 5e-3
+    fitted2, _ = O.loess_fit(d["x"], d["y"], 0.3, 2, 0.01)
+    assert np.abs(np.array(d["weightedFittedR"]) - fitted2).sum() < d["tolerance_sum_abs"]
+
+
+@pytest.mark.parametrize("a,b", [(-5, 5), (0, 5), (-5, 0)])
+def test_golden_section_search(a, b):
+    # CanvasTest/TestUtilities.cs:33-41
+    assert abs(O.lib.orc_golden_section_square(a, b)) < 0.001
+
+
+def test_median_semantics():
+    # CanvasTest/TestUtilities.cs:195-206 (MedianFilter window medians): even length -> mean of middle two
+    v = [2, 1, 3, 5, 4, 6, 7, 8]
+    exp = [1.5, 2, 3, 4, 5, 6, 7, 7.5]
+    for i in range(len(v)):
+        w = v[max(0, i - 1): i + 2]
+        assert O.median_f32(w) == exp[i]
+
+
+def test_genotype_combinations():
+    # CanvasTest/DistributionUtilitiesTests.cs:10-36
+    assert O.genotype_combos(2, 1) == [[1, 1], [1, 2], [2, 1]]
+    assert O.genotype_combos(1, 1) == [[1]]
+    assert O.genotype_combos(3, 2) == [[2, 2, 2]]
+
+
+def test_negative_binomial_argmax():
+    # CanvasTest/DistributionUtilitiesTests.cs:38-48
+    d = O.negbin(50.0, 50.0, 200)
+    assert int(np.argmax(d)) == 49
+    assert abs(d.sum() - 1) < 1e-6
+
+
+def test_split_overlapping_segments():
+    # CanvasTest/CanvasPartition/GenomeSegmentationResultsTests.cs:14-248
+    cases = json.load(open(os.path.join(G, "split_overlapping_cases.json")))
+    assert len(cases) == 9
+    for c in cases:
+        for chrom, exp in c["expected"].items():
+            if len(c["samples"]) == 1:
+                got = c["samples"][0][chrom]   # single sample is returned as is (GenomeSegmentationResults.cs:20)
+            else:
+                st = [np.array([s[0] for s in smp[chrom]], np.uint32) for smp in c["samples"]]
+                en = [np.array([s[1] for s in smp[chrom]], np.uint32) for smp in c["samples"]]
+                a, b = O.split_overlapping(st, en)
+                got = [[int(x), int(y)] for x, y in zip(a, b)]
+            assert got == exp, c["name"]
+
+
+def test_postprocess_segments_reference_case():
+    # CanvasTest/CanvasPartition/SegmentationResultsProcessorTests.cs:10-95 (maxInterBinDist = 100)
+    bs = [np.array([100, 600, 1200, 1300, 4001, 5000], np.uint32)]
+    be = [np.array([500, 890, 1299, 4000, 4500, 5050], np.uint32)]
+    segs = [np.array([1, 1100, 4600], np.uint32)]
+    def groups(ids):
+        out = []
+        for i, k in enumerate(ids):
+            if not out or out[-1][0] != k:
+                out.append([k, int(bs[0][i]), int(be[0][i]), 1])
+            else:
+                out[-1][2] = max(out[-1][2], int(be[0][i])); out[-1][3] += 1
+        return [tuple(g[1:]) for g in out]
+    ids, _ = O.postprocess(bs, be, segs, None, 100)
+    # reference asserts 3 segments with (start, end, nbins): none of the bin starts equals a segment start, so the splits
+    # come from the inter-bin distance rule and the first segment keeps the initial counter value -1 (Q17)
+    assert groups(ids[0]) == [(100, 890, 2), (1200, 4500, 3), (5000, 5050, 1)]
+    assert ids[0].tolist() == [-1, -1, 0, 0, 0, 1]
+    # forbidden zone 525-575 (mid 550) between the first two bins splits the first segment
+    ids, _ = O.postprocess(bs, be, segs, [([525], [575])], 100)
+    assert groups(ids[0]) == [(100, 500, 1), (600, 890, 1), (1200, 4500, 3), (5000, 5050, 1)]
+    # mid = 610 inside the second bin: also counted as a new segment
+    ids, _ = O.postprocess(bs, be, segs, [([585], [635])], 100)
+    assert groups(ids[0]) == [(100, 500, 1), (600, 890, 1), (1200, 4500, 3), (5000, 5050, 1)]
+
+
+def test_partitioned_row_format():
+    # CanvasTest/TestSegments.cs:173-205 rows: chr, start, end, coverage, id; double.ToString() for the coverage column
+    assert O.format_g15(90.0) == "90"
+    assert O.format_g15(101.37) == "101.37"
+    assert O.format_g15(0.5) == "0.5"
+    assert O.format_g15(1e-7) == "1E-07"
+
+
+def test_f2_formatting():
+    # CanvasCommon/IO.cs:21 "{3:F2}" of a float under .NET Core 2.x (7 significant digits, then half-up at 2 decimals)
+    assert O.format_f2(90.0) == "90.00"
+    assert O.format_f2(100.125) == "100.13"
+    assert O.format_f2(np.float32(0.005)) == "0.01"
+    assert O.format_f2(np.float32(123456.789)) == "123456.80"  # 7 significant digits first
+    assert O.format_f2(np.float32(2.675)) == "2.68"            # float 2.675 = 2.67499995.. -> 7 digits 2.675000 -> 2.68
+    assert O.format_f2(0.0) == "0.00"
+
+
+def test_mt19937_matches_numpy():
+    # MT19937 core cross-check (same init_genrand as numpy RandomState): SURVEY §8c
+    rs = np.random.RandomState(12345)
+    raw = rs.randint(0, 2**32, size=2000, dtype=np.uint64).astype(np.uint32)
+    assert (O.mt_u32(12345, 2000) == raw).all()
+
+
+def test_phyper_against_scipy():
+    from scipy.stats import hypergeom
+    for (k, n1s, nperm, i) in [(0, 2, 10000, 100), (1, 5, 10000, 2000), (3, 50, 10000, 500), (10, 100, 10000, 1500)]:
+        ref = hypergeom.cdf(k, nperm, n1s, i)
+        assert abs(O.lib.orc_phyper(k, n1s, nperm - n1s, i) - ref) < 1e-12 * max(1.0, ref) + 1e-15
