@@ -1,0 +1,488 @@
+// CanvasBin merge step on MI355X: rates (CanvasBin.cs:30-83) and BinCountsForChromosome (CanvasBin.cs:568-661).
+//
+// Data layout in HBM (per chromosome, caller-owned): bases u8[L] (FASTA chars), hits u8[L] (HitArray.Data),
+// mask u64[ceil(L/64)] (BitArray layout: bit i -> word i>>6, bit i&63).
+//
+// Geometry: a *tile* is 4096 consecutive positions and is owned by one 64-lane wave (4 iterations x 1024 positions,
+// 16 positions = one 16-byte load per lane per array).  Tiles never span chromosomes.
+//
+// Kernels (all integer arithmetic => bit-identical to the reference by construction):
+//   k_find_pos0     first position whose base is not 'n' (CanvasBin.cs:582), multi-workgroup early-exit scan
+//   k_tile_stats    per tile: popcount(mask) and #(hit>0)                       [1.125 B/base; 0.125 when rates not needed]
+//   k_scan_tiles    per chromosome: exclusive scan of tile popcounts -> rank base per tile, #bins, chromosome totals
+//   k_bin_pass      THE hot kernel: per tile, SWAR over 16-byte groups, wave prefix scans of (possible, GC, clamped hits);
+//                   every lane that holds the binSize-th possible position of a bin writes that bin's stop and the
+//                   tile-local prefix sums at the boundary                       [2.125 B/base read, 12 B/bin written]
+//   k_scan_totals   per chromosome: exclusive scan of the per-tile totals (uint32 wrap-around arithmetic)
+//   k_bin_finalize  per bin: count = prefix(stop_k) - prefix(stop_{k-1}); gc = (int)(100f*GC/len) in float32 (Q4)
+// No atomics, no floating reduction: the prefix-difference formulation is deterministic.
+#include "common.hpp"
+#include <algorithm>
+
+#define TILE_SHIFT 12
+#define TILE 4096
+
+struct BinChrom {            // one per chromosome, in device memory
+    const uint8_t* bases;
+    const uint8_t* hits;
+    const uint64_t* mask;
+    int64_t len;
+    int64_t tileBase;         // first global tile index
+    int64_t ntiles;
+};
+
+__device__ __forceinline__ int find_chrom(const BinChrom* __restrict__ ch, int nchr, int64_t gtile) {
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (ch[mid].tileBase <= gtile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------- k_find_pos0
+__global__ void __launch_bounds__(256) k_find_pos0(const BinChrom* __restrict__ ch, unsigned long long* __restrict__ pos0) {
+    const int c = blockIdx.y;
+    const BinChrom C = ch[c];
+    const int64_t CHUNK = 256 * 16;
+    for (int64_t chunk = blockIdx.x; chunk * CHUNK < C.len; chunk += gridDim.x) {
+        int64_t start = chunk * CHUNK;
+        unsigned long long cur = __hip_atomic_load(&pos0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned long long)start >= cur) break;      // someone already found an earlier non-'n'
+        int64_t p = start + (int64_t)threadIdx.x * 16;
+        int found = 16;
+        if (p + 16 <= C.len) {
+            uint4 v = *reinterpret_cast<const uint4*>(C.bases + p);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 3; q >= 0; q--)
+#pragma unroll
+                for (int b = 3; b >= 0; b--) if (((w[q] >> (8 * b)) & 0xFF) != 'n') found = q * 4 + b;
+        } else {
+            for (int i = 15; i >= 0; i--) if (p + i < C.len && C.bases[p + i] != 'n') found = i;
+        }
+        unsigned long long cand = found < 16 ? (unsigned long long)(p + found) : ~0ull;
+        // workgroup min
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { unsigned long long o = __shfl_xor(cand, d, 64); cand = o < cand ? o : cand; }
+        __shared__ unsigned long long smin[4];
+        if (lane_id() == 0) smin[threadIdx.x >> 6] = cand;
+        __syncthreads();
+        unsigned long long m = smin[0];
+        for (int i = 1; i < 4; i++) m = smin[i] < m ? smin[i] : m;
+        __syncthreads();
+        if (m != ~0ull) { if (threadIdx.x == 0) atomicMin(&pos0[c], m); break; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- k_tile_stats
+__device__ __forceinline__ uint32_t nonzero_bytes4(uint32_t w) {
+    uint32_t z = ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;  // 0x80 where byte == 0
+    return 4u - __popc(z);
+}
+
+__global__ void __launch_bounds__(256) k_tile_stats(const BinChrom* __restrict__ ch, int nchr, int64_t ntilesTotal, int wantObs,
+                                                    uint32_t* __restrict__ tilePop, uint32_t* __restrict__ tileObs) {
+    const int64_t gtile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gtile >= ntilesTotal) return;
+    const int c = find_chrom(ch, nchr, gtile);
+    const BinChrom C = ch[c];
+    const int64_t tileStart = (gtile - C.tileBase) << TILE_SHIFT;
+    const int l = lane_id();
+    // mask: one 64-bit word per lane
+    int64_t wstart = tileStart + (int64_t)l * 64;
+    uint32_t pop = 0;
+    if (wstart < C.len) {
+        uint64_t w = C.mask[wstart >> 6];
+        int64_t valid = C.len - wstart;
+        if (valid < 64) w &= (~0ull) >> (64 - valid);
+        pop = __popcll(w);
+    }
+    pop = wave_reduce_add_u32(pop);
+    uint32_t obs = 0;
+    if (wantObs) {
+        if (tileStart + TILE <= C.len) {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                uint4 v = *reinterpret_cast<const uint4*>(C.hits + tileStart + it * 1024 + l * 16);
+                obs += nonzero_bytes4(v.x) + nonzero_bytes4(v.y) + nonzero_bytes4(v.z) + nonzero_bytes4(v.w);
+            }
+        } else {
+            for (int64_t p = tileStart + l; p < C.len; p += 64) obs += C.hits[p] > 0;
+        }
+        obs = wave_reduce_add_u32(obs);
+    }
+    if (l == 0) { tilePop[gtile] = pop; if (wantObs) tileObs[gtile] = obs; }
+}
+
+// ---------------------------------------------------------------------------------------------- k_scan_tiles
+// one workgroup (1024 threads) per chromosome
+struct ChromOut { long long pop, obs, nbins, popBefore; };
+
+__device__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* sh /*>=17*/, uint32_t& total) {
+    // inclusive wave scan, then scan of 16 wave totals
+    uint32_t inc = wave_inclusive_scan_u32(v);
+    int w = threadIdx.x >> 6, l = lane_id();
+    if (l == 63) sh[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t s = 0; for (int i = 0; i < 16; i++) { uint32_t t = sh[i]; sh[i] = s; s += t; } sh[16] = s; }
+    __syncthreads();
+    uint32_t ex = inc - v + sh[w];
+    total = sh[16];
+    __syncthreads();
+    return ex;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tiles(const BinChrom* __restrict__ ch, const unsigned long long* __restrict__ pos0,
+                                                     const uint32_t* __restrict__ tilePop, const uint32_t* __restrict__ tileObs, int wantObs,
+                                                     int binSize, int32_t* __restrict__ rankBase, ChromOut* __restrict__ out) {
+    __shared__ uint32_t sh[17];
+    __shared__ long long s_popBefore;
+    const int c = blockIdx.x;
+    const BinChrom C = ch[c];
+    const int64_t p0 = (int64_t)pos0[c] < C.len ? (int64_t)pos0[c] : C.len;
+    const int64_t t0 = p0 >> TILE_SHIFT;   // tile containing pos0
+    // partial popcount inside tile t0 before pos0 (one wave is enough: 64 words)
+    if (threadIdx.x < 64) {
+        int64_t wstart = (t0 << TILE_SHIFT) + (int64_t)threadIdx.x * 64;
+        uint32_t pc = 0;
+        if (wstart < p0) {
+            uint64_t w = C.mask[wstart >> 6];
+            int64_t valid = p0 - wstart;
+            if (valid < 64) w &= (~0ull) >> (64 - valid);
+            pc = __popcll(w);
+        }
+        pc = wave_reduce_add_u32(pc);
+        if (threadIdx.x == 0) s_popBefore = pc;
+    }
+    __syncthreads();
+    long long carry = 0, obsSum = 0, popBeforeFull = 0;
+    for (int64_t base = 0; base < C.ntiles; base += 1024) {
+        int64_t t = base + threadIdx.x;
+        uint32_t v = t < C.ntiles ? tilePop[C.tileBase + t] : 0;
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan_1024(v, sh, tot);
+        long long exg = carry + ex;
+        if (t < C.ntiles) rankBase[C.tileBase + t] = (int32_t)exg;   // fixed up below by subtracting popBefore
+        if (t == t0) popBeforeFull = exg;
+        carry += tot;
+        if (wantObs) { uint32_t o = t < C.ntiles ? tileObs[C.tileBase + t] : 0; uint32_t ot; (void)block_exclusive_scan_1024(o, sh, ot); obsSum += ot; }
+    }
+    // popBefore = full tiles before t0 + partial; broadcast from the thread that owns t0
+    __shared__ long long s_full;
+    if (threadIdx.x == 0) s_full = 0;
+    __syncthreads();
+    if (t0 < C.ntiles && (t0 & 1023) == threadIdx.x) s_full = popBeforeFull;
+    __syncthreads();
+    long long popBefore = (t0 < C.ntiles ? s_full : carry) + s_popBefore;
+    for (int64_t t = threadIdx.x; t < C.ntiles; t += 1024) rankBase[C.tileBase + t] -= (int32_t)popBefore;
+    if (threadIdx.x == 0) {
+        ChromOut o; o.pop = carry; o.obs = obsSum; o.popBefore = popBefore;
+        o.nbins = binSize > 0 ? (carry - popBefore) / binSize : 0;
+        out[c] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- k_bin_pass
+__device__ __forceinline__ uint32_t expand4(uint32_t mb) {           // 4 mask bits -> 4 byte masks (0x00 / 0xFF)
+    uint32_t x = __umul24(mb & 0xFu, 0x204081u) & 0x01010101u;
+    return (x << 8) - x;
+}
+__device__ __forceinline__ uint32_t clamp10_bytes(uint32_t w) {      // per byte min(10, b)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    union { uint32_t u; us2 v; } lo, hi, ten;
+    ten.u = 0x000A000Au;
+    lo.u = w & 0x00FF00FFu; hi.u = (w >> 8) & 0x00FF00FFu;
+    lo.v = __builtin_elementwise_min(lo.v, ten.v);
+    hi.v = __builtin_elementwise_min(hi.v, ten.v);
+    return lo.u | (hi.u << 8);
+}
+__device__ __forceinline__ uint32_t gc_bits4(uint32_t w) {           // 4 bits: base is C/c/G/g
+    uint32_t y = ((w | 0x20202020u) ^ 0x63636363u) & 0xFBFBFBFBu;     // 0 for 'c'(0x63) and 'g'(0x67)
+    uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+}
+__device__ __forceinline__ uint32_t sum_bytes(uint32_t w, uint32_t acc) { return __builtin_amdgcn_sad_u8(w, 0u, acc); }
+
+__global__ void __launch_bounds__(256) k_bin_pass(const BinChrom* __restrict__ ch, int nchr, int64_t ntilesTotal,
+                                                  const unsigned long long* __restrict__ pos0, const int32_t* __restrict__ rankBase,
+                                                  const long long* __restrict__ binOffset, int binSize, int clampHits,
+                                                  int32_t* __restrict__ stopOut, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG,
+                                                  uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
+    const int64_t gtile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gtile >= ntilesTotal) return;
+    const int c = find_chrom(ch, nchr, gtile);
+    const BinChrom C = ch[c];
+    const int64_t tileStart = (gtile - C.tileBase) << TILE_SHIFT;
+    const int l = lane_id();
+    const int64_t p0c = (int64_t)pos0[c];
+    const long long boff = binOffset[c];
+    const bool full = (tileStart + TILE <= C.len) && (tileStart >= p0c);
+    int32_t rank0 = rankBase[gtile];          // rank (count of possible positions since pos0) before this tile
+    uint32_t carryC = 0, carryG = 0;
+
+    // issue all loads of the tile up front (memory-level parallelism): 4 x (16 B bases, 16 B hits, 2 B mask)
+    uint4 vb[4], vh[4];
+    uint32_t m16[4];
+    if (full) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            int64_t p = tileStart + it * 1024 + l * 16;
+            vb[it] = *reinterpret_cast<const uint4*>(C.bases + p);
+            vh[it] = *reinterpret_cast<const uint4*>(C.hits + p);
+            m16[it] = reinterpret_cast<const uint16_t*>(C.mask)[p >> 4];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int64_t p = tileStart + it * 1024 + l * 16;
+        uint32_t wb[4], wh[4], mRank, vmask = 0xFFFFu;
+        if (full) {
+            wb[0] = vb[it].x; wb[1] = vb[it].y; wb[2] = vb[it].z; wb[3] = vb[it].w;
+            wh[0] = vh[it].x; wh[1] = vh[it].y; wh[2] = vh[it].z; wh[3] = vh[it].w;
+            mRank = m16[it];
+        } else {   // chromosome head (pos0) or tail tile: bounds-checked byte loads
+            mRank = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { wb[q] = 0; wh[q] = 0; }
+            vmask = 0;
+            for (int i = 0; i < 16; i++) {
+                int64_t pi = p + i;
+                if (pi < C.len) {
+                    uint32_t mbit = (uint32_t)((C.mask[pi >> 6] >> (pi & 63)) & 1ull);
+                    mRank |= mbit << i;
+                    wb[i >> 2] |= (uint32_t)C.bases[pi] << (8 * (i & 3));
+                    wh[i >> 2] |= (uint32_t)C.hits[pi] << (8 * (i & 3));
+                    if (pi >= p0c) vmask |= 1u << i;
+                }
+            }
+        }
+        const uint32_t mVal = mRank & vmask;
+        // per-lane values
+        uint32_t gcb = (gc_bits4(wb[0]) | (gc_bits4(wb[1]) << 4) | (gc_bits4(wb[2]) << 8) | (gc_bits4(wb[3]) << 12)) & vmask;
+        uint32_t cw[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t h = clampHits ? clamp10_bytes(wh[q]) : wh[q];
+            cw[q] = h & expand4(mVal >> (4 * q));
+        }
+        uint32_t cl = sum_bytes(cw[0], sum_bytes(cw[1], sum_bytes(cw[2], sum_bytes(cw[3], 0u))));
+        uint32_t pop = __popc(mRank), g = __popc(gcb);
+        // wave scans: (pop | g<<16) packed, c separate
+        uint32_t pg = pop | (g << 16);
+        uint32_t pgInc = wave_inclusive_scan_u32(pg);
+        uint32_t cInc = wave_inclusive_scan_u32(cl);
+        uint32_t pgEx = pgInc - pg, cEx = cInc - cl;
+        uint32_t popEx = pgEx & 0xFFFFu, gEx = pgEx >> 16;
+        // boundaries inside this lane's 16 positions
+        int32_t r = rank0 + (int32_t)popEx;            // rank before this lane
+        if (pop > 0 && r + (int32_t)pop >= binSize) {  // cheap reject: a boundary needs rank >= binSize
+            int32_t rr = r < 0 ? 0 : r;                // ranks <= 0 can never close a bin
+            uint32_t nextB = ((uint32_t)rr / (uint32_t)binSize + 1u) * (uint32_t)binSize;   // next boundary rank > rr
+            uint32_t mm = mRank;
+            while ((int64_t)nextB - r <= (int64_t)pop && (int64_t)nextB - r >= 1) {
+                uint32_t k = (uint32_t)((int64_t)nextB - r);       // k-th set bit of mm closes the bin
+                uint32_t pos = 0, m = mm, kk = k, cnt;
+                cnt = __popc(m & 0xFFu); if (kk > cnt) { kk -= cnt; pos += 8; m >>= 8; }
+                cnt = __popc(m & 0xFu);  if (kk > cnt) { kk -= cnt; pos += 4; m >>= 4; }
+                cnt = __popc(m & 0x3u);  if (kk > cnt) { kk -= cnt; pos += 2; m >>= 2; }
+                cnt = m & 1u;            if (kk > cnt) { pos += 1; }
+                // head sums: positions <= pos
+                uint32_t hc = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int rel = (int)pos - 4 * q;
+                    uint32_t bm = rel >= 3 ? 0xFFFFFFFFu : (rel < 0 ? 0u : (0xFFFFFFFFu >> (8 * (3 - rel))));
+                    hc = sum_bytes(cw[q] & bm, hc);
+                }
+                uint32_t hg = __popc(gcb & ((2u << pos) - 1u));
+                long long bin = boff + (long long)(nextB / (uint32_t)binSize) - 1;
+                stopOut[bin] = (int32_t)(p + pos + 1);
+                locC[bin] = carryC + cEx + hc;
+                locG[bin] = carryG + gEx + hg;
+                nextB += (uint32_t)binSize;
+            }
+        }
+        // carry to next iteration (wave totals from lane 63)
+        uint32_t pgTot = __shfl(pgInc, 63, 64), cTot = __shfl(cInc, 63, 64);
+        rank0 += (int32_t)(pgTot & 0xFFFFu);
+        carryG += pgTot >> 16;
+        carryC += cTot;
+    }
+    if (l == 0) { tileTotC[gtile] = carryC; tileTotG[gtile] = carryG; }
+}
+
+// ---------------------------------------------------------------------------------------------- k_scan_totals
+__global__ void __launch_bounds__(1024) k_scan_totals(const BinChrom* __restrict__ ch, uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
+    __shared__ uint32_t sh[17];
+    const BinChrom C = ch[blockIdx.x];
+    uint32_t carryC = 0, carryG = 0;
+    for (int64_t base = 0; base < C.ntiles; base += 1024) {
+        int64_t t = base + threadIdx.x;
+        uint32_t vc = t < C.ntiles ? tileTotC[C.tileBase + t] : 0, vg = t < C.ntiles ? tileTotG[C.tileBase + t] : 0;
+        uint32_t totC, totG;
+        uint32_t exC = block_exclusive_scan_1024(vc, sh, totC);
+        uint32_t exG = block_exclusive_scan_1024(vg, sh, totG);
+        if (t < C.ntiles) { tileTotC[C.tileBase + t] = carryC + exC; tileTotG[C.tileBase + t] = carryG + exG; }
+        carryC += totC; carryG += totG;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- k_bin_finalize
+__global__ void __launch_bounds__(256) k_bin_finalize(const BinChrom* __restrict__ ch, int nchr, const long long* __restrict__ binOffset,
+                                                      const unsigned long long* __restrict__ pos0, const int32_t* __restrict__ stopIn,
+                                                      const uint32_t* __restrict__ locC, const uint32_t* __restrict__ locG,
+                                                      const uint32_t* __restrict__ tileExC, const uint32_t* __restrict__ tileExG,
+                                                      int32_t* __restrict__ oChr, int32_t* __restrict__ oStart, int32_t* __restrict__ oStop,
+                                                      int32_t* __restrict__ oGc, float* __restrict__ oCount) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= binOffset[nchr]) return;
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (binOffset[mid] <= i) lo = mid; else hi = mid - 1; }
+    // skip chromosomes without bins that share the same offset
+    while (lo < nchr - 1 && binOffset[lo + 1] <= i) lo++;
+    const int c = lo;
+    const BinChrom C = ch[c];
+    const long long k = i - binOffset[c];
+    const int32_t stop = stopIn[i];
+    const int64_t tile = C.tileBase + ((int64_t)(stop - 1) >> TILE_SHIFT);
+    uint32_t gC = tileExC[tile] + locC[i], gG = tileExG[tile] + locG[i];
+    uint32_t pC = 0, pG = 0;
+    int32_t start = (int32_t)pos0[c];
+    if (k > 0) {
+        const int32_t pstop = stopIn[i - 1];
+        const int64_t ptile = C.tileBase + ((int64_t)(pstop - 1) >> TILE_SHIFT);
+        pC = tileExC[ptile] + locC[i - 1]; pG = tileExG[ptile] + locG[i - 1];
+        start = pstop;
+    }
+    const uint32_t count = gC - pC, gcCount = gG - pG;
+    const int32_t nuc = stop - start;
+    float gcf = 100.0f * (float)(int32_t)gcCount;     // (int)(100f * GCCount / NucleotideCount), CanvasBin.cs:638
+    gcf = gcf / (float)nuc;
+    oChr[i] = c; oStart[i] = start; oStop[i] = stop; oGc[i] = (int32_t)gcf; oCount[i] = (float)(int32_t)count;
+}
+
+// exclusive scan of per-chromosome bin counts (tiny)
+__global__ void k_bin_offsets(const ChromOut* __restrict__ co, int nchr, long long* __restrict__ binOffset) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { long long s = 0; for (int c = 0; c < nchr; c++) { binOffset[c] = s; s += co[c].nbins; } binOffset[nchr] = s; }
+}
+__global__ void k_init_pos0(const BinChrom* __restrict__ ch, int nchr, unsigned long long* __restrict__ pos0) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchr) pos0[c] = (unsigned long long)ch[c].len;
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+struct BinPlan {
+    std::vector<BinChrom> chroms;
+    int64_t ntiles = 0;
+};
+static BinPlan make_plan(int nchr, const uint8_t* const* bases, const uint64_t* const* mask, const uint8_t* const* hits, const int64_t* len) {
+    BinPlan p;
+    p.chroms.resize(nchr);
+    for (int c = 0; c < nchr; c++) {
+        BinChrom& C = p.chroms[c];
+        C.bases = bases ? bases[c] : nullptr; C.hits = hits ? hits[c] : nullptr; C.mask = mask[c]; C.len = len[c];
+        C.tileBase = p.ntiles; C.ntiles = (len[c] + TILE - 1) / TILE;
+        p.ntiles += C.ntiles;
+    }
+    return p;
+}
+
+extern "C" {
+
+int32_t canvas_bin_size_from_rates(const double* h_rates, int32_t n, int32_t counts_per_bin) {
+    if (!h_rates || n <= 0) return CANVAS_ERR_INVALID;
+    std::vector<double> r(h_rates, h_rates + n);
+    std::sort(r.begin(), r.end());
+    double med = (n % 2) ? r[n / 2] : (r[n / 2 - 1] + r[n / 2]) / 2;   // SortedList<double>.Median()
+    return (int32_t)(counts_per_bin / med);                             // CanvasBin.cs:82
+}
+
+int64_t canvas_bin_count_upper_bound(int32_t nchr, const int64_t* h_len, int32_t bin_size) {
+    if (bin_size <= 0 || !h_len) return CANVAS_ERR_INVALID;
+    int64_t s = 0;
+    for (int c = 0; c < nchr; c++) s += h_len[c] / bin_size;
+    return s;
+}
+
+int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_hits, const uint64_t* const* d_mask,
+                         const int64_t* h_len, int64_t* h_observed, int64_t* h_possible, double* h_rate) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !d_hits || !d_mask || !h_len) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_rates: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BinPlan plan = make_plan(nchr, nullptr, d_mask, d_hits, h_len);
+    WsSizer sz; sz.take<BinChrom>(nchr); sz.take<unsigned long long>(nchr); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles);
+    sz.take<int32_t>(plan.ntiles); sz.take<ChromOut>(nchr);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
+    rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + sizeof(ChromOut))); if (rc) return rc;
+    WsCarver ws(ctx->ws);
+    BinChrom* dCh = ws.take<BinChrom>(nchr); unsigned long long* dPos0 = ws.take<unsigned long long>(nchr);
+    uint32_t* tilePop = ws.take<uint32_t>(plan.ntiles); uint32_t* tileObs = ws.take<uint32_t>(plan.ntiles);
+    int32_t* rankBase = ws.take<int32_t>(plan.ntiles); ChromOut* dOut = ws.take<ChromOut>(nchr);
+    memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);   // pos0 = len: popBefore irrelevant here
+    hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, 1, tilePop, tileObs);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut);
+    ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    for (int c = 0; c < nchr; c++) {
+        if (h_observed) h_observed[c] = hOut[c].obs;
+        if (h_possible) h_possible[c] = hOut[c].pop;
+        if (h_rate) h_rate[c] = (int)hOut[c].obs / (double)(int)hOut[c].pop;   // int / (double)int, CanvasBin.cs:60
+    }
+    return CANVAS_OK;
+}
+
+int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                          const uint8_t* const* d_hits, const int64_t* h_len, int32_t bin_size, int32_t mode,
+                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                          int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bad arguments");
+    if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "GCContentWeighted binning (CanvasBin.cs:451-506,626-636) is not built yet");
+    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "unknown coverage mode");
+    for (int c = 0; c < nchr; c++) if (h_len[c] <= 0 || h_len[c] > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "chromosome length must be in [1, 2^31)");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BinPlan plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len);
+    int64_t ub = canvas_bin_count_upper_bound(nchr, h_len, bin_size);
+    WsSizer sz;
+    sz.take<BinChrom>(nchr); sz.take<unsigned long long>(nchr); sz.take<uint32_t>(plan.ntiles); sz.take<int32_t>(plan.ntiles);
+    sz.take<ChromOut>(nchr); sz.take<long long>(nchr + 1); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles);
+    sz.take<int32_t>(ub + 1); sz.take<uint32_t>(ub + 1); sz.take<uint32_t>(ub + 1);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
+    rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + sizeof(ChromOut))); if (rc) return rc;
+    WsCarver ws(ctx->ws);
+    BinChrom* dCh = ws.take<BinChrom>(nchr); unsigned long long* dPos0 = ws.take<unsigned long long>(nchr);
+    uint32_t* tilePop = ws.take<uint32_t>(plan.ntiles); int32_t* rankBase = ws.take<int32_t>(plan.ntiles);
+    ChromOut* dOut = ws.take<ChromOut>(nchr); long long* binOffset = ws.take<long long>(nchr + 1);
+    uint32_t* tileTotC = ws.take<uint32_t>(plan.ntiles); uint32_t* tileTotG = ws.take<uint32_t>(plan.ntiles);
+    int32_t* stopTmp = ws.take<int32_t>(ub + 1); uint32_t* locC = ws.take<uint32_t>(ub + 1); uint32_t* locG = ws.take<uint32_t>(ub + 1);
+    memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);
+    hipLaunchKernelGGL(k_find_pos0, dim3(64, nchr), dim3(256), 0, ctx->stream, dCh, dPos0);
+    hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, 0, tilePop, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, (const uint32_t*)nullptr, 0, bin_size, rankBase, dOut);
+    hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(64), 0, ctx->stream, dOut, nchr, binOffset);
+    ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    int64_t total = 0;
+    for (int c = 0; c < nchr; c++) { if (h_nbins_per_chr) h_nbins_per_chr[c] = hOut[c].nbins; total += hOut[c].nbins; }
+    if (h_nbins_total) *h_nbins_total = total;
+    if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_bin_genome: output capacity too small (see canvas_bin_count_upper_bound)");
+    if (total == 0) return CANVAS_OK;
+    hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
+                       binOffset, bin_size, mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, stopTmp, locC, locG, tileTotC, tileTotG);
+    hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
+    hipLaunchKernelGGL(k_bin_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, stopTmp, locC, locG,
+                       tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count);
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    return CANVAS_OK;
+}
+
+}  // extern "C"

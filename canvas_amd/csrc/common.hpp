@@ -1,0 +1,90 @@
+// Shared host-side plumbing of libcanvas_hip.so (context, error handling, device workspace).
+// Everything in csrc/ is compiled for gfx950 only (hipcc --offload-arch=gfx950 -ffp-contract=off): wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/canvas_hip.h"
+
+struct canvas_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    // growable device scratch (bytes); reused across calls, never shrinks
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // pinned host staging for small D2H results
+    void* pin = nullptr;
+    size_t pin_bytes = 0;
+    void* comm = nullptr;  // ncclComm_t
+    int rank = 0, nranks = 1;
+};
+
+#define CANVAS_HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            return CANVAS_ERR_HIP;                                                                  \
+        }                                                                                           \
+    } while (0)
+
+#define CANVAS_FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
+
+// ensure ctx->ws has at least `bytes`
+static inline int32_t canvas_ws_reserve(canvas_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return CANVAS_OK;
+    if (ctx->ws) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    size_t want = bytes + bytes / 4 + (1u << 20);
+    CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->ws, want));
+    ctx->ws_bytes = want;
+    return CANVAS_OK;
+}
+static inline int32_t canvas_pin_reserve(canvas_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pin_bytes) return CANVAS_OK;
+    if (ctx->pin) { CANVAS_HIP_TRY(ctx, hipHostFree(ctx->pin)); ctx->pin = nullptr; ctx->pin_bytes = 0; }
+    size_t want = bytes + 4096;
+    CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
+    ctx->pin_bytes = want;
+    return CANVAS_OK;
+}
+
+// bump allocator over the workspace
+struct WsCarver {
+    char* base; size_t off = 0;
+    explicit WsCarver(void* p) : base((char*)p) {}
+    template <class T> T* take(size_t n) { off = (off + 255) & ~size_t(255); T* r = (T*)(base + off); off += n * sizeof(T); return r; }
+};
+struct WsSizer {
+    size_t off = 0;
+    template <class T> void take(size_t n) { off = (off + 255) & ~size_t(255); off += n * sizeof(T); }
+};
+
+// ---- device helpers ------------------------------------------------------------------------------------------
+#define WAVE 64
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// inclusive wave scan (64 lanes) via ds_bpermute shuffles
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+    int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_add_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_reduce_add_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}

@@ -1,0 +1,75 @@
+// Context, memory and stream plumbing of libcanvas_hip.so (include/canvas_hip.h "context" section).
+#include "common.hpp"
+
+extern "C" {
+
+const char* canvas_version(void) { return "canvas_hip 0.1 (gfx950)"; }
+
+canvas_ctx* canvas_create(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return nullptr;  // no CPU fallback
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    canvas_ctx* ctx = new canvas_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    ctx->own_stream = true;
+    return ctx;
+}
+
+void canvas_destroy(canvas_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* canvas_last_error(canvas_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context (no usable GPU: this library has no CPU fallback)"; }
+
+int32_t canvas_set_stream(canvas_ctx* ctx, void* hip_stream) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (hip_stream) {
+        if (ctx->own_stream && ctx->stream) CANVAS_HIP_TRY(ctx, hipStreamDestroy(ctx->stream));
+        ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false;
+    } else if (!ctx->own_stream) {
+        CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true;
+    }
+    return CANVAS_OK;
+}
+
+int32_t canvas_synchronize(canvas_ctx* ctx) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+
+void* canvas_device_malloc(canvas_ctx* ctx, int64_t bytes) {
+    if (!ctx || bytes < 0) return nullptr;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)(bytes > 0 ? bytes : 1));
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return nullptr; }
+    return p;
+}
+int32_t canvas_device_free(canvas_ctx* ctx, void* d_ptr) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipFree(d_ptr));
+    return CANVAS_OK;
+}
+int32_t canvas_memcpy_h2d(canvas_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes) {
+    if (!ctx || bytes < 0) return CANVAS_ERR_INVALID;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+int32_t canvas_memcpy_d2h(canvas_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes) {
+    if (!ctx || bytes < 0) return CANVAS_ERR_INVALID;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+
+}  // extern "C"

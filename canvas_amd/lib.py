@@ -1,0 +1,207 @@
+"""ctypes binding of libcanvas_hip.so.  Device memory is handled with torch tensors (plumbing only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(HERE, "libcanvas_hip.so")
+_SYNTH_SO = os.path.join(HERE, "libcanvas_synth.so")
+
+MODE_BINARY, MODE_TDR = 0, 3
+CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD, CLEAN_LOESS = 1, 2, 4, 8, 16
+
+# every symbol include/canvas_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
+    "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
+    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome",
+    "canvas_clean", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_cbs",
+    "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries",
+]
+
+
+class CanvasError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library; fails loudly if it has not been built (python -m canvas_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise CanvasError(f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+    lib = C.CDLL(_SO)
+    lib.canvas_create.restype = C.c_void_p
+    lib.canvas_create.argtypes = [C.c_int]
+    lib.canvas_destroy.argtypes = [C.c_void_p]
+    lib.canvas_last_error.restype = C.c_char_p
+    lib.canvas_last_error.argtypes = [C.c_void_p]
+    lib.canvas_version.restype = C.c_char_p
+    lib.canvas_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.canvas_synchronize.argtypes = [C.c_void_p]
+    lib.canvas_device_malloc.restype = C.c_void_p
+    lib.canvas_device_malloc.argtypes = [C.c_void_p, C.c_int64]
+    lib.canvas_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.canvas_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.canvas_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.canvas_bin_count_upper_bound.restype = C.c_int64
+    lib.canvas_bin_count_upper_bound.argtypes = [C.c_int32, C.c_void_p, C.c_int32]
+    lib.canvas_bin_size_from_rates.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    _lib = lib
+    return lib
+
+
+def _ptr_table(tensors):
+    T = C.c_void_p * len(tensors)
+    return T(*[t.data_ptr() for t in tensors])
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Canvas:
+    """One context = one GPU + one stream.  Method names follow the reference functions they replace."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise CanvasError("no GPU visible: canvas_amd has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(device)
+        raw = self.lib.canvas_create(device)
+        if not raw:
+            raise CanvasError("canvas_create failed: no usable GPU (no CPU fallback)")
+        self.ctx = C.c_void_p(raw)   # always pass as a 64-bit pointer
+        if stream is not None:
+            self._check(self.lib.canvas_set_stream(self.ctx, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None:
+            self.lib.canvas_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CanvasError(f"libcanvas_hip error {rc}: {self.lib.canvas_last_error(self.ctx).decode()}")
+
+    def use_torch_stream(self):
+        """run on torch's current stream so torch.cuda.Event timing sees the kernels"""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.canvas_set_stream(self.ctx, C.c_void_p(s)))
+
+    def synchronize(self):
+        self._check(self.lib.canvas_synchronize(self.ctx))
+
+    # ---- CanvasBin
+    def bin_rates(self, hits, masks, lens):
+        """SampleHitArrays.GetRates (CanvasBin.cs:30-71)"""
+        n = len(hits)
+        lens = np.ascontiguousarray(lens, np.int64)
+        obs = np.zeros(n, np.int64); poss = np.zeros(n, np.int64); rate = np.zeros(n, np.float64)
+        self._check(self.lib.canvas_bin_rates(self.ctx, n, _ptr_table(hits), _ptr_table(masks), _np_ptr(lens), _np_ptr(obs), _np_ptr(poss), _np_ptr(rate)))
+        return obs, poss, rate
+
+    def bin_size_from_rates(self, rates, counts_per_bin):
+        """SampleHitArrays.GetBinSize (CanvasBin.cs:73-83)"""
+        r = np.ascontiguousarray(rates, np.float64)
+        return int(self.lib.canvas_bin_size_from_rates(_np_ptr(r), len(r), counts_per_bin))
+
+    def bin_genome(self, bases, masks, hits, lens, bin_size, mode=MODE_TDR, out=None):
+        """BinCounts (CanvasBin.cs:416-550): returns dict(chr,start,stop,gc,count) device tensors trimmed to the bin count"""
+        torch = self.torch
+        n = len(bases)
+        lens = np.ascontiguousarray(lens, np.int64)
+        cap = int(self.lib.canvas_bin_count_upper_bound(n, _np_ptr(lens), bin_size))
+        if cap < 0:
+            raise CanvasError("bad bin size")
+        if out is None:
+            out = dict(chr=torch.empty(cap + 1, dtype=torch.int32, device=self.device), start=torch.empty(cap + 1, dtype=torch.int32, device=self.device),
+                       stop=torch.empty(cap + 1, dtype=torch.int32, device=self.device), gc=torch.empty(cap + 1, dtype=torch.int32, device=self.device),
+                       count=torch.empty(cap + 1, dtype=torch.float32, device=self.device))
+        per = np.zeros(n, np.int64); total = C.c_int64(0)
+        self._check(self.lib.canvas_bin_genome(self.ctx, n, _ptr_table(bases), _ptr_table(masks), _ptr_table(hits), _np_ptr(lens), bin_size, mode,
+                                               C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),
+                                               C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()), C.c_int64(out["chr"].numel()),
+                                               _np_ptr(per), C.byref(total)))
+        return out, per, total.value
+
+    # ---- CanvasClean
+    def clean(self, bins, n, is_autosome, flags, min_bins_per_gc=100):
+        """CanvasClean.Main (CanvasClean.cs:415-533) in place on device SoA; returns (n_out, local_sd, info)"""
+        ia = np.ascontiguousarray(is_autosome, np.uint8)
+        lsd = C.c_double(-1.0); nout = C.c_int64(0); info = np.zeros(8, np.int32)
+        self._check(self.lib.canvas_clean(self.ctx, C.c_int64(n), C.c_void_p(bins["chr"].data_ptr()), C.c_void_p(bins["start"].data_ptr()),
+                                          C.c_void_p(bins["stop"].data_ptr()), C.c_void_p(bins["count"].data_ptr()), C.c_void_p(bins["gc"].data_ptr()),
+                                          len(ia), _np_ptr(ia), C.c_uint32(flags), min_bins_per_gc, C.byref(lsd), C.byref(nout), _np_ptr(info)))
+        return nout.value, lsd.value, info
+
+    # ---- CanvasPartition
+    def hmm_per_sample(self, cov, chr_offset):
+        """HiddenMarkovModelsRunner.Run(isPerSample) (HiddenMarkovModelsRunner.cs:23-109): Viterbi state per bin"""
+        torch = self.torch
+        off = np.ascontiguousarray(chr_offset, np.int64)
+        state = torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
+        self._check(self.lib.canvas_hmm_per_sample(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_void_p(state.data_ptr())))
+        return state
+
+    def segment_ids(self, chr_offset, state, start, stop, max_inter_bin_dist=1000000):
+        torch = self.torch
+        off = np.ascontiguousarray(chr_offset, np.int64)
+        seg = torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
+        nseg = C.c_int64(0)
+        self._check(self.lib.canvas_segment_ids(self.ctx, len(off) - 1, _np_ptr(off), C.c_void_p(state.data_ptr()), C.c_void_p(start.data_ptr()),
+                                                C.c_void_p(stop.data_ptr()), max_inter_bin_dist, C.c_void_p(seg.data_ptr()), C.byref(nseg)))
+        return seg, nseg.value
+
+    def cbs(self, cov, chr_offset, alpha=0.01, nperm=10000):
+        torch = self.torch
+        off = np.ascontiguousarray(chr_offset, np.int64)
+        seg_len = torch.zeros(int(off[-1]) + 1, dtype=torch.int32, device=self.device)
+        nseg = np.zeros(len(off) - 1, np.int32); stats = np.zeros(8, np.int64)
+        self._check(self.lib.canvas_cbs(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_double(alpha), C.c_uint32(nperm),
+                                        C.c_void_p(seg_len.data_ptr()), _np_ptr(nseg), _np_ptr(stats)))
+        return seg_len, nseg, stats
+
+
+# ---- synthetic generator (bench/test tooling, separate library)
+_synth = None
+
+
+def synth_generate_device(seed, chrom, length, rate, device, thr_dev=None):
+    """generate (bases, hits, mask) for one chromosome directly in HBM; mirrors canvas_amd.synth.generate_chromosome"""
+    import torch
+    from . import synth
+    global _synth
+    if _synth is None:
+        if not os.path.exists(_SYNTH_SO):
+            raise CanvasError(f"{_SYNTH_SO} missing: run build()")
+        _synth = C.CDLL(_SYNTH_SO)
+    if thr_dev is None:
+        thr_dev = torch.from_numpy(synth.poisson_thresholds(rate).astype(np.int64)).to(device).to(torch.int64)
+        thr_dev = (thr_dev & 0xFFFFFFFF).to(torch.int64).to(torch.int32) if False else torch.from_numpy(synth.poisson_thresholds(rate).view(np.int32)).to(device)
+    gap0, g1s, g1e, base_cn = synth.chrom_params(chrom, length)
+    pad = (length + 63) // 64 * 64
+    bases = torch.empty(pad, dtype=torch.uint8, device=device)
+    hits = torch.empty(pad, dtype=torch.uint8, device=device)
+    mask = torch.empty(pad // 64, dtype=torch.int64, device=device)
+    rc = _synth.synth_generate(C.c_uint32(seed), C.c_uint32(chrom), C.c_int64(length), C.c_int64(gap0), C.c_int64(g1s), C.c_int64(g1e), C.c_uint32(base_cn),
+                               C.c_void_p(thr_dev.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(hits.data_ptr()), C.c_void_p(mask.data_ptr()),
+                               C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    if rc != 0:
+        raise CanvasError(f"synth_generate failed: hip error {rc}")
+    return bases, hits, mask, thr_dev

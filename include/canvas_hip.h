@@ -1,0 +1,110 @@
+/* canvas_hip.h — C ABI of libcanvas_hip.so: the MI355X (gfx950) implementation of Canvas's read-depth hot path
+ * (CanvasBin merge step -> CanvasClean -> CanvasPartition).
+ *
+ * The reference (Illumina/canvas, C#) has no in-process FFI for this path: its boundary is three executables that
+ * exchange gzip text files.  This header is the boundary a thin C# `Main` P/Invokes instead of running
+ * the C# loops; each entry point names the reference code it replaces (paths relative to Src/Canvas/).
+ * INTEGRATION.md shows the DllImport stubs.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns int32 status: 0 = ok, <0 = CANVAS_ERR_*;
+ *     the message is available from canvas_last_error(ctx).
+ *   - "d_" pointers are DEVICE pointers (from canvas_device_malloc or any HIP allocation of the same process);
+ *     "h_" pointers are host pointers.  The library never frees or retains caller memory past the call.
+ *   - one context = one GPU + one HIP stream; calls on a context are serialized by the caller.
+ *   - alignment: d_bases / d_hits 16 bytes, d_mask 8 bytes and padded to a multiple of 8 bytes.
+ *   - possible-alignment mask layout = System.Collections.BitArray: bit i of the chromosome is bit (i & 7) of byte i >> 3.
+ */
+#ifndef CANVAS_HIP_H
+#define CANVAS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct canvas_ctx canvas_ctx;
+
+enum {
+    CANVAS_OK = 0,
+    CANVAS_ERR_INVALID = -1,     /* bad argument */
+    CANVAS_ERR_HIP = -2,         /* HIP runtime error (no device, launch failure, OOM) */
+    CANVAS_ERR_UNSUPPORTED = -3, /* reference feature outside the built scope */
+    CANVAS_ERR_CAPACITY = -4,    /* caller buffer too small */
+    CANVAS_ERR_COMM = -5         /* RCCL error */
+};
+
+/* coverage modes: CanvasCommon/Utilities.cs:56-74 (ParseCanvasCoverageMode) */
+enum { CANVAS_MODE_BINARY = 0, CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE = 3, CANVAS_MODE_GC_CONTENT_WEIGHTED = 5 };
+
+/* CanvasClean switches: CanvasClean/CanvasClean.cs:431-446 (-g, -s, -r, --local-sd-metric-file, -m LOESS) */
+enum { CANVAS_CLEAN_GCNORM = 1, CANVAS_CLEAN_FILTSIZE = 2, CANVAS_CLEAN_OUTLIERS = 4, CANVAS_CLEAN_LOCALSD = 8, CANVAS_CLEAN_LOESS = 16 };
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+canvas_ctx* canvas_create(int device);                 /* NULL when no usable GPU (the product has no CPU fallback) */
+void canvas_destroy(canvas_ctx* ctx);
+const char* canvas_last_error(canvas_ctx* ctx);
+const char* canvas_version(void);
+int32_t canvas_set_stream(canvas_ctx* ctx, void* hip_stream); /* run on a caller-owned hipStream_t (NULL = own stream) */
+int32_t canvas_synchronize(canvas_ctx* ctx);
+void* canvas_device_malloc(canvas_ctx* ctx, int64_t bytes);
+int32_t canvas_device_free(canvas_ctx* ctx, void* d_ptr);
+int32_t canvas_memcpy_h2d(canvas_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes);
+int32_t canvas_memcpy_d2h(canvas_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes);
+
+/* ---- CanvasBin ----------------------------------------------------------------------------------------------- */
+/* SampleHitArrays.GetRates (CanvasBin/CanvasBin.cs:30-71) + HitArray.CountSetBits (HitArray.cs:24-32) +
+ * CanvasBin.CountSetBits (CanvasBin.cs:146-156): per chromosome #positions with hit>0 and popcount(mask).
+ * h_observed/h_possible/h_rate have nchr entries (rate = observed/(double)possible). */
+int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_hits, const uint64_t* const* d_mask,
+                         const int64_t* h_len, int64_t* h_observed, int64_t* h_possible, double* h_rate);
+/* SampleHitArrays.GetBinSize (CanvasBin.cs:73-83): (int)(countsPerBin / median(rates)); pass autosome rates only
+ * (MultiSampleHitArrays, :86-110: concatenate the samples' rates). Host scalar code. */
+int32_t canvas_bin_size_from_rates(const double* h_rates, int32_t n, int32_t counts_per_bin);
+/* upper bound for the bin arrays of canvas_bin_genome */
+int64_t canvas_bin_count_upper_bound(int32_t nchr, const int64_t* h_len, int32_t bin_size);
+/* BinCounts / BinCountsForChromosome (CanvasBin.cs:416-661), no predefined bins: emits the genome's bins in chromosome
+ * order as SoA (chromosome index, start, stop, gc, count as float like SampleGenomicBin.Count).  cap = capacity of the
+ * output arrays; *h_nbins_total and h_nbins_per_chr (nchr entries, may be NULL) are written on return (one sync). */
+int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                          const uint8_t* const* d_hits, const int64_t* h_len, int32_t bin_size, int32_t mode,
+                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                          int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+
+/* ---- CanvasClean --------------------------------------------------------------------------------------------- */
+/* CanvasClean.Main (CanvasClean/CanvasClean.cs:415-533) on the whole-genome SoA in file order, in place; bins that
+ * survive are compacted to the front, *h_n_out = surviving count.  h_chr_is_autosome[nchr] answers
+ * GenomeMetadata.SequenceMetadata.IsAutosome for each chromosome index.  min_bins_per_gc = the -w option (default 100).
+ * h_local_sd_out receives the #localSD metric (IO.cs:83-98) or -1.  h_info (may be NULL) gets 8 int32 diagnostics:
+ * [0] after size filter, [1] after outlier filter, [2] after GC strip, [3] after local-SD filter, [4] variance-normalised. */
+int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
+                     int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
+                     double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
+
+/* ---- CanvasPartition ------------------------------------------------------------------------------------------ */
+/* HiddenMarkovModelsRunner.Run with isPerSample (HiddenMarkovModelsRunner.cs:23-109) + BestPathViterbi (HMM.cs:62-130):
+ * one sample, all chromosomes.  d_cov = concatenated coverage (double, file order), h_chr_offset[nchr+1] = chromosome
+ * boundaries in bins.  d_state receives the Viterbi state (CN 0..4) per bin; chromosomes with <= 10 bins are skipped
+ * (state -1), as in :69.  */
+int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state);
+/* breakpoints -> segments -> segment id per bin: SegmentationInput.DeriveSegments (Segmentation.cs:83-125) +
+ * SegmentationResultsProcessor.PostProcessSegments (SegmentationResultsProcessor.cs:17-129, no forbidden intervals /
+ * ploidy file: those stay in the host tool).  d_is_start: 1 where a segment starts at this bin. */
+int32_t canvas_segment_ids(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state,
+                           const int32_t* d_start, const int32_t* d_stop, int32_t max_inter_bin_dist, int32_t* d_segment_id,
+                           int64_t* h_nsegments);
+/* CBSRunner.Run / ChangePoint.ChangePoints (CBSRunner.cs:40-151, ChangePoint.cs:44-153), undo = None.
+ * d_seg_len receives per chromosome the segment lengths, written at d_seg_len + h_chr_offset[c]; h_nseg[c] = count. */
+int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
+                   int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
+
+/* ---- multi-GPU (one process per GPU; chromosomes sharded across ranks) ------------------------------------------ */
+int32_t canvas_comm_unique_id(void* h_id128);  /* ncclGetUniqueId, 128 bytes, rank 0 */
+int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const void* h_id128);
+/* the single RCCL all-gather of the path: every rank contributes nlocal int32 boundary records (padded to max_per_rank) */
+int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank,
+                                    int32_t* d_all, int32_t* h_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

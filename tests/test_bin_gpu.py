@@ -1,0 +1,96 @@
+"""CanvasBin on the GPU vs the CPU oracle (bit-exact: integer work)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from canvas_amd import synth
+from gpu_common import get_canvas, to_dev, pad16
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20260927 + 1
+
+
+def _chroms(lengths, rate=0.105):
+    thr = synth.poisson_thresholds(rate)
+    return [synth.generate_chromosome(SEED, c, L, rate, thr) for c, L in enumerate(lengths)]
+
+
+def _upload(cv, data):
+    bases = [to_dev(pad16(b), cv.device) for b, h, m in data]
+    hits = [to_dev(pad16(h), cv.device) for b, h, m in data]
+    masks = [to_dev(m.view(np.int64), cv.device) for b, h, m in data]
+    return bases, hits, masks
+
+
+def test_device_synth_matches_numpy():
+    import torch
+    from canvas_amd.lib import synth_generate_device
+    cv = get_canvas()
+    L = 300_001
+    b, h, m = synth.generate_chromosome(SEED, 5, L, 0.21)
+    db, dh, dm, _ = synth_generate_device(SEED, 5, L, 0.21, cv.device)
+    torch.cuda.synchronize()
+    assert (db.cpu().numpy()[:L] == b).all()
+    assert (dh.cpu().numpy()[:L] == h).all()
+    assert (dm.cpu().numpy().view(np.uint8)[: len(m)] == m).all()
+
+
+@pytest.mark.parametrize("lengths,bin_size", [([1_500_000, 700_001, 40_961], None), ([300_000], 37), ([200_000, 5_000], 7), ([1_000_000], 5000)])
+def test_bin_genome_matches_oracle(lengths, bin_size):
+    cv = get_canvas()
+    data = _chroms(lengths)
+    bases, hits, masks = _upload(cv, data)
+    lens = np.array(lengths, np.int64)
+    obs, poss, rate = cv.bin_rates(hits, masks, lens)
+    for c, (b, h, m) in enumerate(data):
+        assert rate[c] == O.bin_rate(h, m)
+        assert obs[c] == int((h > 0).sum())
+    if bin_size is None:
+        bin_size = cv.bin_size_from_rates(rate, 100)
+        assert bin_size == O.bin_size(rate, 100)
+    for mode in (3, 0):
+        out, per, total = cv.bin_genome(bases, masks, hits, lens, bin_size, mode)
+        cv.synchronize()
+        off = 0
+        for c, (b, h, m) in enumerate(data):
+            es, ee, eg, ec = O.bin_chromosome(b, m, h, bin_size, mode)
+            assert per[c] == len(es), (c, per[c], len(es))
+            sl = slice(off, off + len(es))
+            assert (out["chr"][sl].cpu().numpy() == c).all()
+            assert (out["start"][sl].cpu().numpy() == es).all()
+            assert (out["stop"][sl].cpu().numpy() == ee).all()
+            assert (out["gc"][sl].cpu().numpy() == eg).all()
+            assert (out["count"][sl].cpu().numpy() == ec.astype(np.float32)).all()
+            off += len(es)
+        assert total == off
+
+
+def test_bin_edge_cases():
+    cv = get_canvas()
+    # all-'n' chromosome (no bins), chromosome with fewer possible positions than one bin, unscreened hits outside the mask
+    L = 10_000
+    rng = np.random.RandomState(3)
+    b1 = np.full(L, ord('n'), np.uint8); h1 = np.zeros(L, np.uint8); m1 = np.zeros((L + 63) // 64 * 8, np.uint8)
+    b2 = rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), L); h2 = rng.randint(0, 30, L).astype(np.uint8)
+    bits = (rng.rand((L + 63) // 64 * 64) < 0.01).astype(np.uint8); bits[L:] = 0
+    m2 = np.packbits(bits, bitorder="little")
+    b3 = rng.choice(np.frombuffer(b"ACGTacgtn", np.uint8), L); b3[:100] = ord('n'); h3 = rng.randint(0, 255, L).astype(np.uint8)
+    bits3 = (rng.rand((L + 63) // 64 * 64) < 0.7).astype(np.uint8); bits3[L:] = 0; bits3[:50] = 1   # possible positions inside the leading n's
+    m3 = np.packbits(bits3, bitorder="little")
+    data = [(b1, h1, m1), (b2, h2, m2), (b3, h3, m3)]
+    bases, hits, masks = _upload(cv, data)
+    lens = np.array([L, L, L], np.int64)
+    for bs in (500, 16, 3, 1):
+        for mode in (3, 0):
+            out, per, total = cv.bin_genome(bases, masks, hits, lens, bs, mode)
+            off = 0
+            for c, (b, h, m) in enumerate(data):
+                es, ee, eg, ec = O.bin_chromosome(b, m, h, bs, mode)
+                assert per[c] == len(es)
+                sl = slice(off, off + len(es))
+                assert (out["start"][sl].cpu().numpy() == es).all()
+                assert (out["stop"][sl].cpu().numpy() == ee).all()
+                assert (out["gc"][sl].cpu().numpy() == eg).all()
+                assert (out["count"][sl].cpu().numpy() == ec.astype(np.float32)).all()
+                off += len(es)
