@@ -1,0 +1,556 @@
+// CanvasClean on MI355X: CanvasClean.Main (CanvasClean/CanvasClean.cs:415-533) over the whole-genome bin SoA.
+//
+// Layout in HBM: struct-of-arrays in file order — chr i32, start i32, stop i32, gc i32, count f32 (SampleGenomicBin.Count is
+// float), plus CountDeviation f64 kept in the workspace.  All arrays fit the 256 MiB Infinity Cache at WGS sizes (5.4 M bins
+// x 28 B = 150 MB), so the stages are launch/latency bound rather than HBM bound; every stage is a streaming pass.
+//
+// Every reduction that feeds a decision is an exact order statistic (radix select, select.hpp) or an integer histogram, and
+// every per-bin floating expression is evaluated element-wise with the reference's operand order and types
+// (-ffp-contract=off), so MedianByGC cleaning is bit-identical to the CPU oracle.
+//
+// Host logic (this file, between launches) only does what the reference does once per file on <= 101 GC buckets / <= a few
+// hundred chromosomes: thresholds, medians of two selected values, quartile interpolation (Utilities.cs:361-419).
+//
+// Not built (returns CANVAS_ERR_UNSUPPORTED): LOESS mode (-m LOESS), manifests (-t), and the neighbour-weighted median for GC
+// buckets holding 1..99 autosomal bins after the GC strip — reachable only with < 10100 autosomal bins and -w < 100
+// (CanvasClean.cs:107-132,226-228).
+#include "common.hpp"
+#include "select.hpp"
+#include <algorithm>
+#include <cmath>
+
+#define NGC 101
+#define CBLK 2048   // elements per compaction block
+
+struct Soa { int32_t *chr, *start, *stop, *gc; float* count; double* dev; };
+
+// ---------------------------------------------------------------- flag kernels
+__global__ void __launch_bounds__(256) k_keys_size(const int32_t* __restrict__ start, const int32_t* __restrict__ stop, int64_t n, uint32_t* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = (uint32_t)(stop[i] - start[i]) ^ 0x80000000u;   // order-preserving image of int32
+}
+__global__ void __launch_bounds__(256) k_flags_size(const int32_t* __restrict__ start, const int32_t* __restrict__ stop, int64_t n, int32_t thresh, uint8_t* __restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = (stop[i] - start[i]) <= thresh;       // CanvasClean.cs:349-352
+}
+// SignificantlyDifferent (CanvasClean.cs:363-381)
+__device__ __forceinline__ bool sig_diff(float a, float b) {
+    double mu = ((double)a + (double)b) / 2;
+    if (a + b == 0) return false;
+    double da = (double)a - mu, db = (double)b - mu;
+    double chi2 = (da * da + db * db) / mu;
+    return chi2 > 6.635;
+}
+// RemoveOutliers (CanvasClean.cs:387-413)
+__global__ void __launch_bounds__(256) k_flags_outlier(const int32_t* __restrict__ chr, const float* __restrict__ count, int64_t n, uint8_t* __restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool hasPrev = i > 0, hasNext = i < n - 1;
+    int32_t c = chr[i];
+    bool prevSame = hasPrev && chr[i - 1] == c, nextSame = hasNext && chr[i + 1] == c;
+    bool keep;
+    if ((hasPrev && !prevSame) && (hasNext && !nextSame)) keep = false;
+    else {
+        float v = count[i];
+        keep = (prevSame && !sig_diff(v, count[i - 1])) || (nextSame && !sig_diff(v, count[i + 1])) || (!hasPrev && !hasNext);
+    }
+    flags[i] = keep;
+}
+__global__ void __launch_bounds__(256) k_flags_gc(const int32_t* __restrict__ gc, int64_t n, const uint8_t* __restrict__ keepGc, uint8_t* __restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = keepGc[gc[i]];
+}
+// RemoveBinsWithExtremeLocalSD (CanvasClean.cs:308-322): drop when CountDeviation > threshold*2.0 (localSDaverage > 5 checked on host)
+__global__ void __launch_bounds__(256) k_flags_localsd(const double* __restrict__ dev, int64_t n, double limit, uint8_t* __restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = !(dev[i] > limit);
+}
+
+// ---------------------------------------------------------------- stable compaction (count / scan / scatter)
+__global__ void __launch_bounds__(256) k_block_count(const uint8_t* __restrict__ flags, int64_t n, uint32_t* __restrict__ blockCnt) {
+    __shared__ uint32_t sh[4];
+    int64_t base = (int64_t)blockIdx.x * CBLK;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < CBLK / 256; j++) { int64_t i = base + j * 256 + threadIdx.x; if (i < n) c += flags[i]; }
+    c = wave_reduce_add_u32(c);
+    if (lane_id() == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blockCnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* __restrict__ blockCnt, int nblocks, unsigned long long* __restrict__ total) {
+    __shared__ uint32_t sh[17];
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 1024) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? blockCnt[i] : 0;
+        uint32_t inc = wave_inclusive_scan_u32(v);
+        int w = threadIdx.x >> 6;
+        if (lane_id() == 63) sh[w] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t s = 0; for (int k = 0; k < 16; k++) { uint32_t t = sh[k]; sh[k] = s; s += t; } sh[16] = s; }
+        __syncthreads();
+        if (i < nblocks) blockCnt[i] = carry + sh[w] + inc - v;
+        carry += sh[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(256) k_scatter(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t n, Soa src, Soa dst) {
+    __shared__ uint32_t sh[4];
+    int64_t base = (int64_t)blockIdx.x * CBLK;
+    uint32_t running = blockOff[blockIdx.x];
+    for (int j = 0; j < CBLK / 256; j++) {
+        int64_t i = base + j * 256 + threadIdx.x;
+        uint32_t f = (i < n) ? flags[i] : 0;
+        uint32_t inc = wave_inclusive_scan_u32(f);
+        if (lane_id() == 63) sh[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) woff += sh[k]; tot += sh[k]; }
+        if (f) {
+            uint32_t d = running + woff + inc - 1;
+            dst.chr[d] = src.chr[i]; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = src.gc[i];
+            dst.count[d] = src.count[i]; dst.dev[d] = src.dev[i];
+        }
+        running += tot;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- GC histogram / grouping
+__global__ void __launch_bounds__(256) k_gc_hist(const int32_t* __restrict__ chr, const int32_t* __restrict__ gc, const uint8_t* __restrict__ isAuto, int64_t n, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[NGC];
+    if (threadIdx.x < NGC) lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        if (isAuto[chr[i]]) atomicAdd(&lh[gc[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x < NGC && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+// scatter the indices of autosomal bins into per-GC contiguous groups (order inside a group is irrelevant: only order statistics are taken)
+__global__ void __launch_bounds__(256) k_group_by_gc(const int32_t* __restrict__ chr, const int32_t* __restrict__ gc, const uint8_t* __restrict__ isAuto, int64_t n,
+                                                     const uint32_t* __restrict__ segOff, uint32_t* __restrict__ cursor, uint32_t* __restrict__ gidx) {
+    __shared__ uint32_t lcnt[NGC], lbase[NGC];
+    if (threadIdx.x < NGC) lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * CBLK;
+    uint32_t myRank[CBLK / 256];
+    int myGc[CBLK / 256];
+#pragma unroll
+    for (int j = 0; j < CBLK / 256; j++) {
+        int64_t i = base + j * 256 + threadIdx.x;
+        myGc[j] = -1;
+        if (i < n && isAuto[chr[i]]) { myGc[j] = gc[i]; myRank[j] = atomicAdd(&lcnt[myGc[j]], 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x < NGC && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], lcnt[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CBLK / 256; j++) {
+        int64_t i = base + j * 256 + threadIdx.x;
+        if (myGc[j] >= 0) gidx[segOff[myGc[j]] + lbase[myGc[j]] + myRank[j]] = (uint32_t)i;
+    }
+}
+__global__ void __launch_bounds__(256) k_gather_keys(const float* __restrict__ count, const uint32_t* __restrict__ gidx, int64_t m, uint32_t* __restrict__ keys) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < m) keys[j] = key_of_float(count[gidx[j]]);
+}
+
+// ---------------------------------------------------------------- element-wise normalisation
+// NormalizeByGC apply (CanvasClean.cs:190-195): count = (float)(globalMedian * (double)count / median) when median > 0
+__global__ void __launch_bounds__(256) k_apply_gc(float* __restrict__ count, const int32_t* __restrict__ gc, int64_t n, const double* __restrict__ medians, double globalMedian) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double median = medians[gc[i]];
+    if (median > 0) count[i] = (float)(globalMedian * (double)count[i] / median);
+}
+// NormalizeVarianceByGC apply (CanvasClean.cs:84-94), float32 arithmetic
+struct VarTab { float localIQR[NGC]; float med[NGC]; float globalIQR; };
+__global__ void __launch_bounds__(256) k_apply_var(float* __restrict__ count, const int32_t* __restrict__ gc, int64_t n, const VarTab* __restrict__ tab) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int g = gc[i];
+    float globalIQR = tab->globalIQR;
+    float scaledLocalIqr = tab->localIQR[g] * 0.8f;
+    if (globalIQR >= scaledLocalIqr) return;
+    float iqrRatio = scaledLocalIqr / globalIQR;
+    float m = tab->med[g];
+    count[i] = m + (count[i] - m) / iqrRatio;
+}
+
+// ---------------------------------------------------------------- local SD (CanvasClean.cs:268-298)
+// one thread per window of 20 consecutive count differences; sequential double arithmetic exactly as
+// Utilities.StandardDeviation(double[], start, end) (Utilities.cs:246-262)
+__global__ void __launch_bounds__(256) k_local_sd(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev) {
+    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= nW) return;
+    int64_t s = w * 20;
+    double d[20];
+    float prev = count[s];
+#pragma unroll
+    for (int k = 0; k < 20; k++) { float nx = count[s + k + 1]; d[k] = (double)(nx - prev); prev = nx; }
+    double sum = 0;
+#pragma unroll
+    for (int k = 0; k < 20; k++) sum += d[k];
+    double mu = sum / 20;
+    double s2 = 0;
+#pragma unroll
+    for (int k = 0; k < 20; k++) { double df = d[k] - mu; s2 += df * df; }
+    double v = sqrt(s2 / 19);
+    sd[w] = v;
+#pragma unroll
+    for (int k = 0; k < 20; k++) dev[s + k] = v;
+}
+__global__ void __launch_bounds__(256) k_fill_f64(double* __restrict__ p, int64_t n, double v) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(256) k_keys_f64(const double* __restrict__ v, int64_t n, unsigned long long* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = key_of_double(v[i]);
+}
+// |sd - median(run)| keys; runStart (window index) sorted ascending
+__global__ void __launch_bounds__(256) k_absdev_keys(const double* __restrict__ sd, int64_t nW, const int64_t* __restrict__ runStart, const double* __restrict__ runMedian,
+                                                     int nruns, unsigned long long* __restrict__ keys) {
+    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= nW) return;
+    int lo = 0, hi = nruns - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (runStart[mid] <= w) lo = mid; else hi = mid - 1; }
+    keys[w] = key_of_double(fabs(sd[w] - runMedian[lo]));
+}
+// chromosome run boundaries of the bin list: positions i with chr[i] != chr[i-1]
+__global__ void __launch_bounds__(256) k_run_bounds(const int32_t* __restrict__ chr, int64_t n, unsigned int* __restrict__ cnt, long long* __restrict__ pos, int cap) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || chr[i] != chr[i - 1]) { unsigned int k = atomicAdd(cnt, 1u); if ((int)k < cap) pos[k] = i; }
+}
+
+// ---------------------------------------------------------------- host helpers (scalar logic of the reference)
+static inline float median_from_two(float a, float b) { return (a + b) / 2; }   // SortedList<float>.Median(), even length
+
+// Utilities.Quartiles (CanvasCommon/Utilities.cs:361-419): which order statistics are needed for length n
+struct QuartIdx { int64_t idx[6]; int n; };
+static QuartIdx quartile_indices(int64_t iSize) {
+    QuartIdx q; q.n = 0;
+    auto add = [&](int64_t v) { q.idx[q.n++] = v; };
+    int64_t iMid = iSize / 2;
+    if (iSize % 2 == 0) {
+        int64_t mm = iMid / 2;
+        add(iMid - 1); add(iMid);
+        if (iMid % 2 == 0) { add(mm - 1); add(mm); add(iMid + mm - 1); add(iMid + mm); }
+        else { add(mm); add(mm + iMid); }
+    } else {
+        add(iMid);
+        if ((iSize - 1) % 4 == 0) { int64_t n = (iSize - 1) / 4; add(n - 1); add(n); add(3 * n); add(3 * n + 1); }
+        else { int64_t n = (iSize - 3) / 4; add(n); add(n + 1); add(3 * n + 1); add(3 * n + 2); }
+    }
+    return q;
+}
+static void quartiles_from_values(int64_t iSize, const float* v, float& q1, float& q2, float& q3) {
+    int64_t iMid = iSize / 2;
+    if (iSize % 2 == 0) {
+        q2 = (v[0] + v[1]) / 2;
+        if (iMid % 2 == 0) { q1 = (v[2] + v[3]) / 2; q3 = (v[4] + v[5]) / 2; }
+        else { q1 = v[2]; q3 = v[3]; }
+    } else {
+        q2 = v[0];
+        if ((iSize - 1) % 4 == 0) { q1 = (v[1] * 0.25f) + (v[2] * 0.75f); q3 = (v[3] * 0.75f) + (v[4] * 0.25f); }
+        else { q1 = (v[1] * 0.75f) + (v[2] * 0.25f); q3 = (v[3] * 0.25f) + (v[4] * 0.75f); }
+    }
+}
+
+struct CleanState {
+    canvas_ctx* ctx;
+    int64_t n;
+    Soa cur, alt;            // cur holds the live bins
+    uint8_t* flags; uint32_t* blockCnt; unsigned long long* dTotal;
+    uint32_t* keys32; unsigned long long* keys64; uint32_t* gidx;
+    uint8_t* dIsAuto;
+};
+
+static inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// compaction cur -> alt by st.flags; swaps; returns new n (one sync)
+static int32_t compact(CleanState& st) {
+    canvas_ctx* ctx = st.ctx;
+    if (st.n == 0) return CANVAS_OK;
+    int nb = (int)nblk(st.n, CBLK);
+    hipLaunchKernelGGL(k_block_count, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.n, st.blockCnt);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, st.blockCnt, nb, st.dTotal);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.blockCnt, st.n, st.cur, st.alt);
+    unsigned long long tot = 0;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&tot, st.dTotal, 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    std::swap(st.cur, st.alt);
+    st.n = (int64_t)tot;
+    return CANVAS_OK;
+}
+
+struct GcGroups {              // autosomal bins grouped by GC
+    uint32_t hist[NGC];
+    std::vector<int64_t> segOff;   // NGC+1
+    int64_t nauto;
+};
+
+static int32_t gc_histogram(CleanState& st, uint32_t* dHist, uint32_t* hist) {
+    canvas_ctx* ctx = st.ctx;
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dHist, 0, NGC * 4, ctx->stream));
+    if (st.n > 0) hipLaunchKernelGGL(k_gc_hist, dim3(std::min<unsigned>(nblk(st.n, 256), 1024u)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.gc, st.dIsAuto, st.n, dHist);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hist, dHist, NGC * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+
+// build gidx for the current bins (call after any compaction)
+static int32_t group_by_gc(CleanState& st, GcGroups& g, uint32_t* dSegOff, uint32_t* dCursor) {
+    canvas_ctx* ctx = st.ctx;
+    g.segOff.assign(NGC + 1, 0);
+    for (int i = 0; i < NGC; i++) g.segOff[i + 1] = g.segOff[i] + g.hist[i];
+    g.nauto = g.segOff[NGC];
+    uint32_t so[NGC + 1];
+    for (int i = 0; i <= NGC; i++) so[i] = (uint32_t)g.segOff[i];
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSegOff, so, sizeof so, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCursor, 0, NGC * 4, ctx->stream));
+    if (st.n > 0) hipLaunchKernelGGL(k_group_by_gc, dim3(nblk(st.n, CBLK)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.gc, st.dIsAuto, st.n, dSegOff, dCursor, st.gidx);
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `so` is a stack buffer
+    return CANVAS_OK;
+}
+
+// NormalizeByGC (CanvasClean.cs:163-196) on the grouped autosomal counts
+static int32_t normalize_by_gc(CleanState& st, const GcGroups& g, double* dMedians) {
+    canvas_ctx* ctx = st.ctx;
+    if (g.nauto == 0) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "NormalizeByGC: no autosomal bins (the reference would throw on an empty median)");
+    hipLaunchKernelGGL(k_gather_keys, dim3(nblk(g.nauto, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.gidx, g.nauto, st.keys32);
+    std::vector<SelQuery> qs;
+    auto addMedian = [&](int lo, int hi, int64_t cnt) { if (cnt % 2) qs.push_back({lo, hi, cnt / 2}); else { qs.push_back({lo, hi, cnt / 2 - 1}); qs.push_back({lo, hi, cnt / 2}); } };
+    addMedian(0, NGC - 1, g.nauto);
+    std::vector<int> first(NGC, -1);
+    for (int gc = 0; gc < NGC; gc++) if (g.hist[gc] > 0) { first[gc] = (int)qs.size(); addMedian(gc, gc, g.hist[gc]); }
+    std::vector<unsigned long long> res;
+    int32_t rc = radix_select<uint32_t>(ctx, st.keys32, NGC, g.segOff, qs, res); if (rc) return rc;
+    auto med = [&](int at, int64_t cnt) -> double {
+        if (cnt % 2) return (double)host_float_of_key((uint32_t)res[at]);
+        return (double)median_from_two(host_float_of_key((uint32_t)res[at]), host_float_of_key((uint32_t)res[at + 1]));
+    };
+    double globalMedian = med(0, g.nauto);
+    double medians[NGC];
+    for (int gc = 0; gc < NGC; gc++) medians[gc] = first[gc] >= 0 ? med(first[gc], g.hist[gc]) : 0.0;   // empty buckets: no bin reads them
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dMedians, medians, sizeof medians, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_apply_gc, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.cur.gc, st.n, dMedians, globalMedian);
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    return CANVAS_OK;
+}
+
+// NormalizeVarianceByGC (CanvasClean.cs:34-97); returns whether counts were changed
+static int32_t normalize_variance_by_gc(CleanState& st, const GcGroups& g, VarTab* dTab, bool& changed) {
+    canvas_ctx* ctx = st.ctx;
+    changed = false;
+    hipLaunchKernelGGL(k_gather_keys, dim3(nblk(g.nauto, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.gidx, g.nauto, st.keys32);
+    std::vector<SelQuery> qs;
+    std::vector<int> first(NGC + 1, -1);
+    auto addQ = [&](int slot, int lo, int hi, int64_t cnt) { first[slot] = (int)qs.size(); QuartIdx qi = quartile_indices(cnt); for (int k = 0; k < qi.n; k++) qs.push_back({lo, hi, qi.idx[k]}); };
+    if (g.nauto < 2) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "NormalizeVarianceByGC: fewer than 2 autosomal bins");
+    addQ(NGC, 0, NGC - 1, g.nauto);
+    for (int gc = 0; gc < NGC; gc++) if (g.hist[gc] >= 100) addQ(gc, gc, gc, g.hist[gc]);
+    std::vector<unsigned long long> res;
+    int32_t rc = radix_select<uint32_t>(ctx, st.keys32, NGC, g.segOff, qs, res); if (rc) return rc;
+    auto quart = [&](int slot, int64_t cnt, float& q1, float& q2, float& q3) {
+        float v[6]; QuartIdx qi = quartile_indices(cnt);
+        for (int k = 0; k < qi.n; k++) v[k] = host_float_of_key((uint32_t)res[first[slot] + k]);
+        quartiles_from_values(cnt, v, q1, q2, q3);
+    };
+    float g1, g2, g3;
+    quart(NGC, g.nauto, g1, g2, g3);
+    VarTab tab;
+    for (int gc = 0; gc < NGC; gc++) {
+        if (g.hist[gc] == 0) { tab.localIQR[gc] = -1.0f; tab.med[gc] = -1.0f; }
+        else { float q1, q2, q3; quart(gc, g.hist[gc], q1, q2, q3); tab.med[gc] = q2; tab.localIQR[gc] = q3 - q1; }
+    }
+    tab.globalIQR = g3 - g1;
+    int significant = 0;
+    for (int i = 10; i < 90; i++) if (tab.globalIQR * 2.0f < tab.localIQR[i]) significant++;
+    if (significant <= 0) return CANVAS_OK;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, &tab, sizeof tab, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_apply_var, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.cur.gc, st.n, dTab);
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    changed = true;
+    return CANVAS_OK;
+}
+
+// GetLocalStandardDeviation + GetLocalStandardDeviationAverage (CanvasClean.cs:243-298); Q8 kept
+static int32_t local_sd(CleanState& st, double* dSd, double* dRunMedian, int64_t* dRunStart, unsigned int* dCnt, long long* dPos, double& localSd) {
+    canvas_ctx* ctx = st.ctx;
+    const int64_t D = st.n - 1;
+    const int64_t nW = D >= 1 ? (D - 1) / 20 : 0;    // windows with windowEnd = 20(w+1) < D
+    if (nW <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "local SD: no complete window");
+    hipLaunchKernelGGL(k_local_sd, dim3(nblk(nW, 256)), dim3(256), 0, ctx->stream, st.cur.count, nW, dSd, st.cur.dev);
+    // chromosome runs of the bin list -> runs of windows (window w belongs to the chromosome of bin 20w)
+    const int cap = 65536;
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCnt, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_run_bounds, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.n, dCnt, dPos, cap);
+    unsigned int nb = 0;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&nb, dCnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((int)nb > cap) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "local SD: more than 65536 chromosome runs");
+    std::vector<long long> bpos(nb);
+    CANVAS_HIP_TRY(ctx, hipMemcpy(bpos.data(), dPos, nb * 8, hipMemcpyDeviceToHost));
+    std::sort(bpos.begin(), bpos.end());
+    std::vector<int32_t> bchr(nb);
+    for (unsigned i = 0; i < nb; i++) CANVAS_HIP_TRY(ctx, hipMemcpy(&bchr[i], st.cur.chr + bpos[i], 4, hipMemcpyDeviceToHost));
+    bpos.push_back(st.n);
+    std::vector<int64_t> runStart; std::vector<int32_t> runChr;
+    for (unsigned r = 0; r < nb; r++) {
+        int64_t w0 = (bpos[r] + 19) / 20, w1 = std::min<int64_t>((bpos[r + 1] + 19) / 20, nW);
+        if (w0 >= w1) continue;
+        if (!runChr.empty() && runChr.back() == bchr[r]) continue;   // adjacent windows with the same chromosome merge
+        runStart.push_back(w0); runChr.push_back(bchr[r]);
+    }
+    const int nruns = (int)runStart.size();
+    std::vector<int64_t> segOff(runStart); segOff.push_back(nW);
+    segOff[0] = 0;
+    // median per run
+    hipLaunchKernelGGL(k_keys_f64, dim3(nblk(nW, 256)), dim3(256), 0, ctx->stream, dSd, nW, st.keys64);
+    std::vector<SelQuery> qs; std::vector<int> first(nruns);
+    for (int r = 0; r < nruns; r++) {
+        int64_t cnt = segOff[r + 1] - segOff[r];
+        first[r] = (int)qs.size();
+        if (cnt % 2) qs.push_back({r, r, cnt / 2}); else { qs.push_back({r, r, cnt / 2 - 1}); qs.push_back({r, r, cnt / 2}); }
+    }
+    std::vector<unsigned long long> res;
+    int32_t rc = radix_select<unsigned long long>(ctx, st.keys64, nruns, segOff, qs, res); if (rc) return rc;
+    auto med = [&](int r) -> double {
+        int64_t cnt = segOff[r + 1] - segOff[r];
+        if (cnt % 2) return host_double_of_key(res[first[r]]);
+        return (host_double_of_key(res[first[r]]) + host_double_of_key(res[first[r] + 1])) / 2;
+    };
+    std::vector<double> medians(nruns);
+    for (int r = 0; r < nruns; r++) medians[r] = med(r);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRunMedian, medians.data(), nruns * 8, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRunStart, segOff.data(), nruns * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_absdev_keys, dim3(nblk(nW, 256)), dim3(256), 0, ctx->stream, dSd, nW, dRunStart, dRunMedian, nruns, st.keys64);
+    rc = radix_select<unsigned long long>(ctx, st.keys64, nruns, segOff, qs, res); if (rc) return rc;
+    double s = 0;
+    for (int r = 0; r < nruns; r++) s += med(r);        // List<double>.Average(): sequential sum / count
+    localSd = s / (double)nruns;
+    return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
+                                int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
+                                double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (n < 0 || nchr <= 0 || !h_chr_is_autosome || !h_n_out) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: bad arguments");
+    if (flags & CANVAS_CLEAN_LOESS) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "CanvasClean -m LOESS (LoessGCNormalizer.cs) is not built yet");
+    if (n >= 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "too many bins");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t info[8] = {0};
+    double localSd = -1.0;
+    if (n == 0) { *h_n_out = 0; if (h_local_sd_out) *h_local_sd_out = -1.0; if (h_info) memcpy(h_info, info, sizeof info); return CANVAS_OK; }
+    // workspace
+    const int64_t nW0 = n / 20 + 2;
+    WsSizer sz;
+    sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n); sz.take<double>(n);
+    sz.take<uint8_t>(n); sz.take<uint32_t>(n / CBLK + 2); sz.take<unsigned long long>(1); sz.take<uint32_t>(n); sz.take<unsigned long long>(nW0); sz.take<uint32_t>(n);
+    sz.take<uint8_t>(nchr); sz.take<uint32_t>(NGC); sz.take<uint32_t>(NGC + 1); sz.take<uint32_t>(NGC); sz.take<double>(NGC); sz.take<VarTab>(1);
+    sz.take<uint8_t>(NGC); sz.take<double>(nW0); sz.take<double>(65536); sz.take<int64_t>(65536 + 1); sz.take<unsigned int>(1); sz.take<long long>(65536);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
+    WsCarver ws(ctx->ws);
+    CleanState st; st.ctx = ctx; st.n = n;
+    st.cur = Soa{d_chr, d_start, d_stop, d_gc, d_count, nullptr};
+    st.alt.chr = ws.take<int32_t>(n); st.alt.start = ws.take<int32_t>(n); st.alt.stop = ws.take<int32_t>(n); st.alt.gc = ws.take<int32_t>(n);
+    st.alt.count = ws.take<float>(n); st.alt.dev = ws.take<double>(n); st.cur.dev = ws.take<double>(n);
+    st.flags = ws.take<uint8_t>(n); st.blockCnt = ws.take<uint32_t>(n / CBLK + 2); st.dTotal = ws.take<unsigned long long>(1);
+    st.keys32 = ws.take<uint32_t>(n); st.keys64 = ws.take<unsigned long long>(nW0); st.gidx = ws.take<uint32_t>(n);
+    st.dIsAuto = ws.take<uint8_t>(nchr);
+    uint32_t* dHist = ws.take<uint32_t>(NGC); uint32_t* dSegOff = ws.take<uint32_t>(NGC + 1); uint32_t* dCursor = ws.take<uint32_t>(NGC);
+    double* dMedians = ws.take<double>(NGC); VarTab* dTab = ws.take<VarTab>(1); uint8_t* dKeepGc = ws.take<uint8_t>(NGC);
+    double* dSd = ws.take<double>(nW0); double* dRunMedian = ws.take<double>(65536); int64_t* dRunStart = ws.take<int64_t>(65536 + 1);
+    unsigned int* dCnt = ws.take<unsigned int>(1); long long* dPos = ws.take<long long>(65536);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(st.dIsAuto, h_chr_is_autosome, nchr, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_fill_f64, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, st.cur.dev, n, -1.0);   // CountDeviation = -1 (GenomicBin.cs:83)
+
+    // RemoveBigBins (CanvasClean.cs:328-355)
+    if (flags & CANVAS_CLEAN_FILTSIZE) {
+        int64_t index = (int64_t)(0.98 * (double)st.n);
+        if (index < st.n) {
+            hipLaunchKernelGGL(k_keys_size, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.start, st.cur.stop, st.n, st.keys32);
+            std::vector<unsigned long long> res;
+            rc = radix_select<uint32_t>(ctx, st.keys32, 1, std::vector<int64_t>{0, st.n}, std::vector<SelQuery>{{0, 0, index}}, res); if (rc) return rc;
+            int32_t thresh = (int32_t)((uint32_t)res[0] ^ 0x80000000u);
+            hipLaunchKernelGGL(k_flags_size, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.start, st.cur.stop, st.n, thresh, st.flags);
+            rc = compact(st); if (rc) return rc;
+        }
+    }
+    info[0] = (int32_t)st.n;
+    // RemoveOutliers (CanvasClean.cs:387-413)
+    if ((flags & CANVAS_CLEAN_OUTLIERS) && st.n > 0) {
+        hipLaunchKernelGGL(k_flags_outlier, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.count, st.n, st.flags);
+        rc = compact(st); if (rc) return rc;
+    }
+    info[1] = (int32_t)st.n;
+    bool haveLocalSd = (flags & CANVAS_CLEAN_LOCALSD) && st.n >= 50000;   // CanvasClean.cs:483-486
+    if (haveLocalSd) { rc = local_sd(st, dSd, dRunMedian, dRunStart, dCnt, dPos, localSd); if (rc) return rc; }
+    if ((flags & CANVAS_CLEAN_GCNORM) && st.n > 0) {
+        // RemoveBinsWithExtremeGC (CanvasClean.cs:207-237)
+        GcGroups g;
+        rc = gc_histogram(st, dHist, g.hist); if (rc) return rc;
+        double totalCount = 0;
+        for (int i = 0; i < NGC; i++) totalCount += g.hist[i];
+        int averageCountPerGC = std::max(min_bins_per_gc, (int)(totalCount / NGC));
+        int threshold = std::min(100, averageCountPerGC);
+        uint8_t keep[NGC]; int64_t kept = 0; bool dropsAny = false;
+        // number of surviving bins is only known after compaction (X/Y bins count too); decide emptiness from the flags
+        for (int i = 0; i < NGC; i++) { keep[i] = (int)g.hist[i] >= threshold; if (!keep[i]) dropsAny = true; }
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dKeepGc, keep, NGC, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_flags_gc, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.gc, st.n, dKeepGc, st.flags);
+        // count survivors without moving data first: "strippedBins.Count == 0 -> proceed without GC correction" (CanvasClean.cs:500-505)
+        int nb = (int)nblk(st.n, CBLK);
+        hipLaunchKernelGGL(k_block_count, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.n, st.blockCnt);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, st.blockCnt, nb, st.dTotal);
+        unsigned long long tot = 0;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&tot, st.dTotal, 8, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        kept = (int64_t)tot;
+        if (kept > 0) {
+            if (dropsAny && kept < st.n) {
+                hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.blockCnt, st.n, st.cur, st.alt);
+                std::swap(st.cur, st.alt); st.n = kept;
+            }
+            for (int i = 0; i < NGC; i++) {
+                if (!keep[i]) g.hist[i] = 0;
+                else if (g.hist[i] > 0 && g.hist[i] < 100) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "weighted median over GC buckets with 1..99 bins (CanvasClean.cs:107-132) is not built");
+            }
+            rc = group_by_gc(st, g, dSegOff, dCursor); if (rc) return rc;
+            rc = normalize_by_gc(st, g, dMedians); if (rc) return rc;
+            if (haveLocalSd && st.n > 500000) {     // CanvasClean.cs:512-519
+                bool changed = false;
+                rc = normalize_variance_by_gc(st, g, dTab, changed); if (rc) return rc;
+                info[4] = changed ? 1 : 0;
+                if (changed) { rc = normalize_by_gc(st, g, dMedians); if (rc) return rc; }
+            }
+        }
+    }
+    info[2] = (int32_t)st.n;
+    if (haveLocalSd && localSd > 5.0 && st.n > 0) {    // RemoveBinsWithExtremeLocalSD (threshold 20 -> 40.0)
+        hipLaunchKernelGGL(k_flags_localsd, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.dev, st.n, 20 * 2.0, st.flags);
+        rc = compact(st); if (rc) return rc;
+    }
+    info[3] = (int32_t)st.n;
+    // results must end in the caller's arrays
+    if (st.cur.chr != d_chr && st.n > 0) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_chr, st.cur.chr, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_start, st.cur.start, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_stop, st.cur.stop, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_gc, st.cur.gc, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_count, st.cur.count, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    *h_n_out = st.n;
+    if (h_local_sd_out) *h_local_sd_out = haveLocalSd ? localSd : -1.0;
+    if (h_info) memcpy(h_info, info, sizeof info);
+    return CANVAS_OK;
+}

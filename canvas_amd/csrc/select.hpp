@@ -1,0 +1,142 @@
+// Exact order statistics on the GPU: multi-segment, multi-query MSB radix select (8-bit digits).
+// Keys are order-preserving unsigned images of float / double / int32 values, so the selected key IS the k-th smallest
+// value bit-for-bit (no floating reduction anywhere => matches a CPU sort exactly).
+//
+//   keys      contiguous array, partitioned in segments; a tile (<= 4096 keys) never crosses a segment
+//   query q   (segLo..segHi, k): k-th smallest (0-based) of the union of segments segLo..segHi
+//             (per-GC medians use segLo == segHi == gc; the genome-wide median uses 0..100 over the same array)
+//   pass p    histogram of digit p among the keys that match the query's prefix so far (LDS-privatised, then
+//             flushed with global atomics), then k_select_pick narrows every query by one digit.
+// After KEYBITS/8 passes qprefix[q] is the answer.
+#pragma once
+#include "common.hpp"
+
+#define SEL_TILE 4096
+#define SEL_MAXQ 16   // max queries that can apply to one tile
+
+struct SelTile { int32_t seg; int64_t begin; int64_t end; };
+struct SelSegQ { int32_t nq; int32_t q[SEL_MAXQ]; };
+
+__device__ __forceinline__ uint32_t key_of_float(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_of_key(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long key_of_double(double d) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+static inline float host_float_of_key(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f; memcpy(&f, &u, 4); return f;
+}
+static inline double host_double_of_key(unsigned long long k) {
+    unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    double d; memcpy(&d, &u, 8); return d;
+}
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys, const SelTile* __restrict__ tiles, const SelSegQ* __restrict__ segq,
+                                                     const unsigned long long* __restrict__ qprefix, int shift, int firstPass,
+                                                     uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[SEL_MAXQ * 256];
+    __shared__ unsigned long long lpre[SEL_MAXQ];
+    const SelTile T = tiles[blockIdx.x];
+    const SelSegQ Q = segq[T.seg];
+    if (Q.nq == 0) return;
+    for (int i = threadIdx.x; i < Q.nq * 256; i += 256) lh[i] = 0;
+    if (threadIdx.x < Q.nq) lpre[threadIdx.x] = qprefix[Q.q[threadIdx.x]];
+    __syncthreads();
+    const int sh2 = firstPass ? 0 : shift + 8;
+    for (int64_t i = T.begin + threadIdx.x; i < T.end; i += 256) {
+        K key = keys[i];
+        uint32_t d = (uint32_t)(key >> shift) & 255u;
+        unsigned long long hi = (unsigned long long)(key >> sh2);   // only compared when !firstPass (then sh2 = shift+8 < bits)
+        for (int q = 0; q < Q.nq; q++)
+            if (firstPass || hi == lpre[q]) atomicAdd(&lh[q * 256 + d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Q.nq * 256; i += 256) {
+        uint32_t v = lh[i];
+        if (v) atomicAdd(&hist[(size_t)Q.q[i >> 8] * 256 + (i & 255)], v);
+    }
+}
+
+// one wave per query: locate the digit holding rank k, narrow (prefix, k), clear the histogram row
+__global__ void __launch_bounds__(64) k_select_pick(uint32_t* __restrict__ hist, unsigned long long* __restrict__ qprefix,
+                                                    unsigned long long* __restrict__ qk, int nq) {
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const int l = threadIdx.x;
+    uint32_t* h = hist + (size_t)q * 256;
+    uint32_t c0 = h[4 * l], c1 = h[4 * l + 1], c2 = h[4 * l + 2], c3 = h[4 * l + 3];
+    uint32_t s = c0 + c1 + c2 + c3;
+    uint32_t inc = wave_inclusive_scan_u32(s);
+    uint32_t ex = inc - s;
+    unsigned long long k = qk[q];
+    // the lane whose range [ex, inc) contains k
+    if (k >= ex && k < inc) {
+        uint32_t r = (uint32_t)(k - ex), d;
+        if (r < c0) { d = 0; }
+        else if (r < c0 + c1) { d = 1; r -= c0; }
+        else if (r < c0 + c1 + c2) { d = 2; r -= c0 + c1; }
+        else { d = 3; r -= c0 + c1 + c2; }
+        qprefix[q] = (qprefix[q] << 8) | (unsigned long long)(4 * l + d);
+        qk[q] = r;
+    }
+    h[4 * l] = 0; h[4 * l + 1] = 0; h[4 * l + 2] = 0; h[4 * l + 3] = 0;
+}
+
+// ---- host driver ----------------------------------------------------------------------------------------------
+struct SelQuery { int32_t segLo, segHi; int64_t k; };
+
+// Runs all queries; results (keys as u64) are returned in `out`.  segOff has nseg+1 entries (host).  One sync at the end.
+template <typename K>
+static int32_t radix_select(canvas_ctx* ctx, const K* d_keys, int nseg, const std::vector<int64_t>& segOff,
+                            const std::vector<SelQuery>& queries, std::vector<unsigned long long>& out) {
+    const int nq = (int)queries.size();
+    out.assign(nq, 0);
+    if (nq == 0) return CANVAS_OK;
+    std::vector<SelTile> tiles;
+    for (int s = 0; s < nseg; s++)
+        for (int64_t b = segOff[s]; b < segOff[s + 1]; b += SEL_TILE) tiles.push_back({s, b, std::min<int64_t>(b + SEL_TILE, segOff[s + 1])});
+    std::vector<SelSegQ> segq(nseg);
+    for (int s = 0; s < nseg; s++) segq[s].nq = 0;
+    for (int q = 0; q < nq; q++)
+        for (int s = queries[q].segLo; s <= queries[q].segHi; s++) {
+            if (segq[s].nq >= SEL_MAXQ) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "radix_select: too many queries per segment");
+            segq[s].q[segq[s].nq++] = q;
+        }
+    if (tiles.empty()) return CANVAS_OK;
+    // device scratch: separate small allocation (the main workspace is owned by the caller stage)
+    size_t bytes = tiles.size() * sizeof(SelTile) + segq.size() * sizeof(SelSegQ) + (size_t)nq * (16 + 1024) + 1024;
+    char* d = nullptr;
+    CANVAS_HIP_TRY(ctx, hipMallocAsync((void**)&d, bytes, ctx->stream));
+    char* p = d;
+    SelTile* dTiles = (SelTile*)p; p += (tiles.size() * sizeof(SelTile) + 255) & ~size_t(255);
+    SelSegQ* dSegq = (SelSegQ*)p; p += (segq.size() * sizeof(SelSegQ) + 255) & ~size_t(255);
+    unsigned long long* dPrefix = (unsigned long long*)p; p += ((size_t)nq * 8 + 255) & ~size_t(255);
+    unsigned long long* dK = (unsigned long long*)p; p += ((size_t)nq * 8 + 255) & ~size_t(255);
+    uint32_t* dHist = (uint32_t*)p;
+    std::vector<unsigned long long> hk(nq);
+    for (int q = 0; q < nq; q++) hk[q] = (unsigned long long)queries[q].k;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTiles, tiles.data(), tiles.size() * sizeof(SelTile), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSegq, segq.data(), segq.size() * sizeof(SelSegQ), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dK, hk.data(), (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dPrefix, 0, (size_t)nq * 8, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dHist, 0, (size_t)nq * 1024, ctx->stream));
+    const int bits = (int)sizeof(K) * 8;
+    for (int shift = bits - 8; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL((k_select_hist<K>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, d_keys, dTiles, dSegq, dPrefix, shift,
+                           shift == bits - 8 ? 1 : 0, dHist);
+        hipLaunchKernelGGL(k_select_pick, dim3(nq), dim3(64), 0, ctx->stream, dHist, dPrefix, dK, nq);
+    }
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(out.data(), dPrefix, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // tiles/segq/hk host vectors must outlive the async copies
+    CANVAS_HIP_TRY(ctx, hipFreeAsync(d, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    return CANVAS_OK;
+}
