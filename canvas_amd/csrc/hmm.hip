@@ -1,0 +1,371 @@
+// CanvasPartition PerSampleHMM on MI355X: HiddenMarkovModelsRunner.Run (HiddenMarkovModelsRunner.cs:23-109),
+// NegativeBinomialWrapper (CanvasCommon/DistributionUtilities.cs:51-69), BestPathViterbi (HMM.cs:62-130) and the
+// state-path -> segment-id step (Segmentation.cs:83-125, SegmentationResultsProcessor.cs:17-129).
+//
+// What runs where
+//   device  per-sample genome-wide quartiles of (float)coverage: exact order statistics (select.hpp)
+//   host    the 5 negative-binomial emission tables (<= a few thousand doubles, libm log/exp/pow/lgamma — the reference calls the
+//           platform libm too, Q13) -> log tables uploaded once
+//   device  k_hmm_index    coverage -> table index: Convert.ToInt32(min(x, 5*haploidMean)), round-half-even   [parallel]
+//   device  k_viterbi      one wave per chromosome; lanes 0..4 own states j=0..4.  The recurrence is evaluated in the
+//                          reference's sequential order and association: tmp = delta[i] + (logpmf_j(x_t) + logA[i][j]),
+//                          strict '>' scan i=0..4 from -DBL_MAX.  A max-plus parallel scan would re-associate the double
+//                          additions and can flip near-tie argmaxes, so the time loop stays sequential (latency-bound,
+//                          not HBM-bound: 16 B/bin algorithmic traffic).  Emissions for 64 steps are staged in LDS by all
+//                          64 lanes in parallel; back-pointers are written as bytes.
+//   device  k_backtrack_*  back-pointer chasing as an exact function-composition scan over 256-step blocks [parallel]
+//   device  k_seg_flags / k_seg_ids   break points + inter-bin-distance rule -> running segment id (prefix sum)
+#include "common.hpp"
+#include "select.hpp"
+#include <cmath>
+#include <limits>
+#include <algorithm>
+
+#define NSTATE 5
+#define BT_BLOCK 256
+
+struct HmmParams {
+    double logA[NSTATE][NSTATE];   // log(transition[i][j])
+    double logPi[NSTATE];
+    int32_t tableLen;              // entries per state in logPmf
+    double maxThreshold;
+};
+
+__global__ void __launch_bounds__(256) k_keys_cov_f32(const double* __restrict__ cov, int64_t n, uint32_t* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = key_of_float((float)cov[i]);     // (float)x, HiddenMarkovModelsRunner.cs:43
+}
+
+// RemoveOutliers (HiddenMarkovModelsRunner.cs:154-162) + Convert.ToInt32 (Distributions.cs:271)
+__global__ void __launch_bounds__(256) k_hmm_index(const double* __restrict__ cov, int64_t n, double maxThreshold, int32_t* __restrict__ idx) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double x = cov[i];
+    x = x > maxThreshold ? maxThreshold : x;
+    int32_t k = (int32_t)rint(x);  // round half to even
+    idx[i] = k < 0 ? 0 : k;        // negative coverage would throw in the reference; never read out of bounds here
+}
+
+struct HmmChrom { int64_t begin; int64_t T; };
+
+// one wave per chromosome
+__global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx, const double* __restrict__ logPmf,
+                                                HmmParams P, uint8_t* __restrict__ psi /* [5][N] */, int64_t N, int32_t* __restrict__ lastState) {
+    extern __shared__ double sTab[];                 // [5][tableLen] when it fits, else unused
+    __shared__ double sE[64 * NSTATE];               // emissions of the current 64-step block
+    const HmmChrom C = chroms[blockIdx.x];
+    const int l = threadIdx.x;
+    const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
+    if (useLds) { for (int i = l; i < P.tableLen * NSTATE; i += 64) sTab[i] = logPmf[i]; }
+    __syncthreads();
+    if (C.T <= 10) { if (l == 0) lastState[blockIdx.x] = -1; return; }     // chromosome skipped (HiddenMarkovModelsRunner.cs:69)
+    const double* tab = useLds ? sTab : logPmf;
+    const int j = l < NSTATE ? l : 0;
+    double la[NSTATE];
+#pragma unroll
+    for (int i = 0; i < NSTATE; i++) la[i] = P.logA[i][j];
+    const double NEG = -1.7976931348623157e308;      // Double.MinValue
+    double delta = 0;
+    const int32_t* ix = idx + C.begin;
+    uint8_t* myPsi = psi + (size_t)j * N + C.begin;
+    for (int64_t t0 = 0; t0 < C.T; t0 += 64) {
+        // all 64 lanes: table look-ups for the next 64 steps
+        int64_t t = t0 + l;
+        if (t < C.T) {
+            int k = ix[t];
+#pragma unroll
+            for (int s = 0; s < NSTATE; s++) sE[l * NSTATE + s] = tab[s * P.tableLen + k];
+        }
+        __syncthreads();
+        const int steps = (int)((C.T - t0) < 64 ? (C.T - t0) : 64);
+        if (l < NSTATE) {
+            for (int s = 0; s < steps; s++) {
+                const double e = sE[s * NSTATE + j];
+                if (t0 + s == 0) {
+                    // bestScore[0][j] = log(pi_j) + EstimateViterbiLikelihood(x0, j, transition[0]) - log(transition[0][j])   (HMM.cs:78)
+                    double lik = e + P.logA[0][j];
+                    delta = P.logPi[j] + lik - P.logA[0][j];
+                    continue;
+                }
+                double d[NSTATE];
+#pragma unroll
+                for (int i = 0; i < NSTATE; i++) d[i] = __shfl(delta, i, 64);
+                int state = 0;
+                double mx = NEG;
+#pragma unroll
+                for (int i = 0; i < NSTATE; i++) {
+                    double vit = e + la[i];          // Math.Log(maxLikelyhood) + Math.Log(transitionLikelihood)
+                    double tmp = d[i] + vit;         // bestScore[t-1][i] + vitLogL
+                    if (tmp > mx) { state = i; mx = tmp; }
+                }
+                delta = mx;
+                myPsi[t0 + s] = (uint8_t)state;
+            }
+        }
+        __syncthreads();
+    }
+    // best final state: strict '>' scan from Double.MinValue, bestState initialised to -1 (HMM.cs:100-111)
+    double d[NSTATE];
+#pragma unroll
+    for (int i = 0; i < NSTATE; i++) d[i] = __shfl(delta, i, 64);
+    if (l == 0) {
+        int best = -1; double m1 = NEG;
+#pragma unroll
+        for (int i = 0; i < NSTATE; i++) if (d[i] > m1) { best = i; m1 = d[i]; }
+        lastState[blockIdx.x] = best;
+    }
+}
+
+// ---- backtracking as function composition over blocks of BT_BLOCK steps
+// block b of a chromosome covers t in (lo, hi] with hi = min(T-1, (b+1)*BT_BLOCK), lo = b*BT_BLOCK; state[t-1] = psi[state[t]][t]
+struct BtBlock { int32_t chrom; int64_t lo, hi; };   // chromosome-relative
+__global__ void __launch_bounds__(256) k_bt_maps(const BtBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const uint8_t* __restrict__ psi,
+                                                 int64_t N, uint8_t* __restrict__ maps /* [nblocks][5] */) {
+    int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const BtBlock B = blocks[b];
+    const int64_t base = chroms[B.chrom].begin;
+    int s[NSTATE] = {0, 1, 2, 3, 4};
+    for (int64_t t = B.hi; t > B.lo; t--) {
+#pragma unroll
+        for (int k = 0; k < NSTATE; k++) s[k] = psi[(size_t)s[k] * N + base + t];
+    }
+#pragma unroll
+    for (int k = 0; k < NSTATE; k++) maps[b * NSTATE + k] = (uint8_t)s[k];
+}
+// one thread per chromosome: entry state of every block (state at t = hi)
+__global__ void k_bt_chain(const int32_t* __restrict__ firstBlock, int nchr, const int32_t* __restrict__ lastState, const uint8_t* __restrict__ maps, int8_t* __restrict__ entry) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchr) return;
+    int s = lastState[c];
+    for (int b = firstBlock[c + 1] - 1; b >= firstBlock[c]; b--) {
+        entry[b] = (int8_t)s;
+        if (s >= 0) s = maps[b * NSTATE + s];
+    }
+}
+__global__ void __launch_bounds__(256) k_bt_states(const BtBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const uint8_t* __restrict__ psi,
+                                                   int64_t N, const int8_t* __restrict__ entry, int32_t* __restrict__ state) {
+    int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const BtBlock B = blocks[b];
+    const int64_t base = chroms[B.chrom].begin;
+    int s = entry[b];
+    for (int64_t t = B.hi; t > B.lo; t--) {
+        state[base + t] = s;
+        if (s >= 0) s = psi[(size_t)s * N + base + t];
+    }
+    if (B.lo == 0) state[base] = s;
+}
+__global__ void __launch_bounds__(256) k_fill_i32(int32_t* __restrict__ p, int64_t begin, int64_t end, int32_t v) {
+    int64_t i = begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < end) p[i] = v;
+}
+
+// ---- segment ids
+__global__ void __launch_bounds__(256) k_seg_flags(const int64_t* __restrict__ chrOff, int nchr, const int32_t* __restrict__ state, const int32_t* __restrict__ start,
+                                                   const int32_t* __restrict__ stop, int64_t n, int32_t maxDist, uint8_t* __restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chrOff[mid] <= i) lo = mid; else hi = mid - 1; }
+    const bool first = (i == chrOff[lo]);
+    const int32_t st = state[i];
+    bool newSeg = st >= 0 && (first || state[i - 1] != st);           // breakpoint -> segment start present in `starts`
+    if (!newSeg && !first) {
+        uint32_t prevEnd = (uint32_t)stop[i - 1];
+        if (prevEnd > 0 && maxDist >= 0 && (uint64_t)prevEnd + (uint64_t)maxDist < (uint64_t)(uint32_t)start[i]) newSeg = true;   // SegmentationResultsProcessor.cs:112-116
+    }
+    flags[i] = newSeg;
+}
+__global__ void __launch_bounds__(256) k_count_blocks(const uint8_t* __restrict__ flags, int64_t n, uint32_t* __restrict__ blockCnt) {
+    __shared__ uint32_t sh[4];
+    int64_t base = (int64_t)blockIdx.x * 2048;
+    uint32_t c = 0;
+    for (int jj = 0; jj < 8; jj++) { int64_t i = base + jj * 256 + threadIdx.x; if (i < n) c += flags[i]; }
+    c = wave_reduce_add_u32(c);
+    if (lane_id() == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blockCnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void __launch_bounds__(1024) k_scan_blocks2(uint32_t* __restrict__ blockCnt, int nblocks, unsigned long long* __restrict__ total) {
+    __shared__ uint32_t sh[17];
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 1024) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? blockCnt[i] : 0;
+        uint32_t inc = wave_inclusive_scan_u32(v);
+        int w = threadIdx.x >> 6;
+        if (lane_id() == 63) sh[w] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t s = 0; for (int k = 0; k < 16; k++) { uint32_t t = sh[k]; sh[k] = s; s += t; } sh[16] = s; }
+        __syncthreads();
+        if (i < nblocks) blockCnt[i] = carry + sh[w] + inc - v;
+        carry += sh[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(256) k_seg_ids(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t n, int32_t* __restrict__ segId) {
+    __shared__ uint32_t sh[4];
+    int64_t base = (int64_t)blockIdx.x * 2048;
+    uint32_t running = blockOff[blockIdx.x];
+    for (int jj = 0; jj < 8; jj++) {
+        int64_t i = base + jj * 256 + threadIdx.x;
+        uint32_t f = (i < n) ? flags[i] : 0;
+        uint32_t inc = wave_inclusive_scan_u32(f);
+        if (lane_id() == 63) sh[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) woff += sh[k]; tot += sh[k]; }
+        if (i < n) segId[i] = (int32_t)(running + woff + inc) - 1;     // counter starts at -1 and increments on every new segment
+        running += tot;
+        __syncthreads();
+    }
+}
+
+// ---- host: emission tables (DistributionUtilities.cs:51-69).  GammaLn/FactorialLn (MathNet) -> lgamma; Math.Pow(x,2) := x*x.
+static void negative_binomial_log_table(double mean, double variance, int maxValue, double* out) {
+    double m = std::max(mean, 0.1);
+    double r = (m * m) / (std::max(variance, mean * 1.2) - mean);
+    r = std::max(2.0, r);
+    for (int x = 0; x < maxValue; x++) {
+        double dens = std::exp(std::log(std::pow(1 + mean / r, -r)) + std::log(std::pow(mean / (mean + r), (double)x)) + std::lgamma(r + x) -
+                               std::lgamma((double)x + 1.0) - std::lgamma(r));
+        if (std::isnan(dens) || std::isinf(dens)) dens = 0;
+        out[x] = std::log(dens);   // EstimateViterbiLikelihood takes Math.Log of the table value (Distributions.cs:322)
+    }
+}
+
+// Utilities.Quartiles index logic (shared with clean.hip semantics)
+static void quartile_idx(int64_t n, int64_t* idx, int& cnt) {
+    cnt = 0;
+    int64_t mid = n / 2;
+    if (n % 2 == 0) {
+        int64_t mm = mid / 2;
+        idx[cnt++] = mid - 1; idx[cnt++] = mid;
+        if (mid % 2 == 0) { idx[cnt++] = mm - 1; idx[cnt++] = mm; idx[cnt++] = mid + mm - 1; idx[cnt++] = mid + mm; }
+        else { idx[cnt++] = mm; idx[cnt++] = mm + mid; }
+    } else {
+        idx[cnt++] = mid;
+        if ((n - 1) % 4 == 0) { int64_t k = (n - 1) / 4; idx[cnt++] = k - 1; idx[cnt++] = k; idx[cnt++] = 3 * k; idx[cnt++] = 3 * k + 1; }
+        else { int64_t k = (n - 3) / 4; idx[cnt++] = k; idx[cnt++] = k + 1; idx[cnt++] = 3 * k + 1; idx[cnt++] = 3 * k + 2; }
+    }
+}
+static void quartile_val(int64_t n, const float* v, float& q1, float& q2, float& q3) {
+    int64_t mid = n / 2;
+    if (n % 2 == 0) {
+        q2 = (v[0] + v[1]) / 2;
+        if (mid % 2 == 0) { q1 = (v[2] + v[3]) / 2; q3 = (v[4] + v[5]) / 2; } else { q1 = v[2]; q3 = v[3]; }
+    } else {
+        q2 = v[0];
+        if ((n - 1) % 4 == 0) { q1 = (v[1] * 0.25f) + (v[2] * 0.75f); q3 = (v[3] * 0.75f) + (v[4] * 0.25f); }
+        else { q1 = (v[1] * 0.75f) + (v[2] * 0.25f); q3 = (v[3] * 0.25f) + (v[4] * 0.75f); }
+    }
+}
+
+static inline unsigned nblk2(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+extern "C" {
+
+int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !d_cov || !h_chr_offset || !d_state) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = h_chr_offset[nchr];
+    if (N < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
+    // blocks for the backtrack
+    std::vector<HmmChrom> chroms(nchr);
+    std::vector<BtBlock> blocks; std::vector<int32_t> firstBlock(nchr + 1);
+    for (int c = 0; c < nchr; c++) {
+        chroms[c].begin = h_chr_offset[c]; chroms[c].T = h_chr_offset[c + 1] - h_chr_offset[c];
+        firstBlock[c] = (int32_t)blocks.size();
+        if (chroms[c].T > 10)
+            for (int64_t lo = 0; lo < chroms[c].T - 1; lo += BT_BLOCK) blocks.push_back({c, lo, std::min<int64_t>(lo + BT_BLOCK, chroms[c].T - 1)});
+    }
+    firstBlock[nchr] = (int32_t)blocks.size();
+    const int nblocks = (int)blocks.size();
+    WsSizer sz;
+    sz.take<uint32_t>(N); sz.take<int32_t>(N); sz.take<uint8_t>((size_t)NSTATE * N); sz.take<HmmChrom>(nchr); sz.take<int32_t>(nchr);
+    sz.take<BtBlock>(nblocks + 1); sz.take<int32_t>(nchr + 1); sz.take<uint8_t>((size_t)nblocks * NSTATE + 8); sz.take<int8_t>(nblocks + 8); sz.take<double>(NSTATE * 70000);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
+    WsCarver ws(ctx->ws);
+    uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N); uint8_t* psi = ws.take<uint8_t>((size_t)NSTATE * N);
+    HmmChrom* dChroms = ws.take<HmmChrom>(nchr); int32_t* dLast = ws.take<int32_t>(nchr);
+    BtBlock* dBlocks = ws.take<BtBlock>(nblocks + 1); int32_t* dFirst = ws.take<int32_t>(nchr + 1);
+    uint8_t* dMaps = ws.take<uint8_t>((size_t)nblocks * NSTATE + 8); int8_t* dEntry = ws.take<int8_t>(nblocks + 8); double* dTab = ws.take<double>(NSTATE * 70000);
+
+    // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
+    hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
+    int64_t qidx[6]; int nq;
+    quartile_idx(N, qidx, nq);
+    std::vector<SelQuery> qs;
+    for (int k = 0; k < nq; k++) qs.push_back({0, 0, qidx[k]});
+    std::vector<unsigned long long> res;
+    rc = radix_select<uint32_t>(ctx, keys, 1, std::vector<int64_t>{0, N}, qs, res); if (rc) return rc;
+    float v[6], q1, q2, q3;
+    for (int k = 0; k < nq; k++) v[k] = host_float_of_key((uint32_t)res[k]);
+    quartile_val(N, v, q1, q2, q3);
+    const double median = (double)q2;
+    const float iqr = q3 - q1;
+    const double pseudoVariance = (double)(iqr * iqr);
+    // 2. emission tables (HiddenMarkovModelsRunner.cs:111-152)
+    const double haploidMean = median / 2.0;
+    HmmParams P;
+    P.maxThreshold = haploidMean * NSTATE;
+    if (!(P.maxThreshold >= 0) || P.maxThreshold > 60000) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: coverage scale outside the supported table size");
+    P.tableLen = (int32_t)std::nearbyint(P.maxThreshold) + 10 + 1;      // >= max over chromosomes of (maxValues + 10)
+    std::vector<double> tab((size_t)NSTATE * P.tableLen);
+    for (int CN = 0; CN < NSTATE; CN++) negative_binomial_log_table(std::max((double)CN, 0.1) * haploidMean, pseudoVariance, P.tableLen, &tab[(size_t)CN * P.tableLen]);
+    const double selfTransition = 0.99;
+    for (int i = 0; i < NSTATE; i++) {
+        for (int j = 0; j < NSTATE; j++) P.logA[i][j] = std::log(i == j ? selfTransition : (1.0 - selfTransition) / (NSTATE - 1));
+        P.logPi[i] = std::log((double)(1.0f / NSTATE));      // 1f / nStates widened (HMM.cs:41)
+    }
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dChroms, chroms.data(), nchr * sizeof(HmmChrom), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dBlocks, blocks.data(), nblocks * sizeof(BtBlock), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirst, firstBlock.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    // 3. index, Viterbi, backtrack
+    hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);
+    size_t tabBytes = (size_t)NSTATE * P.tableLen * 8;
+    size_t lds = tabBytes <= 48 * 1024 ? tabBytes : 0;
+    hipLaunchKernelGGL(k_viterbi, dim3(nchr), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, N, dLast);
+    for (int c = 0; c < nchr; c++)
+        if (chroms[c].T <= 10 && chroms[c].T > 0)
+            hipLaunchKernelGGL(k_fill_i32, dim3(nblk2(chroms[c].T, 256)), dim3(256), 0, ctx->stream, d_state, chroms[c].begin, chroms[c].begin + chroms[c].T, -1);
+    if (nblocks > 0) {
+        hipLaunchKernelGGL(k_bt_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dBlocks, nblocks, dChroms, psi, N, dMaps);
+        hipLaunchKernelGGL(k_bt_chain, dim3(nblk2(nchr, 64)), dim3(64), 0, ctx->stream, dFirst, nchr, dLast, dMaps, dEntry);
+        hipLaunchKernelGGL(k_bt_states, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dBlocks, nblocks, dChroms, psi, N, dEntry, d_state);
+    }
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host vectors feed async copies
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    return CANVAS_OK;
+}
+
+int32_t canvas_segment_ids(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
+                           const int32_t* d_stop, int32_t max_inter_bin_dist, int32_t* d_segment_id, int64_t* h_nsegments) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_chr_offset || !d_state || !d_start || !d_stop || !d_segment_id) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_segment_ids: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = h_chr_offset[nchr];
+    if (N == 0) { if (h_nsegments) *h_nsegments = 0; return CANVAS_OK; }
+    const int nb = (int)nblk2(N, 2048);
+    WsSizer sz; sz.take<int64_t>(nchr + 1); sz.take<uint8_t>(N); sz.take<uint32_t>(nb + 1); sz.take<unsigned long long>(1);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
+    WsCarver ws(ctx->ws);
+    int64_t* dOff = ws.take<int64_t>(nchr + 1); uint8_t* flags = ws.take<uint8_t>(N); uint32_t* blockCnt = ws.take<uint32_t>(nb + 1); unsigned long long* dTot = ws.take<unsigned long long>(1);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_seg_flags, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dOff, nchr, d_state, d_start, d_stop, N, max_inter_bin_dist, flags);
+    hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(256), 0, ctx->stream, flags, N, blockCnt);
+    hipLaunchKernelGGL(k_scan_blocks2, dim3(1), dim3(1024), 0, ctx->stream, blockCnt, nb, dTot);
+    hipLaunchKernelGGL(k_seg_ids, dim3(nb), dim3(256), 0, ctx->stream, flags, blockCnt, N, d_segment_id);
+    unsigned long long tot = 0;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&tot, dTot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    if (h_nsegments) *h_nsegments = (int64_t)tot;
+    return CANVAS_OK;
+}
+
+}  // extern "C"

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys,
 }
 
 // one wave per query: locate the digit holding rank k, narrow (prefix, k), clear the histogram row
-__global__ void __launch_bounds__(64) k_select_pick(uint32_t* __restrict__ hist, unsigned long long* __restrict__ qprefix,
+static __global__ void __launch_bounds__(64) k_select_pick(uint32_t* __restrict__ hist, unsigned long long* __restrict__ qprefix,
                                                     unsigned long long* __restrict__ qk, int nq) {
     const int q = blockIdx.x;
     if (q >= nq) return;

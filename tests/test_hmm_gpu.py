@@ -1,0 +1,71 @@
+"""PerSampleHMM (Viterbi) on the GPU vs the CPU oracle: state paths and segment ids bit-identical."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from canvas_amd import synth
+from gpu_common import get_canvas, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _coverage(seed, n, nchr=24):
+    bins = synth.generate_bins(seed, n, nchr=nchr)
+    # what CanvasPartition reads: the F2-rounded text of CanvasClean's float counts, parsed as double (CanvasSegment.cs:1146)
+    cov = np.round(bins["count"].astype(np.float64), 2)
+    off = np.concatenate([[0], np.cumsum(np.bincount(bins["chr"], minlength=nchr))]).astype(np.int64)
+    return bins, cov, off
+
+
+def _check(cv, bins, cov, off, max_dist=1000000):
+    nchr = len(off) - 1
+    per = [np.ascontiguousarray(cov[off[c]:off[c + 1]]) for c in range(nchr)]
+    paths, ran = O.hmm_genome_per_sample(per, threads=8)
+    dcov = to_dev(cov, cv.device)
+    state = cv.hmm_per_sample(dcov, off)
+    got = state.cpu().numpy()
+    for c in range(nchr):
+        exp = paths[c] if ran[c] else np.full(len(per[c]), -1, np.int32)
+        g = got[off[c]:off[c + 1]]
+        assert (g == exp).all(), (c, int((g != exp).sum()), len(exp))
+    # segment ids
+    bs = [bins["start"][off[c]:off[c + 1]].astype(np.uint32) for c in range(nchr)]
+    be = [bins["stop"][off[c]:off[c + 1]].astype(np.uint32) for c in range(nchr)]
+    segstarts = [O.segments_from_path(paths[c], ran[c], bs[c], be[c])[0] for c in range(nchr)]
+    ids, last = O.postprocess(bs, be, segstarts, None, max_dist)
+    seg, nseg = cv.segment_ids(off, state, to_dev(bins["start"], cv.device), to_dev(bins["stop"], cv.device), max_dist)
+    gseg = seg.cpu().numpy()
+    assert (gseg == np.concatenate(ids)).all()
+    assert nseg == last + 1
+    return got
+
+
+@pytest.mark.parametrize("n,nchr", [(30_000, 24), (5_000, 3), (200_000, 24)])
+def test_viterbi_matches_oracle(n, nchr):
+    cv = get_canvas()
+    bins, cov, off = _coverage(20260927 + 10, n, nchr)
+    got = _check(cv, bins, cov, off)
+    if n >= 200_000:
+        assert len(np.unique(got)) >= 2   # planted CN segments are found
+
+
+def test_viterbi_short_and_skipped_chromosomes():
+    cv = get_canvas()
+    bins, cov, off = _coverage(20260927 + 11, 4_000, 6)
+    # carve chromosome runs of 11, 10 (skipped) and 1 bins out of the tail
+    chr_id = bins["chr"].copy()
+    n = len(chr_id)
+    chr_id[n - 22:n - 11] = 6; chr_id[n - 11:n - 1] = 7; chr_id[n - 1:] = 8
+    bins["chr"] = chr_id
+    off = np.concatenate([[0], np.cumsum(np.bincount(chr_id, minlength=9))]).astype(np.int64)
+    got = _check(cv, bins, cov, off, max_dist=5000)
+    assert (got[off[7]:off[8]] == -1).all() and (got[off[8]:] == -1).all()
+
+
+def test_viterbi_saturated_and_zero_coverage():
+    cv = get_canvas()
+    bins, cov, off = _coverage(20260927 + 12, 20_000, 4)
+    cov[100:400] = 0.0          # homozygous deletion
+    cov[1000:1300] = 5000.0     # far above 5 x haploid mean: capped (HiddenMarkovModelsRunner.cs:154-162)
+    cov[2000] = 124.5; cov[2001] = 125.5   # half-way cases of Convert.ToInt32
+    _check(cv, bins, cov, off)
