@@ -19,6 +19,19 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _torch_lib_dir():
+    """When the library is hosted in a torch process it must use the SAME HIP runtime as torch (torch wheels bundle their own
+    libamdhip64.so / librccl.so): link against those so that one runtime is loaded.  Without torch: /opt/rocm (hipcc default)."""
+    try:
+        import torch
+        d = os.path.join(os.path.dirname(torch.__file__), "lib")
+        if os.path.exists(os.path.join(d, "libamdhip64.so")):
+            return d
+    except Exception:
+        pass
+    return None
+
+
 def _stale(out, srcs):
     if not os.path.exists(out):
         return True
@@ -27,21 +40,41 @@ def _stale(out, srcs):
     return any(os.path.getmtime(s) > t for s in deps)
 
 
+def _compile_and_link(hipcc, srcs, out, extra_libs, verbose):
+    """hipcc -c per source, then an explicit link so that WE choose which libamdhip64 / librccl is recorded as DT_NEEDED
+    (hipcc's own link step always resolves -lamdhip64 in /opt/rocm/lib first)."""
+    cflags = [f for f in FLAGS if f != "-shared"]
+    objs = []
+    for sfile in srcs:
+        o = os.path.join(CSRC, "." + os.path.basename(sfile) + ".o")
+        cmd = [hipcc] + cflags + ["-c", sfile, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    tl = _torch_lib_dir()
+    dirs = ([tl] if tl else []) + ["/opt/rocm/lib"]
+    link = ["g++", "-shared", "-o", out] + objs
+    for d in dirs:
+        link += ["-L" + d, "-Wl,-rpath," + d]
+    link += ["-lamdhip64"] + extra_libs + ["-lpthread", "-ldl"]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
+    for o in objs:
+        os.remove(o)
+
+
 def build(force=False, verbose=False):
     hipcc = _hipcc()
     srcs = [os.path.join(CSRC, s) for s in PRODUCT_SRC if os.path.exists(os.path.join(CSRC, s))]
     out = os.path.join(HERE, "libcanvas_hip.so")
     if force or _stale(out, srcs):
-        cmd = [hipcc] + FLAGS + ["-o", out] + srcs
-        if any(s.endswith("comm.hip") for s in srcs):
-            cmd += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        _compile_and_link(hipcc, srcs, out, ["-lrccl"] if any(s.endswith("comm.hip") for s in srcs) else [], verbose)
     out2 = os.path.join(HERE, "libcanvas_synth.so")
     s2 = [os.path.join(CSRC, "synth.hip")]
     if force or _stale(out2, s2):
-        subprocess.check_call([hipcc] + FLAGS + ["-o", out2] + s2)
+        _compile_and_link(hipcc, s2, out2, [], verbose)
     return out, out2
 
 

@@ -422,7 +422,8 @@ int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_
     memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);   // pos0 = len: popBefore irrelevant here
-    hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, 1, tilePop, tileObs);
+    { ProfScope ps(ctx, "bin_tile_stats");
+      hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, 1, tilePop, tileObs); }
     hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut);
     ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
@@ -476,8 +477,9 @@ int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d
     if (h_nbins_total) *h_nbins_total = total;
     if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_bin_genome: output capacity too small (see canvas_bin_count_upper_bound)");
     if (total == 0) return CANVAS_OK;
-    hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
-                       binOffset, bin_size, mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, stopTmp, locC, locG, tileTotC, tileTotG);
+    { ProfScope ps(ctx, "bin_pass");
+      hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
+                         binOffset, bin_size, mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, stopTmp, locC, locG, tileTotC, tileTotG); }
     hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
     hipLaunchKernelGGL(k_bin_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, stopTmp, locC, locG,
                        tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count);

@@ -22,6 +22,27 @@ struct canvas_ctx {
     size_t pin_bytes = 0;
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
+    // profiling: hipEvent pairs around named kernels
+    bool prof = false;
+    struct ProfSlot { std::string name; std::vector<hipEvent_t> ev; double ms = 0; int launches = 0; };
+    std::vector<ProfSlot> slots;
+};
+
+// scoped event pair: records start now and stop at destruction (on ctx->stream) when profiling is enabled
+struct ProfScope {
+    canvas_ctx* ctx; int slot = -1; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(canvas_ctx* c, const char* name) : ctx(c) {
+        if (!c->prof) return;
+        for (size_t i = 0; i < c->slots.size(); i++) if (c->slots[i].name == name) slot = (int)i;
+        if (slot < 0) { c->slots.push_back({}); slot = (int)c->slots.size() - 1; c->slots[slot].name = name; }
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { slot = -1; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (slot < 0) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->slots[slot].ev.push_back(a); ctx->slots[slot].ev.push_back(b); ctx->slots[slot].launches++;
+    }
 };
 
 #define CANVAS_HIP_TRY(ctx, expr)                                                                   \

@@ -72,4 +72,30 @@ int32_t canvas_memcpy_d2h(canvas_ctx* ctx, void* h_dst, const void* d_src, int64
     return CANVAS_OK;
 }
 
+int32_t canvas_profile_enable(canvas_ctx* ctx, int32_t on) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    ctx->prof = on != 0;
+    return CANVAS_OK;
+}
+int32_t canvas_profile_get(canvas_ctx* ctx, const char* name, double* h_ms_total, int32_t* h_launches, int32_t reset) {
+    if (!ctx || !name) return CANVAS_ERR_INVALID;
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& sl : ctx->slots) {
+        if (sl.name != name) continue;
+        for (size_t i = 0; i + 1 < sl.ev.size(); i += 2) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sl.ev[i], sl.ev[i + 1]) == hipSuccess) sl.ms += ms;
+            (void)hipEventDestroy(sl.ev[i]); (void)hipEventDestroy(sl.ev[i + 1]);
+        }
+        sl.ev.clear();
+        if (h_ms_total) *h_ms_total = sl.ms;
+        if (h_launches) *h_launches = sl.launches;
+        if (reset) { sl.ms = 0; sl.launches = 0; }
+        return CANVAS_OK;
+    }
+    if (h_ms_total) *h_ms_total = 0;
+    if (h_launches) *h_launches = 0;
+    return CANVAS_OK;
+}
+
 }  // extern "C"

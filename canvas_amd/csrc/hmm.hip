@@ -329,7 +329,8 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);
     size_t tabBytes = (size_t)NSTATE * P.tableLen * 8;
     size_t lds = tabBytes <= 48 * 1024 ? tabBytes : 0;
-    hipLaunchKernelGGL(k_viterbi, dim3(nchr), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, N, dLast);
+    { ProfScope ps(ctx, "viterbi");
+      hipLaunchKernelGGL(k_viterbi, dim3(nchr), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, N, dLast); }
     for (int c = 0; c < nchr; c++)
         if (chroms[c].T <= 10 && chroms[c].T > 0)
             hipLaunchKernelGGL(k_fill_i32, dim3(nblk2(chroms[c].T, 256)), dim3(256), 0, ctx->stream, d_state, chroms[c].begin, chroms[c].begin + chroms[c].T, -1);

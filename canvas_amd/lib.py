@@ -16,8 +16,8 @@ ABI_SYMBOLS = [
     "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome",
-    "canvas_clean", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_cbs",
-    "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries",
+    "canvas_clean", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_cbs",
+    "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
 
@@ -33,6 +33,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch wheels bundle their own HIP runtime (SONAME libamdhip64.so.7): load torch FIRST so that the dynamic loader binds
+    # this library to the runtime torch already loaded (one runtime per process, shared device pointers and streams).
+    import torch  # noqa: F401
     if not os.path.exists(_SO):
         raise CanvasError(f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
@@ -138,6 +141,7 @@ class Canvas:
                                                C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),
                                                C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()), C.c_int64(out["chr"].numel()),
                                                _np_ptr(per), C.byref(total)))
+        self.synchronize()   # own non-blocking stream: make the bins visible to torch's stream before handing tensors back
         return out, per, total.value
 
     # ---- CanvasClean
@@ -149,6 +153,21 @@ class Canvas:
                                           C.c_void_p(bins["stop"].data_ptr()), C.c_void_p(bins["count"].data_ptr()), C.c_void_p(bins["gc"].data_ptr()),
                                           len(ia), _np_ptr(ia), C.c_uint32(flags), min_bins_per_gc, C.byref(lsd), C.byref(nout), _np_ptr(info)))
         return nout.value, lsd.value, info
+
+    def quantize_f2(self, count, n):
+        """count.ToString("F2") -> Convert.ToDouble (IO.cs:21 -> CanvasSegment.cs:1146), in memory"""
+        cov = self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+        self._check(self.lib.canvas_quantize_f2(self.ctx, C.c_void_p(count.data_ptr()), C.c_int64(n), C.c_void_p(cov.data_ptr())))
+        self.synchronize()   # the library runs on its own non-blocking stream; make the result visible to torch's stream
+        return cov
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.canvas_profile_enable(self.ctx, int(on)))
+
+    def profile_get(self, name, reset=True):
+        ms = C.c_double(0); k = C.c_int32(0)
+        self._check(self.lib.canvas_profile_get(self.ctx, name.encode(), C.byref(ms), C.byref(k), int(reset)))
+        return ms.value, k.value
 
     # ---- CanvasPartition
     def hmm_per_sample(self, cov, chr_offset):
@@ -188,6 +207,7 @@ def synth_generate_device(seed, chrom, length, rate, device, thr_dev=None):
     from . import synth
     global _synth
     if _synth is None:
+        load_library()
         if not os.path.exists(_SYNTH_SO):
             raise CanvasError(f"{_SYNTH_SO} missing: run build()")
         _synth = C.CDLL(_SYNTH_SO)

@@ -80,6 +80,11 @@ int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_star
                      int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
                      double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
 
+/* The text hand-off between CanvasClean and CanvasPartition, done in memory: CanvasIO.WriteToTextFile prints the float
+ * count with "{3:F2}" (CanvasCommon/IO.cs:21; .NET Core 2.x: 7 significant digits, then half-up at 2 decimals) and
+ * CanvasSegment.ReadBedInput parses that text as double (CanvasCommon/CanvasSegment.cs:1146).  d_cov[i] = that double. */
+int32_t canvas_quantize_f2(canvas_ctx* ctx, const float* d_count, int64_t n, double* d_cov);
+
 /* ---- CanvasPartition ------------------------------------------------------------------------------------------ */
 /* HiddenMarkovModelsRunner.Run with isPerSample (HiddenMarkovModelsRunner.cs:23-109) + BestPathViterbi (HMM.cs:62-130):
  * one sample, all chromosomes.  d_cov = concatenated coverage (double, file order), h_chr_offset[nchr+1] = chromosome
@@ -103,6 +108,11 @@ int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const vo
 /* the single RCCL all-gather of the path: every rank contributes nlocal int32 boundary records (padded to max_per_rank) */
 int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank,
                                     int32_t* d_all, int32_t* h_counts);
+
+/* ---- profiling hooks (hipEvent pairs recorded on the context's stream around the named kernels) --------------------- */
+int32_t canvas_profile_enable(canvas_ctx* ctx, int32_t on);
+/* name: "bin_pass", "bin_tile_stats", "viterbi"; returns accumulated ms and launch count since the last reset */
+int32_t canvas_profile_get(canvas_ctx* ctx, const char* name, double* h_ms_total, int32_t* h_launches, int32_t reset);
 
 #ifdef __cplusplus
 }

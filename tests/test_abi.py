@@ -1,0 +1,56 @@
+"""CPU-side checks of the C-ABI library: it loads here (no GPU) and exports every symbol include/canvas_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from canvas_amd import build
+    so, _ = build.build()
+    return ctypes.CDLL(so)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "canvas_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(canvas_\w+)\s*\(", hdr))
+    assert len(names) >= 20
+    from canvas_amd.lib import ABI_SYMBOLS
+    assert names == set(ABI_SYMBOLS), names ^ set(ABI_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_host_scalar_entry_points_without_gpu(lib):
+    import numpy as np
+    rates = np.array([0.2, 0.1, 0.4, 0.3], np.float64)
+    lib.canvas_bin_size_from_rates.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+    assert lib.canvas_bin_size_from_rates(rates.ctypes.data, 4, 100) == int(100 / 0.25)
+    lens = np.array([1000, 2500], np.int64)
+    lib.canvas_bin_count_upper_bound.restype = ctypes.c_int64
+    lib.canvas_bin_count_upper_bound.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
+    assert lib.canvas_bin_count_upper_bound(2, lens.ctypes.data, 100) == 35
+    lib.canvas_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.canvas_version()
+
+
+def test_no_cpu_fallback():
+    import torch
+    from canvas_amd import Canvas, CanvasError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(CanvasError):
+        Canvas(0)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "canvas_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in txt and "libcanvas_oracle" not in txt and "oracle/" not in txt.replace("the oracle", ""), f
