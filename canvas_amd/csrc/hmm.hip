@@ -48,11 +48,19 @@ __global__ void __launch_bounds__(256) k_hmm_index(const double* __restrict__ co
 
 struct HmmChrom { int64_t begin; int64_t T; };
 
+// broadcast lane `src`'s double to the whole wave through SGPRs (v_readlane_b32 x2: no LDS round trip)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 // one wave per chromosome
 __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx, const double* __restrict__ logPmf,
                                                 HmmParams P, uint8_t* __restrict__ psi /* [5][N] */, int64_t N, int32_t* __restrict__ lastState) {
     extern __shared__ double sTab[];                 // [5][tableLen] when it fits, else unused
-    __shared__ double sE[64 * NSTATE];               // emissions of the current 64-step block
+    __shared__ double sE[2][64 * NSTATE];            // emissions of the current / next 64-step block
+    __shared__ uint8_t sPsi[NSTATE][64];             // back-pointers of the current block, flushed coalesced
     const HmmChrom C = chroms[blockIdx.x];
     const int l = threadIdx.x;
     const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
@@ -67,47 +75,61 @@ __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chr
     const double NEG = -1.7976931348623157e308;      // Double.MinValue
     double delta = 0;
     const int32_t* ix = idx + C.begin;
-    uint8_t* myPsi = psi + (size_t)j * N + C.begin;
-    for (int64_t t0 = 0; t0 < C.T; t0 += 64) {
-        // all 64 lanes: table look-ups for the next 64 steps
-        int64_t t = t0 + l;
-        if (t < C.T) {
-            int k = ix[t];
+    // stage block 0; keep the table index of block 1 in a register (its global load is issued a whole block ahead)
+    { int64_t t = l; if (t < C.T) { int k = ix[t];
 #pragma unroll
-            for (int s = 0; s < NSTATE; s++) sE[l * NSTATE + s] = tab[s * P.tableLen + k];
+        for (int s = 0; s < NSTATE; s++) sE[0][l * NSTATE + s] = tab[s * P.tableLen + k]; } }
+    int kNext = (64 + l < C.T) ? ix[64 + l] : 0;
+    __syncthreads();
+    int buf = 0;
+    for (int64_t t0 = 0; t0 < C.T; t0 += 64, buf ^= 1) {
+        // all 64 lanes: table look-ups for the NEXT 64 steps from the index loaded during the previous block, and the
+        // global load of the index for the block after that (both overlap with the sequential part of this block)
+        { int64_t t = t0 + 64 + l; if (t < C.T) {
+#pragma unroll
+            for (int s = 0; s < NSTATE; s++) sE[buf ^ 1][l * NSTATE + s] = tab[s * P.tableLen + kNext]; }
+          int64_t t2 = t0 + 128 + l; kNext = (t2 < C.T) ? ix[t2] : 0; }
+        const int steps = (int)((C.T - t0) < 64 ? (C.T - t0) : 64);
+        const double* E = sE[buf];
+        int s0 = 0;
+        if (t0 == 0) {
+            // bestScore[0][j] = log(pi_j) + EstimateViterbiLikelihood(x0, j, transition[0]) - log(transition[0][j])   (HMM.cs:78)
+            double lik = E[j] + P.logA[0][j];
+            delta = P.logPi[j] + lik - P.logA[0][j];
+            if (l < NSTATE) sPsi[j][0] = 0;
+            s0 = 1;
+        }
+        double e = E[s0 * NSTATE + j];
+        for (int s = s0; s < steps; s++) {
+            double eNext = E[(s + 1 < 64 ? s + 1 : s) * NSTATE + j];        // prefetch (off the dependent chain)
+            double v0 = e + la[0], v1 = e + la[1], v2 = e + la[2], v3 = e + la[3], v4 = e + la[4];   // Math.Log(pmf) + Math.Log(transition)
+            double t_0 = readlane_f64(delta, 0) + v0;                      // bestScore[t-1][i] + vitLogL
+            double t_1 = readlane_f64(delta, 1) + v1;
+            double t_2 = readlane_f64(delta, 2) + v2;
+            double t_3 = readlane_f64(delta, 3) + v3;
+            double t_4 = readlane_f64(delta, 4) + v4;
+            // strict '>' scan i = 0..4 from Double.MinValue == first index of the maximum (no NaNs can occur), as a tree
+            double a = t_0; int ia = 0; if (t_1 > a) { a = t_1; ia = 1; }
+            double b = t_2; int ib = 2; if (t_3 > b) { b = t_3; ib = 3; }
+            if (b > a) { a = b; ia = ib; }
+            if (t_4 > a) { a = t_4; ia = 4; }
+            if (!(a > NEG)) { a = NEG; ia = 0; }
+            delta = a;
+            if (l < NSTATE) sPsi[j][s] = (uint8_t)ia;
+            e = eNext;
         }
         __syncthreads();
-        const int steps = (int)((C.T - t0) < 64 ? (C.T - t0) : 64);
-        if (l < NSTATE) {
-            for (int s = 0; s < steps; s++) {
-                const double e = sE[s * NSTATE + j];
-                if (t0 + s == 0) {
-                    // bestScore[0][j] = log(pi_j) + EstimateViterbiLikelihood(x0, j, transition[0]) - log(transition[0][j])   (HMM.cs:78)
-                    double lik = e + P.logA[0][j];
-                    delta = P.logPi[j] + lik - P.logA[0][j];
-                    continue;
-                }
-                double d[NSTATE];
+        // flush the block's back-pointers: 5 coalesced 64-byte rows
+        if (l < steps) {
 #pragma unroll
-                for (int i = 0; i < NSTATE; i++) d[i] = __shfl(delta, i, 64);
-                int state = 0;
-                double mx = NEG;
-#pragma unroll
-                for (int i = 0; i < NSTATE; i++) {
-                    double vit = e + la[i];          // Math.Log(maxLikelyhood) + Math.Log(transitionLikelihood)
-                    double tmp = d[i] + vit;         // bestScore[t-1][i] + vitLogL
-                    if (tmp > mx) { state = i; mx = tmp; }
-                }
-                delta = mx;
-                myPsi[t0 + s] = (uint8_t)state;
-            }
+            for (int st = 0; st < NSTATE; st++) psi[(size_t)st * N + C.begin + t0 + l] = sPsi[st][l];
         }
         __syncthreads();
     }
     // best final state: strict '>' scan from Double.MinValue, bestState initialised to -1 (HMM.cs:100-111)
     double d[NSTATE];
 #pragma unroll
-    for (int i = 0; i < NSTATE; i++) d[i] = __shfl(delta, i, 64);
+    for (int i = 0; i < NSTATE; i++) d[i] = readlane_f64(delta, i);
     if (l == 0) {
         int best = -1; double m1 = NEG;
 #pragma unroll
