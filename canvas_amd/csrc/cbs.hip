@@ -1,8 +1,544 @@
-// CanvasPartition CBS entry point (placeholder until the CBS kernels land; see DESIGN.md "CBS").
+// CanvasPartition CBS on MI355X: CBSRunner.Run (CBSRunner.cs:40-151), ChangePoint.ChangePoints / FindChangePoints
+// (ChangePoint.cs:44-153,291-400), CBSTStatistic.TMaxO / HTMaxP / TMaxP / TPermP (CBSTStatistic.cs), GetBoundary, TailProbability.
+//
+// Division of labour (DESIGN.md "CBS"):
+//   * The recursion is a depth-first stack per chromosome that shares ONE Mersenne-Twister stream, every floating sum that feeds
+//     a decision is a sequential left-to-right double accumulation (mean, TSS, prefix sums sx; CBSTStatistic.cs:74-81), and
+//     TPermP (CBSTStatistic.cs:947-1024) is a single chain of nPerm x m1 dependent random swaps.  Those are latency-bound scalar
+//     chains; they run on the host exactly as in the reference (one std::thread per chromosome, CBSRunner.cs:115-147).
+//   * The arithmetic bulk of TMaxO — the maximum of n/(k(n-k)) (S_j - S_i)^2 over all O(n^2) circular arcs — runs on the GPU as an
+//     exhaustive, pruning-free search (k_arc_search: one lane per arc length, LDS-staged prefix sums, 2 FP64 ops per arc).
+//     The reference's sqrt(n)-block pruning is lossless, so the exhaustive maximum is the same double; the arg-max is
+//     the reference's as long as the maximising arc is unique, which the host verifies per call — on an exact floating-point tie it
+//     replays the reference's block order on the host (rare).
+//   * Permutation reference distribution (XPerm + HTMaxP/TMaxP): host in this round (next: device engine).
 #include "common.hpp"
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <limits>
+#include <mutex>
+#include <thread>
+
+// ================================================================================================ device: exhaustive arc search
+// For every arc length L in [1, n-1] (arc = pair i < j = i + L of 0-based prefix-sum indices): dmax[L] = max_i |sx[i+L] - sx[i]|,
+// firstI[L] = smallest such i.  Thread t of the grid owns lengths L = t+1 and n-1-t (balanced: n iterations per thread).
+#define ARC_THREADS 256
+#define ARC_CHUNK 512
+__global__ void __launch_bounds__(ARC_THREADS) k_arc_search(const double* __restrict__ sx, int n, double* __restrict__ dmax, int32_t* __restrict__ firstI) {
+    __shared__ double sA[ARC_CHUNK];                         // sx[i0 .. i0+CHUNK)
+    __shared__ double sB[ARC_CHUNK + ARC_THREADS];           // sx[i0+Lbase .. ) window for the block's lengths
+    const int half = (n - 1 + 1) / 2;                        // number of threads needed: lengths 1..n-1 paired (L, n-L)
+    const int t = blockIdx.x * ARC_THREADS + threadIdx.x;
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: L = t + 1 (ascending with thread id); pass 1: L = n - 1 - t (descending with thread id)
+        const int L = pass == 0 ? t + 1 : n - 1 - t;
+        const bool active = t < half && L >= 1 && L <= n - 1 && !(pass == 1 && L <= half);   // do not do the middle length twice
+        const int Lblock0 = pass == 0 ? blockIdx.x * ARC_THREADS + 1 : n - 1 - (blockIdx.x * ARC_THREADS + ARC_THREADS - 1);   // smallest L of the block
+        const int off = L - Lblock0;                         // 0..ARC_THREADS-1 (may be out of range when inactive)
+        double best = -1.0; int bestI = 0;
+        // longest arc count in this block: lengths >= Lblock0 (clamped to >= 1) -> i ranges over [0, n - Lmin)
+        const int Lmin = Lblock0 < 1 ? 1 : Lblock0;
+        const int iEnd = n - Lmin;
+        for (int i0 = 0; i0 < iEnd; i0 += ARC_CHUNK) {
+            __syncthreads();
+            for (int k = threadIdx.x; k < ARC_CHUNK; k += ARC_THREADS) { int idx = i0 + k; sA[k] = idx < n ? sx[idx] : 0.0; }
+            for (int k = threadIdx.x; k < ARC_CHUNK + ARC_THREADS; k += ARC_THREADS) { long idx = (long)i0 + Lblock0 + k; sB[k] = (idx >= 0 && idx < n) ? sx[idx] : 0.0; }
+            __syncthreads();
+            if (active) {
+                int lim = n - L - i0; if (lim > ARC_CHUNK) lim = ARC_CHUNK;      // i < n - L
+                for (int k = 0; k < lim; k++) {
+                    double d = fabs(sB[k + off] - sA[k]);
+                    if (d > best) { best = d; bestI = i0 + k; }
+                }
+            }
+        }
+        if (active) { dmax[L] = best; firstI[L] = bestI; }
+    }
+}
+
+// ================================================================================================ host: scalar pieces of the reference
+namespace cbs {
+
+static inline double sq(double v) { return v * v; }          // Math.Pow(v, 2) := exact square (Q13)
+static inline int dn_round(double v) { return (int)std::nearbyint(v); }   // Convert.ToInt32: half to even
+
+// MathNet MersenneTwister as assumed in SURVEY §8c (parity unpinned): init_genrand, NextDouble = u32 * 2^-32
+struct MT {
+    uint32_t mt[624]; int mti;
+    explicit MT(uint32_t s) { mt[0] = s; for (mti = 1; mti < 624; mti++) mt[mti] = 1812433253u * (mt[mti - 1] ^ (mt[mti - 1] >> 30)) + (uint32_t)mti; }
+    uint32_t u32() {
+        if (mti >= 624) {
+            static const uint32_t mag[2] = {0u, 0x9908b0dfu};
+            int k; uint32_t y;
+            for (k = 0; k < 227; k++) { y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu); mt[k] = mt[k + 397] ^ (y >> 1) ^ mag[y & 1u]; }
+            for (; k < 623; k++) { y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu); mt[k] = mt[k - 227] ^ (y >> 1) ^ mag[y & 1u]; }
+            y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu); mt[623] = mt[396] ^ (y >> 1) ^ mag[y & 1u];
+            mti = 0;
+        }
+        uint32_t y = mt[mti++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+    double next_double() { return u32() * (1.0 / 4294967296.0); }
+    int32_t next_full_range_int32() { uint32_t v = 0; for (int b = 0; b < 4; b++) v |= (uint32_t)(u32() % 256u) << (8 * b); return (int32_t)v; }
+};
+
+// ---- R nmath subset used by GetBoundary (R.cs:8-160,528-548)
+static double bd0(double x, double np) {
+    if (std::fabs(x - np) < 0.1 * (x + np)) {
+        double v = (x - np) / (x + np), s = (x - np) * v, ej = 2 * x * v;
+        v = v * v;
+        for (int j = 1;; j++) { ej *= v; double s1 = s + ej / ((j << 1) + 1); if (s1 == s) return s1; s = s1; }
+    }
+    return x * std::log(x / np) + np - x;
+}
+static double stirlerr(double n) {
+    static const double S0 = 0.083333333333333333333, S1 = 0.00277777777777777777778, S2 = 0.00079365079365079365079365, S3 = 0.000595238095238095238095238, S4 = 0.0008417508417508417508417508;
+    static const double h[31] = {0.0, 0.1534264097200273452913848, 0.0810614667953272582196702, 0.0548141210519176538961390, 0.0413406959554092940938221, 0.03316287351993628748511048,
+        0.02767792568499833914878929, 0.02374616365629749597132920, 0.02079067210376509311152277, 0.01848845053267318523077934, 0.01664469118982119216319487, 0.01513497322191737887351255,
+        0.01387612882307074799874573, 0.01281046524292022692424986, 0.01189670994589177009505572, 0.01110455975820691732662991, 0.010411265261972096497478567, 0.009799416126158803298389475,
+        0.009255462182712732917728637, 0.008768700134139385462952823, 0.008330563433362871256469318, 0.007934114564314020547248100, 0.007573675487951840794972024, 0.007244554301320383179543912,
+        0.006942840107209529865664152, 0.006665247032707682442354394, 0.006408994188004207068439631, 0.006171712263039457647532867, 0.005951370112758847735624416, 0.005746216513010115682023589,
+        0.005554733551962801371038690};
+    if (n <= 15.0) { double nn = n + n; if (nn == (int)nn) return h[(int)nn]; return std::lgamma(n + 1.0) - (n + 0.5) * std::log(n) + n - 0.918938533204672741780329736406; }
+    double nn = n * n;
+    if (n > 500) return (S0 - S1 / nn) / n;
+    if (n > 80) return (S0 - (S1 - S2 / nn) / nn) / n;
+    if (n > 35) return (S0 - (S1 - (S2 - S3 / nn) / nn) / nn) / n;
+    return (S0 - (S1 - (S2 - (S3 - S4 / nn) / nn) / nn) / nn) / n;
+}
+static double dbinom_raw(double x, double n, double p, double q) {
+    if (p == 0) return x == 0 ? 1.0 : 0.0;
+    if (q == 0) return x == n ? 1.0 : 0.0;
+    if (x == 0) { if (n == 0) return 1.0; double lc = (p < 0.1) ? (-bd0(n, n * q) - n * p) : (n * std::log(q)); return std::exp(lc); }
+    if (x == n) { double lc = (q < 0.1) ? -bd0(n, n * p) - n * q : n * std::log(p); return std::exp(lc); }
+    if (x < 0 || x > n) return 0.0;
+    double lc = stirlerr(n) - stirlerr(x) - stirlerr(n - x) - bd0(x, n * p) - bd0(n - x, n * q);
+    double lf = std::log(2 * M_PI) + std::log(x) + std::log1p(-x / n);
+    return std::exp(lc - 0.5 * lf);
+}
+static double phyper_lower(double x, double NR, double NB, double n) {
+    x = std::floor(x + 1e-7); NR = std::floor(NR + 0.5); NB = std::floor(NB + 0.5); n = std::floor(n + 0.5);
+    bool lower = true;
+    if (x * (NR + NB) > n * NR) { double o = NB; NB = NR; NR = o; x = n - x - 1; lower = !lower; }
+    if (x < 0) return lower ? 0.0 : 1.0;
+    if (x >= NR || x >= n) return lower ? 1.0 : 0.0;
+    double d;
+    if (n < x || NR < x || (n - x) > NB) d = 0.0;
+    else if (n == 0) d = x == 0 ? 1.0 : 0.0;
+    else { double p = n / (NR + NB), q = (NR + NB - n) / (NR + NB); d = dbinom_raw(x, NR, p, q) * dbinom_raw(n - x, NB, p, q) / dbinom_raw(n, NR + NB, p, q); }
+    double sum = 0, term = 1, xx = x;
+    while (xx > 0 && term >= 2.2204460492503131E-16 * sum) { term *= xx * (NB - n + xx) / (n + 1 - xx) / (NR + 1 - xx); sum += term; xx--; }
+    double pv = d * (1 + sum);
+    return lower ? pv : (0.5 - pv + 0.5);
+}
+static double binom_ln(int n, int k) { if (k < 0 || n < 0 || k > n) return -std::numeric_limits<double>::infinity(); return std::lgamma(n + 1.0) - std::lgamma(k + 1.0) - std::lgamma(n - k + 1.0); }
+
+// GetBoundary.cs:19-157
+static void eta_boundary(uint32_t nPerm, double eta0, uint32_t n1s, std::vector<uint32_t>& sb, uint32_t off) {
+    double dn = (double)nPerm - (double)n1s; uint32_t k = 0;
+    for (uint32_t i = 1; i <= nPerm; i++) if (phyper_lower((double)k, (double)n1s, dn, (double)i) <= eta0) { sb[off + k] = i; k++; }
+}
+static double p_exceed(uint32_t nPerm, uint32_t n1s, const std::vector<uint32_t>& sb, uint32_t off) {
+    int n = (int)nPerm, k = (int)n1s, n1 = (int)(nPerm - sb[off]);
+    double dl = binom_ln(n, k), p = std::exp(binom_ln(n1, k) - dl);
+    if (n1s >= 2) { n1 = (int)sb[off]; n = (int)(nPerm - sb[off + 1]); k = (int)(n1s - 1); p += std::exp(std::log((double)n1) + binom_ln(n, k) - dl); }
+    if (n1s >= 3) {
+        n1 = (int)sb[off]; int n2 = (int)sb[off + 1]; n = (int)(nPerm - sb[off + 2]); k = (int)(n1s - 2);
+        p += std::exp(std::log((double)n1) + std::log(n1 - 1.0) - std::log(2.0) + binom_ln(n, k) - dl) + std::exp(std::log((double)n1) + std::log((double)(n2 - n1)) + binom_ln(n, k) - dl);
+    }
+    if (n1s > 3) for (int i = 4; i <= (int)n1s; i++) {
+        n1 = (int)sb[off + i - 4]; int k1 = i - 1, k2 = i - 2, k3 = i - 3, n2 = (int)sb[off + i - 3], n3 = (int)sb[off + i - 2];
+        n = (int)(nPerm - sb[off + i - 1]); k = (int)(n1s - i + 1);
+        p += std::exp(binom_ln(n1, k1) + binom_ln(n, k) - dl) + std::exp(binom_ln(n1, k2) + std::log((double)(n3 - n1)) + binom_ln(n, k) - dl) +
+             std::exp(binom_ln(n1, k3) + std::log((double)(n2 - n1)) + std::log((double)(n3 - n2)) + binom_ln(n, k) - dl) +
+             std::exp(binom_ln(n1, k3) + std::log((double)(n2 - n1)) - std::log(2.0) + std::log(n2 - n1 - 1.0) + binom_ln(n, k) - dl);
+    }
+    return p;
+}
+static void compute_boundary(uint32_t nPerm, double alpha, double eta, std::vector<uint32_t>& sb) {
+    uint32_t maxOnes = (uint32_t)(std::floor(nPerm * alpha) + 1);
+    sb.assign((size_t)maxOnes * (maxOnes + 1) / 2, 0);
+    uint32_t l = 0; sb[0] = nPerm - (uint32_t)(nPerm * eta);
+    double eta0 = eta;
+    for (uint32_t j = 2; j <= maxOnes; j++) {
+        double hi = eta0 * 1.1; eta_boundary(nPerm, hi, j, sb, l + 1); double pHi = p_exceed(nPerm, j, sb, l + 1);
+        double lo = eta0 * 0.25; eta_boundary(nPerm, lo, j, sb, l + 1); double pLo = p_exceed(nPerm, j, sb, l + 1);
+        while ((hi - lo) / lo > 1E-2) {
+            eta0 = lo + (hi - lo) * (eta - pLo) / (pHi - pLo);
+            eta_boundary(nPerm, eta0, j, sb, l + 1); double pe = p_exceed(nPerm, j, sb, l + 1);
+            if (pe > eta) { hi = eta0; pHi = pe; } else { lo = eta0; pLo = pe; }
+        }
+        l += j;
+    }
+}
+
+// TailProbability.cs:21-105 (Normal CDF of MathNet -> erfc, parity unpinned)
+static double pnorm(double x) { return 0.5 * std::erfc(-x / M_SQRT2); }
+static double nu(double x, double tol) {
+    double l1;
+    if (x > 0.01) {
+        l1 = std::log(2.0) - 2 * std::log(x); double l0 = l1; int k = 2; double dk = 0;
+        for (int i = 0; i < k; i++) { dk = dk + 1; double xk = -x * std::sqrt(dk) / 2.0; l1 = l1 - 2.0 * pnorm(xk) / dk; }
+        while (std::fabs((l1 - l0) / l1) > tol) { l0 = l1; for (int i = 0; i < k; i++) { dk = dk + 1; double xk = -x * std::sqrt(dk) / 2.0; l1 = l1 - 2.0 * pnorm(xk) / dk; } k *= 2; }
+    } else l1 = -0.583 * x;
+    return std::exp(l1);
+}
+static double integral_inv(double x, double a) {
+    double y = x + a - 0.5;
+    double r = (8.0 * y) / (1.0 - 4.0 * sq(y)) + 2.0 * std::log((1.0 + 2.0 * y) / (1.0 - 2.0 * y));
+    y = x - 0.5;
+    return r - (8.0 * y) / (1.0 - 4.0 * sq(y)) - 2.0 * std::log((1.0 + 2.0 * y) / (1.0 - 2.0 * y));
+}
+static double tail_p(double b, double delta, int m, int nGrid, double tol) {
+    double dincr = (0.5 - delta) / nGrid, bs = b / std::sqrt((double)m), tl = 0.5 - dincr, t = 0.5 - 0.5 * dincr, tp = 0.0;
+    for (int i = 0; i < nGrid; i++) { tl = tl + dincr; t = t + dincr; double x = bs / std::sqrt(t * (1 - t)); double nx = nu(x, tol); tp = tp + sq(nx) * integral_inv(tl, dincr); }
+    tp = 9.973557E-2 * (b * b * b) * std::exp(-sq(b) / 2) * tp;
+    return 2.0 * tp;
+}
+
+// ---- Array.Sort<double,int> of .NET Core 2.0 (introsort; tie order parity-unpinned, Q11) — used by the host replay of TMaxO/TMaxP
+struct KI { double* k; int* v; };
+static inline void sw(KI a, int i, int j) { if (i != j) { std::swap(a.k[i], a.k[j]); std::swap(a.v[i], a.v[j]); } }
+static inline void sig(KI a, int i, int j) { if (i != j && a.k[i] > a.k[j]) { std::swap(a.k[i], a.k[j]); std::swap(a.v[i], a.v[j]); } }
+static void ins(KI a, int lo, int hi) { for (int i = lo; i < hi; i++) { int j = i; double t = a.k[i + 1]; int tv = a.v[i + 1]; while (j >= lo && t < a.k[j]) { a.k[j + 1] = a.k[j]; a.v[j + 1] = a.v[j]; j--; } a.k[j + 1] = t; a.v[j + 1] = tv; } }
+static void dheap(KI a, int i, int n, int lo) { double d = a.k[lo + i - 1]; int dv = a.v[lo + i - 1]; while (i <= n / 2) { int c = 2 * i; if (c < n && a.k[lo + c - 1] < a.k[lo + c]) c++; if (a.k[lo + c - 1] < d) break; a.k[lo + i - 1] = a.k[lo + c - 1]; a.v[lo + i - 1] = a.v[lo + c - 1]; i = c; } a.k[lo + i - 1] = d; a.v[lo + i - 1] = dv; }
+static void hsort(KI a, int lo, int hi) { int n = hi - lo + 1; for (int i = n / 2; i >= 1; i--) dheap(a, i, n, lo); for (int i = n; i > 1; i--) { sw(a, lo, lo + i - 1); dheap(a, 1, i - 1, lo); } }
+static int part(KI a, int lo, int hi) { int mid = lo + (hi - lo) / 2; sig(a, lo, mid); sig(a, lo, hi); sig(a, mid, hi); double pv = a.k[mid]; sw(a, mid, hi - 1); int l = lo, r = hi - 1; while (l < r) { while (pv > a.k[++l]) ; while (pv < a.k[--r]) ; if (l >= r) break; sw(a, l, r); } sw(a, l, hi - 1); return l; }
+static void intro(KI a, int lo, int hi, int depth) {
+    while (hi > lo) {
+        int ps = hi - lo + 1;
+        if (ps <= 16) { if (ps == 1) return; if (ps == 2) { sig(a, lo, hi); return; } if (ps == 3) { sig(a, lo, hi - 1); sig(a, lo, hi); sig(a, hi - 1, hi); return; } ins(a, lo, hi); return; }
+        if (depth == 0) { hsort(a, lo, hi); return; }
+        depth--; int p = part(a, lo, hi); intro(a, p + 1, hi, depth); hi = p - 1;
+    }
+}
+static void dotnet_sort(double* keys, int* items, int length, int arrayLength) { if (length < 2) return; int fl = 0, n = arrayLength; while (n >= 1) { fl++; n /= 2; } intro(KI{keys, items}, 0, length - 1, 2 * fl); }
+
+// ---- CBSTStatistic.cs restated for the host (small segments, permutations, tie replay)
+struct Blocks { int nb; std::vector<int> bb, ibmin, ibmax; std::vector<double> bpsmin, bpsmax; double psmin0, psmax0; int ipsmin0, ipsmax0; };
+static void build_blocks(const double* x, int n, double* sx, Blocks& B) {     // CBSTStatistic.cs:44-110
+    double rn = (double)n;
+    B.nb = n >= 50 ? dn_round(std::sqrt((double)n)) : 1;
+    int nb = B.nb;
+    B.bb.resize(nb); B.ibmin.resize(nb); B.ibmax.resize(nb); B.bpsmin.resize(nb); B.bpsmax.resize(nb);
+    for (int i = 0; i < nb; i++) B.bb[i] = dn_round(rn * ((i + 1.0) / nb));
+    int ilo = 1; double psum = 0;
+    B.psmin0 = 0; B.psmax0 = 0; B.ipsmin0 = n; B.ipsmax0 = n;
+    for (int j = 0; j < nb; j++) {
+        sx[ilo - 1] = psum + x[ilo - 1];
+        double mn = sx[ilo - 1], mx = mn; int imn = ilo, imx = ilo;
+        for (int i = ilo + 1; i <= B.bb[j]; i++) { sx[i - 1] = sx[i - 2] + x[i - 1]; if (sx[i - 1] < mn) { mn = sx[i - 1]; imn = i; } if (sx[i - 1] > mx) { mx = sx[i - 1]; imx = i; } }
+        B.ibmin[j] = imn; B.ibmax[j] = imx; B.bpsmin[j] = mn; B.bpsmax[j] = mx;
+        if (mn < B.psmin0) { B.psmin0 = mn; B.ipsmin0 = imn; }
+        if (mx > B.psmax0) { B.psmax0 = mx; B.ipsmax0 = imx; }
+        psum = sx[B.bb[j] - 1]; ilo = B.bb[j] + 1;
+    }
+}
+static void block_search(const double* sx, int n, int al0, const Blocks& B, double& bssmax, int& tmaxi, int& tmaxj) {   // CBSTStatistic.cs:128-326
+    double rn = (double)n; int nb = B.nb, nb2 = nb * (nb + 1) / 2;
+    std::vector<double> bssbij(nb2), bssijmax(nb2); std::vector<int> bloci(nb2), blocj(nb2), loc(nb2), alen(nb2);
+    double rnov2 = rn / 2; int l = 0, nal0 = n - al0; const std::vector<int>& bb = B.bb;
+    for (int i = 1; i <= nb; i++) for (int j = i; j <= nb; j++) {
+        int ilo = i == 1 ? 1 : bb[i - 2] + 1, ihi = bb[i - 1], jlo = j == 1 ? 1 : bb[j - 2] + 1, jhi = bb[j - 1];
+        int alenhi = jhi - ilo; if (alenhi > nal0) alenhi = nal0;
+        double rjhi = (double)alenhi;
+        int alenlo = i == j ? 1 : jlo - ihi; if (alenlo < al0) alenlo = al0;
+        double s1 = std::fabs(B.bpsmax[j - 1] - B.bpsmin[i - 1]), s2 = std::fabs(B.bpsmax[i - 1] - B.bpsmin[j - 1]), s0 = std::max(s1, s2);
+        double rjlo = (double)alenlo;
+        double rnj = rn / std::min(rjlo * (rn - rjlo), rjhi * (rn - rjhi));
+        double lim = rnj * sq(s0);
+        if (bssmax <= lim) {
+            loc[l] = l + 1; bloci[l] = i; blocj[l] = j; bssijmax[l] = lim;
+            if (s1 > s2) { alen[l] = std::abs(B.ibmax[j - 1] - B.ibmin[i - 1]); double rj = (double)alen[l]; bssbij[l] = (rn / (rj * (rn - rj))) * sq(s1); }
+            else { alen[l] = std::abs(B.ibmin[j - 1] - B.ibmax[i - 1]); double rj = (double)alen[l]; bssbij[l] = (rn / (rj * (rn - rj))) * sq(s2); }
+            l++;
+        }
+    }
+    int nb1 = l;
+    for (int k = 0; k < nb1; k++) loc[k] = k + 1;
+    dotnet_sort(bssbij.data(), loc.data(), nb1, nb2);
+    auto scan = [&](int i2j, int ilo, int ihi, int jlo, int jhi) {
+        int ixlo = std::max(0, jlo - ilo - i2j), ixhi = std::max(0, ihi + i2j - jhi);
+        double sxmx = 0; int sxmxi = ilo + ixlo - 1;
+        for (int i = ilo + ixlo; i <= ihi - ixhi; i++) { double a = std::fabs(sx[i + i2j - 1] - sx[i - 1]); if (sxmx < a) { sxmx = a; sxmxi = i; } }
+        double rj = (double)i2j; double v = (rn / (rj * (rn - rj))) * sq(sxmx);
+        if (v > bssmax) { bssmax = v; tmaxi = sxmxi; tmaxj = sxmxi + i2j; }
+    };
+    for (l = nb1 - 1; l >= 0; l--) {
+        int k = loc[l] - 1;
+        if (bssmax <= bssijmax[k]) {
+            int bi = bloci[k], bj = blocj[k], alenmax = alen[k];
+            int ilo = bi == 1 ? 1 : bb[bi - 2] + 1, ihi = bb[bi - 1], jlo = bj == 1 ? 1 : bb[bj - 2] + 1, jhi = bb[bj - 1];
+            int alenhi = jhi - ilo; if (alenhi > nal0) alenhi = nal0;
+            double rjhi = (double)alenhi;
+            int alenlo = bi == bj ? 1 : jlo - ihi; if (alenlo < al0) alenlo = al0;
+            double rjlo = (double)alenlo;
+            if (alenmax > n - alenmax) alenmax = n - alenmax;
+            if (rjlo <= rnov2 && alenlo <= alenmax) for (int i2j = alenlo; i2j <= alenmax; i2j++) scan(i2j, ilo, ihi, jlo, jhi);
+            alenmax = n - alenmax;
+            if (rjhi >= rnov2 && alenhi >= alenmax) for (int i2j = alenhi; i2j >= alenmax; i2j--) scan(i2j, ilo, ihi, jlo, jhi);
+        }
+    }
+}
+static double normalise(double bssmax, double tss, double rn) { if (tss <= bssmax + 0.0001) tss = bssmax + 1.0; return bssmax / ((tss - bssmax) / (rn - 2.0)); }   // CBSTStatistic.cs:334-337
+static void tmaxo_host(const double* x, int n, double tss, double* sx, int iseg[2], double& ostat, int al0) {           // CBSTStatistic.cs:19-341
+    Blocks B; build_blocks(x, n, sx, B);
+    double rn = (double)n, psdiff = B.psmax0 - B.psmin0, rj = (double)std::abs(B.ipsmax0 - B.ipsmin0);
+    double bssmax = (rn / (rj * (rn - rj))) * sq(psdiff);
+    int ti = std::min(B.ipsmax0, B.ipsmin0), tj = std::max(B.ipsmax0, B.ipsmin0);
+    if (psdiff <= 0) bssmax = 0; else block_search(sx, n, al0, B, bssmax, ti, tj);
+    ostat = normalise(bssmax, tss, rn); iseg[0] = ti; iseg[1] = tj;
+}
+static double tmaxp_host(double tss, const double* px, int n, double* sx, int al0) {                                     // CBSTStatistic.cs:599-934
+    Blocks B; build_blocks(px, n, sx, B);
+    double rn = (double)n, psdiff = B.psmax0 - B.psmin0, rj = (double)std::abs(B.ipsmax0 - B.ipsmin0);
+    double bssmax = (rn / (rj * (rn - rj))) * sq(psdiff); int a = 0, b = 0;
+    block_search(sx, n, al0, B, bssmax, a, b);
+    return normalise(bssmax, tss, rn);
+}
+static double htmaxp_host(int k, double tss, const double* px, int n, double* sx, int al0) {                             // CBSTStatistic.cs:354-586
+    double rn = (double)n; int nb = (int)(rn / k);
+    std::vector<double> bmx(nb), bmn(nb); std::vector<int> bb(nb);
+    for (int i = 0; i < nb; i++) bb[i] = dn_round(rn * ((double)(i + 1) / nb));
+    int ilo = 1; double psum = 0, h = 0.0;
+    for (int j = 0; j < nb; j++) {
+        sx[ilo - 1] = psum + px[ilo - 1];
+        double mn = sx[ilo - 1], mx = mn; int imn = ilo, imx = ilo;
+        for (int i = ilo; i < bb[j]; i++) { sx[i] = sx[i - 1] + px[i]; if (sx[i] < mn) { mn = sx[i]; imn = i + 1; } if (sx[i] > mx) { mx = sx[i]; imx = i + 1; } }
+        bmn[j] = mn; bmx[j] = mx; psum = sx[bb[j] - 1]; ilo = bb[j] + 1;
+        int d = std::abs(imn - imx);
+        if (d <= k && d >= al0) { double rj = (double)d; double v = (rn / (rj * (rn - rj))) * sq(bmx[j] - bmn[j]); if (h < v) h = v; }
+    }
+    auto arcs = [&](double dsq, auto&& inner) {
+        for (int j = al0; j <= k; j++) { double rj = (double)j, c = rn / (rj * (rn - rj)); if (c * dsq < h) break; double m = inner(j); double v = c * sq(m); if (h < v) h = v; }
+    };
+    arcs(sq(bmx[0] - bmn[0]), [&](int j) { double m = 0; for (int i = 1; i <= bb[0] - j; i++) { double a = std::fabs(sx[i + j - 1] - sx[i - 1]); if (m < a) m = a; } return m; });
+    arcs(sq(std::max(std::fabs(bmx[0] - bmn[nb - 1]), std::fabs(bmx[nb - 1] - bmn[0]))), [&](int j) { double m = 0; int nmj = n - j; for (int i = 0; i < j; i++) { double a = std::fabs(sx[i + nmj] - sx[i]); if (m < a) m = a; } return m; });
+    for (int l = 1; l < nb; l++) {
+        int lo = bb[l - 1] + 1, hi = bb[l];
+        arcs(sq(bmx[l] - bmn[l]), [&](int j) { double m = 0; for (int i = lo; i <= hi - j; i++) { double a = std::fabs(sx[i + j - 1] - sx[i - 1]); if (m < a) m = a; } return m; });
+        arcs(sq(std::max(std::fabs(bmx[l] - bmn[l - 1]), std::fabs(bmx[l - 1] - bmn[l]))), [&](int j) { double m = 0; for (int i = lo - j; i <= lo - 1; i++) { double a = std::fabs(sx[i + j - 1] - sx[i - 1]); if (m < a) m = a; } return m; });
+    }
+    return normalise(h, tss, rn);
+}
+
+struct Stats { std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
+
+// GPU arc search service shared by the chromosome threads
+struct ArcGpu {
+    canvas_ctx* ctx; std::mutex mu;
+    double* dSx = nullptr; double* dMax = nullptr; int32_t* dFirst = nullptr; int cap = 0;
+    std::vector<double> hMax; std::vector<int32_t> hFirst;
+    int32_t ensure(int n) {
+        if (n <= cap) return CANVAS_OK;
+        if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); }
+        cap = n + n / 4 + 1024;
+        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dMax, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dFirst, (size_t)cap * 4));
+        return CANVAS_OK;
+    }
+    ~ArcGpu() { if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); } }
+};
+
+// TMaxO with the O(n^2) search on the GPU.  Returns false when the caller must fall back to the host replay (ambiguous maximum).
+static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* sx, int iseg[2], double& ostat, int al0, Stats& st, bool& ok) {
+    // sequential prefix sums and the initial incumbent exactly as the reference builds them (block structure does not change sx)
+    Blocks B; build_blocks(x, n, sx, B);
+    double rn = (double)n, psdiff = B.psmax0 - B.psmin0, rj0 = (double)std::abs(B.ipsmax0 - B.ipsmin0);
+    double bss0 = (rn / (rj0 * (rn - rj0))) * sq(psdiff);
+    int ti = std::min(B.ipsmax0, B.ipsmin0), tj = std::max(B.ipsmax0, B.ipsmin0);
+    ok = true;
+    if (psdiff <= 0) { ostat = normalise(0.0, tss, rn); iseg[0] = ti; iseg[1] = tj; return CANVAS_OK; }
+    std::vector<double> dmax; std::vector<int32_t> firstI;
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        canvas_ctx* ctx = G.ctx;
+        CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int32_t rc = G.ensure(n); if (rc) return rc;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(G.dSx, sx, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        int half = n / 2 + 1;
+        { ProfScope ps(ctx, "cbs_arc_search");
+          hipLaunchKernelGGL(k_arc_search, dim3((half + ARC_THREADS - 1) / ARC_THREADS), dim3(ARC_THREADS), 0, ctx->stream, G.dSx, n, G.dMax, G.dFirst); }
+        dmax.resize(n); firstI.resize(n);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dmax.data(), G.dMax, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(firstI.data(), G.dFirst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+    }
+    st.gpu_searches++; st.gpu_pairs += (long long)n * (n - 1) / 2;
+    // arcs of length L in [al0, n - al0] (CBSTStatistic.cs:139-151: alenlo >= al0, alenhi <= n - al0)
+    double M = -1.0; int bestL = -1, nbest = 0;
+    for (int L = al0; L <= n - al0; L++) {
+        double rj = (double)L; double v = (rn / (rj * (rn - rj))) * sq(dmax[L]);
+        if (v > M) { M = v; bestL = L; nbest = 1; } else if (v == M) nbest++;
+    }
+    if (!(M > bss0)) { ostat = normalise(bss0, tss, rn); iseg[0] = ti; iseg[1] = tj; return CANVAS_OK; }   // the incumbent survives every strict '>' test
+    if (nbest == 1) {
+        // is the maximising arc unique among all arcs of that length (including rounding plateaus of v)?
+        double rj = (double)bestL, c = rn / (rj * (rn - rj)); int cnt = 0;
+        for (int i = 0; i + bestL < n && cnt < 2; i++) { double d = std::fabs(sx[i + bestL] - sx[i]); if (c * sq(d) == M) cnt++; }
+        if (cnt == 1) { ostat = normalise(M, tss, rn); iseg[0] = firstI[bestL] + 1; iseg[1] = firstI[bestL] + 1 + bestL; return CANVAS_OK; }
+    }
+    ok = false;     // exact tie: the winner depends on the reference's block visiting order
+    return CANVAS_OK;
+}
+
+static double tpermp(int n1, int n2, int n, const double* gd, int off, double* px, uint32_t nPerm, MT& rnd, Stats& st) {   // CBSTStatistic.cs:947-1024
+    double rn1 = (double)n1, rn2 = (double)n2, rn = rn1 + rn2; int nrej;
+    if (n1 == 1 || n2 == 1) nrej = (int)nPerm;
+    else {
+        double xs1 = 0.0, tss = 0.0;
+        for (int i = 0; i < n1; i++) { px[i] = gd[off + i]; xs1 = xs1 + gd[off + i]; tss = tss + sq(gd[off + i]); }
+        double xs2 = 0.0;
+        for (int i = n1; i < n; i++) { px[i] = gd[off + i]; xs2 = xs2 + gd[off + i]; tss = tss + sq(gd[off + i]); }
+        double xbar = (xs1 + xs2) / rn; tss = tss - rn * sq(xbar);
+        int m1; double rm1, ostat, tstat;
+        if (n1 <= n2) { m1 = n1; rm1 = rn1; ostat = 0.99999 * std::fabs(xs1 / rn1 - xbar); tstat = sq(ostat) * rn1 * rn / rn2; }
+        else { m1 = n2; rm1 = rn2; ostat = 0.99999 * std::fabs(xs2 / rn2 - xbar); tstat = sq(ostat) * rn2 * rn / rn1; }
+        nrej = 0; tstat = tstat / ((tss - tstat) / (rn - 2.0));
+        if (!(tstat > 25 && m1 >= 10)) {
+            for (uint32_t np = 0; np < nPerm; np++) {
+                xs1 = 0;
+                for (int i = n - 1; i >= n - m1; i--) { double cc = rnd.next_double(); int j = (int)(cc * (i + 1)); j = j > i ? i : j; std::swap(px[i], px[j]); xs1 = xs1 + px[i]; }
+                if (ostat <= std::fabs(xs1 / rm1 - xbar)) nrej++;
+            }
+            st.tpermp_draws += (long long)nPerm * m1;
+        }
+    }
+    return (double)nrej / nPerm;
+}
+static void xperm(const double* x, double* px, int n, MT& rnd) {                 // ChangePoint.cs:407-421
+    for (int i = 0; i < n; i++) px[i] = x[i];
+    for (int i = n - 1; i >= 0; i--) { double cc = rnd.next_double(); int j = (int)(cc * (i + 1)); j = j > i ? i : j; std::swap(px[i], px[j]); }
+}
+
+#define CBS_GPU_MIN_N 4096
+
+// ChangePoint.FindChangePoints (ChangePoint.cs:291-400)
+static int32_t find_change_points(ArcGpu& G, const double* gd, int n, double tss, uint32_t nPerm, double cutoff, int& nCp, int iCp[2], bool hybrid, int al0, int hk,
+                                  double delta, const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st) {
+    std::vector<double> px(n), sx(n);
+    int iseg[2]; double ostat; int nrej = 0; nCp = 0;
+    bool done = false;
+    if (n >= CBS_GPU_MIN_N) {
+        bool ok = false;
+        int32_t rc = tmaxo_gpu(G, gd, n, tss, sx.data(), iseg, ostat, al0, st, ok); if (rc) return rc;
+        done = ok;
+        if (!ok) st.tie_replays++;
+    }
+    if (!done) tmaxo_host(gd, n, tss, sx.data(), iseg, ostat, al0);
+    st.tmaxo_calls++; st.tmaxo_elems += n;
+    double ostat1 = std::sqrt(ostat); ostat *= 0.99999;
+    if (ostat1 <= 0.1) return CANVAS_OK;
+    int l = std::min(iseg[1] - iseg[0], n - iseg[1] + iseg[0]);
+    if (!(ostat1 >= 7.0 && l >= 10)) {
+        int nrejc, k;
+        if (hybrid) {
+            double p1 = tail_p(ostat1, delta, n, 100, 1E-6);
+            if (p1 > cutoff) { st.tailp_exits++; return CANVAS_OK; }
+            nrejc = (int)((cutoff - p1) * nPerm);
+        } else nrejc = (int)(cutoff * nPerm);
+        k = nrejc * (nrejc + 1) / 2 + 1;
+        for (uint32_t np = 1; np <= nPerm; np++) {
+            xperm(gd, px.data(), n, rnd);
+            double pstat = hybrid ? htmaxp_host(hk, tss, px.data(), n, sx.data(), al0) : tmaxp_host(tss, px.data(), n, sx.data(), al0);
+            st.perms++; st.perm_elems += n;
+            if (ostat <= pstat) { nrej++; k++; }
+            if (nrej > nrejc) return CANVAS_OK;
+            if (np >= sbdry[k - 1]) break;
+        }
+    } else st.big_t++;
+    if (iseg[1] == n) { nCp = 1; iCp[0] = iseg[0]; }
+    else if (iseg[0] == 0) { nCp = 1; iCp[0] = iseg[1]; }
+    else {
+        int n1 = iseg[0], n12 = iseg[1], n2 = n12 - n1;
+        if (tpermp(n1, n2, n12, gd, 0, px.data(), nPerm, rnd, st) <= cutoff) { nCp = 1; iCp[0] = iseg[0]; }
+        int off = iseg[0]; n12 = n - iseg[0]; n2 = n - iseg[1]; n1 = n12 - n2;
+        if (tpermp(n1, n2, n12, gd, off, px.data(), nPerm, rnd, st) <= cutoff) { nCp++; iCp[nCp - 1] = iseg[1]; }
+    }
+    return CANVAS_OK;
+}
+
+// ChangePoint.ChangePoints (ChangePoint.cs:44-153), undo = None
+static int32_t change_points(ArcGpu& G, const double* gd, int n, const std::vector<uint32_t>& sbdry, MT& rnd, double alpha, uint32_t nPerm, std::vector<int>& lengthSeg, Stats& st) {
+    const int minWidth = 2, kMax = 25; const uint32_t nMin = 200;
+    std::vector<int> segEnd = {0, n}, changeLoc;
+    int k = 2, nCp = 0, iCp[2] = {0, 0};
+    while (k > 1) {
+        int cn = segEnd[k - 1] - segEnd[k - 2];
+        if (cn >= 2 * minWidth) {
+            std::vector<double> cur(gd + segEnd[k - 2], gd + segEnd[k - 2] + cn);
+            bool hybrid = false; double delta = 0.0;
+            if (nMin < (uint32_t)cn) { hybrid = true; delta = (kMax + 1.0) / cn; }
+            double mx = cur[0], mn = cur[0];
+            for (double v : cur) { mx = std::max(mx, v); mn = std::min(mn, v); }
+            if (mx == mn) nCp = 0;
+            else {
+                double sum = 0; for (double v : cur) sum += v;
+                double avg = sum / cn;
+                for (double& v : cur) v -= avg;
+                double tss = 0.0; for (double v : cur) tss += 1.0 * v * v;
+                int32_t rc = find_change_points(G, cur.data(), cn, tss, nPerm, alpha, nCp, iCp, hybrid, minWidth, kMax, delta, sbdry, rnd, st); if (rc) return rc;
+            }
+        } else nCp = 0;
+        if (nCp == 0) changeLoc.push_back(segEnd[k - 1]);
+        for (int i = 0; i < nCp; i++) iCp[i] += segEnd[k - 2];
+        if (nCp == 0) segEnd.erase(segEnd.begin() + (k - 1));
+        else if (nCp == 1) segEnd.insert(segEnd.begin() + (k - 1), iCp[0]);
+        else segEnd.insert(segEnd.begin() + (k - 1), iCp, iCp + 2);
+        k = (int)segEnd.size();
+    }
+    std::reverse(changeLoc.begin(), changeLoc.end());
+    lengthSeg.clear(); int prev = 0;
+    for (int e : changeLoc) { lengthSeg.push_back(e - prev); prev = e; }
+    return CANVAS_OK;
+}
+
+}  // namespace cbs
+
 extern "C" int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                               int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats) {
-    (void)nchr; (void)d_cov; (void)h_chr_offset; (void)alpha; (void)nperm; (void)d_seg_len; (void)h_nseg; (void)h_stats;
     if (!ctx) return CANVAS_ERR_INVALID;
-    CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "CBS segmentation (CBSRunner.cs) is not built yet; use PerSampleHMM");
+    if (nchr <= 0 || !d_cov || !h_chr_offset || !d_seg_len || !h_nseg || nperm == 0 || !(alpha > 0 && alpha < 1)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = h_chr_offset[nchr];
+    std::vector<double> cov((size_t)N);
+    if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(cov.data(), d_cov, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < N; i++) if (!std::isfinite(cov[i])) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_cbs: non-finite coverage (CBSRunner.cs:63-89 filter) is not built");
+    // sequential stopping boundary (GetBoundary.cs), cached per (nperm, alpha)
+    static std::mutex bmu; static std::vector<uint32_t> sb; static uint32_t sbN = 0; static double sbA = 0;
+    std::vector<uint32_t> sbdry;
+    { std::lock_guard<std::mutex> lk(bmu); if (sbN != nperm || sbA != alpha) { cbs::compute_boundary(nperm, alpha, 0.05, sb); sbN = nperm; sbA = alpha; } sbdry = sb; }
+    // per-chromosome seeds in file order (CBSRunner.cs:107-112)
+    cbs::MT seeder(0u);
+    std::vector<int32_t> seeds(nchr);
+    for (int c = 0; c < nchr; c++) seeds[c] = seeder.next_full_range_int32();
+    cbs::ArcGpu G; G.ctx = ctx;
+    cbs::Stats st;
+    std::vector<std::vector<int>> segs(nchr);
+    std::vector<int32_t> rcs(nchr, 0);
+    std::atomic_int next{0};
+    auto work = [&]() {
+        for (;;) {
+            int c = next++; if (c >= nchr) break;
+            int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);
+            if (n <= 0) continue;
+            cbs::MT rnd((uint32_t)seeds[c]);
+            rcs[c] = cbs::change_points(G, cov.data() + h_chr_offset[c], n, sbdry, rnd, alpha, nperm, segs[c], st);
+        }
+    };
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
+    int nthreads = (int)std::min<unsigned>(hw, (unsigned)nchr);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(work);
+    for (auto& t : th) t.join();
+    for (int c = 0; c < nchr; c++) if (rcs[c]) return rcs[c];
+    std::vector<int32_t> flat((size_t)N + 1, 0);
+    for (int c = 0; c < nchr; c++) { h_nseg[c] = (int32_t)segs[c].size(); for (size_t i = 0; i < segs[c].size(); i++) flat[h_chr_offset[c] + i] = segs[c][i]; }
+    if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_seg_len, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_stats) { h_stats[0] = st.tmaxo_calls; h_stats[1] = st.tmaxo_elems; h_stats[2] = st.perms; h_stats[3] = st.perm_elems; h_stats[4] = st.tpermp_draws; h_stats[5] = st.tailp_exits; h_stats[6] = st.gpu_searches; h_stats[7] = st.tie_replays; }
+    return CANVAS_OK;
 }

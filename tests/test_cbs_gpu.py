@@ -1,0 +1,55 @@
+"""CBS (host recursion + GPU exhaustive arc search) vs the CPU oracle: segment lengths identical."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from canvas_amd import synth
+from gpu_common import get_canvas, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cv, cov, off, nperm=10000):
+    nchr = len(off) - 1
+    per = [np.ascontiguousarray(cov[off[c]:off[c + 1]]) for c in range(nchr)]
+    exp, est = O.cbs_genome(per, 0.01, nperm, threads=8)
+    seg_len, nseg, stats = cv.cbs(to_dev(cov, cv.device), off, 0.01, nperm)
+    got = seg_len.cpu().numpy()
+    for c in range(nchr):
+        g = got[off[c]:off[c] + nseg[c]]
+        assert nseg[c] == len(exp[c]) and (g == exp[c]).all(), (c, g[:10], exp[c][:10])
+    assert stats[0] == est[0] and stats[2] == est[2] and stats[4] == est[4]    # same number of TMaxO calls, permutations, TPermP draws
+    return stats, exp
+
+
+def test_cbs_planted_segments_matches_oracle():
+    cv = get_canvas()
+    bins = synth.generate_bins(20260927 + 20, 150_000, nchr=8)
+    cov = np.round(bins["count"].astype(np.float64), 2)
+    off = np.concatenate([[0], np.cumsum(np.bincount(bins["chr"], minlength=8))]).astype(np.int64)
+    stats, exp = _run(cv, cov, off)
+    assert stats[6] > 0                      # the GPU search was used
+    assert sum(len(e) for e in exp) > 8      # change points were found
+
+
+def test_cbs_ties_and_small_chromosomes():
+    cv = get_canvas()
+    rng = np.random.RandomState(11)
+    # heavily quantised data (many exactly equal partial sums => exact ties of the statistic), plus tiny chromosomes
+    parts = [rng.randint(95, 106, 6000).astype(np.float64), np.concatenate([rng.randint(98, 103, 5000), rng.randint(100, 105, 4000)]).astype(np.float64),
+             np.full(300, 100.0), rng.randint(90, 110, 3).astype(np.float64), rng.normal(100, 5, 250).round(2), np.array([100.0])]
+    cov = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    _run(cv, cov, off, nperm=2000)
+
+
+def test_cbs_borderline_needs_permutations():
+    cv = get_canvas()
+    rng = np.random.RandomState(12)
+    x = rng.normal(100, 10, 5000)
+    x[2000:2008] += 14       # short weak aberration: t between TailP threshold and 7 => permutation test + edge tests
+    x[3500:3900] += 2.5
+    cov = np.round(x, 2)
+    off = np.array([0, len(cov)], np.int64)
+    stats, exp = _run(cv, cov, off, nperm=2000)
+    assert stats[2] > 0
