@@ -64,7 +64,8 @@ def main():
         cv._check(cv.lib.canvas_comm_init(cv.ctx, rank, world, idbuf))
 
     # ---- synthetic sample resident in HBM
-    seed = 20260927 + 3 + 1000 * rank
+    from canvas_amd.parallel import sample_seed
+    seed = sample_seed(20260927 + 3, rank)
     lengths = [max(200_000, int(L * args.scale)) for L in synth.GRCH38]
     nchr = len(lengths)
     lens = np.array(lengths, np.int64)
@@ -126,13 +127,8 @@ def main():
         bins_step = step(record=(i == args.steps - 1))
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    btot = torch.tensor([float(bins_step)], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(btot, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    total_bins_all = float(btot.item())
+    from canvas_amd import parallel
+    dt, total_bins_all, _ = parallel.aggregate_throughput(dt, float(bins_step), device=device)   # MAX over ranks, SUM of bins
     ms_per_step = dt / args.steps * 1e3
     value = total_bins_all / (dt / args.steps)
 
