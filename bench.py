@@ -139,8 +139,16 @@ def main():
     alg_bytes = 2.125 * total_bases + 16.0 * keep["total"]
     avg_ms = ms_bin / max(1, k_bin)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_bin_pass.json")
+    if os.path.exists(pmc):
+        # PMC counters cannot be read from inside the timed run: FETCH_SIZE/WRITE_SIZE of this same deterministic workload were
+        # collected with rocprofv3 --pmc in separate passes (tools/pmc_summary.py) and are quoted here per launch
+        pj = json.load(open(pmc))
+        if abs(pj["workload"]["scale"] - args.scale) < 1e-9 and abs(pj["workload"]["rate"] - args.rate) < 1e-9:
+            traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/pmc_bin_pass.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
     roofline = {"kernel": "k_bin_pass", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(avg_ms, 4), "launches": k_bin,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_ms": round(avg_ms, 4), "launches": k_bin,
                 "algorithmic_bytes": alg_bytes,
                 "other_kernels": {"k_tile_stats": {"avg_ms": round(ms_stats / max(1, k_stats), 4),
                                                    "achieved_GBs": round(1.125 * total_bases / max(1e-9, ms_stats / max(1, k_stats) * 1e-3) / 1e9, 1)},
