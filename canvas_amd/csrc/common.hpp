@@ -22,6 +22,7 @@ struct canvas_ctx {
     size_t pin_bytes = 0;
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
+    int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
     // profiling: hipEvent pairs around named kernels
     bool prof = false;
     struct ProfSlot { std::string name; std::vector<hipEvent_t> ev; double ms = 0; int launches = 0; };

@@ -57,16 +57,18 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 
 // one wave per chromosome
 __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx, const double* __restrict__ logPmf,
-                                                HmmParams P, uint8_t* __restrict__ psi /* [5][N] */, int64_t N, int32_t* __restrict__ lastState) {
+                                                HmmParams P, uint8_t* __restrict__ psi /* [5][N] */, int64_t N, int32_t* __restrict__ lastState,
+                                                const int32_t* __restrict__ chromList) {
     extern __shared__ double sTab[];                 // [5][tableLen] when it fits, else unused
     __shared__ double sE[2][64 * NSTATE];            // emissions of the current / next 64-step block
     __shared__ uint8_t sPsi[NSTATE][64];             // back-pointers of the current block, flushed coalesced
-    const HmmChrom C = chroms[blockIdx.x];
+    const int cidx = chromList ? chromList[blockIdx.x] : (int)blockIdx.x;
+    const HmmChrom C = chroms[cidx];
     const int l = threadIdx.x;
     const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
     if (useLds) { for (int i = l; i < P.tableLen * NSTATE; i += 64) sTab[i] = logPmf[i]; }
     __syncthreads();
-    if (C.T <= 10) { if (l == 0) lastState[blockIdx.x] = -1; return; }     // chromosome skipped (HiddenMarkovModelsRunner.cs:69)
+    if (C.T <= 10) { if (l == 0) lastState[cidx] = -1; return; }     // chromosome skipped (HiddenMarkovModelsRunner.cs:69)
     const double* tab = useLds ? sTab : logPmf;
     const int j = l < NSTATE ? l : 0;
     double la[NSTATE];
@@ -134,8 +136,238 @@ __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chr
         int best = -1; double m1 = NEG;
 #pragma unroll
         for (int i = 0; i < NSTATE; i++) if (d[i] > m1) { best = i; m1 = d[i]; }
-        lastState[blockIdx.x] = best;
+        lastState[cidx] = best;
     }
+}
+
+
+// =====================================================================================================================
+// Speculative block-parallel Viterbi with exact verification.
+//
+// The recurrence must be evaluated in the reference's order to be bit-identical, which makes k_viterbi a 390 k-step chain for chr1.
+// But the *decisions* (back-pointers) depend only on differences of delta, and those forget their history within a few dozen
+// bins.  So:
+//   A  k_vit_spec      every 256-step block re-runs the SAME recurrence code from a cold start 128 steps earlier and records the
+//                      back-pointers it sees (a guess: its delta differs from the true one by a block constant + rounding noise);
+//   A2 k_bt_*          back-track the guessed pointers -> guessed state path s_t (the "backbone");
+//   B1 k_vit_backbone  the exact delta along the backbone is a plain sequential sum D_t = D_{t-1} + (e_{s_t}(t) + logA[s_{t-1}][s_t])
+//                      with the reference's association: one dependent FP64 add per step (about 4 ns) instead of about 150 ns;
+//   C  k_vit_verify    every block rebuilds the exact delta of all five states from D (off-backbone states are re-anchored to the
+//                      backbone inside a 64-step lead-in), then re-does the exact strict-'>' arg-max at each step and checks it
+//                      against the guess, and checks delta_t(s_t) == D_t bit for bit.
+// If every check passes, induction from the exact t = 0 shows the guessed pointers ARE the reference's (and so is the path); any
+// failed check (a near-tie resolved differently by the cold-start run, a lead-in that did not re-anchor) flags the chromosome,
+// which is then recomputed by the sequential k_viterbi.  Results are therefore always exact; speculation only buys time.
+#define VB 256       // block length
+#define VW 128       // cold-start lead-in of the speculative pass
+#define VW2 64       // lead-in of the verification pass
+struct VitBlock { int32_t chrom; int32_t t0; };   // chromosome-relative start
+
+__device__ __forceinline__ void vit_step(double e, const double* la, double delta, double NEG, double& outDelta, int& outArg) {
+    double t_0 = readlane_f64(delta, 0) + (e + la[0]);
+    double t_1 = readlane_f64(delta, 1) + (e + la[1]);
+    double t_2 = readlane_f64(delta, 2) + (e + la[2]);
+    double t_3 = readlane_f64(delta, 3) + (e + la[3]);
+    double t_4 = readlane_f64(delta, 4) + (e + la[4]);
+    double a = t_0; int ia = 0; if (t_1 > a) { a = t_1; ia = 1; }
+    double b = t_2; int ib = 2; if (t_3 > b) { b = t_3; ib = 3; }
+    if (b > a) { a = b; ia = ib; }
+    if (t_4 > a) { a = t_4; ia = 4; }
+    if (!(a > NEG)) { a = NEG; ia = 0; }
+    outDelta = a; outArg = ia;
+}
+
+// A: one wave per block; lanes 0..4 own the states, all 64 lanes stage emissions
+__global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ blocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
+                                                 const double* __restrict__ logPmf, HmmParams P, uint8_t* __restrict__ psi, int64_t N, int32_t* __restrict__ lastGuess) {
+    extern __shared__ double sTab[];
+    __shared__ double sE[64 * NSTATE];
+    __shared__ uint8_t sPsi[NSTATE][64];
+    const VitBlock B = blocks[blockIdx.x];
+    const HmmChrom C = chroms[B.chrom];
+    const int l = threadIdx.x;
+    const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
+    if (useLds) { for (int i = l; i < P.tableLen * NSTATE; i += 64) sTab[i] = logPmf[i]; }
+    __syncthreads();
+    const double* tab = useLds ? sTab : logPmf;
+    const int j = l < NSTATE ? l : 0;
+    double la[NSTATE];
+#pragma unroll
+    for (int i = 0; i < NSTATE; i++) la[i] = P.logA[i][j];
+    const double NEG = -1.7976931348623157e308;
+    const int32_t* ix = idx + C.begin;
+    const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;       // block covers [tBeg, tEnd)
+    int64_t ts = tBeg - VW; if (ts < 0) ts = 0;                                    // cold start
+    ts &= ~(int64_t)63;                                                            // 64-aligned chunks
+    double delta = 0.0;                                                            // cold start: all states equal (exact init when ts == 0)
+    for (int64_t c0 = ts; c0 < tEnd; c0 += 64) {
+        { int64_t t = c0 + l; if (t < C.T) { int k = ix[t];
+#pragma unroll
+            for (int s = 0; s < NSTATE; s++) sE[l * NSTATE + s] = tab[s * P.tableLen + k]; } }
+        __syncthreads();
+        const int steps = (int)((tEnd - c0) < 64 ? (tEnd - c0) : 64);
+        for (int s = 0; s < steps; s++) {
+            const int64_t t = c0 + s;
+            const double e = sE[s * NSTATE + j];
+            int arg = 0;
+            if (t == 0) { double lik = e + P.logA[0][j]; delta = P.logPi[j] + lik - P.logA[0][j]; }
+            else if (t == ts) { delta = e; }                                       // first step of a cold start: no history
+            else { double nd; vit_step(e, la, delta, NEG, nd, arg); delta = nd; }
+            if (l < NSTATE) sPsi[j][s] = (uint8_t)arg;
+        }
+        __syncthreads();
+        if (l < steps && c0 + l >= tBeg) {
+#pragma unroll
+            for (int st = 0; st < NSTATE; st++) psi[(size_t)st * N + C.begin + c0 + l] = sPsi[st][l];
+        }
+        __syncthreads();
+    }
+    if (tEnd == C.T) {       // last block: guess of the best final state (HMM.cs:100-111 on the shifted delta)
+        double d[NSTATE];
+#pragma unroll
+        for (int i = 0; i < NSTATE; i++) d[i] = readlane_f64(delta, i);
+        if (l == 0) { int best = -1; double m1 = NEG;
+#pragma unroll
+            for (int i = 0; i < NSTATE; i++) if (d[i] > m1) { best = i; m1 = d[i]; }
+            lastGuess[B.chrom] = best; }
+    }
+}
+
+// B1a: per-step increments of the exact delta along the guessed path (parallel): v_0 from HMM.cs:78,
+//      v_t = logpmf_{s_t}(x_t) + logA[s_{t-1}][s_t]  (= Math.Log(emission) + Math.Log(transition), Distributions.cs:322)
+__global__ void __launch_bounds__(256) k_vit_increments(const HmmChrom* __restrict__ chroms, int nchr, const int64_t* __restrict__ chrOff, const int32_t* __restrict__ idx,
+                                                        const double* __restrict__ logPmf, HmmParams P, const int32_t* __restrict__ state, int64_t N, double* __restrict__ D) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chrOff[mid] <= g) lo = mid; else hi = mid - 1; }
+    int s1 = state[g];
+    if (s1 < 0) { D[g] = 0.0; return; }
+    double e = logPmf[(size_t)s1 * P.tableLen + idx[g]];
+    if (g == chroms[lo].begin) { double lik = e + P.logA[0][s1]; D[g] = P.logPi[s1] + lik - P.logA[0][s1]; }
+    else { int s0 = state[g - 1]; D[g] = e + P.logA[s0 < 0 ? 0 : s0][s1]; }
+}
+
+__device__ __forceinline__ double dpp_wave_shr1_f64(double oldv, double src) {
+    // lane k receives lane k-1's value; lane 0 (no source) receives oldv.  DPP_WF_SR1 = 0x138 (gfx9 family).
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), __double2loint(src), 0x138, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), __double2hiint(src), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// B1b: D_t = D_{t-1} + v_t in the reference's (sequential) association, in place.  One wave per chromosome; inside a 64-step
+// chunk the running sum ripples from lane k-1 to lane k through DPP wave shifts (2 DPP moves + 1 FP64 add per step on the
+// dependent chain); the chunk's increments are prefetched one chunk ahead.
+__global__ void __launch_bounds__(64) k_vit_backbone(const HmmChrom* __restrict__ chroms, double* __restrict__ D) {
+    const HmmChrom C = chroms[blockIdx.x];
+    if (C.T <= 10) return;
+    const int l = threadIdx.x;
+    double* Dc = D + C.begin;
+    double carry = 0.0;
+    double vNext = l < C.T ? Dc[l] : 0.0;
+    for (int64_t c0 = 0; c0 < C.T; c0 += 64) {
+        const double v = vNext;
+        { int64_t t2 = c0 + 64 + l; vNext = t2 < C.T ? Dc[t2] : 0.0; }
+        // lane 0 of the very first chunk starts the sum (D_0 = v_0): adding to +0.0 is exact and keeps the bits of v_0
+        double x = carry + v;
+#pragma unroll 1
+        for (int k = 1; k < 64; k++) {
+            double sh = dpp_wave_shr1_f64(carry, x);
+            x = sh + v;
+        }
+        if (c0 + l < C.T) Dc[c0 + l] = x;
+        const int last = (int)((C.T - c0) < 64 ? (C.T - c0 - 1) : 63);
+        carry = readlane_f64(x, 63);
+        if (last != 63) carry = 0.0;   // final partial chunk: no further use
+    }
+}
+
+// C: exact verification, one wave per block
+__global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ blocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
+                                                   const double* __restrict__ logPmf, HmmParams P, const uint8_t* __restrict__ psi, int64_t N,
+                                                   const int32_t* __restrict__ state, const double* __restrict__ D, const int32_t* __restrict__ lastGuess,
+                                                   int32_t* __restrict__ fail) {
+    extern __shared__ double sTab[];
+    __shared__ double sE[64 * NSTATE];
+    __shared__ uint8_t sPsi[NSTATE][64];
+    __shared__ int32_t sState[65];
+    __shared__ double sD[64];
+    const VitBlock B = blocks[blockIdx.x];
+    const HmmChrom C = chroms[B.chrom];
+    const int l = threadIdx.x;
+    const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
+    if (useLds) { for (int i = l; i < P.tableLen * NSTATE; i += 64) sTab[i] = logPmf[i]; }
+    __syncthreads();
+    const double* tab = useLds ? sTab : logPmf;
+    const int j = l < NSTATE ? l : 0;
+    double la[NSTATE];
+#pragma unroll
+    for (int i = 0; i < NSTATE; i++) la[i] = P.logA[i][j];
+    const double NEG = -1.7976931348623157e308;
+    const int32_t* ix = idx + C.begin;
+    const int32_t* st = state + C.begin;
+    const double* Dc = D + C.begin;
+    const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;
+    int64_t ts = tBeg - VW2; if (ts < 0) ts = 0;
+    ts &= ~(int64_t)63;
+    double delta = 0.0;
+    bool valid = false;       // is this lane's delta the exact delta_t(j)?
+    bool bad = false;
+    for (int64_t c0 = ts; c0 < tEnd; c0 += 64) {
+        { int64_t t = c0 + l;
+          if (t < C.T) { int k = ix[t];
+#pragma unroll
+            for (int s = 0; s < NSTATE; s++) { sE[l * NSTATE + s] = tab[s * P.tableLen + k]; sPsi[s][l] = psi[(size_t)s * N + C.begin + t]; }
+            sState[l + 1] = st[t]; sD[l] = Dc[t]; }
+          if (l == 0) sState[0] = c0 > 0 ? st[c0 - 1] : -1; }
+        __syncthreads();
+        const int steps = (int)((tEnd - c0) < 64 ? (tEnd - c0) : 64);
+        for (int s = 0; s < steps; s++) {
+            const int64_t t = c0 + s;
+            const double e = sE[s * NSTATE + j];
+            const int sCur = sState[s + 1], sPrev = sState[s];
+            const double Dt = sD[s];
+            if (t == 0) {
+                double lik = e + P.logA[0][j]; delta = P.logPi[j] + lik - P.logA[0][j]; valid = true;
+                if (j == sCur && delta != Dt) bad = true;
+            } else if (t < tBeg || t == ts) {
+                // lead-in: follow the guessed pointers; a state is exact once its ancestry reaches the backbone
+                const int p = sPsi[j][s];
+                double dp = 0.0; bool vp = false;
+#pragma unroll
+                for (int i = 0; i < NSTATE; i++) { double di = readlane_f64(delta, i); bool vi = __builtin_amdgcn_readlane((int)valid, i) != 0; if (p == i) { dp = di; vp = vi; } }
+                if (t == ts) vp = false;                         // nothing is known before the lead-in
+                if (j == sCur) { delta = Dt; valid = true; }
+                else if (p == sPrev) { delta = sD[s > 0 ? s - 1 : 0]; if (s == 0) delta = Dc[t - 1]; delta = delta + (e + P.logA[p][j]); valid = true; }
+                else if (vp) { delta = dp + (e + la[p]); valid = true; }
+                else valid = false;
+            } else {
+                // inside the block: every state must be exact by now; redo the reference's arg-max and compare with the guess
+                int allValid = 1;
+#pragma unroll
+                for (int i = 0; i < NSTATE; i++) allValid &= __builtin_amdgcn_readlane((int)valid, i);
+                if (!allValid) bad = true;
+                double nd; int arg;
+                vit_step(e, la, delta, NEG, nd, arg);
+                if (l < NSTATE) { if (arg != (int)sPsi[j][s]) bad = true; if (j == sCur && nd != Dt) bad = true; }
+                delta = nd;
+            }
+        }
+        __syncthreads();
+    }
+    if (tEnd == C.T) {
+        double d[NSTATE];
+#pragma unroll
+        for (int i = 0; i < NSTATE; i++) d[i] = readlane_f64(delta, i);
+        int allValid = 1;
+#pragma unroll
+        for (int i = 0; i < NSTATE; i++) allValid &= __builtin_amdgcn_readlane((int)valid, i);
+        int best = -1; double m1 = NEG;
+#pragma unroll
+        for (int i = 0; i < NSTATE; i++) if (d[i] > m1) { best = i; m1 = d[i]; }
+        if (!allValid || best != lastGuess[B.chrom]) bad = true;
+    }
+    if (l < NSTATE && bad) atomicOr(&fail[B.chrom], 1);
 }
 
 // ---- backtracking as function composition over blocks of BT_BLOCK steps
@@ -306,15 +538,20 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     }
     firstBlock[nchr] = (int32_t)blocks.size();
     const int nblocks = (int)blocks.size();
+    std::vector<VitBlock> vblocks;
+    for (int c = 0; c < nchr; c++) if (chroms[c].T > 10) for (int64_t t0 = 0; t0 < chroms[c].T; t0 += VB) vblocks.push_back({c, (int32_t)t0});
     WsSizer sz;
     sz.take<uint32_t>(N); sz.take<int32_t>(N); sz.take<uint8_t>((size_t)NSTATE * N); sz.take<HmmChrom>(nchr); sz.take<int32_t>(nchr);
     sz.take<BtBlock>(nblocks + 1); sz.take<int32_t>(nchr + 1); sz.take<uint8_t>((size_t)nblocks * NSTATE + 8); sz.take<int8_t>(nblocks + 8); sz.take<double>(NSTATE * 70000);
+    sz.take<int64_t>(nchr + 1); sz.take<VitBlock>(vblocks.size() + 1); sz.take<double>(N); sz.take<int32_t>(nchr); sz.take<int32_t>(nchr);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
     WsCarver ws(ctx->ws);
     uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N); uint8_t* psi = ws.take<uint8_t>((size_t)NSTATE * N);
     HmmChrom* dChroms = ws.take<HmmChrom>(nchr); int32_t* dLast = ws.take<int32_t>(nchr);
     BtBlock* dBlocks = ws.take<BtBlock>(nblocks + 1); int32_t* dFirst = ws.take<int32_t>(nchr + 1);
     uint8_t* dMaps = ws.take<uint8_t>((size_t)nblocks * NSTATE + 8); int8_t* dEntry = ws.take<int8_t>(nblocks + 8); double* dTab = ws.take<double>(NSTATE * 70000);
+    int64_t* dOffDev = ws.take<int64_t>(nchr + 1);
+    VitBlock* dVBlocks = ws.take<VitBlock>(vblocks.size() + 1); double* dD = ws.take<double>(N); int32_t* dFail = ws.take<int32_t>(nchr); int32_t* dRedo = ws.take<int32_t>(nchr);
 
     // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
     hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
@@ -347,20 +584,48 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dChroms, chroms.data(), nchr * sizeof(HmmChrom), hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dBlocks, blocks.data(), nblocks * sizeof(BtBlock), hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirst, firstBlock.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOffDev, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!vblocks.empty()) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVBlocks, vblocks.data(), vblocks.size() * sizeof(VitBlock), hipMemcpyHostToDevice, ctx->stream));
     // 3. index, Viterbi, backtrack
     hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);
     size_t tabBytes = (size_t)NSTATE * P.tableLen * 8;
     size_t lds = tabBytes <= 48 * 1024 ? tabBytes : 0;
-    { ProfScope ps(ctx, "viterbi");
-      hipLaunchKernelGGL(k_viterbi, dim3(nchr), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, N, dLast); }
     for (int c = 0; c < nchr; c++)
         if (chroms[c].T <= 10 && chroms[c].T > 0)
             hipLaunchKernelGGL(k_fill_i32, dim3(nblk2(chroms[c].T, 256)), dim3(256), 0, ctx->stream, d_state, chroms[c].begin, chroms[c].begin + chroms[c].T, -1);
-    if (nblocks > 0) {
-        hipLaunchKernelGGL(k_bt_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dBlocks, nblocks, dChroms, psi, N, dMaps);
-        hipLaunchKernelGGL(k_bt_chain, dim3(nblk2(nchr, 64)), dim3(64), 0, ctx->stream, dFirst, nchr, dLast, dMaps, dEntry);
-        hipLaunchKernelGGL(k_bt_states, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dBlocks, nblocks, dChroms, psi, N, dEntry, d_state);
+    auto backtrack = [&]() {
+        if (nblocks > 0) {
+            hipLaunchKernelGGL(k_bt_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dBlocks, nblocks, dChroms, psi, N, dMaps);
+            hipLaunchKernelGGL(k_bt_chain, dim3(nblk2(nchr, 64)), dim3(64), 0, ctx->stream, dFirst, nchr, dLast, dMaps, dEntry);
+            hipLaunchKernelGGL(k_bt_states, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dBlocks, nblocks, dChroms, psi, N, dEntry, d_state);
+        }
+    };
+    const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
+    std::vector<int32_t> redo;
+    if (speculative && !vblocks.empty()) {
+        ProfScope ps(ctx, "viterbi");
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dLast, 0xFF, nchr * 4, ctx->stream));     // -1 for skipped chromosomes
+        hipLaunchKernelGGL(k_vit_spec, dim3((unsigned)vblocks.size()), dim3(64), lds, ctx->stream, dVBlocks, dChroms, idx, dTab, P, psi, N, dLast);
+        backtrack();
+        hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
+        hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD);
+        hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)vblocks.size()), dim3(64), lds, ctx->stream, dVBlocks, dChroms, idx, dTab, P, psi, N, d_state, dD, dLast, dFail);
+        std::vector<int32_t> hFail(nchr, 0);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int c = 0; c < nchr; c++) if (hFail[c] && chroms[c].T > 10) redo.push_back(c);
+    } else {
+        for (int c = 0; c < nchr; c++) redo.push_back(c);
     }
+    if (!redo.empty()) {
+        // exact sequential evaluation (all chromosomes when speculation is disabled, otherwise only those whose verification failed)
+        ProfScope ps(ctx, "viterbi_sequential");
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRedo, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)redo.size()), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, N, dLast, dRedo);
+        backtrack();
+    }
+    ctx->hmm_redo = (int)redo.size();
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host vectors feed async copies
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
