@@ -248,44 +248,35 @@ __global__ void __launch_bounds__(256) k_vit_increments(const HmmChrom* __restri
     else { int s0 = state[g - 1]; D[g] = e + P.logA[s0 < 0 ? 0 : s0][s1]; }
 }
 
-__device__ __forceinline__ double dpp_wave_shr1_f64(double oldv, double src) {
-    // lane k receives lane k-1's value; lane 0 (no source) receives oldv.  DPP_WF_SR1 = 0x138 (gfx9 family).
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), __double2loint(src), 0x138, 0xF, 0xF, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), __double2hiint(src), 0x138, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-// B1b: D_t = D_{t-1} + v_t in the reference's (sequential) association, in place.  One wave per chromosome; inside a 64-step
-// chunk the running sum ripples from lane k-1 to lane k through DPP wave shifts (2 DPP moves + 1 FP64 add per step on the
-// dependent chain); the chunk's increments are prefetched one chunk ahead.
-__global__ void __launch_bounds__(64) k_vit_backbone(const HmmChrom* __restrict__ chroms, double* __restrict__ D) {
+// B1b: D_t = D_{t-1} + v_t in the reference's (sequential) association.  One wave per chromosome; the increments of a 64-step
+// chunk sit one per lane and are broadcast through SGPRs (v_readlane), so the dependent chain is ONE FP64 add per step.  Only the
+// running sum at every chunk start is stored (carry[first bin of chunk] = D_{t-1}); k_vit_verify rebuilds D_t inside its blocks.
+__global__ void __launch_bounds__(64) k_vit_backbone(const HmmChrom* __restrict__ chroms, const double* __restrict__ V, double* __restrict__ carryOut) {
+    __shared__ double sV[2][64];
     const HmmChrom C = chroms[blockIdx.x];
     if (C.T <= 10) return;
     const int l = threadIdx.x;
-    double* Dc = D + C.begin;
-    double carry = 0.0;
-    double vNext = l < C.T ? Dc[l] : 0.0;
-    for (int64_t c0 = 0; c0 < C.T; c0 += 64) {
-        const double v = vNext;
-        { int64_t t2 = c0 + 64 + l; vNext = t2 < C.T ? Dc[t2] : 0.0; }
-        // lane 0 of the very first chunk starts the sum (D_0 = v_0): adding to +0.0 is exact and keeps the bits of v_0
-        double x = carry + v;
-#pragma unroll 1
-        for (int k = 1; k < 64; k++) {
-            double sh = dpp_wave_shr1_f64(carry, x);
-            x = sh + v;
-        }
-        if (c0 + l < C.T) Dc[c0 + l] = x;
-        const int last = (int)((C.T - c0) < 64 ? (C.T - c0 - 1) : 63);
-        carry = readlane_f64(x, 63);
-        if (last != 63) carry = 0.0;   // final partial chunk: no further use
+    const double* __restrict__ Vc = V + C.begin;
+    double acc = 0.0;
+    // lanes past the end of the chromosome hold +0.0: adding it leaves acc unchanged
+    double vNext = l < C.T ? Vc[l] : 0.0;
+    int buf = 0;
+    for (int64_t c0 = 0; c0 < C.T; c0 += 64, buf ^= 1) {
+        sV[buf][l] = vNext;                                            // LDS ops of one wave execute in order: no barrier needed
+        { int64_t t2 = c0 + 64 + l; vNext = t2 < C.T ? Vc[t2] : 0.0; }  // global prefetch one chunk ahead
+        if (l == 0) carryOut[C.begin + c0] = acc;
+        double r[64];
+#pragma unroll
+        for (int s = 0; s < 64; s++) r[s] = sV[buf][s];                // uniform address: LDS broadcast reads, all issued up front
+#pragma unroll
+        for (int s = 0; s < 64; s++) acc = acc + r[s];                 // the dependent chain: one FP64 add per step
     }
 }
 
 // C: exact verification, one wave per block
 __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ blocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                    const double* __restrict__ logPmf, HmmParams P, const uint8_t* __restrict__ psi, int64_t N,
-                                                   const int32_t* __restrict__ state, const double* __restrict__ D, const int32_t* __restrict__ lastGuess,
+                                                   const int32_t* __restrict__ state, const double* __restrict__ V, const double* __restrict__ carry, const int32_t* __restrict__ lastGuess,
                                                    int32_t* __restrict__ fail) {
     extern __shared__ double sTab[];
     __shared__ double sE[64 * NSTATE];
@@ -306,19 +297,20 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
     const double NEG = -1.7976931348623157e308;
     const int32_t* ix = idx + C.begin;
     const int32_t* st = state + C.begin;
-    const double* Dc = D + C.begin;
+    const double* Vc = V + C.begin;
     const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;
     int64_t ts = tBeg - VW2; if (ts < 0) ts = 0;
     ts &= ~(int64_t)63;
     double delta = 0.0;
     bool valid = false;       // is this lane's delta the exact delta_t(j)?
     bool bad = false;
+    double Dprev = carry[C.begin + ts];      // D_{ts-1} (0 at the start of the chromosome)
     for (int64_t c0 = ts; c0 < tEnd; c0 += 64) {
         { int64_t t = c0 + l;
           if (t < C.T) { int k = ix[t];
 #pragma unroll
             for (int s = 0; s < NSTATE; s++) { sE[l * NSTATE + s] = tab[s * P.tableLen + k]; sPsi[s][l] = psi[(size_t)s * N + C.begin + t]; }
-            sState[l + 1] = st[t]; sD[l] = Dc[t]; }
+            sState[l + 1] = st[t]; sD[l] = Vc[t]; }
           if (l == 0) sState[0] = c0 > 0 ? st[c0 - 1] : -1; }
         __syncthreads();
         const int steps = (int)((tEnd - c0) < 64 ? (tEnd - c0) : 64);
@@ -326,7 +318,7 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
             const int64_t t = c0 + s;
             const double e = sE[s * NSTATE + j];
             const int sCur = sState[s + 1], sPrev = sState[s];
-            const double Dt = sD[s];
+            const double Dt = Dprev + sD[s];          // D_t = D_{t-1} + v_t (same association as k_vit_backbone)
             if (t == 0) {
                 double lik = e + P.logA[0][j]; delta = P.logPi[j] + lik - P.logA[0][j]; valid = true;
                 if (j == sCur && delta != Dt) bad = true;
@@ -338,7 +330,7 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
                 for (int i = 0; i < NSTATE; i++) { double di = readlane_f64(delta, i); bool vi = __builtin_amdgcn_readlane((int)valid, i) != 0; if (p == i) { dp = di; vp = vi; } }
                 if (t == ts) vp = false;                         // nothing is known before the lead-in
                 if (j == sCur) { delta = Dt; valid = true; }
-                else if (p == sPrev) { delta = sD[s > 0 ? s - 1 : 0]; if (s == 0) delta = Dc[t - 1]; delta = delta + (e + P.logA[p][j]); valid = true; }
+                else if (p == sPrev) { delta = Dprev + (e + la[p]); valid = true; }
                 else if (vp) { delta = dp + (e + la[p]); valid = true; }
                 else valid = false;
             } else {
@@ -352,6 +344,7 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
                 if (l < NSTATE) { if (arg != (int)sPsi[j][s]) bad = true; if (j == sCur && nd != Dt) bad = true; }
                 delta = nd;
             }
+            Dprev = Dt;
         }
         __syncthreads();
     }
@@ -369,6 +362,9 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
     }
     if (l < NSTATE && bad) atomicOr(&fail[B.chrom], 1);
 }
+
+// test hook (CANVAS_HMM_TEST_CORRUPT): flips one guessed back-pointer so that tests can prove k_vit_verify catches a wrong guess
+__global__ void k_vit_corrupt(uint8_t* __restrict__ psi, int64_t N, int64_t at) { if (threadIdx.x == 0 && blockIdx.x == 0) { psi[(size_t)2 * N + at] = (psi[(size_t)2 * N + at] + 1) % 5; } }
 
 // ---- backtracking as function composition over blocks of BT_BLOCK steps
 // block b of a chromosome covers t in (lo, hi] with hi = min(T-1, (b+1)*BT_BLOCK), lo = b*BT_BLOCK; state[t-1] = psi[state[t]][t]
@@ -543,7 +539,7 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     WsSizer sz;
     sz.take<uint32_t>(N); sz.take<int32_t>(N); sz.take<uint8_t>((size_t)NSTATE * N); sz.take<HmmChrom>(nchr); sz.take<int32_t>(nchr);
     sz.take<BtBlock>(nblocks + 1); sz.take<int32_t>(nchr + 1); sz.take<uint8_t>((size_t)nblocks * NSTATE + 8); sz.take<int8_t>(nblocks + 8); sz.take<double>(NSTATE * 70000);
-    sz.take<int64_t>(nchr + 1); sz.take<VitBlock>(vblocks.size() + 1); sz.take<double>(N); sz.take<int32_t>(nchr); sz.take<int32_t>(nchr);
+    sz.take<int64_t>(nchr + 1); sz.take<VitBlock>(vblocks.size() + 1); sz.take<double>(N); sz.take<double>(N + 64); sz.take<int32_t>(nchr); sz.take<int32_t>(nchr);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
     WsCarver ws(ctx->ws);
     uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N); uint8_t* psi = ws.take<uint8_t>((size_t)NSTATE * N);
@@ -551,7 +547,7 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     BtBlock* dBlocks = ws.take<BtBlock>(nblocks + 1); int32_t* dFirst = ws.take<int32_t>(nchr + 1);
     uint8_t* dMaps = ws.take<uint8_t>((size_t)nblocks * NSTATE + 8); int8_t* dEntry = ws.take<int8_t>(nblocks + 8); double* dTab = ws.take<double>(NSTATE * 70000);
     int64_t* dOffDev = ws.take<int64_t>(nchr + 1);
-    VitBlock* dVBlocks = ws.take<VitBlock>(vblocks.size() + 1); double* dD = ws.take<double>(N); int32_t* dFail = ws.take<int32_t>(nchr); int32_t* dRedo = ws.take<int32_t>(nchr);
+    VitBlock* dVBlocks = ws.take<VitBlock>(vblocks.size() + 1); double* dD = ws.take<double>(N); double* dCarry = ws.take<double>(N + 64); int32_t* dFail = ws.take<int32_t>(nchr); int32_t* dRedo = ws.take<int32_t>(nchr);
 
     // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
     hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
@@ -607,10 +603,11 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dLast, 0xFF, nchr * 4, ctx->stream));     // -1 for skipped chromosomes
         hipLaunchKernelGGL(k_vit_spec, dim3((unsigned)vblocks.size()), dim3(64), lds, ctx->stream, dVBlocks, dChroms, idx, dTab, P, psi, N, dLast);
+        if (getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, N, chroms[0].begin + chroms[0].T / 2);
         backtrack();
         hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
-        hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD);
-        hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)vblocks.size()), dim3(64), lds, ctx->stream, dVBlocks, dChroms, idx, dTab, P, psi, N, d_state, dD, dLast, dFail);
+        hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
+        hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)vblocks.size()), dim3(64), lds, ctx->stream, dVBlocks, dChroms, idx, dTab, P, psi, N, d_state, dD, dCarry, dLast, dFail);
         std::vector<int32_t> hFail(nchr, 0);
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

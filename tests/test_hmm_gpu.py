@@ -69,3 +69,22 @@ def test_viterbi_saturated_and_zero_coverage():
     cov[1000:1300] = 5000.0     # far above 5 x haploid mean: capped (HiddenMarkovModelsRunner.cs:154-162)
     cov[2000] = 124.5; cov[2001] = 125.5   # half-way cases of Convert.ToInt32
     _check(cv, bins, cov, off)
+
+
+def test_speculation_is_verified_and_falls_back(monkeypatch):
+    """A corrupted back-pointer guess must be caught by k_vit_verify; the chromosome is then recomputed sequentially and the
+    result is still identical to the oracle.  Also: the purely sequential path (CANVAS_HMM_SEQUENTIAL) gives the same states."""
+    cv = get_canvas()
+    cv.profile_enable(True)
+    bins, cov, off = _coverage(20260927 + 13, 60_000, 6)
+    cv.profile_get("viterbi_sequential", reset=True)
+    base = _check(cv, bins, cov, off)
+    assert cv.profile_get("viterbi_sequential")[1] == 0          # speculation verified everywhere
+    monkeypatch.setenv("CANVAS_HMM_TEST_CORRUPT", "1")
+    got = _check(cv, bins, cov, off)
+    assert cv.profile_get("viterbi_sequential")[1] == 1          # the corrupted chromosome was recomputed
+    assert (got == base).all()
+    monkeypatch.delenv("CANVAS_HMM_TEST_CORRUPT")
+    monkeypatch.setenv("CANVAS_HMM_SEQUENTIAL", "1")
+    got2 = _check(cv, bins, cov, off)
+    assert (got2 == base).all()
