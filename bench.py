@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of each GRCh38 chromosome length (1.0 = BASELINE config)")
     ap.add_argument("--rate", type=float, default=0.21, help="hits per possible position (0.21 = 60x, 0.105 = 30x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-times", action="store_true", help="print per-stage host wall times (ms) of the last step to stderr")
     args = ap.parse_args()
 
     import torch
@@ -86,20 +87,31 @@ def main():
     gather_recv = torch.zeros(5 * world, dtype=torch.int32, device=device)
     keep = {}
 
+    stage = {}
+
+    def tick(name, t_prev):
+        if args.stage_times:
+            cv.synchronize(); torch.cuda.synchronize()
+            now = time.perf_counter(); stage[name] = round((now - t_prev) * 1e3, 3); return now
+        return t_prev
+
     def step(record=False):
         import ctypes as C
-        obs, poss, rate = cv.bin_rates(hits, masks, lens)
-        bs = cv.bin_size_from_rates(rate[is_auto.astype(bool)], 100)           # CanvasBin -d 100
-        o, per, total = cv.bin_genome(bases, masks, hits, lens, bs, 3, out=out)
+        tp = time.perf_counter()
+        o, per, total, bs = cv.bin_sample(bases, masks, hits, lens, is_auto, 100, -1, 3, out=out)    # CanvasBin -d 100 -m TruncatedDynamicRange
+        tp = tick("bin_sample(rates+binning)", tp)
         if record:
             keep["binned"] = {k: v[:total].clone() for k, v in out.items()}
+            tp = time.perf_counter()
         n_out, lsd, info = cv.clean(out, total, is_auto, flags)
+        tp = tick("clean", tp)
         cov = cv.quantize_f2(out["count"], n_out)
-        off = torch.zeros(nchr + 1, dtype=torch.int64, device=device)
-        off[1:] = torch.cumsum(torch.bincount(out["chr"][:n_out], minlength=nchr), 0)
-        off_h = off.cpu().numpy()
+        off_h = cv.chromosome_offsets(out["chr"], n_out, nchr)
+        tp = tick("f2+offsets", tp)
         state = cv.hmm_per_sample(cov, off_h)
+        tp = tick("hmm", tp)
         seg, nseg = cv.segment_ids(off_h, state, out["start"], out["stop"])
+        tp = tick("segment_ids", tp)
         if world > 1:
             gather_send[0] = int(nseg); gather_send[1] = int(n_out); gather_send[2] = int(total); gather_send[3] = rank
             cnt = np.zeros(world, np.int32)
@@ -124,9 +136,10 @@ def main():
     t0 = time.perf_counter()
     bins_step = 0
     for i in range(args.steps):
-        bins_step = step(record=(i == args.steps - 1))
+        bins_step = step()
     barrier()
     dt = time.perf_counter() - t0
+    step(record=True)        # untimed extra pass that keeps the intermediate arrays for the parity check / config fields
     from canvas_amd import parallel
     dt, total_bins_all, _ = parallel.aggregate_throughput(dt, float(bins_step), device=device)   # MAX over ranks, SUM of bins
     ms_per_step = dt / args.steps * 1e3
@@ -166,6 +179,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(keep, bases, hits, masks, lens, is_auto, flags, total_bases)
     if rank == 0:
+        if args.stage_times:
+            print("stage times (ms, host wall incl. sync): " + json.dumps(stage), file=sys.stderr)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -437,38 +437,53 @@ int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_
     return CANVAS_OK;
 }
 
-int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
-                          const uint8_t* const* d_hits, const int64_t* h_len, int32_t bin_size, int32_t mode,
-                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                          int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
+static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                               const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_is_auto, int32_t counts_per_bin, int32_t bin_size, int32_t mode,
+                               int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                               int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
     if (!ctx) return CANVAS_ERR_INVALID;
-    if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bad arguments");
+    const bool needRates = bin_size <= 0;
+    if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || (needRates && (!h_is_auto || counts_per_bin <= 0))) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bad arguments");
     if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "GCContentWeighted binning (CanvasBin.cs:451-506,626-636) is not built yet");
     if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "unknown coverage mode");
     for (int c = 0; c < nchr; c++) if (h_len[c] <= 0 || h_len[c] > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "chromosome length must be in [1, 2^31)");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BinPlan plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len);
-    int64_t ub = canvas_bin_count_upper_bound(nchr, h_len, bin_size);
+    // the bin arrays are sized by the caller's capacity (the bin size may not be known yet)
+    const int64_t ub = cap;
     WsSizer sz;
-    sz.take<BinChrom>(nchr); sz.take<unsigned long long>(nchr); sz.take<uint32_t>(plan.ntiles); sz.take<int32_t>(plan.ntiles);
+    sz.take<BinChrom>(nchr); sz.take<unsigned long long>(nchr); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles); sz.take<int32_t>(plan.ntiles);
     sz.take<ChromOut>(nchr); sz.take<long long>(nchr + 1); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles);
     sz.take<int32_t>(ub + 1); sz.take<uint32_t>(ub + 1); sz.take<uint32_t>(ub + 1);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + sizeof(ChromOut))); if (rc) return rc;
     WsCarver ws(ctx->ws);
     BinChrom* dCh = ws.take<BinChrom>(nchr); unsigned long long* dPos0 = ws.take<unsigned long long>(nchr);
-    uint32_t* tilePop = ws.take<uint32_t>(plan.ntiles); int32_t* rankBase = ws.take<int32_t>(plan.ntiles);
+    uint32_t* tilePop = ws.take<uint32_t>(plan.ntiles); uint32_t* tileObs = ws.take<uint32_t>(plan.ntiles); int32_t* rankBase = ws.take<int32_t>(plan.ntiles);
     ChromOut* dOut = ws.take<ChromOut>(nchr); long long* binOffset = ws.take<long long>(nchr + 1);
     uint32_t* tileTotC = ws.take<uint32_t>(plan.ntiles); uint32_t* tileTotG = ws.take<uint32_t>(plan.ntiles);
     int32_t* stopTmp = ws.take<int32_t>(ub + 1); uint32_t* locC = ws.take<uint32_t>(ub + 1); uint32_t* locG = ws.take<uint32_t>(ub + 1);
     memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
+    ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
     hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);
     hipLaunchKernelGGL(k_find_pos0, dim3(64, nchr), dim3(256), 0, ctx->stream, dCh, dPos0);
-    hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, 0, tilePop, (uint32_t*)nullptr);
+    { ProfScope ps(ctx, "bin_tile_stats");
+      hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, needRates ? 1 : 0, tilePop, tileObs); }
+    if (needRates) {
+        // rates (CanvasBin.cs:30-83): totals per chromosome, then the bin size on the host
+        hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<double> rates;
+        for (int c = 0; c < nchr; c++) if (h_is_auto[c]) rates.push_back((int)hOut[c].obs / (double)(int)hOut[c].pop);
+        if (rates.empty()) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "no autosome to derive the bin size from");
+        bin_size = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin);
+        if (bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "derived bin size is not positive");
+    }
+    if (h_bin_size_out) *h_bin_size_out = bin_size;
     hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, (const uint32_t*)nullptr, 0, bin_size, rankBase, dOut);
     hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(64), 0, ctx->stream, dOut, nchr, binOffset);
-    ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());
@@ -485,6 +500,23 @@ int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d
                        tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count);
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
+}
+
+int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                          const uint8_t* const* d_hits, const int64_t* h_len, int32_t bin_size, int32_t mode,
+                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                          int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
+    if (ctx && bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bin size must be positive");
+    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, h_len, nullptr, 0, bin_size, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total);
+}
+
+int32_t canvas_bin_sample(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                          const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_chr_is_autosome,
+                          int32_t counts_per_bin, int32_t bin_size_in, int32_t mode,
+                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                          int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
+    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, mode, d_chr, d_start, d_stop, d_gc, d_count, cap,
+                           h_bin_size_out, h_nbins_per_chr, h_nbins_total);
 }
 
 }  // extern "C"

@@ -615,3 +615,28 @@ extern "C" int32_t canvas_quantize_f2(canvas_ctx* ctx, const float* d_count, int
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
 }
+
+// ---------------------------------------------------------------- chromosome offsets of a grouped bin list
+__global__ void __launch_bounds__(256) k_chr_first(const int32_t* __restrict__ chr, int64_t n, int nchr, long long* __restrict__ first) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int c = chr[i];
+    if (c >= 0 && c < nchr && (i == 0 || chr[i - 1] != c)) atomicMin(&first[c], (long long)i);
+}
+extern "C" int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_chr, int64_t n, int32_t nchr, int64_t* h_chr_offset) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (n < 0 || nchr <= 0 || !h_chr_offset || (n > 0 && !d_chr)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_chromosome_offsets: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t rc = canvas_ws_reserve(ctx, (size_t)nchr * 8 + 256); if (rc) return rc;
+    rc = canvas_pin_reserve(ctx, (size_t)nchr * 8); if (rc) return rc;
+    long long* dFirst = (long long*)ctx->ws;
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFirst, 0x7F, (size_t)nchr * 8, ctx->stream));     // "not seen"
+    if (n > 0) hipLaunchKernelGGL(k_chr_first, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_chr, n, nchr, dFirst);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, dFirst, (size_t)nchr * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const long long* f = (const long long*)ctx->pin;
+    h_chr_offset[nchr] = n;
+    for (int c = nchr - 1; c >= 0; c--) h_chr_offset[c] = (f[c] >= 0 && f[c] < n) ? (int64_t)f[c] : h_chr_offset[c + 1];
+    for (int c = 0; c < nchr; c++) if (h_chr_offset[c] > h_chr_offset[c + 1]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "bins are not grouped by increasing chromosome index");
+    return CANVAS_OK;
+}

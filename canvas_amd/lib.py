@@ -15,8 +15,8 @@ CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD, CLEAN_LOESS = 1, 2,
 ABI_SYMBOLS = [
     "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
-    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome",
-    "canvas_clean", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_cbs",
+    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample",
+    "canvas_clean", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_cbs",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -143,6 +143,24 @@ class Canvas:
                                                _np_ptr(per), C.byref(total)))
         self.synchronize()   # own non-blocking stream: make the bins visible to torch's stream before handing tensors back
         return out, per, total.value
+
+    def bin_sample(self, bases, masks, hits, lens, is_autosome, counts_per_bin=100, bin_size=-1, mode=MODE_TDR, out=None):
+        """CanvasBin.RunSingleSample (CanvasBin.cs:914-931): rates -> bin size -> bins in one call"""
+        n = len(bases)
+        lens = np.ascontiguousarray(lens, np.int64)
+        ia = np.ascontiguousarray(is_autosome, np.uint8)
+        per = np.zeros(n, np.int64); total = C.c_int64(0); bs = C.c_int32(0)
+        self._check(self.lib.canvas_bin_sample(self.ctx, n, _ptr_table(bases), _ptr_table(masks), _ptr_table(hits), _np_ptr(lens), _np_ptr(ia), counts_per_bin, bin_size, mode,
+                                               C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),
+                                               C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()), C.c_int64(out["chr"].numel()),
+                                               C.byref(bs), _np_ptr(per), C.byref(total)))
+        self.synchronize()
+        return out, per, total.value, bs.value
+
+    def chromosome_offsets(self, chr_ids, n, nchr):
+        off = np.zeros(nchr + 1, np.int64)
+        self._check(self.lib.canvas_chromosome_offsets(self.ctx, C.c_void_p(chr_ids.data_ptr()), C.c_int64(n), nchr, _np_ptr(off)))
+        return off
 
     # ---- CanvasClean
     def clean(self, bins, n, is_autosome, flags, min_bins_per_gc=100):

@@ -70,6 +70,15 @@ int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d
                           int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                           int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
 
+/* CanvasBin.RunSingleSample (CanvasBin.cs:914-931) in one call: when bin_size_in <= 0 the bin size is derived from the
+ * autosomes' rates with counts_per_bin (-d) exactly as canvas_bin_rates + canvas_bin_size_from_rates would, and the mask
+ * popcounts of the rate pass are reused for the binning pass (saves one 0.125 B/base sweep).  *h_bin_size_out = size used. */
+int32_t canvas_bin_sample(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                          const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_chr_is_autosome,
+                          int32_t counts_per_bin, int32_t bin_size_in, int32_t mode,
+                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                          int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+
 /* ---- CanvasClean --------------------------------------------------------------------------------------------- */
 /* CanvasClean.Main (CanvasClean/CanvasClean.cs:415-533) on the whole-genome SoA in file order, in place; bins that
  * survive are compacted to the front, *h_n_out = surviving count.  h_chr_is_autosome[nchr] answers
@@ -79,6 +88,10 @@ int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d
 int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
                      int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
                      double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
+
+/* bins are grouped by chromosome in file order: h_chr_offset[c] = index of the first bin of chromosome c (nchr+1 entries,
+ * h_chr_offset[nchr] = n); chromosomes without bins get an empty range.  Chromosome indices must be non-decreasing. */
+int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_chr, int64_t n, int32_t nchr, int64_t* h_chr_offset);
 
 /* The text hand-off between CanvasClean and CanvasPartition, done in memory: CanvasIO.WriteToTextFile prints the float
  * count with "{3:F2}" (CanvasCommon/IO.cs:21; .NET Core 2.x: 7 significant digits, then half-up at 2 decimals) and

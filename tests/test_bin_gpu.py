@@ -94,3 +94,30 @@ def test_bin_edge_cases():
                 assert (out["gc"][sl].cpu().numpy() == eg).all()
                 assert (out["count"][sl].cpu().numpy() == ec.astype(np.float32)).all()
                 off += len(es)
+
+
+def test_bin_sample_one_call_equals_two_step_flow():
+    import torch
+    cv = get_canvas()
+    lengths = [900_000, 500_001, 300_000]
+    data = _chroms(lengths, rate=0.21)
+    bases, hits, masks = _upload(cv, data)
+    lens = np.array(lengths, np.int64)
+    is_auto = np.array([1, 1, 0], np.uint8)
+    rates = [O.bin_rate(h, m) for b, h, m in data]
+    bs_exp = O.bin_size([rates[0], rates[1]], 100)      # autosomes only (CanvasBin.cs:44)
+    cap = int(lens.sum() // 50)
+    out = dict(chr=torch.empty(cap, dtype=torch.int32, device=cv.device), start=torch.empty(cap, dtype=torch.int32, device=cv.device),
+               stop=torch.empty(cap, dtype=torch.int32, device=cv.device), gc=torch.empty(cap, dtype=torch.int32, device=cv.device),
+               count=torch.empty(cap, dtype=torch.float32, device=cv.device))
+    o, per, total, bs = cv.bin_sample(bases, masks, hits, lens, is_auto, 100, -1, 3, out=out)
+    assert bs == bs_exp
+    exp = [O.bin_chromosome(b, m, h, bs, 3) for b, h, m in data]
+    assert total == sum(len(e[0]) for e in exp)
+    assert (out["stop"][:total].cpu().numpy() == np.concatenate([e[1] for e in exp])).all()
+    assert (out["count"][:total].cpu().numpy() == np.concatenate([e[3] for e in exp]).astype(np.float32)).all()
+    off = cv.chromosome_offsets(out["chr"], total, 3)
+    assert off.tolist() == [0, len(exp[0][0]), len(exp[0][0]) + len(exp[1][0]), total]
+    # explicit bin size (-z) skips the rate pass
+    o, per, total2, bs2 = cv.bin_sample(bases, masks, hits, lens, is_auto, 100, 777, 3, out=out)
+    assert bs2 == 777 and total2 == sum(len(O.bin_chromosome(b, m, h, 777, 3)[0]) for b, h, m in data)
