@@ -204,27 +204,17 @@ __device__ __forceinline__ uint32_t gc_bits4(uint32_t w) {           // 4 bits: 
 }
 __device__ __forceinline__ uint32_t sum_bytes(uint32_t w, uint32_t acc) { return __builtin_amdgcn_sad_u8(w, 0u, acc); }
 
-__global__ void __launch_bounds__(256) k_bin_pass(const BinChrom* __restrict__ ch, int nchr, int64_t ntilesTotal,
-                                                  const unsigned long long* __restrict__ pos0, const int32_t* __restrict__ rankBase,
-                                                  const long long* __restrict__ binOffset, int binSize, int clampHits,
-                                                  int32_t* __restrict__ stopOut, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG,
-                                                  uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
-    const int64_t gtile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gtile >= ntilesTotal) return;
-    const int c = find_chrom(ch, nchr, gtile);
-    const BinChrom C = ch[c];
-    const int64_t tileStart = (gtile - C.tileBase) << TILE_SHIFT;
+// One tile (4096 positions) per wave.  FULL = the tile lies entirely inside [pos0, len): vector loads, no bounds logic.
+template <bool FULL>
+__device__ __forceinline__ void bin_tile(const BinChrom& C, int64_t gtile, int64_t tileStart, int64_t p0c, int32_t rank0, long long boff, int binSize, int clampHits,
+                                         int32_t* __restrict__ stopOut, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG,
+                                         uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
     const int l = lane_id();
-    const int64_t p0c = (int64_t)pos0[c];
-    const long long boff = binOffset[c];
-    const bool full = (tileStart + TILE <= C.len) && (tileStart >= p0c);
-    int32_t rank0 = rankBase[gtile];          // rank (count of possible positions since pos0) before this tile
     uint32_t carryC = 0, carryG = 0;
-
     // issue all loads of the tile up front (memory-level parallelism): 4 x (16 B bases, 16 B hits, 2 B mask)
     uint4 vb[4], vh[4];
     uint32_t m16[4];
-    if (full) {
+    if (FULL) {
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             int64_t p = tileStart + it * 1024 + l * 16;
@@ -237,7 +227,7 @@ __global__ void __launch_bounds__(256) k_bin_pass(const BinChrom* __restrict__ c
     for (int it = 0; it < 4; it++) {
         const int64_t p = tileStart + it * 1024 + l * 16;
         uint32_t wb[4], wh[4], mRank, vmask = 0xFFFFu;
-        if (full) {
+        if (FULL) {
             wb[0] = vb[it].x; wb[1] = vb[it].y; wb[2] = vb[it].z; wb[3] = vb[it].w;
             wh[0] = vh[it].x; wh[1] = vh[it].y; wh[2] = vh[it].z; wh[3] = vh[it].w;
             mRank = m16[it];
@@ -279,10 +269,9 @@ __global__ void __launch_bounds__(256) k_bin_pass(const BinChrom* __restrict__ c
         if (pop > 0 && r + (int32_t)pop >= binSize) {  // cheap reject: a boundary needs rank >= binSize
             int32_t rr = r < 0 ? 0 : r;                // ranks <= 0 can never close a bin
             uint32_t nextB = ((uint32_t)rr / (uint32_t)binSize + 1u) * (uint32_t)binSize;   // next boundary rank > rr
-            uint32_t mm = mRank;
             while ((int64_t)nextB - r <= (int64_t)pop && (int64_t)nextB - r >= 1) {
-                uint32_t k = (uint32_t)((int64_t)nextB - r);       // k-th set bit of mm closes the bin
-                uint32_t pos = 0, m = mm, kk = k, cnt;
+                uint32_t k = (uint32_t)((int64_t)nextB - r);       // k-th set bit of mRank closes the bin
+                uint32_t pos = 0, m = mRank, kk = k, cnt;
                 cnt = __popc(m & 0xFFu); if (kk > cnt) { kk -= cnt; pos += 8; m >>= 8; }
                 cnt = __popc(m & 0xFu);  if (kk > cnt) { kk -= cnt; pos += 4; m >>= 4; }
                 cnt = __popc(m & 0x3u);  if (kk > cnt) { kk -= cnt; pos += 2; m >>= 2; }
@@ -310,6 +299,46 @@ __global__ void __launch_bounds__(256) k_bin_pass(const BinChrom* __restrict__ c
         carryC += cTot;
     }
     if (l == 0) { tileTotC[gtile] = carryC; tileTotG[gtile] = carryG; }
+}
+
+// the hot kernel: all tiles that lie completely inside [pos0, len) of their chromosome
+__global__ void __launch_bounds__(256) k_bin_pass(const BinChrom* __restrict__ ch, int nchr, int64_t ntilesTotal,
+                                                  const unsigned long long* __restrict__ pos0, const int32_t* __restrict__ rankBase,
+                                                  const long long* __restrict__ binOffset, int binSize, int clampHits,
+                                                  int32_t* __restrict__ stopOut, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG,
+                                                  uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
+    const int64_t gtile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gtile >= ntilesTotal) return;
+    const int c = find_chrom(ch, nchr, gtile);
+    const BinChrom C = ch[c];
+    const int64_t tileStart = (gtile - C.tileBase) << TILE_SHIFT;
+    const int64_t p0c = (int64_t)pos0[c];
+    if (tileStart + TILE > C.len || tileStart < p0c) {
+        // edge tiles (the one holding pos0, the partial tail) belong to k_bin_pass_edges; tiles entirely before pos0 hold no bin data
+        if (tileStart + TILE <= p0c && lane_id() == 0) { tileTotC[gtile] = 0; tileTotG[gtile] = 0; }
+        return;
+    }
+    bin_tile<true>(C, gtile, tileStart, p0c, rankBase[gtile], binOffset[c], binSize, clampHits, stopOut, locC, locG, tileTotC, tileTotG);
+}
+// at most two edge tiles per chromosome: wave 2c -> the tile holding pos0, wave 2c+1 -> the partial tail tile
+__global__ void __launch_bounds__(64) k_bin_pass_edges(const BinChrom* __restrict__ ch, int nchr, const unsigned long long* __restrict__ pos0,
+                                                       const int32_t* __restrict__ rankBase, const long long* __restrict__ binOffset, int binSize, int clampHits,
+                                                       int32_t* __restrict__ stopOut, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG,
+                                                       uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
+    const int c = blockIdx.x >> 1, which = blockIdx.x & 1;
+    if (c >= nchr) return;
+    const BinChrom C = ch[c];
+    const int64_t p0c = (int64_t)pos0[c];
+    const int64_t headTile = (p0c < C.len ? p0c : C.len - 1) >> TILE_SHIFT, tailTile = C.ntiles - 1;
+    int64_t t;
+    if (which == 0) t = headTile;
+    else { if (tailTile == headTile) return; t = tailTile; }
+    const int64_t tileStart = t << TILE_SHIFT;
+    const bool isFull = (tileStart + TILE <= C.len) && (tileStart >= p0c);
+    if (isFull) return;                                   // handled by k_bin_pass
+    if (tileStart + TILE <= p0c) return;                  // entirely before pos0 (all-'n' chromosome): zero totals written by k_bin_pass
+    const int64_t gtile = C.tileBase + t;
+    bin_tile<false>(C, gtile, tileStart, p0c, rankBase[gtile], binOffset[c], binSize, clampHits, stopOut, locC, locG, tileTotC, tileTotG);
 }
 
 // ---------------------------------------------------------------------------------------------- k_scan_totals
@@ -495,6 +524,8 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     { ProfScope ps(ctx, "bin_pass");
       hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
                          binOffset, bin_size, mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, stopTmp, locC, locG, tileTotC, tileTotG); }
+    hipLaunchKernelGGL(k_bin_pass_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, rankBase, binOffset, bin_size,
+                       mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, stopTmp, locC, locG, tileTotC, tileTotG);
     hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
     hipLaunchKernelGGL(k_bin_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, stopTmp, locC, locG,
                        tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count);

@@ -90,14 +90,17 @@ struct WsSizer {
 #define WAVE 64
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-// inclusive wave scan (64 lanes) via ds_bpermute shuffles
+// inclusive wave scan (64 lanes) with DPP: Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8), then the row totals are
+// propagated with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).  6 VALU adds, no LDS-crossbar round trips.
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t x, uint32_t src, int ctrl_dummy) { return x + src; }
+#define CANVAS_DPP(x, ctrl, row_mask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (row_mask), 0xF, true))
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
-    int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (l >= d) v += t;
-    }
+    v += CANVAS_DPP(v, 0x111, 0xF);      // row_shr:1
+    v += CANVAS_DPP(v, 0x112, 0xF);      // row_shr:2
+    v += CANVAS_DPP(v, 0x114, 0xF);      // row_shr:4
+    v += CANVAS_DPP(v, 0x118, 0xF);      // row_shr:8
+    v += CANVAS_DPP(v, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+    v += CANVAS_DPP(v, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ uint32_t wave_reduce_add_u32(uint32_t v) {
