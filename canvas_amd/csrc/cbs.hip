@@ -495,11 +495,70 @@ static int32_t change_points(ArcGpu& G, const double* gd, int n, const std::vect
     return CANVAS_OK;
 }
 
+// ---- undo = SDUndo (ChangePoint.cs:155-196) with the genome-wide trimmed SD (ChangePoint.cs:423-474); host scalar code on a few
+// hundred segments.  Normal.InverseCDF / Density are MathNet (parity unpinned): erfc-based here, as in the oracle.
+static double qnorm(double p) { double lo = -40, hi = 40; for (int it = 0; it < 200; it++) { double mid = 0.5 * (lo + hi); if (pnorm(mid) < p) lo = mid; else hi = mid; } return 0.5 * (lo + hi); }
+static double inflation_factor(double trim) {
+    double a = qnorm(1 - trim), step = 2 * a / 10000, from = -a + step / 2, to = a - step / 2, stp = (to - from) / (10000 - 1), e = 0.0, x1 = from;
+    for (int i = 0; i < 10000; i++) { double xv = i == 0 ? from : (i == 9999 ? to : (x1 = x1 + stp)); e += (xv * xv) * (std::exp(-0.5 * xv * xv) / std::sqrt(2 * M_PI)); }
+    return 1 / (e * step / (1 - 2 * trim));
+}
+static double trimmed_variance(const double* cov, const int64_t* off, int nchr, double trim) {
+    int64_t n = off[nchr];
+    std::vector<double> diff((size_t)(n > 0 ? n - 1 : 0));
+    int64_t i = 0; double last = 0;
+    for (int c = 0; c < nchr; c++) {
+        int64_t len = off[c + 1] - off[c];
+        if (len <= 0) continue;
+        const double* x = cov + off[c];
+        if (i > 0) { diff[i] = x[0] - last; i++; }
+        for (int64_t t = 0; t + 1 < len; t++) diff[i + t] = x[t + 1] - x[t];
+        i += len - 1; last = x[len - 1];
+    }
+    int nKeep = dn_round(std::nearbyint((1 - 2 * trim) * (n - 1)));
+    for (double& d : diff) d = std::fabs(d);
+    std::sort(diff.begin(), diff.end());
+    double sp = 0.0; for (int t = 0; t < nKeep; t++) sp += sq(diff[t]);
+    return inflation_factor(trim) * sp / (2 * nKeep);
+}
+static double helper_median(const double* x, int a, int b) {
+    std::vector<double> y(x + a, x + b); int mid = (int)y.size() / 2;
+    std::nth_element(y.begin(), y.begin() + mid, y.end());
+    double m = y[mid];
+    if (y.size() % 2 == 0) m = (m + *std::max_element(y.begin(), y.begin() + mid)) / 2;
+    return m;
+}
+static void sd_undo(const double* gd, std::vector<int>& lengthSeg, double trimmedSD, double changeSD) {
+    if (lengthSeg.size() <= 1) return;
+    changeSD *= trimmedSD;
+    std::vector<int> cpl(lengthSeg.size()); int acc = 0;
+    for (size_t i = 0; i < lengthSeg.size(); i++) { acc += lengthSeg[i]; cpl[i] = acc; }
+    for (;;) {
+        int k = (int)cpl.size();
+        if (k <= 1) break;
+        std::vector<double> med(k);
+        for (int i = 0; i < k; i++) med[i] = helper_median(gd, i == 0 ? 0 : cpl[i - 1], cpl[i]);
+        double mn = std::fabs(med[1] - med[0]); int iMin = 0;
+        for (int i = 1; i < k - 1; i++) { double d = std::fabs(med[i + 1] - med[i]); if (d < mn) { mn = d; iMin = i; } }
+        if (mn < changeSD) cpl.erase(cpl.begin() + iMin); else break;
+    }
+    lengthSeg.clear(); int prev = 0;
+    for (int e : cpl) { lengthSeg.push_back(e - prev); prev = e; }
+}
+
 }  // namespace cbs
 
+extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
+                                   int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
 extern "C" int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                               int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats) {
+    return canvas_cbs_undo(ctx, nchr, d_cov, h_chr_offset, alpha, nperm, 0, 3.0, d_seg_len, h_nseg, h_stats);
+}
+extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
+                                   int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats) {
     if (!ctx) return CANVAS_ERR_INVALID;
+    if (undo == 1) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "CBS -s Prune (ChangePoint.cs:205-271) is not built");
+    if (undo != 0 && undo != 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "undo must be 0 (None) or 2 (SDUndo)");
     if (nchr <= 0 || !d_cov || !h_chr_offset || !d_seg_len || !h_nseg || nperm == 0 || !(alpha > 0 && alpha < 1)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = h_chr_offset[nchr];
@@ -515,6 +574,8 @@ extern "C" int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     cbs::MT seeder(0u);
     std::vector<int32_t> seeds(nchr);
     for (int c = 0; c < nchr; c++) seeds[c] = seeder.next_full_range_int32();
+    double trimmedSD = 1.0;
+    if (undo == 2 && N > 1) trimmedSD = std::sqrt(cbs::trimmed_variance(cov.data(), h_chr_offset, nchr, 0.025));   // CBSRunner.cs:102
     cbs::ArcGpu G; G.ctx = ctx;
     cbs::Stats st;
     std::vector<std::vector<int>> segs(nchr);
@@ -527,6 +588,7 @@ extern "C" int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov
             if (n <= 0) continue;
             cbs::MT rnd((uint32_t)seeds[c]);
             rcs[c] = cbs::change_points(G, cov.data() + h_chr_offset[c], n, sbdry, rnd, alpha, nperm, segs[c], st);
+            if (rcs[c] == 0 && undo == 2) cbs::sd_undo(cov.data() + h_chr_offset[c], segs[c], trimmedSD, undo_sd);
         }
     };
     unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;

@@ -177,18 +177,26 @@ __device__ __forceinline__ void vit_step(double e, const double* la, double delt
     outDelta = a; outArg = ia;
 }
 
-// A: one wave per block; lanes 0..4 own the states, all 64 lanes stage emissions
-__global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ blocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
+// wave-local LDS hand-off (the four waves of a workgroup work on different blocks with different trip counts: no s_barrier)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define VWPB 4   // blocks (waves) per workgroup, sharing one copy of the emission table in LDS
+
+// A: one wave per block (four per workgroup); lanes 0..4 own the states, all 64 lanes stage emissions
+__global__ void __launch_bounds__(64 * VWPB) k_vit_spec(const VitBlock* __restrict__ blocks, int nblocksTotal, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                  const double* __restrict__ logPmf, HmmParams P, uint8_t* __restrict__ psi, int64_t N, int32_t* __restrict__ lastGuess) {
     extern __shared__ double sTab[];
-    __shared__ double sE[64 * NSTATE];
-    __shared__ uint8_t sPsi[NSTATE][64];
-    const VitBlock B = blocks[blockIdx.x];
-    const HmmChrom C = chroms[B.chrom];
-    const int l = threadIdx.x;
+    __shared__ double sE_[VWPB][64 * NSTATE];
+    __shared__ uint8_t sPsi_[VWPB][NSTATE][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
-    if (useLds) { for (int i = l; i < P.tableLen * NSTATE; i += 64) sTab[i] = logPmf[i]; }
+    if (useLds) { for (int i = threadIdx.x; i < P.tableLen * NSTATE; i += 64 * VWPB) sTab[i] = logPmf[i]; }
     __syncthreads();
+    const int bidx = blockIdx.x * VWPB + w;
+    if (bidx >= nblocksTotal) return;
+    double* sE = sE_[w];
+    uint8_t (*sPsi)[64] = sPsi_[w];
+    const VitBlock B = blocks[bidx];
+    const HmmChrom C = chroms[B.chrom];
     const double* tab = useLds ? sTab : logPmf;
     const int j = l < NSTATE ? l : 0;
     double la[NSTATE];
@@ -204,7 +212,7 @@ __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ bl
         { int64_t t = c0 + l; if (t < C.T) { int k = ix[t];
 #pragma unroll
             for (int s = 0; s < NSTATE; s++) sE[l * NSTATE + s] = tab[s * P.tableLen + k]; } }
-        __syncthreads();
+        WAVE_SYNC();
         const int steps = (int)((tEnd - c0) < 64 ? (tEnd - c0) : 64);
         for (int s = 0; s < steps; s++) {
             const int64_t t = c0 + s;
@@ -215,12 +223,12 @@ __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ bl
             else { double nd; vit_step(e, la, delta, NEG, nd, arg); delta = nd; }
             if (l < NSTATE) sPsi[j][s] = (uint8_t)arg;
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (l < steps && c0 + l >= tBeg) {
 #pragma unroll
             for (int st = 0; st < NSTATE; st++) psi[(size_t)st * N + C.begin + c0 + l] = sPsi[st][l];
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
     if (tEnd == C.T) {       // last block: guess of the best final state (HMM.cs:100-111 on the shifted delta)
         double d[NSTATE];
@@ -274,21 +282,24 @@ __global__ void __launch_bounds__(64) k_vit_backbone(const HmmChrom* __restrict_
 }
 
 // C: exact verification, one wave per block
-__global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ blocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
+__global__ void __launch_bounds__(64 * VWPB) k_vit_verify(const VitBlock* __restrict__ blocks, int nblocksTotal, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                    const double* __restrict__ logPmf, HmmParams P, const uint8_t* __restrict__ psi, int64_t N,
                                                    const int32_t* __restrict__ state, const double* __restrict__ V, const double* __restrict__ carry, const int32_t* __restrict__ lastGuess,
                                                    int32_t* __restrict__ fail) {
     extern __shared__ double sTab[];
-    __shared__ double sE[64 * NSTATE];
-    __shared__ uint8_t sPsi[NSTATE][64];
-    __shared__ int32_t sState[65];
-    __shared__ double sD[64];
-    const VitBlock B = blocks[blockIdx.x];
-    const HmmChrom C = chroms[B.chrom];
-    const int l = threadIdx.x;
+    __shared__ double sE_[VWPB][64 * NSTATE];
+    __shared__ uint8_t sPsi_[VWPB][NSTATE][64];
+    __shared__ int32_t sState_[VWPB][65];
+    __shared__ double sD_[VWPB][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
-    if (useLds) { for (int i = l; i < P.tableLen * NSTATE; i += 64) sTab[i] = logPmf[i]; }
+    if (useLds) { for (int i = threadIdx.x; i < P.tableLen * NSTATE; i += 64 * VWPB) sTab[i] = logPmf[i]; }
     __syncthreads();
+    const int bidx = blockIdx.x * VWPB + w;
+    if (bidx >= nblocksTotal) return;
+    double* sE = sE_[w]; uint8_t (*sPsi)[64] = sPsi_[w]; int32_t* sState = sState_[w]; double* sD = sD_[w];
+    const VitBlock B = blocks[bidx];
+    const HmmChrom C = chroms[B.chrom];
     const double* tab = useLds ? sTab : logPmf;
     const int j = l < NSTATE ? l : 0;
     double la[NSTATE];
@@ -312,7 +323,7 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
             for (int s = 0; s < NSTATE; s++) { sE[l * NSTATE + s] = tab[s * P.tableLen + k]; sPsi[s][l] = psi[(size_t)s * N + C.begin + t]; }
             sState[l + 1] = st[t]; sD[l] = Vc[t]; }
           if (l == 0) sState[0] = c0 > 0 ? st[c0 - 1] : -1; }
-        __syncthreads();
+        WAVE_SYNC();
         const int steps = (int)((tEnd - c0) < 64 ? (tEnd - c0) : 64);
         for (int s = 0; s < steps; s++) {
             const int64_t t = c0 + s;
@@ -346,7 +357,7 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
             }
             Dprev = Dt;
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
     if (tEnd == C.T) {
         double d[NSTATE];
@@ -413,7 +424,8 @@ __global__ void __launch_bounds__(256) k_fill_i32(int32_t* __restrict__ p, int64
 
 // ---- segment ids
 __global__ void __launch_bounds__(256) k_seg_flags(const int64_t* __restrict__ chrOff, int nchr, const int32_t* __restrict__ state, const int32_t* __restrict__ start,
-                                                   const int32_t* __restrict__ stop, int64_t n, int32_t maxDist, uint8_t* __restrict__ flags) {
+                                                   const int32_t* __restrict__ stop, int64_t n, int32_t maxDist, const int64_t* __restrict__ exclOff,
+                                                   const int32_t* __restrict__ exclStart, const int32_t* __restrict__ exclStop, uint8_t* __restrict__ flags) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int lo = 0, hi = nchr - 1;
@@ -421,6 +433,18 @@ __global__ void __launch_bounds__(256) k_seg_flags(const int64_t* __restrict__ c
     const bool first = (i == chrOff[lo]);
     const int32_t st = state[i];
     bool newSeg = st >= 0 && (first || state[i - 1] != st);           // breakpoint -> segment start present in `starts`
+    if (exclOff) {
+        // forbidden intervals (SegmentationResultsProcessor.cs:88-111): excludeIndex = first interval whose Stop >= previousBinEnd
+        // (the reference advances a cursor; with intervals sorted by Stop that is a lower bound), split when the interval's
+        // midpoint lies in (previousBinEnd, end]
+        const uint32_t prevEnd = first ? 0u : (uint32_t)stop[i - 1];
+        int64_t a = exclOff[lo], b = exclOff[lo + 1];
+        while (a < b) { int64_t mid = (a + b) >> 1; if ((int64_t)exclStop[mid] < (int64_t)prevEnd) a = mid + 1; else b = mid; }
+        if (a < exclOff[lo + 1]) {
+            const int forbiddenZoneMid = (exclStart[a] + exclStop[a]) / 2;
+            if ((int64_t)prevEnd < forbiddenZoneMid && (int64_t)(uint32_t)stop[i] >= forbiddenZoneMid) newSeg = true;
+        }
+    }
     if (!newSeg && !first) {
         uint32_t prevEnd = (uint32_t)stop[i - 1];
         if (prevEnd > 0 && maxDist >= 0 && (uint64_t)prevEnd + (uint64_t)maxDist < (uint64_t)(uint32_t)start[i]) newSeg = true;   // SegmentationResultsProcessor.cs:112-116
@@ -602,12 +626,12 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
         ProfScope ps(ctx, "viterbi");
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dLast, 0xFF, nchr * 4, ctx->stream));     // -1 for skipped chromosomes
-        hipLaunchKernelGGL(k_vit_spec, dim3((unsigned)vblocks.size()), dim3(64), lds, ctx->stream, dVBlocks, dChroms, idx, dTab, P, psi, N, dLast);
+        hipLaunchKernelGGL(k_vit_spec, dim3((unsigned)((vblocks.size() + VWPB - 1) / VWPB)), dim3(64 * VWPB), lds, ctx->stream, dVBlocks, (int)vblocks.size(), dChroms, idx, dTab, P, psi, N, dLast);
         if (getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, N, chroms[0].begin + chroms[0].T / 2);
         backtrack();
         hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
         hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
-        hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)vblocks.size()), dim3(64), lds, ctx->stream, dVBlocks, dChroms, idx, dTab, P, psi, N, d_state, dD, dCarry, dLast, dFail);
+        hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)((vblocks.size() + VWPB - 1) / VWPB)), dim3(64 * VWPB), lds, ctx->stream, dVBlocks, (int)vblocks.size(), dChroms, idx, dTab, P, psi, N, d_state, dD, dCarry, dLast, dFail);
         std::vector<int32_t> hFail(nchr, 0);
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -628,20 +652,32 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     return CANVAS_OK;
 }
 
-int32_t canvas_segment_ids(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
-                           const int32_t* d_stop, int32_t max_inter_bin_dist, int32_t* d_segment_id, int64_t* h_nsegments) {
+int32_t canvas_segment_ids_filtered(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
+                                    const int32_t* d_stop, int32_t max_inter_bin_dist, const int64_t* h_excl_offset, const int32_t* h_excl_start,
+                                    const int32_t* h_excl_stop, int32_t* d_segment_id, int64_t* h_nsegments) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !h_chr_offset || !d_state || !d_start || !d_stop || !d_segment_id) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_segment_ids: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = h_chr_offset[nchr];
     if (N == 0) { if (h_nsegments) *h_nsegments = 0; return CANVAS_OK; }
     const int nb = (int)nblk2(N, 2048);
+    const int64_t nex = h_excl_offset ? h_excl_offset[nchr] : 0;
+    if (h_excl_offset && nex > 0 && (!h_excl_start || !h_excl_stop)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_segment_ids_filtered: missing interval arrays");
+    if (h_excl_offset) for (int c = 0; c < nchr; c++) for (int64_t k = h_excl_offset[c] + 1; k < h_excl_offset[c + 1]; k++)
+        if (h_excl_stop[k] < h_excl_stop[k - 1]) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "forbidden intervals must be sorted by end within a chromosome");
     WsSizer sz; sz.take<int64_t>(nchr + 1); sz.take<uint8_t>(N); sz.take<uint32_t>(nb + 1); sz.take<unsigned long long>(1);
+    sz.take<int64_t>(nchr + 1); sz.take<int32_t>(nex + 1); sz.take<int32_t>(nex + 1);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     WsCarver ws(ctx->ws);
     int64_t* dOff = ws.take<int64_t>(nchr + 1); uint8_t* flags = ws.take<uint8_t>(N); uint32_t* blockCnt = ws.take<uint32_t>(nb + 1); unsigned long long* dTot = ws.take<unsigned long long>(1);
+    int64_t* dExOff = ws.take<int64_t>(nchr + 1); int32_t* dExStart = ws.take<int32_t>(nex + 1); int32_t* dExStop = ws.take<int32_t>(nex + 1);
+    if (h_excl_offset) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dExOff, h_excl_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (nex > 0) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dExStart, h_excl_start, nex * 4, hipMemcpyHostToDevice, ctx->stream));
+                       CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dExStop, h_excl_stop, nex * 4, hipMemcpyHostToDevice, ctx->stream)); }
+    }
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_seg_flags, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dOff, nchr, d_state, d_start, d_stop, N, max_inter_bin_dist, flags);
+    hipLaunchKernelGGL(k_seg_flags, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dOff, nchr, d_state, d_start, d_stop, N, max_inter_bin_dist, h_excl_offset ? dExOff : (const int64_t*)nullptr, dExStart, dExStop, flags);
     hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(256), 0, ctx->stream, flags, N, blockCnt);
     hipLaunchKernelGGL(k_scan_blocks2, dim3(1), dim3(1024), 0, ctx->stream, blockCnt, nb, dTot);
     hipLaunchKernelGGL(k_seg_ids, dim3(nb), dim3(256), 0, ctx->stream, flags, blockCnt, N, d_segment_id);
@@ -651,6 +687,34 @@ int32_t canvas_segment_ids(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_o
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     if (h_nsegments) *h_nsegments = (int64_t)tot;
     return CANVAS_OK;
+}
+
+int32_t canvas_segment_ids(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
+                           const int32_t* d_stop, int32_t max_inter_bin_dist, int32_t* d_segment_id, int64_t* h_nsegments) {
+    return canvas_segment_ids_filtered(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, nullptr, nullptr, nullptr, d_segment_id, h_nsegments);
+}
+
+// GenomeSegmentationResults.SplitOverlappingSegments (GenomeSegmentationResults.cs:18-55), one chromosome, host scalar code
+// (a few hundred segments per sample): union of all samples' starts/ends -> minimal non-overlapping partition.
+int32_t canvas_split_overlapping(int32_t nsamples, const uint32_t* const* h_start, const uint32_t* const* h_end, const int32_t* h_nseg,
+                                 uint32_t* h_out_start, uint32_t* h_out_end, int32_t cap, int32_t* h_nout) {
+    if (nsamples <= 0 || !h_start || !h_end || !h_nseg || !h_nout) return CANVAS_ERR_INVALID;
+    if (nsamples == 1) {   // a single sample is returned as is (:20)
+        if (h_nseg[0] > cap) return CANVAS_ERR_CAPACITY;
+        for (int i = 0; i < h_nseg[0]; i++) { h_out_start[i] = h_start[0][i]; h_out_end[i] = h_end[0][i]; }
+        *h_nout = h_nseg[0];
+        return CANVAS_OK;
+    }
+    std::vector<std::pair<uint32_t, int>> ev;
+    for (int s = 0; s < nsamples; s++) for (int i = 0; i < h_nseg[s]; i++) { ev.push_back({h_start[s][i], 0}); ev.push_back({h_end[s][i], 1}); }
+    std::stable_sort(ev.begin(), ev.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.first < b.first; });
+    int overlapping = 0, n = 0; uint32_t cur = 0;
+    for (auto& e : ev) {
+        if (overlapping > 0 && cur != e.first) { if (n < cap) { h_out_start[n] = cur; h_out_end[n] = e.first; } n++; }
+        cur = e.first; overlapping += e.second == 0 ? 1 : -1;
+    }
+    *h_nout = n;
+    return n > cap ? CANVAS_ERR_CAPACITY : CANVAS_OK;
 }
 
 }  // extern "C"

@@ -15,8 +15,9 @@ CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD, CLEAN_LOESS = 1, 2,
 ABI_SYMBOLS = [
     "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
+    "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample",
-    "canvas_clean", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_cbs",
+    "canvas_clean", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -111,6 +112,23 @@ class Canvas:
         self._check(self.lib.canvas_synchronize(self.ctx))
 
     # ---- CanvasBin
+    def mask_from_fasta(self, bases, length):
+        """InitializeAlignmentArrays (CanvasBin.cs:183-200)"""
+        mask = self.torch.empty((length + 63) // 64, dtype=self.torch.int64, device=self.device)
+        self._check(self.lib.canvas_mask_from_fasta(self.ctx, C.c_void_p(bases.data_ptr()), C.c_int64(length), C.c_void_p(mask.data_ptr())))
+        self.synchronize()
+        return mask
+
+    def mask_exclude_intervals(self, mask, length, starts, stops):
+        """ExcludeTagsOverlappingFilterFile (CanvasBin.cs:668-692)"""
+        a = np.ascontiguousarray(starts, np.int32); b = np.ascontiguousarray(stops, np.int32)
+        self._check(self.lib.canvas_mask_exclude_intervals(self.ctx, C.c_void_p(mask.data_ptr()), C.c_int64(length), len(a), _np_ptr(a), _np_ptr(b)))
+
+    def screen_hits(self, hits, mask, length):
+        """ScreenObservedTags (CanvasBin.cs:699-716)"""
+        self._check(self.lib.canvas_screen_hits(self.ctx, C.c_void_p(hits.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_int64(length)))
+        self.synchronize()
+
     def bin_rates(self, hits, masks, lens):
         """SampleHitArrays.GetRates (CanvasBin.cs:30-71)"""
         n = len(hits)
@@ -196,22 +214,32 @@ class Canvas:
         self._check(self.lib.canvas_hmm_per_sample(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_void_p(state.data_ptr())))
         return state
 
-    def segment_ids(self, chr_offset, state, start, stop, max_inter_bin_dist=1000000):
+    def segment_ids(self, chr_offset, state, start, stop, max_inter_bin_dist=1000000, excluded=None):
+        """DeriveSegments + PostProcessSegments; excluded = per-chromosome list of (starts, stops) of the -b BED file"""
         torch = self.torch
         off = np.ascontiguousarray(chr_offset, np.int64)
         seg = torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
         nseg = C.c_int64(0)
-        self._check(self.lib.canvas_segment_ids(self.ctx, len(off) - 1, _np_ptr(off), C.c_void_p(state.data_ptr()), C.c_void_p(start.data_ptr()),
-                                                C.c_void_p(stop.data_ptr()), max_inter_bin_dist, C.c_void_p(seg.data_ptr()), C.byref(nseg)))
+        if excluded is None:
+            self._check(self.lib.canvas_segment_ids(self.ctx, len(off) - 1, _np_ptr(off), C.c_void_p(state.data_ptr()), C.c_void_p(start.data_ptr()),
+                                                    C.c_void_p(stop.data_ptr()), max_inter_bin_dist, C.c_void_p(seg.data_ptr()), C.byref(nseg)))
+        else:
+            eo = np.concatenate([[0], np.cumsum([len(e[0]) for e in excluded])]).astype(np.int64)
+            es = np.ascontiguousarray(np.concatenate([np.asarray(e[0], np.int32) for e in excluded]) if eo[-1] else np.zeros(1), np.int32)
+            ee = np.ascontiguousarray(np.concatenate([np.asarray(e[1], np.int32) for e in excluded]) if eo[-1] else np.zeros(1), np.int32)
+            self._check(self.lib.canvas_segment_ids_filtered(self.ctx, len(off) - 1, _np_ptr(off), C.c_void_p(state.data_ptr()), C.c_void_p(start.data_ptr()),
+                                                             C.c_void_p(stop.data_ptr()), max_inter_bin_dist, _np_ptr(eo), _np_ptr(es), _np_ptr(ee),
+                                                             C.c_void_p(seg.data_ptr()), C.byref(nseg)))
         return seg, nseg.value
 
-    def cbs(self, cov, chr_offset, alpha=0.01, nperm=10000):
+    def cbs(self, cov, chr_offset, alpha=0.01, nperm=10000, undo=0, undo_sd=3.0):
+        """CBSRunner.Run (CBSRunner.cs:40-151); undo: 0 None, 2 SDUndo"""
         torch = self.torch
         off = np.ascontiguousarray(chr_offset, np.int64)
         seg_len = torch.zeros(int(off[-1]) + 1, dtype=torch.int32, device=self.device)
         nseg = np.zeros(len(off) - 1, np.int32); stats = np.zeros(8, np.int64)
-        self._check(self.lib.canvas_cbs(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_double(alpha), C.c_uint32(nperm),
-                                        C.c_void_p(seg_len.data_ptr()), _np_ptr(nseg), _np_ptr(stats)))
+        self._check(self.lib.canvas_cbs_undo(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_double(alpha), C.c_uint32(nperm), undo, C.c_double(undo_sd),
+                                             C.c_void_p(seg_len.data_ptr()), _np_ptr(nseg), _np_ptr(stats)))
         return seg_len, nseg, stats
 
 

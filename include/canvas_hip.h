@@ -52,6 +52,14 @@ int32_t canvas_memcpy_h2d(canvas_ctx* ctx, void* d_dst, const void* h_src, int64
 int32_t canvas_memcpy_d2h(canvas_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes);
 
 /* ---- CanvasBin ----------------------------------------------------------------------------------------------- */
+/* InitializeAlignmentArrays (CanvasBin/CanvasBin.cs:183-200): possible[i] = char.IsUpper(referenceBases[i]).
+ * d_mask must hold ceil(len/64) words; bits at and beyond len are written as 0. */
+int32_t canvas_mask_from_fasta(canvas_ctx* ctx, const uint8_t* d_bases, int64_t len, uint64_t* d_mask);
+/* ExcludeTagsOverlappingFilterFile (CanvasBin.cs:668-692): clear the possible bits of [start, stop) for the n BED intervals
+ * of this chromosome (intervals are clipped to [0, len); the reference would throw past the end). */
+int32_t canvas_mask_exclude_intervals(canvas_ctx* ctx, uint64_t* d_mask, int64_t len, int32_t n, const int32_t* h_start, const int32_t* h_stop);
+/* ScreenObservedTags (CanvasBin.cs:699-716): hits[i] = 0 wherever the position is not a possible alignment. */
+int32_t canvas_screen_hits(canvas_ctx* ctx, uint8_t* d_hits, const uint64_t* d_mask, int64_t len);
 /* SampleHitArrays.GetRates (CanvasBin/CanvasBin.cs:30-71) + HitArray.CountSetBits (HitArray.cs:24-32) +
  * CanvasBin.CountSetBits (CanvasBin.cs:146-156): per chromosome #positions with hit>0 and popcount(mask).
  * h_observed/h_possible/h_rate have nchr entries (rate = observed/(double)possible). */
@@ -110,10 +118,24 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
 int32_t canvas_segment_ids(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state,
                            const int32_t* d_start, const int32_t* d_stop, int32_t max_inter_bin_dist, int32_t* d_segment_id,
                            int64_t* h_nsegments);
+/* same, with the forbidden intervals of the -b BED file (SegmentationResultsProcessor.cs:88-111): a segment is split where the
+ * midpoint of an interval lies between two bins.  h_excl_offset[nchr+1] indexes h_excl_start/stop per chromosome; intervals must be
+ * sorted by end inside a chromosome (the reference walks them with a forward-only cursor). */
+int32_t canvas_segment_ids_filtered(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state,
+                                    const int32_t* d_start, const int32_t* d_stop, int32_t max_inter_bin_dist,
+                                    const int64_t* h_excl_offset, const int32_t* h_excl_start, const int32_t* h_excl_stop,
+                                    int32_t* d_segment_id, int64_t* h_nsegments);
+/* GenomeSegmentationResults.SplitOverlappingSegments (GenomeSegmentationResults.cs:18-55) for one chromosome: host scalar code. */
+int32_t canvas_split_overlapping(int32_t nsamples, const uint32_t* const* h_start, const uint32_t* const* h_end, const int32_t* h_nseg,
+                                 uint32_t* h_out_start, uint32_t* h_out_end, int32_t cap, int32_t* h_nout);
 /* CBSRunner.Run / ChangePoint.ChangePoints (CBSRunner.cs:40-151, ChangePoint.cs:44-153), undo = None.
  * d_seg_len receives per chromosome the segment lengths, written at d_seg_len + h_chr_offset[c]; h_nseg[c] = count. */
 int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                    int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
+
+/* same with -s SDUndo (undo = 2, ChangePoint.cs:155-196; undo_sd = 3 in the reference) or None (0).  Prune (1) is not built. */
+int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
+                        int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
 
 /* ---- multi-GPU (one process per GPU; chromosomes sharded across ranks) ------------------------------------------ */
 int32_t canvas_comm_unique_id(void* h_id128);  /* ncclGetUniqueId, 128 bytes, rank 0 */

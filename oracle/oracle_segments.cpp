@@ -198,15 +198,26 @@ int orc_cbs_chromosome(const double* x, int n, int32_t seed, const uint32_t* sbd
     return (int)ls.size();
 }
 // whole genome CBS (finite data assumed), one std::thread per chromosome (CBSRunner.cs:115-147)
+void orc_cbs_genome_undo(int nchr, const double* const* x, const int64_t* n, const uint32_t* sbdry, int nsbdry, double alpha, uint32_t nPerm,
+                         int undo, int32_t* const* lengthSeg, const int* cap, int32_t* nseg, int64_t* stats7, int threads);
 void orc_cbs_genome(int nchr, const double* const* x, const int64_t* n, const uint32_t* sbdry, int nsbdry, double alpha, uint32_t nPerm,
                     int32_t* const* lengthSeg, const int* cap, int32_t* nseg, int64_t* stats7, int threads) {
+    orc_cbs_genome_undo(nchr, x, n, sbdry, nsbdry, alpha, nPerm, 0, lengthSeg, cap, nseg, stats7, threads);
+}
+void orc_cbs_genome_undo(int nchr, const double* const* x, const int64_t* n, const uint32_t* sbdry, int nsbdry, double alpha, uint32_t nPerm,
+                         int undo, int32_t* const* lengthSeg, const int* cap, int32_t* nseg, int64_t* stats7, int threads) {
+    double trimmedSD = 1.0;
+    if (undo == 2) {   // CBSRunner.cs:102
+        std::vector<const double*> sc(x, x + nchr); std::vector<int> ln(nchr); for (int c = 0; c < nchr; c++) ln[c] = (int)n[c];
+        trimmedSD = std::sqrt(TrimmedVariance(sc, ln, 0.025));
+    }
     std::vector<int32_t> seeds(nchr);
     orc_cbs_seeds(nchr, seeds.data());
     std::vector<int64_t> st((size_t)nchr * 7, 0);
     std::vector<std::thread> th;
     std::atomic_int next{0};
     auto work = [&]() { for (;;) { int c = next++; if (c >= nchr) break;
-        nseg[c] = n[c] > 0 ? orc_cbs_chromosome(x[c], (int)n[c], seeds[c], sbdry, nsbdry, alpha, nPerm, 0, 1.0, lengthSeg[c], cap[c], &st[(size_t)c * 7]) : 0; } };
+        nseg[c] = n[c] > 0 ? orc_cbs_chromosome(x[c], (int)n[c], seeds[c], sbdry, nsbdry, alpha, nPerm, undo, trimmedSD, lengthSeg[c], cap[c], &st[(size_t)c * 7]) : 0; } };
     for (int t = 0; t < std::max(1, threads); t++) th.emplace_back(work);
     for (auto& t : th) t.join();
     if (stats7) { for (int k = 0; k < 7; k++) { stats7[k] = 0; for (int c = 0; c < nchr; c++) stats7[k] += st[(size_t)c * 7 + k]; } }

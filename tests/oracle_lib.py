@@ -262,11 +262,11 @@ def cbs_chromosome(x, seed, sbdry=None, alpha=0.01, n_perm=10000, undo=0, trimme
     return ls[:n].copy(), stats
 
 
-def cbs_genome(xs, alpha=0.01, n_perm=10000, threads=1):
+def cbs_genome(xs, alpha=0.01, n_perm=10000, threads=1, undo=0):
     sb = cbs_boundary(n_perm, alpha)
     n = np.array([len(x) for x in xs], np.int64)
     caps = np.array([len(x) + 1 for x in xs], np.int32)
     ls = [np.zeros(int(c), np.int32) for c in caps]
     nseg = np.zeros(len(xs), np.int32); stats = np.zeros(7, np.int64)
-    lib.orc_cbs_genome(len(xs), _pp(xs), _p(n), _p(sb), len(sb), C.c_double(alpha), C.c_uint32(n_perm), _pp(ls), _p(caps), _p(nseg), _p(stats), threads)
+    lib.orc_cbs_genome_undo(len(xs), _pp(xs), _p(n), _p(sb), len(sb), C.c_double(alpha), C.c_uint32(n_perm), undo, _pp(ls), _p(caps), _p(nseg), _p(stats), threads)
     return [l[:k].copy() for l, k in zip(ls, nseg)], stats

@@ -54,3 +54,24 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in txt and "libcanvas_oracle" not in txt and "oracle/" not in txt.replace("the oracle", ""), f
+
+
+def test_split_overlapping_segments_reference_cases(lib):
+    """canvas_split_overlapping (host scalar entry point) against the reference's own 9 known-answer cases
+    (CanvasTest/CanvasPartition/GenomeSegmentationResultsTests.cs:14-248)"""
+    import json
+    import numpy as np
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "split_overlapping_cases.json")))
+    for c in cases:
+        for chrom, exp in c["expected"].items():
+            st = [np.array([s[0] for s in smp[chrom]], np.uint32) for smp in c["samples"]]
+            en = [np.array([s[1] for s in smp[chrom]], np.uint32) for smp in c["samples"]]
+            n = len(st)
+            P = ctypes.c_void_p * n
+            nseg = np.array([len(s) for s in st], np.int32)
+            os_ = np.zeros(64, np.uint32); oe = np.zeros(64, np.uint32); nout = ctypes.c_int32(0)
+            rc = lib.canvas_split_overlapping(n, P(*[a.ctypes.data for a in st]), P(*[a.ctypes.data for a in en]), nseg.ctypes.data_as(ctypes.c_void_p),
+                                              os_.ctypes.data_as(ctypes.c_void_p), oe.ctypes.data_as(ctypes.c_void_p), 64, ctypes.byref(nout))
+            assert rc == 0
+            got = [[int(a), int(b)] for a, b in zip(os_[:nout.value], oe[:nout.value])]
+            assert got == exp, c["name"]

@@ -121,3 +121,26 @@ def test_bin_sample_one_call_equals_two_step_flow():
     # explicit bin size (-z) skips the rate pass
     o, per, total2, bs2 = cv.bin_sample(bases, masks, hits, lens, is_auto, 100, 777, 3, out=out)
     assert bs2 == 777 and total2 == sum(len(O.bin_chromosome(b, m, h, 777, 3)[0]) for b, h, m in data)
+
+
+def test_prep_kernels_mask_filter_screen():
+    """InitializeAlignmentArrays / ExcludeTagsOverlappingFilterFile / ScreenObservedTags (CanvasBin.cs:183-200,668-716) vs numpy"""
+    cv = get_canvas()
+    rng = np.random.RandomState(21)
+    for L in (1_000_003, 4096, 77):
+        bases = rng.choice(np.frombuffer(b"ACGTNacgtn@[`{Zz", np.uint8), L)
+        hits = rng.randint(0, 256, L).astype(np.uint8)
+        dmask = cv.mask_from_fasta(to_dev(pad16(bases), cv.device), L)
+        exp = (bases >= ord('A')) & (bases <= ord('Z'))
+        got = np.unpackbits(dmask.cpu().numpy().view(np.uint8), bitorder="little")
+        assert (got[:L] == exp).all() and got[L:].sum() == 0
+        starts = np.sort(rng.randint(0, L, 40)); stops = np.minimum(L + 5, starts + rng.randint(1, 3000, 40))
+        starts = np.concatenate([starts, [0, L - 1]]); stops = np.concatenate([stops, [1, L]])
+        cv.mask_exclude_intervals(dmask, L, starts, stops)
+        for a, b in zip(starts, stops):
+            exp[a:min(b, L)] = False
+        got = np.unpackbits(dmask.cpu().numpy().view(np.uint8), bitorder="little")
+        assert (got[:L] == exp).all()
+        dh = to_dev(pad16(hits), cv.device)
+        cv.screen_hits(dh, dmask, L)
+        assert (dh.cpu().numpy()[:L] == np.where(exp, hits, 0)).all()

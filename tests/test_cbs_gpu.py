@@ -9,11 +9,11 @@ from gpu_common import get_canvas, to_dev
 pytestmark = pytest.mark.gpu
 
 
-def _run(cv, cov, off, nperm=10000):
+def _run(cv, cov, off, nperm=10000, undo=0):
     nchr = len(off) - 1
     per = [np.ascontiguousarray(cov[off[c]:off[c + 1]]) for c in range(nchr)]
-    exp, est = O.cbs_genome(per, 0.01, nperm, threads=8)
-    seg_len, nseg, stats = cv.cbs(to_dev(cov, cv.device), off, 0.01, nperm)
+    exp, est = O.cbs_genome(per, 0.01, nperm, threads=8, undo=undo)
+    seg_len, nseg, stats = cv.cbs(to_dev(cov, cv.device), off, 0.01, nperm, undo=undo)
     got = seg_len.cpu().numpy()
     for c in range(nchr):
         g = got[off[c]:off[c] + nseg[c]]
@@ -53,3 +53,18 @@ def test_cbs_borderline_needs_permutations():
     off = np.array([0, len(cov)], np.int64)
     stats, exp = _run(cv, cov, off, nperm=2000)
     assert stats[2] > 0
+
+
+def test_cbs_sdundo_merges_weak_splits():
+    cv = get_canvas()
+    rng = np.random.RandomState(13)
+    parts = []
+    for c in range(3):
+        x = rng.normal(100, 10, 6000)
+        x[1000:1400] += 60; x[3000:3300] += 6; x[4500:4520] -= 25
+        parts.append(np.round(x, 2))
+    cov = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    s0, e0 = _run(cv, cov, off, nperm=2000, undo=0)
+    s2, e2 = _run(cv, cov, off, nperm=2000, undo=2)
+    assert sum(len(e) for e in e2) <= sum(len(e) for e in e0)

@@ -88,3 +88,30 @@ def test_speculation_is_verified_and_falls_back(monkeypatch):
     monkeypatch.setenv("CANVAS_HMM_SEQUENTIAL", "1")
     got2 = _check(cv, bins, cov, off)
     assert (got2 == base).all()
+
+
+def test_segment_ids_with_forbidden_intervals():
+    """SegmentationResultsProcessor.PostProcessSegments with the -b BED intervals (forbidden-zone midpoint rule)"""
+    cv = get_canvas()
+    bins, cov, off = _coverage(20260927 + 14, 40_000, 5)
+    nchr = 5
+    per = [np.ascontiguousarray(cov[off[c]:off[c + 1]]) for c in range(nchr)]
+    paths, ran = O.hmm_genome_per_sample(per, threads=4)
+    rng = np.random.RandomState(3)
+    excl = []
+    for c in range(nchr):
+        s = bins["start"][off[c]:off[c + 1]]; e = bins["stop"][off[c]:off[c + 1]]
+        pick = np.sort(rng.choice(len(s) - 2, 25, replace=False))
+        # intervals in the gaps / over bins, sorted by end
+        st = e[pick] - rng.randint(0, 400, 25); en = st + rng.randint(10, 900, 25)
+        order = np.argsort(en, kind="stable")
+        excl.append((st[order].astype(np.int32), en[order].astype(np.int32)))
+    bs = [bins["start"][off[c]:off[c + 1]].astype(np.uint32) for c in range(nchr)]
+    be = [bins["stop"][off[c]:off[c + 1]].astype(np.uint32) for c in range(nchr)]
+    segstarts = [O.segments_from_path(paths[c], ran[c], bs[c], be[c])[0] for c in range(nchr)]
+    ids, last = O.postprocess(bs, be, segstarts, excl, 1000000)
+    state = to_dev(np.concatenate(paths), cv.device)
+    seg, nseg = cv.segment_ids(off, state, to_dev(bins["start"], cv.device), to_dev(bins["stop"], cv.device), 1000000, excluded=excl)
+    assert (seg.cpu().numpy() == np.concatenate(ids)).all()
+    ids0, _ = O.postprocess(bs, be, segstarts, None, 1000000)
+    assert last > _      # the forbidden zones added splits
