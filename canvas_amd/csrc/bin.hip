@@ -400,6 +400,100 @@ __global__ void k_init_pos0(const BinChrom* __restrict__ ch, int nchr, unsigned 
     if (c < nchr) pos0[c] = (unsigned long long)ch[c].len;
 }
 
+
+// ---------------------------------------------------------------------------------------------- GCContentWeighted mode (mode 5)
+// CanvasBin.cs:416-506 (read-GC profile), :330-405 (observed vs expected), :626-636 (weighted count).  The reference recounts the GC
+// bases of every fragment window (O(L*F)); here the window count is a difference of an inclusive GC prefix array (O(L)).
+__global__ void __launch_bounds__(256) k_nonzero_mean(const int16_t* __restrict__ fl, int64_t len, unsigned long long* __restrict__ sumCnt /* [2] */) {
+    unsigned long long s = 0, c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) { int v = fl[i]; if (v > 0) { s += (unsigned long long)v; c++; } }
+    s = wave_reduce_add_u64(s); c = wave_reduce_add_u64(c);
+    if (lane_id() == 0) { atomicAdd(&sumCnt[0], s); atomicAdd(&sumCnt[1], c); }
+}
+// GC prefix: P[i] = #(C/c/G/g) in bases[0, i).  Tile counts -> scan -> write.
+__global__ void __launch_bounds__(256) k_gcp_tile(const uint8_t* __restrict__ bases, int64_t len, uint32_t* __restrict__ tileCnt) {
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tileStart = tile << TILE_SHIFT;
+    if (tileStart >= len) return;
+    const int l = lane_id();
+    uint32_t g = 0;
+    for (int it = 0; it < 4; it++) {
+        int64_t p = tileStart + it * 1024 + l * 16;
+        if (p + 16 <= len) { uint4 v = *reinterpret_cast<const uint4*>(bases + p); g += __popc(gc_bits4(v.x)) + __popc(gc_bits4(v.y)) + __popc(gc_bits4(v.z)) + __popc(gc_bits4(v.w)); }
+        else for (int i = 0; i < 16 && p + i < len; i++) { uint8_t b = bases[p + i] | 0x20; g += (b == 'c' || b == 'g'); }
+    }
+    g = wave_reduce_add_u32(g);
+    if (l == 0) tileCnt[tile] = g;
+}
+__global__ void __launch_bounds__(1024) k_gcp_scan(uint32_t* __restrict__ tileCnt, int64_t ntiles) {
+    __shared__ uint32_t sh[17];
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < ntiles; base += 1024) {
+        int64_t t = base + threadIdx.x;
+        uint32_t v = t < ntiles ? tileCnt[t] : 0, tot;
+        uint32_t ex = block_exclusive_scan_1024(v, sh, tot);
+        if (t < ntiles) tileCnt[t] = carry + ex;
+        carry += tot;
+    }
+}
+__global__ void __launch_bounds__(256) k_gcp_write(const uint8_t* __restrict__ bases, int64_t len, const uint32_t* __restrict__ tileEx, uint32_t* __restrict__ P) {
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tileStart = tile << TILE_SHIFT;
+    if (tileStart >= len) return;
+    const int l = lane_id();
+    uint32_t run = tileEx[tile];
+    for (int it = 0; it < 4; it++) {
+        int64_t p = tileStart + it * 1024 + l * 16;
+        uint32_t bits = 0;
+        if (p + 16 <= len) { uint4 v = *reinterpret_cast<const uint4*>(bases + p); bits = gc_bits4(v.x) | (gc_bits4(v.y) << 4) | (gc_bits4(v.z) << 8) | (gc_bits4(v.w) << 12); }
+        else for (int i = 0; i < 16 && p + i < len; i++) { uint8_t b = bases[p + i] | 0x20; if (b == 'c' || b == 'g') bits |= 1u << i; }
+        uint32_t cnt = __popc(bits);
+        uint32_t inc = wave_inclusive_scan_u32(cnt);
+        uint32_t ex = run + inc - cnt;
+        for (int i = 0; i < 16; i++) if (p + i <= len) P[p + i] = ex + __popc(bits & ((1u << i) - 1u));    // P has len + 1 entries
+        run += __shfl(inc, 63, 64);
+    }
+}
+// gcContent[pos] (CanvasBin.cs:466-492) + the two 101-bin histograms of ComputeObservedVsExpectedGC (:349-356)
+__global__ void __launch_bounds__(256) k_read_gc(const uint32_t* __restrict__ P, const int16_t* __restrict__ fl, const uint8_t* __restrict__ hits, int64_t len, int meanFrag,
+                                                 uint8_t* __restrict__ readGc, unsigned long long* __restrict__ expectedC, unsigned long long* __restrict__ observedC) {
+    __shared__ unsigned int le[101], lo[101];
+    if (threadIdx.x < 101) { le[threadIdx.x] = 0; lo[threadIdx.x] = 0; }
+    __syncthreads();
+    const int64_t lim = len - (int64_t)meanFrag * 3 - 1;
+    for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < len; pos += (int64_t)gridDim.x * 256) {
+        uint32_t g = 0;
+        if (pos < lim) {
+            int f = fl[pos];
+            int cur = f == 0 ? meanFrag : (f < meanFrag * 3 ? f : meanFrag * 3);
+            long long v = 100ll * (long long)(P[pos + cur] - P[pos]) / (long long)cur;
+            g = (uint32_t)(v < 101 ? v : 101);
+        }
+        readGc[pos] = (uint8_t)g;
+        if (g < 101) { atomicAdd(&le[g], 1u); unsigned h = hits[pos]; if (h) atomicAdd(&lo[g], h); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 101) { if (le[threadIdx.x]) atomicAdd(&expectedC[threadIdx.x], (unsigned long long)le[threadIdx.x]); if (lo[threadIdx.x]) atomicAdd(&observedC[threadIdx.x], (unsigned long long)lo[threadIdx.x]); }
+}
+// weighted count (CanvasBin.cs:626-636): one thread per bin, float32 accumulation in position order, Math.Round half-even
+struct GcChrom { const uint8_t* readGc; };
+__global__ void __launch_bounds__(256) k_bin_weighted(const BinChrom* __restrict__ ch, const GcChrom* __restrict__ gch, long long nbins, const int32_t* __restrict__ oChr,
+                                                      const int32_t* __restrict__ oStart, const int32_t* __restrict__ oStop, const float* __restrict__ w, float* __restrict__ oCount) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nbins) return;
+    const int c = oChr[i];
+    const BinChrom C = ch[c];
+    const uint8_t* rg = gch[c].readGc;
+    float tmp = 0.0f;
+    for (int64_t p = oStart[i]; p < oStop[i]; p++) {
+        if ((C.mask[p >> 6] >> (p & 63)) & 1ull) {
+            float q = (float)(int)C.hits[p] / w[rg[p]];
+            tmp += fminf(10.0f, q);
+        }
+    }
+    oCount[i] = (float)(int)rint((double)tmp);
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 struct BinPlan {
     std::vector<BinChrom> chroms;
@@ -467,17 +561,71 @@ int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_
 }
 
 static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
-                               const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_is_auto, int32_t counts_per_bin, int32_t bin_size, int32_t mode,
+                               const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len, const uint8_t* h_is_auto, int32_t counts_per_bin, int32_t bin_size, int32_t mode,
                                int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                                int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
     if (!ctx) return CANVAS_ERR_INVALID;
     const bool needRates = bin_size <= 0;
     if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || (needRates && (!h_is_auto || counts_per_bin <= 0))) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bad arguments");
-    if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "GCContentWeighted binning (CanvasBin.cs:451-506,626-636) is not built yet");
-    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "unknown coverage mode");
+    const bool gcw = mode == CANVAS_MODE_GC_CONTENT_WEIGHTED;
+    if (gcw && !d_fraglen) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode needs the fragment-length arrays (canvas_bin_sample_gcweighted)");
+    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE && !gcw) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "unknown coverage mode");
     for (int c = 0; c < nchr; c++) if (h_len[c] <= 0 || h_len[c] > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "chromosome length must be in [1, 2^31)");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BinPlan plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len);
+    // ---- mode 5 pre-pass: mean fragment size, read-GC profile, observed/expected weights (kept in a separate allocation)
+    uint8_t* gcArena = nullptr; float* dW = nullptr; GcChrom* dGch = nullptr;
+    struct ArenaFree { canvas_ctx* c; uint8_t** p; ~ArenaFree() { if (*p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(*p); } } } arenaFree{ctx, &gcArena};
+    if (gcw) {
+        int64_t maxLen = 0, totLen = 0;
+        for (int c = 0; c < nchr; c++) { maxLen = std::max(maxLen, h_len[c]); totLen += (h_len[c] + 255) & ~255ll; }
+        const int64_t maxTiles = (maxLen + TILE - 1) / TILE;
+        size_t bytes = (size_t)totLen + (size_t)(maxLen + 1) * 4 + (size_t)maxTiles * 4 + 4096 + (size_t)nchr * (16 + sizeof(GcChrom)) + 202 * 8 + 101 * 4;
+        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&gcArena, bytes));
+        uint8_t* p = gcArena;
+        std::vector<GcChrom> gch(nchr);
+        for (int c = 0; c < nchr; c++) { gch[c].readGc = p; p += (h_len[c] + 255) & ~255ll; }
+        uint32_t* P = (uint32_t*)p; p += ((size_t)(maxLen + 1) * 4 + 255) & ~size_t(255);
+        uint32_t* tileCnt = (uint32_t*)p; p += ((size_t)maxTiles * 4 + 255) & ~size_t(255);
+        unsigned long long* sumCnt = (unsigned long long*)p; p += ((size_t)nchr * 16 + 255) & ~size_t(255);
+        unsigned long long* hist = (unsigned long long*)p; p += 2048;
+        dW = (float*)p; p += 512;
+        dGch = (GcChrom*)p;
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(sumCnt, 0, (size_t)nchr * 16, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(hist, 0, 202 * 8, ctx->stream));
+        for (int c = 0; c < nchr; c++) hipLaunchKernelGGL(k_nonzero_mean, dim3(1024), dim3(256), 0, ctx->stream, d_fraglen[c], h_len[c], sumCnt + 2 * c);
+        std::vector<unsigned long long> hs((size_t)nchr * 2);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs.data(), sumCnt, (size_t)nchr * 16, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // MeanFragmentSize (CanvasBin.cs:164-174): NonZeroMean of the per-chromosome NonZeroMeans, all in Int16 with integer division
+        long long s2 = 0, c2 = 0;
+        for (int c = 0; c < nchr; c++) { int16_t m = hs[2 * c + 1] ? (int16_t)(hs[2 * c] / hs[2 * c + 1]) : 0; if (m > 0) { s2 += m; c2++; } }
+        const int meanFrag = c2 ? (int)(int16_t)(s2 / c2) : 0;
+        if (meanFrag <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "CNV input error - unable to determine fragment size (CanvasBin.cs:431-434)");
+        for (int c = 0; c < nchr; c++) {
+            const int64_t nt = (h_len[c] + TILE - 1) / TILE;
+            hipLaunchKernelGGL(k_gcp_tile, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, d_bases[c], h_len[c], tileCnt);
+            hipLaunchKernelGGL(k_gcp_scan, dim3(1), dim3(1024), 0, ctx->stream, tileCnt, nt);
+            hipLaunchKernelGGL(k_gcp_write, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, d_bases[c], h_len[c], tileCnt, P);
+            hipLaunchKernelGGL(k_read_gc, dim3(2048), dim3(256), 0, ctx->stream, P, d_fraglen[c], d_hits[c], h_len[c], meanFrag, (uint8_t*)gch[c].readGc, hist, hist + 101);
+        }
+        unsigned long long hh[202];
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hh, hist, sizeof hh, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // observed vs expected (CanvasBin.cs:372-391)
+        long long sumObserved = 0, sumExpected = 0;
+        for (int b = 0; b < 101; b++) { sumExpected += (long long)hh[b]; sumObserved += (long long)hh[101 + b]; }
+        float w[101];
+        for (int b = 0; b < 101; b++) {
+            long long e = (long long)hh[b], o = (long long)hh[101 + b];
+            if (e == 0) e = 1;
+            if (o == 0) o = 1;
+            w[b] = ((float)o / (float)e) * ((float)sumExpected / (float)sumObserved);
+        }
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dW, w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dGch, gch.data(), nchr * sizeof(GcChrom), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // the bin arrays are sized by the caller's capacity (the bin size may not be known yet)
     const int64_t ub = cap;
     WsSizer sz;
@@ -529,6 +677,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
     hipLaunchKernelGGL(k_bin_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, stopTmp, locC, locG,
                        tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count);
+    if (gcw) hipLaunchKernelGGL(k_bin_weighted, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, d_count);
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
 }
@@ -538,7 +687,7 @@ int32_t canvas_bin_genome(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d
                           int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                           int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
     if (ctx && bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bin size must be positive");
-    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, h_len, nullptr, 0, bin_size, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total);
+    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, nullptr, 0, bin_size, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total);
 }
 
 int32_t canvas_bin_sample(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
@@ -546,8 +695,17 @@ int32_t canvas_bin_sample(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d
                           int32_t counts_per_bin, int32_t bin_size_in, int32_t mode,
                           int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                           int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
-    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, mode, d_chr, d_start, d_stop, d_gc, d_count, cap,
+    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, mode, d_chr, d_start, d_stop, d_gc, d_count, cap,
                            h_bin_size_out, h_nbins_per_chr, h_nbins_total);
+}
+
+int32_t canvas_bin_sample_gcweighted(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                                     const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len, const uint8_t* h_chr_is_autosome,
+                                     int32_t counts_per_bin, int32_t bin_size_in,
+                                     int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                     int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
+    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, d_fraglen, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, CANVAS_MODE_GC_CONTENT_WEIGHTED,
+                           d_chr, d_start, d_stop, d_gc, d_count, cap, h_bin_size_out, h_nbins_per_chr, h_nbins_total);
 }
 
 }  // extern "C"

@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
-    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample",
+    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
     "canvas_clean", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
@@ -172,6 +172,19 @@ class Canvas:
                                                C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),
                                                C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()), C.c_int64(out["chr"].numel()),
                                                C.byref(bs), _np_ptr(per), C.byref(total)))
+        self.synchronize()
+        return out, per, total.value, bs.value
+
+    def bin_sample_gcweighted(self, bases, masks, hits, fraglens, lens, is_autosome, counts_per_bin=100, bin_size=-1, out=None):
+        """CanvasBin -m GCContentWeighted (CanvasBin.cs:416-506,626-636)"""
+        n = len(bases)
+        lens = np.ascontiguousarray(lens, np.int64)
+        ia = np.ascontiguousarray(is_autosome, np.uint8)
+        per = np.zeros(n, np.int64); total = C.c_int64(0); bs = C.c_int32(0)
+        self._check(self.lib.canvas_bin_sample_gcweighted(self.ctx, n, _ptr_table(bases), _ptr_table(masks), _ptr_table(hits), _ptr_table(fraglens), _np_ptr(lens), _np_ptr(ia),
+                                                          counts_per_bin, bin_size, C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()),
+                                                          C.c_void_p(out["stop"].data_ptr()), C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()),
+                                                          C.c_int64(out["chr"].numel()), C.byref(bs), _np_ptr(per), C.byref(total)))
         self.synchronize()
         return out, per, total.value, bs.value
 

@@ -87,6 +87,15 @@ int32_t canvas_bin_sample(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d
                           int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                           int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
 
+/* GCContentWeighted mode (-m 5, Somatic-WGS): CanvasBin.cs:416-506 (read-GC profile from the per-position fragment lengths, mean
+ * fragment size), :330-405 (observed-vs-expected weights), :626-636 (count = Round(sum min(10, hit / weight[readGC])) in float32,
+ * position order).  d_fraglen = Int16 fragment length per position (0 = no read), one array per chromosome. */
+int32_t canvas_bin_sample_gcweighted(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                                     const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len,
+                                     const uint8_t* h_chr_is_autosome, int32_t counts_per_bin, int32_t bin_size_in,
+                                     int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                     int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+
 /* ---- CanvasClean --------------------------------------------------------------------------------------------- */
 /* CanvasClean.Main (CanvasClean/CanvasClean.cs:415-533) on the whole-genome SoA in file order, in place; bins that
  * survive are compacted to the front, *h_n_out = surviving count.  h_chr_is_autosome[nchr] answers

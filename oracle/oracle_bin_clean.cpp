@@ -136,6 +136,75 @@ int64_t bin_chromosome(const uint8_t* bases, const uint8_t* mask, const uint8_t*
     return nb;
 }
 
+// ---- GCContentWeighted mode (CanvasBin.cs:416-506, 330-405, 626-636)
+// Utilities.NonZeroMean(Int16[]) (CanvasCommon/Utilities.cs:135-151)
+static int16_t NonZeroMean(const int16_t* x, int64_t n) {
+    long long sum = 0, counter = 0;
+    for (int64_t i = 0; i < n; i++) if (x[i] > 0) { sum += x[i]; counter++; }
+    if (counter == 0) return 0;
+    return (int16_t)(sum / counter);
+}
+// MeanFragmentSize (CanvasBin.cs:164-174)
+int16_t mean_fragment_size(int nchr, const int16_t* const* fl, const int64_t* len) {
+    std::vector<int16_t> means;
+    for (int c = 0; c < nchr; c++) means.push_back(NonZeroMean(fl[c], len[c]));
+    return NonZeroMean(means.data(), (int64_t)means.size());
+}
+// read GC content per position (CanvasBin.cs:451-500)
+void read_gc_content(const uint8_t* bases, const int16_t* fl, int64_t L, int meanFragmentSize, uint8_t* gcContent) {
+    const int meanFragmentCutoff = 3;
+    const uint8_t gcCap = 101;
+    for (int64_t i = 0; i < L; i++) gcContent[i] = 0;
+    for (int64_t pos = 0; pos < L - (int64_t)meanFragmentSize * meanFragmentCutoff - 1; pos++) {
+        int16_t currentFragment;
+        if (fl[pos] == 0) currentFragment = (int16_t)meanFragmentSize;
+        else currentFragment = (int16_t)std::min((int)fl[pos], meanFragmentSize * meanFragmentCutoff);
+        uint32_t gcCounter = 0;
+        for (int64_t i = pos; i < pos + currentFragment; i++) switch (bases[i]) { case 'C': case 'c': case 'G': case 'g': gcCounter++; break; default: break; }
+        long long v = (long long)100 * (long long)gcCounter / (long long)currentFragment;
+        gcContent[pos] = (uint8_t)std::min<long long>(v, gcCap);
+    }
+}
+// ComputeObservedVsExpectedGC (CanvasBin.cs:330-405), manifest == null
+void observed_vs_expected_gc(int nchr, const uint8_t* const* readGC, const uint8_t* const* hits, const int64_t* len, float* out101) {
+    long long expectedC[101] = {0}, observedC[101] = {0};
+    for (int c = 0; c < nchr; c++) for (int64_t i = 0; i < len[c]; i++) { expectedC[readGC[c][i]]++; observedC[readGC[c][i]] += hits[c][i]; }
+    long long sumObserved = 0, sumExpected = 0;
+    for (int b = 0; b < 101; b++) { sumObserved += observedC[b]; sumExpected += expectedC[b]; }
+    for (int b = 0; b < 101; b++) {
+        if (expectedC[b] == 0) expectedC[b] = 1;
+        if (observedC[b] == 0) observedC[b] = 1;
+        out101[b] = ((float)observedC[b] / (float)expectedC[b]) * ((float)sumExpected / (float)sumObserved);
+    }
+}
+// BinCountsForChromosome, GCContentWeighted branch (CanvasBin.cs:626-636): float32 accumulation in position order, Math.Round half-even (Q5)
+int64_t bin_chromosome_weighted(const uint8_t* bases, const uint8_t* mask, const uint8_t* hits, const uint8_t* readGC, const float* obsVsExp, int64_t len, int binSize,
+                                int64_t cap, int32_t* start, int32_t* stop, int32_t* gc, int32_t* count) {
+    int64_t pos = 0;
+    while (pos < len && bases[pos] == 'n') pos++;
+    int NucleotideCount = 0, GCCount = 0, PossibleCount = 0;
+    float tmpObservedCount = 0;
+    int64_t StartPosition = -1, nb = 0;
+    for (; pos < len; pos++) {
+        if (StartPosition == -1) StartPosition = pos;
+        NucleotideCount++;
+        switch (bases[pos]) { case 'C': case 'c': case 'G': case 'g': GCCount++; break; default: break; }
+        if ((mask[pos >> 3] >> (pos & 7)) & 1) {
+            PossibleCount++;
+            float q = (float)(int)hits[pos] / obsVsExp[readGC[pos]];
+            tmpObservedCount += std::min(10.0f, q);       // Math.Min(10, float): the int literal widens to float
+        }
+        if (PossibleCount == binSize) {
+            int obs = (int)round_half_even((double)tmpObservedCount);
+            float gcf = 100.0f * (float)GCCount; gcf = gcf / (float)NucleotideCount;
+            if (nb < cap) { start[nb] = (int32_t)StartPosition; stop[nb] = (int32_t)(pos + 1); gc[nb] = (int)gcf; count[nb] = obs; }
+            nb++;
+            NucleotideCount = GCCount = PossibleCount = 0; tmpObservedCount = 0; StartPosition = -1;
+        }
+    }
+    return nb;
+}
+
 // ------------------------------------------------------------------ CanvasClean
 struct Bins {
     std::vector<int32_t> chr, start, stop, gc;

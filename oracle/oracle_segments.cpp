@@ -75,6 +75,13 @@ void orc_bin_rates_genome(int nchr, const uint8_t* const* mask, const uint8_t* c
     for (auto& t : th) t.join();
 }
 
+int orc_mean_fragment_size(int nchr, const int16_t* const* fl, const int64_t* len) { return mean_fragment_size(nchr, fl, len); }
+void orc_read_gc_content(const uint8_t* bases, const int16_t* fl, int64_t L, int meanFrag, uint8_t* out) { read_gc_content(bases, fl, L, meanFrag, out); }
+void orc_observed_vs_expected_gc(int nchr, const uint8_t* const* readGC, const uint8_t* const* hits, const int64_t* len, float* out101) { observed_vs_expected_gc(nchr, readGC, hits, len, out101); }
+int64_t orc_bin_chromosome_weighted(const uint8_t* bases, const uint8_t* mask, const uint8_t* hits, const uint8_t* readGC, const float* w, int64_t len, int binSize,
+                                    int64_t cap, int32_t* start, int32_t* stop, int32_t* gc, int32_t* count) {
+    return bin_chromosome_weighted(bases, mask, hits, readGC, w, len, binSize, cap, start, stop, gc, count);
+}
 int64_t orc_clean(int64_t n, int32_t* chr, int32_t* start, int32_t* stop, float* count, int32_t* gc, int nchr,
                   const uint8_t* isAuto, const uint8_t* isY, uint32_t flags, int minBinsWeighted, double* localSdOut, int32_t* stageCounts) {
     return clean(n, chr, start, stop, count, gc, nchr, isAuto, isY, flags, minBinsWeighted, localSdOut, stageCounts);

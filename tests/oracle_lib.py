@@ -21,6 +21,7 @@ def _load():
     lib = C.CDLL(_SO)
     lib.orc_bin_rate.restype = C.c_double
     lib.orc_bin_chromosome.restype = C.c_int64
+    lib.orc_bin_chromosome_weighted.restype = C.c_int64
     lib.orc_clean.restype = C.c_int64
     lib.orc_median_f32.restype = C.c_float
     lib.orc_golden_section_square.restype = C.c_double
@@ -63,6 +64,27 @@ def bin_chromosome(bases, mask, hits, bin_size, mode=3):
     out = [np.zeros(cap, np.int32) for _ in range(4)]
     n = lib.orc_bin_chromosome(_p(bases), _p(mask), _p(hits), C.c_int64(L), bin_size, mode, C.c_int64(cap), *[_p(o) for o in out])
     return [o[:n].copy() for o in out]
+
+
+def bin_gc_weighted(bases, masks, hits, fraglens, bin_size):
+    """GCContentWeighted binning of a genome (CanvasBin.cs:416-506,626-636): returns (per-chromosome [start,stop,gc,count], mean fragment, weights)"""
+    nchr = len(bases)
+    lens = np.array([len(b) for b in bases], np.int64)
+    m = lib.orc_mean_fragment_size(nchr, _pp(fraglens), _p(lens))
+    rgc = []
+    for c in range(nchr):
+        g = np.zeros(len(bases[c]), np.uint8)
+        lib.orc_read_gc_content(_p(bases[c]), _p(fraglens[c]), C.c_int64(len(bases[c])), m, _p(g))
+        rgc.append(g)
+    w = np.zeros(101, np.float32)
+    lib.orc_observed_vs_expected_gc(nchr, _pp(rgc), _pp(hits), _p(lens), _p(w))
+    res = []
+    for c in range(nchr):
+        L = len(bases[c]); cap = L // max(1, bin_size) + 2
+        out = [np.zeros(cap, np.int32) for _ in range(4)]
+        n = lib.orc_bin_chromosome_weighted(_p(bases[c]), _p(masks[c]), _p(hits[c]), _p(rgc[c]), _p(w), C.c_int64(L), bin_size, C.c_int64(cap), *[_p(o) for o in out])
+        res.append([o[:n].copy() for o in out])
+    return res, m, w, rgc
 
 
 def bin_genome(bases, masks, hits, bin_size, mode=3, threads=1):

@@ -144,3 +144,29 @@ def test_prep_kernels_mask_filter_screen():
         dh = to_dev(pad16(hits), cv.device)
         cv.screen_hits(dh, dmask, L)
         assert (dh.cpu().numpy()[:L] == np.where(exp, hits, 0)).all()
+
+
+def test_bin_gc_content_weighted_mode():
+    """CanvasBin -m GCContentWeighted (CanvasBin.cs:416-506, 330-405, 626-636) vs the oracle"""
+    import torch
+    cv = get_canvas()
+    lengths = [700_000, 410_001]
+    data = _chroms(lengths, rate=0.21)
+    rng = np.random.RandomState(31)
+    fl = [np.where(h > 0, np.clip(rng.normal(350, 60, len(h)), 1, 5000), 0).astype(np.int16) for b, h, m in data]
+    fl[0][1000:1100] = 32767      # clipped at 3 x mean fragment
+    bases, hits, masks = _upload(cv, data)
+    dfl = [to_dev(pad16(f), cv.device) for f in fl]
+    lens = np.array(lengths, np.int64)
+    cap = int(lens.sum() // 50)
+    out = dict(chr=torch.empty(cap, dtype=torch.int32, device=cv.device), start=torch.empty(cap, dtype=torch.int32, device=cv.device),
+               stop=torch.empty(cap, dtype=torch.int32, device=cv.device), gc=torch.empty(cap, dtype=torch.int32, device=cv.device),
+               count=torch.empty(cap, dtype=torch.float32, device=cv.device))
+    for bs in (480, 90):
+        exp, mfrag, w, _ = O.bin_gc_weighted([d[0] for d in data], [d[2] for d in data], [d[1] for d in data], fl, bs)
+        o, per, total, bsz = cv.bin_sample_gcweighted(bases, masks, hits, dfl, lens, [1, 1], 100, bs, out=out)
+        assert total == sum(len(e[0]) for e in exp)
+        assert (out["stop"][:total].cpu().numpy() == np.concatenate([e[1] for e in exp])).all()
+        assert (out["gc"][:total].cpu().numpy() == np.concatenate([e[2] for e in exp])).all()
+        got = out["count"][:total].cpu().numpy(); ex = np.concatenate([e[3] for e in exp]).astype(np.float32)
+        assert (got == ex).all(), (np.nonzero(got != ex)[0][:5], got[got != ex][:5], ex[got != ex][:5])
