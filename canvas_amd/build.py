@@ -75,7 +75,30 @@ def build(force=False, verbose=False):
     s2 = [os.path.join(CSRC, "synth.hip")]
     if force or _stale(out2, s2):
         _compile_and_link(hipcc, s2, out2, [], verbose)
+    build_tools(force=force, verbose=verbose)
     return out, out2
+
+
+def build_tools(force=False, verbose=False):
+    """drop-in tool drivers (plain C++ over the C ABI + zlib): canvas_amd/bin/CanvasClean, canvas_amd/bin/CanvasPartition"""
+    tdir = os.path.join(HERE, "tools")
+    bdir = os.path.join(HERE, "bin")
+    os.makedirs(bdir, exist_ok=True)
+    tl = _torch_lib_dir()
+    outs = []
+    for name, src in (("CanvasClean", "canvas_clean_main.cpp"), ("CanvasPartition", "canvas_partition_main.cpp")):
+        out = os.path.join(bdir, name)
+        srcs = [os.path.join(tdir, src), os.path.join(tdir, "tool_common.hpp")]
+        if force or not os.path.exists(out) or any(os.path.getmtime(x) > os.path.getmtime(out) for x in srcs + [os.path.join(HERE, "libcanvas_hip.so")]):
+            cmd = ["g++", "-O2", "-std=c++17", "-o", out, srcs[0], "-L" + HERE, "-lcanvas_hip", "-lz", "-Wl,-rpath," + HERE]
+            for d in ([tl] if tl else []) + ["/opt/rocm/lib"]:
+                cmd += ["-L" + d, "-Wl,-rpath," + d]
+            cmd += ["-lamdhip64", "-lrccl"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        outs.append(out)
+    return outs
 
 
 if __name__ == "__main__":

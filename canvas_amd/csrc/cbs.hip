@@ -205,7 +205,7 @@ static inline void sig(KI a, int i, int j) { if (i != j && a.k[i] > a.k[j]) { st
 static void ins(KI a, int lo, int hi) { for (int i = lo; i < hi; i++) { int j = i; double t = a.k[i + 1]; int tv = a.v[i + 1]; while (j >= lo && t < a.k[j]) { a.k[j + 1] = a.k[j]; a.v[j + 1] = a.v[j]; j--; } a.k[j + 1] = t; a.v[j + 1] = tv; } }
 static void dheap(KI a, int i, int n, int lo) { double d = a.k[lo + i - 1]; int dv = a.v[lo + i - 1]; while (i <= n / 2) { int c = 2 * i; if (c < n && a.k[lo + c - 1] < a.k[lo + c]) c++; if (a.k[lo + c - 1] < d) break; a.k[lo + i - 1] = a.k[lo + c - 1]; a.v[lo + i - 1] = a.v[lo + c - 1]; i = c; } a.k[lo + i - 1] = d; a.v[lo + i - 1] = dv; }
 static void hsort(KI a, int lo, int hi) { int n = hi - lo + 1; for (int i = n / 2; i >= 1; i--) dheap(a, i, n, lo); for (int i = n; i > 1; i--) { sw(a, lo, lo + i - 1); dheap(a, 1, i - 1, lo); } }
-static int part(KI a, int lo, int hi) { int mid = lo + (hi - lo) / 2; sig(a, lo, mid); sig(a, lo, hi); sig(a, mid, hi); double pv = a.k[mid]; sw(a, mid, hi - 1); int l = lo, r = hi - 1; while (l < r) { while (pv > a.k[++l]) ; while (pv < a.k[--r]) ; if (l >= r) break; sw(a, l, r); } sw(a, l, hi - 1); return l; }
+static int part(KI a, int lo, int hi) { int mid = lo + (hi - lo) / 2; sig(a, lo, mid); sig(a, lo, hi); sig(a, mid, hi); double pv = a.k[mid]; sw(a, mid, hi - 1); int l = lo, r = hi - 1; while (l < r) { while (pv > a.k[++l]) {} while (pv < a.k[--r]) {} if (l >= r) break; sw(a, l, r); } sw(a, l, hi - 1); return l; }
 static void intro(KI a, int lo, int hi, int depth) {
     while (hi > lo) {
         int ps = hi - lo + 1;

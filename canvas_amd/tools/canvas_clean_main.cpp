@@ -1,0 +1,58 @@
+// Drop-in CanvasClean executable on top of the C ABI: same CLI and file formats as CanvasClean.Main (CanvasClean/CanvasClean.cs:415-533).
+//   CanvasClean -i S.binned -o S.cleaned [-g] [-s] [-r] [--local-sd-metric-file F] [-w N] [-m MedianByGC]
+// Exit codes follow the reference: help / missing -i,-o -> 0 (:455-465); missing input file -> 1 (:468-472); unknown arguments throw.
+#include "tool_common.hpp"
+using namespace tool;
+
+int main(int argc, char** argv) {
+    printf(">>>Command-line arguments:\n"); for (int i = 1; i < argc; i++) printf("%s ", argv[i]); printf("\n");   // Utilities.LogCommandLine
+    std::vector<Opt> opts = {{"i", "infile", true}, {"o", "outfile", true}, {"g", "gcnorm", false}, {"s", "filtsize", false}, {"r", "outliers", false},
+                             {"", "local-sd-metric-file", true}, {"t", "manifest", true}, {"w", "weightedmedian", true}, {"m", "mode", true}, {"h", "help", false}};
+    Parsed a = parse(argc, argv, opts);
+    if (!a.extra.empty()) { fprintf(stderr, "Unknown arguments: %s\n", a.extra[0].c_str()); return 2; }
+    auto help = []() { printf("Usage: CanvasClean.exe [OPTIONS]+\nCorrect bin counts based on genomic parameters\n\nOptions:\n  -i, --infile=VALUE  -o, --outfile=VALUE  -g, --gcnorm  -s, --filtsize  -r, --outliers\n"
+                              "      --local-sd-metric-file=VALUE  -t, --manifest=VALUE  -w, --weightedmedian=VALUE  -m, --mode=VALUE  -h, --help\n"); };
+    if (a.has("help") || !a.has("infile") || !a.has("outfile")) { help(); return 0; }
+    const std::string inFile = a.get("infile"), outFile = a.get("outfile");
+    if (!file_exists(inFile)) { printf("CanvasClean.exe: File %s does not exist! Exiting.\n", inFile.c_str()); return 1; }
+    std::string mode = a.get("mode", "medianbygc"); for (auto& c : mode) c = (char)tolower(c);
+    uint32_t flags = (a.has("gcnorm") ? CANVAS_CLEAN_GCNORM : 0) | (a.has("filtsize") ? CANVAS_CLEAN_FILTSIZE : 0) | (a.has("outliers") ? CANVAS_CLEAN_OUTLIERS : 0) |
+                     (a.has("local-sd-metric-file") ? CANVAS_CLEAN_LOCALSD : 0);
+    if (mode == "loess") flags |= CANVAS_CLEAN_LOESS; else if (mode != "medianbygc") { fprintf(stderr, "Invalid CanvasClean mode '%s'\n", mode.c_str()); return 2; }
+    if (a.has("manifest")) { fprintf(stderr, "CanvasClean (MI355X): -t/--manifest is not supported by this build\n"); return 1; }
+    int minBins = a.has("weightedmedian") ? atoi(a.get("weightedmedian").c_str()) : 100;
+
+    // CanvasIO.ReadFromTextFile (CanvasCommon/IO.cs:26-52)
+    std::vector<std::string> chromNames; std::map<std::string, int> chromIndex;
+    std::vector<int32_t> chr, start, stop, gc; std::vector<float> count;
+    { GzReader rd(inFile); std::string row;
+      while (rd.line(row)) { auto f = split_tab(row); if (f.size() < 5) continue;
+          auto it = chromIndex.find(f[0]); int ci; if (it == chromIndex.end()) { ci = (int)chromNames.size(); chromIndex[f[0]] = ci; chromNames.push_back(f[0]); } else ci = it->second;
+          chr.push_back(ci); start.push_back(atoi(f[1].c_str())); stop.push_back(atoi(f[2].c_str())); count.push_back((float)strtod(f[3].c_str(), nullptr)); gc.push_back(atoi(f[4].c_str())); } }
+    const int64_t n = (int64_t)chr.size(); const int nchr = (int)chromNames.size();
+    std::vector<uint8_t> isAuto(nchr > 0 ? nchr : 1, 0);
+    for (int c = 0; c < nchr; c++) isAuto[c] = is_autosome(chromNames[c]);
+    // chromosome indices must be non-decreasing for the library (bins grouped by chromosome in file order): first-appearance indexing gives that
+    int64_t nOut = n; double localSd = -1.0;
+    if (n > 0) {
+        canvas_ctx* ctx = canvas_create(0);
+        if (!ctx) { fprintf(stderr, "CanvasClean (MI355X): no usable GPU (this build has no CPU fallback)\n"); return 1; }
+        { Dev dChr(ctx, n * 4), dStart(ctx, n * 4), dStop(ctx, n * 4), dCount(ctx, n * 4), dGc(ctx, n * 4);
+          TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dChr.p, chr.data(), n * 4)); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dStart.p, start.data(), n * 4));
+          TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dStop.p, stop.data(), n * 4)); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCount.p, count.data(), n * 4));
+          TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dGc.p, gc.data(), n * 4));
+          int32_t info[8];
+          TOOL_TRY(ctx, canvas_clean(ctx, n, dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dCount.as<float>(), dGc.as<int32_t>(), nchr, isAuto.data(), flags, minBins,
+                                    &localSd, &nOut, info));
+          TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, chr.data(), dChr.p, nOut * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, start.data(), dStart.p, nOut * 4));
+          TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, stop.data(), dStop.p, nOut * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, count.data(), dCount.p, nOut * 4));
+          TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, gc.data(), dGc.p, nOut * 4)); }
+        canvas_destroy(ctx);
+    }
+    // CanvasIO.WriteLocalSdMetricToTextFile (IO.cs:83-98) — only when the metric was computed (>= 50000 bins, CanvasClean.cs:483-494)
+    if (a.has("local-sd-metric-file") && localSd >= 0) { FILE* f = fopen(a.get("local-sd-metric-file").c_str(), "wb"); if (f) { fprintf(f, "#localSD\t%s\n", format_g(localSd, 15).c_str()); fclose(f); } }
+    // CanvasIO.WriteToTextFile (IO.cs:15-24)
+    { GzWriter wr(outFile); if (!wr.ok()) { fprintf(stderr, "cannot write %s\n", outFile.c_str()); return 1; }
+      for (int64_t i = 0; i < nOut; i++) wr.line(chromNames[chr[i]] + "\t" + std::to_string(start[i]) + "\t" + std::to_string(stop[i]) + "\t" + format_f2(count[i]) + "\t" + std::to_string(gc[i])); }
+    return 0;
+}

@@ -1,0 +1,151 @@
+// Drop-in CanvasPartition executable on top of the C ABI: CLI and file formats of CanvasPartition.Main (CanvasPartition/CanvasPartition.cs:24-190).
+//   CanvasPartition -i S.cleaned [-i ...] -o S.partitioned [-o ...] -r refDir -m PerSampleHMM|CBS [-b filter.bed] [-s None|SDUndo] [--config params.json]
+// Built methods: PerSampleHMM and CBS.  Wavelets (the reference default) / HMM (joint) / -c / -p are not built: exit code 1 with a message.
+#include "tool_common.hpp"
+#include <algorithm>
+#include <set>
+using namespace tool;
+
+struct Sample {
+    std::vector<std::string> chromNames; std::vector<int64_t> off;           // CoverageInfo in file order
+    std::vector<uint32_t> start, end; std::vector<double> cov;
+};
+
+// GenomicBinFilter.SkipBin (CanvasCommon/GenomicBinFilter.cs:29-58)
+struct BinFilter {
+    const std::map<std::string, std::vector<std::pair<int, int>>>* excl; std::string prevChrom; bool havePrev = false; uint32_t prevStart = 0; const std::vector<std::pair<int, int>>* iv = nullptr; size_t idx = 0;
+    bool skip(const std::string& chrom, uint32_t start, uint32_t stop) {
+        static const std::vector<std::pair<int, int>> none;
+        if (!havePrev || chrom != prevChrom) { prevChrom = chrom; havePrev = true; auto it = excl->find(chrom); iv = it == excl->end() ? &none : &it->second; idx = 0; }
+        else if (start < prevStart) idx = 0;
+        prevStart = start;
+        for (; idx < iv->size(); idx++) { if ((uint32_t)(*iv)[idx].second <= start) continue; if ((uint32_t)(*iv)[idx].first >= stop) return false; return true; }
+        return false;
+    }
+};
+
+int main(int argc, char** argv) {
+    printf(">>>Command-line arguments:\n"); for (int i = 1; i < argc; i++) printf("%s ", argv[i]); printf("\n");
+    std::vector<Opt> opts = {{"i", "infile", true}, {"v", "vaffile", true}, {"o", "outfile", true}, {"m", "method", true}, {"r", "reference", true}, {"s", "split", true},
+                             {"b", "bedfile", true}, {"c", "commoncnvs", true}, {"g", "germline", false}, {"", "evenness-metric-file", true}, {"p", "ploidyVcfFile", true},
+                             {"", "config", true}, {"h", "help", false}};
+    Parsed a = parse(argc, argv, opts);
+    if (!a.extra.empty()) { fprintf(stderr, "Unknown arguments: %s\n", a.extra[0].c_str()); return 2; }
+    auto help = []() { printf("Usage: CanvasPartition.exe [OPTIONS]+\nDivide bins into consistent intervals based on their counts\n\nOptions:\n  -i, --infile=VALUE (repeatable)  -o, --outfile=VALUE (repeatable)  -m, --method=VALUE  -r, --reference=VALUE\n"
+                              "  -s, --split=VALUE  -b, --bedfile=VALUE  -c, --commoncnvs=VALUE  -g, --germline  --evenness-metric-file=VALUE  -p, --ploidyVcfFile=VALUE  --config=VALUE  -h, --help\n"); };
+    auto inFiles = a.all("infile"), outFiles = a.all("outfile");
+    if (a.has("help") || inFiles.empty() || outFiles.empty() || !a.has("reference")) { help(); return 0; }     // CanvasPartition.cs:66-76
+    for (auto& f : inFiles) if (!file_exists(f)) { printf("CanvasPartition.exe: File %s does not exist! Exiting.\n", f.c_str()); return 1; }
+    const std::string bed = a.get("bedfile");
+    if (!bed.empty() && !file_exists(bed)) { printf("CanvasPartition.exe: File %s does not exist! Exiting.\n", bed.c_str()); return 1; }
+    std::string method = a.get("method", "Wavelets");
+    if (method != "PerSampleHMM" && method != "CBS") { fprintf(stderr, "CanvasPartition (MI355X): method %s is not built (PerSampleHMM and CBS are)\n", method.c_str()); return 1; }
+    if (a.has("ploidyVcfFile") || a.has("commoncnvs")) { fprintf(stderr, "CanvasPartition (MI355X): -p / -c are not supported by this build\n"); return 1; }
+    if (inFiles.size() != outFiles.size()) { fprintf(stderr, "CanvasPartition: the number of -o must match the number of -i\n"); return 1; }
+    std::string split = a.get("split", "None");
+    int undo = split == "None" ? 0 : (split == "SDUndo" ? 2 : (split == "Prune" ? 1 : -1));
+    if (undo < 0) { fprintf(stderr, "Invalid split method '%s'\n", split.c_str()); return 2; }
+    // CanvasPartitionParameters.json (CanvasPartitionParameters.cs:11-16): only the two values this path uses
+    int maxInterBinDist = 1000000; double cbsAlpha = 0.01;
+    if (a.has("config")) { FILE* f = fopen(a.get("config").c_str(), "rb"); if (!f) { printf("CanvasPedigreeCaller.exe: File %s does not exist! Exiting.\n", a.get("config").c_str()); return 1; }
+        std::string js; char buf[4096]; size_t k; while ((k = fread(buf, 1, sizeof buf, f)) > 0) js.append(buf, k); fclose(f);
+        auto num = [&](const char* key, double d) { size_t p = js.find(key); if (p == std::string::npos) return d; p = js.find(':', p); return p == std::string::npos ? d : strtod(js.c_str() + p + 1, nullptr); };
+        maxInterBinDist = (int)num("\"MaxInterBinDistInSegment\"", maxInterBinDist); cbsAlpha = num("\"CBSalpha\"", cbsAlpha); }
+    std::map<std::string, std::vector<std::pair<int, int>>> excluded;
+    if (!bed.empty()) load_bed(bed, excluded);
+
+    // CanvasSegment.ReadBedInput (CanvasCommon/CanvasSegment.cs:1117-1163)
+    std::vector<Sample> samples(inFiles.size());
+    for (size_t s = 0; s < inFiles.size(); s++) {
+        Sample& S = samples[s]; BinFilter filt; filt.excl = &excluded;
+        std::map<std::string, int> index; std::vector<std::vector<uint32_t>> st, en; std::vector<std::vector<double>> cv;
+        GzReader rd(inFiles[s]); std::string row;
+        while (rd.line(row)) { auto f = split_tab(row); if (f.size() < 4) continue;
+            uint32_t b = (uint32_t)strtoul(f[1].c_str(), nullptr, 10), e = (uint32_t)strtoul(f[2].c_str(), nullptr, 10);
+            if (filt.skip(f[0], b, e)) continue;
+            auto it = index.find(f[0]); int ci; if (it == index.end()) { ci = (int)S.chromNames.size(); index[f[0]] = ci; S.chromNames.push_back(f[0]); st.emplace_back(); en.emplace_back(); cv.emplace_back(); } else ci = it->second;
+            st[ci].push_back(b); en[ci].push_back(e); cv[ci].push_back(strtod(f[3].c_str(), nullptr)); }
+        S.off.push_back(0);
+        for (size_t c = 0; c < S.chromNames.size(); c++) { S.start.insert(S.start.end(), st[c].begin(), st[c].end()); S.end.insert(S.end.end(), en[c].begin(), en[c].end()); S.cov.insert(S.cov.end(), cv[c].begin(), cv[c].end()); S.off.push_back((int64_t)S.start.size()); }
+    }
+    canvas_ctx* ctx = canvas_create(0);
+    if (!ctx) { fprintf(stderr, "CanvasPartition (MI355X): no usable GPU (this build has no CPU fallback)\n"); return 1; }
+    // per sample: segments per chromosome as (start, end) genomic pairs
+    typedef std::vector<std::pair<uint32_t, uint32_t>> Segs;
+    std::vector<std::map<std::string, Segs>> segBySample(samples.size());
+    for (size_t s = 0; s < samples.size(); s++) {
+        Sample& S = samples[s]; const int nchr = (int)S.chromNames.size(); const int64_t N = S.off.back();
+        if (N == 0) continue;
+        Dev dCov(ctx, N * 8); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCov.p, S.cov.data(), N * 8));
+        if (method == "PerSampleHMM") {
+            printf("Running Per-sample HMM Partitioning\n");
+            Dev dState(ctx, N * 4);
+            TOOL_TRY(ctx, canvas_hmm_per_sample(ctx, nchr, dCov.as<double>(), S.off.data(), dState.as<int32_t>()));
+            std::vector<int32_t> state(N); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, state.data(), dState.p, N * 4));
+            for (int c = 0; c < nchr; c++) {
+                int64_t b0 = S.off[c], T = S.off[c + 1] - b0;
+                if (!(T > 10)) continue;                                     // chromosome skipped: no entry in segmentByChr (HiddenMarkovModelsRunner.cs:69)
+                std::vector<int> bp = {0};
+                for (int64_t i = 1; i < T; i++) if (state[b0 + i] != state[b0 + i - 1]) bp.push_back((int)i);
+                Segs sg;                                                      // SegmentationInput.DeriveSegments (Segmentation.cs:83-125)
+                if (bp.size() >= 2) { for (size_t k = 0; k < bp.size(); k++) { int64_t a0 = bp[k], a1 = (k + 1 < bp.size() ? bp[k + 1] : T) - 1; sg.push_back({S.start[b0 + a0], S.end[b0 + a1]}); } }
+                else sg.push_back({S.start[b0], S.end[b0 + T - 1]});
+                segBySample[s][S.chromNames[c]] = sg;
+            }
+        } else {
+            printf("Running CBS Partitioning\n");
+            Dev dLen(ctx, (N + 1) * 4); std::vector<int32_t> nseg(nchr); int64_t stats[8];
+            TOOL_TRY(ctx, canvas_cbs_undo(ctx, nchr, dCov.as<double>(), S.off.data(), cbsAlpha, 10000, undo, 3.0, dLen.as<int32_t>(), nseg.data(), stats));
+            std::vector<int32_t> lens(N + 1); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, lens.data(), dLen.p, (N + 1) * 4));
+            for (int c = 0; c < nchr; c++) {                                  // CBSRunner.cs:127-137
+                int64_t b0 = S.off[c]; Segs sg; int64_t cs1 = 0, cs2 = -1;
+                for (int k = 0; k < nseg[c]; k++) { cs2 += lens[b0 + k]; sg.push_back({S.start[b0 + cs1], S.end[b0 + cs2]}); cs1 += lens[b0 + k]; }
+                segBySample[s][S.chromNames[c]] = sg;
+            }
+        }
+    }
+    canvas_destroy(ctx);
+    // GenomeSegmentationResults.SplitOverlappingSegments (GenomeSegmentationResults.cs:18-55)
+    std::map<std::string, Segs> merged;
+    if (samples.size() == 1) merged = segBySample[0];
+    else for (auto& kv : segBySample[0]) {
+        const std::string& chrom = kv.first;
+        std::vector<std::vector<uint32_t>> st(samples.size()), en(samples.size()); std::vector<const uint32_t*> ps, pe; std::vector<int32_t> ns;
+        for (size_t s = 0; s < samples.size(); s++) { for (auto& sg : segBySample[s][chrom]) { st[s].push_back(sg.first); en[s].push_back(sg.second); } }
+        for (size_t s = 0; s < samples.size(); s++) { ps.push_back(st[s].data()); pe.push_back(en[s].data()); ns.push_back((int32_t)st[s].size()); }
+        int cap = 2; for (auto v : ns) cap += 2 * v;
+        std::vector<uint32_t> os(cap), oe(cap); int32_t nout = 0;
+        if (canvas_split_overlapping((int32_t)samples.size(), ps.data(), pe.data(), ns.data(), os.data(), oe.data(), cap, &nout) != 0) { fprintf(stderr, "canvas_split_overlapping failed\n"); return 1; }
+        Segs sg; for (int k = 0; k < nout; k++) sg.push_back({os[k], oe[k]});
+        merged[chrom] = sg;
+    }
+    // SegmentationResultsProcessor.PostProcessSegments (SegmentationResultsProcessor.cs:17-129) + WriteCanvasPartitionResults (Segmentation.cs:235-252)
+    for (size_t s = 0; s < samples.size(); s++) {
+        Sample& S = samples[s];
+        GzWriter wr(outFiles[s]); if (!wr.ok()) { fprintf(stderr, "cannot write %s\n", outFiles[s].c_str()); return 1; }
+        int segmentNum = -1;
+        for (size_t c = 0; c < S.chromNames.size(); c++) {
+            const std::string& chrom = S.chromNames[c];
+            std::set<uint32_t> starts; auto mit = merged.find(chrom); if (mit != merged.end()) for (auto& sg : mit->second) starts.insert(sg.first);
+            const std::vector<std::pair<int, int>>* ex = nullptr; auto eit = excluded.find(chrom); if (eit != excluded.end()) ex = &eit->second;
+            size_t exIdx = 0; uint32_t prevEnd = 0;
+            struct Row { uint32_t s, e; double cov; int id; }; std::vector<Row> rows;
+            for (int64_t b = S.off[c]; b < S.off[c + 1]; b++) {
+                uint32_t st = S.start[b], en = S.end[b];
+                bool newSeg = starts.count(st) > 0;
+                if (ex) { while (exIdx < ex->size() && (int64_t)(*ex)[exIdx].second < (int64_t)prevEnd) exIdx++;
+                    if (exIdx < ex->size()) { int mid = ((*ex)[exIdx].first + (*ex)[exIdx].second) / 2; if ((int64_t)prevEnd < mid && (int64_t)en >= mid) newSeg = true; } }
+                if (prevEnd > 0 && maxInterBinDist >= 0 && (int64_t)prevEnd + maxInterBinDist < (int64_t)st && !newSeg) newSeg = true;
+                if (newSeg) segmentNum++;
+                rows.push_back({st, en, S.cov[b], segmentNum});
+                prevEnd = en;
+            }
+            // bins of a segment are written ordered by start (SegmentWithBins.Bins, Models/SegmentWithBins.cs:11-14); OrderBy is stable
+            for (size_t g0 = 0; g0 < rows.size();) { size_t g1 = g0; while (g1 < rows.size() && rows[g1].id == rows[g0].id) g1++;
+                std::stable_sort(rows.begin() + g0, rows.begin() + g1, [](const Row& x, const Row& y) { return x.s < y.s; }); g0 = g1; }
+            for (auto& r : rows) wr.line(chrom + "\t" + std::to_string(r.s) + "\t" + std::to_string(r.e) + "\t" + format_g(r.cov, 15) + "\t" + std::to_string(r.id));
+        }
+    }
+    printf("CanvasPartition results written out\n");
+    return 0;
+}

@@ -1,0 +1,110 @@
+// Shared host code of the drop-in tool drivers (CanvasClean / CanvasPartition): option parsing in the reference's NDesk OptionSet
+// style, gzip text I/O of the intermediate files (CanvasCommon/IO.cs), .NET Core 2.x number formatting, and the
+// IsAutosome assumption (Isas.SequencingFiles is not in /root/reference: "optional chr prefix + integer").
+// The drivers use ONLY the C ABI of include/canvas_hip.h (what the C# hosts would P/Invoke).
+#pragma once
+#include <zlib.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/canvas_hip.h"
+
+namespace tool {
+
+// ---- NDesk.OptionSet-like parsing: -x value, -x=value, --long value, --long=value, /x value; flags without value
+struct Opt { std::string shortName, longName; bool takesValue; };
+struct Parsed { std::multimap<std::string, std::string> values; std::vector<std::string> extra; bool has(const std::string& k) const { return values.count(k) > 0; }
+    std::string get(const std::string& k, const std::string& d = "") const { auto it = values.find(k); return it == values.end() ? d : it->second; }
+    std::vector<std::string> all(const std::string& k) const { std::vector<std::string> r; auto rg = values.equal_range(k); for (auto it = rg.first; it != rg.second; ++it) r.push_back(it->second); return r; } };
+static Parsed parse(int argc, char** argv, const std::vector<Opt>& opts) {
+    Parsed p;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i], name, val; bool hasVal = false;
+        if (a.rfind("--", 0) == 0) name = a.substr(2); else if (a.size() > 1 && (a[0] == '-' || a[0] == '/')) name = a.substr(1); else { p.extra.push_back(a); continue; }
+        size_t eq = name.find_first_of("=:");
+        if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); hasVal = true; }
+        const Opt* o = nullptr;
+        for (auto& c : opts) if (c.shortName == name || c.longName == name) o = &c;
+        if (!o) { p.extra.push_back(a); continue; }
+        std::string key = o->longName.empty() ? o->shortName : o->longName;
+        if (o->takesValue) { if (!hasVal) { if (i + 1 < argc) val = argv[++i]; else { p.extra.push_back(a); continue; } } p.values.insert({key, val}); }
+        else p.values.insert({key, "1"});
+    }
+    return p;
+}
+
+// ---- gzip text
+struct GzReader { gzFile f; explicit GzReader(const std::string& path) { f = gzopen(path.c_str(), "rb"); } ~GzReader() { if (f) gzclose(f); }
+    bool ok() const { return f != nullptr; }
+    bool line(std::string& out) { out.clear(); char buf[1 << 16]; bool any = false;
+        while (gzgets(f, buf, sizeof buf)) { any = true; out += buf; if (!out.empty() && out.back() == '\n') break; }
+        while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
+        return any; } };
+struct GzWriter { gzFile f; explicit GzWriter(const std::string& path) { f = gzopen(path.c_str(), "wb"); } ~GzWriter() { if (f) gzclose(f); }
+    bool ok() const { return f != nullptr; } void line(const std::string& s) { gzwrite(f, s.data(), (unsigned)s.size()); gzputc(f, '\n'); } };
+static std::vector<std::string> split_tab(const std::string& s) { std::vector<std::string> r; size_t a = 0; for (;;) { size_t b = s.find('\t', a); r.push_back(s.substr(a, b == std::string::npos ? b : b - a)); if (b == std::string::npos) break; a = b + 1; } return r; }
+static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) { fclose(f); return true; } return false; }
+
+// ---- .NET Core 2.x formatting: float "F2" (7 significant digits, then half-up at 2 decimals) and double "G15"
+static void sig_digits(double v, int prec, std::string& digits, int& scale) {
+    char buf[64]; snprintf(buf, sizeof buf, "%.*e", prec - 1, std::fabs(v));
+    digits.clear(); const char* p = buf;
+    for (; *p && *p != 'e'; p++) if (*p >= '0' && *p <= '9') digits.push_back(*p);
+    scale = atoi(p + 1) + 1;
+    while (!digits.empty() && digits.back() == '0') digits.pop_back();
+    if (digits.empty()) scale = 0;
+}
+static std::string format_f2(float v) {
+    if (std::isnan(v)) return "NaN"; if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+    std::string d; int scale; sig_digits((double)v, 7, d, scale);
+    int pos = scale + 2;
+    if (pos < 0) d.clear();
+    else if (pos < (int)d.size()) { bool up = d[pos] >= '5'; d.resize(pos); if (up) { int i = pos - 1; while (i >= 0 && d[i] == '9') { d[i] = '0'; i--; } if (i >= 0) d[i]++; else { d.insert(d.begin(), '1'); scale++; } } }
+    std::string ip, fp;
+    for (int i = 0; i < scale; i++) ip.push_back(i < (int)d.size() ? d[i] : '0');
+    if (ip.empty()) ip = "0";
+    for (int i = 0; i < 2; i++) { int k = scale + i; fp.push_back(k >= 0 && k < (int)d.size() ? d[k] : '0'); }
+    bool zero = true; for (char c : ip + fp) if (c != '0') zero = false;
+    return std::string((std::signbit(v) && !zero) ? "-" : "") + ip + "." + fp;
+}
+static std::string format_g(double v, int prec) {
+    if (std::isnan(v)) return "NaN"; if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+    std::string d; int scale; sig_digits(v, prec, d, scale);
+    if (d.empty()) return "0";
+    std::string out = std::signbit(v) ? "-" : ""; int e10 = scale - 1;
+    if (e10 >= prec || e10 < -5) { out.push_back(d[0]); if (d.size() > 1) { out.push_back('.'); out += d.substr(1); } char eb[16]; snprintf(eb, sizeof eb, "E%c%02d", e10 < 0 ? '-' : '+', std::abs(e10)); return out + eb; }
+    if (scale <= 0) return out + "0." + std::string(-scale, '0') + d;
+    for (int i = 0; i < scale; i++) out.push_back(i < (int)d.size() ? d[i] : '0');
+    if ((int)d.size() > scale) { out.push_back('.'); out += d.substr(scale); }
+    return out;
+}
+
+static bool is_autosome(std::string name) {
+    if (name.rfind("chr", 0) == 0) name = name.substr(3);
+    if (name.empty()) return false;
+    for (char c : name) if (c < '0' || c > '9') return false;
+    return true;
+}
+
+// excluded intervals of a BED file (Utilities.LoadBedFile, CanvasCommon/Utilities.cs:793-829): chr -> (start, stop) in file order
+static bool load_bed(const std::string& path, std::map<std::string, std::vector<std::pair<int, int>>>& out) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
+    char buf[1 << 14];
+    while (fgets(buf, sizeof buf, f)) { std::string s(buf); while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back(); auto t = split_tab(s); if (t.size() < 3) continue; out[t[0]].push_back({atoi(t[1].c_str()), atoi(t[2].c_str())}); }
+    fclose(f); return true;
+}
+
+struct Dev {      // tiny RAII around the ABI's device memory
+    canvas_ctx* ctx; void* p = nullptr;
+    Dev(canvas_ctx* c, int64_t bytes) : ctx(c) { p = canvas_device_malloc(c, bytes > 0 ? bytes : 1); }
+    ~Dev() { if (p) canvas_device_free(ctx, p); }
+    template <class T> T* as() { return (T*)p; }
+};
+#define TOOL_TRY(ctx, expr) do { int32_t rc_ = (expr); if (rc_ != 0) { fprintf(stderr, "%s failed (%d): %s\n", #expr, rc_, canvas_last_error(ctx)); return 1; } } while (0)
+
+}  // namespace tool

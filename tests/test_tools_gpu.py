@@ -1,0 +1,103 @@
+"""The drop-in executables (canvas_amd/bin/CanvasClean, CanvasPartition): same CLI and gzip text files as the reference modules
+(SURVEY §8b); outputs compared byte for byte with rows built from the oracle."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from canvas_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "canvas_amd", "bin")
+NAMES = synth.CHROM_NAMES
+
+
+def _write_binned(path, bins):
+    with gzip.open(path, "wt") as f:
+        for c, s, e, n, g in zip(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"]):
+            f.write(f"{NAMES[c]}\t{s}\t{e}\t{O.format_f2(float(n))}\t{g}\n")
+
+
+def _read(path):
+    with gzip.open(path, "rt") as f:
+        return f.read().splitlines()
+
+
+def test_canvas_clean_and_partition_executables(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from canvas_amd import build
+    build.build()
+    nchr = 24
+    bins = synth.generate_bins(20260927 + 30, 70_000, nchr=nchr)
+    binned = str(tmp_path / "S.binned"); cleaned = str(tmp_path / "S.cleaned"); lsd = str(tmp_path / "S.localsd")
+    _write_binned(binned, bins)
+    r = subprocess.run([os.path.join(BIN, "CanvasClean"), "-i", binned, "-o", cleaned, "-g", "-s", "-r", "--local-sd-metric-file", lsd], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    flags = O.CLEAN_GCNORM | O.CLEAN_FILTSIZE | O.CLEAN_OUTLIERS | O.CLEAN_LOCALSD
+    is_y = np.zeros(nchr, np.uint8); is_y[-1] = 1
+    ex = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], synth.IS_AUTOSOME, is_y, flags)
+    exp_rows = [f"{NAMES[c]}\t{s}\t{e}\t{O.format_f2(float(n))}\t{g}" for c, s, e, n, g in zip(ex["chr"], ex["start"], ex["stop"], ex["count"], ex["gc"])]
+    got_rows = _read(cleaned)
+    assert got_rows == exp_rows
+    assert open(lsd).read() == "#localSD\t" + O.format_g15(ex["local_sd"]) + "\n"
+    # error conventions (CanvasClean.cs:455-472)
+    assert subprocess.run([os.path.join(BIN, "CanvasClean")], capture_output=True).returncode == 0
+    assert subprocess.run([os.path.join(BIN, "CanvasClean"), "-i", str(tmp_path / "missing"), "-o", cleaned], capture_output=True).returncode == 1
+
+    # ---- CanvasPartition on the cleaned file, with a filter BED
+    cov = np.array([float(r.split("\t")[3]) for r in exp_rows])
+    chrs = ex["chr"]; st = ex["start"].astype(np.uint32); en = ex["stop"].astype(np.uint32)
+    bed = str(tmp_path / "filter.bed")
+    rng = np.random.RandomState(2)
+    excl = {}
+    with open(bed, "w") as f:
+        for c in (0, 3, 7):
+            idx = np.nonzero(chrs == c)[0]
+            pick = np.sort(rng.choice(len(idx) - 2, 6, replace=False))
+            a = en[idx[pick]] + 1; b = a + 50        # inside the gap after a bin or overlapping the next bin
+            order = np.argsort(b, kind="stable")
+            excl[c] = (a[order].astype(np.int32), b[order].astype(np.int32))
+            for x, y in zip(a[order], b[order]):
+                f.write(f"{NAMES[c]}\t{x}\t{y}\n")
+    # bins overlapping a forbidden interval are dropped on read (GenomicBinFilter)
+    keep = np.ones(len(chrs), bool)
+    for c, (a, b) in excl.items():
+        for x, y in zip(a, b):
+            keep &= ~((chrs == c) & (st < y) & (en > x))
+    chrs, st, en, cov = chrs[keep], st[keep], en[keep], cov[keep]
+    off = np.concatenate([[0], np.cumsum(np.bincount(chrs, minlength=nchr))]).astype(np.int64)
+    per = [np.ascontiguousarray(cov[off[c]:off[c + 1]]) for c in range(nchr)]
+    bs = [np.ascontiguousarray(st[off[c]:off[c + 1]]) for c in range(nchr)]; be = [np.ascontiguousarray(en[off[c]:off[c + 1]]) for c in range(nchr)]
+    ex_list = [excl.get(c, (np.zeros(0, np.int32), np.zeros(0, np.int32))) for c in range(nchr)]
+
+    def rows_from(segstarts):
+        ids, _ = O.postprocess(bs, be, segstarts, ex_list, 1000000)
+        out = []
+        for c in range(nchr):
+            for s_, e_, v, i in zip(bs[c], be[c], per[c], ids[c]):
+                out.append(f"{NAMES[c]}\t{s_}\t{e_}\t{O.format_g15(float(v))}\t{i}")
+        return out
+
+    part = str(tmp_path / "S.partitioned")
+    r = subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-o", part, "-r", str(tmp_path), "-m", "PerSampleHMM", "-b", bed], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    paths, ran = O.hmm_genome_per_sample(per, threads=8)
+    exp = rows_from([O.segments_from_path(paths[c], ran[c], bs[c], be[c])[0] for c in range(nchr)])
+    assert _read(part) == exp
+
+    r = subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-o", part, "-r", str(tmp_path), "-m", "CBS", "-b", bed], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    segl, _ = O.cbs_genome(per, 0.01, 10000, threads=8)
+    segstarts = []
+    for c in range(nchr):
+        pos = np.concatenate([[0], np.cumsum(segl[c])[:-1]]).astype(np.int64) if len(segl[c]) else np.zeros(0, np.int64)
+        segstarts.append(bs[c][pos].astype(np.uint32) if len(pos) else np.zeros(0, np.uint32))
+    assert _read(part) == rows_from(segstarts)
+    # Wavelets (the reference default) is not built: explicit failure, not a silent fallback
+    assert subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-o", part, "-r", str(tmp_path)], capture_output=True).returncode == 1
