@@ -16,6 +16,7 @@
 // (CanvasClean.cs:107-132,226-228).
 #include "common.hpp"
 #include "select.hpp"
+#include "loess.hpp"
 #include <algorithm>
 #include <cmath>
 
@@ -438,12 +439,88 @@ static int32_t local_sd(CleanState& st, double* dSd, double* dRunMedian, int64_t
     return CANVAS_OK;
 }
 
-extern "C" int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
-                                int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
-                                double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info) {
+
+// NormalizeByGC, LOESS flavour (CanvasClean.cs:145-152 -> LoessGCNormalizer): see loess.hpp
+struct LoessModelDev { loess::Grouped G; std::vector<double> P; double medianY = 0; };
+static int32_t loess_build_model(CleanState& st, const uint8_t* dIsY, int excludeY, uint8_t* dKey, double* dY, double* dYg, double* dP, uint32_t* dTileHist, uint32_t* dKeyTot,
+                                 uint32_t* dGroupOff, double* dBlockSum, unsigned long long* dKeys64, unsigned int* dCnt, LoessModelDev& M) {
+    canvas_ctx* ctx = st.ctx;
+    const int64_t n = st.n;
+    const int ntiles = (int)nblk(n, LO_TILE);
+    hipLaunchKernelGGL(k_loess_keys, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.cur.gc, st.cur.chr, dIsY, excludeY, n, dKey, dY);
+    hipLaunchKernelGGL(k_loess_tile_hist, dim3(ntiles), dim3(256), 0, ctx->stream, dKey, n, dTileHist);
+    hipLaunchKernelGGL(k_loess_col_scan, dim3(128), dim3(1024), 0, ctx->stream, dTileHist, ntiles, dKeyTot);
+    uint32_t tot[128];
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(tot, dKeyTot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t goff[128]; int64_t acc = 0;
+    for (int g = 0; g < LO_NGC; g++) { M.G.off[g] = acc; goff[g] = (uint32_t)acc; acc += tot[g]; }
+    M.G.off[LO_NGC] = acc; M.G.n = acc;
+    for (int g = LO_NGC; g < 128; g++) goff[g] = (uint32_t)acc;
+    for (int g = 0; g < LO_NGC; g++) M.G.shift[g] = 0;
+    if (M.G.n < 2) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "LOESS: fewer than 2 usable bins");
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dGroupOff, goff, sizeof goff, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_loess_scatter, dim3(ntiles), dim3(64), 0, ctx->stream, dKey, dY, n, dTileHist, dGroupOff, dYg);
+    const int64_t m = M.G.n; const int nb = (int)nblk(m, LO_TILE);
+    hipLaunchKernelGGL(k_dscan_block, dim3(nb), dim3(256), 0, ctx->stream, dYg, m, dBlockSum);
+    hipLaunchKernelGGL(k_dscan_top, dim3(1), dim3(64), 0, ctx->stream, dBlockSum, nb);
+    hipLaunchKernelGGL(k_dscan_write, dim3(nb), dim3(64), 0, ctx->stream, dYg, m, dBlockSum, dP);
+    M.P.resize((size_t)m + 1);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(M.P.data(), dP, (size_t)(m + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // medianY = Utilities.Median(counts): exact order statistic of the model's y values (excluded elements carry +inf keys)
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCnt, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_loess_ykeys, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, dKey, dY, n, dKeys64, dCnt);
+    std::vector<SelQuery> qs;
+    if (m % 2) qs.push_back({0, 0, m / 2}); else { qs.push_back({0, 0, m / 2 - 1}); qs.push_back({0, 0, m / 2}); }
+    std::vector<unsigned long long> res;
+    int32_t rc = radix_select<unsigned long long>(ctx, dKeys64, 1, std::vector<int64_t>{0, n}, qs, res); if (rc) return rc;
+    M.medianY = (m % 2) ? host_double_of_key(res[0]) : (host_double_of_key(res[0]) + host_double_of_key(res[1])) / 2;
+    M.G.P = M.P.data();
+    return CANVAS_OK;
+}
+
+static int32_t normalize_by_gc_loess(CleanState& st, int nchr, const uint8_t* h_is_y) {
+    canvas_ctx* ctx = st.ctx;
+    const int64_t n = st.n;
+    const int ntiles = (int)nblk(n, LO_TILE);
+    size_t bytes = (size_t)n * (1 + 8 + 8 + 8 + 8) + (size_t)ntiles * 128 * 4 + (size_t)(ntiles + 8) * 8 + 8192 + nchr + 1024 * 8;
+    char* arena = nullptr;
+    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&arena, bytes));
+    struct Free { canvas_ctx* c; char* p; ~Free() { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); } } fr{ctx, arena};
+    WsCarver ws(arena);
+    uint8_t* dKey = ws.take<uint8_t>(n); double* dY = ws.take<double>(n); double* dYg = ws.take<double>(n); double* dP = ws.take<double>(n + 1);
+    unsigned long long* dKeys64 = ws.take<unsigned long long>(n); uint32_t* dTileHist = ws.take<uint32_t>((size_t)ntiles * 128); uint32_t* dKeyTot = ws.take<uint32_t>(128);
+    uint32_t* dGroupOff = ws.take<uint32_t>(128); double* dBlockSum = ws.take<double>(ntiles + 8); unsigned int* dCnt = ws.take<unsigned int>(1);
+    uint8_t* dIsY = ws.take<uint8_t>(nchr); double* dFit = ws.take<double>(256);
+    std::vector<uint8_t> isY(nchr, 0);
+    if (h_is_y) for (int c = 0; c < nchr; c++) isY[c] = h_is_y[c];
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dIsY, isY.data(), nchr, hipMemcpyHostToDevice, ctx->stream));
+    // bandwidth search without chrY (LoessGCNormalizer.cs:63-68)
+    LoessModelDev noY;
+    int32_t rc = loess_build_model(st, dIsY, 1, dKey, dY, dYg, dP, dTileHist, dKeyTot, dGroupOff, dBlockSum, dKeys64, dCnt, noY); if (rc) return rc;
+    double minBw = std::max(2.0 / (double)noY.G.n, 0.3), maxBw = std::min(1.0, 0.75);
+    if (maxBw < minBw) maxBw = minBw;
+    if (noY.G.minX() == 0) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "LOESS: a bin with GC = 0 makes the reference index past fittedByGC (LoessGCNormalizer.cs:74,113)");
+    const double best = loess::golden_section([&](double b) { return loess::objective(b, noY.G, noY.medianY); }, minBw, maxBw);
+    // final fit on all bins (LoessGCNormalizer.cs:70-75)
+    LoessModelDev all;
+    rc = loess_build_model(st, dIsY, 0, dKey, dY, dYg, dP, dTileHist, dKeyTot, dGroupOff, dBlockSum, dKeys64, dCnt, all); if (rc) return rc;
+    const int minGC = all.G.minX(), maxGC = all.G.maxX();
+    std::vector<double> fitted = loess::train_predict(all.G, best, minGC, maxGC);
+    if (fitted.empty() || fitted.size() > 256) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "LOESS: degenerate GC range");
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFit, fitted.data(), fitted.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_loess_apply, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.cur.gc, n, dFit, (int)fitted.size(), minGC, all.medianY);
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
+                                 int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc,
+                                 double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (n < 0 || nchr <= 0 || !h_chr_is_autosome || !h_n_out) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: bad arguments");
-    if (flags & CANVAS_CLEAN_LOESS) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "CanvasClean -m LOESS (LoessGCNormalizer.cs) is not built yet");
+    const bool loessMode = (flags & CANVAS_CLEAN_LOESS) != 0;
     if (n >= 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "too many bins");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int32_t info[8] = {0};
@@ -493,7 +570,20 @@ extern "C" int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int3
     info[1] = (int32_t)st.n;
     bool haveLocalSd = (flags & CANVAS_CLEAN_LOCALSD) && st.n >= 50000;   // CanvasClean.cs:483-486
     if (haveLocalSd) { rc = local_sd(st, dSd, dRunMedian, dRunStart, dCnt, dPos, localSd); if (rc) return rc; }
-    if ((flags & CANVAS_CLEAN_GCNORM) && st.n > 0) {
+    if ((flags & CANVAS_CLEAN_GCNORM) && st.n > 0 && loessMode) {
+        // -m LOESS: no GC strip (CanvasClean.cs:497-499); variance normalisation still uses the MedianByGC quartiles
+        rc = normalize_by_gc_loess(st, nchr, h_chr_is_y); if (rc) return rc;
+        if (haveLocalSd && st.n > 500000) {
+            GcGroups g;
+            rc = gc_histogram(st, dHist, g.hist); if (rc) return rc;
+            for (int i = 0; i < NGC; i++) if (g.hist[i] > 0 && g.hist[i] < 100) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "weighted quartiles over GC buckets with 1..99 bins (CanvasClean.cs:107-132) are not built");
+            rc = group_by_gc(st, g, dSegOff, dCursor); if (rc) return rc;
+            bool changed = false;
+            rc = normalize_variance_by_gc(st, g, dTab, changed); if (rc) return rc;
+            info[4] = changed ? 1 : 0;
+            if (changed) { rc = normalize_by_gc_loess(st, nchr, h_chr_is_y); if (rc) return rc; }
+        }
+    } else if ((flags & CANVAS_CLEAN_GCNORM) && st.n > 0) {
         // RemoveBinsWithExtremeGC (CanvasClean.cs:207-237)
         GcGroups g;
         rc = gc_histogram(st, dHist, g.hist); if (rc) return rc;
@@ -639,4 +729,10 @@ extern "C" int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_c
     for (int c = nchr - 1; c >= 0; c--) h_chr_offset[c] = (f[c] >= 0 && f[c] < n) ? (int64_t)f[c] : h_chr_offset[c + 1];
     for (int c = 0; c < nchr; c++) if (h_chr_offset[c] > h_chr_offset[c + 1]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "bins are not grouped by increasing chromosome index");
     return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
+                                int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
+                                double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info) {
+    return canvas_clean2(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, nullptr, flags, min_bins_per_gc, h_local_sd_out, h_n_out, h_info);
 }

@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
-    "canvas_clean", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo",
+    "canvas_clean", "canvas_clean2", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -194,13 +194,14 @@ class Canvas:
         return off
 
     # ---- CanvasClean
-    def clean(self, bins, n, is_autosome, flags, min_bins_per_gc=100):
+    def clean(self, bins, n, is_autosome, flags, min_bins_per_gc=100, is_y=None):
         """CanvasClean.Main (CanvasClean.cs:415-533) in place on device SoA; returns (n_out, local_sd, info)"""
         ia = np.ascontiguousarray(is_autosome, np.uint8)
+        iy = np.ascontiguousarray(is_y if is_y is not None else np.zeros(len(ia)), np.uint8)
         lsd = C.c_double(-1.0); nout = C.c_int64(0); info = np.zeros(8, np.int32)
-        self._check(self.lib.canvas_clean(self.ctx, C.c_int64(n), C.c_void_p(bins["chr"].data_ptr()), C.c_void_p(bins["start"].data_ptr()),
-                                          C.c_void_p(bins["stop"].data_ptr()), C.c_void_p(bins["count"].data_ptr()), C.c_void_p(bins["gc"].data_ptr()),
-                                          len(ia), _np_ptr(ia), C.c_uint32(flags), min_bins_per_gc, C.byref(lsd), C.byref(nout), _np_ptr(info)))
+        self._check(self.lib.canvas_clean2(self.ctx, C.c_int64(n), C.c_void_p(bins["chr"].data_ptr()), C.c_void_p(bins["start"].data_ptr()),
+                                           C.c_void_p(bins["stop"].data_ptr()), C.c_void_p(bins["count"].data_ptr()), C.c_void_p(bins["gc"].data_ptr()),
+                                           len(ia), _np_ptr(ia), _np_ptr(iy), C.c_uint32(flags), min_bins_per_gc, C.byref(lsd), C.byref(nout), _np_ptr(info)))
         return nout.value, lsd.value, info
 
     def quantize_f2(self, count, n):

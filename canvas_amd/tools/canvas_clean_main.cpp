@@ -30,8 +30,8 @@ int main(int argc, char** argv) {
           auto it = chromIndex.find(f[0]); int ci; if (it == chromIndex.end()) { ci = (int)chromNames.size(); chromIndex[f[0]] = ci; chromNames.push_back(f[0]); } else ci = it->second;
           chr.push_back(ci); start.push_back(atoi(f[1].c_str())); stop.push_back(atoi(f[2].c_str())); count.push_back((float)strtod(f[3].c_str(), nullptr)); gc.push_back(atoi(f[4].c_str())); } }
     const int64_t n = (int64_t)chr.size(); const int nchr = (int)chromNames.size();
-    std::vector<uint8_t> isAuto(nchr > 0 ? nchr : 1, 0);
-    for (int c = 0; c < nchr; c++) isAuto[c] = is_autosome(chromNames[c]);
+    std::vector<uint8_t> isAuto(nchr > 0 ? nchr : 1, 0), isY(nchr > 0 ? nchr : 1, 0);
+    for (int c = 0; c < nchr; c++) { isAuto[c] = is_autosome(chromNames[c]); std::string lo = chromNames[c]; for (auto& ch : lo) ch = (char)tolower(ch); isY[c] = (lo == "chry" || lo == "y"); }   // LoessGCNormalizer.cs:49-50
     // chromosome indices must be non-decreasing for the library (bins grouped by chromosome in file order): first-appearance indexing gives that
     int64_t nOut = n; double localSd = -1.0;
     if (n > 0) {
@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
           TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dStop.p, stop.data(), n * 4)); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCount.p, count.data(), n * 4));
           TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dGc.p, gc.data(), n * 4));
           int32_t info[8];
-          TOOL_TRY(ctx, canvas_clean(ctx, n, dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dCount.as<float>(), dGc.as<int32_t>(), nchr, isAuto.data(), flags, minBins,
+          TOOL_TRY(ctx, canvas_clean2(ctx, n, dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dCount.as<float>(), dGc.as<int32_t>(), nchr, isAuto.data(), isY.data(), flags, minBins,
                                     &localSd, &nOut, info));
           TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, chr.data(), dChr.p, nOut * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, start.data(), dStart.p, nOut * 4));
           TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, stop.data(), dStop.p, nOut * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, count.data(), dCount.p, nOut * 4));

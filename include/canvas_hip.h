@@ -106,6 +106,12 @@ int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_star
                      int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
                      double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
 
+/* same with -m LOESS support (flag CANVAS_CLEAN_LOESS): h_chr_is_y[nchr] marks chrY/Y, which LoessGCNormalizer leaves out of the
+ * bandwidth search (LoessGCNormalizer.cs:49-50,63-68).  LOESS-mode counts match the reference within 1e-5 relative (the floating
+ * sums are re-associated); MedianByGC mode is bit-exact.  NULL h_chr_is_y = no chromosome is chrY. */
+int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
+                      int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags,
+                      int32_t min_bins_per_gc, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
 /* bins are grouped by chromosome in file order: h_chr_offset[c] = index of the first bin of chromosome c (nchr+1 entries,
  * h_chr_offset[nchr] = n); chromosomes without bins get an empty range.  Chromosome indices must be non-decreasing. */
 int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_chr, int64_t n, int32_t nchr, int64_t* h_chr_offset);

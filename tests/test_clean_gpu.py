@@ -70,3 +70,25 @@ def test_clean_unsorted_chromosome_runs_and_tiny_inputs():
     for n in (1, 2, 25):
         b = {k: v[:n].copy() for k, v in bins.items()}
         _run(cv, b, CLEAN_FILTSIZE | CLEAN_OUTLIERS, nchr=6)
+
+
+def test_clean_loess_mode_within_tolerance():
+    """-m LOESS (LoessGCNormalizer): sufficient-statistics LOESS on the GPU vs the oracle's point-by-point LOESS; the reference tolerance
+    for this mode is 1e-5 relative (sums are re-associated), survivors must be identical"""
+    from canvas_amd import CLEAN_LOESS
+    cv = get_canvas()
+    nchr = 24
+    bins = synth.generate_bins(20260927 + 6, 30_000)
+    bins["gc"] = np.clip(bins["gc"], 12, 80)        # GC = 0 makes the reference itself index out of range
+    is_auto = synth.IS_AUTOSOME; is_y = np.zeros(nchr, np.uint8); is_y[-1] = 1
+    flags = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOESS
+    exp = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, flags)
+    dev = {k: to_dev(v, cv.device) for k, v in bins.items()}
+    n_out, lsd, info = cv.clean(dev, len(bins["chr"]), is_auto, flags, is_y=is_y)
+    assert n_out == len(exp["chr"])
+    for k in ("chr", "start", "stop", "gc"):
+        assert (dev[k][:n_out].cpu().numpy() == exp[k]).all()
+    got = dev["count"][:n_out].cpu().numpy().astype(np.float64); ex = exp["count"].astype(np.float64)
+    rel = np.abs(got - ex) / np.maximum(np.abs(ex), 1e-12)
+    assert rel[ex > 0].max() < 1e-5, rel.max()
+    assert ((ex == 0) == (got == 0)).all()
