@@ -83,6 +83,9 @@ def main():
     out = dict(chr=torch.empty(cap, dtype=torch.int32, device=device), start=torch.empty(cap, dtype=torch.int32, device=device),
                stop=torch.empty(cap, dtype=torch.int32, device=device), gc=torch.empty(cap, dtype=torch.int32, device=device),
                count=torch.empty(cap, dtype=torch.float32, device=device))
+    cov_buf = torch.empty(cap, dtype=torch.float64, device=device)
+    state_buf = torch.empty(cap, dtype=torch.int32, device=device)
+    seg_buf = torch.empty(cap, dtype=torch.int32, device=device)
     gather_send = torch.zeros(4, dtype=torch.int32, device=device)
     gather_recv = torch.zeros(5 * world, dtype=torch.int32, device=device)
     keep = {}
@@ -105,12 +108,12 @@ def main():
             tp = time.perf_counter()
         n_out, lsd, info = cv.clean(out, total, is_auto, flags)
         tp = tick("clean", tp)
-        cov = cv.quantize_f2(out["count"], n_out)
+        cov = cv.quantize_f2(out["count"], n_out, out=cov_buf)
         off_h = cv.chromosome_offsets(out["chr"], n_out, nchr)
         tp = tick("f2+offsets", tp)
-        state = cv.hmm_per_sample(cov, off_h)
+        state = cv.hmm_per_sample(cov, off_h, out=state_buf)
         tp = tick("hmm", tp)
-        seg, nseg = cv.segment_ids(off_h, state, out["start"], out["stop"])
+        seg, nseg = cv.segment_ids(off_h, state, out["start"], out["stop"], out=seg_buf)
         tp = tick("segment_ids", tp)
         if world > 1:
             gather_send[0] = int(nseg); gather_send[1] = int(n_out); gather_send[2] = int(total); gather_send[3] = rank
@@ -119,7 +122,7 @@ def main():
                                                          cnt.ctypes.data_as(C.c_void_p)))
         cv.synchronize()
         if record:
-            keep.update(bin_size=bs, total=total, n_out=n_out, lsd=lsd, info=info, cov=cov, off=off_h, state=state, seg=seg, nseg=nseg,
+            keep.update(bin_size=bs, total=total, n_out=n_out, lsd=lsd, info=info, cov=cov.clone(), off=off_h, state=state.clone(), seg=seg.clone(), nseg=nseg,
                         cleaned={k: v[:n_out].clone() for k, v in out.items()})
         return total
 

@@ -203,6 +203,12 @@ __device__ __forceinline__ uint32_t gc_bits4(uint32_t w) {           // 4 bits: 
     return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
 }
 __device__ __forceinline__ uint32_t sum_bytes(uint32_t w, uint32_t acc) { return __builtin_amdgcn_sad_u8(w, 0u, acc); }
+__device__ __forceinline__ uint32_t gc_marks4(uint32_t w) {          // 0x80 in every byte that is C/c/G/g (popcount = GC count of the 4 bases)
+    uint32_t y = ((w | 0x20202020u) ^ 0x63636363u) & 0xFBFBFBFBu;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t marks_to_bits4(uint32_t z) { return (((z >> 7) * 0x01020408u) >> 24) & 0xFu; }
+__device__ __forceinline__ uint32_t any_byte_gt10(uint32_t w) { return (((w & 0x7F7F7F7Fu) + 0x75757575u) | w) & 0x80808080u; }
 
 // One tile (4096 positions) per wave.  FULL = the tile lies entirely inside [pos0, len): vector loads, no bounds logic.
 template <bool FULL>
@@ -248,16 +254,21 @@ __device__ __forceinline__ void bin_tile(const BinChrom& C, int64_t gtile, int64
             }
         }
         const uint32_t mVal = mRank & vmask;
-        // per-lane values
-        uint32_t gcb = (gc_bits4(wb[0]) | (gc_bits4(wb[1]) << 4) | (gc_bits4(wb[2]) << 8) | (gc_bits4(wb[3]) << 12)) & vmask;
+        // per-lane values.  GC: only the COUNT is needed outside the (rare) boundary lanes, so the per-position bits are built lazily.
+        uint32_t gz[4] = {gc_marks4(wb[0]), gc_marks4(wb[1]), gc_marks4(wb[2]), gc_marks4(wb[3])};
+        uint32_t g, gcb = 0;
+        if (FULL) g = __popc(gz[0]) + __popc(gz[1]) + __popc(gz[2]) + __popc(gz[3]);
+        else { gcb = (marks_to_bits4(gz[0]) | (marks_to_bits4(gz[1]) << 4) | (marks_to_bits4(gz[2]) << 8) | (marks_to_bits4(gz[3]) << 12)) & vmask; g = __popc(gcb); }
+        // hits: min(10, h) only matters when some byte exceeds 10 (pile-ups): wave-uniform fast path without the clamp
+        const bool needClamp = clampHits && __any((int)((any_byte_gt10(wh[0]) | any_byte_gt10(wh[1]) | any_byte_gt10(wh[2]) | any_byte_gt10(wh[3])) != 0u));
         uint32_t cw[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            uint32_t h = clampHits ? clamp10_bytes(wh[q]) : wh[q];
+            uint32_t h = needClamp ? clamp10_bytes(wh[q]) : wh[q];
             cw[q] = h & expand4(mVal >> (4 * q));
         }
         uint32_t cl = sum_bytes(cw[0], sum_bytes(cw[1], sum_bytes(cw[2], sum_bytes(cw[3], 0u))));
-        uint32_t pop = __popc(mRank), g = __popc(gcb);
+        uint32_t pop = __popc(mRank);
         // wave scans: (pop | g<<16) packed, c separate
         uint32_t pg = pop | (g << 16);
         uint32_t pgInc = wave_inclusive_scan_u32(pg);
@@ -269,6 +280,7 @@ __device__ __forceinline__ void bin_tile(const BinChrom& C, int64_t gtile, int64
         if (pop > 0 && r + (int32_t)pop >= binSize) {  // cheap reject: a boundary needs rank >= binSize
             int32_t rr = r < 0 ? 0 : r;                // ranks <= 0 can never close a bin
             uint32_t nextB = ((uint32_t)rr / (uint32_t)binSize + 1u) * (uint32_t)binSize;   // next boundary rank > rr
+            if (FULL) gcb = marks_to_bits4(gz[0]) | (marks_to_bits4(gz[1]) << 4) | (marks_to_bits4(gz[2]) << 8) | (marks_to_bits4(gz[3]) << 12);
             while ((int64_t)nextB - r <= (int64_t)pop && (int64_t)nextB - r >= 1) {
                 uint32_t k = (uint32_t)((int64_t)nextB - r);       // k-th set bit of mRank closes the bin
                 uint32_t pos = 0, m = mRank, kk = k, cnt;

@@ -204,9 +204,9 @@ class Canvas:
                                            len(ia), _np_ptr(ia), _np_ptr(iy), C.c_uint32(flags), min_bins_per_gc, C.byref(lsd), C.byref(nout), _np_ptr(info)))
         return nout.value, lsd.value, info
 
-    def quantize_f2(self, count, n):
+    def quantize_f2(self, count, n, out=None):
         """count.ToString("F2") -> Convert.ToDouble (IO.cs:21 -> CanvasSegment.cs:1146), in memory"""
-        cov = self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+        cov = out[:n] if out is not None else self.torch.empty(n, dtype=self.torch.float64, device=self.device)
         self._check(self.lib.canvas_quantize_f2(self.ctx, C.c_void_p(count.data_ptr()), C.c_int64(n), C.c_void_p(cov.data_ptr())))
         self.synchronize()   # the library runs on its own non-blocking stream; make the result visible to torch's stream
         return cov
@@ -220,19 +220,19 @@ class Canvas:
         return ms.value, k.value
 
     # ---- CanvasPartition
-    def hmm_per_sample(self, cov, chr_offset):
+    def hmm_per_sample(self, cov, chr_offset, out=None):
         """HiddenMarkovModelsRunner.Run(isPerSample) (HiddenMarkovModelsRunner.cs:23-109): Viterbi state per bin"""
         torch = self.torch
         off = np.ascontiguousarray(chr_offset, np.int64)
-        state = torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
+        state = out[:int(off[-1])] if out is not None else torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
         self._check(self.lib.canvas_hmm_per_sample(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_void_p(state.data_ptr())))
         return state
 
-    def segment_ids(self, chr_offset, state, start, stop, max_inter_bin_dist=1000000, excluded=None):
+    def segment_ids(self, chr_offset, state, start, stop, max_inter_bin_dist=1000000, excluded=None, out=None):
         """DeriveSegments + PostProcessSegments; excluded = per-chromosome list of (starts, stops) of the -b BED file"""
         torch = self.torch
         off = np.ascontiguousarray(chr_offset, np.int64)
-        seg = torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
+        seg = out[:int(off[-1])] if out is not None else torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
         nseg = C.c_int64(0)
         if excluded is None:
             self._check(self.lib.canvas_segment_ids(self.ctx, len(off) - 1, _np_ptr(off), C.c_void_p(state.data_ptr()), C.c_void_p(start.data_ptr()),
