@@ -11,9 +11,10 @@
 // Host logic (this file, between launches) only does what the reference does once per file on <= 101 GC buckets / <= a few
 // hundred chromosomes: thresholds, medians of two selected values, quartile interpolation (Utilities.cs:361-419).
 //
-// Not built (returns CANVAS_ERR_UNSUPPORTED): LOESS mode (-m LOESS), manifests (-t), and the neighbour-weighted median for GC
-// buckets holding 1..99 autosomal bins after the GC strip — reachable only with < 10100 autosomal bins and -w < 100
-// (CanvasClean.cs:107-132,226-228).
+// GC buckets holding fewer than 100 autosomal bins (reachable with -w < 100 on < 10100 bins, and in LOESS mode where no GC
+// strip runs) take the neighbour-weighted quantiles of CanvasClean.cs:107-132: the few bucket ranges involved are copied to the
+// host and weighted there (a per-file O(hundreds) computation next to the thresholds above).
+// Not built (returns CANVAS_ERR_UNSUPPORTED): manifests (-t).
 #include "common.hpp"
 #include "select.hpp"
 #include "loess.hpp"
@@ -319,8 +320,66 @@ static int32_t group_by_gc(CleanState& st, GcGroups& g, uint32_t* dSegOff, uint3
     return CANVAS_OK;
 }
 
+
+// GetWeightedCounts (CanvasClean.cs:107-132) + Utilities.WeightedQuantiles (Utilities.cs:493-520) for GC buckets with fewer
+// than 100 autosomal bins.  st.keys32 holds the grouped count keys (bucket by bucket, file order inside a bucket), so the
+// reference's insertion order — bucket, bucket+1, bucket-1, bucket+2, ... — is a concatenation of contiguous key ranges.
+// The ranges are copied to the host once (merged), the weighting itself is <= a few thousand elements per bucket.
+struct WQuant { double q[3]; };
+static int32_t weighted_quantiles_sparse(CleanState& st, const GcGroups& g, const std::vector<int>& buckets, const float* probs, int nprobs,
+                                         std::vector<WQuant>& out) {
+    canvas_ctx* ctx = st.ctx;
+    out.assign(buckets.size(), WQuant{{0, 0, 0}});
+    if (buckets.empty()) return CANVAS_OK;
+    struct Piece { int gc; float w; };
+    std::vector<std::vector<Piece>> plan(buckets.size());
+    std::vector<uint8_t> need(NGC, 0);
+    for (size_t b = 0; b < buckets.size(); b++) {
+        const int gcBin = buckets[b];
+        int64_t have = 0; int radius = 0; float weight = 1;
+        while (have < 100) {
+            int hi = gcBin + radius, lo = gcBin - radius;
+            if (hi >= NGC && lo < 0) break;
+            if (hi < NGC) { plan[b].push_back({hi, weight}); have += g.hist[hi]; }
+            if (lo != hi && lo >= 0) { plan[b].push_back({lo, weight}); have += g.hist[lo]; }
+            radius++; weight /= 2;
+        }
+        for (auto& p : plan[b]) if (g.hist[p.gc]) need[p.gc] = 1;
+    }
+    // download merged runs of needed buckets
+    std::vector<uint32_t> hostKeys; std::vector<int64_t> hostAt(NGC, -1);
+    for (int gc = 0; gc < NGC;) {
+        if (!need[gc]) { gc++; continue; }
+        int e = gc; while (e + 1 < NGC && (need[e + 1] || g.hist[e + 1] == 0)) e++;
+        while (!need[e]) e--;
+        int64_t lo = g.segOff[gc], hi = g.segOff[e + 1], at = (int64_t)hostKeys.size();
+        hostKeys.resize(at + (hi - lo));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hostKeys.data() + at, st.keys32 + lo, (hi - lo) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // hostKeys may reallocate on the next run
+        for (int k = gc; k <= e; k++) hostAt[k] = at + (g.segOff[k] - lo);
+        gc = e + 1;
+    }
+    struct WC { float v, w; };
+    std::vector<WC> wc;
+    for (size_t b = 0; b < buckets.size(); b++) {
+        wc.clear();
+        for (auto& p : plan[b]) for (uint32_t k = 0; k < g.hist[p.gc]; k++) wc.push_back({host_float_of_key(hostKeys[hostAt[p.gc] + k]), p.w});
+        double acc = 0;
+        for (auto& t : wc) acc += (double)t.w;                        // LINQ Sum<float>: double accumulator, float result
+        const double totalWeight = (double)(float)acc;
+        std::stable_sort(wc.begin(), wc.end(), [](const WC& a, const WC& c) { return a.v < c.v; });   // OrderBy is stable
+        double cumulativeWeight = 0;
+        for (auto& t : wc) {
+            cumulativeWeight += (double)t.w;
+            const double cumulativeProb = cumulativeWeight / totalWeight;
+            for (int i = 0; i < nprobs; i++) if (cumulativeProb <= (double)probs[i]) out[b].q[i] = (double)t.v;
+        }
+    }
+    return CANVAS_OK;
+}
+
 // NormalizeByGC (CanvasClean.cs:163-196) on the grouped autosomal counts
-static int32_t normalize_by_gc(CleanState& st, const GcGroups& g, double* dMedians) {
+static int32_t normalize_by_gc(CleanState& st, const GcGroups& g, double* dMedians, bool emptyBucketsReadable) {
     canvas_ctx* ctx = st.ctx;
     if (g.nauto == 0) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "NormalizeByGC: no autosomal bins (the reference would throw on an empty median)");
     hipLaunchKernelGGL(k_gather_keys, dim3(nblk(g.nauto, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.gidx, g.nauto, st.keys32);
@@ -328,16 +387,23 @@ static int32_t normalize_by_gc(CleanState& st, const GcGroups& g, double* dMedia
     auto addMedian = [&](int lo, int hi, int64_t cnt) { if (cnt % 2) qs.push_back({lo, hi, cnt / 2}); else { qs.push_back({lo, hi, cnt / 2 - 1}); qs.push_back({lo, hi, cnt / 2}); } };
     addMedian(0, NGC - 1, g.nauto);
     std::vector<int> first(NGC, -1);
-    for (int gc = 0; gc < NGC; gc++) if (g.hist[gc] > 0) { first[gc] = (int)qs.size(); addMedian(gc, gc, g.hist[gc]); }
+    std::vector<int> sparse;
+    for (int gc = 0; gc < NGC; gc++) {
+        if (g.hist[gc] >= 100) { first[gc] = (int)qs.size(); addMedian(gc, gc, g.hist[gc]); }
+        else if (g.hist[gc] > 0 || emptyBucketsReadable) sparse.push_back(gc);     // CanvasClean.cs:178-187
+    }
     std::vector<unsigned long long> res;
     int32_t rc = radix_select<uint32_t>(ctx, st.keys32, NGC, g.segOff, qs, res); if (rc) return rc;
+    std::vector<WQuant> wq; const float half = 0.5f;
+    rc = weighted_quantiles_sparse(st, g, sparse, &half, 1, wq); if (rc) return rc;
     auto med = [&](int at, int64_t cnt) -> double {
         if (cnt % 2) return (double)host_float_of_key((uint32_t)res[at]);
         return (double)median_from_two(host_float_of_key((uint32_t)res[at]), host_float_of_key((uint32_t)res[at + 1]));
     };
     double globalMedian = med(0, g.nauto);
     double medians[NGC];
-    for (int gc = 0; gc < NGC; gc++) medians[gc] = first[gc] >= 0 ? med(first[gc], g.hist[gc]) : 0.0;   // empty buckets: no bin reads them
+    for (int gc = 0; gc < NGC; gc++) medians[gc] = first[gc] >= 0 ? med(first[gc], g.hist[gc]) : 0.0;   // unreadable empty buckets stay 0
+    for (size_t b = 0; b < sparse.size(); b++) medians[sparse[b]] = wq[b].q[0];
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dMedians, medians, sizeof medians, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_apply_gc, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.cur.gc, st.n, dMedians, globalMedian);
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -358,6 +424,10 @@ static int32_t normalize_variance_by_gc(CleanState& st, const GcGroups& g, VarTa
     for (int gc = 0; gc < NGC; gc++) if (g.hist[gc] >= 100) addQ(gc, gc, gc, g.hist[gc]);
     std::vector<unsigned long long> res;
     int32_t rc = radix_select<uint32_t>(ctx, st.keys32, NGC, g.segOff, qs, res); if (rc) return rc;
+    std::vector<int> sparse;
+    for (int gc = 0; gc < NGC; gc++) if (g.hist[gc] > 0 && g.hist[gc] < 100) sparse.push_back(gc);       // CanvasClean.cs:62-68
+    std::vector<WQuant> wq; const float probs[3] = {0.25f, 0.5f, 0.75f};
+    rc = weighted_quantiles_sparse(st, g, sparse, probs, 3, wq); if (rc) return rc;
     auto quart = [&](int slot, int64_t cnt, float& q1, float& q2, float& q3) {
         float v[6]; QuartIdx qi = quartile_indices(cnt);
         for (int k = 0; k < qi.n; k++) v[k] = host_float_of_key((uint32_t)res[first[slot] + k]);
@@ -368,8 +438,9 @@ static int32_t normalize_variance_by_gc(CleanState& st, const GcGroups& g, VarTa
     VarTab tab;
     for (int gc = 0; gc < NGC; gc++) {
         if (g.hist[gc] == 0) { tab.localIQR[gc] = -1.0f; tab.med[gc] = -1.0f; }
-        else { float q1, q2, q3; quart(gc, g.hist[gc], q1, q2, q3); tab.med[gc] = q2; tab.localIQR[gc] = q3 - q1; }
+        else if (g.hist[gc] >= 100) { float q1, q2, q3; quart(gc, g.hist[gc], q1, q2, q3); tab.med[gc] = q2; tab.localIQR[gc] = q3 - q1; }
     }
+    for (size_t b = 0; b < sparse.size(); b++) { tab.med[sparse[b]] = (float)wq[b].q[1]; tab.localIQR[sparse[b]] = (float)(wq[b].q[2] - wq[b].q[0]); }
     tab.globalIQR = g3 - g1;
     int significant = 0;
     for (int i = 10; i < 90; i++) if (tab.globalIQR * 2.0f < tab.localIQR[i]) significant++;
@@ -576,7 +647,6 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
         if (haveLocalSd && st.n > 500000) {
             GcGroups g;
             rc = gc_histogram(st, dHist, g.hist); if (rc) return rc;
-            for (int i = 0; i < NGC; i++) if (g.hist[i] > 0 && g.hist[i] < 100) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "weighted quartiles over GC buckets with 1..99 bins (CanvasClean.cs:107-132) are not built");
             rc = group_by_gc(st, g, dSegOff, dCursor); if (rc) return rc;
             bool changed = false;
             rc = normalize_variance_by_gc(st, g, dTab, changed); if (rc) return rc;
@@ -611,15 +681,15 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
             }
             for (int i = 0; i < NGC; i++) {
                 if (!keep[i]) g.hist[i] = 0;
-                else if (g.hist[i] > 0 && g.hist[i] < 100) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "weighted median over GC buckets with 1..99 bins (CanvasClean.cs:107-132) is not built");
             }
+            const bool emptyReadable = threshold <= 0;   // otherwise every bin of an empty autosomal bucket was stripped above
             rc = group_by_gc(st, g, dSegOff, dCursor); if (rc) return rc;
-            rc = normalize_by_gc(st, g, dMedians); if (rc) return rc;
+            rc = normalize_by_gc(st, g, dMedians, emptyReadable); if (rc) return rc;
             if (haveLocalSd && st.n > 500000) {     // CanvasClean.cs:512-519
                 bool changed = false;
                 rc = normalize_variance_by_gc(st, g, dTab, changed); if (rc) return rc;
                 info[4] = changed ? 1 : 0;
-                if (changed) { rc = normalize_by_gc(st, g, dMedians); if (rc) return rc; }
+                if (changed) { rc = normalize_by_gc(st, g, dMedians, emptyReadable); if (rc) return rc; }
             }
         }
     }

@@ -281,6 +281,130 @@ __global__ void __launch_bounds__(64) k_vit_backbone(const HmmChrom* __restrict_
     }
 }
 
+// B1c: the same sequential sum, evaluated exactly by a parallel scan.  All increments are <= 0, so |D| never decreases and stays
+// inside one binade [2^e, 2^(e+1)) for long stretches (about 21 binades per chromosome).  Inside a binade D = -k*u with u = 2^(e-52)
+// and k an integer in [2^52, 2^53); IEEE round-to-nearest-even of k*u + a is k + A (+1 when the discarded part of a/u is above one
+// half, or exactly one half and k + A is odd).  Each step is therefore a function of the PARITY of k alone, "add a0 if k is even,
+// a1 if it is odd", and such functions compose associatively: a block scan gives every k exactly.  The step that leaves the
+// binade is done with one real FP64 add and the scan restarts behind it with the new u.  One workgroup per chromosome, 8192 steps
+// per iteration.  Anything outside the assumptions (NaN, infinities, positive increments) flags the chromosome for the
+// sequential k_viterbi; k_vit_verify re-checks D bit for bit in any case.
+#define BS_T 1024
+#define BS_I 8
+struct ParFn { unsigned long long a0, a1; };     // amount added to k when the incoming k is even / odd
+__device__ __forceinline__ ParFn parfn_then(ParFn f, ParFn g) {   // f first, then g
+    ParFn h;
+    h.a0 = f.a0 + ((f.a0 & 1ull) ? g.a1 : g.a0);
+    h.a1 = f.a1 + ((f.a1 & 1ull) ? g.a0 : g.a1);
+    return h;
+}
+__device__ __forceinline__ ParFn parfn_shfl_up(ParFn f, int d) {
+    ParFn o;
+    o.a0 = __shfl_up(f.a0, d); o.a1 = __shfl_up(f.a1, d);
+    return o;
+}
+__global__ void __launch_bounds__(BS_T) k_vit_backbone_scan(const HmmChrom* __restrict__ chroms, const double* __restrict__ V, double* __restrict__ carryOut, int32_t* __restrict__ fail) {
+    __shared__ ParFn sAgg[BS_T / 64];
+    __shared__ long long sCross, sP;
+    __shared__ double sM;
+    __shared__ int sBad;
+    const HmmChrom C = chroms[blockIdx.x];
+    if (C.T <= 10) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* __restrict__ Vc = V + C.begin;
+    double* __restrict__ carry = carryOut + C.begin;
+    const unsigned long long TWO53 = 1ull << 53, MANT = (1ull << 52) - 1ull;
+    if (tid == 0) { carry[0] = 0.0; sM = 0.0; sP = 0; sBad = 0; sCross = 0x7fffffffffffffffll; }
+    __syncthreads();
+    for (;;) {
+        const long long p = sP; const double M = sM; const int bad = sBad;     // M = |D_{p-1}|
+        __syncthreads();
+        if (bad || p >= C.T) break;
+        if (!(M >= 2.2250738585072014e-308)) {               // zero (chromosome start) or subnormal: one plain step
+            if (tid == 0) {
+                const double v = Vc[p];
+                const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+                if (((vb >> 52) & 0x7ffull) == 0x7ffull || (!(vb >> 63) && (vb << 1) != 0ull)) { sBad = 1; fail[blockIdx.x] = 1; }
+                else { const double acc = -M + v; if (((p + 1) & 63) == 0 && p + 1 < C.T) carry[p + 1] = acc; sM = -acc; sP = p + 1; }
+            }
+            __syncthreads();
+            continue;
+        }
+        const unsigned long long mb = (unsigned long long)__double_as_longlong(M);
+        const int eM = (int)((mb >> 52) & 0x7ffull);                               // biased exponent of the binade
+        const unsigned long long k0 = (mb & MANT) | (1ull << 52);
+        const long long base = p + (long long)tid * BS_I;
+        ParFn f[BS_I]; bool myBad = false;
+#pragma unroll
+        for (int i = 0; i < BS_I; i++) {
+            const long long t = base + i;
+            unsigned long long A = 0; int r = 0;
+            if (t < C.T) {
+                const unsigned long long vb = (unsigned long long)__double_as_longlong(Vc[t]);
+                const int ea = (int)((vb >> 52) & 0x7ffull);
+                if (ea == 0x7ff || (!(vb >> 63) && (vb << 1) != 0ull)) myBad = true;
+                const unsigned long long ma = ea ? ((vb & MANT) | (1ull << 52)) : (vb & MANT);   // |v| = ma * 2^(max(ea,1) - 1075)
+                const int shift = eM - (ea ? ea : 1);
+                if (shift <= 0) { if (ma) A = TWO53; }                                     // |v| >= 2^e: leaves the binade
+                else if (shift < 64) {
+                    A = ma >> shift;
+                    const unsigned long long rem = ma & ((1ull << shift) - 1ull), half = 1ull << (shift - 1);
+                    r = rem > half ? 1 : (rem == half ? 2 : 0);
+                }
+            }
+            const unsigned long long up = A + (r == 1 ? 1ull : 0ull);
+            f[i].a0 = up + ((r == 2 && (A & 1ull)) ? 1ull : 0ull);
+            f[i].a1 = up + ((r == 2 && !(A & 1ull)) ? 1ull : 0ull);
+        }
+        ParFn g = f[0];
+#pragma unroll
+        for (int i = 1; i < BS_I; i++) g = parfn_then(g, f[i]);
+        // inclusive scan over the workgroup (thread order = step order)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { ParFn o = parfn_shfl_up(g, d); if (lane >= d) g = parfn_then(o, g); }
+        if (lane == 63) sAgg[wave] = g;
+        if (myBad) sBad = 1;
+        __syncthreads();
+        ParFn ex; ex.a0 = 0; ex.a1 = 0;                        // exclusive prefix of this thread
+        for (int w = 0; w < wave; w++) ex = parfn_then(ex, sAgg[w]);
+        { ParFn o = parfn_shfl_up(g, 1); if (lane > 0) ex = parfn_then(ex, o); }
+        if (sBad) { if (tid == 0) fail[blockIdx.x] = 1; break; }
+        unsigned long long k = k0 + ((k0 & 1ull) ? ex.a1 : ex.a0);
+        unsigned long long kAt[BS_I];
+        long long myCross = 0x7fffffffffffffffll; unsigned long long kBefore = 0;
+#pragma unroll
+        for (int i = 0; i < BS_I; i++) {
+            const unsigned long long kp = k;
+            k += (k & 1ull) ? f[i].a1 : f[i].a0;
+            kAt[i] = k;
+            if (k >= TWO53 && myCross == 0x7fffffffffffffffll && base + i < C.T) { myCross = base + i; kBefore = kp; }
+        }
+        if (myCross != 0x7fffffffffffffffll) atomicMin((unsigned long long*)&sCross, (unsigned long long)myCross);
+        __syncthreads();
+        const long long cross = sCross;
+        const long long chunkEnd = (p + (long long)BS_T * BS_I < C.T) ? p + (long long)BS_T * BS_I : C.T;
+        const long long validEnd = cross < chunkEnd ? cross : chunkEnd;            // steps [p, validEnd) are exact
+        const unsigned long long expBits = (unsigned long long)eM << 52;
+#pragma unroll
+        for (int i = 0; i < BS_I; i++) {
+            const long long t = base + i;
+            if (t < validEnd) {
+                const double Mt = __longlong_as_double((long long)(expBits | (kAt[i] & MANT)));
+                if (((t + 1) & 63) == 0 && t + 1 < C.T) carry[t + 1] = -Mt;
+                if (t + 1 == validEnd && cross >= chunkEnd) { sM = Mt; sP = validEnd; }
+            }
+        }
+        __syncthreads();
+        if (cross < chunkEnd && myCross == cross) {             // the owner of the leaving step does it with a real add
+            const double Mprev = __longlong_as_double((long long)(expBits | (kBefore & MANT)));
+            const double acc = -Mprev + Vc[cross];
+            if (((cross + 1) & 63) == 0 && cross + 1 < C.T) carry[cross + 1] = acc;
+            sM = -acc; sP = cross + 1; sCross = 0x7fffffffffffffffll;
+        }
+        __syncthreads();
+    }
+}
+
 // C: exact verification, one wave per block
 __global__ void __launch_bounds__(64 * VWPB) k_vit_verify(const VitBlock* __restrict__ blocks, int nblocksTotal, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                    const double* __restrict__ logPmf, HmmParams P, const uint8_t* __restrict__ psi, int64_t N,
@@ -630,7 +754,8 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
         if (getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, N, chroms[0].begin + chroms[0].T / 2);
         backtrack();
         hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
-        hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
+        if (getenv("CANVAS_HMM_BACKBONE_CHAIN")) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
+        else hipLaunchKernelGGL(k_vit_backbone_scan, dim3(nchr), dim3(BS_T), 0, ctx->stream, dChroms, dD, dCarry, dFail);
         hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)((vblocks.size() + VWPB - 1) / VWPB)), dim3(64 * VWPB), lds, ctx->stream, dVBlocks, (int)vblocks.size(), dChroms, idx, dTab, P, psi, N, d_state, dD, dCarry, dLast, dFail);
         std::vector<int32_t> hFail(nchr, 0);
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -10,12 +10,12 @@ pytestmark = pytest.mark.gpu
 ALL = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD
 
 
-def _run(cv, bins, flags, nchr=24):
-    is_auto = synth.IS_AUTOSOME[:nchr]
+def _run(cv, bins, flags, nchr=24, w=100, is_auto=None):
+    is_auto = synth.IS_AUTOSOME[:nchr] if is_auto is None else np.asarray(is_auto, np.uint8)
     is_y = np.zeros(nchr, np.uint8); is_y[-1] = 1
-    exp = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, flags)
+    exp = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, flags, min_bins_weighted=w)
     dev = {k: to_dev(v, cv.device) for k, v in bins.items()}
-    n_out, lsd, info = cv.clean(dev, len(bins["chr"]), is_auto, flags)
+    n_out, lsd, info = cv.clean(dev, len(bins["chr"]), is_auto, flags, min_bins_per_gc=w)
     assert n_out == len(exp["chr"]), (n_out, len(exp["chr"]), info, exp["stages"])
     for k in ("chr", "start", "stop", "gc"):
         assert (dev[k][:n_out].cpu().numpy() == exp[k]).all(), k
@@ -70,6 +70,59 @@ def test_clean_unsorted_chromosome_runs_and_tiny_inputs():
     for n in (1, 2, 25):
         b = {k: v[:n].copy() for k, v in bins.items()}
         _run(cv, b, CLEAN_FILTSIZE | CLEAN_OUTLIERS, nchr=6)
+
+
+@pytest.mark.parametrize("n,w", [(6_000, 20), (9_000, 1), (3_000, 60), (400, 0)])
+def test_clean_weighted_median_for_sparse_gc_buckets(n, w):
+    """-w < 100 on a small file: GC buckets with fewer than 100 autosomal bins survive the strip and take the neighbour-weighted
+    median (CanvasClean.cs:107-132,178-187); with -w 0 on < 101 bins per bucket even empty buckets are read (by X/Y bins)"""
+    cv = get_canvas()
+    bins = synth.generate_bins(20260927 + 11, n)
+    # ties between buckets of different weight exercise the stable OrderBy
+    bins["count"] = np.round(bins["count"] / 4).astype(np.float32) * 4
+    info, exp = _run(cv, bins, CLEAN_GCNORM, w=w)
+    gc_auto = bins["gc"][synth.IS_AUTOSOME[bins["chr"]] == 1]
+    h = np.bincount(gc_auto, minlength=101)
+    thr = min(100, max(w, len(gc_auto) // 101))
+    assert ((h >= thr) & (h < 100) & (h > 0)).any()           # the weighted branch really ran
+    _run(cv, bins, ALL, w=w)
+
+
+def test_clean_weighted_median_read_by_sex_chromosome_bins_of_empty_buckets():
+    """-w 0 and fewer than 101 autosomal bins: the strip threshold is 0, nothing is removed, and X bins whose GC bucket has no
+    autosomal bin are divided by the neighbour-weighted median of an EMPTY bucket (CanvasClean.cs:112-129,183-186)"""
+    cv = get_canvas()
+    bins = synth.generate_bins(20260927 + 13, 90, nchr=3)
+    n = len(bins["chr"])
+    assert (bins["chr"] < 2).sum() < 101
+    x = bins["chr"] == 2
+    bins["gc"][x] = np.where(np.arange(x.sum()) % 2 == 0, 70, 5)       # GC values no autosomal bin has
+    info, exp = _run(cv, bins, CLEAN_GCNORM, nchr=3, w=0, is_auto=[1, 1, 0])
+    assert info[2] == n
+    assert (exp["count"][x] != bins["count"][x]).any()
+
+
+def test_clean_loess_mode_with_variance_normalisation_and_sparse_buckets():
+    """LOESS mode never strips GC buckets, so NormalizeVarianceByGC meets sparse buckets and uses WeightedQuantiles (CanvasClean.cs:62-68)"""
+    from canvas_amd import CLEAN_LOESS
+    cv = get_canvas()
+    nchr = 24
+    bins = synth.generate_bins(20260927 + 12, 520_000)
+    bins["gc"] = np.clip(bins["gc"], 12, 80)
+    rng = np.random.RandomState(3)
+    noisy = (bins["gc"] >= 50) & (bins["gc"] <= 58)
+    bins["count"] = np.where(noisy, np.maximum(1, bins["count"] + rng.normal(0, 60, len(noisy))), np.maximum(1, bins["count"])).astype(np.float32)
+    is_auto = synth.IS_AUTOSOME; is_y = np.zeros(nchr, np.uint8); is_y[-1] = 1
+    flags = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_LOCALSD | CLEAN_LOESS
+    exp = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, flags)
+    dev = {k: to_dev(v, cv.device) for k, v in bins.items()}
+    n_out, lsd, info = cv.clean(dev, len(bins["chr"]), is_auto, flags, is_y=is_y)
+    assert n_out == len(exp["chr"]) and info[4] == 1 and exp["stages"][4] == 1
+    for k in ("chr", "start", "stop", "gc"):
+        assert (dev[k][:n_out].cpu().numpy() == exp[k]).all()
+    got = dev["count"][:n_out].cpu().numpy().astype(np.float64); ex = exp["count"].astype(np.float64)
+    rel = np.abs(got - ex) / np.maximum(np.abs(ex), 1e-12)
+    assert rel[ex > 0].max() < 1e-5, rel.max()
 
 
 def test_clean_loess_mode_within_tolerance():

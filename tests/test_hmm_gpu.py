@@ -80,6 +80,10 @@ def test_speculation_is_verified_and_falls_back(monkeypatch):
     cv.profile_get("viterbi_sequential", reset=True)
     base = _check(cv, bins, cov, off)
     assert cv.profile_get("viterbi_sequential")[1] == 0          # speculation verified everywhere
+    monkeypatch.setenv("CANVAS_HMM_BACKBONE_CHAIN", "1")         # the wave-sequential backbone instead of the exact parity scan
+    got0 = _check(cv, bins, cov, off)
+    assert cv.profile_get("viterbi_sequential")[1] == 0 and (got0 == base).all()
+    monkeypatch.delenv("CANVAS_HMM_BACKBONE_CHAIN")
     monkeypatch.setenv("CANVAS_HMM_TEST_CORRUPT", "1")
     got = _check(cv, bins, cov, off)
     assert cv.profile_get("viterbi_sequential")[1] == 1          # the corrupted chromosome was recomputed
