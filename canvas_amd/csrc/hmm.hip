@@ -18,11 +18,11 @@
 #include "common.hpp"
 #include "select.hpp"
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <algorithm>
 
 #define NSTATE 5
-#define BT_BLOCK 256
 
 struct HmmParams {
     double logA[NSTATE][NSTATE];   // log(transition[i][j])
@@ -57,7 +57,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 
 // one wave per chromosome
 __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx, const double* __restrict__ logPmf,
-                                                HmmParams P, uint8_t* __restrict__ psi /* [5][N] */, int64_t N, int32_t* __restrict__ lastState,
+                                                HmmParams P, uint16_t* __restrict__ psi /* 5 x 3 bits per bin */, int32_t* __restrict__ lastState,
                                                 const int32_t* __restrict__ chromList) {
     extern __shared__ double sTab[];                 // [5][tableLen] when it fits, else unused
     __shared__ double sE[2][64 * NSTATE];            // emissions of the current / next 64-step block
@@ -121,11 +121,9 @@ __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chr
             e = eNext;
         }
         __syncthreads();
-        // flush the block's back-pointers: 5 coalesced 64-byte rows
-        if (l < steps) {
-#pragma unroll
-            for (int st = 0; st < NSTATE; st++) psi[(size_t)st * N + C.begin + t0 + l] = sPsi[st][l];
-        }
+        // flush the block's back-pointers, packed 3 bits per state: one coalesced 128-byte row
+        if (l < steps)
+            psi[C.begin + t0 + l] = (uint16_t)(sPsi[0][l] | (sPsi[1][l] << 3) | (sPsi[2][l] << 6) | (sPsi[3][l] << 9) | (sPsi[4][l] << 12));
         __syncthreads();
     }
     // best final state: strict '>' scan from Double.MinValue, bestState initialised to -1 (HMM.cs:100-111)
@@ -147,97 +145,143 @@ __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chr
 // The recurrence must be evaluated in the reference's order to be bit-identical, which makes k_viterbi a 390 k-step chain for chr1.
 // But the *decisions* (back-pointers) depend only on differences of delta, and those forget their history within a few dozen
 // bins.  So:
-//   A  k_vit_spec      every 256-step block re-runs the SAME recurrence code from a cold start 128 steps earlier and records the
-//                      back-pointers it sees (a guess: its delta differs from the true one by a block constant + rounding noise);
-//   A2 k_bt_*          back-track the guessed pointers -> guessed state path s_t (the "backbone");
-//   B1 k_vit_backbone  the exact delta along the backbone is a plain sequential sum D_t = D_{t-1} + (e_{s_t}(t) + logA[s_{t-1}][s_t])
-//                      with the reference's association: one dependent FP64 add per step (about 4 ns) instead of about 150 ns;
+//   A  k_vit_spec      every 128-step block re-runs the SAME recurrence code from a cold start 128 steps earlier and records the
+//                      back-pointers it sees (a guess: its delta differs from the true one by a block constant + rounding noise),
+//                      together with the block's back-pointer map (state at the block's last step -> state before its first);
+//   A2 k_bt_*          compose the block maps backwards -> guessed state path s_t (the "backbone");
+//   B1 k_vit_backbone* the exact delta along the backbone is a plain sequential sum D_t = D_{t-1} + (e_{s_t}(t) + logA[s_{t-1}][s_t])
+//                      with the reference's association;
 //   C  k_vit_verify    every block rebuilds the exact delta of all five states from D (off-backbone states are re-anchored to the
 //                      backbone inside a 64-step lead-in), then re-does the exact strict-'>' arg-max at each step and checks it
 //                      against the guess, and checks delta_t(s_t) == D_t bit for bit.
 // If every check passes, induction from the exact t = 0 shows the guessed pointers ARE the reference's (and so is the path); any
 // failed check (a near-tie resolved differently by the cold-start run, a lead-in that did not re-anchor) flags the chromosome,
 // which is then recomputed by the sequential k_viterbi.  Results are therefore always exact; speculation only buys time.
-#define VB 256       // block length
+//
+// Work mapping of A and C: ONE LANE PER BLOCK.  A lane keeps all five delta values of its block in registers, so a step needs no
+// cross-lane traffic at all and a wave advances 64 blocks at once (the earlier one-wave-per-block version used 5 lanes of 64 and
+// was issue-bound).  The emission table sits in LDS transposed to [k][5] so that a lane reads its five log-pmf values from 40
+// contiguous bytes; bin indices / states / increments are fetched through a small per-lane register queue PQ steps ahead.
+// Back-pointers are packed 3 bits per state into one uint16 per bin.
+#define VB 128       // block length
 #define VW 128       // cold-start lead-in of the speculative pass
-#define VW2 64       // lead-in of the verification pass
+#define VW2 64       // lead-in of the verification pass (carry[] holds D at multiples of 64)
+#define PQ 8         // per-lane prefetch depth in steps
+#define MAP_IDENT (0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12))
 struct VitBlock { int32_t chrom; int32_t t0; };   // chromosome-relative start
 
-__device__ __forceinline__ void vit_step(double e, const double* la, double delta, double NEG, double& outDelta, int& outArg) {
-    double t_0 = readlane_f64(delta, 0) + (e + la[0]);
-    double t_1 = readlane_f64(delta, 1) + (e + la[1]);
-    double t_2 = readlane_f64(delta, 2) + (e + la[2]);
-    double t_3 = readlane_f64(delta, 3) + (e + la[3]);
-    double t_4 = readlane_f64(delta, 4) + (e + la[4]);
-    double a = t_0; int ia = 0; if (t_1 > a) { a = t_1; ia = 1; }
-    double b = t_2; int ib = 2; if (t_3 > b) { b = t_3; ib = 3; }
+// new delta and back-pointer of state J:  tmp_i = delta_i + (logpmf_J(x_t) + logA[i][J]),  strict '>' scan i = 0..4 from
+// Double.MinValue == first index of the maximum (evaluated as a tree, no NaNs can occur)   (HMM.cs:84-97, Distributions.cs:322)
+template <int J>
+__device__ __forceinline__ void vit_state(const double (&d)[NSTATE], double e, const HmmParams& P, double& outDelta, uint32_t& outArg) {
+    const double NEG = -1.7976931348623157e308;
+    const double t_0 = d[0] + (e + P.logA[0][J]);
+    const double t_1 = d[1] + (e + P.logA[1][J]);
+    const double t_2 = d[2] + (e + P.logA[2][J]);
+    const double t_3 = d[3] + (e + P.logA[3][J]);
+    const double t_4 = d[4] + (e + P.logA[4][J]);
+    double a = t_0; uint32_t ia = 0; if (t_1 > a) { a = t_1; ia = 1; }
+    double b = t_2; uint32_t ib = 2; if (t_3 > b) { b = t_3; ib = 3; }
     if (b > a) { a = b; ia = ib; }
     if (t_4 > a) { a = t_4; ia = 4; }
     if (!(a > NEG)) { a = NEG; ia = 0; }
     outDelta = a; outArg = ia;
 }
-
-// wave-local LDS hand-off (the four waves of a workgroup work on different blocks with different trip counts: no s_barrier)
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-#define VWPB 4   // blocks (waves) per workgroup, sharing one copy of the emission table in LDS
-
-// A: one wave per block (four per workgroup); lanes 0..4 own the states, all 64 lanes stage emissions
-__global__ void __launch_bounds__(64 * VWPB) k_vit_spec(const VitBlock* __restrict__ blocks, int nblocksTotal, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
-                                                 const double* __restrict__ logPmf, HmmParams P, uint8_t* __restrict__ psi, int64_t N, int32_t* __restrict__ lastGuess) {
-    extern __shared__ double sTab[];
-    __shared__ double sE_[VWPB][64 * NSTATE];
-    __shared__ uint8_t sPsi_[VWPB][NSTATE][64];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
-    if (useLds) { for (int i = threadIdx.x; i < P.tableLen * NSTATE; i += 64 * VWPB) sTab[i] = logPmf[i]; }
-    __syncthreads();
-    const int bidx = blockIdx.x * VWPB + w;
-    if (bidx >= nblocksTotal) return;
-    double* sE = sE_[w];
-    uint8_t (*sPsi)[64] = sPsi_[w];
-    const VitBlock B = blocks[bidx];
-    const HmmChrom C = chroms[B.chrom];
-    const double* tab = useLds ? sTab : logPmf;
-    const int j = l < NSTATE ? l : 0;
-    double la[NSTATE];
+// one full step for all five states; returns the packed back-pointers
+__device__ __forceinline__ uint32_t vit_step5(double (&d)[NSTATE], const double (&e)[NSTATE], const HmmParams& P) {
+    double n0, n1, n2, n3, n4; uint32_t a0, a1, a2, a3, a4;
+    vit_state<0>(d, e[0], P, n0, a0); vit_state<1>(d, e[1], P, n1, a1); vit_state<2>(d, e[2], P, n2, a2);
+    vit_state<3>(d, e[3], P, n3, a3); vit_state<4>(d, e[4], P, n4, a4);
+    d[0] = n0; d[1] = n1; d[2] = n2; d[3] = n3; d[4] = n4;
+    return a0 | (a1 << 3) | (a2 << 6) | (a3 << 9) | (a4 << 12);
+}
+// bestScore[0][j] = log(pi_j) + EstimateViterbiLikelihood(x0, j, transition[0]) - log(transition[0][j])   (HMM.cs:78)
+__device__ __forceinline__ void vit_init5(double (&d)[NSTATE], const double (&e)[NSTATE], const HmmParams& P) {
 #pragma unroll
-    for (int i = 0; i < NSTATE; i++) la[i] = P.logA[i][j];
-    const double NEG = -1.7976931348623157e308;
-    const int32_t* ix = idx + C.begin;
-    const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;       // block covers [tBeg, tEnd)
-    int64_t ts = tBeg - VW; if (ts < 0) ts = 0;                                    // cold start
-    ts &= ~(int64_t)63;                                                            // 64-aligned chunks
-    double delta = 0.0;                                                            // cold start: all states equal (exact init when ts == 0)
-    for (int64_t c0 = ts; c0 < tEnd; c0 += 64) {
-        { int64_t t = c0 + l; if (t < C.T) { int k = ix[t];
+    for (int j = 0; j < NSTATE; j++) { double lik = e[j] + P.logA[0][j]; d[j] = P.logPi[j] + lik - P.logA[0][j]; }
+}
+__device__ __forceinline__ int vit_best5(const double (&d)[NSTATE]) {     // HMM.cs:100-111
+    int best = -1; double m1 = -1.7976931348623157e308;
 #pragma unroll
-            for (int s = 0; s < NSTATE; s++) sE[l * NSTATE + s] = tab[s * P.tableLen + k]; } }
-        WAVE_SYNC();
-        const int steps = (int)((tEnd - c0) < 64 ? (tEnd - c0) : 64);
-        for (int s = 0; s < steps; s++) {
-            const int64_t t = c0 + s;
-            const double e = sE[s * NSTATE + j];
-            int arg = 0;
-            if (t == 0) { double lik = e + P.logA[0][j]; delta = P.logPi[j] + lik - P.logA[0][j]; }
-            else if (t == ts) { delta = e; }                                       // first step of a cold start: no history
-            else { double nd; vit_step(e, la, delta, NEG, nd, arg); delta = nd; }
-            if (l < NSTATE) sPsi[j][s] = (uint8_t)arg;
-        }
-        WAVE_SYNC();
-        if (l < steps && c0 + l >= tBeg) {
+    for (int i = 0; i < NSTATE; i++) if (d[i] > m1) { best = i; m1 = d[i]; }
+    return best;
+}
+__device__ __forceinline__ uint32_t map_get(uint32_t m, uint32_t j) { return (m >> (3u * j)) & 7u; }
+// (first `inner`, then `outer`):  r[j] = outer[inner[j]]
+__device__ __forceinline__ uint32_t map_compose(uint32_t outer, uint32_t inner) {
+    return map_get(outer, map_get(inner, 0)) | (map_get(outer, map_get(inner, 1)) << 3) | (map_get(outer, map_get(inner, 2)) << 6) |
+           (map_get(outer, map_get(inner, 3)) << 9) | (map_get(outer, map_get(inner, 4)) << 12);
+}
+__device__ __forceinline__ double sel5(const double (&d)[NSTATE], uint32_t i) {
+    double r = d[0];
+    r = i == 1 ? d[1] : r; r = i == 2 ? d[2] : r; r = i == 3 ? d[3] : r; r = i == 4 ? d[4] : r;
+    return r;
+}
+// emission row of table index k: LDS copy is transposed to [k][5], the global table is [5][tableLen]
+__device__ __forceinline__ void vit_emissions(double (&e)[NSTATE], const double* __restrict__ sTab, const double* __restrict__ logPmf, bool useLds, int tableLen, int k) {
+    if (useLds) {
 #pragma unroll
-            for (int st = 0; st < NSTATE; st++) psi[(size_t)st * N + C.begin + c0 + l] = sPsi[st][l];
-        }
-        WAVE_SYNC();
+        for (int j = 0; j < NSTATE; j++) e[j] = sTab[k * NSTATE + j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NSTATE; j++) e[j] = logPmf[(size_t)j * tableLen + k];
     }
-    if (tEnd == C.T) {       // last block: guess of the best final state (HMM.cs:100-111 on the shifted delta)
-        double d[NSTATE];
+}
+__device__ __forceinline__ void vit_stage_table(double* sTab, const double* __restrict__ logPmf, int tableLen, bool useLds) {
+    if (useLds) for (int i = threadIdx.x; i < tableLen * NSTATE; i += blockDim.x) { int s = i / tableLen, k = i - s * tableLen; sTab[k * NSTATE + s] = logPmf[i]; }
+    __syncthreads();
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
-        for (int i = 0; i < NSTATE; i++) d[i] = readlane_f64(delta, i);
-        if (l == 0) { int best = -1; double m1 = NEG;
+    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+
+// A: one lane per block
+__global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
+                                                 const double* __restrict__ logPmf, HmmParams P, uint16_t* __restrict__ psi, uint16_t* __restrict__ maps,
+                                                 int32_t* __restrict__ lastGuess) {
+    extern __shared__ double sTab[];
+    const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
+    vit_stage_table(sTab, logPmf, P.tableLen, useLds);
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const bool act = b < nblocks;
+    const VitBlock B = blocks[act ? b : nblocks - 1];
+    const HmmChrom C = chroms[B.chrom];
+    const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;       // block covers [tBeg, tEnd)
+    const int64_t ts = tBeg > VW ? tBeg - VW : 0;                                  // cold start
+    const int nsteps = act ? (int)(tEnd - ts) : 0;
+    const int maxSteps = wave_max_i32(nsteps);
+    const int32_t* __restrict__ ix = idx + C.begin + ts;
+    uint16_t* __restrict__ pp = psi + C.begin;
+    double d[NSTATE] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    uint32_t fm = MAP_IDENT;                                                       // state at t -> state at tBeg - 1
+    int kq[PQ];
 #pragma unroll
-            for (int i = 0; i < NSTATE; i++) if (d[i] > m1) { best = i; m1 = d[i]; }
-            lastGuess[B.chrom] = best; }
+    for (int u = 0; u < PQ; u++) kq[u] = u < nsteps ? ix[u] : 0;
+    for (int s0 = 0; s0 < maxSteps; s0 += PQ) {
+#pragma unroll
+        for (int u = 0; u < PQ; u++) {
+            const int s = s0 + u;
+            const int k = kq[u];
+            kq[u] = (s + PQ < nsteps) ? ix[s + PQ] : 0;
+            if (s < nsteps) {
+                const int64_t t = ts + s;
+                double e[NSTATE];
+                vit_emissions(e, sTab, logPmf, useLds, P.tableLen, k);
+                uint32_t pk = 0;
+                if (t == 0) vit_init5(d, e, P);
+                else if (s == 0) {                                                 // first step of a cold start: no history
+#pragma unroll
+                    for (int j = 0; j < NSTATE; j++) d[j] = e[j];
+                } else pk = vit_step5(d, e, P);
+                if (t >= tBeg) { pp[t] = (uint16_t)pk; if (t > 0) fm = map_compose(fm, pk); }
+            }
+        }
+    }
+    if (act) {
+        maps[b] = (uint16_t)fm;
+        if (tEnd == C.T) lastGuess[B.chrom] = vit_best5(d);      // guess of the best final state (HMM.cs:100-111 on the shifted delta)
     }
 }
 
@@ -405,142 +449,357 @@ __global__ void __launch_bounds__(BS_T) k_vit_backbone_scan(const HmmChrom* __re
     }
 }
 
-// C: exact verification, one wave per block
-__global__ void __launch_bounds__(64 * VWPB) k_vit_verify(const VitBlock* __restrict__ blocks, int nblocksTotal, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
-                                                   const double* __restrict__ logPmf, HmmParams P, const uint8_t* __restrict__ psi, int64_t N,
+// B1d: the parity scan without the sequential chunk loop.  A plain (re-associated) FP64 prefix sum of |v| is accurate to ~1e-13
+// relative, which is enough to PREDICT the binade of every running sum and the ~21 steps per chromosome that leave a binade
+// ("crossings"); the exact computation then needs no search:
+//   k_bb_sums / k_bb_bases   chunk sums of |v| (1024 steps per chunk) and their per-chromosome exclusive scan          [parallel]
+//   k_bb_pieces              per chunk: predicted binade of every step, its parity function under that binade, a segmented
+//                            composition scan that restarts behind every crossing -> the function of every piece between
+//                            crossings, plus the function up to every 64th step                                            [parallel]
+//   k_bb_walk                one wave per chromosome walks chunks and crossings in order: applies the piece functions to the exact
+//                            (k, e), does the ~21 crossing steps with real FP64 adds, and CHECKS every prediction (binade of
+//                            each piece, no piece reaching 2^53); a wrong prediction flags the chromosome for k_viterbi
+//   k_bb_emit                carry[] at the multiples of 64 from the exact piece origins                                   [parallel]
+#define BB_CHUNK 1024
+#define BB_MAXC 16
+struct BbChunk { int32_t chrom; int32_t t0; };
+struct BbCross { ParFn before; double v; int32_t pos; int32_t e; };              // piece before the crossing, the crossing's increment, predicted binade after it
+struct BbChunkOut { ParFn tail; int32_t nCross; int32_t headE; int64_t pad; };    // piece from the last crossing (or chunk start) to the chunk end
+struct BbPost { unsigned long long bits; };                                       // |D| right after a crossing (raw double bits)
+__device__ __forceinline__ bool bb_bad_increment(unsigned long long vb) { return ((vb >> 52) & 0x7ffull) == 0x7ffull || (!(vb >> 63) && (vb << 1) != 0ull); }
+__device__ __forceinline__ ParFn parfn_of(unsigned long long vb, int eM) {       // step "add |v|" inside binade eM (biased, >= 1)
+    const unsigned long long MANT = (1ull << 52) - 1ull;
+    const int ea = (int)((vb >> 52) & 0x7ffull);
+    const unsigned long long ma = ea ? ((vb & MANT) | (1ull << 52)) : (vb & MANT);
+    const int shift = eM - (ea ? ea : 1);
+    unsigned long long A = 0; int r = 0;
+    if (shift <= 0) { if (ma) A = 1ull << 53; }
+    else if (shift < 64) { A = ma >> shift; const unsigned long long rem = ma & ((1ull << shift) - 1ull), half = 1ull << (shift - 1); r = rem > half ? 1 : (rem == half ? 2 : 0); }
+    const unsigned long long up = A + (r == 1 ? 1ull : 0ull);
+    ParFn f; f.a0 = up + ((r == 2 && (A & 1ull)) ? 1ull : 0ull); f.a1 = up + ((r == 2 && !(A & 1ull)) ? 1ull : 0ull);
+    return f;
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int d) { return __hiloint2double(__shfl_up(__double2hiint(v), d), __shfl_up(__double2loint(v), d)); }
+
+__global__ void __launch_bounds__(256) k_bb_sums(const BbChunk* __restrict__ chunks, const HmmChrom* __restrict__ chroms, const double* __restrict__ V, double* __restrict__ chunkSum,
+                                                 int32_t* __restrict__ fail) {
+    __shared__ double sw[4];
+    const BbChunk K = chunks[blockIdx.x];
+    const HmmChrom C = chroms[K.chrom];
+    const double* __restrict__ Vc = V + C.begin;
+    double s = 0.0; bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int64_t t = (int64_t)K.t0 + threadIdx.x * 4 + i;
+        if (t < C.T) { const double v = Vc[t]; bad |= bb_bad_increment((unsigned long long)__double_as_longlong(v)); s += fabs(v); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __hiloint2double(__shfl_xor(__double2hiint(s), d), __shfl_xor(__double2loint(s), d));
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    if (bad) fail[K.chrom] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) chunkSum[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+// one wave per chromosome: exclusive scan of the chunk sums
+__global__ void __launch_bounds__(64) k_bb_bases(const int32_t* __restrict__ firstChunk, const double* __restrict__ chunkSum, double* __restrict__ chunkBase) {
+    const int c = blockIdx.x, l = threadIdx.x;
+    double carry = 0.0;
+    for (int g = firstChunk[c]; g < firstChunk[c + 1]; g += 64) {
+        const int i = g + l;
+        const double v = i < firstChunk[c + 1] ? chunkSum[i] : 0.0;
+        double inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { double o = shfl_up_f64(inc, d); if (l >= d) inc += o; }
+        if (i < firstChunk[c + 1]) chunkBase[i] = carry + (inc - v);
+        carry += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), 63), __builtin_amdgcn_readlane(__double2loint(inc), 63));
+    }
+}
+struct SegFn { ParFn f; uint32_t head; uint32_t cnt; };       // segmented composition + crossing count
+__device__ __forceinline__ SegFn segfn_then(SegFn a, SegFn b) {  // a first, then b
+    SegFn r; r.head = a.head | b.head; r.cnt = a.cnt + b.cnt; r.f = b.head ? b.f : parfn_then(a.f, b.f);
+    return r;
+}
+__global__ void __launch_bounds__(256) k_bb_pieces(const BbChunk* __restrict__ chunks, const HmmChrom* __restrict__ chroms, const double* __restrict__ V,
+                                                   const double* __restrict__ chunkBase, BbChunkOut* __restrict__ outChunk, BbCross* __restrict__ outCross,
+                                                   ParFn* __restrict__ at64Fn, uint8_t* __restrict__ at64Rank, int32_t* __restrict__ fail) {
+    __shared__ double swSum[4];
+    __shared__ SegFn swSeg[4];
+    const BbChunk K = chunks[blockIdx.x];
+    const HmmChrom C = chroms[K.chrom];
+    const double* __restrict__ Vc = V + C.begin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long vb[4]; double a[4]; bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int64_t t = (int64_t)K.t0 + tid * 4 + i;
+        in[i] = t < C.T;
+        const double v = in[i] ? Vc[t] : 0.0;
+        vb[i] = (unsigned long long)__double_as_longlong(v); a[i] = fabs(v);
+    }
+    // approximate running |D| before / after every step
+    const double tsum = ((a[0] + a[1]) + a[2]) + a[3];
+    double inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { double o = shfl_up_f64(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) swSum[wave] = inc;
+    __syncthreads();
+    double base = chunkBase[blockIdx.x];
+    for (int w = 0; w < wave; w++) base += swSum[w];
+    double Mprev = base + (inc - tsum);
+    // per-step functions under the predicted binade; a crossing step restarts the composition behind it
+    SegFn el[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double Mcur = Mprev + a[i];
+        const int ep = (int)(((unsigned long long)__double_as_longlong(Mprev) >> 52) & 0x7ffull), ec = (int)(((unsigned long long)__double_as_longlong(Mcur) >> 52) & 0x7ffull);
+        const bool cross = in[i] && (ep == 0 || ec != ep);
+        el[i].head = cross ? 1u : 0u; el[i].cnt = cross ? 1u : 0u;
+        if (cross || !in[i]) { el[i].f.a0 = 0; el[i].f.a1 = 0; }
+        else el[i].f = parfn_of(vb[i], ep);
+        a[i] = Mcur;                                                 // keep: predicted |D| after the step
+        Mprev = Mcur;
+    }
+    SegFn th = el[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) th = segfn_then(th, el[i]);
+    SegFn sc = th;                                                   // inclusive scan over threads
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        SegFn o; o.f = parfn_shfl_up(sc.f, d); o.head = __shfl_up(sc.head, d); o.cnt = __shfl_up(sc.cnt, d);
+        if (lane >= d) sc = segfn_then(o, sc);
+    }
+    if (lane == 63) swSeg[wave] = sc;
+    __syncthreads();
+    SegFn ex; ex.f.a0 = 0; ex.f.a1 = 0; ex.head = 0; ex.cnt = 0;     // exclusive prefix of this thread
+    for (int w = 0; w < wave; w++) ex = segfn_then(ex, swSeg[w]);
+    { SegFn o; o.f = parfn_shfl_up(sc.f, 1); o.head = __shfl_up(sc.head, 1); o.cnt = __shfl_up(sc.cnt, 1); if (lane > 0) ex = segfn_then(ex, o); }
+    // walk the four steps again with the exclusive prefix
+    SegFn run = ex;
+    BbCross* __restrict__ myCross = outCross + (size_t)blockIdx.x * BB_MAXC;
+    bool overflow = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int pos = tid * 4 + i;
+        if (el[i].head) {
+            if (run.cnt < BB_MAXC) {
+                BbCross R; R.before = run.f; R.v = __longlong_as_double((long long)vb[i]);
+                R.pos = pos; R.e = (int)(((unsigned long long)__double_as_longlong(a[i]) >> 52) & 0x7ffull);
+                myCross[run.cnt] = R;
+            } else overflow = true;
+        }
+        run = segfn_then(run, el[i]);
+        if ((pos & 63) == 63) {
+            at64Fn[(size_t)blockIdx.x * 16 + (pos >> 6)] = run.f;
+            at64Rank[(size_t)blockIdx.x * 16 + (pos >> 6)] = (uint8_t)((run.cnt > 127u ? 127u : run.cnt) | (el[i].head ? 0x80u : 0u));
+        }
+    }
+    if (overflow) fail[K.chrom] = 1;
+    if (tid == 0) {   // binade the first piece was computed under (the first step's predicted "before" exponent)
+        outChunk[blockIdx.x].headE = (int)(((unsigned long long)__double_as_longlong(base) >> 52) & 0x7ffull);
+    }
+    if (tid == 255) { outChunk[blockIdx.x].tail = run.f; outChunk[blockIdx.x].nCross = (int32_t)run.cnt; }
+}
+// one wave per chromosome; lane 0 walks, the wave stages chunk summaries / crossing records through LDS
+__global__ void __launch_bounds__(64) k_bb_walk(const int32_t* __restrict__ firstChunk, const BbChunkOut* __restrict__ chunkOut, const BbCross* __restrict__ cross,
+                                                unsigned long long* __restrict__ chunkBits, BbPost* __restrict__ post, int32_t* __restrict__ fail) {
+    __shared__ BbChunkOut sCh[64];
+    __shared__ BbCross sCr[BB_MAXC];
+    __shared__ unsigned long long sBits; __shared__ int sFail;
+    const int c = blockIdx.x, l = threadIdx.x;
+    const unsigned long long MANT = (1ull << 52) - 1ull, TWO53 = 1ull << 53;
+    if (fail[c]) return;
+    if (l == 0) { sBits = 0ull; sFail = 0; }
+    for (int g = firstChunk[c]; g < firstChunk[c + 1]; g += 64) {
+        const int n = firstChunk[c + 1] - g < 64 ? firstChunk[c + 1] - g : 64;
+        if (l < n) sCh[l] = chunkOut[g + l];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < n; i++) {
+            const int nc = sCh[i].nCross;                            // uniform
+            if (nc > 0) {
+                if (l < nc && l < BB_MAXC) sCr[l] = cross[(size_t)(g + i) * BB_MAXC + l];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
+            if (l == 0 && !sFail) {
+                unsigned long long bits = sBits;
+                chunkBits[g + i] = bits;
+                auto apply = [&](const ParFn& f, int eUsed) {
+                    if (f.a0 == 0ull && f.a1 == 0ull) return;        // empty piece
+                    const int e = (int)(bits >> 52);
+                    if (e != eUsed || e == 0) { sFail = 1; return; }
+                    const unsigned long long k = (bits & MANT) | (1ull << 52);
+                    const unsigned long long k2 = k + ((k & 1ull) ? f.a1 : f.a0);
+                    if (k2 >= TWO53) { sFail = 1; return; }
+                    bits = ((unsigned long long)e << 52) | (k2 & MANT);
+                };
+                int eCur = sCh[i].headE;
+                for (int r = 0; r < nc && r < BB_MAXC; r++) {
+                    apply(sCr[r].before, eCur);
+                    const double acc = -__longlong_as_double((long long)bits) + sCr[r].v;         // the leaving step: a real add
+                    bits = (unsigned long long)__double_as_longlong(-acc) & ~(1ull << 63);
+                    if ((int)(bits >> 52) != sCr[r].e) sFail = 1;
+                    post[(size_t)(g + i) * BB_MAXC + r].bits = bits;
+                    eCur = sCr[r].e;
+                }
+                apply(sCh[i].tail, eCur);
+                sBits = bits;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (l == 0 && sFail) fail[c] = 1;
+}
+__global__ void __launch_bounds__(256) k_bb_emit(const BbChunk* __restrict__ chunks, int nchunks, const HmmChrom* __restrict__ chroms, const unsigned long long* __restrict__ chunkBits,
+                                                 const BbPost* __restrict__ post, const ParFn* __restrict__ at64Fn, const uint8_t* __restrict__ at64Rank, double* __restrict__ carryOut) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = i >> 4, q = i & 15;
+    if (c >= nchunks) return;
+    const BbChunk K = chunks[c];
+    const HmmChrom C = chroms[K.chrom];
+    if (q == 0 && K.t0 == 0) carryOut[C.begin] = 0.0;
+    const int64_t t = (int64_t)K.t0 + q * 64 + 63;
+    if (t + 1 >= C.T) return;
+    const unsigned long long MANT = (1ull << 52) - 1ull;
+    const uint32_t rk = at64Rank[i];
+    const uint32_t rank = rk & 0x7fu;
+    unsigned long long bits = rank == 0 ? chunkBits[c] : post[(size_t)c * BB_MAXC + (rank - 1)].bits;
+    if (!(rk & 0x80u)) {
+        const ParFn f = at64Fn[i];
+        if (f.a0 != 0ull || f.a1 != 0ull) {
+            const unsigned long long k = (bits & MANT) | (1ull << 52);
+            const unsigned long long k2 = k + ((k & 1ull) ? f.a1 : f.a0);
+            bits = (bits & ~MANT) | (k2 & MANT);
+        }
+    }
+    carryOut[C.begin + t + 1] = -__longlong_as_double((long long)bits);
+}
+
+// C: exact verification, one lane per block
+__global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
+                                                   const double* __restrict__ logPmf, HmmParams P, const uint16_t* __restrict__ psi,
                                                    const int32_t* __restrict__ state, const double* __restrict__ V, const double* __restrict__ carry, const int32_t* __restrict__ lastGuess,
                                                    int32_t* __restrict__ fail) {
     extern __shared__ double sTab[];
-    __shared__ double sE_[VWPB][64 * NSTATE];
-    __shared__ uint8_t sPsi_[VWPB][NSTATE][64];
-    __shared__ int32_t sState_[VWPB][65];
-    __shared__ double sD_[VWPB][64];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
-    if (useLds) { for (int i = threadIdx.x; i < P.tableLen * NSTATE; i += 64 * VWPB) sTab[i] = logPmf[i]; }
-    __syncthreads();
-    const int bidx = blockIdx.x * VWPB + w;
-    if (bidx >= nblocksTotal) return;
-    double* sE = sE_[w]; uint8_t (*sPsi)[64] = sPsi_[w]; int32_t* sState = sState_[w]; double* sD = sD_[w];
-    const VitBlock B = blocks[bidx];
+    vit_stage_table(sTab, logPmf, P.tableLen, useLds);
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const bool act = b < nblocks;
+    const VitBlock B = blocks[act ? b : nblocks - 1];
     const HmmChrom C = chroms[B.chrom];
-    const double* tab = useLds ? sTab : logPmf;
-    const int j = l < NSTATE ? l : 0;
-    double la[NSTATE];
-#pragma unroll
-    for (int i = 0; i < NSTATE; i++) la[i] = P.logA[i][j];
-    const double NEG = -1.7976931348623157e308;
-    const int32_t* ix = idx + C.begin;
-    const int32_t* st = state + C.begin;
-    const double* Vc = V + C.begin;
     const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;
-    int64_t ts = tBeg - VW2; if (ts < 0) ts = 0;
-    ts &= ~(int64_t)63;
-    double delta = 0.0;
-    bool valid = false;       // is this lane's delta the exact delta_t(j)?
+    const int64_t ts = tBeg > VW2 ? tBeg - VW2 : 0;                                // a multiple of 64: carry[] is defined there
+    const int nsteps = act ? (int)(tEnd - ts) : 0;
+    const int maxSteps = wave_max_i32(nsteps);
+    const int32_t* __restrict__ ix = idx + C.begin + ts;
+    const int32_t* __restrict__ st = state + C.begin + ts;
+    const double* __restrict__ Vc = V + C.begin + ts;
+    const uint16_t* __restrict__ pp = psi + C.begin + ts;
+    double d[NSTATE] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    uint32_t valid = 0;                         // bit j: d[j] is the exact delta_t(j)
     bool bad = false;
-    double Dprev = carry[C.begin + ts];      // D_{ts-1} (0 at the start of the chromosome)
-    for (int64_t c0 = ts; c0 < tEnd; c0 += 64) {
-        { int64_t t = c0 + l;
-          if (t < C.T) { int k = ix[t];
+    double Dprev = carry[C.begin + ts];         // D_{ts-1} (0 at the start of the chromosome)
+    int sPrev = ts > 0 ? state[C.begin + ts - 1] : -1;
+    int kq[PQ], sq[PQ]; double vq[PQ]; uint32_t pq[PQ];
 #pragma unroll
-            for (int s = 0; s < NSTATE; s++) { sE[l * NSTATE + s] = tab[s * P.tableLen + k]; sPsi[s][l] = psi[(size_t)s * N + C.begin + t]; }
-            sState[l + 1] = st[t]; sD[l] = Vc[t]; }
-          if (l == 0) sState[0] = c0 > 0 ? st[c0 - 1] : -1; }
-        WAVE_SYNC();
-        const int steps = (int)((tEnd - c0) < 64 ? (tEnd - c0) : 64);
-        for (int s = 0; s < steps; s++) {
-            const int64_t t = c0 + s;
-            const double e = sE[s * NSTATE + j];
-            const int sCur = sState[s + 1], sPrev = sState[s];
-            const double Dt = Dprev + sD[s];          // D_t = D_{t-1} + v_t (same association as k_vit_backbone)
-            if (t == 0) {
-                double lik = e + P.logA[0][j]; delta = P.logPi[j] + lik - P.logA[0][j]; valid = true;
-                if (j == sCur && delta != Dt) bad = true;
-            } else if (t < tBeg || t == ts) {
-                // lead-in: follow the guessed pointers; a state is exact once its ancestry reaches the backbone
-                const int p = sPsi[j][s];
-                double dp = 0.0; bool vp = false;
+    for (int u = 0; u < PQ; u++) { const bool in = u < nsteps; kq[u] = in ? ix[u] : 0; sq[u] = in ? st[u] : 0; vq[u] = in ? Vc[u] : 0.0; pq[u] = in ? pp[u] : 0u; }
+    for (int s0 = 0; s0 < maxSteps; s0 += PQ) {
 #pragma unroll
-                for (int i = 0; i < NSTATE; i++) { double di = readlane_f64(delta, i); bool vi = __builtin_amdgcn_readlane((int)valid, i) != 0; if (p == i) { dp = di; vp = vi; } }
-                if (t == ts) vp = false;                         // nothing is known before the lead-in
-                if (j == sCur) { delta = Dt; valid = true; }
-                else if (p == sPrev) { delta = Dprev + (e + la[p]); valid = true; }
-                else if (vp) { delta = dp + (e + la[p]); valid = true; }
-                else valid = false;
-            } else {
-                // inside the block: every state must be exact by now; redo the reference's arg-max and compare with the guess
-                int allValid = 1;
+        for (int u = 0; u < PQ; u++) {
+            const int s = s0 + u;
+            const int k = kq[u], sCur = sq[u]; const double v = vq[u]; const uint32_t pk = pq[u];
+            { const bool in = s + PQ < nsteps; kq[u] = in ? ix[s + PQ] : 0; sq[u] = in ? st[s + PQ] : 0; vq[u] = in ? Vc[s + PQ] : 0.0; pq[u] = in ? pp[s + PQ] : 0u; }
+            if (s < nsteps) {
+                const int64_t t = ts + s;
+                double e[NSTATE];
+                vit_emissions(e, sTab, logPmf, useLds, P.tableLen, k);
+                const double Dt = Dprev + v;                  // D_t = D_{t-1} + v_t (same association as the backbone)
+                if (t == 0) {
+                    vit_init5(d, e, P); valid = 31u;
+                    if (sel5(d, (uint32_t)sCur) != Dt) bad = true;
+                } else if (t < tBeg || s == 0) {
+                    // lead-in: follow the guessed pointers; a state is exact once its ancestry reaches the backbone
+                    double nd[NSTATE]; uint32_t nv = 0;
 #pragma unroll
-                for (int i = 0; i < NSTATE; i++) allValid &= __builtin_amdgcn_readlane((int)valid, i);
-                if (!allValid) bad = true;
-                double nd; int arg;
-                vit_step(e, la, delta, NEG, nd, arg);
-                if (l < NSTATE) { if (arg != (int)sPsi[j][s]) bad = true; if (j == sCur && nd != Dt) bad = true; }
-                delta = nd;
+                    for (int j = 0; j < NSTATE; j++) {
+                        const uint32_t p = map_get(pk, j);
+                        const double dp = sel5(d, p);
+                        const bool vp = s == 0 ? false : ((valid >> p) & 1u) != 0;      // nothing is known before the lead-in
+                        double la = P.logA[0][j];
+                        la = p == 1 ? P.logA[1][j] : la; la = p == 2 ? P.logA[2][j] : la; la = p == 3 ? P.logA[3][j] : la; la = p == 4 ? P.logA[4][j] : la;
+                        const double step = e[j] + la;
+                        double r = d[j]; bool ok = false;
+                        if (j == sCur) { r = Dt; ok = true; }
+                        else if ((int)p == sPrev) { r = Dprev + step; ok = true; }
+                        else if (vp) { r = dp + step; ok = true; }
+                        nd[j] = r; nv |= ok ? (1u << j) : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NSTATE; j++) d[j] = nd[j];
+                    valid = nv;
+                } else {
+                    // inside the block: every state must be exact by now; redo the reference's arg-max and compare with the guess
+                    if (valid != 31u) bad = true;
+                    const uint32_t got = vit_step5(d, e, P);
+                    if (got != pk) bad = true;
+                    if (sel5(d, (uint32_t)sCur) != Dt) bad = true;
+                }
+                Dprev = Dt; sPrev = sCur;
             }
-            Dprev = Dt;
         }
-        WAVE_SYNC();
     }
-    if (tEnd == C.T) {
-        double d[NSTATE];
-#pragma unroll
-        for (int i = 0; i < NSTATE; i++) d[i] = readlane_f64(delta, i);
-        int allValid = 1;
-#pragma unroll
-        for (int i = 0; i < NSTATE; i++) allValid &= __builtin_amdgcn_readlane((int)valid, i);
-        int best = -1; double m1 = NEG;
-#pragma unroll
-        for (int i = 0; i < NSTATE; i++) if (d[i] > m1) { best = i; m1 = d[i]; }
-        if (!allValid || best != lastGuess[B.chrom]) bad = true;
-    }
-    if (l < NSTATE && bad) atomicOr(&fail[B.chrom], 1);
+    if (act && tEnd == C.T) { if (valid != 31u || vit_best5(d) != lastGuess[B.chrom]) bad = true; }
+    if (act && bad) atomicOr(&fail[B.chrom], 1);
 }
 
 // test hook (CANVAS_HMM_TEST_CORRUPT): flips one guessed back-pointer so that tests can prove k_vit_verify catches a wrong guess
-__global__ void k_vit_corrupt(uint8_t* __restrict__ psi, int64_t N, int64_t at) { if (threadIdx.x == 0 && blockIdx.x == 0) { psi[(size_t)2 * N + at] = (psi[(size_t)2 * N + at] + 1) % 5; } }
+__global__ void k_vit_corrupt(uint16_t* __restrict__ psi, int64_t at) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { uint32_t v = psi[at], p = (v >> 6) & 7u; psi[at] = (uint16_t)((v & ~(7u << 6)) | (((p + 1u) % 5u) << 6)); }
+}
 
-// ---- backtracking as function composition over blocks of BT_BLOCK steps
-// block b of a chromosome covers t in (lo, hi] with hi = min(T-1, (b+1)*BT_BLOCK), lo = b*BT_BLOCK; state[t-1] = psi[state[t]][t]
-struct BtBlock { int32_t chrom; int64_t lo, hi; };   // chromosome-relative
-__global__ void __launch_bounds__(256) k_bt_maps(const BtBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const uint8_t* __restrict__ psi,
-                                                 int64_t N, uint8_t* __restrict__ maps /* [nblocks][5] */) {
+// ---- backtracking as function composition over the VB-step blocks: state[t-1] = psi_t[state[t]]
+// map of a block = psi_{tBeg} o ... o psi_{tEnd-1}: state at the block's last step -> state just before its first step
+__global__ void __launch_bounds__(256) k_bt_maps(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const uint16_t* __restrict__ psi,
+                                                 uint16_t* __restrict__ maps) {
     int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nblocks) return;
-    const BtBlock B = blocks[b];
-    const int64_t base = chroms[B.chrom].begin;
-    int s[NSTATE] = {0, 1, 2, 3, 4};
-    for (int64_t t = B.hi; t > B.lo; t--) {
-#pragma unroll
-        for (int k = 0; k < NSTATE; k++) s[k] = psi[(size_t)s[k] * N + base + t];
-    }
-#pragma unroll
-    for (int k = 0; k < NSTATE; k++) maps[b * NSTATE + k] = (uint8_t)s[k];
+    const VitBlock B = blocks[b];
+    const HmmChrom C = chroms[B.chrom];
+    const int64_t tBeg = B.t0 > 0 ? B.t0 : 1, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;
+    uint32_t m = MAP_IDENT;
+    for (int64_t t = tEnd - 1; t >= tBeg; t--) m = map_compose(psi[C.begin + t], m);
+    maps[b] = (uint16_t)m;
 }
-// one thread per chromosome: entry state of every block (state at t = hi)
-__global__ void k_bt_chain(const int32_t* __restrict__ firstBlock, int nchr, const int32_t* __restrict__ lastState, const uint8_t* __restrict__ maps, int8_t* __restrict__ entry) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchr) return;
+// one wave per chromosome: entry[b] = state at the last step of block b.  64 blocks at a time from the end: an inclusive
+// composition scan over the lanes (lane 0 = last block), then the running state is pushed through the whole group.
+__global__ void __launch_bounds__(64) k_bt_chain(const int32_t* __restrict__ firstBlock, const int32_t* __restrict__ lastState, const uint16_t* __restrict__ maps,
+                                                 int8_t* __restrict__ entry) {
+    const int c = blockIdx.x, l = threadIdx.x;
+    const int first = firstBlock[c], last = firstBlock[c + 1] - 1;
     int s = lastState[c];
-    for (int b = firstBlock[c + 1] - 1; b >= firstBlock[c]; b--) {
-        entry[b] = (int8_t)s;
-        if (s >= 0) s = maps[b * NSTATE + s];
+    for (int g = last; g >= first; g -= 64) {
+        const int bi = g - l;
+        uint32_t f = bi >= first ? (uint32_t)maps[bi] : MAP_IDENT;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) { uint32_t o = __shfl_up(f, dlt); if (l >= dlt) f = map_compose(f, o); }   // first the later blocks (o), then this one
+        uint32_t ex = __shfl_up(f, 1);
+        if (bi >= first) entry[bi] = (int8_t)(s < 0 ? s : (l == 0 ? s : (int)map_get(ex, (uint32_t)s)));
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)f, 63);
+        if (s >= 0) s = (int)map_get(all, (uint32_t)s);
     }
 }
-__global__ void __launch_bounds__(256) k_bt_states(const BtBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const uint8_t* __restrict__ psi,
-                                                   int64_t N, const int8_t* __restrict__ entry, int32_t* __restrict__ state) {
+__global__ void __launch_bounds__(256) k_bt_states(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const uint16_t* __restrict__ psi,
+                                                   const int8_t* __restrict__ entry, int32_t* __restrict__ state) {
     int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nblocks) return;
-    const BtBlock B = blocks[b];
-    const int64_t base = chroms[B.chrom].begin;
+    const VitBlock B = blocks[b];
+    const HmmChrom C = chroms[B.chrom];
+    const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;
     int s = entry[b];
-    for (int64_t t = B.hi; t > B.lo; t--) {
-        state[base + t] = s;
-        if (s >= 0) s = psi[(size_t)s * N + base + t];
+    for (int64_t t = tEnd - 1; t >= tBeg; t--) {
+        state[C.begin + t] = s;
+        if (s >= 0 && t > 0) s = (int)map_get(psi[C.begin + t], (uint32_t)s);
     }
-    if (B.lo == 0) state[base] = s;
 }
+
 __global__ void __launch_bounds__(256) k_fill_i32(int32_t* __restrict__ p, int64_t begin, int64_t end, int32_t v) {
     int64_t i = begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < end) p[i] = v;
@@ -671,31 +930,42 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = h_chr_offset[nchr];
     if (N < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
-    // blocks for the backtrack
+    // VB-step blocks (speculation, verification and backtrack share them)
     std::vector<HmmChrom> chroms(nchr);
-    std::vector<BtBlock> blocks; std::vector<int32_t> firstBlock(nchr + 1);
+    std::vector<VitBlock> vblocks; std::vector<int32_t> firstBlock(nchr + 1);
     for (int c = 0; c < nchr; c++) {
         chroms[c].begin = h_chr_offset[c]; chroms[c].T = h_chr_offset[c + 1] - h_chr_offset[c];
-        firstBlock[c] = (int32_t)blocks.size();
-        if (chroms[c].T > 10)
-            for (int64_t lo = 0; lo < chroms[c].T - 1; lo += BT_BLOCK) blocks.push_back({c, lo, std::min<int64_t>(lo + BT_BLOCK, chroms[c].T - 1)});
+        firstBlock[c] = (int32_t)vblocks.size();
+        if (chroms[c].T > 10) for (int64_t t0 = 0; t0 < chroms[c].T; t0 += VB) vblocks.push_back({c, (int32_t)t0});
     }
-    firstBlock[nchr] = (int32_t)blocks.size();
-    const int nblocks = (int)blocks.size();
-    std::vector<VitBlock> vblocks;
-    for (int c = 0; c < nchr; c++) if (chroms[c].T > 10) for (int64_t t0 = 0; t0 < chroms[c].T; t0 += VB) vblocks.push_back({c, (int32_t)t0});
+    firstBlock[nchr] = (int32_t)vblocks.size();
+    const int nblocks = (int)vblocks.size();
+    std::vector<BbChunk> bchunks; std::vector<int32_t> firstChunk(nchr + 1);
+    for (int c = 0; c < nchr; c++) {
+        firstChunk[c] = (int32_t)bchunks.size();
+        if (chroms[c].T > 10) for (int64_t t0 = 0; t0 < chroms[c].T; t0 += BB_CHUNK) bchunks.push_back({c, (int32_t)t0});
+    }
+    firstChunk[nchr] = (int32_t)bchunks.size();
+    const int nchunks = (int)bchunks.size();
     WsSizer sz;
-    sz.take<uint32_t>(N); sz.take<int32_t>(N); sz.take<uint8_t>((size_t)NSTATE * N); sz.take<HmmChrom>(nchr); sz.take<int32_t>(nchr);
-    sz.take<BtBlock>(nblocks + 1); sz.take<int32_t>(nchr + 1); sz.take<uint8_t>((size_t)nblocks * NSTATE + 8); sz.take<int8_t>(nblocks + 8); sz.take<double>(NSTATE * 70000);
-    sz.take<int64_t>(nchr + 1); sz.take<VitBlock>(vblocks.size() + 1); sz.take<double>(N); sz.take<double>(N + 64); sz.take<int32_t>(nchr); sz.take<int32_t>(nchr);
+    sz.take<BbChunk>(nchunks + 1); sz.take<int32_t>(nchr + 1); sz.take<double>(nchunks + 1); sz.take<double>(nchunks + 1); sz.take<BbChunkOut>(nchunks + 1);
+    sz.take<BbCross>((size_t)nchunks * BB_MAXC + 1); sz.take<ParFn>((size_t)nchunks * 16 + 1); sz.take<uint8_t>((size_t)nchunks * 16 + 8);
+    sz.take<unsigned long long>(nchunks + 1); sz.take<BbPost>((size_t)nchunks * BB_MAXC + 1);
+    sz.take<uint32_t>(N); sz.take<int32_t>(N); sz.take<uint16_t>(N + 8); sz.take<HmmChrom>(nchr); sz.take<int32_t>(nchr);
+    sz.take<int32_t>(nchr + 1); sz.take<uint16_t>(nblocks + 8); sz.take<int8_t>(nblocks + 8); sz.take<double>(NSTATE * 70000);
+    sz.take<int64_t>(nchr + 1); sz.take<VitBlock>(nblocks + 1); sz.take<double>(N); sz.take<double>(N + 64); sz.take<int32_t>(nchr); sz.take<int32_t>(nchr);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
     WsCarver ws(ctx->ws);
-    uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N); uint8_t* psi = ws.take<uint8_t>((size_t)NSTATE * N);
+    uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N); uint16_t* psi = ws.take<uint16_t>(N + 8);
     HmmChrom* dChroms = ws.take<HmmChrom>(nchr); int32_t* dLast = ws.take<int32_t>(nchr);
-    BtBlock* dBlocks = ws.take<BtBlock>(nblocks + 1); int32_t* dFirst = ws.take<int32_t>(nchr + 1);
-    uint8_t* dMaps = ws.take<uint8_t>((size_t)nblocks * NSTATE + 8); int8_t* dEntry = ws.take<int8_t>(nblocks + 8); double* dTab = ws.take<double>(NSTATE * 70000);
+    int32_t* dFirst = ws.take<int32_t>(nchr + 1);
+    uint16_t* dMaps = ws.take<uint16_t>(nblocks + 8); int8_t* dEntry = ws.take<int8_t>(nblocks + 8); double* dTab = ws.take<double>(NSTATE * 70000);
     int64_t* dOffDev = ws.take<int64_t>(nchr + 1);
-    VitBlock* dVBlocks = ws.take<VitBlock>(vblocks.size() + 1); double* dD = ws.take<double>(N); double* dCarry = ws.take<double>(N + 64); int32_t* dFail = ws.take<int32_t>(nchr); int32_t* dRedo = ws.take<int32_t>(nchr);
+    VitBlock* dVBlocks = ws.take<VitBlock>(nblocks + 1); double* dD = ws.take<double>(N); double* dCarry = ws.take<double>(N + 64); int32_t* dFail = ws.take<int32_t>(nchr); int32_t* dRedo = ws.take<int32_t>(nchr);
+    BbChunk* dBChunks = ws.take<BbChunk>(nchunks + 1); int32_t* dFirstChunk = ws.take<int32_t>(nchr + 1);
+    double* dChunkSum = ws.take<double>(nchunks + 1); double* dChunkBase = ws.take<double>(nchunks + 1); BbChunkOut* dChunkOut = ws.take<BbChunkOut>(nchunks + 1);
+    BbCross* dCross = ws.take<BbCross>((size_t)nchunks * BB_MAXC + 1); ParFn* dAt64Fn = ws.take<ParFn>((size_t)nchunks * 16 + 1); uint8_t* dAt64Rank = ws.take<uint8_t>((size_t)nchunks * 16 + 8);
+    unsigned long long* dChunkBits = ws.take<unsigned long long>(nchunks + 1); BbPost* dPost = ws.take<BbPost>((size_t)nchunks * BB_MAXC + 1);
 
     // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
     hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
@@ -726,10 +996,11 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     }
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dChroms, chroms.data(), nchr * sizeof(HmmChrom), hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dBlocks, blocks.data(), nblocks * sizeof(BtBlock), hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirst, firstBlock.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOffDev, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (!vblocks.empty()) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVBlocks, vblocks.data(), vblocks.size() * sizeof(VitBlock), hipMemcpyHostToDevice, ctx->stream));
+    if (nchunks > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dBChunks, bchunks.data(), (size_t)nchunks * sizeof(BbChunk), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstChunk, firstChunk.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     // 3. index, Viterbi, backtrack
     hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);
     size_t tabBytes = (size_t)NSTATE * P.tableLen * 8;
@@ -737,11 +1008,12 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     for (int c = 0; c < nchr; c++)
         if (chroms[c].T <= 10 && chroms[c].T > 0)
             hipLaunchKernelGGL(k_fill_i32, dim3(nblk2(chroms[c].T, 256)), dim3(256), 0, ctx->stream, d_state, chroms[c].begin, chroms[c].begin + chroms[c].T, -1);
-    auto backtrack = [&]() {
+    const unsigned laneGrid = (unsigned)((nblocks + 63) / 64);          // one lane per block
+    auto backtrack = [&](bool haveMaps) {
         if (nblocks > 0) {
-            hipLaunchKernelGGL(k_bt_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dBlocks, nblocks, dChroms, psi, N, dMaps);
-            hipLaunchKernelGGL(k_bt_chain, dim3(nblk2(nchr, 64)), dim3(64), 0, ctx->stream, dFirst, nchr, dLast, dMaps, dEntry);
-            hipLaunchKernelGGL(k_bt_states, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dBlocks, nblocks, dChroms, psi, N, dEntry, d_state);
+            if (!haveMaps) hipLaunchKernelGGL(k_bt_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, psi, dMaps);
+            hipLaunchKernelGGL(k_bt_chain, dim3(nchr), dim3(64), 0, ctx->stream, dFirst, dLast, dMaps, dEntry);
+            hipLaunchKernelGGL(k_bt_states, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, psi, dEntry, d_state);
         }
     };
     const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
@@ -750,13 +1022,21 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
         ProfScope ps(ctx, "viterbi");
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dLast, 0xFF, nchr * 4, ctx->stream));     // -1 for skipped chromosomes
-        hipLaunchKernelGGL(k_vit_spec, dim3((unsigned)((vblocks.size() + VWPB - 1) / VWPB)), dim3(64 * VWPB), lds, ctx->stream, dVBlocks, (int)vblocks.size(), dChroms, idx, dTab, P, psi, N, dLast);
-        if (getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, N, chroms[0].begin + chroms[0].T / 2);
-        backtrack();
+        hipLaunchKernelGGL(k_vit_spec, dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, dMaps, dLast);
+        if (getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, chroms[0].begin + chroms[0].T / 2);
+        backtrack(true);
         hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
-        if (getenv("CANVAS_HMM_BACKBONE_CHAIN")) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
-        else hipLaunchKernelGGL(k_vit_backbone_scan, dim3(nchr), dim3(BS_T), 0, ctx->stream, dChroms, dD, dCarry, dFail);
-        hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)((vblocks.size() + VWPB - 1) / VWPB)), dim3(64 * VWPB), lds, ctx->stream, dVBlocks, (int)vblocks.size(), dChroms, idx, dTab, P, psi, N, d_state, dD, dCarry, dLast, dFail);
+        const char* bbMode = getenv("CANVAS_HMM_BACKBONE");      // "chain" | "scan" | default: predicted pieces
+        if (bbMode && !strcmp(bbMode, "chain")) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
+        else if (bbMode && !strcmp(bbMode, "scan")) hipLaunchKernelGGL(k_vit_backbone_scan, dim3(nchr), dim3(BS_T), 0, ctx->stream, dChroms, dD, dCarry, dFail);
+        else {
+            hipLaunchKernelGGL(k_bb_sums, dim3(nchunks), dim3(256), 0, ctx->stream, dBChunks, dChroms, dD, dChunkSum, dFail);
+            hipLaunchKernelGGL(k_bb_bases, dim3(nchr), dim3(64), 0, ctx->stream, dFirstChunk, dChunkSum, dChunkBase);
+            hipLaunchKernelGGL(k_bb_pieces, dim3(nchunks), dim3(256), 0, ctx->stream, dBChunks, dChroms, dD, dChunkBase, dChunkOut, dCross, dAt64Fn, dAt64Rank, dFail);
+            hipLaunchKernelGGL(k_bb_walk, dim3(nchr), dim3(64), 0, ctx->stream, dFirstChunk, dChunkOut, dCross, dChunkBits, dPost, dFail);
+            hipLaunchKernelGGL(k_bb_emit, dim3(nblk2((int64_t)nchunks * 16, 256)), dim3(256), 0, ctx->stream, dBChunks, nchunks, dChroms, dChunkBits, dPost, dAt64Fn, dAt64Rank, dCarry);
+        }
+        hipLaunchKernelGGL(k_vit_verify, dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail);
         std::vector<int32_t> hFail(nchr, 0);
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -768,8 +1048,8 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
         // exact sequential evaluation (all chromosomes when speculation is disabled, otherwise only those whose verification failed)
         ProfScope ps(ctx, "viterbi_sequential");
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRedo, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)redo.size()), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, N, dLast, dRedo);
-        backtrack();
+        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)redo.size()), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, dLast, dRedo);
+        backtrack(false);
     }
     ctx->hmm_redo = (int)redo.size();
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host vectors feed async copies

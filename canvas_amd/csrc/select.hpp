@@ -38,29 +38,58 @@ static inline double host_double_of_key(unsigned long long k) {
     double d; memcpy(&d, &u, 8); return d;
 }
 
+// LDS contention control: (i) queries of one tile that still share a prefix (all of them in the first pass; the k / k+1 pair of
+// a median until the last digits) share ONE LDS histogram row that is replicated at flush time; (ii) digits are concentrated
+// (exponent bytes of similar counts, zero low bytes of integer-valued floats), so a wave first aggregates up to four distinct
+// digits with ballots — one LDS atomic per distinct digit — and only the lanes left over issue their own atomics.
 template <typename K>
 __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys, const SelTile* __restrict__ tiles, const SelSegQ* __restrict__ segq,
                                                      const unsigned long long* __restrict__ qprefix, int shift, int firstPass,
                                                      uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[SEL_MAXQ * 256];
     __shared__ unsigned long long lpre[SEL_MAXQ];
+    __shared__ int srep[SEL_MAXQ], suniq[SEL_MAXQ], snu;
     const SelTile T = tiles[blockIdx.x];
     const SelSegQ Q = segq[T.seg];
     if (Q.nq == 0) return;
     for (int i = threadIdx.x; i < Q.nq * 256; i += 256) lh[i] = 0;
-    if (threadIdx.x < Q.nq) lpre[threadIdx.x] = qprefix[Q.q[threadIdx.x]];
+    if (threadIdx.x < Q.nq) lpre[threadIdx.x] = firstPass ? 0ull : qprefix[Q.q[threadIdx.x]];
     __syncthreads();
+    if (threadIdx.x == 0) {
+        int nu = 0;
+        for (int q = 0; q < Q.nq; q++) {
+            int rep = q;
+            for (int u = 0; u < nu; u++) if (lpre[suniq[u]] == lpre[q]) { rep = suniq[u]; break; }
+            srep[q] = rep;
+            if (rep == q) suniq[nu++] = q;
+        }
+        snu = nu;
+    }
+    __syncthreads();
+    const int nu = snu;
+    const int lane = threadIdx.x & 63;
     const int sh2 = firstPass ? 0 : shift + 8;
     for (int64_t i = T.begin + threadIdx.x; i < T.end; i += 256) {
         K key = keys[i];
-        uint32_t d = (uint32_t)(key >> shift) & 255u;
-        unsigned long long hi = (unsigned long long)(key >> sh2);   // only compared when !firstPass (then sh2 = shift+8 < bits)
-        for (int q = 0; q < Q.nq; q++)
-            if (firstPass || hi == lpre[q]) atomicAdd(&lh[q * 256 + d], 1u);
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        const unsigned long long hi = (unsigned long long)(key >> sh2);   // only compared when !firstPass (then sh2 = shift+8 < bits)
+        for (int u = 0; u < nu; u++) {
+            const int q = suniq[u];
+            const bool m = firstPass || hi == lpre[q];
+            unsigned long long todo = __ballot(m);
+            for (int it = 0; it < 4 && todo; it++) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+                const unsigned long long same = __ballot(m && d == dl) & todo;
+                if (lane == leader) atomicAdd(&lh[q * 256 + dl], (uint32_t)__builtin_popcountll(same));
+                todo &= ~same;
+            }
+            if ((todo >> lane) & 1ull) atomicAdd(&lh[q * 256 + d], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < Q.nq * 256; i += 256) {
-        uint32_t v = lh[i];
+        uint32_t v = lh[srep[i >> 8] * 256 + (i & 255)];
         if (v) atomicAdd(&hist[(size_t)Q.q[i >> 8] * 256 + (i & 255)], v);
     }
 }

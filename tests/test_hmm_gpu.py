@@ -80,10 +80,11 @@ def test_speculation_is_verified_and_falls_back(monkeypatch):
     cv.profile_get("viterbi_sequential", reset=True)
     base = _check(cv, bins, cov, off)
     assert cv.profile_get("viterbi_sequential")[1] == 0          # speculation verified everywhere
-    monkeypatch.setenv("CANVAS_HMM_BACKBONE_CHAIN", "1")         # the wave-sequential backbone instead of the exact parity scan
-    got0 = _check(cv, bins, cov, off)
-    assert cv.profile_get("viterbi_sequential")[1] == 0 and (got0 == base).all()
-    monkeypatch.delenv("CANVAS_HMM_BACKBONE_CHAIN")
+    for mode in ("chain", "scan"):           # the wave-sequential backbone / the single-kernel parity scan instead of the predicted pieces
+        monkeypatch.setenv("CANVAS_HMM_BACKBONE", mode)
+        got0 = _check(cv, bins, cov, off)
+        assert cv.profile_get("viterbi_sequential")[1] == 0 and (got0 == base).all()
+    monkeypatch.delenv("CANVAS_HMM_BACKBONE")
     monkeypatch.setenv("CANVAS_HMM_TEST_CORRUPT", "1")
     got = _check(cv, bins, cov, off)
     assert cv.profile_get("viterbi_sequential")[1] == 1          # the corrupted chromosome was recomputed
