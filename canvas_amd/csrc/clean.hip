@@ -222,10 +222,67 @@ __global__ void __launch_bounds__(256) k_absdev_keys(const double* __restrict__ 
     keys[w] = key_of_double(fabs(sd[w] - runMedian[lo]));
 }
 // chromosome run boundaries of the bin list: positions i with chr[i] != chr[i-1]
+// pos[k] = (position << 20) | chromosome index (chromosome ids < 2^20, positions < 2^43), so one sort orders the records
 __global__ void __launch_bounds__(256) k_run_bounds(const int32_t* __restrict__ chr, int64_t n, unsigned int* __restrict__ cnt, long long* __restrict__ pos, int cap) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (i == 0 || chr[i] != chr[i - 1]) { unsigned int k = atomicAdd(cnt, 1u); if ((int)k < cap) pos[k] = i; }
+    const int32_t c = chr[i];
+    if (i == 0 || c != chr[i - 1]) { unsigned int k = atomicAdd(cnt, 1u); if ((int)k < cap) pos[k] = (long long)((i << 20) | (long long)(c & 0xFFFFF)); }
+}
+
+// Exact order statistics inside ONE workgroup: 8 MSB-radix passes over keyOf(i), i in [lo, hi), for two ranks at once
+// (the k / k+1 pair of an even-length median).  Used where the segments are small (per-chromosome window SDs).
+template <typename F>
+__device__ __forceinline__ void wg_select2(F keyOf, int64_t lo, int64_t hi, unsigned long long rank0, unsigned long long rank1, uint32_t (*sH)[256],
+                                           unsigned long long* sPre, unsigned long long* sK) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) { sPre[0] = 0; sPre[1] = 0; sK[0] = rank0; sK[1] = rank1; }
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 512; i += nt) sH[i >> 8][i & 255] = 0;
+        __syncthreads();
+        const unsigned long long p0 = sPre[0], p1 = sPre[1];
+        const bool same = p0 == p1;
+        for (int64_t i = lo + tid; i < hi; i += nt) {
+            const unsigned long long key = keyOf(i);
+            const uint32_t d = (uint32_t)(key >> shift) & 255u;
+            const unsigned long long hiPart = shift == 56 ? 0ull : key >> (shift + 8);
+            if (hiPart == p0) atomicAdd(&sH[0][d], 1u);
+            if (!same && hiPart == p1) atomicAdd(&sH[1][d], 1u);
+        }
+        __syncthreads();
+        const int w = tid >> 6, l = tid & 63;
+        if (w < 2) {
+            const uint32_t* h = sH[same ? 0 : w];
+            uint32_t c0 = h[4 * l], c1 = h[4 * l + 1], c2 = h[4 * l + 2], c3 = h[4 * l + 3];
+            uint32_t sum = c0 + c1 + c2 + c3;
+            uint32_t inc = wave_inclusive_scan_u32(sum), ex = inc - sum;
+            const unsigned long long k = sK[w];
+            if (k >= ex && k < inc) {
+                uint32_t r = (uint32_t)(k - ex), d;
+                if (r < c0) { d = 0; } else if (r < c0 + c1) { d = 1; r -= c0; } else if (r < c0 + c1 + c2) { d = 2; r -= c0 + c1; } else { d = 3; r -= c0 + c1 + c2; }
+                sPre[w] = (sPre[w] << 8) | (unsigned long long)(4 * l + d);
+                sK[w] = r;
+            }
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ double double_of_key(unsigned long long k) {
+    unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+// Utilities.Mad per chromosome run of the window SDs (CanvasClean.cs:243-258, Utilities.cs Median/Mad): one workgroup per run
+__global__ void __launch_bounds__(1024) k_run_mad(const double* __restrict__ sd, const int64_t* __restrict__ runStart, double* __restrict__ outMad) {
+    __shared__ uint32_t sH[2][256];
+    __shared__ unsigned long long sPre[2], sK[2];
+    const int64_t lo = runStart[blockIdx.x], hi = runStart[blockIdx.x + 1], cnt = hi - lo;
+    if (cnt <= 0) { if (threadIdx.x == 0) outMad[blockIdx.x] = 0.0; return; }
+    const unsigned long long r1 = (unsigned long long)(cnt / 2), r0 = (cnt % 2) ? r1 : r1 - 1;
+    wg_select2([&](int64_t i) { return key_of_double(sd[i]); }, lo, hi, r0, r1, sH, sPre, sK);
+    const double median = (cnt % 2) ? double_of_key(sPre[1]) : (double_of_key(sPre[0]) + double_of_key(sPre[1])) / 2;
+    __syncthreads();
+    wg_select2([&](int64_t i) { return key_of_double(fabs(sd[i] - median)); }, lo, hi, r0, r1, sH, sPre, sK);
+    if (threadIdx.x == 0) outMad[blockIdx.x] = (cnt % 2) ? double_of_key(sPre[1]) : (double_of_key(sPre[0]) + double_of_key(sPre[1])) / 2;
 }
 
 // ---------------------------------------------------------------- host helpers (scalar logic of the reference)
@@ -465,13 +522,15 @@ static int32_t local_sd(CleanState& st, double* dSd, double* dRunMedian, int64_t
     hipLaunchKernelGGL(k_run_bounds, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.n, dCnt, dPos, cap);
     unsigned int nb = 0;
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&nb, dCnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<long long> brec(1024);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(brec.data(), dPos, 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));     // the usual case: all records in one go
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((int)nb > cap) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "local SD: more than 65536 chromosome runs");
-    std::vector<long long> bpos(nb);
-    CANVAS_HIP_TRY(ctx, hipMemcpy(bpos.data(), dPos, nb * 8, hipMemcpyDeviceToHost));
-    std::sort(bpos.begin(), bpos.end());
-    std::vector<int32_t> bchr(nb);
-    for (unsigned i = 0; i < nb; i++) CANVAS_HIP_TRY(ctx, hipMemcpy(&bchr[i], st.cur.chr + bpos[i], 4, hipMemcpyDeviceToHost));
+    if (nb > 1024) { brec.resize(nb); CANVAS_HIP_TRY(ctx, hipMemcpy(brec.data(), dPos, (size_t)nb * 8, hipMemcpyDeviceToHost)); }
+    brec.resize(nb);
+    std::sort(brec.begin(), brec.end());
+    std::vector<long long> bpos(nb); std::vector<int32_t> bchr(nb);
+    for (unsigned i = 0; i < nb; i++) { bpos[i] = brec[i] >> 20; bchr[i] = (int32_t)(brec[i] & 0xFFFFF); }
     bpos.push_back(st.n);
     std::vector<int64_t> runStart; std::vector<int32_t> runChr;
     for (unsigned r = 0; r < nb; r++) {
@@ -483,29 +542,15 @@ static int32_t local_sd(CleanState& st, double* dSd, double* dRunMedian, int64_t
     const int nruns = (int)runStart.size();
     std::vector<int64_t> segOff(runStart); segOff.push_back(nW);
     segOff[0] = 0;
-    // median per run
-    hipLaunchKernelGGL(k_keys_f64, dim3(nblk(nW, 256)), dim3(256), 0, ctx->stream, dSd, nW, st.keys64);
-    std::vector<SelQuery> qs; std::vector<int> first(nruns);
-    for (int r = 0; r < nruns; r++) {
-        int64_t cnt = segOff[r + 1] - segOff[r];
-        first[r] = (int)qs.size();
-        if (cnt % 2) qs.push_back({r, r, cnt / 2}); else { qs.push_back({r, r, cnt / 2 - 1}); qs.push_back({r, r, cnt / 2}); }
-    }
-    std::vector<unsigned long long> res;
-    int32_t rc = radix_select<unsigned long long>(ctx, st.keys64, nruns, segOff, qs, res); if (rc) return rc;
-    auto med = [&](int r) -> double {
-        int64_t cnt = segOff[r + 1] - segOff[r];
-        if (cnt % 2) return host_double_of_key(res[first[r]]);
-        return (host_double_of_key(res[first[r]]) + host_double_of_key(res[first[r] + 1])) / 2;
-    };
-    std::vector<double> medians(nruns);
-    for (int r = 0; r < nruns; r++) medians[r] = med(r);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRunMedian, medians.data(), nruns * 8, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRunStart, segOff.data(), nruns * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_absdev_keys, dim3(nblk(nW, 256)), dim3(256), 0, ctx->stream, dSd, nW, dRunStart, dRunMedian, nruns, st.keys64);
-    rc = radix_select<unsigned long long>(ctx, st.keys64, nruns, segOff, qs, res); if (rc) return rc;
+    // Mad of the window SDs per run (median, then median of |x - median|), one workgroup per run
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRunStart, segOff.data(), (nruns + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nruns > 0) hipLaunchKernelGGL(k_run_mad, dim3(nruns), dim3(1024), 0, ctx->stream, dSd, dRunStart, dRunMedian);
+    std::vector<double> mads(nruns);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(mads.data(), dRunMedian, nruns * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
     double s = 0;
-    for (int r = 0; r < nruns; r++) s += med(r);        // List<double>.Average(): sequential sum / count
+    for (int r = 0; r < nruns; r++) s += mads[r];        // List<double>.Average(): sequential sum / count
     localSd = s / (double)nruns;
     return CANVAS_OK;
 }
@@ -590,7 +635,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
                                  int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc,
                                  double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info) {
     if (!ctx) return CANVAS_ERR_INVALID;
-    if (n < 0 || nchr <= 0 || !h_chr_is_autosome || !h_n_out) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: bad arguments");
+    if (n < 0 || nchr <= 0 || nchr > (1 << 20) || !h_chr_is_autosome || !h_n_out) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: bad arguments");
     const bool loessMode = (flags & CANVAS_CLEAN_LOESS) != 0;
     if (n >= 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "too many bins");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
