@@ -119,66 +119,79 @@ __global__ void __launch_bounds__(256) k_tile_stats(const BinChrom* __restrict__
 // one workgroup (1024 threads) per chromosome
 struct ChromOut { long long pop, obs, nbins, popBefore; };
 
-__device__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* sh /*>=17*/, uint32_t& total) {
-    // inclusive wave scan, then scan of 16 wave totals
-    uint32_t inc = wave_inclusive_scan_u32(v);
-    int w = threadIdx.x >> 6, l = lane_id();
-    if (l == 63) sh[w] = inc;
+// exclusive scan of one or two uint32 values per thread over a 1024-thread workgroup (uint32 wrap-around); ONE barrier per call:
+// the caller alternates `sh` between two buffers so that the next call cannot overwrite totals that are still being read
+struct U2 { uint32_t a, b; };
+__device__ __forceinline__ U2 block_exclusive_scan2_1024(U2 v, U2* sh /*16*/, U2& total) {
+    const uint32_t ia = wave_inclusive_scan_u32(v.a), ib = wave_inclusive_scan_u32(v.b);
+    const int w = threadIdx.x >> 6, l = lane_id();
+    if (l == 63) { sh[w].a = ia; sh[w].b = ib; }
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t s = 0; for (int i = 0; i < 16; i++) { uint32_t t = sh[i]; sh[i] = s; s += t; } sh[16] = s; }
-    __syncthreads();
-    uint32_t ex = inc - v + sh[w];
-    total = sh[16];
-    __syncthreads();
-    return ex;
+    uint32_t ba = 0, bb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const U2 t = sh[i]; if (i < w) { ba += t.a; bb += t.b; } ta += t.a; tb += t.b; }
+    total.a = ta; total.b = tb;
+    U2 r; r.a = ia - v.a + ba; r.b = ib - v.b + bb;
+    return r;
 }
-
+#define ST_ITEMS 8
 __global__ void __launch_bounds__(1024) k_scan_tiles(const BinChrom* __restrict__ ch, const unsigned long long* __restrict__ pos0,
                                                      const uint32_t* __restrict__ tilePop, const uint32_t* __restrict__ tileObs, int wantObs,
                                                      int binSize, int32_t* __restrict__ rankBase, ChromOut* __restrict__ out) {
-    __shared__ uint32_t sh[17];
-    __shared__ long long s_popBefore;
-    const int c = blockIdx.x;
+    __shared__ U2 sh[2][16];
+    __shared__ unsigned long long sRed[2][16];
+    const int c = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const BinChrom C = ch[c];
     const int64_t p0 = (int64_t)pos0[c] < C.len ? (int64_t)pos0[c] : C.len;
     const int64_t t0 = p0 >> TILE_SHIFT;   // tile containing pos0
-    // partial popcount inside tile t0 before pos0 (one wave is enough: 64 words)
-    if (threadIdx.x < 64) {
-        int64_t wstart = (t0 << TILE_SHIFT) + (int64_t)threadIdx.x * 64;
-        uint32_t pc = 0;
+    const uint32_t* __restrict__ pop = tilePop + C.tileBase;
+    // possible positions before pos0: full tiles before t0, plus the part of tile t0 in front of pos0 (64 mask words, wave 0)
+    unsigned long long before = 0;
+    for (int64_t t = tid; t < t0 && t < C.ntiles; t += 1024) before += pop[t];
+    if (w == 0) {
+        int64_t wstart = (t0 << TILE_SHIFT) + (int64_t)l * 64;
         if (wstart < p0) {
-            uint64_t w = C.mask[wstart >> 6];
+            uint64_t mw = C.mask[wstart >> 6];
             int64_t valid = p0 - wstart;
-            if (valid < 64) w &= (~0ull) >> (64 - valid);
-            pc = __popcll(w);
+            if (valid < 64) mw &= (~0ull) >> (64 - valid);
+            before += (unsigned long long)__popcll(mw);
         }
-        pc = wave_reduce_add_u32(pc);
-        if (threadIdx.x == 0) s_popBefore = pc;
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+    if (l == 0) sRed[0][w] = before;
     __syncthreads();
-    long long carry = 0, obsSum = 0, popBeforeFull = 0;
-    for (int64_t base = 0; base < C.ntiles; base += 1024) {
-        int64_t t = base + threadIdx.x;
-        uint32_t v = t < C.ntiles ? tilePop[C.tileBase + t] : 0;
-        uint32_t tot;
-        uint32_t ex = block_exclusive_scan_1024(v, sh, tot);
-        long long exg = carry + ex;
-        if (t < C.ntiles) rankBase[C.tileBase + t] = (int32_t)exg;   // fixed up below by subtracting popBefore
-        if (t == t0) popBeforeFull = exg;
-        carry += tot;
-        if (wantObs) { uint32_t o = t < C.ntiles ? tileObs[C.tileBase + t] : 0; uint32_t ot; (void)block_exclusive_scan_1024(o, sh, ot); obsSum += ot; }
+    unsigned long long popBefore = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) popBefore += sRed[0][i];
+    // exclusive scan of the tile popcounts, ST_ITEMS consecutive tiles per thread
+    long long carry = 0; unsigned long long obsAcc = 0;
+    int buf = 0;
+    for (int64_t base = 0; base < C.ntiles; base += 1024 * ST_ITEMS, buf ^= 1) {
+        const int64_t t = base + (int64_t)tid * ST_ITEMS;
+        uint32_t v[ST_ITEMS]; uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < ST_ITEMS; i++) { v[i] = t + i < C.ntiles ? pop[t + i] : 0u; sum += v[i]; }
+        if (wantObs) {
+#pragma unroll
+            for (int i = 0; i < ST_ITEMS; i++) if (t + i < C.ntiles) obsAcc += tileObs[C.tileBase + t + i];
+        }
+        U2 in; in.a = sum; in.b = 0; U2 tot;
+        const U2 ex = block_exclusive_scan2_1024(in, sh[buf], tot);
+        long long run = carry + (long long)ex.a - (long long)popBefore;
+#pragma unroll
+        for (int i = 0; i < ST_ITEMS; i++) { if (t + i < C.ntiles) rankBase[C.tileBase + t + i] = (int32_t)run; run += v[i]; }
+        carry += tot.a;
     }
-    // popBefore = full tiles before t0 + partial; broadcast from the thread that owns t0
-    __shared__ long long s_full;
-    if (threadIdx.x == 0) s_full = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) obsAcc += __shfl_xor(obsAcc, d);
+    if (l == 0) sRed[1][w] = obsAcc;
     __syncthreads();
-    if (t0 < C.ntiles && (t0 & 1023) == threadIdx.x) s_full = popBeforeFull;
-    __syncthreads();
-    long long popBefore = (t0 < C.ntiles ? s_full : carry) + s_popBefore;
-    for (int64_t t = threadIdx.x; t < C.ntiles; t += 1024) rankBase[C.tileBase + t] -= (int32_t)popBefore;
-    if (threadIdx.x == 0) {
-        ChromOut o; o.pop = carry; o.obs = obsSum; o.popBefore = popBefore;
-        o.nbins = binSize > 0 ? (carry - popBefore) / binSize : 0;
+    if (tid == 0) {
+        unsigned long long obs = 0;
+        for (int i = 0; i < 16; i++) obs += sRed[1][i];
+        ChromOut o; o.pop = carry; o.obs = (long long)obs; o.popBefore = (long long)popBefore;
+        o.nbins = binSize > 0 ? (carry - (long long)popBefore) / binSize : 0;
         out[c] = o;
     }
 }
@@ -355,17 +368,22 @@ __global__ void __launch_bounds__(64) k_bin_pass_edges(const BinChrom* __restric
 
 // ---------------------------------------------------------------------------------------------- k_scan_totals
 __global__ void __launch_bounds__(1024) k_scan_totals(const BinChrom* __restrict__ ch, uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
-    __shared__ uint32_t sh[17];
+    __shared__ U2 sh[2][16];
     const BinChrom C = ch[blockIdx.x];
+    uint32_t* __restrict__ tc = tileTotC + C.tileBase; uint32_t* __restrict__ tg = tileTotG + C.tileBase;
     uint32_t carryC = 0, carryG = 0;
-    for (int64_t base = 0; base < C.ntiles; base += 1024) {
-        int64_t t = base + threadIdx.x;
-        uint32_t vc = t < C.ntiles ? tileTotC[C.tileBase + t] : 0, vg = t < C.ntiles ? tileTotG[C.tileBase + t] : 0;
-        uint32_t totC, totG;
-        uint32_t exC = block_exclusive_scan_1024(vc, sh, totC);
-        uint32_t exG = block_exclusive_scan_1024(vg, sh, totG);
-        if (t < C.ntiles) { tileTotC[C.tileBase + t] = carryC + exC; tileTotG[C.tileBase + t] = carryG + exG; }
-        carryC += totC; carryG += totG;
+    int buf = 0;
+    for (int64_t base = 0; base < C.ntiles; base += 1024 * ST_ITEMS, buf ^= 1) {
+        const int64_t t = base + (int64_t)threadIdx.x * ST_ITEMS;
+        uint32_t vc[ST_ITEMS], vg[ST_ITEMS]; U2 in; in.a = 0; in.b = 0;
+#pragma unroll
+        for (int i = 0; i < ST_ITEMS; i++) { const bool ok = t + i < C.ntiles; vc[i] = ok ? tc[t + i] : 0u; vg[i] = ok ? tg[t + i] : 0u; in.a += vc[i]; in.b += vg[i]; }
+        U2 tot;
+        const U2 ex = block_exclusive_scan2_1024(in, sh[buf], tot);
+        uint32_t rc = carryC + ex.a, rg = carryG + ex.b;
+#pragma unroll
+        for (int i = 0; i < ST_ITEMS; i++) { if (t + i < C.ntiles) { tc[t + i] = rc; tg[t + i] = rg; } rc += vc[i]; rg += vg[i]; }
+        carryC += tot.a; carryG += tot.b;
     }
 }
 
@@ -404,8 +422,12 @@ __global__ void __launch_bounds__(256) k_bin_finalize(const BinChrom* __restrict
 }
 
 // exclusive scan of per-chromosome bin counts (tiny)
-__global__ void k_bin_offsets(const ChromOut* __restrict__ co, int nchr, long long* __restrict__ binOffset) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { long long s = 0; for (int c = 0; c < nchr; c++) { binOffset[c] = s; s += co[c].nbins; } binOffset[nchr] = s; }
+__global__ void k_bin_offsets(ChromOut* __restrict__ co, int nchr, int binSize, long long* __restrict__ binOffset) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long long s = 0;
+        for (int c = 0; c < nchr; c++) { const long long nb = (co[c].pop - co[c].popBefore) / binSize; co[c].nbins = nb; binOffset[c] = s; s += nb; }
+        binOffset[nchr] = s;
+    }
 }
 __global__ void k_init_pos0(const BinChrom* __restrict__ ch, int nchr, unsigned long long* __restrict__ pos0) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,14 +460,15 @@ __global__ void __launch_bounds__(256) k_gcp_tile(const uint8_t* __restrict__ ba
     if (l == 0) tileCnt[tile] = g;
 }
 __global__ void __launch_bounds__(1024) k_gcp_scan(uint32_t* __restrict__ tileCnt, int64_t ntiles) {
-    __shared__ uint32_t sh[17];
+    __shared__ U2 sh[2][16];
     uint32_t carry = 0;
-    for (int64_t base = 0; base < ntiles; base += 1024) {
+    int buf = 0;
+    for (int64_t base = 0; base < ntiles; base += 1024, buf ^= 1) {
         int64_t t = base + threadIdx.x;
-        uint32_t v = t < ntiles ? tileCnt[t] : 0, tot;
-        uint32_t ex = block_exclusive_scan_1024(v, sh, tot);
-        if (t < ntiles) tileCnt[t] = carry + ex;
-        carry += tot;
+        U2 in; in.a = t < ntiles ? tileCnt[t] : 0; in.b = 0; U2 tot;
+        const U2 ex = block_exclusive_scan2_1024(in, sh[buf], tot);
+        if (t < ntiles) tileCnt[t] = carry + ex.a;
+        carry += tot.a;
     }
 }
 __global__ void __launch_bounds__(256) k_gcp_write(const uint8_t* __restrict__ bases, int64_t len, const uint32_t* __restrict__ tileEx, uint32_t* __restrict__ P) {
@@ -671,13 +694,15 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         if (bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "derived bin size is not positive");
     }
     if (h_bin_size_out) *h_bin_size_out = bin_size;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, (const uint32_t*)nullptr, 0, bin_size, rankBase, dOut);
-    hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(64), 0, ctx->stream, dOut, nchr, binOffset);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    if (!needRates) {
+        hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, (const uint32_t*)nullptr, 0, bin_size, rankBase, dOut);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+    }   // else: the scan that produced the rates already left the rank bases and the totals (they do not depend on the bin size)
+    hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(64), 0, ctx->stream, dOut, nchr, bin_size, binOffset);
     int64_t total = 0;
-    for (int c = 0; c < nchr; c++) { if (h_nbins_per_chr) h_nbins_per_chr[c] = hOut[c].nbins; total += hOut[c].nbins; }
+    for (int c = 0; c < nchr; c++) { hOut[c].nbins = (hOut[c].pop - hOut[c].popBefore) / bin_size; if (h_nbins_per_chr) h_nbins_per_chr[c] = hOut[c].nbins; total += hOut[c].nbins; }
     if (h_nbins_total) *h_nbins_total = total;
     if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_bin_genome: output capacity too small (see canvas_bin_count_upper_bound)");
     if (total == 0) return CANVAS_OK;

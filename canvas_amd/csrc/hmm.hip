@@ -237,6 +237,18 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
+// block / chunk lists: entry i of a list with `per` steps per entry, from the per-chromosome first indices (binary search)
+template <typename T>
+__global__ void __launch_bounds__(256) k_make_blocks(const int32_t* __restrict__ first, int nchr, int n, int per, T* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (first[mid] <= i) lo = mid; else hi = mid - 1; }
+    while (lo < nchr - 1 && first[lo + 1] <= i) lo++;        // chromosomes without blocks share an index
+    T b; b.chrom = lo; b.t0 = (i - first[lo]) * per;
+    out[i] = b;
+}
+
 // A: one lane per block
 __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                  const double* __restrict__ logPmf, HmmParams P, uint16_t* __restrict__ psi, uint16_t* __restrict__ maps,
@@ -885,9 +897,11 @@ static void negative_binomial_log_table(double mean, double variance, int maxVal
     double m = std::max(mean, 0.1);
     double r = (m * m) / (std::max(variance, mean * 1.2) - mean);
     r = std::max(2.0, r);
+    // the first and the last term do not depend on x: evaluated once, same calls and arguments, so the values are unchanged
+    const double term0 = std::log(std::pow(1 + mean / r, -r)), lgr = std::lgamma(r), ratio = mean / (mean + r);
     for (int x = 0; x < maxValue; x++) {
-        double dens = std::exp(std::log(std::pow(1 + mean / r, -r)) + std::log(std::pow(mean / (mean + r), (double)x)) + std::lgamma(r + x) -
-                               std::lgamma((double)x + 1.0) - std::lgamma(r));
+        double dens = std::exp(term0 + std::log(std::pow(ratio, (double)x)) + std::lgamma(r + x) -
+                               std::lgamma((double)x + 1.0) - lgr);
         if (std::isnan(dens) || std::isinf(dens)) dens = 0;
         out[x] = std::log(dens);   // EstimateViterbiLikelihood takes Math.Log of the table value (Distributions.cs:322)
     }
@@ -932,21 +946,21 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     if (N < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
     // VB-step blocks (speculation, verification and backtrack share them)
     std::vector<HmmChrom> chroms(nchr);
-    std::vector<VitBlock> vblocks; std::vector<int32_t> firstBlock(nchr + 1);
+    std::vector<int32_t> firstBlock(nchr + 1);
+    int nblocks = 0;
     for (int c = 0; c < nchr; c++) {
         chroms[c].begin = h_chr_offset[c]; chroms[c].T = h_chr_offset[c + 1] - h_chr_offset[c];
-        firstBlock[c] = (int32_t)vblocks.size();
-        if (chroms[c].T > 10) for (int64_t t0 = 0; t0 < chroms[c].T; t0 += VB) vblocks.push_back({c, (int32_t)t0});
+        firstBlock[c] = nblocks;
+        if (chroms[c].T > 10) nblocks += (int)((chroms[c].T + VB - 1) / VB);
     }
-    firstBlock[nchr] = (int32_t)vblocks.size();
-    const int nblocks = (int)vblocks.size();
-    std::vector<BbChunk> bchunks; std::vector<int32_t> firstChunk(nchr + 1);
+    firstBlock[nchr] = nblocks;
+    std::vector<int32_t> firstChunk(nchr + 1);
+    int nchunks = 0;
     for (int c = 0; c < nchr; c++) {
-        firstChunk[c] = (int32_t)bchunks.size();
-        if (chroms[c].T > 10) for (int64_t t0 = 0; t0 < chroms[c].T; t0 += BB_CHUNK) bchunks.push_back({c, (int32_t)t0});
+        firstChunk[c] = nchunks;
+        if (chroms[c].T > 10) nchunks += (int)((chroms[c].T + BB_CHUNK - 1) / BB_CHUNK);
     }
-    firstChunk[nchr] = (int32_t)bchunks.size();
-    const int nchunks = (int)bchunks.size();
+    firstChunk[nchr] = nchunks;
     WsSizer sz;
     sz.take<BbChunk>(nchunks + 1); sz.take<int32_t>(nchr + 1); sz.take<double>(nchunks + 1); sz.take<double>(nchunks + 1); sz.take<BbChunkOut>(nchunks + 1);
     sz.take<BbCross>((size_t)nchunks * BB_MAXC + 1); sz.take<ParFn>((size_t)nchunks * 16 + 1); sz.take<uint8_t>((size_t)nchunks * 16 + 8);
@@ -967,6 +981,13 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     BbCross* dCross = ws.take<BbCross>((size_t)nchunks * BB_MAXC + 1); ParFn* dAt64Fn = ws.take<ParFn>((size_t)nchunks * 16 + 1); uint8_t* dAt64Rank = ws.take<uint8_t>((size_t)nchunks * 16 + 8);
     unsigned long long* dChunkBits = ws.take<unsigned long long>(nchunks + 1); BbPost* dPost = ws.take<BbPost>((size_t)nchunks * BB_MAXC + 1);
 
+    // static descriptors first: they do not depend on the data and overlap with the quartile selection
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dChroms, chroms.data(), nchr * sizeof(HmmChrom), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirst, firstBlock.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOffDev, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstChunk, firstChunk.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nblocks > 0) hipLaunchKernelGGL((k_make_blocks<VitBlock>), dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dFirst, nchr, nblocks, VB, dVBlocks);
+    if (nchunks > 0) hipLaunchKernelGGL((k_make_blocks<BbChunk>), dim3(nblk2(nchunks, 256)), dim3(256), 0, ctx->stream, dFirstChunk, nchr, nchunks, BB_CHUNK, dBChunks);
     // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
     hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
     int64_t qidx[6]; int nq;
@@ -995,12 +1016,6 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
         P.logPi[i] = std::log((double)(1.0f / NSTATE));      // 1f / nStates widened (HMM.cs:41)
     }
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dChroms, chroms.data(), nchr * sizeof(HmmChrom), hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirst, firstBlock.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOffDev, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (!vblocks.empty()) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVBlocks, vblocks.data(), vblocks.size() * sizeof(VitBlock), hipMemcpyHostToDevice, ctx->stream));
-    if (nchunks > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dBChunks, bchunks.data(), (size_t)nchunks * sizeof(BbChunk), hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstChunk, firstChunk.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     // 3. index, Viterbi, backtrack
     hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);
     size_t tabBytes = (size_t)NSTATE * P.tableLen * 8;
@@ -1018,7 +1033,7 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     };
     const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
     std::vector<int32_t> redo;
-    if (speculative && !vblocks.empty()) {
+    if (speculative && nblocks > 0) {
         ProfScope ps(ctx, "viterbi");
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dLast, 0xFF, nchr * 4, ctx->stream));     // -1 for skipped chromosomes
