@@ -135,6 +135,28 @@ __device__ __forceinline__ U2 block_exclusive_scan2_1024(U2 v, U2* sh /*16*/, U2
     return r;
 }
 #define ST_ITEMS 8
+// Eight consecutive uint32 per thread as two 16-byte vectors.  `arr` is 16-byte aligned and `v0` (the virtual index of the first
+// element, a multiple of 8) addresses arr + v0; valid elements are lo <= index < hi, the others read as 0 / are not written
+// (they belong to the neighbouring chromosomes, which other workgroups own).  A lane-contiguous 32 B per thread keeps the
+// accesses coalesced: with scalar accesses at a 32 B lane stride a single CU becomes request-rate bound.
+__device__ __forceinline__ void load8_u32(const uint32_t* __restrict__ arr, int64_t v0, int64_t lo, int64_t hi, uint32_t (&v)[ST_ITEMS]) {
+    if (v0 >= lo && v0 + ST_ITEMS <= hi) {
+        const uint4 a = *reinterpret_cast<const uint4*>(arr + v0), b = *reinterpret_cast<const uint4*>(arr + v0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < ST_ITEMS; i++) v[i] = (v0 + i >= lo && v0 + i < hi) ? arr[v0 + i] : 0u;
+    }
+}
+__device__ __forceinline__ void store8_u32(uint32_t* __restrict__ arr, int64_t v0, int64_t lo, int64_t hi, const uint32_t (&v)[ST_ITEMS]) {
+    if (v0 >= lo && v0 + ST_ITEMS <= hi) {
+        *reinterpret_cast<uint4*>(arr + v0) = make_uint4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint4*>(arr + v0 + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < ST_ITEMS; i++) if (v0 + i >= lo && v0 + i < hi) arr[v0 + i] = v[i];
+    }
+}
 __global__ void __launch_bounds__(1024) k_scan_tiles(const BinChrom* __restrict__ ch, const unsigned long long* __restrict__ pos0,
                                                      const uint32_t* __restrict__ tilePop, const uint32_t* __restrict__ tileObs, int wantObs,
                                                      int binSize, int32_t* __restrict__ rankBase, ChromOut* __restrict__ out) {
@@ -164,23 +186,29 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(const BinChrom* __restrict_
     unsigned long long popBefore = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) popBefore += sRed[0][i];
-    // exclusive scan of the tile popcounts, ST_ITEMS consecutive tiles per thread
+    // exclusive scan of the tile popcounts, ST_ITEMS consecutive tiles per thread (absolute tile indices, 8-aligned chunks)
     long long carry = 0; unsigned long long obsAcc = 0;
     int buf = 0;
-    for (int64_t base = 0; base < C.ntiles; base += 1024 * ST_ITEMS, buf ^= 1) {
-        const int64_t t = base + (int64_t)tid * ST_ITEMS;
+    const int64_t lo = C.tileBase, hi = C.tileBase + C.ntiles;
+    for (int64_t base = lo & ~(int64_t)7; base < hi; base += 1024 * ST_ITEMS, buf ^= 1) {
+        const int64_t v0 = base + (int64_t)tid * ST_ITEMS;
         uint32_t v[ST_ITEMS]; uint32_t sum = 0;
+        load8_u32(tilePop, v0, lo, hi, v);
 #pragma unroll
-        for (int i = 0; i < ST_ITEMS; i++) { v[i] = t + i < C.ntiles ? pop[t + i] : 0u; sum += v[i]; }
+        for (int i = 0; i < ST_ITEMS; i++) sum += v[i];
         if (wantObs) {
+            uint32_t o[ST_ITEMS];
+            load8_u32(tileObs, v0, lo, hi, o);
 #pragma unroll
-            for (int i = 0; i < ST_ITEMS; i++) if (t + i < C.ntiles) obsAcc += tileObs[C.tileBase + t + i];
+            for (int i = 0; i < ST_ITEMS; i++) obsAcc += o[i];
         }
         U2 in; in.a = sum; in.b = 0; U2 tot;
         const U2 ex = block_exclusive_scan2_1024(in, sh[buf], tot);
         long long run = carry + (long long)ex.a - (long long)popBefore;
+        uint32_t r[ST_ITEMS];
 #pragma unroll
-        for (int i = 0; i < ST_ITEMS; i++) { if (t + i < C.ntiles) rankBase[C.tileBase + t + i] = (int32_t)run; run += v[i]; }
+        for (int i = 0; i < ST_ITEMS; i++) { r[i] = (uint32_t)(int32_t)run; run += v[i]; }
+        store8_u32(reinterpret_cast<uint32_t*>(rankBase), v0, lo, hi, r);
         carry += tot.a;
     }
 #pragma unroll
@@ -370,19 +398,21 @@ __global__ void __launch_bounds__(64) k_bin_pass_edges(const BinChrom* __restric
 __global__ void __launch_bounds__(1024) k_scan_totals(const BinChrom* __restrict__ ch, uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
     __shared__ U2 sh[2][16];
     const BinChrom C = ch[blockIdx.x];
-    uint32_t* __restrict__ tc = tileTotC + C.tileBase; uint32_t* __restrict__ tg = tileTotG + C.tileBase;
+    const int64_t lo = C.tileBase, hi = C.tileBase + C.ntiles;
     uint32_t carryC = 0, carryG = 0;
     int buf = 0;
-    for (int64_t base = 0; base < C.ntiles; base += 1024 * ST_ITEMS, buf ^= 1) {
-        const int64_t t = base + (int64_t)threadIdx.x * ST_ITEMS;
+    for (int64_t base = lo & ~(int64_t)7; base < hi; base += 1024 * ST_ITEMS, buf ^= 1) {
+        const int64_t v0 = base + (int64_t)threadIdx.x * ST_ITEMS;
         uint32_t vc[ST_ITEMS], vg[ST_ITEMS]; U2 in; in.a = 0; in.b = 0;
+        load8_u32(tileTotC, v0, lo, hi, vc); load8_u32(tileTotG, v0, lo, hi, vg);
 #pragma unroll
-        for (int i = 0; i < ST_ITEMS; i++) { const bool ok = t + i < C.ntiles; vc[i] = ok ? tc[t + i] : 0u; vg[i] = ok ? tg[t + i] : 0u; in.a += vc[i]; in.b += vg[i]; }
+        for (int i = 0; i < ST_ITEMS; i++) { in.a += vc[i]; in.b += vg[i]; }
         U2 tot;
         const U2 ex = block_exclusive_scan2_1024(in, sh[buf], tot);
         uint32_t rc = carryC + ex.a, rg = carryG + ex.b;
 #pragma unroll
-        for (int i = 0; i < ST_ITEMS; i++) { if (t + i < C.ntiles) { tc[t + i] = rc; tg[t + i] = rg; } rc += vc[i]; rg += vg[i]; }
+        for (int i = 0; i < ST_ITEMS; i++) { const uint32_t c0 = vc[i], g0 = vg[i]; vc[i] = rc; vg[i] = rg; rc += c0; rg += g0; }
+        store8_u32(tileTotC, v0, lo, hi, vc); store8_u32(tileTotG, v0, lo, hi, vg);
         carryC += tot.a; carryG += tot.b;
     }
 }
