@@ -204,6 +204,11 @@ __global__ void __launch_bounds__(256) k_local_sd(const float* __restrict__ coun
 #pragma unroll
     for (int k = 0; k < 20; k++) dev[s + k] = v;
 }
+__global__ void __launch_bounds__(256) k_copy_soa(Soa src, Soa dst, int64_t n) {     // the five caller-visible columns in one launch
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    dst.chr[i] = src.chr[i]; dst.start[i] = src.start[i]; dst.stop[i] = src.stop[i]; dst.gc[i] = src.gc[i]; dst.count[i] = src.count[i];
+}
 __global__ void __launch_bounds__(256) k_fill_f64(double* __restrict__ p, int64_t n, double v) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -370,10 +375,9 @@ static int32_t group_by_gc(CleanState& st, GcGroups& g, uint32_t* dSegOff, uint3
     g.nauto = g.segOff[NGC];
     uint32_t so[NGC + 1];
     for (int i = 0; i <= NGC; i++) so[i] = (uint32_t)g.segOff[i];
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSegOff, so, sizeof so, hipMemcpyHostToDevice, ctx->stream));
+    { int32_t rc = canvas_h2d_small(ctx, dSegOff, so, sizeof so); if (rc) return rc; }
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCursor, 0, NGC * 4, ctx->stream));
     if (st.n > 0) hipLaunchKernelGGL(k_group_by_gc, dim3(nblk(st.n, CBLK)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.gc, st.dIsAuto, st.n, dSegOff, dCursor, st.gidx);
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `so` is a stack buffer
     return CANVAS_OK;
 }
 
@@ -461,9 +465,8 @@ static int32_t normalize_by_gc(CleanState& st, const GcGroups& g, double* dMedia
     double medians[NGC];
     for (int gc = 0; gc < NGC; gc++) medians[gc] = first[gc] >= 0 ? med(first[gc], g.hist[gc]) : 0.0;   // unreadable empty buckets stay 0
     for (size_t b = 0; b < sparse.size(); b++) medians[sparse[b]] = wq[b].q[0];
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dMedians, medians, sizeof medians, hipMemcpyHostToDevice, ctx->stream));
+    rc = canvas_h2d_small(ctx, dMedians, medians, sizeof medians); if (rc) return rc;
     hipLaunchKernelGGL(k_apply_gc, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.cur.gc, st.n, dMedians, globalMedian);
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
 }
@@ -502,15 +505,17 @@ static int32_t normalize_variance_by_gc(CleanState& st, const GcGroups& g, VarTa
     int significant = 0;
     for (int i = 10; i < 90; i++) if (tab.globalIQR * 2.0f < tab.localIQR[i]) significant++;
     if (significant <= 0) return CANVAS_OK;
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, &tab, sizeof tab, hipMemcpyHostToDevice, ctx->stream));
+    rc = canvas_h2d_small(ctx, dTab, &tab, sizeof tab); if (rc) return rc;
     hipLaunchKernelGGL(k_apply_var, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.count, st.cur.gc, st.n, dTab);
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     changed = true;
     return CANVAS_OK;
 }
 
 // GetLocalStandardDeviation + GetLocalStandardDeviationAverage (CanvasClean.cs:243-298); Q8 kept
-static int32_t local_sd(CleanState& st, double* dSd, double* dRunMedian, int64_t* dRunStart, unsigned int* dCnt, long long* dPos, double& localSd) {
+// GetLocalStandardDeviationAverage (CanvasClean.cs:243-298).  The value is only needed at the very end (RemoveBinsWithExtremeLocalSD and
+// the metric file), so the per-chromosome MAD runs on the context's side stream while the GC stages continue on the main one:
+// local_sd_begin enqueues it, local_sd_end waits for the result.
+static int32_t local_sd_begin(CleanState& st, double* dSd, double* dRunMedian, int64_t* dRunStart, unsigned int* dCnt, long long* dPos, int& nrunsOut) {
     canvas_ctx* ctx = st.ctx;
     const int64_t D = st.n - 1;
     const int64_t nW = D >= 1 ? (D - 1) / 20 : 0;    // windows with windowEnd = 20(w+1) < D
@@ -542,15 +547,23 @@ static int32_t local_sd(CleanState& st, double* dSd, double* dRunMedian, int64_t
     const int nruns = (int)runStart.size();
     std::vector<int64_t> segOff(runStart); segOff.push_back(nW);
     segOff[0] = 0;
-    // Mad of the window SDs per run (median, then median of |x - median|), one workgroup per run
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRunStart, segOff.data(), (nruns + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (nruns > 0) hipLaunchKernelGGL(k_run_mad, dim3(nruns), dim3(1024), 0, ctx->stream, dSd, dRunStart, dRunMedian);
-    std::vector<double> mads(nruns);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(mads.data(), dRunMedian, nruns * 8, hipMemcpyDeviceToHost, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    // Mad of the window SDs per run (median, then median of |x - median|), one workgroup per run, on the side stream
+    nrunsOut = nruns;
+    if (nruns > 0) {
+        int32_t rc = canvas_side_init(ctx); if (rc) return rc;
+        int64_t* pinStarts = reinterpret_cast<int64_t*>(ctx->side_pin + 65536);      // k_local_sd finished at the synchronisation above
+        memcpy(pinStarts, segOff.data(), (size_t)(nruns + 1) * 8);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRunStart, pinStarts, (nruns + 1) * 8, hipMemcpyHostToDevice, ctx->side));
+        hipLaunchKernelGGL(k_run_mad, dim3(nruns), dim3(1024), 0, ctx->side, dSd, dRunStart, dRunMedian);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->side_pin, dRunMedian, nruns * 8, hipMemcpyDeviceToHost, ctx->side));
+    }
+    return CANVAS_OK;
+}
+static int32_t local_sd_end(CleanState& st, int nruns, double& localSd) {
+    canvas_ctx* ctx = st.ctx;
+    if (nruns > 0) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->side)); CANVAS_HIP_TRY(ctx, hipGetLastError()); }
     double s = 0;
-    for (int r = 0; r < nruns; r++) s += mads[r];        // List<double>.Average(): sequential sum / count
+    for (int r = 0; r < nruns; r++) s += ctx->side_pin[r];        // List<double>.Average(): sequential sum / count
     localSd = s / (double)nruns;
     return CANVAS_OK;
 }
@@ -662,7 +675,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     double* dMedians = ws.take<double>(NGC); VarTab* dTab = ws.take<VarTab>(1); uint8_t* dKeepGc = ws.take<uint8_t>(NGC);
     double* dSd = ws.take<double>(nW0); double* dRunMedian = ws.take<double>(65536); int64_t* dRunStart = ws.take<int64_t>(65536 + 1);
     unsigned int* dCnt = ws.take<unsigned int>(1); long long* dPos = ws.take<long long>(65536);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(st.dIsAuto, h_chr_is_autosome, nchr, hipMemcpyHostToDevice, ctx->stream));
+    rc = canvas_h2d_small(ctx, st.dIsAuto, h_chr_is_autosome, nchr); if (rc) return rc;
     hipLaunchKernelGGL(k_fill_f64, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, st.cur.dev, n, -1.0);   // CountDeviation = -1 (GenomicBin.cs:83)
 
     // RemoveBigBins (CanvasClean.cs:328-355)
@@ -685,7 +698,8 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     }
     info[1] = (int32_t)st.n;
     bool haveLocalSd = (flags & CANVAS_CLEAN_LOCALSD) && st.n >= 50000;   // CanvasClean.cs:483-486
-    if (haveLocalSd) { rc = local_sd(st, dSd, dRunMedian, dRunStart, dCnt, dPos, localSd); if (rc) return rc; }
+    int sdRuns = 0;
+    if (haveLocalSd) { rc = local_sd_begin(st, dSd, dRunMedian, dRunStart, dCnt, dPos, sdRuns); if (rc) return rc; }
     if ((flags & CANVAS_CLEAN_GCNORM) && st.n > 0 && loessMode) {
         // -m LOESS: no GC strip (CanvasClean.cs:497-499); variance normalisation still uses the MedianByGC quartiles
         rc = normalize_by_gc_loess(st, nchr, h_chr_is_y); if (rc) return rc;
@@ -709,7 +723,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
         uint8_t keep[NGC]; int64_t kept = 0; bool dropsAny = false;
         // number of surviving bins is only known after compaction (X/Y bins count too); decide emptiness from the flags
         for (int i = 0; i < NGC; i++) { keep[i] = (int)g.hist[i] >= threshold; if (!keep[i]) dropsAny = true; }
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dKeepGc, keep, NGC, hipMemcpyHostToDevice, ctx->stream));
+        rc = canvas_h2d_small(ctx, dKeepGc, keep, NGC); if (rc) return rc;
         hipLaunchKernelGGL(k_flags_gc, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.gc, st.n, dKeepGc, st.flags);
         // count survivors without moving data first: "strippedBins.Count == 0 -> proceed without GC correction" (CanvasClean.cs:500-505)
         int nb = (int)nblk(st.n, CBLK);
@@ -739,6 +753,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
         }
     }
     info[2] = (int32_t)st.n;
+    if (haveLocalSd) { rc = local_sd_end(st, sdRuns, localSd); if (rc) return rc; }
     if (haveLocalSd && localSd > 5.0 && st.n > 0) {    // RemoveBinsWithExtremeLocalSD (threshold 20 -> 40.0)
         hipLaunchKernelGGL(k_flags_localsd, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.dev, st.n, 20 * 2.0, st.flags);
         rc = compact(st); if (rc) return rc;
@@ -746,11 +761,8 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     info[3] = (int32_t)st.n;
     // results must end in the caller's arrays
     if (st.cur.chr != d_chr && st.n > 0) {
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_chr, st.cur.chr, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_start, st.cur.start, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_stop, st.cur.stop, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_gc, st.cur.gc, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_count, st.cur.count, st.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        Soa dst; dst.chr = d_chr; dst.start = d_start; dst.stop = d_stop; dst.gc = d_gc; dst.count = d_count; dst.dev = nullptr;
+        hipLaunchKernelGGL(k_copy_soa, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur, dst, st.n);
     }
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());

@@ -20,6 +20,16 @@ struct canvas_ctx {
     // pinned host staging for small D2H results
     void* pin = nullptr;
     size_t pin_bytes = 0;
+    // side stream for work that is off the critical path (per-chromosome MAD of CanvasClean), its fork event and a pinned result buffer
+    hipStream_t side = nullptr;
+    hipEvent_t side_ev = nullptr;
+    double* side_pin = nullptr;        // 65536 results + 65544 int64 run starts
+    // persistent scratch of the radix select (select.hpp): device blob and pinned staging blob
+    void* sel_ws = nullptr; size_t sel_ws_bytes = 0;
+    void* sel_pin = nullptr; size_t sel_pin_bytes = 0;
+    // small pinned staging area for host->device parameter tables (async copies from pinned memory need no synchronisation
+    // to protect the source); bump-allocated, wrapped with a synchronisation when full
+    char* misc_pin = nullptr; size_t misc_off = 0;
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
     int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
@@ -64,6 +74,25 @@ static inline int32_t canvas_ws_reserve(canvas_ctx* ctx, size_t bytes) {
     size_t want = bytes + bytes / 4 + (1u << 20);
     CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->ws, want));
     ctx->ws_bytes = want;
+    return CANVAS_OK;
+}
+#define CANVAS_MISC_PIN_BYTES (256u << 10)
+// copy `bytes` from host memory to the device through the pinned staging area: fully asynchronous, `src` may be a stack buffer
+static inline int32_t canvas_h2d_small(canvas_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    if (bytes > CANVAS_MISC_PIN_BYTES) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream)); CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); return CANVAS_OK; }
+    if (!ctx->misc_pin) CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->misc_pin, CANVAS_MISC_PIN_BYTES, hipHostMallocDefault));
+    const size_t need = (bytes + 63) & ~size_t(63);
+    if (ctx->misc_off + need > CANVAS_MISC_PIN_BYTES) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); ctx->misc_off = 0; }
+    char* p = ctx->misc_pin + ctx->misc_off; ctx->misc_off += need;
+    memcpy(p, src, bytes);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_dst, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return CANVAS_OK;
+}
+static inline int32_t canvas_side_init(canvas_ctx* ctx) {
+    if (ctx->side) return CANVAS_OK;
+    CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
+    CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->side_pin, (65536 + 65544) * sizeof(double), hipHostMallocDefault));
     return CANVAS_OK;
 }
 static inline int32_t canvas_pin_reserve(canvas_ctx* ctx, size_t bytes) {

@@ -20,7 +20,13 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
+    if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->misc_pin) (void)hipHostFree(ctx->misc_pin);
+    if (ctx->sel_ws) (void)hipFree(ctx->sel_ws);
+    if (ctx->sel_pin) (void)hipHostFree(ctx->sel_pin);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

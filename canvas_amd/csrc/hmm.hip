@@ -611,54 +611,78 @@ __global__ void __launch_bounds__(256) k_bb_pieces(const BbChunk* __restrict__ c
     }
     if (tid == 255) { outChunk[blockIdx.x].tail = run.f; outChunk[blockIdx.x].nCross = (int32_t)run.cnt; }
 }
-// one wave per chromosome; lane 0 walks, the wave stages chunk summaries / crossing records through LDS
+// one wave per chromosome.  Runs of chunks without a crossing are handled 64 at a time (a composition scan over the lanes gives
+// every chunk its exact starting value); a chunk with crossings is walked record by record, redundantly in all lanes so that
+// the running value stays wave-uniform.
+__device__ __forceinline__ bool bb_apply(unsigned long long& bits, const ParFn& f, int eUsed) {    // false: a prediction was wrong
+    const unsigned long long MANT = (1ull << 52) - 1ull;
+    if (f.a0 == 0ull && f.a1 == 0ull) return true;        // empty piece
+    const int e = (int)(bits >> 52);
+    if (e != eUsed || e == 0) return false;
+    const unsigned long long k = (bits & MANT) | (1ull << 52);
+    const unsigned long long k2 = k + ((k & 1ull) ? f.a1 : f.a0);
+    if (k2 >= (1ull << 53)) return false;
+    bits = ((unsigned long long)e << 52) | (k2 & MANT);
+    return true;
+}
 __global__ void __launch_bounds__(64) k_bb_walk(const int32_t* __restrict__ firstChunk, const BbChunkOut* __restrict__ chunkOut, const BbCross* __restrict__ cross,
                                                 unsigned long long* __restrict__ chunkBits, BbPost* __restrict__ post, int32_t* __restrict__ fail) {
-    __shared__ BbChunkOut sCh[64];
     __shared__ BbCross sCr[BB_MAXC];
-    __shared__ unsigned long long sBits; __shared__ int sFail;
     const int c = blockIdx.x, l = threadIdx.x;
-    const unsigned long long MANT = (1ull << 52) - 1ull, TWO53 = 1ull << 53;
+    const unsigned long long MANT = (1ull << 52) - 1ull;
     if (fail[c]) return;
-    if (l == 0) { sBits = 0ull; sFail = 0; }
-    for (int g = firstChunk[c]; g < firstChunk[c + 1]; g += 64) {
+    unsigned long long bits = 0ull;       // |D| so far, wave-uniform
+    bool failed = false;                  // wave-uniform
+    for (int g = firstChunk[c]; g < firstChunk[c + 1] && !failed; g += 64) {
         const int n = firstChunk[c + 1] - g < 64 ? firstChunk[c + 1] - g : 64;
-        if (l < n) sCh[l] = chunkOut[g + l];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        for (int i = 0; i < n; i++) {
-            const int nc = sCh[i].nCross;                            // uniform
-            if (nc > 0) {
-                if (l < nc && l < BB_MAXC) sCr[l] = cross[(size_t)(g + i) * BB_MAXC + l];
+        BbChunkOut my; my.tail.a0 = 0; my.tail.a1 = 0; my.nCross = 0; my.headE = 0;
+        if (l < n) my = chunkOut[g + l];
+        unsigned long long crossMask = __ballot(l < n && my.nCross > 0);
+        int cur = 0;
+        while (cur < n && !failed) {
+            const int f = crossMask ? (int)__builtin_ctzll(crossMask) : n;       // next chunk with crossings
+            if (f > cur) {
+                const bool inRun = l >= cur && l < f;
+                ParFn inc; inc.a0 = inRun ? my.tail.a0 : 0ull; inc.a1 = inRun ? my.tail.a1 : 0ull;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { ParFn o = parfn_shfl_up(inc, d); if (l >= d) inc = parfn_then(o, inc); }
+                ParFn ex = parfn_shfl_up(inc, 1); if (l == 0) { ex.a0 = 0; ex.a1 = 0; }
+                const int e = (int)(bits >> 52);
+                const unsigned long long k = (bits & MANT) | (e ? (1ull << 52) : 0ull);
+                const unsigned long long ks = k + ((k & 1ull) ? ex.a1 : ex.a0), ke = k + ((k & 1ull) ? inc.a1 : inc.a0);
+                const bool nonEmpty = my.tail.a0 != 0ull || my.tail.a1 != 0ull;
+                const bool bad = inRun && nonEmpty && (my.headE != e || e == 0 || ke >= (1ull << 53));
+                if (inRun) chunkBits[g + l] = ((unsigned long long)e << 52) | (ks & MANT);
+                if (__ballot(bad)) failed = true;
+                const unsigned long long totLo0 = __shfl(inc.a0, f - 1), totLo1 = __shfl(inc.a1, f - 1);
+                const unsigned long long k2 = k + ((k & 1ull) ? totLo1 : totLo0);
+                bits = ((unsigned long long)e << 52) | (k2 & MANT);
+                cur = f;
+            }
+            if (cur < n && !failed) {      // chunk `cur` has crossings
+                const int nc = __shfl(my.nCross, cur), headE = __shfl(my.headE, cur);
+                ParFn tail; tail.a0 = __shfl(my.tail.a0, cur); tail.a1 = __shfl(my.tail.a1, cur);
+                if (l < nc && l < BB_MAXC) sCr[l] = cross[(size_t)(g + cur) * BB_MAXC + l];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            }
-            if (l == 0 && !sFail) {
-                unsigned long long bits = sBits;
-                chunkBits[g + i] = bits;
-                auto apply = [&](const ParFn& f, int eUsed) {
-                    if (f.a0 == 0ull && f.a1 == 0ull) return;        // empty piece
-                    const int e = (int)(bits >> 52);
-                    if (e != eUsed || e == 0) { sFail = 1; return; }
-                    const unsigned long long k = (bits & MANT) | (1ull << 52);
-                    const unsigned long long k2 = k + ((k & 1ull) ? f.a1 : f.a0);
-                    if (k2 >= TWO53) { sFail = 1; return; }
-                    bits = ((unsigned long long)e << 52) | (k2 & MANT);
-                };
-                int eCur = sCh[i].headE;
-                for (int r = 0; r < nc && r < BB_MAXC; r++) {
-                    apply(sCr[r].before, eCur);
-                    const double acc = -__longlong_as_double((long long)bits) + sCr[r].v;         // the leaving step: a real add
+                if (l == 0) chunkBits[g + cur] = bits;
+                int eCur = headE;
+                for (int r = 0; r < nc && r < BB_MAXC && !failed; r++) {
+                    const BbCross R = sCr[r];
+                    if (!bb_apply(bits, R.before, eCur)) { failed = true; break; }
+                    const double acc = -__longlong_as_double((long long)bits) + R.v;          // the leaving step: a real add
                     bits = (unsigned long long)__double_as_longlong(-acc) & ~(1ull << 63);
-                    if ((int)(bits >> 52) != sCr[r].e) sFail = 1;
-                    post[(size_t)(g + i) * BB_MAXC + r].bits = bits;
-                    eCur = sCr[r].e;
+                    if ((int)(bits >> 52) != R.e) failed = true;
+                    if (l == 0) post[(size_t)(g + cur) * BB_MAXC + r].bits = bits;
+                    eCur = R.e;
                 }
-                apply(sCh[i].tail, eCur);
-                sBits = bits;
+                if (!failed && !bb_apply(bits, tail, eCur)) failed = true;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                crossMask &= ~(1ull << cur);
+                cur++;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
     }
-    if (l == 0 && sFail) fail[c] = 1;
+    if (failed && l == 0) fail[c] = 1;
 }
 __global__ void __launch_bounds__(256) k_bb_emit(const BbChunk* __restrict__ chunks, int nchunks, const HmmChrom* __restrict__ chroms, const unsigned long long* __restrict__ chunkBits,
                                                  const BbPost* __restrict__ post, const ParFn* __restrict__ at64Fn, const uint8_t* __restrict__ at64Rank, double* __restrict__ carryOut) {

@@ -13,6 +13,7 @@
 
 #define SEL_TILE 4096
 #define SEL_MAXQ 16   // max queries that can apply to one tile
+#define SEL_REP 16    // replicas of the global histogram rows: tiles flush into replica (tile % SEL_REP), the pick sums them
 
 struct SelTile { int32_t seg; int64_t begin; int64_t end; };
 struct SelSegQ { int32_t nq; int32_t q[SEL_MAXQ]; };
@@ -45,7 +46,7 @@ static inline double host_double_of_key(unsigned long long k) {
 template <typename K>
 __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys, const SelTile* __restrict__ tiles, const SelSegQ* __restrict__ segq,
                                                      const unsigned long long* __restrict__ qprefix, int shift, int firstPass,
-                                                     uint32_t* __restrict__ hist) {
+                                                     uint32_t* __restrict__ hist /* [SEL_REP][nq][256] */, int nq) {
     __shared__ uint32_t lh[SEL_MAXQ * 256];
     __shared__ unsigned long long lpre[SEL_MAXQ];
     __shared__ int srep[SEL_MAXQ], suniq[SEL_MAXQ], snu;
@@ -69,28 +70,38 @@ __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys,
     const int nu = snu;
     const int lane = threadIdx.x & 63;
     const int sh2 = firstPass ? 0 : shift + 8;
-    for (int64_t i = T.begin + threadIdx.x; i < T.end; i += 256) {
-        K key = keys[i];
+    // all 16 keys of this thread are loaded up front (independent loads in flight), then binned
+    K kreg[SEL_TILE / 256];
+#pragma unroll
+    for (int r = 0; r < SEL_TILE / 256; r++) { const int64_t i = T.begin + threadIdx.x + (int64_t)r * 256; kreg[r] = i < T.end ? keys[i] : (K)0; }
+    bool agg = true;                                      // wave-uniform: is ballot aggregation paying off in this tile?
+#pragma unroll
+    for (int r = 0; r < SEL_TILE / 256; r++) {
+        const bool in = T.begin + threadIdx.x + (int64_t)r * 256 < T.end;
+        const K key = kreg[r];
         const uint32_t d = (uint32_t)(key >> shift) & 255u;
         const unsigned long long hi = (unsigned long long)(key >> sh2);   // only compared when !firstPass (then sh2 = shift+8 < bits)
         for (int u = 0; u < nu; u++) {
             const int q = suniq[u];
-            const bool m = firstPass || hi == lpre[q];
-            unsigned long long todo = __ballot(m);
-            for (int it = 0; it < 4 && todo; it++) {
-                const int leader = __builtin_ctzll(todo);
-                const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
-                const unsigned long long same = __ballot(m && d == dl) & todo;
-                if (lane == leader) atomicAdd(&lh[q * 256 + dl], (uint32_t)__builtin_popcountll(same));
-                todo &= ~same;
-            }
-            if ((todo >> lane) & 1ull) atomicAdd(&lh[q * 256 + d], 1u);
+            const bool m = in && (firstPass || hi == lpre[q]);
+            if (agg) {
+                unsigned long long todo = __ballot(m);
+                for (int it = 0; it < 4 && todo; it++) {
+                    const int leader = __builtin_ctzll(todo);
+                    const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+                    const unsigned long long same = __ballot(m && d == dl) & todo;
+                    if (lane == leader) atomicAdd(&lh[q * 256 + dl], (uint32_t)__builtin_popcountll(same));
+                    todo &= ~same;
+                }
+                if ((todo >> lane) & 1ull) atomicAdd(&lh[q * 256 + d], 1u);
+                if (__builtin_popcountll(todo) > 24) agg = false;       // digits are spread (low mantissa bytes): plain atomics from here on
+            } else if (m) atomicAdd(&lh[q * 256 + d], 1u);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < Q.nq * 256; i += 256) {
         uint32_t v = lh[srep[i >> 8] * 256 + (i & 255)];
-        if (v) atomicAdd(&hist[(size_t)Q.q[i >> 8] * 256 + (i & 255)], v);
+        if (v) atomicAdd(&hist[((size_t)(blockIdx.x % SEL_REP) * nq + Q.q[i >> 8]) * 256 + (i & 255)], v);
     }
 }
 
@@ -100,8 +111,14 @@ static __global__ void __launch_bounds__(64) k_select_pick(uint32_t* __restrict_
     const int q = blockIdx.x;
     if (q >= nq) return;
     const int l = threadIdx.x;
-    uint32_t* h = hist + (size_t)q * 256;
-    uint32_t c0 = h[4 * l], c1 = h[4 * l + 1], c2 = h[4 * l + 2], c3 = h[4 * l + 3];
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+    for (int r = 0; r < SEL_REP; r++) {
+        uint4* h = reinterpret_cast<uint4*>(hist + ((size_t)r * nq + q) * 256) + l;
+        const uint4 v = *h;
+        c0 += v.x; c1 += v.y; c2 += v.z; c3 += v.w;
+        *h = make_uint4(0u, 0u, 0u, 0u);                  // cleared for the next pass
+    }
     uint32_t s = c0 + c1 + c2 + c3;
     uint32_t inc = wave_inclusive_scan_u32(s);
     uint32_t ex = inc - s;
@@ -116,7 +133,6 @@ static __global__ void __launch_bounds__(64) k_select_pick(uint32_t* __restrict_
         qprefix[q] = (qprefix[q] << 8) | (unsigned long long)(4 * l + d);
         qk[q] = r;
     }
-    h[4 * l] = 0; h[4 * l + 1] = 0; h[4 * l + 2] = 0; h[4 * l + 3] = 0;
 }
 
 // ---- host driver ----------------------------------------------------------------------------------------------
@@ -140,32 +156,39 @@ static int32_t radix_select(canvas_ctx* ctx, const K* d_keys, int nseg, const st
             segq[s].q[segq[s].nq++] = q;
         }
     if (tiles.empty()) return CANVAS_OK;
-    // device scratch: separate small allocation (the main workspace is owned by the caller stage)
-    size_t bytes = tiles.size() * sizeof(SelTile) + segq.size() * sizeof(SelSegQ) + (size_t)nq * (16 + 1024) + 1024;
-    char* d = nullptr;
-    CANVAS_HIP_TRY(ctx, hipMallocAsync((void**)&d, bytes, ctx->stream));
-    char* p = d;
-    SelTile* dTiles = (SelTile*)p; p += (tiles.size() * sizeof(SelTile) + 255) & ~size_t(255);
-    SelSegQ* dSegq = (SelSegQ*)p; p += (segq.size() * sizeof(SelSegQ) + 255) & ~size_t(255);
-    unsigned long long* dPrefix = (unsigned long long*)p; p += ((size_t)nq * 8 + 255) & ~size_t(255);
-    unsigned long long* dK = (unsigned long long*)p; p += ((size_t)nq * 8 + 255) & ~size_t(255);
-    uint32_t* dHist = (uint32_t*)p;
-    std::vector<unsigned long long> hk(nq);
+    // persistent scratch of the context: one pinned blob [tiles | segq | ranks | results] <-> one device blob [tiles | segq | ranks | prefix | hist]
+    // (one H2D copy, one memset, one D2H copy per call; every call ends with a synchronisation, so the blobs are reused from offset 0)
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t oTiles = 0, oSegq = al(tiles.size() * sizeof(SelTile)), oK = oSegq + al(segq.size() * sizeof(SelSegQ)), oPrefix = oK + al((size_t)nq * 8),
+                 oHist = oPrefix + al((size_t)nq * 8), devBytes = oHist + (size_t)nq * 1024 * SEL_REP, pinBytes = oPrefix + al((size_t)nq * 8);
+    if (devBytes > ctx->sel_ws_bytes) {
+        if (ctx->sel_ws) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->sel_ws)); ctx->sel_ws = nullptr; ctx->sel_ws_bytes = 0; }
+        CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->sel_ws, devBytes * 2)); ctx->sel_ws_bytes = devBytes * 2;
+    }
+    if (pinBytes > ctx->sel_pin_bytes) {
+        if (ctx->sel_pin) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipHostFree(ctx->sel_pin)); ctx->sel_pin = nullptr; ctx->sel_pin_bytes = 0; }
+        CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->sel_pin, pinBytes * 2, hipHostMallocDefault)); ctx->sel_pin_bytes = pinBytes * 2;
+    }
+    char* d = (char*)ctx->sel_ws; char* h = (char*)ctx->sel_pin;
+    SelTile* dTiles = (SelTile*)(d + oTiles); SelSegQ* dSegq = (SelSegQ*)(d + oSegq);
+    unsigned long long* dK = (unsigned long long*)(d + oK); unsigned long long* dPrefix = (unsigned long long*)(d + oPrefix);
+    uint32_t* dHist = (uint32_t*)(d + oHist);
+    memcpy(h + oTiles, tiles.data(), tiles.size() * sizeof(SelTile));
+    memcpy(h + oSegq, segq.data(), segq.size() * sizeof(SelSegQ));
+    unsigned long long* hk = (unsigned long long*)(h + oK);
     for (int q = 0; q < nq; q++) hk[q] = (unsigned long long)queries[q].k;
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTiles, tiles.data(), tiles.size() * sizeof(SelTile), hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSegq, segq.data(), segq.size() * sizeof(SelSegQ), hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dK, hk.data(), (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dPrefix, 0, (size_t)nq * 8, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dHist, 0, (size_t)nq * 1024, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d, h, oPrefix, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(d + oPrefix, 0, devBytes - oPrefix, ctx->stream));
     const int bits = (int)sizeof(K) * 8;
     for (int shift = bits - 8; shift >= 0; shift -= 8) {
         hipLaunchKernelGGL((k_select_hist<K>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, d_keys, dTiles, dSegq, dPrefix, shift,
-                           shift == bits - 8 ? 1 : 0, dHist);
+                           shift == bits - 8 ? 1 : 0, dHist, nq);
         hipLaunchKernelGGL(k_select_pick, dim3(nq), dim3(64), 0, ctx->stream, dHist, dPrefix, dK, nq);
     }
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(out.data(), dPrefix, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // tiles/segq/hk host vectors must outlive the async copies
-    CANVAS_HIP_TRY(ctx, hipFreeAsync(d, ctx->stream));
+    unsigned long long* hres = (unsigned long long*)(h + oPrefix);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hres, dPrefix, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());
+    for (int q = 0; q < nq; q++) out[q] = hres[q];
     return CANVAS_OK;
 }
