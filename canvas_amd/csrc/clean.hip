@@ -675,6 +675,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     double* dMedians = ws.take<double>(NGC); VarTab* dTab = ws.take<VarTab>(1); uint8_t* dKeepGc = ws.take<uint8_t>(NGC);
     double* dSd = ws.take<double>(nW0); double* dRunMedian = ws.take<double>(65536); int64_t* dRunStart = ws.take<int64_t>(65536 + 1);
     unsigned int* dCnt = ws.take<unsigned int>(1); long long* dPos = ws.take<long long>(65536);
+    ProfScope psTotal(ctx, "clean_total");       // whole CanvasClean on the device timeline (kernels + the gaps of the host decisions)
     rc = canvas_h2d_small(ctx, st.dIsAuto, h_chr_is_autosome, nchr); if (rc) return rc;
     hipLaunchKernelGGL(k_fill_f64, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, st.cur.dev, n, -1.0);   // CountDeviation = -1 (GenomicBin.cs:83)
 
