@@ -546,6 +546,55 @@ static void sd_undo(const double* gd, std::vector<int>& lengthSeg, double trimme
     for (int e : cpl) { lengthSeg.push_back(e - prev); prev = e; }
 }
 
+// ---- undo = Prune (ChangePoint.cs:205-271, Prune.cs): exhaustive search over subsets of the change points for the smallest
+// within-segment sum of squares with j change points, j = K-1 .. 1, stopping when it exceeds (1 + cutoff) x the full model's.
+// Host scalar code on <= a few dozen segments per chromosome; the number of subsets is capped (the reference would simply not return).
+static double error_ssq(const std::vector<int>& len, const std::vector<double>& sum, int k, const std::vector<int>& loc) {
+    auto term = [&](int a, int b) { double sx = 0.0; int nx = 0; for (int i = a; i < b; i++) { sx += sum[i]; nx += len[i]; } return std::pow(sx, 2) / nx; };
+    double e = 0.0;
+    e += term(0, loc[0]);
+    for (int j = 1; j < k; j++) e += term(loc[j - 1], loc[j]);
+    e += term(loc[k - 1], (int)len.size());
+    return e;
+}
+static int32_t prune(const double* gd, int n, std::vector<int>& lengthSeg, double cutoff, std::string& err) {
+    const int nseg = (int)lengthSeg.size(), ncp = nseg - 1;
+    if (ncp < 1) return CANVAS_OK;
+    // work bound: sum over j of C(ncp, j) subsets, each O(nseg)
+    { double total = 0, cmb = 1; for (int j = 1; j <= ncp - 1; j++) { cmb = cmb * (ncp - j + 1) / j; total += cmb; if (total * nseg > 4e9) { err = "CBS -s Prune: too many change points for the exhaustive subset search (ChangePoint.cs:231-246)"; return CANVAS_ERR_UNSUPPORTED; } } }
+    std::vector<double> sx(nseg);
+    double ssq = 0.0;
+    for (int i = 0; i < n; i++) ssq += std::pow(gd[i], 2);
+    { int k = 0; for (int i = 0; i < nseg; i++) { double sp = 0.0; for (int t = k; t < k + lengthSeg[i]; t++) sp += std::pow(gd[t], 1); sx[i] = sp; k += lengthSeg[i]; } }
+    std::vector<int> loc(ncp), best(ncp), kept(ncp);
+    for (int i = 0; i < ncp; i++) { loc[i] = i + 1; kept[i] = i + 1; }
+    const double wssqk = ssq - error_ssq(lengthSeg, sx, ncp, loc);
+    int pruned = 0;                                   // stays 0 when no j exceeds the cut-off: ONE segment (reference behaviour)
+    for (int j = ncp - 1; j > 0; j--) {
+        const int kmj = ncp - j;
+        for (int i = 0; i < j; i++) { loc[i] = i + 1; best[i] = i + 1; }
+        double wssqj = ssq - error_ssq(lengthSeg, sx, j, loc);
+        for (bool left = true; left;) {
+            int i = j - 1;                            // next combination (Prune.cs:62-72)
+            while (loc[i] == kmj + i + 1) i--;
+            loc[i]++;
+            for (int q = i + 1; q < j; q++) loc[q] = loc[q - 1] + 1;
+            if (loc[0] == kmj + 1) left = false;
+            const double w1 = ssq - error_ssq(lengthSeg, sx, j, loc);
+            if (w1 <= wssqj) { wssqj = w1; for (int q = 0; q < j; q++) best[q] = loc[q]; }
+        }
+        if (wssqj / wssqk > 1 + cutoff) { pruned = j + 1; for (int q = 0; q < pruned; q++) loc[q] = kept[q]; break; }
+        for (int q = 0; q < j; q++) kept[q] = best[q];
+    }
+    std::vector<int> cum(nseg); { int a = 0; for (int i = 0; i < nseg; i++) { a += lengthSeg[i]; cum[i] = a; } }
+    std::vector<int> ends;
+    for (int i = 0; i < pruned; i++) ends.push_back(cum[loc[i] - 1]);
+    ends.push_back(n);
+    lengthSeg.clear(); int prev = 0;
+    for (int e : ends) { lengthSeg.push_back(e - prev); prev = e; }
+    return CANVAS_OK;
+}
+
 }  // namespace cbs
 
 extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
@@ -557,8 +606,7 @@ extern "C" int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov
 extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                                    int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats) {
     if (!ctx) return CANVAS_ERR_INVALID;
-    if (undo == 1) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "CBS -s Prune (ChangePoint.cs:205-271) is not built");
-    if (undo != 0 && undo != 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "undo must be 0 (None) or 2 (SDUndo)");
+    if (undo != 0 && undo != 1 && undo != 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "undo must be 0 (None), 1 (Prune) or 2 (SDUndo)");
     if (nchr <= 0 || !d_cov || !h_chr_offset || !d_seg_len || !h_nseg || nperm == 0 || !(alpha > 0 && alpha < 1)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = h_chr_offset[nchr];
@@ -580,6 +628,7 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     cbs::Stats st;
     std::vector<std::vector<int>> segs(nchr);
     std::vector<int32_t> rcs(nchr, 0);
+    std::vector<std::string> errs(nchr);
     std::atomic_int next{0};
     auto work = [&]() {
         for (;;) {
@@ -589,6 +638,7 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
             cbs::MT rnd((uint32_t)seeds[c]);
             rcs[c] = cbs::change_points(G, cov.data() + h_chr_offset[c], n, sbdry, rnd, alpha, nperm, segs[c], st);
             if (rcs[c] == 0 && undo == 2) cbs::sd_undo(cov.data() + h_chr_offset[c], segs[c], trimmedSD, undo_sd);
+            if (rcs[c] == 0 && undo == 1 && segs[c].size() > 1) rcs[c] = cbs::prune(cov.data() + h_chr_offset[c], n, segs[c], 0.05, errs[c]);   // undoPrune = 0.05 (CBSRunner.cs:42)
         }
     };
     unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
@@ -596,7 +646,7 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; t++) th.emplace_back(work);
     for (auto& t : th) t.join();
-    for (int c = 0; c < nchr; c++) if (rcs[c]) return rcs[c];
+    for (int c = 0; c < nchr; c++) if (rcs[c]) { if (!errs[c].empty()) ctx->err = errs[c]; return rcs[c]; }
     std::vector<int32_t> flat((size_t)N + 1, 0);
     for (int c = 0; c < nchr; c++) { h_nseg[c] = (int32_t)segs[c].size(); for (size_t i = 0; i < segs[c].size(); i++) flat[h_chr_offset[c] + i] = segs[c][i]; }
     if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_seg_len, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -247,7 +247,7 @@ class Canvas:
         return seg, nseg.value
 
     def cbs(self, cov, chr_offset, alpha=0.01, nperm=10000, undo=0, undo_sd=3.0):
-        """CBSRunner.Run (CBSRunner.cs:40-151); undo: 0 None, 2 SDUndo"""
+        """CBSRunner.Run (CBSRunner.cs:40-151); undo: 0 None, 1 Prune, 2 SDUndo"""
         torch = self.torch
         off = np.ascontiguousarray(chr_offset, np.int64)
         seg_len = torch.zeros(int(off[-1]) + 1, dtype=torch.int32, device=self.device)

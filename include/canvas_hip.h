@@ -148,7 +148,8 @@ int32_t canvas_split_overlapping(int32_t nsamples, const uint32_t* const* h_star
 int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                    int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
 
-/* same with -s SDUndo (undo = 2, ChangePoint.cs:155-196; undo_sd = 3 in the reference) or None (0).  Prune (1) is not built. */
+/* same with -s Prune (undo = 1, ChangePoint.cs:205-271 + Prune.cs, cut-off 0.05), -s SDUndo (undo = 2, ChangePoint.cs:155-196; undo_sd = 3 in
+   the reference) or None (0). */
 int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                         int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
 

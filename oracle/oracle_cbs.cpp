@@ -679,11 +679,75 @@ static std::vector<int> ChangePointsSDUndo(const double* gd, const std::vector<i
     return out;
 }
 
-// ChangePoint.ChangePoints (ChangePoint.cs:44-153). undoSplits: 0 None, 2 SDUndo (1 Prune not restated -> treated as None).
+// Prune.ErrorSumOfSquares (Prune.cs:18-51): Fortran errssq
+static double ErrorSumOfSquares(const std::vector<int>& lengthSeg, const std::vector<double>& segmentSums, int k, const std::vector<int>& locations) {
+    double errorSumOfSquares = 0.0;
+    double segsx = 0.0; int segnx = 0;
+    for (int i = 0; i < locations[0]; i++) { segsx += segmentSums[i]; segnx += lengthSeg[i]; }
+    errorSumOfSquares += std::pow(segsx, 2) / segnx;
+    for (int j = 1; j < k; j++) {
+        segsx = 0.0; segnx = 0;
+        for (int i = locations[j - 1]; i < locations[j]; i++) { segsx += segmentSums[i]; segnx += lengthSeg[i]; }
+        errorSumOfSquares += std::pow(segsx, 2) / segnx;
+    }
+    segsx = 0.0; segnx = 0;
+    for (int i = locations[k - 1]; i < (int)lengthSeg.size(); i++) { segsx += segmentSums[i]; segnx += lengthSeg[i]; }
+    errorSumOfSquares += std::pow(segsx, 2) / segnx;
+    return errorSumOfSquares;
+}
+// Prune.Combination (Prune.cs:62-72): next r-combination of 1..(r+nmr), AS 88
+static void Combination(int r, int nmr, std::vector<int>& locations, bool& rleft) {
+    int i = r - 1;
+    while (locations[i] == nmr + i + 1) i--;
+    locations[i]++;
+    for (int j = i + 1; j < r; j++) locations[j] = locations[j - 1] + 1;
+    if (locations[0] == nmr + 1) rleft = false;
+}
+// ChangePoint.ChangePointsPrune (ChangePoint.cs:205-271).  Quirks kept: with a single change point the j-loop never runs and the
+// change point is dropped; when no j exceeds the cut-off the result is ONE segment.
+std::vector<int> ChangePointsPrune(const double* gd, int n, const std::vector<int>& lengthSeg, double changeCutoff) {
+    const int nseg = (int)lengthSeg.size(), ncp = nseg - 1;
+    std::vector<double> sx(nseg);
+    std::vector<int> loc(ncp), loc1a(ncp), loc1b(ncp);     // loc1[0,*], loc1[1,*]
+    int prunedNChangePoints = 0;
+    double ssq = 0.0;
+    for (int i = 0; i < n; i++) ssq += std::pow(gd[i], 2);          // Helper.PartialSumOfPowers(x, 2, 0, n)
+    int k = 0;
+    for (int i = 0; i < nseg; i++) { double sp = 0.0; for (int t = k; t < k + lengthSeg[i]; t++) sp += std::pow(gd[t], 1); sx[i] = sp; k += lengthSeg[i]; }
+    for (int i = 0; i < ncp; i++) { loc[i] = i + 1; loc1b[i] = i + 1; }
+    const double wssqk = ssq - ErrorSumOfSquares(lengthSeg, sx, ncp, loc);
+    for (int j = ncp - 1; j > 0; j--) {
+        const int kmj = ncp - j;
+        bool jleft = true;
+        for (int i = 0; i < j; i++) { loc[i] = i + 1; loc1a[i] = i + 1; }
+        double wssqj = ssq - ErrorSumOfSquares(lengthSeg, sx, j, loc);
+        while (jleft) {
+            Combination(j, kmj, loc, jleft);
+            double wssq1 = ssq - ErrorSumOfSquares(lengthSeg, sx, j, loc);
+            if (wssq1 <= wssqj) { wssqj = wssq1; for (int i = 0; i < j; i++) loc1a[i] = loc[i]; }
+        }
+        if (wssqj / wssqk > 1 + changeCutoff) {
+            prunedNChangePoints = j + 1;
+            for (int i = 0; i < prunedNChangePoints; i++) loc[i] = loc1b[i];
+            break;
+        } else {
+            for (int i = 0; i < j; i++) loc1b[i] = loc1a[i];
+        }
+    }
+    std::vector<int> cum(nseg);
+    std::partial_sum(lengthSeg.begin(), lengthSeg.end(), cum.begin());
+    std::vector<int> pcp(prunedNChangePoints + 2);
+    for (int i = 0; i < prunedNChangePoints; i++) pcp[i + 1] = cum[loc[i] - 1];
+    pcp[0] = 0; pcp[pcp.size() - 1] = n;
+    std::vector<int> out(pcp.size() - 1);
+    for (size_t i = 0; i + 1 < pcp.size(); i++) out[i] = pcp[i + 1] - pcp[i];
+    return out;
+}
+
+// ChangePoint.ChangePoints (ChangePoint.cs:44-153). undoSplits: 0 None, 1 Prune, 2 SDUndo.
 std::vector<int> ChangePoints(const double* genomeData, int n, const std::vector<uint32_t>& sbdry, MT19937& rnd, double alpha,
                               uint32_t nPerm, int minWidth, int kMax, uint32_t nMin, int undoSplits, double trimmedSD,
                               double undoPrune, double undoSD, CbsStats* stats) {
-    (void)undoPrune;
     const int nGrid = 100; const double tol = 1E-6;
     std::vector<int> segEnd = {0, n};
     int k = (int)segEnd.size();
@@ -725,6 +789,7 @@ std::vector<int> ChangePoints(const double* genomeData, int n, const std::vector
     segEnds.insert(segEnds.begin(), 0);
     std::vector<int> lengthSeg(nSeg);
     for (int i = 0; i < nSeg; i++) lengthSeg[i] = segEnds[i + 1] - segEnds[i];
+    if (nSeg > 1 && undoSplits == 1) lengthSeg = ChangePointsPrune(genomeData, n, lengthSeg, undoPrune);
     if (nSeg > 1 && undoSplits == 2) lengthSeg = ChangePointsSDUndo(genomeData, lengthSeg, trimmedSD, undoSD);
     return lengthSeg;
 }

@@ -23,6 +23,8 @@ double phyper_lower(double x, double NR, double NB, double n);
 std::vector<int> ChangePoints(const double* genomeData, int n, const std::vector<uint32_t>& sbdry, MT19937& rnd, double alpha,
                               uint32_t nPerm, int minWidth, int kMax, uint32_t nMin, int undoSplits, double trimmedSD,
                               double undoPrune, double undoSD, CbsStats* stats);
+// ChangePoint.ChangePointsPrune (ChangePoint.cs:205-271)
+std::vector<int> ChangePointsPrune(const double* gd, int n, const std::vector<int>& lengthSeg, double changeCutoff);
 double TrimmedVariance(const std::vector<const double*>& scores, const std::vector<int>& lens, double trim);
 void dotnet_sort_keys_items(double* keys, int* items, int index, int length, int arrayLength);
 }  // namespace oracle

@@ -233,6 +233,12 @@ double orc_trimmed_variance(int nchr, const double* const* x, const int* n, doub
     std::vector<const double*> s(x, x + nchr); std::vector<int> l(n, n + nchr);
     return TrimmedVariance(s, l, trim);
 }
+int orc_changepoints_prune(const double* x, int n, const int32_t* lengthSeg, int nseg, double cutoff, int32_t* out, int cap) {
+    std::vector<int> ls(lengthSeg, lengthSeg + nseg);
+    auto r = ChangePointsPrune(x, n, ls, cutoff);
+    for (size_t i = 0; i < r.size() && (int)i < cap; i++) out[i] = r[i];
+    return (int)r.size();
+}
 void orc_sort_keys_items(double* keys, int* items, int n) { dotnet_sort_keys_items(keys, items, 0, n, n); }
 
 }  // extern "C"

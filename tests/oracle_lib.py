@@ -284,6 +284,14 @@ def cbs_chromosome(x, seed, sbdry=None, alpha=0.01, n_perm=10000, undo=0, trimme
     return ls[:n].copy(), stats
 
 
+def changepoints_prune(x, length_seg, cutoff=0.05):
+    """ChangePoint.ChangePointsPrune (ChangePoint.cs:205-271)"""
+    x = np.ascontiguousarray(x, np.float64); ls = np.ascontiguousarray(length_seg, np.int32)
+    out = np.zeros(len(ls) + 1, np.int32)
+    k = lib.orc_changepoints_prune(_p(x), len(x), _p(ls), len(ls), C.c_double(cutoff), _p(out), len(out))
+    return out[:k].copy()
+
+
 def cbs_genome(xs, alpha=0.01, n_perm=10000, threads=1, undo=0):
     sb = cbs_boundary(n_perm, alpha)
     n = np.array([len(x) for x in xs], np.int64)

@@ -68,3 +68,21 @@ def test_cbs_sdundo_merges_weak_splits():
     s0, e0 = _run(cv, cov, off, nperm=2000, undo=0)
     s2, e2 = _run(cv, cov, off, nperm=2000, undo=2)
     assert sum(len(e) for e in e2) <= sum(len(e) for e in e0)
+
+
+def test_cbs_prune_drops_unsupported_change_points():
+    """-s Prune (ChangePoint.cs:205-271): exhaustive subset search over the change points found by the recursion"""
+    cv = get_canvas()
+    rng = np.random.RandomState(17)
+    parts = []
+    for c in range(4):
+        x = rng.normal(100, 10, 5000)
+        x[800:1300] += 50; x[2500:2700] += 12; x[4000:4030] -= 30
+        if c == 3: x = rng.normal(100, 10, 3000)            # no change point at all
+        parts.append(np.round(x, 2))
+    cov = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    s0, e0 = _run(cv, cov, off, nperm=2000, undo=0)
+    s1, e1 = _run(cv, cov, off, nperm=2000, undo=1)
+    assert sum(len(e) for e in e1) <= sum(len(e) for e in e0)
+    assert any(len(a) != len(b) for a, b in zip(e0, e1)) or all(len(a) <= 2 for a in e0)

@@ -124,3 +124,54 @@ def test_phyper_against_scipy():
     for (k, n1s, nperm, i) in [(0, 2, 10000, 100), (1, 5, 10000, 2000), (3, 50, 10000, 500), (10, 100, 10000, 1500)]:
         ref = hypergeom.cdf(k, nperm, n1s, i)
         assert abs(O.lib.orc_phyper(k, n1s, nperm - n1s, i) - ref) < 1e-12 * max(1.0, ref) + 1e-15
+
+
+def _prune_numpy(x, length_seg, cutoff=0.05):
+    """Independent restatement of ChangePointsPrune (ChangePoint.cs:205-271, Prune.cs) with itertools: for j = K-1 .. 1 change points
+    the subset with the smallest within-segment sum of squares (the LAST one in lexicographic order among equals: '<='), stop at the
+    first j whose best is more than (1 + cutoff) x the full model's and keep the best subset of size j + 1."""
+    import itertools
+    x = np.asarray(x, np.float64); ls = list(length_seg); K = len(ls) - 1
+    ends = np.cumsum(ls)
+    seg_sum = [x[e - l:e].sum() for e, l in zip(ends, ls)]
+    ssq = float((x ** 2).sum())
+
+    def wss(cps):   # cps: 1-based indices of the segments after which a change point is kept
+        e = 0.0; a = 0
+        for b in list(cps) + [len(ls)]:
+            e += sum(seg_sum[a:b]) ** 2 / sum(ls[a:b]); a = b
+        return ssq - e
+
+    full = wss(range(1, K + 1))
+    kept = list(range(1, K + 1)); pruned = 0
+    for j in range(K - 1, 0, -1):
+        best, bw = None, None
+        for cps in itertools.combinations(range(1, K + 1), j):
+            w = wss(cps)
+            if bw is None or w <= bw: best, bw = cps, w
+        if full == 0 or bw / full > 1 + cutoff:
+            if full == 0 and not (bw > 0): pass          # 0/0 = NaN compares false in the reference
+            else:
+                pruned = j + 1; break
+        kept = list(best)
+    cps = kept[:pruned]
+    pts = [0] + [int(ends[c - 1]) for c in cps] + [len(x)]
+    return np.diff(pts)
+
+
+def test_changepoints_prune_against_an_independent_restatement():
+    rng = np.random.RandomState(5)
+    for trial in range(40):
+        K = rng.randint(1, 8)
+        ls = rng.randint(3, 40, K + 1)
+        means = rng.choice([100.0, 101.0, 104.0, 120.0, 80.0], K + 1)
+        x = np.concatenate([np.round(rng.normal(m, 3.0, l), 2) for m, l in zip(means, ls)])
+        got = O.changepoints_prune(x, ls)
+        exp = _prune_numpy(x, ls)
+        assert got.sum() == len(x)
+        assert (got == exp).all() if len(got) == len(exp) else False, (trial, ls, got, exp)
+    # reference quirks: a single change point is always dropped; a perfect fit keeps everything
+    x = np.concatenate([np.full(5, 1.0), np.full(5, 9.0)])
+    assert list(O.changepoints_prune(x, [5, 5])) == [10]
+    x = np.concatenate([np.full(4, 0.0), np.full(4, 5.0), np.full(4, 0.0)])
+    assert list(O.changepoints_prune(x, [4, 4, 4])) == [4, 4, 4]
