@@ -235,47 +235,6 @@ __global__ void __launch_bounds__(256) k_run_bounds(const int32_t* __restrict__ 
     if (i == 0 || c != chr[i - 1]) { unsigned int k = atomicAdd(cnt, 1u); if ((int)k < cap) pos[k] = (long long)((i << 20) | (long long)(c & 0xFFFFF)); }
 }
 
-// Exact order statistics inside ONE workgroup: 8 MSB-radix passes over keyOf(i), i in [lo, hi), for two ranks at once
-// (the k / k+1 pair of an even-length median).  Used where the segments are small (per-chromosome window SDs).
-template <typename F>
-__device__ __forceinline__ void wg_select2(F keyOf, int64_t lo, int64_t hi, unsigned long long rank0, unsigned long long rank1, uint32_t (*sH)[256],
-                                           unsigned long long* sPre, unsigned long long* sK) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    if (tid == 0) { sPre[0] = 0; sPre[1] = 0; sK[0] = rank0; sK[1] = rank1; }
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        for (int i = tid; i < 512; i += nt) sH[i >> 8][i & 255] = 0;
-        __syncthreads();
-        const unsigned long long p0 = sPre[0], p1 = sPre[1];
-        const bool same = p0 == p1;
-        for (int64_t i = lo + tid; i < hi; i += nt) {
-            const unsigned long long key = keyOf(i);
-            const uint32_t d = (uint32_t)(key >> shift) & 255u;
-            const unsigned long long hiPart = shift == 56 ? 0ull : key >> (shift + 8);
-            if (hiPart == p0) atomicAdd(&sH[0][d], 1u);
-            if (!same && hiPart == p1) atomicAdd(&sH[1][d], 1u);
-        }
-        __syncthreads();
-        const int w = tid >> 6, l = tid & 63;
-        if (w < 2) {
-            const uint32_t* h = sH[same ? 0 : w];
-            uint32_t c0 = h[4 * l], c1 = h[4 * l + 1], c2 = h[4 * l + 2], c3 = h[4 * l + 3];
-            uint32_t sum = c0 + c1 + c2 + c3;
-            uint32_t inc = wave_inclusive_scan_u32(sum), ex = inc - sum;
-            const unsigned long long k = sK[w];
-            if (k >= ex && k < inc) {
-                uint32_t r = (uint32_t)(k - ex), d;
-                if (r < c0) { d = 0; } else if (r < c0 + c1) { d = 1; r -= c0; } else if (r < c0 + c1 + c2) { d = 2; r -= c0 + c1; } else { d = 3; r -= c0 + c1 + c2; }
-                sPre[w] = (sPre[w] << 8) | (unsigned long long)(4 * l + d);
-                sK[w] = r;
-            }
-        }
-        __syncthreads();
-    }
-}
-__device__ __forceinline__ double double_of_key(unsigned long long k) {
-    unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-    return __longlong_as_double((long long)u);
-}
 // Utilities.Mad per chromosome run of the window SDs (CanvasClean.cs:243-258, Utilities.cs Median/Mad): one workgroup per run
 __global__ void __launch_bounds__(1024) k_run_mad(const double* __restrict__ sd, const int64_t* __restrict__ runStart, double* __restrict__ outMad) {
     __shared__ uint32_t sH[2][256];

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "select.hpp"
 #include <cmath>
+#include <thread>
 #include <cstring>
 #include <limits>
 #include <algorithm>
@@ -916,6 +917,113 @@ __global__ void __launch_bounds__(256) k_seg_ids(const uint8_t* __restrict__ fla
     }
 }
 
+// =====================================================================================================================
+// Joint (multi-sample) mode: HiddenMarkovModelsRunner.Run(inputs, isPerSample: false) (HiddenMarkovModelsRunner.cs:23-152),
+// NegativeBinomialMixture.EstimateViterbiLikelihood with useAllStates = false (Distributions.cs:257-323).
+//
+// Per chromosome and sample: haploid mean = max(1, median)/2 and Utilities.Variance of the uncapped coverage, tables of S x 5 negative
+// binomials of length maxValues + 10.  The likelihood of a step is
+//     log( max over genotype combinations of state j of  prod_s pmf*(x_s) )  +  log( transition term )
+// and the transition term of Distributions.cs:299-320 is A[i][j]: the best combination only holds states j and 2, so coming from
+// diploid (i == 2) the minimum over it is A[2][j], into diploid it is A[i][2], and otherwise the minimum over its non-diploid
+// members is A[i][j] (0.0025 < 0.99).  The recurrence therefore has the per-sample form with a per-bin emission value, and the whole
+// speculate / verify machinery is reused through a [5][N] "table" indexed by the bin itself.
+// Math.Log of the per-bin maximum is evaluated by the HOST libm on all bins (threads), like the emission tables: the reference
+// calls the platform libm there and bit-exactness against it is what keeps near-tie arg-maxes identical (Q13).
+#define JOINT_MAXS 16          // samples
+#define JOINT_MAXCOMBO 15      // multiset permutations of {j x (S'-d), 2 x d}, S' = min(S, 4)
+struct JointCombos { int32_t n[NSTATE]; int8_t g[NSTATE][JOINT_MAXCOMBO][4]; int32_t sp; };
+struct JointPtrs { const double* cov[JOINT_MAXS]; };
+
+// Utilities.Median(IEnumerable<double>) per (chromosome, sample): SortedList<double>.Median()
+__global__ void __launch_bounds__(1024) k_joint_median(JointPtrs cov, const HmmChrom* __restrict__ chroms, int nsamples, double* __restrict__ med) {
+    __shared__ uint32_t sH[2][256];
+    __shared__ unsigned long long sPre[2], sK[2];
+    const int c = blockIdx.x, d = blockIdx.y;
+    const HmmChrom C = chroms[c];
+    if (C.T <= 10) return;
+    const double* __restrict__ x = cov.cov[d];
+    const int64_t cnt = C.T;
+    const unsigned long long r1 = (unsigned long long)(cnt / 2), r0 = (cnt % 2) ? r1 : r1 - 1;
+    wg_select2([&](int64_t i) { return key_of_double(x[i]); }, C.begin, C.begin + C.T, r0, r1, sH, sPre, sK);
+    if (threadIdx.x == 0) med[c * nsamples + d] = (cnt % 2) ? double_of_key(sPre[1]) : (double_of_key(sPre[0]) + double_of_key(sPre[1])) / 2;
+}
+// sequential double sums in list order (Enumerable.Average and the loop of Utilities.Variance, Utilities.cs:290-301): one wave per
+// (chromosome, sample), 64 operands staged per chunk and read back as LDS broadcasts so that the chain is one FP64 add per element.
+// pass 0: sum of x;  pass 1: sum of (x - mu)^2 with mu = sum0 / T
+__global__ void __launch_bounds__(64) k_joint_seqsum(JointPtrs cov, const HmmChrom* __restrict__ chroms, int nsamples, int pass, const double* __restrict__ sum0, double* __restrict__ out) {
+    __shared__ double sV[2][64];
+    const int c = blockIdx.x, d = blockIdx.y, l = threadIdx.x;
+    const HmmChrom C = chroms[c];
+    if (C.T <= 10) return;
+    const double* __restrict__ x = cov.cov[d] + C.begin;
+    const double mu = pass ? sum0[c * nsamples + d] / (double)C.T : 0.0;
+    auto val = [&](int64_t t) -> double { if (t >= C.T) return 0.0; const double v = x[t]; if (!pass) return v; const double df = v - mu; return df * df; };
+    double acc = 0.0;
+    double vNext = val(l);
+    int buf = 0;
+    for (int64_t c0 = 0; c0 < C.T; c0 += 64, buf ^= 1) {
+        sV[buf][l] = vNext;
+        vNext = val(c0 + 64 + l);
+        double r[64];
+#pragma unroll
+        for (int s = 0; s < 64; s++) r[s] = sV[buf][s];
+#pragma unroll
+        for (int s = 0; s < 64; s++) acc = acc + r[s];          // past the end: + 0.0 leaves acc unchanged (acc >= 0)
+    }
+    if (l == 0) out[c * nsamples + d] = acc;
+}
+// RemoveOutliers (HiddenMarkovModelsRunner.cs:154-162) + Convert.ToInt32; per-chromosome maximum of the indices
+__global__ void __launch_bounds__(256) k_joint_index(JointPtrs cov, int nsamples, const int64_t* __restrict__ chrOff, int nchr, const double* __restrict__ thr, int64_t N,
+                                                     int32_t* __restrict__ idxS, int32_t* __restrict__ maxIdx) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chrOff[mid] <= g) lo = mid; else hi = mid - 1; }
+    const double t = thr[lo];
+    int m = 0;
+    for (int d = 0; d < nsamples; d++) {
+        double x = cov.cov[d][g];
+        x = x > t ? t : x;
+        int k = (int)rint(x); k = k < 0 ? 0 : k;
+        idxS[(size_t)d * N + g] = k;
+        m = k > m ? k : m;
+    }
+    atomicMax(&maxIdx[lo], m);
+}
+// per bin and state: max over the genotype combinations of the product of the (grouped) pmf values (Distributions.cs:262-296)
+__global__ void __launch_bounds__(256) k_joint_emission(const int32_t* __restrict__ idxS, int nsamples, const int64_t* __restrict__ chrOff, int nchr, const HmmChrom* __restrict__ chroms,
+                                                        const double* __restrict__ pmf /* [chr][sample][state][stride] */, int stride, JointCombos K, int64_t N,
+                                                        double* __restrict__ maxL /* [5][N] */) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chrOff[mid] <= g) lo = mid; else hi = mid - 1; }
+    if (chroms[lo].T <= 10) { for (int j = 0; j < NSTATE; j++) maxL[(size_t)j * N + g] = 1.0; return; }
+    // grouped probabilities per sample: states 0/1 and 3/4 share the larger of the two (useAllStates == false)
+    double pg[4][NSTATE];
+    for (int s = 0; s < K.sp; s++) {
+        const double* row = pmf + ((size_t)(lo * nsamples + s) * NSTATE) * stride + idxS[(size_t)s * N + g];
+        const double p0 = row[0], p1 = row[(size_t)stride], p2 = row[(size_t)2 * stride], p3 = row[(size_t)3 * stride], p4 = row[(size_t)4 * stride];
+        const double lo01 = p0 > p1 ? p0 : p1, hi34 = p3 > p4 ? p3 : p4;      // Math.Max
+        pg[s][0] = lo01; pg[s][1] = lo01; pg[s][2] = p2; pg[s][3] = hi34; pg[s][4] = hi34;
+    }
+    for (int j = 0; j < NSTATE; j++) {
+        double best = -1.7976931348623157e308;
+        for (int k = 0; k < K.n[j]; k++) {
+            double em = 1.0;
+            for (int s = 0; s < K.sp; s++) em *= pg[s][K.g[j][k][s]];
+            if (em != em || em == INFINITY || em == -INFINITY) em = 0.0;
+            if (best < em) best = em;
+        }
+        maxL[(size_t)j * N + g] = best;
+    }
+}
+__global__ void __launch_bounds__(256) k_iota_i32(int32_t* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+
 // ---- host: emission tables (DistributionUtilities.cs:51-69).  GammaLn/FactorialLn (MathNet) -> lgamma; Math.Pow(x,2) := x*x.
 static void negative_binomial_log_table(double mean, double variance, int maxValue, double* out) {
     double m = std::max(mean, 0.1);
@@ -960,14 +1068,14 @@ static void quartile_val(int64_t n, const float* v, float& q1, float& q2, float&
 
 static inline unsigned nblk2(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-extern "C" {
-
-int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
-    if (!ctx) return CANVAS_ERR_INVALID;
-    if (nchr <= 0 || !d_cov || !h_chr_offset || !d_state) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
-    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+// Shared Viterbi driver of the per-sample and the joint mode.  `prepare` fills the emission source after the common workspace has been
+// carved: idx[N] (table index per bin), the log-emission table dTab ([5][P.tableLen]) and P.  Everything after that — speculation,
+// backtrack, exact backbone, verification, sequential fallback — is mode independent: the likelihood of a step is
+// log-emission_j(t) + logA[i][j] in both modes (for the joint mode see canvas_hmm_joint).
+struct HmmEmis { int32_t* idx = nullptr; double* dTab = nullptr; };
+template <class Prepare>
+static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, size_t extraBytes, Prepare prepare, int32_t* d_state) {
     const int64_t N = h_chr_offset[nchr];
-    if (N < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
     // VB-step blocks (speculation, verification and backtrack share them)
     std::vector<HmmChrom> chroms(nchr);
     std::vector<int32_t> firstBlock(nchr + 1);
@@ -989,15 +1097,15 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     sz.take<BbChunk>(nchunks + 1); sz.take<int32_t>(nchr + 1); sz.take<double>(nchunks + 1); sz.take<double>(nchunks + 1); sz.take<BbChunkOut>(nchunks + 1);
     sz.take<BbCross>((size_t)nchunks * BB_MAXC + 1); sz.take<ParFn>((size_t)nchunks * 16 + 1); sz.take<uint8_t>((size_t)nchunks * 16 + 8);
     sz.take<unsigned long long>(nchunks + 1); sz.take<BbPost>((size_t)nchunks * BB_MAXC + 1);
-    sz.take<uint32_t>(N); sz.take<int32_t>(N); sz.take<uint16_t>(N + 8); sz.take<HmmChrom>(nchr); sz.take<int32_t>(nchr);
-    sz.take<int32_t>(nchr + 1); sz.take<uint16_t>(nblocks + 8); sz.take<int8_t>(nblocks + 8); sz.take<double>(NSTATE * 70000);
+    sz.take<uint16_t>(N + 8); sz.take<HmmChrom>(nchr); sz.take<int32_t>(nchr);
+    sz.take<int32_t>(nchr + 1); sz.take<uint16_t>(nblocks + 8); sz.take<int8_t>(nblocks + 8);
     sz.take<int64_t>(nchr + 1); sz.take<VitBlock>(nblocks + 1); sz.take<double>(N); sz.take<double>(N + 64); sz.take<int32_t>(nchr); sz.take<int32_t>(nchr);
-    int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + extraBytes + 65536); if (rc) return rc;
     WsCarver ws(ctx->ws);
-    uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N); uint16_t* psi = ws.take<uint16_t>(N + 8);
+    uint16_t* psi = ws.take<uint16_t>(N + 8);
     HmmChrom* dChroms = ws.take<HmmChrom>(nchr); int32_t* dLast = ws.take<int32_t>(nchr);
     int32_t* dFirst = ws.take<int32_t>(nchr + 1);
-    uint16_t* dMaps = ws.take<uint16_t>(nblocks + 8); int8_t* dEntry = ws.take<int8_t>(nblocks + 8); double* dTab = ws.take<double>(NSTATE * 70000);
+    uint16_t* dMaps = ws.take<uint16_t>(nblocks + 8); int8_t* dEntry = ws.take<int8_t>(nblocks + 8);
     int64_t* dOffDev = ws.take<int64_t>(nchr + 1);
     VitBlock* dVBlocks = ws.take<VitBlock>(nblocks + 1); double* dD = ws.take<double>(N); double* dCarry = ws.take<double>(N + 64); int32_t* dFail = ws.take<int32_t>(nchr); int32_t* dRedo = ws.take<int32_t>(nchr);
     BbChunk* dBChunks = ws.take<BbChunk>(nchunks + 1); int32_t* dFirstChunk = ws.take<int32_t>(nchr + 1);
@@ -1012,36 +1120,9 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstChunk, firstChunk.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     if (nblocks > 0) hipLaunchKernelGGL((k_make_blocks<VitBlock>), dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dFirst, nchr, nblocks, VB, dVBlocks);
     if (nchunks > 0) hipLaunchKernelGGL((k_make_blocks<BbChunk>), dim3(nblk2(nchunks, 256)), dim3(256), 0, ctx->stream, dFirstChunk, nchr, nchunks, BB_CHUNK, dBChunks);
-    // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
-    hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
-    int64_t qidx[6]; int nq;
-    quartile_idx(N, qidx, nq);
-    std::vector<SelQuery> qs;
-    for (int k = 0; k < nq; k++) qs.push_back({0, 0, qidx[k]});
-    std::vector<unsigned long long> res;
-    rc = radix_select<uint32_t>(ctx, keys, 1, std::vector<int64_t>{0, N}, qs, res); if (rc) return rc;
-    float v[6], q1, q2, q3;
-    for (int k = 0; k < nq; k++) v[k] = host_float_of_key((uint32_t)res[k]);
-    quartile_val(N, v, q1, q2, q3);
-    const double median = (double)q2;
-    const float iqr = q3 - q1;
-    const double pseudoVariance = (double)(iqr * iqr);
-    // 2. emission tables (HiddenMarkovModelsRunner.cs:111-152)
-    const double haploidMean = median / 2.0;
-    HmmParams P;
-    P.maxThreshold = haploidMean * NSTATE;
-    if (!(P.maxThreshold >= 0) || P.maxThreshold > 60000) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: coverage scale outside the supported table size");
-    P.tableLen = (int32_t)std::nearbyint(P.maxThreshold) + 10 + 1;      // >= max over chromosomes of (maxValues + 10)
-    std::vector<double> tab((size_t)NSTATE * P.tableLen);
-    for (int CN = 0; CN < NSTATE; CN++) negative_binomial_log_table(std::max((double)CN, 0.1) * haploidMean, pseudoVariance, P.tableLen, &tab[(size_t)CN * P.tableLen]);
-    const double selfTransition = 0.99;
-    for (int i = 0; i < NSTATE; i++) {
-        for (int j = 0; j < NSTATE; j++) P.logA[i][j] = std::log(i == j ? selfTransition : (1.0 - selfTransition) / (NSTATE - 1));
-        P.logPi[i] = std::log((double)(1.0f / NSTATE));      // 1f / nStates widened (HMM.cs:41)
-    }
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    // 3. index, Viterbi, backtrack
-    hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);
+    HmmParams P; HmmEmis E;
+    rc = prepare(ws, P, E, (const HmmChrom*)dChroms, (const int64_t*)dOffDev); if (rc) return rc;
+    int32_t* idx = E.idx; double* dTab = E.dTab;
     size_t tabBytes = (size_t)NSTATE * P.tableLen * 8;
     size_t lds = tabBytes <= 48 * 1024 ? tabBytes : 0;
     for (int c = 0; c < nchr; c++)
@@ -1095,6 +1176,183 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
 }
+
+extern "C" {
+
+int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !d_cov || !h_chr_offset || !d_state) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = h_chr_offset[nchr];
+    if (N < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
+    WsSizer ex; ex.take<uint32_t>(N); ex.take<int32_t>(N); ex.take<double>(NSTATE * 70000);
+    auto prepare = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom*, const int64_t*) -> int32_t {
+        int32_t rc;
+        uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N); double* dTab = ws.take<double>(NSTATE * 70000);
+    // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
+    hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
+    int64_t qidx[6]; int nq;
+    quartile_idx(N, qidx, nq);
+    std::vector<SelQuery> qs;
+    for (int k = 0; k < nq; k++) qs.push_back({0, 0, qidx[k]});
+    std::vector<unsigned long long> res;
+    rc = radix_select<uint32_t>(ctx, keys, 1, std::vector<int64_t>{0, N}, qs, res); if (rc) return rc;
+    float v[6], q1, q2, q3;
+    for (int k = 0; k < nq; k++) v[k] = host_float_of_key((uint32_t)res[k]);
+    quartile_val(N, v, q1, q2, q3);
+    const double median = (double)q2;
+    const float iqr = q3 - q1;
+    const double pseudoVariance = (double)(iqr * iqr);
+    // 2. emission tables (HiddenMarkovModelsRunner.cs:111-152)
+    const double haploidMean = median / 2.0;
+    P.maxThreshold = haploidMean * NSTATE;
+    if (!(P.maxThreshold >= 0) || P.maxThreshold > 60000) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: coverage scale outside the supported table size");
+    P.tableLen = (int32_t)std::nearbyint(P.maxThreshold) + 10 + 1;      // >= max over chromosomes of (maxValues + 10)
+    std::vector<double> tab((size_t)NSTATE * P.tableLen);
+    for (int CN = 0; CN < NSTATE; CN++) negative_binomial_log_table(std::max((double)CN, 0.1) * haploidMean, pseudoVariance, P.tableLen, &tab[(size_t)CN * P.tableLen]);
+    const double selfTransition = 0.99;
+    for (int i = 0; i < NSTATE; i++) {
+        for (int j = 0; j < NSTATE; j++) P.logA[i][j] = std::log(i == j ? selfTransition : (1.0 - selfTransition) / (NSTATE - 1));
+        P.logPi[i] = std::log((double)(1.0f / NSTATE));      // 1f / nStates widened (HMM.cs:41)
+    }
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    // 3. index, Viterbi, backtrack
+    hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);
+        E.idx = idx; E.dTab = dTab;
+        return CANVAS_OK;
+    };
+    return hmm_pipeline(ctx, nchr, h_chr_offset, ex.off, prepare, d_state);
+}
+
+}  // extern "C"
+
+// NegativeBinomialWrapper density table (DistributionUtilities.cs:51-69), the same calls as negative_binomial_log_table without the final log
+static void negative_binomial_table(double mean, double variance, int maxValue, double* out) {
+    double m = std::max(mean, 0.1);
+    double r = (m * m) / (std::max(variance, mean * 1.2) - mean);
+    r = std::max(2.0, r);
+    const double term0 = std::log(std::pow(1 + mean / r, -r)), lgr = std::lgamma(r), ratio = mean / (mean + r);
+    for (int x = 0; x < maxValue; x++) {
+        double dens = std::exp(term0 + std::log(std::pow(ratio, (double)x)) + std::lgamma(r + x) - std::lgamma((double)x + 1.0) - lgr);
+        if (std::isnan(dens) || std::isinf(dens)) dens = 0;
+        out[x] = dens;
+    }
+}
+// DistributionUtilities.GetGenotypeCombinations (DistributionUtilities.cs:11-40): for every state the distinct arrangements of
+// {state x (S'-d), diploid x d}, d = 0 .. S'-1, each multiset sorted and then enumerated in lexicographic order (Permutations.cs:399-433)
+static void genotype_combinations(int nsamples, JointCombos& K) {
+    const int sp = std::min(nsamples, 4);
+    K.sp = sp;
+    for (int j = 0; j < NSTATE; j++) {
+        int n = 0;
+        if (j == 2) { for (int s = 0; s < 4; s++) K.g[j][0][s] = 2; n = 1; }
+        else for (int nd = 0; nd < sp; nd++) {
+            std::vector<int> st(sp - nd, j); st.insert(st.end(), nd, 2);
+            std::sort(st.begin(), st.end());
+            do { for (int s = 0; s < 4; s++) K.g[j][n][s] = (int8_t)(s < sp ? st[s] : 2); n++; } while (std::next_permutation(st.begin(), st.end()));
+        }
+        K.n[j] = n;
+    }
+}
+template <class F> static void parallel_for(int64_t n, int64_t grain, F f) {
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(hw, (n + grain - 1) / grain));
+    if (nt == 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([=]() { f(n * t / nt, n * (t + 1) / nt); });
+    for (auto& t : th) t.join();
+}
+
+extern "C" int32_t canvas_hmm_joint(canvas_ctx* ctx, int32_t nsamples, int32_t nchr, const double* const* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nsamples <= 0 || nsamples > JOINT_MAXS || nchr <= 0 || !d_cov || !h_chr_offset || !d_state) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_joint: bad arguments (1..16 samples)");
+    for (int d = 0; d < nsamples; d++) if (!d_cov[d]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_joint: null coverage pointer");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = h_chr_offset[nchr];
+    if (N <= 0 || N > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_joint: bin count out of range");
+    const int S = nsamples;
+    JointPtrs ptrs; for (int d = 0; d < JOINT_MAXS; d++) ptrs.cov[d] = d < S ? d_cov[d] : nullptr;
+    std::vector<HmmChrom> chroms(nchr);
+    for (int c = 0; c < nchr; c++) { chroms[c].begin = h_chr_offset[c]; chroms[c].T = h_chr_offset[c + 1] - h_chr_offset[c]; }
+    // ---- phase 1: per chromosome and sample median, mean and variance of the uncapped coverage (HiddenMarkovModelsRunner.cs:117-131)
+    const size_t nCS = (size_t)nchr * S;
+    char* small = nullptr;
+    const size_t smallBytes = ((nchr * sizeof(HmmChrom) + 255) & ~size_t(255)) + 3 * ((nCS * 8 + 255) & ~size_t(255));
+    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&small, smallBytes));
+    struct Free { canvas_ctx* c; char* p; ~Free() { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); } } fr{ctx, small};
+    HmmChrom* dCh = (HmmChrom*)small;
+    double* dMed = (double*)(small + ((nchr * sizeof(HmmChrom) + 255) & ~size_t(255)));
+    double* dSum0 = dMed + ((nCS * 8 + 255) & ~size_t(255)) / 8; double* dSum1 = dSum0 + ((nCS * 8 + 255) & ~size_t(255)) / 8;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, chroms.data(), nchr * sizeof(HmmChrom), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dMed, 0, 3 * ((nCS * 8 + 255) & ~size_t(255)), ctx->stream));
+    hipLaunchKernelGGL(k_joint_median, dim3(nchr, S), dim3(1024), 0, ctx->stream, ptrs, dCh, S, dMed);
+    hipLaunchKernelGGL(k_joint_seqsum, dim3(nchr, S), dim3(64), 0, ctx->stream, ptrs, dCh, S, 0, (const double*)nullptr, dSum0);
+    hipLaunchKernelGGL(k_joint_seqsum, dim3(nchr, S), dim3(64), 0, ctx->stream, ptrs, dCh, S, 1, (const double*)dSum0, dSum1);
+    std::vector<double> hMed(nCS), hS2(nCS);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hMed.data(), dMed, nCS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hS2.data(), dSum1, nCS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    std::vector<double> haploid(nCS, 0.0), variance(nCS, 0.0), thr(nchr, 0.0);
+    int strideUb = 16;
+    for (int c = 0; c < nchr; c++) {
+        if (chroms[c].T <= 10) continue;
+        double mx = 0;
+        for (int d = 0; d < S; d++) {
+            haploid[c * S + d] = std::max(1.0, hMed[c * S + d]) / 2.0;
+            variance[c * S + d] = hS2[c * S + d] / (double)(chroms[c].T - 1);
+            mx = d == 0 ? haploid[c * S + d] : std::max(mx, haploid[c * S + d]);
+        }
+        thr[c] = mx * NSTATE;
+        if (!(thr[c] >= 0) || thr[c] > 60000) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: coverage scale outside the supported table size");
+        strideUb = std::max(strideUb, (int)std::nearbyint(thr[c]) + 11);
+    }
+    JointCombos K; genotype_combinations(S, K);
+    // ---- phase 2 inside the shared pipeline: indices, tables, per-bin maxima, host log, then Viterbi
+    WsSizer ex; ex.take<int32_t>(N); ex.take<int32_t>((size_t)S * N); ex.take<double>((size_t)NSTATE * N); ex.take<double>(nCS * NSTATE * strideUb); ex.take<double>(nchr); ex.take<int32_t>(nchr);
+    auto prepare = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom* dChroms, const int64_t* dOffDev) -> int32_t {
+        int32_t* idx = ws.take<int32_t>(N); int32_t* idxS = ws.take<int32_t>((size_t)S * N); double* dL = ws.take<double>((size_t)NSTATE * N);
+        double* dPmf = ws.take<double>(nCS * NSTATE * strideUb); double* dThr = ws.take<double>(nchr); int32_t* dMaxIdx = ws.take<int32_t>(nchr);
+        int32_t rc = canvas_h2d_small(ctx, dThr, thr.data(), nchr * 8); if (rc) return rc;
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dMaxIdx, 0, nchr * 4, ctx->stream));
+        hipLaunchKernelGGL(k_joint_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, ptrs, S, dOffDev, nchr, dThr, N, idxS, dMaxIdx);
+        std::vector<int32_t> hMax(nchr);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hMax.data(), dMaxIdx, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        int stride = 16;
+        for (int c = 0; c < nchr; c++) if (chroms[c].T > 10) stride = std::max(stride, hMax[c] + 10);
+        if (stride > strideUb) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_hmm_joint: internal table bound exceeded");
+        std::vector<double> tab(nCS * NSTATE * (size_t)stride, 0.0);
+        parallel_for((int64_t)nCS * NSTATE, 1, [&](int64_t a, int64_t b) {
+            for (int64_t i = a; i < b; i++) {
+                const int c = (int)(i / (S * NSTATE)), d = (int)((i / NSTATE) % S), CN = (int)(i % NSTATE);
+                if (chroms[c].T <= 10) continue;
+                negative_binomial_table(std::max((double)CN, 0.1) * haploid[c * S + d], variance[c * S + d], hMax[c] + 10, &tab[(size_t)i * stride]);   // HiddenMarkovModelsRunner.cs:136-147
+            }
+        });
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dPmf, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_joint_emission, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, idxS, S, dOffDev, nchr, dChroms, dPmf, stride, K, N, dL);
+        std::vector<double> hL((size_t)NSTATE * N);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hL.data(), dL, hL.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        parallel_for((int64_t)hL.size(), 1 << 16, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) hL[i] = std::log(hL[i]); });   // Math.Log(maxLikelyhood), Distributions.cs:322
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dL, hL.data(), hL.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_iota_i32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, idx, N);
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // hL / tab are local
+        P.tableLen = (int32_t)N; P.maxThreshold = 0.0;
+        const double selfTransition = 0.99;
+        for (int i = 0; i < NSTATE; i++) {
+            for (int j = 0; j < NSTATE; j++) P.logA[i][j] = std::log(i == j ? selfTransition : (1.0 - selfTransition) / (NSTATE - 1));
+            P.logPi[i] = std::log((double)(1.0f / NSTATE));
+        }
+        E.idx = idx; E.dTab = dL;
+        return CANVAS_OK;
+    };
+    return hmm_pipeline(ctx, nchr, h_chr_offset, ex.off, prepare, d_state);
+}
+
+extern "C" {
 
 int32_t canvas_segment_ids_filtered(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
                                     const int32_t* d_stop, int32_t max_inter_bin_dist, const int64_t* h_excl_offset, const int32_t* h_excl_start,

@@ -127,6 +127,12 @@ int32_t canvas_quantize_f2(canvas_ctx* ctx, const float* d_count, int64_t n, dou
  * boundaries in bins.  d_state receives the Viterbi state (CN 0..4) per bin; chromosomes with <= 10 bins are skipped
  * (state -1), as in :69.  */
 int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state);
+/* -m HMM: HiddenMarkovModelsRunner.Run with isPerSample == false (HiddenMarkovModelsRunner.cs:23-152; CanvasPartition.cs:146-158) and
+ * NegativeBinomialMixture.EstimateViterbiLikelihood over the genotype combinations (Distributions.cs:257-323,
+ * DistributionUtilities.cs:11-40): one state path for nsamples (1..16) samples that share the bins.  h_d_cov[s] = device pointer to
+ * sample s's concatenated coverage (same layout and h_chr_offset for all samples).  Emission parameters are per chromosome (median and
+ * variance of that chromosome, :117-131); chromosomes with <= 10 bins are skipped (state -1). */
+int32_t canvas_hmm_joint(canvas_ctx* ctx, int32_t nsamples, int32_t nchr, const double* const* h_d_cov, const int64_t* h_chr_offset, int32_t* d_state);
 /* breakpoints -> segments -> segment id per bin: SegmentationInput.DeriveSegments (Segmentation.cs:83-125) +
  * SegmentationResultsProcessor.PostProcessSegments (SegmentationResultsProcessor.cs:17-129, no forbidden intervals /
  * ploidy file: those stay in the host tool).  d_is_start: 1 where a segment starts at this bin. */

@@ -120,3 +120,30 @@ def test_segment_ids_with_forbidden_intervals():
     assert (seg.cpu().numpy() == np.concatenate(ids)).all()
     ids0, _ = O.postprocess(bs, be, segstarts, None, 1000000)
     assert last > _      # the forbidden zones added splits
+
+
+@pytest.mark.parametrize("nsamples,n", [(3, 30_000), (1, 12_000), (2, 20_000), (5, 9_000)])
+def test_joint_hmm_matches_oracle(nsamples, n):
+    """-m HMM (joint mode): per-chromosome emission parameters, genotype combinations over the samples (only the first four samples enter
+    the combinations, DistributionUtilities.cs:14-16), grouped 0/1 and 3/4 probabilities; chromosomes with <= 10 bins are skipped"""
+    cv = get_canvas()
+    cv.profile_enable(True)
+    nchr = 5
+    bins, cov0, off = _coverage(20260927 + 30 + nsamples, n, nchr)
+    rng = np.random.RandomState(nsamples)
+    covs = [cov0]
+    for s in range(1, nsamples):
+        scale = [1.0, 0.8, 1.3, 0.6, 1.1][s]
+        c = np.round(cov0 * scale + rng.normal(0, 4, len(cov0)), 2).clip(0)
+        if s == 1: c[off[1] + 200:off[1] + 600] *= 0.5            # a deletion only sample 1 carries
+        covs.append(np.ascontiguousarray(c))
+    covs[0] = covs[0].copy(); covs[0][off[2] + 100:off[2] + 500] *= 1.5     # a gain only sample 0 carries
+    # products of several pmf values underflow to 0 for outlying bins, Math.Log gives -inf there: such chromosomes are (correctly)
+    # handed to the sequential kernel, the others go through speculate / verify — the result must be the oracle's either way
+    got = cv.hmm_joint([to_dev(c, cv.device) for c in covs], off).cpu().numpy()
+    for c in range(nchr):
+        ran, path = O.hmm_chromosome([np.ascontiguousarray(x[off[c]:off[c + 1]]) for x in covs], per_sample=False)
+        g = got[off[c]:off[c + 1]]
+        if not ran: assert (g == -1).all()
+        else: assert (g == path).all(), (c, np.nonzero(g != path)[0][:10])
+    assert len(np.unique(got)) >= 2
