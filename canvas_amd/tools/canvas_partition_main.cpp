@@ -1,6 +1,6 @@
 // Drop-in CanvasPartition executable on top of the C ABI: CLI and file formats of CanvasPartition.Main (CanvasPartition/CanvasPartition.cs:24-190).
-//   CanvasPartition -i S.cleaned [-i ...] -o S.partitioned [-o ...] -r refDir -m PerSampleHMM|CBS [-b filter.bed] [-s None|SDUndo] [--config params.json]
-// Built methods: PerSampleHMM and CBS.  Wavelets (the reference default) / HMM (joint) / -c / -p are not built: exit code 1 with a message.
+//   CanvasPartition -i S.cleaned [-i ...] -o S.partitioned [-o ...] -r refDir -m PerSampleHMM|HMM|CBS [-b filter.bed] [-s None|Prune|SDUndo] [--config params.json]
+// Built methods: PerSampleHMM, HMM (joint) and CBS.  Wavelets (the reference default) / -c / -p are not built: exit code 1 with a message.
 #include "tool_common.hpp"
 #include <algorithm>
 #include <set>
@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     const std::string bed = a.get("bedfile");
     if (!bed.empty() && !file_exists(bed)) { printf("CanvasPartition.exe: File %s does not exist! Exiting.\n", bed.c_str()); return 1; }
     std::string method = a.get("method", "Wavelets");
-    if (method != "PerSampleHMM" && method != "CBS") { fprintf(stderr, "CanvasPartition (MI355X): method %s is not built (PerSampleHMM and CBS are)\n", method.c_str()); return 1; }
+    if (method != "PerSampleHMM" && method != "CBS" && method != "HMM") { fprintf(stderr, "CanvasPartition (MI355X): method %s is not built (PerSampleHMM, HMM and CBS are)\n", method.c_str()); return 1; }
     if (a.has("ploidyVcfFile") || a.has("commoncnvs")) { fprintf(stderr, "CanvasPartition (MI355X): -p / -c are not supported by this build\n"); return 1; }
     if (inFiles.size() != outFiles.size()) { fprintf(stderr, "CanvasPartition: the number of -o must match the number of -i\n"); return 1; }
     std::string split = a.get("split", "None");
@@ -73,7 +73,37 @@ int main(int argc, char** argv) {
     // per sample: segments per chromosome as (start, end) genomic pairs
     typedef std::vector<std::pair<uint32_t, uint32_t>> Segs;
     std::vector<std::map<std::string, Segs>> segBySample(samples.size());
-    for (size_t s = 0; s < samples.size(); s++) {
+    // SegmentationInput.DeriveSegments (Segmentation.cs:83-125) from a state path
+    auto derive = [](const Sample& S, const std::vector<int32_t>& state, std::map<std::string, Segs>& out) {
+        for (size_t c = 0; c < S.chromNames.size(); c++) {
+            int64_t b0 = S.off[c], T = S.off[c + 1] - b0;
+            if (!(T > 10)) continue;                                         // chromosome skipped: no entry in segmentByChr (HiddenMarkovModelsRunner.cs:69)
+            std::vector<int> bp = {0};
+            for (int64_t i = 1; i < T; i++) if (state[b0 + i] != state[b0 + i - 1]) bp.push_back((int)i);
+            Segs sg;
+            if (bp.size() >= 2) { for (size_t k = 0; k < bp.size(); k++) { int64_t a0 = bp[k], a1 = (k + 1 < bp.size() ? bp[k + 1] : T) - 1; sg.push_back({S.start[b0 + a0], S.end[b0 + a1]}); } }
+            else sg.push_back({S.start[b0], S.end[b0 + T - 1]});
+            out[S.chromNames[c]] = sg;
+        }
+    };
+    std::map<std::string, Segs> jointSegs;
+    if (method == "HMM") {
+        // one Viterbi path for all samples over the first sample's bins (HiddenMarkovModelsRunner.cs:51-63; CanvasPartition.cs:146-158)
+        printf("Running HMM Partitioning\n");
+        const Sample& S0 = samples[0]; const int nchr = (int)S0.chromNames.size(); const int64_t N = S0.off.back();
+        for (auto& S : samples) if (S.off != S0.off) { fprintf(stderr, "CanvasPartition: -m HMM needs the same bins in every input\n"); return 1; }
+        if (N > 0) {
+            std::vector<Dev> dCovs; dCovs.reserve(samples.size());      // no reallocation: Dev owns device memory
+            std::vector<const double*> ptrs;
+            for (auto& S : samples) { dCovs.emplace_back(ctx, N * 8); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCovs.back().p, S.cov.data(), N * 8)); }
+            for (auto& d : dCovs) ptrs.push_back(d.as<double>());
+            Dev dState(ctx, N * 4);
+            TOOL_TRY(ctx, canvas_hmm_joint(ctx, (int32_t)samples.size(), nchr, ptrs.data(), S0.off.data(), dState.as<int32_t>()));
+            std::vector<int32_t> state(N); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, state.data(), dState.p, N * 4));
+            derive(S0, state, jointSegs);
+        }
+    }
+    for (size_t s = 0; s < samples.size() && method != "HMM"; s++) {
         Sample& S = samples[s]; const int nchr = (int)S.chromNames.size(); const int64_t N = S.off.back();
         if (N == 0) continue;
         Dev dCov(ctx, N * 8); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCov.p, S.cov.data(), N * 8));
@@ -82,16 +112,7 @@ int main(int argc, char** argv) {
             Dev dState(ctx, N * 4);
             TOOL_TRY(ctx, canvas_hmm_per_sample(ctx, nchr, dCov.as<double>(), S.off.data(), dState.as<int32_t>()));
             std::vector<int32_t> state(N); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, state.data(), dState.p, N * 4));
-            for (int c = 0; c < nchr; c++) {
-                int64_t b0 = S.off[c], T = S.off[c + 1] - b0;
-                if (!(T > 10)) continue;                                     // chromosome skipped: no entry in segmentByChr (HiddenMarkovModelsRunner.cs:69)
-                std::vector<int> bp = {0};
-                for (int64_t i = 1; i < T; i++) if (state[b0 + i] != state[b0 + i - 1]) bp.push_back((int)i);
-                Segs sg;                                                      // SegmentationInput.DeriveSegments (Segmentation.cs:83-125)
-                if (bp.size() >= 2) { for (size_t k = 0; k < bp.size(); k++) { int64_t a0 = bp[k], a1 = (k + 1 < bp.size() ? bp[k + 1] : T) - 1; sg.push_back({S.start[b0 + a0], S.end[b0 + a1]}); } }
-                else sg.push_back({S.start[b0], S.end[b0 + T - 1]});
-                segBySample[s][S.chromNames[c]] = sg;
-            }
+            derive(S, state, segBySample[s]);
         } else {
             printf("Running CBS Partitioning\n");
             Dev dLen(ctx, (N + 1) * 4); std::vector<int32_t> nseg(nchr); int64_t stats[8];
@@ -107,7 +128,8 @@ int main(int argc, char** argv) {
     canvas_destroy(ctx);
     // GenomeSegmentationResults.SplitOverlappingSegments (GenomeSegmentationResults.cs:18-55)
     std::map<std::string, Segs> merged;
-    if (samples.size() == 1) merged = segBySample[0];
+    if (method == "HMM") merged = jointSegs;
+    else if (samples.size() == 1) merged = segBySample[0];
     else for (auto& kv : segBySample[0]) {
         const std::string& chrom = kv.first;
         std::vector<std::vector<uint32_t>> st(samples.size()), en(samples.size()); std::vector<const uint32_t*> ps, pe; std::vector<int32_t> ns;

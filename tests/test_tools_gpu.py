@@ -99,5 +99,26 @@ def test_canvas_clean_and_partition_executables(tmp_path):
         pos = np.concatenate([[0], np.cumsum(segl[c])[:-1]]).astype(np.int64) if len(segl[c]) else np.zeros(0, np.int64)
         segstarts.append(bs[c][pos].astype(np.uint32) if len(pos) else np.zeros(0, np.uint32))
     assert _read(part) == rows_from(segstarts)
+    # ---- -m HMM (joint) over two inputs that share the bins: one state path, every output carries its own coverage column
+    cleaned2 = str(tmp_path / "S2.cleaned")
+    cov2_all = np.array([float(O.format_f2(float(np.float32(float(r.split("\t")[3]) * 0.8 + 3.0)))) for r in exp_rows])
+    with gzip.open(cleaned2, "wt") as f:
+        for r_, v in zip(exp_rows, cov2_all):
+            c_, s_, e_, _, g_ = r_.split("\t")
+            f.write(f"{c_}\t{s_}\t{e_}\t{O.format_f2(float(np.float32(v)))}\t{g_}\n")
+    cov2 = cov2_all[keep]
+    per2 = [np.ascontiguousarray(cov2[off[c]:off[c + 1]]) for c in range(nchr)]
+    part2 = str(tmp_path / "S2.partitioned")
+    r = subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-i", cleaned2, "-o", part, "-o", part2, "-r", str(tmp_path), "-m", "HMM", "-b", bed],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    jstarts = []
+    for c in range(nchr):
+        ran_c, path_c = O.hmm_chromosome([per[c], per2[c]], per_sample=False)
+        jstarts.append(O.segments_from_path(path_c, ran_c, bs[c], be[c])[0])
+    ids, _ = O.postprocess(bs, be, jstarts, ex_list, 1000000)
+    for out_path, pc in ((part, per), (part2, per2)):
+        expj = [f"{NAMES[c]}\t{s_}\t{e_}\t{O.format_g15(float(v))}\t{i}" for c in range(nchr) for s_, e_, v, i in zip(bs[c], be[c], pc[c], ids[c])]
+        assert _read(out_path) == expj
     # Wavelets (the reference default) is not built: explicit failure, not a silent fallback
     assert subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-o", part, "-r", str(tmp_path)], capture_output=True).returncode == 1
