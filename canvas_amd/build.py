@@ -80,13 +80,13 @@ def build(force=False, verbose=False):
 
 
 def build_tools(force=False, verbose=False):
-    """drop-in tool drivers (plain C++ over the C ABI + zlib): canvas_amd/bin/CanvasClean, canvas_amd/bin/CanvasPartition"""
+    """drop-in tool drivers (plain C++ over the C ABI + zlib): canvas_amd/bin/CanvasBin, CanvasClean, CanvasPartition"""
     tdir = os.path.join(HERE, "tools")
     bdir = os.path.join(HERE, "bin")
     os.makedirs(bdir, exist_ok=True)
     tl = _torch_lib_dir()
     outs = []
-    for name, src in (("CanvasClean", "canvas_clean_main.cpp"), ("CanvasPartition", "canvas_partition_main.cpp")):
+    for name, src in (("CanvasBin", "canvas_bin_main.cpp"), ("CanvasClean", "canvas_clean_main.cpp"), ("CanvasPartition", "canvas_partition_main.cpp")):
         out = os.path.join(bdir, name)
         srcs = [os.path.join(tdir, src), os.path.join(tdir, "tool_common.hpp")]
         if force or not os.path.exists(out) or any(os.path.getmtime(x) > os.path.getmtime(out) for x in srcs + [os.path.join(HERE, "libcanvas_hip.so")]):

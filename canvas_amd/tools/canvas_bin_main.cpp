@@ -1,0 +1,294 @@
+// Drop-in CanvasBin executable on top of the C ABI: CLI of CanvasBin (CanvasBin/Program.cs:12-200) and both of its phases
+// (CanvasBin.Run, CanvasBin.cs:955-972):
+//   CanvasBin -b S.bam -r kmer.fa -c chr1 -o chr1.dat -d 100 [-f filter.bed] [-p] [-m mode]            BAM -> per-chromosome intermediate
+//   CanvasBin -b S.bam -r kmer.fa -i chr1.dat -i chr2.dat ... -o S.binned -d 100 [-z size] [-y] [-m]   intermediates -> S.binned
+// Phase 1 keeps the reference's host work (FASTA and BAM parsing; BGZF inflate through zlib) and runs the per-base array
+// preparation on the GPU (possible mask from the FASTA case, BED exclusion, hit screening).  Phase 2 is canvas_bin_sample /
+// canvas_bin_sample_gcweighted.  The intermediate file is private to these two invocations (the pipeline never opens it), so it
+// is a plain binary dump rather than protobuf-net's encoding (CanvasBin.cs:1037-1148).
+// BAM flag semantics follow the SAM specification; Isas.SequencingFiles.BamReader is not part of /root/reference (parity unpinned):
+// IsMainAlignment := neither secondary (0x100) nor supplementary (0x800).
+// Not built (exit code 1 with a message): -t manifest, -n predefined bins, -m Fragment, the multi-sample -j json mode.
+#include "tool_common.hpp"
+#include <algorithm>
+#include <memory>
+using namespace tool;
+
+// ---------------------------------------------------------------- FASTA (kmer.fa: upper case = start of a unique k-mer)
+struct FastaEntry { std::string name, bases; };
+static bool read_fasta(const std::string& path, const std::string* only, std::vector<FastaEntry>& out) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
+    std::vector<char> buf(1 << 20);
+    FastaEntry* cur = nullptr; bool keep = false;
+    std::string line;
+    auto flush_line = [&]() {
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            std::string name = line.substr(1); size_t sp = name.find_first_of(" \t"); if (sp != std::string::npos) name = name.substr(0, sp);
+            keep = !only || name == *only;
+            if (keep) { out.push_back({name, std::string()}); cur = &out.back(); } else cur = nullptr;
+        } else if (keep && cur) cur->bases += line;
+        line.clear();
+    };
+    while (fgets(buf.data(), (int)buf.size(), f)) { line += buf.data(); if (!line.empty() && line.back() == '\n') flush_line(); }
+    if (!line.empty()) flush_line();
+    fclose(f); return true;
+}
+
+// ---------------------------------------------------------------- BGZF / BAM / BAI
+struct Bgzf {
+    FILE* f = nullptr; std::vector<uint8_t> block; size_t pos = 0; int64_t blockAddr = 0; bool eof = false;
+    bool open(const std::string& p) { f = fopen(p.c_str(), "rb"); return f != nullptr; }
+    ~Bgzf() { if (f) fclose(f); }
+    bool next_block() {
+        blockAddr = ftello(f);
+        uint8_t h[18];
+        if (fread(h, 1, 18, f) != 18) { eof = true; return false; }
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
+        const int xlen = h[10] | (h[11] << 8);
+        std::vector<uint8_t> extra(xlen);
+        memcpy(extra.data(), h + 12, std::min(6, xlen));
+        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != (size_t)(xlen - 6)) return false;
+        int bsize = -1;
+        for (int i = 0; i + 4 <= xlen;) { int slen = extra[i + 2] | (extra[i + 3] << 8); if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2) bsize = extra[i + 4] | (extra[i + 5] << 8); i += 4 + slen; }
+        if (bsize < 0) return false;
+        const int clen = bsize - xlen - 19;
+        std::vector<uint8_t> comp(clen + 8);
+        if (fread(comp.data(), 1, clen + 8, f) != (size_t)(clen + 8)) return false;
+        const uint32_t isize = comp[clen + 4] | (comp[clen + 5] << 8) | (comp[clen + 6] << 16) | ((uint32_t)comp[clen + 7] << 24);
+        block.resize(isize); pos = 0;
+        if (isize == 0) return true;
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = comp.data(); zs.avail_in = clen; zs.next_out = block.data(); zs.avail_out = isize;
+        int rc = inflate(&zs, Z_FINISH); inflateEnd(&zs);
+        return rc == Z_STREAM_END;
+    }
+    bool read(void* dst, size_t n) {
+        uint8_t* d = (uint8_t*)dst;
+        while (n) {
+            if (pos >= block.size()) { do { if (!next_block()) return false; } while (block.empty()); }
+            size_t k = std::min(n, block.size() - pos); memcpy(d, block.data() + pos, k); pos += k; d += k; n -= k;
+        }
+        return true;
+    }
+    bool seek_virtual(uint64_t voff) { if (fseeko(f, (off_t)(voff >> 16), SEEK_SET) != 0) return false; if (!next_block()) return false; pos = voff & 0xFFFF; return pos <= block.size(); }
+};
+// smallest virtual offset of a chunk of reference `ref` in the .bai (BamReader.Jump(ref, 0)); 0 = the reference has no reads
+static bool bai_first_offset(const std::string& path, int ref, uint64_t& voff, bool& any) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
+    auto rd = [&](void* p, size_t n) { return fread(p, 1, n, f) == n; };
+    char magic[4]; int32_t nref;
+    if (!rd(magic, 4) || memcmp(magic, "BAI\1", 4) != 0 || !rd(&nref, 4)) { fclose(f); return false; }
+    any = false; voff = ~0ull;
+    for (int r = 0; r < nref; r++) {
+        int32_t nbin; if (!rd(&nbin, 4)) break;
+        for (int b = 0; b < nbin; b++) {
+            uint32_t bin; int32_t nchunk; if (!rd(&bin, 4) || !rd(&nchunk, 4)) { fclose(f); return false; }
+            for (int c = 0; c < nchunk; c++) { uint64_t cb, ce; if (!rd(&cb, 8) || !rd(&ce, 8)) { fclose(f); return false; } if (r == ref && bin != 37450) { any = true; voff = std::min(voff, cb); } }
+        }
+        int32_t nintv; if (!rd(&nintv, 4)) break;
+        if (fseeko(f, (off_t)nintv * 8, SEEK_CUR) != 0) break;
+        if (r == ref) break;
+    }
+    fclose(f); return true;
+}
+
+// LoadObservedAlignmentsBAM (CanvasBin.cs:207-275)
+static int load_bam(const std::string& bam, bool pairedEnd, const std::string& chrom, int mode, std::vector<uint8_t>& hits, std::vector<int16_t>& frag) {
+    if (!file_exists(bam + ".bai")) { fprintf(stderr, "Fatal error: Bam index not found at %s.bai\n", bam.c_str()); return 1; }
+    Bgzf z; if (!z.open(bam)) return 1;
+    char magic[4]; int32_t ltext, nref;
+    if (!z.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0 || !z.read(&ltext, 4)) { fprintf(stderr, "CanvasBin: %s is not a BAM file\n", bam.c_str()); return 1; }
+    { std::vector<char> t(ltext); if (ltext && !z.read(t.data(), ltext)) return 1; }
+    if (!z.read(&nref, 4)) return 1;
+    int desired = -1;
+    for (int r = 0; r < nref; r++) { int32_t ln; if (!z.read(&ln, 4)) return 1; std::vector<char> nm(ln); int32_t lref; if (!z.read(nm.data(), ln) || !z.read(&lref, 4)) return 1; if (chrom == nm.data()) desired = r; }
+    if (desired < 0) { fprintf(stderr, "Unable to retrieve the reference sequence index for %s in %s.\n", chrom.c_str(), bam.c_str()); return 1; }
+    uint64_t voff; bool any;
+    if (!bai_first_offset(bam + ".bai", desired, voff, any)) { fprintf(stderr, "CanvasBin: cannot read %s.bai\n", bam.c_str()); return 1; }
+    if (!any) return 0;                                   // no reads for this chromosome: not an error (:231-235)
+    if (!z.seek_virtual(voff)) return 1;
+    long readCount = 0, kept = 0;
+    std::vector<uint8_t> rec;
+    for (;;) {
+        int32_t bs; if (!z.read(&bs, 4)) break;
+        rec.resize(bs); if (!z.read(rec.data(), bs)) break;
+        readCount++;
+        int32_t refID, pos, lseq, tlen; uint8_t lname; uint16_t ncig, flag;
+        memcpy(&refID, &rec[0], 4); memcpy(&pos, &rec[4], 4); lname = rec[8]; memcpy(&ncig, &rec[12], 2); memcpy(&flag, &rec[14], 2); memcpy(&lseq, &rec[16], 4); memcpy(&tlen, &rec[28], 4);
+        (void)lseq;
+        if (flag & 0x4) continue;                          // !IsMapped
+        if (flag & 0x200) continue;                        // IsFailedQC
+        if (flag & 0x400) continue;                        // IsDuplicate
+        if (flag & 0x10) continue;                         // IsReverseStrand
+        if (flag & 0x900) continue;                        // !IsMainAlignment
+        if (ncig == 0) continue;
+        uint32_t c0; memcpy(&c0, &rec[32 + lname], 4);
+        if ((c0 & 0xF) != 0 || (c0 >> 4) < 35) continue;   // must start with 35 bases of 'M'
+        if (pairedEnd && !(flag & 0x2)) continue;          // IsProperPair
+        if (refID != desired) break;
+        if (refID == -1) continue;
+        kept++;
+        if (pos < 0 || (size_t)pos >= hits.size()) continue;   // the reference would throw IndexOutOfRange
+        if (mode == CANVAS_MODE_BINARY) hits[pos] = 1; else hits[pos] = hits[pos] == 255 ? 255 : (uint8_t)(hits[pos] + 1);
+        if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) frag[pos] = (int16_t)std::max(std::min(32767, tlen), 0);
+    }
+    printf("Kept %ld of %ld total reads\n", kept, readCount);
+    return 0;
+}
+
+// ---------------------------------------------------------------- intermediate file
+struct Inter { std::string name; int64_t len = 0; std::vector<uint8_t> mask, hits; std::vector<int16_t> frag; };
+static bool write_inter(const std::string& path, const Inter& d) {
+    FILE* f = fopen(path.c_str(), "wb"); if (!f) return false;
+    const char magic[12] = "CANVASDAT2\n"; fwrite(magic, 1, 12, f);
+    uint32_t ln = (uint32_t)d.name.size(); fwrite(&ln, 4, 1, f); fwrite(d.name.data(), 1, ln, f);
+    fwrite(&d.len, 8, 1, f);
+    uint64_t nm = d.mask.size(), nh = d.hits.size(), nf = d.frag.size();
+    fwrite(&nm, 8, 1, f); fwrite(d.mask.data(), 1, nm, f); fwrite(&nh, 8, 1, f); fwrite(d.hits.data(), 1, nh, f); fwrite(&nf, 8, 1, f); fwrite(d.frag.data(), 2, nf, f);
+    bool ok = !ferror(f); fclose(f); return ok;
+}
+static bool read_inter(const std::string& path, Inter& d) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
+    char magic[12]; uint32_t ln; uint64_t nm, nh, nf; bool ok = false;
+    do {
+        if (fread(magic, 1, 12, f) != 12 || memcmp(magic, "CANVASDAT2\n", 12) != 0) break;
+        if (fread(&ln, 4, 1, f) != 1 || ln > 4096) break;
+        d.name.resize(ln); if (fread(&d.name[0], 1, ln, f) != ln) break;
+        if (fread(&d.len, 8, 1, f) != 1) break;
+        if (fread(&nm, 8, 1, f) != 1) break; d.mask.resize(nm); if (fread(d.mask.data(), 1, nm, f) != nm) break;
+        if (fread(&nh, 8, 1, f) != 1) break; d.hits.resize(nh); if (fread(d.hits.data(), 1, nh, f) != nh) break;
+        if (fread(&nf, 8, 1, f) != 1) break; d.frag.resize(nf); if (nf && fread(d.frag.data(), 2, nf, f) != nf) break;
+        ok = true;
+    } while (0);
+    fclose(f); return ok;
+}
+
+static int parse_mode(const std::string& m) {       // Utilities.ParseCanvasCoverageMode (CanvasCommon/Utilities.cs:56-74)
+    std::string s; for (char c : m) if (c != ' ' && c != '\t') s.push_back((char)tolower(c));
+    if (s == "0" || s == "binary") return CANVAS_MODE_BINARY;
+    if (s == "3" || s == "truncateddynamicrange") return CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE;
+    if (s == "5" || s == "gccontentweighted") return CANVAS_MODE_GC_CONTENT_WEIGHTED;
+    if (s == "fragment") return -2;
+    return -1;
+}
+
+int main(int argc, char** argv) {
+    printf(">>>Command-line arguments:\n"); for (int i = 1; i < argc; i++) printf("%s ", argv[i]); printf("\n");
+    std::vector<Opt> opts = {{"b", "bam", true}, {"r", "reference", true}, {"c", "chr", true}, {"i", "infile", true}, {"f", "filter", true}, {"d", "bindepth", true}, {"z", "binsize", true},
+                             {"o", "outfile", true}, {"y", "binsizeonly", false}, {"h", "help", false}, {"p", "paired-end", false}, {"m", "mode", true}, {"t", "manifest", true}, {"n", "bins", true}, {"j", "injson", true}};
+    Parsed a = parse(argc, argv, opts);
+    printf("CanvasBin %s (MI355X)\n", canvas_version());
+    if (!a.extra.empty()) { fprintf(stderr, "Unknown arguments: %s\n", a.extra[0].c_str()); return 2; }
+    int mode = CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE;
+    if (a.has("mode")) { mode = parse_mode(a.get("mode")); if (mode == -1) { fprintf(stderr, "Invalid canvas coverage mode '%s'\n", a.get("mode").c_str()); return 2; } }
+    const std::string ref = a.get("reference"), out = a.get("outfile"), chrom = a.get("chr"), bam = a.get("bam"), filter = a.get("filter");
+    auto inters = a.all("infile");
+    const int countsPerBin = a.has("bindepth") ? atoi(a.get("bindepth").c_str()) : -1;
+    int binSize = a.has("binsize") ? atoi(a.get("binsize").c_str()) : -1;
+    bool needHelp = a.has("help");
+    // required arguments (Program.cs:108-133)
+    if (ref.empty()) { fprintf(stderr, "Please specify the Canvas k-uniqueness reference file.\n"); needHelp = true; }
+    else if (out.empty()) { fprintf(stderr, "Please specify an output file name.\n"); needHelp = true; }
+    else if (mode != -2 && countsPerBin == -1) { fprintf(stderr, "Please specify counts per bin.\n"); needHelp = true; }
+    else if (mode != -2 && chrom.empty() && inters.empty() && !a.has("injson")) { fprintf(stderr, "Please specify chromsome to measure coverage for.\n"); needHelp = true; }
+    if (needHelp) { printf("Usage: CanvasBin.exe [OPTIONS]+\nBin alignments into variable-sized genomic intervals.\n\nOptions:\n  -b, --bam=VALUE  -r, --reference=VALUE  -c, --chr=VALUE  -i, --infile=VALUE (repeatable)  -f, --filter=VALUE\n"
+                           "  -d, --bindepth=VALUE  -z, --binsize=VALUE  -o, --outfile=VALUE  -y, --binsizeonly  -p, --paired-end  -m, --mode=VALUE  -t, --manifest=VALUE  -n, --bins=VALUE  -h, --help\n"); return 1; }
+    if (!file_exists(ref)) { printf("CanvasBin.exe: File %s does not exist! Exiting.\n", ref.c_str()); return 1; }
+    if (bam.empty() || !file_exists(bam)) { printf("CanvasBin.exe: Alignment input does not exist! Exiting.\n"); return 1; }       // also required in -i mode (:148-153)
+    if (!filter.empty() && !file_exists(filter)) { printf("CanvasBin.exe: File %s does not exist! Exiting.\n", filter.c_str()); return 1; }
+    if (mode != -2 && countsPerBin < 1) { printf("CanvasBin.exe: Median counts must be strictly positive. Exiting.\n"); return 1; }
+    if (mode == -2 || a.has("manifest") || a.has("bins") || a.has("injson")) { fprintf(stderr, "CanvasBin (MI355X): Fragment mode / -t / -n / -j are not built\n"); return 1; }
+
+    canvas_ctx* ctx = canvas_create(0);
+    if (!ctx) { fprintf(stderr, "CanvasBin (MI355X): no usable GPU (this build has no CPU fallback)\n"); return 1; }
+    struct CtxGuard { canvas_ctx* c; ~CtxGuard() { canvas_destroy(c); } } guard{ctx};
+
+    if (inters.empty()) {
+        // ---- phase 1: CalculateSampleHits / BinOneGenomicInterval (CanvasBin.cs:765-792)
+        std::vector<FastaEntry> fa;
+        if (!read_fasta(ref, &chrom, fa) || fa.empty()) { fprintf(stderr, "CanvasBin: chromosome %s not found in %s\n", chrom.c_str(), ref.c_str()); return 1; }
+        Inter d; d.name = chrom; d.len = (int64_t)fa[0].bases.size();
+        const int64_t L = d.len, words = (L + 63) / 64;
+        d.hits.assign(L, 0); if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) d.frag.assign(L, 0);
+        printf("Initialized alignment arrays\n");
+        if (int rc = load_bam(bam, a.has("paired-end"), chrom, mode, d.hits, d.frag)) return rc;
+        printf("Loaded observed alignments\n");
+        if (L > 0) {
+            Dev dBases(ctx, L), dHits(ctx, L), dMask(ctx, words * 8);
+            TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dBases.p, fa[0].bases.data(), L));
+            TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dHits.p, d.hits.data(), L));
+            TOOL_TRY(ctx, canvas_mask_from_fasta(ctx, dBases.as<uint8_t>(), L, dMask.as<uint64_t>()));
+            if (!filter.empty()) {
+                std::map<std::string, std::vector<std::pair<int, int>>> bed; load_bed(filter, bed);
+                auto it = bed.find(chrom);
+                if (it != bed.end()) { std::vector<int32_t> s, e; for (auto& iv : it->second) { s.push_back(iv.first); e.push_back(iv.second); }
+                    TOOL_TRY(ctx, canvas_mask_exclude_intervals(ctx, dMask.as<uint64_t>(), L, (int32_t)s.size(), s.data(), e.data())); }
+            }
+            TOOL_TRY(ctx, canvas_screen_hits(ctx, dHits.as<uint8_t>(), dMask.as<uint64_t>(), L));
+            std::vector<uint64_t> mw(words);
+            TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, mw.data(), dMask.p, words * 8));
+            TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, d.hits.data(), dHits.p, L));
+            d.mask.resize((L + 7) / 8); memcpy(d.mask.data(), mw.data(), d.mask.size());
+        }
+        if (!write_inter(out, d)) { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
+        printf("Intermediate observedAlignments serialized\n");
+        return 0;
+    }
+
+    // ---- phase 2: RunSingleSample (CanvasBin.cs:914-931)
+    std::map<std::string, std::unique_ptr<Inter>> byChrom;
+    for (auto& p : inters) {
+        if (!file_exists(p)) { fprintf(stderr, "CanvasBin: intermediate file %s does not exist\n", p.c_str()); return 1; }
+        auto d = std::make_unique<Inter>();
+        if (!read_inter(p, *d)) { fprintf(stderr, "CanvasBin: %s is not an intermediate file of this CanvasBin\n", p.c_str()); return 1; }
+        std::string nm = d->name; byChrom[nm] = std::move(d);
+    }
+    std::vector<FastaEntry> fa;
+    if (!read_fasta(ref, nullptr, fa)) return 1;
+    // chromosomes in FASTA order that have an intermediate (CanvasBin.cs:506-540)
+    std::vector<const FastaEntry*> order; std::vector<Inter*> data;
+    for (auto& e : fa) { auto it = byChrom.find(e.name); if (it == byChrom.end()) continue; if ((int64_t)e.bases.size() != it->second->len) { fprintf(stderr, "CanvasBin: length of %s differs between the reference and the intermediate file\n", e.name.c_str()); return 1; } order.push_back(&e); data.push_back(it->second.get()); }
+    const int nchr = (int)order.size();
+    if (nchr == 0) { fprintf(stderr, "CanvasBin: no chromosome to bin\n"); return 1; }
+    std::vector<std::unique_ptr<Dev>> devs;
+    std::vector<const uint8_t*> pBases(nchr), pHits(nchr); std::vector<const uint64_t*> pMask(nchr); std::vector<const int16_t*> pFrag(nchr); std::vector<int64_t> len(nchr); std::vector<uint8_t> isAuto(nchr);
+    for (int c = 0; c < nchr; c++) {
+        const int64_t L = data[c]->len, words = (L + 63) / 64; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
+        auto up = [&](const void* src, int64_t bytes, int64_t alloc) -> void* { devs.push_back(std::make_unique<Dev>(ctx, alloc)); void* p = devs.back()->p; if (bytes > 0 && canvas_memcpy_h2d(ctx, p, src, bytes) != 0) return nullptr; return p; };
+        std::vector<uint8_t> mw((size_t)words * 8, 0); memcpy(mw.data(), data[c]->mask.data(), std::min(mw.size(), data[c]->mask.size()));
+        pBases[c] = (const uint8_t*)up(order[c]->bases.data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits.data(), L, L + 64); pMask[c] = (const uint64_t*)up(mw.data(), words * 8, words * 8 + 64);
+        if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { if ((int64_t)data[c]->frag.size() != L) { fprintf(stderr, "CanvasBin: %s has no fragment lengths (was the intermediate written with -m GCContentWeighted?)\n", order[c]->name.c_str()); return 1; } pFrag[c] = (const int16_t*)up(data[c]->frag.data(), L * 2, L * 2 + 64); }
+        if (!pBases[c] || !pHits[c] || !pMask[c]) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
+    }
+    if (a.has("binsizeonly") || binSize == -1) {
+        // CalculateSingleSampleBinSize: autosomes only (CanvasBin.cs:30-83)
+        std::vector<int64_t> obs(nchr), poss(nchr); std::vector<double> rate(nchr), rates;
+        TOOL_TRY(ctx, canvas_bin_rates(ctx, nchr, pHits.data(), pMask.data(), len.data(), obs.data(), poss.data(), rate.data()));
+        for (int c = 0; c < nchr; c++) if (isAuto[c]) rates.push_back(rate[c]);
+        if (binSize == -1) { if (rates.empty()) { fprintf(stderr, "CanvasBin: no autosome to derive the bin size from\n"); return 1; } binSize = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), countsPerBin); }
+    }
+    if (a.has("binsizeonly")) { FILE* f = fopen((out + ".binsize").c_str(), "wb"); if (!f) return 1; fprintf(f, "%d", binSize); fclose(f); return 0; }   // :926-928, no newline
+    if (binSize <= 0) { fprintf(stderr, "CanvasBin: bin size %d is not positive\n", binSize); return 1; }
+    const int64_t cap = canvas_bin_count_upper_bound(nchr, len.data(), binSize);
+    Dev dChr(ctx, cap * 4 + 4), dStart(ctx, cap * 4 + 4), dStop(ctx, cap * 4 + 4), dGc(ctx, cap * 4 + 4), dCount(ctx, cap * 4 + 4);
+    std::vector<int64_t> perChr(nchr); int64_t total = 0; int32_t used = 0;
+    if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED)
+        TOOL_TRY(ctx, canvas_bin_sample_gcweighted(ctx, nchr, pBases.data(), pMask.data(), pHits.data(), pFrag.data(), len.data(), isAuto.data(), countsPerBin, binSize,
+                                                   dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total));
+    else
+        TOOL_TRY(ctx, canvas_bin_sample(ctx, nchr, pBases.data(), pMask.data(), pHits.data(), len.data(), isAuto.data(), countsPerBin, binSize, mode,
+                                        dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total));
+    std::vector<int32_t> hChr(total), hStart(total), hStop(total), hGc(total); std::vector<float> hCount(total);
+    if (total > 0) {
+        TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hChr.data(), dChr.p, total * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hStart.data(), dStart.p, total * 4));
+        TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hStop.data(), dStop.p, total * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hGc.data(), dGc.p, total * 4));
+        TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hCount.data(), dCount.p, total * 4));
+    }
+    GzWriter wr(out); if (!wr.ok()) { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
+    for (int64_t i = 0; i < total; i++)                                        // CanvasIO.WriteToTextFile (CanvasCommon/IO.cs:15-24)
+        wr.line(order[hChr[i]]->name + "\t" + std::to_string(hStart[i]) + "\t" + std::to_string(hStop[i]) + "\t" + format_f2(hCount[i]) + "\t" + std::to_string(hGc[i]));
+    printf("Output complete\n");
+    return 0;
+}
