@@ -732,6 +732,100 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     return CANVAS_OK;
 }
 
+// ---------------------------------------------------------------- pedigree: bins present in every sample's cleaned list
+// Utilities.MergeMultiSampleCleanedBedFile (CanvasCommon/Utilities.cs:834-920) + CanvasRunner.NormalizeCanvasClean (CanvasRunner.cs:883-903):
+// bins are keyed by (chromosome, start); a bin survives when every sample has it ("if outlier is removed in one sample, remove it in
+// all samples"), its stop is the one read last (the last sample's), its counts are the samples' counts in input order, and the output
+// follows the first sample's order.  Every sample's list is sorted by (chromosome index, start) — CanvasBin / CanvasClean order — so the
+// lookup is a binary search; unsorted input is rejected.
+struct MergePtrs { const int32_t* chr[16]; const int32_t* start[16]; const int32_t* stop[16]; const float* count[16]; float* outCount[16]; long long n[16]; };
+__device__ __forceinline__ unsigned long long merge_key(const int32_t* chr, const int32_t* start, long long i) { return ((unsigned long long)(uint32_t)chr[i] << 32) | (uint32_t)start[i]; }
+__global__ void __launch_bounds__(256) k_merge_check_sorted(MergePtrs P, int nsamples, int* __restrict__ bad) {
+    const int s = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nsamples || i + 1 >= P.n[s]) return;
+    if (P.chr[s][i] < 0 || P.start[s][i] < 0 || merge_key(P.chr[s], P.start[s], i) >= merge_key(P.chr[s], P.start[s], i + 1)) *bad = 1;
+}
+__global__ void __launch_bounds__(256) k_merge_find(MergePtrs P, int nsamples, uint8_t* __restrict__ flags, int32_t* __restrict__ where /* [nsamples][n0] */) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n0 = P.n[0];
+    if (i >= n0) return;
+    const unsigned long long key = merge_key(P.chr[0], P.start[0], i);
+    bool all = true;
+    for (int s = 1; s < nsamples; s++) {
+        long long lo = 0, hi = P.n[s];
+        while (lo < hi) { long long mid = (lo + hi) >> 1; if (merge_key(P.chr[s], P.start[s], mid) < key) lo = mid + 1; else hi = mid; }
+        const bool hit = lo < P.n[s] && merge_key(P.chr[s], P.start[s], lo) == key;
+        where[(size_t)s * n0 + i] = hit ? (int32_t)lo : -1;
+        all = all && hit;
+    }
+    flags[i] = all ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_merge_scatter(MergePtrs P, int nsamples, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, const int32_t* __restrict__ where,
+                                                       int32_t* __restrict__ oChr, int32_t* __restrict__ oStart, int32_t* __restrict__ oStop) {
+    __shared__ uint32_t sh[4];
+    const long long n0 = P.n[0];
+    const long long base = (long long)blockIdx.x * CBLK;
+    uint32_t running = blockOff[blockIdx.x];
+    for (int j = 0; j < CBLK / 256; j++) {
+        const long long i = base + j * 256 + threadIdx.x;
+        const uint32_t f = (i < n0) ? flags[i] : 0;
+        const uint32_t inc = wave_inclusive_scan_u32(f);
+        if (lane_id() == 63) sh[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) woff += sh[k]; tot += sh[k]; }
+        if (f) {
+            const uint32_t d = running + woff + inc - 1;
+            oChr[d] = P.chr[0][i]; oStart[d] = P.start[0][i];
+            const long long last = nsamples > 1 ? (long long)where[(size_t)(nsamples - 1) * n0 + i] : i;
+            oStop[d] = P.stop[nsamples - 1][last];
+            P.outCount[0][d] = P.count[0][i];
+            for (int s = 1; s < nsamples; s++) P.outCount[s][d] = P.count[s][where[(size_t)s * n0 + i]];
+        }
+        running += tot;
+        __syncthreads();
+    }
+}
+extern "C" int32_t canvas_merge_cleaned(canvas_ctx* ctx, int32_t nsamples, const int64_t* h_n, const int32_t* const* h_d_chr, const int32_t* const* h_d_start,
+                                        const int32_t* const* h_d_stop, const float* const* h_d_count, int32_t* d_out_chr, int32_t* d_out_start, int32_t* d_out_stop,
+                                        float* const* h_d_out_count, int64_t* h_n_out) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nsamples <= 0 || nsamples > 16 || !h_n || !h_d_chr || !h_d_start || !h_d_stop || !h_d_count || !d_out_chr || !d_out_start || !d_out_stop || !h_d_out_count || !h_n_out)
+        CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_merge_cleaned: bad arguments (1..16 samples)");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    MergePtrs P; memset(&P, 0, sizeof P);
+    int64_t nmax = 0;
+    for (int s = 0; s < nsamples; s++) {
+        if (h_n[s] < 0 || h_n[s] > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_merge_cleaned: bin count out of range");
+        P.chr[s] = h_d_chr[s]; P.start[s] = h_d_start[s]; P.stop[s] = h_d_stop[s]; P.count[s] = h_d_count[s]; P.outCount[s] = h_d_out_count[s]; P.n[s] = h_n[s];
+        nmax = std::max(nmax, h_n[s]);
+    }
+    const int64_t n0 = h_n[0];
+    *h_n_out = 0;
+    if (n0 == 0) return CANVAS_OK;
+    const int nb = (int)nblk(n0, CBLK);
+    WsSizer sz; sz.take<uint8_t>(n0); sz.take<int32_t>((size_t)nsamples * n0); sz.take<uint32_t>(nb + 2); sz.take<unsigned long long>(1); sz.take<int>(1);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
+    WsCarver ws(ctx->ws);
+    uint8_t* flags = ws.take<uint8_t>(n0); int32_t* where = ws.take<int32_t>((size_t)nsamples * n0); uint32_t* blockCnt = ws.take<uint32_t>(nb + 2);
+    unsigned long long* dTotal = ws.take<unsigned long long>(1); int* dBad = ws.take<int>(1);
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_merge_check_sorted, dim3(nblk(nmax, 256), nsamples), dim3(256), 0, ctx->stream, P, nsamples, dBad);
+    hipLaunchKernelGGL(k_merge_find, dim3(nblk(n0, 256)), dim3(256), 0, ctx->stream, P, nsamples, flags, where);
+    hipLaunchKernelGGL(k_block_count, dim3(nb), dim3(256), 0, ctx->stream, flags, n0, blockCnt);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, blockCnt, nb, dTotal);
+    hipLaunchKernelGGL(k_merge_scatter, dim3(nb), dim3(256), 0, ctx->stream, P, nsamples, flags, blockCnt, where, d_out_chr, d_out_start, d_out_stop);
+    unsigned long long tot = 0; int bad = 0;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&tot, dTotal, 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    if (bad) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_merge_cleaned: every sample must be sorted by (chromosome index, start) without duplicates");
+    *h_n_out = (int64_t)tot;
+    return CANVAS_OK;
+}
+
 // ---------------------------------------------------------------- "{count:F2}" text hand-off in memory (IO.cs:21 -> CanvasSegment.cs:1146)
 // Exact integer arithmetic: float = m * 2^e; 7 significant decimal digits (ties-to-even on the exact value, as the oracle's
 // correctly rounded printf), then half-up on the decimal digits at 2 decimals, then N/100 as a correctly rounded double

@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
-    "canvas_clean", "canvas_clean2", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo",
+    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -203,6 +203,20 @@ class Canvas:
                                            C.c_void_p(bins["stop"].data_ptr()), C.c_void_p(bins["count"].data_ptr()), C.c_void_p(bins["gc"].data_ptr()),
                                            len(ia), _np_ptr(ia), _np_ptr(iy), C.c_uint32(flags), min_bins_per_gc, C.byref(lsd), C.byref(nout), _np_ptr(info)))
         return nout.value, lsd.value, info
+
+    def merge_cleaned(self, samples, ns):
+        """MergeMultiSampleCleanedBedFile (Utilities.cs:834-920): bins every sample still has.  samples = list of SoA dicts (chr, start, stop,
+        count), ns = bins per sample.  Returns (chr, start, stop, [count per sample], n_out)."""
+        torch = self.torch
+        S = len(samples); n0 = int(ns[0])
+        oc = torch.empty(max(n0, 1), dtype=torch.int32, device=self.device); os_ = torch.empty_like(oc); oe = torch.empty_like(oc)
+        ocnt = [torch.empty(max(n0, 1), dtype=torch.float32, device=self.device) for _ in range(S)]
+        arr = lambda key: (C.c_void_p * S)(*[C.c_void_p(s[key].data_ptr()) for s in samples])
+        hn = np.ascontiguousarray(ns, np.int64); nout = C.c_int64(0)
+        self._check(self.lib.canvas_merge_cleaned(self.ctx, S, _np_ptr(hn), arr("chr"), arr("start"), arr("stop"), arr("count"), C.c_void_p(oc.data_ptr()),
+                                                  C.c_void_p(os_.data_ptr()), C.c_void_p(oe.data_ptr()), (C.c_void_p * S)(*[C.c_void_p(t.data_ptr()) for t in ocnt]), C.byref(nout)))
+        k = nout.value
+        return oc[:k], os_[:k], oe[:k], [t[:k] for t in ocnt], k
 
     def quantize_f2(self, count, n, out=None):
         """count.ToString("F2") -> Convert.ToDouble (IO.cs:21 -> CanvasSegment.cs:1146), in memory"""

@@ -112,6 +112,13 @@ int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_star
 int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
                       int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags,
                       int32_t min_bins_per_gc, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
+/* Pedigree workflows: Utilities.MergeMultiSampleCleanedBedFile + CanvasRunner.NormalizeCanvasClean (CanvasCommon/Utilities.cs:834-920,
+ * CanvasRunner.cs:883-903): keep the bins (keyed by chromosome and start) that every sample's cleaned list still has.  Inputs: per
+ * sample the SoA of CanvasClean (sorted by chromosome index, then start).  Outputs: one bin list in the first sample's order (stop taken
+ * from the last sample) and, per sample, the counts of the surviving bins (h_d_out_count[s], capacity h_n[0]). */
+int32_t canvas_merge_cleaned(canvas_ctx* ctx, int32_t nsamples, const int64_t* h_n, const int32_t* const* h_d_chr, const int32_t* const* h_d_start,
+                             const int32_t* const* h_d_stop, const float* const* h_d_count, int32_t* d_out_chr, int32_t* d_out_start, int32_t* d_out_stop,
+                             float* const* h_d_out_count, int64_t* h_n_out);
 /* bins are grouped by chromosome in file order: h_chr_offset[c] = index of the first bin of chromosome c (nchr+1 entries,
  * h_chr_offset[nchr] = n); chromosomes without bins get an empty range.  Chromosome indices must be non-decreasing. */
 int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_chr, int64_t n, int32_t nchr, int64_t* h_chr_offset);

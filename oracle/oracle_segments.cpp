@@ -239,6 +239,35 @@ int orc_changepoints_prune(const double* x, int n, const int32_t* lengthSeg, int
     for (size_t i = 0; i < r.size() && (int)i < cap; i++) out[i] = r[i];
     return (int)r.size();
 }
+// Utilities.MergeMultiSampleCleanedBedFile (CanvasCommon/Utilities.cs:834-920) on SoA inputs (chromosome as an index): chromosomes in
+// the order the HashSet first saw them, bins of a chromosome in the order their start first appeared (Dictionary enumeration order
+// without removals), kept when every file contributed a count; stop = the value read last.  Returns the number of merged bins;
+// outCount is [nsamples][cap].
+int64_t orc_merge_cleaned(int nsamples, const int64_t* n, const int32_t* const* chr, const int32_t* const* start, const int32_t* const* stop, const float* const* count,
+                          int32_t* outChr, int32_t* outStart, int32_t* outStop, float* const* outCount, int64_t cap) {
+    std::vector<int32_t> chromOrder; std::map<int32_t, int> chromIndex;
+    for (int s = 0; s < nsamples; s++) for (int64_t i = 0; i < n[s]; i++) if (!chromIndex.count(chr[s][i])) { chromIndex[chr[s][i]] = (int)chromOrder.size(); chromOrder.push_back(chr[s][i]); }
+    struct Entry { int32_t stop; std::vector<float> counts; };
+    std::vector<std::vector<int32_t>> keyOrder(chromOrder.size());
+    std::vector<std::map<int32_t, Entry>> byPos(chromOrder.size());
+    for (int s = 0; s < nsamples; s++)
+        for (int64_t i = 0; i < n[s]; i++) {
+            int ci = chromIndex[chr[s][i]]; int32_t pos = start[s][i];
+            auto it = byPos[ci].find(pos);
+            if (it == byPos[ci].end()) { keyOrder[ci].push_back(pos); it = byPos[ci].insert({pos, Entry{}}).first; }
+            it->second.stop = stop[s][i];
+            it->second.counts.push_back(count[s][i]);
+        }
+    int64_t k = 0;
+    for (size_t ci = 0; ci < chromOrder.size(); ci++)
+        for (int32_t pos : keyOrder[ci]) {
+            const Entry& e = byPos[ci][pos];
+            if ((int)e.counts.size() < nsamples) continue;
+            if (k < cap) { outChr[k] = chromOrder[ci]; outStart[k] = pos; outStop[k] = e.stop; for (int s = 0; s < nsamples; s++) outCount[s][k] = e.counts[s]; }
+            k++;
+        }
+    return k;
+}
 void orc_sort_keys_items(double* keys, int* items, int n) { dotnet_sort_keys_items(keys, items, 0, n, n); }
 
 }  // extern "C"

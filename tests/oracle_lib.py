@@ -118,6 +118,19 @@ def clean(chr_id, start, stop, count, gc, is_auto, is_y, flags, min_bins_weighte
     return dict(chr=chr_id[:n], start=start[:n], stop=stop[:n], count=count[:n], gc=gc[:n], local_sd=local_sd.value, stages=stages)
 
 
+def merge_cleaned(samples):
+    """Utilities.MergeMultiSampleCleanedBedFile (Utilities.cs:834-920); samples = list of dicts with chr/start/stop/count arrays"""
+    S = len(samples)
+    n = np.array([len(s["chr"]) for s in samples], np.int64)
+    cap = int(n.sum()) + 1
+    chrs = [np.ascontiguousarray(s["chr"], np.int32) for s in samples]; st = [np.ascontiguousarray(s["start"], np.int32) for s in samples]
+    en = [np.ascontiguousarray(s["stop"], np.int32) for s in samples]; cnt = [np.ascontiguousarray(s["count"], np.float32) for s in samples]
+    oc = np.zeros(cap, np.int32); os_ = np.zeros(cap, np.int32); oe = np.zeros(cap, np.int32); ocnt = [np.zeros(cap, np.float32) for _ in range(S)]
+    lib.orc_merge_cleaned.restype = C.c_int64
+    k = lib.orc_merge_cleaned(S, _p(n), _pp(chrs), _pp(st), _pp(en), _pp(cnt), _p(oc), _p(os_), _p(oe), _pp(ocnt), C.c_int64(cap))
+    return oc[:k].copy(), os_[:k].copy(), oe[:k].copy(), [c[:k].copy() for c in ocnt]
+
+
 def _fmt(fn, v):
     buf = C.create_string_buffer(64)
     fn(v, buf, 64)

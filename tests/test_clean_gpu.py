@@ -145,3 +145,33 @@ def test_clean_loess_mode_within_tolerance():
     rel = np.abs(got - ex) / np.maximum(np.abs(ex), 1e-12)
     assert rel[ex > 0].max() < 1e-5, rel.max()
     assert ((ex == 0) == (got == 0)).all()
+
+
+def test_merge_cleaned_keeps_bins_present_in_every_sample():
+    """pedigree step between CanvasClean and CanvasPartition (Utilities.cs:834-920, CanvasRunner.cs:883-903)"""
+    cv = get_canvas()
+    base = synth.generate_bins(20260927 + 40, 50_000, nchr=8)
+    rng = np.random.RandomState(4)
+    samples = []
+    for s in range(3):
+        keep = rng.rand(len(base["chr"])) > (0.03 + 0.02 * s)           # every sample's Clean dropped different bins
+        if s == 1: keep[base["chr"] == 5] = False                       # one chromosome missing entirely in one sample
+        d = {k: v[keep].copy() for k, v in base.items()}
+        d["count"] = (d["count"] * (1 + 0.1 * s) + s).astype(np.float32)
+        if s == 2: d["stop"] = d["stop"] + 1                            # the stop read last wins
+        samples.append(d)
+    ec, es, ee, ecnt = O.merge_cleaned(samples)
+    dev = [{k: to_dev(v, cv.device) for k, v in d.items()} for d in samples]
+    oc, os_, oe, ocnt, k = cv.merge_cleaned(dev, [len(d["chr"]) for d in samples])
+    assert k == len(ec) and 0 < k < len(samples[0]["chr"])
+    assert (oc.cpu().numpy() == ec).all() and (os_.cpu().numpy() == es).all() and (oe.cpu().numpy() == ee).all()
+    for a, b in zip(ocnt, ecnt):
+        assert (a.cpu().numpy().view(np.uint32) == b.view(np.uint32)).all()
+    # single sample: identity; unsorted input: rejected
+    oc1, os1, oe1, ocnt1, k1 = cv.merge_cleaned(dev[:1], [len(samples[0]["chr"])])
+    assert k1 == len(samples[0]["chr"]) and (os1.cpu().numpy() == samples[0]["start"]).all()
+    bad = {k: v.clone() for k, v in dev[1].items()}
+    bad["start"][10], bad["start"][11] = bad["start"][11].clone(), bad["start"][10].clone()
+    from canvas_amd.lib import CanvasError
+    with pytest.raises(CanvasError):
+        cv.merge_cleaned([dev[0], bad], [len(samples[0]["chr"]), len(samples[1]["chr"])])
