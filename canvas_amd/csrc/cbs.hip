@@ -11,7 +11,9 @@
 //     The reference's sqrt(n)-block pruning is lossless, so the exhaustive maximum is the same double; the arg-max is
 //     the reference's as long as the maximising arc is unique, which the host verifies per call — on an exact floating-point tie it
 //     replays the reference's block order on the host (rare).
-//   * Permutation reference distribution (XPerm + HTMaxP/TMaxP): host in this round (next: device engine).
+//   * Permutation reference distribution of the hybrid test (XPerm + HTMaxP, segments of >= 1024 bins): device engine below, in
+//     batches, with the sequential stopping rule and the generator hand-over on the host.  TMaxP (n <= 200) and short hybrid
+//     segments stay on the host.
 #include "common.hpp"
 #include <algorithm>
 #include <atomic>
@@ -19,6 +21,8 @@
 #include <limits>
 #include <mutex>
 #include <thread>
+#include <chrono>
+#include <condition_variable>
 
 // ================================================================================================ device: exhaustive arc search
 // For every arc length L in [1, n-1] (arc = pair i < j = i + L of 0-based prefix-sum indices): dmax[L] = max_i |sx[i+L] - sx[i]|,
@@ -57,6 +61,186 @@ __global__ void __launch_bounds__(ARC_THREADS) k_arc_search(const double* __rest
     }
 }
 
+// ================================================================================================ device: permutation reference distribution
+// XPerm (ChangePoint.cs:407-421) + HTMaxP (CBSTStatistic.cs:354-586) for a batch of B permutations of one segment.
+//
+//  k_mt_draws    MT19937 continues the chromosome's generator on the device: one workgroup regenerates the 624-word state in three
+//                data-parallel phases per twist and emits B*n tempered draws in order; the generator state after every permutation is
+//                snapshotted so that the host can resume exactly where the sequential stopping rule ends.
+//  k_perm_stat   one workgroup per permutation.  The Fisher-Yates chain "for i = n-1..0: swap(px[i], px[j_i])" is evaluated without
+//                replaying it: position i is final after step i and receives what position j_i held just before; a position q is
+//                only modified by the steps that target it, so with list[q] = steps with j = q (ascending),
+//                    final[s_k] = R(s_{k+1})  (x[q] for the largest step of the list),   R(i) = R(g(i)),  g(i) = min{s in list[i] : s > i}
+//                (R(i) = x[i] when no such step exists).  Lists are built with a counting sort, g-chains are resolved by pointer
+//                doubling: exact integer logic, the permutation IS the reference's.
+//                The statistic is the maximum over arcs of length al0..k (and their complements) of c_j * (sx[b]-sx[a])^2; the
+//                reference's block pruning is lossless, so the exhaustive maximum is the same set.  Prefix sums are
+//                re-associated here, so every statistic is returned as an interval [lo, hi] from a worst-case rounding bound; the
+//                host re-evaluates a permutation in the reference's exact order only when the observed statistic falls inside it.
+#define PG_T 512
+#define PG_MAXK 32
+struct PermBuf { uint32_t* draws; int32_t* j; int32_t* off; int32_t* cur; int32_t* items; int32_t* g; int32_t* succ; double* px; double* sx; };
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) { y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18; return y; }
+// one request = one batch of permutations of one segment; a launch serves the requests of all chromosome threads that are waiting
+struct PermReq {
+    const uint32_t* state; long long total; int n; int nb; uint32_t* snaps; const double* x; int hk, al0; double tss, errBound; PermBuf P; double* pstat; int blockBase;
+};
+__global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs) {
+    __shared__ uint32_t mtA[624], mtB[624];
+    const PermReq R = reqs[blockIdx.x];
+    const uint32_t* __restrict__ state = R.state; uint32_t* __restrict__ draws = R.P.draws; uint32_t* __restrict__ snaps = R.snaps;
+    const long long total = R.total; const int n = R.n;
+    const int tid = threadIdx.x;
+    uint32_t* cur = mtA; uint32_t* nxt = mtB;
+    for (int i = tid; i < 624; i += 256) cur[i] = state[i];
+    __syncthreads();
+    int mti = (int)state[624];
+    long long produced = 0, boundary = n; long long bidx = 0;      // next permutation boundary (in draws) and its index
+    while (produced < total) {
+        if (mti >= 624) {
+            // three data-parallel phases into the second buffer: one barrier per phase instead of read / barrier / write / barrier
+            auto mix = [&](uint32_t a, uint32_t b2, uint32_t src) { const uint32_t y = (a & 0x80000000u) | (b2 & 0x7fffffffu); return src ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); };
+            if (tid < 227) nxt[tid] = mix(cur[tid], cur[tid + 1], cur[tid + 397]);
+            __syncthreads();
+            if (tid < 227) nxt[227 + tid] = mix(cur[227 + tid], cur[228 + tid], nxt[tid]);
+            __syncthreads();
+            if (tid < 169) nxt[454 + tid] = mix(cur[454 + tid], cur[455 + tid], nxt[227 + tid]);
+            __syncthreads();
+            if (tid == 0) nxt[623] = mix(cur[623], nxt[0], nxt[396]);
+            __syncthreads();
+            uint32_t* t = cur; cur = nxt; nxt = t;
+            mti = 0;
+        }
+        const long long left = total - produced;
+        const int take = (int)(left < 624 - mti ? left : 624 - mti);
+        for (int t = tid; t < take; t += 256) draws[produced + t] = mt_temper(cur[mti + t]);
+        // generator state at every permutation boundary inside this stretch
+        while (boundary <= produced + take) {
+            uint32_t* sdst = snaps + (size_t)bidx * 625;
+            for (int i = tid; i < 624; i += 256) sdst[i] = cur[i];
+            if (tid == 0) sdst[624] = (uint32_t)(mti + (int)(boundary - produced));
+            boundary += n; bidx++;
+        }
+        produced += take; mti += take;
+    }
+}
+__device__ __forceinline__ int block_excl_scan_i32(int v, int* sh /*PG_T/64 + 1*/, int& total) {
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d); if ((threadIdx.x & 63) >= d) inc += o; }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) sh[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < PG_T / 64; i++) { const int t = sh[i]; if (i < w) base += t; tot += t; }
+    total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+__global__ void __launch_bounds__(PG_T) k_perm_stat(const PermReq* __restrict__ reqs, int nreq) {
+    __shared__ int shI[PG_T / 64 + 1];
+    __shared__ double shD[PG_T / 64 + 1];
+    __shared__ double shM[PG_MAXK + 1][PG_T / 64];
+    int ri = 0;
+    { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
+    const PermReq R = reqs[ri];
+    const double* __restrict__ x = R.x; const int n = R.n, hk = R.hk, al0 = R.al0; const double tss = R.tss, errBound = R.errBound; const PermBuf P = R.P; double* __restrict__ pstat = R.pstat;
+    const int b = (int)blockIdx.x - R.blockBase, tid = threadIdx.x;
+    const size_t o = (size_t)b * n, o1 = (size_t)b * (n + 1);
+    const uint32_t* __restrict__ draws = P.draws + o;
+    int32_t* __restrict__ jj = P.j + o; int32_t* __restrict__ off = P.off + o1; int32_t* __restrict__ cur = P.cur + o1; int32_t* __restrict__ items = P.items + o;
+    int32_t* __restrict__ g = P.g + o; int32_t* __restrict__ succ = P.succ + o; double* __restrict__ px = P.px + o; double* __restrict__ sx = P.sx + o;
+    for (int i = tid; i <= n; i += PG_T) off[i] = 0;
+    __syncthreads();
+    // Fisher-Yates targets: draws are consumed in the order i = n-1, n-2, ..., 0 (ChangePoint.cs:411-419)
+    for (int i = tid; i < n; i += PG_T) {
+        const double cc = (double)draws[n - 1 - i] * (1.0 / 4294967296.0);
+        int t = (int)(cc * (double)(i + 1)); t = t > i ? i : t;
+        jj[i] = t; atomicAdd(&off[t], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the list sizes -> list offsets (off) and fill cursors (cur)
+    int carry = 0;
+    for (int base = 0; base <= n; base += PG_T) {
+        const int i = base + tid; const int v = i <= n ? off[i] : 0; int tot;
+        const int ex = block_excl_scan_i32(v, shI, tot);
+        if (i <= n) { off[i] = carry + ex; cur[i] = carry + ex; }
+        carry += tot;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += PG_T) { const int pos = atomicAdd(&cur[jj[i]], 1); items[pos] = i; }
+    __syncthreads();
+    // successor of every step inside its target's list; g(q) = first step > q that targets q (q itself when there is none)
+    for (int i = tid; i < n; i += PG_T) {
+        { const int q = jj[i]; int s = 0x7fffffff; for (int t = off[q]; t < off[q + 1]; t++) { const int v = items[t]; if (v > i && v < s) s = v; } succ[i] = s; }
+        { int s = 0x7fffffff; for (int t = off[i]; t < off[i + 1]; t++) { const int v = items[t]; if (v > i && v < s) s = v; } g[i] = s == 0x7fffffff ? i : s; }
+    }
+    __syncthreads();
+    // pointer doubling g <- g o g until stable (chains run towards larger indices and end in a fixed point); cur is the second buffer
+    int32_t* ga = g; int32_t* gb = cur;
+    for (int round = 0; round < 32; round++) {
+        int changed = 0;
+        for (int i = tid; i < n; i += PG_T) { const int a = ga[i]; const int t = ga[a]; gb[i] = t; changed |= (t != a); }
+        int32_t* tmp = ga; ga = gb; gb = tmp;
+        if (!__syncthreads_or(changed)) break;
+    }
+    // the permuted data
+    for (int i = tid; i < n; i += PG_T) { const int s = succ[i]; px[i] = s == 0x7fffffff ? x[jj[i]] : x[ga[s]]; }
+    __syncthreads();
+    // prefix sums (re-associated)
+    double dcarry = 0.0;
+    for (int base = 0; base < n; base += PG_T) {
+        const int i = base + tid; const double v = i < n ? px[i] : 0.0;
+        double inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const double oo = __hiloint2double(__shfl_up(__double2hiint(inc), d), __shfl_up(__double2loint(inc), d)); if ((tid & 63) >= d) inc += oo; }
+        const int w = tid >> 6;
+        if ((tid & 63) == 63) shD[w] = inc;
+        __syncthreads();
+        double wb = 0.0, tot = 0.0;
+        for (int k = 0; k < PG_T / 64; k++) { const double t = shD[k]; if (k < w) wb += t; tot += t; }
+        if (i < n) sx[i] = dcarry + wb + inc;
+        dcarry += tot;
+        __syncthreads();
+    }
+    // arcs of length al0..hk: |sx[a+j] - sx[a]|, and their complements |sx[a+n-j] - sx[a]| for a < j
+    double m[PG_MAXK + 1];
+#pragma unroll
+    for (int j = 0; j <= PG_MAXK; j++) m[j] = 0.0;
+    for (int a = tid; a < n; a += PG_T) {
+        const double s0 = sx[a];
+#pragma unroll
+        for (int j = 2; j <= PG_MAXK; j++) {
+            if (j >= al0 && j <= hk) {
+                if (a + j < n) { const double d = fabs(sx[a + j] - s0); m[j] = d > m[j] ? d : m[j]; }
+                if (a < j) { const double d = fabs(sx[a + n - j] - s0); m[j] = d > m[j] ? d : m[j]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 2; j <= PG_MAXK; j++) {
+        double v = m[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double oo = __hiloint2double(__shfl_xor(__double2hiint(v), d), __shfl_xor(__double2loint(v), d)); v = oo > v ? oo : v; }
+        if ((tid & 63) == 0) shM[j][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double rn = (double)n;
+        double hLo = 0.0, hHi = 0.0;
+        for (int j = al0; j <= hk && j <= PG_MAXK; j++) {
+            double v = 0.0; for (int k = 0; k < PG_T / 64; k++) v = shM[j][k] > v ? shM[j][k] : v;
+            const double rj = (double)j, c = rn / (rj * (rn - rj));
+            const double lo = v - errBound > 0.0 ? v - errBound : 0.0, hi = v + errBound;
+            const double a = c * (lo * lo) * (1.0 - 1e-15), bb = c * (hi * hi) * (1.0 + 1e-15);
+            hLo = a > hLo ? a : hLo; hHi = bb > hHi ? bb : hHi;
+        }
+        auto norm = [&](double h) { double t = tss; if (t <= h + 0.0001) t = h + 1.0; return h / ((t - h) / (rn - 2.0)); };   // CBSTStatistic.cs:334-337
+        if ((tss <= hLo + 0.0001) != (tss <= hHi + 0.0001)) { pstat[2 * b] = -INFINITY; pstat[2 * b + 1] = INFINITY; }          // the clamp is not monotone across its switch: let the host decide
+        else { pstat[2 * b] = norm(hLo) * (1.0 - 1e-15); pstat[2 * b + 1] = norm(hHi) * (1.0 + 1e-15); }
+    }
+}
+
 // ================================================================================================ host: scalar pieces of the reference
 namespace cbs {
 
@@ -81,6 +265,8 @@ struct MT {
         return y;
     }
     double next_double() { return u32() * (1.0 / 4294967296.0); }
+    void get_state(uint32_t* s625) const { memcpy(s625, mt, sizeof mt); s625[624] = (uint32_t)mti; }
+    void set_state(const uint32_t* s625) { memcpy(mt, s625, sizeof mt); mti = (int)s625[624]; }
     int32_t next_full_range_int32() { uint32_t v = 0; for (int b = 0; b < 4; b++) v |= (uint32_t)(u32() % 256u) << (8 * b); return (int32_t)v; }
 };
 
@@ -324,7 +510,7 @@ static double htmaxp_host(int k, double tss, const double* px, int n, double* sx
     return normalise(h, tss, rn);
 }
 
-struct Stats { std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
+struct Stats { std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
 
 // GPU arc search service shared by the chromosome threads
 struct ArcGpu {
@@ -413,10 +599,151 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
     for (int i = n - 1; i >= 0; i--) { double cc = rnd.next_double(); int j = (int)(cc * (i + 1)); j = j > i ? i : j; std::swap(px[i], px[j]); }
 }
 
+// ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
+#define PERM_GPU_MIN_N 1024          // shorter segments stay on the host (a permutation there is a few microseconds)
+#define PERM_TARGET_ELEMS (2 << 20)  // permuted elements per batch
+struct PermService;
+struct PermGpu {
+    canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr; char* buf = nullptr; size_t bytes = 0; char* pin = nullptr; size_t pinBytes = 0;
+    int32_t ensure(size_t need, size_t needPin) {
+        if (!stream) { CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device)); CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
+        if (need > bytes) { if (buf) CANVAS_HIP_TRY(ctx, hipFree(buf)); buf = nullptr; bytes = 0; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&buf, need)); bytes = need; }
+        if (needPin > pinBytes) { if (pin) CANVAS_HIP_TRY(ctx, hipHostFree(pin)); pin = nullptr; pinBytes = 0; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, needPin, hipHostMallocDefault)); pinBytes = needPin; }
+        return CANVAS_OK;
+    }
+    ~PermGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (buf) (void)hipFree(buf); if (pin) (void)hipHostFree(pin); }
+};
+// All chromosome threads hand their batches to ONE launcher thread: whatever is waiting goes into a single k_mt_draws launch (one
+// workgroup per request: the generator is sequential per chromosome, the chromosomes are not) and a single k_perm_stat launch (one
+// workgroup per permutation of every request).  Concurrency then does not depend on how many hardware queues the runtime maps the
+// per-thread streams to.
+struct PermHostReq { PermReq r; double* hStat; uint32_t* hSnaps; bool done = false; int32_t rc = CANVAS_OK; };
+struct PermService {
+    canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 64;
+    std::mutex mu; std::condition_variable cvWork, cvDone; std::vector<PermHostReq*> pending; bool stop = false; std::thread th; std::string err;
+    explicit PermService(canvas_ctx* c) : ctx(c) { th = std::thread([this]() { run(); }); }
+    ~PermService() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cvWork.notify_all(); th.join();
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dReqs) (void)hipFree(dReqs); if (hReqs) (void)hipHostFree(hReqs); }
+    int32_t submit(PermHostReq& q) {
+        std::unique_lock<std::mutex> lk(mu);
+        pending.push_back(&q);
+        cvWork.notify_one();
+        cvDone.wait(lk, [&]() { return q.done; });
+        if (q.rc) ctx->err = err;
+        return q.rc;
+    }
+    int32_t launch(std::vector<PermHostReq*>& batch) {
+        CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (!stream) {
+            CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dReqs, cap * sizeof(PermReq)));
+            CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hReqs, cap * sizeof(PermReq), hipHostMallocDefault));
+        }
+        const int R = (int)batch.size();
+        int blocks = 0;
+        for (int i = 0; i < R; i++) { batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; }
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs);
+        hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
+        for (int i = 0; i < R; i++) {
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hStat, batch[i]->r.pstat, (size_t)batch[i]->r.nb * 16, hipMemcpyDeviceToHost, stream));
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hSnaps, batch[i]->r.snaps, (size_t)batch[i]->r.nb * 625 * 4, hipMemcpyDeviceToHost, stream));
+        }
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        return CANVAS_OK;
+    }
+    void run() {
+        for (;;) {
+            std::vector<PermHostReq*> batch;
+            { std::unique_lock<std::mutex> lk(mu); cvWork.wait(lk, [&]() { return stop || !pending.empty(); }); if (pending.empty()) return;
+              while (!pending.empty() && (int)batch.size() < cap) { batch.push_back(pending.front()); pending.erase(pending.begin()); } }
+            std::string saved = ctx->err;
+            int32_t rc = launch(batch);
+            { std::lock_guard<std::mutex> lk(mu); if (rc) { err = ctx->err; ctx->err = saved; } for (auto* q : batch) { q->rc = rc; q->done = true; } }
+            cvDone.notify_all();
+        }
+    }
+};
+// The sequential stopping rule of FindChangePoints (ChangePoint.cs:337-364) over permutations evaluated in device batches.
+// Returns through `outcome`: 0 = not significant (nrej > nrejc), 1 = continue to the edge tests.  rnd ends exactly where the reference's would.
+static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int hk, int al0, double ostat, int nrejc, int k,
+                             const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st, int& outcome) {
+    canvas_ctx* ctx = PG.ctx;
+    const int maxB = (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n));
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t e = (size_t)maxB * n, e1 = (size_t)maxB * (n + 1);
+    const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)maxB * 625 * 4), oDraws = oStat + al((size_t)maxB * 16),
+                 oJ = oDraws + al(e * 4), oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
+                 oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
+    const size_t pState = 0, pSnaps = al(625 * 4), pStat = pSnaps + al((size_t)maxB * 625 * 4), pinTotal = pStat + al((size_t)maxB * 16);
+    int32_t rc = PG.ensure(total, pinTotal); if (rc) return rc;
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    char* d = PG.buf; char* h = PG.pin;
+    double* dX = (double*)(d + oX); uint32_t* dState = (uint32_t*)(d + oState); uint32_t* dSnaps = (uint32_t*)(d + oSnaps); double* dStat = (double*)(d + oStat);
+    PermBuf P; P.draws = (uint32_t*)(d + oDraws); P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
+    P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx);
+    uint32_t* hState = (uint32_t*)(h + pState); uint32_t* hSnaps = (uint32_t*)(h + pSnaps); double* hStat = (double*)(h + pStat);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dX, gd, (size_t)n * 8, hipMemcpyHostToDevice, PG.stream));
+    // worst-case rounding bound of a prefix-sum difference: both orders of summation are within gamma_n * sum|x| of the exact sum
+    double absSum = 0.0; for (int i = 0; i < n; i++) absSum += std::fabs(gd[i]);
+    const double errBound = 4.04 * (double)(n + 8) * 1.1102230246251565e-16 * absSum;
+    std::vector<double> px, sx;
+    uint32_t cur[625]; rnd.get_state(cur);
+    int nrej = 0; uint32_t np = 0;
+    int B = std::min(maxB, 64);
+    outcome = 1;
+    while (np < nPerm) {
+        const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
+        memcpy(hState, cur, sizeof cur);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dState, hState, sizeof cur, hipMemcpyHostToDevice, PG.stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(PG.stream));        // x and the generator state are on the device before the launcher thread takes over
+        PermHostReq q;
+        q.r.state = dState; q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
+        q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
+        rc = PG.svc->submit(q); if (rc) return rc;
+        st.dev_batches++;
+        if (getenv("CANVAS_CBS_TEST_VERIFY")) {      // test hook: every device interval must contain the statistic computed in the reference's order
+            for (int b = 0; b < nb; b++) {
+                MT m2(0u); m2.set_state(b == 0 ? cur : hSnaps + (size_t)(b - 1) * 625);
+                px.resize(n); sx.resize(n);
+                xperm(gd, px.data(), n, m2);
+                const double exact = htmaxp_host(hk, tss, px.data(), n, sx.data(), al0);
+                uint32_t after[625]; m2.get_state(after);
+                st.verified++;
+                if (!(hStat[2 * b] <= exact && exact <= hStat[2 * b + 1]) || memcmp(after, hSnaps + (size_t)b * 625, sizeof after) != 0 ||
+                    !(hStat[2 * b + 1] - hStat[2 * b] <= 1e-6 * std::fabs(exact) + 1e-300)) st.violations++;
+            }
+        }
+        for (int b = 0; b < nb; b++) {
+            np++;
+            st.perms++; st.perm_elems += n; st.dev_perms++;
+            bool rej;
+            const double lo = hStat[2 * b], hi = hStat[2 * b + 1];
+            if (ostat <= lo) rej = true;
+            else if (ostat > hi) rej = false;
+            else {      // inside the rounding interval: this permutation again, in the reference's order of operations
+                MT m2(0u); m2.set_state(b == 0 ? cur : hSnaps + (size_t)(b - 1) * 625);
+                px.resize(n); sx.resize(n);
+                xperm(gd, px.data(), n, m2);
+                rej = ostat <= htmaxp_host(hk, tss, px.data(), n, sx.data(), al0);
+                st.exact_rechecks++;
+            }
+            if (rej) { nrej++; k++; }
+            if (nrej > nrejc) { rnd.set_state(hSnaps + (size_t)b * 625); outcome = 0; return CANVAS_OK; }
+            if (np >= sbdry[k - 1]) { rnd.set_state(hSnaps + (size_t)b * 625); return CANVAS_OK; }
+        }
+        memcpy(cur, hSnaps + (size_t)(nb - 1) * 625, sizeof cur);
+        B = std::min(maxB, B * 2);
+    }
+    rnd.set_state(cur);
+    return CANVAS_OK;
+}
+
 #define CBS_GPU_MIN_N 4096
 
 // ChangePoint.FindChangePoints (ChangePoint.cs:291-400)
-static int32_t find_change_points(ArcGpu& G, const double* gd, int n, double tss, uint32_t nPerm, double cutoff, int& nCp, int iCp[2], bool hybrid, int al0, int hk,
+static int32_t find_change_points(ArcGpu& G, PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, double cutoff, int& nCp, int iCp[2], bool hybrid, int al0, int hk,
                                   double delta, const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st) {
     std::vector<double> px(n), sx(n);
     int iseg[2]; double ostat; int nrej = 0; nCp = 0;
@@ -440,6 +767,15 @@ static int32_t find_change_points(ArcGpu& G, const double* gd, int n, double tss
             nrejc = (int)((cutoff - p1) * nPerm);
         } else nrejc = (int)(cutoff * nPerm);
         k = nrejc * (nrejc + 1) / 2 + 1;
+        auto t0 = std::chrono::steady_clock::now();
+        struct Acc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } };
+        if (hybrid && n >= PERM_GPU_MIN_N && hk <= PG_MAXK && getenv("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr) {
+            Acc acc{st.ns_dev, t0};
+            int outcome = 1;
+            int32_t rc = perm_loop_gpu(PG, gd, n, tss, nPerm, hk, al0, ostat, nrejc, k, sbdry, rnd, st, outcome); if (rc) return rc;
+            if (outcome == 0) return CANVAS_OK;
+        } else {
+        Acc acc{st.ns_hostperm, t0};
         for (uint32_t np = 1; np <= nPerm; np++) {
             xperm(gd, px.data(), n, rnd);
             double pstat = hybrid ? htmaxp_host(hk, tss, px.data(), n, sx.data(), al0) : tmaxp_host(tss, px.data(), n, sx.data(), al0);
@@ -447,6 +783,7 @@ static int32_t find_change_points(ArcGpu& G, const double* gd, int n, double tss
             if (ostat <= pstat) { nrej++; k++; }
             if (nrej > nrejc) return CANVAS_OK;
             if (np >= sbdry[k - 1]) break;
+        }
         }
     } else st.big_t++;
     if (iseg[1] == n) { nCp = 1; iCp[0] = iseg[0]; }
@@ -461,7 +798,7 @@ static int32_t find_change_points(ArcGpu& G, const double* gd, int n, double tss
 }
 
 // ChangePoint.ChangePoints (ChangePoint.cs:44-153), undo = None
-static int32_t change_points(ArcGpu& G, const double* gd, int n, const std::vector<uint32_t>& sbdry, MT& rnd, double alpha, uint32_t nPerm, std::vector<int>& lengthSeg, Stats& st) {
+static int32_t change_points(ArcGpu& G, PermGpu& PG, const double* gd, int n, const std::vector<uint32_t>& sbdry, MT& rnd, double alpha, uint32_t nPerm, std::vector<int>& lengthSeg, Stats& st) {
     const int minWidth = 2, kMax = 25; const uint32_t nMin = 200;
     std::vector<int> segEnd = {0, n}, changeLoc;
     int k = 2, nCp = 0, iCp[2] = {0, 0};
@@ -479,7 +816,7 @@ static int32_t change_points(ArcGpu& G, const double* gd, int n, const std::vect
                 double avg = sum / cn;
                 for (double& v : cur) v -= avg;
                 double tss = 0.0; for (double v : cur) tss += 1.0 * v * v;
-                int32_t rc = find_change_points(G, cur.data(), cn, tss, nPerm, alpha, nCp, iCp, hybrid, minWidth, kMax, delta, sbdry, rnd, st); if (rc) return rc;
+                int32_t rc = find_change_points(G, PG, cur.data(), cn, tss, nPerm, alpha, nCp, iCp, hybrid, minWidth, kMax, delta, sbdry, rnd, st); if (rc) return rc;
             }
         } else nCp = 0;
         if (nCp == 0) changeLoc.push_back(segEnd[k - 1]);
@@ -597,6 +934,15 @@ static int32_t prune(const double* gd, int n, std::vector<int>& lengthSeg, doubl
 
 }  // namespace cbs
 
+// device-engine counters of the last canvas_cbs call: permutations evaluated on the device / on the host, permutations re-evaluated in
+// the reference's exact order because the observed statistic fell inside the rounding interval, device batches; with the test hook
+// CANVAS_CBS_TEST_VERIFY=1 also [4] intervals checked against the exact statistic and [5] violations (must be 0)
+extern "C" int32_t canvas_cbs_device_stats(canvas_ctx* ctx, int64_t* h_out6) {
+    if (!ctx || !h_out6) return CANVAS_ERR_INVALID;
+    for (int i = 0; i < 6; i++) h_out6[i] = ctx->cbs_dev[i];
+    return CANVAS_OK;
+}
+
 extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                                    int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
 extern "C" int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
@@ -630,13 +976,15 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     std::vector<int32_t> rcs(nchr, 0);
     std::vector<std::string> errs(nchr);
     std::atomic_int next{0};
+    cbs::PermService service(ctx);
     auto work = [&]() {
+        cbs::PermGpu PG; PG.ctx = ctx; PG.svc = &service;         // per thread: own buffers, created on first use
         for (;;) {
             int c = next++; if (c >= nchr) break;
             int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);
             if (n <= 0) continue;
             cbs::MT rnd((uint32_t)seeds[c]);
-            rcs[c] = cbs::change_points(G, cov.data() + h_chr_offset[c], n, sbdry, rnd, alpha, nperm, segs[c], st);
+            rcs[c] = cbs::change_points(G, PG, cov.data() + h_chr_offset[c], n, sbdry, rnd, alpha, nperm, segs[c], st);
             if (rcs[c] == 0 && undo == 2) cbs::sd_undo(cov.data() + h_chr_offset[c], segs[c], trimmedSD, undo_sd);
             if (rcs[c] == 0 && undo == 1 && segs[c].size() > 1) rcs[c] = cbs::prune(cov.data() + h_chr_offset[c], n, segs[c], 0.05, errs[c]);   // undoPrune = 0.05 (CBSRunner.cs:42)
         }
@@ -651,6 +999,8 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     for (int c = 0; c < nchr; c++) { h_nseg[c] = (int32_t)segs[c].size(); for (size_t i = 0; i < segs[c].size(); i++) flat[h_chr_offset[c] + i] = segs[c][i]; }
     if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_seg_len, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
+    if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: device permutation loop %.3f, host permutation loop %.3f\n", st.ns_dev.load() * 1e-9, st.ns_hostperm.load() * 1e-9);
     if (h_stats) { h_stats[0] = st.tmaxo_calls; h_stats[1] = st.tmaxo_elems; h_stats[2] = st.perms; h_stats[3] = st.perm_elems; h_stats[4] = st.tpermp_draws; h_stats[5] = st.tailp_exits; h_stats[6] = st.gpu_searches; h_stats[7] = st.tie_replays; }
     return CANVAS_OK;
 }

@@ -32,6 +32,7 @@ struct canvas_ctx {
     char* misc_pin = nullptr; size_t misc_off = 0;
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
+    long long cbs_dev[6] = {0, 0, 0, 0, 0, 0};   // counters of the device permutation engine (canvas_cbs_device_stats)
     int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
     // profiling: hipEvent pairs around named kernels
     bool prof = false;

@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
-    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo",
+    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -241,6 +241,12 @@ class Canvas:
         state = out[:int(off[-1])] if out is not None else torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
         self._check(self.lib.canvas_hmm_per_sample(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_void_p(state.data_ptr())))
         return state
+
+    def cbs_device_stats(self):
+        """[device permutations, host permutations, exact re-evaluations, device batches, verified, violations] of the last cbs() call"""
+        out = np.zeros(6, np.int64)
+        self._check(self.lib.canvas_cbs_device_stats(self.ctx, _np_ptr(out)))
+        return out
 
     def hmm_joint(self, covs, chr_offset, out=None):
         """-m HMM: joint Viterbi over several samples (HiddenMarkovModelsRunner.Run(isPerSample=false), Distributions.cs:257-323)"""

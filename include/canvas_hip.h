@@ -166,6 +166,12 @@ int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int
 int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                         int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
 
+/* counters of the device permutation engine for the last canvas_cbs / canvas_cbs_undo call: [0] permutations evaluated on the device
+ * (XPerm + HTMaxP, CBSTStatistic.cs:354-586), [1] on the host (segments shorter than 1024 bins, TMaxP), [2] device permutations that
+ * were re-evaluated in the reference's exact order because the observed statistic fell inside the rounding interval, [3] batches,
+ * [4]/[5] test hook CANVAS_CBS_TEST_VERIFY=1: device intervals checked against the exact statistic / violations. */
+int32_t canvas_cbs_device_stats(canvas_ctx* ctx, int64_t* h_out6);
+
 /* ---- multi-GPU (one process per GPU; chromosomes sharded across ranks) ------------------------------------------ */
 int32_t canvas_comm_unique_id(void* h_id128);  /* ncclGetUniqueId, 128 bytes, rank 0 */
 int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const void* h_id128);

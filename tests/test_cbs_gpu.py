@@ -86,3 +86,30 @@ def test_cbs_prune_drops_unsupported_change_points():
     s1, e1 = _run(cv, cov, off, nperm=2000, undo=1)
     assert sum(len(e) for e in e1) <= sum(len(e) for e in e0)
     assert any(len(a) != len(b) for a, b in zip(e0, e1)) or all(len(a) <= 2 for a in e0)
+
+
+def test_cbs_device_permutation_engine(monkeypatch):
+    """XPerm + HTMaxP on the device (batches, generator continued on the device, sequential stopping rule on the host): same segments and
+    the same RNG consumption as the oracle; with the test hook every device interval is checked against the statistic computed in the
+    reference's order (it must contain it, be tight, and the generator snapshot must equal the host generator's state)."""
+    cv = get_canvas()
+    rng = np.random.RandomState(23)
+    parts = []
+    for c in range(4):
+        n = 9000 + 4000 * c
+        x = rng.normal(100, 12, n)
+        x[n // 3:] += 0.5 + 0.15 * c                 # weak whole-arm shifts: t is between 0.1 and 7 on segments of thousands of bins,
+        x[2 * n // 3:] -= 0.4                         # so the hybrid permutation test has to decide
+        parts.append(np.round(x, 2))
+    cov = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    monkeypatch.setenv("CANVAS_CBS_TEST_VERIFY", "1")
+    stats, exp = _run(cv, cov, off, nperm=10000)
+    d = cv.cbs_device_stats()
+    assert d[0] > 500 and d[4] >= d[0] and d[5] == 0, d      # the hook also checks the permutations of a batch that lie behind the stopping point
+    monkeypatch.delenv("CANVAS_CBS_TEST_VERIFY")
+    monkeypatch.setenv("CANVAS_CBS_HOST_PERMUTATIONS", "1")
+    stats2, exp2 = _run(cv, cov, off, nperm=10000)
+    d2 = cv.cbs_device_stats()
+    assert d2[0] == 0 and d2[1] == stats2[2]
+    assert [int(v) for v in stats[:5]] == [int(v) for v in stats2[:5]]
