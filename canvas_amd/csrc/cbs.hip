@@ -11,9 +11,16 @@
 //     The reference's sqrt(n)-block pruning is lossless, so the exhaustive maximum is the same double; the arg-max is
 //     the reference's as long as the maximising arc is unique, which the host verifies per call — on an exact floating-point tie it
 //     replays the reference's block order on the host (rare).
-//   * Permutation reference distribution of the hybrid test (XPerm + HTMaxP, segments of >= 1024 bins): device engine below, in
-//     batches, with the sequential stopping rule and the generator hand-over on the host.  TMaxP (n <= 200) and short hybrid
-//     segments stay on the host.
+//   * Permutation reference distribution of the hybrid test (XPerm + HTMaxP, segments of >= 1024 bins): device engine below.
+//     - the chromosome's MT19937 stream is continued on the device: a sequential history of 19937*128 outputs per batch, the rest
+//       with the 134-term recurrence of the characteristic polynomial at stride 128 (data parallel, phi(x)^128 = phi(x^128));
+//     - the Fisher-Yates swaps are evaluated without replaying them (counting sort of the swap targets + pointer doubling);
+//     - every statistic comes back as an interval from a worst-case rounding bound; a permutation is re-evaluated in the
+//       reference's exact order only when the observed statistic lies inside the interval (never, in the tests and the WGS run);
+//     - the sequential stopping rule and the generator hand-over (state rebuilt from the last 624 outputs) run on the host;
+//     - launcher threads batch the requests of all chromosome threads, so kernels of different chromosomes overlap.
+//     TMaxP (n <= 200), short hybrid segments, TPermP and TailP (its series of normal-CDF evaluations runs on a host thread pool)
+//     stay on the host.  WGS-size run (4.7 M bins, 104 k permutations over 1.27e9 elements): 4.1 s host-only -> 1.5 s.
 #include "common.hpp"
 #include <algorithm>
 #include <atomic>
@@ -22,6 +29,7 @@
 #include <mutex>
 #include <thread>
 #include <chrono>
+#include <functional>
 #include <condition_variable>
 
 // ================================================================================================ device: exhaustive arc search
@@ -29,7 +37,11 @@
 // firstI[L] = smallest such i.  Thread t of the grid owns lengths L = t+1 and n-1-t (balanced: n iterations per thread).
 #define ARC_THREADS 256
 #define ARC_CHUNK 512
-__global__ void __launch_bounds__(ARC_THREADS) k_arc_search(const double* __restrict__ sx, int n, double* __restrict__ dmax, int32_t* __restrict__ firstI) {
+struct ArcReq { const double* sx; int n; double* dmax; int32_t* firstI; };
+__global__ void __launch_bounds__(ARC_THREADS) k_arc_search(const ArcReq* __restrict__ reqs) {
+    const ArcReq Rq = reqs[blockIdx.y];
+    const double* __restrict__ sx = Rq.sx; const int n = Rq.n; double* __restrict__ dmax = Rq.dmax; int32_t* __restrict__ firstI = Rq.firstI;
+    if ((int)blockIdx.x * ARC_THREADS >= n / 2 + 1) return;          // this request needs fewer workgroups than the largest one of the launch
     __shared__ double sA[ARC_CHUNK];                         // sx[i0 .. i0+CHUNK)
     __shared__ double sB[ARC_CHUNK + ARC_THREADS];           // sx[i0+Lbase .. ) window for the block's lengths
     const int half = (n - 1 + 1) / 2;                        // number of threads needed: lengths 1..n-1 paired (L, n-L)
@@ -83,22 +95,38 @@ struct PermBuf { uint32_t* draws; int32_t* j; int32_t* off; int32_t* cur; int32_
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) { y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18; return y; }
 // one request = one batch of permutations of one segment; a launch serves the requests of all chromosome threads that are waiting
 struct PermReq {
-    const uint32_t* state; long long total; int n; int nb; uint32_t* snaps; const double* x; int hk, al0; double tss, errBound; PermBuf P; double* pstat; int blockBase;
+    uint32_t state[625];       // generator state at the start of the batch: mt[624], mti
+    long long total; int n; int nb; uint32_t* snaps; const double* x; int hk, al0; double tss, errBound; PermBuf P; double* pstat; int blockBase;
 };
+// MT19937 is linear over GF(2): every bit of its output stream obeys the recurrence of the characteristic polynomial phi (degree 19937,
+// 135 terms), i.e. out[k] = XOR_i out[k - MT_LAG[i]]; and because phi(x)^(2^m) = phi(x^(2^m)) over GF(2) the same holds with every
+// lag multiplied by 2^m.  With stride MT_STRIDE the smallest lag is 623 * MT_STRIDE, so that many outputs are independent of each
+// other: the generator becomes data parallel after a sequentially generated history of 19937 * MT_STRIDE outputs.
+// (MT_LAG was obtained with Berlekamp-Massey from the output stream and is checked against the sequential generator by the tests.)
+#define MT_STRIDE 128
+#define MT_NLAG 134
+#define MT_HISTORY (19937LL * MT_STRIDE)
+#define MT_WIDTH (623 * MT_STRIDE)
+__constant__ int MT_LAG[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700, 1758, 1869, 1985, 2096, 2154, 2212, 2439, 2492, 2608, 2666, 2777, 2893, 3004, 3062, 3115, 3120, 3342, 3347, 3400,
+    3516, 3569, 3574, 3685, 3796, 3801, 3912, 3970, 4028, 4255, 4308, 4361, 4424, 4482, 4588, 4593, 4709, 4820, 4878, 4931, 4936, 4984, 5158, 5163, 5216, 5332, 5385, 5390, 5501, 5612, 5617,
+    5728, 5786, 5844, 6071, 6124, 6177, 6240, 6298, 6404, 6409, 6525, 6636, 6694, 6747, 6752, 6800, 6974, 6979, 7032, 7148, 7201, 7206, 7264, 7317, 7428, 7433, 7544, 7602, 7660, 7940, 7993,
+    8056, 8099, 8220, 8225, 8326, 8452, 8553, 8563, 8616, 8722, 8780, 8790, 8848, 9017, 9176, 9244, 9809, 9968, 10036, 10432, 11731, 11958, 12185, 12354, 12412, 12460, 12808, 13368, 13600,
+    14276, 15184, 15575, 15802, 16029, 16256, 16483, 16710, 16937, 17164, 17444, 18067, 18294, 18352, 18521, 18748, 19937};
+// sequential part: the first min(total, MT_HISTORY) draws of every request
 __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs) {
     __shared__ uint32_t mtA[624], mtB[624];
-    const PermReq R = reqs[blockIdx.x];
-    const uint32_t* __restrict__ state = R.state; uint32_t* __restrict__ draws = R.P.draws; uint32_t* __restrict__ snaps = R.snaps;
-    const long long total = R.total; const int n = R.n;
+    const PermReq& R = reqs[blockIdx.x];
+    uint32_t* __restrict__ draws = R.P.draws;
+    const long long total = R.total < MT_HISTORY ? R.total : MT_HISTORY;
     const int tid = threadIdx.x;
     uint32_t* cur = mtA; uint32_t* nxt = mtB;
-    for (int i = tid; i < 624; i += 256) cur[i] = state[i];
+    for (int i = tid; i < 624; i += 256) cur[i] = R.state[i];
     __syncthreads();
-    int mti = (int)state[624];
-    long long produced = 0, boundary = n; long long bidx = 0;      // next permutation boundary (in draws) and its index
+    int mti = (int)R.state[624];
+    long long produced = 0;
     while (produced < total) {
         if (mti >= 624) {
-            // three data-parallel phases into the second buffer: one barrier per phase instead of read / barrier / write / barrier
+            // three data-parallel phases into the second buffer: one barrier per phase
             auto mix = [&](uint32_t a, uint32_t b2, uint32_t src) { const uint32_t y = (a & 0x80000000u) | (b2 & 0x7fffffffu); return src ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); };
             if (tid < 227) nxt[tid] = mix(cur[tid], cur[tid + 1], cur[tid + 397]);
             __syncthreads();
@@ -114,15 +142,38 @@ __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ re
         const long long left = total - produced;
         const int take = (int)(left < 624 - mti ? left : 624 - mti);
         for (int t = tid; t < take; t += 256) draws[produced + t] = mt_temper(cur[mti + t]);
-        // generator state at every permutation boundary inside this stretch
-        while (boundary <= produced + take) {
-            uint32_t* sdst = snaps + (size_t)bidx * 625;
-            for (int i = tid; i < 624; i += 256) sdst[i] = cur[i];
-            if (tid == 0) sdst[624] = (uint32_t)(mti + (int)(boundary - produced));
-            boundary += n; bidx++;
-        }
         produced += take; mti += take;
     }
+}
+// data-parallel part, one launch per step: draws [MT_HISTORY + step * MT_WIDTH, + MT_WIDTH) of every request that is long enough
+__global__ void __launch_bounds__(256) k_mt_stride(const PermReq* __restrict__ reqs, int step) {
+    const PermReq& R = reqs[blockIdx.y];
+    const long long k = MT_HISTORY + (long long)step * MT_WIDTH + (long long)blockIdx.x * 256 + threadIdx.x;
+    if ((long long)blockIdx.x * 256 + threadIdx.x >= MT_WIDTH || k >= R.total) return;
+    const uint32_t* __restrict__ d = R.P.draws;
+    uint32_t v = 0;
+#pragma unroll 8
+    for (int i = 0; i < MT_NLAG; i++) v ^= d[k - (long long)MT_LAG[i] * MT_STRIDE];
+    R.P.draws[k] = v;
+}
+// generator state after every permutation of the batch, rebuilt from the outputs: the 624 words behind a position are the untempered
+// last 624 outputs, with the read index at 624 (the next draw starts a new block) — what the host generator resumes from
+__device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
+    y ^= y >> 18;
+    y ^= (y << 15) & 0xefc60000u;
+    uint32_t t = y; t = y ^ ((t << 7) & 0x9d2c5680u); t = y ^ ((t << 7) & 0x9d2c5680u); t = y ^ ((t << 7) & 0x9d2c5680u); t = y ^ ((t << 7) & 0x9d2c5680u); y = t;
+    t = y; t = y ^ (t >> 11); t = y ^ (t >> 11); y = t;
+    return y;
+}
+__global__ void __launch_bounds__(256) k_mt_snapshots(const PermReq* __restrict__ reqs, int nreq) {
+    int ri = 0;
+    { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
+    const PermReq& R = reqs[ri];
+    const int b = (int)blockIdx.x - R.blockBase;
+    const long long end = (long long)(b + 1) * R.n;       // >= 1024 > 624
+    uint32_t* s = R.snaps + (size_t)b * 625;
+    for (int i = threadIdx.x; i < 624; i += 256) s[i] = mt_untemper(R.P.draws[end - 624 + i]);
+    if (threadIdx.x == 0) s[624] = 624u;
 }
 __device__ __forceinline__ int block_excl_scan_i32(int v, int* sh /*PG_T/64 + 1*/, int& total) {
     int inc = v;
@@ -143,7 +194,7 @@ __global__ void __launch_bounds__(PG_T) k_perm_stat(const PermReq* __restrict__ 
     __shared__ double shM[PG_MAXK + 1][PG_T / 64];
     int ri = 0;
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
-    const PermReq R = reqs[ri];
+    const PermReq& R = reqs[ri];
     const double* __restrict__ x = R.x; const int n = R.n, hk = R.hk, al0 = R.al0; const double tss = R.tss, errBound = R.errBound; const PermBuf P = R.P; double* __restrict__ pstat = R.pstat;
     const int b = (int)blockIdx.x - R.blockBase, tid = threadIdx.x;
     const size_t o = (size_t)b * n, o1 = (size_t)b * (n + 1);
@@ -377,9 +428,27 @@ static double integral_inv(double x, double a) {
     y = x - 0.5;
     return r - (8.0 * y) / (1.0 - 4.0 * sq(y)) - 2.0 * std::log((1.0 + 2.0 * y) / (1.0 - 2.0 * y));
 }
+// A process-wide pool for the one expensive scalar piece of the hybrid test: Nu(x) is a series of up to ~10^6 normal-CDF evaluations
+// for the small arguments of long segments (TailProbability.cs:52-85), 100 of them per TailP call.  The grid points are independent,
+// so they are evaluated by the pool (the chromosome threads mostly wait for the device) and then accumulated in the reference's order.
+struct HostPool {
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv; std::vector<std::function<void()>> q; bool stop = false;
+    HostPool() { unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 8; if (n > 64) n = 64; for (unsigned i = 0; i < n; i++) th.emplace_back([this]() { run(); }); }
+    ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+    void run() { for (;;) { std::function<void()> f; { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || !q.empty(); }); if (q.empty()) return; f = std::move(q.back()); q.pop_back(); } f(); } }
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+    static HostPool& get() { static HostPool p; return p; }
+};
 static double tail_p(double b, double delta, int m, int nGrid, double tol) {
     double dincr = (0.5 - delta) / nGrid, bs = b / std::sqrt((double)m), tl = 0.5 - dincr, t = 0.5 - 0.5 * dincr, tp = 0.0;
-    for (int i = 0; i < nGrid; i++) { tl = tl + dincr; t = t + dincr; double x = bs / std::sqrt(t * (1 - t)); double nx = nu(x, tol); tp = tp + sq(nx) * integral_inv(tl, dincr); }
+    std::vector<double> xs(nGrid), tls(nGrid), nus(nGrid);
+    for (int i = 0; i < nGrid; i++) { tl = tl + dincr; t = t + dincr; xs[i] = bs / std::sqrt(t * (1 - t)); tls[i] = tl; }
+    {   // nus[i] = Nu(xs[i]) on the pool
+        std::mutex mu; std::condition_variable cv; int left = nGrid;
+        for (int i = 0; i < nGrid; i++) HostPool::get().submit([&, i]() { nus[i] = nu(xs[i], tol); std::lock_guard<std::mutex> lk(mu); if (--left == 0) cv.notify_one(); });
+        std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return left == 0; });
+    }
+    for (int i = 0; i < nGrid; i++) tp = tp + sq(nus[i]) * integral_inv(tls[i], dincr);
     tp = 9.973557E-2 * (b * b * b) * std::exp(-sq(b) / 2) * tp;
     return 2.0 * tp;
 }
@@ -510,21 +579,25 @@ static double htmaxp_host(int k, double tss, const double* px, int n, double* sx
     return normalise(h, tss, rn);
 }
 
-struct Stats { std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
+struct Stats { std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
 
 // GPU arc search service shared by the chromosome threads
-struct ArcGpu {
-    canvas_ctx* ctx; std::mutex mu;
+struct ArcHostReq { ArcReq r; const void* hSx; void* hMax; void* hFirst; bool done = false; int32_t rc = CANVAS_OK; };
+struct PermService;
+static int32_t service_submit_arc(PermService* svc, ArcHostReq& q);
+struct ArcGpu {       // one per chromosome thread: own buffers; the launches go through the launcher thread (PermService) so that the searches of all chromosomes share one launch
+    canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr;
     double* dSx = nullptr; double* dMax = nullptr; int32_t* dFirst = nullptr; int cap = 0;
-    std::vector<double> hMax; std::vector<int32_t> hFirst;
+    char* pin = nullptr; size_t pinBytes = 0;
     int32_t ensure(int n) {
         if (n <= cap) return CANVAS_OK;
-        if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); }
+        if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pin); }
         cap = n + n / 4 + 1024;
         CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dMax, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dFirst, (size_t)cap * 4));
+        pinBytes = (size_t)cap * 20; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
         return CANVAS_OK;
     }
-    ~ArcGpu() { if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); } }
+    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pin); } }
 };
 
 // TMaxO with the O(n^2) search on the GPU.  Returns false when the caller must fall back to the host replay (ambiguous maximum).
@@ -536,21 +609,16 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     int ti = std::min(B.ipsmax0, B.ipsmin0), tj = std::max(B.ipsmax0, B.ipsmin0);
     ok = true;
     if (psdiff <= 0) { ostat = normalise(0.0, tss, rn); iseg[0] = ti; iseg[1] = tj; return CANVAS_OK; }
-    std::vector<double> dmax; std::vector<int32_t> firstI;
+    const double* dmax; const int32_t* firstI;
     {
-        std::lock_guard<std::mutex> lk(G.mu);
         canvas_ctx* ctx = G.ctx;
         CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
         int32_t rc = G.ensure(n); if (rc) return rc;
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(G.dSx, sx, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-        int half = n / 2 + 1;
-        { ProfScope ps(ctx, "cbs_arc_search");
-          hipLaunchKernelGGL(k_arc_search, dim3((half + ARC_THREADS - 1) / ARC_THREADS), dim3(ARC_THREADS), 0, ctx->stream, G.dSx, n, G.dMax, G.dFirst); }
-        dmax.resize(n); firstI.resize(n);
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dmax.data(), G.dMax, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(firstI.data(), G.dFirst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        double* hSx = (double*)G.pin; double* hMax = hSx + G.cap; int32_t* hFirst = (int32_t*)(hMax + G.cap);
+        memcpy(hSx, sx, (size_t)n * 8);
+        ArcHostReq q; q.r.sx = G.dSx; q.r.n = n; q.r.dmax = G.dMax; q.r.firstI = G.dFirst; q.hSx = hSx; q.hMax = hMax; q.hFirst = hFirst;
+        rc = service_submit_arc(G.svc, q); if (rc) return rc;
+        dmax = hMax; firstI = hFirst;
     }
     st.gpu_searches++; st.gpu_pairs += (long long)n * (n - 1) / 2;
     // arcs of length L in [al0, n - al0] (CBSTStatistic.cs:139-151: alenlo >= al0, alenhi <= n - al0)
@@ -601,12 +669,12 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
 
 // ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
 #define PERM_GPU_MIN_N 1024          // shorter segments stay on the host (a permutation there is a few microseconds)
-#define PERM_TARGET_ELEMS (2 << 20)  // permuted elements per batch
+#define PERM_TARGET_ELEMS (32 << 20) // permuted elements per batch (44 B of workspace each)
 struct PermService;
 struct PermGpu {
     canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr; char* buf = nullptr; size_t bytes = 0; char* pin = nullptr; size_t pinBytes = 0;
     int32_t ensure(size_t need, size_t needPin) {
-        if (!stream) { CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device)); CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
+        CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
         if (need > bytes) { if (buf) CANVAS_HIP_TRY(ctx, hipFree(buf)); buf = nullptr; bytes = 0; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&buf, need)); bytes = need; }
         if (needPin > pinBytes) { if (pin) CANVAS_HIP_TRY(ctx, hipHostFree(pin)); pin = nullptr; pinBytes = 0; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, needPin, hipHostMallocDefault)); pinBytes = needPin; }
         return CANVAS_OK;
@@ -617,13 +685,16 @@ struct PermGpu {
 // workgroup per request: the generator is sequential per chromosome, the chromosomes are not) and a single k_perm_stat launch (one
 // workgroup per permutation of every request).  Concurrency then does not depend on how many hardware queues the runtime maps the
 // per-thread streams to.
-struct PermHostReq { PermReq r; double* hStat; uint32_t* hSnaps; bool done = false; int32_t rc = CANVAS_OK; };
+struct PermHostReq { PermReq r; double* hStat; uint32_t* hSnaps; const double* hX = nullptr; double* dX = nullptr; size_t xBytes = 0; bool done = false; int32_t rc = CANVAS_OK; };
 struct PermService {
-    canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 64;
+    canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
+    ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; std::vector<ArcHostReq*> pendingArc;
+    long long rounds = 0, nArc = 0, nPermReq = 0; double secArc = 0, secPerm = 0;
     std::mutex mu; std::condition_variable cvWork, cvDone; std::vector<PermHostReq*> pending; bool stop = false; std::thread th; std::string err;
     explicit PermService(canvas_ctx* c) : ctx(c) { th = std::thread([this]() { run(); }); }
     ~PermService() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cvWork.notify_all(); th.join();
-        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dReqs) (void)hipFree(dReqs); if (hReqs) (void)hipHostFree(hReqs); }
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dReqs) (void)hipFree(dReqs); if (hReqs) (void)hipHostFree(hReqs);
+        if (dArc) (void)hipFree(dArc); if (hArc) (void)hipHostFree(hArc); }
     int32_t submit(PermHostReq& q) {
         std::unique_lock<std::mutex> lk(mu);
         pending.push_back(&q);
@@ -632,18 +703,56 @@ struct PermService {
         if (q.rc) ctx->err = err;
         return q.rc;
     }
-    int32_t launch(std::vector<PermHostReq*>& batch) {
+    int32_t submit_arc(ArcHostReq& q) {
+        std::unique_lock<std::mutex> lk(mu);
+        pendingArc.push_back(&q);
+        cvWork.notify_one();
+        cvDone.wait(lk, [&]() { return q.done; });
+        if (q.rc) ctx->err = err;
+        return q.rc;
+    }
+    int32_t init() {
         CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
         if (!stream) {
             CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
             CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dReqs, cap * sizeof(PermReq)));
             CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hReqs, cap * sizeof(PermReq), hipHostMallocDefault));
+            CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dArc, 64 * sizeof(ArcReq)));
+            CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hArc, 64 * sizeof(ArcReq), hipHostMallocDefault));
         }
+        return CANVAS_OK;
+    }
+    // all waiting exhaustive arc searches in one launch (grid.y = request)
+    int32_t launch_arc(std::vector<ArcHostReq*>& batch) {
+        int32_t rc = init(); if (rc) return rc;
+        const int R = (int)batch.size(); int maxN = 0;
+        for (int i = 0; i < R; i++) {
+            hArc[i] = batch[i]->r; maxN = std::max(maxN, batch[i]->r.n);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync((void*)batch[i]->r.sx, batch[i]->hSx, (size_t)batch[i]->r.n * 8, hipMemcpyHostToDevice, stream));
+        }
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dArc, hArc, R * sizeof(ArcReq), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_arc_search, dim3((maxN / 2 + 1 + ARC_THREADS - 1) / ARC_THREADS, R), dim3(ARC_THREADS), 0, stream, dArc);
+        for (int i = 0; i < R; i++) {
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hMax, batch[i]->r.dmax, (size_t)batch[i]->r.n * 8, hipMemcpyDeviceToHost, stream));
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hFirst, batch[i]->r.firstI, (size_t)batch[i]->r.n * 4, hipMemcpyDeviceToHost, stream));
+        }
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        return CANVAS_OK;
+    }
+    int32_t launch(std::vector<PermHostReq*>& batch) {
+        { int32_t rc0 = init(); if (rc0) return rc0; }
         const int R = (int)batch.size();
-        int blocks = 0;
-        for (int i = 0; i < R; i++) { batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; }
+        int blocks = 0; long long maxTotal = 0;
+        for (int i = 0; i < R; i++) {
+            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; maxTotal = std::max(maxTotal, batch[i]->r.total);
+            if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // pinned source
+        }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs);
+        const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;
+        for (int sidx = 0; sidx < steps; sidx++) hipLaunchKernelGGL(k_mt_stride, dim3((MT_WIDTH + 255) / 256, R), dim3(256), 0, stream, dReqs, sidx);
+        hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
         hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         for (int i = 0; i < R; i++) {
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hStat, batch[i]->r.pstat, (size_t)batch[i]->r.nb * 16, hipMemcpyDeviceToHost, stream));
@@ -655,16 +764,24 @@ struct PermService {
     }
     void run() {
         for (;;) {
-            std::vector<PermHostReq*> batch;
-            { std::unique_lock<std::mutex> lk(mu); cvWork.wait(lk, [&]() { return stop || !pending.empty(); }); if (pending.empty()) return;
-              while (!pending.empty() && (int)batch.size() < cap) { batch.push_back(pending.front()); pending.erase(pending.begin()); } }
+            std::vector<PermHostReq*> batch; std::vector<ArcHostReq*> arcs;
+            { std::unique_lock<std::mutex> lk(mu); cvWork.wait(lk, [&]() { return stop || !pending.empty() || !pendingArc.empty(); }); if (pending.empty() && pendingArc.empty()) return;
+              while (!pending.empty() && (int)batch.size() < cap) { batch.push_back(pending.front()); pending.erase(pending.begin()); }
+              while (!pendingArc.empty() && (int)arcs.size() < 64) { arcs.push_back(pendingArc.front()); pendingArc.erase(pendingArc.begin()); } }
             std::string saved = ctx->err;
-            int32_t rc = launch(batch);
-            { std::lock_guard<std::mutex> lk(mu); if (rc) { err = ctx->err; ctx->err = saved; } for (auto* q : batch) { q->rc = rc; q->done = true; } }
+            auto t0 = std::chrono::steady_clock::now();
+            int32_t rcA = arcs.empty() ? CANVAS_OK : launch_arc(arcs);
+            auto t1 = std::chrono::steady_clock::now();
+            int32_t rc = batch.empty() ? CANVAS_OK : launch(batch);
+            auto t2 = std::chrono::steady_clock::now();
+            rounds++; secArc += std::chrono::duration<double>(t1 - t0).count(); secPerm += std::chrono::duration<double>(t2 - t1).count(); nArc += (long long)arcs.size(); nPermReq += (long long)batch.size();
+            { std::lock_guard<std::mutex> lk(mu); if (rc || rcA) { err = ctx->err; ctx->err = saved; }
+              for (auto* q : batch) { q->rc = rc; q->done = true; } for (auto* q : arcs) { q->rc = rcA; q->done = true; } }
             cvDone.notify_all();
         }
     }
 };
+static int32_t service_submit_arc(PermService* svc, ArcHostReq& q) { return svc->submit_arc(q); }
 // The sequential stopping rule of FindChangePoints (ChangePoint.cs:337-364) over permutations evaluated in device batches.
 // Returns through `outcome`: 0 = not significant (nrej > nrejc), 1 = continue to the edge tests.  rnd ends exactly where the reference's would.
 static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int hk, int al0, double ostat, int nrejc, int k,
@@ -676,15 +793,19 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)maxB * 625 * 4), oDraws = oStat + al((size_t)maxB * 16),
                  oJ = oDraws + al(e * 4), oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
                  oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
-    const size_t pState = 0, pSnaps = al(625 * 4), pStat = pSnaps + al((size_t)maxB * 625 * 4), pinTotal = pStat + al((size_t)maxB * 16);
+    const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)maxB * 625 * 4), pinTotal = pStat + al((size_t)maxB * 16);
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
+    auto tE = now();
     int32_t rc = PG.ensure(total, pinTotal); if (rc) return rc;
+    st.ns_ensure += since(tE);
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     char* d = PG.buf; char* h = PG.pin;
-    double* dX = (double*)(d + oX); uint32_t* dState = (uint32_t*)(d + oState); uint32_t* dSnaps = (uint32_t*)(d + oSnaps); double* dStat = (double*)(d + oStat);
+    double* dX = (double*)(d + oX); uint32_t* dSnaps = (uint32_t*)(d + oSnaps); double* dStat = (double*)(d + oStat);
     PermBuf P; P.draws = (uint32_t*)(d + oDraws); P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
     P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx);
-    uint32_t* hState = (uint32_t*)(h + pState); uint32_t* hSnaps = (uint32_t*)(h + pSnaps); double* hStat = (double*)(h + pStat);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dX, gd, (size_t)n * 8, hipMemcpyHostToDevice, PG.stream));
+    double* hX = (double*)(h + pX); uint32_t* hSnaps = (uint32_t*)(h + pSnaps); double* hStat = (double*)(h + pStat);
+    memcpy(hX, gd, (size_t)n * 8);            // uploaded by the launcher together with the first batch
     // worst-case rounding bound of a prefix-sum difference: both orders of summation are within gamma_n * sum|x| of the exact sum
     double absSum = 0.0; for (int i = 0; i < n; i++) absSum += std::fabs(gd[i]);
     const double errBound = 4.04 * (double)(n + 8) * 1.1102230246251565e-16 * absSum;
@@ -695,13 +816,15 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     outcome = 1;
     while (np < nPerm) {
         const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
-        memcpy(hState, cur, sizeof cur);
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dState, hState, sizeof cur, hipMemcpyHostToDevice, PG.stream));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(PG.stream));        // x and the generator state are on the device before the launcher thread takes over
+        auto tS = now();
         PermHostReq q;
-        q.r.state = dState; q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
+        memcpy(q.r.state, cur, sizeof cur); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
         q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
+        if (np == 0) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; }
         rc = PG.svc->submit(q); if (rc) return rc;
+        st.ns_submit += since(tS);
+        auto tP = now();
+        struct PostAcc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~PostAcc() { a += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } postAcc{st.ns_post, tP};
         st.dev_batches++;
         if (getenv("CANVAS_CBS_TEST_VERIFY")) {      // test hook: every device interval must contain the statistic computed in the reference's order
             for (int b = 0; b < nb; b++) {
@@ -709,9 +832,10 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
                 px.resize(n); sx.resize(n);
                 xperm(gd, px.data(), n, m2);
                 const double exact = htmaxp_host(hk, tss, px.data(), n, sx.data(), al0);
-                uint32_t after[625]; m2.get_state(after);
+                MT m3(0u); m3.set_state(hSnaps + (size_t)b * 625);      // the device snapshot must continue the stream exactly where the host generator is
+                bool same = true; for (int t = 0; t < 1400; t++) if (m2.u32() != m3.u32()) { same = false; break; }
                 st.verified++;
-                if (!(hStat[2 * b] <= exact && exact <= hStat[2 * b + 1]) || memcmp(after, hSnaps + (size_t)b * 625, sizeof after) != 0 ||
+                if (!(hStat[2 * b] <= exact && exact <= hStat[2 * b + 1]) || !same ||
                     !(hStat[2 * b + 1] - hStat[2 * b] <= 1e-6 * std::fabs(exact) + 1e-300)) st.violations++;
             }
         }
@@ -750,11 +874,13 @@ static int32_t find_change_points(ArcGpu& G, PermGpu& PG, const double* gd, int 
     bool done = false;
     if (n >= CBS_GPU_MIN_N) {
         bool ok = false;
+        auto tA = std::chrono::steady_clock::now();
         int32_t rc = tmaxo_gpu(G, gd, n, tss, sx.data(), iseg, ostat, al0, st, ok); if (rc) return rc;
+        st.ns_tmaxo += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tA).count();
         done = ok;
         if (!ok) st.tie_replays++;
     }
-    if (!done) tmaxo_host(gd, n, tss, sx.data(), iseg, ostat, al0);
+    if (!done) { auto tH = std::chrono::steady_clock::now(); tmaxo_host(gd, n, tss, sx.data(), iseg, ostat, al0); st.ns_tmaxo_host += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tH).count(); }
     st.tmaxo_calls++; st.tmaxo_elems += n;
     double ostat1 = std::sqrt(ostat); ostat *= 0.99999;
     if (ostat1 <= 0.1) return CANVAS_OK;
@@ -762,7 +888,9 @@ static int32_t find_change_points(ArcGpu& G, PermGpu& PG, const double* gd, int 
     if (!(ostat1 >= 7.0 && l >= 10)) {
         int nrejc, k;
         if (hybrid) {
+            auto tTP = std::chrono::steady_clock::now();
             double p1 = tail_p(ostat1, delta, n, 100, 1E-6);
+            st.ns_tailp += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tTP).count();
             if (p1 > cutoff) { st.tailp_exits++; return CANVAS_OK; }
             nrejc = (int)((cutoff - p1) * nPerm);
         } else nrejc = (int)(cutoff * nPerm);
@@ -786,6 +914,8 @@ static int32_t find_change_points(ArcGpu& G, PermGpu& PG, const double* gd, int 
         }
         }
     } else st.big_t++;
+    auto tT = std::chrono::steady_clock::now();
+    struct TAcc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~TAcc() { a += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } tAcc{st.ns_tpermp, tT};
     if (iseg[1] == n) { nCp = 1; iCp[0] = iseg[0]; }
     else if (iseg[0] == 0) { nCp = 1; iCp[0] = iseg[1]; }
     else {
@@ -970,20 +1100,27 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     for (int c = 0; c < nchr; c++) seeds[c] = seeder.next_full_range_int32();
     double trimmedSD = 1.0;
     if (undo == 2 && N > 1) trimmedSD = std::sqrt(cbs::trimmed_variance(cov.data(), h_chr_offset, nchr, 0.025));   // CBSRunner.cs:102
-    cbs::ArcGpu G; G.ctx = ctx;
     cbs::Stats st;
     std::vector<std::vector<int>> segs(nchr);
     std::vector<int32_t> rcs(nchr, 0);
     std::vector<std::string> errs(nchr);
     std::atomic_int next{0};
-    cbs::PermService service(ctx);
+    // launcher threads (own streams): arc searches on one, permutation batches spread over four, so that the device always has several
+    // independent kernels in flight (a batch of one chromosome is a chain of latency-bound launches)
+    cbs::PermService arcService(ctx), service(ctx), service1(ctx), service2(ctx), service3(ctx);
+    cbs::PermService* permServices[4] = {&service, &service1, &service2, &service3};
+    std::atomic_int nextService{0};
+    std::mutex chromMu; double maxChromSec = 0, sumChromSec = 0;
     auto work = [&]() {
-        cbs::PermGpu PG; PG.ctx = ctx; PG.svc = &service;         // per thread: own buffers, created on first use
+        cbs::PermGpu PG; PG.ctx = ctx; PG.svc = permServices[nextService++ % 4];         // per thread: own buffers, created on first use
+        cbs::ArcGpu G; G.ctx = ctx; G.svc = &arcService;
         for (;;) {
             int c = next++; if (c >= nchr) break;
             int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);
             if (n <= 0) continue;
             cbs::MT rnd((uint32_t)seeds[c]);
+            auto tC = std::chrono::steady_clock::now();
+            struct CAcc { std::mutex& m; double& mx; double& sm; std::chrono::steady_clock::time_point t; ~CAcc() { double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); std::lock_guard<std::mutex> lk(m); mx = std::max(mx, d); sm += d; } } cAcc{chromMu, maxChromSec, sumChromSec, tC};
             rcs[c] = cbs::change_points(G, PG, cov.data() + h_chr_offset[c], n, sbdry, rnd, alpha, nperm, segs[c], st);
             if (rcs[c] == 0 && undo == 2) cbs::sd_undo(cov.data() + h_chr_offset[c], segs[c], trimmedSD, undo_sd);
             if (rcs[c] == 0 && undo == 1 && segs[c].size() > 1) rcs[c] = cbs::prune(cov.data() + h_chr_offset[c], n, segs[c], 0.05, errs[c]);   // undoPrune = 0.05 (CBSRunner.cs:42)
@@ -1000,7 +1137,10 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_seg_len, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
-    if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: device permutation loop %.3f, host permutation loop %.3f\n", st.ns_dev.load() * 1e-9, st.ns_hostperm.load() * 1e-9);
+    if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: TMaxO on the host %.3f, TailP %.3f\n", st.ns_tmaxo_host.load() * 1e-9, st.ns_tailp.load() * 1e-9),
+                                      fprintf(stderr, "cbs launcher: %lld rounds, %lld arc searches in %.3f s, %lld permutation batches in %.3f s\n", service.rounds + arcService.rounds, arcService.nArc, arcService.secArc, service.nPermReq + service1.nPermReq + service2.nPermReq + service3.nPermReq, std::max(std::max(service.secPerm, service1.secPerm), std::max(service2.secPerm, service3.secPerm))),
+                                      fprintf(stderr, "cbs thread-seconds: TMaxO on the device incl. waiting %.3f, edge tests (TPermP) %.3f; per-chromosome wall max %.3f sum %.3f; ", st.ns_tmaxo.load() * 1e-9, st.ns_tpermp.load() * 1e-9, maxChromSec, sumChromSec),
+                                      fprintf(stderr, "device permutation loop %.3f (buffers %.3f, uploads %.3f, waiting for the launcher %.3f, stopping rule %.3f), host permutation loop %.3f\n", st.ns_dev.load() * 1e-9, st.ns_ensure.load() * 1e-9, st.ns_upload.load() * 1e-9, st.ns_submit.load() * 1e-9, st.ns_post.load() * 1e-9, st.ns_hostperm.load() * 1e-9);
     if (h_stats) { h_stats[0] = st.tmaxo_calls; h_stats[1] = st.tmaxo_elems; h_stats[2] = st.perms; h_stats[3] = st.perm_elems; h_stats[4] = st.tpermp_draws; h_stats[5] = st.tailp_exits; h_stats[6] = st.gpu_searches; h_stats[7] = st.tie_replays; }
     return CANVAS_OK;
 }
