@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--rate", type=float, default=0.21, help="hits per possible position (0.21 = 60x, 0.105 = 30x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage host wall times (ms) of the last step to stderr")
+    ap.add_argument("--no-cbs", action="store_true", help="skip the (untimed) CBS run on the cleaned coverage that is reported as cbs_path")
     args = ap.parse_args()
 
     import torch
@@ -190,6 +191,19 @@ def main():
                          "samples": world, "scale": args.scale, "rate": args.rate},
               "roofline": roofline}
 
+    if rank == 0 and world == 1 and not args.no_cbs:
+        # the other partition method of the path (-m CBS, BASELINE configs[4]) on the same cleaned coverage; reported, not part of `value`
+        t_c = time.perf_counter()
+        cv.cbs(keep["cov"], keep["off"], 0.01, 10000)            # first call: sequential-boundary table (GetBoundary.cs), buffers, thread pool
+        cbs_first = time.perf_counter() - t_c
+        t_c = time.perf_counter()
+        seg_len, nseg_c, cstats = cv.cbs(keep["cov"], keep["off"], 0.01, 10000)
+        cbs_s = time.perf_counter() - t_c
+        dstat = cv.cbs_device_stats()
+        result["cbs_path"] = {"seconds": round(cbs_s, 3), "first_call_seconds": round(cbs_first, 3), "bins_per_s": round(int(keep["n_out"]) / cbs_s, 1), "segments": int(sum(nseg_c)), "tmaxo_calls": int(cstats[0]),
+                              "permutations": int(cstats[2]), "permuted_elements": int(cstats[3]), "device_permutations": int(dstat[0]), "host_permutations": int(dstat[1]),
+                              "exact_reevaluations": int(dstat[2]), "note": "CBSRunner.Run (alpha 0.01, 10000 permutations): recursion and stopping rule on the host, "
+                              "TMaxO arc search + XPerm/HTMaxP + MT19937 on the device"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(keep, bases, hits, masks, lens, is_auto, flags, total_bases)
     if rank == 0:

@@ -73,6 +73,95 @@ __global__ void __launch_bounds__(ARC_THREADS) k_arc_search(const ArcReq* __rest
     }
 }
 
+// ================================================================================================ device: pruned arc search
+// The statistic of an arc (i, j) is c(L) * (sx[j] - sx[i])^2 with L = j - i and c(L) = n / (L (n - L)).  For blocks A <= B of 1024
+// prefix sums every arc from A to B satisfies  stat <= max(c(Lmin), c(Lmax)) * max(max_B - min_A, max_A - min_B)^2  (IEEE operations
+// are monotone, c is evaluated from an exact integer product, so the bound holds for the rounded values too).  Only block pairs whose
+// bound reaches the incumbent (the reference's own starting point: the arc between the global extremes of the prefix sums,
+// CBSTStatistic.cs:112-137) are evaluated arc by arc — typically a few dozen of the (n/1024)^2/2 pairs.  The result is the exact
+// maximum, the number of arcs attaining it and the smallest (L, i) among them: what the host needs to decide between "unique
+// maximiser" and "replay the reference's block order".  If more pairs survive than the list holds, the exhaustive kernel is used.
+#define AP_BK 1024
+#define AP_PAIRCAP 8192
+struct ArcPReq { const double* sx; int n; int al0; double tau; double* bmin; double* bmax; int* pairs; unsigned long long* out /* [0] max key, [1] count, [2] min packed arc, [3] npairs, [4] overflow */; double* pairMax; };
+__global__ void __launch_bounds__(256) k_arcp_blocks(const ArcPReq* __restrict__ reqs) {
+    const ArcPReq R = reqs[blockIdx.y];
+    const int nb = (R.n + AP_BK - 1) / AP_BK;
+    if ((int)blockIdx.x >= nb) return;
+    __shared__ double smn[4], smx[4];
+    double mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
+    for (int k = threadIdx.x; k < AP_BK; k += 256) { const int i = blockIdx.x * AP_BK + k; if (i < R.n) { const double v = R.sx[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; } }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double a = __hiloint2double(__shfl_xor(__double2hiint(mn), d), __shfl_xor(__double2loint(mn), d)), b = __hiloint2double(__shfl_xor(__double2hiint(mx), d), __shfl_xor(__double2loint(mx), d));
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; } R.bmin[blockIdx.x] = mn; R.bmax[blockIdx.x] = mx; }
+}
+__device__ __forceinline__ double arc_c(double rn, int L) { const double rj = (double)L; return rn / (rj * (rn - rj)); }
+__global__ void __launch_bounds__(256) k_arcp_bounds(const ArcPReq* __restrict__ reqs) {
+    const ArcPReq R = reqs[blockIdx.y];
+    const int nb = (R.n + AP_BK - 1) / AP_BK;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)nb * nb) return;
+    const int A = (int)(idx / nb), B = (int)(idx % nb);
+    if (B < A) return;
+    double D = R.bmax[B] - R.bmin[A]; const double D2 = R.bmax[A] - R.bmin[B]; D = D2 > D ? D2 : D;
+    if (!(D > 0.0)) return;
+    const int lmin = B == A ? 1 : (B - A - 1) * AP_BK + 1;
+    int lmax = (B - A + 1) * AP_BK - 1; lmax = lmax > R.n - 1 ? R.n - 1 : lmax;
+    const int llo = lmin > R.al0 ? lmin : R.al0, lhi = lmax < R.n - R.al0 ? lmax : R.n - R.al0;
+    if (llo > lhi) return;
+    const double rn = (double)R.n, c1 = arc_c(rn, llo), c2 = arc_c(rn, lhi), c = c1 > c2 ? c1 : c2;
+    if (c * (D * D) >= R.tau) {
+        const unsigned long long slot = atomicAdd(&R.out[3], 1ull);
+        if (slot < AP_PAIRCAP) R.pairs[slot] = A * 65536 + B; else R.out[4] = 1ull;
+    }
+}
+// pass 0: maximum over the arcs of a surviving block pair; pass 1: count of the arcs that attain the global maximum + the smallest (L, i)
+__global__ void __launch_bounds__(256) k_arcp_eval(const ArcPReq* __restrict__ reqs, int pass) {
+    const ArcPReq R = reqs[blockIdx.y];
+    unsigned long long np = R.out[3]; if (np > AP_PAIRCAP) np = AP_PAIRCAP;
+    if (R.out[4] || (unsigned long long)blockIdx.x >= np) return;
+    if (pass == 1 && (unsigned long long)__double_as_longlong(R.pairMax[blockIdx.x]) != R.out[0]) return;
+    __shared__ double sA[AP_BK], sB[AP_BK], sC[2 * AP_BK];
+    __shared__ double sred[4];
+    const int A = R.pairs[blockIdx.x] >> 16, B = R.pairs[blockIdx.x] & 65535;
+    const int n = R.n, baseL = (B - A) * AP_BK - (AP_BK - 1);          // L = baseL + (jj - ii + AP_BK - 1)
+    const double rn = (double)n;
+    for (int k = threadIdx.x; k < AP_BK; k += 256) { const int i = A * AP_BK + k, j = B * AP_BK + k; sA[k] = i < n ? R.sx[i] : 0.0; sB[k] = j < n ? R.sx[j] : 0.0; }
+    for (int k = threadIdx.x; k < 2 * AP_BK - 1; k += 256) { const int L = baseL + k; sC[k] = (L >= R.al0 && L <= n - R.al0) ? arc_c(rn, L) : -1.0; }   // -1: arc length not allowed
+    __syncthreads();
+    const double target = __longlong_as_double((long long)R.out[0]);
+    double best = -1.0; unsigned long long cnt = 0, arcMin = ~0ull;
+    for (int ii = threadIdx.x; ii < AP_BK; ii += 256) {
+        const int i = A * AP_BK + ii; if (i >= n) break;
+        const double a = sA[ii];
+        const int j0 = A == B ? ii + 1 : 0;
+        int jend = n - B * AP_BK; jend = jend > AP_BK ? AP_BK : jend;
+        for (int jj = j0; jj < jend; jj++) {
+            const double c = sC[jj - ii + AP_BK - 1];
+            if (c < 0.0) continue;
+            const double d = fabs(sB[jj] - a), v = c * (d * d);
+            if (pass == 0) best = v > best ? v : best;
+            else if (v == target) { cnt++; const unsigned long long key = ((unsigned long long)(unsigned)(baseL + jj - ii + AP_BK - 1) << 32) | (unsigned)i; arcMin = key < arcMin ? key : arcMin; }
+        }
+    }
+    if (pass == 0) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double o = __hiloint2double(__shfl_xor(__double2hiint(best), d), __shfl_xor(__double2loint(best), d)); best = o > best ? o : best; }
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; w++) best = sred[w] > best ? sred[w] : best;
+            R.pairMax[blockIdx.x] = best;
+            if (best >= 0.0) atomicMax(&R.out[0], (unsigned long long)__double_as_longlong(best));      // non-negative doubles order like their bit patterns
+        }
+    } else if (cnt) { atomicAdd(&R.out[1], cnt); atomicMin(&R.out[2], arcMin); }
+}
+
 // ================================================================================================ device: permutation reference distribution
 // XPerm (ChangePoint.cs:407-421) + HTMaxP (CBSTStatistic.cs:354-586) for a batch of B permutations of one segment.
 //
@@ -582,22 +671,24 @@ static double htmaxp_host(int k, double tss, const double* px, int n, double* sx
 struct Stats { std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
 
 // GPU arc search service shared by the chromosome threads
-struct ArcHostReq { ArcReq r; const void* hSx; void* hMax; void* hFirst; bool done = false; int32_t rc = CANVAS_OK; };
+struct ArcHostReq { ArcReq r; ArcPReq p; bool pruned = true; const void* hSx; void* hMax; void* hFirst; unsigned long long* hOut; bool done = false; int32_t rc = CANVAS_OK; };
 struct PermService;
 static int32_t service_submit_arc(PermService* svc, ArcHostReq& q);
 struct ArcGpu {       // one per chromosome thread: own buffers; the launches go through the launcher thread (PermService) so that the searches of all chromosomes share one launch
     canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr;
     double* dSx = nullptr; double* dMax = nullptr; int32_t* dFirst = nullptr; int cap = 0;
+    char* dPr = nullptr;          // pruned search: block minima / maxima, pair list, per-pair maxima, result words
     char* pin = nullptr; size_t pinBytes = 0;
     int32_t ensure(int n) {
         if (n <= cap) return CANVAS_OK;
-        if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pin); }
+        if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipFree(dPr); (void)hipHostFree(pin); }
         cap = n + n / 4 + 1024;
+        { const size_t nb = (size_t)cap / AP_BK + 2; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dPr, nb * 16 + AP_PAIRCAP * 12 + 4096)); }
         CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dMax, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dFirst, (size_t)cap * 4));
-        pinBytes = (size_t)cap * 20; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
+        pinBytes = (size_t)cap * 20 + 256; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
         return CANVAS_OK;
     }
-    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pin); } }
+    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipFree(dPr); (void)hipHostFree(pin); } }
 };
 
 // TMaxO with the O(n^2) search on the GPU.  Returns false when the caller must fall back to the host replay (ambiguous maximum).
@@ -609,17 +700,33 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     int ti = std::min(B.ipsmax0, B.ipsmin0), tj = std::max(B.ipsmax0, B.ipsmin0);
     ok = true;
     if (psdiff <= 0) { ostat = normalise(0.0, tss, rn); iseg[0] = ti; iseg[1] = tj; return CANVAS_OK; }
-    const double* dmax; const int32_t* firstI;
-    {
-        canvas_ctx* ctx = G.ctx;
-        CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-        int32_t rc = G.ensure(n); if (rc) return rc;
-        double* hSx = (double*)G.pin; double* hMax = hSx + G.cap; int32_t* hFirst = (int32_t*)(hMax + G.cap);
-        memcpy(hSx, sx, (size_t)n * 8);
-        ArcHostReq q; q.r.sx = G.dSx; q.r.n = n; q.r.dmax = G.dMax; q.r.firstI = G.dFirst; q.hSx = hSx; q.hMax = hMax; q.hFirst = hFirst;
+    canvas_ctx* ctx = G.ctx;
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t rc = G.ensure(n); if (rc) return rc;
+    double* hSx = (double*)G.pin; double* hMax = hSx + G.cap; int32_t* hFirst = (int32_t*)(hMax + G.cap); unsigned long long* hOut = (unsigned long long*)(G.pin + (size_t)G.cap * 20);
+    memcpy(hSx, sx, (size_t)n * 8);
+    const size_t nbk = (size_t)G.cap / AP_BK + 2;
+    ArcHostReq q; q.hSx = hSx; q.hMax = hMax; q.hFirst = hFirst; q.hOut = hOut;
+    q.r.sx = G.dSx; q.r.n = n; q.r.dmax = G.dMax; q.r.firstI = G.dFirst;
+    q.p.sx = G.dSx; q.p.n = n; q.p.al0 = al0; q.p.tau = bss0; q.p.bmin = (double*)G.dPr; q.p.bmax = q.p.bmin + nbk; q.p.pairs = (int*)(q.p.bmax + nbk);
+    q.p.pairMax = (double*)(q.p.pairs + AP_PAIRCAP); q.p.out = (unsigned long long*)(q.p.pairMax + AP_PAIRCAP);
+    q.pruned = getenv("CANVAS_CBS_EXHAUSTIVE_ARCS") == nullptr;
+    if (q.pruned) {
         rc = service_submit_arc(G.svc, q); if (rc) return rc;
-        dmax = hMax; firstI = hFirst;
+        st.gpu_searches++;
+        if (!hOut[4]) {
+            st.gpu_pairs += (long long)hOut[3] * AP_BK * AP_BK;
+            const double M = hOut[3] ? __builtin_bit_cast(double, hOut[0]) : -1.0;
+            if (!(M > bss0)) { ostat = normalise(bss0, tss, rn); iseg[0] = ti; iseg[1] = tj; return CANVAS_OK; }   // the incumbent survives every strict '>' test
+            if (hOut[1] == 1) { const int L = (int)(hOut[2] >> 32), i0 = (int)(hOut[2] & 0xffffffffull); ostat = normalise(M, tss, rn); iseg[0] = i0 + 1; iseg[1] = i0 + 1 + L; return CANVAS_OK; }
+            ok = false;       // several arcs attain the maximum: the winner depends on the reference's block visiting order
+            return CANVAS_OK;
+        }
+        q.pruned = false;     // too many candidate block pairs (flat data): exhaustive search
     }
+    rc = service_submit_arc(G.svc, q); if (rc) return rc;
+    const double* dmax = hMax; const int32_t* firstI = hFirst;
+    if (!getenv("CANVAS_CBS_EXHAUSTIVE_ARCS")) st.gpu_searches--;
     st.gpu_searches++; st.gpu_pairs += (long long)n * (n - 1) / 2;
     // arcs of length L in [al0, n - al0] (CBSTStatistic.cs:139-151: alenlo >= al0, alenhi <= n - al0)
     double M = -1.0; int bestL = -1, nbest = 0;
@@ -688,13 +795,13 @@ struct PermGpu {
 struct PermHostReq { PermReq r; double* hStat; uint32_t* hSnaps; const double* hX = nullptr; double* dX = nullptr; size_t xBytes = 0; bool done = false; int32_t rc = CANVAS_OK; };
 struct PermService {
     canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
-    ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; std::vector<ArcHostReq*> pendingArc;
+    ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
     long long rounds = 0, nArc = 0, nPermReq = 0; double secArc = 0, secPerm = 0;
     std::mutex mu; std::condition_variable cvWork, cvDone; std::vector<PermHostReq*> pending; bool stop = false; std::thread th; std::string err;
     explicit PermService(canvas_ctx* c) : ctx(c) { th = std::thread([this]() { run(); }); }
     ~PermService() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cvWork.notify_all(); th.join();
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dReqs) (void)hipFree(dReqs); if (hReqs) (void)hipHostFree(hReqs);
-        if (dArc) (void)hipFree(dArc); if (hArc) (void)hipHostFree(hArc); }
+        if (dArc) (void)hipFree(dArc); if (hArc) (void)hipHostFree(hArc); if (dArcP) (void)hipFree(dArcP); if (hArcP) (void)hipHostFree(hArcP); }
     int32_t submit(PermHostReq& q) {
         std::unique_lock<std::mutex> lk(mu);
         pending.push_back(&q);
@@ -719,22 +826,37 @@ struct PermService {
             CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hReqs, cap * sizeof(PermReq), hipHostMallocDefault));
             CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dArc, 64 * sizeof(ArcReq)));
             CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hArc, 64 * sizeof(ArcReq), hipHostMallocDefault));
+            CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dArcP, 64 * sizeof(ArcPReq)));
+            CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hArcP, 64 * sizeof(ArcPReq), hipHostMallocDefault));
         }
         return CANVAS_OK;
     }
-    // all waiting exhaustive arc searches in one launch (grid.y = request)
-    int32_t launch_arc(std::vector<ArcHostReq*>& batch) {
+    // all waiting arc searches in shared launches (grid.y = request): pruned pipeline, or the exhaustive kernel for requests that ask for it
+    int32_t launch_arc(std::vector<ArcHostReq*>& all) {
         int32_t rc = init(); if (rc) return rc;
-        const int R = (int)batch.size(); int maxN = 0;
-        for (int i = 0; i < R; i++) {
-            hArc[i] = batch[i]->r; maxN = std::max(maxN, batch[i]->r.n);
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync((void*)batch[i]->r.sx, batch[i]->hSx, (size_t)batch[i]->r.n * 8, hipMemcpyHostToDevice, stream));
+        std::vector<ArcHostReq*> pr, ex;
+        for (auto* q : all) (q->pruned ? pr : ex).push_back(q);
+        for (auto* q : all) CANVAS_HIP_TRY(ctx, hipMemcpyAsync((void*)q->r.sx, q->hSx, (size_t)q->r.n * 8, hipMemcpyHostToDevice, stream));
+        if (!pr.empty()) {
+            const int R = (int)pr.size(); int maxN = 0;
+            for (int i = 0; i < R; i++) { hArcP[i] = pr[i]->p; maxN = std::max(maxN, pr[i]->p.n); CANVAS_HIP_TRY(ctx, hipMemsetAsync(pr[i]->p.out, 0, 40, stream)); CANVAS_HIP_TRY(ctx, hipMemsetAsync(pr[i]->p.out + 2, 0xFF, 8, stream)); }
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dArcP, hArcP, R * sizeof(ArcPReq), hipMemcpyHostToDevice, stream));
+            const int nb = (maxN + AP_BK - 1) / AP_BK;
+            hipLaunchKernelGGL(k_arcp_blocks, dim3(nb, R), dim3(256), 0, stream, dArcP);
+            hipLaunchKernelGGL(k_arcp_bounds, dim3((unsigned)(((long long)nb * nb + 255) / 256), R), dim3(256), 0, stream, dArcP);
+            hipLaunchKernelGGL(k_arcp_eval, dim3(AP_PAIRCAP, R), dim3(256), 0, stream, dArcP, 0);
+            hipLaunchKernelGGL(k_arcp_eval, dim3(AP_PAIRCAP, R), dim3(256), 0, stream, dArcP, 1);
+            for (int i = 0; i < R; i++) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(pr[i]->hOut, pr[i]->p.out, 40, hipMemcpyDeviceToHost, stream));
         }
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dArc, hArc, R * sizeof(ArcReq), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_arc_search, dim3((maxN / 2 + 1 + ARC_THREADS - 1) / ARC_THREADS, R), dim3(ARC_THREADS), 0, stream, dArc);
-        for (int i = 0; i < R; i++) {
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hMax, batch[i]->r.dmax, (size_t)batch[i]->r.n * 8, hipMemcpyDeviceToHost, stream));
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hFirst, batch[i]->r.firstI, (size_t)batch[i]->r.n * 4, hipMemcpyDeviceToHost, stream));
+        if (!ex.empty()) {
+            const int R = (int)ex.size(); int maxN = 0;
+            for (int i = 0; i < R; i++) { hArc[i] = ex[i]->r; maxN = std::max(maxN, ex[i]->r.n); }
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dArc, hArc, R * sizeof(ArcReq), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_arc_search, dim3((maxN / 2 + 1 + ARC_THREADS - 1) / ARC_THREADS, R), dim3(ARC_THREADS), 0, stream, dArc);
+            for (int i = 0; i < R; i++) {
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ex[i]->hMax, ex[i]->r.dmax, (size_t)ex[i]->r.n * 8, hipMemcpyDeviceToHost, stream));
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ex[i]->hFirst, ex[i]->r.firstI, (size_t)ex[i]->r.n * 4, hipMemcpyDeviceToHost, stream));
+            }
         }
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
