@@ -186,6 +186,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) { y ^= y >> 11; y ^= (
 struct PermReq {
     uint32_t state[625];       // generator state at the start of the batch: mt[624], mti
     long long total; int n; int nb; uint32_t* snaps; const double* x; int hk, al0; double tss, errBound; PermBuf P; double* pstat; int blockBase;
+    int cont;                  // the MT_HISTORY outputs in front of P.draws are the tail of the previous batch: no sequential part needed
 };
 // MT19937 is linear over GF(2): every bit of its output stream obeys the recurrence of the characteristic polynomial phi (degree 19937,
 // 135 terms), i.e. out[k] = XOR_i out[k - MT_LAG[i]]; and because phi(x)^(2^m) = phi(x^(2^m)) over GF(2) the same holds with every
@@ -205,6 +206,7 @@ __constant__ int MT_LAG[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700, 1758
 __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs) {
     __shared__ uint32_t mtA[624], mtB[624];
     const PermReq& R = reqs[blockIdx.x];
+    if (R.cont) return;
     uint32_t* __restrict__ draws = R.P.draws;
     const long long total = R.total < MT_HISTORY ? R.total : MT_HISTORY;
     const int tid = threadIdx.x;
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ re
 // data-parallel part, one launch per step: draws [MT_HISTORY + step * MT_WIDTH, + MT_WIDTH) of every request that is long enough
 __global__ void __launch_bounds__(256) k_mt_stride(const PermReq* __restrict__ reqs, int step) {
     const PermReq& R = reqs[blockIdx.y];
-    const long long k = MT_HISTORY + (long long)step * MT_WIDTH + (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long k = (R.cont ? 0 : MT_HISTORY) + (long long)step * MT_WIDTH + (long long)blockIdx.x * 256 + threadIdx.x;
     if ((long long)blockIdx.x * 256 + threadIdx.x >= MT_WIDTH || k >= R.total) return;
     const uint32_t* __restrict__ d = R.P.draws;
     uint32_t v = 0;
@@ -792,7 +794,7 @@ struct PermGpu {
 // workgroup per request: the generator is sequential per chromosome, the chromosomes are not) and a single k_perm_stat launch (one
 // workgroup per permutation of every request).  Concurrency then does not depend on how many hardware queues the runtime maps the
 // per-thread streams to.
-struct PermHostReq { PermReq r; double* hStat; uint32_t* hSnaps; const double* hX = nullptr; double* dX = nullptr; size_t xBytes = 0; bool done = false; int32_t rc = CANVAS_OK; };
+struct PermHostReq { PermReq r; long long prevTotal = 0; double* hStat; uint32_t* hSnaps; const double* hX = nullptr; double* dX = nullptr; size_t xBytes = 0; bool done = false; int32_t rc = CANVAS_OK; };
 struct PermService {
     canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
     ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
@@ -867,7 +869,9 @@ struct PermService {
         const int R = (int)batch.size();
         int blocks = 0; long long maxTotal = 0;
         for (int i = 0; i < R; i++) {
-            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; maxTotal = std::max(maxTotal, batch[i]->r.total);
+            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
+            if (batch[i]->r.cont)    // history of this batch = the last MT_HISTORY outputs of the previous one (same buffer, no overlap: prevTotal >= MT_HISTORY)
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws - MT_HISTORY, batch[i]->r.P.draws + (batch[i]->prevTotal - MT_HISTORY), (size_t)MT_HISTORY * 4, hipMemcpyDeviceToDevice, stream));
             if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // pinned source
         }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
@@ -913,7 +917,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t e = (size_t)maxB * n, e1 = (size_t)maxB * (n + 1);
     const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)maxB * 625 * 4), oDraws = oStat + al((size_t)maxB * 16),
-                 oJ = oDraws + al(e * 4), oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
+                 oJ = oDraws + al((e + (size_t)MT_HISTORY) * 4), oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
                  oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
     const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)maxB * 625 * 4), pinTotal = pStat + al((size_t)maxB * 16);
     auto now = []() { return std::chrono::steady_clock::now(); };
@@ -924,7 +928,8 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     char* d = PG.buf; char* h = PG.pin;
     double* dX = (double*)(d + oX); uint32_t* dSnaps = (uint32_t*)(d + oSnaps); double* dStat = (double*)(d + oStat);
-    PermBuf P; P.draws = (uint32_t*)(d + oDraws); P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
+    PermBuf P; P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY;       // MT_HISTORY outputs of head room for the continuation
+    P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
     P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx);
     double* hX = (double*)(h + pX); uint32_t* hSnaps = (uint32_t*)(h + pSnaps); double* hStat = (double*)(h + pStat);
     memcpy(hX, gd, (size_t)n * 8);            // uploaded by the launcher together with the first batch
@@ -934,6 +939,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     std::vector<double> px, sx;
     uint32_t cur[625]; rnd.get_state(cur);
     int nrej = 0; uint32_t np = 0;
+    long long prevTotal = 0;
     int B = std::min(maxB, 64);
     outcome = 1;
     while (np < nPerm) {
@@ -943,6 +949,8 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         memcpy(q.r.state, cur, sizeof cur); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
         q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
         if (np == 0) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; }
+        q.r.cont = (np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
+        prevTotal = (long long)nb * n;
         rc = PG.svc->submit(q); if (rc) return rc;
         st.ns_submit += since(tS);
         auto tP = now();
