@@ -165,8 +165,8 @@ __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chr
 // contiguous bytes; bin indices / states / increments are fetched through a small per-lane register queue PQ steps ahead.
 // Back-pointers are packed 3 bits per state into one uint16 per bin.
 #define VB 128       // block length
-#define VW 128       // cold-start lead-in of the speculative pass
-#define VW2 64       // lead-in of the verification pass (carry[] holds D at multiples of 64)
+#define VW 128       // cold-start lead-in of the speculative pass, first attempt (a run-time argument: the retry uses 8x)
+#define VW2 64       // lead-in of the verification pass, first attempt (a multiple of 64: carry[] holds D at multiples of 64)
 #define PQ 8         // per-lane prefetch depth in steps
 #define MAP_IDENT (0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12))
 struct VitBlock { int32_t chrom; int32_t t0; };   // chromosome-relative start
@@ -253,16 +253,17 @@ __global__ void __launch_bounds__(256) k_make_blocks(const int32_t* __restrict__
 // A: one lane per block
 __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                  const double* __restrict__ logPmf, HmmParams P, uint16_t* __restrict__ psi, uint16_t* __restrict__ maps,
-                                                 int32_t* __restrict__ lastGuess) {
+                                                 int32_t* __restrict__ lastGuess, int leadIn, const int32_t* __restrict__ todo) {
     extern __shared__ double sTab[];
     const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
     vit_stage_table(sTab, logPmf, P.tableLen, useLds);
     const int b = blockIdx.x * 64 + threadIdx.x;
-    const bool act = b < nblocks;
-    const VitBlock B = blocks[act ? b : nblocks - 1];
+    const bool actBlock = b < nblocks;
+    const VitBlock B = blocks[actBlock ? b : nblocks - 1];
     const HmmChrom C = chroms[B.chrom];
     const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;       // block covers [tBeg, tEnd)
-    const int64_t ts = tBeg > VW ? tBeg - VW : 0;                                  // cold start
+    const int64_t ts = tBeg > leadIn ? tBeg - leadIn : 0;                          // cold start
+    const bool act = actBlock && (!todo || todo[B.chrom]);                         // a retry only recomputes the chromosomes that failed
     const int nsteps = act ? (int)(tEnd - ts) : 0;
     const int maxSteps = wave_max_i32(nsteps);
     const int32_t* __restrict__ ix = idx + C.begin + ts;
@@ -714,16 +715,17 @@ __global__ void __launch_bounds__(256) k_bb_emit(const BbChunk* __restrict__ chu
 __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                    const double* __restrict__ logPmf, HmmParams P, const uint16_t* __restrict__ psi,
                                                    const int32_t* __restrict__ state, const double* __restrict__ V, const double* __restrict__ carry, const int32_t* __restrict__ lastGuess,
-                                                   int32_t* __restrict__ fail) {
+                                                   int32_t* __restrict__ fail, int leadIn, const int32_t* __restrict__ todo) {
     extern __shared__ double sTab[];
     const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
     vit_stage_table(sTab, logPmf, P.tableLen, useLds);
     const int b = blockIdx.x * 64 + threadIdx.x;
-    const bool act = b < nblocks;
-    const VitBlock B = blocks[act ? b : nblocks - 1];
+    const bool actBlock = b < nblocks;
+    const VitBlock B = blocks[actBlock ? b : nblocks - 1];
     const HmmChrom C = chroms[B.chrom];
     const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;
-    const int64_t ts = tBeg > VW2 ? tBeg - VW2 : 0;                                // a multiple of 64: carry[] is defined there
+    const int64_t ts = tBeg > leadIn ? tBeg - leadIn : 0;                          // a multiple of 64: carry[] is defined there
+    const bool act = actBlock && (!todo || todo[B.chrom]);
     const int nsteps = act ? (int)(tEnd - ts) : 0;
     const int maxSteps = wave_max_i32(nsteps);
     const int32_t* __restrict__ ix = idx + C.begin + ts;
@@ -1140,27 +1142,42 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     std::vector<int32_t> redo;
     if (speculative && nblocks > 0) {
         ProfScope ps(ctx, "viterbi");
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dLast, 0xFF, nchr * 4, ctx->stream));     // -1 for skipped chromosomes
-        hipLaunchKernelGGL(k_vit_spec, dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, dMaps, dLast);
-        if (getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, chroms[0].begin + chroms[0].T / 2);
-        backtrack(true);
-        hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
-        const char* bbMode = getenv("CANVAS_HMM_BACKBONE");      // "chain" | "scan" | default: predicted pieces
-        if (bbMode && !strcmp(bbMode, "chain")) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
-        else if (bbMode && !strcmp(bbMode, "scan")) hipLaunchKernelGGL(k_vit_backbone_scan, dim3(nchr), dim3(BS_T), 0, ctx->stream, dChroms, dD, dCarry, dFail);
-        else {
-            hipLaunchKernelGGL(k_bb_sums, dim3(nchunks), dim3(256), 0, ctx->stream, dBChunks, dChroms, dD, dChunkSum, dFail);
-            hipLaunchKernelGGL(k_bb_bases, dim3(nchr), dim3(64), 0, ctx->stream, dFirstChunk, dChunkSum, dChunkBase);
-            hipLaunchKernelGGL(k_bb_pieces, dim3(nchunks), dim3(256), 0, ctx->stream, dBChunks, dChroms, dD, dChunkBase, dChunkOut, dCross, dAt64Fn, dAt64Rank, dFail);
-            hipLaunchKernelGGL(k_bb_walk, dim3(nchr), dim3(64), 0, ctx->stream, dFirstChunk, dChunkOut, dCross, dChunkBits, dPost, dFail);
-            hipLaunchKernelGGL(k_bb_emit, dim3(nblk2((int64_t)nchunks * 16, 256)), dim3(256), 0, ctx->stream, dBChunks, nchunks, dChroms, dChunkBits, dPost, dAt64Fn, dAt64Rank, dCarry);
+        // attempt 0: lead-ins of 128 / 64 steps.  Noisy samples (states that overlap heavily) forget their history more slowly: chromosomes
+        // whose verification fails are tried once more with 8x longer lead-ins before the sequential kernel takes them.
+        const int32_t* dTodo = nullptr;
+        ctx->hmm_retry = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const int leadSpec = attempt == 0 ? VW : 8 * VW, leadVer = attempt == 0 ? VW2 : 8 * VW2;
+            CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
+            hipLaunchKernelGGL(k_vit_spec, dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, dMaps, dLast, leadSpec, dTodo);
+            if (attempt == 0 && getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, chroms[0].begin + chroms[0].T / 2);
+            backtrack(true);
+            hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
+            const char* bbMode = getenv("CANVAS_HMM_BACKBONE");      // "chain" | "scan" | default: predicted pieces
+            if (bbMode && !strcmp(bbMode, "chain")) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
+            else if (bbMode && !strcmp(bbMode, "scan")) hipLaunchKernelGGL(k_vit_backbone_scan, dim3(nchr), dim3(BS_T), 0, ctx->stream, dChroms, dD, dCarry, dFail);
+            else {
+                hipLaunchKernelGGL(k_bb_sums, dim3(nchunks), dim3(256), 0, ctx->stream, dBChunks, dChroms, dD, dChunkSum, dFail);
+                hipLaunchKernelGGL(k_bb_bases, dim3(nchr), dim3(64), 0, ctx->stream, dFirstChunk, dChunkSum, dChunkBase);
+                hipLaunchKernelGGL(k_bb_pieces, dim3(nchunks), dim3(256), 0, ctx->stream, dBChunks, dChroms, dD, dChunkBase, dChunkOut, dCross, dAt64Fn, dAt64Rank, dFail);
+                hipLaunchKernelGGL(k_bb_walk, dim3(nchr), dim3(64), 0, ctx->stream, dFirstChunk, dChunkOut, dCross, dChunkBits, dPost, dFail);
+                hipLaunchKernelGGL(k_bb_emit, dim3(nblk2((int64_t)nchunks * 16, 256)), dim3(256), 0, ctx->stream, dBChunks, nchunks, dChroms, dChunkBits, dPost, dAt64Fn, dAt64Rank, dCarry);
+            }
+            hipLaunchKernelGGL(k_vit_verify, dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail, leadVer, dTodo);
+            std::vector<int32_t> hFail(nchr, 0);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            redo.clear();
+            for (int c = 0; c < nchr; c++) if (hFail[c] && chroms[c].T > 10) redo.push_back(c);
+            if (redo.empty() || getenv("CANVAS_HMM_TEST_CORRUPT") || getenv("CANVAS_HMM_NO_RETRY")) break;
+            if (attempt == 0) {      // the failed chromosomes become the to-do mask of the retry (dRedo doubles as the mask: nchr entries)
+                ctx->hmm_retry = (int)redo.size();
+                { ProfScope pr(ctx, "viterbi_retry"); }      // counted for the tests / bench
+                int32_t rcq = canvas_h2d_small(ctx, dRedo, hFail.data(), nchr * 4); if (rcq) return rcq;
+                dTodo = dRedo;
+            }
         }
-        hipLaunchKernelGGL(k_vit_verify, dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail);
-        std::vector<int32_t> hFail(nchr, 0);
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (int c = 0; c < nchr; c++) if (hFail[c] && chroms[c].T > 10) redo.push_back(c);
     } else {
         for (int c = 0; c < nchr; c++) redo.push_back(c);
     }
