@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Randomised parity soak of CanvasBin on the GPU against the oracle (not part of pytest).  usage: tools/soak_bin.py [minutes]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import oracle_lib as O
+from canvas_amd import Canvas, synth
+
+cv = Canvas(0)
+budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
+pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cv.device)
+rng = np.random.RandomState(7)
+t0 = time.time(); it = 0
+while time.time() - t0 < budget:
+    nchr = int(rng.choice([1, 2, 5]))
+    lengths = [int(rng.choice([4096, 4097, 65_537, 300_000, 1_000_003, 2_500_000])) + int(rng.randint(0, 5000)) for _ in range(nchr)]
+    rate = float(rng.choice([0.02, 0.105, 0.21, 0.9]))
+    seed = int(rng.randint(1, 2**31 - 1))
+    thr = synth.poisson_thresholds(rate)
+    data = [synth.generate_chromosome(seed, c, L, rate, thr) for c, L in enumerate(lengths)]
+    if rng.rand() < 0.3:      # leading stretch without possible positions / a saturated pile-up
+        b, h, m = data[0]; h = h.copy(); h[len(h) // 3: len(h) // 3 + 50] = 255; data[0] = (b, h, m)
+    bases = [dev(pad(b)) for b, h, m in data]; hits = [dev(pad(h)) for b, h, m in data]; masks = [dev(m.view(np.int64)) for b, h, m in data]
+    lens = np.array(lengths, np.int64)
+    mode = int(rng.choice([0, 3]))
+    if rng.rand() < 0.5:
+        bs = int(rng.choice([1, 2, 7, 64, 475, 534, 1000, 4096, 50_000]))
+    else:
+        _, _, r = cv.bin_rates(hits, masks, lens)
+        rr = [O.bin_rate(h, m) for b, h, m in data]
+        assert list(r) == rr, (seed, lengths)
+        bs = cv.bin_size_from_rates(r, 100); assert bs == O.bin_size(rr, 100)
+        if bs <= 0: continue
+    out, per, total = cv.bin_genome(bases, masks, hits, lens, bs, mode)
+    cv.synchronize()
+    exp = [O.bin_chromosome(b, m, h, bs, mode) for b, h, m in data]
+    assert total == sum(len(e[0]) for e in exp), (seed, lengths, bs, mode, total)
+    if total:
+        for k, j in (("start", 0), ("stop", 1), ("gc", 2)):
+            assert (out[k][:total].cpu().numpy() == np.concatenate([e[j] for e in exp])).all(), (k, seed, lengths, bs, mode)
+        assert (out["count"][:total].cpu().numpy() == np.concatenate([e[3] for e in exp]).astype(np.float32)).all(), (seed, lengths, bs, mode)
+    it += 1
+print(f"soak_bin: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s")
