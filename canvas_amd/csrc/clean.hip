@@ -31,8 +31,10 @@ __global__ void __launch_bounds__(256) k_keys_size(const int32_t* __restrict__ s
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) keys[i] = (uint32_t)(stop[i] - start[i]) ^ 0x80000000u;   // order-preserving image of int32
 }
-__global__ void __launch_bounds__(256) k_flags_size(const int32_t* __restrict__ start, const int32_t* __restrict__ stop, int64_t n, int32_t thresh, uint8_t* __restrict__ flags) {
+// threshold = the selected order statistic, read from the select's device result (no host round trip)
+__global__ void __launch_bounds__(256) k_flags_size(const int32_t* __restrict__ start, const int32_t* __restrict__ stop, int64_t n, const unsigned long long* __restrict__ dKey, uint8_t* __restrict__ flags) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int32_t thresh = (int32_t)((uint32_t)dKey[0] ^ 0x80000000u);
     if (i < n) flags[i] = (stop[i] - start[i]) <= thresh;       // CanvasClean.cs:349-352
 }
 // SignificantlyDifferent (CanvasClean.cs:363-381)
@@ -44,8 +46,10 @@ __device__ __forceinline__ bool sig_diff(float a, float b) {
     return chi2 > 6.635;
 }
 // RemoveOutliers (CanvasClean.cs:387-413)
-__global__ void __launch_bounds__(256) k_flags_outlier(const int32_t* __restrict__ chr, const float* __restrict__ count, int64_t n, uint8_t* __restrict__ flags) {
+// dN != NULL: the bin count is still on the device (the previous compaction was not synchronised); the grid covers an upper bound
+__global__ void __launch_bounds__(256) k_flags_outlier(const int32_t* __restrict__ chr, const float* __restrict__ count, int64_t n, const unsigned long long* __restrict__ dN, uint8_t* __restrict__ flags) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (dN) n = (int64_t)*dN;
     if (i >= n) return;
     bool hasPrev = i > 0, hasNext = i < n - 1;
     int32_t c = chr[i];
@@ -69,8 +73,9 @@ __global__ void __launch_bounds__(256) k_flags_localsd(const double* __restrict_
 }
 
 // ---------------------------------------------------------------- stable compaction (count / scan / scatter)
-__global__ void __launch_bounds__(256) k_block_count(const uint8_t* __restrict__ flags, int64_t n, uint32_t* __restrict__ blockCnt) {
+__global__ void __launch_bounds__(256) k_block_count(const uint8_t* __restrict__ flags, int64_t n, uint32_t* __restrict__ blockCnt, const unsigned long long* __restrict__ dN = nullptr) {
     __shared__ uint32_t sh[4];
+    if (dN) n = (int64_t)*dN;
     int64_t base = (int64_t)blockIdx.x * CBLK;
     uint32_t c = 0;
 #pragma unroll
@@ -98,8 +103,9 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* __restrict__ blo
     }
     if (threadIdx.x == 0) *total = carry;
 }
-__global__ void __launch_bounds__(256) k_scatter(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t n, Soa src, Soa dst) {
+__global__ void __launch_bounds__(256) k_scatter(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t n, Soa src, Soa dst, const unsigned long long* __restrict__ dN = nullptr) {
     __shared__ uint32_t sh[4];
+    if (dN) n = (int64_t)*dN;
     int64_t base = (int64_t)blockIdx.x * CBLK;
     uint32_t running = blockOff[blockIdx.x];
     for (int j = 0; j < CBLK / 256; j++) {
@@ -121,14 +127,16 @@ __global__ void __launch_bounds__(256) k_scatter(const uint8_t* __restrict__ fla
 }
 
 // ---------------------------------------------------------------- GC histogram / grouping
+// hist[0..100] = autosomal bins per GC value (what the reference's filters look at), hist[101..201] = the other bins: with both the host
+// knows how many bins a GC strip keeps without counting flags on the device
 __global__ void __launch_bounds__(256) k_gc_hist(const int32_t* __restrict__ chr, const int32_t* __restrict__ gc, const uint8_t* __restrict__ isAuto, int64_t n, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t lh[NGC];
-    if (threadIdx.x < NGC) lh[threadIdx.x] = 0;
+    __shared__ uint32_t lh[2 * NGC];
+    if (threadIdx.x < 2 * NGC) lh[threadIdx.x] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        if (isAuto[chr[i]]) atomicAdd(&lh[gc[i]], 1u);
+        atomicAdd(&lh[(isAuto[chr[i]] ? 0 : NGC) + gc[i]], 1u);
     __syncthreads();
-    if (threadIdx.x < NGC && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 // scatter the indices of autosomal bins into per-GC contiguous groups (order inside a group is irrelevant: only order statistics are taken)
 __global__ void __launch_bounds__(256) k_group_by_gc(const int32_t* __restrict__ chr, const int32_t* __restrict__ gc, const uint8_t* __restrict__ isAuto, int64_t n,
@@ -311,18 +319,31 @@ static int32_t compact(CleanState& st) {
     return CANVAS_OK;
 }
 
+// the same without the host round trip: the new count goes to *dOut, the old one may itself still be on the device (dN); st.n stays an upper bound
+static void compact_launch(CleanState& st, const unsigned long long* dN, unsigned long long* dOut) {
+    canvas_ctx* ctx = st.ctx;
+    int nb = (int)nblk(st.n, CBLK);
+    hipLaunchKernelGGL(k_block_count, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.n, st.blockCnt, dN);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, st.blockCnt, nb, dOut);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.blockCnt, st.n, st.cur, st.alt, dN);
+    std::swap(st.cur, st.alt);
+}
+
 struct GcGroups {              // autosomal bins grouped by GC
     uint32_t hist[NGC];
     std::vector<int64_t> segOff;   // NGC+1
     int64_t nauto;
 };
 
-static int32_t gc_histogram(CleanState& st, uint32_t* dHist, uint32_t* hist) {
+static int32_t gc_histogram(CleanState& st, uint32_t* dHist, uint32_t* hist, uint32_t* histOther = nullptr) {
     canvas_ctx* ctx = st.ctx;
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dHist, 0, NGC * 4, ctx->stream));
+    uint32_t both[2 * NGC];
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dHist, 0, 2 * NGC * 4, ctx->stream));
     if (st.n > 0) hipLaunchKernelGGL(k_gc_hist, dim3(std::min<unsigned>(nblk(st.n, 256), 1024u)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.gc, st.dIsAuto, st.n, dHist);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hist, dHist, NGC * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(both, dHist, sizeof both, hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(hist, both, NGC * 4);
+    if (histOther) memcpy(histOther, both + NGC, NGC * 4);
     return CANVAS_OK;
 }
 
@@ -618,8 +639,8 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     const int64_t nW0 = n / 20 + 2;
     WsSizer sz;
     sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n); sz.take<double>(n);
-    sz.take<uint8_t>(n); sz.take<uint32_t>(n / CBLK + 2); sz.take<unsigned long long>(1); sz.take<uint32_t>(n); sz.take<unsigned long long>(nW0); sz.take<uint32_t>(n);
-    sz.take<uint8_t>(nchr); sz.take<uint32_t>(NGC); sz.take<uint32_t>(NGC + 1); sz.take<uint32_t>(NGC); sz.take<double>(NGC); sz.take<VarTab>(1);
+    sz.take<uint8_t>(n); sz.take<uint32_t>(n / CBLK + 2); sz.take<unsigned long long>(2); sz.take<uint32_t>(n); sz.take<unsigned long long>(nW0); sz.take<uint32_t>(n);
+    sz.take<uint8_t>(nchr); sz.take<uint32_t>(2 * NGC); sz.take<uint32_t>(NGC + 1); sz.take<uint32_t>(NGC); sz.take<double>(NGC); sz.take<VarTab>(1);
     sz.take<uint8_t>(NGC); sz.take<double>(nW0); sz.take<double>(65536); sz.take<int64_t>(65536 + 1); sz.take<unsigned int>(1); sz.take<long long>(65536);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
     WsCarver ws(ctx->ws);
@@ -627,10 +648,10 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     st.cur = Soa{d_chr, d_start, d_stop, d_gc, d_count, nullptr};
     st.alt.chr = ws.take<int32_t>(n); st.alt.start = ws.take<int32_t>(n); st.alt.stop = ws.take<int32_t>(n); st.alt.gc = ws.take<int32_t>(n);
     st.alt.count = ws.take<float>(n); st.alt.dev = ws.take<double>(n); st.cur.dev = ws.take<double>(n);
-    st.flags = ws.take<uint8_t>(n); st.blockCnt = ws.take<uint32_t>(n / CBLK + 2); st.dTotal = ws.take<unsigned long long>(1);
+    st.flags = ws.take<uint8_t>(n); st.blockCnt = ws.take<uint32_t>(n / CBLK + 2); st.dTotal = ws.take<unsigned long long>(2);
     st.keys32 = ws.take<uint32_t>(n); st.keys64 = ws.take<unsigned long long>(nW0); st.gidx = ws.take<uint32_t>(n);
     st.dIsAuto = ws.take<uint8_t>(nchr);
-    uint32_t* dHist = ws.take<uint32_t>(NGC); uint32_t* dSegOff = ws.take<uint32_t>(NGC + 1); uint32_t* dCursor = ws.take<uint32_t>(NGC);
+    uint32_t* dHist = ws.take<uint32_t>(2 * NGC); uint32_t* dSegOff = ws.take<uint32_t>(NGC + 1); uint32_t* dCursor = ws.take<uint32_t>(NGC);
     double* dMedians = ws.take<double>(NGC); VarTab* dTab = ws.take<VarTab>(1); uint8_t* dKeepGc = ws.take<uint8_t>(NGC);
     double* dSd = ws.take<double>(nW0); double* dRunMedian = ws.take<double>(65536); int64_t* dRunStart = ws.take<int64_t>(65536 + 1);
     unsigned int* dCnt = ws.take<unsigned int>(1); long long* dPos = ws.take<long long>(65536);
@@ -638,23 +659,36 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     rc = canvas_h2d_small(ctx, st.dIsAuto, h_chr_is_autosome, nchr); if (rc) return rc;
     hipLaunchKernelGGL(k_fill_f64, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, st.cur.dev, n, -1.0);   // CountDeviation = -1 (GenomicBin.cs:83)
 
-    // RemoveBigBins (CanvasClean.cs:328-355)
+    // RemoveBigBins (CanvasClean.cs:328-355) and RemoveOutliers (CanvasClean.cs:387-413) without a host round trip in between: the size
+    // threshold is read by the flag kernel from the select's device result, the count after the first compaction stays on the device and the
+    // outlier kernels run on an upper-bound grid; both counts come back with ONE synchronisation.
+    const unsigned long long* dN = nullptr; bool sized = false;
+    unsigned long long* dTot2 = st.dTotal;           // two slots
     if (flags & CANVAS_CLEAN_FILTSIZE) {
         int64_t index = (int64_t)(0.98 * (double)st.n);
         if (index < st.n) {
             hipLaunchKernelGGL(k_keys_size, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.start, st.cur.stop, st.n, st.keys32);
-            std::vector<unsigned long long> res;
-            rc = radix_select<uint32_t>(ctx, st.keys32, 1, std::vector<int64_t>{0, st.n}, std::vector<SelQuery>{{0, 0, index}}, res); if (rc) return rc;
-            int32_t thresh = (int32_t)((uint32_t)res[0] ^ 0x80000000u);
-            hipLaunchKernelGGL(k_flags_size, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.start, st.cur.stop, st.n, thresh, st.flags);
-            rc = compact(st); if (rc) return rc;
+            std::vector<unsigned long long> res; const unsigned long long* dKey = nullptr;
+            rc = radix_select<uint32_t>(ctx, st.keys32, 1, std::vector<int64_t>{0, st.n}, std::vector<SelQuery>{{0, 0, index}}, res, &dKey); if (rc) return rc;
+            hipLaunchKernelGGL(k_flags_size, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.start, st.cur.stop, st.n, dKey, st.flags);
+            compact_launch(st, nullptr, dTot2 + 0);
+            dN = dTot2 + 0; sized = true;
         }
     }
-    info[0] = (int32_t)st.n;
-    // RemoveOutliers (CanvasClean.cs:387-413)
+    bool outl = false;
     if ((flags & CANVAS_CLEAN_OUTLIERS) && st.n > 0) {
-        hipLaunchKernelGGL(k_flags_outlier, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.count, st.n, st.flags);
-        rc = compact(st); if (rc) return rc;
+        hipLaunchKernelGGL(k_flags_outlier, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.count, st.n, dN, st.flags);
+        compact_launch(st, dN, dTot2 + 1);
+        dN = dTot2 + 1; outl = true;
+    }
+    info[0] = (int32_t)st.n;
+    if (sized || outl) {
+        unsigned long long tot[2] = {0, 0};
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(tot, dTot2, 16, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        if (sized) info[0] = (int32_t)tot[0];
+        st.n = (int64_t)(outl ? tot[1] : tot[0]);
     }
     info[1] = (int32_t)st.n;
     bool haveLocalSd = (flags & CANVAS_CLEAN_LOCALSD) && st.n >= 50000;   // CanvasClean.cs:483-486
@@ -674,25 +708,23 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
         }
     } else if ((flags & CANVAS_CLEAN_GCNORM) && st.n > 0) {
         // RemoveBinsWithExtremeGC (CanvasClean.cs:207-237)
-        GcGroups g;
-        rc = gc_histogram(st, dHist, g.hist); if (rc) return rc;
+        GcGroups g; uint32_t histOther[NGC];
+        rc = gc_histogram(st, dHist, g.hist, histOther); if (rc) return rc;
         double totalCount = 0;
         for (int i = 0; i < NGC; i++) totalCount += g.hist[i];
         int averageCountPerGC = std::max(min_bins_per_gc, (int)(totalCount / NGC));
         int threshold = std::min(100, averageCountPerGC);
         uint8_t keep[NGC]; int64_t kept = 0; bool dropsAny = false;
-        // number of surviving bins is only known after compaction (X/Y bins count too); decide emptiness from the flags
-        for (int i = 0; i < NGC; i++) { keep[i] = (int)g.hist[i] >= threshold; if (!keep[i]) dropsAny = true; }
-        rc = canvas_h2d_small(ctx, dKeepGc, keep, NGC); if (rc) return rc;
-        hipLaunchKernelGGL(k_flags_gc, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.gc, st.n, dKeepGc, st.flags);
-        // count survivors without moving data first: "strippedBins.Count == 0 -> proceed without GC correction" (CanvasClean.cs:500-505)
+        // survivors = bins of ANY chromosome whose GC value keeps enough autosomal bins; known from the two histograms, so "strippedBins.Count == 0
+        // -> proceed without GC correction" (CanvasClean.cs:500-505) needs no device count
+        for (int i = 0; i < NGC; i++) { keep[i] = (int)g.hist[i] >= threshold; if (!keep[i]) dropsAny = true; else kept += (int64_t)g.hist[i] + (int64_t)histOther[i]; }
         int nb = (int)nblk(st.n, CBLK);
-        hipLaunchKernelGGL(k_block_count, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.n, st.blockCnt);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, st.blockCnt, nb, st.dTotal);
-        unsigned long long tot = 0;
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&tot, st.dTotal, 8, hipMemcpyDeviceToHost, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        kept = (int64_t)tot;
+        if (kept > 0 && dropsAny && kept < st.n) {
+            rc = canvas_h2d_small(ctx, dKeepGc, keep, NGC); if (rc) return rc;
+            hipLaunchKernelGGL(k_flags_gc, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.gc, st.n, dKeepGc, st.flags);
+            hipLaunchKernelGGL(k_block_count, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.n, st.blockCnt);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, st.blockCnt, nb, st.dTotal);
+        }
         if (kept > 0) {
             if (dropsAny && kept < st.n) {
                 hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.blockCnt, st.n, st.cur, st.alt);

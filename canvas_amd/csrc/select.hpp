@@ -183,7 +183,7 @@ struct SelQuery { int32_t segLo, segHi; int64_t k; };
 // Runs all queries; results (keys as u64) are returned in `out`.  segOff has nseg+1 entries (host).  One sync at the end.
 template <typename K>
 static int32_t radix_select(canvas_ctx* ctx, const K* d_keys, int nseg, const std::vector<int64_t>& segOff,
-                            const std::vector<SelQuery>& queries, std::vector<unsigned long long>& out) {
+                            const std::vector<SelQuery>& queries, std::vector<unsigned long long>& out, const unsigned long long** d_results = nullptr) {
     const int nq = (int)queries.size();
     out.assign(nq, 0);
     if (nq == 0) return CANVAS_OK;
@@ -226,6 +226,10 @@ static int32_t radix_select(canvas_ctx* ctx, const K* d_keys, int nseg, const st
         hipLaunchKernelGGL((k_select_hist<K>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, d_keys, dTiles, dSegq, dPrefix, shift,
                            shift == bits - 8 ? 1 : 0, dHist, nq);
         hipLaunchKernelGGL(k_select_pick, dim3(nq), dim3(64), 0, ctx->stream, dHist, dPrefix, dK, nq);
+    }
+    if (d_results) {        // the consumer is a kernel: results stay on the device, no synchronisation.  The caller must synchronise the stream
+        *d_results = dPrefix;   // before the next radix_select (the pinned staging blob is reused from offset 0)
+        return CANVAS_OK;
     }
     unsigned long long* hres = (unsigned long long*)(h + oPrefix);
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hres, dPrefix, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
