@@ -192,8 +192,9 @@ __global__ void __launch_bounds__(256) k_apply_var(float* __restrict__ count, co
 // ---------------------------------------------------------------- local SD (CanvasClean.cs:268-298)
 // one thread per window of 20 consecutive count differences; sequential double arithmetic exactly as
 // Utilities.StandardDeviation(double[], start, end) (Utilities.cs:246-262)
-__global__ void __launch_bounds__(256) k_local_sd(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev) {
+__global__ void __launch_bounds__(256) k_local_sd(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev, const unsigned long long* __restrict__ dN = nullptr) {
     int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (dN) { const int64_t D = (int64_t)*dN - 1; nW = D >= 1 ? (D - 1) / 20 : 0; }      // the bin count is still on the device: grid = upper bound
     if (w >= nW) return;
     int64_t s = w * 20;
     double d[20];
@@ -236,8 +237,9 @@ __global__ void __launch_bounds__(256) k_absdev_keys(const double* __restrict__ 
 }
 // chromosome run boundaries of the bin list: positions i with chr[i] != chr[i-1]
 // pos[k] = (position << 20) | chromosome index (chromosome ids < 2^20, positions < 2^43), so one sort orders the records
-__global__ void __launch_bounds__(256) k_run_bounds(const int32_t* __restrict__ chr, int64_t n, unsigned int* __restrict__ cnt, long long* __restrict__ pos, int cap) {
+__global__ void __launch_bounds__(256) k_run_bounds(const int32_t* __restrict__ chr, int64_t n, unsigned int* __restrict__ cnt, long long* __restrict__ pos, int cap, const unsigned long long* __restrict__ dN = nullptr) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (dN) n = (int64_t)*dN;
     if (i >= n) return;
     const int32_t c = chr[i];
     if (i == 0 || c != chr[i - 1]) { unsigned int k = atomicAdd(cnt, 1u); if ((int)k < cap) pos[k] = (long long)((i << 20) | (long long)(c & 0xFFFFF)); }
@@ -495,21 +497,28 @@ static int32_t normalize_variance_by_gc(CleanState& st, const GcGroups& g, VarTa
 // GetLocalStandardDeviationAverage (CanvasClean.cs:243-298).  The value is only needed at the very end (RemoveBinsWithExtremeLocalSD and
 // the metric file), so the per-chromosome MAD runs on the context's side stream while the GC stages continue on the main one:
 // local_sd_begin enqueues it, local_sd_end waits for the result.
-static int32_t local_sd_begin(CleanState& st, double* dSd, double* dRunMedian, int64_t* dRunStart, unsigned int* dCnt, long long* dPos, int& nrunsOut) {
+struct LocalSdPending { unsigned int nb = 0; std::vector<long long> brec; };
+// part 1: window SDs and chromosome-run records; the bin count may still be on the device (dN).  No synchronisation: the records arrive
+// with the caller's next one.
+static int32_t local_sd_launch(CleanState& st, const unsigned long long* dN, double* dSd, unsigned int* dCnt, long long* dPos, LocalSdPending& P) {
+    canvas_ctx* ctx = st.ctx;
+    const int64_t Du = st.n - 1, nWu = Du >= 1 ? (Du - 1) / 20 : 0;        // upper bounds
+    if (nWu > 0) hipLaunchKernelGGL(k_local_sd, dim3(nblk(nWu, 256)), dim3(256), 0, ctx->stream, st.cur.count, nWu, dSd, st.cur.dev, dN);
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCnt, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_run_bounds, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.n, dCnt, dPos, 65536, dN);
+    P.brec.assign(1024, 0);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&P.nb, dCnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(P.brec.data(), dPos, 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));     // the usual case: all records in one go
+    return CANVAS_OK;
+}
+// part 2 (after a synchronisation, st.n exact): runs of windows per chromosome, then the per-run MAD on the side stream
+static int32_t local_sd_begin(CleanState& st, LocalSdPending& P, double* dSd, double* dRunMedian, int64_t* dRunStart, long long* dPos, int& nrunsOut) {
     canvas_ctx* ctx = st.ctx;
     const int64_t D = st.n - 1;
     const int64_t nW = D >= 1 ? (D - 1) / 20 : 0;    // windows with windowEnd = 20(w+1) < D
     if (nW <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "local SD: no complete window");
-    hipLaunchKernelGGL(k_local_sd, dim3(nblk(nW, 256)), dim3(256), 0, ctx->stream, st.cur.count, nW, dSd, st.cur.dev);
-    // chromosome runs of the bin list -> runs of windows (window w belongs to the chromosome of bin 20w)
     const int cap = 65536;
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCnt, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_run_bounds, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.n, dCnt, dPos, cap);
-    unsigned int nb = 0;
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&nb, dCnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<long long> brec(1024);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(brec.data(), dPos, 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));     // the usual case: all records in one go
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned int nb = P.nb; std::vector<long long>& brec = P.brec;
     if ((int)nb > cap) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "local SD: more than 65536 chromosome runs");
     if (nb > 1024) { brec.resize(nb); CANVAS_HIP_TRY(ctx, hipMemcpy(brec.data(), dPos, (size_t)nb * 8, hipMemcpyDeviceToHost)); }
     brec.resize(nb);
@@ -682,18 +691,22 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
         dN = dTot2 + 1; outl = true;
     }
     info[0] = (int32_t)st.n;
-    if (sized || outl) {
+    // the local-SD kernels go into the same stretch (on the upper-bound grid); whether the metric applies (>= 50000 bins, CanvasClean.cs:483-486)
+    // is decided once the count is back
+    LocalSdPending lsdPending; bool lsdLaunched = false;
+    if ((flags & CANVAS_CLEAN_LOCALSD) && st.n >= 50000) { rc = local_sd_launch(st, dN, dSd, dCnt, dPos, lsdPending); if (rc) return rc; lsdLaunched = true; }
+    if (sized || outl || lsdLaunched) {
         unsigned long long tot[2] = {0, 0};
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(tot, dTot2, 16, hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
         if (sized) info[0] = (int32_t)tot[0];
-        st.n = (int64_t)(outl ? tot[1] : tot[0]);
+        if (sized || outl) st.n = (int64_t)(outl ? tot[1] : tot[0]);
     }
     info[1] = (int32_t)st.n;
     bool haveLocalSd = (flags & CANVAS_CLEAN_LOCALSD) && st.n >= 50000;   // CanvasClean.cs:483-486
     int sdRuns = 0;
-    if (haveLocalSd) { rc = local_sd_begin(st, dSd, dRunMedian, dRunStart, dCnt, dPos, sdRuns); if (rc) return rc; }
+    if (haveLocalSd) { rc = local_sd_begin(st, lsdPending, dSd, dRunMedian, dRunStart, dPos, sdRuns); if (rc) return rc; }
     if ((flags & CANVAS_CLEAN_GCNORM) && st.n > 0 && loessMode) {
         // -m LOESS: no GC strip (CanvasClean.cs:497-499); variance normalisation still uses the MedianByGC quartiles
         rc = normalize_by_gc_loess(st, nchr, h_chr_is_y); if (rc) return rc;
