@@ -394,6 +394,220 @@ __global__ void __launch_bounds__(64) k_bin_pass_edges(const BinChrom* __restric
     bin_tile<false>(C, gtile, tileStart, p0c, rankBase[gtile], binOffset[c], binSize, clampHits, stopOut, locC, locG, tileTotC, tileTotG);
 }
 
+// ---------------------------------------------------------------------------------------------- single-read path (bin size not known yet)
+// When the bin size has to be derived from the sample's own hit rates (CanvasBin.cs:30-83) the per-base arrays would be streamed twice:
+// once for the rates, once for the binning.  Instead the first pass reads bases, hits and mask ONCE and leaves, next to the rate
+// inputs, a 4-byte summary of every 64 positions (one mask word): possible count (7 bits), G/C count (7 bits) and the summed
+// (masked, mode-clamped) hits (14 bits).  None of them depends on the bin size.  After the host has fixed the bin size, k_bin_close
+// walks the summaries (1/34 of the per-base bytes) and opens the per-base arrays only for the 64 positions that hold a bin boundary.
+#define SUM_POP(s) ((s) & 127u)
+#define SUM_GC(s) (((s) >> 7) & 127u)
+#define SUM_HITS(s) ((s) >> 14)
+
+// One tile per wave.  FULL: the tile lies inside [0, len) and not across pos0; `vm` = 0xFFFF (tile at/after pos0) or 0 (tile before pos0:
+// positions in front of the first non-'n' base count as possible/observed for the rates but carry no bin data).
+template <bool FULL>
+__device__ __forceinline__ void summarize_tile(const BinChrom& C, int64_t gtile, int64_t tileStart, int64_t p0c, uint32_t vm, int clampHits, int wantObs,
+                                               uint32_t* __restrict__ S, uint32_t* __restrict__ tilePop, uint32_t* __restrict__ tileObs,
+                                               uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
+    const int l = lane_id();
+    uint4 vb[4], vh[4];
+    uint32_t m16[4];
+    if (FULL) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            int64_t p = tileStart + it * 1024 + l * 16;
+            vb[it] = *reinterpret_cast<const uint4*>(C.bases + p);
+            vh[it] = *reinterpret_cast<const uint4*>(C.hits + p);
+            m16[it] = reinterpret_cast<const uint16_t*>(C.mask)[p >> 4];
+        }
+    }
+    uint32_t keep = 0, obs = 0;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int64_t p = tileStart + it * 1024 + l * 16;
+        uint32_t wb[4], wh[4], mRank, vmask = vm;
+        if (FULL) {
+            wb[0] = vb[it].x; wb[1] = vb[it].y; wb[2] = vb[it].z; wb[3] = vb[it].w;
+            wh[0] = vh[it].x; wh[1] = vh[it].y; wh[2] = vh[it].z; wh[3] = vh[it].w;
+            mRank = m16[it];
+        } else {
+            mRank = 0; vmask = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { wb[q] = 0; wh[q] = 0; }
+            for (int i = 0; i < 16; i++) {
+                int64_t pi = p + i;
+                if (pi < C.len) {
+                    uint32_t mbit = (uint32_t)((C.mask[pi >> 6] >> (pi & 63)) & 1ull);
+                    mRank |= mbit << i;
+                    wb[i >> 2] |= (uint32_t)C.bases[pi] << (8 * (i & 3));
+                    wh[i >> 2] |= (uint32_t)C.hits[pi] << (8 * (i & 3));
+                    if (pi >= p0c) vmask |= 1u << i;
+                }
+            }
+        }
+        const uint32_t mVal = mRank & vmask;
+        uint32_t g;
+        if (FULL) g = vmask ? __popc(gc_marks4(wb[0])) + __popc(gc_marks4(wb[1])) + __popc(gc_marks4(wb[2])) + __popc(gc_marks4(wb[3])) : 0u;
+        else g = __popc((marks_to_bits4(gc_marks4(wb[0])) | (marks_to_bits4(gc_marks4(wb[1])) << 4) | (marks_to_bits4(gc_marks4(wb[2])) << 8) | (marks_to_bits4(gc_marks4(wb[3])) << 12)) & vmask);
+        const bool needClamp = clampHits && __any((int)((any_byte_gt10(wh[0]) | any_byte_gt10(wh[1]) | any_byte_gt10(wh[2]) | any_byte_gt10(wh[3])) != 0u));
+        uint32_t cl = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t h = needClamp ? clamp10_bytes(wh[q]) : wh[q];
+            cl = sum_bytes(h & expand4(mVal >> (4 * q)), cl);
+        }
+        if (wantObs) obs += nonzero_bytes4(wh[0]) + nonzero_bytes4(wh[1]) + nonzero_bytes4(wh[2]) + nonzero_bytes4(wh[3]);
+        // the four lanes of a quad hold one mask word (64 positions): the packed fields cannot carry into each other (64, 64, 16320)
+        uint32_t q4 = (uint32_t)__popc(mRank) | (g << 7) | (cl << 14);
+        q4 += __shfl_xor(q4, 1, 64);
+        q4 += __shfl_xor(q4, 2, 64);
+        if ((l & 3) == it) keep = q4;
+    }
+    // lane 4j+i keeps word 16*i + j of the tile
+    S[gtile * 64 + (l & 3) * 16 + (l >> 2)] = keep;
+    const uint32_t pg = wave_reduce_add_u32(SUM_POP(keep) | (SUM_GC(keep) << 16));
+    const uint32_t ct = wave_reduce_add_u32(SUM_HITS(keep));
+    if (wantObs) obs = wave_reduce_add_u32(obs);
+    if (l == 0) { tilePop[gtile] = pg & 0xFFFFu; tileTotG[gtile] = pg >> 16; tileTotC[gtile] = ct; if (wantObs) tileObs[gtile] = obs; }
+}
+__global__ void __launch_bounds__(256) k_tile_summary(const BinChrom* __restrict__ ch, int nchr, int64_t ntilesTotal, const unsigned long long* __restrict__ pos0,
+                                                      int clampHits, int wantObs, uint32_t* __restrict__ S, uint32_t* __restrict__ tilePop, uint32_t* __restrict__ tileObs,
+                                                      uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
+    // the wave index is uniform: telling the compiler so keeps the chromosome lookup on the scalar unit
+    const int64_t gtile = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (gtile >= ntilesTotal) return;
+    const int c = find_chrom(ch, nchr, gtile);
+    const BinChrom C = ch[c];
+    const int64_t tileStart = (gtile - C.tileBase) << TILE_SHIFT;
+    const int64_t p0c = (int64_t)pos0[c];
+    if (tileStart + TILE > C.len) return;                                   // partial tail: k_tile_summary_edges
+    if (tileStart < p0c && tileStart + TILE > p0c) return;                  // the tile pos0 falls into: k_tile_summary_edges
+    summarize_tile<true>(C, gtile, tileStart, p0c, tileStart >= p0c ? 0xFFFFu : 0u, clampHits, wantObs, S, tilePop, tileObs, tileTotC, tileTotG);
+}
+// at most two edge tiles per chromosome: block 2c -> the tile pos0 falls into (if it is not tile-aligned), block 2c+1 -> the partial tail tile
+__global__ void __launch_bounds__(64) k_tile_summary_edges(const BinChrom* __restrict__ ch, int nchr, const unsigned long long* __restrict__ pos0,
+                                                           int clampHits, int wantObs, uint32_t* __restrict__ S, uint32_t* __restrict__ tilePop, uint32_t* __restrict__ tileObs,
+                                                           uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
+    const int c = blockIdx.x >> 1, which = blockIdx.x & 1;
+    if (c >= nchr) return;
+    const BinChrom C = ch[c];
+    const int64_t p0c = (int64_t)pos0[c];
+    const int64_t tailTile = C.ntiles - 1;
+    const bool tailPartial = (tailTile << TILE_SHIFT) + TILE > C.len;
+    int64_t t;
+    if (which == 1) { if (!tailPartial) return; t = tailTile; }
+    else {
+        if (p0c >= C.len) return;                                           // no non-'n' base: every tile is "before pos0"
+        t = p0c >> TILE_SHIFT;
+        if ((t << TILE_SHIFT) == p0c) return;                               // tile-aligned pos0: nothing straddles
+        if (t == tailTile && tailPartial) return;                           // the tail block takes it
+    }
+    summarize_tile<false>(C, C.tileBase + t, t << TILE_SHIFT, p0c, 0u, clampHits, wantObs, S, tilePop, tileObs, tileTotC, tileTotG);
+}
+
+// Second pass of the single-read path, step 1: one tile per wave, one 64-position summary per lane.  The scans are the ones of bin_tile at
+// a coarser grain.  A lane whose word holds a boundary only records WHERE the bin closes (word start | rank inside the word - 1) and
+// the sums in front of the word; k_bin_resolve opens the per-base arrays with one thread per bin (all lanes busy, no dependent-load chain
+// inside a mostly idle wave).
+#define CLOSE_TILES 4       // tiles per wave: their summary loads are issued together (the kernel is latency-bound, not bandwidth-bound)
+__global__ void __launch_bounds__(256) k_bin_close(const BinChrom* __restrict__ ch, int nchr, int64_t ntilesTotal, const uint32_t* __restrict__ S,
+                                                   const int32_t* __restrict__ rankBase, const long long* __restrict__ binOffset, int binSize,
+                                                   int32_t* __restrict__ stopOut, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG, int32_t* __restrict__ oChr) {
+    const int64_t gtile0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * CLOSE_TILES;   // uniform: scalar lookups
+    if (gtile0 >= ntilesTotal) return;
+    const int l = lane_id();
+    uint32_t sv[CLOSE_TILES]; int32_t rk[CLOSE_TILES];
+#pragma unroll
+    for (int t = 0; t < CLOSE_TILES; t++) {
+        const bool in = gtile0 + t < ntilesTotal;
+        sv[t] = in ? S[(gtile0 + t) * 64 + l] : 0u;
+        rk[t] = in ? rankBase[gtile0 + t] : 0;
+    }
+    int c = find_chrom(ch, nchr, gtile0);
+    int64_t tileBase = ch[c].tileBase, tileEnd = tileBase + ch[c].ntiles;
+    long long boff = binOffset[c];
+#pragma unroll
+    for (int t = 0; t < CLOSE_TILES; t++) {
+        const int64_t gtile = gtile0 + t;
+        if (gtile >= ntilesTotal) break;
+        while (gtile >= tileEnd) { c++; tileBase = ch[c].tileBase; tileEnd = tileBase + ch[c].ntiles; boff = binOffset[c]; }
+        const uint32_t s = sv[t];
+        const uint32_t pop = SUM_POP(s);
+        const uint32_t pg = pop | (SUM_GC(s) << 16), cl = SUM_HITS(s);
+        const uint32_t pgInc = wave_inclusive_scan_u32(pg), cInc = wave_inclusive_scan_u32(cl);
+        const int32_t r = rk[t] + (int32_t)((pgInc - pg) & 0xFFFFu);        // rank before this lane's word
+        if (pop > 0 && r + (int32_t)pop >= binSize) {
+            const uint32_t gEx = (pgInc - pg) >> 16, cEx = cInc - cl;
+            const int64_t wstart = ((gtile - tileBase) << TILE_SHIFT) + (int64_t)l * 64;
+            const int32_t rr = r < 0 ? 0 : r;
+            uint32_t nextB = ((uint32_t)rr / (uint32_t)binSize + 1u) * (uint32_t)binSize;
+            while ((int64_t)nextB - r <= (int64_t)pop && (int64_t)nextB - r >= 1) {
+                const long long bin = boff + (long long)(nextB / (uint32_t)binSize) - 1;
+                stopOut[bin] = (int32_t)(wstart + ((int64_t)nextB - r - 1));    // the (nextB - r)-th possible position of the word closes the bin
+                locC[bin] = cEx;
+                locG[bin] = gEx;
+                oChr[bin] = c;
+                nextB += (uint32_t)binSize;
+            }
+        }
+    }
+}
+// step 2: four lanes per bin (one 16-byte slice of the word's bases / hits each, so a bin's loads are in flight together and coalesce to 64 B).
+// Turns the record of k_bin_close into the stop position and adds the sums of the word's head.
+__global__ void __launch_bounds__(256) k_bin_resolve(const BinChrom* __restrict__ ch, int nchr, const long long* __restrict__ binOffset,
+                                                     const unsigned long long* __restrict__ pos0, int clampHits,
+                                                     const int32_t* __restrict__ oChr, int32_t* __restrict__ stopIO, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = t >> 2;
+    const int sub = (int)(t & 3);
+    if (i >= binOffset[nchr]) return;                                        // whole quads leave together
+    const int32_t rec = stopIO[i];
+    const int c = oChr[i];                                                   // left by k_bin_close
+    const uint8_t* __restrict__ bases = ch[c].bases; const uint8_t* __restrict__ hits = ch[c].hits;
+    const int64_t len = ch[c].len;
+    const int64_t p0c = (int64_t)pos0[c];
+    const int64_t wstart = (int64_t)(rec & ~63);
+    uint32_t kk = (uint32_t)(rec & 63) + 1u;
+    const int64_t cstart = wstart + 16 * sub;                                // this lane's slice
+    uint64_t mw = ch[c].mask[wstart >> 6];
+    uint32_t wb[4] = {0, 0, 0, 0}, wh[4] = {0, 0, 0, 0};
+    if (cstart + 16 <= len) {
+        const uint4 b = *reinterpret_cast<const uint4*>(bases + cstart), h = *reinterpret_cast<const uint4*>(hits + cstart);
+        wb[0] = b.x; wb[1] = b.y; wb[2] = b.z; wb[3] = b.w; wh[0] = h.x; wh[1] = h.y; wh[2] = h.z; wh[3] = h.w;
+    } else {
+        for (int j = 0; j < 16; j++) { const int64_t pi = cstart + j; if (pi < len) { wb[j >> 2] |= (uint32_t)bases[pi] << (8 * (j & 3)); wh[j >> 2] |= (uint32_t)hits[pi] << (8 * (j & 3)); } }
+    }
+    uint64_t valid = ~0ull;                                                  // positions that carry bin data: pos0 <= p < len
+    if (len - wstart < 64) { valid = (~0ull) >> (64 - (len - wstart)); mw &= valid; }
+    if (wstart < p0c) valid = (p0c - wstart >= 64) ? 0ull : (valid & ((~0ull) << (p0c - wstart)));
+    uint32_t pos = 0, cnt;                                                   // the kk-th set bit of mw closes the bin
+    uint64_t m = mw;
+    cnt = __popc((uint32_t)m);           if (kk > cnt) { kk -= cnt; pos += 32; m >>= 32; }
+    cnt = __popc((uint32_t)m & 0xFFFFu); if (kk > cnt) { kk -= cnt; pos += 16; m >>= 16; }
+    cnt = __popc((uint32_t)m & 0xFFu);   if (kk > cnt) { kk -= cnt; pos += 8; m >>= 8; }
+    cnt = __popc((uint32_t)m & 0xFu);    if (kk > cnt) { kk -= cnt; pos += 4; m >>= 4; }
+    cnt = __popc((uint32_t)m & 0x3u);    if (kk > cnt) { kk -= cnt; pos += 2; m >>= 2; }
+    cnt = (uint32_t)m & 1u;              if (kk > cnt) { pos += 1; }
+    const uint64_t head = valid & ((2ull << pos) - 1ull);                    // valid positions <= pos (pos = 63: all of them)
+    const uint32_t head16 = (uint32_t)(head >> (16 * sub)) & 0xFFFFu, mVal16 = (uint32_t)(mw >> (16 * sub)) & head16;
+    uint32_t gc16 = 0, hc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        gc16 |= marks_to_bits4(gc_marks4(wb[q])) << (4 * q);
+        const uint32_t h = clampHits ? clamp10_bytes(wh[q]) : wh[q];
+        hc = sum_bytes(h & expand4(mVal16 >> (4 * q)), hc);
+    }
+    uint32_t hg = __popc(gc16 & head16);
+    hc += __shfl_xor(hc, 1, 64); hg += __shfl_xor(hg, 1, 64);
+    hc += __shfl_xor(hc, 2, 64); hg += __shfl_xor(hg, 2, 64);
+    if (sub == 0) {
+        stopIO[i] = (int32_t)(wstart + pos + 1);
+        locC[i] += hc;
+        locG[i] += hg;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- k_scan_totals
 __global__ void __launch_bounds__(1024) k_scan_totals(const BinChrom* __restrict__ ch, uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
     __shared__ U2 sh[2][16];
@@ -697,6 +911,10 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     sz.take<BinChrom>(nchr); sz.take<unsigned long long>(nchr); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles); sz.take<int32_t>(plan.ntiles);
     sz.take<ChromOut>(nchr); sz.take<long long>(nchr + 1); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles);
     sz.take<int32_t>(ub + 1); sz.take<uint32_t>(ub + 1); sz.take<uint32_t>(ub + 1);
+    // bases/hits/mask streamed once (see k_tile_summary) when the rates are needed too; CANVAS_BIN_SINGLE_READ=1 takes that path for a given bin
+    // size as well and CANVAS_BIN_TWO_PASS=1 never takes it (both are test hooks: the two paths must agree bit for bit)
+    const bool singleRead = (needRates && !getenv("CANVAS_BIN_TWO_PASS")) || getenv("CANVAS_BIN_SINGLE_READ");
+    if (singleRead) sz.take<uint32_t>(plan.ntiles * 64);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + sizeof(ChromOut))); if (rc) return rc;
     WsCarver ws(ctx->ws);
@@ -705,17 +923,28 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     ChromOut* dOut = ws.take<ChromOut>(nchr); long long* binOffset = ws.take<long long>(nchr + 1);
     uint32_t* tileTotC = ws.take<uint32_t>(plan.ntiles); uint32_t* tileTotG = ws.take<uint32_t>(plan.ntiles);
     int32_t* stopTmp = ws.take<int32_t>(ub + 1); uint32_t* locC = ws.take<uint32_t>(ub + 1); uint32_t* locG = ws.take<uint32_t>(ub + 1);
+    uint32_t* wordSum = singleRead ? ws.take<uint32_t>(plan.ntiles * 64) : nullptr;
+    const int clampHits = mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0;
     memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
     ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
     hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);
     hipLaunchKernelGGL(k_find_pos0, dim3(64, nchr), dim3(256), 0, ctx->stream, dCh, dPos0);
-    { ProfScope ps(ctx, "bin_tile_stats");
-      hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, needRates ? 1 : 0, tilePop, tileObs); }
+    if (singleRead) {
+        ProfScope ps(ctx, "bin_summary");
+        hipLaunchKernelGGL(k_tile_summary, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, clampHits, needRates ? 1 : 0,
+                           wordSum, tilePop, tileObs, tileTotC, tileTotG);
+    } else {
+        ProfScope ps(ctx, "bin_tile_stats");
+        hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, needRates ? 1 : 0, tilePop, tileObs);
+    }
+    if (singleRead) hipLaunchKernelGGL(k_tile_summary_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG);
     if (needRates) {
         // rates (CanvasBin.cs:30-83): totals per chromosome, then the bin size on the host
         hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut);
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
+        // the tile totals of the single-read path do not depend on the bin size either: their scan runs while the host derives it
+        if (singleRead) hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<double> rates;
         for (int c = 0; c < nchr; c++) if (h_is_auto[c]) rates.push_back((int)hOut[c].obs / (double)(int)hOut[c].pop);
@@ -736,12 +965,20 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     if (h_nbins_total) *h_nbins_total = total;
     if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_bin_genome: output capacity too small (see canvas_bin_count_upper_bound)");
     if (total == 0) return CANVAS_OK;
-    { ProfScope ps(ctx, "bin_pass");
-      hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
-                         binOffset, bin_size, mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, stopTmp, locC, locG, tileTotC, tileTotG); }
-    hipLaunchKernelGGL(k_bin_pass_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, rankBase, binOffset, bin_size,
-                       mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, stopTmp, locC, locG, tileTotC, tileTotG);
-    hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
+    if (singleRead) {
+        if (!needRates) hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
+        ProfScope ps(ctx, "bin_close");
+        hipLaunchKernelGGL(k_bin_close, dim3((unsigned)((plan.ntiles + 4 * CLOSE_TILES - 1) / (4 * CLOSE_TILES))), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, wordSum, rankBase,
+                           binOffset, bin_size, stopTmp, locC, locG, d_chr);
+        hipLaunchKernelGGL(k_bin_resolve, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, clampHits, d_chr, stopTmp, locC, locG);
+    } else {
+        { ProfScope ps(ctx, "bin_pass");
+          hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
+                             binOffset, bin_size, clampHits, stopTmp, locC, locG, tileTotC, tileTotG); }
+        hipLaunchKernelGGL(k_bin_pass_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, rankBase, binOffset, bin_size,
+                           clampHits, stopTmp, locC, locG, tileTotC, tileTotG);
+        hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
+    }
     hipLaunchKernelGGL(k_bin_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, stopTmp, locC, locG,
                        tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count);
     if (gcw) hipLaunchKernelGGL(k_bin_weighted, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, d_count);

@@ -11,6 +11,14 @@ pytestmark = pytest.mark.gpu
 SEED = 20260927 + 1
 
 
+@pytest.fixture(params=["two_pass", "single_read"])
+def bin_path(request, monkeypatch):
+    """Both CanvasBin device paths run every case: the two-pass path (k_tile_stats + k_bin_pass) and the single-read path
+    (k_tile_summary + k_bin_close) that one-call binning takes when the bin size comes from the sample's own rates."""
+    monkeypatch.setenv("CANVAS_BIN_SINGLE_READ" if request.param == "single_read" else "CANVAS_BIN_TWO_PASS", "1")
+    return request.param
+
+
 def _chroms(lengths, rate=0.105):
     thr = synth.poisson_thresholds(rate)
     return [synth.generate_chromosome(SEED, c, L, rate, thr) for c, L in enumerate(lengths)]
@@ -37,7 +45,7 @@ def test_device_synth_matches_numpy():
 
 
 @pytest.mark.parametrize("lengths,bin_size", [([1_500_000, 700_001, 40_961], None), ([300_000], 37), ([200_000, 5_000], 7), ([1_000_000], 5000)])
-def test_bin_genome_matches_oracle(lengths, bin_size):
+def test_bin_genome_matches_oracle(lengths, bin_size, bin_path):
     cv = get_canvas()
     data = _chroms(lengths)
     bases, hits, masks = _upload(cv, data)
@@ -66,7 +74,7 @@ def test_bin_genome_matches_oracle(lengths, bin_size):
         assert total == off
 
 
-def test_bin_edge_cases():
+def test_bin_edge_cases(bin_path):
     cv = get_canvas()
     # all-'n' chromosome (no bins), chromosome with fewer possible positions than one bin, unscreened hits outside the mask
     L = 10_000
@@ -96,7 +104,7 @@ def test_bin_edge_cases():
                 off += len(es)
 
 
-def test_bin_sample_one_call_equals_two_step_flow():
+def test_bin_sample_one_call_equals_two_step_flow(bin_path):
     import torch
     cv = get_canvas()
     lengths = [900_000, 500_001, 300_000]
@@ -146,7 +154,7 @@ def test_prep_kernels_mask_filter_screen():
         assert (dh.cpu().numpy()[:L] == np.where(exp, hits, 0)).all()
 
 
-def test_bin_gc_content_weighted_mode():
+def test_bin_gc_content_weighted_mode(bin_path):
     """CanvasBin -m GCContentWeighted (CanvasBin.cs:416-506, 330-405, 626-636) vs the oracle"""
     import torch
     cv = get_canvas()

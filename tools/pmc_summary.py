@@ -8,6 +8,7 @@ import json
 import sys
 
 fetch_csv, write_csv, out_txt, out_json = sys.argv[1:5]
+kernel = sys.argv[5] if len(sys.argv) > 5 else "k_tile_summary"
 
 
 def load(path):
@@ -18,7 +19,7 @@ def load(path):
 
 
 F, W = load(fetch_csv), load(write_csv)
-stream16 = {"k_bin_pass", "k_tile_stats"}     # kernels whose reads are 16 B/lane coalesced streams
+stream16 = {"k_bin_pass", "k_tile_stats", "k_tile_summary"}     # kernels whose reads are 16 B/lane coalesced streams
 rows = []
 for k in sorted(set(F) | set(W), key=lambda k: -(sum(F.get(k, [0])) + sum(W.get(k, [0])))):
     f = sum(F.get(k, [0])) / max(1, len(F.get(k, [1]))) * 1024.0
@@ -30,7 +31,7 @@ with open(out_txt, "w") as o:
     o.write("%-44s %6s %16s %5s %16s %16s\n" % ("kernel", "calls", "FETCH_SIZE_B", "corr", "WRITE_SIZE_B", "HBM_bytes"))
     for r in rows[:40]:
         o.write("%-44s %6d %16.0f %5.1f %16.0f %16.0f\n" % (r[0][:44], r[1], r[2], r[3], r[4], r[5]))
-bp = [r for r in rows if r[0] == "k_bin_pass"][0]
-json.dump({"kernel": "k_bin_pass", "fetch_size_bytes_reported": bp[2], "fetch_correction": bp[3], "write_size_bytes": bp[4], "hbm_bytes_per_launch": bp[5],
+bp = [r for r in rows if r[0] == kernel][0]
+json.dump({"kernel": kernel, "fetch_size_bytes_reported": bp[2], "fetch_correction": bp[3], "write_size_bytes": bp[4], "hbm_bytes_per_launch": bp[5],
            "workload": {"scale": 1.0, "rate": 0.21}}, open(out_json, "w"), indent=1)
 print(open(out_txt).read()[:2500])

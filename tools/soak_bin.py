@@ -13,7 +13,7 @@ budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
 pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cv.device)
 rng = np.random.RandomState(7)
-t0 = time.time(); it = 0
+t0 = time.time(); it = 0; npath = {}
 while time.time() - t0 < budget:
     nchr = int(rng.choice([1, 2, 5]))
     lengths = [int(rng.choice([4096, 4097, 65_537, 300_000, 1_000_003, 2_500_000])) + int(rng.randint(0, 5000)) for _ in range(nchr)]
@@ -23,6 +23,12 @@ while time.time() - t0 < budget:
     data = [synth.generate_chromosome(seed, c, L, rate, thr) for c, L in enumerate(lengths)]
     if rng.rand() < 0.3:      # leading stretch without possible positions / a saturated pile-up
         b, h, m = data[0]; h = h.copy(); h[len(h) // 3: len(h) // 3 + 50] = 255; data[0] = (b, h, m)
+    if rng.rand() < 0.5:      # leading 'n' stretch of random length (pos0 inside / at / beyond a tile; possible positions in front of it stay set)
+        c = int(rng.randint(0, nchr)); b, h, m = data[c]; b = b.copy()
+        k = int(rng.choice([1, 63, 64, 100, 4095, 4096, 4097, 9000, len(b)])); b[:min(k, len(b))] = ord("n"); data[c] = (b, h, m)
+    path = "CANVAS_BIN_SINGLE_READ" if rng.rand() < 0.6 else "CANVAS_BIN_TWO_PASS"
+    os.environ.pop("CANVAS_BIN_SINGLE_READ", None); os.environ.pop("CANVAS_BIN_TWO_PASS", None); os.environ[path] = "1"
+    npath[path] = npath.get(path, 0) + 1
     bases = [dev(pad(b)) for b, h, m in data]; hits = [dev(pad(h)) for b, h, m in data]; masks = [dev(m.view(np.int64)) for b, h, m in data]
     lens = np.array(lengths, np.int64)
     mode = int(rng.choice([0, 3]))
@@ -37,10 +43,10 @@ while time.time() - t0 < budget:
     out, per, total = cv.bin_genome(bases, masks, hits, lens, bs, mode)
     cv.synchronize()
     exp = [O.bin_chromosome(b, m, h, bs, mode) for b, h, m in data]
-    assert total == sum(len(e[0]) for e in exp), (seed, lengths, bs, mode, total)
+    assert total == sum(len(e[0]) for e in exp), (seed, lengths, bs, mode, total, path)
     if total:
         for k, j in (("start", 0), ("stop", 1), ("gc", 2)):
-            assert (out[k][:total].cpu().numpy() == np.concatenate([e[j] for e in exp])).all(), (k, seed, lengths, bs, mode)
+            assert (out[k][:total].cpu().numpy() == np.concatenate([e[j] for e in exp])).all(), (k, seed, lengths, bs, mode, path)
         assert (out["count"][:total].cpu().numpy() == np.concatenate([e[3] for e in exp]).astype(np.float32)).all(), (seed, lengths, bs, mode)
     it += 1
-print(f"soak_bin: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s")
+print(f"soak_bin: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s; paths {npath}")
