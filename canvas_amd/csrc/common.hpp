@@ -33,6 +33,7 @@ struct canvas_ctx {
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
     long long cbs_dev[6] = {0, 0, 0, 0, 0, 0};   // counters of the device permutation engine (canvas_cbs_device_stats)
+    long long wv_levels = 0, wv_redone = 0;   // last canvas_wavelets call: tree levels processed, nodes recomputed by the exact chain
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
     int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
     // profiling: hipEvent pairs around named kernels

@@ -1,0 +1,515 @@
+// CanvasPartition -m Wavelets (the reference's default method): unbalanced Haar segmentation.
+//   reference: CanvasPartition/WaveletSegmentation.cs:19-428 (GetInnerProdIter, GetInnerProdMax, FindBestUnbalancedHaarDecomposition, HardThresh,
+//              GetReconstructedVector, GetSegments, GetBreakpointsAfterHealingBadSplits, RefineSegments, HaarWavelets),
+//              WaveletsRunner.cs:52-150 (Run / LaunchWavelets), Segmentation.cs:297-429 (coverage variability inputs).
+//
+// Where the time goes in the reference: every node of the top-down tree runs GetInnerProdIter over its stretch of the chromosome,
+// a pair of first-order recurrences
+//     I+[m] = I+[m-1] * f_m + x_m * g_m          I-[m] = I-[m-1] / f_m - x_m / h_m          (f, g, h: square roots of ratios of n and m)
+// behind a sequential sum of the stretch, and takes the first arg-max of |I+ - I-|.  A level of the tree costs one sweep of the
+// chromosome; a whole-genome sample needs ~35 sweeps.  The recurrences are rounded at every step, so they cannot be re-associated:
+// the order of operations below is exactly the reference's.
+//
+// Device mapping (one launch set per tree LEVEL, all chromosomes and all nodes of the level at once):
+//   * coefficients f, g*x, x/h (6 divisions + 3 square roots per element) carry no dependence: k_wv_coeff computes them for
+//     every element of the long nodes in parallel, together with the refined reciprocal of f (see below);
+//   * k_wv_chain_long: one wave per long node.  The operands of 64 steps are staged through LDS, every lane runs the same
+//     dependent chain on broadcast operands (5 dependent FP64 operations per step: the chain IS the critical path of the method),
+//     lane s keeps |I+ - I-| of step s of each chunk, so the arg-max never touches memory;
+//   * the division I-[m-1] / f_m inside the chain is evaluated as the hardware's own division sequence with its
+//     operand-independent half hoisted out (r = refined reciprocal of f; t = a*r; q = fma(fma(-f, t, a), r, t)): 3 dependent
+//     operations instead of ~15.  k_wv_verify re-checks every step with a plain IEEE division in parallel; a node with any
+//     mismatch is recomputed by the exact variant of the kernel, so results never depend on the shortcut;
+//   * k_wv_short: nodes of at most WV_LONG elements, one LANE per node (millions of them in the deep levels), everything inline.
+// The host keeps the tree (start / breakpoint / end, coefficient per node), applies HardThresh, rebuilds the breakpoints and runs the
+// two median-based clean-up passes (GetBreakpointsAfterHealingBadSplits, RefineSegments), which are sequential decisions over a
+// few hundred breakpoints.
+#include "common.hpp"
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <vector>
+
+#define WV_LONG 256       // nodes longer than this take the wave-per-node path
+#define WV_CHUNK 256      // elements per coefficient / verification work item
+
+struct WvNode { int32_t start; int32_t len; };            // start = index into the concatenated coverage, len >= 2
+struct WvOut { double coef; int32_t ind; int32_t flag; };  // ind = GetInnerProdMax (1-based inside the node); flag: shortcut mismatch
+struct WvItem { int32_t node; int32_t m0; };
+
+__device__ __forceinline__ double wv_factor(long long n, long long m) { return sqrt((double)(n - m - 1) * (double)m / (double)(m + 1) / (double)(n - m)); }
+__device__ __forceinline__ double wv_g(long long n, long long m) { return sqrt(1.0 / (double)(m + 1) - 1.0 / (double)n); }
+__device__ __forceinline__ double wv_h(long long n, long long m) { return sqrt(((double)n * (double)n / (double)(m + 1)) - (double)n); }
+// the operand-independent half of the FP64 division sequence: v_rcp_f64 + two Newton steps
+__device__ __forceinline__ double wv_rcp_refined(double f) {
+    double r = __builtin_amdgcn_rcp(f);
+    double e = __builtin_fma(-f, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-f, r, 1.0); r = __builtin_fma(r, e, r);
+    return r;
+}
+
+__global__ void __launch_bounds__(WV_CHUNK) k_wv_coeff(const WvNode* __restrict__ nodes, const WvItem* __restrict__ items, const double* __restrict__ X,
+                                                       double* __restrict__ F, double* __restrict__ R, double* __restrict__ Cc, double* __restrict__ Dd) {
+    const WvItem it = items[blockIdx.x];
+    const WvNode nd = nodes[it.node];
+    const long long n = nd.len, m = (long long)it.m0 + threadIdx.x;
+    if (m < 1 || m > n - 2) return;
+    const size_t p = (size_t)nd.start + (size_t)m;
+    const double x = X[p];
+    const double f = wv_factor(n, m);
+    F[p] = f; R[p] = wv_rcp_refined(f);
+    Cc[p] = x * wv_g(n, m);
+    Dd[p] = x / wv_h(n, m);
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const double* __restrict__ X,
+                                                      const double* __restrict__ F, const double* __restrict__ R, const double* __restrict__ Cc,
+                                                      const double* __restrict__ Dd, double* __restrict__ Q, WvOut* __restrict__ out) {
+    __shared__ double sA[2][4][64];
+    __shared__ double sIP[64], sQ[64];
+    const int node = list[blockIdx.x];
+    const WvNode nd = nodes[node];
+    const long long n = nd.len;
+    const int l = threadIdx.x;
+    const double* __restrict__ x = X + nd.start;
+    // ---- sumX = x[1] + ... + x[n-1], left to right (WaveletSegmentation.cs:26-30); LDS operations of one wave execute in order
+    double sum = 0.0;
+    {
+        int buf = 0;
+        double nxt = (1 + l < n) ? x[1 + l] : 0.0;
+        for (long long i0 = 1; i0 < n; i0 += 64, buf ^= 1) {
+            sA[buf][0][l] = nxt;
+            __builtin_amdgcn_wave_barrier();
+            { const long long t = i0 + 64 + l; nxt = t < n ? x[t] : 0.0; }
+            const long long cnt = n - i0;
+            if (cnt >= 64) {
+#pragma unroll
+                for (int s = 0; s < 64; s++) sum = sum + sA[buf][0][s];
+            } else {
+                for (int s = 0; s < (int)cnt; s++) sum = sum + sA[buf][0][s];
+            }
+        }
+    }
+    const double x0 = x[0];
+    double p = sqrt(1 - 1.0 / (double)n) * x0;
+    double q = (1.0 / sqrt((double)(n * (n - 1)))) * sum;
+    const double mean = (x0 + sum) / (double)n;
+    // lane s owns the steps m = 1 + 64 c + s; lane 0 also owns m = 0
+    double bestVal = p - q, bestAbs = l == 0 ? fabs(p - q) : -1.0;
+    long long bestIdx = 0;
+    if (l == 0) Q[nd.start] = q;
+    {
+        int buf = 0;
+        const long long last = n - 2;                                     // steps m = 1 .. n-2
+        double nf = 0, nr = 0, nc = 0, ndv = 0;
+        if (1 + l <= last) { const size_t g = (size_t)nd.start + 1 + l; nf = F[g]; nr = R[g]; nc = Cc[g]; ndv = Dd[g]; }
+        for (long long m0 = 1; m0 <= last; m0 += 64, buf ^= 1) {
+            sA[buf][0][l] = nf; sA[buf][1][l] = nr; sA[buf][2][l] = nc; sA[buf][3][l] = ndv;
+            __builtin_amdgcn_wave_barrier();
+            { const long long t = m0 + 64 + l; if (t <= last) { const size_t g = (size_t)nd.start + (size_t)t; nf = F[g]; nr = R[g]; nc = Cc[g]; ndv = Dd[g]; } }
+            const long long cnt = last - m0 + 1;
+#define WV_STEP(s)                                                                                                  \
+            {                                                                                                       \
+                const double f = sA[buf][0][s], c = sA[buf][2][s], d = sA[buf][3][s];                               \
+                const double pn = p * f + c;                                                                        \
+                double qd;                                                                                          \
+                if (FAST) { const double r = sA[buf][1][s]; const double t = q * r; qd = __builtin_fma(__builtin_fma(-f, t, q), r, t); } \
+                else qd = q / f;                                                                                    \
+                const double qn = qd - d;                                                                           \
+                p = pn; q = qn;                                                                                     \
+                sIP[s] = pn - qn; sQ[s] = qn;                                                                       \
+            }
+            if (cnt >= 64) {
+#pragma unroll
+                for (int s = 0; s < 64; s++) WV_STEP(s)
+            } else {
+                for (int s = 0; s < (int)cnt; s++) WV_STEP(s)
+            }
+#undef WV_STEP
+            __builtin_amdgcn_wave_barrier();
+            if (l < cnt) {
+                const double ip = sIP[l], a = fabs(ip);
+                if (a > bestAbs) { bestAbs = a; bestVal = ip; bestIdx = m0 + l; }
+                Q[(size_t)nd.start + (size_t)(m0 + l)] = sQ[l];
+            }
+        }
+    }
+    // first index of the maximum of |I+ - I-| (WaveletSegmentation.cs:54-68)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double oa = __shfl_xor(bestAbs, d, 64), ov = __shfl_xor(bestVal, d, 64);
+        const long long oi = __shfl_xor(bestIdx, d, 64);
+        if (oa > bestAbs || (oa == bestAbs && oi < bestIdx)) { bestAbs = oa; bestVal = ov; bestIdx = oi; }
+    }
+    if (l == 0) { WvOut o; o.coef = bestVal / fmax(0.5, mean / 200.0); o.ind = (int32_t)bestIdx + 1; o.flag = 0; out[node] = o; }
+}
+
+// every step of the shortcut division against the plain IEEE one (bit patterns, so that NaN == NaN)
+__global__ void __launch_bounds__(WV_CHUNK) k_wv_verify(const WvNode* __restrict__ nodes, const WvItem* __restrict__ items, const double* __restrict__ F,
+                                                        const double* __restrict__ Dd, const double* __restrict__ Q, WvOut* __restrict__ out) {
+    const WvItem it = items[blockIdx.x];
+    const WvNode nd = nodes[it.node];
+    const long long n = nd.len, m = (long long)it.m0 + threadIdx.x;
+    if (m < 1 || m > n - 2) return;
+    const size_t p = (size_t)nd.start + (size_t)m;
+    const double want = Q[p - 1] / F[p] - Dd[p];
+    if (__double_as_longlong(want) != __double_as_longlong(Q[p])) out[it.node].flag = 1;
+}
+
+// nodes of at most WV_LONG elements: one lane per node, the reference's loop as it stands
+__global__ void __launch_bounds__(64) k_wv_short(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, int nshort, const double* __restrict__ X,
+                                                 WvOut* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nshort) return;
+    const int node = list[i];
+    const WvNode nd = nodes[node];
+    const long long n = nd.len;
+    const double* __restrict__ x = X + nd.start;
+    double sum = 0.0;
+    for (long long k = 1; k < n; k++) sum = sum + x[k];
+    const double x0 = x[0];
+    double p = sqrt(1 - 1.0 / (double)n) * x0;
+    double q = (1.0 / sqrt((double)(n * (n - 1)))) * sum;
+    const double mean = (x0 + sum) / (double)n;
+    double bestVal = p - q, bestAbs = fabs(bestVal);
+    long long bestIdx = 0;
+    for (long long m = 1; m < n - 1; m++) {
+        const double f = wv_factor(n, m), xm = x[m];
+        p = p * f + xm * wv_g(n, m);
+        q = q / f - xm / wv_h(n, m);
+        const double ip = p - q, a = fabs(ip);
+        if (a > bestAbs) { bestAbs = a; bestVal = ip; bestIdx = m; }
+    }
+    WvOut o; o.coef = bestVal / fmax(0.5, mean / 200.0); o.ind = (int32_t)bestIdx + 1; o.flag = 0;
+    out[node] = o;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+namespace wv {
+// SortedList<T>.Median() / List<T>.Sort(): NaN sorts in front of every number
+template <class T>
+static void dotnet_sort(std::vector<T>& v) { auto mid = std::partition(v.begin(), v.end(), [](T a) { return a != a; }); std::sort(mid, v.end()); }
+template <class T>
+static T median_sorted(const std::vector<T>& v) { const size_t n = v.size(); if (!n) return T(0); return (n & 1) ? v[n / 2] : (T)((v[n / 2 - 1] + v[n / 2]) / (T)2); }
+// Utilities.Median(x, start, end) (Utilities.cs:428-443) on finite data: two order statistics instead of a full sort
+static double median_range(const double* x, int64_t a, int64_t b) {
+    std::vector<double> v(x + a, x + b);
+    const size_t n = v.size();
+    if (!n) return 0.0;
+    std::nth_element(v.begin(), v.begin() + n / 2, v.end());
+    const double hi = v[n / 2];
+    if (n & 1) return hi;
+    const double lo = *std::max_element(v.begin(), v.begin() + n / 2);
+    return (lo + hi) / 2;
+}
+static double mad_range(const double* x, int64_t a, int64_t b) {                 // Utilities.Mad (Utilities.cs:451-462)
+    const double med = median_range(x, a, b);
+    std::vector<double> d((size_t)(b - a));
+    for (int64_t i = a; i < b; i++) d[(size_t)(i - a)] = std::fabs(x[i] - med);
+    return median_range(d.data(), 0, (int64_t)d.size());
+}
+static void quartiles(std::vector<float> s, float& q1, float& q2, float& q3) {    // Utilities.Quartiles (Utilities.cs:361-419)
+    dotnet_sort(s);
+    const int iSize = (int)s.size(), iMid = iSize / 2;
+    q1 = q2 = q3 = 0;
+    if (iSize == 0) return;
+    if (iSize % 2 == 0) {
+        q2 = (s[iMid - 1] + s[iMid]) / 2;
+        const int mm = iMid / 2;
+        if (iMid % 2 == 0) { q1 = (s[mm - 1] + s[mm]) / 2; q3 = (s[iMid + mm - 1] + s[iMid + mm]) / 2; }
+        else { q1 = s[mm]; q3 = s[mm + iMid]; }
+    } else {
+        q2 = s[iMid];
+        if ((iSize - 1) % 4 == 0) { const int n = (iSize - 1) / 4; q1 = (s[n - 1] * 0.25f) + (s[n] * 0.75f); q3 = (s[3 * n] * 0.75f) + (s[3 * n + 1] * 0.25f); }
+        else if ((iSize - 3) % 4 == 0) { const int n = (iSize - 3) / 4; q1 = (s[n] * 0.75f) + (s[n + 1] * 0.25f); q3 = (s[3 * n + 1] * 0.25f) + (s[3 * n + 2] * 0.75f); }
+    }
+}
+// SegmentationInput.reportVariabilityByWindow (Segmentation.cs:334-349): MAD / median per window, as float
+static std::vector<float> variability_by_window(int window, int nchr, const double* cov, const int64_t* off) {
+    std::vector<float> out;
+    for (int c = 0; c < nchr; c++) {
+        const double* x = cov + off[c]; const int64_t L = off[c + 1] - off[c];
+        for (int64_t i = 0; i < L - window; i += window) out.push_back((float)(mad_range(x, i, i + window) / median_range(x, i, i + window)));
+    }
+    return out;
+}
+// SegmentationInput.GetCoverageVariability (Segmentation.cs:308-328)
+static bool coverage_variability(int window, int nchr, const double* cov, const int64_t* off, double& cv) {
+    if (off[nchr] - off[0] < 10 * (int64_t)window) return false;
+    if (window > 10000) {
+        std::vector<float> rv = variability_by_window(10000, nchr, cov, off);
+        float q1, q2, q3; quartiles(rv, q1, q2, q3);
+        if ((q3 - q1) / q2 > 0.015) { cv = q1; return true; }
+    }
+    std::vector<float> rv = variability_by_window(window, nchr, cov, off);
+    dotnet_sort(rv);
+    cv = (double)median_sorted(rv);
+    return true;
+}
+// SegmentationInput.FactorOfThreeCoverageVariabilities (Segmentation.cs:366-429)
+static std::vector<double> factor_of_three(int nchr, const double* cov, const int64_t* off) {
+    const int maxExponent = 8;
+    std::vector<double> f3{0.0};
+    std::vector<std::vector<double>> cur(nchr);
+    for (int c = 0; c < nchr; c++) cur[c].assign(cov + off[c], cov + off[c + 1]);
+    for (int exponent = 1; exponent <= maxExponent; ++exponent) {
+        std::vector<double> cmads;
+        for (int c = 0; c < nchr; c++) {
+            const std::vector<double>& d = cur[c];
+            const size_t n = d.size() / 3;
+            std::vector<double> med(n);
+            for (size_t i = 0; i < n; i++) {
+                double a = d[3 * i], b = d[3 * i + 1], e = d[3 * i + 2];
+                if (a > b) std::swap(a, b);
+                if (a > e) std::swap(a, e);
+                if (b > e) std::swap(b, e);
+                med[i] = b;
+                cmads.push_back((e - a) / 2.0 / b);
+            }
+            cur[c].swap(med);
+        }
+        if (cmads.size() < 50) { const double last = f3.back(); while ((int)f3.size() < maxExponent + 1) f3.push_back(last); break; }
+        dotnet_sort(cmads);
+        f3.push_back(median_sorted(cmads));
+    }
+    return f3;
+}
+
+// Array.Sort<int>(indices, comparison) of .NET Core 2.0 (coreclr ArraySortHelper<T>.IntrospectiveSort): unstable, so the tie order of
+// the level counts in HardThresh follows this exact procedure (parity unpinned, like Q11)
+typedef std::function<int(int, int)> Cmp;
+static void sig(int* k, const Cmp& c, int a, int b) { if (a != b && c(k[a], k[b]) > 0) std::swap(k[a], k[b]); }
+static void ins(int* k, int lo, int hi, const Cmp& c) { for (int i = lo; i < hi; i++) { int j = i, t = k[i + 1]; while (j >= lo && c(t, k[j]) < 0) { k[j + 1] = k[j]; j--; } k[j + 1] = t; } }
+static void down(int* k, int i, int n, int lo, const Cmp& c) {
+    const int d = k[lo + i - 1];
+    while (i <= n / 2) {
+        int ch = 2 * i;
+        if (ch < n && c(k[lo + ch - 1], k[lo + ch]) < 0) ch++;
+        if (!(c(d, k[lo + ch - 1]) < 0)) break;
+        k[lo + i - 1] = k[lo + ch - 1]; i = ch;
+    }
+    k[lo + i - 1] = d;
+}
+static void heap(int* k, int lo, int hi, const Cmp& c) {
+    const int n = hi - lo + 1;
+    for (int i = n / 2; i >= 1; i--) down(k, i, n, lo, c);
+    for (int i = n; i > 1; i--) { std::swap(k[lo], k[lo + i - 1]); down(k, 1, i - 1, lo, c); }
+}
+static int part(int* k, int lo, int hi, const Cmp& c) {
+    const int mid = lo + (hi - lo) / 2;
+    sig(k, c, lo, mid); sig(k, c, lo, hi); sig(k, c, mid, hi);
+    const int pivot = k[mid];
+    std::swap(k[mid], k[hi - 1]);
+    int left = lo, right = hi - 1;
+    while (left < right) {
+        while (c(k[++left], pivot) < 0) ;
+        while (c(pivot, k[--right]) < 0) ;
+        if (left >= right) break;
+        std::swap(k[left], k[right]);
+    }
+    std::swap(k[left], k[hi - 1]);
+    return left;
+}
+static void intro(int* k, int lo, int hi, int depth, const Cmp& c) {
+    while (hi > lo) {
+        const int sz = hi - lo + 1;
+        if (sz <= 16) {
+            if (sz == 1) return;
+            if (sz == 2) { sig(k, c, lo, hi); return; }
+            if (sz == 3) { sig(k, c, lo, hi - 1); sig(k, c, lo, hi); sig(k, c, hi - 1, hi); return; }
+            ins(k, lo, hi, c); return;
+        }
+        if (depth == 0) { heap(k, lo, hi, c); return; }
+        depth--;
+        const int p = part(k, lo, hi, c);
+        intro(k, p + 1, hi, depth, c);
+        hi = p - 1;
+    }
+}
+static void dotnet_sort_ints(std::vector<int>& k, const Cmp& c) {
+    const int n = (int)k.size();
+    if (n < 2) return;
+    int fl = 0; for (int v = n; v >= 1; v /= 2) fl++;
+    intro(k.data(), 0, n - 1, 2 * fl, c);
+}
+
+struct HNode { int32_t chrom, s, e; };                       // 1-based inclusive positions inside the chromosome
+struct Cand { int32_t level; int32_t s, b, e; double coef; };
+struct ChromTree { std::vector<int> counts; std::vector<Cand> cands; double sigma = 0, keepAbove = 0; };
+}  // namespace wv
+
+extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline,
+                                   double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
+                                   int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset) {
+    using namespace wv;
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !d_cov || !h_chr_offset || !h_breakpoints || !h_bp_offset || variability_window <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = h_chr_offset[nchr] - h_chr_offset[0];
+    if (N <= 0 || N > 0x7FFFFFF0ll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: bin count out of range");
+    const int64_t base = h_chr_offset[0];
+    std::vector<int64_t> off(nchr + 1);
+    for (int c = 0; c <= nchr; c++) off[c] = h_chr_offset[c] - base;
+    const double* dX = d_cov + base;
+    // the coverage is needed on both sides: the decomposition runs on the device, the median-based decisions on the host
+    std::vector<double> X((size_t)N);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(X.data(), dX, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < N; i++) if (!std::isfinite(X[i])) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: coverage must be finite");
+    double cv = 0;
+    const bool hasCV = coverage_variability(variability_window, nchr, X.data(), off.data(), cv);
+    const std::vector<double> f3 = factor_of_three(nchr, X.data(), off.data());
+
+    // ---- roots: chromosomes longer than MinSize (WaveletsRunner.cs:117-126)
+    std::vector<ChromTree> trees(nchr);
+    std::vector<HNode> cur, nxt;
+    for (int c = 0; c < nchr; c++) {
+        const int64_t L = off[c + 1] - off[c];
+        if (std::max<int64_t>(L, 1) <= min_size) continue;
+        if (L < 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: a chromosome that passes MinSize needs at least two bins");
+        const double* r = X.data() + off[c];
+        const double median = median_range(r, 0, L);
+        double threshold = mad_factor * (hasCV ? median * cv : mad_range(r, 0, L));       // WaveletSegmentation.cs:394-405
+        if (threshold < threshold_lower) threshold = threshold_lower;
+        if (threshold > threshold_upper) threshold = threshold_upper;
+        trees[c].sigma = threshold;
+        // a coefficient at or below 2 sigma t sqrt(2 ln n) with the smallest possible level weight t is zeroed whatever the level
+        // weights turn out to be: such nodes need not be kept (the margin keeps every borderline node for the exact test)
+        trees[c].keepAbove = 2 * threshold * (is_germline ? 0.8 : 1.0) * std::sqrt(2 * std::log((double)L)) * (1.0 - 1e-9);
+        cur.push_back({c, 1, (int32_t)L});
+    }
+    // ---- device buffers
+    const size_t maxNodes = (size_t)N / 2 + (size_t)nchr + 16, maxItems = (size_t)N / WV_CHUNK + maxNodes / 1 + 16;
+    WsSizer sz;
+    for (int k = 0; k < 5; k++) sz.take<double>((size_t)N);
+    sz.take<WvNode>(maxNodes); sz.take<WvOut>(maxNodes); sz.take<int32_t>(maxNodes); sz.take<int32_t>(maxNodes); sz.take<WvItem>(maxItems);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
+    WsCarver ws(ctx->ws);
+    double* dF = ws.take<double>((size_t)N); double* dR = ws.take<double>((size_t)N); double* dC = ws.take<double>((size_t)N);
+    double* dD = ws.take<double>((size_t)N); double* dQ = ws.take<double>((size_t)N);
+    WvNode* dNodes = ws.take<WvNode>(maxNodes); WvOut* dOut = ws.take<WvOut>(maxNodes);
+    int32_t* dLong = ws.take<int32_t>(maxNodes); int32_t* dShort = ws.take<int32_t>(maxNodes); WvItem* dItems = ws.take<WvItem>(maxItems);
+    std::vector<WvNode> hNodes; std::vector<WvOut> hOut; std::vector<int32_t> hLong, hShort, hRedo; std::vector<WvItem> hItems;
+    long long levels = 0, redone = 0;
+    // ---- FindBestUnbalancedHaarDecomposition (WaveletSegmentation.cs:252-366), level by level for all chromosomes at once
+    for (int level = 0; !cur.empty(); level++, levels++) {
+        const size_t nn = cur.size();
+        hNodes.resize(nn); hOut.resize(nn); hLong.clear(); hItems.clear();
+        std::vector<int32_t> byLen[WV_LONG + 1];
+        for (size_t i = 0; i < nn; i++) {
+            const HNode& h = cur[i];
+            const int32_t len = h.e - h.s + 1;
+            hNodes[i] = {(int32_t)(off[h.chrom] + h.s - 1), len};
+            if (len > WV_LONG) { hLong.push_back((int32_t)i); for (int32_t m0 = 0; m0 < len; m0 += WV_CHUNK) hItems.push_back({(int32_t)i, m0}); }
+            else byLen[len].push_back((int32_t)i);
+        }
+        hShort.clear();                                      // nodes of similar length share a wave
+        for (int len = WV_LONG; len >= 2; len--) hShort.insert(hShort.end(), byLen[len].begin(), byLen[len].end());
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dNodes, hNodes.data(), nn * sizeof(WvNode), hipMemcpyHostToDevice, ctx->stream));
+        if (!hLong.empty()) {
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dLong, hLong.data(), hLong.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dItems, hItems.data(), hItems.size() * sizeof(WvItem), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_wv_coeff, dim3((unsigned)hItems.size()), dim3(WV_CHUNK), 0, ctx->stream, dNodes, dItems, dX, dF, dR, dC, dD);
+            { ProfScope ps(ctx, "wavelet_chain");
+              hipLaunchKernelGGL((k_wv_chain_long<true>), dim3((unsigned)hLong.size()), dim3(64), 0, ctx->stream, dNodes, dLong, dX, dF, dR, dC, dD, dQ, dOut); }
+            hipLaunchKernelGGL(k_wv_verify, dim3((unsigned)hItems.size()), dim3(WV_CHUNK), 0, ctx->stream, dNodes, dItems, dF, dD, dQ, dOut);
+        }
+        if (!hShort.empty()) {
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dShort, hShort.data(), hShort.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_wv_short, dim3((unsigned)((hShort.size() + 63) / 64)), dim3(64), 0, ctx->stream, dNodes, dShort, (int)hShort.size(), dX, dOut);
+        }
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        hRedo.clear();
+        for (int32_t i : hLong) if (hOut[i].flag) hRedo.push_back(i);
+        if (!hRedo.empty()) {                                // the shortcut division disagreed somewhere: exact chain for those nodes
+            redone += (long long)hRedo.size();
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dLong, hRedo.data(), hRedo.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL((k_wv_chain_long<false>), dim3((unsigned)hRedo.size()), dim3(64), 0, ctx->stream, dNodes, dLong, dX, dF, dR, dC, dD, dQ, dOut);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        nxt.clear();
+        for (size_t i = 0; i < nn; i++) {
+            const HNode& h = cur[i];
+            ChromTree& T = trees[h.chrom];
+            if ((int)T.counts.size() <= level) T.counts.resize(level + 1, 0);
+            T.counts[level]++;
+            const int32_t b = h.s + hOut[i].ind - 1;          // "last time point before the breakpoint" (cs:279, 311, 337)
+            if (std::fabs(hOut[i].coef) > T.keepAbove) T.cands.push_back({level, h.s, b, h.e, hOut[i].coef});
+            if (b - h.s >= 1) nxt.push_back({h.chrom, h.s, b});
+            if (h.e - b >= 2) nxt.push_back({h.chrom, b + 1, h.e});
+        }
+        cur.swap(nxt);
+    }
+    ctx->wv_levels = levels; ctx->wv_redone = redone;
+    // ---- per chromosome: HardThresh, reconstruction, healing, refinement (WaveletSegmentation.cs:73-250, 373-425)
+    int64_t total = 0;
+    for (int c = 0; c < nchr; c++) {
+        h_bp_offset[c] = total;
+        const ChromTree& T = trees[c];
+        const int64_t L = off[c + 1] - off[c];
+        if (T.counts.empty()) continue;                       // not segmented: no breakpoints (WaveletsRunner.cs:113-131)
+        const double* r = X.data() + off[c];
+        const int treeSize = (int)T.counts.size();
+        std::vector<double> thresholds((size_t)treeSize, 1.0);
+        std::vector<int> indices((size_t)treeSize);
+        for (int i = 0; i < treeSize; i++) indices[i] = i;
+        if (is_germline) {
+            dotnet_sort_ints(indices, [&](int a, int b) { return T.counts[b] < T.counts[a] ? -1 : (T.counts[b] > T.counts[a] ? 1 : 0); });
+            for (int x = 1; x <= treeSize; x++) thresholds[x - 1] = ((double)x * (1.0 - 0.8)) / treeSize + 0.8;
+        }
+        const double n = (double)L;
+        double smooth = 0;
+        for (int64_t i = 0; i < L; i++) smooth += r[i];
+        smooth = smooth / std::sqrt(n);
+        std::vector<double> rec((size_t)L, 1.0 / std::sqrt(n) * smooth);
+        // nodes whose coefficient is zeroed add +-0 to rec and cannot create or remove a difference: only the survivors are applied,
+        // in the reference's order (level by level, left to right)
+        for (const Cand& k : T.cands) {
+            if (std::fabs(k.coef) <= 2 * T.sigma * (thresholds[indices[k.level]]) * std::sqrt(2 * std::log(n))) continue;
+            const double nn = (double)k.e - (double)k.s + 1, m = (double)k.b - (double)k.s + 1;
+            const double val1 = std::sqrt(1 / m - 1 / nn), val2 = -1.0 / std::sqrt(nn * nn / m - nn);
+            for (int32_t i = k.s - 1; i < k.e; i++) rec[i] = rec[i] + ((double)(i - (k.s - 1)) < m ? val1 : val2) * k.coef;
+        }
+        std::vector<int> prelim{0};
+        for (int64_t i = 1; i < L; i++) if (rec[i] - rec[i - 1] != 0) prelim.push_back((int)i);
+        // GetBreakpointsAfterHealingBadSplits
+        std::vector<int> bp{prelim[0]};
+        const int Lp = (int)prelim.size();
+        for (int i = 1; i < Lp; ++i) {
+            const int leftStart = bp.back(), rightStart = prelim[i], rightEnd = (i < Lp - 1) ? prelim[i + 1] : (int)L;
+            const int leftLength = rightStart - leftStart, rightLength = rightEnd - rightStart;
+            const double leftMedian = median_range(r, leftStart, leftStart + leftLength), rightMedian = median_range(r, rightStart, rightStart + rightLength);
+            const double weightedMedian = (leftLength * leftMedian + rightLength * rightMedian) / (rightEnd - leftStart);
+            const int smaller = std::min(leftLength, rightLength);
+            const int scale = std::min((int)f3.size() - 1, (int)std::ceil(std::log((double)smaller) / std::log(3.0)));
+            if (std::fabs(leftMedian - rightMedian) > f3[scale] * 4 * std::max(weightedMedian, 50.0)) bp.push_back(prelim[i]);
+        }
+        if (is_germline) {                                    // RefineSegments
+            const double totalMedian = median_range(r, 0, L);
+            for (int i = 1; i < (int)bp.size() - 1; i++) {
+                const int li = std::min(5, (bp[i] - bp[i - 1]) / 2), ri = std::min(5, (bp[i + 1] - bp[i]) / 2);
+                double best = std::fabs(median_range(r, bp[i - 1], bp[i]) - totalMedian);
+                int bestBp = bp[i];
+                for (int j = bp[i] - li; j < bp[i] + ri; j++) {
+                    const double t = std::fabs(median_range(r, bp[i - 1], j) - totalMedian);
+                    if (t > best) { best = t; bestBp = j; }
+                }
+                bp[i] = bestBp;
+            }
+        }
+        if (total + (int64_t)bp.size() > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_wavelets: breakpoint capacity too small");
+        for (int v : bp) h_breakpoints[total++] = v;
+    }
+    h_bp_offset[nchr] = total;
+    return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_wavelets_stats(canvas_ctx* ctx, int64_t* h_out2) {
+    if (!ctx || !h_out2) return CANVAS_ERR_INVALID;
+    h_out2[0] = ctx->wv_levels; h_out2[1] = ctx->wv_redone;
+    return CANVAS_OK;
+}

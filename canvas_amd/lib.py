@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
-    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats",
+    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_wavelets", "canvas_wavelets_stats",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -284,6 +284,21 @@ class Canvas:
         self._check(self.lib.canvas_cbs_undo(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_double(alpha), C.c_uint32(nperm), undo, C.c_double(undo_sd),
                                              C.c_void_p(seg_len.data_ptr()), _np_ptr(nseg), _np_ptr(stats)))
         return seg_len, nseg, stats
+
+    def wavelets(self, cov, chr_offset, is_germline=False, threshold_lower=0.05, threshold_upper=80.0, mad_factor=5.0, window=100000, min_size=10):
+        """WaveletsRunner.Run up to the breakpoints (WaveletsRunner.cs:52-150): one array of segment-start bin indices per chromosome"""
+        off = np.ascontiguousarray(chr_offset, np.int64)
+        nchr = len(off) - 1
+        out = np.zeros(int(off[-1] - off[0]) + nchr + 1, np.int32); oo = np.zeros(nchr + 1, np.int64)
+        self._check(self.lib.canvas_wavelets(self.ctx, nchr, C.c_void_p(cov.data_ptr()), _np_ptr(off), int(bool(is_germline)), C.c_double(threshold_lower),
+                                             C.c_double(threshold_upper), C.c_double(mad_factor), int(window), int(min_size), _np_ptr(out), C.c_int64(len(out)), _np_ptr(oo)))
+        return [out[oo[c]:oo[c + 1]].copy() for c in range(nchr)]
+
+    def wavelets_stats(self):
+        """[tree levels processed, nodes recomputed by the exact chain] of the last wavelets() call"""
+        out = np.zeros(2, np.int64)
+        self._check(self.lib.canvas_wavelets_stats(self.ctx, _np_ptr(out)))
+        return out
 
 
 # ---- synthetic generator (bench/test tooling, separate library)

@@ -172,6 +172,20 @@ int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, cons
  * [4]/[5] test hook CANVAS_CBS_TEST_VERIFY=1: device intervals checked against the exact statistic / violations. */
 int32_t canvas_cbs_device_stats(canvas_ctx* ctx, int64_t* h_out6);
 
+/* CanvasPartition -m Wavelets, the reference's default method: WaveletsRunner.Run up to the breakpoints (WaveletsRunner.cs:52-150 =
+ * SegmentationInput.GetCoverageVariability / FactorOfThreeCoverageVariabilities, Segmentation.cs:297-429, then
+ * WaveletSegmentation.HaarWavelets per chromosome, WaveletSegmentation.cs:373-425: unbalanced Haar decomposition, HardThresh,
+ * reconstruction, GetBreakpointsAfterHealingBadSplits and, with is_germline (-g), RefineSegments).  d_cov / h_chr_offset as for canvas_cbs.
+ * The parameters are WaveletsRunnerParams' (WaveletsRunner.cs:28-41): threshold_lower = ThresholdLowerMaf (0.05), threshold_upper = 80,
+ * mad_factor = MadFactor (5), variability_window = EvennessScoreWindow (100000), min_size = 10.  h_breakpoints[h_bp_offset[c] .. h_bp_offset[c+1])
+ * are the bin indices where a segment starts on chromosome c (empty for a chromosome of at most min_size bins): what the reference
+ * hands to SegmentationInput.DeriveSegments (Segmentation.cs:83-125).  Coverage must be finite. */
+int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline,
+                        double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
+                        int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset);
+/* last canvas_wavelets call: [0] tree levels processed, [1] nodes whose shortcut division disagreed with the IEEE one and were recomputed */
+int32_t canvas_wavelets_stats(canvas_ctx* ctx, int64_t* h_out2);
+
 /* ---- multi-GPU (one process per GPU; chromosomes sharded across ranks) ------------------------------------------ */
 int32_t canvas_comm_unique_id(void* h_id128);  /* ncclGetUniqueId, 128 bytes, rank 0 */
 int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const void* h_id128);

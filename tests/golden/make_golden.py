@@ -5,6 +5,7 @@ the JSON files it writes are committed and are what the tests use.  No reference
 
   LOESS vectors            <- CanvasTest/TestLoessInterpolator.cs:13-81
   split-overlapping cases  <- CanvasTest/CanvasPartition/GenomeSegmentationResultsTests.cs:14-248
+  wavelets known answer    <- CanvasTest/CanvasPartition/WaveletTests.cs:10-92 (530 coverage values, 12 expected breakpoints)
 """
 import json, os, re, sys
 
@@ -46,6 +47,23 @@ def split_overlapping():
     print("split cases:", [(c["name"], len(c["samples"])) for c in cases])
 
 
+def wavelets():
+    t = open(f"{REF}/CanvasPartition/WaveletTests.cs", encoding="utf-8-sig").read()
+    body = re.search(r"var coverage = new double\[\]\s*\{(.*?)\};", t, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body)
+    cov = [float(v) for v in body.replace("\n", " ").split(",") if v.strip()]
+    call = re.search(r"GetCoverageVariability\((\d+),", t)
+    hw = re.search(r"HaarWavelets\(coverage,\s*([\d.]+),\s*([\d.]+),\s*breakpoints,\s*(\w+),\s*([\d.]+),", t, re.S)
+    count = int(re.search(r"Assert.Equal\((\d+), breakpoints.Count\)", t).group(1))
+    exp = [int(v) for v, i in sorted(re.findall(r"Assert.Equal\((\d+), breakpoints\[(\d+)\]\)", t), key=lambda p: int(p[1]))]
+    assert len(exp) == count
+    d = {"coverage": cov, "variability_window": int(call.group(1)), "threshold_lower": float(hw.group(1)), "threshold_upper": float(hw.group(2)),
+         "is_germline": hw.group(3) == "true", "mad_factor": float(hw.group(4)), "expected_breakpoints": exp}
+    json.dump(d, open(f"{OUT}/wavelets_minimal.json", "w"))
+    print("wavelets:", len(cov), "values ->", exp)
+
+
 if __name__ == "__main__":
+    wavelets()
     loess()
     split_overlapping()

@@ -313,3 +313,46 @@ def cbs_genome(xs, alpha=0.01, n_perm=10000, threads=1, undo=0):
     nseg = np.zeros(len(xs), np.int32); stats = np.zeros(7, np.int64)
     lib.orc_cbs_genome_undo(len(xs), _pp(xs), _p(n), _p(sb), len(sb), C.c_double(alpha), C.c_uint32(n_perm), undo, _pp(ls), _p(caps), _p(nseg), _p(stats), threads)
     return [l[:k].copy() for l, k in zip(ls, nseg)], stats
+
+
+# ---- Wavelets (oracle_wavelets.cpp)
+lib.orc_haar_wavelets.restype = C.c_int64
+lib.orc_wavelets.restype = C.c_int64
+
+
+def haar_wavelets(x, thr_lower, thr_upper, is_germline, mad_factor, cv, f3):
+    """WaveletSegmentation.HaarWavelets (WaveletSegmentation.cs:373-425); cv None = no coverage variability (MAD is used)"""
+    x = np.ascontiguousarray(x, np.float64); f3 = np.ascontiguousarray(f3, np.float64)
+    out = np.zeros(len(x) + 1, np.int32)
+    k = lib.orc_haar_wavelets(_p(x), C.c_int64(len(x)), C.c_double(thr_lower), C.c_double(thr_upper), int(bool(is_germline)), C.c_double(mad_factor),
+                              0 if cv is None else 1, C.c_double(0.0 if cv is None else cv), _p(f3), len(f3), _p(out), C.c_int64(len(out)))
+    assert k >= 0
+    return out[:k].copy()
+
+
+def coverage_variability(window, per_chr):
+    """SegmentationInput.GetCoverageVariability (Segmentation.cs:308-328); None when there are fewer than 10 windows of data"""
+    cov = np.ascontiguousarray(np.concatenate(per_chr), np.float64)
+    off = np.concatenate([[0], np.cumsum([len(a) for a in per_chr])]).astype(np.int64)
+    cv = C.c_double(0)
+    return cv.value if lib.orc_coverage_variability(int(window), len(per_chr), _p(cov), _p(off), C.byref(cv)) else None
+
+
+def factor_of_three(per_chr):
+    """SegmentationInput.FactorOfThreeCoverageVariabilities (Segmentation.cs:366-402)"""
+    cov = np.ascontiguousarray(np.concatenate(per_chr), np.float64)
+    off = np.concatenate([[0], np.cumsum([len(a) for a in per_chr])]).astype(np.int64)
+    out = np.zeros(9, np.float64)
+    k = lib.orc_factor_of_three(len(per_chr), _p(cov), _p(off), _p(out))
+    return out[:k].copy()
+
+
+def wavelets_genome(per_chr, is_germline=False, thr_lower=0.05, thr_upper=80.0, mad_factor=5.0, window=100000, min_size=10):
+    """WaveletsRunner.Run up to the breakpoints (WaveletsRunner.cs:52-150): list of breakpoint arrays, one per chromosome"""
+    cov = np.ascontiguousarray(np.concatenate(per_chr), np.float64)
+    off = np.concatenate([[0], np.cumsum([len(a) for a in per_chr])]).astype(np.int64)
+    out = np.zeros(len(cov) + len(per_chr) + 1, np.int32); oo = np.zeros(len(per_chr) + 1, np.int64)
+    k = lib.orc_wavelets(len(per_chr), _p(cov), _p(off), int(bool(is_germline)), C.c_double(thr_lower), C.c_double(thr_upper), C.c_double(mad_factor), int(window),
+                         int(min_size), _p(out), C.c_int64(len(out)), _p(oo))
+    assert k >= 0
+    return [out[oo[c]:oo[c + 1]].copy() for c in range(len(per_chr))]

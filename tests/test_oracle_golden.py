@@ -175,3 +175,16 @@ def test_changepoints_prune_against_an_independent_restatement():
     assert list(O.changepoints_prune(x, [5, 5])) == [10]
     x = np.concatenate([np.full(4, 0.0), np.full(4, 5.0), np.full(4, 0.0)])
     assert list(O.changepoints_prune(x, [4, 4, 4])) == [4, 4, 4]
+
+
+def test_wavelets_known_answer():
+    # CanvasTest/CanvasPartition/WaveletTests.cs:10-92: 550 coverage values -> 12 breakpoints (non-germline flavour)
+    d = json.load(open(os.path.join(G, "wavelets_minimal.json")))
+    cov = np.array(d["coverage"])
+    cv = O.coverage_variability(d["variability_window"], [cov])
+    f3 = O.factor_of_three([cov])
+    assert cv is not None and len(f3) == 9 and f3[0] == 0
+    bp = O.haar_wavelets(cov, d["threshold_lower"], d["threshold_upper"], d["is_germline"], d["mad_factor"], cv, f3)
+    assert bp.tolist() == d["expected_breakpoints"]
+    # fewer than ten windows of data -> no coverage variability (Segmentation.cs:310-311)
+    assert O.coverage_variability(100, [cov]) is None

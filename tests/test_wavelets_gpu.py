@@ -1,0 +1,69 @@
+"""CanvasPartition -m Wavelets on the GPU (canvas_wavelets) against the oracle, which the reference's own known-answer test pins
+(tests/test_oracle_golden.py::test_wavelets_known_answer).  Breakpoints are integers: identical or wrong."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_common import get_canvas, to_dev
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run(cv, per_chr, **kw):
+    cov = np.ascontiguousarray(np.concatenate(per_chr), np.float64)
+    off = np.concatenate([[0], np.cumsum([len(a) for a in per_chr])]).astype(np.int64)
+    return cv.wavelets(to_dev(cov, cv.device), off, **kw)
+
+
+def _coverage(rng, n, mean=100.0, events=6, wave=0.0):
+    x = rng.poisson(mean, n).astype(np.float64)
+    for _ in range(events if n > 40 else 0):
+        a = int(rng.randint(0, n - 20)); b = min(n, a + int(rng.choice([12, 40, 300, 2500, n // 4 + 1])))
+        x[a:b] = np.round(x[a:b] * float(rng.choice([0.0, 0.5, 1.5, 2.0])))
+    if wave:
+        x = np.round(x * (1 + wave * np.sin(np.arange(n) / 700.0)))
+    return np.round(x * 100) / 100      # what the cleaned file holds: F2 text
+
+
+def test_reference_known_answer_on_device():
+    cv = get_canvas()
+    d = json.load(open(os.path.join(G, "wavelets_minimal.json")))
+    cov = np.array(d["coverage"])
+    got = _run(cv, [cov], is_germline=d["is_germline"], threshold_lower=d["threshold_lower"], threshold_upper=d["threshold_upper"], mad_factor=d["mad_factor"],
+               window=d["variability_window"])
+    assert got[0].tolist() == d["expected_breakpoints"]
+
+
+@pytest.mark.parametrize("germline", [False, True])
+@pytest.mark.parametrize("seed,lengths,window", [(1, [3000, 11, 10, 800], 100), (2, [40_000, 9_001], 1000), (3, [120_000], 100000), (4, [257, 256, 258, 1025], 11),
+                                                 (5, [60_000, 30_000, 5], 20000)])
+def test_wavelets_match_oracle(seed, lengths, window, germline):
+    cv = get_canvas()
+    rng = np.random.RandomState(seed)
+    per = [_coverage(rng, n, mean=float(rng.choice([30, 100, 400])), wave=0.05 * (seed % 2)) for n in lengths]
+    exp = O.wavelets_genome(per, is_germline=germline, window=window)
+    got = _run(cv, per, is_germline=germline, window=window)
+    assert len(got) == len(exp)
+    for c in range(len(per)):
+        assert got[c].tolist() == exp[c].tolist(), (c, lengths[c])
+    st = cv.wavelets_stats()
+    assert st[0] > 0 and st[1] == 0          # the shortcut division never disagreed with the IEEE one
+    assert sum(len(e) for e in exp) > len([n for n in lengths if n > 10])   # something beyond the chromosome starts was found
+
+
+def test_wavelets_flat_and_degenerate_input():
+    cv = get_canvas()
+    per = [np.full(500, 100.0), np.zeros(300), np.arange(400, dtype=np.float64)]
+    for germline in (False, True):
+        exp = O.wavelets_genome(per, is_germline=germline, window=50)
+        got = _run(cv, per, is_germline=germline, window=50)
+        for c in range(3):
+            assert got[c].tolist() == exp[c].tolist()
+    # non-finite coverage is refused, not silently segmented
+    bad = np.full(100, 50.0); bad[7] = np.nan
+    with pytest.raises(Exception):
+        _run(cv, [bad], window=11)
