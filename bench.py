@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--rate", type=float, default=0.21, help="hits per possible position (0.21 = 60x, 0.105 = 30x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage host wall times (ms) of the last step to stderr")
+    ap.add_argument("--no-wavelets", action="store_true", help="skip the (untimed) Wavelets run on the cleaned coverage that is reported as wavelets_path")
     ap.add_argument("--no-cbs", action="store_true", help="skip the (untimed) CBS run on the cleaned coverage that is reported as cbs_path")
     args = ap.parse_args()
 
@@ -219,6 +220,28 @@ def main():
                               "permutations": int(cstats[2]), "permuted_elements": int(cstats[3]), "device_permutations": int(dstat[0]), "host_permutations": int(dstat[1]),
                               "exact_reevaluations": int(dstat[2]), "note": "CBSRunner.Run (alpha 0.01, 10000 permutations): recursion and stopping rule on the host, "
                               "TMaxO arc search + XPerm/HTMaxP + MT19937 on the device"}
+    if rank == 0 and world == 1 and not args.no_wavelets:
+        # the reference's default partition method (-m Wavelets) on the same cleaned coverage; reported, not part of `value`
+        cv.profile_get("wavelet_chain", reset=True)
+        t_w = time.perf_counter()
+        bps = cv.wavelets(keep["cov"], keep["off"])
+        wv_s = time.perf_counter() - t_w
+        wst = cv.wavelets_stats()
+        ms_chain, k_chain = cv.profile_get("wavelet_chain")
+        wv = {"seconds": round(wv_s, 3), "bins_per_s": round(int(keep["n_out"]) / wv_s, 1), "breakpoints": int(sum(len(b) for b in bps)), "tree_levels": int(wst[0]),
+              "chain_kernel_seconds": round(ms_chain / 1e3, 3), "nodes_recomputed_exactly": int(wst[1]),
+              "note": "WaveletsRunner.Run (somatic flavour, default parameters): unbalanced Haar decomposition on the device level by level, "
+                      "thresholding / healing on the host"}
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            cov_h = keep["cov"].cpu().numpy(); off_h = keep["off"]
+            per = [np.ascontiguousarray(cov_h[off_h[c]:off_h[c + 1]]) for c in range(len(off_h) - 1)]
+            t_o = time.perf_counter()
+            exp = O.wavelets_genome(per)
+            wv["oracle_seconds_1_core"] = round(time.perf_counter() - t_o, 3)
+            wv["parity_vs_oracle"] = bool(all(a.tolist() == b.tolist() for a, b in zip(bps, exp)))
+        result["wavelets_path"] = wv
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(keep, bases, hits, masks, lens, is_auto, flags, total_bases)
     if rank == 0:

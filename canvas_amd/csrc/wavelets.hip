@@ -32,6 +32,7 @@
 
 #define WV_LONG 256       // nodes longer than this take the wave-per-node path
 #define WV_CHUNK 256      // elements per coefficient / verification work item
+#define WV_PB 4           // steps per operand-prefetch block of the chain kernel
 
 struct WvNode { int32_t start; int32_t len; };            // start = index into the concatenated coverage, len >= 2
 struct WvOut { double coef; int32_t ind; int32_t flag; };  // ind = GetInnerProdMax (1-based inside the node); flag: shortcut mismatch
@@ -62,12 +63,25 @@ __global__ void __launch_bounds__(WV_CHUNK) k_wv_coeff(const WvNode* __restrict_
     Dd[p] = x / wv_h(n, m);
 }
 
+// One step of both recurrences on uniform operands (every lane computes the same values).
+template <bool FAST>
+__device__ __forceinline__ void wv_step(double& p, double& q, double f, double r, double c, double d) {
+    const double pn = p * f + c;
+    double qd;
+    if (FAST) { const double t = q * r; qd = __builtin_fma(__builtin_fma(-f, t, q), r, t); }
+    else qd = q / f;
+    q = qd - d;
+    p = pn;
+}
+
 template <bool FAST>
 __global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const double* __restrict__ X,
                                                       const double* __restrict__ F, const double* __restrict__ R, const double* __restrict__ Cc,
                                                       const double* __restrict__ Dd, double* __restrict__ Q, WvOut* __restrict__ out) {
-    __shared__ double sA[2][4][64];
-    __shared__ double sIP[64], sQ[64];
+    // the chain is latency-bound (one wave, 4 dependent FP64 operations per step): the operand reads of the NEXT eight steps are issued
+    // before the current eight are computed; the scheduling barriers keep the compiler from sinking them back to their first use
+    __shared__ double vA[2 * 4 * 64];           // [buf][f, r, c, d][step]
+    __shared__ double vIP[64], vQ[64];
     const int node = list[blockIdx.x];
     const WvNode nd = nodes[node];
     const long long n = nd.len;
@@ -79,15 +93,18 @@ __global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__
         int buf = 0;
         double nxt = (1 + l < n) ? x[1 + l] : 0.0;
         for (long long i0 = 1; i0 < n; i0 += 64, buf ^= 1) {
-            sA[buf][0][l] = nxt;
+            vA[buf * 256 + l] = nxt;
             __builtin_amdgcn_wave_barrier();
             { const long long t = i0 + 64 + l; nxt = t < n ? x[t] : 0.0; }
             const long long cnt = n - i0;
             if (cnt >= 64) {
+                double v[64];
 #pragma unroll
-                for (int s = 0; s < 64; s++) sum = sum + sA[buf][0][s];
+                for (int s = 0; s < 64; s++) v[s] = vA[buf * 256 + s];
+#pragma unroll
+                for (int s = 0; s < 64; s++) sum = sum + v[s];
             } else {
-                for (int s = 0; s < (int)cnt; s++) sum = sum + sA[buf][0][s];
+                for (int s = 0; s < (int)cnt; s++) sum = sum + vA[buf * 256 + s];
             }
         }
     }
@@ -105,33 +122,50 @@ __global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__
         double nf = 0, nr = 0, nc = 0, ndv = 0;
         if (1 + l <= last) { const size_t g = (size_t)nd.start + 1 + l; nf = F[g]; nr = R[g]; nc = Cc[g]; ndv = Dd[g]; }
         for (long long m0 = 1; m0 <= last; m0 += 64, buf ^= 1) {
-            sA[buf][0][l] = nf; sA[buf][1][l] = nr; sA[buf][2][l] = nc; sA[buf][3][l] = ndv;
+            const int bo = buf * 256;
+            vA[bo + l] = nf; vA[bo + 64 + l] = nr; vA[bo + 128 + l] = nc; vA[bo + 192 + l] = ndv;
             __builtin_amdgcn_wave_barrier();
             { const long long t = m0 + 64 + l; if (t <= last) { const size_t g = (size_t)nd.start + (size_t)t; nf = F[g]; nr = R[g]; nc = Cc[g]; ndv = Dd[g]; } }
             const long long cnt = last - m0 + 1;
-#define WV_STEP(s)                                                                                                  \
-            {                                                                                                       \
-                const double f = sA[buf][0][s], c = sA[buf][2][s], d = sA[buf][3][s];                               \
-                const double pn = p * f + c;                                                                        \
-                double qd;                                                                                          \
-                if (FAST) { const double r = sA[buf][1][s]; const double t = q * r; qd = __builtin_fma(__builtin_fma(-f, t, q), r, t); } \
-                else qd = q / f;                                                                                    \
-                const double qn = qd - d;                                                                           \
-                p = pn; q = qn;                                                                                     \
-                sIP[s] = pn - qn; sQ[s] = qn;                                                                       \
-            }
             if (cnt >= 64) {
+                // blocks of WV_PB steps: at most 15 LDS operations may be outstanding for s_waitcnt to tell them apart (lgkmcnt is 4 bits),
+                // 2 x 16-byte reads per step + 1 x 16-byte write per two steps
+                double cur[WV_PB][4], nx[WV_PB][4];
 #pragma unroll
-                for (int s = 0; s < 64; s++) WV_STEP(s)
+                for (int k = 0; k < WV_PB; k++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) cur[k][j] = vA[bo + j * 64 + k];
+#pragma unroll
+                for (int blk = 0; blk < 64 / WV_PB; blk++) {
+                    if (blk < 64 / WV_PB - 1) {
+#pragma unroll
+                        for (int k = 0; k < WV_PB; k++)
+#pragma unroll
+                            for (int j = 0; j < 4; j++) nx[k][j] = vA[bo + j * 64 + (blk + 1) * WV_PB + k];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < WV_PB; k++) {
+                        wv_step<FAST>(p, q, cur[k][0], cur[k][1], cur[k][2], cur[k][3]);
+                        vIP[blk * WV_PB + k] = p - q; vQ[blk * WV_PB + k] = q;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < WV_PB; k++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) cur[k][j] = nx[k][j];
+                }
             } else {
-                for (int s = 0; s < (int)cnt; s++) WV_STEP(s)
+                for (int s = 0; s < (int)cnt; s++) {
+                    wv_step<FAST>(p, q, vA[bo + s], vA[bo + 64 + s], vA[bo + 128 + s], vA[bo + 192 + s]);
+                    vIP[s] = p - q; vQ[s] = q;
+                }
             }
-#undef WV_STEP
             __builtin_amdgcn_wave_barrier();
             if (l < cnt) {
-                const double ip = sIP[l], a = fabs(ip);
+                const double ip = vIP[l], a = fabs(ip);
                 if (a > bestAbs) { bestAbs = a; bestVal = ip; bestIdx = m0 + l; }
-                Q[(size_t)nd.start + (size_t)(m0 + l)] = sQ[l];
+                Q[(size_t)nd.start + (size_t)(m0 + l)] = vQ[l];
             }
         }
     }

@@ -1,6 +1,9 @@
 // Drop-in CanvasPartition executable on top of the C ABI: CLI and file formats of CanvasPartition.Main (CanvasPartition/CanvasPartition.cs:24-190).
-//   CanvasPartition -i S.cleaned [-i ...] -o S.partitioned [-o ...] -r refDir -m PerSampleHMM|HMM|CBS [-b filter.bed] [-s None|Prune|SDUndo] [--config params.json]
-// Built methods: PerSampleHMM, HMM (joint) and CBS.  Wavelets (the reference default) / -c / -p are not built: exit code 1 with a message.
+//   CanvasPartition -i S.cleaned [-i ...] -o S.partitioned [-o ...] -r refDir [-m Wavelets|PerSampleHMM|HMM|CBS] [-g] [-v S.vaf] [-b filter.bed] [-s None|Prune|SDUndo] [--config params.json]
+// Built methods: Wavelets (the default, one sample), PerSampleHMM, HMM (joint) and CBS.  -c / -p / --evenness-metric-file are not built: exit code 1 with a message.
+// Wavelets and -v: WaveletsRunner.Run only derives segments for the chromosomes of SegmentationInput.VafByChr (WaveletsRunner.cs:75), which LoadVAFInput
+// fills for every chromosome of the coverage file when -v is given and leaves empty otherwise (Segmentation.cs:78-79, 158-168).  The allele frequencies themselves
+// never reach the Wavelets method (AdjustBreakpoints gets null, WaveletsRunner.cs:71), so this tool only checks that the -v file exists.
 #include "tool_common.hpp"
 #include <algorithm>
 #include <set>
@@ -39,18 +42,21 @@ int main(int argc, char** argv) {
     const std::string bed = a.get("bedfile");
     if (!bed.empty() && !file_exists(bed)) { printf("CanvasPartition.exe: File %s does not exist! Exiting.\n", bed.c_str()); return 1; }
     std::string method = a.get("method", "Wavelets");
-    if (method != "PerSampleHMM" && method != "CBS" && method != "HMM") { fprintf(stderr, "CanvasPartition (MI355X): method %s is not built (PerSampleHMM, HMM and CBS are)\n", method.c_str()); return 1; }
-    if (a.has("ploidyVcfFile") || a.has("commoncnvs")) { fprintf(stderr, "CanvasPartition (MI355X): -p / -c are not supported by this build\n"); return 1; }
+    if (method != "PerSampleHMM" && method != "CBS" && method != "HMM" && method != "Wavelets") { fprintf(stderr, "CanvasPartition (MI355X): unknown method %s (Wavelets, PerSampleHMM, HMM, CBS)\n", method.c_str()); return 1; }
+    if (a.has("ploidyVcfFile") || a.has("commoncnvs") || a.has("evenness-metric-file")) { fprintf(stderr, "CanvasPartition (MI355X): -p / -c / --evenness-metric-file are not supported by this build\n"); return 1; }
+    for (auto& f : a.all("vaffile")) if (!file_exists(f)) { printf("CanvasPartition.exe: File %s does not exist! Exiting.\n", f.c_str()); return 1; }
+    if (method == "Wavelets" && inFiles.size() != 1) { fprintf(stderr, "CanvasPartition: -m Wavelets takes exactly one sample (segmentationInputs.Single(), CanvasPartition.cs:125)\n"); return 1; }
     if (inFiles.size() != outFiles.size()) { fprintf(stderr, "CanvasPartition: the number of -o must match the number of -i\n"); return 1; }
     std::string split = a.get("split", "None");
     int undo = split == "None" ? 0 : (split == "SDUndo" ? 2 : (split == "Prune" ? 1 : -1));
     if (undo < 0) { fprintf(stderr, "Invalid split method '%s'\n", split.c_str()); return 2; }
     // CanvasPartitionParameters.json (CanvasPartitionParameters.cs:11-16): only the two values this path uses
-    int maxInterBinDist = 1000000; double cbsAlpha = 0.01;
+    int maxInterBinDist = 1000000; double cbsAlpha = 0.01, madFactor = 5.0, thresholdLowerMaf = 0.05; int evennessWindow = 100000;
     if (a.has("config")) { FILE* f = fopen(a.get("config").c_str(), "rb"); if (!f) { printf("CanvasPedigreeCaller.exe: File %s does not exist! Exiting.\n", a.get("config").c_str()); return 1; }
         std::string js; char buf[4096]; size_t k; while ((k = fread(buf, 1, sizeof buf, f)) > 0) js.append(buf, k); fclose(f);
         auto num = [&](const char* key, double d) { size_t p = js.find(key); if (p == std::string::npos) return d; p = js.find(':', p); return p == std::string::npos ? d : strtod(js.c_str() + p + 1, nullptr); };
-        maxInterBinDist = (int)num("\"MaxInterBinDistInSegment\"", maxInterBinDist); cbsAlpha = num("\"CBSalpha\"", cbsAlpha); }
+        maxInterBinDist = (int)num("\"MaxInterBinDistInSegment\"", maxInterBinDist); cbsAlpha = num("\"CBSalpha\"", cbsAlpha);
+        madFactor = num("\"MadFactor\"", madFactor); thresholdLowerMaf = num("\"ThresholdLowerMaf\"", thresholdLowerMaf); evennessWindow = (int)num("\"EvennessScoreWindow\"", evennessWindow); }
     std::map<std::string, std::vector<std::pair<int, int>>> excluded;
     if (!bed.empty()) load_bed(bed, excluded);
 
@@ -107,7 +113,23 @@ int main(int argc, char** argv) {
         Sample& S = samples[s]; const int nchr = (int)S.chromNames.size(); const int64_t N = S.off.back();
         if (N == 0) continue;
         Dev dCov(ctx, N * 8); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCov.p, S.cov.data(), N * 8));
-        if (method == "PerSampleHMM") {
+        if (method == "Wavelets") {
+            printf("Running Wavelet Partitioning\n");
+            std::vector<int32_t> bps((size_t)N + nchr + 1); std::vector<int64_t> bo(nchr + 1);
+            TOOL_TRY(ctx, canvas_wavelets(ctx, nchr, dCov.as<double>(), S.off.data(), a.has("germline") ? 1 : 0, thresholdLowerMaf, 80.0, madFactor, evennessWindow, 10,
+                                          bps.data(), (int64_t)bps.size(), bo.data()));
+            if (!a.has("vaffile")) fprintf(stderr, "CanvasPartition: no -v file: like the reference, Wavelets then derives no segment for any chromosome (WaveletsRunner.cs:75)\n");
+            for (int c = 0; c < nchr && a.has("vaffile"); c++) {            // SegmentationInput.DeriveSegments (Segmentation.cs:83-125)
+                const int64_t b0 = S.off[c], T = S.off[c + 1] - b0;
+                std::vector<int32_t> bp(bps.begin() + bo[c], bps.begin() + bo[c + 1]);
+                Segs sg;
+                if (bp.size() >= 2 && T > 10) {
+                    if (bp[0] != 0) bp.insert(bp.begin(), 0);
+                    for (size_t k = 0; k < bp.size(); k++) { const int64_t a0 = bp[k], a1 = (k + 1 < bp.size() ? bp[k + 1] : T) - 1; sg.push_back({S.start[b0 + a0], S.end[b0 + a1]}); }
+                } else sg.push_back({S.start[b0], S.end[b0 + T - 1]});
+                segBySample[s][S.chromNames[c]] = sg;
+            }
+        } else if (method == "PerSampleHMM") {
             printf("Running Per-sample HMM Partitioning\n");
             Dev dState(ctx, N * 4);
             TOOL_TRY(ctx, canvas_hmm_per_sample(ctx, nchr, dCov.as<double>(), S.off.data(), dState.as<int32_t>()));

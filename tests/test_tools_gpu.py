@@ -120,5 +120,18 @@ def test_canvas_clean_and_partition_executables(tmp_path):
     for out_path, pc in ((part, per), (part2, per2)):
         expj = [f"{NAMES[c]}\t{s_}\t{e_}\t{O.format_g15(float(v))}\t{i}" for c in range(nchr) for s_, e_, v, i in zip(bs[c], be[c], pc[c], ids[c])]
         assert _read(out_path) == expj
-    # Wavelets (the reference default) is not built: explicit failure, not a silent fallback
-    assert subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-o", part, "-r", str(tmp_path)], capture_output=True).returncode == 1
+    # ---- Wavelets, the reference's default method (no -m), with -g and a parameter file; -v only has to exist (see the tool's header)
+    vaf = str(tmp_path / "S.vaf"); open(vaf, "w").write("")
+    cfg = str(tmp_path / "params.json"); open(cfg, "w").write('{"MadFactor": 4.0, "EvennessScoreWindow": 1000, "ThresholdLowerMaf": 0.05}')
+    for extra, germline, kw in (([], False, dict(window=100000)), (["-g", "--config", cfg], True, dict(window=1000, mad_factor=4.0))):
+        r = subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-o", part, "-r", str(tmp_path), "-b", bed, "-v", vaf] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        bps = O.wavelets_genome(per, is_germline=germline, **kw)
+        wstarts = [bs[c][bps[c]].astype(np.uint32) if (len(bps[c]) >= 2 and len(bs[c]) > 10) else bs[c][:1].astype(np.uint32) for c in range(nchr)]
+        assert _read(part) == rows_from(wstarts)
+        assert sum(len(b) for b in bps) > nchr
+    # without -v the reference's Wavelets run derives no segments at all (WaveletsRunner.cs:75): ids only advance at gaps / forbidden intervals
+    r = subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-o", part, "-r", str(tmp_path), "-b", bed], capture_output=True, text=True)
+    assert r.returncode == 0 and _read(part) == rows_from([np.zeros(0, np.uint32)] * nchr)
+    # two samples: segmentationInputs.Single() throws in the reference
+    assert subprocess.run([os.path.join(BIN, "CanvasPartition"), "-i", cleaned, "-i", cleaned2, "-o", part, "-o", part2, "-r", str(tmp_path)], capture_output=True).returncode == 1
