@@ -11,32 +11,42 @@
 // the order of operations below is exactly the reference's.
 //
 // Device mapping (one launch set per tree LEVEL, all chromosomes and all nodes of the level at once):
-//   * coefficients f, g*x, x/h (6 divisions + 3 square roots per element) carry no dependence: k_wv_coeff computes them for
-//     every element of the long nodes in parallel, together with the refined reciprocal of f (see below);
-//   * k_wv_chain_long: one wave per long node.  The operands of 64 steps are staged through LDS, every lane runs the same
-//     dependent chain on broadcast operands (5 dependent FP64 operations per step: the chain IS the critical path of the method),
-//     lane s keeps |I+ - I-| of step s of each chunk, so the arg-max never touches memory;
-//   * the division I-[m-1] / f_m inside the chain is evaluated as the hardware's own division sequence with its
-//     operand-independent half hoisted out (r = refined reciprocal of f; t = a*r; q = fma(fma(-f, t, a), r, t)): 3 dependent
-//     operations instead of ~15.  k_wv_verify re-checks every step with a plain IEEE division in parallel; a node with any
-//     mismatch is recomputed by the exact variant of the kernel, so results never depend on the shortcut;
-//   * k_wv_short: nodes of at most WV_LONG elements, one LANE per node (millions of them in the deep levels), everything inline.
+//   * k_wv_coeff: the coefficients f, g*x, x/h (6 divisions + 3 square roots per element) carry no dependence and are computed for every
+//     element of the long nodes in parallel, together with the refined reciprocal of f (see below);
+//   * k_wv_chain_long: one wave per long node and nothing but the recurrences: the operands of 7 steps at a time are prefetched through
+//     LDS, every lane runs the same chain on broadcast operands (6 FP64 operations per step, issued back to back: the chain IS the
+//     critical path of the method), and the state in front of every chunk of 56 steps is written out;
+//   * the division I-[m-1] / f_m inside the chain is evaluated as the hardware's own division sequence with its operand-independent
+//     half hoisted out (r = refined reciprocal of f; t = a*r; q = fma(fma(-f, t, a), r, t)): 3 dependent operations instead of ~15;
+//   * k_wv_chunks: one LANE per chunk recomputes the chunk from its checkpoint with plain IEEE divisions and must arrive at the next
+//     checkpoint bit for bit.  Checkpoint 0 is exact by construction, so by induction every checkpoint and every value is exact — or the
+//     node is flagged and recomputed with IEEE divisions in the chain; results never depend on the shortcut.  The same lanes take the
+//     first arg-max of their steps, k_wv_reduce combines them per node;
+//   * k_wv_short: nodes of at most WV_LONG elements, one lane per node (millions of them in the deep levels), everything inline.
 // The host keeps the tree (start / breakpoint / end, coefficient per node), applies HardThresh, rebuilds the breakpoints and runs the
 // two median-based clean-up passes (GetBreakpointsAfterHealingBadSplits, RefineSegments), which are sequential decisions over a
-// few hundred breakpoints.
+// few hundred breakpoints; the coverage-variability inputs (windowed MAD / median, factor-of-three CMADs) are order statistics of
+// small windows and run on a few host threads.
 #include "common.hpp"
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <limits>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #define WV_LONG 256       // nodes longer than this take the wave-per-node path
-#define WV_CHUNK 256      // elements per coefficient / verification work item
-#define WV_PB 4           // steps per operand-prefetch block of the chain kernel
+#define WV_CS 56          // steps per chunk of a long node (a checkpoint of the chain state is kept per chunk)
+#define WV_PB 7           // steps per operand-prefetch block: 2 LDS reads per step and at most 15 outstanding for s_waitcnt to tell apart
 
 struct WvNode { int32_t start; int32_t len; };            // start = index into the concatenated coverage, len >= 2
 struct WvOut { double coef; int32_t ind; int32_t flag; };  // ind = GetInnerProdMax (1-based inside the node); flag: shortcut mismatch
-struct WvItem { int32_t node; int32_t m0; };
+struct WvOps { double f, r, c, d; };                       // per step: factor, its refined reciprocal, x*g, x/h
+struct WvCk { double p, q; };                              // chain state in front of a chunk
+struct WvBest { double val; int32_t idx; int32_t pad; };   // first arg-max of |I+ - I-| inside a chunk
+struct WvHead { double mean, ip0; };                       // per long node: mean of the stretch, I+[0] - I-[0]
 
 __device__ __forceinline__ double wv_factor(long long n, long long m) { return sqrt((double)(n - m - 1) * (double)m / (double)(m + 1) / (double)(n - m)); }
 __device__ __forceinline__ double wv_g(long long n, long long m) { return sqrt(1.0 / (double)(m + 1) - 1.0 / (double)n); }
@@ -48,19 +58,28 @@ __device__ __forceinline__ double wv_rcp_refined(double f) {
     e = __builtin_fma(-f, r, 1.0); r = __builtin_fma(r, e, r);
     return r;
 }
+// chunk g of the level -> index into the long-node list (base[k] <= g < base[k+1])
+__device__ __forceinline__ int wv_find(const int32_t* __restrict__ base, int nLong, int g) {
+    int lo = 0, hi = nLong - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (base[mid] <= g) lo = mid; else hi = mid - 1; }
+    return lo;
+}
 
-__global__ void __launch_bounds__(WV_CHUNK) k_wv_coeff(const WvNode* __restrict__ nodes, const WvItem* __restrict__ items, const double* __restrict__ X,
-                                                       double* __restrict__ F, double* __restrict__ R, double* __restrict__ Cc, double* __restrict__ Dd) {
-    const WvItem it = items[blockIdx.x];
-    const WvNode nd = nodes[it.node];
-    const long long n = nd.len, m = (long long)it.m0 + threadIdx.x;
-    if (m < 1 || m > n - 2) return;
+// one block (64 lanes) per chunk, one lane per step
+__global__ void __launch_bounds__(64) k_wv_coeff(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const int32_t* __restrict__ base, int nLong,
+                                                 const double* __restrict__ X, WvOps* __restrict__ ops) {
+    const int g = blockIdx.x;
+    const int k = wv_find(base, nLong, g);
+    const WvNode nd = nodes[list[k]];
+    const long long n = nd.len, m = 1 + (long long)(g - base[k]) * WV_CS + threadIdx.x;
+    if (threadIdx.x >= WV_CS || m > n - 2) return;
     const size_t p = (size_t)nd.start + (size_t)m;
     const double x = X[p];
-    const double f = wv_factor(n, m);
-    F[p] = f; R[p] = wv_rcp_refined(f);
-    Cc[p] = x * wv_g(n, m);
-    Dd[p] = x / wv_h(n, m);
+    WvOps o;
+    o.f = wv_factor(n, m); o.r = wv_rcp_refined(o.f);
+    o.c = x * wv_g(n, m);
+    o.d = x / wv_h(n, m);
+    ops[p] = o;
 }
 
 // One step of both recurrences on uniform operands (every lane computes the same values).
@@ -74,16 +93,16 @@ __device__ __forceinline__ void wv_step(double& p, double& q, double f, double r
     p = pn;
 }
 
+// The critical path of the method: one wave per long node, nothing but the two recurrences (6 dependent-issue FP64 operations per
+// step) behind the sequential sum.  The state in front of every chunk of WV_CS steps is written out; k_wv_chunks recomputes every
+// chunk from its checkpoint with IEEE divisions in parallel, which both proves the checkpoints (by induction over the chunks) and
+// yields the arg-max, so neither the shortcut division nor the arg-max bookkeeping sits on the chain.
 template <bool FAST>
-__global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const double* __restrict__ X,
-                                                      const double* __restrict__ F, const double* __restrict__ R, const double* __restrict__ Cc,
-                                                      const double* __restrict__ Dd, double* __restrict__ Q, WvOut* __restrict__ out) {
-    // the chain is latency-bound (one wave, 4 dependent FP64 operations per step): the operand reads of the NEXT eight steps are issued
-    // before the current eight are computed; the scheduling barriers keep the compiler from sinking them back to their first use
-    __shared__ double vA[2 * 4 * 64];           // [buf][f, r, c, d][step]
-    __shared__ double vIP[64], vQ[64];
-    const int node = list[blockIdx.x];
-    const WvNode nd = nodes[node];
+__global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const int32_t* __restrict__ base,
+                                                      const double* __restrict__ X, const WvOps* __restrict__ ops, WvCk* __restrict__ ck, WvHead* __restrict__ head) {
+    __shared__ double4 sO[2][64];              // [buf][step] = (f, r, c, d); the sum pass uses sO[buf][s].x
+    const int k = blockIdx.x;
+    const WvNode nd = nodes[list[k]];
     const long long n = nd.len;
     const int l = threadIdx.x;
     const double* __restrict__ x = X + nd.start;
@@ -93,102 +112,111 @@ __global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__
         int buf = 0;
         double nxt = (1 + l < n) ? x[1 + l] : 0.0;
         for (long long i0 = 1; i0 < n; i0 += 64, buf ^= 1) {
-            vA[buf * 256 + l] = nxt;
+            sO[buf][l].x = nxt;
             __builtin_amdgcn_wave_barrier();
             { const long long t = i0 + 64 + l; nxt = t < n ? x[t] : 0.0; }
             const long long cnt = n - i0;
             if (cnt >= 64) {
                 double v[64];
 #pragma unroll
-                for (int s = 0; s < 64; s++) v[s] = vA[buf * 256 + s];
+                for (int s = 0; s < 64; s++) v[s] = sO[buf][s].x;
 #pragma unroll
                 for (int s = 0; s < 64; s++) sum = sum + v[s];
             } else {
-                for (int s = 0; s < (int)cnt; s++) sum = sum + vA[buf * 256 + s];
+                for (int s = 0; s < (int)cnt; s++) sum = sum + sO[buf][s].x;
             }
         }
     }
     const double x0 = x[0];
     double p = sqrt(1 - 1.0 / (double)n) * x0;
     double q = (1.0 / sqrt((double)(n * (n - 1)))) * sum;
-    const double mean = (x0 + sum) / (double)n;
-    // lane s owns the steps m = 1 + 64 c + s; lane 0 also owns m = 0
-    double bestVal = p - q, bestAbs = l == 0 ? fabs(p - q) : -1.0;
-    long long bestIdx = 0;
-    if (l == 0) Q[nd.start] = q;
+    if (l == 0) { WvHead h; h.mean = (x0 + sum) / (double)n; h.ip0 = p - q; head[k] = h; }
     {
         int buf = 0;
         const long long last = n - 2;                                     // steps m = 1 .. n-2
-        double nf = 0, nr = 0, nc = 0, ndv = 0;
-        if (1 + l <= last) { const size_t g = (size_t)nd.start + 1 + l; nf = F[g]; nr = R[g]; nc = Cc[g]; ndv = Dd[g]; }
-        for (long long m0 = 1; m0 <= last; m0 += 64, buf ^= 1) {
-            const int bo = buf * 256;
-            vA[bo + l] = nf; vA[bo + 64 + l] = nr; vA[bo + 128 + l] = nc; vA[bo + 192 + l] = ndv;
+        const WvOps* __restrict__ o = ops + nd.start;
+        WvCk* __restrict__ ckn = ck + base[k];
+        double4 nv = make_double4(0, 0, 0, 0);
+        if (l < WV_CS && 1 + l <= last) { const WvOps t = o[1 + l]; nv = make_double4(t.f, t.r, t.c, t.d); }
+        long long c = 0;
+        for (long long m0 = 1; m0 <= last; m0 += WV_CS, buf ^= 1, c++) {
+            if (l == 0) { WvCk t; t.p = p; t.q = q; ckn[c] = t; }
+            sO[buf][l] = nv;
             __builtin_amdgcn_wave_barrier();
-            { const long long t = m0 + 64 + l; if (t <= last) { const size_t g = (size_t)nd.start + (size_t)t; nf = F[g]; nr = R[g]; nc = Cc[g]; ndv = Dd[g]; } }
+            { const long long t = m0 + WV_CS + l; if (l < WV_CS && t <= last) { const WvOps u = o[t]; nv = make_double4(u.f, u.r, u.c, u.d); } }
             const long long cnt = last - m0 + 1;
-            if (cnt >= 64) {
-                // blocks of WV_PB steps: at most 15 LDS operations may be outstanding for s_waitcnt to tell them apart (lgkmcnt is 4 bits),
-                // 2 x 16-byte reads per step + 1 x 16-byte write per two steps
-                double cur[WV_PB][4], nx[WV_PB][4];
+            if (cnt >= WV_CS) {
+                double4 cur[WV_PB], nx[WV_PB];
 #pragma unroll
-                for (int k = 0; k < WV_PB; k++)
+                for (int j = 0; j < WV_PB; j++) cur[j] = sO[buf][j];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) cur[k][j] = vA[bo + j * 64 + k];
+                for (int blk = 0; blk < WV_CS / WV_PB; blk++) {
+                    if (blk < WV_CS / WV_PB - 1) {
 #pragma unroll
-                for (int blk = 0; blk < 64 / WV_PB; blk++) {
-                    if (blk < 64 / WV_PB - 1) {
-#pragma unroll
-                        for (int k = 0; k < WV_PB; k++)
-#pragma unroll
-                            for (int j = 0; j < 4; j++) nx[k][j] = vA[bo + j * 64 + (blk + 1) * WV_PB + k];
+                        for (int j = 0; j < WV_PB; j++) nx[j] = sO[buf][(blk + 1) * WV_PB + j];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < WV_PB; k++) {
-                        wv_step<FAST>(p, q, cur[k][0], cur[k][1], cur[k][2], cur[k][3]);
-                        vIP[blk * WV_PB + k] = p - q; vQ[blk * WV_PB + k] = q;
-                    }
+                    for (int j = 0; j < WV_PB; j++) wv_step<FAST>(p, q, cur[j].x, cur[j].y, cur[j].z, cur[j].w);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < WV_PB; k++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) cur[k][j] = nx[k][j];
+                    for (int j = 0; j < WV_PB; j++) cur[j] = nx[j];
                 }
             } else {
-                for (int s = 0; s < (int)cnt; s++) {
-                    wv_step<FAST>(p, q, vA[bo + s], vA[bo + 64 + s], vA[bo + 128 + s], vA[bo + 192 + s]);
-                    vIP[s] = p - q; vQ[s] = q;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (l < cnt) {
-                const double ip = vIP[l], a = fabs(ip);
-                if (a > bestAbs) { bestAbs = a; bestVal = ip; bestIdx = m0 + l; }
-                Q[(size_t)nd.start + (size_t)(m0 + l)] = vQ[l];
+                for (int s = 0; s < (int)cnt; s++) { const double4 t = sO[buf][s]; wv_step<FAST>(p, q, t.x, t.y, t.z, t.w); }
             }
         }
     }
-    // first index of the maximum of |I+ - I-| (WaveletSegmentation.cs:54-68)
+}
+
+// One lane per chunk: the chunk again, from its checkpoint, with plain IEEE divisions.  Its end state must be the next checkpoint bit
+// for bit (checkpoint 0 is exact by construction, so every checkpoint and therefore every value seen here is exact); the lane keeps the
+// first arg-max of |I+ - I-| of its steps.
+__global__ void __launch_bounds__(64) k_wv_chunks(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const int32_t* __restrict__ base, int nLong,
+                                                  int nChunks, const WvOps* __restrict__ ops, const WvCk* __restrict__ ck, WvBest* __restrict__ best, int32_t* __restrict__ flag) {
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= nChunks) return;
+    const int k = wv_find(base, nLong, g);
+    const WvNode nd = nodes[list[k]];
+    const long long n = nd.len, last = n - 2;
+    const long long m0 = 1 + (long long)(g - base[k]) * WV_CS;
+    const long long cnt = last - m0 + 1 < WV_CS ? last - m0 + 1 : WV_CS;
+    const WvOps* __restrict__ o = ops + nd.start + m0;
+    double p = ck[g].p, q = ck[g].q;
+    double bestVal = 0.0, bestAbs = -1.0; int32_t bestIdx = 0;
+    for (int s = 0; s < (int)cnt; s++) {
+        const WvOps t = o[s];
+        p = p * t.f + t.c;
+        q = q / t.f - t.d;
+        const double ip = p - q, a = fabs(ip);
+        if (a > bestAbs) { bestAbs = a; bestVal = ip; bestIdx = (int32_t)(m0 + s); }
+    }
+    WvBest b; b.val = bestVal; b.idx = bestIdx; b.pad = 0;
+    best[g] = b;
+    if (g + 1 < base[k + 1]) {
+        const WvCk nxt = ck[g + 1];
+        if (__double_as_longlong(nxt.p) != __double_as_longlong(p) || __double_as_longlong(nxt.q) != __double_as_longlong(q)) flag[k] = 1;
+    }
+}
+// one wave per long node: first index of the maximum of |I+ - I-| (WaveletSegmentation.cs:54-68) over m = 0 and the chunk results
+__global__ void __launch_bounds__(64) k_wv_reduce(const int32_t* __restrict__ list, const int32_t* __restrict__ base, const WvHead* __restrict__ head,
+                                                  const WvBest* __restrict__ best, const int32_t* __restrict__ flag, WvOut* __restrict__ out) {
+    const int k = blockIdx.x, l = threadIdx.x;
+    const WvHead h = head[k];
+    double bestVal = h.ip0, bestAbs = l == 0 ? fabs(h.ip0) : -1.0;
+    int32_t bestIdx = 0;
+    for (int g = base[k] + l; g < base[k + 1]; g += 64) {
+        const WvBest b = best[g];
+        const double a = fabs(b.val);
+        if (a > bestAbs) { bestAbs = a; bestVal = b.val; bestIdx = b.idx; }      // chunks arrive in increasing index order within a lane
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const double oa = __shfl_xor(bestAbs, d, 64), ov = __shfl_xor(bestVal, d, 64);
-        const long long oi = __shfl_xor(bestIdx, d, 64);
+        const int32_t oi = __shfl_xor(bestIdx, d, 64);
         if (oa > bestAbs || (oa == bestAbs && oi < bestIdx)) { bestAbs = oa; bestVal = ov; bestIdx = oi; }
     }
-    if (l == 0) { WvOut o; o.coef = bestVal / fmax(0.5, mean / 200.0); o.ind = (int32_t)bestIdx + 1; o.flag = 0; out[node] = o; }
-}
-
-// every step of the shortcut division against the plain IEEE one (bit patterns, so that NaN == NaN)
-__global__ void __launch_bounds__(WV_CHUNK) k_wv_verify(const WvNode* __restrict__ nodes, const WvItem* __restrict__ items, const double* __restrict__ F,
-                                                        const double* __restrict__ Dd, const double* __restrict__ Q, WvOut* __restrict__ out) {
-    const WvItem it = items[blockIdx.x];
-    const WvNode nd = nodes[it.node];
-    const long long n = nd.len, m = (long long)it.m0 + threadIdx.x;
-    if (m < 1 || m > n - 2) return;
-    const size_t p = (size_t)nd.start + (size_t)m;
-    const double want = Q[p - 1] / F[p] - Dd[p];
-    if (__double_as_longlong(want) != __double_as_longlong(Q[p])) out[it.node].flag = 1;
+    if (l == 0) { WvOut o; o.coef = bestVal / fmax(0.5, h.mean / 200.0); o.ind = bestIdx + 1; o.flag = flag[k]; out[list[k]] = o; }
 }
 
 // nodes of at most WV_LONG elements: one lane per node, the reference's loop as it stands
@@ -226,6 +254,21 @@ template <class T>
 static void dotnet_sort(std::vector<T>& v) { auto mid = std::partition(v.begin(), v.end(), [](T a) { return a != a; }); std::sort(mid, v.end()); }
 template <class T>
 static T median_sorted(const std::vector<T>& v) { const size_t n = v.size(); if (!n) return T(0); return (n & 1) ? v[n / 2] : (T)((v[n / 2 - 1] + v[n / 2]) / (T)2); }
+// SortedList<double>.Median() by selection: NaN (which .NET sorts in front of every number) counted as the smallest values
+static double dotnet_median_select(std::vector<double>& v) {
+    const size_t n = v.size();
+    if (!n) return 0.0;
+    auto mid = std::partition(v.begin(), v.end(), [](double a) { return a != a; });
+    const size_t nan = (size_t)(mid - v.begin());
+    auto kth = [&](size_t k) -> double {                  // k-th smallest in .NET order
+        if (k < nan) return std::numeric_limits<double>::quiet_NaN();
+        std::nth_element(mid, v.begin() + k, v.end());
+        return v[k];
+    };
+    if (n & 1) return kth(n / 2);
+    const double hi = kth(n / 2), lo = kth(n / 2 - 1);
+    return (lo + hi) / 2;
+}
 // Utilities.Median(x, start, end) (Utilities.cs:428-443) on finite data: two order statistics instead of a full sort
 static double median_range(const double* x, int64_t a, int64_t b) {
     std::vector<double> v(x + a, x + b);
@@ -259,13 +302,27 @@ static void quartiles(std::vector<float> s, float& q1, float& q2, float& q3) {  
         else if ((iSize - 3) % 4 == 0) { const int n = (iSize - 3) / 4; q1 = (s[n] * 0.75f) + (s[n + 1] * 0.25f); q3 = (s[3 * n + 1] * 0.25f) + (s[3 * n + 2] * 0.75f); }
     }
 }
-// SegmentationInput.reportVariabilityByWindow (Segmentation.cs:334-349): MAD / median per window, as float
+// the windows / chromosomes of the variability statistics are independent: a few host threads share them
+template <class Fn>
+static void host_parallel_for(int64_t n, const Fn& fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::min<int64_t>(n, std::max(1u, std::min(hw ? hw : 1u, 16u)));
+    if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int64_t> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([&]() { for (int64_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& t : th) t.join();
+}
+// SegmentationInput.reportVariabilityByWindow (Segmentation.cs:334-349): MAD / median per window, as float (the order of the values does
+// not matter: the callers only take order statistics of them)
 static std::vector<float> variability_by_window(int window, int nchr, const double* cov, const int64_t* off) {
-    std::vector<float> out;
-    for (int c = 0; c < nchr; c++) {
-        const double* x = cov + off[c]; const int64_t L = off[c + 1] - off[c];
-        for (int64_t i = 0; i < L - window; i += window) out.push_back((float)(mad_range(x, i, i + window) / median_range(x, i, i + window)));
-    }
+    std::vector<std::pair<int, int64_t>> wins;
+    for (int c = 0; c < nchr; c++) { const int64_t L = off[c + 1] - off[c]; for (int64_t i = 0; i < L - window; i += window) wins.push_back({c, i}); }
+    std::vector<float> out(wins.size());
+    host_parallel_for((int64_t)wins.size(), [&](int64_t w) {
+        const double* x = cov + off[wins[w].first]; const int64_t i = wins[w].second;
+        out[w] = (float)(mad_range(x, i, i + window) / median_range(x, i, i + window));
+    });
     return out;
 }
 // SegmentationInput.GetCoverageVariability (Segmentation.cs:308-328)
@@ -288,24 +345,25 @@ static std::vector<double> factor_of_three(int nchr, const double* cov, const in
     std::vector<std::vector<double>> cur(nchr);
     for (int c = 0; c < nchr; c++) cur[c].assign(cov + off[c], cov + off[c + 1]);
     for (int exponent = 1; exponent <= maxExponent; ++exponent) {
-        std::vector<double> cmads;
-        for (int c = 0; c < nchr; c++) {
+        std::vector<std::vector<double>> part(nchr);
+        host_parallel_for(nchr, [&](int64_t c) {
             const std::vector<double>& d = cur[c];
             const size_t n = d.size() / 3;
-            std::vector<double> med(n);
+            std::vector<double> med(n); part[c].resize(n);
             for (size_t i = 0; i < n; i++) {
                 double a = d[3 * i], b = d[3 * i + 1], e = d[3 * i + 2];
                 if (a > b) std::swap(a, b);
                 if (a > e) std::swap(a, e);
                 if (b > e) std::swap(b, e);
                 med[i] = b;
-                cmads.push_back((e - a) / 2.0 / b);
+                part[c][i] = (e - a) / 2.0 / b;
             }
             cur[c].swap(med);
-        }
+        });
+        std::vector<double> cmads;
+        for (int c = 0; c < nchr; c++) cmads.insert(cmads.end(), part[c].begin(), part[c].end());
         if (cmads.size() < 50) { const double last = f3.back(); while ((int)f3.size() < maxExponent + 1) f3.push_back(last); break; }
-        dotnet_sort(cmads);
-        f3.push_back(median_sorted(cmads));
+        f3.push_back(dotnet_median_select(cmads));
     }
     return f3;
 }
@@ -391,10 +449,14 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(X.data(), dX, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t i = 0; i < N; i++) if (!std::isfinite(X[i])) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: coverage must be finite");
+    const bool timing = getenv("CANVAS_WV_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     double cv = 0;
     const bool hasCV = coverage_variability(variability_window, nchr, X.data(), off.data(), cv);
     const std::vector<double> f3 = factor_of_three(nchr, X.data(), off.data());
 
+    const double t1 = now();
     // ---- roots: chromosomes longer than MinSize (WaveletsRunner.cs:117-126)
     std::vector<ChromTree> trees(nchr);
     std::vector<HNode> cur, nxt;
@@ -414,41 +476,50 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         cur.push_back({c, 1, (int32_t)L});
     }
     // ---- device buffers
-    const size_t maxNodes = (size_t)N / 2 + (size_t)nchr + 16, maxItems = (size_t)N / WV_CHUNK + maxNodes / 1 + 16;
+    const size_t maxNodes = (size_t)N / 2 + (size_t)nchr + 16, maxLong = (size_t)N / WV_LONG + 16, maxChunks = (size_t)N / WV_CS + maxLong + 16;
     WsSizer sz;
-    for (int k = 0; k < 5; k++) sz.take<double>((size_t)N);
-    sz.take<WvNode>(maxNodes); sz.take<WvOut>(maxNodes); sz.take<int32_t>(maxNodes); sz.take<int32_t>(maxNodes); sz.take<WvItem>(maxItems);
+    sz.take<WvOps>((size_t)N); sz.take<WvNode>(maxNodes); sz.take<WvOut>(maxNodes); sz.take<int32_t>(maxNodes); sz.take<int32_t>(maxLong);
+    sz.take<int32_t>(maxLong + 1); sz.take<int32_t>(maxLong); sz.take<WvHead>(maxLong); sz.take<WvCk>(maxChunks); sz.take<WvBest>(maxChunks);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     WsCarver ws(ctx->ws);
-    double* dF = ws.take<double>((size_t)N); double* dR = ws.take<double>((size_t)N); double* dC = ws.take<double>((size_t)N);
-    double* dD = ws.take<double>((size_t)N); double* dQ = ws.take<double>((size_t)N);
-    WvNode* dNodes = ws.take<WvNode>(maxNodes); WvOut* dOut = ws.take<WvOut>(maxNodes);
-    int32_t* dLong = ws.take<int32_t>(maxNodes); int32_t* dShort = ws.take<int32_t>(maxNodes); WvItem* dItems = ws.take<WvItem>(maxItems);
-    std::vector<WvNode> hNodes; std::vector<WvOut> hOut; std::vector<int32_t> hLong, hShort, hRedo; std::vector<WvItem> hItems;
+    WvOps* dOps = ws.take<WvOps>((size_t)N); WvNode* dNodes = ws.take<WvNode>(maxNodes); WvOut* dOut = ws.take<WvOut>(maxNodes);
+    int32_t* dShort = ws.take<int32_t>(maxNodes); int32_t* dLong = ws.take<int32_t>(maxLong); int32_t* dBase = ws.take<int32_t>(maxLong + 1);
+    int32_t* dFlag = ws.take<int32_t>(maxLong); WvHead* dHead = ws.take<WvHead>(maxLong); WvCk* dCk = ws.take<WvCk>(maxChunks); WvBest* dBest = ws.take<WvBest>(maxChunks);
+    std::vector<WvNode> hNodes; std::vector<WvOut> hOut; std::vector<int32_t> hLong, hBase, hShort, hRedo;
     long long levels = 0, redone = 0;
+    // the kernels of one level for the long nodes in dLong / dBase (chain = the shortcut or the IEEE division)
+    auto long_pass = [&](size_t nLong, int nChunks, bool fast) -> int32_t {
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFlag, 0, nLong * sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(k_wv_coeff, dim3((unsigned)nChunks), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, (int)nLong, dX, dOps);
+        { ProfScope ps(ctx, "wavelet_chain");
+          if (fast) hipLaunchKernelGGL((k_wv_chain_long<true>), dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, dX, dOps, dCk, dHead);
+          else hipLaunchKernelGGL((k_wv_chain_long<false>), dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, dX, dOps, dCk, dHead); }
+        hipLaunchKernelGGL(k_wv_chunks, dim3((unsigned)((nChunks + 63) / 64)), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, (int)nLong, nChunks, dOps, dCk, dBest, dFlag);
+        hipLaunchKernelGGL(k_wv_reduce, dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dLong, dBase, dHead, dBest, dFlag, dOut);
+        return CANVAS_OK;
+    };
+    auto upload_long = [&](const std::vector<int32_t>& list) -> int {          // returns the number of chunks
+        hBase.assign(1, 0);
+        for (int32_t i : list) hBase.push_back(hBase.back() + (int32_t)((hNodes[i].len - 2 + WV_CS - 1) / WV_CS));
+        (void)hipMemcpyAsync(dLong, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(dBase, hBase.data(), hBase.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        return hBase.back();
+    };
     // ---- FindBestUnbalancedHaarDecomposition (WaveletSegmentation.cs:252-366), level by level for all chromosomes at once
     for (int level = 0; !cur.empty(); level++, levels++) {
         const size_t nn = cur.size();
-        hNodes.resize(nn); hOut.resize(nn); hLong.clear(); hItems.clear();
+        hNodes.resize(nn); hOut.resize(nn); hLong.clear();
         std::vector<int32_t> byLen[WV_LONG + 1];
         for (size_t i = 0; i < nn; i++) {
             const HNode& h = cur[i];
             const int32_t len = h.e - h.s + 1;
             hNodes[i] = {(int32_t)(off[h.chrom] + h.s - 1), len};
-            if (len > WV_LONG) { hLong.push_back((int32_t)i); for (int32_t m0 = 0; m0 < len; m0 += WV_CHUNK) hItems.push_back({(int32_t)i, m0}); }
-            else byLen[len].push_back((int32_t)i);
+            if (len > WV_LONG) hLong.push_back((int32_t)i); else byLen[len].push_back((int32_t)i);
         }
         hShort.clear();                                      // nodes of similar length share a wave
         for (int len = WV_LONG; len >= 2; len--) hShort.insert(hShort.end(), byLen[len].begin(), byLen[len].end());
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dNodes, hNodes.data(), nn * sizeof(WvNode), hipMemcpyHostToDevice, ctx->stream));
-        if (!hLong.empty()) {
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dLong, hLong.data(), hLong.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dItems, hItems.data(), hItems.size() * sizeof(WvItem), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_wv_coeff, dim3((unsigned)hItems.size()), dim3(WV_CHUNK), 0, ctx->stream, dNodes, dItems, dX, dF, dR, dC, dD);
-            { ProfScope ps(ctx, "wavelet_chain");
-              hipLaunchKernelGGL((k_wv_chain_long<true>), dim3((unsigned)hLong.size()), dim3(64), 0, ctx->stream, dNodes, dLong, dX, dF, dR, dC, dD, dQ, dOut); }
-            hipLaunchKernelGGL(k_wv_verify, dim3((unsigned)hItems.size()), dim3(WV_CHUNK), 0, ctx->stream, dNodes, dItems, dF, dD, dQ, dOut);
-        }
+        if (!hLong.empty()) { const int nChunks = upload_long(hLong); rc = long_pass(hLong.size(), nChunks, true); if (rc) return rc; }
         if (!hShort.empty()) {
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dShort, hShort.data(), hShort.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(k_wv_short, dim3((unsigned)((hShort.size() + 63) / 64)), dim3(64), 0, ctx->stream, dNodes, dShort, (int)hShort.size(), dX, dOut);
@@ -457,13 +528,15 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
         hRedo.clear();
-        for (int32_t i : hLong) if (hOut[i].flag) hRedo.push_back(i);
-        if (!hRedo.empty()) {                                // the shortcut division disagreed somewhere: exact chain for those nodes
-            redone += (long long)hRedo.size();
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dLong, hRedo.data(), hRedo.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL((k_wv_chain_long<false>), dim3((unsigned)hRedo.size()), dim3(64), 0, ctx->stream, dNodes, dLong, dX, dF, dR, dC, dD, dQ, dOut);
+        for (int32_t i : hLong) if (hOut[i].flag || getenv("CANVAS_WV_TEST_EXACT")) hRedo.push_back(i);
+        if (!hRedo.empty()) {                                // a checkpoint of the shortcut chain was not reproduced: IEEE divisions in the chain for those nodes
+            if (!getenv("CANVAS_WV_TEST_EXACT")) redone += (long long)hRedo.size();
+            const int nChunks = upload_long(hRedo);
+            rc = long_pass(hRedo.size(), nChunks, false); if (rc) return rc;
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipGetLastError());
+            for (int32_t i : hRedo) if (hOut[i].flag) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the exact chain was not reproduced by its own check");
         }
         nxt.clear();
         for (size_t i = 0; i < nn; i++) {
@@ -479,6 +552,7 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         cur.swap(nxt);
     }
     ctx->wv_levels = levels; ctx->wv_redone = redone;
+    const double t2 = now();
     // ---- per chromosome: HardThresh, reconstruction, healing, refinement (WaveletSegmentation.cs:73-250, 373-425)
     int64_t total = 0;
     for (int c = 0; c < nchr; c++) {
@@ -539,6 +613,7 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         for (int v : bp) h_breakpoints[total++] = v;
     }
     h_bp_offset[nchr] = total;
+    if (timing) fprintf(stderr, "canvas_wavelets: variability %.3f s, decomposition %.3f s (%lld levels), thresholds/reconstruction/healing %.3f s\n", t1 - t0, t2 - t1, levels, now() - t2);
     return CANVAS_OK;
 }
 

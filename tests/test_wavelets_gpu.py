@@ -67,3 +67,16 @@ def test_wavelets_flat_and_degenerate_input():
     bad = np.full(100, 50.0); bad[7] = np.nan
     with pytest.raises(Exception):
         _run(cv, [bad], window=11)
+
+
+def test_exact_chain_fallback_gives_the_same_tree(monkeypatch):
+    """CANVAS_WV_TEST_EXACT=1 recomputes every long node with IEEE divisions in the chain (the path taken when a checkpoint of the shortcut
+    chain is not reproduced): same breakpoints, and the run is not counted as a disagreement."""
+    cv = get_canvas()
+    rng = np.random.RandomState(11)
+    per = [_coverage(rng, 50_000, wave=0.05), _coverage(rng, 3_000)]
+    exp = O.wavelets_genome(per, is_germline=True, window=5000)
+    monkeypatch.setenv("CANVAS_WV_TEST_EXACT", "1")
+    got = _run(cv, per, is_germline=True, window=5000)
+    assert [g.tolist() for g in got] == [e.tolist() for e in exp]
+    assert cv.wavelets_stats()[1] == 0
