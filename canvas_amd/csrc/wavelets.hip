@@ -473,6 +473,7 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         // a coefficient at or below 2 sigma t sqrt(2 ln n) with the smallest possible level weight t is zeroed whatever the level
         // weights turn out to be: such nodes need not be kept (the margin keeps every borderline node for the exact test)
         trees[c].keepAbove = 2 * threshold * (is_germline ? 0.8 : 1.0) * std::sqrt(2 * std::log((double)L)) * (1.0 - 1e-9);
+        if (!(trees[c].keepAbove == trees[c].keepAbove)) trees[c].keepAbove = -1.0;   // NaN threshold (a window with median 0): nothing is ever zeroed
         cur.push_back({c, 1, (int32_t)L});
     }
     // ---- device buffers

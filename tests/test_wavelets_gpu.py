@@ -80,3 +80,16 @@ def test_exact_chain_fallback_gives_the_same_tree(monkeypatch):
     got = _run(cv, per, is_germline=True, window=5000)
     assert [g.tolist() for g in got] == [e.tolist() for e in exp]
     assert cv.wavelets_stats()[1] == 0
+
+
+def test_nan_threshold_keeps_every_coefficient():
+    """Most windows have median 0, so MAD / median is NaN, the coverage variability is NaN and so is the threshold: HardThresh's
+    '<=' is then never true and no coefficient is zeroed (found by tools/soak_wavelets.py)."""
+    cv = get_canvas()
+    rng = np.random.RandomState(5)
+    x = np.zeros(1200); x[800:] = rng.poisson(40, 400)
+    assert np.isnan(O.coverage_variability(100, [x]))
+    for germline in (False, True):
+        exp = O.wavelets_genome([x], is_germline=germline, window=100)
+        got = _run(cv, [x], is_germline=germline, window=100)
+        assert got[0].tolist() == exp[0].tolist() and len(exp[0]) > 20
