@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
-    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_wavelets", "canvas_wavelets_stats",
+    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -293,6 +293,30 @@ class Canvas:
         self._check(self.lib.canvas_wavelets(self.ctx, nchr, C.c_void_p(cov.data_ptr()), _np_ptr(off), int(bool(is_germline)), C.c_double(threshold_lower),
                                              C.c_double(threshold_upper), C.c_double(mad_factor), int(window), int(min_size), _np_ptr(out), C.c_int64(len(out)), _np_ptr(oo)))
         return [out[oo[c]:oo[c + 1]].copy() for c in range(nchr)]
+
+    # ---- CanvasNormalize (ratio path)
+    def normalize_reference(self, counts, on_target_idx=None):
+        """WeightedAverageReferenceGenerator.Run for several control samples: (weighted counts f64 tensor, weights)"""
+        torch = self.torch
+        n = int(counts[0].numel())
+        ptrs = (C.c_void_p * len(counts))(*[C.c_void_p(c.data_ptr()) for c in counts])
+        out = torch.empty(n, dtype=torch.float64, device=self.device); w = np.zeros(len(counts), np.float64)
+        self._check(self.lib.canvas_normalize_reference(self.ctx, len(counts), ptrs, C.c_int64(n), C.c_void_p(on_target_idx.data_ptr()) if on_target_idx is not None else None,
+                                                        C.c_int64(int(on_target_idx.numel()) if on_target_idx is not None else 0), C.c_void_p(out.data_ptr()), _np_ptr(w)))
+        return out, w
+
+    def normalize_ratio(self, sample, reference, on_target_idx=None, mode=0, min_ref=1.0, max_ref=float("inf"), ploidy=None):
+        """LSNorm (mode 0) / Raw (mode 1) ratio + RatiosToCounts: (kept bin indices, ratios, counts, library-size factor)"""
+        torch = self.torch
+        n = int(sample.numel())
+        keep = torch.empty(n, dtype=torch.int32, device=self.device); ratio = torch.empty(n, dtype=torch.float32, device=self.device); count = torch.empty(n, dtype=torch.float32, device=self.device)
+        n_out = C.c_int64(0); lsf = C.c_double(0)
+        self._check(self.lib.canvas_normalize_ratio(self.ctx, C.c_int64(n), C.c_void_p(sample.data_ptr()), C.c_void_p(reference.data_ptr()),
+                                                    C.c_void_p(on_target_idx.data_ptr()) if on_target_idx is not None else None, C.c_int64(int(on_target_idx.numel()) if on_target_idx is not None else 0),
+                                                    int(mode), C.c_double(min_ref), C.c_double(max_ref), C.c_void_p(ploidy.data_ptr()) if ploidy is not None else None,
+                                                    C.c_void_p(keep.data_ptr()), C.c_void_p(ratio.data_ptr()), C.c_void_p(count.data_ptr()), C.byref(n_out), C.byref(lsf)))
+        k = n_out.value
+        return keep[:k], ratio[:k], count[:k], lsf.value
 
     def wavelets_stats(self):
         """[tree levels processed, nodes recomputed by the exact chain] of the last wavelets() call"""

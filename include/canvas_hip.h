@@ -186,6 +186,23 @@ int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* d_cov, cons
 /* last canvas_wavelets call: [0] tree levels processed, [1] nodes whose shortcut division disagreed with the IEEE one and were recomputed */
 int32_t canvas_wavelets_stats(canvas_ctx* ctx, int64_t* h_out2);
 
+/* ---- CanvasNormalize, ratio path (enrichment / tumour-normal workflows) -------------------------------------------------
+ * canvas_normalize_reference = WeightedAverageReferenceGenerator.Run for more than one control sample (WeightedAverageReferenceGenerator.cs:
+ * 38-68): weight_i = 1 / median_i (0 if the median is not positive), normalised to sum 1, median_i = BinCounts.OnTargetMedianBinCount
+ * (BinCounts.cs:36-60) over the bins listed in d_on_target_idx (NULL: all bins; the list is what BinCounts.LoadBinCounts derives from the
+ * Nextera manifest, BinCounts.cs:118-166); d_weighted[j] = sum_i weight_i * counts_i[j].  h_d_counts: nsamples device pointers to n doubles
+ * each (the 4th column of the control .binned files, double.Parse).  With one control sample the reference copies the file instead. */
+int32_t canvas_normalize_reference(canvas_ctx* ctx, int32_t nsamples, const double* const* h_d_counts, int64_t n, const int32_t* d_on_target_idx, int64_t n_on_target,
+                                   double* d_weighted, double* h_weights);
+/* LSNormRatioCalculator.Run (mode 0, LSNormRatioCalculator.cs:20-48: library-size factor = reference median / sample median over the on-target
+ * bins, bins whose reference count is below 1 are dropped) or RawRatioCalculator.Run (mode 1, RawRatioCalculator.cs:21-46: bins whose reference
+ * count lies outside [min_ref, max_ref] are dropped), followed by CanvasNormalizeUtilities.RatiosToCounts (CanvasNormalizeUtilities.cs:23-33:
+ * count = ratio * 40 * ploidy / 2; d_ploidy = reference copy number per bin from the ploidy VCF, NULL = 2).  d_sample / d_reference are the float
+ * counts of the two .binned files.  Outputs (capacity n): d_keep_idx = indices of the bins that are kept, d_ratio / d_count per kept bin. */
+int32_t canvas_normalize_ratio(canvas_ctx* ctx, int64_t n, const float* d_sample, const float* d_reference, const int32_t* d_on_target_idx, int64_t n_on_target,
+                               int32_t mode, double min_ref, double max_ref, const int32_t* d_ploidy, int32_t* d_keep_idx, float* d_ratio, float* d_count,
+                               int64_t* h_n_out, double* h_library_size_factor);
+
 /* ---- multi-GPU (one process per GPU; chromosomes sharded across ranks) ------------------------------------------ */
 int32_t canvas_comm_unique_id(void* h_id128);  /* ncclGetUniqueId, 128 bytes, rank 0 */
 int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const void* h_id128);

@@ -356,3 +356,24 @@ def wavelets_genome(per_chr, is_germline=False, thr_lower=0.05, thr_upper=80.0, 
                          int(min_size), _p(out), C.c_int64(len(out)), _p(oo))
     assert k >= 0
     return [out[oo[c]:oo[c + 1]].copy() for c in range(len(per_chr))]
+
+
+# ---- CanvasNormalize (oracle_normalize.cpp)
+lib.orc_norm_ratio.restype = C.c_int64
+
+
+def norm_weighted_reference(counts, on_idx=None):
+    counts = [np.ascontiguousarray(c, np.float64) for c in counts]
+    n = len(counts[0]); out = np.zeros(n, np.float64); w = np.zeros(len(counts), np.float64)
+    oi = None if on_idx is None else np.ascontiguousarray(on_idx, np.int32)
+    lib.orc_norm_weighted_reference(len(counts), _pp(counts), C.c_int64(n), None if oi is None else _p(oi), C.c_int64(0 if oi is None else len(oi)), _p(out), _p(w))
+    return out, w
+
+
+def norm_ratio(sample, reference, on_idx=None, mode=0, min_ref=1.0, max_ref=float("inf"), ploidy=None):
+    s = np.ascontiguousarray(sample, np.float32); r = np.ascontiguousarray(reference, np.float32); n = len(s)
+    oi = None if on_idx is None else np.ascontiguousarray(on_idx, np.int32); pl = None if ploidy is None else np.ascontiguousarray(ploidy, np.int32)
+    keep = np.zeros(n, np.int32); ratio = np.zeros(n, np.float32); count = np.zeros(n, np.float32)
+    k = lib.orc_norm_ratio(C.c_int64(n), _p(s), _p(r), None if oi is None else _p(oi), C.c_int64(0 if oi is None else len(oi)), int(mode), C.c_double(min_ref), C.c_double(max_ref),
+                           None if pl is None else _p(pl), _p(keep), _p(ratio), _p(count))
+    return keep[:k].copy(), ratio[:k].copy(), count[:k].copy()
