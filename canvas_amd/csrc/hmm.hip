@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) k_make_blocks(const int32_t* __restrict__
 // A: one lane per block
 __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                  const double* __restrict__ logPmf, HmmParams P, uint16_t* __restrict__ psi, uint16_t* __restrict__ maps,
-                                                 int32_t* __restrict__ lastGuess, int leadIn, const int32_t* __restrict__ todo) {
+                                                 int32_t* __restrict__ lastGuess, int leadIn, const int32_t* __restrict__ todo, int vb) {
     extern __shared__ double sTab[];
     const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
     vit_stage_table(sTab, logPmf, P.tableLen, useLds);
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ bl
     const bool actBlock = b < nblocks;
     const VitBlock B = blocks[actBlock ? b : nblocks - 1];
     const HmmChrom C = chroms[B.chrom];
-    const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;       // block covers [tBeg, tEnd)
+    const int64_t tBeg = B.t0, tEnd = (B.t0 + vb < C.T) ? B.t0 + vb : C.T;       // block covers [tBeg, tEnd)
     const int64_t ts = tBeg > leadIn ? tBeg - leadIn : 0;                          // cold start
     const bool act = actBlock && (!todo || todo[B.chrom]);                         // a retry only recomputes the chromosomes that failed
     const int nsteps = act ? (int)(tEnd - ts) : 0;
@@ -297,6 +297,24 @@ __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ bl
         maps[b] = (uint16_t)fm;
         if (tEnd == C.T) lastGuess[B.chrom] = vit_best5(d);      // guess of the best final state (HMM.cs:100-111 on the shifted delta)
     }
+}
+
+// The speculative pass is latency-bound at one wave per SIMD (a second wave per SIMD is nearly free), the verification is issue-bound:
+// speculation therefore runs on blocks of VBS = VB / 2 steps (twice the waves, 3/4 of the steps per lane) and the maps of the two halves
+// of a VB block are composed here for the backtrack (first the later half, then the earlier one).
+#define VBS (VB / 2)
+__global__ void __launch_bounds__(256) k_pair_maps(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ firstS,
+                                                   const uint16_t* __restrict__ mapsS, uint16_t* __restrict__ maps, const int32_t* __restrict__ todo) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const VitBlock B = blocks[b];
+    if (todo && !todo[B.chrom]) return;
+    const int64_t T = chroms[B.chrom].T;
+    const int s0 = firstS[B.chrom] + B.t0 / VBS;
+    uint32_t m = mapsS[s0];
+#pragma unroll
+    for (int k = 1; k < VB / VBS; k++) if (B.t0 + (int64_t)k * VBS < T) m = map_compose(m, mapsS[s0 + k]);
+    maps[b] = (uint16_t)m;
 }
 
 // B1a: per-step increments of the exact delta along the guessed path (parallel): v_0 from HMM.cs:78,
@@ -1088,6 +1106,10 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         if (chroms[c].T > 10) nblocks += (int)((chroms[c].T + VB - 1) / VB);
     }
     firstBlock[nchr] = nblocks;
+    std::vector<int32_t> firstS(nchr + 1);                      // blocks of the speculative pass (VBS steps)
+    int nblocksS = 0;
+    for (int c = 0; c < nchr; c++) { firstS[c] = nblocksS; if (chroms[c].T > 10) nblocksS += (int)((chroms[c].T + VBS - 1) / VBS); }
+    firstS[nchr] = nblocksS;
     std::vector<int32_t> firstChunk(nchr + 1);
     int nchunks = 0;
     for (int c = 0; c < nchr; c++) {
@@ -1102,6 +1124,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     sz.take<uint16_t>(N + 8); sz.take<HmmChrom>(nchr); sz.take<int32_t>(nchr);
     sz.take<int32_t>(nchr + 1); sz.take<uint16_t>(nblocks + 8); sz.take<int8_t>(nblocks + 8);
     sz.take<int64_t>(nchr + 1); sz.take<VitBlock>(nblocks + 1); sz.take<double>(N); sz.take<double>(N + 64); sz.take<int32_t>(nchr); sz.take<int32_t>(nchr);
+    sz.take<VitBlock>(nblocksS + 1); sz.take<uint16_t>(nblocksS + 8); sz.take<int32_t>(nchr + 1);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + extraBytes + 65536); if (rc) return rc;
     WsCarver ws(ctx->ws);
     uint16_t* psi = ws.take<uint16_t>(N + 8);
@@ -1110,6 +1133,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     uint16_t* dMaps = ws.take<uint16_t>(nblocks + 8); int8_t* dEntry = ws.take<int8_t>(nblocks + 8);
     int64_t* dOffDev = ws.take<int64_t>(nchr + 1);
     VitBlock* dVBlocks = ws.take<VitBlock>(nblocks + 1); double* dD = ws.take<double>(N); double* dCarry = ws.take<double>(N + 64); int32_t* dFail = ws.take<int32_t>(nchr); int32_t* dRedo = ws.take<int32_t>(nchr);
+    VitBlock* dSBlocks = ws.take<VitBlock>(nblocksS + 1); uint16_t* dMapsS = ws.take<uint16_t>(nblocksS + 8); int32_t* dFirstS = ws.take<int32_t>(nchr + 1);
     BbChunk* dBChunks = ws.take<BbChunk>(nchunks + 1); int32_t* dFirstChunk = ws.take<int32_t>(nchr + 1);
     double* dChunkSum = ws.take<double>(nchunks + 1); double* dChunkBase = ws.take<double>(nchunks + 1); BbChunkOut* dChunkOut = ws.take<BbChunkOut>(nchunks + 1);
     BbCross* dCross = ws.take<BbCross>((size_t)nchunks * BB_MAXC + 1); ParFn* dAt64Fn = ws.take<ParFn>((size_t)nchunks * 16 + 1); uint8_t* dAt64Rank = ws.take<uint8_t>((size_t)nchunks * 16 + 8);
@@ -1120,7 +1144,9 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirst, firstBlock.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOffDev, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstChunk, firstChunk.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstS, firstS.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     if (nblocks > 0) hipLaunchKernelGGL((k_make_blocks<VitBlock>), dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dFirst, nchr, nblocks, VB, dVBlocks);
+    if (nblocksS > 0) hipLaunchKernelGGL((k_make_blocks<VitBlock>), dim3(nblk2(nblocksS, 256)), dim3(256), 0, ctx->stream, dFirstS, nchr, nblocksS, VBS, dSBlocks);
     if (nchunks > 0) hipLaunchKernelGGL((k_make_blocks<BbChunk>), dim3(nblk2(nchunks, 256)), dim3(256), 0, ctx->stream, dFirstChunk, nchr, nchunks, BB_CHUNK, dBChunks);
     HmmParams P; HmmEmis E;
     rc = prepare(ws, P, E, (const HmmChrom*)dChroms, (const int64_t*)dOffDev); if (rc) return rc;
@@ -1150,7 +1176,8 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         for (int attempt = 0; attempt < 2; attempt++) {
             const int leadSpec = attempt == 0 ? VW : 8 * VW, leadVer = attempt == 0 ? VW2 : 8 * VW2;
             CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
-            hipLaunchKernelGGL(k_vit_spec, dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, dMaps, dLast, leadSpec, dTodo);
+            hipLaunchKernelGGL(k_vit_spec, dim3((unsigned)((nblocksS + 63) / 64)), dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
+            hipLaunchKernelGGL(k_pair_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, dFirstS, dMapsS, dMaps, dTodo);
             if (attempt == 0 && getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, chroms[0].begin + chroms[0].T / 2);
             backtrack(true);
             hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
