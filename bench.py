@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--rate", type=float, default=0.21, help="hits per possible position (0.21 = 60x, 0.105 = 30x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage host wall times (ms) of the last step to stderr")
+    ap.add_argument("--staged", action="store_true", help="time the six per-stage library calls from Python instead of the one-call canvas_sample_pipeline")
     ap.add_argument("--no-wavelets", action="store_true", help="skip the (untimed) Wavelets run on the cleaned coverage that is reported as wavelets_path")
     ap.add_argument("--no-cbs", action="store_true", help="skip the (untimed) CBS run on the cleaned coverage that is reported as cbs_path")
     args = ap.parse_args()
@@ -102,6 +103,16 @@ def main():
 
     def step(record=False):
         import ctypes as C
+        if not record and not args.staged and not args.stage_times:
+            # the whole path in ONE library call (canvas_sample_pipeline): same stages, no host-language overhead between them
+            r = cv.sample_pipeline(bases, masks, hits, lens, is_auto, out, cov_buf, state_buf, seg_buf, counts_per_bin=100, bin_size=-1, mode=3, flags=flags)
+            if world > 1:
+                gather_send[0] = int(r["nseg"]); gather_send[1] = int(r["n_out"]); gather_send[2] = int(r["total"]); gather_send[3] = rank
+                cnt = np.zeros(world, np.int32)
+                cv._check(cv.lib.canvas_allgather_boundaries(cv.ctx, C.c_void_p(gather_send.data_ptr()), 4, 4, C.c_void_p(gather_recv.data_ptr()),
+                                                             cnt.ctypes.data_as(C.c_void_p)))
+            cv.synchronize()
+            return r["total"]
         tp = time.perf_counter()
         o, per, total, bs = cv.bin_sample(bases, masks, hits, lens, is_auto, 100, -1, 3, out=out)    # CanvasBin -d 100 -m TruncatedDynamicRange
         tp = tick("bin_sample(rates+binning)", tp)

@@ -1,0 +1,34 @@
+// One sample through the whole read-depth path in one call: CanvasBin (rates, bin size, bins) -> CanvasClean -> the F2 text hand-off ->
+// CanvasPartition -m PerSampleHMM -> segment ids.  A host that keeps the three modules in one process makes this one
+// call instead of six: nothing is computed here that the individual entry points do not compute, the call only removes the host
+// language's per-call overhead between the stages (arrays stay in HBM, five small results cross PCIe).
+#include "common.hpp"
+#include <vector>
+
+extern "C" int32_t canvas_sample_pipeline(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits,
+                                          const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, int32_t counts_per_bin, int32_t bin_size_in,
+                                          int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                          double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                          int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (!d_cov || !d_state || !d_segment_id || !h_chr_offset) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline: bad arguments");
+    int32_t binSize = 0; int64_t total = 0, nClean = 0, nseg = 0; double lsd = -1.0; int32_t info[8];
+    std::vector<int64_t> perChr((size_t)nchr);
+    int32_t rc = canvas_bin_sample(ctx, nchr, d_bases, d_mask, d_hits, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, mode, d_chr, d_start, d_stop, d_gc, d_count, cap,
+                                   &binSize, perChr.data(), &total);
+    if (rc) return rc;
+    if (h_bin_size) *h_bin_size = binSize;
+    if (h_nbins) *h_nbins = total;
+    std::vector<uint8_t> noY((size_t)nchr, 0);
+    rc = canvas_clean2(ctx, total, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y ? h_chr_is_y : noY.data(), clean_flags, min_bins_per_gc, &lsd, &nClean, info);
+    if (rc) return rc;
+    if (h_nbins_clean) *h_nbins_clean = nClean;
+    if (h_local_sd) *h_local_sd = lsd;
+    rc = canvas_quantize_f2(ctx, d_count, nClean, d_cov); if (rc) return rc;
+    rc = canvas_chromosome_offsets(ctx, d_chr, nClean, nchr, h_chr_offset); if (rc) return rc;
+    rc = canvas_hmm_per_sample(ctx, nchr, d_cov, h_chr_offset, d_state); if (rc) return rc;
+    rc = canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
+    if (h_nsegments) *h_nsegments = nseg;
+    return CANVAS_OK;
+}

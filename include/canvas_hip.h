@@ -186,6 +186,18 @@ int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* d_cov, cons
 /* last canvas_wavelets call: [0] tree levels processed, [1] nodes whose shortcut division disagreed with the IEEE one and were recomputed */
 int32_t canvas_wavelets_stats(canvas_ctx* ctx, int64_t* h_out2);
 
+/* ---- one sample through the whole path in one call -------------------------------------------------------------
+ * canvas_bin_sample -> canvas_clean2 -> canvas_quantize_f2 -> canvas_chromosome_offsets -> canvas_hmm_per_sample -> canvas_segment_ids with
+ * the arguments of those calls (h_chr_is_y may be NULL).  Outputs: the cleaned bins in d_chr..d_count (first *h_nbins_clean entries), d_cov,
+ * d_state and d_segment_id per cleaned bin, h_chr_offset[nchr+1], the bin size, bin counts, #localSD and the number of segments.  Nothing
+ * is computed that the individual entry points do not compute: it only saves the caller's per-call overhead between the stages. */
+int32_t canvas_sample_pipeline(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits,
+                               const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, int32_t counts_per_bin, int32_t bin_size_in,
+                               int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                               int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                               double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                               int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments);
+
 /* ---- CanvasNormalize, ratio path (enrichment / tumour-normal workflows) -------------------------------------------------
  * canvas_normalize_reference = WeightedAverageReferenceGenerator.Run for more than one control sample (WeightedAverageReferenceGenerator.cs:
  * 38-68): weight_i = 1 / median_i (0 if the median is not positive), normalised to sum 1, median_i = BinCounts.OnTargetMedianBinCount
