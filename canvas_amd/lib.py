@@ -320,6 +320,7 @@ class Canvas:
         out = torch.empty(n, dtype=torch.float64, device=self.device); w = np.zeros(len(counts), np.float64)
         self._check(self.lib.canvas_normalize_reference(self.ctx, len(counts), ptrs, C.c_int64(n), C.c_void_p(on_target_idx.data_ptr()) if on_target_idx is not None else None,
                                                         C.c_int64(int(on_target_idx.numel()) if on_target_idx is not None else 0), C.c_void_p(out.data_ptr()), _np_ptr(w)))
+        self.synchronize()   # the weighted sum is still in flight on the library's stream
         return out, w
 
     def normalize_ratio(self, sample, reference, on_target_idx=None, mode=0, min_ref=1.0, max_ref=float("inf"), ploidy=None):
