@@ -22,7 +22,8 @@
 //     checkpoint bit for bit.  Checkpoint 0 is exact by construction, so by induction every checkpoint and every value is exact — or the
 //     node is flagged and recomputed with IEEE divisions in the chain; results never depend on the shortcut.  The same lanes take the
 //     first arg-max of their steps, k_wv_reduce combines them per node;
-//   * k_wv_short: nodes of at most WV_LONG elements, one lane per node (millions of them in the deep levels), everything inline.
+//   * k_wv_subtree: a node of at most WV_LONG elements leaves the level loop together with its whole subtree: one lane walks it depth-first
+//     (millions of small nodes in the deep levels never reach the host), on a second stream next to the long chains.
 // The host keeps the tree (start / breakpoint / end, coefficient per node), applies HardThresh, rebuilds the breakpoints and runs the
 // two median-based clean-up passes (GetBreakpointsAfterHealingBadSplits, RefineSegments), which are sequential decisions over a
 // few hundred breakpoints; the coverage-variability inputs (windowed MAD / median, factor-of-three CMADs) are order statistics of
@@ -219,32 +220,63 @@ __global__ void __launch_bounds__(64) k_wv_reduce(const int32_t* __restrict__ li
     if (l == 0) { WvOut o; o.coef = bestVal / fmax(0.5, h.mean / 200.0); o.ind = bestIdx + 1; o.flag = flag[k]; out[list[k]] = o; }
 }
 
-// nodes of at most WV_LONG elements: one lane per node, the reference's loop as it stands
-__global__ void __launch_bounds__(64) k_wv_short(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, int nshort, const double* __restrict__ X,
-                                                 WvOut* __restrict__ out) {
+// A node of at most WV_LONG elements with its whole SUBTREE: one lane per such node.  The lane walks the subtree depth-first (the pending
+// right children sit on a stack kept in the node's own slice of a per-position array, so no allocation is needed: a subtree of len
+// positions never has more than len - 1 pending nodes), runs the reference's loop as it stands on every node, counts the nodes per
+// (chromosome, level) for HardThresh's level weights and appends the coefficients that can survive the threshold to a global list
+// (the host sorts that list back into the reference's order: level by level, left to right).  These kernels run on a second stream
+// next to the long chains, so the host only ever handles the few thousand long nodes.
+struct WvRoot { int32_t start; int32_t len; int32_t chrom; int32_t level; int32_t s1; int32_t cbase; };   // s1: 1-based start inside the chromosome; cbase: first bin of the chromosome
+struct WvCand { int32_t chrom, level, s, b, e, pad; double coef; };
+__global__ void __launch_bounds__(64) k_wv_subtree(const WvRoot* __restrict__ roots, int nroots, const double* __restrict__ X, const double* __restrict__ keepAbove,
+                                                   uint32_t* __restrict__ stack, int32_t* __restrict__ counts, WvCand* __restrict__ cands,
+                                                   unsigned long long* __restrict__ ncand, unsigned long long capCand, int32_t* __restrict__ overflow) {
     const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= nshort) return;
-    const int node = list[i];
-    const WvNode nd = nodes[node];
-    const long long n = nd.len;
-    const double* __restrict__ x = X + nd.start;
-    double sum = 0.0;
-    for (long long k = 1; k < n; k++) sum = sum + x[k];
-    const double x0 = x[0];
-    double p = sqrt(1 - 1.0 / (double)n) * x0;
-    double q = (1.0 / sqrt((double)(n * (n - 1)))) * sum;
-    const double mean = (x0 + sum) / (double)n;
-    double bestVal = p - q, bestAbs = fabs(bestVal);
-    long long bestIdx = 0;
-    for (long long m = 1; m < n - 1; m++) {
-        const double f = wv_factor(n, m), xm = x[m];
-        p = p * f + xm * wv_g(n, m);
-        q = q / f - xm / wv_h(n, m);
-        const double ip = p - q, a = fabs(ip);
-        if (a > bestAbs) { bestAbs = a; bestVal = ip; bestIdx = m; }
+    if (i >= nroots) return;
+    const WvRoot R = roots[i];
+    const double* __restrict__ xr = X + R.start;
+    uint32_t* __restrict__ st = stack + R.start;
+    const double keep = keepAbove[R.chrom];
+    int sp = 0;
+    uint32_t cur = 0u | ((uint32_t)(R.len - 1) << 9) | ((uint32_t)0 << 18);   // (first, last) relative to the root, 9 bits each; level offset above
+    bool have = true;
+    while (have) {
+        const int a = (int)(cur & 511u), e = (int)((cur >> 9) & 511u), lv = (int)(cur >> 18);
+        const long long n = e - a + 1;
+        const double* __restrict__ x = xr + a;
+        double sum = 0.0;
+        for (long long k = 1; k < n; k++) sum = sum + x[k];
+        const double x0 = x[0];
+        double p = sqrt(1 - 1.0 / (double)n) * x0;
+        double q = (1.0 / sqrt((double)(n * (n - 1)))) * sum;
+        const double mean = (x0 + sum) / (double)n;
+        double bestVal = p - q, bestAbs = fabs(bestVal);
+        long long bestIdx = 0;
+        for (long long m = 1; m < n - 1; m++) {
+            const double f = wv_factor(n, m), xm = x[m];
+            p = p * f + xm * wv_g(n, m);
+            q = q / f - xm / wv_h(n, m);
+            const double ip = p - q, ab = fabs(ip);
+            if (ab > bestAbs) { bestAbs = ab; bestVal = ip; bestIdx = m; }
+        }
+        const double coef = bestVal / fmax(0.5, mean / 200.0);
+        const int b = a + (int)bestIdx;                                        // last position before the breakpoint, relative to the root
+        const int level = R.level + lv;
+        atomicAdd(&counts[(size_t)R.cbase + level], 1);                          // a tree over L bins has fewer than L levels: the chromosome's own slice
+        if (fabs(coef) > keep) {
+            const unsigned long long slot = atomicAdd(ncand, 1ull);
+            if (slot < capCand) { WvCand c; c.chrom = R.chrom; c.level = level; c.s = R.s1 + a; c.b = R.s1 + b; c.e = R.s1 + e; c.pad = 0; c.coef = coef; cands[slot] = c; }
+            else *overflow = 1;
+        }
+        // children (WaveletSegmentation.cs:297, 323): left [a, b] if it has at least two positions, right [b + 1, e] likewise
+        const bool left = b - a >= 1, right = e - b >= 2;
+        const uint32_t lvn = (uint32_t)(lv + 1) << 18;
+        if (left && right) { st[sp++] = (uint32_t)(b + 1) | ((uint32_t)e << 9) | lvn; cur = (uint32_t)a | ((uint32_t)b << 9) | lvn; }
+        else if (left) cur = (uint32_t)a | ((uint32_t)b << 9) | lvn;
+        else if (right) cur = (uint32_t)(b + 1) | ((uint32_t)e << 9) | lvn;
+        else if (sp > 0) cur = st[--sp];
+        else have = false;
     }
-    WvOut o; o.coef = bestVal / fmax(0.5, mean / 200.0); o.ind = (int32_t)bestIdx + 1; o.flag = 0;
-    out[node] = o;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -477,17 +509,57 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         cur.push_back({c, 1, (int32_t)L});
     }
     // ---- device buffers
-    const size_t maxNodes = (size_t)N / 2 + (size_t)nchr + 16, maxLong = (size_t)N / WV_LONG + 16, maxChunks = (size_t)N / WV_CS + maxLong + 16;
+    const size_t maxLong = (size_t)N / WV_LONG + (size_t)nchr + 16, maxChunks = (size_t)N / WV_CS + maxLong + 16, maxRoots = (size_t)N / 2 + (size_t)nchr + 16;
+    const unsigned long long capCand = (unsigned long long)N + 16;
     WsSizer sz;
-    sz.take<WvOps>((size_t)N); sz.take<WvNode>(maxNodes); sz.take<WvOut>(maxNodes); sz.take<int32_t>(maxNodes); sz.take<int32_t>(maxLong);
+    sz.take<WvOps>((size_t)N); sz.take<WvNode>(maxLong); sz.take<WvOut>(maxLong); sz.take<int32_t>(maxLong);
     sz.take<int32_t>(maxLong + 1); sz.take<int32_t>(maxLong); sz.take<WvHead>(maxLong); sz.take<WvCk>(maxChunks); sz.take<WvBest>(maxChunks);
+    sz.take<WvRoot>(maxRoots); sz.take<uint32_t>((size_t)N); sz.take<int32_t>((size_t)N); sz.take<WvCand>((size_t)capCand); sz.take<double>(nchr); sz.take<unsigned long long>(2);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
+    rc = canvas_side_init(ctx); if (rc) return rc;
     WsCarver ws(ctx->ws);
-    WvOps* dOps = ws.take<WvOps>((size_t)N); WvNode* dNodes = ws.take<WvNode>(maxNodes); WvOut* dOut = ws.take<WvOut>(maxNodes);
-    int32_t* dShort = ws.take<int32_t>(maxNodes); int32_t* dLong = ws.take<int32_t>(maxLong); int32_t* dBase = ws.take<int32_t>(maxLong + 1);
+    WvOps* dOps = ws.take<WvOps>((size_t)N); WvNode* dNodes = ws.take<WvNode>(maxLong); WvOut* dOut = ws.take<WvOut>(maxLong);
+    int32_t* dLong = ws.take<int32_t>(maxLong); int32_t* dBase = ws.take<int32_t>(maxLong + 1);
     int32_t* dFlag = ws.take<int32_t>(maxLong); WvHead* dHead = ws.take<WvHead>(maxLong); WvCk* dCk = ws.take<WvCk>(maxChunks); WvBest* dBest = ws.take<WvBest>(maxChunks);
-    std::vector<WvNode> hNodes; std::vector<WvOut> hOut; std::vector<int32_t> hLong, hBase, hShort, hRedo;
+    WvRoot* dRoots = ws.take<WvRoot>(maxRoots); uint32_t* dStack = ws.take<uint32_t>((size_t)N); int32_t* dCounts = ws.take<int32_t>((size_t)N);
+    WvCand* dCands = ws.take<WvCand>((size_t)capCand); double* dKeep = ws.take<double>(nchr); unsigned long long* dNcand = ws.take<unsigned long long>(2);
+    int32_t* dOverflow = (int32_t*)(dNcand + 1);
+    {
+        std::vector<double> keep(nchr);
+        for (int c = 0; c < nchr; c++) keep[c] = trees[c].keepAbove;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dKeep, keep.data(), nchr * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCounts, 0, (size_t)N * sizeof(int32_t), ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dNcand, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the side stream starts from initialised buffers
+    }
+    std::vector<WvNode> hNodes; std::vector<WvOut> hOut; std::vector<int32_t> hLong, hBase, hRedo; std::vector<WvRoot> hRoots;
+    std::vector<std::vector<WvRoot>> rootBatches;
+    size_t rootsUsed = 0;
     long long levels = 0, redone = 0;
+    // short nodes leave the level loop with their whole subtree: one lane each, on the side stream (nothing waits for them until the end)
+    // (kernels on one stream run one after the other and a subtree lane is latency-bound, so the roots of many levels share a launch)
+    auto flush_roots = [&](bool force) -> int32_t {
+        if (hRoots.empty() || (!force && hRoots.size() < 4096)) return CANVAS_OK;
+        if (rootsUsed + hRoots.size() > maxRoots) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: root list overflow");
+        rootBatches.emplace_back(std::move(hRoots)); hRoots.clear();         // the host copy stays alive until the side stream has been drained
+        const std::vector<WvRoot>& B = rootBatches.back();
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRoots + rootsUsed, B.data(), B.size() * sizeof(WvRoot), hipMemcpyHostToDevice, ctx->side));
+        hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((B.size() + 63) / 64)), dim3(64), 0, ctx->side, dRoots + rootsUsed, (int)B.size(), dX, dKeep, dStack, dCounts,
+                           dCands, dNcand, capCand, dOverflow);
+        rootsUsed += B.size();
+        return CANVAS_OK;
+    };
+    auto place = [&](int chrom, int32_t s1, int32_t e1, int level) {          // a node of the next level: long -> level loop, short -> subtree list
+        const int32_t len = e1 - s1 + 1;
+        if (len > WV_LONG) nxt.push_back({chrom, s1, e1});
+        else hRoots.push_back({(int32_t)(off[chrom] + s1 - 1), len, chrom, level, s1, (int32_t)off[chrom]});
+    };
+    {   // level 0: chromosomes that are short themselves
+        std::vector<HNode> longRoots;
+        for (const HNode& h : cur) { nxt.clear(); place(h.chrom, h.s, h.e, 0); if (!nxt.empty()) longRoots.push_back(nxt[0]); }
+        nxt.clear(); cur.swap(longRoots);
+        rc = flush_roots(false); if (rc) return rc;
+    }
     // the kernels of one level for the long nodes in dLong / dBase (chain = the shortcut or the IEEE division)
     auto long_pass = [&](size_t nLong, int nChunks, bool fast) -> int32_t {
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFlag, 0, nLong * sizeof(int32_t), ctx->stream));
@@ -506,25 +578,14 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         (void)hipMemcpyAsync(dBase, hBase.data(), hBase.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
         return hBase.back();
     };
-    // ---- FindBestUnbalancedHaarDecomposition (WaveletSegmentation.cs:252-366), level by level for all chromosomes at once
+    // ---- FindBestUnbalancedHaarDecomposition (WaveletSegmentation.cs:252-366): the long nodes level by level for all chromosomes at once
     for (int level = 0; !cur.empty(); level++, levels++) {
         const size_t nn = cur.size();
-        hNodes.resize(nn); hOut.resize(nn); hLong.clear();
-        std::vector<int32_t> byLen[WV_LONG + 1];
-        for (size_t i = 0; i < nn; i++) {
-            const HNode& h = cur[i];
-            const int32_t len = h.e - h.s + 1;
-            hNodes[i] = {(int32_t)(off[h.chrom] + h.s - 1), len};
-            if (len > WV_LONG) hLong.push_back((int32_t)i); else byLen[len].push_back((int32_t)i);
-        }
-        hShort.clear();                                      // nodes of similar length share a wave
-        for (int len = WV_LONG; len >= 2; len--) hShort.insert(hShort.end(), byLen[len].begin(), byLen[len].end());
+        if (nn > maxLong) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: long-node list overflow");
+        hNodes.resize(nn); hOut.resize(nn); hLong.resize(nn);
+        for (size_t i = 0; i < nn; i++) { const HNode& h = cur[i]; hNodes[i] = {(int32_t)(off[h.chrom] + h.s - 1), h.e - h.s + 1}; hLong[i] = (int32_t)i; }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dNodes, hNodes.data(), nn * sizeof(WvNode), hipMemcpyHostToDevice, ctx->stream));
-        if (!hLong.empty()) { const int nChunks = upload_long(hLong); rc = long_pass(hLong.size(), nChunks, true); if (rc) return rc; }
-        if (!hShort.empty()) {
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dShort, hShort.data(), hShort.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_wv_short, dim3((unsigned)((hShort.size() + 63) / 64)), dim3(64), 0, ctx->stream, dNodes, dShort, (int)hShort.size(), dX, dOut);
-        }
+        { const int nChunks = upload_long(hLong); rc = long_pass(nn, nChunks, true); if (rc) return rc; }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
@@ -547,10 +608,38 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
             T.counts[level]++;
             const int32_t b = h.s + hOut[i].ind - 1;          // "last time point before the breakpoint" (cs:279, 311, 337)
             if (std::fabs(hOut[i].coef) > T.keepAbove) T.cands.push_back({level, h.s, b, h.e, hOut[i].coef});
-            if (b - h.s >= 1) nxt.push_back({h.chrom, h.s, b});
-            if (h.e - b >= 2) nxt.push_back({h.chrom, b + 1, h.e});
+            if (b - h.s >= 1) place(h.chrom, h.s, b, level + 1);
+            if (h.e - b >= 2) place(h.chrom, b + 1, h.e, level + 1);
         }
+        rc = flush_roots(false); if (rc) return rc;
         cur.swap(nxt);
+    }
+    rc = flush_roots(true); if (rc) return rc;
+    // ---- the subtrees: node counts per level and the surviving coefficients come back in one piece
+    {
+        unsigned long long hN[2] = {0, 0};
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        CANVAS_HIP_TRY(ctx, hipMemcpy(hN, dNcand, sizeof hN, hipMemcpyDeviceToHost));
+        if (hN[1] & 0xFFFFFFFFull) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: candidate list overflow");
+        std::vector<int32_t> hCounts((size_t)N);
+        CANVAS_HIP_TRY(ctx, hipMemcpy(hCounts.data(), dCounts, hCounts.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<WvCand> hc((size_t)hN[0]);
+        if (hN[0]) CANVAS_HIP_TRY(ctx, hipMemcpy(hc.data(), dCands, hc.size() * sizeof(WvCand), hipMemcpyDeviceToHost));
+        for (int c = 0; c < nchr; c++) {
+            ChromTree& T = trees[c];
+            const int32_t* cc = hCounts.data() + off[c];
+            const int64_t L = off[c + 1] - off[c];
+            int64_t top = -1;
+            for (int64_t lv = 0; lv < L; lv++) if (cc[lv]) top = lv;
+            if (top >= (int64_t)T.counts.size()) T.counts.resize((size_t)top + 1, 0);
+            for (int64_t lv = 0; lv <= top; lv++) T.counts[(size_t)lv] += cc[lv];
+            levels = std::max<long long>(levels, (long long)T.counts.size());
+        }
+        for (const WvCand& k : hc) trees[k.chrom].cands.push_back({k.level, k.s, k.b, k.e, k.coef});
+        // the reference's order: level by level, inside a level from left to right
+        for (int c = 0; c < nchr; c++)
+            std::sort(trees[c].cands.begin(), trees[c].cands.end(), [](const Cand& a, const Cand& b) { return a.level != b.level ? a.level < b.level : a.s < b.s; });
     }
     ctx->wv_levels = levels; ctx->wv_redone = redone;
     const double t2 = now();
