@@ -843,18 +843,31 @@ __global__ void __launch_bounds__(64) k_bt_chain(const int32_t* __restrict__ fir
         if (s >= 0) s = (int)map_get(all, (uint32_t)s);
     }
 }
+// One wave per block: the states of the block are the suffix compositions of its back-pointer maps applied to the state at the block's last
+// step, state[tEnd-1-j] = (h_j o ... o h_1)(entry) with h_j = psi[tEnd-j].  Two steps per lane, a composition scan over the lanes, coalesced
+// loads and stores (one lane per block walked its 128 steps behind 128 dependent loads and wrote with a 512-byte stride).
 __global__ void __launch_bounds__(256) k_bt_states(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const uint16_t* __restrict__ psi,
                                                    const int8_t* __restrict__ entry, int32_t* __restrict__ state) {
-    int b = blockIdx.x * 256 + threadIdx.x;
+    static_assert(VB <= 128, "two steps per lane");
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
     if (b >= nblocks) return;
     const VitBlock B = blocks[b];
     const HmmChrom C = chroms[B.chrom];
     const int64_t tBeg = B.t0, tEnd = (B.t0 + VB < C.T) ? B.t0 + VB : C.T;
-    int s = entry[b];
-    for (int64_t t = tEnd - 1; t >= tBeg; t--) {
-        state[C.begin + t] = s;
-        if (s >= 0 && t > 0) s = (int)map_get(psi[C.begin + t], (uint32_t)s);
-    }
+    const int cnt = (int)(tEnd - tBeg);
+    const int s = entry[b];
+    const int j0 = 2 * l, j1 = 2 * l + 1;
+    const uint32_t a0 = (j0 >= 1 && j0 < cnt) ? (uint32_t)psi[C.begin + tEnd - j0] : MAP_IDENT;     // h_0 is the identity (the entry state itself)
+    const uint32_t a1 = (j1 < cnt) ? (uint32_t)psi[C.begin + tEnd - j1] : MAP_IDENT;
+    const uint32_t x1 = map_compose(a1, a0);                                                         // first h_{2l}, then h_{2l+1}
+    uint32_t v = x1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d); if (l >= d) v = map_compose(v, o); }   // first the earlier lanes (o), then this one
+    uint32_t ex = __shfl_up(v, 1);
+    if (l == 0) ex = MAP_IDENT;
+    const uint32_t m0 = map_compose(a0, ex), m1 = map_compose(x1, ex);
+    if (j0 < cnt) state[C.begin + tEnd - 1 - j0] = s < 0 ? s : (int)map_get(m0, (uint32_t)s);
+    if (j1 < cnt) state[C.begin + tEnd - 1 - j1] = s < 0 ? s : (int)map_get(m1, (uint32_t)s);
 }
 
 __global__ void __launch_bounds__(256) k_fill_i32(int32_t* __restrict__ p, int64_t begin, int64_t end, int32_t v) {
@@ -1161,7 +1174,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         if (nblocks > 0) {
             if (!haveMaps) hipLaunchKernelGGL(k_bt_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, psi, dMaps);
             hipLaunchKernelGGL(k_bt_chain, dim3(nchr), dim3(64), 0, ctx->stream, dFirst, dLast, dMaps, dEntry);
-            hipLaunchKernelGGL(k_bt_states, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, psi, dEntry, d_state);
+            hipLaunchKernelGGL(k_bt_states, dim3(nblk2(nblocks, 4)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, psi, dEntry, d_state);
         }
     };
     const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
