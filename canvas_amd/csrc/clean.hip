@@ -296,7 +296,8 @@ static void quartiles_from_values(int64_t iSize, const float* v, float& q1, floa
 struct CleanState {
     canvas_ctx* ctx;
     int64_t n;
-    Soa cur, alt;            // cur holds the live bins
+    Soa cur, alt;            // cur holds the live bins; alt = destination of the next compaction (pick_alt)
+    Soa bufs[3];             // [0] the caller's arrays, [1] and [2] scratch
     uint8_t* flags; uint32_t* blockCnt; unsigned long long* dTotal;
     uint32_t* keys32; unsigned long long* keys64; uint32_t* gidx;
     uint8_t* dIsAuto;
@@ -304,10 +305,18 @@ struct CleanState {
 
 static inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+// Destination of the next compaction.  The result must end in the caller's arrays: the two filters that always run go caller -> scratch 1
+// -> scratch 2 and the later, data-dependent compactions (GC strip, local-SD filter) aim at the caller's arrays, so the usual sequence
+// (size filter, outlier filter, GC strip) needs no copy at the end.
+static void pick_alt(CleanState& st, bool preferCaller) {
+    const int ci = st.cur.chr == st.bufs[0].chr ? 0 : (st.cur.chr == st.bufs[1].chr ? 1 : 2);
+    st.alt = (preferCaller && ci != 0) ? st.bufs[0] : st.bufs[ci == 1 ? 2 : 1];
+}
 // compaction cur -> alt by st.flags; swaps; returns new n (one sync)
-static int32_t compact(CleanState& st) {
+static int32_t compact(CleanState& st, bool preferCaller) {
     canvas_ctx* ctx = st.ctx;
     if (st.n == 0) return CANVAS_OK;
+    pick_alt(st, preferCaller);
     int nb = (int)nblk(st.n, CBLK);
     hipLaunchKernelGGL(k_block_count, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.n, st.blockCnt);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, st.blockCnt, nb, st.dTotal);
@@ -322,8 +331,9 @@ static int32_t compact(CleanState& st) {
 }
 
 // the same without the host round trip: the new count goes to *dOut, the old one may itself still be on the device (dN); st.n stays an upper bound
-static void compact_launch(CleanState& st, const unsigned long long* dN, unsigned long long* dOut) {
+static void compact_launch(CleanState& st, const unsigned long long* dN, unsigned long long* dOut, bool preferCaller) {
     canvas_ctx* ctx = st.ctx;
+    pick_alt(st, preferCaller);
     int nb = (int)nblk(st.n, CBLK);
     hipLaunchKernelGGL(k_block_count, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.n, st.blockCnt, dN);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, st.blockCnt, nb, dOut);
@@ -648,6 +658,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     const int64_t nW0 = n / 20 + 2;
     WsSizer sz;
     sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n); sz.take<double>(n);
+    sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n);
     sz.take<uint8_t>(n); sz.take<uint32_t>(n / CBLK + 2); sz.take<unsigned long long>(2); sz.take<uint32_t>(n); sz.take<unsigned long long>(nW0); sz.take<uint32_t>(n);
     sz.take<uint8_t>(nchr); sz.take<uint32_t>(2 * NGC); sz.take<uint32_t>(NGC + 1); sz.take<uint32_t>(NGC); sz.take<double>(NGC); sz.take<VarTab>(1);
     sz.take<uint8_t>(NGC); sz.take<double>(nW0); sz.take<double>(65536); sz.take<int64_t>(65536 + 1); sz.take<unsigned int>(1); sz.take<long long>(65536);
@@ -657,6 +668,9 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     st.cur = Soa{d_chr, d_start, d_stop, d_gc, d_count, nullptr};
     st.alt.chr = ws.take<int32_t>(n); st.alt.start = ws.take<int32_t>(n); st.alt.stop = ws.take<int32_t>(n); st.alt.gc = ws.take<int32_t>(n);
     st.alt.count = ws.take<float>(n); st.alt.dev = ws.take<double>(n); st.cur.dev = ws.take<double>(n);
+    st.bufs[0] = st.cur; st.bufs[1] = st.alt;
+    st.bufs[2].chr = ws.take<int32_t>(n); st.bufs[2].start = ws.take<int32_t>(n); st.bufs[2].stop = ws.take<int32_t>(n); st.bufs[2].gc = ws.take<int32_t>(n);
+    st.bufs[2].count = ws.take<float>(n); st.bufs[2].dev = ws.take<double>(n);
     st.flags = ws.take<uint8_t>(n); st.blockCnt = ws.take<uint32_t>(n / CBLK + 2); st.dTotal = ws.take<unsigned long long>(2);
     st.keys32 = ws.take<uint32_t>(n); st.keys64 = ws.take<unsigned long long>(nW0); st.gidx = ws.take<uint32_t>(n);
     st.dIsAuto = ws.take<uint8_t>(nchr);
@@ -680,14 +694,14 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
             std::vector<unsigned long long> res; const unsigned long long* dKey = nullptr;
             rc = radix_select<uint32_t>(ctx, st.keys32, 1, std::vector<int64_t>{0, st.n}, std::vector<SelQuery>{{0, 0, index}}, res, &dKey); if (rc) return rc;
             hipLaunchKernelGGL(k_flags_size, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.start, st.cur.stop, st.n, dKey, st.flags);
-            compact_launch(st, nullptr, dTot2 + 0);
+            compact_launch(st, nullptr, dTot2 + 0, false);
             dN = dTot2 + 0; sized = true;
         }
     }
     bool outl = false;
     if ((flags & CANVAS_CLEAN_OUTLIERS) && st.n > 0) {
         hipLaunchKernelGGL(k_flags_outlier, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.count, st.n, dN, st.flags);
-        compact_launch(st, dN, dTot2 + 1);
+        compact_launch(st, dN, dTot2 + 1, false);
         dN = dTot2 + 1; outl = true;
     }
     info[0] = (int32_t)st.n;
@@ -740,6 +754,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
         }
         if (kept > 0) {
             if (dropsAny && kept < st.n) {
+                pick_alt(st, true);
                 hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, ctx->stream, st.flags, st.blockCnt, st.n, st.cur, st.alt);
                 std::swap(st.cur, st.alt); st.n = kept;
             }
@@ -761,7 +776,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     if (haveLocalSd) { rc = local_sd_end(st, sdRuns, localSd); if (rc) return rc; }
     if (haveLocalSd && localSd > 5.0 && st.n > 0) {    // RemoveBinsWithExtremeLocalSD (threshold 20 -> 40.0)
         hipLaunchKernelGGL(k_flags_localsd, dim3(nblk(st.n, 256)), dim3(256), 0, ctx->stream, st.cur.dev, st.n, 20 * 2.0, st.flags);
-        rc = compact(st); if (rc) return rc;
+        rc = compact(st, true); if (rc) return rc;
     }
     info[3] = (int32_t)st.n;
     // results must end in the caller's arrays
