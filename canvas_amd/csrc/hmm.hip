@@ -299,6 +299,20 @@ __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ bl
     }
 }
 
+// chromosome of global bin g: the offsets (nchr + 1 of them) are staged in LDS when they fit, so that the per-thread binary search does not
+// turn into five dependent global loads.  Every thread of the block must call stage_chr_offsets before the bounds check.
+#define CHR_LDS_CAP 1024
+__device__ __forceinline__ const int64_t* stage_chr_offsets(const int64_t* __restrict__ chrOff, int nchr, int64_t* sOff) {
+    if (nchr + 1 > CHR_LDS_CAP) return chrOff;
+    for (int k = threadIdx.x; k <= nchr; k += blockDim.x) sOff[k] = chrOff[k];
+    __syncthreads();
+    return sOff;
+}
+__device__ __forceinline__ int chrom_of_bin(const int64_t* off, int nchr, int64_t g) {
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= g) lo = mid; else hi = mid - 1; }
+    return lo;
+}
 // The speculative pass is latency-bound at one wave per SIMD (a second wave per SIMD is nearly free), the verification is issue-bound:
 // speculation therefore runs on blocks of VBS = VB / 2 steps (twice the waves, 3/4 of the steps per lane) and the maps of the two halves
 // of a VB block are composed here for the backtrack (first the later half, then the earlier one).
@@ -321,10 +335,11 @@ __global__ void __launch_bounds__(256) k_pair_maps(const VitBlock* __restrict__ 
 //      v_t = logpmf_{s_t}(x_t) + logA[s_{t-1}][s_t]  (= Math.Log(emission) + Math.Log(transition), Distributions.cs:322)
 __global__ void __launch_bounds__(256) k_vit_increments(const HmmChrom* __restrict__ chroms, int nchr, const int64_t* __restrict__ chrOff, const int32_t* __restrict__ idx,
                                                         const double* __restrict__ logPmf, HmmParams P, const int32_t* __restrict__ state, int64_t N, double* __restrict__ D) {
+    __shared__ int64_t sOff[CHR_LDS_CAP];
+    const int64_t* off = stage_chr_offsets(chrOff, nchr, sOff);
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= N) return;
-    int lo = 0, hi = nchr - 1;
-    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chrOff[mid] <= g) lo = mid; else hi = mid - 1; }
+    const int lo = chrom_of_bin(off, nchr, g);
     int s1 = state[g];
     if (s1 < 0) { D[g] = 0.0; return; }
     double e = logPmf[(size_t)s1 * P.tableLen + idx[g]];
@@ -898,11 +913,12 @@ __global__ void __launch_bounds__(256) k_fill_i32(int32_t* __restrict__ p, int64
 __global__ void __launch_bounds__(256) k_seg_flags(const int64_t* __restrict__ chrOff, int nchr, const int32_t* __restrict__ state, const int32_t* __restrict__ start,
                                                    const int32_t* __restrict__ stop, int64_t n, int32_t maxDist, const int64_t* __restrict__ exclOff,
                                                    const int32_t* __restrict__ exclStart, const int32_t* __restrict__ exclStop, uint8_t* __restrict__ flags) {
+    __shared__ int64_t sOff[CHR_LDS_CAP];
+    const int64_t* off = stage_chr_offsets(chrOff, nchr, sOff);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    int lo = 0, hi = nchr - 1;
-    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chrOff[mid] <= i) lo = mid; else hi = mid - 1; }
-    const bool first = (i == chrOff[lo]);
+    const int lo = chrom_of_bin(off, nchr, i);
+    const bool first = (i == off[lo]);
     const int32_t st = state[i];
     bool newSeg = st >= 0 && (first || state[i - 1] != st);           // breakpoint -> segment start present in `starts`
     if (exclOff) {
