@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU (not part of pytest): many seeds / sizes of Clean, F2, PerSampleHMM and segment ids against the oracle.
-usage: tools/soak.py [minutes]"""
+usage: tools/soak.py [minutes [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,7 @@ from canvas_amd import Canvas, synth, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIE
 cv = Canvas(0); cv.profile_enable(True)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
 t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}
-rng = np.random.RandomState(1)
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 while time.time() - t0 < budget:
     seed = int(rng.randint(1, 2**31 - 1)); n = int(rng.choice([3_000, 30_000, 120_000, 600_000])); nchr = int(rng.choice([1, 3, 24]))
     bins = synth.generate_bins(seed, n, nchr=nchr)

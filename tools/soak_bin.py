@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity soak of CanvasBin on the GPU against the oracle (not part of pytest).  usage: tools/soak_bin.py [minutes]"""
+"""Randomised parity soak of CanvasBin on the GPU against the oracle (not part of pytest).  usage: tools/soak_bin.py [minutes [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,7 @@ cv = Canvas(0)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
 pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cv.device)
-rng = np.random.RandomState(7)
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 t0 = time.time(); it = 0; npath = {}
 while time.time() - t0 < budget:
     nchr = int(rng.choice([1, 2, 5]))

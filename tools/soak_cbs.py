@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak of CBS (device arc search + device permutation engine) against the oracle: segment lengths and RNG consumption.
-usage: tools/soak_cbs.py [minutes]"""
+usage: tools/soak_cbs.py [minutes [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ from canvas_amd import Canvas
 
 cv = Canvas(0)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
-rng = np.random.RandomState(11)
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
 t0 = time.time(); it = 0; devp = 0; rechecks = 0
 while time.time() - t0 < budget:
     nchr = int(rng.choice([1, 2, 4]))

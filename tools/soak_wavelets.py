@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity soak of canvas_wavelets on the GPU against the oracle (not part of pytest).  usage: tools/soak_wavelets.py [minutes]"""
+"""Randomised parity soak of canvas_wavelets on the GPU against the oracle (not part of pytest).  usage: tools/soak_wavelets.py [minutes [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ from canvas_amd import Canvas
 
 cv = Canvas(0)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
-rng = np.random.RandomState(17)
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 17)
 t0 = time.time(); it = 0; redone = 0; nbp = 0
 while time.time() - t0 < budget:
     nchr = int(rng.choice([1, 2, 4]))
