@@ -170,6 +170,8 @@ __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chr
 #define PQ 8         // per-lane prefetch depth in steps
 #define MAP_IDENT (0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12))
 struct VitBlock { int32_t chrom; int32_t t0; };   // chromosome-relative start
+struct __attribute__((aligned(4))) VecI4 { int v[4]; };      // 16-byte load at 4-byte alignment (the per-lane streams start anywhere)
+struct __attribute__((aligned(8))) VecD2 { double v[2]; };
 
 // new delta and back-pointer of state J:  tmp_i = delta_i + (logpmf_J(x_t) + logA[i][J]),  strict '>' scan i = 0..4 from
 // Double.MinValue == first index of the maximum (evaluated as a tree, no NaNs can occur)   (HMM.cs:84-97, Distributions.cs:322)
@@ -251,11 +253,11 @@ __global__ void __launch_bounds__(256) k_make_blocks(const int32_t* __restrict__
 }
 
 // A: one lane per block
+template <bool useLds>      // compile-time: with both emission sources in one kernel every step waited for ALL outstanding memory operations
 __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                  const double* __restrict__ logPmf, HmmParams P, uint16_t* __restrict__ psi, uint16_t* __restrict__ maps,
                                                  int32_t* __restrict__ lastGuess, int leadIn, const int32_t* __restrict__ todo, int vb) {
     extern __shared__ double sTab[];
-    const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
     vit_stage_table(sTab, logPmf, P.tableLen, useLds);
     const int b = blockIdx.x * 64 + threadIdx.x;
     const bool actBlock = b < nblocks;
@@ -270,28 +272,46 @@ __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ bl
     uint16_t* __restrict__ pp = psi + C.begin;
     double d[NSTATE] = {0.0, 0.0, 0.0, 0.0, 0.0};
     uint32_t fm = MAP_IDENT;                                                       // state at t -> state at tBeg - 1
-    int kq[PQ];
+    const int lead = (int)(tBeg - ts);                                             // steps in front of the block
+    // The loop body is straight-line code: per-lane conditions (a lane past its last step, a lane still in its lead-in) select results
+    // instead of branching, the first step (no history) is peeled off, the bin indices of eight steps arrive with two 16-byte loads one group
+    // ahead and the eight back-pointers leave together.  With a branch per condition the compiler could no longer tell which memory
+    // operations were pending and waited for ALL of them at every step (SQ_WAIT_ANY: 40 % of the wave cycles).
+    if (nsteps > 0) {
+        double e[NSTATE];
+        vit_emissions(e, sTab, logPmf, useLds, P.tableLen, ix[0]);
+        if (ts == 0) vit_init5(d, e, P);
+        else {
 #pragma unroll
-    for (int u = 0; u < PQ; u++) kq[u] = u < nsteps ? ix[u] : 0;
-    for (int s0 = 0; s0 < maxSteps; s0 += PQ) {
+            for (int j = 0; j < NSTATE; j++) d[j] = e[j];                          // first step of a cold start: no history
+        }
+        if (lead == 0) pp[ts] = 0;                                                 // only the first bin of a chromosome: it has no back-pointer
+    }
+    // (the loads run up to 2 * PQ elements past a lane's own range: idx is padded for that, and steps past the range are discarded)
+    VecI4 qa = *reinterpret_cast<const VecI4*>(ix + 1), qb = *reinterpret_cast<const VecI4*>(ix + 5);
+    double eCur[NSTATE];                                                            // emission row of the step about to run: read one step ahead,
+    vit_emissions(eCur, sTab, logPmf, useLds, P.tableLen, 1 < nsteps ? qa.v[0] : 0);   // so that the LDS latency hides behind the previous step's arithmetic
+    for (int s0 = 1; s0 < maxSteps; s0 += PQ) {
+        const VecI4 na = *reinterpret_cast<const VecI4*>(ix + s0 + PQ), nb = *reinterpret_cast<const VecI4*>(ix + s0 + PQ + 4);
+        uint32_t pks[PQ];
 #pragma unroll
         for (int u = 0; u < PQ; u++) {
             const int s = s0 + u;
-            const int k = kq[u];
-            kq[u] = (s + PQ < nsteps) ? ix[s + PQ] : 0;
-            if (s < nsteps) {
-                const int64_t t = ts + s;
-                double e[NSTATE];
-                vit_emissions(e, sTab, logPmf, useLds, P.tableLen, k);
-                uint32_t pk = 0;
-                if (t == 0) vit_init5(d, e, P);
-                else if (s == 0) {                                                 // first step of a cold start: no history
+            const bool on = s < nsteps;
+            const int kNext = (s + 1 < nsteps) ? (u + 1 < 4 ? qa.v[(u + 1) & 3] : (u + 1 < 8 ? qb.v[(u + 1) & 3] : na.v[0])) : 0;
+            double eNext[NSTATE], dn[NSTATE];
+            vit_emissions(eNext, sTab, logPmf, useLds, P.tableLen, kNext);
 #pragma unroll
-                    for (int j = 0; j < NSTATE; j++) d[j] = e[j];
-                } else pk = vit_step5(d, e, P);
-                if (t >= tBeg) { pp[t] = (uint16_t)pk; if (t > 0) fm = map_compose(fm, pk); }
-            }
+            for (int j = 0; j < NSTATE; j++) dn[j] = d[j];
+            const uint32_t pk = vit_step5(dn, eCur, P);
+#pragma unroll
+            for (int j = 0; j < NSTATE; j++) { d[j] = on ? dn[j] : d[j]; eCur[j] = eNext[j]; }
+            fm = (on && s >= lead) ? map_compose(fm, pk) : fm;
+            pks[u] = pk;
         }
+#pragma unroll
+        for (int u = 0; u < PQ; u++) { const int s = s0 + u; if (s < nsteps && s >= lead) pp[ts + s] = (uint16_t)pks[u]; }
+        qa = na; qb = nb;
     }
     if (act) {
         maps[b] = (uint16_t)fm;
@@ -745,12 +765,12 @@ __global__ void __launch_bounds__(256) k_bb_emit(const BbChunk* __restrict__ chu
 }
 
 // C: exact verification, one lane per block
+template <bool useLds>
 __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                    const double* __restrict__ logPmf, HmmParams P, const uint16_t* __restrict__ psi,
                                                    const int32_t* __restrict__ state, const double* __restrict__ V, const double* __restrict__ carry, const int32_t* __restrict__ lastGuess,
                                                    int32_t* __restrict__ fail, int leadIn, const int32_t* __restrict__ todo) {
     extern __shared__ double sTab[];
-    const bool useLds = P.tableLen * NSTATE * 8 <= 48 * 1024;
     vit_stage_table(sTab, logPmf, P.tableLen, useLds);
     const int b = blockIdx.x * 64 + threadIdx.x;
     const bool actBlock = b < nblocks;
@@ -774,11 +794,29 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
 #pragma unroll
     for (int u = 0; u < PQ; u++) { const bool in = u < nsteps; kq[u] = in ? ix[u] : 0; sq[u] = in ? st[u] : 0; vq[u] = in ? Vc[u] : 0.0; pq[u] = in ? pp[u] : 0u; }
     for (int s0 = 0; s0 < maxSteps; s0 += PQ) {
+        // the next group of PQ steps is fetched with 16-byte loads at the start of the group (one 4/8-byte load per array and step kept the
+        // lane's cache lines travelling between L1 and L2 and made every step wait for them: SQ_WAIT_ANY was 62 % of the wave cycles).
+        // The vector loads stay inside the lane's own range (state[] is the caller's array); the last groups take the guarded loads.
+        int kn[PQ], sn[PQ]; double vn[PQ]; uint32_t pn[PQ];
+        if (s0 + 2 * PQ <= nsteps) {
+            const int o = s0 + PQ;
+            const VecI4 ka = *reinterpret_cast<const VecI4*>(ix + o), kb = *reinterpret_cast<const VecI4*>(ix + o + 4);
+            const VecI4 sa = *reinterpret_cast<const VecI4*>(st + o), sb = *reinterpret_cast<const VecI4*>(st + o + 4);
+            const VecD2 v0 = *reinterpret_cast<const VecD2*>(Vc + o), v1 = *reinterpret_cast<const VecD2*>(Vc + o + 2), v2 = *reinterpret_cast<const VecD2*>(Vc + o + 4),
+                        v3 = *reinterpret_cast<const VecD2*>(Vc + o + 6);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { kn[u] = ka.v[u]; kn[4 + u] = kb.v[u]; sn[u] = sa.v[u]; sn[4 + u] = sb.v[u]; }
+            vn[0] = v0.v[0]; vn[1] = v0.v[1]; vn[2] = v1.v[0]; vn[3] = v1.v[1]; vn[4] = v2.v[0]; vn[5] = v2.v[1]; vn[6] = v3.v[0]; vn[7] = v3.v[1];
+#pragma unroll
+            for (int u = 0; u < PQ; u++) pn[u] = pp[o + u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < PQ; u++) { const bool in = s0 + PQ + u < nsteps; kn[u] = in ? ix[s0 + PQ + u] : 0; sn[u] = in ? st[s0 + PQ + u] : 0; vn[u] = in ? Vc[s0 + PQ + u] : 0.0; pn[u] = in ? pp[s0 + PQ + u] : 0u; }
+        }
 #pragma unroll
         for (int u = 0; u < PQ; u++) {
             const int s = s0 + u;
             const int k = kq[u], sCur = sq[u]; const double v = vq[u]; const uint32_t pk = pq[u];
-            { const bool in = s + PQ < nsteps; kq[u] = in ? ix[s + PQ] : 0; sq[u] = in ? st[s + PQ] : 0; vq[u] = in ? Vc[s + PQ] : 0.0; pq[u] = in ? pp[s + PQ] : 0u; }
             if (s < nsteps) {
                 const int64_t t = ts + s;
                 double e[NSTATE];
@@ -817,6 +855,8 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
                 Dprev = Dt; sPrev = sCur;
             }
         }
+#pragma unroll
+        for (int u = 0; u < PQ; u++) { kq[u] = kn[u]; sq[u] = sn[u]; vq[u] = vn[u]; pq[u] = pn[u]; }
     }
     if (act && tEnd == C.T) { if (valid != 31u || vit_best5(d) != lastGuess[B.chrom]) bad = true; }
     if (act && bad) atomicOr(&fail[B.chrom], 1);
@@ -1233,7 +1273,8 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         for (int attempt = 0; attempt < 2; attempt++) {
             const int leadSpec = attempt == 0 ? VW : 8 * VW, leadVer = attempt == 0 ? VW2 : 8 * VW2;
             CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
-            hipLaunchKernelGGL(k_vit_spec, dim3((unsigned)((nblocksS + 63) / 64)), dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
+            if (lds) hipLaunchKernelGGL((k_vit_spec<true>), dim3((unsigned)((nblocksS + 63) / 64)), dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
+            else hipLaunchKernelGGL((k_vit_spec<false>), dim3((unsigned)((nblocksS + 63) / 64)), dim3(64), 0, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             hipLaunchKernelGGL(k_pair_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, dFirstS, dMapsS, dMaps, dTodo);
             if (attempt == 0 && getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, chroms[0].begin + chroms[0].T / 2);
             backtrack(true);
@@ -1248,7 +1289,8 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
                 hipLaunchKernelGGL(k_bb_walk, dim3(nchr), dim3(64), 0, ctx->stream, dFirstChunk, dChunkOut, dCross, dChunkBits, dPost, dFail);
                 hipLaunchKernelGGL(k_bb_emit, dim3(nblk2((int64_t)nchunks * 16, 256)), dim3(256), 0, ctx->stream, dBChunks, nchunks, dChroms, dChunkBits, dPost, dAt64Fn, dAt64Rank, dCarry);
             }
-            hipLaunchKernelGGL(k_vit_verify, dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail, leadVer, dTodo);
+            if (lds) hipLaunchKernelGGL((k_vit_verify<true>), dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail, leadVer, dTodo);
+            else hipLaunchKernelGGL((k_vit_verify<false>), dim3(laneGrid), dim3(64), 0, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail, leadVer, dTodo);
             std::vector<int32_t> hFail(nchr, 0);
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1286,10 +1328,10 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = h_chr_offset[nchr];
     if (N < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
-    WsSizer ex; ex.take<uint32_t>(N); ex.take<int32_t>(N); ex.take<double>(NSTATE * 70000);
+    WsSizer ex; ex.take<uint32_t>(N); ex.take<int32_t>(N + 256); ex.take<double>(NSTATE * 70000);
     auto prepare = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom*, const int64_t*) -> int32_t {
         int32_t rc;
-        uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N); double* dTab = ws.take<double>(NSTATE * 70000);
+        uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N + 256); double* dTab = ws.take<double>(NSTATE * 70000);   // idx: padded for the group loads of k_vit_spec
     // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
     hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
     int64_t qidx[6]; int nq;
@@ -1410,9 +1452,9 @@ extern "C" int32_t canvas_hmm_joint(canvas_ctx* ctx, int32_t nsamples, int32_t n
     }
     JointCombos K; genotype_combinations(S, K);
     // ---- phase 2 inside the shared pipeline: indices, tables, per-bin maxima, host log, then Viterbi
-    WsSizer ex; ex.take<int32_t>(N); ex.take<int32_t>((size_t)S * N); ex.take<double>((size_t)NSTATE * N); ex.take<double>(nCS * NSTATE * strideUb); ex.take<double>(nchr); ex.take<int32_t>(nchr);
+    WsSizer ex; ex.take<int32_t>(N + 256); ex.take<int32_t>((size_t)S * N); ex.take<double>((size_t)NSTATE * N); ex.take<double>(nCS * NSTATE * strideUb); ex.take<double>(nchr); ex.take<int32_t>(nchr);
     auto prepare = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom* dChroms, const int64_t* dOffDev) -> int32_t {
-        int32_t* idx = ws.take<int32_t>(N); int32_t* idxS = ws.take<int32_t>((size_t)S * N); double* dL = ws.take<double>((size_t)NSTATE * N);
+        int32_t* idx = ws.take<int32_t>(N + 256); int32_t* idxS = ws.take<int32_t>((size_t)S * N); double* dL = ws.take<double>((size_t)NSTATE * N);
         double* dPmf = ws.take<double>(nCS * NSTATE * strideUb); double* dThr = ws.take<double>(nchr); int32_t* dMaxIdx = ws.take<int32_t>(nchr);
         int32_t rc = canvas_h2d_small(ctx, dThr, thr.data(), nchr * 8); if (rc) return rc;
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dMaxIdx, 0, nchr * 4, ctx->stream));
