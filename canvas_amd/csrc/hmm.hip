@@ -790,74 +790,94 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
     bool bad = false;
     double Dprev = carry[C.begin + ts];         // D_{ts-1} (0 at the start of the chromosome)
     int sPrev = ts > 0 ? state[C.begin + ts - 1] : -1;
-    int kq[PQ], sq[PQ]; double vq[PQ]; uint32_t pq[PQ];
+    const int lead = (int)(tBeg - ts);
+    // lead-in step: follow the guessed pointers; a state is exact once its ancestry reaches the backbone (valid == 0 in front of the lead-in:
+    // nothing is known there).  `on` == false leaves everything as it is.
+    auto leadStep = [&](bool on, int k, int sCur, double v, uint32_t pk) {
+        double e[NSTATE];
+        vit_emissions(e, sTab, logPmf, useLds, P.tableLen, on ? k : 0);
+        const double Dt = Dprev + v;                  // D_t = D_{t-1} + v_t (same association as the backbone)
+        double nd[NSTATE]; uint32_t nv = 0;
 #pragma unroll
-    for (int u = 0; u < PQ; u++) { const bool in = u < nsteps; kq[u] = in ? ix[u] : 0; sq[u] = in ? st[u] : 0; vq[u] = in ? Vc[u] : 0.0; pq[u] = in ? pp[u] : 0u; }
-    for (int s0 = 0; s0 < maxSteps; s0 += PQ) {
-        // the next group of PQ steps is fetched with 16-byte loads at the start of the group (one 4/8-byte load per array and step kept the
-        // lane's cache lines travelling between L1 and L2 and made every step wait for them: SQ_WAIT_ANY was 62 % of the wave cycles).
-        // The vector loads stay inside the lane's own range (state[] is the caller's array); the last groups take the guarded loads.
-        int kn[PQ], sn[PQ]; double vn[PQ]; uint32_t pn[PQ];
-        if (s0 + 2 * PQ <= nsteps) {
-            const int o = s0 + PQ;
-            const VecI4 ka = *reinterpret_cast<const VecI4*>(ix + o), kb = *reinterpret_cast<const VecI4*>(ix + o + 4);
-            const VecI4 sa = *reinterpret_cast<const VecI4*>(st + o), sb = *reinterpret_cast<const VecI4*>(st + o + 4);
-            const VecD2 v0 = *reinterpret_cast<const VecD2*>(Vc + o), v1 = *reinterpret_cast<const VecD2*>(Vc + o + 2), v2 = *reinterpret_cast<const VecD2*>(Vc + o + 4),
-                        v3 = *reinterpret_cast<const VecD2*>(Vc + o + 6);
-#pragma unroll
-            for (int u = 0; u < 4; u++) { kn[u] = ka.v[u]; kn[4 + u] = kb.v[u]; sn[u] = sa.v[u]; sn[4 + u] = sb.v[u]; }
-            vn[0] = v0.v[0]; vn[1] = v0.v[1]; vn[2] = v1.v[0]; vn[3] = v1.v[1]; vn[4] = v2.v[0]; vn[5] = v2.v[1]; vn[6] = v3.v[0]; vn[7] = v3.v[1];
-#pragma unroll
-            for (int u = 0; u < PQ; u++) pn[u] = pp[o + u];
-        } else {
-#pragma unroll
-            for (int u = 0; u < PQ; u++) { const bool in = s0 + PQ + u < nsteps; kn[u] = in ? ix[s0 + PQ + u] : 0; sn[u] = in ? st[s0 + PQ + u] : 0; vn[u] = in ? Vc[s0 + PQ + u] : 0.0; pn[u] = in ? pp[s0 + PQ + u] : 0u; }
+        for (int j = 0; j < NSTATE; j++) {
+            const uint32_t p = map_get(pk, j);
+            const double dp = sel5(d, p);
+            const bool vp = ((valid >> p) & 1u) != 0;
+            double la = P.logA[0][j];
+            la = p == 1 ? P.logA[1][j] : la; la = p == 2 ? P.logA[2][j] : la; la = p == 3 ? P.logA[3][j] : la; la = p == 4 ? P.logA[4][j] : la;
+            const double step = e[j] + la;
+            double r = d[j]; bool ok = false;
+            if (j == sCur) { r = Dt; ok = true; }
+            else if ((int)p == sPrev) { r = Dprev + step; ok = true; }
+            else if (vp) { r = dp + step; ok = true; }
+            nd[j] = r; nv |= ok ? (1u << j) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < PQ; u++) {
-            const int s = s0 + u;
-            const int k = kq[u], sCur = sq[u]; const double v = vq[u]; const uint32_t pk = pq[u];
-            if (s < nsteps) {
-                const int64_t t = ts + s;
-                double e[NSTATE];
-                vit_emissions(e, sTab, logPmf, useLds, P.tableLen, k);
-                const double Dt = Dprev + v;                  // D_t = D_{t-1} + v_t (same association as the backbone)
-                if (t == 0) {
-                    vit_init5(d, e, P); valid = 31u;
-                    if (sel5(d, (uint32_t)sCur) != Dt) bad = true;
-                } else if (t < tBeg || s == 0) {
-                    // lead-in: follow the guessed pointers; a state is exact once its ancestry reaches the backbone
-                    double nd[NSTATE]; uint32_t nv = 0;
+        for (int j = 0; j < NSTATE; j++) d[j] = on ? nd[j] : d[j];
+        valid = on ? nv : valid; Dprev = on ? Dt : Dprev; sPrev = on ? sCur : sPrev;
+    };
+    // block step: every state must be exact by now; redo the reference's arg-max and compare with the guess
+    auto blockStep = [&](bool on, int k, int sCur, double v, uint32_t pk) {
+        double e[NSTATE], dn[NSTATE];
+        vit_emissions(e, sTab, logPmf, useLds, P.tableLen, on ? k : 0);
+        const double Dt = Dprev + v;
 #pragma unroll
-                    for (int j = 0; j < NSTATE; j++) {
-                        const uint32_t p = map_get(pk, j);
-                        const double dp = sel5(d, p);
-                        const bool vp = s == 0 ? false : ((valid >> p) & 1u) != 0;      // nothing is known before the lead-in
-                        double la = P.logA[0][j];
-                        la = p == 1 ? P.logA[1][j] : la; la = p == 2 ? P.logA[2][j] : la; la = p == 3 ? P.logA[3][j] : la; la = p == 4 ? P.logA[4][j] : la;
-                        const double step = e[j] + la;
-                        double r = d[j]; bool ok = false;
-                        if (j == sCur) { r = Dt; ok = true; }
-                        else if ((int)p == sPrev) { r = Dprev + step; ok = true; }
-                        else if (vp) { r = dp + step; ok = true; }
-                        nd[j] = r; nv |= ok ? (1u << j) : 0u;
-                    }
+        for (int j = 0; j < NSTATE; j++) dn[j] = d[j];
+        const uint32_t got = vit_step5(dn, e, P);
+        bad = bad || (on && (valid != 31u || got != pk || sel5(dn, (uint32_t)(on ? sCur : 0)) != Dt));
 #pragma unroll
-                    for (int j = 0; j < NSTATE; j++) d[j] = nd[j];
-                    valid = nv;
-                } else {
-                    // inside the block: every state must be exact by now; redo the reference's arg-max and compare with the guess
-                    if (valid != 31u) bad = true;
-                    const uint32_t got = vit_step5(d, e, P);
-                    if (got != pk) bad = true;
-                    if (sel5(d, (uint32_t)sCur) != Dt) bad = true;
-                }
-                Dprev = Dt; sPrev = sCur;
+        for (int j = 0; j < NSTATE; j++) d[j] = on ? dn[j] : d[j];
+        Dprev = on ? Dt : Dprev; sPrev = on ? sCur : sPrev;
+    };
+    // A phase = `cnt` consecutive steps of one kind starting at step `start` of the lane (per-lane values; the wave runs max(cnt) rounds and the
+    // lanes that are done are switched off by predicate, so the step code is straight-line).  The operands of the next eight steps are fetched
+    // with 16-byte loads one group ahead; they stay inside the lane's own range (state[] is the caller's array), the last group is loaded guarded.
+    // With one load per array and step and a branch per condition every step used to wait for ALL outstanding loads (SQ_WAIT_ANY 62 %).
+    auto phase = [&](int start, int cnt, auto stepFn) {
+        const int maxCnt = wave_max_i32(cnt);
+        const int32_t* __restrict__ ixp = ix + start; const int32_t* __restrict__ stp = st + start;
+        const double* __restrict__ vp = Vc + start; const uint16_t* __restrict__ ppp = pp + start;
+        int kq[PQ], sq[PQ]; double vq[PQ]; uint32_t pq[PQ];
+#pragma unroll
+        for (int u = 0; u < PQ; u++) { const bool in = u < cnt; kq[u] = in ? ixp[u] : 0; sq[u] = in ? stp[u] : 0; vq[u] = in ? vp[u] : 0.0; pq[u] = in ? ppp[u] : 0u; }
+        for (int j0 = 0; j0 < maxCnt; j0 += PQ) {
+            int kn[PQ], sn[PQ]; double vn[PQ]; uint32_t pn[PQ];
+            if (j0 + 2 * PQ <= cnt) {
+                const int o = j0 + PQ;
+                const VecI4 ka = *reinterpret_cast<const VecI4*>(ixp + o), kb = *reinterpret_cast<const VecI4*>(ixp + o + 4);
+                const VecI4 sa = *reinterpret_cast<const VecI4*>(stp + o), sb = *reinterpret_cast<const VecI4*>(stp + o + 4);
+                const VecD2 v0 = *reinterpret_cast<const VecD2*>(vp + o), v1 = *reinterpret_cast<const VecD2*>(vp + o + 2), v2 = *reinterpret_cast<const VecD2*>(vp + o + 4),
+                            v3 = *reinterpret_cast<const VecD2*>(vp + o + 6);
+#pragma unroll
+                for (int u = 0; u < 4; u++) { kn[u] = ka.v[u]; kn[4 + u] = kb.v[u]; sn[u] = sa.v[u]; sn[4 + u] = sb.v[u]; }
+                vn[0] = v0.v[0]; vn[1] = v0.v[1]; vn[2] = v1.v[0]; vn[3] = v1.v[1]; vn[4] = v2.v[0]; vn[5] = v2.v[1]; vn[6] = v3.v[0]; vn[7] = v3.v[1];
+#pragma unroll
+                for (int u = 0; u < PQ; u++) pn[u] = ppp[o + u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < PQ; u++) { const bool in = j0 + PQ + u < cnt; kn[u] = in ? ixp[j0 + PQ + u] : 0; sn[u] = in ? stp[j0 + PQ + u] : 0; vn[u] = in ? vp[j0 + PQ + u] : 0.0; pn[u] = in ? ppp[j0 + PQ + u] : 0u; }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < PQ; u++) { kq[u] = kn[u]; sq[u] = sn[u]; vq[u] = vn[u]; pq[u] = pn[u]; }
+            for (int u = 0; u < PQ; u++) stepFn(j0 + u < cnt, kq[u], sq[u], vq[u], pq[u]);
+#pragma unroll
+            for (int u = 0; u < PQ; u++) { kq[u] = kn[u]; sq[u] = sn[u]; vq[u] = vn[u]; pq[u] = pn[u]; }
+        }
+    };
+    // step 0 on its own: the first bin of a chromosome starts the recurrence (HMM.cs:78), any other first step is a lead-in step without history
+    if (nsteps > 0) {
+        if (ts == 0) {
+            double e[NSTATE];
+            vit_emissions(e, sTab, logPmf, useLds, P.tableLen, ix[0]);
+            const double Dt = Dprev + Vc[0];
+            const int sCur = st[0];
+            vit_init5(d, e, P); valid = 31u;
+            if (sel5(d, (uint32_t)sCur) != Dt) bad = true;
+            Dprev = Dt; sPrev = sCur;
+        } else leadStep(true, ix[0], st[0], Vc[0], (uint32_t)pp[0]);
     }
+    const int start2 = lead > 1 ? lead : 1;
+    phase(1, nsteps > 0 && lead > 1 ? lead - 1 : 0, leadStep);
+    phase(start2, nsteps > start2 ? nsteps - start2 : 0, blockStep);
     if (act && tEnd == C.T) { if (valid != 31u || vit_best5(d) != lastGuess[B.chrom]) bad = true; }
     if (act && bad) atomicOr(&fail[B.chrom], 1);
 }
