@@ -764,7 +764,94 @@ __global__ void __launch_bounds__(256) k_bb_emit(const BbChunk* __restrict__ chu
     carryOut[C.begin + t + 1] = -__longlong_as_double((long long)bits);
 }
 
-// C: exact verification, one lane per block
+// the 25 transition terms as separate scalars held in registers: as an array (or read from the argument block) the select over the guessed
+// predecessor turns into a table lookup in memory -- a load and a wait per state and step
+struct LogA25 { double a00, a01, a02, a03, a04, a10, a11, a12, a13, a14, a20, a21, a22, a23, a24, a30, a31, a32, a33, a34, a40, a41, a42, a43, a44; };
+#define LOGA_COL(A, j) A.a0##j, A.a1##j, A.a2##j, A.a3##j, A.a4##j
+__device__ __forceinline__ double pick5(uint32_t p, double x0, double x1, double x2, double x3, double x4) {
+    double r = x0;
+    r = p == 1 ? x1 : r; r = p == 2 ? x2 : r; r = p == 3 ? x3 : r; r = p == 4 ? x4 : r;
+    return r;
+}
+// ---- C: exact verification.  State of one lane:
+struct VerState { double d[NSTATE]; uint32_t valid; bool bad; double Dprev; int sPrev; };   // valid bit j: d[j] is the exact delta_t(j)
+// lead-in step: follow the guessed pointers; a state is exact once its ancestry reaches the backbone (valid == 0 in front of the lead-in:
+// nothing is known there).  `on` == false leaves everything as it is.
+template <bool useLds>
+__device__ __forceinline__ void ver_lead_step(VerState& S, const LogA25& A, const double* __restrict__ sTab, const double* __restrict__ logPmf, int tableLen,
+                                              bool on, int k, int sCur, double v, uint32_t pk) {
+    double e[NSTATE];
+    vit_emissions(e, sTab, logPmf, useLds, tableLen, on ? k : 0);
+    const double Dt = S.Dprev + v;                    // D_t = D_{t-1} + v_t (same association as the backbone)
+    double nd[NSTATE]; uint32_t nv = 0;
+    const double la5[NSTATE] = {pick5(map_get(pk, 0), LOGA_COL(A, 0)), pick5(map_get(pk, 1), LOGA_COL(A, 1)), pick5(map_get(pk, 2), LOGA_COL(A, 2)),
+                                pick5(map_get(pk, 3), LOGA_COL(A, 3)), pick5(map_get(pk, 4), LOGA_COL(A, 4))};
+#pragma unroll
+    for (int j = 0; j < NSTATE; j++) {
+        const uint32_t p = map_get(pk, j);
+        const double dp = pick5(p, S.d[0], S.d[1], S.d[2], S.d[3], S.d[4]);
+        const bool vp = ((S.valid >> p) & 1u) != 0;
+        const double step = e[j] + la5[j];
+        const bool isCur = j == sCur, fromPrev = (int)p == S.sPrev;
+        const double r = isCur ? Dt : (fromPrev ? S.Dprev + step : (vp ? dp + step : S.d[j]));
+        nd[j] = r; nv |= (isCur || fromPrev || vp) ? (1u << j) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NSTATE; j++) S.d[j] = on ? nd[j] : S.d[j];
+    S.valid = on ? nv : S.valid; S.Dprev = on ? Dt : S.Dprev; S.sPrev = on ? sCur : S.sPrev;
+}
+// block step: every state must be exact by now; redo the reference's arg-max and compare with the guess
+template <bool useLds>
+__device__ __forceinline__ void ver_block_step(VerState& S, const HmmParams& P, const double* __restrict__ sTab, const double* __restrict__ logPmf, bool on, int k, int sCur,
+                                               double v, uint32_t pk) {
+    double e[NSTATE], dn[NSTATE];
+    vit_emissions(e, sTab, logPmf, useLds, P.tableLen, on ? k : 0);
+    const double Dt = S.Dprev + v;
+#pragma unroll
+    for (int j = 0; j < NSTATE; j++) dn[j] = S.d[j];
+    const uint32_t got = vit_step5(dn, e, P);
+    S.bad = S.bad || (on && (S.valid != 31u || got != pk || sel5(dn, (uint32_t)(on ? sCur : 0)) != Dt));
+#pragma unroll
+    for (int j = 0; j < NSTATE; j++) S.d[j] = on ? dn[j] : S.d[j];
+    S.Dprev = on ? Dt : S.Dprev; S.sPrev = on ? sCur : S.sPrev;
+}
+// A phase = `cnt` consecutive steps of one kind (per-lane count; the wave runs max(cnt) rounds and the lanes that are done are switched off by
+// predicate, so the step code is straight-line).  The operands of the next eight steps are fetched with 16-byte loads one group ahead; they stay
+// inside the lane's own range (state[] is the caller's array), the last group is loaded guarded.  With one load per array and step and a
+// branch per condition every step used to wait for ALL outstanding loads (SQ_WAIT_ANY 62 % of the wave cycles).
+template <bool useLds, bool LEAD>
+__device__ __forceinline__ void ver_phase(VerState& S, const LogA25& A, const HmmParams& P, const double* __restrict__ sTab, const double* __restrict__ logPmf,
+                                          const int32_t* __restrict__ ixp, const int32_t* __restrict__ stp, const double* __restrict__ vp, const uint16_t* __restrict__ ppp, int cnt) {
+    const int maxCnt = wave_max_i32(cnt);
+    int kq[PQ], sq[PQ]; double vq[PQ]; uint32_t pq[PQ];
+#pragma unroll
+    for (int u = 0; u < PQ; u++) { const bool in = u < cnt; kq[u] = in ? ixp[u] : 0; sq[u] = in ? stp[u] : 0; vq[u] = in ? vp[u] : 0.0; pq[u] = in ? ppp[u] : 0u; }
+    for (int j0 = 0; j0 < maxCnt; j0 += PQ) {
+        int kn[PQ], sn[PQ]; double vn[PQ]; uint32_t pn[PQ];
+        if (j0 + 2 * PQ <= cnt) {
+            const int o = j0 + PQ;
+            const VecI4 ka = *reinterpret_cast<const VecI4*>(ixp + o), kb = *reinterpret_cast<const VecI4*>(ixp + o + 4);
+            const VecI4 sa = *reinterpret_cast<const VecI4*>(stp + o), sb = *reinterpret_cast<const VecI4*>(stp + o + 4);
+            const VecD2 v0 = *reinterpret_cast<const VecD2*>(vp + o), v1 = *reinterpret_cast<const VecD2*>(vp + o + 2), v2 = *reinterpret_cast<const VecD2*>(vp + o + 4),
+                        v3 = *reinterpret_cast<const VecD2*>(vp + o + 6);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { kn[u] = ka.v[u]; kn[4 + u] = kb.v[u]; sn[u] = sa.v[u]; sn[4 + u] = sb.v[u]; }
+            vn[0] = v0.v[0]; vn[1] = v0.v[1]; vn[2] = v1.v[0]; vn[3] = v1.v[1]; vn[4] = v2.v[0]; vn[5] = v2.v[1]; vn[6] = v3.v[0]; vn[7] = v3.v[1];
+#pragma unroll
+            for (int u = 0; u < PQ; u++) pn[u] = ppp[o + u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < PQ; u++) { const bool in = j0 + PQ + u < cnt; kn[u] = in ? ixp[j0 + PQ + u] : 0; sn[u] = in ? stp[j0 + PQ + u] : 0; vn[u] = in ? vp[j0 + PQ + u] : 0.0; pn[u] = in ? ppp[j0 + PQ + u] : 0u; }
+        }
+#pragma unroll
+        for (int u = 0; u < PQ; u++) {
+            if (LEAD) ver_lead_step<useLds>(S, A, sTab, logPmf, P.tableLen, j0 + u < cnt, kq[u], sq[u], vq[u], pq[u]);
+            else ver_block_step<useLds>(S, P, sTab, logPmf, j0 + u < cnt, kq[u], sq[u], vq[u], pq[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PQ; u++) { kq[u] = kn[u]; sq[u] = sn[u]; vq[u] = vn[u]; pq[u] = pn[u]; }
+    }
+}
 template <bool useLds>
 __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                    const double* __restrict__ logPmf, HmmParams P, const uint16_t* __restrict__ psi,
@@ -785,99 +872,37 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
     const int32_t* __restrict__ st = state + C.begin + ts;
     const double* __restrict__ Vc = V + C.begin + ts;
     const uint16_t* __restrict__ pp = psi + C.begin + ts;
-    double d[NSTATE] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    uint32_t valid = 0;                         // bit j: d[j] is the exact delta_t(j)
-    bool bad = false;
-    double Dprev = carry[C.begin + ts];         // D_{ts-1} (0 at the start of the chromosome)
-    int sPrev = ts > 0 ? state[C.begin + ts - 1] : -1;
+    VerState S;
+#pragma unroll
+    for (int j = 0; j < NSTATE; j++) S.d[j] = 0.0;
+    S.valid = 0; S.bad = false;
+    S.Dprev = carry[C.begin + ts];              // D_{ts-1} (0 at the start of the chromosome)
+    S.sPrev = ts > 0 ? state[C.begin + ts - 1] : -1;
+    // the transition terms as opaque register values: left as loads from the argument block, the select over the guessed predecessor below
+    // becomes a select over ADDRESSES followed by a load (and a wait) per state and step
+    LogA25 A;
+#define LOGA_LOAD(i, j) A.a##i##j = P.logA[i][j]; asm volatile("" : "+v"(A.a##i##j));
+    LOGA_LOAD(0, 0) LOGA_LOAD(0, 1) LOGA_LOAD(0, 2) LOGA_LOAD(0, 3) LOGA_LOAD(0, 4) LOGA_LOAD(1, 0) LOGA_LOAD(1, 1) LOGA_LOAD(1, 2) LOGA_LOAD(1, 3) LOGA_LOAD(1, 4)
+    LOGA_LOAD(2, 0) LOGA_LOAD(2, 1) LOGA_LOAD(2, 2) LOGA_LOAD(2, 3) LOGA_LOAD(2, 4) LOGA_LOAD(3, 0) LOGA_LOAD(3, 1) LOGA_LOAD(3, 2) LOGA_LOAD(3, 3) LOGA_LOAD(3, 4)
+    LOGA_LOAD(4, 0) LOGA_LOAD(4, 1) LOGA_LOAD(4, 2) LOGA_LOAD(4, 3) LOGA_LOAD(4, 4)
+#undef LOGA_LOAD
     const int lead = (int)(tBeg - ts);
-    // lead-in step: follow the guessed pointers; a state is exact once its ancestry reaches the backbone (valid == 0 in front of the lead-in:
-    // nothing is known there).  `on` == false leaves everything as it is.
-    auto leadStep = [&](bool on, int k, int sCur, double v, uint32_t pk) {
-        double e[NSTATE];
-        vit_emissions(e, sTab, logPmf, useLds, P.tableLen, on ? k : 0);
-        const double Dt = Dprev + v;                  // D_t = D_{t-1} + v_t (same association as the backbone)
-        double nd[NSTATE]; uint32_t nv = 0;
-#pragma unroll
-        for (int j = 0; j < NSTATE; j++) {
-            const uint32_t p = map_get(pk, j);
-            const double dp = sel5(d, p);
-            const bool vp = ((valid >> p) & 1u) != 0;
-            double la = P.logA[0][j];
-            la = p == 1 ? P.logA[1][j] : la; la = p == 2 ? P.logA[2][j] : la; la = p == 3 ? P.logA[3][j] : la; la = p == 4 ? P.logA[4][j] : la;
-            const double step = e[j] + la;
-            double r = d[j]; bool ok = false;
-            if (j == sCur) { r = Dt; ok = true; }
-            else if ((int)p == sPrev) { r = Dprev + step; ok = true; }
-            else if (vp) { r = dp + step; ok = true; }
-            nd[j] = r; nv |= ok ? (1u << j) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < NSTATE; j++) d[j] = on ? nd[j] : d[j];
-        valid = on ? nv : valid; Dprev = on ? Dt : Dprev; sPrev = on ? sCur : sPrev;
-    };
-    // block step: every state must be exact by now; redo the reference's arg-max and compare with the guess
-    auto blockStep = [&](bool on, int k, int sCur, double v, uint32_t pk) {
-        double e[NSTATE], dn[NSTATE];
-        vit_emissions(e, sTab, logPmf, useLds, P.tableLen, on ? k : 0);
-        const double Dt = Dprev + v;
-#pragma unroll
-        for (int j = 0; j < NSTATE; j++) dn[j] = d[j];
-        const uint32_t got = vit_step5(dn, e, P);
-        bad = bad || (on && (valid != 31u || got != pk || sel5(dn, (uint32_t)(on ? sCur : 0)) != Dt));
-#pragma unroll
-        for (int j = 0; j < NSTATE; j++) d[j] = on ? dn[j] : d[j];
-        Dprev = on ? Dt : Dprev; sPrev = on ? sCur : sPrev;
-    };
-    // A phase = `cnt` consecutive steps of one kind starting at step `start` of the lane (per-lane values; the wave runs max(cnt) rounds and the
-    // lanes that are done are switched off by predicate, so the step code is straight-line).  The operands of the next eight steps are fetched
-    // with 16-byte loads one group ahead; they stay inside the lane's own range (state[] is the caller's array), the last group is loaded guarded.
-    // With one load per array and step and a branch per condition every step used to wait for ALL outstanding loads (SQ_WAIT_ANY 62 %).
-    auto phase = [&](int start, int cnt, auto stepFn) {
-        const int maxCnt = wave_max_i32(cnt);
-        const int32_t* __restrict__ ixp = ix + start; const int32_t* __restrict__ stp = st + start;
-        const double* __restrict__ vp = Vc + start; const uint16_t* __restrict__ ppp = pp + start;
-        int kq[PQ], sq[PQ]; double vq[PQ]; uint32_t pq[PQ];
-#pragma unroll
-        for (int u = 0; u < PQ; u++) { const bool in = u < cnt; kq[u] = in ? ixp[u] : 0; sq[u] = in ? stp[u] : 0; vq[u] = in ? vp[u] : 0.0; pq[u] = in ? ppp[u] : 0u; }
-        for (int j0 = 0; j0 < maxCnt; j0 += PQ) {
-            int kn[PQ], sn[PQ]; double vn[PQ]; uint32_t pn[PQ];
-            if (j0 + 2 * PQ <= cnt) {
-                const int o = j0 + PQ;
-                const VecI4 ka = *reinterpret_cast<const VecI4*>(ixp + o), kb = *reinterpret_cast<const VecI4*>(ixp + o + 4);
-                const VecI4 sa = *reinterpret_cast<const VecI4*>(stp + o), sb = *reinterpret_cast<const VecI4*>(stp + o + 4);
-                const VecD2 v0 = *reinterpret_cast<const VecD2*>(vp + o), v1 = *reinterpret_cast<const VecD2*>(vp + o + 2), v2 = *reinterpret_cast<const VecD2*>(vp + o + 4),
-                            v3 = *reinterpret_cast<const VecD2*>(vp + o + 6);
-#pragma unroll
-                for (int u = 0; u < 4; u++) { kn[u] = ka.v[u]; kn[4 + u] = kb.v[u]; sn[u] = sa.v[u]; sn[4 + u] = sb.v[u]; }
-                vn[0] = v0.v[0]; vn[1] = v0.v[1]; vn[2] = v1.v[0]; vn[3] = v1.v[1]; vn[4] = v2.v[0]; vn[5] = v2.v[1]; vn[6] = v3.v[0]; vn[7] = v3.v[1];
-#pragma unroll
-                for (int u = 0; u < PQ; u++) pn[u] = ppp[o + u];
-            } else {
-#pragma unroll
-                for (int u = 0; u < PQ; u++) { const bool in = j0 + PQ + u < cnt; kn[u] = in ? ixp[j0 + PQ + u] : 0; sn[u] = in ? stp[j0 + PQ + u] : 0; vn[u] = in ? vp[j0 + PQ + u] : 0.0; pn[u] = in ? ppp[j0 + PQ + u] : 0u; }
-            }
-#pragma unroll
-            for (int u = 0; u < PQ; u++) stepFn(j0 + u < cnt, kq[u], sq[u], vq[u], pq[u]);
-#pragma unroll
-            for (int u = 0; u < PQ; u++) { kq[u] = kn[u]; sq[u] = sn[u]; vq[u] = vn[u]; pq[u] = pn[u]; }
-        }
-    };
     // step 0 on its own: the first bin of a chromosome starts the recurrence (HMM.cs:78), any other first step is a lead-in step without history
     if (nsteps > 0) {
         if (ts == 0) {
             double e[NSTATE];
             vit_emissions(e, sTab, logPmf, useLds, P.tableLen, ix[0]);
-            const double Dt = Dprev + Vc[0];
+            const double Dt = S.Dprev + Vc[0];
             const int sCur = st[0];
-            vit_init5(d, e, P); valid = 31u;
-            if (sel5(d, (uint32_t)sCur) != Dt) bad = true;
-            Dprev = Dt; sPrev = sCur;
-        } else leadStep(true, ix[0], st[0], Vc[0], (uint32_t)pp[0]);
+            vit_init5(S.d, e, P); S.valid = 31u;
+            if (sel5(S.d, (uint32_t)sCur) != Dt) S.bad = true;
+            S.Dprev = Dt; S.sPrev = sCur;
+        } else ver_lead_step<useLds>(S, A, sTab, logPmf, P.tableLen, true, ix[0], st[0], Vc[0], (uint32_t)pp[0]);
     }
     const int start2 = lead > 1 ? lead : 1;
-    phase(1, nsteps > 0 && lead > 1 ? lead - 1 : 0, leadStep);
-    phase(start2, nsteps > start2 ? nsteps - start2 : 0, blockStep);
+    ver_phase<useLds, true>(S, A, P, sTab, logPmf, ix + 1, st + 1, Vc + 1, pp + 1, nsteps > 0 && lead > 1 ? lead - 1 : 0);
+    ver_phase<useLds, false>(S, A, P, sTab, logPmf, ix + start2, st + start2, Vc + start2, pp + start2, nsteps > start2 ? nsteps - start2 : 0);
+    double (&d)[NSTATE] = S.d; const uint32_t valid = S.valid; bool bad = S.bad;
     if (act && tEnd == C.T) { if (valid != 31u || vit_best5(d) != lastGuess[B.chrom]) bad = true; }
     if (act && bad) atomicOr(&fail[B.chrom], 1);
 }
