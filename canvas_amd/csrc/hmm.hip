@@ -183,10 +183,10 @@ __device__ __forceinline__ void vit_state(const double (&d)[NSTATE], double e, c
     const double t_2 = d[2] + (e + P.logA[2][J]);
     const double t_3 = d[3] + (e + P.logA[3][J]);
     const double t_4 = d[4] + (e + P.logA[4][J]);
-    double a = t_0; uint32_t ia = 0; if (t_1 > a) { a = t_1; ia = 1; }
-    double b = t_2; uint32_t ib = 2; if (t_3 > b) { b = t_3; ib = 3; }
-    if (b > a) { a = b; ia = ib; }
-    if (t_4 > a) { a = t_4; ia = 4; }
+    // maximum first (v_max_f64), then the first index that attains it: fewer selects than carrying (value, index) through the scan
+    double a = __builtin_fmax(__builtin_fmax(__builtin_fmax(t_0, t_1), __builtin_fmax(t_2, t_3)), t_4);
+    uint32_t ia = t_3 == a ? 3u : 4u;
+    ia = t_2 == a ? 2u : ia; ia = t_1 == a ? 1u : ia; ia = t_0 == a ? 0u : ia;
     if (!(a > NEG)) { a = NEG; ia = 0; }
     outDelta = a; outArg = ia;
 }
