@@ -1263,6 +1263,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     sz.take<int64_t>(nchr + 1); sz.take<VitBlock>(nblocks + 1); sz.take<double>(N); sz.take<double>(N + 64); sz.take<int32_t>(nchr); sz.take<int32_t>(nchr);
     sz.take<VitBlock>(nblocksS + 1); sz.take<uint16_t>(nblocksS + 8); sz.take<int32_t>(nchr + 1);
     sz.take<int32_t>(nchr + 1); sz.take<uint16_t>(nblocks + 8); sz.take<uint16_t>(ngroups + 8); sz.take<int8_t>(ngroups + 8);
+    sz.take<char>(8 * 256 + (size_t)nchr * 64 + 64);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + extraBytes + 65536); if (rc) return rc;
     WsCarver ws(ctx->ws);
     uint16_t* psi = ws.take<uint16_t>(N + 8);
@@ -1279,13 +1280,20 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     BbCross* dCross = ws.take<BbCross>((size_t)nchunks * BB_MAXC + 1); ParFn* dAt64Fn = ws.take<ParFn>((size_t)nchunks * 16 + 1); uint8_t* dAt64Rank = ws.take<uint8_t>((size_t)nchunks * 16 + 8);
     unsigned long long* dChunkBits = ws.take<unsigned long long>(nchunks + 1); BbPost* dPost = ws.take<BbPost>((size_t)nchunks * BB_MAXC + 1);
 
-    // static descriptors first: they do not depend on the data and overlap with the quartile selection
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dChroms, chroms.data(), nchr * sizeof(HmmChrom), hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirst, firstBlock.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOffDev, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstChunk, firstChunk.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstS, firstS.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dFirstGroup, firstGroup.data(), (nchr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    // static descriptors first (they do not depend on the data and overlap with the quartile selection): six small tables in ONE packed upload
+    {
+        auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+        const size_t oCh = 0, oFirst = al((size_t)nchr * sizeof(HmmChrom)), oOff = oFirst + al((size_t)(nchr + 1) * 4), oChunk = oOff + al((size_t)(nchr + 1) * 8),
+                     oS = oChunk + al((size_t)(nchr + 1) * 4), oG = oS + al((size_t)(nchr + 1) * 4), total = oG + al((size_t)(nchr + 1) * 4);
+        std::vector<char> blob(total, 0);
+        memcpy(blob.data() + oCh, chroms.data(), (size_t)nchr * sizeof(HmmChrom)); memcpy(blob.data() + oFirst, firstBlock.data(), (size_t)(nchr + 1) * 4);
+        memcpy(blob.data() + oOff, h_chr_offset, (size_t)(nchr + 1) * 8); memcpy(blob.data() + oChunk, firstChunk.data(), (size_t)(nchr + 1) * 4);
+        memcpy(blob.data() + oS, firstS.data(), (size_t)(nchr + 1) * 4); memcpy(blob.data() + oG, firstGroup.data(), (size_t)(nchr + 1) * 4);
+        char* dBlob = ws.take<char>(total);
+        rc = canvas_h2d_small(ctx, dBlob, blob.data(), total); if (rc) return rc;
+        dChroms = (HmmChrom*)(dBlob + oCh); dFirst = (int32_t*)(dBlob + oFirst); dOffDev = (int64_t*)(dBlob + oOff); dFirstChunk = (int32_t*)(dBlob + oChunk);
+        dFirstS = (int32_t*)(dBlob + oS); dFirstGroup = (int32_t*)(dBlob + oG);
+    }
     if (nblocks > 0) hipLaunchKernelGGL((k_make_blocks<VitBlock>), dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dFirst, nchr, nblocks, VB, dVBlocks);
     if (nblocksS > 0) hipLaunchKernelGGL((k_make_blocks<VitBlock>), dim3(nblk2(nblocksS, 256)), dim3(256), 0, ctx->stream, dFirstS, nchr, nblocksS, VBS, dSBlocks);
     if (nchunks > 0) hipLaunchKernelGGL((k_make_blocks<BbChunk>), dim3(nblk2(nchunks, 256)), dim3(256), 0, ctx->stream, dFirstChunk, nchr, nchunks, BB_CHUNK, dBChunks);
