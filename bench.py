@@ -105,7 +105,9 @@ def main():
         import ctypes as C
         if not record and not args.staged and not args.stage_times:
             # the whole path in ONE library call (canvas_sample_pipeline): same stages, no host-language overhead between them
-            r = cv.sample_pipeline(bases, masks, hits, lens, is_auto, out, cov_buf, state_buf, seg_buf, counts_per_bin=100, bin_size=-1, mode=3, flags=flags)
+            r = cv.sample_pipeline(bases, masks, hits, lens, is_auto, out, cov_buf, state_buf, seg_buf, counts_per_bin=100, bin_size=-1, mode=3, flags=flags,
+                                   prepared=keep.get("prepared"))
+            keep["prepared"] = r["prepared"]          # the marshalled pointer tables of the (unchanged) input arrays
             if world > 1:
                 gather_send[0] = int(r["nseg"]); gather_send[1] = int(r["n_out"]); gather_send[2] = int(r["total"]); gather_send[3] = rank
                 cnt = np.zeros(world, np.int32)
