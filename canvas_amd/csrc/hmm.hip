@@ -17,6 +17,7 @@
 //   device  k_seg_flags / k_seg_ids   break points + inter-bin-distance rule -> running segment id (prefix sum)
 #include "common.hpp"
 #include "select.hpp"
+#include <mutex>
 #include <cmath>
 #include <thread>
 #include <cstring>
@@ -1178,7 +1179,18 @@ __global__ void __launch_bounds__(256) k_iota_i32(int32_t* __restrict__ p, int64
 }
 
 // ---- host: emission tables (DistributionUtilities.cs:51-69).  GammaLn/FactorialLn (MathNet) -> lgamma; Math.Pow(x,2) := x*x.
+// lgamma(x + 1.0) for integer x does not depend on the sample: filled once per process (same call, same argument, same value)
+static const double* lgamma1_table(int n) {
+    static std::mutex mu;
+    static std::vector<double> tab(70016);
+    static int filled = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (n > (int)tab.size()) return nullptr;
+    for (; filled < n; filled++) tab[filled] = std::lgamma((double)filled + 1.0);
+    return tab.data();
+}
 static void negative_binomial_log_table(double mean, double variance, int maxValue, double* out) {
+    const double* lg1 = lgamma1_table(maxValue);
     double m = std::max(mean, 0.1);
     double r = (m * m) / (std::max(variance, mean * 1.2) - mean);
     r = std::max(2.0, r);
@@ -1186,7 +1198,7 @@ static void negative_binomial_log_table(double mean, double variance, int maxVal
     const double term0 = std::log(std::pow(1 + mean / r, -r)), lgr = std::lgamma(r), ratio = mean / (mean + r);
     for (int x = 0; x < maxValue; x++) {
         double dens = std::exp(term0 + std::log(std::pow(ratio, (double)x)) + std::lgamma(r + x) -
-                               std::lgamma((double)x + 1.0) - lgr);
+                               (lg1 ? lg1[x] : std::lgamma((double)x + 1.0)) - lgr);
         if (std::isnan(dens) || std::isinf(dens)) dens = 0;
         out[x] = std::log(dens);   // EstimateViterbiLikelihood takes Math.Log of the table value (Distributions.cs:322)
     }
