@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chr
 struct VitBlock { int32_t chrom; int32_t t0; };   // chromosome-relative start
 struct __attribute__((aligned(4))) VecI4 { int v[4]; };      // 16-byte load at 4-byte alignment (the per-lane streams start anywhere)
 struct __attribute__((aligned(8))) VecD2 { double v[2]; };
+struct __attribute__((aligned(2))) VecH8 { uint32_t w[4]; };   // eight packed 16-bit values
 
 // new delta and back-pointer of state J:  tmp_i = delta_i + (logpmf_J(x_t) + logA[i][J]),  strict '>' scan i = 0..4 from
 // Double.MinValue == first index of the maximum (evaluated as a tree, no NaNs can occur)   (HMM.cs:84-97, Distributions.cs:322)
@@ -794,7 +795,8 @@ __device__ __forceinline__ void ver_lead_step(VerState& S, const LogA25& A, cons
         const bool vp = ((S.valid >> p) & 1u) != 0;
         const double step = e[j] + la5[j];
         const bool isCur = j == sCur, fromPrev = (int)p == S.sPrev;
-        const double r = isCur ? Dt : (fromPrev ? S.Dprev + step : (vp ? dp + step : S.d[j]));
+        const double viaPrev = S.Dprev + step, viaAnc = dp + step;                 // both computed: the selects below then carry no arithmetic (no branches)
+        const double r0 = vp ? viaAnc : S.d[j], r1 = fromPrev ? viaPrev : r0, r = isCur ? Dt : r1;
         nd[j] = r; nv |= (isCur || fromPrev || vp) ? (1u << j) : 0u;
     }
 #pragma unroll
@@ -828,29 +830,31 @@ __device__ __forceinline__ void ver_phase(VerState& S, const LogA25& A, const Hm
 #pragma unroll
     for (int u = 0; u < PQ; u++) { const bool in = u < cnt; kq[u] = in ? ixp[u] : 0; sq[u] = in ? stp[u] : 0; vq[u] = in ? vp[u] : 0.0; pq[u] = in ? ppp[u] : 0u; }
     for (int j0 = 0; j0 < maxCnt; j0 += PQ) {
-        int kn[PQ], sn[PQ]; double vn[PQ]; uint32_t pn[PQ];
-        if (j0 + 2 * PQ <= cnt) {
+        int kn[PQ], sn[PQ]; double vn[PQ]; VecH8 pn;          // (the packed back-pointers are only taken apart at the end of the group: unpacking them
+        if (j0 + 2 * PQ <= cnt) {                              //  here would make the group wait for its own prefetch)
             const int o = j0 + PQ;
             const VecI4 ka = *reinterpret_cast<const VecI4*>(ixp + o), kb = *reinterpret_cast<const VecI4*>(ixp + o + 4);
             const VecI4 sa = *reinterpret_cast<const VecI4*>(stp + o), sb = *reinterpret_cast<const VecI4*>(stp + o + 4);
             const VecD2 v0 = *reinterpret_cast<const VecD2*>(vp + o), v1 = *reinterpret_cast<const VecD2*>(vp + o + 2), v2 = *reinterpret_cast<const VecD2*>(vp + o + 4),
                         v3 = *reinterpret_cast<const VecD2*>(vp + o + 6);
+            pn = *reinterpret_cast<const VecH8*>(ppp + o);
 #pragma unroll
             for (int u = 0; u < 4; u++) { kn[u] = ka.v[u]; kn[4 + u] = kb.v[u]; sn[u] = sa.v[u]; sn[4 + u] = sb.v[u]; }
             vn[0] = v0.v[0]; vn[1] = v0.v[1]; vn[2] = v1.v[0]; vn[3] = v1.v[1]; vn[4] = v2.v[0]; vn[5] = v2.v[1]; vn[6] = v3.v[0]; vn[7] = v3.v[1];
-#pragma unroll
-            for (int u = 0; u < PQ; u++) pn[u] = ppp[o + u];
         } else {
 #pragma unroll
-            for (int u = 0; u < PQ; u++) { const bool in = j0 + PQ + u < cnt; kn[u] = in ? ixp[j0 + PQ + u] : 0; sn[u] = in ? stp[j0 + PQ + u] : 0; vn[u] = in ? vp[j0 + PQ + u] : 0.0; pn[u] = in ? ppp[j0 + PQ + u] : 0u; }
+            for (int u = 0; u < PQ; u++) { const bool in = j0 + PQ + u < cnt; kn[u] = in ? ixp[j0 + PQ + u] : 0; sn[u] = in ? stp[j0 + PQ + u] : 0; vn[u] = in ? vp[j0 + PQ + u] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) pn.w[u] = (uint32_t)(j0 + PQ + 2 * u < cnt ? ppp[j0 + PQ + 2 * u] : (uint16_t)0) | ((uint32_t)(j0 + PQ + 2 * u + 1 < cnt ? ppp[j0 + PQ + 2 * u + 1] : (uint16_t)0) << 16);
         }
 #pragma unroll
         for (int u = 0; u < PQ; u++) {
             if (LEAD) ver_lead_step<useLds>(S, A, sTab, logPmf, P.tableLen, j0 + u < cnt, kq[u], sq[u], vq[u], pq[u]);
             else ver_block_step<useLds>(S, P, sTab, logPmf, j0 + u < cnt, kq[u], sq[u], vq[u], pq[u]);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < PQ; u++) { kq[u] = kn[u]; sq[u] = sn[u]; vq[u] = vn[u]; pq[u] = pn[u]; }
+        for (int u = 0; u < PQ; u++) { kq[u] = kn[u]; sq[u] = sn[u]; vq[u] = vn[u]; pq[u] = (pn.w[u >> 1] >> (16 * (u & 1))) & 0xFFFFu; }
     }
 }
 template <bool useLds>
