@@ -75,6 +75,31 @@ __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys,
 #pragma unroll
     for (int r = 0; r < SEL_TILE / 256; r++) { const int64_t i = T.begin + threadIdx.x + (int64_t)r * 256; kreg[r] = i < T.end ? keys[i] : (K)0; }
     bool agg = true;                                      // wave-uniform: is ballot aggregation paying off in this tile?
+    if (nu == 1) {
+        // one histogram row for the whole tile (every first pass, every single-query select): prefix and row index in registers, no LDS
+        // reads and no loop over rows inside the key loop
+        const int q = suniq[0];
+        const unsigned long long pre = lpre[q];
+#pragma unroll
+        for (int r = 0; r < SEL_TILE / 256; r++) {
+            const bool in = T.begin + threadIdx.x + (int64_t)r * 256 < T.end;
+            const K key = kreg[r];
+            const uint32_t d = (uint32_t)(key >> shift) & 255u;
+            const bool m = in && (firstPass || (unsigned long long)(key >> sh2) == pre);
+            if (agg) {
+                unsigned long long todo = __ballot(m);
+                for (int it = 0; it < 4 && todo; it++) {
+                    const int leader = __builtin_ctzll(todo);
+                    const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+                    const unsigned long long same = __ballot(m && d == dl) & todo;
+                    if (lane == leader) atomicAdd(&lh[q * 256 + dl], (uint32_t)__builtin_popcountll(same));
+                    todo &= ~same;
+                }
+                if ((todo >> lane) & 1ull) atomicAdd(&lh[q * 256 + d], 1u);
+                if (__builtin_popcountll(todo) > 24) agg = false;
+            } else if (m) atomicAdd(&lh[q * 256 + d], 1u);
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < SEL_TILE / 256; r++) {
         const bool in = T.begin + threadIdx.x + (int64_t)r * 256 < T.end;
