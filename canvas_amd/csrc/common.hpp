@@ -26,6 +26,7 @@ struct canvas_ctx {
     double* side_pin = nullptr;        // 65536 results + 65544 int64 run starts
     // persistent scratch of the radix select (select.hpp): device blob and pinned staging blob
     void* sel_ws = nullptr; size_t sel_ws_bytes = 0;
+    void* sel_hist = nullptr; size_t sel_hist_bytes = 0;   // replicated histograms: all zero between calls (k_select_pick clears what it reads)
     void* sel_pin = nullptr; size_t sel_pin_bytes = 0;
     // small pinned staging area for host->device parameter tables (async copies from pinned memory need no synchronisation
     // to protect the source); bump-allocated, wrapped with a synchronisation when full

@@ -26,6 +26,7 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->misc_pin) (void)hipHostFree(ctx->misc_pin);
     if (ctx->sel_ws) (void)hipFree(ctx->sel_ws);
+    if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
     if (ctx->sel_pin) (void)hipHostFree(ctx->sel_pin);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

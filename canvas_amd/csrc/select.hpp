@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys,
 
 // one wave per query: locate the digit holding rank k, narrow (prefix, k), clear the histogram row
 static __global__ void __launch_bounds__(64) k_select_pick(uint32_t* __restrict__ hist, unsigned long long* __restrict__ qprefix,
-                                                    unsigned long long* __restrict__ qk, int nq) {
+                                                    unsigned long long* __restrict__ qk, int nq, int firstPass) {
     const int q = blockIdx.x;
     if (q >= nq) return;
     const int l = threadIdx.x;
@@ -155,7 +155,7 @@ static __global__ void __launch_bounds__(64) k_select_pick(uint32_t* __restrict_
         else if (r < c0 + c1) { d = 1; r -= c0; }
         else if (r < c0 + c1 + c2) { d = 2; r -= c0 + c1; }
         else { d = 3; r -= c0 + c1 + c2; }
-        qprefix[q] = (qprefix[q] << 8) | (unsigned long long)(4 * l + d);
+        qprefix[q] = ((firstPass ? 0ull : qprefix[q]) << 8) | (unsigned long long)(4 * l + d);   // (the prefix array is not cleared between calls)
         qk[q] = r;
     }
 }
@@ -224,13 +224,20 @@ static int32_t radix_select(canvas_ctx* ctx, const K* d_keys, int nseg, const st
         }
     if (tiles.empty()) return CANVAS_OK;
     // persistent scratch of the context: one pinned blob [tiles | segq | ranks | results] <-> one device blob [tiles | segq | ranks | prefix | hist]
-    // (one H2D copy, one memset, one D2H copy per call; every call ends with a synchronisation, so the blobs are reused from offset 0)
+    // (one H2D copy and one D2H copy per call; every call ends with a synchronisation, so the blobs are reused from offset 0)
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t oTiles = 0, oSegq = al(tiles.size() * sizeof(SelTile)), oK = oSegq + al(segq.size() * sizeof(SelSegQ)), oPrefix = oK + al((size_t)nq * 8),
-                 oHist = oPrefix + al((size_t)nq * 8), devBytes = oHist + (size_t)nq * 1024 * SEL_REP, pinBytes = oPrefix + al((size_t)nq * 8);
+                 devBytes = oPrefix + al((size_t)nq * 8), histBytes = (size_t)nq * 1024 * SEL_REP, pinBytes = oPrefix + al((size_t)nq * 8);
     if (devBytes > ctx->sel_ws_bytes) {
         if (ctx->sel_ws) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->sel_ws)); ctx->sel_ws = nullptr; ctx->sel_ws_bytes = 0; }
         CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->sel_ws, devBytes * 2)); ctx->sel_ws_bytes = devBytes * 2;
+    }
+    if (histBytes > ctx->sel_hist_bytes) {
+        // the histograms live in their own buffer and are zero at the start of every call: cleared here once, and k_select_pick clears every
+        // row it has read (all replicas, after the last pass too), so there is no per-call memset
+        if (ctx->sel_hist) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->sel_hist)); ctx->sel_hist = nullptr; ctx->sel_hist_bytes = 0; }
+        CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->sel_hist, histBytes * 2)); ctx->sel_hist_bytes = histBytes * 2;
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->sel_hist, 0, ctx->sel_hist_bytes, ctx->stream));
     }
     if (pinBytes > ctx->sel_pin_bytes) {
         if (ctx->sel_pin) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipHostFree(ctx->sel_pin)); ctx->sel_pin = nullptr; ctx->sel_pin_bytes = 0; }
@@ -239,18 +246,17 @@ static int32_t radix_select(canvas_ctx* ctx, const K* d_keys, int nseg, const st
     char* d = (char*)ctx->sel_ws; char* h = (char*)ctx->sel_pin;
     SelTile* dTiles = (SelTile*)(d + oTiles); SelSegQ* dSegq = (SelSegQ*)(d + oSegq);
     unsigned long long* dK = (unsigned long long*)(d + oK); unsigned long long* dPrefix = (unsigned long long*)(d + oPrefix);
-    uint32_t* dHist = (uint32_t*)(d + oHist);
+    uint32_t* dHist = (uint32_t*)ctx->sel_hist;
     memcpy(h + oTiles, tiles.data(), tiles.size() * sizeof(SelTile));
     memcpy(h + oSegq, segq.data(), segq.size() * sizeof(SelSegQ));
     unsigned long long* hk = (unsigned long long*)(h + oK);
     for (int q = 0; q < nq; q++) hk[q] = (unsigned long long)queries[q].k;
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d, h, oPrefix, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(d + oPrefix, 0, devBytes - oPrefix, ctx->stream));
     const int bits = (int)sizeof(K) * 8;
     for (int shift = bits - 8; shift >= 0; shift -= 8) {
         hipLaunchKernelGGL((k_select_hist<K>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, d_keys, dTiles, dSegq, dPrefix, shift,
                            shift == bits - 8 ? 1 : 0, dHist, nq);
-        hipLaunchKernelGGL(k_select_pick, dim3(nq), dim3(64), 0, ctx->stream, dHist, dPrefix, dK, nq);
+        hipLaunchKernelGGL(k_select_pick, dim3(nq), dim3(64), 0, ctx->stream, dHist, dPrefix, dK, nq, shift == bits - 8 ? 1 : 0);
     }
     if (d_results) {        // the consumer is a kernel: results stay on the device, no synchronisation.  The caller must synchronise the stream
         *d_results = dPrefix;   // before the next radix_select (the pinned staging blob is reused from offset 0)
