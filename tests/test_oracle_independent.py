@@ -1,0 +1,325 @@
+"""Second, independent restatements of the stages the reference's own tests do not pin (BinCountsForChromosome, the bin
+size, PerSampleHMM / Viterbi), written directly from the C# as plain Python loops and compared with the C++ oracle on seeded inputs.
+They share no code with oracle/*.cpp: an error in reading the C# would have to be made twice, in two languages, to go unnoticed.
+CPU only; small sizes (pure-Python loops)."""
+import math
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# CanvasBin.BinCountsForChromosome, CanvasBin.cs:568-661, without predefined bins; modes Binary (0) and TruncatedDynamicRange (3)
+def py_bin_counts_for_chromosome(bases, possible, observed, bin_size, mode):
+    bins = []
+    pos = 0
+    while bases[pos] == ord("n"):                                  # :581-582 (an all-'n' sequence throws in the reference)
+        pos += 1
+    nucleotides = gc = poss = obs = 0
+    start = -1
+    seen = []
+    while pos < len(bases):
+        if start == -1:
+            start = pos
+        nucleotides += 1                                            # :592 compares a char with the string "n": never equal, every base counts
+        if chr(bases[pos]) in "CcGg":
+            gc += 1
+        if possible[pos]:
+            poss += 1
+            obs += int(observed[pos])
+            seen.append(int(observed[pos]))
+        if poss == bin_size:
+            if mode == 3:
+                obs = sum(min(10, v) for v in seen)
+            gc_pct = int(np.float32(100.0) * np.float32(gc) / np.float32(nucleotides))     # (int)(100f * GCCount / NucleotideCount)
+            bins.append((start, pos + 1, gc_pct, obs))
+            nucleotides = gc = poss = obs = 0
+            start = -1
+            seen = []
+        pos += 1
+    return bins
+
+
+def _random_chromosome(rng, L):
+    bases = rng.choice(np.frombuffer(b"ACGTacgtnN", np.uint8), size=L, p=[.2, .2, .2, .2, .04, .04, .04, .04, .03, .01]).astype(np.uint8)
+    lead = int(rng.randint(0, 40)) if rng.rand() < 0.5 else 0
+    bases[:lead] = ord("n")
+    if (bases == ord("n")).all():                                 # the reference throws on an all-'n' sequence
+        bases[-1] = ord("A")
+    possible = (rng.rand(L) < rng.uniform(0.2, 0.95))
+    observed = np.where(possible, rng.poisson(rng.uniform(0.2, 6.0), L), 0).clip(0, 255).astype(np.uint8)
+    if rng.rand() < 0.3:
+        observed[rng.randint(0, L, size=3)] = 255
+        observed[~possible] = 0
+    return bases, possible, observed
+
+
+def _pack_mask(possible):
+    L = len(possible)
+    padded = np.zeros((L + 63) // 64 * 64, np.uint8)
+    padded[:L] = possible
+    return np.packbits(padded, bitorder="little").view(np.uint64)
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+def test_bin_counts_for_chromosome_two_restatements(mode):
+    rng = np.random.RandomState(1234 + mode)
+    for it in range(150):
+        L = int(rng.randint(1, 700))
+        bases, possible, observed = _random_chromosome(rng, L)
+        bin_size = int(rng.randint(1, 60))
+        want = py_bin_counts_for_chromosome(bases, possible, observed, bin_size, mode)
+        got = O.bin_chromosome(bases, _pack_mask(possible), observed, bin_size, mode)
+        got = list(zip(*[g.tolist() for g in got]))
+        assert got == want, (it, L, bin_size)
+
+
+# SampleHitArrays.GetRates / GetBinSize (CanvasBin.cs:30-83), HitArray.CountSetBits (HitArray.cs:24-32), Utilities.Median (Utilities.cs:340-344)
+def py_bin_size(possible_by_chr, observed_by_chr, counts_per_bin):
+    rates = []
+    for p, o in zip(possible_by_chr, observed_by_chr):
+        rates.append(sum(1 for v in o if v > 0) / float(sum(1 for b in p if b)))
+    s = sorted(rates)
+    n = len(s)
+    median = s[n // 2] if n % 2 else (s[n // 2 - 1] + s[n // 2]) / 2
+    return int(counts_per_bin / median)
+
+
+def test_bin_size_two_restatements():
+    rng = np.random.RandomState(99)
+    for it in range(60):
+        nchr = int(rng.randint(1, 7))
+        chroms = [_random_chromosome(rng, int(rng.randint(50, 900))) for _ in range(nchr)]
+        cpb = int(rng.randint(1, 300))
+        want = py_bin_size([c[1] for c in chroms], [c[2] for c in chroms], cpb)
+        rates = [O.bin_rate(c[2], _pack_mask(c[1])) for c in chroms]
+        assert O.bin_size(rates, cpb) == want, it
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# PerSampleHMM for one sample: HiddenMarkovModelsRunner.cs:23-162, HMM.cs:24-130, Distributions.cs:22-78,255-316,
+# DistributionUtilities.cs:51-69, Utilities.Quartiles (Utilities.cs:361-420)
+def _to_int32(v):                                                   # Convert.ToInt32(double): round half to even
+    return int(np.rint(v))
+
+
+def py_quartiles(values):
+    s = np.sort(np.asarray(values, np.float32))
+    n = len(s)
+    mid = n // 2
+    f = np.float32
+    if n % 2 == 0:
+        q2 = (s[mid - 1] + s[mid]) / f(2)
+        mm = mid // 2
+        if mid % 2 == 0:
+            q1 = (s[mm - 1] + s[mm]) / f(2)
+            q3 = (s[mid + mm - 1] + s[mid + mm]) / f(2)
+        else:
+            q1 = s[mm]
+            q3 = s[mm + mid]
+    else:
+        q2 = s[mid]
+        q1 = q3 = f(0)
+        if (n - 1) % 4 == 0:
+            k = (n - 1) // 4
+            q1 = s[k - 1] * f(.25) + s[k] * f(.75)
+            q3 = s[3 * k] * f(.75) + s[3 * k + 1] * f(.25)
+        elif (n - 3) % 4 == 0:
+            k = (n - 3) // 4
+            q1 = s[k] * f(.75) + s[k + 1] * f(.25)
+            q3 = s[3 * k + 1] * f(.25) + s[3 * k + 2] * f(.75)
+    return f(q1), f(q2), f(q3)
+
+
+def py_negative_binomial(mean, variance, max_value):
+    def log(v):
+        return math.log(v) if v > 0 else -math.inf
+    r = max(max(mean, 0.1) ** 2 / (max(variance, mean * 1.2) - mean), 2.0)
+    out = []
+    for x in range(max_value):
+        try:
+            head = (1 + mean / r) ** (-r)
+        except OverflowError:
+            head = math.inf
+        t = log(head) + log((mean / (mean + r)) ** x) + math.lgamma(r + x) - math.lgamma(x + 1.0) - math.lgamma(r)
+        try:
+            d = math.exp(t)
+        except OverflowError:
+            d = math.inf
+        out.append(0.0 if (math.isnan(d) or math.isinf(d)) else d)
+    return out
+
+
+def py_hmm_per_sample(chromosomes, n_states=5, min_size=10):
+    all_values = np.concatenate([np.asarray(c, np.float64).astype(np.float32) for c in chromosomes])
+    q1, q2, q3 = py_quartiles(all_values)
+    iqr = np.float32(q3 - q1)
+    median, pseudo_variance = float(q2), float(np.float32(iqr * iqr))
+    log = lambda v: math.log(v) if v > 0 else -math.inf
+    trans = [[0.99 if i == j else (1.0 - 0.99) / (n_states - 1) for j in range(n_states)] for i in range(n_states)]
+    prior = float(np.float32(1.0) / np.float32(n_states))
+    paths = []
+    for cov in chromosomes:
+        T = len(cov)
+        if T <= min_size:
+            paths.append(None)
+            continue
+        haploid = median / 2.0
+        cap = haploid * n_states
+        data = [cap if v > cap else v for v in cov]
+        max_value = max(_to_int32(v) for v in data)
+        tables = [py_negative_binomial(max(cn, 0.1) * haploid, pseudo_variance, max_value + 10) for cn in range(n_states)]
+
+        def viterbi_likelihood(x, j, row):                          # one sample: the only genotype list is [j]
+            return log(tables[j][_to_int32(x)]) + log(trans[row][j])
+        score = [log(prior) + viterbi_likelihood(data[0], j, 0) - log(trans[0][j]) for j in range(n_states)]
+        back = []
+        for t in range(1, T):
+            new, frm = [], []
+            for j in range(n_states):
+                state, best = 0, -sys.float_info.max
+                for i in range(n_states):
+                    cand = score[i] + viterbi_likelihood(data[t], j, i)
+                    if cand > best:
+                        state, best = i, cand
+                new.append(best)
+                frm.append(state)
+            score = new
+            back.append(frm)
+        state, best = -1, -sys.float_info.max
+        for i in range(n_states):
+            if score[i] > best:
+                state, best = i, score[i]
+        path = [state]
+        for frm in reversed(back):
+            state = frm[state]
+            path.append(state)
+        paths.append(path[::-1])
+    return paths, median, pseudo_variance
+
+
+def _random_coverage(rng, T, depth):
+    cn = np.full(T, 2)
+    for _ in range(int(rng.randint(0, 4))):
+        a = int(rng.randint(0, T)); b = min(T, a + int(rng.randint(1, max(2, T // 3))))
+        cn[a:b] = rng.choice([0, 1, 3, 4, 6])
+    lam = np.maximum(cn, 0.02) * depth / 2.0
+    shape = rng.uniform(3, 40)
+    v = rng.poisson(rng.gamma(shape, lam / shape)).astype(np.float64)
+    v += rng.randint(0, 100, T) / 100.0                            # two decimals, as parsed from the F2 text of the cleaned file
+    if rng.rand() < 0.3:
+        v[rng.randint(0, T, 2)] *= 7                                # outliers beyond the cap
+    return np.round(v, 2)
+
+
+def test_per_sample_hmm_two_restatements():
+    rng = np.random.RandomState(4321)
+    segmented = with_events = 0
+    for it in range(25):
+        depth = float(rng.choice([8, 30, 70, 150]))
+        chroms = [_random_coverage(rng, int(rng.choice([4, 10, 11, 37, 120, 300])), depth) for _ in range(int(rng.randint(1, 5)))]
+        if sum(len(c) for c in chroms) < 8:
+            continue
+        want, median, pv = py_hmm_per_sample(chroms)
+        med, var = O.hmm_global_params(chroms)
+        assert (med, var) == (median, pv), it
+        paths, ran = O.hmm_genome_per_sample(chroms, threads=1)
+        for c, w in enumerate(want):
+            if w is None:
+                assert ran[c] == 0, (it, c)
+            else:
+                assert ran[c] == 1 and paths[c].tolist() == w, (it, c)
+                segmented += 1
+                with_events += len(set(w)) > 1
+    assert segmented > 20 and with_events > 10
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# CanvasClean with -s -r -g (MedianByGC): CanvasClean.cs:328-352 (RemoveBigBins), :363-412 (SignificantlyDifferent, RemoveOutliers),
+# :207-239 (RemoveBinsWithExtremeGC), :163-199 (NormalizeByGC), EnrichmentUtilities.cs:65-86 (GetCountsByGC), Utilities.cs:470-474 (Median)
+def _significantly_different(a, b):
+    mu = (float(a) + float(b)) / 2
+    if np.float32(a) + np.float32(b) == 0:
+        return False
+    da, db = float(a) - mu, float(b) - mu
+    return (da * da + db * db) / mu > 6.635
+
+
+def _median_f32(values):
+    s = np.sort(np.asarray(values, np.float32))
+    n = len(s)
+    return float(s[n // 2]) if n % 2 else float((s[n // 2 - 1] + s[n // 2]) / np.float32(2))
+
+
+def py_clean(bins, is_autosome):
+    """bins: list of [chr, start, stop, count(float32), gc]"""
+    sizes = sorted(b[2] - b[1] for b in bins)                      # RemoveBigBins
+    index = int(0.98 * float(len(bins)))
+    if index < len(sizes):
+        bins = [b for b in bins if b[2] - b[1] <= sizes[index]]
+    kept = []                                                      # RemoveOutliers
+    for i, b in enumerate(bins):
+        prev = bins[i - 1] if i > 0 else None
+        nxt = bins[i + 1] if i < len(bins) - 1 else None
+        if prev is not None and prev[0] != b[0] and nxt is not None and nxt[0] != b[0]:
+            continue
+        if (prev is not None and prev[0] == b[0] and not _significantly_different(b[3], prev[3])) \
+                or (nxt is not None and nxt[0] == b[0] and not _significantly_different(b[3], nxt[3])) or (prev is None and nxt is None):
+            kept.append(b)
+    bins = kept
+    per_gc = [0] * 101                                             # RemoveBinsWithExtremeGC(bins, 100)
+    total = 0.0
+    for b in bins:
+        if is_autosome[b[0]]:
+            per_gc[b[4]] += 1
+            total += 1
+    threshold = min(100, max(100, int(total / 101)))
+    stripped = [b for b in bins if per_gc[b[4]] >= threshold]
+    if not stripped:
+        return bins
+    bins = [list(b) for b in stripped]
+    by_gc = [[] for _ in range(101)]                               # NormalizeByGC
+    autosomal = []
+    for b in bins:
+        if is_autosome[b[0]]:
+            by_gc[b[4]].append(b[3])
+            autosomal.append(b[3])
+    global_median = _median_f32(autosomal)
+    medians = [_median_f32(v) if len(v) >= 100 else None for v in by_gc]      # fewer than 100: weighted median, never looked up after the strip
+    for b in bins:
+        m = medians[b[4]]
+        if m is not None and m > 0:
+            b[3] = np.float32(global_median * float(b[3]) / m)
+    return bins
+
+
+def test_clean_median_by_gc_two_restatements():
+    from canvas_amd import CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS
+    rng = np.random.RandomState(777)
+    normalised = dropped = 0
+    for it in range(6):
+        nchr = int(rng.randint(2, 6))
+        is_auto = np.ones(nchr, np.uint8); is_auto[-1] = 0
+        bins = []
+        for c in range(nchr):
+            n = int(rng.randint(1, 1500))
+            pos = 0
+            for _ in range(n):
+                size = int(rng.choice([100, 101, 105, 140, 400], p=[.5, .3, .15, .04, .01]))
+                gc = int(np.clip(rng.normal(45, 4 if it % 2 else 9), 0, 100))
+                lam = 80.0 * (1 + (gc - 45) * 0.012) * (1 if c else 1.5)
+                cnt = np.float32(rng.poisson(max(lam, 0.0)) if rng.rand() > 0.02 else rng.choice([0, 0, 400]))
+                bins.append([c, pos, pos + size, cnt, gc])
+                pos += size + int(rng.randint(0, 50))
+        want = py_clean(bins, is_auto)
+        a = [np.array([b[k] for b in bins]) for k in range(5)]
+        got = O.clean(a[0], a[1], a[2], a[3], a[4], is_auto, np.zeros(nchr, np.uint8), CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS)
+        assert len(got["chr"]) == len(want), it
+        dropped += len(bins) - len(want)
+        normalised += sum(1 for b in want if float(b[3]) != float(int(b[3])))
+        assert got["chr"].tolist() == [b[0] for b in want] and got["start"].tolist() == [b[1] for b in want]
+        assert (got["count"].view(np.uint32) == np.array([b[3] for b in want], np.float32).view(np.uint32)).all(), it
+    assert normalised > 1000 and dropped > 100                     # the cases did reach the normalisation and the filters
