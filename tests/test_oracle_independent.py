@@ -323,3 +323,58 @@ def test_clean_median_by_gc_two_restatements():
         assert got["chr"].tolist() == [b[0] for b in want] and got["start"].tolist() == [b[1] for b in want]
         assert (got["count"].view(np.uint32) == np.array([b[3] for b in want], np.float32).view(np.uint32)).all(), it
     assert normalised > 1000 and dropped > 100                     # the cases did reach the normalisation and the filters
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# CBS statistics: the block-pruned searches of CBSTStatistic.cs (TMaxO :19-343, HTMaxP :354-590, TMaxP :599-930) against a search over
+# every arc.  What the three compute, read from the C#: the maximum over circular arcs of n / (len (n - len)) * (arc sum)^2, arc lengths
+# al0..n-al0 (HTMaxP: al0..k), TMaxO / TMaxP seeded with the arc between the global maximum and minimum of the partial sums whatever its
+# length (:686-700), then scaled by the residual variance.  Arc and complement are the same arc mathematically but not in rounding, hence
+# the 1e-11 relative tolerance; bit-level agreement between oracle and device is what tests/test_cbs_gpu.py and tools/soak_cbs.py check.
+def _max_min_seed(px):
+    n = len(px)
+    hi = lo = acc = 0.0
+    at_hi = at_lo = n
+    for i in range(n):
+        acc += px[i]
+        if acc < lo:
+            lo, at_lo = acc, i + 1
+        if acc > hi:
+            hi, at_hi = acc, i + 1
+    rj = abs(at_hi - at_lo)
+    return n / (rj * (float(n) - rj)) * (hi - lo) ** 2
+
+
+def _every_arc_statistic(px, tss, longest, al0, seeded):
+    n = len(px)
+    sums = np.concatenate([[0.0], np.cumsum(np.concatenate([px, px]))])
+    best = _max_min_seed(px) if seeded else 0.0
+    for length in range(al0, longest + 1):
+        arc = np.abs(sums[length:length + n] - sums[:n]).max()
+        best = max(best, n / (length * (float(n) - length)) * arc ** 2)
+    if tss <= best + 0.0001:
+        tss = best + 1.0
+    return best / ((tss - best) / (n - 2.0))
+
+
+def test_cbs_statistics_against_every_arc():
+    rng = np.random.RandomState(7)
+    for it in range(250):
+        n = int(rng.randint(5, 450))
+        x = rng.normal(0, 1, n)
+        if rng.rand() < 0.5:
+            a = int(rng.randint(0, n)); x[a:a + int(rng.randint(1, 60))] += rng.normal(0, 3)
+        if rng.rand() < 0.3:
+            x = np.round(x, 1)                                       # exact ties
+        x -= x.mean()
+        tss = float(np.sum(x * x))
+        if tss == 0:
+            continue
+        want = _every_arc_statistic(x, tss, n - 2, 2, True)
+        ostat, iseg, _ = O.tmaxo(x, 2)
+        assert abs(ostat - want) <= 1e-11 * max(1.0, want), (it, n)
+        assert 0 <= iseg[0] < iseg[1] <= n
+        assert abs(O.tmaxp(x, tss, 2) - want) <= 1e-11 * max(1.0, want), (it, n)
+        if n >= 60:
+            k = int(rng.choice([10, 25, 40]))
+            assert abs(O.htmaxp(x, tss, k, 2) - _every_arc_statistic(x, tss, k, 2, False)) <= 1e-11 * max(1.0, want), (it, n, k)
