@@ -378,3 +378,51 @@ def test_cbs_statistics_against_every_arc():
         if n >= 60:
             k = int(rng.choice([10, 25, 40]))
             assert abs(O.htmaxp(x, tss, k, 2) - _every_arc_statistic(x, tss, k, 2, False)) <= 1e-11 * max(1.0, want), (it, n, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# CanvasNormalize: WeightedAverageReferenceGenerator.cs:38-68, BinCounts.cs:30-62, LSNormRatioCalculator.cs:20-47,
+# CanvasNormalizeUtilities.cs:23-33
+def _median_f64(values):
+    s = sorted(float(v) for v in values)
+    n = len(s)
+    return s[n // 2] if n % 2 else (s[n // 2 - 1] + s[n // 2]) / 2
+
+
+def test_normalize_two_restatements():
+    rng = np.random.RandomState(31)
+    for it in range(20):
+        n = int(rng.randint(1, 400))
+        on = None if it % 3 else np.sort(rng.choice(n, size=max(1, n // 3), replace=False)).astype(np.int32)
+        controls = [np.round(rng.gamma(4, 20 * (s + 1), n), int(rng.randint(0, 4))) * (rng.rand(n) > 0.1) for s in range(int(rng.randint(2, 5)))]
+        weights = []
+        for c in controls:
+            m = _median_f64(c if on is None else [c[i] for i in on])
+            weights.append(1.0 / m if m > 0 else 0.0)
+        total = sum(weights)
+        weights = [w / total for w in weights]
+        reference = []
+        for j in range(n):
+            acc = 0.0
+            for w, c in zip(weights, controls):
+                acc += w * float(c[j])
+            reference.append(acc)
+        got_ref, got_w = O.norm_weighted_reference(controls, on)
+        assert got_w.tolist() == weights and got_ref.tolist() == reference, it
+        sample = np.round(rng.gamma(4, 25, n), 2).astype(np.float32)
+        ref32 = np.asarray(reference, np.float32)                      # the reference file is read back as float counts
+        ploidy = rng.choice([1, 2, 2, 2, 3], n).astype(np.int32) if it % 2 else None
+        sm = _median_f64(sample if on is None else [sample[i] for i in on])
+        rm = _median_f64(ref32 if on is None else [ref32[i] for i in on])
+        factor = rm / sm if (sm > 0 and rm > 0) else 1.0
+        keep, ratios, counts = [], [], []
+        for j in range(n):
+            if ref32[j] < 1:
+                continue
+            ratio = np.float32(float(np.float32(sample[j] / ref32[j])) * factor)
+            keep.append(j)
+            ratios.append(ratio)
+            counts.append(np.float32(float(ratio) * (40.0 * (2 if ploidy is None else int(ploidy[j])) / 2.0)))
+        k, r, c = O.norm_ratio(sample, ref32, on, mode=0, ploidy=ploidy)
+        assert k.tolist() == keep, it
+        assert (r.view(np.uint32) == np.asarray(ratios, np.float32).view(np.uint32)).all() and (c.view(np.uint32) == np.asarray(counts, np.float32).view(np.uint32)).all(), it
