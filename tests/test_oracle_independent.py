@@ -426,3 +426,117 @@ def test_normalize_two_restatements():
         k, r, c = O.norm_ratio(sample, ref32, on, mode=0, ploidy=ploidy)
         assert k.tolist() == keep, it
         assert (r.view(np.uint32) == np.asarray(ratios, np.float32).view(np.uint32)).all() and (c.view(np.uint32) == np.asarray(counts, np.float32).view(np.uint32)).all(), it
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# CanvasClean, whole-genome branches (more than 500 000 bins): Main's order of stages (CanvasClean.cs:473-528), GetLocalStandardDeviation
+# (:268-300, :243-258), NormalizeVarianceByGC (:34-97, the GC values that survive the strip all have 100+ bins, so the quartiles are the plain
+# ones), the second NormalizeByGC, RemoveBinsWithExtremeLocalSD (:308-322); Utilities.cs:199-257 (Mean / StandardDeviation), :428-462 (Median / Mad).
+# Vectorised with numpy where the C# order of the floating-point operations is kept (sequential sums run column by column).
+def _np_normalize_by_gc(count, gc, auto):
+    global_median = _median_f32(count[auto])
+    out = count.copy()
+    for g in np.unique(gc):
+        sel = auto & (gc == g)
+        if sel.sum() >= 100:
+            m = _median_f32(count[sel])
+            if m > 0:
+                rows = gc == g
+                out[rows] = (global_median * count[rows].astype(np.float64) / m).astype(np.float32)
+    return out
+
+
+def np_clean_whole_genome(chrom, start, stop, count, gc, is_autosome):
+    size = stop - start                                              # RemoveBigBins
+    keep = size <= np.sort(size)[int(0.98 * float(len(size)))]
+    chrom, start, stop, count, gc = [a[keep] for a in (chrom, start, stop, count, gc)]
+    n = len(count)                                                   # RemoveOutliers
+    c64 = count.astype(np.float64)
+
+    def different(a, b):
+        mu = (a + b) / 2
+        with np.errstate(invalid="ignore", divide="ignore"):
+            chi2 = ((a - mu) ** 2 + (b - mu) ** 2) / mu
+        return np.where(a + b == 0, False, chi2 > 6.635)
+    same_prev = np.zeros(n, bool); same_next = np.zeros(n, bool)
+    same_prev[1:] = chrom[1:] == chrom[:-1]; same_next[:-1] = chrom[:-1] == chrom[1:]
+    ok_prev = np.zeros(n, bool); ok_next = np.zeros(n, bool)
+    ok_prev[1:] = same_prev[1:] & ~different(c64[1:], c64[:-1]); ok_next[:-1] = same_next[:-1] & ~different(c64[:-1], c64[1:])
+    keep = ok_prev | ok_next
+    chrom, start, stop, count, gc = [a[keep] for a in (chrom, start, stop, count, gc)]
+    n = len(count)
+    assert n >= 50000
+    diffs = (count[1:] - count[:-1]).astype(np.float64)              # GetLocalStandardDeviation
+    nw = (len(diffs) - 1) // 20                                      # windows [20w, 20w+20) with 20w+20 < len(diffs)
+    w = diffs[: nw * 20].reshape(nw, 20)
+    total = np.zeros(nw)
+    for k in range(20):
+        total = total + w[:, k]
+    mu = total / 20
+    ss = np.zeros(nw)
+    for k in range(20):
+        d = w[:, k] - mu
+        ss = ss + d * d
+    local_sd = np.sqrt(ss / 19)
+    deviation = np.full(n, -1.0)
+    deviation[: nw * 20] = np.repeat(local_sd, 20)
+    window_chrom = chrom[np.arange(nw) * 20]
+    mads = []
+    edges = [0] + [i for i in range(1, nw) if window_chrom[i] != window_chrom[i - 1]] + [nw]
+    for a, b in zip(edges[:-1], edges[1:]):                          # the C# compares with the first window of the run: the same for sorted input
+        med = _median_f64(local_sd[a:b])
+        mads.append(_median_f64(np.abs(local_sd[a:b] - med)))
+    acc = 0.0
+    for m in mads:
+        acc += m
+    local_sd_average = acc / len(mads)
+    auto = is_autosome[chrom].astype(bool)                           # RemoveBinsWithExtremeGC
+    per_gc = np.bincount(gc[auto], minlength=101)
+    threshold = min(100, max(100, int(float(auto.sum()) / 101)))
+    keep = per_gc[gc] >= threshold
+    assert keep.any()
+    chrom, start, stop, count, gc, deviation, auto = [a[keep] for a in (chrom, start, stop, count, gc, deviation, auto)]
+    count = _np_normalize_by_gc(count, gc, auto)
+    assert len(count) > 500000
+    f = np.float32                                                   # NormalizeVarianceByGC
+    gq = py_quartiles(count[auto])
+    global_iqr = f(gq[2] - gq[0])
+    local_iqr = np.full(101, -1, np.float32); local_median = np.full(101, -1, np.float32)
+    for g in range(101):
+        v = count[auto & (gc == g)]
+        if len(v):
+            q = py_quartiles(v)
+            local_iqr[g] = f(q[2] - q[0]); local_median[g] = q[1]
+    variance_normalised = bool((global_iqr * f(2) < local_iqr[10:90]).any())
+    if variance_normalised:
+        scaled = local_iqr[gc] * f(0.8)
+        rows = ~(global_iqr >= scaled)
+        ratio = (scaled[rows] / global_iqr).astype(np.float32)
+        med = local_median[gc][rows]
+        count = count.copy()
+        count[rows] = med + (count[rows] - med) / ratio
+        count = _np_normalize_by_gc(count, gc, auto)
+    keep = ~((deviation > 20 * 2.0) & (local_sd_average > 5.0))      # RemoveBinsWithExtremeLocalSD
+    return chrom[keep], start[keep], count[keep], local_sd_average, variance_normalised, int((~keep).sum())
+
+
+def test_clean_whole_genome_branches_two_restatements():
+    from canvas_amd import CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD
+    rng = np.random.RandomState(2024)
+    per_chr = [270_000, 240_000, 160_000, 50_000]
+    is_auto = np.array([1, 1, 1, 0], np.uint8)
+    n = sum(per_chr)
+    chrom = np.repeat(np.arange(4), per_chr).astype(np.int32)
+    size = rng.choice([100, 101, 105, 140, 400], n, p=[.5, .3, .15, .04, .01]).astype(np.int32)
+    start = np.concatenate([np.cumsum(np.r_[0, s[:-1] + 7]) for s in np.split(size, np.cumsum(per_chr)[:-1])]).astype(np.int32)
+    gc = np.clip(rng.normal(45, 6, n), 0, 100).astype(np.int32)
+    mean = 90.0 * (1 + (gc - 45) * 0.01)
+    spread = np.where((gc >= 30) & (gc <= 36), 4.0, 1.0)              # GC values whose spread is far beyond the genome's: variance normalisation runs
+    noise = np.repeat(rng.choice([1.0, 5.0], n // 1500 + 1), 1500)[:n]  # FFPE-like: the local SD wanders, part of it beyond the filter's threshold
+    count = np.rint(np.maximum(rng.normal(mean, np.sqrt(mean) * spread * noise), 0)).astype(np.float32)
+    want = np_clean_whole_genome(chrom, start, start + size, count, gc, is_auto)
+    assert want[4] and want[5] > 1000 and want[3] > 5.0               # both branches taken
+    got = O.clean(chrom, start, start + size, count, gc, is_auto, np.zeros(4, np.uint8), CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD)
+    assert got["local_sd"] == want[3]
+    assert len(got["chr"]) == len(want[0]) and (got["chr"] == want[0]).all() and (got["start"] == want[1]).all()
+    assert (got["count"].view(np.uint32) == want[2].view(np.uint32)).all()
