@@ -540,3 +540,122 @@ def test_clean_whole_genome_branches_two_restatements():
     assert got["local_sd"] == want[3]
     assert len(got["chr"]) == len(want[0]) and (got["chr"] == want[0]).all() and (got["start"] == want[1]).all()
     assert (got["count"].view(np.uint32) == want[2].view(np.uint32)).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Joint HMM over several samples of a pedigree (isPerSample = false): HiddenMarkovModelsRunner.cs:74-152 (per-chromosome median and variance,
+# RemoveOutliers, NB tables), Distributions.cs:255-316 (the best genotype combination per copy-number state and what the transition is charged
+# on), DistributionUtilities.cs:11-40 (GetGenotypeCombinations; distinct permutations in lexicographic order, Combinatorics/Permutations.cs),
+# Utilities.cs:290-302 (Variance), HMM.cs:60-128
+def py_genotype_combinations(n_samples, state):
+    import itertools
+    n_samples = min(n_samples, 4)
+    if state == 2:
+        return [[2] * n_samples]
+    combos = []
+    for n_diploid in range(n_samples):
+        combos += [list(p) for p in sorted(set(itertools.permutations([state] * (n_samples - n_diploid) + [2] * n_diploid)))]
+    return combos or [[state]]
+
+
+def py_hmm_joint_chromosome(samples, n_states=5, min_size=10):
+    S, T = len(samples), len(samples[0])
+    if T <= min_size:
+        return None
+    log = lambda v: math.log(v) if v > 0 else -math.inf
+    haploid, variance = [], []
+    for s in range(S):
+        col = [float(v) for v in samples[s]]
+        haploid.append(max(1.0, _median_f64(col)) / 2.0)
+        acc = 0.0
+        for v in col:
+            acc += v
+        mu = acc / T
+        ss = 0.0
+        for v in col:
+            ss += (v - mu) * (v - mu)
+        variance.append(ss / (T - 1))
+    cap = max(haploid) * n_states
+    data = [[cap if samples[s][t] > cap else float(samples[s][t]) for s in range(S)] for t in range(T)]
+    max_value = max(_to_int32(max(row)) for row in data)
+    tables = [[py_negative_binomial(max(cn, 0.1) * haploid[s], variance[s], max_value + 10) for s in range(S)] for cn in range(n_states)]
+    combos = [py_genotype_combinations(S, cn) for cn in range(n_states)]
+    trans = [[0.99 if i == j else (1.0 - 0.99) / (n_states - 1) for j in range(n_states)] for i in range(n_states)]
+    prior = float(np.float32(1.0) / np.float32(n_states))
+
+    def best_combination(row_data, cn):                             # does not depend on the state we come from
+        best, best_l = [], -sys.float_info.max
+        for combo in combos[cn]:
+            e = 1.0
+            for s, g in enumerate(combo):
+                c = _to_int32(row_data[s])
+                if g in (0, 1):
+                    e *= max(tables[0][s][c], tables[1][s][c])
+                elif g in (3, 4):
+                    e *= max(tables[3][s][c], tables[4][s][c])
+                else:
+                    e *= tables[g][s][c]
+            if math.isnan(e) or math.isinf(e):
+                e = 0.0
+            if best_l < e:
+                best, best_l = combo, e
+        return best, best_l
+
+    def viterbi_likelihood(chosen, cn, row):
+        best, best_l = chosen
+        if max(trans[row]) == trans[row][2]:
+            charge = min(trans[row][g] for g in best)
+        elif cn == 2:
+            charge = trans[row][2]
+        else:
+            charge = min(trans[row][g] for g in best if g != 2)
+        return log(best_l) + log(charge)
+    chosen = [best_combination(data[0], j) for j in range(n_states)]
+    score = [log(prior) + viterbi_likelihood(chosen[j], j, 0) - log(trans[0][j]) for j in range(n_states)]
+    back = []
+    for t in range(1, T):
+        chosen = [best_combination(data[t], j) for j in range(n_states)]
+        new, frm = [], []
+        for j in range(n_states):
+            state, best = 0, -sys.float_info.max
+            for i in range(n_states):
+                cand = score[i] + viterbi_likelihood(chosen[j], j, i)
+                if cand > best:
+                    state, best = i, cand
+            new.append(best)
+            frm.append(state)
+        score = new
+        back.append(frm)
+    state, best = -1, -sys.float_info.max
+    for i in range(n_states):
+        if score[i] > best:
+            state, best = i, score[i]
+    path = [state]
+    for frm in reversed(back):
+        state = frm[state]
+        path.append(state)
+    return path[::-1]
+
+
+def test_joint_hmm_two_restatements():
+    rng = np.random.RandomState(8642)
+    segmented = with_events = 0
+    for it in range(24):
+        S = int(rng.choice([1, 2, 3, 4]))
+        T = int(rng.choice([9, 11, 40, 150, 260]))
+        depths = rng.choice([12.0, 35.0, 80.0], S)
+        samples = [_random_coverage(rng, T, float(d)) for d in depths]
+        if rng.rand() < 0.5 and T > 30:                              # an event the samples share
+            a = int(rng.randint(0, T - 10)); b = a + int(rng.randint(5, T // 2))
+            f = rng.choice([0.5, 1.5, 2.0])
+            for s in range(S):
+                samples[s][a:b] = np.round(samples[s][a:b] * f, 2)
+        want = py_hmm_joint_chromosome(samples)
+        ran, path = O.hmm_chromosome(samples, per_sample=False)
+        if want is None:
+            assert ran == 0, it
+        else:
+            assert ran == 1 and path.tolist() == want, (it, S, T)
+            segmented += 1
+            with_events += len(set(want)) > 1
+    assert segmented > 15 and with_events > 8
