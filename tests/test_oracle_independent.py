@@ -659,3 +659,78 @@ def test_joint_hmm_two_restatements():
             segmented += 1
             with_events += len(set(want)) > 1
     assert segmented > 15 and with_events > 8
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# GCContentWeighted binning (-m 5): Utilities.NonZeroMean (Utilities.cs:136-151), MeanFragmentSize (CanvasBin.cs:164-174), the read-GC profile
+# (:452-496), ComputeObservedVsExpectedGC (:330-394, no manifest), the weighted count of BinCountsForChromosome (:606-636)
+def py_gc_weighted(bases, possible, observed, fragment_lengths, bin_size):
+    def non_zero_mean(values):
+        total = count = 0
+        for v in values:
+            if v > 0:
+                total += int(v); count += 1
+        return total // count if count else 0
+    mean_fragment = non_zero_mean([non_zero_mean(f) for f in fragment_lengths])
+    read_gc = []
+    for b, fl in zip(bases, fragment_lengths):
+        is_gc = [chr(c) in "CcGg" for c in b]
+        g = [0] * len(b)
+        for pos in range(len(b) - mean_fragment * 3 - 1):
+            frag = mean_fragment if fl[pos] == 0 else min(int(fl[pos]), mean_fragment * 3)
+            g[pos] = min(100 * sum(is_gc[pos:pos + frag]) // frag, 101)
+        read_gc.append(g)
+    expected = [0] * 101; seen = [0] * 101
+    for g, o in zip(read_gc, observed):
+        for i, v in enumerate(g):
+            expected[v] += 1; seen[v] += int(o[i])
+    f = np.float32
+    sum_expected, sum_seen = sum(expected), sum(seen)
+    weights = []
+    for k in range(101):
+        e = expected[k] or 1; s = seen[k] or 1
+        weights.append((f(s) / f(e)) * (f(sum_expected) / f(sum_seen)))
+    out = []
+    for b, p, o, g in zip(bases, possible, observed, read_gc):
+        bins = []
+        pos = 0
+        while b[pos] == ord("n"):
+            pos += 1
+        nucleotides = gc = poss = 0
+        start = -1
+        acc = f(0)
+        while pos < len(b):
+            if start == -1:
+                start = pos
+            nucleotides += 1
+            gc += chr(b[pos]) in "CcGg"
+            if p[pos]:
+                poss += 1
+                acc = f(acc + min(f(10), f(f(int(o[pos])) / weights[g[pos]])))
+            if poss == bin_size:
+                bins.append((start, pos + 1, int(f(100.0) * f(gc) / f(nucleotides)), int(np.rint(float(acc)))))
+                nucleotides = gc = poss = 0
+                start = -1
+                acc = f(0)
+            pos += 1
+        out.append(bins)
+    return out, mean_fragment, weights, read_gc
+
+
+def test_gc_content_weighted_two_restatements():
+    rng = np.random.RandomState(555)
+    for it in range(12):
+        nchr = int(rng.randint(1, 4))
+        chroms = [_random_chromosome(rng, int(rng.randint(400, 1500))) for _ in range(nchr)]
+        frag = []
+        for b, p, o in chroms:
+            fl = np.where(o > 0, rng.randint(20, 140, len(b)), 0).astype(np.int16)
+            fl[rng.randint(0, len(b), 3)] = 600                        # beyond three mean fragments: capped
+            frag.append(fl)
+        bin_size = int(rng.randint(3, 50))
+        want, mean_fragment, weights, read_gc = py_gc_weighted([c[0] for c in chroms], [c[1] for c in chroms], [c[2] for c in chroms], frag, bin_size)
+        res, m, w, rgc = O.bin_gc_weighted([c[0] for c in chroms], [_pack_mask(c[1]) for c in chroms], [c[2] for c in chroms], frag, bin_size)
+        assert m == mean_fragment and (w.view(np.uint32) == np.asarray(weights, np.float32).view(np.uint32)).all(), it
+        for c in range(nchr):
+            assert rgc[c].tolist() == read_gc[c], (it, c)
+            assert list(zip(*[a.tolist() for a in res[c]])) == want[c], (it, c)
