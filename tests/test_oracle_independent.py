@@ -734,3 +734,187 @@ def test_gc_content_weighted_two_restatements():
         for c in range(nchr):
             assert rgc[c].tolist() == read_gc[c], (it, c)
             assert list(zip(*[a.tolist() for a in res[c]])) == want[c], (it, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Wavelets: WaveletSegmentation.cs:19-48 (GetInnerProdIter), :54-68 (GetInnerProdMax), :264-383 (FindBestUnbalancedHaarDecomposition),
+# :72-115 (HardThresh), :118-171 (GetUnbalHaarVector, GetReconstructedVector), :174-185 (GetSegments), :194-234 (healing), :237-258
+# (RefineSegments), :385-425 (HaarWavelets).  The reference's own known-answer test pins the non-germline flavour on one vector
+# (tests/test_oracle_golden.py); this second reading runs both flavours on many.  Germline's Array.Sort with a comparison is restated as
+# .NET Core's introsort (insertion sort up to 16 elements, median-of-three partition above; a case that would reach its heapsort is skipped).
+def _inner_products(x):
+    n = len(x)
+    plus = [0.0] * (n - 1); minus = [0.0] * (n - 1)
+    plus[0] = math.sqrt(1 - 1.0 / n) * x[0]
+    rest = 0.0
+    for v in x[1:]:
+        rest += v
+    mean = (x[0] + rest) / n
+    minus[0] = (1.0 / math.sqrt(n * (n - 1))) * rest
+    for m in range(1, n - 1):
+        factor = math.sqrt(float(n - m - 1) * m / float(m + 1) / float(n - m))
+        plus[m] = plus[m - 1] * factor + x[m] * math.sqrt(1.0 / (m + 1) - 1.0 / n)
+        minus[m] = minus[m - 1] / factor - x[m] / math.sqrt((float(n) * n / float(m + 1)) - float(n))
+    return [p - q for p, q in zip(plus, minus)], mean
+
+
+def _first_largest(ipi):
+    top = max(abs(v) for v in ipi)
+    for k, v in enumerate(ipi):
+        if abs(v) == top:
+            return k + 1
+
+
+class _NeedsHeapsort(Exception):
+    pass
+
+
+def _dotnet_sort(keys, compare):
+    def swap_if_greater(a, b):
+        if a != b and compare(keys[a], keys[b]) > 0:
+            keys[a], keys[b] = keys[b], keys[a]
+
+    def intro(lo, hi, depth):
+        while hi > lo:
+            size = hi - lo + 1
+            if size <= 16:
+                if size == 2:
+                    swap_if_greater(lo, hi)
+                elif size == 3:
+                    swap_if_greater(lo, hi - 1); swap_if_greater(lo, hi); swap_if_greater(hi - 1, hi)
+                elif size > 3:
+                    for i in range(lo, hi):
+                        j, t = i, keys[i + 1]
+                        while j >= lo and compare(t, keys[j]) < 0:
+                            keys[j + 1] = keys[j]
+                            j -= 1
+                        keys[j + 1] = t
+                return
+            if depth == 0:
+                raise _NeedsHeapsort()
+            depth -= 1
+            mid = lo + (hi - lo) // 2
+            swap_if_greater(lo, mid); swap_if_greater(lo, hi); swap_if_greater(mid, hi)
+            pivot = keys[mid]
+            keys[mid], keys[hi - 1] = keys[hi - 1], keys[mid]
+            left, right = lo, hi - 1
+            while left < right:
+                left += 1
+                while compare(keys[left], pivot) < 0:
+                    left += 1
+                right -= 1
+                while compare(pivot, keys[right]) < 0:
+                    right -= 1
+                if left >= right:
+                    break
+                keys[left], keys[right] = keys[right], keys[left]
+            keys[left], keys[hi - 1] = keys[hi - 1], keys[left]
+            intro(left + 1, hi, depth)
+            hi = left - 1
+    n = len(keys)
+    if n < 2:
+        return
+    depth, k = 0, n
+    while k >= 1:
+        depth += 1
+        k //= 2
+    intro(0, n - 1, 2 * depth)
+
+
+def py_haar_wavelets(x, thr_lower, thr_upper, germline, mad_factor, cv, factor_of_three):
+    x = [float(v) for v in x]
+    n = len(x)
+    ipi, mean = _inner_products(x)
+    k = _first_largest(ipi)
+    tree = [[[1.0, ipi[k - 1] / max(0.5, mean / 200.0), 1, k, n]]]     # node = [index, coefficient, start, split, end], positions 1-based
+    while sum(node[4] - node[2] - 1 for node in tree[-1]) != 0:
+        level = []
+        for index, _, start, split, end in tree[-1]:
+            if split - start >= 1:
+                ipi, mean = _inner_products(x[start - 1:split])
+                k = _first_largest(ipi)
+                level.append([2 * index - 1, ipi[k - 1] / max(0.5, mean / 200.0), start, k + start - 1, split])
+            if end - split >= 2:
+                ipi, mean = _inner_products(x[split:end])
+                k = _first_largest(ipi)
+                level.append([2 * index, ipi[k - 1] / max(0.5, mean / 200.0), split + 1, k + split, end])
+        tree.append(level)
+    smooth = 0.0
+    for v in x:
+        smooth += v
+    smooth /= math.sqrt(n)
+    median = _median_f64(x)
+    variability = median * cv if cv is not None else _median_f64([abs(v - median) for v in x])
+    threshold = mad_factor * variability
+    if threshold < thr_lower:
+        threshold = thr_lower
+    if threshold > thr_upper:
+        threshold = thr_upper
+    depth = len(tree)                                                   # HardThresh
+    order = list(range(depth))
+    if germline:
+        counts = [len(level) for level in tree]
+        _dotnet_sort(order, lambda a, b: (counts[b] > counts[a]) - (counts[b] < counts[a]))
+        weights = [(float(r) * (1.0 - 0.8)) / depth + 0.8 for r in range(1, depth + 1)]
+    else:
+        weights = [1.0] * depth
+    for j, level in enumerate(tree):
+        for node in level:
+            if abs(node[1]) <= 2 * threshold * weights[order[j]] * math.sqrt(2 * math.log(float(n))):
+                node[1] = 0.0
+    rec = np.full(n, 1.0 / math.sqrt(n) * smooth)                       # GetReconstructedVector
+    for level in tree:
+        for _, coefficient, start, split, end in level:
+            span = float(end - start + 1); head = float(split - start + 1)
+            vector = np.empty(end - start + 1)
+            vector[: split - start + 1] = math.sqrt(1 / head - 1 / span)
+            vector[split - start + 1:] = -1.0 / math.sqrt(span * span / head - span)
+            rec[start - 1:end] = rec[start - 1:end] + vector * coefficient
+    prelim = [0] + [i for i in range(1, n) if rec[i] - rec[i - 1] != 0]
+    breakpoints = [prelim[0]]                                            # GetBreakpointsAfterHealingBadSplits
+    for i in range(1, len(prelim)):
+        left_start, right_start = breakpoints[-1], prelim[i]
+        right_end = prelim[i + 1] if i < len(prelim) - 1 else n
+        left_len, right_len = right_start - left_start, right_end - right_start
+        left_median, right_median = _median_f64(x[left_start:right_start]), _median_f64(x[right_start:right_end])
+        weighted = (left_len * left_median + right_len * right_median) / (right_end - left_start)
+        scale = min(len(factor_of_three) - 1, int(math.ceil(math.log(min(left_len, right_len)) / math.log(3))))
+        if abs(left_median - right_median) > factor_of_three[scale] * 4 * max(weighted, 50.0):
+            breakpoints.append(prelim[i])
+    if germline:                                                         # RefineSegments
+        for i in range(1, len(breakpoints) - 1):
+            left = min(5, (breakpoints[i] - breakpoints[i - 1]) // 2)
+            right = min(5, (breakpoints[i + 1] - breakpoints[i]) // 2)
+            best_difference = abs(_median_f64(x[breakpoints[i - 1]:breakpoints[i]]) - median)
+            best = breakpoints[i]
+            for j in range(breakpoints[i] - left, breakpoints[i] + right):
+                difference = abs(_median_f64(x[breakpoints[i - 1]:j]) - median)
+                if difference > best_difference:
+                    best_difference, best = difference, j
+            breakpoints[i] = best
+    return breakpoints, depth
+
+
+def test_haar_wavelets_two_restatements():
+    rng = np.random.RandomState(606)
+    ran = deep = events = 0
+    for it in range(80):
+        n = int(rng.choice([2, 3, 5, 21, 80, 250, 600, 600, 900]))
+        level = float(rng.choice([40.0, 100.0]))
+        x = rng.normal(level, level * rng.uniform(0.03, 0.15), n)
+        for _ in range(int(rng.randint(0, 4))):
+            if n > 40:
+                a = int(rng.randint(0, n - 10)); x[a:a + int(rng.randint(3, n // 2))] *= rng.choice([0.5, 1.5, 2.0])
+        x = np.round(np.maximum(x, 0), int(rng.choice([0, 2])))          # whole numbers: exact ties between inner products and medians
+        germline = bool(it % 2)
+        cv = None if it % 3 == 0 else float(rng.uniform(0.02, 0.2))
+        f3 = np.sort(rng.uniform(0.01, 0.08, int(rng.randint(1, 9))))[::-1].copy()
+        mad_factor = float(rng.choice([2.0, 5.0]))
+        try:
+            want, depth = py_haar_wavelets(x, 5.0, 80.0, germline, mad_factor, cv, f3.tolist())
+        except _NeedsHeapsort:
+            continue
+        got = O.haar_wavelets(x, 5.0, 80.0, germline, mad_factor, cv, f3)
+        assert got.tolist() == want, (it, n, germline)
+        ran += 1; deep += depth > 16 and germline; events += len(want) > 1
+    assert ran > 60 and deep > 8 and events > 20, (ran, deep, events)
