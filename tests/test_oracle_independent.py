@@ -918,3 +918,43 @@ def test_haar_wavelets_two_restatements():
         assert got.tolist() == want, (it, n, germline)
         ran += 1; deep += depth > 16 and germline; events += len(want) > 1
     assert ran > 60 and deep > 8 and events > 20, (ran, deep, events)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Utilities.MergeMultiSampleCleanedBedFile + CanvasRunner.NormalizeCanvasClean (Utilities.cs:834-920, CanvasRunner.cs:883-903): dictionaries
+# keyed by chromosome and start in insertion order, a bin survives when every sample contributed a count, the stop is the last one read
+def py_merge_cleaned(samples):
+    stops, counts = {}, {}
+    for s in samples:
+        for c, a, b, v in zip(s["chr"], s["start"], s["stop"], s["count"]):
+            stops.setdefault(int(c), {})[int(a)] = int(b)
+            counts.setdefault(int(c), {}).setdefault(int(a), []).append(v)
+    rows = []
+    for c in stops:
+        for a in stops[c]:
+            if len(counts[c][a]) < len(samples):
+                continue
+            rows.append((c, a, stops[c][a], counts[c][a]))
+    return rows
+
+
+def test_merge_cleaned_two_restatements():
+    rng = np.random.RandomState(17)
+    for it in range(30):
+        nchr = int(rng.randint(1, 5)); S = int(rng.randint(1, 5))
+        base = []
+        for c in range(nchr):
+            starts = np.cumsum(rng.randint(1, 200, int(rng.randint(0, 300))))
+            base += [(c, int(a), int(a) + int(rng.randint(1, 150))) for a in starts]
+        samples = []
+        for s in range(S):
+            keep = [r for r in base if rng.rand() > 0.15]
+            samples.append(dict(chr=np.array([r[0] for r in keep], np.int32), start=np.array([r[1] for r in keep], np.int32),
+                                stop=np.array([r[2] + (s if rng.rand() < 0.05 else 0) for r in keep], np.int32),
+                                count=rng.gamma(5, 20, len(keep)).astype(np.float32)))
+        want = py_merge_cleaned(samples)
+        oc, os_, oe, ocnt = O.merge_cleaned(samples)
+        assert len(oc) == len(want), it
+        assert list(zip(oc.tolist(), os_.tolist(), oe.tolist())) == [r[:3] for r in want], it
+        for s in range(S):
+            assert (ocnt[s].view(np.uint32) == np.array([r[3][s] for r in want], np.float32).view(np.uint32)).all(), (it, s)
