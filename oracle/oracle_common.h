@@ -5,7 +5,9 @@
 // Parity status: the C# reference cannot be built in this image (no dotnet, private NuGet packages), so this
 // restatement is pinned only by the reference's own known-answer tests (tests/golden/*, see tests/test_oracle_golden.py).
 // Everything the reference's tests do not cover (BinCountsForChromosome, CanvasClean stages, CBS, Viterbi) is
-// "parity unpinned" against the real binaries: it follows the cited C# statement by statement.
+// "parity unpinned" against the real binaries: it follows the cited C# statement by statement.  Those stages are
+// cross-checked against a second reading of the C#, plain Python that shares no code with this directory
+// (tests/test_oracle_independent.py); that excludes a slip made once, it is not a reference-generated vector.
 //
 // .NET semantics restated here:
 //   (int)x            -> truncation toward zero
