@@ -958,3 +958,58 @@ def test_merge_cleaned_two_restatements():
         assert list(zip(oc.tolist(), os_.tolist(), oe.tolist())) == [r[:3] for r in want], it
         for s in range(S):
             assert (ocnt[s].view(np.uint32) == np.array([r[3][s] for r in want], np.float32).view(np.uint32)).all(), (it, s)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# SegmentationInput.GetCoverageVariability / reportVariabilityByWindow (Segmentation.cs:304-338) and FactorOfThreeCoverageVariabilities /
+# GetTripletMediansAndCMADs (:345-429): the two genome-wide inputs of HaarWavelets
+def py_coverage_variability(window, per_chr):
+    if sum(len(c) for c in per_chr) < 10 * window:
+        return None
+
+    def by_window(w):
+        out = []
+        for c in per_chr:
+            for index in range(0, len(c) - w, w):
+                chunk = [float(v) for v in c[index:index + w]]
+                med = _median_f64(chunk)
+                out.append(np.float32(_median_f64([abs(v - med) for v in chunk]) / med))
+        return out
+    if window > 10000:
+        q1, q2, q3 = py_quartiles(by_window(10000))
+        if float(np.float32(np.float32(q3 - q1) / q2)) > 0.015:
+            return float(q1)
+    return _median_f32(by_window(window))
+
+
+def py_factor_of_three(per_chr, max_exponent=8):
+    out = [0.0]
+    data = [[float(v) for v in c] for c in per_chr]
+    exponent = 1
+    while exponent <= max_exponent:
+        cmads, nxt = [], []
+        for c in data:
+            medians = []
+            for i in range(len(c) // 3):
+                a, b, d = sorted(c[3 * i:3 * i + 3])
+                medians.append(b)
+                cmads.append((d - a) / 2.0 / b)
+            nxt.append(medians)
+        data = nxt
+        if len(cmads) < 50:
+            out += [out[-1]] * (max_exponent - len(out) + 1)
+            break
+        out.append(_median_f64(cmads))
+        exponent += 1
+    return out
+
+
+def test_wavelet_genome_inputs_two_restatements():
+    rng = np.random.RandomState(909)
+    for it in range(25):
+        per_chr = [np.round(np.maximum(rng.normal(100, rng.uniform(3, 20), int(rng.randint(3, 9000))), 1.0), 2) for _ in range(int(rng.randint(1, 5)))]
+        if it % 4 == 0:                                                # a long chromosome: the 10 000-bin windows of the large-window branch
+            per_chr.append(np.round(np.maximum(rng.normal(100, 8, 125_000) * np.repeat(rng.choice([1.0, 1.0, 1.5], 125), 1000), 1.0), 2))
+        window = int(rng.choice([11, 100, 2000, 10001, 12000]))
+        assert O.coverage_variability(window, per_chr) == py_coverage_variability(window, per_chr), (it, window)
+        assert O.factor_of_three(per_chr).tolist() == py_factor_of_three(per_chr), it
