@@ -1013,3 +1013,39 @@ def test_wavelet_genome_inputs_two_restatements():
         window = int(rng.choice([11, 100, 2000, 10001, 12000]))
         assert O.coverage_variability(window, per_chr) == py_coverage_variability(window, per_chr), (it, window)
         assert O.factor_of_three(per_chr).tolist() == py_factor_of_three(per_chr), it
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# CBS, SegmentSplitUndo.SDUndo (ChangePoint.cs:155-202; Helper.cs:30-44 Median, :245-263 ArgMin): applied here to the segmentation the oracle
+# finds without undo (same seed, so the same change points before the undo step) and compared with the oracle's own SDUndo run
+def py_sd_undo(x, lengths, trimmed_sd, change_sd=3.0):
+    change_sd *= trimmed_sd
+    ends = np.cumsum(lengths).tolist()
+    while len(ends) > 1:
+        starts = [0] + ends[:-1]
+        medians = [_median_f64(x[a:b]) for a, b in zip(starts, ends)]
+        gaps = [abs(b - a) for a, b in zip(medians[:-1], medians[1:])]
+        smallest, at = gaps[0], 0
+        for i in range(1, len(gaps)):
+            if gaps[i] < smallest:
+                smallest, at = gaps[i], i
+        if smallest < change_sd:
+            del ends[at]
+        else:
+            break
+    return np.diff([0] + ends).tolist()
+
+
+def test_cbs_sd_undo_two_restatements():
+    rng = np.random.RandomState(1212)
+    undone = 0
+    for it in range(12):
+        parts = [rng.normal(m, 1.0, int(rng.randint(15, 120))) for m in rng.choice([0.0, 0.8, 2.5, 4.0, -3.0], int(rng.randint(2, 7)))]
+        x = np.round(np.concatenate(parts), 2)
+        sd = float(rng.choice([0.4, 1.0, 2.0]))
+        plain, _ = O.cbs_chromosome(x, seed=it + 1, undo=0)
+        with_undo, _ = O.cbs_chromosome(x, seed=it + 1, undo=2, trimmed_sd=sd)
+        want = py_sd_undo(x, plain.tolist(), sd) if len(plain) > 1 else plain.tolist()
+        assert with_undo.tolist() == want, it
+        undone += len(want) < len(plain)
+    assert undone >= 3
