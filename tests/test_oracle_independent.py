@@ -1049,3 +1049,156 @@ def test_cbs_sd_undo_two_restatements():
         assert with_undo.tolist() == want, it
         undone += len(want) < len(plain)
     assert undone >= 3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# CBS: the recursion and the permutation tests (ChangePoint.cs:44-136 ChangePoints, :291-404 FindChangePoints, :407-421 XPerm,
+# CBSTStatistic.cs:935-1015 TPermP) restated on top of the oracle's statistics, which are checked on their own above (TMaxO / HTMaxP / TMaxP
+# against every arc) — what is second-sourced here is the control flow around them: segment stack, hybrid switch, early stopping against the
+# boundary, the two TPermP tests, and the order in which random numbers are drawn (numpy's MT19937 stream, one 32-bit output per NextDouble).
+class _DotNetRandom:
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+        self.buf, self.at, self.drawn = [], 0, 0
+
+    def next_double(self):
+        if self.at == len(self.buf):
+            self.buf = self.rs.randint(0, 2 ** 32, size=1 << 16, dtype=np.uint64).tolist()
+            self.at = 0
+        v = self.buf[self.at]
+        self.at += 1; self.drawn += 1
+        return v * (1.0 / 4294967296.0)
+
+
+def _py_tpermp(n1, n2, n, data, offset, n_perm, rnd):
+    import ctypes as C
+    if n1 == 1 or n2 == 1:
+        return float(n_perm) / n_perm
+    px = [0.0] * n
+    sum1 = sum2 = tss = 0.0
+    for i in range(n1):
+        px[i] = data[offset + i]; sum1 += px[i]; tss += px[i] ** 2
+    for i in range(n1, n):
+        px[i] = data[offset + i]; sum2 += px[i]; tss += px[i] ** 2
+    rn1, rn2 = float(n1), float(n2)
+    rn = rn1 + rn2
+    xbar = (sum1 + sum2) / rn
+    tss -= rn * xbar ** 2
+    if n1 <= n2:
+        m1, rm1 = n1, rn1
+        ostat = 0.99999 * abs(sum1 / rn1 - xbar)
+        tstat = ostat ** 2 * rn1 * rn / rn2
+    else:
+        m1, rm1 = n2, rn2
+        ostat = 0.99999 * abs(sum2 / rn2 - xbar)
+        tstat = ostat ** 2 * rn2 * rn / rn1
+    tstat = tstat / ((tss - tstat) / (rn - 2.0))
+    rejected = 0
+    if not (tstat > 25 and m1 >= 10):
+        for _ in range(n_perm):
+            s = 0.0
+            for i in range(n - 1, n - m1 - 1, -1):
+                j = int(rnd.next_double() * (i + 1))
+                j = i if j > i else j
+                px[i], px[j] = px[j], px[i]
+                s += px[i]
+            if ostat <= abs(s / rm1 - xbar):
+                rejected += 1
+    return float(rejected) / n_perm
+
+
+def _py_find_change_points(x, tss, n_perm, alpha, hybrid, delta, sbdry, rnd, al0=2, hk=25):
+    import ctypes as C
+    n = len(x)
+    arr = np.ascontiguousarray(x, np.float64); sx = np.zeros(n); iseg = np.zeros(2, np.int32); ostat = C.c_double()
+    O.lib.orc_tmaxo(O._p(arr), n, C.c_double(tss), O._p(sx), O._p(iseg), C.byref(ostat), al0)
+    ostat = ostat.value
+    ostat1 = math.sqrt(ostat)
+    ostat *= 0.99999
+    if ostat1 <= 0.1:
+        return []
+    shorter = min(int(iseg[1] - iseg[0]), n - int(iseg[1]) + int(iseg[0]))
+    if not (ostat1 >= 7.0 and shorter >= 10):
+        if hybrid:
+            p1 = O.lib.orc_tailp(ostat1, delta, n, 100, 1e-6)
+            if p1 > alpha:
+                return []
+            limit = int((alpha - p1) * n_perm)
+        else:
+            limit = int(alpha * n_perm)
+        k = limit * (limit + 1) // 2 + 1
+        rejected = 0
+        px = np.zeros(n)
+        for np_ in range(1, n_perm + 1):
+            perm = list(x)                                             # XPerm
+            for i in range(n - 1, -1, -1):
+                j = int(rnd.next_double() * (i + 1))
+                j = i if j > i else j
+                perm[i], perm[j] = perm[j], perm[i]
+            px[:] = perm
+            pstat = O.lib.orc_htmaxp(hk, C.c_double(tss), O._p(px), n, O._p(sx), al0) if hybrid else O.lib.orc_tmaxp(C.c_double(tss), O._p(px), n, O._p(sx), al0)
+            if ostat <= pstat:
+                rejected += 1; k += 1
+            if rejected > limit:
+                return []
+            if np_ >= sbdry[k - 1]:
+                break
+    a, b = int(iseg[0]), int(iseg[1])
+    if b == n:
+        return [a]
+    if a == 0:
+        return [b]
+    found = []
+    if _py_tpermp(a, b - a, b, x, 0, n_perm, rnd) <= alpha:
+        found.append(a)
+    if _py_tpermp((n - a) - (n - b), n - b, n - a, x, a, n_perm, rnd) <= alpha:
+        found.append(b)
+    return found
+
+
+def py_cbs_change_points(data, seed, sbdry, n_perm, alpha=0.01, min_width=2, k_max=25, n_min=200):
+    rnd = _DotNetRandom(seed)
+    data = [float(v) for v in data]
+    ends = [0, len(data)]
+    closed = []
+    while len(ends) > 1:
+        lo, hi = ends[-2], ends[-1]
+        n = hi - lo
+        found = []
+        if n >= 2 * min_width:
+            cur = data[lo:hi]
+            if max(cur) != min(cur):
+                acc = 0.0
+                for v in cur:
+                    acc += v
+                mean = acc / n
+                cur = [v - mean for v in cur]
+                tss = 0.0
+                for v in cur:
+                    tss += v * v
+                hybrid = n_min < n
+                found = _py_find_change_points(cur, tss, n_perm, alpha, hybrid, (k_max + 1.0) / n if hybrid else 0.0, sbdry, rnd)
+        if not found:
+            closed.append(hi)
+            ends.pop()
+        else:
+            ends[-1:-1] = [lo + f for f in found]
+    closed.reverse()
+    return np.diff([0] + closed).tolist(), rnd.drawn
+
+
+def test_cbs_recursion_two_restatements():
+    rng = np.random.RandomState(3434)
+    n_perm = 200
+    sbdry = O.cbs_boundary(n_perm, 0.01)
+    split = hybrid_runs = 0
+    for it in range(14):
+        parts = [rng.normal(m, 1.0, int(rng.randint(8, 160))) for m in rng.choice([0.0, 0.6, 1.2, 3.0, -2.0], int(rng.randint(1, 6)))]
+        x = np.round(np.concatenate(parts), 2)
+        seed = int(O.cbs_seeds(24)[it % 24])
+        want, drawn = py_cbs_change_points(x, seed, sbdry, n_perm)
+        got, stats = O.cbs_chromosome(x, seed=seed, sbdry=sbdry, n_perm=n_perm, undo=0)
+        assert got.tolist() == want, (it, len(x))
+        assert int(stats[3] + stats[4]) == drawn, (it, stats.tolist(), drawn)     # the same number of random numbers consumed
+        split += len(want) > 1; hybrid_runs += len(x) > 200
+    assert split >= 6 and hybrid_runs >= 4
