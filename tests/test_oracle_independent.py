@@ -1202,3 +1202,51 @@ def test_cbs_recursion_two_restatements():
         assert int(stats[3] + stats[4]) == drawn, (it, stats.tolist(), drawn)     # the same number of random numbers consumed
         split += len(want) > 1; hybrid_runs += len(x) > 200
     assert split >= 6 and hybrid_runs >= 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# TailProbability.TailP / Nu / IntegralInvT1tSq (TailProbability.cs:8-107) with the normal CDF written through erfc in place of MathNet's:
+# agreement to 1e-10 relative — the value is only compared with the p-value cutoff
+def py_tailp(b, delta, m, n_grid=100, tol=1e-6):
+    cdf = lambda z: 0.5 * math.erfc(-z / math.sqrt(2.0))
+
+    def nu(x):
+        if x <= 0.01:
+            return math.exp(-0.583 * x)
+        l1 = math.log(2.0) - 2 * math.log(x)
+        l0 = l1
+        k, dk = 2, 0.0
+        for _ in range(k):
+            dk += 1
+            l1 -= 2.0 * cdf(-x * math.sqrt(dk) / 2.0) / dk
+        while abs((l1 - l0) / l1) > tol:
+            l0 = l1
+            for _ in range(k):
+                dk += 1
+                l1 -= 2.0 * cdf(-x * math.sqrt(dk) / 2.0) / dk
+            k *= 2
+        return math.exp(l1)
+
+    def integral(x, a):
+        y = x + a - 0.5
+        v = (8.0 * y) / (1.0 - 4.0 * y ** 2) + 2.0 * math.log((1.0 + 2.0 * y) / (1.0 - 2.0 * y))
+        y = x - 0.5
+        return v - (8.0 * y) / (1.0 - 4.0 * y ** 2) - 2.0 * math.log((1.0 + 2.0 * y) / (1.0 - 2.0 * y))
+    step = (0.5 - delta) / n_grid
+    scaled = b / math.sqrt(m)
+    tl, t, total = 0.5 - step, 0.5 - 0.5 * step, 0.0
+    for _ in range(n_grid):
+        tl += step; t += step
+        total += nu(scaled / math.sqrt(t * (1 - t))) ** 2 * integral(tl, step)
+    return 2.0 * (9.973557e-2 * b ** 3 * math.exp(-b ** 2 / 2) * total)
+
+
+def test_tail_probability_two_restatements():
+    rng = np.random.RandomState(88)
+    for it in range(10):
+        m = int(rng.randint(201, 3000))
+        b = float(rng.uniform(2.5, 7.0))                             # small b: the Nu series needs 10^5 terms per grid point
+        delta = 26.0 / m
+        want = py_tailp(b, delta, m)
+        got = O.lib.orc_tailp(b, delta, m, 100, 1e-6)
+        assert abs(got - want) <= 1e-10 * max(abs(want), 1e-300), (it, b, m, got, want)
