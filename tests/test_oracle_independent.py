@@ -1250,3 +1250,66 @@ def test_tail_probability_two_restatements():
         want = py_tailp(b, delta, m)
         got = O.lib.orc_tailp(b, delta, m, 100, 1e-6)
         assert abs(got - want) <= 1e-10 * max(abs(want), 1e-300), (it, b, m, got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# GetBoundary.ComputeBoundary / EtaBoundary / PExceed (GetBoundary.cs:9-150): the sequential stopping boundary of the permutation tests, with
+# scipy's hypergeometric CDF in place of the reference's R.phyper port and lgamma for MathNet's BinomialLn
+def py_cbs_boundary(n_perm, alpha, eta=0.05, tol=1e-2):
+    from scipy.stats import hypergeom
+    max_ones = int(math.floor(n_perm * alpha) + 1)
+    sbdry = [0] * (max_ones * (max_ones + 1) // 2)
+    draws = np.arange(1, n_perm + 1)
+
+    def binomial_ln(n, k):
+        if k < 0 or n < 0 or k > n:
+            return -math.inf
+        return math.lgamma(n + 1) - math.lgamma(k + 1) - math.lgamma(n - k + 1)
+
+    def eta_boundary(eta0, ones, at, table):
+        k = 0
+        for i in range(1, n_perm + 1):
+            if table[k][i - 1] <= eta0:
+                sbdry[at + k] = i
+                k += 1
+
+    def p_exceed(ones, at):
+        log = lambda v: math.log(v) if v > 0 else -math.inf
+        whole = binomial_ln(n_perm, ones)
+        p = math.exp(binomial_ln(n_perm - sbdry[at], ones) - whole)
+        if ones >= 2:
+            p += math.exp(log(sbdry[at]) + binomial_ln(n_perm - sbdry[at + 1], ones - 1) - whole)
+        if ones >= 3:
+            n1, n2, n, k = sbdry[at], sbdry[at + 1], n_perm - sbdry[at + 2], ones - 2
+            p += math.exp(log(n1) + log(n1 - 1.0) - math.log(2.0) + binomial_ln(n, k) - whole) + math.exp(log(n1) + log(n2 - n1) + binomial_ln(n, k) - whole)
+        for i in range(4, ones + 1):
+            n1, n2, n3 = sbdry[at + i - 4], sbdry[at + i - 3], sbdry[at + i - 2]
+            n, k = n_perm - sbdry[at + i - 1], ones - i + 1
+            tail = binomial_ln(n, k) - whole
+            p += (math.exp(binomial_ln(n1, i - 1) + tail) + math.exp(binomial_ln(n1, i - 2) + log(n3 - n1) + tail)
+                  + math.exp(binomial_ln(n1, i - 3) + log(n2 - n1) + log(n3 - n2) + tail)
+                  + math.exp(binomial_ln(n1, i - 3) + log(n2 - n1) - math.log(2.0) + log(n2 - n1 - 1.0) + tail))
+        return p
+    sbdry[0] = n_perm - int(n_perm * eta)
+    eta0 = eta
+    at = 0
+    for ones in range(2, max_ones + 1):
+        table = [hypergeom.cdf(k, n_perm, ones, draws) for k in range(ones + 1)]
+        hi = eta0 * 1.1
+        eta_boundary(hi, ones, at + 1, table); p_hi = p_exceed(ones, at + 1)
+        lo = eta0 * 0.25
+        eta_boundary(lo, ones, at + 1, table); p_lo = p_exceed(ones, at + 1)
+        while (hi - lo) / lo > tol:
+            eta0 = lo + (hi - lo) * (eta - p_lo) / (p_hi - p_lo)
+            eta_boundary(eta0, ones, at + 1, table); p = p_exceed(ones, at + 1)
+            if p > eta:
+                hi, p_hi = eta0, p
+            else:
+                lo, p_lo = eta0, p
+        at += ones
+    return sbdry
+
+
+@pytest.mark.parametrize("n_perm,alpha", [(200, 0.01), (500, 0.01), (1000, 0.01), (400, 0.05)])
+def test_cbs_boundary_two_restatements(n_perm, alpha):
+    assert O.cbs_boundary(n_perm, alpha).tolist() == py_cbs_boundary(n_perm, alpha)
