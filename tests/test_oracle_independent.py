@@ -1313,3 +1313,55 @@ def py_cbs_boundary(n_perm, alpha, eta=0.05, tol=1e-2):
 @pytest.mark.parametrize("n_perm,alpha", [(200, 0.01), (500, 0.01), (1000, 0.01), (400, 0.05)])
 def test_cbs_boundary_two_restatements(n_perm, alpha):
     assert O.cbs_boundary(n_perm, alpha).tolist() == py_cbs_boundary(n_perm, alpha)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# ChangePoint.TrimmedVariance / InflationFactor (ChangePoint.cs:423-470; Helper.Seq :305-314): the SD estimate behind SDUndo, with scipy's
+# normal quantile and density in place of MathNet's — 1e-10 relative
+def py_trimmed_variance(per_chr, trim=0.025):
+    from scipy.stats import norm
+    n = sum(len(c) for c in per_chr)
+    diff = [0.0] * (n - 1)                                             # slots the loop does not reach stay 0 and are sorted with the rest
+    i, last = 0, float("nan")
+    for c in per_chr:
+        if len(c) == 0:
+            continue
+        if i > 0:
+            diff[i] = float(c[0]) - last
+            i += 1
+        for a, b in zip(c[:-1], c[1:]):
+            diff[i] = float(b) - float(a)
+            i += 1
+        last = float(c[-1])
+    keep = int(np.rint((1 - 2 * trim) * (n - 1)))
+    kept = sorted(abs(d) for d in diff)[:keep]
+    total = 0.0
+    for d in kept:
+        total += d ** 2
+    a = norm.ppf(1 - trim)
+    step = 2 * a / 10000
+    lo, hi = -a + step / 2, a - step / 2
+    inc = (hi - lo) / 9999
+    xs = [lo]
+    for _ in range(9998):
+        xs.append(xs[-1] + inc)
+    xs.append(hi)
+    ex2 = 0.0
+    for v in xs:
+        ex2 += (v * v) * norm.pdf(v)
+    ex2 = ex2 * step / (1 - 2 * trim)
+    return (1 / ex2) * total / (2 * keep)
+
+
+def test_trimmed_variance_two_restatements():
+    import ctypes as C
+    rng = np.random.RandomState(66)
+    for it in range(4):
+        per_chr = [np.round(rng.normal(0, rng.uniform(0.5, 3), int(rng.randint(2, 400))), 2) for _ in range(int(rng.randint(1, 5)))]
+        if it == 3:
+            per_chr.insert(0, np.array([1.25]))                         # a one-bin first chromosome: no junction difference is formed after it
+        arrs = [np.ascontiguousarray(c, np.float64) for c in per_chr]
+        lens = np.array([len(c) for c in arrs], np.int32)
+        got = O.lib.orc_trimmed_variance(len(arrs), O._pp(arrs), O._p(lens), C.c_double(0.025))
+        want = py_trimmed_variance(per_chr)
+        assert abs(got - want) <= 1e-10 * want, (it, got, want)
