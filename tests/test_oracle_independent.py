@@ -254,7 +254,34 @@ def _median_f32(values):
     return float(s[n // 2]) if n % 2 else float((s[n // 2 - 1] + s[n // 2]) / np.float32(2))
 
 
-def py_clean(bins, is_autosome):
+# CanvasClean.GetWeightedCounts (CanvasClean.cs:107-134) + Utilities.WeightedQuantiles / WeightedMedian (Utilities.cs:493-520): GC values with
+# fewer than 100 bins borrow their neighbours' counts at half the weight per step; reached with -w below 100
+def _py_weighted_median(by_gc, gc):
+    pairs = []
+    radius, weight = 0, np.float32(1)
+    while len(pairs) < 100:
+        hi, lo = gc + radius, gc - radius
+        if hi >= len(by_gc) and lo < 0:
+            break
+        if hi < len(by_gc):
+            pairs += [(c, weight) for c in by_gc[hi]]
+        if lo != hi and lo >= 0:
+            pairs += [(c, weight) for c in by_gc[lo]]
+        radius += 1
+        weight = np.float32(weight / np.float32(2))
+    acc = 0.0
+    for _, w in pairs:
+        acc += float(w)
+    total = float(np.float32(acc))                                     # LINQ Sum over a float selector: double accumulator, float result
+    cumulative, quantile = 0.0, 0.0
+    for c, w in sorted(pairs, key=lambda t: t[0]):                      # OrderBy: stable
+        cumulative += float(w)
+        if cumulative / total <= float(np.float32(0.5)):
+            quantile = float(c)
+    return quantile
+
+
+def py_clean(bins, is_autosome, min_bins_weighted=100):
     """bins: list of [chr, start, stop, count(float32), gc]"""
     sizes = sorted(b[2] - b[1] for b in bins)                      # RemoveBigBins
     index = int(0.98 * float(len(bins)))
@@ -276,7 +303,7 @@ def py_clean(bins, is_autosome):
         if is_autosome[b[0]]:
             per_gc[b[4]] += 1
             total += 1
-    threshold = min(100, max(100, int(total / 101)))
+    threshold = min(100, max(min_bins_weighted, int(total / 101)))
     stripped = [b for b in bins if per_gc[b[4]] >= threshold]
     if not stripped:
         return bins
@@ -288,7 +315,7 @@ def py_clean(bins, is_autosome):
             by_gc[b[4]].append(b[3])
             autosomal.append(b[3])
     global_median = _median_f32(autosomal)
-    medians = [_median_f32(v) if len(v) >= 100 else None for v in by_gc]      # fewer than 100: weighted median, never looked up after the strip
+    medians = [_median_f32(v) if len(v) >= 100 else _py_weighted_median(by_gc, g) for g, v in enumerate(by_gc)]
     for b in bins:
         m = medians[b[4]]
         if m is not None and m > 0:
@@ -1365,3 +1392,29 @@ def test_trimmed_variance_two_restatements():
         got = O.lib.orc_trimmed_variance(len(arrs), O._pp(arrs), O._p(lens), C.c_double(0.025))
         want = py_trimmed_variance(per_chr)
         assert abs(got - want) <= 1e-10 * want, (it, got, want)
+
+
+def test_clean_weighted_median_two_restatements():
+    from canvas_amd import CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS
+    rng = np.random.RandomState(4040)
+    weighted_used = 0
+    for it in range(6):
+        nchr = 3
+        is_auto = np.array([1, 1, 0], np.uint8)
+        bins = []
+        for c in range(nchr):
+            pos = 0
+            for _ in range(int(rng.randint(300, 900))):
+                gc = int(np.clip(rng.normal(45, 7), 0, 100))
+                cnt = np.float32(rng.poisson(60.0 * (1 + (gc - 45) * 0.015)))
+                bins.append([c, pos, pos + 100, cnt, gc])
+                pos += 100
+        w = int(rng.choice([5, 20, 40]))
+        want = py_clean(bins, is_auto, min_bins_weighted=w)
+        a = [np.array([b[k] for b in bins]) for k in range(5)]
+        got = O.clean(a[0], a[1], a[2], a[3], a[4], is_auto, np.zeros(nchr, np.uint8), CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS, min_bins_weighted=w)
+        assert len(got["chr"]) == len(want), it
+        assert (got["count"].view(np.uint32) == np.array([b[3] for b in want], np.float32).view(np.uint32)).all(), it
+        per_gc = np.bincount([b[4] for b in want if is_auto[b[0]]], minlength=101)
+        weighted_used += int(((per_gc > 0) & (per_gc < 100)).sum())
+    assert weighted_used > 20
