@@ -1418,3 +1418,23 @@ def test_clean_weighted_median_two_restatements():
         per_gc = np.bincount([b[4] for b in want if is_auto[b[0]]], minlength=101)
         weighted_used += int(((per_gc > 0) & (per_gc < 100)).sum())
     assert weighted_used > 20
+
+
+# RawRatioCalculator.Run (RawRatioCalculator.cs:23-44) followed by RatiosToCounts
+def test_normalize_raw_ratio_two_restatements():
+    rng = np.random.RandomState(32)
+    for it in range(10):
+        n = int(rng.randint(1, 300))
+        sample = np.round(rng.gamma(4, 25, n), 2).astype(np.float32)
+        reference = np.round(rng.gamma(2, 30, n), 2).astype(np.float32) * (rng.rand(n) > 0.1)
+        lo, hi = float(rng.choice([1.0, 5.0])), float(rng.choice([np.inf, 150.0]))
+        keep, ratios = [], []
+        for j in range(n):
+            if float(reference[j]) < lo or float(reference[j]) > hi:
+                continue
+            keep.append(j)
+            ratios.append(np.float32(sample[j] / reference[j]))
+        counts = [np.float32(float(r) * (40.0 * 2 / 2.0)) for r in ratios]
+        k, r, c = O.norm_ratio(sample, reference, None, mode=1, min_ref=lo, max_ref=hi)
+        assert k.tolist() == keep, it
+        assert (r.view(np.uint32) == np.asarray(ratios, np.float32).view(np.uint32)).all() and (c.view(np.uint32) == np.asarray(counts, np.float32).view(np.uint32)).all(), it
