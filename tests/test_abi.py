@@ -26,6 +26,19 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), n
 
 
+def test_nothing_undeclared_is_exported():
+    """the other direction: every canvas_* symbol the library exports is declared in the header (no private entry points)"""
+    import shutil
+    import subprocess
+    from canvas_amd import build
+    so, _ = build.build()
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith("canvas_")}
+    from canvas_amd.lib import ABI_SYMBOLS
+    assert exported == set(ABI_SYMBOLS), exported ^ set(ABI_SYMBOLS)
+
+
 def test_host_scalar_entry_points_without_gpu(lib):
     import numpy as np
     rates = np.array([0.2, 0.1, 0.4, 0.3], np.float64)
