@@ -3,6 +3,7 @@
   canvas_amd/libcanvas_synth.so  synthetic-input generator used by bench/tests only
 """
 import glob
+import hashlib
 import os
 import subprocess
 
@@ -32,26 +33,67 @@ def _torch_lib_dir():
     return None
 
 
+HASH_MARKER = b"CANVAS_SRC_HASH="
+LAST_BUILD_MODE = {}   # output path -> "compiled" | "reused (source hash matches)"; printed by __graft_entry__.smoke()
+
+
+def source_hash(srcs):
+    """sha256 over the flags and the contents of everything a library is compiled from (its .hip files, every csrc/*.hpp, the header).
+    The hash is compiled INTO the library (-DCANVAS_SRC_HASH, see ctx.hip / synth.hip) and read back from the file's bytes, so a shipped
+    .so that does not correspond to the sources next to it is rebuilt no matter what its mtime says."""
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    deps = sorted(srcs) + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "canvas_hip.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:32]
+
+
+def embedded_hash(path):
+    """the source hash a built file carries (None if absent)"""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        blob = f.read()
+    i = blob.find(HASH_MARKER)
+    if i < 0:
+        return None
+    j = i + len(HASH_MARKER)
+    return blob[j:j + 32].decode("ascii", "replace")
+
+
 def _stale(out, srcs):
-    if not os.path.exists(out):
-        return True
-    t = os.path.getmtime(out)
-    deps = list(srcs) + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "canvas_hip.h")]
-    return any(os.path.getmtime(s) > t for s in deps)
+    return embedded_hash(out) != source_hash(srcs)
 
 
-def _compile_and_link(hipcc, srcs, out, extra_libs, verbose):
+def _compile_and_link(hipcc, srcs, out, extra_libs, verbose, src_hash=""):
     """hipcc -c per source, then an explicit link so that WE choose which libamdhip64 / librccl is recorded as DT_NEEDED
     (hipcc's own link step always resolves -lamdhip64 in /opt/rocm/lib first)."""
-    cflags = [f for f in FLAGS if f != "-shared"]
-    objs = []
-    for sfile in srcs:
-        o = os.path.join(CSRC, "." + os.path.basename(sfile) + ".o")
-        cmd = [hipcc] + cflags + ["-c", sfile, "-o", o]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(o)
+    cflags = [f for f in FLAGS if f != "-shared"] + ['-DCANVAS_SRC_HASH="%s"' % src_hash]
+    # objects are cached per source under csrc/.obj (keyed by the hash of that source + every header + the flags, and by the library
+    # hash for the one file that embeds it), and the sources compile in parallel: a one-file edit rebuilds in seconds
+    from concurrent.futures import ThreadPoolExecutor
+    odir = os.path.join(CSRC, ".obj")
+    os.makedirs(odir, exist_ok=True)
+
+    def one(sfile):
+        embeds = b"CANVAS_SRC_HASH" in open(sfile, "rb").read()
+        key = source_hash([sfile]) + ("-" + src_hash if embeds else "")
+        o = os.path.join(odir, os.path.basename(sfile) + "." + key + ".o")
+        if not os.path.exists(o):
+            for stale in glob.glob(os.path.join(odir, os.path.basename(sfile) + ".*.o")):
+                os.remove(stale)
+            cmd = [hipcc] + cflags + ["-c", sfile, "-o", o + ".tmp.o"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(o + ".tmp.o", o)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, srcs))
     tl = _torch_lib_dir()
     dirs = ([tl] if tl else []) + ["/opt/rocm/lib"]
     link = ["g++", "-shared", "-o", out] + objs
@@ -61,8 +103,6 @@ def _compile_and_link(hipcc, srcs, out, extra_libs, verbose):
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
-    for o in objs:
-        os.remove(o)
 
 
 def build(force=False, verbose=False):
@@ -70,13 +110,28 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in PRODUCT_SRC if os.path.exists(os.path.join(CSRC, s))]
     out = os.path.join(HERE, "libcanvas_hip.so")
     if force or _stale(out, srcs):
-        _compile_and_link(hipcc, srcs, out, ["-lrccl"] if any(s.endswith("comm.hip") for s in srcs) else [], verbose)
+        _compile_and_link(hipcc, srcs, out, ["-lrccl"] if any(s.endswith("comm.hip") for s in srcs) else [], verbose, source_hash(srcs))
+        LAST_BUILD_MODE[out] = "compiled"
+    else:
+        LAST_BUILD_MODE[out] = "reused (embedded source hash matches the sources)"
+    assert embedded_hash(out) == source_hash(srcs), "libcanvas_hip.so does not carry the hash of its sources"
     out2 = os.path.join(HERE, "libcanvas_synth.so")
     s2 = [os.path.join(CSRC, "synth.hip")]
     if force or _stale(out2, s2):
-        _compile_and_link(hipcc, s2, out2, [], verbose)
+        _compile_and_link(hipcc, s2, out2, [], verbose, source_hash(s2))
+        LAST_BUILD_MODE[out2] = "compiled"
+    else:
+        LAST_BUILD_MODE[out2] = "reused (embedded source hash matches the sources)"
     build_tools(force=force, verbose=verbose)
     return out, out2
+
+
+def _tool_hash(srcs):
+    h = hashlib.sha256()
+    for d in list(srcs) + [os.path.join(HERE, "..", "include", "canvas_hip.h")]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:32]
 
 
 def build_tools(force=False, verbose=False):
@@ -89,8 +144,9 @@ def build_tools(force=False, verbose=False):
     for name, src in (("CanvasBin", "canvas_bin_main.cpp"), ("CanvasClean", "canvas_clean_main.cpp"), ("CanvasPartition", "canvas_partition_main.cpp")):
         out = os.path.join(bdir, name)
         srcs = [os.path.join(tdir, src), os.path.join(tdir, "tool_common.hpp")]
-        if force or not os.path.exists(out) or any(os.path.getmtime(x) > os.path.getmtime(out) for x in srcs + [os.path.join(HERE, "libcanvas_hip.so")]):
-            cmd = ["g++", "-O2", "-std=c++17", "-o", out, srcs[0], "-L" + HERE, "-lcanvas_hip", "-lz", "-Wl,-rpath," + HERE]
+        th = _tool_hash(srcs)
+        if force or embedded_hash(out) != th:
+            cmd = ["g++", "-O2", "-std=c++17", '-DCANVAS_SRC_HASH="%s"' % th, "-o", out, srcs[0], "-L" + HERE, "-lcanvas_hip", "-lz", "-Wl,-rpath," + HERE]
             for d in ([tl] if tl else []) + ["/opt/rocm/lib"]:
                 cmd += ["-L" + d, "-Wl,-rpath," + d]
             cmd += ["-lamdhip64", "-lrccl"]

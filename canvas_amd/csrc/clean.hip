@@ -218,9 +218,14 @@ __global__ void __launch_bounds__(256) k_copy_soa(Soa src, Soa dst, int64_t n) {
     if (i >= n) return;
     dst.chr[i] = src.chr[i]; dst.start[i] = src.start[i]; dst.stop[i] = src.stop[i]; dst.gc[i] = src.gc[i]; dst.count[i] = src.count[i];
 }
-__global__ void __launch_bounds__(256) k_fill_f64(double* __restrict__ p, int64_t n, double v) {
+// CountDeviation = -1 for every bin, and the range check the reference gets for free from its managed arrays: a gc outside 0..100 (or a
+// chromosome index outside the table) would index past the GC tables below, where the C# throws IndexOutOfRangeException
+__global__ void __launch_bounds__(256) k_init_validate(const int32_t* __restrict__ chr, const int32_t* __restrict__ gc, int64_t n, int nchr, double* __restrict__ dev, unsigned int* __restrict__ bad) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = v;
+    if (i >= n) return;
+    dev[i] = -1.0;
+    const int32_t g = gc[i], c = chr[i];
+    if ((uint32_t)g > 100u || (uint32_t)c >= (uint32_t)nchr) *bad = 1u;
 }
 __global__ void __launch_bounds__(256) k_keys_f64(const double* __restrict__ v, int64_t n, unsigned long long* __restrict__ keys) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -661,7 +666,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n);
     sz.take<uint8_t>(n); sz.take<uint32_t>(n / CBLK + 2); sz.take<unsigned long long>(2); sz.take<uint32_t>(n); sz.take<unsigned long long>(nW0); sz.take<uint32_t>(n);
     sz.take<uint8_t>(nchr); sz.take<uint32_t>(2 * NGC); sz.take<uint32_t>(NGC + 1); sz.take<uint32_t>(NGC); sz.take<double>(NGC); sz.take<VarTab>(1);
-    sz.take<uint8_t>(NGC); sz.take<double>(nW0); sz.take<double>(65536); sz.take<int64_t>(65536 + 1); sz.take<unsigned int>(1); sz.take<long long>(65536);
+    sz.take<uint8_t>(NGC); sz.take<double>(nW0); sz.take<double>(65536); sz.take<int64_t>(65536 + 1); sz.take<unsigned int>(1); sz.take<long long>(65536); sz.take<unsigned int>(1);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
     WsCarver ws(ctx->ws);
     CleanState st; st.ctx = ctx; st.n = n;
@@ -678,9 +683,17 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     double* dMedians = ws.take<double>(NGC); VarTab* dTab = ws.take<VarTab>(1); uint8_t* dKeepGc = ws.take<uint8_t>(NGC);
     double* dSd = ws.take<double>(nW0); double* dRunMedian = ws.take<double>(65536); int64_t* dRunStart = ws.take<int64_t>(65536 + 1);
     unsigned int* dCnt = ws.take<unsigned int>(1); long long* dPos = ws.take<long long>(65536);
+    unsigned int* dBad = ws.take<unsigned int>(1);
     ProfScope psTotal(ctx, "clean_total");       // whole CanvasClean on the device timeline (kernels + the gaps of the host decisions)
     rc = canvas_h2d_small(ctx, st.dIsAuto, h_chr_is_autosome, nchr); if (rc) return rc;
-    hipLaunchKernelGGL(k_fill_f64, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, st.cur.dev, n, -1.0);   // CountDeviation = -1 (GenomicBin.cs:83)
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_init_validate, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, st.cur.chr, st.cur.gc, n, nchr, st.cur.dev, dBad);   // CountDeviation = -1 (GenomicBin.cs:83)
+    {   // the range check comes back before any kernel indexes a table with gc / chr (one 4-byte read; the stage has several synchronisations anyway)
+        unsigned int bad = 0;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (bad) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: a bin has gc outside 0..100 or a chromosome index outside [0, nchr) (the reference throws IndexOutOfRangeException)");
+    }
 
     // RemoveBigBins (CanvasClean.cs:328-355) and RemoveOutliers (CanvasClean.cs:387-413) without a host round trip in between: the size
     // threshold is read by the flag kernel from the select's device result, the count after the first compaction stays on the device and the

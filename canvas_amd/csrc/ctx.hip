@@ -3,7 +3,13 @@
 
 extern "C" {
 
-const char* canvas_version(void) { return "canvas_hip 0.1 (gfx950)"; }
+#ifndef CANVAS_SRC_HASH
+#define CANVAS_SRC_HASH "unhashed-build-0000000000000000"
+#endif
+// the hash of the sources this library was compiled from (canvas_amd/build.py::source_hash): build() reads it back from the file's bytes and
+// recompiles on a mismatch, so a shipped binary always corresponds to the sources next to it
+__attribute__((used)) static const char src_hash_marker[] = "CANVAS_SRC_HASH=" CANVAS_SRC_HASH;
+const char* canvas_version(void) { return "canvas_hip 0.2 (gfx950) src=" CANVAS_SRC_HASH; }
 
 canvas_ctx* canvas_create(int device) {
     int ndev = 0;

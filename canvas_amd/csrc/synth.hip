@@ -74,6 +74,10 @@ __global__ void __launch_bounds__(256) k_synth(SynthParams P, const uint32_t* __
     mask[w] = mw;
 }
 
+#ifndef CANVAS_SRC_HASH
+#define CANVAS_SRC_HASH "unhashed-build-0000000000000000"
+#endif
+__attribute__((used)) static const char src_hash_marker[] = "CANVAS_SRC_HASH=" CANVAS_SRC_HASH;
 extern "C" int synth_generate(uint32_t seed, uint32_t chr, int64_t len, int64_t gap0_end, int64_t gap1_start, int64_t gap1_end, uint32_t baseCN,
                               const uint32_t* d_thr, uint8_t* d_bases, uint8_t* d_hits, uint64_t* d_mask, void* stream) {
     SynthParams P{seed, chr, len, gap0_end, gap1_start, gap1_end, baseCN};

@@ -14,6 +14,11 @@
 #include <vector>
 #include "../../include/canvas_hip.h"
 
+#ifndef CANVAS_SRC_HASH
+#define CANVAS_SRC_HASH "unhashed-build-0000000000000000"
+#endif
+__attribute__((used)) static const char tool_src_hash_marker[] = "CANVAS_SRC_HASH=" CANVAS_SRC_HASH;
+
 namespace tool {
 
 // ---- NDesk.OptionSet-like parsing: -x value, -x=value, --long value, --long=value, /x value; flags without value

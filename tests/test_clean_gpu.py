@@ -175,3 +175,16 @@ def test_merge_cleaned_keeps_bins_present_in_every_sample():
     from canvas_amd.lib import CanvasError
     with pytest.raises(CanvasError):
         cv.merge_cleaned([dev[0], bad], [len(samples[0]["chr"]), len(samples[1]["chr"])])
+
+
+def test_clean_rejects_out_of_range_gc_and_chromosome():
+    """a malformed .binned row (gc outside 0..100, chromosome index outside the table) makes the reference throw IndexOutOfRangeException;
+    the library refuses it instead of indexing past its GC tables"""
+    from canvas_amd.lib import CanvasError
+    cv = get_canvas()
+    for field, value in (("gc", 101), ("gc", -1), ("gc", 150), ("chr", 24), ("chr", -2)):
+        bins = synth.generate_bins(20260927 + 5, 20_000)
+        bins[field] = bins[field].copy(); bins[field][12_345] = value
+        dev = {k: to_dev(v, cv.device) for k, v in bins.items()}
+        with pytest.raises(CanvasError, match="gc outside 0..100"):
+            cv.clean(dev, len(bins["chr"]), synth.IS_AUTOSOME, ALL)
