@@ -1002,7 +1002,9 @@ __global__ void __launch_bounds__(256) k_fill_i32(int32_t* __restrict__ p, int64
 // ---- segment ids
 __global__ void __launch_bounds__(256) k_seg_flags(const int64_t* __restrict__ chrOff, int nchr, const int32_t* __restrict__ state, const int32_t* __restrict__ start,
                                                    const int32_t* __restrict__ stop, int64_t n, int32_t maxDist, const int64_t* __restrict__ exclOff,
-                                                   const int32_t* __restrict__ exclStart, const int32_t* __restrict__ exclStop, uint8_t* __restrict__ flags) {
+                                                   const int32_t* __restrict__ exclStart, const int32_t* __restrict__ exclStop,
+                                                   const int64_t* __restrict__ plOff, const int32_t* __restrict__ plStart, const int32_t* __restrict__ plEnd, const int32_t* __restrict__ plCn,
+                                                   uint8_t* __restrict__ flags) {
     __shared__ int64_t sOff[CHR_LDS_CAP];
     const int64_t* off = stage_chr_offsets(chrOff, nchr, sOff);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1026,6 +1028,25 @@ __global__ void __launch_bounds__(256) k_seg_flags(const int64_t* __restrict__ c
     if (!newSeg && !first) {
         uint32_t prevEnd = (uint32_t)stop[i - 1];
         if (prevEnd > 0 && maxDist >= 0 && (uint64_t)prevEnd + (uint64_t)maxDist < (uint64_t)(uint32_t)start[i]) newSeg = true;   // SegmentationResultsProcessor.cs:112-116
+    }
+    if (!newSeg && plOff) {
+        // reference ploidy changes between the end of the previous bin and the end of this one (SegmentationResultsProcessor.cs:117-128):
+        // PloidyInfo.getPloidyCounts over the one-based interval [previousBinEnd > 0 ? previousBinEnd : 1, end] (PloidyInfo.cs:93-110); a chromosome
+        // has a handful of records (PAR / non-PAR stretches of the sex chromosomes), so every bin walks its chromosome's list
+        const uint32_t prevEnd = first ? 0u : (uint32_t)stop[i - 1];
+        const int qs = prevEnd > 0 ? (int)prevEnd : 1, qe = (int)(uint32_t)stop[i];
+        int bc0 = 0, bc1 = 0, bc2 = qe - qs + 1, bc3 = 0, bc4 = 0;
+        for (int64_t k = plOff[lo]; k < plOff[lo + 1]; k++) {
+            const int p = plCn[k];
+            if (p == 2) continue;
+            const int overlapStart = max(qs - 1, plStart[k] - 1);
+            if (overlapStart > plEnd[k]) continue;
+            const int overlapBases = min(qe, plEnd[k]) - overlapStart;
+            if (overlapBases <= 0) continue;
+            bc2 -= overlapBases;
+            bc0 += p == 0 ? overlapBases : 0; bc1 += p == 1 ? overlapBases : 0; bc3 += p == 3 ? overlapBases : 0; bc4 += p == 4 ? overlapBases : 0;
+        }
+        if ((bc0 > 0) + (bc1 > 0) + (bc2 > 0) + (bc3 > 0) + (bc4 > 0) >= 2) newSeg = true;
     }
     flags[i] = newSeg;
 }
@@ -1566,9 +1587,10 @@ extern "C" int32_t canvas_hmm_joint(canvas_ctx* ctx, int32_t nsamples, int32_t n
 
 extern "C" {
 
-int32_t canvas_segment_ids_filtered(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
-                                    const int32_t* d_stop, int32_t max_inter_bin_dist, const int64_t* h_excl_offset, const int32_t* h_excl_start,
-                                    const int32_t* h_excl_stop, int32_t* d_segment_id, int64_t* h_nsegments) {
+int32_t canvas_segment_ids_ploidy(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
+                                  const int32_t* d_stop, int32_t max_inter_bin_dist, const int64_t* h_excl_offset, const int32_t* h_excl_start,
+                                  const int32_t* h_excl_stop, const int64_t* h_ploidy_offset, const int32_t* h_ploidy_start, const int32_t* h_ploidy_end,
+                                  const int32_t* h_ploidy_cn, int32_t* d_segment_id, int64_t* h_nsegments) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !h_chr_offset || !d_state || !d_start || !d_stop || !d_segment_id) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_segment_ids: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1579,19 +1601,32 @@ int32_t canvas_segment_ids_filtered(canvas_ctx* ctx, int32_t nchr, const int64_t
     if (h_excl_offset && nex > 0 && (!h_excl_start || !h_excl_stop)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_segment_ids_filtered: missing interval arrays");
     if (h_excl_offset) for (int c = 0; c < nchr; c++) for (int64_t k = h_excl_offset[c] + 1; k < h_excl_offset[c + 1]; k++)
         if (h_excl_stop[k] < h_excl_stop[k - 1]) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "forbidden intervals must be sorted by end within a chromosome");
+    const int64_t npl = h_ploidy_offset ? h_ploidy_offset[nchr] : 0;
+    if (h_ploidy_offset && npl > 0 && (!h_ploidy_start || !h_ploidy_end || !h_ploidy_cn)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_segment_ids_ploidy: missing ploidy arrays");
+    for (int64_t k = 0; k < npl; k++) if (h_ploidy_cn[k] < 0 || h_ploidy_cn[k] > 4)
+        CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "reference ploidy outside 0..4 (PloidyInfo.getPloidyCounts indexes a 5-element array: the reference throws)");
     WsSizer sz; sz.take<int64_t>(nchr + 1); sz.take<uint8_t>(N); sz.take<uint32_t>(nb + 1); sz.take<unsigned long long>(1);
     sz.take<int64_t>(nchr + 1); sz.take<int32_t>(nex + 1); sz.take<int32_t>(nex + 1);
+    sz.take<int64_t>(nchr + 1); sz.take<int32_t>(npl + 1); sz.take<int32_t>(npl + 1); sz.take<int32_t>(npl + 1);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     WsCarver ws(ctx->ws);
     int64_t* dOff = ws.take<int64_t>(nchr + 1); uint8_t* flags = ws.take<uint8_t>(N); uint32_t* blockCnt = ws.take<uint32_t>(nb + 1); unsigned long long* dTot = ws.take<unsigned long long>(1);
     int64_t* dExOff = ws.take<int64_t>(nchr + 1); int32_t* dExStart = ws.take<int32_t>(nex + 1); int32_t* dExStop = ws.take<int32_t>(nex + 1);
+    int64_t* dPlOff = ws.take<int64_t>(nchr + 1); int32_t* dPlStart = ws.take<int32_t>(npl + 1); int32_t* dPlEnd = ws.take<int32_t>(npl + 1); int32_t* dPlCn = ws.take<int32_t>(npl + 1);
+    if (h_ploidy_offset) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dPlOff, h_ploidy_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (npl > 0) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dPlStart, h_ploidy_start, npl * 4, hipMemcpyHostToDevice, ctx->stream));
+                       CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dPlEnd, h_ploidy_end, npl * 4, hipMemcpyHostToDevice, ctx->stream));
+                       CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dPlCn, h_ploidy_cn, npl * 4, hipMemcpyHostToDevice, ctx->stream)); }
+    }
     if (h_excl_offset) {
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dExOff, h_excl_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         if (nex > 0) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dExStart, h_excl_start, nex * 4, hipMemcpyHostToDevice, ctx->stream));
                        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dExStop, h_excl_stop, nex * 4, hipMemcpyHostToDevice, ctx->stream)); }
     }
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, h_chr_offset, (nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_seg_flags, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dOff, nchr, d_state, d_start, d_stop, N, max_inter_bin_dist, h_excl_offset ? dExOff : (const int64_t*)nullptr, dExStart, dExStop, flags);
+    hipLaunchKernelGGL(k_seg_flags, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dOff, nchr, d_state, d_start, d_stop, N, max_inter_bin_dist, h_excl_offset ? dExOff : (const int64_t*)nullptr, dExStart, dExStop,
+                       h_ploidy_offset ? dPlOff : (const int64_t*)nullptr, dPlStart, dPlEnd, dPlCn, flags);
     hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(256), 0, ctx->stream, flags, N, blockCnt);
     hipLaunchKernelGGL(k_scan_blocks2, dim3(1), dim3(1024), 0, ctx->stream, blockCnt, nb, dTot);
     hipLaunchKernelGGL(k_seg_ids, dim3(nb), dim3(256), 0, ctx->stream, flags, blockCnt, N, d_segment_id);
@@ -1601,6 +1636,13 @@ int32_t canvas_segment_ids_filtered(canvas_ctx* ctx, int32_t nchr, const int64_t
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     if (h_nsegments) *h_nsegments = (int64_t)tot;
     return CANVAS_OK;
+}
+
+int32_t canvas_segment_ids_filtered(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
+                                    const int32_t* d_stop, int32_t max_inter_bin_dist, const int64_t* h_excl_offset, const int32_t* h_excl_start,
+                                    const int32_t* h_excl_stop, int32_t* d_segment_id, int64_t* h_nsegments) {
+    return canvas_segment_ids_ploidy(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, h_excl_offset, h_excl_start, h_excl_stop,
+                                     nullptr, nullptr, nullptr, nullptr, d_segment_id, h_nsegments);
 }
 
 int32_t canvas_segment_ids(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,

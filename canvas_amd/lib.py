@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
-    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
+    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -257,13 +257,32 @@ class Canvas:
         self._check(self.lib.canvas_hmm_joint(self.ctx, len(covs), len(off) - 1, ptrs, _np_ptr(off), C.c_void_p(state.data_ptr())))
         return state
 
-    def segment_ids(self, chr_offset, state, start, stop, max_inter_bin_dist=1000000, excluded=None, out=None):
-        """DeriveSegments + PostProcessSegments; excluded = per-chromosome list of (starts, stops) of the -b BED file"""
+    def evenness_score(self, cov, chr_offset, window=100000):
+        """SegmentationInput.GetEvennessScore (Segmentation.cs:260-296): the value of --evenness-metric-file, or None when the reference writes no file"""
+        off = np.ascontiguousarray(chr_offset, np.int64)
+        score = C.c_double(0); valid = C.c_int32(0)
+        self._check(self.lib.canvas_evenness_score(self.ctx, len(off) - 1, C.c_void_p(cov.data_ptr()), _np_ptr(off), int(window), C.byref(score), C.byref(valid)))
+        return score.value if valid.value else None
+
+    def segment_ids(self, chr_offset, state, start, stop, max_inter_bin_dist=1000000, excluded=None, out=None, ploidy=None):
+        """DeriveSegments + PostProcessSegments; excluded = per-chromosome list of (starts, stops) of the -b BED file; ploidy = per-chromosome list
+        of (one-based starts, ends, copy numbers) of the -p VCF"""
         torch = self.torch
         off = np.ascontiguousarray(chr_offset, np.int64)
         seg = out[:int(off[-1])] if out is not None else torch.empty(int(off[-1]), dtype=torch.int32, device=self.device)
         nseg = C.c_int64(0)
-        if excluded is None:
+        if ploidy is not None:
+            cat = lambda k, src: np.ascontiguousarray(np.concatenate([np.asarray(e[k], np.int32) for e in src] + [np.zeros(1, np.int32)]), np.int32)
+            po = np.concatenate([[0], np.cumsum([len(e[0]) for e in ploidy])]).astype(np.int64)
+            ps, pe, pc = cat(0, ploidy), cat(1, ploidy), cat(2, ploidy)
+            if excluded is not None:
+                eo = np.concatenate([[0], np.cumsum([len(e[0]) for e in excluded])]).astype(np.int64); es, ee = cat(0, excluded), cat(1, excluded)
+            self._check(self.lib.canvas_segment_ids_ploidy(self.ctx, len(off) - 1, _np_ptr(off), C.c_void_p(state.data_ptr()), C.c_void_p(start.data_ptr()),
+                                                           C.c_void_p(stop.data_ptr()), max_inter_bin_dist,
+                                                           _np_ptr(eo) if excluded is not None else None, _np_ptr(es) if excluded is not None else None,
+                                                           _np_ptr(ee) if excluded is not None else None, _np_ptr(po), _np_ptr(ps), _np_ptr(pe), _np_ptr(pc),
+                                                           C.c_void_p(seg.data_ptr()), C.byref(nseg)))
+        elif excluded is None:
             self._check(self.lib.canvas_segment_ids(self.ctx, len(off) - 1, _np_ptr(off), C.c_void_p(state.data_ptr()), C.c_void_p(start.data_ptr()),
                                                     C.c_void_p(stop.data_ptr()), max_inter_bin_dist, C.c_void_p(seg.data_ptr()), C.byref(nseg)))
         else:

@@ -1,6 +1,12 @@
 // Drop-in CanvasPartition executable on top of the C ABI: CLI and file formats of CanvasPartition.Main (CanvasPartition/CanvasPartition.cs:24-190).
 //   CanvasPartition -i S.cleaned [-i ...] -o S.partitioned [-o ...] -r refDir [-m Wavelets|PerSampleHMM|HMM|CBS] [-g] [-v S.vaf] [-b filter.bed] [-s None|Prune|SDUndo] [--config params.json]
-// Built methods: Wavelets (the default, one sample), PerSampleHMM, HMM (joint) and CBS.  -c / -p / --evenness-metric-file are not built: exit code 1 with a message.
+// Built methods: Wavelets (the default, one sample), PerSampleHMM, HMM (joint) and CBS.
+//   -p ploidy.vcf            reference ploidy (CanvasRunner.InvokeCanvasPartition ALWAYS passes it, CanvasRunner.cs:950): a segment also starts where the reference
+//                            ploidy changes between two bins (SegmentationResultsProcessor.cs:117-128, PloidyInfo.cs:78-165)
+//   --evenness-metric-file F "#evenness\t<score>" (Somatic-WGS, CanvasRunner.cs:958-960): canvas_evenness_score; like the reference only the Wavelets method
+//                            computes it (WaveletsRunner.cs:58-67)
+//   -c commonCNVs.bed        accepted and, exactly as in the reference, unused: CanvasPartition.cs:121 hands the path to WaveletsRunnerParams.CommonCNVs
+//                            (WaveletsRunner.cs:20,34), which nothing reads; the other methods never see it (CanvasRunner.cs:916-917 passes it with PerSampleHMM)
 // Wavelets and -v: WaveletsRunner.Run only derives segments for the chromosomes of SegmentationInput.VafByChr (WaveletsRunner.cs:75), which LoadVAFInput
 // fills for every chromosome of the coverage file when -v is given and leaves empty otherwise (Segmentation.cs:78-79, 158-168).  The allele frequencies themselves
 // never reach the Wavelets method (AdjustBreakpoints gets null, WaveletsRunner.cs:71), so this tool only checks that the -v file exists.
@@ -27,6 +33,54 @@ struct BinFilter {
     }
 };
 
+// PloidyInterval (PloidyInfo.cs:182-198): one-based Start = POS, End = INFO/END, Ploidy = the sample's CN field ("." = 2)
+struct PloidyIv { int start, end, ploidy; };
+// the single-sample ploidy VCF as Isas' VcfReader exposes it to PloidyInfo.LoadPloidyFromVcfFile (PloidyInfo.cs:112-165); plain or gzip text
+static bool load_ploidy_vcf(const std::string& path, std::map<std::string, std::vector<PloidyIv>>& out, std::string& err) {
+    GzReader rd(path); if (!rd.ok()) { err = "cannot open ploidy VCF '" + path + "'"; return false; }
+    std::string row; int samples = -1;
+    while (rd.line(row)) {
+        if (row.empty()) continue;
+        if (row[0] == '#') { if (row.rfind("#CHROM", 0) == 0) { auto h = split_tab(row); samples = (int)h.size() > 9 ? (int)h.size() - 9 : 0; } continue; }
+        if (samples < 0) { err = "File '" + path + "' has no #CHROM header line"; return false; }
+        if (samples == 0) { err = "File '" + path + "' does not contain any genotype column"; return false; }
+        if (samples > 1) { err = "File '" + path + "' cannot have more than one genotype columns when no sample ID provided"; return false; }
+        auto f = split_tab(row);
+        if (f.size() < 10) { err = "malformed ploidy VCF record: " + row; return false; }
+        PloidyIv iv; iv.start = atoi(f[1].c_str()); iv.end = -1; iv.ploidy = 2;
+        bool haveEnd = false;
+        for (size_t a0 = 0; a0 <= f[7].size();) { size_t b = f[7].find(';', a0); std::string kv = f[7].substr(a0, b == std::string::npos ? b : b - a0);
+            if (kv.rfind("END=", 0) == 0) { iv.end = atoi(kv.c_str() + 4); haveEnd = true; } if (b == std::string::npos) break; a0 = b + 1; }
+        if (!haveEnd) { err = "ploidy VCF record without INFO/END: " + row; return false; }            // InfoFields["END"] throws KeyNotFoundException
+        std::vector<std::string> keys, vals;
+        for (int which = 0; which < 2; which++) { const std::string& src = f[which == 0 ? 8 : 9]; auto& dst = which == 0 ? keys : vals;
+            for (size_t a0 = 0;;) { size_t b = src.find(':', a0); dst.push_back(src.substr(a0, b == std::string::npos ? b : b - a0)); if (b == std::string::npos) break; a0 = b + 1; } }
+        bool haveCn = false;
+        for (size_t k = 0; k < keys.size() && k < vals.size(); k++) if (keys[k] == "CN") { haveCn = true; iv.ploidy = vals[k] == "." ? 2 : atoi(vals[k].c_str()); }
+        if (!haveCn) { err = "File '" + path + "' must contain one genotype CN column!"; return false; }
+        out[f[0]].push_back(iv);
+    }
+    if (samples < 0) { err = "File '" + path + "' has no #CHROM header line"; return false; }
+    if (samples == 0) { err = "File '" + path + "' does not contain any genotype column"; return false; }
+    if (samples > 1) { err = "File '" + path + "' cannot have more than one genotype columns when no sample ID provided"; return false; }
+    return true;
+}
+// PloidyInfo.IsUniformReferencePloidy over the one-based interval [qs, qe] (PloidyInfo.cs:78-110); -1: a ploidy outside 0..4 indexes past baseCounts (the reference throws)
+static int is_uniform_reference_ploidy(const std::vector<PloidyIv>& ivs, int qs, int qe) {
+    int baseCounts[5] = {0, 0, qe - qs + 1, 0, 0};
+    for (auto& iv : ivs) {
+        if (iv.ploidy == 2) continue;
+        const int overlapStart = std::max(qs - 1, iv.start - 1);
+        if (overlapStart > iv.end) continue;
+        const int overlapBases = std::min(qe, iv.end) - overlapStart;
+        if (overlapBases <= 0) continue;
+        if (iv.ploidy < 0 || iv.ploidy > 4) return -1;
+        baseCounts[2] -= overlapBases; baseCounts[iv.ploidy] += overlapBases;
+    }
+    int nonZero = 0; for (int v : baseCounts) if (v > 0) nonZero++;
+    return nonZero < 2 ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     printf(">>>Command-line arguments:\n"); for (int i = 1; i < argc; i++) printf("%s ", argv[i]); printf("\n");
     std::vector<Opt> opts = {{"i", "infile", true}, {"v", "vaffile", true}, {"o", "outfile", true}, {"m", "method", true}, {"r", "reference", true}, {"s", "split", true},
@@ -43,7 +97,13 @@ int main(int argc, char** argv) {
     if (!bed.empty() && !file_exists(bed)) { printf("CanvasPartition.exe: File %s does not exist! Exiting.\n", bed.c_str()); return 1; }
     std::string method = a.get("method", "Wavelets");
     if (method != "PerSampleHMM" && method != "CBS" && method != "HMM" && method != "Wavelets") { fprintf(stderr, "CanvasPartition (MI355X): unknown method %s (Wavelets, PerSampleHMM, HMM, CBS)\n", method.c_str()); return 1; }
-    if (a.has("ploidyVcfFile") || a.has("commoncnvs") || a.has("evenness-metric-file")) { fprintf(stderr, "CanvasPartition (MI355X): -p / -c / --evenness-metric-file are not supported by this build\n"); return 1; }
+    const std::string ploidyVcf = a.get("ploidyVcfFile");
+    if (!ploidyVcf.empty() && !file_exists(ploidyVcf)) { printf("CanvasPartition.exe: File %s does not exist! Exiting.\n", ploidyVcf.c_str()); return 1; }   // CanvasPartition.cs:96-100
+    // PloidyInfo.LoadPloidyFromVcfFileNoSampleId (PloidyInfo.cs:112-165).  `-p ""` (CanvasRunner.cs:950 with no ploidy VCF configured) reaches the loader in the
+    // reference as well (ploidyVcfPath != null, CanvasPartition.cs:114) and throws there: same outcome here, exit code 1.
+    std::map<std::string, std::vector<PloidyIv>> ploidyByChrom; const bool havePloidy = a.has("ploidyVcfFile");
+    if (havePloidy) { std::string err; if (!load_ploidy_vcf(ploidyVcf, ploidyByChrom, err)) { fprintf(stderr, "CanvasPartition: %s\n", err.c_str()); return 1; } }
+    const std::string evennessFile = a.get("evenness-metric-file");
     for (auto& f : a.all("vaffile")) if (!file_exists(f)) { printf("CanvasPartition.exe: File %s does not exist! Exiting.\n", f.c_str()); return 1; }
     if (method == "Wavelets" && inFiles.size() != 1) { fprintf(stderr, "CanvasPartition: -m Wavelets takes exactly one sample (segmentationInputs.Single(), CanvasPartition.cs:125)\n"); return 1; }
     if (inFiles.size() != outFiles.size()) { fprintf(stderr, "CanvasPartition: the number of -o must match the number of -i\n"); return 1; }
@@ -115,6 +175,13 @@ int main(int argc, char** argv) {
         Dev dCov(ctx, N * 8); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCov.p, S.cov.data(), N * 8));
         if (method == "Wavelets") {
             printf("Running Wavelet Partitioning\n");
+            if (!evennessFile.empty()) {      // WaveletsRunner.cs:58-67: score first, "#evenness\t<double>" (IO.cs:88-98); no file when the reference's Quartiles / Median throw
+                double score = 0; int32_t valid = 0;
+                TOOL_TRY(ctx, canvas_evenness_score(ctx, nchr, dCov.as<double>(), S.off.data(), evennessWindow, &score, &valid));
+                if (valid) { FILE* ef = fopen(evennessFile.c_str(), "wb"); if (!ef) { fprintf(stderr, "cannot write %s\n", evennessFile.c_str()); return 1; }
+                    fprintf(ef, "#evenness\t%s\n", format_g(score, 15).c_str()); fclose(ef); }
+                else fprintf(stderr, "Unable to calculate an evenness score, using coverage for segmentation\n");
+            }
             std::vector<int32_t> bps((size_t)N + nchr + 1); std::vector<int64_t> bo(nchr + 1);
             TOOL_TRY(ctx, canvas_wavelets(ctx, nchr, dCov.as<double>(), S.off.data(), a.has("germline") ? 1 : 0, thresholdLowerMaf, 80.0, madFactor, evennessWindow, 10,
                                           bps.data(), (int64_t)bps.size(), bo.data()));
@@ -172,6 +239,7 @@ int main(int argc, char** argv) {
             const std::string& chrom = S.chromNames[c];
             std::set<uint32_t> starts; auto mit = merged.find(chrom); if (mit != merged.end()) for (auto& sg : mit->second) starts.insert(sg.first);
             const std::vector<std::pair<int, int>>* ex = nullptr; auto eit = excluded.find(chrom); if (eit != excluded.end()) ex = &eit->second;
+            const std::vector<PloidyIv>* pl = nullptr; if (havePloidy) { auto pit = ploidyByChrom.find(chrom); if (pit != ploidyByChrom.end()) pl = &pit->second; }
             size_t exIdx = 0; uint32_t prevEnd = 0;
             struct Row { uint32_t s, e; double cov; int id; }; std::vector<Row> rows;
             for (int64_t b = S.off[c]; b < S.off[c + 1]; b++) {
@@ -180,6 +248,11 @@ int main(int argc, char** argv) {
                 if (ex) { while (exIdx < ex->size() && (int64_t)(*ex)[exIdx].second < (int64_t)prevEnd) exIdx++;
                     if (exIdx < ex->size()) { int mid = ((*ex)[exIdx].first + (*ex)[exIdx].second) / 2; if ((int64_t)prevEnd < mid && (int64_t)en >= mid) newSeg = true; } }
                 if (prevEnd > 0 && maxInterBinDist >= 0 && (int64_t)prevEnd + maxInterBinDist < (int64_t)st && !newSeg) newSeg = true;
+                if (!newSeg && pl) {                                          // SegmentationResultsProcessor.cs:117-128
+                    const int u = is_uniform_reference_ploidy(*pl, prevEnd > 0 ? (int)prevEnd : 1, (int)en);
+                    if (u < 0) { fprintf(stderr, "CanvasPartition: reference ploidy outside 0..4 on %s (the reference throws IndexOutOfRangeException)\n", chrom.c_str()); return 1; }
+                    if (!u) newSeg = true;
+                }
                 if (newSeg) segmentNum++;
                 rows.push_back({st, en, S.cov[b], segmentNum});
                 prevEnd = en;

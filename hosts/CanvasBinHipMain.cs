@@ -1,0 +1,66 @@
+// CanvasBin with the GPU library: the patch to CanvasBin.RunSingleSample (Src/Canvas/CanvasBin/CanvasBin.cs:914-931) and, through it, to
+// SampleHitArrays.GetRates / GetBinSize (:30-83) and BinCounts / BinCountsForChromosome (:416-661).
+// Kept from the module: Program.Main and its options, the per-chromosome BAM pass (-c, :207-275) and LoadIntermediateData (:965-1035).
+// NOT COMPILED HERE (no dotnet SDK in the image); canvas_amd/tools/canvas_bin_main.cpp is the same program in C++ and is what the tests run.
+using System;
+using System.Collections;
+using System.Collections.Generic;
+using System.Linq;
+using CanvasCommon;
+using Isas.SequencingFiles;
+using static CanvasHipInterop.CanvasHip;
+
+namespace CanvasBin
+{
+    static class HipBin
+    {
+        /// <param name="bases">chromosome -> reference bases (StringBuilder / byte[] of the kmer.fa entry)</param>
+        /// <param name="possible">chromosome -> possible-alignment BitArray (CanvasBin.cs:183-200, after the BED exclusion :668-692)</param>
+        /// <param name="observed">chromosome -> HitArray (already screened, :699-716)</param>
+        /// <param name="fragmentLengths">chromosome -> Int16[] (GCContentWeighted mode only)</param>
+        public static List<SampleGenomicBin> Run(List<string> chromosomes, IDictionary<string, byte[]> bases, IDictionary<string, BitArray> possible,
+            IDictionary<string, HitArray> observed, IDictionary<string, short[]> fragmentLengths, CanvasBinParameters parameters, out int binSizeUsed)
+        {
+            IntPtr ctx = canvas_create(0);
+            if (ctx == IntPtr.Zero) throw new InvalidOperationException("no usable GPU (libcanvas_hip has no CPU fallback)");
+            var owned = new List<DeviceBuffer>();
+            try
+            {
+                int nchr = chromosomes.Count;
+                var len = new long[nchr]; var dBases = new IntPtr[nchr]; var dMask = new IntPtr[nchr]; var dHits = new IntPtr[nchr]; var dFrag = new IntPtr[nchr];
+                for (int c = 0; c < nchr; c++)
+                {
+                    string chr = chromosomes[c]; long L = bases[chr].Length; len[c] = L; long padded = (L + 63) / 64 * 64;
+                    var maskBytes = new byte[padded / 8]; possible[chr].CopyTo(maskBytes, 0);                      // BitArray order == the library's mask layout
+                    DeviceBuffer b = new DeviceBuffer(ctx, padded), m = new DeviceBuffer(ctx, padded / 8), h = new DeviceBuffer(ctx, padded);
+                    owned.Add(b); owned.Add(m); owned.Add(h);
+                    Check(ctx, canvas_memcpy_h2d(ctx, b.Ptr, bases[chr], L), "upload bases"); Check(ctx, canvas_memcpy_h2d(ctx, m.Ptr, maskBytes, maskBytes.Length), "upload mask");
+                    Check(ctx, canvas_memcpy_h2d(ctx, h.Ptr, observed[chr].Data, L), "upload hits");
+                    dBases[c] = b.Ptr; dMask[c] = m.Ptr; dHits[c] = h.Ptr;
+                    if (parameters.coverageMode == CanvasCoverageMode.GCContentWeighted)
+                    { var f = new DeviceBuffer(ctx, 2 * padded); owned.Add(f); Check(ctx, canvas_memcpy_h2d(ctx, f.Ptr, fragmentLengths[chr], 2 * L), "upload fragment lengths"); dFrag[c] = f.Ptr; }
+                }
+                byte[] isAutosome = chromosomes.Select(c => (byte)(GenomeMetadata.SequenceMetadata.IsAutosome(c) ? 1 : 0)).ToArray();   // CanvasBin.cs:44
+                long cap = len.Sum() / Math.Max(1, parameters.binSize > 0 ? parameters.binSize : 50) + nchr + 16;
+                var cols = Enumerable.Range(0, 5).Select(_ => new DeviceBuffer(ctx, 4 * cap)).ToList(); owned.AddRange(cols);
+                var perChr = new long[nchr]; long total;
+                if (parameters.coverageMode == CanvasCoverageMode.GCContentWeighted)
+                    Check(ctx, canvas_bin_sample_gcweighted(ctx, nchr, dBases, dMask, dHits, dFrag, len, isAutosome, parameters.countsPerBin, parameters.binSize,
+                                                            cols[0].Ptr, cols[1].Ptr, cols[2].Ptr, cols[3].Ptr, cols[4].Ptr, cap, out binSizeUsed, perChr, out total), "canvas_bin_sample_gcweighted");
+                else
+                    Check(ctx, canvas_bin_sample(ctx, nchr, dBases, dMask, dHits, len, isAutosome, parameters.countsPerBin, parameters.binSize, (int)parameters.coverageMode,
+                                                 cols[0].Ptr, cols[1].Ptr, cols[2].Ptr, cols[3].Ptr, cols[4].Ptr, cap, out binSizeUsed, perChr, out total), "canvas_bin_sample");
+                int[] chrIdx = new int[total], start = new int[total], stop = new int[total], gc = new int[total]; float[] count = new float[total];
+                Check(ctx, canvas_memcpy_d2h(ctx, chrIdx, cols[0].Ptr, 4 * total), "download"); Check(ctx, canvas_memcpy_d2h(ctx, start, cols[1].Ptr, 4 * total), "download");
+                Check(ctx, canvas_memcpy_d2h(ctx, stop, cols[2].Ptr, 4 * total), "download"); Check(ctx, canvas_memcpy_d2h(ctx, gc, cols[3].Ptr, 4 * total), "download");
+                Check(ctx, canvas_memcpy_d2h(ctx, count, cols[4].Ptr, 4 * total), "download");
+                var bins = new List<SampleGenomicBin>((int)total);
+                for (long i = 0; i < total; i++) bins.Add(new SampleGenomicBin(chromosomes[chrIdx[i]], start[i], stop[i], gc[i], count[i]));
+                return bins;                                                          // CanvasIO.WriteToTextFile(parameters.outFile, bins) as before (:929)
+            }
+            finally { foreach (var d in owned) d.Dispose(); canvas_destroy(ctx); }
+        }
+        // parameters.binSize == -1 lets the library derive the size from the autosomes' rates (countsPerBin / median rate, :73-83); with -y the module
+        // writes binSizeUsed to "<outFile>.binsize" (:927) and stops.  Predefined bins (-n), manifests (-t) and Fragment mode keep the module's C# path.
+    }
+}

@@ -1,0 +1,81 @@
+// P/Invoke binding of libcanvas_hip.so (include/canvas_hip.h) for the three Canvas modules.  Host code stays C# (netcore): the modules keep their
+// Main, option parsing and file readers / writers and call the entry points below instead of their compute loops.
+// NOT COMPILED IN THIS REPOSITORY'S IMAGE (no dotnet SDK; Illumina.Common / Isas.* are private NuGet packages).  The same ABI is exercised by
+// canvas_amd/lib.py (ctypes) and by the C++ drop-in tools under canvas_amd/tools/, which are what the test-suite runs.
+using System;
+using System.Runtime.InteropServices;
+
+namespace CanvasHipInterop
+{
+    internal static class CanvasHip
+    {
+        const string Lib = "canvas_hip";   // libcanvas_hip.so next to the module's dll, or on LD_LIBRARY_PATH
+
+        public const int ModeBinary = 0, ModeTruncatedDynamicRange = 3, ModeGCContentWeighted = 5;                 // Utilities.cs:56-74
+        public const uint CleanGcNorm = 1, CleanFiltSize = 2, CleanOutliers = 4, CleanLocalSd = 8, CleanLoess = 16;  // CanvasClean.cs:431-446
+
+        // ---- context, memory
+        [DllImport(Lib)] public static extern IntPtr canvas_create(int device);
+        [DllImport(Lib)] public static extern void canvas_destroy(IntPtr ctx);
+        [DllImport(Lib)] public static extern IntPtr canvas_last_error(IntPtr ctx);
+        [DllImport(Lib)] public static extern IntPtr canvas_version();
+        [DllImport(Lib)] public static extern int canvas_synchronize(IntPtr ctx);
+        [DllImport(Lib)] public static extern IntPtr canvas_device_malloc(IntPtr ctx, long bytes);
+        [DllImport(Lib)] public static extern int canvas_device_free(IntPtr ctx, IntPtr dptr);
+        [DllImport(Lib)] public static extern int canvas_memcpy_h2d(IntPtr ctx, IntPtr dDst, byte[] hSrc, long bytes);
+        [DllImport(Lib)] public static extern int canvas_memcpy_h2d(IntPtr ctx, IntPtr dDst, short[] hSrc, long bytes);
+        [DllImport(Lib)] public static extern int canvas_memcpy_h2d(IntPtr ctx, IntPtr dDst, int[] hSrc, long bytes);
+        [DllImport(Lib)] public static extern int canvas_memcpy_h2d(IntPtr ctx, IntPtr dDst, float[] hSrc, long bytes);
+        [DllImport(Lib)] public static extern int canvas_memcpy_h2d(IntPtr ctx, IntPtr dDst, double[] hSrc, long bytes);
+        [DllImport(Lib)] public static extern int canvas_memcpy_d2h(IntPtr ctx, int[] hDst, IntPtr dSrc, long bytes);
+        [DllImport(Lib)] public static extern int canvas_memcpy_d2h(IntPtr ctx, float[] hDst, IntPtr dSrc, long bytes);
+
+        // ---- CanvasBin
+        [DllImport(Lib)] public static extern int canvas_mask_from_fasta(IntPtr ctx, IntPtr dBases, long len, IntPtr dMask);
+        [DllImport(Lib)] public static extern int canvas_mask_exclude_intervals(IntPtr ctx, IntPtr dMask, long len, int n, int[] start, int[] stop);
+        [DllImport(Lib)] public static extern int canvas_screen_hits(IntPtr ctx, IntPtr dHits, IntPtr dMask, long len);
+        [DllImport(Lib)] public static extern int canvas_bin_rates(IntPtr ctx, int nchr, IntPtr[] dHits, IntPtr[] dMask, long[] len, long[] observed, long[] possible, double[] rate);
+        [DllImport(Lib)] public static extern int canvas_bin_size_from_rates(double[] rates, int n, int countsPerBin);
+        [DllImport(Lib)] public static extern long canvas_bin_count_upper_bound(int nchr, long[] len, int binSize);
+        [DllImport(Lib)] public static extern int canvas_bin_sample(IntPtr ctx, int nchr, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, long[] len, byte[] chrIsAutosome,
+            int countsPerBin, int binSizeIn, int mode, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, long[] nbinsPerChr, out long nbinsTotal);
+        [DllImport(Lib)] public static extern int canvas_bin_sample_gcweighted(IntPtr ctx, int nchr, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, IntPtr[] dFragLen, long[] len,
+            byte[] chrIsAutosome, int countsPerBin, int binSizeIn, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, long[] nbinsPerChr, out long nbinsTotal);
+
+        // ---- CanvasClean
+        [DllImport(Lib)] public static extern int canvas_clean2(IntPtr ctx, long n, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dCount, IntPtr dGc, int nchr,
+            byte[] chrIsAutosome, byte[] chrIsY, uint flags, int minBinsPerGc, out double localSd, out long nOut, int[] info8);
+
+        // ---- CanvasPartition
+        [DllImport(Lib)] public static extern int canvas_evenness_score(IntPtr ctx, int nchr, IntPtr dCov, long[] chrOffset, int windowSize, out double score, out int valid);
+        [DllImport(Lib)] public static extern int canvas_wavelets(IntPtr ctx, int nchr, IntPtr dCov, long[] chrOffset, int isGermline, double thresholdLower, double thresholdUpper,
+            double madFactor, int variabilityWindow, int minSize, int[] breakpoints, long cap, long[] bpOffset);
+        [DllImport(Lib)] public static extern int canvas_cbs_undo(IntPtr ctx, int nchr, IntPtr dCov, long[] chrOffset, double alpha, uint nperm, int undo, double undoSd,
+            IntPtr dSegLen, int[] nseg, long[] stats8);
+        [DllImport(Lib)] public static extern int canvas_hmm_per_sample(IntPtr ctx, int nchr, IntPtr dCov, long[] chrOffset, IntPtr dState);
+        [DllImport(Lib)] public static extern int canvas_hmm_joint(IntPtr ctx, int nsamples, int nchr, IntPtr[] dCovPerSample, long[] chrOffset, IntPtr dState);
+        [DllImport(Lib)] public static extern int canvas_segment_ids_ploidy(IntPtr ctx, int nchr, long[] chrOffset, IntPtr dState, IntPtr dStart, IntPtr dStop, int maxInterBinDist,
+            long[] exclOffset, int[] exclStart, int[] exclStop, long[] ploidyOffset, int[] ploidyStart, int[] ploidyEnd, int[] ploidyCn, IntPtr dSegmentId, out long nSegments);
+        [DllImport(Lib)] public static extern int canvas_split_overlapping(int nsamples, IntPtr[] hStart, IntPtr[] hEnd, int[] nseg, uint[] outStart, uint[] outEnd, int cap, out int nOut);
+
+        // ---- multi-GPU (one process per GPU, chromosome groups per rank; see hosts/README.md)
+        [DllImport(Lib)] public static extern int canvas_comm_unique_id(byte[] id128);
+        [DllImport(Lib)] public static extern int canvas_comm_init(IntPtr ctx, int rank, int nranks, byte[] id128);
+        [DllImport(Lib)] public static extern int canvas_allgather_boundaries(IntPtr ctx, IntPtr dLocal, int nLocal, int maxPerRank, IntPtr dAll, int[] counts);
+
+        /// <summary>Turns a non-zero status into the module's own failure convention (message on stderr, exit code 1).</summary>
+        public static void Check(IntPtr ctx, int status, string what)
+        {
+            if (status == 0) return;
+            throw new InvalidOperationException($"{what} failed ({status}): {Marshal.PtrToStringAnsi(canvas_last_error(ctx))}");
+        }
+
+        /// <summary>Device array with the lifetime of a using block.</summary>
+        public sealed class DeviceBuffer : IDisposable
+        {
+            readonly IntPtr _ctx; public IntPtr Ptr { get; }
+            public DeviceBuffer(IntPtr ctx, long bytes) { _ctx = ctx; Ptr = canvas_device_malloc(ctx, Math.Max(1, bytes)); if (Ptr == IntPtr.Zero) throw new OutOfMemoryException("canvas_device_malloc"); }
+            public void Dispose() { canvas_device_free(_ctx, Ptr); }
+        }
+    }
+}

@@ -153,6 +153,23 @@ int32_t canvas_segment_ids_filtered(canvas_ctx* ctx, int32_t nchr, const int64_t
                                     const int32_t* d_start, const int32_t* d_stop, int32_t max_inter_bin_dist,
                                     const int64_t* h_excl_offset, const int32_t* h_excl_start, const int32_t* h_excl_stop,
                                     int32_t* d_segment_id, int64_t* h_nsegments);
+/* same, with the reference ploidy of CanvasPartition -p (CanvasPartition.cs:114; CanvasRunner.InvokeCanvasPartition always passes it, CanvasRunner.cs:950):
+ * a new segment also starts where PloidyInfo.IsUniformReferencePloidy is false for the one-based interval [previous bin end (or 1), this bin's end]
+ * (SegmentationResultsProcessor.cs:117-128, PloidyInfo.cs:78-110).  h_ploidy_offset[nchr+1] indexes the records of the ploidy VCF per chromosome
+ * (PloidyInfo.LoadPloidyFromVcfFile, PloidyInfo.cs:128-165): h_ploidy_start = POS (one-based), h_ploidy_end = INFO/END, h_ploidy_cn = the CN genotype
+ * field ("." = 2), 0..4.  A chromosome without records behaves like one that is not in the VCF.  h_ploidy_offset == NULL: no -p.  The forbidden
+ * intervals are optional as above (h_excl_offset == NULL: no -b). */
+int32_t canvas_segment_ids_ploidy(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
+                                  const int32_t* d_stop, int32_t max_inter_bin_dist,
+                                  const int64_t* h_excl_offset, const int32_t* h_excl_start, const int32_t* h_excl_stop,
+                                  const int64_t* h_ploidy_offset, const int32_t* h_ploidy_start, const int32_t* h_ploidy_end, const int32_t* h_ploidy_cn,
+                                  int32_t* d_segment_id, int64_t* h_nsegments);
+/* CanvasPartition --evenness-metric-file (Somatic-WGS, CanvasRunner.cs:958-960): SegmentationInput.GetEvennessScore (Segmentation.cs:260-296) as
+ * WaveletsRunner.Run computes it before segmenting (WaveletsRunner.cs:58-67).  d_cov / h_chr_offset as for canvas_cbs; window_size =
+ * CanvasPartitionParameters.EvennessScoreWindow (100000).  *h_valid = 0 when the reference's Quartiles / Median throw (fewer than two 10000-bin windows,
+ * or no window of window_size: the reference then writes no metric file), otherwise *h_score is the value written as "#evenness\t<score>"
+ * (IO.cs:88-98).  Bit-exact: the window sums are evaluated in list order. */
+int32_t canvas_evenness_score(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t window_size, double* h_score, int32_t* h_valid);
 /* GenomeSegmentationResults.SplitOverlappingSegments (GenomeSegmentationResults.cs:18-55) for one chromosome: host scalar code. */
 int32_t canvas_split_overlapping(int32_t nsamples, const uint32_t* const* h_start, const uint32_t* const* h_end, const int32_t* h_nseg,
                                  uint32_t* h_out_start, uint32_t* h_out_end, int32_t cap, int32_t* h_nout);

@@ -139,12 +139,41 @@ int orc_split_overlapping(int nSamples, const uint32_t* const* starts, const uin
     return SplitOverlapping(nSamples, starts, ends, nseg, outStart, outEnd, cap);
 }
 
-// SegmentationResultsProcessor.PostProcessSegments (CanvasPartition/SegmentationResultsProcessor.cs:17-129), referencePloidy == null.
+// PloidyInfo.getPloidyCounts + IsUniformReferencePloidy (CanvasCommon/PloidyInfo.cs:78-110) for the query interval [oneBasedStart, oneBasedEnd]
+// (Isas.SequencingFiles.Interval is not in /root/reference: one-based inclusive, Length = end - start + 1 — assumption, see oracle_common.h).
+// Intervals are the chromosome's ploidy.vcf records (one-based Start = POS, End = INFO/END, Ploidy = CN) in file order.
+// Returns 1 when uniform, 0 when not, -1 when a ploidy outside 0..4 would index past baseCounts (the C# throws IndexOutOfRangeException).
+static int IsUniformReferencePloidy(int64_t oneBasedStart, int64_t oneBasedEnd, int nIv, const int32_t* ivStart, const int32_t* ivEnd, const int32_t* ivPloidy) {
+    int baseCounts[5] = {0, 0, 0, 0, 0};
+    baseCounts[2] = (int)(oneBasedEnd - oneBasedStart + 1);
+    for (int k = 0; k < nIv; k++) {
+        if (ivPloidy[k] == 2) continue;
+        int overlapStart = std::max((int)oneBasedStart - 1, ivStart[k] - 1);
+        if (overlapStart > ivEnd[k]) continue;
+        int overlapEnd = std::min((int)oneBasedEnd, ivEnd[k]);
+        int overlapBases = overlapEnd - overlapStart;
+        if (overlapBases <= 0) continue;
+        if (ivPloidy[k] < 0 || ivPloidy[k] > 4) return -1;
+        baseCounts[2] -= overlapBases;
+        baseCounts[ivPloidy[k]] += overlapBases;
+    }
+    int nonZeroCount = 0;
+    for (int cn = 0; cn < 5; cn++) if (baseCounts[cn] > 0) nonZeroCount++;
+    return nonZeroCount < 2 ? 1 : 0;
+}
+int orc_is_uniform_reference_ploidy(int64_t oneBasedStart, int64_t oneBasedEnd, int nIv, const int32_t* ivStart, const int32_t* ivEnd, const int32_t* ivPloidy) {
+    return IsUniformReferencePloidy(oneBasedStart, oneBasedEnd, nIv, ivStart, ivEnd, ivPloidy);
+}
+
+// SegmentationResultsProcessor.PostProcessSegments (CanvasPartition/SegmentationResultsProcessor.cs:17-129).
 // Chromosomes are given in CoverageInfo (file) order. segStart[c] lists the segment starts of chromosome c (may be empty: Q17).
-// excl*: forbidden intervals per chromosome. Output: segment id per bin; returns the final counter value.
-int orc_postprocess(int nchr, const int64_t* nbins, const uint32_t* const* binStart, const uint32_t* const* binEnd,
-                    const int* nseg, const uint32_t* const* segStart, const int* nexcl, const int32_t* const* exclStart,
-                    const int32_t* const* exclStop, int maxInterBinDist, int32_t* const* segId) {
+// excl*: forbidden intervals per chromosome.  nploidy == NULL: referencePloidy == null; otherwise nploidy[c] = -1 when the chromosome is not a key of
+// PloidyByChromosome (IsUniformReferencePloidy returns true, PloidyInfo.cs:80-81), else the number of its intervals.
+// Output: segment id per bin; returns the final counter value (-1000 if a ploidy outside 0..4 was hit: the reference throws).
+int orc_postprocess_ploidy(int nchr, const int64_t* nbins, const uint32_t* const* binStart, const uint32_t* const* binEnd,
+                           const int* nseg, const uint32_t* const* segStart, const int* nexcl, const int32_t* const* exclStart,
+                           const int32_t* const* exclStop, int maxInterBinDist, const int* nploidy, const int32_t* const* plStart,
+                           const int32_t* const* plEnd, const int32_t* const* plCn, int32_t* const* segId) {
     int segmentNum = -1;
     for (int c = 0; c < nchr; c++) {
         std::set<uint32_t> starts(segStart[c], segStart[c] + nseg[c]);
@@ -162,6 +191,11 @@ int orc_postprocess(int nchr, const int64_t* nbins, const uint32_t* const* binSt
                 }
             }
             if (previousBinEnd > 0 && maxInterBinDist >= 0 && (int64_t)previousBinEnd + maxInterBinDist < (int64_t)start && !newSegment) newSegment = true;
+            if (!newSegment && nploidy && nploidy[c] >= 0) {                                   // :117-128
+                int u = IsUniformReferencePloidy(previousBinEnd > 0 ? previousBinEnd : 1, end, nploidy[c], plStart[c], plEnd[c], plCn[c]);
+                if (u < 0) return -1000;
+                if (!u) newSegment = true;
+            }
             if (newSegment) { segmentNum++; haveCurrent = true; }
             else if (!haveCurrent) haveCurrent = true;   // new SegmentWithBins(segmentNum, bin) re-using the current counter (Q17)
             segId[c][b] = segmentNum;
@@ -169,6 +203,51 @@ int orc_postprocess(int nchr, const int64_t* nbins, const uint32_t* const* binSt
         }
     }
     return segmentNum;
+}
+int orc_postprocess(int nchr, const int64_t* nbins, const uint32_t* const* binStart, const uint32_t* const* binEnd,
+                    const int* nseg, const uint32_t* const* segStart, const int* nexcl, const int32_t* const* exclStart,
+                    const int32_t* const* exclStop, int maxInterBinDist, int32_t* const* segId) {
+    return orc_postprocess_ploidy(nchr, nbins, binStart, binEnd, nseg, segStart, nexcl, exclStart, exclStop, maxInterBinDist, nullptr, nullptr, nullptr, nullptr, segId);
+}
+
+// SegmentationInput.reportScoresByWindow (CanvasPartition/Segmentation.cs:275-296): per chromosome, windows at index = 0, windowSize, ... while
+// index < length - windowSize; each window takes windowSize - 1 values (Skip(index).Take(windowSize - 1)).  LINQ Average() and Sum() of doubles
+// are sequential sums in list order.  Scores that are infinite or NaN are dropped.  (The ConcurrentBag's order is not deterministic, but both
+// consumers sort.)
+static std::vector<double> reportScoresByWindow(int nchr, const double* const* cov, const int64_t* n, int windowSize) {
+    std::vector<double> evennessScores;
+    for (int c = 0; c < nchr; c++)
+        for (int64_t index = 0; index < n[c] - windowSize; index += windowSize) {
+            const double* tmp = cov[c] + index; const int64_t cnt = windowSize - 1;
+            double sum = 0; for (int64_t i = 0; i < cnt; i++) sum += tmp[i];
+            double average = sum / (double)cnt;
+            double tmpEvenness = 0;
+            for (int coverageBin = 0; coverageBin <= average; coverageBin++) {
+                int count = 0; for (int64_t i = 0; i < cnt; i++) if (tmp[i] >= coverageBin) count++;
+                tmpEvenness += count / sum;
+            }
+            if (!std::isinf(tmpEvenness) && !std::isnan(tmpEvenness)) evennessScores.push_back(tmpEvenness);
+        }
+    return evennessScores;
+}
+// SegmentationInput.GetEvennessScore (Segmentation.cs:260-269).  Returns 0 and *score, or 1 when the reference would throw inside Quartiles / Median
+// (fewer than 2 scores at the 10000-bin window or none at the requested one: WaveletsRunner.cs:58-67 catches it and writes no file).
+int orc_evenness_score(int nchr, const double* const* cov, const int64_t* n, int windowSize, double* score) {
+    const double IQRthreshold = 0.015; const int windowSizeIQR = 10000;
+    auto evennessScoresIQR = reportScoresByWindow(nchr, cov, n, windowSizeIQR);
+    if (evennessScoresIQR.size() < 2) return 1;                       // Quartiles indexes sorted[-1]
+    std::vector<float> f; for (double v : evennessScoresIQR) f.push_back((float)v);   // Convert.ToSingle
+    float q1, q2, q3; Quartiles(f, q1, q2, q3);
+    auto evennessScores = reportScoresByWindow(nchr, cov, n, windowSize);
+    if (evennessScores.empty()) return 1;
+    double median = median_copy(evennessScores);              // Utilities.Median(IEnumerable<double>) -> SortedList<double>.Median()
+    *score = (q3 - q1 > IQRthreshold) ? q3 * 100.0 : median * 100.0;
+    return 0;
+}
+int orc_evenness_window_scores(int nchr, const double* const* cov, const int64_t* n, int windowSize, double* out, int cap) {
+    auto v = reportScoresByWindow(nchr, cov, n, windowSize);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+    return (int)v.size();
 }
 
 // ---- CBS

@@ -222,6 +222,46 @@ def split_overlapping(starts, ends):
     return os_[:n].copy(), oe[:n].copy()
 
 
+def is_uniform_reference_ploidy(q_start, q_end, ivs):
+    """PloidyInfo.IsUniformReferencePloidy for the one-based interval [q_start, q_end]; ivs = (starts, ends, cns) of the chromosome"""
+    a = np.ascontiguousarray(ivs[0], np.int32); b = np.ascontiguousarray(ivs[1], np.int32); c = np.ascontiguousarray(ivs[2], np.int32)
+    return lib.orc_is_uniform_reference_ploidy(C.c_int64(q_start), C.c_int64(q_end), len(a), _p(a), _p(b), _p(c))
+
+
+def postprocess_ploidy(bin_start, bin_end, seg_start, excl, ploidy, max_inter_bin_dist=1000000):
+    """PostProcessSegments with a reference ploidy: ploidy[c] = None (chromosome not in the VCF) or (starts, ends, cns), one-based"""
+    nchr = len(bin_start)
+    nb = np.array([len(b) for b in bin_start], np.int64)
+    nseg = np.array([len(s) for s in seg_start], np.int32)
+    seg_id = [np.zeros(len(b), np.int32) for b in bin_start]
+    z = np.zeros(0, np.int32)
+    excl = excl if excl is not None else [(z, z)] * nchr
+    es = [np.ascontiguousarray(e[0], np.int32) for e in excl]; ee = [np.ascontiguousarray(e[1], np.int32) for e in excl]
+    ne = np.array([len(e) for e in es], np.int32)
+    pl = [p if p is not None else (z, z, z) for p in ploidy]
+    ps = [np.ascontiguousarray(q[0], np.int32) for q in pl]; pe = [np.ascontiguousarray(q[1], np.int32) for q in pl]; pc = [np.ascontiguousarray(q[2], np.int32) for q in pl]
+    npl = np.array([-1 if p is None else len(p[0]) for p in ploidy], np.int32)
+    last = lib.orc_postprocess_ploidy(nchr, _p(nb), _pp(bin_start), _pp(bin_end), _p(nseg), _pp(seg_start), _p(ne), _pp(es), _pp(ee), max_inter_bin_dist,
+                                      _p(npl), _pp(ps), _pp(pe), _pp(pc), _pp(seg_id))
+    return seg_id, last
+
+
+def evenness_score(per_chr_cov, window=100000):
+    """SegmentationInput.GetEvennessScore (Segmentation.cs:260-296); None when the reference would throw (no metric file written)"""
+    n = np.array([len(c) for c in per_chr_cov], np.int64)
+    out = C.c_double(0)
+    rc = lib.orc_evenness_score(len(per_chr_cov), _pp(per_chr_cov), _p(n), int(window), C.byref(out))
+    return None if rc else out.value
+
+
+def evenness_window_scores(per_chr_cov, window):
+    n = np.array([len(c) for c in per_chr_cov], np.int64)
+    cap = int(sum(max(0, len(c) // max(1, window)) for c in per_chr_cov)) + 8
+    out = np.zeros(cap, np.float64)
+    k = lib.orc_evenness_window_scores(len(per_chr_cov), _pp(per_chr_cov), _p(n), int(window), _p(out), cap)
+    return out[:k].copy()
+
+
 def postprocess(bin_start, bin_end, seg_start, excl=None, max_inter_bin_dist=1000000):
     nchr = len(bin_start)
     nb = np.array([len(b) for b in bin_start], np.int64)

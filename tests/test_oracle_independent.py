@@ -1438,3 +1438,117 @@ def test_normalize_raw_ratio_two_restatements():
         k, r, c = O.norm_ratio(sample, reference, None, mode=1, min_ref=lo, max_ref=hi)
         assert k.tolist() == keep, it
         assert (r.view(np.uint32) == np.asarray(ratios, np.float32).view(np.uint32)).all() and (c.view(np.uint32) == np.asarray(counts, np.float32).view(np.uint32)).all(), it
+
+
+# ---- CanvasPartition -p: PloidyInfo.IsUniformReferencePloidy + the reference-ploidy branch of IsNewSegment (SegmentationResultsProcessor.cs:117-128),
+# read a second time with inclusive one-based overlaps [max(qs, a), min(qe, b)] instead of the C#'s zero-based overlapStart / overlapEnd pair
+def py_is_uniform(q_start, q_end, ivs):
+    counts = [0] * 5
+    counts[2] = q_end - q_start + 1
+    for a, b, cn in ivs:                                  # one-based inclusive [a, b]
+        if cn == 2:
+            continue
+        # overlapStart = max(qs - 1, a - 1); "if overlapStart > End continue"; overlapEnd = min(qe, b); bases = overlapEnd - overlapStart
+        lo = max(q_start, a); hi = min(q_end, b)
+        bases = hi - lo + 1
+        if max(q_start - 1, a - 1) > b or bases <= 0:
+            continue
+        counts[2] -= bases; counts[cn] += bases
+    return sum(1 for v in counts if v > 0) < 2
+
+
+def py_postprocess_ploidy(bin_start, bin_end, seg_starts, ploidy, max_dist):
+    seg_num = -1; out = []
+    for c in range(len(bin_start)):
+        starts = set(int(v) for v in seg_starts[c]); prev_end = 0; ids = []
+        for s, e in zip(bin_start[c], bin_end[c]):
+            s, e = int(s), int(e)
+            new = s in starts
+            if prev_end > 0 and max_dist >= 0 and prev_end + max_dist < s and not new:
+                new = True
+            if not new and ploidy[c] is not None and not py_is_uniform(prev_end if prev_end > 0 else 1, e, list(zip(*[[int(v) for v in col] for col in ploidy[c]]))):
+                new = True
+            if new:
+                seg_num += 1
+            ids.append(seg_num); prev_end = e
+        out.append(np.array(ids, np.int32))
+    return out, seg_num
+
+
+def test_reference_ploidy_postprocess_two_restatements():
+    rng = np.random.RandomState(20260928)
+    for trial in range(30):
+        nchr = 4
+        bs, be, segs, ploidy = [], [], [], []
+        for c in range(nchr):
+            nb = int(rng.randint(5, 120))
+            gaps = rng.randint(0, 40, nb); sizes = rng.randint(50, 400, nb)
+            st = np.cumsum(gaps + np.concatenate([[0], sizes[:-1]])) + 100
+            en = st + sizes
+            bs.append(st.astype(np.uint32)); be.append(en.astype(np.uint32))
+            k = int(rng.randint(0, 5))
+            segs.append(np.sort(rng.choice(st, k, replace=False)).astype(np.uint32) if k else np.zeros(0, np.uint32))
+            if c == 0 and trial % 3 == 0:
+                ploidy.append(None)                        # chromosome absent from the VCF
+            else:
+                m = int(rng.randint(0, 5)); a = rng.randint(1, int(en[-1]) + 50, m); b = a + rng.randint(-5, int(en[-1]) // 2 + 1, m)
+                ploidy.append((a.astype(np.int32), b.astype(np.int32), rng.choice([0, 1, 2, 3, 4], m).astype(np.int32)))
+        exp, last = py_postprocess_ploidy(bs, be, segs, ploidy, 1000000)
+        got, last_o = O.postprocess_ploidy(bs, be, segs, None, ploidy, 1000000)
+        assert last == last_o
+        for c in range(nchr):
+            assert (got[c] == exp[c]).all(), (trial, c)
+    # the query interval itself: a record ending exactly on the previous bin's end / starting on this bin's end
+    assert O.is_uniform_reference_ploidy(100, 200, ([201], [300], [1])) == 1
+    assert O.is_uniform_reference_ploidy(100, 200, ([200], [300], [1])) == 0
+    assert O.is_uniform_reference_ploidy(100, 200, ([1], [99], [1])) == 1
+    assert O.is_uniform_reference_ploidy(100, 200, ([1], [100], [1])) == 0
+    assert O.is_uniform_reference_ploidy(100, 200, ([1], [1000], [1])) == 1      # all haploid
+    assert O.is_uniform_reference_ploidy(100, 200, ([1], [1000], [7])) == -1     # baseCounts[7]: IndexOutOfRangeException in the C#
+
+
+# ---- GetEvennessScore (Segmentation.cs:260-296): written from the formula in the paper the C# cites — per window, with S = sum(x) and
+# a = mean(x): score = sum_{k=0..floor(a)} #{x >= k} / S — on numpy, sequential sums kept (np.cumsum adds left to right like LINQ's Sum)
+def py_evenness(per_chr, window):
+    def scores(w):
+        out = []
+        for x in per_chr:
+            for index in range(0, max(0, len(x) - w), w):
+                if not index < len(x) - w:
+                    break
+                t = x[index:index + w - 1]
+                s = float(np.cumsum(t)[-1]); avg = s / len(t)
+                if not avg >= 0:
+                    out.append(0.0); continue
+                acc = 0.0
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    for k in range(0, int(math.floor(avg)) + 1):
+                        acc = acc + np.float64(int(np.count_nonzero(t >= k))) / np.float64(s)
+                if math.isfinite(acc):
+                    out.append(float(acc))
+        return out
+    iqr = scores(10000); med = scores(window)
+    if len(iqr) < 2 or not med:
+        return None
+    q1, _, q3 = py_quartiles([np.float32(v) for v in iqr])
+    m = sorted(med); n = len(m)
+    median = m[n // 2] if n % 2 else (m[n // 2 - 1] + m[n // 2]) / 2
+    return float(np.float32(q3)) * 100.0 if float(np.float32(q3) - np.float32(q1)) > 0.015 else median * 100.0
+
+
+def test_evenness_score_two_restatements():
+    rng = np.random.RandomState(77)
+    for trial, (sizes, window) in enumerate([((25_000, 31_000, 900), 4000), ((12_000, 10_001, 10_000), 700), ((45_000,), 1000), ((9_000, 8_000), 500), ((33_000, 21_000), 40_000)]):
+        per = []
+        for n in sizes:
+            x = np.round(rng.gamma(25, 4, n), 2)
+            if trial == 0: x[5_000:16_000] = 0.0                      # windows whose sum is 0
+            if trial == 1: x[100:400] = -2.0
+            if trial == 2: x[20_000:] *= 3
+            per.append(np.ascontiguousarray(x))
+        exp = py_evenness(per, window)
+        got = O.evenness_score(per, window)
+        assert (exp is None) == (got is None), (trial, exp, got)
+        if exp is not None:
+            assert np.float64(exp).tobytes() == np.float64(got).tobytes(), (trial, exp, got)
+    assert O.evenness_score([np.ones(9_000)], 500) is None
