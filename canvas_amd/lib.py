@@ -333,6 +333,39 @@ class Canvas:
                                                     C.byref(bs), C.byref(total), C.byref(nclean), C.byref(lsd), _np_ptr(off), C.byref(nseg)))
         return dict(bin_size=bs.value, total=total.value, n_out=nclean.value, lsd=lsd.value, off=off, nseg=nseg.value, prepared=prepared)
 
+    def tumor_normal_flow(self, bases, masks, hits_t, fraglen_t, hits_n, lens, is_autosome, clean_flags, alpha=0.01, nperm=10000, counts_per_bin=100, is_y=None, keep=False):
+        """BASELINE configs[4] in memory, the hand-offs of the reference's tumour / normal flow: CanvasBin -m GCContentWeighted on the tumour (bin size from
+        the tumour's own rates) and -m TruncatedDynamicRange -z <that size> on the normal (same mask => same bins), CanvasNormalize's LSNorm ratio x 40
+        (LSNormRatioCalculator.cs:31-44, CanvasNormalizeUtilities.cs:23-33), its "{count:F2}" file read back with float.Parse (IO.cs:21,40), CanvasClean,
+        the F2 hand-off to CanvasPartition and CBS (alpha, nperm).  Returns a dict; with keep=True every intermediate array is kept for checking."""
+        torch = self.torch
+        nchr = len(bases)
+        cap = int(sum(int(l) for l in lens) // 50) + 64
+        mk = lambda dt: torch.empty(cap, dtype=dt, device=self.device)
+        T = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+        N = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+        _, perT, nT, bs = self.bin_sample_gcweighted(bases, masks, hits_t, fraglen_t, lens, is_autosome, counts_per_bin, -1, out=T)
+        _, perN, nN, _ = self.bin_sample(bases, masks, hits_n, lens, is_autosome, counts_per_bin, bs, MODE_TDR, out=N)
+        if nN != nT:
+            raise CanvasError(f"tumour and normal bins differ ({nT} vs {nN}): they must share the reference mask")
+        kidx, ratio, count, lsf = self.normalize_ratio(T["count"][:nT], N["count"][:nN], None, mode=0)
+        k = int(kidx.numel())
+        ki = kidx.long()
+        R = dict(chr=T["chr"][:nT][ki].contiguous(), start=T["start"][:nT][ki].contiguous(), stop=T["stop"][:nT][ki].contiguous(), gc=T["gc"][:nT][ki].contiguous(),
+                 count=self.quantize_f2(count, k).float().contiguous())       # the ratio file's F2 text, float.Parse'd by CanvasClean
+        res = dict(bin_size=bs, n_bins=nT, n_ratio=k, library_size_factor=lsf)
+        if keep:
+            res.update(tumour={a: T[a][:nT].clone() for a in T}, normal_count=N["count"][:nN].clone(), keep_idx=kidx.clone(), ratio=ratio.clone(), ratio_count=count.clone(),
+                       to_clean={a: R[a].clone() for a in R})
+        n_out, lsd, info = self.clean(R, k, is_autosome, clean_flags, is_y=is_y)
+        cov = self.quantize_f2(R["count"], n_out)
+        off = self.chromosome_offsets(R["chr"], n_out, nchr)
+        seg_len, nseg, stats = self.cbs(cov, off, alpha, nperm)
+        res.update(n_clean=n_out, local_sd=lsd, chr_offset=off, nseg=nseg, cbs_stats=stats, segments=int(nseg.sum()))
+        if keep:
+            res.update(cleaned={a: R[a][:n_out].clone() for a in R}, cov=cov.clone(), seg_len=seg_len)
+        return res
+
     # ---- CanvasNormalize (ratio path)
     def normalize_reference(self, counts, on_target_idx=None):
         """WeightedAverageReferenceGenerator.Run for several control samples: (weighted counts f64 tensor, weights)"""
@@ -369,6 +402,30 @@ class Canvas:
 _synth = None
 
 
+def synth_generate_sample_device(seed, hit_seed, chrom, length, thr_dev, device, with_fraglen=False, bases=None, mask=None):
+    """a further sample over the reference of `seed` (tumour / normal pairs): (hits, fraglen or None); mirrors synth.generate_chromosome(hit_seed=...).
+    bases / mask tensors are (re)written when given."""
+    import torch
+    from . import synth
+    global _synth
+    if _synth is None:
+        load_library()
+        if not os.path.exists(_SYNTH_SO):
+            raise CanvasError(f"{_SYNTH_SO} missing: run build()")
+        _synth = C.CDLL(_SYNTH_SO)
+    gap0, g1s, g1e, base_cn = synth.chrom_params(chrom, length)
+    pad = (length + 63) // 64 * 64
+    hits = torch.zeros(pad, dtype=torch.uint8, device=device)
+    fl = torch.zeros(pad, dtype=torch.int16, device=device) if with_fraglen else None
+    rc = _synth.synth_generate_sample(C.c_uint32(seed), C.c_uint32(hit_seed), C.c_uint32(chrom), C.c_int64(length), C.c_int64(gap0), C.c_int64(g1s), C.c_int64(g1e), C.c_uint32(base_cn),
+                                      C.c_void_p(thr_dev.data_ptr()), C.c_void_p(bases.data_ptr()) if bases is not None else None, C.c_void_p(hits.data_ptr()),
+                                      C.c_void_p(mask.data_ptr()) if mask is not None else None, C.c_void_p(fl.data_ptr()) if fl is not None else None,
+                                      C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    if rc != 0:
+        raise CanvasError(f"synth_generate_sample failed: hip error {rc}")
+    return hits, fl
+
+
 def synth_generate_device(seed, chrom, length, rate, device, thr_dev=None):
     """generate (bases, hits, mask) for one chromosome directly in HBM; mirrors canvas_amd.synth.generate_chromosome"""
     import torch
@@ -380,8 +437,7 @@ def synth_generate_device(seed, chrom, length, rate, device, thr_dev=None):
             raise CanvasError(f"{_SYNTH_SO} missing: run build()")
         _synth = C.CDLL(_SYNTH_SO)
     if thr_dev is None:
-        thr_dev = torch.from_numpy(synth.poisson_thresholds(rate).astype(np.int64)).to(device).to(torch.int64)
-        thr_dev = (thr_dev & 0xFFFFFFFF).to(torch.int64).to(torch.int32) if False else torch.from_numpy(synth.poisson_thresholds(rate).view(np.int32)).to(device)
+        thr_dev = torch.from_numpy(synth.poisson_thresholds(rate).view(np.int32)).to(device)
     gap0, g1s, g1e, base_cn = synth.chrom_params(chrom, length)
     pad = (length + 63) // 64 * 64
     bases = torch.empty(pad, dtype=torch.uint8, device=device)

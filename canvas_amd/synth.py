@@ -25,12 +25,14 @@ def H(seed, chrom, stream, p):
         return mix32(a ^ k)
 
 
-def poisson_thresholds(rate):
-    """[5 CN][16 gc levels][8] uint32 cumulative thresholds: hits = #(u >= thr)."""
+def poisson_thresholds(rate, purity=1.0, flat=False):
+    """[5 CN][16 gc levels][8] uint32 cumulative thresholds: hits = #(u >= thr).  purity < 1: a tumour sample whose copy-number segments are diluted by
+    normal cells (effective CN = purity * CN + (1 - purity) * 2); flat: a matched normal (every segment diploid)."""
     import math
     thr = np.zeros((5, 16, 8), np.uint32)
     for cn in range(5):
         cnf = 0.02 if cn == 0 else cn / 2.0
+        cnf = 1.0 if flat else purity * cnf + (1.0 - purity) * 1.0
         for lvl in range(16):
             g = 26 + 2 * lvl
             lam = rate * cnf * (1 + 0.004 * (g - 41) - 0.0003 * (g - 41) ** 2)
@@ -49,12 +51,33 @@ def chrom_params(chrom, length):
     return gap0, g1s, g1e, base_cn
 
 
-def generate_chromosome(seed, chrom, length, rate, thr=None):
-    """numpy mirror of k_synth: returns (bases u8[L], hits u8[L], mask u8[ceil(L/64)*8])"""
+def generate_chromosome(seed, chrom, length, rate, thr=None, hit_seed=None, with_fraglen=False):
+    """numpy mirror of k_synth: returns (bases u8[L], hits u8[L], mask u8[ceil(L/64)*8]) [+ Int16 fragment lengths with with_fraglen].
+    hit_seed (default: seed) drives the copy-number segments and the hit draws: samples that share `seed` share the reference."""
     if thr is None:
         thr = poisson_thresholds(rate)
-    gap0, g1s, g1e, base_cn = chrom_params(chrom, length)
-    p = np.arange(length, dtype=np.uint32)
+    if hit_seed is None:
+        hit_seed = seed
+    CH = 1 << 22                      # every value is a function of the position alone: long chromosomes are generated in pieces (bounded memory)
+    if length > CH:
+        parts = [_generate_range(seed, chrom, length, thr, hit_seed, with_fraglen, a, min(length, a + CH)) for a in range(0, length, CH)]
+        b = np.concatenate([q[0] for q in parts]); h = np.concatenate([q[1] for q in parts]); m = np.concatenate([q[2] for q in parts])
+        out = (b, h, _pack_mask_bits(m, length))
+        return out + (np.concatenate([q[3] for q in parts]),) if with_fraglen else out
+    b, h, m, fl = _generate_range(seed, chrom, length, thr, hit_seed, with_fraglen, 0, length)
+    return (b, h, _pack_mask_bits(m, length), fl) if with_fraglen else (b, h, _pack_mask_bits(m, length))
+
+
+def _pack_mask_bits(m, length):
+    words = (length + 63) // 64
+    bits = np.zeros(words * 64, np.uint8); bits[:length] = m
+    return np.packbits(bits, bitorder="little")
+
+
+def _generate_range(seed, chrom, total_length, thr, hit_seed, with_fraglen, lo, hi):
+    gap0, g1s, g1e, base_cn = chrom_params(chrom, total_length)
+    p = np.arange(lo, hi, dtype=np.uint32)
+    length = hi - lo
     gap = (p < gap0) | ((p >= g1s) & (p < g1e))
     cell1k = p >> _M(10); off = p & _M(1023)
     hc = H(seed, chrom, 1, cell1k)
@@ -71,20 +94,22 @@ def generate_chromosome(seed, chrom, length, rate, thr=None):
     which = ((ub >> _M(16)) & _M(1)).astype(bool)
     b = np.where(isgc, np.where(which, ord('G'), ord('C')), np.where(which, ord('A'), ord('T'))).astype(np.uint8)
     b = np.where(m, b, b | 0x20).astype(np.uint8)
-    hcn = H(seed, chrom, 6, p >> _M(20)) % _M(1000)
+    hcn = H(hit_seed, chrom, 6, p >> _M(20)) % _M(1000)
     cn = np.full(length, base_cn, np.int64)
     cn = np.where(hcn < 15, base_cn - 1, np.where(hcn < 30, base_cn + 1, np.where(hcn < 33, 0, np.where(hcn < 36, base_cn + 2, cn))))
     cn = np.minimum(cn, 4)
-    u = H(seed, chrom, 7, p)
+    u = H(hit_seed, chrom, 7, p)
     t = thr.reshape(-1, 8)[cn * 16 + lvl.astype(np.int64)]
     h = (u[:, None] >= t).sum(1).astype(np.uint8)
     m &= ~gap
     b[gap] = ord('n')
     h[~m] = 0
-    words = (length + 63) // 64
-    bits = np.zeros(words * 64, np.uint8); bits[:length] = m
-    mask = np.packbits(bits, bitorder="little")
-    return b, h, mask
+    fl = None
+    if with_fraglen:
+        uf = H(hit_seed, chrom, 8, p)
+        ssum = (uf & _M(255)) + ((uf >> _M(8)) & _M(255)) + ((uf >> _M(16)) & _M(255)) + (uf >> _M(24))
+        fl = np.where(h > 0, _M(143) + ssum * _M(60) // _M(148), 0).astype(np.int16)
+    return b, h, m, fl
 
 
 def generate_bins(seed, n, nchr=24, lengths=None):
