@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-result"]
-PRODUCT_SRC = ["ctx.hip", "prep.hip", "bin.hip", "clean.hip", "hmm.hip", "cbs.hip", "wavelets.hip", "evenness.hip", "normalize.hip", "pipeline.hip", "comm.hip"]
+PRODUCT_SRC = ["ctx.hip", "prep.hip", "bin.hip", "clean.hip", "hmm.hip", "cbs.hip", "wavelets.hip", "evenness.hip", "normalize.hip", "pipeline.hip", "sharded.hip", "comm.hip"]
 
 
 def _hipcc():

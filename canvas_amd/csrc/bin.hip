@@ -41,8 +41,8 @@ __device__ __forceinline__ int find_chrom(const BinChrom* __restrict__ ch, int n
 }
 
 // ---------------------------------------------------------------------------------------------- k_find_pos0
-__global__ void __launch_bounds__(256) k_find_pos0(const BinChrom* __restrict__ ch, unsigned long long* __restrict__ pos0) {
-    const int c = blockIdx.y;
+__global__ void __launch_bounds__(256) k_find_pos0(const BinChrom* __restrict__ ch, unsigned long long* __restrict__ pos0, int c0) {
+    const int c = blockIdx.y + c0;
     const BinChrom C = ch[c];
     const int64_t CHUNK = 256 * 16;
     for (int64_t chunk = blockIdx.x; chunk * CHUNK < C.len; chunk += gridDim.x) {
@@ -473,9 +473,10 @@ __device__ __forceinline__ void summarize_tile(const BinChrom& C, int64_t gtile,
 }
 __global__ void __launch_bounds__(256) k_tile_summary(const BinChrom* __restrict__ ch, int nchr, int64_t ntilesTotal, const unsigned long long* __restrict__ pos0,
                                                       int clampHits, int wantObs, uint32_t* __restrict__ S, uint32_t* __restrict__ tilePop, uint32_t* __restrict__ tileObs,
-                                                      uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
-    // the wave index is uniform: telling the compiler so keeps the chromosome lookup on the scalar unit
-    const int64_t gtile = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                                                      uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG, int64_t tile0) {
+    // the wave index is uniform: telling the compiler so keeps the chromosome lookup on the scalar unit.  tile0 / ntilesTotal = the range of global tiles
+    // this launch covers (the whole genome, or one chromosome when the launch follows that chromosome's upload)
+    const int64_t gtile = tile0 + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (gtile >= ntilesTotal) return;
     const int c = find_chrom(ch, nchr, gtile);
     const BinChrom C = ch[c];
@@ -488,8 +489,8 @@ __global__ void __launch_bounds__(256) k_tile_summary(const BinChrom* __restrict
 // at most two edge tiles per chromosome: block 2c -> the tile pos0 falls into (if it is not tile-aligned), block 2c+1 -> the partial tail tile
 __global__ void __launch_bounds__(64) k_tile_summary_edges(const BinChrom* __restrict__ ch, int nchr, const unsigned long long* __restrict__ pos0,
                                                            int clampHits, int wantObs, uint32_t* __restrict__ S, uint32_t* __restrict__ tilePop, uint32_t* __restrict__ tileObs,
-                                                           uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG) {
-    const int c = blockIdx.x >> 1, which = blockIdx.x & 1;
+                                                           uint32_t* __restrict__ tileTotC, uint32_t* __restrict__ tileTotG, int c0) {
+    const int c = (blockIdx.x >> 1) + c0, which = blockIdx.x & 1;
     if (c >= nchr) return;
     const BinChrom C = ch[c];
     const int64_t p0c = (int64_t)pos0[c];
@@ -790,6 +791,10 @@ static BinPlan make_plan(int nchr, const uint8_t* const* bases, const uint64_t* 
     return p;
 }
 
+int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
+                              int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+
 extern "C" {
 
 int32_t canvas_bin_size_from_rates(const double* h_rates, int32_t n, int32_t counts_per_bin) {
@@ -812,6 +817,7 @@ int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !d_hits || !d_mask || !h_len) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_rates: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int32_t rcf = canvas_upload_fence(ctx); if (rcf) return rcf; }
     BinPlan plan = make_plan(nchr, nullptr, d_mask, d_hits, h_len);
     WsSizer sz; sz.take<BinChrom>(nchr); sz.take<unsigned long long>(nchr); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles);
     sz.take<int32_t>(plan.ntiles); sz.take<ChromOut>(nchr);
@@ -842,10 +848,10 @@ int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_
 static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
                                const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len, const uint8_t* h_is_auto, int32_t counts_per_bin, int32_t bin_size, int32_t mode,
                                int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                               int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
+                               int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total, cvx_bin_size_hook hook = nullptr, void* hookUser = nullptr) {
     if (!ctx) return CANVAS_ERR_INVALID;
     const bool needRates = bin_size <= 0;
-    if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || (needRates && (!h_is_auto || counts_per_bin <= 0))) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bad arguments");
+    if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || (needRates && !hook && (!h_is_auto || counts_per_bin <= 0))) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bad arguments");
     const bool gcw = mode == CANVAS_MODE_GC_CONTENT_WEIGHTED;
     if (gcw && !d_fraglen) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode needs the fragment-length arrays (canvas_bin_sample_gcweighted)");
     if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE && !gcw) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "unknown coverage mode");
@@ -913,7 +919,12 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     sz.take<int32_t>(ub + 1); sz.take<uint32_t>(ub + 1); sz.take<uint32_t>(ub + 1);
     // bases/hits/mask streamed once (see k_tile_summary) when the rates are needed too; CANVAS_BIN_SINGLE_READ=1 takes that path for a given bin
     // size as well and CANVAS_BIN_TWO_PASS=1 never takes it (both are test hooks: the two paths must agree bit for bit)
-    const bool singleRead = (needRates && !getenv("CANVAS_BIN_TWO_PASS")) || getenv("CANVAS_BIN_SINGLE_READ");
+    // a pending upload (canvas_upload_genome_begin) of exactly these arrays: every chromosome is swept as soon as it has arrived (single-read path only)
+    bool streamed = ctx->up_active && (int)ctx->up_bases.size() == nchr && !gcw;
+    for (int c = 0; streamed && c < nchr; c++) streamed = ctx->up_bases[c] == d_bases[c] && ctx->up_mask[c] == d_mask[c] && ctx->up_hits[c] == d_hits[c];
+    if (ctx->up_active && !streamed) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); }    // other arrays (or mode 5): plain dependency on the whole upload
+    ctx->up_active = false;
+    const bool singleRead = streamed || (needRates && !getenv("CANVAS_BIN_TWO_PASS")) || getenv("CANVAS_BIN_SINGLE_READ");
     if (singleRead) sz.take<uint32_t>(plan.ntiles * 64);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + sizeof(ChromOut))); if (rc) return rc;
@@ -929,16 +940,28 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
     ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
     hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);
-    hipLaunchKernelGGL(k_find_pos0, dim3(64, nchr), dim3(256), 0, ctx->stream, dCh, dPos0);
-    if (singleRead) {
+    if (streamed) {
+        // copy / compute overlap: chromosome c's sweep waits for chromosome c's event only, chromosome c + 1 is on its way meanwhile
+        for (int c = 0; c < nchr; c++) {
+            const BinChrom& C = plan.chroms[c];
+            CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[c], 0));
+            hipLaunchKernelGGL(k_find_pos0, dim3(64, 1), dim3(256), 0, ctx->stream, dCh, dPos0, c);
+            ProfScope ps(ctx, "bin_summary_streamed");
+            hipLaunchKernelGGL(k_tile_summary, dim3((unsigned)((C.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, C.tileBase + C.ntiles, dPos0, clampHits, needRates ? 1 : 0,
+                               wordSum, tilePop, tileObs, tileTotC, tileTotG, C.tileBase);
+            hipLaunchKernelGGL(k_tile_summary_edges, dim3(2), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG, c);
+        }
+    } else hipLaunchKernelGGL(k_find_pos0, dim3(64, nchr), dim3(256), 0, ctx->stream, dCh, dPos0, 0);
+    if (streamed) {
+    } else if (singleRead) {
         ProfScope ps(ctx, "bin_summary");
         hipLaunchKernelGGL(k_tile_summary, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, clampHits, needRates ? 1 : 0,
-                           wordSum, tilePop, tileObs, tileTotC, tileTotG);
+                           wordSum, tilePop, tileObs, tileTotC, tileTotG, (int64_t)0);
     } else {
         ProfScope ps(ctx, "bin_tile_stats");
         hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, needRates ? 1 : 0, tilePop, tileObs);
     }
-    if (singleRead) hipLaunchKernelGGL(k_tile_summary_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG);
+    if (singleRead && !streamed) hipLaunchKernelGGL(k_tile_summary_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG, 0);
     if (needRates) {
         // rates (CanvasBin.cs:30-83): totals per chromosome, then the bin size on the host
         hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut);
@@ -946,10 +969,17 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         // the tile totals of the single-read path do not depend on the bin size either: their scan runs while the host derives it
         if (singleRead) hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        std::vector<double> rates;
-        for (int c = 0; c < nchr; c++) if (h_is_auto[c]) rates.push_back((int)hOut[c].obs / (double)(int)hOut[c].pop);
-        if (rates.empty()) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "no autosome to derive the bin size from");
-        bin_size = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin);
+        if (hook) {
+            // chromosome-sharded pipeline: the rate pairs of every rank's chromosomes are exchanged inside the hook, every rank derives the same size
+            std::vector<long long> o(nchr), p(nchr), pb(nchr);
+            for (int c = 0; c < nchr; c++) { o[c] = hOut[c].obs; p[c] = hOut[c].pop; pb[c] = hOut[c].popBefore; }
+            int32_t rch = hook(hookUser, nchr, o.data(), p.data(), pb.data(), &bin_size); if (rch) return rch;
+        } else {
+            std::vector<double> rates;
+            for (int c = 0; c < nchr; c++) if (h_is_auto[c]) rates.push_back((int)hOut[c].obs / (double)(int)hOut[c].pop);
+            if (rates.empty()) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "no autosome to derive the bin size from");
+            bin_size = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin);
+        }
         if (bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "derived bin size is not positive");
     }
     if (h_bin_size_out) *h_bin_size_out = bin_size;
@@ -1013,3 +1043,9 @@ int32_t canvas_bin_sample_gcweighted(canvas_ctx* ctx, int32_t nchr, const uint8_
 }
 
 }  // extern "C"
+
+int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
+                              int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
+    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, nullptr, 0, -1, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total, hook, user);
+}

@@ -18,7 +18,34 @@ __global__ void k_pack_boundaries(const int32_t* __restrict__ local, int nlocal,
     if (i < maxPer) send[1 + i] = i < nlocal ? local[i] : 0;
 }
 
+// all-gather between device buffers on the context's stream.  RCCL when the ranks share a communicator (one GPU per rank, xGMI); the host-callback transport when
+// they do not (ranks that share a GPU, hosts that bring their own MPI): device -> pinned host -> callback -> device, synchronous.
+int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+    if (ctx->nranks == 1 && !ctx->comm) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream)); return CANVAS_OK; }
+    if (ctx->comm) { CANVAS_NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream)); return CANVAS_OK; }
+    if (!ctx->host_allgather) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "no communicator: call canvas_comm_init or canvas_comm_init_host first");
+    const size_t need = bytes * (size_t)(ctx->nranks + 1);
+    if (need > ctx->comm_pin_bytes) {
+        if (ctx->comm_pin) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipHostFree(ctx->comm_pin)); ctx->comm_pin = nullptr; ctx->comm_pin_bytes = 0; }
+        CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->comm_pin, need * 2, hipHostMallocDefault)); ctx->comm_pin_bytes = need * 2;
+    }
+    char* hs = (char*)ctx->comm_pin; char* hr = hs + bytes;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->host_allgather(ctx->host_allgather_user, hs, (int64_t)bytes, hr) != 0) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "host all-gather callback failed");
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_recv, hr, bytes * (size_t)ctx->nranks, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the pinned staging area is reused by the next call
+    return CANVAS_OK;
+}
+
 extern "C" {
+
+int32_t canvas_comm_init_host(canvas_ctx* ctx, int32_t rank, int32_t nranks, canvas_host_allgather_fn fn, void* user) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_comm_init_host: bad arguments");
+    ctx->comm = nullptr; ctx->rank = rank; ctx->nranks = nranks; ctx->host_allgather = fn; ctx->host_allgather_user = user;
+    return CANVAS_OK;
+}
 
 int32_t canvas_comm_unique_id(void* h_id128) {
     if (!h_id128) return CANVAS_ERR_INVALID;
@@ -50,11 +77,7 @@ int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int
     int32_t rc = canvas_ws_reserve(ctx, (size_t)rec * 4 + 256); if (rc) return rc;
     int32_t* send = (int32_t*)ctx->ws;
     hipLaunchKernelGGL(k_pack_boundaries, dim3((rec + 255) / 256), dim3(256), 0, ctx->stream, d_local, nlocal, max_per_rank, send);
-    if (ctx->nranks == 1 || !ctx->comm) {
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_all, send, (size_t)rec * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
-        CANVAS_NCCL_TRY(ctx, ncclAllGather(send, d_all, rec, ncclInt32, (ncclComm_t)ctx->comm, ctx->stream));
-    }
+    rc = cvx_allgather(ctx, send, d_all, (size_t)rec * 4); if (rc) return rc;
     if (h_counts) {
         for (int r = 0; r < ctx->nranks; r++) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&h_counts[r], d_all + (size_t)r * rec, 4, hipMemcpyDeviceToHost, ctx->stream));
     }

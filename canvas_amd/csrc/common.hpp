@@ -31,8 +31,22 @@ struct canvas_ctx {
     // small pinned staging area for host->device parameter tables (async copies from pinned memory need no synchronisation
     // to protect the source); bump-allocated, wrapped with a synchronisation when full
     char* misc_pin = nullptr; size_t misc_off = 0;
+    // pending genome upload (canvas_upload_genome_begin): copy stream, one "arrived" event per chromosome and the destination tables the next
+    // binning call is matched against
+    hipStream_t copy = nullptr;
+    std::vector<hipEvent_t> up_ev;
+    hipEvent_t up_fence = nullptr;     // compute stream -> copy stream: the destinations may still be read by the previous pass
+    std::vector<const void*> up_bases, up_mask, up_hits;
+    bool up_active = false;
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
+    // host-callback transport of the collectives (canvas_comm_init_host): used when the ranks cannot form an RCCL communicator
+    int32_t (*host_allgather)(void* user, const void* send, int64_t bytes_per_rank, void* recv) = nullptr;
+    void* host_allgather_user = nullptr;
+    void* comm_pin = nullptr; size_t comm_pin_bytes = 0;
+    // persistent buffers of the chromosome-sharded pipeline (sharded.hip)
+    void* shard_ws = nullptr; size_t shard_ws_bytes = 0;
+    long long shard_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long cbs_dev[6] = {0, 0, 0, 0, 0, 0};   // counters of the device permutation engine (canvas_cbs_device_stats)
     long long wv_levels = 0, wv_redone = 0;   // last canvas_wavelets call: tree levels processed, nodes recomputed by the exact chain
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
@@ -105,6 +119,25 @@ static inline int32_t canvas_pin_reserve(canvas_ctx* ctx, size_t bytes) {
     size_t want = bytes + 4096;
     CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
     ctx->pin_bytes = want;
+    return CANVAS_OK;
+}
+
+// ---- internal cross-file entry points (hidden: not part of the C ABI)
+#define CVX_INTERNAL __attribute__((visibility("hidden")))
+// all-gather of bytes_per_rank bytes between device buffers on ctx->stream: RCCL (ncclAllGather over xGMI), the host-callback transport, or a copy when nranks == 1
+CVX_INTERNAL int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+// canvas_bin_sample on the chromosomes this rank owns, with the bin size decided by `hook` from the per-chromosome (#hit > 0, popcount(mask), possible positions
+// in front of the first non-'n' base): the hook is where the sharded pipeline exchanges the rate pairs so that every rank derives the same size
+typedef int32_t (*cvx_bin_size_hook)(void* user, int nchr, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut);
+CVX_INTERNAL int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
+                                           int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                           int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+// canvas_hmm_per_sample on a subset of chromosomes (d_cov / h_chr_offset: the subset, contiguous) with the genome-wide quartiles taken from d_cov_all[0, n_all)
+CVX_INTERNAL int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state);
+
+// entry points that read per-base arrays without the per-chromosome overlap wait for a pending canvas_upload_genome_begin as a whole
+static inline int32_t canvas_upload_fence(canvas_ctx* ctx) {
+    if (ctx->up_active) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); ctx->up_active = false; }
     return CANVAS_OK;
 }
 

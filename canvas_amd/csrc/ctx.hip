@@ -27,6 +27,9 @@ void canvas_destroy(canvas_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
+    for (auto e : ctx->up_ev) (void)hipEventDestroy(e);
+    if (ctx->up_fence) (void)hipEventDestroy(ctx->up_fence);
     if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
     if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     if (ctx->ws) (void)hipFree(ctx->ws);
@@ -82,6 +85,51 @@ int32_t canvas_memcpy_d2h(canvas_ctx* ctx, void* h_dst, const void* d_src, int64
     if (!ctx || bytes < 0) return CANVAS_ERR_INVALID;
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+
+int32_t canvas_host_register(canvas_ctx* ctx, void* h_ptr, int64_t bytes) {
+    if (!ctx || !h_ptr || bytes <= 0) return CANVAS_ERR_INVALID;
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CANVAS_HIP_TRY(ctx, hipHostRegister(h_ptr, (size_t)bytes, hipHostRegisterDefault));
+    return CANVAS_OK;
+}
+int32_t canvas_host_unregister(canvas_ctx* ctx, void* h_ptr) {
+    if (!ctx || !h_ptr) return CANVAS_ERR_INVALID;
+    CANVAS_HIP_TRY(ctx, hipHostUnregister(h_ptr));
+    return CANVAS_OK;
+}
+
+// The per-base arrays always come from host memory (CanvasBin.LoadIntermediateData, CanvasBin.cs:965-969): chromosome after chromosome goes out on a
+// copy stream of its own, each followed by an event, and the binning call that follows sweeps a chromosome as soon as it has arrived.
+int32_t canvas_upload_genome_begin(canvas_ctx* ctx, int32_t nchr, const int64_t* h_len, const uint8_t* const* h_bases, uint8_t* const* d_bases,
+                                   const uint64_t* const* h_mask, uint64_t* const* d_mask, const uint8_t* const* h_hits, uint8_t* const* d_hits) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_len || !d_bases || !d_mask || !d_hits) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_upload_genome_begin: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy) CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    while ((int)ctx->up_ev.size() < nchr) { hipEvent_t e; CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->up_ev.push_back(e); }
+    // the destinations may still be read by work queued on the compute stream (the previous pass): the copies start after it
+    if (!ctx->up_fence) CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->up_fence, hipEventDisableTiming));
+    CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->up_fence, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy, ctx->up_fence, 0));
+    ctx->up_bases.assign(nchr, nullptr); ctx->up_mask.assign(nchr, nullptr); ctx->up_hits.assign(nchr, nullptr);
+    for (int c = 0; c < nchr; c++) {
+        if (h_len[c] <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_upload_genome_begin: chromosome length must be positive");
+        const size_t L = (size_t)h_len[c], mbytes = (size_t)((h_len[c] + 63) / 64) * 8;
+        if (h_bases && h_bases[c]) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_bases[c], h_bases[c], L, hipMemcpyHostToDevice, ctx->copy));
+        if (h_mask && h_mask[c]) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_mask[c], h_mask[c], mbytes, hipMemcpyHostToDevice, ctx->copy));
+        if (h_hits && h_hits[c]) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_hits[c], h_hits[c], L, hipMemcpyHostToDevice, ctx->copy));
+        CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->up_ev[c], ctx->copy));
+        ctx->up_bases[c] = d_bases[c]; ctx->up_mask[c] = d_mask[c]; ctx->up_hits[c] = d_hits[c];
+    }
+    ctx->up_active = true;
+    return CANVAS_OK;
+}
+int32_t canvas_upload_genome_wait(canvas_ctx* ctx) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (ctx->copy) CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy));
+    ctx->up_active = false;
     return CANVAS_OK;
 }
 

@@ -1412,27 +1412,28 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
 
 extern "C" {
 
-int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
+static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t nAll, int32_t* d_state) {
     if (!ctx) return CANVAS_ERR_INVALID;
-    if (nchr <= 0 || !d_cov || !h_chr_offset || !d_state) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
+    if (nchr <= 0 || !d_cov || !h_chr_offset || !d_state || !d_cov_all) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = h_chr_offset[nchr];
-    if (N < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
-    WsSizer ex; ex.take<uint32_t>(N); ex.take<int32_t>(N + 256); ex.take<double>(NSTATE * 70000);
+    // nAll / d_cov_all: the genome the quartiles are taken over (the whole sample; == the chromosomes handled here unless the sample is sharded)
+    if (nAll < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
+    WsSizer ex; ex.take<uint32_t>(nAll); ex.take<int32_t>(N + 256); ex.take<double>(NSTATE * 70000);
     auto prepare = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom*, const int64_t*) -> int32_t {
         int32_t rc;
-        uint32_t* keys = ws.take<uint32_t>(N); int32_t* idx = ws.take<int32_t>(N + 256); double* dTab = ws.take<double>(NSTATE * 70000);   // idx: padded for the group loads of k_vit_spec
+        uint32_t* keys = ws.take<uint32_t>(nAll); int32_t* idx = ws.take<int32_t>(N + 256); double* dTab = ws.take<double>(NSTATE * 70000);   // idx: padded for the group loads of k_vit_spec
     // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
-    hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, keys);
+    hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(nAll, 256)), dim3(256), 0, ctx->stream, d_cov_all, nAll, keys);
     int64_t qidx[6]; int nq;
-    quartile_idx(N, qidx, nq);
+    quartile_idx(nAll, qidx, nq);
     std::vector<SelQuery> qs;
     for (int k = 0; k < nq; k++) qs.push_back({0, 0, qidx[k]});
     std::vector<unsigned long long> res;
-    rc = radix_select<uint32_t>(ctx, keys, 1, std::vector<int64_t>{0, N}, qs, res); if (rc) return rc;
+    rc = radix_select<uint32_t>(ctx, keys, 1, std::vector<int64_t>{0, nAll}, qs, res); if (rc) return rc;
     float v[6], q1, q2, q3;
     for (int k = 0; k < nq; k++) v[k] = host_float_of_key((uint32_t)res[k]);
-    quartile_val(N, v, q1, q2, q3);
+    quartile_val(nAll, v, q1, q2, q3);
     const double median = (double)q2;
     const float iqr = q3 - q1;
     const double pseudoVariance = (double)(iqr * iqr);
@@ -1456,8 +1457,17 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
     };
     return hmm_pipeline(ctx, nchr, h_chr_offset, ex.off, prepare, d_state);
 }
+int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_chr_offset) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
+    return hmm_per_sample_impl(ctx, nchr, d_cov, h_chr_offset, d_cov, h_chr_offset[nchr], d_state);
+}
 
 }  // extern "C"
+
+int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state) {
+    return hmm_per_sample_impl(ctx, nchr, d_cov, h_chr_offset, d_cov_all, n_all, d_state);
+}
 
 // NegativeBinomialWrapper density table (DistributionUtilities.cs:51-69), the same calls as negative_binomial_log_table without the final log
 static void negative_binomial_table(double mean, double variance, int maxValue, double* out) {

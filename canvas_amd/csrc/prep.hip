@@ -69,6 +69,7 @@ int32_t canvas_mask_from_fasta(canvas_ctx* ctx, const uint8_t* d_bases, int64_t 
     if (!ctx) return CANVAS_ERR_INVALID;
     if (len <= 0 || !d_bases || !d_mask) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_mask_from_fasta: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int32_t rcf = canvas_upload_fence(ctx); if (rcf) return rcf; }
     int64_t words = (len + 63) / 64;
     hipLaunchKernelGGL(k_mask_from_fasta, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, len, d_mask);
     CANVAS_HIP_TRY(ctx, hipGetLastError());
@@ -80,6 +81,7 @@ int32_t canvas_mask_exclude_intervals(canvas_ctx* ctx, uint64_t* d_mask, int64_t
     if (len <= 0 || !d_mask || n < 0 || (n > 0 && (!h_start || !h_stop))) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_mask_exclude_intervals: bad arguments");
     if (n == 0) return CANVAS_OK;
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int32_t rcf = canvas_upload_fence(ctx); if (rcf) return rcf; }
     std::vector<Interval> iv(n);
     for (int i = 0; i < n; i++) iv[i] = Interval{h_start[i], h_stop[i]};
     int32_t rc = canvas_ws_reserve(ctx, (size_t)n * sizeof(Interval) + 256); if (rc) return rc;
@@ -94,6 +96,7 @@ int32_t canvas_screen_hits(canvas_ctx* ctx, uint8_t* d_hits, const uint64_t* d_m
     if (!ctx) return CANVAS_ERR_INVALID;
     if (len <= 0 || !d_hits || !d_mask) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_screen_hits: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int32_t rcf = canvas_upload_fence(ctx); if (rcf) return rcf; }
     int64_t groups = (len + 15) / 16;
     hipLaunchKernelGGL(k_screen_hits, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream, d_hits, d_mask, len);
     CANVAS_HIP_TRY(ctx, hipGetLastError());

@@ -1,0 +1,310 @@
+// One sample, chromosomes sharded over the ranks of a node (north_star / SURVEY 8e; BASELINE configs[3], [4]): one process per GPU, rank r holds the per-base
+// arrays of an LPT group of chromosomes only.  The reference runs CanvasBin and CanvasPartition as independent per-chromosome tasks (CanvasBin.cs:513-539,
+// HiddenMarkovModelsRunner.cs:51-104); the genome-wide couplings are few and small, and each becomes ONE all-gather (RCCL over xGMI, cvx_allgather):
+//
+//   local   sweep of the owned chromosomes (k_tile_summary)                                   -> (#hit > 0, popcount(mask), positions before pos0) per chromosome
+//   GATHER  the 3 x nchr rate table (576 B per rank)                                           -> same bin size on every rank (CanvasBin.cs:73-83), #bins of every chromosome
+//   local   bins of the owned chromosomes closed from the summaries
+//   GATHER  the owned bins, 16 B/bin packed to the largest rank's count (~2.4 MB per rank at 8 x) -> whole-genome SoA in file order on every rank
+//   every   CanvasClean on the whole-genome SoA: redundant and deterministic (its order statistics are genome-wide; exchanging 16 radix histograms
+//           per select would cost more than recomputing 1 ms), F2 hand-off, chromosome offsets
+//   local   PerSampleHMM of the owned chromosomes, emission parameters from the genome-wide quartiles (HiddenMarkovModelsRunner.cs:36-50)
+//   GATHER  the segment boundary records [n, (chr, startBin, endBin, state) ...] (KBs)         -> canvas_allgather_boundaries: THE collective north_star names
+//   every   state per bin from the records, PostProcessSegments: running segment id in file order (SegmentationResultsProcessor.cs:57-62, Q17)
+//
+// Every rank ends with the same cleaned bins, states and segment ids, bit-identical to the single-rank canvas_sample_pipeline (tests/test_sharded_gpu.py).
+#include "common.hpp"
+#include <algorithm>
+#include <vector>
+
+#define SH_BLK 2048
+
+__global__ void __launch_bounds__(256) k_sh_unshard(const int32_t* __restrict__ recv, int64_t maxB, const long long* __restrict__ binOff, const int32_t* __restrict__ owner,
+                                                    const long long* __restrict__ rankOff, int nchr, int64_t total, int32_t* __restrict__ oChr, int32_t* __restrict__ oStart,
+                                                    int32_t* __restrict__ oStop, int32_t* __restrict__ oGc, float* __restrict__ oCount) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (binOff[mid] <= g) lo = mid; else hi = mid - 1; }
+    const int32_t* base = recv + (size_t)owner[lo] * 4 * (size_t)maxB;
+    const int64_t j = rankOff[lo] + (g - binOff[lo]);
+    oChr[g] = lo; oStart[g] = base[j]; oStop[g] = base[maxB + j]; oGc[g] = base[2 * maxB + j]; oCount[g] = __int_as_float(base[3 * maxB + j]);
+}
+// a record starts at the first bin of a chromosome and wherever the state changes
+__global__ void __launch_bounds__(256) k_sh_flags(const int32_t* __restrict__ state, const long long* __restrict__ loff, int nl, int64_t n, uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = nl - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (loff[mid] <= i) lo = mid; else hi = mid - 1; }
+    flags[i] = (i == loff[lo] || state[i] != state[i - 1]) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_sh_count(const uint8_t* __restrict__ flags, int64_t n, uint32_t* __restrict__ blockCnt) {
+    __shared__ uint32_t sh[4];
+    const int64_t base = (int64_t)blockIdx.x * SH_BLK;
+    uint32_t c = 0;
+    for (int j = 0; j < SH_BLK / 256; j++) { const int64_t i = base + j * 256 + threadIdx.x; if (i < n) c += flags[i]; }
+    c = wave_reduce_add_u32(c);
+    if (lane_id() == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blockCnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void __launch_bounds__(64) k_sh_scan(uint32_t* __restrict__ blockCnt, int nblocks, unsigned int* __restrict__ total) {
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 64) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? blockCnt[i] : 0;
+        const uint32_t inc = wave_inclusive_scan_u32(v);
+        if (i < nblocks) blockCnt[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+// records (chrGlobal, startBin, endBin, state); endBin is filled by k_sh_ends
+__global__ void __launch_bounds__(256) k_sh_scatter(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, const int32_t* __restrict__ state, const long long* __restrict__ loff,
+                                                    const int32_t* __restrict__ localToGlobal, int nl, int64_t n, int32_t cap, int32_t* __restrict__ rec) {
+    __shared__ uint32_t sh[4];
+    const int64_t base = (int64_t)blockIdx.x * SH_BLK;
+    uint32_t running = blockOff[blockIdx.x];
+    for (int j = 0; j < SH_BLK / 256; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const uint32_t f = i < n ? flags[i] : 0;
+        const uint32_t inc = wave_inclusive_scan_u32(f);
+        if (lane_id() == 63) sh[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) woff += sh[k]; tot += sh[k]; }
+        if (f) {
+            const uint32_t d = running + woff + inc - 1;
+            if ((int32_t)d < cap) {
+                int lo = 0, hi = nl - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (loff[mid] <= i) lo = mid; else hi = mid - 1; }
+                rec[4 * d] = localToGlobal[lo]; rec[4 * d + 1] = (int32_t)(i - loff[lo]); rec[4 * d + 2] = (int32_t)(loff[lo + 1] - loff[lo]) - 1; rec[4 * d + 3] = state[i];
+            }
+        }
+        running += tot;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_sh_ends(int32_t* __restrict__ rec, const unsigned int* __restrict__ nrec, int32_t cap) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n = min((int)*nrec, cap);
+    if (k + 1 < n && rec[4 * (k + 1)] == rec[4 * k]) rec[4 * k + 2] = rec[4 * (k + 1) + 1] - 1;     // otherwise: the chromosome's last bin, written by k_sh_scatter
+}
+// state of every bin of the genome from the gathered records of the rank that owns its chromosome
+__global__ void __launch_bounds__(256) k_sh_fill_state(const int32_t* __restrict__ all, int recStride, const int32_t* __restrict__ owner, const long long* __restrict__ chrOff, int nchr,
+                                                       int64_t N, int32_t* __restrict__ state, int* __restrict__ bad) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    int c = 0, hi = nchr - 1;
+    while (c < hi) { const int mid = (c + hi + 1) >> 1; if (chrOff[mid] <= g) c = mid; else hi = mid - 1; }
+    const int32_t* blk = all + (size_t)owner[c] * recStride;
+    const int n = blk[0] / 4; const int32_t* rec = blk + 1;
+    const int32_t b = (int32_t)(g - chrOff[c]);
+    int lo = 0, hj = n - 1;                                                // last record with (chr, start) <= (c, b)
+    while (lo < hj) { const int mid = (lo + hj + 1) >> 1; const int32_t rc = rec[4 * mid], rs = rec[4 * mid + 1]; if (rc < c || (rc == c && rs <= b)) lo = mid; else hj = mid - 1; }
+    if (n <= 0 || rec[4 * lo] != c || rec[4 * lo + 1] > b || rec[4 * lo + 2] < b) { *bad = 1; state[g] = -1; return; }
+    state[g] = rec[4 * lo + 3];
+}
+
+namespace {
+struct ShardHook {
+    canvas_ctx* ctx; int nchr; const int32_t* owner; const uint8_t* isAuto; int countsPerBin; int binSizeIn; const int* localToGlobal;
+    long long* dBuf;                       // device: [1 + nranks][nchr * 3]
+    std::vector<long long> obs, pop, popBefore;      // every chromosome, after the exchange
+};
+int32_t shard_rates_exchange(ShardHook& H, int nl, const long long* obs, const long long* pop, const long long* popBefore) {
+    canvas_ctx* ctx = H.ctx;
+    const int W = ctx->nranks, n3 = H.nchr * 3;
+    std::vector<long long> mine(n3, 0), all((size_t)W * n3, 0);
+    for (int i = 0; i < nl; i++) { const int c = H.localToGlobal[i]; mine[3 * c] = obs[i]; mine[3 * c + 1] = pop[i]; mine[3 * c + 2] = popBefore[i]; }
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(H.dBuf, mine.data(), (size_t)n3 * 8, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = cvx_allgather(ctx, H.dBuf, H.dBuf + n3, (size_t)n3 * 8); if (rc) return rc;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(all.data(), H.dBuf + n3, (size_t)W * n3 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    H.obs.assign(H.nchr, 0); H.pop.assign(H.nchr, 0); H.popBefore.assign(H.nchr, 0);
+    for (int c = 0; c < H.nchr; c++) { const long long* e = &all[(size_t)H.owner[c] * n3 + 3 * c]; H.obs[c] = e[0]; H.pop[c] = e[1]; H.popBefore[c] = e[2]; }
+    return CANVAS_OK;
+}
+int32_t shard_bin_size_hook(void* user, int nl, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut) {
+    ShardHook& H = *(ShardHook*)user;
+    int32_t rc = shard_rates_exchange(H, nl, obs, pop, popBefore); if (rc) return rc;
+    if (H.binSizeIn > 0) { *binSizeOut = H.binSizeIn; return CANVAS_OK; }
+    std::vector<double> rates;                                              // SampleHitArrays.GetRates / GetBinSize over the autosomes (CanvasBin.cs:30-83)
+    for (int c = 0; c < H.nchr; c++) if (H.isAuto[c]) rates.push_back((int)H.obs[c] / (double)(int)H.pop[c]);
+    if (rates.empty()) CANVAS_FAIL(H.ctx, CANVAS_ERR_INVALID, "no autosome to derive the bin size from");
+    *binSizeOut = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), H.countsPerBin);
+    return CANVAS_OK;
+}
+}  // namespace
+
+extern "C" int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                                                  const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y,
+                                                  int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                                  int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                                  double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                                  int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_chr_owner || !d_bases || !d_mask || !d_hits || !h_len || !h_chr_is_autosome || !d_chr || !d_start || !d_stop || !d_gc || !d_count || !d_cov || !d_state ||
+        !d_segment_id || !h_chr_offset || (bin_size_in <= 0 && counts_per_bin <= 0))
+        CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline_sharded: bad arguments");
+    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_sample_pipeline_sharded: modes 0 and 3");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->nranks, me = ctx->rank;
+    for (int c = 0; c < nchr; c++) if (h_chr_owner[c] < 0 || h_chr_owner[c] >= W || h_len[c] <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline_sharded: owner outside [0, nranks)");
+    std::vector<int> mine;                                         // owned chromosomes, file order
+    for (int c = 0; c < nchr; c++) if (h_chr_owner[c] == me) mine.push_back(c);
+    const int nl = (int)mine.size();
+    // upper bounds that every rank can compute: bins per rank for the smallest possible bin size
+    const int64_t minBin = bin_size_in > 0 ? bin_size_in : std::max(1, counts_per_bin);
+    std::vector<int64_t> capRank(W, 16);
+    for (int c = 0; c < nchr; c++) capRank[h_chr_owner[c]] += h_len[c] / minBin + 1;
+    const int64_t capLocal = capRank[me], capMax = *std::max_element(capRank.begin(), capRank.end());
+    const int32_t maxRecInts = 4 * 16384;                            // boundary records per rank in the first attempt (grown if a rank has more)
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const int nbLocal = (int)((capLocal + SH_BLK - 1) / SH_BLK) + 1;
+    size_t need = 0;
+    const size_t oBins = need; need += 5 * al((size_t)capLocal * 4);
+    const size_t oSend = need; need += al((size_t)capMax * 16);
+    const size_t oRecv = need; need += al((size_t)W * capMax * 16);
+    const size_t oRates = need; need += al((size_t)(W + 1) * nchr * 3 * 8);
+    const size_t oTab = need; need += 6 * al((size_t)(nchr + 2) * 8);
+    const size_t oCovL = need; need += al((size_t)capLocal * 8);
+    const size_t oStateL = need; need += al((size_t)capLocal * 4);
+    const size_t oFlags = need; need += al((size_t)capLocal);
+    const size_t oBlk = need; need += al((size_t)nbLocal * 4);
+    const size_t oCnt = need; need += 256;
+    if (need > ctx->shard_ws_bytes) {
+        if (ctx->shard_ws) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->shard_ws)); ctx->shard_ws = nullptr; ctx->shard_ws_bytes = 0; }
+        CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->shard_ws, need)); ctx->shard_ws_bytes = need;
+    }
+    char* S = (char*)ctx->shard_ws;
+    int32_t* lChr = (int32_t*)(S + oBins); int32_t* lStart = (int32_t*)(S + oBins + al((size_t)capLocal * 4)); int32_t* lStop = (int32_t*)(S + oBins + 2 * al((size_t)capLocal * 4));
+    int32_t* lGc = (int32_t*)(S + oBins + 3 * al((size_t)capLocal * 4)); float* lCount = (float*)(S + oBins + 4 * al((size_t)capLocal * 4));
+    int32_t* dSend = (int32_t*)(S + oSend); int32_t* dRecv = (int32_t*)(S + oRecv);
+    long long* dRates = (long long*)(S + oRates);
+    const size_t tabStride = al((size_t)(nchr + 2) * 8);
+    long long* dBinOff = (long long*)(S + oTab); int32_t* dOwner = (int32_t*)(S + oTab + tabStride); long long* dRankOff = (long long*)(S + oTab + 2 * tabStride);
+    long long* dChrOff = (long long*)(S + oTab + 3 * tabStride); long long* dLoff = (long long*)(S + oTab + 4 * tabStride); int32_t* dL2G = (int32_t*)(S + oTab + 5 * tabStride);
+    double* dCovL = (double*)(S + oCovL); int32_t* dStateL = (int32_t*)(S + oStateL); uint8_t* dFlags = (uint8_t*)(S + oFlags); uint32_t* dBlk = (uint32_t*)(S + oBlk);
+    unsigned int* dNrec = (unsigned int*)(S + oCnt); int* dBad = (int*)(S + oCnt + 64);
+
+    // ---- 1. local sweep, exchange of the rate table, one bin size, local bins
+    ShardHook H{ctx, nchr, h_chr_owner, h_chr_is_autosome, counts_per_bin, bin_size_in, mine.data(), dRates, {}, {}, {}};
+    int32_t binSize = 0; int64_t nbMine = 0;
+    int32_t rc;
+    if (nl > 0) {
+        std::vector<const uint8_t*> lb(nl), lh(nl); std::vector<const uint64_t*> lm(nl); std::vector<int64_t> ll(nl), perChr(nl);
+        for (int i = 0; i < nl; i++) { lb[i] = d_bases[mine[i]]; lm[i] = d_mask[mine[i]]; lh[i] = d_hits[mine[i]]; ll[i] = h_len[mine[i]];
+            if (!lb[i] || !lm[i] || !lh[i]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline_sharded: an owned chromosome has no arrays"); }
+        rc = cvx_bin_sample_hooked(ctx, nl, lb.data(), lm.data(), lh.data(), ll.data(), mode, shard_bin_size_hook, &H, lChr, lStart, lStop, lGc, lCount, capLocal, perChr.data(), &nbMine);
+        if (rc) return rc;
+    } else {                                                         // more ranks than chromosomes: this rank only takes part in the exchanges
+        rc = shard_rates_exchange(H, 0, nullptr, nullptr, nullptr); if (rc) return rc;
+    }
+    {   // the bin size of the hook, recomputed here so that a rank without chromosomes has it too
+        if (bin_size_in > 0) binSize = bin_size_in;
+        else { std::vector<double> rates; for (int c = 0; c < nchr; c++) if (h_chr_is_autosome[c]) rates.push_back((int)H.obs[c] / (double)(int)H.pop[c]);
+               if (rates.empty()) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "no autosome to derive the bin size from");
+               binSize = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin); }
+        if (binSize <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "derived bin size is not positive");
+    }
+    if (h_bin_size) *h_bin_size = binSize;
+    // ---- 2. bins of every chromosome: counts are known everywhere, the columns travel in ONE all-gather
+    std::vector<long long> binOff(nchr + 1, 0), rankOff(nchr, 0), nbRank(W, 0);
+    for (int c = 0; c < nchr; c++) { const long long nb = (H.pop[c] - H.popBefore[c]) / binSize; binOff[c + 1] = binOff[c] + nb; rankOff[c] = nbRank[h_chr_owner[c]]; nbRank[h_chr_owner[c]] += nb; }
+    const int64_t total = binOff[nchr];
+    if (nbRank[me] != nbMine) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_sample_pipeline_sharded: local bin count disagrees with the exchanged table");
+    if (h_nbins) *h_nbins = total;
+    if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_sample_pipeline_sharded: output capacity too small");
+    if (total == 0) { if (h_nbins_clean) *h_nbins_clean = 0; if (h_nsegments) *h_nsegments = 0; for (int c = 0; c <= nchr; c++) h_chr_offset[c] = 0; if (h_local_sd) *h_local_sd = -1.0; return CANVAS_OK; }
+    const int64_t maxB = std::max<long long>(1, *std::max_element(nbRank.begin(), nbRank.end()));
+    if (nbMine > 0) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSend, lStart, (size_t)nbMine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSend + maxB, lStop, (size_t)nbMine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSend + 2 * maxB, lGc, (size_t)nbMine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSend + 3 * maxB, lCount, (size_t)nbMine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    rc = cvx_allgather(ctx, dSend, dRecv, (size_t)maxB * 16); if (rc) return rc;
+    {
+        std::vector<long long> off64(nchr + 1);
+        rc = canvas_h2d_small(ctx, dBinOff, binOff.data(), (size_t)(nchr + 1) * 8); if (rc) return rc;
+        rc = canvas_h2d_small(ctx, dOwner, h_chr_owner, (size_t)nchr * 4); if (rc) return rc;
+        rc = canvas_h2d_small(ctx, dRankOff, rankOff.data(), (size_t)nchr * 8); if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_sh_unshard, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dRecv, maxB, dBinOff, dOwner, dRankOff, nchr, total, d_chr, d_start, d_stop, d_gc, d_count);
+    // ---- 3. CanvasClean on the whole genome (every rank, deterministic), F2 hand-off, chromosome offsets of the cleaned bins
+    std::vector<uint8_t> noY((size_t)nchr, 0);
+    double lsd = -1.0; int64_t nClean = 0; int32_t info[8];
+    rc = canvas_clean2(ctx, total, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y ? h_chr_is_y : noY.data(), clean_flags, min_bins_per_gc, &lsd, &nClean, info);
+    if (rc) return rc;
+    if (h_nbins_clean) *h_nbins_clean = nClean;
+    if (h_local_sd) *h_local_sd = lsd;
+    rc = canvas_quantize_f2(ctx, d_count, nClean, d_cov); if (rc) return rc;
+    rc = canvas_chromosome_offsets(ctx, d_chr, nClean, nchr, h_chr_offset); if (rc) return rc;
+    // ---- 4. PerSampleHMM of the owned chromosomes (compact copy of their coverage; quartiles over the whole sample)
+    std::vector<int64_t> loff(nl + 1, 0);
+    for (int i = 0; i < nl; i++) loff[i + 1] = loff[i] + (h_chr_offset[mine[i] + 1] - h_chr_offset[mine[i]]);
+    const int64_t nLocal = loff[nl];
+    int32_t maxPer = maxRecInts, nrecInts = 0;
+    if (nLocal > 0) {
+        for (int i = 0; i < nl; i++) { const int64_t b0 = h_chr_offset[mine[i]], T = loff[i + 1] - loff[i];
+            if (T > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCovL + loff[i], d_cov + b0, (size_t)T * 8, hipMemcpyDeviceToDevice, ctx->stream)); }
+        rc = cvx_hmm_per_sample_subset(ctx, nl, dCovL, loff.data(), d_cov, nClean, dStateL); if (rc) return rc;
+        // boundary records of the owned chromosomes
+        std::vector<long long> loff64(loff.begin(), loff.end()); std::vector<int32_t> l2g(mine.begin(), mine.end());
+        rc = canvas_h2d_small(ctx, dLoff, loff64.data(), (size_t)(nl + 1) * 8); if (rc) return rc;
+        rc = canvas_h2d_small(ctx, dL2G, l2g.data(), (size_t)nl * 4); if (rc) return rc;
+        const int nb = (int)((nLocal + SH_BLK - 1) / SH_BLK);
+        hipLaunchKernelGGL(k_sh_flags, dim3((unsigned)((nLocal + 255) / 256)), dim3(256), 0, ctx->stream, dStateL, dLoff, nl, nLocal, dFlags);
+        hipLaunchKernelGGL(k_sh_count, dim3(nb), dim3(256), 0, ctx->stream, dFlags, nLocal, dBlk);
+        hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(64), 0, ctx->stream, dBlk, nb, dNrec);
+    }
+    // the records are built in the workspace of the context (nothing else runs between here and the gather); its size follows maxPer
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const size_t recBytes = al((size_t)maxPer * 4) + al((size_t)W * (1 + (size_t)maxPer) * 4) + 4096;
+        rc = canvas_ws_reserve(ctx, recBytes + (size_t)(1 + maxPer) * 4 + 4096); if (rc) return rc;
+        // canvas_allgather_boundaries packs into the FRONT of the workspace: records and the gathered table sit behind that area
+        char* wsb = (char*)ctx->ws + al((size_t)(1 + maxPer) * 4 + 256);
+        int32_t* dRec = (int32_t*)wsb; int32_t* dAll = (int32_t*)(wsb + al((size_t)maxPer * 4));
+        unsigned int nrec = 0;
+        if (nLocal > 0) {
+            const int nb = (int)((nLocal + SH_BLK - 1) / SH_BLK);
+            hipLaunchKernelGGL(k_sh_scatter, dim3(nb), dim3(256), 0, ctx->stream, dFlags, dBlk, dStateL, dLoff, dL2G, nl, nLocal, maxPer / 4, dRec);
+            hipLaunchKernelGGL(k_sh_ends, dim3((unsigned)((maxPer / 4 + 255) / 256)), dim3(256), 0, ctx->stream, dRec, dNrec, maxPer / 4);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&nrec, dNrec, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        nrecInts = (int32_t)std::min<long long>((long long)nrec * 4, maxPer);      // a rank with more records than fit announces the full count below
+        std::vector<int32_t> counts(W, 0);
+        // ---- 5. THE collective: segment boundaries of every rank
+        rc = canvas_allgather_boundaries(ctx, dRec, nrecInts, maxPer, dAll, counts.data()); if (rc) return rc;
+        // overflow protocol without a second collective type: a rank whose records did not fit sends count = maxPer and everyone retries with the bound every rank can derive
+        bool overflow = false;
+        for (int r = 0; r < W; r++) if (counts[r] >= maxPer) overflow = true;
+        if ((long long)nrec * 4 >= maxPer) overflow = true;
+        if (overflow && attempt == 0) { maxPer = (int32_t)std::min<long long>(4ll * (capMax + 16), 0x7FFFFFF0ll); continue; }
+        if (overflow) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_sample_pipeline_sharded: boundary records do not fit");
+        ctx->shard_stats[0] = W; ctx->shard_stats[1] = nl; ctx->shard_stats[2] = nbMine; ctx->shard_stats[3] = maxB * 16; ctx->shard_stats[4] = nrec; ctx->shard_stats[5] = (long long)(1 + maxPer) * 4;
+        // ---- 6. state of every bin from the records, then the running segment id in file order
+        std::vector<long long> chrOff64(h_chr_offset, h_chr_offset + nchr + 1);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dChrOff, chrOff64.data(), (size_t)(nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_sh_fill_state, dim3((unsigned)((nClean + 255) / 256)), dim3(256), 0, ctx->stream, dAll, 1 + maxPer, dOwner, dChrOff, nchr, nClean, d_state, dBad);
+        int bad = 0;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        if (bad) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_sample_pipeline_sharded: the gathered boundary records do not cover every bin");
+        break;
+    }
+    int64_t nseg = 0;
+    rc = canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
+    if (h_nsegments) *h_nsegments = nseg;
+    return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6) {
+    if (!ctx || !h_out6) return CANVAS_ERR_INVALID;
+    for (int i = 0; i < 6; i++) h_out6[i] = ctx->shard_stats[i];
+    return CANVAS_OK;
+}

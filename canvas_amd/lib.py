@@ -14,11 +14,11 @@ CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD, CLEAN_LOESS = 1, 2,
 # every symbol include/canvas_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
-    "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h",
+    "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h", "canvas_host_register", "canvas_host_unregister", "canvas_upload_genome_begin", "canvas_upload_genome_wait",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
     "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
-    "canvas_comm_unique_id", "canvas_comm_init", "canvas_allgather_boundaries", "canvas_profile_enable", "canvas_profile_get",
+    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sharded_stats", "canvas_profile_enable", "canvas_profile_get",
 ]
 
 
@@ -110,6 +110,20 @@ class Canvas:
 
     def synchronize(self):
         self._check(self.lib.canvas_synchronize(self.ctx))
+
+    def upload_genome_begin(self, lens, h_bases, d_bases, h_mask, d_mask, h_hits, d_hits):
+        """queue the per-chromosome upload of host arrays (pinned torch tensors / numpy arrays; None = already resident) on the context's copy stream;
+        the next binning call on the same destination tensors overlaps it (canvas_upload_genome_begin)"""
+        n = len(d_bases)
+        hl = np.ascontiguousarray(lens, np.int64)
+        hp = lambda ts: None if ts is None else (C.c_void_p * n)(*[None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else t.ctypes.data) for t in ts])
+        self._check(self.lib.canvas_upload_genome_begin(self.ctx, n, _np_ptr(hl), hp(h_bases), _ptr_table(d_bases), hp(h_mask), _ptr_table(d_mask), hp(h_hits), _ptr_table(d_hits)))
+
+    def upload_genome_wait(self):
+        self._check(self.lib.canvas_upload_genome_wait(self.ctx))
+
+    def memcpy_d2h(self, h_dst, d_src, nbytes):
+        self._check(self.lib.canvas_memcpy_d2h(self.ctx, C.c_void_p(h_dst.data_ptr() if hasattr(h_dst, "data_ptr") else h_dst.ctypes.data), C.c_void_p(d_src.data_ptr()), C.c_int64(nbytes)))
 
     # ---- CanvasBin
     def mask_from_fasta(self, bases, length):
@@ -365,6 +379,28 @@ class Canvas:
         if keep:
             res.update(cleaned={a: R[a][:n_out].clone() for a in R}, cov=cov.clone(), seg_len=seg_len)
         return res
+
+    def sample_pipeline_sharded(self, owner, bases, masks, hits, lens, is_autosome, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=0, min_bins_per_gc=100,
+                                max_inter_bin_dist=1000000, is_y=None):
+        """canvas_sample_pipeline_sharded: `owner[c]` = rank that holds chromosome c; bases / masks / hits are lists over ALL chromosomes with None for the ones this rank
+        does not own.  Every rank gets the whole result (same dict as sample_pipeline)."""
+        nchr = len(owner)
+        tab = lambda ts: (C.c_void_p * nchr)(*[None if t is None else C.c_void_p(t.data_ptr()) for t in ts])
+        ow = np.ascontiguousarray(owner, np.int32); hl = np.ascontiguousarray(lens, np.int64); ia = np.ascontiguousarray(is_autosome, np.uint8)
+        iy = None if is_y is None else np.ascontiguousarray(is_y, np.uint8)
+        bs = C.c_int32(0); total = C.c_int64(0); nclean = C.c_int64(0); lsd = C.c_double(-1.0); nseg = C.c_int64(0); off = np.zeros(nchr + 1, np.int64)
+        self._check(self.lib.canvas_sample_pipeline_sharded(self.ctx, nchr, _np_ptr(ow), tab(bases), tab(masks), tab(hits), _np_ptr(hl), _np_ptr(ia), None if iy is None else _np_ptr(iy),
+                                                            int(counts_per_bin), int(bin_size), int(mode), C.c_uint32(flags), int(min_bins_per_gc), int(max_inter_bin_dist),
+                                                            C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),
+                                                            C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()), C.c_int64(int(out["chr"].numel())),
+                                                            C.c_void_p(cov.data_ptr()), C.c_void_p(state.data_ptr()), C.c_void_p(seg.data_ptr()),
+                                                            C.byref(bs), C.byref(total), C.byref(nclean), C.byref(lsd), _np_ptr(off), C.byref(nseg)))
+        return dict(bin_size=bs.value, total=total.value, n_out=nclean.value, lsd=lsd.value, off=off, nseg=nseg.value)
+
+    def sharded_stats(self):
+        out = np.zeros(6, np.int64)
+        self._check(self.lib.canvas_sharded_stats(self.ctx, _np_ptr(out)))
+        return out
 
     # ---- CanvasNormalize (ratio path)
     def normalize_reference(self, counts, on_target_idx=None):

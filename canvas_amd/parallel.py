@@ -1,11 +1,17 @@
-"""Multi-process plumbing of the hot path (one process per GPU).  The path shards by independent units (samples of a cohort /
-chromosomes of a sample) with NO data-path collective; the only exchanges are the boundary all-gather (RCCL, in the library) and the
-throughput bookkeeping below, which works on any torch.distributed backend (nccl on the GPU box, gloo in the CPU tests)."""
+"""Multi-process plumbing of the hot path (one process per GPU).
+
+Two ways to use N GPUs:
+  * chromosome sharding of ONE sample (north_star; BASELINE configs[3], [4]): rank r holds an LPT group of chromosomes, the library's
+    canvas_sample_pipeline_sharded does the three exchanges (rate table, bins, segment boundaries) over RCCL; `owner_table` gives the assignment;
+  * a cohort: one sample per rank, no data-path collective.
+The bookkeeping below works on any torch.distributed backend (nccl on the GPU box, gloo in the CPU tests)."""
+import ctypes as C
+
 import numpy as np
 
 
 def shard_units(weights, world):
-    """Longest-processing-time assignment of units (e.g. chromosomes by length, SURVEY §8e) to ranks: returns a list of index lists."""
+    """Longest-processing-time assignment of units (e.g. chromosomes by length, SURVEY 8e) to ranks: returns a list of index lists."""
     order = np.argsort(-np.asarray(weights, dtype=np.float64), kind="stable")
     load = np.zeros(world)
     out = [[] for _ in range(world)]
@@ -14,6 +20,15 @@ def shard_units(weights, world):
         out[r].append(int(i))
         load[r] += weights[i]
     return [sorted(o) for o in out]
+
+
+def owner_table(lengths, world):
+    """owner[c] = rank that holds chromosome c (LPT on length): the h_chr_owner argument of canvas_sample_pipeline_sharded"""
+    owner = np.zeros(len(lengths), np.int32)
+    for r, units in enumerate(shard_units(lengths, world)):
+        for c in units:
+            owner[c] = r
+    return owner
 
 
 def sample_seed(base_seed, rank):
@@ -33,6 +48,15 @@ def aggregate_throughput(seconds, units, device=None):
     return float(t.item()), float(u.item()), float(u.item()) / float(t.item())
 
 
+def max_over_ranks(seconds, device=None):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def gather_boundary_records(local_records, max_per_rank):
     """reference semantics of canvas_allgather_boundaries on any backend: every rank contributes [count, rec...] padded to
     1 + max_per_rank int32; returns (counts per rank, [records of rank r])"""
@@ -48,3 +72,207 @@ def gather_boundary_records(local_records, max_per_rank):
     dist.all_gather(out, rec)
     counts = [int(o[0]) for o in out]
     return counts, [o[1:1 + c].tolist() for o, c in zip(out, counts)]
+
+
+# ---- the bookkeeping of canvas_sample_pipeline_sharded, restated on host arrays (what the library does between its kernels; exercised on gloo by the CPU tests)
+def bin_layout(owner, pop, pop_before, bin_size, world):
+    """from the exchanged rate table: bins per chromosome, file-order offsets, offset of every chromosome inside its owner's packed block, bins per rank"""
+    nb = [(int(p) - int(b)) // int(bin_size) for p, b in zip(pop, pop_before)]
+    bin_off = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
+    rank_off = np.zeros(len(owner), np.int64); per_rank = np.zeros(world, np.int64)
+    for c, r in enumerate(owner):
+        rank_off[c] = per_rank[r]; per_rank[r] += nb[c]
+    return np.array(nb, np.int64), bin_off, rank_off, per_rank
+
+
+def boundary_records(chroms, states_per_chrom):
+    """[(chr, startBin, endBin, state) ...] of the chromosomes a rank owns: one record per run of equal states, flat int32 list"""
+    out = []
+    for c, st in zip(chroms, states_per_chrom):
+        st = np.asarray(st)
+        if len(st) == 0:
+            continue
+        starts = np.concatenate([[0], np.nonzero(st[1:] != st[:-1])[0] + 1])
+        ends = np.concatenate([starts[1:] - 1, [len(st) - 1]])
+        for a, b in zip(starts, ends):
+            out += [int(c), int(a), int(b), int(st[a])]
+    return out
+
+
+def states_from_records(records_per_rank, owner, chr_offset):
+    """every rank rebuilds the state of every bin of the genome from the gathered records"""
+    n = int(chr_offset[-1])
+    state = np.full(n, -9, np.int32)
+    for recs in records_per_rank:
+        for k in range(0, len(recs), 4):
+            c, a, b, s = recs[k:k + 4]
+            state[chr_offset[c] + a:chr_offset[c] + b + 1] = s
+    return state
+
+
+def segment_ids_from_states(state, chr_offset, start, stop, max_inter_bin_dist=1000000):
+    """SegmentationResultsProcessor.PostProcessSegments without forbidden intervals / ploidy: the running id in file order (Q17)"""
+    seg = np.zeros(len(state), np.int32); cur = -1
+    for c in range(len(chr_offset) - 1):
+        prev_end = 0
+        for i in range(int(chr_offset[c]), int(chr_offset[c + 1])):
+            first = i == chr_offset[c]
+            new = state[i] >= 0 and (first or state[i - 1] != state[i])
+            if not new and not first and prev_end > 0 and max_inter_bin_dist >= 0 and prev_end + max_inter_bin_dist < int(start[i]):
+                new = True
+            if new:
+                cur += 1
+            seg[i] = cur; prev_end = int(stop[i])
+    return seg
+
+
+# ---- communicators of the library
+def init_library_comm(cv, rank, world):
+    """RCCL communicator of the library's own collectives: rank 0 creates the unique id, torch.distributed carries the 128 bytes"""
+    import torch.distributed as dist
+    ident = [None]
+    if rank == 0:
+        buf = (C.c_ubyte * 128)()
+        cv._check(cv.lib.canvas_comm_unique_id(buf))
+        ident[0] = bytes(buf)
+    dist.broadcast_object_list(ident, src=0)
+    idbuf = (C.c_ubyte * 128).from_buffer_copy(ident[0])
+    cv._check(cv.lib.canvas_comm_init(cv.ctx, rank, world, idbuf))
+
+
+_HOST_ALLGATHER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+def init_host_comm(cv, rank, world, group=None):
+    """host-callback transport (canvas_comm_init_host): the exchanges go through torch.distributed on CPU tensors (gloo).  For ranks that cannot form an RCCL
+    communicator, e.g. two processes that share one GPU in the tests."""
+    import torch
+    import torch.distributed as dist
+
+    def cb(user, send, nbytes, recv):
+        try:
+            s = torch.frombuffer((C.c_ubyte * nbytes).from_address(send), dtype=torch.uint8).clone()
+            if world == 1:
+                outs = [s]
+            else:
+                outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(outs, s, group=group)
+            r = torch.cat(outs).contiguous()
+            C.memmove(recv, r.data_ptr(), nbytes * world)
+            return 0
+        except Exception:                                # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    fn = _HOST_ALLGATHER(cb)
+    cv._host_allgather_cb = fn                            # keep the trampoline alive as long as the context
+    cv.lib.canvas_comm_init_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _HOST_ALLGATHER, C.c_void_p]
+    cv._check(cv.lib.canvas_comm_init_host(cv.ctx, rank, world, fn, None))
+
+
+# ---- bench.py --gpus N --multi sharded
+def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
+    """ONE 60x sample sharded by chromosome over the ranks (strong scaling); afterwards rank 0 runs the same sample on its own GPU and compares every output,
+    and every rank runs the cohort mode (one sample per rank) so that both scalings come out of one launch."""
+    import json
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import synth, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD
+    from .lib import synth_generate_device
+
+    seed = 20260927 + 3
+    lengths = [max(200_000, int(L * args.scale)) for L in synth.GRCH38]
+    nchr = len(lengths); lens = np.array(lengths, np.int64); total_bases = int(lens.sum())
+    owner = owner_table(lengths, world)
+    is_auto = synth.IS_AUTOSOME
+    flags = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD
+    thr = None
+    bases, hits, masks = [None] * nchr, [None] * nchr, [None] * nchr
+    for c in range(nchr):
+        if owner[c] == rank:
+            bases[c], hits[c], masks[c], thr = synth_generate_device(seed, c, lengths[c], args.rate, device, thr)
+    torch.cuda.synchronize()
+    cap = int(total_bases // 100) + 16
+    mk = lambda dt: torch.empty(cap, dtype=dt, device=device)
+    out = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+    cov, state, seg = mk(torch.float64), mk(torch.int32), mk(torch.int32)
+
+    def barrier():
+        cv.synchronize(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    def step():
+        r = cv.sample_pipeline_sharded(owner, bases, masks, hits, lens, is_auto, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=flags)
+        cv.synchronize()
+        return r
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, device)
+    st = cv.sharded_stats()
+    sharded = {"seconds_per_pass": dt / args.steps, "bins": int(r["total"]), "n_out": int(r["n_out"]), "nseg": int(r["nseg"]), "bin_size": int(r["bin_size"])}
+    # every rank must hold the same result: compare a digest of the segment ids and the cleaned counts across ranks
+    n = int(r["n_out"])
+    dig = torch.stack([seg[:n].to(torch.int64).sum(), (seg[:n].to(torch.int64) * torch.arange(n, device=device) % 1000003).sum(), state[:n].to(torch.int64).sum(),
+                       out["count"][:n].view(torch.int32).to(torch.int64).sum()])
+    digs = [torch.zeros_like(dig) for _ in range(world)]
+    dist.all_gather(digs, dig)
+    same_on_all_ranks = bool(all((d == digs[0]).all() for d in digs))
+    keep_seg = seg[:n].clone(); keep_state = state[:n].clone(); keep_count = out["count"][:n].clone(); keep_start = out["start"][:n].clone()
+
+    # ---- the same sample on ONE GPU (rank 0 generates the chromosomes it does not own); untimed check + the 1-GPU time of this very sample for the speed-up
+    # ---- cohort mode: one sample per rank (rank r: the cohort's sample r)
+    cseed = sample_seed(seed, rank)
+    cb, ch, cm = [], [], []
+    for c in range(nchr):
+        if cseed == seed and bases[c] is not None:
+            cb.append(bases[c]); ch.append(hits[c]); cm.append(masks[c])
+        else:
+            b_, h_, m_, thr = synth_generate_device(cseed, c, lengths[c], args.rate, device, thr)
+            cb.append(b_); ch.append(h_); cm.append(m_)
+    torch.cuda.synchronize()
+    prepared = None
+
+    def cstep():
+        nonlocal prepared
+        rr = cv.sample_pipeline(cb, cm, ch, lens, is_auto, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=flags, prepared=prepared)
+        prepared = rr["prepared"]
+        cv.synchronize()
+        return rr
+
+    for _ in range(args.warmup):
+        cstep()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rr = cstep()
+    barrier()
+    cdt, cbins, _ = aggregate_throughput(time.perf_counter() - t0, float(rr["total"]), device=device)
+    equals_single = None
+    if rank == 0:                                             # rank 0's cohort sample IS the sharded sample: its single-GPU result is the reference
+        n1 = int(rr["n_out"])
+        equals_single = bool(n1 == n and int(rr["nseg"]) == sharded["nseg"] and int(rr["total"]) == sharded["bins"] and (seg[:n1] == keep_seg).all() and (state[:n1] == keep_state).all()
+                             and (out["count"][:n1].view(torch.int32) == keep_count.view(torch.int32)).all() and (out["start"][:n1] == keep_start).all())
+    if rank == 0:
+        value = sharded["bins"] / sharded["seconds_per_pass"]
+        result = {"metric": "genome-bins/sec (bin+clean+partition)", "value": round(value, 1), "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": round(sharded["seconds_per_pass"] * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                  "dtype": "u8/int32 (bin), f32/f64 (clean, viterbi)", "data": "synthetic",
+                  "config": {"workload": "BASELINE configs[2] sharded as configs[3]/[4] prescribe: ONE whole-genome GRCh38 60x sample, chromosomes LPT-sharded over the ranks, "
+                                         "rate-table + bins + segment-boundary all-gathers over RCCL",
+                             "bases_per_sample": total_bases, "bins_per_sample": sharded["bins"], "bins_after_clean": sharded["n_out"], "bin_size": sharded["bin_size"],
+                             "partition": "PerSampleHMM", "clean_flags": "-g -s -r --local-sd-metric-file", "segments": sharded["nseg"], "multi": "sharded",
+                             "owner_of_chromosome": [int(x) for x in owner], "scale": args.scale, "rate": args.rate},
+                  "sharded": {"chromosomes_owned_rank0": int(st[1]), "bins_binned_rank0": int(st[2]), "bins_allgather_bytes_per_rank": int(st[3]), "boundary_records_rank0": int(st[4]),
+                              "boundary_allgather_bytes_per_rank": int(st[5]), "identical_on_all_ranks": same_on_all_ranks, "equals_single_gpu_result": equals_single,
+                              "note": "CanvasClean runs redundantly on every rank (its order statistics are genome-wide): the pass cannot drop below Clean + the collectives"},
+                  "cohort_mode": {"value": round(cbins / (cdt / args.steps), 1), "ms_per_step": round(cdt / args.steps * 1e3, 3), "scaling": "weak", "samples": world,
+                                  "note": "one 60x sample per rank, no data-path collective (python bench.py --multi cohort prints this mode as the headline)"}}
+        print(json.dumps(result))
+    dist.destroy_process_group()

@@ -51,6 +51,20 @@ int32_t canvas_device_free(canvas_ctx* ctx, void* d_ptr);
 int32_t canvas_memcpy_h2d(canvas_ctx* ctx, void* d_dst, const void* h_src, int64_t bytes);
 int32_t canvas_memcpy_d2h(canvas_ctx* ctx, void* h_dst, const void* d_src, int64_t bytes);
 
+/* Pins a host array (hipHostRegister) so that uploads from it run at the full PCIe rate and asynchronously: what a C# host does once with the arrays
+ * LoadIntermediateData left in memory (GCHandle.Alloc(..., Pinned) + this call). */
+int32_t canvas_host_register(canvas_ctx* ctx, void* h_ptr, int64_t bytes);
+int32_t canvas_host_unregister(canvas_ctx* ctx, void* h_ptr);
+/* The per-base arrays of CanvasBin always start in host memory (CanvasBin.LoadIntermediateData, CanvasBin/CanvasBin.cs:965-969).  This call queues their upload
+ * chromosome by chromosome on a copy stream of the context (h_* = host sources, d_* = caller-owned device destinations of at least h_len[c] bytes, the mask
+ * ceil(len/64) words; a NULL source table or entry = that array is already resident, e.g. the reference bases and the mask of a cohort) and returns at once.
+ * The next canvas_bin_sample / canvas_bin_genome / canvas_sample_pipeline call on this context that is given exactly these destination tables sweeps every
+ * chromosome as soon as it has arrived, so the upload of chromosome c + 1 overlaps the sweep of chromosome c: pass time ~ max(PCIe, compute), not the sum.
+ * Any other call must be preceded by canvas_upload_genome_wait.  Sources must stay valid (and should be pinned) until the binning call has returned. */
+int32_t canvas_upload_genome_begin(canvas_ctx* ctx, int32_t nchr, const int64_t* h_len, const uint8_t* const* h_bases, uint8_t* const* d_bases,
+                                   const uint64_t* const* h_mask, uint64_t* const* d_mask, const uint8_t* const* h_hits, uint8_t* const* d_hits);
+int32_t canvas_upload_genome_wait(canvas_ctx* ctx);
+
 /* ---- CanvasBin ----------------------------------------------------------------------------------------------- */
 /* InitializeAlignmentArrays (CanvasBin/CanvasBin.cs:183-200): possible[i] = char.IsUpper(referenceBases[i]).
  * d_mask must hold ceil(len/64) words; bits at and beyond len are written as 0. */
@@ -235,9 +249,31 @@ int32_t canvas_normalize_ratio(canvas_ctx* ctx, int64_t n, const float* d_sample
 /* ---- multi-GPU (one process per GPU; chromosomes sharded across ranks) ------------------------------------------ */
 int32_t canvas_comm_unique_id(void* h_id128);  /* ncclGetUniqueId, 128 bytes, rank 0 */
 int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const void* h_id128);
+/* transport for ranks that cannot form an RCCL communicator (several ranks on one GPU, a host with its own MPI): fn must all-gather bytes_per_rank bytes from
+ * `send` of every rank into `recv` (rank order), host memory, and return 0.  The library stages the device buffers through pinned host memory around it. */
+typedef int32_t (*canvas_host_allgather_fn)(void* user, const void* send, int64_t bytes_per_rank, void* recv);
+int32_t canvas_comm_init_host(canvas_ctx* ctx, int32_t rank, int32_t nranks, canvas_host_allgather_fn fn, void* user);
 /* the single RCCL all-gather of the path: every rank contributes nlocal int32 boundary records (padded to max_per_rank) */
 int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank,
                                     int32_t* d_all, int32_t* h_counts);
+
+/* ONE sample, chromosomes sharded over the ranks (BASELINE configs[3], [4]): canvas_sample_pipeline for a rank that holds the per-base arrays of the
+ * chromosomes with h_chr_owner[c] == its rank only (entries of the other chromosomes in d_bases / d_mask / d_hits are ignored; h_len, the autosome flags and the owner
+ * table describe the whole genome and are the same on every rank).  The reference's per-chromosome tasks (CanvasBin.cs:513-539, HiddenMarkovModelsRunner.cs:51-104) run on
+ * the owner; the genome-wide couplings are exchanged with three all-gathers on the communicator of canvas_comm_init / canvas_comm_init_host: the per-chromosome
+ * (observed, possible) table (one bin size for everybody, CanvasBin.cs:73-83), the owned bins (16 B/bin), and — the collective north_star names — the segment boundary
+ * records [n, (chr, startBin, endBin, state) ...] through canvas_allgather_boundaries.  CanvasClean runs on the gathered whole-genome SoA on every rank (deterministic,
+ * redundant).  Every rank returns the same outputs as canvas_sample_pipeline on one GPU, bit for bit: all cleaned bins, coverage, states and the running segment ids
+ * in file order (SegmentationResultsProcessor.cs:57-62).  Must be called by all ranks.  Modes 0 and 3. */
+int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                                       const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y,
+                                       int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                       int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                       double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                       int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments);
+/* last canvas_sample_pipeline_sharded call: [0] ranks, [1] chromosomes owned, [2] bins binned locally, [3] bytes this rank contributed to the bins all-gather,
+ * [4] boundary records of this rank, [5] bytes per rank of the boundary all-gather */
+int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6);
 
 /* ---- profiling hooks (hipEvent pairs recorded on the context's stream around the named kernels) --------------------- */
 int32_t canvas_profile_enable(canvas_ctx* ctx, int32_t on);

@@ -178,3 +178,57 @@ def test_bin_gc_content_weighted_mode(bin_path):
         assert (out["gc"][:total].cpu().numpy() == np.concatenate([e[2] for e in exp])).all()
         got = out["count"][:total].cpu().numpy(); ex = np.concatenate([e[3] for e in exp]).astype(np.float32)
         assert (got == ex).all(), (np.nonzero(got != ex)[0][:5], got[got != ex][:5], ex[got != ex][:5])
+
+
+def test_device_synth_sample_pair_matches_numpy():
+    """synth_generate_sample (tumour / normal over one reference, fragment lengths) is the numpy mirror byte for byte"""
+    import torch
+    from canvas_amd.lib import synth_generate_device, synth_generate_sample_device
+    cv = get_canvas()
+    L = 300_001
+    thr_t = synth.poisson_thresholds(0.28, purity=0.7)
+    b, h, m, fl = synth.generate_chromosome(SEED, 5, L, 0.28, thr_t, hit_seed=SEED + 77, with_fraglen=True)
+    db, _, dm, _ = synth_generate_device(SEED, 5, L, 0.28, cv.device)
+    dthr = torch.from_numpy(thr_t.view(np.int32)).to(cv.device)
+    dh, dfl = synth_generate_sample_device(SEED, SEED + 77, 5, L, dthr, cv.device, with_fraglen=True)
+    torch.cuda.synchronize()
+    assert (db[:L].cpu().numpy() == b).all() and (dm.cpu().numpy().view(np.uint8) == m).all()
+    assert (dh[:L].cpu().numpy() == h).all() and (dfl[:L].cpu().numpy() == fl).all()
+
+
+@pytest.mark.parametrize("resident_reference", [False, True])
+def test_streamed_upload_bins_match_oracle(resident_reference):
+    """canvas_upload_genome_begin + canvas_bin_sample: the per-chromosome sweeps start as the chromosomes arrive from host memory; same bins as the oracle.
+    resident_reference: bases and mask are already on the device (a cohort's shared reference), only the hits are uploaded."""
+    import torch
+    cv = get_canvas()
+    lengths = [900_001, 4096 * 50, 333_333, 1_000_000, 70_000]
+    data = _chroms(lengths, rate=0.21)
+    lens = np.array(lengths, np.int64)
+    pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+    hb = [pin(pad16(b)) for b, h, m in data]; hh = [pin(pad16(h)) for b, h, m in data]; hm = [pin(m.view(np.int64)) for b, h, m in data]
+    db = [torch.zeros_like(t, device=cv.device) for t in hb]; dh = [torch.zeros_like(t, device=cv.device) for t in hh]; dm = [torch.zeros_like(t, device=cv.device) for t in hm]
+    if resident_reference:
+        for d, s in zip(db + dm, hb + hm): d.copy_(s)
+        torch.cuda.synchronize()
+    cap = int(lens.sum() // 50)
+    mk = lambda dt: torch.empty(cap, dtype=dt, device=cv.device)
+    out = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+    rates = [O.bin_rate(h, m) for b, h, m in data]
+    for rep in range(2):                                  # twice: the second upload must wait for the first pass's readers
+        for t in dh: t.zero_()
+        torch.cuda.synchronize()
+        cv.upload_genome_begin(lens, None if resident_reference else hb, db, None if resident_reference else hm, dm, hh, dh)
+        _, per, total, bs = cv.bin_sample(db, dm, dh, lens, [1, 1, 1, 1, 0], 100, -1, 3, out=out)
+        assert bs == O.bin_size(rates[:4], 100)
+        exp = [O.bin_chromosome(b, m, h, bs) for b, h, m in data]
+        assert total == sum(len(e[0]) for e in exp)
+        for k, j in (("start", 0), ("stop", 1), ("gc", 2)):
+            assert (out[k][:total].cpu().numpy() == np.concatenate([e[j] for e in exp])).all(), k
+        assert (out["count"][:total].cpu().numpy() == np.concatenate([e[3] for e in exp]).astype(np.float32)).all()
+    # a pending upload followed by a call on OTHER arrays is simply waited for
+    cv.upload_genome_begin(lens, hb, db, hm, dm, hh, dh)
+    db2 = [t.clone() for t in db]
+    _, per, total2, bs2 = cv.bin_sample(db2, dm, dh, lens, [1, 1, 1, 1, 0], 100, -1, 3, out=out)
+    assert total2 == total and bs2 == bs
+    cv.upload_genome_wait()

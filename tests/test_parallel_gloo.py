@@ -44,7 +44,78 @@ def test_two_rank_bookkeeping():
     assert abs(l0 - l1) / (l0 + l1) < 0.02                                    # LPT balance by chromosome length
 
 
+def _shard_worker(rank, world, port, q):
+    """the bookkeeping of the chromosome-sharded pipeline on host arrays: what canvas_sample_pipeline_sharded does between its kernels, with the oracle standing in for
+    the kernels and gloo for RCCL.  Three exchanges: rate table, bins, boundary records."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_lib as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lengths = [500_000, 410_000, 300_001, 200_000, 120_000]; nchr = len(lengths); is_auto = [1, 1, 1, 1, 0]
+    owner = parallel.owner_table(lengths, world)
+    thr = synth.poisson_thresholds(0.21)
+    data = {c: synth.generate_chromosome(11, c, lengths[c], 0.21, thr) for c in range(nchr) if owner[c] == rank}
+    # 1. rate table: (observed, possible, possible before pos0) of the owned chromosomes, all-gathered
+    mine = torch.zeros(nchr * 3, dtype=torch.int64)
+    for c, (b, h, m) in data.items():
+        bits = np.unpackbits(m, bitorder="little")[:lengths[c]]
+        pos0 = int(np.argmax(b != ord("n"))) if (b != ord("n")).any() else lengths[c]
+        mine[3 * c] = int((h > 0).sum()); mine[3 * c + 1] = int(bits.sum()); mine[3 * c + 2] = int(bits[:pos0].sum())
+    tabs = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(tabs, mine)
+    tab = np.stack([t.numpy() for t in tabs])
+    obs = np.array([tab[owner[c], 3 * c] for c in range(nchr)]); pop = np.array([tab[owner[c], 3 * c + 1] for c in range(nchr)]); popb = np.array([tab[owner[c], 3 * c + 2] for c in range(nchr)])
+    bin_size = O.bin_size([obs[c] / float(pop[c]) for c in range(nchr) if is_auto[c]], 100)
+    nb, bin_off, rank_off, per_rank = parallel.bin_layout(owner, pop, popb, bin_size, world)
+    # 2. local bins, packed [4][maxB] and all-gathered, reassembled in file order
+    maxb = int(per_rank.max())
+    send = torch.zeros(4 * maxb, dtype=torch.int32)
+    for c, (b, h, m) in data.items():
+        st, en, gc, cnt = O.bin_chromosome(b, m, h, bin_size)
+        assert len(st) == nb[c]
+        for f, col in enumerate((st, en, gc, cnt)):
+            send[f * maxb + rank_off[c]: f * maxb + rank_off[c] + nb[c]] = torch.from_numpy(np.asarray(col, np.int32))
+    recv = [torch.zeros_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    cols = [np.concatenate([recv[owner[c]][f * maxb + rank_off[c]: f * maxb + rank_off[c] + nb[c]].numpy() for c in range(nchr)]) for f in range(4)]
+    chr_id = np.repeat(np.arange(nchr, dtype=np.int32), nb)
+    # 3. every rank: the same whole-genome arrays -> (here: no cleaning) coverage; 4. states of the owned chromosomes; 5. boundary records all-gathered
+    cov = cols[3].astype(np.float64); off = bin_off
+    paths, ran = O.hmm_genome_per_sample([np.ascontiguousarray(cov[off[c]:off[c + 1]]) for c in range(nchr)])       # genome-wide quartiles: every rank has all bins
+    owned = [c for c in range(nchr) if owner[c] == rank]
+    recs = parallel.boundary_records(owned, [paths[c] if ran[c] else np.full(nb[c], -1, np.int32) for c in owned])
+    counts, all_recs = parallel.gather_boundary_records(recs, 4 * 4096)
+    state = parallel.states_from_records(all_recs, owner, off)
+    seg = parallel.segment_ids_from_states(state, off, cols[0], cols[1])
+    q.put((rank, int(bin_size), chr_id.tolist(), [c.tolist() for c in cols], state.tolist(), seg.tolist(), counts))
+    dist.destroy_process_group()
+
+
+def test_sharded_bookkeeping_two_ranks_equals_one():
+    """world_size 2 on gloo: the sharded flow's exchanges and index arithmetic reproduce the single-process result exactly (bins, states, segment ids)"""
+    res = {}
+    for world in (1, 2):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs: p.start()
+        res[world] = sorted([q.get(timeout=300) for _ in range(world)])
+        for p in procs: p.join(30)
+    one = res[1][0]
+    for r in res[2]:
+        assert r[1:6] == one[1:6]
+        assert len(r[6]) == 2 and all(c > 0 and c % 4 == 0 for c in r[6])
+    assert len(set(one[5])) >= 5 and one[5][0] == 0 and one[5] == sorted(one[5])
+
+
 def test_single_process_paths():
     assert parallel.aggregate_throughput(2.0, 10.0) == (2.0, 10.0, 5.0)
     assert parallel.gather_boundary_records([4, 5], 4) == ([2], [[4, 5]])
     assert parallel.shard_units([5, 1, 1, 1, 1, 1], 2) == [[0], [1, 2, 3, 4, 5]]
+    assert parallel.owner_table([5, 1, 1, 1, 1, 1], 2).tolist() == [0, 1, 1, 1, 1, 1]
+    nb, off, roff, per = parallel.bin_layout([0, 1, 0], [100, 50, 31], [0, 10, 1], 10, 2)
+    assert nb.tolist() == [10, 4, 3] and off.tolist() == [0, 10, 14, 17] and roff.tolist() == [0, 0, 10] and per.tolist() == [13, 4]
+    recs = parallel.boundary_records([2, 5], [[1, 1, 2, 2, 2], [3]])
+    assert recs == [2, 0, 1, 1, 2, 2, 4, 2, 5, 0, 0, 3]

@@ -1,0 +1,148 @@
+"""The chromosome-sharded pipeline (canvas_sample_pipeline_sharded) must return, on every rank, exactly what the single-GPU pipeline returns.
+Two processes share the one GPU of the test box, so they cannot form an RCCL communicator: their exchanges go through the library's host-callback transport
+(torch.distributed / gloo underneath); the RCCL transport is exercised with a one-rank communicator in test_single_rank_rccl_communicator."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LENGTHS = [1_400_000, 1_100_003, 900_000, 650_000, 420_000, 300_001, 90_000]
+SEED = 20260927 + 4
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _inputs(device, only=None):
+    import torch
+    from canvas_amd import synth
+    thr = synth.poisson_thresholds(0.21)
+    pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+    bases, hits, masks = [], [], []
+    for c, L in enumerate(LENGTHS):
+        if only is not None and c not in only:
+            bases.append(None); hits.append(None); masks.append(None); continue
+        b, h, m = synth.generate_chromosome(SEED, c, L, 0.21, thr)
+        bases.append(torch.from_numpy(pad(b)).to(device)); hits.append(torch.from_numpy(pad(h)).to(device)); masks.append(torch.from_numpy(m.view(np.int64).copy()).to(device))
+    return bases, hits, masks
+
+
+def _buffers(device):
+    import torch
+    cap = sum(LENGTHS) // 100 + 64
+    mk = lambda dt: torch.empty(cap, dtype=dt, device=device)
+    return dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32)), mk(torch.float64), mk(torch.int32), mk(torch.int32)
+
+
+FLAGS = 1 | 2 | 4 | 8
+IS_AUTO = np.array([1, 1, 1, 1, 1, 0, 0], np.uint8)
+
+
+def _single(cv):
+    bases, hits, masks = _inputs(cv.device)
+    out, cov, state, seg = _buffers(cv.device)
+    r = cv.sample_pipeline(bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
+    cv.synchronize()
+    n = r["n_out"]
+    return r, {k: v[:n].cpu().numpy() for k, v in out.items()}, cov[:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy()
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        owner = parallel.owner_table(LENGTHS, world)
+        mine = [c for c in range(len(LENGTHS)) if owner[c] == rank]
+        bases, hits, masks = _inputs(cv.device, only=mine)
+        out, cov, state, seg = _buffers(cv.device)
+        res = []
+        for bin_size in (-1, 250):                              # derived from the exchanged rates / given (-z)
+            r = cv.sample_pipeline_sharded(owner, bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=bin_size, mode=3, flags=FLAGS)
+            cv.synchronize()
+            n = r["n_out"]
+            res.append((dict(r, off=r["off"].tolist()), {k: v[:n].cpu().numpy() for k, v in out.items()}, cov[:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy(),
+                        cv.sharded_stats().tolist()))
+        q.put((rank, owner.tolist(), res))
+        dist.destroy_process_group()
+    except Exception as e:                                      # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_rank_result():
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    for g in got:
+        assert g[1] != "error", g[2]
+    from canvas_amd import Canvas
+    cv = Canvas(0)
+    owner = got[0][1]
+    assert sorted(set(owner)) == [0, 1]
+    for k, bin_size in enumerate((-1, 250)):
+        if bin_size == -1:
+            ref = _single(cv)
+        else:
+            bases, hits, masks = _inputs(cv.device)
+            out, cov, state, seg = _buffers(cv.device)
+            r = cv.sample_pipeline(bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=bin_size, mode=3, flags=FLAGS)
+            cv.synchronize(); n = r["n_out"]
+            ref = (r, {kk: v[:n].cpu().numpy() for kk, v in out.items()}, cov[:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy())
+        r1 = ref[0]
+        for rank, _, res in got:
+            r, o, cv_, st, sg, stats = res[k]
+            assert (r["bin_size"], r["total"], r["n_out"], r["nseg"], r["lsd"]) == (r1["bin_size"], r1["total"], r1["n_out"], r1["nseg"], r1["lsd"]), (rank, bin_size)
+            assert r["off"] == r1["off"].tolist()
+            for key in ("chr", "start", "stop", "gc"):
+                assert (o[key] == ref[1][key]).all(), (rank, key)
+            assert (o["count"].view(np.uint32) == ref[1]["count"].view(np.uint32)).all()
+            assert (cv_ == ref[2]).all() and (st == ref[3]).all() and (sg == ref[4]).all()
+            assert stats[0] == 2 and stats[1] == owner.count(rank) and stats[4] > 0
+        assert r1["nseg"] > len(LENGTHS)                      # the planted copy-number segments are there
+
+
+def test_single_rank_rccl_communicator():
+    """the RCCL transport (ncclAllGather on the library's stream) with a communicator of one rank: same code path as N ranks, same result as the plain pipeline"""
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from canvas_amd import Canvas
+    cv = Canvas(0)
+    buf = (C.c_ubyte * 128)()
+    cv._check(cv.lib.canvas_comm_unique_id(buf))
+    cv._check(cv.lib.canvas_comm_init(cv.ctx, 0, 1, buf))
+    ref = _single(cv)
+    bases, hits, masks = _inputs(cv.device)
+    out, cov, state, seg = _buffers(cv.device)
+    r = cv.sample_pipeline_sharded(np.zeros(len(LENGTHS), np.int32), bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
+    cv.synchronize()
+    n = r["n_out"]
+    assert (r["total"], n, r["nseg"]) == (ref[0]["total"], ref[0]["n_out"], ref[0]["nseg"])
+    assert (seg[:n].cpu().numpy() == ref[4]).all() and (state[:n].cpu().numpy() == ref[3]).all()
+    assert (out["count"][:n].cpu().numpy().view(np.uint32) == ref[1]["count"].view(np.uint32)).all()
+    # the boundary all-gather itself, as the ABI exposes it
+    rec = torch.tensor([3, 0, 9, 2, 3, 10, 40, 1], dtype=torch.int32, device=cv.device)
+    allb = torch.zeros(1 + 16, dtype=torch.int32, device=cv.device)
+    cnt = np.zeros(1, np.int32)
+    torch.cuda.synchronize()
+    cv._check(cv.lib.canvas_allgather_boundaries(cv.ctx, C.c_void_p(rec.data_ptr()), 8, 16, C.c_void_p(allb.data_ptr()), cnt.ctypes.data_as(C.c_void_p)))
+    assert cnt[0] == 8 and allb[:9].cpu().tolist() == [8, 3, 0, 9, 2, 3, 10, 40, 1]
