@@ -27,6 +27,9 @@ def _inputs(device, only=None):
         if only is not None and c not in only:
             bases.append(None); hits.append(None); masks.append(None); continue
         b, h, m = synth.generate_chromosome(SEED, c, L, 0.21, thr)
+        if c in (0, 2, 5):                                      # a heterozygous deletion: every other hit of a stretch removed, so that the HMM has segments to find
+            a0, a1 = L // 4, L // 2
+            h = h.copy(); h[a0:a1] = np.where(np.arange(a0, a1) % 2 == 0, h[a0:a1], 0)
         bases.append(torch.from_numpy(pad(b)).to(device)); hits.append(torch.from_numpy(pad(h)).to(device)); masks.append(torch.from_numpy(m.view(np.int64).copy()).to(device))
     return bases, hits, masks
 
