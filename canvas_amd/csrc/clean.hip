@@ -251,9 +251,10 @@ __global__ void __launch_bounds__(256) k_run_bounds(const int32_t* __restrict__ 
 }
 
 // Utilities.Mad per chromosome run of the window SDs (CanvasClean.cs:243-258, Utilities.cs Median/Mad): one workgroup per run
-__global__ void __launch_bounds__(1024) k_run_mad(const double* __restrict__ sd, const int64_t* __restrict__ runStart, double* __restrict__ outMad) {
+__global__ void __launch_bounds__(1024) k_run_mad(const double* __restrict__ sd, const int64_t* __restrict__ runStart, double* __restrict__ outMad, const int* __restrict__ nrunsDev = nullptr) {
     __shared__ uint32_t sH[2][256];
     __shared__ unsigned long long sPre[2], sK[2];
+    if (nrunsDev && (int)blockIdx.x >= *nrunsDev) return;         // device-built run table: the grid is an upper bound
     const int64_t lo = runStart[blockIdx.x], hi = runStart[blockIdx.x + 1], cnt = hi - lo;
     if (cnt <= 0) { if (threadIdx.x == 0) outMad[blockIdx.x] = 0.0; return; }
     const unsigned long long r1 = (unsigned long long)(cnt / 2), r0 = (cnt % 2) ? r1 : r1 - 1;
@@ -265,11 +266,11 @@ __global__ void __launch_bounds__(1024) k_run_mad(const double* __restrict__ sd,
 }
 
 // ---------------------------------------------------------------- host helpers (scalar logic of the reference)
-static inline float median_from_two(float a, float b) { return (a + b) / 2; }   // SortedList<float>.Median(), even length
+static __host__ __device__ inline float median_from_two(float a, float b) { return (a + b) / 2; }   // SortedList<float>.Median(), even length
 
 // Utilities.Quartiles (CanvasCommon/Utilities.cs:361-419): which order statistics are needed for length n
 struct QuartIdx { int64_t idx[6]; int n; };
-static QuartIdx quartile_indices(int64_t iSize) {
+static __host__ __device__ QuartIdx quartile_indices(int64_t iSize) {
     QuartIdx q; q.n = 0;
     auto add = [&](int64_t v) { q.idx[q.n++] = v; };
     int64_t iMid = iSize / 2;
@@ -285,7 +286,7 @@ static QuartIdx quartile_indices(int64_t iSize) {
     }
     return q;
 }
-static void quartiles_from_values(int64_t iSize, const float* v, float& q1, float& q2, float& q3) {
+static __host__ __device__ void quartiles_from_values(int64_t iSize, const float* v, float& q1, float& q2, float& q3) {
     int64_t iMid = iSize / 2;
     if (iSize % 2 == 0) {
         q2 = (v[0] + v[1]) / 2;
@@ -648,6 +649,8 @@ static int32_t normalize_by_gc_loess(CleanState& st, int nchr, const uint8_t* h_
     return CANVAS_OK;
 }
 
+#include "clean_fast.hpp"
+
 extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
                                  int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc,
                                  double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info) {
@@ -659,6 +662,15 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     int32_t info[8] = {0};
     double localSd = -1.0;
     if (n == 0) { *h_n_out = 0; if (h_local_sd_out) *h_local_sd_out = -1.0; if (h_info) memcpy(h_info, info, sizeof info); return CANVAS_OK; }
+    // MedianByGC with the default weighted-median setting: the whole stage is driven from the device (clean_fast.hpp), one synchronisation at the end.  The host-driven
+    // path below stays for -m LOESS, -w < 100 (sparse GC buckets take the neighbour-weighted quantiles) and inputs with more than CF_MAXRUN chromosome runs;
+    // CANVAS_CLEAN_HOST_DRIVEN=1 forces it (test hook: the two paths must agree bit for bit)
+    if (!loessMode && min_bins_per_gc >= 100 && !getenv("CANVAS_CLEAN_HOST_DRIVEN")) {
+        bool handled = false;
+        int32_t rcf = clean_device_driven(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc, h_local_sd_out, h_n_out, h_info, &handled);
+        if (rcf) return rcf;
+        if (handled) return CANVAS_OK;
+    }
     // workspace
     const int64_t nW0 = n / 20 + 2;
     WsSizer sz;

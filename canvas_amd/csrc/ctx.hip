@@ -31,6 +31,7 @@ void canvas_destroy(canvas_ctx* ctx) {
     for (auto e : ctx->up_ev) (void)hipEventDestroy(e);
     if (ctx->up_fence) (void)hipEventDestroy(ctx->up_fence);
     if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
+    if (ctx->side_ev2) (void)hipEventDestroy(ctx->side_ev2);
     if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->misc_pin) (void)hipHostFree(ctx->misc_pin);

@@ -46,10 +46,11 @@ static inline double host_double_of_key(unsigned long long k) {
 template <typename K>
 __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys, const SelTile* __restrict__ tiles, const SelSegQ* __restrict__ segq,
                                                      const unsigned long long* __restrict__ qprefix, int shift, int firstPass,
-                                                     uint32_t* __restrict__ hist /* [SEL_REP][nq][256] */, int nq) {
+                                                     uint32_t* __restrict__ hist /* [SEL_REP][nq][256] */, int nq, const uint32_t* __restrict__ hdr = nullptr) {
     __shared__ uint32_t lh[SEL_MAXQ * 256];
     __shared__ unsigned long long lpre[SEL_MAXQ];
     __shared__ int srep[SEL_MAXQ], suniq[SEL_MAXQ], snu;
+    if (hdr && blockIdx.x >= hdr[0]) return;              // device-built problem (clean_fast.hpp): hdr = {tiles, queries}; the grid is an upper bound
     const SelTile T = tiles[blockIdx.x];
     const SelSegQ Q = segq[T.seg];
     if (Q.nq == 0) return;
@@ -132,9 +133,9 @@ __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys,
 
 // one wave per query: locate the digit holding rank k, narrow (prefix, k), clear the histogram row
 static __global__ void __launch_bounds__(64) k_select_pick(uint32_t* __restrict__ hist, unsigned long long* __restrict__ qprefix,
-                                                    unsigned long long* __restrict__ qk, int nq, int firstPass) {
+                                                    unsigned long long* __restrict__ qk, int nq, int firstPass, const uint32_t* __restrict__ hdr = nullptr) {
     const int q = blockIdx.x;
-    if (q >= nq) return;
+    if (q >= nq || (hdr && (uint32_t)q >= hdr[1])) return;
     const int l = threadIdx.x;
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll

@@ -10,6 +10,15 @@ pytestmark = pytest.mark.gpu
 ALL = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD
 
 
+@pytest.fixture(params=["device_driven", "host_driven"], autouse=True)
+def clean_path(request, monkeypatch):
+    """Both CanvasClean orchestrations run every case: the device-driven one (clean_fast.hpp: decisions in one-workgroup kernels, one synchronisation) that the default
+    options take, and the host-driven one (CANVAS_CLEAN_HOST_DRIVEN=1) that remains for -m LOESS, -w < 100 and inputs with very many chromosome runs."""
+    if request.param == "host_driven":
+        monkeypatch.setenv("CANVAS_CLEAN_HOST_DRIVEN", "1")
+    return request.param
+
+
 def _run(cv, bins, flags, nchr=24, w=100, is_auto=None):
     is_auto = synth.IS_AUTOSOME[:nchr] if is_auto is None else np.asarray(is_auto, np.uint8)
     is_y = np.zeros(nchr, np.uint8); is_y[-1] = 1
@@ -188,3 +197,21 @@ def test_clean_rejects_out_of_range_gc_and_chromosome():
         dev = {k: to_dev(v, cv.device) for k, v in bins.items()}
         with pytest.raises(CanvasError, match="gc outside 0..100"):
             cv.clean(dev, len(bins["chr"]), synth.IS_AUTOSOME, ALL)
+
+
+def test_clean_many_chromosome_runs_falls_back_untouched():
+    """more chromosome runs than the device-driven path sorts in one workgroup (interleaved chromosomes): it must notice on the device, leave the caller's arrays as
+    they were and let the host-driven path produce the result"""
+    cv = get_canvas()
+    bins = synth.generate_bins(20260927 + 6, 60_000, nchr=24)
+    bins["chr"] = ((np.arange(len(bins["chr"])) // 20) % 24).astype(np.int32)        # blocks of 20 bins cycle through the chromosomes: ~3000 runs
+    info, exp = _run(cv, bins, ALL)
+    assert exp["local_sd"] >= 0
+
+
+def test_clean_small_inputs_and_flag_subsets():
+    cv = get_canvas()
+    for n, flags in ((1, ALL), (2, ALL), (19, CLEAN_OUTLIERS), (200, CLEAN_GCNORM), (50_001, CLEAN_LOCALSD), (50_500, CLEAN_FILTSIZE | CLEAN_LOCALSD), (600_000, CLEAN_GCNORM | CLEAN_LOCALSD)):
+        bins = synth.generate_bins(20260927 + 7, max(n, 24), nchr=24 if n >= 24 else 1)
+        bins = {k: v[:n] if n < 24 else v for k, v in bins.items()}
+        _run(cv, bins, flags, nchr=24 if n >= 24 else 1, is_auto=None if n >= 24 else [1])
