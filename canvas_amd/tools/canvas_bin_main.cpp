@@ -4,12 +4,13 @@
 //   CanvasBin -b S.bam -r kmer.fa -i chr1.dat -i chr2.dat ... -o S.binned -d 100 [-z size] [-y] [-m]   intermediates -> S.binned
 // Phase 1 keeps the reference's host work (FASTA and BAM parsing; BGZF inflate through zlib) and runs the per-base array
 // preparation on the GPU (possible mask from the FASTA case, BED exclusion, hit screening).  Phase 2 is canvas_bin_sample /
-// canvas_bin_sample_gcweighted.  The intermediate file is private to these two invocations (the pipeline never opens it), so it
-// is a plain binary dump rather than protobuf-net's encoding (CanvasBin.cs:1037-1148).
+// canvas_bin_sample_gcweighted.  The intermediate file is the reference's: protobuf-net's encoding of CanvasBin.IntermediateData (CanvasBin.cs:1037-1148,
+// protobuf_dat.hpp) including the bit-order quirk of its writer / reader pair, so the C# CanvasBin -c and this CanvasBin -i (or the other way round) can be mixed.
 // BAM flag semantics follow the SAM specification; Isas.SequencingFiles.BamReader is not part of /root/reference (parity unpinned):
 // IsMainAlignment := neither secondary (0x100) nor supplementary (0x800).
 // Not built (exit code 1 with a message): -t manifest, -n predefined bins, -m Fragment, the multi-sample -j json mode.
 #include "tool_common.hpp"
+#include "protobuf_dat.hpp"
 #include <algorithm>
 #include <memory>
 using namespace tool;
@@ -138,32 +139,8 @@ static int load_bam(const std::string& bam, bool pairedEnd, const std::string& c
     return 0;
 }
 
-// ---------------------------------------------------------------- intermediate file
-struct Inter { std::string name; int64_t len = 0; std::vector<uint8_t> mask, hits; std::vector<int16_t> frag; };
-static bool write_inter(const std::string& path, const Inter& d) {
-    FILE* f = fopen(path.c_str(), "wb"); if (!f) return false;
-    const char magic[12] = "CANVASDAT2\n"; fwrite(magic, 1, 12, f);
-    uint32_t ln = (uint32_t)d.name.size(); fwrite(&ln, 4, 1, f); fwrite(d.name.data(), 1, ln, f);
-    fwrite(&d.len, 8, 1, f);
-    uint64_t nm = d.mask.size(), nh = d.hits.size(), nf = d.frag.size();
-    fwrite(&nm, 8, 1, f); fwrite(d.mask.data(), 1, nm, f); fwrite(&nh, 8, 1, f); fwrite(d.hits.data(), 1, nh, f); fwrite(&nf, 8, 1, f); fwrite(d.frag.data(), 2, nf, f);
-    bool ok = !ferror(f); fclose(f); return ok;
-}
-static bool read_inter(const std::string& path, Inter& d) {
-    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
-    char magic[12]; uint32_t ln; uint64_t nm, nh, nf; bool ok = false;
-    do {
-        if (fread(magic, 1, 12, f) != 12 || memcmp(magic, "CANVASDAT2\n", 12) != 0) break;
-        if (fread(&ln, 4, 1, f) != 1 || ln > 4096) break;
-        d.name.resize(ln); if (fread(&d.name[0], 1, ln, f) != ln) break;
-        if (fread(&d.len, 8, 1, f) != 1) break;
-        if (fread(&nm, 8, 1, f) != 1) break; d.mask.resize(nm); if (fread(d.mask.data(), 1, nm, f) != nm) break;
-        if (fread(&nh, 8, 1, f) != 1) break; d.hits.resize(nh); if (fread(d.hits.data(), 1, nh, f) != nh) break;
-        if (fread(&nf, 8, 1, f) != 1) break; d.frag.resize(nf); if (nf && fread(d.frag.data(), 2, nf, f) != nf) break;
-        ok = true;
-    } while (0);
-    fclose(f); return ok;
-}
+// ---------------------------------------------------------------- intermediate file: see protobuf_dat.hpp
+struct Inter { std::string name; int64_t len = 0; std::vector<uint64_t> maskWords; std::vector<uint8_t> hits; std::vector<int16_t> frag; };
 
 static int parse_mode(const std::string& m) {       // Utilities.ParseCanvasCoverageMode (CanvasCommon/Utilities.cs:56-74)
     std::string s; for (char c : m) if (c != ' ' && c != '\t') s.push_back((char)tolower(c));
@@ -211,6 +188,7 @@ int main(int argc, char** argv) {
         if (!read_fasta(ref, &chrom, fa) || fa.empty()) { fprintf(stderr, "CanvasBin: chromosome %s not found in %s\n", chrom.c_str(), ref.c_str()); return 1; }
         Inter d; d.name = chrom; d.len = (int64_t)fa[0].bases.size();
         const int64_t L = d.len, words = (L + 63) / 64;
+        std::vector<uint64_t> mw(words, 0);
         d.hits.assign(L, 0); if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) d.frag.assign(L, 0);
         printf("Initialized alignment arrays\n");
         if (int rc = load_bam(bam, a.has("paired-end"), chrom, mode, d.hits, d.frag)) return rc;
@@ -227,12 +205,13 @@ int main(int argc, char** argv) {
                     TOOL_TRY(ctx, canvas_mask_exclude_intervals(ctx, dMask.as<uint64_t>(), L, (int32_t)s.size(), s.data(), e.data())); }
             }
             TOOL_TRY(ctx, canvas_screen_hits(ctx, dHits.as<uint8_t>(), dMask.as<uint64_t>(), L));
-            std::vector<uint64_t> mw(words);
             TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, mw.data(), dMask.p, words * 8));
             TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, d.hits.data(), dHits.p, L));
-            d.mask.resize((L + 7) / 8); memcpy(d.mask.data(), mw.data(), d.mask.size());
         }
-        if (!write_inter(out, d)) { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
+        pbdat::Data pd; pbdat::Chromosome& pc = pd[chrom];
+        pbdat::pack_possible_msb(mw.data(), L, pc.possibleBytes, pc.bitsInLastByte);        // most significant bit first, as the C# writer (Q2)
+        pc.observed.swap(d.hits); pc.fragmentLengths.swap(d.frag);
+        if (!pbdat::write_file(out, pd, mode == CANVAS_MODE_GC_CONTENT_WEIGHTED)) { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
         printf("Intermediate observedAlignments serialized\n");
         return 0;
     }
@@ -241,9 +220,16 @@ int main(int argc, char** argv) {
     std::map<std::string, std::unique_ptr<Inter>> byChrom;
     for (auto& p : inters) {
         if (!file_exists(p)) { fprintf(stderr, "CanvasBin: intermediate file %s does not exist\n", p.c_str()); return 1; }
-        auto d = std::make_unique<Inter>();
-        if (!read_inter(p, *d)) { fprintf(stderr, "CanvasBin: %s is not an intermediate file of this CanvasBin\n", p.c_str()); return 1; }
-        std::string nm = d->name; byChrom[nm] = std::move(d);
+        pbdat::Data pd; std::string perr;
+        if (!pbdat::read_file(p, pd, perr)) { fprintf(stderr, "CanvasBin: %s\n", perr.c_str()); return 1; }
+        for (auto& kv : pd) {                                                               // DeserializeCanvasData + IntermediateData.GetData (CanvasBin.cs:725-762,1089-1104)
+            auto d = std::make_unique<Inter>(); d->name = kv.first;
+            d->len = pbdat::unpack_possible_lsb(kv.second.possibleBytes, kv.second.bitsInLastByte, d->maskWords);      // least significant bit first, as the C# reader (Q2)
+            d->hits.swap(kv.second.observed); d->frag.swap(kv.second.fragmentLengths);
+            if ((int64_t)d->hits.size() != d->len) { fprintf(stderr, "CanvasBin: %s: %s has %lld possible-alignment bits but %zu observed-alignment bytes\n", p.c_str(), kv.first.c_str(), (long long)d->len, d->hits.size()); return 1; }
+            if (byChrom.count(kv.first)) { fprintf(stderr, "CanvasBin: chromosome %s appears in more than one intermediate file (Dictionary.Add throws in the reference)\n", kv.first.c_str()); return 1; }
+            byChrom[kv.first] = std::move(d);
+        }
     }
     std::vector<FastaEntry> fa;
     if (!read_fasta(ref, nullptr, fa)) return 1;
@@ -257,8 +243,7 @@ int main(int argc, char** argv) {
     for (int c = 0; c < nchr; c++) {
         const int64_t L = data[c]->len, words = (L + 63) / 64; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
         auto up = [&](const void* src, int64_t bytes, int64_t alloc) -> void* { devs.push_back(std::make_unique<Dev>(ctx, alloc)); void* p = devs.back()->p; if (bytes > 0 && canvas_memcpy_h2d(ctx, p, src, bytes) != 0) return nullptr; return p; };
-        std::vector<uint8_t> mw((size_t)words * 8, 0); memcpy(mw.data(), data[c]->mask.data(), std::min(mw.size(), data[c]->mask.size()));
-        pBases[c] = (const uint8_t*)up(order[c]->bases.data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits.data(), L, L + 64); pMask[c] = (const uint64_t*)up(mw.data(), words * 8, words * 8 + 64);
+        pBases[c] = (const uint8_t*)up(order[c]->bases.data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits.data(), L, L + 64); pMask[c] = (const uint64_t*)up(data[c]->maskWords.data(), words * 8, words * 8 + 64);
         if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { if ((int64_t)data[c]->frag.size() != L) { fprintf(stderr, "CanvasBin: %s has no fragment lengths (was the intermediate written with -m GCContentWeighted?)\n", order[c]->name.c_str()); return 1; } pFrag[c] = (const int16_t*)up(data[c]->frag.data(), L * 2, L * 2 + 64); }
         if (!pBases[c] || !pHits[c] || !pMask[c]) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
     }

@@ -59,6 +59,77 @@ def _write_bam(path, refs, reads):
     open(path + ".bai", "wb").write(bai)
 
 
+# ---- protobuf wire format, written from the specification (varints, tags = field << 3 | wire type, length-delimited fields): the fixtures below do not share
+# code with canvas_amd/tools/protobuf_dat.hpp
+def _varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80); v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _ld(field, payload):
+    return _varint(field << 3 | 2) + _varint(len(payload)) + payload
+
+
+def _encode_dat(name, possible_bytes, observed, bits_in_last_byte, frag=None, packed=False, omit_zero=False):
+    """CanvasBin.IntermediateData of one chromosome as protobuf-net lays it out: every dictionary = repeated { 1: key, 2: value } entries under its member number"""
+    key = _ld(1, name.encode())
+    msg = _ld(1, key + _ld(2, bytes(possible_bytes))) + _ld(2, key + _ld(2, bytes(observed)))
+    msg += _ld(3, key + (b"" if (omit_zero and bits_in_last_byte == 0) else _varint(2 << 3 | 0) + _varint(bits_in_last_byte)))
+    if frag is not None:
+        if packed:
+            msg += _ld(4, key + _ld(2, b"".join(_varint(int(v)) for v in frag)))
+        else:
+            msg += _ld(4, key + b"".join(_varint(2 << 3 | 0) + _varint(int(v)) for v in frag))
+    return msg
+
+
+def _decode_dat(blob):
+    """{member number: {key: value}} of a .dat (bytes values as bytes, member 3 as int, member 4 as list of ints)"""
+    def rd(buf, i):
+        v = 0; sh = 0
+        while True:
+            b = buf[i]; i += 1; v |= (b & 0x7F) << sh; sh += 7
+            if not b & 0x80: return v, i
+    out = {}
+    i = 0
+    while i < len(blob):
+        tag, i = rd(blob, i); field, wire = tag >> 3, tag & 7
+        assert wire == 2
+        n, i = rd(blob, i); entry = blob[i:i + n]; i += n
+        j = 0; key = None; val = [] if field == 4 else None
+        while j < len(entry):
+            t, j = rd(entry, j); f2, w2 = t >> 3, t & 7
+            if w2 == 2:
+                k, j = rd(entry, j); payload = entry[j:j + k]; j += k
+                if f2 == 1: key = payload.decode()
+                else: val = payload
+            else:
+                v, j = rd(entry, j)
+                if v >= 1 << 63: v -= 1 << 64
+                if field == 4: val.append(v)
+                else: val = v
+        out.setdefault(field, {})[key] = val
+    return out
+
+
+def _msb_pack(bits):
+    """IntermediateData's writer (CanvasBin.cs:1052-1072): most significant bit of every byte first; a last partial byte keeps its bits in the low positions"""
+    out = bytearray((len(bits) + 7) // 8)
+    for i, b in enumerate(bits):
+        out[i >> 3] = (out[i >> 3] * 2 + int(b)) & 0xFF
+    return bytes(out)
+
+
+def _lsb_unpack(data, bits_in_last_byte):
+    """IntermediateData.Convert (CanvasBin.cs:1106-1135): new BitArray(bytes) is least significant bit first"""
+    n = 8 * (len(data) - 1) + bits_in_last_byte if bits_in_last_byte > 0 else 8 * len(data)
+    return np.array([(data[i >> 3] >> (i & 7)) & 1 for i in range(n)], bool)
+
+
 def _kept(r, paired):
     f = r["flag"]
     if f & 0x4 or f & 0x200 or f & 0x400 or f & 0x10 or f & 0x900: return False
@@ -122,6 +193,8 @@ def test_canvasbin_bam_to_binned(tmp_path):
         for c, ivs in excl.items():
             for a, b in ivs: f.write(f"{c}\t{a}\t{b}\n")
 
+    true_masks = {}
+
     def expected_arrays(paired, mode):
         masks, hits = {}, {}
         for ri, (name, ln) in enumerate(refs):
@@ -131,8 +204,12 @@ def test_canvasbin_bam_to_binned(tmp_path):
             ps = np.array([r["pos"] for r in reads if r["ref"] == ri and _kept(r, paired)], np.int64)
             np.add.at(h, ps, 1)
             h = np.minimum(h, 1 if mode == 0 else 255)
-            h[~m] = 0
-            masks[name] = np.packbits(m, bitorder="little"); hits[name] = h.astype(np.uint8)
+            h[~m] = 0                                     # ScreenObservedTags runs BEFORE the .dat round trip, with the mask as computed (CanvasBin.cs:780)
+            # ... and the bins are made from what CanvasBin -i reads back: the writer packs MSB-first, the reader unpacks LSB-first
+            m_read = _lsb_unpack(_msb_pack(m), ln % 8)
+            assert len(m_read) == ln
+            true_masks[name] = m
+            masks[name] = np.packbits(m_read, bitorder="little"); hits[name] = h.astype(np.uint8)
         return masks, hits
 
     for paired, mode, mflag in ((True, 3, "TruncatedDynamicRange"), (False, 0, "0")):
@@ -158,9 +235,47 @@ def test_canvasbin_bam_to_binned(tmp_path):
         with gzip.open(binned, "rt") as f:
             got = f.read().splitlines()
         assert len(got) > 50 and got == exp
+        # the intermediate files are the reference's protobuf-net encoding of IntermediateData: decoded here by an independent reader
+        for name, ln in refs:
+            d = _decode_dat(open(str(tmp_path / f"{name}.{mode}.dat"), "rb").read())
+            assert set(d) == {1, 2, 3} and list(d[1]) == [name] and list(d[2]) == [name]
+            assert d[3][name] == ln % 8 and d[1][name] == _msb_pack(true_masks[name]) and d[2][name] == hits[name].tobytes()
         # -y: bin size only, written without a newline (CanvasBin.cs:926-928)
         r = subprocess.run([BIN, "-b", bam, "-r", fa, "-o", binned, "-d", "100", "-y", "-m", mflag] + dats, capture_output=True, text=True)
         assert r.returncode == 0 and open(binned + ".binsize").read() == str(bs)
+    # ---- a .dat that this tool did not write: hand-encoded per the wire specification (what a C# CanvasBin -c leaves behind), incl. the variants a protobuf
+    # writer may choose (packed fragment lengths, an omitted zero) and -m GCContentWeighted with its fragment-length member
+    rng2 = np.random.RandomState(5)
+    fa2 = str(tmp_path / "two.fa"); lens2 = {"chrA": 40_003, "chrB": 24_000}
+    seq2 = {n: rng2.choice(np.frombuffer(b"ACGTacgt", np.uint8), L, p=[0.2, 0.2, 0.2, 0.2, 0.05, 0.05, 0.05, 0.05]) for n, L in lens2.items()}
+    with open(fa2, "w") as f:
+        for n, b in seq2.items():
+            f.write(f">{n}\n" + b.tobytes().decode() + "\n")
+    for mode, mflag in ((3, "3"), (5, "GCContentWeighted")):
+        args = []; mk, hk, fk = [], [], []
+        for k, (n, L) in enumerate(lens2.items()):
+            stored = rng2.randint(0, 256, (L + 7) // 8).astype(np.uint8)                   # the bytes as they sit in the file
+            m_read = _lsb_unpack(stored.tobytes(), L % 8)
+            h = (rng2.poisson(0.3, L) * m_read).astype(np.uint8)
+            fl = np.where(h > 0, rng2.randint(150, 500, L), 0).astype(np.int16)
+            dat = str(tmp_path / f"hand.{n}.{mode}.dat")
+            open(dat, "wb").write(_encode_dat(n, stored.tobytes(), h.tobytes(), L % 8, frag=fl if mode == 5 else None, packed=(k == 1), omit_zero=True))
+            args += ["-i", dat]; mk.append(np.packbits(m_read, bitorder="little")); hk.append(h); fk.append(fl)
+        binned = str(tmp_path / f"hand.{mode}.binned")
+        r = subprocess.run([BIN, "-b", bam, "-r", fa2, "-o", binned, "-d", "100", "-z", "150", "-m", mflag] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        names2 = list(lens2)
+        if mode == 3:
+            res = O.bin_genome([seq2[n] for n in names2], mk, hk, 150, mode=3, threads=2)
+            exp = [f"{n}\t{s}\t{e}\t{O.format_f2(float(k))}\t{g}" for c, n in enumerate(names2) for s, e, g, k in zip(res[0][c], res[1][c], res[2][c], res[3][c])]
+        else:
+            resw, _, _, _ = O.bin_gc_weighted([seq2[n] for n in names2], mk, hk, fk, 150)
+            exp = [f"{n}\t{s}\t{e}\t{O.format_f2(float(k))}\t{g}" for c, n in enumerate(names2) for s, e, g, k in zip(resw[c][0], resw[c][1], resw[c][2], resw[c][3])]
+        with gzip.open(binned, "rt") as f:
+            assert f.read().splitlines() == exp
+    # a truncated file is refused
+    bad = str(tmp_path / "bad.dat"); open(bad, "wb").write(_encode_dat("chrA", b"\xff" * 10, b"\x01" * 80, 0)[:-7])
+    assert subprocess.run([BIN, "-b", bam, "-r", fa2, "-o", str(tmp_path / "x.binned"), "-d", "100", "-i", bad], capture_output=True).returncode == 1
     # error conventions (Program.cs:108-170)
     assert subprocess.run([BIN], capture_output=True).returncode == 1
     assert subprocess.run([BIN, "-b", str(tmp_path / "none.bam"), "-r", fa, "-c", "chr1", "-o", str(tmp_path / "x.dat"), "-d", "100"], capture_output=True).returncode == 1
