@@ -1049,3 +1049,77 @@ int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* cons
                               int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
     return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, nullptr, 0, -1, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total, hook, user);
 }
+
+// ---------------------------------------------------------------------------------------------- predefined bins (CanvasBin -n)
+// BinCountsForChromosome with usePredefinedBins (CanvasBin.cs:575-655): the cursor jumps from interval to interval, so every bin is the range [Start, Stop) of its own —
+// except the chromosome's FIRST bin, whose leading 'n' bases are skipped before anything is counted (:582-584).  One wave per bin, 64 positions per step.
+struct PreChrom { const uint8_t* bases; const uint8_t* hits; const uint64_t* mask; long long len; long long binBegin, binEnd; };
+__global__ void __launch_bounds__(256) k_bin_predefined(const PreChrom* __restrict__ ch, int nchr, long long nbins, const int32_t* __restrict__ bStart, const int32_t* __restrict__ bStop, int clampHits,
+                                                        int32_t* __restrict__ oGc, float* __restrict__ oCount, int* __restrict__ err) {
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nbins) return;
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ch[mid].binBegin <= b) lo = mid; else hi = mid - 1; }
+    const PreChrom C = ch[lo];
+    const int l = lane_id();
+    long long s = bStart[b]; const long long e = bStop[b];
+    if (b == C.binBegin) {                                   // "Skip past leading Ns" from the first bin's start
+        for (;;) {
+            const long long p = s + l;
+            const bool isn = p < C.len && C.bases[p] == 'n';
+            const unsigned long long m = __ballot(!isn);
+            if (m) { s += __builtin_ctzll(m); break; }
+            s += 64;
+            if (s >= C.len) break;
+        }
+        if (s > e - 1) { if (l == 0) atomicExch(err, 1); return; }      // the reference's cursor never meets Stop - 1 again: no bin of this chromosome would ever be closed
+    }
+    uint32_t gcn = 0, obs = 0;
+    for (long long p0 = s; p0 < e; p0 += 64) {
+        const long long p = p0 + l;
+        if (p < e) {
+            const uint8_t c = C.bases[p];
+            gcn += (c == 'C' || c == 'c' || c == 'G' || c == 'g') ? 1u : 0u;
+            if ((C.mask[p >> 6] >> (p & 63)) & 1ull) { const uint32_t h = C.hits[p]; obs += clampHits ? min(10u, h) : h; }
+        }
+    }
+    gcn = wave_reduce_add_u32(gcn); obs = wave_reduce_add_u32(obs);
+    if (l == 0) {
+        const int nucleotideCount = (int)(e - s);            // every position counts: "!Bases[pos].Equals("n")" compares a char with a string and is always true (:594)
+        oGc[b] = (int32_t)(100.0f * (float)(int)gcn / (float)nucleotideCount);
+        oCount[b] = (float)(int)obs;
+    }
+}
+
+extern "C" int32_t canvas_bin_predefined(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
+                                         int32_t mode, const int64_t* h_bin_offset, const int32_t* h_bin_start, const int32_t* h_bin_stop, const int32_t* d_bin_start, const int32_t* d_bin_stop,
+                                         int32_t* d_gc, float* d_count) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || !h_bin_offset || !h_bin_start || !h_bin_stop || !d_bin_start || !d_bin_stop || !d_gc || !d_count)
+        CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_predefined: bad arguments");
+    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_bin_predefined: coverage modes 0 and 3");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int32_t rcf = canvas_upload_fence(ctx); if (rcf) return rcf; }
+    const long long nbins = h_bin_offset[nchr];
+    std::vector<PreChrom> pc(nchr);
+    for (int c = 0; c < nchr; c++) {
+        pc[c] = PreChrom{d_bases[c], d_hits[c], d_mask[c], (long long)h_len[c], (long long)h_bin_offset[c], (long long)h_bin_offset[c + 1]};
+        for (long long b = h_bin_offset[c]; b < h_bin_offset[c + 1]; b++) {
+            if (h_bin_start[b] < 0 || h_bin_start[b] >= h_bin_stop[b]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "predefined bin with Start < 0 or Start >= Stop (Utilities.LoadBedFile throws)");
+            if (h_bin_stop[b] > h_len[c]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "predefined bin beyond the end of its chromosome (the reference's cursor never closes it)");
+        }
+    }
+    if (nbins == 0) return CANVAS_OK;
+    int32_t rc = canvas_ws_reserve(ctx, (size_t)nchr * sizeof(PreChrom) + 512); if (rc) return rc;
+    PreChrom* dCh = (PreChrom*)ctx->ws; int* dErr = (int*)((char*)ctx->ws + (((size_t)nchr * sizeof(PreChrom) + 255) & ~size_t(255)));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, pc.data(), (size_t)nchr * sizeof(PreChrom), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dErr, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_bin_predefined, dim3((unsigned)((nbins + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, nbins, d_bin_start, d_bin_stop, mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, d_gc, d_count, dErr);
+    int err = 0;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&err, dErr, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    if (err) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "the first predefined bin of a chromosome lies entirely in leading 'n' bases (the reference then fills no bin of that chromosome)");
+    return CANVAS_OK;
+}
+

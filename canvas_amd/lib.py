@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h", "canvas_host_register", "canvas_host_unregister", "canvas_upload_genome_begin", "canvas_upload_genome_wait",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
-    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted",
+    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
     "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sharded_stats", "canvas_profile_enable", "canvas_profile_get",
 ]
@@ -201,6 +201,21 @@ class Canvas:
                                                           C.c_int64(out["chr"].numel()), C.byref(bs), _np_ptr(per), C.byref(total)))
         self.synchronize()
         return out, per, total.value, bs.value
+
+    def bin_predefined(self, bases, masks, hits, lens, bin_starts, bin_stops, mode=MODE_TDR):
+        """CanvasBin -n (BinCountsForChromosome with predefined bins): bin_starts / bin_stops = one array per chromosome; returns (gc, count) tensors over the concatenated bins"""
+        torch = self.torch
+        n = len(bases)
+        lens = np.ascontiguousarray(lens, np.int64)
+        off = np.concatenate([[0], np.cumsum([len(b) for b in bin_starts])]).astype(np.int64)
+        hs = np.ascontiguousarray(np.concatenate([np.asarray(b, np.int32) for b in bin_starts] + [np.zeros(0, np.int32)]), np.int32)
+        he = np.ascontiguousarray(np.concatenate([np.asarray(b, np.int32) for b in bin_stops] + [np.zeros(0, np.int32)]), np.int32)
+        ds = torch.from_numpy(hs if len(hs) else np.zeros(1, np.int32)).to(self.device); de = torch.from_numpy(he if len(he) else np.zeros(1, np.int32)).to(self.device)
+        gc = torch.empty(max(1, len(hs)), dtype=torch.int32, device=self.device); cnt = torch.empty(max(1, len(hs)), dtype=torch.float32, device=self.device)
+        self.torch.cuda.synchronize()
+        self._check(self.lib.canvas_bin_predefined(self.ctx, n, _ptr_table(bases), _ptr_table(masks), _ptr_table(hits), _np_ptr(lens), int(mode), _np_ptr(off), _np_ptr(hs), _np_ptr(he),
+                                                   C.c_void_p(ds.data_ptr()), C.c_void_p(de.data_ptr()), C.c_void_p(gc.data_ptr()), C.c_void_p(cnt.data_ptr())))
+        return gc[:len(hs)], cnt[:len(hs)]
 
     def chromosome_offsets(self, chr_ids, n, nchr):
         off = np.zeros(nchr + 1, np.int64)

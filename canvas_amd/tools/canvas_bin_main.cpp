@@ -8,11 +8,16 @@
 // protobuf_dat.hpp) including the bit-order quirk of its writer / reader pair, so the C# CanvasBin -c and this CanvasBin -i (or the other way round) can be mixed.
 // BAM flag semantics follow the SAM specification; Isas.SequencingFiles.BamReader is not part of /root/reference (parity unpinned):
 // IsMainAlignment := neither secondary (0x100) nor supplementary (0x800).
-// Not built (exit code 1 with a message): -t manifest, -n predefined bins, -m Fragment, the multi-sample -j json mode.
+//   CanvasBin -b S.bam -r kmer.fa -i ... -n bins.bed -o S.binned -d 100 [-m 0|3]                       predefined bins (canvas_bin_predefined)
+//   CanvasBin -b S.bam -r genome.fa -n bins.bed -o S.binned -m Fragment -p                              FragmentBinner.Bin (FragmentBinner.cs:26-80): host code
+// Fragment mode is a sequential dictionary algorithm over the BAM stream keyed by read name (the mate confirms or undoes what the first read of the pair did): its cost is
+// BGZF inflation and string hashing, there is no data-parallel part, so it runs on the host exactly as in the reference.
+// Not built (exit code 1 with a message): -t manifest (the Nextera manifest parser lives in Isas.Manifests, outside /root/reference) and the multi-sample -j json mode.
 #include "tool_common.hpp"
 #include "protobuf_dat.hpp"
 #include <algorithm>
 #include <memory>
+#include <set>
 using namespace tool;
 
 // ---------------------------------------------------------------- FASTA (kmer.fa: upper case = start of a unique k-mer)
@@ -142,6 +147,108 @@ static int load_bam(const std::string& bam, bool pairedEnd, const std::string& c
 // ---------------------------------------------------------------- intermediate file: see protobuf_dat.hpp
 struct Inter { std::string name; int64_t len = 0; std::vector<uint64_t> maskWords; std::vector<uint8_t> hits; std::vector<int16_t> frag; };
 
+// ---------------------------------------------------------------- predefined bins: Utilities.LoadBedFile(path, gcIndex: 3) (CanvasCommon/Utilities.cs:793-829)
+struct PreBin { int start, stop, gc; float count; };
+static bool load_predefined_bins(const std::string& path, std::map<std::string, std::vector<PreBin>>& out, std::vector<std::string>& chromOrder, std::string& err) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) { err = "cannot open " + path; return false; }
+    char buf[1 << 14];
+    while (fgets(buf, sizeof buf, f)) {
+        std::string s(buf); while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+        auto t = split_tab(s);
+        if (t.size() < 3) { fclose(f); err = "malformed BED line: " + s; return false; }
+        PreBin b{atoi(t[1].c_str()), atoi(t[2].c_str()), 0, 0.0f};
+        if (b.start < 0) { fclose(f); err = "Start must be non-negative in a BED file: " + s; return false; }
+        if (b.start >= b.stop) { fclose(f); err = "Start must be less than Stop in a BED file: " + s; return false; }
+        if (t.size() > 3) b.gc = atoi(t[3].c_str());
+        if (!out.count(t[0])) chromOrder.push_back(t[0]);
+        out[t[0]].push_back(b);
+    }
+    fclose(f); return true;
+}
+
+// ---------------------------------------------------------------- Fragment mode: FragmentBinner.BinTask (FragmentBinner.cs:98-371)
+// FindBestBin (:349-369): the bin with the largest overlap, the first one on ties, scanning from binIndexStart until a bin does not overlap
+static int find_best_bin(const std::vector<PreBin>& bins, int binIndexStart, int fragmentStart, int fragmentStop) {
+    int bestBinIndex = -1, bestOverlap = 0;
+    for (int i = binIndexStart; i < (int)bins.size(); i++) {
+        const int overlap = std::min(bins[i].stop, fragmentStop) - std::max(bins[i].start, fragmentStart);
+        if (overlap <= 0) break;
+        if (overlap > bestOverlap) { bestOverlap = overlap; bestBinIndex = i; }
+    }
+    return bestBinIndex;
+}
+struct FragAln { std::string name; int32_t refID, pos, mateRefID, matePos, tlen; uint16_t flag; uint8_t mapq; };
+// BinOneAlignment (:256-311)
+static void bin_one_alignment(const FragAln& a, unsigned qualityThreshold, std::map<std::string, int>& readNameToBinIndex, std::set<std::string>& samePositionReadNames,
+                              long& usableFragmentCount, std::vector<PreBin>& bins, int& binIndexStart) {
+    if (a.flag & 0x4) return;                                  // !IsMapped
+    if (a.flag & 0x8) return;                                  // !IsMateMapped
+    if (a.flag & 0x100) return;                                // !IsPrimaryAlignment
+    if (!((a.flag & 0x1) && (a.flag & 0x2))) return;           // IsPaired && IsProperPair
+    const bool bad = (a.flag & 0x400) || (a.flag & 0x200) || a.mapq == 255 || a.mapq < qualityThreshold;      // IsDuplicateFailedQCLowQuality (:321-332)
+    auto it = readNameToBinIndex.find(a.name);
+    if (it != readNameToBinIndex.end()) {                      // the mate was binned: undo when this read is bad
+        if (bad) { usableFragmentCount--; bins[it->second].count--; }
+        readNameToBinIndex.erase(it);
+        return;
+    }
+    if (bad) return;
+    if (a.refID != a.mateRefID) return;
+    if (a.pos > a.matePos) return;                             // IsRightMostInPair
+    if (a.pos == a.matePos) {
+        auto sp = samePositionReadNames.find(a.name);
+        if (sp != samePositionReadNames.end()) { samePositionReadNames.erase(sp); return; }
+        samePositionReadNames.insert(a.name);
+    }
+    if (a.tlen == 0) return;
+    const int fragmentStart = a.pos, fragmentStop = a.pos + a.tlen;
+    while (binIndexStart < (int)bins.size() && bins[binIndexStart].stop <= fragmentStart) binIndexStart++;
+    if (binIndexStart >= (int)bins.size()) return;
+    const int best = find_best_bin(bins, binIndexStart, fragmentStart, fragmentStop);
+    if (best >= 0) { usableFragmentCount++; bins[best].count++; readNameToBinIndex[a.name] = best; }
+}
+struct BamHeader { std::vector<std::string> refNames; };
+static bool read_bam_header(Bgzf& z, BamHeader& h) {
+    char magic[4]; int32_t ltext, nref;
+    if (!z.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0 || !z.read(&ltext, 4)) return false;
+    { std::vector<char> t(ltext); if (ltext && !z.read(t.data(), ltext)) return false; }
+    if (!z.read(&nref, 4)) return false;
+    for (int r = 0; r < nref; r++) { int32_t ln, lref; if (!z.read(&ln, 4)) return false; std::vector<char> nm(ln); if (!z.read(nm.data(), ln) || !z.read(&lref, 4)) return false; h.refNames.push_back(nm.data()); }
+    return true;
+}
+// binFragments (:186-244) for one chromosome; 0 ok, 1 error (message printed)
+static int bin_fragments(const std::string& bam, const std::string& chrom, std::vector<PreBin>& bins, long& usableFragmentCount) {
+    if (!file_exists(bam + ".bai")) { fprintf(stderr, "Fatal error: Bam index not found at %s.bai\n", bam.c_str()); return 1; }
+    Bgzf z; if (!z.open(bam)) return 1;
+    BamHeader h; if (!read_bam_header(z, h)) { fprintf(stderr, "CanvasBin: %s is not a BAM file\n", bam.c_str()); return 1; }
+    int desired = -1; for (size_t r = 0; r < h.refNames.size(); r++) if (h.refNames[r] == chrom) desired = (int)r;
+    if (desired < 0) { fprintf(stderr, "Unable to retrieve the reference sequence index for %s in %s.\n", chrom.c_str(), bam.c_str()); return 1; }
+    uint64_t voff; bool any;
+    if (!bai_first_offset(bam + ".bai", desired, voff, any)) { fprintf(stderr, "CanvasBin: cannot read %s.bai\n", bam.c_str()); return 1; }
+    usableFragmentCount = 0;
+    if (!any) return 0;                                        // no reads for this chromosome: not an error (:205-210)
+    if (!z.seek_virtual(voff)) return 1;
+    std::map<std::string, int> readNameToBinIndex; std::set<std::string> samePositionReadNames;
+    int binIndexStart = 0, prevPosition = -1; long pairedAlignmentCount = 0;
+    std::vector<uint8_t> rec;
+    for (;;) {
+        int32_t bs; if (!z.read(&bs, 4)) break;
+        rec.resize(bs); if (!z.read(rec.data(), bs)) break;
+        FragAln a; uint8_t lname;
+        memcpy(&a.refID, &rec[0], 4); memcpy(&a.pos, &rec[4], 4); lname = rec[8]; a.mapq = rec[9]; memcpy(&a.flag, &rec[14], 2);
+        memcpy(&a.mateRefID, &rec[20], 4); memcpy(&a.matePos, &rec[24], 4); memcpy(&a.tlen, &rec[28], 4);
+        a.name.assign((const char*)&rec[32], lname > 0 ? lname - 1 : 0);
+        if (a.refID != desired) break;
+        if (a.refID == -1) continue;
+        if (a.pos < prevPosition) { fprintf(stderr, "The alignment on %s are not properly sorted in %s: %s\n", chrom.c_str(), bam.c_str(), a.name.c_str()); return 1; }
+        prevPosition = a.pos;
+        if (a.flag & 0x1) pairedAlignmentCount++;
+        bin_one_alignment(a, 3, readNameToBinIndex, samePositionReadNames, usableFragmentCount, bins, binIndexStart);
+    }
+    if (pairedAlignmentCount == 0) { fprintf(stderr, "No paired alignments found for %s in %s\n", chrom.c_str(), bam.c_str()); return 1; }
+    return 0;
+}
+
 static int parse_mode(const std::string& m) {       // Utilities.ParseCanvasCoverageMode (CanvasCommon/Utilities.cs:56-74)
     std::string s; for (char c : m) if (c != ' ' && c != '\t') s.push_back((char)tolower(c));
     if (s == "0" || s == "binary") return CANVAS_MODE_BINARY;
@@ -176,7 +283,37 @@ int main(int argc, char** argv) {
     if (bam.empty() || !file_exists(bam)) { printf("CanvasBin.exe: Alignment input does not exist! Exiting.\n"); return 1; }       // also required in -i mode (:148-153)
     if (!filter.empty() && !file_exists(filter)) { printf("CanvasBin.exe: File %s does not exist! Exiting.\n", filter.c_str()); return 1; }
     if (mode != -2 && countsPerBin < 1) { printf("CanvasBin.exe: Median counts must be strictly positive. Exiting.\n"); return 1; }
-    if (mode == -2 || a.has("manifest") || a.has("bins") || a.has("injson")) { fprintf(stderr, "CanvasBin (MI355X): Fragment mode / -t / -n / -j are not built\n"); return 1; }
+    if (a.has("manifest") || a.has("injson")) { fprintf(stderr, "CanvasBin (MI355X): -t / -j are not built\n"); return 1; }
+    std::map<std::string, std::vector<PreBin>> predefined; std::vector<std::string> predefinedOrder;
+    if (a.has("bins")) { std::string perr; if (!load_predefined_bins(a.get("bins"), predefined, predefinedOrder, perr)) { fprintf(stderr, "CanvasBin: %s\n", perr.c_str()); return 1; } }
+    if (mode == -2) {
+        // ---- FragmentBinner.Bin (FragmentBinner.cs:26-80)
+        if (!a.has("bins")) { fprintf(stderr, "Predefined bins in BED is required for fragment binning.\n"); return 1; }
+        if (!a.has("paired-end")) { fprintf(stderr, "Paired-end reads are required for fragment binning.\n"); return 1; }
+        BamHeader bh; { Bgzf z; if (!z.open(bam) || !read_bam_header(z, bh)) { fprintf(stderr, "CanvasBin: %s is not a BAM file\n", bam.c_str()); return 1; } }
+        for (auto& kv : predefined) if (std::find(bh.refNames.begin(), bh.refNames.end(), kv.first) == bh.refNames.end()) {
+            fprintf(stderr, "Not all chromosomes in %s are found in %s.\n", a.get("bins").c_str(), bam.c_str()); return 1; }
+        long usable = 0;
+        for (auto& chromName : bh.refNames) {
+            auto it = predefined.find(chromName); if (it == predefined.end()) continue;
+            for (auto& b : it->second) b.count = 0;                                   // InitializeBins
+            bool gcAvailable = true; for (auto& b : it->second) if (b.gc < 0) gcAvailable = false;
+            if (!gcAvailable) {                                                       // PopulateBinGC (:163-181)
+                std::vector<FastaEntry> fa; if (!read_fasta(ref, &chromName, fa) || fa.empty()) { fprintf(stderr, "CanvasBin: chromosome %s not found in %s\n", chromName.c_str(), ref.c_str()); return 1; }
+                const std::string& bases = fa[0].bases;
+                for (auto& b : it->second) { double nt = 0, gcn = 0; for (int p = b.start; p < b.stop && p < (int)bases.size(); p++) { if (bases[p] == 'n') continue; nt++; const char ch = bases[p]; if (ch == 'C' || ch == 'c' || ch == 'G' || ch == 'g') gcn++; }
+                    b.gc = nt > 0 ? (int)(100 * gcn / nt) : 0; }
+            }
+            long u = 0; if (int rc = bin_fragments(bam, chromName, it->second, u)) return rc;
+            usable += u;
+        }
+        if (usable == 0) { fprintf(stderr, "No passing-filter fragments overlapping bins are found in %s\n", bam.c_str()); return 1; }
+        GzWriter wr(out); if (!wr.ok()) { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
+        for (auto& chromName : bh.refNames) { auto it = predefined.find(chromName); if (it == predefined.end()) continue;
+            for (auto& b : it->second) wr.line(chromName + "\t" + std::to_string(b.start) + "\t" + std::to_string(b.stop) + "\t" + format_f2(b.count) + "\t" + std::to_string(b.gc)); }
+        printf("Output complete\n");
+        return 0;
+    }
 
     canvas_ctx* ctx = canvas_create(0);
     if (!ctx) { fprintf(stderr, "CanvasBin (MI355X): no usable GPU (this build has no CPU fallback)\n"); return 1; }
@@ -246,6 +383,27 @@ int main(int argc, char** argv) {
         pBases[c] = (const uint8_t*)up(order[c]->bases.data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits.data(), L, L + 64); pMask[c] = (const uint64_t*)up(data[c]->maskWords.data(), words * 8, words * 8 + 64);
         if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { if ((int64_t)data[c]->frag.size() != L) { fprintf(stderr, "CanvasBin: %s has no fragment lengths (was the intermediate written with -m GCContentWeighted?)\n", order[c]->name.c_str()); return 1; } pFrag[c] = (const int16_t*)up(data[c]->frag.data(), L * 2, L * 2 + 64); }
         if (!pBases[c] || !pHits[c] || !pMask[c]) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
+    }
+    if (a.has("bins") && !a.has("binsizeonly")) {
+        // ---- predefined bins (BinCounts with predefinedBins, CanvasBin.cs:506-547): chromosomes in FASTA order that have both an intermediate and bins
+        if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { fprintf(stderr, "CanvasBin (MI355X): -n with -m GCContentWeighted is not built\n"); return 1; }
+        std::vector<const uint8_t*> qB, qH; std::vector<const uint64_t*> qM; std::vector<int64_t> qL, off{0}; std::vector<int32_t> hs, he; std::vector<std::string> qName;
+        for (int c = 0; c < nchr; c++) { auto it = predefined.find(order[c]->name); if (it == predefined.end()) continue;
+            qB.push_back(pBases[c]); qH.push_back(pHits[c]); qM.push_back(pMask[c]); qL.push_back(len[c]); qName.push_back(order[c]->name);
+            for (auto& b : it->second) { hs.push_back(b.start); he.push_back(b.stop); } off.push_back((int64_t)hs.size()); }
+        const int64_t nb = (int64_t)hs.size();
+        std::vector<int32_t> hGc(nb); std::vector<float> hCount(nb);
+        if (nb > 0) {
+            Dev dS(ctx, nb * 4), dE(ctx, nb * 4), dG(ctx, nb * 4), dC(ctx, nb * 4);
+            TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dS.p, hs.data(), nb * 4)); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dE.p, he.data(), nb * 4));
+            TOOL_TRY(ctx, canvas_bin_predefined(ctx, (int32_t)qL.size(), qB.data(), qM.data(), qH.data(), qL.data(), mode, off.data(), hs.data(), he.data(), dS.as<int32_t>(), dE.as<int32_t>(), dG.as<int32_t>(), dC.as<float>()));
+            TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hGc.data(), dG.p, nb * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hCount.data(), dC.p, nb * 4));
+        }
+        GzWriter wr(out); if (!wr.ok()) { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
+        for (size_t c = 0; c + 1 < off.size(); c++) for (int64_t i = off[c]; i < off[c + 1]; i++)
+            wr.line(qName[c] + "\t" + std::to_string(hs[i]) + "\t" + std::to_string(he[i]) + "\t" + format_f2(hCount[i]) + "\t" + std::to_string(hGc[i]));
+        printf("Output complete\n");
+        return 0;
     }
     if (a.has("binsizeonly") || binSize == -1) {
         // CalculateSingleSampleBinSize: autosomes only (CanvasBin.cs:30-83)

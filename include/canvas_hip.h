@@ -110,6 +110,14 @@ int32_t canvas_bin_sample_gcweighted(canvas_ctx* ctx, int32_t nchr, const uint8_
                                      int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                                      int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
 
+/* Predefined bins (CanvasBin -n; BinCountsForChromosome with usePredefinedBins, CanvasBin.cs:575-655): count and GC of the given intervals instead of bins of a fixed
+ * number of possible positions.  Bins of all chromosomes are concatenated in chromosome order, h_bin_offset[nchr+1] indexes them; start / stop (0-based, half open) are
+ * given twice, on the host (validated as Utilities.LoadBedFile does) and on the device.  d_count = sum over the possible positions of hit (mode 0) or min(10, hit) (mode 3),
+ * d_gc = (int)(100f * #[CcGg] / #positions) — the first bin of a chromosome starts counting at its first base that is not 'n' (:582-584). */
+int32_t canvas_bin_predefined(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
+                              int32_t mode, const int64_t* h_bin_offset, const int32_t* h_bin_start, const int32_t* h_bin_stop, const int32_t* d_bin_start, const int32_t* d_bin_stop,
+                              int32_t* d_gc, float* d_count);
+
 /* ---- CanvasClean --------------------------------------------------------------------------------------------- */
 /* CanvasClean.Main (CanvasClean/CanvasClean.cs:415-533) on the whole-genome SoA in file order, in place; bins that
  * survive are compacted to the front, *h_n_out = surviving count.  h_chr_is_autosome[nchr] answers

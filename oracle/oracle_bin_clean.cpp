@@ -136,6 +136,32 @@ int64_t bin_chromosome(const uint8_t* bases, const uint8_t* mask, const uint8_t*
     return nb;
 }
 
+// BinCountsForChromosome with predefined bins (CanvasBin -n; CanvasBin.cs:568-661 with usePredefinedBins): the cursor starts at the first bin's Start, skips leading 'n',
+// closes a bin when it stands on Stop - 1 and jumps to the next bin's Start.  Returns the number of bins closed (the others keep gc / count as loaded from the BED file),
+// or -1 where the C# would index past the end of the chromosome while skipping 'n'.  Modes 0 / 3.
+int64_t bin_chromosome_predefined(const uint8_t* bases, const uint8_t* mask, const uint8_t* hits, int64_t len, int mode, int64_t nbins, const int32_t* binStart, const int32_t* binStop,
+                                  int32_t* gc, int32_t* count) {
+    if (nbins == 0) return 0;
+    int64_t predefinedBinIndex = 0;
+    int64_t pos = binStart[0];
+    while (true) { if (pos >= len) return -1; if (bases[pos] != 'n') break; pos++; }       // :582-584
+    int NucleotideCount = 0, GCCount = 0, ObservedCount = 0, TruncObserved = 0;
+    for (; pos < len; pos++) {
+        NucleotideCount++;                                                                  // :592-593 (char.Equals(string): always counted)
+        switch (bases[pos]) { case 'C': case 'c': case 'G': case 'g': GCCount++; break; default: break; }
+        if ((mask[pos >> 3] >> (pos & 7)) & 1) { ObservedCount += hits[pos]; TruncObserved += std::min(10, (int)hits[pos]); }
+        if (pos == (int64_t)binStop[predefinedBinIndex] - 1) {                              // :616
+            float gcf = 100.0f * (float)GCCount; gcf = gcf / (float)NucleotideCount;
+            gc[predefinedBinIndex] = (int)gcf; count[predefinedBinIndex] = (mode == 3) ? TruncObserved : ObservedCount;
+            predefinedBinIndex++;
+            if (predefinedBinIndex >= nbins) break;
+            pos = (int64_t)binStart[predefinedBinIndex] - 1;                                // :646
+            NucleotideCount = GCCount = ObservedCount = TruncObserved = 0;
+        }
+    }
+    return predefinedBinIndex;
+}
+
 // ---- GCContentWeighted mode (CanvasBin.cs:416-506, 330-405, 626-636)
 // Utilities.NonZeroMean(Int16[]) (CanvasCommon/Utilities.cs:135-151)
 static int16_t NonZeroMean(const int16_t* x, int64_t n) {

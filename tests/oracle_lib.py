@@ -66,6 +66,15 @@ def bin_chromosome(bases, mask, hits, bin_size, mode=3):
     return [o[:n].copy() for o in out]
 
 
+def bin_predefined(bases, mask, hits, bin_start, bin_stop, mode=3):
+    """BinCountsForChromosome with predefined bins (CanvasBin -n): (bins closed, gc, count); bins never closed keep gc = count = 0"""
+    bs = np.ascontiguousarray(bin_start, np.int32); be = np.ascontiguousarray(bin_stop, np.int32)
+    gc = np.zeros(len(bs), np.int32); cnt = np.zeros(len(bs), np.int32)
+    lib.orc_bin_chromosome_predefined.restype = C.c_int64
+    k = lib.orc_bin_chromosome_predefined(_p(bases), _p(mask), _p(hits), C.c_int64(len(bases)), int(mode), C.c_int64(len(bs)), _p(bs), _p(be), _p(gc), _p(cnt))
+    return int(k), gc, cnt
+
+
 def bin_gc_weighted(bases, masks, hits, fraglens, bin_size):
     """GCContentWeighted binning of a genome (CanvasBin.cs:416-506,626-636): returns (per-chromosome [start,stop,gc,count], mean fragment, weights)"""
     nchr = len(bases)

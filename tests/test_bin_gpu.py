@@ -232,3 +232,33 @@ def test_streamed_upload_bins_match_oracle(resident_reference):
     _, per, total2, bs2 = cv.bin_sample(db2, dm, dh, lens, [1, 1, 1, 1, 0], 100, -1, 3, out=out)
     assert total2 == total and bs2 == bs
     cv.upload_genome_wait()
+
+
+def test_predefined_bins_match_oracle():
+    """canvas_bin_predefined (CanvasBin -n): counts and GC of given intervals, incl. the leading-'n' skip of a chromosome's first bin, touching / overlapping / 1-base bins"""
+    cv = get_canvas()
+    lengths = [400_000, 130_001]
+    data = _chroms(lengths, rate=0.21)
+    bases, hits, masks = _upload(cv, data)
+    rng = np.random.RandomState(17)
+    starts, stops = [], []
+    for c, L in enumerate(lengths):
+        s0 = np.sort(rng.choice(L - 3000, 300, replace=False)); e0 = s0 + rng.randint(1, 2500, 300)
+        s0[0] = 0                                                     # inside the leading 'n' stretch of the synthetic chromosome
+        e0[0] = max(e0[0], 12_000)
+        e0[-1] = L                                                    # to the last base
+        starts.append(s0.astype(np.int32)); stops.append(np.minimum(e0, L).astype(np.int32))
+    for mode in (3, 0):
+        gc, cnt = cv.bin_predefined(bases, masks, hits, np.array(lengths, np.int64), starts, stops, mode=mode)
+        off = 0
+        for c in range(2):
+            k, eg, ec = O.bin_predefined(data[c][0], data[c][2], data[c][1], starts[c], stops[c], mode)
+            assert k == len(starts[c])
+            n = len(starts[c])
+            assert (gc[off:off + n].cpu().numpy() == eg).all() and (cnt[off:off + n].cpu().numpy() == ec.astype(np.float32)).all()
+            off += n
+    from canvas_amd.lib import CanvasError
+    with pytest.raises(CanvasError):                                  # a bin past the end of the chromosome: the reference's cursor never closes it
+        cv.bin_predefined(bases, masks, hits, np.array(lengths, np.int64), [np.array([10], np.int32), np.array([5], np.int32)], [np.array([20], np.int32), np.array([lengths[1] + 1], np.int32)])
+    with pytest.raises(CanvasError):                                  # first bin entirely inside the leading n's
+        cv.bin_predefined(bases, masks, hits, np.array(lengths, np.int64), [np.array([0], np.int32), np.array([20_000], np.int32)], [np.array([50], np.int32), np.array([21_000], np.int32)])

@@ -39,10 +39,10 @@ def _write_bam(path, refs, reads):
     for ref in sorted(by_ref, key=lambda x: (x < 0, x)):
         data = bytearray()
         for r in by_ref[ref]:
-            name = b"r\x00"
+            name = r.get("name", "r").encode() + b"\x00"
             cig = b"".join(struct.pack("<I", (ln << 4) | "MIDNSHP=X".index(op)) for ln, op in r["cigar"])
             lseq = 36
-            body = struct.pack("<iiBBHHHiiii", r["ref"], r["pos"], len(name), 30, 4680, len(r["cigar"]), r["flag"], lseq, -1, -1, r.get("tlen", 0))
+            body = struct.pack("<iiBBHHHiiii", r["ref"], r["pos"], len(name), r.get("mapq", 30), 4680, len(r["cigar"]), r["flag"], lseq, r.get("mate_ref", -1), r.get("mate_pos", -1), r.get("tlen", 0))
             body += name + cig + bytes((lseq + 1) // 2) + bytes([30] * lseq)
             data += struct.pack("<i", len(body)) + body
         first[ref] = len(out) << 16
@@ -266,6 +266,7 @@ def test_canvasbin_bam_to_binned(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         names2 = list(lens2)
         if mode == 3:
+            args_mode3, mk3, hk3 = list(args), mk, hk
             res = O.bin_genome([seq2[n] for n in names2], mk, hk, 150, mode=3, threads=2)
             exp = [f"{n}\t{s}\t{e}\t{O.format_f2(float(k))}\t{g}" for c, n in enumerate(names2) for s, e, g, k in zip(res[0][c], res[1][c], res[2][c], res[3][c])]
         else:
@@ -273,6 +274,22 @@ def test_canvasbin_bam_to_binned(tmp_path):
             exp = [f"{n}\t{s}\t{e}\t{O.format_f2(float(k))}\t{g}" for c, n in enumerate(names2) for s, e, g, k in zip(resw[c][0], resw[c][1], resw[c][2], resw[c][3])]
         with gzip.open(binned, "rt") as f:
             assert f.read().splitlines() == exp
+    # ---- predefined bins (-n): counts and GC of given intervals from the same intermediates (BinCountsForChromosome with usePredefinedBins, CanvasBin.cs:575-655)
+    pre = str(tmp_path / "predefined.bed")
+    pre_bins = {"chrA": [(0, 700), (700, 1500), (1400, 2000), (30_000, 40_003)], "chrB": [(5, 6), (100, 24_000)]}          # touching, overlapping, to the last base; chrB's first bin is 1 base
+    with open(pre, "w") as f:
+        for n, bl in pre_bins.items():
+            for a_, b_ in bl: f.write(f"{n}\t{a_}\t{b_}\n")
+    binned = str(tmp_path / "pre.binned")
+    r = subprocess.run([BIN, "-b", bam, "-r", fa2, "-o", binned, "-d", "100", "-m", "3", "-n", pre] + args_mode3, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = []
+    for c, n in enumerate(names2):
+        k, g, cnt = O.bin_predefined(seq2[n], mk3[c], hk3[c], [b[0] for b in pre_bins[n]], [b[1] for b in pre_bins[n]], 3)
+        assert k == len(pre_bins[n])
+        exp += [f"{n}\t{a_}\t{b_}\t{O.format_f2(float(cc))}\t{gg}" for (a_, b_), gg, cc in zip(pre_bins[n], g, cnt)]
+    with gzip.open(binned, "rt") as f:
+        assert f.read().splitlines() == exp
     # a truncated file is refused
     bad = str(tmp_path / "bad.dat"); open(bad, "wb").write(_encode_dat("chrA", b"\xff" * 10, b"\x01" * 80, 0)[:-7])
     assert subprocess.run([BIN, "-b", bam, "-r", fa2, "-o", str(tmp_path / "x.binned"), "-d", "100", "-i", bad], capture_output=True).returncode == 1
@@ -280,3 +297,113 @@ def test_canvasbin_bam_to_binned(tmp_path):
     assert subprocess.run([BIN], capture_output=True).returncode == 1
     assert subprocess.run([BIN, "-b", str(tmp_path / "none.bam"), "-r", fa, "-c", "chr1", "-o", str(tmp_path / "x.dat"), "-d", "100"], capture_output=True).returncode == 1
     assert subprocess.run([BIN, "-b", bam, "-r", fa, "-c", "chr1", "-o", str(tmp_path / "x.dat"), "-d", "0"], capture_output=True).returncode == 1
+
+
+# ---- Fragment mode (-m Fragment): FragmentBinner.BinTask.BinOneAlignment restated in Python (FragmentBinner.cs:256-369)
+def _py_fragment_counts(bins, reads, quality_threshold=3):
+    count = [0] * len(bins); name_to_bin = {}; same_pos = set(); usable = 0; start_idx = 0
+    for r in reads:
+        f = r["flag"]
+        if f & 0x4 or f & 0x8 or f & 0x100 or not (f & 0x1 and f & 0x2):
+            continue
+        bad = bool(f & 0x400 or f & 0x200 or r["mapq"] == 255 or r["mapq"] < quality_threshold)
+        if r["name"] in name_to_bin:
+            if bad:
+                usable -= 1; count[name_to_bin[r["name"]]] -= 1
+            del name_to_bin[r["name"]]
+            continue
+        if bad or r["ref"] != r["mate_ref"] or r["pos"] > r["mate_pos"]:
+            continue
+        if r["pos"] == r["mate_pos"]:
+            if r["name"] in same_pos:
+                same_pos.remove(r["name"]); continue
+            same_pos.add(r["name"])
+        if r["tlen"] == 0:
+            continue
+        fs, fe = r["pos"], r["pos"] + r["tlen"]
+        while start_idx < len(bins) and bins[start_idx][1] <= fs:
+            start_idx += 1
+        if start_idx >= len(bins):
+            continue
+        best, best_ov = -1, 0
+        for i in range(start_idx, len(bins)):
+            ov = min(bins[i][1], fe) - max(bins[i][0], fs)
+            if ov <= 0: break
+            if ov > best_ov: best_ov, best = ov, i
+        if best >= 0:
+            usable += 1; count[best] += 1; name_to_bin[r["name"]] = best
+    return count, usable
+
+
+def test_canvasbin_fragment_mode(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    refs = [("chr1", 50_000), ("chr2", 30_000), ("chr3", 10_000)]
+    fa = str(tmp_path / "genome.fa")
+    rng = np.random.RandomState(3)
+    seqs = {n: rng.choice(np.frombuffer(b"ACGTn", np.uint8), L, p=[0.27, 0.2, 0.2, 0.27, 0.06]) for n, L in refs}
+    with open(fa, "w") as f:
+        for n, _ in refs: f.write(f">{n}\n" + seqs[n].tobytes().decode() + "\n")
+    # ---- the reference's own unit test (TestCanvasBin.cs:14-78): one bin chr1:100-200, one pair at (pos1, pos2), four quality combinations -> count 1, 0, 0, 0
+    bed1 = str(tmp_path / "one.bed"); open(bed1, "w").write("chr1\t100\t200\t50\n")
+    for pos1, pos2 in ((100, 120), (100, 100)):
+        for q1, q2, expect in ((10, 10, 1), (10, 2, 0), (2, 10, 0), (2, 2, 0)):
+            reads = [dict(ref=0, pos=pos1, flag=0x1 | 0x2, cigar=[(36, "M")], name="ReadName", mate_ref=0, mate_pos=pos2, tlen=100, mapq=q1),
+                     dict(ref=0, pos=pos2, flag=0x1 | 0x2, cigar=[(36, "M")], name="ReadName", mate_ref=0, mate_pos=pos1, tlen=-100, mapq=q2)]
+            bam = str(tmp_path / f"ut_{pos1}_{pos2}_{q1}_{q2}.bam"); _write_bam(bam, refs, reads)
+            out = str(tmp_path / "ut.binned")
+            r = subprocess.run([BIN, "-b", bam, "-r", fa, "-n", bed1, "-o", out, "-m", "Fragment", "-p"], capture_output=True, text=True)
+            if expect == 0:
+                assert r.returncode == 1 and "No passing-filter fragments" in r.stderr            # usableFragmentCount == 0 (FragmentBinner.cs:63-67)
+            else:
+                assert r.returncode == 0, r.stdout + r.stderr
+                assert gzip.open(out, "rt").read().splitlines() == ["chr1\t100\t200\t1.00\t50"]
+    # ---- a randomised sample: pairs with duplicates / QC failures / low mapping quality on either mate, same-position mates, improper pairs, fragments between and across bins
+    bins = {"chr1": [], "chr2": []}
+    for n, L in (("chr1", 50_000), ("chr2", 30_000)):
+        p = 500
+        while p + 900 < L:
+            size = int(rng.randint(120, 800)); bins[n].append((p, p + size)); p += size + int(rng.choice([0, 0, 37, 400]))
+    bed = str(tmp_path / "bins.bed")
+    with open(bed, "w") as f:
+        for n in ("chr2", "chr1"):                                   # BED order differs from the BAM's: the output follows the BAM header (FragmentBinner.cs:69-75)
+            for k, (a_, b_) in enumerate(bins[n]):
+                f.write(f"{n}\t{a_}\t{b_}" + ("\t-1" if n == "chr2" else f"\t{40 + k % 20}") + "\n")      # chr2: GC missing (-1) -> PopulateBinGC
+    reads = []
+    for ri, (n, L) in enumerate(refs[:2]):
+        for k in range(6000):
+            pos = int(rng.randint(0, L - 700)); tlen = int(rng.choice([0, 150, 300, 450, 600], p=[0.02, 0.2, 0.4, 0.28, 0.1])); mpos = pos + max(0, tlen - 36) if rng.rand() > 0.03 else pos
+            name = f"q{ri}_{k}"
+            f1 = f2 = 0x1 | 0x2
+            u = rng.rand()
+            if u < 0.05: f1 |= 0x400
+            elif u < 0.10: f2 |= 0x400
+            elif u < 0.13: f1 |= 0x200
+            elif u < 0.16: f2 &= ~0x2
+            elif u < 0.18: f1 |= 0x100
+            elif u < 0.20: f2 |= 0x8
+            q1, q2 = (int(rng.choice([0, 2, 3, 30, 60, 255], p=[0.03, 0.03, 0.04, 0.45, 0.42, 0.03])) for _ in range(2))
+            reads.append(dict(ref=ri, pos=pos, flag=f1 | 0x40, cigar=[(36, "M")], name=name, mate_ref=ri, mate_pos=mpos, tlen=tlen, mapq=q1))
+            reads.append(dict(ref=ri, pos=mpos, flag=f2 | 0x80 | 0x10, cigar=[(36, "M")], name=name, mate_ref=ri, mate_pos=pos, tlen=-tlen, mapq=q2))
+    reads.sort(key=lambda r: (r["ref"], r["pos"]))
+    bam = str(tmp_path / "pairs.bam"); _write_bam(bam, refs, reads)
+    out = str(tmp_path / "pairs.binned")
+    r = subprocess.run([BIN, "-b", bam, "-r", fa, "-n", bed, "-o", out, "-m", "Fragment", "-p"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = []; total_usable = 0
+    for ri, n in enumerate(("chr1", "chr2")):
+        cnt, usable = _py_fragment_counts(bins[n], [x for x in reads if x["ref"] == ri]); total_usable += usable
+        for k, ((a_, b_), c_) in enumerate(zip(bins[n], cnt)):
+            if n == "chr1": gc = 40 + k % 20
+            else:
+                seg = seqs[n][a_:b_]; nt = int((seg != ord("n")).sum()); g = int(np.isin(seg, np.frombuffer(b"CGcg", np.uint8)).sum()); gc = int(100 * g / nt) if nt else 0
+            exp.append(f"{n}\t{a_}\t{b_}\t{O.format_f2(float(c_))}\t{gc}")
+    assert total_usable > 1000
+    assert gzip.open(out, "rt").read().splitlines() == exp
+    # error conventions: no -n, no -p, a chromosome of the BED file that the BAM does not have
+    assert subprocess.run([BIN, "-b", bam, "-r", fa, "-o", out, "-m", "Fragment", "-p"], capture_output=True).returncode == 1
+    assert subprocess.run([BIN, "-b", bam, "-r", fa, "-n", bed, "-o", out, "-m", "Fragment"], capture_output=True).returncode == 1
+    bedU = str(tmp_path / "u.bed"); open(bedU, "w").write("chrU\t1\t100\n")
+    r = subprocess.run([BIN, "-b", bam, "-r", fa, "-n", bedU, "-o", out, "-m", "Fragment", "-p"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Not all chromosomes" in r.stderr
