@@ -229,8 +229,8 @@ def main():
         t_c = time.perf_counter()
         seg_len, nseg_c, cstats = cv.cbs(keep["cov"], keep["off"], 0.01, 10000)
         cbs_s = time.perf_counter() - t_c
-        dstat = cv.cbs_device_stats()
-        cb = {"seconds": round(cbs_s, 3), "first_call_seconds": round(cbs_first, 3), "bins_per_s": round(int(keep["n_out"]) / cbs_s, 1), "segments": int(sum(nseg_c)), "tmaxo_calls": int(cstats[0]),
+        dstat = cv.cbs_device_stats(); tstat = cv.cbs_tailp_stats()
+        cb = {"tailp_decided_on_device": int(tstat[0]), "tailp_recomputed_on_host": int(tstat[1]), "seconds": round(cbs_s, 3), "first_call_seconds": round(cbs_first, 3), "bins_per_s": round(int(keep["n_out"]) / cbs_s, 1), "segments": int(sum(nseg_c)), "tmaxo_calls": int(cstats[0]),
               "permutations": int(cstats[2]), "permuted_elements": int(cstats[3]), "device_permutations": int(dstat[0]), "host_permutations": int(dstat[1]),
               "exact_reevaluations": int(dstat[2]), "note": "CBSRunner.Run (alpha 0.01, 10000 permutations): recursion and stopping rule on the host, "
               "TMaxO arc search + XPerm/HTMaxP + MT19937 on the device"}

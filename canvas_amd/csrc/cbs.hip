@@ -32,6 +32,44 @@
 #include <functional>
 #include <condition_variable>
 
+// ================================================================================================ device: Nu(x) of the analytic tail probability
+// TailProbability.Nu (TailProbability.cs:52-85): l1 = log 2 - 2 log x - sum_dk 2 Phi(-x sqrt(dk) / 2) / dk, summed in blocks of 2, 2, 4, 8, ... terms until the relative change of
+// a block drops below tol; up to ~10^6 normal-CDF evaluations for the small arguments of long segments, 100 arguments per TailP call — 10 host thread-seconds per WGS sample.
+// One workgroup per argument evaluates the blocks in parallel.  The sums are re-associated and erfc / log / exp are the device's, so the value is an APPROXIMATION (relative error
+// far below 1e-9); it only feeds two decisions of FindChangePoints (p1 > cutoff; nrejc = (int)((cutoff - p1) nPerm), ChangePoint.cs:318-323), and the host accepts it only when both
+// come out the same for every p1 within 1e-8 relative — otherwise, and whenever a stopping comparison of the series itself is within 1e-6 relative of tol (flag), the call is
+// redone with the host libm in the reference's order.
+__global__ void __launch_bounds__(256) k_tail_nu(const double* __restrict__ xs, int n, double tol, double* __restrict__ nus, int* __restrict__ flags) {
+    __shared__ double sh[4];
+    const int g = blockIdx.x; if (g >= n) return;
+    const double x = xs[g];
+    const int t = threadIdx.x;
+    if (!(x > 0.01)) { if (t == 0) { nus[g] = exp(-0.583 * x); flags[g] = 0; } return; }
+    double l1 = log(2.0) - 2.0 * log(x), l0 = l1;
+    long long dk = 0; long long k = 2; int flag = 0;
+    auto block = [&](long long cnt) -> double {           // sum_{i=1..cnt} 2 Phi(-x sqrt(dk + i) / 2) / (dk + i), all threads return the same value
+        double acc = 0.0;
+        for (long long i = t + 1; i <= cnt; i += 256) { const double d = (double)(dk + i); acc += erfc(x * sqrt(d) / 2.0 / 1.4142135623730951) / d; }     // 2 * (0.5 erfc(-xk / sqrt 2)), xk = -x sqrt(d) / 2
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        __syncthreads();
+        if ((t & 63) == 0) sh[t >> 6] = acc;
+        __syncthreads();
+        return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    };
+    l1 = l1 - block(k); dk += k;
+    for (;;) {
+        const double rel = fabs((l1 - l0) / l1);
+        if (fabs(rel - tol) <= tol * 1e-6) flag = 1;        // the reference's comparison could go either way: redo on the host
+        if (!(rel > tol)) break;
+        if (k > (1ll << 40)) { flag = 1; break; }
+        l0 = l1;
+        l1 = l1 - block(k); dk += k;
+        k *= 2;
+    }
+    if (t == 0) { nus[g] = exp(l1); flags[g] = flag; }
+}
+
 // ================================================================================================ device: exhaustive arc search
 // For every arc length L in [1, n-1] (arc = pair i < j = i + L of 0-based prefix-sum indices): dmax[L] = max_i |sx[i+L] - sx[i]|,
 // firstI[L] = smallest such i.  Thread t of the grid owns lengths L = t+1 and n-1-t (balanced: n iterations per thread).
@@ -670,7 +708,7 @@ static double htmaxp_host(int k, double tss, const double* px, int n, double* sx
     return normalise(h, tss, rn);
 }
 
-struct Stats { std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
+struct Stats { std::atomic<long long> tailp_dev{0}, tailp_host{0}; std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
 
 // GPU arc search service shared by the chromosome threads
 struct ArcHostReq { ArcReq r; ArcPReq p; bool pruned = true; const void* hSx; void* hMax; void* hFirst; unsigned long long* hOut; bool done = false; int32_t rc = CANVAS_OK; };
@@ -782,14 +820,56 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
 struct PermService;
 struct PermGpu {
     canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr; char* buf = nullptr; size_t bytes = 0; char* pin = nullptr; size_t pinBytes = 0;
+    // analytic tail probability on the device (k_tail_nu): own stream, 3 x 128 values on the device and in pinned memory
+    hipStream_t tailStream = nullptr; char* tailDev = nullptr; char* tailPin = nullptr;
+    int32_t ensure_tail() {
+        if (tailStream) return CANVAS_OK;
+        CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&tailStream, hipStreamNonBlocking));
+        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&tailDev, 128 * 24)); CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&tailPin, 128 * 24, hipHostMallocDefault));
+        return CANVAS_OK;
+    }
     int32_t ensure(size_t need, size_t needPin) {
         CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
         if (need > bytes) { if (buf) CANVAS_HIP_TRY(ctx, hipFree(buf)); buf = nullptr; bytes = 0; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&buf, need)); bytes = need; }
         if (needPin > pinBytes) { if (pin) CANVAS_HIP_TRY(ctx, hipHostFree(pin)); pin = nullptr; pinBytes = 0; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, needPin, hipHostMallocDefault)); pinBytes = needPin; }
         return CANVAS_OK;
     }
-    ~PermGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (buf) (void)hipFree(buf); if (pin) (void)hipHostFree(pin); }
+    ~PermGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (buf) (void)hipFree(buf); if (pin) (void)hipHostFree(pin);
+                 if (tailStream) { (void)hipStreamSynchronize(tailStream); (void)hipStreamDestroy(tailStream); } if (tailDev) (void)hipFree(tailDev); if (tailPin) (void)hipHostFree(tailPin); }
 };
+// TailP for the two decisions of FindChangePoints: device approximation, accepted only when every p1 within 1e-8 relative gives the same decisions; else the exact host series
+static int32_t tail_p_decide(PermGpu& PG, double b, double delta, int m, double cutoff, uint32_t nPerm, Stats& st, bool& exitNoSplit, int& nrejc) {
+    const int nGrid = 100; const double tol = 1E-6;
+    auto exact = [&]() { const double p1 = tail_p(b, delta, m, nGrid, tol); st.tailp_host++; exitNoSplit = p1 > cutoff; nrejc = exitNoSplit ? 0 : (int)((cutoff - p1) * nPerm); };
+    if (getenv("CANVAS_CBS_HOST_TAILP")) { exact(); return CANVAS_OK; }
+    canvas_ctx* ctx = PG.ctx;
+    int32_t rc = PG.ensure_tail(); if (rc) return rc;
+    double* hX = (double*)PG.tailPin; double* hNu = hX + 128; int* hFlag = (int*)(hNu + 128);
+    double* dX = (double*)PG.tailDev; double* dNu = dX + 128; int* dFlag = (int*)(dNu + 128);
+    const double dincr = (0.5 - delta) / nGrid, bs = b / std::sqrt((double)m);
+    double tl = 0.5 - dincr, t = 0.5 - 0.5 * dincr, tls[128];
+    for (int i = 0; i < nGrid; i++) { tl = tl + dincr; t = t + dincr; hX[i] = bs / std::sqrt(t * (1 - t)); tls[i] = tl; }
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dX, hX, nGrid * 8, hipMemcpyHostToDevice, PG.tailStream));
+    hipLaunchKernelGGL(k_tail_nu, dim3(nGrid), dim3(256), 0, PG.tailStream, dX, nGrid, tol, dNu, dFlag);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hNu, dNu, nGrid * 8, hipMemcpyDeviceToHost, PG.tailStream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFlag, dFlag, nGrid * 4, hipMemcpyDeviceToHost, PG.tailStream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(PG.tailStream));
+    bool flagged = false; for (int i = 0; i < nGrid; i++) if (hFlag[i] || !(hNu[i] == hNu[i])) flagged = true;
+    if (flagged) { exact(); return CANVAS_OK; }
+    double tp = 0.0;
+    for (int i = 0; i < nGrid; i++) tp = tp + sq(hNu[i]) * integral_inv(tls[i], dincr);
+    tp = 9.973557E-2 * (b * b * b) * std::exp(-sq(b) / 2) * tp;
+    const double p1 = 2.0 * tp, eps = 1e-8 * std::fabs(p1) + 1e-300;
+    const double lo = p1 - eps, hi = p1 + eps;
+    if ((lo > cutoff) != (hi > cutoff)) { exact(); return CANVAS_OK; }
+    if (lo > cutoff) { exitNoSplit = true; nrejc = 0; st.tailp_dev++; return CANVAS_OK; }
+    const int a = (int)((cutoff - lo) * nPerm), c = (int)((cutoff - hi) * nPerm);
+    if (a != c) { exact(); return CANVAS_OK; }
+    exitNoSplit = false; nrejc = a; st.tailp_dev++;
+    return CANVAS_OK;
+}
+
 // All chromosome threads hand their batches to ONE launcher thread: whatever is waiting goes into a single k_mt_draws launch (one
 // workgroup per request: the generator is sequential per chromosome, the chromosomes are not) and a single k_perm_stat launch (one
 // workgroup per permutation of every request).  Concurrency then does not depend on how many hardware queues the runtime maps the
@@ -1019,10 +1099,10 @@ static int32_t find_change_points(ArcGpu& G, PermGpu& PG, const double* gd, int 
         int nrejc, k;
         if (hybrid) {
             auto tTP = std::chrono::steady_clock::now();
-            double p1 = tail_p(ostat1, delta, n, 100, 1E-6);
+            bool exitNoSplit = false; nrejc = 0;
+            { int32_t rct = tail_p_decide(PG, ostat1, delta, n, cutoff, nPerm, st, exitNoSplit, nrejc); if (rct) return rct; }      // TailP(ostat1, delta, n, 100, 1E-6): p1 > cutoff, (int)((cutoff - p1) nPerm)
             st.ns_tailp += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tTP).count();
-            if (p1 > cutoff) { st.tailp_exits++; return CANVAS_OK; }
-            nrejc = (int)((cutoff - p1) * nPerm);
+            if (exitNoSplit) { st.tailp_exits++; return CANVAS_OK; }
         } else nrejc = (int)(cutoff * nPerm);
         k = nrejc * (nrejc + 1) / 2 + 1;
         auto t0 = std::chrono::steady_clock::now();
@@ -1197,6 +1277,11 @@ static int32_t prune(const double* gd, int n, std::vector<int>& lengthSeg, doubl
 // device-engine counters of the last canvas_cbs call: permutations evaluated on the device / on the host, permutations re-evaluated in
 // the reference's exact order because the observed statistic fell inside the rounding interval, device batches; with the test hook
 // CANVAS_CBS_TEST_VERIFY=1 also [4] intervals checked against the exact statistic and [5] violations (must be 0)
+extern "C" int32_t canvas_cbs_tailp_stats(canvas_ctx* ctx, int64_t* h_out2) {
+    if (!ctx || !h_out2) return CANVAS_ERR_INVALID;
+    h_out2[0] = ctx->cbs_tailp[0]; h_out2[1] = ctx->cbs_tailp[1];
+    return CANVAS_OK;
+}
 extern "C" int32_t canvas_cbs_device_stats(canvas_ctx* ctx, int64_t* h_out6) {
     if (!ctx || !h_out6) return CANVAS_ERR_INVALID;
     for (int i = 0; i < 6; i++) h_out6[i] = ctx->cbs_dev[i];
@@ -1267,7 +1352,8 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_seg_len, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
-    if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: TMaxO on the host %.3f, TailP %.3f\n", st.ns_tmaxo_host.load() * 1e-9, st.ns_tailp.load() * 1e-9),
+    ctx->cbs_tailp[0] = st.tailp_dev; ctx->cbs_tailp[1] = st.tailp_host;
+    if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: TMaxO on the host %.3f, TailP %.3f (%lld decided from the device series, %lld by the host series)\n", st.ns_tmaxo_host.load() * 1e-9, st.ns_tailp.load() * 1e-9, (long long)st.tailp_dev.load(), (long long)st.tailp_host.load()),
                                       fprintf(stderr, "cbs launcher: %lld rounds, %lld arc searches in %.3f s, %lld permutation batches in %.3f s\n", service.rounds + arcService.rounds, arcService.nArc, arcService.secArc, service.nPermReq + service1.nPermReq + service2.nPermReq + service3.nPermReq, std::max(std::max(service.secPerm, service1.secPerm), std::max(service2.secPerm, service3.secPerm))),
                                       fprintf(stderr, "cbs thread-seconds: TMaxO on the device incl. waiting %.3f, edge tests (TPermP) %.3f; per-chromosome wall max %.3f sum %.3f; ", st.ns_tmaxo.load() * 1e-9, st.ns_tpermp.load() * 1e-9, maxChromSec, sumChromSec),
                                       fprintf(stderr, "device permutation loop %.3f (buffers %.3f, uploads %.3f, waiting for the launcher %.3f, stopping rule %.3f), host permutation loop %.3f\n", st.ns_dev.load() * 1e-9, st.ns_ensure.load() * 1e-9, st.ns_upload.load() * 1e-9, st.ns_submit.load() * 1e-9, st.ns_post.load() * 1e-9, st.ns_hostperm.load() * 1e-9);

@@ -47,7 +47,8 @@ struct canvas_ctx {
     // persistent buffers of the chromosome-sharded pipeline (sharded.hip)
     void* shard_ws = nullptr; size_t shard_ws_bytes = 0;
     long long shard_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long cbs_dev[6] = {0, 0, 0, 0, 0, 0};   // counters of the device permutation engine (canvas_cbs_device_stats)
+    long long cbs_dev[6] = {0, 0, 0, 0, 0, 0};
+    long long cbs_tailp[2] = {0, 0};   // last CBS call: TailP decisions taken from the device series / recomputed by the host series   // counters of the device permutation engine (canvas_cbs_device_stats)
     long long wv_levels = 0, wv_redone = 0;   // last canvas_wavelets call: tree levels processed, nodes recomputed by the exact chain
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
     int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
