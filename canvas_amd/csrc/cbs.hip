@@ -815,7 +815,7 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
 }
 
 // ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
-#define PERM_GPU_MIN_N 1024          // shorter segments stay on the host (a permutation there is a few microseconds)
+#define PERM_GPU_MIN_N 1024          // shorter segments stay on the host: measured with 201 (every hybrid segment on the device) the WGS run is identical but 12 % slower (0.555 vs 0.496 s) — a permutation of a few hundred elements is microseconds of host work and a launch round trip on the device
 #define PERM_TARGET_ELEMS (32 << 20) // permuted elements per batch (44 B of workspace each)
 struct PermService;
 struct PermGpu {
