@@ -20,6 +20,7 @@
 #include "loess.hpp"
 #include <algorithm>
 #include <cmath>
+#include <thread>
 
 #define NGC 101
 #define CBLK 2048   // elements per compaction block
@@ -995,6 +996,47 @@ extern "C" int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_c
     for (int c = nchr - 1; c >= 0; c--) h_chr_offset[c] = (f[c] >= 0 && f[c] < n) ? (int64_t)f[c] : h_chr_offset[c + 1];
     for (int c = 0; c < nchr; c++) if (h_chr_offset[c] > h_chr_offset[c + 1]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "bins are not grouped by increasing chromosome index");
     return CANVAS_OK;
+}
+
+// A cohort through CanvasClean in one call: every sample on a stream of its own (child contexts with their own workspaces), all of them enqueued before the first
+// synchronisation.  The single-sample stage is a chain of ~60 launches on 134 MB that sit in the Infinity Cache, bound by launch latency and one-workgroup decision
+// kernels; with B samples in flight the chains overlap and the working set (B x 134 MB) streams from HBM: this is the mode in which the stage's HBM roofline fraction
+// means something (hard part 3).  Results per sample are exactly those of canvas_clean2.
+extern "C" int32_t canvas_clean_batch(canvas_ctx* ctx, int32_t nsamples, const int64_t* h_n, int32_t* const* h_d_chr, int32_t* const* h_d_start, int32_t* const* h_d_stop, float* const* h_d_count,
+                                      int32_t* const* h_d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc,
+                                      double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nsamples <= 0 || nsamples > 64 || !h_n || !h_d_chr || !h_d_start || !h_d_stop || !h_d_count || !h_d_gc || !h_chr_is_autosome || !h_n_out) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean_batch: bad arguments (1..64 samples)");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                      // the children start after whatever the parent stream still has queued
+    while ((int)ctx->children.size() < nsamples) { canvas_ctx* ch = canvas_create(ctx->device); if (!ch) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_clean_batch: cannot create a stream"); ctx->children.push_back(ch); }
+    const bool fast = !(flags & CANVAS_CLEAN_LOESS) && min_bins_per_gc >= 100 && !getenv("CANVAS_CLEAN_HOST_DRIVEN");
+    std::vector<char> enq(nsamples, 0);
+    int32_t rcAll = CANVAS_OK;
+    if (fast) {
+        // one host thread per sample enqueues that sample's ~80 launches: the enqueue cost (not the device) is what bounds a cohort when a single thread does it
+        std::vector<int32_t> rcs(nsamples, CANVAS_OK);
+        std::vector<std::thread> th;
+        for (int s = 0; s < nsamples; s++) {
+            canvas_ctx* ch = ctx->children[s]; ch->prof = false;
+            if (h_n[s] <= 0 || h_n[s] >= 0x7FFFFFFFll || nchr <= 0) continue;
+            enq[s] = 1;
+            th.emplace_back([&, s, ch]() { (void)hipSetDevice(ctx->device);
+                rcs[s] = clean_device_driven_enqueue(ch, h_n[s], h_d_chr[s], h_d_start[s], h_d_stop[s], h_d_count[s], h_d_gc[s], nchr, h_chr_is_autosome, flags, min_bins_per_gc); });
+        }
+        for (auto& t : th) t.join();
+        for (int s = 0; s < nsamples; s++) if (rcs[s] && rcAll == CANVAS_OK) { ctx->err = ctx->children[s]->err; rcAll = rcs[s]; enq[s] = 0; }
+    }
+    for (int s = 0; s < nsamples; s++) {
+        canvas_ctx* ch = ctx->children[s];
+        bool handled = false; int32_t rc = CANVAS_OK;
+        if (enq[s]) rc = clean_device_driven_finish(ch, h_local_sd_out ? h_local_sd_out + s : nullptr, h_n_out + s, h_info ? h_info + 8 * s : nullptr, &handled);
+        if (rc == CANVAS_OK && !handled && rcAll == CANVAS_OK)                     // empty sample, LOESS / -w < 100, or the device path handed the sample back
+            rc = canvas_clean2(ch, h_n[s], h_d_chr[s], h_d_start[s], h_d_stop[s], h_d_count[s], h_d_gc[s], nchr, h_chr_is_autosome, h_chr_is_y, flags, min_bins_per_gc,
+                               h_local_sd_out ? h_local_sd_out + s : nullptr, h_n_out + s, h_info ? h_info + 8 * s : nullptr);
+        if (rc && rcAll == CANVAS_OK) { ctx->err = ch->err; rcAll = rc; }
+    }
+    return rcAll;
 }
 
 extern "C" int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,

@@ -365,9 +365,10 @@ __global__ void __launch_bounds__(256) k_cf_flags_final(const int32_t* __restric
     __syncthreads();
     if (threadIdx.x == 0) blockCnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ void __launch_bounds__(256) k_cf_scatter_final(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t nUpper, Soa src, Soa dst, const CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(256) k_cf_scatter_final(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t nUpper, Soa src, Soa dst, const CleanDev* __restrict__ D, int secondPhase) {
     __shared__ uint32_t sh[4];
     if (D->fallback || D->bad) return;                                        // the caller's arrays stay as they were
+    if (D->changed && !secondPhase) return;                                   // the variance normalisation changed the counts: the host enqueues the second NormalizeByGC, then this kernel again
     const int64_t n = (int64_t)D->nAB;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
@@ -416,10 +417,10 @@ static void cf_select_passes(canvas_ctx* ctx, const uint32_t* keysG, SelTile* dT
     }
 }
 
-// returns CANVAS_OK and sets *handled = false when the host-driven path has to take over (nothing was modified)
-static int32_t clean_device_driven(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count, int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome,
-                                   uint32_t flags, int32_t min_bins_per_gc, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, bool* handled) {
-    *handled = false;
+struct CleanPending { int64_t n; int nb; unsigned tilesUpper; Soa S1, caller; uint8_t* dFlags; uint32_t* dBlk; uint32_t* keysG; SelTile* dTiles; CfSel* P; CleanDev* D; };
+// Enqueues the whole stage on ctx->stream (no synchronisation): the CleanDev block arrives in ctx->pin.  clean_device_driven_finish waits for it.
+static int32_t clean_device_driven_enqueue(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count, int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome,
+                                           uint32_t flags, int32_t min_bins_per_gc) {
     const int64_t nW0 = n / 20 + 2;
     const int nb = (int)nblk(n, CBLK);
     const unsigned tilesUpper = (unsigned)(n / SEL_TILE + NGC + 1);
@@ -484,12 +485,8 @@ static int32_t clean_device_driven(canvas_ctx* ctx, int64_t n, int32_t* d_chr, i
             hipLaunchKernelGGL(k_cf_xform_gc, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, keysG, D, P + 1);
             cf_select_passes(ctx, keysG, dTiles + tilesUpper, P + 1, n);
             hipLaunchKernelGGL(k_cf_dec_f, dim3(1), dim3(128), 0, ctx->stream, P + 1, D);
-            hipLaunchKernelGGL(k_cf_apply_var, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, S1.count, S1.gc, n, D);
-            hipLaunchKernelGGL(k_cf_xform_var, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, keysG, D);
-            hipLaunchKernelGGL(k_cf_sel_setup, dim3(1), dim3(128), 0, ctx->stream, 0, 2, D, P + 2, dTiles + 2 * (size_t)tilesUpper);
-            cf_select_passes(ctx, keysG, dTiles + 2 * (size_t)tilesUpper, P + 2, n);
-            hipLaunchKernelGGL(k_cf_dec_e, dim3(1), dim3(128), 0, ctx->stream, P + 2, D);
-            hipLaunchKernelGGL(k_cf_apply_gc, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, S1.count, S1.gc, n, D, P + 2);
+            // ... which it rarely does: the last compaction below is enqueued on the assumption that it does not; when k_cf_dec_f says it did, that compaction does nothing
+            // and clean_device_driven_finish enqueues the variance scaling, the second NormalizeByGC and the compaction (one more synchronisation, in that case only)
         }
     }
     // ---- local-SD average, last compaction into the caller's arrays
@@ -500,11 +497,36 @@ static int32_t clean_device_driven(canvas_ctx* ctx, int64_t n, int32_t* d_chr, i
     hipLaunchKernelGGL(k_cf_lsd_avg, dim3(1), dim3(64), 0, ctx->stream, dRunMad, D);
     hipLaunchKernelGGL(k_cf_flags_final, dim3(nb), dim3(256), 0, ctx->stream, S1.gc, S1.dev, n, D, dFlags, dBlk);
     hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, dBlk, D, &D->nFinal);
-    hipLaunchKernelGGL(k_cf_scatter_final, dim3(nb), dim3(256), 0, ctx->stream, dFlags, dBlk, n, S1, caller, D);
+    hipLaunchKernelGGL(k_cf_scatter_final, dim3(nb), dim3(256), 0, ctx->stream, dFlags, dBlk, n, S1, caller, D, 0);
     rc = canvas_pin_reserve(ctx, sizeof(CleanDev)); if (rc) return rc;
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, D, sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
+    CleanPending pend{n, nb, tilesUpper, S1, caller, dFlags, dBlk, keysG, dTiles, P, D};
+    ctx->clean_pending.assign((const char*)&pend, (const char*)&pend + sizeof pend);
+    return CANVAS_OK;
+}
+// returns CANVAS_OK and sets *handled = false when the host-driven path has to take over (nothing was modified)
+static int32_t clean_device_driven_finish(canvas_ctx* ctx, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, bool* handled) {
+    *handled = false;
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());
+    if (((const CleanDev*)ctx->pin)->changed && !((const CleanDev*)ctx->pin)->fallback && !((const CleanDev*)ctx->pin)->bad && ctx->clean_pending.size() == sizeof(CleanPending)) {
+        // NormalizeVarianceByGC changed the counts (CanvasClean.cs:512-519): scale them, NormalizeByGC again on the new counts, then the last compaction
+        CleanPending q; memcpy(&q, ctx->clean_pending.data(), sizeof q);
+        const int64_t n = q.n;
+        hipLaunchKernelGGL(k_cf_apply_var, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, q.S1.count, q.S1.gc, n, q.D);
+        hipLaunchKernelGGL(k_cf_xform_var, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, q.keysG, q.D);
+        hipLaunchKernelGGL(k_cf_sel_setup, dim3(1), dim3(128), 0, ctx->stream, 0, 2, q.D, q.P + 2, q.dTiles + 2 * (size_t)q.tilesUpper);
+        cf_select_passes(ctx, q.keysG, q.dTiles + 2 * (size_t)q.tilesUpper, q.P + 2, n);
+        hipLaunchKernelGGL(k_cf_dec_e, dim3(1), dim3(128), 0, ctx->stream, q.P + 2, q.D);
+        hipLaunchKernelGGL(k_cf_apply_gc, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, q.S1.count, q.S1.gc, n, q.D, q.P + 2);
+        hipLaunchKernelGGL(k_cf_flags_final, dim3(q.nb), dim3(256), 0, ctx->stream, q.S1.gc, q.S1.dev, n, q.D, q.dFlags, q.dBlk);
+        hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, q.dBlk, q.D, &q.D->nFinal);
+        hipLaunchKernelGGL(k_cf_scatter_final, dim3(q.nb), dim3(256), 0, ctx->stream, q.dFlags, q.dBlk, n, q.S1, q.caller, q.D, 1);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, q.D, sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+    }
+    ctx->clean_pending.clear();
     const CleanDev& H = *(const CleanDev*)ctx->pin;
     if (H.bad) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: a bin has gc outside 0..100 or a chromosome index outside [0, nchr) (the reference throws IndexOutOfRangeException)");
     if (H.fallback) return CANVAS_OK;                                  // *handled stays false: nothing was written to the caller's arrays
@@ -517,4 +539,10 @@ static int32_t clean_device_driven(canvas_ctx* ctx, int64_t n, int32_t* d_chr, i
         memcpy(h_info, info, sizeof info);
     }
     return CANVAS_OK;
+}
+static int32_t clean_device_driven(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count, int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome,
+                                   uint32_t flags, int32_t min_bins_per_gc, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, bool* handled) {
+    *handled = false;
+    int32_t rc = clean_device_driven_enqueue(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc); if (rc) return rc;
+    return clean_device_driven_finish(ctx, h_local_sd_out, h_n_out, h_info, handled);
 }

@@ -38,6 +38,8 @@ struct canvas_ctx {
     hipEvent_t up_fence = nullptr;     // compute stream -> copy stream: the destinations may still be read by the previous pass
     std::vector<const void*> up_bases, up_mask, up_hits;
     bool up_active = false;
+    std::vector<char> clean_pending;     // clean_fast.hpp: what the second phase of the device-driven CanvasClean needs (set by enqueue, consumed by finish)
+    std::vector<canvas_ctx*> children;   // contexts of canvas_clean_batch: one stream + workspace per sample in flight
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
     // host-callback transport of the collectives (canvas_comm_init_host): used when the ranks cannot form an RCCL communicator

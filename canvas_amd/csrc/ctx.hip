@@ -24,6 +24,8 @@ canvas_ctx* canvas_create(int device) {
 
 void canvas_destroy(canvas_ctx* ctx) {
     if (!ctx) return;
+    for (canvas_ctx* ch : ctx->children) canvas_destroy(ch);
+    ctx->children.clear();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }

@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h", "canvas_host_register", "canvas_host_unregister", "canvas_upload_genome_begin", "canvas_upload_genome_wait",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
-    "canvas_clean", "canvas_clean2", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
+    "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sharded_stats", "canvas_profile_enable", "canvas_profile_get",
 ]
 
@@ -232,6 +232,18 @@ class Canvas:
                                            C.c_void_p(bins["stop"].data_ptr()), C.c_void_p(bins["count"].data_ptr()), C.c_void_p(bins["gc"].data_ptr()),
                                            len(ia), _np_ptr(ia), _np_ptr(iy), C.c_uint32(flags), min_bins_per_gc, C.byref(lsd), C.byref(nout), _np_ptr(info)))
         return nout.value, lsd.value, info
+
+    def clean_batch(self, samples, ns, is_autosome, flags, min_bins_per_gc=100, is_y=None):
+        """canvas_clean_batch: CanvasClean of several samples at once (list of SoA dicts, bins per sample); returns ([n_out], [local_sd], info[S][8])"""
+        S = len(samples)
+        ia = np.ascontiguousarray(is_autosome, np.uint8)
+        iy = np.ascontiguousarray(is_y if is_y is not None else np.zeros(len(ia)), np.uint8)
+        arr = lambda key: (C.c_void_p * S)(*[C.c_void_p(s[key].data_ptr()) for s in samples])
+        hn = np.ascontiguousarray(ns, np.int64); lsd = np.full(S, -1.0, np.float64); nout = np.zeros(S, np.int64); info = np.zeros((S, 8), np.int32)
+        self.torch.cuda.synchronize()
+        self._check(self.lib.canvas_clean_batch(self.ctx, S, _np_ptr(hn), arr("chr"), arr("start"), arr("stop"), arr("count"), arr("gc"), len(ia), _np_ptr(ia), _np_ptr(iy),
+                                                C.c_uint32(flags), int(min_bins_per_gc), _np_ptr(lsd), _np_ptr(nout), _np_ptr(info)))
+        return nout, lsd, info
 
     def merge_cleaned(self, samples, ns):
         """MergeMultiSampleCleanedBedFile (Utilities.cs:834-920): bins every sample still has.  samples = list of SoA dicts (chr, start, stop,

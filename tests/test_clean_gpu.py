@@ -215,3 +215,24 @@ def test_clean_small_inputs_and_flag_subsets():
         bins = synth.generate_bins(20260927 + 7, max(n, 24), nchr=24 if n >= 24 else 1)
         bins = {k: v[:n] if n < 24 else v for k, v in bins.items()}
         _run(cv, bins, flags, nchr=24 if n >= 24 else 1, is_auto=None if n >= 24 else [1])
+
+
+def test_clean_batch_equals_single_calls():
+    """canvas_clean_batch: a cohort in one call, every sample on its own stream — each sample's result is the one of its own canvas_clean2 call (and of the oracle)"""
+    cv = get_canvas()
+    specs = [(70_000, 24, False), (600_000, 24, False), (3_000, 3, False), (60_000, 24, True), (120_000, 24, False)]
+    samples, exps, ns = [], [], []
+    is_auto = synth.IS_AUTOSOME; is_y = np.zeros(24, np.uint8); is_y[-1] = 1
+    for k, (n, nchr, interleave) in enumerate(specs):
+        bins = synth.generate_bins(20260927 + 40 + k, n, nchr=nchr)
+        if interleave: bins["chr"] = ((np.arange(len(bins["chr"])) // 20) % 24).astype(np.int32)      # > 1024 chromosome runs: handed back to the host-driven path
+        exps.append(O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, ALL))
+        samples.append({kk: to_dev(v, cv.device) for kk, v in bins.items()}); ns.append(len(bins["chr"]))
+    nout, lsd, info = cv.clean_batch(samples, ns, is_auto, ALL, is_y=is_y)
+    for k, ex in enumerate(exps):
+        assert nout[k] == len(ex["chr"]) and lsd[k] == ex["local_sd"], k
+        m = int(nout[k])
+        for key in ("chr", "start", "stop", "gc"):
+            assert (samples[k][key][:m].cpu().numpy() == ex[key]).all(), (k, key)
+        assert (samples[k]["count"][:m].cpu().numpy().view(np.uint32) == ex["count"].view(np.uint32)).all(), k
+        assert info[k][3] == m
