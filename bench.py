@@ -382,7 +382,7 @@ def somatic_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, devi
     sec = time.perf_counter() - t0
     o = {"seconds": round(sec, 3), "first_call_seconds": round(first, 3), "bins": int(r["n_bins"]), "bins_per_s": round(int(r["n_bins"]) / sec, 1), "bin_size": int(r["bin_size"]),
          "bins_with_ratio": int(r["n_ratio"]), "bins_after_clean": int(r["n_clean"]), "library_size_factor": r["library_size_factor"], "segments": int(r["segments"]),
-         "cbs_tmaxo_calls": int(r["cbs_stats"][0]), "cbs_permutations": int(r["cbs_stats"][2]),
+         "cbs_tmaxo_calls": int(r["cbs_stats"][0]), "cbs_permutations": int(r["cbs_stats"][2]), "stage_seconds": r["stage_seconds"],
          "workload": "BASELINE configs[4]: tumour 80x (rate %.3f, purity 0.7, -m GCContentWeighted) / normal 40x (rate %.3f), LSNorm x 40, Clean, CBS" % (rt, rn)}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -38,6 +38,7 @@ struct canvas_ctx {
     hipEvent_t up_fence = nullptr;     // compute stream -> copy stream: the destinations may still be read by the previous pass
     std::vector<const void*> up_bases, up_mask, up_hits;
     bool up_active = false;
+    void* gc_arena = nullptr; size_t gc_arena_bytes = 0;   // GCContentWeighted binning: read-GC profile of every position + GC prefix array (grow-only)
     std::vector<char> clean_pending;     // clean_fast.hpp: what the second phase of the device-driven CanvasClean needs (set by enqueue, consumed by finish)
     std::vector<canvas_ctx*> children;   // contexts of canvas_clean_batch: one stream + workspace per sample in flight
     void* comm = nullptr;  // ncclComm_t

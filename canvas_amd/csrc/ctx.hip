@@ -36,6 +36,9 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->side_ev2) (void)hipEventDestroy(ctx->side_ev2);
     if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->gc_arena) (void)hipFree(ctx->gc_arena);
+    if (ctx->shard_ws) (void)hipFree(ctx->shard_ws);
+    if (ctx->comm_pin) (void)hipHostFree(ctx->comm_pin);
     if (ctx->misc_pin) (void)hipHostFree(ctx->misc_pin);
     if (ctx->sel_ws) (void)hipFree(ctx->sel_ws);
     if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);

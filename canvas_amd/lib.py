@@ -385,14 +385,22 @@ class Canvas:
         the tumour's own rates) and -m TruncatedDynamicRange -z <that size> on the normal (same mask => same bins), CanvasNormalize's LSNorm ratio x 40
         (LSNormRatioCalculator.cs:31-44, CanvasNormalizeUtilities.cs:23-33), its "{count:F2}" file read back with float.Parse (IO.cs:21,40), CanvasClean,
         the F2 hand-off to CanvasPartition and CBS (alpha, nperm).  Returns a dict; with keep=True every intermediate array is kept for checking."""
+        import time
         torch = self.torch
         nchr = len(bases)
         cap = int(sum(int(l) for l in lens) // 50) + 64
         mk = lambda dt: torch.empty(cap, dtype=dt, device=self.device)
+        stage = {}; t_prev = [time.perf_counter()]
+
+        def tick(name):
+            self.synchronize(); torch.cuda.synchronize()
+            now = time.perf_counter(); stage[name] = round(now - t_prev[0], 4); t_prev[0] = now
         T = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
         N = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
         _, perT, nT, bs = self.bin_sample_gcweighted(bases, masks, hits_t, fraglen_t, lens, is_autosome, counts_per_bin, -1, out=T)
+        tick("bin_tumour_gcweighted")
         _, perN, nN, _ = self.bin_sample(bases, masks, hits_n, lens, is_autosome, counts_per_bin, bs, MODE_TDR, out=N)
+        tick("bin_normal")
         if nN != nT:
             raise CanvasError(f"tumour and normal bins differ ({nT} vs {nN}): they must share the reference mask")
         kidx, ratio, count, lsf = self.normalize_ratio(T["count"][:nT], N["count"][:nN], None, mode=0)
@@ -400,15 +408,19 @@ class Canvas:
         ki = kidx.long()
         R = dict(chr=T["chr"][:nT][ki].contiguous(), start=T["start"][:nT][ki].contiguous(), stop=T["stop"][:nT][ki].contiguous(), gc=T["gc"][:nT][ki].contiguous(),
                  count=self.quantize_f2(count, k).float().contiguous())       # the ratio file's F2 text, float.Parse'd by CanvasClean
+        tick("normalize_ratio+f2")
         res = dict(bin_size=bs, n_bins=nT, n_ratio=k, library_size_factor=lsf)
         if keep:
             res.update(tumour={a: T[a][:nT].clone() for a in T}, normal_count=N["count"][:nN].clone(), keep_idx=kidx.clone(), ratio=ratio.clone(), ratio_count=count.clone(),
                        to_clean={a: R[a].clone() for a in R})
         n_out, lsd, info = self.clean(R, k, is_autosome, clean_flags, is_y=is_y)
+        tick("clean")
         cov = self.quantize_f2(R["count"], n_out)
         off = self.chromosome_offsets(R["chr"], n_out, nchr)
+        tick("f2+offsets")
         seg_len, nseg, stats = self.cbs(cov, off, alpha, nperm)
-        res.update(n_clean=n_out, local_sd=lsd, chr_offset=off, nseg=nseg, cbs_stats=stats, segments=int(nseg.sum()))
+        tick("cbs")
+        res.update(n_clean=n_out, local_sd=lsd, chr_offset=off, nseg=nseg, cbs_stats=stats, segments=int(nseg.sum()), stage_seconds=stage)
         if keep:
             res.update(cleaned={a: R[a][:n_out].clone() for a in R}, cov=cov.clone(), seg_len=seg_len)
         return res
