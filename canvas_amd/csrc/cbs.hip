@@ -276,14 +276,24 @@ __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ re
 }
 // data-parallel part, one launch per step: draws [MT_HISTORY + step * MT_WIDTH, + MT_WIDTH) of every request that is long enough
 __global__ void __launch_bounds__(256) k_mt_stride(const PermReq* __restrict__ reqs, int step) {
+    // four consecutive draws per thread: every lag is a multiple of MT_STRIDE (a multiple of 4), so the 134 operands of the four draws are 134 aligned 16-byte loads
     const PermReq& R = reqs[blockIdx.y];
-    const long long k = (R.cont ? 0 : MT_HISTORY) + (long long)step * MT_WIDTH + (long long)blockIdx.x * 256 + threadIdx.x;
-    if ((long long)blockIdx.x * 256 + threadIdx.x >= MT_WIDTH || k >= R.total) return;
+    const long long j = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long long k = (R.cont ? 0 : MT_HISTORY) + (long long)step * MT_WIDTH + j;
+    if (j >= MT_WIDTH || k >= R.total) return;
     const uint32_t* __restrict__ d = R.P.draws;
-    uint32_t v = 0;
+    if (k + 4 <= R.total && ((reinterpret_cast<uintptr_t>(d + k) & 15) == 0)) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 8
-    for (int i = 0; i < MT_NLAG; i++) v ^= d[k - (long long)MT_LAG[i] * MT_STRIDE];
-    R.P.draws[k] = v;
+        for (int i = 0; i < MT_NLAG; i++) { const uint4 t = *reinterpret_cast<const uint4*>(d + (k - (long long)MT_LAG[i] * MT_STRIDE)); v.x ^= t.x; v.y ^= t.y; v.z ^= t.z; v.w ^= t.w; }
+        *reinterpret_cast<uint4*>(R.P.draws + k) = v;
+    } else {
+        for (int e = 0; e < 4 && k + e < R.total; e++) {
+            uint32_t v = 0;
+            for (int i = 0; i < MT_NLAG; i++) v ^= d[k + e - (long long)MT_LAG[i] * MT_STRIDE];
+            R.P.draws[k + e] = v;
+        }
+    }
 }
 // generator state after every permutation of the batch, rebuilt from the outputs: the 624 words behind a position are the untempered
 // last 624 outputs, with the read index at 624 (the next draw starts a new block) — what the host generator resumes from
@@ -816,7 +826,7 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
 
 // ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
 #define PERM_GPU_MIN_N 1024          // shorter segments stay on the host: measured with 201 (every hybrid segment on the device) the WGS run is identical but 12 % slower (0.555 vs 0.496 s) — a permutation of a few hundred elements is microseconds of host work and a launch round trip on the device
-#define PERM_TARGET_ELEMS (32 << 20) // permuted elements per batch (44 B of workspace each)
+#define PERM_TARGET_ELEMS (64 << 20) // permuted elements per batch (44 B of workspace each)
 struct PermService;
 struct PermGpu {
     canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr; char* buf = nullptr; size_t bytes = 0; char* pin = nullptr; size_t pinBytes = 0;
@@ -957,7 +967,7 @@ struct PermService {
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs);
         const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;
-        for (int sidx = 0; sidx < steps; sidx++) hipLaunchKernelGGL(k_mt_stride, dim3((MT_WIDTH + 255) / 256, R), dim3(256), 0, stream, dReqs, sidx);
+        for (int sidx = 0; sidx < steps; sidx++) hipLaunchKernelGGL(k_mt_stride, dim3((MT_WIDTH / 4 + 255) / 256, R), dim3(256), 0, stream, dReqs, sidx);
         hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
         hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         for (int i = 0; i < R; i++) {
