@@ -11,7 +11,8 @@
 #pragma once
 #include "common.hpp"
 
-#define SEL_TILE 4096
+#define SEL_TILE 4096      // keys per workgroup: LDS rows are zeroed and flushed once per tile, the keys go through in chunks of SEL_CHUNK
+#define SEL_CHUNK 4096
 #define SEL_MAXQ 16   // max queries that can apply to one tile
 #define SEL_REP 16    // replicas of the global histogram rows: tiles flush into replica (tile % SEL_REP), the pick sums them
 
@@ -71,19 +72,20 @@ __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys,
     const int nu = snu;
     const int lane = threadIdx.x & 63;
     const int sh2 = firstPass ? 0 : shift + 8;
-    // all 16 keys of this thread are loaded up front (independent loads in flight), then binned
-    K kreg[SEL_TILE / 256];
-#pragma unroll
-    for (int r = 0; r < SEL_TILE / 256; r++) { const int64_t i = T.begin + threadIdx.x + (int64_t)r * 256; kreg[r] = i < T.end ? keys[i] : (K)0; }
     bool agg = true;                                      // wave-uniform: is ballot aggregation paying off in this tile?
+    for (int64_t cbeg = T.begin; cbeg < T.end; cbeg += SEL_CHUNK) {
+    // all 16 keys of this thread are loaded up front (independent loads in flight), then binned
+    K kreg[SEL_CHUNK / 256];
+#pragma unroll
+    for (int r = 0; r < SEL_CHUNK / 256; r++) { const int64_t i = cbeg + threadIdx.x + (int64_t)r * 256; kreg[r] = i < T.end ? keys[i] : (K)0; }
     if (nu == 1) {
         // one histogram row for the whole tile (every first pass, every single-query select): prefix and row index in registers, no LDS
         // reads and no loop over rows inside the key loop
         const int q = suniq[0];
         const unsigned long long pre = lpre[q];
 #pragma unroll
-        for (int r = 0; r < SEL_TILE / 256; r++) {
-            const bool in = T.begin + threadIdx.x + (int64_t)r * 256 < T.end;
+        for (int r = 0; r < SEL_CHUNK / 256; r++) {
+            const bool in = cbeg + threadIdx.x + (int64_t)r * 256 < T.end;
             const K key = kreg[r];
             const uint32_t d = (uint32_t)(key >> shift) & 255u;
             const bool m = in && (firstPass || (unsigned long long)(key >> sh2) == pre);
@@ -102,8 +104,8 @@ __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys,
         }
     } else
 #pragma unroll
-    for (int r = 0; r < SEL_TILE / 256; r++) {
-        const bool in = T.begin + threadIdx.x + (int64_t)r * 256 < T.end;
+    for (int r = 0; r < SEL_CHUNK / 256; r++) {
+        const bool in = cbeg + threadIdx.x + (int64_t)r * 256 < T.end;
         const K key = kreg[r];
         const uint32_t d = (uint32_t)(key >> shift) & 255u;
         const unsigned long long hi = (unsigned long long)(key >> sh2);   // only compared when !firstPass (then sh2 = shift+8 < bits)
@@ -124,6 +126,7 @@ __global__ void __launch_bounds__(256) k_select_hist(const K* __restrict__ keys,
             } else if (m) atomicAdd(&lh[q * 256 + d], 1u);
         }
     }
+    }   // chunks of the tile
     __syncthreads();
     for (int i = threadIdx.x; i < Q.nq * 256; i += 256) {
         uint32_t v = lh[srep[i >> 8] * 256 + (i & 255)];
