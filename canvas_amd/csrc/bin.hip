@@ -18,6 +18,8 @@
 // No atomics, no floating reduction: the prefix-difference formulation is deterministic.
 #include "common.hpp"
 #include <algorithm>
+#include <thread>
+#include <emmintrin.h>
 
 #define TILE_SHIFT 12
 #define TILE 4096
@@ -45,10 +47,15 @@ __global__ void __launch_bounds__(256) k_find_pos0(const BinChrom* __restrict__ 
     const int c = blockIdx.y + c0;
     const BinChrom C = ch[c];
     const int64_t CHUNK = 256 * 16;
+    __shared__ unsigned long long scur;
     for (int64_t chunk = blockIdx.x; chunk * CHUNK < C.len; chunk += gridDim.x) {
         int64_t start = chunk * CHUNK;
-        unsigned long long cur = __hip_atomic_load(&pos0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned long long)start >= cur) break;      // someone already found an earlier non-'n'
+        // ONE read of the running minimum per workgroup: if every thread read it for itself, waves of one workgroup could disagree (another workgroup's atomicMin
+        // lands in between) and leave the loop at different iterations — the ones that stay would then take the minimum over LDS slots nobody wrote
+        if (threadIdx.x == 0) scur = __hip_atomic_load(&pos0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned long long cur = scur;
+        if ((unsigned long long)start >= cur) break;      // someone already found an earlier non-'n' (uniform over the workgroup)
         int64_t p = start + (int64_t)threadIdx.x * 16;
         int found = 16;
         if (p + 16 <= C.len) {
@@ -159,7 +166,7 @@ __device__ __forceinline__ void store8_u32(uint32_t* __restrict__ arr, int64_t v
 }
 __global__ void __launch_bounds__(1024) k_scan_tiles(const BinChrom* __restrict__ ch, const unsigned long long* __restrict__ pos0,
                                                      const uint32_t* __restrict__ tilePop, const uint32_t* __restrict__ tileObs, int wantObs,
-                                                     int binSize, int32_t* __restrict__ rankBase, ChromOut* __restrict__ out) {
+                                                     int binSize, int32_t* __restrict__ rankBase, ChromOut* __restrict__ out, int packed = 0) {
     __shared__ U2 sh[2][16];
     __shared__ unsigned long long sRed[2][16];
     const int c = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -173,7 +180,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(const BinChrom* __restrict_
     if (w == 0) {
         int64_t wstart = (t0 << TILE_SHIFT) + (int64_t)l * 64;
         if (wstart < p0) {
-            uint64_t mw = C.mask[wstart >> 6];
+            uint64_t mw = packed ? reinterpret_cast<const ulonglong2*>(C.bases)[wstart >> 6].x : C.mask[wstart >> 6];    // bin_packed.hpp: {possible, gc} pairs
             int64_t valid = p0 - wstart;
             if (valid < 64) mw &= (~0ull) >> (64 - valid);
             before += (unsigned long long)__popcll(mw);
@@ -784,6 +791,8 @@ __global__ void __launch_bounds__(256) k_bin_weighted(const BinChrom* __restrict
     if (l == 0) oCount[i] = (float)(int)rint((double)tmp);
 }
 
+#include "bin_packed.hpp"
+
 // ---------------------------------------------------------------------------------------------- host side
 struct BinPlan {
     std::vector<BinChrom> chroms;
@@ -858,12 +867,15 @@ int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_
 static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
                                const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len, const uint8_t* h_is_auto, int32_t counts_per_bin, int32_t bin_size, int32_t mode,
                                int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                               int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total, cvx_bin_size_hook hook = nullptr, void* hookUser = nullptr) {
+                               int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total, cvx_bin_size_hook hook = nullptr, void* hookUser = nullptr,
+                               const int64_t* h_pos0_packed = nullptr) {
     if (!ctx) return CANVAS_ERR_INVALID;
     const bool needRates = bin_size <= 0;
+    const bool packed = h_pos0_packed != nullptr;       // bin_packed.hpp: d_bases = the reference planes, d_hits = the hit planes, d_mask unused
     if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || (needRates && !hook && (!h_is_auto || counts_per_bin <= 0))) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_genome: bad arguments");
     const bool gcw = mode == CANVAS_MODE_GC_CONTENT_WEIGHTED;
     if (gcw && !d_fraglen) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode needs the fragment-length arrays (canvas_bin_sample_gcweighted)");
+    if (gcw && packed) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "the packed planes serve Binary and TruncatedDynamicRange; GCContentWeighted reads the per-base arrays");
     if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE && !gcw) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "unknown coverage mode");
     for (int c = 0; c < nchr; c++) if (h_len[c] <= 0 || h_len[c] > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "chromosome length must be in [1, 2^31)");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -937,10 +949,10 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     for (int c = 0; streamed && c < nchr; c++) streamed = ctx->up_bases[c] == d_bases[c] && ctx->up_mask[c] == d_mask[c] && ctx->up_hits[c] == d_hits[c];
     if (ctx->up_active && !streamed) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); }    // other arrays (or mode 5): plain dependency on the whole upload
     ctx->up_active = false;
-    const bool singleRead = streamed || (needRates && !getenv("CANVAS_BIN_TWO_PASS")) || getenv("CANVAS_BIN_SINGLE_READ");
+    const bool singleRead = packed || streamed || (needRates && !getenv("CANVAS_BIN_TWO_PASS")) || getenv("CANVAS_BIN_SINGLE_READ");
     if (singleRead) sz.take<uint32_t>(plan.ntiles * 64);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
-    rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + sizeof(ChromOut))); if (rc) return rc;
+    rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + sizeof(ChromOut) + 8)); if (rc) return rc;
     WsCarver ws(ctx->ws);
     BinChrom* dCh = ws.take<BinChrom>(nchr); unsigned long long* dPos0 = ws.take<unsigned long long>(nchr);
     uint32_t* tilePop = ws.take<uint32_t>(plan.ntiles); uint32_t* tileObs = ws.take<uint32_t>(plan.ntiles); int32_t* rankBase = ws.take<int32_t>(plan.ntiles);
@@ -952,6 +964,29 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
     ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
+    const unsigned pkGrid = (unsigned)((plan.ntiles + 4 * PK_TILES - 1) / (4 * PK_TILES));
+    if (packed) {
+        // pos0 comes with the planes (the packer found it)
+        unsigned long long* hp0 = (unsigned long long*)((char*)ctx->pin + nchr * (sizeof(BinChrom) + sizeof(ChromOut)));
+        for (int c = 0; c < nchr; c++) {
+            if (h_pos0_packed[c] < 0 || h_pos0_packed[c] > h_len[c]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_sample_packed: pos0 outside [0, len]");
+            hp0[c] = (unsigned long long)h_pos0_packed[c];
+        }
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dPos0, hp0, (size_t)nchr * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (streamed) {
+            for (int c = 0; c < nchr; c++) {
+                const BinChrom& C = plan.chroms[c];
+                CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[c], 0));
+                ProfScope ps(ctx, "bin_summary_packed_streamed");
+                hipLaunchKernelGGL(k_tile_summary_packed, dim3((unsigned)((C.ntiles + 4 * PK_TILES - 1) / (4 * PK_TILES))), dim3(256), 0, ctx->stream, dCh, nchr, C.tileBase + C.ntiles, dPos0,
+                                   clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG, C.tileBase);
+            }
+        } else {
+            ProfScope ps(ctx, "bin_summary_packed");
+            hipLaunchKernelGGL(k_tile_summary_packed, dim3(pkGrid), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, clampHits, needRates ? 1 : 0,
+                               wordSum, tilePop, tileObs, tileTotC, tileTotG, (int64_t)0);
+        }
+    } else {
     hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);
     if (streamed) {
         // copy / compute overlap: chromosome c's sweep waits for chromosome c's event only, chromosome c + 1 is on its way meanwhile
@@ -975,9 +1010,10 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, needRates ? 1 : 0, tilePop, tileObs);
     }
     if (singleRead && !streamed) hipLaunchKernelGGL(k_tile_summary_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG, 0);
+    }   // byte arrays
     if (needRates) {
         // rates (CanvasBin.cs:30-83): totals per chromosome, then the bin size on the host
-        hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut, packed ? 1 : 0);
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
         // the tile totals of the single-read path do not depend on the bin size either: their scan runs while the host derives it
         if (singleRead) hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
@@ -997,7 +1033,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     }
     if (h_bin_size_out) *h_bin_size_out = bin_size;
     if (!needRates) {
-        hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, (const uint32_t*)nullptr, 0, bin_size, rankBase, dOut);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, (const uint32_t*)nullptr, 0, bin_size, rankBase, dOut, packed ? 1 : 0);
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
@@ -1013,7 +1049,8 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         ProfScope ps(ctx, "bin_close");
         hipLaunchKernelGGL(k_bin_close, dim3((unsigned)((plan.ntiles + 4 * CLOSE_TILES - 1) / (4 * CLOSE_TILES))), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, wordSum, rankBase,
                            binOffset, bin_size, stopTmp, locC, locG, d_chr);
-        hipLaunchKernelGGL(k_bin_resolve, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, clampHits, d_chr, stopTmp, locC, locG);
+        if (packed) hipLaunchKernelGGL(k_bin_resolve_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, clampHits, d_chr, stopTmp, locC, locG);
+        else hipLaunchKernelGGL(k_bin_resolve, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, clampHits, d_chr, stopTmp, locC, locG);
     } else {
         { ProfScope ps(ctx, "bin_pass");
           hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
@@ -1053,6 +1090,141 @@ int32_t canvas_bin_sample_gcweighted(canvas_ctx* ctx, int32_t nchr, const uint8_
                                      int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
     return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, d_fraglen, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, CANVAS_MODE_GC_CONTENT_WEIGHTED,
                            d_chr, d_start, d_stop, d_gc, d_count, cap, h_bin_size_out, h_nbins_per_chr, h_nbins_total);
+}
+
+// ---- packed planes (bin_packed.hpp)
+int32_t canvas_packed_plane_bytes(int64_t len, int64_t* ref_bytes, int64_t* hit_bytes) {
+    if (len <= 0) return CANVAS_ERR_INVALID;
+    const int64_t words = ((len + TILE - 1) / TILE) * 64;               // padded to whole tiles
+    if (ref_bytes) *ref_bytes = words * 16;
+    if (hit_bytes) *hit_bytes = words * 32;
+    return CANVAS_OK;
+}
+
+int32_t canvas_bin_sample_packed(canvas_ctx* ctx, int32_t nchr, const uint64_t* const* d_ref, const uint64_t* const* d_hit_planes, const int64_t* h_len, const int64_t* h_pos0,
+                                 const uint8_t* h_chr_is_autosome, int32_t counts_per_bin, int32_t bin_size_in, int32_t mode,
+                                 int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                 int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (!h_pos0 || !d_ref || !d_hit_planes) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_sample_packed: bad arguments");
+    return bin_genome_impl(ctx, nchr, (const uint8_t* const*)d_ref, d_ref, (const uint8_t* const*)d_hit_planes, nullptr, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, mode,
+                           d_chr, d_start, d_stop, d_gc, d_count, cap, h_bin_size_out, h_nbins_per_chr, h_nbins_total, nullptr, nullptr, h_pos0);
+}
+
+// per-base arrays already in HBM -> planes (either half may be omitted: a second sample over a packed reference passes d_bases = d_mask = NULL)
+int32_t canvas_pack_genome_device(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
+                                  uint64_t* const* d_ref_out, uint64_t* const* d_hit_planes_out, int64_t* h_pos0_out, int64_t* h_saturated_out) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    const bool doRef = d_bases && d_mask && d_ref_out, doHits = d_hits && d_hit_planes_out;
+    if (nchr <= 0 || !h_len || (!doRef && !doHits) || (doRef && !h_pos0_out)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_pack_genome_device: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int32_t rcf = canvas_upload_fence(ctx); if (rcf) return rcf; }
+    for (int c = 0; c < nchr; c++) if (h_len[c] <= 0 || h_len[c] > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "chromosome length must be in [1, 2^31)");
+    WsSizer sz; sz.take<BinChrom>(nchr); sz.take<unsigned long long>(nchr + 1);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
+    rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + 8) + 8); if (rc) return rc;
+    WsCarver ws(ctx->ws);
+    BinChrom* dCh = ws.take<BinChrom>(nchr); unsigned long long* dPos0 = ws.take<unsigned long long>(nchr + 1);   // [nchr] = saturated positions
+    if (doRef) {
+        BinPlan plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len);
+        memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);
+        hipLaunchKernelGGL(k_find_pos0, dim3(64, nchr), dim3(256), 0, ctx->stream, dCh, dPos0, 0);
+    }
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dPos0 + nchr, 0, 8, ctx->stream));
+    for (int c = 0; c < nchr; c++) {
+        const int64_t words = ((h_len[c] + TILE - 1) / TILE) * 64;
+        if (doRef) hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_bases[c], d_mask[c], h_len[c], words, (ulonglong2*)d_ref_out[c]);
+        if (doHits) hipLaunchKernelGGL(k_pack_hits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_hits[c], h_len[c], words, (ulonglong2*)d_hit_planes_out[c], dPos0 + nchr);
+    }
+    unsigned long long* hres = (unsigned long long*)((char*)ctx->pin + nchr * sizeof(BinChrom));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hres, dPos0, (size_t)(nchr + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    if (doRef) for (int c = 0; c < nchr; c++) h_pos0_out[c] = (int64_t)std::min<unsigned long long>(hres[c], (unsigned long long)h_len[c]);
+    if (h_saturated_out) *h_saturated_out = (int64_t)hres[nchr];
+    return CANVAS_OK;
+}
+
+// ---- the same packing on the host (no device involved): what a host that holds byte arrays runs before the upload; a host that fills the planes while it parses
+// the FASTA / the BAM needs neither.  `threads` <= 0: one per hardware thread (at most 32).
+static int pack_threads(int threads, int64_t words) {
+    int t = threads > 0 ? threads : (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(t, words / 4096 + 1));
+}
+int32_t canvas_pack_reference_host(const uint8_t* bases, const uint64_t* mask, int64_t len, uint64_t* ref_out, int64_t* pos0_out, int32_t threads) {
+    if (!bases || !mask || !ref_out || len <= 0) return CANVAS_ERR_INVALID;
+    const int64_t words = ((len + TILE - 1) / TILE) * 64;
+    const int nt = pack_threads(threads, words);
+    std::vector<int64_t> first((size_t)nt, len);
+    auto work = [&](int t) {
+        const int64_t w0 = words * t / nt, w1 = words * (t + 1) / nt;
+        int64_t firstNonN = len;
+        for (int64_t w = w0; w < w1; w++) {
+            const int64_t p = w << 6;
+            uint64_t m = 0, g = 0;
+            if (p < len) {
+                const int n = (int)std::min<int64_t>(64, len - p);
+                m = mask[w]; if (n < 64) m &= (~0ull) >> (64 - n);
+                for (int i = 0; i < n; i++) {
+                    const uint8_t b = bases[p + i];
+                    const uint8_t lb = b | 0x20;
+                    g |= (uint64_t)(lb == 'c' || lb == 'g') << i;
+                    if (b != 'n' && firstNonN == len) firstNonN = p + i;
+                }
+            }
+            ref_out[2 * w] = m; ref_out[2 * w + 1] = g;
+        }
+        first[t] = firstNonN;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    if (pos0_out) { int64_t p0 = len; for (int t = 0; t < nt; t++) p0 = std::min(p0, first[t]); *pos0_out = p0; }
+    return CANVAS_OK;
+}
+int32_t canvas_pack_hits_host(const uint8_t* hits, int64_t len, uint64_t* planes_out, int64_t* saturated_out, int32_t threads) {
+    if (!hits || !planes_out || len <= 0) return CANVAS_ERR_INVALID;
+    const int64_t words = ((len + TILE - 1) / TILE) * 64;
+    const int nt = pack_threads(threads, words);
+    std::vector<int64_t> sat((size_t)nt, 0);
+    auto work = [&](int t) {
+        const int64_t w0 = words * t / nt, w1 = words * (t + 1) / nt;
+        int64_t nsat = 0;
+        const __m128i fifteen = _mm_set1_epi8(15);
+        for (int64_t w = w0; w < w1; w++) {
+            const int64_t p = w << 6;
+            uint64_t b[4] = {0, 0, 0, 0};
+            if (p + 64 <= len) {
+                // 16 positions at a time: the k-th bit of every byte moved to the byte's top bit, then one movemask
+                for (int q = 0; q < 4; q++) {
+                    const __m128i v = _mm_loadu_si128((const __m128i*)(hits + p + 16 * q));
+                    const __m128i c = _mm_min_epu8(v, fifteen);
+                    nsat += __builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(c, v)) ^ 0xFFFFu);
+                    b[0] |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_slli_epi16(c, 7)) << (16 * q);
+                    b[1] |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_slli_epi16(c, 6)) << (16 * q);
+                    b[2] |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_slli_epi16(c, 5)) << (16 * q);
+                    b[3] |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_slli_epi16(c, 4)) << (16 * q);
+                }
+            } else if (p < len) {
+                for (int i = 0; p + i < len; i++) {
+                    unsigned h = hits[p + i];
+                    if (h > 15u) { h = 15u; nsat++; }
+                    for (int k = 0; k < 4; k++) b[k] |= (uint64_t)((h >> k) & 1u) << i;
+                }
+            }
+            planes_out[4 * w] = b[0]; planes_out[4 * w + 1] = b[1]; planes_out[4 * w + 2] = b[2]; planes_out[4 * w + 3] = b[3];
+        }
+        sat[t] = nsat;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    if (saturated_out) { int64_t s2 = 0; for (int t = 0; t < nt; t++) s2 += sat[t]; *saturated_out = s2; }
+    return CANVAS_OK;
 }
 
 }  // extern "C"

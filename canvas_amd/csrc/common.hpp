@@ -139,6 +139,8 @@ CVX_INTERNAL int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const 
 // canvas_hmm_per_sample on a subset of chromosomes (d_cov / h_chr_offset: the subset, contiguous) with the genome-wide quartiles taken from d_cov_all[0, n_all)
 CVX_INTERNAL int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state);
 
+// (Polling the stream with hipStreamQuery instead of blocking in hipStreamSynchronize was tried for the short waits of a pass: no gain on the pass time, and
+// hipStreamQuery reported completion early on streams that wait for another stream's event — results arrived before their kernels.  Every wait blocks.)
 // entry points that read per-base arrays without the per-chromosome overlap wait for a pending canvas_upload_genome_begin as a whole
 static inline int32_t canvas_upload_fence(canvas_ctx* ctx) {
     if (ctx->up_active) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); ctx->up_active = false; }

@@ -132,6 +132,29 @@ int32_t canvas_upload_genome_begin(canvas_ctx* ctx, int32_t nchr, const int64_t*
     ctx->up_active = true;
     return CANVAS_OK;
 }
+// the packed planes of bin_packed.hpp: 16 B (reference) + 32 B (hits) per 64 positions, whole tiles; h_ref may be NULL (reference planes already resident)
+int32_t canvas_upload_packed_begin(canvas_ctx* ctx, int32_t nchr, const int64_t* h_len, const uint64_t* const* h_ref, uint64_t* const* d_ref,
+                                   const uint64_t* const* h_hit_planes, uint64_t* const* d_hit_planes) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_len || !d_ref || !d_hit_planes) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_upload_packed_begin: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy) CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    while ((int)ctx->up_ev.size() < nchr) { hipEvent_t e; CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->up_ev.push_back(e); }
+    if (!ctx->up_fence) CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->up_fence, hipEventDisableTiming));
+    CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->up_fence, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy, ctx->up_fence, 0));
+    ctx->up_bases.assign(nchr, nullptr); ctx->up_mask.assign(nchr, nullptr); ctx->up_hits.assign(nchr, nullptr);
+    for (int c = 0; c < nchr; c++) {
+        if (h_len[c] <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_upload_packed_begin: chromosome length must be positive");
+        const size_t words = (size_t)((h_len[c] + 4095) / 4096) * 64;
+        if (h_ref && h_ref[c]) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_ref[c], h_ref[c], words * 16, hipMemcpyHostToDevice, ctx->copy));
+        if (h_hit_planes && h_hit_planes[c]) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_hit_planes[c], h_hit_planes[c], words * 32, hipMemcpyHostToDevice, ctx->copy));
+        CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->up_ev[c], ctx->copy));
+        ctx->up_bases[c] = d_ref[c]; ctx->up_mask[c] = d_ref[c]; ctx->up_hits[c] = d_hit_planes[c];
+    }
+    ctx->up_active = true;
+    return CANVAS_OK;
+}
 int32_t canvas_upload_genome_wait(canvas_ctx* ctx) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (ctx->copy) CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy));

@@ -5,18 +5,21 @@
 #include "common.hpp"
 #include <vector>
 
-extern "C" int32_t canvas_sample_pipeline(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits,
-                                          const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, int32_t counts_per_bin, int32_t bin_size_in,
-                                          int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
-                                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                                          double* d_cov, int32_t* d_state, int32_t* d_segment_id,
-                                          int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+// h_pos0 != NULL: d_bases / d_hits are the packed planes of canvas_bin_sample_packed (d_mask unused)
+static int32_t sample_pipeline_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_pos0,
+                                    const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, int32_t counts_per_bin, int32_t bin_size_in,
+                                    int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                    int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                    double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                    int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (!d_cov || !d_state || !d_segment_id || !h_chr_offset) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline: bad arguments");
     int32_t binSize = 0; int64_t total = 0, nClean = 0, nseg = 0; double lsd = -1.0; int32_t info[8];
     std::vector<int64_t> perChr((size_t)nchr);
-    int32_t rc = canvas_bin_sample(ctx, nchr, d_bases, d_mask, d_hits, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, mode, d_chr, d_start, d_stop, d_gc, d_count, cap,
-                                   &binSize, perChr.data(), &total);
+    int32_t rc = h_pos0 ? canvas_bin_sample_packed(ctx, nchr, (const uint64_t* const*)d_bases, (const uint64_t* const*)d_hits, h_len, h_pos0, h_chr_is_autosome, counts_per_bin, bin_size_in, mode,
+                                                   d_chr, d_start, d_stop, d_gc, d_count, cap, &binSize, perChr.data(), &total)
+                        : canvas_bin_sample(ctx, nchr, d_bases, d_mask, d_hits, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, mode, d_chr, d_start, d_stop, d_gc, d_count, cap,
+                                            &binSize, perChr.data(), &total);
     if (rc) return rc;
     if (h_bin_size) *h_bin_size = binSize;
     if (h_nbins) *h_nbins = total;
@@ -31,4 +34,26 @@ extern "C" int32_t canvas_sample_pipeline(canvas_ctx* ctx, int32_t nchr, const u
     rc = canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
     if (h_nsegments) *h_nsegments = nseg;
     return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_sample_pipeline(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits,
+                                          const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, int32_t counts_per_bin, int32_t bin_size_in,
+                                          int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                          int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                          double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                          int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+    return sample_pipeline_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, h_chr_is_autosome, h_chr_is_y, counts_per_bin, bin_size_in, mode, clean_flags, min_bins_per_gc,
+                                max_inter_bin_dist, d_chr, d_start, d_stop, d_gc, d_count, cap, d_cov, d_state, d_segment_id, h_bin_size, h_nbins, h_nbins_clean, h_local_sd, h_chr_offset, h_nsegments);
+}
+// the same call over the packed planes (canvas_bin_sample_packed)
+extern "C" int32_t canvas_sample_pipeline_packed(canvas_ctx* ctx, int32_t nchr, const uint64_t* const* d_ref, const uint64_t* const* d_hit_planes, const int64_t* h_len, const int64_t* h_pos0,
+                                                 const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, int32_t counts_per_bin, int32_t bin_size_in,
+                                                 int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                                 int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                                 double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                                 int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+    if (ctx && !h_pos0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline_packed: pos0 missing");
+    return sample_pipeline_impl(ctx, nchr, (const uint8_t* const*)d_ref, d_ref, (const uint8_t* const*)d_hit_planes, h_pos0, h_len, h_chr_is_autosome, h_chr_is_y, counts_per_bin, bin_size_in, mode,
+                                clean_flags, min_bins_per_gc, max_inter_bin_dist, d_chr, d_start, d_stop, d_gc, d_count, cap, d_cov, d_state, d_segment_id, h_bin_size, h_nbins, h_nbins_clean,
+                                h_local_sd, h_chr_offset, h_nsegments);
 }

@@ -15,6 +15,7 @@ CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD, CLEAN_LOESS = 1, 2,
 ABI_SYMBOLS = [
     "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h", "canvas_host_register", "canvas_host_unregister", "canvas_upload_genome_begin", "canvas_upload_genome_wait",
+    "canvas_packed_plane_bytes", "canvas_pack_reference_host", "canvas_pack_hits_host", "canvas_pack_genome_device", "canvas_upload_packed_begin", "canvas_bin_sample_packed", "canvas_sample_pipeline_packed",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
     "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
@@ -57,6 +58,9 @@ def load_library():
     lib.canvas_bin_count_upper_bound.restype = C.c_int64
     lib.canvas_bin_count_upper_bound.argtypes = [C.c_int32, C.c_void_p, C.c_int32]
     lib.canvas_bin_size_from_rates.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.canvas_packed_plane_bytes.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
+    lib.canvas_pack_reference_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.canvas_pack_hits_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
     _lib = lib
     return lib
 
@@ -68,6 +72,40 @@ def _ptr_table(tensors):
 
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def packed_plane_words(length):
+    """64-position words of the packed planes of one chromosome (whole tiles of 4096 positions): the reference planes hold 2 u64 per word, the hit planes 4"""
+    return ((int(length) + 4095) // 4096) * 64
+
+
+def _host_addr(a):
+    return C.c_void_p(a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data)
+
+
+def pack_reference_host(bases, mask, length, out=None, threads=0):
+    """canvas_pack_reference_host (plain host code, no GPU): (bases u8[len], mask u64[ceil(len/64)]) -> ({possible, gc} u64 pairs, pos0).
+    Arrays are numpy arrays or (pinned) CPU torch tensors; `out` = u64[2 * packed_plane_words(len)]"""
+    lib = load_library()
+    if out is None:
+        out = np.zeros(2 * packed_plane_words(length), np.uint64)
+    p0 = C.c_int64(0)
+    rc = lib.canvas_pack_reference_host(_host_addr(bases), _host_addr(mask), C.c_int64(int(length)), _host_addr(out), C.byref(p0), int(threads))
+    if rc:
+        raise CanvasError(f"canvas_pack_reference_host: error {rc}")
+    return out, p0.value
+
+
+def pack_hits_host(hits, length, out=None, threads=0):
+    """canvas_pack_hits_host (plain host code, no GPU): hits u8[len] -> bit-sliced 4-bit planes u64[4 * packed_plane_words(len)]; returns (planes, #saturated positions)"""
+    lib = load_library()
+    if out is None:
+        out = np.zeros(4 * packed_plane_words(length), np.uint64)
+    sat = C.c_int64(0)
+    rc = lib.canvas_pack_hits_host(_host_addr(hits), C.c_int64(int(length)), _host_addr(out), C.byref(sat), int(threads))
+    if rc:
+        raise CanvasError(f"canvas_pack_hits_host: error {rc}")
+    return out, sat.value
 
 
 class Canvas:
@@ -118,6 +156,39 @@ class Canvas:
         hl = np.ascontiguousarray(lens, np.int64)
         hp = lambda ts: None if ts is None else (C.c_void_p * n)(*[None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else t.ctypes.data) for t in ts])
         self._check(self.lib.canvas_upload_genome_begin(self.ctx, n, _np_ptr(hl), hp(h_bases), _ptr_table(d_bases), hp(h_mask), _ptr_table(d_mask), hp(h_hits), _ptr_table(d_hits)))
+
+    def upload_packed_begin(self, lens, h_ref, d_ref, h_planes, d_planes):
+        """canvas_upload_packed_begin: the packed planes, chromosome by chromosome on the copy stream (h_ref None = reference planes already resident)"""
+        n = len(d_ref)
+        hl = np.ascontiguousarray(lens, np.int64)
+        hp = lambda ts: None if ts is None else (C.c_void_p * n)(*[None if t is None else _host_addr(t) for t in ts])
+        self._check(self.lib.canvas_upload_packed_begin(self.ctx, n, _np_ptr(hl), hp(h_ref), _ptr_table(d_ref), hp(h_planes), _ptr_table(d_planes)))
+
+    def pack_genome_device(self, bases, masks, hits, lens):
+        """canvas_pack_genome_device: per-base arrays in HBM -> (ref planes, hit planes, pos0, #saturated); bases/masks or hits may be None"""
+        torch = self.torch
+        n = len(lens)
+        hl = np.ascontiguousarray(lens, np.int64)
+        ref = [torch.empty(2 * packed_plane_words(L), dtype=torch.int64, device=self.device) for L in lens] if bases is not None else None
+        planes = [torch.empty(4 * packed_plane_words(L), dtype=torch.int64, device=self.device) for L in lens] if hits is not None else None
+        pos0 = np.zeros(n, np.int64); sat = C.c_int64(0)
+        tab = lambda ts: None if ts is None else _ptr_table(ts)
+        self._check(self.lib.canvas_pack_genome_device(self.ctx, n, tab(bases), tab(masks), tab(hits), _np_ptr(hl), tab(ref), tab(planes),
+                                                       _np_ptr(pos0) if bases is not None else None, C.byref(sat)))
+        return ref, planes, (pos0 if bases is not None else None), sat.value
+
+    def bin_sample_packed(self, ref, planes, lens, pos0, is_autosome, counts_per_bin=100, bin_size=-1, mode=MODE_TDR, out=None):
+        """canvas_bin_sample over the packed planes (bit-identical outputs)"""
+        n = len(ref)
+        lens = np.ascontiguousarray(lens, np.int64); p0 = np.ascontiguousarray(pos0, np.int64)
+        ia = np.ascontiguousarray(is_autosome, np.uint8)
+        per = np.zeros(n, np.int64); total = C.c_int64(0); bs = C.c_int32(0)
+        self._check(self.lib.canvas_bin_sample_packed(self.ctx, n, _ptr_table(ref), _ptr_table(planes), _np_ptr(lens), _np_ptr(p0), _np_ptr(ia), counts_per_bin, bin_size, mode,
+                                                      C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),
+                                                      C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()), C.c_int64(out["chr"].numel()),
+                                                      C.byref(bs), _np_ptr(per), C.byref(total)))
+        self.synchronize()
+        return out, per, total.value, bs.value
 
     def upload_genome_wait(self):
         self._check(self.lib.canvas_upload_genome_wait(self.ctx))
@@ -361,27 +432,30 @@ class Canvas:
         return [out[oo[c]:oo[c + 1]].copy() for c in range(nchr)]
 
     def sample_pipeline(self, bases, masks, hits, lens, is_autosome, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=0, min_bins_per_gc=100,
-                        max_inter_bin_dist=1000000, is_y=None, prepared=None):
+                        max_inter_bin_dist=1000000, is_y=None, prepared=None, pos0=None):
         """bin_sample -> clean -> quantize_f2 -> chromosome_offsets -> hmm_per_sample -> segment_ids in ONE library call (canvas_sample_pipeline).
         Returns dict(bin_size, total, n_out, lsd, off, nseg, prepared); results are left in `out`, `cov`, `state`, `seg`.  Passing the returned `prepared` back repeats the
-        call on the SAME tensors and options without marshalling the arguments again (every other argument is then ignored)."""
-        nchr = len(bases)
+        call on the SAME tensors and options without marshalling the arguments again (every other argument is then ignored).
+        pos0 given: `bases` / `hits` are the packed reference / hit planes (canvas_sample_pipeline_packed; `masks` is ignored)."""
+        nchr = len(bases) if prepared is None else 0
         # the whole marshalled call (pointer tables, scalars, out-parameters) is cached per set of tensors: a native host keeps these arrays anyway, and per pass
         # the Python side is then one foreign call (building ~30 ctypes arguments costs ~0.1 ms, 3 % of a pass)
         if prepared is None:
             arr = lambda ts: (C.c_void_p * nchr)(*[C.c_void_p(t.data_ptr()) for t in ts])
-            pb, pm, ph = arr(bases), arr(masks), arr(hits)
+            pb, pm, ph = arr(bases), (arr(masks) if pos0 is None else None), arr(hits)
             hl = np.ascontiguousarray(lens, np.int64); ia = np.ascontiguousarray(is_autosome, np.uint8); iy = None if is_y is None else np.ascontiguousarray(is_y, np.uint8)
             bs = C.c_int32(0); total = C.c_int64(0); nclean = C.c_int64(0); lsd = C.c_double(-1.0); nseg = C.c_int64(0); off = np.zeros(nchr + 1, np.int64)
-            args = (self.ctx, nchr, pb, pm, ph, _np_ptr(hl), _np_ptr(ia), None if iy is None else _np_ptr(iy),
+            p0 = None if pos0 is None else np.ascontiguousarray(pos0, np.int64)
+            head = (self.ctx, nchr, pb, pm, ph, _np_ptr(hl)) if p0 is None else (self.ctx, nchr, pb, ph, _np_ptr(hl), _np_ptr(p0))
+            args = head + (_np_ptr(ia), None if iy is None else _np_ptr(iy),
                     int(counts_per_bin), int(bin_size), int(mode), C.c_uint32(flags), int(min_bins_per_gc), int(max_inter_bin_dist),
                     C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),
                     C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()), C.c_int64(int(out["chr"].numel())),
                     C.c_void_p(cov.data_ptr()), C.c_void_p(state.data_ptr()), C.c_void_p(seg.data_ptr()),
                     C.byref(bs), C.byref(total), C.byref(nclean), C.byref(lsd), _np_ptr(off), C.byref(nseg))
-            prepared = dict(args=args, keep=(pb, pm, ph, hl, ia, iy), outs=(bs, total, nclean, lsd, nseg, off))     # valid for exactly these tensors and options
+            prepared = dict(args=args, keep=(pb, pm, ph, hl, ia, iy, p0), outs=(bs, total, nclean, lsd, nseg, off), packed=p0 is not None)     # valid for exactly these tensors and options
         bs, total, nclean, lsd, nseg, off = prepared["outs"]
-        self._check(self.lib.canvas_sample_pipeline(*prepared["args"]))
+        self._check((self.lib.canvas_sample_pipeline_packed if prepared["packed"] else self.lib.canvas_sample_pipeline)(*prepared["args"]))
         return dict(bin_size=bs.value, total=total.value, n_out=nclean.value, lsd=lsd.value, off=off.copy(), nseg=nseg.value, prepared=prepared)
 
     def tumor_normal_flow(self, bases, masks, hits_t, fraglen_t, hits_n, lens, is_autosome, clean_flags, alpha=0.01, nperm=10000, counts_per_bin=100, is_y=None, keep=False):

@@ -65,6 +65,35 @@ int32_t canvas_upload_genome_begin(canvas_ctx* ctx, int32_t nchr, const int64_t*
                                    const uint64_t* const* h_mask, uint64_t* const* d_mask, const uint8_t* const* h_hits, uint8_t* const* d_hits);
 int32_t canvas_upload_genome_wait(canvas_ctx* ctx);
 
+/* ---- packed per-base inputs -------------------------------------------------------------------------------------
+ * The loops this library replaces read, per position, one BitArray bit (CanvasBin.cs:593), whether the base is G/C (CanvasBin.cs:599-606), whether it is 'n'
+ * (only to find the first one that is not, CanvasBin.cs:582-584) and min(10, hits) (TruncatedDynamicRange, CanvasBin.cs:618-619) or a 0/1 hit (Binary).
+ * The packed planes carry exactly that, 0.75 B/base instead of 2.125 B/base (PCIe, which bounds a whole pass, and the one full HBM sweep both shrink 2.8x):
+ *   reference planes  per 64 positions {u64 possible, u64 gc}                        16 B   (depends on the reference genome only)
+ *   hit planes        per 64 positions {u64 b0, b1, b2, b3}, bit i of b_k = bit k of min(15, hits[i])   32 B
+ *   pos0              first position whose base is not 'n' (len if there is none)
+ * Both planes cover whole tiles of 4096 positions (canvas_packed_plane_bytes) and are zero beyond len.  Results are bit-identical to the byte-array entry
+ * points in Binary and TruncatedDynamicRange modes (hits above 15 cannot occur in Binary mode and read as 10 in TruncatedDynamicRange either way; the packers
+ * report the number of saturated positions).  GCContentWeighted mode reads fragment lengths per base and stays on the byte arrays. */
+int32_t canvas_packed_plane_bytes(int64_t len, int64_t* ref_bytes, int64_t* hit_bytes);
+/* Host-side packers (plain CPU code, no device, thread-parallel; `threads` <= 0 = one per hardware thread, at most 32): what a host that holds the reference's byte
+ * arrays (CanvasBin.cs:965-969) runs once per reference / once per sample before the upload.  A host that fills the planes while parsing needs neither. */
+int32_t canvas_pack_reference_host(const uint8_t* bases, const uint64_t* mask, int64_t len, uint64_t* ref_out, int64_t* pos0_out, int32_t threads);
+int32_t canvas_pack_hits_host(const uint8_t* hits, int64_t len, uint64_t* planes_out, int64_t* saturated_out, int32_t threads);
+/* The same packing for arrays that already are in HBM.  d_bases + d_mask + d_ref_out + h_pos0_out may all be NULL (hits only: a second sample over a packed
+ * reference), or d_hits + d_hit_planes_out (reference only). */
+int32_t canvas_pack_genome_device(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
+                                  uint64_t* const* d_ref_out, uint64_t* const* d_hit_planes_out, int64_t* h_pos0_out, int64_t* h_saturated_out);
+/* canvas_upload_genome_begin for the planes (h_ref NULL or h_ref[c] NULL: already resident); the next canvas_bin_sample_packed / canvas_sample_pipeline_packed call
+ * over these destination tables sweeps chromosome c while chromosome c + 1 is in flight.  canvas_upload_genome_wait applies. */
+int32_t canvas_upload_packed_begin(canvas_ctx* ctx, int32_t nchr, const int64_t* h_len, const uint64_t* const* h_ref, uint64_t* const* d_ref,
+                                   const uint64_t* const* h_hit_planes, uint64_t* const* d_hit_planes);
+/* canvas_bin_sample (below) over the planes: same arguments otherwise, same outputs bit for bit (modes 0 and 3). */
+int32_t canvas_bin_sample_packed(canvas_ctx* ctx, int32_t nchr, const uint64_t* const* d_ref, const uint64_t* const* d_hit_planes, const int64_t* h_len, const int64_t* h_pos0,
+                                 const uint8_t* h_chr_is_autosome, int32_t counts_per_bin, int32_t bin_size_in, int32_t mode,
+                                 int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                 int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+
 /* ---- CanvasBin ----------------------------------------------------------------------------------------------- */
 /* InitializeAlignmentArrays (CanvasBin/CanvasBin.cs:183-200): possible[i] = char.IsUpper(referenceBases[i]).
  * d_mask must hold ceil(len/64) words; bits at and beyond len are written as 0. */
@@ -246,6 +275,14 @@ int32_t canvas_sample_pipeline(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
                                int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                                double* d_cov, int32_t* d_state, int32_t* d_segment_id,
                                int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments);
+
+/* canvas_sample_pipeline over the packed planes (canvas_bin_sample_packed). */
+int32_t canvas_sample_pipeline_packed(canvas_ctx* ctx, int32_t nchr, const uint64_t* const* d_ref, const uint64_t* const* d_hit_planes, const int64_t* h_len, const int64_t* h_pos0,
+                                      const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, int32_t counts_per_bin, int32_t bin_size_in,
+                                      int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                      int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                      double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                      int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments);
 
 /* ---- CanvasNormalize, ratio path (enrichment / tumour-normal workflows) -------------------------------------------------
  * canvas_normalize_reference = WeightedAverageReferenceGenerator.Run for more than one control sample (WeightedAverageReferenceGenerator.cs:

@@ -175,7 +175,8 @@ def test_bin_gc_content_weighted_mode(bin_path):
         o, per, total, bsz = cv.bin_sample_gcweighted(bases, masks, hits, dfl, lens, [1, 1], 100, bs, out=out)
         assert total == sum(len(e[0]) for e in exp)
         assert (out["stop"][:total].cpu().numpy() == np.concatenate([e[1] for e in exp])).all()
-        assert (out["gc"][:total].cpu().numpy() == np.concatenate([e[2] for e in exp])).all()
+        ggot = out["gc"][:total].cpu().numpy(); gex = np.concatenate([e[2] for e in exp])
+        assert (ggot == gex).all(), (bs, np.nonzero(ggot != gex)[0][:8], ggot[ggot != gex][:8], gex[ggot != gex][:8], out["start"][:total].cpu().numpy()[ggot != gex][:8])
         got = out["count"][:total].cpu().numpy(); ex = np.concatenate([e[3] for e in exp]).astype(np.float32)
         assert (got == ex).all(), (np.nonzero(got != ex)[0][:5], got[got != ex][:5], ex[got != ex][:5])
 

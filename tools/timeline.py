@@ -9,7 +9,7 @@ min_gap = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 rows = [(n.split("(")[0].replace("void ", ""), s, e) for n, s, e in rows]
 # a pass starts at k_find_pos0 / k_tile_stats (first kernel of canvas_bin_sample)
-starts = [i for i, r in enumerate(rows) if r[0].startswith("k_tile_stats") or r[0].startswith("k_tile_summary<") or r[0] == "k_tile_summary"]
+starts = [i for i, r in enumerate(rows) if r[0].startswith("k_tile_stats") or r[0].startswith("k_tile_summary<") or r[0] in ("k_tile_summary", "k_tile_summary_packed")]
 if len(starts) < 2:
     sys.exit("no passes found")
 a, b = starts[-2], starts[-1]
