@@ -16,6 +16,7 @@
 // host and weighted there (a per-file O(hundreds) computation next to the thresholds above).
 // Not built (returns CANVAS_ERR_UNSUPPORTED): manifests (-t).
 #include "common.hpp"
+#include <chrono>
 #include "select.hpp"
 #include "loess.hpp"
 #include <algorithm>
@@ -1026,6 +1027,20 @@ extern "C" int32_t canvas_clean_batch(canvas_ctx* ctx, int32_t nsamples, const i
         }
         for (auto& t : th) t.join();
         for (int s = 0; s < nsamples; s++) if (rcs[s] && rcAll == CANVAS_OK) { ctx->err = ctx->children[s]->err; rcAll = rcs[s]; enq[s] = 0; }
+        // Wait for ALL the chains before the first per-sample wait: one event per chain, polled round-robin, so that the per-sample waits below find idle streams.
+        // (What bounds a cohort is the host: ~80 launches per sample.  B = 8 takes 4.6 ms on one box and 9 ms on another whose cores are slower, for ~4.5 ms of device work.)
+        std::vector<char> pending(nsamples, 0); int npend = 0;
+        for (int s = 0; s < nsamples; s++) {
+            if (!enq[s]) continue;
+            canvas_ctx* ch = ctx->children[s];
+            if (!ch->batch_ev && hipEventCreateWithFlags(&ch->batch_ev, hipEventDisableTiming) != hipSuccess) continue;
+            if (hipEventRecord(ch->batch_ev, ch->stream) == hipSuccess) { pending[s] = 1; npend++; }
+        }
+        const auto tPoll = std::chrono::steady_clock::now();
+        while (npend > 0) {
+            for (int s = 0; s < nsamples; s++) if (pending[s] && hipEventQuery(ctx->children[s]->batch_ev) != hipErrorNotReady) { pending[s] = 0; npend--; }
+            if (std::chrono::steady_clock::now() - tPoll > std::chrono::milliseconds(200)) break;      // the blocking waits below take over
+        }
     }
     for (int s = 0; s < nsamples; s++) {
         canvas_ctx* ch = ctx->children[s];

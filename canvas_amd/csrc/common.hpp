@@ -22,7 +22,7 @@ struct canvas_ctx {
     size_t pin_bytes = 0;
     // side stream for work that is off the critical path (per-chromosome MAD of CanvasClean), its fork event and a pinned result buffer
     hipStream_t side = nullptr;
-    hipEvent_t side_ev = nullptr, side_ev2 = nullptr;
+    hipEvent_t side_ev = nullptr, side_ev2 = nullptr, batch_ev = nullptr;
     double* side_pin = nullptr;        // 65536 results + 65544 int64 run starts
     // persistent scratch of the radix select (select.hpp): device blob and pinned staging blob
     void* sel_ws = nullptr; size_t sel_ws_bytes = 0;

@@ -377,7 +377,22 @@ int main(int argc, char** argv) {
     if (nchr == 0) { fprintf(stderr, "CanvasBin: no chromosome to bin\n"); return 1; }
     std::vector<std::unique_ptr<Dev>> devs;
     std::vector<const uint8_t*> pBases(nchr), pHits(nchr); std::vector<const uint64_t*> pMask(nchr); std::vector<const int16_t*> pFrag(nchr); std::vector<int64_t> len(nchr); std::vector<uint8_t> isAuto(nchr);
-    for (int c = 0; c < nchr; c++) {
+    // Binary / TruncatedDynamicRange binning goes over the packed planes (include/canvas_hip.h, "packed per-base inputs"): packed on the host threads, 0.75 B/base over
+    // PCIe instead of 2.125 B/base, same bins.  CANVAS_BIN_BYTE_ARRAYS=1 keeps the byte arrays (-n, -y and GCContentWeighted always use them).
+    const bool usePacked = mode != CANVAS_MODE_GC_CONTENT_WEIGHTED && !a.has("bins") && !a.has("binsizeonly") && !getenv("CANVAS_BIN_BYTE_ARRAYS");
+    std::vector<const uint64_t*> pRef(nchr), pPlanes(nchr); std::vector<int64_t> pos0(nchr);
+    for (int c = 0; usePacked && c < nchr; c++) {
+        const int64_t L = data[c]->len; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
+        int64_t refBytes = 0, hitBytes = 0, sat = 0;
+        if (canvas_packed_plane_bytes(L, &refBytes, &hitBytes) != 0) { fprintf(stderr, "CanvasBin: bad chromosome length\n"); return 1; }
+        std::vector<uint64_t> ref((size_t)refBytes / 8), planes((size_t)hitBytes / 8);
+        if (canvas_pack_reference_host((const uint8_t*)order[c]->bases.data(), data[c]->maskWords.data(), L, ref.data(), &pos0[c], 0) != 0 ||
+            canvas_pack_hits_host(data[c]->hits.data(), L, planes.data(), &sat, 0) != 0) { fprintf(stderr, "CanvasBin: packing %s failed\n", order[c]->name.c_str()); return 1; }
+        devs.push_back(std::make_unique<Dev>(ctx, refBytes)); pRef[c] = (const uint64_t*)devs.back()->p;
+        devs.push_back(std::make_unique<Dev>(ctx, hitBytes)); pPlanes[c] = (const uint64_t*)devs.back()->p;
+        if (canvas_memcpy_h2d(ctx, (void*)pRef[c], ref.data(), refBytes) != 0 || canvas_memcpy_h2d(ctx, (void*)pPlanes[c], planes.data(), hitBytes) != 0) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
+    }
+    for (int c = 0; !usePacked && c < nchr; c++) {
         const int64_t L = data[c]->len, words = (L + 63) / 64; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
         auto up = [&](const void* src, int64_t bytes, int64_t alloc) -> void* { devs.push_back(std::make_unique<Dev>(ctx, alloc)); void* p = devs.back()->p; if (bytes > 0 && canvas_memcpy_h2d(ctx, p, src, bytes) != 0) return nullptr; return p; };
         pBases[c] = (const uint8_t*)up(order[c]->bases.data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits.data(), L, L + 64); pMask[c] = (const uint64_t*)up(data[c]->maskWords.data(), words * 8, words * 8 + 64);
@@ -405,7 +420,7 @@ int main(int argc, char** argv) {
         printf("Output complete\n");
         return 0;
     }
-    if (a.has("binsizeonly") || binSize == -1) {
+    if (!usePacked && (a.has("binsizeonly") || binSize == -1)) {
         // CalculateSingleSampleBinSize: autosomes only (CanvasBin.cs:30-83)
         std::vector<int64_t> obs(nchr), poss(nchr); std::vector<double> rate(nchr), rates;
         TOOL_TRY(ctx, canvas_bin_rates(ctx, nchr, pHits.data(), pMask.data(), len.data(), obs.data(), poss.data(), rate.data()));
@@ -413,13 +428,20 @@ int main(int argc, char** argv) {
         if (binSize == -1) { if (rates.empty()) { fprintf(stderr, "CanvasBin: no autosome to derive the bin size from\n"); return 1; } binSize = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), countsPerBin); }
     }
     if (a.has("binsizeonly")) { FILE* f = fopen((out + ".binsize").c_str(), "wb"); if (!f) return 1; fprintf(f, "%d", binSize); fclose(f); return 0; }   // :926-928, no newline
-    if (binSize <= 0) { fprintf(stderr, "CanvasBin: bin size %d is not positive\n", binSize); return 1; }
-    const int64_t cap = canvas_bin_count_upper_bound(nchr, len.data(), binSize);
+    if (binSize <= 0 && !(usePacked && binSize == -1)) { fprintf(stderr, "CanvasBin: bin size %d is not positive\n", binSize); return 1; }
+    // the packed call derives the bin size from the rates itself (CalculateSingleSampleBinSize, CanvasBin.cs:30-83): the capacity then is the number of positions / 1
+    int64_t cap = 0;
+    if (binSize > 0) cap = canvas_bin_count_upper_bound(nchr, len.data(), binSize);
+    else { for (int c = 0; c < nchr; c++) cap += len[c] / 16 + 1; }                    // a bin holds countsPerBin / rate possible positions; rates above 100/16 hits per position do not occur
+
     Dev dChr(ctx, cap * 4 + 4), dStart(ctx, cap * 4 + 4), dStop(ctx, cap * 4 + 4), dGc(ctx, cap * 4 + 4), dCount(ctx, cap * 4 + 4);
     std::vector<int64_t> perChr(nchr); int64_t total = 0; int32_t used = 0;
     if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED)
         TOOL_TRY(ctx, canvas_bin_sample_gcweighted(ctx, nchr, pBases.data(), pMask.data(), pHits.data(), pFrag.data(), len.data(), isAuto.data(), countsPerBin, binSize,
                                                    dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total));
+    else if (usePacked)
+        TOOL_TRY(ctx, canvas_bin_sample_packed(ctx, nchr, pRef.data(), pPlanes.data(), len.data(), pos0.data(), isAuto.data(), countsPerBin, binSize, mode,
+                                               dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total));
     else
         TOOL_TRY(ctx, canvas_bin_sample(ctx, nchr, pBases.data(), pMask.data(), pHits.data(), len.data(), isAuto.data(), countsPerBin, binSize, mode,
                                         dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total));

@@ -16,6 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "canvas_amd", "bin", "CanvasBin")
 
 
+@pytest.fixture(autouse=True, params=["packed_planes", "byte_arrays"])
+def input_format(request, monkeypatch):
+    """The executable bins Binary / TruncatedDynamicRange over the packed planes by default; CANVAS_BIN_BYTE_ARRAYS=1 keeps the byte arrays.  Both must write the same files."""
+    if request.param == "byte_arrays":
+        monkeypatch.setenv("CANVAS_BIN_BYTE_ARRAYS", "1")
+    else:
+        monkeypatch.delenv("CANVAS_BIN_BYTE_ARRAYS", raising=False)
+    return request.param
+
+
 def _bgzf_block(data):
     co = zlib.compressobj(6, zlib.DEFLATED, -15)
     c = co.compress(data) + co.flush()

@@ -19,7 +19,7 @@ def load(path):
 
 
 F, W = load(fetch_csv), load(write_csv)
-stream16 = {"k_bin_pass", "k_tile_stats", "k_tile_summary"}     # kernels whose reads are 16 B/lane coalesced streams
+stream16 = {"k_bin_pass", "k_tile_stats", "k_tile_summary", "k_tile_summary_packed"}     # kernels whose reads are 16 B/lane coalesced streams
 rows = []
 for k in sorted(set(F) | set(W), key=lambda k: -(sum(F.get(k, [0])) + sum(W.get(k, [0])))):
     f = sum(F.get(k, [0])) / max(1, len(F.get(k, [1]))) * 1024.0

@@ -40,7 +40,23 @@ while time.time() - t0 < budget:
         assert list(r) == rr, (seed, lengths)
         bs = cv.bin_size_from_rates(r, 100); assert bs == O.bin_size(rr, 100)
         if bs <= 0: continue
-    out, per, total = cv.bin_genome(bases, masks, hits, lens, bs, mode)
+    if mode == 0:                 # Binary mode: the hit array holds 0 / 1 (CanvasBin.cs:259-262)
+        data = [(b, np.minimum(h, 1), m) for b, h, m in data]; hits = [dev(pad(h)) for b, h, m in data]
+    if rng.rand() < 0.4:          # the packed planes (host packer for the reference planes, device packer for the hit planes, or the other way round)
+        from canvas_amd.lib import pack_reference_host, pack_hits_host
+        path = "packed"; npath[path] = npath.get(path, 0) + 1
+        if rng.rand() < 0.5:
+            dref, dpl, pos0, _ = cv.pack_genome_device(bases, masks, hits, lens)
+        else:
+            hr = [pack_reference_host(np.ascontiguousarray(b), np.ascontiguousarray(m).view(np.uint64), len(b), threads=int(rng.choice([1, 4]))) for b, h, m in data]
+            dref = [dev(r.view(np.int64)) for r, _ in hr]; pos0 = np.array([p for _, p in hr], np.int64)
+            dpl = [dev(pack_hits_host(np.ascontiguousarray(h), len(h))[0].view(np.int64)) for b, h, m in data]
+        cap = int(sum(lengths) // bs) + 8
+        mk = lambda dt: torch.empty(cap, dtype=dt, device=cv.device)
+        out = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+        out, per, total, _ = cv.bin_sample_packed(dref, dpl, lens, pos0, [1] * nchr, 100, bs, mode, out=out)
+    else:
+        out, per, total = cv.bin_genome(bases, masks, hits, lens, bs, mode)
     cv.synchronize()
     exp = [O.bin_chromosome(b, m, h, bs, mode) for b, h, m in data]
     assert total == sum(len(e[0]) for e in exp), (seed, lengths, bs, mode, total, path)
