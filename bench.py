@@ -394,10 +394,17 @@ def packed_region(args, cv, torch, host, bases, masks, hits, lens, is_auto, flag
     ntiles = sum((int(L) + 4095) // 4096 for L in lens)
     alg = 48.0 * ntiles * 64 + 4.0 * ntiles * 64 + 16.0 * ntiles             # planes read, summaries + tile totals written
     avg_ms = ms_k / max(1, k_k)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_tile_summary_packed.json")
+    if os.path.exists(pmc):
+        pj = json.load(open(pmc))
+        if abs(pj["workload"]["scale"] - args.scale) < 1e-9 and abs(pj["workload"]["rate"] - args.rate) < 1e-9:
+            traffic = pj["hbm_bytes_per_launch"]
     res = {"value": round(int(r["total"]) / t_res, 1), "ms_per_step": round(t_res * 1e3, 3), "steps": args.steps, "identical_to_byte_array_path": same,
            "input_bytes_per_base": 0.75, "saturated_hit_positions": int(sat),
            "roofline": {"kernel": "k_tile_summary_packed", "bound": "hbm", "achieved": round(alg / max(1e-9, avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(alg / max(1e-9, avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_ms": round(avg_ms, 4), "launches": k_k, "algorithmic_bytes": alg,
+                        "frac": round(alg / max(1e-9, avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(avg_ms, 4), "launches": k_k, "algorithmic_bytes": alg,
+                        "traffic_source": "profiles/pmc_tile_summary_packed.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" if traffic else None,
                         "note": "48 B read per 64 positions (0.75 B/base) + 4 B summary per 64 positions + 16 B per tile written; the byte-array sweep moves 6.77 GB for the same result"},
            "note": "same pass, same results; inputs = reference planes {possible, gc} (16 B / 64 positions, per reference genome) + hit planes (bit-sliced min(15, hits), 32 B / 64 positions)"}
     if host is not None and not args.no_h2d:

@@ -47,7 +47,7 @@ namespace CanvasBin
                 if (parameters.coverageMode == CanvasCoverageMode.GCContentWeighted)
                     Check(ctx, canvas_bin_sample_gcweighted(ctx, nchr, dBases, dMask, dHits, dFrag, len, isAutosome, parameters.countsPerBin, parameters.binSize,
                                                             cols[0].Ptr, cols[1].Ptr, cols[2].Ptr, cols[3].Ptr, cols[4].Ptr, cap, out binSizeUsed, perChr, out total), "canvas_bin_sample_gcweighted");
-                else
+                else    // (Binary / TruncatedDynamicRange can also go over the packed planes, 2.8x fewer bytes over PCIe: canvas_pack_*_host + canvas_bin_sample_packed, INTEGRATION.md 5b)
                     Check(ctx, canvas_bin_sample(ctx, nchr, dBases, dMask, dHits, len, isAutosome, parameters.countsPerBin, parameters.binSize, (int)parameters.coverageMode,
                                                  cols[0].Ptr, cols[1].Ptr, cols[2].Ptr, cols[3].Ptr, cols[4].Ptr, cap, out binSizeUsed, perChr, out total), "canvas_bin_sample");
                 int[] chrIdx = new int[total], start = new int[total], stop = new int[total], gc = new int[total]; float[] count = new float[total];

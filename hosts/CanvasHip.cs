@@ -42,6 +42,14 @@ namespace CanvasHipInterop
         [DllImport(Lib)] public static extern int canvas_bin_sample_gcweighted(IntPtr ctx, int nchr, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, IntPtr[] dFragLen, long[] len,
             byte[] chrIsAutosome, int countsPerBin, int binSizeIn, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, long[] nbinsPerChr, out long nbinsTotal);
 
+        // ---- packed per-base inputs (INTEGRATION.md 5b): 0.75 B/base over PCIe instead of 2.125 B/base, same bins
+        [DllImport(Lib)] public static extern int canvas_packed_plane_bytes(long len, out long refBytes, out long hitBytes);
+        [DllImport(Lib)] public static extern int canvas_pack_reference_host(byte[] bases, ulong[] mask, long len, IntPtr refOut, out long pos0, int threads);
+        [DllImport(Lib)] public static extern int canvas_pack_hits_host(byte[] hits, long len, IntPtr planesOut, out long saturated, int threads);
+        [DllImport(Lib)] public static extern int canvas_upload_packed_begin(IntPtr ctx, int nchr, long[] len, IntPtr[] hRef, IntPtr[] dRef, IntPtr[] hPlanes, IntPtr[] dPlanes);
+        [DllImport(Lib)] public static extern int canvas_bin_sample_packed(IntPtr ctx, int nchr, IntPtr[] dRef, IntPtr[] dPlanes, long[] len, long[] pos0, byte[] chrIsAutosome,
+            int countsPerBin, int binSizeIn, int mode, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, long[] nbinsPerChr, out long nbinsTotal);
+
         // ---- CanvasClean
         [DllImport(Lib)] public static extern int canvas_clean2(IntPtr ctx, long n, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dCount, IntPtr dGc, int nchr,
             byte[] chrIsAutosome, byte[] chrIsY, uint flags, int minBinsPerGc, out double localSd, out long nOut, int[] info8);
