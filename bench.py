@@ -61,12 +61,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_sharded = bool(os.environ.get("CANVAS_BENCH_FORCE_SHARDED")) and "RANK" in os.environ      # test hook: the N > 1 code path on a one-rank communicator
+    if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     cv = Canvas(local_rank)
     cv.profile_enable(True)
-    if world > 1:
+    if world > 1 or force_sharded:
         from canvas_amd import parallel
         parallel.init_library_comm(cv, rank, world)
         if args.multi == "sharded":
@@ -407,6 +408,42 @@ def packed_region(args, cv, torch, host, bases, masks, hits, lens, is_auto, flag
                         "traffic_source": "profiles/pmc_tile_summary_packed.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" if traffic else None,
                         "note": "48 B read per 64 positions (0.75 B/base) + 4 B summary per 64 positions + 16 B per tile written; the byte-array sweep moves 6.77 GB for the same result"},
            "note": "same pass, same results; inputs = reference planes {possible, gc} (16 B / 64 positions, per reference genome) + hit planes (bit-sliced min(15, hits), 32 B / 64 positions)"}
+    # several samples of a cohort in flight on ONE GPU (one context + host thread per sample over the same resident reference planes): the latency-bound stages of
+    # one sample fill the gaps of another's
+    import threading
+    from canvas_amd import Canvas
+    S = 4
+    ctxs, preps, bufs = [], [], []
+    for i in range(S):
+        c2 = Canvas(cv.device.index)
+        mk = lambda dt: torch.empty(out["chr"].numel(), dtype=dt, device=cv.device)
+        o2 = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+        b2 = (o2, mk(torch.float64), mk(torch.int32), mk(torch.int32))
+        r2 = c2.sample_pipeline(dref, None, dpl, lens, is_auto, b2[0], b2[1], b2[2], b2[3], **kw)
+        c2.synchronize()
+        ctxs.append(c2); preps.append(r2["prepared"]); bufs.append(b2)
+
+    def run(i, k):
+        for _ in range(k):
+            ctxs[i].sample_pipeline(None, None, None, None, None, None, None, None, None, prepared=preps[i])
+        ctxs[i].synchronize()
+
+    k_each = max(3, args.steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=run, args=(i, k_each)) for i in range(S)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    t_fl = (time.perf_counter() - t0) / (S * k_each)
+    same_fl = bool(all(torch.equal(b[3][:n], keep["seg"][:n]) and torch.equal(b[0]["count"][:n], keep["cleaned"]["count"][:n]) for b in bufs))
+    res["samples_in_flight"] = {"samples": S, "passes_each": k_each, "ms_per_sample": round(t_fl * 1e3, 3), "value": round(int(r["total"]) / t_fl, 1), "identical_results": same_fl,
+                                "note": "cohort on one GPU: S contexts, one host thread each, same resident reference planes, each sample's own hit planes would differ in production"}
+    for c2 in ctxs:
+        c2.close()
+    ctxs = preps = bufs = None
     if host is not None and not args.no_h2d:
         cores = min(os.cpu_count() or 1, 24)
         href = [torch.empty(2 * packed_plane_words(L), dtype=torch.int64, pin_memory=True) for L in lens]

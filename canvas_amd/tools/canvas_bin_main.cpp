@@ -283,7 +283,14 @@ int main(int argc, char** argv) {
     if (bam.empty() || !file_exists(bam)) { printf("CanvasBin.exe: Alignment input does not exist! Exiting.\n"); return 1; }       // also required in -i mode (:148-153)
     if (!filter.empty() && !file_exists(filter)) { printf("CanvasBin.exe: File %s does not exist! Exiting.\n", filter.c_str()); return 1; }
     if (mode != -2 && countsPerBin < 1) { printf("CanvasBin.exe: Median counts must be strictly positive. Exiting.\n"); return 1; }
-    if (a.has("manifest") || a.has("injson")) { fprintf(stderr, "CanvasBin (MI355X): -t / -j are not built\n"); return 1; }
+    if (a.has("injson") && !file_exists(a.get("injson"))) { printf("CanvasBin.exe: File %s does not exist! Exiting.\n", a.get("injson").c_str()); return 1; }      // Program.cs:163-167
+    if (a.has("manifest")) { fprintf(stderr, "CanvasBin (MI355X): -t is not built (the Nextera manifest parser is outside the reference tree)\n"); return 1; }
+    if (a.has("injson")) {
+        // CanvasBin.Run (CanvasBin.cs:949-963): -i together with -j throws; -j alone calls RunMultiSample, which hands CalculateMultiSampleBins an EMPTY list of
+        // samples (CanvasBin.cs:936-944: the json file is never read in this version of the reference) — nothing is binned, nothing is written, exit code 0
+        if (!inters.empty()) { fprintf(stderr, "Unhandled exception: System.ArgumentException: -i/--infile or -j/--injson are mutually exclusive arguments\n"); return 1; }
+        return 0;
+    }
     std::map<std::string, std::vector<PreBin>> predefined; std::vector<std::string> predefinedOrder;
     if (a.has("bins")) { std::string perr; if (!load_predefined_bins(a.get("bins"), predefined, predefinedOrder, perr)) { fprintf(stderr, "CanvasBin: %s\n", perr.c_str()); return 1; } }
     if (mode == -2) {

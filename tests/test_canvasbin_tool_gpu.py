@@ -305,6 +305,12 @@ def test_canvasbin_bam_to_binned(tmp_path):
     assert subprocess.run([BIN, "-b", bam, "-r", fa2, "-o", str(tmp_path / "x.binned"), "-d", "100", "-i", bad], capture_output=True).returncode == 1
     # error conventions (Program.cs:108-170)
     assert subprocess.run([BIN], capture_output=True).returncode == 1
+    # -j: the reference's RunMultiSample works on an empty sample list (CanvasBin.cs:936-944): exit 0, nothing written; missing file / -i together with -j: exit 1
+    js = str(tmp_path / "samples.json"); open(js, "w").write("{}")
+    r = subprocess.run([BIN, "-b", bam, "-r", fa, "-o", str(tmp_path / "multi.binned"), "-d", "100", "-j", js], capture_output=True)
+    assert r.returncode == 0 and not os.path.exists(str(tmp_path / "multi.binned"))
+    assert subprocess.run([BIN, "-b", bam, "-r", fa, "-o", str(tmp_path / "multi.binned"), "-d", "100", "-j", str(tmp_path / "absent.json")], capture_output=True).returncode == 1
+    assert subprocess.run([BIN, "-b", bam, "-r", fa, "-o", str(tmp_path / "multi.binned"), "-d", "100", "-j", js, "-i", bad], capture_output=True).returncode == 1
     assert subprocess.run([BIN, "-b", str(tmp_path / "none.bam"), "-r", fa, "-c", "chr1", "-o", str(tmp_path / "x.dat"), "-d", "100"], capture_output=True).returncode == 1
     assert subprocess.run([BIN, "-b", bam, "-r", fa, "-c", "chr1", "-o", str(tmp_path / "x.dat"), "-d", "0"], capture_output=True).returncode == 1
 
