@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) k_apply_var(float* __restrict__ count, co
 // ---------------------------------------------------------------- local SD (CanvasClean.cs:268-298)
 // one thread per window of 20 consecutive count differences; sequential double arithmetic exactly as
 // Utilities.StandardDeviation(double[], start, end) (Utilities.cs:246-262)
-__global__ void __launch_bounds__(256) k_local_sd(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev, const unsigned long long* __restrict__ dN = nullptr) {
+__device__ __forceinline__ void local_sd_body(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev, const unsigned long long* __restrict__ dN) {
     int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (dN) { const int64_t D = (int64_t)*dN - 1; nW = D >= 1 ? (D - 1) / 20 : 0; }      // the bin count is still on the device: grid = upper bound
     if (w >= nW) return;
@@ -214,6 +214,9 @@ __global__ void __launch_bounds__(256) k_local_sd(const float* __restrict__ coun
     sd[w] = v;
 #pragma unroll
     for (int k = 0; k < 20; k++) dev[s + k] = v;
+}
+__global__ void __launch_bounds__(256) k_local_sd(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev, const unsigned long long* __restrict__ dN = nullptr) {
+    local_sd_body(count, nW, sd, dev, dN);
 }
 __global__ void __launch_bounds__(256) k_copy_soa(Soa src, Soa dst, int64_t n) {     // the five caller-visible columns in one launch
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -253,7 +256,7 @@ __global__ void __launch_bounds__(256) k_run_bounds(const int32_t* __restrict__ 
 }
 
 // Utilities.Mad per chromosome run of the window SDs (CanvasClean.cs:243-258, Utilities.cs Median/Mad): one workgroup per run
-__global__ void __launch_bounds__(1024) k_run_mad(const double* __restrict__ sd, const int64_t* __restrict__ runStart, double* __restrict__ outMad, const int* __restrict__ nrunsDev = nullptr) {
+__device__ __forceinline__ void run_mad_body(const double* __restrict__ sd, const int64_t* __restrict__ runStart, double* __restrict__ outMad, const int* __restrict__ nrunsDev) {
     __shared__ uint32_t sH[2][256];
     __shared__ unsigned long long sPre[2], sK[2];
     if (nrunsDev && (int)blockIdx.x >= *nrunsDev) return;         // device-built run table: the grid is an upper bound
@@ -265,6 +268,9 @@ __global__ void __launch_bounds__(1024) k_run_mad(const double* __restrict__ sd,
     __syncthreads();
     wg_select2([&](int64_t i) { return key_of_double(fabs(sd[i] - median)); }, lo, hi, r0, r1, sH, sPre, sK);
     if (threadIdx.x == 0) outMad[blockIdx.x] = (cnt % 2) ? double_of_key(sPre[1]) : (double_of_key(sPre[0]) + double_of_key(sPre[1])) / 2;
+}
+__global__ void __launch_bounds__(1024) k_run_mad(const double* __restrict__ sd, const int64_t* __restrict__ runStart, double* __restrict__ outMad, const int* __restrict__ nrunsDev = nullptr) {
+    run_mad_body(sd, runStart, outMad, nrunsDev);
 }
 
 // ---------------------------------------------------------------- host helpers (scalar logic of the reference)
@@ -999,57 +1005,43 @@ extern "C" int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_c
     return CANVAS_OK;
 }
 
-// A cohort through CanvasClean in one call: every sample on a stream of its own (child contexts with their own workspaces), all of them enqueued before the first
-// synchronisation.  The single-sample stage is a chain of ~60 launches on 134 MB that sit in the Infinity Cache, bound by launch latency and one-workgroup decision
-// kernels; with B samples in flight the chains overlap and the working set (B x 134 MB) streams from HBM: this is the mode in which the stage's HBM roofline fraction
-// means something (hard part 3).  Results per sample are exactly those of canvas_clean2.
+// A cohort through CanvasClean in one call.  The single-sample stage is a chain of ~55 launches on 134 MB that sit in the Infinity Cache, bound by launch latency and one-workgroup
+// decision kernels.  The device-driven path is batch-native (clean_fast.hpp): the B samples share every launch (grid.y = B), so the chain is paid once per cohort and the
+// working set (B x 134 MB) streams from HBM — the mode in which the stage's HBM roofline fraction means something (hard part 3).  Results per sample are exactly
+// those of canvas_clean2.  (Round 2 first ran every sample on a stream and a context of its own: 0.57-1.1 ms per sample, bound by the host's ~80 launches per sample.)
 extern "C" int32_t canvas_clean_batch(canvas_ctx* ctx, int32_t nsamples, const int64_t* h_n, int32_t* const* h_d_chr, int32_t* const* h_d_start, int32_t* const* h_d_stop, float* const* h_d_count,
                                       int32_t* const* h_d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc,
                                       double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nsamples <= 0 || nsamples > 64 || !h_n || !h_d_chr || !h_d_start || !h_d_stop || !h_d_count || !h_d_gc || !h_chr_is_autosome || !h_n_out) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean_batch: bad arguments (1..64 samples)");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                      // the children start after whatever the parent stream still has queued
-    while ((int)ctx->children.size() < nsamples) { canvas_ctx* ch = canvas_create(ctx->device); if (!ch) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_clean_batch: cannot create a stream"); ctx->children.push_back(ch); }
     const bool fast = !(flags & CANVAS_CLEAN_LOESS) && min_bins_per_gc >= 100 && !getenv("CANVAS_CLEAN_HOST_DRIVEN");
-    std::vector<char> enq(nsamples, 0);
     int32_t rcAll = CANVAS_OK;
+    std::vector<char> done(nsamples, 0);
     if (fast) {
-        // one host thread per sample enqueues that sample's ~80 launches: the enqueue cost (not the device) is what bounds a cohort when a single thread does it
-        std::vector<int32_t> rcs(nsamples, CANVAS_OK);
-        std::vector<std::thread> th;
-        for (int s = 0; s < nsamples; s++) {
-            canvas_ctx* ch = ctx->children[s]; ch->prof = false;
-            if (h_n[s] <= 0 || h_n[s] >= 0x7FFFFFFFll || nchr <= 0) continue;
-            enq[s] = 1;
-            th.emplace_back([&, s, ch]() { (void)hipSetDevice(ctx->device);
-                rcs[s] = clean_device_driven_enqueue(ch, h_n[s], h_d_chr[s], h_d_start[s], h_d_stop[s], h_d_count[s], h_d_gc[s], nchr, h_chr_is_autosome, flags, min_bins_per_gc); });
-        }
-        for (auto& t : th) t.join();
-        for (int s = 0; s < nsamples; s++) if (rcs[s] && rcAll == CANVAS_OK) { ctx->err = ctx->children[s]->err; rcAll = rcs[s]; enq[s] = 0; }
-        // Wait for ALL the chains before the first per-sample wait: one event per chain, polled round-robin, so that the per-sample waits below find idle streams.
-        // (What bounds a cohort is the host: ~80 launches per sample.  B = 8 takes 4.6 ms on one box and 9 ms on another whose cores are slower, for ~4.5 ms of device work.)
-        std::vector<char> pending(nsamples, 0); int npend = 0;
-        for (int s = 0; s < nsamples; s++) {
-            if (!enq[s]) continue;
-            canvas_ctx* ch = ctx->children[s];
-            if (!ch->batch_ev && hipEventCreateWithFlags(&ch->batch_ev, hipEventDisableTiming) != hipSuccess) continue;
-            if (hipEventRecord(ch->batch_ev, ch->stream) == hipSuccess) { pending[s] = 1; npend++; }
-        }
-        const auto tPoll = std::chrono::steady_clock::now();
-        while (npend > 0) {
-            for (int s = 0; s < nsamples; s++) if (pending[s] && hipEventQuery(ctx->children[s]->batch_ev) != hipErrorNotReady) { pending[s] = 0; npend--; }
-            if (std::chrono::steady_clock::now() - tPoll > std::chrono::milliseconds(200)) break;      // the blocking waits below take over
+        // the samples the device-driven path takes form ONE batch: every kernel of the stage runs once with grid.y = the number of samples (clean_fast.hpp)
+        std::vector<int> idx;
+        for (int s = 0; s < nsamples; s++) if (h_n[s] > 0 && h_n[s] < 0x7FFFFFFFll) idx.push_back(s);
+        if (!idx.empty()) {
+            const int B = (int)idx.size();
+            std::vector<int64_t> n(B), nOut(B, 0); std::vector<int32_t*> c(B), st(B), sp(B), g(B); std::vector<float*> cnt(B);
+            std::vector<double> lsd(B, -1.0); std::vector<int32_t> info((size_t)8 * B, 0); std::vector<char> handled(B, 0);
+            for (int k = 0; k < B; k++) { const int s = idx[k]; n[k] = h_n[s]; c[k] = h_d_chr[s]; st[k] = h_d_start[s]; sp[k] = h_d_stop[s]; g[k] = h_d_gc[s]; cnt[k] = h_d_count[s]; }
+            int32_t rc = clean_batch_enqueue(ctx, B, n.data(), c.data(), st.data(), sp.data(), cnt.data(), g.data(), nchr, h_chr_is_autosome, flags, min_bins_per_gc);
+            if (rc == CANVAS_OK) rc = clean_batch_finish(ctx, lsd.data(), nOut.data(), info.data(), handled.data());
+            if (rc) return rc;
+            for (int k = 0; k < B; k++) if (handled[k]) {
+                const int s = idx[k]; done[s] = 1; h_n_out[s] = nOut[k];
+                if (h_local_sd_out) h_local_sd_out[s] = lsd[k];
+                if (h_info) memcpy(h_info + 8 * s, info.data() + 8 * k, 8 * sizeof(int32_t));
+            }
         }
     }
     for (int s = 0; s < nsamples; s++) {
-        canvas_ctx* ch = ctx->children[s];
-        bool handled = false; int32_t rc = CANVAS_OK;
-        if (enq[s]) rc = clean_device_driven_finish(ch, h_local_sd_out ? h_local_sd_out + s : nullptr, h_n_out + s, h_info ? h_info + 8 * s : nullptr, &handled);
-        if (rc == CANVAS_OK && !handled && rcAll == CANVAS_OK)                     // empty sample, LOESS / -w < 100, or the device path handed the sample back
-            rc = canvas_clean2(ch, h_n[s], h_d_chr[s], h_d_start[s], h_d_stop[s], h_d_count[s], h_d_gc[s], nchr, h_chr_is_autosome, h_chr_is_y, flags, min_bins_per_gc,
-                               h_local_sd_out ? h_local_sd_out + s : nullptr, h_n_out + s, h_info ? h_info + 8 * s : nullptr);
-        if (rc && rcAll == CANVAS_OK) { ctx->err = ch->err; rcAll = rc; }
+        if (done[s]) continue;                      // empty sample, LOESS / -w < 100, or the device path handed the sample back (its arrays are untouched)
+        const int32_t rc = canvas_clean2(ctx, h_n[s], h_d_chr[s], h_d_start[s], h_d_stop[s], h_d_count[s], h_d_gc[s], nchr, h_chr_is_autosome, h_chr_is_y, flags, min_bins_per_gc,
+                                         h_local_sd_out ? h_local_sd_out + s : nullptr, h_n_out + s, h_info ? h_info + 8 * s : nullptr);
+        if (rc && rcAll == CANVAS_OK) rcAll = rc;
     }
     return rcAll;
 }

@@ -7,10 +7,14 @@
 //   caller's arrays --(size filter + outlier filter: ONE compaction)--> scratch SoA  ...in-place normalisation...  --(GC strip + local-SD filter: ONE compaction)--> caller's arrays
 // The caller's arrays are not written before the last kernel, so a case this path does not cover (more than CF_MAXRUN chromosome runs) is detected on the device, leaves the
 // input intact and is handed to the host-driven path of clean.hip.  All per-bin arithmetic and all order statistics are the ones of that path: results are bit-identical.
+//
+// The stage is BATCH-NATIVE: every kernel takes a table of per-sample argument blocks (CfArgs, in device memory) and works on the block of blockIdx.y, so a cohort of B samples
+// costs the same ~55 launches as one sample (grid.y = B) and no sample's launch latency is paid B times.  One sample is a batch of one.
 #pragma once
 
 #define CF_MAXQ 640          // 6 + 6 * 101 quartile queries (variance normalisation); 2 + 2 * 101 median queries
 #define CF_MAXRUN 1024       // chromosome runs of the bin list handled on the device
+#define CF_NPROB 4           // select problems of a sample: [0] size percentile, [1] medians, [2] quartiles, [3] medians after the variance normalisation
 
 struct CleanDev {
     unsigned long long nAB;          // bins after RemoveBigBins + RemoveOutliers
@@ -36,20 +40,111 @@ struct CfSel {                       // a select problem built on the device (se
     unsigned long long qk[CF_MAXQ], qprefix[CF_MAXQ];
     SelSegQ segq[NGC];
 };
+struct CfArgs {                      // one sample of the batch
+    int64_t n;                       // bins handed in
+    int32_t nb, nchr, minBinsPerGc, wantLsd, doSize, doOutlier;
+    uint32_t flags, tilesUpper;
+    Soa caller, S1;                  // the caller's arrays; the scratch copy between the two compactions
+    uint8_t* dFlags; uint32_t* dBlk; uint32_t* keys32; uint32_t* keysG; const uint8_t* isAuto;
+    double* dSd; double* dRunMad; int64_t* dRunStart; long long* dPos;
+    CleanDev* D; CfSel* P; SelTile* tiles; uint32_t* hist;
+};
+#define CF_SAMPLE const CfArgs& A = AA[blockIdx.y]
+
+// ---------------------------------------------------------------- RemoveBigBins threshold (CanvasClean.cs:328-348): keys of the bin sizes
+__global__ void __launch_bounds__(256) k_cf_keys_size(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    if (!A.doSize) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < A.n) A.keys32[i] = (uint32_t)(A.caller.stop[i] - A.caller.start[i]) ^ 0x80000000u;   // order-preserving image of int32
+}
+// the select problems: mode 0 = medians (NormalizeByGC, CanvasClean.cs:163-189), mode 1 = quartiles (NormalizeVarianceByGC, :34-66), both over the grouped keys, genome + every kept
+// bucket; mode 2 = the 98th percentile of the bin sizes over keys32 (one segment, one rank).  gate: which CleanDev flag switches the problem on (0 gcActive, 1 varActive, 2 changed, 3 doSize)
+__global__ void __launch_bounds__(128) k_cf_sel_setup(const CfArgs* __restrict__ AA, int which, int mode, int gate) {
+    CF_SAMPLE;
+    __shared__ uint32_t so[NGC + 1], tileBase[NGC + 1];
+    __shared__ int qFirst[NGC + 2];                     // first query of slot s (slot NGC = the genome, placed FIRST: queries 0 .. nrG-1), prefix sums
+    const CleanDev* D = A.D; CfSel* P = A.P + which; SelTile* tiles = A.tiles + (size_t)which * A.tilesUpper;
+    const int t = threadIdx.x;
+    if (mode == 2) {
+        const int64_t index = (int64_t)(0.98 * (double)A.n);                   // CanvasClean.cs:339
+        const bool on = A.doSize && index < A.n;
+        if (!on) { if (t == 0) { P->hdr[0] = 0; P->hdr[1] = 0; } return; }
+        const uint32_t nt = (uint32_t)((A.n + SEL_TILE - 1) / SEL_TILE);
+        if (t == 0) {
+            P->hdr[0] = nt; P->hdr[1] = 1; P->qk[0] = (unsigned long long)index; P->qprefix[0] = 0ull;
+            SelSegQ Q; Q.nq = 1; Q.q[0] = 0; P->segq[0] = Q;
+        }
+        for (uint32_t k = t; k < nt; k += 128) tiles[k] = SelTile{0, (int64_t)k * SEL_TILE, min<int64_t>((int64_t)(k + 1) * SEL_TILE, A.n)};
+        return;
+    }
+    const bool on = gate == 0 ? D->gcActive != 0 : (gate == 1 ? D->varActive != 0 : D->changed != 0);
+    if (!on) { if (t == 0) { P->hdr[0] = 0; P->hdr[1] = 0; } return; }
+    if (t <= NGC) so[t] = D->segOff[t];
+    __syncthreads();
+    auto ranksOf = [&](int64_t cnt, int64_t* ranks) -> int {
+        if (cnt <= 0) return 0;
+        if (mode == 0) { if (cnt % 2) { ranks[0] = cnt / 2; return 1; } ranks[0] = cnt / 2 - 1; ranks[1] = cnt / 2; return 2; }
+        const QuartIdx qi = quartile_indices(cnt); for (int k = 0; k < qi.n; k++) ranks[k] = qi.idx[k]; return qi.n;
+    };
+    int64_t myRanks[6]; int myN = 0;
+    if (t < NGC) myN = ranksOf((int64_t)so[t + 1] - (int64_t)so[t], myRanks);
+    else if (t == NGC) myN = ranksOf((int64_t)so[NGC], myRanks);
+    if (t <= NGC) qFirst[t] = myN;                      // counts first
+    __syncthreads();
+    if (t == 0) {
+        const int nG = qFirst[NGC];
+        int acc = nG; uint32_t tacc = 0;
+        for (int s2 = 0; s2 < NGC; s2++) { const int c = qFirst[s2]; qFirst[s2] = acc; acc += c; tileBase[s2] = tacc; tacc += (so[s2 + 1] - so[s2] + SEL_TILE - 1) / SEL_TILE; }
+        qFirst[NGC] = 0; qFirst[NGC + 1] = nG;
+        tileBase[NGC] = tacc;
+        P->hdr[0] = tacc; P->hdr[1] = (uint32_t)acc;
+    }
+    __syncthreads();
+    const int nG = qFirst[NGC + 1];
+    if (t <= NGC) {
+        const int f = qFirst[t];
+        P->first[t] = myN > 0 ? f : -1;
+        for (int k = 0; k < myN; k++) { P->qk[f + k] = (unsigned long long)myRanks[k]; P->qprefix[f + k] = 0ull; }
+    }
+    if (t < NGC) {
+        SelSegQ Q; Q.nq = 0;
+        if (so[t + 1] > so[t]) { for (int k = 0; k < nG; k++) Q.q[Q.nq++] = k; for (int k = 0; k < myN; k++) Q.q[Q.nq++] = qFirst[t] + k; }
+        P->segq[t] = Q;
+        uint32_t k = tileBase[t];
+        for (int64_t b = so[t]; b < (int64_t)so[t + 1]; b += SEL_TILE) tiles[k++] = SelTile{t, b, min<int64_t>(b + SEL_TILE, (int64_t)so[t + 1])};
+    }
+}
+// the radix passes of a device-built problem (grids are upper bounds: tiles <= n / SEL_TILE + NGC + 1, queries <= CF_MAXQ)
+__global__ void __launch_bounds__(256) k_cf_select_hist(const CfArgs* __restrict__ AA, int which, int shift, int firstPass) {
+    CF_SAMPLE;
+    const CfSel* P = A.P + which;
+    select_hist_body<uint32_t>(which == 0 ? A.keys32 : A.keysG, A.tiles + (size_t)which * A.tilesUpper, P->segq, P->qprefix, shift, firstPass, A.hist, CF_MAXQ, P->hdr);
+}
+__global__ void __launch_bounds__(64) k_cf_select_pick(const CfArgs* __restrict__ AA, int which, int firstPass) {
+    CF_SAMPLE;
+    CfSel* P = A.P + which;
+    select_pick_body(A.hist, P->qprefix, P->qk, CF_MAXQ, firstPass, P->hdr);
+}
 
 // ---------------------------------------------------------------- RemoveBigBins + RemoveOutliers in one pass over the caller's arrays
 // keepA(j) = size <= threshold (CanvasClean.cs:349-352); RemoveOutliers (:387-413) looks at the neighbours in the list RemoveBigBins left, i.e. at the nearest
 // bins on either side that pass keepA.  Also the range check of gc / chr, the count after the size filter, and the block counts of the compaction.
-__global__ void __launch_bounds__(256) k_cf_flags_ab(const int32_t* __restrict__ chr, const int32_t* __restrict__ start, const int32_t* __restrict__ stop, const int32_t* __restrict__ gc,
-                                                     const float* __restrict__ count, int64_t n, int nchr, const unsigned long long* __restrict__ dKey, int doOutlier,
-                                                     uint8_t* __restrict__ flags, uint32_t* __restrict__ blockCnt, CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
     __shared__ uint32_t sh[8];
     __shared__ uint8_t sA[CBLK];                          // keepA, chromosome and count of this block's bins: the neighbour search reads them from LDS
     __shared__ int32_t sChr[CBLK];
     __shared__ float sCnt[CBLK];
-    const bool doSize = dKey != nullptr;
-    const int32_t thresh = doSize ? (int32_t)((uint32_t)dKey[0] ^ 0x80000000u) : 0;
+    const int64_t n = A.n;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
+    if (base >= n) return;
+    const int32_t* __restrict__ chr = A.caller.chr; const int32_t* __restrict__ start = A.caller.start; const int32_t* __restrict__ stop = A.caller.stop;
+    const int32_t* __restrict__ gc = A.caller.gc; const float* __restrict__ count = A.caller.count;
+    uint8_t* __restrict__ flags = A.dFlags; CleanDev* __restrict__ D = A.D;
+    const int nchr = A.nchr, doOutlier = A.doOutlier;
+    const bool doSize = A.P[0].hdr[1] != 0;               // the size problem is switched off when the filter is, or when the percentile index falls past the end
+    const int32_t thresh = doSize ? (int32_t)((uint32_t)A.P[0].qprefix[0] ^ 0x80000000u) : 0;
     uint32_t nKeep = 0, nSize = 0, bad = 0;
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) {
@@ -93,17 +188,43 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const int32_t* __restrict__
     if (lane_id() == 0) { sh[threadIdx.x >> 6] = nKeep; sh[4 + (threadIdx.x >> 6)] = nSize; }
     if (bad) D->bad = 1u;
     __syncthreads();
-    if (threadIdx.x == 0) { blockCnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; atomicAdd(&D->nA, sh[4] + sh[5] + sh[6] + sh[7]); }
+    if (threadIdx.x == 0) { A.dBlk[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; atomicAdd(&D->nA, sh[4] + sh[5] + sh[6] + sh[7]); }
+}
+// exclusive scan of the block counts: phase 0 over the blocks of the input (total -> nAB), phase 1 over the blocks of the nAB surviving bins (total -> nFinal)
+__global__ void __launch_bounds__(1024) k_cf_scan_blocks(const CfArgs* __restrict__ AA, int phase) {
+    CF_SAMPLE;
+    __shared__ uint32_t sh[17];
+    uint32_t* __restrict__ blockCnt = A.dBlk;
+    const int nblocks = phase == 0 ? A.nb : (int)(((int64_t)A.D->nAB + CBLK - 1) / CBLK);
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? blockCnt[i] : 0;
+        const uint32_t inc = wave_inclusive_scan_u32(v);
+        const int w = threadIdx.x >> 6;
+        if (lane_id() == 63) sh[w] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t s = 0; for (int k = 0; k < 16; k++) { const uint32_t tt = sh[k]; sh[k] = s; s += tt; } sh[16] = s; }
+        __syncthreads();
+        if (i < nblocks) blockCnt[i] = carry + sh[w] + inc - v;
+        carry += sh[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { if (phase == 0) A.D->nAB = carry; else A.D->nFinal = carry; }
 }
 // the compaction itself: caller's arrays -> scratch SoA, CountDeviation = -1 (GenomicBin.cs:83), and the GC histogram of what survives (CanvasClean.cs:207-223)
-__global__ void __launch_bounds__(256) k_cf_scatter_ab(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t n, Soa src, Soa dst, const uint8_t* __restrict__ isAuto,
-                                                       int nchr, CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
     __shared__ uint32_t sh[4];
     __shared__ uint32_t lh[2 * NGC];
+    const int64_t n = A.n;
+    const int64_t base = (int64_t)blockIdx.x * CBLK;
+    if (base >= n) return;
+    const uint8_t* __restrict__ flags = A.dFlags; const uint8_t* __restrict__ isAuto = A.isAuto;
+    const Soa src = A.caller, dst = A.S1; const int nchr = A.nchr;
     if (threadIdx.x < 2 * NGC) lh[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * CBLK;
-    uint32_t running = blockOff[blockIdx.x];
+    uint32_t running = A.dBlk[blockIdx.x];
     for (int j = 0; j < CBLK / 256; j++) {
         const int64_t i = base + j * 256 + threadIdx.x;
         const uint32_t f = (i < n) ? flags[i] : 0;
@@ -123,18 +244,34 @@ __global__ void __launch_bounds__(256) k_cf_scatter_ab(const uint8_t* __restrict
         running += tot;
         __syncthreads();
     }
-    if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&D->hist[threadIdx.x], lh[threadIdx.x]);
+    if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&A.D->hist[threadIdx.x], lh[threadIdx.x]);
 }
 
-// ---------------------------------------------------------------- chromosome runs of the window SDs (GetLocalStandardDeviationAverage, CanvasClean.cs:243-258)
-// one workgroup: sorts the (position << 20 | chromosome) records of k_run_bounds, derives the runs of windows per chromosome exactly as local_sd_begin does on the host
-__global__ void __launch_bounds__(1024) k_cf_runs_build(const long long* __restrict__ recs, const unsigned int* __restrict__ nrecDev, int64_t* __restrict__ runStart, CleanDev* __restrict__ D, int wantLocalSd) {
+// ---------------------------------------------------------------- local SD (CanvasClean.cs:243-298)
+__global__ void __launch_bounds__(256) k_cf_local_sd(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    if (!A.wantLsd) return;
+    local_sd_body(A.S1.count, 0, A.dSd, A.S1.dev, &A.D->nAB);
+}
+__global__ void __launch_bounds__(256) k_cf_run_bounds(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    if (!A.wantLsd) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)A.D->nAB) return;
+    const int32_t* __restrict__ chr = A.S1.chr;
+    const int32_t c = chr[i];
+    if (i == 0 || c != chr[i - 1]) { const unsigned int k = atomicAdd(&A.D->nRunRec, 1u); if (k < 65536u) A.dPos[k] = (long long)((i << 20) | (long long)(c & 0xFFFFF)); }
+}
+// one workgroup: sorts the (position << 20 | chromosome) records of k_cf_run_bounds, derives the runs of windows per chromosome exactly as local_sd_begin does on the host
+__global__ void __launch_bounds__(1024) k_cf_runs_build(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
     __shared__ long long s[CF_MAXRUN];
+    CleanDev* __restrict__ D = A.D; const long long* __restrict__ recs = A.dPos; int64_t* __restrict__ runStart = A.dRunStart;
     const unsigned long long nAB = D->nAB;
-    const int have = wantLocalSd && nAB >= 50000ull;                       // CanvasClean.cs:483-486
+    const int have = A.wantLsd && nAB >= 50000ull;                         // CanvasClean.cs:483-486
     if (threadIdx.x == 0) D->haveLocalSd = have;
     if (!have) { if (threadIdx.x == 0) D->nruns = 0; return; }
-    const unsigned int nb = *nrecDev;
+    const unsigned int nb = D->nRunRec;
     if (nb > CF_MAXRUN) { if (threadIdx.x == 0) { D->fallback = 1u; D->nruns = 0; } return; }
     const int t = threadIdx.x;
     s[t] = t < (int)nb ? recs[t] : 0x7FFFFFFFFFFFFFFFll;
@@ -161,19 +298,28 @@ __global__ void __launch_bounds__(1024) k_cf_runs_build(const long long* __restr
         D->nruns = nruns;
     }
 }
-__global__ void k_cf_lsd_avg(const double* __restrict__ runMad, CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(1024) k_cf_run_mad(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    if (!A.wantLsd) return;
+    run_mad_body(A.dSd, A.dRunStart, A.dRunMad, &A.D->nruns);
+}
+__global__ void k_cf_lsd_avg(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
     if (threadIdx.x || blockIdx.x) return;
+    CleanDev* D = A.D;
     if (!D->haveLocalSd) { D->localSd = -1.0; return; }
     double s = 0;
-    for (int r = 0; r < D->nruns; r++) s += runMad[r];                     // List<double>.Average(): sequential sum / count
+    for (int r = 0; r < D->nruns; r++) s += A.dRunMad[r];                  // List<double>.Average(): sequential sum / count
     D->localSd = s / (double)D->nruns;
 }
 
 // ---------------------------------------------------------------- RemoveBinsWithExtremeGC decision (CanvasClean.cs:207-237) and what follows from it
-__global__ void __launch_bounds__(128) k_cf_dec_gc(uint32_t flags, int minBinsPerGc, CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(128) k_cf_dec_gc(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
     __shared__ uint32_t hA[NGC], hO[NGC], so[NGC + 1];
     __shared__ uint8_t kp[NGC];
     __shared__ long long sKept; __shared__ int sActive;
+    CleanDev* __restrict__ D = A.D; const uint32_t flags = A.flags; const int minBinsPerGc = A.minBinsPerGc;
     const int t = threadIdx.x;
     const long long nAB = (long long)D->nAB;
     if (t < NGC) { hA[t] = D->hist[t]; hO[t] = D->hist[NGC + t]; }
@@ -202,17 +348,21 @@ __global__ void __launch_bounds__(128) k_cf_dec_gc(uint32_t flags, int minBinsPe
     if (t < NGC) { D->keepGc[t] = kp[t]; D->cursor[t] = 0; D->medians[t] = 0.0; D->segOff[t] = so[t]; }
     if (t == 0) {
         D->segOff[NGC] = so[NGC]; D->kept = sKept; D->gcActive = sActive; D->changed = 0;
-        D->varActive = (sActive && D->haveLocalSd && sKept > 500000) ? 1 : 0;                    // CanvasClean.cs:512-519
+        // NormalizeVarianceByGC runs for whole-genome samples only (CanvasClean.cs:512-519); the host enqueues its kernels when the INPUT has more than 500000 bins
+        D->varActive = (sActive && D->haveLocalSd && sKept > 500000 && (flags & CANVAS_CLEAN_LOCALSD) && A.n > 500000) ? 1 : 0;
     }
 }
 // grouped keys of the autosomal bins with a kept GC value (order inside a bucket is irrelevant: only order statistics are taken)
-__global__ void __launch_bounds__(256) k_cf_group_keys(const int32_t* __restrict__ chr, const int32_t* __restrict__ gc, const float* __restrict__ count, const uint8_t* __restrict__ isAuto,
-                                                       int64_t nUpper, CleanDev* __restrict__ D, uint32_t* __restrict__ keysG) {
+__global__ void __launch_bounds__(256) k_cf_group_keys(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
     __shared__ uint32_t lcnt[NGC], lbase[NGC];
+    CleanDev* __restrict__ D = A.D;
     if (!D->gcActive) return;
     const int64_t n = (int64_t)D->nAB;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
+    const int32_t* __restrict__ chr = A.S1.chr; const int32_t* __restrict__ gc = A.S1.gc; const float* __restrict__ count = A.S1.count;
+    const uint8_t* __restrict__ isAuto = A.isAuto; uint32_t* __restrict__ keysG = A.keysG;
     if (threadIdx.x < NGC) lcnt[threadIdx.x] = 0;
     __syncthreads();
     uint32_t myRank[CBLK / 256]; int myGc[CBLK / 256]; uint32_t myKey[CBLK / 256];
@@ -228,51 +378,10 @@ __global__ void __launch_bounds__(256) k_cf_group_keys(const int32_t* __restrict
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) if (myGc[j] >= 0) keysG[D->segOff[myGc[j]] + lbase[myGc[j]] + myRank[j]] = myKey[j];
 }
-// the select problem over the grouped keys: mode 0 = medians (NormalizeByGC, CanvasClean.cs:163-189), mode 1 = quartiles (NormalizeVarianceByGC, :34-66); genome + every kept bucket.
-// gate: which CleanDev flag switches the problem on (0 gcActive, 1 varActive, 2 changed)
-__global__ void __launch_bounds__(128) k_cf_sel_setup(int mode, int gate, const CleanDev* __restrict__ D, CfSel* __restrict__ P, SelTile* __restrict__ tiles) {
-    __shared__ uint32_t so[NGC + 1], tileBase[NGC + 1];
-    __shared__ int qFirst[NGC + 2];                     // first query of slot s (slot NGC = the genome, placed FIRST: queries 0 .. nrG-1), prefix sums
-    const int t = threadIdx.x;
-    const bool on = gate == 0 ? D->gcActive != 0 : (gate == 1 ? D->varActive != 0 : D->changed != 0);
-    if (!on) { if (t == 0) { P->hdr[0] = 0; P->hdr[1] = 0; } return; }
-    if (t <= NGC) so[t] = D->segOff[t];
-    __syncthreads();
-    auto ranksOf = [&](int64_t cnt, int64_t* ranks) -> int {
-        if (cnt <= 0) return 0;
-        if (mode == 0) { if (cnt % 2) { ranks[0] = cnt / 2; return 1; } ranks[0] = cnt / 2 - 1; ranks[1] = cnt / 2; return 2; }
-        const QuartIdx qi = quartile_indices(cnt); for (int k = 0; k < qi.n; k++) ranks[k] = qi.idx[k]; return qi.n;
-    };
-    int64_t myRanks[6]; int myN = 0;
-    if (t < NGC) myN = ranksOf((int64_t)so[t + 1] - (int64_t)so[t], myRanks);
-    else if (t == NGC) myN = ranksOf((int64_t)so[NGC], myRanks);
-    if (t <= NGC) qFirst[t] = myN;                      // counts first
-    __syncthreads();
-    if (t == 0) {
-        const int nG = qFirst[NGC];
-        int acc = nG; uint32_t tacc = 0;
-        for (int s2 = 0; s2 < NGC; s2++) { const int c = qFirst[s2]; qFirst[s2] = acc; acc += c; tileBase[s2] = tacc; tacc += (so[s2 + 1] - so[s2] + SEL_TILE - 1) / SEL_TILE; }
-        qFirst[NGC] = 0; qFirst[NGC + 1] = nG;
-        tileBase[NGC] = tacc;
-        P->hdr[0] = tacc; P->hdr[1] = (uint32_t)acc;
-    }
-    __syncthreads();
-    const int nG = qFirst[NGC + 1];
-    if (t <= NGC) {
-        const int f = qFirst[t];
-        P->first[t] = myN > 0 ? f : -1;
-        for (int k = 0; k < myN; k++) { P->qk[f + k] = (unsigned long long)myRanks[k]; P->qprefix[f + k] = 0ull; }
-    }
-    if (t < NGC) {
-        SelSegQ Q; Q.nq = 0;
-        if (so[t + 1] > so[t]) { for (int k = 0; k < nG; k++) Q.q[Q.nq++] = k; for (int k = 0; k < myN; k++) Q.q[Q.nq++] = qFirst[t] + k; }
-        P->segq[t] = Q;
-        uint32_t k = tileBase[t];
-        for (int64_t b = so[t]; b < (int64_t)so[t + 1]; b += SEL_TILE) tiles[k++] = SelTile{t, b, min<int64_t>(b + SEL_TILE, (int64_t)so[t + 1])};
-    }
-}
 // NormalizeByGC decision: genome median and per-GC medians from the selected keys (CanvasClean.cs:170-189)
-__global__ void __launch_bounds__(128) k_cf_dec_e(const CfSel* __restrict__ P, CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(128) k_cf_dec_e(const CfArgs* __restrict__ AA, int which) {
+    CF_SAMPLE;
+    const CfSel* __restrict__ P = A.P + which; CleanDev* __restrict__ D = A.D;
     if (P->hdr[1] == 0) return;
     const int t = threadIdx.x;
     auto med = [&](int slot, int64_t cnt) -> double {
@@ -283,29 +392,65 @@ __global__ void __launch_bounds__(128) k_cf_dec_e(const CfSel* __restrict__ P, C
     if (t < NGC) { const int64_t cnt = (int64_t)D->segOff[t + 1] - (int64_t)D->segOff[t]; D->medians[t] = (cnt > 0 && P->first[t] >= 0) ? med(t, cnt) : 0.0; }
     if (t == NGC) D->globalMedian = med(NGC, (int64_t)D->segOff[NGC]);
 }
-__global__ void __launch_bounds__(256) k_cf_apply_gc(float* __restrict__ count, const int32_t* __restrict__ gc, int64_t nUpper, const CleanDev* __restrict__ D, const CfSel* __restrict__ P) {
-    if (P->hdr[1] == 0) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)D->nAB) return;
-    const double median = D->medians[gc[i]];
-    if (median > 0) count[i] = (float)(D->globalMedian * (double)count[i] / median);         // CanvasClean.cs:190-195
+#define CF_EPT 4             // bins / keys per thread of the element-wise normalisation kernels (the per-GC tables are staged in LDS once per workgroup)
+__global__ void __launch_bounds__(256) k_cf_apply_gc(const CfArgs* __restrict__ AA, int which) {
+    CF_SAMPLE;
+    __shared__ double sMed[NGC];
+    const CleanDev* __restrict__ D = A.D;
+    if (A.P[which].hdr[1] == 0) return;
+    const int64_t n = (int64_t)D->nAB, base = (int64_t)blockIdx.x * (256 * CF_EPT);
+    if (base >= n) return;
+    if (threadIdx.x < NGC) sMed[threadIdx.x] = D->medians[threadIdx.x];
+    __syncthreads();
+    float* __restrict__ count = A.S1.count; const int32_t* __restrict__ gc = A.S1.gc;
+    const double globalMedian = D->globalMedian;
+#pragma unroll
+    for (int j = 0; j < CF_EPT; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i >= n) break;
+        const double median = sMed[gc[i]];
+        if (median > 0) count[i] = (float)(globalMedian * (double)count[i] / median);        // CanvasClean.cs:190-195
+    }
 }
 // the same normalisation applied to the grouped keys (the order statistics of the next step are taken from the updated counts)
-__device__ __forceinline__ int cf_bucket_of(const uint32_t* __restrict__ segOff, uint32_t p) {
+// bucket of grouped position p: the buckets are contiguous, so a workgroup's first position is located by bisection and the rest walk forward
+__device__ __forceinline__ int cf_bucket_walk(const uint32_t* sSeg, uint32_t p, int b) {
+    while (b < NGC - 1 && p >= sSeg[b + 1]) b++;
+    return b;
+}
+__device__ __forceinline__ int cf_bucket_of(const uint32_t* segOff, uint32_t p) {
     int lo = 0, hi = NGC - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segOff[mid] <= p) lo = mid; else hi = mid - 1; }
     return lo;
 }
-__global__ void __launch_bounds__(256) k_cf_xform_gc(uint32_t* __restrict__ keysG, const CleanDev* __restrict__ D, const CfSel* __restrict__ nextProblem) {
-    if (nextProblem->hdr[1] == 0) return;
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= D->segOff[NGC]) return;
-    const double median = D->medians[cf_bucket_of(D->segOff, p)];
-    if (median > 0) keysG[p] = key_of_float((float)(D->globalMedian * (double)float_of_key(keysG[p]) / median));
+__global__ void __launch_bounds__(256) k_cf_xform_gc(const CfArgs* __restrict__ AA, int nextProblem) {
+    CF_SAMPLE;
+    __shared__ uint32_t sSeg[NGC + 1];
+    __shared__ double sMed[NGC];
+    const CleanDev* __restrict__ D = A.D;
+    if (A.P[nextProblem].hdr[1] == 0) return;
+    const uint32_t total = D->segOff[NGC], base = blockIdx.x * (256u * CF_EPT);
+    if (base >= total) return;
+    if (threadIdx.x <= NGC) sSeg[threadIdx.x] = D->segOff[threadIdx.x];
+    if (threadIdx.x < NGC) sMed[threadIdx.x] = D->medians[threadIdx.x];
+    __syncthreads();
+    uint32_t* __restrict__ keysG = A.keysG;
+    const double globalMedian = D->globalMedian;
+    int b = cf_bucket_of(sSeg, base);
+#pragma unroll
+    for (int j = 0; j < CF_EPT; j++) {
+        const uint32_t p = base + j * 256u + threadIdx.x;
+        if (p >= total) break;
+        b = cf_bucket_walk(sSeg, p, b);
+        const double median = sMed[b];
+        if (median > 0) keysG[p] = key_of_float((float)(globalMedian * (double)float_of_key(keysG[p]) / median));
+    }
 }
 // NormalizeVarianceByGC decision (CanvasClean.cs:34-83)
-__global__ void __launch_bounds__(128) k_cf_dec_f(const CfSel* __restrict__ P, CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(128) k_cf_dec_f(const CfArgs* __restrict__ AA, int which) {
+    CF_SAMPLE;
     __shared__ int sig;
+    const CfSel* __restrict__ P = A.P + which; CleanDev* __restrict__ D = A.D;
     if (P->hdr[1] == 0) return;
     const int t = threadIdx.x;
     if (t == 0) sig = 0;
@@ -328,34 +473,64 @@ __global__ void __launch_bounds__(128) k_cf_dec_f(const CfSel* __restrict__ P, C
     __syncthreads();
     if (t == 0) { D->tab.globalIQR = globalIQR; D->changed = sig > 0 ? 1 : 0; }
 }
-__global__ void __launch_bounds__(256) k_cf_apply_var(float* __restrict__ count, const int32_t* __restrict__ gc, int64_t nUpper, const CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(256) k_cf_apply_var(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    __shared__ float sIqr[NGC], sMedF[NGC];
+    const CleanDev* __restrict__ D = A.D;
     if (!D->changed) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)D->nAB) return;
-    const int g = gc[i];
-    const float globalIQR = D->tab.globalIQR, scaledLocalIqr = D->tab.localIQR[g] * 0.8f;
-    if (globalIQR >= scaledLocalIqr) return;
-    const float iqrRatio = scaledLocalIqr / globalIQR, m = D->tab.med[g];
-    count[i] = m + (count[i] - m) / iqrRatio;                                                // CanvasClean.cs:84-94
+    const int64_t n = (int64_t)D->nAB, base = (int64_t)blockIdx.x * (256 * CF_EPT);
+    if (base >= n) return;
+    if (threadIdx.x < NGC) { sIqr[threadIdx.x] = D->tab.localIQR[threadIdx.x]; sMedF[threadIdx.x] = D->tab.med[threadIdx.x]; }
+    __syncthreads();
+    float* __restrict__ count = A.S1.count; const int32_t* __restrict__ gc = A.S1.gc;
+    const float globalIQR = D->tab.globalIQR;
+#pragma unroll
+    for (int j = 0; j < CF_EPT; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i >= n) break;
+        const int g = gc[i];
+        const float scaledLocalIqr = sIqr[g] * 0.8f;
+        if (globalIQR >= scaledLocalIqr) continue;
+        const float iqrRatio = scaledLocalIqr / globalIQR, m = sMedF[g];
+        count[i] = m + (count[i] - m) / iqrRatio;                                            // CanvasClean.cs:84-94
+    }
 }
-__global__ void __launch_bounds__(256) k_cf_xform_var(uint32_t* __restrict__ keysG, const CleanDev* __restrict__ D) {
+__global__ void __launch_bounds__(256) k_cf_xform_var(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    __shared__ uint32_t sSeg[NGC + 1];
+    __shared__ float sIqr[NGC], sMedF[NGC];
+    const CleanDev* __restrict__ D = A.D;
     if (!D->changed) return;
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= D->segOff[NGC]) return;
-    const int g = cf_bucket_of(D->segOff, p);
-    const float globalIQR = D->tab.globalIQR, scaledLocalIqr = D->tab.localIQR[g] * 0.8f;
-    if (globalIQR >= scaledLocalIqr) return;
-    const float iqrRatio = scaledLocalIqr / globalIQR, m = D->tab.med[g];
-    keysG[p] = key_of_float(m + (float_of_key(keysG[p]) - m) / iqrRatio);
+    const uint32_t total = D->segOff[NGC], base = blockIdx.x * (256u * CF_EPT);
+    if (base >= total) return;
+    if (threadIdx.x <= NGC) sSeg[threadIdx.x] = D->segOff[threadIdx.x];
+    if (threadIdx.x < NGC) { sIqr[threadIdx.x] = D->tab.localIQR[threadIdx.x]; sMedF[threadIdx.x] = D->tab.med[threadIdx.x]; }
+    __syncthreads();
+    uint32_t* __restrict__ keysG = A.keysG;
+    const float globalIQR = D->tab.globalIQR;
+    int b = cf_bucket_of(sSeg, base);
+#pragma unroll
+    for (int j = 0; j < CF_EPT; j++) {
+        const uint32_t p = base + j * 256u + threadIdx.x;
+        if (p >= total) break;
+        b = cf_bucket_walk(sSeg, p, b);
+        const float scaledLocalIqr = sIqr[b] * 0.8f;
+        if (globalIQR >= scaledLocalIqr) continue;
+        const float iqrRatio = scaledLocalIqr / globalIQR, m = sMedF[b];
+        keysG[p] = key_of_float(m + (float_of_key(keysG[p]) - m) / iqrRatio);
+    }
 }
 
 // ---------------------------------------------------------------- last compaction: GC strip (CanvasClean.cs:226-235) + RemoveBinsWithExtremeLocalSD (:308-322) -> caller's arrays
-__global__ void __launch_bounds__(256) k_cf_flags_final(const int32_t* __restrict__ gc, const double* __restrict__ dev, int64_t nUpper, const CleanDev* __restrict__ D,
-                                                        uint8_t* __restrict__ flags, uint32_t* __restrict__ blockCnt) {
+__global__ void __launch_bounds__(256) k_cf_flags_final(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
     __shared__ uint32_t sh[4];
+    const CleanDev* __restrict__ D = A.D;
     const int64_t n = (int64_t)D->nAB;
-    const bool sdFilter = D->haveLocalSd && D->localSd > 5.0;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
+    if (base >= n) return;
+    const int32_t* __restrict__ gc = A.S1.gc; const double* __restrict__ dev = A.S1.dev; uint8_t* __restrict__ flags = A.dFlags;
+    const bool sdFilter = D->haveLocalSd && D->localSd > 5.0;
     uint32_t c = 0;
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) {
@@ -367,16 +542,19 @@ __global__ void __launch_bounds__(256) k_cf_flags_final(const int32_t* __restric
     c = wave_reduce_add_u32(c);
     if (lane_id() == 0) sh[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) blockCnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) A.dBlk[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ void __launch_bounds__(256) k_cf_scatter_final(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t nUpper, Soa src, Soa dst, const CleanDev* __restrict__ D, int secondPhase) {
+__global__ void __launch_bounds__(256) k_cf_scatter_final(const CfArgs* __restrict__ AA, int secondPhase) {
+    CF_SAMPLE;
     __shared__ uint32_t sh[4];
+    const CleanDev* __restrict__ D = A.D;
     if (D->fallback || D->bad) return;                                        // the caller's arrays stay as they were
     if (D->changed && !secondPhase) return;                                   // the variance normalisation changed the counts: the host enqueues the second NormalizeByGC, then this kernel again
     const int64_t n = (int64_t)D->nAB;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
-    uint32_t running = blockOff[blockIdx.x];
+    const uint8_t* __restrict__ flags = A.dFlags; const Soa src = A.S1, dst = A.caller;
+    uint32_t running = A.dBlk[blockIdx.x];
     for (int j = 0; j < CBLK / 256; j++) {
         const int64_t i = base + j * 256 + threadIdx.x;
         const uint32_t f = (i < n) ? flags[i] : 0;
@@ -390,164 +568,175 @@ __global__ void __launch_bounds__(256) k_cf_scatter_final(const uint8_t* __restr
         __syncthreads();
     }
 }
-// k_scan_blocks over a device-side element count
-__global__ void __launch_bounds__(1024) k_cf_scan_blocks(uint32_t* __restrict__ blockCnt, const CleanDev* __restrict__ D, unsigned long long* __restrict__ total) {
-    __shared__ uint32_t sh[17];
-    const int nblocks = (int)(((int64_t)D->nAB + CBLK - 1) / CBLK);
-    uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? blockCnt[i] : 0;
-        const uint32_t inc = wave_inclusive_scan_u32(v);
-        const int w = threadIdx.x >> 6;
-        if (lane_id() == 63) sh[w] = inc;
-        __syncthreads();
-        if (threadIdx.x == 0) { uint32_t s = 0; for (int k = 0; k < 16; k++) { const uint32_t tt = sh[k]; sh[k] = s; s += tt; } sh[16] = s; }
-        __syncthreads();
-        if (i < nblocks) blockCnt[i] = carry + sh[w] + inc - v;
-        carry += sh[16];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
 
-// the four radix passes of a device-built select problem (grids are upper bounds: tiles <= n / SEL_TILE + NGC + 1, queries <= CF_MAXQ)
-static void cf_select_passes(canvas_ctx* ctx, const uint32_t* keysG, SelTile* dTiles, CfSel* P, int64_t nUpper) {
-    const unsigned tilesUpper = (unsigned)(nUpper / SEL_TILE + NGC + 1);
-    uint32_t* dHist = (uint32_t*)ctx->sel_hist;
+// ---------------------------------------------------------------- host side
+struct CleanPending { int B; unsigned gxN, gxB, gxT; bool anyLsd, anyVar, anyGc; CfArgs* dArgs; CleanDev* dD; std::vector<CfArgs> h; };
+
+static void cf_select_passes(canvas_ctx* ctx, const CfArgs* dArgs, int B, unsigned gxT, int which) {
     for (int shift = 24; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL((k_select_hist<uint32_t>), dim3(tilesUpper), dim3(256), 0, ctx->stream, keysG, dTiles, P->segq, P->qprefix, shift, shift == 24 ? 1 : 0, dHist, CF_MAXQ, P->hdr);
-        hipLaunchKernelGGL(k_select_pick, dim3(CF_MAXQ), dim3(64), 0, ctx->stream, dHist, P->qprefix, P->qk, CF_MAXQ, shift == 24 ? 1 : 0, P->hdr);
+        hipLaunchKernelGGL(k_cf_select_hist, dim3(gxT, B), dim3(256), 0, ctx->stream, dArgs, which, shift, shift == 24 ? 1 : 0);
+        hipLaunchKernelGGL(k_cf_select_pick, dim3(CF_MAXQ, B), dim3(64), 0, ctx->stream, dArgs, which, shift == 24 ? 1 : 0);
     }
 }
+// NormalizeByGC on problem `which` (1: first time, 3: after the variance normalisation) and the last compaction; `args`: the whole batch or one sample's block
+static void cf_gcnorm_and_compact(canvas_ctx* ctx, const CfArgs* args, int B, unsigned gxN, unsigned gxB, unsigned gxT, int which, int gate, int secondPhase, bool selectToo) {
+    if (selectToo) {
+        hipLaunchKernelGGL(k_cf_sel_setup, dim3(1, B), dim3(128), 0, ctx->stream, args, which, 0, gate);
+        cf_select_passes(ctx, args, B, gxT, which);
+        hipLaunchKernelGGL(k_cf_dec_e, dim3(1, B), dim3(128), 0, ctx->stream, args, which);
+        hipLaunchKernelGGL(k_cf_apply_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, B), dim3(256), 0, ctx->stream, args, which);
+    }
+    (void)secondPhase;
+}
 
-struct CleanPending { int64_t n; int nb; unsigned tilesUpper; Soa S1, caller; uint8_t* dFlags; uint32_t* dBlk; uint32_t* keysG; SelTile* dTiles; CfSel* P; CleanDev* D; };
-// Enqueues the whole stage on ctx->stream (no synchronisation): the CleanDev block arrives in ctx->pin.  clean_device_driven_finish waits for it.
-static int32_t clean_device_driven_enqueue(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count, int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome,
-                                           uint32_t flags, int32_t min_bins_per_gc) {
-    const int64_t nW0 = n / 20 + 2;
-    const int nb = (int)nblk(n, CBLK);
-    const unsigned tilesUpper = (unsigned)(n / SEL_TILE + NGC + 1);
+// Enqueues the whole stage for B samples on ctx->stream (no synchronisation): the CleanDev blocks arrive in ctx->pin.  clean_batch_finish waits for them.
+static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t* const* d_chr, int32_t* const* d_start, int32_t* const* d_stop, float* const* d_count, int32_t* const* d_gc,
+                                   int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc) {
     WsSizer sz;
-    sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n);
-    sz.take<uint8_t>(n); sz.take<uint32_t>(2 * (nb + 2)); sz.take<uint32_t>(n); sz.take<uint32_t>(n); sz.take<uint8_t>(nchr); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
-    sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CleanDev>(1); sz.take<CfSel>(3); sz.take<SelTile>((size_t)tilesUpper * 3);
+    sz.take<CleanDev>(B); sz.take<CfArgs>(B); sz.take<uint8_t>(nchr);
+    int64_t nMax = 0; bool anyLsd = false, anyVar = false;
+    for (int s = 0; s < B; s++) {
+        const int64_t n = h_n[s], nW0 = n / 20 + 2, nb = nblk(n, CBLK); const size_t tilesUpper = (size_t)(n / SEL_TILE + NGC + 1);
+        nMax = std::max(nMax, n);
+        sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n);
+        sz.take<uint8_t>(n); sz.take<uint32_t>(2 * (nb + 2)); sz.take<uint32_t>(n); sz.take<uint32_t>(n); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
+        sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CfSel>(CF_NPROB); sz.take<SelTile>(tilesUpper * CF_NPROB);
+    }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
-    const size_t histBytes = (size_t)CF_MAXQ * 1024 * SEL_REP;
+    const size_t histPer = (size_t)CF_MAXQ * 1024 * SEL_REP, histBytes = histPer * (size_t)B;
     if (histBytes > ctx->sel_hist_bytes) {
         if (ctx->sel_hist) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->sel_hist)); ctx->sel_hist = nullptr; ctx->sel_hist_bytes = 0; }
         CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->sel_hist, histBytes)); ctx->sel_hist_bytes = histBytes;
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->sel_hist, 0, ctx->sel_hist_bytes, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->sel_hist, 0, ctx->sel_hist_bytes, ctx->stream));       // zero once: k_select_pick clears every row it has read
     }
     WsCarver ws(ctx->ws);
-    Soa caller{d_chr, d_start, d_stop, d_gc, d_count, nullptr};
-    Soa S1; S1.chr = ws.take<int32_t>(n); S1.start = ws.take<int32_t>(n); S1.stop = ws.take<int32_t>(n); S1.gc = ws.take<int32_t>(n); S1.count = ws.take<float>(n); S1.dev = ws.take<double>(n);
-    uint8_t* dFlags = ws.take<uint8_t>(n); uint32_t* dBlk = ws.take<uint32_t>(2 * (nb + 2)); uint32_t* keys32 = ws.take<uint32_t>(n); uint32_t* keysG = ws.take<uint32_t>(n);
-    uint8_t* dIsAuto = ws.take<uint8_t>(nchr); double* dSd = ws.take<double>(nW0); double* dRunMad = ws.take<double>(CF_MAXRUN + 8); int64_t* dRunStart = ws.take<int64_t>(CF_MAXRUN + 8);
-    long long* dPos = ws.take<long long>(65536); CleanDev* D = ws.take<CleanDev>(1); CfSel* P = ws.take<CfSel>(3); SelTile* dTiles = ws.take<SelTile>((size_t)tilesUpper * 3);
+    CleanDev* dD = ws.take<CleanDev>(B); CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr);
+    CleanPending pend; pend.B = B; pend.dArgs = dArgs; pend.dD = dD; pend.h.resize(B);
+    unsigned gxT = 1;
+    for (int s = 0; s < B; s++) {
+        const int64_t n = h_n[s], nW0 = n / 20 + 2; const int nb = (int)nblk(n, CBLK); const unsigned tilesUpper = (unsigned)(n / SEL_TILE + NGC + 1);
+        CfArgs& A = pend.h[s];
+        A.n = n; A.nb = nb; A.nchr = nchr; A.minBinsPerGc = min_bins_per_gc; A.flags = flags; A.tilesUpper = tilesUpper;
+        A.wantLsd = ((flags & CANVAS_CLEAN_LOCALSD) && n >= 50000) ? 1 : 0;
+        A.doSize = (flags & CANVAS_CLEAN_FILTSIZE) ? 1 : 0; A.doOutlier = (flags & CANVAS_CLEAN_OUTLIERS) ? 1 : 0;
+        A.caller = Soa{d_chr[s], d_start[s], d_stop[s], d_gc[s], d_count[s], nullptr};
+        A.S1.chr = ws.take<int32_t>(n); A.S1.start = ws.take<int32_t>(n); A.S1.stop = ws.take<int32_t>(n); A.S1.gc = ws.take<int32_t>(n); A.S1.count = ws.take<float>(n); A.S1.dev = ws.take<double>(n);
+        A.dFlags = ws.take<uint8_t>(n); A.dBlk = ws.take<uint32_t>(2 * (nb + 2)); A.keys32 = ws.take<uint32_t>(n); A.keysG = ws.take<uint32_t>(n);
+        A.dSd = ws.take<double>(nW0); A.dRunMad = ws.take<double>(CF_MAXRUN + 8); A.dRunStart = ws.take<int64_t>(CF_MAXRUN + 8); A.dPos = ws.take<long long>(65536);
+        A.P = ws.take<CfSel>(CF_NPROB); A.tiles = ws.take<SelTile>((size_t)tilesUpper * CF_NPROB);
+        A.isAuto = dIsAuto; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
+        gxT = std::max(gxT, tilesUpper);
+        anyLsd = anyLsd || A.wantLsd; anyVar = anyVar || (A.wantLsd && n > 500000);
+    }
+    const unsigned gxN = (unsigned)nblk(nMax, 256), gxB = (unsigned)nblk(nMax, CBLK);
+    pend.gxN = gxN; pend.gxB = gxB; pend.gxT = gxT; pend.anyLsd = anyLsd; pend.anyVar = anyVar; pend.anyGc = (flags & CANVAS_CLEAN_GCNORM) != 0;
     ProfScope psTotal(ctx, "clean_total");
     rc = canvas_h2d_small(ctx, dIsAuto, h_chr_is_autosome, nchr); if (rc) return rc;
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(D, 0, sizeof(CleanDev), ctx->stream));
+    rc = canvas_h2d_small(ctx, dArgs, pend.h.data(), (size_t)B * sizeof(CfArgs)); if (rc) return rc;
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dD, 0, (size_t)B * sizeof(CleanDev), ctx->stream));
     // ---- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes, left on the device
-    const unsigned long long* dKey = nullptr;
-    if (flags & CANVAS_CLEAN_FILTSIZE) {
-        const int64_t index = (int64_t)(0.98 * (double)n);
-        if (index < n) {
-            hipLaunchKernelGGL(k_keys_size, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_start, d_stop, n, keys32);
-            std::vector<unsigned long long> res;
-            rc = radix_select<uint32_t>(ctx, keys32, 1, std::vector<int64_t>{0, n}, std::vector<SelQuery>{{0, 0, index}}, res, &dKey); if (rc) return rc;
-        }
-    }
+    if (flags & CANVAS_CLEAN_FILTSIZE) hipLaunchKernelGGL(k_cf_keys_size, dim3(gxN, B), dim3(256), 0, ctx->stream, dArgs);
+    hipLaunchKernelGGL(k_cf_sel_setup, dim3(1, B), dim3(128), 0, ctx->stream, dArgs, 0, 2, 3);
+    if (flags & CANVAS_CLEAN_FILTSIZE) cf_select_passes(ctx, dArgs, B, gxT, 0);
     // ---- size filter + outlier filter: one compaction, caller -> S1
-    // (a one-bin-per-thread variant of this kernel was measured: 68 us against 53 us for the staged one)
-    hipLaunchKernelGGL(k_cf_flags_ab, dim3(nb), dim3(256), 0, ctx->stream, d_chr, d_start, d_stop, d_gc, d_count, n, nchr, dKey, (flags & CANVAS_CLEAN_OUTLIERS) ? 1 : 0, dFlags, dBlk, D);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, dBlk, nb, &D->nAB);
-    hipLaunchKernelGGL(k_cf_scatter_ab, dim3(nb), dim3(256), 0, ctx->stream, dFlags, dBlk, n, caller, S1, dIsAuto, nchr, D);
+    // (a one-bin-per-thread variant of the flag kernel was measured: 68 us against 53 us for the staged one)
+    hipLaunchKernelGGL(k_cf_flags_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
+    hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1, B), dim3(1024), 0, ctx->stream, dArgs, 0);
+    hipLaunchKernelGGL(k_cf_scatter_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
     // ---- local SD (CanvasClean.cs:243-298): window SDs and chromosome runs on the main stream, the per-run MAD on the side stream
-    const bool wantLsd = (flags & CANVAS_CLEAN_LOCALSD) && n >= 50000;
-    if (wantLsd) {
-        const int64_t nWu = (n - 2) / 20;
-        if (nWu > 0) hipLaunchKernelGGL(k_local_sd, dim3(nblk(nWu, 256)), dim3(256), 0, ctx->stream, S1.count, nWu, dSd, S1.dev, &D->nAB);
-        hipLaunchKernelGGL(k_run_bounds, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, S1.chr, n, &D->nRunRec, dPos, 65536, &D->nAB);
-        hipLaunchKernelGGL(k_cf_runs_build, dim3(1), dim3(CF_MAXRUN), 0, ctx->stream, dPos, &D->nRunRec, dRunStart, D, 1);
+    if (anyLsd) {
+        hipLaunchKernelGGL(k_cf_local_sd, dim3((unsigned)nblk(nMax / 20 + 1, 256), B), dim3(256), 0, ctx->stream, dArgs);
+        hipLaunchKernelGGL(k_cf_run_bounds, dim3(gxN, B), dim3(256), 0, ctx->stream, dArgs);
+    }
+    hipLaunchKernelGGL(k_cf_runs_build, dim3(1, B), dim3(CF_MAXRUN), 0, ctx->stream, dArgs);
+    if (anyLsd) {
         rc = canvas_side_init(ctx); if (rc) return rc;
         if (!ctx->side_ev2) CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_ev2, hipEventDisableTiming));
         CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
-        hipLaunchKernelGGL(k_run_mad, dim3(CF_MAXRUN), dim3(1024), 0, ctx->side, dSd, dRunStart, dRunMad, &D->nruns);
+        hipLaunchKernelGGL(k_cf_run_mad, dim3(CF_MAXRUN, B), dim3(1024), 0, ctx->side, dArgs);
     }
     // ---- GC strip decision, grouping, NormalizeByGC
-    hipLaunchKernelGGL(k_cf_dec_gc, dim3(1), dim3(128), 0, ctx->stream, flags, min_bins_per_gc, D);
+    hipLaunchKernelGGL(k_cf_dec_gc, dim3(1, B), dim3(128), 0, ctx->stream, dArgs);
     if (flags & CANVAS_CLEAN_GCNORM) {
-        hipLaunchKernelGGL(k_cf_group_keys, dim3(nb), dim3(256), 0, ctx->stream, S1.chr, S1.gc, S1.count, dIsAuto, n, D, keysG);
-        hipLaunchKernelGGL(k_cf_sel_setup, dim3(1), dim3(128), 0, ctx->stream, 0, 0, D, P + 0, dTiles);
-        cf_select_passes(ctx, keysG, dTiles, P + 0, n);
-        hipLaunchKernelGGL(k_cf_dec_e, dim3(1), dim3(128), 0, ctx->stream, P + 0, D);
-        hipLaunchKernelGGL(k_cf_apply_gc, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, S1.count, S1.gc, n, D, P + 0);
-        if (wantLsd && n > 500000) {
+        hipLaunchKernelGGL(k_cf_group_keys, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
+        cf_gcnorm_and_compact(ctx, dArgs, B, gxN, gxB, gxT, 1, 0, 0, true);
+        if (anyVar) {
             // NormalizeVarianceByGC (CanvasClean.cs:512-519): quartiles of the normalised counts; if it changes anything, NormalizeByGC once more
-            hipLaunchKernelGGL(k_cf_sel_setup, dim3(1), dim3(128), 0, ctx->stream, 1, 1, D, P + 1, dTiles + tilesUpper);
-            hipLaunchKernelGGL(k_cf_xform_gc, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, keysG, D, P + 1);
-            cf_select_passes(ctx, keysG, dTiles + tilesUpper, P + 1, n);
-            hipLaunchKernelGGL(k_cf_dec_f, dim3(1), dim3(128), 0, ctx->stream, P + 1, D);
-            // ... which it rarely does: the last compaction below is enqueued on the assumption that it does not; when k_cf_dec_f says it did, that compaction does nothing
-            // and clean_device_driven_finish enqueues the variance scaling, the second NormalizeByGC and the compaction (one more synchronisation, in that case only)
+            hipLaunchKernelGGL(k_cf_sel_setup, dim3(1, B), dim3(128), 0, ctx->stream, dArgs, 2, 1, 1);
+            hipLaunchKernelGGL(k_cf_xform_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, B), dim3(256), 0, ctx->stream, dArgs, 2);
+            cf_select_passes(ctx, dArgs, B, gxT, 2);
+            hipLaunchKernelGGL(k_cf_dec_f, dim3(1, B), dim3(128), 0, ctx->stream, dArgs, 2);
+            // ... which it rarely does: the last compaction below is enqueued on the assumption that it does not; when k_cf_dec_f says it did, that compaction does nothing for
+            // the sample and clean_batch_finish enqueues the variance scaling, the second NormalizeByGC and the compaction for it (one more synchronisation, in that case only)
         }
     }
     // ---- local-SD average, last compaction into the caller's arrays
-    if (wantLsd) {
+    if (anyLsd) {
         CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev2, ctx->side));
         CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev2, 0));
     }
-    hipLaunchKernelGGL(k_cf_lsd_avg, dim3(1), dim3(64), 0, ctx->stream, dRunMad, D);
-    hipLaunchKernelGGL(k_cf_flags_final, dim3(nb), dim3(256), 0, ctx->stream, S1.gc, S1.dev, n, D, dFlags, dBlk);
-    hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, dBlk, D, &D->nFinal);
-    hipLaunchKernelGGL(k_cf_scatter_final, dim3(nb), dim3(256), 0, ctx->stream, dFlags, dBlk, n, S1, caller, D, 0);
-    rc = canvas_pin_reserve(ctx, sizeof(CleanDev)); if (rc) return rc;
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, D, sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
-    CleanPending pend{n, nb, tilesUpper, S1, caller, dFlags, dBlk, keysG, dTiles, P, D};
-    ctx->clean_pending.assign((const char*)&pend, (const char*)&pend + sizeof pend);
+    hipLaunchKernelGGL(k_cf_lsd_avg, dim3(1, B), dim3(64), 0, ctx->stream, dArgs);
+    hipLaunchKernelGGL(k_cf_flags_final, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
+    hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1, B), dim3(1024), 0, ctx->stream, dArgs, 1);
+    hipLaunchKernelGGL(k_cf_scatter_final, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs, 0);
+    rc = canvas_pin_reserve(ctx, (size_t)B * sizeof(CleanDev)); if (rc) return rc;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, dD, (size_t)B * sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->clean_batch = std::make_shared<CleanPending>(std::move(pend));
     return CANVAS_OK;
 }
-// returns CANVAS_OK and sets *handled = false when the host-driven path has to take over (nothing was modified)
-static int32_t clean_device_driven_finish(canvas_ctx* ctx, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, bool* handled) {
-    *handled = false;
+// Waits for the batch.  handled[s] = false: the host-driven path has to take sample s over (nothing of it was modified).  Per-sample outputs as canvas_clean2.
+static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, char* handled) {
+    std::shared_ptr<CleanPending> pp = std::static_pointer_cast<CleanPending>(ctx->clean_batch);
+    ctx->clean_batch.reset();
+    if (!pp) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_clean: no pending batch");
+    const CleanPending& q = *pp;
+    const int B = q.B;
+    for (int s = 0; s < B; s++) handled[s] = 0;
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());
-    if (((const CleanDev*)ctx->pin)->changed && !((const CleanDev*)ctx->pin)->fallback && !((const CleanDev*)ctx->pin)->bad && ctx->clean_pending.size() == sizeof(CleanPending)) {
-        // NormalizeVarianceByGC changed the counts (CanvasClean.cs:512-519): scale them, NormalizeByGC again on the new counts, then the last compaction
-        CleanPending q; memcpy(&q, ctx->clean_pending.data(), sizeof q);
-        const int64_t n = q.n;
-        hipLaunchKernelGGL(k_cf_apply_var, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, q.S1.count, q.S1.gc, n, q.D);
-        hipLaunchKernelGGL(k_cf_xform_var, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, q.keysG, q.D);
-        hipLaunchKernelGGL(k_cf_sel_setup, dim3(1), dim3(128), 0, ctx->stream, 0, 2, q.D, q.P + 2, q.dTiles + 2 * (size_t)q.tilesUpper);
-        cf_select_passes(ctx, q.keysG, q.dTiles + 2 * (size_t)q.tilesUpper, q.P + 2, n);
-        hipLaunchKernelGGL(k_cf_dec_e, dim3(1), dim3(128), 0, ctx->stream, q.P + 2, q.D);
-        hipLaunchKernelGGL(k_cf_apply_gc, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, q.S1.count, q.S1.gc, n, q.D, q.P + 2);
-        hipLaunchKernelGGL(k_cf_flags_final, dim3(q.nb), dim3(256), 0, ctx->stream, q.S1.gc, q.S1.dev, n, q.D, q.dFlags, q.dBlk);
-        hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, q.dBlk, q.D, &q.D->nFinal);
-        hipLaunchKernelGGL(k_cf_scatter_final, dim3(q.nb), dim3(256), 0, ctx->stream, q.dFlags, q.dBlk, n, q.S1, q.caller, q.D, 1);
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, q.D, sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
+    bool again = false;
+    for (int s = 0; s < B; s++) {
+        const CleanDev& H = ((const CleanDev*)ctx->pin)[s];
+        if (!(H.changed && !H.fallback && !H.bad)) continue;
+        // NormalizeVarianceByGC changed the counts of this sample (CanvasClean.cs:512-519): scale them, NormalizeByGC again on the new counts, then the last compaction
+        const CfArgs* a = q.dArgs + s;
+        const unsigned gxN = (unsigned)nblk(q.h[s].n, 256), gxB = (unsigned)nblk(q.h[s].n, CBLK), gxT = q.h[s].tilesUpper;
+        hipLaunchKernelGGL(k_cf_apply_var, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_cf_xform_var, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a);
+        cf_gcnorm_and_compact(ctx, a, 1, gxN, gxB, gxT, 3, 2, 1, true);
+        hipLaunchKernelGGL(k_cf_flags_final, dim3(gxB, 1), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1, 1), dim3(1024), 0, ctx->stream, a, 1);
+        hipLaunchKernelGGL(k_cf_scatter_final, dim3(gxB, 1), dim3(256), 0, ctx->stream, a, 1);
+        again = true;
+    }
+    if (again) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, q.dD, (size_t)B * sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
     }
-    ctx->clean_pending.clear();
-    const CleanDev& H = *(const CleanDev*)ctx->pin;
-    if (H.bad) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: a bin has gc outside 0..100 or a chromosome index outside [0, nchr) (the reference throws IndexOutOfRangeException)");
-    if (H.fallback) return CANVAS_OK;                                  // *handled stays false: nothing was written to the caller's arrays
-    *handled = true;
-    *h_n_out = (int64_t)H.nFinal;
-    if (h_local_sd_out) *h_local_sd_out = H.haveLocalSd ? H.localSd : -1.0;
-    if (h_info) {
-        int32_t info[8] = {0};
-        info[0] = (int32_t)H.nA; info[1] = (int32_t)H.nAB; info[2] = (int32_t)(H.gcActive ? H.kept : (long long)H.nAB); info[3] = (int32_t)H.nFinal; info[4] = H.changed;
-        memcpy(h_info, info, sizeof info);
+    for (int s = 0; s < B; s++) {
+        const CleanDev& H = ((const CleanDev*)ctx->pin)[s];
+        if (H.bad) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: a bin has gc outside 0..100 or a chromosome index outside [0, nchr) (the reference throws IndexOutOfRangeException)");
+        if (H.fallback) continue;                                          // handled[s] stays 0: nothing was written to the caller's arrays
+        handled[s] = 1;
+        h_n_out[s] = (int64_t)H.nFinal;
+        if (h_local_sd_out) h_local_sd_out[s] = H.haveLocalSd ? H.localSd : -1.0;
+        if (h_info) {
+            int32_t info[8] = {0};
+            info[0] = (int32_t)H.nA; info[1] = (int32_t)H.nAB; info[2] = (int32_t)(H.gcActive ? H.kept : (long long)H.nAB); info[3] = (int32_t)H.nFinal; info[4] = H.changed;
+            memcpy(h_info + 8 * s, info, sizeof info);
+        }
     }
     return CANVAS_OK;
 }
+// one sample = a batch of one
 static int32_t clean_device_driven(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count, int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome,
                                    uint32_t flags, int32_t min_bins_per_gc, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, bool* handled) {
     *handled = false;
-    int32_t rc = clean_device_driven_enqueue(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc); if (rc) return rc;
-    return clean_device_driven_finish(ctx, h_local_sd_out, h_n_out, h_info, handled);
+    int32_t rc = clean_batch_enqueue(ctx, 1, &n, &d_chr, &d_start, &d_stop, &d_count, &d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc); if (rc) return rc;
+    char h = 0; double lsd = -1.0; int64_t nOut = 0; int32_t info[8] = {0};
+    rc = clean_batch_finish(ctx, &lsd, &nOut, info, &h); if (rc) return rc;
+    if (h) { *handled = true; *h_n_out = nOut; if (h_local_sd_out) *h_local_sd_out = lsd; if (h_info) memcpy(h_info, info, sizeof info); }
+    return CANVAS_OK;
 }

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/canvas_hip.h"
@@ -22,7 +23,7 @@ struct canvas_ctx {
     size_t pin_bytes = 0;
     // side stream for work that is off the critical path (per-chromosome MAD of CanvasClean), its fork event and a pinned result buffer
     hipStream_t side = nullptr;
-    hipEvent_t side_ev = nullptr, side_ev2 = nullptr, batch_ev = nullptr;
+    hipEvent_t side_ev = nullptr, side_ev2 = nullptr;
     double* side_pin = nullptr;        // 65536 results + 65544 int64 run starts
     // persistent scratch of the radix select (select.hpp): device blob and pinned staging blob
     void* sel_ws = nullptr; size_t sel_ws_bytes = 0;
@@ -39,8 +40,7 @@ struct canvas_ctx {
     std::vector<const void*> up_bases, up_mask, up_hits;
     bool up_active = false;
     void* gc_arena = nullptr; size_t gc_arena_bytes = 0;   // GCContentWeighted binning: read-GC profile of every position + GC prefix array (grow-only)
-    std::vector<char> clean_pending;     // clean_fast.hpp: what the second phase of the device-driven CanvasClean needs (set by enqueue, consumed by finish)
-    std::vector<canvas_ctx*> children;   // contexts of canvas_clean_batch: one stream + workspace per sample in flight
+    std::shared_ptr<void> clean_batch;   // clean_fast.hpp: the batch that clean_batch_enqueue queued (consumed by clean_batch_finish)
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
     // host-callback transport of the collectives (canvas_comm_init_host): used when the ranks cannot form an RCCL communicator

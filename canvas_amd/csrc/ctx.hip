@@ -24,8 +24,6 @@ canvas_ctx* canvas_create(int device) {
 
 void canvas_destroy(canvas_ctx* ctx) {
     if (!ctx) return;
-    for (canvas_ctx* ch : ctx->children) canvas_destroy(ch);
-    ctx->children.clear();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
@@ -34,7 +32,6 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->up_fence) (void)hipEventDestroy(ctx->up_fence);
     if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
     if (ctx->side_ev2) (void)hipEventDestroy(ctx->side_ev2);
-    if (ctx->batch_ev) (void)hipEventDestroy(ctx->batch_ev);
     if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gc_arena) (void)hipFree(ctx->gc_arena);
