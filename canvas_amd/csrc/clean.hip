@@ -194,10 +194,7 @@ __global__ void __launch_bounds__(256) k_apply_var(float* __restrict__ count, co
 // ---------------------------------------------------------------- local SD (CanvasClean.cs:268-298)
 // one thread per window of 20 consecutive count differences; sequential double arithmetic exactly as
 // Utilities.StandardDeviation(double[], start, end) (Utilities.cs:246-262)
-__device__ __forceinline__ void local_sd_body(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev, const unsigned long long* __restrict__ dN) {
-    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (dN) { const int64_t D = (int64_t)*dN - 1; nW = D >= 1 ? (D - 1) / 20 : 0; }      // the bin count is still on the device: grid = upper bound
-    if (w >= nW) return;
+__device__ __forceinline__ void local_sd_window(const float* __restrict__ count, int64_t w, double* __restrict__ sd, double* __restrict__ dev) {
     int64_t s = w * 20;
     double d[20];
     float prev = count[s];
@@ -214,6 +211,12 @@ __device__ __forceinline__ void local_sd_body(const float* __restrict__ count, i
     sd[w] = v;
 #pragma unroll
     for (int k = 0; k < 20; k++) dev[s + k] = v;
+}
+__device__ __forceinline__ void local_sd_body(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev, const unsigned long long* __restrict__ dN) {
+    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (dN) { const int64_t D = (int64_t)*dN - 1; nW = D >= 1 ? (D - 1) / 20 : 0; }      // the bin count is still on the device: grid = upper bound
+    if (w >= nW) return;
+    local_sd_window(count, w, sd, dev);
 }
 __global__ void __launch_bounds__(256) k_local_sd(const float* __restrict__ count, int64_t nW, double* __restrict__ sd, double* __restrict__ dev, const unsigned long long* __restrict__ dN = nullptr) {
     local_sd_body(count, nW, sd, dev, dN);

@@ -136,9 +136,13 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
     __shared__ uint8_t sA[CBLK];                          // keepA, chromosome and count of this block's bins: the neighbour search reads them from LDS
     __shared__ int32_t sChr[CBLK];
     __shared__ float sCnt[CBLK];
+    __shared__ uint8_t sGc[CBLK];
+    __shared__ uint32_t lh[2 * NGC];                      // GC histogram of the survivors (CanvasClean.cs:207-223): [0..100] autosomal, [101..201] the others
     const int64_t n = A.n;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
+    if (threadIdx.x < 2 * NGC) lh[threadIdx.x] = 0;
+    const uint8_t* __restrict__ isAuto = A.isAuto;
     const int32_t* __restrict__ chr = A.caller.chr; const int32_t* __restrict__ start = A.caller.start; const int32_t* __restrict__ stop = A.caller.stop;
     const int32_t* __restrict__ gc = A.caller.gc; const float* __restrict__ count = A.caller.count;
     uint8_t* __restrict__ flags = A.dFlags; CleanDev* __restrict__ D = A.D;
@@ -149,13 +153,13 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) {
         const int64_t i = base + j * 256 + threadIdx.x;
-        uint8_t a = 0; int32_t c = -1; float v = 0.0f;
+        uint8_t a = 0; int32_t c = -1; float v = 0.0f; int32_t g = 0;
         if (i < n) {
-            c = chr[i]; v = count[i];
-            if ((uint32_t)gc[i] > 100u || (uint32_t)c >= (uint32_t)nchr) bad = 1;
+            c = chr[i]; v = count[i]; g = gc[i];
+            if ((uint32_t)g > 100u || (uint32_t)c >= (uint32_t)nchr) bad = 1;
             a = (!doSize || (stop[i] - start[i]) <= thresh) ? 1 : 0;
         }
-        sA[j * 256 + threadIdx.x] = a; sChr[j * 256 + threadIdx.x] = c; sCnt[j * 256 + threadIdx.x] = v;
+        sA[j * 256 + threadIdx.x] = a; sChr[j * 256 + threadIdx.x] = c; sCnt[j * 256 + threadIdx.x] = v; sGc[j * 256 + threadIdx.x] = (uint8_t)((uint32_t)g > 100u ? 100 : g);
         nSize += a;
     }
     __syncthreads();
@@ -183,12 +187,17 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
         }
         flags[i] = keep;
         nKeep += keep;
+        if (keep) {                                       // out-of-range input is reported through D->bad and nothing is returned: clamped here so that no table is overrun
+            const int32_t c0 = sChr[j * 256 + threadIdx.x], c = (uint32_t)c0 >= (uint32_t)nchr ? 0 : c0;
+            atomicAdd(&lh[(isAuto[c] ? 0 : NGC) + sGc[j * 256 + threadIdx.x]], 1u);
+        }
     }
     nKeep = wave_reduce_add_u32(nKeep); nSize = wave_reduce_add_u32(nSize);
     if (lane_id() == 0) { sh[threadIdx.x >> 6] = nKeep; sh[4 + (threadIdx.x >> 6)] = nSize; }
     if (bad) D->bad = 1u;
     __syncthreads();
     if (threadIdx.x == 0) { A.dBlk[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; atomicAdd(&D->nA, sh[4] + sh[5] + sh[6] + sh[7]); }
+    if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&D->hist[threadIdx.x], lh[threadIdx.x]);
 }
 // exclusive scan of the block counts: phase 0 over the blocks of the input (total -> nAB), phase 1 over the blocks of the nAB surviving bins (total -> nFinal)
 __global__ void __launch_bounds__(1024) k_cf_scan_blocks(const CfArgs* __restrict__ AA, int phase) {
@@ -212,19 +221,25 @@ __global__ void __launch_bounds__(1024) k_cf_scan_blocks(const CfArgs* __restric
     }
     if (threadIdx.x == 0) { if (phase == 0) A.D->nAB = carry; else A.D->nFinal = carry; }
 }
-// the compaction itself: caller's arrays -> scratch SoA, CountDeviation = -1 (GenomicBin.cs:83), and the GC histogram of what survives (CanvasClean.cs:207-223)
+// the compaction itself: caller's arrays -> scratch SoA, and — the GC strip is decided by then (k_cf_dec_gc) — the order-preserving keys of the autosomal survivors with a kept GC
+// value, grouped by GC (order inside a bucket is irrelevant: only order statistics are taken).  CountDeviation is written by k_cf_local_sd (or never read).
 __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ uint32_t sh[4];
-    __shared__ uint32_t lh[2 * NGC];
+    __shared__ uint32_t lcnt[NGC], lbase[NGC];
+    __shared__ uint8_t sKeepGc[NGC];
     const int64_t n = A.n;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
     const uint8_t* __restrict__ flags = A.dFlags; const uint8_t* __restrict__ isAuto = A.isAuto;
     const Soa src = A.caller, dst = A.S1; const int nchr = A.nchr;
-    if (threadIdx.x < 2 * NGC) lh[threadIdx.x] = 0;
+    CleanDev* __restrict__ D = A.D;
+    const bool group = D->gcActive != 0;
+    if (threadIdx.x < NGC) { lcnt[threadIdx.x] = 0; sKeepGc[threadIdx.x] = D->keepGc[threadIdx.x]; }
     __syncthreads();
     uint32_t running = A.dBlk[blockIdx.x];
+    uint32_t myRank[CBLK / 256], myKey[CBLK / 256]; int myGc[CBLK / 256];
+#pragma unroll
     for (int j = 0; j < CBLK / 256; j++) {
         const int64_t i = base + j * 256 + threadIdx.x;
         const uint32_t f = (i < n) ? flags[i] : 0;
@@ -233,36 +248,48 @@ __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict_
         __syncthreads();
         uint32_t woff = 0, tot = 0;
         for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) woff += sh[k]; tot += sh[k]; }
+        myGc[j] = -1;
         if (f) {
             const uint32_t d = running + woff + inc - 1;
             // out-of-range input is reported through D->bad (k_cf_flags_ab) and nothing is returned; the scratch copy holds clamped values so that no later kernel indexes past a table
             const int32_t c0 = src.chr[i], g0 = src.gc[i];
             const int32_t g = (uint32_t)g0 > 100u ? 100 : g0, c = (uint32_t)c0 >= (uint32_t)nchr ? 0 : c0;
-            dst.chr[d] = c; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = g; dst.count[d] = src.count[i]; dst.dev[d] = -1.0;
-            atomicAdd(&lh[(isAuto[c] ? 0 : NGC) + g], 1u);
+            const float v = src.count[i];
+            dst.chr[d] = c; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = g; dst.count[d] = v;
+            if (group && isAuto[c] && sKeepGc[g]) { myGc[j] = g; myKey[j] = key_of_float(v); myRank[j] = atomicAdd(&lcnt[g], 1u); }
         }
         running += tot;
         __syncthreads();
     }
-    if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&A.D->hist[threadIdx.x], lh[threadIdx.x]);
+    if (!group) return;
+    if (threadIdx.x < NGC && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&D->cursor[threadIdx.x], lcnt[threadIdx.x]);
+    __syncthreads();
+    uint32_t* __restrict__ keysG = A.keysG;
+#pragma unroll
+    for (int j = 0; j < CBLK / 256; j++) if (myGc[j] >= 0) keysG[D->segOff[myGc[j]] + lbase[myGc[j]] + myRank[j]] = myKey[j];
 }
 
 // ---------------------------------------------------------------- local SD (CanvasClean.cs:243-298)
+// one thread per window of 20 count differences (Utilities.StandardDeviation, CanvasClean.cs:262-298) + the chromosome boundaries among the window's bins (the run records that
+// GetLocalStandardDeviationAverage's per-chromosome grouping needs) + CountDeviation = -1 (GenomicBin.cs:83) for the bins behind the last window
 __global__ void __launch_bounds__(256) k_cf_local_sd(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     if (!A.wantLsd) return;
-    local_sd_body(A.S1.count, 0, A.dSd, A.S1.dev, &A.D->nAB);
-}
-__global__ void __launch_bounds__(256) k_cf_run_bounds(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    if (!A.wantLsd) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)A.D->nAB) return;
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nAB = (int64_t)A.D->nAB, Dn = nAB - 1, nW = Dn >= 1 ? (Dn - 1) / 20 : 0;
+    if (w > nW) return;
+    const int64_t lo = w * 20, hi = w < nW ? lo + 20 : nAB;             // thread nW takes the tail
+    if (w < nW) local_sd_window(A.S1.count, w, A.dSd, A.S1.dev);
+    else for (int64_t i = lo; i < hi; i++) A.S1.dev[i] = -1.0;
     const int32_t* __restrict__ chr = A.S1.chr;
-    const int32_t c = chr[i];
-    if (i == 0 || c != chr[i - 1]) { const unsigned int k = atomicAdd(&A.D->nRunRec, 1u); if (k < 65536u) A.dPos[k] = (long long)((i << 20) | (long long)(c & 0xFFFFF)); }
+    int32_t prev = lo > 0 ? chr[lo - 1] : -1;
+    for (int64_t i = lo; i < hi; i++) {
+        const int32_t c = chr[i];
+        if (i == 0 || c != prev) { const unsigned int k = atomicAdd(&A.D->nRunRec, 1u); if (k < 65536u) A.dPos[k] = (long long)((i << 20) | (long long)(c & 0xFFFFF)); }
+        prev = c;
+    }
 }
-// one workgroup: sorts the (position << 20 | chromosome) records of k_cf_run_bounds, derives the runs of windows per chromosome exactly as local_sd_begin does on the host
+// one workgroup: sorts the (position << 20 | chromosome) records of k_cf_local_sd, derives the runs of windows per chromosome exactly as local_sd_begin does on the host
 __global__ void __launch_bounds__(1024) k_cf_runs_build(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ long long s[CF_MAXRUN];
@@ -349,34 +376,9 @@ __global__ void __launch_bounds__(128) k_cf_dec_gc(const CfArgs* __restrict__ AA
     if (t == 0) {
         D->segOff[NGC] = so[NGC]; D->kept = sKept; D->gcActive = sActive; D->changed = 0;
         // NormalizeVarianceByGC runs for whole-genome samples only (CanvasClean.cs:512-519); the host enqueues its kernels when the INPUT has more than 500000 bins
-        D->varActive = (sActive && D->haveLocalSd && sKept > 500000 && (flags & CANVAS_CLEAN_LOCALSD) && A.n > 500000) ? 1 : 0;
+        const bool haveLsd = A.wantLsd && nAB >= 50000;                       // what k_cf_runs_build will store in haveLocalSd (CanvasClean.cs:483-486)
+        D->varActive = (sActive && haveLsd && sKept > 500000 && A.n > 500000) ? 1 : 0;
     }
-}
-// grouped keys of the autosomal bins with a kept GC value (order inside a bucket is irrelevant: only order statistics are taken)
-__global__ void __launch_bounds__(256) k_cf_group_keys(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ uint32_t lcnt[NGC], lbase[NGC];
-    CleanDev* __restrict__ D = A.D;
-    if (!D->gcActive) return;
-    const int64_t n = (int64_t)D->nAB;
-    const int64_t base = (int64_t)blockIdx.x * CBLK;
-    if (base >= n) return;
-    const int32_t* __restrict__ chr = A.S1.chr; const int32_t* __restrict__ gc = A.S1.gc; const float* __restrict__ count = A.S1.count;
-    const uint8_t* __restrict__ isAuto = A.isAuto; uint32_t* __restrict__ keysG = A.keysG;
-    if (threadIdx.x < NGC) lcnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t myRank[CBLK / 256]; int myGc[CBLK / 256]; uint32_t myKey[CBLK / 256];
-#pragma unroll
-    for (int j = 0; j < CBLK / 256; j++) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        myGc[j] = -1;
-        if (i < n) { const int g = gc[i]; if (isAuto[chr[i]] && D->keepGc[g]) { myGc[j] = g; myKey[j] = key_of_float(count[i]); myRank[j] = atomicAdd(&lcnt[g], 1u); } }
-    }
-    __syncthreads();
-    if (threadIdx.x < NGC && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&D->cursor[threadIdx.x], lcnt[threadIdx.x]);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < CBLK / 256; j++) if (myGc[j] >= 0) keysG[D->segOff[myGc[j]] + lbase[myGc[j]] + myRank[j]] = myKey[j];
 }
 // NormalizeByGC decision: genome median and per-GC medians from the selected keys (CanvasClean.cs:170-189)
 __global__ void __launch_bounds__(128) k_cf_dec_e(const CfArgs* __restrict__ AA, int which) {
@@ -642,12 +644,10 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     // (a one-bin-per-thread variant of the flag kernel was measured: 68 us against 53 us for the staged one)
     hipLaunchKernelGGL(k_cf_flags_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
     hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1, B), dim3(1024), 0, ctx->stream, dArgs, 0);
+    hipLaunchKernelGGL(k_cf_dec_gc, dim3(1, B), dim3(128), 0, ctx->stream, dArgs);             // the GC strip decision (the histogram of the survivors came with the flags)
     hipLaunchKernelGGL(k_cf_scatter_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
     // ---- local SD (CanvasClean.cs:243-298): window SDs and chromosome runs on the main stream, the per-run MAD on the side stream
-    if (anyLsd) {
-        hipLaunchKernelGGL(k_cf_local_sd, dim3((unsigned)nblk(nMax / 20 + 1, 256), B), dim3(256), 0, ctx->stream, dArgs);
-        hipLaunchKernelGGL(k_cf_run_bounds, dim3(gxN, B), dim3(256), 0, ctx->stream, dArgs);
-    }
+    if (anyLsd) hipLaunchKernelGGL(k_cf_local_sd, dim3((unsigned)nblk(nMax / 20 + 2, 256), B), dim3(256), 0, ctx->stream, dArgs);
     hipLaunchKernelGGL(k_cf_runs_build, dim3(1, B), dim3(CF_MAXRUN), 0, ctx->stream, dArgs);
     if (anyLsd) {
         rc = canvas_side_init(ctx); if (rc) return rc;
@@ -656,10 +656,8 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
         hipLaunchKernelGGL(k_cf_run_mad, dim3(CF_MAXRUN, B), dim3(1024), 0, ctx->side, dArgs);
     }
-    // ---- GC strip decision, grouping, NormalizeByGC
-    hipLaunchKernelGGL(k_cf_dec_gc, dim3(1, B), dim3(128), 0, ctx->stream, dArgs);
+    // ---- NormalizeByGC on the grouped keys the compaction left
     if (flags & CANVAS_CLEAN_GCNORM) {
-        hipLaunchKernelGGL(k_cf_group_keys, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
         cf_gcnorm_and_compact(ctx, dArgs, B, gxN, gxB, gxT, 1, 0, 0, true);
         if (anyVar) {
             // NormalizeVarianceByGC (CanvasClean.cs:512-519): quartiles of the normalised counts; if it changes anything, NormalizeByGC once more
