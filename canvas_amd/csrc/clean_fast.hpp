@@ -14,7 +14,9 @@
 
 #define CF_MAXQ 640          // 6 + 6 * 101 quartile queries (variance normalisation); 2 + 2 * 101 median queries
 #define CF_MAXRUN 1024       // chromosome runs of the bin list handled on the device
-#define CF_NPROB 4           // select problems of a sample: [0] size percentile, [1] medians, [2] quartiles, [3] medians after the variance normalisation
+#define CF_NPROB 4           // select problems of a sample: [1] medians, [2] quartiles, [3] medians after the variance normalisation ([0] unused)
+#define CF_SZ_BINS 65536     // bin sizes counted exactly (a larger 98th percentile hands the sample to the host-driven path)
+#define CF_SZ_LDS 4096       // ... of which the first CF_SZ_LDS are counted in LDS per workgroup (WGS bins are a few hundred to a few thousand positions)
 
 struct CleanDev {
     unsigned long long nAB;          // bins after RemoveBigBins + RemoveOutliers
@@ -23,6 +25,10 @@ struct CleanDev {
     unsigned int bad;                // a gc outside 0..100 or a chromosome index outside the table
     unsigned int fallback;           // not covered on the device: the host-driven path takes over (the caller's arrays are untouched)
     unsigned int nRunRec;
+    unsigned int sizeOn;             // RemoveBigBins applies (the filter is switched on and the percentile index lies inside the list)
+    int32_t sizeThresh;              // its threshold (CanvasClean.cs:328-348)
+    unsigned long long sizeBelow;    // bins with a negative size (they sort in front of every counted size)
+    unsigned int nOver, pad1;        // bins of CF_SZ_BINS positions and more (kept in a list: the percentile is taken from it when it lies that far out)
     uint32_t hist[2 * NGC];          // [0..100] autosomal bins per GC, [101..201] the other bins (after the first compaction)
     uint32_t segOff[NGC + 1];        // grouped autosomal bins of the kept GC values
     uint32_t cursor[NGC];
@@ -45,39 +51,96 @@ struct CfArgs {                      // one sample of the batch
     int32_t nb, nchr, minBinsPerGc, wantLsd, doSize, doOutlier;
     uint32_t flags, tilesUpper;
     Soa caller, S1;                  // the caller's arrays; the scratch copy between the two compactions
-    uint8_t* dFlags; uint32_t* dBlk; uint32_t* keys32; uint32_t* keysG; const uint8_t* isAuto;
+    uint8_t* dFlags; uint32_t* dBlk; uint32_t* szHist; uint32_t* szOver; uint32_t szOverCap, padA; uint32_t* keysG; const uint8_t* isAuto;
     double* dSd; double* dRunMad; int64_t* dRunStart; long long* dPos;
     CleanDev* D; CfSel* P; SelTile* tiles; uint32_t* hist;
 };
 #define CF_SAMPLE const CfArgs& A = AA[blockIdx.y]
 
-// ---------------------------------------------------------------- RemoveBigBins threshold (CanvasClean.cs:328-348): keys of the bin sizes
-__global__ void __launch_bounds__(256) k_cf_keys_size(const CfArgs* __restrict__ AA) {
+// ---------------------------------------------------------------- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes
+// Sizes are small integers, so the order statistic is read off an exact count per size (one sweep of start / stop, no key array, no radix passes): sizes below CF_SZ_LDS are
+// counted in LDS per workgroup and flushed, sizes up to CF_SZ_BINS go to the global counters directly, larger ones only matter if the percentile itself is that large.
+#define CF_SZ_GRID 128       // workgroups per sample in the size count: each takes n / 128 bins, so its LDS counters absorb many bins per distinct size before the flush
+__global__ void __launch_bounds__(1024) k_cf_size_hist(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
+    __shared__ uint32_t lh[CF_SZ_LDS];
     if (!A.doSize) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < A.n) A.keys32[i] = (uint32_t)(A.caller.stop[i] - A.caller.start[i]) ^ 0x80000000u;   // order-preserving image of int32
+    const int64_t n = A.n;
+    for (int i = threadIdx.x; i < CF_SZ_LDS; i += 1024) lh[i] = 0;
+    __syncthreads();
+    const int32_t* __restrict__ start = A.caller.start; const int32_t* __restrict__ stop = A.caller.stop;
+    uint32_t neg = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)CF_SZ_GRID * 1024) {
+        const int32_t sz = stop[i] - start[i];
+        if (sz < 0) neg++;
+        else if (sz < CF_SZ_LDS) atomicAdd(&lh[sz], 1u);
+        else if (sz < CF_SZ_BINS) atomicAdd(&A.szHist[sz], 1u);
+        else { const unsigned int k = atomicAdd(&A.D->nOver, 1u); if (k < A.szOverCap) A.szOver[k] = (uint32_t)sz; }
+    }
+    neg = wave_reduce_add_u32(neg);
+    if (lane_id() == 0 && neg) atomicAdd(&A.D->sizeBelow, (unsigned long long)neg);
+    __syncthreads();
+    for (int i = threadIdx.x; i < CF_SZ_LDS; i += 1024) { const uint32_t v = lh[i]; if (v) atomicAdd(&A.szHist[i], v); }
 }
-// the select problems: mode 0 = medians (NormalizeByGC, CanvasClean.cs:163-189), mode 1 = quartiles (NormalizeVarianceByGC, :34-66), both over the grouped keys, genome + every kept
-// bucket; mode 2 = the 98th percentile of the bin sizes over keys32 (one segment, one rank).  gate: which CleanDev flag switches the problem on (0 gcActive, 1 varActive, 2 changed, 3 doSize)
+// one workgroup per sample: the size with cumulative count > index (the element at `index` of the sorted sizes)
+__global__ void __launch_bounds__(1024) k_cf_size_pick(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    __shared__ unsigned long long sTot[1024 / 64];
+    __shared__ int sFound;
+    CleanDev* __restrict__ D = A.D;
+    const int64_t index = (int64_t)(0.98 * (double)A.n);                       // CanvasClean.cs:339
+    const bool on = A.doSize && index < A.n;
+    if (!on) { if (threadIdx.x == 0) D->sizeOn = 0u; return; }
+    const unsigned long long want = (unsigned long long)index, below = D->sizeBelow;
+    if (threadIdx.x == 0) sFound = 0;
+    // the counters are scanned in two stretches of 4 x 1024 x k bins (16-byte loads): [0, CF_SZ_LDS) first — where the bins of a WGS sample are — then the rest
+    unsigned long long total = below;
+    for (int part = 0; part < 2; part++) {
+        const int lo = part == 0 ? 0 : CF_SZ_LDS, per = part == 0 ? CF_SZ_LDS / 1024 : (CF_SZ_BINS - CF_SZ_LDS) / 1024;      // 4, 60 bins per thread
+        const uint32_t* __restrict__ h = A.szHist + lo + (size_t)threadIdx.x * per;
+        unsigned long long mine = 0;
+        for (int k = 0; k < per; k += 4) { const uint4 q = *reinterpret_cast<const uint4*>(h + k); mine += (unsigned long long)q.x + q.y + q.z + q.w; }
+        unsigned long long inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if ((int)lane_id() >= d) inc += o; }
+        __syncthreads();                                                       // sTot of the previous stretch has been read by everybody
+        if (lane_id() == 63) sTot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        unsigned long long before = total, sum = 0;
+        for (int w = 0; w < 1024 / 64; w++) { if (w < (int)(threadIdx.x >> 6)) before += sTot[w]; sum += sTot[w]; }
+        before += inc - mine;
+        if (want >= before && want < before + mine) {
+            unsigned long long cum = before;
+            for (int k = 0; k < per; k++) { cum += h[k]; if (want < cum) { D->sizeThresh = lo + (int)threadIdx.x * per + k; break; } }
+            sFound = 1;
+        }
+        total += sum;
+        __syncthreads();
+        if (sFound) break;
+    }
+    if (threadIdx.x == 0) {
+        D->sizeOn = 1u;
+        if (want < below || (want >= total && D->nOver > A.szOverCap)) D->fallback = 1u;     // a negative percentile, or more large bins than the list holds: the host-driven path
+    }
+    if (!sFound && want >= total && D->nOver <= A.szOverCap) {
+        // the percentile lies among the bins of CF_SZ_BINS positions and more (a heavy tail of bins across assembly gaps): exact order statistic of the list, in this workgroup
+        __shared__ uint32_t sH[2][256];
+        __shared__ unsigned long long sPre[2], sK[2];
+        const uint32_t* __restrict__ ov = A.szOver;
+        const unsigned long long t = want - total;
+        __syncthreads();
+        wg_select2([&](int64_t i) { return (unsigned long long)ov[i]; }, 0, (int64_t)D->nOver, t, t, sH, sPre, sK);
+        if (threadIdx.x == 0) D->sizeThresh = (int32_t)(uint32_t)sPre[0];
+    }
+}
+// the select problems over the grouped keys, genome + every kept bucket: mode 0 = medians (NormalizeByGC, CanvasClean.cs:163-189), mode 1 = quartiles (NormalizeVarianceByGC, :34-66).
+// gate: which CleanDev flag switches the problem on (0 gcActive, 1 varActive, 2 changed)
 __global__ void __launch_bounds__(128) k_cf_sel_setup(const CfArgs* __restrict__ AA, int which, int mode, int gate) {
     CF_SAMPLE;
     __shared__ uint32_t so[NGC + 1], tileBase[NGC + 1];
     __shared__ int qFirst[NGC + 2];                     // first query of slot s (slot NGC = the genome, placed FIRST: queries 0 .. nrG-1), prefix sums
     const CleanDev* D = A.D; CfSel* P = A.P + which; SelTile* tiles = A.tiles + (size_t)which * A.tilesUpper;
     const int t = threadIdx.x;
-    if (mode == 2) {
-        const int64_t index = (int64_t)(0.98 * (double)A.n);                   // CanvasClean.cs:339
-        const bool on = A.doSize && index < A.n;
-        if (!on) { if (t == 0) { P->hdr[0] = 0; P->hdr[1] = 0; } return; }
-        const uint32_t nt = (uint32_t)((A.n + SEL_TILE - 1) / SEL_TILE);
-        if (t == 0) {
-            P->hdr[0] = nt; P->hdr[1] = 1; P->qk[0] = (unsigned long long)index; P->qprefix[0] = 0ull;
-            SelSegQ Q; Q.nq = 1; Q.q[0] = 0; P->segq[0] = Q;
-        }
-        for (uint32_t k = t; k < nt; k += 128) tiles[k] = SelTile{0, (int64_t)k * SEL_TILE, min<int64_t>((int64_t)(k + 1) * SEL_TILE, A.n)};
-        return;
-    }
     const bool on = gate == 0 ? D->gcActive != 0 : (gate == 1 ? D->varActive != 0 : D->changed != 0);
     if (!on) { if (t == 0) { P->hdr[0] = 0; P->hdr[1] = 0; } return; }
     if (t <= NGC) so[t] = D->segOff[t];
@@ -119,7 +182,7 @@ __global__ void __launch_bounds__(128) k_cf_sel_setup(const CfArgs* __restrict__
 __global__ void __launch_bounds__(256) k_cf_select_hist(const CfArgs* __restrict__ AA, int which, int shift, int firstPass) {
     CF_SAMPLE;
     const CfSel* P = A.P + which;
-    select_hist_body<uint32_t>(which == 0 ? A.keys32 : A.keysG, A.tiles + (size_t)which * A.tilesUpper, P->segq, P->qprefix, shift, firstPass, A.hist, CF_MAXQ, P->hdr);
+    select_hist_body<uint32_t>(A.keysG, A.tiles + (size_t)which * A.tilesUpper, P->segq, P->qprefix, shift, firstPass, A.hist, CF_MAXQ, P->hdr);
 }
 __global__ void __launch_bounds__(64) k_cf_select_pick(const CfArgs* __restrict__ AA, int which, int firstPass) {
     CF_SAMPLE;
@@ -147,8 +210,8 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
     const int32_t* __restrict__ gc = A.caller.gc; const float* __restrict__ count = A.caller.count;
     uint8_t* __restrict__ flags = A.dFlags; CleanDev* __restrict__ D = A.D;
     const int nchr = A.nchr, doOutlier = A.doOutlier;
-    const bool doSize = A.P[0].hdr[1] != 0;               // the size problem is switched off when the filter is, or when the percentile index falls past the end
-    const int32_t thresh = doSize ? (int32_t)((uint32_t)A.P[0].qprefix[0] ^ 0x80000000u) : 0;
+    const bool doSize = D->sizeOn != 0;                   // off when the filter is, or when the percentile index falls past the end
+    const int32_t thresh = doSize ? D->sizeThresh : 0;
     uint32_t nKeep = 0, nSize = 0, bad = 0;
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) {
@@ -595,13 +658,13 @@ static void cf_gcnorm_and_compact(canvas_ctx* ctx, const CfArgs* args, int B, un
 static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t* const* d_chr, int32_t* const* d_start, int32_t* const* d_stop, float* const* d_count, int32_t* const* d_gc,
                                    int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc) {
     WsSizer sz;
-    sz.take<CleanDev>(B); sz.take<CfArgs>(B); sz.take<uint8_t>(nchr);
+    sz.take<CleanDev>(B); sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<uint32_t>((size_t)B * CF_SZ_BINS);
     int64_t nMax = 0; bool anyLsd = false, anyVar = false;
     for (int s = 0; s < B; s++) {
         const int64_t n = h_n[s], nW0 = n / 20 + 2, nb = nblk(n, CBLK); const size_t tilesUpper = (size_t)(n / SEL_TILE + NGC + 1);
         nMax = std::max(nMax, n);
         sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n);
-        sz.take<uint8_t>(n); sz.take<uint32_t>(2 * (nb + 2)); sz.take<uint32_t>(n); sz.take<uint32_t>(n); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
+        sz.take<uint8_t>(n); sz.take<uint32_t>(2 * (nb + 2)); sz.take<uint32_t>(n); sz.take<uint32_t>(n / 8 + 1024); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
         sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CfSel>(CF_NPROB); sz.take<SelTile>(tilesUpper * CF_NPROB);
     }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
@@ -612,7 +675,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->sel_hist, 0, ctx->sel_hist_bytes, ctx->stream));       // zero once: k_select_pick clears every row it has read
     }
     WsCarver ws(ctx->ws);
-    CleanDev* dD = ws.take<CleanDev>(B); CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr);
+    CleanDev* dD = ws.take<CleanDev>(B); CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS);
     CleanPending pend; pend.B = B; pend.dArgs = dArgs; pend.dD = dD; pend.h.resize(B);
     unsigned gxT = 1;
     for (int s = 0; s < B; s++) {
@@ -623,10 +686,10 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         A.doSize = (flags & CANVAS_CLEAN_FILTSIZE) ? 1 : 0; A.doOutlier = (flags & CANVAS_CLEAN_OUTLIERS) ? 1 : 0;
         A.caller = Soa{d_chr[s], d_start[s], d_stop[s], d_gc[s], d_count[s], nullptr};
         A.S1.chr = ws.take<int32_t>(n); A.S1.start = ws.take<int32_t>(n); A.S1.stop = ws.take<int32_t>(n); A.S1.gc = ws.take<int32_t>(n); A.S1.count = ws.take<float>(n); A.S1.dev = ws.take<double>(n);
-        A.dFlags = ws.take<uint8_t>(n); A.dBlk = ws.take<uint32_t>(2 * (nb + 2)); A.keys32 = ws.take<uint32_t>(n); A.keysG = ws.take<uint32_t>(n);
+        A.dFlags = ws.take<uint8_t>(n); A.dBlk = ws.take<uint32_t>(2 * (nb + 2)); A.keysG = ws.take<uint32_t>(n); A.szOverCap = (uint32_t)(n / 8 + 1024); A.padA = 0; A.szOver = ws.take<uint32_t>(A.szOverCap);
         A.dSd = ws.take<double>(nW0); A.dRunMad = ws.take<double>(CF_MAXRUN + 8); A.dRunStart = ws.take<int64_t>(CF_MAXRUN + 8); A.dPos = ws.take<long long>(65536);
         A.P = ws.take<CfSel>(CF_NPROB); A.tiles = ws.take<SelTile>((size_t)tilesUpper * CF_NPROB);
-        A.isAuto = dIsAuto; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
+        A.isAuto = dIsAuto; A.szHist = dSz + (size_t)s * CF_SZ_BINS; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
         gxT = std::max(gxT, tilesUpper);
         anyLsd = anyLsd || A.wantLsd; anyVar = anyVar || (A.wantLsd && n > 500000);
     }
@@ -636,10 +699,12 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     rc = canvas_h2d_small(ctx, dIsAuto, h_chr_is_autosome, nchr); if (rc) return rc;
     rc = canvas_h2d_small(ctx, dArgs, pend.h.data(), (size_t)B * sizeof(CfArgs)); if (rc) return rc;
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dD, 0, (size_t)B * sizeof(CleanDev), ctx->stream));
-    // ---- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes, left on the device
-    if (flags & CANVAS_CLEAN_FILTSIZE) hipLaunchKernelGGL(k_cf_keys_size, dim3(gxN, B), dim3(256), 0, ctx->stream, dArgs);
-    hipLaunchKernelGGL(k_cf_sel_setup, dim3(1, B), dim3(128), 0, ctx->stream, dArgs, 0, 2, 3);
-    if (flags & CANVAS_CLEAN_FILTSIZE) cf_select_passes(ctx, dArgs, B, gxT, 0);
+    // ---- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes from exact per-size counts, left on the device
+    if (flags & CANVAS_CLEAN_FILTSIZE) {
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dSz, 0, (size_t)B * CF_SZ_BINS * 4, ctx->stream));
+        hipLaunchKernelGGL(k_cf_size_hist, dim3(CF_SZ_GRID, B), dim3(1024), 0, ctx->stream, dArgs);
+        hipLaunchKernelGGL(k_cf_size_pick, dim3(1, B), dim3(1024), 0, ctx->stream, dArgs);        // sizeOn stays 0 (the memset of the CleanDev blocks) without the filter
+    }
     // ---- size filter + outlier filter: one compaction, caller -> S1
     // (a one-bin-per-thread variant of the flag kernel was measured: 68 us against 53 us for the staged one)
     hipLaunchKernelGGL(k_cf_flags_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);

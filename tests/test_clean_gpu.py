@@ -236,3 +236,17 @@ def test_clean_batch_equals_single_calls():
             assert (samples[k][key][:m].cpu().numpy() == ex[key]).all(), (k, key)
         assert (samples[k]["count"][:m].cpu().numpy().view(np.uint32) == ex["count"].view(np.uint32)).all(), k
         assert info[k][3] == m
+
+
+@pytest.mark.parametrize("frac_huge,huge", [(0.05, 200_000), (0.015, 70_000), (0.5, 66_000)])
+def test_clean_size_percentile_among_huge_bins(frac_huge, huge):
+    """RemoveBigBins' 98th percentile (CanvasClean.cs:328-348) when it lies among bins of 65536 positions and more (the device path takes it from its list of large bins),
+    just below them, and when half the bins are that large (more than the list holds: the host-driven path takes the sample)"""
+    cv = get_canvas()
+    bins = synth.generate_bins(20260927 + 21, 90_000)
+    n = len(bins["chr"])
+    rng = np.random.RandomState(5)
+    pick = rng.rand(n) < frac_huge
+    bins["stop"] = np.where(pick, bins["start"] + huge + rng.randint(0, 5000, n), np.minimum(bins["stop"], bins["start"] + 60_000)).astype(np.int32)
+    info, exp = _run(cv, bins, ALL)
+    assert info[0] == exp["stages"][0]
