@@ -534,6 +534,16 @@ def somatic_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, devi
         cov = r["cov"].cpu().numpy()
         o["normal_bins_chr21_22_vs_oracle"] = ok
         o["median_coverage"] = float(np.median(cov))                  # a diploid bin sits at ratio 1 x 40
+        # the CBS stage at full size on the host cores (the oracle, one task per chromosome as CBSRunner.cs:62-89 does): seconds beside the GPU's, segments and RNG consumption compared
+        cores = min(os.cpu_count() or 1, 24)
+        off_h = r["chr_offset"]
+        per = [np.ascontiguousarray(cov[off_h[c]:off_h[c + 1]]) for c in range(len(off_h) - 1)]
+        t_o = time.perf_counter()
+        exp_seg, est = O.cbs_genome(per, 0.01, 10000, threads=cores)
+        o["cbs_oracle_seconds"] = round(time.perf_counter() - t_o, 3); o["cbs_oracle_threads"] = cores
+        got = r["seg_len"].cpu().numpy(); nseg_c = r["nseg"]; cst = r["cbs_stats"]
+        o["cbs_parity_vs_oracle"] = bool(all(int(nseg_c[c]) == len(exp_seg[c]) and (got[off_h[c]:off_h[c] + nseg_c[c]] == exp_seg[c]).all() for c in range(len(per)))
+                                         and int(cst[0]) == int(est[0]) and int(cst[2]) == int(est[2]) and int(cst[4]) == int(est[4]))
     return o
 
 

@@ -11,7 +11,7 @@ from canvas_amd import Canvas, synth, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIE
 
 cv = Canvas(0); cv.profile_enable(True)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
-t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}
+t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}; nbatch = 0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 while time.time() - t0 < budget:
     seed = int(rng.randint(1, 2**31 - 1)); n = int(rng.choice([3_000, 30_000, 120_000, 600_000])); nchr = int(rng.choice([1, 3, 24]))
@@ -22,7 +22,23 @@ while time.time() - t0 < budget:
     is_auto = synth.IS_AUTOSOME[:nchr]; is_y = np.zeros(nchr, np.uint8)
     ex = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, flags)
     dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(cv.device) for k, v in bins.items()}
-    n_out, lsd, info = cv.clean(dev, len(bins["chr"]), is_auto, flags)
+    if rng.rand() < 0.3:
+        # the sample as one of a cohort of 2-4 different samples through canvas_clean_batch (one launch chain for all of them); the others are checked too
+        others = []
+        for _ in range(int(rng.randint(1, 4))):
+            b2 = synth.generate_bins(int(rng.randint(1, 2**31 - 1)), int(rng.choice([3_000, 30_000, 120_000, 600_000])), nchr=nchr)
+            others.append((b2, O.clean(b2["chr"], b2["start"], b2["stop"], b2["count"], b2["gc"], is_auto, is_y, flags)))
+        devs = [dev] + [{k: torch.from_numpy(np.ascontiguousarray(v)).to(cv.device) for k, v in b2.items()} for b2, _ in others]
+        pos = int(rng.randint(0, len(devs))); devs[0], devs[pos] = devs[pos], devs[0]
+        exps = [ex] + [e for _, e in others]; exps[0], exps[pos] = exps[pos], exps[0]
+        nouts, lsds, infos = cv.clean_batch(devs, [int(d["chr"].numel()) for d in devs], is_auto, flags)
+        for d, e, no, ls in zip(devs, exps, nouts, lsds):
+            assert int(no) == len(e["chr"]) and float(ls) == e["local_sd"], ("batch", seed, n, nchr, flags)
+            assert (d["count"][:int(no)].cpu().numpy().view(np.uint32) == e["count"].view(np.uint32)).all() and (d["stop"][:int(no)].cpu().numpy() == e["stop"]).all(), ("batch", seed, n, nchr, flags)
+        nbatch += 1
+        n_out, lsd = int(nouts[pos]), float(lsds[pos])
+    else:
+        n_out, lsd, info = cv.clean(dev, len(bins["chr"]), is_auto, flags)
     assert n_out == len(ex["chr"]) and lsd == ex["local_sd"], (seed, n, nchr, flags)
     got = dev["count"][:n_out].cpu().numpy()
     assert (got.view(np.uint32) == ex["count"].view(np.uint32)).all() and (dev["start"][:n_out].cpu().numpy() == ex["start"]).all(), (seed, n, nchr, flags)
@@ -41,4 +57,4 @@ while time.time() - t0 < budget:
             assert (st[off[c]:off[c + 1]] == e).all(), ("hmm", seed, n, nchr, c)
     it += 1
 print("fallback runs by (n, nchr, noise):", sorted(fb.items()))
-print(f"soak: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s; second speculative attempts: {retries}, sequential Viterbi fallbacks: {fallbacks}")
+print(f"soak: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s; {nbatch} of them inside a cohort call; second speculative attempts: {retries}, sequential Viterbi fallbacks: {fallbacks}")
