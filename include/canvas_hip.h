@@ -164,8 +164,9 @@ int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_sta
                       int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags,
                       int32_t min_bins_per_gc, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
 /* canvas_clean2 for a cohort (CanvasRunner launches one CanvasClean per sample of a pedigree, CanvasRunner.cs:1010-1070): sample s uses h_n[s] and the device arrays
- * h_d_*[s]; the samples run concurrently, each on a stream of its own, and are all enqueued before the first synchronisation.  Outputs per sample: h_n_out[s],
- * h_local_sd_out[s] (may be NULL), h_info[8 * s ..] (may be NULL).  Results are exactly those of nsamples canvas_clean2 calls. */
+ * h_d_*[s] (1 .. 64 samples).  The MedianByGC stage is batch-native: the samples share every kernel launch (one launch chain and one wait for the whole cohort); LOESS
+ * mode and -w < 100 run sample after sample.  Outputs per sample: h_n_out[s], h_local_sd_out[s] (may be NULL), h_info[8 * s ..] (may be NULL).  Results are exactly
+ * those of nsamples canvas_clean2 calls. */
 int32_t canvas_clean_batch(canvas_ctx* ctx, int32_t nsamples, const int64_t* h_n, int32_t* const* h_d_chr, int32_t* const* h_d_start, int32_t* const* h_d_stop, float* const* h_d_count,
                            int32_t* const* h_d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc,
                            double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
