@@ -310,6 +310,10 @@ def main():
             for k in ("value", "value_incl_h2d", "value_incl_h2d_reference_resident", "value_incl_h2d_and_host_packing_of_the_hits"):
                 if k in result["packed_path"]:
                     result["packed_path"]["speedup_vs_cpu_baseline_" + k] = round(result["packed_path"][k] / result["cpu_baseline"]["value"], 2)
+            tb = result["packed_path"].get("two_bit_wire_form")
+            if tb:
+                for k in ("value_incl_h2d", "value_incl_h2d_reference_resident", "value_incl_h2d_and_host_packing_of_the_hits"):
+                    tb["speedup_vs_cpu_baseline_" + k] = round(tb[k] / result["cpu_baseline"]["value"], 2)
     host = None
     if rank == 0 and world == 1 and not args.no_somatic:
         result["somatic_flow"] = somatic_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, device)
@@ -532,6 +536,47 @@ def packed_region(args, cv, torch, host, bases, masks, hits, lens, is_auto, flag
         res["cohort_incl_h2d_two_samples_in_flight"] = {"value": round(int(rb["total"]) / t_pipe, 1), "seconds_per_sample": round(t_pipe, 5), "samples_in_flight": S2, "passes_each": k_each,
                                                          "results_identical": ok_pipe,
                                                          "note": "reference planes resident; per sample 1.54 GB of hit planes up, 168 MB of results back; the two samples' uploads share the link"}
+        # the hit planes in their two-bit wire form (0.25 B/base + the few words with four hits and more), expanded on the device behind each chromosome's transfer
+        from canvas_amd.lib import pack_hits2_host
+        W = [packed_plane_words(L) for L in lens]
+        h_lo = [torch.empty(2 * w, dtype=torch.int64, pin_memory=True) for w in W]; h_hdr = [torch.empty(2 * (w // 64), dtype=torch.int64, pin_memory=True) for w in W]
+        h_ex = [torch.empty(2 * (w // 16 + 64), dtype=torch.int64, pin_memory=True) for w in W]
+        t0 = time.perf_counter()
+        nx = [pack_hits2_host(host["hits"][c], int(lens[c]), lo=h_lo[c], hdr=h_hdr[c], extras=h_ex[c], threads=cores)[3] for c in range(len(lens))]
+        t_p2 = time.perf_counter() - t0
+
+        def one2(hits_only):
+            cv.upload_packed2_begin(lens, None if hits_only else href, dref, h_lo, h_hdr, h_ex, nx, dpl)
+            rr = cv.sample_pipeline(None, None, None, None, None, None, None, None, None, prepared=prepared)
+            m2 = int(rr["n_out"])
+            for k in ("chr", "start", "stop", "gc", "count"):
+                cv.memcpy_d2h(res_host[k], out[k], m2 * out[k].element_size())
+            cv.memcpy_d2h(res_host["cov"], cov_buf, m2 * 8); cv.memcpy_d2h(res_host["state"], state_buf, m2 * 4); cv.memcpy_d2h(res_host["seg"], seg_buf, m2 * 4)
+            return rr
+
+        def timed2(hits_only):
+            for t in dpl:
+                t.zero_()
+            one2(hits_only)
+            cv.synchronize(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                rr = one2(hits_only)
+            cv.synchronize(); torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps, rr
+
+        t2_all, r2a = timed2(False)
+        t2_hits, r2b = timed2(True)
+        m2 = int(r2b["n_out"])
+        ok2 = bool(int(r2b["total"]) == int(keep["total"]) and m2 == int(keep["n_out"]) and (res_host["seg"][:m2] == keep["seg"][:m2].cpu()).all()
+                   and (res_host["count"][:m2] == keep["cleaned"]["count"][:m2].cpu()).all())
+        b2 = sum(int(t.numel()) * 8 for t in h_lo + h_hdr) + 16 * int(sum(nx))
+        res["two_bit_wire_form"] = {"value_incl_h2d": round(int(r2a["total"]) / t2_all, 1), "seconds_per_pass_incl_h2d": round(t2_all, 5),
+                                    "value_incl_h2d_reference_resident": round(int(r2b["total"]) / t2_hits, 1), "seconds_per_pass_reference_resident": round(t2_hits, 5),
+                                    "hit_plane_bytes_over_pcie": b2, "words_with_four_hits_and_more": int(sum(nx)), "results_identical": ok2,
+                                    "host_pack_seconds_from_byte_array": round(t_p2, 4),
+                                    "value_incl_h2d_and_host_packing_of_the_hits": round(int(r2b["total"]) / (t2_hits + t_p2), 1),
+                                    "note": "hit planes as {b0, b1} per word + a per-tile header + the {b2, b3} of the words that have them (canvas_pack_hits2_host / canvas_upload_packed2_begin)"}
         res.update({"value_incl_h2d": round(int(ra["total"]) / t_all, 1), "seconds_per_pass_incl_h2d": round(t_all, 5), "h2d_bytes": nbytes,
                     "value_incl_h2d_reference_resident": round(int(rb["total"]) / t_hits, 1), "seconds_per_pass_reference_resident": round(t_hits, 5),
                     "h2d_results_identical": ok, "host_packers_agree_with_device_packer": packers_agree,

@@ -1227,6 +1227,112 @@ int32_t canvas_pack_hits_host(const uint8_t* hits, int64_t len, uint64_t* planes
     return CANVAS_OK;
 }
 
+// ---- two-bit wire format of the hit planes (bin_packed.hpp): host packer
+int32_t canvas_pack_hits2_host(const uint8_t* hits, int64_t len, uint64_t* lo_out, uint64_t* hdr_out, uint64_t* extras_out, int64_t extras_cap_words, int64_t* n_extras_out,
+                               int64_t* saturated_out, int32_t threads) {
+    if (!hits || !lo_out || !hdr_out || !extras_out || !n_extras_out || len <= 0 || extras_cap_words < 0) return CANVAS_ERR_INVALID;
+    const int64_t words = ((len + TILE - 1) / TILE) * 64, tiles = words / 64;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(pack_threads(threads, words), tiles));
+    std::vector<std::vector<uint64_t>> ext((size_t)nt);          // {b2, b3} of this thread's words that have one, in word order
+    std::vector<int64_t> sat((size_t)nt, 0);
+    auto work = [&](int t) {
+        const int64_t t0 = tiles * t / nt, t1 = tiles * (t + 1) / nt;    // whole tiles per thread: a tile's header entry has one writer
+        int64_t nsat = 0;
+        const __m128i fifteen = _mm_set1_epi8(15);
+        std::vector<uint64_t>& E = ext[t];
+        for (int64_t tile = t0; tile < t1; tile++) {
+            uint64_t xmask = 0; const uint64_t firstLocal = E.size() / 2;
+            for (int wi = 0; wi < 64; wi++) {
+                const int64_t w = tile * 64 + wi, p = w << 6;
+                uint64_t b[4] = {0, 0, 0, 0};
+                if (p + 64 <= len) {
+                    for (int q = 0; q < 4; q++) {
+                        const __m128i v = _mm_loadu_si128((const __m128i*)(hits + p + 16 * q));
+                        const __m128i c = _mm_min_epu8(v, fifteen);
+                        nsat += __builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(c, v)) ^ 0xFFFFu);
+                        b[0] |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_slli_epi16(c, 7)) << (16 * q);
+                        b[1] |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_slli_epi16(c, 6)) << (16 * q);
+                        b[2] |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_slli_epi16(c, 5)) << (16 * q);
+                        b[3] |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_slli_epi16(c, 4)) << (16 * q);
+                    }
+                } else if (p < len) {
+                    for (int i = 0; p + i < len; i++) {
+                        unsigned h = hits[p + i];
+                        if (h > 15u) { h = 15u; nsat++; }
+                        for (int k = 0; k < 4; k++) b[k] |= (uint64_t)((h >> k) & 1u) << i;
+                    }
+                }
+                lo_out[2 * w] = b[0]; lo_out[2 * w + 1] = b[1];
+                if (b[2] | b[3]) { xmask |= 1ull << wi; E.push_back(b[2]); E.push_back(b[3]); }
+            }
+            hdr_out[2 * tile] = xmask; hdr_out[2 * tile + 1] = firstLocal;       // local index: the thread's base is added below
+        }
+        sat[t] = nsat;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    int64_t total = 0; std::vector<int64_t> base((size_t)nt, 0);
+    for (int t = 0; t < nt; t++) { base[t] = total; total += (int64_t)ext[t].size() / 2; }
+    *n_extras_out = total;
+    if (saturated_out) { int64_t s2 = 0; for (int t = 0; t < nt; t++) s2 += sat[t]; *saturated_out = s2; }
+    if (total > extras_cap_words) return CANVAS_ERR_CAPACITY;
+    auto fix = [&](int t) {
+        const int64_t t0 = tiles * t / nt, t1 = tiles * (t + 1) / nt;
+        for (int64_t tile = t0; tile < t1; tile++) hdr_out[2 * tile + 1] += (uint64_t)base[t];
+        if (!ext[t].empty()) memcpy(extras_out + 2 * base[t], ext[t].data(), ext[t].size() * 8);
+    };
+    std::vector<std::thread> th2;
+    for (int t = 1; t < nt; t++) th2.emplace_back(fix, t);
+    fix(0);
+    for (auto& x : th2) x.join();
+    return CANVAS_OK;
+}
+
+// canvas_upload_packed_begin with the hit planes in their two-bit wire form: per chromosome the three pieces travel to a staging area of the context and are expanded
+// into d_hit_planes[c] on the copy stream, right behind their transfer; the chromosome's event is recorded after the expansion
+int32_t canvas_upload_packed2_begin(canvas_ctx* ctx, int32_t nchr, const int64_t* h_len, const uint64_t* const* h_ref, uint64_t* const* d_ref,
+                                    const uint64_t* const* h_lo, const uint64_t* const* h_hdr, const uint64_t* const* h_extras, const int64_t* h_n_extras, uint64_t* const* d_hit_planes) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_len || !d_ref || !h_lo || !h_hdr || !h_extras || !h_n_extras || !d_hit_planes) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_upload_packed2_begin: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy) CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    while ((int)ctx->up_ev.size() < nchr) { hipEvent_t e; CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->up_ev.push_back(e); }
+    if (!ctx->up_fence) CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->up_fence, hipEventDisableTiming));
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t need = 0;
+    for (int c = 0; c < nchr; c++) {
+        if (h_len[c] <= 0 || h_n_extras[c] < 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_upload_packed2_begin: bad chromosome");
+        const size_t words = (size_t)((h_len[c] + TILE - 1) / TILE) * 64;
+        need += al(words * 16) + al(words / 64 * 16) + al((size_t)h_n_extras[c] * 16 + 16);
+    }
+    if (need > ctx->up2_stage_bytes) {
+        if (ctx->up2_stage) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); CANVAS_HIP_TRY(ctx, hipFree(ctx->up2_stage)); ctx->up2_stage = nullptr; ctx->up2_stage_bytes = 0; }
+        CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->up2_stage, need + need / 8)); ctx->up2_stage_bytes = need + need / 8;
+    }
+    // the staging area and the destinations may still be read by work queued on the compute stream (the previous pass): the copies start after it
+    CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->up_fence, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy, ctx->up_fence, 0));
+    ctx->up_bases.assign(nchr, nullptr); ctx->up_mask.assign(nchr, nullptr); ctx->up_hits.assign(nchr, nullptr);
+    char* st = (char*)ctx->up2_stage;
+    for (int c = 0; c < nchr; c++) {
+        const size_t words = (size_t)((h_len[c] + TILE - 1) / TILE) * 64;
+        char* dLo = st; st += al(words * 16); char* dHdr = st; st += al(words / 64 * 16); char* dEx = st; st += al((size_t)h_n_extras[c] * 16 + 16);
+        if (h_ref && h_ref[c]) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_ref[c], h_ref[c], words * 16, hipMemcpyHostToDevice, ctx->copy));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dLo, h_lo[c], words * 16, hipMemcpyHostToDevice, ctx->copy));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dHdr, h_hdr[c], words / 64 * 16, hipMemcpyHostToDevice, ctx->copy));
+        if (h_n_extras[c] > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dEx, h_extras[c], (size_t)h_n_extras[c] * 16, hipMemcpyHostToDevice, ctx->copy));
+        hipLaunchKernelGGL(k_expand_hits2, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->copy, (const ulonglong2*)dLo, (const ulonglong2*)dHdr, (const ulonglong2*)dEx, (int64_t)words,
+                           (ulonglong2*)d_hit_planes[c]);
+        CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->up_ev[c], ctx->copy));
+        ctx->up_bases[c] = d_ref[c]; ctx->up_mask[c] = d_ref[c]; ctx->up_hits[c] = d_hit_planes[c];
+    }
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    ctx->up_active = true;
+    return CANVAS_OK;
+}
+
 }  // extern "C"
 
 int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,

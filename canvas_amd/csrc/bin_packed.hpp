@@ -150,3 +150,21 @@ __global__ void __launch_bounds__(256) k_pack_hits(const uint8_t* __restrict__ h
     out[2 * w] = make_ulonglong2(b[0], b[1]); out[2 * w + 1] = make_ulonglong2(b[2], b[3]);
     if (sat) atomicAdd(saturated, (unsigned long long)sat);
 }
+
+// ---------------------------------------------------------------------------------------------- two-bit wire format of the hit planes
+// At WGS depth a position with four hits or more is rare (6.6e-5 at 60x), so b2 and b3 are almost entirely zero.  Over PCIe the hit planes travel as
+//   lo        per 64 positions {u64 b0, b1}                                   16 B
+//   header    per tile (64 words) {u64 xmask, u64 xoff}: bit w of xmask = word w of the tile has a non-zero b2 or b3; xoff = index of the tile's first entry in `extras`
+//   extras    {u64 b2, b3} of the words that have one, in word order
+// = 0.25 B/base + a few MB instead of 0.5 B/base, and are expanded into the four planes on the device (one lane per word) before the sweep reads them: the expansion
+// runs on the copy stream right behind each chromosome's transfer, so everything downstream sees the planes of canvas_bin_sample_packed.
+__global__ void __launch_bounds__(256) k_expand_hits2(const ulonglong2* __restrict__ lo, const ulonglong2* __restrict__ hdr, const ulonglong2* __restrict__ extras, int64_t nwords, ulonglong2* __restrict__ planes) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    const ulonglong2 h = hdr[w >> 6];
+    const int b = (int)(w & 63);
+    ulonglong2 hi = make_ulonglong2(0, 0);
+    if ((h.x >> b) & 1ull) hi = extras[h.y + (unsigned long long)__popcll(h.x & ((1ull << b) - 1ull))];
+    planes[2 * w] = lo[w];
+    planes[2 * w + 1] = hi;
+}

@@ -37,6 +37,7 @@ struct canvas_ctx {
     hipStream_t copy = nullptr;
     std::vector<hipEvent_t> up_ev;
     hipEvent_t up_fence = nullptr;     // compute stream -> copy stream: the destinations may still be read by the previous pass
+    void* up2_stage = nullptr; size_t up2_stage_bytes = 0;      // canvas_upload_packed2_begin: the two-bit wire form of the hit planes before its expansion
     std::vector<const void*> up_bases, up_mask, up_hits;
     bool up_active = false;
     void* gc_arena = nullptr; size_t gc_arena_bytes = 0;   // GCContentWeighted binning: read-GC profile of every position + GC prefix array (grow-only)

@@ -32,6 +32,7 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->up_fence) (void)hipEventDestroy(ctx->up_fence);
     if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
     if (ctx->side_ev2) (void)hipEventDestroy(ctx->side_ev2);
+    if (ctx->up2_stage) (void)hipFree(ctx->up2_stage);
     if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gc_arena) (void)hipFree(ctx->gc_arena);

@@ -15,7 +15,7 @@ CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD, CLEAN_LOESS = 1, 2,
 ABI_SYMBOLS = [
     "canvas_create", "canvas_destroy", "canvas_last_error", "canvas_version", "canvas_set_stream", "canvas_synchronize",
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h", "canvas_host_register", "canvas_host_unregister", "canvas_upload_genome_begin", "canvas_upload_genome_wait",
-    "canvas_packed_plane_bytes", "canvas_pack_reference_host", "canvas_pack_hits_host", "canvas_pack_genome_device", "canvas_upload_packed_begin", "canvas_bin_sample_packed", "canvas_sample_pipeline_packed",
+    "canvas_packed_plane_bytes", "canvas_pack_reference_host", "canvas_pack_hits_host", "canvas_pack_genome_device", "canvas_upload_packed_begin", "canvas_bin_sample_packed", "canvas_sample_pipeline_packed", "canvas_pack_hits2_host", "canvas_upload_packed2_begin",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
     "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
@@ -61,6 +61,7 @@ def load_library():
     lib.canvas_packed_plane_bytes.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
     lib.canvas_pack_reference_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
     lib.canvas_pack_hits_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.canvas_pack_hits2_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
     _lib = lib
     return lib
 
@@ -106,6 +107,25 @@ def pack_hits_host(hits, length, out=None, threads=0):
     if rc:
         raise CanvasError(f"canvas_pack_hits_host: error {rc}")
     return out, sat.value
+
+
+def pack_hits2_host(hits, length, lo=None, hdr=None, extras=None, threads=0):
+    """canvas_pack_hits2_host (plain host code): hits u8[len] -> the two-bit wire form (lo u64[2 W], hdr u64[2 W / 64], extras u64[2 n_extras]); returns
+    (lo, hdr, extras, n_extras, #saturated).  The extras buffer is sized W / 16 entries unless given; it is grown once if the sample needs more."""
+    lib = load_library()
+    W = packed_plane_words(length)
+    lo = np.zeros(2 * W, np.uint64) if lo is None else lo
+    hdr = np.zeros(2 * (W // 64), np.uint64) if hdr is None else hdr
+    extras = np.zeros(2 * (W // 16 + 64), np.uint64) if extras is None else extras
+    for attempt in range(2):
+        nx = C.c_int64(0); sat = C.c_int64(0)
+        cap = int((extras.numel() if hasattr(extras, "numel") else len(extras)) // 2)
+        rc = lib.canvas_pack_hits2_host(_host_addr(hits), C.c_int64(int(length)), _host_addr(lo), _host_addr(hdr), _host_addr(extras), C.c_int64(cap), C.byref(nx), C.byref(sat), int(threads))
+        if rc == -4 and attempt == 0 and not hasattr(extras, "numel"):           # CANVAS_ERR_CAPACITY: more words with four hits and more than the default holds
+            extras = np.zeros(2 * (nx.value + 64), np.uint64); continue
+        if rc:
+            raise CanvasError(f"canvas_pack_hits2_host: error {rc} (extras needed: {nx.value})")
+        return lo, hdr, extras, nx.value, sat.value
 
 
 class Canvas:
@@ -163,6 +183,13 @@ class Canvas:
         hl = np.ascontiguousarray(lens, np.int64)
         hp = lambda ts: None if ts is None else (C.c_void_p * n)(*[None if t is None else _host_addr(t) for t in ts])
         self._check(self.lib.canvas_upload_packed_begin(self.ctx, n, _np_ptr(hl), hp(h_ref), _ptr_table(d_ref), hp(h_planes), _ptr_table(d_planes)))
+
+    def upload_packed2_begin(self, lens, h_ref, d_ref, h_lo, h_hdr, h_extras, n_extras, d_planes):
+        """canvas_upload_packed2_begin: the hit planes in their two-bit wire form (pack_hits2_host), expanded into d_planes on the device behind each chromosome's transfer"""
+        n = len(d_ref)
+        hl = np.ascontiguousarray(lens, np.int64); nx = np.ascontiguousarray(n_extras, np.int64)
+        hp = lambda ts: None if ts is None else (C.c_void_p * n)(*[None if t is None else _host_addr(t) for t in ts])
+        self._check(self.lib.canvas_upload_packed2_begin(self.ctx, n, _np_ptr(hl), hp(h_ref), _ptr_table(d_ref), hp(h_lo), hp(h_hdr), hp(h_extras), _np_ptr(nx), _ptr_table(d_planes)))
 
     def pack_genome_device(self, bases, masks, hits, lens):
         """canvas_pack_genome_device: per-base arrays in HBM -> (ref planes, hit planes, pos0, #saturated); bases/masks or hits may be None"""

@@ -47,6 +47,8 @@ namespace CanvasHipInterop
         [DllImport(Lib)] public static extern int canvas_pack_reference_host(byte[] bases, ulong[] mask, long len, IntPtr refOut, out long pos0, int threads);
         [DllImport(Lib)] public static extern int canvas_pack_hits_host(byte[] hits, long len, IntPtr planesOut, out long saturated, int threads);
         [DllImport(Lib)] public static extern int canvas_upload_packed_begin(IntPtr ctx, int nchr, long[] len, IntPtr[] hRef, IntPtr[] dRef, IntPtr[] hPlanes, IntPtr[] dPlanes);
+        [DllImport(Lib)] public static extern int canvas_pack_hits2_host(byte[] hits, long len, IntPtr loOut, IntPtr hdrOut, IntPtr extrasOut, long extrasCapWords, out long nExtras, out long saturated, int threads);
+        [DllImport(Lib)] public static extern int canvas_upload_packed2_begin(IntPtr ctx, int nchr, long[] len, IntPtr[] hRef, IntPtr[] dRef, IntPtr[] hLo, IntPtr[] hHdr, IntPtr[] hExtras, long[] nExtras, IntPtr[] dPlanes);
         [DllImport(Lib)] public static extern int canvas_bin_sample_packed(IntPtr ctx, int nchr, IntPtr[] dRef, IntPtr[] dPlanes, long[] len, long[] pos0, byte[] chrIsAutosome,
             int countsPerBin, int binSizeIn, int mode, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, long[] nbinsPerChr, out long nbinsTotal);
 

@@ -88,6 +88,17 @@ int32_t canvas_pack_genome_device(canvas_ctx* ctx, int32_t nchr, const uint8_t* 
  * over these destination tables sweeps chromosome c while chromosome c + 1 is in flight.  canvas_upload_genome_wait applies. */
 int32_t canvas_upload_packed_begin(canvas_ctx* ctx, int32_t nchr, const int64_t* h_len, const uint64_t* const* h_ref, uint64_t* const* d_ref,
                                    const uint64_t* const* h_hit_planes, uint64_t* const* d_hit_planes);
+/* Two-bit wire form of the hit planes.  At WGS depth four hits or more at one position are rare (6.6e-5 of the positions at 60x), so the planes b2 and b3 are almost
+ * entirely zero: over PCIe the hit planes can travel as  lo: per 64 positions {u64 b0, b1} (16 B);  hdr: per tile of 64 words {u64 xmask, u64 xoff} (bit w of xmask: word w
+ * of the tile has a non-zero b2 or b3, xoff: index of the tile's first entry in extras);  extras: {u64 b2, b3} of those words, in word order  — 0.25 B/base plus a few MB
+ * instead of 0.5 B/base.  canvas_pack_hits2_host builds the three pieces from the byte array (lo_out: 2 u64 per word, hdr_out: 2 u64 per tile, extras_out: room for
+ * extras_cap_words entries; CANVAS_ERR_CAPACITY with *n_extras_out = the number needed if that is too small).  canvas_upload_packed2_begin is canvas_upload_packed_begin
+ * for this form: the pieces are expanded into d_hit_planes[c] (the four planes) on the device right behind their transfer, so canvas_bin_sample_packed /
+ * canvas_sample_pipeline_packed are called exactly as after canvas_upload_packed_begin. */
+int32_t canvas_pack_hits2_host(const uint8_t* hits, int64_t len, uint64_t* lo_out, uint64_t* hdr_out, uint64_t* extras_out, int64_t extras_cap_words, int64_t* n_extras_out,
+                               int64_t* saturated_out, int32_t threads);
+int32_t canvas_upload_packed2_begin(canvas_ctx* ctx, int32_t nchr, const int64_t* h_len, const uint64_t* const* h_ref, uint64_t* const* d_ref,
+                                    const uint64_t* const* h_lo, const uint64_t* const* h_hdr, const uint64_t* const* h_extras, const int64_t* h_n_extras, uint64_t* const* d_hit_planes);
 /* canvas_bin_sample (below) over the planes: same arguments otherwise, same outputs bit for bit (modes 0 and 3). */
 int32_t canvas_bin_sample_packed(canvas_ctx* ctx, int32_t nchr, const uint64_t* const* d_ref, const uint64_t* const* d_hit_planes, const int64_t* h_len, const int64_t* h_pos0,
                                  const uint8_t* h_chr_is_autosome, int32_t counts_per_bin, int32_t bin_size_in, int32_t mode,

@@ -183,3 +183,41 @@ def test_packed_pipeline_equals_pipeline():
         assert torch.equal(out1[k][:n], out2[k][:n]), k
     assert torch.equal(cov1[:n], cov2[:n]) and torch.equal(st1[:n], st2[:n]) and torch.equal(seg1[:n], seg2[:n])
     assert n > 5_000 and r1["nseg"] >= 3
+
+
+def test_two_bit_upload_expands_to_the_same_planes_and_bins():
+    """canvas_upload_packed2_begin: the hit planes travel in their two-bit wire form (lo / header / extras) and are expanded on the device behind each chromosome's
+    transfer; the expanded planes and the bins are those of the four-plane upload (pile-ups and scattered positions with four hits and more included)"""
+    import torch
+    from canvas_amd.lib import pack_hits2_host
+    cv = get_canvas()
+    lengths = [900_001, 4096 * 50, 333_333, 70_000]
+    data = _chroms(lengths)
+    rng = np.random.RandomState(11)
+    for b, h, m in data:
+        idx = rng.randint(0, len(h), len(h) // 300); h[idx] = rng.randint(4, 40, len(idx)).astype(np.uint8)
+    data[1][1][:] = np.minimum(data[1][1], 3)                     # a chromosome without any extras
+    lens = np.array(lengths, np.int64)
+    href, hpl, pos0, _ = _host_planes(data)
+    pin = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).pin_memory()
+    parts = [pack_hits2_host(np.ascontiguousarray(h), len(h), threads=2) for b, h, m in data]
+    assert parts[1][3] == 0 and parts[0][3] > 100
+    h_lo = [pin(p[0]) for p in parts]; h_hdr = [pin(p[1]) for p in parts]; h_ex = [pin(p[2]) for p in parts]; nx = [p[3] for p in parts]
+    p_ref = [pin(r) for r in href]
+    dref = [torch.zeros(len(r), dtype=torch.int64, device=cv.device) for r in href]
+    dpl = [torch.zeros(len(p), dtype=torch.int64, device=cv.device) for p in hpl]
+    cap = int(lens.sum() // 50)
+    o1 = _out(cv, cap); o2 = _out(cv, cap)
+    d1 = [to_dev(r.view(np.int64), cv.device) for r in href]; p1 = [to_dev(p.view(np.int64), cv.device) for p in hpl]
+    _, per1, tot1, bs1 = cv.bin_sample_packed(d1, p1, lens, pos0, [1, 1, 1, 0], 100, -1, 3, out=o1)
+    for rep in range(2):
+        for t in dpl: t.zero_()
+        torch.cuda.synchronize()
+        cv.upload_packed2_begin(lens, p_ref if rep == 0 else None, dref, h_lo, h_hdr, h_ex, nx, dpl)
+        _, per2, tot2, bs2 = cv.bin_sample_packed(dref, dpl, lens, pos0, [1, 1, 1, 0], 100, -1, 3, out=o2)
+        assert (bs1, tot1, per1.tolist()) == (bs2, tot2, per2.tolist())
+        for k in o1:
+            assert torch.equal(o1[k][:tot1], o2[k][:tot1]), (k, rep)
+        for c in range(len(lengths)):
+            assert (dpl[c].cpu().numpy().view(np.uint64) == hpl[c]).all(), c
+    _check_against_oracle(o2, per2, tot2, data, bs2, 3)
