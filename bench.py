@@ -246,6 +246,8 @@ def main():
         result["packed_path"] = packed_region(args, cv, torch, host, bases, masks, hits, lens, is_auto, flags, out, cov_buf, state_buf, seg_buf, keep, total_bases)
         if "value_incl_h2d" in result["packed_path"]:
             result["value_incl_h2d_packed"] = result["packed_path"]["value_incl_h2d"]
+        if "two_bit_wire_form" in result["packed_path"]:
+            result["value_incl_h2d_packed_two_bit"] = result["packed_path"]["two_bit_wire_form"]["value_incl_h2d"]
     if rank == 0 and world == 1 and not args.no_cbs:
         # the other partition method of the path (-m CBS, BASELINE configs[4]) on the same cleaned coverage; reported, not part of `value`
         t_c = time.perf_counter()
