@@ -485,8 +485,11 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     double cv = 0;
+    // the factor-of-three CMADs are needed by the healing step only: they are computed on a host thread while the device decomposes
+    std::vector<double> f3;
+    std::thread f3Thread([&]() { f3 = factor_of_three(nchr, X.data(), off.data()); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } f3Join{f3Thread};      // joined on every exit path
     const bool hasCV = coverage_variability(variability_window, nchr, X.data(), off.data(), cv);
-    const std::vector<double> f3 = factor_of_three(nchr, X.data(), off.data());
 
     const double t1 = now();
     // ---- roots: chromosomes longer than MinSize (WaveletsRunner.cs:117-126)
@@ -643,13 +646,14 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
     }
     ctx->wv_levels = levels; ctx->wv_redone = redone;
     const double t2 = now();
-    // ---- per chromosome: HardThresh, reconstruction, healing, refinement (WaveletSegmentation.cs:73-250, 373-425)
-    int64_t total = 0;
-    for (int c = 0; c < nchr; c++) {
-        h_bp_offset[c] = total;
+    // ---- per chromosome: HardThresh, reconstruction, healing, refinement (WaveletSegmentation.cs:73-250, 373-425); the chromosomes are independent (the reference runs
+    // them under Parallel.ForEach, WaveletsRunner.cs:115-135): one task per chromosome on a few host threads, results concatenated in chromosome order
+    if (f3Thread.joinable()) f3Thread.join();
+    std::vector<std::vector<int>> bpOf((size_t)nchr);
+    auto finishChrom = [&](int c) {
         const ChromTree& T = trees[c];
         const int64_t L = off[c + 1] - off[c];
-        if (T.counts.empty()) continue;                       // not segmented: no breakpoints (WaveletsRunner.cs:113-131)
+        if (T.counts.empty()) return;                         // not segmented: no breakpoints (WaveletsRunner.cs:113-131)
         const double* r = X.data() + off[c];
         const int treeSize = (int)T.counts.size();
         std::vector<double> thresholds((size_t)treeSize, 1.0);
@@ -699,8 +703,22 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
                 bp[i] = bestBp;
             }
         }
-        if (total + (int64_t)bp.size() > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_wavelets: breakpoint capacity too small");
-        for (int v : bp) h_breakpoints[total++] = v;
+        bpOf[(size_t)c] = std::move(bp);
+    };
+    {
+        std::atomic<int> next{0};
+        const int nth = (int)std::max(1u, std::min(16u, std::min((unsigned)nchr, std::thread::hardware_concurrency())));
+        auto worker = [&]() { for (int c = next.fetch_add(1); c < nchr; c = next.fetch_add(1)) finishChrom(c); };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; t++) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+    }
+    int64_t total = 0;
+    for (int c = 0; c < nchr; c++) {
+        h_bp_offset[c] = total;
+        if (total + (int64_t)bpOf[(size_t)c].size() > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_wavelets: breakpoint capacity too small");
+        for (int v : bpOf[(size_t)c]) h_breakpoints[total++] = v;
     }
     h_bp_offset[nchr] = total;
     if (timing) fprintf(stderr, "canvas_wavelets: variability %.3f s, decomposition %.3f s (%lld levels), thresholds/reconstruction/healing %.3f s\n", t1 - t0, t2 - t1, levels, now() - t2);
