@@ -460,6 +460,22 @@ static void dotnet_sort_ints(std::vector<int>& k, const Cmp& c) {
 
 struct HNode { int32_t chrom, s, e; };                       // 1-based inclusive positions inside the chromosome
 struct Cand { int32_t level; int32_t s, b, e; double coef; };
+// host staging of the level loop in pinned memory: the per-level copies (a few KB each, 4 per level, ~300 levels) then run as real asynchronous transfers
+template <typename T> struct PinVec {
+    T* p = nullptr; size_t n = 0, cap = 0;
+    PinVec() = default; PinVec(const PinVec&) = delete; PinVec& operator=(const PinVec&) = delete;
+    ~PinVec() { if (p) (void)hipHostFree(p); }
+    bool reserve(size_t c) { if (c <= cap) return true; T* q = nullptr; if (hipHostMalloc((void**)&q, c * sizeof(T), hipHostMallocDefault) != hipSuccess) return false; if (p) { memcpy(q, p, n * sizeof(T)); (void)hipHostFree(p); } p = q; cap = c; return true; }
+    bool resize(size_t m) { if (m > cap && !reserve(std::max(m, cap * 2))) return false; n = m; return true; }
+    bool push_back(const T& v) { if (n == cap && !reserve(std::max<size_t>(64, cap * 2))) return false; p[n++] = v; return true; }
+    void clear() { n = 0; }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    T* data() { return p; } const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
+    T& back() { return p[n - 1]; }
+    T* begin() { return p; } T* end() { return p + n; } const T* begin() const { return p; } const T* end() const { return p + n; }
+};
 struct ChromTree { std::vector<int> counts; std::vector<Cand> cands; double sigma = 0, keepAbove = 0; };
 }  // namespace wv
 
@@ -535,7 +551,8 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dNcand, 0, 2 * sizeof(unsigned long long), ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the side stream starts from initialised buffers
     }
-    std::vector<WvNode> hNodes; std::vector<WvOut> hOut; std::vector<int32_t> hLong, hBase, hRedo; std::vector<WvRoot> hRoots;
+    PinVec<WvNode> hNodes; PinVec<WvOut> hOut; PinVec<int32_t> hLong, hBase, hRedo; std::vector<WvRoot> hRoots;
+    if (!hNodes.reserve(maxLong) || !hOut.reserve(maxLong) || !hLong.reserve(maxLong) || !hBase.reserve(maxLong + 1) || !hRedo.reserve(maxLong)) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: cannot pin the staging buffers");
     std::vector<std::vector<WvRoot>> rootBatches;
     size_t rootsUsed = 0;
     long long levels = 0, redone = 0;
@@ -574,8 +591,8 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         hipLaunchKernelGGL(k_wv_reduce, dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dLong, dBase, dHead, dBest, dFlag, dOut);
         return CANVAS_OK;
     };
-    auto upload_long = [&](const std::vector<int32_t>& list) -> int {          // returns the number of chunks
-        hBase.assign(1, 0);
+    auto upload_long = [&](const PinVec<int32_t>& list) -> int {                // returns the number of chunks
+        hBase.clear(); hBase.push_back(0);
         for (int32_t i : list) hBase.push_back(hBase.back() + (int32_t)((hNodes[i].len - 2 + WV_CS - 1) / WV_CS));
         (void)hipMemcpyAsync(dLong, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
         (void)hipMemcpyAsync(dBase, hBase.data(), hBase.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
