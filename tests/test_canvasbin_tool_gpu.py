@@ -423,3 +423,58 @@ def test_canvasbin_fragment_mode(tmp_path):
     bedU = str(tmp_path / "u.bed"); open(bedU, "w").write("chrU\t1\t100\n")
     r = subprocess.run([BIN, "-b", bam, "-r", fa, "-n", bedU, "-o", out, "-m", "Fragment", "-p"], capture_output=True, text=True)
     assert r.returncode == 1 and "Not all chromosomes" in r.stderr
+
+
+def _read_bam(path):
+    """independent reader of a BAM file (BGZF = concatenated gzip members; SAM specification section 4): ([(name, length)], [read dicts as _kept() wants them])"""
+    raw = gzip.decompress(open(path, "rb").read())
+    assert raw[:4] == b"BAM\x01"
+    l_text, = struct.unpack_from("<i", raw, 4); p = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, p); p += 4
+    refs = []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, p); p += 4
+        name = raw[p:p + l_name - 1].decode(); p += l_name
+        l_ref, = struct.unpack_from("<i", raw, p); p += 4
+        refs.append((name, l_ref))
+    reads = []
+    while p < len(raw):
+        block_size, = struct.unpack_from("<i", raw, p); p += 4
+        ref_id, pos, l_read_name, mapq, _bin, n_cigar, flag, l_seq, next_ref, next_pos, tlen = struct.unpack_from("<iiBBHHHiiii", raw, p)
+        q = p + 32 + l_read_name
+        cigar = []
+        for k in range(n_cigar):
+            v, = struct.unpack_from("<I", raw, q + 4 * k); cigar.append((v >> 4, "MIDNSHP=X"[v & 15]))
+        reads.append(dict(ref=ref_id, pos=pos, flag=flag, mapq=mapq, cigar=cigar, tlen=tlen))
+        p += block_size
+    return refs, reads
+
+
+def test_canvasbin_on_the_references_own_bam(tmp_path):
+    """CanvasBin -c chrM on CanvasTest/Data/single-end.bam (the reference's fixture, tests/golden/ref_data): the hit array of the intermediate file must hold one hit per
+    read that passes the reference's filters (CanvasBin.cs:239-270), as counted by an independent BAM reader"""
+    bam = os.path.join(ROOT, "tests", "golden", "ref_data", "single-end.bam")
+    refs, reads = _read_bam(bam)
+    names = [n for n, _ in refs]
+    assert "chrM" in names
+    cid = names.index("chrM"); L = refs[cid][1]
+    rng = np.random.RandomState(4)
+    seq = rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), L)
+    fa = str(tmp_path / "kmer.fa")
+    with open(fa, "wb") as f:
+        f.write(b">chrM\n")
+        for i in range(0, L, 70): f.write(seq[i:i + 70].tobytes() + b"\n")
+    dat = str(tmp_path / "chrM.dat")
+    r = subprocess.run([BIN, "-b", bam, "-r", fa, "-c", "chrM", "-o", dat, "-d", "100", "-m", "TruncatedDynamicRange"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = _decode_dat(open(dat, "rb").read())
+    exp = np.zeros(L, np.int64)
+    kept = [x for x in reads if x["ref"] == cid and x["cigar"] and _kept(x, False)]
+    for x in kept: exp[x["pos"]] += 1
+    mask = (seq >= ord("A")) & (seq <= ord("Z"))
+    exp = np.where(mask, np.minimum(exp, 255), 0)                       # ScreenObservedTags (CanvasBin.cs:694-716): hits outside the possible positions are dropped
+    got = np.frombuffer(d[2]["chrM"], np.uint8)
+    assert len(got) == L and (got == exp).all()
+    # the fixture holds nine chrM reads and every one of them starts with a soft clip: the reference's "first CIGAR operation is a match of 35 and more" rule keeps none
+    assert len(reads) == 9 and len(kept) == 0 and int(got.sum()) == 0
+    assert "Kept 0 of 9 total reads" in r.stdout
