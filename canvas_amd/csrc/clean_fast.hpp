@@ -619,6 +619,13 @@ __global__ void __launch_bounds__(256) k_cf_scatter_final(const CfArgs* __restri
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
     const uint8_t* __restrict__ flags = A.dFlags; const Soa src = A.S1, dst = A.caller;
+    // first phase: NormalizeByGC has only been decided (k_cf_dec_e), not applied to the scratch counts — nothing between here and there reads them — so it is applied while
+    // the survivors are copied out.  (When the second phase runs, clean_batch_finish applies it to the scratch counts first: NormalizeVarianceByGC works on normalised counts.)
+    const bool normalise = !secondPhase && (A.flags & CANVAS_CLEAN_GCNORM) && A.P[1].hdr[1] != 0;
+    __shared__ double sMed[NGC];
+    if (normalise && threadIdx.x < NGC) sMed[threadIdx.x] = D->medians[threadIdx.x];
+    const double globalMedian = D->globalMedian;
+    __syncthreads();
     uint32_t running = A.dBlk[blockIdx.x];
     for (int j = 0; j < CBLK / 256; j++) {
         const int64_t i = base + j * 256 + threadIdx.x;
@@ -628,7 +635,13 @@ __global__ void __launch_bounds__(256) k_cf_scatter_final(const CfArgs* __restri
         __syncthreads();
         uint32_t woff = 0, tot = 0;
         for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) woff += sh[k]; tot += sh[k]; }
-        if (f) { const uint32_t d = running + woff + inc - 1; dst.chr[d] = src.chr[i]; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = src.gc[i]; dst.count[d] = src.count[i]; }
+        if (f) {
+            const uint32_t d = running + woff + inc - 1;
+            const int32_t g = src.gc[i];
+            float v = src.count[i];
+            if (normalise) { const double median = sMed[g]; if (median > 0) v = (float)(globalMedian * (double)v / median); }        // CanvasClean.cs:190-195, applied on the way out
+            dst.chr[d] = src.chr[i]; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = g; dst.count[d] = v;
+        }
         running += tot;
         __syncthreads();
     }
@@ -644,14 +657,13 @@ static void cf_select_passes(canvas_ctx* ctx, const CfArgs* dArgs, int B, unsign
     }
 }
 // NormalizeByGC on problem `which` (1: first time, 3: after the variance normalisation) and the last compaction; `args`: the whole batch or one sample's block
-static void cf_gcnorm_and_compact(canvas_ctx* ctx, const CfArgs* args, int B, unsigned gxN, unsigned gxB, unsigned gxT, int which, int gate, int secondPhase, bool selectToo) {
-    if (selectToo) {
-        hipLaunchKernelGGL(k_cf_sel_setup, dim3(1, B), dim3(128), 0, ctx->stream, args, which, 0, gate);
-        cf_select_passes(ctx, args, B, gxT, which);
-        hipLaunchKernelGGL(k_cf_dec_e, dim3(1, B), dim3(128), 0, ctx->stream, args, which);
-        hipLaunchKernelGGL(k_cf_apply_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, B), dim3(256), 0, ctx->stream, args, which);
-    }
-    (void)secondPhase;
+// the medians of NormalizeByGC on problem `which` (1: first time, 3: after the variance normalisation); apply = scale the scratch counts now (second phase) instead of in
+// the last compaction (first phase)
+static void cf_gc_medians(canvas_ctx* ctx, const CfArgs* args, int B, unsigned gxN, unsigned gxT, int which, int gate, bool apply) {
+    hipLaunchKernelGGL(k_cf_sel_setup, dim3(1, B), dim3(128), 0, ctx->stream, args, which, 0, gate);
+    cf_select_passes(ctx, args, B, gxT, which);
+    hipLaunchKernelGGL(k_cf_dec_e, dim3(1, B), dim3(128), 0, ctx->stream, args, which);
+    if (apply) hipLaunchKernelGGL(k_cf_apply_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, B), dim3(256), 0, ctx->stream, args, which);
 }
 
 // Enqueues the whole stage for B samples on ctx->stream (no synchronisation): the CleanDev blocks arrive in ctx->pin.  clean_batch_finish waits for them.
@@ -723,7 +735,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     }
     // ---- NormalizeByGC on the grouped keys the compaction left
     if (flags & CANVAS_CLEAN_GCNORM) {
-        cf_gcnorm_and_compact(ctx, dArgs, B, gxN, gxB, gxT, 1, 0, 0, true);
+        cf_gc_medians(ctx, dArgs, B, gxN, gxT, 1, 0, false);
         if (anyVar) {
             // NormalizeVarianceByGC (CanvasClean.cs:512-519): quartiles of the normalised counts; if it changes anything, NormalizeByGC once more
             hipLaunchKernelGGL(k_cf_sel_setup, dim3(1, B), dim3(128), 0, ctx->stream, dArgs, 2, 1, 1);
@@ -765,9 +777,10 @@ static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64
         // NormalizeVarianceByGC changed the counts of this sample (CanvasClean.cs:512-519): scale them, NormalizeByGC again on the new counts, then the last compaction
         const CfArgs* a = q.dArgs + s;
         const unsigned gxN = (unsigned)nblk(q.h[s].n, 256), gxB = (unsigned)nblk(q.h[s].n, CBLK), gxT = q.h[s].tilesUpper;
+        hipLaunchKernelGGL(k_cf_apply_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a, 1);      // the first NormalizeByGC, deferred until now (medians of problem 1 are still in CleanDev)
         hipLaunchKernelGGL(k_cf_apply_var, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(k_cf_xform_var, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a);
-        cf_gcnorm_and_compact(ctx, a, 1, gxN, gxB, gxT, 3, 2, 1, true);
+        cf_gc_medians(ctx, a, 1, gxN, gxT, 3, 2, true);
         hipLaunchKernelGGL(k_cf_flags_final, dim3(gxB, 1), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1, 1), dim3(1024), 0, ctx->stream, a, 1);
         hipLaunchKernelGGL(k_cf_scatter_final, dim3(gxB, 1), dim3(256), 0, ctx->stream, a, 1);
