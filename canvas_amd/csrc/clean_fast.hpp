@@ -133,12 +133,19 @@ __global__ void __launch_bounds__(1024) k_cf_size_pick(const CfArgs* __restrict_
         if (threadIdx.x == 0) D->sizeThresh = (int32_t)(uint32_t)sPre[0];
     }
 }
+// exclusive prefix sum of one uint32 per thread over a 128-thread workgroup (two waves); *total = the sum.  One barrier.
+__device__ __forceinline__ uint32_t cf_excl_scan128(uint32_t v, uint32_t* sh2 /* [2] */, uint32_t* total) {
+    const uint32_t inc = wave_inclusive_scan_u32(v);
+    if ((threadIdx.x & 63) == 63) sh2[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    *total = sh2[0] + sh2[1];
+    return inc - v + (threadIdx.x >= 64 ? sh2[0] : 0u);
+}
 // the select problems over the grouped keys, genome + every kept bucket: mode 0 = medians (NormalizeByGC, CanvasClean.cs:163-189), mode 1 = quartiles (NormalizeVarianceByGC, :34-66).
 // gate: which CleanDev flag switches the problem on (0 gcActive, 1 varActive, 2 changed)
 __global__ void __launch_bounds__(128) k_cf_sel_setup(const CfArgs* __restrict__ AA, int which, int mode, int gate) {
     CF_SAMPLE;
-    __shared__ uint32_t so[NGC + 1], tileBase[NGC + 1];
-    __shared__ int qFirst[NGC + 2];                     // first query of slot s (slot NGC = the genome, placed FIRST: queries 0 .. nrG-1), prefix sums
+    __shared__ uint32_t so[NGC + 1];
     const CleanDev* D = A.D; CfSel* P = A.P + which; SelTile* tiles = A.tiles + (size_t)which * A.tilesUpper;
     const int t = threadIdx.x;
     const bool on = gate == 0 ? D->gcActive != 0 : (gate == 1 ? D->varActive != 0 : D->changed != 0);
@@ -153,28 +160,25 @@ __global__ void __launch_bounds__(128) k_cf_sel_setup(const CfArgs* __restrict__
     int64_t myRanks[6]; int myN = 0;
     if (t < NGC) myN = ranksOf((int64_t)so[t + 1] - (int64_t)so[t], myRanks);
     else if (t == NGC) myN = ranksOf((int64_t)so[NGC], myRanks);
-    if (t <= NGC) qFirst[t] = myN;                      // counts first
-    __syncthreads();
-    if (t == 0) {
-        const int nG = qFirst[NGC];
-        int acc = nG; uint32_t tacc = 0;
-        for (int s2 = 0; s2 < NGC; s2++) { const int c = qFirst[s2]; qFirst[s2] = acc; acc += c; tileBase[s2] = tacc; tacc += (so[s2 + 1] - so[s2] + SEL_TILE - 1) / SEL_TILE; }
-        qFirst[NGC] = 0; qFirst[NGC + 1] = nG;
-        tileBase[NGC] = tacc;
-        P->hdr[0] = tacc; P->hdr[1] = (uint32_t)acc;
-    }
-    __syncthreads();
-    const int nG = qFirst[NGC + 1];
+    // query numbering: the genome's queries first (0 .. nG-1), then the buckets' in GC order; tile numbering: the buckets' tiles in GC order (two 128-thread scans)
+    __shared__ uint32_t shQ[2], shT[2]; __shared__ int sNG;
+    if (t == NGC) sNG = myN;
+    uint32_t totQ, totT;
+    const uint32_t exQ = cf_excl_scan128(t < NGC ? (uint32_t)myN : 0u, shQ, &totQ);          // (the barrier inside also publishes sNG)
+    const uint32_t myTiles = t < NGC ? (so[t + 1] - so[t] + SEL_TILE - 1) / SEL_TILE : 0u;
+    const uint32_t exT = cf_excl_scan128(myTiles, shT, &totT);
+    const int nG = sNG;
+    if (t == 0) { P->hdr[0] = totT; P->hdr[1] = (uint32_t)nG + totQ; }
+    const int f = t < NGC ? nG + (int)exQ : 0;                                              // slot NGC (the genome) starts at query 0
     if (t <= NGC) {
-        const int f = qFirst[t];
         P->first[t] = myN > 0 ? f : -1;
         for (int k = 0; k < myN; k++) { P->qk[f + k] = (unsigned long long)myRanks[k]; P->qprefix[f + k] = 0ull; }
     }
     if (t < NGC) {
         SelSegQ Q; Q.nq = 0;
-        if (so[t + 1] > so[t]) { for (int k = 0; k < nG; k++) Q.q[Q.nq++] = k; for (int k = 0; k < myN; k++) Q.q[Q.nq++] = qFirst[t] + k; }
+        if (so[t + 1] > so[t]) { for (int k = 0; k < nG; k++) Q.q[Q.nq++] = k; for (int k = 0; k < myN; k++) Q.q[Q.nq++] = f + k; }
         P->segq[t] = Q;
-        uint32_t k = tileBase[t];
+        uint32_t k = exT;
         for (int64_t b = so[t]; b < (int64_t)so[t + 1]; b += SEL_TILE) tiles[k++] = SelTile{t, b, min<int64_t>(b + SEL_TILE, (int64_t)so[t + 1])};
     }
 }
@@ -366,6 +370,10 @@ __global__ void __launch_bounds__(1024) k_cf_runs_build(const CfArgs* __restrict
     const int t = threadIdx.x;
     s[t] = t < (int)nb ? recs[t] : 0x7FFFFFFFFFFFFFFFll;
     __syncthreads();
+    if (nb <= 64u) {                                                          // one record per chromosome of a sorted file: an insertion sort by one thread beats 55 barriers
+        if (t == 0) for (unsigned i = 1; i < nb; i++) { const long long v = s[i]; int j = (int)i - 1; while (j >= 0 && s[j] > v) { s[j + 1] = s[j]; j--; } s[j + 1] = v; }
+        __syncthreads();
+    } else
     for (int k = 2; k <= CF_MAXRUN; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             const int ixj = t ^ j;
@@ -406,41 +414,32 @@ __global__ void k_cf_lsd_avg(const CfArgs* __restrict__ AA) {
 // ---------------------------------------------------------------- RemoveBinsWithExtremeGC decision (CanvasClean.cs:207-237) and what follows from it
 __global__ void __launch_bounds__(128) k_cf_dec_gc(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
-    __shared__ uint32_t hA[NGC], hO[NGC], so[NGC + 1];
-    __shared__ uint8_t kp[NGC];
-    __shared__ long long sKept; __shared__ int sActive;
+    __shared__ uint32_t shA[2], shB[2], shC[2], shD[2];
     CleanDev* __restrict__ D = A.D; const uint32_t flags = A.flags; const int minBinsPerGc = A.minBinsPerGc;
     const int t = threadIdx.x;
     const long long nAB = (long long)D->nAB;
-    if (t < NGC) { hA[t] = D->hist[t]; hO[t] = D->hist[NGC + t]; }
-    __syncthreads();
-    if (t == 0) {                                        // 101-element loops over LDS: the decision the reference takes once per file
-        sActive = 0; sKept = nAB;
-        for (int i = 0; i < NGC; i++) kp[i] = 1;
-        for (int i = 0; i <= NGC; i++) so[i] = 0;
-        if ((flags & CANVAS_CLEAN_GCNORM) && nAB > 0) {
-            double totalCount = 0;
-            for (int i = 0; i < NGC; i++) totalCount += hA[i];
-            const int averageCountPerGC = max(minBinsPerGc, (int)(totalCount / NGC));
-            const int threshold = min(100, averageCountPerGC);
-            long long kept = 0;
-            for (int i = 0; i < NGC; i++) { const bool k = (int)hA[i] >= threshold; kp[i] = k; if (k) kept += (long long)hA[i] + (long long)hO[i]; }
-            if (kept <= 0) { for (int i = 0; i < NGC; i++) kp[i] = 1; }            // "proceed without GC correction" (CanvasClean.cs:500-505)
-            else {
-                sKept = kept; sActive = 1;
-                uint32_t acc = 0;
-                for (int i = 0; i < NGC; i++) { so[i] = acc; if (kp[i]) acc += hA[i]; }
-                so[NGC] = acc;
-            }
-        }
-    }
-    __syncthreads();
-    if (t < NGC) { D->keepGc[t] = kp[t]; D->cursor[t] = 0; D->medians[t] = 0.0; D->segOff[t] = so[t]; }
+    const uint32_t hA = t < NGC ? D->hist[t] : 0u, hO = t < NGC ? D->hist[NGC + t] : 0u;
+    // the counts are integers below 2^32 and there are 101 of them: their double sum (CanvasClean.cs:219-222) is exact in any order
+    uint32_t totalA; (void)cf_excl_scan128(hA, shA, &totalA);
+    const bool consider = (flags & CANVAS_CLEAN_GCNORM) && nAB > 0;
+    const int averageCountPerGC = max(minBinsPerGc, (int)((double)totalA / NGC));
+    const int threshold = min(100, averageCountPerGC);
+    bool kp = true;
+    if (consider && t < NGC) kp = (int)hA >= threshold;
+    // bins of any chromosome in the kept buckets (each term < 2^32, 101 terms: the 64-bit total is split over two 32-bit scans of the halves)
+    const unsigned long long mine = (consider && t < NGC && kp) ? (unsigned long long)hA + (unsigned long long)hO : 0ull;
+    uint32_t totLo, totHi; (void)cf_excl_scan128((uint32_t)(mine & 0xFFFFu), shB, &totLo); (void)cf_excl_scan128((uint32_t)(mine >> 16), shC, &totHi);
+    const long long kept = (long long)totLo + ((long long)totHi << 16);
+    const bool active = consider && kept > 0;                               // kept <= 0: "proceed without GC correction" (CanvasClean.cs:500-505)
+    if (!active) kp = true;
+    uint32_t totalKept; const uint32_t so = cf_excl_scan128((active && t < NGC && kp) ? hA : 0u, shD, &totalKept);
+    if (t < NGC) { D->keepGc[t] = kp ? 1 : 0; D->cursor[t] = 0; D->medians[t] = 0.0; D->segOff[t] = active ? so : 0u; }
     if (t == 0) {
-        D->segOff[NGC] = so[NGC]; D->kept = sKept; D->gcActive = sActive; D->changed = 0;
+        const long long sKept = active ? kept : nAB;
+        D->segOff[NGC] = active ? totalKept : 0u; D->kept = sKept; D->gcActive = active ? 1 : 0; D->changed = 0;
         // NormalizeVarianceByGC runs for whole-genome samples only (CanvasClean.cs:512-519); the host enqueues its kernels when the INPUT has more than 500000 bins
         const bool haveLsd = A.wantLsd && nAB >= 50000;                       // what k_cf_runs_build will store in haveLocalSd (CanvasClean.cs:483-486)
-        D->varActive = (sActive && haveLsd && sKept > 500000 && A.n > 500000) ? 1 : 0;
+        D->varActive = (active && haveLsd && sKept > 500000 && A.n > 500000) ? 1 : 0;
     }
 }
 // NormalizeByGC decision: genome median and per-GC medians from the selected keys (CanvasClean.cs:170-189)
