@@ -17,7 +17,6 @@
 
 #define PK_TILES 4          // tiles per wave in the packed sweep: 4 x (16 + 32) B per lane in flight
 
-struct PkWord { unsigned long long b0, b1, b2, b3; };
 
 __device__ __forceinline__ void pk_clamp10(unsigned long long& b0, unsigned long long& b1, unsigned long long& b2, unsigned long long b3) {
     const unsigned long long over = b3 & (b2 | (b1 & b0));          // 11..15 -> 10 = 1010b
