@@ -56,6 +56,10 @@ namespace CanvasHipInterop
         [DllImport(Lib)] public static extern int canvas_clean2(IntPtr ctx, long n, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dCount, IntPtr dGc, int nchr,
             byte[] chrIsAutosome, byte[] chrIsY, uint flags, int minBinsPerGc, out double localSd, out long nOut, int[] info8);
 
+        // a cohort through CanvasClean in one call (one launch chain for all samples; pedigree runs clean every member, CanvasRunner.cs:1010-1070)
+        [DllImport(Lib)] public static extern int canvas_clean_batch(IntPtr ctx, int nsamples, long[] n, IntPtr[] dChr, IntPtr[] dStart, IntPtr[] dStop, IntPtr[] dCount, IntPtr[] dGc, int nchr,
+            byte[] chrIsAutosome, byte[] chrIsY, uint flags, int minBinsPerGc, double[] localSd, long[] nOut, int[] info8PerSample);
+
         // ---- CanvasPartition
         [DllImport(Lib)] public static extern int canvas_evenness_score(IntPtr ctx, int nchr, IntPtr dCov, long[] chrOffset, int windowSize, out double score, out int valid);
         [DllImport(Lib)] public static extern int canvas_wavelets(IntPtr ctx, int nchr, IntPtr dCov, long[] chrOffset, int isGermline, double thresholdLower, double thresholdUpper,
