@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--staged", action="store_true", help="time the six per-stage library calls from Python instead of the one-call canvas_sample_pipeline")
     ap.add_argument("--no-wavelets", action="store_true", help="skip the (untimed) Wavelets run on the cleaned coverage that is reported as wavelets_path")
     ap.add_argument("--no-cbs", action="store_true", help="skip the (untimed) CBS run on the cleaned coverage that is reported as cbs_path")
+    ap.add_argument("--no-pedigree", action="store_true", help="skip the trio flow of BASELINE configs[3] that is reported as pedigree_flow")
     ap.add_argument("--no-somatic", action="store_true", help="skip the tumour / normal flow of BASELINE configs[4] that is reported as somatic_flow")
     args = ap.parse_args()
 
@@ -319,6 +320,8 @@ def main():
     host = None
     if rank == 0 and world == 1 and not args.no_somatic:
         result["somatic_flow"] = somatic_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, device)
+    if rank == 0 and world == 1 and not args.no_pedigree:
+        result["pedigree_flow"] = pedigree_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, device)
     if rank == 0:
         if args.stage_times:
             print("stage times (ms, host wall incl. sync): " + json.dumps(stage), file=sys.stderr)
@@ -636,6 +639,94 @@ def somatic_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, devi
         got = r["seg_len"].cpu().numpy(); nseg_c = r["nseg"]; cst = r["cbs_stats"]
         o["cbs_parity_vs_oracle"] = bool(all(int(nseg_c[c]) == len(exp_seg[c]) and (got[off_h[c]:off_h[c] + nseg_c[c]] == exp_seg[c]).all() for c in range(len(per)))
                                          and int(cst[0]) == int(est[0]) and int(cst[2]) == int(est[2]) and int(cst[4]) == int(est[4]))
+    return o
+
+
+def pedigree_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, device):
+    """BASELINE configs[3] at whole-genome size on one GPU: a trio over one reference (60x each) -> multi-sample bin size (median of the autosome rates of all samples,
+    CanvasBin.cs:86-110) -> CanvasBin per sample on that size -> CanvasClean of the three samples in ONE cohort call (canvas_clean_batch) -> the bins every sample still has
+    (MergeMultiSampleCleanedBedFile, Utilities.cs:834-920) -> F2 hand-off and PerSampleHMM per sample.  Reported, not part of `value`; the small-scale hand-off-by-hand-off
+    parity incl. SplitOverlappingSegments is tests/test_pedigree_flow_gpu.py.  With the CPU baseline enabled: every sample's bins and cleaned bins and the merged list are
+    compared with the oracle at full size."""
+    from canvas_amd import synth
+    from canvas_amd.lib import synth_generate_sample_device
+    nchr = len(lens)
+    thr = torch.from_numpy(synth.poisson_thresholds(args.rate).view(np.int32)).to(device)
+    hits = [[synth_generate_sample_device(seed, seed + 3000 + 17 * s, c, int(L), thr, device)[0] for c, L in enumerate(lens)] for s in range(3)]
+    torch.cuda.synchronize()
+    cap = int(int(lens.sum()) // 100) + 16
+    mk = lambda dt: torch.empty(cap, dtype=dt, device=device)
+    outs = [dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32)) for _ in range(3)]
+    stage = {}
+
+    def run(keep):
+        t = [time.perf_counter()]
+
+        def tick(name):
+            cv.synchronize(); torch.cuda.synchronize()
+            now = time.perf_counter(); stage[name] = round(now - t[0], 4); t[0] = now
+        rates = []
+        for s in range(3):
+            _, _, r = cv.bin_rates(hits[s], masks, lens)
+            rates += [r[c] for c in range(nchr) if is_auto[c]]
+        bin_size = cv.bin_size_from_rates(rates, 100)
+        tick("rates+bin_size")
+        totals = []
+        for s in range(3):
+            _, per, total = cv.bin_genome(bases, masks, hits[s], lens, bin_size, 3, out=outs[s])
+            totals.append(int(total))
+        tick("bin x3")
+        binned = [{k: v[:totals[s]].clone() for k, v in outs[s].items()} for s in range(3)] if keep else None
+        t[0] = time.perf_counter()
+        nout, lsd, _ = cv.clean_batch(outs, totals, is_auto, flags)
+        tick("clean (cohort call)")
+        mc, ms, me, mcnt, k = cv.merge_cleaned(outs, [int(x) for x in nout])
+        off = cv.chromosome_offsets(mc, k, nchr)
+        tick("merge")
+        nseg = []
+        for s in range(3):
+            cov = cv.quantize_f2(mcnt[s], k)
+            st = cv.hmm_per_sample(cov, off)
+            change = (st[1:] != st[:-1])
+            starts = torch.zeros(k, dtype=torch.bool, device=device); starts[torch.from_numpy(np.asarray(off[:-1][np.diff(off) > 0], np.int64)).to(device)] = True
+            nseg.append(int((change | starts[1:]).sum().item()) + 1)
+        tick("f2+hmm x3")
+        return dict(bin_size=int(bin_size), totals=totals, nout=[int(x) for x in nout], lsd=[float(x) for x in lsd], merged=int(k), nseg=nseg, binned=binned,
+                    merged_arrays=(mc, ms, me, mcnt) if keep else None)
+
+    run(False)
+    t0 = time.perf_counter()
+    r = run(not args.no_cpu_baseline)
+    sec = time.perf_counter() - t0
+    o = {"seconds": round(sec, 3), "samples": 3, "bin_size": r["bin_size"], "bins_per_sample": r["totals"], "bins_after_clean": r["nout"], "bins_common_to_all": r["merged"],
+         "segments_per_sample": r["nseg"], "stage_seconds": dict(stage), "bins_per_s": round(sum(r["totals"]) / sec, 1),
+         "workload": "BASELINE configs[3]: trio, 60x each (rate %.3f), one reference; multi-sample bin size, CanvasBin x 3, CanvasClean as one cohort call, bin intersection, PerSampleHMM x 3" % args.rate}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        cores = min(os.cpu_count() or 1, 24)
+        hb = [b[:int(L)].cpu().numpy() for b, L in zip(bases, lens)]; hm = [m.cpu().numpy().view(np.uint8) for m in masks]
+        is_y = np.zeros(nchr, np.uint8)
+        ok_bin = ok_clean = True; exps = []
+        t_o = time.perf_counter()
+        for s in range(3):
+            hh = [h[:int(L)].cpu().numpy() for h, L in zip(hits[s], lens)]
+            res = O.bin_genome(hb, hm, hh, r["bin_size"], mode=3, threads=cores)
+            e = dict(chr=np.concatenate([np.full(len(res[0][c]), c, np.int32) for c in range(nchr)]), start=np.concatenate(res[0]), stop=np.concatenate(res[1]),
+                     gc=np.concatenate(res[2]), count=np.concatenate(res[3]).astype(np.float32))
+            b = r["binned"][s]
+            ok_bin &= bool(len(e["chr"]) == r["totals"][s] and (b["stop"].cpu().numpy() == e["stop"]).all() and (b["count"].cpu().numpy() == e["count"]).all() and (b["gc"].cpu().numpy() == e["gc"]).all())
+            ex = O.clean(e["chr"], e["start"], e["stop"], e["count"], e["gc"], is_auto, is_y, flags)
+            n = r["nout"][s]
+            ok_clean &= bool(n == len(ex["chr"]) and ex["local_sd"] == r["lsd"][s] and (outs[s]["count"][:n].cpu().numpy().view(np.uint32) == ex["count"].view(np.uint32)).all()
+                             and (outs[s]["start"][:n].cpu().numpy() == ex["start"]).all())
+            exps.append(ex)
+        ec, es, ee, ecnt = O.merge_cleaned(exps)
+        mc, ms, me, mcnt = r["merged_arrays"]
+        ok_merge = bool(len(ec) == r["merged"] and (ms.cpu().numpy() == es).all() and (me.cpu().numpy() == ee).all()
+                        and all((mcnt[s].cpu().numpy().view(np.uint32) == ecnt[s].view(np.uint32)).all() for s in range(3)))
+        o["oracle_seconds_bin_clean_merge"] = round(time.perf_counter() - t_o, 3); o["oracle_threads"] = cores
+        o["parity_vs_oracle"] = {"bins_x3": ok_bin, "clean_x3_bitexact": ok_clean, "merged_bins": ok_merge}
     return o
 
 
