@@ -15,7 +15,7 @@ N > 1 (launched by torch.distributed.run, one rank per GPU):
     --multi cohort             one sample per rank, no data-path collective.  "scaling": "weak".
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant HBM kernel, hipEvent-timed inside the library on its own stream), "cpu_baseline" (the CPU
-oracle on this box's host cores, whole genome, no extrapolation; rank 0, N = 1 only), "h2d", "cbs_path", "wavelets_path", "somatic_flow" (BASELINE configs[4]).
+oracle on this box's host cores, whole genome, no extrapolation; rank 0, N = 1 only), "h2d", "packed_path", "cbs_path", "wavelets_path", "somatic_flow" (BASELINE configs[4]), "pedigree_flow" (BASELINE configs[3]).
 """
 import argparse
 import json
