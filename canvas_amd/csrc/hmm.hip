@@ -38,6 +38,79 @@ __global__ void __launch_bounds__(256) k_keys_cov_f32(const double* __restrict__
     if (i < n) keys[i] = key_of_float((float)cov[i]);     // (float)x, HiddenMarkovModelsRunner.cs:43
 }
 
+// ---- genome-wide quartiles of the coverage by counting (HiddenMarkovModelsRunner.cs:36-50 takes them from a sorted copy)
+// The coverage CanvasPartition reads is the F2 text of CanvasClean (IO.cs:21,40): every value is k / 100 for an integer k, and (float)x is monotone in x, so the order
+// statistics of (float)coverage are (float)(k / 100) for the order statistics k of the integers.  One sweep counts the k of a window of CQ_WIN values around the sample's
+// level in LDS (the quartiles of a sample lie within a few units of its median) and the elements below the window; a one-workgroup pick reads the ranks off the counters.
+// Every element is checked ((double)k / 100 == x, bit for bit); a value that is not of that form, or a rank outside the window, hands the call to the radix select.
+#define CQ_WIN 8192
+struct CovQ { unsigned long long rank[8]; unsigned long long below; uint32_t nq, bad, fail, pad; int32_t lo; int32_t resultK[8]; };
+__device__ __forceinline__ bool covq_key(double x, long long& k) {
+    k = llrint(x * 100.0);
+    return x == x && k >= 0 && k < (1ll << 30) && (double)k / 100.0 == x && !(k == 0 && __double2hiint(x) < 0);     // (-0.0 has its own place in the sorted order)
+}
+__global__ void __launch_bounds__(1024) k_covq_hist(const double* __restrict__ cov, int64_t n, CovQ* __restrict__ Q, uint32_t* __restrict__ win) {
+    __shared__ uint32_t lw[CQ_WIN];
+    __shared__ long long sv[33];
+    __shared__ int sLo;
+    // the sample's level: median of 33 strided elements (the same in every workgroup); 33 lanes fetch them, one sorts
+    if (threadIdx.x < 33) { const int64_t i = (int64_t)((double)n * (threadIdx.x + 0.5) / 33.0); long long k = -1; if (i < n && !covq_key(cov[i], k)) k = -1; sv[threadIdx.x] = k; }
+    for (int i = threadIdx.x; i < CQ_WIN; i += 1024) lw[i] = 0;
+    __syncthreads();
+    if (threadIdx.x < 33) {                                  // every lane ranks its own sample among the valid ones; the one in the middle sets the window
+        const long long mine = sv[threadIdx.x];
+        int m = 0, rank = 0;
+        for (int j = 0; j < 33; j++) { const long long o = sv[j]; if (o >= 0) { m++; if (o < mine || (o == mine && j < (int)threadIdx.x)) rank++; } }
+        if (m == 0) { if (threadIdx.x == 0) sLo = 0; }
+        else if (mine >= 0 && rank == m / 2) sLo = (int)(mine > CQ_WIN / 2 ? mine - CQ_WIN / 2 : 0);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) Q->lo = sLo;
+    const long long lo = sLo;
+    uint32_t below = 0, bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * stride; x[u] = i < n ? cov[i] : 0.0; }          // four loads in flight
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + u * stride >= n) break;
+            long long k;
+            if (!covq_key(x[u], k)) { bad = 1; continue; }
+            if (k < lo) below++;
+            else if (k - lo < CQ_WIN) atomicAdd(&lw[k - lo], 1u);
+        }
+    }
+    below = wave_reduce_add_u32(below);
+    if ((threadIdx.x & 63) == 0 && below) atomicAdd(&Q->below, (unsigned long long)below);
+    if (bad) Q->bad = 1u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CQ_WIN; i += 1024) { const uint32_t v = lw[i]; if (v) atomicAdd(&win[i], v); }
+}
+__global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, const uint32_t* __restrict__ win) {
+    __shared__ unsigned long long sTot[16];
+    const int PER = CQ_WIN / 1024;
+    uint32_t c[PER]; unsigned long long mine = 0;
+    for (int k = 0; k < PER; k++) { c[k] = win[threadIdx.x * PER + k]; mine += c[k]; }
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += o; }
+    if ((threadIdx.x & 63) == 63) sTot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned long long before = Q->below, total = Q->below;
+    for (int w = 0; w < 16; w++) { if (w < (int)(threadIdx.x >> 6)) before += sTot[w]; total += sTot[w]; }
+    before += inc - mine;
+    for (uint32_t j = 0; j < Q->nq; j++) {
+        const unsigned long long want = Q->rank[j];
+        if (threadIdx.x == 0 && (want < Q->below || want >= total)) Q->fail = 1u;          // a quartile outside the window
+        if (want >= before && want < before + mine) {
+            unsigned long long cum = before;
+            for (int k = 0; k < PER; k++) { cum += c[k]; if (want < cum) { Q->resultK[j] = Q->lo + (int)threadIdx.x * PER + k; break; } }
+        }
+    }
+}
+
 // RemoveOutliers (HiddenMarkovModelsRunner.cs:154-162) + Convert.ToInt32 (Distributions.cs:271)
 __global__ void __launch_bounds__(256) k_hmm_index(const double* __restrict__ cov, int64_t n, double maxThreshold, int32_t* __restrict__ idx) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1419,20 +1492,40 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     const int64_t N = h_chr_offset[nchr];
     // nAll / d_cov_all: the genome the quartiles are taken over (the whole sample; == the chromosomes handled here unless the sample is sharded)
     if (nAll < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
-    WsSizer ex; ex.take<uint32_t>(nAll); ex.take<int32_t>(N + 256); ex.take<double>(NSTATE * 70000);
+    WsSizer ex; ex.take<uint32_t>(nAll); ex.take<int32_t>(N + 256); ex.take<double>(NSTATE * 70000); ex.take<CovQ>(1); ex.take<uint32_t>(CQ_WIN);
     auto prepare = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom*, const int64_t*) -> int32_t {
         int32_t rc;
         uint32_t* keys = ws.take<uint32_t>(nAll); int32_t* idx = ws.take<int32_t>(N + 256); double* dTab = ws.take<double>(NSTATE * 70000);   // idx: padded for the group loads of k_vit_spec
-    // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50)
-    hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(nAll, 256)), dim3(256), 0, ctx->stream, d_cov_all, nAll, keys);
+    // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50): by counting when the coverage is F2 text (k_covq_hist), by the radix select otherwise
+    //    (CANVAS_HMM_RADIX_SELECT=1 forces the latter: test hook, both must agree)
     int64_t qidx[6]; int nq;
     quartile_idx(nAll, qidx, nq);
-    std::vector<SelQuery> qs;
-    for (int k = 0; k < nq; k++) qs.push_back({0, 0, qidx[k]});
-    std::vector<unsigned long long> res;
-    rc = radix_select<uint32_t>(ctx, keys, 1, std::vector<int64_t>{0, nAll}, qs, res); if (rc) return rc;
     float v[6], q1, q2, q3;
-    for (int k = 0; k < nq; k++) v[k] = host_float_of_key((uint32_t)res[k]);
+    bool radix = getenv("CANVAS_HMM_RADIX_SELECT") != nullptr;
+    if (!radix) {
+        CovQ* dQ = ws.take<CovQ>(1); uint32_t* dWin = ws.take<uint32_t>(CQ_WIN);
+        CovQ hQ; memset(&hQ, 0, sizeof hQ); hQ.nq = (uint32_t)nq;
+        for (int k = 0; k < nq; k++) hQ.rank[k] = (unsigned long long)qidx[k];
+        rc = canvas_h2d_small(ctx, dQ, &hQ, sizeof hQ); if (rc) return rc;
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dWin, 0, CQ_WIN * 4, ctx->stream));
+        hipLaunchKernelGGL(k_covq_hist, dim3(256), dim3(1024), 0, ctx->stream, d_cov_all, nAll, dQ, dWin);
+        hipLaunchKernelGGL(k_covq_pick, dim3(1), dim3(1024), 0, ctx->stream, dQ, dWin);
+        rc = canvas_pin_reserve(ctx, sizeof(CovQ)); if (rc) return rc;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, dQ, sizeof(CovQ), hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+        const CovQ& R = *(const CovQ*)ctx->pin;
+        if (R.bad || R.fail) radix = true;                 // coverage that is not F2 text, or a sample whose quartiles lie more than 40 units from its level
+        else for (int k = 0; k < nq; k++) v[k] = (float)((double)R.resultK[k] / 100.0);
+    }
+    if (radix) {
+        hipLaunchKernelGGL(k_keys_cov_f32, dim3(nblk2(nAll, 256)), dim3(256), 0, ctx->stream, d_cov_all, nAll, keys);
+        std::vector<SelQuery> qs;
+        for (int k = 0; k < nq; k++) qs.push_back({0, 0, qidx[k]});
+        std::vector<unsigned long long> res;
+        rc = radix_select<uint32_t>(ctx, keys, 1, std::vector<int64_t>{0, nAll}, qs, res); if (rc) return rc;
+        for (int k = 0; k < nq; k++) v[k] = host_float_of_key((uint32_t)res[k]);
+    }
     quartile_val(nAll, v, q1, q2, q3);
     const double median = (double)q2;
     const float iqr = q3 - q1;

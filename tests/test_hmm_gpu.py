@@ -147,3 +147,20 @@ def test_joint_hmm_matches_oracle(nsamples, n):
         if not ran: assert (g == -1).all()
         else: assert (g == path).all(), (c, np.nonzero(g != path)[0][:10])
     assert len(np.unique(got)) >= 2
+
+
+@pytest.mark.parametrize("case", ["radix_forced", "not_f2_text", "quartiles_outside_the_window", "negative_zero"])
+def test_quartiles_by_counting_fall_back_to_the_radix_select(case, monkeypatch):
+    """The genome-wide quartiles are read off per-value counts when the coverage is F2 text (k / 100); anything else — a value that is not of that form, a -0.0,
+    quartiles further than the counting window from the sample's level — must end in the radix select with the same states as the oracle"""
+    cv = get_canvas()
+    bins, cov, off = _coverage(20260927 + 140, 60_000, 24)
+    if case == "radix_forced":
+        monkeypatch.setenv("CANVAS_HMM_RADIX_SELECT", "1")
+    elif case == "not_f2_text":
+        cov = cov + 1e-7 * np.arange(len(cov)) / len(cov)
+    elif case == "quartiles_outside_the_window":
+        cov = cov.copy(); cov[::2] = np.round(cov[::2] * 3 + 500, 2)            # bimodal: the upper quartile sits hundreds of units above the median
+    elif case == "negative_zero":
+        cov = cov.copy(); cov[5] = -0.0
+    _check(cv, bins, cov, off)
