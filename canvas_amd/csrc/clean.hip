@@ -1030,7 +1030,8 @@ extern "C" int32_t canvas_clean_batch(canvas_ctx* ctx, int32_t nsamples, const i
             std::vector<int64_t> n(B), nOut(B, 0); std::vector<int32_t*> c(B), st(B), sp(B), g(B); std::vector<float*> cnt(B);
             std::vector<double> lsd(B, -1.0); std::vector<int32_t> info((size_t)8 * B, 0); std::vector<char> handled(B, 0);
             for (int k = 0; k < B; k++) { const int s = idx[k]; n[k] = h_n[s]; c[k] = h_d_chr[s]; st[k] = h_d_start[s]; sp[k] = h_d_stop[s]; g[k] = h_d_gc[s]; cnt[k] = h_d_count[s]; }
-            int32_t rc = clean_batch_enqueue(ctx, B, n.data(), c.data(), st.data(), sp.data(), cnt.data(), g.data(), nchr, h_chr_is_autosome, flags, min_bins_per_gc);
+            ctx->clean_cq_failed = false;
+            int32_t rc = clean_batch_enqueue(ctx, B, n.data(), c.data(), st.data(), sp.data(), cnt.data(), g.data(), nchr, h_chr_is_autosome, flags, min_bins_per_gc, clean_counting_selects());
             if (rc == CANVAS_OK) rc = clean_batch_finish(ctx, lsd.data(), nOut.data(), info.data(), handled.data());
             if (rc) return rc;
             for (int k = 0; k < B; k++) if (handled[k]) {
@@ -1040,6 +1041,8 @@ extern "C" int32_t canvas_clean_batch(canvas_ctx* ctx, int32_t nsamples, const i
             }
         }
     }
+    ctx->clean_cq_skip = ctx->clean_cq_failed;       // samples the counting selects gave up on go straight to the radix selects
+    struct Unskip { canvas_ctx* c; ~Unskip() { c->clean_cq_skip = false; } } unskip{ctx};
     for (int s = 0; s < nsamples; s++) {
         if (done[s]) continue;                      // empty sample, LOESS / -w < 100, or the device path handed the sample back (its arrays are untouched)
         const int32_t rc = canvas_clean2(ctx, h_n[s], h_d_chr[s], h_d_start[s], h_d_stop[s], h_d_count[s], h_d_gc[s], nchr, h_chr_is_autosome, h_chr_is_y, flags, min_bins_per_gc,

@@ -34,7 +34,9 @@ struct CleanDev {
     uint32_t cursor[NGC];
     uint8_t keepGc[NGC + 3];
     long long kept;                  // bins of any chromosome that survive the GC strip
-    int gcActive, haveLocalSd, varActive, changed, nruns, pad0;
+    int gcActive, haveLocalSd, varActive, changed, nruns;
+    int cqFail;                      // the counting selects could not decide (a count that is not a two-decimal value, an order statistic outside the window): fallback is set with it
+
     double medians[NGC];
     double globalMedian;
     VarTab tab;
@@ -46,6 +48,24 @@ struct CfSel {                       // a select problem built on the device (se
     unsigned long long qk[CF_MAXQ], qprefix[CF_MAXQ];
     SelSegQ segq[NGC];
 };
+// Counting selects.  CanvasClean reads its counts from the F2 text CanvasBin (or CanvasNormalize) wrote, so every count is the float of a two-decimal value k / 100 and
+// x -> k = llrint(100 x) is strictly increasing on them: an order statistic of the counts is an order statistic of the integers k, and those are read off exact counters
+// per value (one sweep) instead of four radix passes.  The counters cover a window of CQW values around the sample's level (estimated from 33 strided keys), one row per GC
+// bucket plus one for the genome; keys below the window are counted per row, keys above it are what is left.  Every key is checked ((float)(k / 100.0) == x) and every
+// requested rank must fall inside the window: otherwise cqFail is raised and the sample is redone with the radix selects — the result never depends on the window.
+#define CQW 16384            // counter slots per row: +-82 count units around the level
+#define CQ_TILE 32768        // keys per workgroup of the counting sweep (the 64 KB of LDS counters are zeroed and flushed once per tile)
+struct CfCq {
+    int32_t lo; uint32_t bad, fail, ntiles;
+    uint32_t below[NGC + 1];         // keys under the window, per bucket and [NGC] for the genome
+    uint32_t inWin[NGC + 1];         // keys inside it
+    int32_t kq[NGC][6];              // the quartile order statistics of a bucket (as k), in quartile_indices order
+};
+__device__ __forceinline__ bool cq_key(float x, long long& k) {
+    k = llrint((double)x * 100.0);
+    return x == x && k >= 0 && k < (1ll << 30) && (float)((double)k / 100.0) == x && !(k == 0 && (__float_as_uint(x) >> 31));      // (-0.0 sorts in front of 0.0)
+}
+__device__ __forceinline__ float cq_value(long long k) { return (float)((double)k / 100.0); }
 struct CfArgs {                      // one sample of the batch
     int64_t n;                       // bins handed in
     int32_t nb, nchr, minBinsPerGc, wantLsd, doSize, doOutlier;
@@ -54,6 +74,7 @@ struct CfArgs {                      // one sample of the batch
     uint8_t* dFlags; uint32_t* dBlk; uint32_t* szHist; uint32_t* szOver; uint32_t szOverCap, padA; uint32_t* keysG; const uint8_t* isAuto;
     double* dSd; double* dRunMad; int64_t* dRunStart; long long* dPos;
     CleanDev* D; CfSel* P; SelTile* tiles; uint32_t* hist;
+    CfCq* cq; uint32_t* cqHist; SelTile* cqTiles;      // the counting selects (below)
 };
 #define CF_SAMPLE const CfArgs& A = AA[blockIdx.y]
 
@@ -537,6 +558,208 @@ __global__ void __launch_bounds__(128) k_cf_dec_f(const CfArgs* __restrict__ AA,
     __syncthreads();
     if (t == 0) { D->tab.globalIQR = globalIQR; D->changed = sig > 0 ? 1 : 0; }
 }
+// ---------------------------------------------------------------- the counting selects (see CfCq)
+// window, sweep tiles and the marker / queries the later kernels look at; gated like k_cf_sel_setup(…, gate 0)
+__global__ void __launch_bounds__(128) k_cq_setup(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    __shared__ uint32_t so[NGC + 1];
+    __shared__ long long sv[33];
+    __shared__ uint32_t shT[2];
+    const CleanDev* D = A.D; CfCq* C = A.cq; CfSel* P1 = A.P + 1; CfSel* P2 = A.P + 2;
+    const int t = threadIdx.x;
+    if (t <= NGC) so[t] = D->segOff[t];
+    __syncthreads();
+    const uint32_t total = so[NGC];
+    if (!D->gcActive || total == 0) { if (t == 0) { P1->hdr[0] = 0; P1->hdr[1] = 0; P2->hdr[0] = 0; P2->hdr[1] = 0; C->ntiles = 0; } return; }
+    if (t < 33) { const uint32_t i = (uint32_t)((double)total * (t + 0.5) / 33.0); long long k = -1; if (i < total && !cq_key(float_of_key(A.keysG[i]), k)) k = -1; sv[t] = k; }
+    __syncthreads();
+    if (t < 33) {                                            // every lane ranks its own sample among the valid ones; the one in the middle sets the window
+        const long long mine = sv[t];
+        int m = 0, rank = 0;
+        for (int j = 0; j < 33; j++) { const long long o = sv[j]; if (o >= 0) { m++; if (o < mine || (o == mine && j < t)) rank++; } }
+        if (m == 0) { if (t == 0) C->lo = 0; }
+        else if (mine >= 0 && rank == m / 2) C->lo = (int32_t)(mine > CQW / 2 ? mine - CQW / 2 : 0);
+    }
+    uint32_t totT;
+    const uint32_t myTiles = t < NGC ? (so[t + 1] - so[t] + CQ_TILE - 1) / CQ_TILE : 0u;
+    const uint32_t exT = cf_excl_scan128(myTiles, shT, &totT);
+    if (t < NGC) { uint32_t k = exT; for (int64_t b = so[t]; b < (int64_t)so[t + 1]; b += CQ_TILE) A.cqTiles[k++] = SelTile{t, b, min<int64_t>(b + CQ_TILE, (int64_t)so[t + 1])}; }
+    if (t == 0) {
+        C->ntiles = totT;
+        P1->hdr[0] = 0; P1->hdr[1] = 1;                      // "NormalizeByGC has been decided" for k_cf_scatter_final / k_cf_apply_gc
+        P2->hdr[0] = 0; P2->hdr[1] = 0;
+        if (D->varActive) {                                  // the genome's quartile ranks: the only queries left to a (weighted) radix select
+            const QuartIdx qi = quartile_indices((int64_t)total);
+            for (int k = 0; k < qi.n; k++) { P2->qk[k] = (unsigned long long)qi.idx[k]; P2->qprefix[k] = 0ull; }
+            P2->hdr[1] = (uint32_t)qi.n; P2->first[NGC] = 0;
+        }
+    }
+}
+// one sweep of the grouped keys: counters per value in LDS, flushed into the bucket's row and the genome's
+__global__ void __launch_bounds__(1024) k_cq_hist(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    __shared__ uint32_t lw[CQW];
+    CfCq* __restrict__ C = A.cq;
+    if (blockIdx.x >= C->ntiles) return;
+    const SelTile T = A.cqTiles[blockIdx.x];
+    const long long lo = C->lo;
+    for (int i = threadIdx.x; i < CQW; i += 1024) lw[i] = 0;
+    __syncthreads();
+    const uint32_t* __restrict__ keys = A.keysG;
+    uint32_t below = 0, bad = 0;
+    for (int64_t i0 = T.begin + threadIdx.x; i0 < T.end; i0 += 4 * 1024) {
+        uint32_t kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + (int64_t)u * 1024; kk[u] = i < T.end ? keys[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + (int64_t)u * 1024 >= T.end) break;
+            long long k;
+            if (!cq_key(float_of_key(kk[u]), k)) { bad = 1; continue; }
+            if (k < lo) below++;
+            else if (k - lo < CQW) atomicAdd(&lw[k - lo], 1u);
+        }
+    }
+    below = wave_reduce_add_u32(below);
+    if ((threadIdx.x & 63) == 0 && below) { atomicAdd(&C->below[T.seg], below); atomicAdd(&C->below[NGC], below); }
+    if (bad) C->bad = 1u;
+    __syncthreads();
+    uint32_t* __restrict__ row = A.cqHist + (size_t)T.seg * CQW; uint32_t* __restrict__ all = A.cqHist + (size_t)NGC * CQW;
+    for (int i = threadIdx.x; i < CQW; i += 1024) { const uint32_t v = lw[i]; if (v) { atomicAdd(&row[i], v); atomicAdd(&all[i], v); } }
+}
+// workgroup g: the order statistics of bucket g (g == NGC: of the genome) from its counters — the NormalizeByGC medians (CanvasClean.cs:170-189) and, for the variance
+// normalisation, the bucket's quartile statistics as k (a bucket is scaled by one factor, so they keep their ranks)
+__global__ void __launch_bounds__(1024) k_cq_pick(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    __shared__ uint32_t swave[16];
+    __shared__ long long sK[8];
+    __shared__ int sFail;
+    CleanDev* __restrict__ D = A.D; CfCq* __restrict__ C = A.cq;
+    if (A.P[1].hdr[1] == 0) return;
+    const int g = blockIdx.x, t = threadIdx.x;
+    if (g == 0 && t == 0 && C->bad) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; }
+    const int64_t cnt = g < NGC ? (int64_t)D->segOff[g + 1] - (int64_t)D->segOff[g] : (int64_t)D->segOff[NGC];
+    if (cnt <= 0) return;
+    int64_t ranks[8]; int nr = 0;
+    if (cnt % 2) ranks[nr++] = cnt / 2; else { ranks[nr++] = cnt / 2 - 1; ranks[nr++] = cnt / 2; }
+    const int nMed = nr;
+    if (g < NGC && D->varActive) { const QuartIdx qi = quartile_indices(cnt); for (int k = 0; k < qi.n; k++) ranks[nr++] = qi.idx[k]; }
+    const uint4* __restrict__ row = reinterpret_cast<const uint4*>(A.cqHist + (size_t)g * CQW) + 4 * t;     // 16 consecutive counters per thread
+    uint32_t c[16];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const uint4 v = row[u]; c[4 * u] = v.x; c[4 * u + 1] = v.y; c[4 * u + 2] = v.z; c[4 * u + 3] = v.w; }
+    uint32_t s = 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) s += c[u];
+    const uint32_t inc = wave_inclusive_scan_u32(s);
+    if ((t & 63) == 63) swave[t >> 6] = inc;
+    if (t == 0) sFail = 0;
+    __syncthreads();
+    uint32_t woff = 0, inWin = 0;
+    for (int w = 0; w < 16; w++) { if (w < (t >> 6)) woff += swave[w]; inWin += swave[w]; }
+    const uint32_t ex = woff + inc - s;
+    const int64_t below = (int64_t)C->below[g];
+    const long long lo = C->lo;
+    for (int q = 0; q < nr; q++) {
+        const int64_t r = ranks[q] - below;
+        if (r < 0 || r >= (int64_t)inWin) { if (t == 0) sFail = 1; continue; }
+        if (r >= (int64_t)ex && r < (int64_t)ex + s) {
+            uint32_t left = (uint32_t)(r - ex); int u = 0;
+            while (left >= c[u]) { left -= c[u]; u++; }
+            sK[q] = lo + 16 * t + u;
+        }
+    }
+    __syncthreads();
+    if (t != 0) return;
+    C->inWin[g] = inWin;
+    if (sFail) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; return; }
+    const double med = nMed == 1 ? (double)cq_value(sK[0]) : (double)median_from_two(cq_value(sK[0]), cq_value(sK[1]));
+    if (g < NGC) { D->medians[g] = med; for (int k = nMed; k < nr; k++) C->kq[g][k - nMed] = (int32_t)sK[k]; }
+    else D->globalMedian = med;
+}
+// NormalizeByGC as a function of k for bucket g (what k_cf_xform_gc does to a key)
+__device__ __forceinline__ float cq_normalised(long long k, double median, double globalMedian) {
+    const float x = cq_value(k);
+    return median > 0 ? (float)(globalMedian * (double)x / median) : x;
+}
+// one pass of the weighted radix select for the genome's quartiles of the normalised counts (CanvasClean.cs:34-66): the items are the counters (value = the
+// normalised count of the slot, weight = the counter); keys below / above a bucket's window enter as weights at the smallest / largest key, which k_cq_dec_f checks
+#define CQ_WSLOTS 4096       // counter slots per workgroup
+__global__ void __launch_bounds__(256) k_cq_whist(const CfArgs* __restrict__ AA, int shift, int firstPass) {
+    CF_SAMPLE;
+    __shared__ uint32_t lh[8 * 256];
+    __shared__ unsigned long long lpre[8];
+    const CfSel* __restrict__ P = A.P + 2; const CleanDev* __restrict__ D = A.D; const CfCq* __restrict__ C = A.cq;
+    const int nq = (int)P->hdr[1];
+    if (nq == 0) return;
+    const int g = blockIdx.x / (CQW / CQ_WSLOTS), part = blockIdx.x % (CQW / CQ_WSLOTS);
+    const int64_t cnt = (int64_t)D->segOff[g + 1] - (int64_t)D->segOff[g];
+    if (cnt <= 0) return;
+    for (int i = threadIdx.x; i < nq * 256; i += 256) lh[i] = 0;
+    if (threadIdx.x < nq) lpre[threadIdx.x] = firstPass ? 0ull : P->qprefix[threadIdx.x];
+    __syncthreads();
+    const int sh2 = firstPass ? 0 : shift + 8;
+    auto add = [&](uint32_t key, uint32_t w) {
+        const unsigned long long hi = (unsigned long long)(key >> sh2); const uint32_t d = (key >> shift) & 255u;
+        for (int q = 0; q < nq; q++) if (firstPass || hi == lpre[q]) atomicAdd(&lh[q * 256 + d], w);
+    };
+    const double median = D->medians[g], globalMedian = D->globalMedian;
+    const long long lo = C->lo;
+    const uint32_t* __restrict__ row = A.cqHist + (size_t)g * CQW + (size_t)part * CQ_WSLOTS;
+    for (int j = threadIdx.x; j < CQ_WSLOTS; j += 256) {
+        const uint32_t w = row[j];
+        if (w) add(key_of_float(cq_normalised(lo + part * CQ_WSLOTS + j, median, globalMedian)), w);
+    }
+    if (part == 0 && threadIdx.x == 0) {
+        const uint32_t below = C->below[g], above = (uint32_t)(cnt - (int64_t)below - (int64_t)C->inWin[g]);
+        if (below) add(0u, below);
+        if (above) add(0xFFFFFFFFu, above);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq * 256; i += 256) { const uint32_t v = lh[i]; if (v) atomicAdd(&A.hist[((size_t)(blockIdx.x % SEL_REP) * CF_MAXQ + (i >> 8)) * 256 + (i & 255)], v); }
+}
+// NormalizeVarianceByGC decision (CanvasClean.cs:34-83) from the buckets' k statistics and the genome's selected keys
+__global__ void __launch_bounds__(128) k_cq_dec_f(const CfArgs* __restrict__ AA) {
+    CF_SAMPLE;
+    __shared__ int sig, sFail;
+    const CfSel* __restrict__ P = A.P + 2; CleanDev* __restrict__ D = A.D; const CfCq* __restrict__ C = A.cq;
+    if (P->hdr[1] == 0) return;
+    const int t = threadIdx.x;
+    if (t == 0) { sig = 0; sFail = 0; }
+    __syncthreads();
+    const int64_t total = (int64_t)D->segOff[NGC];
+    const QuartIdx gi = quartile_indices(total);
+    float gv[6]; uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (int k = 0; k < gi.n; k++) { const uint32_t key = (uint32_t)P->qprefix[k]; gv[k] = float_of_key(key); kmin = min(kmin, key); kmax = max(kmax, key); }
+    float g1, g2, g3;
+    quartiles_from_values(total, gv, g1, g2, g3);
+    const float globalIQR = g3 - g1;
+    const double globalMedian = D->globalMedian;
+    const long long lo = C->lo;
+    if (t < NGC) {
+        const int64_t cnt = (int64_t)D->segOff[t + 1] - (int64_t)D->segOff[t];
+        float liqr = -1.0f, med = -1.0f;
+        if (cnt > 0) {
+            const double median = D->medians[t];
+            const QuartIdx qi = quartile_indices(cnt);
+            float v[6];
+            for (int k = 0; k < qi.n; k++) v[k] = cq_normalised(C->kq[t][k], median, globalMedian);
+            float q1, q2, q3; quartiles_from_values(cnt, v, q1, q2, q3);
+            med = q2; liqr = q3 - q1;
+            // the genome's answers are right only if every key that was left out of this bucket's window lies on the side it was counted on
+            const uint32_t below = C->below[t], above = (uint32_t)(cnt - (int64_t)below - (int64_t)C->inWin[t]);
+            if (below && key_of_float(cq_normalised(lo, median, globalMedian)) > kmin) atomicOr(&sFail, 1);
+            if (above && key_of_float(cq_normalised(lo + CQW - 1, median, globalMedian)) < kmax) atomicOr(&sFail, 1);
+        }
+        D->tab.localIQR[t] = liqr; D->tab.med[t] = med;
+        if (t >= 10 && t < 90 && globalIQR * 2.0f < liqr) atomicAdd(&sig, 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (kmin == 0u || kmax == 0xFFFFFFFFu || sFail) { A.cq->fail = 1u; D->cqFail = 1; D->fallback = 1u; D->changed = 0; return; }
+        D->tab.globalIQR = globalIQR; D->changed = sig > 0 ? 1 : 0;
+    }
+}
 __global__ void __launch_bounds__(256) k_cf_apply_var(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ float sIqr[NGC], sMedF[NGC];
@@ -647,7 +870,7 @@ __global__ void __launch_bounds__(256) k_cf_scatter_final(const CfArgs* __restri
 }
 
 // ---------------------------------------------------------------- host side
-struct CleanPending { int B; unsigned gxN, gxB, gxT; bool anyLsd, anyVar, anyGc; CfArgs* dArgs; CleanDev* dD; std::vector<CfArgs> h; };
+struct CleanPending { int B; unsigned gxN, gxB, gxT; bool anyLsd, anyVar, anyGc, useCq; CfArgs* dArgs; CleanDev* dD; std::vector<CfArgs> h; };
 
 static void cf_select_passes(canvas_ctx* ctx, const CfArgs* dArgs, int B, unsigned gxT, int which) {
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -665,18 +888,22 @@ static void cf_gc_medians(canvas_ctx* ctx, const CfArgs* args, int B, unsigned g
     if (apply) hipLaunchKernelGGL(k_cf_apply_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, B), dim3(256), 0, ctx->stream, args, which);
 }
 
+// CANVAS_CLEAN_RADIX_SELECT=1 switches the counting selects off (test hook: both ways must agree)
+static inline bool clean_counting_selects() { return getenv("CANVAS_CLEAN_RADIX_SELECT") == nullptr; }
 // Enqueues the whole stage for B samples on ctx->stream (no synchronisation): the CleanDev blocks arrive in ctx->pin.  clean_batch_finish waits for them.
 static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t* const* d_chr, int32_t* const* d_start, int32_t* const* d_stop, float* const* d_count, int32_t* const* d_gc,
-                                   int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc) {
+                                   int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc, bool useCq) {
+    useCq = useCq && (flags & CANVAS_CLEAN_GCNORM);
+    const size_t cqWords = useCq ? (size_t)B * (NGC + 1) * CQW : 0;
     WsSizer sz;
-    sz.take<CleanDev>(B); sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<uint32_t>((size_t)B * CF_SZ_BINS);
+    sz.take<CleanDev>(B); sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<CfCq>(B); sz.take<uint32_t>(cqWords);
     int64_t nMax = 0; bool anyLsd = false, anyVar = false;
     for (int s = 0; s < B; s++) {
         const int64_t n = h_n[s], nW0 = n / 20 + 2, nb = nblk(n, CBLK); const size_t tilesUpper = (size_t)(n / SEL_TILE + NGC + 1);
         nMax = std::max(nMax, n);
         sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n);
         sz.take<uint8_t>(n); sz.take<uint32_t>(2 * (nb + 2)); sz.take<uint32_t>(n); sz.take<uint32_t>(n / 8 + 1024); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
-        sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CfSel>(CF_NPROB); sz.take<SelTile>(tilesUpper * CF_NPROB);
+        sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CfSel>(CF_NPROB); sz.take<SelTile>(tilesUpper * CF_NPROB); sz.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1));
     }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
     const size_t histPer = (size_t)CF_MAXQ * 1024 * SEL_REP, histBytes = histPer * (size_t)B;
@@ -687,8 +914,9 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     }
     WsCarver ws(ctx->ws);
     CleanDev* dD = ws.take<CleanDev>(B); CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS);
-    CleanPending pend; pend.B = B; pend.dArgs = dArgs; pend.dD = dD; pend.h.resize(B);
-    unsigned gxT = 1;
+    CfCq* dCq = ws.take<CfCq>(B); uint32_t* dCqHist = ws.take<uint32_t>(cqWords);             // adjacent: one memset clears both
+    CleanPending pend; pend.useCq = useCq; pend.B = B; pend.dArgs = dArgs; pend.dD = dD; pend.h.resize(B);
+    unsigned gxT = 1, gxTcq = 1;
     for (int s = 0; s < B; s++) {
         const int64_t n = h_n[s], nW0 = n / 20 + 2; const int nb = (int)nblk(n, CBLK); const unsigned tilesUpper = (unsigned)(n / SEL_TILE + NGC + 1);
         CfArgs& A = pend.h[s];
@@ -700,6 +928,8 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         A.dFlags = ws.take<uint8_t>(n); A.dBlk = ws.take<uint32_t>(2 * (nb + 2)); A.keysG = ws.take<uint32_t>(n); A.szOverCap = (uint32_t)(n / 8 + 1024); A.padA = 0; A.szOver = ws.take<uint32_t>(A.szOverCap);
         A.dSd = ws.take<double>(nW0); A.dRunMad = ws.take<double>(CF_MAXRUN + 8); A.dRunStart = ws.take<int64_t>(CF_MAXRUN + 8); A.dPos = ws.take<long long>(65536);
         A.P = ws.take<CfSel>(CF_NPROB); A.tiles = ws.take<SelTile>((size_t)tilesUpper * CF_NPROB);
+        A.cqTiles = ws.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1)); A.cq = dCq + s; A.cqHist = dCqHist + (size_t)s * (NGC + 1) * CQW;
+        gxTcq = std::max(gxTcq, (unsigned)(n / CQ_TILE + NGC + 1));
         A.isAuto = dIsAuto; A.szHist = dSz + (size_t)s * CF_SZ_BINS; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
         gxT = std::max(gxT, tilesUpper);
         anyLsd = anyLsd || A.wantLsd; anyVar = anyVar || (A.wantLsd && n > 500000);
@@ -710,6 +940,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     rc = canvas_h2d_small(ctx, dIsAuto, h_chr_is_autosome, nchr); if (rc) return rc;
     rc = canvas_h2d_small(ctx, dArgs, pend.h.data(), (size_t)B * sizeof(CfArgs)); if (rc) return rc;
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dD, 0, (size_t)B * sizeof(CleanDev), ctx->stream));
+    if (useCq) CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCq, 0, (size_t)((char*)(dCqHist + cqWords) - (char*)dCq), ctx->stream));
     // ---- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes from exact per-size counts, left on the device
     if (flags & CANVAS_CLEAN_FILTSIZE) {
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dSz, 0, (size_t)B * CF_SZ_BINS * 4, ctx->stream));
@@ -733,7 +964,20 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         hipLaunchKernelGGL(k_cf_run_mad, dim3(CF_MAXRUN, B), dim3(1024), 0, ctx->side, dArgs);
     }
     // ---- NormalizeByGC on the grouped keys the compaction left
-    if (flags & CANVAS_CLEAN_GCNORM) {
+    if (useCq) {
+        // counting selects (CfCq): one sweep + one pick for every median and every bucket's quartiles; the genome's quartiles of the normalised counts by a weighted
+        // radix select over the counters
+        hipLaunchKernelGGL(k_cq_setup, dim3(1, B), dim3(128), 0, ctx->stream, dArgs);
+        hipLaunchKernelGGL(k_cq_hist, dim3(gxTcq, B), dim3(1024), 0, ctx->stream, dArgs);
+        hipLaunchKernelGGL(k_cq_pick, dim3(NGC + 1, B), dim3(1024), 0, ctx->stream, dArgs);
+        if (anyVar) {
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                hipLaunchKernelGGL(k_cq_whist, dim3(NGC * (CQW / CQ_WSLOTS), B), dim3(256), 0, ctx->stream, dArgs, shift, shift == 24 ? 1 : 0);
+                hipLaunchKernelGGL(k_cf_select_pick, dim3(8, B), dim3(64), 0, ctx->stream, dArgs, 2, shift == 24 ? 1 : 0);
+            }
+            hipLaunchKernelGGL(k_cq_dec_f, dim3(1, B), dim3(128), 0, ctx->stream, dArgs);
+        }
+    } else if (flags & CANVAS_CLEAN_GCNORM) {
         cf_gc_medians(ctx, dArgs, B, gxN, gxT, 1, 0, false);
         if (anyVar) {
             // NormalizeVarianceByGC (CanvasClean.cs:512-519): quartiles of the normalised counts; if it changes anything, NormalizeByGC once more
@@ -778,6 +1022,7 @@ static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64
         const unsigned gxN = (unsigned)nblk(q.h[s].n, 256), gxB = (unsigned)nblk(q.h[s].n, CBLK), gxT = q.h[s].tilesUpper;
         hipLaunchKernelGGL(k_cf_apply_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a, 1);      // the first NormalizeByGC, deferred until now (medians of problem 1 are still in CleanDev)
         hipLaunchKernelGGL(k_cf_apply_var, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a);
+        if (q.useCq) hipLaunchKernelGGL(k_cf_xform_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a, 2);       // the counting selects left the grouped keys as they were
         hipLaunchKernelGGL(k_cf_xform_var, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a);
         cf_gc_medians(ctx, a, 1, gxN, gxT, 3, 2, true);
         hipLaunchKernelGGL(k_cf_flags_final, dim3(gxB, 1), dim3(256), 0, ctx->stream, a);
@@ -793,13 +1038,14 @@ static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64
     for (int s = 0; s < B; s++) {
         const CleanDev& H = ((const CleanDev*)ctx->pin)[s];
         if (H.bad) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: a bin has gc outside 0..100 or a chromosome index outside [0, nchr) (the reference throws IndexOutOfRangeException)");
+        if (H.cqFail) ctx->clean_cq_failed = true;                         // the caller redoes the sample with the radix selects
         if (H.fallback) continue;                                          // handled[s] stays 0: nothing was written to the caller's arrays
         handled[s] = 1;
         h_n_out[s] = (int64_t)H.nFinal;
         if (h_local_sd_out) h_local_sd_out[s] = H.haveLocalSd ? H.localSd : -1.0;
         if (h_info) {
             int32_t info[8] = {0};
-            info[0] = (int32_t)H.nA; info[1] = (int32_t)H.nAB; info[2] = (int32_t)(H.gcActive ? H.kept : (long long)H.nAB); info[3] = (int32_t)H.nFinal; info[4] = H.changed;
+            info[0] = (int32_t)H.nA; info[1] = (int32_t)H.nAB; info[2] = (int32_t)(H.gcActive ? H.kept : (long long)H.nAB); info[3] = (int32_t)H.nFinal; info[4] = H.changed; info[5] = q.useCq ? 1 : 0;
             memcpy(h_info + 8 * s, info, sizeof info);
         }
     }
@@ -809,9 +1055,14 @@ static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64
 static int32_t clean_device_driven(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count, int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome,
                                    uint32_t flags, int32_t min_bins_per_gc, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, bool* handled) {
     *handled = false;
-    int32_t rc = clean_batch_enqueue(ctx, 1, &n, &d_chr, &d_start, &d_stop, &d_count, &d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc); if (rc) return rc;
     char h = 0; double lsd = -1.0; int64_t nOut = 0; int32_t info[8] = {0};
-    rc = clean_batch_finish(ctx, &lsd, &nOut, info, &h); if (rc) return rc;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool useCq = attempt == 0 && clean_counting_selects() && !ctx->clean_cq_skip;
+        ctx->clean_cq_failed = false;
+        int32_t rc = clean_batch_enqueue(ctx, 1, &n, &d_chr, &d_start, &d_stop, &d_count, &d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc, useCq); if (rc) return rc;
+        rc = clean_batch_finish(ctx, &lsd, &nOut, info, &h); if (rc) return rc;
+        if (h || !ctx->clean_cq_failed) break;                              // (a sample the counting selects gave up on is redone once, with the radix selects)
+    }
     if (h) { *handled = true; *h_n_out = nOut; if (h_local_sd_out) *h_local_sd_out = lsd; if (h_info) memcpy(h_info, info, sizeof info); }
     return CANVAS_OK;
 }

@@ -163,7 +163,9 @@ int32_t canvas_bin_predefined(canvas_ctx* ctx, int32_t nchr, const uint8_t* cons
  * survive are compacted to the front, *h_n_out = surviving count.  h_chr_is_autosome[nchr] answers
  * GenomeMetadata.SequenceMetadata.IsAutosome for each chromosome index.  min_bins_per_gc = the -w option (default 100).
  * h_local_sd_out receives the #localSD metric (IO.cs:83-98) or -1.  h_info (may be NULL) gets 8 int32 diagnostics:
- * [0] after size filter, [1] after outlier filter, [2] after GC strip, [3] after local-SD filter, [4] variance-normalised. */
+ * [0] after size filter, [1] after outlier filter, [2] after GC strip, [3] after local-SD filter, [4] variance-normalised,
+ * [5] 1 = the medians / quartiles were read off exact per-value counters (counts that are two-decimal values, as the F2 text
+ * of a .binned file always is), 0 = radix selects (any other input; same results). */
 int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
                      int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
                      double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);

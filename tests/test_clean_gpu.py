@@ -10,16 +10,34 @@ pytestmark = pytest.mark.gpu
 ALL = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD
 
 
-@pytest.fixture(params=["device_driven", "host_driven"], autouse=True)
+@pytest.fixture(params=["device_driven", "device_driven_radix", "host_driven"], autouse=True)
 def clean_path(request, monkeypatch):
     """Both CanvasClean orchestrations run every case: the device-driven one (clean_fast.hpp: decisions in one-workgroup kernels, one synchronisation) that the default
     options take, and the host-driven one (CANVAS_CLEAN_HOST_DRIVEN=1) that remains for -m LOESS, -w < 100 and inputs with very many chromosome runs."""
     if request.param == "host_driven":
         monkeypatch.setenv("CANVAS_CLEAN_HOST_DRIVEN", "1")
+    if request.param == "device_driven_radix":          # the order statistics by radix selects instead of the per-value counters (same results)
+        monkeypatch.setenv("CANVAS_CLEAN_RADIX_SELECT", "1")
     return request.param
 
 
-def _run(cv, bins, flags, nchr=24, w=100, is_auto=None):
+def _f2(count):
+    """The counts as CanvasClean reads them from a .binned file: floats of two-decimal values."""
+    return (np.round(count.astype(np.float64) * 100.0) / 100.0).astype(np.float32)
+
+
+def _run(cv, bins, flags, nchr=24, w=100, is_auto=None, f2_too=True):
+    info, exp = _run1(cv, bins, flags, nchr, w, is_auto)
+    if f2_too and not (_f2(bins["count"]).view(np.uint32) == bins["count"].view(np.uint32)).all():
+        # counts with more decimals than a .binned file can hold went through the radix selects: the same case on two-decimal counts takes the counters
+        b2 = dict(bins); b2["count"] = _f2(bins["count"])
+        info2, _ = _run1(cv, b2, flags, nchr, w, is_auto)
+        assert info[5] == 0
+        info = info2
+    return info, exp
+
+
+def _run1(cv, bins, flags, nchr=24, w=100, is_auto=None):
     is_auto = synth.IS_AUTOSOME[:nchr] if is_auto is None else np.asarray(is_auto, np.uint8)
     is_y = np.zeros(nchr, np.uint8); is_y[-1] = 1
     exp = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, flags, min_bins_weighted=w)
@@ -250,3 +268,31 @@ def test_clean_size_percentile_among_huge_bins(frac_huge, huge):
     bins["stop"] = np.where(pick, bins["start"] + huge + rng.randint(0, 5000, n), np.minimum(bins["stop"], bins["start"] + 60_000)).astype(np.int32)
     info, exp = _run(cv, bins, ALL)
     assert info[0] == exp["stages"][0]
+
+
+def test_clean_counting_selects_taken_and_given_up(clean_path):
+    """The per-value counters decide the order statistics only when they can do so exactly: integer and two-decimal counts around one level take them; counts with
+    more decimals, a level whose GC buckets spread beyond the counter window, negative zero and huge outliers inside a bucket's quartile range hand the sample to the
+    radix selects.  Either way the result is the oracle's."""
+    cv = get_canvas()
+    flags = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_LOCALSD
+    base = synth.generate_bins(20260928 + 1, 640_000)
+    want = 1 if clean_path == "device_driven" else 0
+    info, _ = _run1(cv, base, flags)                                        # integer counts
+    assert info[5] == want
+    b = dict(base); b["count"] = _f2(base["count"] * np.float32(0.37))      # two decimals, level ~ 37 (the pseudo-counts of a tumour / normal ratio)
+    info, _ = _run1(cv, b, flags)
+    assert info[5] == want
+    b = dict(base); b["count"] = (base["count"] * np.float32(1.0001)).astype(np.float32)      # not two-decimal values
+    info, _ = _run1(cv, b, flags)
+    assert info[5] == 0
+    b = dict(base); b["count"] = _f2(base["count"] * np.float32(23.0))      # level ~ 2300: the GC buckets' medians lie hundreds of counts apart
+    info, _ = _run1(cv, b, flags)
+    assert info[5] == 0
+    b = dict(base); b["count"] = base["count"].copy(); b["count"][::1000] = -0.0
+    info, _ = _run1(cv, b, flags)
+    assert info[5] == 0
+    rng = np.random.RandomState(5)
+    b = dict(base); c = base["count"].copy(); hot = (base["gc"] == 41) & (rng.rand(len(c)) < 0.4); c[hot] = c[hot] + 5000; b["count"] = c      # 40 % of one bucket far above the window
+    info, _ = _run1(cv, b, flags)
+    assert info[5] == 0

@@ -11,13 +11,19 @@ from canvas_amd import Canvas, synth, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIE
 
 cv = Canvas(0); cv.profile_enable(True)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
-t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}; nbatch = 0
+t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}; nbatch = 0; ncount = 0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 while time.time() - t0 < budget:
     seed = int(rng.randint(1, 2**31 - 1)); n = int(rng.choice([3_000, 30_000, 120_000, 600_000])); nchr = int(rng.choice([1, 3, 24]))
     bins = synth.generate_bins(seed, n, nchr=nchr)
     noise = rng.choice([0.0, 10.0, 40.0])
     if noise: bins["count"] = (bins["count"] + rng.normal(0, noise, len(bins["count"]))).clip(0).astype(np.float32)
+    # two thirds of the samples carry two-decimal counts (what CanvasClean reads from a .binned file) at some level: the per-value counters decide their order statistics
+    # when the level allows; the rest go through the radix selects
+    shape = rng.choice(["as_is", "f2", "f2_scaled"])
+    if shape != "as_is":
+        scale = 1.0 if shape == "f2" else float(rng.choice([0.05, 0.4, 1.7, 4.0]))
+        bins["count"] = (np.round(bins["count"].astype(np.float64) * scale * 100.0) / 100.0).astype(np.float32)
     flags = int(rng.choice([CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD, CLEAN_GCNORM, CLEAN_FILTSIZE | CLEAN_OUTLIERS, CLEAN_GCNORM | CLEAN_LOCALSD | CLEAN_FILTSIZE]))
     is_auto = synth.IS_AUTOSOME[:nchr]; is_y = np.zeros(nchr, np.uint8)
     ex = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, flags)
@@ -37,8 +43,10 @@ while time.time() - t0 < budget:
             assert (d["count"][:int(no)].cpu().numpy().view(np.uint32) == e["count"].view(np.uint32)).all() and (d["stop"][:int(no)].cpu().numpy() == e["stop"]).all(), ("batch", seed, n, nchr, flags)
         nbatch += 1
         n_out, lsd = int(nouts[pos]), float(lsds[pos])
+        ncount += int(infos[pos][5])
     else:
         n_out, lsd, info = cv.clean(dev, len(bins["chr"]), is_auto, flags)
+        ncount += int(info[5])
     assert n_out == len(ex["chr"]) and lsd == ex["local_sd"], (seed, n, nchr, flags)
     got = dev["count"][:n_out].cpu().numpy()
     assert (got.view(np.uint32) == ex["count"].view(np.uint32)).all() and (dev["start"][:n_out].cpu().numpy() == ex["start"]).all(), (seed, n, nchr, flags)
@@ -57,4 +65,4 @@ while time.time() - t0 < budget:
             assert (st[off[c]:off[c + 1]] == e).all(), ("hmm", seed, n, nchr, c)
     it += 1
 print("fallback runs by (n, nchr, noise):", sorted(fb.items()))
-print(f"soak: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s; {nbatch} of them inside a cohort call; second speculative attempts: {retries}, sequential Viterbi fallbacks: {fallbacks}")
+print(f"soak: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s; {nbatch} of them inside a cohort call; {ncount} decided by the per-value counters; second speculative attempts: {retries}, sequential Viterbi fallbacks: {fallbacks}")
