@@ -896,7 +896,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     useCq = useCq && (flags & CANVAS_CLEAN_GCNORM);
     const size_t cqWords = useCq ? (size_t)B * (NGC + 1) * CQW : 0;
     WsSizer sz;
-    sz.take<CleanDev>(B); sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<CfCq>(B); sz.take<uint32_t>(cqWords);
+    sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<CleanDev>(B); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<CfCq>(B); sz.take<uint32_t>(cqWords);
     int64_t nMax = 0; bool anyLsd = false, anyVar = false;
     for (int s = 0; s < B; s++) {
         const int64_t n = h_n[s], nW0 = n / 20 + 2, nb = nblk(n, CBLK); const size_t tilesUpper = (size_t)(n / SEL_TILE + NGC + 1);
@@ -913,8 +913,9 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->sel_hist, 0, ctx->sel_hist_bytes, ctx->stream));       // zero once: k_select_pick clears every row it has read
     }
     WsCarver ws(ctx->ws);
-    CleanDev* dD = ws.take<CleanDev>(B); CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS);
-    CfCq* dCq = ws.take<CfCq>(B); uint32_t* dCqHist = ws.take<uint32_t>(cqWords);             // adjacent: one memset clears both
+    // two adjacent groups: what the host sends (one copy) and what starts as zero (one memset)
+    CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr);
+    CleanDev* dD = ws.take<CleanDev>(B); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS); CfCq* dCq = ws.take<CfCq>(B); uint32_t* dCqHist = ws.take<uint32_t>(cqWords);
     CleanPending pend; pend.useCq = useCq; pend.B = B; pend.dArgs = dArgs; pend.dD = dD; pend.h.resize(B);
     unsigned gxT = 1, gxTcq = 1;
     for (int s = 0; s < B; s++) {
@@ -937,13 +938,14 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     const unsigned gxN = (unsigned)nblk(nMax, 256), gxB = (unsigned)nblk(nMax, CBLK);
     pend.gxN = gxN; pend.gxB = gxB; pend.gxT = gxT; pend.anyLsd = anyLsd; pend.anyVar = anyVar; pend.anyGc = (flags & CANVAS_CLEAN_GCNORM) != 0;
     ProfScope psTotal(ctx, "clean_total");
-    rc = canvas_h2d_small(ctx, dIsAuto, h_chr_is_autosome, nchr); if (rc) return rc;
-    rc = canvas_h2d_small(ctx, dArgs, pend.h.data(), (size_t)B * sizeof(CfArgs)); if (rc) return rc;
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dD, 0, (size_t)B * sizeof(CleanDev), ctx->stream));
-    if (useCq) CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCq, 0, (size_t)((char*)(dCqHist + cqWords) - (char*)dCq), ctx->stream));
+    {
+        std::vector<char> up((size_t)((char*)(dIsAuto + nchr) - (char*)dArgs), 0);
+        memcpy(up.data(), pend.h.data(), (size_t)B * sizeof(CfArgs)); memcpy(up.data() + ((char*)dIsAuto - (char*)dArgs), h_chr_is_autosome, nchr);
+        rc = canvas_h2d_small(ctx, dArgs, up.data(), up.size()); if (rc) return rc;
+    }
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dD, 0, (size_t)((char*)(dCqHist + cqWords) - (char*)dD), ctx->stream));      // CleanDev blocks, size counters, CfCq blocks, value counters
     // ---- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes from exact per-size counts, left on the device
     if (flags & CANVAS_CLEAN_FILTSIZE) {
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dSz, 0, (size_t)B * CF_SZ_BINS * 4, ctx->stream));
         hipLaunchKernelGGL(k_cf_size_hist, dim3(CF_SZ_GRID, B), dim3(1024), 0, ctx->stream, dArgs);
         hipLaunchKernelGGL(k_cf_size_pick, dim3(1, B), dim3(1024), 0, ctx->stream, dArgs);        // sizeOn stays 0 (the memset of the CleanDev blocks) without the filter
     }
