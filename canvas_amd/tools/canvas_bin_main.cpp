@@ -12,7 +12,8 @@
 //   CanvasBin -b S.bam -r genome.fa -n bins.bed -o S.binned -m Fragment -p                              FragmentBinner.Bin (FragmentBinner.cs:26-80): host code
 // Fragment mode is a sequential dictionary algorithm over the BAM stream keyed by read name (the mate confirms or undoes what the first read of the pair did): its cost is
 // BGZF inflation and string hashing, there is no data-parallel part, so it runs on the host exactly as in the reference.
-// Not built (exit code 1 with a message): -t manifest (the Nextera manifest parser lives in Isas.Manifests, outside /root/reference) and the multi-sample -j json mode.
+// Not built (exit code 1 with a message): -t manifest (the Nextera manifest parser lives in Isas.Manifests, outside /root/reference).  -j behaves as in this version of the
+// reference: the json file must exist and is never read, nothing is binned or written (CanvasBin.cs:936-944), exit code 0; with -i it is the reference's ArgumentException.
 #include "tool_common.hpp"
 #include "protobuf_dat.hpp"
 #include <algorithm>
