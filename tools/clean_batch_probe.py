@@ -1,4 +1,4 @@
-"""canvas_clean_batch on B copies of one WGS-size bin list (for rocprofv3): python tools/clean_batch_probe.py [B] [reps]"""
+"""canvas_clean_batch on B copies of one WGS-size bin list (for rocprofv3): python tools/clean_batch_probe.py [B] [reps] [count scale]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,6 +18,8 @@ mk = lambda dt: torch.empty(cap, dtype=dt, device=dev)
 out = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
 _, per, total, bs = cv.bin_sample(bases, masks, hits, lens, synth.IS_AUTOSOME, 100, -1, 3, out=out)
 binned = {k: v[:total].clone() for k, v in out.items()}
+if len(sys.argv) > 3:          # two-decimal counts at another level (e.g. 0.37: the pseudo-counts of a tumour / normal ratio) instead of integer read counts
+    binned["count"] = (torch.round(binned["count"].double() * float(sys.argv[3]) * 100.0) / 100.0).float()
 flags = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD
 for r in range(reps):
     copies = [{k: v.clone() for k, v in binned.items()} for _ in range(B)]
