@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_tile_stats(const BinChrom* __restrict__
         if (tileStart + TILE <= C.len) {
 #pragma unroll
             for (int it = 0; it < 4; it++) {
-                uint4 v = *reinterpret_cast<const uint4*>(C.hits + tileStart + it * 1024 + l * 16);
+                uint4 v = gload_uint4(as_global(C.hits) + tileStart + it * 1024 + l * 16);
                 obs += nonzero_bytes4(v.x) + nonzero_bytes4(v.y) + nonzero_bytes4(v.z) + nonzero_bytes4(v.w);
             }
         } else {
@@ -272,9 +272,9 @@ __device__ __forceinline__ void bin_tile(const BinChrom& C, int64_t gtile, int64
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             int64_t p = tileStart + it * 1024 + l * 16;
-            vb[it] = *reinterpret_cast<const uint4*>(C.bases + p);
-            vh[it] = *reinterpret_cast<const uint4*>(C.hits + p);
-            m16[it] = reinterpret_cast<const uint16_t*>(C.mask)[p >> 4];
+            vb[it] = gload_uint4(as_global(C.bases) + p);
+            vh[it] = gload_uint4(as_global(C.hits) + p);
+            m16[it] = reinterpret_cast<gptr<const uint16_t>>(as_global(C.mask))[p >> 4];
         }
     }
 #pragma unroll
@@ -424,9 +424,9 @@ __device__ __forceinline__ void summarize_tile(const BinChrom& C, int64_t gtile,
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             int64_t p = tileStart + it * 1024 + l * 16;
-            vb[it] = *reinterpret_cast<const uint4*>(C.bases + p);
-            vh[it] = *reinterpret_cast<const uint4*>(C.hits + p);
-            m16[it] = reinterpret_cast<const uint16_t*>(C.mask)[p >> 4];
+            vb[it] = gload_uint4(as_global(C.bases) + p);           // global_load, not flat_load (common.hpp)
+            vh[it] = gload_uint4(as_global(C.hits) + p);
+            m16[it] = reinterpret_cast<gptr<const uint16_t>>(as_global(C.mask))[p >> 4];
         }
     }
     uint32_t keep = 0, obs = 0;
@@ -572,16 +572,16 @@ __global__ void __launch_bounds__(256) k_bin_resolve(const BinChrom* __restrict_
     if (i >= binOffset[nchr]) return;                                        // whole quads leave together
     const int32_t rec = stopIO[i];
     const int c = oChr[i];                                                   // left by k_bin_close
-    const uint8_t* __restrict__ bases = ch[c].bases; const uint8_t* __restrict__ hits = ch[c].hits;
+    const gptr<const uint8_t> bases = as_global(ch[c].bases), hits = as_global(ch[c].hits);
     const int64_t len = ch[c].len;
     const int64_t p0c = (int64_t)pos0[c];
     const int64_t wstart = (int64_t)(rec & ~63);
     uint32_t kk = (uint32_t)(rec & 63) + 1u;
     const int64_t cstart = wstart + 16 * sub;                                // this lane's slice
-    uint64_t mw = ch[c].mask[wstart >> 6];
+    uint64_t mw = as_global(ch[c].mask)[wstart >> 6];
     uint32_t wb[4] = {0, 0, 0, 0}, wh[4] = {0, 0, 0, 0};
     if (cstart + 16 <= len) {
-        const uint4 b = *reinterpret_cast<const uint4*>(bases + cstart), h = *reinterpret_cast<const uint4*>(hits + cstart);
+        const uint4 b = gload_uint4(bases + cstart), h = gload_uint4(hits + cstart);
         wb[0] = b.x; wb[1] = b.y; wb[2] = b.z; wb[3] = b.w; wh[0] = h.x; wh[1] = h.y; wh[2] = h.z; wh[3] = h.w;
     } else {
         for (int j = 0; j < 16; j++) { const int64_t pi = cstart + j; if (pi < len) { wb[j >> 2] |= (uint32_t)bases[pi] << (8 * (j & 3)); wh[j >> 2] |= (uint32_t)hits[pi] << (8 * (j & 3)); } }

@@ -40,8 +40,8 @@ __global__ void __launch_bounds__(256) k_tile_summary_packed(const BinChrom* __r
     const int l = lane_id();
     int c = find_chrom(ch, nchr, g0);
     int64_t tileBase = ch[c].tileBase, tileEnd = tileBase + ch[c].ntiles;
-    const ulonglong2* __restrict__ ref = reinterpret_cast<const ulonglong2*>(ch[c].bases);
-    const ulonglong2* __restrict__ hp = reinterpret_cast<const ulonglong2*>(ch[c].hits);
+    gptr<const ulonglong2> ref = reinterpret_cast<gptr<const ulonglong2>>(as_global(ch[c].bases));           // global_load, not flat_load (common.hpp)
+    gptr<const ulonglong2> hp = reinterpret_cast<gptr<const ulonglong2>>(as_global(ch[c].hits));
     int64_t p0c = (int64_t)pos0[c];
     ulonglong2 r[PK_TILES], ha[PK_TILES], hb[PK_TILES];
     unsigned long long valid[PK_TILES];
@@ -51,10 +51,10 @@ __global__ void __launch_bounds__(256) k_tile_summary_packed(const BinChrom* __r
         if (gtile < ntilesTotal) {
             while (gtile >= tileEnd) {
                 c++; tileBase = ch[c].tileBase; tileEnd = tileBase + ch[c].ntiles; p0c = (int64_t)pos0[c];
-                ref = reinterpret_cast<const ulonglong2*>(ch[c].bases); hp = reinterpret_cast<const ulonglong2*>(ch[c].hits);
+                ref = reinterpret_cast<gptr<const ulonglong2>>(as_global(ch[c].bases)); hp = reinterpret_cast<gptr<const ulonglong2>>(as_global(ch[c].hits));
             }
             const int64_t w = ((gtile - tileBase) << 6) + l;
-            r[t] = ref[w]; ha[t] = hp[2 * w]; hb[t] = hp[2 * w + 1];
+            r[t] = gload_ulonglong2(ref + w); ha[t] = gload_ulonglong2(hp + 2 * w); hb[t] = gload_ulonglong2(hp + 2 * w + 1);
             valid[t] = pk_valid(w << 6, p0c);
         } else { r[t] = make_ulonglong2(0, 0); ha[t] = r[t]; hb[t] = r[t]; valid[t] = 0; }
     }
@@ -85,8 +85,9 @@ __global__ void __launch_bounds__(256) k_bin_resolve_packed(const BinChrom* __re
     const int c = oChr[i];
     const int64_t wstart = (int64_t)(rec & ~63), w = wstart >> 6;
     uint32_t kk = (uint32_t)(rec & 63) + 1u;
-    const ulonglong2 r = reinterpret_cast<const ulonglong2*>(ch[c].bases)[w];
-    const ulonglong2 ha = reinterpret_cast<const ulonglong2*>(ch[c].hits)[2 * w], hb = reinterpret_cast<const ulonglong2*>(ch[c].hits)[2 * w + 1];
+    const gptr<const ulonglong2> hp = reinterpret_cast<gptr<const ulonglong2>>(as_global(ch[c].hits));
+    const ulonglong2 r = gload_ulonglong2(reinterpret_cast<gptr<const ulonglong2>>(as_global(ch[c].bases)) + w);
+    const ulonglong2 ha = gload_ulonglong2(hp + 2 * w), hb = gload_ulonglong2(hp + 2 * w + 1);
     const unsigned long long valid = pk_valid(wstart, (int64_t)pos0[c]);
     uint32_t pos = 0, cnt;                                                   // the kk-th set bit of the possible word closes the bin
     uint64_t m = r.x;

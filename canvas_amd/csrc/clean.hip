@@ -27,6 +27,8 @@
 #define CBLK 2048   // elements per compaction block
 
 struct Soa { int32_t *chr, *start, *stop, *gc; float* count; double* dev; };
+struct GSoa { gptr<int32_t> chr, start, stop, gc; gptr<float> count; gptr<double> dev; };      // the same arrays as global-address-space pointers (common.hpp: as_global)
+__device__ __forceinline__ GSoa as_global(const Soa& s) { return GSoa{as_global(s.chr), as_global(s.start), as_global(s.stop), as_global(s.gc), as_global(s.count), as_global(s.dev)}; }
 
 // ---------------------------------------------------------------- flag kernels
 __global__ void __launch_bounds__(256) k_keys_size(const int32_t* __restrict__ start, const int32_t* __restrict__ stop, int64_t n, uint32_t* __restrict__ keys) {
@@ -194,7 +196,8 @@ __global__ void __launch_bounds__(256) k_apply_var(float* __restrict__ count, co
 // ---------------------------------------------------------------- local SD (CanvasClean.cs:268-298)
 // one thread per window of 20 consecutive count differences; sequential double arithmetic exactly as
 // Utilities.StandardDeviation(double[], start, end) (Utilities.cs:246-262)
-__device__ __forceinline__ void local_sd_window(const float* __restrict__ count, int64_t w, double* __restrict__ sd, double* __restrict__ dev) {
+template <class PC, class PD>          // plain pointers, or gptr<> when they come out of a table in device memory (clean_fast.hpp)
+__device__ __forceinline__ void local_sd_window(PC count, int64_t w, PD sd, PD dev) {
     int64_t s = w * 20;
     double d[20];
     float prev = count[s];

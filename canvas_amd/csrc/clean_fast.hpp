@@ -16,6 +16,8 @@
 #define CF_MAXRUN 1024       // chromosome runs of the bin list handled on the device
 #define CF_NPROB 4           // select problems of a sample: [1] medians, [2] quartiles, [3] medians after the variance normalisation ([0] unused)
 #define CF_SZ_BINS 65536     // bin sizes counted exactly (a larger 98th percentile hands the sample to the host-driven path)
+#define CF_HREP 16           // replicas of the per-GC counters the flag / scatter kernels add to (workgroup % CF_HREP picks one): 2 338 workgroups adding to ONE address
+                             // are a serial chain at the memory side (measured: a single per-workgroup atomicAdd on one word cost k_cf_flags_ab 31 of its 82 us)
 #define CF_SZ_LDS 4096       // ... of which the first CF_SZ_LDS are counted in LDS per workgroup (WGS bins are a few hundred to a few thousand positions)
 
 struct CleanDev {
@@ -31,7 +33,6 @@ struct CleanDev {
     unsigned int nOver, pad1;        // bins of CF_SZ_BINS positions and more (kept in a list: the percentile is taken from it when it lies that far out)
     uint32_t hist[2 * NGC];          // [0..100] autosomal bins per GC, [101..201] the other bins (after the first compaction)
     uint32_t segOff[NGC + 1];        // grouped autosomal bins of the kept GC values
-    uint32_t cursor[NGC];
     uint8_t keepGc[NGC + 3];
     long long kept;                  // bins of any chromosome that survive the GC strip
     int gcActive, haveLocalSd, varActive, changed, nruns;
@@ -75,6 +76,7 @@ struct CfArgs {                      // one sample of the batch
     double* dSd; double* dRunMad; int64_t* dRunStart; long long* dPos;
     CleanDev* D; CfSel* P; SelTile* tiles; uint32_t* hist;
     CfCq* cq; uint32_t* cqHist; SelTile* cqTiles;      // the counting selects (below)
+    uint32_t* repl;                  // [CF_HREP][2 * NGC] GC counts of the survivors per replica (k_cf_flags_ab), then [CF_HREP][NGC] write cursors into the grouped keys (k_cf_dec_gc -> k_cf_scatter_ab)
 };
 #define CF_SAMPLE const CfArgs& A = AA[blockIdx.y]
 
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(1024) k_cf_size_hist(const CfArgs* __restrict_
     const int64_t n = A.n;
     for (int i = threadIdx.x; i < CF_SZ_LDS; i += 1024) lh[i] = 0;
     __syncthreads();
-    const int32_t* __restrict__ start = A.caller.start; const int32_t* __restrict__ stop = A.caller.stop;
+    const gptr<const int32_t> start = as_global(A.caller.start), stop = as_global(A.caller.stop);
     uint32_t neg = 0;
     for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)CF_SZ_GRID * 1024) {
         const int32_t sz = stop[i] - start[i];
@@ -221,71 +223,96 @@ __global__ void __launch_bounds__(64) k_cf_select_pick(const CfArgs* __restrict_
 __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ uint32_t sh[8];
-    __shared__ uint8_t sA[CBLK];                          // keepA, chromosome and count of this block's bins: the neighbour search reads them from LDS
-    __shared__ int32_t sChr[CBLK];
-    __shared__ float sCnt[CBLK];
+    // keepA, chromosome and count of this block's bins and of the bin on either side of it: slot 0 = bin base - 1, slots 1 .. L = the block, slot L + 1 = bin base + L.
+    // The neighbour search below runs on these slots with 32-bit indices; it leaves them only when the halo bin itself fails the size filter (slow path, global memory).
+    __shared__ uint8_t sA[CBLK + 2];
+    __shared__ int32_t sChr[CBLK + 2];
+    __shared__ float sCnt[CBLK + 2];
     __shared__ uint8_t sGc[CBLK];
+    __shared__ uint8_t sAuto[256];                        // isAuto of the first 256 chromosomes (more than that: read from the table)
     __shared__ uint32_t lh[2 * NGC];                      // GC histogram of the survivors (CanvasClean.cs:207-223): [0..100] autosomal, [101..201] the others
     const int64_t n = A.n;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
+    const int L = (int)min<int64_t>(CBLK, n - base);
     if (threadIdx.x < 2 * NGC) lh[threadIdx.x] = 0;
-    const uint8_t* __restrict__ isAuto = A.isAuto;
-    const int32_t* __restrict__ chr = A.caller.chr; const int32_t* __restrict__ start = A.caller.start; const int32_t* __restrict__ stop = A.caller.stop;
-    const int32_t* __restrict__ gc = A.caller.gc; const float* __restrict__ count = A.caller.count;
-    uint8_t* __restrict__ flags = A.dFlags; CleanDev* __restrict__ D = A.D;
+    const gptr<const uint8_t> isAuto = as_global(A.isAuto);         // (pointers out of the argument table: converted so that the accesses are global_load, not flat_load)
+    const GSoa in = as_global(A.caller);
+    const gptr<const int32_t> chr = in.chr, start = in.start, stop = in.stop, gc = in.gc; const gptr<const float> count = in.count;
+    const gptr<uint8_t> flags = as_global(A.dFlags); CleanDev* __restrict__ D = A.D;
     const int nchr = A.nchr, doOutlier = A.doOutlier;
     const bool doSize = D->sizeOn != 0;                   // off when the filter is, or when the percentile index falls past the end
     const int32_t thresh = doSize ? D->sizeThresh : 0;
+    sAuto[threadIdx.x] = (int)threadIdx.x < nchr ? isAuto[threadIdx.x] : 0;
     uint32_t nKeep = 0, nSize = 0, bad = 0;
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) {
-        const int64_t i = base + j * 256 + threadIdx.x;
+        const int li = j * 256 + threadIdx.x;
         uint8_t a = 0; int32_t c = -1; float v = 0.0f; int32_t g = 0;
-        if (i < n) {
+        if (li < L) {
+            const int64_t i = base + li;
             c = chr[i]; v = count[i]; g = gc[i];
             if ((uint32_t)g > 100u || (uint32_t)c >= (uint32_t)nchr) bad = 1;
             a = (!doSize || (stop[i] - start[i]) <= thresh) ? 1 : 0;
         }
-        sA[j * 256 + threadIdx.x] = a; sChr[j * 256 + threadIdx.x] = c; sCnt[j * 256 + threadIdx.x] = v; sGc[j * 256 + threadIdx.x] = (uint8_t)((uint32_t)g > 100u ? 100 : g);
+        sA[1 + li] = a; sChr[1 + li] = c; sCnt[1 + li] = v; sGc[li] = (uint8_t)((uint32_t)g > 100u ? 100 : g);
         nSize += a;
     }
+    const bool hasLeft = base > 0, hasRight = base + L < n;
+    if (threadIdx.x < 2) {
+        const int64_t i = threadIdx.x == 0 ? base - 1 : base + L;
+        uint8_t a = 0; int32_t c = -1; float v = 0.0f;
+        if (threadIdx.x == 0 ? hasLeft : hasRight) { c = chr[i]; v = count[i]; a = (!doSize || (stop[i] - start[i]) <= thresh) ? 1 : 0; }
+        const int slot = threadIdx.x == 0 ? 0 : L + 1;
+        sA[slot] = a; sChr[slot] = c; sCnt[slot] = v;
+    }
     __syncthreads();
-    const int64_t blockEnd = base + CBLK;
-    auto keepA = [&](int64_t j) -> bool { return (j >= base && j < blockEnd) ? sA[j - base] != 0 : (!doSize || (stop[j] - start[j]) <= thresh); };
-    auto chrAt = [&](int64_t j) -> int32_t { return (j >= base && j < blockEnd) ? sChr[j - base] : chr[j]; };
-    auto cntAt = [&](int64_t j) -> float { return (j >= base && j < blockEnd) ? sCnt[j - base] : count[j]; };
 #pragma unroll 2
     for (int j = 0; j < CBLK / 256; j++) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        if (i >= n) continue;
-        bool keep = sA[j * 256 + threadIdx.x] != 0;
+        const int li = j * 256 + threadIdx.x;
+        if (li >= L) continue;
+        const int s = li + 1;
+        bool keep = sA[s] != 0;
+        const int32_t c = sChr[s];
         if (keep && doOutlier) {
-            const int32_t c = sChr[j * 256 + threadIdx.x];
-            int64_t p = i - 1, q = i + 1;
-            while (p >= 0 && !keepA(p)) p--;
-            while (q < n && !keepA(q)) q++;
-            const bool hasPrev = p >= 0, hasNext = q < n;
-            const bool prevSame = hasPrev && chrAt(p) == c, nextSame = hasNext && chrAt(q) == c;
+            // nearest bins on either side that pass the size filter (RemoveOutliers runs on the list RemoveBigBins left, CanvasClean.cs:387-413)
+            int ps = s - 1, qs = s + 1;
+            while (ps >= 1 && !sA[ps]) ps--;
+            while (qs <= L && !sA[qs]) qs++;
+            bool hasPrev, hasNext; int32_t cp = -1, cq = -1; float vp = 0.0f, vq = 0.0f;
+            if (ps >= 1 || !hasLeft || sA[0]) { hasPrev = ps >= 1 || hasLeft; if (hasPrev) { cp = sChr[ps]; vp = sCnt[ps]; } }
+            else {                                        // the bin in front of the block fails the size filter too: keep looking in global memory
+                int64_t p = base - 2;
+                while (p >= 0 && (stop[p] - start[p]) > thresh) p--;
+                hasPrev = p >= 0; if (hasPrev) { cp = chr[p]; vp = count[p]; }
+            }
+            if (qs <= L || !hasRight || sA[L + 1]) { hasNext = qs <= L || hasRight; if (hasNext) { cq = sChr[qs]; vq = sCnt[qs]; } }
+            else {
+                int64_t q = base + L + 1;
+                while (q < n && (stop[q] - start[q]) > thresh) q++;
+                hasNext = q < n; if (hasNext) { cq = chr[q]; vq = count[q]; }
+            }
+            const bool prevSame = hasPrev && cp == c, nextSame = hasNext && cq == c;
             if ((hasPrev && !prevSame) && (hasNext && !nextSame)) keep = false;
             else {
-                const float v = sCnt[j * 256 + threadIdx.x];
-                keep = (prevSame && !sig_diff(v, cntAt(p))) || (nextSame && !sig_diff(v, cntAt(q))) || (!hasPrev && !hasNext);
+                const float v = sCnt[s];
+                keep = (prevSame && !sig_diff(v, vp)) || (nextSame && !sig_diff(v, vq)) || (!hasPrev && !hasNext);
             }
         }
-        flags[i] = keep;
+        flags[base + li] = keep;
         nKeep += keep;
         if (keep) {                                       // out-of-range input is reported through D->bad and nothing is returned: clamped here so that no table is overrun
-            const int32_t c0 = sChr[j * 256 + threadIdx.x], c = (uint32_t)c0 >= (uint32_t)nchr ? 0 : c0;
-            atomicAdd(&lh[(isAuto[c] ? 0 : NGC) + sGc[j * 256 + threadIdx.x]], 1u);
+            const int32_t cc = (uint32_t)c >= (uint32_t)nchr ? 0 : c;
+            const uint8_t au = cc < 256 ? sAuto[cc] : isAuto[cc];
+            atomicAdd(&lh[(au ? 0 : NGC) + sGc[li]], 1u);
         }
     }
     nKeep = wave_reduce_add_u32(nKeep); nSize = wave_reduce_add_u32(nSize);
     if (lane_id() == 0) { sh[threadIdx.x >> 6] = nKeep; sh[4 + (threadIdx.x >> 6)] = nSize; }
     if (bad) D->bad = 1u;
     __syncthreads();
-    if (threadIdx.x == 0) { A.dBlk[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; atomicAdd(&D->nA, sh[4] + sh[5] + sh[6] + sh[7]); }
-    if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&D->hist[threadIdx.x], lh[threadIdx.x]);
+    if (threadIdx.x == 0) { A.dBlk[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; A.dBlk[A.nb + 2 + blockIdx.x] = sh[4] + sh[5] + sh[6] + sh[7]; }      // (k_cf_scan_blocks sums the second column into nA)
+    if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&A.repl[(blockIdx.x % CF_HREP) * (2 * NGC) + threadIdx.x], lh[threadIdx.x]);
 }
 // exclusive scan of the block counts: phase 0 over the blocks of the input (total -> nAB), phase 1 over the blocks of the nAB surviving bins (total -> nFinal)
 __global__ void __launch_bounds__(1024) k_cf_scan_blocks(const CfArgs* __restrict__ AA, int phase) {
@@ -308,6 +335,14 @@ __global__ void __launch_bounds__(1024) k_cf_scan_blocks(const CfArgs* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0) { if (phase == 0) A.D->nAB = carry; else A.D->nFinal = carry; }
+    if (phase == 0) {                                     // bins after RemoveBigBins alone: the second column of k_cf_flags_ab's block counts
+        uint32_t v = 0;
+        for (int i = threadIdx.x; i < nblocks; i += 1024) v += blockCnt[A.nb + 2 + i];
+        v = wave_reduce_add_u32(v);
+        if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < 16; k++) t += sh[k]; A.D->nA = t; }
+    }
 }
 // the compaction itself: caller's arrays -> scratch SoA, and — the GC strip is decided by then (k_cf_dec_gc) — the order-preserving keys of the autosomal survivors with a kept GC
 // value, grouped by GC (order inside a bucket is irrelevant: only order statistics are taken).  CountDeviation is written by k_cf_local_sd (or never read).
@@ -319,8 +354,8 @@ __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict_
     const int64_t n = A.n;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
-    const uint8_t* __restrict__ flags = A.dFlags; const uint8_t* __restrict__ isAuto = A.isAuto;
-    const Soa src = A.caller, dst = A.S1; const int nchr = A.nchr;
+    const gptr<const uint8_t> flags = as_global(A.dFlags), isAuto = as_global(A.isAuto);
+    const GSoa src = as_global(A.caller), dst = as_global(A.S1); const int nchr = A.nchr;
     CleanDev* __restrict__ D = A.D;
     const bool group = D->gcActive != 0;
     if (threadIdx.x < NGC) { lcnt[threadIdx.x] = 0; sKeepGc[threadIdx.x] = D->keepGc[threadIdx.x]; }
@@ -350,11 +385,11 @@ __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict_
         __syncthreads();
     }
     if (!group) return;
-    if (threadIdx.x < NGC && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&D->cursor[threadIdx.x], lcnt[threadIdx.x]);
+    if (threadIdx.x < NGC && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&A.repl[CF_HREP * (2 * NGC) + (blockIdx.x % CF_HREP) * NGC + threadIdx.x], lcnt[threadIdx.x]);      // absolute position in keysG
     __syncthreads();
-    uint32_t* __restrict__ keysG = A.keysG;
+    const gptr<uint32_t> keysG = as_global(A.keysG);
 #pragma unroll
-    for (int j = 0; j < CBLK / 256; j++) if (myGc[j] >= 0) keysG[D->segOff[myGc[j]] + lbase[myGc[j]] + myRank[j]] = myKey[j];
+    for (int j = 0; j < CBLK / 256; j++) if (myGc[j] >= 0) keysG[lbase[myGc[j]] + myRank[j]] = myKey[j];
 }
 
 // ---------------------------------------------------------------- local SD (CanvasClean.cs:243-298)
@@ -367,9 +402,10 @@ __global__ void __launch_bounds__(256) k_cf_local_sd(const CfArgs* __restrict__ 
     const int64_t nAB = (int64_t)A.D->nAB, Dn = nAB - 1, nW = Dn >= 1 ? (Dn - 1) / 20 : 0;
     if (w > nW) return;
     const int64_t lo = w * 20, hi = w < nW ? lo + 20 : nAB;             // thread nW takes the tail
-    if (w < nW) local_sd_window(A.S1.count, w, A.dSd, A.S1.dev);
-    else for (int64_t i = lo; i < hi; i++) A.S1.dev[i] = -1.0;
-    const int32_t* __restrict__ chr = A.S1.chr;
+    const GSoa S1 = as_global(A.S1);
+    if (w < nW) local_sd_window(gptr<const float>(S1.count), w, as_global(A.dSd), S1.dev);
+    else for (int64_t i = lo; i < hi; i++) S1.dev[i] = -1.0;
+    const gptr<const int32_t> chr = S1.chr;
     int32_t prev = lo > 0 ? chr[lo - 1] : -1;
     for (int64_t i = lo; i < hi; i++) {
         const int32_t c = chr[i];
@@ -439,7 +475,9 @@ __global__ void __launch_bounds__(128) k_cf_dec_gc(const CfArgs* __restrict__ AA
     CleanDev* __restrict__ D = A.D; const uint32_t flags = A.flags; const int minBinsPerGc = A.minBinsPerGc;
     const int t = threadIdx.x;
     const long long nAB = (long long)D->nAB;
-    const uint32_t hA = t < NGC ? D->hist[t] : 0u, hO = t < NGC ? D->hist[NGC + t] : 0u;
+    uint32_t hA = 0, hO = 0;
+    if (t < NGC) for (int r = 0; r < CF_HREP; r++) { hA += A.repl[r * (2 * NGC) + t]; hO += A.repl[r * (2 * NGC) + NGC + t]; }
+    if (t < NGC) { D->hist[t] = hA; D->hist[NGC + t] = hO; }
     // the counts are integers below 2^32 and there are 101 of them: their double sum (CanvasClean.cs:219-222) is exact in any order
     uint32_t totalA; (void)cf_excl_scan128(hA, shA, &totalA);
     const bool consider = (flags & CANVAS_CLEAN_GCNORM) && nAB > 0;
@@ -454,7 +492,12 @@ __global__ void __launch_bounds__(128) k_cf_dec_gc(const CfArgs* __restrict__ AA
     const bool active = consider && kept > 0;                               // kept <= 0: "proceed without GC correction" (CanvasClean.cs:500-505)
     if (!active) kp = true;
     uint32_t totalKept; const uint32_t so = cf_excl_scan128((active && t < NGC && kp) ? hA : 0u, shD, &totalKept);
-    if (t < NGC) { D->keepGc[t] = kp ? 1 : 0; D->cursor[t] = 0; D->medians[t] = 0.0; D->segOff[t] = active ? so : 0u; }
+    if (t < NGC) {
+        D->keepGc[t] = kp ? 1 : 0; D->medians[t] = 0.0; D->segOff[t] = active ? so : 0u;
+        // the bucket's stretch of the grouped keys is filled replica by replica (the order inside a bucket is irrelevant: only order statistics are taken from it)
+        uint32_t at = so;
+        for (int r = 0; r < CF_HREP; r++) { A.repl[CF_HREP * (2 * NGC) + r * NGC + t] = at; at += A.repl[r * (2 * NGC) + t]; }
+    }
     if (t == 0) {
         const long long sKept = active ? kept : nAB;
         D->segOff[NGC] = active ? totalKept : 0u; D->kept = sKept; D->gcActive = active ? 1 : 0; D->changed = 0;
@@ -605,7 +648,7 @@ __global__ void __launch_bounds__(1024) k_cq_hist(const CfArgs* __restrict__ AA)
     const long long lo = C->lo;
     for (int i = threadIdx.x; i < CQW; i += 1024) lw[i] = 0;
     __syncthreads();
-    const uint32_t* __restrict__ keys = A.keysG;
+    const gptr<const uint32_t> keys = as_global(A.keysG);
     uint32_t below = 0, bad = 0;
     for (int64_t i0 = T.begin + threadIdx.x; i0 < T.end; i0 += 4 * 1024) {
         uint32_t kk[4];
@@ -816,7 +859,7 @@ __global__ void __launch_bounds__(256) k_cf_flags_final(const CfArgs* __restrict
     const int64_t n = (int64_t)D->nAB;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
-    const int32_t* __restrict__ gc = A.S1.gc; const double* __restrict__ dev = A.S1.dev; uint8_t* __restrict__ flags = A.dFlags;
+    const gptr<const int32_t> gc = as_global(A.S1.gc); const gptr<const double> dev = as_global(A.S1.dev); const gptr<uint8_t> flags = as_global(A.dFlags);
     const bool sdFilter = D->haveLocalSd && D->localSd > 5.0;
     uint32_t c = 0;
 #pragma unroll
@@ -840,7 +883,7 @@ __global__ void __launch_bounds__(256) k_cf_scatter_final(const CfArgs* __restri
     const int64_t n = (int64_t)D->nAB;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
-    const uint8_t* __restrict__ flags = A.dFlags; const Soa src = A.S1, dst = A.caller;
+    const gptr<const uint8_t> flags = as_global(A.dFlags); const GSoa src = as_global(A.S1), dst = as_global(A.caller);
     // first phase: NormalizeByGC has only been decided (k_cf_dec_e), not applied to the scratch counts — nothing between here and there reads them — so it is applied while
     // the survivors are copied out.  (When the second phase runs, clean_batch_finish applies it to the scratch counts first: NormalizeVarianceByGC works on normalised counts.)
     const bool normalise = !secondPhase && (A.flags & CANVAS_CLEAN_GCNORM) && A.P[1].hdr[1] != 0;
@@ -896,7 +939,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     useCq = useCq && (flags & CANVAS_CLEAN_GCNORM);
     const size_t cqWords = useCq ? (size_t)B * (NGC + 1) * CQW : 0;
     WsSizer sz;
-    sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<CleanDev>(B); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<CfCq>(B); sz.take<uint32_t>(cqWords);
+    sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<CleanDev>(B); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); sz.take<CfCq>(B); sz.take<uint32_t>(cqWords);
     int64_t nMax = 0; bool anyLsd = false, anyVar = false;
     for (int s = 0; s < B; s++) {
         const int64_t n = h_n[s], nW0 = n / 20 + 2, nb = nblk(n, CBLK); const size_t tilesUpper = (size_t)(n / SEL_TILE + NGC + 1);
@@ -915,7 +958,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     WsCarver ws(ctx->ws);
     // two adjacent groups: what the host sends (one copy) and what starts as zero (one memset)
     CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr);
-    CleanDev* dD = ws.take<CleanDev>(B); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS); CfCq* dCq = ws.take<CfCq>(B); uint32_t* dCqHist = ws.take<uint32_t>(cqWords);
+    CleanDev* dD = ws.take<CleanDev>(B); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS); uint32_t* dRepl = ws.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); CfCq* dCq = ws.take<CfCq>(B); uint32_t* dCqHist = ws.take<uint32_t>(cqWords);
     CleanPending pend; pend.useCq = useCq; pend.B = B; pend.dArgs = dArgs; pend.dD = dD; pend.h.resize(B);
     unsigned gxT = 1, gxTcq = 1;
     for (int s = 0; s < B; s++) {
@@ -931,7 +974,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         A.P = ws.take<CfSel>(CF_NPROB); A.tiles = ws.take<SelTile>((size_t)tilesUpper * CF_NPROB);
         A.cqTiles = ws.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1)); A.cq = dCq + s; A.cqHist = dCqHist + (size_t)s * (NGC + 1) * CQW;
         gxTcq = std::max(gxTcq, (unsigned)(n / CQ_TILE + NGC + 1));
-        A.isAuto = dIsAuto; A.szHist = dSz + (size_t)s * CF_SZ_BINS; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
+        A.isAuto = dIsAuto; A.repl = dRepl + (size_t)s * CF_HREP * 3 * NGC; A.szHist = dSz + (size_t)s * CF_SZ_BINS; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
         gxT = std::max(gxT, tilesUpper);
         anyLsd = anyLsd || A.wantLsd; anyVar = anyVar || (A.wantLsd && n > 500000);
     }

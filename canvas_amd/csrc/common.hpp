@@ -162,6 +162,16 @@ struct WsSizer {
 
 // ---- device helpers ------------------------------------------------------------------------------------------
 #define WAVE 64
+// A pointer that a kernel reads out of a table in device memory (BinChrom, CfArgs, ...) is a generic pointer to the compiler: every access through it becomes a
+// flat_load / flat_store (address-space check per access, LDS and vector-memory counters both tied up).  Kernel ARGUMENTS are inferred to be global; table entries are
+// not, so the kernels convert them once: gptr<T> is T* in the global address space, and the loads come out as global_load.
+template <class T> using gptr = __attribute__((address_space(1))) T*;
+template <class T> __device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)p; }
+// 16-byte loads through a gptr (uint4 / ulonglong2 are class types whose copy constructors take generic references: the load goes through a builtin vector type)
+typedef unsigned int canvas_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long canvas_u64x2 __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ uint4 gload_uint4(gptr<T> p) { const canvas_u32x4 v = *reinterpret_cast<gptr<const canvas_u32x4>>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+template <class T> __device__ __forceinline__ ulonglong2 gload_ulonglong2(gptr<T> p) { const canvas_u64x2 v = *reinterpret_cast<gptr<const canvas_u64x2>>(p); return make_ulonglong2(v.x, v.y); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // inclusive wave scan (64 lanes) with DPP: Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8), then the row totals are
