@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(64) k_tile_summary_edges(const BinChrom* __res
 // inside a mostly idle wave).
 #define CLOSE_TILES 4       // tiles per wave: their summary loads are issued together (the kernel is latency-bound, not bandwidth-bound)
 __global__ void __launch_bounds__(256) k_bin_close(const BinChrom* __restrict__ ch, int nchr, int64_t ntilesTotal, const uint32_t* __restrict__ S,
-                                                   const int32_t* __restrict__ rankBase, const long long* __restrict__ binOffset, int binSize,
+                                                   const int32_t* __restrict__ rankBase, const long long* __restrict__ binOffset, int binSize, unsigned long long binMagic,
                                                    int32_t* __restrict__ stopOut, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG, int32_t* __restrict__ oChr) {
     const int64_t gtile0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * CLOSE_TILES;   // uniform: scalar lookups
     if (gtile0 >= ntilesTotal) return;
@@ -549,9 +549,12 @@ __global__ void __launch_bounds__(256) k_bin_close(const BinChrom* __restrict__ 
             const uint32_t gEx = (pgInc - pg) >> 16, cEx = cInc - cl;
             const int64_t wstart = ((gtile - tileBase) << TILE_SHIFT) + (int64_t)l * 64;
             const int32_t rr = r < 0 ? 0 : r;
-            uint32_t nextB = ((uint32_t)rr / (uint32_t)binSize + 1u) * (uint32_t)binSize;
-            while ((int64_t)nextB - r <= (int64_t)pop && (int64_t)nextB - r >= 1) {
-                const long long bin = boff + (long long)(nextB / (uint32_t)binSize) - 1;
+            // rr / binSize without a division (the kernel is VALU-bound and an integer division is ~30 instructions): binMagic = floor(2^64 / binSize) + 1, and
+            // mulhi64(x, binMagic) == x / binSize for every x < 2^32 (the error term x * (binMagic * binSize - 2^64) / 2^64 / binSize stays below 1 / binSize)
+            uint32_t q = binMagic ? (uint32_t)__umul64hi((unsigned long long)(uint32_t)rr, binMagic) : (uint32_t)rr;      // (binMagic == 0: binSize 1)
+            uint32_t nextB = (q + 1u) * (uint32_t)binSize;
+            for (; (int64_t)nextB - r <= (int64_t)pop && (int64_t)nextB - r >= 1; q++) {
+                const long long bin = boff + (long long)q;
                 stopOut[bin] = (int32_t)(wstart + ((int64_t)nextB - r - 1));    // the (nextB - r)-th possible position of the word closes the bin
                 locC[bin] = cEx;
                 locG[bin] = gEx;
@@ -645,14 +648,18 @@ __global__ void __launch_bounds__(256) k_bin_finalize(const BinChrom* __restrict
                                                       const uint32_t* __restrict__ locC, const uint32_t* __restrict__ locG,
                                                       const uint32_t* __restrict__ tileExC, const uint32_t* __restrict__ tileExG,
                                                       int32_t* __restrict__ oChr, int32_t* __restrict__ oStart, int32_t* __restrict__ oStop,
-                                                      int32_t* __restrict__ oGc, float* __restrict__ oCount) {
+                                                      int32_t* __restrict__ oGc, float* __restrict__ oCount, int haveChr) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= binOffset[nchr]) return;
-    int lo = 0, hi = nchr - 1;
-    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (binOffset[mid] <= i) lo = mid; else hi = mid - 1; }
-    // skip chromosomes without bins that share the same offset
-    while (lo < nchr - 1 && binOffset[lo + 1] <= i) lo++;
-    const int c = lo;
+    int c;
+    if (haveChr) c = oChr[i];                             // k_bin_close left the chromosome of every bin: one load instead of a bisection (five dependent ones)
+    else {
+        int lo = 0, hi = nchr - 1;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (binOffset[mid] <= i) lo = mid; else hi = mid - 1; }
+        // skip chromosomes without bins that share the same offset
+        while (lo < nchr - 1 && binOffset[lo + 1] <= i) lo++;
+        c = lo;
+    }
     const BinChrom C = ch[c];
     const long long k = i - binOffset[c];
     const int32_t stop = stopIn[i];
@@ -1048,7 +1055,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         if (!needRates) hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
         ProfScope ps(ctx, "bin_close");
         hipLaunchKernelGGL(k_bin_close, dim3((unsigned)((plan.ntiles + 4 * CLOSE_TILES - 1) / (4 * CLOSE_TILES))), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, wordSum, rankBase,
-                           binOffset, bin_size, stopTmp, locC, locG, d_chr);
+                           binOffset, bin_size, bin_size > 1 ? ~0ull / (unsigned long long)bin_size + 1ull : 0ull, stopTmp, locC, locG, d_chr);
         if (packed) hipLaunchKernelGGL(k_bin_resolve_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, clampHits, d_chr, stopTmp, locC, locG);
         else hipLaunchKernelGGL(k_bin_resolve, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, clampHits, d_chr, stopTmp, locC, locG);
     } else {
@@ -1060,7 +1067,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
     }
     hipLaunchKernelGGL(k_bin_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, stopTmp, locC, locG,
-                       tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count);
+                       tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count, singleRead ? 1 : 0);
     if (gcw) hipLaunchKernelGGL(k_bin_weighted, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, d_count);
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
