@@ -651,6 +651,10 @@ __global__ void __launch_bounds__(256) k_bin_finalize(const BinChrom* __restrict
                                                       int32_t* __restrict__ oGc, float* __restrict__ oCount, int haveChr) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= binOffset[nchr]) return;
+    // the per-bin records of this bin and of the one in front of it do not depend on the chromosome: requested first, all at once
+    const long long ip = i > 0 ? i - 1 : 0;
+    const int32_t stopHere = stopIn[i], pstop = stopIn[ip];
+    const uint32_t lc = locC[i], lg = locG[i], plc = locC[ip], plg = locG[ip];
     int c;
     if (haveChr) c = oChr[i];                             // k_bin_close left the chromosome of every bin: one load instead of a bisection (five dependent ones)
     else {
@@ -662,17 +666,14 @@ __global__ void __launch_bounds__(256) k_bin_finalize(const BinChrom* __restrict
     }
     const BinChrom C = ch[c];
     const long long k = i - binOffset[c];
-    const int32_t stop = stopIn[i];
+    const int32_t stop = stopHere;
     const int64_t tile = C.tileBase + ((int64_t)(stop - 1) >> TILE_SHIFT);
-    uint32_t gC = tileExC[tile] + locC[i], gG = tileExG[tile] + locG[i];
+    const int64_t ptile = C.tileBase + ((int64_t)((k > 0 ? pstop : 1) - 1) >> TILE_SHIFT);      // (k == 0: any valid tile, the value is not used)
+    const uint32_t exC = tileExC[tile], exG = tileExG[tile], pexC = tileExC[ptile], pexG = tileExG[ptile];      // four loads in flight
+    uint32_t gC = exC + lc, gG = exG + lg;
     uint32_t pC = 0, pG = 0;
     int32_t start = (int32_t)pos0[c];
-    if (k > 0) {
-        const int32_t pstop = stopIn[i - 1];
-        const int64_t ptile = C.tileBase + ((int64_t)(pstop - 1) >> TILE_SHIFT);
-        pC = tileExC[ptile] + locC[i - 1]; pG = tileExG[ptile] + locG[i - 1];
-        start = pstop;
-    }
+    if (k > 0) { pC = pexC + plc; pG = pexG + plg; start = pstop; }
     const uint32_t count = gC - pC, gcCount = gG - pG;
     const int32_t nuc = stop - start;
     float gcf = 100.0f * (float)(int32_t)gcCount;     // (int)(100f * GCCount / NucleotideCount), CanvasBin.cs:638

@@ -435,12 +435,13 @@ __global__ void __launch_bounds__(256) k_vit_increments(const HmmChrom* __restri
     const int64_t* off = stage_chr_offsets(chrOff, nchr, sOff);
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= N) return;
+    const int s1 = state[g], sPrev = state[g > 0 ? g - 1 : 0], ix = idx[g];          // requested together: the table lookup below is the only dependent load
     const int lo = chrom_of_bin(off, nchr, g);
-    int s1 = state[g];
+    const int64_t begin = chroms[lo].begin;
     if (s1 < 0) { D[g] = 0.0; return; }
-    double e = logPmf[(size_t)s1 * P.tableLen + idx[g]];
-    if (g == chroms[lo].begin) { double lik = e + P.logA[0][s1]; D[g] = P.logPi[s1] + lik - P.logA[0][s1]; }
-    else { int s0 = state[g - 1]; D[g] = e + P.logA[s0 < 0 ? 0 : s0][s1]; }
+    double e = logPmf[(size_t)s1 * P.tableLen + ix];
+    if (g == begin) { double lik = e + P.logA[0][s1]; D[g] = P.logPi[s1] + lik - P.logA[0][s1]; }
+    else { const int s0 = sPrev; D[g] = e + P.logA[s0 < 0 ? 0 : s0][s1]; }
 }
 
 // B1b: D_t = D_{t-1} + v_t in the reference's (sequential) association.  One wave per chromosome; the increments of a 64-step
@@ -1083,32 +1084,34 @@ __global__ void __launch_bounds__(256) k_seg_flags(const int64_t* __restrict__ c
     const int64_t* off = stage_chr_offsets(chrOff, nchr, sOff);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // everything the decisions below may look at is requested up front (four loads in flight instead of up to three round trips one after the other)
+    const int64_t im = i > 0 ? i - 1 : 0;
+    const int32_t st = state[i], stPrev = state[im], stopPrev = stop[im], stopHere = stop[i], startHere = start[i];
     const int lo = chrom_of_bin(off, nchr, i);
     const bool first = (i == off[lo]);
-    const int32_t st = state[i];
-    bool newSeg = st >= 0 && (first || state[i - 1] != st);           // breakpoint -> segment start present in `starts`
+    bool newSeg = st >= 0 && (first || stPrev != st);                 // breakpoint -> segment start present in `starts`
     if (exclOff) {
         // forbidden intervals (SegmentationResultsProcessor.cs:88-111): excludeIndex = first interval whose Stop >= previousBinEnd
         // (the reference advances a cursor; with intervals sorted by Stop that is a lower bound), split when the interval's
         // midpoint lies in (previousBinEnd, end]
-        const uint32_t prevEnd = first ? 0u : (uint32_t)stop[i - 1];
+        const uint32_t prevEnd = first ? 0u : (uint32_t)stopPrev;
         int64_t a = exclOff[lo], b = exclOff[lo + 1];
         while (a < b) { int64_t mid = (a + b) >> 1; if ((int64_t)exclStop[mid] < (int64_t)prevEnd) a = mid + 1; else b = mid; }
         if (a < exclOff[lo + 1]) {
             const int forbiddenZoneMid = (exclStart[a] + exclStop[a]) / 2;
-            if ((int64_t)prevEnd < forbiddenZoneMid && (int64_t)(uint32_t)stop[i] >= forbiddenZoneMid) newSeg = true;
+            if ((int64_t)prevEnd < forbiddenZoneMid && (int64_t)(uint32_t)stopHere >= forbiddenZoneMid) newSeg = true;
         }
     }
     if (!newSeg && !first) {
-        uint32_t prevEnd = (uint32_t)stop[i - 1];
-        if (prevEnd > 0 && maxDist >= 0 && (uint64_t)prevEnd + (uint64_t)maxDist < (uint64_t)(uint32_t)start[i]) newSeg = true;   // SegmentationResultsProcessor.cs:112-116
+        uint32_t prevEnd = (uint32_t)stopPrev;
+        if (prevEnd > 0 && maxDist >= 0 && (uint64_t)prevEnd + (uint64_t)maxDist < (uint64_t)(uint32_t)startHere) newSeg = true;   // SegmentationResultsProcessor.cs:112-116
     }
     if (!newSeg && plOff) {
         // reference ploidy changes between the end of the previous bin and the end of this one (SegmentationResultsProcessor.cs:117-128):
         // PloidyInfo.getPloidyCounts over the one-based interval [previousBinEnd > 0 ? previousBinEnd : 1, end] (PloidyInfo.cs:93-110); a chromosome
         // has a handful of records (PAR / non-PAR stretches of the sex chromosomes), so every bin walks its chromosome's list
-        const uint32_t prevEnd = first ? 0u : (uint32_t)stop[i - 1];
-        const int qs = prevEnd > 0 ? (int)prevEnd : 1, qe = (int)(uint32_t)stop[i];
+        const uint32_t prevEnd = first ? 0u : (uint32_t)stopPrev;
+        const int qs = prevEnd > 0 ? (int)prevEnd : 1, qe = (int)(uint32_t)stopHere;
         int bc0 = 0, bc1 = 0, bc2 = qe - qs + 1, bc3 = 0, bc4 = 0;
         for (int64_t k = plOff[lo]; k < plOff[lo + 1]; k++) {
             const int p = plCn[k];
