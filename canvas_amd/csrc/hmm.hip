@@ -411,7 +411,7 @@ __device__ __forceinline__ int chrom_of_bin(const int64_t* off, int nchr, int64_
 // The speculative pass is latency-bound at one wave per SIMD (a second wave per SIMD is nearly free), the verification is issue-bound:
 // speculation therefore runs on blocks of VBS = VB / 2 steps (twice the waves, 3/4 of the steps per lane) and the maps of the two halves
 // of a VB block are composed here for the backtrack (first the later half, then the earlier one).
-// (VB / 4 was measured too: 161 us against 140 us for the WGS sample — with two waves per SIMD the pass is issue-bound and the extra lead-in steps cost more than they hide.)
+// (VB / 1: 167 us.)  (VB / 4 was measured too: 161 us against 140 us for the WGS sample — with two waves per SIMD the pass is issue-bound and the extra lead-in steps cost more than they hide.)
 #define VBS (VB / 2)
 __global__ void __launch_bounds__(256) k_pair_maps(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ firstS,
                                                    const uint16_t* __restrict__ mapsS, uint16_t* __restrict__ maps, const int32_t* __restrict__ todo) {
