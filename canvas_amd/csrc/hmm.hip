@@ -16,6 +16,7 @@
 //   device  k_backtrack_*  back-pointer chasing as an exact function-composition scan over 256-step blocks [parallel]
 //   device  k_seg_flags / k_seg_ids   break points + inter-bin-distance rule -> running segment id (prefix sum)
 #include "common.hpp"
+#include <type_traits>
 #include "select.hpp"
 #include <mutex>
 #include <cmath>
@@ -250,14 +251,17 @@ struct __attribute__((aligned(2))) VecH8 { uint32_t w[4]; };   // eight packed 1
 
 // new delta and back-pointer of state J:  tmp_i = delta_i + (logpmf_J(x_t) + logA[i][J]),  strict '>' scan i = 0..4 from
 // Double.MinValue == first index of the maximum (evaluated as a tree, no NaNs can occur)   (HMM.cs:84-97, Distributions.cs:322)
-template <int J>
+// TWO: the transition matrix has one value on the diagonal and one off it (the HMMs of CanvasPartition: 0.99 / 0.0025) — the five sums e + logA[i][J] are then two
+// different additions, each with the same operands and therefore the same result as in the reference's expression
+template <int J, bool TWO = false>
 __device__ __forceinline__ void vit_state(const double (&d)[NSTATE], double e, const HmmParams& P, double& outDelta, uint32_t& outArg) {
     const double NEG = -1.7976931348623157e308;
-    const double t_0 = d[0] + (e + P.logA[0][J]);
-    const double t_1 = d[1] + (e + P.logA[1][J]);
-    const double t_2 = d[2] + (e + P.logA[2][J]);
-    const double t_3 = d[3] + (e + P.logA[3][J]);
-    const double t_4 = d[4] + (e + P.logA[4][J]);
+    const double cOff = e + P.logA[J == 0 ? 1 : 0][J], cDiag = e + P.logA[J][J];
+    const double t_0 = d[0] + (TWO ? (J == 0 ? cDiag : cOff) : (e + P.logA[0][J]));
+    const double t_1 = d[1] + (TWO ? (J == 1 ? cDiag : cOff) : (e + P.logA[1][J]));
+    const double t_2 = d[2] + (TWO ? (J == 2 ? cDiag : cOff) : (e + P.logA[2][J]));
+    const double t_3 = d[3] + (TWO ? (J == 3 ? cDiag : cOff) : (e + P.logA[3][J]));
+    const double t_4 = d[4] + (TWO ? (J == 4 ? cDiag : cOff) : (e + P.logA[4][J]));
     // maximum first (v_max_f64), then the first index that attains it: fewer selects than carrying (value, index) through the scan
     double a = __builtin_fmax(__builtin_fmax(__builtin_fmax(t_0, t_1), __builtin_fmax(t_2, t_3)), t_4);
     uint32_t ia = t_3 == a ? 3u : 4u;
@@ -266,10 +270,11 @@ __device__ __forceinline__ void vit_state(const double (&d)[NSTATE], double e, c
     outDelta = a; outArg = ia;
 }
 // one full step for all five states; returns the packed back-pointers
+template <bool TWO = false>
 __device__ __forceinline__ uint32_t vit_step5(double (&d)[NSTATE], const double (&e)[NSTATE], const HmmParams& P) {
     double n0, n1, n2, n3, n4; uint32_t a0, a1, a2, a3, a4;
-    vit_state<0>(d, e[0], P, n0, a0); vit_state<1>(d, e[1], P, n1, a1); vit_state<2>(d, e[2], P, n2, a2);
-    vit_state<3>(d, e[3], P, n3, a3); vit_state<4>(d, e[4], P, n4, a4);
+    vit_state<0, TWO>(d, e[0], P, n0, a0); vit_state<1, TWO>(d, e[1], P, n1, a1); vit_state<2, TWO>(d, e[2], P, n2, a2);
+    vit_state<3, TWO>(d, e[3], P, n3, a3); vit_state<4, TWO>(d, e[4], P, n4, a4);
     d[0] = n0; d[1] = n1; d[2] = n2; d[3] = n3; d[4] = n4;
     return a0 | (a1 << 3) | (a2 << 6) | (a3 << 9) | (a4 << 12);
 }
@@ -328,7 +333,7 @@ __global__ void __launch_bounds__(256) k_make_blocks(const int32_t* __restrict__
 }
 
 // A: one lane per block
-template <bool useLds>      // compile-time: with both emission sources in one kernel every step waited for ALL outstanding memory operations
+template <bool useLds, bool TWO>      // compile-time: with both emission sources in one kernel every step waited for ALL outstanding memory operations
 __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ blocks, int nblocks, const HmmChrom* __restrict__ chroms, const int32_t* __restrict__ idx,
                                                  const double* __restrict__ logPmf, HmmParams P, uint16_t* __restrict__ psi, uint16_t* __restrict__ maps,
                                                  int32_t* __restrict__ lastGuess, int leadIn, const int32_t* __restrict__ todo, int vb) {
@@ -366,7 +371,10 @@ __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ bl
     VecI4 qa = *reinterpret_cast<const VecI4*>(ix + 1), qb = *reinterpret_cast<const VecI4*>(ix + 5);
     double eCur[NSTATE];                                                            // emission row of the step about to run: read one step ahead,
     vit_emissions(eCur, sTab, logPmf, useLds, P.tableLen, 1 < nsteps ? qa.v[0] : 0);   // so that the LDS latency hides behind the previous step's arithmetic
-    for (int s0 = 1; s0 < maxSteps; s0 += PQ) {
+    // one group of PQ steps; `withMaps`: some lane of the wave is past its lead-in in this group, so back-pointers are stored and composed into the block map
+    // (two thirds of a lane's steps are lead-in: the groups in front of the wave's shortest lead-in run without those ~25 integer instructions per step)
+    auto group = [&](int s0, auto withMaps) {
+        constexpr bool WM = decltype(withMaps)::value;
         const VecI4 na = *reinterpret_cast<const VecI4*>(ix + s0 + PQ), nb = *reinterpret_cast<const VecI4*>(ix + s0 + PQ + 4);
         uint32_t pks[PQ];
 #pragma unroll
@@ -378,16 +386,21 @@ __global__ void __launch_bounds__(64) k_vit_spec(const VitBlock* __restrict__ bl
             vit_emissions(eNext, sTab, logPmf, useLds, P.tableLen, kNext);
 #pragma unroll
             for (int j = 0; j < NSTATE; j++) dn[j] = d[j];
-            const uint32_t pk = vit_step5(dn, eCur, P);
+            const uint32_t pk = vit_step5<TWO>(dn, eCur, P);
 #pragma unroll
             for (int j = 0; j < NSTATE; j++) { d[j] = on ? dn[j] : d[j]; eCur[j] = eNext[j]; }
-            fm = (on && s >= lead) ? map_compose(fm, pk) : fm;
-            pks[u] = pk;
+            if (WM) { fm = (on && s >= lead) ? map_compose(fm, pk) : fm; pks[u] = pk; }
         }
+        if (WM) {
 #pragma unroll
-        for (int u = 0; u < PQ; u++) { const int s = s0 + u; if (s < nsteps && s >= lead) pp[ts + s] = (uint16_t)pks[u]; }
+            for (int u = 0; u < PQ; u++) { const int s = s0 + u; if (s < nsteps && s >= lead) pp[ts + s] = (uint16_t)pks[u]; }
+        }
         qa = na; qb = nb;
-    }
+    };
+    const int leadMin = -wave_max_i32(nsteps > 0 ? -lead : -0x7FFFFFFF);           // shortest lead-in among the wave's active lanes
+    int s0 = 1;
+    for (; s0 + PQ <= leadMin && s0 < maxSteps; s0 += PQ) group(s0, std::false_type{});
+    for (; s0 < maxSteps; s0 += PQ) group(s0, std::true_type{});
     if (act) {
         maps[b] = (uint16_t)fm;
         if (tEnd == C.T) lastGuess[B.chrom] = vit_best5(d);      // guess of the best final state (HMM.cs:100-111 on the shifted delta)
@@ -887,7 +900,7 @@ __device__ __forceinline__ void ver_block_step(VerState& S, const HmmParams& P, 
     const double Dt = S.Dprev + v;
 #pragma unroll
     for (int j = 0; j < NSTATE; j++) dn[j] = S.d[j];
-    const uint32_t got = vit_step5(dn, e, P);
+    const uint32_t got = vit_step5(dn, e, P);       // (the two-constant form of the speculative pass was measured here too: no change, 151 us)
     S.bad = S.bad || (on && (S.valid != 31u || got != pk || sel5(dn, (uint32_t)(on ? sCur : 0)) != Dt));
 #pragma unroll
     for (int j = 0; j < NSTATE; j++) S.d[j] = on ? dn[j] : S.d[j];
@@ -1428,6 +1441,12 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             hipLaunchKernelGGL(k_bt_states, dim3(nblk2(nblocks, 4)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, psi, dFirst, dFirstGroup, dPre, dGentry, d_state);
         }
     };
+    // one value on the diagonal of the transition matrix and one off it (bit patterns compared): the speculative pass then adds two constants per state instead of five
+    bool twoValued = true;
+    for (int i = 0; i < NSTATE; i++) for (int j = 0; j < NSTATE; j++) {
+        const double ref = i == j ? P.logA[0][0] : P.logA[0][1];
+        if (memcmp(&P.logA[i][j], &ref, sizeof(double)) != 0) twoValued = false;
+    }
     const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
     std::vector<int32_t> redo;
     if (speculative && nblocks > 0) {
@@ -1440,8 +1459,11 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         for (int attempt = 0; attempt < 2; attempt++) {
             const int leadSpec = attempt == 0 ? VW : 8 * VW, leadVer = attempt == 0 ? VW2 : 8 * VW2;
             CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
-            if (lds) hipLaunchKernelGGL((k_vit_spec<true>), dim3((unsigned)((nblocksS + 63) / 64)), dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
-            else hipLaunchKernelGGL((k_vit_spec<false>), dim3((unsigned)((nblocksS + 63) / 64)), dim3(64), 0, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
+            const dim3 gs((unsigned)((nblocksS + 63) / 64));
+            if (lds && twoValued) hipLaunchKernelGGL((k_vit_spec<true, true>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
+            else if (lds) hipLaunchKernelGGL((k_vit_spec<true, false>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
+            else if (twoValued) hipLaunchKernelGGL((k_vit_spec<false, true>), gs, dim3(64), 0, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
+            else hipLaunchKernelGGL((k_vit_spec<false, false>), gs, dim3(64), 0, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             hipLaunchKernelGGL(k_pair_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, dFirstS, dMapsS, dMaps, dTodo);
             if (attempt == 0 && getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, chroms[0].begin + chroms[0].T / 2);
             backtrack(true);
