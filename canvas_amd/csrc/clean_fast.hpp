@@ -394,6 +394,7 @@ __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict_
 }
 
 // ---------------------------------------------------------------- local SD (CanvasClean.cs:243-298)
+// (a variant that staged 5120 bins per workgroup through LDS for coalesced loads / stores was measured: 39 us against 27 us — the strided accesses hit in L2)
 // one thread per window of 20 count differences (Utilities.StandardDeviation, CanvasClean.cs:262-298) + the chromosome boundaries among the window's bins (the run records that
 // GetLocalStandardDeviationAverage's per-chromosome grouping needs) + CountDeviation = -1 (GenomicBin.cs:83) for the bins behind the last window
 __global__ void __launch_bounds__(256) k_cf_local_sd(const CfArgs* __restrict__ AA) {
@@ -426,18 +427,18 @@ __global__ void __launch_bounds__(1024) k_cf_runs_build(const CfArgs* __restrict
     const unsigned int nb = D->nRunRec;
     if (nb > CF_MAXRUN) { if (threadIdx.x == 0) { D->fallback = 1u; D->nruns = 0; } return; }
     const int t = threadIdx.x;
-    s[t] = t < (int)nb ? recs[t] : 0x7FFFFFFFFFFFFFFFll;
+    __shared__ long long raw[CF_MAXRUN];
+    raw[t] = t < (int)nb ? recs[t] : 0x7FFFFFFFFFFFFFFFll;
     __syncthreads();
-    if (nb <= 64u) {                                                          // one record per chromosome of a sorted file: an insertion sort by one thread beats 55 barriers
-        if (t == 0) for (unsigned i = 1; i < nb; i++) { const long long v = s[i]; int j = (int)i - 1; while (j >= 0 && s[j] > v) { s[j + 1] = s[j]; j--; } s[j + 1] = v; }
-        __syncthreads();
-    } else
-    for (int k = 2; k <= CF_MAXRUN; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const int ixj = t ^ j;
-            if (ixj > t) { const long long a = s[t], b = s[ixj]; const bool up = (t & k) == 0; if ((a > b) == up) { s[t] = b; s[ixj] = a; } }
-            __syncthreads();
-        }
+    // rank sort: every record counts the records in front of it (independent broadcast reads of LDS).  A one-thread insertion sort of the ~24 records of a sorted
+    // file was a chain of dependent LDS accesses (10 of the kernel's 17 us), the bitonic network 55 barriers.
+    if (t < (int)nb) {
+        const long long mine = raw[t];
+        int rank = 0;
+        for (int j = 0; j < (int)nb; j++) { const long long o = raw[j]; rank += (o < mine || (o == mine && j < t)) ? 1 : 0; }
+        s[rank] = mine;
+    }
+    __syncthreads();
     if (t == 0) {
         const int64_t n = (int64_t)nAB, Dn = n - 1, nW = Dn >= 1 ? (Dn - 1) / 20 : 0;
         int nruns = 0; int32_t lastChr = -1; bool any = false;
