@@ -9,7 +9,11 @@
 // input intact and is handed to the host-driven path of clean.hip.  All per-bin arithmetic and all order statistics are the ones of that path: results are bit-identical.
 //
 // The stage is BATCH-NATIVE: every kernel takes a table of per-sample argument blocks (CfArgs, in device memory) and works on the block of blockIdx.y, so a cohort of B samples
-// costs the same ~55 launches as one sample (grid.y = B) and no sample's launch latency is paid B times.  One sample is a batch of one.
+// costs the same ~30 launches as one sample (grid.y = B) and no sample's launch latency is paid B times.  One sample is a batch of one.
+//
+// Order statistics: the counts of a .binned file are two-decimal values, so the medians and quartiles are read off exact per-value counters (CfCq below) — one sweep and
+// one pick per stage instead of four radix passes per select; the radix selects (select.hpp) remain for any other input and for the rare second NormalizeByGC.
+// No kernel ends with an atomic on ONE address per workgroup (a serial chain at the memory side): the per-GC counters and cursors are replicated CF_HREP times.
 #pragma once
 
 #define CF_MAXQ 640          // 6 + 6 * 101 quartile queries (variance normalisation); 2 + 2 * 101 median queries
