@@ -69,8 +69,9 @@ struct CfCq {
 };
 // k -> cq_value(k) may be ANY non-decreasing map as long as the check and the reconstruction use the same one: a key is accepted only if cq_value(k) gives it back bit for
 // bit, so accepted keys are in strictly increasing correspondence with their k.  (float)(k * 0.01) is that map (one multiplication; the division k / 100.0 made
-// k_cq_hist VALU-bound: 37 -> 25 us).  It reproduces every integer count and the float.Parse of a two-decimal text except where the double product lies within
-// 2^-29 of a float rounding boundary (a few samples in a thousand have such a count: they take the radix selects).
+// k_cq_hist VALU-bound: 37 -> 31 us).  It reproduces every integer count — the read counts of a WGS .binned file — and the float.Parse of a two-decimal text except where
+// the double product lies within an ulp of a float rounding boundary (~7e-9 of the values: about 2 % of 3 M-bin samples with fractional counts hold one and take the
+// radix selects; tests/test_counting_key_map.py restates the map in numpy).
 __device__ __forceinline__ float cq_value(long long k) { return (float)((double)k * 0.01); }
 __device__ __forceinline__ bool cq_key(float x, long long& k) {
     const double y = (double)x * 100.0;
