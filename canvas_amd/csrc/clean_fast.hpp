@@ -1,15 +1,26 @@
 // CanvasClean without host round trips (included by clean.hip): CanvasClean.Main (CanvasClean/CanvasClean.cs:415-533) for the MedianByGC flavour with the default
 // weighted-median setting (-w >= 100, which makes every GC bucket that survives RemoveBinsWithExtremeGC hold >= 100 autosomal bins: CanvasClean.cs:207-237,178-187).
 //
-// Every decision the reference takes once per file — the size threshold, the GC strip, the per-GC medians, whether the variance normalisation applies and changes
-// anything, the local-SD filter — is taken by a one-workgroup kernel that leaves its result in device memory (CleanDev); the kernels that follow read it from there
-// and the kernels of a branch that is not taken find an empty problem and return.  The host enqueues the whole stage in one go and synchronises once, at the end.
-//   caller's arrays --(size filter + outlier filter: ONE compaction)--> scratch SoA  ...in-place normalisation...  --(GC strip + local-SD filter: ONE compaction)--> caller's arrays
+// The stage is EIGHT launches and one synchronisation:
+//   k_cf_init        zeroes the stage's counters and publishes the argument table (which arrives as a kernel argument: no copy engine, no memset node)
+//   k_cf_size        exact per-size counts of the bins; the last workgroup to finish reads the 98th percentile off them (RemoveBigBins threshold, CanvasClean.cs:328-348)
+//   k_cf_flags_ab    RemoveBigBins + RemoveOutliers flags in one pass + the GC histogram of the survivors; the last workgroup totals the block counts, takes the
+//                    RemoveBinsWithExtremeGC decision (:207-237) and prepares the counting selects (window, tiles, ranks)
+//   k_cf_scatter_ab  ONE compaction caller -> scratch (every workgroup sums the counts of the blocks in front of it: no scan kernel) + the autosomal keys grouped by GC
+//   k_cf_hist_lsd    two roles in one grid: per-value counters of the grouped keys  |  window SDs of the compacted counts (:243-298); the last window workgroup builds
+//                    the chromosome runs
+//   k_cf_pick_mad    two roles: per-GC medians / quartile statistics from the counters, the weighted count of the normalised values, and in the last workgroup the genome's
+//                    quartiles + the NormalizeVarianceByGC decision (:34-83)  |  median and MAD of every chromosome run's window SDs; the last one averages them
+//   k_cf_flags_final GC strip + local-SD filter flags (CountDeviation is read from the window SDs: it is never stored per bin)
+//   k_cf_scatter_final the last compaction, scratch -> caller's arrays, applying NormalizeByGC on the way out
+// Every decision the reference takes once per file is taken by the LAST workgroup of the kernel that produces its input (an arrival ticket per kernel): what that
+// workgroup reads from the others was published with device-scope atomics or write-through stores and is read back with sc1 loads (cf_ld / cf_st below), its results go
+// to CleanDev with plain stores and are read by the NEXT kernel.  (Round 2 ran each decision as a one-workgroup kernel: ten launches of 5-12 us and their boundaries.)
 // The caller's arrays are not written before the last kernel, so a case this path does not cover (more than CF_MAXRUN chromosome runs) is detected on the device, leaves the
 // input intact and is handed to the host-driven path of clean.hip.  All per-bin arithmetic and all order statistics are the ones of that path: results are bit-identical.
 //
 // The stage is BATCH-NATIVE: every kernel takes a table of per-sample argument blocks (CfArgs, in device memory) and works on the block of blockIdx.y, so a cohort of B samples
-// costs the same ~30 launches as one sample (grid.y = B) and no sample's launch latency is paid B times.  One sample is a batch of one.
+// costs the same launches as one sample (grid.y = B).  One sample is a batch of one.
 //
 // Order statistics: the counts of a .binned file are two-decimal values, so the medians and quartiles are read off exact per-value counters (CfCq below) — one sweep and
 // one pick per stage instead of four radix passes per select; the radix selects (select.hpp) remain for any other input and for the rare second NormalizeByGC.
@@ -23,6 +34,8 @@
 #define CF_HREP 16           // replicas of the per-GC counters the flag / scatter kernels add to (workgroup % CF_HREP picks one): 2 338 workgroups adding to ONE address
                              // are a serial chain at the memory side (measured: a single per-workgroup atomicAdd on one word cost k_cf_flags_ab 31 of its 82 us)
 #define CF_SZ_LDS 4096       // ... of which the first CF_SZ_LDS are counted in LDS per workgroup (WGS bins are a few hundred to a few thousand positions)
+#define CF_MADB 64           // workgroups of the run-MAD role (each takes runs r, r + CF_MADB, ...)
+#define CF_BYVAL 4           // samples whose argument blocks travel as a kernel argument of k_cf_init (a larger cohort uses one small H2D copy)
 
 struct CleanDev {
     unsigned long long nAB;          // bins after RemoveBigBins + RemoveOutliers
@@ -55,21 +68,22 @@ struct CfSel {                       // a select problem built on the device (se
 };
 // Counting selects.  CanvasClean reads its counts from the F2 text CanvasBin (or CanvasNormalize) wrote, so every count is the float of a two-decimal value k / 100 and
 // x -> k = llrint(100 x) is strictly increasing on them: an order statistic of the counts is an order statistic of the integers k, and those are read off exact counters
-// per value (one sweep) instead of four radix passes.  The counters cover a window of CQW values around the sample's level (estimated from 33 strided keys), one row per GC
+// per value (one sweep) instead of four radix passes.  The counters cover a window of CQW values around the sample's level (estimated from 33 strided counts), one row per GC
 // bucket plus one for the genome; keys below the window are counted per row, keys above it are what is left.  Every key is checked (cq_value(k) == x, below) and every
 // requested rank must fall inside the window: otherwise cqFail is raised and the sample is redone with the radix selects — the result never depends on the window.
 #define CQW 16384            // counter slots per row: +-82 count units around the level
 #define CQ_TILE 32768        // keys per workgroup of the counting sweep (the 64 KB of LDS counters are zeroed and flushed once per tile)
+#define CQ_ROWS (NGC + 2)    // counter rows of a sample: one per GC bucket, [NGC] the genome, [NGC + 1] the weighted count of the normalised values
 struct CfCq {
     int32_t lo; uint32_t bad, fail, ntiles;
-    unsigned long long nbelow;       // normalised counts under the window of k_cq_nhist
+    unsigned long long nbelow;       // normalised counts under the window of the weighted count
     uint32_t below[NGC + 1];         // keys under the window, per bucket and [NGC] for the genome
     uint32_t inWin[NGC + 1];         // keys inside it
     int32_t kq[NGC][6];              // the quartile order statistics of a bucket (as k), in quartile_indices order
 };
 // k -> cq_value(k) may be ANY non-decreasing map as long as the check and the reconstruction use the same one: a key is accepted only if cq_value(k) gives it back bit for
 // bit, so accepted keys are in strictly increasing correspondence with their k.  (float)(k * 0.01) is that map (one multiplication; the division k / 100.0 made
-// k_cq_hist VALU-bound: 37 -> 31 us).  It reproduces every integer count — the read counts of a WGS .binned file — and the float.Parse of a two-decimal text except where
+// the counting sweep VALU-bound: 37 -> 31 us).  It reproduces every integer count — the read counts of a WGS .binned file — and the float.Parse of a two-decimal text except where
 // the double product lies within an ulp of a float rounding boundary (~7e-9 of the values: about 2 % of 3 M-bin samples with fractional counts hold one and take the
 // radix selects; tests/test_counting_key_map.py restates the map in numpy).
 __device__ __forceinline__ float cq_value(long long k) { return (float)((double)k * 0.01); }
@@ -80,62 +94,144 @@ __device__ __forceinline__ bool cq_key(float x, long long& k) {
     k = ki;
     return ki >= 0 && cq_value(ki) == x && !(ki == 0 && (__float_as_uint(x) >> 31));      // (-0.0 sorts in front of 0.0)
 }
+// the scratch copy between the two compactions: the five columns of the survivors, GC as one byte; CountDeviation (GenomicBin.cs:83) is never materialised —
+// the only reader (RemoveBinsWithExtremeLocalSD, :308-322) takes it from the window SD of the bin's window
+struct Soa1 { int32_t *chr, *start, *stop; float* count; uint8_t* gc; };
+struct GSoa1 { gptr<int32_t> chr, start, stop; gptr<float> count; gptr<uint8_t> gc; };
+__device__ __forceinline__ GSoa1 as_global(const Soa1& s) { return GSoa1{as_global(s.chr), as_global(s.start), as_global(s.stop), as_global(s.count), as_global(s.gc)}; }
 struct CfArgs {                      // one sample of the batch
     int64_t n;                       // bins handed in
     int32_t nb, nchr, minBinsPerGc, wantLsd, doSize, doOutlier;
     uint32_t flags, tilesUpper;
-    Soa caller, S1;                  // the caller's arrays; the scratch copy between the two compactions
-    uint8_t* dFlags; uint32_t* dBlk; uint32_t* szHist; uint32_t* szOver; uint32_t szOverCap, padA; uint32_t* keysG; const uint8_t* isAuto;
+    int32_t useCq, padB;
+    Soa caller; Soa1 S1;             // the caller's arrays; the scratch copy between the two compactions
+    uint8_t* dFlags;
+    unsigned long long* dBlk;        // per block of the input: survivors of both filters | survivors of the size filter << 32 (k_cf_flags_ab)
+    uint32_t* dBlkF;                 // per block of the scratch copy: survivors of the last compaction (k_cf_flags_final)
+    uint32_t* szHist; uint32_t* szOver; uint32_t szOverCap, padA; uint32_t* keysG; const uint8_t* isAuto;
     double* dSd; double* dRunMad; int64_t* dRunStart; long long* dPos;
     CleanDev* D; CfSel* P; SelTile* tiles; uint32_t* hist;
     CfCq* cq; uint32_t* cqHist; SelTile* cqTiles;      // the counting selects (below)
-    uint32_t* repl;                  // [CF_HREP][2 * NGC] GC counts of the survivors per replica (k_cf_flags_ab), then [CF_HREP][NGC] write cursors into the grouped keys (k_cf_dec_gc -> k_cf_scatter_ab)
+    uint32_t* repl;                  // [CF_HREP][2 * NGC] GC counts of the survivors per replica (k_cf_flags_ab), then [CF_HREP][NGC] write cursors into the grouped keys (its last workgroup -> k_cf_scatter_ab)
+    uint32_t* tick;                  // [8] arrival tickets: 0 k_cf_size, 1 k_cf_flags_ab, 2 window role of k_cf_hist_lsd, 3 / 4 pick and run role of k_cf_pick_mad
 };
+struct CfArgsPack { CfArgs a[CF_BYVAL]; uint8_t isAuto[256]; };
 #define CF_SAMPLE const CfArgs& A = AA[blockIdx.y]
+
+// ---------------------------------------------------------------- hand-off inside a launch
+// A value one workgroup publishes for the last workgroup of the same launch: write-through (sc1) store / device-scope atomic on the producer's side, sc1 load on the
+// consumer's ("sc1 stores AND sc1 loads": the per-XCD L2s are not coherent and a CU's L1 is never refreshed by another CU's stores).
+template <class T> __device__ __forceinline__ void cf_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ T cf_ld(const T* p) { return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cf_st_f64(double* p, double v) { cf_st(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v)); }
+__device__ __forceinline__ double cf_ld_f64(const double* p) { return __longlong_as_double((long long)cf_ld(reinterpret_cast<const unsigned long long*>(p))); }
+// Arrival ticket (zero at launch): true in the workgroup that arrives last.  Every wave drains its own stores and atomics first, so whatever a workgroup published is
+// in memory before its ticket is.
+__device__ __forceinline__ bool cf_arrive_last(uint32_t* tick, uint32_t expected, int* sFlag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *sFlag = (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == expected) ? 1 : 0;
+    __syncthreads();
+    return *sFlag != 0;
+}
+// sum of one uint32 / uint64 per thread over the workgroup (any multiple of 64 threads up to 1024); every thread gets the total.  Two barriers.
+__device__ __forceinline__ unsigned long long cf_block_sum_u64(unsigned long long v, unsigned long long* sh16) {
+    v = wave_reduce_add_u64(v);
+    __syncthreads();
+    if (lane_id() == 0) sh16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += sh16[w];
+    return t;
+}
+// exclusive prefix sum of one uint32 per thread over a 256-thread workgroup; *total = the sum.  Two barriers.
+__device__ __forceinline__ uint32_t cf_excl_scan256(uint32_t v, uint32_t* sh4, uint32_t* total) {
+    const uint32_t inc = wave_inclusive_scan_u32(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) sh4[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (int w = 0; w < 4; w++) { if (w < (int)(threadIdx.x >> 6)) off += sh4[w]; tot += sh4[w]; }
+    *total = tot;
+    return inc - v + off;
+}
+// exclusive prefix sum of one uint32 per thread over a 128-thread workgroup (two waves); *total = the sum.  One barrier.
+__device__ __forceinline__ uint32_t cf_excl_scan128(uint32_t v, uint32_t* sh2 /* [2] */, uint32_t* total) {
+    const uint32_t inc = wave_inclusive_scan_u32(v);
+    if ((threadIdx.x & 63) == 63) sh2[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    *total = sh2[0] + sh2[1];
+    return inc - v + (threadIdx.x >= 64 ? sh2[0] : 0u);
+}
+
+// ---------------------------------------------------------------- k_cf_init: the stage's zeros and its argument table
+// zero: CleanDev blocks, size counters, replica counters, CfCq blocks, tickets, value counters of all samples (one contiguous region, 16-byte granules)
+__global__ void __launch_bounds__(1024) k_cf_init(CfArgs* __restrict__ table, uint8_t* __restrict__ isAutoDev, const CfArgsPack pack, int npack, int nchr, uint4* __restrict__ zero, size_t nvec) {
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 1024) zero[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && npack > 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&pack.a[0]); uint32_t* dst = reinterpret_cast<uint32_t*>(table);
+        const int words = npack * (int)(sizeof(CfArgs) / 4);
+        for (int i = threadIdx.x; i < words; i += 1024) dst[i] = src[i];
+        for (int i = threadIdx.x; i < nchr; i += 1024) isAutoDev[i] = pack.isAuto[i];
+    }
+}
 
 // ---------------------------------------------------------------- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes
 // Sizes are small integers, so the order statistic is read off an exact count per size (one sweep of start / stop, no key array, no radix passes): sizes below CF_SZ_LDS are
 // counted in LDS per workgroup and flushed, sizes up to CF_SZ_BINS go to the global counters directly, larger ones only matter if the percentile itself is that large.
-#define CF_SZ_GRID 128       // workgroups per sample in the size count: each takes n / 128 bins, so its LDS counters absorb many bins per distinct size before the flush
-__global__ void __launch_bounds__(1024) k_cf_size_hist(const CfArgs* __restrict__ AA) {
+#define CF_SZ_GRID 256       // workgroups per sample in the size count
+__device__ __forceinline__ void cf_size_count(const CfArgs& A, int32_t sz, uint32_t* lh, uint32_t& neg) {
+    if (sz < 0) neg++;
+    else if (sz < CF_SZ_LDS) atomicAdd(&lh[sz], 1u);
+    else if (sz < CF_SZ_BINS) atomicAdd(&A.szHist[sz], 1u);
+    else { const unsigned int k = atomicAdd(&A.D->nOver, 1u); if (k < A.szOverCap) cf_st(&A.szOver[k], (uint32_t)sz); }
+}
+__global__ void __launch_bounds__(1024) k_cf_size(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ uint32_t lh[CF_SZ_LDS];
-    if (!A.doSize) return;
+    __shared__ int sLast;
+    if (!A.doSize) return;                                                      // sizeOn stays 0 (k_cf_init)
     const int64_t n = A.n;
     for (int i = threadIdx.x; i < CF_SZ_LDS; i += 1024) lh[i] = 0;
     __syncthreads();
     const gptr<const int32_t> start = as_global(A.caller.start), stop = as_global(A.caller.stop);
     uint32_t neg = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)CF_SZ_GRID * 1024) {
-        const int32_t sz = stop[i] - start[i];
-        if (sz < 0) neg++;
-        else if (sz < CF_SZ_LDS) atomicAdd(&lh[sz], 1u);
-        else if (sz < CF_SZ_BINS) atomicAdd(&A.szHist[sz], 1u);
-        else { const unsigned int k = atomicAdd(&A.D->nOver, 1u); if (k < A.szOverCap) A.szOver[k] = (uint32_t)sz; }
+    const bool vec = (((uintptr_t)A.caller.start | (uintptr_t)A.caller.stop) & 15) == 0;
+    const int64_t nvec = vec ? n / 4 : 0;
+    for (int64_t v = (int64_t)blockIdx.x * 1024 + threadIdx.x; v < nvec; v += (int64_t)CF_SZ_GRID * 2048) {      // two 16-byte loads per column in flight
+        const int64_t v2 = v + (int64_t)CF_SZ_GRID * 1024;
+        const uint4 a0 = gload_uint4(start + 4 * v), b0 = gload_uint4(stop + 4 * v);
+        uint4 a1 = make_uint4(0, 0, 0, 0), b1 = a1;
+        if (v2 < nvec) { a1 = gload_uint4(start + 4 * v2); b1 = gload_uint4(stop + 4 * v2); }
+        cf_size_count(A, (int32_t)b0.x - (int32_t)a0.x, lh, neg); cf_size_count(A, (int32_t)b0.y - (int32_t)a0.y, lh, neg);
+        cf_size_count(A, (int32_t)b0.z - (int32_t)a0.z, lh, neg); cf_size_count(A, (int32_t)b0.w - (int32_t)a0.w, lh, neg);
+        if (v2 < nvec) {
+            cf_size_count(A, (int32_t)b1.x - (int32_t)a1.x, lh, neg); cf_size_count(A, (int32_t)b1.y - (int32_t)a1.y, lh, neg);
+            cf_size_count(A, (int32_t)b1.z - (int32_t)a1.z, lh, neg); cf_size_count(A, (int32_t)b1.w - (int32_t)a1.w, lh, neg);
+        }
     }
+    for (int64_t i = 4 * nvec + (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)CF_SZ_GRID * 1024) cf_size_count(A, stop[i] - start[i], lh, neg);
     neg = wave_reduce_add_u32(neg);
     if (lane_id() == 0 && neg) atomicAdd(&A.D->sizeBelow, (unsigned long long)neg);
     __syncthreads();
     for (int i = threadIdx.x; i < CF_SZ_LDS; i += 1024) { const uint32_t v = lh[i]; if (v) atomicAdd(&A.szHist[i], v); }
-}
-// one workgroup per sample: the size with cumulative count > index (the element at `index` of the sorted sizes)
-__global__ void __launch_bounds__(1024) k_cf_size_pick(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
+    if (!cf_arrive_last(A.tick + 0, CF_SZ_GRID, &sLast)) return;
+    // ---- last workgroup: the size with cumulative count > index (the element at `index` of the sorted sizes)
     __shared__ unsigned long long sTot[1024 / 64];
     __shared__ int sFound;
     CleanDev* __restrict__ D = A.D;
     const int64_t index = (int64_t)(0.98 * (double)A.n);                       // CanvasClean.cs:339
-    const bool on = A.doSize && index < A.n;
-    if (!on) { if (threadIdx.x == 0) D->sizeOn = 0u; return; }
-    const unsigned long long want = (unsigned long long)index, below = D->sizeBelow;
+    if (!(index < A.n)) return;                                                // the percentile index falls past the end: the filter is off (sizeOn stays 0)
+    const unsigned long long want = (unsigned long long)index, below = cf_ld(&D->sizeBelow);
+    const unsigned int nOver = cf_ld(&D->nOver);
     if (threadIdx.x == 0) sFound = 0;
-    // the counters are scanned in two stretches of 4 x 1024 x k bins (16-byte loads): [0, CF_SZ_LDS) first — where the bins of a WGS sample are — then the rest
+    // the counters are scanned in two stretches of 1024 x k bins: [0, CF_SZ_LDS) first — where the bins of a WGS sample are — then the rest
     unsigned long long total = below;
     for (int part = 0; part < 2; part++) {
         const int lo = part == 0 ? 0 : CF_SZ_LDS, per = part == 0 ? CF_SZ_LDS / 1024 : (CF_SZ_BINS - CF_SZ_LDS) / 1024;      // 4, 60 bins per thread
         const uint32_t* __restrict__ h = A.szHist + lo + (size_t)threadIdx.x * per;
         unsigned long long mine = 0;
-        for (int k = 0; k < per; k += 4) { const uint4 q = *reinterpret_cast<const uint4*>(h + k); mine += (unsigned long long)q.x + q.y + q.z + q.w; }
+        for (int k = 0; k < per; k += 2) { const unsigned long long q = cf_ld(reinterpret_cast<const unsigned long long*>(h + k)); mine += (q & 0xFFFFFFFFull) + (q >> 32); }
         unsigned long long inc = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if ((int)lane_id() >= d) inc += o; }
@@ -147,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_cf_size_pick(const CfArgs* __restrict_
         before += inc - mine;
         if (want >= before && want < before + mine) {
             unsigned long long cum = before;
-            for (int k = 0; k < per; k++) { cum += h[k]; if (want < cum) { D->sizeThresh = lo + (int)threadIdx.x * per + k; break; } }
+            for (int k = 0; k < per; k++) { cum += cf_ld(h + k); if (want < cum) { D->sizeThresh = lo + (int)threadIdx.x * per + k; break; } }
             sFound = 1;
         }
         total += sum;
@@ -156,26 +252,18 @@ __global__ void __launch_bounds__(1024) k_cf_size_pick(const CfArgs* __restrict_
     }
     if (threadIdx.x == 0) {
         D->sizeOn = 1u;
-        if (want < below || (want >= total && D->nOver > A.szOverCap)) D->fallback = 1u;     // a negative percentile, or more large bins than the list holds: the host-driven path
+        if (want < below || (want >= total && nOver > A.szOverCap)) D->fallback = 1u;     // a negative percentile, or more large bins than the list holds: the host-driven path
     }
-    if (!sFound && want >= total && D->nOver <= A.szOverCap) {
+    if (!sFound && want >= total && nOver <= A.szOverCap) {
         // the percentile lies among the bins of CF_SZ_BINS positions and more (a heavy tail of bins across assembly gaps): exact order statistic of the list, in this workgroup
         __shared__ uint32_t sH[2][256];
         __shared__ unsigned long long sPre[2], sK[2];
         const uint32_t* __restrict__ ov = A.szOver;
         const unsigned long long t = want - total;
         __syncthreads();
-        wg_select2([&](int64_t i) { return (unsigned long long)ov[i]; }, 0, (int64_t)D->nOver, t, t, sH, sPre, sK);
+        wg_select2([&](int64_t i) { return (unsigned long long)cf_ld(ov + i); }, 0, (int64_t)nOver, t, t, sH, sPre, sK);
         if (threadIdx.x == 0) D->sizeThresh = (int32_t)(uint32_t)sPre[0];
     }
-}
-// exclusive prefix sum of one uint32 per thread over a 128-thread workgroup (two waves); *total = the sum.  One barrier.
-__device__ __forceinline__ uint32_t cf_excl_scan128(uint32_t v, uint32_t* sh2 /* [2] */, uint32_t* total) {
-    const uint32_t inc = wave_inclusive_scan_u32(v);
-    if ((threadIdx.x & 63) == 63) sh2[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    *total = sh2[0] + sh2[1];
-    return inc - v + (threadIdx.x >= 64 ? sh2[0] : 0u);
 }
 // the select problems over the grouped keys, genome + every kept bucket: mode 0 = medians (NormalizeByGC, CanvasClean.cs:163-189), mode 1 = quartiles (NormalizeVarianceByGC, :34-66).
 // gate: which CleanDev flag switches the problem on (0 gcActive, 1 varActive, 2 changed)
@@ -233,17 +321,96 @@ __global__ void __launch_bounds__(64) k_cf_select_pick(const CfArgs* __restrict_
 // ---------------------------------------------------------------- RemoveBigBins + RemoveOutliers in one pass over the caller's arrays
 // keepA(j) = size <= threshold (CanvasClean.cs:349-352); RemoveOutliers (:387-413) looks at the neighbours in the list RemoveBigBins left, i.e. at the nearest
 // bins on either side that pass keepA.  Also the range check of gc / chr, the count after the size filter, and the block counts of the compaction.
+// A thread takes four consecutive bins per round (16-byte loads; the neighbours inside the quad stay in registers, only the quad's outer neighbours are looked up in LDS).
+#define CF_OFF 4             // LDS slot of the block's first bin: slot CF_OFF - 1 = the bin in front of the block, slot CF_OFF + L = the bin behind it
+// the last workgroup of k_cf_flags_ab (256 threads): totals, RemoveBinsWithExtremeGC decision (CanvasClean.cs:207-237) and what follows from it, counting-select set-up
+__device__ __forceinline__ void cf_decide_gc(const CfArgs& A) {
+    __shared__ unsigned long long sh16[16];
+    __shared__ uint32_t shA[4], shB[4], shC[4], shD[4], shT[4];
+    __shared__ uint32_t so[NGC + 1];
+    __shared__ long long sv[33];
+    CleanDev* __restrict__ D = A.D; const uint32_t flags = A.flags; const int minBinsPerGc = A.minBinsPerGc;
+    const int t = threadIdx.x;
+    // ---- bins after both filters / after RemoveBigBins alone: the two halves of the block counts
+    unsigned long long mineT = 0;
+    for (int j = t; j < A.nb; j += 256) mineT += cf_ld(&A.dBlk[j]);
+    const unsigned long long tot = cf_block_sum_u64(mineT, sh16);
+    const long long nAB = (long long)(tot & 0xFFFFFFFFull);
+    if (t == 0) { D->nAB = (unsigned long long)nAB; D->nA = (unsigned int)(tot >> 32); }
+    // ---- GC histogram of the survivors (sum of the replicas)
+    uint32_t hA = 0, hO = 0;
+    if (t < NGC) for (int r = 0; r < CF_HREP; r++) { hA += cf_ld(&A.repl[r * (2 * NGC) + t]); hO += cf_ld(&A.repl[r * (2 * NGC) + NGC + t]); }
+    if (t < NGC) { D->hist[t] = hA; D->hist[NGC + t] = hO; }
+    // the counts are integers below 2^32 and there are 101 of them: their double sum (CanvasClean.cs:219-222) is exact in any order
+    uint32_t totalA; (void)cf_excl_scan256(hA, shA, &totalA);
+    const bool consider = (flags & CANVAS_CLEAN_GCNORM) && nAB > 0;
+    const int averageCountPerGC = max(minBinsPerGc, (int)((double)totalA / NGC));
+    const int threshold = min(100, averageCountPerGC);
+    bool kp = true;
+    if (consider && t < NGC) kp = (int)hA >= threshold;
+    // bins of any chromosome in the kept buckets (each term < 2^32, 101 terms: the 64-bit total is split over two 32-bit scans of the halves)
+    const unsigned long long mine = (consider && t < NGC && kp) ? (unsigned long long)hA + (unsigned long long)hO : 0ull;
+    uint32_t totLo, totHi; (void)cf_excl_scan256((uint32_t)(mine & 0xFFFFu), shB, &totLo); (void)cf_excl_scan256((uint32_t)(mine >> 16), shC, &totHi);
+    const long long kept = (long long)totLo + ((long long)totHi << 16);
+    const bool active = consider && kept > 0;                               // kept <= 0: "proceed without GC correction" (CanvasClean.cs:500-505)
+    if (!active) kp = true;
+    uint32_t totalKept; const uint32_t soff = cf_excl_scan256((active && t < NGC && kp) ? hA : 0u, shD, &totalKept);
+    if (t < NGC) {
+        D->keepGc[t] = kp ? 1 : 0; D->medians[t] = 0.0; D->segOff[t] = active ? soff : 0u; so[t] = active ? soff : 0u;
+        // the bucket's stretch of the grouped keys is filled replica by replica (the order inside a bucket is irrelevant: only order statistics are taken from it)
+        uint32_t at = soff;
+        for (int r = 0; r < CF_HREP; r++) { const uint32_t c = cf_ld(&A.repl[r * (2 * NGC) + t]); A.repl[CF_HREP * (2 * NGC) + r * NGC + t] = at; at += c; }
+    }
+    const long long sKept = active ? kept : nAB;
+    // NormalizeVarianceByGC runs for whole-genome samples only (CanvasClean.cs:512-519); the host enqueues its kernels when the INPUT has more than 500000 bins
+    const bool haveLsd = A.wantLsd && nAB >= 50000;                           // what the window role of k_cf_hist_lsd will store in haveLocalSd (CanvasClean.cs:483-486)
+    const bool varActive = active && haveLsd && sKept > 500000 && A.n > 500000;
+    if (t == 0) {
+        so[NGC] = active ? totalKept : 0u;
+        D->segOff[NGC] = active ? totalKept : 0u; D->kept = sKept; D->gcActive = active ? 1 : 0; D->changed = 0; D->varActive = varActive ? 1 : 0;
+    }
+    if (!A.useCq) return;
+    // ---- counting selects: window, sweep tiles and the marker / ranks the later kernels look at
+    __syncthreads();
+    CfCq* __restrict__ C = A.cq; CfSel* P1 = A.P + 1; CfSel* P2 = A.P + 2;
+    const uint32_t total = so[NGC];
+    if (!active || total == 0) return;                       // hdr[] and ntiles stay 0 (k_cf_init)
+    // the sample's level: the middle one of 33 strided counts of the input that are two-decimal values (any estimate is correct: the window only decides whether the counters suffice)
+    if (t < 33) { const int64_t i = (int64_t)((double)A.n * (t + 0.5) / 33.0); long long k = -1; if (i < A.n && !cq_key(as_global(A.caller.count)[i], k)) k = -1; sv[t] = k; }
+    __syncthreads();
+    if (t < 33) {                                            // every lane ranks its own sample among the valid ones; the one in the middle sets the window
+        const long long mineK = sv[t];
+        int m = 0, rank = 0;
+        for (int j = 0; j < 33; j++) { const long long o = sv[j]; if (o >= 0) { m++; if (o < mineK || (o == mineK && j < t)) rank++; } }
+        if (m == 0) { if (t == 0) C->lo = 0; }
+        else if (mineK >= 0 && rank == m / 2) C->lo = (int32_t)(mineK > CQW / 2 ? mineK - CQW / 2 : 0);
+    }
+    uint32_t totT;
+    const uint32_t myTiles = t < NGC ? (so[t + 1] - so[t] + CQ_TILE - 1) / CQ_TILE : 0u;
+    const uint32_t exT = cf_excl_scan256(myTiles, shT, &totT);
+    if (t < NGC) { uint32_t k = exT; for (int64_t b = so[t]; b < (int64_t)so[t + 1]; b += CQ_TILE) A.cqTiles[k++] = SelTile{t, b, min<int64_t>(b + CQ_TILE, (int64_t)so[t + 1])}; }
+    if (t == 0) {
+        C->ntiles = totT;
+        P1->hdr[0] = 0; P1->hdr[1] = 1;                      // "NormalizeByGC has been decided" for k_cf_scatter_final / k_cf_apply_gc
+        P2->hdr[0] = 0; P2->hdr[1] = 0;
+        if (varActive) {                                     // the genome's quartile ranks (weighted count + resolve in k_cf_pick_mad)
+            const QuartIdx qi = quartile_indices((int64_t)total);
+            for (int k = 0; k < qi.n; k++) { P2->qk[k] = (unsigned long long)qi.idx[k]; P2->qprefix[k] = 0ull; }
+            P2->hdr[1] = (uint32_t)qi.n; P2->first[NGC] = 0;
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ uint32_t sh[8];
-    // keepA, chromosome and count of this block's bins and of the bin on either side of it: slot 0 = bin base - 1, slots 1 .. L = the block, slot L + 1 = bin base + L.
-    // The neighbour search below runs on these slots with 32-bit indices; it leaves them only when the halo bin itself fails the size filter (slow path, global memory).
-    __shared__ uint8_t sA[CBLK + 2];
-    __shared__ int32_t sChr[CBLK + 2];
-    __shared__ float sCnt[CBLK + 2];
-    __shared__ uint8_t sGc[CBLK];
+    // keepA, chromosome and count of this block's bins and of the bin on either side of it.  The neighbour search below runs on these slots with 32-bit indices; it
+    // leaves them only when the halo bin itself fails the size filter (slow path, global memory).
+    __shared__ __attribute__((aligned(16))) uint8_t sA[CBLK + 2 * CF_OFF];
+    __shared__ __attribute__((aligned(16))) int32_t sChr[CBLK + 2 * CF_OFF];
+    __shared__ __attribute__((aligned(16))) float sCnt[CBLK + 2 * CF_OFF];
     __shared__ uint8_t sAuto[256];                        // isAuto of the first 256 chromosomes (more than that: read from the table)
     __shared__ uint32_t lh[2 * NGC];                      // GC histogram of the survivors (CanvasClean.cs:207-223): [0..100] autosomal, [101..201] the others
+    __shared__ int sLast;
     const int64_t n = A.n;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
@@ -257,147 +424,165 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
     const bool doSize = D->sizeOn != 0;                   // off when the filter is, or when the percentile index falls past the end
     const int32_t thresh = doSize ? D->sizeThresh : 0;
     sAuto[threadIdx.x] = (int)threadIdx.x < nchr ? isAuto[threadIdx.x] : 0;
+    const bool vec = ((((uintptr_t)A.caller.chr | (uintptr_t)A.caller.start | (uintptr_t)A.caller.stop | (uintptr_t)A.caller.gc | (uintptr_t)A.caller.count) & 15) == 0);
     uint32_t nKeep = 0, nSize = 0, bad = 0;
+    int32_t rc[CBLK / 1024][4], rg[CBLK / 1024][4]; float rv[CBLK / 1024][4]; uint8_t ra[CBLK / 1024][4];
 #pragma unroll
-    for (int j = 0; j < CBLK / 256; j++) {
-        const int li = j * 256 + threadIdx.x;
-        uint8_t a = 0; int32_t c = -1; float v = 0.0f; int32_t g = 0;
-        if (li < L) {
-            const int64_t i = base + li;
-            c = chr[i]; v = count[i]; g = gc[i];
-            if ((uint32_t)g > 100u || (uint32_t)c >= (uint32_t)nchr) bad = 1;
-            a = (!doSize || (stop[i] - start[i]) <= thresh) ? 1 : 0;
+    for (int r = 0; r < CBLK / 1024; r++) {
+        const int li0 = r * 1024 + 4 * (int)threadIdx.x;
+        int32_t s4[4], e4[4];
+        if (vec && li0 + 3 < L) {
+            const int64_t i = base + li0;
+            const uint4 c = gload_uint4(chr + i), g = gload_uint4(gc + i), s = gload_uint4(start + i), e = gload_uint4(stop + i), v = gload_uint4(count + i);
+            rc[r][0] = (int32_t)c.x; rc[r][1] = (int32_t)c.y; rc[r][2] = (int32_t)c.z; rc[r][3] = (int32_t)c.w;
+            rg[r][0] = (int32_t)g.x; rg[r][1] = (int32_t)g.y; rg[r][2] = (int32_t)g.z; rg[r][3] = (int32_t)g.w;
+            s4[0] = (int32_t)s.x; s4[1] = (int32_t)s.y; s4[2] = (int32_t)s.z; s4[3] = (int32_t)s.w;
+            e4[0] = (int32_t)e.x; e4[1] = (int32_t)e.y; e4[2] = (int32_t)e.z; e4[3] = (int32_t)e.w;
+            rv[r][0] = __uint_as_float(v.x); rv[r][1] = __uint_as_float(v.y); rv[r][2] = __uint_as_float(v.z); rv[r][3] = __uint_as_float(v.w);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                rc[r][e] = -1; rg[r][e] = 0; rv[r][e] = 0.0f; s4[e] = 1; e4[e] = 0;
+                if (li0 + e < L) { const int64_t i = base + li0 + e; rc[r][e] = chr[i]; rg[r][e] = gc[i]; rv[r][e] = count[i]; s4[e] = start[i]; e4[e] = stop[i]; }
+            }
         }
-        sA[1 + li] = a; sChr[1 + li] = c; sCnt[1 + li] = v; sGc[li] = (uint8_t)((uint32_t)g > 100u ? 100 : g);
-        nSize += a;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool in = li0 + e < L;
+            if (in && ((uint32_t)rg[r][e] > 100u || (uint32_t)rc[r][e] >= (uint32_t)nchr)) bad = 1;
+            ra[r][e] = (in && (!doSize || (e4[e] - s4[e]) <= thresh)) ? 1 : 0;
+            nSize += ra[r][e];
+        }
+        *reinterpret_cast<uint32_t*>(&sA[CF_OFF + li0]) = (uint32_t)ra[r][0] | ((uint32_t)ra[r][1] << 8) | ((uint32_t)ra[r][2] << 16) | ((uint32_t)ra[r][3] << 24);
+        *reinterpret_cast<int4*>(&sChr[CF_OFF + li0]) = make_int4(rc[r][0], rc[r][1], rc[r][2], rc[r][3]);
+        *reinterpret_cast<float4*>(&sCnt[CF_OFF + li0]) = make_float4(rv[r][0], rv[r][1], rv[r][2], rv[r][3]);
     }
     const bool hasLeft = base > 0, hasRight = base + L < n;
     if (threadIdx.x < 2) {
         const int64_t i = threadIdx.x == 0 ? base - 1 : base + L;
         uint8_t a = 0; int32_t c = -1; float v = 0.0f;
         if (threadIdx.x == 0 ? hasLeft : hasRight) { c = chr[i]; v = count[i]; a = (!doSize || (stop[i] - start[i]) <= thresh) ? 1 : 0; }
-        const int slot = threadIdx.x == 0 ? 0 : L + 1;
+        const int slot = threadIdx.x == 0 ? CF_OFF - 1 : CF_OFF + L;
         sA[slot] = a; sChr[slot] = c; sCnt[slot] = v;
     }
     __syncthreads();
-#pragma unroll 2
-    for (int j = 0; j < CBLK / 256; j++) {
-        const int li = j * 256 + threadIdx.x;
-        if (li >= L) continue;
-        const int s = li + 1;
-        bool keep = sA[s] != 0;
-        const int32_t c = sChr[s];
-        if (keep && doOutlier) {
-            // nearest bins on either side that pass the size filter (RemoveOutliers runs on the list RemoveBigBins left, CanvasClean.cs:387-413)
-            int ps = s - 1, qs = s + 1;
-            while (ps >= 1 && !sA[ps]) ps--;
-            while (qs <= L && !sA[qs]) qs++;
-            bool hasPrev, hasNext; int32_t cp = -1, cq = -1; float vp = 0.0f, vq = 0.0f;
-            if (ps >= 1 || !hasLeft || sA[0]) { hasPrev = ps >= 1 || hasLeft; if (hasPrev) { cp = sChr[ps]; vp = sCnt[ps]; } }
-            else {                                        // the bin in front of the block fails the size filter too: keep looking in global memory
-                int64_t p = base - 2;
-                while (p >= 0 && (stop[p] - start[p]) > thresh) p--;
-                hasPrev = p >= 0; if (hasPrev) { cp = chr[p]; vp = count[p]; }
+#pragma unroll
+    for (int r = 0; r < CBLK / 1024; r++) {
+        const int li0 = r * 1024 + 4 * (int)threadIdx.x;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int li = li0 + e;
+            if (li >= L) continue;
+            const int s = li + CF_OFF;
+            bool keep = ra[r][e] != 0;
+            const int32_t c = rc[r][e];
+            if (keep && doOutlier) {
+                // nearest bins on either side that pass the size filter (RemoveOutliers runs on the list RemoveBigBins left, CanvasClean.cs:387-413)
+                bool hasPrev, hasNext; int32_t cp = -1, cq = -1; float vp = 0.0f, vq = 0.0f;
+                if (e > 0 && ra[r][e > 0 ? e - 1 : 0]) { hasPrev = true; cp = rc[r][e > 0 ? e - 1 : 0]; vp = rv[r][e > 0 ? e - 1 : 0]; }
+                else {
+                    int ps = s - 1;
+                    while (ps >= CF_OFF && !sA[ps]) ps--;
+                    if (ps >= CF_OFF || !hasLeft || sA[CF_OFF - 1]) { hasPrev = ps >= CF_OFF || hasLeft; if (hasPrev) { cp = sChr[ps]; vp = sCnt[ps]; } }
+                    else {                                    // the bin in front of the block fails the size filter too: keep looking in global memory
+                        int64_t p = base - 2;
+                        while (p >= 0 && (stop[p] - start[p]) > thresh) p--;
+                        hasPrev = p >= 0; if (hasPrev) { cp = chr[p]; vp = count[p]; }
+                    }
+                }
+                if (e < 3 && li + 1 < L && ra[r][e < 3 ? e + 1 : 3]) { hasNext = true; cq = rc[r][e < 3 ? e + 1 : 3]; vq = rv[r][e < 3 ? e + 1 : 3]; }
+                else {
+                    int qs = s + 1;
+                    while (qs < CF_OFF + L && !sA[qs]) qs++;
+                    if (qs < CF_OFF + L || !hasRight || sA[CF_OFF + L]) { hasNext = qs < CF_OFF + L || hasRight; if (hasNext) { cq = sChr[qs]; vq = sCnt[qs]; } }
+                    else {
+                        int64_t q = base + L + 1;
+                        while (q < n && (stop[q] - start[q]) > thresh) q++;
+                        hasNext = q < n; if (hasNext) { cq = chr[q]; vq = count[q]; }
+                    }
+                }
+                const bool prevSame = hasPrev && cp == c, nextSame = hasNext && cq == c;
+                if ((hasPrev && !prevSame) && (hasNext && !nextSame)) keep = false;
+                else {
+                    const float v = rv[r][e];
+                    keep = (prevSame && !sig_diff(v, vp)) || (nextSame && !sig_diff(v, vq)) || (!hasPrev && !hasNext);
+                }
             }
-            if (qs <= L || !hasRight || sA[L + 1]) { hasNext = qs <= L || hasRight; if (hasNext) { cq = sChr[qs]; vq = sCnt[qs]; } }
-            else {
-                int64_t q = base + L + 1;
-                while (q < n && (stop[q] - start[q]) > thresh) q++;
-                hasNext = q < n; if (hasNext) { cq = chr[q]; vq = count[q]; }
-            }
-            const bool prevSame = hasPrev && cp == c, nextSame = hasNext && cq == c;
-            if ((hasPrev && !prevSame) && (hasNext && !nextSame)) keep = false;
-            else {
-                const float v = sCnt[s];
-                keep = (prevSame && !sig_diff(v, vp)) || (nextSame && !sig_diff(v, vq)) || (!hasPrev && !hasNext);
+            packed |= (keep ? 1u : 0u) << (8 * e);
+            nKeep += keep;
+            if (keep) {                                       // out-of-range input is reported through D->bad and nothing is returned: clamped here so that no table is overrun
+                const int32_t cc = (uint32_t)c >= (uint32_t)nchr ? 0 : c;
+                const uint8_t au = cc < 256 ? sAuto[cc] : isAuto[cc];
+                atomicAdd(&lh[(au ? 0 : NGC) + ((uint32_t)rg[r][e] > 100u ? 100 : rg[r][e])], 1u);
             }
         }
-        flags[base + li] = keep;
-        nKeep += keep;
-        if (keep) {                                       // out-of-range input is reported through D->bad and nothing is returned: clamped here so that no table is overrun
-            const int32_t cc = (uint32_t)c >= (uint32_t)nchr ? 0 : c;
-            const uint8_t au = cc < 256 ? sAuto[cc] : isAuto[cc];
-            atomicAdd(&lh[(au ? 0 : NGC) + sGc[li]], 1u);
-        }
+        if (li0 + 3 < L) *reinterpret_cast<gptr<uint32_t>>(flags + base + li0) = packed;
+        else for (int e = 0; e < 4; e++) if (li0 + e < L) flags[base + li0 + e] = (uint8_t)((packed >> (8 * e)) & 1u);
     }
     nKeep = wave_reduce_add_u32(nKeep); nSize = wave_reduce_add_u32(nSize);
     if (lane_id() == 0) { sh[threadIdx.x >> 6] = nKeep; sh[4 + (threadIdx.x >> 6)] = nSize; }
     if (bad) D->bad = 1u;
     __syncthreads();
-    if (threadIdx.x == 0) { A.dBlk[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; A.dBlk[A.nb + 2 + blockIdx.x] = sh[4] + sh[5] + sh[6] + sh[7]; }      // (k_cf_scan_blocks sums the second column into nA)
+    if (threadIdx.x == 0) cf_st(&A.dBlk[blockIdx.x], (unsigned long long)(sh[0] + sh[1] + sh[2] + sh[3]) | ((unsigned long long)(sh[4] + sh[5] + sh[6] + sh[7]) << 32));
     if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&A.repl[(blockIdx.x % CF_HREP) * (2 * NGC) + threadIdx.x], lh[threadIdx.x]);
+    if (cf_arrive_last(A.tick + 1, (uint32_t)A.nb, &sLast)) cf_decide_gc(A);
 }
-// exclusive scan of the block counts: phase 0 over the blocks of the input (total -> nAB), phase 1 over the blocks of the nAB surviving bins (total -> nFinal)
-__global__ void __launch_bounds__(1024) k_cf_scan_blocks(const CfArgs* __restrict__ AA, int phase) {
-    CF_SAMPLE;
-    __shared__ uint32_t sh[17];
-    uint32_t* __restrict__ blockCnt = A.dBlk;
-    const int nblocks = phase == 0 ? A.nb : (int)(((int64_t)A.D->nAB + CBLK - 1) / CBLK);
-    uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? blockCnt[i] : 0;
-        const uint32_t inc = wave_inclusive_scan_u32(v);
-        const int w = threadIdx.x >> 6;
-        if (lane_id() == 63) sh[w] = inc;
-        __syncthreads();
-        if (threadIdx.x == 0) { uint32_t s = 0; for (int k = 0; k < 16; k++) { const uint32_t tt = sh[k]; sh[k] = s; s += tt; } sh[16] = s; }
-        __syncthreads();
-        if (i < nblocks) blockCnt[i] = carry + sh[w] + inc - v;
-        carry += sh[16];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { if (phase == 0) A.D->nAB = carry; else A.D->nFinal = carry; }
-    if (phase == 0) {                                     // bins after RemoveBigBins alone: the second column of k_cf_flags_ab's block counts
-        uint32_t v = 0;
-        for (int i = threadIdx.x; i < nblocks; i += 1024) v += blockCnt[A.nb + 2 + i];
-        v = wave_reduce_add_u32(v);
-        if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < 16; k++) t += sh[k]; A.D->nA = t; }
-    }
+// sum of the counts of the blocks in front of this one (every workgroup of a scatter kernel does this for itself: the counts are a few KB in L2, and the stage has no
+// scan kernel); lo32: the counts are the low halves of 64-bit records
+template <bool LO32, class T>
+__device__ __forceinline__ uint32_t cf_block_offset(const T* __restrict__ cnt, int nbefore, unsigned long long* sh16) {
+    unsigned long long mine = 0;
+    for (int j = threadIdx.x; j < nbefore; j += blockDim.x) mine += LO32 ? ((unsigned long long)cnt[j] & 0xFFFFFFFFull) : (unsigned long long)cnt[j];
+    return (uint32_t)cf_block_sum_u64(mine, sh16);
 }
-// the compaction itself: caller's arrays -> scratch SoA, and — the GC strip is decided by then (k_cf_dec_gc) — the order-preserving keys of the autosomal survivors with a kept GC
-// value, grouped by GC (order inside a bucket is irrelevant: only order statistics are taken).  CountDeviation is written by k_cf_local_sd (or never read).
+// the compaction itself: caller's arrays -> scratch SoA, and — the GC strip is decided by then — the order-preserving keys of the autosomal survivors with a kept GC
+// value, grouped by GC (order inside a bucket is irrelevant: only order statistics are taken).  All flags of the block are scanned first (one barrier), then every
+// load of the survivors is in flight at once.
 __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
-    __shared__ uint32_t sh[4];
+    __shared__ unsigned long long sh16[16];
+    __shared__ uint32_t shW[CBLK / 256][4];
     __shared__ uint32_t lcnt[NGC], lbase[NGC];
     __shared__ uint8_t sKeepGc[NGC];
     const int64_t n = A.n;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
     const gptr<const uint8_t> flags = as_global(A.dFlags), isAuto = as_global(A.isAuto);
-    const GSoa src = as_global(A.caller), dst = as_global(A.S1); const int nchr = A.nchr;
+    const GSoa src = as_global(A.caller); const GSoa1 dst = as_global(A.S1); const int nchr = A.nchr;
     CleanDev* __restrict__ D = A.D;
     const bool group = D->gcActive != 0;
     if (threadIdx.x < NGC) { lcnt[threadIdx.x] = 0; sKeepGc[threadIdx.x] = D->keepGc[threadIdx.x]; }
+    uint32_t f[CBLK / 256], inc[CBLK / 256];
+#pragma unroll
+    for (int j = 0; j < CBLK / 256; j++) { const int64_t i = base + j * 256 + threadIdx.x; f[j] = (i < n) ? flags[i] : 0; }
+    const uint32_t blockOff = cf_block_offset<true>(A.dBlk, (int)blockIdx.x, sh16);          // (its barriers also publish lcnt / sKeepGc)
+#pragma unroll
+    for (int j = 0; j < CBLK / 256; j++) { inc[j] = wave_inclusive_scan_u32(f[j]); if (lane_id() == 63) shW[j][threadIdx.x >> 6] = inc[j]; }
     __syncthreads();
-    uint32_t running = A.dBlk[blockIdx.x];
+    uint32_t running = blockOff;
     uint32_t myRank[CBLK / 256], myKey[CBLK / 256]; int myGc[CBLK / 256];
+    const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        const uint32_t f = (i < n) ? flags[i] : 0;
-        const uint32_t inc = wave_inclusive_scan_u32(f);
-        if (lane_id() == 63) sh[threadIdx.x >> 6] = inc;
-        __syncthreads();
         uint32_t woff = 0, tot = 0;
-        for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) woff += sh[k]; tot += sh[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t v = shW[j][k]; if (k < w) woff += v; tot += v; }
         myGc[j] = -1;
-        if (f) {
-            const uint32_t d = running + woff + inc - 1;
+        if (f[j]) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            const uint32_t d = running + woff + inc[j] - 1;
             // out-of-range input is reported through D->bad (k_cf_flags_ab) and nothing is returned; the scratch copy holds clamped values so that no later kernel indexes past a table
             const int32_t c0 = src.chr[i], g0 = src.gc[i];
             const int32_t g = (uint32_t)g0 > 100u ? 100 : g0, c = (uint32_t)c0 >= (uint32_t)nchr ? 0 : c0;
             const float v = src.count[i];
-            dst.chr[d] = c; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = g; dst.count[d] = v;
+            dst.chr[d] = c; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = (uint8_t)g; dst.count[d] = v;
             if (group && isAuto[c] && sKeepGc[g]) { myGc[j] = g; myKey[j] = key_of_float(v); myRank[j] = atomicAdd(&lcnt[g], 1u); }
         }
         running += tot;
-        __syncthreads();
     }
     if (!group) return;
+    __syncthreads();
     if (threadIdx.x < NGC && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&A.repl[CF_HREP * (2 * NGC) + (blockIdx.x % CF_HREP) * NGC + threadIdx.x], lcnt[threadIdx.x]);      // absolute position in keysG
     __syncthreads();
     const gptr<uint32_t> keysG = as_global(A.keysG);
@@ -405,45 +590,29 @@ __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict_
     for (int j = 0; j < CBLK / 256; j++) if (myGc[j] >= 0) keysG[lbase[myGc[j]] + myRank[j]] = myKey[j];
 }
 
-// ---------------------------------------------------------------- local SD (CanvasClean.cs:243-298)
-// (a variant that staged 5120 bins per workgroup through LDS for coalesced loads / stores was measured: 39 us against 27 us — the strided accesses hit in L2)
-// one thread per window of 20 count differences (Utilities.StandardDeviation, CanvasClean.cs:262-298) + the chromosome boundaries among the window's bins (the run records that
-// GetLocalStandardDeviationAverage's per-chromosome grouping needs) + CountDeviation = -1 (GenomicBin.cs:83) for the bins behind the last window
-__global__ void __launch_bounds__(256) k_cf_local_sd(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    if (!A.wantLsd) return;
-    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t nAB = (int64_t)A.D->nAB, Dn = nAB - 1, nW = Dn >= 1 ? (Dn - 1) / 20 : 0;
-    if (w > nW) return;
-    const int64_t lo = w * 20, hi = w < nW ? lo + 20 : nAB;             // thread nW takes the tail
-    const GSoa S1 = as_global(A.S1);
-    if (w < nW) local_sd_window(gptr<const float>(S1.count), w, as_global(A.dSd), S1.dev);
-    else for (int64_t i = lo; i < hi; i++) S1.dev[i] = -1.0;
-    const gptr<const int32_t> chr = S1.chr;
-    int32_t prev = lo > 0 ? chr[lo - 1] : -1;
-    for (int64_t i = lo; i < hi; i++) {
-        const int32_t c = chr[i];
-        if (i == 0 || c != prev) { const unsigned int k = atomicAdd(&A.D->nRunRec, 1u); if (k < 65536u) A.dPos[k] = (long long)((i << 20) | (long long)(c & 0xFFFFF)); }
-        prev = c;
-    }
+// ---------------------------------------------------------------- k_cf_hist_lsd: counting sweep of the grouped keys | window SDs (CanvasClean.cs:243-298)
+// Role 1, workgroups [0, nHist): one sweep of the grouped keys, counters per value in LDS, flushed into the bucket's row and the genome's.
+// Role 2, workgroups [nHist, nHist + nLsd): one thread per window of 20 count differences (Utilities.StandardDeviation, CanvasClean.cs:262-298) + the chromosome boundaries
+// among the window's bins (the run records that GetLocalStandardDeviationAverage's per-chromosome grouping needs); the last of these workgroups sorts the records and
+// derives the runs of windows per chromosome exactly as local_sd_begin does on the host.  Neither role reads what the other writes.
+__device__ __forceinline__ void cq_count_key(uint32_t key, long long lo, uint32_t* lw, uint32_t& below, uint32_t& bad) {
+    long long k;
+    if (!cq_key(float_of_key(key), k)) { bad = 1; return; }
+    if (k < lo) below++;
+    else if (k - lo < CQW) atomicAdd(&lw[k - lo], 1u);
 }
-// one workgroup: sorts the (position << 20 | chromosome) records of k_cf_local_sd, derives the runs of windows per chromosome exactly as local_sd_begin does on the host
-__global__ void __launch_bounds__(1024) k_cf_runs_build(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ long long s[CF_MAXRUN];
+__device__ __forceinline__ void cf_runs_build(const CfArgs& A, long long* s /* [CF_MAXRUN] */, long long* raw /* [CF_MAXRUN] */) {
     CleanDev* __restrict__ D = A.D; const long long* __restrict__ recs = A.dPos; int64_t* __restrict__ runStart = A.dRunStart;
     const unsigned long long nAB = D->nAB;
     const int have = A.wantLsd && nAB >= 50000ull;                         // CanvasClean.cs:483-486
     if (threadIdx.x == 0) D->haveLocalSd = have;
     if (!have) { if (threadIdx.x == 0) D->nruns = 0; return; }
-    const unsigned int nb = D->nRunRec;
+    const unsigned int nb = cf_ld(&D->nRunRec);
     if (nb > CF_MAXRUN) { if (threadIdx.x == 0) { D->fallback = 1u; D->nruns = 0; } return; }
     const int t = threadIdx.x;
-    __shared__ long long raw[CF_MAXRUN];
-    raw[t] = t < (int)nb ? recs[t] : 0x7FFFFFFFFFFFFFFFll;
+    raw[t] = t < (int)nb ? (long long)cf_ld(reinterpret_cast<const unsigned long long*>(recs + t)) : 0x7FFFFFFFFFFFFFFFll;
     __syncthreads();
-    // rank sort: every record counts the records in front of it (independent broadcast reads of LDS).  A one-thread insertion sort of the ~24 records of a sorted
-    // file was a chain of dependent LDS accesses (10 of the kernel's 17 us), the bitonic network 55 barriers.
+    // rank sort: every record counts the records in front of it (independent broadcast reads of LDS)
     if (t < (int)nb) {
         const long long mine = raw[t];
         int rank = 0;
@@ -467,59 +636,431 @@ __global__ void __launch_bounds__(1024) k_cf_runs_build(const CfArgs* __restrict
         D->nruns = nruns;
     }
 }
-__global__ void __launch_bounds__(1024) k_cf_run_mad(const CfArgs* __restrict__ AA) {
+__global__ void __launch_bounds__(1024) k_cf_hist_lsd(const CfArgs* __restrict__ AA, int nHist, int nLsd) {
     CF_SAMPLE;
+    __shared__ __attribute__((aligned(16))) uint32_t lw[CQW];       // counters of the sweep role; scratch of the window role's last workgroup (its first 16 KB)
+    int* const sLast = reinterpret_cast<int*>(&lw[CQW - 1]);
+    if ((int)blockIdx.x < nHist) {
+        CfCq* __restrict__ C = A.cq;
+        if (blockIdx.x >= C->ntiles) return;
+        const SelTile T = A.cqTiles[blockIdx.x];
+        const long long lo = C->lo;
+        for (int i = threadIdx.x; i < CQW / 4; i += 1024) reinterpret_cast<uint4*>(lw)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        const gptr<const uint32_t> keys = as_global(A.keysG);
+        uint32_t below = 0, bad = 0;
+        // the tile's 16-byte aligned middle with 16-byte loads (all of a thread's loads in flight), its unaligned ends key by key
+        const int64_t a0 = min<int64_t>((T.begin + 3) & ~(int64_t)3, T.end), nv = (T.end - a0) / 4, a1 = a0 + 4 * nv;
+        uint4 kk[CQ_TILE / 4096];
+#pragma unroll
+        for (int u = 0; u < CQ_TILE / 4096; u++) { const int64_t v = (int64_t)u * 1024 + threadIdx.x; kk[u] = v < nv ? gload_uint4(keys + a0 + 4 * v) : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < CQ_TILE / 4096; u++) {
+            if ((int64_t)u * 1024 + threadIdx.x >= nv) break;
+            cq_count_key(kk[u].x, lo, lw, below, bad); cq_count_key(kk[u].y, lo, lw, below, bad); cq_count_key(kk[u].z, lo, lw, below, bad); cq_count_key(kk[u].w, lo, lw, below, bad);
+        }
+        if (threadIdx.x < 8) {
+            const int64_t i = threadIdx.x < 4 ? T.begin + threadIdx.x : a1 + (threadIdx.x - 4);
+            if (threadIdx.x < 4 ? i < a0 : i < T.end) cq_count_key(keys[i], lo, lw, below, bad);
+        }
+        below = wave_reduce_add_u32(below);
+        if ((threadIdx.x & 63) == 0 && below) { atomicAdd(&C->below[T.seg], below); atomicAdd(&C->below[NGC], below); }
+        if (bad) C->bad = 1u;
+        __syncthreads();
+        uint32_t* __restrict__ row = A.cqHist + (size_t)T.seg * CQW; uint32_t* __restrict__ all = A.cqHist + (size_t)NGC * CQW;
+        for (int i = threadIdx.x; i < CQW; i += 1024) { const uint32_t v = lw[i]; if (v) { atomicAdd(&row[i], v); atomicAdd(&all[i], v); } }
+        return;
+    }
+    // ---- window role
     if (!A.wantLsd) return;
-    run_mad_body(A.dSd, A.dRunStart, A.dRunMad, &A.D->nruns);
-}
-__global__ void k_cf_lsd_avg(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    if (threadIdx.x || blockIdx.x) return;
-    CleanDev* D = A.D;
-    if (!D->haveLocalSd) { D->localSd = -1.0; return; }
-    double s = 0;
-    for (int r = 0; r < D->nruns; r++) s += A.dRunMad[r];                  // List<double>.Average(): sequential sum / count
-    D->localSd = s / (double)D->nruns;
+    const int64_t w = (int64_t)((int)blockIdx.x - nHist) * 1024 + threadIdx.x;
+    const int64_t nAB = (int64_t)A.D->nAB, Dn = nAB - 1, nW = Dn >= 1 ? (Dn - 1) / 20 : 0;
+    if (w <= nW) {
+        const int64_t lo = w * 20, hi = w < nW ? lo + 20 : nAB;         // thread nW takes the tail (bins behind the last window: CountDeviation stays -1, GenomicBin.cs:83)
+        const GSoa1 S1 = as_global(A.S1);
+        if (w < nW) {
+            // Utilities.StandardDeviation(double[], start, end) (Utilities.cs:246-262): sequential double arithmetic
+            const gptr<const float> count = S1.count;
+            double d[20];
+            float prev = count[lo];
+#pragma unroll
+            for (int k = 0; k < 20; k++) { const float nx = count[lo + k + 1]; d[k] = (double)(nx - prev); prev = nx; }
+            double sum = 0;
+#pragma unroll
+            for (int k = 0; k < 20; k++) sum += d[k];
+            const double mu = sum / 20;
+            double s2 = 0;
+#pragma unroll
+            for (int k = 0; k < 20; k++) { const double df = d[k] - mu; s2 += df * df; }
+            as_global(A.dSd)[w] = sqrt(s2 / 19);
+        }
+        const gptr<const int32_t> chr = S1.chr;
+        int32_t prevC = lo > 0 ? chr[lo - 1] : -1;
+        for (int64_t i = lo; i < hi; i++) {
+            const int32_t c = chr[i];
+            if (i == 0 || c != prevC) { const unsigned int k = atomicAdd(&A.D->nRunRec, 1u); if (k < 65536u) cf_st(reinterpret_cast<unsigned long long*>(A.dPos + k), (unsigned long long)((i << 20) | (long long)(c & 0xFFFFF))); }
+            prevC = c;
+        }
+    }
+    if (cf_arrive_last(A.tick + 2, (uint32_t)nLsd, sLast)) cf_runs_build(A, reinterpret_cast<long long*>(lw), reinterpret_cast<long long*>(lw) + CF_MAXRUN);
 }
 
-// ---------------------------------------------------------------- RemoveBinsWithExtremeGC decision (CanvasClean.cs:207-237) and what follows from it
-__global__ void __launch_bounds__(128) k_cf_dec_gc(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ uint32_t shA[2], shB[2], shC[2], shD[2];
-    CleanDev* __restrict__ D = A.D; const uint32_t flags = A.flags; const int minBinsPerGc = A.minBinsPerGc;
-    const int t = threadIdx.x;
-    const long long nAB = (long long)D->nAB;
-    uint32_t hA = 0, hO = 0;
-    if (t < NGC) for (int r = 0; r < CF_HREP; r++) { hA += A.repl[r * (2 * NGC) + t]; hO += A.repl[r * (2 * NGC) + NGC + t]; }
-    if (t < NGC) { D->hist[t] = hA; D->hist[NGC + t] = hO; }
-    // the counts are integers below 2^32 and there are 101 of them: their double sum (CanvasClean.cs:219-222) is exact in any order
-    uint32_t totalA; (void)cf_excl_scan128(hA, shA, &totalA);
-    const bool consider = (flags & CANVAS_CLEAN_GCNORM) && nAB > 0;
-    const int averageCountPerGC = max(minBinsPerGc, (int)((double)totalA / NGC));
-    const int threshold = min(100, averageCountPerGC);
-    bool kp = true;
-    if (consider && t < NGC) kp = (int)hA >= threshold;
-    // bins of any chromosome in the kept buckets (each term < 2^32, 101 terms: the 64-bit total is split over two 32-bit scans of the halves)
-    const unsigned long long mine = (consider && t < NGC && kp) ? (unsigned long long)hA + (unsigned long long)hO : 0ull;
-    uint32_t totLo, totHi; (void)cf_excl_scan128((uint32_t)(mine & 0xFFFFu), shB, &totLo); (void)cf_excl_scan128((uint32_t)(mine >> 16), shC, &totHi);
-    const long long kept = (long long)totLo + ((long long)totHi << 16);
-    const bool active = consider && kept > 0;                               // kept <= 0: "proceed without GC correction" (CanvasClean.cs:500-505)
-    if (!active) kp = true;
-    uint32_t totalKept; const uint32_t so = cf_excl_scan128((active && t < NGC && kp) ? hA : 0u, shD, &totalKept);
-    if (t < NGC) {
-        D->keepGc[t] = kp ? 1 : 0; D->medians[t] = 0.0; D->segOff[t] = active ? so : 0u;
-        // the bucket's stretch of the grouped keys is filled replica by replica (the order inside a bucket is irrelevant: only order statistics are taken from it)
-        uint32_t at = so;
-        for (int r = 0; r < CF_HREP; r++) { A.repl[CF_HREP * (2 * NGC) + r * NGC + t] = at; at += A.repl[r * (2 * NGC) + t]; }
+// ---------------------------------------------------------------- k_cf_pick_mad: order statistics from the counters | median and MAD of the window SDs per chromosome run
+// Exact order statistics r0 <= r1 of up to MAD_REG x 1024 values held in registers (or streamed from memory), inside one 1024-thread workgroup.  The keys of a run share
+// their leading bits (window SDs of one chromosome lie within a few binades), so (1) an AND / OR reduction finds the common prefix, (2) 8-bit radix passes run below it
+// only until both ranks have at most MAD_CAND candidates left — two passes for 20 000 values — and (3) the candidates are ranked against each other in LDS.
+// (Round 2 ran eight full passes per select, the first of them with all 1024 threads adding to one or two LDS counters: 89 us for chr1.)
+#define MAD_REG 24
+#define MAD_CAND 256
+struct MadShared { uint32_t sH[2][256]; unsigned long long sPre[2], sK[2], sRed[2][16], sCand[2][MAD_CAND]; uint32_t sCnt[2], sNc[2]; };
+template <class KeyFn>
+__device__ __forceinline__ void wg_select2_fast(KeyFn forEachKey /* (callback(key)) */, int64_t cnt, unsigned long long rank0, unsigned long long rank1, MadShared& S, unsigned long long* out /* [2], thread 0 */) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    // (1) common prefix
+    unsigned long long a = ~0ull, o = 0ull;
+    forEachKey([&](unsigned long long key) { a &= key; o |= key; });
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
+    __syncthreads();
+    if (l == 0) { S.sRed[0][w] = a; S.sRed[1][w] = o; }
+    __syncthreads();
+    a = ~0ull; o = 0ull;
+    for (int k = 0; k < 16; k++) { a &= S.sRed[0][k]; o |= S.sRed[1][k]; }
+    const unsigned long long diff = a ^ o;
+    if (diff == 0ull) { if (tid == 0) { out[0] = a; out[1] = a; } return; }          // all keys equal
+    const int sh0 = __builtin_clzll(diff);                                             // keys' = key << sh0: order kept among keys that share the prefix
+    if (tid == 0) { S.sPre[0] = 0; S.sPre[1] = 0; S.sK[0] = rank0; S.sK[1] = rank1; S.sCnt[0] = S.sCnt[1] = (uint32_t)min<int64_t>(cnt, 0xFFFFFFFFll); }
+    __syncthreads();
+    int passes = 0;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (S.sCnt[0] <= MAD_CAND && S.sCnt[1] <= MAD_CAND) break;
+        for (int i = tid; i < 512; i += 1024) S.sH[i >> 8][i & 255] = 0;
+        __syncthreads();
+        const unsigned long long p0 = S.sPre[0], p1 = S.sPre[1];
+        const bool same = p0 == p1;
+        forEachKey([&](unsigned long long key0) {
+            const unsigned long long key = key0 << sh0;
+            const uint32_t dgt = (uint32_t)(key >> shift) & 255u;
+            const unsigned long long hiPart = shift == 56 ? 0ull : key >> (shift + 8);
+            if (hiPart == p0) atomicAdd(&S.sH[0][dgt], 1u);
+            if (!same && hiPart == p1) atomicAdd(&S.sH[1][dgt], 1u);
+        });
+        __syncthreads();
+        if (w < 2) {
+            const uint32_t* h = S.sH[same ? 0 : w];
+            const uint32_t c0 = h[4 * l], c1 = h[4 * l + 1], c2 = h[4 * l + 2], c3 = h[4 * l + 3];
+            const uint32_t sum = c0 + c1 + c2 + c3;
+            const uint32_t inc = wave_inclusive_scan_u32(sum), ex = inc - sum;
+            const unsigned long long k = S.sK[w];
+            if (k >= ex && k < inc) {
+                uint32_t r = (uint32_t)(k - ex), dgt, c;
+                if (r < c0) { dgt = 0; c = c0; } else if (r < c0 + c1) { dgt = 1; r -= c0; c = c1; } else if (r < c0 + c1 + c2) { dgt = 2; r -= c0 + c1; c = c2; } else { dgt = 3; r -= c0 + c1 + c2; c = c3; }
+                S.sPre[w] = (S.sPre[w] << 8) | (unsigned long long)(4 * l + dgt);
+                S.sK[w] = r; S.sCnt[w] = c;
+            }
+        }
+        passes++;
+        __syncthreads();
     }
-    if (t == 0) {
-        const long long sKept = active ? kept : nAB;
-        D->segOff[NGC] = active ? totalKept : 0u; D->kept = sKept; D->gcActive = active ? 1 : 0; D->changed = 0;
-        // NormalizeVarianceByGC runs for whole-genome samples only (CanvasClean.cs:512-519); the host enqueues its kernels when the INPUT has more than 500000 bins
-        const bool haveLsd = A.wantLsd && nAB >= 50000;                       // what k_cf_runs_build will store in haveLocalSd (CanvasClean.cs:483-486)
-        D->varActive = (active && haveLsd && sKept > 500000 && A.n > 500000) ? 1 : 0;
+    if (passes == 8) {                                                                 // every bit resolved (ties heavier than MAD_CAND): the key is the prefix
+        if (tid == 0) {
+            const int hb = 63 - sh0; const unsigned long long lowmask = hb == 63 ? ~0ull : ((1ull << (hb + 1)) - 1ull);
+            out[0] = (a & ~lowmask) | (S.sPre[0] >> sh0); out[1] = (a & ~lowmask) | (S.sPre[1] >> sh0);
+        }
+        return;
+    }
+    // (3) the candidates of both ranks, ranked against each other
+    if (tid == 0) { S.sNc[0] = 0; S.sNc[1] = 0; }
+    __syncthreads();
+    const unsigned long long p0 = S.sPre[0], p1 = S.sPre[1];
+    const bool same = p0 == p1;
+    const int top = 64 - 8 * passes;
+    forEachKey([&](unsigned long long key0) {
+        const unsigned long long hiPart = passes == 0 ? 0ull : (key0 << sh0) >> top;
+        if (hiPart == p0) { const uint32_t at = atomicAdd(&S.sNc[0], 1u); if (at < MAD_CAND) S.sCand[0][at] = key0; }
+        if (!same && hiPart == p1) { const uint32_t at = atomicAdd(&S.sNc[1], 1u); if (at < MAD_CAND) S.sCand[1][at] = key0; }
+    });
+    __syncthreads();
+    for (int q = 0; q < 2; q++) {
+        const int src = same ? 0 : q;
+        const uint32_t nc = min(S.sNc[src], (uint32_t)MAD_CAND);
+        if ((uint32_t)tid < nc) {
+            const unsigned long long mine = S.sCand[src][tid];
+            uint32_t less = 0;
+            for (uint32_t j = 0; j < nc; j++) { const unsigned long long ok = S.sCand[src][j]; less += (ok < mine || (ok == mine && j < (uint32_t)tid)) ? 1u : 0u; }
+            if ((unsigned long long)less == S.sK[q]) out[q] = mine;
+        }
     }
 }
+// median and MAD of the window SDs of chromosome run r (CanvasClean.cs:243-258, Utilities.cs Median / Mad)
+template <bool REG>
+__device__ __forceinline__ void cf_run_mad(const gptr<const double> sd, int64_t lo, int64_t hi, MadShared& S, unsigned long long* sOut /* LDS [2] */, double* outMad) {
+    const int64_t cnt = hi - lo;
+    const unsigned long long r1 = (unsigned long long)(cnt / 2), r0 = (cnt % 2) ? r1 : r1 - 1;
+    double v[MAD_REG];
+    // register flavour: thread t holds the MAD_REG consecutive values from lo + t * MAD_REG on (one address, immediate offsets; the order of the values is irrelevant)
+    const int64_t mine0 = lo + (int64_t)threadIdx.x * MAD_REG;
+    const int nMine = REG ? (int)max<int64_t>(0, min<int64_t>(MAD_REG, hi - mine0)) : 0;
+    if (REG) {
+        const gptr<const double> p = sd + mine0;
+#pragma unroll
+        for (int k = 0; k < MAD_REG; k++) v[k] = k < nMine ? p[k] : 0.0;
+    }
+    auto sweep = [&](auto&& fn, auto&& body) {
+        if (REG) {
+#pragma unroll
+            for (int k = 0; k < MAD_REG; k++) { if (k < nMine) body(fn(v[k])); }
+        } else for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) body(fn(sd[i]));
+    };
+    wg_select2_fast([&](auto&& body) { sweep([](double x) { return key_of_double(x); }, body); }, cnt, r0, r1, S, sOut);
+    __syncthreads();
+    const double median = (cnt % 2) ? double_of_key(sOut[1]) : (double_of_key(sOut[0]) + double_of_key(sOut[1])) / 2;
+    __syncthreads();
+    wg_select2_fast([&](auto&& body) { sweep([median](double x) { return key_of_double(fabs(x - median)); }, body); }, cnt, r0, r1, S, sOut);
+    __syncthreads();
+    if (threadIdx.x == 0) cf_st_f64(outMad, (cnt % 2) ? double_of_key(sOut[1]) : (double_of_key(sOut[0]) + double_of_key(sOut[1])) / 2);
+    __syncthreads();
+}
+// NormalizeByGC as a function of k for bucket g (what k_cf_xform_gc does to a key)
+__device__ __forceinline__ float cq_normalised(long long k, double median, double globalMedian) {
+    const float x = cq_value(k);
+    return median > 0 ? (float)(globalMedian * (double)x / median) : x;
+}
+// The genome's quartiles of the normalised counts (CanvasClean.cs:34-66) by counting once more.  The items are the counters: value = the normalised count of the slot,
+// weight = the counter.  The normalised values are not on a grid, but v -> floor((v - L0) * 100) is non-decreasing, so one weighted count over CQW bins of 0.01 around the
+// genome's median locates, for every rank, the bin that holds it and the rank inside that bin; the bin's few candidates — per bucket the slots whose value
+// falls into it, found by bisection because the value is monotone in the slot — are then ordered exactly by their float keys.  Keys below / above a
+// bucket's window count as smaller / larger than everything, which the decision checks against the answers.
+__device__ __forceinline__ double cq_nbin_origin(double globalMedian) { return globalMedian - (double)CQW / 200.0; }
+__device__ __forceinline__ long long cq_nbin(float v, double origin) { return (long long)floor(((double)v - origin) * 100.0); }
+#define CQ_NCAND 1024        // candidates of one bin (a bucket contributes about median / globalMedian slots per bin)
+// ranks[0 .. nr) of a row of CQW counters held 16 consecutive per thread -> sK[q] = the slot that holds rank q.  False (in every thread) when a rank lies outside the window.
+__device__ __forceinline__ bool cq_pick_ranks(const uint32_t (&c)[16], const int64_t* ranks, int nr, int64_t below, uint32_t* swave, long long* sK, int* sFail, uint32_t* inWinOut) {
+    const int t = threadIdx.x;
+    uint32_t s = 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) s += c[u];
+    const uint32_t inc = wave_inclusive_scan_u32(s);
+    __syncthreads();
+    if ((t & 63) == 63) swave[t >> 6] = inc;
+    if (t == 0) *sFail = 0;
+    __syncthreads();
+    uint32_t woff = 0, inWin = 0;
+    for (int w = 0; w < 16; w++) { if (w < (t >> 6)) woff += swave[w]; inWin += swave[w]; }
+    const uint32_t ex = woff + inc - s;
+    for (int q = 0; q < nr; q++) {
+        const int64_t r = ranks[q] - below;
+        if (r < 0 || r >= (int64_t)inWin) { if (t == 0) *sFail = 1; continue; }
+        if (r >= (int64_t)ex && r < (int64_t)ex + s) {
+            uint32_t left = (uint32_t)(r - ex); int u = 0; bool found = false;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { if (!found) { if (left < c[k]) { u = k; found = true; } else left -= c[k]; } }       // (no dynamic index into the register array)
+            sK[q] = 16 * t + u;
+        }
+    }
+    __syncthreads();
+    *inWinOut = inWin;
+    return *sFail == 0;
+}
+__device__ __forceinline__ void cq_load_row(const uint32_t* __restrict__ rowBase, uint32_t (&c)[16]) {
+    const uint4* __restrict__ row = reinterpret_cast<const uint4*>(rowBase) + 4 * threadIdx.x;     // 16 consecutive counters per thread
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const uint4 v = row[u]; c[4 * u] = v.x; c[4 * u + 1] = v.y; c[4 * u + 2] = v.z; c[4 * u + 3] = v.w; }
+}
+// the last workgroup of the pick role: the genome's quartiles of the normalised counts from the weighted count, then the NormalizeVarianceByGC decision (CanvasClean.cs:34-83)
+__device__ __forceinline__ void cf_resolve_var(const CfArgs& A, uint32_t* lw, uint32_t* swave) {
+    __shared__ int sBin[6], sFailR[6], sig, sFailD;
+    __shared__ uint32_t sR[6], sKeyOut[6];
+    __shared__ unsigned int sN[6];
+    CfSel* __restrict__ P = A.P + 2; CleanDev* __restrict__ D = A.D; const CfCq* __restrict__ C = A.cq;
+    const int t = threadIdx.x;
+    const int nq = min((int)P->hdr[1], 6);
+    // ---- the bin and the rank inside it, for every rank: one scan of the weighted count
+    uint32_t c[16];
+    {
+        const unsigned long long* __restrict__ row = reinterpret_cast<const unsigned long long*>(A.cqHist + (size_t)(NGC + 1) * CQW) + 8 * t;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const unsigned long long q = cf_ld(row + u); c[2 * u] = (uint32_t)q; c[2 * u + 1] = (uint32_t)(q >> 32); }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) s += c[u];
+    const uint32_t inc = wave_inclusive_scan_u32(s);
+    __syncthreads();
+    if ((t & 63) == 63) swave[t >> 6] = inc;
+    if (t < 6) { sBin[t] = -1; sN[t] = 0; sFailR[t] = 0; sKeyOut[t] = 0u; }
+    if (t == 0) { sig = 0; sFailD = 0; }
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < (t >> 6); w++) woff += swave[w];
+    const uint32_t ex = woff + inc - s;
+    const long long nbelow = (long long)cf_ld(&C->nbelow);
+    for (int q = 0; q < nq; q++) {
+        const long long r = (long long)P->qk[q] - nbelow;
+        if (r >= (long long)ex && r < (long long)ex + s) {
+            uint32_t left = (uint32_t)(r - ex); int u = 0; bool found = false;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { if (!found) { if (left < c[k]) { u = k; found = true; } else left -= c[k]; } }
+            sBin[q] = 16 * t + u; sR[q] = left;
+        }
+    }
+    __syncthreads();
+    // ---- the candidates of every bin: per bucket the slots whose normalised value falls into it (keys at lw[q * 2048 + i], weights at lw[q * 2048 + 1024 + i])
+    const double globalMedian = cf_ld_f64(&D->globalMedian);
+    const long long lo = C->lo;
+    const int64_t cntT = t < NGC ? (int64_t)D->segOff[t + 1] - (int64_t)D->segOff[t] : 0;
+    const double medianT = (t < NGC && cntT > 0) ? cf_ld_f64(&D->medians[t]) : 0.0;
+    if (t < NGC && cntT > 0) {
+        const double origin = cq_nbin_origin(globalMedian);
+        for (int q = 0; q < nq; q++) {
+            const int bin = sBin[q];
+            if (bin < 0) continue;
+            int a = 0, b = CQW;                           // first slot whose value falls into bin `bin` or a later one
+            while (a < b) { const int mid = (a + b) >> 1; if (cq_nbin(cq_normalised(lo + mid, medianT, globalMedian), origin) < (long long)bin) a = mid + 1; else b = mid; }
+            for (int j = a; j < CQW; j++) {
+                const float v = cq_normalised(lo + j, medianT, globalMedian);
+                if (cq_nbin(v, origin) != (long long)bin) break;
+                const uint32_t w = A.cqHist[(size_t)t * CQW + j];
+                if (w) { const unsigned int at = atomicAdd(&sN[q], 1u); if (at < CQ_NCAND) { lw[q * 2048 + at] = key_of_float(v); lw[q * 2048 + 1024 + at] = w; } else sFailR[q] = 1; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < nq; q++) {
+        if (sBin[q] < 0 || sFailR[q]) continue;          // the rank lies outside the bins, or too many candidates: key 0 makes the decision give the sample up
+        const unsigned int n = sN[q];
+        const uint32_t rq = sR[q];
+        if ((unsigned int)t < n) {                        // the candidate whose weights [less, less + w) cover the rank inside the bin
+            const uint32_t key = lw[q * 2048 + t];
+            unsigned long long less = 0;
+            for (unsigned int o = 0; o < n; o++) { const uint32_t ko = lw[q * 2048 + o]; if (ko < key || (ko == key && o < (unsigned int)t)) less += lw[q * 2048 + 1024 + o]; }
+            if ((unsigned long long)rq >= less && (unsigned long long)rq < less + lw[q * 2048 + 1024 + t]) sKeyOut[q] = key;
+        }
+    }
+    __syncthreads();
+    if (t < nq) P->qprefix[t] = (unsigned long long)sKeyOut[t];
+    // ---- NormalizeVarianceByGC decision from the buckets' k statistics and the genome's keys
+    const int64_t total = (int64_t)D->segOff[NGC];
+    const QuartIdx gi = quartile_indices(total);
+    float gv[6]; uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (int k = 0; k < gi.n; k++) { const uint32_t key = sKeyOut[k]; gv[k] = float_of_key(key); kmin = min(kmin, key); kmax = max(kmax, key); }
+    float g1, g2, g3;
+    quartiles_from_values(total, gv, g1, g2, g3);
+    const float globalIQR = g3 - g1;
+    if (t < NGC) {
+        float liqr = -1.0f, med = -1.0f;
+        if (cntT > 0) {
+            const QuartIdx qi = quartile_indices(cntT);
+            float v[6];
+            for (int k = 0; k < qi.n; k++) v[k] = cq_normalised((long long)cf_ld(&C->kq[t][k]), medianT, globalMedian);
+            float q1, q2, q3; quartiles_from_values(cntT, v, q1, q2, q3);
+            med = q2; liqr = q3 - q1;
+            // the genome's answers are right only if every key that was left out of this bucket's window lies on the side it was counted on
+            const uint32_t below = C->below[t], above = (uint32_t)(cntT - (int64_t)below - (int64_t)cf_ld(&C->inWin[t]));
+            if (below && key_of_float(cq_normalised(lo, medianT, globalMedian)) > kmin) atomicOr(&sFailD, 1);
+            if (above && key_of_float(cq_normalised(lo + CQW - 1, medianT, globalMedian)) < kmax) atomicOr(&sFailD, 1);
+        }
+        D->tab.localIQR[t] = liqr; D->tab.med[t] = med;
+        if (t >= 10 && t < 90 && globalIQR * 2.0f < liqr) atomicAdd(&sig, 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (kmin == 0u || kmax == 0xFFFFFFFFu || sFailD) { A.cq->fail = 1u; D->cqFail = 1; D->fallback = 1u; D->changed = 0; return; }
+        D->tab.globalIQR = globalIQR; D->changed = sig > 0 ? 1 : 0;
+    }
+}
+__global__ void __launch_bounds__(1024) k_cf_pick_mad(const CfArgs* __restrict__ AA, int nPick) {
+    CF_SAMPLE;
+    __shared__ __attribute__((aligned(16))) uint32_t lw[CQW];       // pick role: the weighted count, then the last workgroup's candidate lists; run role: MadShared
+    MadShared& S = *reinterpret_cast<MadShared*>(lw);
+    __shared__ uint32_t swave[16];
+    __shared__ long long sK[8];
+    __shared__ unsigned long long sOut[2];
+    __shared__ int sFail, sLast;
+    CleanDev* __restrict__ D = A.D;
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x < nPick) {
+        // ---- workgroup g: the order statistics of bucket g (g == NGC: of the genome) from its counters — the NormalizeByGC medians (CanvasClean.cs:170-189) and, for the
+        // variance normalisation, the bucket's quartile statistics as k (a bucket is scaled by one factor, so they keep their ranks) and its share of the weighted count
+        CfCq* __restrict__ C = A.cq;
+        if (!A.useCq || A.P[1].hdr[1] == 0) return;
+        const int g = blockIdx.x;
+        if (g == 0 && t == 0 && C->bad) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; }
+        const bool var = D->varActive != 0;
+        const int64_t total = (int64_t)D->segOff[NGC];
+        const int64_t cnt = g < NGC ? (int64_t)D->segOff[g + 1] - (int64_t)D->segOff[g] : total;
+        const long long lo = C->lo;
+        bool ok = true; double globalMedian = 0.0;
+        if ((g == NGC || (var && cnt > 0)) && total > 0) {              // the genome's median (every workgroup that goes on to the weighted count takes it for itself)
+            uint32_t cG[16]; cq_load_row(A.cqHist + (size_t)NGC * CQW, cG);
+            int64_t ranks[2]; int nr = 0;
+            if (total % 2) ranks[nr++] = total / 2; else { ranks[nr++] = total / 2 - 1; ranks[nr++] = total / 2; }
+            uint32_t inWin;
+            ok = cq_pick_ranks(cG, ranks, nr, (int64_t)C->below[NGC], swave, sK, &sFail, &inWin);
+            if (ok) globalMedian = nr == 1 ? (double)cq_value(lo + sK[0]) : (double)median_from_two(cq_value(lo + sK[0]), cq_value(lo + sK[1]));
+            if (g == NGC && t == 0) {
+                cf_st(&C->inWin[NGC], inWin);
+                if (!ok) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; } else cf_st_f64(&D->globalMedian, globalMedian);
+            }
+        }
+        if (g < NGC && cnt > 0) {
+            uint32_t c[16]; cq_load_row(A.cqHist + (size_t)g * CQW, c);
+            int64_t ranks[8]; int nr = 0;
+            if (cnt % 2) ranks[nr++] = cnt / 2; else { ranks[nr++] = cnt / 2 - 1; ranks[nr++] = cnt / 2; }
+            const int nMed = nr;
+            if (var) { const QuartIdx qi = quartile_indices(cnt); for (int k = 0; k < qi.n; k++) ranks[nr++] = qi.idx[k]; }
+            uint32_t inWin;
+            const unsigned long long belowG = (unsigned long long)C->below[g];
+            const bool okOwn = cq_pick_ranks(c, ranks, nr, (int64_t)belowG, swave, sK, &sFail, &inWin);
+            double median = 0.0;
+            if (okOwn) median = nMed == 1 ? (double)cq_value(lo + sK[0]) : (double)median_from_two(cq_value(lo + sK[0]), cq_value(lo + sK[1]));
+            if (t == 0) {
+                cf_st(&C->inWin[g], inWin);
+                if (!okOwn) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; }
+                else { cf_st_f64(&D->medians[g], median); for (int k = nMed; k < nr; k++) cf_st(&C->kq[g][k - nMed], (int32_t)(lo + sK[k])); }
+            }
+            if (var && ok && okOwn) {
+                // this bucket's share of the weighted count: value = the normalised count of a slot, weight = its counter
+                for (int i = t; i < CQW / 4; i += 1024) reinterpret_cast<uint4*>(lw)[i] = make_uint4(0u, 0u, 0u, 0u);
+                __syncthreads();
+                const double origin = cq_nbin_origin(globalMedian);
+                unsigned long long below = t == 0 ? belowG : 0ull;
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const uint32_t w = c[u];
+                    if (!w) continue;
+                    const long long b = cq_nbin(cq_normalised(lo + 16 * t + u, median, globalMedian), origin);
+                    if (b < 0) below += w; else if (b < CQW) atomicAdd(&lw[b], w);
+                }
+                below = wave_reduce_add_u64(below);
+                if ((t & 63) == 0 && below) atomicAdd(&C->nbelow, below);
+                __syncthreads();
+                uint32_t* __restrict__ all = A.cqHist + (size_t)(NGC + 1) * CQW;
+                for (int i = t; i < CQW; i += 1024) { const uint32_t v = lw[i]; if (v) atomicAdd(&all[i], v); }
+            }
+        }
+        if (!var) return;
+        if (cf_arrive_last(A.tick + 3, (uint32_t)nPick, &sLast)) cf_resolve_var(A, lw, swave);
+        return;
+    }
+    // ---- run role: median and MAD of the window SDs of runs b, b + CF_MADB, ... (Utilities.Mad per chromosome, CanvasClean.cs:243-258); the last workgroup averages them
+    if (!A.wantLsd) return;
+    const int b = (int)blockIdx.x - nPick, nruns = D->nruns;
+    const gptr<const double> sd = as_global(A.dSd);
+    for (int r = b; r < nruns; r += CF_MADB) {
+        const int64_t lo = A.dRunStart[r], hi = A.dRunStart[r + 1], cnt = hi - lo;
+        if (cnt <= 0) { if (t == 0) cf_st_f64(&A.dRunMad[r], 0.0); }
+        else if (cnt <= (int64_t)MAD_REG * 1024) cf_run_mad<true>(sd, lo, hi, S, sOut, &A.dRunMad[r]);
+        else cf_run_mad<false>(sd, lo, hi, S, sOut, &A.dRunMad[r]);
+    }
+    if (!cf_arrive_last(A.tick + 4, (uint32_t)CF_MADB, &sLast) || t != 0) return;
+    if (!D->haveLocalSd) { D->localSd = -1.0; return; }
+    double s = 0;
+    for (int r = 0; r < nruns; r++) s += cf_ld_f64(&A.dRunMad[r]);               // List<double>.Average(): sequential sum / count
+    D->localSd = s / (double)nruns;
+}
+
+// ---------------------------------------------------------------- the radix-select flavour of the decisions, and the second phase (NormalizeVarianceByGC changed the counts)
 // NormalizeByGC decision: genome median and per-GC medians from the selected keys (CanvasClean.cs:170-189)
 __global__ void __launch_bounds__(128) k_cf_dec_e(const CfArgs* __restrict__ AA, int which) {
     CF_SAMPLE;
@@ -544,7 +1085,7 @@ __global__ void __launch_bounds__(256) k_cf_apply_gc(const CfArgs* __restrict__ 
     if (base >= n) return;
     if (threadIdx.x < NGC) sMed[threadIdx.x] = D->medians[threadIdx.x];
     __syncthreads();
-    float* __restrict__ count = A.S1.count; const int32_t* __restrict__ gc = A.S1.gc;
+    float* __restrict__ count = A.S1.count; const uint8_t* __restrict__ gc = A.S1.gc;
     const double globalMedian = D->globalMedian;
 #pragma unroll
     for (int j = 0; j < CF_EPT; j++) {
@@ -615,268 +1156,6 @@ __global__ void __launch_bounds__(128) k_cf_dec_f(const CfArgs* __restrict__ AA,
     __syncthreads();
     if (t == 0) { D->tab.globalIQR = globalIQR; D->changed = sig > 0 ? 1 : 0; }
 }
-// ---------------------------------------------------------------- the counting selects (see CfCq)
-// window, sweep tiles and the marker / queries the later kernels look at; gated like k_cf_sel_setup(…, gate 0)
-__global__ void __launch_bounds__(128) k_cq_setup(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ uint32_t so[NGC + 1];
-    __shared__ long long sv[33];
-    __shared__ uint32_t shT[2];
-    const CleanDev* D = A.D; CfCq* C = A.cq; CfSel* P1 = A.P + 1; CfSel* P2 = A.P + 2;
-    const int t = threadIdx.x;
-    if (t <= NGC) so[t] = D->segOff[t];
-    __syncthreads();
-    const uint32_t total = so[NGC];
-    if (!D->gcActive || total == 0) { if (t == 0) { P1->hdr[0] = 0; P1->hdr[1] = 0; P2->hdr[0] = 0; P2->hdr[1] = 0; C->ntiles = 0; } return; }
-    if (t < 33) { const uint32_t i = (uint32_t)((double)total * (t + 0.5) / 33.0); long long k = -1; if (i < total && !cq_key(float_of_key(A.keysG[i]), k)) k = -1; sv[t] = k; }
-    __syncthreads();
-    if (t < 33) {                                            // every lane ranks its own sample among the valid ones; the one in the middle sets the window
-        const long long mine = sv[t];
-        int m = 0, rank = 0;
-        for (int j = 0; j < 33; j++) { const long long o = sv[j]; if (o >= 0) { m++; if (o < mine || (o == mine && j < t)) rank++; } }
-        if (m == 0) { if (t == 0) C->lo = 0; }
-        else if (mine >= 0 && rank == m / 2) C->lo = (int32_t)(mine > CQW / 2 ? mine - CQW / 2 : 0);
-    }
-    uint32_t totT;
-    const uint32_t myTiles = t < NGC ? (so[t + 1] - so[t] + CQ_TILE - 1) / CQ_TILE : 0u;
-    const uint32_t exT = cf_excl_scan128(myTiles, shT, &totT);
-    if (t < NGC) { uint32_t k = exT; for (int64_t b = so[t]; b < (int64_t)so[t + 1]; b += CQ_TILE) A.cqTiles[k++] = SelTile{t, b, min<int64_t>(b + CQ_TILE, (int64_t)so[t + 1])}; }
-    if (t == 0) {
-        C->ntiles = totT;
-        P1->hdr[0] = 0; P1->hdr[1] = 1;                      // "NormalizeByGC has been decided" for k_cf_scatter_final / k_cf_apply_gc
-        P2->hdr[0] = 0; P2->hdr[1] = 0;
-        if (D->varActive) {                                  // the genome's quartile ranks (k_cq_nhist / k_cq_nresolve)
-            const QuartIdx qi = quartile_indices((int64_t)total);
-            for (int k = 0; k < qi.n; k++) { P2->qk[k] = (unsigned long long)qi.idx[k]; P2->qprefix[k] = 0ull; }
-            P2->hdr[1] = (uint32_t)qi.n; P2->first[NGC] = 0;
-        }
-    }
-}
-// one sweep of the grouped keys: counters per value in LDS, flushed into the bucket's row and the genome's
-__global__ void __launch_bounds__(1024) k_cq_hist(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ uint32_t lw[CQW];
-    CfCq* __restrict__ C = A.cq;
-    if (blockIdx.x >= C->ntiles) return;
-    const SelTile T = A.cqTiles[blockIdx.x];
-    const long long lo = C->lo;
-    for (int i = threadIdx.x; i < CQW; i += 1024) lw[i] = 0;
-    __syncthreads();
-    const gptr<const uint32_t> keys = as_global(A.keysG);
-    uint32_t below = 0, bad = 0;
-    for (int64_t i0 = T.begin + threadIdx.x; i0 < T.end; i0 += 4 * 1024) {
-        uint32_t kk[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int64_t i = i0 + (int64_t)u * 1024; kk[u] = i < T.end ? keys[i] : 0u; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (i0 + (int64_t)u * 1024 >= T.end) break;
-            long long k;
-            if (!cq_key(float_of_key(kk[u]), k)) { bad = 1; continue; }
-            if (k < lo) below++;
-            else if (k - lo < CQW) atomicAdd(&lw[k - lo], 1u);
-        }
-    }
-    below = wave_reduce_add_u32(below);
-    if ((threadIdx.x & 63) == 0 && below) { atomicAdd(&C->below[T.seg], below); atomicAdd(&C->below[NGC], below); }
-    if (bad) C->bad = 1u;
-    __syncthreads();
-    uint32_t* __restrict__ row = A.cqHist + (size_t)T.seg * CQW; uint32_t* __restrict__ all = A.cqHist + (size_t)NGC * CQW;
-    for (int i = threadIdx.x; i < CQW; i += 1024) { const uint32_t v = lw[i]; if (v) { atomicAdd(&row[i], v); atomicAdd(&all[i], v); } }
-}
-// workgroup g: the order statistics of bucket g (g == NGC: of the genome) from its counters — the NormalizeByGC medians (CanvasClean.cs:170-189) and, for the variance
-// normalisation, the bucket's quartile statistics as k (a bucket is scaled by one factor, so they keep their ranks)
-__global__ void __launch_bounds__(1024) k_cq_pick(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ uint32_t swave[16];
-    __shared__ long long sK[8];
-    __shared__ int sFail;
-    CleanDev* __restrict__ D = A.D; CfCq* __restrict__ C = A.cq;
-    if (A.P[1].hdr[1] == 0) return;
-    const int g = blockIdx.x, t = threadIdx.x;
-    if (g == 0 && t == 0 && C->bad) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; }
-    const int64_t cnt = g < NGC ? (int64_t)D->segOff[g + 1] - (int64_t)D->segOff[g] : (int64_t)D->segOff[NGC];
-    if (cnt <= 0) return;
-    int64_t ranks[8]; int nr = 0;
-    if (cnt % 2) ranks[nr++] = cnt / 2; else { ranks[nr++] = cnt / 2 - 1; ranks[nr++] = cnt / 2; }
-    const int nMed = nr;
-    if (g < NGC && D->varActive) { const QuartIdx qi = quartile_indices(cnt); for (int k = 0; k < qi.n; k++) ranks[nr++] = qi.idx[k]; }
-    const uint4* __restrict__ row = reinterpret_cast<const uint4*>(A.cqHist + (size_t)g * CQW) + 4 * t;     // 16 consecutive counters per thread
-    uint32_t c[16];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const uint4 v = row[u]; c[4 * u] = v.x; c[4 * u + 1] = v.y; c[4 * u + 2] = v.z; c[4 * u + 3] = v.w; }
-    if (g == NGC) {                                       // the genome's row has served its purpose: cleared, k_cq_nhist counts the normalised values in it
-        uint4* wr = reinterpret_cast<uint4*>(A.cqHist + (size_t)NGC * CQW) + 4 * t;
-#pragma unroll
-        for (int u = 0; u < 4; u++) wr[u] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    uint32_t s = 0;
-#pragma unroll
-    for (int u = 0; u < 16; u++) s += c[u];
-    const uint32_t inc = wave_inclusive_scan_u32(s);
-    if ((t & 63) == 63) swave[t >> 6] = inc;
-    if (t == 0) sFail = 0;
-    __syncthreads();
-    uint32_t woff = 0, inWin = 0;
-    for (int w = 0; w < 16; w++) { if (w < (t >> 6)) woff += swave[w]; inWin += swave[w]; }
-    const uint32_t ex = woff + inc - s;
-    const int64_t below = (int64_t)C->below[g];
-    const long long lo = C->lo;
-    for (int q = 0; q < nr; q++) {
-        const int64_t r = ranks[q] - below;
-        if (r < 0 || r >= (int64_t)inWin) { if (t == 0) sFail = 1; continue; }
-        if (r >= (int64_t)ex && r < (int64_t)ex + s) {
-            uint32_t left = (uint32_t)(r - ex); int u = 0;
-            while (left >= c[u]) { left -= c[u]; u++; }
-            sK[q] = lo + 16 * t + u;
-        }
-    }
-    __syncthreads();
-    if (t != 0) return;
-    C->inWin[g] = inWin;
-    if (sFail) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; return; }
-    const double med = nMed == 1 ? (double)cq_value(sK[0]) : (double)median_from_two(cq_value(sK[0]), cq_value(sK[1]));
-    if (g < NGC) { D->medians[g] = med; for (int k = nMed; k < nr; k++) C->kq[g][k - nMed] = (int32_t)sK[k]; }
-    else D->globalMedian = med;
-}
-// NormalizeByGC as a function of k for bucket g (what k_cf_xform_gc does to a key)
-__device__ __forceinline__ float cq_normalised(long long k, double median, double globalMedian) {
-    const float x = cq_value(k);
-    return median > 0 ? (float)(globalMedian * (double)x / median) : x;
-}
-// The genome's quartiles of the normalised counts (CanvasClean.cs:34-66) by counting once more.  The items are the counters: value = the normalised count of the slot,
-// weight = the counter.  The normalised values are not on a grid, but v -> floor((v - L0) * 100) is non-decreasing, so one weighted count over CQW bins of 0.01 around the
-// genome's median locates, for every rank, the bin that holds it and the rank inside that bin (k_cq_nhist); the bin's few candidates — per bucket the slots whose value
-// falls into it, found by bisection because the value is monotone in the slot — are then ordered exactly by their float keys (k_cq_nresolve).  Keys below / above a
-// bucket's window count as smaller / larger than everything, which k_cq_dec_f checks against the answers.  (This replaced four weighted radix passes + picks: 70 -> 20 us.)
-__device__ __forceinline__ double cq_nbin_origin(double globalMedian) { return globalMedian - (double)CQW / 200.0; }
-__device__ __forceinline__ long long cq_nbin(float v, double origin) { return (long long)floor(((double)v - origin) * 100.0); }
-__global__ void __launch_bounds__(1024) k_cq_nhist(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ uint32_t lw[CQW];
-    const CfSel* __restrict__ P = A.P + 2; const CleanDev* __restrict__ D = A.D; CfCq* __restrict__ C = A.cq;
-    if (P->hdr[1] == 0) return;
-    const int g = blockIdx.x;
-    const int64_t cnt = (int64_t)D->segOff[g + 1] - (int64_t)D->segOff[g];
-    if (cnt <= 0) return;
-    for (int i = threadIdx.x; i < CQW; i += 1024) lw[i] = 0;
-    __syncthreads();
-    const double median = D->medians[g], globalMedian = D->globalMedian, origin = cq_nbin_origin(globalMedian);
-    const long long lo = C->lo;
-    const gptr<const uint32_t> row = as_global(A.cqHist) + (size_t)g * CQW;
-    unsigned long long below = threadIdx.x == 0 ? (unsigned long long)C->below[g] : 0ull;
-    for (int j = threadIdx.x; j < CQW; j += 1024) {
-        const uint32_t w = row[j];
-        if (!w) continue;
-        const long long b = cq_nbin(cq_normalised(lo + j, median, globalMedian), origin);
-        if (b < 0) below += w; else if (b < CQW) atomicAdd(&lw[b], w);
-    }
-    below = wave_reduce_add_u64(below);
-    if ((threadIdx.x & 63) == 0 && below) atomicAdd(&C->nbelow, below);
-    __syncthreads();
-    uint32_t* __restrict__ all = A.cqHist + (size_t)NGC * CQW;
-    for (int i = threadIdx.x; i < CQW; i += 1024) { const uint32_t v = lw[i]; if (v) atomicAdd(&all[i], v); }
-}
-#define CQ_NCAND 1024        // candidates of one bin (a bucket contributes about median / globalMedian slots per bin)
-__global__ void __launch_bounds__(1024) k_cq_nresolve(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ uint32_t swave[16];
-    __shared__ uint32_t sKey[CQ_NCAND], sW[CQ_NCAND];
-    __shared__ unsigned int sN; __shared__ int sBin, sFail; __shared__ uint32_t sR;
-    CfSel* __restrict__ P = A.P + 2; const CleanDev* __restrict__ D = A.D; const CfCq* __restrict__ C = A.cq;
-    const int q = blockIdx.x, t = threadIdx.x;
-    if ((uint32_t)q >= P->hdr[1]) return;
-    const uint4* __restrict__ row = reinterpret_cast<const uint4*>(A.cqHist + (size_t)NGC * CQW) + 4 * t;
-    uint32_t c[16];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const uint4 v = row[u]; c[4 * u] = v.x; c[4 * u + 1] = v.y; c[4 * u + 2] = v.z; c[4 * u + 3] = v.w; }
-    uint32_t s = 0;
-#pragma unroll
-    for (int u = 0; u < 16; u++) s += c[u];
-    const uint32_t inc = wave_inclusive_scan_u32(s);
-    if ((t & 63) == 63) swave[t >> 6] = inc;
-    if (t == 0) { sN = 0; sBin = -1; sFail = 0; }
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < (t >> 6); w++) woff += swave[w];
-    const uint32_t ex = woff + inc - s;
-    const long long r = (long long)P->qk[q] - (long long)C->nbelow;
-    if (r >= (long long)ex && r < (long long)ex + s) {
-        uint32_t left = (uint32_t)(r - ex); int u = 0;
-        while (left >= c[u]) { left -= c[u]; u++; }
-        sBin = 16 * t + u; sR = left;
-    }
-    __syncthreads();
-    const int bin = sBin;
-    if (bin < 0) { if (t == 0) P->qprefix[q] = 0ull; return; }          // the rank lies outside the bins: key 0 makes k_cq_dec_f give the sample up
-    if (t < NGC) {
-        const int64_t cnt = (int64_t)D->segOff[t + 1] - (int64_t)D->segOff[t];
-        if (cnt > 0) {
-            const double median = D->medians[t], globalMedian = D->globalMedian, origin = cq_nbin_origin(globalMedian);
-            const long long lo = C->lo;
-            int a = 0, b = CQW;                           // first slot whose value falls into bin `bin` or a later one
-            while (a < b) { const int mid = (a + b) >> 1; if (cq_nbin(cq_normalised(lo + mid, median, globalMedian), origin) < (long long)bin) a = mid + 1; else b = mid; }
-            for (int j = a; j < CQW; j++) {
-                const float v = cq_normalised(lo + j, median, globalMedian);
-                if (cq_nbin(v, origin) != (long long)bin) break;
-                const uint32_t w = A.cqHist[(size_t)t * CQW + j];
-                if (w) { const unsigned int at = atomicAdd(&sN, 1u); if (at < CQ_NCAND) { sKey[at] = key_of_float(v); sW[at] = w; } else sFail = 1; }
-            }
-        }
-    }
-    __syncthreads();
-    if (sFail) { if (t == 0) P->qprefix[q] = 0ull; return; }
-    const unsigned int n = sN;
-    const uint32_t rq = sR;
-    if ((unsigned int)t < n) {                            // the candidate whose weights [less, less + w) cover the rank inside the bin
-        const uint32_t key = sKey[t];
-        unsigned long long less = 0;
-        for (unsigned int o = 0; o < n; o++) { const uint32_t ko = sKey[o]; if (ko < key || (ko == key && o < (unsigned int)t)) less += sW[o]; }
-        if ((unsigned long long)rq >= less && (unsigned long long)rq < less + sW[t]) P->qprefix[q] = (unsigned long long)key;
-    }
-}
-// NormalizeVarianceByGC decision (CanvasClean.cs:34-83) from the buckets' k statistics and the genome's selected keys
-__global__ void __launch_bounds__(128) k_cq_dec_f(const CfArgs* __restrict__ AA) {
-    CF_SAMPLE;
-    __shared__ int sig, sFail;
-    const CfSel* __restrict__ P = A.P + 2; CleanDev* __restrict__ D = A.D; const CfCq* __restrict__ C = A.cq;
-    if (P->hdr[1] == 0) return;
-    const int t = threadIdx.x;
-    if (t == 0) { sig = 0; sFail = 0; }
-    __syncthreads();
-    const int64_t total = (int64_t)D->segOff[NGC];
-    const QuartIdx gi = quartile_indices(total);
-    float gv[6]; uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (int k = 0; k < gi.n; k++) { const uint32_t key = (uint32_t)P->qprefix[k]; gv[k] = float_of_key(key); kmin = min(kmin, key); kmax = max(kmax, key); }
-    float g1, g2, g3;
-    quartiles_from_values(total, gv, g1, g2, g3);
-    const float globalIQR = g3 - g1;
-    const double globalMedian = D->globalMedian;
-    const long long lo = C->lo;
-    if (t < NGC) {
-        const int64_t cnt = (int64_t)D->segOff[t + 1] - (int64_t)D->segOff[t];
-        float liqr = -1.0f, med = -1.0f;
-        if (cnt > 0) {
-            const double median = D->medians[t];
-            const QuartIdx qi = quartile_indices(cnt);
-            float v[6];
-            for (int k = 0; k < qi.n; k++) v[k] = cq_normalised(C->kq[t][k], median, globalMedian);
-            float q1, q2, q3; quartiles_from_values(cnt, v, q1, q2, q3);
-            med = q2; liqr = q3 - q1;
-            // the genome's answers are right only if every key that was left out of this bucket's window lies on the side it was counted on
-            const uint32_t below = C->below[t], above = (uint32_t)(cnt - (int64_t)below - (int64_t)C->inWin[t]);
-            if (below && key_of_float(cq_normalised(lo, median, globalMedian)) > kmin) atomicOr(&sFail, 1);
-            if (above && key_of_float(cq_normalised(lo + CQW - 1, median, globalMedian)) < kmax) atomicOr(&sFail, 1);
-        }
-        D->tab.localIQR[t] = liqr; D->tab.med[t] = med;
-        if (t >= 10 && t < 90 && globalIQR * 2.0f < liqr) atomicAdd(&sig, 1);
-    }
-    __syncthreads();
-    if (t == 0) {
-        if (kmin == 0u || kmax == 0xFFFFFFFFu || sFail) { A.cq->fail = 1u; D->cqFail = 1; D->fallback = 1u; D->changed = 0; return; }
-        D->tab.globalIQR = globalIQR; D->changed = sig > 0 ? 1 : 0;
-    }
-}
 __global__ void __launch_bounds__(256) k_cf_apply_var(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ float sIqr[NGC], sMedF[NGC];
@@ -886,7 +1165,7 @@ __global__ void __launch_bounds__(256) k_cf_apply_var(const CfArgs* __restrict__
     if (base >= n) return;
     if (threadIdx.x < NGC) { sIqr[threadIdx.x] = D->tab.localIQR[threadIdx.x]; sMedF[threadIdx.x] = D->tab.med[threadIdx.x]; }
     __syncthreads();
-    float* __restrict__ count = A.S1.count; const int32_t* __restrict__ gc = A.S1.gc;
+    float* __restrict__ count = A.S1.count; const uint8_t* __restrict__ gc = A.S1.gc;
     const float globalIQR = D->tab.globalIQR;
 #pragma unroll
     for (int j = 0; j < CF_EPT; j++) {
@@ -926,64 +1205,90 @@ __global__ void __launch_bounds__(256) k_cf_xform_var(const CfArgs* __restrict__
 }
 
 // ---------------------------------------------------------------- last compaction: GC strip (CanvasClean.cs:226-235) + RemoveBinsWithExtremeLocalSD (:308-322) -> caller's arrays
+// CountDeviation of a bin = the SD of its window of 20 (CanvasClean.cs:268-298), -1 behind the last window (GenomicBin.cs:83): read from the window SDs, eight bins per thread
 __global__ void __launch_bounds__(256) k_cf_flags_final(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ uint32_t sh[4];
+    __shared__ uint8_t sKeepGc[NGC + 3];
     const CleanDev* __restrict__ D = A.D;
     const int64_t n = (int64_t)D->nAB;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
-    const gptr<const int32_t> gc = as_global(A.S1.gc); const gptr<const double> dev = as_global(A.S1.dev); const gptr<uint8_t> flags = as_global(A.dFlags);
+    const gptr<const uint8_t> gc = as_global(A.S1.gc); const gptr<const double> sd = as_global(A.dSd); const gptr<uint8_t> flags = as_global(A.dFlags);
     const bool sdFilter = D->haveLocalSd && D->localSd > 5.0;
+    const int64_t Dn = n - 1, nW = Dn >= 1 ? (Dn - 1) / 20 : 0;
+    if (threadIdx.x < NGC) sKeepGc[threadIdx.x] = D->keepGc[threadIdx.x];
+    __syncthreads();
+    const int64_t i0 = base + 8 * (int64_t)threadIdx.x;
     uint32_t c = 0;
+    if (i0 + 7 < n) {
+        const unsigned long long g8 = *reinterpret_cast<gptr<const unsigned long long>>(gc + i0);
+        const int64_t w0 = i0 / 20, w1 = (i0 + 7) / 20;
+        bool ex0 = false, ex1 = false;
+        if (sdFilter) { ex0 = w0 < nW && sd[w0] > 20 * 2.0; ex1 = w1 == w0 ? ex0 : (w1 < nW && sd[w1] > 20 * 2.0); }
+        unsigned long long out = 0;
 #pragma unroll
-    for (int j = 0; j < CBLK / 256; j++) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        if (i >= n) continue;
-        const bool keep = D->keepGc[gc[i]] && !(sdFilter && dev[i] > 20 * 2.0);
-        flags[i] = keep; c += keep;
+        for (int e = 0; e < 8; e++) {
+            const bool keep = sKeepGc[(g8 >> (8 * e)) & 0xFF] && !(((i0 + e) / 20 == w0) ? ex0 : ex1);
+            out |= (unsigned long long)(keep ? 1 : 0) << (8 * e); c += keep;
+        }
+        *reinterpret_cast<gptr<unsigned long long>>(flags + i0) = out;
+    } else {
+        for (int e = 0; e < 8; e++) {
+            const int64_t i = i0 + e;
+            if (i >= n) break;
+            const int64_t w = i / 20;
+            const bool keep = sKeepGc[gc[i]] && !(sdFilter && w < nW && sd[w] > 20 * 2.0);
+            flags[i] = keep; c += keep;
+        }
     }
     c = wave_reduce_add_u32(c);
     if (lane_id() == 0) sh[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) A.dBlk[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) A.dBlkF[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 __global__ void __launch_bounds__(256) k_cf_scatter_final(const CfArgs* __restrict__ AA, int secondPhase) {
     CF_SAMPLE;
-    __shared__ uint32_t sh[4];
-    const CleanDev* __restrict__ D = A.D;
+    __shared__ unsigned long long sh16[16];
+    __shared__ uint32_t shW[CBLK / 256][4];
+    CleanDev* __restrict__ D = A.D;
     if (D->fallback || D->bad) return;                                        // the caller's arrays stay as they were
     if (D->changed && !secondPhase) return;                                   // the variance normalisation changed the counts: the host enqueues the second NormalizeByGC, then this kernel again
     const int64_t n = (int64_t)D->nAB;
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
-    const gptr<const uint8_t> flags = as_global(A.dFlags); const GSoa src = as_global(A.S1), dst = as_global(A.caller);
-    // first phase: NormalizeByGC has only been decided (k_cf_dec_e), not applied to the scratch counts — nothing between here and there reads them — so it is applied while
+    const gptr<const uint8_t> flags = as_global(A.dFlags); const GSoa1 src = as_global(A.S1); const GSoa dst = as_global(A.caller);
+    // first phase: NormalizeByGC has only been decided, not applied to the scratch counts — nothing between here and there reads them — so it is applied while
     // the survivors are copied out.  (When the second phase runs, clean_batch_finish applies it to the scratch counts first: NormalizeVarianceByGC works on normalised counts.)
     const bool normalise = !secondPhase && (A.flags & CANVAS_CLEAN_GCNORM) && A.P[1].hdr[1] != 0;
     __shared__ double sMed[NGC];
     if (normalise && threadIdx.x < NGC) sMed[threadIdx.x] = D->medians[threadIdx.x];
     const double globalMedian = D->globalMedian;
+    uint32_t f[CBLK / 256], inc[CBLK / 256];
+#pragma unroll
+    for (int j = 0; j < CBLK / 256; j++) { const int64_t i = base + j * 256 + threadIdx.x; f[j] = (i < n) ? flags[i] : 0; }
+    const uint32_t blockOff = cf_block_offset<false>(A.dBlkF, (int)blockIdx.x, sh16);       // (its barriers also publish sMed)
+#pragma unroll
+    for (int j = 0; j < CBLK / 256; j++) { inc[j] = wave_inclusive_scan_u32(f[j]); if (lane_id() == 63) shW[j][threadIdx.x >> 6] = inc[j]; }
     __syncthreads();
-    uint32_t running = A.dBlk[blockIdx.x];
+    uint32_t running = blockOff;
+    const int w = threadIdx.x >> 6;
+#pragma unroll
     for (int j = 0; j < CBLK / 256; j++) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        const uint32_t f = (i < n) ? flags[i] : 0;
-        const uint32_t inc = wave_inclusive_scan_u32(f);
-        if (lane_id() == 63) sh[threadIdx.x >> 6] = inc;
-        __syncthreads();
         uint32_t woff = 0, tot = 0;
-        for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) woff += sh[k]; tot += sh[k]; }
-        if (f) {
-            const uint32_t d = running + woff + inc - 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t v = shW[j][k]; if (k < w) woff += v; tot += v; }
+        if (f[j]) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            const uint32_t d = running + woff + inc[j] - 1;
             const int32_t g = src.gc[i];
             float v = src.count[i];
             if (normalise) { const double median = sMed[g]; if (median > 0) v = (float)(globalMedian * (double)v / median); }        // CanvasClean.cs:190-195, applied on the way out
             dst.chr[d] = src.chr[i]; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = g; dst.count[d] = v;
         }
         running += tot;
-        __syncthreads();
     }
+    if (base + CBLK >= n && threadIdx.x == 0) D->nFinal = running;            // the last block's end = the number of bins that are left
 }
 
 // ---------------------------------------------------------------- host side
@@ -995,9 +1300,8 @@ static void cf_select_passes(canvas_ctx* ctx, const CfArgs* dArgs, int B, unsign
         hipLaunchKernelGGL(k_cf_select_pick, dim3(CF_MAXQ, B), dim3(64), 0, ctx->stream, dArgs, which, shift == 24 ? 1 : 0);
     }
 }
-// NormalizeByGC on problem `which` (1: first time, 3: after the variance normalisation) and the last compaction; `args`: the whole batch or one sample's block
-// the medians of NormalizeByGC on problem `which` (1: first time, 3: after the variance normalisation); apply = scale the scratch counts now (second phase) instead of in
-// the last compaction (first phase)
+// the medians of NormalizeByGC on problem `which` (1: first time, 3: after the variance normalisation) with the radix selects; apply = scale the scratch counts now
+// (second phase) instead of in the last compaction (first phase)
 static void cf_gc_medians(canvas_ctx* ctx, const CfArgs* args, int B, unsigned gxN, unsigned gxT, int which, int gate, bool apply) {
     hipLaunchKernelGGL(k_cf_sel_setup, dim3(1, B), dim3(128), 0, ctx->stream, args, which, 0, gate);
     cf_select_passes(ctx, args, B, gxT, which);
@@ -1011,15 +1315,15 @@ static inline bool clean_counting_selects() { return getenv("CANVAS_CLEAN_RADIX_
 static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t* const* d_chr, int32_t* const* d_start, int32_t* const* d_stop, float* const* d_count, int32_t* const* d_gc,
                                    int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc, bool useCq) {
     useCq = useCq && (flags & CANVAS_CLEAN_GCNORM);
-    const size_t cqWords = useCq ? (size_t)B * (NGC + 1) * CQW : 0;
+    const size_t cqWords = useCq ? (size_t)B * CQ_ROWS * CQW : 0;
     WsSizer sz;
-    sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<CleanDev>(B); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); sz.take<CfCq>(B); sz.take<uint32_t>(cqWords);
+    sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<CleanDev>(B); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); sz.take<CfCq>(B); sz.take<uint32_t>((size_t)B * 8); sz.take<uint32_t>(cqWords + 4);
     int64_t nMax = 0; bool anyLsd = false, anyVar = false;
     for (int s = 0; s < B; s++) {
         const int64_t n = h_n[s], nW0 = n / 20 + 2, nb = nblk(n, CBLK); const size_t tilesUpper = (size_t)(n / SEL_TILE + NGC + 1);
         nMax = std::max(nMax, n);
-        sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<double>(n);
-        sz.take<uint8_t>(n); sz.take<uint32_t>(2 * (nb + 2)); sz.take<uint32_t>(n); sz.take<uint32_t>(n / 8 + 1024); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
+        sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<uint8_t>(n + 16);
+        sz.take<uint8_t>(n + 16); sz.take<unsigned long long>(nb + 2); sz.take<uint32_t>(nb + 2); sz.take<uint32_t>(n); sz.take<uint32_t>(n / 8 + 1024); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
         sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CfSel>(CF_NPROB); sz.take<SelTile>(tilesUpper * CF_NPROB); sz.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1));
     }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
@@ -1030,71 +1334,58 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->sel_hist, 0, ctx->sel_hist_bytes, ctx->stream));       // zero once: k_select_pick clears every row it has read
     }
     WsCarver ws(ctx->ws);
-    // two adjacent groups: what the host sends (one copy) and what starts as zero (one memset)
+    // two adjacent groups: what the host sends (the argument table) and what starts as zero (k_cf_init)
     CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr);
-    CleanDev* dD = ws.take<CleanDev>(B); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS); uint32_t* dRepl = ws.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); CfCq* dCq = ws.take<CfCq>(B); uint32_t* dCqHist = ws.take<uint32_t>(cqWords);
+    CleanDev* dD = ws.take<CleanDev>(B); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS); uint32_t* dRepl = ws.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); CfCq* dCq = ws.take<CfCq>(B);
+    uint32_t* dTick = ws.take<uint32_t>((size_t)B * 8); uint32_t* dCqHist = ws.take<uint32_t>(cqWords + 4);
     CleanPending pend; pend.useCq = useCq; pend.B = B; pend.dArgs = dArgs; pend.dD = dD; pend.h.resize(B);
     unsigned gxT = 1, gxTcq = 1;
     for (int s = 0; s < B; s++) {
         const int64_t n = h_n[s], nW0 = n / 20 + 2; const int nb = (int)nblk(n, CBLK); const unsigned tilesUpper = (unsigned)(n / SEL_TILE + NGC + 1);
         CfArgs& A = pend.h[s];
-        A.n = n; A.nb = nb; A.nchr = nchr; A.minBinsPerGc = min_bins_per_gc; A.flags = flags; A.tilesUpper = tilesUpper;
+        memset(&A, 0, sizeof A);
+        A.n = n; A.nb = nb; A.nchr = nchr; A.minBinsPerGc = min_bins_per_gc; A.flags = flags; A.tilesUpper = tilesUpper; A.useCq = useCq ? 1 : 0;
         A.wantLsd = ((flags & CANVAS_CLEAN_LOCALSD) && n >= 50000) ? 1 : 0;
         A.doSize = (flags & CANVAS_CLEAN_FILTSIZE) ? 1 : 0; A.doOutlier = (flags & CANVAS_CLEAN_OUTLIERS) ? 1 : 0;
         A.caller = Soa{d_chr[s], d_start[s], d_stop[s], d_gc[s], d_count[s], nullptr};
-        A.S1.chr = ws.take<int32_t>(n); A.S1.start = ws.take<int32_t>(n); A.S1.stop = ws.take<int32_t>(n); A.S1.gc = ws.take<int32_t>(n); A.S1.count = ws.take<float>(n); A.S1.dev = ws.take<double>(n);
-        A.dFlags = ws.take<uint8_t>(n); A.dBlk = ws.take<uint32_t>(2 * (nb + 2)); A.keysG = ws.take<uint32_t>(n); A.szOverCap = (uint32_t)(n / 8 + 1024); A.padA = 0; A.szOver = ws.take<uint32_t>(A.szOverCap);
+        A.S1.chr = ws.take<int32_t>(n); A.S1.start = ws.take<int32_t>(n); A.S1.stop = ws.take<int32_t>(n); A.S1.count = ws.take<float>(n); A.S1.gc = ws.take<uint8_t>(n + 16);
+        A.dFlags = ws.take<uint8_t>(n + 16); A.dBlk = ws.take<unsigned long long>(nb + 2); A.dBlkF = ws.take<uint32_t>(nb + 2); A.keysG = ws.take<uint32_t>(n); A.szOverCap = (uint32_t)(n / 8 + 1024); A.szOver = ws.take<uint32_t>(A.szOverCap);
         A.dSd = ws.take<double>(nW0); A.dRunMad = ws.take<double>(CF_MAXRUN + 8); A.dRunStart = ws.take<int64_t>(CF_MAXRUN + 8); A.dPos = ws.take<long long>(65536);
         A.P = ws.take<CfSel>(CF_NPROB); A.tiles = ws.take<SelTile>((size_t)tilesUpper * CF_NPROB);
-        A.cqTiles = ws.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1)); A.cq = dCq + s; A.cqHist = dCqHist + (size_t)s * (NGC + 1) * CQW;
+        A.cqTiles = ws.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1)); A.cq = dCq + s; A.cqHist = dCqHist + (size_t)s * CQ_ROWS * CQW;
         gxTcq = std::max(gxTcq, (unsigned)(n / CQ_TILE + NGC + 1));
         A.isAuto = dIsAuto; A.repl = dRepl + (size_t)s * CF_HREP * 3 * NGC; A.szHist = dSz + (size_t)s * CF_SZ_BINS; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
+        A.tick = dTick + (size_t)s * 8;
         gxT = std::max(gxT, tilesUpper);
         anyLsd = anyLsd || A.wantLsd; anyVar = anyVar || (A.wantLsd && n > 500000);
     }
     const unsigned gxN = (unsigned)nblk(nMax, 256), gxB = (unsigned)nblk(nMax, CBLK);
     pend.gxN = gxN; pend.gxB = gxB; pend.gxT = gxT; pend.anyLsd = anyLsd; pend.anyVar = anyVar; pend.anyGc = (flags & CANVAS_CLEAN_GCNORM) != 0;
     ProfScope psTotal(ctx, "clean_total");
+    // ---- the zeros of the stage (CleanDev blocks, size counters, replica counters, CfCq blocks, tickets, value counters) and the argument table, in one launch
     {
-        std::vector<char> up((size_t)((char*)(dIsAuto + nchr) - (char*)dArgs), 0);
-        memcpy(up.data(), pend.h.data(), (size_t)B * sizeof(CfArgs)); memcpy(up.data() + ((char*)dIsAuto - (char*)dArgs), h_chr_is_autosome, nchr);
-        rc = canvas_h2d_small(ctx, dArgs, up.data(), up.size()); if (rc) return rc;
-    }
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dD, 0, (size_t)((char*)(dCqHist + cqWords) - (char*)dD), ctx->stream));      // CleanDev blocks, size counters, CfCq blocks, value counters
-    // ---- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes from exact per-size counts, left on the device
-    if (flags & CANVAS_CLEAN_FILTSIZE) {
-        hipLaunchKernelGGL(k_cf_size_hist, dim3(CF_SZ_GRID, B), dim3(1024), 0, ctx->stream, dArgs);
-        hipLaunchKernelGGL(k_cf_size_pick, dim3(1, B), dim3(1024), 0, ctx->stream, dArgs);        // sizeOn stays 0 (the memset of the CleanDev blocks) without the filter
-    }
-    // ---- size filter + outlier filter: one compaction, caller -> S1
-    // (a one-bin-per-thread variant of the flag kernel was measured: 68 us against 53 us for the staged one)
-    hipLaunchKernelGGL(k_cf_flags_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
-    hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1, B), dim3(1024), 0, ctx->stream, dArgs, 0);
-    hipLaunchKernelGGL(k_cf_dec_gc, dim3(1, B), dim3(128), 0, ctx->stream, dArgs);             // the GC strip decision (the histogram of the survivors came with the flags)
-    hipLaunchKernelGGL(k_cf_scatter_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
-    // ---- local SD (CanvasClean.cs:243-298): window SDs and chromosome runs on the main stream, the per-run MAD on the side stream
-    if (anyLsd) hipLaunchKernelGGL(k_cf_local_sd, dim3((unsigned)nblk(nMax / 20 + 2, 256), B), dim3(256), 0, ctx->stream, dArgs);
-    hipLaunchKernelGGL(k_cf_runs_build, dim3(1, B), dim3(CF_MAXRUN), 0, ctx->stream, dArgs);
-    if (anyLsd) {
-        rc = canvas_side_init(ctx); if (rc) return rc;
-        if (!ctx->side_ev2) CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_ev2, hipEventDisableTiming));
-        CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
-        hipLaunchKernelGGL(k_cf_run_mad, dim3(CF_MAXRUN, B), dim3(1024), 0, ctx->side, dArgs);
-    }
-    // ---- NormalizeByGC on the grouped keys the compaction left
-    if (useCq) {
-        // counting selects (CfCq): one sweep + one pick for every median and every bucket's quartiles; the genome's quartiles of the normalised counts by a second
-        // (weighted) count over the counters and an exact resolve of the bin each rank falls into
-        hipLaunchKernelGGL(k_cq_setup, dim3(1, B), dim3(128), 0, ctx->stream, dArgs);
-        hipLaunchKernelGGL(k_cq_hist, dim3(gxTcq, B), dim3(1024), 0, ctx->stream, dArgs);
-        hipLaunchKernelGGL(k_cq_pick, dim3(NGC + 1, B), dim3(1024), 0, ctx->stream, dArgs);
-        if (anyVar) {
-            hipLaunchKernelGGL(k_cq_nhist, dim3(NGC, B), dim3(1024), 0, ctx->stream, dArgs);
-            hipLaunchKernelGGL(k_cq_nresolve, dim3(6, B), dim3(1024), 0, ctx->stream, dArgs);
-            hipLaunchKernelGGL(k_cq_dec_f, dim3(1, B), dim3(128), 0, ctx->stream, dArgs);
+        const size_t zeroBytes = ((size_t)((char*)(dCqHist + cqWords) - (char*)dD) + 15) & ~size_t(15);
+        CfArgsPack pack;                                     // (the kernel argument is copied at launch)
+        int npack = 0;
+        if (B <= CF_BYVAL && nchr <= 256) {
+            memset(&pack, 0, sizeof pack);
+            memcpy(pack.a, pend.h.data(), (size_t)B * sizeof(CfArgs)); memcpy(pack.isAuto, h_chr_is_autosome, nchr);
+            npack = B;
+        } else {
+            std::vector<char> up((size_t)((char*)(dIsAuto + nchr) - (char*)dArgs), 0);
+            memcpy(up.data(), pend.h.data(), (size_t)B * sizeof(CfArgs)); memcpy(up.data() + ((char*)dIsAuto - (char*)dArgs), h_chr_is_autosome, nchr);
+            rc = canvas_h2d_small(ctx, dArgs, up.data(), up.size()); if (rc) return rc;
         }
-    } else if (flags & CANVAS_CLEAN_GCNORM) {
+        const unsigned gz = (unsigned)std::min<size_t>(512, (zeroBytes / 16 + 1023) / 1024 + 1);
+        hipLaunchKernelGGL(k_cf_init, dim3(gz), dim3(1024), 0, ctx->stream, dArgs, dIsAuto, pack, npack, nchr, (uint4*)dD, zeroBytes / 16);
+    }
+    // ---- RemoveBigBins threshold (CanvasClean.cs:328-348): the 98th percentile of the bin sizes from exact per-size counts, left on the device
+    if (flags & CANVAS_CLEAN_FILTSIZE) hipLaunchKernelGGL(k_cf_size, dim3(CF_SZ_GRID, B), dim3(1024), 0, ctx->stream, dArgs);        // sizeOn stays 0 without the filter
+    // ---- size filter + outlier filter: one compaction, caller -> S1; the GC strip decision and the set-up of the counting selects ride on the flag kernel's last workgroup
+    hipLaunchKernelGGL(k_cf_flags_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
+    hipLaunchKernelGGL(k_cf_scatter_ab, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
+    if (!useCq && (flags & CANVAS_CLEAN_GCNORM)) {
+        // NormalizeByGC on the grouped keys with the radix selects
         cf_gc_medians(ctx, dArgs, B, gxN, gxT, 1, 0, false);
         if (anyVar) {
             // NormalizeVarianceByGC (CanvasClean.cs:512-519): quartiles of the normalised counts; if it changes anything, NormalizeByGC once more
@@ -1102,18 +1393,17 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
             hipLaunchKernelGGL(k_cf_xform_gc, dim3((gxN + CF_EPT - 1) / CF_EPT, B), dim3(256), 0, ctx->stream, dArgs, 2);
             cf_select_passes(ctx, dArgs, B, gxT, 2);
             hipLaunchKernelGGL(k_cf_dec_f, dim3(1, B), dim3(128), 0, ctx->stream, dArgs, 2);
-            // ... which it rarely does: the last compaction below is enqueued on the assumption that it does not; when k_cf_dec_f says it did, that compaction does nothing for
-            // the sample and clean_batch_finish enqueues the variance scaling, the second NormalizeByGC and the compaction for it (one more synchronisation, in that case only)
         }
     }
-    // ---- local-SD average, last compaction into the caller's arrays
-    if (anyLsd) {
-        CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev2, ctx->side));
-        CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev2, 0));
-    }
-    hipLaunchKernelGGL(k_cf_lsd_avg, dim3(1, B), dim3(64), 0, ctx->stream, dArgs);
+    // ---- counting sweep | window SDs and chromosome runs (CanvasClean.cs:243-298); then order statistics and the variance decision | per-run MADs and their average.
+    // ... the variance normalisation rarely changes anything: the last compaction below is enqueued on the assumption that it does not; when it did, that compaction does
+    // nothing for the sample and clean_batch_finish enqueues the variance scaling, the second NormalizeByGC and the compaction for it (one more synchronisation, in that case only)
+    const int nHist = useCq ? (int)gxTcq : 0, nLsd = anyLsd ? (int)nblk(nMax / 20 + 2, 1024) : 0;
+    if (nHist + nLsd > 0) hipLaunchKernelGGL(k_cf_hist_lsd, dim3(nHist + nLsd, B), dim3(1024), 0, ctx->stream, dArgs, nHist, nLsd);
+    const int nPick = useCq ? NGC + 1 : 0, nMad = anyLsd ? CF_MADB : 0;
+    if (nPick + nMad > 0) hipLaunchKernelGGL(k_cf_pick_mad, dim3(nPick + nMad, B), dim3(1024), 0, ctx->stream, dArgs, nPick);
+    // ---- last compaction into the caller's arrays
     hipLaunchKernelGGL(k_cf_flags_final, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
-    hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1, B), dim3(1024), 0, ctx->stream, dArgs, 1);
     hipLaunchKernelGGL(k_cf_scatter_final, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs, 0);
     rc = canvas_pin_reserve(ctx, (size_t)B * sizeof(CleanDev)); if (rc) return rc;
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, dD, (size_t)B * sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
@@ -1143,7 +1433,6 @@ static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64
         hipLaunchKernelGGL(k_cf_xform_var, dim3((gxN + CF_EPT - 1) / CF_EPT, 1), dim3(256), 0, ctx->stream, a);
         cf_gc_medians(ctx, a, 1, gxN, gxT, 3, 2, true);
         hipLaunchKernelGGL(k_cf_flags_final, dim3(gxB, 1), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL(k_cf_scan_blocks, dim3(1, 1), dim3(1024), 0, ctx->stream, a, 1);
         hipLaunchKernelGGL(k_cf_scatter_final, dim3(gxB, 1), dim3(256), 0, ctx->stream, a, 1);
         again = true;
     }
