@@ -94,6 +94,22 @@ __device__ __forceinline__ bool cq_key(float x, long long& k) {
     k = ki;
     return ki >= 0 && cq_value(ki) == x && !(ki == 0 && (__float_as_uint(x) >> 31));      // (-0.0 sorts in front of 0.0)
 }
+// Utilities.Quartiles (CanvasCommon/Utilities.cs:361-419) without arrays (a local array indexed by a loop variable lives in scratch memory, and a kernel that uses scratch
+// is dispatched more slowly — 40 -> 60 us for k_cf_flags_ab): how many order statistics a list of iSize needs, and the k-th of them in quartile_indices' order
+__device__ __forceinline__ int quart_n(int64_t iSize) { if (iSize % 2 == 0) return ((iSize / 2) % 2 == 0) ? 6 : 4; return 5; }
+__device__ __forceinline__ int64_t quart_idx(int64_t iSize, int k) {
+    const int64_t iMid = iSize / 2;
+    if (iSize % 2 == 0) {
+        const int64_t mm = iMid / 2;
+        if (k == 0) return iMid - 1;
+        if (k == 1) return iMid;
+        if (iMid % 2 == 0) return k == 2 ? mm - 1 : (k == 3 ? mm : (k == 4 ? iMid + mm - 1 : iMid + mm));
+        return k == 2 ? mm : mm + iMid;
+    }
+    if (k == 0) return iMid;
+    if ((iSize - 1) % 4 == 0) { const int64_t n = (iSize - 1) / 4; return k == 1 ? n - 1 : (k == 2 ? n : (k == 3 ? 3 * n : 3 * n + 1)); }
+    const int64_t n = (iSize - 3) / 4; return k == 1 ? n : (k == 2 ? n + 1 : (k == 3 ? 3 * n + 1 : 3 * n + 2));
+}
 // the scratch copy between the two compactions: the five columns of the survivors, GC as one byte; CountDeviation (GenomicBin.cs:83) is never materialised —
 // the only reader (RemoveBinsWithExtremeLocalSD, :308-322) takes it from the window SD of the bin's window
 struct Soa1 { int32_t *chr, *start, *stop; float* count; uint8_t* gc; };
@@ -113,24 +129,32 @@ struct CfArgs {                      // one sample of the batch
     CleanDev* D; CfSel* P; SelTile* tiles; uint32_t* hist;
     CfCq* cq; uint32_t* cqHist; SelTile* cqTiles;      // the counting selects (below)
     uint32_t* repl;                  // [CF_HREP][2 * NGC] GC counts of the survivors per replica (k_cf_flags_ab), then [CF_HREP][NGC] write cursors into the grouped keys (its last workgroup -> k_cf_scatter_ab)
+    unsigned long long* dbg;         // profiling hook (CANVAS_CLEAN_DEBUG_CLOCKS=1): [64] wall-clock stamps of selected workgroups, else nullptr
     uint32_t* tick;                  // [8] arrival tickets: 0 k_cf_size, 1 k_cf_flags_ab, 2 window role of k_cf_hist_lsd, 3 / 4 pick and run role of k_cf_pick_mad
 };
 struct CfArgsPack { CfArgs a[CF_BYVAL]; uint8_t isAuto[256]; };
 #define CF_SAMPLE const CfArgs& A = AA[blockIdx.y]
+#define CF_STAMP(slot) do { if (A.dbg && threadIdx.x == 0) A.dbg[slot] = wall_clock64(); } while (0)
 
 // ---------------------------------------------------------------- hand-off inside a launch
-// A value one workgroup publishes for the last workgroup of the same launch: write-through (sc1) store / device-scope atomic on the producer's side, sc1 load on the
-// consumer's ("sc1 stores AND sc1 loads": the per-XCD L2s are not coherent and a CU's L1 is never refreshed by another CU's stores).
+// A value one workgroup publishes for the last workgroup of the same launch: write-through (sc1) store / device-scope atomic on the producer's side (no release fence:
+// the per-XCD L2s are not coherent and a CU's L1 is never refreshed by another CU's stores); the last workgroup issues ONE agent-scope acquire after its ticket
+// (cf_arrive_last) and reads with plain loads, which the compiler keeps in flight together — sc1 loads (cf_ld) are issued one at a time: a tail of 40 of them per
+// thread was 20 us.
 template <class T> __device__ __forceinline__ void cf_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class T> __device__ __forceinline__ T cf_ld(const T* p) { return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ T cf_ld(const T* p) { return *p; }        // (after the acquire of cf_arrive_last)
 __device__ __forceinline__ void cf_st_f64(double* p, double v) { cf_st(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v)); }
-__device__ __forceinline__ double cf_ld_f64(const double* p) { return __longlong_as_double((long long)cf_ld(reinterpret_cast<const unsigned long long*>(p))); }
+__device__ __forceinline__ double cf_ld_f64(const double* p) { return *p; }
 // Arrival ticket (zero at launch): true in the workgroup that arrives last.  Every wave drains its own stores and atomics first, so whatever a workgroup published is
 // in memory before its ticket is.
 __device__ __forceinline__ bool cf_arrive_last(uint32_t* tick, uint32_t expected, int* sFlag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) *sFlag = (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == expected) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        const int last = (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == expected) ? 1 : 0;
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // buffer_inv sc1: this CU's L1 and the XCD's L2 hold nothing stale of what the others published
+        *sFlag = last;
+    }
     __syncthreads();
     return *sFlag != 0;
 }
@@ -322,7 +346,7 @@ __global__ void __launch_bounds__(64) k_cf_select_pick(const CfArgs* __restrict_
 // keepA(j) = size <= threshold (CanvasClean.cs:349-352); RemoveOutliers (:387-413) looks at the neighbours in the list RemoveBigBins left, i.e. at the nearest
 // bins on either side that pass keepA.  Also the range check of gc / chr, the count after the size filter, and the block counts of the compaction.
 // A thread takes four consecutive bins per round (16-byte loads; the neighbours inside the quad stay in registers, only the quad's outer neighbours are looked up in LDS).
-#define CF_OFF 4             // LDS slot of the block's first bin: slot CF_OFF - 1 = the bin in front of the block, slot CF_OFF + L = the bin behind it
+#define CF_OFF 8             // LDS slot of the block's first bin: slot CF_OFF - 1 = the bin in front of the block, slot CF_OFF + L = the bin behind it
 // the last workgroup of k_cf_flags_ab (256 threads): totals, RemoveBinsWithExtremeGC decision (CanvasClean.cs:207-237) and what follows from it, counting-select set-up
 __device__ __forceinline__ void cf_decide_gc(const CfArgs& A) {
     __shared__ unsigned long long sh16[16];
@@ -331,15 +355,29 @@ __device__ __forceinline__ void cf_decide_gc(const CfArgs& A) {
     __shared__ long long sv[33];
     CleanDev* __restrict__ D = A.D; const uint32_t flags = A.flags; const int minBinsPerGc = A.minBinsPerGc;
     const int t = threadIdx.x;
-    // ---- bins after both filters / after RemoveBigBins alone: the two halves of the block counts
+    // ---- everything this workgroup reads from the others is requested first (one round of memory latency): block counts, GC counter replicas, the 33 sample counts
     unsigned long long mineT = 0;
-    for (int j = t; j < A.nb; j += 256) mineT += cf_ld(&A.dBlk[j]);
+    for (int j0 = t; j0 < A.nb; j0 += 8 * 256) {
+        unsigned long long part[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int j = j0 + u * 256; part[u] = j < A.nb ? cf_ld(&A.dBlk[j]) : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) mineT += part[u];
+    }
+    uint32_t cr[CF_HREP]; uint32_t hA = 0, hO = 0;
+#pragma unroll
+    for (int r = 0; r < CF_HREP; r++) { cr[r] = 0; if (t < NGC) { cr[r] = cf_ld(&A.repl[r * (2 * NGC) + t]); hO += cf_ld(&A.repl[r * (2 * NGC) + NGC + t]); } }
+    float sampleCount = 0.0f; bool haveSample = false;
+    if (A.useCq && t < 33) { const int64_t i = (int64_t)((double)A.n * (t + 0.5) / 33.0); if (i < A.n) { sampleCount = as_global(A.caller.count)[i]; haveSample = true; } }
+#pragma unroll
+    for (int r = 0; r < CF_HREP; r++) hA += cr[r];
+    // ---- bins after both filters / after RemoveBigBins alone: the two halves of the block counts
+    CF_STAMP(7);
     const unsigned long long tot = cf_block_sum_u64(mineT, sh16);
+    CF_STAMP(8);
     const long long nAB = (long long)(tot & 0xFFFFFFFFull);
     if (t == 0) { D->nAB = (unsigned long long)nAB; D->nA = (unsigned int)(tot >> 32); }
     // ---- GC histogram of the survivors (sum of the replicas)
-    uint32_t hA = 0, hO = 0;
-    if (t < NGC) for (int r = 0; r < CF_HREP; r++) { hA += cf_ld(&A.repl[r * (2 * NGC) + t]); hO += cf_ld(&A.repl[r * (2 * NGC) + NGC + t]); }
     if (t < NGC) { D->hist[t] = hA; D->hist[NGC + t] = hO; }
     // the counts are integers below 2^32 and there are 101 of them: their double sum (CanvasClean.cs:219-222) is exact in any order
     uint32_t totalA; (void)cf_excl_scan256(hA, shA, &totalA);
@@ -359,7 +397,8 @@ __device__ __forceinline__ void cf_decide_gc(const CfArgs& A) {
         D->keepGc[t] = kp ? 1 : 0; D->medians[t] = 0.0; D->segOff[t] = active ? soff : 0u; so[t] = active ? soff : 0u;
         // the bucket's stretch of the grouped keys is filled replica by replica (the order inside a bucket is irrelevant: only order statistics are taken from it)
         uint32_t at = soff;
-        for (int r = 0; r < CF_HREP; r++) { const uint32_t c = cf_ld(&A.repl[r * (2 * NGC) + t]); A.repl[CF_HREP * (2 * NGC) + r * NGC + t] = at; at += c; }
+#pragma unroll
+        for (int r = 0; r < CF_HREP; r++) { A.repl[CF_HREP * (2 * NGC) + r * NGC + t] = at; at += cr[r]; }
     }
     const long long sKept = active ? kept : nAB;
     // NormalizeVarianceByGC runs for whole-genome samples only (CanvasClean.cs:512-519); the host enqueues its kernels when the INPUT has more than 500000 bins
@@ -369,6 +408,7 @@ __device__ __forceinline__ void cf_decide_gc(const CfArgs& A) {
         so[NGC] = active ? totalKept : 0u;
         D->segOff[NGC] = active ? totalKept : 0u; D->kept = sKept; D->gcActive = active ? 1 : 0; D->changed = 0; D->varActive = varActive ? 1 : 0;
     }
+    CF_STAMP(9);
     if (!A.useCq) return;
     // ---- counting selects: window, sweep tiles and the marker / ranks the later kernels look at
     __syncthreads();
@@ -376,7 +416,7 @@ __device__ __forceinline__ void cf_decide_gc(const CfArgs& A) {
     const uint32_t total = so[NGC];
     if (!active || total == 0) return;                       // hdr[] and ntiles stay 0 (k_cf_init)
     // the sample's level: the middle one of 33 strided counts of the input that are two-decimal values (any estimate is correct: the window only decides whether the counters suffice)
-    if (t < 33) { const int64_t i = (int64_t)((double)A.n * (t + 0.5) / 33.0); long long k = -1; if (i < A.n && !cq_key(as_global(A.caller.count)[i], k)) k = -1; sv[t] = k; }
+    if (t < 33) { long long k = -1; if (haveSample && !cq_key(sampleCount, k)) k = -1; sv[t] = k; }
     __syncthreads();
     if (t < 33) {                                            // every lane ranks its own sample among the valid ones; the one in the middle sets the window
         const long long mineK = sv[t];
@@ -393,18 +433,16 @@ __device__ __forceinline__ void cf_decide_gc(const CfArgs& A) {
         C->ntiles = totT;
         P1->hdr[0] = 0; P1->hdr[1] = 1;                      // "NormalizeByGC has been decided" for k_cf_scatter_final / k_cf_apply_gc
         P2->hdr[0] = 0; P2->hdr[1] = 0;
-        if (varActive) {                                     // the genome's quartile ranks (weighted count + resolve in k_cf_pick_mad)
-            const QuartIdx qi = quartile_indices((int64_t)total);
-            for (int k = 0; k < qi.n; k++) { P2->qk[k] = (unsigned long long)qi.idx[k]; P2->qprefix[k] = 0ull; }
-            P2->hdr[1] = (uint32_t)qi.n; P2->first[NGC] = 0;
-        }
+        if (varActive) { P2->hdr[1] = (uint32_t)quart_n((int64_t)total); P2->first[NGC] = 0; }
     }
+    // the genome's quartile ranks (weighted count + resolve in k_cf_pick_mad), one thread each
+    if (varActive && t < quart_n((int64_t)total)) { P2->qk[t] = (unsigned long long)quart_idx((int64_t)total, t); P2->qprefix[t] = 0ull; }
 }
 __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ AA) {
     CF_SAMPLE;
     __shared__ uint32_t sh[8];
-    // keepA, chromosome and count of this block's bins and of the bin on either side of it.  The neighbour search below runs on these slots with 32-bit indices; it
-    // leaves them only when the halo bin itself fails the size filter (slow path, global memory).
+    // keepA, chromosome and count of this block's bins and of the bin on either side of it, for the neighbour searches that leave a thread's own eight bins; the search
+    // leaves these slots only when the halo bin itself fails the size filter (slow path, global memory).
     __shared__ __attribute__((aligned(16))) uint8_t sA[CBLK + 2 * CF_OFF];
     __shared__ __attribute__((aligned(16))) int32_t sChr[CBLK + 2 * CF_OFF];
     __shared__ __attribute__((aligned(16))) float sCnt[CBLK + 2 * CF_OFF];
@@ -415,6 +453,7 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
     const int64_t base = (int64_t)blockIdx.x * CBLK;
     if (base >= n) return;
     const int L = (int)min<int64_t>(CBLK, n - base);
+    if (blockIdx.x == 0) CF_STAMP(0);
     if (threadIdx.x < 2 * NGC) lh[threadIdx.x] = 0;
     const gptr<const uint8_t> isAuto = as_global(A.isAuto);         // (pointers out of the argument table: converted so that the accesses are global_load, not flat_load)
     const GSoa in = as_global(A.caller);
@@ -425,37 +464,42 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
     const int32_t thresh = doSize ? D->sizeThresh : 0;
     sAuto[threadIdx.x] = (int)threadIdx.x < nchr ? isAuto[threadIdx.x] : 0;
     const bool vec = ((((uintptr_t)A.caller.chr | (uintptr_t)A.caller.start | (uintptr_t)A.caller.stop | (uintptr_t)A.caller.gc | (uintptr_t)A.caller.count) & 15) == 0);
-    uint32_t nKeep = 0, nSize = 0, bad = 0;
-    int32_t rc[CBLK / 1024][4], rg[CBLK / 1024][4]; float rv[CBLK / 1024][4]; uint8_t ra[CBLK / 1024][4];
+    uint32_t nSize = 0, bad = 0;
+    // ---- eight consecutive bins per thread (two 16-byte loads per column, all in flight together)
+    const int li0 = 8 * (int)threadIdx.x;
+    int32_t rc[8], rg[8], sz[8]; float rv[8];
+    if (vec && li0 + 7 < L) {
+        const int64_t i = base + li0;
 #pragma unroll
-    for (int r = 0; r < CBLK / 1024; r++) {
-        const int li0 = r * 1024 + 4 * (int)threadIdx.x;
-        int32_t s4[4], e4[4];
-        if (vec && li0 + 3 < L) {
-            const int64_t i = base + li0;
-            const uint4 c = gload_uint4(chr + i), g = gload_uint4(gc + i), s = gload_uint4(start + i), e = gload_uint4(stop + i), v = gload_uint4(count + i);
-            rc[r][0] = (int32_t)c.x; rc[r][1] = (int32_t)c.y; rc[r][2] = (int32_t)c.z; rc[r][3] = (int32_t)c.w;
-            rg[r][0] = (int32_t)g.x; rg[r][1] = (int32_t)g.y; rg[r][2] = (int32_t)g.z; rg[r][3] = (int32_t)g.w;
-            s4[0] = (int32_t)s.x; s4[1] = (int32_t)s.y; s4[2] = (int32_t)s.z; s4[3] = (int32_t)s.w;
-            e4[0] = (int32_t)e.x; e4[1] = (int32_t)e.y; e4[2] = (int32_t)e.z; e4[3] = (int32_t)e.w;
-            rv[r][0] = __uint_as_float(v.x); rv[r][1] = __uint_as_float(v.y); rv[r][2] = __uint_as_float(v.z); rv[r][3] = __uint_as_float(v.w);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                rc[r][e] = -1; rg[r][e] = 0; rv[r][e] = 0.0f; s4[e] = 1; e4[e] = 0;
-                if (li0 + e < L) { const int64_t i = base + li0 + e; rc[r][e] = chr[i]; rg[r][e] = gc[i]; rv[r][e] = count[i]; s4[e] = start[i]; e4[e] = stop[i]; }
-            }
+        for (int h = 0; h < 2; h++) {
+            const uint4 c = gload_uint4(chr + i + 4 * h), g = gload_uint4(gc + i + 4 * h), s = gload_uint4(start + i + 4 * h), e = gload_uint4(stop + i + 4 * h), v = gload_uint4(count + i + 4 * h);
+            rc[4 * h] = (int32_t)c.x; rc[4 * h + 1] = (int32_t)c.y; rc[4 * h + 2] = (int32_t)c.z; rc[4 * h + 3] = (int32_t)c.w;
+            rg[4 * h] = (int32_t)g.x; rg[4 * h + 1] = (int32_t)g.y; rg[4 * h + 2] = (int32_t)g.z; rg[4 * h + 3] = (int32_t)g.w;
+            sz[4 * h] = (int32_t)e.x - (int32_t)s.x; sz[4 * h + 1] = (int32_t)e.y - (int32_t)s.y; sz[4 * h + 2] = (int32_t)e.z - (int32_t)s.z; sz[4 * h + 3] = (int32_t)e.w - (int32_t)s.w;
+            rv[4 * h] = __uint_as_float(v.x); rv[4 * h + 1] = __uint_as_float(v.y); rv[4 * h + 2] = __uint_as_float(v.z); rv[4 * h + 3] = __uint_as_float(v.w);
         }
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const bool in = li0 + e < L;
-            if (in && ((uint32_t)rg[r][e] > 100u || (uint32_t)rc[r][e] >= (uint32_t)nchr)) bad = 1;
-            ra[r][e] = (in && (!doSize || (e4[e] - s4[e]) <= thresh)) ? 1 : 0;
-            nSize += ra[r][e];
+        for (int e = 0; e < 8; e++) {
+            rc[e] = -1; rg[e] = 0; rv[e] = 0.0f; sz[e] = 0;
+            if (li0 + e < L) { const int64_t i = base + li0 + e; rc[e] = chr[i]; rg[e] = gc[i]; rv[e] = count[i]; sz[e] = stop[i] - start[i]; }
         }
-        *reinterpret_cast<uint32_t*>(&sA[CF_OFF + li0]) = (uint32_t)ra[r][0] | ((uint32_t)ra[r][1] << 8) | ((uint32_t)ra[r][2] << 16) | ((uint32_t)ra[r][3] << 24);
-        *reinterpret_cast<int4*>(&sChr[CF_OFF + li0]) = make_int4(rc[r][0], rc[r][1], rc[r][2], rc[r][3]);
-        *reinterpret_cast<float4*>(&sCnt[CF_OFF + li0]) = make_float4(rv[r][0], rv[r][1], rv[r][2], rv[r][3]);
+    }
+    uint32_t aM = 0;                                      // bit e: bin li0 + e exists and passes the size filter
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const bool in = li0 + e < L;
+        if (in && ((uint32_t)rg[e] > 100u || (uint32_t)rc[e] >= (uint32_t)nchr)) bad = 1;
+        if (in && (!doSize || sz[e] <= thresh)) aM |= 1u << e;
+    }
+    nSize = (uint32_t)__builtin_popcount(aM);
+    {
+        unsigned long long a8 = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) a8 |= (unsigned long long)((aM >> e) & 1u) << (8 * e);
+        *reinterpret_cast<unsigned long long*>(&sA[CF_OFF + li0]) = a8;
+        *reinterpret_cast<int4*>(&sChr[CF_OFF + li0]) = make_int4(rc[0], rc[1], rc[2], rc[3]); *reinterpret_cast<int4*>(&sChr[CF_OFF + li0 + 4]) = make_int4(rc[4], rc[5], rc[6], rc[7]);
+        *reinterpret_cast<float4*>(&sCnt[CF_OFF + li0]) = make_float4(rv[0], rv[1], rv[2], rv[3]); *reinterpret_cast<float4*>(&sCnt[CF_OFF + li0 + 4]) = make_float4(rv[4], rv[5], rv[6], rv[7]);
     }
     const bool hasLeft = base > 0, hasRight = base + L < n;
     if (threadIdx.x < 2) {
@@ -466,67 +510,75 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
         sA[slot] = a; sChr[slot] = c; sCnt[slot] = v;
     }
     __syncthreads();
+    if (blockIdx.x == 0) CF_STAMP(1);
+    // ---- RemoveOutliers (CanvasClean.cs:387-413) on the list RemoveBigBins left: a bin is compared with the nearest bins on either side that pass the size filter.
+    // keep = okPrev || okNext || (no neighbour at all), ok = same chromosome && !SignificantlyDifferent; the test is symmetric in its two counts, so a pair of
+    // neighbours inside the thread's eight bins is evaluated ONCE (it is the left bin's next-test and the right bin's prev-test): nine divisions per thread, not sixteen
+    uint32_t keepM = aM;
+    if (doOutlier && aM) {
+        uint32_t hasPrevM = 0, okPM = 0, hasNextM = 0, okNM = 0;
+        int pe = -1; int32_t cpv = 0; float vpv = 0.0f;       // the previous bin of this thread that passes the size filter
 #pragma unroll
-    for (int r = 0; r < CBLK / 1024; r++) {
-        const int li0 = r * 1024 + 4 * (int)threadIdx.x;
-        uint32_t packed = 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int li = li0 + e;
-            if (li >= L) continue;
-            const int s = li + CF_OFF;
-            bool keep = ra[r][e] != 0;
-            const int32_t c = rc[r][e];
-            if (keep && doOutlier) {
-                // nearest bins on either side that pass the size filter (RemoveOutliers runs on the list RemoveBigBins left, CanvasClean.cs:387-413)
-                bool hasPrev, hasNext; int32_t cp = -1, cq = -1; float vp = 0.0f, vq = 0.0f;
-                if (e > 0 && ra[r][e > 0 ? e - 1 : 0]) { hasPrev = true; cp = rc[r][e > 0 ? e - 1 : 0]; vp = rv[r][e > 0 ? e - 1 : 0]; }
-                else {
-                    int ps = s - 1;
-                    while (ps >= CF_OFF && !sA[ps]) ps--;
-                    if (ps >= CF_OFF || !hasLeft || sA[CF_OFF - 1]) { hasPrev = ps >= CF_OFF || hasLeft; if (hasPrev) { cp = sChr[ps]; vp = sCnt[ps]; } }
-                    else {                                    // the bin in front of the block fails the size filter too: keep looking in global memory
-                        int64_t p = base - 2;
-                        while (p >= 0 && (stop[p] - start[p]) > thresh) p--;
-                        hasPrev = p >= 0; if (hasPrev) { cp = chr[p]; vp = count[p]; }
-                    }
+        for (int e = 0; e < 8; e++) {
+            if (!((aM >> e) & 1u)) continue;
+            if (pe >= 0) {
+                hasPrevM |= 1u << e; hasNextM |= 1u << pe;
+                if (cpv == rc[e] && !sig_diff(rv[e], vpv)) { okPM |= 1u << e; okNM |= 1u << pe; }
+            } else {
+                int ps = CF_OFF + li0 + e - 1;
+                while (ps >= CF_OFF && !sA[ps]) ps--;
+                bool hasPrev; int32_t cp = -1; float vp = 0.0f;
+                if (ps >= CF_OFF || !hasLeft || sA[CF_OFF - 1]) { hasPrev = ps >= CF_OFF || hasLeft; if (hasPrev) { cp = sChr[ps]; vp = sCnt[ps]; } }
+                else {                                    // the bin in front of the block fails the size filter too: keep looking in global memory
+                    int64_t p = base - 2;
+                    while (p >= 0 && (stop[p] - start[p]) > thresh) p--;
+                    hasPrev = p >= 0; if (hasPrev) { cp = chr[p]; vp = count[p]; }
                 }
-                if (e < 3 && li + 1 < L && ra[r][e < 3 ? e + 1 : 3]) { hasNext = true; cq = rc[r][e < 3 ? e + 1 : 3]; vq = rv[r][e < 3 ? e + 1 : 3]; }
-                else {
-                    int qs = s + 1;
-                    while (qs < CF_OFF + L && !sA[qs]) qs++;
-                    if (qs < CF_OFF + L || !hasRight || sA[CF_OFF + L]) { hasNext = qs < CF_OFF + L || hasRight; if (hasNext) { cq = sChr[qs]; vq = sCnt[qs]; } }
-                    else {
-                        int64_t q = base + L + 1;
-                        while (q < n && (stop[q] - start[q]) > thresh) q++;
-                        hasNext = q < n; if (hasNext) { cq = chr[q]; vq = count[q]; }
-                    }
-                }
-                const bool prevSame = hasPrev && cp == c, nextSame = hasNext && cq == c;
-                if ((hasPrev && !prevSame) && (hasNext && !nextSame)) keep = false;
-                else {
-                    const float v = rv[r][e];
-                    keep = (prevSame && !sig_diff(v, vp)) || (nextSame && !sig_diff(v, vq)) || (!hasPrev && !hasNext);
-                }
+                if (hasPrev) { hasPrevM |= 1u << e; if (cp == rc[e] && !sig_diff(rv[e], vp)) okPM |= 1u << e; }
             }
-            packed |= (keep ? 1u : 0u) << (8 * e);
-            nKeep += keep;
-            if (keep) {                                       // out-of-range input is reported through D->bad and nothing is returned: clamped here so that no table is overrun
-                const int32_t cc = (uint32_t)c >= (uint32_t)nchr ? 0 : c;
+            pe = e; cpv = rc[e]; vpv = rv[e];
+        }
+        {   // the last of them looks to the right of the thread's bins
+            int qs = CF_OFF + li0 + pe + 1;
+            while (qs < CF_OFF + L && !sA[qs]) qs++;
+            bool hasNext; int32_t cq = -1; float vq = 0.0f;
+            if (qs < CF_OFF + L || !hasRight || sA[CF_OFF + L]) { hasNext = qs < CF_OFF + L || hasRight; if (hasNext) { cq = sChr[qs]; vq = sCnt[qs]; } }
+            else {
+                int64_t q = base + L + 1;
+                while (q < n && (stop[q] - start[q]) > thresh) q++;
+                hasNext = q < n; if (hasNext) { cq = chr[q]; vq = count[q]; }
+            }
+            if (hasNext) { hasNextM |= 1u << pe; if (cq == cpv && !sig_diff(vpv, vq)) okNM |= 1u << pe; }
+        }
+        keepM = aM & (okPM | okNM | ~(hasPrevM | hasNextM));
+    }
+    const uint32_t nKeepT = (uint32_t)__builtin_popcount(keepM);
+    {
+        unsigned long long f8 = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t k = (keepM >> e) & 1u;
+            f8 |= (unsigned long long)k << (8 * e);
+            if (k) {                                          // out-of-range input is reported through D->bad and nothing is returned: clamped here so that no table is overrun
+                const int32_t cc = (uint32_t)rc[e] >= (uint32_t)nchr ? 0 : rc[e];
                 const uint8_t au = cc < 256 ? sAuto[cc] : isAuto[cc];
-                atomicAdd(&lh[(au ? 0 : NGC) + ((uint32_t)rg[r][e] > 100u ? 100 : rg[r][e])], 1u);
+                atomicAdd(&lh[(au ? 0 : NGC) + ((uint32_t)rg[e] > 100u ? 100 : rg[e])], 1u);
             }
         }
-        if (li0 + 3 < L) *reinterpret_cast<gptr<uint32_t>>(flags + base + li0) = packed;
-        else for (int e = 0; e < 4; e++) if (li0 + e < L) flags[base + li0 + e] = (uint8_t)((packed >> (8 * e)) & 1u);
+        if (li0 + 7 < L) *reinterpret_cast<gptr<unsigned long long>>(flags + base + li0) = f8;
+        else for (int e = 0; e < 8; e++) if (li0 + e < L) flags[base + li0 + e] = (uint8_t)((f8 >> (8 * e)) & 1ull);
     }
-    nKeep = wave_reduce_add_u32(nKeep); nSize = wave_reduce_add_u32(nSize);
+    if (blockIdx.x == 0) CF_STAMP(2);
+    uint32_t nKeep = wave_reduce_add_u32(nKeepT); nSize = wave_reduce_add_u32(nSize);
     if (lane_id() == 0) { sh[threadIdx.x >> 6] = nKeep; sh[4 + (threadIdx.x >> 6)] = nSize; }
     if (bad) D->bad = 1u;
     __syncthreads();
     if (threadIdx.x == 0) cf_st(&A.dBlk[blockIdx.x], (unsigned long long)(sh[0] + sh[1] + sh[2] + sh[3]) | ((unsigned long long)(sh[4] + sh[5] + sh[6] + sh[7]) << 32));
     if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&A.repl[(blockIdx.x % CF_HREP) * (2 * NGC) + threadIdx.x], lh[threadIdx.x]);
-    if (cf_arrive_last(A.tick + 1, (uint32_t)A.nb, &sLast)) cf_decide_gc(A);
+    if (blockIdx.x == 0) CF_STAMP(3);
+    const bool last = cf_arrive_last(A.tick + 1, (uint32_t)A.nb, &sLast);
+    if (blockIdx.x == 0) CF_STAMP(4);
+    if (last) { CF_STAMP(5); cf_decide_gc(A); __syncthreads(); CF_STAMP(6); }
 }
 // sum of the counts of the blocks in front of this one (every workgroup of a scatter kernel does this for itself: the counts are a few KB in L2, and the stage has no
 // scan kernel); lo32: the counts are the low halves of 64-bit records
@@ -679,12 +731,28 @@ __global__ void __launch_bounds__(1024) k_cf_hist_lsd(const CfArgs* __restrict__
         const int64_t lo = w * 20, hi = w < nW ? lo + 20 : nAB;         // thread nW takes the tail (bins behind the last window: CountDeviation stays -1, GenomicBin.cs:83)
         const GSoa1 S1 = as_global(A.S1);
         if (w < nW) {
-            // Utilities.StandardDeviation(double[], start, end) (Utilities.cs:246-262): sequential double arithmetic
+            // Utilities.StandardDeviation(double[], start, end) (Utilities.cs:246-262): sequential double arithmetic.  The window's 20 counts and chromosomes are five
+            // 16-byte loads each (lo is a multiple of 20 and the scratch arrays are 256-byte aligned), all in flight together; the bin in front of the window and
+            // the one behind it are two more
             const gptr<const float> count = S1.count;
-            double d[20];
-            float prev = count[lo];
+            float x[21];
 #pragma unroll
-            for (int k = 0; k < 20; k++) { const float nx = count[lo + k + 1]; d[k] = (double)(nx - prev); prev = nx; }
+            for (int q = 0; q < 5; q++) { const uint4 v4 = gload_uint4(count + lo + 4 * q); x[4 * q] = __uint_as_float(v4.x); x[4 * q + 1] = __uint_as_float(v4.y); x[4 * q + 2] = __uint_as_float(v4.z); x[4 * q + 3] = __uint_as_float(v4.w); }
+            x[20] = count[lo + 20];
+            int32_t cw[21];
+            cw[0] = lo > 0 ? S1.chr[lo - 1] : -1;
+#pragma unroll
+            for (int q = 0; q < 5; q++) { const uint4 v4 = gload_uint4(S1.chr + lo + 4 * q); cw[4 * q + 1] = (int32_t)v4.x; cw[4 * q + 2] = (int32_t)v4.y; cw[4 * q + 3] = (int32_t)v4.z; cw[4 * q + 4] = (int32_t)v4.w; }
+#pragma unroll
+            for (int k = 0; k < 20; k++) {
+                if (lo + k == 0 || cw[k + 1] != cw[k]) {
+                    const unsigned int at = atomicAdd(&A.D->nRunRec, 1u);
+                    if (at < 65536u) cf_st(reinterpret_cast<unsigned long long*>(A.dPos + at), (unsigned long long)(((lo + k) << 20) | (long long)(cw[k + 1] & 0xFFFFF)));
+                }
+            }
+            double d[20];
+#pragma unroll
+            for (int k = 0; k < 20; k++) d[k] = (double)(x[k + 1] - x[k]);
             double sum = 0;
 #pragma unroll
             for (int k = 0; k < 20; k++) sum += d[k];
@@ -696,7 +764,7 @@ __global__ void __launch_bounds__(1024) k_cf_hist_lsd(const CfArgs* __restrict__
         }
         const gptr<const int32_t> chr = S1.chr;
         int32_t prevC = lo > 0 ? chr[lo - 1] : -1;
-        for (int64_t i = lo; i < hi; i++) {
+        if (w == nW) for (int64_t i = lo; i < hi; i++) {                  // the tail behind the last window (the windows did their own bins above)
             const int32_t c = chr[i];
             if (i == 0 || c != prevC) { const unsigned int k = atomicAdd(&A.D->nRunRec, 1u); if (k < 65536u) cf_st(reinterpret_cast<unsigned long long*>(A.dPos + k), (unsigned long long)((i << 20) | (long long)(c & 0xFFFFF))); }
             prevC = c;
@@ -706,118 +774,182 @@ __global__ void __launch_bounds__(1024) k_cf_hist_lsd(const CfArgs* __restrict__
 }
 
 // ---------------------------------------------------------------- k_cf_pick_mad: order statistics from the counters | median and MAD of the window SDs per chromosome run
-// Exact order statistics r0 <= r1 of up to MAD_REG x 1024 values held in registers (or streamed from memory), inside one 1024-thread workgroup.  The keys of a run share
-// their leading bits (window SDs of one chromosome lie within a few binades), so (1) an AND / OR reduction finds the common prefix, (2) 8-bit radix passes run below it
-// only until both ranks have at most MAD_CAND candidates left — two passes for 20 000 values — and (3) the candidates are ranked against each other in LDS.
-// (Round 2 ran eight full passes per select, the first of them with all 1024 threads adding to one or two LDS counters: 89 us for chr1.)
-#define MAD_REG 24
+// Exact order statistics r0 <= r1 of up to MAD_REG x 1024 values held in registers (or streamed from memory), inside one 1024-thread workgroup: MSB radix passes that stop
+// as soon as both ranks have at most MAD_CAND candidates left, which are then ranked against each other in LDS.  The first digit is sign + exponent (12 bits): the window SDs
+// of a chromosome — and their absolute deviations — sit in a handful of binades, so that pass separates them whatever outliers (an all-zero window, a copy-number edge)
+// the run holds, and because its digits are that concentrated a wave first adds them up with ballots (one LDS atomic per distinct digit and wave); the second digit
+// (8 mantissa bits) is spread and usually ends the search: two counting sweeps + one collecting sweep per select.
+// (Round 2 ran eight full 8-bit passes per select with every thread adding to one or two LDS counters in the exponent passes: 89 us for chr1.)
+#define MAD_REG 20
 #define MAD_CAND 256
-struct MadShared { uint32_t sH[2][256]; unsigned long long sPre[2], sK[2], sRed[2][16], sCand[2][MAD_CAND]; uint32_t sCnt[2], sNc[2]; };
-template <class KeyFn>
-__device__ __forceinline__ void wg_select2_fast(KeyFn forEachKey /* (callback(key)) */, int64_t cnt, unsigned long long rank0, unsigned long long rank1, MadShared& S, unsigned long long* out /* [2], thread 0 */) {
+#define MAD_BITS0 12
+struct MadShared { uint32_t sH[2][1 << MAD_BITS0]; unsigned long long sPre[2], sK[2], sCand[2][MAD_CAND]; uint32_t sCnt[2], sNc[2], sScan[2][16]; };
+template <class KeyFn, class Pass0Fn>
+__device__ __forceinline__ void wg_select2_fast(KeyFn forEachKey /* (callback(key)) */, Pass0Fn pass0 /* (hist, shift) -> true if it counted the first digit itself */, int64_t cnt, unsigned long long rank0, unsigned long long rank1, MadShared& S, unsigned long long* out /* [2], LDS */, unsigned long long* dbg = nullptr) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    // (1) common prefix
-    unsigned long long a = ~0ull, o = 0ull;
-    forEachKey([&](unsigned long long key) { a &= key; o |= key; });
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
     __syncthreads();
-    if (l == 0) { S.sRed[0][w] = a; S.sRed[1][w] = o; }
-    __syncthreads();
-    a = ~0ull; o = 0ull;
-    for (int k = 0; k < 16; k++) { a &= S.sRed[0][k]; o |= S.sRed[1][k]; }
-    const unsigned long long diff = a ^ o;
-    if (diff == 0ull) { if (tid == 0) { out[0] = a; out[1] = a; } return; }          // all keys equal
-    const int sh0 = __builtin_clzll(diff);                                             // keys' = key << sh0: order kept among keys that share the prefix
     if (tid == 0) { S.sPre[0] = 0; S.sPre[1] = 0; S.sK[0] = rank0; S.sK[1] = rank1; S.sCnt[0] = S.sCnt[1] = (uint32_t)min<int64_t>(cnt, 0xFFFFFFFFll); }
     __syncthreads();
-    int passes = 0;
-    for (int shift = 56; shift >= 0; shift -= 8) {
+    int done = 0;                                                                      // leading bits of the answers that are known
+    unsigned long long p0 = 0, p1 = 0;
+    for (int pass = 0; done < 64; pass++) {
+        p0 = S.sPre[0]; p1 = S.sPre[1];
+        const unsigned long long k0 = S.sK[0], k1 = S.sK[1];
         if (S.sCnt[0] <= MAD_CAND && S.sCnt[1] <= MAD_CAND) break;
-        for (int i = tid; i < 512; i += 1024) S.sH[i >> 8][i & 255] = 0;
-        __syncthreads();
-        const unsigned long long p0 = S.sPre[0], p1 = S.sPre[1];
+        const int bits = pass == 0 ? MAD_BITS0 : min(10, 64 - done), shift = 64 - done - bits, nb = 1 << bits;
         const bool same = p0 == p1;
-        forEachKey([&](unsigned long long key0) {
-            const unsigned long long key = key0 << sh0;
-            const uint32_t dgt = (uint32_t)(key >> shift) & 255u;
-            const unsigned long long hiPart = shift == 56 ? 0ull : key >> (shift + 8);
-            if (hiPart == p0) atomicAdd(&S.sH[0][dgt], 1u);
-            if (!same && hiPart == p1) atomicAdd(&S.sH[1][dgt], 1u);
-        });
+        for (int i = tid; i < 2 * nb; i += 1024) S.sH[i >= nb ? 1 : 0][i & (nb - 1)] = 0;
         __syncthreads();
-        if (w < 2) {
-            const uint32_t* h = S.sH[same ? 0 : w];
-            const uint32_t c0 = h[4 * l], c1 = h[4 * l + 1], c2 = h[4 * l + 2], c3 = h[4 * l + 3];
-            const uint32_t sum = c0 + c1 + c2 + c3;
-            const uint32_t inc = wave_inclusive_scan_u32(sum), ex = inc - sum;
-            const unsigned long long k = S.sK[w];
-            if (k >= ex && k < inc) {
-                uint32_t r = (uint32_t)(k - ex), dgt, c;
-                if (r < c0) { dgt = 0; c = c0; } else if (r < c0 + c1) { dgt = 1; r -= c0; c = c1; } else if (r < c0 + c1 + c2) { dgt = 2; r -= c0 + c1; c = c2; } else { dgt = 3; r -= c0 + c1 + c2; c = c3; }
-                S.sPre[w] = (S.sPre[w] << 8) | (unsigned long long)(4 * l + dgt);
-                S.sK[w] = r; S.sCnt[w] = c;
+        if (pass == 0 && pass0(S.sH[0], shift)) {
+        } else if (pass == 0) {
+            forEachKey([&](unsigned long long key) {
+                const uint32_t dgt = (uint32_t)(key >> shift);
+                unsigned long long todo = __ballot(1);
+#pragma unroll 1
+                for (int it = 0; it < 6 && todo; it++) {
+                    const int leader = __builtin_ctzll(todo);
+                    const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)dgt, leader);
+                    const unsigned long long eq = __ballot(dgt == dl) & todo;
+                    if (l == leader) atomicAdd(&S.sH[0][dl], (uint32_t)__builtin_popcountll(eq));
+                    todo &= ~eq;
+                }
+                if ((todo >> l) & 1ull) atomicAdd(&S.sH[0][dgt], 1u);
+            });
+        } else {
+            forEachKey([&](unsigned long long key) {
+                const uint32_t dgt = (uint32_t)(key >> shift) & (uint32_t)(nb - 1);
+                const unsigned long long hiPart = key >> (64 - done);
+                if (hiPart == p0) atomicAdd(&S.sH[0][dgt], 1u);
+                if (!same && hiPart == p1) atomicAdd(&S.sH[1][dgt], 1u);
+            });
+        }
+        __syncthreads();
+        // the digit that holds each rank: thread t sums bins 4t .. 4t + 3 (the rows are 4 * 1024 bins long at most), block scan, the thread whose stretch covers the rank narrows it
+        uint32_t c[2][4], sum[2], inc[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t* h = S.sH[same ? 0 : q];
+#pragma unroll
+            for (int e = 0; e < 4; e++) c[q][e] = 4 * tid + e < nb ? h[4 * tid + e] : 0u;
+            sum[q] = c[q][0] + c[q][1] + c[q][2] + c[q][3];
+            inc[q] = wave_inclusive_scan_u32(sum[q]);
+            if (l == 63) S.sScan[q][w] = inc[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint32_t woff = 0;
+            for (int ww = 0; ww < w; ww++) woff += S.sScan[q][ww];
+            const uint32_t ex = woff + inc[q] - sum[q];
+            const unsigned long long k = q == 0 ? k0 : k1;
+            if (k >= ex && k < (unsigned long long)ex + sum[q]) {
+                uint32_t r = (uint32_t)(k - ex), dgt, cc;
+                if (r < c[q][0]) { dgt = 0; cc = c[q][0]; } else if (r < c[q][0] + c[q][1]) { dgt = 1; r -= c[q][0]; cc = c[q][1]; }
+                else if (r < c[q][0] + c[q][1] + c[q][2]) { dgt = 2; r -= c[q][0] + c[q][1]; cc = c[q][2]; } else { dgt = 3; r -= c[q][0] + c[q][1] + c[q][2]; cc = c[q][3]; }
+                S.sPre[q] = ((q == 0 ? p0 : p1) << bits) | (unsigned long long)(4 * tid + dgt);
+                S.sK[q] = r; S.sCnt[q] = cc;
             }
         }
-        passes++;
+        done += bits;
         __syncthreads();
+        if (dbg && tid == 0) dbg[pass] = wall_clock64();
     }
-    if (passes == 8) {                                                                 // every bit resolved (ties heavier than MAD_CAND): the key is the prefix
-        if (tid == 0) {
-            const int hb = 63 - sh0; const unsigned long long lowmask = hb == 63 ? ~0ull : ((1ull << (hb + 1)) - 1ull);
-            out[0] = (a & ~lowmask) | (S.sPre[0] >> sh0); out[1] = (a & ~lowmask) | (S.sPre[1] >> sh0);
-        }
-        return;
-    }
-    // (3) the candidates of both ranks, ranked against each other
+    if (done == 64) { if (tid == 0) { out[0] = S.sPre[0]; out[1] = S.sPre[1]; } return; }      // every bit resolved (ties heavier than MAD_CAND): the prefix is the key
+    // the candidates of both ranks, ranked against each other
+    if (dbg && tid == 0) dbg[8] = wall_clock64();
     if (tid == 0) { S.sNc[0] = 0; S.sNc[1] = 0; }
     __syncthreads();
-    const unsigned long long p0 = S.sPre[0], p1 = S.sPre[1];
     const bool same = p0 == p1;
-    const int top = 64 - 8 * passes;
-    forEachKey([&](unsigned long long key0) {
-        const unsigned long long hiPart = passes == 0 ? 0ull : (key0 << sh0) >> top;
-        if (hiPart == p0) { const uint32_t at = atomicAdd(&S.sNc[0], 1u); if (at < MAD_CAND) S.sCand[0][at] = key0; }
-        if (!same && hiPart == p1) { const uint32_t at = atomicAdd(&S.sNc[1], 1u); if (at < MAD_CAND) S.sCand[1][at] = key0; }
+    forEachKey([&](unsigned long long key) {
+        const unsigned long long hiPart = done == 0 ? 0ull : key >> (64 - done);
+        if (hiPart == p0) { const uint32_t at = atomicAdd(&S.sNc[0], 1u); if (at < MAD_CAND) S.sCand[0][at] = key; }
+        if (!same && hiPart == p1) { const uint32_t at = atomicAdd(&S.sNc[1], 1u); if (at < MAD_CAND) S.sCand[1][at] = key; }
     });
     __syncthreads();
-    for (int q = 0; q < 2; q++) {
-        const int src = same ? 0 : q;
-        const uint32_t nc = min(S.sNc[src], (uint32_t)MAD_CAND);
+    if (dbg && tid == 0) dbg[9] = wall_clock64();
+    for (int q = 0; q < (same ? 1 : 2); q++) {
+        const uint32_t nc = min(S.sNc[q], (uint32_t)MAD_CAND);
         if ((uint32_t)tid < nc) {
-            const unsigned long long mine = S.sCand[src][tid];
+            const unsigned long long mine = S.sCand[q][tid];
             uint32_t less = 0;
-            for (uint32_t j = 0; j < nc; j++) { const unsigned long long ok = S.sCand[src][j]; less += (ok < mine || (ok == mine && j < (uint32_t)tid)) ? 1u : 0u; }
+#pragma unroll 8
+            for (uint32_t j = 0; j < nc; j++) { const unsigned long long ok = S.sCand[q][j]; less += (ok < mine || (ok == mine && j < (uint32_t)tid)) ? 1u : 0u; }
             if ((unsigned long long)less == S.sK[q]) out[q] = mine;
+            if (same && (unsigned long long)less == S.sK[1]) out[1] = mine;
         }
     }
 }
 // median and MAD of the window SDs of chromosome run r (CanvasClean.cs:243-258, Utilities.cs Median / Mad)
 template <bool REG>
-__device__ __forceinline__ void cf_run_mad(const gptr<const double> sd, int64_t lo, int64_t hi, MadShared& S, unsigned long long* sOut /* LDS [2] */, double* outMad) {
+__device__ __forceinline__ void cf_run_mad(const gptr<const double> sd, int64_t lo, int64_t hi, MadShared& S, unsigned long long* sOut /* LDS [2] */, double* outMad, unsigned long long* dbg) {
     const int64_t cnt = hi - lo;
     const unsigned long long r1 = (unsigned long long)(cnt / 2), r0 = (cnt % 2) ? r1 : r1 - 1;
-    double v[MAD_REG];
-    // register flavour: thread t holds the MAD_REG consecutive values from lo + t * MAD_REG on (one address, immediate offsets; the order of the values is irrelevant)
-    const int64_t mine0 = lo + (int64_t)threadIdx.x * MAD_REG;
-    const int nMine = REG ? (int)max<int64_t>(0, min<int64_t>(MAD_REG, hi - mine0)) : 0;
+    // register flavour: thread t holds the KEYS of values lo + t, lo + t + 1024, ...  Only the keys are kept — the value is double_of_key(key) — and the second select rewrites them in place: with the values AND both key sets live
+    // (the compiler hoists the key computations out of the sweeps) the role needed 144 registers, spilled, and every sweep waited for scratch loads.
+    unsigned long long key[MAD_REG];
+    const int64_t mine0 = lo + threadIdx.x;                                           // values mine0 + k * 1024 (coalesced; the order of the values is irrelevant)
+    const int nMine = REG ? (int)max<int64_t>(0, (hi - mine0 + 1023) / 1024) : 0;
     if (REG) {
-        const gptr<const double> p = sd + mine0;
 #pragma unroll
-        for (int k = 0; k < MAD_REG; k++) v[k] = k < nMine ? p[k] : 0.0;
+        for (int k = 0; k < MAD_REG; k++) key[k] = k < nMine ? key_of_double(sd[mine0 + (int64_t)k * 1024]) : 0ull;
     }
-    auto sweep = [&](auto&& fn, auto&& body) {
+    double median = 0.0; bool second = false;
+    auto sweep = [&](auto&& body) {
         if (REG) {
 #pragma unroll
-            for (int k = 0; k < MAD_REG; k++) { if (k < nMine) body(fn(v[k])); }
-        } else for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) body(fn(sd[i]));
+            for (int k = 0; k < MAD_REG; k++) { if (k < nMine) body(key[k]); __builtin_amdgcn_sched_barrier(0); }      // one value at a time: interleaved, the unrolled bodies spill
+        } else if (!second) { for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) body(key_of_double(sd[i])); }
+        else for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) body(key_of_double(fabs(sd[i] - median)));
     };
-    wg_select2_fast([&](auto&& body) { sweep([](double x) { return key_of_double(x); }, body); }, cnt, r0, r1, S, sOut);
+    // first digit (sign + exponent) of the register flavour: a thread counts the values that share the digit of its first one, a wave adds those counts up for the
+    // lanes that agree with its first lane, and only what is left goes to the LDS counters one by one (the digits of a run are a handful of binades: 20 atomics per thread
+    // on two or three LDS words were 12 us per select)
+    auto pass0 = [&](uint32_t* h, int shift) -> bool {
+        if (!REG) return false;
+        const int l = threadIdx.x & 63;
+        // the thread's two most likely digits (the first value's, and the first one that differs from it) are counted in registers
+        const uint32_t d0 = (uint32_t)(key[0] >> shift);
+        uint32_t d1 = d0, c0 = 0, c1 = 0;
+#pragma unroll
+        for (int k = 0; k < MAD_REG; k++) {
+            if (k < nMine) {
+                const uint32_t d = (uint32_t)(key[k] >> shift);
+                if (d == d0) c0++;
+                else { if (d1 == d0) d1 = d; if (d == d1) c1++; else atomicAdd(&h[d], 1u); }
+            }
+        }
+        // ... and added up over the wave for the two digits its first active lane holds
+        const bool active = nMine > 0;
+        const unsigned long long todo = __ballot(active);
+        if (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t da = (uint32_t)__builtin_amdgcn_readlane((int)d0, leader), db = (uint32_t)__builtin_amdgcn_readlane((int)d1, leader);
+            uint32_t ca = 0, cb = 0;
+            if (active) {
+                if (d0 == da) { ca += c0; c0 = 0; } else if (d0 == db) { cb += c0; c0 = 0; }
+                if (c1) { if (d1 == da) { ca += c1; c1 = 0; } else if (d1 == db && db != da) { cb += c1; c1 = 0; } }
+            }
+            ca = wave_reduce_add_u32(ca); cb = wave_reduce_add_u32(cb);
+            if (l == leader) { atomicAdd(&h[da], ca); if (cb) atomicAdd(&h[db], cb); }
+            if (active && c0) atomicAdd(&h[d0], c0);
+            if (active && c1) atomicAdd(&h[d1], c1);
+        }
+        return true;
+    };
+    if (dbg && threadIdx.x == 0) dbg[31] = wall_clock64();
+    wg_select2_fast(sweep, pass0, cnt, r0, r1, S, sOut, dbg ? dbg + 40 : nullptr);
     __syncthreads();
-    const double median = (cnt % 2) ? double_of_key(sOut[1]) : (double_of_key(sOut[0]) + double_of_key(sOut[1])) / 2;
+    if (dbg && threadIdx.x == 0) dbg[32] = wall_clock64();
+    median = (cnt % 2) ? double_of_key(sOut[1]) : (double_of_key(sOut[0]) + double_of_key(sOut[1])) / 2;
+    second = true;
+    if (REG) {
+#pragma unroll
+        for (int k = 0; k < MAD_REG; k++) key[k] = key_of_double(fabs(double_of_key(key[k]) - median));
+    }
     __syncthreads();
-    wg_select2_fast([&](auto&& body) { sweep([median](double x) { return key_of_double(fabs(x - median)); }, body); }, cnt, r0, r1, S, sOut);
+    wg_select2_fast(sweep, pass0, cnt, r0, r1, S, sOut);
     __syncthreads();
+    if (dbg && threadIdx.x == 0) dbg[33] = wall_clock64();
     if (threadIdx.x == 0) cf_st_f64(outMad, (cnt % 2) ? double_of_key(sOut[1]) : (double_of_key(sOut[0]) + double_of_key(sOut[1])) / 2);
     __syncthreads();
 }
@@ -835,7 +967,7 @@ __device__ __forceinline__ double cq_nbin_origin(double globalMedian) { return g
 __device__ __forceinline__ long long cq_nbin(float v, double origin) { return (long long)floor(((double)v - origin) * 100.0); }
 #define CQ_NCAND 1024        // candidates of one bin (a bucket contributes about median / globalMedian slots per bin)
 // ranks[0 .. nr) of a row of CQW counters held 16 consecutive per thread -> sK[q] = the slot that holds rank q.  False (in every thread) when a rank lies outside the window.
-__device__ __forceinline__ bool cq_pick_ranks(const uint32_t (&c)[16], const int64_t* ranks, int nr, int64_t below, uint32_t* swave, long long* sK, int* sFail, uint32_t* inWinOut) {
+__device__ __forceinline__ bool cq_pick_ranks(const uint32_t (&c)[16], const long long* ranks /* LDS */, int nr, int64_t below, uint32_t* swave, long long* sK, int* sFail, uint32_t* inWinOut) {
     const int t = threadIdx.x;
     uint32_t s = 0;
 #pragma unroll
@@ -905,54 +1037,64 @@ __device__ __forceinline__ void cf_resolve_var(const CfArgs& A, uint32_t* lw, ui
         }
     }
     __syncthreads();
-    // ---- the candidates of every bin: per bucket the slots whose normalised value falls into it (keys at lw[q * 2048 + i], weights at lw[q * 2048 + 1024 + i])
+    CF_STAMP(21);
+    // ---- the candidates of every bin: per bucket the slots whose normalised value falls into it (keys at lw[q * 2048 + i], weights at lw[q * 2048 + 1024 + i]);
+    // one thread per (rank, bucket)
     const double globalMedian = cf_ld_f64(&D->globalMedian);
     const long long lo = C->lo;
-    const int64_t cntT = t < NGC ? (int64_t)D->segOff[t + 1] - (int64_t)D->segOff[t] : 0;
-    const double medianT = (t < NGC && cntT > 0) ? cf_ld_f64(&D->medians[t]) : 0.0;
-    if (t < NGC && cntT > 0) {
-        const double origin = cq_nbin_origin(globalMedian);
-        for (int q = 0; q < nq; q++) {
-            const int bin = sBin[q];
-            if (bin < 0) continue;
+    if (t < 6 * NGC) {
+        const int q = t / NGC, bkt = t - q * NGC;
+        const int64_t cntB = (int64_t)D->segOff[bkt + 1] - (int64_t)D->segOff[bkt];
+        const int bin = q < nq ? sBin[q] : -1;
+        if (cntB > 0 && bin >= 0) {
+            const double medianB = cf_ld_f64(&D->medians[bkt]), origin = cq_nbin_origin(globalMedian);
             int a = 0, b = CQW;                           // first slot whose value falls into bin `bin` or a later one
-            while (a < b) { const int mid = (a + b) >> 1; if (cq_nbin(cq_normalised(lo + mid, medianT, globalMedian), origin) < (long long)bin) a = mid + 1; else b = mid; }
+            while (a < b) { const int mid = (a + b) >> 1; if (cq_nbin(cq_normalised(lo + mid, medianB, globalMedian), origin) < (long long)bin) a = mid + 1; else b = mid; }
             for (int j = a; j < CQW; j++) {
-                const float v = cq_normalised(lo + j, medianT, globalMedian);
+                const float v = cq_normalised(lo + j, medianB, globalMedian);
                 if (cq_nbin(v, origin) != (long long)bin) break;
-                const uint32_t w = A.cqHist[(size_t)t * CQW + j];
+                const uint32_t w = A.cqHist[(size_t)bkt * CQW + j];
                 if (w) { const unsigned int at = atomicAdd(&sN[q], 1u); if (at < CQ_NCAND) { lw[q * 2048 + at] = key_of_float(v); lw[q * 2048 + 1024 + at] = w; } else sFailR[q] = 1; }
             }
         }
     }
     __syncthreads();
-    for (int q = 0; q < nq; q++) {
-        if (sBin[q] < 0 || sFailR[q]) continue;          // the rank lies outside the bins, or too many candidates: key 0 makes the decision give the sample up
-        const unsigned int n = sN[q];
-        const uint32_t rq = sR[q];
-        if ((unsigned int)t < n) {                        // the candidate whose weights [less, less + w) cover the rank inside the bin
-            const uint32_t key = lw[q * 2048 + t];
-            unsigned long long less = 0;
-            for (unsigned int o = 0; o < n; o++) { const uint32_t ko = lw[q * 2048 + o]; if (ko < key || (ko == key && o < (unsigned int)t)) less += lw[q * 2048 + 1024 + o]; }
-            if ((unsigned long long)rq >= less && (unsigned long long)rq < less + lw[q * 2048 + 1024 + t]) sKeyOut[q] = key;
+    CF_STAMP(22);
+    {   // the candidate whose weights [less, less + w) cover the rank inside the bin: 170 threads per rank
+        const int q = t / 170, idx = t - q * 170;
+        if (q < nq && sBin[q] >= 0 && !sFailR[q]) {     // (a rank outside the bins, or too many candidates: key 0 makes the decision give the sample up)
+            const unsigned int n = sN[q];
+            const uint32_t rq = sR[q];
+            for (unsigned int i = idx; i < n; i += 170) {
+                const uint32_t key = lw[q * 2048 + i];
+                unsigned long long less = 0;
+#pragma unroll 8
+                for (unsigned int o = 0; o < n; o++) { const uint32_t ko = lw[q * 2048 + o]; if (ko < key || (ko == key && o < i)) less += lw[q * 2048 + 1024 + o]; }
+                if ((unsigned long long)rq >= less && (unsigned long long)rq < less + lw[q * 2048 + 1024 + i]) sKeyOut[q] = key;
+            }
         }
     }
     __syncthreads();
+    CF_STAMP(23);
     if (t < nq) P->qprefix[t] = (unsigned long long)sKeyOut[t];
     // ---- NormalizeVarianceByGC decision from the buckets' k statistics and the genome's keys
     const int64_t total = (int64_t)D->segOff[NGC];
-    const QuartIdx gi = quartile_indices(total);
+    const int64_t cntT = t < NGC ? (int64_t)D->segOff[t + 1] - (int64_t)D->segOff[t] : 0;
+    const double medianT = (t < NGC && cntT > 0) ? cf_ld_f64(&D->medians[t]) : 0.0;
+    const int gn = quart_n(total);
     float gv[6]; uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (int k = 0; k < gi.n; k++) { const uint32_t key = sKeyOut[k]; gv[k] = float_of_key(key); kmin = min(kmin, key); kmax = max(kmax, key); }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { gv[k] = 0.0f; if (k < gn) { const uint32_t key = sKeyOut[k]; gv[k] = float_of_key(key); kmin = min(kmin, key); kmax = max(kmax, key); } }
     float g1, g2, g3;
     quartiles_from_values(total, gv, g1, g2, g3);
     const float globalIQR = g3 - g1;
     if (t < NGC) {
         float liqr = -1.0f, med = -1.0f;
         if (cntT > 0) {
-            const QuartIdx qi = quartile_indices(cntT);
+            const int qn = quart_n(cntT);
             float v[6];
-            for (int k = 0; k < qi.n; k++) v[k] = cq_normalised((long long)cf_ld(&C->kq[t][k]), medianT, globalMedian);
+#pragma unroll
+            for (int k = 0; k < 6; k++) v[k] = k < qn ? cq_normalised((long long)cf_ld(&C->kq[t][k]), medianT, globalMedian) : 0.0f;
             float q1, q2, q3; quartiles_from_values(cntT, v, q1, q2, q3);
             med = q2; liqr = q3 - q1;
             // the genome's answers are right only if every key that was left out of this bucket's window lies on the side it was counted on
@@ -969,12 +1111,36 @@ __device__ __forceinline__ void cf_resolve_var(const CfArgs& A, uint32_t* lw, ui
         D->tab.globalIQR = globalIQR; D->changed = sig > 0 ? 1 : 0;
     }
 }
+// run role of k_cf_pick_mad
+__device__ __forceinline__ void cf_role_mad(const CfArgs* __restrict__ AA, uint32_t* lw, unsigned long long* sOut, int* sLastP, int nPick) {
+    CF_SAMPLE;
+    MadShared& S = *reinterpret_cast<MadShared*>(lw);
+    CleanDev* __restrict__ D = A.D;
+    const int t = threadIdx.x;
+    // ---- run role: median and MAD of the window SDs of runs b, b + CF_MADB, ... (Utilities.Mad per chromosome, CanvasClean.cs:243-258); the last workgroup averages them
+    if (!A.wantLsd) return;
+    const int b = (int)blockIdx.x - nPick, nruns = D->nruns;
+    const gptr<const double> sd = as_global(A.dSd);
+    if (b == 0) CF_STAMP(30);
+    for (int r = b; r < nruns; r += CF_MADB) {
+        const int64_t lo = A.dRunStart[r], hi = A.dRunStart[r + 1], cnt = hi - lo;
+        if (cnt <= 0) { if (t == 0) cf_st_f64(&A.dRunMad[r], 0.0); }
+        else if (cnt <= (int64_t)MAD_REG * 1024) cf_run_mad<true>(sd, lo, hi, S, sOut, &A.dRunMad[r], r == 0 ? A.dbg : nullptr);
+        else cf_run_mad<false>(sd, lo, hi, S, sOut, &A.dRunMad[r], r == 0 ? A.dbg : nullptr);
+    }
+    if (b == 0) CF_STAMP(35);
+    if (!cf_arrive_last(A.tick + 4, (uint32_t)CF_MADB, sLastP) || t != 0) return;
+    if (!D->haveLocalSd) { D->localSd = -1.0; return; }
+    double s = 0;
+    for (int r = 0; r < nruns; r++) s += cf_ld_f64(&A.dRunMad[r]);               // List<double>.Average(): sequential sum / count
+    D->localSd = s / (double)nruns;
+}
 __global__ void __launch_bounds__(1024) k_cf_pick_mad(const CfArgs* __restrict__ AA, int nPick) {
     CF_SAMPLE;
     __shared__ __attribute__((aligned(16))) uint32_t lw[CQW];       // pick role: the weighted count, then the last workgroup's candidate lists; run role: MadShared
     MadShared& S = *reinterpret_cast<MadShared*>(lw);
     __shared__ uint32_t swave[16];
-    __shared__ long long sK[8];
+    __shared__ long long sK[8], sRanks[8];
     __shared__ unsigned long long sOut[2];
     __shared__ int sFail, sLast;
     CleanDev* __restrict__ D = A.D;
@@ -991,27 +1157,30 @@ __global__ void __launch_bounds__(1024) k_cf_pick_mad(const CfArgs* __restrict__
         const int64_t cnt = g < NGC ? (int64_t)D->segOff[g + 1] - (int64_t)D->segOff[g] : total;
         const long long lo = C->lo;
         bool ok = true; double globalMedian = 0.0;
+        if (g == 41) CF_STAMP(10);
         if ((g == NGC || (var && cnt > 0)) && total > 0) {              // the genome's median (every workgroup that goes on to the weighted count takes it for itself)
             uint32_t cG[16]; cq_load_row(A.cqHist + (size_t)NGC * CQW, cG);
-            int64_t ranks[2]; int nr = 0;
-            if (total % 2) ranks[nr++] = total / 2; else { ranks[nr++] = total / 2 - 1; ranks[nr++] = total / 2; }
+            const int nr = (total % 2) ? 1 : 2;
+            __syncthreads();
+            if (t == 0) { if (total % 2) sRanks[0] = total / 2; else { sRanks[0] = total / 2 - 1; sRanks[1] = total / 2; } }
             uint32_t inWin;
-            ok = cq_pick_ranks(cG, ranks, nr, (int64_t)C->below[NGC], swave, sK, &sFail, &inWin);
+            ok = cq_pick_ranks(cG, sRanks, nr, (int64_t)C->below[NGC], swave, sK, &sFail, &inWin);          // (its first barrier publishes sRanks)
             if (ok) globalMedian = nr == 1 ? (double)cq_value(lo + sK[0]) : (double)median_from_two(cq_value(lo + sK[0]), cq_value(lo + sK[1]));
             if (g == NGC && t == 0) {
                 cf_st(&C->inWin[NGC], inWin);
                 if (!ok) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; } else cf_st_f64(&D->globalMedian, globalMedian);
             }
         }
+        if (g == 41) CF_STAMP(11);
         if (g < NGC && cnt > 0) {
             uint32_t c[16]; cq_load_row(A.cqHist + (size_t)g * CQW, c);
-            int64_t ranks[8]; int nr = 0;
-            if (cnt % 2) ranks[nr++] = cnt / 2; else { ranks[nr++] = cnt / 2 - 1; ranks[nr++] = cnt / 2; }
-            const int nMed = nr;
-            if (var) { const QuartIdx qi = quartile_indices(cnt); for (int k = 0; k < qi.n; k++) ranks[nr++] = qi.idx[k]; }
+            const int nMed = (cnt % 2) ? 1 : 2, nQ = var ? quart_n(cnt) : 0, nr = nMed + nQ;
+            __syncthreads();
+            if (t == 0) { if (cnt % 2) sRanks[0] = cnt / 2; else { sRanks[0] = cnt / 2 - 1; sRanks[1] = cnt / 2; } }
+            if (t < nQ) sRanks[nMed + t] = quart_idx(cnt, t);
             uint32_t inWin;
             const unsigned long long belowG = (unsigned long long)C->below[g];
-            const bool okOwn = cq_pick_ranks(c, ranks, nr, (int64_t)belowG, swave, sK, &sFail, &inWin);
+            const bool okOwn = cq_pick_ranks(c, sRanks, nr, (int64_t)belowG, swave, sK, &sFail, &inWin);
             double median = 0.0;
             if (okOwn) median = nMed == 1 ? (double)cq_value(lo + sK[0]) : (double)median_from_two(cq_value(lo + sK[0]), cq_value(lo + sK[1]));
             if (t == 0) {
@@ -1019,6 +1188,7 @@ __global__ void __launch_bounds__(1024) k_cf_pick_mad(const CfArgs* __restrict__
                 if (!okOwn) { C->fail = 1u; D->cqFail = 1; D->fallback = 1u; }
                 else { cf_st_f64(&D->medians[g], median); for (int k = nMed; k < nr; k++) cf_st(&C->kq[g][k - nMed], (int32_t)(lo + sK[k])); }
             }
+            if (g == 41) CF_STAMP(12);
             if (var && ok && okOwn) {
                 // this bucket's share of the weighted count: value = the normalised count of a slot, weight = its counter
                 for (int i = t; i < CQW / 4; i += 1024) reinterpret_cast<uint4*>(lw)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1039,25 +1209,14 @@ __global__ void __launch_bounds__(1024) k_cf_pick_mad(const CfArgs* __restrict__
                 for (int i = t; i < CQW; i += 1024) { const uint32_t v = lw[i]; if (v) atomicAdd(&all[i], v); }
             }
         }
+        if (g == 41) CF_STAMP(13);
         if (!var) return;
-        if (cf_arrive_last(A.tick + 3, (uint32_t)nPick, &sLast)) cf_resolve_var(A, lw, swave);
+        const bool lastP = cf_arrive_last(A.tick + 3, (uint32_t)nPick, &sLast);
+        if (g == 41) CF_STAMP(14);
+        if (lastP) { CF_STAMP(20); cf_resolve_var(A, lw, swave); __syncthreads(); CF_STAMP(25); }
         return;
     }
-    // ---- run role: median and MAD of the window SDs of runs b, b + CF_MADB, ... (Utilities.Mad per chromosome, CanvasClean.cs:243-258); the last workgroup averages them
-    if (!A.wantLsd) return;
-    const int b = (int)blockIdx.x - nPick, nruns = D->nruns;
-    const gptr<const double> sd = as_global(A.dSd);
-    for (int r = b; r < nruns; r += CF_MADB) {
-        const int64_t lo = A.dRunStart[r], hi = A.dRunStart[r + 1], cnt = hi - lo;
-        if (cnt <= 0) { if (t == 0) cf_st_f64(&A.dRunMad[r], 0.0); }
-        else if (cnt <= (int64_t)MAD_REG * 1024) cf_run_mad<true>(sd, lo, hi, S, sOut, &A.dRunMad[r]);
-        else cf_run_mad<false>(sd, lo, hi, S, sOut, &A.dRunMad[r]);
-    }
-    if (!cf_arrive_last(A.tick + 4, (uint32_t)CF_MADB, &sLast) || t != 0) return;
-    if (!D->haveLocalSd) { D->localSd = -1.0; return; }
-    double s = 0;
-    for (int r = 0; r < nruns; r++) s += cf_ld_f64(&A.dRunMad[r]);               // List<double>.Average(): sequential sum / count
-    D->localSd = s / (double)nruns;
+    cf_role_mad(AA, lw, sOut, &sLast, nPick);
 }
 
 // ---------------------------------------------------------------- the radix-select flavour of the decisions, and the second phase (NormalizeVarianceByGC changed the counts)
@@ -1324,7 +1483,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         nMax = std::max(nMax, n);
         sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<int32_t>(n); sz.take<float>(n); sz.take<uint8_t>(n + 16);
         sz.take<uint8_t>(n + 16); sz.take<unsigned long long>(nb + 2); sz.take<uint32_t>(nb + 2); sz.take<uint32_t>(n); sz.take<uint32_t>(n / 8 + 1024); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
-        sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CfSel>(CF_NPROB); sz.take<SelTile>(tilesUpper * CF_NPROB); sz.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1));
+        sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CfSel>(CF_NPROB); sz.take<SelTile>(tilesUpper * CF_NPROB); sz.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1)); sz.take<unsigned long long>(64);
     }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
     const size_t histPer = (size_t)CF_MAXQ * 1024 * SEL_REP, histBytes = histPer * (size_t)B;
@@ -1356,6 +1515,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         gxTcq = std::max(gxTcq, (unsigned)(n / CQ_TILE + NGC + 1));
         A.isAuto = dIsAuto; A.repl = dRepl + (size_t)s * CF_HREP * 3 * NGC; A.szHist = dSz + (size_t)s * CF_SZ_BINS; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
         A.tick = dTick + (size_t)s * 8;
+        { unsigned long long* dbg = ws.take<unsigned long long>(64); A.dbg = getenv("CANVAS_CLEAN_DEBUG_CLOCKS") ? dbg : nullptr; }
         gxT = std::max(gxT, tilesUpper);
         anyLsd = anyLsd || A.wantLsd; anyVar = anyVar || (A.wantLsd && n > 500000);
     }
@@ -1399,9 +1559,16 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     // ... the variance normalisation rarely changes anything: the last compaction below is enqueued on the assumption that it does not; when it did, that compaction does
     // nothing for the sample and clean_batch_finish enqueues the variance scaling, the second NormalizeByGC and the compaction for it (one more synchronisation, in that case only)
     const int nHist = useCq ? (int)gxTcq : 0, nLsd = anyLsd ? (int)nblk(nMax / 20 + 2, 1024) : 0;
-    if (nHist + nLsd > 0) hipLaunchKernelGGL(k_cf_hist_lsd, dim3(nHist + nLsd, B), dim3(1024), 0, ctx->stream, dArgs, nHist, nLsd);
     const int nPick = useCq ? NGC + 1 : 0, nMad = anyLsd ? CF_MADB : 0;
-    if (nPick + nMad > 0) hipLaunchKernelGGL(k_cf_pick_mad, dim3(nPick + nMad, B), dim3(1024), 0, ctx->stream, dArgs, nPick);
+    if (getenv("CANVAS_CLEAN_SPLIT_ROLES")) {               // profiling hook: every role as a launch of its own (same kernels, same results)
+        if (nHist) hipLaunchKernelGGL(k_cf_hist_lsd, dim3(nHist, B), dim3(1024), 0, ctx->stream, dArgs, nHist, 0);
+        if (nLsd) hipLaunchKernelGGL(k_cf_hist_lsd, dim3(nLsd, B), dim3(1024), 0, ctx->stream, dArgs, 0, nLsd);
+        if (nPick) hipLaunchKernelGGL(k_cf_pick_mad, dim3(nPick, B), dim3(1024), 0, ctx->stream, dArgs, nPick);
+        if (nMad) hipLaunchKernelGGL(k_cf_pick_mad, dim3(nMad, B), dim3(1024), 0, ctx->stream, dArgs, 0);
+    } else {
+        if (nHist + nLsd > 0) hipLaunchKernelGGL(k_cf_hist_lsd, dim3(nHist + nLsd, B), dim3(1024), 0, ctx->stream, dArgs, nHist, nLsd);
+        if (nPick + nMad > 0) hipLaunchKernelGGL(k_cf_pick_mad, dim3(nPick + nMad, B), dim3(1024), 0, ctx->stream, dArgs, nPick);
+    }
     // ---- last compaction into the caller's arrays
     hipLaunchKernelGGL(k_cf_flags_final, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs);
     hipLaunchKernelGGL(k_cf_scatter_final, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs, 0);
@@ -1420,6 +1587,13 @@ static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64
     for (int s = 0; s < B; s++) handled[s] = 0;
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());
+    if (q.h[0].dbg) {                                                      // profiling hook: wall-clock stamps (100 MHz) of selected workgroups, relative to the first one
+        unsigned long long st[64];
+        CANVAS_HIP_TRY(ctx, hipMemcpy(st, q.h[0].dbg, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "clean stamps (us):");
+        for (int i = 0; i < 64; i++) if (st[i]) fprintf(stderr, " [%d]%.2f", i, (double)(long long)(st[i] - st[0]) / 100.0);
+        fprintf(stderr, "\n");
+    }
     bool again = false;
     for (int s = 0; s < B; s++) {
         const CleanDev& H = ((const CleanDev*)ctx->pin)[s];
