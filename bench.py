@@ -281,11 +281,13 @@ def main():
         t_w = time.perf_counter()
         bps = cv.wavelets(keep["cov"], keep["off"])
         wv_s = time.perf_counter() - t_w
-        wst = cv.wavelets_stats()
+        wst = cv.wavelets_stats(); wdec = cv.wavelets_decisions()
         ms_chain, k_chain = cv.profile_get("wavelet_chain")
         wv = {"seconds": round(wv_s, 3), "bins_per_s": round(int(keep["n_out"]) / wv_s, 1), "breakpoints": int(sum(len(b) for b in bps)), "tree_levels": int(wst[0]),
+              "long_nodes_decided_from_the_closed_form": wdec[0], "long_nodes_undecided_sent_to_the_exact_chain": wdec[1], "long_nodes_chained_for_their_coefficient": wdec[2],
               "chain_kernel_seconds": round(ms_chain / 1e3, 3), "nodes_recomputed_exactly": int(wst[1]),
-              "note": "WaveletsRunner.Run (somatic flavour, default parameters): unbalanced Haar decomposition on the device level by level, "
+              "note": "WaveletsRunner.Run (somatic flavour, default parameters): unbalanced Haar tree built on the device — arg-max of every long node decided from exact integer "
+                      "prefix sums + a rounding-error bound of the reference's recurrences, exact chains only for undecided nodes and for coefficients that may survive HardThresh — "
                       "thresholding / healing on the host"}
         t_e = time.perf_counter()
         ev = cv.evenness_score(keep["cov"], keep["off"], 100000)
@@ -295,9 +297,10 @@ def main():
             import oracle_lib as O
             cov_h = keep["cov"].cpu().numpy(); off_h = keep["off"]
             per = [np.ascontiguousarray(cov_h[off_h[c]:off_h[c + 1]]) for c in range(len(off_h) - 1)]
+            cores = min(os.cpu_count() or 1, 24)
             t_o = time.perf_counter()
-            exp = O.wavelets_genome(per)
-            wv["oracle_seconds_1_core"] = round(time.perf_counter() - t_o, 3)
+            exp = O.wavelets_genome(per, threads=cores)          # one task per chromosome, as WaveletsRunner.Run (Parallel.ForEach, WaveletsRunner.cs:89-135): the convention of every oracle_seconds of this file
+            wv["oracle_seconds"] = round(time.perf_counter() - t_o, 3); wv["oracle_threads"] = cores
             wv["parity_vs_oracle"] = bool(all(a.tolist() == b.tolist() for a, b in zip(bps, exp)))
             t_o = time.perf_counter()
             ev_o = O.evenness_score(per, 100000)

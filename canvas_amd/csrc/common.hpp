@@ -55,6 +55,8 @@ struct canvas_ctx {
     long long cbs_dev[6] = {0, 0, 0, 0, 0, 0};
     long long cbs_tailp[2] = {0, 0};   // last CBS call: TailP decisions taken from the device series / recomputed by the host series   // counters of the device permutation engine (canvas_cbs_device_stats)
     long long wv_levels = 0, wv_redone = 0;   // last canvas_wavelets call: tree levels processed, nodes recomputed by the exact chain
+    void* wv_pin = nullptr; size_t wv_pin_bytes = 0;   // pinned arena of canvas_wavelets (host copy of the coverage + staging lists), kept between calls
+    long long wv_stats[4] = {0, 0, 0, 0};     // ... long nodes decided from the closed form / sent to the chain undecided / chained for their coefficient; closed form in use
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
     int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
     // profiling: hipEvent pairs around named kernels

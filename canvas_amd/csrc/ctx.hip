@@ -34,6 +34,7 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->side_ev2) (void)hipEventDestroy(ctx->side_ev2);
     if (ctx->up2_stage) (void)hipFree(ctx->up2_stage);
     if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
+    if (ctx->wv_pin) (void)hipHostFree(ctx->wv_pin);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gc_arena) (void)hipFree(ctx->gc_arena);
     if (ctx->shard_ws) (void)hipFree(ctx->shard_ws);

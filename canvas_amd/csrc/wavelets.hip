@@ -68,19 +68,19 @@ __device__ __forceinline__ int wv_find(const int32_t* __restrict__ base, int nLo
 
 // one block (64 lanes) per chunk, one lane per step
 __global__ void __launch_bounds__(64) k_wv_coeff(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const int32_t* __restrict__ base, int nLong,
-                                                 const double* __restrict__ X, WvOps* __restrict__ ops) {
+                                                 const double* __restrict__ X, WvOps* __restrict__ ops, const long long* __restrict__ opsOff, const int32_t* __restrict__ lim) {
     const int g = blockIdx.x;
     const int k = wv_find(base, nLong, g);
     const WvNode nd = nodes[list[k]];
     const long long n = nd.len, m = 1 + (long long)(g - base[k]) * WV_CS + threadIdx.x;
-    if (threadIdx.x >= WV_CS || m > n - 2) return;
+    if (threadIdx.x >= WV_CS || m > (lim ? min<long long>(n - 2, lim[k]) : n - 2)) return;      // (lim: the chain of node k stops after step lim[k] — its arg-max is known)
     const size_t p = (size_t)nd.start + (size_t)m;
     const double x = X[p];
     WvOps o;
     o.f = wv_factor(n, m); o.r = wv_rcp_refined(o.f);
     o.c = x * wv_g(n, m);
     o.d = x / wv_h(n, m);
-    ops[p] = o;
+    ops[(opsOff ? (size_t)opsOff[k] : (size_t)nd.start) + (size_t)m] = o;      // (opsOff: a slice of its own per node, for lists whose nodes overlap in position)
 }
 
 // One step of both recurrences on uniform operands (every lane computes the same values).
@@ -100,7 +100,7 @@ __device__ __forceinline__ void wv_step(double& p, double& q, double f, double r
 // yields the arg-max, so neither the shortcut division nor the arg-max bookkeeping sits on the chain.
 template <bool FAST>
 __global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const int32_t* __restrict__ base,
-                                                      const double* __restrict__ X, const WvOps* __restrict__ ops, WvCk* __restrict__ ck, WvHead* __restrict__ head) {
+                                                      const double* __restrict__ X, const WvOps* __restrict__ ops, WvCk* __restrict__ ck, WvHead* __restrict__ head, const long long* __restrict__ opsOff, const int32_t* __restrict__ lim) {
     __shared__ double4 sO[2][64];              // [buf][step] = (f, r, c, d); the sum pass uses sO[buf][s].x
     const int k = blockIdx.x;
     const WvNode nd = nodes[list[k]];
@@ -134,17 +134,21 @@ __global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__
     if (l == 0) { WvHead h; h.mean = (x0 + sum) / (double)n; h.ip0 = p - q; head[k] = h; }
     {
         int buf = 0;
-        const long long last = n - 2;                                     // steps m = 1 .. n-2
-        const WvOps* __restrict__ o = ops + nd.start;
+        const long long last = lim ? min<long long>(n - 2, lim[k]) : n - 2;   // steps m = 1 .. n-2
+        const WvOps* __restrict__ o = ops + (opsOff ? (size_t)opsOff[k] : (size_t)nd.start);
         WvCk* __restrict__ ckn = ck + base[k];
-        double4 nv = make_double4(0, 0, 0, 0);
+        // the operands of a chunk are requested TWO chunks ahead (with the exact chains of a whole tree side by side the operand array no longer fits the Infinity Cache:
+        // one chunk of 56 steps = 1.5 us of lead was less than a loaded HBM round trip, and the chain ran at half its speed)
+        double4 nv = make_double4(0, 0, 0, 0), nv2 = make_double4(0, 0, 0, 0);
         if (l < WV_CS && 1 + l <= last) { const WvOps t = o[1 + l]; nv = make_double4(t.f, t.r, t.c, t.d); }
+        if (l < WV_CS && 1 + WV_CS + l <= last) { const WvOps t = o[1 + WV_CS + l]; nv2 = make_double4(t.f, t.r, t.c, t.d); }
         long long c = 0;
         for (long long m0 = 1; m0 <= last; m0 += WV_CS, buf ^= 1, c++) {
             if (l == 0) { WvCk t; t.p = p; t.q = q; ckn[c] = t; }
             sO[buf][l] = nv;
             __builtin_amdgcn_wave_barrier();
-            { const long long t = m0 + WV_CS + l; if (l < WV_CS && t <= last) { const WvOps u = o[t]; nv = make_double4(u.f, u.r, u.c, u.d); } }
+            nv = nv2;
+            { const long long t = m0 + 2 * WV_CS + l; if (l < WV_CS && t <= last) { const WvOps u = o[t]; nv2 = make_double4(u.f, u.r, u.c, u.d); } }
             const long long cnt = last - m0 + 1;
             if (cnt >= WV_CS) {
                 double4 cur[WV_PB], nx[WV_PB];
@@ -174,15 +178,15 @@ __global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__
 // for bit (checkpoint 0 is exact by construction, so every checkpoint and therefore every value seen here is exact); the lane keeps the
 // first arg-max of |I+ - I-| of its steps.
 __global__ void __launch_bounds__(64) k_wv_chunks(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const int32_t* __restrict__ base, int nLong,
-                                                  int nChunks, const WvOps* __restrict__ ops, const WvCk* __restrict__ ck, WvBest* __restrict__ best, int32_t* __restrict__ flag) {
+                                                  int nChunks, const WvOps* __restrict__ ops, const WvCk* __restrict__ ck, WvBest* __restrict__ best, int32_t* __restrict__ flag, const long long* __restrict__ opsOff, const int32_t* __restrict__ lim) {
     const int g = blockIdx.x * 64 + threadIdx.x;
     if (g >= nChunks) return;
     const int k = wv_find(base, nLong, g);
     const WvNode nd = nodes[list[k]];
-    const long long n = nd.len, last = n - 2;
+    const long long n = nd.len, last = lim ? min<long long>(n - 2, lim[k]) : n - 2;
     const long long m0 = 1 + (long long)(g - base[k]) * WV_CS;
     const long long cnt = last - m0 + 1 < WV_CS ? last - m0 + 1 : WV_CS;
-    const WvOps* __restrict__ o = ops + nd.start + m0;
+    const WvOps* __restrict__ o = ops + (opsOff ? (size_t)opsOff[k] : (size_t)nd.start) + m0;
     double p = ck[g].p, q = ck[g].q;
     double bestVal = 0.0, bestAbs = -1.0; int32_t bestIdx = 0;
     for (int s = 0; s < (int)cnt; s++) {
@@ -276,6 +280,191 @@ __global__ void __launch_bounds__(64) k_wv_subtree(const WvRoot* __restrict__ ro
         else if (right) cur = (uint32_t)(b + 1) | ((uint32_t)e << 9) | lvn;
         else if (sp > 0) cur = st[--sp];
         else have = false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ closed-form decisions (the default path of the long nodes)
+// What a node contributes to the segmentation is (a) the FIRST arg-max of |I+ - I-| (it places the children) and (b) its coefficient — but only if that
+// survives HardThresh.  Both are decisions about the reference's rounded values, and those values lie within a computable distance of the exact ones:
+//     I+*[m] = sqrt((n-m-1) / (n (m+1))) S_{m+1}        I-*[m] = sqrt((m+1) / (n (n-m-1))) (S_n - S_{m+1})        S_j = x_0 + ... + x_{j-1}
+// (the recurrences of GetInnerProdIter are these products, advanced one element at a time).  CanvasPartition reads its coverage from F2 text, so 100 x is a non-negative
+// integer and every S_j is EXACT in 64-bit integers: two prefix arrays per chromosome (the sums and the sums of the sums), built once, give T[m] = I+*[m] - I-*[m] for
+// every node of every level with no dependence between elements.  The reference's value differs from T[m] by the rounding errors of its own evaluation; carried through
+// the two recurrences (I+ contracts by f_m per step, I- expands by 1 / f_m, and the products of the f telescope) they are bounded by
+//     B[m] = u { A_m [4.02 SS_m + (3 + n/(n-m-1)) S_{m+1}]  +  C_m [(n + 1.01) R_1 + 4.03 RR_m + (3.5 + n/(2(n-m-1))) S_{m+1}]  +  9 (A_m S_{m+1} + C_m R_{m+1}) } (1 + 1e-2)
+// with u = 2^-53, A_m / C_m the two square roots above, R_j = S_n - S_j, SS_m = S_0 + ... + S_m, RR_m = R_1 + ... + R_m (derivation: DESIGN.md, Wavelets; the terms are the
+// per-step rounding of factor, of the two coefficients — whose subtractions 1/(m+1) - 1/n and n^2/(m+1) - n cancel near the end of the node, hence n/(n-m-1) — of the
+// products and the sums, and of the left-to-right sum of the stretch, (n-2) u S_n, which enters I-[0] and is carried along).  A node is DECIDED when one index's lower bound
+// |T| - B lies above every other index's upper bound |T| + B: that index is the reference's first arg-max whatever the rounding did.  Its coefficient is then bracketed the
+// same way; a node whose bracket lies at or below the threshold every level weight implies is zeroed by HardThresh, and nothing else about it matters.  Undecided nodes
+// (exact ties: flat or periodic input) and nodes whose coefficient may survive go through the exact chain above — the latter all at once at the end, because only the
+// arg-max is needed to go on.  The whole tree is built on the device: a level is ONE launch over the node list the previous level left, the host looks at the
+// counters once per batch of levels.  (Round 2 ran every long node through the chain: 14 M dependent steps and ~300 host round trips for a WGS sample, 0.5 s.)
+#define WV_LB 128         // levels enqueued per batch (even; a launch over an empty list is not free: 512 per batch were 9 ms for a 312-level tree)
+struct WvDNode { int32_t start, len, chrom, level; };      // start: index into the concatenated coverage
+struct WvDev { unsigned int cnt[WV_LB + 2], nch[WV_LB + 2]; unsigned int nRoots, nExact, nUndec, overflow; };
+__device__ __forceinline__ long long wv_block_scan_i64(long long v, long long* sh /* [17] */, long long* total) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(inc, d, 64); if (l >= d) inc += o; }
+    __syncthreads();
+    if (l == 63) sh[w] = inc;
+    __syncthreads();
+    long long offw = 0, tot = 0;
+    for (int k = 0; k < 16; k++) { if (k < w) offw += sh[k]; tot += sh[k]; }
+    *total = tot;
+    return inc + offw;
+}
+// one workgroup per chromosome: k = 100 x as integers (checked bit for bit), P1[i] = k_0 + ... + k_i, P2[i] = P1[0] + ... + P1[i] (both restart at every chromosome)
+__global__ void __launch_bounds__(1024) k_wv_prefix(const double* __restrict__ X, const long long* __restrict__ off, long long* __restrict__ P1, long long* __restrict__ P2, int* __restrict__ bad) {
+    __shared__ long long sh[17];
+    const long long lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+    long long carry1 = 0, carry2 = 0;
+    int myBad = 0;
+    for (long long base = lo; base < hi; base += 1024) {
+        const long long i = base + threadIdx.x;
+        long long k = 0;
+        if (i < hi) {
+            const double x = X[i];
+            if (!(x >= 0.0 && x < 2.0e7)) myBad = 1;
+            else { k = llrint(x * 100.0); if ((double)k / 100.0 != x) myBad = 1; }
+        }
+        long long t1, t2;
+        const long long l1 = wv_block_scan_i64(k, sh, &t1);                      // tile-local inclusive sums
+        const long long l2 = wv_block_scan_i64(i < hi ? l1 : 0, sh, &t2);
+        const long long cntTile = min<long long>(1024, hi - base);
+        if (i < hi) { P1[i] = carry1 + l1; P2[i] = carry2 + (long long)(threadIdx.x + 1) * carry1 + l2; }
+        carry2 += cntTile * carry1 + t2; carry1 += t1;
+        if (carry2 > (1ll << 61) || (hi - lo) * carry1 > (1ll << 61)) myBad = 1;   // the bound's integer terms stay inside 64 bits
+    }
+    if (myBad) *bad = 1;
+}
+// A node is evaluated in chunks of WV_CH elements, one workgroup per chunk; the last chunk of a node to finish combines the partial results and takes the node's decision
+// (arrival counter per node; partial results are published with write-through stores and read after one agent-scope acquire).  A 380 000-bin chromosome is 186 chunks: its
+// level costs the same few microseconds as a level of short nodes.
+#define WV_CH 2048
+struct WvPart { double lw, t, b, u1, u2; int32_t idx, i1; };
+struct WvSlot { WvDNode nd; int32_t chunkBase, arrived; };      // a node of the current level + where its chunks start + how many of them are done
+__device__ __forceinline__ void wv_st_f64(double* p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wv_st_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// appends a long node to the list of iteration `it` (count dev->cnt[it], chunks dev->nch[it]): slot, chunk range, chunk -> slot map
+__device__ __forceinline__ void wv_push_long(WvSlot* __restrict__ list, int32_t* __restrict__ chunkNode, WvDev* __restrict__ dev, int it, unsigned maxList, unsigned maxChunks, const WvDNode& nd) {
+    const unsigned slot = atomicAdd(&dev->cnt[it], 1u);
+    const int nch = (int)((nd.len - 1 + WV_CH - 1) / WV_CH);                    // m = 0 .. len - 2
+    const unsigned cb = atomicAdd(&dev->nch[it], (unsigned)nch);
+    if (slot >= maxList || cb + (unsigned)nch > maxChunks) { dev->overflow = 1u; return; }
+    WvSlot sl; sl.nd = nd; sl.chunkBase = (int32_t)cb; sl.arrived = 0;
+    list[slot] = sl;
+    for (int c = 0; c < nch; c++) chunkNode[cb + c] = (int32_t)slot;
+}
+// the host's node list (level 0, or the children of nodes the chain decided) becomes the list of iteration 0
+__global__ void __launch_bounds__(256) k_wv_list_init(const WvDNode* __restrict__ in, int n, WvSlot* __restrict__ list, int32_t* __restrict__ chunkNode, WvDev* __restrict__ dev, unsigned maxList, unsigned maxChunks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) wv_push_long(list, chunkNode, dev, 0, maxList, maxChunks, in[i]);
+}
+// One level of the tree for the long nodes in `cur` (dev->cnt[it] nodes, dev->nch[it] chunks): a workgroup per chunk (grid-stride).
+__global__ void __launch_bounds__(256) k_wv_level(WvSlot* __restrict__ cur, const int32_t* __restrict__ curChunkNode, WvSlot* __restrict__ nxt, int32_t* __restrict__ nxtChunkNode, WvPart* __restrict__ parts,
+                                                  WvDev* __restrict__ dev, int it, unsigned maxList, unsigned maxChunks, unsigned maxList2,
+                                                  const long long* __restrict__ P1, const long long* __restrict__ P2, const long long* __restrict__ off, const double* __restrict__ keepAbove,
+                                                  WvRoot* __restrict__ roots, unsigned maxRoots, WvDNode* __restrict__ exactList, int32_t* __restrict__ exactInd, WvDNode* __restrict__ undecList, int32_t* __restrict__ counts) {
+    __shared__ WvPart sP[4];
+    __shared__ int sLast;
+    const unsigned nChunks = min(dev->nch[it], maxChunks);
+    const double u = 1.1102230246251565e-16;
+    for (unsigned ch = blockIdx.x; ch < nChunks; ch += gridDim.x) {
+        const int slot = curChunkNode[ch];
+        const WvDNode nd = cur[slot].nd;
+        const int cbIdx = cur[slot].chunkBase;
+        const long long n = nd.len, s = nd.start, cbase = off[nd.chrom];
+        const long long pm1 = s > cbase ? P1[s - 1] : 0, qm1 = s > cbase ? P2[s - 1] : 0;       // sums in front of the node
+        const long long Ktot = P1[s + n - 1] - pm1, KR1 = Ktot - (P1[s] - pm1);
+        const double dn = (double)n, invN = 1.0 / dn;
+        // ---- the chunk's m: T, B; the thread keeps its best lower bound and its two largest upper bounds
+        double bLw = -1.0e300, bT = 0.0, bB = 0.0; int32_t bIdx = 0x7FFFFFFF;
+        double u1 = -1.0e300, u2 = -1.0e300; int32_t i1 = -1;
+        const long long m0 = (long long)(ch - (unsigned)cbIdx) * WV_CH, m1 = min<long long>(m0 + WV_CH, n - 1);
+        for (long long m = m0 + threadIdx.x; m < m1; m += 256) {
+            const long long Kp = P1[s + m] - pm1, Kr = Ktot - Kp;
+            const long long KS = m > 0 ? (P2[s + m - 1] - qm1) - m * pm1 : 0;          // 100 SS_m
+            const long long KRR = m * Ktot - KS;                                       // 100 RR_m
+            const double sp = (double)Kp, sr = (double)Kr, dm1 = (double)(m + 1), dr = (double)(n - m - 1);
+            // A_m = sqrt((n-m-1) / ((m+1) n)), C_m = 1 / (n A_m): one division, one square root and one more division per element (2.6 u and 4.6 u off the exact
+            // square roots: with the products and the subtraction below, T is within 6.6 u (I+* + I-*) of its exact value — the 9 u of the bound); n / (n-m-1) only
+            // enters the bound and is taken from the single-precision reciprocal, rounded up
+            const double a = sqrt((dr / dm1) * invN), c = 1.0 / (dn * a);
+            const double ip = a * sp, im = c * sr;
+            const double T = ip - im;
+            const double ndr = dn * (double)(__frcp_rn((float)dr) * 1.000001f) * 1.000001;
+            const double B = u * (a * (4.02 * (double)KS + (3.0 + ndr) * sp) + c * ((dn + 1.01) * (double)KR1 + 4.03 * (double)KRR + (3.5 + 0.5 * ndr) * sp) + 9.0 * (ip + im)) * 1.01;
+            const double at = fabs(T), lw = at - B, up = at + B;
+            if (lw > bLw) { bLw = lw; bT = T; bB = B; bIdx = (int32_t)m; }
+            if (up > u1) { u2 = u1; u1 = up; i1 = (int32_t)m; } else if (up > u2) u2 = up;
+        }
+        // ---- workgroup: best lower bound; the two largest upper bounds
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double oLw = __shfl_xor(bLw, d, 64), oT = __shfl_xor(bT, d, 64), oB = __shfl_xor(bB, d, 64); const int32_t oI = __shfl_xor(bIdx, d, 64);
+            if (oLw > bLw || (oLw == bLw && oI < bIdx)) { bLw = oLw; bT = oT; bB = oB; bIdx = oI; }
+            const double o1 = __shfl_xor(u1, d, 64), o2 = __shfl_xor(u2, d, 64); const int32_t oi1 = __shfl_xor(i1, d, 64);
+            if (o1 > u1) { u2 = fmax(u1, o2); u1 = o1; i1 = oi1; } else u2 = fmax(u2, o1);
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { WvPart pk; pk.lw = bLw; pk.t = bT; pk.b = bB; pk.u1 = u1; pk.u2 = u2; pk.idx = bIdx; pk.i1 = i1; sP[threadIdx.x >> 6] = pk; }
+        __syncthreads();
+        const int nch = (int)((n - 1 + WV_CH - 1) / WV_CH);
+        if (threadIdx.x == 0) {
+            WvPart best = sP[0];
+            for (int w = 1; w < 4; w++) {
+                const WvPart o = sP[w];
+                if (o.u1 > best.u1) { best.u2 = fmax(best.u1, o.u2); best.u1 = o.u1; best.i1 = o.i1; } else best.u2 = fmax(best.u2, o.u1);
+                if (o.lw > best.lw || (o.lw == best.lw && o.idx < best.idx)) { best.lw = o.lw; best.t = o.t; best.b = o.b; best.idx = o.idx; }
+            }
+            int last = 1;
+            if (nch > 1) {
+                // publish the chunk's result (write-through), then the arrival ticket; the last chunk of the node acquires and combines
+                WvPart* pp = parts + ch;
+                wv_st_f64(&pp->lw, best.lw); wv_st_f64(&pp->t, best.t); wv_st_f64(&pp->b, best.b); wv_st_f64(&pp->u1, best.u1); wv_st_f64(&pp->u2, best.u2); wv_st_i32(&pp->idx, best.idx); wv_st_i32(&pp->i1, best.i1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                last = (__hip_atomic_fetch_add(&cur[slot].arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == nch) ? 1 : 0;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    for (int c = 0; c < nch; c++) {
+                        if ((unsigned)(cbIdx + c) == ch) continue;
+                        const WvPart o = parts[cbIdx + c];
+                        if (o.u1 > best.u1) { best.u2 = fmax(best.u1, o.u2); best.u1 = o.u1; best.i1 = o.i1; } else best.u2 = fmax(best.u2, o.u1);
+                        if (o.lw > best.lw || (o.lw == best.lw && o.idx < best.idx)) { best.lw = o.lw; best.t = o.t; best.b = o.b; best.idx = o.idx; }
+                    }
+                }
+            }
+            if (last) {
+                const double others = best.i1 == best.idx ? best.u2 : best.u1;   // the largest upper bound among the OTHER indices
+                const bool decided = best.lw > others;
+                atomicAdd(&counts[(size_t)cbase + nd.level], 1);                // node count per (chromosome, level): HardThresh's level weights
+                if (!decided) {
+                    const unsigned k = atomicAdd(&dev->nUndec, 1u);
+                    if (k < maxList2) undecList[k] = nd; else dev->overflow = 1u;
+                } else {
+                    // children (WaveletSegmentation.cs:297, 323): left [s, b] if it has at least two positions, right [b + 1, e] likewise
+                    const long long b = s + best.idx, e = s + n - 1;
+                    auto place = [&](long long cs, long long ce) {
+                        const int32_t len = (int32_t)(ce - cs + 1);
+                        if (len > WV_LONG) wv_push_long(nxt, nxtChunkNode, dev, it + 1, maxList, maxChunks, WvDNode{(int32_t)cs, len, nd.chrom, nd.level + 1});
+                        else { const unsigned k = atomicAdd(&dev->nRoots, 1u); if (k < maxRoots) roots[k] = WvRoot{(int32_t)cs, len, nd.chrom, nd.level + 1, (int32_t)(cs - cbase + 1), (int32_t)cbase}; else dev->overflow = 1u; }
+                    };
+                    if (b - s >= 1) place(s, b);
+                    if (e - b >= 2) place(b + 1, e);
+                    // the coefficient ipi[ind - 1] / max(0.5, mean / 200) (cs:282, 314, 340), bracketed: mean = fl(fl(x0 + sumX) / n) lies within (n + 2) u of S_n / n
+                    const double meanX = (double)Ktot * 0.01 / dn, mLo = meanX * (1.0 - (dn + 4.0) * u), denLo = fmax(0.5, mLo / 200.0) * (1.0 - 4.0 * u);
+                    const double coefHi = 0.01 * (fabs(best.t) + best.b) / denLo * (1.0 + 8.0 * u);
+                    if (!(coefHi <= keepAbove[nd.chrom])) {                        // may survive HardThresh (or the threshold is NaN): the exact value is needed
+                        const unsigned k = atomicAdd(&dev->nExact, 1u);
+                        if (k < maxList2) { exactList[k] = nd; exactInd[k] = best.idx + 1; } else dev->overflow = 1u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -464,8 +653,10 @@ struct Cand { int32_t level; int32_t s, b, e; double coef; };
 template <typename T> struct PinVec {
     T* p = nullptr; size_t n = 0, cap = 0;
     PinVec() = default; PinVec(const PinVec&) = delete; PinVec& operator=(const PinVec&) = delete;
-    ~PinVec() { if (p) (void)hipHostFree(p); }
-    bool reserve(size_t c) { if (c <= cap) return true; T* q = nullptr; if (hipHostMalloc((void**)&q, c * sizeof(T), hipHostMallocDefault) != hipSuccess) return false; if (p) { memcpy(q, p, n * sizeof(T)); (void)hipHostFree(p); } p = q; cap = c; return true; }
+    ~PinVec() { if (p && !ext) (void)hipHostFree(p); }
+    bool ext = false;                                         // storage handed in by the caller (a slice of the context's pinned arena): fixed capacity, not freed here
+    void attach(void* q, size_t c) { p = (T*)q; cap = c; n = 0; ext = true; }
+    bool reserve(size_t c) { if (c <= cap) return true; if (ext) return false; T* q = nullptr; if (hipHostMalloc((void**)&q, c * sizeof(T), hipHostMallocDefault) != hipSuccess) return false; if (p) { memcpy(q, p, n * sizeof(T)); (void)hipHostFree(p); } p = q; cap = c; return true; }
     bool resize(size_t m) { if (m > cap && !reserve(std::max(m, cap * 2))) return false; n = m; return true; }
     bool push_back(const T& v) { if (n == cap && !reserve(std::max<size_t>(64, cap * 2))) return false; p[n++] = v; return true; }
     void clear() { n = 0; }
@@ -493,10 +684,22 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
     for (int c = 0; c <= nchr; c++) off[c] = h_chr_offset[c] - base;
     const double* dX = d_cov + base;
     // the coverage is needed on both sides: the decomposition runs on the device, the median-based decisions on the host
-    std::vector<double> X((size_t)N);
+    // (pinned, kept by the context: a pageable destination is staged by the runtime — 37 MB took 8 ms — and five hipHostMalloc per call were 3 ms)
+    const size_t maxLongPin = (size_t)N / WV_LONG + (size_t)nchr + 16;
+    const size_t pinBytes = (((size_t)N * sizeof(double) + 255) & ~size_t(255)) + (maxLongPin + 8) * (sizeof(WvNode) + sizeof(WvOut) + 4 * sizeof(int32_t)) + 4096;
+    if (pinBytes > ctx->wv_pin_bytes) {
+        if (ctx->wv_pin) { (void)hipHostFree(ctx->wv_pin); ctx->wv_pin = nullptr; ctx->wv_pin_bytes = 0; }
+        CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->wv_pin, pinBytes + pinBytes / 4, hipHostMallocDefault)); ctx->wv_pin_bytes = pinBytes + pinBytes / 4;
+    }
+    struct XView { double* p; double* data() const { return p; } double operator[](size_t i) const { return p[i]; } } X{(double*)ctx->wv_pin};
+    char* pinCursor = (char*)ctx->wv_pin + (((size_t)N * sizeof(double) + 255) & ~size_t(255));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(X.data(), dX, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int64_t i = 0; i < N; i++) if (!std::isfinite(X[i])) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: coverage must be finite");
+    {
+        std::atomic<int> nonFinite{0};
+        host_parallel_for((N + 262143) / 262144, [&](int64_t blk) { const int64_t a = blk * 262144, b = std::min<int64_t>(N, a + 262144); bool ok = true; for (int64_t i = a; i < b; i++) ok &= std::isfinite(X[(size_t)i]); if (!ok) nonFinite = 1; });
+        if (nonFinite) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: coverage must be finite");
+    }
     const bool timing = getenv("CANVAS_WV_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
@@ -511,10 +714,16 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
     // ---- roots: chromosomes longer than MinSize (WaveletsRunner.cs:117-126)
     std::vector<ChromTree> trees(nchr);
     std::vector<HNode> cur, nxt;
+    std::vector<char> isRoot((size_t)nchr, 0);
     for (int c = 0; c < nchr; c++) {
         const int64_t L = off[c + 1] - off[c];
         if (std::max<int64_t>(L, 1) <= min_size) continue;
         if (L < 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: a chromosome that passes MinSize needs at least two bins");
+        isRoot[(size_t)c] = 1;
+    }
+    host_parallel_for(nchr, [&](int64_t c) {                  // (order statistics of whole chromosomes: one host thread each)
+        if (!isRoot[(size_t)c]) return;
+        const int64_t L = off[c + 1] - off[c];
         const double* r = X.data() + off[c];
         const double median = median_range(r, 0, L);
         double threshold = mad_factor * (hasCV ? median * cv : mad_range(r, 0, L));       // WaveletSegmentation.cs:394-405
@@ -525,24 +734,34 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         // weights turn out to be: such nodes need not be kept (the margin keeps every borderline node for the exact test)
         trees[c].keepAbove = 2 * threshold * (is_germline ? 0.8 : 1.0) * std::sqrt(2 * std::log((double)L)) * (1.0 - 1e-9);
         if (!(trees[c].keepAbove == trees[c].keepAbove)) trees[c].keepAbove = -1.0;   // NaN threshold (a window with median 0): nothing is ever zeroed
-        cur.push_back({c, 1, (int32_t)L});
-    }
+    });
+    for (int c = 0; c < nchr; c++) if (isRoot[(size_t)c]) cur.push_back({c, 1, (int32_t)(off[c + 1] - off[c])});
     // ---- device buffers
-    const size_t maxLong = (size_t)N / WV_LONG + (size_t)nchr + 16, maxChunks = (size_t)N / WV_CS + maxLong + 16, maxRoots = (size_t)N / 2 + (size_t)nchr + 16;
+    const size_t maxLong = (size_t)N / WV_LONG + (size_t)nchr + 16, maxChunks = 3 * (size_t)N / WV_CS + maxLong + 16, maxRoots = (size_t)N / 2 + (size_t)nchr + 16;
     const unsigned long long capCand = (unsigned long long)N + 16;
     WsSizer sz;
-    sz.take<WvOps>((size_t)N); sz.take<WvNode>(maxLong); sz.take<WvOut>(maxLong); sz.take<int32_t>(maxLong);
+    const size_t opsCap = 3 * (size_t)N;                                  // the exact chains of nodes of several levels (which overlap in position) run side by side
+    sz.take<WvOps>(opsCap); sz.take<WvNode>(maxLong); sz.take<WvOut>(maxLong); sz.take<int32_t>(maxLong);
     sz.take<int32_t>(maxLong + 1); sz.take<int32_t>(maxLong); sz.take<WvHead>(maxLong); sz.take<WvCk>(maxChunks); sz.take<WvBest>(maxChunks);
     sz.take<WvRoot>(maxRoots); sz.take<uint32_t>((size_t)N); sz.take<int32_t>((size_t)N); sz.take<WvCand>((size_t)capCand); sz.take<double>(nchr); sz.take<unsigned long long>(2);
+    const size_t maxList2 = (size_t)N / 8 + 1024;                          // nodes of ALL levels that wait for the exact chain
+    const size_t maxCh = (size_t)N / WV_CH + maxLong + 16;
+    sz.take<long long>((size_t)N); sz.take<long long>((size_t)N); sz.take<long long>(nchr + 1); sz.take<int>(4); sz.take<WvSlot>(maxLong); sz.take<WvSlot>(maxLong); sz.take<WvDNode>(maxList2); sz.take<int32_t>(maxList2);
+    sz.take<int32_t>(maxCh); sz.take<int32_t>(maxCh); sz.take<WvPart>(maxCh); sz.take<WvDNode>(maxLong);
+    sz.take<WvDNode>(maxList2); sz.take<WvDev>(1); sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_side_init(ctx); if (rc) return rc;
     WsCarver ws(ctx->ws);
-    WvOps* dOps = ws.take<WvOps>((size_t)N); WvNode* dNodes = ws.take<WvNode>(maxLong); WvOut* dOut = ws.take<WvOut>(maxLong);
+    WvOps* dOps = ws.take<WvOps>(opsCap); WvNode* dNodes = ws.take<WvNode>(maxLong); WvOut* dOut = ws.take<WvOut>(maxLong);
     int32_t* dLong = ws.take<int32_t>(maxLong); int32_t* dBase = ws.take<int32_t>(maxLong + 1);
     int32_t* dFlag = ws.take<int32_t>(maxLong); WvHead* dHead = ws.take<WvHead>(maxLong); WvCk* dCk = ws.take<WvCk>(maxChunks); WvBest* dBest = ws.take<WvBest>(maxChunks);
     WvRoot* dRoots = ws.take<WvRoot>(maxRoots); uint32_t* dStack = ws.take<uint32_t>((size_t)N); int32_t* dCounts = ws.take<int32_t>((size_t)N);
     WvCand* dCands = ws.take<WvCand>((size_t)capCand); double* dKeep = ws.take<double>(nchr); unsigned long long* dNcand = ws.take<unsigned long long>(2);
     int32_t* dOverflow = (int32_t*)(dNcand + 1);
+    long long* dP1 = ws.take<long long>((size_t)N); long long* dP2 = ws.take<long long>((size_t)N); long long* dOff = ws.take<long long>(nchr + 1); int* dBad = ws.take<int>(4);
+    WvSlot* dListA = ws.take<WvSlot>(maxLong); WvSlot* dListB = ws.take<WvSlot>(maxLong); WvDNode* dExact = ws.take<WvDNode>(maxList2); int32_t* dExactInd = ws.take<int32_t>(maxList2);
+    int32_t* dChA = ws.take<int32_t>(maxCh); int32_t* dChB = ws.take<int32_t>(maxCh); WvPart* dParts = ws.take<WvPart>(maxCh); WvDNode* dListIn = ws.take<WvDNode>(maxLong);
+    WvDNode* dUndec = ws.take<WvDNode>(maxList2); WvDev* dDev = ws.take<WvDev>(1); long long* dOpsOff = ws.take<long long>(maxLong); int32_t* dLim = ws.take<int32_t>(maxLong);
     {
         std::vector<double> keep(nchr);
         for (int c = 0; c < nchr; c++) keep[c] = trees[c].keepAbove;
@@ -552,6 +771,12 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the side stream starts from initialised buffers
     }
     PinVec<WvNode> hNodes; PinVec<WvOut> hOut; PinVec<int32_t> hLong, hBase, hRedo; std::vector<WvRoot> hRoots;
+    {   // slices of the context's pinned arena
+        auto slice = [&](size_t bytes) { void* q = pinCursor; pinCursor += (bytes + 255) & ~size_t(255); return q; };
+        if (maxLong > maxLongPin) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: staging layout");
+        hNodes.attach(slice((maxLong + 1) * sizeof(WvNode)), maxLong + 1); hOut.attach(slice((maxLong + 1) * sizeof(WvOut)), maxLong + 1);
+        hLong.attach(slice((maxLong + 1) * 4), maxLong + 1); hBase.attach(slice((maxLong + 2) * 4), maxLong + 2); hRedo.attach(slice((maxLong + 1) * 4), maxLong + 1);
+    }
     if (!hNodes.reserve(maxLong) || !hOut.reserve(maxLong) || !hLong.reserve(maxLong) || !hBase.reserve(maxLong + 1) || !hRedo.reserve(maxLong)) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: cannot pin the staging buffers");
     std::vector<std::vector<WvRoot>> rootBatches;
     size_t rootsUsed = 0;
@@ -581,24 +806,182 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
         rc = flush_roots(false); if (rc) return rc;
     }
     // the kernels of one level for the long nodes in dLong / dBase (chain = the shortcut or the IEEE division)
-    auto long_pass = [&](size_t nLong, int nChunks, bool fast) -> int32_t {
+    auto long_pass = [&](size_t nLong, int nChunks, bool fast, const long long* opsOff = nullptr, const int32_t* lim = nullptr) -> int32_t {
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFlag, 0, nLong * sizeof(int32_t), ctx->stream));
-        hipLaunchKernelGGL(k_wv_coeff, dim3((unsigned)nChunks), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, (int)nLong, dX, dOps);
+        if (nChunks > 0) hipLaunchKernelGGL(k_wv_coeff, dim3((unsigned)nChunks), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, (int)nLong, dX, dOps, opsOff, lim);
         { ProfScope ps(ctx, "wavelet_chain");
-          if (fast) hipLaunchKernelGGL((k_wv_chain_long<true>), dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, dX, dOps, dCk, dHead);
-          else hipLaunchKernelGGL((k_wv_chain_long<false>), dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, dX, dOps, dCk, dHead); }
-        hipLaunchKernelGGL(k_wv_chunks, dim3((unsigned)((nChunks + 63) / 64)), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, (int)nLong, nChunks, dOps, dCk, dBest, dFlag);
+          if (fast) hipLaunchKernelGGL((k_wv_chain_long<true>), dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, dX, dOps, dCk, dHead, opsOff, lim);
+          else hipLaunchKernelGGL((k_wv_chain_long<false>), dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, dX, dOps, dCk, dHead, opsOff, lim); }
+        if (nChunks > 0) hipLaunchKernelGGL(k_wv_chunks, dim3((unsigned)((nChunks + 63) / 64)), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, (int)nLong, nChunks, dOps, dCk, dBest, dFlag, opsOff, lim);
         hipLaunchKernelGGL(k_wv_reduce, dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dLong, dBase, dHead, dBest, dFlag, dOut);
         return CANVAS_OK;
     };
-    auto upload_long = [&](const PinVec<int32_t>& list) -> int {                // returns the number of chunks
+    auto upload_long = [&](const PinVec<int32_t>& list, const std::vector<int32_t>* lim = nullptr) -> int {                // returns the number of chunks
         hBase.clear(); hBase.push_back(0);
-        for (int32_t i : list) hBase.push_back(hBase.back() + (int32_t)((hNodes[i].len - 2 + WV_CS - 1) / WV_CS));
+        size_t at = 0;
+        for (int32_t i : list) { const int32_t last = lim ? std::min<int32_t>(hNodes[i].len - 2, (*lim)[at]) : hNodes[i].len - 2; at++; hBase.push_back(hBase.back() + (int32_t)((last + WV_CS - 1) / WV_CS)); }
         (void)hipMemcpyAsync(dLong, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
         (void)hipMemcpyAsync(dBase, hBase.data(), hBase.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
         return hBase.back();
     };
-    // ---- FindBestUnbalancedHaarDecomposition (WaveletSegmentation.cs:252-366): the long nodes level by level for all chromosomes at once
+    // ---- the exact prefix sums of the closed-form decisions; a coverage that is not made of non-negative two-decimal values takes the chains for every long node
+    const double tSetup = now();
+    if (timing) fprintf(stderr, "canvas_wavelets: set-up %.4f s\n", tSetup - t1);
+    bool closedForm = false;
+    long long nDecided = 0, nUndecided = 0, nExactChains = 0;
+    if (!getenv("CANVAS_WV_CHAIN_ONLY") && !cur.empty()) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, off.data(), (nchr + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_wv_prefix, dim3(nchr), dim3(1024), 0, ctx->stream, dX, dOff, dP1, dP2, dBad);
+        int bad = 1;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&bad, dBad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        closedForm = bad == 0;
+    }
+    double tcA = now(), tcLevels = 0, tcUndec = 0, tcExact = 0;
+    if (closedForm) {
+        // ---- FindBestUnbalancedHaarDecomposition (WaveletSegmentation.cs:252-366) on the device: one launch per level, the host reads the counters once per batch of levels
+        std::vector<WvDNode> hList;
+        for (const HNode& h : cur) hList.push_back({(int32_t)(off[h.chrom] + h.s - 1), h.e - h.s + 1, h.chrom, 0});
+        WvDev hdev; memset(&hdev, 0, sizeof hdev);
+        // the short chromosomes placed above are the first roots of the device-side list
+        std::vector<WvRoot> firstRoots(hRoots.begin(), hRoots.end()); hRoots.clear();          // (what flush_roots has launched already stays in front of them)
+        const size_t rootsLaunched = rootsUsed;
+        if (firstRoots.size() + rootsUsed > maxRoots) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: root list overflow");
+        if (!firstRoots.empty()) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRoots + rootsUsed, firstRoots.data(), firstRoots.size() * sizeof(WvRoot), hipMemcpyHostToDevice, ctx->stream));
+        hdev.nRoots = (unsigned)(rootsUsed + firstRoots.size());
+        std::vector<WvDNode> hExact, hUndec; std::vector<int32_t> hExactInd;
+        while (!hList.empty()) {
+            if (hList.size() > maxLong) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: long-node list overflow");
+            const int nIn = (int)hList.size();
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dListIn, hList.data(), hList.size() * sizeof(WvDNode), hipMemcpyHostToDevice, ctx->stream));
+            hList.clear();
+            bool first = true;
+            hdev.cnt[0] = 0; hdev.nch[0] = 0;
+            for (;;) {
+                for (int i = 1; i < WV_LB + 2; i++) { hdev.cnt[i] = 0; hdev.nch[i] = 0; }
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dDev, &hdev, sizeof hdev, hipMemcpyHostToDevice, ctx->stream));
+                if (first) { hipLaunchKernelGGL(k_wv_list_init, dim3((unsigned)((nIn + 255) / 256)), dim3(256), 0, ctx->stream, dListIn, nIn, dListA, dChA, dDev, (unsigned)maxLong, (unsigned)maxCh); first = false; }
+                for (int it = 0; it < WV_LB; it++)
+                    hipLaunchKernelGGL(k_wv_level, dim3(320), dim3(256), 0, ctx->stream, (it & 1) ? dListB : dListA, (it & 1) ? dChB : dChA, (it & 1) ? dListA : dListB, (it & 1) ? dChA : dChB, dParts,
+                                       dDev, it, (unsigned)maxLong, (unsigned)maxCh, (unsigned)maxList2, dP1, dP2, dOff, dKeep, dRoots, (unsigned)maxRoots, dExact, dExactInd, dUndec, dCounts);
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&hdev, dDev, sizeof hdev, hipMemcpyDeviceToHost, ctx->stream));
+                CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                CANVAS_HIP_TRY(ctx, hipGetLastError());
+                if (hdev.overflow) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: a node list of the device-side tree overflowed");
+                for (int i = 0; i < WV_LB; i++) nDecided += hdev.cnt[i];
+                if (hdev.cnt[WV_LB] == 0) break;
+                hdev.cnt[0] = hdev.cnt[WV_LB]; hdev.nch[0] = hdev.nch[WV_LB];      // WV_LB is even: the pending level sits in list A again (with its chunk map)
+            }
+            nDecided -= hdev.nUndec;
+            tcLevels += now() - tcA; tcA = now();
+            // ---- undecided nodes (exact ties between candidates): the chain decides them, their children go on as a new list
+            if (hdev.nUndec) {
+                const size_t nu = hdev.nUndec;
+                nUndecided += (long long)nu;
+                hUndec.resize(nu);
+                CANVAS_HIP_TRY(ctx, hipMemcpy(hUndec.data(), dUndec, nu * sizeof(WvDNode), hipMemcpyDeviceToHost));
+                // (a node and its descendants are never undecided together — the descendants do not exist yet — so the stretches are disjoint: but the list may exceed
+                // the per-level bound, so it goes through in slices)
+                for (size_t a = 0; a < nu; a += maxLong) {
+                    const size_t nn = std::min(maxLong, nu - a);
+                    hNodes.resize(nn); hOut.resize(nn); hLong.resize(nn);
+                    for (size_t i = 0; i < nn; i++) { hNodes[i] = {hUndec[a + i].start, hUndec[a + i].len}; hLong[i] = (int32_t)i; }
+                    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dNodes, hNodes.data(), nn * sizeof(WvNode), hipMemcpyHostToDevice, ctx->stream));
+                    { const int nChunks = upload_long(hLong); rc = long_pass(nn, nChunks, false); if (rc) return rc; }
+                    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
+                    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    CANVAS_HIP_TRY(ctx, hipGetLastError());
+                    for (size_t i = 0; i < nn; i++) {
+                        const WvDNode& u = hUndec[a + i];
+                        if (hOut[i].flag) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the exact chain was not reproduced by its own check");
+                        ChromTree& T = trees[u.chrom];
+                        const int32_t s1 = (int32_t)(u.start - off[u.chrom] + 1), e1 = s1 + u.len - 1, b = s1 + hOut[i].ind - 1;
+                        if (std::fabs(hOut[i].coef) > T.keepAbove || !(T.keepAbove == T.keepAbove)) T.cands.push_back({u.level, s1, b, e1, hOut[i].coef});
+                        auto placeD = [&](int32_t cs, int32_t ce) {
+                            const int32_t len = ce - cs + 1;
+                            if (len > WV_LONG) hList.push_back({(int32_t)(off[u.chrom] + cs - 1), len, u.chrom, u.level + 1});
+                            else hRoots.push_back({(int32_t)(off[u.chrom] + cs - 1), len, u.chrom, u.level + 1, cs, (int32_t)off[u.chrom]});
+                        };
+                        if (b - s1 >= 1) placeD(s1, b);
+                        if (e1 - b >= 2) placeD(b + 1, e1);
+                    }
+                }
+                if (!hRoots.empty()) {
+                    if (hdev.nRoots + hRoots.size() > maxRoots) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: root list overflow");
+                    CANVAS_HIP_TRY(ctx, hipMemcpy(dRoots + hdev.nRoots, hRoots.data(), hRoots.size() * sizeof(WvRoot), hipMemcpyHostToDevice));
+                    hdev.nRoots += (unsigned)hRoots.size(); hRoots.clear();
+                }
+                hdev.nUndec = 0;
+            }
+            tcUndec += now() - tcA; tcA = now();
+        }
+        // ---- the short nodes with their whole subtrees: one lane each, next to the exact chains below
+        if (hdev.nRoots) {
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const size_t nr = hdev.nRoots - rootsLaunched;
+            if (nr) hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, ctx->side, dRoots + rootsLaunched, (int)nr, dX, dKeep, dStack, dCounts, dCands, dNcand, capCand, dOverflow);
+        }
+        // ---- the nodes whose coefficient may survive HardThresh: exact chains, all levels at once (every node gets a slice of the operand array of its own, longest first)
+        if (hdev.nExact) {
+            size_t ne = hdev.nExact;
+            nExactChains = (long long)ne;
+            hExact.resize(ne); hExactInd.resize(ne);
+            CANVAS_HIP_TRY(ctx, hipMemcpy(hExact.data(), dExact, ne * sizeof(WvDNode), hipMemcpyDeviceToHost));
+            CANVAS_HIP_TRY(ctx, hipMemcpy(hExactInd.data(), dExactInd, ne * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::vector<size_t> order(ne);
+            for (size_t i = 0; i < ne; i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hExactInd[a] != hExactInd[b] ? hExactInd[a] > hExactInd[b] : a < b; });
+            std::vector<long long> hOpsOff; std::vector<int32_t> hLim;
+            if (getenv("CANVAS_WV_DEBUG_CHAINS")) ne = std::min<size_t>(ne, (size_t)atoi(getenv("CANVAS_WV_DEBUG_CHAINS")));      // timing experiment: only the longest chains (the result is then wrong)
+            if (timing) { long long sum = 0, mx = 0, mxl = 0; for (size_t i = 0; i < ne; i++) { sum += hExactInd[i]; mx = std::max<long long>(mx, hExactInd[i]); mxl = std::max<long long>(mxl, hExact[i].len); } fprintf(stderr, "canvas_wavelets: %zu exact chains, %lld steps in all, longest %lld (node %lld)\n", ne, sum, mx, mxl); }
+            for (size_t a = 0; a < ne;) {
+                size_t nn = 0; long long used = 0;
+                hOpsOff.clear();
+                hLim.clear();
+                while (a + nn < ne && nn < maxLong && used + hExactInd[order[a + nn]] + 8 <= (long long)opsCap) { hOpsOff.push_back(used); hLim.push_back(hExactInd[order[a + nn]] - 1); used += hExactInd[order[a + nn]] + 8; nn++; }
+                if (nn == 0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: exact-chain batching");
+                hNodes.resize(nn); hOut.resize(nn); hLong.resize(nn);
+                for (size_t i = 0; i < nn; i++) { const WvDNode& u = hExact[order[a + i]]; hNodes[i] = {u.start, u.len}; hLong[i] = (int32_t)i; }
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dNodes, hNodes.data(), nn * sizeof(WvNode), hipMemcpyHostToDevice, ctx->stream));
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOpsOff, hOpsOff.data(), nn * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dLim, hLim.data(), nn * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));      // the chain stops at the decided arg-max: nothing behind it enters the coefficient
+                { const int nChunks = upload_long(hLong, &hLim); rc = long_pass(nn, nChunks, true, dOpsOff, dLim); if (rc) return rc; }
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
+                CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                CANVAS_HIP_TRY(ctx, hipGetLastError());
+                hRedo.clear();
+                for (size_t i = 0; i < nn; i++) if (hOut[i].flag) hRedo.push_back((int32_t)i);
+                if (!hRedo.empty()) {                            // a checkpoint of the shortcut chain was not reproduced: IEEE divisions in the chain for those nodes
+                    redone += (long long)hRedo.size();
+                    // (the slices of the operand array follow the list order: the redo list keeps the nodes' own offsets and limits)
+                    std::vector<long long> ro; std::vector<int32_t> rl; for (int32_t i : hRedo) { ro.push_back(hOpsOff[(size_t)i]); rl.push_back(hLim[(size_t)i]); }
+                    const int nChunks = upload_long(hRedo, &rl);
+                    CANVAS_HIP_TRY(ctx, hipMemcpy(dOpsOff, ro.data(), ro.size() * sizeof(long long), hipMemcpyHostToDevice));
+                    CANVAS_HIP_TRY(ctx, hipMemcpy(dLim, rl.data(), rl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    rc = long_pass(hRedo.size(), nChunks, false, dOpsOff, dLim); if (rc) return rc;
+                    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
+                    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    CANVAS_HIP_TRY(ctx, hipGetLastError());
+                    for (int32_t i : hRedo) if (hOut[i].flag) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the exact chain was not reproduced by its own check");
+                }
+                for (size_t i = 0; i < nn; i++) {
+                    const WvDNode& u = hExact[order[a + i]];
+                    if (hOut[i].ind != hExactInd[order[a + i]]) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: a decided arg-max disagrees with the exact chain (error bound violated)");
+                    ChromTree& T = trees[u.chrom];
+                    const int32_t s1 = (int32_t)(u.start - off[u.chrom] + 1), e1 = s1 + u.len - 1, b = s1 + hOut[i].ind - 1;
+                    if (std::fabs(hOut[i].coef) > T.keepAbove) T.cands.push_back({u.level, s1, b, e1, hOut[i].coef});
+                }
+                a += nn;
+            }
+        }
+        tcExact = now() - tcA;
+        if (timing) fprintf(stderr, "canvas_wavelets: closed-form levels %.4f s, undecided nodes %.4f s, exact chains %.4f s (%u roots)\n", tcLevels, tcUndec, tcExact, hdev.nRoots);
+        rootsUsed = hdev.nRoots;
+        cur.clear();
+    }
+    ctx->wv_stats[0] = nDecided; ctx->wv_stats[1] = nUndecided; ctx->wv_stats[2] = nExactChains; ctx->wv_stats[3] = closedForm ? 1 : 0;
+    // ---- the same with the chain for every long node (coverage that is not two-decimal text, or CANVAS_WV_CHAIN_ONLY=1), level by level for all chromosomes at once
     for (int level = 0; !cur.empty(); level++, levels++) {
         const size_t nn = cur.size();
         if (nn > maxLong) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: long-node list overflow");
@@ -638,7 +1021,9 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
     // ---- the subtrees: node counts per level and the surviving coefficients come back in one piece
     {
         unsigned long long hN[2] = {0, 0};
+        const double tSide0 = now();
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+        if (timing) fprintf(stderr, "canvas_wavelets: waited %.4f s for the subtrees\n", now() - tSide0);
         CANVAS_HIP_TRY(ctx, hipGetLastError());
         CANVAS_HIP_TRY(ctx, hipMemcpy(hN, dNcand, sizeof hN, hipMemcpyDeviceToHost));
         if (hN[1] & 0xFFFFFFFFull) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: candidate list overflow");
@@ -663,6 +1048,7 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
     }
     ctx->wv_levels = levels; ctx->wv_redone = redone;
     const double t2 = now();
+    if (timing) fprintf(stderr, "canvas_wavelets: prefix + roots %.4f s after variability\n", t2 - t1);
     // ---- per chromosome: HardThresh, reconstruction, healing, refinement (WaveletSegmentation.cs:73-250, 373-425); the chromosomes are independent (the reference runs
     // them under Parallel.ForEach, WaveletsRunner.cs:115-135): one task per chromosome on a few host threads, results concatenated in chromosome order
     if (f3Thread.joinable()) f3Thread.join();
@@ -745,5 +1131,10 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
 extern "C" int32_t canvas_wavelets_stats(canvas_ctx* ctx, int64_t* h_out2) {
     if (!ctx || !h_out2) return CANVAS_ERR_INVALID;
     h_out2[0] = ctx->wv_levels; h_out2[1] = ctx->wv_redone;
+    return CANVAS_OK;
+}
+extern "C" int32_t canvas_wavelets_decisions(canvas_ctx* ctx, int64_t* h_out4) {
+    if (!ctx || !h_out4) return CANVAS_ERR_INVALID;
+    for (int i = 0; i < 4; i++) h_out4[i] = ctx->wv_stats[i];
     return CANVAS_OK;
 }

@@ -277,6 +277,10 @@ int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* d_cov, cons
                         int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset);
 /* last canvas_wavelets call: [0] tree levels processed, [1] nodes whose shortcut division disagreed with the IEEE one and were recomputed */
 int32_t canvas_wavelets_stats(canvas_ctx* ctx, int64_t* h_out2);
+/* last canvas_wavelets call: [0] long nodes whose arg-max was decided from the closed form (exact prefix sums + rounding-error bound of WaveletSegmentation.cs:19-48),
+   [1] long nodes the bound could not decide (exact chain), [2] long nodes chained for their coefficient (candidates to survive HardThresh, WaveletSegmentation.cs:73-117),
+   [3] 1 if the closed form was in use (coverage of non-negative two-decimal values) */
+int32_t canvas_wavelets_decisions(canvas_ctx* ctx, int64_t* h_out4);
 
 /* ---- one sample through the whole path in one call -------------------------------------------------------------
  * canvas_bin_sample -> canvas_clean2 -> canvas_quantize_f2 -> canvas_chromosome_offsets -> canvas_hmm_per_sample -> canvas_segment_ids with

@@ -9,6 +9,8 @@
 // and both depend on the platform's log() (Math.Log -> libm on Linux).
 #include "oracle_common.h"
 #include "oracle_api.h"
+#include <atomic>
+#include <thread>
 #include <functional>
 
 namespace oracle {
@@ -351,6 +353,33 @@ int64_t orc_wavelets(int nchr, const double* cov, const int64_t* off, int is_ger
         if (std::max<int64_t>(L, 1) > min_size) wv::HaarWavelets(cov + off[c], (int)L, thr_lower, thr_upper, bp, is_germline != 0, mad_factor, hasCV, cv, f3);
         if (total + (int64_t)bp.size() > cap) return -1;
         for (int v : bp) out[total++] = v;
+    }
+    out_off[nchr] = total;
+    return total;
+}
+// the same with one task per chromosome on `threads` host threads, as WaveletsRunner.Run does (Parallel.ForEach over the chromosomes, WaveletsRunner.cs:89-135):
+// the timing baseline of bench.py; results are those of orc_wavelets
+int64_t orc_wavelets_threads(int nchr, const double* cov, const int64_t* off, int is_germline, double thr_lower, double thr_upper, double mad_factor, int window,
+                             int min_size, int32_t* out, int64_t cap, int64_t* out_off, int threads) {
+    double cv = 0; bool hasCV = wv::CoverageVariability(window, nchr, cov, off, cv);
+    std::vector<double> f3 = wv::FactorOfThree(nchr, cov, off);
+    std::vector<std::vector<int>> bps((size_t)nchr);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (int c = next.fetch_add(1); c < nchr; c = next.fetch_add(1)) {
+            const int64_t L = off[c + 1] - off[c];
+            if (std::max<int64_t>(L, 1) > min_size) wv::HaarWavelets(cov + off[c], (int)L, thr_lower, thr_upper, bps[(size_t)c], is_germline != 0, mad_factor, hasCV, cv, f3);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < std::max(1, std::min(threads, nchr)); t++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    int64_t total = 0;
+    for (int c = 0; c < nchr; c++) {
+        out_off[c] = total;
+        if (total + (int64_t)bps[(size_t)c].size() > cap) return -1;
+        for (int v : bps[(size_t)c]) out[total++] = v;
     }
     out_off[nchr] = total;
     return total;

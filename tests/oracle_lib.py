@@ -396,19 +396,25 @@ def factor_of_three(per_chr):
     return out[:k].copy()
 
 
-def wavelets_genome(per_chr, is_germline=False, thr_lower=0.05, thr_upper=80.0, mad_factor=5.0, window=100000, min_size=10):
-    """WaveletsRunner.Run up to the breakpoints (WaveletsRunner.cs:52-150): list of breakpoint arrays, one per chromosome"""
+def wavelets_genome(per_chr, is_germline=False, thr_lower=0.05, thr_upper=80.0, mad_factor=5.0, window=100000, min_size=10, threads=1):
+    """WaveletsRunner.Run up to the breakpoints (WaveletsRunner.cs:52-150): list of breakpoint arrays, one per chromosome; threads > 1: one task per chromosome
+    (the reference's Parallel.ForEach, WaveletsRunner.cs:89-135), same results"""
     cov = np.ascontiguousarray(np.concatenate(per_chr), np.float64)
     off = np.concatenate([[0], np.cumsum([len(a) for a in per_chr])]).astype(np.int64)
     out = np.zeros(len(cov) + len(per_chr) + 1, np.int32); oo = np.zeros(len(per_chr) + 1, np.int64)
-    k = lib.orc_wavelets(len(per_chr), _p(cov), _p(off), int(bool(is_germline)), C.c_double(thr_lower), C.c_double(thr_upper), C.c_double(mad_factor), int(window),
-                         int(min_size), _p(out), C.c_int64(len(out)), _p(oo))
+    if threads > 1:
+        k = lib.orc_wavelets_threads(len(per_chr), _p(cov), _p(off), int(bool(is_germline)), C.c_double(thr_lower), C.c_double(thr_upper), C.c_double(mad_factor), int(window),
+                                     int(min_size), _p(out), C.c_int64(len(out)), _p(oo), int(threads))
+    else:
+        k = lib.orc_wavelets(len(per_chr), _p(cov), _p(off), int(bool(is_germline)), C.c_double(thr_lower), C.c_double(thr_upper), C.c_double(mad_factor), int(window),
+                             int(min_size), _p(out), C.c_int64(len(out)), _p(oo))
     assert k >= 0
     return [out[oo[c]:oo[c + 1]].copy() for c in range(len(per_chr))]
 
 
 # ---- CanvasNormalize (oracle_normalize.cpp)
 lib.orc_norm_ratio.restype = C.c_int64
+lib.orc_wavelets_threads.restype = C.c_int64
 
 
 def norm_weighted_reference(counts, on_idx=None):

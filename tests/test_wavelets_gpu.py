@@ -93,3 +93,25 @@ def test_nan_threshold_keeps_every_coefficient():
         exp = O.wavelets_genome([x], is_germline=germline, window=100)
         got = _run(cv, [x], is_germline=germline, window=100)
         assert got[0].tolist() == exp[0].tolist() and len(exp[0]) > 20
+
+
+def test_closed_form_decisions_agree_with_the_chains(monkeypatch):
+    """Default path: the arg-max of every long node is decided from exact prefix sums + the rounding-error bound of the reference's recurrences (canvas_wavelets_decisions);
+    exact ties (a flat chromosome) cannot be decided and go through the chain.  CANVAS_WV_CHAIN_ONLY=1 runs every long node through the chain: same breakpoints.  A coverage
+    that is not made of two-decimal values (no exact integer sums) takes the chains by itself."""
+    cv = get_canvas()
+    rng = np.random.RandomState(21)
+    per = [_coverage(rng, 90_000, wave=0.05), _coverage(rng, 20_000), np.full(3000, 77.0)]
+    exp = O.wavelets_genome(per, window=5000)
+    got = _run(cv, per, window=5000)
+    dec = cv.wavelets_decisions()
+    assert [g.tolist() for g in got] == [e.tolist() for e in exp]
+    assert dec[3] == 1 and dec[0] > 50 and dec[1] >= 1 and dec[2] >= 1, dec
+    monkeypatch.setenv("CANVAS_WV_CHAIN_ONLY", "1")
+    got2 = _run(cv, per, window=5000)
+    assert [g.tolist() for g in got2] == [e.tolist() for e in exp] and cv.wavelets_decisions()[3] == 0
+    monkeypatch.delenv("CANVAS_WV_CHAIN_ONLY")
+    per3 = [per[0] * 1.0000001, per[1]]
+    exp3 = O.wavelets_genome(per3, window=5000)
+    got3 = _run(cv, per3, window=5000)
+    assert [g.tolist() for g in got3] == [e.tolist() for e in exp3] and cv.wavelets_decisions()[3] == 0

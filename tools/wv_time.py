@@ -11,4 +11,5 @@ for n in (100_000, 400_000):
     cv.profile_get("wavelet_chain", reset=True)
     t = time.perf_counter(); bp = cv.wavelets(d, off); dt = time.perf_counter() - t
     ms, k = cv.profile_get("wavelet_chain"); st = cv.wavelets_stats()
-    print(f"n={n}: total {dt*1e3:.1f} ms, chain kernels {ms:.1f} ms over {k} launches, levels {st[0]}, first-level est {ms/k:.2f} ms avg; breakpoints {len(bp[0])}")
+    print("decisions [closed-form, undecided, exact chains, closed form on]:", cv.wavelets_decisions())
+    print(f"n={n}: total {dt*1e3:.1f} ms, chain kernels {ms:.1f} ms over {k} launches, levels {st[0]}, first-level est {ms/max(1,k):.2f} ms avg; breakpoints {len(bp[0])}")
