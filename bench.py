@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--stage-times", action="store_true", help="print per-stage host wall times (ms) of the last step to stderr")
     ap.add_argument("--staged", action="store_true", help="time the six per-stage library calls from Python instead of the one-call canvas_sample_pipeline")
     ap.add_argument("--no-wavelets", action="store_true", help="skip the (untimed) Wavelets run on the cleaned coverage that is reported as wavelets_path")
+    ap.add_argument("--no-executables", action="store_true", help="skip the (untimed for `value`) run of the three drop-in executables on files: the file-I/O-inclusive figure of SURVEY 8(d)")
     ap.add_argument("--no-cbs", action="store_true", help="skip the (untimed) CBS run on the cleaned coverage that is reported as cbs_path")
     ap.add_argument("--no-pedigree", action="store_true", help="skip the trio flow of BASELINE configs[3] that is reported as pedigree_flow")
     ap.add_argument("--no-somatic", action="store_true", help="skip the tumour / normal flow of BASELINE configs[4] that is reported as somatic_flow")
@@ -321,6 +322,8 @@ def main():
                 for k in ("value_incl_h2d", "value_incl_h2d_reference_resident", "value_incl_h2d_and_host_packing_of_the_hits"):
                     tb["speedup_vs_cpu_baseline_" + k] = round(tb[k] / result["cpu_baseline"]["value"], 2)
     host = None
+    if rank == 0 and world == 1 and not args.no_executables:
+        result["executables"] = executables_leg(args, bases, masks, hits, lens, keep, result.get("cpu_baseline"))
     if rank == 0 and world == 1 and not args.no_somatic:
         result["somatic_flow"] = somatic_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, device)
     if rank == 0 and world == 1 and not args.no_pedigree:
@@ -593,6 +596,110 @@ def packed_region(args, cv, torch, host, bases, masks, hits, lens, is_auto, flag
                                                   "a host that fills the planes while it parses the BAM pays neither"},
                     "value_incl_h2d_and_host_packing_of_the_hits": round(int(rb["total"]) / (t_hits + t_phit), 1)})
     return res
+
+
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80); v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _ld_header(field, nbytes):
+    return _varint(field << 3 | 2) + _varint(nbytes)
+
+
+def _write_dat(path, name, mask_bytes, hits, L):
+    """CanvasBin.IntermediateData of one chromosome as protobuf-net writes it (CanvasBin.cs:1037-1072; the layout tests/test_canvasbin_tool_gpu.py pins):
+    member 1 possible-alignment bits (read back least significant bit first), member 2 observed alignments, member 3 bits in the last byte"""
+    key = _ld_header(1, len(name)) + name.encode()
+    with open(path, "wb") as f:
+        for field, payload in ((1, mask_bytes), (2, hits)):
+            val = _ld_header(2, len(payload))
+            f.write(_ld_header(field, len(key) + len(val) + len(payload)) + key + val)
+            payload.tofile(f)
+        last = _varint(2 << 3 | 0) + _varint(int(L % 8))
+        f.write(_ld_header(3, len(key) + len(last)) + key + last)
+
+
+def executables_leg(args, bases, masks, hits, lens, keep, cpu):
+    """What a user of the reference launches (CanvasRunner.cs:123-128): the three drop-in executables exchanging files.  The synthetic sample is written once as kmer.fa +
+    per-chromosome .dat intermediates (CanvasBin -c's output), then CanvasBin -i -> CanvasClean -g -s -r --local-sd-metric-file -> CanvasPartition -m {PerSampleHMM, CBS,
+    Wavelets} run as processes, wall-clock, file I/O (gzip text, protobuf, FASTA) and host-side packing included; every tool reports how its wall time splits into reading,
+    device work (incl. H2D / D2H and context creation) and writing.  The CPU column is an ESTIMATE: the same tools with the device phase replaced by the oracle's seconds on
+    24 threads (cpu_baseline) — the reference's C# cannot be built here, and its file I/O is the same work."""
+    import shutil, subprocess, tempfile
+    from canvas_amd import synth
+    root = tempfile.mkdtemp(prefix="canvas_exe_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        total_bytes = int(sum(int(L) for L in lens))
+        free = shutil.disk_usage(root).free
+        nchr = len(lens)
+        if free < 2.6 * total_bytes + (2 << 30):
+            return {"skipped": "not enough space under %s for the sample's files (%.1f GB free, %.1f GB needed)" % (root, free / 1e9, (2.6 * total_bytes + (2 << 30)) / 1e9)}
+        names = synth.CHROM_NAMES[:nchr]
+        t0 = time.perf_counter()
+        fa = os.path.join(root, "kmer.fa"); dats = []
+        with open(fa, "wb") as f:
+            for c in range(nchr):
+                L = int(lens[c])
+                f.write((">%s\n" % names[c]).encode()); bases[c][:L].cpu().numpy().tofile(f); f.write(b"\n")
+        for c in range(nchr):
+            L = int(lens[c])
+            d = os.path.join(root, names[c] + ".dat"); dats.append(d)
+            _write_dat(d, names[c], masks[c].cpu().numpy().view(np.uint8)[:(L + 7) // 8], hits[c][:L].cpu().numpy(), L)
+        bam = os.path.join(root, "S.bam"); open(bam, "wb").write(b"")          # -b must exist even with -i (CanvasBin/Program.cs:148-153)
+        ref = os.path.join(root, "WholeGenomeFasta"); os.mkdir(ref)
+        t_inputs = time.perf_counter() - t0
+        bdir = os.path.join(ROOT, "canvas_amd", "bin")
+        env = dict(os.environ, CANVAS_TOOL_TIMING="1")
+
+        def run(tool, argv):
+            t = time.perf_counter()
+            r = subprocess.run([os.path.join(bdir, tool)] + argv, capture_output=True, text=True, env=env)
+            wall = time.perf_counter() - t
+            ph = None
+            for line in r.stderr.splitlines():
+                if line.startswith('{"tool"'):
+                    ph = json.loads(line)
+            o = {"wall_seconds": round(wall, 3), "exit_code": r.returncode}
+            if ph:
+                o["phases"] = {k: round(v, 3) for k, v in ph["phases"].items()}
+            if r.returncode != 0:
+                o["stderr_tail"] = r.stderr[-300:]
+            return o
+        binned = os.path.join(root, "S.binned"); cleaned = os.path.join(root, "S.cleaned"); lsd = os.path.join(root, "LocalSD.txt")
+        res = {"inputs": {"kmer_fa_GB": round(os.path.getsize(fa) / 1e9, 2), "dat_GB": round(sum(os.path.getsize(d) for d in dats) / 1e9, 2), "seconds_to_write_them": round(t_inputs, 1)}}
+        argv = ["-b", bam, "-r", fa, "-o", binned, "-d", "100", "-m", "TruncatedDynamicRange"]
+        for d in dats:
+            argv += ["-i", d]
+        res["CanvasBin"] = run("CanvasBin", argv)
+        res["CanvasClean"] = run("CanvasClean", ["-i", binned, "-o", cleaned, "-g", "-s", "-r", "--local-sd-metric-file=" + lsd])
+        for method in ("PerSampleHMM", "CBS", "Wavelets"):
+            res["CanvasPartition -m " + method] = run("CanvasPartition", ["-i", cleaned, "-o", os.path.join(root, "S.%s.partitioned" % method), "-r", ref, "-m", method])
+        ok = all(v.get("exit_code") == 0 for k, v in res.items() if k.startswith("Canvas"))
+        res["all_exit_codes_zero"] = ok
+        if ok:
+            import gzip
+            with gzip.open(cleaned, "rb") as f:
+                res["cleaned_rows"] = sum(1 for _ in f)
+            res["cleaned_rows_equal_the_library_call"] = bool(res["cleaned_rows"] == int(keep["n_out"]))
+            wall = res["CanvasBin"]["wall_seconds"] + res["CanvasClean"]["wall_seconds"] + res["CanvasPartition -m PerSampleHMM"]["wall_seconds"]
+            res["wall_seconds_bin_clean_partition(PerSampleHMM)"] = round(wall, 3)
+            res["bins_per_s_file_io_inclusive"] = round(int(keep["total"]) / wall, 1)
+            if cpu and "seconds" in cpu:
+                io = 0.0
+                for k in ("CanvasBin", "CanvasClean", "CanvasPartition -m PerSampleHMM"):
+                    ph = res[k].get("phases", {})
+                    io += sum(v for n, v in ph.items() if n in ("read", "write"))
+                est = io + float(cpu["seconds"]["total"])
+                res["cpu_tools_estimate"] = {"seconds": round(est, 3), "file_io_seconds_of_the_same_tools": round(io, 3), "oracle_compute_seconds": cpu["seconds"]["total"], "threads": cpu.get("cores"),
+                                             "note": "estimate: read + write phases of the drop-in tools + the oracle's Bin + Clean + PerSampleHMM seconds (cpu_baseline)"}
+                res["speedup_file_io_inclusive_vs_estimate"] = round(est / wall, 2)
+        return res
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def somatic_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, device):

@@ -23,23 +23,44 @@ using namespace tool;
 
 // ---------------------------------------------------------------- FASTA (kmer.fa: upper case = start of a unique k-mer)
 struct FastaEntry { std::string name, bases; };
+// the file is mapped, the entry headers are located in one scan and the entries are copied (line ends dropped) on several threads
 static bool read_fasta(const std::string& path, const std::string* only, std::vector<FastaEntry>& out) {
-    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
-    std::vector<char> buf(1 << 20);
-    FastaEntry* cur = nullptr; bool keep = false;
-    std::string line;
-    auto flush_line = [&]() {
-        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
-        if (!line.empty() && line[0] == '>') {
-            std::string name = line.substr(1); size_t sp = name.find_first_of(" \t"); if (sp != std::string::npos) name = name.substr(0, sp);
-            keep = !only || name == *only;
-            if (keep) { out.push_back({name, std::string()}); cur = &out.back(); } else cur = nullptr;
-        } else if (keep && cur) cur->bases += line;
-        line.clear();
-    };
-    while (fgets(buf.data(), (int)buf.size(), f)) { line += buf.data(); if (!line.empty() && line.back() == '\n') flush_line(); }
-    if (!line.empty()) flush_line();
-    fclose(f); return true;
+    MappedFile mf; if (!mf.open(path)) return false;
+    const char* p = mf.p; const size_t n = mf.n;
+    struct Ent { size_t hdr, seq, end; std::string name; };
+    std::vector<Ent> ents;
+    {   // '>' at the start of a line (scanned in slices on several threads, then put in order)
+        const int nt = io_threads();
+        std::vector<std::vector<size_t>> found((size_t)nt);
+        parallel_for(nt, [&](int64_t t) {
+            size_t a = n / (size_t)nt * (size_t)t, b = t == nt - 1 ? n : n / (size_t)nt * (size_t)(t + 1);
+            for (const char* q = p + a; q < p + b;) { q = (const char*)memchr(q, '>', (size_t)(p + b - q)); if (!q) break; if (q == p || q[-1] == '\n') found[(size_t)t].push_back((size_t)(q - p)); q++; }
+        });
+        for (auto& v : found) for (size_t h : v) { Ent e; e.hdr = h; e.seq = e.end = n; ents.push_back(e); }
+    }
+    for (size_t i = 0; i < ents.size(); i++) {
+        const char* le = (const char*)memchr(p + ents[i].hdr, '\n', n - ents[i].hdr);
+        const size_t lineEnd = le ? (size_t)(le - p) : n;
+        std::string name(p + ents[i].hdr + 1, lineEnd - ents[i].hdr - 1);
+        while (!name.empty() && (name.back() == '\r')) name.pop_back();
+        const size_t sp = name.find_first_of(" \t"); if (sp != std::string::npos) name = name.substr(0, sp);
+        ents[i].name = name; ents[i].seq = std::min(n, lineEnd + 1); ents[i].end = i + 1 < ents.size() ? ents[i + 1].hdr : n;
+    }
+    std::vector<size_t> keep;
+    for (size_t i = 0; i < ents.size(); i++) if (!only || ents[i].name == *only) keep.push_back(i);
+    const size_t base = out.size();
+    out.resize(base + keep.size());
+    parallel_for((int64_t)keep.size(), [&](int64_t k) {
+        const Ent& e = ents[keep[(size_t)k]]; FastaEntry& fe = out[base + (size_t)k];
+        fe.name = e.name; fe.bases.clear(); fe.bases.reserve(e.end - e.seq);
+        for (const char* q = p + e.seq; q < p + e.end;) {
+            const char* le = (const char*)memchr(q, '\n', (size_t)(p + e.end - q)); const char* stop = le ? le : p + e.end;
+            const char* te = stop; while (te > q && te[-1] == '\r') te--;
+            fe.bases.append(q, (size_t)(te - q));
+            q = le ? le + 1 : p + e.end;
+        }
+    });
+    return true;
 }
 
 // ---------------------------------------------------------------- BGZF / BAM / BAI
@@ -260,6 +281,7 @@ static int parse_mode(const std::string& m) {       // Utilities.ParseCanvasCove
 }
 
 int main(int argc, char** argv) {
+    Phases ph("CanvasBin");
     printf(">>>Command-line arguments:\n"); for (int i = 1; i < argc; i++) printf("%s ", argv[i]); printf("\n");
     std::vector<Opt> opts = {{"b", "bam", true}, {"r", "reference", true}, {"c", "chr", true}, {"i", "infile", true}, {"f", "filter", true}, {"d", "bindepth", true}, {"z", "binsize", true},
                              {"o", "outfile", true}, {"y", "binsizeonly", false}, {"h", "help", false}, {"p", "paired-end", false}, {"m", "mode", true}, {"t", "manifest", true}, {"n", "bins", true}, {"j", "injson", true}};
@@ -363,21 +385,37 @@ int main(int argc, char** argv) {
 
     // ---- phase 2: RunSingleSample (CanvasBin.cs:914-931)
     std::map<std::string, std::unique_ptr<Inter>> byChrom;
-    for (auto& p : inters) {
-        if (!file_exists(p)) { fprintf(stderr, "CanvasBin: intermediate file %s does not exist\n", p.c_str()); return 1; }
-        pbdat::Data pd; std::string perr;
-        if (!pbdat::read_file(p, pd, perr)) { fprintf(stderr, "CanvasBin: %s\n", perr.c_str()); return 1; }
-        for (auto& kv : pd) {                                                               // DeserializeCanvasData + IntermediateData.GetData (CanvasBin.cs:725-762,1089-1104)
-            auto d = std::make_unique<Inter>(); d->name = kv.first;
-            d->len = pbdat::unpack_possible_lsb(kv.second.possibleBytes, kv.second.bitsInLastByte, d->maskWords);      // least significant bit first, as the C# reader (Q2)
-            d->hits.swap(kv.second.observed); d->frag.swap(kv.second.fragmentLengths);
-            if ((int64_t)d->hits.size() != d->len) { fprintf(stderr, "CanvasBin: %s: %s has %lld possible-alignment bits but %zu observed-alignment bytes\n", p.c_str(), kv.first.c_str(), (long long)d->len, d->hits.size()); return 1; }
-            if (byChrom.count(kv.first)) { fprintf(stderr, "CanvasBin: chromosome %s appears in more than one intermediate file (Dictionary.Add throws in the reference)\n", kv.first.c_str()); return 1; }
-            byChrom[kv.first] = std::move(d);
+    for (auto& p : inters) if (!file_exists(p)) { fprintf(stderr, "CanvasBin: intermediate file %s does not exist\n", p.c_str()); return 1; }
+    {   // one host thread per intermediate file (the reference deserialises them one after the other, CanvasBin.cs:725-762); merged in command-line order
+        std::vector<pbdat::Data> pds(inters.size()); std::vector<std::string> perr(inters.size()); std::vector<char> okv(inters.size(), 0);
+        std::vector<std::vector<std::unique_ptr<Inter>>> made(inters.size()); std::vector<std::string> badEntry(inters.size());
+        parallel_for((int64_t)inters.size(), [&](int64_t i) {
+            okv[(size_t)i] = pbdat::read_file(inters[(size_t)i], pds[(size_t)i], perr[(size_t)i]) ? 1 : 0;
+            if (!okv[(size_t)i]) return;
+            for (auto& kv : pds[(size_t)i]) {                                                 // DeserializeCanvasData + IntermediateData.GetData (CanvasBin.cs:725-762,1089-1104)
+                auto d = std::make_unique<Inter>(); d->name = kv.first;
+                d->len = pbdat::unpack_possible_lsb(kv.second.possibleBytes, kv.second.bitsInLastByte, d->maskWords, kv.second.haveBits);      // least significant bit first, as the C# reader (Q2)
+                if (d->len < 0) { badEntry[(size_t)i] = kv.first; return; }
+                std::vector<uint8_t>().swap(kv.second.possibleBytes);
+                d->hits.swap(kv.second.observed); d->frag.swap(kv.second.fragmentLengths);
+                made[(size_t)i].push_back(std::move(d));
+            }
+        });
+        for (size_t i = 0; i < inters.size(); i++) {
+            const std::string& p = inters[i];
+            if (!okv[i]) { fprintf(stderr, "CanvasBin: %s\n", perr[i].c_str()); return 1; }
+            if (!badEntry[i].empty()) { fprintf(stderr, "CanvasBin: %s: %s has no valid count of bits in the last possible-alignment byte (0..7 expected)\n", p.c_str(), badEntry[i].c_str()); return 1; }
+            for (auto& d : made[i]) {
+                if ((int64_t)d->hits.size() != d->len) { fprintf(stderr, "CanvasBin: %s: %s has %lld possible-alignment bits but %zu observed-alignment bytes\n", p.c_str(), d->name.c_str(), (long long)d->len, d->hits.size()); return 1; }
+                if (byChrom.count(d->name)) { fprintf(stderr, "CanvasBin: chromosome %s appears in more than one intermediate file (Dictionary.Add throws in the reference)\n", d->name.c_str()); return 1; }
+                const std::string nm = d->name;
+                byChrom[nm] = std::move(d);
+            }
         }
     }
     std::vector<FastaEntry> fa;
     if (!read_fasta(ref, nullptr, fa)) return 1;
+    ph.mark("read");
     // chromosomes in FASTA order that have an intermediate (CanvasBin.cs:506-540)
     std::vector<const FastaEntry*> order; std::vector<Inter*> data;
     for (auto& e : fa) { auto it = byChrom.find(e.name); if (it == byChrom.end()) continue; if ((int64_t)e.bases.size() != it->second->len) { fprintf(stderr, "CanvasBin: length of %s differs between the reference and the intermediate file\n", e.name.c_str()); return 1; } order.push_back(&e); data.push_back(it->second.get()); }
@@ -407,6 +445,7 @@ int main(int argc, char** argv) {
         if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { if ((int64_t)data[c]->frag.size() != L) { fprintf(stderr, "CanvasBin: %s has no fragment lengths (was the intermediate written with -m GCContentWeighted?)\n", order[c]->name.c_str()); return 1; } pFrag[c] = (const int16_t*)up(data[c]->frag.data(), L * 2, L * 2 + 64); }
         if (!pBases[c] || !pHits[c] || !pMask[c]) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
     }
+    ph.mark("pack_upload");
     if (a.has("bins") && !a.has("binsizeonly")) {
         // ---- predefined bins (BinCounts with predefinedBins, CanvasBin.cs:506-547): chromosomes in FASTA order that have both an intermediate and bins
         if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { fprintf(stderr, "CanvasBin (MI355X): -n with -m GCContentWeighted is not built\n"); return 1; }
@@ -459,9 +498,11 @@ int main(int argc, char** argv) {
         TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hStop.data(), dStop.p, total * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hGc.data(), dGc.p, total * 4));
         TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hCount.data(), dCount.p, total * 4));
     }
-    GzWriter wr(out); if (!wr.ok()) { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
-    for (int64_t i = 0; i < total; i++)                                        // CanvasIO.WriteToTextFile (CanvasCommon/IO.cs:15-24)
-        wr.line(order[hChr[i]]->name + "\t" + std::to_string(hStart[i]) + "\t" + std::to_string(hStop[i]) + "\t" + format_f2(hCount[i]) + "\t" + std::to_string(hGc[i]));
+    ph.mark("device");
+    if (!write_gz_rows(out, total, [&](int64_t i, std::string& o) {                 // CanvasIO.WriteToTextFile (CanvasCommon/IO.cs:15-24)
+            o += order[hChr[i]]->name; o.push_back('\t'); append_int(o, hStart[i]); o.push_back('\t'); append_int(o, hStop[i]); o.push_back('\t'); o += format_f2(hCount[i]); o.push_back('\t'); append_int(o, hGc[i]); }))
+        { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
+    ph.mark("write");
     printf("Output complete\n");
     return 0;
 }

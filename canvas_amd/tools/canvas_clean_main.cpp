@@ -22,17 +22,23 @@ int main(int argc, char** argv) {
     if (a.has("manifest")) { fprintf(stderr, "CanvasClean (MI355X): -t/--manifest is not supported by this build\n"); return 1; }
     int minBins = a.has("weightedmedian") ? atoi(a.get("weightedmedian").c_str()) : 100;
 
+    Phases ph("CanvasClean");
     // CanvasIO.ReadFromTextFile (CanvasCommon/IO.cs:26-52)
-    std::vector<std::string> chromNames; std::map<std::string, int> chromIndex;
+    std::vector<std::string> chromNames;
     std::vector<int32_t> chr, start, stop, gc; std::vector<float> count;
-    { GzReader rd(inFile); std::string row;
-      while (rd.line(row)) { auto f = split_tab(row); if (f.size() < 5) continue;
-          auto it = chromIndex.find(f[0]); int ci; if (it == chromIndex.end()) { ci = (int)chromNames.size(); chromIndex[f[0]] = ci; chromNames.push_back(f[0]); } else ci = it->second;
-          chr.push_back(ci); start.push_back(atoi(f[1].c_str())); stop.push_back(atoi(f[2].c_str())); count.push_back((float)strtod(f[3].c_str(), nullptr)); gc.push_back(atoi(f[4].c_str())); } }
+    {   // rows with fewer than five fields are skipped; chromosome indices in order of first appearance (parsed on several threads: fast_io.hpp)
+        TextRows rows;
+        if (!read_text_rows(inFile, 5, rows)) { printf("CanvasClean.exe: cannot read %s\n", inFile.c_str()); return 1; }
+        const size_t m = rows.chr.size();
+        chromNames = rows.chromNames; chr = std::move(rows.chr); start.resize(m); stop.resize(m); gc = std::move(rows.gc); count.resize(m);
+        parallel_for((int64_t)((m + 65535) / 65536), [&](int64_t blk) { const size_t a = (size_t)blk * 65536, b = std::min(m, a + 65536);
+            for (size_t i = a; i < b; i++) { start[i] = (int32_t)rows.start[i]; stop[i] = (int32_t)rows.stop[i]; count[i] = (float)rows.value[i]; } });
+    }
     const int64_t n = (int64_t)chr.size(); const int nchr = (int)chromNames.size();
     std::vector<uint8_t> isAuto(nchr > 0 ? nchr : 1, 0), isY(nchr > 0 ? nchr : 1, 0);
     for (int c = 0; c < nchr; c++) { isAuto[c] = is_autosome(chromNames[c]); std::string lo = chromNames[c]; for (auto& ch : lo) ch = (char)tolower(ch); isY[c] = (lo == "chry" || lo == "y"); }   // LoessGCNormalizer.cs:49-50
     // chromosome indices must be non-decreasing for the library (bins grouped by chromosome in file order): first-appearance indexing gives that
+    ph.mark("read");
     int64_t nOut = n; double localSd = -1.0;
     if (n > 0) {
         canvas_ctx* ctx = canvas_create(0);
@@ -49,10 +55,13 @@ int main(int argc, char** argv) {
           TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, gc.data(), dGc.p, nOut * 4)); }
         canvas_destroy(ctx);
     }
+    ph.mark("device");
     // CanvasIO.WriteLocalSdMetricToTextFile (IO.cs:83-98) — only when the metric was computed (>= 50000 bins, CanvasClean.cs:483-494)
     if (a.has("local-sd-metric-file") && localSd >= 0) { FILE* f = fopen(a.get("local-sd-metric-file").c_str(), "wb"); if (f) { fprintf(f, "#localSD\t%s\n", format_g(localSd, 15).c_str()); fclose(f); } }
     // CanvasIO.WriteToTextFile (IO.cs:15-24)
-    { GzWriter wr(outFile); if (!wr.ok()) { fprintf(stderr, "cannot write %s\n", outFile.c_str()); return 1; }
-      for (int64_t i = 0; i < nOut; i++) wr.line(chromNames[chr[i]] + "\t" + std::to_string(start[i]) + "\t" + std::to_string(stop[i]) + "\t" + format_f2(count[i]) + "\t" + std::to_string(gc[i])); }
+    if (!write_gz_rows(outFile, nOut, [&](int64_t i, std::string& o) {
+            o += chromNames[chr[i]]; o.push_back('\t'); append_int(o, start[i]); o.push_back('\t'); append_int(o, stop[i]); o.push_back('\t'); o += format_f2(count[i]); o.push_back('\t'); append_int(o, gc[i]); }))
+        { fprintf(stderr, "cannot write %s\n", outFile.c_str()); return 1; }
+    ph.mark("write");
     return 0;
 }

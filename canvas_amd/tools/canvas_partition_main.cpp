@@ -120,20 +120,26 @@ int main(int argc, char** argv) {
     std::map<std::string, std::vector<std::pair<int, int>>> excluded;
     if (!bed.empty()) load_bed(bed, excluded);
 
+    Phases ph("CanvasPartition");
     // CanvasSegment.ReadBedInput (CanvasCommon/CanvasSegment.cs:1117-1163)
     std::vector<Sample> samples(inFiles.size());
     for (size_t s = 0; s < inFiles.size(); s++) {
         Sample& S = samples[s]; BinFilter filt; filt.excl = &excluded;
         std::map<std::string, int> index; std::vector<std::vector<uint32_t>> st, en; std::vector<std::vector<double>> cv;
-        GzReader rd(inFiles[s]); std::string row;
-        while (rd.line(row)) { auto f = split_tab(row); if (f.size() < 4) continue;
-            uint32_t b = (uint32_t)strtoul(f[1].c_str(), nullptr, 10), e = (uint32_t)strtoul(f[2].c_str(), nullptr, 10);
-            if (filt.skip(f[0], b, e)) continue;
-            auto it = index.find(f[0]); int ci; if (it == index.end()) { ci = (int)S.chromNames.size(); index[f[0]] = ci; S.chromNames.push_back(f[0]); st.emplace_back(); en.emplace_back(); cv.emplace_back(); } else ci = it->second;
-            st[ci].push_back(b); en[ci].push_back(e); cv[ci].push_back(strtod(f[3].c_str(), nullptr)); }
+        TextRows rows;
+        if (!read_text_rows(inFiles[s], 4, rows)) { fprintf(stderr, "CanvasPartition: cannot read %s\n", inFiles[s].c_str()); return 1; }      // (rows with fewer than four fields are skipped)
+        std::vector<int> ciOf(rows.chromNames.size(), -1);     // chromosome of the file -> chromosome of the sample (a chromosome whose bins are all filtered never gets one)
+        for (size_t i = 0; i < rows.chr.size(); i++) {
+            const std::string& name = rows.chromNames[(size_t)rows.chr[i]];
+            const uint32_t b = rows.start[i], e = rows.stop[i];
+            if (filt.skip(name, b, e)) continue;
+            int& ci = ciOf[(size_t)rows.chr[i]];
+            if (ci < 0) { ci = (int)S.chromNames.size(); index[name] = ci; S.chromNames.push_back(name); st.emplace_back(); en.emplace_back(); cv.emplace_back(); }
+            st[ci].push_back(b); en[ci].push_back(e); cv[ci].push_back(rows.value[i]); }
         S.off.push_back(0);
         for (size_t c = 0; c < S.chromNames.size(); c++) { S.start.insert(S.start.end(), st[c].begin(), st[c].end()); S.end.insert(S.end.end(), en[c].begin(), en[c].end()); S.cov.insert(S.cov.end(), cv[c].begin(), cv[c].end()); S.off.push_back((int64_t)S.start.size()); }
     }
+    ph.mark("read");
     canvas_ctx* ctx = canvas_create(0);
     if (!ctx) { fprintf(stderr, "CanvasPartition (MI355X): no usable GPU (this build has no CPU fallback)\n"); return 1; }
     // per sample: segments per chromosome as (start, end) genomic pairs
@@ -215,6 +221,7 @@ int main(int argc, char** argv) {
         }
     }
     canvas_destroy(ctx);
+    ph.mark("device");
     // GenomeSegmentationResults.SplitOverlappingSegments (GenomeSegmentationResults.cs:18-55)
     std::map<std::string, Segs> merged;
     if (method == "HMM") merged = jointSegs;
@@ -233,7 +240,7 @@ int main(int argc, char** argv) {
     // SegmentationResultsProcessor.PostProcessSegments (SegmentationResultsProcessor.cs:17-129) + WriteCanvasPartitionResults (Segmentation.cs:235-252)
     for (size_t s = 0; s < samples.size(); s++) {
         Sample& S = samples[s];
-        GzWriter wr(outFiles[s]); if (!wr.ok()) { fprintf(stderr, "cannot write %s\n", outFiles[s].c_str()); return 1; }
+        struct OutRow { uint32_t s, e; double cov; int id; int chrom; }; std::vector<OutRow> outRows;
         int segmentNum = -1;
         for (size_t c = 0; c < S.chromNames.size(); c++) {
             const std::string& chrom = S.chromNames[c];
@@ -260,9 +267,13 @@ int main(int argc, char** argv) {
             // bins of a segment are written ordered by start (SegmentWithBins.Bins, Models/SegmentWithBins.cs:11-14); OrderBy is stable
             for (size_t g0 = 0; g0 < rows.size();) { size_t g1 = g0; while (g1 < rows.size() && rows[g1].id == rows[g0].id) g1++;
                 std::stable_sort(rows.begin() + g0, rows.begin() + g1, [](const Row& x, const Row& y) { return x.s < y.s; }); g0 = g1; }
-            for (auto& r : rows) wr.line(chrom + "\t" + std::to_string(r.s) + "\t" + std::to_string(r.e) + "\t" + format_g(r.cov, 15) + "\t" + std::to_string(r.id));
+            for (auto& r : rows) outRows.push_back({r.s, r.e, r.cov, r.id, (int)c});
         }
+        if (!write_gz_rows(outFiles[s], (int64_t)outRows.size(), [&](int64_t i, std::string& o) { const OutRow& r = outRows[(size_t)i];
+                o += S.chromNames[(size_t)r.chrom]; o.push_back('\t'); append_uint(o, r.s); o.push_back('\t'); append_uint(o, r.e); o.push_back('\t'); o += format_g(r.cov, 15); o.push_back('\t'); append_int(o, r.id); }))
+            { fprintf(stderr, "cannot write %s\n", outFiles[s].c_str()); return 1; }
     }
     printf("CanvasPartition results written out\n");
+    ph.mark("write");
     return 0;
 }

@@ -109,10 +109,14 @@ static void pack_possible_msb(const uint64_t* lsbWords, int64_t length, std::vec
 }
 // IntermediateData.Convert (CanvasBin.cs:1106-1135): new BitArray(bytes) is least significant bit first; of the last byte only bitsInLastByte bits are taken (when it is not 0).
 // Returns the number of positions and the bits in the library's mask layout (bit i of the chromosome = bit (i & 63) of word i >> 6).
-static int64_t unpack_possible_lsb(const std::vector<uint8_t>& bytes, int bitsInLastByte, std::vector<uint64_t>& words) {
+// -1: the entry is malformed (no bit count, a count outside 0..7, or a partial last byte without any byte) — the reference's writer only emits length % 8
+static int64_t unpack_possible_lsb(const std::vector<uint8_t>& bytes, int bitsInLastByte, std::vector<uint64_t>& words, bool haveBits = true) {
+    if (!haveBits || bitsInLastByte < 0 || bitsInLastByte > 7 || (bitsInLastByte > 0 && bytes.empty())) return -1;
     const int64_t length = bitsInLastByte > 0 ? 8 * ((int64_t)bytes.size() - 1) + bitsInLastByte : 8 * (int64_t)bytes.size();
     words.assign((size_t)((length + 63) / 64), 0);
-    for (int64_t i = 0; i < length; i++) if ((bytes[(size_t)(i >> 3)] >> (i & 7)) & 1) words[(size_t)(i >> 6)] |= 1ull << (i & 63);
+    // bit i of the chromosome = bit (i & 7) of byte i >> 3 = bit (i & 63) of the little-endian word i >> 6: the bytes ARE the words
+    if (!bytes.empty()) memcpy(words.data(), bytes.data(), std::min(bytes.size(), words.size() * 8));
+    if (length & 63) words.back() &= (~0ull) >> (64 - (length & 63));         // bits of the last byte beyond bitsInLastByte are not part of the chromosome
     return length;
 }
 

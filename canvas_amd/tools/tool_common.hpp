@@ -4,6 +4,7 @@
 // The drivers use ONLY the C ABI of include/canvas_hip.h (what the C# hosts would P/Invoke).
 #pragma once
 #include <zlib.h>
+#include <time.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -13,6 +14,7 @@
 #include <string>
 #include <vector>
 #include "../../include/canvas_hip.h"
+#include "fast_io.hpp"
 
 #ifndef CANVAS_SRC_HASH
 #define CANVAS_SRC_HASH "unhashed-build-0000000000000000"
@@ -51,7 +53,8 @@ struct GzReader { gzFile f; explicit GzReader(const std::string& path) { f = gzo
         while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
         return any; } };
 struct GzWriter { gzFile f; explicit GzWriter(const std::string& path) { f = gzopen(path.c_str(), "wb"); } ~GzWriter() { if (f) gzclose(f); }
-    bool ok() const { return f != nullptr; } void line(const std::string& s) { gzwrite(f, s.data(), (unsigned)s.size()); gzputc(f, '\n'); } };
+    bool ok() const { return f != nullptr; } void line(const std::string& s) { gzwrite(f, s.data(), (unsigned)s.size()); gzputc(f, '\n'); }
+    void close() { if (f) { gzclose(f); f = nullptr; } } };
 static std::vector<std::string> split_tab(const std::string& s) { std::vector<std::string> r; size_t a = 0; for (;;) { size_t b = s.find('\t', a); r.push_back(s.substr(a, b == std::string::npos ? b : b - a)); if (b == std::string::npos) break; a = b + 1; } return r; }
 static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) { fclose(f); return true; } return false; }
 
@@ -109,6 +112,20 @@ struct Dev {      // tiny RAII around the ABI's device memory
     Dev(canvas_ctx* c, int64_t bytes) : ctx(c) { p = canvas_device_malloc(c, bytes > 0 ? bytes : 1); }
     ~Dev() { if (p) canvas_device_free(ctx, p); }
     template <class T> T* as() { return (T*)p; }
+};
+// wall-clock phases of a tool run, printed as one JSON line on stderr when CANVAS_TOOL_TIMING is set (bench.py's `executables` leg: what part of a run is file I/O)
+struct Phases {
+    const char* tool; std::vector<std::pair<std::string, double>> v; double t0;
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+    explicit Phases(const char* name) : tool(name), t0(now()) {}
+    void mark(const char* phase) { v.push_back({phase, now()}); }
+    ~Phases() {
+        if (!getenv("CANVAS_TOOL_TIMING")) return;
+        std::string js = std::string("{\"tool\": \"") + tool + "\", \"phases\": {"; double prev = t0;
+        for (size_t i = 0; i < v.size(); i++) { char b[96]; snprintf(b, sizeof b, "%s\"%s\": %.4f", i ? ", " : "", v[i].first.c_str(), v[i].second - prev); js += b; prev = v[i].second; }
+        char b[64]; snprintf(b, sizeof b, "}, \"total\": %.4f}", now() - t0); js += b;
+        fprintf(stderr, "%s\n", js.c_str());
+    }
 };
 #define TOOL_TRY(ctx, expr) do { int32_t rc_ = (expr); if (rc_ != 0) { fprintf(stderr, "%s failed (%d): %s\n", #expr, rc_, canvas_last_error(ctx)); return 1; } } while (0)
 
