@@ -21,6 +21,7 @@ __global__ void k_pack_boundaries(const int32_t* __restrict__ local, int nlocal,
 // all-gather between device buffers on the context's stream.  RCCL when the ranks share a communicator (one GPU per rank, xGMI); the host-callback transport when
 // they do not (ranks that share a GPU, hosts that bring their own MPI): device -> pinned host -> callback -> device, synchronous.
 int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+    ProfScope ps(ctx, "allgather");                     // (hipEvents on the library's stream around every collective: bench.py --gpus N reports their sum per pass)
     if (ctx->nranks == 1 && !ctx->comm) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream)); return CANVAS_OK; }
     if (ctx->comm) { CANVAS_NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream)); return CANVAS_OK; }
     if (!ctx->host_allgather) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "no communicator: call canvas_comm_init or canvas_comm_init_host first");
@@ -72,17 +73,24 @@ int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int
                                     int32_t* d_all, int32_t* h_counts) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nlocal < 0 || max_per_rank < nlocal || !d_all) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_allgather_boundaries: bad arguments");
+    return cvx_allgather_boundaries_status(ctx, d_local, nlocal, max_per_rank, d_all, h_counts);
+}
+
+}  // extern "C"
+
+// the gather itself; nlocal < 0: this rank has failed and announces its (negative) error code in the count slot, with no records (canvas_sample_pipeline_sharded)
+int32_t cvx_allgather_boundaries_status(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank, int32_t* d_all, int32_t* h_counts) {
+    if (max_per_rank < nlocal || !d_all) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_allgather_boundaries: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int rec = 1 + max_per_rank;
     int32_t rc = canvas_ws_reserve(ctx, (size_t)rec * 4 + 256); if (rc) return rc;
     int32_t* send = (int32_t*)ctx->ws;
     hipLaunchKernelGGL(k_pack_boundaries, dim3((rec + 255) / 256), dim3(256), 0, ctx->stream, d_local, nlocal, max_per_rank, send);
     rc = cvx_allgather(ctx, send, d_all, (size_t)rec * 4); if (rc) return rc;
-    if (h_counts) {
-        for (int r = 0; r < ctx->nranks; r++) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&h_counts[r], d_all + (size_t)r * rec, 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    if (h_counts)          // the count slot of every rank's slice: one strided copy
+        CANVAS_HIP_TRY(ctx, hipMemcpy2DAsync(h_counts, 4, d_all, (size_t)rec * 4, 4, (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CANVAS_OK;
 }
 
-}  // extern "C"
+

@@ -134,6 +134,8 @@ static inline int32_t canvas_pin_reserve(canvas_ctx* ctx, size_t bytes) {
 #define CVX_INTERNAL __attribute__((visibility("hidden")))
 // all-gather of bytes_per_rank bytes between device buffers on ctx->stream: RCCL (ncclAllGather over xGMI), the host-callback transport, or a copy when nranks == 1
 CVX_INTERNAL int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+// canvas_allgather_boundaries with a status: nlocal < 0 announces a failed rank (its error code travels in the count slot, no records)
+CVX_INTERNAL int32_t cvx_allgather_boundaries_status(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank, int32_t* d_all, int32_t* h_counts);
 // canvas_bin_sample on the chromosomes this rank owns, with the bin size decided by `hook` from the per-chromosome (#hit > 0, popcount(mask), possible positions
 // in front of the first non-'n' base): the hook is where the sharded pipeline exchanges the rate pairs so that every rank derives the same size
 typedef int32_t (*cvx_bin_size_hook)(void* user, int nchr, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut);

@@ -19,14 +19,14 @@
 
 #define SH_BLK 2048
 
-__global__ void __launch_bounds__(256) k_sh_unshard(const int32_t* __restrict__ recv, int64_t maxB, const long long* __restrict__ binOff, const int32_t* __restrict__ owner,
+__global__ void __launch_bounds__(256) k_sh_unshard(const int32_t* __restrict__ recv, int64_t slotInts /* ints per rank: 4 columns of maxB + the status word */, int64_t maxB, const long long* __restrict__ binOff, const int32_t* __restrict__ owner,
                                                     const long long* __restrict__ rankOff, int nchr, int64_t total, int32_t* __restrict__ oChr, int32_t* __restrict__ oStart,
                                                     int32_t* __restrict__ oStop, int32_t* __restrict__ oGc, float* __restrict__ oCount) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     int lo = 0, hi = nchr - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (binOff[mid] <= g) lo = mid; else hi = mid - 1; }
-    const int32_t* base = recv + (size_t)owner[lo] * 4 * (size_t)maxB;
+    const int32_t* base = recv + (size_t)owner[lo] * (size_t)slotInts;
     const int64_t j = rankOff[lo] + (g - binOff[lo]);
     oChr[g] = lo; oStart[g] = base[j]; oStop[g] = base[maxB + j]; oGc[g] = base[2 * maxB + j]; oCount[g] = __int_as_float(base[3 * maxB + j]);
 }
@@ -109,25 +109,32 @@ __global__ void __launch_bounds__(256) k_sh_fill_state(const int32_t* __restrict
 namespace {
 struct ShardHook {
     canvas_ctx* ctx; int nchr; const int32_t* owner; const uint8_t* isAuto; int countsPerBin; int binSizeIn; const int* localToGlobal;
-    long long* dBuf;                       // device: [1 + nranks][nchr * 3]
+    long long* dBuf;                       // device: [1 + nranks][nchr * 3 + 1]
     std::vector<long long> obs, pop, popBefore;      // every chromosome, after the exchange
+    bool exchanged = false;                // the rate exchange has taken place on this rank (a rank that fails before it still has to take part: see canvas_sample_pipeline_sharded)
+    int failedRank = -1; long long failedCode = 0;   // a peer announced a failure in its status slot
 };
-int32_t shard_rates_exchange(ShardHook& H, int nl, const long long* obs, const long long* pop, const long long* popBefore) {
+// every rank's slice ends with a status word: 0, or the error code of a rank that failed before the exchange and only takes part so that nobody waits for it
+int32_t shard_rates_exchange(ShardHook& H, int nl, const long long* obs, const long long* pop, const long long* popBefore, int32_t status = 0) {
     canvas_ctx* ctx = H.ctx;
-    const int W = ctx->nranks, n3 = H.nchr * 3;
-    std::vector<long long> mine(n3, 0), all((size_t)W * n3, 0);
+    const int W = ctx->nranks, n3 = H.nchr * 3, slice = n3 + 1;
+    std::vector<long long> mine(slice, 0), all((size_t)W * slice, 0);
     for (int i = 0; i < nl; i++) { const int c = H.localToGlobal[i]; mine[3 * c] = obs[i]; mine[3 * c + 1] = pop[i]; mine[3 * c + 2] = popBefore[i]; }
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(H.dBuf, mine.data(), (size_t)n3 * 8, hipMemcpyHostToDevice, ctx->stream));
-    int32_t rc = cvx_allgather(ctx, H.dBuf, H.dBuf + n3, (size_t)n3 * 8); if (rc) return rc;
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(all.data(), H.dBuf + n3, (size_t)W * n3 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    mine[n3] = status;
+    H.exchanged = true;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(H.dBuf, mine.data(), (size_t)slice * 8, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = cvx_allgather(ctx, H.dBuf, H.dBuf + slice, (size_t)slice * 8); if (rc) return rc;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(all.data(), H.dBuf + slice, (size_t)W * slice * 8, hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     H.obs.assign(H.nchr, 0); H.pop.assign(H.nchr, 0); H.popBefore.assign(H.nchr, 0);
-    for (int c = 0; c < H.nchr; c++) { const long long* e = &all[(size_t)H.owner[c] * n3 + 3 * c]; H.obs[c] = e[0]; H.pop[c] = e[1]; H.popBefore[c] = e[2]; }
+    for (int c = 0; c < H.nchr; c++) { const long long* e = &all[(size_t)H.owner[c] * slice + 3 * c]; H.obs[c] = e[0]; H.pop[c] = e[1]; H.popBefore[c] = e[2]; }
+    for (int r = 0; r < W; r++) if (all[(size_t)r * slice + n3] != 0 && H.failedRank < 0) { H.failedRank = r; H.failedCode = all[(size_t)r * slice + n3]; }
     return CANVAS_OK;
 }
 int32_t shard_bin_size_hook(void* user, int nl, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut) {
     ShardHook& H = *(ShardHook*)user;
     int32_t rc = shard_rates_exchange(H, nl, obs, pop, popBefore); if (rc) return rc;
+    if (H.failedRank >= 0) CANVAS_FAIL(H.ctx, CANVAS_ERR_COMM, "canvas_sample_pipeline_sharded: rank " + std::to_string(H.failedRank) + " failed before the rate exchange (code " + std::to_string(H.failedCode) + ")");
     if (H.binSizeIn > 0) { *binSizeOut = H.binSizeIn; return CANVAS_OK; }
     std::vector<double> rates;                                              // SampleHitArrays.GetRates / GetBinSize over the autosomes (CanvasBin.cs:30-83)
     for (int c = 0; c < H.nchr; c++) if (H.isAuto[c]) rates.push_back((int)H.obs[c] / (double)(int)H.pop[c]);
@@ -164,9 +171,9 @@ extern "C" int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr,
     const int nbLocal = (int)((capLocal + SH_BLK - 1) / SH_BLK) + 1;
     size_t need = 0;
     const size_t oBins = need; need += 5 * al((size_t)capLocal * 4);
-    const size_t oSend = need; need += al((size_t)capMax * 16);
-    const size_t oRecv = need; need += al((size_t)W * capMax * 16);
-    const size_t oRates = need; need += al((size_t)(W + 1) * nchr * 3 * 8);
+    const size_t oSend = need; need += al((size_t)capMax * 16 + 16);
+    const size_t oRecv = need; need += al((size_t)W * ((size_t)capMax * 16 + 16));
+    const size_t oRates = need; need += al((size_t)(W + 1) * (nchr * 3 + 1) * 8);
     const size_t oTab = need; need += 6 * al((size_t)(nchr + 2) * 8);
     const size_t oCovL = need; need += al((size_t)capLocal * 8);
     const size_t oStateL = need; need += al((size_t)capLocal * 4);
@@ -188,86 +195,120 @@ extern "C" int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr,
     double* dCovL = (double*)(S + oCovL); int32_t* dStateL = (int32_t*)(S + oStateL); uint8_t* dFlags = (uint8_t*)(S + oFlags); uint32_t* dBlk = (uint32_t*)(S + oBlk);
     unsigned int* dNrec = (unsigned int*)(S + oCnt); int* dBad = (int*)(S + oCnt + 64);
 
+    // A failure on ONE rank must not leave the others waiting in a collective (ncclAllGather / the host callback would block for ever): every exchange carries a status
+    // word per rank — an extra slot of the rate table, 16 bytes behind the bin columns, a negative count in the boundary gather — a rank that has failed keeps taking part
+    // in the remaining exchanges with an empty payload, and every rank returns an error once it has seen a non-zero status (its own error for the rank that failed,
+    // CANVAS_ERR_COMM naming that rank for the others).
+    int32_t localErr = CANVAS_OK; std::string localMsg;
+    auto fail_local = [&](int32_t code) { if (!localErr) { localErr = code ? code : CANVAS_ERR_HIP; localMsg = ctx->err; } };
+    auto peer_failed = [&](int r, long long code, const char* where) -> int32_t {
+        if (localErr) { ctx->err = localMsg; return localErr; }
+        CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string("canvas_sample_pipeline_sharded: rank ") + std::to_string(r) + " failed " + where + " (code " + std::to_string(code) + ")");
+    };
     // ---- 1. local sweep, exchange of the rate table, one bin size, local bins
     ShardHook H{ctx, nchr, h_chr_owner, h_chr_is_autosome, counts_per_bin, bin_size_in, mine.data(), dRates, {}, {}, {}};
     int32_t binSize = 0; int64_t nbMine = 0;
     int32_t rc;
     if (nl > 0) {
         std::vector<const uint8_t*> lb(nl), lh(nl); std::vector<const uint64_t*> lm(nl); std::vector<int64_t> ll(nl), perChr(nl);
-        for (int i = 0; i < nl; i++) { lb[i] = d_bases[mine[i]]; lm[i] = d_mask[mine[i]]; lh[i] = d_hits[mine[i]]; ll[i] = h_len[mine[i]];
-            if (!lb[i] || !lm[i] || !lh[i]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline_sharded: an owned chromosome has no arrays"); }
-        rc = cvx_bin_sample_hooked(ctx, nl, lb.data(), lm.data(), lh.data(), ll.data(), mode, shard_bin_size_hook, &H, lChr, lStart, lStop, lGc, lCount, capLocal, perChr.data(), &nbMine);
-        if (rc) return rc;
+        bool haveArrays = true;
+        for (int i = 0; i < nl; i++) { lb[i] = d_bases[mine[i]]; lm[i] = d_mask[mine[i]]; lh[i] = d_hits[mine[i]]; ll[i] = h_len[mine[i]]; if (!lb[i] || !lm[i] || !lh[i]) haveArrays = false; }
+        if (!haveArrays) { ctx->err = "canvas_sample_pipeline_sharded: an owned chromosome has no arrays"; fail_local(CANVAS_ERR_INVALID); }
+        else { rc = cvx_bin_sample_hooked(ctx, nl, lb.data(), lm.data(), lh.data(), ll.data(), mode, shard_bin_size_hook, &H, lChr, lStart, lStop, lGc, lCount, capLocal, perChr.data(), &nbMine); if (rc) fail_local(rc); }
+        if (localErr && !H.exchanged) { rc = shard_rates_exchange(H, 0, nullptr, nullptr, nullptr, localErr); if (rc) return rc; }      // failed before the hook ran: the exchange still takes place
     } else {                                                         // more ranks than chromosomes: this rank only takes part in the exchanges
         rc = shard_rates_exchange(H, 0, nullptr, nullptr, nullptr); if (rc) return rc;
     }
-    {   // the bin size of the hook, recomputed here so that a rank without chromosomes has it too
+    if (H.failedRank >= 0) return peer_failed(H.failedRank, H.failedCode, "before the rate exchange");
+    if (!localErr) {   // the bin size of the hook, recomputed here so that a rank without chromosomes has it too
         if (bin_size_in > 0) binSize = bin_size_in;
         else { std::vector<double> rates; for (int c = 0; c < nchr; c++) if (h_chr_is_autosome[c]) rates.push_back((int)H.obs[c] / (double)(int)H.pop[c]);
-               if (rates.empty()) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "no autosome to derive the bin size from");
-               binSize = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin); }
-        if (binSize <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "derived bin size is not positive");
+               if (rates.empty()) { ctx->err = "no autosome to derive the bin size from"; fail_local(CANVAS_ERR_INVALID); }
+               else binSize = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin); }
+        if (!localErr && binSize <= 0) { ctx->err = "derived bin size is not positive"; fail_local(CANVAS_ERR_INVALID); }
+    }
+    // (the rate table is the same everywhere, so the two failures above happen on every rank or on none; a rank whose sweep failed AFTER the exchange goes on to the
+    //  next one with its status set)
+    if (localErr && binSize <= 0) {
+        // no bin size: nothing below can be sized.  Every rank has the same table, so every healthy rank computed a size; this rank cannot know maxB — it derives it from the
+        // table with the size the others use only if that size can be recomputed; otherwise the failure is global (same table, same result) and everybody returns here
+        if (bin_size_in > 0) binSize = bin_size_in;
+        else { std::vector<double> rates; for (int c = 0; c < nchr; c++) if (h_chr_is_autosome[c] && H.pop[c] > 0) rates.push_back((int)H.obs[c] / (double)(int)H.pop[c]);
+               if (!rates.empty()) binSize = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin); }
+        if (binSize <= 0) { ctx->err = localMsg; return localErr; }
     }
     if (h_bin_size) *h_bin_size = binSize;
     // ---- 2. bins of every chromosome: counts are known everywhere, the columns travel in ONE all-gather
     std::vector<long long> binOff(nchr + 1, 0), rankOff(nchr, 0), nbRank(W, 0);
     for (int c = 0; c < nchr; c++) { const long long nb = (H.pop[c] - H.popBefore[c]) / binSize; binOff[c + 1] = binOff[c] + nb; rankOff[c] = nbRank[h_chr_owner[c]]; nbRank[h_chr_owner[c]] += nb; }
     const int64_t total = binOff[nchr];
-    if (nbRank[me] != nbMine) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_sample_pipeline_sharded: local bin count disagrees with the exchanged table");
+    if (!localErr && nbRank[me] != nbMine) { ctx->err = "canvas_sample_pipeline_sharded: local bin count disagrees with the exchanged table"; fail_local(CANVAS_ERR_COMM); }
     if (h_nbins) *h_nbins = total;
-    if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_sample_pipeline_sharded: output capacity too small");
-    if (total == 0) { if (h_nbins_clean) *h_nbins_clean = 0; if (h_nsegments) *h_nsegments = 0; for (int c = 0; c <= nchr; c++) h_chr_offset[c] = 0; if (h_local_sd) *h_local_sd = -1.0; return CANVAS_OK; }
+    if (!localErr && total > cap) { ctx->err = "canvas_sample_pipeline_sharded: output capacity too small"; fail_local(CANVAS_ERR_CAPACITY); }
     const int64_t maxB = std::max<long long>(1, *std::max_element(nbRank.begin(), nbRank.end()));
-    if (nbMine > 0) {
+    if ((size_t)maxB > (size_t)capMax) { ctx->err = "canvas_sample_pipeline_sharded: bin table exceeds the exchange buffers"; return localErr ? localErr : CANVAS_ERR_CAPACITY; }   // (global: same table everywhere)
+    if (!localErr && nbMine > 0) {
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSend, lStart, (size_t)nbMine * 4, hipMemcpyDeviceToDevice, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSend + maxB, lStop, (size_t)nbMine * 4, hipMemcpyDeviceToDevice, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSend + 2 * maxB, lGc, (size_t)nbMine * 4, hipMemcpyDeviceToDevice, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dSend + 3 * maxB, lCount, (size_t)nbMine * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    rc = cvx_allgather(ctx, dSend, dRecv, (size_t)maxB * 16); if (rc) return rc;
+    const size_t slotB = (size_t)maxB * 16 + 16;                     // the four columns + the status word of the rank
     {
-        std::vector<long long> off64(nchr + 1);
-        rc = canvas_h2d_small(ctx, dBinOff, binOff.data(), (size_t)(nchr + 1) * 8); if (rc) return rc;
-        rc = canvas_h2d_small(ctx, dOwner, h_chr_owner, (size_t)nchr * 4); if (rc) return rc;
-        rc = canvas_h2d_small(ctx, dRankOff, rankOff.data(), (size_t)nchr * 8); if (rc) return rc;
+        const int32_t st4[4] = {localErr, 0, 0, 0};
+        rc = canvas_h2d_small(ctx, dSend + 4 * maxB, st4, sizeof st4); if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_sh_unshard, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dRecv, maxB, dBinOff, dOwner, dRankOff, nchr, total, d_chr, d_start, d_stop, d_gc, d_count);
+    rc = cvx_allgather(ctx, dSend, dRecv, slotB); if (rc) return rc;
+    {
+        std::vector<int32_t> st((size_t)W, 0);
+        CANVAS_HIP_TRY(ctx, hipMemcpy2DAsync(st.data(), 4, (const char*)dRecv + (size_t)maxB * 16, slotB, 4, (size_t)W, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int r = 0; r < W; r++) if (st[(size_t)r] != 0) return peer_failed(r, st[(size_t)r], "before the bin exchange");
+    }
+    if (total == 0) { if (h_nbins_clean) *h_nbins_clean = 0; if (h_nsegments) *h_nsegments = 0; for (int c = 0; c <= nchr; c++) h_chr_offset[c] = 0; if (h_local_sd) *h_local_sd = -1.0; return CANVAS_OK; }
+    {
+        rc = canvas_h2d_small(ctx, dBinOff, binOff.data(), (size_t)(nchr + 1) * 8); if (rc) fail_local(rc);
+        if (!localErr) { rc = canvas_h2d_small(ctx, dOwner, h_chr_owner, (size_t)nchr * 4); if (rc) fail_local(rc); }
+        if (!localErr) { rc = canvas_h2d_small(ctx, dRankOff, rankOff.data(), (size_t)nchr * 8); if (rc) fail_local(rc); }
+    }
+    if (!localErr) hipLaunchKernelGGL(k_sh_unshard, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dRecv, (int64_t)(slotB / 4), maxB, dBinOff, dOwner, dRankOff, nchr, total, d_chr, d_start, d_stop, d_gc, d_count);
     // ---- 3. CanvasClean on the whole genome (every rank, deterministic), F2 hand-off, chromosome offsets of the cleaned bins
     std::vector<uint8_t> noY((size_t)nchr, 0);
     double lsd = -1.0; int64_t nClean = 0; int32_t info[8];
-    rc = canvas_clean2(ctx, total, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y ? h_chr_is_y : noY.data(), clean_flags, min_bins_per_gc, &lsd, &nClean, info);
-    if (rc) return rc;
+    if (!localErr) { rc = canvas_clean2(ctx, total, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y ? h_chr_is_y : noY.data(), clean_flags, min_bins_per_gc, &lsd, &nClean, info); if (rc) fail_local(rc); }
     if (h_nbins_clean) *h_nbins_clean = nClean;
     if (h_local_sd) *h_local_sd = lsd;
-    rc = canvas_quantize_f2(ctx, d_count, nClean, d_cov); if (rc) return rc;
-    rc = canvas_chromosome_offsets(ctx, d_chr, nClean, nchr, h_chr_offset); if (rc) return rc;
+    if (!localErr) { rc = canvas_quantize_f2(ctx, d_count, nClean, d_cov); if (rc) fail_local(rc); }
+    if (!localErr) { rc = canvas_chromosome_offsets(ctx, d_chr, nClean, nchr, h_chr_offset); if (rc) fail_local(rc); }
     // ---- 4. PerSampleHMM of the owned chromosomes (compact copy of their coverage; quartiles over the whole sample)
     std::vector<int64_t> loff(nl + 1, 0);
-    for (int i = 0; i < nl; i++) loff[i + 1] = loff[i] + (h_chr_offset[mine[i] + 1] - h_chr_offset[mine[i]]);
-    const int64_t nLocal = loff[nl];
+    if (!localErr) for (int i = 0; i < nl; i++) loff[i + 1] = loff[i] + (h_chr_offset[mine[i] + 1] - h_chr_offset[mine[i]]);
+    const int64_t nLocal = localErr ? 0 : loff[nl];
     int32_t maxPer = maxRecInts, nrecInts = 0;
     if (nLocal > 0) {
-        for (int i = 0; i < nl; i++) { const int64_t b0 = h_chr_offset[mine[i]], T = loff[i + 1] - loff[i];
-            if (T > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCovL + loff[i], d_cov + b0, (size_t)T * 8, hipMemcpyDeviceToDevice, ctx->stream)); }
-        rc = cvx_hmm_per_sample_subset(ctx, nl, dCovL, loff.data(), d_cov, nClean, dStateL); if (rc) return rc;
+        for (int i = 0; i < nl && !localErr; i++) { const int64_t b0 = h_chr_offset[mine[i]], T = loff[i + 1] - loff[i];
+            if (T > 0 && hipMemcpyAsync(dCovL + loff[i], d_cov + b0, (size_t)T * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = "canvas_sample_pipeline_sharded: copy of the owned coverage failed"; fail_local(CANVAS_ERR_HIP); } }
+        if (!localErr) { rc = cvx_hmm_per_sample_subset(ctx, nl, dCovL, loff.data(), d_cov, nClean, dStateL); if (rc) fail_local(rc); }
         // boundary records of the owned chromosomes
         std::vector<long long> loff64(loff.begin(), loff.end()); std::vector<int32_t> l2g(mine.begin(), mine.end());
-        rc = canvas_h2d_small(ctx, dLoff, loff64.data(), (size_t)(nl + 1) * 8); if (rc) return rc;
-        rc = canvas_h2d_small(ctx, dL2G, l2g.data(), (size_t)nl * 4); if (rc) return rc;
-        const int nb = (int)((nLocal + SH_BLK - 1) / SH_BLK);
-        hipLaunchKernelGGL(k_sh_flags, dim3((unsigned)((nLocal + 255) / 256)), dim3(256), 0, ctx->stream, dStateL, dLoff, nl, nLocal, dFlags);
-        hipLaunchKernelGGL(k_sh_count, dim3(nb), dim3(256), 0, ctx->stream, dFlags, nLocal, dBlk);
-        hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(64), 0, ctx->stream, dBlk, nb, dNrec);
+        if (!localErr) { rc = canvas_h2d_small(ctx, dLoff, loff64.data(), (size_t)(nl + 1) * 8); if (rc) fail_local(rc); }
+        if (!localErr) { rc = canvas_h2d_small(ctx, dL2G, l2g.data(), (size_t)nl * 4); if (rc) fail_local(rc); }
+        if (!localErr) {
+            const int nb = (int)((nLocal + SH_BLK - 1) / SH_BLK);
+            hipLaunchKernelGGL(k_sh_flags, dim3((unsigned)((nLocal + 255) / 256)), dim3(256), 0, ctx->stream, dStateL, dLoff, nl, nLocal, dFlags);
+            hipLaunchKernelGGL(k_sh_count, dim3(nb), dim3(256), 0, ctx->stream, dFlags, nLocal, dBlk);
+            hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(64), 0, ctx->stream, dBlk, nb, dNrec);
+        }
     }
     // the records are built in the workspace of the context (nothing else runs between here and the gather); its size follows maxPer
     for (int attempt = 0; attempt < 2; attempt++) {
         const size_t recBytes = al((size_t)maxPer * 4) + al((size_t)W * (1 + (size_t)maxPer) * 4) + 4096;
-        rc = canvas_ws_reserve(ctx, recBytes + (size_t)(1 + maxPer) * 4 + 4096); if (rc) return rc;
+        rc = canvas_ws_reserve(ctx, recBytes + (size_t)(1 + maxPer) * 4 + 4096); if (rc) return rc;      // (the same allocation on every rank: a failure here is an out-of-memory device, nothing to salvage)
         // canvas_allgather_boundaries packs into the FRONT of the workspace: records and the gathered table sit behind that area
         char* wsb = (char*)ctx->ws + al((size_t)(1 + maxPer) * 4 + 256);
         int32_t* dRec = (int32_t*)wsb; int32_t* dAll = (int32_t*)(wsb + al((size_t)maxPer * 4));
         unsigned int nrec = 0;
-        if (nLocal > 0) {
+        if (nLocal > 0 && !localErr) {
             const int nb = (int)((nLocal + SH_BLK - 1) / SH_BLK);
             hipLaunchKernelGGL(k_sh_scatter, dim3(nb), dim3(256), 0, ctx->stream, dFlags, dBlk, dStateL, dLoff, dL2G, nl, nLocal, maxPer / 4, dRec);
             hipLaunchKernelGGL(k_sh_ends, dim3((unsigned)((maxPer / 4 + 255) / 256)), dim3(256), 0, ctx->stream, dRec, dNrec, maxPer / 4);
@@ -276,16 +317,17 @@ extern "C" int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr,
         }
         nrecInts = (int32_t)std::min<long long>((long long)nrec * 4, maxPer);      // a rank with more records than fit announces the full count below
         std::vector<int32_t> counts(W, 0);
-        // ---- 5. THE collective: segment boundaries of every rank
-        rc = canvas_allgather_boundaries(ctx, dRec, nrecInts, maxPer, dAll, counts.data()); if (rc) return rc;
+        // ---- 5. THE collective: segment boundaries of every rank (a rank that has failed sends its negative error code as its count)
+        rc = cvx_allgather_boundaries_status(ctx, dRec, localErr ? (localErr < 0 ? localErr : -localErr) : nrecInts, maxPer, dAll, counts.data()); if (rc) return rc;
+        for (int r = 0; r < W; r++) if (counts[r] < 0) return peer_failed(r, counts[r], "before the boundary exchange");
         // overflow protocol without a second collective type: a rank whose records did not fit sends count = maxPer and everyone retries with the bound every rank can derive
         bool overflow = false;
         for (int r = 0; r < W; r++) if (counts[r] >= maxPer) overflow = true;
         if ((long long)nrec * 4 >= maxPer) overflow = true;
         if (overflow && attempt == 0) { maxPer = (int32_t)std::min<long long>(4ll * (capMax + 16), 0x7FFFFFF0ll); continue; }
         if (overflow) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_sample_pipeline_sharded: boundary records do not fit");
-        ctx->shard_stats[0] = W; ctx->shard_stats[1] = nl; ctx->shard_stats[2] = nbMine; ctx->shard_stats[3] = maxB * 16; ctx->shard_stats[4] = nrec; ctx->shard_stats[5] = (long long)(1 + maxPer) * 4;
-        // ---- 6. state of every bin from the records, then the running segment id in file order
+        ctx->shard_stats[0] = W; ctx->shard_stats[1] = nl; ctx->shard_stats[2] = nbMine; ctx->shard_stats[3] = (long long)slotB; ctx->shard_stats[4] = nrec; ctx->shard_stats[5] = (long long)(1 + maxPer) * 4;
+        // ---- 6. state of every bin from the records, then the running segment id in file order (no further exchange: a failure from here on is local)
         std::vector<long long> chrOff64(h_chr_offset, h_chr_offset + nchr + 1);
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dChrOff, chrOff64.data(), (size_t)(nchr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4, ctx->stream));

@@ -253,7 +253,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
     def watchdog():
         if not done.wait(float(os.environ.get("CANVAS_SHARDED_TIMEOUT", "240"))):
             fallback_line("the sharded pipeline did not finish within the watchdog's limit")
-            os._exit(0)
+            os._exit(3)                                           # the line carries the cohort number and the reason; the exit status says the sharded mode failed
 
     threading.Thread(target=watchdog, daemon=True).start()
     try:
@@ -264,12 +264,16 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
 
         for _ in range(args.warmup):
             step()
+        cv.profile_enable(True)
+        for name in ("bin_summary", "allgather", "clean_total"):
+            cv.profile_get(name, reset=True)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             r = step()
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0, device)
+        ms_sum, k_sum = cv.profile_get("bin_summary"); ms_ag, k_ag = cv.profile_get("allgather"); ms_cl, k_cl = cv.profile_get("clean_total")
         st = cv.sharded_stats()
         sharded = {"seconds_per_pass": dt / args.steps, "bins": int(r["total"]), "n_out": int(r["n_out"]), "nseg": int(r["nseg"]), "bin_size": int(r["bin_size"])}
         # every rank must hold the same result: compare a digest of the segment ids and the cleaned counts across ranks
@@ -287,17 +291,33 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
     except Exception as e:                                        # a library error on this rank: the others are stopped by their watchdogs
         done.set()
         fallback_line("%s: %s" % (type(e).__name__, e))
-        os._exit(0)
+        os._exit(3)
     done.set()
+    wrong = [None]
+    if rank == 0 and not (same_on_all_ranks and equals_single):
+        wrong[0] = "the sharded result is %s" % ("not the same on every rank" if not same_on_all_ranks else "not the single-GPU result")
+    dist.broadcast_object_list(wrong, src=0)
+    if wrong[0]:
+        fallback_line(wrong[0])
+        os._exit(4)
     if rank == 0:
         value = sharded["bins"] / sharded["seconds_per_pass"]
+        # the dominant kernel on rank 0: the single sweep over the per-base arrays of the chromosomes it owns (2.125 B/base + 4 B per 64 positions + 16 B per 4096-position tile)
+        own_bases = int(sum(lengths[c] for c in range(nchr) if owner[c] == 0))
+        tiles = int(sum((lengths[c] + 4095) // 4096 for c in range(nchr) if owner[c] == 0))
+        alg = 2.125 * own_bases + 4.0 * (own_bases / 64.0) + 16.0 * tiles
+        avg_ms = ms_sum / max(1, k_sum)
+        rank0_roofline = {"kernel": "k_tile_summary (rank 0: its own chromosomes)", "bound": "hbm", "achieved": round(alg / max(1e-9, avg_ms * 1e-3) / 1e9, 1), "peak": hbm_peak_gbs, "unit": "GB/s",
+                          "frac": round(alg / max(1e-9, avg_ms * 1e-3) / 1e9 / hbm_peak_gbs, 4), "traffic": None, "avg_ms": round(avg_ms, 4), "launches": int(k_sum), "algorithmic_bytes": alg}
         result = {**base, "value": round(value, 1), "ms_per_step": round(sharded["seconds_per_pass"] * 1e3, 3), "scaling": "strong",
                   "config": {"workload": "BASELINE configs[2] sharded as configs[3]/[4] prescribe: ONE whole-genome GRCh38 60x sample, chromosomes LPT-sharded over the ranks, "
                                          "rate-table + bins + segment-boundary all-gathers over RCCL",
                              "bases_per_sample": total_bases, "bins_per_sample": sharded["bins"], "bins_after_clean": sharded["n_out"], "bin_size": sharded["bin_size"],
                              "partition": "PerSampleHMM", "clean_flags": "-g -s -r --local-sd-metric-file", "segments": sharded["nseg"], "multi": "sharded",
                              "owner_of_chromosome": [int(x) for x in owner], "scale": args.scale, "rate": args.rate},
-                  "sharded": {"chromosomes_owned_rank0": int(st[1]), "bins_binned_rank0": int(st[2]), "bins_allgather_bytes_per_rank": int(st[3]), "boundary_records_rank0": int(st[4]),
+                  "roofline": rank0_roofline,
+                  "sharded": {"collectives_per_pass": int(round(k_ag / max(1, args.steps))), "collectives_ms_per_pass_rank0": round(ms_ag / max(1, args.steps), 4),
+                              "clean_ms_per_pass_rank0": round(ms_cl / max(1, k_cl), 4), "chromosomes_owned_rank0": int(st[1]), "bins_binned_rank0": int(st[2]), "bins_allgather_bytes_per_rank": int(st[3]), "boundary_records_rank0": int(st[4]),
                               "boundary_allgather_bytes_per_rank": int(st[5]), "identical_on_all_ranks": same_on_all_ranks, "equals_single_gpu_result": equals_single,
                               "note": "CanvasClean runs redundantly on every rank (its order statistics are genome-wide): the pass cannot drop below Clean + the collectives"},
                   "cohort_mode": cohort}

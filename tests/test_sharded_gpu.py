@@ -149,3 +149,108 @@ def test_single_rank_rccl_communicator():
     torch.cuda.synchronize()
     cv._check(cv.lib.canvas_allgather_boundaries(cv.ctx, C.c_void_p(rec.data_ptr()), 8, 16, C.c_void_p(allb.data_ptr()), cnt.ctypes.data_as(C.c_void_p)))
     assert cnt[0] == 8 and allb[:9].cpu().tolist() == [8, 3, 0, 9, 2, 3, 10, 40, 1]
+
+
+def _failing_worker(rank, world, port, q, where):
+    """rank 1 fails on its own — before the first exchange (an owned chromosome without arrays) or between the exchanges (an output capacity only it finds too small);
+    the library must bring BOTH ranks back with an error instead of leaving rank 0 in an all-gather"""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        from canvas_amd.lib import CanvasError
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        owner = parallel.owner_table(LENGTHS, world)
+        mine = [c for c in range(len(LENGTHS)) if owner[c] == rank]
+        bases, hits, masks = _inputs(cv.device, only=mine)
+        out, cov, state, seg = _buffers(cv.device)
+        if rank == 1 and where == "before":
+            hits[mine[0]] = None
+        if rank == 1 and where == "between":
+            out = {k: v[:1000] for k, v in out.items()}          # far fewer rows than the sample has bins: CANVAS_ERR_CAPACITY on this rank only
+        try:
+            cv.sample_pipeline_sharded(owner, bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
+            q.put((rank, "returned", ""))
+        except CanvasError as e:
+            q.put((rank, "raised", str(e)))
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("where", ["before", "between"])
+def test_a_failure_on_one_rank_fails_every_rank_instead_of_deadlocking(where):
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, where)) for r in range(world)]
+    for p in procs: p.start()
+    try:
+        got = dict((r, (what, msg)) for r, what, msg in [q.get(timeout=180) for _ in range(world)])
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive(): p.kill()
+    assert got[0][0] == "raised" and got[1][0] == "raised", got
+    assert "rank 1 failed" in got[0][1], got[0][1]            # the healthy rank names the one that failed
+    assert ("no arrays" in got[1][1]) if where == "before" else ("capacity" in got[1][1]), got[1][1]
+
+
+def _rccl_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(rank)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        cv = Canvas(rank)
+        parallel.init_library_comm(cv, rank, world)
+        owner = parallel.owner_table(LENGTHS, world)
+        mine = [c for c in range(len(LENGTHS)) if owner[c] == rank]
+        bases, hits, masks = _inputs(cv.device, only=mine)
+        out, cov, state, seg = _buffers(cv.device)
+        r = cv.sample_pipeline_sharded(owner, bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
+        cv.synchronize()
+        n = r["n_out"]
+        q.put((rank, dict(r, off=r["off"].tolist()), out["count"][:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy()))
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_rccl_all_gather_between_real_ranks():
+    """ncclAllGather over xGMI with one process per GPU: runs wherever the box has at least two GPUs (the single-GPU test boxes skip it)"""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs at least two GPUs")
+    world = min(torch.cuda.device_count(), 8)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    try:
+        got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive(): p.kill()
+    for g in got:
+        assert g[1] != "error", g[2]
+    from canvas_amd import Canvas
+    ref = _single(Canvas(0))
+    for rank, r, count, state, seg in got:
+        assert (r["bin_size"], r["total"], r["n_out"], r["nseg"], r["lsd"]) == (ref[0]["bin_size"], ref[0]["total"], ref[0]["n_out"], ref[0]["nseg"], ref[0]["lsd"]), rank
+        assert (count.view(np.uint32) == ref[1]["count"].view(np.uint32)).all() and (state == ref[3]).all() and (seg == ref[4]).all(), rank
