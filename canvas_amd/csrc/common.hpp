@@ -55,6 +55,7 @@ struct canvas_ctx {
     long long cbs_dev[6] = {0, 0, 0, 0, 0, 0};
     long long cbs_tailp[2] = {0, 0};   // last CBS call: TailP decisions taken from the device series / recomputed by the host series   // counters of the device permutation engine (canvas_cbs_device_stats)
     long long wv_levels = 0, wv_redone = 0;   // last canvas_wavelets call: tree levels processed, nodes recomputed by the exact chain
+    void* covq_dev = nullptr; void* covq_pin = nullptr;   // pipeline.hip: counters / result of the genome-wide coverage quartiles counted while the coverage is quantised (hmm.hip)
     void* wv_pin = nullptr; size_t wv_pin_bytes = 0;   // pinned arena of canvas_wavelets (host copy of the coverage + staging lists), kept between calls
     long long wv_stats[4] = {0, 0, 0, 0};     // ... long nodes decided from the closed form / sent to the chain undecided / chained for their coefficient; closed form in use
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
@@ -136,6 +137,10 @@ static inline int32_t canvas_pin_reserve(canvas_ctx* ctx, size_t bytes) {
 CVX_INTERNAL int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 // canvas_allgather_boundaries with a status: nlocal < 0 announces a failed rank (its error code travels in the count slot, no records)
 CVX_INTERNAL int32_t cvx_allgather_boundaries_status(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank, int32_t* d_all, int32_t* h_counts);
+// canvas_quantize_f2 fused with the counting of the genome-wide quartiles PerSampleHMM starts from (the same sweep); the result travels to *h_covq_out (pinned, valid after the
+// next synchronisation of ctx->stream) and is handed to cvx_hmm_per_sample_preq, which then needs neither the counting sweep nor a round trip of its own
+CVX_INTERNAL int32_t cvx_quantize_f2_covq(canvas_ctx* ctx, const float* d_count, int64_t n, double* d_cov, const void** h_covq_out);
+CVX_INTERNAL int32_t cvx_hmm_per_sample_preq(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state, const void* h_covq);
 // canvas_bin_sample on the chromosomes this rank owns, with the bin size decided by `hook` from the per-chromosome (#hit > 0, popcount(mask), possible positions
 // in front of the first non-'n' base): the hook is where the sharded pipeline exchanges the rate pairs so that every rank derives the same size
 typedef int32_t (*cvx_bin_size_hook)(void* user, int nchr, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut);

@@ -35,6 +35,8 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->up2_stage) (void)hipFree(ctx->up2_stage);
     if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     if (ctx->wv_pin) (void)hipHostFree(ctx->wv_pin);
+    if (ctx->covq_pin) (void)hipHostFree(ctx->covq_pin);
+    if (ctx->covq_dev) (void)hipFree(ctx->covq_dev);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gc_arena) (void)hipFree(ctx->gc_arena);
     if (ctx->shard_ws) (void)hipFree(ctx->shard_ws);

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include <type_traits>
 #include "select.hpp"
+#include "quantize.hpp"
 #include <mutex>
 #include <cmath>
 #include <thread>
@@ -110,6 +111,49 @@ __global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, const 
             for (int k = 0; k < PER; k++) { cum += c[k]; if (want < cum) { Q->resultK[j] = Q->lo + (int)threadIdx.x * PER + k; break; } }
         }
     }
+}
+
+// The same count inside the sweep that produces the coverage (pipeline.hip): cov[i] = F2(count[i]) is written and counted in one pass — the value is N / 100 by construction,
+// N comes out of the digit arithmetic — so PerSampleHMM starts without a sweep of its own (37 us for a WGS sample) and without its own round trip for the six ranks.
+__global__ void __launch_bounds__(1024) k_quant_covq(const float* __restrict__ count, int64_t n, double* __restrict__ cov, CovQ* __restrict__ Q, uint32_t* __restrict__ win) {
+    __shared__ uint32_t lw[CQ_WIN];
+    __shared__ long long sv[33];
+    __shared__ int sLo;
+    if (threadIdx.x < 33) { const int64_t i = (int64_t)((double)n * (threadIdx.x + 0.5) / 33.0); long long k = -1; if (i < n) (void)quantize_f2_one(count[i], &k); sv[threadIdx.x] = k; }
+    for (int i = threadIdx.x; i < CQ_WIN; i += 1024) lw[i] = 0;
+    __syncthreads();
+    if (threadIdx.x < 33) {                                  // every lane ranks its own sample among the valid ones; the one in the middle sets the window
+        const long long mine = sv[threadIdx.x];
+        int m = 0, rank = 0;
+        for (int j = 0; j < 33; j++) { const long long o = sv[j]; if (o >= 0) { m++; if (o < mine || (o == mine && j < (int)threadIdx.x)) rank++; } }
+        if (m == 0) { if (threadIdx.x == 0) sLo = 0; }
+        else if (mine >= 0 && rank == m / 2) sLo = (int)(mine > CQ_WIN / 2 ? mine - CQ_WIN / 2 : 0);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) Q->lo = sLo;
+    const long long lo = sLo;
+    uint32_t below = 0, bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        float c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * stride; c[u] = i < n ? count[i] : 0.0f; }          // four loads in flight
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n) break;
+            long long k;
+            cov[i] = quantize_f2_one(c[u], &k);
+            if (k < 0) { bad = 1; continue; }                // NaN, a negative count, a count beyond the table: the radix select decides (as for any coverage that is not F2 text)
+            if (k < lo) below++;
+            else if (k - lo < CQ_WIN) atomicAdd(&lw[k - lo], 1u);
+        }
+    }
+    below = wave_reduce_add_u32(below);
+    if ((threadIdx.x & 63) == 0 && below) atomicAdd(&Q->below, (unsigned long long)below);
+    if (bad) Q->bad = 1u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CQ_WIN; i += 1024) { const uint32_t v = lw[i]; if (v) atomicAdd(&win[i], v); }
 }
 
 // RemoveOutliers (HiddenMarkovModelsRunner.cs:154-162) + Convert.ToInt32 (Distributions.cs:271)
@@ -1453,11 +1497,13 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         ProfScope ps(ctx, "viterbi");
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dLast, 0xFF, nchr * 4, ctx->stream));     // -1 for skipped chromosomes
         // attempt 0: lead-ins of 128 / 64 steps.  Noisy samples (states that overlap heavily) forget their history more slowly: chromosomes
-        // whose verification fails are tried once more with 8x longer lead-ins before the sequential kernel takes them.
+        // whose verification fails are tried again with 8x and then 64x longer lead-ins before the sequential kernel takes them (57 ms for a chr1-size chromosome: a noisy
+        // sample used to fall off that cliff 2-15 times per soak run; the 64x attempt costs about 0.6 ms for the same chromosome).
         const int32_t* dTodo = nullptr;
         ctx->hmm_retry = 0;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            const int leadSpec = attempt == 0 ? VW : 8 * VW, leadVer = attempt == 0 ? VW2 : 8 * VW2;
+        for (int attempt = 0; attempt < 3; attempt++) {
+            const int mult = attempt == 0 ? 1 : (attempt == 1 ? 8 : 64);
+            const int leadSpec = mult * VW, leadVer = mult * VW2;
             CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
             const dim3 gs((unsigned)((nblocksS + 63) / 64));
             if (lds && twoValued) hipLaunchKernelGGL((k_vit_spec<true, true>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
@@ -1486,9 +1532,8 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             redo.clear();
             for (int c = 0; c < nchr; c++) if (hFail[c] && chroms[c].T > 10) redo.push_back(c);
             if (redo.empty() || getenv("CANVAS_HMM_TEST_CORRUPT") || getenv("CANVAS_HMM_NO_RETRY")) break;
-            if (attempt == 0) {      // the failed chromosomes become the to-do mask of the retry (dRedo doubles as the mask: nchr entries)
-                ctx->hmm_retry = (int)redo.size();
-                { ProfScope pr(ctx, "viterbi_retry"); }      // counted for the tests / bench
+            if (attempt < 2) {       // the failed chromosomes become the to-do mask of the next attempt (dRedo doubles as the mask: nchr entries)
+                if (attempt == 0) { ctx->hmm_retry = (int)redo.size(); { ProfScope pr(ctx, "viterbi_retry"); } }     // counted for the tests / bench
                 int32_t rcq = canvas_h2d_small(ctx, dRedo, hFail.data(), nchr * 4); if (rcq) return rcq;
                 dTodo = dRedo;
             }
@@ -1511,7 +1556,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
 
 extern "C" {
 
-static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t nAll, int32_t* d_state) {
+static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t nAll, int32_t* d_state, const CovQ* preQ = nullptr) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !d_cov || !h_chr_offset || !d_state || !d_cov_all) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1528,7 +1573,11 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     quartile_idx(nAll, qidx, nq);
     float v[6], q1, q2, q3;
     bool radix = getenv("CANVAS_HMM_RADIX_SELECT") != nullptr;
-    if (!radix) {
+    if (!radix && preQ && preQ->nq == (uint32_t)nq) {        // counted while the coverage was quantised (cvx_quantize_f2_covq): the ranks are already on the host
+        bool same = true; for (int k = 0; k < nq; k++) same = same && preQ->rank[k] == (unsigned long long)qidx[k];
+        if (same && !preQ->bad && !preQ->fail) for (int k = 0; k < nq; k++) v[k] = (float)((double)preQ->resultK[k] / 100.0);
+        else radix = true;
+    } else if (!radix) {
         CovQ* dQ = ws.take<CovQ>(1); uint32_t* dWin = ws.take<uint32_t>(CQ_WIN);
         CovQ hQ; memset(&hQ, 0, sizeof hQ); hQ.nq = (uint32_t)nq;
         for (int k = 0; k < nq; k++) hQ.rank[k] = (unsigned long long)qidx[k];
@@ -1583,6 +1632,32 @@ int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov
 }
 
 }  // extern "C"
+
+int32_t cvx_hmm_per_sample_preq(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state, const void* h_covq) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_chr_offset) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
+    return hmm_per_sample_impl(ctx, nchr, d_cov, h_chr_offset, d_cov, h_chr_offset[nchr], d_state, (const CovQ*)h_covq);
+}
+int32_t cvx_quantize_f2_covq(canvas_ctx* ctx, const float* d_count, int64_t n, double* d_cov, const void** h_covq_out) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    *h_covq_out = nullptr;
+    if (n < 5 || getenv("CANVAS_HMM_RADIX_SELECT")) return canvas_quantize_f2(ctx, d_count, n, d_cov);     // (fewer than 5 bins: PerSampleHMM refuses the sample anyway)
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->covq_dev) CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->covq_dev, 256 + CQ_WIN * 4));
+    if (!ctx->covq_pin) CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->covq_pin, 256, hipHostMallocDefault));
+    CovQ* dQ = (CovQ*)ctx->covq_dev; uint32_t* dWin = (uint32_t*)((char*)ctx->covq_dev + 256);
+    int64_t qidx[6]; int nq;
+    quartile_idx(n, qidx, nq);
+    CovQ hQ; memset(&hQ, 0, sizeof hQ); hQ.nq = (uint32_t)nq;
+    for (int k = 0; k < nq; k++) hQ.rank[k] = (unsigned long long)qidx[k];
+    int32_t rc = canvas_h2d_small(ctx, dQ, &hQ, sizeof hQ); if (rc) return rc;
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dWin, 0, CQ_WIN * 4, ctx->stream));
+    hipLaunchKernelGGL(k_quant_covq, dim3(256), dim3(1024), 0, ctx->stream, d_count, n, d_cov, dQ, dWin);
+    hipLaunchKernelGGL(k_covq_pick, dim3(1), dim3(1024), 0, ctx->stream, dQ, dWin);
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->covq_pin, dQ, sizeof(CovQ), hipMemcpyDeviceToHost, ctx->stream));
+    *h_covq_out = ctx->covq_pin;
+    return CANVAS_OK;
+}
 
 int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state) {
     return hmm_per_sample_impl(ctx, nchr, d_cov, h_chr_offset, d_cov_all, n_all, d_state);

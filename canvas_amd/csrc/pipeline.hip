@@ -28,9 +28,11 @@ static int32_t sample_pipeline_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t
     if (rc) return rc;
     if (h_nbins_clean) *h_nbins_clean = nClean;
     if (h_local_sd) *h_local_sd = lsd;
-    rc = canvas_quantize_f2(ctx, d_count, nClean, d_cov); if (rc) return rc;
+    // the quantisation also counts the genome-wide quartiles PerSampleHMM starts from; they come back with the chromosome offsets (one synchronisation)
+    const void* hCovQ = nullptr;
+    rc = cvx_quantize_f2_covq(ctx, d_count, nClean, d_cov, &hCovQ); if (rc) return rc;
     rc = canvas_chromosome_offsets(ctx, d_chr, nClean, nchr, h_chr_offset); if (rc) return rc;
-    rc = canvas_hmm_per_sample(ctx, nchr, d_cov, h_chr_offset, d_state); if (rc) return rc;
+    rc = hCovQ ? cvx_hmm_per_sample_preq(ctx, nchr, d_cov, h_chr_offset, d_state, hCovQ) : canvas_hmm_per_sample(ctx, nchr, d_cov, h_chr_offset, d_state); if (rc) return rc;
     rc = canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
     if (h_nsegments) *h_nsegments = nseg;
     return CANVAS_OK;

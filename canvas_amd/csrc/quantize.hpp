@@ -1,0 +1,53 @@
+// "{0:F2}" of a float count, parsed back as a double: the hand-off between CanvasClean and CanvasPartition (CanvasCommon/IO.cs:21 -> CanvasSegment.cs:1146), in memory.
+// Shared by clean.hip (canvas_quantize_f2) and hmm.hip (the quantisation fused with the counting of the genome-wide quartiles, pipeline.hip).
+#pragma once
+// ---------------------------------------------------------------- "{count:F2}" text hand-off in memory (IO.cs:21 -> CanvasSegment.cs:1146)
+// Exact integer arithmetic: float = m * 2^e; 7 significant decimal digits (ties-to-even on the exact value, as the oracle's
+// correctly rounded printf), then half-up on the decimal digits at 2 decimals, then N/100 as a correctly rounded double
+// (= parsing the printed text).
+__device__ inline double quantize_f2_one(float v, long long* kOut = nullptr) {
+    if (kOut) *kOut = -1;                                       // the integer N with result = N / 100, when the value went through the digit arithmetic and is not negative
+    const float af = fabsf(v);
+    if (af != af) return (double)v;                             // NaN passes through
+    if (af < 0.001f) { if (kOut) *kOut = 0; return 0.0; }       // prints 0.00
+    if (af >= 1.0e15f) return (double)v;                                                  // outside the supported count range
+    const uint32_t bits = __float_as_uint(af);
+    const int ex = (int)(bits >> 23);
+    unsigned long long m = ex ? ((bits & 0x7FFFFFu) | 0x800000u) : (bits & 0x7FFFFFu);
+    const int e = (ex ? ex : 1) - 150;                          // af = m * 2^e exactly
+    const double a = (double)af;
+    const double p10[17] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16};
+    const unsigned long long ip10[17] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull, 1000000000ull,
+                                         10000000000ull, 100000000000ull, 1000000000000ull, 10000000000000ull, 100000000000000ull, 1000000000000000ull, 10000000000000000ull};
+    int scale;                                                  // number of integer digits (<= 0 below 1)
+    if (a >= 1.0) { scale = 1; while (scale < 16 && a >= p10[scale]) scale++; }
+    else if (a >= 0.1) scale = 0; else if (a >= 0.01) scale = -1; else scale = -2;
+    const int d = 7 - scale;                                    // decimals kept by the 7-significant-digit stage
+    unsigned long long R7;
+    if (d >= 0) {
+        unsigned long long num = m * ip10[d];                   // < 2^24 * 10^9 < 2^54
+        if (e >= 0) R7 = num << e;                              // only when d == 0..: af >= 2^23, fits
+        else {
+            int s = -e;                                         // <= 34 for af >= 0.001
+            unsigned long long q = num >> s, rem = num & ((1ull << s) - 1ull), half = 1ull << (s - 1);
+            if (rem > half || (rem == half && (q & 1ull))) q++;
+            R7 = q;
+        }
+    } else {
+        unsigned long long A = e >= 0 ? (m << e) : (m >> (-e));  // af >= 1e7 > 2^23: integer valued, e >= 0 except the first binade
+        unsigned long long P = ip10[-d], q = A / P, rem = A % P;
+        if (rem * 2 > P || (rem * 2 == P && (q & 1ull))) q++;
+        R7 = q;
+    }
+    unsigned long long N2;
+    const int dd = d - 2;
+    if (dd <= 0) N2 = R7 * ip10[-dd];
+    else if (dd > 16) N2 = 0;
+    else {
+        unsigned long long P = ip10[dd];
+        N2 = R7 / P + (((R7 / ip10[dd - 1]) % 10ull) >= 5ull ? 1ull : 0ull);
+    }
+    double r = (double)N2 / 100.0;
+    if (kOut && !(v < 0) && N2 < (1ull << 30)) *kOut = (long long)N2;
+    return v < 0 ? -r : r;
+}
