@@ -890,6 +890,11 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     BinPlan plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len);
     // ---- mode 5 pre-pass: mean fragment size, read-GC profile, observed/expected weights (kept in a separate allocation)
     uint8_t* gcArena = nullptr; float* dW = nullptr; GcChrom* dGch = nullptr;       // the arena (1 B/base read-GC profile + a prefix array) lives in the context and only grows
+    if (gcw && ctx->up_active) {
+        // the pre-pass below reads the per-base arrays on ctx->stream: a pending canvas_upload_genome_begin of them (copy stream) has to have landed first — mode 5 has no
+        // per-chromosome overlap (the fence further down, which the other modes rely on, comes after these kernels)
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); ctx->up_active = false;
+    }
     if (gcw) {
         int64_t maxLen = 0, totLen = 0;
         for (int c = 0; c < nchr; c++) { maxLen = std::max(maxLen, h_len[c]); totLen += (h_len[c] + 255) & ~255ll; }

@@ -486,9 +486,19 @@ int main(int argc, char** argv) {
     if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED)
         TOOL_TRY(ctx, canvas_bin_sample_gcweighted(ctx, nchr, pBases.data(), pMask.data(), pHits.data(), pFrag.data(), len.data(), isAuto.data(), countsPerBin, binSize,
                                                    dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total));
-    else if (usePacked)
-        TOOL_TRY(ctx, canvas_bin_sample_packed(ctx, nchr, pRef.data(), pPlanes.data(), len.data(), pos0.data(), isAuto.data(), countsPerBin, binSize, mode,
-                                               dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total));
+    else if (usePacked) {
+        int32_t rcb = canvas_bin_sample_packed(ctx, nchr, pRef.data(), pPlanes.data(), len.data(), pos0.data(), isAuto.data(), countsPerBin, binSize, mode,
+                                               dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total);
+        if (rcb == CANVAS_ERR_CAPACITY && binSize == -1 && used > 0) {
+            // the capacity above was a guess (the bin size is derived inside the call: a small -d or a high hit rate gives bins of fewer than 16 positions); the failed call
+            // still reported the size it derived: size the columns exactly as the byte-array path does and bin again with that size
+            const int64_t cap2 = canvas_bin_count_upper_bound(nchr, len.data(), used);
+            Dev dChr2(ctx, cap2 * 4 + 4), dStart2(ctx, cap2 * 4 + 4), dStop2(ctx, cap2 * 4 + 4), dGc2(ctx, cap2 * 4 + 4), dCount2(ctx, cap2 * 4 + 4);
+            TOOL_TRY(ctx, canvas_bin_sample_packed(ctx, nchr, pRef.data(), pPlanes.data(), len.data(), pos0.data(), isAuto.data(), countsPerBin, used, mode,
+                                                   dChr2.as<int32_t>(), dStart2.as<int32_t>(), dStop2.as<int32_t>(), dGc2.as<int32_t>(), dCount2.as<float>(), cap2, &used, perChr.data(), &total));
+            std::swap(dChr.p, dChr2.p); std::swap(dStart.p, dStart2.p); std::swap(dStop.p, dStop2.p); std::swap(dGc.p, dGc2.p); std::swap(dCount.p, dCount2.p);
+        } else if (rcb != 0) { fprintf(stderr, "canvas_bin_sample_packed failed (%d): %s\n", rcb, canvas_last_error(ctx)); return 1; }
+    }
     else
         TOOL_TRY(ctx, canvas_bin_sample(ctx, nchr, pBases.data(), pMask.data(), pHits.data(), len.data(), isAuto.data(), countsPerBin, binSize, mode,
                                         dChr.as<int32_t>(), dStart.as<int32_t>(), dStop.as<int32_t>(), dGc.as<int32_t>(), dCount.as<float>(), cap, &used, perChr.data(), &total));
