@@ -31,6 +31,9 @@
 #include <chrono>
 #include <functional>
 #include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
 
 // ================================================================================================ device: Nu(x) of the analytic tail probability
 // TailProbability.Nu (TailProbability.cs:52-85): l1 = log 2 - 2 log x - sum_dk 2 Phi(-x sqrt(dk) / 2) / dk, summed in blocks of 2, 2, 4, 8, ... terms until the relative change of
@@ -293,6 +296,41 @@ __global__ void __launch_bounds__(256) k_mt_stride(const PermReq* __restrict__ r
             for (int i = 0; i < MT_NLAG; i++) v ^= d[k + e - (long long)MT_LAG[i] * MT_STRIDE];
             R.P.draws[k + e] = v;
         }
+    }
+}
+// data-parallel part, one launch for the whole batch.  With every lag a multiple of MT_STRIDE the stream falls apart into MT_STRIDE interleaved sequences (position mod
+// MT_STRIDE) that never read each other: y_r[t] = out[r + MT_STRIDE t] obeys the ORIGINAL 134-term recurrence, y[t] = XOR_i y[t - MT_LAG[i]].  One workgroup owns one
+// sequence and keeps its last 19937 values in a ring in LDS (80 KB), so the 134 operands of a value are LDS reads instead of 134 loads from a 10 MB window in the
+// L2 / Infinity Cache; the smallest lag is 623, so 623 values are computed per barrier.  (k_mt_stride, one launch per 623 * MT_STRIDE outputs with the history in
+// global memory, was 37 us per step — 1.2 TB/s of cache traffic for 0.3 MB of output — and 8 of the 14 ms of a 256-permutation batch of a 67 k-bin segment.)
+#define MTC_T 640
+#define MTC_RING 20608            // >= 19937 + 623: the slots written in an iteration are older than anything the iteration reads
+__global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict__ reqs) {
+    __shared__ uint32_t ring[MTC_RING];
+    const PermReq& R = reqs[blockIdx.y];
+    const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    uint32_t* __restrict__ d = R.P.draws;
+    const long long start = R.cont ? 0 : MT_HISTORY;                 // first position to generate; the MT_HISTORY positions in front of it are there
+    const long long left = R.total - start - r;
+    if (left <= 0) return;
+    const long long cnt = (left + MT_STRIDE - 1) / MT_STRIDE;        // values of this sequence to generate
+    const uint32_t* __restrict__ hist = d + (start - MT_HISTORY + r);
+    for (int t = tid; t < 19937; t += MTC_T) ring[t] = hist[(long long)t * MT_STRIDE];
+    __syncthreads();
+    uint32_t* __restrict__ out = d + (start + r);
+    int head = 19937;                                                // ring slot of the next value
+    for (long long u0 = 0; u0 < cnt; u0 += 623) {
+        const long long m = cnt - u0 < 623 ? cnt - u0 : 623;
+        if (tid < m) {
+            int p = head + tid; p = p >= MTC_RING ? p - MTC_RING : p;
+            uint32_t v = 0;
+#pragma unroll 8
+            for (int i = 0; i < MT_NLAG; i++) { int q = p - MT_LAG[i]; q = q < 0 ? q + MTC_RING : q; v ^= ring[q]; }
+            ring[p] = v;
+            out[(u0 + tid) * MT_STRIDE] = v;
+        }
+        head += 623; head = head >= MTC_RING ? head - MTC_RING : head;
+        __syncthreads();
     }
 }
 // generator state after every permutation of the batch, rebuilt from the outputs: the 624 words behind a position are the untempered
@@ -827,6 +865,8 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
 // ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
 #define PERM_GPU_MIN_N 1024          // shorter segments stay on the host: measured with 201 (every hybrid segment on the device) the WGS run is identical but 12 % slower (0.555 vs 0.496 s) — a permutation of a few hundred elements is microseconds of host work and a launch round trip on the device
 #define PERM_TARGET_ELEMS (64 << 20) // permuted elements per batch (44 B of workspace each)
+// (batches of up to 2048 permutations for loops that run long were tried: k_perm_stat then takes 26 ms instead of 3.5 ms for 256 — the same rate per permutation — so
+//  a larger batch only saves launcher round trips, 0.45 -> 0.44 s on the 4.7 M-bin sample, for 8.4 GB of workspace per engine)
 struct PermService;
 struct PermGpu {
     canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr; char* buf = nullptr; size_t bytes = 0; char* pin = nullptr; size_t pinBytes = 0;
@@ -965,11 +1005,21 @@ struct PermService {
             if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // pinned source
         }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
+        static const bool dbg = getenv("CANVAS_CBS_DEBUG_BATCHES") != nullptr;
+        auto tp0 = std::chrono::steady_clock::now(); double msA = 0, msB = 0;
+        auto lap = [&]() { (void)hipStreamSynchronize(stream); auto t = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; return ms; };
+        if (dbg) lap();
         hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs);
+        if (dbg) msA = lap();
         const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;
-        for (int sidx = 0; sidx < steps; sidx++) hipLaunchKernelGGL(k_mt_stride, dim3((MT_WIDTH / 4 + 255) / 256, R), dim3(256), 0, stream, dReqs, sidx);
+        static const bool stepwise = getenv("CANVAS_CBS_MT_STEPWISE") != nullptr;     // the previous generator, kept for comparison
+        if (stepwise) for (int sidx = 0; sidx < steps; sidx++) hipLaunchKernelGGL(k_mt_stride, dim3((MT_WIDTH / 4 + 255) / 256, R), dim3(256), 0, stream, dReqs, sidx);
+        else if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs);
+        if (dbg) msB = lap();
         hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
         hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
+        if (dbg) { const double msC = lap(); int nc = 0, maxN = 0; for (int i = 0; i < R; i++) { nc += batch[i]->r.cont; maxN = std::max(maxN, batch[i]->r.n); }
+                   fprintf(stderr, "cbs batch: %d requests (%d continued), %d permutations, longest segment %d, %d stride steps: sequential %.2f ms, strided %.2f ms, statistics %.2f ms\n", R, nc, blocks, maxN, steps, msA, msB, msC); }
         for (int i = 0; i < R; i++) {
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hStat, batch[i]->r.pstat, (size_t)batch[i]->r.nb * 16, hipMemcpyDeviceToHost, stream));
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hSnaps, batch[i]->r.snaps, (size_t)batch[i]->r.nb * 625 * 4, hipMemcpyDeviceToHost, stream));
@@ -1005,24 +1055,30 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     canvas_ctx* ctx = PG.ctx;
     const int maxB = (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n));
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-    const size_t e = (size_t)maxB * n, e1 = (size_t)maxB * (n + 1);
-    const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)maxB * 625 * 4), oDraws = oStat + al((size_t)maxB * 16),
-                 oJ = oDraws + al((e + (size_t)MT_HISTORY) * 4), oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
-                 oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
-    const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)maxB * 625 * 4), pinTotal = pStat + al((size_t)maxB * 16);
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
-    auto tE = now();
-    int32_t rc = PG.ensure(total, pinTotal); if (rc) return rc;
-    st.ns_ensure += since(tE);
+    double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
+    auto setup = [&](int mb) -> int32_t {
+        const size_t e = (size_t)mb * n, e1 = (size_t)mb * (n + 1);
+        const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)mb * 625 * 4), oDraws = oStat + al((size_t)mb * 16),
+                     oJ = oDraws + al((e + (size_t)MT_HISTORY) * 4), oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
+                     oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
+        const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pinTotal = pStat + al((size_t)mb * 16);
+        auto tE = now();
+        int32_t rc0 = PG.ensure(total, pinTotal); if (rc0) return rc0;
+        st.ns_ensure += since(tE);
+        char* d = PG.buf; char* h = PG.pin;
+        dX = (double*)(d + oX); dSnaps = (uint32_t*)(d + oSnaps); dStat = (double*)(d + oStat);
+        P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY;       // MT_HISTORY outputs of head room for the continuation
+        P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
+        P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx);
+        hX = (double*)(h + pX); hSnaps = (uint32_t*)(h + pSnaps); hStat = (double*)(h + pStat);
+        return CANVAS_OK;
+    };
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    char* d = PG.buf; char* h = PG.pin;
-    double* dX = (double*)(d + oX); uint32_t* dSnaps = (uint32_t*)(d + oSnaps); double* dStat = (double*)(d + oStat);
-    PermBuf P; P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY;       // MT_HISTORY outputs of head room for the continuation
-    P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
-    P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx);
-    double* hX = (double*)(h + pX); uint32_t* hSnaps = (uint32_t*)(h + pSnaps); double* hStat = (double*)(h + pStat);
+    int32_t rc = setup(maxB); if (rc) return rc;
     memcpy(hX, gd, (size_t)n * 8);            // uploaded by the launcher together with the first batch
+    bool needUpload = true;
     // worst-case rounding bound of a prefix-sum difference: both orders of summation are within gamma_n * sum|x| of the exact sum
     double absSum = 0.0; for (int i = 0; i < n; i++) absSum += std::fabs(gd[i]);
     const double errBound = 4.04 * (double)(n + 8) * 1.1102230246251565e-16 * absSum;
@@ -1030,7 +1086,10 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     uint32_t cur[625]; rnd.get_state(cur);
     int nrej = 0; uint32_t np = 0;
     long long prevTotal = 0;
-    int B = std::min(maxB, 64);
+    // first batch: without a single rejection the sequential rule stops at permutation sbdry[k - 1] — known now — and that is what a segment with a real change point
+    // does; asking for that many at once saves the 64 / 128 / 256 ramp its two extra launcher round trips (a segment without one leaves after a handful either way)
+    int B = std::min(maxB, std::max(64, (int)std::min<uint32_t>(sbdry[k - 1], 4096u)));
+    if (getenv("CANVAS_CBS_B0")) B = std::min(maxB, atoi(getenv("CANVAS_CBS_B0")));
     outcome = 1;
     while (np < nPerm) {
         const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
@@ -1038,7 +1097,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         PermHostReq q;
         memcpy(q.r.state, cur, sizeof cur); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
         q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
-        if (np == 0) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; }
+        if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.r.cont = (np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
         prevTotal = (long long)nb * n;
         rc = PG.svc->submit(q); if (rc) return rc;
@@ -1086,56 +1145,100 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
 
 #define CBS_GPU_MIN_N 4096
 
-// ChangePoint.FindChangePoints (ChangePoint.cs:291-400)
-static int32_t find_change_points(ArcGpu& G, PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, double cutoff, int& nCp, int iCp[2], bool hybrid, int al0, int hk,
-                                  double delta, const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st) {
-    std::vector<double> px(n), sx(n);
-    int iseg[2]; double ostat; int nrej = 0; nCp = 0;
+// ChangePoint.FindChangePoints (ChangePoint.cs:291-400) in two phases.
+//   phase 1  everything in front of the first random number: centring, TSS, TMaxO, the analytic tail probability of the hybrid test.  It depends on the segment's data
+//            only, so the segments a split leaves on the stack are worked on AHEAD of the recursion, by a pool of helper threads (their arc searches and tail series share
+//            the launcher rounds of all chromosomes), while the chromosome's own thread is busy with the permutations of the segment on top.
+//   phase 2  the permutation reference distribution, the sequential stopping rule and the edge tests: they draw from the chromosome's ONE generator, in the reference's
+//            order, on the chromosome's thread.
+// Every segment that reaches the stack is processed sooner or later, so nothing is computed that the sequential order would not compute; the results and the number of
+// random numbers drawn are the reference's.  (Before: per chromosome a chain arc search -> tail probability -> permutation batches, every link a launcher round trip.)
+// where the wall time of one chromosome goes (CANVAS_CBS_TIMING): seconds waiting for / running phase 1, in the device and host permutation loops, in the edge tests
+struct ChromClock { double p1 = 0, dev = 0, host = 0, edge = 0; int segments = 0, devLoops = 0, hostLoops = 0; };
+static thread_local ChromClock tlClock;
+struct Phase1 {
+    int32_t rc = CANVAS_OK; int cn = 0; bool trivial = false;          // fewer than 2 * minWidth values, or constant data: no change point
+    std::vector<double> cur, sx; double tss = 0; bool hybrid = false; double delta = 0;
+    int iseg[2] = {0, 0}; double ostat = 0, ostat1 = 0; bool stop = false;   // stop: sqrt(ostat) <= 0.1, no change point
+    bool bigT = false, exitNoSplit = false; int nrejc = 0;
+};
+static void phase1_run(ArcGpu& G, PermGpu& PG, const double* gd, int cn, uint32_t nPerm, double cutoff, Stats& st, Phase1& P) {
+    const int minWidth = 2, kMax = 25; const uint32_t nMin = 200;
+    P.cn = cn;
+    if (cn < 2 * minWidth) { P.trivial = true; return; }
+    P.cur.assign(gd, gd + cn);
+    std::vector<double>& cur = P.cur;
+    if (nMin < (uint32_t)cn) { P.hybrid = true; P.delta = (kMax + 1.0) / cn; }
+    double mx = cur[0], mn = cur[0];
+    for (double v : cur) { mx = std::max(mx, v); mn = std::min(mn, v); }
+    if (mx == mn) { P.trivial = true; return; }
+    double sum = 0; for (double v : cur) sum += v;
+    const double avg = sum / cn;
+    for (double& v : cur) v -= avg;
+    double tss = 0.0; for (double v : cur) tss += 1.0 * v * v;
+    P.tss = tss;
+    P.sx.resize(cn);
+    const int n = cn, al0 = minWidth;
     bool done = false;
     if (n >= CBS_GPU_MIN_N) {
         bool ok = false;
         auto tA = std::chrono::steady_clock::now();
-        int32_t rc = tmaxo_gpu(G, gd, n, tss, sx.data(), iseg, ostat, al0, st, ok); if (rc) return rc;
+        P.rc = tmaxo_gpu(G, cur.data(), n, tss, P.sx.data(), P.iseg, P.ostat, al0, st, ok); if (P.rc) return;
         st.ns_tmaxo += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tA).count();
         done = ok;
         if (!ok) st.tie_replays++;
     }
-    if (!done) { auto tH = std::chrono::steady_clock::now(); tmaxo_host(gd, n, tss, sx.data(), iseg, ostat, al0); st.ns_tmaxo_host += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tH).count(); }
+    if (!done) { auto tH = std::chrono::steady_clock::now(); tmaxo_host(cur.data(), n, tss, P.sx.data(), P.iseg, P.ostat, al0); st.ns_tmaxo_host += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tH).count(); }
     st.tmaxo_calls++; st.tmaxo_elems += n;
-    double ostat1 = std::sqrt(ostat); ostat *= 0.99999;
-    if (ostat1 <= 0.1) return CANVAS_OK;
-    int l = std::min(iseg[1] - iseg[0], n - iseg[1] + iseg[0]);
-    if (!(ostat1 >= 7.0 && l >= 10)) {
-        int nrejc, k;
-        if (hybrid) {
+    P.ostat1 = std::sqrt(P.ostat); P.ostat *= 0.99999;
+    if (P.ostat1 <= 0.1) { P.stop = true; return; }
+    const int l = std::min(P.iseg[1] - P.iseg[0], n - P.iseg[1] + P.iseg[0]);
+    if (!(P.ostat1 >= 7.0 && l >= 10)) {
+        if (P.hybrid) {
             auto tTP = std::chrono::steady_clock::now();
-            bool exitNoSplit = false; nrejc = 0;
-            { int32_t rct = tail_p_decide(PG, ostat1, delta, n, cutoff, nPerm, st, exitNoSplit, nrejc); if (rct) return rct; }      // TailP(ostat1, delta, n, 100, 1E-6): p1 > cutoff, (int)((cutoff - p1) nPerm)
+            P.rc = tail_p_decide(PG, P.ostat1, P.delta, n, cutoff, nPerm, st, P.exitNoSplit, P.nrejc); if (P.rc) return;      // TailP(ostat1, delta, n, 100, 1E-6): p1 > cutoff, (int)((cutoff - p1) nPerm)
             st.ns_tailp += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tTP).count();
-            if (exitNoSplit) { st.tailp_exits++; return CANVAS_OK; }
-        } else nrejc = (int)(cutoff * nPerm);
-        k = nrejc * (nrejc + 1) / 2 + 1;
+            if (P.exitNoSplit) st.tailp_exits++;
+        } else P.nrejc = (int)(cutoff * nPerm);
+    } else { P.bigT = true; st.big_t++; }
+}
+static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff, int& nCp, int iCp[2], const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st) {
+    const int minWidth = 2, kMax = 25;
+    nCp = 0;
+    if (P.rc) return P.rc;
+    if (P.trivial || P.stop) return CANVAS_OK;
+    const int n = P.cn, al0 = minWidth, hk = kMax; const double* gd = P.cur.data(); const double tss = P.tss, ostat = P.ostat; const bool hybrid = P.hybrid;
+    const int* iseg = P.iseg;
+    std::vector<double> px(n); std::vector<double>& sx = P.sx;
+    int nrej = 0;
+    if (!P.bigT) {
+        if (hybrid && P.exitNoSplit) return CANVAS_OK;
+        const int nrejc = P.nrejc;
+        int k = nrejc * (nrejc + 1) / 2 + 1;
         auto t0 = std::chrono::steady_clock::now();
         struct Acc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } };
         if (hybrid && n >= PERM_GPU_MIN_N && hk <= PG_MAXK && getenv("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr) {
             Acc acc{st.ns_dev, t0};
+            struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.devLoops++; } } lc{t0};
             int outcome = 1;
             int32_t rc = perm_loop_gpu(PG, gd, n, tss, nPerm, hk, al0, ostat, nrejc, k, sbdry, rnd, st, outcome); if (rc) return rc;
             if (outcome == 0) return CANVAS_OK;
         } else {
-        Acc acc{st.ns_hostperm, t0};
-        for (uint32_t np = 1; np <= nPerm; np++) {
-            xperm(gd, px.data(), n, rnd);
-            double pstat = hybrid ? htmaxp_host(hk, tss, px.data(), n, sx.data(), al0) : tmaxp_host(tss, px.data(), n, sx.data(), al0);
-            st.perms++; st.perm_elems += n;
-            if (ostat <= pstat) { nrej++; k++; }
-            if (nrej > nrejc) return CANVAS_OK;
-            if (np >= sbdry[k - 1]) break;
+            Acc acc{st.ns_hostperm, t0};
+            struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.host += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.hostLoops++; } } lc{t0};
+            for (uint32_t np = 1; np <= nPerm; np++) {
+                xperm(gd, px.data(), n, rnd);
+                double pstat = hybrid ? htmaxp_host(hk, tss, px.data(), n, sx.data(), al0) : tmaxp_host(tss, px.data(), n, sx.data(), al0);
+                st.perms++; st.perm_elems += n;
+                if (ostat <= pstat) { nrej++; k++; }
+                if (nrej > nrejc) return CANVAS_OK;
+                if (np >= sbdry[k - 1]) break;
+            }
         }
-        }
-    } else st.big_t++;
+    }
     auto tT = std::chrono::steady_clock::now();
     struct TAcc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~TAcc() { a += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } tAcc{st.ns_tpermp, tT};
+    struct LE { std::chrono::steady_clock::time_point t; ~LE() { tlClock.edge += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } le{tT};
     if (iseg[1] == n) { nCp = 1; iCp[0] = iseg[0]; }
     else if (iseg[0] == 0) { nCp = 1; iCp[0] = iseg[1]; }
     else {
@@ -1146,34 +1249,82 @@ static int32_t find_change_points(ArcGpu& G, PermGpu& PG, const double* gd, int 
     }
     return CANVAS_OK;
 }
+// the engines' buffers outlive a call: a thread borrows an ArcGpu / PermGpu from the context's cache and hands it back (the buffers only grow)
+struct EngineCache {
+    std::mutex mu; std::vector<std::unique_ptr<ArcGpu>> arcs; std::vector<std::unique_ptr<PermGpu>> perms;
+    static EngineCache& of(canvas_ctx* ctx) {
+        static std::mutex g; std::lock_guard<std::mutex> lk(g);
+        if (!ctx->cbs_cache) ctx->cbs_cache = std::shared_ptr<void>(new EngineCache(), [](void* p) { delete (EngineCache*)p; });
+        return *(EngineCache*)ctx->cbs_cache.get();
+    }
+    std::unique_ptr<ArcGpu> arc(canvas_ctx* ctx, PermService* svc) { std::unique_ptr<ArcGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!arcs.empty()) { g = std::move(arcs.back()); arcs.pop_back(); } } if (!g) { g.reset(new ArcGpu()); g->ctx = ctx; } g->svc = svc; return g; }
+    std::unique_ptr<PermGpu> perm(canvas_ctx* ctx, PermService* svc) { std::unique_ptr<PermGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!perms.empty()) { g = std::move(perms.back()); perms.pop_back(); } } if (!g) { g.reset(new PermGpu()); g->ctx = ctx; } g->svc = svc; return g; }
+    void give(std::unique_ptr<ArcGpu> g) { std::lock_guard<std::mutex> lk(mu); arcs.push_back(std::move(g)); }
+    void give(std::unique_ptr<PermGpu> g) { std::lock_guard<std::mutex> lk(mu); perms.push_back(std::move(g)); }
+};
+// helper threads of phase 1 (own arc-search and tail-series buffers each); a chromosome thread that needs a segment no helper has started yet runs it itself
+struct SpecTask { const double* gd; int cn; Phase1 out; std::atomic<int> state{0}; };      // 0 queued, 1 running, 2 done
+struct SpecPool {
+    canvas_ctx* ctx; PermService** arcSvcs /* [3] */; uint32_t nPerm; double cutoff; Stats* st; std::atomic_int nextArc{0};
+    std::mutex mu; std::condition_variable cvWork, cvDone; std::deque<std::shared_ptr<SpecTask>> queue; bool stopping = false; std::vector<std::thread> workers;
+    void start(int n) {
+        for (int i = 0; i < n; i++) workers.emplace_back([this]() {
+            EngineCache& cache = EngineCache::of(ctx);
+            std::unique_ptr<ArcGpu> gp = cache.arc(ctx, arcSvcs[nextArc++ % 3]); std::unique_ptr<PermGpu> pgp = cache.perm(ctx, nullptr);
+            struct Back { EngineCache& c; std::unique_ptr<ArcGpu>& a; std::unique_ptr<PermGpu>& p; ~Back() { c.give(std::move(a)); c.give(std::move(p)); } } back{cache, gp, pgp};
+            ArcGpu& G = *gp; PermGpu& PG = *pgp;
+            for (;;) {
+                std::shared_ptr<SpecTask> t;
+                { std::unique_lock<std::mutex> lk(mu); cvWork.wait(lk, [&]() { return stopping || !queue.empty(); }); if (queue.empty()) return; t = queue.front(); queue.pop_front(); }
+                int expect = 0;
+                if (!t->state.compare_exchange_strong(expect, 1)) continue;          // the chromosome thread took it
+                phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out);
+                { std::lock_guard<std::mutex> lk(mu); t->state = 2; }
+                cvDone.notify_all();
+            }
+        });
+    }
+    std::shared_ptr<SpecTask> submit(const double* gd, int cn) {
+        auto t = std::make_shared<SpecTask>(); t->gd = gd; t->cn = cn;
+        { std::lock_guard<std::mutex> lk(mu); queue.push_back(t); }
+        cvWork.notify_one();
+        return t;
+    }
+    // the result of a task: run here if nobody has started it, otherwise wait for the helper
+    Phase1& get(const std::shared_ptr<SpecTask>& t, ArcGpu& G, PermGpu& PG) {
+        int expect = 0;
+        if (t->state.compare_exchange_strong(expect, 1)) { phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out); t->state = 2; return t->out; }
+        std::unique_lock<std::mutex> lk(mu); cvDone.wait(lk, [&]() { return t->state.load() == 2; });
+        return t->out;
+    }
+    ~SpecPool() { { std::lock_guard<std::mutex> lk(mu); stopping = true; } cvWork.notify_all(); for (auto& w : workers) w.join(); }
+};
 
 // ChangePoint.ChangePoints (ChangePoint.cs:44-153), undo = None
-static int32_t change_points(ArcGpu& G, PermGpu& PG, const double* gd, int n, const std::vector<uint32_t>& sbdry, MT& rnd, double alpha, uint32_t nPerm, std::vector<int>& lengthSeg, Stats& st) {
-    const int minWidth = 2, kMax = 25; const uint32_t nMin = 200;
+static int32_t change_points(ArcGpu& G, PermGpu& PG, SpecPool* pool, const double* gd, int n, const std::vector<uint32_t>& sbdry, MT& rnd, double alpha, uint32_t nPerm, std::vector<int>& lengthSeg, Stats& st) {
     std::vector<int> segEnd = {0, n}, changeLoc;
+    std::map<std::pair<int, int>, std::shared_ptr<SpecTask>> ahead;        // phase 1 of the segments on the stack, keyed by (start, end)
     int k = 2, nCp = 0, iCp[2] = {0, 0};
     while (k > 1) {
-        int cn = segEnd[k - 1] - segEnd[k - 2];
-        if (cn >= 2 * minWidth) {
-            std::vector<double> cur(gd + segEnd[k - 2], gd + segEnd[k - 2] + cn);
-            bool hybrid = false; double delta = 0.0;
-            if (nMin < (uint32_t)cn) { hybrid = true; delta = (kMax + 1.0) / cn; }
-            double mx = cur[0], mn = cur[0];
-            for (double v : cur) { mx = std::max(mx, v); mn = std::min(mn, v); }
-            if (mx == mn) nCp = 0;
-            else {
-                double sum = 0; for (double v : cur) sum += v;
-                double avg = sum / cn;
-                for (double& v : cur) v -= avg;
-                double tss = 0.0; for (double v : cur) tss += 1.0 * v * v;
-                int32_t rc = find_change_points(G, PG, cur.data(), cn, tss, nPerm, alpha, nCp, iCp, hybrid, minWidth, kMax, delta, sbdry, rnd, st); if (rc) return rc;
-            }
-        } else nCp = 0;
+        const int s0 = segEnd[k - 2], cn = segEnd[k - 1] - s0;
+        Phase1 local; Phase1* P = &local;
+        auto it = ahead.find({s0, segEnd[k - 1]});
+        std::shared_ptr<SpecTask> hold;
+        auto tP1 = std::chrono::steady_clock::now();
+        if (it != ahead.end()) { hold = it->second; ahead.erase(it); P = &pool->get(hold, G, PG); }
+        else phase1_run(G, PG, gd + s0, cn, nPerm, alpha, st, local);
+        tlClock.p1 += std::chrono::duration<double>(std::chrono::steady_clock::now() - tP1).count(); tlClock.segments++;
+        int32_t rc = phase2_run(PG, *P, nPerm, alpha, nCp, iCp, sbdry, rnd, st); if (rc) return rc;
         if (nCp == 0) changeLoc.push_back(segEnd[k - 1]);
-        for (int i = 0; i < nCp; i++) iCp[i] += segEnd[k - 2];
+        for (int i = 0; i < nCp; i++) iCp[i] += s0;
         if (nCp == 0) segEnd.erase(segEnd.begin() + (k - 1));
         else if (nCp == 1) segEnd.insert(segEnd.begin() + (k - 1), iCp[0]);
         else segEnd.insert(segEnd.begin() + (k - 1), iCp, iCp + 2);
+        if (nCp > 0 && pool) {
+            // the split left nCp + 1 segments where one was: all of them are submitted (the top one is needed next: the chromosome thread takes it itself unless a helper is faster)
+            const int first = k - 2;                            // segEnd[first] = s0
+            for (int j = first + nCp; j >= first; j--) { const int a = segEnd[j], b = segEnd[j + 1]; if (b - a >= 4) ahead[{a, b}] = pool->submit(gd + a, b - a); }
+        }
         k = (int)segEnd.size();
     }
     std::reverse(changeLoc.begin(), changeLoc.end());
@@ -1332,13 +1483,25 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     std::atomic_int next{0};
     // launcher threads (own streams): arc searches on one, permutation batches spread over four, so that the device always has several
     // independent kernels in flight (a batch of one chromosome is a chain of latency-bound launches)
-    cbs::PermService arcService(ctx), service(ctx), service1(ctx), service2(ctx), service3(ctx);
-    cbs::PermService* permServices[4] = {&service, &service1, &service2, &service3};
+    cbs::PermService arcService(ctx), arcService1(ctx), arcService2(ctx), service(ctx), service1(ctx), service2(ctx), service3(ctx);
+    const int nPermSvc = std::max(1, std::min(16, getenv("CANVAS_CBS_PERM_SERVICES") ? atoi(getenv("CANVAS_CBS_PERM_SERVICES")) : 4));
+    std::vector<std::unique_ptr<cbs::PermService>> moreServices;
+    for (int i = 4; i < nPermSvc; i++) moreServices.emplace_back(new cbs::PermService(ctx));
+    cbs::PermService* arcServices[3] = {&arcService, &arcService1, &arcService2};      // (one launcher synchronises after every round: requests that arrive meanwhile would wait a whole round)
+    std::atomic_int nextArc{0};
+    std::vector<cbs::PermService*> permServices = {&service, &service1, &service2, &service3};
+    for (auto& m : moreServices) permServices.push_back(m.get());
+    permServices.resize((size_t)nPermSvc);
     std::atomic_int nextService{0};
-    std::mutex chromMu; double maxChromSec = 0, sumChromSec = 0;
+    std::mutex chromMu; double maxChromSec = 0, sumChromSec = 0, slowSec = 0; std::string slowLine; const bool timing = getenv("CANVAS_CBS_TIMING") != nullptr;
+    // helper threads for the deterministic front half of every segment on a recursion stack (cbs::SpecPool); CANVAS_CBS_NO_SPECULATION=1: the plain sequential order (test hook)
+    std::unique_ptr<cbs::SpecPool> specPool;
+    if (!getenv("CANVAS_CBS_NO_SPECULATION")) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nperm, alpha, &st}); specPool->start((int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4))); }
     auto work = [&]() {
-        cbs::PermGpu PG; PG.ctx = ctx; PG.svc = permServices[nextService++ % 4];         // per thread: own buffers, created on first use
-        cbs::ArcGpu G; G.ctx = ctx; G.svc = &arcService;
+        cbs::EngineCache& cache = cbs::EngineCache::of(ctx);                             // per thread: own buffers, borrowed from the context's cache (created on first use)
+        std::unique_ptr<cbs::PermGpu> pgp = cache.perm(ctx, permServices[(size_t)(nextService++ % nPermSvc)]); std::unique_ptr<cbs::ArcGpu> gp = cache.arc(ctx, arcServices[nextArc++ % 3]);
+        struct Back { cbs::EngineCache& c; std::unique_ptr<cbs::ArcGpu>& a; std::unique_ptr<cbs::PermGpu>& p; ~Back() { c.give(std::move(a)); c.give(std::move(p)); } } back{cache, gp, pgp};
+        cbs::PermGpu& PG = *pgp; cbs::ArcGpu& G = *gp;
         for (;;) {
             int c = next++; if (c >= nchr) break;
             int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);
@@ -1346,7 +1509,10 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
             cbs::MT rnd((uint32_t)seeds[c]);
             auto tC = std::chrono::steady_clock::now();
             struct CAcc { std::mutex& m; double& mx; double& sm; std::chrono::steady_clock::time_point t; ~CAcc() { double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); std::lock_guard<std::mutex> lk(m); mx = std::max(mx, d); sm += d; } } cAcc{chromMu, maxChromSec, sumChromSec, tC};
-            rcs[c] = cbs::change_points(G, PG, cov.data() + h_chr_offset[c], n, sbdry, rnd, alpha, nperm, segs[c], st);
+            cbs::tlClock = cbs::ChromClock();
+            rcs[c] = cbs::change_points(G, PG, specPool.get(), cov.data() + h_chr_offset[c], n, sbdry, rnd, alpha, nperm, segs[c], st);
+            if (timing) { const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - tC).count(); const cbs::ChromClock& k = cbs::tlClock; std::lock_guard<std::mutex> lk(chromMu);
+                if (d > slowSec) { slowSec = d; char b[400]; snprintf(b, sizeof b, "slowest chromosome %d (%d bins): %.3f s = phase 1 %.3f + device permutation loops %.3f (%d) + host permutation loops %.3f (%d) + edge tests %.3f; %d segments tested", c, n, d, k.p1, k.dev, k.devLoops, k.host, k.hostLoops, k.edge, k.segments); slowLine = b; } }
             if (rcs[c] == 0 && undo == 2) cbs::sd_undo(cov.data() + h_chr_offset[c], segs[c], trimmedSD, undo_sd);
             if (rcs[c] == 0 && undo == 1 && segs[c].size() > 1) rcs[c] = cbs::prune(cov.data() + h_chr_offset[c], n, segs[c], 0.05, errs[c]);   // undoPrune = 0.05 (CBSRunner.cs:42)
         }
@@ -1363,8 +1529,9 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
     ctx->cbs_tailp[0] = st.tailp_dev; ctx->cbs_tailp[1] = st.tailp_host;
+    if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());
     if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: TMaxO on the host %.3f, TailP %.3f (%lld decided from the device series, %lld by the host series)\n", st.ns_tmaxo_host.load() * 1e-9, st.ns_tailp.load() * 1e-9, (long long)st.tailp_dev.load(), (long long)st.tailp_host.load()),
-                                      fprintf(stderr, "cbs launcher: %lld rounds, %lld arc searches in %.3f s, %lld permutation batches in %.3f s\n", service.rounds + arcService.rounds, arcService.nArc, arcService.secArc, service.nPermReq + service1.nPermReq + service2.nPermReq + service3.nPermReq, std::max(std::max(service.secPerm, service1.secPerm), std::max(service2.secPerm, service3.secPerm))),
+                                      fprintf(stderr, "cbs launcher: %lld rounds, %lld arc searches in %.3f s, %lld permutation batches in %.3f s\n", service.rounds + arcService.rounds + arcService1.rounds + arcService2.rounds, arcService.nArc + arcService1.nArc + arcService2.nArc, std::max(arcService.secArc, std::max(arcService1.secArc, arcService2.secArc)), service.nPermReq + service1.nPermReq + service2.nPermReq + service3.nPermReq, std::max(std::max(service.secPerm, service1.secPerm), std::max(service2.secPerm, service3.secPerm))),
                                       fprintf(stderr, "cbs thread-seconds: TMaxO on the device incl. waiting %.3f, edge tests (TPermP) %.3f; per-chromosome wall max %.3f sum %.3f; ", st.ns_tmaxo.load() * 1e-9, st.ns_tpermp.load() * 1e-9, maxChromSec, sumChromSec),
                                       fprintf(stderr, "device permutation loop %.3f (buffers %.3f, uploads %.3f, waiting for the launcher %.3f, stopping rule %.3f), host permutation loop %.3f\n", st.ns_dev.load() * 1e-9, st.ns_ensure.load() * 1e-9, st.ns_upload.load() * 1e-9, st.ns_submit.load() * 1e-9, st.ns_post.load() * 1e-9, st.ns_hostperm.load() * 1e-9);
     if (h_stats) { h_stats[0] = st.tmaxo_calls; h_stats[1] = st.tmaxo_elems; h_stats[2] = st.perms; h_stats[3] = st.perm_elems; h_stats[4] = st.tpermp_draws; h_stats[5] = st.tailp_exits; h_stats[6] = st.gpu_searches; h_stats[7] = st.tie_replays; }

@@ -42,6 +42,7 @@ struct canvas_ctx {
     bool up_active = false;
     void* gc_arena = nullptr; size_t gc_arena_bytes = 0;   // GCContentWeighted binning: read-GC profile of every position + GC prefix array (grow-only)
     bool clean_cq_failed = false, clean_cq_skip = false;   // clean_fast.hpp: a sample's counting selects gave up (it is redone with the radix selects)
+    std::shared_ptr<void> cbs_cache;     // cbs.hip: device / pinned buffers of the arc-search and permutation engines, kept between calls (a call used to spend tens of ms in hipMalloc / hipHostMalloc)
     std::shared_ptr<void> clean_batch;   // clean_fast.hpp: the batch that clean_batch_enqueue queued (consumed by clean_batch_finish)
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;

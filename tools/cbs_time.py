@@ -1,17 +1,24 @@
-import time, numpy as np, torch, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""Wall time of canvas_cbs on a synthetic genome (tools only; set CANVAS_CBS_TIMING=1 / CANVAS_CBS_DEBUG_BATCHES=1 for the library's own breakdown).
+
+usage: python tools/cbs_time.py [bins] [calls] [seed offset]
+"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from canvas_amd import synth
 from canvas_amd.lib import Canvas
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_700_000
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+so = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 cv = Canvas(0)
-n = 4_700_000
-bins = synth.generate_bins(20260927 + 2, n)
+bins = synth.generate_bins(20260927 + so, n)
 cov = np.round(bins["count"].astype(np.float64), 2)
 off = np.concatenate([[0], np.cumsum(np.bincount(bins["chr"], minlength=24))]).astype(np.int64)
 d = torch.from_numpy(cov).to(cv.device)
-for undo in (0,):
-    t = time.perf_counter()
-    seg_len, nseg, stats = cv.cbs(d, off, 0.01, 10000, undo=undo)
-    dt = time.perf_counter() - t
-    print("cbs WGS-size", n, "bins:", round(dt, 3), "s; segments", int(sum(nseg)), "stats [tmaxo_calls, tmaxo_elems, perms, perm_elems, tpermp_draws, tailp_exits, gpu_searches, tie_replays] =", list(map(int, stats)))
-print("device stats [dev perms, host perms, exact rechecks, batches, verified, violations]:", list(map(int, cv.cbs_device_stats())))
-t = time.perf_counter(); seg_len, nseg, stats = cv.cbs(d, off, 0.01, 10000); print("second call", round(time.perf_counter() - t, 3), "s")
+ts = []
+for r in range(calls):
+    t = time.perf_counter(); seg_len, nseg, stats = cv.cbs(d, off, 0.01, 10000); ts.append(time.perf_counter() - t)
+print("cbs calls:", [round(x, 3) for x in ts], "segments", int(sum(nseg)), "perms", int(stats[2]), "device stats", cv.cbs_device_stats(), flush=True)
+cv.close()
