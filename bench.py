@@ -334,7 +334,8 @@ def main():
     if rank == 0:
         if args.stage_times:
             print("stage times (ms, host wall incl. sync): " + json.dumps(stage), file=sys.stderr)
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    cv.close()              # streams, engines and workspaces go while the runtime is still up (not from __del__ at interpreter shutdown)
     if world > 1:
         dist.destroy_process_group()
 

@@ -870,6 +870,7 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
 struct PermService;
 struct PermGpu {
     canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr; char* buf = nullptr; size_t bytes = 0; char* pin = nullptr; size_t pinBytes = 0;
+    size_t reserveElems = 0, reserveN = 0;     // the call's longest chromosome: the first allocation is made for it (growing means hipFree + hipMalloc, which stall every stream of the device)
     // analytic tail probability on the device (k_tail_nu): own stream, 3 x 128 values on the device and in pinned memory
     hipStream_t tailStream = nullptr; char* tailDev = nullptr; char* tailPin = nullptr;
     int32_t ensure_tail() {
@@ -1065,7 +1066,11 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
                      oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
         const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pinTotal = pStat + al((size_t)mb * 16);
         auto tE = now();
-        int32_t rc0 = PG.ensure(total, pinTotal); if (rc0) return rc0;
+        size_t want = total, wantPin = pinTotal;
+        if (PG.reserveElems) { const size_t re = PG.reserveElems, rn = PG.reserveN;      // same layout, for the longest segment this call can meet
+            want = std::max(want, al(rn * 8) + al(625 * 4) + al(256 * 625 * 4) + al(256 * 16) + al((re + (size_t)MT_HISTORY) * 4) + 5 * al(re * 4) + 2 * al((re + 256) * 4) + 2 * al(re * 8));
+            wantPin = std::max(wantPin, al(rn * 8) + al(256 * 625 * 4) + al(256 * 16)); }
+        int32_t rc0 = PG.ensure(want, wantPin); if (rc0) return rc0;
         st.ns_ensure += since(tE);
         char* d = PG.buf; char* h = PG.pin;
         dX = (double*)(d + oX); dSnaps = (uint32_t*)(d + oSnaps); dStat = (double*)(d + oStat);
@@ -1481,6 +1486,7 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     std::vector<int32_t> rcs(nchr, 0);
     std::vector<std::string> errs(nchr);
     std::atomic_int next{0};
+    long long nMax = 0; for (int c = 0; c < nchr; c++) nMax = std::max<long long>(nMax, h_chr_offset[c + 1] - h_chr_offset[c]);
     // launcher threads (own streams): arc searches on one, permutation batches spread over four, so that the device always has several
     // independent kernels in flight (a batch of one chromosome is a chain of latency-bound launches)
     cbs::PermService arcService(ctx), arcService1(ctx), arcService2(ctx), service(ctx), service1(ctx), service2(ctx), service3(ctx);
@@ -1502,6 +1508,7 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
         std::unique_ptr<cbs::PermGpu> pgp = cache.perm(ctx, permServices[(size_t)(nextService++ % nPermSvc)]); std::unique_ptr<cbs::ArcGpu> gp = cache.arc(ctx, arcServices[nextArc++ % 3]);
         struct Back { cbs::EngineCache& c; std::unique_ptr<cbs::ArcGpu>& a; std::unique_ptr<cbs::PermGpu>& p; ~Back() { c.give(std::move(a)); c.give(std::move(p)); } } back{cache, gp, pgp};
         cbs::PermGpu& PG = *pgp; cbs::ArcGpu& G = *gp;
+        PG.reserveN = (size_t)nMax; PG.reserveElems = (size_t)std::min<long long>((long long)256 * nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * nMax));
         for (;;) {
             int c = next++; if (c >= nchr) break;
             int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);

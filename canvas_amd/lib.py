@@ -1,4 +1,5 @@
 """ctypes binding of libcanvas_hip.so.  Device memory is handled with torch tensors (plumbing only)."""
+import sys
 import ctypes as C
 import os
 
@@ -152,8 +153,10 @@ class Canvas:
             self.ctx = None
 
     def __del__(self):
+        # not at interpreter shutdown: the HIP runtime (and a profiler attached to it) may already be finalised, and the process exit frees everything anyway
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 
