@@ -1463,8 +1463,23 @@ extern "C" int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov
 extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                                    int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats) {
     if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_chr_offset || !d_seg_len || !h_nseg) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs: bad arguments");
+    std::vector<std::vector<int>> segs;
+    int32_t rc = cvx_cbs_masked(ctx, nchr, d_cov, h_chr_offset, alpha, nperm, undo, undo_sd, nullptr, segs, h_stats); if (rc) return rc;
+    const int64_t N = h_chr_offset[nchr];
+    std::vector<int32_t> flat((size_t)N + 1, 0);
+    for (int c = 0; c < nchr; c++) { h_nseg[c] = (int32_t)segs[c].size(); for (size_t i = 0; i < segs[c].size(); i++) flat[h_chr_offset[c] + i] = segs[c][i]; }
+    if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_seg_len, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+// the segmentation itself; h_mask (optional) = the chromosomes to segment (canvas_cbs_sharded: the ones this rank owns).  Everything genome-wide — the seeds, drawn for every
+// chromosome in file order (CBSRunner.cs:107-112), and the trimmed SD of SDUndo (CBSRunner.cs:102) — is computed from the whole coverage whatever the mask says.
+int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm, int32_t undo, double undo_sd,
+                       const uint8_t* h_mask, std::vector<std::vector<int>>& segs, int64_t* h_stats) {
+    if (!ctx) return CANVAS_ERR_INVALID;
     if (undo != 0 && undo != 1 && undo != 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "undo must be 0 (None), 1 (Prune) or 2 (SDUndo)");
-    if (nchr <= 0 || !d_cov || !h_chr_offset || !d_seg_len || !h_nseg || nperm == 0 || !(alpha > 0 && alpha < 1)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs: bad arguments");
+    if (nchr <= 0 || !d_cov || !h_chr_offset || nperm == 0 || !(alpha > 0 && alpha < 1)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = h_chr_offset[nchr];
     std::vector<double> cov((size_t)N);
@@ -1482,11 +1497,11 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     double trimmedSD = 1.0;
     if (undo == 2 && N > 1) trimmedSD = std::sqrt(cbs::trimmed_variance(cov.data(), h_chr_offset, nchr, 0.025));   // CBSRunner.cs:102
     cbs::Stats st;
-    std::vector<std::vector<int>> segs(nchr);
+    segs.assign((size_t)nchr, std::vector<int>());
     std::vector<int32_t> rcs(nchr, 0);
     std::vector<std::string> errs(nchr);
     std::atomic_int next{0};
-    long long nMax = 0; for (int c = 0; c < nchr; c++) nMax = std::max<long long>(nMax, h_chr_offset[c + 1] - h_chr_offset[c]);
+    long long nMax = 0; for (int c = 0; c < nchr; c++) if (!h_mask || h_mask[c]) nMax = std::max<long long>(nMax, h_chr_offset[c + 1] - h_chr_offset[c]);
     // launcher threads (own streams): arc searches on one, permutation batches spread over four, so that the device always has several
     // independent kernels in flight (a batch of one chromosome is a chain of latency-bound launches)
     cbs::PermService arcService(ctx), arcService1(ctx), arcService2(ctx), service(ctx), service1(ctx), service2(ctx), service3(ctx);
@@ -1512,7 +1527,7 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
         for (;;) {
             int c = next++; if (c >= nchr) break;
             int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);
-            if (n <= 0) continue;
+            if (n <= 0 || (h_mask && !h_mask[c])) continue;
             cbs::MT rnd((uint32_t)seeds[c]);
             auto tC = std::chrono::steady_clock::now();
             struct CAcc { std::mutex& m; double& mx; double& sm; std::chrono::steady_clock::time_point t; ~CAcc() { double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); std::lock_guard<std::mutex> lk(m); mx = std::max(mx, d); sm += d; } } cAcc{chromMu, maxChromSec, sumChromSec, tC};
@@ -1530,10 +1545,6 @@ extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* 
     for (int t = 0; t < nthreads; t++) th.emplace_back(work);
     for (auto& t : th) t.join();
     for (int c = 0; c < nchr; c++) if (rcs[c]) { if (!errs[c].empty()) ctx->err = errs[c]; return rcs[c]; }
-    std::vector<int32_t> flat((size_t)N + 1, 0);
-    for (int c = 0; c < nchr; c++) { h_nseg[c] = (int32_t)segs[c].size(); for (size_t i = 0; i < segs[c].size(); i++) flat[h_chr_offset[c] + i] = segs[c][i]; }
-    if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_seg_len, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
     ctx->cbs_tailp[0] = st.tailp_dev; ctx->cbs_tailp[1] = st.tailp_host;
     if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());

@@ -149,6 +149,11 @@ CVX_INTERNAL int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const 
                                            int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                                            int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
 // canvas_hmm_per_sample on a subset of chromosomes (d_cov / h_chr_offset: the subset, contiguous) with the genome-wide quartiles taken from d_cov_all[0, n_all)
+// CanvasPartition -m CBS / -m Wavelets for the chromosomes h_mask selects (NULL: all); genome-wide inputs (seeds in file order, trimmed SD, coverage variability) always use the whole coverage
+CVX_INTERNAL int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm, int32_t undo, double undo_sd,
+                                    const uint8_t* h_mask, std::vector<std::vector<int>>& segs, int64_t* h_stats);
+CVX_INTERNAL int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline, double threshold_lower, double threshold_upper,
+                                         double mad_factor, int32_t variability_window, int32_t min_size, const uint8_t* h_mask, int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset);
 CVX_INTERNAL int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state);
 
 // (Polling the stream with hipStreamQuery instead of blocking in hipStreamSynchronize was tried for the short waits of a pass: no gain on the pass time, and

@@ -350,3 +350,122 @@ extern "C" int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6) {
     for (int i = 0; i < 6; i++) h_out6[i] = ctx->shard_stats[i];
     return CANVAS_OK;
 }
+
+// ================================================================================================ CanvasPartition -m CBS / -m Wavelets, chromosomes sharded over the ranks
+// Both methods work chromosome by chromosome (CBSRunner.cs:62-89 one task per chromosome, WaveletsRunner.cs:115-135 Parallel.ForEach over chromosomes); what couples the
+// chromosomes is computed from the whole coverage on every rank — the seeds drawn in file order and the trimmed SD of SDUndo (CBSRunner.cs:102-112), the coverage variability
+// (Segmentation.cs:297-330) — and every rank HAS the whole cleaned coverage (canvas_sample_pipeline_sharded leaves it everywhere).  So a rank segments the chromosomes it
+// owns and ONE exchange of variable-length integer lists ([chromosome, count, values ...] per owned chromosome) gives every rank the whole result.  The exchange is
+// canvas_allgather_boundaries' (count slot + payload, padded to the largest rank; a count that does not fit announces itself and everybody retries with the bound all ranks
+// can derive); a rank that failed locally still enters it and sends its negative error code as its count, so nobody waits for it.
+static int32_t exchange_lists(canvas_ctx* ctx, const std::vector<int32_t>& mine, int32_t localErr, const std::string& localMsg, int64_t hardMax, const char* what, std::vector<std::vector<int32_t>>& all) {
+    const int W = ctx->nranks;
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    int64_t maxPer = std::min<int64_t>(hardMax, 1 << 16);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const size_t front = al((size_t)(1 + maxPer) * 4 + 256);
+        int32_t rc = canvas_ws_reserve(ctx, front + al((size_t)maxPer * 4) + al((size_t)W * (1 + (size_t)maxPer) * 4) + 4096); if (rc) return rc;
+        char* wsb = (char*)ctx->ws + front;
+        int32_t* dRec = (int32_t*)wsb; int32_t* dAll = (int32_t*)(wsb + al((size_t)maxPer * 4));
+        const bool fits = (int64_t)mine.size() < maxPer;
+        if (!localErr && fits && !mine.empty()) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRec, mine.data(), mine.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        std::vector<int32_t> counts((size_t)W, 0);
+        const int32_t announce = localErr ? (localErr < 0 ? localErr : -localErr) : (fits ? (int32_t)mine.size() : (int32_t)maxPer);
+        rc = cvx_allgather_boundaries_status(ctx, dRec, announce, (int32_t)maxPer, dAll, counts.data()); if (rc) return rc;
+        for (int r = 0; r < W; r++) if (counts[(size_t)r] < 0) {
+            if (localErr) { ctx->err = localMsg; return localErr; }
+            CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string(what) + ": rank " + std::to_string(r) + " failed before the exchange (code " + std::to_string(counts[(size_t)r]) + ")");
+        }
+        bool overflow = false;
+        for (int r = 0; r < W; r++) if (counts[(size_t)r] >= maxPer) overflow = true;
+        if (overflow && attempt == 0 && maxPer < hardMax) { maxPer = hardMax; continue; }
+        if (overflow) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, std::string(what) + ": the lists do not fit the exchange");
+        std::vector<int32_t> flat((size_t)W * (1 + (size_t)maxPer));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(flat.data(), dAll, flat.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        all.assign((size_t)W, std::vector<int32_t>());
+        for (int r = 0; r < W; r++) { const int32_t* p = flat.data() + (size_t)r * (1 + (size_t)maxPer); all[(size_t)r].assign(p + 1, p + 1 + counts[(size_t)r]); }
+        return CANVAS_OK;
+    }
+    return CANVAS_OK;
+}
+// the lists of every rank -> per-chromosome lists; every chromosome must come from exactly its owner
+static int32_t lists_by_chromosome(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const std::vector<std::vector<int32_t>>& all, const char* what, std::vector<std::vector<int32_t>>& perChr) {
+    perChr.assign((size_t)nchr, std::vector<int32_t>());
+    std::vector<char> seen((size_t)nchr, 0);
+    for (size_t r = 0; r < all.size(); r++) {
+        const std::vector<int32_t>& v = all[r];
+        for (size_t i = 0; i < v.size();) {
+            if (i + 2 > v.size()) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string(what) + ": truncated list");
+            const int32_t c = v[i], n = v[i + 1];
+            if (c < 0 || c >= nchr || n < 0 || i + 2 + (size_t)n > v.size() || h_chr_owner[c] != (int32_t)r || seen[(size_t)c]) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string(what) + ": malformed list");
+            seen[(size_t)c] = 1; perChr[(size_t)c].assign(v.begin() + (long)i + 2, v.begin() + (long)i + 2 + n);
+            i += 2 + (size_t)n;
+        }
+    }
+    for (int c = 0; c < nchr; c++) if (!seen[(size_t)c] && h_chr_owner[c] >= 0 && h_chr_owner[c] < (int32_t)all.size()) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string(what) + ": a chromosome's list is missing");
+    return CANVAS_OK;
+}
+static int32_t check_owner_table(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const char* what) {
+    if (nchr <= 0 || !h_chr_owner) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, std::string(what) + ": bad arguments");
+    for (int c = 0; c < nchr; c++) if (h_chr_owner[c] < 0 || h_chr_owner[c] >= ctx->nranks) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, std::string(what) + ": owner outside [0, ranks)");
+    return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_cbs_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
+                                      int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    const char* what = "canvas_cbs_sharded";
+    int32_t rc = check_owner_table(ctx, nchr, h_chr_owner, what); if (rc) return rc;          // (the same table on every rank: fails everywhere or nowhere)
+    if (!h_chr_offset || !d_seg_len || !h_nseg) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs_sharded: bad arguments");
+    std::vector<uint8_t> mine((size_t)nchr);
+    for (int c = 0; c < nchr; c++) mine[(size_t)c] = h_chr_owner[c] == ctx->rank;
+    std::vector<std::vector<int>> segs;
+    int32_t localErr = cvx_cbs_masked(ctx, nchr, d_cov, h_chr_offset, alpha, nperm, undo, undo_sd, mine.data(), segs, h_stats);
+    const std::string localMsg = ctx->err;
+    std::vector<int32_t> list;
+    if (!localErr) for (int c = 0; c < nchr; c++) if (mine[(size_t)c]) { list.push_back(c); list.push_back((int32_t)segs[(size_t)c].size()); for (int v : segs[(size_t)c]) list.push_back(v); }
+    const int64_t N = h_chr_offset[nchr];
+    std::vector<std::vector<int32_t>> all, perChr;
+    rc = exchange_lists(ctx, list, localErr, localMsg, N + 2 * (int64_t)nchr + 16, what, all); if (rc) return rc;
+    rc = lists_by_chromosome(ctx, nchr, h_chr_owner, all, what, perChr); if (rc) return rc;
+    std::vector<int32_t> flat((size_t)N + 1, 0);
+    for (int c = 0; c < nchr; c++) {
+        const int64_t L = h_chr_offset[c + 1] - h_chr_offset[c]; long long sum = 0;
+        for (int32_t v : perChr[(size_t)c]) sum += v;
+        if ((int64_t)perChr[(size_t)c].size() > L || (L > 0 && sum != L)) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_cbs_sharded: a gathered chromosome's segment lengths do not add up to its bins");
+        h_nseg[c] = (int32_t)perChr[(size_t)c].size();
+        for (size_t i = 0; i < perChr[(size_t)c].size(); i++) flat[(size_t)h_chr_offset[c] + i] = perChr[(size_t)c][i];
+    }
+    if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_seg_len, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_wavelets_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline,
+                                           double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
+                                           int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    const char* what = "canvas_wavelets_sharded";
+    int32_t rc = check_owner_table(ctx, nchr, h_chr_owner, what); if (rc) return rc;
+    if (!h_chr_offset || !h_breakpoints || !h_bp_offset || cap < 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets_sharded: bad arguments");
+    std::vector<uint8_t> mine((size_t)nchr);
+    for (int c = 0; c < nchr; c++) mine[(size_t)c] = h_chr_owner[c] == ctx->rank;
+    const int64_t N = h_chr_offset[nchr] - h_chr_offset[0];
+    std::vector<int32_t> bp((size_t)std::max<int64_t>(N, 1)); std::vector<int64_t> bo((size_t)nchr + 1, 0);
+    int32_t localErr = cvx_wavelets_masked(ctx, nchr, d_cov, h_chr_offset, is_germline, threshold_lower, threshold_upper, mad_factor, variability_window, min_size, mine.data(), bp.data(), (int64_t)bp.size(), bo.data());
+    const std::string localMsg = ctx->err;
+    std::vector<int32_t> list;
+    if (!localErr) for (int c = 0; c < nchr; c++) if (mine[(size_t)c]) { list.push_back(c); list.push_back((int32_t)(bo[(size_t)c + 1] - bo[(size_t)c])); list.insert(list.end(), bp.begin() + bo[(size_t)c], bp.begin() + bo[(size_t)c + 1]); }
+    std::vector<std::vector<int32_t>> all, perChr;
+    rc = exchange_lists(ctx, list, localErr, localMsg, N + 2 * (int64_t)nchr + 16, what, all); if (rc) return rc;
+    rc = lists_by_chromosome(ctx, nchr, h_chr_owner, all, what, perChr); if (rc) return rc;
+    int64_t total = 0;
+    for (int c = 0; c < nchr; c++) {
+        h_bp_offset[c] = total;
+        if (total + (int64_t)perChr[(size_t)c].size() > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_wavelets_sharded: breakpoint capacity too small");
+        for (int32_t v : perChr[(size_t)c]) h_breakpoints[total++] = v;
+    }
+    h_bp_offset[nchr] = total;
+    return CANVAS_OK;
+}

@@ -673,6 +673,13 @@ struct ChromTree { std::vector<int> counts; std::vector<Cand> cands; double sigm
 extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline,
                                    double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
                                    int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset) {
+    return cvx_wavelets_masked(ctx, nchr, d_cov, h_chr_offset, is_germline, threshold_lower, threshold_upper, mad_factor, variability_window, min_size, nullptr, h_breakpoints, cap, h_bp_offset);
+}
+// h_mask (optional): the chromosomes to decompose (canvas_wavelets_sharded: the ones this rank owns; the others get no breakpoints).  The coverage variability is genome-wide
+// (Segmentation.cs:297-330) and is computed from the whole coverage whatever the mask says.
+int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline,
+                            double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
+                            const uint8_t* h_mask, int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset) {
     using namespace wv;
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !d_cov || !h_chr_offset || !h_breakpoints || !h_bp_offset || variability_window <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: bad arguments");
@@ -717,7 +724,7 @@ extern "C" int32_t canvas_wavelets(canvas_ctx* ctx, int32_t nchr, const double* 
     std::vector<char> isRoot((size_t)nchr, 0);
     for (int c = 0; c < nchr; c++) {
         const int64_t L = off[c + 1] - off[c];
-        if (std::max<int64_t>(L, 1) <= min_size) continue;
+        if (std::max<int64_t>(L, 1) <= min_size || (h_mask && !h_mask[c])) continue;
         if (L < 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: a chromosome that passes MinSize needs at least two bins");
         isRoot[(size_t)c] = 1;
     }

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
     "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_wavelets_decisions", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
-    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sharded_stats", "canvas_profile_enable", "canvas_profile_get",
+    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_profile_enable", "canvas_profile_get",
 ]
 
 
@@ -549,6 +549,25 @@ class Canvas:
                                                             C.c_void_p(cov.data_ptr()), C.c_void_p(state.data_ptr()), C.c_void_p(seg.data_ptr()),
                                                             C.byref(bs), C.byref(total), C.byref(nclean), C.byref(lsd), _np_ptr(off), C.byref(nseg)))
         return dict(bin_size=bs.value, total=total.value, n_out=nclean.value, lsd=lsd.value, off=off, nseg=nseg.value)
+
+    def cbs_sharded(self, owner, cov, chr_offset, alpha=0.01, nperm=10000, undo=0, undo_sd=3.0):
+        """canvas_cbs_sharded: every rank holds the whole coverage, segments the chromosomes it owns and receives everybody's segments (same return as cbs)"""
+        torch = self.torch
+        off = np.ascontiguousarray(chr_offset, np.int64); ow = np.ascontiguousarray(owner, np.int32)
+        seg_len = torch.zeros(int(off[-1]) + 1, dtype=torch.int32, device=self.device)
+        nseg = np.zeros(len(off) - 1, np.int32); stats = np.zeros(8, np.int64)
+        self._check(self.lib.canvas_cbs_sharded(self.ctx, len(off) - 1, _np_ptr(ow), C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_double(alpha), C.c_uint32(nperm), int(undo), C.c_double(undo_sd),
+                                                C.c_void_p(seg_len.data_ptr()), _np_ptr(nseg), _np_ptr(stats)))
+        return seg_len, nseg, stats
+
+    def wavelets_sharded(self, owner, cov, chr_offset, is_germline=False, threshold_lower=0.05, threshold_upper=80.0, mad_factor=5.0, window=100000, min_size=10):
+        """canvas_wavelets_sharded: same return as wavelets, on every rank"""
+        off = np.ascontiguousarray(chr_offset, np.int64); ow = np.ascontiguousarray(owner, np.int32)
+        nchr = len(off) - 1
+        out = np.zeros(int(off[-1] - off[0]) + nchr + 1, np.int32); oo = np.zeros(nchr + 1, np.int64)
+        self._check(self.lib.canvas_wavelets_sharded(self.ctx, nchr, _np_ptr(ow), C.c_void_p(cov.data_ptr()), _np_ptr(off), int(bool(is_germline)), C.c_double(threshold_lower),
+                                                     C.c_double(threshold_upper), C.c_double(mad_factor), int(window), int(min_size), _np_ptr(out), C.c_int64(len(out)), _np_ptr(oo)))
+        return [out[oo[c]:oo[c + 1]].copy() for c in range(nchr)]
 
     def sharded_stats(self):
         out = np.zeros(6, np.int64)

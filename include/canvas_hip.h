@@ -347,6 +347,18 @@ int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr, const int3
 /* last canvas_sample_pipeline_sharded call: [0] ranks, [1] chromosomes owned, [2] bins binned locally, [3] bytes this rank contributed to the bins all-gather,
  * [4] boundary records of this rank, [5] bytes per rank of the boundary all-gather */
 int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6);
+/* CanvasPartition -m CBS / -m Wavelets with the chromosomes sharded over the ranks (the tumour / normal flow of BASELINE configs[4] ends in CBS, the
+ * reference's default method is Wavelets).  d_cov / h_chr_offset describe the WHOLE cleaned coverage and are the same on every rank (what canvas_sample_pipeline_sharded
+ * leaves everywhere); a rank segments the chromosomes with h_chr_owner[c] == its rank — the reference's own per-chromosome tasks (CBSRunner.cs:62-89, WaveletsRunner.cs:115-135)
+ * — while everything that couples chromosomes is computed from the whole coverage on every rank: the per-chromosome seeds drawn in file order and the genome-wide trimmed SD of
+ * SDUndo (CBSRunner.cs:102-112), the coverage variability (Segmentation.cs:297-330).  ONE exchange of variable-length lists (the mechanism of
+ * canvas_allgather_boundaries) then gives every rank the complete result, identical to canvas_cbs_undo / canvas_wavelets on one GPU.  Must be called by all ranks; a rank
+ * that fails locally still takes part in the exchange and every rank returns an error.  h_stats of canvas_cbs_sharded counts this rank's chromosomes only. */
+int32_t canvas_cbs_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
+                           int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
+int32_t canvas_wavelets_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline,
+                                double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
+                                int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset);
 
 /* ---- profiling hooks (hipEvent pairs recorded on the context's stream around the named kernels) --------------------- */
 int32_t canvas_profile_enable(canvas_ctx* ctx, int32_t on);

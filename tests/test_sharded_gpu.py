@@ -222,7 +222,11 @@ def _rccl_worker(rank, world, port, q):
         r = cv.sample_pipeline_sharded(owner, bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
         cv.synchronize()
         n = r["n_out"]
-        q.put((rank, dict(r, off=r["off"].tolist()), out["count"][:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy()))
+        # the sharded partition methods on the coverage the pipeline left on every rank
+        seg_len, nseg_c, _ = cv.cbs_sharded(owner, cov, r["off"], 0.01, 500)
+        cbs = [seg_len.cpu().numpy()[int(r["off"][c]):int(r["off"][c]) + int(nseg_c[c])].tolist() for c in range(len(LENGTHS))]
+        wv = [b.tolist() for b in cv.wavelets_sharded(owner, cov, r["off"], window=2000)]
+        q.put((rank, dict(r, off=r["off"].tolist()), out["count"][:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy(), cbs, wv))
         dist.destroy_process_group()
     except Exception:                                           # noqa: BLE001
         import traceback
@@ -250,7 +254,118 @@ def test_rccl_all_gather_between_real_ranks():
     for g in got:
         assert g[1] != "error", g[2]
     from canvas_amd import Canvas
-    ref = _single(Canvas(0))
-    for rank, r, count, state, seg in got:
+    cv0 = Canvas(0)
+    ref = _single(cv0)
+    dcov = torch.from_numpy(ref[2]).to(cv0.device); off = ref[0]["off"]
+    seg_len, nseg_c, _ = cv0.cbs(dcov, off, 0.01, 500)
+    cbs1 = [seg_len.cpu().numpy()[int(off[c]):int(off[c]) + int(nseg_c[c])].tolist() for c in range(len(LENGTHS))]
+    wv1 = [b.tolist() for b in cv0.wavelets(dcov, off, window=2000)]
+    for rank, r, count, state, seg, cbs, wv in got:
         assert (r["bin_size"], r["total"], r["n_out"], r["nseg"], r["lsd"]) == (ref[0]["bin_size"], ref[0]["total"], ref[0]["n_out"], ref[0]["nseg"], ref[0]["lsd"]), rank
         assert (count.view(np.uint32) == ref[1]["count"].view(np.uint32)).all() and (state == ref[3]).all() and (seg == ref[4]).all(), rank
+        assert cbs == cbs1 and wv == wv1, rank
+
+
+# ---- CanvasPartition -m CBS / -m Wavelets with the chromosomes sharded over the ranks (canvas_cbs_sharded, canvas_wavelets_sharded)
+PART_LENS = [6000, 4100, 3000, 2500, 1200, 700, 9]            # the last chromosome is below Wavelets' MinSize
+
+
+def _partition_coverage():
+    rng = np.random.default_rng(SEED + 11)
+    parts = []
+    for c, L in enumerate(PART_LENS):
+        x = rng.normal(60.0, 6.0, L)
+        for k in range(1 + c % 3):                              # planted copy-number changes
+            a = int(rng.integers(0, max(1, L - 50))); b = min(L, a + int(rng.integers(30, max(31, L // 3))))
+            x[a:b] *= rng.choice([0.5, 1.5, 2.0])
+        parts.append(np.round(np.clip(x, 0, None), 2))
+    cov = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum(PART_LENS)]).astype(np.int64)
+    return cov, off
+
+
+def _partition_worker(rank, world, port, q, fail):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        from canvas_amd.lib import CanvasError
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        owner = parallel.owner_table(PART_LENS, world)
+        cov, off = _partition_coverage()
+        if fail and rank == 1:
+            cov = cov.copy(); cov[int(off[2]) + 3] = np.nan          # only rank 1's copy of the coverage is damaged: it fails locally, rank 0 has nothing to complain about
+        d = torch.from_numpy(cov).to(cv.device)
+        res = {}
+        try:
+            for undo in (0, 2):
+                seg_len, nseg, _ = cv.cbs_sharded(owner, d, off, 0.01, 500, undo=undo, undo_sd=3.0)
+                res["cbs%d" % undo] = [seg_len.cpu().numpy()[int(off[c]):int(off[c]) + int(nseg[c])].tolist() for c in range(len(PART_LENS))]
+            for germ in (False, True):
+                res["wv%d" % int(germ)] = [b.tolist() for b in cv.wavelets_sharded(owner, d, off, is_germline=germ, window=500)]
+            res["error"] = None
+        except CanvasError as e:
+            res["error"] = str(e)
+        q.put((rank, owner.tolist(), res))
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def _run_partition(fail):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_partition_worker, args=(r, world, port, q, fail)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    for g in got:
+        assert g[1] != "error", g[2]
+    return got
+
+
+def test_sharded_cbs_and_wavelets_equal_the_single_rank_result_and_the_oracle():
+    import torch
+    import oracle_lib as O
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    got = _run_partition(False)
+    from canvas_amd import Canvas
+    cv = Canvas(0)
+    cov, off = _partition_coverage()
+    d = torch.from_numpy(cov).to(cv.device)
+    nchr = len(PART_LENS)
+    assert sorted(set(got[0][1])) == [0, 1]
+    for undo in (0, 2):
+        seg_len, nseg, _ = cv.cbs(d, off, 0.01, 500, undo=undo, undo_sd=3.0)
+        single = [seg_len.cpu().numpy()[int(off[c]):int(off[c]) + int(nseg[c])].tolist() for c in range(nchr)]
+        orc = O.cbs_genome([cov[int(off[c]):int(off[c + 1])] for c in range(nchr)], 0.01, 500, threads=4, undo=undo)
+        assert [list(map(int, s)) for s in orc[0]] == single
+        for rank, _, res in got:
+            assert res["error"] is None, res["error"]
+            assert res["cbs%d" % undo] == single, (rank, undo)
+        assert sum(len(s) for s in single) > nchr                # the planted changes are found
+    for germ in (False, True):
+        single = [b.tolist() for b in cv.wavelets(d, off, is_germline=germ, window=500)]
+        orc = O.wavelets_genome([cov[int(off[c]):int(off[c + 1])] for c in range(nchr)], is_germline=germ, window=500)
+        assert [list(map(int, b)) for b in orc] == single
+        for rank, _, res in got:
+            assert res["wv%d" % int(germ)] == single, (rank, germ)
+        assert single[-1] == []                                   # below MinSize: not segmented
+
+
+def test_sharded_partition_failure_is_collective():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    got = _run_partition(True)                                   # rank 1 holds a NaN: it fails locally, rank 0 must not hang and must fail too
+    for rank, _, res in got:
+        assert res["error"] is not None, rank
+    assert "rank 1 failed" in got[0][2]["error"] or "finite" in got[0][2]["error"]
