@@ -369,3 +369,22 @@ def test_sharded_partition_failure_is_collective():
     for rank, _, res in got:
         assert res["error"] is not None, rank
     assert "rank 1 failed" in got[0][2]["error"] or "finite" in got[0][2]["error"]
+
+
+def test_the_rccl_worker_with_a_one_rank_communicator():
+    """the code of test_rccl_all_gather_between_real_ranks (pipeline + sharded CBS + sharded Wavelets over ncclAllGather) on the one GPU every test box has"""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    try:
+        g = q.get(timeout=600)
+    finally:
+        p.join(60)
+        if p.is_alive(): p.kill()
+    assert g[1] != "error", g[2]
+    assert len(g) == 7 and sum(len(s) for s in g[5]) >= len(LENGTHS) and len(g[6]) == len(LENGTHS)
