@@ -321,5 +321,49 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
                               "boundary_allgather_bytes_per_rank": int(st[5]), "identical_on_all_ranks": same_on_all_ranks, "equals_single_gpu_result": equals_single,
                               "note": "CanvasClean runs redundantly on every rank (its order statistics are genome-wide): the pass cannot drop below Clean + the collectives"},
                   "cohort_mode": cohort}
+    # ---- CanvasPartition -m CBS / -m Wavelets sharded the same way, on the coverage the pipeline left on every rank (untimed for `value`; one warm call, one timed call each).
+    # A hang here must not cost the launch its line: after 300 s rank 0 prints the line without this leg and every rank leaves.
+    result = result if rank == 0 else None
+    leg_done = threading.Event()
+
+    def leg_watchdog():
+        if not leg_done.wait(float(os.environ.get("CANVAS_SHARDED_PARTITION_TIMEOUT", "300"))):
+            if rank == 0:
+                result["partition_sharded"] = {"error": "did not finish within the watchdog's limit"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+    threading.Thread(target=leg_watchdog, daemon=True).start()
+    part = {}
+    try:
+        n = int(r["n_out"]); off = r["off"]
+        for name, call, single_call in (("cbs", lambda: cv.cbs_sharded(owner, cov, off, 0.01, 10000), lambda: cv.cbs(cov, off, 0.01, 10000)),
+                                        ("wavelets", lambda: cv.wavelets_sharded(owner, cov, off), lambda: cv.wavelets(cov, off))):
+            call(); barrier()
+            t0 = time.perf_counter(); got = call(); barrier()
+            sec = max_over_ranks(time.perf_counter() - t0, device)
+            if name == "cbs":
+                flat = got[0][:n].to(torch.int64); dig = torch.stack([flat.sum(), (flat * (torch.arange(n, device=device) % 1009)).sum(), torch.tensor(int(got[1].sum()), device=device)])
+            else:
+                allbp = np.concatenate([np.asarray(b, np.int64) for b in got] + [np.zeros(1, np.int64)])
+                dig = torch.tensor([int(allbp.sum()), int((allbp * (np.arange(len(allbp)) % 1009)).sum()), len(allbp)], device=device)
+            digs = [torch.zeros_like(dig) for _ in range(world)]
+            dist.all_gather(digs, dig)
+            same = bool(all((d == digs[0]).all() for d in digs))
+            eq = None; sec1 = None
+            if rank == 0:
+                single_call(); t1 = time.perf_counter(); one = single_call(); sec1 = time.perf_counter() - t1
+                if name == "cbs":
+                    eq = bool((one[0][:n] == got[0][:n]).all() and (one[1] == got[1]).all())
+                else:
+                    eq = bool(len(one) == len(got) and all(np.array_equal(a, b) for a, b in zip(one, got)))
+            part[name] = {"seconds": round(sec, 4), "single_gpu_seconds_rank0": None if sec1 is None else round(sec1, 4), "identical_on_all_ranks": same, "equals_single_gpu_result": eq}
+            barrier()
+    except Exception as e:                                        # noqa: BLE001
+        part["error"] = "%s: %s" % (type(e).__name__, e)
+    leg_done.set()
+    if rank == 0:
+        part["note"] = "canvas_cbs_sharded / canvas_wavelets_sharded: every rank segments its own chromosomes (the reference's per-chromosome tasks), one list exchange; genome-wide inputs (seeds in file order, coverage variability) from the whole coverage on every rank"
+        result["partition_sharded"] = part
         print(json.dumps(result), flush=True)
     dist.destroy_process_group()
