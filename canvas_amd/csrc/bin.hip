@@ -820,7 +820,7 @@ static BinPlan make_plan(int nchr, const uint8_t* const* bases, const uint64_t* 
 
 int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
                               int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed);
 
 extern "C" {
 
@@ -1350,8 +1350,9 @@ int32_t canvas_upload_packed2_begin(canvas_ctx* ctx, int32_t nchr, const int64_t
 
 int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
                               int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total) {
-    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, nullptr, 0, -1, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total, hook, user);
+                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed) {
+    // h_pos0_packed given: d_bases / d_hits are the packed reference / hit planes of these chromosomes (canvas_bin_sample_packed)
+    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, nullptr, 0, -1, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total, hook, user, h_pos0_packed);
 }
 
 // ---------------------------------------------------------------------------------------------- predefined bins (CanvasBin -n)

@@ -147,7 +147,7 @@ CVX_INTERNAL int32_t cvx_hmm_per_sample_preq(canvas_ctx* ctx, int32_t nchr, cons
 typedef int32_t (*cvx_bin_size_hook)(void* user, int nchr, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut);
 CVX_INTERNAL int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
                                            int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                                           int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+                                           int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed = nullptr);
 // canvas_hmm_per_sample on a subset of chromosomes (d_cov / h_chr_offset: the subset, contiguous) with the genome-wide quartiles taken from d_cov_all[0, n_all)
 // CanvasPartition -m CBS / -m Wavelets for the chromosomes h_mask selects (NULL: all); genome-wide inputs (seeds in file order, trimmed SD, coverage variability) always use the whole coverage
 CVX_INTERNAL int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm, int32_t undo, double undo_sd,

@@ -144,12 +144,13 @@ int32_t shard_bin_size_hook(void* user, int nl, const long long* obs, const long
 }
 }  // namespace
 
-extern "C" int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
-                                                  const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y,
-                                                  int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
-                                                  int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                                                  double* d_cov, int32_t* d_state, int32_t* d_segment_id,
-                                                  int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+// h_pos0 != NULL: d_bases / d_hits are the packed reference / hit planes of the owned chromosomes (canvas_bin_sample_packed), d_mask is not read
+static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                                     const uint8_t* const* d_hits, const int64_t* h_pos0, const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y,
+                                     int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                     int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                     double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                     int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !h_chr_owner || !d_bases || !d_mask || !d_hits || !h_len || !h_chr_is_autosome || !d_chr || !d_start || !d_stop || !d_gc || !d_count || !d_cov || !d_state ||
         !d_segment_id || !h_chr_offset || (bin_size_in <= 0 && counts_per_bin <= 0))
@@ -210,11 +211,13 @@ extern "C" int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr,
     int32_t binSize = 0; int64_t nbMine = 0;
     int32_t rc;
     if (nl > 0) {
-        std::vector<const uint8_t*> lb(nl), lh(nl); std::vector<const uint64_t*> lm(nl); std::vector<int64_t> ll(nl), perChr(nl);
+        std::vector<const uint8_t*> lb(nl), lh(nl); std::vector<const uint64_t*> lm(nl); std::vector<int64_t> ll(nl), perChr(nl), lp0(nl, 0);
         bool haveArrays = true;
-        for (int i = 0; i < nl; i++) { lb[i] = d_bases[mine[i]]; lm[i] = d_mask[mine[i]]; lh[i] = d_hits[mine[i]]; ll[i] = h_len[mine[i]]; if (!lb[i] || !lm[i] || !lh[i]) haveArrays = false; }
+        for (int i = 0; i < nl; i++) { lb[i] = d_bases[mine[i]]; lm[i] = h_pos0 ? (const uint64_t*)d_bases[mine[i]] : d_mask[mine[i]]; lh[i] = d_hits[mine[i]]; ll[i] = h_len[mine[i]]; if (h_pos0) lp0[i] = h_pos0[mine[i]];
+                                       if (!lb[i] || !lm[i] || !lh[i]) haveArrays = false; }
         if (!haveArrays) { ctx->err = "canvas_sample_pipeline_sharded: an owned chromosome has no arrays"; fail_local(CANVAS_ERR_INVALID); }
-        else { rc = cvx_bin_sample_hooked(ctx, nl, lb.data(), lm.data(), lh.data(), ll.data(), mode, shard_bin_size_hook, &H, lChr, lStart, lStop, lGc, lCount, capLocal, perChr.data(), &nbMine); if (rc) fail_local(rc); }
+        else { rc = cvx_bin_sample_hooked(ctx, nl, lb.data(), lm.data(), lh.data(), ll.data(), mode, shard_bin_size_hook, &H, lChr, lStart, lStop, lGc, lCount, capLocal, perChr.data(), &nbMine, h_pos0 ? lp0.data() : nullptr);
+               if (rc) fail_local(rc); }
         if (localErr && !H.exchanged) { rc = shard_rates_exchange(H, 0, nullptr, nullptr, nullptr, localErr); if (rc) return rc; }      // failed before the hook ran: the exchange still takes place
     } else {                                                         // more ranks than chromosomes: this rank only takes part in the exchanges
         rc = shard_rates_exchange(H, 0, nullptr, nullptr, nullptr); if (rc) return rc;
@@ -343,6 +346,28 @@ extern "C" int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr,
     rc = canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
     if (h_nsegments) *h_nsegments = nseg;
     return CANVAS_OK;
+}
+
+extern "C" int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                                                  const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y,
+                                                  int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                                  int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                                  double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                                  int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+    return pipeline_sharded_impl(ctx, nchr, h_chr_owner, d_bases, d_mask, d_hits, nullptr, h_len, h_chr_is_autosome, h_chr_is_y, counts_per_bin, bin_size_in, mode, clean_flags, min_bins_per_gc,
+                                 max_inter_bin_dist, d_chr, d_start, d_stop, d_gc, d_count, cap, d_cov, d_state, d_segment_id, h_bin_size, h_nbins, h_nbins_clean, h_local_sd, h_chr_offset, h_nsegments);
+}
+// the same over the packed planes (0.75 B/base): d_ref / d_hit_planes / h_pos0 as for canvas_sample_pipeline_packed, entries of chromosomes this rank does not own are ignored
+extern "C" int32_t canvas_sample_pipeline_sharded_packed(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint64_t* const* d_ref, const uint64_t* const* d_hit_planes,
+                                                         const int64_t* h_len, const int64_t* h_pos0, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y,
+                                                         int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                                         int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                                         double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                                         int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+    if (ctx && !h_pos0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline_sharded_packed: pos0 missing");
+    return pipeline_sharded_impl(ctx, nchr, h_chr_owner, (const uint8_t* const*)d_ref, d_ref, (const uint8_t* const*)d_hit_planes, h_pos0, h_len, h_chr_is_autosome, h_chr_is_y, counts_per_bin, bin_size_in, mode,
+                                 clean_flags, min_bins_per_gc, max_inter_bin_dist, d_chr, d_start, d_stop, d_gc, d_count, cap, d_cov, d_state, d_segment_id, h_bin_size, h_nbins, h_nbins_clean, h_local_sd,
+                                 h_chr_offset, h_nsegments);
 }
 
 extern "C" int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6) {

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
     "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_wavelets_decisions", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
-    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_profile_enable", "canvas_profile_get",
+    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_profile_enable", "canvas_profile_get",
 ]
 
 
@@ -534,7 +534,7 @@ class Canvas:
         return res
 
     def sample_pipeline_sharded(self, owner, bases, masks, hits, lens, is_autosome, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=0, min_bins_per_gc=100,
-                                max_inter_bin_dist=1000000, is_y=None):
+                                max_inter_bin_dist=1000000, is_y=None, pos0=None):
         """canvas_sample_pipeline_sharded: `owner[c]` = rank that holds chromosome c; bases / masks / hits are lists over ALL chromosomes with None for the ones this rank
         does not own.  Every rank gets the whole result (same dict as sample_pipeline)."""
         nchr = len(owner)
@@ -542,6 +542,15 @@ class Canvas:
         ow = np.ascontiguousarray(owner, np.int32); hl = np.ascontiguousarray(lens, np.int64); ia = np.ascontiguousarray(is_autosome, np.uint8)
         iy = None if is_y is None else np.ascontiguousarray(is_y, np.uint8)
         bs = C.c_int32(0); total = C.c_int64(0); nclean = C.c_int64(0); lsd = C.c_double(-1.0); nseg = C.c_int64(0); off = np.zeros(nchr + 1, np.int64)
+        if pos0 is not None:       # packed planes: `bases` = reference planes, `hits` = hit planes (None for chromosomes of other ranks), `masks` ignored
+            p0 = np.ascontiguousarray(pos0, np.int64)
+            self._check(self.lib.canvas_sample_pipeline_sharded_packed(self.ctx, nchr, _np_ptr(ow), tab(bases), tab(hits), _np_ptr(hl), _np_ptr(p0), _np_ptr(ia), None if iy is None else _np_ptr(iy),
+                                                                       int(counts_per_bin), int(bin_size), int(mode), C.c_uint32(flags), int(min_bins_per_gc), int(max_inter_bin_dist),
+                                                                       C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),
+                                                                       C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()), C.c_int64(int(out["chr"].numel())),
+                                                                       C.c_void_p(cov.data_ptr()), C.c_void_p(state.data_ptr()), C.c_void_p(seg.data_ptr()),
+                                                                       C.byref(bs), C.byref(total), C.byref(nclean), C.byref(lsd), _np_ptr(off), C.byref(nseg)))
+            return dict(bin_size=bs.value, total=total.value, n_out=nclean.value, lsd=lsd.value, off=off, nseg=nseg.value)
         self._check(self.lib.canvas_sample_pipeline_sharded(self.ctx, nchr, _np_ptr(ow), tab(bases), tab(masks), tab(hits), _np_ptr(hl), _np_ptr(ia), None if iy is None else _np_ptr(iy),
                                                             int(counts_per_bin), int(bin_size), int(mode), C.c_uint32(flags), int(min_bins_per_gc), int(max_inter_bin_dist),
                                                             C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()), C.c_void_p(out["stop"].data_ptr()),

@@ -344,6 +344,14 @@ int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr, const int3
                                        int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                                        double* d_cov, int32_t* d_state, int32_t* d_segment_id,
                                        int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments);
+/* canvas_sample_pipeline_sharded over the packed planes of canvas_bin_sample_packed (0.75 B/base; d_ref / d_hit_planes / h_pos0 as for canvas_sample_pipeline_packed,
+ * entries of the chromosomes this rank does not own are ignored): same exchanges, same outputs, bit for bit. */
+int32_t canvas_sample_pipeline_sharded_packed(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint64_t* const* d_ref, const uint64_t* const* d_hit_planes,
+                                              const int64_t* h_len, const int64_t* h_pos0, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y,
+                                              int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
+                                              int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
+                                              double* d_cov, int32_t* d_state, int32_t* d_segment_id,
+                                              int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments);
 /* last canvas_sample_pipeline_sharded call: [0] ranks, [1] chromosomes owned, [2] bins binned locally, [3] bytes this rank contributed to the bins all-gather,
  * [4] boundary records of this rank, [5] bytes per rank of the boundary all-gather */
 int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6);

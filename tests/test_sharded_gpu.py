@@ -74,6 +74,18 @@ def _worker(rank, world, port, q):
             n = r["n_out"]
             res.append((dict(r, off=r["off"].tolist()), {k: v[:n].cpu().numpy() for k, v in out.items()}, cov[:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy(),
                         cv.sharded_stats().tolist()))
+        # the same two passes over the packed planes of the owned chromosomes (canvas_sample_pipeline_sharded_packed): results are appended, the test expects them to repeat
+        lens_mine = [LENGTHS[c] for c in mine]
+        ref_m, planes_m, pos0_m, _ = cv.pack_genome_device([bases[c] for c in mine], [masks[c] for c in mine], [hits[c] for c in mine], lens_mine)
+        ref, planes, pos0 = [None] * len(LENGTHS), [None] * len(LENGTHS), np.zeros(len(LENGTHS), np.int64)
+        for i, c in enumerate(mine):
+            ref[c], planes[c], pos0[c] = ref_m[i], planes_m[i], pos0_m[i]
+        for bin_size in (-1, 250):
+            r = cv.sample_pipeline_sharded(owner, ref, None, planes, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=bin_size, mode=3, flags=FLAGS, pos0=pos0)
+            cv.synchronize()
+            n = r["n_out"]
+            res.append((dict(r, off=r["off"].tolist()), {k: v[:n].cpu().numpy() for k, v in out.items()}, cov[:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy(),
+                        cv.sharded_stats().tolist()))
         q.put((rank, owner.tolist(), res))
         dist.destroy_process_group()
     except Exception as e:                                      # noqa: BLE001
@@ -110,7 +122,7 @@ def test_two_ranks_on_one_gpu_equal_the_single_rank_result():
             cv.synchronize(); n = r["n_out"]
             ref = (r, {kk: v[:n].cpu().numpy() for kk, v in out.items()}, cov[:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy())
         r1 = ref[0]
-        for rank, _, res in got:
+        for rank, _, res in [(g[0], g[1], g[2]) for g in got] + [(g[0], g[1], g[2][2:]) for g in got]:      # byte arrays, then the packed planes
             r, o, cv_, st, sg, stats = res[k]
             assert (r["bin_size"], r["total"], r["n_out"], r["nseg"], r["lsd"]) == (r1["bin_size"], r1["total"], r1["n_out"], r1["nseg"], r1["lsd"]), (rank, bin_size)
             assert r["off"] == r1["off"].tolist()
