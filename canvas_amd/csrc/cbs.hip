@@ -228,6 +228,7 @@ struct PermReq {
     uint32_t state[625];       // generator state at the start of the batch: mt[624], mti
     long long total; int n; int nb; uint32_t* snaps; const double* x; int hk, al0; double tss, errBound; PermBuf P; double* pstat; int blockBase;
     int cont;                  // the MT_HISTORY outputs in front of P.draws are the tail of the previous batch: no sequential part needed
+    int fy;                    // 1: k_perm_fy evaluates this request's permutations, 0: k_perm_stat
 };
 // MT19937 is linear over GF(2): every bit of its output stream obeys the recurrence of the characteristic polynomial phi (degree 19937,
 // 135 terms), i.e. out[k] = XOR_i out[k - MT_LAG[i]]; and because phi(x)^(2^m) = phi(x^(2^m)) over GF(2) the same holds with every
@@ -365,13 +366,93 @@ __device__ __forceinline__ int block_excl_scan_i32(int v, int* sh /*PG_T/64 + 1*
     __syncthreads();
     return base + inc - v;
 }
+// the statistic of one permuted sequence px[0, n) (shared by the two permutation kernels): prefix sums, arcs of length al0..hk and their complements, the interval
+// Prefix sums and arcs go tile by tile through LDS (PT_TILE prefix values + a halo of the previous tile's last PT_HALO): the arcs of position a need sx[a + 2 .. a + hk], i.e.
+// they are evaluated PT_HALO positions behind the prefix front, 24 LDS reads per position instead of 48 loads through the vector cache; the prefix array never goes to
+// global memory — the complements (a < j) only need its first and last PT_HALO values, kept aside.
+#define PT_TILE 2048
+#define PT_HALO 32
+#define PT_PER (PT_TILE / PG_T)
+__device__ __forceinline__ void perm_stat_tail(const double* __restrict__ px, double* __restrict__ /*sx: not used any more*/, int n, int hk, int al0, double tss, double errBound, double* __restrict__ pstat, int b,
+                                               double* shD /* [PG_T / 64 + 1] */, double (*shM)[PG_T / 64] /* [PG_MAXK + 1] */, double* sT /* [PT_TILE + PT_HALO] */, double* sEdge /* [2 * PT_HALO] */) {
+    const int tid = threadIdx.x, w = tid >> 6;
+    double m[PG_MAXK + 1];
+#pragma unroll
+    for (int j = 0; j <= PG_MAXK; j++) m[j] = 0.0;
+    double dcarry = 0.0;
+    for (int base = 0; base < n; base += PT_TILE) {
+        // prefix sums of the tile (re-associated: PT_PER consecutive values per thread, wave scan of the thread totals, wave totals through LDS)
+        double v[PT_PER]; double run = 0.0;
+#pragma unroll
+        for (int r = 0; r < PT_PER; r++) { const int i = base + tid * PT_PER + r; run += i < n ? px[i] : 0.0; v[r] = run; }
+        double inc = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const double oo = __hiloint2double(__shfl_up(__double2hiint(inc), d), __shfl_up(__double2loint(inc), d)); if ((tid & 63) >= d) inc += oo; }
+        if ((tid & 63) == 63) shD[w] = inc;
+        __syncthreads();
+        double wb = 0.0, tot = 0.0;
+        for (int k = 0; k < PG_T / 64; k++) { const double t = shD[k]; if (k < w) wb += t; tot += t; }
+        const double before = dcarry + wb + (inc - run);
+#pragma unroll
+        for (int r = 0; r < PT_PER; r++) sT[PT_HALO + tid * PT_PER + r] = before + v[r];
+        dcarry += tot;
+        __syncthreads();
+        const int cnt = n - base < PT_TILE ? n - base : PT_TILE;          // prefix values of this tile: sT[PT_HALO, PT_HALO + cnt)
+        if (base == 0 && tid < PT_HALO) sEdge[tid] = sT[PT_HALO + tid];   // sx[0 .. PT_HALO)  (n >= 2 PT_HALO: the device path starts at 1024 bins)
+        if (base + PT_TILE >= n && tid < PT_HALO) sEdge[PT_HALO + tid] = sT[cnt + tid];      // sx[n - PT_HALO .. n)
+        // arcs that start PT_HALO positions behind the front: LDS index u <-> position a = base - PT_HALO + u; the last tile also takes its own last PT_HALO positions
+        const int uEnd = base + PT_TILE >= n ? cnt + PT_HALO : PT_TILE;
+        for (int u = tid; u < uEnd; u += PG_T) {
+            const int a = base - PT_HALO + u;
+            if (a < 0) continue;
+            const double s0 = sT[u];
+#pragma unroll
+            for (int j = 2; j <= PG_MAXK; j++)
+                if (j >= al0 && j <= hk && a + j < n) { const double d = fabs(sT[u + j] - s0); m[j] = d > m[j] ? d : m[j]; }
+        }
+        __syncthreads();
+        if (tid < PT_HALO) sT[tid] = sT[PT_TILE + tid];                   // the halo of the next tile
+        __syncthreads();
+    }
+    // complements |sx[a + n - j] - sx[a]| for a < j <= hk <= PG_MAXK < PT_HALO
+    if (tid < PT_HALO) {
+        const int a = tid;
+#pragma unroll
+        for (int j = 2; j <= PG_MAXK; j++)
+            if (j >= al0 && j <= hk && a < j) { const double d = fabs(sEdge[PT_HALO + (a + PT_HALO - j)] - sEdge[a]); m[j] = d > m[j] ? d : m[j]; }      // sx[a + n - j] = sEdge[PT_HALO + (a + n - j) - (n - PT_HALO)]
+    }
+#pragma unroll
+    for (int j = 2; j <= PG_MAXK; j++) {
+        double vv = m[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double oo = __hiloint2double(__shfl_xor(__double2hiint(vv), d), __shfl_xor(__double2loint(vv), d)); vv = oo > vv ? oo : vv; }
+        if ((tid & 63) == 0) shM[j][tid >> 6] = vv;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double rn = (double)n;
+        double hLo = 0.0, hHi = 0.0;
+        for (int j = al0; j <= hk && j <= PG_MAXK; j++) {
+            double vv = 0.0; for (int k = 0; k < PG_T / 64; k++) vv = shM[j][k] > vv ? shM[j][k] : vv;
+            const double rj = (double)j, c = rn / (rj * (rn - rj));
+            const double lo = vv - errBound > 0.0 ? vv - errBound : 0.0, hi = vv + errBound;
+            const double a = c * (lo * lo) * (1.0 - 1e-15), bb = c * (hi * hi) * (1.0 + 1e-15);
+            hLo = a > hLo ? a : hLo; hHi = bb > hHi ? bb : hHi;
+        }
+        auto norm = [&](double h) { double t = tss; if (t <= h + 0.0001) t = h + 1.0; return h / ((t - h) / (rn - 2.0)); };   // CBSTStatistic.cs:334-337
+        if ((tss <= hLo + 0.0001) != (tss <= hHi + 0.0001)) { pstat[2 * b] = -INFINITY; pstat[2 * b + 1] = INFINITY; }          // the clamp is not monotone across its switch: let the host decide
+        else { pstat[2 * b] = norm(hLo) * (1.0 - 1e-15); pstat[2 * b + 1] = norm(hHi) * (1.0 + 1e-15); }
+    }
+}
 __global__ void __launch_bounds__(PG_T) k_perm_stat(const PermReq* __restrict__ reqs, int nreq) {
     __shared__ int shI[PG_T / 64 + 1];
     __shared__ double shD[PG_T / 64 + 1];
     __shared__ double shM[PG_MAXK + 1][PG_T / 64];
+    __shared__ double sT[PT_TILE + PT_HALO], sEdge[2 * PT_HALO];
     int ri = 0;
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
     const PermReq& R = reqs[ri];
+    if (R.fy) return;
     const double* __restrict__ x = R.x; const int n = R.n, hk = R.hk, al0 = R.al0; const double tss = R.tss, errBound = R.errBound; const PermBuf P = R.P; double* __restrict__ pstat = R.pstat;
     const int b = (int)blockIdx.x - R.blockBase, tid = threadIdx.x;
     const size_t o = (size_t)b * n, o1 = (size_t)b * (n + 1);
@@ -415,58 +496,163 @@ __global__ void __launch_bounds__(PG_T) k_perm_stat(const PermReq* __restrict__ 
     // the permuted data
     for (int i = tid; i < n; i += PG_T) { const int s = succ[i]; px[i] = s == 0x7fffffff ? x[jj[i]] : x[ga[s]]; }
     __syncthreads();
-    // prefix sums (re-associated)
-    double dcarry = 0.0;
-    for (int base = 0; base < n; base += PG_T) {
-        const int i = base + tid; const double v = i < n ? px[i] : 0.0;
-        double inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const double oo = __hiloint2double(__shfl_up(__double2hiint(inc), d), __shfl_up(__double2loint(inc), d)); if ((tid & 63) >= d) inc += oo; }
-        const int w = tid >> 6;
-        if ((tid & 63) == 63) shD[w] = inc;
+    perm_stat_tail(px, sx, n, hk, al0, tss, errBound, pstat, b, shD, shM, sT, sEdge);
+}
+
+// ---- the same statistic with Fisher-Yates SIMULATED instead of resolved (k_perm_stat's counting sort + pointer doubling costs ~15 scattered 4-byte accesses per element into
+// GBs of per-batch workspace: 64-byte HBM sectors moved for 4 bytes; this one costs one scattered read and one scattered write).  The swaps a[i] <-> a[t_i], i = n-1 .. 0,
+// t_i <= i, are executed on an index array a (a[p] = p at the start) in BLOCKS of consecutive steps [I0, I1): the block's own positions sit in LDS; two steps of a block commute
+// unless they share a position, and with targets uniform in [0, i] that is rare when the block is short against i (expected 1.5 Bk^2 / i of Bk steps; Bk = 8 sqrt(I1), <= 4096,
+// keeps it near a hundred).  Steps that share nothing (the target lies below the block, no other step of the block has the same target — detected with two hashed bitmaps, false
+// positives only move a step to the other class — and no step of the block targets the step's own position) run in parallel, one global read and one global write each.  The
+// others are compacted in step order, the values under their targets are gathered into LDS (one slot per distinct position, found through a small hash map), ONE thread replays
+// them in the reference's order on LDS, and the slots go back.  When a block has more than PF_CMAX such steps the permutation is given up: its statistic comes back as
+// [-inf, inf] and the host evaluates it in the reference's order, like any other undecided one.
+#define PF_BK 4096
+#define PF_SPT (PF_BK / PG_T)
+#define PF_HS (1 << 18)
+#define PF_CMAX 1024
+#define PF_MAP 4096
+__global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ reqs, int nreq) {
+    __shared__ uint32_t sM1[PF_HS / 32], sM2[PF_HS / 32];
+    __shared__ int32_t sA[PF_BK];
+    __shared__ uint32_t sHit[PF_BK / 32];
+    __shared__ int32_t sCI[PF_CMAX], sCT[PF_CMAX], sCV[PF_CMAX], sCanon[PF_CMAX];
+    __shared__ uint32_t sMapKey[PF_MAP];
+    __shared__ int32_t sMapVal[PF_MAP];
+    __shared__ int shI[PG_T / 64 + 1];
+    __shared__ double shD[PG_T / 64 + 1];
+    __shared__ double shM[PG_MAXK + 1][PG_T / 64];
+    __shared__ int sOver;
+    __shared__ double sT[PT_TILE + PT_HALO], sEdge[2 * PT_HALO];
+    __shared__ int16_t sDep1[PF_CMAX], sDep2[PF_CMAX];
+    __shared__ uint8_t sDone[PF_CMAX];
+    int ri = 0;
+    { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
+    const PermReq& R = reqs[ri];
+    if (!R.fy) return;
+    const double* __restrict__ x = R.x; const int n = R.n; const PermBuf P = R.P;
+    const int b = (int)blockIdx.x - R.blockBase, tid = threadIdx.x;
+    const size_t o = (size_t)b * n;
+    const uint32_t* __restrict__ draws = P.draws + o;
+    int32_t* __restrict__ a = P.j + o; double* __restrict__ px = P.px + o; double* __restrict__ sx = P.sx + o;
+    for (int p = tid; p < n; p += PG_T) a[p] = p;
+    if (tid == 0) sOver = 0;
+    __syncthreads();
+    int I1 = n;
+    while (I1 > 0) {
+        int Bk = (int)(8.0 * sqrt((double)I1)); Bk = Bk < 64 ? 64 : (Bk > PF_BK ? PF_BK : Bk);
+        const int I0 = I1 - Bk > 0 ? I1 - Bk : 0; Bk = I1 - I0;
+        // ---- the block's own positions, clean detection tables
+        for (int p = tid; p < Bk; p += PG_T) sA[p] = a[I0 + p];
+        { uint4* z1 = reinterpret_cast<uint4*>(sM1); uint4* z2 = reinterpret_cast<uint4*>(sM2); const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+          for (int w = tid; w < PF_HS / 128; w += PG_T) { z1[w] = z; z2[w] = z; } }
+        for (int w = tid; w < PF_BK / 32; w += PG_T) sHit[w] = 0u;
+        for (int w = tid; w < PF_MAP; w += PG_T) { sMapKey[w] = 0xFFFFFFFFu; sMapVal[w] = 0x7FFFFFFF; }
         __syncthreads();
-        double wb = 0.0, tot = 0.0;
-        for (int k = 0; k < PG_T / 64; k++) { const double t = shD[k]; if (k < w) wb += t; tot += t; }
-        if (i < n) sx[i] = dcarry + wb + inc;
-        dcarry += tot;
-        __syncthreads();
-    }
-    // arcs of length al0..hk: |sx[a+j] - sx[a]|, and their complements |sx[a+n-j] - sx[a]| for a < j
-    double m[PG_MAXK + 1];
+        // ---- targets (ChangePoint.cs:411-419: the draw of step i is draws[n - 1 - i]); thread tid owns the steps I1 - 1 - (tid * PF_SPT + q): ascending (tid, q) = the reference's order
+        int t[PF_SPT];
 #pragma unroll
-    for (int j = 0; j <= PG_MAXK; j++) m[j] = 0.0;
-    for (int a = tid; a < n; a += PG_T) {
-        const double s0 = sx[a];
-#pragma unroll
-        for (int j = 2; j <= PG_MAXK; j++) {
-            if (j >= al0 && j <= hk) {
-                if (a + j < n) { const double d = fabs(sx[a + j] - s0); m[j] = d > m[j] ? d : m[j]; }
-                if (a < j) { const double d = fabs(sx[a + n - j] - s0); m[j] = d > m[j] ? d : m[j]; }
+        for (int q = 0; q < PF_SPT; q++) {
+            const int k = tid * PF_SPT + q;
+            t[q] = -1;
+            if (k < Bk) {
+                const int i = I1 - 1 - k;
+                const double cc = (double)draws[n - 1 - i] * (1.0 / 4294967296.0);
+                int tt = (int)(cc * (double)(i + 1)); tt = tt > i ? i : tt;
+                if (tt != i) {                                  // (a step that targets itself changes nothing)
+                    t[q] = tt;
+                    if (tt >= I0) atomicOr(&sHit[(tt - I0) >> 5], 1u << ((tt - I0) & 31));
+                    else { const uint32_t h = (uint32_t)tt & (PF_HS - 1), bit = 1u << (h & 31); const uint32_t old = atomicOr(&sM1[h >> 5], bit); if (old & bit) atomicOr(&sM2[h >> 5], bit); }
+                }
             }
         }
-    }
+        __syncthreads();
+        // ---- steps that share a position with another step of the block: compacted in step order; the others are executed here
+        unsigned cm = 0; int cnt = 0;
 #pragma unroll
-    for (int j = 2; j <= PG_MAXK; j++) {
-        double v = m[j];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const double oo = __hiloint2double(__shfl_xor(__double2hiint(v), d), __shfl_xor(__double2loint(v), d)); v = oo > v ? oo : v; }
-        if ((tid & 63) == 0) shM[j][tid >> 6] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const double rn = (double)n;
-        double hLo = 0.0, hHi = 0.0;
-        for (int j = al0; j <= hk && j <= PG_MAXK; j++) {
-            double v = 0.0; for (int k = 0; k < PG_T / 64; k++) v = shM[j][k] > v ? shM[j][k] : v;
-            const double rj = (double)j, c = rn / (rj * (rn - rj));
-            const double lo = v - errBound > 0.0 ? v - errBound : 0.0, hi = v + errBound;
-            const double a = c * (lo * lo) * (1.0 - 1e-15), bb = c * (hi * hi) * (1.0 + 1e-15);
-            hLo = a > hLo ? a : hLo; hHi = bb > hHi ? bb : hHi;
+        for (int q = 0; q < PF_SPT; q++) {
+            if (t[q] < 0) continue;
+            const int i = I1 - 1 - (tid * PF_SPT + q), tt = t[q];
+            bool c = tt >= I0 || ((sHit[(i - I0) >> 5] >> ((i - I0) & 31)) & 1u);
+            if (!c) { const uint32_t h = (uint32_t)tt & (PF_HS - 1); c = (sM2[h >> 5] >> (h & 31)) & 1u; }
+            if (c) { cm |= 1u << q; cnt++; }
         }
-        auto norm = [&](double h) { double t = tss; if (t <= h + 0.0001) t = h + 1.0; return h / ((t - h) / (rn - 2.0)); };   // CBSTStatistic.cs:334-337
-        if ((tss <= hLo + 0.0001) != (tss <= hHi + 0.0001)) { pstat[2 * b] = -INFINITY; pstat[2 * b + 1] = INFINITY; }          // the clamp is not monotone across its switch: let the host decide
-        else { pstat[2 * b] = norm(hLo) * (1.0 - 1e-15); pstat[2 * b + 1] = norm(hHi) * (1.0 + 1e-15); }
+        int nC;
+        int base = block_excl_scan_i32(cnt, shI, nC);
+        if (nC > PF_CMAX) { if (tid == 0) sOver = 1; __syncthreads(); break; }
+#pragma unroll
+        for (int q = 0; q < PF_SPT; q++) {
+            if (t[q] < 0) continue;
+            const int i = I1 - 1 - (tid * PF_SPT + q), tt = t[q];
+            if ((cm >> q) & 1u) { sCI[base] = i; sCT[base] = tt; base++; }
+            else { const int vt = a[tt]; a[tt] = sA[i - I0]; sA[i - I0] = vt; }
+        }
+        __syncthreads();
+        // ---- one LDS slot per distinct target below the block: the first step (list order) that names it owns the slot
+        for (int k = tid; k < nC; k += PG_T) {
+            const int tt = sCT[k];
+            if (tt < I0) {
+                uint32_t slot = ((uint32_t)tt * 2654435761u) >> 20;
+                for (;;) {
+                    const uint32_t prev = atomicCAS(&sMapKey[slot], 0xFFFFFFFFu, (uint32_t)tt);
+                    if (prev == 0xFFFFFFFFu || prev == (uint32_t)tt) { atomicMin(&sMapVal[slot], k); sCanon[k] = (int32_t)slot; break; }
+                    slot = (slot + 1) & (PF_MAP - 1);
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < nC; k += PG_T) {
+            const int tt = sCT[k];
+            if (tt < I0) { const int kc = sMapVal[sCanon[k]]; sCanon[k] = kc; if (kc == k) sCV[k] = a[tt]; }
+        }
+        __syncthreads();
+        // ---- the replay, in the reference's order where the order matters: a step waits for the latest earlier step of the list that touches one of its two positions
+        // (found by looking back through the list: ~a hundred entries), steps that wait for nothing swap in the same round.  Most entries are pairs of steps with a common
+        // target: two or three rounds; the last blocks of a permutation (every target inside the block) degenerate into one step per round, on LDS.
+        for (int k = tid >> 6; k < nC; k += PG_T / 64) {     // one wave per step, 64 earlier entries per look
+            const int i = sCI[k], tt = sCT[k], lane = tid & 63;
+            int d1 = -1, d2 = -1;                      // latest earlier step that touches position i / position tt
+            for (int top = k - 1; top >= 0 && (d1 < 0 || d2 < 0); top -= 64) {
+                const int e = top - lane;
+                const int ie = e >= 0 ? sCI[e] : -1, te = e >= 0 ? sCT[e] : -2;
+                const unsigned long long h1 = __ballot(te == i), h2 = __ballot(te == tt || ie == tt);      // (ie == i is impossible: one step per position)
+                if (d1 < 0 && h1) d1 = top - (__ffsll((long long)h1) - 1);      // lane 0 holds the latest entry of the look
+                if (d2 < 0 && h2) d2 = top - (__ffsll((long long)h2) - 1);
+            }
+            if (lane == 0) { sDep1[k] = (int16_t)d1; sDep2[k] = (int16_t)d2; sDone[k] = 0; }
+        }
+        __syncthreads();
+        for (;;) {
+            int left = 0;
+            for (int k = tid; k < nC; k += PG_T) {
+                if (sDone[k]) continue;
+                const int d1 = sDep1[k], d2 = sDep2[k];
+                if ((d1 < 0 || sDone[d1] == 1) && (d2 < 0 || sDone[d2] == 1)) {
+                    const int i = sCI[k], tt = sCT[k];
+                    const int vi = sA[i - I0];
+                    int vt;
+                    if (tt >= I0) { vt = sA[tt - I0]; sA[tt - I0] = vi; }
+                    else { const int kc = sCanon[k]; vt = sCV[kc]; sCV[kc] = vi; }
+                    sA[i - I0] = vt;
+                    sDone[k] = 2;                      // done in this round: visible as 1 from the next round on
+                } else left = 1;
+            }
+            const int more = __syncthreads_or(left);
+            for (int k = tid; k < nC; k += PG_T) if (sDone[k] == 2) sDone[k] = 1;
+            __syncthreads();
+            if (!more) break;
+        }
+       
+        for (int k = tid; k < nC; k += PG_T) { const int tt = sCT[k]; if (tt < I0 && sCanon[k] == k) a[tt] = sCV[k]; }
+        // position i is final after step i: the permuted data of the block
+        for (int p = tid; p < Bk; p += PG_T) px[I0 + p] = x[sA[p]];
+        I1 = I0;
+        __syncthreads();
     }
+    if (sOver) { if (tid == 0) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; } return; }
+    __syncthreads();
+    perm_stat_tail(px, sx, n, R.hk, R.al0, R.tss, R.errBound, R.pstat, b, shD, shM, sT, sEdge);
 }
 
 // ================================================================================================ host: scalar pieces of the reference
@@ -865,6 +1051,7 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
 // ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
 #define PERM_GPU_MIN_N 1024          // shorter segments stay on the host: measured with 201 (every hybrid segment on the device) the WGS run is identical but 12 % slower (0.555 vs 0.496 s) — a permutation of a few hundred elements is microseconds of host work and a launch round trip on the device
 #define PERM_TARGET_ELEMS (64 << 20) // permuted elements per batch (44 B of workspace each)
+#define PERM_FY_MIN_N 16384          // segments from this length on take k_perm_fy (block-wise simulation of the swaps); shorter ones k_perm_stat (CANVAS_CBS_FY_MIN_N overrides: test hook)
 // (batches of up to 2048 permutations for loops that run long were tried: k_perm_stat then takes 26 ms instead of 3.5 ms for 256 — the same rate per permutation — so
 //  a larger batch only saves launcher round trips, 0.45 -> 0.44 s on the 4.7 M-bin sample, for 8.4 GB of workspace per engine)
 struct PermService;
@@ -1018,7 +1205,9 @@ struct PermService {
         else if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs);
         if (dbg) msB = lap();
         hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
-        hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
+        bool anyFy = false, anyOld = false; for (int i = 0; i < R; i++) (batch[i]->r.fy ? anyFy : anyOld) = true;
+        if (anyOld) hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
+        if (anyFy) hipLaunchKernelGGL(k_perm_fy, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         if (dbg) { const double msC = lap(); int nc = 0, maxN = 0; for (int i = 0; i < R; i++) { nc += batch[i]->r.cont; maxN = std::max(maxN, batch[i]->r.n); }
                    fprintf(stderr, "cbs batch: %d requests (%d continued), %d permutations, longest segment %d, %d stride steps: sequential %.2f ms, strided %.2f ms, statistics %.2f ms\n", R, nc, blocks, maxN, steps, msA, msB, msC); }
         for (int i = 0; i < R; i++) {
@@ -1104,6 +1293,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.r.cont = (np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
+        { static const int fyMin = getenv("CANVAS_CBS_FY_MIN_N") ? atoi(getenv("CANVAS_CBS_FY_MIN_N")) : PERM_FY_MIN_N; q.r.fy = n >= fyMin ? 1 : 0; }
         prevTotal = (long long)nb * n;
         rc = PG.svc->submit(q); if (rc) return rc;
         st.ns_submit += since(tS);
@@ -1256,7 +1446,7 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
 }
 // the engines' buffers outlive a call: a thread borrows an ArcGpu / PermGpu from the context's cache and hands it back (the buffers only grow)
 struct EngineCache {
-    std::mutex mu; std::vector<std::unique_ptr<ArcGpu>> arcs; std::vector<std::unique_ptr<PermGpu>> perms;
+    std::mutex mu; std::vector<std::unique_ptr<ArcGpu>> arcs; std::vector<std::unique_ptr<PermGpu>> perms, tails;      // tails: engines of the helper threads (tail series only: they never grow a permutation workspace and must not take one of those away from a chromosome thread)
     static EngineCache& of(canvas_ctx* ctx) {
         static std::mutex g; std::lock_guard<std::mutex> lk(g);
         if (!ctx->cbs_cache) ctx->cbs_cache = std::shared_ptr<void>(new EngineCache(), [](void* p) { delete (EngineCache*)p; });
@@ -1264,6 +1454,8 @@ struct EngineCache {
     }
     std::unique_ptr<ArcGpu> arc(canvas_ctx* ctx, PermService* svc) { std::unique_ptr<ArcGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!arcs.empty()) { g = std::move(arcs.back()); arcs.pop_back(); } } if (!g) { g.reset(new ArcGpu()); g->ctx = ctx; } g->svc = svc; return g; }
     std::unique_ptr<PermGpu> perm(canvas_ctx* ctx, PermService* svc) { std::unique_ptr<PermGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!perms.empty()) { g = std::move(perms.back()); perms.pop_back(); } } if (!g) { g.reset(new PermGpu()); g->ctx = ctx; } g->svc = svc; return g; }
+    std::unique_ptr<PermGpu> tail(canvas_ctx* ctx) { std::unique_ptr<PermGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!tails.empty()) { g = std::move(tails.back()); tails.pop_back(); } } if (!g) { g.reset(new PermGpu()); g->ctx = ctx; } g->svc = nullptr; return g; }
+    void give_tail(std::unique_ptr<PermGpu> g) { std::lock_guard<std::mutex> lk(mu); tails.push_back(std::move(g)); }
     void give(std::unique_ptr<ArcGpu> g) { std::lock_guard<std::mutex> lk(mu); arcs.push_back(std::move(g)); }
     void give(std::unique_ptr<PermGpu> g) { std::lock_guard<std::mutex> lk(mu); perms.push_back(std::move(g)); }
 };
@@ -1275,8 +1467,8 @@ struct SpecPool {
     void start(int n) {
         for (int i = 0; i < n; i++) workers.emplace_back([this]() {
             EngineCache& cache = EngineCache::of(ctx);
-            std::unique_ptr<ArcGpu> gp = cache.arc(ctx, arcSvcs[nextArc++ % 3]); std::unique_ptr<PermGpu> pgp = cache.perm(ctx, nullptr);
-            struct Back { EngineCache& c; std::unique_ptr<ArcGpu>& a; std::unique_ptr<PermGpu>& p; ~Back() { c.give(std::move(a)); c.give(std::move(p)); } } back{cache, gp, pgp};
+            std::unique_ptr<ArcGpu> gp = cache.arc(ctx, arcSvcs[nextArc++ % 3]); std::unique_ptr<PermGpu> pgp = cache.tail(ctx);
+            struct Back { EngineCache& c; std::unique_ptr<ArcGpu>& a; std::unique_ptr<PermGpu>& p; ~Back() { c.give(std::move(a)); c.give_tail(std::move(p)); } } back{cache, gp, pgp};
             ArcGpu& G = *gp; PermGpu& PG = *pgp;
             for (;;) {
                 std::shared_ptr<SpecTask> t;
