@@ -244,6 +244,13 @@ __constant__ int MT_LAG[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700, 1758
     5728, 5786, 5844, 6071, 6124, 6177, 6240, 6298, 6404, 6409, 6525, 6636, 6694, 6747, 6752, 6800, 6974, 6979, 7032, 7148, 7201, 7206, 7264, 7317, 7428, 7433, 7544, 7602, 7660, 7940, 7993,
     8056, 8099, 8220, 8225, 8326, 8452, 8553, 8563, 8616, 8722, 8780, 8790, 8848, 9017, 9176, 9244, 9809, 9968, 10036, 10432, 11731, 11958, 12185, 12354, 12412, 12460, 12808, 13368, 13600,
     14276, 15184, 15575, 15802, 16029, 16256, 16483, 16710, 16937, 17164, 17444, 18067, 18294, 18352, 18521, 18748, 19937};
+// the same table as compile-time constants: k_mt_classes unrolls its 134 terms completely, so every lag is an immediate operand (with the lags fetched by scalar loads the
+// wave waited on lgkmcnt — the counter the LDS reads share — at every group: 5.5 us per 623-value iteration instead of 1.5)
+static constexpr int MT_LAG_C[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700, 1758, 1869, 1985, 2096, 2154, 2212, 2439, 2492, 2608, 2666, 2777, 2893, 3004, 3062, 3115, 3120, 3342, 3347, 3400,
+    3516, 3569, 3574, 3685, 3796, 3801, 3912, 3970, 4028, 4255, 4308, 4361, 4424, 4482, 4588, 4593, 4709, 4820, 4878, 4931, 4936, 4984, 5158, 5163, 5216, 5332, 5385, 5390, 5501, 5612, 5617,
+    5728, 5786, 5844, 6071, 6124, 6177, 6240, 6298, 6404, 6409, 6525, 6636, 6694, 6747, 6752, 6800, 6974, 6979, 7032, 7148, 7201, 7206, 7264, 7317, 7428, 7433, 7544, 7602, 7660, 7940, 7993,
+    8056, 8099, 8220, 8225, 8326, 8452, 8553, 8563, 8616, 8722, 8780, 8790, 8848, 9017, 9176, 9244, 9809, 9968, 10036, 10432, 11731, 11958, 12185, 12354, 12412, 12460, 12808, 13368, 13600,
+    14276, 15184, 15575, 15802, 16029, 16256, 16483, 16710, 16937, 17164, 17444, 18067, 18294, 18352, 18521, 18748, 19937};
 // sequential part: the first min(total, MT_HISTORY) draws of every request
 __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs) {
     __shared__ uint32_t mtA[624], mtB[624];
@@ -305,9 +312,9 @@ __global__ void __launch_bounds__(256) k_mt_stride(const PermReq* __restrict__ r
 // L2 / Infinity Cache; the smallest lag is 623, so 623 values are computed per barrier.  (k_mt_stride, one launch per 623 * MT_STRIDE outputs with the history in
 // global memory, was 37 us per step — 1.2 TB/s of cache traffic for 0.3 MB of output — and 8 of the 14 ms of a 256-permutation batch of a 67 k-bin segment.)
 #define MTC_T 640
-#define MTC_RING 20608            // >= 19937 + 623: the slots written in an iteration are older than anything the iteration reads
+#define MTC_BUF 40000             // words of LDS: the 19937-value history + 32 iterations of 623 new values; then the last 19937 move to the front
 __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict__ reqs) {
-    __shared__ uint32_t ring[MTC_RING];
+    __shared__ uint32_t ring[MTC_BUF];
     const PermReq& R = reqs[blockIdx.y];
     const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
     uint32_t* __restrict__ d = R.P.draws;
@@ -319,18 +326,30 @@ __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict_
     for (int t = tid; t < 19937; t += MTC_T) ring[t] = hist[(long long)t * MT_STRIDE];
     __syncthreads();
     uint32_t* __restrict__ out = d + (start + r);
-    int head = 19937;                                                // ring slot of the next value
+    int head = 19937;                                                // slot of the next value; the buffer is linear, so every operand sits at a CONSTANT distance below the
+                                                                     // value's own slot: 134 ds_read_b32 with immediate offsets, no address arithmetic, issued back to back
+                                                                     // (with a ring and a wrap per operand the compiler waited for every single read: 4.5 us per iteration)
     for (long long u0 = 0; u0 < cnt; u0 += 623) {
+        if (head + 623 > MTC_BUF) {                                  // out of room: the last 19937 values become the history at the front (through registers: the ranges overlap)
+            uint32_t keep[(19937 + MTC_T - 1) / MTC_T];
+#pragma unroll
+            for (int k = 0; k < (19937 + MTC_T - 1) / MTC_T; k++) { const int t = tid + k * MTC_T; keep[k] = t < 19937 ? ring[head - 19937 + t] : 0u; }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < (19937 + MTC_T - 1) / MTC_T; k++) { const int t = tid + k * MTC_T; if (t < 19937) ring[t] = keep[k]; }
+            head = 19937;
+            __syncthreads();
+        }
         const long long m = cnt - u0 < 623 ? cnt - u0 : 623;
         if (tid < m) {
-            int p = head + tid; p = p >= MTC_RING ? p - MTC_RING : p;
+            const uint32_t* __restrict__ w = ring + (head + tid - 19937);
             uint32_t v = 0;
-#pragma unroll 8
-            for (int i = 0; i < MT_NLAG; i++) { int q = p - MT_LAG[i]; q = q < 0 ? q + MTC_RING : q; v ^= ring[q]; }
-            ring[p] = v;
+#pragma unroll
+            for (int i = 0; i < MT_NLAG; i++) v ^= w[19937 - MT_LAG_C[i]];
+            ring[head + tid] = v;
             out[(u0 + tid) * MT_STRIDE] = v;
         }
-        head += 623; head = head >= MTC_RING ? head - MTC_RING : head;
+        head += 623;
         __syncthreads();
     }
 }
@@ -380,11 +399,16 @@ __device__ __forceinline__ void perm_stat_tail(const double* __restrict__ px, do
 #pragma unroll
     for (int j = 0; j <= PG_MAXK; j++) m[j] = 0.0;
     double dcarry = 0.0;
+    double nx[PT_PER];                                          // the next tile's values are requested while this tile is worked on
+#pragma unroll
+    for (int r = 0; r < PT_PER; r++) { const int i = tid * PT_PER + r; nx[r] = i < n ? px[i] : 0.0; }
     for (int base = 0; base < n; base += PT_TILE) {
         // prefix sums of the tile (re-associated: PT_PER consecutive values per thread, wave scan of the thread totals, wave totals through LDS)
         double v[PT_PER]; double run = 0.0;
 #pragma unroll
-        for (int r = 0; r < PT_PER; r++) { const int i = base + tid * PT_PER + r; run += i < n ? px[i] : 0.0; v[r] = run; }
+        for (int r = 0; r < PT_PER; r++) { run += nx[r]; v[r] = run; }
+#pragma unroll
+        for (int r = 0; r < PT_PER; r++) { const int i = base + PT_TILE + tid * PT_PER + r; nx[r] = i < n ? px[i] : 0.0; }
         double inc = run;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const double oo = __hiloint2double(__shfl_up(__double2hiint(inc), d), __shfl_up(__double2loint(inc), d)); if ((tid & 63) >= d) inc += oo; }
@@ -551,11 +575,12 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
         for (int w = tid; w < PF_MAP; w += PG_T) { sMapKey[w] = 0xFFFFFFFFu; sMapVal[w] = 0x7FFFFFFF; }
         __syncthreads();
         // ---- targets (ChangePoint.cs:411-419: the draw of step i is draws[n - 1 - i]); thread tid owns the steps I1 - 1 - (tid * PF_SPT + q): ascending (tid, q) = the reference's order
-        int t[PF_SPT];
+        int t[PF_SPT], pre[PF_SPT];                            // pre: what lies under a target below the block (valid for the steps that turn out to share nothing: the
+                                                                //      previous block's writes are complete, and nobody else in this block touches that position)
 #pragma unroll
         for (int q = 0; q < PF_SPT; q++) {
             const int k = tid * PF_SPT + q;
-            t[q] = -1;
+            t[q] = -1; pre[q] = 0;
             if (k < Bk) {
                 const int i = I1 - 1 - k;
                 const double cc = (double)draws[n - 1 - i] * (1.0 / 4294967296.0);
@@ -563,7 +588,7 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
                 if (tt != i) {                                  // (a step that targets itself changes nothing)
                     t[q] = tt;
                     if (tt >= I0) atomicOr(&sHit[(tt - I0) >> 5], 1u << ((tt - I0) & 31));
-                    else { const uint32_t h = (uint32_t)tt & (PF_HS - 1), bit = 1u << (h & 31); const uint32_t old = atomicOr(&sM1[h >> 5], bit); if (old & bit) atomicOr(&sM2[h >> 5], bit); }
+                    else { pre[q] = a[tt]; const uint32_t h = (uint32_t)tt & (PF_HS - 1), bit = 1u << (h & 31); const uint32_t old = atomicOr(&sM1[h >> 5], bit); if (old & bit) atomicOr(&sM2[h >> 5], bit); }
                 }
             }
         }
@@ -586,7 +611,7 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
             if (t[q] < 0) continue;
             const int i = I1 - 1 - (tid * PF_SPT + q), tt = t[q];
             if ((cm >> q) & 1u) { sCI[base] = i; sCT[base] = tt; base++; }
-            else { const int vt = a[tt]; a[tt] = sA[i - I0]; sA[i - I0] = vt; }
+            else { a[tt] = sA[i - I0]; sA[i - I0] = pre[q]; }
         }
         __syncthreads();
         // ---- one LDS slot per distinct target below the block: the first step (list order) that names it owns the slot
