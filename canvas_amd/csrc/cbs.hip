@@ -1381,6 +1381,7 @@ struct Phase1 {
     std::vector<double> cur, sx; double tss = 0; bool hybrid = false; double delta = 0;
     int iseg[2] = {0, 0}; double ostat = 0, ostat1 = 0; bool stop = false;   // stop: sqrt(ostat) <= 0.1, no change point
     bool bigT = false, exitNoSplit = false; int nrejc = 0;
+    bool searched = false;                                  // TMaxO ran
 };
 static void phase1_run(ArcGpu& G, PermGpu& PG, const double* gd, int cn, uint32_t nPerm, double cutoff, Stats& st, Phase1& P) {
     const int minWidth = 2, kMax = 25; const uint32_t nMin = 200;
@@ -1409,7 +1410,7 @@ static void phase1_run(ArcGpu& G, PermGpu& PG, const double* gd, int cn, uint32_
         if (!ok) st.tie_replays++;
     }
     if (!done) { auto tH = std::chrono::steady_clock::now(); tmaxo_host(cur.data(), n, tss, P.sx.data(), P.iseg, P.ostat, al0); st.ns_tmaxo_host += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tH).count(); }
-    st.tmaxo_calls++; st.tmaxo_elems += n;
+    P.searched = true;                                      // (counted when the recursion consumes the result: a helper's guess that is never looked at is not a call of the reference)
     P.ostat1 = std::sqrt(P.ostat); P.ostat *= 0.99999;
     if (P.ostat1 <= 0.1) { P.stop = true; return; }
     const int l = std::min(P.iseg[1] - P.iseg[0], n - P.iseg[1] + P.iseg[0]);
@@ -1418,14 +1419,15 @@ static void phase1_run(ArcGpu& G, PermGpu& PG, const double* gd, int cn, uint32_
             auto tTP = std::chrono::steady_clock::now();
             P.rc = tail_p_decide(PG, P.ostat1, P.delta, n, cutoff, nPerm, st, P.exitNoSplit, P.nrejc); if (P.rc) return;      // TailP(ostat1, delta, n, 100, 1E-6): p1 > cutoff, (int)((cutoff - p1) nPerm)
             st.ns_tailp += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tTP).count();
-            if (P.exitNoSplit) st.tailp_exits++;
+
         } else P.nrejc = (int)(cutoff * nPerm);
-    } else { P.bigT = true; st.big_t++; }
+    } else P.bigT = true;
 }
 static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff, int& nCp, int iCp[2], const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st) {
     const int minWidth = 2, kMax = 25;
     nCp = 0;
     if (P.rc) return P.rc;
+    if (P.searched) { st.tmaxo_calls++; st.tmaxo_elems += P.cn; if (P.bigT) st.big_t++; if (P.hybrid && !P.bigT && P.exitNoSplit) st.tailp_exits++; }
     if (P.trivial || P.stop) return CANVAS_OK;
     const int n = P.cn, al0 = minWidth, hk = kMax; const double* gd = P.cur.data(); const double tss = P.tss, ostat = P.ostat; const bool hybrid = P.hybrid;
     const int* iseg = P.iseg;
@@ -1485,14 +1487,40 @@ struct EngineCache {
     void give(std::unique_ptr<PermGpu> g) { std::lock_guard<std::mutex> lk(mu); perms.push_back(std::move(g)); }
 };
 // helper threads of phase 1 (own arc-search and tail-series buffers each); a chromosome thread that needs a segment no helper has started yet runs it itself
-struct SpecTask { const double* gd; int cn; Phase1 out; std::atomic<int> state{0}; };      // 0 queued, 1 running, 2 done
+#define CBS_SPEC_MIN_N 4
+struct SpecTask { const double* gd; int cn; bool guess = false; Phase1 out; std::atomic<int> state{0}; };      // 0 queued, 1 running, 2 done; guess: put there by a helper, not (yet) asked for by the recursion
 struct SpecPool {
-    canvas_ctx* ctx; PermService** arcSvcs /* [3] */; uint32_t nPerm; double cutoff; Stats* st; std::atomic_int nextArc{0};
+    canvas_ctx* ctx; PermService** arcSvcs; int nArcSvc; uint32_t nPerm; double cutoff; Stats* st; std::atomic_int nextArc{0};
     std::mutex mu; std::condition_variable cvWork, cvDone; std::deque<std::shared_ptr<SpecTask>> queue; bool stopping = false; std::vector<std::thread> workers;
+    // every task of the call by (data pointer, length): a segment is looked up here before anything is computed for it.  Helpers put the segments a finished phase 1 makes
+    // LIKELY there as well — its two candidate change points are the arc maximiser's (iseg); if the tests of phase 2 keep both, the children are [0, i0), [i0, i1), [i1, n) —
+    // so that the first child's arc search and tail series run while the parent is still permuting, one level ahead of the recursion.  A guess that does not come true (an
+    // edge test drops a change point, the permutation test rejects) costs a helper some work and is never looked at.
+    std::map<std::pair<const double*, int>, std::shared_ptr<SpecTask>> reg;
+    std::atomic<long long> guessed{0}, guessedUsed{0};
+    std::shared_ptr<SpecTask> find_or_submit(const double* gd, int cn, bool guess) {
+        std::shared_ptr<SpecTask> t;
+        { std::lock_guard<std::mutex> lk(mu);
+          auto it = reg.find({gd, cn});
+          if (it != reg.end()) { if (!guess && it->second->guess) { it->second->guess = false; guessedUsed++; } return it->second; }
+          t = std::make_shared<SpecTask>(); t->gd = gd; t->cn = cn; t->guess = guess; reg[{gd, cn}] = t;
+          if (guess) { guessed++; queue.push_back(t); } else queue.push_front(t); }       // what the recursion asks for goes first
+        cvWork.notify_one();
+        return t;
+    }
+    void guess_children(const SpecTask& t) {
+        const Phase1& P = t.out;
+        if (P.rc || P.trivial || P.stop || (P.hybrid && !P.bigT && P.exitNoSplit)) return;
+        const int n = P.cn, i0 = P.iseg[0], i1 = P.iseg[1];
+        auto go = [&](int a, int b) { if (b - a >= CBS_SPEC_MIN_N) find_or_submit(t.gd + a, b - a, true); };
+        if (i1 == n) { go(0, i0); go(i0, n); }
+        else if (i0 == 0) { go(0, i1); go(i1, n); }
+        else { go(0, i0); go(i0, i1); go(i1, n); }
+    }
     void start(int n) {
         for (int i = 0; i < n; i++) workers.emplace_back([this]() {
             EngineCache& cache = EngineCache::of(ctx);
-            std::unique_ptr<ArcGpu> gp = cache.arc(ctx, arcSvcs[nextArc++ % 3]); std::unique_ptr<PermGpu> pgp = cache.tail(ctx);
+            std::unique_ptr<ArcGpu> gp = cache.arc(ctx, arcSvcs[nextArc++ % nArcSvc]); std::unique_ptr<PermGpu> pgp = cache.tail(ctx);
             struct Back { EngineCache& c; std::unique_ptr<ArcGpu>& a; std::unique_ptr<PermGpu>& p; ~Back() { c.give(std::move(a)); c.give_tail(std::move(p)); } } back{cache, gp, pgp};
             ArcGpu& G = *gp; PermGpu& PG = *pgp;
             for (;;) {
@@ -1503,19 +1531,15 @@ struct SpecPool {
                 phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out);
                 { std::lock_guard<std::mutex> lk(mu); t->state = 2; }
                 cvDone.notify_all();
+                if (guessAhead) guess_children(*t);
             }
         });
     }
-    std::shared_ptr<SpecTask> submit(const double* gd, int cn) {
-        auto t = std::make_shared<SpecTask>(); t->gd = gd; t->cn = cn;
-        { std::lock_guard<std::mutex> lk(mu); queue.push_back(t); }
-        cvWork.notify_one();
-        return t;
-    }
+    bool guessAhead = getenv("CANVAS_CBS_NO_GUESSES") == nullptr;
     // the result of a task: run here if nobody has started it, otherwise wait for the helper
     Phase1& get(const std::shared_ptr<SpecTask>& t, ArcGpu& G, PermGpu& PG) {
         int expect = 0;
-        if (t->state.compare_exchange_strong(expect, 1)) { phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out); t->state = 2; return t->out; }
+        if (t->state.compare_exchange_strong(expect, 1)) { phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out); { std::lock_guard<std::mutex> lk(mu); t->state = 2; } cvDone.notify_all(); if (guessAhead) guess_children(*t); return t->out; }
         std::unique_lock<std::mutex> lk(mu); cvDone.wait(lk, [&]() { return t->state.load() == 2; });
         return t->out;
     }
@@ -1525,15 +1549,13 @@ struct SpecPool {
 // ChangePoint.ChangePoints (ChangePoint.cs:44-153), undo = None
 static int32_t change_points(ArcGpu& G, PermGpu& PG, SpecPool* pool, const double* gd, int n, const std::vector<uint32_t>& sbdry, MT& rnd, double alpha, uint32_t nPerm, std::vector<int>& lengthSeg, Stats& st) {
     std::vector<int> segEnd = {0, n}, changeLoc;
-    std::map<std::pair<int, int>, std::shared_ptr<SpecTask>> ahead;        // phase 1 of the segments on the stack, keyed by (start, end)
     int k = 2, nCp = 0, iCp[2] = {0, 0};
     while (k > 1) {
         const int s0 = segEnd[k - 2], cn = segEnd[k - 1] - s0;
         Phase1 local; Phase1* P = &local;
-        auto it = ahead.find({s0, segEnd[k - 1]});
         std::shared_ptr<SpecTask> hold;
         auto tP1 = std::chrono::steady_clock::now();
-        if (it != ahead.end()) { hold = it->second; ahead.erase(it); P = &pool->get(hold, G, PG); }
+        if (pool && cn >= CBS_SPEC_MIN_N) { hold = pool->find_or_submit(gd + s0, cn, false); P = &pool->get(hold, G, PG); }
         else phase1_run(G, PG, gd + s0, cn, nPerm, alpha, st, local);
         tlClock.p1 += std::chrono::duration<double>(std::chrono::steady_clock::now() - tP1).count(); tlClock.segments++;
         int32_t rc = phase2_run(PG, *P, nPerm, alpha, nCp, iCp, sbdry, rnd, st); if (rc) return rc;
@@ -1545,7 +1567,7 @@ static int32_t change_points(ArcGpu& G, PermGpu& PG, SpecPool* pool, const doubl
         if (nCp > 0 && pool) {
             // the split left nCp + 1 segments where one was: all of them are submitted (the top one is needed next: the chromosome thread takes it itself unless a helper is faster)
             const int first = k - 2;                            // segEnd[first] = s0
-            for (int j = first + nCp; j >= first; j--) { const int a = segEnd[j], b = segEnd[j + 1]; if (b - a >= 4) ahead[{a, b}] = pool->submit(gd + a, b - a); }
+            for (int j = first; j <= first + nCp; j++) { const int a = segEnd[j], b = segEnd[j + 1]; if (b - a >= CBS_SPEC_MIN_N) pool->find_or_submit(gd + a, b - a, false); }      // (front of the queue: the last one pushed — the top of the stack — is served first)
         }
         k = (int)segEnd.size();
     }
@@ -1725,7 +1747,11 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     const int nPermSvc = std::max(1, std::min(16, getenv("CANVAS_CBS_PERM_SERVICES") ? atoi(getenv("CANVAS_CBS_PERM_SERVICES")) : 4));
     std::vector<std::unique_ptr<cbs::PermService>> moreServices;
     for (int i = 4; i < nPermSvc; i++) moreServices.emplace_back(new cbs::PermService(ctx));
-    cbs::PermService* arcServices[3] = {&arcService, &arcService1, &arcService2};      // (one launcher synchronises after every round: requests that arrive meanwhile would wait a whole round)
+    const int nArcSvc = std::max(1, std::min(16, getenv("CANVAS_CBS_ARC_SERVICES") ? atoi(getenv("CANVAS_CBS_ARC_SERVICES")) : 3));
+    std::vector<std::unique_ptr<cbs::PermService>> moreArc;
+    for (int i = 3; i < nArcSvc; i++) moreArc.emplace_back(new cbs::PermService(ctx));
+    cbs::PermService* arcServices[16] = {&arcService, &arcService1, &arcService2};      // (one launcher synchronises after every round: requests that arrive meanwhile would wait a whole round)
+    for (int i = 3; i < nArcSvc; i++) arcServices[i] = moreArc[(size_t)i - 3].get();
     std::atomic_int nextArc{0};
     std::vector<cbs::PermService*> permServices = {&service, &service1, &service2, &service3};
     for (auto& m : moreServices) permServices.push_back(m.get());
@@ -1734,10 +1760,10 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     std::mutex chromMu; double maxChromSec = 0, sumChromSec = 0, slowSec = 0; std::string slowLine; const bool timing = getenv("CANVAS_CBS_TIMING") != nullptr;
     // helper threads for the deterministic front half of every segment on a recursion stack (cbs::SpecPool); CANVAS_CBS_NO_SPECULATION=1: the plain sequential order (test hook)
     std::unique_ptr<cbs::SpecPool> specPool;
-    if (!getenv("CANVAS_CBS_NO_SPECULATION")) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nperm, alpha, &st}); specPool->start((int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4))); }
+    if (!getenv("CANVAS_CBS_NO_SPECULATION")) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nArcSvc, nperm, alpha, &st}); specPool->start((int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4))); }
     auto work = [&]() {
         cbs::EngineCache& cache = cbs::EngineCache::of(ctx);                             // per thread: own buffers, borrowed from the context's cache (created on first use)
-        std::unique_ptr<cbs::PermGpu> pgp = cache.perm(ctx, permServices[(size_t)(nextService++ % nPermSvc)]); std::unique_ptr<cbs::ArcGpu> gp = cache.arc(ctx, arcServices[nextArc++ % 3]);
+        std::unique_ptr<cbs::PermGpu> pgp = cache.perm(ctx, permServices[(size_t)(nextService++ % nPermSvc)]); std::unique_ptr<cbs::ArcGpu> gp = cache.arc(ctx, arcServices[nextArc++ % nArcSvc]);
         struct Back { cbs::EngineCache& c; std::unique_ptr<cbs::ArcGpu>& a; std::unique_ptr<cbs::PermGpu>& p; ~Back() { c.give(std::move(a)); c.give(std::move(p)); } } back{cache, gp, pgp};
         cbs::PermGpu& PG = *pgp; cbs::ArcGpu& G = *gp;
         PG.reserveN = (size_t)nMax; PG.reserveElems = (size_t)std::min<long long>((long long)256 * nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * nMax));
