@@ -534,11 +534,12 @@ __global__ void __launch_bounds__(PG_T) k_perm_stat(const PermReq* __restrict__ 
 // [-inf, inf] and the host evaluates it in the reference's order, like any other undecided one.
 #define PF_BK 4096
 #define PF_SPT (PF_BK / PG_T)
-#define PF_HS (1 << 18)
-#define PF_CMAX 1024
-#define PF_MAP 4096
+#define PF_HS (1 << 18)           // bits of the "some step of the block targets this position" table (hashed by the low bits of the position)
+#define PF_HS2 (1 << 16)          // bits of the "two steps do" table: few are ever set, so a smaller table gives no more false positives
+#define PF_CMAX 512
+#define PF_MAP 1024               // (the kernel's LDS stays under half a CU's 160 KB: two workgroups per CU)
 __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ reqs, int nreq) {
-    __shared__ uint32_t sM1[PF_HS / 32], sM2[PF_HS / 32];
+    __shared__ uint32_t sM1[PF_HS / 32], sM2[PF_HS2 / 32];
     __shared__ int32_t sA[PF_BK];
     __shared__ uint32_t sHit[PF_BK / 32];
     __shared__ int32_t sCI[PF_CMAX], sCT[PF_CMAX], sCV[PF_CMAX], sCanon[PF_CMAX];
@@ -548,7 +549,9 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
     __shared__ double shD[PG_T / 64 + 1];
     __shared__ double shM[PG_MAXK + 1][PG_T / 64];
     __shared__ int sOver;
-    __shared__ double sT[PT_TILE + PT_HALO], sEdge[2 * PT_HALO];
+    __shared__ double sEdge[2 * PT_HALO];
+    double* sT = reinterpret_cast<double*>(sM1);             // the statistic's tile buffer lives where the detection table was (PT_TILE + PT_HALO doubles < PF_HS / 8 bytes)
+    static_assert((PT_TILE + PT_HALO) * 8 <= PF_HS / 8, "tile buffer does not fit the detection table");
     __shared__ int16_t sDep1[PF_CMAX], sDep2[PF_CMAX];
     __shared__ uint8_t sDone[PF_CMAX];
     int ri = 0;
@@ -570,7 +573,8 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
         // ---- the block's own positions, clean detection tables
         for (int p = tid; p < Bk; p += PG_T) sA[p] = a[I0 + p];
         { uint4* z1 = reinterpret_cast<uint4*>(sM1); uint4* z2 = reinterpret_cast<uint4*>(sM2); const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-          for (int w = tid; w < PF_HS / 128; w += PG_T) { z1[w] = z; z2[w] = z; } }
+          for (int w = tid; w < PF_HS / 128; w += PG_T) z1[w] = z;
+          for (int w = tid; w < PF_HS2 / 128; w += PG_T) z2[w] = z; }
         for (int w = tid; w < PF_BK / 32; w += PG_T) sHit[w] = 0u;
         for (int w = tid; w < PF_MAP; w += PG_T) { sMapKey[w] = 0xFFFFFFFFu; sMapVal[w] = 0x7FFFFFFF; }
         __syncthreads();
@@ -588,7 +592,7 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
                 if (tt != i) {                                  // (a step that targets itself changes nothing)
                     t[q] = tt;
                     if (tt >= I0) atomicOr(&sHit[(tt - I0) >> 5], 1u << ((tt - I0) & 31));
-                    else { pre[q] = a[tt]; const uint32_t h = (uint32_t)tt & (PF_HS - 1), bit = 1u << (h & 31); const uint32_t old = atomicOr(&sM1[h >> 5], bit); if (old & bit) atomicOr(&sM2[h >> 5], bit); }
+                    else { pre[q] = a[tt]; const uint32_t h = (uint32_t)tt & (PF_HS - 1), bit = 1u << (h & 31); const uint32_t old = atomicOr(&sM1[h >> 5], bit); if (old & bit) { const uint32_t h2 = (uint32_t)tt & (PF_HS2 - 1); atomicOr(&sM2[h2 >> 5], 1u << (h2 & 31)); } }
                 }
             }
         }
@@ -600,7 +604,7 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
             if (t[q] < 0) continue;
             const int i = I1 - 1 - (tid * PF_SPT + q), tt = t[q];
             bool c = tt >= I0 || ((sHit[(i - I0) >> 5] >> ((i - I0) & 31)) & 1u);
-            if (!c) { const uint32_t h = (uint32_t)tt & (PF_HS - 1); c = (sM2[h >> 5] >> (h & 31)) & 1u; }
+            if (!c) { const uint32_t h2 = (uint32_t)tt & (PF_HS2 - 1); c = (sM2[h2 >> 5] >> (h2 & 31)) & 1u; }
             if (c) { cm |= 1u << q; cnt++; }
         }
         int nC;
@@ -618,7 +622,7 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
         for (int k = tid; k < nC; k += PG_T) {
             const int tt = sCT[k];
             if (tt < I0) {
-                uint32_t slot = ((uint32_t)tt * 2654435761u) >> 20;
+                uint32_t slot = ((uint32_t)tt * 2654435761u) >> 22;
                 for (;;) {
                     const uint32_t prev = atomicCAS(&sMapKey[slot], 0xFFFFFFFFu, (uint32_t)tt);
                     if (prev == 0xFFFFFFFFu || prev == (uint32_t)tt) { atomicMin(&sMapVal[slot], k); sCanon[k] = (int32_t)slot; break; }
