@@ -1492,7 +1492,7 @@ struct EngineCache {
 };
 // helper threads of phase 1 (own arc-search and tail-series buffers each); a chromosome thread that needs a segment no helper has started yet runs it itself
 #define CBS_SPEC_MIN_N 4
-struct SpecTask { const double* gd; int cn; bool guess = false; Phase1 out; std::atomic<int> state{0}; };      // 0 queued, 1 running, 2 done; guess: put there by a helper, not (yet) asked for by the recursion
+struct SpecTask { const double* gd; int cn; std::atomic<bool> guess{false}; Phase1 out; std::atomic<int> state{0}; };      // 0 queued, 1 running, 2 done; guess: put there by a helper, not (yet) asked for by the recursion
 struct SpecPool {
     canvas_ctx* ctx; PermService** arcSvcs; int nArcSvc; uint32_t nPerm; double cutoff; Stats* st; std::atomic_int nextArc{0};
     std::mutex mu; std::condition_variable cvWork, cvDone; std::deque<std::shared_ptr<SpecTask>> queue; bool stopping = false; std::vector<std::thread> workers;
@@ -1504,9 +1504,14 @@ struct SpecPool {
     std::atomic<long long> guessed{0}, guessedUsed{0};
     std::shared_ptr<SpecTask> find_or_submit(const double* gd, int cn, bool guess) {
         std::shared_ptr<SpecTask> t;
+        { std::shared_ptr<SpecTask> hit; bool promote = false;
+          { std::lock_guard<std::mutex> lk(mu);
+            auto it = reg.find({gd, cn});
+            if (it != reg.end()) { hit = it->second; if (!guess && hit->guess) { hit->guess = false; guessedUsed++; promote = hit->state.load() == 2; } } }
+          if (hit) { if (promote && guessAhead) guess_children(*hit); return hit; } }     // a guess that came true and is finished: ITS likely children go out now (one level ahead, never more)
         { std::lock_guard<std::mutex> lk(mu);
           auto it = reg.find({gd, cn});
-          if (it != reg.end()) { if (!guess && it->second->guess) { it->second->guess = false; guessedUsed++; } return it->second; }
+          if (it != reg.end()) return it->second;
           t = std::make_shared<SpecTask>(); t->gd = gd; t->cn = cn; t->guess = guess; reg[{gd, cn}] = t;
           if (guess) { guessed++; queue.push_back(t); } else queue.push_front(t); }       // what the recursion asks for goes first
         cvWork.notify_one();
@@ -1535,7 +1540,7 @@ struct SpecPool {
                 phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out);
                 { std::lock_guard<std::mutex> lk(mu); t->state = 2; }
                 cvDone.notify_all();
-                if (guessAhead) guess_children(*t);
+                if (guessAhead && !t->guess) guess_children(*t);      // only for segments the recursion has asked for: guesses do not breed guesses (2 279 guessed, 358 used when they did)
             }
         });
     }
@@ -1543,7 +1548,7 @@ struct SpecPool {
     // the result of a task: run here if nobody has started it, otherwise wait for the helper
     Phase1& get(const std::shared_ptr<SpecTask>& t, ArcGpu& G, PermGpu& PG) {
         int expect = 0;
-        if (t->state.compare_exchange_strong(expect, 1)) { phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out); { std::lock_guard<std::mutex> lk(mu); t->state = 2; } cvDone.notify_all(); if (guessAhead) guess_children(*t); return t->out; }
+        if (t->state.compare_exchange_strong(expect, 1)) { phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out); { std::lock_guard<std::mutex> lk(mu); t->state = 2; } cvDone.notify_all(); if (guessAhead && !t->guess) guess_children(*t); return t->out; }
         std::unique_lock<std::mutex> lk(mu); cvDone.wait(lk, [&]() { return t->state.load() == 2; });
         return t->out;
     }
@@ -1795,6 +1800,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
     ctx->cbs_tailp[0] = st.tailp_dev; ctx->cbs_tailp[1] = st.tailp_host;
     if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());
+    if (timing && specPool) fprintf(stderr, "cbs helpers: %lld segments guessed from a finished phase 1, %lld of them asked for by the recursion\n", (long long)specPool->guessed.load(), (long long)specPool->guessedUsed.load());
     if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: TMaxO on the host %.3f, TailP %.3f (%lld decided from the device series, %lld by the host series)\n", st.ns_tmaxo_host.load() * 1e-9, st.ns_tailp.load() * 1e-9, (long long)st.tailp_dev.load(), (long long)st.tailp_host.load()),
                                       fprintf(stderr, "cbs launcher: %lld rounds, %lld arc searches in %.3f s, %lld permutation batches in %.3f s\n", service.rounds + arcService.rounds + arcService1.rounds + arcService2.rounds, arcService.nArc + arcService1.nArc + arcService2.nArc, std::max(arcService.secArc, std::max(arcService1.secArc, arcService2.secArc)), service.nPermReq + service1.nPermReq + service2.nPermReq + service3.nPermReq, std::max(std::max(service.secPerm, service1.secPerm), std::max(service2.secPerm, service3.secPerm))),
                                       fprintf(stderr, "cbs thread-seconds: TMaxO on the device incl. waiting %.3f, edge tests (TPermP) %.3f; per-chromosome wall max %.3f sum %.3f; ", st.ns_tmaxo.load() * 1e-9, st.ns_tpermp.load() * 1e-9, maxChromSec, sumChromSec),
