@@ -238,6 +238,7 @@ struct PermReq {
 #define MT_STRIDE 128
 #define MT_NLAG 134
 #define MT_HISTORY (19937LL * MT_STRIDE)
+#define MT_BOOT_MIN 600000LL      // requests with fewer draws than this generate their (whole) stream in the sequential kernel: the seven doubling launches cost ~0.5 ms, the sequential kernel ~1.6 us per 1000 draws
 #define MT_WIDTH (623 * MT_STRIDE)
 __constant__ int MT_LAG[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700, 1758, 1869, 1985, 2096, 2154, 2212, 2439, 2492, 2608, 2666, 2777, 2893, 3004, 3062, 3115, 3120, 3342, 3347, 3400,
     3516, 3569, 3574, 3685, 3796, 3801, 3912, 3970, 4028, 4255, 4308, 4361, 4424, 4482, 4588, 4593, 4709, 4820, 4878, 4931, 4936, 4984, 5158, 5163, 5216, 5332, 5385, 5390, 5501, 5612, 5617,
@@ -252,12 +253,13 @@ static constexpr int MT_LAG_C[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700
     8056, 8099, 8220, 8225, 8326, 8452, 8553, 8563, 8616, 8722, 8780, 8790, 8848, 9017, 9176, 9244, 9809, 9968, 10036, 10432, 11731, 11958, 12185, 12354, 12412, 12460, 12808, 13368, 13600,
     14276, 15184, 15575, 15802, 16029, 16256, 16483, 16710, 16937, 17164, 17444, 18067, 18294, 18352, 18521, 18748, 19937};
 // sequential part: the first min(total, MT_HISTORY) draws of every request
-__global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs) {
+__global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs, int bootstrap) {
     __shared__ uint32_t mtA[624], mtB[624];
     const PermReq& R = reqs[blockIdx.x];
     if (R.cont) return;
     uint32_t* __restrict__ draws = R.P.draws;
-    const long long total = R.total < MT_HISTORY ? R.total : MT_HISTORY;
+    const long long seqMax = bootstrap && R.total >= MT_BOOT_MIN ? 19937LL : MT_HISTORY;     // bootstrap: only the first 19937 outputs come from here (see k_mt_classes)
+    const long long total = R.total < seqMax ? R.total : seqMax;
     const int tid = threadIdx.x;
     uint32_t* cur = mtA; uint32_t* nxt = mtB;
     for (int i = tid; i < 624; i += 256) cur[i] = R.state[i];
@@ -313,17 +315,22 @@ __global__ void __launch_bounds__(256) k_mt_stride(const PermReq* __restrict__ r
 // global memory, was 37 us per step — 1.2 TB/s of cache traffic for 0.3 MB of output — and 8 of the 14 ms of a 256-permutation batch of a 67 k-bin segment.)
 #define MTC_T 640
 #define MTC_BUF 40000             // words of LDS: the 19937-value history + 32 iterations of 623 new values; then the last 19937 move to the front
-__global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict__ reqs) {
+// stride / boot: the recurrence holds at every power-of-two stride, so the sequentially generated history itself is grown the same way — 19937 outputs from the sequential
+// kernel, then stride 1 doubles them (one workgroup), stride 2 doubles again (two) ... stride 64 reaches the 19937 * 128 outputs the main launch (stride 128, boot = 0)
+// starts from: seven short launches instead of 2.5 M outputs from one workgroup (4.3 ms per permutation loop of a long segment, 16 % of the somatic flow's kernel time).
+__global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict__ reqs, int stride, int boot) {
     __shared__ uint32_t ring[MTC_BUF];
     const PermReq& R = reqs[blockIdx.y];
     const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (boot && (R.cont || R.total < MT_BOOT_MIN)) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
     uint32_t* __restrict__ d = R.P.draws;
-    const long long start = R.cont ? 0 : MT_HISTORY;                 // first position to generate; the MT_HISTORY positions in front of it are there
-    const long long left = R.total - start - r;
+    const long long start = boot ? 19937LL * stride : (R.cont ? 0 : MT_HISTORY);        // first position to generate; the 19937 * stride positions in front of it are there
+    const long long end = boot ? (R.total < 19937LL * 2 * stride ? R.total : 19937LL * 2 * stride) : R.total;
+    const long long left = end - start - r;
     if (left <= 0) return;
-    const long long cnt = (left + MT_STRIDE - 1) / MT_STRIDE;        // values of this sequence to generate
-    const uint32_t* __restrict__ hist = d + (start - MT_HISTORY + r);
-    for (int t = tid; t < 19937; t += MTC_T) ring[t] = hist[(long long)t * MT_STRIDE];
+    const long long cnt = (left + stride - 1) / stride;              // values of this sequence to generate
+    const uint32_t* __restrict__ hist = d + (start - 19937LL * stride + r);
+    for (int t = tid; t < 19937; t += MTC_T) ring[t] = hist[(long long)t * stride];
     __syncthreads();
     uint32_t* __restrict__ out = d + (start + r);
     int head = 19937;                                                // slot of the next value; the buffer is linear, so every operand sits at a CONSTANT distance below the
@@ -347,7 +354,7 @@ __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict_
 #pragma unroll
             for (int i = 0; i < MT_NLAG; i++) v ^= w[19937 - MT_LAG_C[i]];
             ring[head + tid] = v;
-            out[(u0 + tid) * MT_STRIDE] = v;
+            out[(u0 + tid) * stride] = v;
         }
         head += 623;
         __syncthreads();
@@ -1226,12 +1233,17 @@ struct PermService {
         auto tp0 = std::chrono::steady_clock::now(); double msA = 0, msB = 0;
         auto lap = [&]() { (void)hipStreamSynchronize(stream); auto t = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; return ms; };
         if (dbg) lap();
-        hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs);
+        static const bool stepwise = getenv("CANVAS_CBS_MT_STEPWISE") != nullptr;     // the previous generator (one launch per 79 744 outputs), kept for comparison
+        static const bool bootstrap = !stepwise && getenv("CANVAS_CBS_MT_NO_BOOTSTRAP") == nullptr;
+        bool anyFresh = false; long long maxFresh = 0;
+        for (int i = 0; i < R; i++) if (!batch[i]->r.cont) { anyFresh = true; if (batch[i]->r.total >= MT_BOOT_MIN) maxFresh = std::max(maxFresh, batch[i]->r.total); }
+        if (anyFresh) hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs, bootstrap ? 1 : 0);
+        if (anyFresh && bootstrap)
+            for (int sd = 1; sd < MT_STRIDE && 19937LL * sd < maxFresh; sd <<= 1) hipLaunchKernelGGL(k_mt_classes, dim3(sd, R), dim3(MTC_T), 0, stream, dReqs, sd, 1);
         if (dbg) msA = lap();
         const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;
-        static const bool stepwise = getenv("CANVAS_CBS_MT_STEPWISE") != nullptr;     // the previous generator, kept for comparison
         if (stepwise) for (int sidx = 0; sidx < steps; sidx++) hipLaunchKernelGGL(k_mt_stride, dim3((MT_WIDTH / 4 + 255) / 256, R), dim3(256), 0, stream, dReqs, sidx);
-        else if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs);
+        else if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
         if (dbg) msB = lap();
         hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
         bool anyFy = false, anyOld = false; for (int i = 0; i < R; i++) (batch[i]->r.fy ? anyFy : anyOld) = true;
