@@ -1749,7 +1749,9 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     // sequential stopping boundary (GetBoundary.cs), cached per (nperm, alpha)
     static std::mutex bmu; static std::vector<uint32_t> sb; static uint32_t sbN = 0; static double sbA = 0;
     std::vector<uint32_t> sbdry;
-    { std::lock_guard<std::mutex> lk(bmu); if (sbN != nperm || sbA != alpha) { cbs::compute_boundary(nperm, alpha, 0.05, sb); sbN = nperm; sbA = alpha; } sbdry = sb; }
+    { std::lock_guard<std::mutex> lk(bmu); auto tB = std::chrono::steady_clock::now(); const bool fresh = sbN != nperm || sbA != alpha;
+      if (fresh) { cbs::compute_boundary(nperm, alpha, 0.05, sb); sbN = nperm; sbA = alpha; } sbdry = sb;
+      if (fresh && getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs: sequential boundary table (GetBoundary.cs) computed in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count()); }
     // per-chromosome seeds in file order (CBSRunner.cs:107-112)
     cbs::MT seeder(0u);
     std::vector<int32_t> seeds(nchr);
