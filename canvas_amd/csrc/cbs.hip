@@ -124,31 +124,61 @@ __global__ void __launch_bounds__(ARC_THREADS) k_arc_search(const ArcReq* __rest
 // maximiser" and "replay the reference's block order".  If more pairs survive than the list holds, the exhaustive kernel is used.
 #define AP_BK 1024
 #define AP_PAIRCAP 8192
-struct ArcPReq { const double* sx; int n; int al0; double tau; double* bmin; double* bmax; int* pairs; unsigned long long* out /* [0] max key, [1] count, [2] min packed arc, [3] npairs, [4] overflow */; double* pairMax; };
+struct ArcPReq { const double* sx; int n; int al0; double tau; double* bmin; double* bmax; int* pairs; unsigned long long* out /* [0] max key, [1] count, [2] min packed arc, [3] npairs, [4] overflow, [5] best block-extreme arc (bits) */; double* pairMax;
+                 int* bpos /* [2 nb]: position of every block's first minimum / first maximum */; };
 __global__ void __launch_bounds__(256) k_arcp_blocks(const ArcPReq* __restrict__ reqs) {
     const ArcPReq R = reqs[blockIdx.y];
     const int nb = (R.n + AP_BK - 1) / AP_BK;
     if ((int)blockIdx.x >= nb) return;
-    __shared__ double smn[4], smx[4];
-    double mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
-    for (int k = threadIdx.x; k < AP_BK; k += 256) { const int i = blockIdx.x * AP_BK + k; if (i < R.n) { const double v = R.sx[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; } }
+    __shared__ double smn[4], smx[4]; __shared__ int pmn[4], pmx[4];
+    double mn = 1.7976931348623157e308, mx = -1.7976931348623157e308; int imn = 0x7fffffff, imx = 0x7fffffff;
+    for (int k = threadIdx.x; k < AP_BK; k += 256) { const int i = blockIdx.x * AP_BK + k; if (i < R.n) { const double v = R.sx[i]; if (v < mn) { mn = v; imn = i; } if (v > mx) { mx = v; imx = i; } } }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const double a = __hiloint2double(__shfl_xor(__double2hiint(mn), d), __shfl_xor(__double2loint(mn), d)), b = __hiloint2double(__shfl_xor(__double2hiint(mx), d), __shfl_xor(__double2loint(mx), d));
-        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        const int ia = __shfl_xor(imn, d), ib = __shfl_xor(imx, d);
+        if (a < mn || (a == mn && ia < imn)) { mn = a; imn = ia; }
+        if (b > mx || (b == mx && ib < imx)) { mx = b; imx = ib; }
     }
-    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; pmn[threadIdx.x >> 6] = imn; pmx[threadIdx.x >> 6] = imx; }
     __syncthreads();
-    if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; } R.bmin[blockIdx.x] = mn; R.bmax[blockIdx.x] = mx; }
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { if (smn[w] < mn || (smn[w] == mn && pmn[w] < imn)) { mn = smn[w]; imn = pmn[w]; } if (smx[w] > mx || (smx[w] == mx && pmx[w] < imx)) { mx = smx[w]; imx = pmx[w]; } }
+        R.bmin[blockIdx.x] = mn; R.bmax[blockIdx.x] = mx; R.bpos[2 * blockIdx.x] = imn; R.bpos[2 * blockIdx.x + 1] = imx;
+    }
 }
 __device__ __forceinline__ double arc_c(double rn, int L) { const double rj = (double)L; return rn / (rj * (rn - rj)); }
-__global__ void __launch_bounds__(256) k_arcp_bounds(const ArcPReq* __restrict__ reqs) {
+// pass 0: a better incumbent than the reference's starting arc — for every block pair the two arcs between the blocks' extremes (real arcs, evaluated exactly as k_arcp_eval
+// evaluates them, so the true maximum is at least that large); pass 1: the pairs whose bound reaches the larger of the two incumbents.  (With the starting arc alone thousands of
+// pairs survived on a segment without a strong change — the bound of a pair near the diagonal is loose because c(L) is large there — and k_arcp_eval was 40 % of the kernel time
+// of a WGS-size CBS call; every arc that attains the maximum still lies in a surviving pair: its pair's bound is at least the maximum, which is at least the incumbent.)
+__global__ void __launch_bounds__(256) k_arcp_bounds(const ArcPReq* __restrict__ reqs, int pass) {
     const ArcPReq R = reqs[blockIdx.y];
     const int nb = (R.n + AP_BK - 1) / AP_BK;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)nb * nb) return;
-    const int A = (int)(idx / nb), B = (int)(idx % nb);
-    if (B < A) return;
+    const bool live = idx < (long long)nb * nb;
+    const int A = live ? (int)(idx / nb) : 0, B = live ? (int)(idx % nb) : 0;
+    if (pass == 0) {
+        __shared__ double sbest[4];
+        double best = 0.0;
+        if (live && B >= A) {
+            const double rn = (double)R.n;
+            auto arc = [&](int p, int q, double vp, double vq) {           // positions p, q and their prefix sums
+                const int L = p < q ? q - p : p - q;
+                if (L >= R.al0 && L <= R.n - R.al0) { const double d = fabs(vq - vp), v = arc_c(rn, L) * (d * d); best = v > best ? v : best; }
+            };
+            arc(R.bpos[2 * A], R.bpos[2 * B + 1], R.bmin[A], R.bmax[B]);
+            arc(R.bpos[2 * A + 1], R.bpos[2 * B], R.bmax[A], R.bmin[B]);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double o = __hiloint2double(__shfl_xor(__double2hiint(best), d), __shfl_xor(__double2loint(best), d)); best = o > best ? o : best; }
+        if ((threadIdx.x & 63) == 0) sbest[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) best = sbest[w] > best ? sbest[w] : best; if (best > 0.0) atomicMax(&R.out[5], (unsigned long long)__double_as_longlong(best)); }
+        return;
+    }
+    if (!live || B < A) return;
+    const double tau2 = __longlong_as_double((long long)R.out[5]), tau = tau2 > R.tau ? tau2 : R.tau;
     double D = R.bmax[B] - R.bmin[A]; const double D2 = R.bmax[A] - R.bmin[B]; D = D2 > D ? D2 : D;
     if (!(D > 0.0)) return;
     const int lmin = B == A ? 1 : (B - A - 1) * AP_BK + 1;
@@ -156,51 +186,57 @@ __global__ void __launch_bounds__(256) k_arcp_bounds(const ArcPReq* __restrict__
     const int llo = lmin > R.al0 ? lmin : R.al0, lhi = lmax < R.n - R.al0 ? lmax : R.n - R.al0;
     if (llo > lhi) return;
     const double rn = (double)R.n, c1 = arc_c(rn, llo), c2 = arc_c(rn, lhi), c = c1 > c2 ? c1 : c2;
-    if (c * (D * D) >= R.tau) {
+    if (c * (D * D) >= tau) {
         const unsigned long long slot = atomicAdd(&R.out[3], 1ull);
         if (slot < AP_PAIRCAP) R.pairs[slot] = A * 65536 + B; else R.out[4] = 1ull;
     }
 }
 // pass 0: maximum over the arcs of a surviving block pair; pass 1: count of the arcs that attain the global maximum + the smallest (L, i)
+// (a grid-stride loop over the surviving pairs: a launch of AP_PAIRCAP workgroups per request, nearly all of which returned at once, cost 0.1-1 ms in dispatch alone)
+#define AP_EVAL_GRID 512
 __global__ void __launch_bounds__(256) k_arcp_eval(const ArcPReq* __restrict__ reqs, int pass) {
     const ArcPReq R = reqs[blockIdx.y];
     unsigned long long np = R.out[3]; if (np > AP_PAIRCAP) np = AP_PAIRCAP;
-    if (R.out[4] || (unsigned long long)blockIdx.x >= np) return;
-    if (pass == 1 && (unsigned long long)__double_as_longlong(R.pairMax[blockIdx.x]) != R.out[0]) return;
+    if (R.out[4]) return;
     __shared__ double sA[AP_BK], sB[AP_BK], sC[2 * AP_BK];
     __shared__ double sred[4];
-    const int A = R.pairs[blockIdx.x] >> 16, B = R.pairs[blockIdx.x] & 65535;
-    const int n = R.n, baseL = (B - A) * AP_BK - (AP_BK - 1);          // L = baseL + (jj - ii + AP_BK - 1)
+    const int n = R.n;
     const double rn = (double)n;
-    for (int k = threadIdx.x; k < AP_BK; k += 256) { const int i = A * AP_BK + k, j = B * AP_BK + k; sA[k] = i < n ? R.sx[i] : 0.0; sB[k] = j < n ? R.sx[j] : 0.0; }
-    for (int k = threadIdx.x; k < 2 * AP_BK - 1; k += 256) { const int L = baseL + k; sC[k] = (L >= R.al0 && L <= n - R.al0) ? arc_c(rn, L) : -1.0; }   // -1: arc length not allowed
-    __syncthreads();
     const double target = __longlong_as_double((long long)R.out[0]);
-    double best = -1.0; unsigned long long cnt = 0, arcMin = ~0ull;
-    for (int ii = threadIdx.x; ii < AP_BK; ii += 256) {
-        const int i = A * AP_BK + ii; if (i >= n) break;
-        const double a = sA[ii];
-        const int j0 = A == B ? ii + 1 : 0;
-        int jend = n - B * AP_BK; jend = jend > AP_BK ? AP_BK : jend;
-        for (int jj = j0; jj < jend; jj++) {
-            const double c = sC[jj - ii + AP_BK - 1];
-            if (c < 0.0) continue;
-            const double d = fabs(sB[jj] - a), v = c * (d * d);
-            if (pass == 0) best = v > best ? v : best;
-            else if (v == target) { cnt++; const unsigned long long key = ((unsigned long long)(unsigned)(baseL + jj - ii + AP_BK - 1) << 32) | (unsigned)i; arcMin = key < arcMin ? key : arcMin; }
-        }
-    }
-    if (pass == 0) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const double o = __hiloint2double(__shfl_xor(__double2hiint(best), d), __shfl_xor(__double2loint(best), d)); best = o > best ? o : best; }
-        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = best;
+    for (unsigned long long pi = blockIdx.x; pi < np; pi += gridDim.x) {
+        if (pass == 1 && (unsigned long long)__double_as_longlong(R.pairMax[pi]) != R.out[0]) continue;
+        const int A = R.pairs[pi] >> 16, B = R.pairs[pi] & 65535;
+        const int baseL = (B - A) * AP_BK - (AP_BK - 1);          // L = baseL + (jj - ii + AP_BK - 1)
+        __syncthreads();                                           // (the previous pair's LDS tiles are no longer read)
+        for (int k = threadIdx.x; k < AP_BK; k += 256) { const int i = A * AP_BK + k, j = B * AP_BK + k; sA[k] = i < n ? R.sx[i] : 0.0; sB[k] = j < n ? R.sx[j] : 0.0; }
+        for (int k = threadIdx.x; k < 2 * AP_BK - 1; k += 256) { const int L = baseL + k; sC[k] = (L >= R.al0 && L <= n - R.al0) ? arc_c(rn, L) : -1.0; }   // -1: arc length not allowed
         __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; w++) best = sred[w] > best ? sred[w] : best;
-            R.pairMax[blockIdx.x] = best;
-            if (best >= 0.0) atomicMax(&R.out[0], (unsigned long long)__double_as_longlong(best));      // non-negative doubles order like their bit patterns
+        double best = -1.0; unsigned long long cnt = 0, arcMin = ~0ull;
+        for (int ii = threadIdx.x; ii < AP_BK; ii += 256) {
+            const int i = A * AP_BK + ii; if (i >= n) break;
+            const double a = sA[ii];
+            const int j0 = A == B ? ii + 1 : 0;
+            int jend = n - B * AP_BK; jend = jend > AP_BK ? AP_BK : jend;
+            for (int jj = j0; jj < jend; jj++) {
+                const double c = sC[jj - ii + AP_BK - 1];
+                if (c < 0.0) continue;
+                const double d = fabs(sB[jj] - a), v = c * (d * d);
+                if (pass == 0) best = v > best ? v : best;
+                else if (v == target) { cnt++; const unsigned long long key = ((unsigned long long)(unsigned)(baseL + jj - ii + AP_BK - 1) << 32) | (unsigned)i; arcMin = key < arcMin ? key : arcMin; }
+            }
         }
-    } else if (cnt) { atomicAdd(&R.out[1], cnt); atomicMin(&R.out[2], arcMin); }
+        if (pass == 0) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const double o = __hiloint2double(__shfl_xor(__double2hiint(best), d), __shfl_xor(__double2loint(best), d)); best = o > best ? o : best; }
+            if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < 4; w++) best = sred[w] > best ? sred[w] : best;
+                R.pairMax[pi] = best;
+                if (best >= 0.0) atomicMax(&R.out[0], (unsigned long long)__double_as_longlong(best));      // non-negative doubles order like their bit patterns
+            }
+        } else if (cnt) { atomicAdd(&R.out[1], cnt); atomicMin(&R.out[2], arcMin); }
+    }
 }
 
 // ================================================================================================ device: permutation reference distribution
@@ -993,7 +1029,7 @@ struct ArcGpu {       // one per chromosome thread: own buffers; the launches go
         if (n <= cap) return CANVAS_OK;
         if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipFree(dPr); (void)hipHostFree(pin); }
         cap = n + n / 4 + 1024;
-        { const size_t nb = (size_t)cap / AP_BK + 2; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dPr, nb * 16 + AP_PAIRCAP * 12 + 4096)); }
+        { const size_t nb = (size_t)cap / AP_BK + 2; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dPr, nb * 24 + AP_PAIRCAP * 12 + 4096)); }
         CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dMax, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dFirst, (size_t)cap * 4));
         pinBytes = (size_t)cap * 20 + 256; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
         return CANVAS_OK;
@@ -1019,7 +1055,7 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     ArcHostReq q; q.hSx = hSx; q.hMax = hMax; q.hFirst = hFirst; q.hOut = hOut;
     q.r.sx = G.dSx; q.r.n = n; q.r.dmax = G.dMax; q.r.firstI = G.dFirst;
     q.p.sx = G.dSx; q.p.n = n; q.p.al0 = al0; q.p.tau = bss0; q.p.bmin = (double*)G.dPr; q.p.bmax = q.p.bmin + nbk; q.p.pairs = (int*)(q.p.bmax + nbk);
-    q.p.pairMax = (double*)(q.p.pairs + AP_PAIRCAP); q.p.out = (unsigned long long*)(q.p.pairMax + AP_PAIRCAP);
+    q.p.pairMax = (double*)(q.p.pairs + AP_PAIRCAP); q.p.out = (unsigned long long*)(q.p.pairMax + AP_PAIRCAP); q.p.bpos = (int*)(q.p.out + 8);
     q.pruned = getenv("CANVAS_CBS_EXHAUSTIVE_ARCS") == nullptr;
     if (q.pruned) {
         rc = service_submit_arc(G.svc, q); if (rc) return rc;
@@ -1195,13 +1231,14 @@ struct PermService {
         for (auto* q : all) CANVAS_HIP_TRY(ctx, hipMemcpyAsync((void*)q->r.sx, q->hSx, (size_t)q->r.n * 8, hipMemcpyHostToDevice, stream));
         if (!pr.empty()) {
             const int R = (int)pr.size(); int maxN = 0;
-            for (int i = 0; i < R; i++) { hArcP[i] = pr[i]->p; maxN = std::max(maxN, pr[i]->p.n); CANVAS_HIP_TRY(ctx, hipMemsetAsync(pr[i]->p.out, 0, 40, stream)); CANVAS_HIP_TRY(ctx, hipMemsetAsync(pr[i]->p.out + 2, 0xFF, 8, stream)); }
+            for (int i = 0; i < R; i++) { hArcP[i] = pr[i]->p; maxN = std::max(maxN, pr[i]->p.n); CANVAS_HIP_TRY(ctx, hipMemsetAsync(pr[i]->p.out, 0, 48, stream)); CANVAS_HIP_TRY(ctx, hipMemsetAsync(pr[i]->p.out + 2, 0xFF, 8, stream)); }
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dArcP, hArcP, R * sizeof(ArcPReq), hipMemcpyHostToDevice, stream));
             const int nb = (maxN + AP_BK - 1) / AP_BK;
             hipLaunchKernelGGL(k_arcp_blocks, dim3(nb, R), dim3(256), 0, stream, dArcP);
-            hipLaunchKernelGGL(k_arcp_bounds, dim3((unsigned)(((long long)nb * nb + 255) / 256), R), dim3(256), 0, stream, dArcP);
-            hipLaunchKernelGGL(k_arcp_eval, dim3(AP_PAIRCAP, R), dim3(256), 0, stream, dArcP, 0);
-            hipLaunchKernelGGL(k_arcp_eval, dim3(AP_PAIRCAP, R), dim3(256), 0, stream, dArcP, 1);
+            hipLaunchKernelGGL(k_arcp_bounds, dim3((unsigned)(((long long)nb * nb + 255) / 256), R), dim3(256), 0, stream, dArcP, 0);
+            hipLaunchKernelGGL(k_arcp_bounds, dim3((unsigned)(((long long)nb * nb + 255) / 256), R), dim3(256), 0, stream, dArcP, 1);
+            hipLaunchKernelGGL(k_arcp_eval, dim3(AP_EVAL_GRID, R), dim3(256), 0, stream, dArcP, 0);
+            hipLaunchKernelGGL(k_arcp_eval, dim3(AP_EVAL_GRID, R), dim3(256), 0, stream, dArcP, 1);
             for (int i = 0; i < R; i++) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(pr[i]->hOut, pr[i]->p.out, 40, hipMemcpyDeviceToHost, stream));
         }
         if (!ex.empty()) {
