@@ -494,3 +494,73 @@ extern "C" int32_t canvas_wavelets_sharded(canvas_ctx* ctx, int32_t nchr, const 
     h_bp_offset[nchr] = total;
     return CANVAS_OK;
 }
+
+// ================================================================================================ the sample axis: one sample of a pedigree per rank
+// CanvasRunner runs CanvasBin and CanvasClean once per sample of a pedigree (CanvasRunner.cs:905-927, 1010-1070) — independent until two points: the multi-sample bin
+// size (the median rate over ALL samples' autosomes, CanvasBin.cs:86-110) and the bin intersection between CanvasClean and CanvasPartition
+// (MergeMultiSampleCleanedBedFile, Utilities.cs:834-920).  With one sample per rank those are two exchanges:
+//   canvas_allgather_host          a few host bytes per rank (the per-chromosome rates): every rank then derives the same bin size with canvas_bin_size_from_rates;
+//   canvas_merge_cleaned_sharded   every rank contributes the (chr, start, stop) columns of its cleaned bins, padded to the largest sample (12 B per bin), receives
+//                                  everybody's and runs the same intersection as canvas_merge_cleaned with the samples in rank order: the merged bin list (first sample's
+//                                  order, stop from the last sample) comes out identical on every rank, together with THIS rank's counts of the surviving bins.
+// The count exchange in front of the columns carries the status word: a rank that failed sends a negative count and every rank returns an error.
+static int32_t shard_ws_reserve(canvas_ctx* ctx, size_t need) {
+    if (need <= ctx->shard_ws_bytes) return CANVAS_OK;
+    if (ctx->shard_ws) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->shard_ws)); ctx->shard_ws = nullptr; ctx->shard_ws_bytes = 0; }
+    CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->shard_ws, need)); ctx->shard_ws_bytes = need;
+    return CANVAS_OK;
+}
+extern "C" int32_t canvas_allgather_host(canvas_ctx* ctx, const void* h_send, int64_t bytes_per_rank, void* h_recv) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (!h_send || !h_recv || bytes_per_rank <= 0 || bytes_per_rank > (1 << 24)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_allgather_host: 1 .. 16 MiB per rank");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t b = ((size_t)bytes_per_rank + 255) & ~size_t(255);
+    int32_t rc = shard_ws_reserve(ctx, b * (size_t)(ctx->nranks + 1) + 256); if (rc) return rc;
+    char* dS = (char*)ctx->shard_ws; char* dR = dS + b;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dS, h_send, (size_t)bytes_per_rank, hipMemcpyHostToDevice, ctx->stream));
+    rc = cvx_allgather(ctx, dS, dR, b); if (rc) return rc;
+    for (int r = 0; r < ctx->nranks; r++) CANVAS_HIP_TRY(ctx, hipMemcpyAsync((char*)h_recv + (size_t)r * (size_t)bytes_per_rank, dR + (size_t)r * b, (size_t)bytes_per_rank, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+extern "C" int32_t canvas_merge_cleaned_sharded(canvas_ctx* ctx, int64_t n_mine, const int32_t* d_chr, const int32_t* d_start, const int32_t* d_stop, const float* d_count,
+                                                int32_t* d_out_chr, int32_t* d_out_start, int32_t* d_out_stop, float* d_out_count, int64_t cap, int64_t* h_n_out) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    const int W = ctx->nranks, me = ctx->rank;
+    if (W > 16) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_merge_cleaned_sharded: at most 16 samples (ranks)");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t localErr = CANVAS_OK; std::string localMsg;
+    if (n_mine < 0 || n_mine > 0x7FFFFFF0ll || !h_n_out || (n_mine > 0 && (!d_chr || !d_start || !d_stop || !d_count)) || !d_out_chr || !d_out_start || !d_out_stop || !d_out_count) {
+        localErr = CANVAS_ERR_INVALID; localMsg = "canvas_merge_cleaned_sharded: bad arguments";
+    }
+    // ---- 1. how many bins every sample has (negative: that rank has failed)
+    std::vector<int64_t> ns((size_t)W, 0);
+    { const int64_t mine = localErr ? (int64_t)(localErr < 0 ? localErr : -localErr) : n_mine;
+      int32_t rc = canvas_allgather_host(ctx, &mine, 8, ns.data()); if (rc) return rc; }
+    for (int r = 0; r < W; r++) if (ns[(size_t)r] < 0) {
+        if (localErr) { ctx->err = localMsg; return localErr; }
+        CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string("canvas_merge_cleaned_sharded: rank ") + std::to_string(r) + " failed before the exchange (code " + std::to_string((long long)ns[(size_t)r]) + ")");
+    }
+    const int64_t nmax = std::max<int64_t>(1, *std::max_element(ns.begin(), ns.end()));
+    // ---- 2. the key columns of every sample
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t col = al((size_t)nmax * 4), slot = 3 * col;
+    int32_t rc = shard_ws_reserve(ctx, slot * (size_t)(W + 1) + al((size_t)ns[0] * 4 + 4) + 4096); if (rc) return rc;       // (the same size on every rank)
+    char* dS = (char*)ctx->shard_ws; char* dR = dS + slot; float* dScratch = (float*)(dR + slot * (size_t)W);
+    if (n_mine > 0) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dS, d_chr, (size_t)n_mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dS + col, d_start, (size_t)n_mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dS + 2 * col, d_stop, (size_t)n_mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    rc = cvx_allgather(ctx, dS, dR, slot); if (rc) return rc;
+    // ---- 3. the intersection, samples in rank order (no further exchange: a failure from here on is local)
+    if (cap < ns[0]) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_merge_cleaned_sharded: the output arrays must hold the first sample's bins");
+    std::vector<const int32_t*> pc((size_t)W), ps((size_t)W), pe((size_t)W); std::vector<const float*> pv((size_t)W); std::vector<float*> po((size_t)W);
+    for (int r = 0; r < W; r++) {
+        const char* base = dR + (size_t)r * slot;
+        pc[(size_t)r] = (const int32_t*)base; ps[(size_t)r] = (const int32_t*)(base + col); pe[(size_t)r] = (const int32_t*)(base + 2 * col);
+        pv[(size_t)r] = r == me ? d_count : (const float*)(base + col);          // the other samples' counts are not here and not needed: any readable array of their length
+        po[(size_t)r] = r == me ? d_out_count : dScratch;
+    }
+    return canvas_merge_cleaned(ctx, W, ns.data(), pc.data(), ps.data(), pe.data(), pv.data(), d_out_chr, d_out_start, d_out_stop, po.data(), h_n_out);
+}

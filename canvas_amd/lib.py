@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
     "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_wavelets_decisions", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
-    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_profile_enable", "canvas_profile_get",
+    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_allgather_host", "canvas_merge_cleaned_sharded", "canvas_profile_enable", "canvas_profile_get",
 ]
 
 
@@ -144,6 +144,7 @@ class Canvas:
         if not raw:
             raise CanvasError("canvas_create failed: no usable GPU (no CPU fallback)")
         self.ctx = C.c_void_p(raw)   # always pass as a 64-bit pointer
+        self.comm_size = 1           # ranks of the library communicator (parallel.init_library_comm / init_host_comm set it)
         if stream is not None:
             self._check(self.lib.canvas_set_stream(self.ctx, C.c_void_p(stream)))
 
@@ -577,6 +578,25 @@ class Canvas:
         self._check(self.lib.canvas_wavelets_sharded(self.ctx, nchr, _np_ptr(ow), C.c_void_p(cov.data_ptr()), _np_ptr(off), int(bool(is_germline)), C.c_double(threshold_lower),
                                                      C.c_double(threshold_upper), C.c_double(mad_factor), int(window), int(min_size), _np_ptr(out), C.c_int64(len(out)), _np_ptr(oo)))
         return [out[oo[c]:oo[c + 1]].copy() for c in range(nchr)]
+
+    def allgather_host(self, arr):
+        """canvas_allgather_host: a small numpy array from every rank -> array of shape (ranks,) + arr.shape"""
+        a = np.ascontiguousarray(arr)
+        out = np.zeros((self.comm_size,) + a.shape, a.dtype)
+        self._check(self.lib.canvas_allgather_host(self.ctx, _np_ptr(a), C.c_int64(a.nbytes), _np_ptr(out)))
+        return out
+
+    def merge_cleaned_sharded(self, bins, n):
+        """canvas_merge_cleaned_sharded: this rank's cleaned SoA (dict chr/start/stop/count, n bins) -> (chr, start, stop, this sample's counts, n_out); one sample per rank"""
+        torch = self.torch
+        cap = int(bins["chr"].numel())
+        mk = lambda dt: torch.empty(cap, dtype=dt, device=self.device)
+        oc, os_, oe, ov = mk(torch.int32), mk(torch.int32), mk(torch.int32), mk(torch.float32)
+        k = C.c_int64(0)
+        self._check(self.lib.canvas_merge_cleaned_sharded(self.ctx, C.c_int64(int(n)), C.c_void_p(bins["chr"].data_ptr()), C.c_void_p(bins["start"].data_ptr()), C.c_void_p(bins["stop"].data_ptr()),
+                                                          C.c_void_p(bins["count"].data_ptr()), C.c_void_p(oc.data_ptr()), C.c_void_p(os_.data_ptr()), C.c_void_p(oe.data_ptr()), C.c_void_p(ov.data_ptr()),
+                                                          C.c_int64(cap), C.byref(k)))
+        return oc[:k.value], os_[:k.value], oe[:k.value], ov[:k.value], k.value
 
     def sharded_stats(self):
         out = np.zeros(6, np.int64)

@@ -138,6 +138,7 @@ def init_library_comm(cv, rank, world):
     dist.broadcast_object_list(ident, src=0)
     idbuf = (C.c_ubyte * 128).from_buffer_copy(ident[0])
     cv._check(cv.lib.canvas_comm_init(cv.ctx, rank, world, idbuf))
+    cv.comm_size = world
 
 
 _HOST_ALLGATHER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -169,6 +170,28 @@ def init_host_comm(cv, rank, world, group=None):
     cv._host_allgather_cb = fn                            # keep the trampoline alive as long as the context
     cv.lib.canvas_comm_init_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _HOST_ALLGATHER, C.c_void_p]
     cv._check(cv.lib.canvas_comm_init_host(cv.ctx, rank, world, fn, None))
+    cv.comm_size = world
+
+
+# ---- the sample axis: one sample of a pedigree per rank (BASELINE configs[3])
+def pedigree_sample_flow(cv, bases, masks, hits, lens, is_autosome, flags, counts_per_bin=100, is_y=None):
+    """This rank's sample of a pedigree through CanvasBin -> CanvasClean -> bin intersection -> F2 -> PerSampleHMM; every rank (= sample) calls it.  The samples meet twice:
+    canvas_allgather_host (every sample's autosomal rates -> ONE bin size, CanvasBin.cs:86-110) and canvas_merge_cleaned_sharded (the bins every sample still has,
+    Utilities.cs:834-920).  Returns dict(bin_size, n_binned, n_clean, chr, start, stop, count (this sample, merged bins), n, off, cov, state)."""
+    nchr = len(lens)
+    ia = np.ascontiguousarray(is_autosome, np.uint8)
+    _, _, rate = cv.bin_rates(hits, masks, lens)
+    mine = np.array([rate[c] if ia[c] else -1.0 for c in range(nchr)], np.float64)       # -1: not an autosome (dropped below, like the reference's filter)
+    allr = cv.allgather_host(mine)
+    rates = [float(allr[r, c]) for r in range(allr.shape[0]) for c in range(nchr) if ia[c]]      # sample by sample, chromosomes in file order: the order of the reference's list
+    bin_size = cv.bin_size_from_rates(rates, counts_per_bin)
+    out, per, total = cv.bin_genome(bases, masks, hits, lens, bin_size, 3)
+    n_clean, _, _ = cv.clean(out, total, is_autosome, flags, is_y=is_y)
+    mc, ms, me, mv, k = cv.merge_cleaned_sharded(out, n_clean)
+    off = cv.chromosome_offsets(mc, k, nchr)
+    cov = cv.quantize_f2(mv, k)
+    state = cv.hmm_per_sample(cov, off)
+    return dict(bin_size=bin_size, n_binned=int(total), n_clean=int(n_clean), chr=mc, start=ms, stop=me, count=mv, n=int(k), off=off, cov=cov, state=state)
 
 
 # ---- bench.py --gpus N --multi sharded
@@ -327,7 +350,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
     leg_done = threading.Event()
 
     def leg_watchdog():
-        if not leg_done.wait(float(os.environ.get("CANVAS_SHARDED_PARTITION_TIMEOUT", "300"))):
+        if not leg_done.wait(float(os.environ.get("CANVAS_SHARDED_PARTITION_TIMEOUT", "420"))):
             if rank == 0:
                 result["partition_sharded"] = {"error": "did not finish within the watchdog's limit"}
                 print(json.dumps(result), flush=True)
@@ -361,8 +384,67 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             barrier()
     except Exception as e:                                        # noqa: BLE001
         part["error"] = "%s: %s" % (type(e).__name__, e)
+    # ---- the sample axis (BASELINE configs[3]): a pedigree of `world` members over ONE reference, one sample per rank — CanvasBin / CanvasClean / PerSampleHMM local, the
+    # multi-sample bin size and the bin intersection as exchanges (canvas_allgather_host, canvas_merge_cleaned_sharded); rank 0 repeats the flow for all members on its own
+    # GPU and compares.  Untimed for `value`, weak scaling (one 60x sample per rank).
+    ped = {}
+    try:
+        if world <= 16 and "error" not in part:
+            from .lib import synth_generate_sample_device
+            thr_t = torch.from_numpy(synth.poisson_thresholds(args.rate).view(np.int32)).to(device)
+            if rank == 0:
+                rb, rm = cb, cm                                   # rank 0's cohort sample was generated from `seed`: its bases / masks ARE the reference
+            else:
+                rb, rm = [], []
+                for c in range(nchr):
+                    b_, _, m_, thr = synth_generate_device(seed, c, lengths[c], args.rate, device, thr)
+                    rb.append(b_); rm.append(m_)
+            sample_hits = lambda s: [synth_generate_sample_device(seed, seed + 3000 + 17 * s, c, int(L), thr_t, device)[0] for c, L in enumerate(lengths)]
+            my_hits = sample_hits(rank)
+            torch.cuda.synchronize()
+            pedigree_sample_flow(cv, rb, rm, my_hits, lens, is_auto, flags)                 # warm
+            barrier()
+            t0 = time.perf_counter()
+            pr = pedigree_sample_flow(cv, rb, rm, my_hits, lens, is_auto, flags)
+            barrier()
+            psec = max_over_ranks(time.perf_counter() - t0, device)
+            k = pr["n"]
+            dig = torch.stack([pr["start"].to(torch.int64).sum(), pr["stop"].to(torch.int64).sum(), (pr["chr"].to(torch.int64) * (torch.arange(k, device=device) % 1009)).sum(),
+                               torch.tensor(k, device=device), torch.tensor(int(pr["bin_size"]), device=device)])
+            digs = [torch.zeros_like(dig) for _ in range(world)]
+            dist.all_gather(digs, dig)
+            same = bool(all((d == digs[0]).all() for d in digs))
+            binned = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+            dist.all_gather(binned, torch.tensor([pr["n_binned"]], dtype=torch.int64, device=device))
+            eq = None; sec1 = None
+            if rank == 0:
+                t1 = time.perf_counter()
+                allh = [my_hits] + [sample_hits(s_) for s_ in range(1, world)]
+                rates = []
+                for s_ in range(world):
+                    _, _, r_ = cv.bin_rates(allh[s_], rm, lens)
+                    rates += [r_[c] for c in range(nchr) if is_auto[c]]
+                bs1 = cv.bin_size_from_rates(rates, 100)
+                outs1, tot1 = [], []
+                for s_ in range(world):
+                    o_ = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+                    _, _, t_ = cv.bin_genome(rb, rm, allh[s_], lens, bs1, 3, out=o_)
+                    outs1.append(o_); tot1.append(int(t_))
+                nout1, _, _ = cv.clean_batch(outs1, tot1, is_auto, flags)
+                mc1, ms1, me1, mcnt1, k1 = cv.merge_cleaned(outs1, [int(x) for x in nout1])
+                sec1 = time.perf_counter() - t1
+                eq = bool(bs1 == pr["bin_size"] and k1 == k and (ms1[:k1] == pr["start"]).all() and (me1[:k1] == pr["stop"]).all() and (mc1[:k1] == pr["chr"]).all()
+                          and (mcnt1[0][:k1].view(torch.int32) == pr["count"].view(torch.int32)).all())
+                del allh, outs1
+            ped = {"samples": world, "seconds": round(psec, 4), "bins_per_s": round(float(sum(int(b.item()) for b in binned)) / psec, 1), "scaling": "weak", "bin_size": int(pr["bin_size"]),
+                   "bins_common_to_all": int(k), "identical_on_all_ranks": same, "equals_single_gpu_flow_rank0": eq, "single_gpu_seconds_incl_generating_the_other_samples_rank0": None if sec1 is None else round(sec1, 3),
+                   "note": "one sample per rank over one reference: rates all-gather -> one bin size, CanvasBin + CanvasClean local, canvas_merge_cleaned_sharded (12 B per bin per rank), F2 + PerSampleHMM local"}
+            barrier()
+    except Exception as e:                                        # noqa: BLE001
+        ped = {"error": "%s: %s" % (type(e).__name__, e)}
     leg_done.set()
     if rank == 0:
+        result["pedigree_sharded"] = ped
         part["note"] = "canvas_cbs_sharded / canvas_wavelets_sharded: every rank segments its own chromosomes (the reference's per-chromosome tasks), one list exchange; genome-wide inputs (seeds in file order, coverage variability) from the whole coverage on every rank"
         result["partition_sharded"] = part
         print(json.dumps(result), flush=True)

@@ -368,6 +368,18 @@ int32_t canvas_wavelets_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_
                                 double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
                                 int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset);
 
+/* The sample axis ("samples of a trio add a second axis"; BASELINE configs[3]): one sample of a pedigree per rank.  CanvasBin / CanvasClean / CanvasPartition of
+ * a sample run on its rank with the single-GPU entry points; the two places where the reference couples the samples are exchanges:
+ *   canvas_allgather_host         bytes_per_rank host bytes from every rank, rank order — the per-chromosome rates of canvas_bin_rates, from which every rank derives the
+ *                                 multi-sample bin size (MultiSampleHitArrays / GetBinSize over all samples' autosomes, CanvasBin.cs:86-110) with canvas_bin_size_from_rates;
+ *   canvas_merge_cleaned_sharded  MergeMultiSampleCleanedBedFile (Utilities.cs:834-920) with the samples in rank order: this rank's cleaned SoA in, the merged bin list
+ *                                 (identical on every rank; capacity cap >= the first sample's bin count) and THIS sample's counts of the surviving bins out — what
+ *                                 canvas_merge_cleaned returns for that sample on one GPU.  The (chr, start, stop) columns travel (12 B per bin), padded to the largest sample.
+ * Both must be called by all ranks; a rank that fails locally announces it in the exchange and every rank returns an error. */
+int32_t canvas_allgather_host(canvas_ctx* ctx, const void* h_send, int64_t bytes_per_rank, void* h_recv);
+int32_t canvas_merge_cleaned_sharded(canvas_ctx* ctx, int64_t n_mine, const int32_t* d_chr, const int32_t* d_start, const int32_t* d_stop, const float* d_count,
+                                     int32_t* d_out_chr, int32_t* d_out_start, int32_t* d_out_stop, float* d_out_count, int64_t cap, int64_t* h_n_out);
+
 /* ---- profiling hooks (hipEvent pairs recorded on the context's stream around the named kernels) --------------------- */
 int32_t canvas_profile_enable(canvas_ctx* ctx, int32_t on);
 /* name: "bin_pass", "bin_tile_stats", "viterbi"; returns accumulated ms and launch count since the last reset */

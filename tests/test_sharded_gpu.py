@@ -400,3 +400,91 @@ def test_the_rccl_worker_with_a_one_rank_communicator():
         if p.is_alive(): p.kill()
     assert g[1] != "error", g[2]
     assert len(g) == 7 and sum(len(s) for s in g[5]) >= len(LENGTHS) and len(g[6]) == len(LENGTHS)
+
+
+# ---- the sample axis: one sample of a trio per rank (canvas_allgather_host, canvas_merge_cleaned_sharded)
+TRIO_LENS = [1_300_000, 950_000, 600_000]
+TRIO_AUTO = np.array([1, 1, 0], np.uint8)
+
+
+def _trio_inputs(sample):
+    """reference (bases, mask) shared by the samples; hits of `sample` (the child, sample 2, carries a deletion)"""
+    from canvas_amd import synth
+    thr = synth.poisson_thresholds(0.21)
+    ref = [synth.generate_chromosome(SEED + 60, c, L, 0.21, thr) for c, L in enumerate(TRIO_LENS)]
+    hits = []
+    for c, (b, h, m) in enumerate(ref):
+        other = synth.generate_chromosome(SEED + 61 + sample, c, TRIO_LENS[c], 0.21, thr)[1]
+        poss = np.unpackbits(m.view(np.uint8), bitorder="little")[: TRIO_LENS[c]].astype(bool)
+        h2 = np.where(poss, other, 0).astype(np.uint8)
+        if c == 0 and sample == 2: h2[400_000:650_000] = h2[400_000:650_000] // 2
+        hits.append(h2)
+    return [r[0] for r in ref], [r[2] for r in ref], hits
+
+
+def _trio_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        bases, masks, hits = _trio_inputs(rank)
+        pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+        db = [torch.from_numpy(pad(b)).to(cv.device) for b in bases]; dm = [torch.from_numpy(m.view(np.int64).copy()).to(cv.device) for m in masks]
+        dh = [torch.from_numpy(pad(h)).to(cv.device) for h in hits]
+        r = parallel.pedigree_sample_flow(cv, db, dm, dh, np.array(TRIO_LENS, np.int64), TRIO_AUTO, CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS)
+        q.put((rank, dict(bin_size=r["bin_size"], n_binned=r["n_binned"], n_clean=r["n_clean"], n=r["n"], off=[int(x) for x in r["off"]]),
+               r["chr"].cpu().numpy(), r["start"].cpu().numpy(), r["stop"].cpu().numpy(), r["count"].cpu().numpy(), r["state"][:r["n"]].cpu().numpy()))
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_three_samples_on_three_ranks_equal_the_single_gpu_trio_flow():
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trio_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    for g in got:
+        assert g[1] != "error", g[2]
+    # the same trio on one GPU with the single-GPU entry points (the flow tests/test_pedigree_flow_gpu.py checks against the oracle hand-off by hand-off)
+    from canvas_amd import Canvas, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS
+    cv = Canvas(0)
+    lens = np.array(TRIO_LENS, np.int64); nchr = len(TRIO_LENS)
+    pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+    rates, dev = [], []
+    for s in range(3):
+        bases, masks, hits = _trio_inputs(s)
+        db = [torch.from_numpy(pad(b)).to(cv.device) for b in bases]; dm = [torch.from_numpy(m.view(np.int64).copy()).to(cv.device) for m in masks]
+        dh = [torch.from_numpy(pad(h)).to(cv.device) for h in hits]
+        _, _, rate = cv.bin_rates(dh, dm, lens)
+        rates += [rate[c] for c in range(nchr) if TRIO_AUTO[c]]
+        dev.append((db, dm, dh))
+    bin_size = cv.bin_size_from_rates(rates, 100)
+    cleaned = []
+    for db, dm, dh in dev:
+        out, per, total = cv.bin_genome(db, dm, dh, lens, bin_size, 3)
+        n_clean, _, _ = cv.clean(out, total, TRIO_AUTO, CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS)
+        cleaned.append((out, n_clean, int(total)))
+    mc, ms, me, mcnt, k = cv.merge_cleaned([o for o, _, _ in cleaned], [n for _, n, _ in cleaned])
+    off = cv.chromosome_offsets(mc, k, nchr)
+    assert k > 1000 and len({n for _, n, _ in cleaned}) > 1               # the samples lose different bins: the intersection does something
+    for rank, info, c_, s_, e_, v_, st_ in got:
+        assert info["bin_size"] == bin_size and info["n_binned"] == cleaned[rank][2] and info["n_clean"] == cleaned[rank][1] and info["n"] == k, (rank, info)
+        assert info["off"] == [int(x) for x in off]
+        assert (c_ == mc[:k].cpu().numpy()).all() and (s_ == ms[:k].cpu().numpy()).all() and (e_ == me[:k].cpu().numpy()).all(), rank
+        assert (v_.view(np.uint32) == mcnt[rank][:k].cpu().numpy().view(np.uint32)).all(), rank
+        cov = cv.quantize_f2(mcnt[rank], k)
+        assert (st_ == cv.hmm_per_sample(cov, off)[:k].cpu().numpy()).all(), rank
