@@ -4,6 +4,8 @@
 // language's per-call overhead between the stages (arrays stay in HBM, five small results cross PCIe).
 #include "common.hpp"
 #include <vector>
+#include <chrono>
+#include <cstdio>
 
 // h_pos0 != NULL: d_bases / d_hits are the packed planes of canvas_bin_sample_packed (d_mask unused)
 static int32_t sample_pipeline_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_pos0,
@@ -14,6 +16,11 @@ static int32_t sample_pipeline_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t
                                     int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (!d_cov || !d_state || !d_segment_id || !h_chr_offset) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline: bad arguments");
+    static const bool timing = getenv("CANVAS_PIPELINE_TIMING") != nullptr;      // host wall time of every stage call (each ends in a synchronisation) and of the pause since the previous call returned
+    static thread_local std::chrono::steady_clock::time_point lastReturn; static thread_local bool haveLast = false;
+    auto tNow = []() { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const auto t0 = tNow();
     int32_t binSize = 0; int64_t total = 0, nClean = 0, nseg = 0; double lsd = -1.0; int32_t info[8];
     std::vector<int64_t> perChr((size_t)nchr);
     int32_t rc = h_pos0 ? canvas_bin_sample_packed(ctx, nchr, (const uint64_t* const*)d_bases, (const uint64_t* const*)d_hits, h_len, h_pos0, h_chr_is_autosome, counts_per_bin, bin_size_in, mode,
@@ -21,20 +28,26 @@ static int32_t sample_pipeline_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t
                         : canvas_bin_sample(ctx, nchr, d_bases, d_mask, d_hits, h_len, h_chr_is_autosome, counts_per_bin, bin_size_in, mode, d_chr, d_start, d_stop, d_gc, d_count, cap,
                                             &binSize, perChr.data(), &total);
     if (rc) return rc;
+    const auto t1 = tNow();
     if (h_bin_size) *h_bin_size = binSize;
     if (h_nbins) *h_nbins = total;
     std::vector<uint8_t> noY((size_t)nchr, 0);
     rc = canvas_clean2(ctx, total, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y ? h_chr_is_y : noY.data(), clean_flags, min_bins_per_gc, &lsd, &nClean, info);
     if (rc) return rc;
+    const auto t2 = tNow();
     if (h_nbins_clean) *h_nbins_clean = nClean;
     if (h_local_sd) *h_local_sd = lsd;
     // the quantisation also counts the genome-wide quartiles PerSampleHMM starts from; they come back with the chromosome offsets (one synchronisation)
     const void* hCovQ = nullptr;
     rc = cvx_quantize_f2_covq(ctx, d_count, nClean, d_cov, &hCovQ); if (rc) return rc;
     rc = canvas_chromosome_offsets(ctx, d_chr, nClean, nchr, h_chr_offset); if (rc) return rc;
+    const auto t3 = tNow();
     rc = hCovQ ? cvx_hmm_per_sample_preq(ctx, nchr, d_cov, h_chr_offset, d_state, hCovQ) : canvas_hmm_per_sample(ctx, nchr, d_cov, h_chr_offset, d_state); if (rc) return rc;
+    const auto t4 = tNow();
     rc = canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
     if (h_nsegments) *h_nsegments = nseg;
+    if (timing) { const auto t5 = tNow(); fprintf(stderr, "pipeline us: since the previous call returned %.0f | bin %.0f clean %.0f f2+offsets %.0f hmm %.0f segment ids %.0f | total %.0f\n", haveLast ? us(lastReturn, t0) : 0.0, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5), us(t0, t5)); }
+    lastReturn = tNow(); haveLast = true;
     return CANVAS_OK;
 }
 
