@@ -194,15 +194,23 @@ __global__ void __launch_bounds__(256) k_arcp_bounds(const ArcPReq* __restrict__
 // pass 0: maximum over the arcs of a surviving block pair; pass 1: count of the arcs that attain the global maximum + the smallest (L, i)
 // (a grid-stride loop over the surviving pairs: a launch of AP_PAIRCAP workgroups per request, nearly all of which returned at once, cost 0.1-1 ms in dispatch alone)
 #define AP_EVAL_GRID 512
+// Inside a surviving pair the same bound is applied once more to the 16 x 16 pairs of 64-element sub-blocks (their extremes are taken from the LDS tiles): on a segment
+// without a strong change thousands of pairs survive the first level — c(L) spans three orders of magnitude inside a pair near the diagonal, and the extremes of 1024
+// prefix sums are far apart — but few of their sub-pairs do.  An arc that attains the maximum lies in a sub-pair whose bound is at least the maximum, so nothing is lost.
+#define AP_SUB 64
+#define AP_NSUB (AP_BK / AP_SUB)
 __global__ void __launch_bounds__(256) k_arcp_eval(const ArcPReq* __restrict__ reqs, int pass) {
     const ArcPReq R = reqs[blockIdx.y];
     unsigned long long np = R.out[3]; if (np > AP_PAIRCAP) np = AP_PAIRCAP;
     if (R.out[4]) return;
     __shared__ double sA[AP_BK], sB[AP_BK], sC[2 * AP_BK];
+    __shared__ double sMn[2][AP_NSUB], sMx[2][AP_NSUB];
     __shared__ double sred[4];
     const int n = R.n;
     const double rn = (double)n;
     const double target = __longlong_as_double((long long)R.out[0]);
+    const double tau2 = __longlong_as_double((long long)R.out[5]);
+    const double thr = pass == 1 ? target : (tau2 > R.tau ? tau2 : R.tau);      // pass 0: the incumbent (a lower bound of the maximum); pass 1: the maximum itself
     for (unsigned long long pi = blockIdx.x; pi < np; pi += gridDim.x) {
         if (pass == 1 && (unsigned long long)__double_as_longlong(R.pairMax[pi]) != R.out[0]) continue;
         const int A = R.pairs[pi] >> 16, B = R.pairs[pi] & 65535;
@@ -211,18 +219,41 @@ __global__ void __launch_bounds__(256) k_arcp_eval(const ArcPReq* __restrict__ r
         for (int k = threadIdx.x; k < AP_BK; k += 256) { const int i = A * AP_BK + k, j = B * AP_BK + k; sA[k] = i < n ? R.sx[i] : 0.0; sB[k] = j < n ? R.sx[j] : 0.0; }
         for (int k = threadIdx.x; k < 2 * AP_BK - 1; k += 256) { const int L = baseL + k; sC[k] = (L >= R.al0 && L <= n - R.al0) ? arc_c(rn, L) : -1.0; }   // -1: arc length not allowed
         __syncthreads();
+        if (threadIdx.x < 2 * AP_NSUB) {                           // extremes of the sub-blocks (positions beyond n do not take part)
+            const int which = threadIdx.x / AP_NSUB, sb = threadIdx.x % AP_NSUB;
+            const double* src = which ? sB : sA; const int g0 = (which ? B : A) * AP_BK + sb * AP_SUB;
+            double mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
+            for (int k = 0; k < AP_SUB; k++) if (g0 + k < n) { const double v = src[sb * AP_SUB + k]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+            sMn[which][sb] = mn; sMx[which][sb] = mx;
+        }
+        __syncthreads();
         double best = -1.0; unsigned long long cnt = 0, arcMin = ~0ull;
-        for (int ii = threadIdx.x; ii < AP_BK; ii += 256) {
-            const int i = A * AP_BK + ii; if (i >= n) break;
-            const double a = sA[ii];
-            const int j0 = A == B ? ii + 1 : 0;
-            int jend = n - B * AP_BK; jend = jend > AP_BK ? AP_BK : jend;
-            for (int jj = j0; jj < jend; jj++) {
-                const double c = sC[jj - ii + AP_BK - 1];
-                if (c < 0.0) continue;
-                const double d = fabs(sB[jj] - a), v = c * (d * d);
-                if (pass == 0) best = v > best ? v : best;
-                else if (v == target) { cnt++; const unsigned long long key = ((unsigned long long)(unsigned)(baseL + jj - ii + AP_BK - 1) << 32) | (unsigned)i; arcMin = key < arcMin ? key : arcMin; }
+        const int li = threadIdx.x & (AP_SUB - 1), lj0 = (threadIdx.x >> 6) * (AP_SUB / 4);      // thread: one row of the sub-pair, a quarter of its columns
+        for (int sa = 0; sa < AP_NSUB; sa++) {
+            if (A * AP_BK + sa * AP_SUB >= n) break;
+            for (int sb = (A == B ? sa : 0); sb < AP_NSUB; sb++) {
+                if (B * AP_BK + sb * AP_SUB >= n) break;
+                // bound of the sub-pair (the same for every thread: no divergence)
+                double D = sMx[1][sb] - sMn[0][sa]; const double D2 = sMx[0][sa] - sMn[1][sb]; D = D2 > D ? D2 : D;
+                if (!(D > 0.0)) continue;
+                int lmin = (B - A) * AP_BK + (sb - sa) * AP_SUB - (AP_SUB - 1), lmax = (B - A) * AP_BK + (sb - sa) * AP_SUB + (AP_SUB - 1);
+                lmin = lmin < 1 ? 1 : lmin; lmax = lmax > n - 1 ? n - 1 : lmax;
+                const int llo = lmin > R.al0 ? lmin : R.al0, lhi = lmax < n - R.al0 ? lmax : n - R.al0;
+                if (llo > lhi) continue;
+                const double c1 = arc_c(rn, llo), c2 = arc_c(rn, lhi), cb = c1 > c2 ? c1 : c2;
+                if (cb * (D * D) < thr) continue;
+                const int ii = sa * AP_SUB + li, i = A * AP_BK + ii;
+                if (i >= n) continue;
+                const double a = sA[ii];
+                for (int q = 0; q < AP_SUB / 4; q++) {
+                    const int jj = sb * AP_SUB + lj0 + q;
+                    if (B * AP_BK + jj >= n || (A == B && jj <= ii)) continue;
+                    const double c = sC[jj - ii + AP_BK - 1];
+                    if (c < 0.0) continue;
+                    const double d = fabs(sB[jj] - a), v = c * (d * d);
+                    if (pass == 0) best = v > best ? v : best;
+                    else if (v == target) { cnt++; const unsigned long long key = ((unsigned long long)(unsigned)(baseL + jj - ii + AP_BK - 1) << 32) | (unsigned)i; arcMin = key < arcMin ? key : arcMin; }
+                }
             }
         }
         if (pass == 0) {
