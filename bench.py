@@ -282,13 +282,19 @@ def main():
         result["cbs_path"] = cb
     if rank == 0 and world == 1 and not args.no_wavelets:
         # the reference's default partition method (-m Wavelets) on the same cleaned coverage; reported, not part of `value`
-        cv.profile_get("wavelet_chain", reset=True)
         t_w = time.perf_counter()
-        bps = cv.wavelets(keep["cov"], keep["off"])
-        wv_s = time.perf_counter() - t_w
+        cv.wavelets(keep["cov"], keep["off"])                   # first call: pinned staging arena, workspace, side stream (the same convention as cbs_path)
+        wv_first = time.perf_counter() - t_w
+        wv_runs = []
+        for _ in range(3):
+            cv.profile_get("wavelet_chain", reset=True)
+            t_w = time.perf_counter()
+            bps = cv.wavelets(keep["cov"], keep["off"])
+            wv_runs.append(time.perf_counter() - t_w)
+        wv_s = sorted(wv_runs)[1]
         wst = cv.wavelets_stats(); wdec = cv.wavelets_decisions()
         ms_chain, k_chain = cv.profile_get("wavelet_chain")
-        wv = {"seconds": round(wv_s, 3), "bins_per_s": round(int(keep["n_out"]) / wv_s, 1), "breakpoints": int(sum(len(b) for b in bps)), "tree_levels": int(wst[0]),
+        wv = {"seconds": round(wv_s, 3), "seconds_of_each_call": [round(x, 3) for x in wv_runs], "first_call_seconds": round(wv_first, 3), "bins_per_s": round(int(keep["n_out"]) / wv_s, 1), "breakpoints": int(sum(len(b) for b in bps)), "tree_levels": int(wst[0]),
               "long_nodes_decided_from_the_closed_form": wdec[0], "long_nodes_undecided_sent_to_the_exact_chain": wdec[1], "long_nodes_chained_for_their_coefficient": wdec[2],
               "chain_kernel_seconds": round(ms_chain / 1e3, 3), "nodes_recomputed_exactly": int(wst[1]),
               "note": "WaveletsRunner.Run (somatic flavour, default parameters): unbalanced Haar tree built on the device — arg-max of every long node decided from exact integer "
