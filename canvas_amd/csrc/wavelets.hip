@@ -316,6 +316,18 @@ __device__ __forceinline__ long long wv_block_scan_i64(long long v, long long* s
     *total = tot;
     return inc + offw;
 }
+// highest level of every chromosome that has a node (one workgroup per chromosome scans the chromosome's slice of the counters)
+__global__ void __launch_bounds__(256) k_wv_tops(const int32_t* __restrict__ counts, const long long* __restrict__ off, int32_t* __restrict__ top) {
+    __shared__ int sTop[4];
+    const long long lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+    int t = -1;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) if (counts[i]) t = (int)(i - lo);      // (ascending per thread: the last hit is the thread's highest)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(t, d, 64); t = o > t ? o : t; }
+    if ((threadIdx.x & 63) == 0) sTop[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) t = sTop[w] > t ? sTop[w] : t; top[blockIdx.x] = t; }
+}
 // one workgroup per chromosome: k = 100 x as integers (checked bit for bit), P1[i] = k_0 + ... + k_i, P2[i] = P1[0] + ... + P1[i] (both restart at every chromosome)
 __global__ void __launch_bounds__(1024) k_wv_prefix(const double* __restrict__ X, const long long* __restrict__ off, long long* __restrict__ P1, long long* __restrict__ P2, int* __restrict__ bad) {
     __shared__ long long sh[17];
@@ -1034,8 +1046,19 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         CANVAS_HIP_TRY(ctx, hipGetLastError());
         CANVAS_HIP_TRY(ctx, hipMemcpy(hN, dNcand, sizeof hN, hipMemcpyDeviceToHost));
         if (hN[1] & 0xFFFFFFFFull) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: candidate list overflow");
-        std::vector<int32_t> hCounts((size_t)N);
-        CANVAS_HIP_TRY(ctx, hipMemcpy(hCounts.data(), dCounts, hCounts.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        // node counts per (chromosome, level): a chromosome's slice is as long as the chromosome, but only its first few hundred entries are used — the device finds the
+        // highest used level per chromosome and only that much comes back (the whole 4 N bytes took several milliseconds)
+        std::vector<int32_t> hCounts((size_t)N, 0);
+        {
+            int32_t* dTop = (int32_t*)dStack;                    // (the subtree stacks are no longer needed)
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, off.data(), (nchr + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));      // (the chain-only path has not uploaded it)
+            hipLaunchKernelGGL(k_wv_tops, dim3(nchr), dim3(256), 0, ctx->stream, dCounts, dOff, dTop);
+            std::vector<int32_t> top((size_t)nchr, -1);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(top.data(), dTop, (size_t)nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (int c = 0; c < nchr; c++) if (top[(size_t)c] >= 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hCounts.data() + off[c], dCounts + off[c], ((size_t)top[(size_t)c] + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
         std::vector<WvCand> hc((size_t)hN[0]);
         if (hN[0]) CANVAS_HIP_TRY(ctx, hipMemcpy(hc.data(), dCands, hc.size() * sizeof(WvCand), hipMemcpyDeviceToHost));
         for (int c = 0; c < nchr; c++) {
