@@ -388,7 +388,10 @@ __global__ void __launch_bounds__(256) k_mt_stride(const PermReq* __restrict__ r
 __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict__ reqs, int stride, int boot) {
     __shared__ uint32_t ring[MTC_BUF];
     const PermReq& R = reqs[blockIdx.y];
-    const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    // XCD-aware placement: workgroups go round-robin over the 8 XCDs, and the 4-byte stores of 16 neighbouring sequences make up one 64-byte line — with sequence = workgroup
+    // index every line was written by 8 different L2s, 4 bytes at a time (PMC: 43 GB of WRITE_SIZE for 4.8 GB of draws).  Sequences r = x * (stride / 8) + k for the k-th
+    // workgroup of XCD x: a line's 16 writers share an L2 and run side by side.
+    const int bx = (int)blockIdx.x, r = stride >= 8 ? (bx & 7) * (stride >> 3) + (bx >> 3) : bx, tid = (int)threadIdx.x;
     if (boot && (R.cont || R.total < MT_BOOT_MIN)) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
     uint32_t* __restrict__ d = R.P.draws;
     const long long start = boot ? 19937LL * stride : (R.cont ? 0 : MT_HISTORY);        // first position to generate; the 19937 * stride positions in front of it are there
