@@ -488,3 +488,44 @@ def test_three_samples_on_three_ranks_equal_the_single_gpu_trio_flow():
         assert (v_.view(np.uint32) == mcnt[rank][:k].cpu().numpy().view(np.uint32)).all(), rank
         cov = cv.quantize_f2(mcnt[rank], k)
         assert (st_ == cv.hmm_per_sample(cov, off)[:k].cpu().numpy()).all(), rank
+
+
+def _merge_fail_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        from canvas_amd.lib import CanvasError
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        n = 1000
+        bins = dict(chr=torch.zeros(n, dtype=torch.int32, device=cv.device), start=torch.arange(n, dtype=torch.int32, device=cv.device) * 100,
+                    stop=torch.arange(n, dtype=torch.int32, device=cv.device) * 100 + 100, count=torch.ones(n, dtype=torch.float32, device=cv.device))
+        try:
+            cv.merge_cleaned_sharded(bins, -7 if rank == 1 else n)          # rank 1 hands in a negative bin count: a local argument error
+            q.put((rank, None))
+        except CanvasError as e:
+            q.put((rank, str(e)))
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error: " + traceback.format_exc()))
+
+
+def test_a_failing_sample_fails_the_bin_intersection_on_every_rank():
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_fail_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs: p.join(60)
+    assert got[0] is not None and "rank 1 failed" in got[0], got
+    assert got[1] is not None and "bad arguments" in got[1], got
