@@ -154,7 +154,8 @@ CVX_INTERNAL int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double*
                                     const uint8_t* h_mask, std::vector<std::vector<int>>& segs, int64_t* h_stats);
 CVX_INTERNAL int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline, double threshold_lower, double threshold_upper,
                                          double mad_factor, int32_t variability_window, int32_t min_size, const uint8_t* h_mask, int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset);
-CVX_INTERNAL int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state);
+CVX_INTERNAL int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state,
+                                               const void* h_covq = nullptr);      // h_covq: the quartile counters of cvx_quantize_f2_covq over d_cov_all (saves the counting sweep and its round trip)
 
 // (Polling the stream with hipStreamQuery instead of blocking in hipStreamSynchronize was tried for the short waits of a pass: no gain on the pass time, and
 // hipStreamQuery reported completion early on streams that wait for another stream's event — results arrived before their kernels.  Every wait blocks.)

@@ -1659,8 +1659,8 @@ int32_t cvx_quantize_f2_covq(canvas_ctx* ctx, const float* d_count, int64_t n, d
     return CANVAS_OK;
 }
 
-int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state) {
-    return hmm_per_sample_impl(ctx, nchr, d_cov, h_chr_offset, d_cov_all, n_all, d_state);
+int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state, const void* h_covq) {
+    return hmm_per_sample_impl(ctx, nchr, d_cov, h_chr_offset, d_cov_all, n_all, d_state, (const CovQ*)h_covq);
 }
 
 // NegativeBinomialWrapper density table (DistributionUtilities.cs:51-69), the same calls as negative_binomial_log_table without the final log

@@ -16,6 +16,8 @@
 #include "common.hpp"
 #include <algorithm>
 #include <vector>
+#include <chrono>
+#include <cstdio>
 
 #define SH_BLK 2048
 
@@ -206,6 +208,10 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
         if (localErr) { ctx->err = localMsg; return localErr; }
         CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string("canvas_sample_pipeline_sharded: rank ") + std::to_string(r) + " failed " + where + " (code " + std::to_string(code) + ")");
     };
+    static const bool shTiming = getenv("CANVAS_PIPELINE_TIMING") != nullptr;
+    std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
+    auto mark = [&](const char* what) { if (shTiming) { (void)hipStreamSynchronize(ctx->stream); marks.push_back({what, std::chrono::steady_clock::now()}); } };
+    mark("start");
     // ---- 1. local sweep, exchange of the rate table, one bin size, local bins
     ShardHook H{ctx, nchr, h_chr_owner, h_chr_is_autosome, counts_per_bin, bin_size_in, mine.data(), dRates, {}, {}, {}};
     int32_t binSize = 0; int64_t nbMine = 0;
@@ -241,6 +247,7 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
         if (binSize <= 0) { ctx->err = localMsg; return localErr; }
     }
     if (h_bin_size) *h_bin_size = binSize;
+    mark("sweep + rate exchange + local bins");
     // ---- 2. bins of every chromosome: counts are known everywhere, the columns travel in ONE all-gather
     std::vector<long long> binOff(nchr + 1, 0), rankOff(nchr, 0), nbRank(W, 0);
     for (int c = 0; c < nchr; c++) { const long long nb = (H.pop[c] - H.popBefore[c]) / binSize; binOff[c + 1] = binOff[c] + nb; rankOff[c] = nbRank[h_chr_owner[c]]; nbRank[h_chr_owner[c]] += nb; }
@@ -275,14 +282,17 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
         if (!localErr) { rc = canvas_h2d_small(ctx, dRankOff, rankOff.data(), (size_t)nchr * 8); if (rc) fail_local(rc); }
     }
     if (!localErr) hipLaunchKernelGGL(k_sh_unshard, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dRecv, (int64_t)(slotB / 4), maxB, dBinOff, dOwner, dRankOff, nchr, total, d_chr, d_start, d_stop, d_gc, d_count);
+    mark("bin all-gather + unshard");
     // ---- 3. CanvasClean on the whole genome (every rank, deterministic), F2 hand-off, chromosome offsets of the cleaned bins
     std::vector<uint8_t> noY((size_t)nchr, 0);
     double lsd = -1.0; int64_t nClean = 0; int32_t info[8];
     if (!localErr) { rc = canvas_clean2(ctx, total, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y ? h_chr_is_y : noY.data(), clean_flags, min_bins_per_gc, &lsd, &nClean, info); if (rc) fail_local(rc); }
     if (h_nbins_clean) *h_nbins_clean = nClean;
     if (h_local_sd) *h_local_sd = lsd;
-    if (!localErr) { rc = canvas_quantize_f2(ctx, d_count, nClean, d_cov); if (rc) fail_local(rc); }
+    const void* hCovQ = nullptr;                                   // the genome-wide quartile counters come out of the quantisation sweep and arrive with the offsets' synchronisation
+    if (!localErr) { rc = cvx_quantize_f2_covq(ctx, d_count, nClean, d_cov, &hCovQ); if (rc) fail_local(rc); }
     if (!localErr) { rc = canvas_chromosome_offsets(ctx, d_chr, nClean, nchr, h_chr_offset); if (rc) fail_local(rc); }
+    mark("clean + f2 + offsets");
     // ---- 4. PerSampleHMM of the owned chromosomes (compact copy of their coverage; quartiles over the whole sample)
     std::vector<int64_t> loff(nl + 1, 0);
     if (!localErr) for (int i = 0; i < nl; i++) loff[i + 1] = loff[i] + (h_chr_offset[mine[i] + 1] - h_chr_offset[mine[i]]);
@@ -291,7 +301,7 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
     if (nLocal > 0) {
         for (int i = 0; i < nl && !localErr; i++) { const int64_t b0 = h_chr_offset[mine[i]], T = loff[i + 1] - loff[i];
             if (T > 0 && hipMemcpyAsync(dCovL + loff[i], d_cov + b0, (size_t)T * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = "canvas_sample_pipeline_sharded: copy of the owned coverage failed"; fail_local(CANVAS_ERR_HIP); } }
-        if (!localErr) { rc = cvx_hmm_per_sample_subset(ctx, nl, dCovL, loff.data(), d_cov, nClean, dStateL); if (rc) fail_local(rc); }
+        if (!localErr) { rc = cvx_hmm_per_sample_subset(ctx, nl, dCovL, loff.data(), d_cov, nClean, dStateL, hCovQ); if (rc) fail_local(rc); }
         // boundary records of the owned chromosomes
         std::vector<long long> loff64(loff.begin(), loff.end()); std::vector<int32_t> l2g(mine.begin(), mine.end());
         if (!localErr) { rc = canvas_h2d_small(ctx, dLoff, loff64.data(), (size_t)(nl + 1) * 8); if (rc) fail_local(rc); }
@@ -303,6 +313,7 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
             hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(64), 0, ctx->stream, dBlk, nb, dNrec);
         }
     }
+    mark("hmm of the owned chromosomes + record flags");
     // the records are built in the workspace of the context (nothing else runs between here and the gather); its size follows maxPer
     for (int attempt = 0; attempt < 2; attempt++) {
         const size_t recBytes = al((size_t)maxPer * 4) + al((size_t)W * (1 + (size_t)maxPer) * 4) + 4096;
@@ -342,9 +353,12 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
         if (bad) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_sample_pipeline_sharded: the gathered boundary records do not cover every bin");
         break;
     }
+    mark("boundary records + all-gather + states");
     int64_t nseg = 0;
     rc = canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
     if (h_nsegments) *h_nsegments = nseg;
+    mark("segment ids");
+    if (shTiming && ctx->rank == 0) { fprintf(stderr, "sharded pipeline us:"); for (size_t i = 1; i < marks.size(); i++) fprintf(stderr, " %s %.0f |", marks[i].first, std::chrono::duration<double, std::micro>(marks[i].second - marks[i - 1].second).count()); fprintf(stderr, "\n"); }
     return CANVAS_OK;
 }
 
