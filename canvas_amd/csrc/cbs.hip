@@ -323,7 +323,7 @@ static constexpr int MT_LAG_C[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700
 __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs, int bootstrap) {
     __shared__ uint32_t mtA[624], mtB[624];
     const PermReq& R = reqs[blockIdx.x];
-    if (R.cont) return;
+    if (R.cont || R.fy == 2) return;
     uint32_t* __restrict__ draws = R.P.draws;
     const long long seqMax = bootstrap && R.total >= MT_BOOT_MIN ? 19937LL : MT_HISTORY;     // bootstrap: only the first 19937 outputs come from here (see k_mt_classes)
     const long long total = R.total < seqMax ? R.total : seqMax;
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict_
     // index every line was written by 8 different L2s, 4 bytes at a time (PMC: 43 GB of WRITE_SIZE for 4.8 GB of draws).  Sequences r = x * (stride / 8) + k for the k-th
     // workgroup of XCD x: a line's 16 writers share an L2 and run side by side.
     const int bx = (int)blockIdx.x, r = stride >= 8 ? (bx & 7) * (stride >> 3) + (bx >> 3) : bx, tid = (int)threadIdx.x;
-    if (boot && (R.cont || R.total < MT_BOOT_MIN)) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
+    if (R.fy == 2 || (boot && (R.cont || R.total < MT_BOOT_MIN))) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
     uint32_t* __restrict__ d = R.P.draws;
     const long long start = boot ? 19937LL * stride : (R.cont ? 0 : MT_HISTORY);        // first position to generate; the 19937 * stride positions in front of it are there
     const long long end = boot ? (R.total < 19937LL * 2 * stride ? R.total : 19937LL * 2 * stride) : R.total;
@@ -444,7 +444,8 @@ __global__ void __launch_bounds__(256) k_mt_snapshots(const PermReq* __restrict_
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
     const PermReq& R = reqs[ri];
     const int b = (int)blockIdx.x - R.blockBase;
-    const long long end = (long long)(b + 1) * R.n;       // >= 1024 > 624
+    if (R.fy == 2) return;                                 // (draws of short segments come from the host: perm_loop_small_gpu)
+    const long long end = (long long)(b + 1) * R.n;       // (fewer than 624 outputs in front of it in a batch that continues nothing: the host advances the start state instead, perm_loop_gpu)
     uint32_t* s = R.snaps + (size_t)b * 625;
     for (int i = threadIdx.x; i < 624; i += 256) s[i] = mt_untemper(R.P.draws[end - 624 + i]);
     if (threadIdx.x == 0) s[624] = 624u;
@@ -634,7 +635,7 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
     int ri = 0;
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
     const PermReq& R = reqs[ri];
-    if (!R.fy) return;
+    if (R.fy != 1) return;
     const double* __restrict__ x = R.x; const int n = R.n; const PermBuf P = R.P;
     const int b = (int)blockIdx.x - R.blockBase, tid = threadIdx.x;
     const size_t o = (size_t)b * n;
@@ -759,6 +760,51 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
     if (sOver) { if (tid == 0) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; } return; }
     __syncthreads();
     perm_stat_tail(px, sx, n, R.hk, R.al0, R.tss, R.errBound, R.pstat, b, shD, shM, sT, sEdge);
+}
+
+// ---- segments of at most 200 bins (the non-hybrid test, TMaxP: CBSTStatistic.cs:599-934): one wave per permutation, and the value is EXACT — the swaps and the prefix sums run
+// on lane 0 in the reference's order (200 dependent steps on LDS), the arc maximum is order-free and every arc is evaluated with the host's expression, the reference's block
+// pruning is lossless.  The draws come with the request (the host generator produces them: a few thousand per batch), so no device generator is involved.
+#define PS_MAXN 256
+__global__ void __launch_bounds__(64) k_perm_small(const PermReq* __restrict__ reqs, int nreq) {
+    __shared__ double px[PS_MAXN], sx[PS_MAXN], sC[PS_MAXN];
+    __shared__ double sBss0;
+    int ri = 0;
+    { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
+    const PermReq& R = reqs[ri];
+    if (R.fy != 2) return;
+    const int n = R.n, al0 = R.al0, b = (int)blockIdx.x - R.blockBase, lane = threadIdx.x;
+    const double rn = (double)n;
+    const uint32_t* __restrict__ draws = R.P.draws + (size_t)b * n;
+    for (int i = lane; i < n; i += 64) px[i] = R.x[i];
+    for (int L = lane; L < n; L += 64) { const double rj = (double)L; sC[L] = (L >= al0 && L <= n - al0) ? rn / (rj * (rn - rj)) : -1.0; }
+    __syncthreads();
+    if (lane == 0) {
+        for (int i = n - 1; i >= 0; i--) {                          // ChangePoint.cs:411-419
+            const double cc = (double)draws[n - 1 - i] * (1.0 / 4294967296.0);
+            int j = (int)(cc * (double)(i + 1)); j = j > i ? i : j;
+            const double t = px[i]; px[i] = px[j]; px[j] = t;
+        }
+        // prefix sums and the global extremes as build_blocks finds them (CBSTStatistic.cs:44-110): both start at (0, position n); strictly smaller / larger values replace them
+        double run = 0.0, mn = 0.0, mx = 0.0; int imn = n, imx = n;
+        for (int i = 0; i < n; i++) { run = run + px[i]; sx[i] = run; if (run < mn) { mn = run; imn = i + 1; } if (run > mx) { mx = run; imx = i + 1; } }
+        const double rj = (double)(imx > imn ? imx - imn : imn - imx), d = mx - mn;
+        sBss0 = (rn / (rj * (rn - rj))) * (d * d);
+    }
+    __syncthreads();
+    double best = -1.0;
+    for (int a = lane; a < n; a += 64) {
+        const double s0 = sx[a];
+        for (int L = al0; a + L < n && L <= n - al0; L++) { const double d = fabs(sx[a + L] - s0), v = sC[L] * (d * d); best = v > best ? v : best; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const double o = __hiloint2double(__shfl_xor(__double2hiint(best), d), __shfl_xor(__double2loint(best), d)); best = o > best ? o : best; }
+    if (lane == 0) {
+        double bss = sBss0; if (best > bss) bss = best;
+        double t = R.tss; if (t <= bss + 0.0001) t = bss + 1.0;       // CBSTStatistic.cs:334-337
+        const double v = bss / ((t - bss) / (rn - 2.0));
+        R.pstat[2 * b] = v; R.pstat[2 * b + 1] = v;
+    }
 }
 
 // ================================================================================================ host: scalar pieces of the reference
@@ -1200,7 +1246,7 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
 }
 
 // ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
-#define PERM_GPU_MIN_N 1024          // shorter segments stay on the host: measured with 201 (every hybrid segment on the device) the WGS run is identical but 12 % slower (0.555 vs 0.496 s) — a permutation of a few hundred elements is microseconds of host work and a launch round trip on the device
+#define PERM_GPU_MIN_N 201           // every hybrid segment (> 200 bins) takes the device engine (round 2 kept those below 1024 bins on the host: 12 % slower on the device then; with this round's kernels 0.19 vs 0.23 s on the 4.7 M-bin probe); CANVAS_CBS_PERM_GPU_MIN_N overrides
 #define PERM_TARGET_ELEMS (64 << 20) // permuted elements per batch (44 B of workspace each)
 #define PERM_FY_MIN_N 16384          // segments from this length on take k_perm_fy (block-wise simulation of the swaps); shorter ones k_perm_stat (CANVAS_CBS_FY_MIN_N overrides: test hook)
 // (batches of up to 2048 permutations for loops that run long were tried: k_perm_stat then takes 26 ms instead of 3.5 ms for 256 — the same rate per permutation — so
@@ -1263,7 +1309,9 @@ static int32_t tail_p_decide(PermGpu& PG, double b, double delta, int m, double 
 // workgroup per request: the generator is sequential per chromosome, the chromosomes are not) and a single k_perm_stat launch (one
 // workgroup per permutation of every request).  Concurrency then does not depend on how many hardware queues the runtime maps the
 // per-thread streams to.
-struct PermHostReq { PermReq r; long long prevTotal = 0; double* hStat; uint32_t* hSnaps; const double* hX = nullptr; double* dX = nullptr; size_t xBytes = 0; bool done = false; int32_t rc = CANVAS_OK; };
+struct PermHostReq { PermReq r; long long prevTotal = 0; double* hStat; uint32_t* hSnaps; const double* hX = nullptr; double* dX = nullptr; size_t xBytes = 0;
+                     const uint32_t* hDraws = nullptr; size_t drawBytes = 0;      // short segments: the draws of the batch, produced by the host generator
+                     bool done = false; int32_t rc = CANVAS_OK; };
 struct PermService {
     canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
     ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
@@ -1339,10 +1387,11 @@ struct PermService {
         const int R = (int)batch.size();
         int blocks = 0; long long maxTotal = 0;
         for (int i = 0; i < R; i++) {
-            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
+            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
             if (batch[i]->r.cont)    // history of this batch = the last MT_HISTORY outputs of the previous one (same buffer, no overlap: prevTotal >= MT_HISTORY)
                 CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws - MT_HISTORY, batch[i]->r.P.draws + (batch[i]->prevTotal - MT_HISTORY), (size_t)MT_HISTORY * 4, hipMemcpyDeviceToDevice, stream));
             if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // pinned source
+            if (batch[i]->drawBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws, batch[i]->hDraws, batch[i]->drawBytes, hipMemcpyHostToDevice, stream));
         }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
         static const bool dbg = getenv("CANVAS_CBS_DEBUG_BATCHES") != nullptr;
@@ -1352,7 +1401,7 @@ struct PermService {
         static const bool stepwise = getenv("CANVAS_CBS_MT_STEPWISE") != nullptr;     // the previous generator (one launch per 79 744 outputs), kept for comparison
         static const bool bootstrap = !stepwise && getenv("CANVAS_CBS_MT_NO_BOOTSTRAP") == nullptr;
         bool anyFresh = false; long long maxFresh = 0;
-        for (int i = 0; i < R; i++) if (!batch[i]->r.cont) { anyFresh = true; if (batch[i]->r.total >= MT_BOOT_MIN) maxFresh = std::max(maxFresh, batch[i]->r.total); }
+        for (int i = 0; i < R; i++) if (!batch[i]->r.cont && batch[i]->r.fy != 2) { anyFresh = true; if (batch[i]->r.total >= MT_BOOT_MIN) maxFresh = std::max(maxFresh, batch[i]->r.total); }
         if (anyFresh) hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs, bootstrap ? 1 : 0);
         if (anyFresh && bootstrap)
             for (int sd = 1; sd < MT_STRIDE && 19937LL * sd < maxFresh; sd <<= 1) hipLaunchKernelGGL(k_mt_classes, dim3(sd, R), dim3(MTC_T), 0, stream, dReqs, sd, 1);
@@ -1362,14 +1411,15 @@ struct PermService {
         else if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
         if (dbg) msB = lap();
         hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
-        bool anyFy = false, anyOld = false; for (int i = 0; i < R; i++) (batch[i]->r.fy ? anyFy : anyOld) = true;
+        bool anyFy = false, anyOld = false, anySmall = false; for (int i = 0; i < R; i++) (batch[i]->r.fy == 2 ? anySmall : batch[i]->r.fy ? anyFy : anyOld) = true;
         if (anyOld) hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         if (anyFy) hipLaunchKernelGGL(k_perm_fy, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
+        if (anySmall) hipLaunchKernelGGL(k_perm_small, dim3(blocks), dim3(64), 0, stream, dReqs, R);
         if (dbg) { const double msC = lap(); int nc = 0, maxN = 0; for (int i = 0; i < R; i++) { nc += batch[i]->r.cont; maxN = std::max(maxN, batch[i]->r.n); }
                    fprintf(stderr, "cbs batch: %d requests (%d continued), %d permutations, longest segment %d, %d stride steps: sequential %.2f ms, strided %.2f ms, statistics %.2f ms\n", R, nc, blocks, maxN, steps, msA, msB, msC); }
         for (int i = 0; i < R; i++) {
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hStat, batch[i]->r.pstat, (size_t)batch[i]->r.nb * 16, hipMemcpyDeviceToHost, stream));
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hSnaps, batch[i]->r.snaps, (size_t)batch[i]->r.nb * 625 * 4, hipMemcpyDeviceToHost, stream));
+            if (batch[i]->hSnaps) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hSnaps, batch[i]->r.snaps, (size_t)batch[i]->r.nb * 625 * 4, hipMemcpyDeviceToHost, stream));
         }
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
@@ -1457,13 +1507,22 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         auto tP = now();
         struct PostAcc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~PostAcc() { a += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } postAcc{st.ns_post, tP};
         st.dev_batches++;
+        // generator state behind permutation b of this batch.  The device snapshot is rebuilt from the last 624 outputs in front of that point: fewer than 624 exist when a
+        // batch that does not continue another one is cut short inside its first permutations (segments of a few hundred bins) — then the batch's start state is advanced on
+        // the host, at most 623 draws.
+        const bool contBatch = q.r.cont != 0;
+        uint32_t tmpState[625];
+        auto state_after = [&](int b) -> const uint32_t* {
+            if (contBatch || (long long)(b + 1) * n >= 624) return hSnaps + (size_t)b * 625;
+            MT m(0u); m.set_state(cur); for (long long t = 0; t < (long long)(b + 1) * n; t++) (void)m.u32(); m.get_state(tmpState); return tmpState;
+        };
         if (getenv("CANVAS_CBS_TEST_VERIFY")) {      // test hook: every device interval must contain the statistic computed in the reference's order
             for (int b = 0; b < nb; b++) {
-                MT m2(0u); m2.set_state(b == 0 ? cur : hSnaps + (size_t)(b - 1) * 625);
+                MT m2(0u); m2.set_state(b == 0 ? cur : state_after(b - 1));
                 px.resize(n); sx.resize(n);
                 xperm(gd, px.data(), n, m2);
                 const double exact = htmaxp_host(hk, tss, px.data(), n, sx.data(), al0);
-                MT m3(0u); m3.set_state(hSnaps + (size_t)b * 625);      // the device snapshot must continue the stream exactly where the host generator is
+                MT m3(0u); m3.set_state(state_after(b));      // the device snapshot must continue the stream exactly where the host generator is
                 bool same = true; for (int t = 0; t < 1400; t++) if (m2.u32() != m3.u32()) { same = false; break; }
                 st.verified++;
                 if (!(hStat[2 * b] <= exact && exact <= hStat[2 * b + 1]) || !same ||
@@ -1478,20 +1537,80 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
             if (ostat <= lo) rej = true;
             else if (ostat > hi) rej = false;
             else {      // inside the rounding interval: this permutation again, in the reference's order of operations
-                MT m2(0u); m2.set_state(b == 0 ? cur : hSnaps + (size_t)(b - 1) * 625);
+                MT m2(0u); m2.set_state(b == 0 ? cur : state_after(b - 1));
                 px.resize(n); sx.resize(n);
                 xperm(gd, px.data(), n, m2);
                 rej = ostat <= htmaxp_host(hk, tss, px.data(), n, sx.data(), al0);
                 st.exact_rechecks++;
             }
             if (rej) { nrej++; k++; }
-            if (nrej > nrejc) { rnd.set_state(hSnaps + (size_t)b * 625); outcome = 0; return CANVAS_OK; }
-            if (np >= sbdry[k - 1]) { rnd.set_state(hSnaps + (size_t)b * 625); return CANVAS_OK; }
+            if (nrej > nrejc) { rnd.set_state(state_after(b)); outcome = 0; return CANVAS_OK; }
+            if (np >= sbdry[k - 1]) { rnd.set_state(state_after(b)); return CANVAS_OK; }
         }
-        memcpy(cur, hSnaps + (size_t)(nb - 1) * 625, sizeof cur);
+        { const uint32_t* sEnd = state_after(nb - 1); uint32_t keepState[625]; memcpy(keepState, sEnd, sizeof keepState); memcpy(cur, keepState, sizeof cur); }
         B = std::min(maxB, B * 2);
     }
     rnd.set_state(cur);
+    return CANVAS_OK;
+}
+
+// The same stopping rule for the segments of at most 200 bins (the non-hybrid test: XPerm + TMaxP, ChangePoint.cs:337-364): batches of up to 2048 permutations, one wave each
+// (k_perm_small).  The draws of a batch are produced by the chromosome's host generator in the reference's order and travel with the request; the statistic comes back exact, so
+// the comparison ostat <= pstat is the reference's own.  rnd ends behind the last permutation the rule looked at: the batch's start state advanced by that many draws.
+static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int al0, double ostat, int nrejc, int k, const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st, int& outcome) {
+    canvas_ctx* ctx = PG.ctx;
+    const int maxB = 2048;
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t oX = 0, oStat = al((size_t)n * 8), oDraws = oStat + al((size_t)maxB * 16), total = oDraws + al(((size_t)maxB * n + (size_t)MT_HISTORY) * 4) + 256;
+    const size_t pX = 0, pStat = al((size_t)n * 8), pDraws = pStat + al((size_t)maxB * 16), pinTotal = pDraws + al((size_t)maxB * n * 4);
+    size_t want = total, wantPin = pinTotal;
+    if (PG.reserveElems) { const size_t re = PG.reserveElems, rn = PG.reserveN;      // never shrink below what perm_loop_gpu will ask for: one allocation per engine
+        want = std::max(want, al(rn * 8) + al(625 * 4) + al(256 * 625 * 4) + al(256 * 16) + al((re + (size_t)MT_HISTORY) * 4) + 5 * al(re * 4) + 2 * al((re + 256) * 4) + 2 * al(re * 8));
+        wantPin = std::max(wantPin, al(rn * 8) + al(256 * 625 * 4) + al(256 * 16)); }
+    int32_t rc = PG.ensure(want, wantPin); if (rc) return rc;
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    char* d = PG.buf; char* h = PG.pin;
+    double* dX = (double*)(d + oX); double* dStat = (double*)(d + oStat); uint32_t* dDraws = (uint32_t*)(d + oDraws) + MT_HISTORY;
+    double* hX = (double*)(h + pX); double* hStat = (double*)(h + pStat); uint32_t* hDraws = (uint32_t*)(h + pDraws);
+    memcpy(hX, gd, (size_t)n * 8);
+    bool needUpload = true;
+    int nrej = 0; uint32_t np = 0;
+    int B = 256;
+    outcome = 1;
+    std::vector<double> px, sx;
+    while (np < nPerm) {
+        const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
+        const MT start = rnd;                                      // the batch's draws: nb * n outputs of the chromosome's generator, in order
+        for (size_t t = 0; t < (size_t)nb * n; t++) hDraws[t] = rnd.u32();
+        PermHostReq q;
+        memset(q.r.state, 0, sizeof q.r.state); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = nullptr; q.r.x = dX; q.r.hk = 0; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = 0.0;
+        memset(&q.r.P, 0, sizeof q.r.P); q.r.P.draws = dDraws; q.r.pstat = dStat; q.r.blockBase = 0; q.r.cont = 0; q.r.fy = 2; q.hStat = hStat; q.hSnaps = nullptr;
+        if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
+        q.hDraws = hDraws; q.drawBytes = (size_t)nb * n * 4;
+        auto tS = std::chrono::steady_clock::now();
+        rc = PG.svc->submit(q); if (rc) return rc;
+        st.ns_submit += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tS).count();
+        st.dev_batches++;
+        auto stop_at = [&](int b) { rnd = start; for (size_t t = 0; t < (size_t)(b + 1) * n; t++) (void)rnd.u32(); };
+        for (int b = 0; b < nb; b++) {
+            np++;
+            st.perms++; st.perm_elems += n; st.dev_perms++;
+            double pstat = hStat[2 * b];
+            if (!(pstat == pstat) || getenv("CANVAS_CBS_TEST_VERIFY")) {      // a NaN (degenerate extremes) or the test hook: this permutation again on the host, in the reference's order
+                MT m2 = start; for (size_t t = 0; t < (size_t)b * n; t++) (void)m2.u32();
+                px.resize(n); sx.resize(n);
+                xperm(gd, px.data(), n, m2);
+                const double exact = tmaxp_host(tss, px.data(), n, sx.data(), al0);
+                if (getenv("CANVAS_CBS_TEST_VERIFY")) { st.verified++; if (memcmp(&exact, &pstat, 8) != 0 && (exact == exact || pstat == pstat)) st.violations++; }
+                else st.exact_rechecks++;
+                pstat = exact;
+            }
+            if (ostat <= pstat) { nrej++; k++; }
+            if (nrej > nrejc) { stop_at(b); outcome = 0; return CANVAS_OK; }
+            if (np >= sbdry[k - 1]) { stop_at(b); return CANVAS_OK; }
+        }
+        B = std::min(maxB, B * 2);
+    }
     return CANVAS_OK;
 }
 
@@ -1571,11 +1690,18 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
         int k = nrejc * (nrejc + 1) / 2 + 1;
         auto t0 = std::chrono::steady_clock::now();
         struct Acc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } };
-        if (hybrid && n >= PERM_GPU_MIN_N && hk <= PG_MAXK && getenv("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr) {
+        static const int permGpuMinN = getenv("CANVAS_CBS_PERM_GPU_MIN_N") ? atoi(getenv("CANVAS_CBS_PERM_GPU_MIN_N")) : PERM_GPU_MIN_N;
+        if (hybrid && n >= permGpuMinN && hk <= PG_MAXK && getenv("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr) {
             Acc acc{st.ns_dev, t0};
             struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.devLoops++; } } lc{t0};
             int outcome = 1;
             int32_t rc = perm_loop_gpu(PG, gd, n, tss, nPerm, hk, al0, ostat, nrejc, k, sbdry, rnd, st, outcome); if (rc) return rc;
+            if (outcome == 0) return CANVAS_OK;
+        } else if (!hybrid && n <= 200 && n >= 4 && PG.svc && getenv("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr && getenv("CANVAS_CBS_HOST_SMALL") == nullptr) {
+            Acc acc{st.ns_dev, t0};
+            struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.devLoops++; } } lc{t0};
+            int outcome = 1;
+            int32_t rc = perm_loop_small_gpu(PG, gd, n, tss, nPerm, al0, ostat, nrejc, k, sbdry, rnd, st, outcome); if (rc) return rc;
             if (outcome == 0) return CANVAS_OK;
         } else {
             Acc acc{st.ns_hostperm, t0};
