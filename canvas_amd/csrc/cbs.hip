@@ -762,12 +762,20 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
     perm_stat_tail(px, sx, n, R.hk, R.al0, R.tss, R.errBound, R.pstat, b, shD, shM, sT, sEdge);
 }
 
-// ---- segments of at most 200 bins (the non-hybrid test, TMaxP: CBSTStatistic.cs:599-934): one wave per permutation, and the value is EXACT — the swaps and the prefix sums run
-// on lane 0 in the reference's order (200 dependent steps on LDS), the arc maximum is order-free and every arc is evaluated with the host's expression, the reference's block
-// pruning is lossless.  The draws come with the request (the host generator produces them: a few thousand per batch), so no device generator is involved.
+// ---- segments of at most 200 bins (the non-hybrid test, TMaxP: CBSTStatistic.cs:599-934): one wave per permutation, and the value is EXACT.  The swaps and the prefix sums run
+// on lane 0 in the reference's order (200 dependent steps on LDS) together with build_blocks' block extremes (CBSTStatistic.cs:44-110).  The arc maximum itself is order-free,
+// but WHICH arcs the reference looks at is part of the result for blocks this small: for a block pair it scans the lengths alenlo .. min(alen, n - alen) and n - min(alen, n - alen)
+// .. alenhi, alen being the distance between the pair's extremes (CBSTStatistic.cs:233-326) — when the extremes are closer than the minimum width nothing of the pair is scanned,
+// and with a dozen elements per block that happens (a randomised soak run found a permutation whose exhaustive maximum is larger than the reference's).  Every lane therefore
+// evaluates its arcs with the host's expression and keeps those whose length lies in the reference's ranges for the arc's block pair; pairs the reference skips because their
+// bound is below the running maximum cannot hold the maximum of the scanned set, so the order of its visits does not matter.  The draws come with the request (host generator).
 #define PS_MAXN 256
+#define PS_MAXB 16
 __global__ void __launch_bounds__(64) k_perm_small(const PermReq* __restrict__ reqs, int nreq) {
     __shared__ double px[PS_MAXN], sx[PS_MAXN], sC[PS_MAXN];
+    __shared__ double sBmn[PS_MAXB], sBmx[PS_MAXB];
+    __shared__ int sBB[PS_MAXB + 1], sImn[PS_MAXB], sImx[PS_MAXB], sBlkOf[PS_MAXN + 1];
+    __shared__ int sR[PS_MAXB * PS_MAXB][4];
     __shared__ double sBss0;
     int ri = 0;
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
@@ -775,27 +783,63 @@ __global__ void __launch_bounds__(64) k_perm_small(const PermReq* __restrict__ r
     if (R.fy != 2) return;
     const int n = R.n, al0 = R.al0, b = (int)blockIdx.x - R.blockBase, lane = threadIdx.x;
     const double rn = (double)n;
+    const int nb = n >= 50 ? (int)rint(sqrt(rn)) : 1;            // dn_round(sqrt(n)): half to even (at most 14 for n <= 200)
     const uint32_t* __restrict__ draws = R.P.draws + (size_t)b * n;
     for (int i = lane; i < n; i += 64) px[i] = R.x[i];
     for (int L = lane; L < n; L += 64) { const double rj = (double)L; sC[L] = (L >= al0 && L <= n - al0) ? rn / (rj * (rn - rj)) : -1.0; }
+    if (lane < nb) sBB[lane + 1] = (int)rint(rn * (((double)lane + 1.0) / (double)nb));      // bb[i] = round(rn * ((i + 1.0) / nb)), 1-based last position of block i
+    if (lane == 0) sBB[0] = 0;
     __syncthreads();
+    for (int p = 1 + lane; p <= n; p += 64) { int k = 0; while (k + 1 < nb && p > sBB[k + 1]) k++; sBlkOf[p] = k; }
     if (lane == 0) {
         for (int i = n - 1; i >= 0; i--) {                          // ChangePoint.cs:411-419
             const double cc = (double)draws[n - 1 - i] * (1.0 / 4294967296.0);
             int j = (int)(cc * (double)(i + 1)); j = j > i ? i : j;
             const double t = px[i]; px[i] = px[j]; px[j] = t;
         }
-        // prefix sums and the global extremes as build_blocks finds them (CBSTStatistic.cs:44-110): both start at (0, position n); strictly smaller / larger values replace them
-        double run = 0.0, mn = 0.0, mx = 0.0; int imn = n, imx = n;
-        for (int i = 0; i < n; i++) { run = run + px[i]; sx[i] = run; if (run < mn) { mn = run; imn = i + 1; } if (run > mx) { mx = run; imx = i + 1; } }
-        const double rj = (double)(imx > imn ? imx - imn : imn - imx), d = mx - mn;
+        // build_blocks: prefix sums; per block the first minimum / maximum (1-based positions); the global extremes start at (0, position n) and are replaced by strictly smaller / larger block extremes
+        double run = 0.0, gmn = 0.0, gmx = 0.0; int igmn = n, igmx = n;
+        for (int k = 0; k < nb; k++) {
+            const int ilo = sBB[k] + 1, ihi = sBB[k + 1];
+            run = run + px[ilo - 1]; sx[ilo - 1] = run;
+            double mn = run, mx = run; int imn = ilo, imx = ilo;
+            for (int i = ilo + 1; i <= ihi; i++) { run = run + px[i - 1]; sx[i - 1] = run; if (run < mn) { mn = run; imn = i; } if (run > mx) { mx = run; imx = i; } }
+            sBmn[k] = mn; sBmx[k] = mx; sImn[k] = imn; sImx[k] = imx;
+            if (mn < gmn) { gmn = mn; igmn = imn; }
+            if (mx > gmx) { gmx = mx; igmx = imx; }
+        }
+        const double rj = (double)(igmx > igmn ? igmx - igmn : igmn - igmx), d = gmx - gmn;
         sBss0 = (rn / (rj * (rn - rj))) * (d * d);
     }
     __syncthreads();
+    // the lengths the reference scans for every block pair (bi <= bj): [lo1, hi1] and [lo2, hi2]
+    for (int t = lane; t < nb * nb; t += 64) {
+        const int bi = t / nb, bj = t % nb;
+        int lo1 = 1, hi1 = 0, lo2 = 1, hi2 = 0;
+        if (bi <= bj) {
+            const int ilo = sBB[bi] + 1, ihi = sBB[bi + 1], jlo = sBB[bj] + 1, jhi = sBB[bj + 1], nal0 = n - al0;
+            int alenhi = jhi - ilo; if (alenhi > nal0) alenhi = nal0;
+            int alenlo = bi == bj ? 1 : jlo - ihi; if (alenlo < al0) alenlo = al0;
+            const double s1 = fabs(sBmx[bj] - sBmn[bi]), s2 = fabs(sBmx[bi] - sBmn[bj]);
+            int alen = s1 > s2 ? sImx[bj] - sImn[bi] : sImn[bj] - sImx[bi]; alen = alen < 0 ? -alen : alen;
+            int amax = alen > n - alen ? n - alen : alen;
+            const double rnov2 = rn / 2;
+            if ((double)alenlo <= rnov2 && alenlo <= amax) { lo1 = alenlo; hi1 = amax; }
+            amax = n - amax;
+            if ((double)alenhi >= rnov2 && alenhi >= amax) { lo2 = amax; hi2 = alenhi; }
+        }
+        sR[bi * PS_MAXB + bj][0] = lo1; sR[bi * PS_MAXB + bj][1] = hi1; sR[bi * PS_MAXB + bj][2] = lo2; sR[bi * PS_MAXB + bj][3] = hi2;
+    }
+    __syncthreads();
     double best = -1.0;
-    for (int a = lane; a < n; a += 64) {
+    for (int a = lane; a < n; a += 64) {                            // arc between the prefix sums a and a + L = 1-based positions p = a + 1, q = p + L
         const double s0 = sx[a];
-        for (int L = al0; a + L < n && L <= n - al0; L++) { const double d = fabs(sx[a + L] - s0), v = sC[L] * (d * d); best = v > best ? v : best; }
+        const int bi = sBlkOf[a + 1];
+        for (int L = al0; a + L < n && L <= n - al0; L++) {
+            const int* r = sR[bi * PS_MAXB + sBlkOf[a + 1 + L]];
+            if (!((L >= r[0] && L <= r[1]) || (L >= r[2] && L <= r[3]))) continue;
+            const double d = fabs(sx[a + L] - s0), v = sC[L] * (d * d); best = v > best ? v : best;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const double o = __hiloint2double(__shfl_xor(__double2hiint(best), d), __shfl_xor(__double2loint(best), d)); best = o > best ? o : best; }
@@ -1097,6 +1141,25 @@ static void block_search(const double* sx, int n, int al0, const Blocks& B, doub
         }
     }
 }
+// Would block_search look at the arc from position p (1-based) of length L?  For a block pair it scans the lengths alenlo .. min(alen, n - alen) and n - min(alen, n - alen) .. alenhi,
+// alen = the distance between the pair's extremes (CBSTStatistic.cs:233-326): the lengths in between cannot beat the arc between the extremes — but when that arc is shorter than
+// the minimum width (or otherwise outside the scanned lengths) nothing vouches for them, and the reference simply does not see those arcs.  The device searches take the maximum
+// over ALL admissible arcs; they are the reference's result only if the maximiser is an arc the reference scans (checked with this; otherwise the host replays the search).
+static bool ref_scans_arc(const Blocks& B, int n, int al0, int p, int L) {
+    const std::vector<int>& bb = B.bb; const int nb = B.nb, q = p + L;
+    auto block_of = [&](int pos) { int k = 0; while (k + 1 < nb && pos > bb[k]) k++; return k; };       // 0-based block of a 1-based position
+    const int bi = block_of(p), bj = block_of(q);
+    const int ilo = bi == 0 ? 1 : bb[bi - 1] + 1, ihi = bb[bi], jlo = bj == 0 ? 1 : bb[bj - 1] + 1, jhi = bb[bj], nal0 = n - al0;
+    int alenhi = jhi - ilo; if (alenhi > nal0) alenhi = nal0;
+    int alenlo = bi == bj ? 1 : jlo - ihi; if (alenlo < al0) alenlo = al0;
+    const double s1 = std::fabs(B.bpsmax[bj] - B.bpsmin[bi]), s2 = std::fabs(B.bpsmax[bi] - B.bpsmin[bj]);
+    int alen = s1 > s2 ? std::abs(B.ibmax[bj] - B.ibmin[bi]) : std::abs(B.ibmin[bj] - B.ibmax[bi]);
+    int amax = alen > n - alen ? n - alen : alen;
+    const double rn = (double)n, rnov2 = rn / 2;
+    if ((double)alenlo <= rnov2 && alenlo <= amax && L >= alenlo && L <= amax) return true;
+    amax = n - amax;
+    return (double)alenhi >= rnov2 && alenhi >= amax && L >= amax && L <= alenhi;
+}
 static double normalise(double bssmax, double tss, double rn) { if (tss <= bssmax + 0.0001) tss = bssmax + 1.0; return bssmax / ((tss - bssmax) / (rn - 2.0)); }   // CBSTStatistic.cs:334-337
 static void tmaxo_host(const double* x, int n, double tss, double* sx, int iseg[2], double& ostat, int al0) {           // CBSTStatistic.cs:19-341
     Blocks B; build_blocks(x, n, sx, B);
@@ -1139,7 +1202,7 @@ static double htmaxp_host(int k, double tss, const double* px, int n, double* sx
     return normalise(h, tss, rn);
 }
 
-struct Stats { std::atomic<long long> tailp_dev{0}, tailp_host{0}; std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
+struct Stats { std::atomic<long long> unscanned_max{0}; std::atomic<long long> tailp_dev{0}, tailp_host{0}; std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
 
 // GPU arc search service shared by the chromosome threads
 struct ArcHostReq { ArcReq r; ArcPReq p; bool pruned = true; const void* hSx; void* hMax; void* hFirst; unsigned long long* hOut; bool done = false; int32_t rc = CANVAS_OK; };
@@ -1189,7 +1252,11 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
             st.gpu_pairs += (long long)hOut[3] * AP_BK * AP_BK;
             const double M = hOut[3] ? __builtin_bit_cast(double, hOut[0]) : -1.0;
             if (!(M > bss0)) { ostat = normalise(bss0, tss, rn); iseg[0] = ti; iseg[1] = tj; return CANVAS_OK; }   // the incumbent survives every strict '>' test
-            if (hOut[1] == 1) { const int L = (int)(hOut[2] >> 32), i0 = (int)(hOut[2] & 0xffffffffull); ostat = normalise(M, tss, rn); iseg[0] = i0 + 1; iseg[1] = i0 + 1 + L; return CANVAS_OK; }
+            if (hOut[1] == 1) {
+                const int L = (int)(hOut[2] >> 32), i0 = (int)(hOut[2] & 0xffffffffull);
+                if (ref_scans_arc(B, n, al0, i0 + 1, L)) { ostat = normalise(M, tss, rn); iseg[0] = i0 + 1; iseg[1] = i0 + 1 + L; return CANVAS_OK; }
+                st.unscanned_max++;      // the best admissible arc is one the reference does not look at: its own (smaller) maximum comes from the host replay
+            }
             ok = false;       // several arcs attain the maximum: the winner depends on the reference's block visiting order
             return CANVAS_OK;
         }
@@ -1210,7 +1277,8 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
         // is the maximising arc unique among all arcs of that length (including rounding plateaus of v)?
         double rj = (double)bestL, c = rn / (rj * (rn - rj)); int cnt = 0;
         for (int i = 0; i + bestL < n && cnt < 2; i++) { double d = std::fabs(sx[i + bestL] - sx[i]); if (c * sq(d) == M) cnt++; }
-        if (cnt == 1) { ostat = normalise(M, tss, rn); iseg[0] = firstI[bestL] + 1; iseg[1] = firstI[bestL] + 1 + bestL; return CANVAS_OK; }
+        if (cnt == 1 && ref_scans_arc(B, n, al0, firstI[bestL] + 1, bestL)) { ostat = normalise(M, tss, rn); iseg[0] = firstI[bestL] + 1; iseg[1] = firstI[bestL] + 1 + bestL; return CANVAS_OK; }
+        if (cnt == 1) st.unscanned_max++;
     }
     ok = false;     // exact tie: the winner depends on the reference's block visiting order
     return CANVAS_OK;
@@ -2056,6 +2124,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
     ctx->cbs_tailp[0] = st.tailp_dev; ctx->cbs_tailp[1] = st.tailp_host;
     if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());
+    if (timing) fprintf(stderr, "cbs arc searches whose best admissible arc the reference does not scan (replayed on the host): %lld\n", (long long)st.unscanned_max.load());
     if (timing && specPool) fprintf(stderr, "cbs helpers: %lld segments guessed from a finished phase 1, %lld of them asked for by the recursion\n", (long long)specPool->guessed.load(), (long long)specPool->guessedUsed.load());
     if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: TMaxO on the host %.3f, TailP %.3f (%lld decided from the device series, %lld by the host series)\n", st.ns_tmaxo_host.load() * 1e-9, st.ns_tailp.load() * 1e-9, (long long)st.tailp_dev.load(), (long long)st.tailp_host.load()),
                                       fprintf(stderr, "cbs launcher: %lld rounds, %lld arc searches in %.3f s, %lld permutation batches in %.3f s\n", service.rounds + arcService.rounds + arcService1.rounds + arcService2.rounds, arcService.nArc + arcService1.nArc + arcService2.nArc, std::max(arcService.secArc, std::max(arcService1.secArc, arcService2.secArc)), service.nPermReq + service1.nPermReq + service2.nPermReq + service3.nPermReq, std::max(std::max(service.secPerm, service1.secPerm), std::max(service2.secPerm, service3.secPerm))),

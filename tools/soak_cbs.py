@@ -36,5 +36,6 @@ while time.time() - t0 < budget:
         assert nseg[c] == len(exp[c]) and (g == exp[c]).all(), (it, c, g[:8], exp[c][:8])
     assert stats[0] == est[0] and stats[2] == est[2] and stats[4] == est[4], (it, list(stats), list(est))
     d = cv.cbs_device_stats(); devp += int(d[0]); rechecks += int(d[2])
+    assert int(d[5]) == 0, (it, "CANVAS_CBS_TEST_VERIFY: a device statistic or generator snapshot disagrees with the host", list(d))      # (only counted when the hook is set)
     it += 1
 print(f"soak_cbs: {it} random configurations with identical segments and RNG consumption in {time.time() - t0:.0f} s; {devp} device permutations, {rechecks} exact re-evaluations")
