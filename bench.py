@@ -265,8 +265,8 @@ def main():
         dstat = cv.cbs_device_stats(); tstat = cv.cbs_tailp_stats()
         cb = {"tailp_decided_on_device": int(tstat[0]), "tailp_recomputed_on_host": int(tstat[1]), "seconds": round(cbs_s, 3), "seconds_of_each_call": [round(x, 3) for x in cbs_runs], "first_call_seconds": round(cbs_first, 3), "bins_per_s": round(int(keep["n_out"]) / cbs_s, 1), "segments": int(sum(nseg_c)), "tmaxo_calls": int(cstats[0]),
               "permutations": int(cstats[2]), "permuted_elements": int(cstats[3]), "device_permutations": int(dstat[0]), "host_permutations": int(dstat[1]),
-              "exact_reevaluations": int(dstat[2]), "note": "CBSRunner.Run (alpha 0.01, 10000 permutations): recursion and stopping rule on the host, "
-              "TMaxO arc search + XPerm/HTMaxP + MT19937 on the device"}
+              "exact_reevaluations": int(dstat[2]), "note": "CBSRunner.Run (alpha 0.01, 10000 permutations): recursion, stopping rule and the edge tests (TPermP) on the host; TMaxO arc search, TailP series, MT19937 and every "
+              "permutation of the reference distribution (XPerm + HTMaxP / TMaxP) on the device; seconds = median of three warm calls"}
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
