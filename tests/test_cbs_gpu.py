@@ -113,3 +113,31 @@ def test_cbs_device_permutation_engine(monkeypatch):
     d2 = cv.cbs_device_stats()
     assert d2[0] == 0 and d2[1] == stats2[2]
     assert [int(v) for v in stats[:5]] == [int(v) for v in stats2[:5]]
+
+
+def test_short_segments_run_on_the_device_with_the_references_own_statistic(monkeypatch):
+    """Segments of at most 200 bins take the non-hybrid test (XPerm + TMaxP): k_perm_small must return tmaxp_host's value bit for bit — including the arcs the reference's block
+    search does NOT look at (its pruning is not lossless for blocks of a dozen elements) — and hybrid segments of a few hundred bins go through the device engine with the
+    generator state of a batch that is cut short inside its first 624 draws taken from the host.  Many short chromosomes with and without a jump; the hook checks every
+    permutation, the oracle the segments and the RNG consumption."""
+    cv = get_canvas()
+    rng = np.random.RandomState(77)
+    parts = []
+    for c in range(60):
+        n = int(rng.choice([12, 30, 49, 50, 51, 80, 120, 199, 200, 201, 230, 400, 640, 1023]))
+        x = rng.normal(60, 7, n)
+        if c % 3 == 0: x[n // 2:] += rng.choice([3.0, 6.0, 12.0])
+        if c % 7 == 0: x = np.round(x)                    # heavy ties
+        parts.append(np.round(np.clip(x, 0, None), 2))
+    cov = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    monkeypatch.setenv("CANVAS_CBS_TEST_VERIFY", "1")
+    stats, exp = _run(cv, cov, off, nperm=10000)
+    d = cv.cbs_device_stats()
+    assert d[1] == 0 and d[0] == stats[2] and d[0] > 20000, d          # every permutation on the device
+    assert d[4] >= d[0] and d[5] == 0, d                                 # every one checked against the host, none differs
+    monkeypatch.delenv("CANVAS_CBS_TEST_VERIFY")
+    monkeypatch.setenv("CANVAS_CBS_HOST_PERMUTATIONS", "1")
+    stats2, _ = _run(cv, cov, off, nperm=10000)
+    assert cv.cbs_device_stats()[0] == 0
+    assert [int(v) for v in stats[:5]] == [int(v) for v in stats2[:5]]
