@@ -1610,6 +1610,7 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     P.maxThreshold = haploidMean * NSTATE;
     if (!(P.maxThreshold >= 0) || P.maxThreshold > 60000) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: coverage scale outside the supported table size");
     P.tableLen = (int32_t)std::nearbyint(P.maxThreshold) + 10 + 1;      // >= max over chromosomes of (maxValues + 10)
+    hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);      // (needs the threshold only: runs while the host fills the tables below)
     std::vector<double> tab((size_t)NSTATE * P.tableLen);
     for (int CN = 0; CN < NSTATE; CN++) negative_binomial_log_table(std::max((double)CN, 0.1) * haploidMean, pseudoVariance, P.tableLen, &tab[(size_t)CN * P.tableLen]);
     const double selfTransition = 0.99;
@@ -1618,8 +1619,7 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
         P.logPi[i] = std::log((double)(1.0f / NSTATE));      // 1f / nStates widened (HMM.cs:41)
     }
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    // 3. index, Viterbi, backtrack
-    hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);
+    // 3. Viterbi and backtrack: hmm_pipeline
         E.idx = idx; E.dTab = dTab;
         return CANVAS_OK;
     };
