@@ -2013,6 +2013,15 @@ static int32_t prune(const double* gd, int n, std::vector<int>& lengthSeg, doubl
 // device-engine counters of the last canvas_cbs call: permutations evaluated on the device / on the host, permutations re-evaluated in
 // the reference's exact order because the observed statistic fell inside the rounding interval, device batches; with the test hook
 // CANVAS_CBS_TEST_VERIFY=1 also [4] intervals checked against the exact statistic and [5] violations (must be 0)
+// host-only: the table of sequential stopping points canvas_cbs works with (GetBoundary.cs:19-157, eta = 0.05 as CBSRunner passes it), evaluated on the host pool
+extern "C" int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h_out, int64_t cap) {
+    if (nperm == 0 || !(alpha > 0 && alpha < 1) || !h_out) return CANVAS_ERR_INVALID;
+    std::vector<uint32_t> sb;
+    cbs::compute_boundary(nperm, alpha, 0.05, sb);
+    if ((int64_t)sb.size() > cap) return CANVAS_ERR_CAPACITY;
+    for (size_t i = 0; i < sb.size(); i++) h_out[i] = sb[i];
+    return (int64_t)sb.size();
+}
 extern "C" int32_t canvas_cbs_tailp_stats(canvas_ctx* ctx, int64_t* h_out2) {
     if (!ctx || !h_out2) return CANVAS_ERR_INVALID;
     h_out2[0] = ctx->cbs_tailp[0]; h_out2[1] = ctx->cbs_tailp[1];

@@ -263,6 +263,10 @@ int32_t canvas_cbs_device_stats(canvas_ctx* ctx, int64_t* h_out6);
  * FindChangePoints (ChangePoint.cs:318-323).  [0] calls decided from the device evaluation of its series (accepted only when every value within 1e-8 relative gives the same
  * decisions), [1] calls recomputed with the host libm in the reference's order. */
 int32_t canvas_cbs_tailp_stats(canvas_ctx* ctx, int64_t* h_out2);
+/* Host-only (no context, no GPU): the sequential stopping boundary canvas_cbs uses for (nperm, alpha) — GetBoundary.ComputeBoundary (GetBoundary.cs:19-157) with eta = 0.05 as
+ * CBSRunner passes it: maxOnes (maxOnes + 1) / 2 entries with maxOnes = floor(nperm alpha) + 1.  Returns the number of entries (or a negative error code).  The library
+ * evaluates the table's scans on its host thread pool with the scans' own evaluations and comparisons; exposed so that the table can be checked without a device. */
+int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h_out, int64_t cap);
 
 /* CanvasPartition -m Wavelets, the reference's default method: WaveletsRunner.Run up to the breakpoints (WaveletsRunner.cs:52-150 =
  * SegmentationInput.GetCoverageVariability / FactorOfThreeCoverageVariabilities, Segmentation.cs:297-429, then
