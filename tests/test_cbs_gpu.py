@@ -141,3 +141,22 @@ def test_short_segments_run_on_the_device_with_the_references_own_statistic(monk
     stats2, _ = _run(cv, cov, off, nperm=10000)
     assert cv.cbs_device_stats()[0] == 0
     assert [int(v) for v in stats[:5]] == [int(v) for v in stats2[:5]]
+
+
+def test_spiky_coverage_where_the_reference_search_leaves_arcs_out():
+    """Coverage with isolated spikes puts a block's extremes next to each other; block_search then scans nothing of that block pair (CBSTStatistic.cs:233-326) and the reference's
+    maximum can be below the maximum over every admissible arc.  The device arc search takes the latter and is only accepted when its maximiser is an arc the reference scans
+    (otherwise the host replays the reference's search); short segments follow the scanned ranges on the device.  Segments and RNG consumption must be the oracle's."""
+    cv = get_canvas()
+    rng = np.random.RandomState(99)
+    parts = []
+    for c in range(6):
+        n = [5000, 9000, 16000, 150, 640, 30000][c]
+        x = rng.normal(80, 8, n)
+        spikes = rng.choice(n, max(3, n // 400), replace=False)
+        x[spikes] += rng.standard_cauchy(len(spikes)) * 60
+        if c % 2 == 0: x[n // 2:] += 4.0
+        parts.append(np.round(np.clip(x, 0, 5000), 2))
+    cov = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    _run(cv, cov, off, nperm=2000)
