@@ -23,6 +23,9 @@ while time.time() - t0 < budget:
         for _ in range(int(rng.randint(0, 5))):
             a = int(rng.randint(0, n)); ln = int(rng.choice([5, 40, 400, n // 3 + 1])); x[a:a + ln] += float(rng.choice([-1, 1])) * sd * float(rng.choice([0.15, 0.4, 1.0, 3.0]))
         if rng.rand() < 0.3: x = np.round(x)              # heavy quantisation: exact ties
+        if rng.rand() < 0.3:                              # isolated spikes: a block's extremes next to each other, where the reference's arc search leaves arcs out (DESIGN, CBS)
+            sp = rng.choice(n, max(1, n // int(rng.choice([50, 300, 2000]))), replace=False)
+            x[sp] += rng.standard_cauchy(len(sp)) * sd * 5; x = np.clip(x, 0, 20000)
         parts.append(np.round(x, 2))
     cov = np.concatenate(parts)
     off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
