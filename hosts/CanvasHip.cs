@@ -76,6 +76,22 @@ namespace CanvasHipInterop
         [DllImport(Lib)] public static extern int canvas_comm_unique_id(byte[] id128);
         [DllImport(Lib)] public static extern int canvas_comm_init(IntPtr ctx, int rank, int nranks, byte[] id128);
         [DllImport(Lib)] public static extern int canvas_allgather_boundaries(IntPtr ctx, IntPtr dLocal, int nLocal, int maxPerRank, IntPtr dAll, int[] counts);
+        // ONE sample, chromosomes sharded over the ranks (chrOwner[c] = rank that holds chromosome c); every rank receives the whole result
+        [DllImport(Lib)] public static extern int canvas_sample_pipeline_sharded(IntPtr ctx, int nchr, int[] chrOwner, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, long[] len, byte[] chrIsAutosome, byte[] chrIsY,
+            int countsPerBin, int binSizeIn, int mode, uint cleanFlags, int minBinsPerGc, int maxInterBinDist, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap,
+            IntPtr dCov, IntPtr dState, IntPtr dSegmentId, out int binSize, out long nBins, out long nBinsClean, out double localSd, long[] chrOffset, out long nSegments);
+        [DllImport(Lib)] public static extern int canvas_sample_pipeline_sharded_packed(IntPtr ctx, int nchr, int[] chrOwner, IntPtr[] dRef, IntPtr[] dHitPlanes, long[] len, long[] pos0, byte[] chrIsAutosome, byte[] chrIsY,
+            int countsPerBin, int binSizeIn, int mode, uint cleanFlags, int minBinsPerGc, int maxInterBinDist, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap,
+            IntPtr dCov, IntPtr dState, IntPtr dSegmentId, out int binSize, out long nBins, out long nBinsClean, out double localSd, long[] chrOffset, out long nSegments);
+        // CanvasPartition -m CBS / -m Wavelets on the coverage that call leaves on every rank (CBSRunner.cs:62-112, WaveletsRunner.cs:89-135: per-chromosome tasks on the owner)
+        [DllImport(Lib)] public static extern int canvas_cbs_sharded(IntPtr ctx, int nchr, int[] chrOwner, IntPtr dCov, long[] chrOffset, double alpha, uint nperm, int undo, double undoSd,
+            IntPtr dSegLen, int[] nseg, long[] stats8);
+        [DllImport(Lib)] public static extern int canvas_wavelets_sharded(IntPtr ctx, int nchr, int[] chrOwner, IntPtr dCov, long[] chrOffset, int isGermline, double thresholdLower, double thresholdUpper,
+            double madFactor, int variabilityWindow, int minSize, int[] breakpoints, long cap, long[] bpOffset);
+        // a pedigree, one sample per rank: the rates of every sample (multi-sample bin size, CanvasBin.cs:86-110) and the bin intersection (Utilities.cs:834-920)
+        [DllImport(Lib)] public static extern int canvas_allgather_host(IntPtr ctx, double[] send, long bytesPerRank, double[] recv);
+        [DllImport(Lib)] public static extern int canvas_merge_cleaned_sharded(IntPtr ctx, long nMine, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dCount,
+            IntPtr dOutChr, IntPtr dOutStart, IntPtr dOutStop, IntPtr dOutCount, long cap, out long nOut);
 
         /// <summary>Turns a non-zero status into the module's own failure convention (message on stderr, exit code 1).</summary>
         public static void Check(IntPtr ctx, int status, string what)
