@@ -800,8 +800,16 @@ __global__ void __launch_bounds__(256) k_bin_weighted(const BinChrom* __restrict
 }
 
 #include "bin_packed.hpp"
+#include "bin_tail.hpp"
 
 // ---------------------------------------------------------------------------------------------- host side
+// workgroups of `fn` that are resident on the device at the same time (grid of a persistent kernel)
+static unsigned resident_grid(const void* fn, int threads, int device) {
+    int perCu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, fn, threads, 0) != hipSuccess || perCu <= 0) perCu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    return (unsigned)(perCu * cus);
+}
 struct BinPlan {
     std::vector<BinChrom> chroms;
     int64_t ntiles = 0;
@@ -857,7 +865,7 @@ int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_
     memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);   // pos0 = len: popBefore irrelevant here
-    { ProfScope ps(ctx, "bin_tile_stats");
+    { ProfScope ps(ctx, "bin_tile_stats", true);
       hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, 1, tilePop, tileObs); }
     hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut);
     ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
@@ -952,7 +960,8 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     // the bin arrays are sized by the caller's capacity (the bin size may not be known yet)
     const int64_t ub = cap;
     WsSizer sz;
-    sz.take<BinChrom>(nchr); sz.take<unsigned long long>(nchr); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles); sz.take<int32_t>(plan.ntiles);
+    const size_t tabSlots = (size_t)nchr + ((size_t)nchr + sizeof(BinChrom) - 1) / sizeof(BinChrom);      // the chromosome table + one byte per chromosome (is autosome) behind it: one upload
+    sz.take<BinChrom>(tabSlots); sz.take<unsigned long long>(nchr); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles); sz.take<int32_t>(plan.ntiles);
     sz.take<ChromOut>(nchr); sz.take<long long>(nchr + 1); sz.take<uint32_t>(plan.ntiles); sz.take<uint32_t>(plan.ntiles);
     sz.take<int32_t>(ub + 1); sz.take<uint32_t>(ub + 1); sz.take<uint32_t>(ub + 1);
     // bases/hits/mask streamed once (see k_tile_summary) when the rates are needed too; CANVAS_BIN_SINGLE_READ=1 takes that path for a given bin
@@ -963,24 +972,37 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     if (ctx->up_active && !streamed) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); }    // other arrays (or mode 5): plain dependency on the whole upload
     ctx->up_active = false;
     const bool singleRead = packed || streamed || (needRates && !getenv("CANVAS_BIN_TWO_PASS")) || getenv("CANVAS_BIN_SINGLE_READ");
-    if (singleRead) sz.take<uint32_t>(plan.ntiles * 64);
+    const int nchunks = (int)((plan.ntiles + TS_CHUNK - 1) / TS_CHUNK);
+    if (singleRead) { sz.take<uint32_t>(plan.ntiles * 64); sz.take<uint32_t>(plan.ntiles + 8); sz.take<TsPart>(nchunks + 1); sz.take<TsPart>(nchunks + 1); sz.take<unsigned long long>(nchr);
+                      sz.take<TsPart>(nchr + 1); sz.take<ChromDev>(nchr); }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
-    rc = canvas_pin_reserve(ctx, nchr * (sizeof(BinChrom) + sizeof(ChromOut) + 8)); if (rc) return rc;
+    // pinned staging: [chromosome table | is-autosome bytes] (one H2D), then what comes back: per-chromosome totals, (packed: pos0 going up), the decisions
+    const size_t oAuto = (size_t)nchr * sizeof(BinChrom), oOut = (oAuto + (size_t)nchr + 15) & ~size_t(15), oP0 = oOut + (size_t)nchr * sizeof(ChromOut), oBd = oP0 + (size_t)nchr * 8;
+    rc = canvas_pin_reserve(ctx, oBd + sizeof(BinDev) + 64); if (rc) return rc;
     WsCarver ws(ctx->ws);
-    BinChrom* dCh = ws.take<BinChrom>(nchr); unsigned long long* dPos0 = ws.take<unsigned long long>(nchr);
+    BinChrom* dCh = ws.take<BinChrom>(tabSlots); unsigned long long* dPos0 = ws.take<unsigned long long>(nchr);
     uint32_t* tilePop = ws.take<uint32_t>(plan.ntiles); uint32_t* tileObs = ws.take<uint32_t>(plan.ntiles); int32_t* rankBase = ws.take<int32_t>(plan.ntiles);
     ChromOut* dOut = ws.take<ChromOut>(nchr); long long* binOffset = ws.take<long long>(nchr + 1);
     uint32_t* tileTotC = ws.take<uint32_t>(plan.ntiles); uint32_t* tileTotG = ws.take<uint32_t>(plan.ntiles);
     int32_t* stopTmp = ws.take<int32_t>(ub + 1); uint32_t* locC = ws.take<uint32_t>(ub + 1); uint32_t* locG = ws.take<uint32_t>(ub + 1);
     uint32_t* wordSum = singleRead ? ws.take<uint32_t>(plan.ntiles * 64) : nullptr;
+    uint32_t* rankRaw = nullptr; TsPart* tsPart = nullptr; TsPart* tsPartEx = nullptr; unsigned long long* dPopBefore = nullptr; TsPart* chrPre = nullptr; ChromDev* chrDev = nullptr; uint8_t* dIsAuto = (uint8_t*)(dCh + nchr);
+    if (singleRead) { rankRaw = ws.take<uint32_t>(plan.ntiles + 8); tsPart = ws.take<TsPart>(nchunks + 1); tsPartEx = ws.take<TsPart>(nchunks + 1); dPopBefore = ws.take<unsigned long long>(nchr);
+                      chrPre = ws.take<TsPart>(nchr + 1); chrDev = ws.take<ChromDev>(nchr); }
+    if (singleRead && !ctx->bin_dev) {
+        CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->bin_dev, 256)); CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->bin_dev, 0, 256, ctx->stream));      // the tickets clean up after themselves
+        CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->bin_ev, hipEventDisableTiming));
+    }
+    uint32_t* dTick = (uint32_t*)ctx->bin_dev; BinDev* dBd = (BinDev*)((char*)ctx->bin_dev + 64);
     const int clampHits = mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0;
     memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream));
-    ChromOut* hOut = (ChromOut*)((char*)ctx->pin + nchr * sizeof(BinChrom));
+    for (int c = 0; c < nchr; c++) ((uint8_t*)ctx->pin)[oAuto + c] = h_is_auto ? (h_is_auto[c] ? 1 : 0) : 0;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, oAuto + (size_t)nchr, hipMemcpyHostToDevice, ctx->stream));
+    ChromOut* hOut = (ChromOut*)((char*)ctx->pin + oOut);
     const unsigned pkGrid = (unsigned)((plan.ntiles + 4 * PK_TILES - 1) / (4 * PK_TILES));
     if (packed) {
         // pos0 comes with the planes (the packer found it)
-        unsigned long long* hp0 = (unsigned long long*)((char*)ctx->pin + nchr * (sizeof(BinChrom) + sizeof(ChromOut)));
+        unsigned long long* hp0 = (unsigned long long*)((char*)ctx->pin + oP0);
         for (int c = 0; c < nchr; c++) {
             if (h_pos0_packed[c] < 0 || h_pos0_packed[c] > h_len[c]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_sample_packed: pos0 outside [0, len]");
             hp0[c] = (unsigned long long)h_pos0_packed[c];
@@ -990,12 +1012,12 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             for (int c = 0; c < nchr; c++) {
                 const BinChrom& C = plan.chroms[c];
                 CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[c], 0));
-                ProfScope ps(ctx, "bin_summary_packed_streamed");
+                ProfScope ps(ctx, "bin_summary_packed_streamed", true);
                 hipLaunchKernelGGL(k_tile_summary_packed, dim3((unsigned)((C.ntiles + 4 * PK_TILES - 1) / (4 * PK_TILES))), dim3(256), 0, ctx->stream, dCh, nchr, C.tileBase + C.ntiles, dPos0,
                                    clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG, C.tileBase);
             }
         } else {
-            ProfScope ps(ctx, "bin_summary_packed");
+            ProfScope ps(ctx, "bin_summary_packed", true);
             hipLaunchKernelGGL(k_tile_summary_packed, dim3(pkGrid), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, clampHits, needRates ? 1 : 0,
                                wordSum, tilePop, tileObs, tileTotC, tileTotG, (int64_t)0);
         }
@@ -1007,7 +1029,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             const BinChrom& C = plan.chroms[c];
             CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[c], 0));
             hipLaunchKernelGGL(k_find_pos0, dim3(64, 1), dim3(256), 0, ctx->stream, dCh, dPos0, c);
-            ProfScope ps(ctx, "bin_summary_streamed");
+            ProfScope ps(ctx, "bin_summary_streamed", true);
             hipLaunchKernelGGL(k_tile_summary, dim3((unsigned)((C.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, C.tileBase + C.ntiles, dPos0, clampHits, needRates ? 1 : 0,
                                wordSum, tilePop, tileObs, tileTotC, tileTotG, C.tileBase);
             hipLaunchKernelGGL(k_tile_summary_edges, dim3(2), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG, c);
@@ -1015,24 +1037,88 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     } else hipLaunchKernelGGL(k_find_pos0, dim3(64, nchr), dim3(256), 0, ctx->stream, dCh, dPos0, 0);
     if (streamed) {
     } else if (singleRead) {
-        ProfScope ps(ctx, "bin_summary");
+        ProfScope ps(ctx, "bin_summary", true);
         hipLaunchKernelGGL(k_tile_summary, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, clampHits, needRates ? 1 : 0,
                            wordSum, tilePop, tileObs, tileTotC, tileTotG, (int64_t)0);
     } else {
-        ProfScope ps(ctx, "bin_tile_stats");
+        ProfScope ps(ctx, "bin_tile_stats", true);
         hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, needRates ? 1 : 0, tilePop, tileObs);
     }
     if (singleRead && !streamed) hipLaunchKernelGGL(k_tile_summary_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, clampHits, needRates ? 1 : 0, wordSum, tilePop, tileObs, tileTotC, tileTotG, 0);
     }   // byte arrays
-    if (needRates) {
-        // rates (CanvasBin.cs:30-83): totals per chromosome, then the bin size on the host
-        hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut, packed ? 1 : 0);
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
-        // the tile totals of the single-read path do not depend on the bin size either: their scan runs while the host derives it
-        if (singleRead) hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t total = 0;
+    if (singleRead) {
+        // ---- the single-read path after the sweep: two scan launches, the sample's decisions taken by the last workgroup of the second (bin_tail.hpp), close + resolve
+        // enqueued behind them; the host reads the decisions back while those run
+        const int binSizeArg = !needRates ? bin_size : (hook ? -1 : 0);
+        const uint32_t* obsArr = needRates ? tileObs : (const uint32_t*)nullptr;
+        hipLaunchKernelGGL(k_tscan_reduce, dim3((unsigned)(nchunks + nchr)), dim3(TS_T), 0, ctx->stream, dCh, nchr, dPos0, packed ? 1 : 0, plan.ntiles, nchunks, tilePop, obsArr, tileTotC, tileTotG,
+                           tsPart, tsPartEx, dPopBefore, dTick);
+        hipLaunchKernelGGL(k_tscan_apply, dim3((unsigned)nchunks), dim3(TS_T), 0, ctx->stream, dCh, nchr, plan.ntiles, nchunks, tilePop, obsArr, tileTotC, tileTotG, rankRaw, tsPartEx, dPopBefore, chrPre,
+                           dIsAuto, counts_per_bin, binSizeArg, (long long)cap, dOut, chrDev, binOffset, dBd, dTick + 1);
+        auto launch_close_resolve = [&]() {
+            { ProfScope ps(ctx, "bin_close");
+              hipLaunchKernelGGL(k_bin_close2, dim3((unsigned)((plan.ntiles + 4 * CLOSE_TILES - 1) / (4 * CLOSE_TILES))), dim3(256), 0, ctx->stream, dCh, chrDev, nchr, plan.ntiles, wordSum, rankRaw,
+                                 tileTotC, tileTotG, binOffset, dBd, stopTmp, locC, locG, d_chr); }
+            ProfScope ps(ctx, "bin_resolve");
+            // persistent workgroups (the number of bins is only known on the device): as many as are resident at once
+            static const unsigned gridP = resident_grid((const void*)k_bin_resolve_fin<true>, 256, ctx->device), gridB = resident_grid((const void*)k_bin_resolve_fin<false>, 256, ctx->device);
+            if (packed) hipLaunchKernelGGL((k_bin_resolve_fin<true>), dim3(gridP), dim3(256), 0, ctx->stream, dCh, chrDev, binOffset, dPos0, dBd, clampHits, d_chr, stopTmp, locC, locG, d_start, d_stop, d_gc, d_count);
+            else hipLaunchKernelGGL((k_bin_resolve_fin<false>), dim3(gridB), dim3(256), 0, ctx->stream, dCh, chrDev, binOffset, dPos0, dBd, clampHits, d_chr, stopTmp, locC, locG, d_start, d_stop, d_gc, d_count);
+        };
+        auto host_totals = [&]() {
+            total = 0;
+            for (int c = 0; c < nchr; c++) { hOut[c].nbins = (hOut[c].pop - hOut[c].popBefore) / bin_size; if (h_nbins_per_chr) h_nbins_per_chr[c] = hOut[c].nbins; total += hOut[c].nbins; }
+        };
         if (hook) {
             // chromosome-sharded pipeline: the rate pairs of every rank's chromosomes are exchanged inside the hook, every rank derives the same size
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            std::vector<long long> o(nchr), p(nchr), pb(nchr);
+            for (int c = 0; c < nchr; c++) { o[c] = hOut[c].obs; p[c] = hOut[c].pop; pb[c] = hOut[c].popBefore; }
+            int32_t rch = hook(hookUser, nchr, o.data(), p.data(), pb.data(), &bin_size); if (rch) return rch;
+            if (bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "derived bin size is not positive");
+            if (h_bin_size_out) *h_bin_size_out = bin_size;
+            host_totals();
+            if (h_nbins_total) *h_nbins_total = total;
+            if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_bin_genome: output capacity too small (see canvas_bin_count_upper_bound)");
+            if (total == 0) return CANVAS_OK;
+            hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(TS_T), 0, ctx->stream, nchr, dOut, binOffset, dBd, bin_size, (long long)cap);
+            launch_close_resolve();
+        } else {
+            BinDev* hBd = (BinDev*)((char*)ctx->pin + oBd);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hBd, dBd, sizeof(BinDev), hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->bin_ev, ctx->stream));
+            launch_close_resolve();
+            CANVAS_HIP_TRY(ctx, hipEventSynchronize(ctx->bin_ev));       // the decisions are on the host; close / resolve are still running
+            if (needRates && (hBd->flags & (BD_BAD_RATE | BD_TOO_MANY))) {
+                // an autosome without possible positions, or more autosomes than the device sort holds: decided here as before (the kernels above did nothing)
+                std::vector<double> rates;
+                for (int c = 0; c < nchr; c++) if (h_is_auto[c]) rates.push_back((int)hOut[c].obs / (double)(int)hOut[c].pop);
+                bin_size = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin);
+                if (bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "derived bin size is not positive");
+                host_totals();
+                if (total <= cap && total > 0) { hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(TS_T), 0, ctx->stream, nchr, dOut, binOffset, dBd, bin_size, (long long)cap); launch_close_resolve(); }
+            } else {
+                if (needRates && (hBd->flags & BD_NO_AUTOSOME)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "no autosome to derive the bin size from");
+                bin_size = hBd->binSize;
+                if (bin_size <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "derived bin size is not positive");
+                total = hBd->total;
+                for (int c = 0; c < nchr; c++) if (h_nbins_per_chr) h_nbins_per_chr[c] = hOut[c].nbins;
+            }
+            if (h_bin_size_out) *h_bin_size_out = bin_size;
+            if (h_nbins_total) *h_nbins_total = total;
+            if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_bin_genome: output capacity too small (see canvas_bin_count_upper_bound)");
+            if (total == 0) return CANVAS_OK;
+        }
+    } else {
+    if (needRates) {
+        // two-pass path (CANVAS_BIN_TWO_PASS=1): rates (CanvasBin.cs:30-83) from the tile statistics, then the bin size on the host
+        hipLaunchKernelGGL(k_scan_tiles, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, dPos0, tilePop, tileObs, 1, 0, rankBase, dOut, packed ? 1 : 0);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (hook) {
             std::vector<long long> o(nchr), p(nchr), pb(nchr);
             for (int c = 0; c < nchr; c++) { o[c] = hOut[c].obs; p[c] = hOut[c].pop; pb[c] = hOut[c].popBefore; }
             int32_t rch = hook(hookUser, nchr, o.data(), p.data(), pb.data(), &bin_size); if (rch) return rch;
@@ -1050,30 +1136,21 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
-    }   // else: the scan that produced the rates already left the rank bases and the totals (they do not depend on the bin size)
+    }   // else: the scan that produced the rates already left the rank bases (they do not depend on the bin size)
     hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(64), 0, ctx->stream, dOut, nchr, bin_size, binOffset);
-    int64_t total = 0;
     for (int c = 0; c < nchr; c++) { hOut[c].nbins = (hOut[c].pop - hOut[c].popBefore) / bin_size; if (h_nbins_per_chr) h_nbins_per_chr[c] = hOut[c].nbins; total += hOut[c].nbins; }
     if (h_nbins_total) *h_nbins_total = total;
     if (total > cap) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_bin_genome: output capacity too small (see canvas_bin_count_upper_bound)");
     if (total == 0) return CANVAS_OK;
-    if (singleRead) {
-        if (!needRates) hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
-        ProfScope ps(ctx, "bin_close");
-        hipLaunchKernelGGL(k_bin_close, dim3((unsigned)((plan.ntiles + 4 * CLOSE_TILES - 1) / (4 * CLOSE_TILES))), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, wordSum, rankBase,
-                           binOffset, bin_size, bin_size > 1 ? ~0ull / (unsigned long long)bin_size + 1ull : 0ull, stopTmp, locC, locG, d_chr);
-        if (packed) hipLaunchKernelGGL(k_bin_resolve_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, clampHits, d_chr, stopTmp, locC, locG);
-        else hipLaunchKernelGGL(k_bin_resolve, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, clampHits, d_chr, stopTmp, locC, locG);
-    } else {
-        { ProfScope ps(ctx, "bin_pass");
-          hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
-                             binOffset, bin_size, clampHits, stopTmp, locC, locG, tileTotC, tileTotG); }
-        hipLaunchKernelGGL(k_bin_pass_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, rankBase, binOffset, bin_size,
-                           clampHits, stopTmp, locC, locG, tileTotC, tileTotG);
-        hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
-    }
+    { ProfScope ps(ctx, "bin_pass", true);
+      hipLaunchKernelGGL(k_bin_pass, dim3((unsigned)((plan.ntiles + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, plan.ntiles, dPos0, rankBase,
+                         binOffset, bin_size, clampHits, stopTmp, locC, locG, tileTotC, tileTotG); }
+    hipLaunchKernelGGL(k_bin_pass_edges, dim3(2 * nchr), dim3(64), 0, ctx->stream, dCh, nchr, dPos0, rankBase, binOffset, bin_size,
+                       clampHits, stopTmp, locC, locG, tileTotC, tileTotG);
+    hipLaunchKernelGGL(k_scan_totals, dim3(nchr), dim3(1024), 0, ctx->stream, dCh, tileTotC, tileTotG);
     hipLaunchKernelGGL(k_bin_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, stopTmp, locC, locG,
-                       tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count, singleRead ? 1 : 0);
+                       tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count, 0);
+    }
     if (gcw) hipLaunchKernelGGL(k_bin_weighted, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, d_count);
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;

@@ -40,6 +40,7 @@ struct canvas_ctx {
     void* up2_stage = nullptr; size_t up2_stage_bytes = 0;      // canvas_upload_packed2_begin: the two-bit wire form of the hit planes before its expansion
     std::vector<const void*> up_bases, up_mask, up_hits;
     bool up_active = false;
+    void* bin_dev = nullptr; hipEvent_t bin_ev = nullptr;      // bin_tail.hpp: arrival tickets + the sample's decisions (BinDev) in device memory; event behind their D2H copy
     void* gc_arena = nullptr; size_t gc_arena_bytes = 0;   // GCContentWeighted binning: read-GC profile of every position + GC prefix array (grow-only)
     bool clean_cq_failed = false, clean_cq_skip = false;   // clean_fast.hpp: a sample's counting selects gave up (it is redone with the radix selects)
     std::shared_ptr<void> cbs_cache;     // cbs.hip: device / pinned buffers of the arc-search and permutation engines, kept between calls (a call used to spend tens of ms in hipMalloc / hipHostMalloc)
@@ -62,7 +63,7 @@ struct canvas_ctx {
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
     int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
     // profiling: hipEvent pairs around named kernels
-    bool prof = false;
+    int prof = 0;          // 0 off; 1 every named scope; 2 only the scopes of the dominant (roofline) kernel of a stage: a scope costs two barrier packets, ~10 us of the pass
     struct ProfSlot { std::string name; std::vector<hipEvent_t> ev; double ms = 0; int launches = 0; };
     std::vector<ProfSlot> slots;
 };
@@ -70,8 +71,8 @@ struct canvas_ctx {
 // scoped event pair: records start now and stop at destruction (on ctx->stream) when profiling is enabled
 struct ProfScope {
     canvas_ctx* ctx; int slot = -1; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(canvas_ctx* c, const char* name) : ctx(c) {
-        if (!c->prof) return;
+    ProfScope(canvas_ctx* c, const char* name, bool dominant = false) : ctx(c) {
+        if (!c->prof || (c->prof == 2 && !dominant)) return;
         for (size_t i = 0; i < c->slots.size(); i++) if (c->slots[i].name == name) slot = (int)i;
         if (slot < 0) { c->slots.push_back({}); slot = (int)c->slots.size() - 1; c->slots[slot].name = name; }
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { slot = -1; return; }

@@ -39,6 +39,8 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->covq_dev) (void)hipFree(ctx->covq_dev);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gc_arena) (void)hipFree(ctx->gc_arena);
+    if (ctx->bin_dev) (void)hipFree(ctx->bin_dev);
+    if (ctx->bin_ev) (void)hipEventDestroy(ctx->bin_ev);
     if (ctx->shard_ws) (void)hipFree(ctx->shard_ws);
     if (ctx->comm_pin) (void)hipHostFree(ctx->comm_pin);
     if (ctx->misc_pin) (void)hipHostFree(ctx->misc_pin);
@@ -166,7 +168,7 @@ int32_t canvas_upload_genome_wait(canvas_ctx* ctx) {
 
 int32_t canvas_profile_enable(canvas_ctx* ctx, int32_t on) {
     if (!ctx) return CANVAS_ERR_INVALID;
-    ctx->prof = on != 0;
+    ctx->prof = on < 0 ? 0 : (on > 2 ? 1 : on);
     return CANVAS_OK;
 }
 int32_t canvas_profile_get(canvas_ctx* ctx, const char* name, double* h_ms_total, int32_t* h_launches, int32_t reset) {

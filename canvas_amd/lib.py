@@ -369,7 +369,7 @@ class Canvas:
         return cov
 
     def profile_enable(self, on=True):
-        self._check(self.lib.canvas_profile_enable(self.ctx, int(on)))
+        self._check(self.lib.canvas_profile_enable(self.ctx, int(on)))      # True / 1: every scope; 2: only the dominant kernel's scope
 
     def profile_get(self, name, reset=True):
         ms = C.c_double(0); k = C.c_int32(0)

@@ -385,6 +385,8 @@ int32_t canvas_merge_cleaned_sharded(canvas_ctx* ctx, int64_t n_mine, const int3
                                      int32_t* d_out_chr, int32_t* d_out_start, int32_t* d_out_stop, float* d_out_count, int64_t cap, int64_t* h_n_out);
 
 /* ---- profiling hooks (hipEvent pairs recorded on the context's stream around the named kernels) --------------------- */
+/* on: 0 off; 1 every named scope; 2 only the scopes around the dominant (HBM-bound) kernel of CanvasBin — "bin_summary", "bin_summary_packed", "bin_pass",
+   "bin_tile_stats" — so that a timed pass carries two event records instead of a dozen (each scope costs two barrier packets on the stream) */
 int32_t canvas_profile_enable(canvas_ctx* ctx, int32_t on);
 /* name: "bin_pass", "bin_tile_stats", "viterbi"; returns accumulated ms and launch count since the last reset */
 int32_t canvas_profile_get(canvas_ctx* ctx, const char* name, double* h_ms_total, int32_t* h_launches, int32_t reset);

@@ -18,6 +18,10 @@ t0 = seg[0][1]
 busy = sum(e - s for _, s, e in seg)
 span = seg[-1][2] - t0
 print("pass: %d kernels, span %.1f us, busy %.1f us, idle %.1f us" % (len(seg), span / 1e3, busy / 1e3, (span - busy) / 1e3))
+import os, json
+if os.environ.get("TIMELINE_JSON"):      # the pass summary for bench.py (roofline.idle_us_per_pass): TIMELINE_JSON=<file> TIMELINE_SCALE=1.0 TIMELINE_RATE=0.21
+    json.dump({"span_us": round(span / 1e3, 1), "busy_us": round(busy / 1e3, 1), "idle_us": round((span - busy) / 1e3, 1), "kernels": len(seg),
+               "scale": float(os.environ.get("TIMELINE_SCALE", "1.0")), "rate": float(os.environ.get("TIMELINE_RATE", "0.21"))}, open(os.environ["TIMELINE_JSON"], "w"))
 prev_end = t0
 for n, s, e in seg:
     gap = (s - prev_end) / 1e3
