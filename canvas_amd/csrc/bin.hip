@@ -689,6 +689,16 @@ __global__ void k_bin_offsets(ChromOut* __restrict__ co, int nchr, int binSize, 
         binOffset[nchr] = s;
     }
 }
+// The chromosome table arrives BY VALUE as a kernel argument (<= BIN_BYVAL chromosomes: the argument block is copied at launch, no H2D copy and no blit kernel in front of
+// the pass): published to the table the other kernels read, together with the is-autosome bytes and the initial pos0 (the chromosome's length, or the packer's pos0).
+#define BIN_BYVAL 64
+struct BinChromPack { BinChrom c[BIN_BYVAL]; unsigned long long pos0[BIN_BYVAL]; uint8_t isAuto[BIN_BYVAL]; };
+__global__ void __launch_bounds__(256) k_bin_begin(BinChrom* __restrict__ ch, uint8_t* __restrict__ isAuto, const BinChromPack pack, int nchr, unsigned long long* __restrict__ pos0, int pos0Given) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&pack.c[0]); uint32_t* dst = reinterpret_cast<uint32_t*>(ch);
+    const int words = nchr * (int)(sizeof(BinChrom) / 4);
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+    for (int c = threadIdx.x; c < nchr; c += 256) { isAuto[c] = pack.isAuto[c]; pos0[c] = pos0Given ? pack.pos0[c] : (unsigned long long)pack.c[c].len; }
+}
 __global__ void k_init_pos0(const BinChrom* __restrict__ ch, int nchr, unsigned long long* __restrict__ pos0) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < nchr) pos0[c] = (unsigned long long)ch[c].len;
@@ -974,7 +984,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     const bool singleRead = packed || streamed || (needRates && !getenv("CANVAS_BIN_TWO_PASS")) || getenv("CANVAS_BIN_SINGLE_READ");
     const int nchunks = (int)((plan.ntiles + TS_CHUNK - 1) / TS_CHUNK);
     if (singleRead) { sz.take<uint32_t>(plan.ntiles * 64); sz.take<uint32_t>(plan.ntiles + 8); sz.take<TsPart>(nchunks + 1); sz.take<TsPart>(nchunks + 1); sz.take<unsigned long long>(nchr);
-                      sz.take<TsPart>(nchr + 1); sz.take<ChromDev>(nchr); }
+                      sz.take<TsPart>(nchr + 1); sz.take<ChromDev>(nchr); sz.take<uint4>(ub + 1); }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     // pinned staging: [chromosome table | is-autosome bytes] (one H2D), then what comes back: per-chromosome totals, (packed: pos0 going up), the decisions
     const size_t oAuto = (size_t)nchr * sizeof(BinChrom), oOut = (oAuto + (size_t)nchr + 15) & ~size_t(15), oP0 = oOut + (size_t)nchr * sizeof(ChromOut), oBd = oP0 + (size_t)nchr * 8;
@@ -986,28 +996,41 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     uint32_t* tileTotC = ws.take<uint32_t>(plan.ntiles); uint32_t* tileTotG = ws.take<uint32_t>(plan.ntiles);
     int32_t* stopTmp = ws.take<int32_t>(ub + 1); uint32_t* locC = ws.take<uint32_t>(ub + 1); uint32_t* locG = ws.take<uint32_t>(ub + 1);
     uint32_t* wordSum = singleRead ? ws.take<uint32_t>(plan.ntiles * 64) : nullptr;
-    uint32_t* rankRaw = nullptr; TsPart* tsPart = nullptr; TsPart* tsPartEx = nullptr; unsigned long long* dPopBefore = nullptr; TsPart* chrPre = nullptr; ChromDev* chrDev = nullptr; uint8_t* dIsAuto = (uint8_t*)(dCh + nchr);
+    uint32_t* rankRaw = nullptr; TsPart* tsPart = nullptr; TsPart* tsPartEx = nullptr; unsigned long long* dPopBefore = nullptr; TsPart* chrPre = nullptr; ChromDev* chrDev = nullptr; uint4* binRec = nullptr; uint8_t* dIsAuto = (uint8_t*)(dCh + nchr);
     if (singleRead) { rankRaw = ws.take<uint32_t>(plan.ntiles + 8); tsPart = ws.take<TsPart>(nchunks + 1); tsPartEx = ws.take<TsPart>(nchunks + 1); dPopBefore = ws.take<unsigned long long>(nchr);
-                      chrPre = ws.take<TsPart>(nchr + 1); chrDev = ws.take<ChromDev>(nchr); }
+                      chrPre = ws.take<TsPart>(nchr + 1); chrDev = ws.take<ChromDev>(nchr); binRec = ws.take<uint4>(ub + 1); }
     if (singleRead && !ctx->bin_dev) {
         CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->bin_dev, 256)); CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->bin_dev, 0, 256, ctx->stream));      // the tickets clean up after themselves
         CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->bin_ev, hipEventDisableTiming));
     }
     uint32_t* dTick = (uint32_t*)ctx->bin_dev; BinDev* dBd = (BinDev*)((char*)ctx->bin_dev + 64);
     const int clampHits = mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0;
-    memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
-    for (int c = 0; c < nchr; c++) ((uint8_t*)ctx->pin)[oAuto + c] = h_is_auto ? (h_is_auto[c] ? 1 : 0) : 0;
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, oAuto + (size_t)nchr, hipMemcpyHostToDevice, ctx->stream));
+    const bool byVal = nchr <= BIN_BYVAL;
+    if (byVal) {
+        BinChromPack pack; memset(&pack, 0, sizeof pack);
+        memcpy(pack.c, plan.chroms.data(), nchr * sizeof(BinChrom));
+        for (int c = 0; c < nchr; c++) {
+            pack.isAuto[c] = h_is_auto ? (h_is_auto[c] ? 1 : 0) : 0;
+            if (packed) { if (h_pos0_packed[c] < 0 || h_pos0_packed[c] > h_len[c]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_sample_packed: pos0 outside [0, len]"); pack.pos0[c] = (unsigned long long)h_pos0_packed[c]; }
+        }
+        hipLaunchKernelGGL(k_bin_begin, dim3(1), dim3(256), 0, ctx->stream, dCh, dIsAuto, pack, nchr, dPos0, packed ? 1 : 0);
+    } else {
+        memcpy(ctx->pin, plan.chroms.data(), nchr * sizeof(BinChrom));
+        for (int c = 0; c < nchr; c++) ((uint8_t*)ctx->pin)[oAuto + c] = h_is_auto ? (h_is_auto[c] ? 1 : 0) : 0;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, ctx->pin, oAuto + (size_t)nchr, hipMemcpyHostToDevice, ctx->stream));
+    }
     ChromOut* hOut = (ChromOut*)((char*)ctx->pin + oOut);
     const unsigned pkGrid = (unsigned)((plan.ntiles + 4 * PK_TILES - 1) / (4 * PK_TILES));
     if (packed) {
         // pos0 comes with the planes (the packer found it)
-        unsigned long long* hp0 = (unsigned long long*)((char*)ctx->pin + oP0);
-        for (int c = 0; c < nchr; c++) {
-            if (h_pos0_packed[c] < 0 || h_pos0_packed[c] > h_len[c]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_sample_packed: pos0 outside [0, len]");
-            hp0[c] = (unsigned long long)h_pos0_packed[c];
+        if (!byVal) {
+            unsigned long long* hp0 = (unsigned long long*)((char*)ctx->pin + oP0);
+            for (int c = 0; c < nchr; c++) {
+                if (h_pos0_packed[c] < 0 || h_pos0_packed[c] > h_len[c]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_sample_packed: pos0 outside [0, len]");
+                hp0[c] = (unsigned long long)h_pos0_packed[c];
+            }
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dPos0, hp0, (size_t)nchr * 8, hipMemcpyHostToDevice, ctx->stream));
         }
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dPos0, hp0, (size_t)nchr * 8, hipMemcpyHostToDevice, ctx->stream));
         if (streamed) {
             for (int c = 0; c < nchr; c++) {
                 const BinChrom& C = plan.chroms[c];
@@ -1022,7 +1045,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
                                wordSum, tilePop, tileObs, tileTotC, tileTotG, (int64_t)0);
         }
     } else {
-    hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);
+    if (!byVal) hipLaunchKernelGGL(k_init_pos0, dim3((nchr + 63) / 64), dim3(64), 0, ctx->stream, dCh, nchr, dPos0);
     if (streamed) {
         // copy / compute overlap: chromosome c's sweep waits for chromosome c's event only, chromosome c + 1 is on its way meanwhile
         for (int c = 0; c < nchr; c++) {
@@ -1055,16 +1078,18 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         hipLaunchKernelGGL(k_tscan_reduce, dim3((unsigned)(nchunks + nchr)), dim3(TS_T), 0, ctx->stream, dCh, nchr, dPos0, packed ? 1 : 0, plan.ntiles, nchunks, tilePop, obsArr, tileTotC, tileTotG,
                            tsPart, tsPartEx, dPopBefore, dTick);
         hipLaunchKernelGGL(k_tscan_apply, dim3((unsigned)nchunks), dim3(TS_T), 0, ctx->stream, dCh, nchr, plan.ntiles, nchunks, tilePop, obsArr, tileTotC, tileTotG, rankRaw, tsPartEx, dPopBefore, chrPre,
-                           dIsAuto, counts_per_bin, binSizeArg, (long long)cap, dOut, chrDev, binOffset, dBd, dTick + 1);
+                           dIsAuto, counts_per_bin, binSizeArg, (long long)cap, dOut, chrDev, binOffset, dBd, dTick + 1, hook ? (ChromOut*)nullptr : hOut, hook ? (BinDev*)nullptr : (BinDev*)((char*)ctx->pin + oBd));
         auto launch_close_resolve = [&]() {
+            // (measured and dropped: close + resolve + finalize fused into one kernel — a wave collects its boundaries as tasks in LDS and resolves them densely — 376 us + a
+            //  fix-up pass for each wave's first bin against 87 + 317 us for the two kernels below: the resolve is bound by the 128-byte line fills under the boundaries either way)
             { ProfScope ps(ctx, "bin_close");
               hipLaunchKernelGGL(k_bin_close2, dim3((unsigned)((plan.ntiles + 4 * CLOSE_TILES - 1) / (4 * CLOSE_TILES))), dim3(256), 0, ctx->stream, dCh, chrDev, nchr, plan.ntiles, wordSum, rankRaw,
-                                 tileTotC, tileTotG, binOffset, dBd, stopTmp, locC, locG, d_chr); }
+                                 tileTotC, tileTotG, binOffset, dBd, binRec, d_chr); }
             ProfScope ps(ctx, "bin_resolve");
             // persistent workgroups (the number of bins is only known on the device): as many as are resident at once
             static const unsigned gridP = resident_grid((const void*)k_bin_resolve_fin<true>, 256, ctx->device), gridB = resident_grid((const void*)k_bin_resolve_fin<false>, 256, ctx->device);
-            if (packed) hipLaunchKernelGGL((k_bin_resolve_fin<true>), dim3(gridP), dim3(256), 0, ctx->stream, dCh, chrDev, binOffset, dPos0, dBd, clampHits, d_chr, stopTmp, locC, locG, d_start, d_stop, d_gc, d_count);
-            else hipLaunchKernelGGL((k_bin_resolve_fin<false>), dim3(gridB), dim3(256), 0, ctx->stream, dCh, chrDev, binOffset, dPos0, dBd, clampHits, d_chr, stopTmp, locC, locG, d_start, d_stop, d_gc, d_count);
+            if (packed) hipLaunchKernelGGL((k_bin_resolve_fin<true>), dim3(gridP), dim3(256), 0, ctx->stream, dCh, chrDev, binOffset, dPos0, dBd, clampHits, binRec, d_start, d_stop, d_gc, d_count);
+            else hipLaunchKernelGGL((k_bin_resolve_fin<false>), dim3(gridB), dim3(256), 0, ctx->stream, dCh, chrDev, binOffset, dPos0, dBd, clampHits, binRec, d_start, d_stop, d_gc, d_count);
         };
         auto host_totals = [&]() {
             total = 0;
@@ -1086,9 +1111,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(TS_T), 0, ctx->stream, nchr, dOut, binOffset, dBd, bin_size, (long long)cap);
             launch_close_resolve();
         } else {
-            BinDev* hBd = (BinDev*)((char*)ctx->pin + oBd);
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut, dOut, nchr * sizeof(ChromOut), hipMemcpyDeviceToHost, ctx->stream));
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hBd, dBd, sizeof(BinDev), hipMemcpyDeviceToHost, ctx->stream));
+            BinDev* hBd = (BinDev*)((char*)ctx->pin + oBd);       // (k_tscan_apply's last workgroup wrote the totals and the decisions into the pinned buffer itself)
             CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->bin_ev, ctx->stream));
             launch_close_resolve();
             CANVAS_HIP_TRY(ctx, hipEventSynchronize(ctx->bin_ev));       // the decisions are on the host; close / resolve are still running

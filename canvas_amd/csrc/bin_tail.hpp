@@ -142,8 +142,9 @@ __device__ __forceinline__ unsigned long long ts_block_excl_u64(unsigned long lo
     return inc - v + off;
 }
 // bins per chromosome and their offsets for a given bin size (the last lines of SampleHitArrays / BinCounts: every chromosome yields floor(possible after pos0 / binSize) bins)
+// hostOut / hostBd (optional): the same results written straight into pinned host memory (visible to the host once the kernel has completed: no D2H copy behind the kernel)
 __device__ void plan_offsets(int nchr, const ChromOut* __restrict__ totals /* pop, popBefore valid */, ChromOut* __restrict__ dOut, long long* __restrict__ binOffset, BinDev* __restrict__ bd,
-                             int binSize, long long cap, int flags, int nAuto, unsigned long long* sh16) {
+                             int binSize, long long cap, int flags, int nAuto, unsigned long long* sh16, ChromOut* __restrict__ hostOut = nullptr, BinDev* __restrict__ hostBd = nullptr) {
     const int tid = threadIdx.x;
     const int per = (nchr + TS_T - 1) / TS_T;
     const int cA = tid * per < nchr ? tid * per : nchr, cB = cA + per < nchr ? cA + per : nchr;
@@ -154,6 +155,7 @@ __device__ void plan_offsets(int nchr, const ChromOut* __restrict__ totals /* po
     for (int c = cA; c < cB; c++) {
         const long long nb = binSize > 0 ? (totals[c].pop - totals[c].popBefore) / binSize : 0;
         binOffset[c] = (long long)run; dOut[c].nbins = nb; run += (unsigned long long)nb;
+        if (hostOut) { ChromOut o = totals[c]; o.nbins = nb; hostOut[c] = o; }
     }
     if (tid == 0) {
         binOffset[nchr] = (long long)total;
@@ -161,6 +163,7 @@ __device__ void plan_offsets(int nchr, const ChromOut* __restrict__ totals /* po
         BinDev o; o.binSize = binSize; o.run = (binSize > 0 && !(flags & BD_CAPACITY)) ? 1 : 0;
         o.binMagic = binSize > 1 ? ~0ull / (unsigned long long)binSize + 1ull : 0ull; o.total = (long long)total; o.flags = flags; o.nAuto = nAuto;
         *bd = o;
+        if (hostBd) *hostBd = o;
     }
 }
 __global__ void __launch_bounds__(TS_T) k_bin_plan(int nchr, ChromOut* __restrict__ dOut, long long* __restrict__ binOffset, BinDev* __restrict__ bd, int binSize, long long cap) {
@@ -175,7 +178,7 @@ __global__ void __launch_bounds__(TS_T) k_tscan_apply(const BinChrom* __restrict
                                                       const TsPart* __restrict__ partEx, const unsigned long long* __restrict__ popBefore, TsPart* __restrict__ chrPre,
                                                       const uint8_t* __restrict__ isAuto, int countsPerBin, int binSizeArg, long long cap,
                                                       ChromOut* __restrict__ dOut, ChromDev* __restrict__ chrDev, long long* __restrict__ binOffset, BinDev* __restrict__ bd,
-                                                      uint32_t* __restrict__ tick) {
+                                                      uint32_t* __restrict__ tick, ChromOut* __restrict__ hostOut, BinDev* __restrict__ hostBd) {
     __shared__ U2 sh2[2][16];
     __shared__ int sLast, sCA;
     __shared__ unsigned long long sh16[16];
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(TS_T) k_tscan_apply(const BinChrom* __restrict
     }
     if (binSizeArg < 0) return;        // k_bin_plan follows
     __syncthreads();
-    plan_offsets(nchr, dOut, dOut, binOffset, bd, sBinSize, cap, sFlags, sN, sh16);
+    plan_offsets(nchr, dOut, dOut, binOffset, bd, sBinSize, cap, sFlags, sN, sh16, hostOut, hostBd);
 }
 
 // ---- k_bin_close with the decisions read on the device.  The record of a bin: where it closes (word start | rank inside the word - 1) and the masked-hit / G/C sums of the
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(TS_T) k_tscan_apply(const BinChrom* __restrict
 __global__ void __launch_bounds__(256) k_bin_close2(const BinChrom* __restrict__ ch, const ChromDev* __restrict__ chrDev, int nchr, int64_t ntilesTotal, const uint32_t* __restrict__ S,
                                                     const uint32_t* __restrict__ rankRaw, const uint32_t* __restrict__ tileExC, const uint32_t* __restrict__ tileExG,
                                                     const long long* __restrict__ binOffset, const BinDev* __restrict__ bd,
-                                                    int32_t* __restrict__ stopOut, uint32_t* __restrict__ locC, uint32_t* __restrict__ locG, int32_t* __restrict__ oChr) {
+                                                    uint4* __restrict__ binRec, int32_t* __restrict__ oChr) {
     const int64_t gtile0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * CLOSE_TILES;   // uniform: scalar lookups
     if (gtile0 >= ntilesTotal) return;
     if (!bd->run) return;
@@ -313,9 +316,7 @@ __global__ void __launch_bounds__(256) k_bin_close2(const BinChrom* __restrict__
             uint32_t nextB = (q + 1u) * (uint32_t)binSize;
             for (; (int64_t)nextB - r <= (int64_t)pop && (int64_t)nextB - r >= 1; q++) {
                 const long long bin = boff + (long long)q;
-                stopOut[bin] = (int32_t)(wstart + ((int64_t)nextB - r - 1));
-                locC[bin] = cEx;
-                locG[bin] = gEx;
+                binRec[bin] = make_uint4((uint32_t)(wstart + ((int64_t)nextB - r - 1)), cEx, gEx, (uint32_t)c);      // one 16-byte store per bin (four 4-byte arrays before: 87 -> .. us)
                 oChr[bin] = c;
                 nextB += (uint32_t)binSize;
             }
@@ -344,7 +345,7 @@ __device__ __forceinline__ uint32_t kth_set_bit(uint64_t m, uint32_t kk) {
 template <bool PACKED>
 __global__ void __launch_bounds__(256) k_bin_resolve_fin(const BinChrom* __restrict__ ch, const ChromDev* __restrict__ chrDev, const long long* __restrict__ binOffset,
                                                          const unsigned long long* __restrict__ pos0, const BinDev* __restrict__ bd, int clampHits,
-                                                         const int32_t* __restrict__ oChr, const int32_t* __restrict__ rec, const uint32_t* __restrict__ locC, const uint32_t* __restrict__ locG,
+                                                         const uint4* __restrict__ binRec,
                                                          int32_t* __restrict__ oStart, int32_t* __restrict__ oStop, int32_t* __restrict__ oGc, float* __restrict__ oCount) {
     constexpr int LANES = PACKED ? 1 : 4, SLOTS = 256 / LANES, RF_NEW = SLOTS - 1;
     __shared__ int32_t sStop[SLOTS], sChr[SLOTS]; __shared__ uint32_t sC[SLOTS], sG[SLOTS];
@@ -357,9 +358,10 @@ __global__ void __launch_bounds__(256) k_bin_resolve_fin(const BinChrom* __restr
         const bool live = i >= 0 && i < total;
         int32_t stop = 0; uint32_t aC = 0, aG = 0, hc = 0, hg = 0; int c = 0;
         if (live) {
-            const int32_t r = rec[i];
-            c = oChr[i];
-            aC = locC[i]; aG = locG[i];
+            const uint4 R = binRec[i];
+            const int32_t r = (int32_t)R.x;
+            c = (int)R.w;
+            aC = R.y; aG = R.z;
             const int64_t p0c = (int64_t)pos0[c];
             const int64_t wstart = (int64_t)(r & ~63);
             uint32_t kk = (uint32_t)(r & 63) + 1u;

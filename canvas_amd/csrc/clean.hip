@@ -663,6 +663,7 @@ static int32_t normalize_by_gc_loess(CleanState& st, int nchr, const uint8_t* h_
     return CANVAS_OK;
 }
 
+#include "quantize.hpp"
 #include "clean_fast.hpp"
 
 extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
@@ -925,26 +926,32 @@ extern "C" int32_t canvas_merge_cleaned(canvas_ctx* ctx, int32_t nsamples, const
     return CANVAS_OK;
 }
 
-#include "quantize.hpp"
-__global__ void __launch_bounds__(256) k_quantize_f2(const float* __restrict__ count, int64_t n, double* __restrict__ cov) {
+__global__ void __launch_bounds__(256) k_quantize_f2(const float* __restrict__ count, int64_t n, double* __restrict__ cov, int generalOnly) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) cov[i] = quantize_f2_one(count[i]);
+    if (i < n) cov[i] = quantize_f2_one(count[i], nullptr, generalOnly != 0);
 }
 extern "C" int32_t canvas_quantize_f2(canvas_ctx* ctx, const float* d_count, int64_t n, double* d_cov) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (n < 0 || (n > 0 && (!d_count || !d_cov))) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_quantize_f2: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (n > 0) hipLaunchKernelGGL(k_quantize_f2, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_count, n, d_cov);
+    if (n > 0) hipLaunchKernelGGL(k_quantize_f2, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_count, n, d_cov, getenv("CANVAS_F2_GENERAL") ? 1 : 0);      // (test hook: the general digit arithmetic for every value)
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
 }
 
 // ---------------------------------------------------------------- chromosome offsets of a grouped bin list
-__global__ void __launch_bounds__(256) k_chr_first(const int32_t* __restrict__ chr, int64_t n, int nchr, long long* __restrict__ first) {
+__global__ void __launch_bounds__(256) k_chr_first(const int32_t* __restrict__ chr, int64_t n, int nchr, long long* __restrict__ first, const unsigned long long* __restrict__ nDev = nullptr) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (nDev) n = (int64_t)*nDev < n ? (int64_t)*nDev : n;       // (enqueued behind the stage that produces the bins: the grid covers an upper bound)
     if (i >= n) return;
     int c = chr[i];
     if (c >= 0 && c < nchr && (i == 0 || chr[i - 1] != c)) atomicMin(&first[c], (long long)i);
+}
+static int32_t offsets_from_first(canvas_ctx* ctx, const long long* f, int64_t n, int32_t nchr, int64_t* h_chr_offset) {
+    h_chr_offset[nchr] = n;
+    for (int c = nchr - 1; c >= 0; c--) h_chr_offset[c] = (f[c] >= 0 && f[c] < n) ? (int64_t)f[c] : h_chr_offset[c + 1];
+    for (int c = 0; c < nchr; c++) if (h_chr_offset[c] > h_chr_offset[c + 1]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "bins are not grouped by increasing chromosome index");
+    return CANVAS_OK;
 }
 extern "C" int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_chr, int64_t n, int32_t nchr, int64_t* h_chr_offset) {
     if (!ctx) return CANVAS_ERR_INVALID;
@@ -957,11 +964,47 @@ extern "C" int32_t canvas_chromosome_offsets(canvas_ctx* ctx, const int32_t* d_c
     if (n > 0) hipLaunchKernelGGL(k_chr_first, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_chr, n, nchr, dFirst);
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, dFirst, (size_t)nchr * 8, hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const long long* f = (const long long*)ctx->pin;
-    h_chr_offset[nchr] = n;
-    for (int c = nchr - 1; c >= 0; c--) h_chr_offset[c] = (f[c] >= 0 && f[c] < n) ? (int64_t)f[c] : h_chr_offset[c + 1];
-    for (int c = 0; c < nchr; c++) if (h_chr_offset[c] > h_chr_offset[c + 1]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "bins are not grouped by increasing chromosome index");
-    return CANVAS_OK;
+    return offsets_from_first(ctx, (const long long*)ctx->pin, n, nchr, h_chr_offset);
+}
+
+int32_t cvx_clean_f2_offsets(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count, int32_t* d_gc, int32_t nchr,
+                             const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc, double* d_cov,
+                             double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, int64_t* h_chr_offset, const void** h_covq_out) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (n < 0 || n >= 0x7FFFFFFFll || nchr <= 0 || nchr > (1 << 20) || !h_chr_is_autosome || !h_n_out || !h_chr_offset || !h_covq_out || !d_cov) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline: bad arguments");
+    *h_covq_out = nullptr;
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool fused = n > 0 && !(flags & CANVAS_CLEAN_LOESS) && min_bins_per_gc >= 100 && !getenv("CANVAS_CLEAN_HOST_DRIVEN") && !getenv("CANVAS_HMM_RADIX_SELECT") && !getenv("CANVAS_PIPELINE_UNFUSED");
+    bool cleaned = false;
+    if (fused) {
+        // everything the three stages send back lands in ctx->pin: reserved BEFORE the first copy is enqueued (a later, larger reservation would free the buffer under it)
+        const size_t oFirst = (sizeof(CleanDev) + 255) & ~size_t(255);
+        int32_t rc = canvas_pin_reserve(ctx, oFirst + (size_t)nchr * 8 + 256); if (rc) return rc;
+        const bool useCq = clean_counting_selects() && !ctx->clean_cq_skip;
+        ctx->clean_cq_failed = false;
+        rc = clean_batch_enqueue(ctx, 1, &n, &d_chr, &d_start, &d_stop, &d_count, &d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc, useCq); if (rc) return rc;
+        const CleanPending& q = *std::static_pointer_cast<CleanPending>(ctx->clean_batch);
+        const unsigned long long* dN = &q.dD->nFinal;          // 0 until the last compaction has run (and stays 0 when the sample leaves the first phase: nothing below does anything then)
+        const void* hq = nullptr;
+        // (measured and dropped: the F2 hand-off written by the last compaction itself + a counting sweep over its integer keys — the compaction grows from 39 to 61 us, the
+        //  counting sweep takes 16: 10 us less per pass than k_quant_covq, at the price of a CanvasClean stage that is 21 us slower by its own account)
+        rc = cvx_quant_covq_enqueue(ctx, d_count, n, dN, d_cov, &hq); if (rc) return rc;
+        long long* dFirst = (long long*)((char*)ctx->ws + ctx->clean_ws_end);
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFirst, 0x7F, (size_t)nchr * 8, ctx->stream));     // "not seen"
+        hipLaunchKernelGGL(k_chr_first, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_chr, n, nchr, dFirst, dN);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->pin + oFirst, dFirst, (size_t)nchr * 8, hipMemcpyDeviceToHost, ctx->stream));
+        char handled = 0; bool second = false; double lsd = -1.0; int64_t nOut = 0; int32_t info[8] = {0};
+        rc = clean_batch_finish(ctx, &lsd, &nOut, info, &handled, &second); if (rc) return rc;      // the one synchronisation
+        if (handled) {
+            cleaned = true;
+            *h_n_out = nOut; if (h_local_sd_out) *h_local_sd_out = lsd; if (h_info) memcpy(h_info, info, sizeof info);
+            if (!second) { *h_covq_out = hq; return offsets_from_first(ctx, (const long long*)((const char*)ctx->pin + oFirst), nOut, nchr, h_chr_offset); }
+            // NormalizeVarianceByGC changed the counts: the last compaction ran in the second phase, after the quantisation had looked at an empty list
+        }
+    }
+    if (!cleaned) { int32_t rc = canvas_clean2(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y, flags, min_bins_per_gc, h_local_sd_out, h_n_out, h_info); if (rc) return rc; }
+    int32_t rc = cvx_quantize_f2_covq(ctx, d_count, *h_n_out, d_cov, h_covq_out); if (rc) return rc;
+    return canvas_chromosome_offsets(ctx, d_chr, *h_n_out, nchr, h_chr_offset);
 }
 
 // A cohort through CanvasClean in one call.  The single-sample stage is a chain of ~55 launches on 134 MB that sit in the Infinity Cache, bound by launch latency and one-workgroup

@@ -1485,7 +1485,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         sz.take<uint8_t>(n + 16); sz.take<unsigned long long>(nb + 2); sz.take<uint32_t>(nb + 2); sz.take<uint32_t>(n); sz.take<uint32_t>(n / 8 + 1024); sz.take<double>(nW0); sz.take<double>(CF_MAXRUN + 8);
         sz.take<int64_t>(CF_MAXRUN + 8); sz.take<long long>(65536); sz.take<CfSel>(CF_NPROB); sz.take<SelTile>(tilesUpper * CF_NPROB); sz.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1)); sz.take<unsigned long long>(64);
     }
-    int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192); if (rc) return rc;
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 8192 + (size_t)nchr * 8 + 1024); if (rc) return rc;      // (+ the chromosome-offset table cvx_clean_f2_offsets enqueues behind the stage)
     const size_t histPer = (size_t)CF_MAXQ * 1024 * SEL_REP, histBytes = histPer * (size_t)B;
     if (histBytes > ctx->sel_hist_bytes) {
         if (ctx->sel_hist) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->sel_hist)); ctx->sel_hist = nullptr; ctx->sel_hist_bytes = 0; }
@@ -1574,11 +1574,12 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     hipLaunchKernelGGL(k_cf_scatter_final, dim3(gxB, B), dim3(256), 0, ctx->stream, dArgs, 0);
     rc = canvas_pin_reserve(ctx, (size_t)B * sizeof(CleanDev)); if (rc) return rc;
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, dD, (size_t)B * sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->clean_ws_end = (ws.off + 255) & ~size_t(255);
     ctx->clean_batch = std::make_shared<CleanPending>(std::move(pend));
     return CANVAS_OK;
 }
 // Waits for the batch.  handled[s] = false: the host-driven path has to take sample s over (nothing of it was modified).  Per-sample outputs as canvas_clean2.
-static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, char* handled) {
+static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, char* handled, bool* secondPhase = nullptr) {
     std::shared_ptr<CleanPending> pp = std::static_pointer_cast<CleanPending>(ctx->clean_batch);
     ctx->clean_batch.reset();
     if (!pp) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_clean: no pending batch");
@@ -1610,6 +1611,7 @@ static int32_t clean_batch_finish(canvas_ctx* ctx, double* h_local_sd_out, int64
         hipLaunchKernelGGL(k_cf_scatter_final, dim3(gxB, 1), dim3(256), 0, ctx->stream, a, 1);
         again = true;
     }
+    if (secondPhase) *secondPhase = again;
     if (again) {
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, q.dD, (size_t)B * sizeof(CleanDev), hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -42,6 +42,7 @@ struct canvas_ctx {
     bool up_active = false;
     void* bin_dev = nullptr; hipEvent_t bin_ev = nullptr;      // bin_tail.hpp: arrival tickets + the sample's decisions (BinDev) in device memory; event behind their D2H copy
     void* gc_arena = nullptr; size_t gc_arena_bytes = 0;   // GCContentWeighted binning: read-GC profile of every position + GC prefix array (grow-only)
+    size_t clean_ws_end = 0;          // clean_fast.hpp: bytes of ctx->ws the last clean_batch_enqueue carved (what is enqueued behind it must not alias them: a second phase may follow)
     bool clean_cq_failed = false, clean_cq_skip = false;   // clean_fast.hpp: a sample's counting selects gave up (it is redone with the radix selects)
     std::shared_ptr<void> cbs_cache;     // cbs.hip: device / pinned buffers of the arc-search and permutation engines, kept between calls (a call used to spend tens of ms in hipMalloc / hipHostMalloc)
     std::shared_ptr<void> clean_batch;   // clean_fast.hpp: the batch that clean_batch_enqueue queued (consumed by clean_batch_finish)
@@ -142,7 +143,15 @@ CVX_INTERNAL int32_t cvx_allgather_boundaries_status(canvas_ctx* ctx, const int3
 // canvas_quantize_f2 fused with the counting of the genome-wide quartiles PerSampleHMM starts from (the same sweep); the result travels to *h_covq_out (pinned, valid after the
 // next synchronisation of ctx->stream) and is handed to cvx_hmm_per_sample_preq, which then needs neither the counting sweep nor a round trip of its own
 CVX_INTERNAL int32_t cvx_quantize_f2_covq(canvas_ctx* ctx, const float* d_count, int64_t n, double* d_cov, const void** h_covq_out);
+CVX_INTERNAL int32_t cvx_quant_covq_enqueue(canvas_ctx* ctx, const float* d_count, int64_t n, const unsigned long long* d_n, double* d_cov, const void** h_covq_out);
+// pipeline.hip: CanvasClean, the F2 hand-off (with the quartile counters) and the chromosome offsets enqueued back to back with the bin count read on the device: ONE
+// synchronisation for the three stages; samples CanvasClean does not finish in its first device-driven phase take the stage-by-stage calls
+CVX_INTERNAL int32_t cvx_clean_f2_offsets(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count, int32_t* d_gc, int32_t nchr,
+                                          const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc, double* d_cov,
+                                          double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info, int64_t* h_chr_offset, const void** h_covq_out);
 CVX_INTERNAL int32_t cvx_hmm_per_sample_preq(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state, const void* h_covq);
+CVX_INTERNAL int32_t cvx_hmm_per_sample_segments(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state, const void* h_covq,
+                                                 const int32_t* d_start, const int32_t* d_stop, int32_t max_inter_bin_dist, int32_t* d_segment_id, int64_t* h_nsegments);
 // canvas_bin_sample on the chromosomes this rank owns, with the bin size decided by `hook` from the per-chromosome (#hit > 0, popcount(mask), possible positions
 // in front of the first non-'n' base): the hook is where the sharded pipeline exchanges the rate pairs so that every rank derives the same size
 typedef int32_t (*cvx_bin_size_hook)(void* user, int nchr, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut);

@@ -46,7 +46,22 @@ __global__ void __launch_bounds__(256) k_keys_cov_f32(const double* __restrict__
 // level in LDS (the quartiles of a sample lie within a few units of its median) and the elements below the window; a one-workgroup pick reads the ranks off the counters.
 // Every element is checked ((double)k / 100 == x, bit for bit); a value that is not of that form, or a rank outside the window, hands the call to the radix select.
 #define CQ_WIN 8192
-struct CovQ { unsigned long long rank[8]; unsigned long long below; uint32_t nq, bad, fail, pad; int32_t lo; int32_t resultK[8]; };
+struct CovQ { unsigned long long rank[8]; unsigned long long below; uint32_t nq, bad, fail, pad; int32_t lo; int32_t resultK[8]; long long n; };
+// Utilities.Quartiles index logic (the host's quartile_idx below, on the device: the number of bins is only known there when the quantisation is enqueued behind CanvasClean)
+__device__ inline void quartile_idx_dev(long long n, unsigned long long* idx, uint32_t& cnt) {
+    cnt = 0;
+    const long long mid = n / 2;
+    if (n % 2 == 0) {
+        const long long mm = mid / 2;
+        idx[cnt++] = mid - 1; idx[cnt++] = mid;
+        if (mid % 2 == 0) { idx[cnt++] = mm - 1; idx[cnt++] = mm; idx[cnt++] = mid + mm - 1; idx[cnt++] = mid + mm; }
+        else { idx[cnt++] = mm; idx[cnt++] = mm + mid; }
+    } else {
+        idx[cnt++] = mid;
+        if ((n - 1) % 4 == 0) { const long long k = (n - 1) / 4; idx[cnt++] = k - 1; idx[cnt++] = k; idx[cnt++] = 3 * k; idx[cnt++] = 3 * k + 1; }
+        else { const long long k = (n - 3) / 4; idx[cnt++] = k; idx[cnt++] = k + 1; idx[cnt++] = 3 * k + 1; idx[cnt++] = 3 * k + 2; }
+    }
+}
 __device__ __forceinline__ bool covq_key(double x, long long& k) {
     k = llrint(x * 100.0);
     return x == x && k >= 0 && k < (1ll << 30) && (double)k / 100.0 == x && !(k == 0 && __double2hiint(x) < 0);     // (-0.0 has its own place in the sorted order)
@@ -90,9 +105,19 @@ __global__ void __launch_bounds__(1024) k_covq_hist(const double* __restrict__ c
     __syncthreads();
     for (int i = threadIdx.x; i < CQ_WIN; i += 1024) { const uint32_t v = lw[i]; if (v) atomicAdd(&win[i], v); }
 }
-__global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, const uint32_t* __restrict__ win) {
+// Qres == NULL: the ranks were written by the host, the result stays in Q.  Qres != NULL (pipeline): the ranks are derived here from the number of bins (n, or *nDev when the
+// host does not know it yet), the result goes to Qres and Q / win are left all zero for the next call (the counters live in the context, nothing is uploaded or cleared per call).
+__global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, uint32_t* __restrict__ win, long long n = -1, const unsigned long long* __restrict__ nDev = nullptr, CovQ* __restrict__ Qres = nullptr) {
     __shared__ unsigned long long sTot[16];
+    __shared__ unsigned long long sRank[8];
+    __shared__ uint32_t sNq, sFail;
+    __shared__ int32_t sRes[8];
     const int PER = CQ_WIN / 1024;
+    if (Qres) {
+        if (nDev) n = (long long)*nDev < n ? (long long)*nDev : n;
+        if (threadIdx.x == 0) { sFail = 0; uint32_t c = 0; if (n >= 5) quartile_idx_dev(n, sRank, c); else sFail = 1; sNq = c; }
+        if (threadIdx.x < 8) sRes[threadIdx.x] = 0;
+    } else if (threadIdx.x == 0) { sNq = Q->nq; sFail = 0; for (uint32_t j = 0; j < Q->nq && j < 8; j++) sRank[j] = Q->rank[j]; }
     uint32_t c[PER]; unsigned long long mine = 0;
     for (int k = 0; k < PER; k++) { c[k] = win[threadIdx.x * PER + k]; mine += c[k]; }
     unsigned long long inc = mine;
@@ -100,23 +125,36 @@ __global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, const 
     for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += o; }
     if ((threadIdx.x & 63) == 63) sTot[threadIdx.x >> 6] = inc;
     __syncthreads();
-    unsigned long long before = Q->below, total = Q->below;
+    const unsigned long long below = Q->below; const int32_t lo = Q->lo;
+    unsigned long long before = below, total = below;
     for (int w = 0; w < 16; w++) { if (w < (int)(threadIdx.x >> 6)) before += sTot[w]; total += sTot[w]; }
     before += inc - mine;
-    for (uint32_t j = 0; j < Q->nq; j++) {
-        const unsigned long long want = Q->rank[j];
-        if (threadIdx.x == 0 && (want < Q->below || want >= total)) Q->fail = 1u;          // a quartile outside the window
+    const uint32_t nq = sNq;
+    for (uint32_t j = 0; j < nq; j++) {
+        const unsigned long long want = sRank[j];
+        if (threadIdx.x == 0 && (want < below || want >= total)) { if (Qres) sFail = 1; else Q->fail = 1u; }          // a quartile outside the window
         if (want >= before && want < before + mine) {
             unsigned long long cum = before;
-            for (int k = 0; k < PER; k++) { cum += c[k]; if (want < cum) { Q->resultK[j] = Q->lo + (int)threadIdx.x * PER + k; break; } }
+            for (int k = 0; k < PER; k++) { cum += c[k]; if (want < cum) { const int32_t r = lo + (int)threadIdx.x * PER + k; if (Qres) sRes[j] = r; else Q->resultK[j] = r; break; } }
         }
+    }
+    if (!Qres) return;
+    __syncthreads();
+    for (int k = 0; k < PER; k++) win[threadIdx.x * PER + k] = 0u;
+    if (threadIdx.x == 0) {
+        CovQ o; memset(&o, 0, sizeof o);
+        o.nq = nq; o.bad = Q->bad; o.fail = sFail; o.lo = lo; o.below = below; o.n = n;
+        for (uint32_t j = 0; j < nq; j++) { o.rank[j] = sRank[j]; o.resultK[j] = sRes[j]; }
+        *Qres = o;
+        CovQ z; memset(&z, 0, sizeof z); *Q = z;
     }
 }
 
 // The same count inside the sweep that produces the coverage (pipeline.hip): cov[i] = F2(count[i]) is written and counted in one pass — the value is N / 100 by construction,
 // N comes out of the digit arithmetic — so PerSampleHMM starts without a sweep of its own (37 us for a WGS sample) and without its own round trip for the six ranks.
-__global__ void __launch_bounds__(1024) k_quant_covq(const float* __restrict__ count, int64_t n, double* __restrict__ cov, CovQ* __restrict__ Q, uint32_t* __restrict__ win) {
+__global__ void __launch_bounds__(1024) k_quant_covq(const float* __restrict__ count, int64_t n, double* __restrict__ cov, CovQ* __restrict__ Q, uint32_t* __restrict__ win, const unsigned long long* __restrict__ nDev = nullptr) {
     __shared__ uint32_t lw[CQ_WIN];
+    if (nDev) n = (int64_t)*nDev < n ? (int64_t)*nDev : n;        // (enqueued behind CanvasClean: its bin count is still on the device)
     __shared__ long long sv[33];
     __shared__ int sLo;
     if (threadIdx.x < 33) { const int64_t i = (int64_t)((double)n * (threadIdx.x + 0.5) / 33.0); long long k = -1; if (i < n) (void)quantize_f2_one(count[i], &k); sv[threadIdx.x] = k; }
@@ -374,6 +412,41 @@ __global__ void __launch_bounds__(256) k_make_blocks(const int32_t* __restrict__
     while (lo < nchr - 1 && first[lo + 1] <= i) lo++;        // chromosomes without blocks share an index
     T b; b.chrom = lo; b.t0 = (i - first[lo]) * per;
     out[i] = b;
+}
+
+// The data-independent tables of the stage in ONE launch: the three block / chunk lists (k_make_blocks), the per-chromosome result slots, and — PerSampleHMM — the
+// table index of every bin (k_hmm_index: it needs nothing but the threshold).  Round 3 issued them as seven launches / fills between two host round trips.
+template <typename T> __device__ __forceinline__ void make_block_entry(const int32_t* __restrict__ first, int nchr, int i, int per, T* __restrict__ out) {
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (first[mid] <= i) lo = mid; else hi = mid - 1; }
+    while (lo < nchr - 1 && first[lo + 1] <= i) lo++;        // chromosomes without blocks share an index
+    T b; b.chrom = lo; b.t0 = (i - first[lo]) * per;
+    out[i] = b;
+}
+// the per-chromosome descriptors of the stage, BY VALUE (<= HMM_BYVAL chromosomes: the argument block is copied at launch, no H2D copy in front of the stage)
+#define HMM_BYVAL 64
+struct HmmDescPack { HmmChrom chroms[HMM_BYVAL]; int64_t off[HMM_BYVAL + 1]; int32_t first[HMM_BYVAL + 1], firstChunk[HMM_BYVAL + 1], firstS[HMM_BYVAL + 1], firstGroup[HMM_BYVAL + 1]; };
+struct HmmDescDev { HmmChrom* chroms; int64_t* off; int32_t* first; int32_t* firstChunk; int32_t* firstS; int32_t* firstGroup; };
+template <typename VB_T, typename BB_T>
+__global__ void __launch_bounds__(256) k_hmm_setup(const HmmDescPack pack, int usePack, HmmDescDev D, int nchr,
+                                                   int nblocks, int nblocksS, int nchunks, int vb, int vbs, int bbChunk, VB_T* __restrict__ vBlocks, VB_T* __restrict__ sBlocks, BB_T* __restrict__ bChunks,
+                                                   const double* __restrict__ cov, int64_t N, double maxThreshold, int32_t* __restrict__ idx, int32_t* __restrict__ dLast, int32_t* __restrict__ dFail) {
+    const int32_t* first = usePack ? pack.first : D.first; const int32_t* firstS = usePack ? pack.firstS : D.firstS; const int32_t* firstChunk = usePack ? pack.firstChunk : D.firstChunk;
+    if (usePack && blockIdx.x == 0) {        // publish the tables for the kernels that follow
+        for (int c = threadIdx.x; c < nchr; c += 256) D.chroms[c] = pack.chroms[c];
+        for (int c = threadIdx.x; c <= nchr; c += 256) { D.off[c] = pack.off[c]; D.first[c] = pack.first[c]; D.firstChunk[c] = pack.firstChunk[c]; D.firstS[c] = pack.firstS[c]; D.firstGroup[c] = pack.firstGroup[c]; }
+    }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nblocks) make_block_entry(first, nchr, (int)i, vb, vBlocks);
+    if (i < nblocksS) make_block_entry(firstS, nchr, (int)i, vbs, sBlocks);
+    if (i < nchunks) make_block_entry(firstChunk, nchr, (int)i, bbChunk, bChunks);
+    if (i < nchr) { dLast[i] = -1; dFail[i] = 0; }            // -1: skipped chromosomes
+    if (cov && i < N) {                                       // RemoveOutliers (HiddenMarkovModelsRunner.cs:154-162) + Convert.ToInt32 (Distributions.cs:271)
+        double x = cov[i];
+        x = x > maxThreshold ? maxThreshold : x;
+        const int32_t k = (int32_t)rint(x);
+        idx[i] = k < 0 ? 0 : k;
+    }
 }
 
 // A: one lane per block
@@ -1396,9 +1469,16 @@ static inline unsigned nblk2(int64_t n, int per) { return (unsigned)((n + per - 
 // carved: idx[N] (table index per bin), the log-emission table dTab ([5][P.tableLen]) and P.  Everything after that — speculation,
 // backtrack, exact backbone, verification, sequential fallback — is mode independent: the likelihood of a step is
 // log-emission_j(t) + logA[i][j] in both modes (for the joint mode see canvas_hmm_joint).
-struct HmmEmis { int32_t* idx = nullptr; double* dTab = nullptr; };
-template <class Prepare>
-static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, size_t extraBytes, Prepare prepare, int32_t* d_state) {
+struct HmmEmis { int32_t* idx = nullptr; double* dTab = nullptr;
+                 const double* indexCov = nullptr; };   // != NULL (PerSampleHMM): idx[i] = Convert.ToInt32(min(indexCov[i], P.maxThreshold)) is filled by the set-up kernel
+// the running segment ids of the bins (canvas_segment_ids without forbidden intervals / reference ploidy) enqueued right behind the verification: one synchronisation
+// serves both; when a chromosome takes another attempt the caller derives the ids once the states are final (*valid stays false)
+struct SegPost { const int32_t* d_start; const int32_t* d_stop; int32_t maxDist; int32_t* d_segment_id; int64_t nseg = 0; bool valid = false; };
+static void enqueue_segment_ids(canvas_ctx* ctx, const int64_t* dOff, int nchr, const int32_t* d_state, const int32_t* d_start, const int32_t* d_stop, int64_t N, int32_t maxDist,
+                                uint8_t* flags, uint32_t* blockCnt, unsigned long long* dTot, int32_t* d_segment_id);
+template <class PrepareA, class PrepareB>
+static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, size_t extraBytes, PrepareA prepareA, PrepareB prepareB, int32_t* d_state, SegPost* seg = nullptr,
+                            bool descByValue = false /* prepareA launches nothing that reads the descriptor tables: they may arrive with the set-up kernel */) {
     const int64_t N = h_chr_offset[nchr];
     // VB-step blocks (speculation, verification and backtrack share them)
     std::vector<HmmChrom> chroms(nchr);
@@ -1425,6 +1505,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         if (chroms[c].T > 10) nchunks += (int)((chroms[c].T + BB_CHUNK - 1) / BB_CHUNK);
     }
     firstChunk[nchr] = nchunks;
+    const int nbSeg = (int)nblk2(N, 2048);
     WsSizer sz;
     sz.take<BbChunk>(nchunks + 1); sz.take<int32_t>(nchr + 1); sz.take<double>(nchunks + 1); sz.take<double>(nchunks + 1); sz.take<BbChunkOut>(nchunks + 1);
     sz.take<BbCross>((size_t)nchunks * BB_MAXC + 1); sz.take<ParFn>((size_t)nchunks * 16 + 1); sz.take<uint8_t>((size_t)nchunks * 16 + 8);
@@ -1435,7 +1516,9 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     sz.take<VitBlock>(nblocksS + 1); sz.take<uint16_t>(nblocksS + 8); sz.take<int32_t>(nchr + 1);
     sz.take<int32_t>(nchr + 1); sz.take<uint16_t>(nblocks + 8); sz.take<uint16_t>(ngroups + 8); sz.take<int8_t>(ngroups + 8);
     sz.take<char>(8 * 256 + (size_t)nchr * 64 + 64);
+    if (seg) { sz.take<uint8_t>(N + 16); sz.take<uint32_t>(nbSeg + 1); sz.take<unsigned long long>(1); }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + extraBytes + 65536); if (rc) return rc;
+    rc = canvas_pin_reserve(ctx, (size_t)nchr * 4 + 64); if (rc) return rc;         // verification flags (+ the segment count) come back here
     WsCarver ws(ctx->ws);
     uint16_t* psi = ws.take<uint16_t>(N + 8);
     HmmChrom* dChroms = ws.take<HmmChrom>(nchr); int32_t* dLast = ws.take<int32_t>(nchr);
@@ -1450,26 +1533,41 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     double* dChunkSum = ws.take<double>(nchunks + 1); double* dChunkBase = ws.take<double>(nchunks + 1); BbChunkOut* dChunkOut = ws.take<BbChunkOut>(nchunks + 1);
     BbCross* dCross = ws.take<BbCross>((size_t)nchunks * BB_MAXC + 1); ParFn* dAt64Fn = ws.take<ParFn>((size_t)nchunks * 16 + 1); uint8_t* dAt64Rank = ws.take<uint8_t>((size_t)nchunks * 16 + 8);
     unsigned long long* dChunkBits = ws.take<unsigned long long>(nchunks + 1); BbPost* dPost = ws.take<BbPost>((size_t)nchunks * BB_MAXC + 1);
+    uint8_t* segFlags = nullptr; uint32_t* segBlockCnt = nullptr; unsigned long long* segTot = nullptr;
+    if (seg) { segFlags = ws.take<uint8_t>(N + 16); segBlockCnt = ws.take<uint32_t>(nbSeg + 1); segTot = ws.take<unsigned long long>(1); seg->valid = false; }
 
-    // static descriptors first (they do not depend on the data and overlap with the quartile selection): six small tables in ONE packed upload
+    // static descriptors: six small tables, by value with the set-up kernel (<= HMM_BYVAL chromosomes) or in ONE packed upload
+    const bool byVal = descByValue && nchr <= HMM_BYVAL;
+    HmmDescPack pack;
     {
         auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
         const size_t oCh = 0, oFirst = al((size_t)nchr * sizeof(HmmChrom)), oOff = oFirst + al((size_t)(nchr + 1) * 4), oChunk = oOff + al((size_t)(nchr + 1) * 8),
                      oS = oChunk + al((size_t)(nchr + 1) * 4), oG = oS + al((size_t)(nchr + 1) * 4), total = oG + al((size_t)(nchr + 1) * 4);
-        std::vector<char> blob(total, 0);
-        memcpy(blob.data() + oCh, chroms.data(), (size_t)nchr * sizeof(HmmChrom)); memcpy(blob.data() + oFirst, firstBlock.data(), (size_t)(nchr + 1) * 4);
-        memcpy(blob.data() + oOff, h_chr_offset, (size_t)(nchr + 1) * 8); memcpy(blob.data() + oChunk, firstChunk.data(), (size_t)(nchr + 1) * 4);
-        memcpy(blob.data() + oS, firstS.data(), (size_t)(nchr + 1) * 4); memcpy(blob.data() + oG, firstGroup.data(), (size_t)(nchr + 1) * 4);
         char* dBlob = ws.take<char>(total);
-        rc = canvas_h2d_small(ctx, dBlob, blob.data(), total); if (rc) return rc;
+        if (byVal) {
+            memset(&pack, 0, sizeof pack);
+            memcpy(pack.chroms, chroms.data(), (size_t)nchr * sizeof(HmmChrom)); memcpy(pack.off, h_chr_offset, (size_t)(nchr + 1) * 8); memcpy(pack.first, firstBlock.data(), (size_t)(nchr + 1) * 4);
+            memcpy(pack.firstChunk, firstChunk.data(), (size_t)(nchr + 1) * 4); memcpy(pack.firstS, firstS.data(), (size_t)(nchr + 1) * 4); memcpy(pack.firstGroup, firstGroup.data(), (size_t)(nchr + 1) * 4);
+        } else {
+            std::vector<char> blob(total, 0);
+            memcpy(blob.data() + oCh, chroms.data(), (size_t)nchr * sizeof(HmmChrom)); memcpy(blob.data() + oFirst, firstBlock.data(), (size_t)(nchr + 1) * 4);
+            memcpy(blob.data() + oOff, h_chr_offset, (size_t)(nchr + 1) * 8); memcpy(blob.data() + oChunk, firstChunk.data(), (size_t)(nchr + 1) * 4);
+            memcpy(blob.data() + oS, firstS.data(), (size_t)(nchr + 1) * 4); memcpy(blob.data() + oG, firstGroup.data(), (size_t)(nchr + 1) * 4);
+            rc = canvas_h2d_small(ctx, dBlob, blob.data(), total); if (rc) return rc;
+        }
         dChroms = (HmmChrom*)(dBlob + oCh); dFirst = (int32_t*)(dBlob + oFirst); dOffDev = (int64_t*)(dBlob + oOff); dFirstChunk = (int32_t*)(dBlob + oChunk);
         dFirstS = (int32_t*)(dBlob + oS); dFirstGroup = (int32_t*)(dBlob + oG);
     }
-    if (nblocks > 0) hipLaunchKernelGGL((k_make_blocks<VitBlock>), dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dFirst, nchr, nblocks, VB, dVBlocks);
-    if (nblocksS > 0) hipLaunchKernelGGL((k_make_blocks<VitBlock>), dim3(nblk2(nblocksS, 256)), dim3(256), 0, ctx->stream, dFirstS, nchr, nblocksS, VBS, dSBlocks);
-    if (nchunks > 0) hipLaunchKernelGGL((k_make_blocks<BbChunk>), dim3(nblk2(nchunks, 256)), dim3(256), 0, ctx->stream, dFirstChunk, nchr, nchunks, BB_CHUNK, dBChunks);
+    // phase A of the mode: everything the set-up kernel needs (PerSampleHMM: the threshold); phase B: the emission tables, computed on the host while the set-up kernel runs
     HmmParams P; HmmEmis E;
-    rc = prepare(ws, P, E, (const HmmChrom*)dChroms, (const int64_t*)dOffDev); if (rc) return rc;
+    rc = prepareA(ws, P, E, (const HmmChrom*)dChroms, (const int64_t*)dOffDev); if (rc) return rc;
+    {
+        const int64_t most = std::max<int64_t>(std::max<int64_t>(E.indexCov ? N : 0, nblocks), std::max<int64_t>(std::max(nblocksS, nchunks), nchr));
+        HmmDescDev DD{dChroms, dOffDev, dFirst, dFirstChunk, dFirstS, dFirstGroup};
+        hipLaunchKernelGGL((k_hmm_setup<VitBlock, BbChunk>), dim3(nblk2(most, 256)), dim3(256), 0, ctx->stream, pack, byVal ? 1 : 0, DD, nchr, nblocks, nblocksS, nchunks, VB, VBS, BB_CHUNK,
+                           dVBlocks, dSBlocks, dBChunks, E.indexCov, N, P.maxThreshold, E.idx, dLast, dFail);
+    }
+    rc = prepareB(ws, P, E); if (rc) return rc;
     int32_t* idx = E.idx; double* dTab = E.dTab;
     size_t tabBytes = (size_t)NSTATE * P.tableLen * 8;
     size_t lds = tabBytes <= 48 * 1024 ? tabBytes : 0;
@@ -1493,9 +1591,10 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     }
     const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
     std::vector<int32_t> redo;
+    int32_t* hFail = (int32_t*)ctx->pin; unsigned long long* hSegTot = (unsigned long long*)((char*)ctx->pin + (((size_t)nchr * 4 + 15) & ~size_t(15)));
+    bool segEnqueued = false;
     if (speculative && nblocks > 0) {
         ProfScope ps(ctx, "viterbi");
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dLast, 0xFF, nchr * 4, ctx->stream));     // -1 for skipped chromosomes
         // attempt 0: lead-ins of 128 / 64 steps.  Noisy samples (states that overlap heavily) forget their history more slowly: chromosomes
         // whose verification fails are tried again with 8x and then 64x longer lead-ins before the sequential kernel takes them (57 ms for a chr1-size chromosome: a noisy
         // sample used to fall off that cliff 2-15 times per soak run; the 64x attempt costs about 0.6 ms for the same chromosome).
@@ -1504,7 +1603,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         for (int attempt = 0; attempt < 3; attempt++) {
             const int mult = attempt == 0 ? 1 : (attempt == 1 ? 8 : 64);
             const int leadSpec = mult * VW, leadVer = mult * VW2;
-            CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));
+            if (attempt > 0) CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));      // (attempt 0: cleared by the set-up kernel)
             const dim3 gs((unsigned)((nblocksS + 63) / 64));
             if (lds && twoValued) hipLaunchKernelGGL((k_vit_spec<true, true>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             else if (lds) hipLaunchKernelGGL((k_vit_spec<true, false>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
@@ -1526,25 +1625,31 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             }
             if (lds) hipLaunchKernelGGL((k_vit_verify<true>), dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail, leadVer, dTodo);
             else hipLaunchKernelGGL((k_vit_verify<false>), dim3(laneGrid), dim3(64), 0, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail, leadVer, dTodo);
-            std::vector<int32_t> hFail(nchr, 0);
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail.data(), dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail, dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (seg && attempt == 0 && !getenv("CANVAS_HMM_TEST_CORRUPT")) {
+                // the states are final unless a chromosome fails its verification (rare): the segment ids are derived now, under the same synchronisation
+                (void)segTot;
+                enqueue_segment_ids(ctx, dOffDev, nchr, d_state, seg->d_start, seg->d_stop, N, seg->maxDist, segFlags, segBlockCnt, hSegTot /* pinned: the count is written straight to the host */, seg->d_segment_id);
+                segEnqueued = true;
+            }
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             redo.clear();
             for (int c = 0; c < nchr; c++) if (hFail[c] && chroms[c].T > 10) redo.push_back(c);
             if (redo.empty() || getenv("CANVAS_HMM_TEST_CORRUPT") || getenv("CANVAS_HMM_NO_RETRY")) break;
             if (attempt < 2) {       // the failed chromosomes become the to-do mask of the next attempt (dRedo doubles as the mask: nchr entries)
                 if (attempt == 0) { ctx->hmm_retry = (int)redo.size(); { ProfScope pr(ctx, "viterbi_retry"); } }     // counted for the tests / bench
-                int32_t rcq = canvas_h2d_small(ctx, dRedo, hFail.data(), nchr * 4); if (rcq) return rcq;
+                int32_t rcq = canvas_h2d_small(ctx, dRedo, hFail, nchr * 4); if (rcq) return rcq;
                 dTodo = dRedo;
             }
         }
+        if (seg && segEnqueued && redo.empty() && ctx->hmm_retry == 0) { seg->valid = true; seg->nseg = (int64_t)*hSegTot; }
     } else {
         for (int c = 0; c < nchr; c++) redo.push_back(c);
     }
     if (!redo.empty()) {
         // exact sequential evaluation (all chromosomes when speculation is disabled, otherwise only those whose verification failed)
         ProfScope ps(ctx, "viterbi_sequential");
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRedo, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        rc = canvas_h2d_small(ctx, dRedo, redo.data(), redo.size() * 4); if (rc) return rc;
         hipLaunchKernelGGL(k_viterbi, dim3((unsigned)redo.size()), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, dLast, dRedo);
         backtrack(false);
     }
@@ -1556,7 +1661,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
 
 extern "C" {
 
-static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t nAll, int32_t* d_state, const CovQ* preQ = nullptr) {
+static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t nAll, int32_t* d_state, const CovQ* preQ = nullptr, SegPost* seg = nullptr) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !d_cov || !h_chr_offset || !d_state || !d_cov_all) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1564,7 +1669,8 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     // nAll / d_cov_all: the genome the quartiles are taken over (the whole sample; == the chromosomes handled here unless the sample is sharded)
     if (nAll < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
     WsSizer ex; ex.take<uint32_t>(nAll); ex.take<int32_t>(N + 256); ex.take<double>(NSTATE * 70000); ex.take<CovQ>(1); ex.take<uint32_t>(CQ_WIN);
-    auto prepare = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom*, const int64_t*) -> int32_t {
+    double haploidMean = 0, pseudoVariance = 0;
+    auto prepareA = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom*, const int64_t*) -> int32_t {
         int32_t rc;
         uint32_t* keys = ws.take<uint32_t>(nAll); int32_t* idx = ws.take<int32_t>(N + 256); double* dTab = ws.take<double>(NSTATE * 70000);   // idx: padded for the group loads of k_vit_spec
     // 1. genome-wide quartiles of (float)coverage (HiddenMarkovModelsRunner.cs:36-50): by counting when the coverage is F2 text (k_covq_hist), by the radix select otherwise
@@ -1573,7 +1679,7 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     quartile_idx(nAll, qidx, nq);
     float v[6], q1, q2, q3;
     bool radix = getenv("CANVAS_HMM_RADIX_SELECT") != nullptr;
-    if (!radix && preQ && preQ->nq == (uint32_t)nq) {        // counted while the coverage was quantised (cvx_quantize_f2_covq): the ranks are already on the host
+    if (!radix && preQ && preQ->nq == (uint32_t)nq && preQ->n == nAll) {        // counted while the coverage was quantised (cvx_quantize_f2_covq): the ranks are already on the host
         bool same = true; for (int k = 0; k < nq; k++) same = same && preQ->rank[k] == (unsigned long long)qidx[k];
         if (same && !preQ->bad && !preQ->fail) for (int k = 0; k < nq; k++) v[k] = (float)((double)preQ->resultK[k] / 100.0);
         else radix = true;
@@ -1604,13 +1710,16 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     quartile_val(nAll, v, q1, q2, q3);
     const double median = (double)q2;
     const float iqr = q3 - q1;
-    const double pseudoVariance = (double)(iqr * iqr);
+    pseudoVariance = (double)(iqr * iqr);
     // 2. emission tables (HiddenMarkovModelsRunner.cs:111-152)
-    const double haploidMean = median / 2.0;
+    haploidMean = median / 2.0;
     P.maxThreshold = haploidMean * NSTATE;
     if (!(P.maxThreshold >= 0) || P.maxThreshold > 60000) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: coverage scale outside the supported table size");
     P.tableLen = (int32_t)std::nearbyint(P.maxThreshold) + 10 + 1;      // >= max over chromosomes of (maxValues + 10)
-    hipLaunchKernelGGL(k_hmm_index, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, d_cov, N, P.maxThreshold, idx);      // (needs the threshold only: runs while the host fills the tables below)
+        E.idx = idx; E.dTab = dTab; E.indexCov = d_cov;                 // the table indices need the threshold only: the set-up kernel fills them while the host fills the tables below
+        return CANVAS_OK;
+    };
+    auto prepareB = [&](WsCarver&, HmmParams& P, HmmEmis& E) -> int32_t {
     std::vector<double> tab((size_t)NSTATE * P.tableLen);
     for (int CN = 0; CN < NSTATE; CN++) negative_binomial_log_table(std::max((double)CN, 0.1) * haploidMean, pseudoVariance, P.tableLen, &tab[(size_t)CN * P.tableLen]);
     const double selfTransition = 0.99;
@@ -1618,12 +1727,10 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
         for (int j = 0; j < NSTATE; j++) P.logA[i][j] = std::log(i == j ? selfTransition : (1.0 - selfTransition) / (NSTATE - 1));
         P.logPi[i] = std::log((double)(1.0f / NSTATE));      // 1f / nStates widened (HMM.cs:41)
     }
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     // 3. Viterbi and backtrack: hmm_pipeline
-        E.idx = idx; E.dTab = dTab;
-        return CANVAS_OK;
+        return canvas_h2d_small(ctx, E.dTab, tab.data(), tab.size() * 8);          // (through the pinned staging area: `tab` is a local)
     };
-    return hmm_pipeline(ctx, nchr, h_chr_offset, ex.off, prepare, d_state);
+    return hmm_pipeline(ctx, nchr, h_chr_offset, ex.off, prepareA, prepareB, d_state, seg, true);
 }
 int32_t canvas_hmm_per_sample(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
     if (!ctx) return CANVAS_ERR_INVALID;
@@ -1638,25 +1745,36 @@ int32_t cvx_hmm_per_sample_preq(canvas_ctx* ctx, int32_t nchr, const double* d_c
     if (nchr <= 0 || !h_chr_offset) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample: bad arguments");
     return hmm_per_sample_impl(ctx, nchr, d_cov, h_chr_offset, d_cov, h_chr_offset[nchr], d_state, (const CovQ*)h_covq);
 }
+// PerSampleHMM + the running segment ids (canvas_segment_ids) with the ids enqueued behind the verification of the speculative Viterbi pass: one synchronisation for both
+int32_t cvx_hmm_per_sample_segments(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state, const void* h_covq,
+                                    const int32_t* d_start, const int32_t* d_stop, int32_t max_inter_bin_dist, int32_t* d_segment_id, int64_t* h_nsegments) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr <= 0 || !h_chr_offset || !d_start || !d_stop || !d_segment_id) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline: bad arguments");
+    SegPost sp; sp.d_start = d_start; sp.d_stop = d_stop; sp.maxDist = max_inter_bin_dist; sp.d_segment_id = d_segment_id;
+    const int64_t N = h_chr_offset[nchr];
+    int32_t rc = hmm_per_sample_impl(ctx, nchr, d_cov, h_chr_offset, d_cov, N, d_state, (const CovQ*)h_covq, N > 0 ? &sp : nullptr); if (rc) return rc;
+    if (sp.valid) { if (h_nsegments) *h_nsegments = sp.nseg; return CANVAS_OK; }
+    return canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, h_nsegments);
+}
+// d_n != NULL: the number of bins is min(n, *d_n), read on the device (the call is enqueued behind the CanvasClean that produces it)
+int32_t cvx_quant_covq_enqueue(canvas_ctx* ctx, const float* d_count, int64_t n, const unsigned long long* d_n, double* d_cov, const void** h_covq_out) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    *h_covq_out = nullptr;
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->covq_dev) { CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->covq_dev, 512 + CQ_WIN * 4)); CANVAS_HIP_TRY(ctx, hipMemsetAsync(ctx->covq_dev, 0, 512 + CQ_WIN * 4, ctx->stream)); }      // k_covq_pick leaves the counters zero
+    if (!ctx->covq_pin) CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->covq_pin, 256, hipHostMallocDefault));
+    CovQ* dQ = (CovQ*)ctx->covq_dev; CovQ* dQres = (CovQ*)ctx->covq_pin; uint32_t* dWin = (uint32_t*)((char*)ctx->covq_dev + 512);       // (the result goes straight into pinned host memory)
+    static_assert(sizeof(CovQ) <= 256, "CovQ");
+    hipLaunchKernelGGL(k_quant_covq, dim3(256), dim3(1024), 0, ctx->stream, d_count, n, d_cov, dQ, dWin, d_n);
+    hipLaunchKernelGGL(k_covq_pick, dim3(1), dim3(1024), 0, ctx->stream, dQ, dWin, (long long)n, d_n, dQres);
+    *h_covq_out = ctx->covq_pin;
+    return CANVAS_OK;
+}
 int32_t cvx_quantize_f2_covq(canvas_ctx* ctx, const float* d_count, int64_t n, double* d_cov, const void** h_covq_out) {
     if (!ctx) return CANVAS_ERR_INVALID;
     *h_covq_out = nullptr;
     if (n < 5 || getenv("CANVAS_HMM_RADIX_SELECT")) return canvas_quantize_f2(ctx, d_count, n, d_cov);     // (fewer than 5 bins: PerSampleHMM refuses the sample anyway)
-    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->covq_dev) CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->covq_dev, 256 + CQ_WIN * 4));
-    if (!ctx->covq_pin) CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->covq_pin, 256, hipHostMallocDefault));
-    CovQ* dQ = (CovQ*)ctx->covq_dev; uint32_t* dWin = (uint32_t*)((char*)ctx->covq_dev + 256);
-    int64_t qidx[6]; int nq;
-    quartile_idx(n, qidx, nq);
-    CovQ hQ; memset(&hQ, 0, sizeof hQ); hQ.nq = (uint32_t)nq;
-    for (int k = 0; k < nq; k++) hQ.rank[k] = (unsigned long long)qidx[k];
-    int32_t rc = canvas_h2d_small(ctx, dQ, &hQ, sizeof hQ); if (rc) return rc;
-    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dWin, 0, CQ_WIN * 4, ctx->stream));
-    hipLaunchKernelGGL(k_quant_covq, dim3(256), dim3(1024), 0, ctx->stream, d_count, n, d_cov, dQ, dWin);
-    hipLaunchKernelGGL(k_covq_pick, dim3(1), dim3(1024), 0, ctx->stream, dQ, dWin);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->covq_pin, dQ, sizeof(CovQ), hipMemcpyDeviceToHost, ctx->stream));
-    *h_covq_out = ctx->covq_pin;
-    return CANVAS_OK;
+    return cvx_quant_covq_enqueue(ctx, d_count, n, nullptr, d_cov, h_covq_out);
 }
 
 int32_t cvx_hmm_per_sample_subset(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, const double* d_cov_all, int64_t n_all, int32_t* d_state, const void* h_covq) {
@@ -1786,11 +1904,22 @@ extern "C" int32_t canvas_hmm_joint(canvas_ctx* ctx, int32_t nsamples, int32_t n
         E.idx = idx; E.dTab = dL;
         return CANVAS_OK;
     };
-    return hmm_pipeline(ctx, nchr, h_chr_offset, ex.off, prepare, d_state);
+    return hmm_pipeline(ctx, nchr, h_chr_offset, ex.off, prepare, [](WsCarver&, HmmParams&, HmmEmis&) -> int32_t { return CANVAS_OK; }, d_state);
 }
 
 extern "C" {
 
+}  // extern "C"
+static void enqueue_segment_ids(canvas_ctx* ctx, const int64_t* dOff, int nchr, const int32_t* d_state, const int32_t* d_start, const int32_t* d_stop, int64_t N, int32_t maxDist,
+                                uint8_t* flags, uint32_t* blockCnt, unsigned long long* dTot, int32_t* d_segment_id) {
+    const int nb = (int)nblk2(N, 2048);
+    hipLaunchKernelGGL(k_seg_flags, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dOff, nchr, d_state, d_start, d_stop, N, maxDist, (const int64_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                       (const int64_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, flags);
+    hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(256), 0, ctx->stream, flags, N, blockCnt);
+    hipLaunchKernelGGL(k_scan_blocks2, dim3(1), dim3(1024), 0, ctx->stream, blockCnt, nb, dTot);
+    hipLaunchKernelGGL(k_seg_ids, dim3(nb), dim3(256), 0, ctx->stream, flags, blockCnt, N, d_segment_id);
+}
+extern "C" {
 int32_t canvas_segment_ids_ploidy(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, const int32_t* d_state, const int32_t* d_start,
                                   const int32_t* d_stop, int32_t max_inter_bin_dist, const int64_t* h_excl_offset, const int32_t* h_excl_start,
                                   const int32_t* h_excl_stop, const int64_t* h_ploidy_offset, const int32_t* h_ploidy_start, const int32_t* h_ploidy_end,

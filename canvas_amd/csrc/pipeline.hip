@@ -31,20 +31,18 @@ static int32_t sample_pipeline_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t
     const auto t1 = tNow();
     if (h_bin_size) *h_bin_size = binSize;
     if (h_nbins) *h_nbins = total;
-    std::vector<uint8_t> noY((size_t)nchr, 0);
-    rc = canvas_clean2(ctx, total, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y ? h_chr_is_y : noY.data(), clean_flags, min_bins_per_gc, &lsd, &nClean, info);
+    // CanvasClean, the F2 hand-off and the chromosome offsets under ONE synchronisation (the quantisation and the offsets are enqueued behind CanvasClean with the bin count
+    // read on the device; the quantisation also counts the genome-wide quartiles PerSampleHMM starts from)
+    const void* hCovQ = nullptr;
+    rc = cvx_clean_f2_offsets(ctx, total, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_chr_is_y, clean_flags, min_bins_per_gc, d_cov, &lsd, &nClean, info, h_chr_offset, &hCovQ);
     if (rc) return rc;
     const auto t2 = tNow();
     if (h_nbins_clean) *h_nbins_clean = nClean;
     if (h_local_sd) *h_local_sd = lsd;
-    // the quantisation also counts the genome-wide quartiles PerSampleHMM starts from; they come back with the chromosome offsets (one synchronisation)
-    const void* hCovQ = nullptr;
-    rc = cvx_quantize_f2_covq(ctx, d_count, nClean, d_cov, &hCovQ); if (rc) return rc;
-    rc = canvas_chromosome_offsets(ctx, d_chr, nClean, nchr, h_chr_offset); if (rc) return rc;
     const auto t3 = tNow();
-    rc = hCovQ ? cvx_hmm_per_sample_preq(ctx, nchr, d_cov, h_chr_offset, d_state, hCovQ) : canvas_hmm_per_sample(ctx, nchr, d_cov, h_chr_offset, d_state); if (rc) return rc;
+    // PerSampleHMM with the segment ids enqueued behind the verification of its speculative pass (hCovQ == NULL: the quartiles are still to be taken, inside)
+    rc = cvx_hmm_per_sample_segments(ctx, nchr, d_cov, h_chr_offset, d_state, hCovQ, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
     const auto t4 = tNow();
-    rc = canvas_segment_ids(ctx, nchr, h_chr_offset, d_state, d_start, d_stop, max_inter_bin_dist, d_segment_id, &nseg); if (rc) return rc;
     if (h_nsegments) *h_nsegments = nseg;
     if (timing) { const auto t5 = tNow(); fprintf(stderr, "pipeline us: since the previous call returned %.0f | bin %.0f clean %.0f f2+offsets %.0f hmm %.0f segment ids %.0f | total %.0f\n", haveLast ? us(lastReturn, t0) : 0.0, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5), us(t0, t5)); }
     lastReturn = tNow(); haveLast = true;

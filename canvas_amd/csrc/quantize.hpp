@@ -5,9 +5,42 @@
 // Exact integer arithmetic: float = m * 2^e; 7 significant decimal digits (ties-to-even on the exact value, as the oracle's
 // correctly rounded printf), then half-up on the decimal digits at 2 decimals, then N/100 as a correctly rounded double
 // (= parsing the printed text).
-__device__ inline double quantize_f2_one(float v, long long* kOut = nullptr) {
+// The counts of the path lie in [0.001, 1e7): there the seven significant digits fit 32 bits and the whole conversion is a 24 x 30-bit product, one shift with
+// round-half-even, one 32-bit division by a power of ten and one by ten (the general code below: 64-bit divisions and loops, ~2000 cycles per wave and element — it made
+// k_quant_covq VALU-bound at 58 us per WGS sample).  Same arithmetic, same results (tests/test_quantize_gpu.py compares the two on random bit patterns).
+__device__ __forceinline__ bool quantize_f2_fast(float v, float af, double& out, long long* kOut) {
+    if (!(af >= 0.001f && af < 1.0e7f)) return false;
+    const uint32_t bits = __float_as_uint(af);
+    const uint32_t m = (bits & 0x7FFFFFu) | 0x800000u;          // normal: af >= 0.001
+    const int s = 150 - (int)(bits >> 23);                      // af = m * 2^-s, 0 <= s <= 33
+    int d;                                                      // decimals kept by the 7-significant-digit stage = 7 - number of integer digits
+    if (af >= 1.0f) d = 6 - (af >= 10.0f) - (af >= 100.0f) - (af >= 1000.0f) - (af >= 10000.0f) - (af >= 100000.0f) - (af >= 1000000.0f);
+    else { const double a = (double)af; d = a >= 0.1 ? 7 : (a >= 0.01 ? 8 : 9); }
+    uint32_t p = 1u;                                            // 10^d
+    p = d >= 1 ? 10u : p; p = d >= 2 ? 100u : p; p = d >= 3 ? 1000u : p; p = d >= 4 ? 10000u : p; p = d >= 5 ? 100000u : p;
+    p = d >= 6 ? 1000000u : p; p = d >= 7 ? 10000000u : p; p = d >= 8 ? 100000000u : p; p = d >= 9 ? 1000000000u : p;
+    const unsigned long long num = (unsigned long long)m * (unsigned long long)p;      // < 2^24 * 10^9 < 2^54
+    uint32_t R7;                                                // round-half-even of num / 2^s: in [10^6, 10^7]
+    if (s == 0) R7 = (uint32_t)num;
+    else {
+        unsigned long long q = num >> s; const unsigned long long rem = num & ((1ull << s) - 1ull), half = 1ull << (s - 1);
+        if (rem > half || (rem == half && (q & 1ull))) q++;
+        R7 = (uint32_t)q;
+    }
+    const int dd = d - 2;                                       // digits dropped by the two-decimal stage (half-up on the decimal digits)
+    uint32_t N2;
+    if (dd <= 0) N2 = R7 * (dd == 0 ? 1u : (dd == -1 ? 10u : 100u));
+    else { const uint32_t p1 = p / 1000u;                       // 10^(dd - 1)
+           N2 = (R7 / p1 + 5u) / 10u; }
+    const double r = (double)N2 / 100.0;
+    if (kOut && !(v < 0) && N2 < (1u << 30)) *kOut = (long long)N2;
+    out = v < 0 ? -r : r;
+    return true;
+}
+__device__ inline double quantize_f2_one(float v, long long* kOut = nullptr, bool generalOnly = false) {
     if (kOut) *kOut = -1;                                       // the integer N with result = N / 100, when the value went through the digit arithmetic and is not negative
     const float af = fabsf(v);
+    { double fast; if (!generalOnly && quantize_f2_fast(v, af, fast, kOut)) return fast; }
     if (af != af) return (double)v;                             // NaN passes through
     if (af < 0.001f) { if (kOut) *kOut = 0; return 0.0; }       // prints 0.00
     if (af >= 1.0e15f) return (double)v;                                                  // outside the supported count range

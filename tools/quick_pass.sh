@@ -13,5 +13,5 @@ for l in sys.stdin.read().splitlines()[::-1]:
     except Exception: pass
 "
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o pass -- python $R/bench.py $FLAGS --steps 5 --warmup 2 "$@" > /tmp/bench_prof.log 2>&1; echo "pass profile rc $?"
-db=$(find /tmp/prof1 -name "*.db" | head -1); (cd $R; python tools/rocprof_summary.py $db $O/kernel_stats.txt /tmp/bench_prof.log > /dev/null; python tools/timeline.py $db 6 > $O/pass_timeline.txt 2>&1)
+db=$(find /tmp/prof1 -name "*.db" | head -1); (cd $R; python tools/rocprof_summary.py $db $O/kernel_stats.txt /tmp/bench_prof.log > /dev/null; TIMELINE_PASS=6 TIMELINE_JSON=$O/pass_timeline.json python tools/timeline.py $db 6 > $O/pass_timeline.txt 2>&1)
 cat $O/pass_timeline.txt

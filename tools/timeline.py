@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-pass kernel timeline of bench.py from a rocprofv3 (rocpd sqlite) kernel trace: which kernels ran in the last timed pass, their
 durations and the idle gaps between them.  usage: tools/timeline.py <results.db> [min_gap_us]"""
+import os
 import sqlite3
 import sys
 
@@ -12,7 +13,9 @@ rows = [(n.split("(")[0].replace("void ", ""), s, e) for n, s, e in rows]
 starts = [i for i, r in enumerate(rows) if r[0].startswith("k_tile_stats") or r[0].startswith("k_tile_summary<") or r[0] in ("k_tile_summary", "k_tile_summary_packed")]
 if len(starts) < 2:
     sys.exit("no passes found")
-a, b = starts[-2], starts[-1]
+# which pass: TIMELINE_PASS = index of the pass among the passes of the run (bench.py: warmup + steps - 1 = the last timed one); default: the one before the last
+pi = int(os.environ.get("TIMELINE_PASS", "-2"))
+a, b = starts[pi], starts[pi + 1]
 seg = rows[a:b]
 t0 = seg[0][1]
 busy = sum(e - s for _, s, e in seg)
