@@ -45,6 +45,7 @@ struct canvas_ctx {
     size_t clean_ws_end = 0;          // clean_fast.hpp: bytes of ctx->ws the last clean_batch_enqueue carved (what is enqueued behind it must not alias them: a second phase may follow)
     bool clean_cq_failed = false, clean_cq_skip = false;   // clean_fast.hpp: a sample's counting selects gave up (it is redone with the radix selects)
     std::shared_ptr<void> cbs_cache;     // cbs.hip: device / pinned buffers of the arc-search and permutation engines, kept between calls (a call used to spend tens of ms in hipMalloc / hipHostMalloc)
+    std::shared_ptr<void> hmm_pool;      // hmm.hip: helper threads that fill the negative-binomial emission tables of a sample
     std::shared_ptr<void> clean_batch;   // clean_fast.hpp: the batch that clean_batch_enqueue queued (consumed by clean_batch_finish)
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;

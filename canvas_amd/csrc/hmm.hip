@@ -1436,6 +1436,36 @@ static void negative_binomial_log_table(double mean, double variance, int maxVal
     }
 }
 
+// The five emission tables of a sample are independent: helper threads of the context fill four of them while the calling thread builds the descriptors of the stage and
+// fills the fifth (same calls, same arguments, same values; 1400 entries of pow / log / lgamma / exp / log are 50-90 us on one core — on the critical path of every pass,
+// with the device idle: the quartiles they depend on have only just arrived)
+#include <condition_variable>
+struct NbJob { double mean, variance; int len; double* out; };
+class NbPool {
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv, cvDone; std::vector<NbJob> jobs; size_t next = 0; int pending = 0; bool stop = false;
+    void loop() {
+        for (;;) {
+            NbJob j;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || next < jobs.size(); }); if (stop) return; j = jobs[next++]; }
+            negative_binomial_log_table(j.mean, j.variance, j.len, j.out);
+            { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cvDone.notify_all(); }
+        }
+    }
+public:
+    explicit NbPool(int n) { for (int i = 0; i < n; i++) th.emplace_back([this] { loop(); }); }
+    ~NbPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+    void submit(const NbJob* j, int n) { { std::lock_guard<std::mutex> lk(mu); jobs.assign(j, j + n); next = 0; pending = n; } cv.notify_all(); }
+    void finish() {                         // the caller takes what is still waiting, then waits for the helpers
+        for (;;) {
+            NbJob j;
+            { std::lock_guard<std::mutex> lk(mu); if (next >= jobs.size()) break; j = jobs[next++]; }
+            negative_binomial_log_table(j.mean, j.variance, j.len, j.out);
+            { std::lock_guard<std::mutex> lk(mu); --pending; }
+        }
+        std::unique_lock<std::mutex> lk(mu); cvDone.wait(lk, [&] { return pending == 0; });
+    }
+};
+
 // Utilities.Quartiles index logic (shared with clean.hip semantics)
 static void quartile_idx(int64_t n, int64_t* idx, int& cnt) {
     cnt = 0;
@@ -1670,6 +1700,8 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     if (nAll < 5) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: fewer than 5 bins genome-wide (Quartiles would throw in the reference)");
     WsSizer ex; ex.take<uint32_t>(nAll); ex.take<int32_t>(N + 256); ex.take<double>(NSTATE * 70000); ex.take<CovQ>(1); ex.take<uint32_t>(CQ_WIN);
     double haploidMean = 0, pseudoVariance = 0;
+    std::vector<double> tab;
+    struct Joiner { NbPool* p = nullptr; ~Joiner() { if (p) p->finish(); } } joiner;      // (an early return must not leave helpers writing into `tab`)
     auto prepareA = [&](WsCarver& ws, HmmParams& P, HmmEmis& E, const HmmChrom*, const int64_t*) -> int32_t {
         int32_t rc;
         uint32_t* keys = ws.take<uint32_t>(nAll); int32_t* idx = ws.take<int32_t>(N + 256); double* dTab = ws.take<double>(NSTATE * 70000);   // idx: padded for the group loads of k_vit_spec
@@ -1717,11 +1749,18 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     if (!(P.maxThreshold >= 0) || P.maxThreshold > 60000) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "HMM: coverage scale outside the supported table size");
     P.tableLen = (int32_t)std::nearbyint(P.maxThreshold) + 10 + 1;      // >= max over chromosomes of (maxValues + 10)
         E.idx = idx; E.dTab = dTab; E.indexCov = d_cov;                 // the table indices need the threshold only: the set-up kernel fills them while the host fills the tables below
+        // the emission tables start now, on the context's helper threads (the calling thread joins in once the set-up kernel is enqueued)
+        if (!ctx->hmm_pool) ctx->hmm_pool = std::make_shared<NbPool>(NSTATE - 1);
+        (void)lgamma1_table(P.tableLen);                                 // (filled once per process, before the helpers read it)
+        tab.assign((size_t)NSTATE * P.tableLen, 0.0);
+        NbJob jobs[NSTATE];
+        for (int CN = 0; CN < NSTATE; CN++) jobs[CN] = NbJob{std::max((double)CN, 0.1) * haploidMean, pseudoVariance, P.tableLen, &tab[(size_t)CN * P.tableLen]};
+        joiner.p = static_cast<NbPool*>(ctx->hmm_pool.get());
+        joiner.p->submit(jobs, NSTATE);
         return CANVAS_OK;
     };
     auto prepareB = [&](WsCarver&, HmmParams& P, HmmEmis& E) -> int32_t {
-    std::vector<double> tab((size_t)NSTATE * P.tableLen);
-    for (int CN = 0; CN < NSTATE; CN++) negative_binomial_log_table(std::max((double)CN, 0.1) * haploidMean, pseudoVariance, P.tableLen, &tab[(size_t)CN * P.tableLen]);
+    std::static_pointer_cast<NbPool>(ctx->hmm_pool)->finish();
     const double selfTransition = 0.99;
     for (int i = 0; i < NSTATE; i++) {
         for (int j = 0; j < NSTATE; j++) P.logA[i][j] = std::log(i == j ? selfTransition : (1.0 - selfTransition) / (NSTATE - 1));
