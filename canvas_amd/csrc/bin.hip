@@ -705,109 +705,7 @@ __global__ void k_init_pos0(const BinChrom* __restrict__ ch, int nchr, unsigned 
 }
 
 
-// ---------------------------------------------------------------------------------------------- GCContentWeighted mode (mode 5)
-// CanvasBin.cs:416-506 (read-GC profile), :330-405 (observed vs expected), :626-636 (weighted count).  The reference recounts the GC
-// bases of every fragment window (O(L*F)); here the window count is a difference of an inclusive GC prefix array (O(L)).
-__global__ void __launch_bounds__(256) k_nonzero_mean(const int16_t* __restrict__ fl, int64_t len, unsigned long long* __restrict__ sumCnt /* [2] */) {
-    unsigned long long s = 0, c = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) { int v = fl[i]; if (v > 0) { s += (unsigned long long)v; c++; } }
-    s = wave_reduce_add_u64(s); c = wave_reduce_add_u64(c);
-    if (lane_id() == 0) { atomicAdd(&sumCnt[0], s); atomicAdd(&sumCnt[1], c); }
-}
-// GC prefix: P[i] = #(C/c/G/g) in bases[0, i).  Tile counts -> scan -> write.
-__global__ void __launch_bounds__(256) k_gcp_tile(const uint8_t* __restrict__ bases, int64_t len, uint32_t* __restrict__ tileCnt) {
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t tileStart = tile << TILE_SHIFT;
-    if (tileStart >= len) return;
-    const int l = lane_id();
-    uint32_t g = 0;
-    for (int it = 0; it < 4; it++) {
-        int64_t p = tileStart + it * 1024 + l * 16;
-        if (p + 16 <= len) { uint4 v = *reinterpret_cast<const uint4*>(bases + p); g += __popc(gc_bits4(v.x)) + __popc(gc_bits4(v.y)) + __popc(gc_bits4(v.z)) + __popc(gc_bits4(v.w)); }
-        else for (int i = 0; i < 16 && p + i < len; i++) { uint8_t b = bases[p + i] | 0x20; g += (b == 'c' || b == 'g'); }
-    }
-    g = wave_reduce_add_u32(g);
-    if (l == 0) tileCnt[tile] = g;
-}
-__global__ void __launch_bounds__(1024) k_gcp_scan(uint32_t* __restrict__ tileCnt, int64_t ntiles) {
-    __shared__ U2 sh[2][16];
-    uint32_t carry = 0;
-    int buf = 0;
-    for (int64_t base = 0; base < ntiles; base += 1024, buf ^= 1) {
-        int64_t t = base + threadIdx.x;
-        U2 in; in.a = t < ntiles ? tileCnt[t] : 0; in.b = 0; U2 tot;
-        const U2 ex = block_exclusive_scan2_1024(in, sh[buf], tot);
-        if (t < ntiles) tileCnt[t] = carry + ex.a;
-        carry += tot.a;
-    }
-}
-__global__ void __launch_bounds__(256) k_gcp_write(const uint8_t* __restrict__ bases, int64_t len, const uint32_t* __restrict__ tileEx, uint32_t* __restrict__ P) {
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t tileStart = tile << TILE_SHIFT;
-    if (tileStart >= len) return;
-    const int l = lane_id();
-    uint32_t run = tileEx[tile];
-    for (int it = 0; it < 4; it++) {
-        int64_t p = tileStart + it * 1024 + l * 16;
-        uint32_t bits = 0;
-        if (p + 16 <= len) { uint4 v = *reinterpret_cast<const uint4*>(bases + p); bits = gc_bits4(v.x) | (gc_bits4(v.y) << 4) | (gc_bits4(v.z) << 8) | (gc_bits4(v.w) << 12); }
-        else for (int i = 0; i < 16 && p + i < len; i++) { uint8_t b = bases[p + i] | 0x20; if (b == 'c' || b == 'g') bits |= 1u << i; }
-        uint32_t cnt = __popc(bits);
-        uint32_t inc = wave_inclusive_scan_u32(cnt);
-        uint32_t ex = run + inc - cnt;
-        for (int i = 0; i < 16; i++) if (p + i <= len) P[p + i] = ex + __popc(bits & ((1u << i) - 1u));    // P has len + 1 entries
-        run += __shfl(inc, 63, 64);
-    }
-}
-// gcContent[pos] (CanvasBin.cs:466-492) + the two 101-bin histograms of ComputeObservedVsExpectedGC (:349-356)
-__global__ void __launch_bounds__(256) k_read_gc(const uint32_t* __restrict__ P, const int16_t* __restrict__ fl, const uint8_t* __restrict__ hits, int64_t len, int meanFrag,
-                                                 uint8_t* __restrict__ readGc, unsigned long long* __restrict__ expectedC, unsigned long long* __restrict__ observedC) {
-    __shared__ unsigned int le[101], lo[101];
-    if (threadIdx.x < 101) { le[threadIdx.x] = 0; lo[threadIdx.x] = 0; }
-    __syncthreads();
-    const int64_t lim = len - (int64_t)meanFrag * 3 - 1;
-    for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < len; pos += (int64_t)gridDim.x * 256) {
-        uint32_t g = 0;
-        if (pos < lim) {
-            int f = fl[pos];
-            int cur = f == 0 ? meanFrag : (f < meanFrag * 3 ? f : meanFrag * 3);
-            long long v = 100ll * (long long)(P[pos + cur] - P[pos]) / (long long)cur;
-            g = (uint32_t)(v < 101 ? v : 101);
-        }
-        readGc[pos] = (uint8_t)g;
-        if (g < 101) { atomicAdd(&le[g], 1u); unsigned h = hits[pos]; if (h) atomicAdd(&lo[g], h); }
-    }
-    __syncthreads();
-    if (threadIdx.x < 101) { if (le[threadIdx.x]) atomicAdd(&expectedC[threadIdx.x], (unsigned long long)le[threadIdx.x]); if (lo[threadIdx.x]) atomicAdd(&observedC[threadIdx.x], (unsigned long long)lo[threadIdx.x]); }
-}
-// weighted count (CanvasBin.cs:626-636): float32 accumulation in position order, Math.Round half-even.  One wave per bin: 64 positions per step are loaded coalesced and
-// their terms min(10, hit / weight[readGC]) computed in parallel; the sum itself must round like the reference's sequential loop, so the NON-ZERO terms are added one by one in
-// position order (a position without a hit contributes +0.0f, which leaves the sum as it is) — the lane that holds the next term is picked from a ballot and its value
-// broadcast through a scalar register.  (One thread per bin walking its ~400 positions took 0.61 s per 80x genome: uncoalesced byte loads; this form streams the arrays once.)
-struct GcChrom { const uint8_t* readGc; };
-__global__ void __launch_bounds__(256) k_bin_weighted(const BinChrom* __restrict__ ch, const GcChrom* __restrict__ gch, long long nbins, const int32_t* __restrict__ oChr,
-                                                      const int32_t* __restrict__ oStart, const int32_t* __restrict__ oStop, const float* __restrict__ w, float* __restrict__ oCount) {
-    const long long i = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (i >= nbins) return;
-    const int c = oChr[i];
-    const BinChrom C = ch[c];
-    const uint8_t* __restrict__ rg = gch[c].readGc;
-    const int l = lane_id();
-    const int64_t s = oStart[i], e = oStop[i];
-    float tmp = 0.0f;
-    for (int64_t p0 = s; p0 < e; p0 += 64) {
-        const int64_t p = p0 + l;
-        float term = 0.0f;
-        if (p < e && ((C.mask[p >> 6] >> (p & 63)) & 1ull)) { const int h = C.hits[p]; if (h) term = fminf(10.0f, (float)h / w[rg[p]]); }
-        unsigned long long todo = __ballot(term != 0.0f);
-        while (todo) {
-            const int src = __builtin_ctzll(todo);
-            tmp += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), src));
-            todo &= todo - 1ull;
-        }
-    }
-    if (l == 0) oCount[i] = (float)(int)rint((double)tmp);
-}
+#include "bin_gcw.hpp"
 
 #include "bin_packed.hpp"
 #include "bin_tail.hpp"
@@ -907,7 +805,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BinPlan plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len);
     // ---- mode 5 pre-pass: mean fragment size, read-GC profile, observed/expected weights (kept in a separate allocation)
-    uint8_t* gcArena = nullptr; float* dW = nullptr; GcChrom* dGch = nullptr;       // the arena (1 B/base read-GC profile + a prefix array) lives in the context and only grows
+    std::vector<GcwChrom> hGch; uint8_t* gcArena = nullptr; float* dW = nullptr; GcwChrom* dGch = nullptr; unsigned long long* dGcStats = nullptr; float* dLut = nullptr; int32_t rc0 = 0;       // the arena (1 B/base read-GC profile + a prefix array) lives in the context and only grows
     if (gcw && ctx->up_active) {
         // the pre-pass below reads the per-base arrays on ctx->stream: a pending canvas_upload_genome_begin of them (copy stream) has to have landed first — mode 5 has no
         // per-chromosome overlap (the fence further down, which the other modes rely on, comes after these kernels)
@@ -917,42 +815,61 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         int64_t maxLen = 0, totLen = 0;
         for (int c = 0; c < nchr; c++) { maxLen = std::max(maxLen, h_len[c]); totLen += (h_len[c] + 255) & ~255ll; }
         const int64_t maxTiles = (maxLen + TILE - 1) / TILE;
-        size_t bytes = (size_t)totLen + (size_t)(maxLen + 1) * 4 + (size_t)maxTiles * 4 + 4096 + (size_t)nchr * (16 + sizeof(GcChrom)) + 202 * 8 + 101 * 4;
+        (void)maxTiles; (void)maxLen;
+        for (int c = 0; c < nchr; c++) if (((uintptr_t)d_fraglen[c] | (uintptr_t)d_bases[c] | (uintptr_t)d_hits[c]) & 15) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: bases, hits and fragment lengths must be 16-byte aligned");
+        int64_t totWords = 0; for (int c = 0; c < nchr; c++) totWords += (((h_len[c] + 63) >> 6) + 31) & ~31ll;
+        size_t bytes = (size_t)totLen + (size_t)totWords * 9 + 4096 + (size_t)nchr * (16 + sizeof(GcwChrom)) + (size_t)RG_REP * 202 * 8 + 101 * 4 + (GCW_HMAX + 1) * 101 * 4 + 8192;
         if (bytes > ctx->gc_arena_bytes) {
             if (ctx->gc_arena) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->gc_arena)); ctx->gc_arena = nullptr; ctx->gc_arena_bytes = 0; }
             CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->gc_arena, bytes)); ctx->gc_arena_bytes = bytes;
         }
         gcArena = (uint8_t*)ctx->gc_arena;
         uint8_t* p = gcArena;
-        std::vector<GcChrom> gch(nchr);
+        hGch.assign(nchr, GcwChrom{nullptr, nullptr, nullptr}); std::vector<GcwChrom>& gch = hGch;
         for (int c = 0; c < nchr; c++) { gch[c].readGc = p; p += (h_len[c] + 255) & ~255ll; }
-        uint32_t* P = (uint32_t*)p; p += ((size_t)(maxLen + 1) * 4 + 255) & ~size_t(255);
-        uint32_t* tileCnt = (uint32_t*)p; p += ((size_t)maxTiles * 4 + 255) & ~size_t(255);
+        for (int c = 0; c < nchr; c++) { gch[c].wordSum = (double*)p; p += (size_t)((((h_len[c] + 63) >> 6) + 31) & ~31ll) * 8; }      // per 64 positions: exact sum of the weighted terms ...
+        for (int c = 0; c < nchr; c++) { gch[c].wordN = p; p += (size_t)((((h_len[c] + 63) >> 6) + 31) & ~31ll); }                      // ... and how many of them are not zero
+        p = (uint8_t*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         unsigned long long* sumCnt = (unsigned long long*)p; p += ((size_t)nchr * 16 + 255) & ~size_t(255);
-        unsigned long long* hist = (unsigned long long*)p; p += 2048;
+        unsigned long long* hist = (unsigned long long*)p; p += ((size_t)RG_REP * 202 * 8 + 255) & ~size_t(255);      // RG_REP replicas of {expected[101], observed[101]}
+        dGcStats = (unsigned long long*)p; p += 256;       // GCW_REP counters of replayed bins
         dW = (float*)p; p += 512;
-        dGch = (GcChrom*)p;
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(sumCnt, 0, (size_t)nchr * 16, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(hist, 0, 202 * 8, ctx->stream));
-        for (int c = 0; c < nchr; c++) hipLaunchKernelGGL(k_nonzero_mean, dim3(1024), dim3(256), 0, ctx->stream, d_fraglen[c], h_len[c], sumCnt + 2 * c);
-        std::vector<unsigned long long> hs((size_t)nchr * 2);
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs.data(), sumCnt, (size_t)nchr * 16, hipMemcpyDeviceToHost, ctx->stream));
+        dLut = (float*)p; p += (((GCW_HMAX + 1) * 101 * 4 + 255) & ~255);
+        dGch = (GcwChrom*)p;
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(sumCnt, 0, (size_t)((char*)dW - (char*)sumCnt), ctx->stream));       // fragment sums, histogram replicas, decision counters: one fill
+        for (int c = 0; c < nchr; c++) hipLaunchKernelGGL(k_nonzero_mean2, dim3((unsigned)std::min<int64_t>(2048, (h_len[c] / 8 + 255) / 256 + 1)), dim3(256), 0, ctx->stream, d_fraglen[c], h_len[c], sumCnt + 2 * c);
+        rc0 = canvas_pin_reserve(ctx, (size_t)nchr * 16 + (size_t)RG_REP * 202 * 8 + 64); if (rc0) return rc0;
+        unsigned long long* hs = (unsigned long long*)ctx->pin;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, sumCnt, (size_t)nchr * 16, hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // MeanFragmentSize (CanvasBin.cs:164-174): NonZeroMean of the per-chromosome NonZeroMeans, all in Int16 with integer division
         long long s2 = 0, c2 = 0;
         for (int c = 0; c < nchr; c++) { int16_t m = hs[2 * c + 1] ? (int16_t)(hs[2 * c] / hs[2 * c + 1]) : 0; if (m > 0) { s2 += m; c2++; } }
         const int meanFrag = c2 ? (int)(int16_t)(s2 / c2) : 0;
         if (meanFrag <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "CNV input error - unable to determine fragment size (CanvasBin.cs:431-434)");
-        for (int c = 0; c < nchr; c++) {
-            const int64_t nt = (h_len[c] + TILE - 1) / TILE;
-            hipLaunchKernelGGL(k_gcp_tile, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, d_bases[c], h_len[c], tileCnt);
-            hipLaunchKernelGGL(k_gcp_scan, dim3(1), dim3(1024), 0, ctx->stream, tileCnt, nt);
-            hipLaunchKernelGGL(k_gcp_write, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, d_bases[c], h_len[c], tileCnt, P);
-            hipLaunchKernelGGL(k_read_gc, dim3(2048), dim3(256), 0, ctx->stream, P, d_fraglen[c], d_hits[c], h_len[c], meanFrag, (uint8_t*)gch[c].readGc, hist, hist + 101);
+        {
+            const int nWmax = (RG_T + 3 * meanFrag) / 64 + 2;
+            const size_t ldsRg = (size_t)nWmax * 12;
+            int perCu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void*)k_read_gc2, 256, ldsRg) != hipSuccess || perCu <= 0) perCu = 2;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+            const unsigned gridRg = (unsigned)(perCu * cus);
+            // x / meanFrag as (x * ceil(2^40 / meanFrag)) >> 40: exact while x < 2^22 and meanFrag < 2^15 (x = 100 * count <= 100 * 32767)
+            const unsigned long long mean40 = ((1ull << 40) + (unsigned long long)meanFrag - 1ull) / (unsigned long long)meanFrag;
+            ProfScope ps(ctx, "gcw_read_gc");
+            for (int c = 0; c < nchr; c++) {
+                const int64_t ntile = (h_len[c] + RG_T - 1) / RG_T;
+                hipLaunchKernelGGL(k_read_gc2, dim3((unsigned)std::min<int64_t>(gridRg, ntile)), dim3(256), ldsRg, ctx->stream, d_bases[c], d_fraglen[c], d_hits[c], h_len[c], meanFrag, mean40, nWmax,
+                                   (uint8_t*)gch[c].readGc, hist);
+            }
         }
         unsigned long long hh[202];
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hh, hist, sizeof hh, hipMemcpyDeviceToHost, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        {
+            unsigned long long* hr = (unsigned long long*)ctx->pin;
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hr, hist, (size_t)RG_REP * 202 * 8, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (int b = 0; b < 202; b++) { hh[b] = 0; for (int r = 0; r < RG_REP; r++) hh[b] += hr[(size_t)r * 202 + b]; }
+        }
         // observed vs expected (CanvasBin.cs:372-391)
         long long sumObserved = 0, sumExpected = 0;
         for (int b = 0; b < 101; b++) { sumExpected += (long long)hh[b]; sumObserved += (long long)hh[101 + b]; }
@@ -964,7 +881,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             w[b] = ((float)o / (float)e) * ((float)sumExpected / (float)sumObserved);
         }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dW, w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dGch, gch.data(), nchr * sizeof(GcChrom), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dGch, gch.data(), nchr * sizeof(GcwChrom), hipMemcpyHostToDevice, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     // the bin arrays are sized by the caller's capacity (the bin size may not be known yet)
@@ -1174,8 +1091,31 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     hipLaunchKernelGGL(k_bin_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dCh, nchr, binOffset, dPos0, stopTmp, locC, locG,
                        tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count, 0);
     }
-    if (gcw) hipLaunchKernelGGL(k_bin_weighted, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, d_count);
+    if (gcw) {
+        ProfScope ps(ctx, "gcw_weighted");
+        static const unsigned gridW = resident_grid((const void*)k_bin_weighted3, 256, ctx->device), gridS = resident_grid((const void*)k_gcw_words, 256, ctx->device);
+        hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, dW, dLut);
+        if (!getenv("CANVAS_GCW_SERIAL"))
+            for (int c = 0; c < nchr; c++)
+                hipLaunchKernelGGL(k_gcw_words, dim3((unsigned)std::min<int64_t>(gridS, (h_len[c] / 16 + 255) / 256 + 1)), dim3(256), 0, ctx->stream, d_mask[c], d_hits[c], hGch[c].readGc, h_len[c], dW, dLut,
+                                   hGch[c].wordSum, hGch[c].wordN);
+        hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridW, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats,
+                           getenv("CANVAS_GCW_SERIAL") ? 1 : 0);      // (test hook: every bin through the reference's own order of additions)
+        ctx->gcw_stats_dev = dGcStats; ctx->gcw_total = (long long)total;       // how many bins the interval decided / how many replayed the reference's additions: canvas_bin_gcw_stats
+    }
     CANVAS_HIP_TRY(ctx, hipGetLastError());
+    return CANVAS_OK;
+}
+
+int32_t canvas_bin_gcw_stats(canvas_ctx* ctx, int64_t* h_out2) {
+    if (!ctx || !h_out2) return CANVAS_ERR_INVALID;
+    h_out2[0] = h_out2[1] = 0;
+    if (!ctx->gcw_stats_dev) return CANVAS_OK;
+    unsigned long long v[GCW_REP];
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpy(v, ctx->gcw_stats_dev, sizeof v, hipMemcpyDeviceToHost));
+    long long rep = 0; for (int r = 0; r < GCW_REP; r++) rep += (long long)v[r];
+    h_out2[0] = ctx->gcw_total - rep; h_out2[1] = rep;
     return CANVAS_OK;
 }
 

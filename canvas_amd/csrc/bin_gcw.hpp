@@ -1,0 +1,401 @@
+// CanvasBin -m GCContentWeighted (mode 5, the Somatic-WGS default; included by bin.hip): CanvasBin.cs:416-506 (read-GC profile), :330-405 (observed vs expected),
+// :626-636 (weighted count).  Round 3 ran this chain at 55 ms per 80x genome (~0.06 of its roofline): a 4 B/base GC prefix array materialised in HBM and read twice,
+// fragment lengths streamed with 2-byte loads, and the weighted count of a bin added term by term through readlane.  This version:
+//   k_nonzero_mean2   Utilities.NonZeroMean of the fragment lengths with 16-byte loads                                         [2 B/base]
+//   k_read_gc2        the read-GC profile of a tile from a GC prefix that only ever exists in LDS: per 64 positions one bit word + one running count, for the tile and
+//                     a halo of 3 x meanFragment positions behind it; the count of the window [pos, pos + cur) is a difference of two prefix values.  Histograms of
+//                     ComputeObservedVsExpectedGC in LDS, flushed once per (persistent) workgroup into 16 replicas                 [~(1 + halo) + 2 + 1 read, 1 written B/base]
+//   k_bin_weighted2   per bin: the terms min(10, hit / weight[readGC]) are floats, so their sum in double is exact in any order; the reference adds them in float32, in
+//                     position order — its result lies within n * 2^-24 * sum of the exact sum (every partial sum is at most the final one: the terms are not negative).
+//                     When that interval does not contain a value that rounds differently, (int)Math.Round is decided; the other bins (a few per thousand) replay the
+//                     reference's additions one by one                                                                            [1/8 + 1 + 1 B/base]
+#pragma once
+
+// ---- Utilities.NonZeroMean(Int16[]) (CanvasCommon/Utilities.cs:135-151): sum and number of the positive lengths
+__global__ void __launch_bounds__(256) k_nonzero_mean2(const int16_t* __restrict__ fl, int64_t len, unsigned long long* __restrict__ sumCnt /* [2] */) {
+    unsigned long long s = 0, c = 0;
+    const int64_t n8 = len >> 3, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n8; i0 += 4 * stride) {      // four 16-byte loads in flight per thread (one at a time: 86 % of the wave cycles waiting)
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * stride; v[u] = i < n8 ? reinterpret_cast<const uint4*>(fl)[i] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int a = (int)(int16_t)(w[q] & 0xFFFFu), b = (int)(int16_t)(w[q] >> 16);
+                if (a > 0) { s += (unsigned long long)a; c++; }
+                if (b > 0) { s += (unsigned long long)b; c++; }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < (len & 7)) { const int v = fl[(n8 << 3) + threadIdx.x]; if (v > 0) { s += (unsigned long long)v; c++; } }
+    s = wave_reduce_add_u64(s); c = wave_reduce_add_u64(c);
+    __shared__ unsigned long long sh[2][4];
+    if (lane_id() == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(&sumCnt[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]); atomicAdd(&sumCnt[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]); }
+}
+
+// ---- gcContent[pos] (CanvasBin.cs:466-492) + the two 101-bin histograms of ComputeObservedVsExpectedGC (:349-356)
+// A tile of RG_T positions per workgroup round:
+//   1. the GC prefix of [tile, tile + 3 meanFragment): one bit word + one running count per 64 positions, in LDS only;
+//   2. per half tile: (a) every position as if it started no fragment (length 0 -> window [pos, pos + meanFragment)): the count slides by one position, i.e. follows from the
+//      previous one with the two bits at the window's ends, one prefix lookup per 16 positions; the positions that DO carry a fragment length are collected in an LDS list;
+//      (b) the list is worked off by all lanes (two prefix lookups and a division each) and patches the bytes of step (a); (c) histograms and the 16-byte stores.
+// History (80x genome): prefix array in HBM + two kernels 24 ms (round 3); LDS prefix, two lookups and a division per position 7 ms (VALU-bound); sliding counts, but the
+// positions with a length handled by their own lane in a count-trailing-zeros loop 7.6 ms (3.6 ms of it that loop: nine rounds per wave for the lane with the most of them).
+#define RG_T 8192                      // positions per tile
+#define RG_HALF 4096
+#define RG_LREP 4                      // histogram replicas in LDS
+#define RG_REP 16                      // histogram replicas in global memory (workgroup % RG_REP): a single set of 202 counters would be a serial chain of atomics
+__device__ __forceinline__ uint64_t gc_bits64(const uint8_t* __restrict__ bases, int64_t p, int64_t len) {
+    uint64_t g = 0;
+    if (p + 64 <= len) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(bases + p + 16 * q);
+            const uint64_t b16 = (uint64_t)(marks_to_bits4(gc_marks4(v.x)) | (marks_to_bits4(gc_marks4(v.y)) << 4) | (marks_to_bits4(gc_marks4(v.z)) << 8) | (marks_to_bits4(gc_marks4(v.w)) << 12));
+            g |= b16 << (16 * q);
+        }
+    } else {
+        for (int i = 0; i < 64 && p + i < len; i++) { const uint8_t b = bases[p + i] | 0x20; if (b == 'c' || b == 'g') g |= 1ull << i; }
+    }
+    return g;
+}
+// dynamic LDS: uint64 sBits[nWmax], then uint32 sCum[nWmax]   (nWmax = (RG_T + 3 meanFragment) / 64 + 2: a kilobyte or two for real fragment sizes, 20 KB for the largest Int16)
+__global__ void __launch_bounds__(256) k_read_gc2(const uint8_t* __restrict__ bases, const int16_t* __restrict__ fl, const uint8_t* __restrict__ hits, int64_t len, int meanFrag,
+                                                  unsigned long long mean40 /* ceil(2^40 / meanFrag): x * mean40 >> 40 == x / meanFrag for x < 2^22 */, int nWmax,
+                                                  uint8_t* __restrict__ readGc, unsigned long long* __restrict__ histRep) {
+    extern __shared__ uint64_t sDyn[];
+    uint64_t* __restrict__ sBits = sDyn; uint32_t* __restrict__ sCum = reinterpret_cast<uint32_t*>(sDyn + nWmax);
+    __shared__ unsigned int le[RG_LREP][101], lo[RG_LREP][101];
+    __shared__ uint32_t sWave[4];
+    __shared__ __attribute__((aligned(16))) uint8_t sG[RG_HALF];         // gcContent of the half tile
+    __shared__ uint32_t sList[RG_HALF];                                 // positions with a fragment length: (offset in the tile) << 16 | length
+    __shared__ uint32_t sListN;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < RG_LREP * 101; i += 256) { (&le[0][0])[i] = 0; (&lo[0][0])[i] = 0; }
+    unsigned int* __restrict__ myE = le[tid % RG_LREP]; unsigned int* __restrict__ myO = lo[tid % RG_LREP];
+    const int H = 3 * meanFrag;
+    const int64_t lim = len - (int64_t)H - 1;                      // positions from `lim` on keep gcContent 0 (the loop of CanvasBin.cs:466 stops there)
+    const int64_t ntile = (len + RG_T - 1) / RG_T;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t t0 = tile * RG_T;
+        const int64_t tEnd = t0 + RG_T < len ? t0 + RG_T : len;
+        // ---- 1. the GC prefix of [t0, tEnd + H)
+        const int64_t last = tEnd + H < len ? tEnd + H : len;
+        const int nW = (int)((last - t0 + 63) >> 6) + 1;           // (+1: a window may end exactly on the word behind the last one)
+        __syncthreads();                                           // the previous tile's readers are done with sBits / sCum
+        uint32_t carry = 0;
+        for (int base = 0; base < nW; base += 256) {
+            const int w = base + tid;
+            uint64_t g = 0;
+            if (w < nW) { const int64_t p = t0 + ((int64_t)w << 6); if (p < len) g = gc_bits64(bases, p, len); sBits[w] = g; }
+            const uint32_t cnt = (uint32_t)__popcll(g);
+            const uint32_t inc = wave_inclusive_scan_u32(cnt);
+            if ((tid & 63) == 63) sWave[tid >> 6] = inc;
+            __syncthreads();
+            uint32_t off = carry, tot = 0;
+            for (int k = 0; k < 4; k++) { if (k < (tid >> 6)) off += sWave[k]; tot += sWave[k]; }
+            if (w < nW) sCum[w] = off + inc - cnt;
+            carry += tot;
+            __syncthreads();
+        }
+        // ---- 2. the two halves of the tile, one 16-position group per thread
+        for (int half = 0; half < RG_T / RG_HALF; half++) {
+            const int64_t p = t0 + (int64_t)half * RG_HALF + 16 * (int64_t)tid;
+            if (tid == 0) sListN = 0;
+            __syncthreads();
+            uint32_t hw[4] = {0, 0, 0, 0};
+            const bool in = p < tEnd;
+            if (in) {
+                uint32_t fw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p + 16 <= len) {
+                    const uint4 h = *reinterpret_cast<const uint4*>(hits + p), f0 = *reinterpret_cast<const uint4*>(fl + p), f1 = *reinterpret_cast<const uint4*>(fl + p + 8);
+                    hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w;
+                    fw[0] = f0.x; fw[1] = f0.y; fw[2] = f0.z; fw[3] = f0.w; fw[4] = f1.x; fw[5] = f1.y; fw[6] = f1.z; fw[7] = f1.w;
+                } else {
+                    for (int j = 0; j < 16 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); fw[j >> 1] |= (uint32_t)(uint16_t)fl[p + j] << (16 * (j & 1)); }
+                }
+                const int a0 = (int)(p - t0);                                    // multiple of 16: the 16 bits at a0 lie inside one word
+                const int nlim = lim - p >= 16 ? 16 : (lim - p > 0 ? (int)(lim - p) : 0);      // positions of this group in front of `lim`
+                uint32_t out[4] = {0, 0, 0, 0};
+                if (nlim > 0) {
+                    const int b0 = a0 + meanFrag;
+                    const uint32_t bitsA = (uint32_t)(sBits[a0 >> 6] >> (a0 & 63)) & 0xFFFFu;
+                    const uint64_t wlo = sBits[b0 >> 6], whi = sBits[(b0 >> 6) + 1];
+                    const uint32_t bitsB = (uint32_t)(((b0 & 63) ? (wlo >> (b0 & 63)) | (whi << (64 - (b0 & 63))) : wlo) & 0xFFFFull);
+                    uint32_t cnt = (sCum[b0 >> 6] + (uint32_t)__popcll(wlo & ((1ull << (b0 & 63)) - 1ull))) - (sCum[a0 >> 6] + (uint32_t)__popcll(sBits[a0 >> 6] & ((1ull << (a0 & 63)) - 1ull)));
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const uint32_t v = (uint32_t)(((unsigned long long)(100u * cnt) * mean40) >> 40);      // 100 * gcCounter / meanFragmentSize (exact: 100 * cnt < 2^22, see the host)
+                        const uint32_t g = j < nlim ? (v < 101u ? v : 101u) : 0u;
+                        out[j >> 2] |= g << (8 * (j & 3));
+                        cnt += ((bitsB >> j) & 1u) - ((bitsA >> j) & 1u);
+                    }
+                    // the positions in front of `lim` that carry a fragment length go on the list
+                    uint32_t nzf = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) nzf |= ((fw[q] & 0xFFFFu) ? 1u : 0u) << (2 * q) | ((fw[q] >> 16) ? 1u : 0u) << (2 * q + 1);
+                    nzf &= nlim >= 16 ? 0xFFFFu : ((1u << nlim) - 1u);
+                    if (nzf) {
+                        uint32_t at = atomicAdd(&sListN, (uint32_t)__popc(nzf));
+#pragma unroll
+                        for (int j = 0; j < 16; j++) if ((nzf >> j) & 1u) sList[at++] = ((uint32_t)(a0 + j) << 16) | ((fw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+                    }
+                }
+                *reinterpret_cast<uint4*>(sG + 16 * tid) = make_uint4(out[0], out[1], out[2], out[3]);
+            }
+            __syncthreads();
+            // (b) the listed positions, all lanes busy: window [pos, pos + min(length, 3 meanFragment))
+            const int nl = (int)sListN;
+            for (int k = tid; k < nl; k += 256) {
+                const uint32_t ent = sList[k];
+                const int a = (int)(ent >> 16), f = (int)(int16_t)(ent & 0xFFFFu);
+                const int cur = f < H ? f : H;
+                uint32_t g = 0;
+                if (cur > 0) {                                                   // (a negative length: an empty window in the reference, gcContent 0)
+                    const int b = a + cur;
+                    const uint32_t pa = sCum[a >> 6] + (uint32_t)__popcll(sBits[a >> 6] & ((1ull << (a & 63)) - 1ull));
+                    const uint32_t pb = sCum[b >> 6] + (uint32_t)__popcll(sBits[b >> 6] & ((1ull << (b & 63)) - 1ull));
+                    const uint32_t v = 100u * (pb - pa) / (uint32_t)cur;         // 100 * gcCounter / currentFragment
+                    g = v < 101u ? v : 101u;
+                }
+                sG[a - half * RG_HALF] = (uint8_t)g;
+            }
+            __syncthreads();
+            // (c) histograms (runs of equal gcContent inside the 16 positions share one pair of updates) and the store
+            if (in) {
+                const uint4 o4 = *reinterpret_cast<const uint4*>(sG + 16 * tid);
+                const uint32_t out[4] = {o4.x, o4.y, o4.z, o4.w};
+                uint32_t runG = 0xFFFFFFFFu, runN = 0, runObs = 0;
+                const int nval = len - p >= 16 ? 16 : (int)(len - p);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (j < nval) {
+                        const uint32_t g = (out[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                        const uint32_t h = (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                        if (g != runG) {
+                            if (runN && runG < 101u) { atomicAdd(&myE[runG], runN); if (runObs) atomicAdd(&myO[runG], runObs); }
+                            runG = g; runN = 0; runObs = 0;
+                        }
+                        runN++; runObs += h;
+                    }
+                }
+                if (runN && runG < 101u) { atomicAdd(&myE[runG], runN); if (runObs) atomicAdd(&myO[runG], runObs); }
+                if (p + 16 <= len) *reinterpret_cast<uint4*>(readGc + p) = o4;
+                else for (int j = 0; j < 16 && p + j < len; j++) readGc[p + j] = (uint8_t)((out[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long* rep = histRep + (size_t)(blockIdx.x % RG_REP) * 202;
+    if (tid < 101) {
+        unsigned long long e = 0, o = 0;
+        for (int r = 0; r < RG_LREP; r++) { e += le[r][tid]; o += lo[r][tid]; }
+        if (e) atomicAdd(&rep[tid], e);
+        if (o) atomicAdd(&rep[101 + tid], o);
+    }
+}
+
+// ---- weighted count (CanvasBin.cs:626-636): tmp += Math.Min(10, (float)hit / weight[readGC]) over the possible positions in position order (float32), then (int)Math.Round
+#define GCW_REP 32
+// the reference's own order, 64 positions (one mask word) per step: the non-zero terms added one by one (a position without a hit adds +0.0f, which leaves the sum as it
+// is).  A bin can span megabases (a centromere, an assembly gap: 411 possible positions may lie far apart), so the wave first looks at 64 mask words at once and only
+// visits the words that hold a possible position.
+__device__ __forceinline__ float weighted_serial(const BinChrom& C, const uint8_t* __restrict__ rg, const float* __restrict__ w, int64_t s, int64_t e) {
+    const int l = lane_id();
+    float tmp = 0.0f;
+    const int64_t wS = s >> 6, wE = (e - 1) >> 6;
+    for (int64_t wb = wS; wb <= wE; wb += 64) {
+        const int64_t wq = wb + l;
+        uint64_t mw = 0;
+        if (wq <= wE) {
+            mw = C.mask[wq];
+            if (wq == wS) mw &= (~0ull) << (s & 63);
+            if (wq == wE && (e & 63)) mw &= (~0ull) >> (64 - (e & 63));
+        }
+        unsigned long long words = __ballot(mw != 0ull);
+        while (words) {
+            const int wl = __builtin_ctzll(words); words &= words - 1ull;
+            const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mw >> 32), wl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mw, wl);
+            const int64_t p = ((wb + wl) << 6) + l;
+            float term = 0.0f;
+            if ((m >> l) & 1ull) { const int h = C.hits[p]; if (h) term = fminf(10.0f, (float)h / w[rg[p]]); }
+            unsigned long long todo = __ballot(term != 0.0f);
+            while (todo) {
+                const int src = __builtin_ctzll(todo);
+                tmp += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), src));
+                todo &= todo - 1ull;
+            }
+        }
+    }
+    return tmp;
+}
+// The weighted count in two steps.  History (80x genome, 6.2 M bins): one wave per bin adding the terms through readlane 19.5 ms (round 3); exact sum in double, one bin per
+// wave 5.6 ms, 16 lanes per bin 5.2 ms, terms from a table + only the positions with a hit visited 6.8 ms — the SQ counters showed 1.9 ms of VALU time per SIMD (a wave
+// instruction occupies its SIMD for four cycles) on top of a chain of four dependent loads per bin.  Now:
+//   k_gcw_words      a streaming sweep like k_tile_summary: per 64-position word the exact sum (double) and the number of the non-zero terms min(10, hit / weight[readGC])
+//                    over its possible positions.  Branch-free: the term comes from a table in LDS indexed by (hit, readGC) — row 0 is 0.0f, so a position without a hit or
+//                    outside the mask costs the same five instructions as any other; hits above GCW_HMAX (a handful per genome) take a division.
+//   k_bin_weighted3  per bin (16 lanes): the sums of its whole words + the two words its ends cut, opened like k_bin_resolve does; then the interval decision.
+#define GCW_HMAX 20
+#define GCW_LONG 64          // whole words between the two end words of a bin beyond which the entire wave sums them
+__global__ void __launch_bounds__(256) k_gcw_terms(const float* __restrict__ w, float* __restrict__ lut /* [GCW_HMAX + 1][101] */) {
+    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) { const int h = i / 101, gc = i - h * 101; lut[i] = h ? fminf(10.0f, (float)h / w[gc]) : 0.0f; }
+}
+// the terms of 16 consecutive positions (hw: their hits, already zero where the position does not count; gw: their read-GC values) -> exact sum in double, number of non-zero terms
+__device__ __forceinline__ void gcw_terms16(const uint32_t (&hw)[4], const uint32_t (&gw)[4], const float* __restrict__ sT, const float* __restrict__ sW, double& sum, uint32_t& n) {
+    uint32_t big = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) big |= ((hw[q] & 0x7F7F7F7Fu) + 0x6B6B6B6Bu) | hw[q];       // bit 7 of a byte set <=> the byte is > GCW_HMAX (20 = 0x14: 0x14 + 0x6B = 0x7F)
+    big &= 0x80808080u;
+    float t[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t h = (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu, gc0 = (gw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const uint32_t gc = gc0 < 101u ? gc0 : 100u;
+        t[j] = sT[(h <= (uint32_t)GCW_HMAX ? h : 0u) * 101u + gc];
+    }
+    if (big) {          // (rare) a hit count beyond the table: the division itself
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t h = (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            if (h > (uint32_t)GCW_HMAX) { const uint32_t gc0 = (gw[j >> 2] >> (8 * (j & 3))) & 0xFFu; t[j] = fminf(10.0f, (float)(int)h / sW[gc0 < 101u ? gc0 : 100u]); }
+        }
+    }
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) { s0 += (double)t[j]; s1 += (double)t[j + 1]; s2 += (double)t[j + 2]; s3 += (double)t[j + 3]; }
+    sum = (s0 + s1) + (s2 + s3);
+    uint32_t nz = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t x = hw[q]; nz += (uint32_t)__popc((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u); }
+    n = nz;
+}
+struct GcwChrom { const uint8_t* readGc; double* wordSum; uint8_t* wordN; };
+__global__ void __launch_bounds__(256) k_gcw_words(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ hits, const uint8_t* __restrict__ rg, int64_t len,
+                                                   const float* __restrict__ w, const float* __restrict__ lut, double* __restrict__ wordSum, uint8_t* __restrict__ wordN) {
+    __shared__ float sW[101];
+    __shared__ float sT[(GCW_HMAX + 1) * 101];
+    if (threadIdx.x < 101) sW[threadIdx.x] = w[threadIdx.x];
+    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = lut[i];
+    __syncthreads();
+    const int64_t ngrp = (len + 15) >> 4;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ((ngrp + 3) & ~3ll); g += (int64_t)gridDim.x * 256) {      // (whole quads: the shuffles below)
+        const int64_t p = g << 4;
+        uint32_t hw[4] = {0, 0, 0, 0}, gw[4] = {0, 0, 0, 0};
+        uint32_t m16 = 0;
+        if (p < len) {
+            m16 = (uint32_t)((mask[p >> 6] >> (p & 63)) & 0xFFFFull);
+            if (p + 16 <= len) {
+                const uint4 h = *reinterpret_cast<const uint4*>(hits + p), gq = *reinterpret_cast<const uint4*>(rg + p);
+                hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w; gw[0] = gq.x; gw[1] = gq.y; gw[2] = gq.z; gw[3] = gq.w;
+            } else {
+                m16 &= 0xFFFFu >> (p + 16 - len);
+                for (int j = 0; j < 16 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); gw[j >> 2] |= (uint32_t)rg[p + j] << (8 * (j & 3)); }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) hw[q] &= expand4(m16 >> (4 * q));       // only possible positions count
+        }
+        double sum; uint32_t n;
+        gcw_terms16(hw, gw, sT, sW, sum, n);
+        sum += __shfl_xor(sum, 1, 64); n += __shfl_xor(n, 1, 64);
+        sum += __shfl_xor(sum, 2, 64); n += __shfl_xor(n, 2, 64);
+        if ((threadIdx.x & 3) == 0 && p < len) { wordSum[p >> 6] = sum; wordN[p >> 6] = (uint8_t)n; }
+    }
+}
+// 16 lanes per bin: lanes 0-3 open the word the bin starts in, lanes 4-7 the word it ends in (when that is another one), lanes 8-15 add the sums of the words in between
+__global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restrict__ ch, const GcwChrom* __restrict__ gch, long long nbins, const int32_t* __restrict__ oChr,
+                                                       const int32_t* __restrict__ oStart, const int32_t* __restrict__ oStop, const float* __restrict__ w, const float* __restrict__ lut,
+                                                       float* __restrict__ oCount, unsigned long long* __restrict__ replayed /* [GCW_REP] replicas: bins that replayed the reference's additions */,
+                                                       int serialOnly) {
+    __shared__ float sW[101];
+    __shared__ float sT[(GCW_HMAX + 1) * 101];
+    if (threadIdx.x < 101) sW[threadIdx.x] = w[threadIdx.x];
+    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = lut[i];
+    __syncthreads();
+    const int l = lane_id(), grp = l >> 4, sub = l & 15;
+    const long long waveId = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (long long)gridDim.x * 4;
+    for (long long i0 = waveId * 4; i0 < nbins; i0 += nwaves * 4) {      // four bins per wave and round
+        const long long i = i0 + grp;
+        const bool live = i < nbins;
+        const int c = live ? oChr[i] : 0;
+        const int64_t s = live ? oStart[i] : 0, e = live ? oStop[i] : 0;
+        double sum = 0.0; uint32_t nterms = 0;
+        if (!serialOnly && live && e > s) {
+            const int64_t wS = s >> 6, wE = (e - 1) >> 6;
+            if (sub < 8) {
+                // an end word: positions [max(s, 64 w), min(e, 64 w + 64)) of word w, one 16-position slice per lane
+                const int64_t wq = sub < 4 ? wS : wE;
+                if (sub < 4 || wE != wS) {
+                    const int64_t p = (wq << 6) + 16 * (sub & 3);
+                    const int64_t lo = s > p ? s : p, hi = e < p + 16 ? e : p + 16;
+                    if (lo < hi) {
+                        const gptr<const uint64_t> mask = as_global(ch[c].mask); const gptr<const uint8_t> hits = as_global(ch[c].hits); const gptr<const uint8_t> rg = as_global(gch[c].readGc);
+                        const int64_t len = ch[c].len;
+                        uint32_t m16 = (uint32_t)((mask[p >> 6] >> (p & 63)) & 0xFFFFull);
+                        m16 &= (0xFFFFu << (lo - p)) & (0xFFFFu >> (p + 16 - hi));
+                        uint32_t hw[4] = {0, 0, 0, 0}, gw[4] = {0, 0, 0, 0};
+                        if (p + 16 <= len) {
+                            const uint4 h = gload_uint4(hits + p), gq = gload_uint4(rg + p);
+                            hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w; gw[0] = gq.x; gw[1] = gq.y; gw[2] = gq.z; gw[3] = gq.w;
+                        } else {
+                            for (int j = 0; j < 16 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); gw[j >> 2] |= (uint32_t)rg[p + j] << (8 * (j & 3)); }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) hw[q] &= expand4(m16 >> (4 * q));
+                        gcw_terms16(hw, gw, sT, sW, sum, nterms);
+                    }
+                }
+            } else if (wE - wS - 1 <= GCW_LONG) {
+                const gptr<const double> ws = as_global(gch[c].wordSum); const gptr<const uint8_t> wn = as_global(gch[c].wordN);
+                for (int64_t wq = wS + 1 + (sub - 8); wq < wE; wq += 8) { sum += ws[wq]; nterms += wn[wq]; }
+            }
+        }
+        // a bin that spans a gap of the mask (centromere, assembly gap: up to megabases for a few hundred possible positions) would keep its eight lanes busy for thousands of
+        // dependent loads while the rest of the device waits for them (measured: 3 of the kernel's 3.9 ms): its whole words are summed by the entire wave, four loads in flight per lane
+        {
+            unsigned long long longBins = __ballot(!serialOnly && live && e > s && sub == 0 && ((e - 1) >> 6) - (s >> 6) - 1 > GCW_LONG);
+            while (longBins) {
+                const int src = __builtin_ctzll(longBins); longBins &= longBins - 1ull;
+                const long long ib = i0 + (src >> 4);
+                const int cb = oChr[ib];
+                const int64_t wS = (int64_t)oStart[ib] >> 6, wE = ((int64_t)oStop[ib] - 1) >> 6;
+                const gptr<const double> ws = as_global(gch[cb].wordSum); const gptr<const uint8_t> wn = as_global(gch[cb].wordN);
+                double s4[4] = {0, 0, 0, 0}; uint32_t n4 = 0;
+                for (int64_t wq = wS + 1 + l; wq < wE; wq += 256) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int64_t x = wq + 64 * u; if (x < wE) { s4[u] += ws[x]; n4 += wn[x]; } }
+                }
+                double ls = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { ls += __shfl_xor(ls, d, 64); n4 += __shfl_xor(n4, d, 64); }
+                if (l == src) { sum += ls; nterms += n4; }
+            }
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { sum += __shfl_xor(sum, d, 64); nterms += __shfl_xor(nterms, d, 64); }      // within the bin's 16 lanes
+        // the float32 running sum of the reference differs from the exact sum by at most nterms roundings of half an ulp of a partial sum <= the final sum (+ its own last ulp)
+        // (E <= eps (S + E) with eps = nterms 2^-24  =>  E <= eps S / (1 - eps); a few more roundings' worth for the additions in double; 2 % margin)
+        const double eps = ((double)nterms + 4.0) * 5.9604644775390625e-8;
+        const double bound = eps * sum * 1.02 + 1e-30;
+        const double rl = rint(sum - bound), rh = rint(sum + bound);
+        // decided when both ends of the interval round (half to even) to the same integer: rounding is monotone, so every value in between does too
+        const bool decided = !serialOnly && eps < 0.01 && rl == rh;
+        if (live && decided && sub == 0) oCount[i] = (float)(int)rl;
+        // the bins that are not decided replay the reference's own order of additions, the whole wave on one bin at a time
+        unsigned long long todo = __ballot(live && !decided && sub == 0);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const long long ib = i0 + (src >> 4);
+            const int cb = oChr[ib];
+            const BinChrom CB = ch[cb];
+            const float r = weighted_serial(CB, gch[cb].readGc, sW, (int64_t)oStart[ib], (int64_t)oStop[ib]);
+            if (l == 0) { oCount[ib] = (float)(int)rint((double)r); if (replayed) atomicAdd(&replayed[blockIdx.x % GCW_REP], 1ull); }
+        }
+    }
+}

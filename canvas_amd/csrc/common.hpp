@@ -41,6 +41,7 @@ struct canvas_ctx {
     std::vector<const void*> up_bases, up_mask, up_hits;
     bool up_active = false;
     void* bin_dev = nullptr; hipEvent_t bin_ev = nullptr;      // bin_tail.hpp: arrival tickets + the sample's decisions (BinDev) in device memory; event behind their D2H copy
+    long long gcw_total = 0; void* gcw_stats_dev = nullptr;     // last GCContentWeighted binning: {bins whose weighted count was decided from the exact sum's interval, bins replayed in the reference's order} (in gc_arena)
     void* gc_arena = nullptr; size_t gc_arena_bytes = 0;   // GCContentWeighted binning: read-GC profile of every position + GC prefix array (grow-only)
     size_t clean_ws_end = 0;          // clean_fast.hpp: bytes of ctx->ws the last clean_batch_enqueue carved (what is enqueued behind it must not alias them: a second phase may follow)
     bool clean_cq_failed = false, clean_cq_skip = false;   // clean_fast.hpp: a sample's counting selects gave up (it is redone with the radix selects)

@@ -149,6 +149,9 @@ int32_t canvas_bin_sample_gcweighted(canvas_ctx* ctx, int32_t nchr, const uint8_
                                      const uint8_t* h_chr_is_autosome, int32_t counts_per_bin, int32_t bin_size_in,
                                      int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                                      int32_t* h_bin_size_out, int64_t* h_nbins_per_chr, int64_t* h_nbins_total);
+/* last canvas_bin_sample_gcweighted of the context: h_out2[0] = bins whose weighted count (CanvasBin.cs:626-636) was decided from the exact sum of its terms and the rounding-error
+   interval of the reference's float32 accumulation, h_out2[1] = bins that replayed the reference's additions in position order (an interval that straddles a rounding boundary) */
+int32_t canvas_bin_gcw_stats(canvas_ctx* ctx, int64_t* h_out2);
 
 /* Predefined bins (CanvasBin -n; BinCountsForChromosome with usePredefinedBins, CanvasBin.cs:575-655): count and GC of the given intervals instead of bins of a fixed
  * number of possible positions.  Bins of all chromosomes are concatenated in chromosome order, h_bin_offset[nchr+1] indexes them; start / stop (0-based, half open) are

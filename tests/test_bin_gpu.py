@@ -179,6 +179,40 @@ def test_bin_gc_content_weighted_mode(bin_path):
         assert (ggot == gex).all(), (bs, np.nonzero(ggot != gex)[0][:8], ggot[ggot != gex][:8], gex[ggot != gex][:8], out["start"][:total].cpu().numpy()[ggot != gex][:8])
         got = out["count"][:total].cpu().numpy(); ex = np.concatenate([e[3] for e in exp]).astype(np.float32)
         assert (got == ex).all(), (np.nonzero(got != ex)[0][:5], got[got != ex][:5], ex[got != ex][:5])
+        decided, replayed = cv.bin_gcw_stats()
+        assert decided + replayed == total and decided > 0.9 * total, (decided, replayed, total)      # the exact-sum interval decides nearly every bin
+
+
+def test_gc_weighted_interval_decisions_equal_the_serial_order(monkeypatch):
+    """k_bin_weighted2 decides (int)Math.Round of the float32 running sum from the exact sum of the terms and a rounding-error interval; CANVAS_GCW_SERIAL=1 sends every bin
+    through the reference's own order of additions instead: same counts (and both equal the oracle, incl. negative fragment lengths, which the reference reads as an empty window)."""
+    import torch
+    cv = get_canvas()
+    lengths = [900_001, 130_000]
+    data = _chroms(lengths, rate=0.28)
+    rng = np.random.RandomState(32)
+    fl = [np.where(h > 0, np.clip(rng.normal(520, 140, len(h)), 1, 5000), 0).astype(np.int16) for b, h, m in data]
+    fl[0][5000:5050] = -7
+    fl[1][-3000:] = 900
+    bases, hits, masks = _upload(cv, data)
+    dfl = [to_dev(pad16(f), cv.device) for f in fl]
+    lens = np.array(lengths, np.int64)
+    cap = int(lens.sum() // 20)
+    mk = lambda dt: torch.empty(cap, dtype=dt, device=cv.device)
+    out = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+    for bs in (300, 64, 31):
+        exp, mfrag, w, _ = O.bin_gc_weighted([d[0] for d in data], [d[2] for d in data], [d[1] for d in data], fl, bs)
+        ex = np.concatenate([e[3] for e in exp]).astype(np.float32)
+        monkeypatch.delenv("CANVAS_GCW_SERIAL", raising=False)
+        o, per, total, _ = cv.bin_sample_gcweighted(bases, masks, hits, dfl, lens, [1, 1], 100, bs, out=out)
+        fast = out["count"][:total].cpu().numpy().copy()
+        d1 = cv.bin_gcw_stats()
+        monkeypatch.setenv("CANVAS_GCW_SERIAL", "1")
+        o, per, total2, _ = cv.bin_sample_gcweighted(bases, masks, hits, dfl, lens, [1, 1], 100, bs, out=out)
+        serial = out["count"][:total2].cpu().numpy()
+        d2 = cv.bin_gcw_stats()
+        assert total == total2 == len(ex) and (fast == ex).all() and (serial == ex).all(), (bs, np.nonzero(fast != ex)[0][:5], np.nonzero(serial != ex)[0][:5])
+        assert d1[0] > 0 and d2[0] == 0 and d2[1] == total
 
 
 def test_device_synth_sample_pair_matches_numpy():
