@@ -143,7 +143,7 @@ def build_tools(force=False, verbose=False):
     outs = []
     for name, src in (("CanvasBin", "canvas_bin_main.cpp"), ("CanvasClean", "canvas_clean_main.cpp"), ("CanvasPartition", "canvas_partition_main.cpp")):
         out = os.path.join(bdir, name)
-        srcs = [os.path.join(tdir, src), os.path.join(tdir, "tool_common.hpp"), os.path.join(tdir, "protobuf_dat.hpp")]
+        srcs = [os.path.join(tdir, src), os.path.join(tdir, "tool_common.hpp"), os.path.join(tdir, "protobuf_dat.hpp"), os.path.join(tdir, "fast_io.hpp")]
         th = _tool_hash(srcs)
         if force or embedded_hash(out) != th:
             cmd = ["g++", "-O2", "-std=c++17", '-DCANVAS_SRC_HASH="%s"' % th, "-o", out, srcs[0], "-L" + HERE, "-lcanvas_hip", "-lz", "-Wl,-rpath," + HERE]

@@ -1332,9 +1332,17 @@ struct PermGpu {
         CANVAS_HIP_TRY(ctx, hipMalloc((void**)&tailDev, 128 * 24)); CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&tailPin, 128 * 24, hipHostMallocDefault));
         return CANVAS_OK;
     }
-    int32_t ensure(size_t need, size_t needPin) {
+    // need: what the reservation asks for (the call's longest chromosome); minNeed: what this request cannot do without — taken when the reservation does not fit the device
+    int32_t ensure(size_t need, size_t needPin, size_t minNeed = 0) {
         CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-        if (need > bytes) { if (buf) CANVAS_HIP_TRY(ctx, hipFree(buf)); buf = nullptr; bytes = 0; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&buf, need)); bytes = need; }
+        if (need > bytes) {
+            if (buf) CANVAS_HIP_TRY(ctx, hipFree(buf));
+            buf = nullptr; bytes = 0;
+            hipError_t e = hipMalloc((void**)&buf, need);
+            if (e != hipSuccess && minNeed && minNeed < need) { (void)hipGetLastError(); buf = nullptr; need = minNeed; e = hipMalloc((void**)&buf, need); }
+            if (e != hipSuccess) { buf = nullptr; ctx->err = std::string("hipMalloc of the permutation workspace: ") + hipGetErrorString(e); return CANVAS_ERR_HIP; }
+            bytes = need;
+        }
         if (needPin > pinBytes) { if (pin) CANVAS_HIP_TRY(ctx, hipHostFree(pin)); pin = nullptr; pinBytes = 0; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, needPin, hipHostMallocDefault)); pinBytes = needPin; }
         return CANVAS_OK;
     }
@@ -1534,7 +1542,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         if (PG.reserveElems) { const size_t re = PG.reserveElems, rn = PG.reserveN;      // same layout, for the longest segment this call can meet
             want = std::max(want, al(rn * 8) + al(625 * 4) + al(256 * 625 * 4) + al(256 * 16) + al((re + (size_t)MT_HISTORY) * 4) + 5 * al(re * 4) + 2 * al((re + 256) * 4) + 2 * al(re * 8));
             wantPin = std::max(wantPin, al(rn * 8) + al(256 * 625 * 4) + al(256 * 16)); }
-        int32_t rc0 = PG.ensure(want, wantPin); if (rc0) return rc0;
+        int32_t rc0 = PG.ensure(want, wantPin, total); if (rc0) return rc0;
         st.ns_ensure += since(tE);
         char* d = PG.buf; char* h = PG.pin;
         dX = (double*)(d + oX); dSnaps = (uint32_t*)(d + oSnaps); dStat = (double*)(d + oStat);
@@ -1635,7 +1643,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
     if (PG.reserveElems) { const size_t re = PG.reserveElems, rn = PG.reserveN;      // never shrink below what perm_loop_gpu will ask for: one allocation per engine
         want = std::max(want, al(rn * 8) + al(625 * 4) + al(256 * 625 * 4) + al(256 * 16) + al((re + (size_t)MT_HISTORY) * 4) + 5 * al(re * 4) + 2 * al((re + 256) * 4) + 2 * al(re * 8));
         wantPin = std::max(wantPin, al(rn * 8) + al(256 * 625 * 4) + al(256 * 16)); }
-    int32_t rc = PG.ensure(want, wantPin); if (rc) return rc;
+    int32_t rc = PG.ensure(want, wantPin, total); if (rc) return rc;
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     char* d = PG.buf; char* h = PG.pin;
     double* dX = (double*)(d + oX); double* dStat = (double*)(d + oStat); uint32_t* dDraws = (uint32_t*)(d + oDraws) + MT_HISTORY;
@@ -1856,7 +1864,7 @@ struct SpecPool {
             ArcGpu& G = *gp; PermGpu& PG = *pgp;
             for (;;) {
                 std::shared_ptr<SpecTask> t;
-                { std::unique_lock<std::mutex> lk(mu); cvWork.wait(lk, [&]() { return stopping || !queue.empty(); }); if (queue.empty()) return; t = queue.front(); queue.pop_front(); }
+                { std::unique_lock<std::mutex> lk(mu); cvWork.wait(lk, [&]() { return stopping || !queue.empty(); }); if (stopping || queue.empty()) return; t = queue.front(); queue.pop_front(); }      // (stopping: guesses nobody will read are dropped, not computed)
                 int expect = 0;
                 if (!t->state.compare_exchange_strong(expect, 1)) continue;          // the chromosome thread took it
                 phase1_run(G, PG, t->gd, t->cn, nPerm, cutoff, *st, t->out);
@@ -2103,12 +2111,20 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     // helper threads for the deterministic front half of every segment on a recursion stack (cbs::SpecPool); CANVAS_CBS_NO_SPECULATION=1: the plain sequential order (test hook)
     std::unique_ptr<cbs::SpecPool> specPool;
     if (!getenv("CANVAS_CBS_NO_SPECULATION")) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nArcSvc, nperm, alpha, &st}); specPool->start((int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4))); }
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
+    const int nthreads = (int)std::min<unsigned>(hw, (unsigned)nchr);
+    size_t perEngineBudget = ~size_t(0);
+    { size_t freeB = 0, totB = 0; if (hipMemGetInfo(&freeB, &totB) == hipSuccess) perEngineBudget = (freeB / 2) / (size_t)std::max(1, nthreads); }
     auto work = [&]() {
         cbs::EngineCache& cache = cbs::EngineCache::of(ctx);                             // per thread: own buffers, borrowed from the context's cache (created on first use)
         std::unique_ptr<cbs::PermGpu> pgp = cache.perm(ctx, permServices[(size_t)(nextService++ % nPermSvc)]); std::unique_ptr<cbs::ArcGpu> gp = cache.arc(ctx, arcServices[nextArc++ % nArcSvc]);
         struct Back { cbs::EngineCache& c; std::unique_ptr<cbs::ArcGpu>& a; std::unique_ptr<cbs::PermGpu>& p; ~Back() { c.give(std::move(a)); c.give(std::move(p)); } } back{cache, gp, pgp};
         cbs::PermGpu& PG = *pgp; cbs::ArcGpu& G = *gp;
+        // the first allocation of an engine is made for the call's longest chromosome (growing later means hipFree + hipMalloc, which stall every stream of the device) —
+        // as long as all engines of the call together stay inside half of what the device has free: many contigs on a many-core host, or several contexts on one GPU,
+        // would otherwise run out of memory where grow-on-demand engines fit
         PG.reserveN = (size_t)nMax; PG.reserveElems = (size_t)std::min<long long>((long long)256 * nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * nMax));
+        if (PG.reserveElems * 48 > perEngineBudget) { const size_t capE = perEngineBudget / 48; PG.reserveElems = capE >= 8 * (size_t)nMax ? capE : 0; if (!PG.reserveElems) PG.reserveN = 0; }
         for (;;) {
             int c = next++; if (c >= nchr) break;
             int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);
@@ -2124,8 +2140,6 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
             if (rcs[c] == 0 && undo == 1 && segs[c].size() > 1) rcs[c] = cbs::prune(cov.data() + h_chr_offset[c], n, segs[c], 0.05, errs[c]);   // undoPrune = 0.05 (CBSRunner.cs:42)
         }
     };
-    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
-    int nthreads = (int)std::min<unsigned>(hw, (unsigned)nchr);
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; t++) th.emplace_back(work);
     for (auto& t : th) t.join();

@@ -242,7 +242,7 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
         // no bin size: nothing below can be sized.  Every rank has the same table, so every healthy rank computed a size; this rank cannot know maxB — it derives it from the
         // table with the size the others use only if that size can be recomputed; otherwise the failure is global (same table, same result) and everybody returns here
         if (bin_size_in > 0) binSize = bin_size_in;
-        else { std::vector<double> rates; for (int c = 0; c < nchr; c++) if (h_chr_is_autosome[c] && H.pop[c] > 0) rates.push_back((int)H.obs[c] / (double)(int)H.pop[c]);
+        else { std::vector<double> rates; for (int c = 0; c < nchr; c++) if (h_chr_is_autosome[c]) rates.push_back((int)H.obs[c] / (double)(int)H.pop[c]);      // (the SAME expression as the healthy ranks': a different filter here would size the next exchange differently on this rank)
                if (!rates.empty()) binSize = canvas_bin_size_from_rates(rates.data(), (int32_t)rates.size(), counts_per_bin); }
         if (binSize <= 0) { ctx->err = localMsg; return localErr; }
     }

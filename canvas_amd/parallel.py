@@ -270,6 +270,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
 
     # a collective that never returns must not cost the launch its line: after CANVAS_SHARDED_TIMEOUT seconds (default 240) every rank leaves, rank 0 prints the cohort line first
     import os
+    import sys
     import threading
     done = threading.Event()
 
@@ -354,7 +355,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             if rank == 0:
                 result["partition_sharded"] = {"error": "did not finish within the watchdog's limit"}
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(5)            # the line is out, but a hung sharded CBS / Wavelets / pedigree leg is a failure of the launch (as a hung pipeline leg is: 3 / 4)
 
     threading.Thread(target=leg_watchdog, daemon=True).start()
     part = {}
@@ -449,3 +450,10 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
         result["partition_sharded"] = part
         print(json.dumps(result), flush=True)
     dist.destroy_process_group()
+    # a leg that raised, or whose result differs between the ranks / from the single-GPU result, fails the launch (the line above still says what happened)
+    bad = "error" in part or "error" in ped
+    for leg in list(part.values()) + [ped]:
+        if isinstance(leg, dict) and (leg.get("identical_on_all_ranks") is False or leg.get("equals_single_gpu_result") is False or leg.get("equals_single_gpu_flow_rank0") is False):
+            bad = True
+    if bad:
+        sys.exit(6)

@@ -43,11 +43,20 @@ static bool write_gz_rows(const std::string& path, int64_t nrows, const std::fun
         C.len = text.size(); C.crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef*)text.data(), (uInt)text.size());
         z_stream zs; memset(&zs, 0, sizeof zs);
         if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { C.ok = false; return; }
-        C.z.resize(deflateBound(&zs, (uLong)text.size()) + 64);
+        // deflateBound covers Z_FINISH only: room for the stored-block overhead of an incompressible chunk and the flush marker on top, and the flush is complete only
+        // when it returns with output space LEFT (zlib: Z_OK with avail_out == 0 means more is pending) — otherwise the buffer grows and the call is repeated
+        C.z.resize(deflateBound(&zs, (uLong)text.size()) + text.size() / 1000 + 512);
         zs.next_in = (Bytef*)text.data(); zs.avail_in = (uInt)text.size(); zs.next_out = C.z.data(); zs.avail_out = (uInt)C.z.size();
         const int last = c == nchunks - 1;
-        const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);          // a sync flush ends on a byte boundary without the final-block bit: the next chunk's blocks follow
-        if ((last && rc != Z_STREAM_END) || (!last && (rc != Z_OK || zs.avail_in != 0))) C.ok = false;
+        for (;;) {
+            const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);      // a sync flush ends on a byte boundary without the final-block bit: the next chunk's blocks follow
+            if (last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0 && zs.avail_out > 0)) break;
+            if ((rc == Z_OK || rc == Z_BUF_ERROR) && zs.avail_out == 0) {     // output full: more room, again
+                const size_t used = C.z.size(); C.z.resize(used * 2 + 4096); zs.next_out = C.z.data() + used; zs.avail_out = (uInt)(C.z.size() - used);
+                continue;
+            }
+            C.ok = false; break;
+        }
         C.z.resize(C.z.size() - zs.avail_out);
         deflateEnd(&zs);
     });
