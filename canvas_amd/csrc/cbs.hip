@@ -22,6 +22,7 @@
 //     TMaxP (n <= 200), short hybrid segments, TPermP and TailP (its series of normal-CDF evaluations runs on a host thread pool)
 //     stay on the host.  WGS-size run (4.7 M bins, 104 k permutations over 1.27e9 elements): 4.1 s host-only -> 1.5 s.
 #include "common.hpp"
+#include "cbs_boundary_default.hpp"
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -954,7 +955,16 @@ static double p_exceed(uint32_t nPerm, uint32_t n1s, const std::vector<uint32_t>
     return p;
 }
 static void eta_boundary_fast(uint32_t nPerm, double eta0, uint32_t n1s, std::vector<uint32_t>& sb, uint32_t off);
+static void compute_boundary_fresh(uint32_t nPerm, double alpha, double eta, std::vector<uint32_t>& sb);
+// CanvasPartition's default parameters take the table that was computed once and compiled in (cbs_boundary_default.hpp); CANVAS_CBS_NO_EMBEDDED_BOUNDARY=1 computes it anew (test hook)
 static void compute_boundary(uint32_t nPerm, double alpha, double eta, std::vector<uint32_t>& sb) {
+    if (nPerm == CBS_DEFAULT_NPERM && alpha == CBS_DEFAULT_ALPHA && eta == 0.05 && sizeof(kCbsDefaultBoundary) > 4 && !getenv("CANVAS_CBS_NO_EMBEDDED_BOUNDARY")) {
+        sb.assign(kCbsDefaultBoundary, kCbsDefaultBoundary + sizeof(kCbsDefaultBoundary) / sizeof(uint32_t));
+        return;
+    }
+    compute_boundary_fresh(nPerm, alpha, eta, sb);
+}
+static void compute_boundary_fresh(uint32_t nPerm, double alpha, double eta, std::vector<uint32_t>& sb) {
     uint32_t maxOnes = (uint32_t)(std::floor(nPerm * alpha) + 1);
     sb.assign((size_t)maxOnes * (maxOnes + 1) / 2, 0);
     uint32_t l = 0; sb[0] = nPerm - (uint32_t)(nPerm * eta);

@@ -19,3 +19,19 @@ def test_boundary_table_equals_the_oracles(nperm, alpha):
     exp = O.cbs_boundary(nperm, alpha)
     assert n == len(exp) and n == (int(np.floor(nperm * alpha)) + 1) * (int(np.floor(nperm * alpha)) + 2) // 2
     assert (out[:n] == exp).all()
+
+
+def test_the_compiled_in_default_table_equals_a_fresh_computation(monkeypatch):
+    """canvas_amd/csrc/cbs_boundary_default.hpp (tools/gen_boundary_table.py) holds the table for CanvasPartition's defaults (10000 permutations, alpha 0.01): what the library
+    hands out by default must equal what it computes when told not to use the constant, and the oracle's."""
+    lib = load_library()
+    lib.canvas_cbs_boundary.restype = C.c_int64
+    a = np.zeros(1 << 14, np.uint32); b = np.zeros(1 << 14, np.uint32)
+    monkeypatch.delenv("CANVAS_CBS_NO_EMBEDDED_BOUNDARY", raising=False)
+    na = lib.canvas_cbs_boundary(C.c_uint32(10000), C.c_double(0.01), a.ctypes.data_as(C.c_void_p), C.c_int64(len(a)))
+    monkeypatch.setenv("CANVAS_CBS_NO_EMBEDDED_BOUNDARY", "1")
+    nb = lib.canvas_cbs_boundary(C.c_uint32(10000), C.c_double(0.01), b.ctypes.data_as(C.c_void_p), C.c_int64(len(b)))
+    assert na == nb == 5151 and (a[:na] == b[:nb]).all()
+    assert (a[:na] == O.cbs_boundary(10000, 0.01)).all()
+    src = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "canvas_amd", "csrc", "cbs_boundary_default.hpp")).read()
+    assert "kCbsDefaultBoundary[5151]" in src
