@@ -750,6 +750,7 @@ def executables_leg(args, bases, masks, hits, lens, keep, cpu):
     import shutil, subprocess, tempfile
     from canvas_amd import synth
     root = tempfile.mkdtemp(prefix="canvas_exe_", dir=os.environ.get("TMPDIR", "/tmp"))
+    keep_dir = os.environ.get("CANVAS_EXE_KEEP")            # experiments on the tools: the sample's files stay, the CanvasBin command line is written next to them
     try:
         total_bytes = int(sum(int(L) for L in lens))
         free = shutil.disk_usage(root).free
@@ -792,6 +793,9 @@ def executables_leg(args, bases, masks, hits, lens, keep, cpu):
         argv = ["-b", bam, "-r", fa, "-o", binned, "-d", "100", "-m", "TruncatedDynamicRange"]
         for d in dats:
             argv += ["-i", d]
+        if keep_dir:
+            open(os.path.join(root, "bin_cmd.txt"), "w").write(" ".join([os.path.join(bdir, "CanvasBin")] + argv) + "\n")
+            open(keep_dir, "w").write(root + "\n")
         res["CanvasBin"] = run("CanvasBin", argv)
         res["CanvasClean"] = run("CanvasClean", ["-i", binned, "-o", cleaned, "-g", "-s", "-r", "--local-sd-metric-file=" + lsd])
         for method in ("PerSampleHMM", "CBS", "Wavelets"):
@@ -817,7 +821,8 @@ def executables_leg(args, bases, masks, hits, lens, keep, cpu):
                 res["speedup_file_io_inclusive_vs_estimate"] = round(est / wall, 2)
         return res
     finally:
-        shutil.rmtree(root, ignore_errors=True)
+        if not keep_dir:
+            shutil.rmtree(root, ignore_errors=True)
 
 
 def somatic_flow(args, cv, torch, seed, bases, masks, lens, is_auto, flags, device):

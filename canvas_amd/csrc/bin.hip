@@ -1217,7 +1217,17 @@ int32_t canvas_pack_reference_host(const uint8_t* bases, const uint64_t* mask, i
         for (int64_t w = w0; w < w1; w++) {
             const int64_t p = w << 6;
             uint64_t m = 0, g = 0;
-            if (p < len) {
+            if (p + 64 <= len) {
+                // 16 bases at a time: case folded, compared with 'c' and 'g', one movemask; the first base that is not 'n' from the same registers
+                m = mask[w];
+                const __m128i fold = _mm_set1_epi8(0x20), cc = _mm_set1_epi8('c'), gg = _mm_set1_epi8('g'), nn = _mm_set1_epi8('n');
+                for (int q = 0; q < 4; q++) {
+                    const __m128i v = _mm_loadu_si128((const __m128i*)(bases + p + 16 * q));
+                    const __m128i lb = _mm_or_si128(v, fold);
+                    g |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_or_si128(_mm_cmpeq_epi8(lb, cc), _mm_cmpeq_epi8(lb, gg))) << (16 * q);
+                    if (firstNonN == len) { const unsigned notN = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, nn)) ^ 0xFFFFu; if (notN) firstNonN = p + 16 * q + __builtin_ctz(notN); }
+                }
+            } else if (p < len) {
                 const int n = (int)std::min<int64_t>(64, len - p);
                 m = mask[w]; if (n < 64) m &= (~0ull) >> (64 - n);
                 for (int i = 0; i < n; i++) {

@@ -345,9 +345,11 @@ int main(int argc, char** argv) {
         return 0;
     }
 
-    canvas_ctx* ctx = canvas_create(0);
-    if (!ctx) { fprintf(stderr, "CanvasBin (MI355X): no usable GPU (this build has no CPU fallback)\n"); return 1; }
-    struct CtxGuard { canvas_ctx* c; ~CtxGuard() { canvas_destroy(c); } } guard{ctx};
+    ExitStamp es0("context destroyed");
+    AsyncCtx actx;                                              // the context comes up while the intermediates and the FASTA file are read
+    struct CtxGuard { AsyncCtx& a; ~CtxGuard() { if (canvas_ctx* c = a.get()) canvas_destroy(c); } } guard{actx};
+    canvas_ctx* ctx = nullptr;
+    auto need_ctx = [&]() -> bool { ctx = actx.get(); if (!ctx) fprintf(stderr, "CanvasBin (MI355X): no usable GPU (this build has no CPU fallback)\n"); return ctx != nullptr; };
 
     if (inters.empty()) {
         // ---- phase 1: CalculateSampleHits / BinOneGenomicInterval (CanvasBin.cs:765-792)
@@ -360,6 +362,7 @@ int main(int argc, char** argv) {
         printf("Initialized alignment arrays\n");
         if (int rc = load_bam(bam, a.has("paired-end"), chrom, mode, d.hits, d.frag)) return rc;
         printf("Loaded observed alignments\n");
+        if (!need_ctx()) return 1;
         if (L > 0) {
             Dev dBases(ctx, L), dHits(ctx, L), dMask(ctx, words * 8);
             TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dBases.p, fa[0].bases.data(), L));
@@ -384,6 +387,7 @@ int main(int argc, char** argv) {
     }
 
     // ---- phase 2: RunSingleSample (CanvasBin.cs:914-931)
+    ExitStamp es1("intermediates freed");
     std::map<std::string, std::unique_ptr<Inter>> byChrom;
     for (auto& p : inters) if (!file_exists(p)) { fprintf(stderr, "CanvasBin: intermediate file %s does not exist\n", p.c_str()); return 1; }
     {   // one host thread per intermediate file (the reference deserialises them one after the other, CanvasBin.cs:725-762); merged in command-line order
@@ -413,30 +417,49 @@ int main(int argc, char** argv) {
             }
         }
     }
+    ExitStamp es2("FASTA entries freed");
     std::vector<FastaEntry> fa;
     if (!read_fasta(ref, nullptr, fa)) return 1;
+    if (!need_ctx()) return 1;
     ph.mark("read");
     // chromosomes in FASTA order that have an intermediate (CanvasBin.cs:506-540)
     std::vector<const FastaEntry*> order; std::vector<Inter*> data;
     for (auto& e : fa) { auto it = byChrom.find(e.name); if (it == byChrom.end()) continue; if ((int64_t)e.bases.size() != it->second->len) { fprintf(stderr, "CanvasBin: length of %s differs between the reference and the intermediate file\n", e.name.c_str()); return 1; } order.push_back(&e); data.push_back(it->second.get()); }
     const int nchr = (int)order.size();
     if (nchr == 0) { fprintf(stderr, "CanvasBin: no chromosome to bin\n"); return 1; }
+    ExitStamp es3("input planes freed on the device");
     std::vector<std::unique_ptr<Dev>> devs;
     std::vector<const uint8_t*> pBases(nchr), pHits(nchr); std::vector<const uint64_t*> pMask(nchr); std::vector<const int16_t*> pFrag(nchr); std::vector<int64_t> len(nchr); std::vector<uint8_t> isAuto(nchr);
     // Binary / TruncatedDynamicRange binning goes over the packed planes (include/canvas_hip.h, "packed per-base inputs"): packed on the host threads, 0.75 B/base over
     // PCIe instead of 2.125 B/base, same bins.  CANVAS_BIN_BYTE_ARRAYS=1 keeps the byte arrays (-n, -y and GCContentWeighted always use them).
     const bool usePacked = mode != CANVAS_MODE_GC_CONTENT_WEIGHTED && !a.has("bins") && !a.has("binsizeonly") && !getenv("CANVAS_BIN_BYTE_ARRAYS");
     std::vector<const uint64_t*> pRef(nchr), pPlanes(nchr); std::vector<int64_t> pos0(nchr);
-    for (int c = 0; usePacked && c < nchr; c++) {
-        const int64_t L = data[c]->len; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
-        int64_t refBytes = 0, hitBytes = 0, sat = 0;
-        if (canvas_packed_plane_bytes(L, &refBytes, &hitBytes) != 0) { fprintf(stderr, "CanvasBin: bad chromosome length\n"); return 1; }
-        std::vector<uint64_t> ref((size_t)refBytes / 8), planes((size_t)hitBytes / 8);
-        if (canvas_pack_reference_host((const uint8_t*)order[c]->bases.data(), data[c]->maskWords.data(), L, ref.data(), &pos0[c], 0) != 0 ||
-            canvas_pack_hits_host(data[c]->hits.data(), L, planes.data(), &sat, 0) != 0) { fprintf(stderr, "CanvasBin: packing %s failed\n", order[c]->name.c_str()); return 1; }
-        devs.push_back(std::make_unique<Dev>(ctx, refBytes)); pRef[c] = (const uint64_t*)devs.back()->p;
-        devs.push_back(std::make_unique<Dev>(ctx, hitBytes)); pPlanes[c] = (const uint64_t*)devs.back()->p;
-        if (canvas_memcpy_h2d(ctx, (void*)pRef[c], ref.data(), refBytes) != 0 || canvas_memcpy_h2d(ctx, (void*)pPlanes[c], planes.data(), hitBytes) != 0) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
+    if (usePacked) {
+        // one device allocation for all planes; two host staging sets: while chromosome c is packed by the host threads, a helper thread uploads chromosome c-1
+        std::vector<int64_t> refB(nchr), hitB(nchr), offR(nchr), offH(nchr); int64_t tot = 0, maxR = 0, maxH = 0;
+        for (int c = 0; c < nchr; c++) {
+            const int64_t L = data[c]->len; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
+            if (canvas_packed_plane_bytes(L, &refB[c], &hitB[c]) != 0) { fprintf(stderr, "CanvasBin: bad chromosome length\n"); return 1; }
+            offR[c] = tot; tot += (refB[c] + 255) & ~255ll; offH[c] = tot; tot += (hitB[c] + 255) & ~255ll;
+            maxR = std::max(maxR, refB[c]); maxH = std::max(maxH, hitB[c]);
+        }
+        devs.push_back(std::make_unique<Dev>(ctx, tot)); uint8_t* base = (uint8_t*)devs.back()->p;
+        if (!base) { fprintf(stderr, "CanvasBin: device allocation of %lld bytes failed: %s\n", (long long)tot, canvas_last_error(ctx)); return 1; }
+        std::unique_ptr<uint64_t[]> sRef[2], sHit[2];               // (every word of a plane is written by the packers: no zero fill)
+        for (int s = 0; s < 2 && s < nchr; s++) { sRef[s].reset(new uint64_t[(size_t)maxR / 8]); sHit[s].reset(new uint64_t[(size_t)maxH / 8]); }
+        std::thread up; int upRc = 0;
+        for (int c = 0; c < nchr; c++) {
+            const int s = c & 1; int64_t sat = 0;
+            pRef[c] = (const uint64_t*)(base + offR[c]); pPlanes[c] = (const uint64_t*)(base + offH[c]);
+            const bool ok = canvas_pack_reference_host((const uint8_t*)order[c]->bases.data(), data[c]->maskWords.data(), len[c], sRef[s].get(), &pos0[c], 0) == 0 &&
+                            canvas_pack_hits_host(data[c]->hits.data(), len[c], sHit[s].get(), &sat, 0) == 0;
+            if (up.joinable()) up.join();
+            if (!ok) { fprintf(stderr, "CanvasBin: packing %s failed\n", order[c]->name.c_str()); return 1; }
+            if (upRc) break;
+            up = std::thread([&, c, s] { if (canvas_memcpy_h2d(ctx, (void*)pRef[c], sRef[s].get(), refB[c]) != 0 || canvas_memcpy_h2d(ctx, (void*)pPlanes[c], sHit[s].get(), hitB[c]) != 0) upRc = 1; });
+        }
+        if (up.joinable()) up.join();
+        if (upRc) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
     }
     for (int c = 0; !usePacked && c < nchr; c++) {
         const int64_t L = data[c]->len, words = (L + 63) / 64; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
@@ -481,6 +504,7 @@ int main(int argc, char** argv) {
     if (binSize > 0) cap = canvas_bin_count_upper_bound(nchr, len.data(), binSize);
     else { for (int c = 0; c < nchr; c++) cap += len[c] / 16 + 1; }                    // a bin holds countsPerBin / rate possible positions; rates above 100/16 hits per position do not occur
 
+    ExitStamp es4("bin columns freed on the device");
     Dev dChr(ctx, cap * 4 + 4), dStart(ctx, cap * 4 + 4), dStop(ctx, cap * 4 + 4), dGc(ctx, cap * 4 + 4), dCount(ctx, cap * 4 + 4);
     std::vector<int64_t> perChr(nchr); int64_t total = 0; int32_t used = 0;
     if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED)
@@ -514,5 +538,6 @@ int main(int argc, char** argv) {
         { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }
     ph.mark("write");
     printf("Output complete\n");
-    return 0;
+    ExitStamp es5("start of the unwinding");
+    return finish(ph, 0);
 }

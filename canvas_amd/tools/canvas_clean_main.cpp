@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
     int minBins = a.has("weightedmedian") ? atoi(a.get("weightedmedian").c_str()) : 100;
 
     Phases ph("CanvasClean");
+    AsyncCtx actx;                                              // the context comes up while the file is read
     // CanvasIO.ReadFromTextFile (CanvasCommon/IO.cs:26-52)
     std::vector<std::string> chromNames;
     std::vector<int32_t> chr, start, stop, gc; std::vector<float> count;
@@ -41,7 +42,7 @@ int main(int argc, char** argv) {
     ph.mark("read");
     int64_t nOut = n; double localSd = -1.0;
     if (n > 0) {
-        canvas_ctx* ctx = canvas_create(0);
+        canvas_ctx* ctx = actx.get();
         if (!ctx) { fprintf(stderr, "CanvasClean (MI355X): no usable GPU (this build has no CPU fallback)\n"); return 1; }
         { Dev dChr(ctx, n * 4), dStart(ctx, n * 4), dStop(ctx, n * 4), dCount(ctx, n * 4), dGc(ctx, n * 4);
           TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dChr.p, chr.data(), n * 4)); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dStart.p, start.data(), n * 4));
@@ -53,7 +54,7 @@ int main(int argc, char** argv) {
           TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, chr.data(), dChr.p, nOut * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, start.data(), dStart.p, nOut * 4));
           TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, stop.data(), dStop.p, nOut * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, count.data(), dCount.p, nOut * 4));
           TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, gc.data(), dGc.p, nOut * 4)); }
-        canvas_destroy(ctx);
+        if (getenv("CANVAS_TOOL_FULL_TEARDOWN")) canvas_destroy(ctx);
     }
     ph.mark("device");
     // CanvasIO.WriteLocalSdMetricToTextFile (IO.cs:83-98) — only when the metric was computed (>= 50000 bins, CanvasClean.cs:483-494)
@@ -63,5 +64,5 @@ int main(int argc, char** argv) {
             o += chromNames[chr[i]]; o.push_back('\t'); append_int(o, start[i]); o.push_back('\t'); append_int(o, stop[i]); o.push_back('\t'); o += format_f2(count[i]); o.push_back('\t'); append_int(o, gc[i]); }))
         { fprintf(stderr, "cannot write %s\n", outFile.c_str()); return 1; }
     ph.mark("write");
-    return 0;
+    return finish(ph, 0);
 }

@@ -121,6 +121,7 @@ int main(int argc, char** argv) {
     if (!bed.empty()) load_bed(bed, excluded);
 
     Phases ph("CanvasPartition");
+    AsyncCtx actx;                                              // the context comes up while the files are read
     // CanvasSegment.ReadBedInput (CanvasCommon/CanvasSegment.cs:1117-1163)
     std::vector<Sample> samples(inFiles.size());
     for (size_t s = 0; s < inFiles.size(); s++) {
@@ -140,7 +141,7 @@ int main(int argc, char** argv) {
         for (size_t c = 0; c < S.chromNames.size(); c++) { S.start.insert(S.start.end(), st[c].begin(), st[c].end()); S.end.insert(S.end.end(), en[c].begin(), en[c].end()); S.cov.insert(S.cov.end(), cv[c].begin(), cv[c].end()); S.off.push_back((int64_t)S.start.size()); }
     }
     ph.mark("read");
-    canvas_ctx* ctx = canvas_create(0);
+    canvas_ctx* ctx = actx.get();
     if (!ctx) { fprintf(stderr, "CanvasPartition (MI355X): no usable GPU (this build has no CPU fallback)\n"); return 1; }
     // per sample: segments per chromosome as (start, end) genomic pairs
     typedef std::vector<std::pair<uint32_t, uint32_t>> Segs;
@@ -220,7 +221,7 @@ int main(int argc, char** argv) {
             }
         }
     }
-    canvas_destroy(ctx);
+    if (getenv("CANVAS_TOOL_FULL_TEARDOWN")) canvas_destroy(ctx);
     ph.mark("device");
     // GenomeSegmentationResults.SplitOverlappingSegments (GenomeSegmentationResults.cs:18-55)
     std::map<std::string, Segs> merged;
@@ -275,5 +276,5 @@ int main(int argc, char** argv) {
     }
     printf("CanvasPartition results written out\n");
     ph.mark("write");
-    return 0;
+    return finish(ph, 0);
 }
