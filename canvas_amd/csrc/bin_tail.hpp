@@ -157,13 +157,15 @@ __device__ void plan_offsets(int nchr, const ChromOut* __restrict__ totals /* po
         binOffset[c] = (long long)run; dOut[c].nbins = nb; run += (unsigned long long)nb;
         if (hostOut) { ChromOut o = totals[c]; o.nbins = nb; hostOut[c] = o; }
     }
+    if (hostOut) __threadfence_system();      // (results in pinned host memory are read behind an event: the fence puts them there before the kernel can be seen as complete —
+                                              // without it a report of canvas_wavelets' level loop was, rarely, read before it had arrived)
     if (tid == 0) {
         binOffset[nchr] = (long long)total;
         if (binSize > 0 && (long long)total > cap) flags |= BD_CAPACITY;
         BinDev o; o.binSize = binSize; o.run = (binSize > 0 && !(flags & BD_CAPACITY)) ? 1 : 0;
         o.binMagic = binSize > 1 ? ~0ull / (unsigned long long)binSize + 1ull : 0ull; o.total = (long long)total; o.flags = flags; o.nAuto = nAuto;
         *bd = o;
-        if (hostBd) *hostBd = o;
+        if (hostBd) { *hostBd = o; __threadfence_system(); }
     }
 }
 __global__ void __launch_bounds__(TS_T) k_bin_plan(int nchr, ChromOut* __restrict__ dOut, long long* __restrict__ binOffset, BinDev* __restrict__ bd, int binSize, long long cap) {

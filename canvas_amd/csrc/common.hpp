@@ -61,6 +61,9 @@ struct canvas_ctx {
     long long cbs_tailp[2] = {0, 0};   // last CBS call: TailP decisions taken from the device series / recomputed by the host series   // counters of the device permutation engine (canvas_cbs_device_stats)
     long long wv_levels = 0, wv_redone = 0;   // last canvas_wavelets call: tree levels processed, nodes recomputed by the exact chain
     void* covq_dev = nullptr; void* covq_pin = nullptr;   // pipeline.hip: counters / result of the genome-wide coverage quartiles counted while the coverage is quantised (hmm.hip)
+    hipStream_t wv_main = nullptr, wv_chain = nullptr, wv_sub = nullptr, wv_sub2 = nullptr;
+    void* wv_fgh = nullptr; int wv_fgh_len = 0;          // canvas_wavelets: the step coefficients of every (node length, position) of the short nodes, computed once  // canvas_wavelets: streams confined to disjoint sets of compute units (the exact chains keep theirs to themselves)
+    int wv_streams_tried = 0; unsigned wv_calls = 1;
     void* wv_pin = nullptr; size_t wv_pin_bytes = 0;   // pinned arena of canvas_wavelets (host copy of the coverage + staging lists), kept between calls
     long long wv_stats[4] = {0, 0, 0, 0};     // ... long nodes decided from the closed form / sent to the chain undecided / chained for their coefficient; closed form in use
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
@@ -71,19 +74,19 @@ struct canvas_ctx {
     std::vector<ProfSlot> slots;
 };
 
-// scoped event pair: records start now and stop at destruction (on ctx->stream) when profiling is enabled
+// scoped event pair: records start now and stop at destruction (on ctx->stream, or on the stream given) when profiling is enabled
 struct ProfScope {
-    canvas_ctx* ctx; int slot = -1; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(canvas_ctx* c, const char* name, bool dominant = false) : ctx(c) {
+    canvas_ctx* ctx; int slot = -1; hipEvent_t a = nullptr, b = nullptr; hipStream_t st = nullptr;
+    ProfScope(canvas_ctx* c, const char* name, bool dominant = false, hipStream_t on = nullptr) : ctx(c), st(on ? on : c->stream) {
         if (!c->prof || (c->prof == 2 && !dominant)) return;
         for (size_t i = 0; i < c->slots.size(); i++) if (c->slots[i].name == name) slot = (int)i;
         if (slot < 0) { c->slots.push_back({}); slot = (int)c->slots.size() - 1; c->slots[slot].name = name; }
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { slot = -1; return; }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, st);
     }
     ~ProfScope() {
         if (slot < 0) return;
-        (void)hipEventRecord(b, ctx->stream);
+        (void)hipEventRecord(b, st);
         ctx->slots[slot].ev.push_back(a); ctx->slots[slot].ev.push_back(b); ctx->slots[slot].launches++;
     }
 };
@@ -124,6 +127,7 @@ static inline int32_t canvas_side_init(canvas_ctx* ctx) {
     if (ctx->side) return CANVAS_OK;
     CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
+    CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_ev2, hipEventDisableTiming));
     CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->side_pin, (65536 + 65544) * sizeof(double), hipHostMallocDefault));
     return CANVAS_OK;
 }

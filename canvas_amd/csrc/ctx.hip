@@ -35,6 +35,11 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->up2_stage) (void)hipFree(ctx->up2_stage);
     if (ctx->side_pin) (void)hipHostFree(ctx->side_pin);
     if (ctx->wv_pin) (void)hipHostFree(ctx->wv_pin);
+    if (ctx->wv_main) (void)hipStreamDestroy(ctx->wv_main);
+    if (ctx->wv_chain) (void)hipStreamDestroy(ctx->wv_chain);
+    if (ctx->wv_sub) (void)hipStreamDestroy(ctx->wv_sub);
+    if (ctx->wv_sub2) (void)hipStreamDestroy(ctx->wv_sub2);
+    if (ctx->wv_fgh) (void)hipFree(ctx->wv_fgh);
     if (ctx->covq_pin) (void)hipHostFree(ctx->covq_pin);
     if (ctx->covq_dev) (void)hipFree(ctx->covq_dev);
     if (ctx->ws) (void)hipFree(ctx->ws);

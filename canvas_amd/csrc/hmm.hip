@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, uint32
         CovQ o; memset(&o, 0, sizeof o);
         o.nq = nq; o.bad = Q->bad; o.fail = sFail; o.lo = lo; o.below = below; o.n = n;
         for (uint32_t j = 0; j < nq; j++) { o.rank[j] = sRank[j]; o.resultK[j] = sRes[j]; }
-        *Qres = o;
+        *Qres = o; __threadfence_system();      // (pinned host memory, read behind an event)
         CovQ z; memset(&z, 0, sizeof z); *Q = z;
     }
 }
@@ -1283,7 +1283,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks2(uint32_t* __restrict__ bl
         carry += sh[16];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) { *total = carry; __threadfence_system(); }      // (may be pinned host memory, read behind a synchronisation)
 }
 __global__ void __launch_bounds__(256) k_seg_ids(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t n, int32_t* __restrict__ segId) {
     __shared__ uint32_t sh[4];

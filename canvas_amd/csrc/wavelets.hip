@@ -33,12 +33,16 @@
 #include <cmath>
 #include <functional>
 #include <limits>
+#include <map>
 #include <atomic>
 #include <chrono>
 #include <thread>
 #include <vector>
 
-#define WV_LONG 256       // nodes longer than this take the wave-per-node path
+#define WV_LONG_MAX 256   // (the subtree walker packs positions relative to its root into 9 bits)
+#define WV_LONG_DEFAULT 64 // nodes longer than this stay in the level loop; shorter ones leave it with their whole subtree, one lane each (CANVAS_WV_LONG = 8 .. 256 overrides).
+                          // A lane walks its subtree node by node with the reference's sequential loop, and an unbalanced tree over L positions costs up to L^2 / 2 steps:
+                          // with 256 the slowest lanes of a WGS sample kept k_wv_subtree busy for 20 ms next to (and on the same SIMDs as) the exact chains
 #define WV_CS 56          // steps per chunk of a long node (a checkpoint of the chain state is kept per chunk)
 #define WV_PB 7           // steps per operand-prefetch block: 2 LDS reads per step and at most 15 outstanding for s_waitcnt to tell apart
 
@@ -102,6 +106,7 @@ template <bool FAST>
 __global__ void __launch_bounds__(64) k_wv_chain_long(const WvNode* __restrict__ nodes, const int32_t* __restrict__ list, const int32_t* __restrict__ base,
                                                       const double* __restrict__ X, const WvOps* __restrict__ ops, WvCk* __restrict__ ck, WvHead* __restrict__ head, const long long* __restrict__ opsOff, const int32_t* __restrict__ lim) {
     __shared__ double4 sO[2][64];              // [buf][step] = (f, r, c, d); the sum pass uses sO[buf][s].x
+    __builtin_amdgcn_s_setprio(3);             // the chain is a string of dependent FP64 operations (9-10 cycles each, tools/dp_latency.hip): whatever shares the SIMD issues behind it
     const int k = blockIdx.x;
     const WvNode nd = nodes[list[k]];
     const long long n = nd.len;
@@ -232,9 +237,20 @@ __global__ void __launch_bounds__(64) k_wv_reduce(const int32_t* __restrict__ li
 // next to the long chains, so the host only ever handles the few thousand long nodes.
 struct WvRoot { int32_t start; int32_t len; int32_t chrom; int32_t level; int32_t s1; int32_t cbase; };   // s1: 1-based start inside the chromosome; cbase: first bin of the chromosome
 struct WvCand { int32_t chrom, level, s, b, e, pad; double coef; };
+// The step coefficients depend on (n, m) only, and a short node has n <= WV_LONG: a table of all of them (3 square roots and 6 divisions per entry, the same expressions as
+// above, so the same bits) turns a step of the walker from ~250 FP64 instructions into two divisions and a handful of operations — its launches were 1-4 ms of one lane's latency.
+struct WvFgh { double f, g, h; };
+__global__ void __launch_bounds__(256) k_wv_fgh_table(WvFgh* __restrict__ tab, int L) {
+    const long long n = blockIdx.x;
+    for (long long m = threadIdx.x; m <= L; m += 256) {
+        WvFgh t; t.f = 0.0; t.g = 0.0; t.h = 1.0;
+        if (n >= 3 && m >= 1 && m <= n - 2) { t.f = wv_factor(n, m); t.g = wv_g(n, m); t.h = wv_h(n, m); }
+        tab[(size_t)n * (size_t)(L + 1) + (size_t)m] = t;
+    }
+}
 __global__ void __launch_bounds__(64) k_wv_subtree(const WvRoot* __restrict__ roots, int nroots, const double* __restrict__ X, const double* __restrict__ keepAbove,
                                                    uint32_t* __restrict__ stack, int32_t* __restrict__ counts, WvCand* __restrict__ cands,
-                                                   unsigned long long* __restrict__ ncand, unsigned long long capCand, int32_t* __restrict__ overflow) {
+                                                   unsigned long long* __restrict__ ncand, unsigned long long capCand, int32_t* __restrict__ overflow, const WvFgh* __restrict__ fgh, int fghLen) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nroots) return;
     const WvRoot R = roots[i];
@@ -256,6 +272,24 @@ __global__ void __launch_bounds__(64) k_wv_subtree(const WvRoot* __restrict__ ro
         const double mean = (x0 + sum) / (double)n;
         double bestVal = p - q, bestAbs = fabs(bestVal);
         long long bestIdx = 0;
+        if (n <= fghLen) {
+            const WvFgh* __restrict__ row = fgh + (size_t)n * (size_t)(fghLen + 1);
+            long long m = 1;
+            for (; m + 3 < n - 1; m += 4) {                                      // the operands of four steps are requested together: nothing about them depends on the chain
+                const WvFgh t0 = row[m], t1 = row[m + 1], t2 = row[m + 2], t3 = row[m + 3];
+                const double x0m = x[m], x1m = x[m + 1], x2m = x[m + 2], x3m = x[m + 3];
+                { p = p * t0.f + x0m * t0.g; q = q / t0.f - x0m / t0.h; const double ip = p - q, ab = fabs(ip); if (ab > bestAbs) { bestAbs = ab; bestVal = ip; bestIdx = m; } }
+                { p = p * t1.f + x1m * t1.g; q = q / t1.f - x1m / t1.h; const double ip = p - q, ab = fabs(ip); if (ab > bestAbs) { bestAbs = ab; bestVal = ip; bestIdx = m + 1; } }
+                { p = p * t2.f + x2m * t2.g; q = q / t2.f - x2m / t2.h; const double ip = p - q, ab = fabs(ip); if (ab > bestAbs) { bestAbs = ab; bestVal = ip; bestIdx = m + 2; } }
+                { p = p * t3.f + x3m * t3.g; q = q / t3.f - x3m / t3.h; const double ip = p - q, ab = fabs(ip); if (ab > bestAbs) { bestAbs = ab; bestVal = ip; bestIdx = m + 3; } }
+            }
+            for (; m < n - 1; m++) {
+                const WvFgh t = row[m]; const double xm = x[m];
+                p = p * t.f + xm * t.g; q = q / t.f - xm / t.h;
+                const double ip = p - q, ab = fabs(ip);
+                if (ab > bestAbs) { bestAbs = ab; bestVal = ip; bestIdx = m; }
+            }
+        } else
         for (long long m = 1; m < n - 1; m++) {
             const double f = wv_factor(n, m), xm = x[m];
             p = p * f + xm * wv_g(n, m);
@@ -302,7 +336,9 @@ __global__ void __launch_bounds__(64) k_wv_subtree(const WvRoot* __restrict__ ro
 // counters once per batch of levels.  (Round 2 ran every long node through the chain: 14 M dependent steps and ~300 host round trips for a WGS sample, 0.5 s.)
 #define WV_LB 128         // levels enqueued per batch (even; a launch over an empty list is not free: 512 per batch were 9 ms for a 312-level tree)
 struct WvDNode { int32_t start, len, chrom, level; };      // start: index into the concatenated coverage
-struct WvDev { unsigned int cnt[WV_LB + 2], nch[WV_LB + 2]; unsigned int nRoots, nExact, nUndec, overflow; };
+struct LongBufs { WvNode* nodes; WvOut* out; int32_t *list, *base, *flag; WvHead* head; WvCk* ck; WvBest* best; };      // what one pass of the chain kernels works on
+#define WV_EB 1024        // launches of early exact chains between two harvests (each takes a base entry more than it has nodes)
+struct WvDev { unsigned int cnt[WV_LB + 2], nch[WV_LB + 2]; unsigned int nRoots, nExact, nUndec, overflow, exactReported, seq, pad[2]; };      // seq: number of the batch whose end wrote this report (written last)
 __device__ __forceinline__ long long wv_block_scan_i64(long long v, long long* sh /* [17] */, long long* total) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     long long inc = v;
@@ -379,7 +415,7 @@ __global__ void __launch_bounds__(256) k_wv_list_init(const WvDNode* __restrict_
 __global__ void __launch_bounds__(256) k_wv_level(WvSlot* __restrict__ cur, const int32_t* __restrict__ curChunkNode, WvSlot* __restrict__ nxt, int32_t* __restrict__ nxtChunkNode, WvPart* __restrict__ parts,
                                                   WvDev* __restrict__ dev, int it, unsigned maxList, unsigned maxChunks, unsigned maxList2,
                                                   const long long* __restrict__ P1, const long long* __restrict__ P2, const long long* __restrict__ off, const double* __restrict__ keepAbove,
-                                                  WvRoot* __restrict__ roots, unsigned maxRoots, WvDNode* __restrict__ exactList, int32_t* __restrict__ exactInd, WvDNode* __restrict__ undecList, int32_t* __restrict__ counts) {
+                                                  WvRoot* __restrict__ roots, unsigned maxRoots, WvDNode* __restrict__ exactList, int32_t* __restrict__ exactInd, WvDNode* __restrict__ undecList, int32_t* __restrict__ counts, int WV_LONG) {
     __shared__ WvPart sP[4];
     __shared__ int sLast;
     const unsigned nChunks = min(dev->nch[it], maxChunks);
@@ -477,6 +513,25 @@ __global__ void __launch_bounds__(256) k_wv_level(WvSlot* __restrict__ cur, cons
             }
         }
         __syncthreads();
+    }
+}
+
+// End of a batch of `lb` levels, on the device: the counters as they stand and the entries the exact list has gained go straight into pinned host memory (the host waits
+// for an event and reads them: no copy on the stream — one behind a batch of levels stood still until the chain kernel on the OTHER stream had finished, 9 ms), then the pending
+// level becomes level 0 of the next batch.  The next batch is enqueued before this one has been looked at; if nothing is pending its launches find empty lists.
+__global__ void __launch_bounds__(256) k_wv_batch_end(WvDev* __restrict__ dev, int lb, const WvDNode* __restrict__ exactList, const int32_t* __restrict__ exactInd,
+                                                      WvDev* __restrict__ pinDev, WvDNode* __restrict__ pinExact, int32_t* __restrict__ pinExactInd, unsigned maxCopy, unsigned seq) {
+    const unsigned from = dev->exactReported, nE = dev->nExact;
+    const unsigned k = nE > from ? min(nE - from, maxCopy) : 0u;
+    { const unsigned* src = (const unsigned*)dev; unsigned* dst = (unsigned*)pinDev; for (unsigned i = threadIdx.x; i < sizeof(WvDev) / 4; i += 256) if (i != offsetof(WvDev, seq) / 4) dst[i] = src[i]; }
+    for (unsigned i = threadIdx.x; i < k; i += 256) { pinExact[i] = exactList[from + i]; pinExactInd[i] = exactInd[from + i]; }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&pinDev->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word: everything above is in host memory before it
+        const unsigned c = dev->cnt[lb], n = dev->nch[lb];
+        for (int i = 1; i < WV_LB + 2; i++) { dev->cnt[i] = 0; dev->nch[i] = 0; }
+        dev->cnt[0] = c; dev->nch[0] = n; dev->exactReported = from + k;
     }
 }
 
@@ -696,16 +751,19 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !d_cov || !h_chr_offset || !h_breakpoints || !h_bp_offset || variability_window <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t rc0 = CANVAS_OK;
     const int64_t N = h_chr_offset[nchr] - h_chr_offset[0];
     if (N <= 0 || N > 0x7FFFFFF0ll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: bin count out of range");
     const int64_t base = h_chr_offset[0];
+    static const int WV_LONG = [] { const char* e = getenv("CANVAS_WV_LONG"); const int v = e ? atoi(e) : WV_LONG_DEFAULT; return v >= 8 && v <= WV_LONG_MAX ? v : WV_LONG_DEFAULT; }();
     std::vector<int64_t> off(nchr + 1);
     for (int c = 0; c <= nchr; c++) off[c] = h_chr_offset[c] - base;
     const double* dX = d_cov + base;
     // the coverage is needed on both sides: the decomposition runs on the device, the median-based decisions on the host
     // (pinned, kept by the context: a pageable destination is staged by the runtime — 37 MB took 8 ms — and five hipHostMalloc per call were 3 ms)
     const size_t maxLongPin = (size_t)N / WV_LONG + (size_t)nchr + 16;
-    const size_t pinBytes = (((size_t)N * sizeof(double) + 255) & ~size_t(255)) + (maxLongPin + 8) * (sizeof(WvNode) + sizeof(WvOut) + 4 * sizeof(int32_t)) + 4096;
+    const size_t pinBytes = (((size_t)N * sizeof(double) + 255) & ~size_t(255)) + (maxLongPin + 8) * (sizeof(WvNode) + sizeof(WvOut) + 4 * sizeof(int32_t)) + 4096
+                          + (maxLongPin + 8) * (sizeof(WvNode) + 3 * sizeof(int32_t) + sizeof(long long)) + WV_EB * sizeof(int32_t) + 3 * sizeof(WvDev) + 2 * (maxLongPin + 8) * (sizeof(WvDNode) + sizeof(int32_t)) + 16 * 256;      // + the staging of the early exact chains
     if (pinBytes > ctx->wv_pin_bytes) {
         if (ctx->wv_pin) { (void)hipHostFree(ctx->wv_pin); ctx->wv_pin = nullptr; ctx->wv_pin_bytes = 0; }
         CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->wv_pin, pinBytes + pinBytes / 4, hipHostMallocDefault)); ctx->wv_pin_bytes = pinBytes + pinBytes / 4;
@@ -719,7 +777,35 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         host_parallel_for((N + 262143) / 262144, [&](int64_t blk) { const int64_t a = blk * 262144, b = std::min<int64_t>(N, a + 262144); bool ok = true; for (int64_t i = a; i < b; i++) ok &= std::isfinite(X[(size_t)i]); if (!ok) nonFinite = 1; });
         if (nonFinite) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: coverage must be finite");
     }
-    const bool timing = getenv("CANVAS_WV_TIMING") != nullptr;
+    // ---- from here on the call runs on two streams of its own, confined to disjoint sets of compute units: the exact chains are single waves of dependent FP64 operations
+    // (s_setprio 3), and whatever shares a SIMD with one of them runs at a third of its speed — with a common pool the level kernels paid for the chains started next to
+    // them (levels 12.6 -> 19.2 ms).  CANVAS_WV_CHAIN_CUS = compute units set aside for the chains (an experiment that measured no gain: default 0 = the context's own streams, no masks).
+    if (!ctx->wv_streams_tried) {
+        ctx->wv_streams_tried = 1;
+        const char* e = getenv("CANVAS_WV_CHAIN_CUS"); int k = e ? atoi(e) : 0;
+        hipDeviceProp_t prop;
+        if (k > 0 && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount >= 4 * k) {
+            const int ncu = prop.multiProcessorCount; std::vector<uint32_t> m((size_t)(ncu + 31) / 32, 0u), inv((size_t)(ncu + 31) / 32, 0u);
+            for (int i = 0; i < ncu; i++) (i < k ? m : inv)[(size_t)i / 32] |= 1u << (i % 32);
+            hipStream_t a = nullptr, b = nullptr;
+            if (hipExtStreamCreateWithCUMask(&a, (uint32_t)m.size(), m.data()) == hipSuccess && hipExtStreamCreateWithCUMask(&b, (uint32_t)inv.size(), inv.data()) == hipSuccess) { ctx->wv_chain = a; ctx->wv_main = b; }
+            else { if (a) (void)hipStreamDestroy(a); if (b) (void)hipStreamDestroy(b); (void)hipGetLastError(); }
+        }
+    }
+    rc0 = canvas_side_init(ctx); if (rc0) return rc0;
+    if (!ctx->wv_sub2) CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wv_sub2, hipStreamNonBlocking));
+    if (ctx->wv_fgh_len != WV_LONG) {
+        if (ctx->wv_fgh) { (void)hipFree(ctx->wv_fgh); ctx->wv_fgh = nullptr; ctx->wv_fgh_len = 0; }
+        CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->wv_fgh, (size_t)(WV_LONG + 1) * (size_t)(WV_LONG + 1) * sizeof(WvFgh)));
+        hipLaunchKernelGGL(k_wv_fgh_table, dim3((unsigned)(WV_LONG + 1)), dim3(256), 0, ctx->stream, (WvFgh*)ctx->wv_fgh, WV_LONG);
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->wv_fgh_len = WV_LONG;
+    }
+    const WvFgh* dFgh = getenv("CANVAS_WV_NO_TABLE") ? nullptr : (const WvFgh*)ctx->wv_fgh; const int fghLen = dFgh ? WV_LONG : 0;
+    if (!ctx->wv_sub) CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wv_sub, hipStreamNonBlocking));      // the subtree walkers of the roots a batch of levels leaves: next to the following levels and to the chains
+    struct StreamSwap { canvas_ctx* c; hipStream_t s0, s1; StreamSwap(canvas_ctx* x) : c(x), s0(x->stream), s1(x->side) { if (x->wv_main && x->wv_chain) { x->stream = x->wv_main; x->side = x->wv_chain; } }
+                        ~StreamSwap() { if (c->stream != s0) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->side); } (void)hipStreamSynchronize(c->wv_sub); (void)hipStreamSynchronize(c->wv_sub2); c->stream = s0; c->side = s1; } } streamSwap(ctx);      // (the context's stream is idle: the copy above has been waited for; both are drained on every way out)
+    const bool timing = getenv("CANVAS_WV_TIMING") != nullptr, trace = getenv("CANVAS_WV_TRACE") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     double cv = 0;
@@ -755,11 +841,12 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         if (!(trees[c].keepAbove == trees[c].keepAbove)) trees[c].keepAbove = -1.0;   // NaN threshold (a window with median 0): nothing is ever zeroed
     });
     for (int c = 0; c < nchr; c++) if (isRoot[(size_t)c]) cur.push_back({c, 1, (int32_t)(off[c + 1] - off[c])});
+    if (trace) { fprintf(stderr, "canvas_wavelets: cv %.17g (%d)", cv, (int)hasCV); for (int c = 0; c < nchr && c < 4; c++) fprintf(stderr, "  chr%d sigma %.17g keep %.17g", c, trees[c].sigma, trees[c].keepAbove); fprintf(stderr, "\n"); }
     // ---- device buffers
     const size_t maxLong = (size_t)N / WV_LONG + (size_t)nchr + 16, maxChunks = 3 * (size_t)N / WV_CS + maxLong + 16, maxRoots = (size_t)N / 2 + (size_t)nchr + 16;
     const unsigned long long capCand = (unsigned long long)N + 16;
     WsSizer sz;
-    const size_t opsCap = 3 * (size_t)N;                                  // the exact chains of nodes of several levels (which overlap in position) run side by side
+    const size_t opsCap = 5 * (size_t)N;                                  // the exact chains of nodes of several levels (which overlap in position) run side by side: [N, 5 N); the first N belong to the level loop's own passes
     sz.take<WvOps>(opsCap); sz.take<WvNode>(maxLong); sz.take<WvOut>(maxLong); sz.take<int32_t>(maxLong);
     sz.take<int32_t>(maxLong + 1); sz.take<int32_t>(maxLong); sz.take<WvHead>(maxLong); sz.take<WvCk>(maxChunks); sz.take<WvBest>(maxChunks);
     sz.take<WvRoot>(maxRoots); sz.take<uint32_t>((size_t)N); sz.take<int32_t>((size_t)N); sz.take<WvCand>((size_t)capCand); sz.take<double>(nchr); sz.take<unsigned long long>(2);
@@ -768,6 +855,8 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     sz.take<long long>((size_t)N); sz.take<long long>((size_t)N); sz.take<long long>(nchr + 1); sz.take<int>(4); sz.take<WvSlot>(maxLong); sz.take<WvSlot>(maxLong); sz.take<WvDNode>(maxList2); sz.take<int32_t>(maxList2);
     sz.take<int32_t>(maxCh); sz.take<int32_t>(maxCh); sz.take<WvPart>(maxCh); sz.take<WvDNode>(maxLong);
     sz.take<WvDNode>(maxList2); sz.take<WvDev>(1); sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
+    sz.take<WvNode>(maxLong); sz.take<WvOut>(maxLong); sz.take<int32_t>(maxLong); sz.take<int32_t>(maxLong + WV_EB); sz.take<int32_t>(maxLong); sz.take<WvHead>(maxLong); sz.take<WvCk>(maxChunks); sz.take<WvBest>(maxChunks);
+    sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_side_init(ctx); if (rc) return rc;
     WsCarver ws(ctx->ws);
@@ -781,6 +870,10 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     WvSlot* dListA = ws.take<WvSlot>(maxLong); WvSlot* dListB = ws.take<WvSlot>(maxLong); WvDNode* dExact = ws.take<WvDNode>(maxList2); int32_t* dExactInd = ws.take<int32_t>(maxList2);
     int32_t* dChA = ws.take<int32_t>(maxCh); int32_t* dChB = ws.take<int32_t>(maxCh); WvPart* dParts = ws.take<WvPart>(maxCh); WvDNode* dListIn = ws.take<WvDNode>(maxLong);
     WvDNode* dUndec = ws.take<WvDNode>(maxList2); WvDev* dDev = ws.take<WvDev>(1); long long* dOpsOff = ws.take<long long>(maxLong); int32_t* dLim = ws.take<int32_t>(maxLong);
+    // a second set for the exact chains that start while the level loop is still running (side stream; slices handed out by running offsets, see exact_launch below)
+    LongBufs E; E.nodes = ws.take<WvNode>(maxLong); E.out = ws.take<WvOut>(maxLong); E.list = ws.take<int32_t>(maxLong); E.base = ws.take<int32_t>(maxLong + WV_EB); E.flag = ws.take<int32_t>(maxLong);
+    E.head = ws.take<WvHead>(maxLong); E.ck = ws.take<WvCk>(maxChunks); E.best = ws.take<WvBest>(maxChunks);
+    long long* dOpsOffE = ws.take<long long>(maxLong); int32_t* dLimE = ws.take<int32_t>(maxLong);
     {
         std::vector<double> keep(nchr);
         for (int c = 0; c < nchr; c++) keep[c] = trees[c].keepAbove;
@@ -790,11 +883,15 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the side stream starts from initialised buffers
     }
     PinVec<WvNode> hNodes; PinVec<WvOut> hOut; PinVec<int32_t> hLong, hBase, hRedo; std::vector<WvRoot> hRoots;
+    WvNode* hNodesE = nullptr; int32_t *hLongE = nullptr, *hBaseE = nullptr, *hLimE = nullptr; long long* hOpsOffE = nullptr; WvDev *hdevIn = nullptr, *hdevRep[2] = {nullptr, nullptr}; WvDNode* hExactPin[2] = {nullptr, nullptr}; int32_t* hExactIndPin[2] = {nullptr, nullptr};
     {   // slices of the context's pinned arena
         auto slice = [&](size_t bytes) { void* q = pinCursor; pinCursor += (bytes + 255) & ~size_t(255); return q; };
         if (maxLong > maxLongPin) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: staging layout");
         hNodes.attach(slice((maxLong + 1) * sizeof(WvNode)), maxLong + 1); hOut.attach(slice((maxLong + 1) * sizeof(WvOut)), maxLong + 1);
         hLong.attach(slice((maxLong + 1) * 4), maxLong + 1); hBase.attach(slice((maxLong + 2) * 4), maxLong + 2); hRedo.attach(slice((maxLong + 1) * 4), maxLong + 1);
+        hNodesE = (WvNode*)slice((maxLong + 1) * sizeof(WvNode)); hLongE = (int32_t*)slice((maxLong + 1) * 4); hBaseE = (int32_t*)slice((maxLong + 1 + WV_EB) * 4); hLimE = (int32_t*)slice((maxLong + 1) * 4);
+        hOpsOffE = (long long*)slice((maxLong + 1) * sizeof(long long)); hdevIn = (WvDev*)slice(sizeof(WvDev));
+        for (int k = 0; k < 2; k++) { hdevRep[k] = (WvDev*)slice(sizeof(WvDev)); hExactPin[k] = (WvDNode*)slice((maxLong + 1) * sizeof(WvDNode)); hExactIndPin[k] = (int32_t*)slice((maxLong + 1) * 4); }
     }
     if (!hNodes.reserve(maxLong) || !hOut.reserve(maxLong) || !hLong.reserve(maxLong) || !hBase.reserve(maxLong + 1) || !hRedo.reserve(maxLong)) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: cannot pin the staging buffers");
     std::vector<std::vector<WvRoot>> rootBatches;
@@ -809,7 +906,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         const std::vector<WvRoot>& B = rootBatches.back();
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRoots + rootsUsed, B.data(), B.size() * sizeof(WvRoot), hipMemcpyHostToDevice, ctx->side));
         hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((B.size() + 63) / 64)), dim3(64), 0, ctx->side, dRoots + rootsUsed, (int)B.size(), dX, dKeep, dStack, dCounts,
-                           dCands, dNcand, capCand, dOverflow);
+                           dCands, dNcand, capCand, dOverflow, dFgh, fghLen);
         rootsUsed += B.size();
         return CANVAS_OK;
     };
@@ -825,16 +922,18 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         rc = flush_roots(false); if (rc) return rc;
     }
     // the kernels of one level for the long nodes in dLong / dBase (chain = the shortcut or the IEEE division)
-    auto long_pass = [&](size_t nLong, int nChunks, bool fast, const long long* opsOff = nullptr, const int32_t* lim = nullptr) -> int32_t {
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFlag, 0, nLong * sizeof(int32_t), ctx->stream));
-        if (nChunks > 0) hipLaunchKernelGGL(k_wv_coeff, dim3((unsigned)nChunks), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, (int)nLong, dX, dOps, opsOff, lim);
-        { ProfScope ps(ctx, "wavelet_chain");
-          if (fast) hipLaunchKernelGGL((k_wv_chain_long<true>), dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, dX, dOps, dCk, dHead, opsOff, lim);
-          else hipLaunchKernelGGL((k_wv_chain_long<false>), dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, dX, dOps, dCk, dHead, opsOff, lim); }
-        if (nChunks > 0) hipLaunchKernelGGL(k_wv_chunks, dim3((unsigned)((nChunks + 63) / 64)), dim3(64), 0, ctx->stream, dNodes, dLong, dBase, (int)nLong, nChunks, dOps, dCk, dBest, dFlag, opsOff, lim);
-        hipLaunchKernelGGL(k_wv_reduce, dim3((unsigned)nLong), dim3(64), 0, ctx->stream, dLong, dBase, dHead, dBest, dFlag, dOut);
+    auto long_pass_on = [&](hipStream_t st, const LongBufs& B, size_t nLong, int nChunks, bool fast, const long long* opsOff, const int32_t* lim) -> int32_t {
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(B.flag, 0, nLong * sizeof(int32_t), st));
+        if (nChunks > 0) hipLaunchKernelGGL(k_wv_coeff, dim3((unsigned)nChunks), dim3(64), 0, st, B.nodes, B.list, B.base, (int)nLong, dX, dOps, opsOff, lim);
+        { ProfScope ps(ctx, "wavelet_chain", false, st);
+          if (fast) hipLaunchKernelGGL((k_wv_chain_long<true>), dim3((unsigned)nLong), dim3(64), 0, st, B.nodes, B.list, B.base, dX, dOps, B.ck, B.head, opsOff, lim);
+          else hipLaunchKernelGGL((k_wv_chain_long<false>), dim3((unsigned)nLong), dim3(64), 0, st, B.nodes, B.list, B.base, dX, dOps, B.ck, B.head, opsOff, lim); }
+        if (nChunks > 0) hipLaunchKernelGGL(k_wv_chunks, dim3((unsigned)((nChunks + 63) / 64)), dim3(64), 0, st, B.nodes, B.list, B.base, (int)nLong, nChunks, dOps, B.ck, B.best, B.flag, opsOff, lim);
+        hipLaunchKernelGGL(k_wv_reduce, dim3((unsigned)nLong), dim3(64), 0, st, B.list, B.base, B.head, B.best, B.flag, B.out);
         return CANVAS_OK;
     };
+    LongBufs M; M.nodes = dNodes; M.out = dOut; M.list = dLong; M.base = dBase; M.flag = dFlag; M.head = dHead; M.ck = dCk; M.best = dBest;
+    auto long_pass = [&](size_t nLong, int nChunks, bool fast, const long long* opsOff = nullptr, const int32_t* lim = nullptr) -> int32_t { return long_pass_on(ctx->stream, M, nLong, nChunks, fast, opsOff, lim); };
     auto upload_long = [&](const PinVec<int32_t>& list, const std::vector<int32_t>* lim = nullptr) -> int {                // returns the number of chunks
         hBase.clear(); hBase.push_back(0);
         size_t at = 0;
@@ -865,33 +964,173 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         WvDev hdev; memset(&hdev, 0, sizeof hdev);
         // the short chromosomes placed above are the first roots of the device-side list
         std::vector<WvRoot> firstRoots(hRoots.begin(), hRoots.end()); hRoots.clear();          // (what flush_roots has launched already stays in front of them)
-        const size_t rootsLaunched = rootsUsed;
+        size_t rootsLaunched = rootsUsed; unsigned subLaunches = 0;
+        const bool subLate = getenv("CANVAS_WV_SUB_LATE") != nullptr, oneSub = getenv("CANVAS_WV_ONE_SUB") != nullptr;      // (experiments)
+        auto launch_subtrees = [&](unsigned upTo) {             // the roots [rootsLaunched, upTo) of the device's list: written by kernels that have completed
+            if (upTo <= rootsLaunched) return;
+            const size_t nr = upTo - rootsLaunched;
+            hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, ((subLaunches++ & 1) && !oneSub) ? ctx->wv_sub2 : ctx->wv_sub, dRoots + rootsLaunched, (int)nr, dX, dKeep, dStack, dCounts, dCands, dNcand, capCand, dOverflow, dFgh, fghLen);      // (a launch lasts as long as its slowest lane: two streams take turns)
+            rootsLaunched = upTo;
+        };
         if (firstRoots.size() + rootsUsed > maxRoots) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: root list overflow");
         if (!firstRoots.empty()) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRoots + rootsUsed, firstRoots.data(), firstRoots.size() * sizeof(WvRoot), hipMemcpyHostToDevice, ctx->stream));
         hdev.nRoots = (unsigned)(rootsUsed + firstRoots.size());
-        std::vector<WvDNode> hExact, hUndec; std::vector<int32_t> hExactInd;
+        std::vector<WvDNode> hUndec;
+        // ---- the nodes whose coefficient may survive HardThresh need the exact chain — one wave of dependent FP64 operations per node, 10 ms for the longest of a WGS sample —
+        // but nothing waits for its result: the chains of the nodes a batch of levels has found start on the side stream while the next levels run.  Every launch takes slices
+        // of the E buffers and of the operand array (positions [N, 3 N): the first N belong to the undecided nodes' passes) by running offsets; harvest() drains the side
+        // stream, checks the results, and hands the slices out again.
+        struct EPending { WvDNode nd; int32_t ind; };
+        std::vector<EPending> ePend;                                     // slot i of the E buffers belongs to ePend[i]
+        size_t eNodes = 0, eChunks = 0, eBase = 0, exactSeen = 0; long long eOps = N;
+        unsigned batchSeq = (unsigned)(ctx->wv_calls++ << 20);     // (never the number a previous call left in the pinned report slots)
+        std::vector<WvOut> hOutE;
+        long long chainSteps = 0, chainLongest = 0;
+        auto harvest = [&]() -> int32_t {
+            if (eNodes == 0) { eChunks = eBase = 0; eOps = N; return CANVAS_OK; }
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+            CANVAS_HIP_TRY(ctx, hipGetLastError());
+            hOutE.resize(eNodes);
+            CANVAS_HIP_TRY(ctx, hipMemcpy(hOutE.data(), E.out, eNodes * sizeof(WvOut), hipMemcpyDeviceToHost));
+            std::vector<int32_t> redo;
+            for (size_t i = 0; i < eNodes; i++) if (hOutE[i].flag) redo.push_back((int32_t)i);
+            if (!redo.empty()) {                                 // a checkpoint of the shortcut chain was not reproduced: IEEE divisions in the chain for those nodes (their own operand slices)
+                redone += (long long)redo.size();
+                std::vector<long long> ro; std::vector<int32_t> rl, rb{0};
+                for (int32_t i : redo) { ro.push_back(hOpsOffE[(size_t)i]); rl.push_back(hLimE[(size_t)i]); const int32_t last = std::min<int32_t>(hNodesE[(size_t)i].len - 2, hLimE[(size_t)i]); rb.push_back(rb.back() + (int32_t)((last + WV_CS - 1) / WV_CS)); }
+                CANVAS_HIP_TRY(ctx, hipMemcpy(E.list, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                CANVAS_HIP_TRY(ctx, hipMemcpy(E.base, rb.data(), rb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                CANVAS_HIP_TRY(ctx, hipMemcpy(dOpsOffE, ro.data(), ro.size() * sizeof(long long), hipMemcpyHostToDevice));
+                CANVAS_HIP_TRY(ctx, hipMemcpy(dLimE, rl.data(), rl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                int32_t rcr = long_pass_on(ctx->side, E, redo.size(), rb.back(), false, dOpsOffE, dLimE); if (rcr) return rcr;
+                CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+                CANVAS_HIP_TRY(ctx, hipGetLastError());
+                CANVAS_HIP_TRY(ctx, hipMemcpy(hOutE.data(), E.out, eNodes * sizeof(WvOut), hipMemcpyDeviceToHost));
+                for (int32_t i : redo) if (hOutE[(size_t)i].flag) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the exact chain was not reproduced by its own check");
+            }
+            for (size_t i = 0; i < eNodes; i++) {
+                const WvDNode& u = ePend[i].nd;
+                if (hOutE[i].ind != ePend[i].ind) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: a decided arg-max disagrees with the exact chain (error bound violated)");
+                ChromTree& T = trees[u.chrom];
+                const int32_t s1 = (int32_t)(u.start - off[u.chrom] + 1), e1 = s1 + u.len - 1, b = s1 + hOutE[i].ind - 1;
+                if (std::fabs(hOutE[i].coef) > T.keepAbove) T.cands.push_back({u.level, s1, b, e1, hOutE[i].coef});
+            }
+            ePend.clear(); eNodes = eChunks = eBase = 0; eOps = N;
+            return CANVAS_OK;
+        };
+        std::vector<WvDNode> hExactNew; std::vector<int32_t> hExactIndNew;
+        std::vector<WvDNode> hDeferred; std::vector<int32_t> hDeferredInd;
+        auto exact_launch = [&](bool mayWait) -> int32_t {       // the entries of hExactNew / hExactIndNew, longest chain first
+            size_t ne = hExactNew.size();
+            std::vector<size_t> order(ne);
+            for (size_t i = 0; i < ne; i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return hExactIndNew[x] != hExactIndNew[y] ? hExactIndNew[x] > hExactIndNew[y] : x < y; });
+            if (getenv("CANVAS_WV_DEBUG_CHAINS")) ne = std::min<size_t>(ne, (size_t)atoi(getenv("CANVAS_WV_DEBUG_CHAINS")));      // timing experiment: only the longest chains (the result is then wrong)
+            for (size_t a = 0; a < ne;) {
+                size_t nn = 0; long long used = 0; size_t chunks = 0;
+                while (a + nn < ne && eNodes + nn < maxLong && eBase + nn + 2 <= maxLong + WV_EB) {
+                    const int32_t ind = hExactIndNew[order[a + nn]], len = hExactNew[order[a + nn]].len;
+                    const int32_t last = std::min<int32_t>(len - 2, ind - 1);
+                    const size_t ch = (size_t)((last + WV_CS - 1) / WV_CS);
+                    if (eOps + used + ind + 8 > (long long)opsCap || eChunks + chunks + ch > maxChunks) break;
+                    used += ind + 8; chunks += ch; nn++;
+                }
+                if (nn == 0) {
+                    if (eNodes == 0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: exact-chain batching");
+                    if (!mayWait) { for (; a < ne; a++) { hDeferred.push_back(hExactNew[order[a]]); hDeferredInd.push_back(hExactIndNew[order[a]]); } break; }      // (the level loop must not stand still behind the chains: these wait for its end)
+                    int32_t rch = harvest(); if (rch) return rch;
+                    continue;
+                }
+                long long o = eOps; int32_t cb = 0;
+                hBaseE[eBase] = 0;
+                for (size_t i = 0; i < nn; i++) {
+                    const WvDNode& u = hExactNew[order[a + i]]; const int32_t ind = hExactIndNew[order[a + i]];
+                    hNodesE[eNodes + i] = {u.start, u.len}; hLongE[eNodes + i] = (int32_t)i; hOpsOffE[eNodes + i] = o; hLimE[eNodes + i] = ind - 1;      // the chain stops at the decided arg-max: nothing behind it enters the coefficient
+                    o += ind + 8; cb += (int32_t)((std::min<int32_t>(u.len - 2, ind - 1) + WV_CS - 1) / WV_CS); hBaseE[eBase + i + 1] = cb;
+                    ePend.push_back({u, ind}); nExactChains++; chainSteps += ind; chainLongest = std::max<long long>(chainLongest, ind);
+                }
+                LongBufs B; B.nodes = E.nodes + eNodes; B.out = E.out + eNodes; B.list = E.list + eNodes; B.base = E.base + eBase; B.flag = E.flag + eNodes; B.head = E.head + eNodes; B.ck = E.ck + eChunks; B.best = E.best + eChunks;
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(B.nodes, hNodesE + eNodes, nn * sizeof(WvNode), hipMemcpyHostToDevice, ctx->side));
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(B.list, hLongE + eNodes, nn * sizeof(int32_t), hipMemcpyHostToDevice, ctx->side));
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(B.base, hBaseE + eBase, (nn + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->side));
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOpsOffE + eNodes, hOpsOffE + eNodes, nn * sizeof(long long), hipMemcpyHostToDevice, ctx->side));
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dLimE + eNodes, hLimE + eNodes, nn * sizeof(int32_t), hipMemcpyHostToDevice, ctx->side));
+                int32_t rcl = long_pass_on(ctx->side, B, nn, cb, true, dOpsOffE + eNodes, dLimE + eNodes); if (rcl) return rcl;
+                eNodes += nn; eBase += nn + 1; eChunks += (size_t)cb; eOps = o;
+                a += nn;
+            }
+            return CANVAS_OK;
+        };
+        // the new entries of the device's exact list (the main stream has just been drained: the copy costs a few microseconds of it)
+        auto fetch_exact = [&](unsigned upTo) -> int32_t {       // at most maxLong entries per call (the pinned staging); the caller comes back for the rest
+            hExactNew.clear(); hExactIndNew.clear();
+            if (upTo <= exactSeen) return CANVAS_OK;
+            const size_t k = std::min<size_t>(upTo - exactSeen, maxLong);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hExactPin[0], dExact + exactSeen, k * sizeof(WvDNode), hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hExactIndPin[0], dExactInd + exactSeen, k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            hExactNew.assign(hExactPin[0], hExactPin[0] + k); hExactIndNew.assign(hExactIndPin[0], hExactIndPin[0] + k);
+            exactSeen += k;
+            return CANVAS_OK;
+        };
+        static const unsigned levelGrid = [] { const char* e = getenv("CANVAS_WV_LEVEL_GRID"); const int v = e ? atoi(e) : 1024; return (unsigned)(v >= 64 && v <= 8192 ? v : 1024); }();
         while (!hList.empty()) {
             if (hList.size() > maxLong) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: long-node list overflow");
             const int nIn = (int)hList.size();
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dListIn, hList.data(), hList.size() * sizeof(WvDNode), hipMemcpyHostToDevice, ctx->stream));
             hList.clear();
-            bool first = true;
-            hdev.cnt[0] = 0; hdev.nch[0] = 0;
-            for (;;) {
-                for (int i = 1; i < WV_LB + 2; i++) { hdev.cnt[i] = 0; hdev.nch[i] = 0; }
-                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dDev, &hdev, sizeof hdev, hipMemcpyHostToDevice, ctx->stream));
-                if (first) { hipLaunchKernelGGL(k_wv_list_init, dim3((unsigned)((nIn + 255) / 256)), dim3(256), 0, ctx->stream, dListIn, nIn, dListA, dChA, dDev, (unsigned)maxLong, (unsigned)maxCh); first = false; }
-                for (int it = 0; it < WV_LB; it++)
-                    hipLaunchKernelGGL(k_wv_level, dim3(320), dim3(256), 0, ctx->stream, (it & 1) ? dListB : dListA, (it & 1) ? dChB : dChA, (it & 1) ? dListA : dListB, (it & 1) ? dChA : dChB, dParts,
-                                       dDev, it, (unsigned)maxLong, (unsigned)maxCh, (unsigned)maxList2, dP1, dP2, dOff, dKeep, dRoots, (unsigned)maxRoots, dExact, dExactInd, dUndec, dCounts);
-                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&hdev, dDev, sizeof hdev, hipMemcpyDeviceToHost, ctx->stream));
-                CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                CANVAS_HIP_TRY(ctx, hipGetLastError());
+            // batches of levels, short ones first (the longest chains hang off the first levels), one batch enqueued ahead of the one the host is waiting for
+            for (int i = 0; i < WV_LB + 2; i++) { hdev.cnt[i] = 0; hdev.nch[i] = 0; }
+            hdev.exactReported = (unsigned)exactSeen;
+            *hdevIn = hdev;
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dDev, hdevIn, sizeof hdev, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_wv_list_init, dim3((unsigned)((nIn + 255) / 256)), dim3(256), 0, ctx->stream, dListIn, nIn, dListA, dChA, dDev, (unsigned)maxLong, (unsigned)maxCh);
+            hipEvent_t ev[2] = {ctx->side_ev, ctx->side_ev2};
+            int lbOf[2] = {0, 0}, lbNext = 16; unsigned seqOf[2] = {0, 0};
+            auto enqueue_batch = [&](int slot) -> int32_t {
+                const int lb = lbNext; lbOf[slot] = lb; lbNext = std::min(64, lbNext * 2);
+                for (int it = 0; it < lb; it++)
+                    hipLaunchKernelGGL(k_wv_level, dim3(levelGrid), dim3(256), 0, ctx->stream, (it & 1) ? dListB : dListA, (it & 1) ? dChB : dChA, (it & 1) ? dListA : dListB, (it & 1) ? dChA : dChB, dParts,
+                                       dDev, it, (unsigned)maxLong, (unsigned)maxCh, (unsigned)maxList2, dP1, dP2, dOff, dKeep, dRoots, (unsigned)maxRoots, dExact, dExactInd, dUndec, dCounts, WV_LONG);
+                hipLaunchKernelGGL(k_wv_batch_end, dim3(1), dim3(256), 0, ctx->stream, dDev, lb, dExact, dExactInd, hdevRep[slot], hExactPin[slot], hExactIndPin[slot], (unsigned)maxLong, ++batchSeq);
+                seqOf[slot] = batchSeq;
+                CANVAS_HIP_TRY(ctx, hipEventRecord(ev[slot], ctx->stream));
+                return CANVAS_OK;
+            };
+            rc = enqueue_batch(0); if (rc) return rc;
+            rc = enqueue_batch(1); if (rc) return rc;
+            for (int k = 0;; k++) {
+                const int slot = k & 1, lb = lbOf[slot];
+                const double tw0 = now();
+                CANVAS_HIP_TRY(ctx, hipEventSynchronize(ev[slot]));
+                {   // the report carries the number of its batch in its last word
+                    const volatile unsigned* sq = &hdevRep[slot]->seq;
+                    if (*sq != seqOf[slot]) {
+                        if (trace) fprintf(stderr, "canvas_wavelets: the event of batch %d was complete before its report (seq %u, expected %u)\n", k, *sq, seqOf[slot]);
+                        const double tp = now();
+                        while (*sq != seqOf[slot]) { if (now() - tp > 20.0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the report of a batch of levels did not arrive"); __builtin_ia32_pause(); }
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                }
+                const double tw1 = now();
+                hdev = *hdevRep[slot];
                 if (hdev.overflow) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: a node list of the device-side tree overflowed");
-                for (int i = 0; i < WV_LB; i++) nDecided += hdev.cnt[i];
-                if (hdev.cnt[WV_LB] == 0) break;
-                hdev.cnt[0] = hdev.cnt[WV_LB]; hdev.nch[0] = hdev.nch[WV_LB];      // WV_LB is even: the pending level sits in list A again (with its chunk map)
+                for (int i = 0; i < lb; i++) nDecided += hdev.cnt[i];
+                const bool pending = hdev.cnt[lb] != 0;
+                hExactNew.clear(); hExactIndNew.clear();
+                if (hdev.exactReported != exactSeen) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: exact-list bookkeeping");
+                { const size_t cnt = hdev.nExact > hdev.exactReported ? std::min<size_t>(hdev.nExact - hdev.exactReported, maxLong) : 0;
+                  hExactNew.assign(hExactPin[slot], hExactPin[slot] + cnt); hExactIndNew.assign(hExactIndPin[slot], hExactIndPin[slot] + cnt); exactSeen += cnt; }
+                if (pending) { rc = enqueue_batch(slot); if (rc) return rc; }                 // (batch k + 2; batch k + 1 is running)
+                if (!subLate) launch_subtrees(std::min<unsigned>(hdev.nRoots, (unsigned)maxRoots));         // (the host's first roots were uploaded on the main stream in front of batch 0: complete as well)
+                const double tw2 = now(); const size_t nNew = hExactNew.size();
+                if (!hExactNew.empty()) { rc = exact_launch(false); if (rc) return rc; }
+                if (trace && k == 0) fprintf(stderr, "canvas_wavelets: first report: nodes per level %u %u %u %u %u %u, chunks %u %u %u %u, undecided %u, roots %u, exact %u\n", hdev.cnt[0], hdev.cnt[1], hdev.cnt[2], hdev.cnt[3], hdev.cnt[4], hdev.cnt[5], hdev.nch[0], hdev.nch[1], hdev.nch[2], hdev.nch[3], hdev.nUndec, hdev.nRoots, hdev.nExact);
+                if (trace) fprintf(stderr, "canvas_wavelets: batch %d (%d levels): waited %.0f us from %.0f us, enqueue %.0f us, %zu chains launched in %.0f us, pending %u nodes\n", k, lb, (tw1 - tw0) * 1e6, (tw0 - tSetup) * 1e6, (tw2 - tw1) * 1e6, nNew, (now() - tw2) * 1e6, hdev.cnt[lb]);
+                if (!pending) break;                                                        // (batch k + 1 finds empty lists)
             }
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipGetLastError());
             nDecided -= hdev.nUndec;
             tcLevels += now() - tcA; tcA = now();
             // ---- undecided nodes (exact ties between candidates): the chain decides them, their children go on as a new list
@@ -899,7 +1138,8 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
                 const size_t nu = hdev.nUndec;
                 nUndecided += (long long)nu;
                 hUndec.resize(nu);
-                CANVAS_HIP_TRY(ctx, hipMemcpy(hUndec.data(), dUndec, nu * sizeof(WvDNode), hipMemcpyDeviceToHost));
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hUndec.data(), dUndec, nu * sizeof(WvDNode), hipMemcpyDeviceToHost, ctx->stream));
+                CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                 // (a node and its descendants are never undecided together — the descendants do not exist yet — so the stretches are disjoint: but the list may exceed
                 // the per-level bound, so it goes through in slices)
                 for (size_t a = 0; a < nu; a += maxLong) {
@@ -928,74 +1168,26 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
                 }
                 if (!hRoots.empty()) {
                     if (hdev.nRoots + hRoots.size() > maxRoots) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: root list overflow");
-                    CANVAS_HIP_TRY(ctx, hipMemcpy(dRoots + hdev.nRoots, hRoots.data(), hRoots.size() * sizeof(WvRoot), hipMemcpyHostToDevice));
+                    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRoots + hdev.nRoots, hRoots.data(), hRoots.size() * sizeof(WvRoot), hipMemcpyHostToDevice, ctx->stream));
+                    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                     hdev.nRoots += (unsigned)hRoots.size(); hRoots.clear();
                 }
                 hdev.nUndec = 0;
             }
             tcUndec += now() - tcA; tcA = now();
         }
-        // ---- the short nodes with their whole subtrees: one lane each, next to the exact chains below
-        if (hdev.nRoots) {
-            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            const size_t nr = hdev.nRoots - rootsLaunched;
-            if (nr) hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, ctx->side, dRoots + rootsLaunched, (int)nr, dX, dKeep, dStack, dCounts, dCands, dNcand, capCand, dOverflow);
-        }
-        // ---- the nodes whose coefficient may survive HardThresh: exact chains, all levels at once (every node gets a slice of the operand array of its own, longest first)
-        if (hdev.nExact) {
-            size_t ne = hdev.nExact;
-            nExactChains = (long long)ne;
-            hExact.resize(ne); hExactInd.resize(ne);
-            CANVAS_HIP_TRY(ctx, hipMemcpy(hExact.data(), dExact, ne * sizeof(WvDNode), hipMemcpyDeviceToHost));
-            CANVAS_HIP_TRY(ctx, hipMemcpy(hExactInd.data(), dExactInd, ne * sizeof(int32_t), hipMemcpyDeviceToHost));
-            std::vector<size_t> order(ne);
-            for (size_t i = 0; i < ne; i++) order[i] = i;
-            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hExactInd[a] != hExactInd[b] ? hExactInd[a] > hExactInd[b] : a < b; });
-            std::vector<long long> hOpsOff; std::vector<int32_t> hLim;
-            if (getenv("CANVAS_WV_DEBUG_CHAINS")) ne = std::min<size_t>(ne, (size_t)atoi(getenv("CANVAS_WV_DEBUG_CHAINS")));      // timing experiment: only the longest chains (the result is then wrong)
-            if (timing) { long long sum = 0, mx = 0, mxl = 0; for (size_t i = 0; i < ne; i++) { sum += hExactInd[i]; mx = std::max<long long>(mx, hExactInd[i]); mxl = std::max<long long>(mxl, hExact[i].len); } fprintf(stderr, "canvas_wavelets: %zu exact chains, %lld steps in all, longest %lld (node %lld)\n", ne, sum, mx, mxl); }
-            for (size_t a = 0; a < ne;) {
-                size_t nn = 0; long long used = 0;
-                hOpsOff.clear();
-                hLim.clear();
-                while (a + nn < ne && nn < maxLong && used + hExactInd[order[a + nn]] + 8 <= (long long)opsCap) { hOpsOff.push_back(used); hLim.push_back(hExactInd[order[a + nn]] - 1); used += hExactInd[order[a + nn]] + 8; nn++; }
-                if (nn == 0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: exact-chain batching");
-                hNodes.resize(nn); hOut.resize(nn); hLong.resize(nn);
-                for (size_t i = 0; i < nn; i++) { const WvDNode& u = hExact[order[a + i]]; hNodes[i] = {u.start, u.len}; hLong[i] = (int32_t)i; }
-                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dNodes, hNodes.data(), nn * sizeof(WvNode), hipMemcpyHostToDevice, ctx->stream));
-                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOpsOff, hOpsOff.data(), nn * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
-                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dLim, hLim.data(), nn * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));      // the chain stops at the decided arg-max: nothing behind it enters the coefficient
-                { const int nChunks = upload_long(hLong, &hLim); rc = long_pass(nn, nChunks, true, dOpsOff, dLim); if (rc) return rc; }
-                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
-                CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                CANVAS_HIP_TRY(ctx, hipGetLastError());
-                hRedo.clear();
-                for (size_t i = 0; i < nn; i++) if (hOut[i].flag) hRedo.push_back((int32_t)i);
-                if (!hRedo.empty()) {                            // a checkpoint of the shortcut chain was not reproduced: IEEE divisions in the chain for those nodes
-                    redone += (long long)hRedo.size();
-                    // (the slices of the operand array follow the list order: the redo list keeps the nodes' own offsets and limits)
-                    std::vector<long long> ro; std::vector<int32_t> rl; for (int32_t i : hRedo) { ro.push_back(hOpsOff[(size_t)i]); rl.push_back(hLim[(size_t)i]); }
-                    const int nChunks = upload_long(hRedo, &rl);
-                    CANVAS_HIP_TRY(ctx, hipMemcpy(dOpsOff, ro.data(), ro.size() * sizeof(long long), hipMemcpyHostToDevice));
-                    CANVAS_HIP_TRY(ctx, hipMemcpy(dLim, rl.data(), rl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-                    rc = long_pass(hRedo.size(), nChunks, false, dOpsOff, dLim); if (rc) return rc;
-                    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
-                    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                    CANVAS_HIP_TRY(ctx, hipGetLastError());
-                    for (int32_t i : hRedo) if (hOut[i].flag) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the exact chain was not reproduced by its own check");
-                }
-                for (size_t i = 0; i < nn; i++) {
-                    const WvDNode& u = hExact[order[a + i]];
-                    if (hOut[i].ind != hExactInd[order[a + i]]) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: a decided arg-max disagrees with the exact chain (error bound violated)");
-                    ChromTree& T = trees[u.chrom];
-                    const int32_t s1 = (int32_t)(u.start - off[u.chrom] + 1), e1 = s1 + u.len - 1, b = s1 + hOut[i].ind - 1;
-                    if (std::fabs(hOut[i].coef) > T.keepAbove) T.cands.push_back({u.level, s1, b, e1, hOut[i].coef});
-                }
-                a += nn;
-            }
-        }
+        // ---- the chains that were not started early (more entries than one report holds), then the short nodes with their whole subtrees: one lane each,
+        // on the main stream (the side stream belongs to the chains); then everything the chains have found
+        while (exactSeen < hdev.nExact) { rc = fetch_exact(hdev.nExact); if (rc) return rc; rc = exact_launch(true); if (rc) return rc; }
+        if (!hDeferred.empty()) { hExactNew.swap(hDeferred); hExactIndNew.swap(hDeferredInd); rc = exact_launch(true); if (rc) return rc; }
+        launch_subtrees(hdev.nRoots);
+        rc = harvest(); if (rc) return rc;
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->wv_sub));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->wv_sub2));
+        if (timing) fprintf(stderr, "canvas_wavelets: %lld exact chains, %lld steps in all, longest %lld (device list %u entries, %zu seen)\n", nExactChains, chainSteps, chainLongest, hdev.nExact, exactSeen);
         tcExact = now() - tcA;
-        if (timing) fprintf(stderr, "canvas_wavelets: closed-form levels %.4f s, undecided nodes %.4f s, exact chains %.4f s (%u roots)\n", tcLevels, tcUndec, tcExact, hdev.nRoots);
+        if (timing) fprintf(stderr, "canvas_wavelets: closed-form levels %.4f s, undecided nodes %.4f s, rest of the exact chains + subtrees %.4f s (%u roots)\n", tcLevels, tcUndec, tcExact, hdev.nRoots);
         rootsUsed = hdev.nRoots;
         cur.clear();
     }
@@ -1100,17 +1292,39 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         double smooth = 0;
         for (int64_t i = 0; i < L; i++) smooth += r[i];
         smooth = smooth / std::sqrt(n);
-        std::vector<double> rec((size_t)L, 1.0 / std::sqrt(n) * smooth);
-        // nodes whose coefficient is zeroed add +-0 to rec and cannot create or remove a difference: only the survivors are applied,
-        // in the reference's order (level by level, left to right)
-        for (const Cand& k : T.cands) {
-            if (std::fabs(k.coef) <= 2 * T.sigma * (thresholds[indices[k.level]]) * std::sqrt(2 * std::log(n))) continue;
-            const double nn = (double)k.e - (double)k.s + 1, m = (double)k.b - (double)k.s + 1;
-            const double val1 = std::sqrt(1 / m - 1 / nn), val2 = -1.0 / std::sqrt(nn * nn / m - nn);
-            for (int32_t i = k.s - 1; i < k.e; i++) rec[i] = rec[i] + ((double)(i - (k.s - 1)) < m ? val1 : val2) * k.coef;
-        }
+        // GetReconstructedVector + GetSegments (WaveletSegmentation.cs:166-204): rec starts as one constant and every surviving node adds one value to its left part and one
+        // to its right part, so rec is piecewise constant with at most three new piece boundaries per survivor.  The pieces are kept instead of the L elements (a WGS chromosome
+        // spent 5 ms adding constants to 380 000 doubles per survivor): every piece receives exactly the additions, in the same order, that each of its elements would.
+        // nodes whose coefficient is zeroed add +-0 to rec and cannot create or remove a difference: only the survivors are applied, in the reference's order (level by level,
+        // left to right)
         std::vector<int> prelim{0};
-        for (int64_t i = 1; i < L; i++) if (rec[i] - rec[i - 1] != 0) prelim.push_back((int)i);
+        {
+            std::map<int64_t, double> piece;                  // start of a piece -> its value
+            piece[0] = 1.0 / std::sqrt(n) * smooth;
+            auto split = [&](int64_t p) { if (p <= 0 || p >= L) return; auto it = piece.upper_bound(p); --it; if (it->first != p) piece.emplace_hint(std::next(it), p, it->second); };
+            bool finite = true;
+            for (const Cand& k : T.cands) {
+                if (std::fabs(k.coef) <= 2 * T.sigma * (thresholds[indices[k.level]]) * std::sqrt(2 * std::log(n))) continue;
+                const double nn = (double)k.e - (double)k.s + 1, m = (double)k.b - (double)k.s + 1;
+                const double val1 = std::sqrt(1 / m - 1 / nn), val2 = -1.0 / std::sqrt(nn * nn / m - nn);
+                const int64_t a = k.s - 1, b = k.b, c = k.e;  // elements [a, b) take val1 * coef, [b, c) val2 * coef
+                split(a); split(b); split(c);
+                for (auto it = piece.lower_bound(a); it != piece.end() && it->first < c; ++it) { it->second = it->second + (it->first < b ? val1 : val2) * k.coef; if (!std::isfinite(it->second)) finite = false; }
+            }
+            if (finite) {
+                double prev = 0; bool first = true;
+                for (const auto& kv : piece) { if (!first && kv.second - prev != 0) prelim.push_back((int)kv.first); prev = kv.second; first = false; }
+            } else {                                          // (a difference of infinities is NaN at EVERY element of a piece: the element-wise form decides)
+                std::vector<double> rec((size_t)L, 1.0 / std::sqrt(n) * smooth);
+                for (const Cand& k : T.cands) {
+                    if (std::fabs(k.coef) <= 2 * T.sigma * (thresholds[indices[k.level]]) * std::sqrt(2 * std::log(n))) continue;
+                    const double nn = (double)k.e - (double)k.s + 1, m = (double)k.b - (double)k.s + 1;
+                    const double val1 = std::sqrt(1 / m - 1 / nn), val2 = -1.0 / std::sqrt(nn * nn / m - nn);
+                    for (int32_t i = k.s - 1; i < k.e; i++) rec[i] = rec[i] + ((double)(i - (k.s - 1)) < m ? val1 : val2) * k.coef;
+                }
+                for (int64_t i = 1; i < L; i++) if (rec[i] - rec[i - 1] != 0) prelim.push_back((int)i);
+            }
+        }
         // GetBreakpointsAfterHealingBadSplits
         std::vector<int> bp{prelim[0]};
         const int Lp = (int)prelim.size();
