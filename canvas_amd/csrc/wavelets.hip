@@ -352,17 +352,14 @@ __device__ __forceinline__ long long wv_block_scan_i64(long long v, long long* s
     *total = tot;
     return inc + offw;
 }
-// highest level of every chromosome that has a node (one workgroup per chromosome scans the chromosome's slice of the counters)
+// highest level of every chromosome that has a node (blockIdx.y = chromosome, the workgroups of a row share the chromosome's slice of the counters; top[] starts at -1)
 __global__ void __launch_bounds__(256) k_wv_tops(const int32_t* __restrict__ counts, const long long* __restrict__ off, int32_t* __restrict__ top) {
-    __shared__ int sTop[4];
-    const long long lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+    const long long lo = off[blockIdx.y], hi = off[blockIdx.y + 1];
     int t = -1;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) if (counts[i]) t = (int)(i - lo);      // (ascending per thread: the last hit is the thread's highest)
+    for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long long)gridDim.x * 256) if (counts[i]) t = (int)(i - lo);      // (ascending per thread: the last hit is the thread's highest)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(t, d, 64); t = o > t ? o : t; }
-    if ((threadIdx.x & 63) == 0) sTop[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) t = sTop[w] > t ? sTop[w] : t; top[blockIdx.x] = t; }
+    if ((threadIdx.x & 63) == 0 && t >= 0) atomicMax(&top[blockIdx.y], t);
 }
 // one workgroup per chromosome: k = 100 x as integers (checked bit for bit), P1[i] = k_0 + ... + k_i, P2[i] = P1[0] + ... + P1[i] (both restart at every chromosome)
 __global__ void __launch_bounds__(1024) k_wv_prefix(const double* __restrict__ X, const long long* __restrict__ off, long long* __restrict__ P1, long long* __restrict__ P2, int* __restrict__ bad) {
@@ -533,6 +530,118 @@ __global__ void __launch_bounds__(256) k_wv_batch_end(WvDev* __restrict__ dev, i
         for (int i = 1; i < WV_LB + 2; i++) { dev->cnt[i] = 0; dev->nch[i] = 0; }
         dev->cnt[0] = c; dev->nch[0] = n; dev->exactReported = from + k;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ factor-of-three coverage variabilities on the device
+// SegmentationInput.FactorOfThreeCoverageVariabilities (Segmentation.cs:366-429): per exponent, every chromosome is cut into triplets, each triplet leaves its median (the next
+// exponent's series) and (max - min) / 2 / median, and the MEDIAN of all those ratios is the exponent's value.  The triplets are independent; the median of up to N / 3 doubles is
+// a radix selection over order-preserving 64-bit keys (8 passes of 8 bits: a histogram kernel over all keys that still match the prefix, and one workgroup that picks the digit).
+// NaN sorts in front of every number (SortedList<double> of .NET): its key is 0.  The host thread this replaces needed 30 ms for a WGS sample — more than the decomposition.
+#define WV_F3_MAXCHR 64
+struct WvF3Level { long long inOff[WV_F3_MAXCHR + 1], outOff[WV_F3_MAXCHR + 1]; int nchr; };      // chromosome c: series [inOff[c], inOff[c+1]) -> triplets [outOff[c], outOff[c+1])
+struct WvF3Sel { unsigned long long prefix[2]; unsigned long long rank[2]; unsigned int hist[2][256]; };
+__device__ __forceinline__ unsigned long long wv_f3_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    if (v != v) return 0ull;
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__global__ void __launch_bounds__(256) k_f3_triplets(const double* __restrict__ in, double* __restrict__ med, unsigned long long* __restrict__ key, const WvF3Level lv) {
+    const long long total = lv.outOff[lv.nchr];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int c = 0; while (c + 1 < lv.nchr && i >= lv.outOff[c + 1]) c++;
+        const long long j = lv.inOff[c] + 3 * (i - lv.outOff[c]);
+        double a = in[j], b = in[j + 1], e = in[j + 2];
+        if (a > b) { const double t = a; a = b; b = t; }
+        if (a > e) { const double t = a; a = e; e = t; }
+        if (b > e) { const double t = b; b = e; e = t; }
+        med[i] = b;
+        key[i] = wv_f3_key((e - a) / 2.0 / b);
+    }
+}
+// ranks (0-based, in .NET order) of the two middle elements; hist cleared
+__global__ void k_f3_sel_init(WvF3Sel* __restrict__ S, unsigned long long rank0, unsigned long long rank1) {
+    const int t = threadIdx.x;
+    if (t < 2) { S->prefix[t] = 0ull; S->rank[t] = t == 0 ? rank0 : rank1; }
+    for (int i = t; i < 512; i += blockDim.x) (&S->hist[0][0])[i] = 0u;
+}
+__global__ void __launch_bounds__(256) k_f3_hist(const unsigned long long* __restrict__ key, long long n, int shift, WvF3Sel* __restrict__ S) {
+    __shared__ unsigned int sh[2][256];
+    sh[0][threadIdx.x] = 0u; sh[1][threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned long long p0 = S->prefix[0], p1 = S->prefix[1];
+    const unsigned long long hiMask = shift >= 56 ? 0ull : ~0ull << (shift + 8);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned long long k = key[i];
+        const unsigned d = (unsigned)((k >> shift) & 255ull);
+        if ((k & hiMask) == p0) atomicAdd(&sh[0][d], 1u);
+        if (p1 != p0 && (k & hiMask) == p1) atomicAdd(&sh[1][d], 1u);
+    }
+    __syncthreads();
+    if (sh[0][threadIdx.x]) atomicAdd(&S->hist[0][threadIdx.x], sh[0][threadIdx.x]);
+    if (sh[1][threadIdx.x]) atomicAdd(&S->hist[1][threadIdx.x], sh[1][threadIdx.x]);
+}
+// one workgroup: the digit that holds each rank, the rank inside it; after the last pass the two keys go to `out` (pinned host memory)
+__global__ void __launch_bounds__(64) k_f3_pick(WvF3Sel* __restrict__ S, int shift, unsigned long long* __restrict__ out) {
+    const int w = threadIdx.x;
+    unsigned long long np = 0, nr = 0;
+    if (w < 2) {
+        const unsigned long long p0 = S->prefix[0], p1 = S->prefix[1];
+        const unsigned int* h = S->hist[(w == 1 && p0 != p1) ? 1 : 0];
+        const unsigned long long r = S->rank[w]; unsigned long long cum = 0; int d = 0;
+        for (; d < 255; d++) { if (r < cum + h[d]) break; cum += h[d]; }
+        nr = r - cum; np = (w == 0 ? p0 : p1) | ((unsigned long long)d << shift);
+    }
+    __syncthreads();
+    if (w < 2) { S->prefix[w] = np; S->rank[w] = nr; if (shift == 0) { out[w] = np; __threadfence_system(); } }
+    for (int i = w; i < 512; i += 64) (&S->hist[0][0])[i] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------ coverage variability per window on the device
+// SegmentationInput.reportVariabilityByWindow (Segmentation.cs:334-349): MAD / median of every window of `window` bins, as float.  One workgroup per window: the median is a
+// radix selection over order-preserving keys made on the fly from the coverage (both middle ranks at once for an even window), the MAD a second selection over
+// |x - median|.  The coverage is finite (checked by the caller), so there are no NaN keys; the window's 8 x 2 passes read it from the cache.  (470 windows of 10 000 bins,
+// four order statistics each, took the host's 16 threads 6 ms per WGS sample.)
+__device__ __forceinline__ unsigned long long wv_key_finite(double v) { const unsigned long long b = (unsigned long long)__double_as_longlong(v); return (b >> 63) ? ~b : (b | 0x8000000000000000ull); }
+__device__ __forceinline__ double wv_unkey_finite(unsigned long long k) { return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k)); }
+template <bool DEV>
+__device__ __forceinline__ double wv_window_median(const double* __restrict__ x, int n, double center, unsigned int (*hist)[256], unsigned long long* sel /* [4]: prefix0, prefix1, rank0, rank1 */) {
+    const int t = threadIdx.x;
+    if (t < 2) { sel[t] = 0ull; sel[2 + t] = (unsigned long long)(t == 0 ? ((n & 1) ? n / 2 : n / 2 - 1) : n / 2); }
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int i = t; i < 512; i += blockDim.x) (&hist[0][0])[i] = 0u;
+        __syncthreads();
+        const unsigned long long p0 = sel[0], p1 = sel[1];
+        const unsigned long long hiMask = shift >= 56 ? 0ull : ~0ull << (shift + 8);
+        for (int i = t; i < n; i += blockDim.x) {
+            const double v = DEV ? fabs(x[i] - center) : x[i];
+            const unsigned long long k = wv_key_finite(v);
+            const unsigned d = (unsigned)((k >> shift) & 255ull);
+            if ((k & hiMask) == p0) atomicAdd(&hist[0][d], 1u);
+            if (p1 != p0 && (k & hiMask) == p1) atomicAdd(&hist[1][d], 1u);
+        }
+        __syncthreads();
+        unsigned long long np = 0, nr = 0;
+        if (t < 2) {
+            const unsigned int* h = hist[(t == 1 && p0 != p1) ? 1 : 0];
+            const unsigned long long r = sel[2 + t]; unsigned long long cum = 0; int d = 0;
+            for (; d < 255; d++) { if (r < cum + h[d]) break; cum += h[d]; }
+            nr = r - cum; np = (t == 0 ? p0 : p1) | ((unsigned long long)d << shift);
+        }
+        __syncthreads();
+        if (t < 2) { sel[t] = np; sel[2 + t] = nr; }
+        __syncthreads();
+    }
+    const double lo = wv_unkey_finite(sel[0]), hi = wv_unkey_finite(sel[1]);
+    __syncthreads();
+    return (n & 1) ? hi : (lo + hi) / 2;                        // Utilities.Median (Utilities.cs:428-443)
+}
+__global__ void __launch_bounds__(1024) k_wv_variability(const double* __restrict__ X, const long long* __restrict__ start, int window, float* __restrict__ out) {
+    __shared__ unsigned int hist[2][256];
+    __shared__ unsigned long long sel[4];
+    const double* __restrict__ x = X + start[blockIdx.x];
+    const double median = wv_window_median<false>(x, window, 0.0, hist, sel);
+    const double mad = wv_window_median<true>(x, window, median, hist, sel);      // Utilities.Mad (Utilities.cs:451-462)
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(mad / median);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -749,6 +858,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
                             const uint8_t* h_mask, int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset) {
     using namespace wv;
     if (!ctx) return CANVAS_ERR_INVALID;
+    const double tEntry = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (nchr <= 0 || !d_cov || !h_chr_offset || !h_breakpoints || !h_bp_offset || variability_window <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int32_t rc0 = CANVAS_OK;
@@ -763,13 +873,14 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     // (pinned, kept by the context: a pageable destination is staged by the runtime — 37 MB took 8 ms — and five hipHostMalloc per call were 3 ms)
     const size_t maxLongPin = (size_t)N / WV_LONG + (size_t)nchr + 16;
     const size_t pinBytes = (((size_t)N * sizeof(double) + 255) & ~size_t(255)) + (maxLongPin + 8) * (sizeof(WvNode) + sizeof(WvOut) + 4 * sizeof(int32_t)) + 4096
-                          + (maxLongPin + 8) * (sizeof(WvNode) + 3 * sizeof(int32_t) + sizeof(long long)) + WV_EB * sizeof(int32_t) + 3 * sizeof(WvDev) + 2 * (maxLongPin + 8) * (sizeof(WvDNode) + sizeof(int32_t)) + 16 * 256;      // + the staging of the early exact chains
+                          + (maxLongPin + 8) * (sizeof(WvNode) + 3 * sizeof(int32_t) + sizeof(long long)) + WV_EB * sizeof(int32_t) + 3 * sizeof(WvDev) + 2 * (maxLongPin + 8) * (sizeof(WvDNode) + sizeof(int32_t)) + 17 * 256;      // + the staging of the early exact chains
     if (pinBytes > ctx->wv_pin_bytes) {
         if (ctx->wv_pin) { (void)hipHostFree(ctx->wv_pin); ctx->wv_pin = nullptr; ctx->wv_pin_bytes = 0; }
         CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->wv_pin, pinBytes + pinBytes / 4, hipHostMallocDefault)); ctx->wv_pin_bytes = pinBytes + pinBytes / 4;
     }
     struct XView { double* p; double* data() const { return p; } double operator[](size_t i) const { return p[i]; } } X{(double*)ctx->wv_pin};
     char* pinCursor = (char*)ctx->wv_pin + (((size_t)N * sizeof(double) + 255) & ~size_t(255));
+    unsigned long long* hF3Keys = (unsigned long long*)pinCursor; pinCursor += 256;      // the two middle keys of every exponent (factor-of-three statistics on the device)
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(X.data(), dX, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     {
@@ -811,37 +922,10 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     double cv = 0;
     // the factor-of-three CMADs are needed by the healing step only: they are computed on a host thread while the device decomposes
     std::vector<double> f3;
-    std::thread f3Thread([&]() { f3 = factor_of_three(nchr, X.data(), off.data()); });
+    double f3Seconds = 0;
+    const bool f3OnDevice = nchr <= WV_F3_MAXCHR && !getenv("CANVAS_WV_F3_HOST"), f3Check = getenv("CANVAS_WV_F3_CHECK") != nullptr;
+    std::thread f3Thread([&]() { if (f3OnDevice && !f3Check) return; const double a = now(); f3 = factor_of_three(nchr, X.data(), off.data()); f3Seconds = now() - a; });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } f3Join{f3Thread};      // joined on every exit path
-    const bool hasCV = coverage_variability(variability_window, nchr, X.data(), off.data(), cv);
-
-    const double t1 = now();
-    // ---- roots: chromosomes longer than MinSize (WaveletsRunner.cs:117-126)
-    std::vector<ChromTree> trees(nchr);
-    std::vector<HNode> cur, nxt;
-    std::vector<char> isRoot((size_t)nchr, 0);
-    for (int c = 0; c < nchr; c++) {
-        const int64_t L = off[c + 1] - off[c];
-        if (std::max<int64_t>(L, 1) <= min_size || (h_mask && !h_mask[c])) continue;
-        if (L < 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: a chromosome that passes MinSize needs at least two bins");
-        isRoot[(size_t)c] = 1;
-    }
-    host_parallel_for(nchr, [&](int64_t c) {                  // (order statistics of whole chromosomes: one host thread each)
-        if (!isRoot[(size_t)c]) return;
-        const int64_t L = off[c + 1] - off[c];
-        const double* r = X.data() + off[c];
-        const double median = median_range(r, 0, L);
-        double threshold = mad_factor * (hasCV ? median * cv : mad_range(r, 0, L));       // WaveletSegmentation.cs:394-405
-        if (threshold < threshold_lower) threshold = threshold_lower;
-        if (threshold > threshold_upper) threshold = threshold_upper;
-        trees[c].sigma = threshold;
-        // a coefficient at or below 2 sigma t sqrt(2 ln n) with the smallest possible level weight t is zeroed whatever the level
-        // weights turn out to be: such nodes need not be kept (the margin keeps every borderline node for the exact test)
-        trees[c].keepAbove = 2 * threshold * (is_germline ? 0.8 : 1.0) * std::sqrt(2 * std::log((double)L)) * (1.0 - 1e-9);
-        if (!(trees[c].keepAbove == trees[c].keepAbove)) trees[c].keepAbove = -1.0;   // NaN threshold (a window with median 0): nothing is ever zeroed
-    });
-    for (int c = 0; c < nchr; c++) if (isRoot[(size_t)c]) cur.push_back({c, 1, (int32_t)(off[c + 1] - off[c])});
-    if (trace) { fprintf(stderr, "canvas_wavelets: cv %.17g (%d)", cv, (int)hasCV); for (int c = 0; c < nchr && c < 4; c++) fprintf(stderr, "  chr%d sigma %.17g keep %.17g", c, trees[c].sigma, trees[c].keepAbove); fprintf(stderr, "\n"); }
     // ---- device buffers
     const size_t maxLong = (size_t)N / WV_LONG + (size_t)nchr + 16, maxChunks = 3 * (size_t)N / WV_CS + maxLong + 16, maxRoots = (size_t)N / 2 + (size_t)nchr + 16;
     const unsigned long long capCand = (unsigned long long)N + 16;
@@ -857,6 +941,10 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     sz.take<WvDNode>(maxList2); sz.take<WvDev>(1); sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
     sz.take<WvNode>(maxLong); sz.take<WvOut>(maxLong); sz.take<int32_t>(maxLong); sz.take<int32_t>(maxLong + WV_EB); sz.take<int32_t>(maxLong); sz.take<WvHead>(maxLong); sz.take<WvCk>(maxChunks); sz.take<WvBest>(maxChunks);
     sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
+    const size_t f3Cap = (size_t)N / 3 + 16;
+    const size_t varCap = (size_t)N / (size_t)std::max(1, std::min(variability_window, 10000)) + (size_t)nchr + 16;
+    sz.take<long long>(varCap); sz.take<float>(varCap);
+    sz.take<double>(f3Cap); sz.take<double>(f3Cap); sz.take<unsigned long long>(f3Cap); sz.take<WvF3Sel>(1);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_side_init(ctx); if (rc) return rc;
     WsCarver ws(ctx->ws);
@@ -874,13 +962,121 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     LongBufs E; E.nodes = ws.take<WvNode>(maxLong); E.out = ws.take<WvOut>(maxLong); E.list = ws.take<int32_t>(maxLong); E.base = ws.take<int32_t>(maxLong + WV_EB); E.flag = ws.take<int32_t>(maxLong);
     E.head = ws.take<WvHead>(maxLong); E.ck = ws.take<WvCk>(maxChunks); E.best = ws.take<WvBest>(maxChunks);
     long long* dOpsOffE = ws.take<long long>(maxLong); int32_t* dLimE = ws.take<int32_t>(maxLong);
+    double* dF3Med[2] = {ws.take<double>(f3Cap), nullptr}; dF3Med[1] = ws.take<double>(f3Cap); unsigned long long* dF3Key = ws.take<unsigned long long>(f3Cap); WvF3Sel* dF3Sel = ws.take<WvF3Sel>(1);
+    long long* dVarStart = ws.take<long long>(varCap); float* dVarOut = ws.take<float>(varCap);
+    // what does not depend on the thresholds starts now, next to the host's order statistics: counters cleared, the exact prefix sums of the closed-form decisions
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCounts, 0, (size_t)N * sizeof(int32_t), ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(dNcand, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    const bool tryClosedForm = !getenv("CANVAS_WV_CHAIN_ONLY");
+    if (tryClosedForm) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, off.data(), (nchr + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_wv_prefix, dim3(nchr), dim3(1024), 0, ctx->stream, dX, dOff, dP1, dP2, dBad);
+    }
+    // ---- the factor-of-three statistics (needed by the healing step only): enqueued now on a stream of their own, read at the end
+    int f3Levels = 0; long long f3Count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (f3OnDevice) {
+        const int maxExponent = 8;
+        WvF3Level lv; lv.nchr = nchr;
+        std::vector<long long> len((size_t)nchr);
+        for (int c = 0; c < nchr; c++) len[(size_t)c] = off[c + 1] - off[c];
+        for (int c = 0; c <= nchr; c++) lv.inOff[c] = off[c];                   // exponent 1 reads the coverage itself
+        for (int e = 1; e <= maxExponent; e++) {
+            lv.outOff[0] = 0;
+            for (int c = 0; c < nchr; c++) lv.outOff[c + 1] = lv.outOff[c] + len[(size_t)c] / 3;
+            const long long M = lv.outOff[nchr];
+            if (M < 50) break;                                                   // (Segmentation.cs:415-421: the remaining exponents repeat the last value)
+            if ((size_t)M > f3Cap) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: factor-of-three staging");
+            const double* in = e == 1 ? dX : dF3Med[e & 1]; double* out = dF3Med[(e + 1) & 1];
+            hipLaunchKernelGGL(k_f3_triplets, dim3((unsigned)std::min<long long>(2048, (M + 255) / 256)), dim3(256), 0, ctx->wv_sub2, in, out, dF3Key, lv);
+            hipLaunchKernelGGL(k_f3_sel_init, dim3(1), dim3(256), 0, ctx->wv_sub2, dF3Sel, (unsigned long long)((M & 1) ? M / 2 : M / 2 - 1), (unsigned long long)(M / 2));
+            for (int shift = 56; shift >= 0; shift -= 8) {
+                hipLaunchKernelGGL(k_f3_hist, dim3((unsigned)std::min<long long>(1024, (M + 1023) / 1024)), dim3(256), 0, ctx->wv_sub2, dF3Key, M, shift, dF3Sel);
+                hipLaunchKernelGGL(k_f3_pick, dim3(1), dim3(64), 0, ctx->wv_sub2, dF3Sel, shift, hF3Keys + 2 * (e - 1));
+            }
+            f3Count[e - 1] = M; f3Levels = e;
+            for (int c = 0; c < nchr; c++) { len[(size_t)c] /= 3; lv.inOff[c] = lv.outOff[c]; }
+            lv.inOff[nchr] = lv.outOff[nchr];
+        }
+    }
+    // ---- SegmentationInput.GetCoverageVariability (Segmentation.cs:308-328): the per-window statistics come from the device (CANVAS_WV_VAR_HOST=1: the host threads;
+    // CANVAS_WV_VAR_CHECK=1: both, compared), the order statistics over the few hundred windows stay on the host
+    const bool varOnDevice = !getenv("CANVAS_WV_VAR_HOST"), varCheck = getenv("CANVAS_WV_VAR_CHECK") != nullptr;
+    std::vector<long long> varStart;
+    auto var_enqueue = [&](int window) -> int32_t {          // one workgroup per window, results left in dVarOut
+        varStart.clear();
+        for (int c = 0; c < nchr; c++) { const int64_t L = off[c + 1] - off[c]; for (int64_t i = 0; i < L - window; i += window) varStart.push_back(off[c] + i); }
+        if (varStart.size() > varCap) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: variability staging");
+        if (varStart.empty()) return CANVAS_OK;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVarStart, varStart.data(), varStart.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_wv_variability, dim3((unsigned)varStart.size()), dim3(1024), 0, ctx->stream, dX, dVarStart, window, dVarOut);
+        return CANVAS_OK;
+    };
+    auto var_collect = [&](int window, std::vector<float>& rv) -> int32_t {
+        rv.assign(varStart.size(), 0.0f);
+        if (!rv.empty()) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(rv.data(), dVarOut, rv.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream)); CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+        if (varCheck) {
+            const std::vector<float> hv = variability_by_window(window, nchr, X.data(), off.data());
+            bool same = hv.size() == rv.size();
+            for (size_t i = 0; same && i < hv.size(); i++) same = memcmp(&hv[i], &rv[i], 4) == 0 || (hv[i] != hv[i] && rv[i] != rv[i]);
+            if (!same) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's window variabilities differ from the host's");
+        }
+        return CANVAS_OK;
+    };
+    const bool hasCV = N >= 10 * (int64_t)variability_window;
+    const int firstWindow = variability_window > 10000 ? 10000 : variability_window;
+    if (hasCV && varOnDevice) { rc = var_enqueue(firstWindow); if (rc) return rc; }
+    // ---- roots: chromosomes longer than MinSize (WaveletsRunner.cs:117-126); their medians (order statistics of whole chromosomes: one host thread each) next to the device
+    std::vector<char> isRoot((size_t)nchr, 0);
+    for (int c = 0; c < nchr; c++) {
+        const int64_t L = off[c + 1] - off[c];
+        if (std::max<int64_t>(L, 1) <= min_size || (h_mask && !h_mask[c])) continue;
+        if (L < 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: a chromosome that passes MinSize needs at least two bins");
+        isRoot[(size_t)c] = 1;
+    }
+    std::vector<double> chromMedian((size_t)nchr, 0.0), chromMad((size_t)nchr, 0.0);
+    host_parallel_for(nchr, [&](int64_t c) {
+        if (!isRoot[(size_t)c]) return;
+        const int64_t L = off[c + 1] - off[c];
+        const double* r = X.data() + off[c];
+        chromMedian[(size_t)c] = median_range(r, 0, L);
+        if (!hasCV) chromMad[(size_t)c] = mad_range(r, 0, L);
+    });
+    if (hasCV && !varOnDevice) { const bool got = coverage_variability(variability_window, nchr, X.data(), off.data(), cv); (void)got; }
+    else if (hasCV) {
+        std::vector<float> rv;
+        rc = var_collect(firstWindow, rv); if (rc) return rc;
+        bool done = false;
+        if (variability_window > 10000) { float q1, q2, q3; quartiles(rv, q1, q2, q3); if ((q3 - q1) / q2 > 0.015) { cv = q1; done = true; } }
+        if (!done) {
+            if (variability_window > 10000) { rc = var_enqueue(variability_window); if (rc) return rc; rc = var_collect(variability_window, rv); if (rc) return rc; }
+            dotnet_sort(rv);
+            cv = (double)median_sorted(rv);
+        }
+    }
+
+    const double t1 = now();
+    std::vector<ChromTree> trees(nchr);
+    std::vector<HNode> cur, nxt;
+    for (int c = 0; c < nchr; c++) {
+        if (!isRoot[(size_t)c]) continue;
+        const int64_t L = off[c + 1] - off[c];
+        double threshold = mad_factor * (hasCV ? chromMedian[(size_t)c] * cv : chromMad[(size_t)c]);       // WaveletSegmentation.cs:394-405
+        if (threshold < threshold_lower) threshold = threshold_lower;
+        if (threshold > threshold_upper) threshold = threshold_upper;
+        trees[c].sigma = threshold;
+        // a coefficient at or below 2 sigma t sqrt(2 ln n) with the smallest possible level weight t is zeroed whatever the level
+        // weights turn out to be: such nodes need not be kept (the margin keeps every borderline node for the exact test)
+        trees[c].keepAbove = 2 * threshold * (is_germline ? 0.8 : 1.0) * std::sqrt(2 * std::log((double)L)) * (1.0 - 1e-9);
+        if (!(trees[c].keepAbove == trees[c].keepAbove)) trees[c].keepAbove = -1.0;   // NaN threshold (a window with median 0): nothing is ever zeroed
+    }
+    for (int c = 0; c < nchr; c++) if (isRoot[(size_t)c]) cur.push_back({c, 1, (int32_t)(off[c + 1] - off[c])});
+    if (trace) { fprintf(stderr, "canvas_wavelets: cv %.17g (%d)", cv, (int)hasCV); for (int c = 0; c < nchr && c < 4; c++) fprintf(stderr, "  chr%d sigma %.17g keep %.17g", c, trees[c].sigma, trees[c].keepAbove); fprintf(stderr, "\n"); }
     {
         std::vector<double> keep(nchr);
         for (int c = 0; c < nchr; c++) keep[c] = trees[c].keepAbove;
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dKeep, keep.data(), nchr * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCounts, 0, (size_t)N * sizeof(int32_t), ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dNcand, 0, 2 * sizeof(unsigned long long), ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the side stream starts from initialised buffers
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the other streams start from initialised buffers
     }
     PinVec<WvNode> hNodes; PinVec<WvOut> hOut; PinVec<int32_t> hLong, hBase, hRedo; std::vector<WvRoot> hRoots;
     WvNode* hNodesE = nullptr; int32_t *hLongE = nullptr, *hBaseE = nullptr, *hLimE = nullptr; long long* hOpsOffE = nullptr; WvDev *hdevIn = nullptr, *hdevRep[2] = {nullptr, nullptr}; WvDNode* hExactPin[2] = {nullptr, nullptr}; int32_t* hExactIndPin[2] = {nullptr, nullptr};
@@ -947,10 +1143,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     if (timing) fprintf(stderr, "canvas_wavelets: set-up %.4f s\n", tSetup - t1);
     bool closedForm = false;
     long long nDecided = 0, nUndecided = 0, nExactChains = 0;
-    if (!getenv("CANVAS_WV_CHAIN_ONLY") && !cur.empty()) {
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, off.data(), (nchr + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4 * sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_wv_prefix, dim3(nchr), dim3(1024), 0, ctx->stream, dX, dOff, dP1, dP2, dBad);
+    if (tryClosedForm && !cur.empty()) {
         int bad = 1;
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&bad, dBad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1240,27 +1433,26 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         if (hN[1] & 0xFFFFFFFFull) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: candidate list overflow");
         // node counts per (chromosome, level): a chromosome's slice is as long as the chromosome, but only its first few hundred entries are used — the device finds the
         // highest used level per chromosome and only that much comes back (the whole 4 N bytes took several milliseconds)
-        std::vector<int32_t> hCounts((size_t)N, 0);
+        std::vector<std::vector<int32_t>> hCounts((size_t)nchr);
         {
             int32_t* dTop = (int32_t*)dStack;                    // (the subtree stacks are no longer needed)
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, off.data(), (nchr + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));      // (the chain-only path has not uploaded it)
-            hipLaunchKernelGGL(k_wv_tops, dim3(nchr), dim3(256), 0, ctx->stream, dCounts, dOff, dTop);
+            CANVAS_HIP_TRY(ctx, hipMemsetAsync(dTop, 0xFF, (size_t)nchr * 4, ctx->stream));
+            hipLaunchKernelGGL(k_wv_tops, dim3(32, (unsigned)nchr), dim3(256), 0, ctx->stream, dCounts, dOff, dTop);
             std::vector<int32_t> top((size_t)nchr, -1);
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(top.data(), dTop, (size_t)nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            for (int c = 0; c < nchr; c++) if (top[(size_t)c] >= 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hCounts.data() + off[c], dCounts + off[c], ((size_t)top[(size_t)c] + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+            for (int c = 0; c < nchr; c++) if (top[(size_t)c] >= 0) { hCounts[(size_t)c].resize((size_t)top[(size_t)c] + 1); CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hCounts[(size_t)c].data(), dCounts + off[c], ((size_t)top[(size_t)c] + 1) * 4, hipMemcpyDeviceToHost, ctx->stream)); }
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
         std::vector<WvCand> hc((size_t)hN[0]);
         if (hN[0]) CANVAS_HIP_TRY(ctx, hipMemcpy(hc.data(), dCands, hc.size() * sizeof(WvCand), hipMemcpyDeviceToHost));
         for (int c = 0; c < nchr; c++) {
             ChromTree& T = trees[c];
-            const int32_t* cc = hCounts.data() + off[c];
-            const int64_t L = off[c + 1] - off[c];
-            int64_t top = -1;
-            for (int64_t lv = 0; lv < L; lv++) if (cc[lv]) top = lv;
+            const std::vector<int32_t>& cc = hCounts[(size_t)c];
+            const int64_t top = (int64_t)cc.size() - 1;          // (its last entry is the highest level that has a node)
             if (top >= (int64_t)T.counts.size()) T.counts.resize((size_t)top + 1, 0);
-            for (int64_t lv = 0; lv <= top; lv++) T.counts[(size_t)lv] += cc[lv];
+            for (int64_t lv = 0; lv <= top; lv++) T.counts[(size_t)lv] += cc[(size_t)lv];
             levels = std::max<long long>(levels, (long long)T.counts.size());
         }
         for (const WvCand& k : hc) trees[k.chrom].cands.push_back({k.level, k.s, k.b, k.e, k.coef});
@@ -1274,6 +1466,20 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     // ---- per chromosome: HardThresh, reconstruction, healing, refinement (WaveletSegmentation.cs:73-250, 373-425); the chromosomes are independent (the reference runs
     // them under Parallel.ForEach, WaveletsRunner.cs:115-135): one task per chromosome on a few host threads, results concatenated in chromosome order
     if (f3Thread.joinable()) f3Thread.join();
+    if (f3OnDevice) {
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->wv_sub2));
+        auto dec = [](unsigned long long k) -> double { if (k == 0ull) return std::numeric_limits<double>::quiet_NaN(); const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k; double v; memcpy(&v, &b, 8); return v; };
+        std::vector<double> g{0.0};
+        for (int e = 1; e <= f3Levels; e++) { const double lo = dec(hF3Keys[2 * (e - 1)]), hi = dec(hF3Keys[2 * (e - 1) + 1]); g.push_back((f3Count[e - 1] & 1) ? hi : (lo + hi) / 2); }
+        { const double last = g.back(); while ((int)g.size() < 9) g.push_back(last); }
+        if (f3Check) {
+            bool same = g.size() == f3.size();
+            for (size_t i = 0; same && i < g.size(); i++) same = (g[i] != g[i] && f3[i] != f3[i]) || g[i] == f3[i];
+            if (!same) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's factor-of-three statistics differ from the host's");
+        }
+        f3.swap(g);
+    }
+    if (timing) fprintf(stderr, "canvas_wavelets: waited %.4f s for the factor-of-three statistics (%.4f s on their thread)\n", now() - t2, f3Seconds);
     std::vector<std::vector<int>> bpOf((size_t)nchr);
     auto finishChrom = [&](int c) {
         const ChromTree& T = trees[c];
@@ -1368,6 +1574,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         for (int v : bpOf[(size_t)c]) h_breakpoints[total++] = v;
     }
     h_bp_offset[nchr] = total;
+    if (timing) fprintf(stderr, "canvas_wavelets: %.4f s from the entry to the host copy of the coverage\n", t0 - tEntry);
     if (timing) fprintf(stderr, "canvas_wavelets: variability %.3f s, decomposition %.3f s (%lld levels), thresholds/reconstruction/healing %.3f s\n", t1 - t0, t2 - t1, levels, now() - t2);
     return CANVAS_OK;
 }

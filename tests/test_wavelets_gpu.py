@@ -115,3 +115,18 @@ def test_closed_form_decisions_agree_with_the_chains(monkeypatch):
     exp3 = O.wavelets_genome(per3, window=5000)
     got3 = _run(cv, per3, window=5000)
     assert [g.tolist() for g in got3] == [e.tolist() for e in exp3] and cv.wavelets_decisions()[3] == 0
+
+
+def test_factor_of_three_statistics_on_the_device_equal_the_host_thread(monkeypatch):
+    """SegmentationInput.FactorOfThreeCoverageVariabilities runs on the device (triplet medians + a radix selection of the median ratio per exponent); CANVAS_WV_F3_CHECK=1
+    makes the call compute the host version as well and fail on any difference (NaN ratios — triplets with median 0 — sort in front of every number, as in .NET)."""
+    cv = get_canvas()
+    monkeypatch.setenv("CANVAS_WV_F3_CHECK", "1")
+    monkeypatch.setenv("CANVAS_WV_VAR_CHECK", "1")           # the same for the per-window MAD / median of GetCoverageVariability (one workgroup per window, radix selections)
+    rng = np.random.RandomState(77)
+    zeros = _coverage(rng, 30_000); zeros[5000:21000] = 0.0           # most triplets have median 0: NaN and infinite ratios
+    for per in ([_coverage(rng, 120_000, wave=0.05), _coverage(rng, 7_001), _coverage(rng, 200)], [zeros, _coverage(rng, 9_000)], [_coverage(rng, 160)]):
+        for window in (5000, 12000, 999):                   # 12000: windows of 10 000 first (Segmentation.cs:314-322), of 12 000 if their spread is small
+            exp = O.wavelets_genome(per, window=window)
+            got = _run(cv, per, window=window)
+            assert [g.tolist() for g in got] == [e.tolist() for e in exp]
