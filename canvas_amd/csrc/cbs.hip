@@ -1212,7 +1212,7 @@ static double htmaxp_host(int k, double tss, const double* px, int n, double* sx
     return normalise(h, tss, rn);
 }
 
-struct Stats { std::atomic<long long> unscanned_max{0}; std::atomic<long long> tailp_dev{0}, tailp_host{0}; std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
+struct Stats { std::atomic<long long> unscanned_max{0}; std::atomic<long long> tailp_dev{0}, tailp_host{0}; std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tpermp_device{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
 
 // GPU arc search service shared by the chromosome threads
 struct ArcHostReq { ArcReq r; ArcPReq p; bool pruned = true; const void* hSx; void* hMax; void* hFirst; unsigned long long* hOut; bool done = false; int32_t rc = CANVAS_OK; };
@@ -1294,7 +1294,83 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     return CANVAS_OK;
 }
 
+// TPermP on the device (CANVAS_CBS_DEVICE_TPERMP=1).  The test is ONE chain: nPerm x min(n1, n2) swaps, each at a position drawn from the chromosome's
+// Mersenne Twister (whose state every later permutation of the chromosome continues from) and each reading what the previous ones wrote — nothing in it is independent, so one
+// lane of one wave walks it exactly as the reference does: the segment's copy in LDS when it fits (else in global scratch), the generator's 624 words in LDS, twisted in place.
+// A lane needs ~0.15 us per swap where a host core needs 5 ns: the host chain stays the default, this kernel is the parity-tested drop-in for a host without spare cores.
+#define TPERMP_LDS_MAX 16384
+__global__ void __launch_bounds__(64) k_tpermp(const double* __restrict__ gd, int n1, int n2, uint32_t nPerm, uint32_t* __restrict__ mtState /* 624 words + index, in and out */,
+                                               double* __restrict__ scratch, int32_t* __restrict__ out /* nrej, swaps made (0: the shortcut) */) {
+    __shared__ uint32_t mt[624];
+    __shared__ double spx[TPERMP_LDS_MAX];
+    const int n = n1 + n2;
+    for (int i = threadIdx.x; i < 624; i += 64) mt[i] = mtState[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int mti = (int)mtState[624];
+    double* px = n <= TPERMP_LDS_MAX ? spx : scratch;
+    const double rn1 = (double)n1, rn2 = (double)n2, rn = rn1 + rn2;
+    int nrej = 0; long long swaps = 0;
+    if (n1 == 1 || n2 == 1) nrej = (int)nPerm;
+    else {
+        double xs1 = 0.0, tss = 0.0;
+        for (int i = 0; i < n1; i++) { px[i] = gd[i]; xs1 = xs1 + gd[i]; tss = tss + gd[i] * gd[i]; }
+        double xs2 = 0.0;
+        for (int i = n1; i < n; i++) { px[i] = gd[i]; xs2 = xs2 + gd[i]; tss = tss + gd[i] * gd[i]; }
+        const double xbar = (xs1 + xs2) / rn; tss = tss - rn * (xbar * xbar);
+        int m1; double rm1, ostat, tstat;
+        if (n1 <= n2) { m1 = n1; rm1 = rn1; ostat = 0.99999 * fabs(xs1 / rn1 - xbar); tstat = (ostat * ostat) * rn1 * rn / rn2; }
+        else { m1 = n2; rm1 = rn2; ostat = 0.99999 * fabs(xs2 / rn2 - xbar); tstat = (ostat * ostat) * rn2 * rn / rn1; }
+        tstat = tstat / ((tss - tstat) / (rn - 2.0));
+        if (!(tstat > 25 && m1 >= 10)) {
+            for (uint32_t np = 0; np < nPerm; np++) {
+                xs1 = 0;
+                for (int i = n - 1; i >= n - m1; i--) {
+                    if (mti >= 624) {                            // MT19937 twist (the generator of MersenneTwister.cs, as cbs::MT::u32)
+                        int k; uint32_t y;
+                        for (k = 0; k < 227; k++) { y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu); mt[k] = mt[k + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+                        for (; k < 623; k++) { y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu); mt[k] = mt[k - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+                        y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu); mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                        mti = 0;
+                    }
+                    uint32_t y = mt[mti++];
+                    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+                    const double cc = (double)y * (1.0 / 4294967296.0);
+                    int j = (int)(cc * (double)(i + 1)); j = j > i ? i : j;
+                    const double a = px[i], b = px[j]; px[i] = b; px[j] = a;
+                    xs1 = xs1 + px[i];
+                }
+                if (ostat <= fabs(xs1 / rm1 - xbar)) nrej++;
+            }
+            swaps = (long long)nPerm * m1;
+        }
+    }
+    for (int i = 0; i < 624; i++) mtState[i] = mt[i];
+    mtState[624] = (uint32_t)mti;
+    out[0] = nrej; out[1] = swaps > 0 ? 1 : 0;
+}
+static double tpermp(int n1, int n2, int n, const double* gd, int off, double* px, uint32_t nPerm, MT& rnd, Stats& st);
+static bool tpermp_device(int n1, int n2, int n, const double* gd, int off, uint32_t nPerm, MT& rnd, Stats& st, double& p) {
+    char* d = nullptr;
+    const size_t bytesX = (size_t)n * 8, offState = (bytesX + 255) & ~size_t(255), offScr = offState + 4096, offOut = offScr + ((bytesX + 255) & ~size_t(255));
+    if (hipMalloc((void**)&d, offOut + 256) != hipSuccess) { (void)hipGetLastError(); return false; }
+    uint32_t state[625]; rnd.get_state(state);
+    int32_t out[2] = {0, 0};
+    bool ok = hipMemcpy(d, gd + off, bytesX, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d + offState, state, sizeof state, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_tpermp, dim3(1), dim3(64), 0, 0, (const double*)d, n1, n2, nPerm, (uint32_t*)(d + offState), (double*)(d + offScr), (int32_t*)(d + offOut));
+        ok = hipMemcpy(out, d + offOut, sizeof out, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(state, d + offState, sizeof state, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    if (!ok) { (void)hipGetLastError(); return false; }
+    rnd.set_state(state);
+    if (out[1]) st.tpermp_draws += (long long)nPerm * std::min(n1, n2);
+    st.tpermp_device++;
+    p = (double)out[0] / nPerm;
+    return true;
+}
 static double tpermp(int n1, int n2, int n, const double* gd, int off, double* px, uint32_t nPerm, MT& rnd, Stats& st) {   // CBSTStatistic.cs:947-1024
+    { static const bool onDevice = getenv("CANVAS_CBS_DEVICE_TPERMP") != nullptr; double p; if (onDevice && tpermp_device(n1, n2, n, gd, off, nPerm, rnd, st, p)) return p; }
     double rn1 = (double)n1, rn2 = (double)n2, rn = rn1 + rn2; int nrej;
     if (n1 == 1 || n2 == 1) nrej = (int)nPerm;
     else {
@@ -2051,6 +2127,11 @@ extern "C" int32_t canvas_cbs_device_stats(canvas_ctx* ctx, int64_t* h_out6) {
     return CANVAS_OK;
 }
 
+extern "C" int32_t canvas_cbs_tpermp_stats(canvas_ctx* ctx, int64_t* h_out2) {
+    if (!ctx || !h_out2) return CANVAS_ERR_INVALID;
+    h_out2[0] = ctx->cbs_tpermp[0]; h_out2[1] = ctx->cbs_tpermp[1];
+    return CANVAS_OK;
+}
 extern "C" int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                                    int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
 extern "C" int32_t canvas_cbs(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
@@ -2154,6 +2235,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     for (int t = 0; t < nthreads; t++) th.emplace_back(work);
     for (auto& t : th) t.join();
     for (int c = 0; c < nchr; c++) if (rcs[c]) { if (!errs[c].empty()) ctx->err = errs[c]; return rcs[c]; }
+    ctx->cbs_tpermp[0] = st.tpermp_device; ctx->cbs_tpermp[1] = st.tpermp_draws;
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
     ctx->cbs_tailp[0] = st.tailp_dev; ctx->cbs_tailp[1] = st.tailp_host;
     if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());

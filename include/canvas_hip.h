@@ -262,6 +262,9 @@ int32_t canvas_cbs_undo(canvas_ctx* ctx, int32_t nchr, const double* d_cov, cons
  * were re-evaluated in the reference's exact order because the observed statistic fell inside the rounding interval, [3] batches,
  * [4]/[5] test hook CANVAS_CBS_TEST_VERIFY=1: device intervals checked against the exact statistic / violations. */
 int32_t canvas_cbs_device_stats(canvas_ctx* ctx, int64_t* h_out6);
+/* the edge tests (CBSTStatistic.TPermP, CBSTStatistic.cs:947-1024) of the last canvas_cbs / canvas_cbs_undo call: [0] tests run by the device kernel (one lane walks the
+ * chain of nPerm x min(n1, n2) dependent swaps; CANVAS_CBS_DEVICE_TPERMP=1 — the default is the host chain, which is 30x faster per swap), [1] swaps of all edge tests. */
+int32_t canvas_cbs_tpermp_stats(canvas_ctx* ctx, int64_t* h_out2);
 /* last canvas_cbs / canvas_cbs_undo call: the analytic tail probability of the hybrid test (TailProbability.TailP, TailProbability.cs:21-85) only feeds two decisions of
  * FindChangePoints (ChangePoint.cs:318-323).  [0] calls decided from the device evaluation of its series (accepted only when every value within 1e-8 relative gives the same
  * decisions), [1] calls recomputed with the host libm in the reference's order. */

@@ -160,3 +160,32 @@ def test_spiky_coverage_where_the_reference_search_leaves_arcs_out():
     cov = np.concatenate(parts)
     off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
     _run(cv, cov, off, nperm=2000)
+
+
+def test_edge_tests_on_the_device_equal_the_host_chain():
+    """CBSTStatistic.TPermP (CBSTStatistic.cs:947-1024) as a device kernel (CANVAS_CBS_DEVICE_TPERMP=1): one lane walks the chain of nPerm x min(n1, n2) dependent swaps with the
+    chromosome's Mersenne Twister, whose state the following permutations continue from.  Same segments, same number of draws as the oracle (whose generator is the reference's);
+    segments longer than the kernel's LDS copy (16 384 bins) take its global scratch.  Run in a process of its own: the switch is read once."""
+    import json, os, subprocess, sys
+    code = r"""
+import json, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle_lib as O
+from gpu_common import get_canvas, to_dev
+cv = get_canvas()
+rng = np.random.RandomState(12)
+x = rng.normal(100, 10, 5000); x[2000:2008] += 40; x[3500:3900] += 2.5          # an aberration of 8 bins inside the chromosome: both edge tests walk their chains (fewer than 10 bins on one side)
+y = rng.normal(100, 10, 40000); y[18000:18006] += 45                              # an edge test over more than 16 384 bins
+parts = [np.round(x, 2), np.round(y, 2)]
+cov = np.concatenate(parts); off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+exp, est = O.cbs_genome(parts, 0.01, 1000, threads=2)
+seg_len, nseg, stats = cv.cbs(to_dev(cov, cv.device), off, 0.01, 1000)
+got = seg_len.cpu().numpy()
+same = all(int(nseg[c]) == len(exp[c]) and (got[off[c]:off[c] + nseg[c]] == exp[c]).all() for c in range(2))
+print(json.dumps({"same": bool(same), "stats": [int(v) for v in stats], "est": [int(v) for v in est], "tpermp": [int(v) for v in cv.cbs_tpermp_stats()]}))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, CANVAS_CBS_DEVICE_TPERMP="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["same"] and d["stats"][0] == d["est"][0] and d["stats"][2] == d["est"][2] and d["stats"][4] == d["est"][4], d
+    assert d["tpermp"][0] >= 2 and d["tpermp"][1] == d["est"][4] and d["est"][4] > 0, d
