@@ -69,6 +69,41 @@ int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const vo
     return CANVAS_OK;
 }
 
+// Sub-communicators (BASELINE configs[3]: samples x chromosome groups): the ranks that pass the same color form a communicator of their own, ordered by key, and every
+// sharded call that follows runs inside it — a trio on 8 GPUs is three groups of 3 + 3 + 2 ranks, each sharding its sample's chromosomes.  The parent stays alive and
+// comes back with canvas_comm_restore (the bin-size exchange and the bin intersection of a pedigree span all samples).  RCCL communicators only: a host-callback
+// transport brings its own group with canvas_comm_init_host (canvas_amd/parallel.py: init_host_comm(group=...)).
+int32_t canvas_comm_split(canvas_ctx* ctx, int32_t color, int32_t key) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (!ctx->comm) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_comm_split: no RCCL communicator (canvas_comm_init first; the host transport takes its group from canvas_comm_init_host)");
+    if (ctx->comm_parent) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_comm_split: already inside a sub-communicator (canvas_comm_restore first)");
+    if (color < 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_comm_split: color must not be negative");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ncclComm_t sub = nullptr;
+    CANVAS_NCCL_TRY(ctx, ncclCommSplit((ncclComm_t)ctx->comm, color, key, &sub, nullptr));
+    int r = 0, n = 0;
+    CANVAS_NCCL_TRY(ctx, ncclCommUserRank(sub, &r));
+    CANVAS_NCCL_TRY(ctx, ncclCommCount(sub, &n));
+    ctx->comm_parent = ctx->comm; ctx->rank_parent = ctx->rank; ctx->nranks_parent = ctx->nranks;
+    ctx->comm = (void*)sub; ctx->rank = r; ctx->nranks = n;
+    return CANVAS_OK;
+}
+int32_t canvas_comm_restore(canvas_ctx* ctx) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (!ctx->comm_parent) return CANVAS_OK;
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)ncclCommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = ctx->comm_parent; ctx->rank = ctx->rank_parent; ctx->nranks = ctx->nranks_parent; ctx->comm_parent = nullptr;
+    return CANVAS_OK;
+}
+int32_t canvas_comm_rank(canvas_ctx* ctx, int32_t* h_rank, int32_t* h_nranks) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (h_rank) *h_rank = ctx->rank;
+    if (h_nranks) *h_nranks = ctx->nranks;
+    return CANVAS_OK;
+}
+
 int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank,
                                     int32_t* d_all, int32_t* h_counts) {
     if (!ctx) return CANVAS_ERR_INVALID;

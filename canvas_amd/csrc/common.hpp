@@ -49,6 +49,7 @@ struct canvas_ctx {
     std::shared_ptr<void> hmm_pool;      // hmm.hip: helper threads that fill the negative-binomial emission tables of a sample
     std::shared_ptr<void> clean_batch;   // clean_fast.hpp: the batch that clean_batch_enqueue queued (consumed by clean_batch_finish)
     void* comm = nullptr;  // ncclComm_t
+    void* comm_parent = nullptr; int rank_parent = 0, nranks_parent = 1;      // canvas_comm_split: the communicator the sub-communicator was split from
     int rank = 0, nranks = 1;
     // host-callback transport of the collectives (canvas_comm_init_host): used when the ranks cannot form an RCCL communicator
     int32_t (*host_allgather)(void* user, const void* send, int64_t bytes_per_rank, void* recv) = nullptr;

@@ -31,6 +31,39 @@ def owner_table(lengths, world):
     return owner
 
 
+def sample_groups(world, nsamples, weights=None):
+    """Samples x chromosome groups (BASELINE configs[3]: a trio on 8 GPUs): the ranks are dealt to the samples in contiguous groups whose sizes follow the samples' weights
+    (equal by default), every sample gets at least one rank and no rank stays idle while world >= nsamples.  Returns one (sample, rank in the group, group size) per world
+    rank; with world < nsamples the samples are dealt round-robin instead and every group has one rank (several samples per rank: the caller loops)."""
+    if world <= nsamples:
+        return [(r, 0, 1) for r in range(world)]
+    w = np.ones(nsamples) if weights is None else np.asarray(weights, dtype=np.float64)
+    sizes = np.ones(nsamples, dtype=np.int64)
+    for _ in range(world - nsamples):                       # the next rank goes to the sample with the most work per rank
+        sizes[int(np.argmax(w / sizes))] += 1
+    out = []
+    for s in range(nsamples):
+        out += [(s, k, int(sizes[s])) for k in range(int(sizes[s]))]
+    return out
+
+
+def split_library_comm(cv, color, key):
+    """canvas_comm_split: the RCCL communicator of init_library_comm split by color (ranks of one sample), ordered by key; sharded calls run inside it until restore_library_comm"""
+    cv._check(cv.lib.canvas_comm_split(cv.ctx, int(color), int(key)))
+    r, n = C.c_int32(0), C.c_int32(0)
+    cv._check(cv.lib.canvas_comm_rank(cv.ctx, C.byref(r), C.byref(n)))
+    cv.comm_size = n.value
+    return r.value, n.value
+
+
+def restore_library_comm(cv):
+    cv._check(cv.lib.canvas_comm_restore(cv.ctx))
+    r, n = C.c_int32(0), C.c_int32(0)
+    cv._check(cv.lib.canvas_comm_rank(cv.ctx, C.byref(r), C.byref(n)))
+    cv.comm_size = n.value
+    return r.value, n.value
+
+
 def sample_seed(base_seed, rank):
     """cohort mode: rank r owns sample r"""
     return base_seed + 1000 * rank

@@ -336,6 +336,14 @@ int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const vo
  * `send` of every rank into `recv` (rank order), host memory, and return 0.  The library stages the device buffers through pinned host memory around it. */
 typedef int32_t (*canvas_host_allgather_fn)(void* user, const void* send, int64_t bytes_per_rank, void* recv);
 int32_t canvas_comm_init_host(canvas_ctx* ctx, int32_t rank, int32_t nranks, canvas_host_allgather_fn fn, void* user);
+/* Sub-communicators for samples x chromosome groups (BASELINE configs[3]; the reference runs the samples of a pedigree as independent CanvasBin / CanvasClean tasks,
+ * CanvasRunner.cs:123-128): the ranks that pass the same color form an RCCL communicator of their own (ncclCommSplit), ordered by key, and every sharded call that
+ * follows runs inside it; canvas_comm_restore goes back to the communicator of canvas_comm_init (the bin size of a pedigree and its bin intersection span all samples).
+ * Collective over the parent communicator.  The host-callback transport has no split: its caller hands canvas_comm_init_host the callback of the group.
+ * canvas_comm_rank: rank and size in the communicator the next collective will use. */
+int32_t canvas_comm_split(canvas_ctx* ctx, int32_t color, int32_t key);
+int32_t canvas_comm_restore(canvas_ctx* ctx);
+int32_t canvas_comm_rank(canvas_ctx* ctx, int32_t* h_rank, int32_t* h_nranks);
 /* the single RCCL all-gather of the path: every rank contributes nlocal int32 boundary records (padded to max_per_rank) */
 int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank,
                                     int32_t* d_all, int32_t* h_counts);

@@ -119,3 +119,42 @@ def test_single_process_paths():
     assert nb.tolist() == [10, 4, 3] and off.tolist() == [0, 10, 14, 17] and roff.tolist() == [0, 0, 10] and per.tolist() == [13, 4]
     recs = parallel.boundary_records([2, 5], [[1, 1, 2, 2, 2], [3]])
     assert recs == [2, 0, 1, 1, 2, 2, 4, 2, 5, 0, 0, 3]
+
+
+def _group_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nsamples = 2
+    layout = parallel.sample_groups(world, nsamples, weights=[3, 1])
+    groups = []
+    for s in range(nsamples):                                   # every rank creates every group (torch.distributed's rule), and keeps its own
+        members = [r for r in range(world) if layout[r][0] == s]
+        groups.append(dist.new_group(ranks=members, backend="gloo"))
+    sample, grank, gsize = layout[rank]
+    outs = [torch.zeros(2, dtype=torch.int64) for _ in range(gsize)]
+    dist.all_gather(outs, torch.tensor([rank, sample], dtype=torch.int64), group=groups[sample])      # what the host transport's callback does inside a sample's group
+    # the chromosomes of the sample, sharded inside the group; the world-level exchange (one bin size for the pedigree) still sees every rank
+    shards = parallel.shard_units(synth.GRCH38, gsize)
+    allr = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allr, torch.tensor([len(shards[grank])], dtype=torch.int64))
+    q.put((rank, sample, grank, gsize, [o.tolist() for o in outs], [int(a.item()) for a in allr]))
+    dist.destroy_process_group()
+
+
+def test_samples_times_chromosome_groups_bookkeeping():
+    """BASELINE configs[3] on more ranks than samples: parallel.sample_groups deals the ranks to the samples (3 + 1 for weights 3 : 1), a collective inside a group only sees the
+    group (the sub-communicator: canvas_comm_split for RCCL, the group of init_host_comm for the host transport), a world-level collective sees everybody."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs: p.join(30)
+    assert [(r[1], r[2], r[3]) for r in res] == [(0, 0, 3), (0, 1, 3), (0, 2, 3), (1, 0, 1)]
+    for rank, sample, grank, gsize, outs, allr in res:
+        assert outs == [[r, sample] for r in range(world) if res[r][1] == sample]
+        assert sum(allr[:3]) == 24 and allr[3] == 24            # the three ranks of sample 0 share its 24 chromosomes, the single rank of sample 1 has them all
+    assert parallel.sample_groups(8, 3) == [(0, 0, 3), (0, 1, 3), (0, 2, 3), (1, 0, 3), (1, 1, 3), (1, 2, 3), (2, 0, 2), (2, 1, 2)]
+    assert parallel.sample_groups(2, 3) == [(0, 0, 1), (1, 0, 1)]

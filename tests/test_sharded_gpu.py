@@ -529,3 +529,115 @@ def test_a_failing_sample_fails_the_bin_intersection_on_every_rank():
     for p in procs: p.join(60)
     assert got[0] is not None and "rank 1 failed" in got[0], got
     assert got[1] is not None and "bad arguments" in got[1], got
+
+
+# ---------------------------------------------------------------- samples x chromosome groups (BASELINE configs[3] on more ranks than samples)
+def _inputs_of_sample(device, sample, only=None):
+    """sample 0: the inputs above; sample 1: another seed, its deletion on other chromosomes"""
+    import torch
+    from canvas_amd import synth
+    if sample == 0:
+        return _inputs(device, only)
+    thr = synth.poisson_thresholds(0.21)
+    pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+    bases, hits, masks = [], [], []
+    for c, L in enumerate(LENGTHS):
+        if only is not None and c not in only:
+            bases.append(None); hits.append(None); masks.append(None); continue
+        b, h, m = synth.generate_chromosome(SEED + 77 * sample, c, L, 0.21, thr)
+        if c in (1, 3):
+            a0, a1 = L // 3, 2 * L // 3
+            h = h.copy(); h[a0:a1] = np.where(np.arange(a0, a1) % 2 == 0, h[a0:a1], 0)
+        bases.append(torch.from_numpy(pad(b)).to(device)); hits.append(torch.from_numpy(pad(h)).to(device)); masks.append(torch.from_numpy(m.view(np.int64).copy()).to(device))
+    return bases, hits, masks
+
+
+def _grid_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        layout = parallel.sample_groups(world, 2)
+        groups = [dist.new_group(ranks=[r for r in range(world) if layout[r][0] == s], backend="gloo") for s in range(2)]
+        sample, grank, gsize = layout[rank]
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, grank, gsize, group=groups[sample])       # the sub-communicator of this sample's ranks
+        owner = parallel.owner_table(LENGTHS, gsize)
+        mine = [c for c in range(len(LENGTHS)) if owner[c] == grank]
+        bases, hits, masks = _inputs_of_sample(cv.device, sample, only=mine)
+        out, cov, state, seg = _buffers(cv.device)
+        r = cv.sample_pipeline_sharded(owner, bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
+        cv.synchronize()
+        n = r["n_out"]
+        q.put((rank, sample, (dict(r, off=r["off"].tolist()), {k: v[:n].cpu().numpy() for k, v in out.items()}, cov[:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy())))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_two_samples_times_two_chromosome_groups_on_four_ranks():
+    """Four ranks, two samples: parallel.sample_groups gives every sample a group of two ranks, each group shards ITS sample's chromosomes and runs the sharded pipeline inside
+    its own communicator (host transport: the group's callback; RCCL: canvas_comm_split) at the same time as the other group.  Every rank must hold exactly what one GPU computes
+    for its sample."""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    for g in got:
+        assert g[1] != "error", g[2]
+    assert [g[1] for g in got] == [0, 0, 1, 1]
+    from canvas_amd import Canvas
+    cv = Canvas(0)
+    for sample in (0, 1):
+        bases, hits, masks = _inputs_of_sample(cv.device, sample)
+        out, cov, state, seg = _buffers(cv.device)
+        r1 = cv.sample_pipeline(bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
+        cv.synchronize(); n = r1["n_out"]
+        ref = ({k: v[:n].cpu().numpy() for k, v in out.items()}, cov[:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy())
+        for rank, s, (r, o, cv_, st, sg) in got:
+            if s != sample: continue
+            assert (r["bin_size"], r["total"], r["n_out"], r["nseg"], r["lsd"]) == (r1["bin_size"], r1["total"], r1["n_out"], r1["nseg"], r1["lsd"]), (rank, sample)
+            for key in ("chr", "start", "stop", "gc"):
+                assert (o[key] == ref[0][key]).all(), (rank, key)
+            assert (o["count"].view(np.uint32) == ref[0]["count"].view(np.uint32)).all()
+            assert (cv_ == ref[1]).all() and (st == ref[2]).all() and (sg == ref[3]).all()
+        assert r1["nseg"] > len(LENGTHS)
+    # the two samples differ (the groups did not see each other's data)
+    assert got[0][2][0]["total"] != got[2][2][0]["total"] or not np.array_equal(got[0][2][2], got[2][2][2])
+
+
+def test_rccl_sub_communicator_of_one_rank():
+    """canvas_comm_split / canvas_comm_restore on the RCCL transport (a one-rank communicator split into a one-rank group: the same calls as samples x chromosome groups on a node)"""
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from canvas_amd import Canvas, parallel
+    cv = Canvas(0)
+    buf = (C.c_ubyte * 128)()
+    cv._check(cv.lib.canvas_comm_unique_id(buf))
+    cv._check(cv.lib.canvas_comm_init(cv.ctx, 0, 1, buf))
+    assert parallel.split_library_comm(cv, color=3, key=0) == (0, 1)
+    assert cv.lib.canvas_comm_split(cv.ctx, 0, 0) != 0          # no split inside a split
+    ref = _single(cv)
+    bases, hits, masks = _inputs(cv.device)
+    out, cov, state, seg = _buffers(cv.device)
+    r = cv.sample_pipeline_sharded(np.zeros(len(LENGTHS), np.int32), bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
+    cv.synchronize()
+    n = r["n_out"]
+    assert (r["total"], n, r["nseg"]) == (ref[0]["total"], ref[0]["n_out"], ref[0]["nseg"]) and (seg[:n].cpu().numpy() == ref[4]).all()
+    assert parallel.restore_library_comm(cv) == (0, 1)
+    r = cv.sample_pipeline_sharded(np.zeros(len(LENGTHS), np.int32), bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
+    cv.synchronize()
+    assert r["n_out"] == ref[0]["n_out"]
