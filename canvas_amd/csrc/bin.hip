@@ -736,7 +736,7 @@ static BinPlan make_plan(int nchr, const uint8_t* const* bases, const uint64_t* 
 
 int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
                               int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed);
+                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed, const int16_t* const* d_fraglen);
 
 extern "C" {
 
@@ -845,6 +845,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         // MeanFragmentSize (CanvasBin.cs:164-174): NonZeroMean of the per-chromosome NonZeroMeans, all in Int16 with integer division
         long long s2 = 0, c2 = 0;
         for (int c = 0; c < nchr; c++) { int16_t m = hs[2 * c + 1] ? (int16_t)(hs[2 * c] / hs[2 * c + 1]) : 0; if (m > 0) { s2 += m; c2++; } }
+        if (ctx->gcw_reduce) { unsigned long long v[2] = {(unsigned long long)s2, (unsigned long long)c2}; int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, v, 2); if (rcr) return rcr; s2 = (long long)v[0]; c2 = (long long)v[1]; }      // chromosomes of the other ranks (canvas_bin_sample_sharded)
         const int meanFrag = c2 ? (int)(int16_t)(s2 / c2) : 0;
         if (meanFrag <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "CNV input error - unable to determine fragment size (CanvasBin.cs:431-434)");
         {
@@ -869,6 +870,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hr, hist, (size_t)RG_REP * 202 * 8, hipMemcpyDeviceToHost, ctx->stream));
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             for (int b = 0; b < 202; b++) { hh[b] = 0; for (int r = 0; r < RG_REP; r++) hh[b] += hr[(size_t)r * 202 + b]; }
+            if (ctx->gcw_reduce) { int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, hh, 202); if (rcr) return rcr; }      // the read-GC profile is the whole genome's (CanvasBin.cs:372-391)
         }
         // observed vs expected (CanvasBin.cs:372-391)
         long long sumObserved = 0, sumExpected = 0;
@@ -1400,9 +1402,9 @@ int32_t canvas_upload_packed2_begin(canvas_ctx* ctx, int32_t nchr, const int64_t
 
 int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
                               int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed) {
-    // h_pos0_packed given: d_bases / d_hits are the packed reference / hit planes of these chromosomes (canvas_bin_sample_packed)
-    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, nullptr, 0, -1, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total, hook, user, h_pos0_packed);
+                              int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed, const int16_t* const* d_fraglen) {
+    // h_pos0_packed given: d_bases / d_hits are the packed reference / hit planes of these chromosomes (canvas_bin_sample_packed); d_fraglen: GCContentWeighted
+    return bin_genome_impl(ctx, nchr, d_bases, d_mask, d_hits, d_fraglen, h_len, nullptr, 0, -1, mode, d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, h_nbins_per_chr, h_nbins_total, hook, user, h_pos0_packed);
 }
 
 // ---------------------------------------------------------------------------------------------- predefined bins (CanvasBin -n)

@@ -49,6 +49,7 @@ struct canvas_ctx {
     std::shared_ptr<void> hmm_pool;      // hmm.hip: helper threads that fill the negative-binomial emission tables of a sample
     std::shared_ptr<void> clean_batch;   // clean_fast.hpp: the batch that clean_batch_enqueue queued (consumed by clean_batch_finish)
     void* comm = nullptr;  // ncclComm_t
+    int32_t (*gcw_reduce)(void* user, unsigned long long* v, int n) = nullptr; void* gcw_reduce_user = nullptr;      // element-wise sum over the ranks of a sharded GCContentWeighted binning (fragment means, read-GC profile)
     void* comm_parent = nullptr; int rank_parent = 0, nranks_parent = 1;      // canvas_comm_split: the communicator the sub-communicator was split from
     int rank = 0, nranks = 1;
     // host-callback transport of the collectives (canvas_comm_init_host): used when the ranks cannot form an RCCL communicator
@@ -165,7 +166,7 @@ CVX_INTERNAL int32_t cvx_hmm_per_sample_segments(canvas_ctx* ctx, int32_t nchr, 
 typedef int32_t (*cvx_bin_size_hook)(void* user, int nchr, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut);
 CVX_INTERNAL int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
                                            int32_t mode, cvx_bin_size_hook hook, void* user, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
-                                           int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed = nullptr);
+                                           int64_t* h_nbins_per_chr, int64_t* h_nbins_total, const int64_t* h_pos0_packed = nullptr, const int16_t* const* d_fraglen = nullptr);
 // canvas_hmm_per_sample on a subset of chromosomes (d_cov / h_chr_offset: the subset, contiguous) with the genome-wide quartiles taken from d_cov_all[0, n_all)
 // CanvasPartition -m CBS / -m Wavelets for the chromosomes h_mask selects (NULL: all); genome-wide inputs (seeds in file order, trimmed SD, coverage variability) always use the whole coverage
 CVX_INTERNAL int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm, int32_t undo, double undo_sd,

@@ -113,6 +113,7 @@ struct ShardHook {
     canvas_ctx* ctx; int nchr; const int32_t* owner; const uint8_t* isAuto; int countsPerBin; int binSizeIn; const int* localToGlobal;
     long long* dBuf;                       // device: [1 + nranks][nchr * 3 + 1]
     std::vector<long long> obs, pop, popBefore;      // every chromosome, after the exchange
+    int gcwDone = 0;                       // reductions of the GCContentWeighted pre-pass that have taken place on this rank (2 per call: fragment means, read-GC profile)
     bool exchanged = false;                // the rate exchange has taken place on this rank (a rank that fails before it still has to take part: see canvas_sample_pipeline_sharded)
     int failedRank = -1; long long failedCode = 0;   // a peer announced a failure in its status slot
 };
@@ -131,6 +132,28 @@ int32_t shard_rates_exchange(ShardHook& H, int nl, const long long* obs, const l
     H.obs.assign(H.nchr, 0); H.pop.assign(H.nchr, 0); H.popBefore.assign(H.nchr, 0);
     for (int c = 0; c < H.nchr; c++) { const long long* e = &all[(size_t)H.owner[c] * slice + 3 * c]; H.obs[c] = e[0]; H.pop[c] = e[1]; H.popBefore[c] = e[2]; }
     for (int r = 0; r < W; r++) if (all[(size_t)r * slice + n3] != 0 && H.failedRank < 0) { H.failedRank = r; H.failedCode = all[(size_t)r * slice + n3]; }
+    return CANVAS_OK;
+}
+// element-wise sum of n counters over the ranks (+ the status word, as above): the genome-wide statistics of the GCContentWeighted pre-pass (CanvasBin.cs:164-174, 372-391)
+int32_t shard_reduce(ShardHook& H, unsigned long long* v, int n, int32_t status = 0) {
+    canvas_ctx* ctx = H.ctx;
+    const int W = ctx->nranks, slice = n + 1;
+    std::vector<long long> mine(slice, 0), all((size_t)W * slice, 0);
+    for (int i = 0; i < n; i++) mine[i] = v ? (long long)v[i] : 0;
+    mine[n] = status;
+    H.gcwDone++;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(H.dBuf, mine.data(), (size_t)slice * 8, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = cvx_allgather(ctx, H.dBuf, H.dBuf + slice, (size_t)slice * 8); if (rc) return rc;
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(all.data(), H.dBuf + slice, (size_t)W * slice * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; v && i < n; i++) { unsigned long long t = 0; for (int r = 0; r < W; r++) t += (unsigned long long)all[(size_t)r * slice + i]; v[i] = t; }
+    for (int r = 0; r < W; r++) if (all[(size_t)r * slice + n] != 0 && H.failedRank < 0) { H.failedRank = r; H.failedCode = all[(size_t)r * slice + n]; }
+    return CANVAS_OK;
+}
+int32_t shard_gcw_reduce_hook(void* user, unsigned long long* v, int n) {
+    ShardHook& H = *(ShardHook*)user;
+    int32_t rc = shard_reduce(H, v, n); if (rc) return rc;
+    if (H.failedRank >= 0) CANVAS_FAIL(H.ctx, CANVAS_ERR_COMM, "canvas_bin_sample_sharded: rank " + std::to_string(H.failedRank) + " failed in the GCContentWeighted pre-pass (code " + std::to_string(H.failedCode) + ")");
     return CANVAS_OK;
 }
 int32_t shard_bin_size_hook(void* user, int nl, const long long* obs, const long long* pop, const long long* popBefore, int32_t* binSizeOut) {
@@ -152,12 +175,15 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
                                      int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,
                                      int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
                                      double* d_cov, int32_t* d_state, int32_t* d_segment_id,
-                                     int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
+                                     int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments,
+                                     const int16_t* const* d_fraglen = nullptr, bool binsOnly = false /* canvas_bin_sample_sharded: return with the whole-genome bins */) {
     if (!ctx) return CANVAS_ERR_INVALID;
-    if (nchr <= 0 || !h_chr_owner || !d_bases || !d_mask || !d_hits || !h_len || !h_chr_is_autosome || !d_chr || !d_start || !d_stop || !d_gc || !d_count || !d_cov || !d_state ||
-        !d_segment_id || !h_chr_offset || (bin_size_in <= 0 && counts_per_bin <= 0))
+    if (nchr <= 0 || !h_chr_owner || !d_bases || !d_mask || !d_hits || !h_len || !h_chr_is_autosome || !d_chr || !d_start || !d_stop || !d_gc || !d_count ||
+        (!binsOnly && (!d_cov || !d_state || !d_segment_id || !h_chr_offset)) || (bin_size_in <= 0 && counts_per_bin <= 0))
         CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline_sharded: bad arguments");
-    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_sample_pipeline_sharded: modes 0 and 3");
+    const bool gcw = mode == CANVAS_MODE_GC_CONTENT_WEIGHTED;
+    if (gcw && (!d_fraglen || h_pos0)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_sample_sharded: GCContentWeighted needs the fragment lengths and the per-base arrays");
+    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE && !gcw) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_sample_pipeline_sharded: modes 0, 3 and 5");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int W = ctx->nranks, me = ctx->rank;
     for (int c = 0; c < nchr; c++) if (h_chr_owner[c] < 0 || h_chr_owner[c] >= W || h_len[c] <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline_sharded: owner outside [0, nranks)");
@@ -176,7 +202,7 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
     const size_t oBins = need; need += 5 * al((size_t)capLocal * 4);
     const size_t oSend = need; need += al((size_t)capMax * 16 + 16);
     const size_t oRecv = need; need += al((size_t)W * ((size_t)capMax * 16 + 16));
-    const size_t oRates = need; need += al((size_t)(W + 1) * (nchr * 3 + 1) * 8);
+    const size_t oRates = need; need += al((size_t)(W + 1) * (size_t)std::max(nchr * 3 + 1, 203) * 8);      // (the rate table; the 202 counters of the read-GC profile)
     const size_t oTab = need; need += 6 * al((size_t)(nchr + 2) * 8);
     const size_t oCovL = need; need += al((size_t)capLocal * 8);
     const size_t oStateL = need; need += al((size_t)capLocal * 4);
@@ -222,10 +248,23 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
         for (int i = 0; i < nl; i++) { lb[i] = d_bases[mine[i]]; lm[i] = h_pos0 ? (const uint64_t*)d_bases[mine[i]] : d_mask[mine[i]]; lh[i] = d_hits[mine[i]]; ll[i] = h_len[mine[i]]; if (h_pos0) lp0[i] = h_pos0[mine[i]];
                                        if (!lb[i] || !lm[i] || !lh[i]) haveArrays = false; }
         if (!haveArrays) { ctx->err = "canvas_sample_pipeline_sharded: an owned chromosome has no arrays"; fail_local(CANVAS_ERR_INVALID); }
-        else { rc = cvx_bin_sample_hooked(ctx, nl, lb.data(), lm.data(), lh.data(), ll.data(), mode, shard_bin_size_hook, &H, lChr, lStart, lStop, lGc, lCount, capLocal, perChr.data(), &nbMine, h_pos0 ? lp0.data() : nullptr);
-               if (rc) fail_local(rc); }
-        if (localErr && !H.exchanged) { rc = shard_rates_exchange(H, 0, nullptr, nullptr, nullptr, localErr); if (rc) return rc; }      // failed before the hook ran: the exchange still takes place
+        else {
+            std::vector<const int16_t*> lf(nl, nullptr);
+            if (gcw) for (int i = 0; i < nl; i++) { lf[i] = d_fraglen[mine[i]]; if (!lf[i]) haveArrays = false; }
+            if (!haveArrays) { ctx->err = "canvas_bin_sample_sharded: an owned chromosome has no fragment lengths"; fail_local(CANVAS_ERR_INVALID); }
+            else {
+                if (gcw) { ctx->gcw_reduce = shard_gcw_reduce_hook; ctx->gcw_reduce_user = &H; }
+                rc = cvx_bin_sample_hooked(ctx, nl, lb.data(), lm.data(), lh.data(), ll.data(), mode, shard_bin_size_hook, &H, lChr, lStart, lStop, lGc, lCount, capLocal, perChr.data(), &nbMine, h_pos0 ? lp0.data() : nullptr,
+                                           gcw ? lf.data() : nullptr);
+                ctx->gcw_reduce = nullptr; ctx->gcw_reduce_user = nullptr;
+                if (rc) fail_local(rc);
+            }
+        }
+        // failed before a hook ran: the exchanges it would have made still take place, in their order (two reductions of the GCContentWeighted pre-pass, then the rate table)
+        if (gcw) { static const int nRed[2] = {2, 202}; while (H.gcwDone < 2) { rc = shard_reduce(H, nullptr, nRed[H.gcwDone], localErr ? localErr : CANVAS_ERR_COMM); if (rc) return rc; } }
+        if (localErr && !H.exchanged) { rc = shard_rates_exchange(H, 0, nullptr, nullptr, nullptr, localErr); if (rc) return rc; }
     } else {                                                         // more ranks than chromosomes: this rank only takes part in the exchanges
+        if (gcw) { rc = shard_reduce(H, nullptr, 2); if (rc) return rc; rc = shard_reduce(H, nullptr, 202); if (rc) return rc; }
         rc = shard_rates_exchange(H, 0, nullptr, nullptr, nullptr); if (rc) return rc;
     }
     if (H.failedRank >= 0) return peer_failed(H.failedRank, H.failedCode, "before the rate exchange");
@@ -275,7 +314,7 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (int r = 0; r < W; r++) if (st[(size_t)r] != 0) return peer_failed(r, st[(size_t)r], "before the bin exchange");
     }
-    if (total == 0) { if (h_nbins_clean) *h_nbins_clean = 0; if (h_nsegments) *h_nsegments = 0; for (int c = 0; c <= nchr; c++) h_chr_offset[c] = 0; if (h_local_sd) *h_local_sd = -1.0; return CANVAS_OK; }
+    if (total == 0) { if (h_nbins_clean) *h_nbins_clean = 0; if (h_nsegments) *h_nsegments = 0; if (h_chr_offset) for (int c = 0; c <= nchr; c++) h_chr_offset[c] = 0; if (h_local_sd) *h_local_sd = -1.0; return CANVAS_OK; }
     {
         rc = canvas_h2d_small(ctx, dBinOff, binOff.data(), (size_t)(nchr + 1) * 8); if (rc) fail_local(rc);
         if (!localErr) { rc = canvas_h2d_small(ctx, dOwner, h_chr_owner, (size_t)nchr * 4); if (rc) fail_local(rc); }
@@ -283,6 +322,11 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
     }
     if (!localErr) hipLaunchKernelGGL(k_sh_unshard, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dRecv, (int64_t)(slotB / 4), maxB, dBinOff, dOwner, dRankOff, nchr, total, d_chr, d_start, d_stop, d_gc, d_count);
     mark("bin all-gather + unshard");
+    if (binsOnly) {
+        if (localErr) { ctx->err = localMsg; return localErr; }
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return CANVAS_OK;
+    }
     // ---- 3. CanvasClean on the whole genome (every rank, deterministic), F2 hand-off, chromosome offsets of the cleaned bins
     std::vector<uint8_t> noY((size_t)nchr, 0);
     double lsd = -1.0; int64_t nClean = 0; int32_t info[8];
@@ -382,6 +426,16 @@ extern "C" int32_t canvas_sample_pipeline_sharded_packed(canvas_ctx* ctx, int32_
     return pipeline_sharded_impl(ctx, nchr, h_chr_owner, (const uint8_t* const*)d_ref, d_ref, (const uint8_t* const*)d_hit_planes, h_pos0, h_len, h_chr_is_autosome, h_chr_is_y, counts_per_bin, bin_size_in, mode,
                                  clean_flags, min_bins_per_gc, max_inter_bin_dist, d_chr, d_start, d_stop, d_gc, d_count, cap, d_cov, d_state, d_segment_id, h_bin_size, h_nbins, h_nbins_clean, h_local_sd,
                                  h_chr_offset, h_nsegments);
+}
+
+// CanvasBin alone, chromosomes sharded over the ranks: every rank ends with the bins of the whole genome (modes 0, 3 and 5; mode 5 adds two small reductions — the
+// per-chromosome fragment means and the 202 counters of the read-GC profile, CanvasBin.cs:164-174, 372-391 — in front of the rate table).  BASELINE configs[4]: the tumour's bins.
+extern "C" int32_t canvas_bin_sample_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                                             const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len, const uint8_t* h_chr_is_autosome,
+                                             int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count,
+                                             int64_t cap, int32_t* h_bin_size, int64_t* h_nbins) {
+    return pipeline_sharded_impl(ctx, nchr, h_chr_owner, d_bases, d_mask, d_hits, nullptr, h_len, h_chr_is_autosome, nullptr, counts_per_bin, bin_size_in, mode, 0u, 0, 0,
+                                 d_chr, d_start, d_stop, d_gc, d_count, cap, nullptr, nullptr, nullptr, h_bin_size, h_nbins, nullptr, nullptr, nullptr, nullptr, d_fraglen, true);
 }
 
 extern "C" int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6) {

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(HERE, "libcanvas_hip.so")
 _SYNTH_SO = os.path.join(HERE, "libcanvas_synth.so")
 
-MODE_BINARY, MODE_TDR = 0, 3
+MODE_BINARY, MODE_TDR, MODE_GCW = 0, 3, 5
 CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS, CLEAN_LOCALSD, CLEAN_LOESS = 1, 2, 4, 8, 16
 
 # every symbol include/canvas_hip.h declares (checked by tests/test_abi.py)
@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
     "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_cbs_boundary", "canvas_wavelets", "canvas_wavelets_stats", "canvas_wavelets_decisions", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
-    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_allgather_host", "canvas_merge_cleaned_sharded", "canvas_profile_enable", "canvas_profile_get", "canvas_bin_gcw_stats", "canvas_cbs_tpermp_stats", "canvas_comm_split", "canvas_comm_restore", "canvas_comm_rank",
+    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_allgather_host", "canvas_merge_cleaned_sharded", "canvas_profile_enable", "canvas_profile_get", "canvas_bin_gcw_stats", "canvas_cbs_tpermp_stats", "canvas_comm_split", "canvas_comm_restore", "canvas_comm_rank", "canvas_bin_sample_sharded",
 ]
 
 
@@ -304,6 +304,20 @@ class Canvas:
         self.synchronize()
         return out, per, total.value, bs.value
 
+    def bin_sample_sharded(self, owner, bases, masks, hits, lens, is_autosome, out, counts_per_bin=100, bin_size=-1, mode=MODE_TDR, fraglens=None):
+        """canvas_bin_sample_sharded: CanvasBin with the chromosomes sharded over the ranks (entries of chromosomes this rank does not own may be None); every rank gets the
+        whole genome's bins in `out`.  fraglens: mode 5 (GCContentWeighted).  Returns (bin size, number of bins)."""
+        n = len(bases)
+        lens = np.ascontiguousarray(lens, np.int64); ia = np.ascontiguousarray(is_autosome, np.uint8); ow = np.ascontiguousarray(owner, np.int32)
+        bs = C.c_int32(0); total = C.c_int64(0)
+        tab = lambda ts: (C.c_void_p * n)(*[None if t is None else C.c_void_p(t.data_ptr()) for t in ts])
+        self._check(self.lib.canvas_bin_sample_sharded(self.ctx, n, _np_ptr(ow), tab(bases), tab(masks), tab(hits), tab(fraglens) if fraglens is not None else None,
+                                                       _np_ptr(lens), _np_ptr(ia), counts_per_bin, bin_size, mode, C.c_void_p(out["chr"].data_ptr()), C.c_void_p(out["start"].data_ptr()),
+                                                       C.c_void_p(out["stop"].data_ptr()), C.c_void_p(out["gc"].data_ptr()), C.c_void_p(out["count"].data_ptr()),
+                                                       C.c_int64(out["chr"].numel()), C.byref(bs), C.byref(total)))
+        self.synchronize()
+        return bs.value, total.value
+
     def bin_gcw_stats(self):
         """last bin_sample_gcweighted: (bins whose weighted count was decided from the exact sum + error interval, bins replayed in the reference's order)"""
         v = np.zeros(2, np.int64)
@@ -501,11 +515,13 @@ class Canvas:
         self._check((self.lib.canvas_sample_pipeline_packed if prepared["packed"] else self.lib.canvas_sample_pipeline)(*prepared["args"]))
         return dict(bin_size=bs.value, total=total.value, n_out=nclean.value, lsd=lsd.value, off=off.copy(), nseg=nseg.value, prepared=prepared)
 
-    def tumor_normal_flow(self, bases, masks, hits_t, fraglen_t, hits_n, lens, is_autosome, clean_flags, alpha=0.01, nperm=10000, counts_per_bin=100, is_y=None, keep=False):
+    def tumor_normal_flow(self, bases, masks, hits_t, fraglen_t, hits_n, lens, is_autosome, clean_flags, alpha=0.01, nperm=10000, counts_per_bin=100, is_y=None, keep=False, owner=None):
         """BASELINE configs[4] in memory, the hand-offs of the reference's tumour / normal flow: CanvasBin -m GCContentWeighted on the tumour (bin size from
         the tumour's own rates) and -m TruncatedDynamicRange -z <that size> on the normal (same mask => same bins), CanvasNormalize's LSNorm ratio x 40
         (LSNormRatioCalculator.cs:31-44, CanvasNormalizeUtilities.cs:23-33), its "{count:F2}" file read back with float.Parse (IO.cs:21,40), CanvasClean,
-        the F2 hand-off to CanvasPartition and CBS (alpha, nperm).  Returns a dict; with keep=True every intermediate array is kept for checking."""
+        the F2 hand-off to CanvasPartition and CBS (alpha, nperm).  Returns a dict; with keep=True every intermediate array is kept for checking.
+        owner given (one entry per chromosome): the chromosome-sharded flow over the communicator of the context — this rank holds the arrays of its own chromosomes only (None
+        elsewhere); both binnings are canvas_bin_sample_sharded, the ratio and CanvasClean run on the whole genome on every rank, CBS is canvas_cbs_sharded: same result on every rank."""
         import time
         torch = self.torch
         nchr = len(bases)
@@ -518,9 +534,14 @@ class Canvas:
             now = time.perf_counter(); stage[name] = round(now - t_prev[0], 4); t_prev[0] = now
         T = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
         N = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
-        _, perT, nT, bs = self.bin_sample_gcweighted(bases, masks, hits_t, fraglen_t, lens, is_autosome, counts_per_bin, -1, out=T)
-        tick("bin_tumour_gcweighted")
-        _, perN, nN, _ = self.bin_sample(bases, masks, hits_n, lens, is_autosome, counts_per_bin, bs, MODE_TDR, out=N)
+        if owner is None:
+            _, perT, nT, bs = self.bin_sample_gcweighted(bases, masks, hits_t, fraglen_t, lens, is_autosome, counts_per_bin, -1, out=T)
+            tick("bin_tumour_gcweighted")
+            _, perN, nN, _ = self.bin_sample(bases, masks, hits_n, lens, is_autosome, counts_per_bin, bs, MODE_TDR, out=N)
+        else:
+            bs, nT = self.bin_sample_sharded(owner, bases, masks, hits_t, lens, is_autosome, T, counts_per_bin, -1, MODE_GCW, fraglens=fraglen_t)
+            tick("bin_tumour_gcweighted")
+            _, nN = self.bin_sample_sharded(owner, bases, masks, hits_n, lens, is_autosome, N, counts_per_bin, bs, MODE_TDR)
         tick("bin_normal")
         if nN != nT:
             raise CanvasError(f"tumour and normal bins differ ({nT} vs {nN}): they must share the reference mask")
@@ -539,7 +560,7 @@ class Canvas:
         cov = self.quantize_f2(R["count"], n_out)
         off = self.chromosome_offsets(R["chr"], n_out, nchr)
         tick("f2+offsets")
-        seg_len, nseg, stats = self.cbs(cov, off, alpha, nperm)
+        seg_len, nseg, stats = self.cbs(cov, off, alpha, nperm) if owner is None else self.cbs_sharded(owner, cov, off, alpha, nperm)
         tick("cbs")
         res.update(n_clean=n_out, local_sd=lsd, chr_offset=off, nseg=nseg, cbs_stats=stats, segments=int(nseg.sum()), stage_seconds=stage)
         if keep:

@@ -356,6 +356,15 @@ int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int
  * records [n, (chr, startBin, endBin, state) ...] through canvas_allgather_boundaries.  CanvasClean runs on the gathered whole-genome SoA on every rank (deterministic,
  * redundant).  Every rank returns the same outputs as canvas_sample_pipeline on one GPU, bit for bit: all cleaned bins, coverage, states and the running segment ids
  * in file order (SegmentationResultsProcessor.cs:57-62).  Must be called by all ranks.  Modes 0 and 3. */
+/* CanvasBin alone with the chromosomes sharded over the ranks (BASELINE configs[4]: the tumour's GCContentWeighted bins): canvas_bin_sample / canvas_bin_sample_gcweighted for
+ * a rank that holds the arrays of its own chromosomes only; every rank ends with the bins of the whole genome in file order, bit-identical to the single-GPU call.
+ * d_fraglen: mode 5 only (NULL otherwise).  Mode 5 adds two reductions over the ranks in front of the rate table: the per-chromosome NonZeroMeans of the fragment
+ * lengths (MeanFragmentSize, CanvasBin.cs:164-174) and the 2 x 101 counters of the read-GC profile (CanvasBin.cs:372-391).  Must be called by all ranks; a failure on one
+ * rank is announced in every exchange and fails all of them. */
+int32_t canvas_bin_sample_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
+                                  const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len, const uint8_t* h_chr_is_autosome,
+                                  int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count,
+                                  int64_t cap, int32_t* h_bin_size, int64_t* h_nbins);
 int32_t canvas_sample_pipeline_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
                                        const uint8_t* const* d_hits, const int64_t* h_len, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y,
                                        int32_t counts_per_bin, int32_t bin_size_in, int32_t mode, uint32_t clean_flags, int32_t min_bins_per_gc, int32_t max_inter_bin_dist,

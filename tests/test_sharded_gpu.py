@@ -641,3 +641,182 @@ def test_rccl_sub_communicator_of_one_rank():
     r = cv.sample_pipeline_sharded(np.zeros(len(LENGTHS), np.int32), bases, masks, hits, np.array(LENGTHS, np.int64), IS_AUTO, out, cov, state, seg, counts_per_bin=100, bin_size=-1, mode=3, flags=FLAGS)
     cv.synchronize()
     assert r["n_out"] == ref[0]["n_out"]
+
+
+# ---------------------------------------------------------------- CanvasBin alone, sharded (BASELINE configs[4]: the tumour's GCContentWeighted bins)
+GCW_LENGTHS = [700_000, 410_001, 300_000, 150_016]
+GCW_AUTO = [1, 1, 1, 0]
+
+
+def _gcw_inputs(device, only=None):
+    import torch
+    from canvas_amd import synth
+    thr = synth.poisson_thresholds(0.21)
+    pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+    rng = np.random.RandomState(31)
+    bases, hits, masks, frag = [], [], [], []
+    for c, L in enumerate(GCW_LENGTHS):
+        b, h, m = synth.generate_chromosome(SEED + 9, c, L, 0.21, thr)
+        f = np.where(h > 0, np.clip(rng.normal(350 + 10 * c, 60, L), 1, 5000), 0).astype(np.int16)      # (drawn for every chromosome: the ranks generate the same data)
+        if only is not None and c not in only:
+            bases.append(None); hits.append(None); masks.append(None); frag.append(None); continue
+        bases.append(torch.from_numpy(pad(b)).to(device)); hits.append(torch.from_numpy(pad(h)).to(device)); masks.append(torch.from_numpy(m.view(np.int64).copy()).to(device))
+        frag.append(torch.from_numpy(pad(f)).to(device))
+    return bases, hits, masks, frag
+
+
+def _bins_out(device):
+    import torch
+    cap = sum(GCW_LENGTHS) // 40 + 64
+    return {k: torch.empty(cap, dtype=(torch.float32 if k == "count" else torch.int32), device=device) for k in ("chr", "start", "stop", "gc", "count")}
+
+
+def _bins_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        owner = parallel.owner_table(GCW_LENGTHS, world)
+        mine = [c for c in range(len(GCW_LENGTHS)) if owner[c] == rank]
+        bases, hits, masks, frag = _gcw_inputs(cv.device, only=mine)
+        out = _bins_out(cv.device)
+        res = []
+        for mode, bin_size in ((5, -1), (5, 300), (3, -1)):
+            bs, total = cv.bin_sample_sharded(owner, bases, masks, hits, np.array(GCW_LENGTHS, np.int64), GCW_AUTO, out, counts_per_bin=100, bin_size=bin_size, mode=mode, fraglens=frag if mode == 5 else None)
+            res.append((bs, total, {k: v[:total].cpu().numpy() for k, v in out.items()}))
+        q.put((rank, owner.tolist(), res))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_sharded_binning_incl_gc_content_weighted_equals_the_single_gpu_call():
+    """canvas_bin_sample_sharded on two ranks: the whole genome's bins on every rank, bit-identical to canvas_bin_sample_gcweighted / canvas_bin_sample on one GPU.  Mode 5 needs
+    the genome-wide mean fragment size and read-GC profile: two reductions over the ranks in front of the rate table (a derived bin size and a given one)."""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bins_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    for g in got:
+        assert g[1] != "error", g[2]
+    assert sorted(set(got[0][1])) == [0, 1]
+    from canvas_amd import Canvas
+    cv = Canvas(0)
+    bases, hits, masks, frag = _gcw_inputs(cv.device)
+    lens = np.array(GCW_LENGTHS, np.int64)
+    for k, (mode, bin_size) in enumerate(((5, -1), (5, 300), (3, -1))):
+        out = _bins_out(cv.device)
+        if mode == 5:
+            _, per, total, bs = cv.bin_sample_gcweighted(bases, masks, hits, frag, lens, GCW_AUTO, 100, bin_size, out=out)
+        else:
+            r = cv.bin_sample(bases, masks, hits, lens, GCW_AUTO, 100, bin_size, mode, out=out)
+            total, bs = r[2], r[3]
+        ref = {kk: v[:total].cpu().numpy() for kk, v in out.items()}
+        for rank, _, res in got:
+            gbs, gtotal, o = res[k]
+            assert (gbs, gtotal) == (bs, total), (rank, mode, bin_size, gbs, gtotal, bs, total)
+            for key in ("chr", "start", "stop", "gc"):
+                assert (o[key] == ref[key]).all(), (rank, mode, key)
+            assert (o["count"].view(np.uint32) == ref["count"].view(np.uint32)).all(), (rank, mode)
+        assert total > 1000
+
+
+# ---------------------------------------------------------------- BASELINE configs[4], chromosomes sharded: tumour (mode 5) + normal -> ratio -> Clean -> CBS
+SOM_LENGTHS = [2_500_000, 1_300_001, 1_000_000, 600_000]
+SOM_FLAGS = 1 | 2 | 4
+
+
+def _somatic_inputs(device, only=None):
+    import torch
+    from canvas_amd import synth
+    pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+    seed = 20260927 + 5
+    thr_t = synth.poisson_thresholds(0.28, purity=0.7); thr_n = synth.poisson_thresholds(0.14, flat=True)
+    up = lambda a: torch.from_numpy(pad(a)).to(device)
+    bases, masks, hits_t, fl, hits_n = [], [], [], [], []
+    for c, L in enumerate(SOM_LENGTHS):
+        if only is not None and c not in only:
+            for lst in (bases, masks, hits_t, fl, hits_n): lst.append(None)
+            continue
+        t = synth.generate_chromosome(seed, c, L, 0.28, thr_t, hit_seed=seed + 1000, with_fraglen=True)
+        n = synth.generate_chromosome(seed, c, L, 0.14, thr_n, hit_seed=seed + 2000)
+        bases.append(up(t[0])); masks.append(torch.from_numpy(t[2].view(np.int64).copy()).to(device)); hits_t.append(up(t[1])); fl.append(up(t[3])); hits_n.append(up(n[1]))
+    return bases, masks, hits_t, fl, hits_n
+
+
+def _somatic_summary(r):
+    h = lambda t: t.cpu().numpy()
+    return dict(bin_size=int(r["bin_size"]), n_bins=int(r["n_bins"]), n_ratio=int(r["n_ratio"]), n_clean=int(r["n_clean"]), lsf=float(r["library_size_factor"]), nseg=r["nseg"].tolist(),
+                stats=[int(v) for v in r["cbs_stats"][:5]], cov=h(r["cov"]), seg_len=h(r["seg_len"]), start=h(r["cleaned"]["start"]), count=h(r["cleaned"]["count"]).view(np.uint32),
+                off=np.asarray(r["chr_offset"]).tolist())
+
+
+def _somatic_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        owner = parallel.owner_table(SOM_LENGTHS, world)
+        mine = [c for c in range(len(SOM_LENGTHS)) if owner[c] == rank]
+        bases, masks, hits_t, fl, hits_n = _somatic_inputs(cv.device, only=mine)
+        r = cv.tumor_normal_flow(bases, masks, hits_t, fl, hits_n, np.array(SOM_LENGTHS, np.int64), [1, 1, 1, 0], SOM_FLAGS, alpha=0.01, nperm=2000, keep=True, owner=owner)
+        q.put((rank, owner.tolist(), _somatic_summary(r)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_sharded_tumour_normal_flow_equals_the_single_gpu_flow():
+    """BASELINE configs[4] with the chromosomes of the pair sharded over two ranks (Canvas.tumor_normal_flow(owner=...)): tumour bins -m GCContentWeighted and the normal's bins
+    through canvas_bin_sample_sharded, ratio + CanvasClean on every rank, CBS through canvas_cbs_sharded — every rank ends with the single-GPU flow's bins, coverage, segments and
+    random-number consumption (which tests/test_somatic_flow_gpu.py pins to the chained oracle)."""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_somatic_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    for g in got:
+        assert g[1] != "error", g[2]
+    assert sorted(set(got[0][1])) == [0, 1]
+    from canvas_amd import Canvas
+    cv = Canvas(0)
+    bases, masks, hits_t, fl, hits_n = _somatic_inputs(cv.device)
+    ref = _somatic_summary(cv.tumor_normal_flow(bases, masks, hits_t, fl, hits_n, np.array(SOM_LENGTHS, np.int64), [1, 1, 1, 0], SOM_FLAGS, alpha=0.01, nperm=2000, keep=True))
+    assert ref["n_clean"] > 1000 and sum(ref["nseg"]) >= len(SOM_LENGTHS)
+    for rank, _, s in got:
+        for k in ("bin_size", "n_bins", "n_ratio", "n_clean", "lsf", "nseg", "off"):
+            assert s[k] == ref[k], (rank, k, s[k], ref[k])
+        for k in ("cov", "start", "count"):
+            assert np.array_equal(s[k], ref[k]), (rank, k)
+        n = sum(ref["nseg"])
+        for c in range(len(SOM_LENGTHS)):
+            a = ref["off"][c]
+            assert np.array_equal(s["seg_len"][a:a + ref["nseg"][c]], ref["seg_len"][a:a + ref["nseg"][c]]), (rank, c)
+    # the counters of canvas_cbs_sharded are this rank's chromosomes only: together they are the single-GPU call's (same arc searches, permutations, edge-test draws)
+    for k in (0, 2, 4):
+        assert sum(s["stats"][k] for _, _, s in got) == ref["stats"][k], (k, [s["stats"] for _, _, s in got], ref["stats"])
