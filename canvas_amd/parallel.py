@@ -476,15 +476,73 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             barrier()
     except Exception as e:                                        # noqa: BLE001
         ped = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- BASELINE configs[4], chromosomes sharded: tumour 80x (GCContentWeighted) + normal 40x of the owned chromosomes -> canvas_bin_sample_sharded x 2 -> ratio + CanvasClean on
+    # every rank -> canvas_cbs_sharded.  Strong scaling (one pair, N ranks); rank 0 repeats the flow on its own GPU and compares.  Untimed for `value`.
     leg_done.set()
+    som = {}
+    som_done = threading.Event()
+
+    def som_watchdog():            # this leg is reported, never fatal: if it hangs, the line goes out without it
+        if not som_done.wait(float(os.environ.get("CANVAS_SHARDED_SOMATIC_TIMEOUT", "300"))):
+            if rank == 0:
+                result["pedigree_sharded"] = ped
+                result["partition_sharded"] = part
+                result["somatic_sharded"] = {"error": "did not finish within the watchdog's limit"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+    threading.Thread(target=som_watchdog, daemon=True).start()
+    try:
+        if "error" not in part and "error" not in ped and (world > 1 or os.environ.get("CANVAS_BENCH_FORCE_SHARDED")) and not os.environ.get("CANVAS_SHARDED_NO_SOMATIC"):
+            from .lib import synth_generate_sample_device
+            rt, rn = args.rate * 4.0 / 3.0, args.rate * 2.0 / 3.0
+            thr_tt = torch.from_numpy(synth.poisson_thresholds(rt, purity=0.7).view(np.int32)).to(device)
+            thr_nn = torch.from_numpy(synth.poisson_thresholds(rn, flat=True).view(np.int32)).to(device)
+            def pair(which):
+                ht, fl, hn = [None] * nchr, [None] * nchr, [None] * nchr
+                for c in which:
+                    ht[c], fl[c] = synth_generate_sample_device(seed, seed + 1000, c, int(lengths[c]), thr_tt, device, with_fraglen=True)
+                    hn[c], _ = synth_generate_sample_device(seed, seed + 2000, c, int(lengths[c]), thr_nn, device)
+                return ht, fl, hn
+            mine = [c for c in range(nchr) if owner[c] == rank]
+            ht, fl, hn = pair(mine)
+            bb, mm = bases, masks                                  # the reference of the sharded sample: this rank's chromosomes (None elsewhere)
+            torch.cuda.synchronize()
+            call = lambda: cv.tumor_normal_flow(bb, mm, ht, fl, hn, lens, is_auto, flags, 0.01, 10000, owner=owner, keep=True)
+            call(); barrier()
+            t0 = time.perf_counter(); sr = call(); barrier()
+            ssec = max_over_ranks(time.perf_counter() - t0, device)
+            nc = int(sr["n_clean"])
+            dig = torch.stack([sr["cov"][:nc].sum().to(torch.float64), sr["seg_len"].to(torch.float64).sum(), torch.tensor(float(nc), device=device, dtype=torch.float64),
+                               torch.tensor(float(sr["bin_size"]), device=device, dtype=torch.float64), torch.tensor(float(int(sr["nseg"].sum())), device=device, dtype=torch.float64)])
+            digs = [torch.zeros_like(dig) for _ in range(world)]
+            dist.all_gather(digs, dig)
+            same = bool(all((d == digs[0]).all() for d in digs))
+            eq = None; sec1 = None
+            if rank == 0:
+                ht1, fl1, hn1 = pair(range(nchr))
+                cv.tumor_normal_flow(cb, cm, ht1, fl1, hn1, lens, is_auto, flags, 0.01, 10000)      # (rank 0's cohort sample was generated from `seed`: its bases / masks ARE the reference)
+                t1 = time.perf_counter(); one = cv.tumor_normal_flow(cb, cm, ht1, fl1, hn1, lens, is_auto, flags, 0.01, 10000, keep=True); sec1 = time.perf_counter() - t1
+                eq = bool(one["bin_size"] == sr["bin_size"] and int(one["n_clean"]) == nc and (one["cov"][:nc] == sr["cov"][:nc]).all() and (np.asarray(one["nseg"]) == np.asarray(sr["nseg"])).all()
+                          and (one["seg_len"] == sr["seg_len"]).all())
+                del ht1, fl1, hn1
+            som = {"seconds": round(ssec, 4), "single_gpu_seconds_rank0": None if sec1 is None else round(sec1, 4), "scaling": "strong", "bins": int(sr["n_bins"]), "bins_after_clean": nc,
+                   "segments": int(sr["nseg"].sum()), "stage_seconds_rank0": sr["stage_seconds"] if rank == 0 else None, "identical_on_all_ranks": same, "equals_single_gpu_flow_rank0": eq,
+                   "note": "one tumour / normal pair, chromosomes sharded: tumour bins -m GCContentWeighted (two small reductions + rate table + bin all-gather) and the normal's bins "
+                           "through canvas_bin_sample_sharded, ratio + CanvasClean redundant, canvas_cbs_sharded"}
+            barrier()
+    except Exception as e:                                        # noqa: BLE001
+        som = {"error": "%s: %s" % (type(e).__name__, e)}
+    som_done.set()
     if rank == 0:
         result["pedigree_sharded"] = ped
+        result["somatic_sharded"] = som
         part["note"] = "canvas_cbs_sharded / canvas_wavelets_sharded: every rank segments its own chromosomes (the reference's per-chromosome tasks), one list exchange; genome-wide inputs (seeds in file order, coverage variability) from the whole coverage on every rank"
         result["partition_sharded"] = part
         print(json.dumps(result), flush=True)
     dist.destroy_process_group()
     # a leg that raised, or whose result differs between the ranks / from the single-GPU result, fails the launch (the line above still says what happened)
-    bad = "error" in part or "error" in ped
+    bad = "error" in part or "error" in ped                     # (the somatic leg is reported only)
     for leg in list(part.values()) + [ped]:
         if isinstance(leg, dict) and (leg.get("identical_on_all_ranks") is False or leg.get("equals_single_gpu_result") is False or leg.get("equals_single_gpu_flow_rank0") is False):
             bad = True
