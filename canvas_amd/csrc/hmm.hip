@@ -577,10 +577,10 @@ __global__ void __launch_bounds__(256) k_vit_increments(const HmmChrom* __restri
 // B1b: D_t = D_{t-1} + v_t in the reference's (sequential) association.  One wave per chromosome; the increments of a 64-step
 // chunk sit one per lane and are broadcast through SGPRs (v_readlane), so the dependent chain is ONE FP64 add per step.  Only the
 // running sum at every chunk start is stored (carry[first bin of chunk] = D_{t-1}); k_vit_verify rebuilds D_t inside its blocks.
-__global__ void __launch_bounds__(64) k_vit_backbone(const HmmChrom* __restrict__ chroms, const double* __restrict__ V, double* __restrict__ carryOut) {
+__global__ void __launch_bounds__(64) k_vit_backbone(const HmmChrom* __restrict__ chroms, const double* __restrict__ V, double* __restrict__ carryOut, const int32_t* __restrict__ todo = nullptr) {
     __shared__ double sV[2][64];
     const HmmChrom C = chroms[blockIdx.x];
-    if (C.T <= 10) return;
+    if (C.T <= 10 || (todo && !todo[blockIdx.x])) return;
     const int l = threadIdx.x;
     const double* __restrict__ Vc = V + C.begin;
     double acc = 0.0;
@@ -981,7 +981,7 @@ __device__ __forceinline__ double pick5(uint32_t p, double x0, double x1, double
     return r;
 }
 // ---- C: exact verification.  State of one lane:
-struct VerState { double d[NSTATE]; uint32_t valid; bool bad; double Dprev; int sPrev; };   // valid bit j: d[j] is the exact delta_t(j)
+struct VerState { double d[NSTATE]; uint32_t valid; bool bad; double Dprev; int sPrev; uint32_t why; };   // valid bit j: d[j] is the exact delta_t(j)
 // lead-in step: follow the guessed pointers; a state is exact once its ancestry reaches the backbone (valid == 0 in front of the lead-in:
 // nothing is known there).  `on` == false leaves everything as it is.
 template <bool useLds>
@@ -1019,6 +1019,7 @@ __device__ __forceinline__ void ver_block_step(VerState& S, const HmmParams& P, 
     for (int j = 0; j < NSTATE; j++) dn[j] = S.d[j];
     const uint32_t got = vit_step5(dn, e, P);       // (the two-constant form of the speculative pass was measured here too: no change, 151 us)
     S.bad = S.bad || (on && (S.valid != 31u || got != pk || sel5(dn, (uint32_t)(on ? sCur : 0)) != Dt));
+    S.why |= on ? ((S.valid != 31u ? 2u : 0u) | (got != pk ? 4u : 0u) | (sel5(dn, (uint32_t)(on ? sCur : 0)) != Dt ? 8u : 0u)) : 0u;      // (which check: CANVAS_HMM_DEBUG_FAIL)
 #pragma unroll
     for (int j = 0; j < NSTATE; j++) S.d[j] = on ? dn[j] : S.d[j];
     S.Dprev = on ? Dt : S.Dprev; S.sPrev = on ? sCur : S.sPrev;
@@ -1085,7 +1086,7 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
     VerState S;
 #pragma unroll
     for (int j = 0; j < NSTATE; j++) S.d[j] = 0.0;
-    S.valid = 0; S.bad = false;
+    S.valid = 0; S.bad = false; S.why = 0;
     S.Dprev = carry[C.begin + ts];              // D_{ts-1} (0 at the start of the chromosome)
     S.sPrev = ts > 0 ? state[C.begin + ts - 1] : -1;
     // the transition terms as opaque register values: left as loads from the argument block, the select over the guessed predecessor below
@@ -1105,7 +1106,7 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
             const double Dt = S.Dprev + Vc[0];
             const int sCur = st[0];
             vit_init5(S.d, e, P); S.valid = 31u;
-            if (sel5(S.d, (uint32_t)sCur) != Dt) S.bad = true;
+            if (sel5(S.d, (uint32_t)sCur) != Dt) { S.bad = true; S.why |= 16u; }
             S.Dprev = Dt; S.sPrev = sCur;
         } else ver_lead_step<useLds>(S, A, sTab, logPmf, P.tableLen, true, ix[0], st[0], Vc[0], (uint32_t)pp[0]);
     }
@@ -1113,8 +1114,9 @@ __global__ void __launch_bounds__(64) k_vit_verify(const VitBlock* __restrict__ 
     ver_phase<useLds, true>(S, A, P, sTab, logPmf, ix + 1, st + 1, Vc + 1, pp + 1, nsteps > 0 && lead > 1 ? lead - 1 : 0);
     ver_phase<useLds, false>(S, A, P, sTab, logPmf, ix + start2, st + start2, Vc + start2, pp + start2, nsteps > start2 ? nsteps - start2 : 0);
     double (&d)[NSTATE] = S.d; const uint32_t valid = S.valid; bool bad = S.bad;
-    if (act && tEnd == C.T) { if (valid != 31u || vit_best5(d) != lastGuess[B.chrom]) bad = true; }
-    if (act && bad) atomicOr(&fail[B.chrom], 1);
+    uint32_t why = S.why;
+    if (act && tEnd == C.T) { if (valid != 31u || vit_best5(d) != lastGuess[B.chrom]) { bad = true; why |= 32u; } }
+    if (act && bad) atomicOr(&fail[B.chrom], (int32_t)(1u | why));
 }
 
 // test hook (CANVAS_HMM_TEST_CORRUPT): flips one guessed back-pointer so that tests can prove k_vit_verify catches a wrong guess
@@ -1614,10 +1616,10 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         }
     };
     // one value on the diagonal of the transition matrix and one off it (bit patterns compared): the speculative pass then adds two constants per state instead of five
-    bool twoValued = true;
+    bool twoValuedAll = true;
     for (int i = 0; i < NSTATE; i++) for (int j = 0; j < NSTATE; j++) {
         const double ref = i == j ? P.logA[0][0] : P.logA[0][1];
-        if (memcmp(&P.logA[i][j], &ref, sizeof(double)) != 0) twoValued = false;
+        if (memcmp(&P.logA[i][j], &ref, sizeof(double)) != 0) twoValuedAll = false;
     }
     const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
     std::vector<int32_t> redo;
@@ -1630,11 +1632,17 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         // sample used to fall off that cliff 2-15 times per soak run; the 64x attempt costs about 0.6 ms for the same chromosome).
         const int32_t* dTodo = nullptr;
         ctx->hmm_retry = 0;
-        for (int attempt = 0; attempt < 3; attempt++) {
-            const int mult = attempt == 0 ? 1 : (attempt == 1 ? 8 : 64);
+        // (a fourth attempt with 512x: 65 536 / 32 768 steps reach the start of every chromosome of up to ~65 000 bins, where both passes then start from the exact
+        // initial state — the last fallbacks of the noise-40 soak were such chromosomes, whose off-backbone states did not re-anchor within 4 096 steps; for a chr1-size
+        // chromosome the attempt costs ~7 ms, an eighth of the sequential kernel)
+        for (int attempt = 0; attempt < 4; attempt++) {
+            const int mult = attempt == 0 ? 1 : (attempt == 1 ? 8 : (attempt == 2 ? 64 : 512));
             const int leadSpec = mult * VW, leadVer = mult * VW2;
             if (attempt > 0) CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));      // (attempt 0: cleared by the set-up kernel)
             const dim3 gs((unsigned)((nblocksS + 63) / 64));
+            // (the last two attempts run the recurrence in the reference's own form: the two-constant form of the transition term rounds differently, and a near-tie that it
+            // resolves the other way fails the verification whatever the lead-in — together with a lead-in that reaches the chromosome's start the guess is then exact)
+            const bool twoValued = twoValuedAll && attempt < 2;
             if (lds && twoValued) hipLaunchKernelGGL((k_vit_spec<true, true>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             else if (lds) hipLaunchKernelGGL((k_vit_spec<true, false>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             else if (twoValued) hipLaunchKernelGGL((k_vit_spec<false, true>), gs, dim3(64), 0, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
@@ -1644,7 +1652,9 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             backtrack(true);
             hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
             const char* bbMode = getenv("CANVAS_HMM_BACKBONE");      // "chain" | "scan" | default: predicted pieces
-            if (bbMode && !strcmp(bbMode, "chain")) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry);
+            // (a retry takes the plain chain for its backbone: the predicted pieces below give up on increments they cannot bracket — more binade crossings in a chunk than
+            // they keep, exponents that do not behave — and no longer lead-in changes that; the chain is one FP64 add per step, 1.5 ms for a chr1-size chromosome)
+            if ((bbMode && !strcmp(bbMode, "chain")) || (attempt > 0 && !bbMode)) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry, dTodo);
             else if (bbMode && !strcmp(bbMode, "scan")) hipLaunchKernelGGL(k_vit_backbone_scan, dim3(nchr), dim3(BS_T), 0, ctx->stream, dChroms, dD, dCarry, dFail);
             else {
                 hipLaunchKernelGGL(k_bb_sums, dim3(nchunks), dim3(256), 0, ctx->stream, dBChunks, dChroms, dD, dChunkSum, dFail);
@@ -1665,8 +1675,9 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             redo.clear();
             for (int c = 0; c < nchr; c++) if (hFail[c] && chroms[c].T > 10) redo.push_back(c);
+            if (!redo.empty() && getenv("CANVAS_HMM_DEBUG_FAIL")) { fprintf(stderr, "viterbi attempt %d (lead-in x%d):", attempt, mult); for (int c : redo) fprintf(stderr, " chr%d(T=%lld, why=0x%x)", c, (long long)chroms[c].T, (unsigned)hFail[c]); fprintf(stderr, "\n"); }
             if (redo.empty() || getenv("CANVAS_HMM_TEST_CORRUPT") || getenv("CANVAS_HMM_NO_RETRY")) break;
-            if (attempt < 2) {       // the failed chromosomes become the to-do mask of the next attempt (dRedo doubles as the mask: nchr entries)
+            if (attempt < 3) {       // the failed chromosomes become the to-do mask of the next attempt (dRedo doubles as the mask: nchr entries)
                 if (attempt == 0) { ctx->hmm_retry = (int)redo.size(); { ProfScope pr(ctx, "viterbi_retry"); } }     // counted for the tests / bench
                 int32_t rcq = canvas_h2d_small(ctx, dRedo, hFail, nchr * 4); if (rcq) return rcq;
                 dTodo = dRedo;
@@ -1678,7 +1689,11 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     }
     if (!redo.empty()) {
         // exact sequential evaluation (all chromosomes when speculation is disabled, otherwise only those whose verification failed)
-        ProfScope ps(ctx, "viterbi_sequential");
+        // ("viterbi_sequential" counts FALLBACKS — chromosomes the speculative attempts gave up on; a call without any block to speculate on, every chromosome at most ten bins
+        // long or empty, runs the same kernel for its few steps under another name: 27 of the 27 'fallbacks' of a noise-40 soak were such calls)
+        const bool isFallback = speculative && nblocks > 0;
+        ProfScope ps(ctx, isFallback ? "viterbi_sequential" : "viterbi_small");
+        if (getenv("CANVAS_HMM_DEBUG_FAIL")) { fprintf(stderr, "viterbi sequential kernel for %zu chromosomes (speculative %d, blocks %d):", redo.size(), (int)speculative, nblocks); for (size_t i = 0; i < redo.size() && i < 6; i++) fprintf(stderr, " chr%d(T=%lld)", redo[i], (long long)chroms[redo[i]].T); fprintf(stderr, "\n"); }
         rc = canvas_h2d_small(ctx, dRedo, redo.data(), redo.size() * 4); if (rc) return rc;
         hipLaunchKernelGGL(k_viterbi, dim3((unsigned)redo.size()), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, dLast, dRedo);
         backtrack(false);

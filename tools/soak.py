@@ -15,8 +15,11 @@ t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}; nbatch = 0; ncoun
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 while time.time() - t0 < budget:
     seed = int(rng.randint(1, 2**31 - 1)); n = int(rng.choice([3_000, 30_000, 120_000, 600_000])); nchr = int(rng.choice([1, 3, 24]))
+    if os.environ.get("SOAK_N"): n = int(rng.choice([int(v) for v in os.environ["SOAK_N"].split(",")]))          # (hooks for hunting a rare case: fixed sizes / noise level)
+    if os.environ.get("SOAK_NCHR"): nchr = int(os.environ["SOAK_NCHR"])
     bins = synth.generate_bins(seed, n, nchr=nchr)
     noise = rng.choice([0.0, 10.0, 40.0])
+    if os.environ.get("SOAK_NOISE"): noise = float(os.environ["SOAK_NOISE"])
     if noise: bins["count"] = (bins["count"] + rng.normal(0, noise, len(bins["count"]))).clip(0).astype(np.float32)
     # two thirds of the samples carry two-decimal counts (what CanvasClean reads from a .binned file) at some level: the per-value counters decide their order statistics
     # when the level allows; the rest go through the radix selects
