@@ -76,6 +76,16 @@ namespace CanvasHipInterop
         [DllImport(Lib)] public static extern int canvas_comm_unique_id(byte[] id128);
         [DllImport(Lib)] public static extern int canvas_comm_init(IntPtr ctx, int rank, int nranks, byte[] id128);
         [DllImport(Lib)] public static extern int canvas_allgather_boundaries(IntPtr ctx, IntPtr dLocal, int nLocal, int maxPerRank, IntPtr dAll, int[] counts);
+        // samples x chromosome groups: ranks with the same color form a sub-communicator (ncclCommSplit); restore goes back to the communicator of canvas_comm_init
+        [DllImport(Lib)] public static extern int canvas_comm_split(IntPtr ctx, int color, int key);
+        [DllImport(Lib)] public static extern int canvas_comm_restore(IntPtr ctx);
+        [DllImport(Lib)] public static extern int canvas_comm_rank(IntPtr ctx, out int rank, out int nranks);
+        // CanvasBin alone, chromosomes sharded over the ranks (modes 0, 3, 5; dFraglen: mode 5 only): every rank receives the whole genome's bins
+        [DllImport(Lib)] public static extern int canvas_bin_sample_sharded(IntPtr ctx, int nchr, int[] chrOwner, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, IntPtr[] dFraglen, long[] len, byte[] chrIsAutosome,
+                                                                            int countsPerBin, int binSizeIn, int mode, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, out long nBins);
+        // diagnostics of the last call: mode 5 bins decided by the interval / replayed; edge tests on the device kernel / swaps of all edge tests
+        [DllImport(Lib)] public static extern int canvas_bin_gcw_stats(IntPtr ctx, long[] out2);
+        [DllImport(Lib)] public static extern int canvas_cbs_tpermp_stats(IntPtr ctx, long[] out2);
         // ONE sample, chromosomes sharded over the ranks (chrOwner[c] = rank that holds chromosome c); every rank receives the whole result
         [DllImport(Lib)] public static extern int canvas_sample_pipeline_sharded(IntPtr ctx, int nchr, int[] chrOwner, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, long[] len, byte[] chrIsAutosome, byte[] chrIsY,
             int countsPerBin, int binSizeIn, int mode, uint cleanFlags, int minBinsPerGc, int maxInterBinDist, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap,
