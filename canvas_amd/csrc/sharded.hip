@@ -535,6 +535,60 @@ extern "C" int32_t canvas_cbs_sharded(canvas_ctx* ctx, int32_t nchr, const int32
     return CANVAS_OK;
 }
 
+static int32_t shard_ws_reserve(canvas_ctx* ctx, size_t need);
+// PerSampleHMM with the chromosomes sharded over the ranks, on a coverage every rank holds (e.g. behind the bin intersection of a pedigree: the step that lies between
+// CanvasClean and CanvasPartition there, so canvas_sample_pipeline_sharded cannot serve it).  The emission parameters come from the quartiles of the WHOLE coverage
+// (HiddenMarkovModelsRunner.cs:36-50); a rank runs the Viterbi passes of its own chromosomes (cvx_hmm_per_sample_subset on a compact copy) and one exchange of the state runs
+// [chromosome, 2 k, (first bin, state) x k] gives every rank every chromosome's path.
+extern "C" int32_t canvas_hmm_per_sample_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    const char* what = "canvas_hmm_per_sample_sharded";
+    int32_t rc = check_owner_table(ctx, nchr, h_chr_owner, what); if (rc) return rc;
+    if (!h_chr_offset || !d_cov || !d_state || h_chr_offset[0] != 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample_sharded: bad arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = h_chr_offset[nchr];
+    std::vector<int> mine; std::vector<int64_t> loff{0};
+    for (int c = 0; c < nchr; c++) if (h_chr_owner[c] == ctx->rank) { mine.push_back(c); loff.push_back(loff.back() + (h_chr_offset[c + 1] - h_chr_offset[c])); }
+    const int nl = (int)mine.size(); const int64_t nLocal = loff.back();
+    int32_t localErr = CANVAS_OK; std::string localMsg;
+    std::vector<int32_t> hState((size_t)std::max<int64_t>(nLocal, 1));
+    if (nLocal > 0) {
+        auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+        localErr = shard_ws_reserve(ctx, al((size_t)nLocal * 8) + al((size_t)nLocal * 4) + 256);
+        if (!localErr) {
+            double* dCovL = (double*)ctx->shard_ws; int32_t* dStateL = (int32_t*)((char*)ctx->shard_ws + al((size_t)nLocal * 8));
+            for (int i = 0; i < nl && !localErr; i++) { const int64_t T = loff[(size_t)i + 1] - loff[(size_t)i];
+                if (T > 0 && hipMemcpyAsync(dCovL + loff[(size_t)i], d_cov + h_chr_offset[mine[(size_t)i]], (size_t)T * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = std::string(what) + ": copy of the owned coverage failed"; localErr = CANVAS_ERR_HIP; } }
+            if (!localErr) localErr = cvx_hmm_per_sample_subset(ctx, nl, dCovL, loff.data(), d_cov, N, dStateL, nullptr);
+            if (!localErr && (hipMemcpyAsync(hState.data(), dStateL, (size_t)nLocal * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) { ctx->err = std::string(what) + ": copy of the states failed"; localErr = CANVAS_ERR_HIP; }
+        }
+        if (localErr) localMsg = ctx->err;
+    }
+    std::vector<int32_t> list;
+    if (!localErr) for (int i = 0; i < nl; i++) {
+        const int32_t* st = hState.data() + loff[(size_t)i]; const int64_t T = loff[(size_t)i + 1] - loff[(size_t)i];
+        list.push_back(mine[(size_t)i]); const size_t at = list.size(); list.push_back(0);
+        for (int64_t t = 0; t < T; t++) if (t == 0 || st[t] != st[t - 1]) { list.push_back((int32_t)t); list.push_back(st[t]); }
+        list[at] = (int32_t)(list.size() - at - 1);
+    }
+    std::vector<std::vector<int32_t>> all, perChr;
+    rc = exchange_lists(ctx, list, localErr, localMsg, 2 * N + 2 * (int64_t)nchr + 16, what, all); if (rc) return rc;
+    rc = lists_by_chromosome(ctx, nchr, h_chr_owner, all, what, perChr); if (rc) return rc;
+    std::vector<int32_t> flat((size_t)std::max<int64_t>(N, 1), -1);
+    for (int c = 0; c < nchr; c++) {
+        const int64_t b0 = h_chr_offset[c], T = h_chr_offset[c + 1] - b0; const std::vector<int32_t>& r = perChr[(size_t)c];
+        if ((r.size() & 1) || (T > 0 && (r.empty() || r[0] != 0))) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_hmm_per_sample_sharded: the gathered state runs of a chromosome do not start at its first bin");
+        for (size_t k = 0; k + 1 < r.size(); k += 2) {
+            const int64_t a = r[k], e = k + 2 < r.size() ? r[k + 2] : T;
+            if (a < 0 || e > T || e <= a) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_hmm_per_sample_sharded: the gathered state runs of a chromosome are not increasing");
+            std::fill(flat.begin() + b0 + a, flat.begin() + b0 + e, r[k + 1]);
+        }
+    }
+    if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_state, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANVAS_OK;
+}
+
 extern "C" int32_t canvas_wavelets_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline,
                                            double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
                                            int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset) {

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
     "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_cbs_boundary", "canvas_wavelets", "canvas_wavelets_stats", "canvas_wavelets_decisions", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
-    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_allgather_host", "canvas_merge_cleaned_sharded", "canvas_profile_enable", "canvas_profile_get", "canvas_bin_gcw_stats", "canvas_cbs_tpermp_stats", "canvas_comm_split", "canvas_comm_restore", "canvas_comm_rank", "canvas_bin_sample_sharded",
+    "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_allgather_host", "canvas_merge_cleaned_sharded", "canvas_profile_enable", "canvas_profile_get", "canvas_bin_gcw_stats", "canvas_cbs_tpermp_stats", "canvas_comm_split", "canvas_comm_restore", "canvas_comm_rank", "canvas_bin_sample_sharded", "canvas_hmm_per_sample_sharded",
 ]
 
 
@@ -592,6 +592,14 @@ class Canvas:
                                                             C.c_void_p(cov.data_ptr()), C.c_void_p(state.data_ptr()), C.c_void_p(seg.data_ptr()),
                                                             C.byref(bs), C.byref(total), C.byref(nclean), C.byref(lsd), _np_ptr(off), C.byref(nseg)))
         return dict(bin_size=bs.value, total=total.value, n_out=nclean.value, lsd=lsd.value, off=off, nseg=nseg.value)
+
+    def hmm_per_sample_sharded(self, owner, cov, chr_offset):
+        """canvas_hmm_per_sample_sharded: every rank holds the whole coverage, decodes the chromosomes it owns and receives everybody's state runs (same return as hmm_per_sample)"""
+        torch = self.torch
+        off = np.ascontiguousarray(chr_offset, np.int64); ow = np.ascontiguousarray(owner, np.int32)
+        state = torch.empty(max(int(off[-1]), 1), dtype=torch.int32, device=self.device)
+        self._check(self.lib.canvas_hmm_per_sample_sharded(self.ctx, len(off) - 1, _np_ptr(ow), C.c_void_p(cov.data_ptr()), _np_ptr(off), C.c_void_p(state.data_ptr())))
+        return state[:int(off[-1])]
 
     def cbs_sharded(self, owner, cov, chr_offset, alpha=0.01, nperm=10000, undo=0, undo_sd=3.0):
         """canvas_cbs_sharded: every rank holds the whole coverage, segments the chromosomes it owns and receives everybody's segments (same return as cbs)"""

@@ -227,6 +227,55 @@ def pedigree_sample_flow(cv, bases, masks, hits, lens, is_autosome, flags, count
     return dict(bin_size=bin_size, n_binned=int(total), n_clean=int(n_clean), chr=mc, start=ms, stop=me, count=mv, n=int(k), off=off, cov=cov, state=state)
 
 
+def pedigree_grid_flow(cv, layout, world_rank, enter_world, enter_group, bases, masks, hits, lens, is_autosome, flags, counts_per_bin=100, is_y=None):
+    """Samples x chromosome groups (BASELINE configs[3] on more ranks than samples; layout = sample_groups(world, nsamples)): this rank is rank `g` of the group of sample `s`
+    and holds the arrays of ITS chromosomes of THAT sample (None elsewhere; owner = owner_table(lens, group size)).  The pedigree's couplings span the world communicator —
+    the multi-sample bin size (CanvasBin.cs:86-110: every rank contributes the rates of the chromosomes it owns) and the bin intersection (Utilities.cs:834-920:
+    canvas_merge_cleaned_sharded, where the ranks of a group all hold their sample's cleaned bins: a sample that appears twice does not change an intersection) —, CanvasBin
+    and PerSampleHMM run sharded inside the sample's group (canvas_bin_sample_sharded, canvas_hmm_per_sample_sharded), CanvasClean redundantly on the group's ranks.
+    enter_world() / enter_group() switch the context's communicator (RCCL: restore_library_comm / split_library_comm; host transport: init_host_comm with the group).
+    Returns the dict of pedigree_sample_flow; every rank of a group ends with its sample's result."""
+    import torch
+    sample, grank, gsize = layout[world_rank]
+    world = len(layout)
+    nchr = len(lens)
+    ia = np.ascontiguousarray(is_autosome, np.uint8)
+    owner = owner_table(lens, gsize)
+    mine = [c for c in range(nchr) if owner[c] == grank]
+    # ---- one bin size for the pedigree: the autosomal rates of every sample, each chromosome from the rank that owns it
+    enter_world()
+    rates_mine = np.full(nchr, -2.0, np.float64)                    # -2: not mine
+    if mine:
+        _, _, r = cv.bin_rates([hits[c] for c in mine], [masks[c] for c in mine], [lens[c] for c in mine])
+        for i, c in enumerate(mine):
+            rates_mine[c] = r[i] if ia[c] else -1.0                 # -1: not an autosome
+    allr = cv.allgather_host(rates_mine)
+    rates = []
+    for s in sorted(set(l[0] for l in layout)):                      # sample by sample, chromosomes in file order: the order of the reference's list
+        ranks = [r for r in range(world) if layout[r][0] == s]
+        ow = owner_table(lens, len(ranks))
+        for c in range(nchr):
+            if ia[c]:
+                rates.append(float(allr[ranks[int(ow[c])], c]))
+    bin_size = cv.bin_size_from_rates(rates, counts_per_bin)
+    # ---- CanvasBin of the sample inside its group, CanvasClean on every rank of the group
+    enter_group()
+    cap = int(sum(int(L) for L in lens) // max(1, bin_size)) + nchr + 64
+    mk = lambda dt: torch.empty(cap, dtype=dt, device=cv.device)
+    out = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+    _, total = cv.bin_sample_sharded(owner, bases, masks, hits, lens, is_autosome, out, counts_per_bin, bin_size, 3)
+    n_clean, _, _ = cv.clean(out, total, is_autosome, flags, is_y=is_y)
+    # ---- the bins every sample still has: all ranks
+    enter_world()
+    mc, ms, me, mv, k = cv.merge_cleaned_sharded(out, n_clean)
+    off = cv.chromosome_offsets(mc, k, nchr)
+    cov = cv.quantize_f2(mv, k)
+    # ---- PerSampleHMM inside the group
+    enter_group()
+    state = cv.hmm_per_sample_sharded(owner, cov, off)
+    return dict(bin_size=bin_size, n_binned=int(total), n_clean=int(n_clean), chr=mc, start=ms, stop=me, count=mv, n=int(k), off=off, cov=cov, state=state, sample=sample)
+
+
 # ---- bench.py --gpus N --multi sharded
 def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
     """ONE 60x sample sharded by chromosome over the ranks (strong scaling); afterwards rank 0 runs the same sample on its own GPU and compares every output,

@@ -83,6 +83,8 @@ namespace CanvasHipInterop
         // CanvasBin alone, chromosomes sharded over the ranks (modes 0, 3, 5; dFraglen: mode 5 only): every rank receives the whole genome's bins
         [DllImport(Lib)] public static extern int canvas_bin_sample_sharded(IntPtr ctx, int nchr, int[] chrOwner, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, IntPtr[] dFraglen, long[] len, byte[] chrIsAutosome,
                                                                             int countsPerBin, int binSizeIn, int mode, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, out long nBins);
+        // PerSampleHMM with the chromosomes sharded over the ranks, on a coverage every rank holds (behind the bin intersection of a pedigree)
+        [DllImport(Lib)] public static extern int canvas_hmm_per_sample_sharded(IntPtr ctx, int nchr, int[] chrOwner, IntPtr dCov, long[] chrOffset, IntPtr dState);
         // diagnostics of the last call: mode 5 bins decided by the interval / replayed; edge tests on the device kernel / swaps of all edge tests
         [DllImport(Lib)] public static extern int canvas_bin_gcw_stats(IntPtr ctx, long[] out2);
         [DllImport(Lib)] public static extern int canvas_cbs_tpermp_stats(IntPtr ctx, long[] out2);

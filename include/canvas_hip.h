@@ -391,6 +391,10 @@ int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6);
  * that fails locally still takes part in the exchange and every rank returns an error.  h_stats of canvas_cbs_sharded counts this rank's chromosomes only. */
 int32_t canvas_cbs_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, double alpha, uint32_t nperm,
                            int32_t undo, double undo_sd, int32_t* d_seg_len, int32_t* h_nseg, int64_t* h_stats);
+/* PerSampleHMM with the chromosomes sharded over the ranks, on a coverage EVERY rank holds (d_cov / h_chr_offset: the whole sample, h_chr_offset[0] = 0) — e.g. behind the bin
+ * intersection of a pedigree, which lies between CanvasClean and CanvasPartition (Utilities.cs:834-920).  Emission parameters from the quartiles of the whole coverage
+ * (HiddenMarkovModelsRunner.cs:36-50); a rank decodes its own chromosomes, one exchange of state runs gives every rank d_state[0 .. N): identical to canvas_hmm_per_sample. */
+int32_t canvas_hmm_per_sample_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state);
 int32_t canvas_wavelets_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, int32_t is_germline,
                                 double threshold_lower, double threshold_upper, double mad_factor, int32_t variability_window, int32_t min_size,
                                 int32_t* h_breakpoints, int64_t cap, int64_t* h_bp_offset);

@@ -820,3 +820,82 @@ def test_sharded_tumour_normal_flow_equals_the_single_gpu_flow():
     # the counters of canvas_cbs_sharded are this rank's chromosomes only: together they are the single-GPU call's (same arc searches, permutations, edge-test draws)
     for k in (0, 2, 4):
         assert sum(s["stats"][k] for _, _, s in got) == ref["stats"][k], (k, [s["stats"] for _, _, s in got], ref["stats"])
+
+
+# ---------------------------------------------------------------- the pedigree flow on samples x chromosome groups
+def _trio_grid_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS
+        layout = parallel.sample_groups(world, 3)                 # four ranks: (0,0,2) (0,1,2) (1,0,1) (2,0,1)
+        groups = [dist.new_group(ranks=[r for r in range(world) if layout[r][0] == s], backend="gloo") for s in range(3)]
+        sample, grank, gsize = layout[rank]
+        cv = Canvas(0)
+        enter_world = lambda: parallel.init_host_comm(cv, rank, world)
+        enter_group = lambda: parallel.init_host_comm(cv, grank, gsize, group=groups[sample])
+        owner = parallel.owner_table(TRIO_LENS, gsize)
+        bases, masks, hits = _trio_inputs(sample)
+        pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+        up = lambda lst, f: [f(x) if owner[c] == grank else None for c, x in enumerate(lst)]
+        db = up(bases, lambda b: torch.from_numpy(pad(b)).to(cv.device)); dm = up(masks, lambda m: torch.from_numpy(m.view(np.int64).copy()).to(cv.device))
+        dh = up(hits, lambda h: torch.from_numpy(pad(h)).to(cv.device))
+        r = parallel.pedigree_grid_flow(cv, layout, rank, enter_world, enter_group, db, dm, dh, np.array(TRIO_LENS, np.int64), TRIO_AUTO, CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS)
+        q.put((rank, dict(bin_size=r["bin_size"], n_binned=r["n_binned"], n_clean=r["n_clean"], n=r["n"], off=[int(x) for x in r["off"]], sample=sample),
+               r["chr"].cpu().numpy(), r["start"].cpu().numpy(), r["stop"].cpu().numpy(), r["count"].cpu().numpy(), r["state"][:r["n"]].cpu().numpy()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_a_trio_on_four_ranks_as_samples_times_chromosome_groups():
+    """BASELINE configs[3] on more ranks than samples (parallel.pedigree_grid_flow): the first sample's chromosomes are sharded over two ranks, the other two samples have a rank
+    each; the bin size and the bin intersection span all four ranks, CanvasBin and PerSampleHMM run inside the sample's group (canvas_bin_sample_sharded,
+    canvas_hmm_per_sample_sharded).  Every rank must end with what the single-GPU trio flow gives for its sample."""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trio_grid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    for g in got:
+        assert g[1] != "error", g[2]
+    assert [g[1]["sample"] for g in got] == [0, 0, 1, 2]
+    from canvas_amd import Canvas, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIERS
+    cv = Canvas(0)
+    lens = np.array(TRIO_LENS, np.int64); nchr = len(TRIO_LENS)
+    pad = lambda a: np.concatenate([a, np.zeros((-len(a)) % 64, a.dtype)])
+    rates, dev = [], []
+    for s in range(3):
+        bases, masks, hits = _trio_inputs(s)
+        db = [torch.from_numpy(pad(b)).to(cv.device) for b in bases]; dm = [torch.from_numpy(m.view(np.int64).copy()).to(cv.device) for m in masks]
+        dh = [torch.from_numpy(pad(h)).to(cv.device) for h in hits]
+        _, _, rate = cv.bin_rates(dh, dm, lens)
+        rates += [rate[c] for c in range(nchr) if TRIO_AUTO[c]]
+        dev.append((db, dm, dh))
+    bin_size = cv.bin_size_from_rates(rates, 100)
+    cleaned = []
+    for db, dm, dh in dev:
+        out, per, total = cv.bin_genome(db, dm, dh, lens, bin_size, 3)
+        n_clean, _, _ = cv.clean(out, total, TRIO_AUTO, CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS)
+        cleaned.append((out, n_clean, int(total)))
+    mc, ms, me, mcnt, k = cv.merge_cleaned([o for o, _, _ in cleaned], [n for _, n, _ in cleaned])
+    off = cv.chromosome_offsets(mc, k, nchr)
+    for rank, info, c_, s_, e_, v_, st_ in got:
+        s = info["sample"]
+        assert info["bin_size"] == bin_size and info["n_binned"] == cleaned[s][2] and info["n_clean"] == cleaned[s][1] and info["n"] == k, (rank, info)
+        assert info["off"] == [int(x) for x in off]
+        assert (c_ == mc[:k].cpu().numpy()).all() and (s_ == ms[:k].cpu().numpy()).all() and (e_ == me[:k].cpu().numpy()).all(), rank
+        assert (v_.view(np.uint32) == mcnt[s][:k].cpu().numpy().view(np.uint32)).all(), rank
+        cov = cv.quantize_f2(mcnt[s], k)
+        assert (st_ == cv.hmm_per_sample(cov, off)[:k].cpu().numpy()).all(), rank
