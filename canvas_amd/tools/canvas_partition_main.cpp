@@ -121,7 +121,19 @@ int main(int argc, char** argv) {
     if (!bed.empty()) load_bed(bed, excluded);
 
     Phases ph("CanvasPartition");
-    AsyncCtx actx;                                              // the context comes up while the files are read
+    // the context comes up while the files are read; for -m CBS the helper thread also runs the method once on a toy sample (three chromosomes of 4 000 bins with a step)
+    auto warmCbs = [cbsAlpha, undo](canvas_ctx* c) {
+        const int nchr = 3; const int64_t per = 4000, N = nchr * per;
+        std::vector<double> cov((size_t)N); std::vector<int64_t> off{0, per, 2 * per, 3 * per};
+        uint32_t x = 12345u;
+        for (int64_t i = 0; i < N; i++) { x = x * 1664525u + 1013904223u; cov[(size_t)i] = 100.0 + (double)((x >> 16) % 21) - 10.0 + ((i % per) > per / 2 && (i % per) < per / 2 + 300 ? 4.0 : 0.0); }
+        void* dCov = canvas_device_malloc(c, N * 8); void* dLen = canvas_device_malloc(c, (N + 1) * 4);
+        std::vector<int32_t> nseg(nchr); int64_t stats[8];
+        if (dCov && dLen && canvas_memcpy_h2d(c, dCov, cov.data(), N * 8) == 0) (void)canvas_cbs_undo(c, nchr, (const double*)dCov, off.data(), cbsAlpha, 10000, undo, 3.0, (int32_t*)dLen, nseg.data(), stats);
+        if (dCov) canvas_device_free(c, dCov);
+        if (dLen) canvas_device_free(c, dLen);
+    };
+    AsyncCtx actx(method == "CBS" ? std::function<void(canvas_ctx*)>(warmCbs) : nullptr);
     // CanvasSegment.ReadBedInput (CanvasCommon/CanvasSegment.cs:1117-1163)
     std::vector<Sample> samples(inFiles.size());
     for (size_t s = 0; s < inFiles.size(); s++) {

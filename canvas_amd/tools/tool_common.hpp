@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <thread>
@@ -171,7 +172,9 @@ struct Phases {
 // take 0.15-0.3 s on a cold process; no file of a tool depends on it).  get() joins.
 struct AsyncCtx {
     std::thread th; canvas_ctx* ctx = nullptr;
-    AsyncCtx() { th = std::thread([this] { ctx = canvas_create(0); }); }
+    // warm (optional): run on the helper thread behind canvas_create — e.g. a CBS call on a toy sample, so that the code objects are loaded and the launcher threads, streams
+    // and engine buffers of the method exist by the time the real coverage has been read (a cold process paid 0.45 s in the device phase of -m CBS for 0.1 s of work)
+    explicit AsyncCtx(std::function<void(canvas_ctx*)> warm = nullptr) { th = std::thread([this, warm] { ctx = canvas_create(0); if (ctx && warm && !getenv("CANVAS_TOOL_NO_WARMUP")) warm(ctx); }); }
     canvas_ctx* get() { if (th.joinable()) th.join(); return ctx; }
     ~AsyncCtx() { if (th.joinable()) th.join(); }
 };
