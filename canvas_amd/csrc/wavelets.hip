@@ -1534,10 +1534,12 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         // GetBreakpointsAfterHealingBadSplits
         std::vector<int> bp{prelim[0]};
         const int Lp = (int)prelim.size();
+        int cachedStart = -1; double cachedMedian = 0;             // the median of [cachedStart, prelim[i]): the right segment of the previous step is the left one of this step when its breakpoint was kept
         for (int i = 1; i < Lp; ++i) {
             const int leftStart = bp.back(), rightStart = prelim[i], rightEnd = (i < Lp - 1) ? prelim[i + 1] : (int)L;
             const int leftLength = rightStart - leftStart, rightLength = rightEnd - rightStart;
-            const double leftMedian = median_range(r, leftStart, leftStart + leftLength), rightMedian = median_range(r, rightStart, rightStart + rightLength);
+            const double leftMedian = leftStart == cachedStart ? cachedMedian : median_range(r, leftStart, leftStart + leftLength), rightMedian = median_range(r, rightStart, rightStart + rightLength);
+            cachedStart = rightStart; cachedMedian = rightMedian;
             const double weightedMedian = (leftLength * leftMedian + rightLength * rightMedian) / (rightEnd - leftStart);
             const int smaller = std::min(leftLength, rightLength);
             const int scale = std::min((int)f3.size() - 1, (int)std::ceil(std::log((double)smaller) / std::log(3.0)));
