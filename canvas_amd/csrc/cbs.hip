@@ -1223,16 +1223,28 @@ struct ArcGpu {       // one per chromosome thread: own buffers; the launches go
     double* dSx = nullptr; double* dMax = nullptr; int32_t* dFirst = nullptr; int cap = 0;
     char* dPr = nullptr;          // pruned search: block minima / maxima, pair list, per-pair maxima, result words
     char* pin = nullptr; size_t pinBytes = 0;
+    char* pinEx = nullptr; int capEx = 0;      // the exhaustive search's per-length maxima (device + pinned): only flat data or the test hook ever need them
+    // (a cold process creates some fifty engines — chromosome threads and helpers — and paid for 20 pinned bytes and three device arrays per bin of each: 0.3 s of the
+    // CanvasPartition -m CBS executable; the pruned search needs the prefix sums and a few result words)
     int32_t ensure(int n) {
         if (n <= cap) return CANVAS_OK;
-        if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipFree(dPr); (void)hipHostFree(pin); }
+        if (dSx) { (void)hipFree(dSx); (void)hipFree(dPr); (void)hipHostFree(pin); }
         cap = n + n / 4 + 1024;
         { const size_t nb = (size_t)cap / AP_BK + 2; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dPr, nb * 24 + AP_PAIRCAP * 12 + 4096)); }
-        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dMax, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dFirst, (size_t)cap * 4));
-        pinBytes = (size_t)cap * 20 + 256; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
+        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, (size_t)cap * 8));
+        pinBytes = (size_t)cap * 8 + 256; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
         return CANVAS_OK;
     }
-    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx) { (void)hipFree(dSx); (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipFree(dPr); (void)hipHostFree(pin); } }
+    int32_t ensure_exhaustive() {
+        if (capEx >= cap) return CANVAS_OK;
+        if (dMax) { (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pinEx); dMax = nullptr; dFirst = nullptr; pinEx = nullptr; }
+        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dMax, (size_t)cap * 8)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dFirst, (size_t)cap * 4));
+        CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pinEx, (size_t)cap * 12 + 256, hipHostMallocDefault));
+        capEx = cap;
+        return CANVAS_OK;
+    }
+    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx) { (void)hipFree(dSx); (void)hipFree(dPr); (void)hipHostFree(pin); }
+                if (dMax) { (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pinEx); } }
 };
 
 // TMaxO with the O(n^2) search on the GPU.  Returns false when the caller must fall back to the host replay (ambiguous maximum).
@@ -1247,7 +1259,7 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     canvas_ctx* ctx = G.ctx;
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int32_t rc = G.ensure(n); if (rc) return rc;
-    double* hSx = (double*)G.pin; double* hMax = hSx + G.cap; int32_t* hFirst = (int32_t*)(hMax + G.cap); unsigned long long* hOut = (unsigned long long*)(G.pin + (size_t)G.cap * 20);
+    double* hSx = (double*)G.pin; double* hMax = nullptr; int32_t* hFirst = nullptr; unsigned long long* hOut = (unsigned long long*)(G.pin + (size_t)G.cap * 8);
     memcpy(hSx, sx, (size_t)n * 8);
     const size_t nbk = (size_t)G.cap / AP_BK + 2;
     ArcHostReq q; q.hSx = hSx; q.hMax = hMax; q.hFirst = hFirst; q.hOut = hOut;
@@ -1272,6 +1284,9 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
         }
         q.pruned = false;     // too many candidate block pairs (flat data): exhaustive search
     }
+    rc = G.ensure_exhaustive(); if (rc) return rc;
+    hMax = (double*)G.pinEx; hFirst = (int32_t*)(hMax + G.cap);
+    q.hMax = hMax; q.hFirst = hFirst; q.r.dmax = G.dMax; q.r.firstI = G.dFirst;
     rc = service_submit_arc(G.svc, q); if (rc) return rc;
     const double* dmax = hMax; const int32_t* firstI = hFirst;
     if (!getenv("CANVAS_CBS_EXHAUSTIVE_ARCS")) st.gpu_searches--;
