@@ -644,6 +644,17 @@ __global__ void __launch_bounds__(1024) k_wv_variability(const double* __restric
     if (threadIdx.x == 0) out[blockIdx.x] = (float)(mad / median);
 }
 
+// median of every root chromosome (the threshold of a chromosome is mad_factor x median x coverage variability, WaveletSegmentation.cs:394-405): one workgroup per chromosome,
+// the same radix selection (the host's nth_element over 380 000 doubles kept the level loop waiting for 3 ms)
+__global__ void __launch_bounds__(1024) k_wv_chrom_median(const double* __restrict__ X, const long long* __restrict__ off, const uint8_t* __restrict__ isRoot, double* __restrict__ out) {
+    __shared__ unsigned int hist[2][256];
+    __shared__ unsigned long long sel[4];
+    if (!isRoot[blockIdx.x]) { if (threadIdx.x == 0) out[blockIdx.x] = 0.0; return; }
+    const long long lo = off[blockIdx.x], n = off[blockIdx.x + 1] - lo;
+    const double m = wv_window_median<false>(X + lo, (int)n, 0.0, hist, sel);
+    if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 namespace wv {
 // SortedList<T>.Median() / List<T>.Sort(): NaN sorts in front of every number
@@ -943,7 +954,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
     const size_t f3Cap = (size_t)N / 3 + 16;
     const size_t varCap = (size_t)N / (size_t)std::max(1, std::min(variability_window, 10000)) + (size_t)nchr + 16;
-    sz.take<long long>(varCap); sz.take<float>(varCap);
+    sz.take<long long>(varCap); sz.take<float>(varCap); sz.take<double>(nchr + 1); sz.take<uint8_t>(nchr + 1);
     sz.take<double>(f3Cap); sz.take<double>(f3Cap); sz.take<unsigned long long>(f3Cap); sz.take<WvF3Sel>(1);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_side_init(ctx); if (rc) return rc;
@@ -963,7 +974,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     E.head = ws.take<WvHead>(maxLong); E.ck = ws.take<WvCk>(maxChunks); E.best = ws.take<WvBest>(maxChunks);
     long long* dOpsOffE = ws.take<long long>(maxLong); int32_t* dLimE = ws.take<int32_t>(maxLong);
     double* dF3Med[2] = {ws.take<double>(f3Cap), nullptr}; dF3Med[1] = ws.take<double>(f3Cap); unsigned long long* dF3Key = ws.take<unsigned long long>(f3Cap); WvF3Sel* dF3Sel = ws.take<WvF3Sel>(1);
-    long long* dVarStart = ws.take<long long>(varCap); float* dVarOut = ws.take<float>(varCap);
+    long long* dVarStart = ws.take<long long>(varCap); float* dVarOut = ws.take<float>(varCap); double* dChromMed = ws.take<double>(nchr + 1); uint8_t* dIsRoot = ws.take<uint8_t>(nchr + 1);
     // what does not depend on the thresholds starts now, next to the host's order statistics: counters cleared, the exact prefix sums of the closed-form decisions
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCounts, 0, (size_t)N * sizeof(int32_t), ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dNcand, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -1035,13 +1046,26 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         isRoot[(size_t)c] = 1;
     }
     std::vector<double> chromMedian((size_t)nchr, 0.0), chromMad((size_t)nchr, 0.0);
-    host_parallel_for(nchr, [&](int64_t c) {
-        if (!isRoot[(size_t)c]) return;
-        const int64_t L = off[c + 1] - off[c];
-        const double* r = X.data() + off[c];
-        chromMedian[(size_t)c] = median_range(r, 0, L);
-        if (!hasCV) chromMad[(size_t)c] = mad_range(r, 0, L);
-    });
+    const bool medOnDevice = hasCV && varOnDevice && tryClosedForm && !getenv("CANVAS_WV_MEDIAN_HOST");      // (tryClosedForm: dOff is on the device)
+    if (medOnDevice) {
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dIsRoot, isRoot.data(), (size_t)nchr, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_wv_chrom_median, dim3((unsigned)nchr), dim3(1024), 0, ctx->stream, dX, dOff, dIsRoot, dChromMed);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(chromMedian.data(), dChromMed, (size_t)nchr * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));      // (waited for with the window statistics below)
+    }
+    if (!medOnDevice || varCheck) {
+        std::vector<double> hostMedian((size_t)nchr, 0.0);
+        host_parallel_for(nchr, [&](int64_t c) {
+            if (!isRoot[(size_t)c]) return;
+            const int64_t L = off[c + 1] - off[c];
+            const double* r = X.data() + off[c];
+            hostMedian[(size_t)c] = median_range(r, 0, L);
+            if (!hasCV) chromMad[(size_t)c] = mad_range(r, 0, L);
+        });
+        if (medOnDevice) {       // CANVAS_WV_VAR_CHECK: both, compared
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (int c = 0; c < nchr; c++) if (isRoot[(size_t)c] && memcmp(&hostMedian[(size_t)c], &chromMedian[(size_t)c], 8) != 0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's chromosome medians differ from the host's");
+        } else chromMedian.swap(hostMedian);
+    }
     if (hasCV && !varOnDevice) { const bool got = coverage_variability(variability_window, nchr, X.data(), off.data(), cv); (void)got; }
     else if (hasCV) {
         std::vector<float> rv;
@@ -1279,7 +1303,8 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dDev, hdevIn, sizeof hdev, hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(k_wv_list_init, dim3((unsigned)((nIn + 255) / 256)), dim3(256), 0, ctx->stream, dListIn, nIn, dListA, dChA, dDev, (unsigned)maxLong, (unsigned)maxCh);
             hipEvent_t ev[2] = {ctx->side_ev, ctx->side_ev2};
-            int lbOf[2] = {0, 0}, lbNext = 16; unsigned seqOf[2] = {0, 0};
+            static const int firstBatch = [] { const char* e = getenv("CANVAS_WV_FIRST_BATCH"); const int v = e ? atoi(e) : 16; return v >= 2 && v <= 64 && !(v & 1) ? v : 16; }();
+            int lbOf[2] = {0, 0}, lbNext = firstBatch; unsigned seqOf[2] = {0, 0};       // (16, 32, 64 ... levels.  Smaller first batches start the longest chain earlier but split the chains over several launches of ONE in-order stream, which then run one after the other: 2, 4, 8 ... was 9 ms slower)
             auto enqueue_batch = [&](int slot) -> int32_t {
                 const int lb = lbNext; lbOf[slot] = lb; lbNext = std::min(64, lbNext * 2);
                 for (int it = 0; it < lb; it++)
