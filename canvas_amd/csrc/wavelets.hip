@@ -655,6 +655,15 @@ __global__ void __launch_bounds__(1024) k_wv_chrom_median(const double* __restri
     if (threadIdx.x == 0) out[blockIdx.x] = m;
 }
 
+// medians of the stretches between preliminary breakpoints (GetBreakpointsAfterHealingBadSplits compares the medians left and right of every breakpoint): seg = start << 32 | length
+__global__ void __launch_bounds__(1024) k_wv_segment_median(const double* __restrict__ X, const unsigned long long* __restrict__ seg, double* __restrict__ out) {
+    __shared__ unsigned int hist[2][256];
+    __shared__ unsigned long long sel[4];
+    const unsigned long long s = seg[blockIdx.x];
+    const double m = wv_window_median<false>(X + (long long)(s >> 32), (int)(s & 0xFFFFFFFFull), 0.0, hist, sel);
+    if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 namespace wv {
 // SortedList<T>.Median() / List<T>.Sort(): NaN sorts in front of every number
@@ -954,7 +963,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
     const size_t f3Cap = (size_t)N / 3 + 16;
     const size_t varCap = (size_t)N / (size_t)std::max(1, std::min(variability_window, 10000)) + (size_t)nchr + 16;
-    sz.take<long long>(varCap); sz.take<float>(varCap); sz.take<double>(nchr + 1); sz.take<uint8_t>(nchr + 1);
+    sz.take<long long>(varCap); sz.take<float>(varCap); sz.take<double>(nchr + 1); sz.take<uint8_t>(nchr + 1); sz.take<double>(varCap);
     sz.take<double>(f3Cap); sz.take<double>(f3Cap); sz.take<unsigned long long>(f3Cap); sz.take<WvF3Sel>(1);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_side_init(ctx); if (rc) return rc;
@@ -974,7 +983,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     E.head = ws.take<WvHead>(maxLong); E.ck = ws.take<WvCk>(maxChunks); E.best = ws.take<WvBest>(maxChunks);
     long long* dOpsOffE = ws.take<long long>(maxLong); int32_t* dLimE = ws.take<int32_t>(maxLong);
     double* dF3Med[2] = {ws.take<double>(f3Cap), nullptr}; dF3Med[1] = ws.take<double>(f3Cap); unsigned long long* dF3Key = ws.take<unsigned long long>(f3Cap); WvF3Sel* dF3Sel = ws.take<WvF3Sel>(1);
-    long long* dVarStart = ws.take<long long>(varCap); float* dVarOut = ws.take<float>(varCap); double* dChromMed = ws.take<double>(nchr + 1); uint8_t* dIsRoot = ws.take<uint8_t>(nchr + 1);
+    long long* dVarStart = ws.take<long long>(varCap); float* dVarOut = ws.take<float>(varCap); double* dChromMed = ws.take<double>(nchr + 1); uint8_t* dIsRoot = ws.take<uint8_t>(nchr + 1); double* dSegMed = ws.take<double>(varCap);
     // what does not depend on the thresholds starts now, next to the host's order statistics: counters cleared, the exact prefix sums of the closed-form decisions
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCounts, 0, (size_t)N * sizeof(int32_t), ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dNcand, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -1505,12 +1514,47 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         f3.swap(g);
     }
     if (timing) fprintf(stderr, "canvas_wavelets: waited %.4f s for the factor-of-three statistics (%.4f s on their thread)\n", now() - t2, f3Seconds);
-    std::vector<std::vector<int>> bpOf((size_t)nchr);
-    auto finishChrom = [&](int c) {
+    std::vector<std::vector<int>> bpOf((size_t)nchr), prelimOf((size_t)nchr);
+    std::vector<int64_t> segBase((size_t)nchr + 1, 0); std::vector<double> segMed; bool segOnDevice = false;      // medians of [prelim[i], prelim[i + 1]) per chromosome, from the device
+    auto finishChrom = [&](int c, int phase) {               // phase 0: thresholds, reconstruction, preliminary breakpoints; phase 1: healing, refinement
         const ChromTree& T = trees[c];
         const int64_t L = off[c + 1] - off[c];
         if (T.counts.empty()) return;                         // not segmented: no breakpoints (WaveletsRunner.cs:113-131)
         const double* r = X.data() + off[c];
+        if (phase == 1) {
+            const std::vector<int>& prelim = prelimOf[(size_t)c];
+            // GetBreakpointsAfterHealingBadSplits
+            std::vector<int> bp{prelim[0]};
+            const int Lp = (int)prelim.size();
+            int cachedStart = -1; double cachedMedian = 0;         // the median of [cachedStart, prelim[i]): the right segment of the previous step is the left one of this step when its breakpoint was kept
+            for (int i = 1; i < Lp; ++i) {
+                const int leftStart = bp.back(), rightStart = prelim[i], rightEnd = (i < Lp - 1) ? prelim[i + 1] : (int)L;
+                const int leftLength = rightStart - leftStart, rightLength = rightEnd - rightStart;
+                const double* sm = segOnDevice ? segMed.data() + segBase[(size_t)c] : nullptr;
+                const double leftMedian = leftStart == cachedStart ? cachedMedian : (sm && leftStart == prelim[i - 1] ? sm[i - 1] : median_range(r, leftStart, leftStart + leftLength));
+                const double rightMedian = sm ? sm[i] : median_range(r, rightStart, rightStart + rightLength);
+                cachedStart = rightStart; cachedMedian = rightMedian;
+                const double weightedMedian = (leftLength * leftMedian + rightLength * rightMedian) / (rightEnd - leftStart);
+                const int smaller = std::min(leftLength, rightLength);
+                const int scale = std::min((int)f3.size() - 1, (int)std::ceil(std::log((double)smaller) / std::log(3.0)));
+                if (std::fabs(leftMedian - rightMedian) > f3[scale] * 4 * std::max(weightedMedian, 50.0)) bp.push_back(prelim[i]);
+            }
+            if (is_germline) {                                    // RefineSegments
+                const double totalMedian = median_range(r, 0, L);
+                for (int i = 1; i < (int)bp.size() - 1; i++) {
+                    const int li = std::min(5, (bp[i] - bp[i - 1]) / 2), ri = std::min(5, (bp[i + 1] - bp[i]) / 2);
+                    double best = std::fabs(median_range(r, bp[i - 1], bp[i]) - totalMedian);
+                    int bestBp = bp[i];
+                    for (int j = bp[i] - li; j < bp[i] + ri; j++) {
+                        const double t = std::fabs(median_range(r, bp[i - 1], j) - totalMedian);
+                        if (t > best) { best = t; bestBp = j; }
+                    }
+                    bp[i] = bestBp;
+                }
+            }
+            bpOf[(size_t)c] = std::move(bp);
+            return;
+        }
         const int treeSize = (int)T.counts.size();
         std::vector<double> thresholds((size_t)treeSize, 1.0);
         std::vector<int> indices((size_t)treeSize);
@@ -1556,44 +1600,43 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
                 for (int64_t i = 1; i < L; i++) if (rec[i] - rec[i - 1] != 0) prelim.push_back((int)i);
             }
         }
-        // GetBreakpointsAfterHealingBadSplits
-        std::vector<int> bp{prelim[0]};
-        const int Lp = (int)prelim.size();
-        int cachedStart = -1; double cachedMedian = 0;             // the median of [cachedStart, prelim[i]): the right segment of the previous step is the left one of this step when its breakpoint was kept
-        for (int i = 1; i < Lp; ++i) {
-            const int leftStart = bp.back(), rightStart = prelim[i], rightEnd = (i < Lp - 1) ? prelim[i + 1] : (int)L;
-            const int leftLength = rightStart - leftStart, rightLength = rightEnd - rightStart;
-            const double leftMedian = leftStart == cachedStart ? cachedMedian : median_range(r, leftStart, leftStart + leftLength), rightMedian = median_range(r, rightStart, rightStart + rightLength);
-            cachedStart = rightStart; cachedMedian = rightMedian;
-            const double weightedMedian = (leftLength * leftMedian + rightLength * rightMedian) / (rightEnd - leftStart);
-            const int smaller = std::min(leftLength, rightLength);
-            const int scale = std::min((int)f3.size() - 1, (int)std::ceil(std::log((double)smaller) / std::log(3.0)));
-            if (std::fabs(leftMedian - rightMedian) > f3[scale] * 4 * std::max(weightedMedian, 50.0)) bp.push_back(prelim[i]);
-        }
-        if (is_germline) {                                    // RefineSegments
-            const double totalMedian = median_range(r, 0, L);
-            for (int i = 1; i < (int)bp.size() - 1; i++) {
-                const int li = std::min(5, (bp[i] - bp[i - 1]) / 2), ri = std::min(5, (bp[i + 1] - bp[i]) / 2);
-                double best = std::fabs(median_range(r, bp[i - 1], bp[i]) - totalMedian);
-                int bestBp = bp[i];
-                for (int j = bp[i] - li; j < bp[i] + ri; j++) {
-                    const double t = std::fabs(median_range(r, bp[i - 1], j) - totalMedian);
-                    if (t > best) { best = t; bestBp = j; }
-                }
-                bp[i] = bestBp;
-            }
-        }
-        bpOf[(size_t)c] = std::move(bp);
+        prelimOf[(size_t)c] = std::move(prelim);
     };
-    {
+    auto run_phase = [&](int phase) {
         std::atomic<int> next{0};
         const int nth = (int)std::max(1u, std::min(16u, std::min((unsigned)nchr, std::thread::hardware_concurrency())));
-        auto worker = [&]() { for (int c = next.fetch_add(1); c < nchr; c = next.fetch_add(1)) finishChrom(c); };
+        auto worker = [&]() { for (int c = next.fetch_add(1); c < nchr; c = next.fetch_add(1)) finishChrom(c, phase); };
         std::vector<std::thread> pool;
         for (int t = 1; t < nth; t++) pool.emplace_back(worker);
         worker();
         for (auto& t : pool) t.join();
+    };
+    run_phase(0);
+    {   // the medians between consecutive preliminary breakpoints, all chromosomes in one launch (one workgroup per stretch); CANVAS_WV_HEAL_HOST=1: on the host as before
+        std::vector<unsigned long long> segs;
+        for (int c = 0; c < nchr; c++) {
+            segBase[(size_t)c] = (int64_t)segs.size();
+            const std::vector<int>& pr = prelimOf[(size_t)c]; const int64_t L = off[c + 1] - off[c];
+            for (size_t i = 0; i < pr.size(); i++) { const int64_t a = pr[i], b = i + 1 < pr.size() ? pr[i + 1] : L; segs.push_back(((unsigned long long)(off[c] + a) << 32) | (unsigned long long)(b - a)); }
+        }
+        segBase[(size_t)nchr] = (int64_t)segs.size();
+        bool okLen = true; for (unsigned long long v : segs) if ((v & 0xFFFFFFFFull) == 0) okLen = false;
+        if (!segs.empty() && okLen && segs.size() <= varCap && !getenv("CANVAS_WV_HEAL_HOST")) {
+            segMed.assign(segs.size(), 0.0);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVarStart, segs.data(), segs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_wv_segment_median, dim3((unsigned)segs.size()), dim3(1024), 0, ctx->stream, dX, (const unsigned long long*)dVarStart, dSegMed);
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(segMed.data(), dSegMed, segs.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipGetLastError());
+            segOnDevice = true;
+            if (getenv("CANVAS_WV_VAR_CHECK")) for (size_t k = 0; k < segs.size(); k++) {
+                const int64_t a = (int64_t)(segs[k] >> 32), n = (int64_t)(segs[k] & 0xFFFFFFFFull);
+                const double h = median_range(X.data(), a, a + n);
+                if (memcmp(&h, &segMed[k], 8) != 0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's segment medians differ from the host's");
+            }
+        }
     }
+    run_phase(1);
     int64_t total = 0;
     for (int c = 0; c < nchr; c++) {
         h_bp_offset[c] = total;
