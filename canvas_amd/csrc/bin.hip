@@ -818,7 +818,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         (void)maxTiles; (void)maxLen;
         for (int c = 0; c < nchr; c++) if (((uintptr_t)d_fraglen[c] | (uintptr_t)d_bases[c] | (uintptr_t)d_hits[c]) & 15) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: bases, hits and fragment lengths must be 16-byte aligned");
         int64_t totWords = 0; for (int c = 0; c < nchr; c++) totWords += (((h_len[c] + 63) >> 6) + 31) & ~31ll;
-        size_t bytes = (size_t)totLen + (size_t)totWords * 9 + 4096 + (size_t)nchr * (16 + sizeof(GcwChrom)) + (size_t)RG_REP * 202 * 8 + 101 * 4 + (GCW_HMAX + 1) * 101 * 4 + 8192;
+        size_t bytes = (size_t)totLen + (size_t)totWords * 9 + 4096 + (size_t)nchr * (16 * NZ_REP + sizeof(GcwChrom) + sizeof(RgChrom)) + (size_t)RG_REP_ALL * 202 * 8 + 101 * 4 + (GCW_HMAX + 1) * 101 * 4 + 8192;
         if (bytes > ctx->gc_arena_bytes) {
             if (ctx->gc_arena) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->gc_arena)); ctx->gc_arena = nullptr; ctx->gc_arena_bytes = 0; }
             CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->gc_arena, bytes)); ctx->gc_arena_bytes = bytes;
@@ -830,35 +830,52 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         for (int c = 0; c < nchr; c++) { gch[c].wordSum = (double*)p; p += (size_t)((((h_len[c] + 63) >> 6) + 31) & ~31ll) * 8; }      // per 64 positions: exact sum of the weighted terms ...
         for (int c = 0; c < nchr; c++) { gch[c].wordN = p; p += (size_t)((((h_len[c] + 63) >> 6) + 31) & ~31ll); }                      // ... and how many of them are not zero
         p = (uint8_t*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-        unsigned long long* sumCnt = (unsigned long long*)p; p += ((size_t)nchr * 16 + 255) & ~size_t(255);
-        unsigned long long* hist = (unsigned long long*)p; p += ((size_t)RG_REP * 202 * 8 + 255) & ~size_t(255);      // RG_REP replicas of {expected[101], observed[101]}
+        unsigned long long* sumCnt = (unsigned long long*)p; p += ((size_t)nchr * NZ_REP * 16 + 255) & ~size_t(255);   // NZ_REP replicas of {sum, count} per chromosome
+        unsigned long long* hist = (unsigned long long*)p; p += ((size_t)RG_REP_ALL * 202 * 8 + 255) & ~size_t(255);    // replicas of {expected[101], observed[101]}
         dGcStats = (unsigned long long*)p; p += 256;       // GCW_REP counters of replayed bins
         dW = (float*)p; p += 512;
         dLut = (float*)p; p += (((GCW_HMAX + 1) * 101 * 4 + 255) & ~255);
-        dGch = (GcwChrom*)p;
+        dGch = (GcwChrom*)p; p += ((size_t)nchr * sizeof(GcwChrom) + 255) & ~size_t(255);
+        RgChrom* dRg = (RgChrom*)p;
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(sumCnt, 0, (size_t)((char*)dW - (char*)sumCnt), ctx->stream));       // fragment sums, histogram replicas, decision counters: one fill
-        for (int c = 0; c < nchr; c++) hipLaunchKernelGGL(k_nonzero_mean2, dim3((unsigned)std::min<int64_t>(2048, (h_len[c] / 8 + 255) / 256 + 1)), dim3(256), 0, ctx->stream, d_fraglen[c], h_len[c], sumCnt + 2 * c);
-        rc0 = canvas_pin_reserve(ctx, (size_t)nchr * 16 + (size_t)RG_REP * 202 * 8 + 64); if (rc0) return rc0;
-        unsigned long long* hs = (unsigned long long*)ctx->pin;
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, sumCnt, (size_t)nchr * 16, hipMemcpyDeviceToHost, ctx->stream));
+        // the chromosome table of the two genome-wide launches: tiles of RG_T positions, numbered through the chromosomes
+        rc0 = canvas_pin_reserve(ctx, (size_t)nchr * (sizeof(RgChrom) + NZ_REP * 16) + (size_t)RG_REP_ALL * 202 * 8 + 64); if (rc0) return rc0;
+        int64_t ntileAll = 0;
+        {
+            RgChrom* hRg = (RgChrom*)ctx->pin;
+            for (int c = 0; c < nchr; c++) { hRg[c] = RgChrom{d_bases[c], d_fraglen[c], d_hits[c], (uint8_t*)gch[c].readGc, h_len[c], ntileAll}; ntileAll += (h_len[c] + RG_T - 1) / RG_T; }
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRg, hRg, (size_t)nchr * sizeof(RgChrom), hipMemcpyHostToDevice, ctx->stream));
+        }
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+        hipLaunchKernelGGL(k_nonzero_mean_all, dim3((unsigned)std::min<int64_t>((int64_t)cus * 8, ntileAll)), dim3(256), 0, ctx->stream, dRg, nchr, ntileAll, sumCnt);
+        unsigned long long* hs = (unsigned long long*)((char*)ctx->pin + (((size_t)nchr * sizeof(RgChrom) + 63) & ~size_t(63)));      // (behind the table: its upload may still be reading it)
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, sumCnt, (size_t)nchr * NZ_REP * 16, hipMemcpyDeviceToHost, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // MeanFragmentSize (CanvasBin.cs:164-174): NonZeroMean of the per-chromosome NonZeroMeans, all in Int16 with integer division
         long long s2 = 0, c2 = 0;
-        for (int c = 0; c < nchr; c++) { int16_t m = hs[2 * c + 1] ? (int16_t)(hs[2 * c] / hs[2 * c + 1]) : 0; if (m > 0) { s2 += m; c2++; } }
+        for (int c = 0; c < nchr; c++) {
+            unsigned long long sc = 0, cc = 0;
+            for (int r = 0; r < NZ_REP; r++) { sc += hs[((size_t)c * NZ_REP + r) * 2]; cc += hs[((size_t)c * NZ_REP + r) * 2 + 1]; }
+            int16_t m = cc ? (int16_t)(sc / cc) : 0; if (m > 0) { s2 += m; c2++; }
+        }
         if (ctx->gcw_reduce) { unsigned long long v[2] = {(unsigned long long)s2, (unsigned long long)c2}; int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, v, 2); if (rcr) return rcr; s2 = (long long)v[0]; c2 = (long long)v[1]; }      // chromosomes of the other ranks (canvas_bin_sample_sharded)
         const int meanFrag = c2 ? (int)(int16_t)(s2 / c2) : 0;
         if (meanFrag <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "CNV input error - unable to determine fragment size (CanvasBin.cs:431-434)");
         {
             const int nWmax = (RG_T + 3 * meanFrag) / 64 + 2;
-            const size_t ldsRg = (size_t)nWmax * 12;
-            int perCu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void*)k_read_gc2, 256, ldsRg) != hipSuccess || perCu <= 0) perCu = 2;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+            // k_read_gc3 follows the default window from position to position, which needs |100 d| < meanFragment; shorter fragments (and CANVAS_GCW_READ_GC2=1, the A/B and test
+            // hook) take k_read_gc2, one launch per chromosome
+            const bool rg3 = meanFrag > 100 && !getenv("CANVAS_GCW_READ_GC2");
+            const size_t ldsRg = (size_t)nWmax * (rg3 ? 16 : 12);
+            int perCu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, rg3 ? (const void*)k_read_gc3 : (const void*)k_read_gc2, 256, ldsRg) != hipSuccess || perCu <= 0) perCu = 2;
             const unsigned gridRg = (unsigned)(perCu * cus);
             // x / meanFrag as (x * ceil(2^40 / meanFrag)) >> 40: exact while x < 2^22 and meanFrag < 2^15 (x = 100 * count <= 100 * 32767)
             const unsigned long long mean40 = ((1ull << 40) + (unsigned long long)meanFrag - 1ull) / (unsigned long long)meanFrag;
             ProfScope ps(ctx, "gcw_read_gc");
-            for (int c = 0; c < nchr; c++) {
+            if (rg3) hipLaunchKernelGGL(k_read_gc3, dim3((unsigned)std::min<int64_t>(gridRg, ntileAll)), dim3(256), ldsRg, ctx->stream, dRg, nchr, ntileAll, meanFrag, mean40, nWmax, hist);
+            else for (int c = 0; c < nchr; c++) {
                 const int64_t ntile = (h_len[c] + RG_T - 1) / RG_T;
                 hipLaunchKernelGGL(k_read_gc2, dim3((unsigned)std::min<int64_t>(gridRg, ntile)), dim3(256), ldsRg, ctx->stream, d_bases[c], d_fraglen[c], d_hits[c], h_len[c], meanFrag, mean40, nWmax,
                                    (uint8_t*)gch[c].readGc, hist);
@@ -867,9 +884,9 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         unsigned long long hh[202];
         {
             unsigned long long* hr = (unsigned long long*)ctx->pin;
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hr, hist, (size_t)RG_REP * 202 * 8, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hr, hist, (size_t)RG_REP_ALL * 202 * 8, hipMemcpyDeviceToHost, ctx->stream));
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            for (int b = 0; b < 202; b++) { hh[b] = 0; for (int r = 0; r < RG_REP; r++) hh[b] += hr[(size_t)r * 202 + b]; }
+            for (int b = 0; b < 202; b++) { hh[b] = 0; for (int r = 0; r < RG_REP_ALL; r++) hh[b] += hr[(size_t)r * 202 + b]; }
             if (ctx->gcw_reduce) { int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, hh, 202); if (rcr) return rcr; }      // the read-GC profile is the whole genome's (CanvasBin.cs:372-391)
         }
         // observed vs expected (CanvasBin.cs:372-391)

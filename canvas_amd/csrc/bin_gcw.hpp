@@ -1,7 +1,7 @@
 // CanvasBin -m GCContentWeighted (mode 5, the Somatic-WGS default; included by bin.hip): CanvasBin.cs:416-506 (read-GC profile), :330-405 (observed vs expected),
 // :626-636 (weighted count).  Round 3 ran this chain at 55 ms per 80x genome (~0.06 of its roofline): a 4 B/base GC prefix array materialised in HBM and read twice,
 // fragment lengths streamed with 2-byte loads, and the weighted count of a bin added term by term through readlane.  This version:
-//   k_nonzero_mean2   Utilities.NonZeroMean of the fragment lengths with 16-byte loads                                         [2 B/base]
+//   k_nonzero_mean_all Utilities.NonZeroMean of the fragment lengths with 16-byte loads, one launch for all chromosomes            [2 B/base]
 //   k_read_gc2        the read-GC profile of a tile from a GC prefix that only ever exists in LDS: per 64 positions one bit word + one running count, for the tile and
 //                     a halo of 3 x meanFragment positions behind it; the count of the window [pos, pos + cur) is a difference of two prefix values.  Histograms of
 //                     ComputeObservedVsExpectedGC in LDS, flushed once per (persistent) workgroup into 16 replicas                 [~(1 + halo) + 2 + 1 read, 1 written B/base]
@@ -10,33 +10,6 @@
 //                     When that interval does not contain a value that rounds differently, (int)Math.Round is decided; the other bins (a few per thousand) replay the
 //                     reference's additions one by one                                                                            [1/8 + 1 + 1 B/base]
 #pragma once
-
-// ---- Utilities.NonZeroMean(Int16[]) (CanvasCommon/Utilities.cs:135-151): sum and number of the positive lengths
-__global__ void __launch_bounds__(256) k_nonzero_mean2(const int16_t* __restrict__ fl, int64_t len, unsigned long long* __restrict__ sumCnt /* [2] */) {
-    unsigned long long s = 0, c = 0;
-    const int64_t n8 = len >> 3, stride = (int64_t)gridDim.x * 256;
-    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n8; i0 += 4 * stride) {      // four 16-byte loads in flight per thread (one at a time: 86 % of the wave cycles waiting)
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * stride; v[u] = i < n8 ? reinterpret_cast<const uint4*>(fl)[i] : make_uint4(0u, 0u, 0u, 0u); }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int a = (int)(int16_t)(w[q] & 0xFFFFu), b = (int)(int16_t)(w[q] >> 16);
-                if (a > 0) { s += (unsigned long long)a; c++; }
-                if (b > 0) { s += (unsigned long long)b; c++; }
-            }
-        }
-    }
-    if (blockIdx.x == 0 && (int64_t)threadIdx.x < (len & 7)) { const int v = fl[(n8 << 3) + threadIdx.x]; if (v > 0) { s += (unsigned long long)v; c++; } }
-    s = wave_reduce_add_u64(s); c = wave_reduce_add_u64(c);
-    __shared__ unsigned long long sh[2][4];
-    if (lane_id() == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = c; }
-    __syncthreads();
-    if (threadIdx.x == 0) { atomicAdd(&sumCnt[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]); atomicAdd(&sumCnt[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]); }
-}
 
 // ---- gcContent[pos] (CanvasBin.cs:466-492) + the two 101-bin histograms of ComputeObservedVsExpectedGC (:349-356)
 // A tile of RG_T positions per workgroup round:
@@ -197,6 +170,259 @@ __global__ void __launch_bounds__(256) k_read_gc2(const uint8_t* __restrict__ ba
         for (int r = 0; r < RG_LREP; r++) { e += le[r][tid]; o += lo[r][tid]; }
         if (e) atomicAdd(&rep[tid], e);
         if (o) atomicAdd(&rep[101 + tid], o);
+    }
+}
+
+// ---- Utilities.NonZeroMean(Int16[]) (CanvasCommon/Utilities.cs:135-151): sum and number of the positive lengths, per chromosome (k_nonzero_mean_all), and the read-GC
+// profile (k_read_gc3) in one launch each for the whole genome: the per-chromosome launches of round 3 paid 37 us each for the 2 048 workgroups' atomics on the
+// chromosome's two counters (same-line atomics serialise at ~12 ns) and a ramp / tail per launch.  A tile is RG_T positions of one chromosome; RgChrom::tile0 numbers them.
+struct RgChrom { const uint8_t* bases; const int16_t* fl; const uint8_t* hits; uint8_t* readGc; int64_t len; int64_t tile0; };
+#define NZ_REP 32                      // replicas of a chromosome's {sum, count} (workgroup % NZ_REP)
+#define RG_REP_ALL 64                  // histogram replicas of k_read_gc3 (the host adds up RG_REP_ALL of them; k_read_gc2 uses the first RG_REP)
+__device__ __forceinline__ int rg_find_chrom(const RgChrom* __restrict__ ch, int nchr, int64_t tile) {      // the chromosome whose tiles contain `tile`
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ch[mid].tile0 <= tile) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ void __launch_bounds__(256) k_nonzero_mean_all(const RgChrom* __restrict__ ch, int nchr, int64_t ntileAll, unsigned long long* __restrict__ sumCnt /* [nchr][NZ_REP][2] */) {
+    __shared__ unsigned long long sh[2][4];
+    unsigned long long s = 0, c = 0;
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;                                        // (uniform over the workgroup)
+        s = wave_reduce_add_u64(s); c = wave_reduce_add_u64(c);
+        __syncthreads();
+        if (lane_id() == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = c; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long* dst = sumCnt + ((size_t)cur * NZ_REP + blockIdx.x % NZ_REP) * 2;
+            atomicAdd(&dst[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]); atomicAdd(&dst[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+        }
+        s = 0; c = 0;
+    };
+    for (int64_t tile = blockIdx.x; tile < ntileAll; tile += gridDim.x) {
+        const int ci = rg_find_chrom(ch, nchr, tile);
+        if (ci != cur) { flush(); cur = ci; }
+        const int16_t* __restrict__ fl = ch[ci].fl; const int64_t len = ch[ci].len;
+        const int64_t p0 = (tile - ch[ci].tile0) * RG_T;
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {                                // RG_T positions = 4 x 256 x 8 lengths
+            const int64_t p = p0 + ((int64_t)(u * 256 + (int)threadIdx.x) << 3);
+            if (p + 8 <= len) v[u] = *reinterpret_cast<const uint4*>(fl + p);
+            else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 8 && p + j < len; j++) w[j >> 1] |= (uint32_t)(uint16_t)fl[p + j] << (16 * (j & 1));
+                v[u] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            uint32_t s32 = 0, c32 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int a = (int)(int16_t)(w[q] & 0xFFFFu), b = (int)(int16_t)(w[q] >> 16);
+                if (a > 0) { s32 += (uint32_t)a; c32++; }
+                if (b > 0) { s32 += (uint32_t)b; c32++; }
+            }
+            s += s32; c += c32;
+        }
+    }
+    flush();
+}
+
+// ---- k_read_gc3: the same result as k_read_gc2 for meanFragment > 100.  k_read_gc2 took 6.5 ms per 80x genome (2.5x its HBM time) and a first rewrite with a third of its
+// instructions took exactly as long: the kernel is a chain of phases — load, barrier, compute, barrier, list, barrier, store — in which a workgroup waits for its own loads, and
+// four workgroups per CU do not cover that.  Here the workgroup only builds the tile's GC prefix together; then every WAVE works through its own quarter of the tile in rounds of
+// 512 positions (8 per lane) with no workgroup barrier, the next round's hits and fragment lengths already in flight:
+//   (a) every position as if it carried no fragment length: with x = 100 * count, v = x / meanFragment and r = x % meanFragment the count moves by d in {-1, 0, 1} from one
+//       position to the next, r by 100 d, and |100 d| < meanFragment means at most one step of v either way — no division per position.  32 histogram replicas laid out
+//       [gcContent][lane % 32]: a lane owns its LDS bank, the atomics of a wave never meet, every position simply adds (1, hits) — no run tracking, no branches;
+//   (b) positions WITH a fragment length are patches of that default: they go on a wave-private list as (offset, length, hits) in one word (wave prefix sum of the lanes'
+//       counts, no atomics), all lanes then work the list off: two lookups in the {32 GC bits, running count} table, a float reciprocal with an exact correction
+//       (quotient <= 100, operands < 2^24), the byte replaced and the histograms corrected by -default +actual (32-bit counters in modular arithmetic, flushed before they can wrap);
+//   (c) 8-byte stores.
+#define RG3_HR 32
+#define RG3_FLUSH_TILES 512            // 512 x 8192 positions x 255 hits < 2^32
+#define RG3_WR 512                     // positions of a wave round
+__device__ __forceinline__ uint32_t rg3_prefix(const uint2* __restrict__ sPre, int a) {      // GC positions in [tile start, tile start + a)
+    const uint2 e = sPre[a >> 5];
+    return e.y + (uint32_t)__popc(e.x & ((1u << (a & 31)) - 1u));
+}
+__device__ __forceinline__ uint32_t rg3_div100(uint32_t c, uint32_t cur) {                  // 100 * c / cur for c <= cur < 2^17 (100 c < 2^24: exact as a float)
+    const uint32_t x = 100u * c;
+    uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)cur));                  // within 1 of the quotient (which is <= 100)
+    const int32_t r = (int32_t)x - (int32_t)(q * cur);
+    if (r < 0) q--; else if ((uint32_t)r >= cur) q++;
+    return q;
+}
+__device__ __forceinline__ void rg3_load8(const uint8_t* __restrict__ hits, const int16_t* __restrict__ fl, int64_t p, int64_t len, uint32_t (&hw)[2], uint32_t (&fw)[4]) {
+    hw[0] = hw[1] = 0; fw[0] = fw[1] = fw[2] = fw[3] = 0;
+    if (p + 8 <= len) {
+        const uint2 h = *reinterpret_cast<const uint2*>(hits + p); const uint4 f = *reinterpret_cast<const uint4*>(fl + p);
+        hw[0] = h.x; hw[1] = h.y; fw[0] = f.x; fw[1] = f.y; fw[2] = f.z; fw[3] = f.w;
+    } else {
+        for (int j = 0; j < 8 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); fw[j >> 1] |= (uint32_t)(uint16_t)fl[p + j] << (16 * (j & 1)); }
+    }
+}
+// dynamic LDS: uint2 sPre[2 * nWmax]  ({GC bits of 32 positions, GC positions of the tile in front of them})
+__global__ void __launch_bounds__(256) k_read_gc3(const RgChrom* __restrict__ ch, int nchr, int64_t ntileAll, int meanFrag, unsigned long long mean40, int nWmax,
+                                                  unsigned long long* __restrict__ histRep) {
+    extern __shared__ __attribute__((aligned(16))) uint2 sPre[];
+    __shared__ unsigned int sHist[2 * 101 * RG3_HR];                    // expected [101][32], observed [101][32]
+    __shared__ uint32_t sWave[4];
+    __shared__ __attribute__((aligned(16))) uint8_t sGW[4][RG3_WR];      // gcContent of the wave's round
+    __shared__ uint32_t sListW[4][RG3_WR];                              // the wave's positions with a fragment length: offset in the round << 23 | max(length, 0) << 8 | hits
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t lane32 = (uint32_t)tid & 31u;
+    for (int i = tid; i < 2 * 101 * RG3_HR; i += 256) sHist[i] = 0;
+    const int M = meanFrag, H = 3 * meanFrag;
+    unsigned long long* rep = histRep + (size_t)(blockIdx.x % RG_REP_ALL) * 202;
+    uint8_t* __restrict__ sG = sGW[wv]; uint32_t* __restrict__ sList = sListW[wv];
+    int sinceFlush = 0;
+    for (int64_t tile = blockIdx.x; tile < ntileAll; tile += gridDim.x) {
+        const int ci = rg_find_chrom(ch, nchr, tile);
+        const uint8_t* __restrict__ bases = ch[ci].bases; const int16_t* __restrict__ fl = ch[ci].fl; const uint8_t* __restrict__ hits = ch[ci].hits; uint8_t* __restrict__ readGc = ch[ci].readGc;
+        const int64_t len = ch[ci].len;
+        const int64_t lim = len - (int64_t)H - 1;                  // positions from `lim` on keep gcContent 0 (the loop of CanvasBin.cs:466 stops there)
+        const int64_t t0 = (tile - ch[ci].tile0) * RG_T;
+        const int64_t tEnd = t0 + RG_T < len ? t0 + RG_T : len;
+        const int64_t wBase = t0 + (int64_t)wv * (RG_T / 4);       // this wave's quarter of the tile
+        // the first round's hits and lengths are requested before the prefix is built
+        uint32_t hwN[2], fwN[4];
+        rg3_load8(hits, fl, wBase + 8 * lane, wBase + 8 * lane < tEnd ? len : 0, hwN, fwN);
+        // ---- 1. the GC prefix of [t0, tEnd + H)
+        const int64_t last = tEnd + H < len ? tEnd + H : len;
+        const int nW = (int)((last - t0 + 63) >> 6) + 1;           // 64-position words (+1: a window may end exactly on the word behind the last one)
+        __syncthreads();                                           // the previous tile's readers are done with sPre (and the zeroing of sHist is visible)
+        if (sinceFlush == RG3_FLUSH_TILES) {
+            if (tid < 101) {
+                unsigned int e = 0, o = 0;
+                for (int r = 0; r < RG3_HR; r++) { e += sHist[tid * RG3_HR + r]; o += sHist[(101 + tid) * RG3_HR + r]; sHist[tid * RG3_HR + r] = 0; sHist[(101 + tid) * RG3_HR + r] = 0; }
+                if (e) atomicAdd(&rep[tid], (unsigned long long)e);
+                if (o) atomicAdd(&rep[101 + tid], (unsigned long long)o);
+            }
+            sinceFlush = 0;
+            __syncthreads();
+        }
+        sinceFlush++;
+        uint32_t carry = 0;
+        for (int base = 0; base < nW; base += 256) {
+            const int w = base + tid;
+            uint64_t g = 0;
+            if (w < nW) { const int64_t p = t0 + ((int64_t)w << 6); if (p < len) g = gc_bits64(bases, p, len); }
+            const uint32_t cnt = (uint32_t)__popcll(g);
+            const uint32_t inc = wave_inclusive_scan_u32(cnt);
+            if ((tid & 63) == 63) sWave[tid >> 6] = inc;
+            __syncthreads();
+            uint32_t off = carry, tot = 0;
+            for (int k = 0; k < 4; k++) { if (k < (tid >> 6)) off += sWave[k]; tot += sWave[k]; }
+            if (w < nW) {
+                const uint32_t c0 = off + inc - cnt, glo = (uint32_t)g;
+                *reinterpret_cast<uint4*>(&sPre[2 * w]) = make_uint4(glo, c0, (uint32_t)(g >> 32), c0 + (uint32_t)__popc(glo));
+            }
+            carry += tot;
+            __syncthreads();
+        }
+        // ---- 2. the wave's rounds
+        for (int rd = 0; rd < RG_T / 4 / RG3_WR; rd++) {
+            const int64_t rBase = wBase + (int64_t)rd * RG3_WR;
+            if (rBase >= tEnd) break;                                // (uniform over the wave)
+            const int64_t p = rBase + 8 * lane;
+            const bool in = p < tEnd;
+            uint32_t hw[2] = {hwN[0], hwN[1]}, fw[4] = {fwN[0], fwN[1], fwN[2], fwN[3]};
+            if (rd + 1 < RG_T / 4 / RG3_WR) rg3_load8(hits, fl, p + RG3_WR, p + RG3_WR < tEnd ? len : 0, hwN, fwN);      // the next round's, in flight during this one
+            const int a0 = (int)(p - t0);                                        // multiple of 8: the 8 bits at a0 lie inside one 32-bit word
+            uint32_t out[2] = {0, 0};
+            uint32_t nzf = 0;
+            if (in) {
+                int nlim = 8;
+                if (p + 8 <= lim) {
+                    // (a) window [pos, pos + meanFragment), followed from position to position
+                    const int b0 = a0 + M;
+                    const uint32_t bitsA = (sPre[a0 >> 5].x >> (a0 & 31)) & 0xFFu;
+                    const uint2 eB = sPre[b0 >> 5];
+                    const uint32_t bitsB = __builtin_amdgcn_alignbit(sPre[(b0 >> 5) + 1].x, eB.x, (uint32_t)(b0 & 31)) & 0xFFu;
+                    const uint32_t cnt = (eB.y + (uint32_t)__popc(eB.x & ((1u << (b0 & 31)) - 1u))) - rg3_prefix(sPre, a0);
+                    const uint32_t x = 100u * cnt;
+                    uint32_t v = (uint32_t)(((unsigned long long)x * mean40) >> 40);      // 100 * gcCounter / meanFragmentSize (exact: x < 2^22, see the host)
+                    int32_t r = (int32_t)(x - v * (uint32_t)M);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        out[j >> 2] |= v << (8 * (j & 3));
+                        const uint32_t idx = v * RG3_HR + lane32;
+                        atomicAdd(&sHist[idx], 1u);
+                        atomicAdd(&sHist[101 * RG3_HR + idx], (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                        r = __mul24(100, (int32_t)((bitsB >> j) & 1u) - (int32_t)((bitsA >> j) & 1u)) + r;
+                        const int32_t adj = (r >> 31) - ((M - 1 - r) >> 31);       // +1: r >= M, -1: r < 0
+                        r -= __mul24(adj, M);
+                        v += (uint32_t)adj;
+                    }
+                } else {
+                    // the last groups of the chromosome: positions behind `lim` keep 0, positions behind `len` do not exist
+                    nlim = lim - p > 0 ? (int)(lim - p) : 0;
+                    const int nval = len - p >= 8 ? 8 : (int)(len - p);
+                    for (int j = 0; j < nval; j++) {
+                        uint32_t g = 0;
+                        if (j < nlim) g = (uint32_t)(((unsigned long long)(100u * (rg3_prefix(sPre, a0 + j + M) - rg3_prefix(sPre, a0 + j))) * mean40) >> 40);
+                        out[j >> 2] |= g << (8 * (j & 3));
+                        atomicAdd(&sHist[g * RG3_HR + lane32], 1u);
+                        atomicAdd(&sHist[(101 + g) * RG3_HR + lane32], (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                    }
+                }
+                // the positions in front of `lim` that carry a fragment length
+#pragma unroll
+                for (int q = 0; q < 4; q++) nzf |= ((fw[q] & 0xFFFFu) ? 1u : 0u) << (2 * q) | ((fw[q] >> 16) ? 1u : 0u) << (2 * q + 1);
+                nzf &= nlim >= 8 ? 0xFFu : ((1u << nlim) - 1u);
+            }
+            const uint32_t nMine = (uint32_t)__popc(nzf);
+            const uint32_t incl = wave_inclusive_scan_u32(nMine);
+            const int nl = __builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t at = incl - nMine;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if ((nzf >> j) & 1u) {
+                    const int f = (int)(int16_t)((fw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+                    sList[at++] = ((uint32_t)(8 * lane + j) << 23) | ((uint32_t)(f > 0 ? f : 0) << 8) | ((hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                }
+            }
+            *reinterpret_cast<uint2*>(sG + 8 * lane) = make_uint2(out[0], out[1]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            // (b) the listed positions, all lanes busy: window [pos, pos + min(length, 3 meanFragment)); the default value is replaced, the histograms follow
+            const int aR = (int)(rBase - t0);
+            for (int k = lane; k < nl; k += 64) {
+                const uint32_t ent = sList[k];
+                const int o = (int)(ent >> 23), f = (int)((ent >> 8) & 0x7FFFu);
+                const uint32_t h = ent & 0xFFu;
+                const int a = aR + o;
+                const int cur = f < H ? f : H;
+                uint32_t g = 0;
+                if (cur > 0) g = rg3_div100(rg3_prefix(sPre, a + cur) - rg3_prefix(sPre, a), (uint32_t)cur);      // (a negative length: an empty window in the reference, gcContent 0)
+                const uint32_t gd = sG[o];
+                if (g != gd) {
+                    sG[o] = (uint8_t)g;
+                    atomicAdd(&sHist[gd * RG3_HR + lane32], 0xFFFFFFFFu);
+                    atomicAdd(&sHist[g * RG3_HR + lane32], 1u);
+                    if (h) { atomicAdd(&sHist[(101 + gd) * RG3_HR + lane32], 0u - h); atomicAdd(&sHist[(101 + g) * RG3_HR + lane32], h); }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            // (c) the store
+            if (in) {
+                const uint2 o2 = *reinterpret_cast<const uint2*>(sG + 8 * lane);
+                if (p + 8 <= len) *reinterpret_cast<uint2*>(readGc + p) = o2;
+                else { const uint32_t o[2] = {o2.x, o2.y}; for (int j = 0; j < 8 && p + j < len; j++) readGc[p + j] = (uint8_t)((o[j >> 2] >> (8 * (j & 3))) & 0xFFu); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    if (tid < 101) {
+        unsigned int e = 0, o = 0;
+        for (int r = 0; r < RG3_HR; r++) { e += sHist[tid * RG3_HR + r]; o += sHist[(101 + tid) * RG3_HR + r]; }
+        if (e) atomicAdd(&rep[tid], (unsigned long long)e);
+        if (o) atomicAdd(&rep[101 + tid], (unsigned long long)o);
     }
 }
 

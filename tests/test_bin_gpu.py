@@ -183,6 +183,46 @@ def test_bin_gc_content_weighted_mode(bin_path):
         assert decided + replayed == total and decided > 0.9 * total, (decided, replayed, total)      # the exact-sum interval decides nearly every bin
 
 
+@pytest.mark.parametrize("mean_sd", [(350, 60), (104, 3), (101, 0), (60, 10), (1500, 400), (97, 0)])
+def test_read_gc_profile_kernels_over_fragment_size_regimes(monkeypatch, mean_sd):
+    """The read-GC profile (CanvasBin.cs:416-506) comes from k_read_gc3 when the mean fragment is above 100 (the default window's value is followed from position to position, which
+    needs |100 d| < meanFragment) and from k_read_gc2 otherwise; CANVAS_GCW_READ_GC2=1 forces the latter.  Both against the oracle through the weighted counts of small bins (every
+    term is hit / weight[readGC]: a wrong gcContent byte or a wrong histogram counter moves them), with lengths that are no multiple of 16, a chromosome shorter than 3 x the mean
+    fragment, hits without a fragment length, fragment lengths without a hit, negative and clipped lengths, and saturated hit counts."""
+    import torch
+    cv = get_canvas()
+    mean, sd = mean_sd
+    lengths = [640_007, 270_001, 3 * mean - 5, 3 * mean + 40]
+    data = _chroms(lengths, rate=0.3)
+    rng = np.random.RandomState(33 + mean)
+    fl = []
+    for b, h, m in data:
+        f = np.where(h > 0, np.clip(rng.normal(mean, sd, len(h)), 1, 30000), 0).astype(np.int16)
+        drop = rng.rand(len(h)) < 0.2; f[drop] = 0                                   # hits without a fragment length
+        add = (rng.rand(len(h)) < 0.01) & (h == 0); f[add] = mean                    # a fragment length without a hit
+        fl.append(f)
+    fl[0][7000:7040] = -5; fl[0][9000:9100] = min(32767, 40 * mean); fl[1][-2000:] = max(1, mean // 2)
+    for k in (0, 1):
+        sel = rng.randint(0, lengths[k], 300); data[k][1][sel] = 255                  # saturated counts
+    bases, hits, masks = _upload(cv, data)
+    dfl = [to_dev(pad16(f), cv.device) for f in fl]
+    lens = np.array(lengths, np.int64)
+    cap = int(lens.sum() // 8)
+    mk = lambda dt: torch.empty(cap, dtype=dt, device=cv.device)
+    out = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+    for bs in (200, 24):
+        exp, mfrag, w, _ = O.bin_gc_weighted([d[0] for d in data], [d[2] for d in data], [d[1] for d in data], fl, bs)
+        assert (mfrag > 100) == (mean > 100), (mfrag, mean)                         # the regime this case is meant for
+        ex = np.concatenate([e[3] for e in exp]).astype(np.float32)
+        for force_old in (False, True):
+            if force_old: monkeypatch.setenv("CANVAS_GCW_READ_GC2", "1")
+            else: monkeypatch.delenv("CANVAS_GCW_READ_GC2", raising=False)
+            o, per, total, _ = cv.bin_sample_gcweighted(bases, masks, hits, dfl, lens, [1, 1, 1, 1], 100, bs, out=out)
+            got = out["count"][:total].cpu().numpy()
+            assert total == len(ex) and (got == ex).all(), (mean_sd, bs, force_old, np.nonzero(got != ex)[0][:5], got[got != ex][:5], ex[got != ex][:5])
+    monkeypatch.delenv("CANVAS_GCW_READ_GC2", raising=False)
+
+
 def test_gc_weighted_interval_decisions_equal_the_serial_order(monkeypatch):
     """k_bin_weighted2 decides (int)Math.Round of the float32 running sum from the exact sum of the terms and a rounding-error interval; CANVAS_GCW_SERIAL=1 sends every bin
     through the reference's own order of additions instead: same counts (and both equal the oracle, incl. negative fragment lengths, which the reference reads as an empty window)."""
