@@ -1112,12 +1112,10 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     }
     if (gcw) {
         ProfScope ps(ctx, "gcw_weighted");
-        static const unsigned gridW = resident_grid((const void*)k_bin_weighted3, 256, ctx->device), gridS = resident_grid((const void*)k_gcw_words, 256, ctx->device);
+        static const unsigned gridW = resident_grid((const void*)k_bin_weighted3, 256, ctx->device), gridS = resident_grid((const void*)k_gcw_words_all, 256, ctx->device);
         hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, dW, dLut);
         if (!getenv("CANVAS_GCW_SERIAL"))
-            for (int c = 0; c < nchr; c++)
-                hipLaunchKernelGGL(k_gcw_words, dim3((unsigned)std::min<int64_t>(gridS, (h_len[c] / 16 + 255) / 256 + 1)), dim3(256), 0, ctx->stream, d_mask[c], d_hits[c], hGch[c].readGc, h_len[c], dW, dLut,
-                                   hGch[c].wordSum, hGch[c].wordN);
+            hipLaunchKernelGGL(k_gcw_words_all, dim3((unsigned)std::min<int64_t>(gridS, plan.ntiles)), dim3(256), 0, ctx->stream, dCh, dGch, nchr, (int64_t)plan.ntiles, dW, dLut);
         hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridW, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats,
                            getenv("CANVAS_GCW_SERIAL") ? 1 : 0);      // (test hook: every bin through the reference's own order of additions)
         ctx->gcw_stats_dev = dGcStats; ctx->gcw_total = (long long)total;       // how many bins the interval decided / how many replayed the reference's additions: canvas_bin_gcw_stats

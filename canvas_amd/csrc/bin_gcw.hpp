@@ -335,7 +335,6 @@ __global__ void __launch_bounds__(256) k_read_gc3(const RgChrom* __restrict__ ch
             if (rd + 1 < RG_T / 4 / RG3_WR) rg3_load8(hits, fl, p + RG3_WR, p + RG3_WR < tEnd ? len : 0, hwN, fwN);      // the next round's, in flight during this one
             const int a0 = (int)(p - t0);                                        // multiple of 8: the 8 bits at a0 lie inside one 32-bit word
             uint32_t out[2] = {0, 0};
-            uint32_t nzf = 0;
             if (in) {
                 int nlim = 8;
                 if (p + 8 <= lim) {
@@ -371,27 +370,28 @@ __global__ void __launch_bounds__(256) k_read_gc3(const RgChrom* __restrict__ ch
                         atomicAdd(&sHist[(101 + g) * RG3_HR + lane32], (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
                     }
                 }
-                // the positions in front of `lim` that carry a fragment length
+                if (nlim < 8) {                                                   // positions from `lim` on are no list entries: their lengths are dropped here
 #pragma unroll
-                for (int q = 0; q < 4; q++) nzf |= ((fw[q] & 0xFFFFu) ? 1u : 0u) << (2 * q) | ((fw[q] >> 16) ? 1u : 0u) << (2 * q + 1);
-                nzf &= nlim >= 8 ? 0xFFu : ((1u << nlim) - 1u);
+                    for (int j = 0; j < 8; j++) if (j >= nlim) fw[j >> 1] &= ~(0xFFFFu << (16 * (j & 1)));
+                }
             }
-            const uint32_t nMine = (uint32_t)__popc(nzf);
-            const uint32_t incl = wave_inclusive_scan_u32(nMine);
-            const int nl = __builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t at = incl - nMine;
+            // the positions that carry a fragment length, position j of every lane at a time: the lanes' ranks come from the comparison's lane mask (no per-lane bit set, no scan)
+            uint32_t nl = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                if ((nzf >> j) & 1u) {
-                    const int f = (int)(int16_t)((fw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-                    sList[at++] = ((uint32_t)(8 * lane + j) << 23) | ((uint32_t)(f > 0 ? f : 0) << 8) | ((hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                const int f = (int)(int16_t)((fw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+                const unsigned long long has = __ballot(f != 0);
+                if (f != 0) {
+                    const uint32_t at = nl + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
+                    sList[at] = ((uint32_t)(8 * lane + j) << 23) | ((uint32_t)(f > 0 ? f : 0) << 8) | ((hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
                 }
+                nl += (uint32_t)__popcll(has);
             }
             *reinterpret_cast<uint2*>(sG + 8 * lane) = make_uint2(out[0], out[1]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             // (b) the listed positions, all lanes busy: window [pos, pos + min(length, 3 meanFragment)); the default value is replaced, the histograms follow
             const int aR = (int)(rBase - t0);
-            for (int k = lane; k < nl; k += 64) {
+            for (int k = lane; k < (int)nl; k += 64) {
                 const uint32_t ent = sList[k];
                 const int o = (int)(ent >> 23), f = (int)((ent >> 8) & 0x7FFFu);
                 const uint32_t h = ent & 0xFFu;
@@ -531,6 +531,44 @@ __global__ void __launch_bounds__(256) k_gcw_words(const uint64_t* __restrict__ 
         sum += __shfl_xor(sum, 1, 64); n += __shfl_xor(n, 1, 64);
         sum += __shfl_xor(sum, 2, 64); n += __shfl_xor(n, 2, 64);
         if ((threadIdx.x & 3) == 0 && p < len) { wordSum[p >> 6] = sum; wordN[p >> 6] = (uint8_t)n; }
+    }
+}
+// the same sweep as one launch over every chromosome's tiles (BinChrom::tileBase numbers them): the per-chromosome launches each paid for a ramp, a tail and the table load
+__device__ __forceinline__ int gcw_find_chrom(const BinChrom* __restrict__ ch, int nchr, int64_t tile) {
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ch[mid].tileBase <= tile) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ void __launch_bounds__(256) k_gcw_words_all(const BinChrom* __restrict__ ch, const GcwChrom* __restrict__ gch, int nchr, int64_t ntiles, const float* __restrict__ w, const float* __restrict__ lut) {
+    __shared__ float sW[101];
+    __shared__ float sT[(GCW_HMAX + 1) * 101];
+    if (threadIdx.x < 101) sW[threadIdx.x] = w[threadIdx.x];
+    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = lut[i];
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int c = gcw_find_chrom(ch, nchr, tile);
+        const uint64_t* __restrict__ mask = ch[c].mask; const uint8_t* __restrict__ hits = ch[c].hits; const uint8_t* __restrict__ rg = gch[c].readGc;
+        const int64_t len = ch[c].len;
+        const int64_t p = (tile - ch[c].tileBase) * TILE + 16 * (int64_t)threadIdx.x;      // TILE = 256 groups of 16 positions: whole quads (the shuffles below)
+        uint32_t hw[4] = {0, 0, 0, 0}, gw[4] = {0, 0, 0, 0};
+        uint32_t m16 = 0;
+        if (p < len) {
+            m16 = (uint32_t)((mask[p >> 6] >> (p & 63)) & 0xFFFFull);
+            if (p + 16 <= len) {
+                const uint4 h = *reinterpret_cast<const uint4*>(hits + p), gq = *reinterpret_cast<const uint4*>(rg + p);
+                hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w; gw[0] = gq.x; gw[1] = gq.y; gw[2] = gq.z; gw[3] = gq.w;
+            } else {
+                m16 &= 0xFFFFu >> (p + 16 - len);
+                for (int j = 0; j < 16 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); gw[j >> 2] |= (uint32_t)rg[p + j] << (8 * (j & 3)); }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) hw[q] &= expand4(m16 >> (4 * q));       // only possible positions count
+        }
+        double sum; uint32_t n;
+        gcw_terms16(hw, gw, sT, sW, sum, n);
+        sum += __shfl_xor(sum, 1, 64); n += __shfl_xor(n, 1, 64);
+        sum += __shfl_xor(sum, 2, 64); n += __shfl_xor(n, 2, 64);
+        if ((threadIdx.x & 3) == 0 && p < len) { gch[c].wordSum[p >> 6] = sum; gch[c].wordN[p >> 6] = (uint8_t)n; }
     }
 }
 // 16 lanes per bin: lanes 0-3 open the word the bin starts in, lanes 4-7 the word it ends in (when that is another one), lanes 8-15 add the sums of the words in between
