@@ -1117,7 +1117,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         if (!getenv("CANVAS_GCW_SERIAL"))
             hipLaunchKernelGGL(k_gcw_words_all, dim3((unsigned)std::min<int64_t>(gridS, plan.ntiles)), dim3(256), 0, ctx->stream, dCh, dGch, nchr, (int64_t)plan.ntiles, dW, dLut);
         hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridW, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats,
-                           getenv("CANVAS_GCW_SERIAL") ? 1 : 0);      // (test hook: every bin through the reference's own order of additions)
+                           getenv("CANVAS_GCW_SERIAL") ? 1 : 0, nchr);      // (test hook: every bin through the reference's own order of additions)
         ctx->gcw_stats_dev = dGcStats; ctx->gcw_total = (long long)total;       // how many bins the interval decided / how many replayed the reference's additions: canvas_bin_gcw_stats
     }
     CANVAS_HIP_TRY(ctx, hipGetLastError());
