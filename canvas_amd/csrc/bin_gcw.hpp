@@ -2,10 +2,10 @@
 // :626-636 (weighted count).  Round 3 ran this chain at 55 ms per 80x genome (~0.06 of its roofline): a 4 B/base GC prefix array materialised in HBM and read twice,
 // fragment lengths streamed with 2-byte loads, and the weighted count of a bin added term by term through readlane.  This version:
 //   k_nonzero_mean_all Utilities.NonZeroMean of the fragment lengths with 16-byte loads, one launch for all chromosomes            [2 B/base]
-//   k_read_gc2        the read-GC profile of a tile from a GC prefix that only ever exists in LDS: per 64 positions one bit word + one running count, for the tile and
+//   k_read_gc3 / _gc2 the read-GC profile of a tile (k_read_gc3: mean fragment > 100, one launch; k_read_gc2: the rest, one launch per chromosome) from a GC prefix that only ever exists in LDS: per 64 positions one bit word + one running count, for the tile and
 //                     a halo of 3 x meanFragment positions behind it; the count of the window [pos, pos + cur) is a difference of two prefix values.  Histograms of
 //                     ComputeObservedVsExpectedGC in LDS, flushed once per (persistent) workgroup into 16 replicas                 [~(1 + halo) + 2 + 1 read, 1 written B/base]
-//   k_bin_weighted2   per bin: the terms min(10, hit / weight[readGC]) are floats, so their sum in double is exact in any order; the reference adds them in float32, in
+//   k_gcw_words_all + k_bin_weighted3   per bin: the terms min(10, hit / weight[readGC]) are floats, so their sum in double is exact in any order; the reference adds them in float32, in
 //                     position order — its result lies within n * 2^-24 * sum of the exact sum (every partial sum is at most the final one: the terms are not negative).
 //                     When that interval does not contain a value that rounds differently, (int)Math.Round is decided; the other bins (a few per thousand) replay the
 //                     reference's additions one by one                                                                            [1/8 + 1 + 1 B/base]
@@ -463,7 +463,7 @@ __device__ __forceinline__ float weighted_serial(const BinChrom& C, const uint8_
 // The weighted count in two steps.  History (80x genome, 6.2 M bins): one wave per bin adding the terms through readlane 19.5 ms (round 3); exact sum in double, one bin per
 // wave 5.6 ms, 16 lanes per bin 5.2 ms, terms from a table + only the positions with a hit visited 6.8 ms — the SQ counters showed 1.9 ms of VALU time per SIMD (a wave
 // instruction occupies its SIMD for four cycles) on top of a chain of four dependent loads per bin.  Now:
-//   k_gcw_words      a streaming sweep like k_tile_summary: per 64-position word the exact sum (double) and the number of the non-zero terms min(10, hit / weight[readGC])
+//   k_gcw_words_all  a streaming sweep like k_tile_summary: per 64-position word the exact sum (double) and the number of the non-zero terms min(10, hit / weight[readGC])
 //                    over its possible positions.  Branch-free: the term comes from a table in LDS indexed by (hit, readGC) — row 0 is 0.0f, so a position without a hit or
 //                    outside the mask costs the same five instructions as any other; hits above GCW_HMAX (a handful per genome) take a division.
 //   k_bin_weighted3  per bin (16 lanes): the sums of its whole words + the two words its ends cut, opened like k_bin_resolve does; then the interval decision.
@@ -474,12 +474,12 @@ __global__ void __launch_bounds__(256) k_gcw_terms(const float* __restrict__ w, 
     for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) { const int h = i / 101, gc = i - h * 101; lut[i] = h ? fminf(10.0f, (float)h / w[gc]) : 0.0f; }
 }
 // the terms of 16 consecutive positions (hw: their hits, already zero where the position does not count; gw: their read-GC values) -> exact sum in double, number of non-zero terms
-__device__ __forceinline__ void gcw_terms16(const uint32_t (&hw)[4], const uint32_t (&gw)[4], const float* __restrict__ sT, const float* __restrict__ sW, double& sum, uint32_t& n) {
+__device__ __forceinline__ void gcw_terms16(const uint32_t (&hw)[4], const uint32_t (&gw)[4], const double* __restrict__ sT, const float* __restrict__ sW, double& sum, uint32_t& n) {      // sT: the term table as doubles (the same values: no conversion per term)
     uint32_t big = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) big |= ((hw[q] & 0x7F7F7F7Fu) + 0x6B6B6B6Bu) | hw[q];       // bit 7 of a byte set <=> the byte is > GCW_HMAX (20 = 0x14: 0x14 + 0x6B = 0x7F)
     big &= 0x80808080u;
-    float t[16];
+    double t[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t h = (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu, gc0 = (gw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
@@ -490,12 +490,12 @@ __device__ __forceinline__ void gcw_terms16(const uint32_t (&hw)[4], const uint3
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint32_t h = (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            if (h > (uint32_t)GCW_HMAX) { const uint32_t gc0 = (gw[j >> 2] >> (8 * (j & 3))) & 0xFFu; t[j] = fminf(10.0f, (float)(int)h / sW[gc0 < 101u ? gc0 : 100u]); }
+            if (h > (uint32_t)GCW_HMAX) { const uint32_t gc0 = (gw[j >> 2] >> (8 * (j & 3))) & 0xFFu; t[j] = (double)fminf(10.0f, (float)(int)h / sW[gc0 < 101u ? gc0 : 100u]); }
         }
     }
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j += 4) { s0 += (double)t[j]; s1 += (double)t[j + 1]; s2 += (double)t[j + 2]; s3 += (double)t[j + 3]; }
+    for (int j = 0; j < 16; j += 4) { s0 += t[j]; s1 += t[j + 1]; s2 += t[j + 2]; s3 += t[j + 3]; }
     sum = (s0 + s1) + (s2 + s3);
     uint32_t nz = 0;
 #pragma unroll
@@ -503,38 +503,7 @@ __device__ __forceinline__ void gcw_terms16(const uint32_t (&hw)[4], const uint3
     n = nz;
 }
 struct GcwChrom { const uint8_t* readGc; double* wordSum; uint8_t* wordN; };
-__global__ void __launch_bounds__(256) k_gcw_words(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ hits, const uint8_t* __restrict__ rg, int64_t len,
-                                                   const float* __restrict__ w, const float* __restrict__ lut, double* __restrict__ wordSum, uint8_t* __restrict__ wordN) {
-    __shared__ float sW[101];
-    __shared__ float sT[(GCW_HMAX + 1) * 101];
-    if (threadIdx.x < 101) sW[threadIdx.x] = w[threadIdx.x];
-    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = lut[i];
-    __syncthreads();
-    const int64_t ngrp = (len + 15) >> 4;
-    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ((ngrp + 3) & ~3ll); g += (int64_t)gridDim.x * 256) {      // (whole quads: the shuffles below)
-        const int64_t p = g << 4;
-        uint32_t hw[4] = {0, 0, 0, 0}, gw[4] = {0, 0, 0, 0};
-        uint32_t m16 = 0;
-        if (p < len) {
-            m16 = (uint32_t)((mask[p >> 6] >> (p & 63)) & 0xFFFFull);
-            if (p + 16 <= len) {
-                const uint4 h = *reinterpret_cast<const uint4*>(hits + p), gq = *reinterpret_cast<const uint4*>(rg + p);
-                hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w; gw[0] = gq.x; gw[1] = gq.y; gw[2] = gq.z; gw[3] = gq.w;
-            } else {
-                m16 &= 0xFFFFu >> (p + 16 - len);
-                for (int j = 0; j < 16 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); gw[j >> 2] |= (uint32_t)rg[p + j] << (8 * (j & 3)); }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) hw[q] &= expand4(m16 >> (4 * q));       // only possible positions count
-        }
-        double sum; uint32_t n;
-        gcw_terms16(hw, gw, sT, sW, sum, n);
-        sum += __shfl_xor(sum, 1, 64); n += __shfl_xor(n, 1, 64);
-        sum += __shfl_xor(sum, 2, 64); n += __shfl_xor(n, 2, 64);
-        if ((threadIdx.x & 3) == 0 && p < len) { wordSum[p >> 6] = sum; wordN[p >> 6] = (uint8_t)n; }
-    }
-}
-// the same sweep as one launch over every chromosome's tiles (BinChrom::tileBase numbers them): the per-chromosome launches each paid for a ramp, a tail and the table load
+// one launch over every chromosome's tiles (BinChrom::tileBase numbers them)
 __device__ __forceinline__ int gcw_find_chrom(const BinChrom* __restrict__ ch, int nchr, int64_t tile) {
     int lo = 0, hi = nchr - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ch[mid].tileBase <= tile) lo = mid; else hi = mid - 1; }
@@ -542,9 +511,9 @@ __device__ __forceinline__ int gcw_find_chrom(const BinChrom* __restrict__ ch, i
 }
 __global__ void __launch_bounds__(256) k_gcw_words_all(const BinChrom* __restrict__ ch, const GcwChrom* __restrict__ gch, int nchr, int64_t ntiles, const float* __restrict__ w, const float* __restrict__ lut) {
     __shared__ float sW[101];
-    __shared__ float sT[(GCW_HMAX + 1) * 101];
+    __shared__ double sT[(GCW_HMAX + 1) * 101];
     if (threadIdx.x < 101) sW[threadIdx.x] = w[threadIdx.x];
-    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = lut[i];
+    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = (double)lut[i];
     __syncthreads();
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int c = gcw_find_chrom(ch, nchr, tile);
@@ -578,13 +547,13 @@ __global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restric
                                                        float* __restrict__ oCount, unsigned long long* __restrict__ replayed /* [GCW_REP] replicas: bins that replayed the reference's additions */,
                                                        int serialOnly, int nchr) {
     __shared__ float sW[101];
-    __shared__ float sT[(GCW_HMAX + 1) * 101];
+    __shared__ double sT[(GCW_HMAX + 1) * 101];
     // A round was a chain of three dependent trips to memory — the bin's (chromosome, start, stop), that chromosome's pointers, the data under them — and a wave makes some
     // two hundred rounds: 74 % of its cycles waiting (SQ counters), 1.57 ms for 6.2 M bins.  The pointer tables now sit in LDS and the next round's bin is requested while this one works.
     struct Tab { const uint64_t* mask; const uint8_t* hits; const uint8_t* rg; const double* ws; const uint8_t* wn; int64_t len; };
     __shared__ Tab sTab[GCW_TAB];
     if (threadIdx.x < 101) sW[threadIdx.x] = w[threadIdx.x];
-    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = lut[i];
+    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = (double)lut[i];
     for (int i = threadIdx.x; i < nchr && i < GCW_TAB; i += 256) sTab[i] = Tab{ch[i].mask, ch[i].hits, gch[i].readGc, gch[i].wordSum, gch[i].wordN, ch[i].len};
     __syncthreads();
     auto tab = [&](int c) -> Tab { return c < GCW_TAB ? sTab[c] : Tab{ch[c].mask, ch[c].hits, gch[c].readGc, gch[c].wordSum, gch[c].wordN, ch[c].len}; };

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the per-round evidence under gpurun_out/<tag>/ on a GPU box (copy what is to be judged into profiles/):
-#   kernel summary + timeline of the bench pass, kernel summaries of the somatic flow and of the CBS probe (rocprofv3 --kernel-trace --stats), the four parity soaks.
+#   kernel summary + timeline of the bench pass, kernel summaries of the somatic flow and of the CBS probe (rocprofv3 --kernel-trace --stats), the five parity soaks.
 # usage: tools/round_profiles.sh <tag> [soak minutes]      (run from the repo root or via gpurun; every step is bounded by `timeout`)
 tag=${1:-rXX}; mins=${2:-6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$tag; mkdir -p $O
@@ -16,5 +16,6 @@ cd $R; lim=$((mins * 60 + 90))
 (timeout $lim python tools/soak_bin.py $mins 31337 2>&1 | tail -2 >> $O/soak.txt)
 (timeout $lim python tools/soak_wavelets.py $mins 31337 2>&1 | tail -2 >> $O/soak.txt)
 (timeout $lim python tools/soak_cbs.py $mins 31337 2>&1 | tail -2 >> $O/soak.txt)
+(timeout $lim python tools/soak_gcw.py $mins 31337 2>&1 | tail -1 >> $O/soak.txt)
 (CANVAS_CBS_FY_MIN_N=1024 timeout 330 python tools/soak_cbs.py 4 4242 2>&1 | tail -2 | sed -e 's/^/[k_perm_fy on every device segment] /' >> $O/soak.txt)
 cat $O/soak.txt
