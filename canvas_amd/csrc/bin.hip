@@ -811,6 +811,32 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         // per-chromosome overlap (the fence further down, which the other modes rely on, comes after these kernels)
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); ctx->up_active = false;
     }
+    // the second half of the pre-pass: histograms of the read-GC profile -> observed vs expected weights (CanvasBin.cs:372-391) -> device.  Staging in the side stream's pinned
+    // buffer ({replicas of the histograms, the 101 weights, the GcwChrom table}: pinned copies are asynchronous whatever other streams are doing)
+    bool gcwOverlap = false, gcwPending = false;
+    struct SideJoin { canvas_ctx* c; bool* pending; ~SideJoin() { if (*pending && c->side) (void)hipStreamSynchronize(c->side); } } sideJoin{ctx, &gcwPending};      // an early return leaves nothing running on the arena
+    auto gcw_finish = [&]() -> int32_t {
+        CANVAS_HIP_TRY(ctx, hipEventSynchronize(ctx->side_ev2));
+        gcwPending = false;
+        const unsigned long long* hr = (const unsigned long long*)ctx->side_pin;
+        unsigned long long hh[202];
+        for (int b = 0; b < 202; b++) { hh[b] = 0; for (int r = 0; r < RG_REP_ALL; r++) hh[b] += hr[(size_t)r * 202 + b]; }
+        if (ctx->gcw_reduce) { int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, hh, 202); if (rcr) return rcr; }      // the read-GC profile is the whole genome's (CanvasBin.cs:372-391)
+        long long sumObserved = 0, sumExpected = 0;
+        for (int b = 0; b < 101; b++) { sumExpected += (long long)hh[b]; sumObserved += (long long)hh[101 + b]; }
+        float* w = (float*)((char*)ctx->side_pin + (size_t)RG_REP_ALL * 202 * 8);
+        for (int b = 0; b < 101; b++) {
+            long long e = (long long)hh[b], o = (long long)hh[101 + b];
+            if (e == 0) e = 1;
+            if (o == 0) o = 1;
+            w[b] = ((float)o / (float)e) * ((float)sumExpected / (float)sumObserved);
+        }
+        GcwChrom* hg = (GcwChrom*)((char*)ctx->side_pin + (size_t)RG_REP_ALL * 202 * 8 + 512);
+        for (int c = 0; c < nchr; c++) hg[c] = hGch[c];
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dW, w, 101 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dGch, hg, nchr * sizeof(GcwChrom), hipMemcpyHostToDevice, ctx->stream));
+        return CANVAS_OK;
+    };
     if (gcw) {
         int64_t maxLen = 0, totLen = 0;
         for (int c = 0; c < nchr; c++) { maxLen = std::max(maxLen, h_len[c]); totLen += (h_len[c] + 255) & ~255ll; }
@@ -837,21 +863,34 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         dLut = (float*)p; p += (((GCW_HMAX + 1) * 101 * 4 + 255) & ~255);
         dGch = (GcwChrom*)p; p += ((size_t)nchr * sizeof(GcwChrom) + 255) & ~size_t(255);
         RgChrom* dRg = (RgChrom*)p;
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(sumCnt, 0, (size_t)((char*)dW - (char*)sumCnt), ctx->stream));       // fragment sums, histogram replicas, decision counters: one fill
+        // Single GPU: the pre-pass runs on the side stream and the binning sweep below (k_tile_summary ... the bin boundaries: HBM-bound, no LDS, independent of the weights) runs
+        // beside k_read_gc3, which is bound by its VALU / LDS work and leaves half of the memory bandwidth idle; the two meet in gcw_finish() in front of the weighted counts.
+        // Sharded (ctx->gcw_reduce: the reductions have their place in the ranks' exchange order) and CANVAS_GCW_NO_OVERLAP=1: everything on ctx->stream, one after the other.
+        rc0 = canvas_side_init(ctx); if (rc0) return rc0;
+        const size_t sidePinBytes = (65536 + 65544) * sizeof(double);
+        const size_t offW = (size_t)RG_REP_ALL * 202 * 8, offG = offW + 512;
+        if (offG + (size_t)nchr * sizeof(GcwChrom) > sidePinBytes) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: too many chromosomes for the pinned staging buffer");
+        gcwOverlap = !ctx->gcw_reduce && !getenv("CANVAS_GCW_NO_OVERLAP");
+        hipStream_t sp = ctx->stream;
+        if (gcwOverlap) {
+            CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev, ctx->stream)); CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));      // the inputs are ready with respect to ctx->stream
+            sp = ctx->side;
+        }
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(sumCnt, 0, (size_t)((char*)dW - (char*)sumCnt), sp));       // fragment sums, histogram replicas, decision counters: one fill
         // the chromosome table of the two genome-wide launches: tiles of RG_T positions, numbered through the chromosomes
-        rc0 = canvas_pin_reserve(ctx, (size_t)nchr * (sizeof(RgChrom) + NZ_REP * 16) + (size_t)RG_REP_ALL * 202 * 8 + 64); if (rc0) return rc0;
+        rc0 = canvas_pin_reserve(ctx, (size_t)nchr * (sizeof(RgChrom) + NZ_REP * 16) + 128); if (rc0) return rc0;
         int64_t ntileAll = 0;
         {
             RgChrom* hRg = (RgChrom*)ctx->pin;
             for (int c = 0; c < nchr; c++) { hRg[c] = RgChrom{d_bases[c], d_fraglen[c], d_hits[c], (uint8_t*)gch[c].readGc, h_len[c], ntileAll}; ntileAll += (h_len[c] + RG_T - 1) / RG_T; }
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRg, hRg, (size_t)nchr * sizeof(RgChrom), hipMemcpyHostToDevice, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRg, hRg, (size_t)nchr * sizeof(RgChrom), hipMemcpyHostToDevice, sp));
         }
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
-        hipLaunchKernelGGL(k_nonzero_mean_all, dim3((unsigned)std::min<int64_t>((int64_t)cus * 8, ntileAll)), dim3(256), 0, ctx->stream, dRg, nchr, ntileAll, sumCnt);
+        hipLaunchKernelGGL(k_nonzero_mean_all, dim3((unsigned)std::min<int64_t>((int64_t)cus * 8, ntileAll)), dim3(256), 0, sp, dRg, nchr, ntileAll, sumCnt);
         unsigned long long* hs = (unsigned long long*)((char*)ctx->pin + (((size_t)nchr * sizeof(RgChrom) + 63) & ~size_t(63)));      // (behind the table: its upload may still be reading it)
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, sumCnt, (size_t)nchr * NZ_REP * 16, hipMemcpyDeviceToHost, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, sumCnt, (size_t)nchr * NZ_REP * 16, hipMemcpyDeviceToHost, sp));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(sp));
         // MeanFragmentSize (CanvasBin.cs:164-174): NonZeroMean of the per-chromosome NonZeroMeans, all in Int16 with integer division
         long long s2 = 0, c2 = 0;
         for (int c = 0; c < nchr; c++) {
@@ -873,35 +912,18 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             const unsigned gridRg = (unsigned)(perCu * cus);
             // x / meanFrag as (x * ceil(2^40 / meanFrag)) >> 40: exact while x < 2^22 and meanFrag < 2^15 (x = 100 * count <= 100 * 32767)
             const unsigned long long mean40 = ((1ull << 40) + (unsigned long long)meanFrag - 1ull) / (unsigned long long)meanFrag;
-            ProfScope ps(ctx, "gcw_read_gc");
-            if (rg3) hipLaunchKernelGGL(k_read_gc3, dim3((unsigned)std::min<int64_t>(gridRg, ntileAll)), dim3(256), ldsRg, ctx->stream, dRg, nchr, ntileAll, meanFrag, mean40, nWmax, hist);
+            ProfScope ps(ctx, "gcw_read_gc", false, sp);
+            if (rg3) hipLaunchKernelGGL(k_read_gc3, dim3((unsigned)std::min<int64_t>(gridRg, ntileAll)), dim3(256), ldsRg, sp, dRg, nchr, ntileAll, meanFrag, mean40, nWmax, hist);
             else for (int c = 0; c < nchr; c++) {
                 const int64_t ntile = (h_len[c] + RG_T - 1) / RG_T;
-                hipLaunchKernelGGL(k_read_gc2, dim3((unsigned)std::min<int64_t>(gridRg, ntile)), dim3(256), ldsRg, ctx->stream, d_bases[c], d_fraglen[c], d_hits[c], h_len[c], meanFrag, mean40, nWmax,
+                hipLaunchKernelGGL(k_read_gc2, dim3((unsigned)std::min<int64_t>(gridRg, ntile)), dim3(256), ldsRg, sp, d_bases[c], d_fraglen[c], d_hits[c], h_len[c], meanFrag, mean40, nWmax,
                                    (uint8_t*)gch[c].readGc, hist);
             }
         }
-        unsigned long long hh[202];
-        {
-            unsigned long long* hr = (unsigned long long*)ctx->pin;
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hr, hist, (size_t)RG_REP_ALL * 202 * 8, hipMemcpyDeviceToHost, ctx->stream));
-            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            for (int b = 0; b < 202; b++) { hh[b] = 0; for (int r = 0; r < RG_REP_ALL; r++) hh[b] += hr[(size_t)r * 202 + b]; }
-            if (ctx->gcw_reduce) { int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, hh, 202); if (rcr) return rcr; }      // the read-GC profile is the whole genome's (CanvasBin.cs:372-391)
-        }
-        // observed vs expected (CanvasBin.cs:372-391)
-        long long sumObserved = 0, sumExpected = 0;
-        for (int b = 0; b < 101; b++) { sumExpected += (long long)hh[b]; sumObserved += (long long)hh[101 + b]; }
-        float w[101];
-        for (int b = 0; b < 101; b++) {
-            long long e = (long long)hh[b], o = (long long)hh[101 + b];
-            if (e == 0) e = 1;
-            if (o == 0) o = 1;
-            w[b] = ((float)o / (float)e) * ((float)sumExpected / (float)sumObserved);
-        }
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dW, w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dGch, gch.data(), nchr * sizeof(GcwChrom), hipMemcpyHostToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->side_pin, hist, (size_t)RG_REP_ALL * 202 * 8, hipMemcpyDeviceToHost, sp));
+        CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev2, sp));
+        gcwPending = true;
+        if (!gcwOverlap) { rc0 = gcw_finish(); if (rc0) return rc0; }
     }
     // the bin arrays are sized by the caller's capacity (the bin size may not be known yet)
     const int64_t ub = cap;
@@ -1111,6 +1133,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
                        tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count, 0);
     }
     if (gcw) {
+        if (gcwPending) { int32_t rcf = gcw_finish(); if (rcf) return rcf; }       // (single GPU) k_read_gc3 ran beside the kernels above
         ProfScope ps(ctx, "gcw_weighted");
         static const unsigned gridW = resident_grid((const void*)k_bin_weighted3, 256, ctx->device), gridS = resident_grid((const void*)k_gcw_words_all, 256, ctx->device);
         hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, dW, dLut);
