@@ -1135,12 +1135,18 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     if (gcw) {
         if (gcwPending) { int32_t rcf = gcw_finish(); if (rcf) return rcf; }       // (single GPU) k_read_gc3 ran beside the kernels above
         ProfScope ps(ctx, "gcw_weighted");
-        static const unsigned gridW = resident_grid((const void*)k_bin_weighted3, 256, ctx->device), gridS = resident_grid((const void*)k_gcw_words_all, 256, ctx->device);
+        // one kernel that computes every position's term once, inside the bin that owns it; CANVAS_GCW_WORDS=1 (the A/B and test hook) takes the two-kernel form of the first half
+        // of the round (per-word sums in memory, then per bin its whole words + the two end words opened again)
+        const bool fused = !getenv("CANVAS_GCW_WORDS");
+        const int serialOnly = getenv("CANVAS_GCW_SERIAL") ? 1 : 0;      // (test hook: every bin through the reference's own order of additions)
+        static const unsigned gridW = resident_grid((const void*)k_bin_weighted3<false>, 256, ctx->device), gridF = resident_grid((const void*)k_bin_weighted3<true>, 256, ctx->device),
+                              gridS = resident_grid((const void*)k_gcw_words_all, 256, ctx->device);
         hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, dW, dLut);
-        if (!getenv("CANVAS_GCW_SERIAL"))
-            hipLaunchKernelGGL(k_gcw_words_all, dim3((unsigned)std::min<int64_t>(gridS, plan.ntiles)), dim3(256), 0, ctx->stream, dCh, dGch, nchr, (int64_t)plan.ntiles, dW, dLut);
-        hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridW, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats,
-                           getenv("CANVAS_GCW_SERIAL") ? 1 : 0, nchr);      // (test hook: every bin through the reference's own order of additions)
+        if (fused) hipLaunchKernelGGL(k_bin_weighted3<true>, dim3((unsigned)std::min<int64_t>(gridF, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats, serialOnly, nchr);
+        else {
+            if (!serialOnly) hipLaunchKernelGGL(k_gcw_words_all, dim3((unsigned)std::min<int64_t>(gridS, plan.ntiles)), dim3(256), 0, ctx->stream, dCh, dGch, nchr, (int64_t)plan.ntiles, dW, dLut);
+            hipLaunchKernelGGL(k_bin_weighted3<false>, dim3((unsigned)std::min<int64_t>(gridW, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats, serialOnly, nchr);
+        }
         ctx->gcw_stats_dev = dGcStats; ctx->gcw_total = (long long)total;       // how many bins the interval decided / how many replayed the reference's additions: canvas_bin_gcw_stats
     }
     CANVAS_HIP_TRY(ctx, hipGetLastError());

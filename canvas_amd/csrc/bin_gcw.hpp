@@ -480,17 +480,27 @@ __device__ __forceinline__ void gcw_terms16(const uint32_t (&hw)[4], const uint3
     for (int q = 0; q < 4; q++) big |= ((hw[q] & 0x7F7F7F7Fu) + 0x6B6B6B6Bu) | hw[q];       // bit 7 of a byte set <=> the byte is > GCW_HMAX (20 = 0x14: 0x14 + 0x6B = 0x7F)
     big &= 0x80808080u;
     double t[16];
+    if (!big) {
+        // every hit count is inside the table: the 16 indices hit * 101 + min(readGC, 100) two at a time in packed 16-bit arithmetic (byte pairs spread by v_perm_b32, one packed
+        // minimum, one packed multiply-add) instead of seven scalar operations each
+        typedef unsigned short gcw_u16x2 __attribute__((ext_vector_type(2)));
+        const gcw_u16x2 k101 = {101, 101}, k100 = {100, 100};
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t h = (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu, gc0 = (gw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        const uint32_t gc = gc0 < 101u ? gc0 : 100u;
-        t[j] = sT[(h <= (uint32_t)GCW_HMAX ? h : 0u) * 101u + gc];
-    }
-    if (big) {          // (rare) a hit count beyond the table: the division itself
+        for (int q = 0; q < 4; q++) {
+            const uint32_t hl = __builtin_amdgcn_perm(0u, hw[q], 0x0c010c00u), hh = __builtin_amdgcn_perm(0u, hw[q], 0x0c030c02u);      // {byte0, byte1} / {byte2, byte3} as 16-bit lanes
+            const uint32_t gl = __builtin_amdgcn_perm(0u, gw[q], 0x0c010c00u), gh = __builtin_amdgcn_perm(0u, gw[q], 0x0c030c02u);
+            gcw_u16x2 vhl, vhh, vgl, vgh;
+            __builtin_memcpy(&vhl, &hl, 4); __builtin_memcpy(&vhh, &hh, 4); __builtin_memcpy(&vgl, &gl, 4); __builtin_memcpy(&vgh, &gh, 4);
+            vgl = vgl < k100 ? vgl : k100; vgh = vgh < k100 ? vgh : k100;
+            const gcw_u16x2 il = vhl * k101 + vgl, ih = vhh * k101 + vgh;
+            t[4 * q] = sT[il.x]; t[4 * q + 1] = sT[il.y]; t[4 * q + 2] = sT[ih.x]; t[4 * q + 3] = sT[ih.y];
+        }
+    } else {          // (rare) a hit count beyond the table: the division itself for those positions
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const uint32_t h = (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            if (h > (uint32_t)GCW_HMAX) { const uint32_t gc0 = (gw[j >> 2] >> (8 * (j & 3))) & 0xFFu; t[j] = (double)fminf(10.0f, (float)(int)h / sW[gc0 < 101u ? gc0 : 100u]); }
+            const uint32_t h = (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu, gc0 = (gw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t gc = gc0 < 101u ? gc0 : 100u;
+            t[j] = h <= (uint32_t)GCW_HMAX ? sT[h * 101u + gc] : (double)fminf(10.0f, (float)(int)h / sW[gc]);
         }
     }
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -542,6 +552,11 @@ __global__ void __launch_bounds__(256) k_gcw_words_all(const BinChrom* __restric
     }
 }
 // 16 lanes per bin: lanes 0-3 open the word the bin starts in, lanes 4-7 the word it ends in (when that is another one), lanes 8-15 add the sums of the words in between
+// FUSED: the bins partition the positions, so the terms of every position can be computed ONCE, by the bin that owns it — no per-word sums in memory, no end words opened a second
+// time (the two-kernel form computes 1.3 terms per position: every word once in k_gcw_words_all, the two words under a bin's ends again here).  16 lanes walk their bin 256 positions
+// at a time; a bin that spans more than GCW4_SPAN positions (centromeres, assembly gaps) is scanned by the whole wave, mask words first.
+#define GCW4_SPAN 4096
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restrict__ ch, const GcwChrom* __restrict__ gch, long long nbins, const int32_t* __restrict__ oChr,
                                                        const int32_t* __restrict__ oStart, const int32_t* __restrict__ oStop, const float* __restrict__ w, const float* __restrict__ lut,
                                                        float* __restrict__ oCount, unsigned long long* __restrict__ replayed /* [GCW_REP] replicas: bins that replayed the reference's additions */,
@@ -568,6 +583,79 @@ __global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restric
         const int64_t s = sN, e = eN;
         { const long long in = i + nwaves * 4; cN = 0; sN = 0; eN = 0; if (in < nbins) { cN = oChr[in]; sN = oStart[in]; eN = oStop[in]; } }
         double sum = 0.0; uint32_t nterms = 0;
+        if constexpr (FUSED) {
+            if (!serialOnly && live && e > s && e - s <= GCW4_SPAN) {
+                const Tab T = tab(c);
+                const gptr<const uint64_t> mask = as_global(T.mask); const gptr<const uint8_t> hits = as_global(T.hits); const gptr<const uint8_t> rg = as_global(T.rg);
+                // 16-aligned slices (the 16 mask bits of a slice lie inside one word), two slices per lane and step with all their loads in flight together: a bin of the
+                // usual size (a few hundred positions) is one step
+                auto load_slice = [&](int64_t p, uint32_t& m16, uint32_t (&hw)[4], uint32_t (&gw)[4]) {
+                    m16 = 0; hw[0] = hw[1] = hw[2] = hw[3] = 0; gw[0] = gw[1] = gw[2] = gw[3] = 0;
+                    const int64_t lo = s > p ? s : p, hi = e < p + 16 ? e : p + 16;
+                    if (lo >= hi) return;
+                    m16 = (uint32_t)((mask[p >> 6] >> (p & 63)) & 0xFFFFull) & (0xFFFFu << (lo - p)) & (0xFFFFu >> (p + 16 - hi));
+                    if (p + 16 <= T.len) {
+                        const uint4 h = gload_uint4(hits + p), gq = gload_uint4(rg + p);
+                        hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w; gw[0] = gq.x; gw[1] = gq.y; gw[2] = gq.z; gw[3] = gq.w;
+                    } else {
+                        for (int j = 0; j < 16 && p + j < T.len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); gw[j >> 2] |= (uint32_t)rg[p + j] << (8 * (j & 3)); }
+                    }
+                };
+                for (int64_t p = (s & ~15ll) + 16 * sub; p < e; p += 512) {
+                    uint32_t mA, mB, hA[4], gA[4], hB[4], gB[4];
+                    load_slice(p, mA, hA, gA);
+                    load_slice(p + 256, mB, hB, gB);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { hA[q] &= expand4(mA >> (4 * q)); hB[q] &= expand4(mB >> (4 * q)); }
+                    double ps; uint32_t pn;
+                    if (mA) { gcw_terms16(hA, gA, sT, sW, ps, pn); sum += ps; nterms += pn; }
+                    if (mB) { gcw_terms16(hB, gB, sT, sW, ps, pn); sum += ps; nterms += pn; }
+                }
+            }
+            // the long bins: the whole wave, 64 mask words per step, only words that hold a possible position are opened
+            unsigned long long longBins = __ballot(!serialOnly && live && e > s && sub == 0 && e - s > GCW4_SPAN);
+            while (longBins) {
+                const int src = __builtin_ctzll(longBins); longBins &= longBins - 1ull;
+                const long long ib = i0 + (src >> 4);
+                const int cb = oChr[ib];
+                const int64_t sB = oStart[ib], eB = oStop[ib];
+                const Tab T = tab(cb);
+                const gptr<const uint64_t> mask = as_global(T.mask); const gptr<const uint8_t> hits = as_global(T.hits); const gptr<const uint8_t> rg = as_global(T.rg);
+                const int64_t wS = sB >> 6, wE = (eB - 1) >> 6;
+                double ls = 0.0; uint32_t ln = 0;
+                for (int64_t wb = wS; wb <= wE; wb += 64) {
+                    const int64_t wq = wb + l;
+                    uint64_t mw = 0;
+                    if (wq <= wE) {
+                        mw = mask[wq];
+                        if (wq == wS) mw &= (~0ull) << (sB & 63);
+                        if (wq == wE && (eB & 63)) mw &= (~0ull) >> (64 - (eB & 63));
+                    }
+                    if (mw) {
+                        for (int q4 = 0; q4 < 4; q4++) {
+                            const uint32_t m16 = (uint32_t)(mw >> (16 * q4)) & 0xFFFFu;
+                            if (!m16) continue;
+                            const int64_t p = (wq << 6) + 16 * q4;
+                            uint32_t hw[4] = {0, 0, 0, 0}, gw[4] = {0, 0, 0, 0};
+                            if (p + 16 <= T.len) {
+                                const uint4 h = gload_uint4(hits + p), gq = gload_uint4(rg + p);
+                                hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w; gw[0] = gq.x; gw[1] = gq.y; gw[2] = gq.z; gw[3] = gq.w;
+                            } else {
+                                for (int j = 0; j < 16 && p + j < T.len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); gw[j >> 2] |= (uint32_t)rg[p + j] << (8 * (j & 3)); }
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) hw[q] &= expand4(m16 >> (4 * q));
+                            double ps; uint32_t pn;
+                            gcw_terms16(hw, gw, sT, sW, ps, pn);
+                            ls += ps; ln += pn;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { ls += __shfl_xor(ls, d, 64); ln += __shfl_xor(ln, d, 64); }
+                if (l == src) { sum += ls; nterms += ln; }
+            }
+        } else {
         if (!serialOnly && live && e > s) {
             const int64_t wS = s >> 6, wE = (e - 1) >> 6;
             if (sub < 8) {
@@ -621,6 +709,7 @@ __global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restric
                 if (l == src) { sum += ls; nterms += n4; }
             }
         }
+        }   // (!FUSED)
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) { sum += __shfl_xor(sum, d, 64); nterms += __shfl_xor(nterms, d, 64); }      // within the bin's 16 lanes
         // the float32 running sum of the reference differs from the exact sum by at most nterms roundings of half an ulp of a partial sum <= the final sum (+ its own last ulp)
