@@ -806,6 +806,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     BinPlan plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len);
     // ---- mode 5 pre-pass: mean fragment size, read-GC profile, observed/expected weights (kept in a separate allocation)
     std::vector<GcwChrom> hGch; uint8_t* gcArena = nullptr; float* dW = nullptr; GcwChrom* dGch = nullptr; unsigned long long* dGcStats = nullptr; float* dLut = nullptr; int32_t rc0 = 0;       // the arena (1 B/base read-GC profile + a prefix array) lives in the context and only grows
+    if (gcw) { ctx->gcw_stats_dev = nullptr; ctx->gcw_total = 0; }       // (set again behind the weighted kernels: a call that fails or returns early in between leaves no pointer into an arena that may have been freed and regrown)
     if (gcw && ctx->up_active) {
         // the pre-pass below reads the per-base arrays on ctx->stream: a pending canvas_upload_genome_begin of them (copy stream) has to have landed first — mode 5 has no
         // per-chromosome overlap (the fence further down, which the other modes rely on, comes after these kernels)

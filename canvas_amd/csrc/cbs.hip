@@ -1493,6 +1493,7 @@ struct PermService {
     canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
     ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
     long long rounds = 0, nArc = 0, nPermReq = 0; double secArc = 0, secPerm = 0;
+    bool probeTiming = false; double lastMs[3] = {0, 0, 0};      // canvas_cbs_perm_probe: generator (sequential + bootstrap), generator (strided), permutation + statistic of the last launch
     std::mutex mu; std::condition_variable cvWork, cvDone; std::vector<PermHostReq*> pending; bool stop = false; std::thread th; std::string err;
     explicit PermService(canvas_ctx* c) : ctx(c) { th = std::thread([this]() { run(); }); }
     ~PermService() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cvWork.notify_all(); th.join();
@@ -1571,7 +1572,7 @@ struct PermService {
             if (batch[i]->drawBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws, batch[i]->hDraws, batch[i]->drawBytes, hipMemcpyHostToDevice, stream));
         }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
-        static const bool dbg = getenv("CANVAS_CBS_DEBUG_BATCHES") != nullptr;
+        static const bool dbgEnv = getenv("CANVAS_CBS_DEBUG_BATCHES") != nullptr; const bool dbg = dbgEnv || probeTiming;
         auto tp0 = std::chrono::steady_clock::now(); double msA = 0, msB = 0;
         auto lap = [&]() { (void)hipStreamSynchronize(stream); auto t = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; return ms; };
         if (dbg) lap();
@@ -1592,7 +1593,8 @@ struct PermService {
         if (anyOld) hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         if (anyFy) hipLaunchKernelGGL(k_perm_fy, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         if (anySmall) hipLaunchKernelGGL(k_perm_small, dim3(blocks), dim3(64), 0, stream, dReqs, R);
-        if (dbg) { const double msC = lap(); int nc = 0, maxN = 0; for (int i = 0; i < R; i++) { nc += batch[i]->r.cont; maxN = std::max(maxN, batch[i]->r.n); }
+        if (probeTiming) { lastMs[0] = msA; lastMs[1] = msB; lastMs[2] = lap(); }
+        else if (dbg) { const double msC = lap(); int nc = 0, maxN = 0; for (int i = 0; i < R; i++) { nc += batch[i]->r.cont; maxN = std::max(maxN, batch[i]->r.n); }
                    fprintf(stderr, "cbs batch: %d requests (%d continued), %d permutations, longest segment %d, %d stride steps: sequential %.2f ms, strided %.2f ms, statistics %.2f ms\n", R, nc, blocks, maxN, steps, msA, msB, msC); }
         for (int i = 0; i < R; i++) {
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hStat, batch[i]->r.pstat, (size_t)batch[i]->r.nb * 16, hipMemcpyDeviceToHost, stream));
@@ -1622,6 +1624,9 @@ struct PermService {
     }
 };
 static int32_t service_submit_arc(PermService* svc, ArcHostReq& q) { return svc->submit_arc(q); }
+// where the wall time of one chromosome goes (CANVAS_CBS_TIMING): seconds waiting for / running phase 1, in the device and host permutation loops, in the edge tests
+struct ChromClock { double p1 = 0, dev = 0, host = 0, edge = 0; int segments = 0, devLoops = 0, hostLoops = 0; long long loopPerms = 0, loopBatches = 0; };
+static thread_local ChromClock tlClock;
 // The sequential stopping rule of FindChangePoints (ChangePoint.cs:337-364) over permutations evaluated in device batches.
 // Returns through `outcome`: 0 = not significant (nrej > nrejc), 1 = continue to the edge tests.  rnd ends exactly where the reference's would.
 static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int hk, int al0, double ostat, int nrejc, int k,
@@ -1683,7 +1688,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         st.ns_submit += since(tS);
         auto tP = now();
         struct PostAcc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~PostAcc() { a += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } postAcc{st.ns_post, tP};
-        st.dev_batches++;
+        st.dev_batches++; tlClock.loopBatches++;
         // generator state behind permutation b of this batch.  The device snapshot is rebuilt from the last 624 outputs in front of that point: fewer than 624 exist when a
         // batch that does not continue another one is cut short inside its first permutations (segments of a few hundred bins) — then the batch's start state is advanced on
         // the host, at most 623 draws.
@@ -1707,7 +1712,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
             }
         }
         for (int b = 0; b < nb; b++) {
-            np++;
+            np++; tlClock.loopPerms++;
             st.perms++; st.perm_elems += n; st.dev_perms++;
             bool rej;
             const double lo = hStat[2 * b], hi = hStat[2 * b + 1];
@@ -1801,9 +1806,6 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
 //            order, on the chromosome's thread.
 // Every segment that reaches the stack is processed sooner or later, so nothing is computed that the sequential order would not compute; the results and the number of
 // random numbers drawn are the reference's.  (Before: per chromosome a chain arc search -> tail probability -> permutation batches, every link a launcher round trip.)
-// where the wall time of one chromosome goes (CANVAS_CBS_TIMING): seconds waiting for / running phase 1, in the device and host permutation loops, in the edge tests
-struct ChromClock { double p1 = 0, dev = 0, host = 0, edge = 0; int segments = 0, devLoops = 0, hostLoops = 0; };
-static thread_local ChromClock tlClock;
 struct Phase1 {
     int32_t rc = CANVAS_OK; int cn = 0; bool trivial = false;          // fewer than 2 * minWidth values, or constant data: no change point
     std::vector<double> cur, sx; double tss = 0; bool hybrid = false; double delta = 0;
@@ -1872,7 +1874,11 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
             Acc acc{st.ns_dev, t0};
             struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.devLoops++; } } lc{t0};
             int outcome = 1;
+            tlClock.loopPerms = 0; tlClock.loopBatches = 0;
             int32_t rc = perm_loop_gpu(PG, gd, n, tss, nPerm, hk, al0, ostat, nrejc, k, sbdry, rnd, st, outcome); if (rc) return rc;
+            { static const bool logLoops = getenv("CANVAS_CBS_TIMING") && atoi(getenv("CANVAS_CBS_TIMING")) >= 2;
+              if (logLoops) fprintf(stderr, "cbs loop: n %d nrejc %d stop-if-no-rejection %u outcome %d seconds %.4f perms %lld batches %lld\n", n, nrejc, sbdry[(size_t)k - 1], outcome,
+                                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), tlClock.loopPerms, tlClock.loopBatches); }
             if (outcome == 0) return CANVAS_OK;
         } else if (!hybrid && n <= 200 && n >= 4 && PG.svc && getenv("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr && getenv("CANVAS_CBS_HOST_SMALL") == nullptr) {
             Acc acc{st.ns_dev, t0};
@@ -2130,6 +2136,40 @@ extern "C" int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h
     if ((int64_t)sb.size() > cap) return CANVAS_ERR_CAPACITY;
     for (size_t i = 0; i < sb.size(); i++) h_out[i] = sb[i];
     return (int64_t)sb.size();
+}
+// Diagnostic / test entry: ONE batch of nb permutations of the (centred) segment h_x[n] through the device permutation engine, exactly as FindChangePoints' hybrid test
+// runs it (XPerm + HTMaxP with hk = 25, al0 = 2; ChangePoint.cs:337-364,407-421; CBSTStatistic.cs:354-586) from a generator seeded with `seed`.  kernel: 0 = k_perm_stat,
+// 1 = k_perm_fy.  h_lohi[2 nb]: the interval of every permutation's statistic (the exact value lies inside); h_ms3: milliseconds of the generator's sequential part, of its
+// strided part and of the permutation + statistic kernel.  tests/test_cbs_gpu.py compares the intervals with the oracle's XPerm + HTMaxP; tools/perm_probe.py times the kernels.
+extern "C" int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int32_t n, uint32_t seed, int32_t nb, int32_t kernel, double tss, double* h_lohi, double* h_ms3) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (!h_x || !h_lohi || n < 1024 || nb < 1 || (kernel != 0 && kernel != 1) || (long long)n * nb > (1ll << 30)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs_perm_probe: bad arguments (n >= 1024, n * nb <= 2^30, kernel 0 or 1)");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    cbs::PermService svc(ctx); svc.probeTiming = true;
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t e = (size_t)nb * n, e1 = (size_t)nb * (n + 1);
+    const size_t oX = 0, oSnaps = oX + al((size_t)n * 8), oStat = oSnaps + al((size_t)nb * 625 * 4), oDraws = oStat + al((size_t)nb * 16), oJ = oDraws + al((e + (size_t)MT_HISTORY) * 4), oOff = oJ + al(e * 4),
+                 oCur = oOff + al(kernel == 0 ? e1 * 4 : 0), oItems = oCur + al(kernel == 0 ? e1 * 4 : 0), oG = oItems + al(kernel == 0 ? e * 4 : 0), oSucc = oG + al(kernel == 0 ? e * 4 : 0), oPx = oSucc + al(kernel == 0 ? e * 4 : 0),
+                 oSx = oPx + al(e * 8), total = oSx + al(kernel == 0 ? e * 8 : 0);
+    char* d = nullptr; char* h = nullptr;
+    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&d, total));
+    struct Free { char*& d; char*& h; ~Free() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); } } fr{d, h};
+    const size_t pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)nb * 625 * 4);
+    CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&h, pStat + al((size_t)nb * 16), hipHostMallocDefault));
+    memcpy(h, h_x, (size_t)n * 8);
+    double absSum = 0.0; for (int i = 0; i < n; i++) absSum += std::fabs(h_x[i]);
+    cbs::PermHostReq q;
+    { cbs::MT m(seed); m.get_state(q.r.state); }
+    q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = (uint32_t*)(d + oSnaps); q.r.x = (double*)(d + oX); q.r.hk = 25; q.r.al0 = 2; q.r.tss = tss;
+    q.r.errBound = 4.04 * (double)(n + 8) * 1.1102230246251565e-16 * absSum;
+    q.r.P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY; q.r.P.j = (int32_t*)(d + oJ); q.r.P.off = (int32_t*)(d + oOff); q.r.P.cur = (int32_t*)(d + oCur); q.r.P.items = (int32_t*)(d + oItems);
+    q.r.P.g = (int32_t*)(d + oG); q.r.P.succ = (int32_t*)(d + oSucc); q.r.P.px = (double*)(d + oPx); q.r.P.sx = (double*)(d + oSx);
+    q.r.pstat = (double*)(d + oStat); q.r.blockBase = 0; q.r.cont = 0; q.r.fy = kernel; q.hStat = (double*)(h + pStat); q.hSnaps = (uint32_t*)(h + pSnaps);
+    q.hX = (const double*)h; q.dX = (double*)(d + oX); q.xBytes = (size_t)n * 8;
+    int32_t rc = svc.submit(q); if (rc) return rc;
+    memcpy(h_lohi, q.hStat, (size_t)nb * 16);
+    if (h_ms3) for (int i = 0; i < 3; i++) h_ms3[i] = svc.lastMs[i];
+    return CANVAS_OK;
 }
 extern "C" int32_t canvas_cbs_tailp_stats(canvas_ctx* ctx, int64_t* h_out2) {
     if (!ctx || !h_out2) return CANVAS_ERR_INVALID;

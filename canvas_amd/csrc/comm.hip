@@ -44,6 +44,8 @@ extern "C" {
 int32_t canvas_comm_init_host(canvas_ctx* ctx, int32_t rank, int32_t nranks, canvas_host_allgather_fn fn, void* user) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_comm_init_host: bad arguments");
+    if (ctx->comm_parent) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_comm_init_host: inside a sub-communicator (canvas_comm_restore first)");
+    if (ctx->comm) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)ncclCommDestroy((ncclComm_t)ctx->comm); }      // the host transport replaces an RCCL communicator: it is released, not dropped
     ctx->comm = nullptr; ctx->rank = rank; ctx->nranks = nranks; ctx->host_allgather = fn; ctx->host_allgather_user = user;
     return CANVAS_OK;
 }
@@ -60,11 +62,13 @@ int32_t canvas_comm_unique_id(void* h_id128) {
 int32_t canvas_comm_init(canvas_ctx* ctx, int32_t rank, int32_t nranks, const void* h_id128) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nranks < 1 || rank < 0 || rank >= nranks || !h_id128) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_comm_init: bad arguments");
+    if (ctx->comm_parent) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_comm_init: inside a sub-communicator (canvas_comm_restore first)");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ncclUniqueId id;
     memcpy(&id, h_id128, 128);
     ncclComm_t comm;
     CANVAS_NCCL_TRY(ctx, ncclCommInitRank(&comm, nranks, id, rank));
+    if (ctx->comm) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)ncclCommDestroy((ncclComm_t)ctx->comm); }      // re-initialisation: the previous communicator is released
     ctx->comm = (void*)comm; ctx->rank = rank; ctx->nranks = nranks;
     return CANVAS_OK;
 }
@@ -83,8 +87,8 @@ int32_t canvas_comm_split(canvas_ctx* ctx, int32_t color, int32_t key) {
     ncclComm_t sub = nullptr;
     CANVAS_NCCL_TRY(ctx, ncclCommSplit((ncclComm_t)ctx->comm, color, key, &sub, nullptr));
     int r = 0, n = 0;
-    CANVAS_NCCL_TRY(ctx, ncclCommUserRank(sub, &r));
-    CANVAS_NCCL_TRY(ctx, ncclCommCount(sub, &n));
+    { const ncclResult_t e1 = ncclCommUserRank(sub, &r), e2 = e1 == ncclSuccess ? ncclCommCount(sub, &n) : e1;
+      if (e2 != ncclSuccess) { (void)ncclCommDestroy(sub); ctx->err = std::string("canvas_comm_split: rank / size of the sub-communicator: ") + ncclGetErrorString(e2); return CANVAS_ERR_COMM; } }
     ctx->comm_parent = ctx->comm; ctx->rank_parent = ctx->rank; ctx->nranks_parent = ctx->nranks;
     ctx->comm = (void*)sub; ctx->rank = r; ctx->nranks = n;
     return CANVAS_OK;
@@ -112,6 +116,12 @@ int32_t canvas_allgather_boundaries(canvas_ctx* ctx, const int32_t* d_local, int
 }
 
 }  // extern "C"
+
+// canvas_destroy: the sub-communicator (if the context dies inside one) and the communicator itself
+void cvx_comm_destroy(canvas_ctx* ctx) {
+    if (ctx->comm_parent) { if (ctx->comm) (void)ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = ctx->comm_parent; ctx->comm_parent = nullptr; }
+    if (ctx->comm) { (void)ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
+}
 
 // the gather itself; nlocal < 0: this rank has failed and announces its (negative) error code in the count slot, with no records (canvas_sample_pipeline_sharded)
 int32_t cvx_allgather_boundaries_status(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank, int32_t* d_all, int32_t* h_counts) {

@@ -150,6 +150,7 @@ static inline int32_t canvas_pin_reserve(canvas_ctx* ctx, size_t bytes) {
 CVX_INTERNAL int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 // canvas_allgather_boundaries with a status: nlocal < 0 announces a failed rank (its error code travels in the count slot, no records)
 CVX_INTERNAL int32_t cvx_allgather_boundaries_status(canvas_ctx* ctx, const int32_t* d_local, int32_t nlocal, int32_t max_per_rank, int32_t* d_all, int32_t* h_counts);
+CVX_INTERNAL void cvx_comm_destroy(canvas_ctx* ctx);      // comm.hip: releases the (sub-)communicator of a context that is being destroyed
 // canvas_quantize_f2 fused with the counting of the genome-wide quartiles PerSampleHMM starts from (the same sweep); the result travels to *h_covq_out (pinned, valid after the
 // next synchronisation of ctx->stream) and is handed to cvx_hmm_per_sample_preq, which then needs neither the counting sweep nor a round trip of its own
 CVX_INTERNAL int32_t cvx_quantize_f2_covq(canvas_ctx* ctx, const float* d_count, int64_t n, double* d_cov, const void** h_covq_out);

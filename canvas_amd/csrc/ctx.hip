@@ -26,6 +26,7 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    cvx_comm_destroy(ctx);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
     for (auto e : ctx->up_ev) (void)hipEventDestroy(e);

@@ -269,6 +269,12 @@ int32_t canvas_cbs_tpermp_stats(canvas_ctx* ctx, int64_t* h_out2);
  * FindChangePoints (ChangePoint.cs:318-323).  [0] calls decided from the device evaluation of its series (accepted only when every value within 1e-8 relative gives the same
  * decisions), [1] calls recomputed with the host libm in the reference's order. */
 int32_t canvas_cbs_tailp_stats(canvas_ctx* ctx, int64_t* h_out2);
+/* Diagnostic / test entry: ONE batch of nb permutations of the centred segment h_x[n] (n >= 1024, n * nb <= 2^30) through the device permutation engine exactly as the hybrid test of
+ * FindChangePoints runs it — XPerm (ChangePoint.cs:407-421) + HTMaxP with k = 25, minimum width 2 (CBSTStatistic.cs:354-586) — from MersenneTwister(seed).  kernel selects the
+ * permutation kernel: 0 counting sort + pointer doubling, 1 block-wise simulation of the swaps in global memory, 2 range-partitioned simulation in LDS.  h_lohi[2 nb]: the interval
+ * the engine returns for every permutation's statistic (the exact value lies inside; the stopping rule re-evaluates a permutation on the host only when the observed statistic does too).
+ * h_ms3 (optional): milliseconds of the generator's sequential part, its strided part, and the permutation + statistic kernel.  No reference counterpart: the engine's test bench. */
+int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int32_t n, uint32_t seed, int32_t nb, int32_t kernel, double tss, double* h_lohi, double* h_ms3);
 /* Host-only (no context, no GPU): the sequential stopping boundary canvas_cbs uses for (nperm, alpha) — GetBoundary.ComputeBoundary (GetBoundary.cs:19-157) with eta = 0.05 as
  * CBSRunner passes it: maxOnes (maxOnes + 1) / 2 entries with maxOnes = floor(nperm alpha) + 1.  Returns the number of entries (or a negative error code).  The library
  * evaluates the table's scans on its host thread pool with the scans' own evaluations and comparisons; exposed so that the table can be checked without a device. */
