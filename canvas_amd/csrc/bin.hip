@@ -1034,10 +1034,13 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         // enqueued behind them; the host reads the decisions back while those run
         const int binSizeArg = !needRates ? bin_size : (hook ? -1 : 0);
         const uint32_t* obsArr = needRates ? tileObs : (const uint32_t*)nullptr;
+        unsigned* hBdSeq = (unsigned*)((char*)ctx->pin + oBd + sizeof(BinDev));       // the decisions' mailbox stamp (cvx_mail_*, common.hpp)
+        const unsigned bdSeq = hook ? 0u : cvx_mail_arm(ctx, hBdSeq);
         hipLaunchKernelGGL(k_tscan_reduce, dim3((unsigned)(nchunks + nchr)), dim3(TS_T), 0, ctx->stream, dCh, nchr, dPos0, packed ? 1 : 0, plan.ntiles, nchunks, tilePop, obsArr, tileTotC, tileTotG,
                            tsPart, tsPartEx, dPopBefore, dTick);
         hipLaunchKernelGGL(k_tscan_apply, dim3((unsigned)nchunks), dim3(TS_T), 0, ctx->stream, dCh, nchr, plan.ntiles, nchunks, tilePop, obsArr, tileTotC, tileTotG, rankRaw, tsPartEx, dPopBefore, chrPre,
-                           dIsAuto, counts_per_bin, binSizeArg, (long long)cap, dOut, chrDev, binOffset, dBd, dTick + 1, hook ? (ChromOut*)nullptr : hOut, hook ? (BinDev*)nullptr : (BinDev*)((char*)ctx->pin + oBd));
+                           dIsAuto, counts_per_bin, binSizeArg, (long long)cap, dOut, chrDev, binOffset, dBd, dTick + 1, hook ? (ChromOut*)nullptr : hOut, hook ? (BinDev*)nullptr : (BinDev*)((char*)ctx->pin + oBd),
+                           hBdSeq, bdSeq);
         auto launch_close_resolve = [&]() {
             // (measured and dropped: close + resolve + finalize fused into one kernel — a wave collects its boundaries as tasks in LDS and resolves them densely — 376 us + a
             //  fix-up pass for each wave's first bin against 87 + 317 us for the two kernels below: the resolve is bound by the 128-byte line fills under the boundaries either way)
@@ -1074,6 +1077,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->bin_ev, ctx->stream));
             launch_close_resolve();
             CANVAS_HIP_TRY(ctx, hipEventSynchronize(ctx->bin_ev));       // the decisions are on the host; close / resolve are still running
+            { int32_t rcm = cvx_mail_await(ctx, hBdSeq, bdSeq, "canvas_bin: bin size and totals"); if (rcm) return rcm; }
             if (needRates && (hBd->flags & (BD_BAD_RATE | BD_TOO_MANY))) {
                 // an autosome without possible positions, or more autosomes than the device sort holds: decided here as before (the kernels above did nothing)
                 std::vector<double> rates;

@@ -144,7 +144,8 @@ __device__ __forceinline__ unsigned long long ts_block_excl_u64(unsigned long lo
 // bins per chromosome and their offsets for a given bin size (the last lines of SampleHitArrays / BinCounts: every chromosome yields floor(possible after pos0 / binSize) bins)
 // hostOut / hostBd (optional): the same results written straight into pinned host memory (visible to the host once the kernel has completed: no D2H copy behind the kernel)
 __device__ void plan_offsets(int nchr, const ChromOut* __restrict__ totals /* pop, popBefore valid */, ChromOut* __restrict__ dOut, long long* __restrict__ binOffset, BinDev* __restrict__ bd,
-                             int binSize, long long cap, int flags, int nAuto, unsigned long long* sh16, ChromOut* __restrict__ hostOut = nullptr, BinDev* __restrict__ hostBd = nullptr) {
+                             int binSize, long long cap, int flags, int nAuto, unsigned long long* sh16, ChromOut* __restrict__ hostOut = nullptr, BinDev* __restrict__ hostBd = nullptr,
+                             unsigned* __restrict__ hostSeq = nullptr, unsigned seq = 0) {
     const int tid = threadIdx.x;
     const int per = (nchr + TS_T - 1) / TS_T;
     const int cA = tid * per < nchr ? tid * per : nchr, cB = cA + per < nchr ? cA + per : nchr;
@@ -157,15 +158,14 @@ __device__ void plan_offsets(int nchr, const ChromOut* __restrict__ totals /* po
         binOffset[c] = (long long)run; dOut[c].nbins = nb; run += (unsigned long long)nb;
         if (hostOut) { ChromOut o = totals[c]; o.nbins = nb; hostOut[c] = o; }
     }
-    if (hostOut) __threadfence_system();      // (results in pinned host memory are read behind an event: the fence puts them there before the kernel can be seen as complete —
-                                              // without it a report of canvas_wavelets' level loop was, rarely, read before it had arrived)
+    if (hostOut) { __threadfence_system(); __syncthreads(); }      // (every thread's rows are in host memory before thread 0 stamps the mailbox: cvx_mail_publish, common.hpp)
     if (tid == 0) {
         binOffset[nchr] = (long long)total;
         if (binSize > 0 && (long long)total > cap) flags |= BD_CAPACITY;
         BinDev o; o.binSize = binSize; o.run = (binSize > 0 && !(flags & BD_CAPACITY)) ? 1 : 0;
         o.binMagic = binSize > 1 ? ~0ull / (unsigned long long)binSize + 1ull : 0ull; o.total = (long long)total; o.flags = flags; o.nAuto = nAuto;
         *bd = o;
-        if (hostBd) { *hostBd = o; __threadfence_system(); }
+        if (hostBd) { *hostBd = o; cvx_mail_publish(hostSeq, seq); }
     }
 }
 __global__ void __launch_bounds__(TS_T) k_bin_plan(int nchr, ChromOut* __restrict__ dOut, long long* __restrict__ binOffset, BinDev* __restrict__ bd, int binSize, long long cap) {
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(TS_T) k_tscan_apply(const BinChrom* __restrict
                                                       const TsPart* __restrict__ partEx, const unsigned long long* __restrict__ popBefore, TsPart* __restrict__ chrPre,
                                                       const uint8_t* __restrict__ isAuto, int countsPerBin, int binSizeArg, long long cap,
                                                       ChromOut* __restrict__ dOut, ChromDev* __restrict__ chrDev, long long* __restrict__ binOffset, BinDev* __restrict__ bd,
-                                                      uint32_t* __restrict__ tick, ChromOut* __restrict__ hostOut, BinDev* __restrict__ hostBd) {
+                                                      uint32_t* __restrict__ tick, ChromOut* __restrict__ hostOut, BinDev* __restrict__ hostBd, unsigned* __restrict__ hostSeq, unsigned seq) {
     __shared__ U2 sh2[2][16];
     __shared__ int sLast, sCA;
     __shared__ unsigned long long sh16[16];
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(TS_T) k_tscan_apply(const BinChrom* __restrict
     }
     if (binSizeArg < 0) return;        // k_bin_plan follows
     __syncthreads();
-    plan_offsets(nchr, dOut, dOut, binOffset, bd, sBinSize, cap, sFlags, sN, sh16, hostOut, hostBd);
+    plan_offsets(nchr, dOut, dOut, binOffset, bd, sBinSize, cap, sFlags, sN, sh16, hostOut, hostBd, hostSeq, seq);
 }
 
 // ---- k_bin_close with the decisions read on the device.  The record of a bin: where it closes (word start | rank inside the word - 1) and the masked-hit / G/C sums of the

@@ -296,7 +296,10 @@ struct PermReq {
     uint32_t state[625];       // generator state at the start of the batch: mt[624], mti
     long long total; int n; int nb; uint32_t* snaps; const double* x; int hk, al0; double tss, errBound; PermBuf P; double* pstat; int blockBase;
     int cont;                  // the MT_HISTORY outputs in front of P.draws are the tail of the previous batch: no sequential part needed
-    int fy;                    // 1: k_perm_fy evaluates this request's permutations, 0: k_perm_stat
+    int fy;                    // 0: k_perm_stat, 1: k_perm_fy, 2: k_perm_small, 3: k_perm_rp evaluates this request's permutations
+    // k_perm_rp: rpWGs persistent workgroups (blocks rpBase .. rpBase + rpWGs of its launch), each with its own scratch of rp.stride words behind rpScratch
+    int rpBase, rpWGs; uint32_t* rpScratch; long long* rpClk;      // rpClk (probe only): cycles of workgroup 0 per phase
+    struct RpPlan { int K, nT; uint32_t inOff[32], inCap[32]; uint32_t oEndsIn, oEndsOwn, oInbox, oOutIn, oOutOwn, stride; } rp;
 };
 // MT19937 is linear over GF(2): every bit of its output stream obeys the recurrence of the characteristic polynomial phi (degree 19937,
 // 135 terms), i.e. out[k] = XOR_i out[k - MT_LAG[i]]; and because phi(x)^(2^m) = phi(x^(2^m)) over GF(2) the same holds with every
@@ -761,6 +764,328 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
     if (sOver) { if (tid == 0) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; } return; }
     __syncthreads();
     perm_stat_tail(px, sx, n, R.hk, R.al0, R.tss, R.errBound, R.pstat, b, shD, shM, sT, sEdge);
+}
+
+// ---- Fisher-Yates with every position in LDS (k_perm_rp; replaces k_perm_fy and, from 1024 bins on, k_perm_stat).  k_perm_fy keeps the index array of a permutation in global
+// memory: every step reads and writes one scattered word of it, and a block of steps is a chain of dependent global round trips (read what lies under the targets, write, read
+// the next block's own positions) — 21 G elements/s with the whole device busy, which made the permutation loops of a tumour / normal sample (10 G elements) device-bound.
+// Here the positions are cut into RANGES of 16 384 that are processed from the top one down, each entirely in LDS:
+//   * a step i swaps a[i] with a[t], t <= i.  If t lies in a LOWER range the step only needs the value under i (V) now; what lies under t is owed to position i by the range that
+//     holds t.  The step appends the message (i, t, V) to that range's inbox and is done.  All steps of the ranges above a range precede its own steps in time, so the range first
+//     applies its inbox (old = a[t]; a[t] = V; "position i receives old"), then runs its own steps; nothing ever flows upwards except those results.
+//   * steps run in blocks that never straddle a multiple of 2048 (a "tile").  Two steps of a block commute unless they share a position; the targets inside the range are marked
+//     in a bitmap of the range (exact, no hashing: the range is the bitmap's domain), steps that share nothing run at once, the others are replayed in the reference's order by
+//     rounds (a step waits for the latest earlier step on each of its two positions).  Messages of an inbox are applied the same way: those that are alone on their position at
+//     once, the others chained by their time stamps.  The last 2048 steps, where everything depends on everything, are run by one wave, 64 steps at a time, wave-synchronously.
+//   * results ("position i holds value old") are appended to streams in tile order — the inbox results at the index of their message, the own results per tile — so the statistic
+//     finds the values of a tile as a handful of contiguous segments: it scatters x[old] into an LDS tile and forms prefix sums and arcs as perm_stat_tail does.
+// Per element: 4 bytes of draws, 8 + 8 bytes of message, 4 + 4 bytes of result, one gather from x (L2-resident) — streams instead of two scattered 128-byte line fills.  The
+// permutation is the reference's (integer logic); the statistic is an interval as before.  An inbox that outgrows its (generous) capacity, or a block with more than RP_CMAX
+// ordered steps, gives the permutation up: [-inf, inf], the host evaluates it in the reference's order.
+#define RP_R 16384
+#define RP_RSHIFT 14
+#define RP_T PG_T
+#define RP_SPT 4
+#define RP_BK (RP_T * RP_SPT)             // 2048 = PT_TILE
+#define RP_TPR (RP_R / RP_BK)
+#define RP_MAXK 32                         // n <= 524 288
+#define RP_MAXT (RP_MAXK * RP_TPR)
+#define RP_CMAX 448
+#define RP_TAIL 2048                       // the last steps: one wave
+static_assert(RP_BK == PT_TILE, "a block of steps is a tile of the statistic");
+__device__ __forceinline__ int rp_target(const uint32_t* __restrict__ draws, int n, int i) {      // ChangePoint.cs:411-419: the draw of step i is draws[n - 1 - i]
+    const double cc = (double)draws[n - 1 - i] * (1.0 / 4294967296.0);
+    int tt = (int)(cc * (double)(i + 1)); return tt > i ? i : tt;
+}
+__global__ void __launch_bounds__(RP_T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_perm_rp(const PermReq* __restrict__ reqs, int nreq) {
+    // FY phase: sA 64 KB | two bitmaps | four lists | deps | row of the inbox table;   statistic: tile of values | prefix tile | the tables | maxima
+    __shared__ __align__(16) unsigned char sRaw[65536 + 2048 + 2048 + 4 * RP_CMAX * 4 + 2 * RP_CMAX * 2 + RP_CMAX + (RP_MAXT + 1) * 4 + 64];
+    __shared__ uint32_t sCnt[RP_MAXK], sInOff[RP_MAXK], sInCap[RP_MAXK];
+    __shared__ uint32_t sOwn; __shared__ int sNC, sOver;
+    int32_t* sA = reinterpret_cast<int32_t*>(sRaw);
+    uint32_t* sTb = reinterpret_cast<uint32_t*>(sRaw + 65536); uint32_t* sDb = sTb + 512;
+    int32_t* sCI = reinterpret_cast<int32_t*>(sDb + 512); int32_t* sCT = sCI + RP_CMAX; uint32_t* sCV = reinterpret_cast<uint32_t*>(sCT + RP_CMAX); uint32_t* sCJ = sCV + RP_CMAX;
+    int16_t* sDep1 = reinterpret_cast<int16_t*>(sCJ + RP_CMAX); int16_t* sDep2 = sDep1 + RP_CMAX; uint8_t* sDone = reinterpret_cast<uint8_t*>(sDep2 + RP_CMAX);
+    uint32_t* sRow = reinterpret_cast<uint32_t*>(sRaw + 65536 + 4096 + 4 * RP_CMAX * 4 + 2 * RP_CMAX * 2 + RP_CMAX);
+    int ri = 0;
+    { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].rpBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
+    const PermReq& R = reqs[ri];
+    if (R.fy != 3) return;
+    const int w = (int)blockIdx.x - R.rpBase, tid = threadIdx.x, lane = tid & 63;
+    if (w >= R.rpWGs) return;
+    const int n = R.n, K = R.rp.K, nT = R.rp.nT;
+    const double* __restrict__ x = R.x;
+    uint32_t* scr = R.rpScratch + (size_t)w * R.rp.stride;
+    uint32_t* endsIn = scr + R.rp.oEndsIn; uint32_t* endsOwn = scr + R.rp.oEndsOwn; uint2* inbox = reinterpret_cast<uint2*>(scr + R.rp.oInbox); uint32_t* outIn = scr + R.rp.oOutIn; uint32_t* outOwn = scr + R.rp.oOutOwn;
+    auto bit = [](const uint32_t* m, int p) -> bool { return (m[p >> 5] >> (p & 31)) & 1u; };
+    if (tid < RP_MAXK) { sInOff[tid] = R.rp.inOff[tid]; sInCap[tid] = R.rp.inCap[tid]; }
+    long long* clk = (w == 0 && tid == 0) ? R.rpClk : nullptr; long long tClk = clk ? clock64() : 0;
+    auto lapc = [&](int slot) { if (clk) { const long long t = clock64(); clk[slot] += t - tClk; tClk = t; } };
+    for (int b = w; b < R.nb; b += R.rpWGs) {
+        const uint32_t* __restrict__ draws = R.P.draws + (size_t)b * n;
+        if (tid < RP_MAXK) sCnt[tid] = 0u;
+        if (tid == 0) { sOwn = 0u; sOver = 0; endsOwn[nT] = 0u; }
+        if (tid < K - 1) endsIn[(size_t)tid * (nT + 1) + nT] = 0u;
+        __syncthreads();
+        for (int k = K - 1; k >= 0; k--) {
+            const int lo = k << RP_RSHIFT, hi = n < lo + RP_R ? n : lo + RP_R;
+            for (int p = tid; p < hi - lo; p += RP_T) sA[p] = lo + p;
+            sTb[tid] = 0u; sDb[tid] = 0u;
+            if (k < K - 1) for (int t = tid; t <= nT; t += RP_T) sRow[t] = endsIn[(size_t)k * (nT + 1) + t];
+            __syncthreads();
+            lapc(0);
+            // ---- the inbox: everything the ranges above owe to / want from this range, in chunks of whole producer tiles (inside a chunk the time stamps order the messages)
+            if (k < K - 1) {
+                const uint2* __restrict__ ib = inbox + sInOff[k]; uint32_t* __restrict__ ob = outIn + sInOff[k];
+                const int tauLo = (k + 1) * RP_TPR;
+                int tau = nT - 1; uint32_t c0 = 0u;
+                while (tau >= tauLo) {
+                    int t2 = tau; uint32_t c1 = sRow[t2];
+                    while (t2 - 1 >= tauLo && sRow[t2 - 1] - c0 <= (uint32_t)RP_BK) { t2--; c1 = sRow[t2]; }
+                    if (c1 > c0) {
+                        uint2 m[RP_SPT]; bool valid[RP_SPT];
+#pragma unroll
+                        for (int q = 0; q < RP_SPT; q++) { const uint32_t j = c0 + (uint32_t)(q * RP_T + tid); valid[q] = j < c1; m[q] = valid[q] ? ib[j] : make_uint2(0u, 0u); }
+#pragma unroll
+                        for (int q = 0; q < RP_SPT; q++) if (valid[q]) { const int tl = (int)(m[q].y & 16383u); const uint32_t bt = 1u << (tl & 31); const uint32_t old = atomicOr(&sTb[tl >> 5], bt); if (old & bt) atomicOr(&sDb[tl >> 5], bt); }
+                        if (tid == 0) sNC = 0;
+                        __syncthreads();
+#pragma unroll
+                        for (int q = 0; q < RP_SPT; q++) if (valid[q]) {
+                            const uint32_t j = c0 + (uint32_t)(q * RP_T + tid); const int tl = (int)(m[q].y & 16383u); const uint32_t v = m[q].x & 0xFFFFFu, io = m[q].x >> 20;
+                            if (!bit(sDb, tl)) { const int old = sA[tl]; sA[tl] = (int)v; ob[j] = (uint32_t)old | (io << 20); }
+                            else { const int sidx = atomicAdd(&sNC, 1); if (sidx < RP_CMAX) { sCI[sidx] = (int)(((m[q].y >> 14) << 11) | io); sCT[sidx] = tl; sCV[sidx] = v; sCJ[sidx] = j; } }
+                        }
+                        __syncthreads();
+                        const int nC = sNC;
+                        if (nC > RP_CMAX) { if (tid == 0) sOver = 1; }
+                        else if (nC > 0) {
+                            bool last = false; int tlE = 0; uint32_t vE = 0u;
+                            if (tid < nC) {
+                                const int iE = sCI[tid]; tlE = sCT[tid]; vE = sCV[tid];
+                                int pred = -1, predI = 0x7fffffff; bool succ = false;
+                                for (int f = 0; f < nC; f++) if (sCT[f] == tlE && f != tid) { const int iF = sCI[f]; if (iF > iE) { if (iF < predI) { predI = iF; pred = f; } } else succ = true; }
+                                const uint32_t old = pred >= 0 ? sCV[pred] : (uint32_t)sA[tlE];
+                                ob[sCJ[tid]] = old | ((uint32_t)(iE & 2047) << 20);
+                                last = !succ;
+                            }
+                            __syncthreads();
+                            if (last) sA[tlE] = (int)vE;
+                        }
+                        __syncthreads();
+                        sTb[tid] = 0u; sDb[tid] = 0u;
+                        __syncthreads();
+                    }
+                    c0 = c1; tau = t2 - 1;
+                }
+            }
+            lapc(1);
+            // ---- the range's own steps, hi - 1 down to lo (the last RP_TAIL of range 0 further down)
+            const int stop = k == 0 ? (hi < RP_TAIL ? hi : RP_TAIL) : lo;
+            int I1 = hi;
+            auto emit_own = [&](int i, int val) { const uint32_t sidx = atomicAdd(&sOwn, 1u); outOwn[sidx] = (uint32_t)val | ((uint32_t)(i & 2047) << 20); };
+            auto exec = [&](int i, int tt, int tau) {
+                const int v = sA[i - lo];
+                if (tt == i) emit_own(i, v);
+                else if (tt < lo) {
+                    const int d = tt >> RP_RSHIFT; const uint32_t sidx = atomicAdd(&sCnt[d], 1u);
+                    if (sidx < sInCap[d]) inbox[sInOff[d] + sidx] = make_uint2((uint32_t)v | ((uint32_t)(i & 2047) << 20), (uint32_t)(tt & 16383) | ((uint32_t)tau << 14));
+                    else sOver = 1;
+                } else { const int old = sA[tt - lo]; sA[tt - lo] = v; emit_own(i, old); }
+            };
+            while (I1 > stop) {
+                const int tileBase = ((I1 - 1) >> 11) << 11, tau = tileBase >> 11;
+                int I0 = tileBase > stop ? tileBase : stop;
+                if (k == 0) { int bk = (int)(8.0 * sqrt((double)I1)); bk = bk < 64 ? 64 : (bk > RP_BK ? RP_BK : bk); if (I1 - bk > I0) I0 = I1 - bk; }
+                const int Bk = I1 - I0;
+                int t[RP_SPT];
+#pragma unroll
+                for (int q = 0; q < RP_SPT; q++) {
+                    const int kk = tid * RP_SPT + q; t[q] = -1;
+                    if (kk < Bk) {
+                        const int i = I1 - 1 - kk, tt = rp_target(draws, n, i); t[q] = tt;
+                        if (tt >= lo && tt != i) { const int tl = tt - lo; const uint32_t bt = 1u << (tl & 31); const uint32_t old = atomicOr(&sTb[tl >> 5], bt); if (old & bt) atomicOr(&sDb[tl >> 5], bt); }
+                    }
+                }
+                if (tid == 0) sNC = 0;
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < RP_SPT; q++) {
+                    const int kk = tid * RP_SPT + q;
+                    if (kk < Bk) {
+                        const int i = I1 - 1 - kk, tt = t[q];
+                        const bool dirty = bit(sTb, i - lo) || (tt >= lo && tt != i && bit(sDb, tt - lo));
+                        if (!dirty) exec(i, tt, tau);
+                        else { const int sidx = atomicAdd(&sNC, 1); if (sidx < RP_CMAX) { sCI[sidx] = i; sCT[sidx] = tt; } }
+                    }
+                }
+                __syncthreads();
+                lapc(2);
+                const int nC = sNC;
+                if (nC > RP_CMAX) { if (tid == 0) sOver = 1; }
+                else if (nC > 0) {
+                    // a step waits for the latest earlier step (larger i) that names one of its two positions as its target
+                    int iE = 0, tE = 0;
+                    if (tid < nC) {
+                        iE = sCI[tid]; tE = sCT[tid];
+                        int d1 = -1, d1i = 0x7fffffff, d2 = -1, d2i = 0x7fffffff; const bool isB = tE >= lo && tE != iE;
+                        for (int f = 0; f < nC; f++) { const int iF = sCI[f], tF = sCT[f]; if (iF > iE) { if (tF == iE && iF < d1i) { d1i = iF; d1 = f; } if (isB && tF == tE && iF < d2i) { d2i = iF; d2 = f; } } }
+                        sDep1[tid] = (int16_t)d1; sDep2[tid] = (int16_t)d2; sDone[tid] = 0;
+                    }
+                    __syncthreads();
+                    for (;;) {
+                        int left = 0;
+                        if (tid < nC && !sDone[tid]) {
+                            const int d1 = sDep1[tid], d2 = sDep2[tid];
+                            if ((d1 < 0 || sDone[d1] == 1) && (d2 < 0 || sDone[d2] == 1)) { exec(iE, tE, tau); sDone[tid] = 2; } else left = 1;
+                        }
+                        const int more = __syncthreads_or(left);
+                        if (tid < nC && sDone[tid] == 2) sDone[tid] = 1;
+                        __syncthreads();
+                        if (!more) break;
+                    }
+                }
+                __syncthreads();
+                lapc(3);
+                sTb[tid] = 0u; sDb[tid] = 0u;
+                if (I0 == tileBase) { if (tid < k) endsIn[(size_t)tid * (nT + 1) + tau] = sCnt[tid]; if (tid == 0) endsOwn[tau] = sOwn; }
+                I1 = I0;
+                __syncthreads();
+            }
+            lapc(2);
+            // ---- the last steps of the permutation: one wave, 64 steps at a time, each waiting for the latest earlier lane on its two positions (every target lies in LDS here)
+            if (k == 0) {
+                if (tid < 64) {
+                    volatile int32_t* vA = sA;
+                    for (int base = I1; base > 0; base -= 64) {
+                        const int i = base - 1 - lane; const bool active = i >= 0;
+                        const int tt = active ? rp_target(draws, n, i) : -1;
+                        int d1 = -1, d2 = -1;
+#pragma unroll 8
+                        for (int j = 0; j < 63; j++) { const int tj = __shfl(tt, j, 64); if (lane > j && active) { if (tj == i) d1 = j; if (tj == tt && tt != i) d2 = j; } }
+                        unsigned long long done = ~__ballot(active);
+                        bool mine = !active;
+                        while (~done) {
+                            const bool ready = !mine && (d1 < 0 || ((done >> d1) & 1ull)) && (d2 < 0 || ((done >> d2) & 1ull));
+                            if (ready) { const int v = vA[i]; int old = v; if (tt != i) { old = vA[tt]; vA[tt] = v; } emit_own(i, old); mine = true; }
+                            __builtin_amdgcn_wave_barrier();
+                            done |= __ballot(ready);
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) endsOwn[0] = sOwn;
+                lapc(4);
+            }
+            __syncthreads();
+        }
+        if (sOver) { if (tid == 0) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; } __syncthreads(); continue; }
+        // ---- the statistic (as perm_stat_tail; the values of a tile are gathered from the result streams into LDS instead of read from a px array)
+        {
+            double* sPx = reinterpret_cast<double*>(sRaw); double* sT = sPx + PT_TILE;                      // [PT_TILE], [PT_TILE + PT_HALO]
+            uint32_t* sTab = reinterpret_cast<uint32_t*>(sT + PT_TILE + PT_HALO);                            // endsOwn[nT + 1], then endsIn[K - 1][nT + 1]
+            double (*shM)[RP_T / 64] = reinterpret_cast<double (*)[RP_T / 64]>(sTab + (((size_t)K * (nT + 1) + 3) & ~size_t(1)));      // (an even number of words in front: 8-byte aligned)
+            double* shD = reinterpret_cast<double*>(shM + (PG_MAXK + 1)); double* sEdge = shD + (RP_T / 64 + 1);
+            int* sSrcOff = reinterpret_cast<int*>(sEdge + 2 * PT_HALO); uint32_t* sSrcBase = reinterpret_cast<uint32_t*>(sSrcOff + RP_MAXK + 2);
+            const int hk = R.hk, al0 = R.al0; const double tss = R.tss, errBound = R.errBound;
+            for (int t = tid; t <= nT; t += RP_T) sTab[t] = endsOwn[t];
+            for (int d = 0; d < K - 1; d++) for (int t = tid; t <= nT; t += RP_T) sTab[(size_t)(d + 1) * (nT + 1) + t] = endsIn[(size_t)d * (nT + 1) + t];
+            __syncthreads();
+            const int wv = tid >> 6;
+            double mx[PG_MAXK + 1];
+#pragma unroll
+            for (int j = 0; j <= PG_MAXK; j++) mx[j] = 0.0;
+            double dcarry = 0.0; int bad = 0;
+            for (int base = 0, tau = 0; base < n; base += PT_TILE, tau++) {
+                const int cnt = n - base < PT_TILE ? n - base : PT_TILE;
+                // sources of the tile: the own stream, and the inbox results of every lower range
+                const int S = (tau >> 3) + 1;
+                if (tid == 0) {
+                    int run = 0;
+                    for (int sI = 0; sI < S; sI++) {
+                        const uint32_t beg = sTab[(size_t)sI * (nT + 1) + tau + 1], end = sTab[(size_t)sI * (nT + 1) + tau];
+                        sSrcOff[sI] = run; sSrcBase[sI] = (sI == 0 ? R.rp.oOutOwn : R.rp.oOutIn + sInOff[sI - 1]) + beg; run += (int)(end - beg);
+                    }
+                    sSrcOff[S] = run;
+                }
+                __syncthreads();
+                lapc(5);
+                if (sSrcOff[S] != cnt) bad = 1;
+                else {
+#pragma unroll
+                    for (int q = 0; q < RP_SPT; q++) {
+                        const int e = q * RP_T + tid;
+                        if (e < cnt) {
+                            int sI = 0; while (sI + 1 < S && sSrcOff[sI + 1] <= e) sI++;
+                            const uint32_t ent = scr[sSrcBase[sI] + (uint32_t)(e - sSrcOff[sI])];
+                            sPx[ent >> 20] = x[ent & 0xFFFFFu];
+                        }
+                    }
+                }
+                __syncthreads();
+                lapc(6);
+                double v[PT_PER]; double run = 0.0;
+#pragma unroll
+                for (int r = 0; r < PT_PER; r++) { const int i = tid * PT_PER + r; run += i < cnt ? sPx[i] : 0.0; v[r] = run; }
+                double inc = run;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const double oo = __hiloint2double(__shfl_up(__double2hiint(inc), d), __shfl_up(__double2loint(inc), d)); if ((tid & 63) >= d) inc += oo; }
+                if ((tid & 63) == 63) shD[wv] = inc;
+                __syncthreads();
+                double wb = 0.0, tot = 0.0;
+                for (int kq = 0; kq < RP_T / 64; kq++) { const double tq = shD[kq]; if (kq < wv) wb += tq; tot += tq; }
+                const double before = dcarry + wb + (inc - run);
+#pragma unroll
+                for (int r = 0; r < PT_PER; r++) sT[PT_HALO + tid * PT_PER + r] = before + v[r];
+                dcarry += tot;
+                __syncthreads();
+                if (base == 0 && tid < PT_HALO) sEdge[tid] = sT[PT_HALO + tid];
+                if (base + PT_TILE >= n && tid < PT_HALO) sEdge[PT_HALO + tid] = sT[cnt + tid];
+                const int uEnd = base + PT_TILE >= n ? cnt + PT_HALO : PT_TILE;
+                for (int u = tid; u < uEnd; u += RP_T) {
+                    const int a = base - PT_HALO + u;
+                    if (a < 0) continue;
+                    const double s0 = sT[u];
+#pragma unroll
+                    for (int j = 2; j <= PG_MAXK; j++)
+                        if (j >= al0 && j <= hk && a + j < n) { const double d = fabs(sT[u + j] - s0); mx[j] = d > mx[j] ? d : mx[j]; }
+                }
+                __syncthreads();
+                if (tid < PT_HALO) sT[tid] = sT[PT_TILE + tid];
+                __syncthreads();
+            }
+            if (tid < PT_HALO) {
+                const int a = tid;
+#pragma unroll
+                for (int j = 2; j <= PG_MAXK; j++)
+                    if (j >= al0 && j <= hk && a < j) { const double d = fabs(sEdge[PT_HALO + (a + PT_HALO - j)] - sEdge[a]); mx[j] = d > mx[j] ? d : mx[j]; }
+            }
+#pragma unroll
+            for (int j = 2; j <= PG_MAXK; j++) {
+                double vv = mx[j];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { const double oo = __hiloint2double(__shfl_xor(__double2hiint(vv), d), __shfl_xor(__double2loint(vv), d)); vv = oo > vv ? oo : vv; }
+                if ((tid & 63) == 0) shM[j][tid >> 6] = vv;
+            }
+            lapc(7);
+            const int anyBad = __syncthreads_or(bad);
+            if (tid == 0) {
+                const double rn = (double)n;
+                double hLo = 0.0, hHi = 0.0;
+                for (int j = al0; j <= hk && j <= PG_MAXK; j++) {
+                    double vv = 0.0; for (int kq = 0; kq < RP_T / 64; kq++) vv = shM[j][kq] > vv ? shM[j][kq] : vv;
+                    const double rj = (double)j, c = rn / (rj * (rn - rj));
+                    const double lo2 = vv - errBound > 0.0 ? vv - errBound : 0.0, hi2 = vv + errBound;
+                    const double aa = c * (lo2 * lo2) * (1.0 - 1e-15), bb = c * (hi2 * hi2) * (1.0 + 1e-15);
+                    hLo = aa > hLo ? aa : hLo; hHi = bb > hHi ? bb : hHi;
+                }
+                auto norm = [&](double h) { double tq = tss; if (tq <= h + 0.0001) tq = h + 1.0; return h / ((tq - h) / (rn - 2.0)); };   // CBSTStatistic.cs:334-337
+                if (anyBad || (tss <= hLo + 0.0001) != (tss <= hHi + 0.0001)) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; }
+                else { R.pstat[2 * b] = norm(hLo) * (1.0 - 1e-15); R.pstat[2 * b + 1] = norm(hHi) * (1.0 + 1e-15); }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ---- segments of at most 200 bins (the non-hybrid test, TMaxP: CBSTStatistic.cs:599-934): one wave per permutation, and the value is EXACT.  The swaps and the prefix sums run
@@ -1414,6 +1739,31 @@ static void xperm(const double* x, double* px, int n, MT& rnd) {                
     for (int i = n - 1; i >= 0; i--) { double cc = rnd.next_double(); int j = (int)(cc * (i + 1)); j = j > i ? i : j; std::swap(px[i], px[j]); }
 }
 
+// the plan of k_perm_rp for a segment of n bins: ranges, tiles, the capacity of every range's inbox and the layout of a workgroup's scratch (in 4-byte words)
+#define PERM_RP_MIN_N 1024
+#define PERM_RP_MAX_N (RP_MAXK * RP_R)
+#define PERM_RP_GRID 512             // persistent workgroups per request (two per CU are resident)
+static void rp_plan(int n, PermReq::RpPlan& P) {
+    const int K = (n + RP_R - 1) / RP_R, nT = (n + RP_BK - 1) / RP_BK;
+    P.K = K; P.nT = nT;
+    uint32_t ent = 0;
+    for (int d = 0; d < RP_MAXK; d++) { P.inOff[d] = 0; P.inCap[d] = 0; }
+    for (int d = 0; d + 1 < K; d++) {
+        // messages into range d: one per step i >= (d + 1) R whose target falls into it, probability R / (i + 1): at most R ln(n / ((d + 1) R)) expected, variance below the mean
+        const double E = (double)RP_R * std::log((double)n / (double)((d + 1) * RP_R));
+        uint32_t cap = (uint32_t)(E + 8.0 * std::sqrt(E + 1.0) + 64.0); cap = (cap + 1u) & ~1u;
+        P.inOff[d] = ent; P.inCap[d] = cap; ent += cap;
+    }
+    uint32_t o = 0;
+    P.oEndsIn = o; o += (uint32_t)((K > 1 ? K - 1 : 0) * (nT + 1));
+    P.oEndsOwn = o; o += (uint32_t)(nT + 1);
+    o = (o + 1u) & ~1u; P.oInbox = o; o += 2u * ent;
+    P.oOutIn = o; o += ent;
+    P.oOutOwn = o; o += (uint32_t)n;
+    P.stride = (o + 63u) & ~63u;
+}
+static size_t rp_scratch_bytes(int n, int wgs) { PermReq::RpPlan P; rp_plan(n, P); return (size_t)P.stride * 4 * (size_t)wgs; }
+
 // ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
 #define PERM_GPU_MIN_N 201           // every hybrid segment (> 200 bins) takes the device engine (round 2 kept those below 1024 bins on the host: 12 % slower on the device then; with this round's kernels 0.19 vs 0.23 s on the 4.7 M-bin probe); CANVAS_CBS_PERM_GPU_MIN_N overrides
 #define PERM_TARGET_ELEMS (64 << 20) // permuted elements per batch (44 B of workspace each)
@@ -1424,6 +1774,7 @@ struct PermService;
 struct PermGpu {
     canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr; char* buf = nullptr; size_t bytes = 0; char* pin = nullptr; size_t pinBytes = 0;
     size_t reserveElems = 0, reserveN = 0;     // the call's longest chromosome: the first allocation is made for it (growing means hipFree + hipMalloc, which stall every stream of the device)
+    size_t reserveBytes = 0, reservePin = 0;   // ... in bytes of device / pinned memory (perm_reserve_bytes)
     // analytic tail probability on the device (k_tail_nu): own stream, 3 x 128 values on the device and in pinned memory
     hipStream_t tailStream = nullptr; char* tailDev = nullptr; char* tailPin = nullptr;
     int32_t ensure_tail() {
@@ -1563,8 +1914,9 @@ struct PermService {
     int32_t launch(std::vector<PermHostReq*>& batch) {
         { int32_t rc0 = init(); if (rc0) return rc0; }
         const int R = (int)batch.size();
-        int blocks = 0; long long maxTotal = 0;
+        int blocks = 0, rpBlocks = 0; long long maxTotal = 0;
         for (int i = 0; i < R; i++) {
+            batch[i]->r.rpBase = rpBlocks; if (batch[i]->r.fy == 3) rpBlocks += batch[i]->r.rpWGs; else batch[i]->r.rpWGs = 0;
             batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
             if (batch[i]->r.cont)    // history of this batch = the last MT_HISTORY outputs of the previous one (same buffer, no overlap: prevTotal >= MT_HISTORY)
                 CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws - MT_HISTORY, batch[i]->r.P.draws + (batch[i]->prevTotal - MT_HISTORY), (size_t)MT_HISTORY * 4, hipMemcpyDeviceToDevice, stream));
@@ -1589,9 +1941,10 @@ struct PermService {
         else if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
         if (dbg) msB = lap();
         hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
-        bool anyFy = false, anyOld = false, anySmall = false; for (int i = 0; i < R; i++) (batch[i]->r.fy == 2 ? anySmall : batch[i]->r.fy ? anyFy : anyOld) = true;
+        bool anyFy = false, anyOld = false, anySmall = false; for (int i = 0; i < R; i++) (batch[i]->r.fy == 2 ? anySmall : batch[i]->r.fy == 1 ? anyFy : batch[i]->r.fy == 0 ? anyOld : anySmall /* (3: below) */) |= batch[i]->r.fy != 3;
         if (anyOld) hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         if (anyFy) hipLaunchKernelGGL(k_perm_fy, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
+        if (rpBlocks) hipLaunchKernelGGL(k_perm_rp, dim3(rpBlocks), dim3(RP_T), 0, stream, dReqs, R);
         if (anySmall) hipLaunchKernelGGL(k_perm_small, dim3(blocks), dim3(64), 0, stream, dReqs, R);
         if (probeTiming) { lastMs[0] = msA; lastMs[1] = msB; lastMs[2] = lap(); }
         else if (dbg) { const double msC = lap(); int nc = 0, maxN = 0; for (int i = 0; i < R; i++) { nc += batch[i]->r.cont; maxN = std::max(maxN, batch[i]->r.n); }
@@ -1627,14 +1980,36 @@ static int32_t service_submit_arc(PermService* svc, ArcHostReq& q) { return svc-
 // where the wall time of one chromosome goes (CANVAS_CBS_TIMING): seconds waiting for / running phase 1, in the device and host permutation loops, in the edge tests
 struct ChromClock { double p1 = 0, dev = 0, host = 0, edge = 0; int segments = 0, devLoops = 0, hostLoops = 0; long long loopPerms = 0, loopBatches = 0; };
 static thread_local ChromClock tlClock;
+// ---- workspace of a permutation loop.  k_perm_rp (segments of PERM_RP_MIN_N .. PERM_RP_MAX_N bins): the draws of a batch + the scratch of its persistent workgroups;
+// the older kernels (shorter / longer segments): 48 bytes per permuted element.
+#define PERM_RP_SCRATCH_BYTES (size_t(2) << 30)
+#define PERM_RP_MAXB 1024
+static inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
+static inline bool perm_use_rp(int n) { static const bool off = getenv("CANVAS_CBS_NO_RP") != nullptr; static const int minN = getenv("CANVAS_CBS_RP_MIN_N") ? atoi(getenv("CANVAS_CBS_RP_MIN_N")) : PERM_RP_MIN_N; return !off && n >= minN && n <= PERM_RP_MAX_N; }
+static inline int perm_max_batch(int n) { return perm_use_rp(n) ? (int)std::max<long long>(8, std::min<long long>(PERM_RP_MAXB, PERM_TARGET_ELEMS / n)) : (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n)); }
+static inline int perm_rp_wgs(int n) { PermReq::RpPlan P; rp_plan(n, P); const size_t per = (size_t)P.stride * 4; return (int)std::max<size_t>(64, std::min<size_t>(PERM_RP_GRID, PERM_RP_SCRATCH_BYTES / per)); }
+// device / pinned bytes that serve every segment of up to nMax bins
+static void perm_reserve_bytes(size_t nMax, size_t& dev, size_t& pin) {
+    const size_t head = al256(nMax * 8) + al256(625 * 4) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
+    const size_t elemsRp = std::max<size_t>(PERM_TARGET_ELEMS, 8 * nMax);
+    dev = head + al256((elemsRp + (size_t)MT_HISTORY) * 4) + PERM_RP_SCRATCH_BYTES + (size_t(64) << 20);
+    if (nMax > (size_t)PERM_RP_MAX_N || !perm_use_rp((int)std::min<size_t>(nMax, PERM_RP_MAX_N))) {
+        const size_t re = (size_t)std::min<long long>((long long)256 * (long long)nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * (long long)nMax));
+        dev = std::max(dev, head + al256((re + (size_t)MT_HISTORY) * 4) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
+    }
+    pin = al256(nMax * 8) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
+}
+
 // The sequential stopping rule of FindChangePoints (ChangePoint.cs:337-364) over permutations evaluated in device batches.
 // Returns through `outcome`: 0 = not significant (nrej > nrejc), 1 = continue to the edge tests.  rnd ends exactly where the reference's would.
 static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int hk, int al0, double ostat, int nrejc, int k,
                              const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st, int& outcome) {
     canvas_ctx* ctx = PG.ctx;
-    const int maxB = (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n));
+    const bool useRp = perm_use_rp(n);
+    const int maxB = perm_max_batch(n);
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     auto now = []() { return std::chrono::steady_clock::now(); };
+    uint32_t* dRpScratch = nullptr; int rpWGs = 0; PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP);
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
     auto setup = [&](int mb) -> int32_t {
@@ -1644,17 +2019,21 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
                      oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
         const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pinTotal = pStat + al((size_t)mb * 16);
         auto tE = now();
-        size_t want = total, wantPin = pinTotal;
-        if (PG.reserveElems) { const size_t re = PG.reserveElems, rn = PG.reserveN;      // same layout, for the longest segment this call can meet
-            want = std::max(want, al(rn * 8) + al(625 * 4) + al(256 * 625 * 4) + al(256 * 16) + al((re + (size_t)MT_HISTORY) * 4) + 5 * al(re * 4) + 2 * al((re + 256) * 4) + 2 * al(re * 8));
-            wantPin = std::max(wantPin, al(rn * 8) + al(256 * 625 * 4) + al(256 * 16)); }
-        int32_t rc0 = PG.ensure(want, wantPin, total); if (rc0) return rc0;
+        // k_perm_rp: the draws and, behind them, the scratch of the persistent workgroups (results travel in streams: no per-element workspace)
+        size_t oScratch = 0, totalRp = 0;
+        if (useRp) { rp_plan(n, rpP); rpWGs = std::min(perm_rp_wgs(n), mb); oScratch = oDraws + al((e + (size_t)MT_HISTORY) * 4); totalRp = oScratch + al((size_t)rpP.stride * 4 * (size_t)rpWGs); }
+        const size_t need = useRp ? totalRp : total;
+        size_t want = need, wantPin = pinTotal;
+        if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // the first allocation serves the longest segment this call can meet
+        int32_t rc0 = PG.ensure(want, wantPin, need); if (rc0) return rc0;
         st.ns_ensure += since(tE);
         char* d = PG.buf; char* h = PG.pin;
         dX = (double*)(d + oX); dSnaps = (uint32_t*)(d + oSnaps); dStat = (double*)(d + oStat);
         P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY;       // MT_HISTORY outputs of head room for the continuation
+        if (useRp) { memset(&P.j, 0, sizeof(PermBuf) - sizeof(uint32_t*)); dRpScratch = (uint32_t*)(d + oScratch); }
+        else {
         P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
-        P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx);
+        P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx); }
         hX = (double*)(h + pX); hSnaps = (uint32_t*)(h + pSnaps); hStat = (double*)(h + pStat);
         return CANVAS_OK;
     };
@@ -1682,7 +2061,8 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.r.cont = (np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
-        { static const int fyMin = getenv("CANVAS_CBS_FY_MIN_N") ? atoi(getenv("CANVAS_CBS_FY_MIN_N")) : PERM_FY_MIN_N; q.r.fy = n >= fyMin ? 1 : 0; }
+        { static const int fyMin = getenv("CANVAS_CBS_FY_MIN_N") ? atoi(getenv("CANVAS_CBS_FY_MIN_N")) : PERM_FY_MIN_N; q.r.fy = useRp ? 3 : (n >= fyMin ? 1 : 0); }
+        q.r.rpBase = 0; q.r.rpWGs = useRp ? std::min(rpWGs, nb) : 0; q.r.rpScratch = dRpScratch; q.r.rp = rpP; q.r.rpClk = nullptr;
         prevTotal = (long long)nb * n;
         rc = PG.svc->submit(q); if (rc) return rc;
         st.ns_submit += since(tS);
@@ -1746,9 +2126,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
     const size_t oX = 0, oStat = al((size_t)n * 8), oDraws = oStat + al((size_t)maxB * 16), total = oDraws + al(((size_t)maxB * n + (size_t)MT_HISTORY) * 4) + 256;
     const size_t pX = 0, pStat = al((size_t)n * 8), pDraws = pStat + al((size_t)maxB * 16), pinTotal = pDraws + al((size_t)maxB * n * 4);
     size_t want = total, wantPin = pinTotal;
-    if (PG.reserveElems) { const size_t re = PG.reserveElems, rn = PG.reserveN;      // never shrink below what perm_loop_gpu will ask for: one allocation per engine
-        want = std::max(want, al(rn * 8) + al(625 * 4) + al(256 * 625 * 4) + al(256 * 16) + al((re + (size_t)MT_HISTORY) * 4) + 5 * al(re * 4) + 2 * al((re + 256) * 4) + 2 * al(re * 8));
-        wantPin = std::max(wantPin, al(rn * 8) + al(256 * 625 * 4) + al(256 * 16)); }
+    if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // never shrink below what perm_loop_gpu will ask for: one allocation per engine
     int32_t rc = PG.ensure(want, wantPin, total); if (rc) return rc;
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     char* d = PG.buf; char* h = PG.pin;
@@ -1767,6 +2145,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
         PermHostReq q;
         memset(q.r.state, 0, sizeof q.r.state); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = nullptr; q.r.x = dX; q.r.hk = 0; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = 0.0;
         memset(&q.r.P, 0, sizeof q.r.P); q.r.P.draws = dDraws; q.r.pstat = dStat; q.r.blockBase = 0; q.r.cont = 0; q.r.fy = 2; q.hStat = hStat; q.hSnaps = nullptr;
+        q.r.rpBase = 0; q.r.rpWGs = 0; q.r.rpScratch = nullptr; q.r.rpClk = nullptr; memset(&q.r.rp, 0, sizeof q.r.rp);
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.hDraws = hDraws; q.drawBytes = (size_t)nb * n * 4;
         auto tS = std::chrono::steady_clock::now();
@@ -2143,14 +2522,17 @@ extern "C" int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h
 // strided part and of the permutation + statistic kernel.  tests/test_cbs_gpu.py compares the intervals with the oracle's XPerm + HTMaxP; tools/perm_probe.py times the kernels.
 extern "C" int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int32_t n, uint32_t seed, int32_t nb, int32_t kernel, double tss, double* h_lohi, double* h_ms3) {
     if (!ctx) return CANVAS_ERR_INVALID;
-    if (!h_x || !h_lohi || n < 1024 || nb < 1 || (kernel != 0 && kernel != 1) || (long long)n * nb > (1ll << 30)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs_perm_probe: bad arguments (n >= 1024, n * nb <= 2^30, kernel 0 or 1)");
+    if (!h_x || !h_lohi || n < 1024 || nb < 1 || kernel < 0 || kernel > 2 || (long long)n * nb > (1ll << 30) || (kernel == 2 && n > PERM_RP_MAX_N)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs_perm_probe: bad arguments (n >= 1024, n * nb <= 2^30, kernel 0, 1 or 2 (n <= 524288))");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     cbs::PermService svc(ctx); svc.probeTiming = true;
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t e = (size_t)nb * n, e1 = (size_t)nb * (n + 1);
     const size_t oX = 0, oSnaps = oX + al((size_t)n * 8), oStat = oSnaps + al((size_t)nb * 625 * 4), oDraws = oStat + al((size_t)nb * 16), oJ = oDraws + al((e + (size_t)MT_HISTORY) * 4), oOff = oJ + al(e * 4),
                  oCur = oOff + al(kernel == 0 ? e1 * 4 : 0), oItems = oCur + al(kernel == 0 ? e1 * 4 : 0), oG = oItems + al(kernel == 0 ? e * 4 : 0), oSucc = oG + al(kernel == 0 ? e * 4 : 0), oPx = oSucc + al(kernel == 0 ? e * 4 : 0),
-                 oSx = oPx + al(e * 8), total = oSx + al(kernel == 0 ? e * 8 : 0);
+                 oSx = oPx + al(kernel == 2 ? 0 : e * 8), oScr = oSx + al(kernel == 0 ? e * 8 : 0);
+    PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP); int rpWGs = 0;
+    if (kernel == 2) { cbs::rp_plan(n, rpP); rpWGs = std::min(cbs::perm_rp_wgs(n), (int)nb); }
+    const size_t total = oScr + al((size_t)rpP.stride * 4 * (size_t)rpWGs);
     char* d = nullptr; char* h = nullptr;
     CANVAS_HIP_TRY(ctx, hipMalloc((void**)&d, total));
     struct Free { char*& d; char*& h; ~Free() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); } } fr{d, h};
@@ -2164,10 +2546,16 @@ extern "C" int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int
     q.r.errBound = 4.04 * (double)(n + 8) * 1.1102230246251565e-16 * absSum;
     q.r.P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY; q.r.P.j = (int32_t*)(d + oJ); q.r.P.off = (int32_t*)(d + oOff); q.r.P.cur = (int32_t*)(d + oCur); q.r.P.items = (int32_t*)(d + oItems);
     q.r.P.g = (int32_t*)(d + oG); q.r.P.succ = (int32_t*)(d + oSucc); q.r.P.px = (double*)(d + oPx); q.r.P.sx = (double*)(d + oSx);
-    q.r.pstat = (double*)(d + oStat); q.r.blockBase = 0; q.r.cont = 0; q.r.fy = kernel; q.hStat = (double*)(h + pStat); q.hSnaps = (uint32_t*)(h + pSnaps);
+    q.r.pstat = (double*)(d + oStat); q.r.blockBase = 0; q.r.cont = 0; q.r.fy = kernel == 2 ? 3 : kernel; q.hStat = (double*)(h + pStat); q.hSnaps = (uint32_t*)(h + pSnaps);
+    q.r.rpBase = 0; q.r.rpWGs = rpWGs; q.r.rpScratch = (uint32_t*)(d + oScr); q.r.rp = rpP; q.r.rpClk = nullptr;
+    long long* dClk = nullptr; const bool wantClk = kernel == 2 && getenv("CANVAS_CBS_PROBE_CLOCKS");
+    if (wantClk) { CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dClk, 64)); CANVAS_HIP_TRY(ctx, hipMemset(dClk, 0, 64)); q.r.rpClk = dClk; }
     q.hX = (const double*)h; q.dX = (double*)(d + oX); q.xBytes = (size_t)n * 8;
     int32_t rc = svc.submit(q); if (rc) return rc;
     memcpy(h_lohi, q.hStat, (size_t)nb * 16);
+    if (dClk) { long long c[8]; (void)hipMemcpy(c, dClk, 64, hipMemcpyDeviceToHost); (void)hipFree(dClk);
+        fprintf(stderr, "k_perm_rp workgroup 0 (n %d, %d permutations): cycles range set-up %lld, inbox %lld, own steps: targets + independent steps %lld, ordered replay %lld, last steps (one wave) %lld, statistic: tables %lld, gather %lld, sums + arcs %lld\n",
+                n, (nb + rpWGs - 1) / rpWGs, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); }
     if (h_ms3) for (int i = 0; i < 3; i++) h_ms3[i] = svc.lastMs[i];
     return CANVAS_OK;
 }
@@ -2269,8 +2657,8 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
         // the first allocation of an engine is made for the call's longest chromosome (growing later means hipFree + hipMalloc, which stall every stream of the device) —
         // as long as all engines of the call together stay inside half of what the device has free: many contigs on a many-core host, or several contexts on one GPU,
         // would otherwise run out of memory where grow-on-demand engines fit
-        PG.reserveN = (size_t)nMax; PG.reserveElems = (size_t)std::min<long long>((long long)256 * nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * nMax));
-        if (PG.reserveElems * 48 > perEngineBudget) { const size_t capE = perEngineBudget / 48; PG.reserveElems = capE >= 8 * (size_t)nMax ? capE : 0; if (!PG.reserveElems) PG.reserveN = 0; }
+        PG.reserveN = (size_t)nMax; cbs::perm_reserve_bytes((size_t)nMax, PG.reserveBytes, PG.reservePin);
+        if (PG.reserveBytes > perEngineBudget) { PG.reserveBytes = 0; PG.reservePin = 0; PG.reserveN = 0; }       // the engines then grow on demand
         for (;;) {
             int c = next++; if (c >= nchr) break;
             int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);

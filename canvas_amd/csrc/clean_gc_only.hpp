@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) k_go_decide(uint32_t* __restrict__ cnt, u
 // K3: in-place apply + strip.  Workgroup w owns the bins [w * 4096, (w + 1) * 4096), thread t of it the GO_KMAX consecutive bins behind a + t * GO_KMAX: four 16-byte loads
 // per column, and a kept bin's slot is (kept bins of the ranges in front) + (kept bins of the threads in front) + (kept bins of the thread in front of it).
 __global__ void __launch_bounds__(256) k_go_apply(int32_t* __restrict__ chr, int32_t* __restrict__ start, int32_t* __restrict__ stop, int32_t* __restrict__ gc, float* __restrict__ count, long long n,
-                                                  const GoDec* __restrict__ dec, uint32_t* __restrict__ pub, uint32_t* __restrict__ tick3, GoDec* __restrict__ hostDec) {
+                                                  const GoDec* __restrict__ dec, uint32_t* __restrict__ pub, uint32_t* __restrict__ tick3, GoDec* __restrict__ hostDec, unsigned* __restrict__ hostSeq, unsigned seq) {
     __shared__ double sMed[NGC];
     __shared__ uint32_t sKeep[NGC];
     __shared__ uint32_t sh4[4];
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_go_apply(int32_t* __restrict__ chr, int
     __shared__ int sLast;
     const uint32_t bad = dec->bad, noop = dec->noop;
     if (bad || noop) {                                                         // nothing is touched; the last workgroup reports (and clears the flag for the next call)
-        if (cf_arrive_last(tick3, gridDim.x, &sLast) && threadIdx.x == 0) { hostDec->bad = bad; hostDec->noop = noop; hostDec->nOut = (unsigned long long)n; __threadfence_system(); const_cast<GoDec*>(dec)->bad = 0u; }
+        if (cf_arrive_last(tick3, gridDim.x, &sLast) && threadIdx.x == 0) { hostDec->bad = bad; hostDec->noop = noop; hostDec->nOut = (unsigned long long)n; cvx_mail_publish(hostSeq, seq); const_cast<GoDec*>(dec)->bad = 0u; }
         return;
     }
     for (int i = threadIdx.x; i < NGC; i += 256) { sMed[i] = dec->med[i]; sKeep[i] = dec->keep[i]; }
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) k_go_apply(int32_t* __restrict__ chr, int
             o++;
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { hostDec->bad = 0u; hostDec->noop = 0u; hostDec->nOut = before + totalW; hostDec->globalMedian = gm; __threadfence_system(); }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { hostDec->bad = 0u; hostDec->noop = 0u; hostDec->nOut = before + totalW; hostDec->globalMedian = gm; cvx_mail_publish(hostSeq, seq); }
 }
 
 // Returns handled = false when the stage has to go through the general chain (nothing was modified).
@@ -198,16 +198,18 @@ static int32_t clean_gc_only(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t
     uint32_t* tick = (uint32_t*)((char*)dec + ((sizeof(GoDec) + 63) & ~size_t(63))); uint32_t* tick3 = tick + 16; unsigned long long* nCounted = (unsigned long long*)(tick + 32); unsigned long long* nFound = nCounted + 2;
     uint32_t* pub = tick + 64;
     int32_t rc = canvas_pin_reserve(ctx, sizeof(GoDec) + 64); if (rc) return rc;
-    GoDec* hostDec = (GoDec*)ctx->pin;
+    GoDec* hostDec = (GoDec*)ctx->pin; unsigned* hostSeq = (unsigned*)((char*)ctx->pin + ((sizeof(GoDec) + 15) & ~size_t(15)));
+    const unsigned goSeq = cvx_mail_arm(ctx, hostSeq);       // the decisions' mailbox stamp (common.hpp)
     GoIsAuto ia; memset(&ia, 0, sizeof ia); memcpy(ia.v, h_chr_is_autosome, (size_t)nchr);
     // the grid of the apply kernel: every workgroup resident, ranges of whole 256-bin rounds
     const unsigned gA = (unsigned)((n + 256 * GO_KMAX - 1) / (256 * GO_KMAX));
     ProfScope ps(ctx, "clean_total");
     hipLaunchKernelGGL(k_go_count, dim3((unsigned)std::min<long long>(2048, (n + 1023) / 1024)), dim3(256), 0, ctx->stream, d_chr, d_gc, d_count, (long long)n, ia, (int)nchr, cnt, dec, nCounted);
     hipLaunchKernelGGL(k_go_decide, dim3(NGC), dim3(256), 0, ctx->stream, cnt, all, dec, tick, pub, (int)gA, 100, tick3, nCounted, nFound);
-    hipLaunchKernelGGL(k_go_apply, dim3(gA), dim3(256), 0, ctx->stream, d_chr, d_start, d_stop, d_gc, d_count, (long long)n, dec, pub, tick3, hostDec);
+    hipLaunchKernelGGL(k_go_apply, dim3(gA), dim3(256), 0, ctx->stream, d_chr, d_start, d_stop, d_gc, d_count, (long long)n, dec, pub, tick3, hostDec, hostSeq, goSeq);
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());
+    { int32_t rcm = cvx_mail_await(ctx, hostSeq, goSeq, "CanvasClean -g: decisions"); if (rcm) return rcm; }
     if (hostDec->bad) return CANVAS_OK;                                        // nothing was modified
     *handled = true;
     *h_n_out = (int64_t)hostDec->nOut;

@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <vector>
@@ -70,6 +72,8 @@ struct canvas_ctx {
     int wv_streams_tried = 0; unsigned wv_calls = 1;
     void* wv_pin = nullptr; size_t wv_pin_bytes = 0;   // pinned arena of canvas_wavelets (host copy of the coverage + staging lists), kept between calls
     long long wv_stats[4] = {0, 0, 0, 0};     // ... long nodes decided from the closed form / sent to the chain undecided / chained for their coefficient; closed form in use
+    unsigned mail_seq = 0;      // sequence numbers of the results kernels write straight into pinned host memory (cvx_mail_*, below)
+    unsigned covq_seq = 0;      // ... the one the pending quartile result (covq_pin) will carry
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
     int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
     // profiling: hipEvent pairs around named kernels
@@ -105,6 +109,43 @@ struct ProfScope {
     } while (0)
 
 #define CANVAS_FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
+
+// ---- results a kernel writes STRAIGHT into pinned host memory ("mailboxes": bin size and totals, quartiles, segment count, Wavelets reports).  That a stream or an event has
+// completed does not by itself put such stores in front of the host's reads on this platform: in round 4 a Wavelets report was read before it had arrived about once in eight
+// process starts (gpurun_out/wv_fail_*.log) — silently wrong breakpoints.  So every mailbox carries a sequence word: the kernel stores the payload, fences at system scope, and
+// stores the call's sequence number LAST with release semantics; the host resets the word before it enqueues the kernel, and after the synchronisation compares it with the number
+// it handed out, polling until it matches (cvx_mail_await).  canvas_stale_reads reports how often a mailbox was looked at and how often the look came too early.
+// Results that travel by hipMemcpyAsync(DeviceToHost) + synchronisation are ordinary DMA copies and need none of this.
+extern std::atomic<long long> g_cvx_mail_awaits, g_cvx_mail_waited;       // ctx.hip
+#if defined(__HIPCC__)
+// ONE thread calls this, after every payload store of its workgroup is complete: the storing threads have executed __threadfence_system() and a barrier lies in between
+__device__ __forceinline__ void cvx_mail_publish(unsigned* seqWord, unsigned seq) {
+    __threadfence_system();
+    __hip_atomic_store(seqWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+// a fresh number for one mailbox use; the word itself is reset here so that nothing an earlier use left there can pass for this one (call BEFORE the kernel is enqueued)
+static inline unsigned cvx_mail_arm(canvas_ctx* ctx, volatile unsigned* seqWord) {
+    unsigned s = ++ctx->mail_seq; if (s == 0) s = ++ctx->mail_seq;
+    *seqWord = 0u;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    return s;
+}
+// after the stream / event the kernel was enqueued on has been waited for: returns when the mailbox carries `expect`
+static inline int32_t cvx_mail_await(canvas_ctx* ctx, const volatile unsigned* seqWord, unsigned expect, const char* what) {
+    g_cvx_mail_awaits.fetch_add(1, std::memory_order_relaxed);
+    if (*seqWord != expect) {
+        g_cvx_mail_waited.fetch_add(1, std::memory_order_relaxed);
+        if (getenv("CANVAS_MAIL_TRACE")) fprintf(stderr, "canvas: %s: the synchronisation returned before the result had arrived in host memory (sequence %u, expected %u): polling\n", what, *seqWord, expect);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (*seqWord != expect) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) { ctx->err = std::string(what) + ": a result written to pinned host memory did not arrive"; return CANVAS_ERR_HIP; }
+            __builtin_ia32_pause();
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return CANVAS_OK;
+}
 
 // ensure ctx->ws has at least `bytes`
 static inline int32_t canvas_ws_reserve(canvas_ctx* ctx, size_t bytes) {

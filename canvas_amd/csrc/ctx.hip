@@ -1,7 +1,17 @@
 // Context, memory and stream plumbing of libcanvas_hip.so (include/canvas_hip.h "context" section).
 #include "common.hpp"
 
+std::atomic<long long> g_cvx_mail_awaits{0}, g_cvx_mail_waited{0};       // common.hpp: cvx_mail_await
+
 extern "C" {
+
+// process-wide: [0] how often a result that a kernel wrote straight into pinned host memory was looked at behind its synchronisation, [1] how often that first look found the
+// previous contents (the synchronisation had returned before the stores had landed) and the library polled the result's sequence word until it arrived
+int32_t canvas_stale_reads(int64_t* h_out2) {
+    if (!h_out2) return CANVAS_ERR_INVALID;
+    h_out2[0] = g_cvx_mail_awaits.load(); h_out2[1] = g_cvx_mail_waited.load();
+    return CANVAS_OK;
+}
 
 #ifndef CANVAS_SRC_HASH
 #define CANVAS_SRC_HASH "unhashed-build-0000000000000000"

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(1024) k_covq_hist(const double* __restrict__ c
 }
 // Qres == NULL: the ranks were written by the host, the result stays in Q.  Qres != NULL (pipeline): the ranks are derived here from the number of bins (n, or *nDev when the
 // host does not know it yet), the result goes to Qres and Q / win are left all zero for the next call (the counters live in the context, nothing is uploaded or cleared per call).
-__global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, uint32_t* __restrict__ win, long long n = -1, const unsigned long long* __restrict__ nDev = nullptr, CovQ* __restrict__ Qres = nullptr) {
+__global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, uint32_t* __restrict__ win, long long n = -1, const unsigned long long* __restrict__ nDev = nullptr, CovQ* __restrict__ Qres = nullptr, unsigned seq = 0) {
     __shared__ unsigned long long sTot[16];
     __shared__ unsigned long long sRank[8];
     __shared__ uint32_t sNq, sFail;
@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, uint32
         CovQ o; memset(&o, 0, sizeof o);
         o.nq = nq; o.bad = Q->bad; o.fail = sFail; o.lo = lo; o.below = below; o.n = n;
         for (uint32_t j = 0; j < nq; j++) { o.rank[j] = sRank[j]; o.resultK[j] = sRes[j]; }
-        *Qres = o; __threadfence_system();      // (pinned host memory, read behind an event)
+        // (o.pad = 0: the mailbox stamp lives in the block's spare word; the host armed it with 0 and waits for the number the line below stores)
+        *Qres = o; cvx_mail_publish(&Qres->pad, seq);      // (pinned host memory, read behind a synchronisation: common.hpp)
         CovQ z; memset(&z, 0, sizeof z); *Q = z;
     }
 }
@@ -1269,7 +1270,7 @@ __global__ void __launch_bounds__(256) k_count_blocks(const uint8_t* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) blockCnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ void __launch_bounds__(1024) k_scan_blocks2(uint32_t* __restrict__ blockCnt, int nblocks, unsigned long long* __restrict__ total) {
+__global__ void __launch_bounds__(1024) k_scan_blocks2(uint32_t* __restrict__ blockCnt, int nblocks, unsigned long long* __restrict__ total, unsigned* __restrict__ totalSeq = nullptr, unsigned seq = 0) {
     __shared__ uint32_t sh[17];
     uint32_t carry = 0;
     for (int base = 0; base < nblocks; base += 1024) {
@@ -1285,7 +1286,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks2(uint32_t* __restrict__ bl
         carry += sh[16];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { *total = carry; __threadfence_system(); }      // (may be pinned host memory, read behind a synchronisation)
+    if (threadIdx.x == 0) { *total = carry; if (totalSeq) cvx_mail_publish(totalSeq, seq); }      // (total in pinned host memory: stamped, common.hpp)
 }
 __global__ void __launch_bounds__(256) k_seg_ids(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blockOff, int64_t n, int32_t* __restrict__ segId) {
     __shared__ uint32_t sh[4];
@@ -1507,7 +1508,7 @@ struct HmmEmis { int32_t* idx = nullptr; double* dTab = nullptr;
 // serves both; when a chromosome takes another attempt the caller derives the ids once the states are final (*valid stays false)
 struct SegPost { const int32_t* d_start; const int32_t* d_stop; int32_t maxDist; int32_t* d_segment_id; int64_t nseg = 0; bool valid = false; };
 static void enqueue_segment_ids(canvas_ctx* ctx, const int64_t* dOff, int nchr, const int32_t* d_state, const int32_t* d_start, const int32_t* d_stop, int64_t N, int32_t maxDist,
-                                uint8_t* flags, uint32_t* blockCnt, unsigned long long* dTot, int32_t* d_segment_id);
+                                uint8_t* flags, uint32_t* blockCnt, unsigned long long* dTot, int32_t* d_segment_id, unsigned* totSeq = nullptr, unsigned seq = 0);
 template <class PrepareA, class PrepareB>
 static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_offset, size_t extraBytes, PrepareA prepareA, PrepareB prepareB, int32_t* d_state, SegPost* seg = nullptr,
                             bool descByValue = false /* prepareA launches nothing that reads the descriptor tables: they may arrive with the set-up kernel */) {
@@ -1550,7 +1551,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     sz.take<char>(8 * 256 + (size_t)nchr * 64 + 64);
     if (seg) { sz.take<uint8_t>(N + 16); sz.take<uint32_t>(nbSeg + 1); sz.take<unsigned long long>(1); }
     int32_t rc = canvas_ws_reserve(ctx, sz.off + extraBytes + 65536); if (rc) return rc;
-    rc = canvas_pin_reserve(ctx, (size_t)nchr * 4 + 64); if (rc) return rc;         // verification flags (+ the segment count) come back here
+    rc = canvas_pin_reserve(ctx, (size_t)nchr * 4 + 64); if (rc) return rc;         // verification flags (+ the segment count and its mailbox stamp) come back here
     WsCarver ws(ctx->ws);
     uint16_t* psi = ws.take<uint16_t>(N + 8);
     HmmChrom* dChroms = ws.take<HmmChrom>(nchr); int32_t* dLast = ws.take<int32_t>(nchr);
@@ -1624,7 +1625,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
     std::vector<int32_t> redo;
     int32_t* hFail = (int32_t*)ctx->pin; unsigned long long* hSegTot = (unsigned long long*)((char*)ctx->pin + (((size_t)nchr * 4 + 15) & ~size_t(15)));
-    bool segEnqueued = false;
+    bool segEnqueued = false; unsigned* hSegSeq = (unsigned*)(hSegTot + 1); unsigned segSeq = 0;
     if (speculative && nblocks > 0) {
         ProfScope ps(ctx, "viterbi");
         // attempt 0: lead-ins of 128 / 64 steps.  Noisy samples (states that overlap heavily) forget their history more slowly: chromosomes
@@ -1669,7 +1670,8 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             if (seg && attempt == 0 && !getenv("CANVAS_HMM_TEST_CORRUPT")) {
                 // the states are final unless a chromosome fails its verification (rare): the segment ids are derived now, under the same synchronisation
                 (void)segTot;
-                enqueue_segment_ids(ctx, dOffDev, nchr, d_state, seg->d_start, seg->d_stop, N, seg->maxDist, segFlags, segBlockCnt, hSegTot /* pinned: the count is written straight to the host */, seg->d_segment_id);
+                segSeq = cvx_mail_arm(ctx, hSegSeq);
+                enqueue_segment_ids(ctx, dOffDev, nchr, d_state, seg->d_start, seg->d_stop, N, seg->maxDist, segFlags, segBlockCnt, hSegTot /* pinned: the count is written straight to the host */, seg->d_segment_id, hSegSeq, segSeq);
                 segEnqueued = true;
             }
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1683,7 +1685,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
                 dTodo = dRedo;
             }
         }
-        if (seg && segEnqueued && redo.empty() && ctx->hmm_retry == 0) { seg->valid = true; seg->nseg = (int64_t)*hSegTot; }
+        if (seg && segEnqueued && redo.empty() && ctx->hmm_retry == 0) { int32_t rcm = cvx_mail_await(ctx, hSegSeq, segSeq, "PerSampleHMM: segment count"); if (rcm) return rcm; seg->valid = true; seg->nseg = (int64_t)*hSegTot; }
     } else {
         for (int c = 0; c < nchr; c++) redo.push_back(c);
     }
@@ -1726,6 +1728,7 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     quartile_idx(nAll, qidx, nq);
     float v[6], q1, q2, q3;
     bool radix = getenv("CANVAS_HMM_RADIX_SELECT") != nullptr;
+    if (!radix && preQ) { rc = cvx_mail_await(ctx, &preQ->pad, ctx->covq_seq, "PerSampleHMM: coverage quartiles"); if (rc) return rc; }      // (preQ is always the context's pinned block: cvx_quant_covq_enqueue)
     if (!radix && preQ && preQ->nq == (uint32_t)nq && preQ->n == nAll) {        // counted while the coverage was quantised (cvx_quantize_f2_covq): the ranks are already on the host
         bool same = true; for (int k = 0; k < nq; k++) same = same && preQ->rank[k] == (unsigned long long)qidx[k];
         if (same && !preQ->bad && !preQ->fail) for (int k = 0; k < nq; k++) v[k] = (float)((double)preQ->resultK[k] / 100.0);
@@ -1820,7 +1823,8 @@ int32_t cvx_quant_covq_enqueue(canvas_ctx* ctx, const float* d_count, int64_t n,
     CovQ* dQ = (CovQ*)ctx->covq_dev; CovQ* dQres = (CovQ*)ctx->covq_pin; uint32_t* dWin = (uint32_t*)((char*)ctx->covq_dev + 512);       // (the result goes straight into pinned host memory)
     static_assert(sizeof(CovQ) <= 256, "CovQ");
     hipLaunchKernelGGL(k_quant_covq, dim3(256), dim3(1024), 0, ctx->stream, d_count, n, d_cov, dQ, dWin, d_n);
-    hipLaunchKernelGGL(k_covq_pick, dim3(1), dim3(1024), 0, ctx->stream, dQ, dWin, (long long)n, d_n, dQres);
+    ctx->covq_seq = cvx_mail_arm(ctx, &dQres->pad);
+    hipLaunchKernelGGL(k_covq_pick, dim3(1), dim3(1024), 0, ctx->stream, dQ, dWin, (long long)n, d_n, dQres, ctx->covq_seq);
     *h_covq_out = ctx->covq_pin;
     return CANVAS_OK;
 }
@@ -1965,12 +1969,12 @@ extern "C" {
 
 }  // extern "C"
 static void enqueue_segment_ids(canvas_ctx* ctx, const int64_t* dOff, int nchr, const int32_t* d_state, const int32_t* d_start, const int32_t* d_stop, int64_t N, int32_t maxDist,
-                                uint8_t* flags, uint32_t* blockCnt, unsigned long long* dTot, int32_t* d_segment_id) {
+                                uint8_t* flags, uint32_t* blockCnt, unsigned long long* dTot, int32_t* d_segment_id, unsigned* totSeq, unsigned seq) {
     const int nb = (int)nblk2(N, 2048);
     hipLaunchKernelGGL(k_seg_flags, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dOff, nchr, d_state, d_start, d_stop, N, maxDist, (const int64_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
                        (const int64_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, flags);
     hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(256), 0, ctx->stream, flags, N, blockCnt);
-    hipLaunchKernelGGL(k_scan_blocks2, dim3(1), dim3(1024), 0, ctx->stream, blockCnt, nb, dTot);
+    hipLaunchKernelGGL(k_scan_blocks2, dim3(1), dim3(1024), 0, ctx->stream, blockCnt, nb, dTot, totSeq, seq);
     hipLaunchKernelGGL(k_seg_ids, dim3(nb), dim3(256), 0, ctx->stream, flags, blockCnt, N, d_segment_id);
 }
 extern "C" {

@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256) k_f3_hist(const unsigned long long* __res
     if (sh[1][threadIdx.x]) atomicAdd(&S->hist[1][threadIdx.x], sh[1][threadIdx.x]);
 }
 // one workgroup: the digit that holds each rank, the rank inside it; after the last pass the two keys go to `out` (pinned host memory)
-__global__ void __launch_bounds__(64) k_f3_pick(WvF3Sel* __restrict__ S, int shift, unsigned long long* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_f3_pick(WvF3Sel* __restrict__ S, int shift, unsigned long long* __restrict__ out, unsigned* __restrict__ outSeq, unsigned seq) {
     const int w = threadIdx.x;
     unsigned long long np = 0, nr = 0;
     if (w < 2) {
@@ -593,6 +593,7 @@ __global__ void __launch_bounds__(64) k_f3_pick(WvF3Sel* __restrict__ S, int shi
     }
     __syncthreads();
     if (w < 2) { S->prefix[w] = np; S->rank[w] = nr; if (shift == 0) { out[w] = np; __threadfence_system(); } }
+    if (shift == 0) { __syncthreads(); if (w == 0) cvx_mail_publish(outSeq, seq); }      // (pinned host memory: the two keys, then the mailbox stamp — common.hpp)
     for (int i = w; i < 512; i += 64) (&S->hist[0][0])[i] = 0u;
 }
 
@@ -900,7 +901,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     }
     struct XView { double* p; double* data() const { return p; } double operator[](size_t i) const { return p[i]; } } X{(double*)ctx->wv_pin};
     char* pinCursor = (char*)ctx->wv_pin + (((size_t)N * sizeof(double) + 255) & ~size_t(255));
-    unsigned long long* hF3Keys = (unsigned long long*)pinCursor; pinCursor += 256;      // the two middle keys of every exponent (factor-of-three statistics on the device)
+    unsigned long long* hF3Keys = (unsigned long long*)pinCursor; unsigned* hF3Seq = (unsigned*)(pinCursor + 128); unsigned f3Seq[8] = {0, 0, 0, 0, 0, 0, 0, 0}; pinCursor += 256;      // the two middle keys of every exponent (factor-of-three statistics on the device)
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(X.data(), dX, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     {
@@ -1009,10 +1010,11 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             if ((size_t)M > f3Cap) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: factor-of-three staging");
             const double* in = e == 1 ? dX : dF3Med[e & 1]; double* out = dF3Med[(e + 1) & 1];
             hipLaunchKernelGGL(k_f3_triplets, dim3((unsigned)std::min<long long>(2048, (M + 255) / 256)), dim3(256), 0, ctx->wv_sub2, in, out, dF3Key, lv);
+            f3Seq[e - 1] = cvx_mail_arm(ctx, hF3Seq + (e - 1));
             hipLaunchKernelGGL(k_f3_sel_init, dim3(1), dim3(256), 0, ctx->wv_sub2, dF3Sel, (unsigned long long)((M & 1) ? M / 2 : M / 2 - 1), (unsigned long long)(M / 2));
             for (int shift = 56; shift >= 0; shift -= 8) {
                 hipLaunchKernelGGL(k_f3_hist, dim3((unsigned)std::min<long long>(1024, (M + 1023) / 1024)), dim3(256), 0, ctx->wv_sub2, dF3Key, M, shift, dF3Sel);
-                hipLaunchKernelGGL(k_f3_pick, dim3(1), dim3(64), 0, ctx->wv_sub2, dF3Sel, shift, hF3Keys + 2 * (e - 1));
+                hipLaunchKernelGGL(k_f3_pick, dim3(1), dim3(64), 0, ctx->wv_sub2, dF3Sel, shift, hF3Keys + 2 * (e - 1), hF3Seq + (e - 1), f3Seq[e - 1]);
             }
             f3Count[e - 1] = M; f3Levels = e;
             for (int c = 0; c < nchr; c++) { len[(size_t)c] /= 3; lv.inOff[c] = lv.outOff[c]; }
@@ -1502,6 +1504,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     if (f3Thread.joinable()) f3Thread.join();
     if (f3OnDevice) {
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->wv_sub2));
+        for (int e = 1; e <= f3Levels; e++) { int32_t rcm = cvx_mail_await(ctx, hF3Seq + (e - 1), f3Seq[e - 1], "canvas_wavelets: factor-of-three medians"); if (rcm) return rcm; }
         auto dec = [](unsigned long long k) -> double { if (k == 0ull) return std::numeric_limits<double>::quiet_NaN(); const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k; double v; memcpy(&v, &b, 8); return v; };
         std::vector<double> g{0.0};
         for (int e = 1; e <= f3Levels; e++) { const double lo = dec(hF3Keys[2 * (e - 1)]), hi = dec(hF3Keys[2 * (e - 1) + 1]); g.push_back((f3Count[e - 1] & 1) ? hi : (lo + hi) / 2); }

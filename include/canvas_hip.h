@@ -44,6 +44,11 @@ canvas_ctx* canvas_create(int device);                 /* NULL when no usable GP
 void canvas_destroy(canvas_ctx* ctx);
 const char* canvas_last_error(canvas_ctx* ctx);
 const char* canvas_version(void);
+/* Process-wide counters of the results that kernels write straight into pinned host memory (bin size and totals of CanvasBin, quartiles and segment count of
+ * CanvasPartition, Wavelets reports ...).  Each carries a sequence word that the kernel stores last (system-scope release) and the host checks after its synchronisation:
+ * h_out2[0] = results looked at, h_out2[1] = looks that came before the result had arrived, after which the library polled the word until it did (0 on a quiet system;
+ * a synchronisation that returns early was observed about once in eight process starts in round 4).  No reference counterpart. */
+int32_t canvas_stale_reads(int64_t* h_out2);
 int32_t canvas_set_stream(canvas_ctx* ctx, void* hip_stream); /* run on a caller-owned hipStream_t (NULL = own stream) */
 int32_t canvas_synchronize(canvas_ctx* ctx);
 void* canvas_device_malloc(canvas_ctx* ctx, int64_t bytes);
