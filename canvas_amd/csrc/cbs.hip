@@ -774,14 +774,16 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
 //     holds t.  The step appends the message (i, t, V) to that range's inbox and is done.  All steps of the ranges above a range precede its own steps in time, so the range first
 //     applies its inbox (old = a[t]; a[t] = V; "position i receives old"), then runs its own steps; nothing ever flows upwards except those results.
 //   * steps run in blocks that never straddle a multiple of 2048 (a "tile").  Two steps of a block commute unless they share a position; the targets inside the range are marked
-//     in a bitmap of the range (exact, no hashing: the range is the bitmap's domain), steps that share nothing run at once, the others are replayed in the reference's order by
-//     rounds (a step waits for the latest earlier step on each of its two positions).  Messages of an inbox are applied the same way: those that are alone on their position at
-//     once, the others chained by their time stamps.  The last 2048 steps, where everything depends on everything, are run by one wave, 64 steps at a time, wave-synchronously.
+//     in a bitmap of the range (exact, no hashing: the range is the bitmap's domain), and steps that share nothing run at once.  The others — and the messages of an inbox chunk
+//     that name the same position — are PEELED in the reference's order: every position they touch gets a slot of a small hash table, every pending step posts its time stamp
+//     (tagged with the round, so that nothing has to be reset) to the slots of its positions with atomicMax, and runs when it holds the maximum of all of them, i.e. when it is
+//     the earliest pending step on each of its positions; steps that run in the same round share no position.  The last 512 steps of a permutation, where every step depends on
+//     another, go through one wave 64 at a time (each lane waits for the latest earlier lane on its two positions).
 //   * results ("position i holds value old") are appended to streams in tile order — the inbox results at the index of their message, the own results per tile — so the statistic
 //     finds the values of a tile as a handful of contiguous segments: it scatters x[old] into an LDS tile and forms prefix sums and arcs as perm_stat_tail does.
 // Per element: 4 bytes of draws, 8 + 8 bytes of message, 4 + 4 bytes of result, one gather from x (L2-resident) — streams instead of two scattered 128-byte line fills.  The
-// permutation is the reference's (integer logic); the statistic is an interval as before.  An inbox that outgrows its (generous) capacity, or a block with more than RP_CMAX
-// ordered steps, gives the permutation up: [-inf, inf], the host evaluates it in the reference's order.
+// permutation is the reference's (integer logic); the statistic is an interval as before.  An inbox that outgrows its (generous) capacity gives the permutation up: [-inf, inf],
+// the host evaluates it in the reference's order — as does a block whose ordered steps touch more positions than the table has slots.  The phases are separate functions (not inlined) so that each gets its own register allocation: 128 VGPRs, two workgroups per CU.
 #define RP_R 16384
 #define RP_RSHIFT 14
 #define RP_T PG_T
@@ -790,301 +792,486 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
 #define RP_TPR (RP_R / RP_BK)
 #define RP_MAXK 32                         // n <= 524 288
 #define RP_MAXT (RP_MAXK * RP_TPR)
-#define RP_CMAX 448
-#define RP_TAIL 2048                       // the last steps: one wave
+#define RP_HASH 1024                       // slots for the positions that several steps / messages of a block touch
+#define RP_TAIL 512                        // the last steps: the wave routine alone
 static_assert(RP_BK == PT_TILE, "a block of steps is a tile of the statistic");
+// LDS of a workgroup (dynamic: the phase functions address it by constant offsets)
+extern __shared__ __align__(16) unsigned char rp_lds[];
+#define RPL_A 0                            // int32[RP_R]: the range's positions
+#define RPL_TB (RP_R * 4)                  // uint32[512]: positions of the range that a step / message of the block targets
+#define RPL_DB (RPL_TB + 2048)             // uint32[512]: ... that two do
+#define RPL_HKEY (RPL_DB + 2048)           // uint32[RP_HASH]  (the fallback's lists sCI / sCT alias it)
+#define RPL_HSTAMP (RPL_HKEY + RP_HASH * 4)
+#define RPL_ROW (RPL_HSTAMP + RP_HASH * 4) // uint32[RP_MAXT + 1]: the inbox table's row of the range
+#define RPL_CNT (RPL_ROW + (RP_MAXT + 2) * 4)
+#define RPL_INOFF (RPL_CNT + RP_MAXK * 4)
+#define RPL_INCAP (RPL_INOFF + RP_MAXK * 4)
+#define RPL_MISC (RPL_INCAP + RP_MAXK * 4) // [0] own results so far, [1] give-up flag, [2..] scan scratch
+#define RPL_TOTAL (RPL_MISC + 64)
+static_assert(RPL_TOTAL <= 81920, "two workgroups per CU");
+#define RP_LDS(T, off) (reinterpret_cast<T*>(rp_lds + (off)))
 __device__ __forceinline__ int rp_target(const uint32_t* __restrict__ draws, int n, int i) {      // ChangePoint.cs:411-419: the draw of step i is draws[n - 1 - i]
     const double cc = (double)draws[n - 1 - i] * (1.0 / 4294967296.0);
     int tt = (int)(cc * (double)(i + 1)); return tt > i ? i : tt;
 }
+__device__ __forceinline__ bool rp_bit(const uint32_t* m, int p) { return (m[p >> 5] >> (p & 31)) & 1u; }
+__device__ __forceinline__ uint32_t rp_slot(uint32_t* hKey, uint32_t key, int* over) {             // the hash slot of a position (inserted on first sight)
+    uint32_t h = (key * 2654435761u) >> 22; int probes = 0;
+    for (;;) { const uint32_t prev = atomicCAS(&hKey[h], 0xFFFFFFFFu, key); if (prev == 0xFFFFFFFFu || prev == key) return h; h = (h + 1) & (RP_HASH - 1); if (++probes > RP_HASH) { *over = 1; return h; } }
+}
+// exclusive scan of a small count over the wave + one LDS atomic for the wave's total: the first slot of this lane (all lanes arrive together)
+__device__ __forceinline__ uint32_t rp_wave_reserve(uint32_t* cnt, int c) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int inc = (int)wave_inclusive_scan_u32((uint32_t)c);      // (DPP: no LDS round trips)
+    const int total = __builtin_amdgcn_readlane(inc, 63);
+    uint32_t base = 0u;
+    if (total) { if (lane == 63) base = atomicAdd(cnt, (uint32_t)total); base = __builtin_amdgcn_readlane(base, 63); }
+    return base + (uint32_t)(inc - c);
+}
+// inclusive sum over the wave of a double, the lanes' values added in ascending lane order within rows and rows in ascending order (DPP moves: no LDS round trips; lanes that a
+// shift does not reach receive +0.0)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double rp_dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rp_wave_scan_f64(double v) {
+    v += rp_dpp_f64<0x111, 0xF>(v);      // row_shr:1
+    v += rp_dpp_f64<0x112, 0xF>(v);      // row_shr:2
+    v += rp_dpp_f64<0x114, 0xF>(v);      // row_shr:4
+    v += rp_dpp_f64<0x118, 0xF>(v);      // row_shr:8
+    v += rp_dpp_f64<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    v += rp_dpp_f64<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+struct RpPtr { const uint32_t* draws; const double* x; uint32_t* scr; uint32_t* endsIn; uint32_t* endsOwn; uint2* inbox; uint32_t* outIn; uint32_t* outOwn; int n, K, nT; };
+__device__ __forceinline__ RpPtr rp_ptr(const PermReq& R, int w, int b) {
+    RpPtr P; P.n = R.n; P.K = R.rp.K; P.nT = R.rp.nT; P.draws = R.P.draws + (size_t)b * R.n; P.x = R.x;
+    P.scr = R.rpScratch + (size_t)w * R.rp.stride; P.endsIn = P.scr + R.rp.oEndsIn; P.endsOwn = P.scr + R.rp.oEndsOwn; P.inbox = reinterpret_cast<uint2*>(P.scr + R.rp.oInbox);
+    P.outIn = P.scr + R.rp.oOutIn; P.outOwn = P.scr + R.rp.oOutOwn;
+    return P;
+}
+// one step, by itself (ordered replay / the last steps)
+__device__ __forceinline__ void rp_exec1(const RpPtr& P, int lo, int i, int tt) {
+    int32_t* sA = RP_LDS(int32_t, RPL_A); uint32_t* sCnt = RP_LDS(uint32_t, RPL_CNT); uint32_t* sMisc = RP_LDS(uint32_t, RPL_MISC);
+    const int v = sA[i - lo];
+    if (tt < lo) {
+        const int d = tt >> RP_RSHIFT; const uint32_t sidx = atomicAdd(&sCnt[d], 1u);
+        if (sidx < RP_LDS(uint32_t, RPL_INCAP)[d]) P.inbox[RP_LDS(uint32_t, RPL_INOFF)[d] + sidx] = make_uint2((uint32_t)v | ((uint32_t)(i & 2047) << 20), (uint32_t)(tt & 16383) | ((uint32_t)(i >> 11) << 14));
+        else sMisc[1] = 1u;
+    } else {
+        int old = v; if (tt != i) { old = sA[tt - lo]; sA[tt - lo] = v; }
+        const uint32_t sidx = atomicAdd(&sMisc[0], 1u); P.outOwn[sidx] = (uint32_t)old | ((uint32_t)(i & 2047) << 20);
+    }
+}
+// The last RP_TAIL steps of a permutation, 64 at a time in the reference's order on one wave (lane = step, smaller lane = earlier; every position < RP_TAIL): a lane runs when
+// the latest earlier lane on each of its two positions has run.  Those lanes are found in a table of 64-bit lane masks per position (one ds_or + two reads per lane); the table
+// (RP_TAIL x 8 bytes over the hash keys) is all zero before and after
+__device__ __noinline__ void rp_tail_ordered(const RpPtr& P, int i, int tt, bool active) {
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long* mask = RP_LDS(unsigned long long, RPL_HKEY);
+    const bool isB = active && tt != i;
+    if (isB) atomicOr(&mask[tt], 1ull << lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long m1 = active ? mask[i] & below : 0ull, m2 = isB ? mask[tt] & below : 0ull;
+    const int d1 = m1 ? 63 - __clzll((long long)m1) : -1, d2 = m2 ? 63 - __clzll((long long)m2) : -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (isB) mask[tt] = 0ull;
+    unsigned long long done = ~__ballot(active);
+    bool mine = !active;
+    while (~done) {
+        const bool ready = !mine && (d1 < 0 || ((done >> d1) & 1ull)) && (d2 < 0 || ((done >> d2) & 1ull));
+        if (ready) { rp_exec1(P, 0, i, tt); mine = true; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        done |= __ballot(ready);
+    }
+}
+// ---- the inbox of range k: everything the ranges above owe to / want from this range, in chunks of whole producer tiles (inside a chunk the time stamps order the messages)
+__device__ __noinline__ void rp_range_inbox(const PermReq& R, int w, int b, int k) {
+    const RpPtr P = rp_ptr(R, w, b);
+    const int tid = threadIdx.x, nT = P.nT;
+    int32_t* sA = RP_LDS(int32_t, RPL_A); uint32_t* sTb = RP_LDS(uint32_t, RPL_TB); uint32_t* sDb = RP_LDS(uint32_t, RPL_DB);
+    uint32_t* hKey = RP_LDS(uint32_t, RPL_HKEY); uint32_t* hStamp = RP_LDS(uint32_t, RPL_HSTAMP); uint32_t* sRow = RP_LDS(uint32_t, RPL_ROW); int* sOver = RP_LDS(int, RPL_MISC) + 1;
+    const uint32_t inOff = RP_LDS(uint32_t, RPL_INOFF)[k];
+    const uint2* __restrict__ ib = P.inbox + inOff; uint32_t* __restrict__ ob = P.outIn + inOff;
+    const int tauLo = (k + 1) * RP_TPR;
+    int tau = nT - 1; uint32_t c0 = 0u;
+    // the chunk [c0, c1) = tiles tau .. t2 (uniform: every thread walks the row in LDS)
+    auto next_chunk = [&](int tauIn, uint32_t cIn, int& t2o, uint32_t& c1o) { int t2 = tauIn; uint32_t c1 = sRow[t2]; while (t2 - 1 >= tauLo && sRow[t2 - 1] - cIn <= (uint32_t)RP_BK) { t2--; c1 = sRow[t2]; } t2o = t2; c1o = c1; };
+    int t2 = tau; uint32_t c1 = 0u;
+    uint2 m[RP_SPT]; bool valid[RP_SPT];
+#pragma unroll
+    for (int q = 0; q < RP_SPT; q++) { valid[q] = false; m[q] = make_uint2(0u, 0u); }
+    if (tau >= tauLo) {
+        next_chunk(tau, c0, t2, c1);
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) { const uint32_t j = c0 + (uint32_t)(q * RP_T + tid); valid[q] = j < c1; if (valid[q]) m[q] = ib[j]; }
+    }
+    while (tau >= tauLo) {
+        // the messages of this chunk are in registers; those of the next one are requested before this one is worked on
+        const uint32_t cc0 = c0; const int tauN = t2 - 1; const uint32_t cN0 = c1;
+        int t2N = tauN; uint32_t cN1 = cN0; uint2 mN[RP_SPT]; bool validN[RP_SPT];
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) { validN[q] = false; mN[q] = make_uint2(0u, 0u); }
+        if (tauN >= tauLo) {
+            next_chunk(tauN, cN0, t2N, cN1);
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) { const uint32_t j = cN0 + (uint32_t)(q * RP_T + tid); validN[q] = j < cN1; if (validN[q]) mN[q] = ib[j]; }
+        }
+        if (c1 > cc0) {
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) if (valid[q]) { const int tl = (int)(m[q].y & 16383u); const uint32_t bt = 1u << (tl & 31); const uint32_t old = atomicOr(&sTb[tl >> 5], bt); if (old & bt) atomicOr(&sDb[tl >> 5], bt); }
+            __syncthreads();
+            unsigned pend = 0u; int slotq[RP_SPT];
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) {
+                slotq[q] = 0;
+                if (valid[q]) {
+                    const uint32_t j = cc0 + (uint32_t)(q * RP_T + tid); const int tl = (int)(m[q].y & 16383u); const uint32_t v = m[q].x & 0xFFFFFu, io = m[q].x >> 20;
+                    if (!rp_bit(sDb, tl)) { const int old = sA[tl]; sA[tl] = (int)v; ob[j] = (uint32_t)old | (io << 20); }
+                    else { slotq[q] = (int)rp_slot(hKey, (uint32_t)tl, sOver); pend |= 1u << q; }      // several messages name this position
+                }
+            }
+            int more = __syncthreads_or((int)pend);
+            const int dirtyChunk = more;
+            for (uint32_t round = 1; more; round++) {
+                // the earliest pending message of every position (largest i) applies; a later round's stamps outrank every earlier round's
+#pragma unroll
+                for (int q = 0; q < RP_SPT; q++) if ((pend >> q) & 1u) { const uint32_t iE = ((m[q].y >> 14) << 11) | (m[q].x >> 20); atomicMax(&hStamp[slotq[q]], (round << 20) | (iE + 1u)); }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < RP_SPT; q++) if ((pend >> q) & 1u) {
+                    const uint32_t iE = ((m[q].y >> 14) << 11) | (m[q].x >> 20);
+                    if (hStamp[slotq[q]] == ((round << 20) | (iE + 1u))) {
+                        const uint32_t j = cc0 + (uint32_t)(q * RP_T + tid); const int tl = (int)(m[q].y & 16383u);
+                        const int old = sA[tl]; sA[tl] = (int)(m[q].x & 0xFFFFFu); ob[j] = (uint32_t)old | ((m[q].x >> 20) << 20);
+                        pend &= ~(1u << q);
+                    }
+                }
+                more = __syncthreads_or((int)pend);
+                if (round > 4000u) { if (tid == 0) *sOver = 1; break; }
+            }
+            sTb[tid] = 0u; sDb[tid] = 0u;
+            if (dirtyChunk) { hKey[tid] = 0xFFFFFFFFu; hKey[tid + RP_T] = 0xFFFFFFFFu; hStamp[tid] = 0u; hStamp[tid + RP_T] = 0u; }
+            __syncthreads();
+        }
+        c0 = c1; tau = tauN; t2 = t2N; c1 = cN1;
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) { m[q] = mN[q]; valid[q] = validN[q]; }
+    }
+}
+// ---- the own steps of range k, hi - 1 down to lo (range 0: down to RP_TAIL, then the last steps through one wave)
+__device__ __noinline__ void rp_range_own(const PermReq& R, int w, int b, int k, long long* clk) {
+    const RpPtr P = rp_ptr(R, w, b);
+    const int tid = threadIdx.x, lane = tid & 63, n = P.n, nT = P.nT;
+    const int lo = k << RP_RSHIFT, hi = n < lo + RP_R ? n : lo + RP_R;
+    int32_t* sA = RP_LDS(int32_t, RPL_A); uint32_t* sTb = RP_LDS(uint32_t, RPL_TB); uint32_t* sDb = RP_LDS(uint32_t, RPL_DB);
+    uint32_t* hKey = RP_LDS(uint32_t, RPL_HKEY); uint32_t* hStamp = RP_LDS(uint32_t, RPL_HSTAMP);
+    uint32_t* sCnt = RP_LDS(uint32_t, RPL_CNT); uint32_t* sInOff = RP_LDS(uint32_t, RPL_INOFF); uint32_t* sInCap = RP_LDS(uint32_t, RPL_INCAP);
+    uint32_t* sMisc = RP_LDS(uint32_t, RPL_MISC); int* sOver = RP_LDS(int, RPL_MISC) + 1;
+    long long tClk = clk ? clock64() : 0;
+    auto lapc = [&](int slot) { if (clk) { const long long t = clock64(); clk[slot] += t - tClk; tClk = t; } };
+    const int stop = k == 0 ? (hi < RP_TAIL ? hi : RP_TAIL) : lo;
+    auto geometry = [&](int I1, int& I0o) { const int tileBase = ((I1 - 1) >> 11) << 11; int I0 = tileBase > stop ? tileBase : stop;
+                                              if (k == 0) { int bk = (int)(8.0 * sqrt((double)I1)); bk = bk < 64 ? 64 : (bk > RP_BK ? RP_BK : bk); if (I1 - bk > I0) I0 = I1 - bk; } I0o = I0; };
+    int I1 = hi, I0 = hi;
+    int t[RP_SPT];
+#pragma unroll
+    for (int q = 0; q < RP_SPT; q++) t[q] = -1;
+    if (I1 > stop) {
+        geometry(I1, I0);
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) { const int kk = tid * RP_SPT + q; if (kk < I1 - I0) t[q] = rp_target(P.draws, n, I1 - 1 - kk); }
+    }
+    while (I1 > stop) {
+        const int Bk = I1 - I0, tileBase = ((I1 - 1) >> 11) << 11, tau = tileBase >> 11;
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) {
+            const int kk = tid * RP_SPT + q;
+            if (kk < Bk) { const int i = I1 - 1 - kk, tt = t[q];
+                if (tt >= lo && tt != i) { const int tl = tt - lo; const uint32_t bt = 1u << (tl & 31); const uint32_t old = atomicOr(&sTb[tl >> 5], bt); if (old & bt) atomicOr(&sDb[tl >> 5], bt); } }
+        }
+        // the next block's targets are requested now: their loads fly while this block is worked on
+        const int I1n = I0; int I0n = I0;
+        int tn[RP_SPT];
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) tn[q] = -1;
+        if (I1n > stop) {
+            geometry(I1n, I0n);
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) { const int kk = tid * RP_SPT + q; if (kk < I1n - I0n) tn[q] = rp_target(P.draws, n, I1n - 1 - kk); }
+        }
+        __syncthreads();
+        // independent steps run here; their results and messages are appended with one reservation per wave (and destination)
+        unsigned dm = 0u, ownm = 0u, msgm = 0u; int vv[RP_SPT], ov[RP_SPT];
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) {
+            const int kk = tid * RP_SPT + q; const bool in = kk < Bk;
+            const int i = I1 - 1 - kk, tt = t[q];
+            const bool dirty = in && (rp_bit(sTb, i - lo) || (tt >= lo && tt != i && rp_bit(sDb, tt - lo)));
+            vv[q] = 0; ov[q] = 0;
+            if (in && !dirty) { const int v = sA[i - lo]; vv[q] = v; ov[q] = v; if (tt < lo) msgm |= 1u << q; else { ownm |= 1u << q; if (tt != i) { ov[q] = sA[tt - lo]; sA[tt - lo] = v; } } }
+            if (dirty) dm |= 1u << q;
+        }
+        {
+            uint32_t so = rp_wave_reserve(&sMisc[0], __popc(ownm));
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) if ((ownm >> q) & 1u) { const int i = I1 - 1 - (tid * RP_SPT + q); P.outOwn[so++] = (uint32_t)ov[q] | ((uint32_t)(i & 2047) << 20); }
+        }
+        for (int d = 0; d < k; d++) {
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) if (((msgm >> q) & 1u) && (t[q] >> RP_RSHIFT) == d) c++;
+            if (!__ballot(c > 0)) continue;
+            uint32_t sm = rp_wave_reserve(&sCnt[d], c);
+            const uint32_t cap = sInCap[d], off = sInOff[d];
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) if (((msgm >> q) & 1u) && (t[q] >> RP_RSHIFT) == d) {
+                const int i = I1 - 1 - (tid * RP_SPT + q);
+                if (sm < cap) P.inbox[off + sm] = make_uint2((uint32_t)vv[q] | ((uint32_t)(i & 2047) << 20), (uint32_t)(t[q] & 16383) | ((uint32_t)tau << 14)); else *sOver = 1;
+                sm++;
+            }
+        }
+        // ---- peel the ordered steps: a slot per position they touch; the earliest pending step on all its positions runs (a later round's stamps outrank every earlier
+        // round's).  The first round's stamps are posted right here, so a block without ordered steps costs one barrier more and a block with them two per round.
+        int sI[RP_SPT], sT2[RP_SPT];
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) { sI[q] = 0; sT2[q] = -1;
+            if ((dm >> q) & 1u) { const int i = I1 - 1 - (tid * RP_SPT + q), tt = t[q]; sI[q] = (int)rp_slot(hKey, (uint32_t)(i - lo), sOver); if (tt >= lo && tt != i) sT2[q] = (int)rp_slot(hKey, (uint32_t)(tt - lo), sOver); } }
+        unsigned pend = dm;
+        int more = __syncthreads_or((int)dm);                      // (also: every independent step has run, nobody reads the bitmaps any more)
+        const int anyOrdered = more;
+        sTb[tid] = 0u; sDb[tid] = 0u;
+        lapc(2);
+        for (uint32_t round = 1; more; round++) {
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) if ((pend >> q) & 1u) { const uint32_t key = (round << 20) | (uint32_t)(I1 - (tid * RP_SPT + q)); atomicMax(&hStamp[sI[q]], key); if (sT2[q] >= 0) atomicMax(&hStamp[sT2[q]], key); }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) if ((pend >> q) & 1u) {
+                const uint32_t key = (round << 20) | (uint32_t)(I1 - (tid * RP_SPT + q));
+                if (hStamp[sI[q]] == key && (sT2[q] < 0 || hStamp[sT2[q]] == key)) { rp_exec1(P, lo, I1 - 1 - (tid * RP_SPT + q), t[q]); pend &= ~(1u << q); }
+            }
+            more = __syncthreads_or((int)pend);
+            if (round > 4000u) { if (tid == 0) *sOver = 1; break; }
+        }
+        if (anyOrdered) { hKey[tid] = 0xFFFFFFFFu; hKey[tid + RP_T] = 0xFFFFFFFFu; hStamp[tid] = 0u; hStamp[tid + RP_T] = 0u; }
+        else __syncthreads();                                      // (the cleared bitmaps in front of the next block's marks; with ordered steps the rounds' barriers stand there)
+        lapc(3);
+        // (every step of the block has run behind the last barrier; the next block touches the counters only behind its own first barrier)
+        if (I0 == tileBase) { if (tid < k) P.endsIn[(size_t)tid * (nT + 1) + tau] = sCnt[tid]; if (tid == 0) P.endsOwn[tau] = sMisc[0]; }
+        I1 = I1n; I0 = I0n;
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) t[q] = tn[q];
+    }
+    __syncthreads();
+    if (k == 0) {
+        static_assert(RP_TAIL * 8 <= RP_HASH * 4 && RP_TAIL == RP_T, "the lane-mask table of the last steps lies over the hash keys, one entry per thread");
+        RP_LDS(unsigned long long, RPL_HKEY)[tid] = 0ull;
+        __syncthreads();
+        if (tid < 64) for (int base = I1; base > 0; base -= 64) { const int i = base - 1 - lane; const bool act = i >= 0; rp_tail_ordered(P, act ? i : -1, act ? rp_target(P.draws, n, i) : -1, act); }
+        __syncthreads();
+        if (tid == 0) P.endsOwn[0] = sMisc[0];
+        lapc(4);
+    }
+}
+// ---- the statistic (as perm_stat_tail, for FindChangePoints' own parameters: arcs of 2 .. 25 bins).  The values of a tile are gathered from the result streams into LDS
+// instead of read from a px array: the entries of tile t + 2 and the values of tile t + 1 are in flight while tile t is worked on.
+#define RP_J0 2
+#define RP_J1 25
+#define RP_NJ (RP_J1 - RP_J0 + 1)
+__device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long long* clk) {
+    const RpPtr P = rp_ptr(R, w, b);
+    const int tid = threadIdx.x, n = P.n, K = P.K, nT = P.nT;
+    long long tClk = clk ? clock64() : 0;
+    auto lapc = [&](int slot) { if (clk) { const long long t = clock64(); clk[slot] += t - tClk; tClk = t; } };
+    double* sPx = RP_LDS(double, 0); double* sT = sPx + PT_TILE;                                     // [PT_TILE], [PT_TILE + PT_HALO]
+    uint32_t* sTab = reinterpret_cast<uint32_t*>(sT + PT_TILE + PT_HALO);                            // endsOwn[nT + 1], then endsIn[K - 1][nT + 1]
+    double (*shM)[RP_T / 64] = reinterpret_cast<double (*)[RP_T / 64]>(sTab + (((size_t)K * (nT + 1) + 3) & ~size_t(1)));      // (an even number of words in front: 8-byte aligned)
+    double* shD = reinterpret_cast<double*>(shM + RP_NJ); double* sEdge = shD + (RP_T / 64 + 1);
+    int* sSrcOff = reinterpret_cast<int*>(sEdge + 2 * PT_HALO); uint32_t* sSrcBase = reinterpret_cast<uint32_t*>(sSrcOff + 4 * (RP_MAXK + 2));      // four tables each (tile & 3)
+    const uint32_t* sInOff = RP_LDS(uint32_t, RPL_INOFF);
+    const double tss = R.tss, errBound = R.errBound;
+    for (int t = tid; t <= nT; t += RP_T) sTab[t] = P.endsOwn[t];
+    for (int d = 0; d < K - 1; d++) for (int t = tid; t <= nT; t += RP_T) sTab[(size_t)(d + 1) * (nT + 1) + t] = P.endsIn[(size_t)d * (nT + 1) + t];
+    __syncthreads();
+    // sources of a tile: the own stream, and the inbox results of every lower range
+    auto fill_sources = [&](int tau) {
+        int* so = sSrcOff + (tau & 3) * (RP_MAXK + 2); uint32_t* sb = sSrcBase + (tau & 3) * (RP_MAXK + 2);
+        const int S = (tau >> 3) + 1; int run = 0;
+        for (int sI = 0; sI < S; sI++) {
+            const uint32_t beg = sTab[(size_t)sI * (nT + 1) + tau + 1], end = sTab[(size_t)sI * (nT + 1) + tau];
+            so[sI] = run; sb[sI] = (sI == 0 ? R.rp.oOutOwn : R.rp.oOutIn + sInOff[sI - 1]) + beg; run += (int)(end - beg);
+        }
+        so[S] = run;
+    };
+    auto load_entries = [&](int tau, uint32_t* ent) -> int {      // the 4 entries of this thread for the tile; 0xFFFFFFFF = none; returns 1 when the tile's sources do not add up
+        const int base = tau * PT_TILE, cnt = n - base < PT_TILE ? n - base : PT_TILE, S = (tau >> 3) + 1;
+        const int* so = sSrcOff + (tau & 3) * (RP_MAXK + 2); const uint32_t* sb = sSrcBase + (tau & 3) * (RP_MAXK + 2);
+        const bool okT = so[S] == cnt;
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) {
+            const int e = q * RP_T + tid; ent[q] = 0xFFFFFFFFu;
+            if (okT && e < cnt) { int sI = 0; while (sI + 1 < S && so[sI + 1] <= e) sI++; ent[q] = P.scr[sb[sI] + (uint32_t)(e - so[sI])]; }
+        }
+        return okT ? 0 : 1;
+    };
+    if (tid == 0) { fill_sources(0); if (nT > 1) fill_sources(1); if (nT > 2) fill_sources(2); }
+    __syncthreads();
+    uint32_t ent[RP_SPT]; int io[RP_SPT]; double xv[RP_SPT];
+    int bad = load_entries(0, ent);
+#pragma unroll
+    for (int q = 0; q < RP_SPT; q++) { io[q] = ent[q] == 0xFFFFFFFFu ? -1 : (int)(ent[q] >> 20); xv[q] = io[q] >= 0 ? P.x[ent[q] & 0xFFFFFu] : 0.0; }
+    if (nT > 1) bad |= load_entries(1, ent);
+    else {
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) ent[q] = 0xFFFFFFFFu;
+    }
+    const int wv = tid >> 6;
+    double mx[RP_NJ];
+#pragma unroll
+    for (int j = 0; j < RP_NJ; j++) mx[j] = 0.0;
+    double dcarry = 0.0;
+    for (int base = 0, tau = 0; base < n; base += PT_TILE, tau++) {
+        const int cnt = n - base < PT_TILE ? n - base : PT_TILE;
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) if (io[q] >= 0) sPx[io[q]] = xv[q];
+        __syncthreads();
+        lapc(6);
+        // values of the next tile, entries of the one after it
+#pragma unroll
+        for (int q = 0; q < RP_SPT; q++) { io[q] = ent[q] == 0xFFFFFFFFu ? -1 : (int)(ent[q] >> 20); xv[q] = io[q] >= 0 ? P.x[ent[q] & 0xFFFFFu] : 0.0; }
+        if (tau + 2 < nT) bad |= load_entries(tau + 2, ent);
+        else {
+#pragma unroll
+            for (int q = 0; q < RP_SPT; q++) ent[q] = 0xFFFFFFFFu;
+        }
+        double v[PT_PER]; double run = 0.0;
+#pragma unroll
+        for (int r = 0; r < PT_PER; r++) { const int i = tid * PT_PER + r; run += i < cnt ? sPx[i] : 0.0; v[r] = run; }
+        const double inc = rp_wave_scan_f64(run);
+        if ((tid & 63) == 63) shD[wv] = inc;
+        __syncthreads();
+        if (tid == 0 && tau + 3 < nT) fill_sources(tau + 3);      // (slot (tau + 3) & 3 held tile tau - 1: last read two iterations ago)
+        double wb = 0.0, tot = 0.0;
+        for (int kq = 0; kq < RP_T / 64; kq++) { const double tq = shD[kq]; if (kq < wv) wb += tq; tot += tq; }
+        const double before = dcarry + wb + (inc - run);
+#pragma unroll
+        for (int r = 0; r < PT_PER; r++) sT[PT_HALO + tid * PT_PER + r] = before + v[r];
+        dcarry += tot;
+        __syncthreads();
+        if (base == 0 && tid < PT_HALO) sEdge[tid] = sT[PT_HALO + tid];
+        if (base + PT_TILE >= n && tid < PT_HALO) sEdge[PT_HALO + tid] = sT[cnt + tid];
+        if (base > 0 && base + PT_TILE < n) {
+            // positions u = 4 tid .. 4 tid + 3: arcs of 2 .. 13 from sT[4 tid .. 4 tid + 16], arcs of 14 .. 25 from sT[4 tid + 14 .. 4 tid + 28] — two windows in registers, 96 arcs from 36 reads
+            const double* wp = sT + tid * PT_PER;
+            double w0[PT_PER];
+#pragma unroll
+            for (int r = 0; r < PT_PER; r++) w0[r] = wp[r];
+            {
+                double wa[15];      // wp[2 .. 16]
+#pragma unroll
+                for (int e = 0; e < 15; e++) wa[e] = wp[2 + e];
+#pragma unroll
+                for (int r = 0; r < PT_PER; r++) {
+#pragma unroll
+                    for (int j = 2; j <= 13; j++) { const double d = fabs(wa[r + j - 2] - w0[r]); mx[j - RP_J0] = d > mx[j - RP_J0] ? d : mx[j - RP_J0]; }
+                }
+            }
+            {
+                double wb2[15];     // wp[14 .. 28]
+#pragma unroll
+                for (int e = 0; e < 15; e++) wb2[e] = wp[14 + e];
+#pragma unroll
+                for (int r = 0; r < PT_PER; r++) {
+#pragma unroll
+                    for (int j = 14; j <= 25; j++) { const double d = fabs(wb2[r + j - 14] - w0[r]); mx[j - RP_J0] = d > mx[j - RP_J0] ? d : mx[j - RP_J0]; }
+                }
+            }
+        } else {
+            const int uEnd = base + PT_TILE >= n ? cnt + PT_HALO : PT_TILE;
+            for (int u = tid; u < uEnd; u += RP_T) {
+                const int a = base - PT_HALO + u;
+                if (a < 0) continue;
+                const double s0 = sT[u];
+#pragma unroll
+                for (int j = RP_J0; j <= RP_J1; j++)
+                    if (a + j < n) { const double d = fabs(sT[u + j] - s0); mx[j - RP_J0] = d > mx[j - RP_J0] ? d : mx[j - RP_J0]; }
+            }
+        }
+        __syncthreads();
+        if (tid < PT_HALO) sT[tid] = sT[PT_TILE + tid];      // (the next tile's halo; read behind two more barriers)
+        lapc(5);
+    }
+    if (tid < PT_HALO) {
+        const int a = tid;
+#pragma unroll
+        for (int j = RP_J0; j <= RP_J1; j++)
+            if (a < j) { const double d = fabs(sEdge[PT_HALO + (a + PT_HALO - j)] - sEdge[a]); mx[j - RP_J0] = d > mx[j - RP_J0] ? d : mx[j - RP_J0]; }
+    }
+#pragma unroll
+    for (int j = 0; j < RP_NJ; j++) {
+        double vv = mx[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double oo = __hiloint2double(__shfl_xor(__double2hiint(vv), d), __shfl_xor(__double2loint(vv), d)); vv = oo > vv ? oo : vv; }
+        if ((tid & 63) == 0) shM[j][tid >> 6] = vv;
+    }
+    lapc(7);
+    const int anyBad = __syncthreads_or(bad);
+    if (tid == 0) {
+        const double rn = (double)n;
+        double hLo = 0.0, hHi = 0.0;
+        for (int j = RP_J0; j <= RP_J1; j++) {
+            double vv = 0.0; for (int kq = 0; kq < RP_T / 64; kq++) vv = shM[j - RP_J0][kq] > vv ? shM[j - RP_J0][kq] : vv;
+            const double rj = (double)j, c = rn / (rj * (rn - rj));
+            const double lo2 = vv - errBound > 0.0 ? vv - errBound : 0.0, hi2 = vv + errBound;
+            const double aa = c * (lo2 * lo2) * (1.0 - 1e-15), bb = c * (hi2 * hi2) * (1.0 + 1e-15);
+            hLo = aa > hLo ? aa : hLo; hHi = bb > hHi ? bb : hHi;
+        }
+        auto norm = [&](double h) { double tq = tss; if (tq <= h + 0.0001) tq = h + 1.0; return h / ((tq - h) / (rn - 2.0)); };   // CBSTStatistic.cs:334-337
+        if (anyBad || (tss <= hLo + 0.0001) != (tss <= hHi + 0.0001)) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; }
+        else { R.pstat[2 * b] = norm(hLo) * (1.0 - 1e-15); R.pstat[2 * b + 1] = norm(hHi) * (1.0 + 1e-15); }
+    }
+    __syncthreads();
+}
 __global__ void __launch_bounds__(RP_T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_perm_rp(const PermReq* __restrict__ reqs, int nreq) {
-    // FY phase: sA 64 KB | two bitmaps | four lists | deps | row of the inbox table;   statistic: tile of values | prefix tile | the tables | maxima
-    __shared__ __align__(16) unsigned char sRaw[65536 + 2048 + 2048 + 4 * RP_CMAX * 4 + 2 * RP_CMAX * 2 + RP_CMAX + (RP_MAXT + 1) * 4 + 64];
-    __shared__ uint32_t sCnt[RP_MAXK], sInOff[RP_MAXK], sInCap[RP_MAXK];
-    __shared__ uint32_t sOwn; __shared__ int sNC, sOver;
-    int32_t* sA = reinterpret_cast<int32_t*>(sRaw);
-    uint32_t* sTb = reinterpret_cast<uint32_t*>(sRaw + 65536); uint32_t* sDb = sTb + 512;
-    int32_t* sCI = reinterpret_cast<int32_t*>(sDb + 512); int32_t* sCT = sCI + RP_CMAX; uint32_t* sCV = reinterpret_cast<uint32_t*>(sCT + RP_CMAX); uint32_t* sCJ = sCV + RP_CMAX;
-    int16_t* sDep1 = reinterpret_cast<int16_t*>(sCJ + RP_CMAX); int16_t* sDep2 = sDep1 + RP_CMAX; uint8_t* sDone = reinterpret_cast<uint8_t*>(sDep2 + RP_CMAX);
-    uint32_t* sRow = reinterpret_cast<uint32_t*>(sRaw + 65536 + 4096 + 4 * RP_CMAX * 4 + 2 * RP_CMAX * 2 + RP_CMAX);
     int ri = 0;
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].rpBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
     const PermReq& R = reqs[ri];
     if (R.fy != 3) return;
-    const int w = (int)blockIdx.x - R.rpBase, tid = threadIdx.x, lane = tid & 63;
+    const int w = (int)blockIdx.x - R.rpBase, tid = threadIdx.x;
     if (w >= R.rpWGs) return;
     const int n = R.n, K = R.rp.K, nT = R.rp.nT;
-    const double* __restrict__ x = R.x;
-    uint32_t* scr = R.rpScratch + (size_t)w * R.rp.stride;
-    uint32_t* endsIn = scr + R.rp.oEndsIn; uint32_t* endsOwn = scr + R.rp.oEndsOwn; uint2* inbox = reinterpret_cast<uint2*>(scr + R.rp.oInbox); uint32_t* outIn = scr + R.rp.oOutIn; uint32_t* outOwn = scr + R.rp.oOutOwn;
-    auto bit = [](const uint32_t* m, int p) -> bool { return (m[p >> 5] >> (p & 31)) & 1u; };
-    if (tid < RP_MAXK) { sInOff[tid] = R.rp.inOff[tid]; sInCap[tid] = R.rp.inCap[tid]; }
+    int32_t* sA = RP_LDS(int32_t, RPL_A); uint32_t* sTb = RP_LDS(uint32_t, RPL_TB); uint32_t* sDb = RP_LDS(uint32_t, RPL_DB);
+    uint32_t* hKey = RP_LDS(uint32_t, RPL_HKEY); uint32_t* hStamp = RP_LDS(uint32_t, RPL_HSTAMP); uint32_t* sRow = RP_LDS(uint32_t, RPL_ROW);
+    uint32_t* sCnt = RP_LDS(uint32_t, RPL_CNT); uint32_t* sMisc = RP_LDS(uint32_t, RPL_MISC);
     long long* clk = (w == 0 && tid == 0) ? R.rpClk : nullptr; long long tClk = clk ? clock64() : 0;
     auto lapc = [&](int slot) { if (clk) { const long long t = clock64(); clk[slot] += t - tClk; tClk = t; } };
     for (int b = w; b < R.nb; b += R.rpWGs) {
-        const uint32_t* __restrict__ draws = R.P.draws + (size_t)b * n;
-        if (tid < RP_MAXK) sCnt[tid] = 0u;
-        if (tid == 0) { sOwn = 0u; sOver = 0; endsOwn[nT] = 0u; }
-        if (tid < K - 1) endsIn[(size_t)tid * (nT + 1) + nT] = 0u;
+        const RpPtr P = rp_ptr(R, w, b);
+        if (tid < RP_MAXK) { sCnt[tid] = 0u; RP_LDS(uint32_t, RPL_INOFF)[tid] = R.rp.inOff[tid]; RP_LDS(uint32_t, RPL_INCAP)[tid] = R.rp.inCap[tid]; }      // (the statistic of the previous permutation wrote over them)
+        if (tid == 0) { sMisc[0] = 0u; sMisc[1] = 0u; sMisc[2] = 0u; P.endsOwn[nT] = 0u; }
+        if (tid < K - 1) P.endsIn[(size_t)tid * (nT + 1) + nT] = 0u;
         __syncthreads();
         for (int k = K - 1; k >= 0; k--) {
             const int lo = k << RP_RSHIFT, hi = n < lo + RP_R ? n : lo + RP_R;
             for (int p = tid; p < hi - lo; p += RP_T) sA[p] = lo + p;
             sTb[tid] = 0u; sDb[tid] = 0u;
-            if (k < K - 1) for (int t = tid; t <= nT; t += RP_T) sRow[t] = endsIn[(size_t)k * (nT + 1) + t];
+            hKey[tid] = 0xFFFFFFFFu; hKey[tid + RP_T] = 0xFFFFFFFFu; hStamp[tid] = 0u; hStamp[tid + RP_T] = 0u;
+            if (k < K - 1) for (int t = tid; t <= nT; t += RP_T) sRow[t] = P.endsIn[(size_t)k * (nT + 1) + t];
             __syncthreads();
             lapc(0);
-            // ---- the inbox: everything the ranges above owe to / want from this range, in chunks of whole producer tiles (inside a chunk the time stamps order the messages)
-            if (k < K - 1) {
-                const uint2* __restrict__ ib = inbox + sInOff[k]; uint32_t* __restrict__ ob = outIn + sInOff[k];
-                const int tauLo = (k + 1) * RP_TPR;
-                int tau = nT - 1; uint32_t c0 = 0u;
-                while (tau >= tauLo) {
-                    int t2 = tau; uint32_t c1 = sRow[t2];
-                    while (t2 - 1 >= tauLo && sRow[t2 - 1] - c0 <= (uint32_t)RP_BK) { t2--; c1 = sRow[t2]; }
-                    if (c1 > c0) {
-                        uint2 m[RP_SPT]; bool valid[RP_SPT];
-#pragma unroll
-                        for (int q = 0; q < RP_SPT; q++) { const uint32_t j = c0 + (uint32_t)(q * RP_T + tid); valid[q] = j < c1; m[q] = valid[q] ? ib[j] : make_uint2(0u, 0u); }
-#pragma unroll
-                        for (int q = 0; q < RP_SPT; q++) if (valid[q]) { const int tl = (int)(m[q].y & 16383u); const uint32_t bt = 1u << (tl & 31); const uint32_t old = atomicOr(&sTb[tl >> 5], bt); if (old & bt) atomicOr(&sDb[tl >> 5], bt); }
-                        if (tid == 0) sNC = 0;
-                        __syncthreads();
-#pragma unroll
-                        for (int q = 0; q < RP_SPT; q++) if (valid[q]) {
-                            const uint32_t j = c0 + (uint32_t)(q * RP_T + tid); const int tl = (int)(m[q].y & 16383u); const uint32_t v = m[q].x & 0xFFFFFu, io = m[q].x >> 20;
-                            if (!bit(sDb, tl)) { const int old = sA[tl]; sA[tl] = (int)v; ob[j] = (uint32_t)old | (io << 20); }
-                            else { const int sidx = atomicAdd(&sNC, 1); if (sidx < RP_CMAX) { sCI[sidx] = (int)(((m[q].y >> 14) << 11) | io); sCT[sidx] = tl; sCV[sidx] = v; sCJ[sidx] = j; } }
-                        }
-                        __syncthreads();
-                        const int nC = sNC;
-                        if (nC > RP_CMAX) { if (tid == 0) sOver = 1; }
-                        else if (nC > 0) {
-                            bool last = false; int tlE = 0; uint32_t vE = 0u;
-                            if (tid < nC) {
-                                const int iE = sCI[tid]; tlE = sCT[tid]; vE = sCV[tid];
-                                int pred = -1, predI = 0x7fffffff; bool succ = false;
-                                for (int f = 0; f < nC; f++) if (sCT[f] == tlE && f != tid) { const int iF = sCI[f]; if (iF > iE) { if (iF < predI) { predI = iF; pred = f; } } else succ = true; }
-                                const uint32_t old = pred >= 0 ? sCV[pred] : (uint32_t)sA[tlE];
-                                ob[sCJ[tid]] = old | ((uint32_t)(iE & 2047) << 20);
-                                last = !succ;
-                            }
-                            __syncthreads();
-                            if (last) sA[tlE] = (int)vE;
-                        }
-                        __syncthreads();
-                        sTb[tid] = 0u; sDb[tid] = 0u;
-                        __syncthreads();
-                    }
-                    c0 = c1; tau = t2 - 1;
-                }
-            }
+            if (k < K - 1) rp_range_inbox(R, w, b, k);
             lapc(1);
-            // ---- the range's own steps, hi - 1 down to lo (the last RP_TAIL of range 0 further down)
-            const int stop = k == 0 ? (hi < RP_TAIL ? hi : RP_TAIL) : lo;
-            int I1 = hi;
-            auto emit_own = [&](int i, int val) { const uint32_t sidx = atomicAdd(&sOwn, 1u); outOwn[sidx] = (uint32_t)val | ((uint32_t)(i & 2047) << 20); };
-            auto exec = [&](int i, int tt, int tau) {
-                const int v = sA[i - lo];
-                if (tt == i) emit_own(i, v);
-                else if (tt < lo) {
-                    const int d = tt >> RP_RSHIFT; const uint32_t sidx = atomicAdd(&sCnt[d], 1u);
-                    if (sidx < sInCap[d]) inbox[sInOff[d] + sidx] = make_uint2((uint32_t)v | ((uint32_t)(i & 2047) << 20), (uint32_t)(tt & 16383) | ((uint32_t)tau << 14));
-                    else sOver = 1;
-                } else { const int old = sA[tt - lo]; sA[tt - lo] = v; emit_own(i, old); }
-            };
-            while (I1 > stop) {
-                const int tileBase = ((I1 - 1) >> 11) << 11, tau = tileBase >> 11;
-                int I0 = tileBase > stop ? tileBase : stop;
-                if (k == 0) { int bk = (int)(8.0 * sqrt((double)I1)); bk = bk < 64 ? 64 : (bk > RP_BK ? RP_BK : bk); if (I1 - bk > I0) I0 = I1 - bk; }
-                const int Bk = I1 - I0;
-                int t[RP_SPT];
-#pragma unroll
-                for (int q = 0; q < RP_SPT; q++) {
-                    const int kk = tid * RP_SPT + q; t[q] = -1;
-                    if (kk < Bk) {
-                        const int i = I1 - 1 - kk, tt = rp_target(draws, n, i); t[q] = tt;
-                        if (tt >= lo && tt != i) { const int tl = tt - lo; const uint32_t bt = 1u << (tl & 31); const uint32_t old = atomicOr(&sTb[tl >> 5], bt); if (old & bt) atomicOr(&sDb[tl >> 5], bt); }
-                    }
-                }
-                if (tid == 0) sNC = 0;
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < RP_SPT; q++) {
-                    const int kk = tid * RP_SPT + q;
-                    if (kk < Bk) {
-                        const int i = I1 - 1 - kk, tt = t[q];
-                        const bool dirty = bit(sTb, i - lo) || (tt >= lo && tt != i && bit(sDb, tt - lo));
-                        if (!dirty) exec(i, tt, tau);
-                        else { const int sidx = atomicAdd(&sNC, 1); if (sidx < RP_CMAX) { sCI[sidx] = i; sCT[sidx] = tt; } }
-                    }
-                }
-                __syncthreads();
-                lapc(2);
-                const int nC = sNC;
-                if (nC > RP_CMAX) { if (tid == 0) sOver = 1; }
-                else if (nC > 0) {
-                    // a step waits for the latest earlier step (larger i) that names one of its two positions as its target
-                    int iE = 0, tE = 0;
-                    if (tid < nC) {
-                        iE = sCI[tid]; tE = sCT[tid];
-                        int d1 = -1, d1i = 0x7fffffff, d2 = -1, d2i = 0x7fffffff; const bool isB = tE >= lo && tE != iE;
-                        for (int f = 0; f < nC; f++) { const int iF = sCI[f], tF = sCT[f]; if (iF > iE) { if (tF == iE && iF < d1i) { d1i = iF; d1 = f; } if (isB && tF == tE && iF < d2i) { d2i = iF; d2 = f; } } }
-                        sDep1[tid] = (int16_t)d1; sDep2[tid] = (int16_t)d2; sDone[tid] = 0;
-                    }
-                    __syncthreads();
-                    for (;;) {
-                        int left = 0;
-                        if (tid < nC && !sDone[tid]) {
-                            const int d1 = sDep1[tid], d2 = sDep2[tid];
-                            if ((d1 < 0 || sDone[d1] == 1) && (d2 < 0 || sDone[d2] == 1)) { exec(iE, tE, tau); sDone[tid] = 2; } else left = 1;
-                        }
-                        const int more = __syncthreads_or(left);
-                        if (tid < nC && sDone[tid] == 2) sDone[tid] = 1;
-                        __syncthreads();
-                        if (!more) break;
-                    }
-                }
-                __syncthreads();
-                lapc(3);
-                sTb[tid] = 0u; sDb[tid] = 0u;
-                if (I0 == tileBase) { if (tid < k) endsIn[(size_t)tid * (nT + 1) + tau] = sCnt[tid]; if (tid == 0) endsOwn[tau] = sOwn; }
-                I1 = I0;
-                __syncthreads();
-            }
-            lapc(2);
-            // ---- the last steps of the permutation: one wave, 64 steps at a time, each waiting for the latest earlier lane on its two positions (every target lies in LDS here)
-            if (k == 0) {
-                if (tid < 64) {
-                    volatile int32_t* vA = sA;
-                    for (int base = I1; base > 0; base -= 64) {
-                        const int i = base - 1 - lane; const bool active = i >= 0;
-                        const int tt = active ? rp_target(draws, n, i) : -1;
-                        int d1 = -1, d2 = -1;
-#pragma unroll 8
-                        for (int j = 0; j < 63; j++) { const int tj = __shfl(tt, j, 64); if (lane > j && active) { if (tj == i) d1 = j; if (tj == tt && tt != i) d2 = j; } }
-                        unsigned long long done = ~__ballot(active);
-                        bool mine = !active;
-                        while (~done) {
-                            const bool ready = !mine && (d1 < 0 || ((done >> d1) & 1ull)) && (d2 < 0 || ((done >> d2) & 1ull));
-                            if (ready) { const int v = vA[i]; int old = v; if (tt != i) { old = vA[tt]; vA[tt] = v; } emit_own(i, old); mine = true; }
-                            __builtin_amdgcn_wave_barrier();
-                            done |= __ballot(ready);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) endsOwn[0] = sOwn;
-                lapc(4);
-            }
+            rp_range_own(R, w, b, k, clk);
+            if (clk) tClk = clock64();
             __syncthreads();
         }
-        if (sOver) { if (tid == 0) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; } __syncthreads(); continue; }
-        // ---- the statistic (as perm_stat_tail; the values of a tile are gathered from the result streams into LDS instead of read from a px array)
-        {
-            double* sPx = reinterpret_cast<double*>(sRaw); double* sT = sPx + PT_TILE;                      // [PT_TILE], [PT_TILE + PT_HALO]
-            uint32_t* sTab = reinterpret_cast<uint32_t*>(sT + PT_TILE + PT_HALO);                            // endsOwn[nT + 1], then endsIn[K - 1][nT + 1]
-            double (*shM)[RP_T / 64] = reinterpret_cast<double (*)[RP_T / 64]>(sTab + (((size_t)K * (nT + 1) + 3) & ~size_t(1)));      // (an even number of words in front: 8-byte aligned)
-            double* shD = reinterpret_cast<double*>(shM + (PG_MAXK + 1)); double* sEdge = shD + (RP_T / 64 + 1);
-            int* sSrcOff = reinterpret_cast<int*>(sEdge + 2 * PT_HALO); uint32_t* sSrcBase = reinterpret_cast<uint32_t*>(sSrcOff + RP_MAXK + 2);
-            const int hk = R.hk, al0 = R.al0; const double tss = R.tss, errBound = R.errBound;
-            for (int t = tid; t <= nT; t += RP_T) sTab[t] = endsOwn[t];
-            for (int d = 0; d < K - 1; d++) for (int t = tid; t <= nT; t += RP_T) sTab[(size_t)(d + 1) * (nT + 1) + t] = endsIn[(size_t)d * (nT + 1) + t];
-            __syncthreads();
-            const int wv = tid >> 6;
-            double mx[PG_MAXK + 1];
-#pragma unroll
-            for (int j = 0; j <= PG_MAXK; j++) mx[j] = 0.0;
-            double dcarry = 0.0; int bad = 0;
-            for (int base = 0, tau = 0; base < n; base += PT_TILE, tau++) {
-                const int cnt = n - base < PT_TILE ? n - base : PT_TILE;
-                // sources of the tile: the own stream, and the inbox results of every lower range
-                const int S = (tau >> 3) + 1;
-                if (tid == 0) {
-                    int run = 0;
-                    for (int sI = 0; sI < S; sI++) {
-                        const uint32_t beg = sTab[(size_t)sI * (nT + 1) + tau + 1], end = sTab[(size_t)sI * (nT + 1) + tau];
-                        sSrcOff[sI] = run; sSrcBase[sI] = (sI == 0 ? R.rp.oOutOwn : R.rp.oOutIn + sInOff[sI - 1]) + beg; run += (int)(end - beg);
-                    }
-                    sSrcOff[S] = run;
-                }
-                __syncthreads();
-                lapc(5);
-                if (sSrcOff[S] != cnt) bad = 1;
-                else {
-#pragma unroll
-                    for (int q = 0; q < RP_SPT; q++) {
-                        const int e = q * RP_T + tid;
-                        if (e < cnt) {
-                            int sI = 0; while (sI + 1 < S && sSrcOff[sI + 1] <= e) sI++;
-                            const uint32_t ent = scr[sSrcBase[sI] + (uint32_t)(e - sSrcOff[sI])];
-                            sPx[ent >> 20] = x[ent & 0xFFFFFu];
-                        }
-                    }
-                }
-                __syncthreads();
-                lapc(6);
-                double v[PT_PER]; double run = 0.0;
-#pragma unroll
-                for (int r = 0; r < PT_PER; r++) { const int i = tid * PT_PER + r; run += i < cnt ? sPx[i] : 0.0; v[r] = run; }
-                double inc = run;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const double oo = __hiloint2double(__shfl_up(__double2hiint(inc), d), __shfl_up(__double2loint(inc), d)); if ((tid & 63) >= d) inc += oo; }
-                if ((tid & 63) == 63) shD[wv] = inc;
-                __syncthreads();
-                double wb = 0.0, tot = 0.0;
-                for (int kq = 0; kq < RP_T / 64; kq++) { const double tq = shD[kq]; if (kq < wv) wb += tq; tot += tq; }
-                const double before = dcarry + wb + (inc - run);
-#pragma unroll
-                for (int r = 0; r < PT_PER; r++) sT[PT_HALO + tid * PT_PER + r] = before + v[r];
-                dcarry += tot;
-                __syncthreads();
-                if (base == 0 && tid < PT_HALO) sEdge[tid] = sT[PT_HALO + tid];
-                if (base + PT_TILE >= n && tid < PT_HALO) sEdge[PT_HALO + tid] = sT[cnt + tid];
-                const int uEnd = base + PT_TILE >= n ? cnt + PT_HALO : PT_TILE;
-                for (int u = tid; u < uEnd; u += RP_T) {
-                    const int a = base - PT_HALO + u;
-                    if (a < 0) continue;
-                    const double s0 = sT[u];
-#pragma unroll
-                    for (int j = 2; j <= PG_MAXK; j++)
-                        if (j >= al0 && j <= hk && a + j < n) { const double d = fabs(sT[u + j] - s0); mx[j] = d > mx[j] ? d : mx[j]; }
-                }
-                __syncthreads();
-                if (tid < PT_HALO) sT[tid] = sT[PT_TILE + tid];
-                __syncthreads();
-            }
-            if (tid < PT_HALO) {
-                const int a = tid;
-#pragma unroll
-                for (int j = 2; j <= PG_MAXK; j++)
-                    if (j >= al0 && j <= hk && a < j) { const double d = fabs(sEdge[PT_HALO + (a + PT_HALO - j)] - sEdge[a]); mx[j] = d > mx[j] ? d : mx[j]; }
-            }
-#pragma unroll
-            for (int j = 2; j <= PG_MAXK; j++) {
-                double vv = mx[j];
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) { const double oo = __hiloint2double(__shfl_xor(__double2hiint(vv), d), __shfl_xor(__double2loint(vv), d)); vv = oo > vv ? oo : vv; }
-                if ((tid & 63) == 0) shM[j][tid >> 6] = vv;
-            }
-            lapc(7);
-            const int anyBad = __syncthreads_or(bad);
-            if (tid == 0) {
-                const double rn = (double)n;
-                double hLo = 0.0, hHi = 0.0;
-                for (int j = al0; j <= hk && j <= PG_MAXK; j++) {
-                    double vv = 0.0; for (int kq = 0; kq < RP_T / 64; kq++) vv = shM[j][kq] > vv ? shM[j][kq] : vv;
-                    const double rj = (double)j, c = rn / (rj * (rn - rj));
-                    const double lo2 = vv - errBound > 0.0 ? vv - errBound : 0.0, hi2 = vv + errBound;
-                    const double aa = c * (lo2 * lo2) * (1.0 - 1e-15), bb = c * (hi2 * hi2) * (1.0 + 1e-15);
-                    hLo = aa > hLo ? aa : hLo; hHi = bb > hHi ? bb : hHi;
-                }
-                auto norm = [&](double h) { double tq = tss; if (tq <= h + 0.0001) tq = h + 1.0; return h / ((tq - h) / (rn - 2.0)); };   // CBSTStatistic.cs:334-337
-                if (anyBad || (tss <= hLo + 0.0001) != (tss <= hHi + 0.0001)) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; }
-                else { R.pstat[2 * b] = norm(hLo) * (1.0 - 1e-15); R.pstat[2 * b + 1] = norm(hHi) * (1.0 + 1e-15); }
-            }
-            __syncthreads();
-        }
+        if (sMisc[1]) { __syncthreads(); if (tid == 0) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; } continue; }
+        rp_statistic(R, w, b, clk);
+        if (clk) tClk = clock64();
     }
 }
 
@@ -1944,7 +2131,11 @@ struct PermService {
         bool anyFy = false, anyOld = false, anySmall = false; for (int i = 0; i < R; i++) (batch[i]->r.fy == 2 ? anySmall : batch[i]->r.fy == 1 ? anyFy : batch[i]->r.fy == 0 ? anyOld : anySmall /* (3: below) */) |= batch[i]->r.fy != 3;
         if (anyOld) hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         if (anyFy) hipLaunchKernelGGL(k_perm_fy, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
-        if (rpBlocks) hipLaunchKernelGGL(k_perm_rp, dim3(rpBlocks), dim3(RP_T), 0, stream, dReqs, R);
+        if (rpBlocks) {
+            static const hipError_t ldsAttr = hipFuncSetAttribute((const void*)k_perm_rp, hipFuncAttributeMaxDynamicSharedMemorySize, RPL_TOTAL);      // (more than the 64 KB a kernel gets without asking)
+            CANVAS_HIP_TRY(ctx, ldsAttr);
+            hipLaunchKernelGGL(k_perm_rp, dim3(rpBlocks), dim3(RP_T), RPL_TOTAL, stream, dReqs, R);
+        }
         if (anySmall) hipLaunchKernelGGL(k_perm_small, dim3(blocks), dim3(64), 0, stream, dReqs, R);
         if (probeTiming) { lastMs[0] = msA; lastMs[1] = msB; lastMs[2] = lap(); }
         else if (dbg) { const double msC = lap(); int nc = 0, maxN = 0; for (int i = 0; i < R; i++) { nc += batch[i]->r.cont; maxN = std::max(maxN, batch[i]->r.n); }
@@ -2005,7 +2196,7 @@ static void perm_reserve_bytes(size_t nMax, size_t& dev, size_t& pin) {
 static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int hk, int al0, double ostat, int nrejc, int k,
                              const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st, int& outcome) {
     canvas_ctx* ctx = PG.ctx;
-    const bool useRp = perm_use_rp(n);
+    const bool useRp = perm_use_rp(n) && hk == RP_J1 && al0 == RP_J0;      // (k_perm_rp's statistic is written for FindChangePoints' own arc lengths)
     const int maxB = perm_max_batch(n);
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     auto now = []() { return std::chrono::steady_clock::now(); };
