@@ -144,7 +144,7 @@ def main():
 
     # the timed passes carry ONE hipEvent pair (around the dominant kernel, for `roofline`): every further scope costs two barrier packets on the stream (~10 us of a pass);
     # the other stages' device times come from untimed passes with every scope on, right after the timed region
-    ALL_SCOPES = ("bin_pass", "bin_tile_stats", "bin_summary", "bin_close", "bin_resolve", "viterbi", "viterbi_sequential", "viterbi_retry", "clean_total")
+    ALL_SCOPES = ("bin_pass", "bin_tile_stats", "bin_summary", "bin_close", "bin_resolve", "viterbi", "viterbi_sequential", "viterbi_retry", "clean_total", "pass_span")
     cv.profile_enable(2)
     for _ in range(args.warmup):
         step()
@@ -160,6 +160,7 @@ def main():
     ms_bin, k_bin = cv.profile_get("bin_pass")
     ms_stats, k_stats = cv.profile_get("bin_tile_stats")
     ms_sum, k_sum = cv.profile_get("bin_summary")
+    ms_span, k_span = cv.profile_get("pass_span")      # the timed passes' own device spans (one event pair per pass, on the library's stream)
     cv.profile_enable(1)
     for name in ALL_SCOPES:
         cv.profile_get(name, reset=True)
@@ -227,6 +228,11 @@ def main():
     roofline["bin_tail_ms"] = round(ms_close / max(1, k_close) + ms_res / max(1, k_res), 4) if single_read else None
     roofline["viterbi_ms"] = round(ms_vit / max(1, k_vit), 4)
     roofline["stage_scopes_from"] = "%d untimed passes with every scope on, after the timed region (the timed passes carry only the dominant kernel's event pair)" % PROF_PASSES
+    if k_span:
+        # measured IN the timed run: the device span of a pass (event pair around canvas_sample_pipeline on its own stream) against the wall time per pass
+        roofline["pass_span_ms"] = round(ms_span / k_span, 4)
+        roofline["hand_over_us_per_pass"] = round(max(0.0, ms_per_step - ms_span / k_span) * 1e3, 1)
+        roofline["hand_over_source"] = "ms_per_step - pass_span_ms of the %d timed passes (hipEvent pair around the whole call, library stream): the device time per pass that belongs to no pass" % k_span
     tl = os.path.join(ROOT, "profiles", "pass_timeline.json")
     if os.path.exists(tl):
         tj = json.load(open(tl))

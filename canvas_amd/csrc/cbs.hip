@@ -2025,7 +2025,7 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
 // Mersenne Twister (whose state every later permutation of the chromosome continues from) and each reading what the previous ones wrote — nothing in it is independent, so one
 // lane of one wave walks it exactly as the reference does: the segment's copy in LDS when it fits (else in global scratch), the generator's 624 words in LDS, twisted in place.
 // A lane needs ~0.15 us per swap where a host core needs 5 ns: the host chain stays the default, this kernel is the parity-tested drop-in for a host without spare cores.
-#define TPERMP_LDS_MAX 16384
+#define TPERMP_LDS_MAX 4096              // (32 KB of LDS; longer segments walk a copy in global scratch)
 __global__ void __launch_bounds__(64) k_tpermp(const double* __restrict__ gd, int n1, int n2, uint32_t nPerm, uint32_t* __restrict__ mtState /* 624 words + index, in and out */,
                                                double* __restrict__ scratch, int32_t* __restrict__ out /* nrej, swaps made (0: the shortcut) */) {
     __shared__ uint32_t mt[624];
@@ -2076,17 +2076,20 @@ __global__ void __launch_bounds__(64) k_tpermp(const double* __restrict__ gd, in
     mtState[624] = (uint32_t)mti;
     out[0] = nrej; out[1] = swaps > 0 ? 1 : 0;
 }
-static double tpermp(int n1, int n2, int n, const double* gd, int off, double* px, uint32_t nPerm, MT& rnd, Stats& st);
-static bool tpermp_device(int n1, int n2, int n, const double* gd, int off, uint32_t nPerm, MT& rnd, Stats& st, double& p) {
+struct PermGpu;
+static bool tpermp_device(PermGpu& PG, int n1, int n2, int n, const double* gd, int off, uint32_t nPerm, MT& rnd, Stats& st, double& p);
+static bool tpermp_device_impl(canvas_ctx* ctx, hipStream_t stream, int n1, int n2, int n, const double* gd, int off, uint32_t nPerm, MT& rnd, Stats& st, double& p) {
+    if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); return false; }      // (chromosome and helper threads: the context's device, its engine's own stream)
     char* d = nullptr;
     const size_t bytesX = (size_t)n * 8, offState = (bytesX + 255) & ~size_t(255), offScr = offState + 4096, offOut = offScr + ((bytesX + 255) & ~size_t(255));
     if (hipMalloc((void**)&d, offOut + 256) != hipSuccess) { (void)hipGetLastError(); return false; }
     uint32_t state[625]; rnd.get_state(state);
     int32_t out[2] = {0, 0};
-    bool ok = hipMemcpy(d, gd + off, bytesX, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d + offState, state, sizeof state, hipMemcpyHostToDevice) == hipSuccess;
+    bool ok = hipMemcpyAsync(d, gd + off, bytesX, hipMemcpyHostToDevice, stream) == hipSuccess && hipMemcpyAsync(d + offState, state, sizeof state, hipMemcpyHostToDevice, stream) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_tpermp, dim3(1), dim3(64), 0, 0, (const double*)d, n1, n2, nPerm, (uint32_t*)(d + offState), (double*)(d + offScr), (int32_t*)(d + offOut));
-        ok = hipMemcpy(out, d + offOut, sizeof out, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(state, d + offState, sizeof state, hipMemcpyDeviceToHost) == hipSuccess;
+        hipLaunchKernelGGL(k_tpermp, dim3(1), dim3(64), 0, stream, (const double*)d, n1, n2, nPerm, (uint32_t*)(d + offState), (double*)(d + offScr), (int32_t*)(d + offOut));
+        ok = hipMemcpyAsync(out, d + offOut, sizeof out, hipMemcpyDeviceToHost, stream) == hipSuccess && hipMemcpyAsync(state, d + offState, sizeof state, hipMemcpyDeviceToHost, stream) == hipSuccess
+             && hipStreamSynchronize(stream) == hipSuccess;
     }
     (void)hipFree(d);
     if (!ok) { (void)hipGetLastError(); return false; }
@@ -2096,8 +2099,8 @@ static bool tpermp_device(int n1, int n2, int n, const double* gd, int off, uint
     p = (double)out[0] / nPerm;
     return true;
 }
-static double tpermp(int n1, int n2, int n, const double* gd, int off, double* px, uint32_t nPerm, MT& rnd, Stats& st) {   // CBSTStatistic.cs:947-1024
-    { static const bool onDevice = getenv("CANVAS_CBS_DEVICE_TPERMP") != nullptr; double p; if (onDevice && tpermp_device(n1, n2, n, gd, off, nPerm, rnd, st, p)) return p; }
+static double tpermp(PermGpu& PG, int n1, int n2, int n, const double* gd, int off, double* px, uint32_t nPerm, MT& rnd, Stats& st) {   // CBSTStatistic.cs:947-1024
+    { static const bool onDevice = getenv("CANVAS_CBS_DEVICE_TPERMP") != nullptr; double p; if (onDevice && tpermp_device(PG, n1, n2, n, gd, off, nPerm, rnd, st, p)) return p; }
     double rn1 = (double)n1, rn2 = (double)n2, rn = rn1 + rn2; int nrej;
     if (n1 == 1 || n2 == 1) nrej = (int)nPerm;
     else {
@@ -2188,6 +2191,10 @@ struct PermGpu {
     ~PermGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (buf) (void)hipFree(buf); if (pin) (void)hipHostFree(pin);
                  if (tailStream) { (void)hipStreamSynchronize(tailStream); (void)hipStreamDestroy(tailStream); } if (tailDev) (void)hipFree(tailDev); if (tailPin) (void)hipHostFree(tailPin); }
 };
+static bool tpermp_device(PermGpu& PG, int n1, int n2, int n, const double* gd, int off, uint32_t nPerm, MT& rnd, Stats& st, double& p) {
+    if (PG.ensure_tail() != CANVAS_OK) return false;
+    return tpermp_device_impl(PG.ctx, PG.tailStream, n1, n2, n, gd, off, nPerm, rnd, st, p);
+}
 // TailP for the two decisions of FindChangePoints: device approximation, accepted only when every p1 within 1e-8 relative gives the same decisions; else the exact host series
 static int32_t tail_p_decide(PermGpu& PG, double b, double delta, int m, double cutoff, uint32_t nPerm, Stats& st, bool& exitNoSplit, int& nrejc) {
     const int nGrid = 100; const double tol = 1E-6;
@@ -2697,9 +2704,9 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
     else if (iseg[0] == 0) { nCp = 1; iCp[0] = iseg[1]; }
     else {
         int n1 = iseg[0], n12 = iseg[1], n2 = n12 - n1;
-        if (tpermp(n1, n2, n12, gd, 0, px.data(), nPerm, rnd, st) <= cutoff) { nCp = 1; iCp[0] = iseg[0]; }
+        if (tpermp(PG, n1, n2, n12, gd, 0, px.data(), nPerm, rnd, st) <= cutoff) { nCp = 1; iCp[0] = iseg[0]; }
         int off = iseg[0]; n12 = n - iseg[0]; n2 = n - iseg[1]; n1 = n12 - n2;
-        if (tpermp(n1, n2, n12, gd, off, px.data(), nPerm, rnd, st) <= cutoff) { nCp++; iCp[nCp - 1] = iseg[1]; }
+        if (tpermp(PG, n1, n2, n12, gd, off, px.data(), nPerm, rnd, st) <= cutoff) { nCp++; iCp[nCp - 1] = iseg[1]; }
     }
     return CANVAS_OK;
 }

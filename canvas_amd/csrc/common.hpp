@@ -74,6 +74,7 @@ struct canvas_ctx {
     long long wv_stats[4] = {0, 0, 0, 0};     // ... long nodes decided from the closed form / sent to the chain undecided / chained for their coefficient; closed form in use
     unsigned mail_seq = 0;      // sequence numbers of the results kernels write straight into pinned host memory (cvx_mail_*, below)
     unsigned covq_seq = 0;      // ... the one the pending quartile result (covq_pin) will carry
+    double hmm_dispersion = 1e9;      // IQR / median of the coverage PerSampleHMM was last set up for (hmm.hip: the first speculative attempt's lead-in)
     int hmm_retry = 0;     // chromosomes that needed the second speculative attempt (longer lead-ins) in the last HMM call
     int hmm_redo = 0;      // chromosomes recomputed sequentially by the last canvas_hmm_per_sample (speculation failures)
     // profiling: hipEvent pairs around named kernels

@@ -323,7 +323,8 @@ __global__ void __launch_bounds__(64) k_viterbi(const HmmChrom* __restrict__ chr
 // contiguous bytes; bin indices / states / increments are fetched through a small per-lane register queue PQ steps ahead.
 // Back-pointers are packed 3 bits per state into one uint16 per bin.
 #define VB 128       // block length
-#define VW 128       // cold-start lead-in of the speculative pass, first attempt (a run-time argument: the retry uses 8x)
+#define VW0 16       // cold-start lead-in of the speculative pass, first attempt
+#define VW 128       // ... second attempt (a run-time argument; the later ones use 8x, 64x, 512x)
 #define VW2 64       // lead-in of the verification pass, first attempt (a multiple of 64: carry[] holds D at multiples of 64)
 #define PQ 8         // per-lane prefetch depth in steps
 #define MAP_IDENT (0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12))
@@ -1593,6 +1594,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
     }
     // phase A of the mode: everything the set-up kernel needs (PerSampleHMM: the threshold); phase B: the emission tables, computed on the host while the set-up kernel runs
     HmmParams P; HmmEmis E;
+    ctx->hmm_dispersion = 1e9;          // (prepareA of the per-sample model sets it; the joint model keeps the long first lead-in)
     rc = prepareA(ws, P, E, (const HmmChrom*)dChroms, (const int64_t*)dOffDev); if (rc) return rc;
     {
         const int64_t most = std::max<int64_t>(std::max<int64_t>(E.indexCov ? N : 0, nblocks), std::max<int64_t>(std::max(nblocksS, nchunks), nchr));
@@ -1636,14 +1638,23 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         // (a fourth attempt with 512x: 65 536 / 32 768 steps reach the start of every chromosome of up to ~65 000 bins, where both passes then start from the exact
         // initial state — the last fallbacks of the noise-40 soak were such chromosomes, whose off-backbone states did not re-anchor within 4 096 steps; for a chr1-size
         // chromosome the attempt costs ~7 ms, an eighth of the sequential kernel)
-        for (int attempt = 0; attempt < 4; attempt++) {
-            const int mult = attempt == 0 ? 1 : (attempt == 1 ? 8 : (attempt == 2 ? 64 : 512));
-            const int leadSpec = mult * VW, leadVer = mult * VW2;
+        // (round 5: two thirds of a speculative lane's steps were lead-in.  At the coverage CanvasPartition sees, the five states' paths merge within a handful of bins, so the
+        // first attempt now starts VW0 = 16 steps in front of its block — k_vit_spec 122 -> 60 us on the WGS sample — and a chromosome that fails its verification first gets
+        // the 128-step lead-in of the earlier rounds, with the same cheap backbone, before the long lead-ins with the plain chain)
+        // How fast the paths merge goes with how well the states are separated, i.e. with the sample's relative dispersion r = IQR / median of the coverage (known on the host:
+        // the emission model is built from the same quartiles).  Share of randomised PerSampleHMM calls that needed the second attempt (tools/soak.py, SOAK_DISPERSION=1):
+        // r < 0.20: 0 % at 16 steps; 0.20-0.30: 8-34 % at 16, 4-7 % at 32, 0.2 % at 64; r >= 0.30: most at 16 / 32, 5 % (r < 0.4) to 25-90 % at 64 — those keep 128
+        static const int vwEnv = getenv("CANVAS_HMM_LEAD") ? atoi(getenv("CANVAS_HMM_LEAD")) : 0;      // (test hook: the first attempt's cold-start lead-in)
+        const int vw0 = vwEnv > 0 ? vwEnv : (ctx->hmm_dispersion < 0.20 ? VW0 : (ctx->hmm_dispersion < 0.30 ? 64 : VW));
+        const int nAttempts = 5;
+        for (int attempt = 0; attempt < nAttempts; attempt++) {
+            const int mult = attempt <= 1 ? 1 : (attempt == 2 ? 8 : (attempt == 3 ? 64 : 512));
+            const int leadSpec = attempt == 0 ? vw0 : mult * VW, leadVer = mult * VW2;
             if (attempt > 0) CANVAS_HIP_TRY(ctx, hipMemsetAsync(dFail, 0, nchr * 4, ctx->stream));      // (attempt 0: cleared by the set-up kernel)
             const dim3 gs((unsigned)((nblocksS + 63) / 64));
             // (the last two attempts run the recurrence in the reference's own form: the two-constant form of the transition term rounds differently, and a near-tie that it
             // resolves the other way fails the verification whatever the lead-in — together with a lead-in that reaches the chromosome's start the guess is then exact)
-            const bool twoValued = twoValuedAll && attempt < 2;
+            const bool twoValued = twoValuedAll && attempt < 3;
             if (lds && twoValued) hipLaunchKernelGGL((k_vit_spec<true, true>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             else if (lds) hipLaunchKernelGGL((k_vit_spec<true, false>), gs, dim3(64), lds, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             else if (twoValued) hipLaunchKernelGGL((k_vit_spec<false, true>), gs, dim3(64), 0, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
@@ -1655,7 +1666,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             const char* bbMode = getenv("CANVAS_HMM_BACKBONE");      // "chain" | "scan" | default: predicted pieces
             // (a retry takes the plain chain for its backbone: the predicted pieces below give up on increments they cannot bracket — more binade crossings in a chunk than
             // they keep, exponents that do not behave — and no longer lead-in changes that; the chain is one FP64 add per step, 1.5 ms for a chr1-size chromosome)
-            if ((bbMode && !strcmp(bbMode, "chain")) || (attempt > 0 && !bbMode)) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry, dTodo);
+            if ((bbMode && !strcmp(bbMode, "chain")) || (attempt > 1 && !bbMode)) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry, dTodo);
             else if (bbMode && !strcmp(bbMode, "scan")) hipLaunchKernelGGL(k_vit_backbone_scan, dim3(nchr), dim3(BS_T), 0, ctx->stream, dChroms, dD, dCarry, dFail);
             else {
                 hipLaunchKernelGGL(k_bb_sums, dim3(nchunks), dim3(256), 0, ctx->stream, dBChunks, dChroms, dD, dChunkSum, dFail);
@@ -1679,7 +1690,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             for (int c = 0; c < nchr; c++) if (hFail[c] && chroms[c].T > 10) redo.push_back(c);
             if (!redo.empty() && getenv("CANVAS_HMM_DEBUG_FAIL")) { fprintf(stderr, "viterbi attempt %d (lead-in x%d):", attempt, mult); for (int c : redo) fprintf(stderr, " chr%d(T=%lld, why=0x%x)", c, (long long)chroms[c].T, (unsigned)hFail[c]); fprintf(stderr, "\n"); }
             if (redo.empty() || getenv("CANVAS_HMM_TEST_CORRUPT") || getenv("CANVAS_HMM_NO_RETRY")) break;
-            if (attempt < 3) {       // the failed chromosomes become the to-do mask of the next attempt (dRedo doubles as the mask: nchr entries)
+            if (attempt < nAttempts - 1) {       // the failed chromosomes become the to-do mask of the next attempt (dRedo doubles as the mask: nchr entries)
                 if (attempt == 0) { ctx->hmm_retry = (int)redo.size(); { ProfScope pr(ctx, "viterbi_retry"); } }     // counted for the tests / bench
                 int32_t rcq = canvas_h2d_small(ctx, dRedo, hFail, nchr * 4); if (rcq) return rcq;
                 dTodo = dRedo;
@@ -1760,6 +1771,7 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     quartile_val(nAll, v, q1, q2, q3);
     const double median = (double)q2;
     const float iqr = q3 - q1;
+    ctx->hmm_dispersion = q2 > 0 ? (double)iqr / (double)q2 : 1e9;      // (chooses the first attempt's lead-in: hmm_pipeline)
     pseudoVariance = (double)(iqr * iqr);
     // 2. emission tables (HiddenMarkovModelsRunner.cs:111-152)
     haploidMean = median / 2.0;

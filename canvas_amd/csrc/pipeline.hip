@@ -21,6 +21,7 @@ static int32_t sample_pipeline_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t
     auto tNow = []() { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     const auto t0 = tNow();
+    ProfScope psSpan(ctx, "pass_span", true);      // the pass on the device timeline: from where the stream stands when the call starts to behind its last kernel (bench.py: hand-over between passes = wall - span)
     int32_t binSize = 0; int64_t total = 0, nClean = 0, nseg = 0; double lsd = -1.0; int32_t info[8];
     std::vector<int64_t> perChr((size_t)nchr);
     int32_t rc = h_pos0 ? canvas_bin_sample_packed(ctx, nchr, (const uint64_t* const*)d_bases, (const uint64_t* const*)d_hits, h_len, h_pos0, h_chr_is_autosome, counts_per_bin, bin_size_in, mode,

@@ -11,7 +11,7 @@ from canvas_amd import Canvas, synth, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIE
 
 cv = Canvas(0); cv.profile_enable(True)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
-t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}; nbatch = 0; ncount = 0
+t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}; nbatch = 0; ncount = 0; by_noise = {}; by_disp = {}
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 while time.time() - t0 < budget:
     seed = int(rng.randint(1, 2**31 - 1)); n = int(rng.choice([3_000, 30_000, 120_000, 600_000])); nchr = int(rng.choice([1, 3, 24]))
@@ -58,7 +58,11 @@ while time.time() - t0 < budget:
         off = cv.chromosome_offsets(dev["chr"], n_out, nchr)
         cv.profile_get("viterbi_sequential", reset=True); cv.profile_get("viterbi_retry", reset=True)
         st = cv.hmm_per_sample(cov, off).cpu().numpy()
-        f1 = cv.profile_get("viterbi_sequential")[1]; fallbacks += f1; retries += cv.profile_get("viterbi_retry")[1]
+        f1 = cv.profile_get("viterbi_sequential")[1]; fallbacks += f1; r1 = cv.profile_get("viterbi_retry")[1]; retries += r1
+        rn = by_noise.setdefault(float(noise), [0, 0]); rn[0] += 1; rn[1] += 1 if r1 else 0
+        if os.environ.get("SOAK_DISPERSION"):      # (how the need for a second attempt goes with the sample's relative dispersion: the quantity the first lead-in is chosen from)
+            hq = np.percentile(cov.cpu().numpy(), [25, 50, 75]); rr = (hq[2] - hq[0]) / max(hq[1], 1e-9)
+            key = min(20, int(rr / 0.05)); dv = by_disp.setdefault(key, [0, 0]); dv[0] += 1; dv[1] += 1 if r1 else 0
         if f1: fb[(n, nchr, float(noise))] = fb.get((n, nchr, float(noise)), 0) + 1
         hc = cov.cpu().numpy()
         per = [np.ascontiguousarray(hc[off[c]:off[c + 1]]) for c in range(nchr)]
@@ -68,4 +72,6 @@ while time.time() - t0 < budget:
             assert (st[off[c]:off[c + 1]] == e).all(), ("hmm", seed, n, nchr, c)
     it += 1
 print("fallback runs by (n, nchr, noise):", sorted(fb.items()))
+print("PerSampleHMM calls that needed a second speculative attempt, by the noise added to the counts:", {k: "%d of %d" % (v[1], v[0]) for k, v in sorted(by_noise.items())})
+if by_disp: print("... by iqr / median of the coverage (bins of 0.05):", {"%.2f" % (k * 0.05): "%d of %d" % (v[1], v[0]) for k, v in sorted(by_disp.items())})
 print(f"soak: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s; {nbatch} of them inside a cohort call; {ncount} decided by the per-value counters; second speculative attempts: {retries}, sequential Viterbi fallbacks: {fallbacks}")
