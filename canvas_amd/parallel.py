@@ -525,6 +525,71 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             barrier()
     except Exception as e:                                        # noqa: BLE001
         ped = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- BASELINE configs[3] on more ranks than samples: a TRIO on samples x chromosome groups (3 + 3 + 2 ranks at N = 8; sample_groups) — the multi-sample bin size and the bin
+    # intersection span the world communicator, CanvasBin and PerSampleHMM run sharded inside each sample's sub-communicator (canvas_comm_split / canvas_comm_restore).  Rank 0
+    # repeats the trio on its own GPU and compares its sample's result; the ranks of one sample must agree among themselves.  Untimed for `value`.
+    grid = {}
+    try:
+        if world >= 3 and "error" not in part and "error" not in ped:
+            from .lib import synth_generate_sample_device
+            layout = sample_groups(world, 3)
+            gs_, gg_, gn_ = layout[rank]
+            gowner = owner_table(lengths, gn_)
+            thr_g = torch.from_numpy(synth.poisson_thresholds(args.rate).view(np.int32)).to(device)
+            gb, gm, gh = [None] * nchr, [None] * nchr, [None] * nchr
+            for c in range(nchr):
+                if gowner[c] == gg_:
+                    if rank == 0: gb[c], gm[c] = cb[c], cm[c]                       # (rank 0's cohort sample was generated from `seed`: its bases / masks ARE the reference)
+                    else: gb[c], _, gm[c], thr = synth_generate_device(seed, c, lengths[c], args.rate, device, thr)
+                    gh[c] = synth_generate_sample_device(seed, seed + 5000 + 31 * gs_, c, int(lengths[c]), thr_g, device)[0]
+            torch.cuda.synchronize()
+            enter_world = lambda: restore_library_comm(cv)
+            enter_group = lambda: split_library_comm(cv, gs_, gg_)
+            flow = lambda: pedigree_grid_flow(cv, layout, rank, enter_world, enter_group, gb, gm, gh, lens, is_auto, flags)
+            flow(); enter_world(); barrier()
+            t0 = time.perf_counter(); gr = flow(); enter_world(); barrier()
+            gsec = max_over_ranks(time.perf_counter() - t0, device)
+            k = gr["n"]
+            dig = torch.stack([gr["start"].to(torch.int64).sum(), gr["stop"].to(torch.int64).sum(), (gr["chr"].to(torch.int64) * (torch.arange(k, device=device) % 1009)).sum(),
+                               torch.tensor(k, device=device), torch.tensor(int(gr["bin_size"]), device=device), gr["count"].view(torch.int32).to(torch.int64).sum(),
+                               (gr["state"][:k].to(torch.int64) * (torch.arange(k, device=device) % 1013)).sum()])
+            digs = [torch.zeros_like(dig) for _ in range(world)]
+            dist.all_gather(digs, dig)
+            # the bins (first five words) are the pedigree's: the same on every rank; counts and states are the sample's: the same inside a group
+            same_bins = bool(all((d[:5] == digs[0][:5]).all() for d in digs))
+            same_in_group = bool(all((digs[r_] == digs[rr_]).all() for r_ in range(world) for rr_ in range(world) if layout[r_][0] == layout[rr_][0]))
+            eq = None; sec1 = None
+            if rank == 0:
+                t1 = time.perf_counter()
+                allh = [[synth_generate_sample_device(seed, seed + 5000 + 31 * s_, c, int(lengths[c]), thr_g, device)[0] for c in range(nchr)] for s_ in range(3)]
+                rates = []
+                for s_ in range(3):
+                    _, _, r_ = cv.bin_rates(allh[s_], cm, lens)
+                    rates += [r_[c] for c in range(nchr) if is_auto[c]]
+                bs1 = cv.bin_size_from_rates(rates, 100)
+                outs1, tot1 = [], []
+                for s_ in range(3):
+                    o_ = dict(chr=mk(torch.int32), start=mk(torch.int32), stop=mk(torch.int32), gc=mk(torch.int32), count=mk(torch.float32))
+                    _, _, t_ = cv.bin_genome(cb, cm, allh[s_], lens, bs1, 3, out=o_)
+                    outs1.append(o_); tot1.append(int(t_))
+                nout1, _, _ = cv.clean_batch(outs1, tot1, is_auto, flags)
+                mc1, ms1, me1, mcnt1, k1 = cv.merge_cleaned(outs1, [int(x) for x in nout1])
+                off1 = cv.chromosome_offsets(mc1, k1, nchr)
+                st1 = cv.hmm_per_sample(cv.quantize_f2(mcnt1[gs_], k1), off1)
+                sec1 = time.perf_counter() - t1
+                eq = bool(bs1 == gr["bin_size"] and k1 == k and (ms1[:k1] == gr["start"]).all() and (me1[:k1] == gr["stop"]).all() and (mc1[:k1] == gr["chr"]).all()
+                          and (mcnt1[gs_][:k1].view(torch.int32) == gr["count"].view(torch.int32)).all() and (st1[:k1] == gr["state"][:k1]).all())
+                del allh, outs1
+            grid = {"samples": 3, "ranks_per_sample": [int(sum(1 for l in layout if l[0] == s_)) for s_ in range(3)], "seconds": round(gsec, 4), "scaling": "strong (three samples, N ranks)",
+                    "bin_size": int(gr["bin_size"]), "bins_common_to_all": int(k), "identical_on_all_ranks": bool(same_bins and same_in_group), "equals_single_gpu_flow_rank0": eq,
+                    "single_gpu_seconds_incl_generating_the_samples_rank0": None if sec1 is None else round(sec1, 3),
+                    "note": "a trio on samples x chromosome groups: rates all-gather (world) -> one bin size, canvas_bin_sample_sharded inside the sample's sub-communicator (canvas_comm_split), CanvasClean on "
+                            "the group's ranks, canvas_merge_cleaned_sharded (world), canvas_hmm_per_sample_sharded (group)"}
+            barrier()
+    except Exception as e:                                        # noqa: BLE001
+        grid = {"error": "%s: %s" % (type(e).__name__, e)}
+        try: restore_library_comm(cv)
+        except Exception: pass
     # ---- BASELINE configs[4], chromosomes sharded: tumour 80x (GCContentWeighted) + normal 40x of the owned chromosomes -> canvas_bin_sample_sharded x 2 -> ratio + CanvasClean on
     # every rank -> canvas_cbs_sharded.  Strong scaling (one pair, N ranks); rank 0 repeats the flow on its own GPU and compares.  Untimed for `value`.
     leg_done.set()
@@ -535,6 +600,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
         if not som_done.wait(float(os.environ.get("CANVAS_SHARDED_SOMATIC_TIMEOUT", "300"))):
             if rank == 0:
                 result["pedigree_sharded"] = ped
+                result["pedigree_grid"] = grid
                 result["partition_sharded"] = part
                 result["somatic_sharded"] = {"error": "did not finish within the watchdog's limit"}
                 print(json.dumps(result), flush=True)
@@ -585,13 +651,14 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
     som_done.set()
     if rank == 0:
         result["pedigree_sharded"] = ped
+        result["pedigree_grid"] = grid if grid else {"skipped": "needs at least three ranks (a trio)"}
         result["somatic_sharded"] = som
         part["note"] = "canvas_cbs_sharded / canvas_wavelets_sharded: every rank segments its own chromosomes (the reference's per-chromosome tasks), one list exchange; genome-wide inputs (seeds in file order, coverage variability) from the whole coverage on every rank"
         result["partition_sharded"] = part
         print(json.dumps(result), flush=True)
     dist.destroy_process_group()
     # a leg that raised, or whose result differs between the ranks / from the single-GPU result, fails the launch (the line above still says what happened)
-    bad = "error" in part or "error" in ped                     # (the somatic leg is reported only)
+    bad = "error" in part or "error" in ped                     # (the somatic and the grid legs are reported only: neither has ever run on more than one GPU)
     for leg in list(part.values()) + [ped]:
         if isinstance(leg, dict) and (leg.get("identical_on_all_ranks") is False or leg.get("equals_single_gpu_result") is False or leg.get("equals_single_gpu_flow_rank0") is False):
             bad = True
