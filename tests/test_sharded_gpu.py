@@ -238,7 +238,19 @@ def _rccl_worker(rank, world, port, q):
         seg_len, nseg_c, _ = cv.cbs_sharded(owner, cov, r["off"], 0.01, 500)
         cbs = [seg_len.cpu().numpy()[int(r["off"][c]):int(r["off"][c]) + int(nseg_c[c])].tolist() for c in range(len(LENGTHS))]
         wv = [b.tolist() for b in cv.wavelets_sharded(owner, cov, r["off"], window=2000)]
-        q.put((rank, dict(r, off=r["off"].tolist()), out["count"][:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy(), cbs, wv))
+        # ---- sub-communicators of two colors (even / odd ranks): the group's rank and size, an exchange inside the group, the parent back afterwards
+        gr, gn = parallel.split_library_comm(cv, rank % 2, rank)
+        members = [x for x in range(world) if x % 2 == rank % 2]
+        inside = cv.allgather_host(np.array([rank], np.int64)).ravel().tolist()
+        pr, pn = parallel.restore_library_comm(cv)
+        split = dict(group_rank=gr, group_size=gn, expected=(members.index(rank), len(members)), gathered=inside, members=members, parent=(pr, pn))
+        # ---- CanvasBin -m GCContentWeighted with the chromosomes sharded (two reductions + the rate table + the bins over RCCL)
+        gowner = parallel.owner_table(GCW_LENGTHS, world)
+        gb, gh, gm, gf = _gcw_inputs(cv.device, only=[c for c in range(len(GCW_LENGTHS)) if gowner[c] == rank])
+        gout = _bins_out(cv.device)
+        gbs, gtotal = cv.bin_sample_sharded(gowner, gb, gm, gh, np.array(GCW_LENGTHS, np.int64), GCW_AUTO, gout, counts_per_bin=100, bin_size=-1, mode=5, fraglens=gf)
+        gcw = (gbs, gtotal, {k: v[:gtotal].cpu().numpy() for k, v in gout.items()})
+        q.put((rank, dict(r, off=r["off"].tolist()), out["count"][:n].cpu().numpy(), state[:n].cpu().numpy(), seg[:n].cpu().numpy(), cbs, wv, split, gcw))
         dist.destroy_process_group()
     except Exception:                                           # noqa: BLE001
         import traceback
@@ -272,10 +284,15 @@ def test_rccl_all_gather_between_real_ranks():
     seg_len, nseg_c, _ = cv0.cbs(dcov, off, 0.01, 500)
     cbs1 = [seg_len.cpu().numpy()[int(off[c]):int(off[c]) + int(nseg_c[c])].tolist() for c in range(len(LENGTHS))]
     wv1 = [b.tolist() for b in cv0.wavelets(dcov, off, window=2000)]
-    for rank, r, count, state, seg, cbs, wv in got:
+    gb, gh, gm, gf = _gcw_inputs(cv0.device)
+    g1 = _bins_out(cv0.device)
+    _, _, gtot1, gbs1 = cv0.bin_sample_gcweighted(gb, gm, gh, gf, np.array(GCW_LENGTHS, np.int64), GCW_AUTO, 100, -1, out=g1)
+    for rank, r, count, state, seg, cbs, wv, split, gcw in got:
         assert (r["bin_size"], r["total"], r["n_out"], r["nseg"], r["lsd"]) == (ref[0]["bin_size"], ref[0]["total"], ref[0]["n_out"], ref[0]["nseg"], ref[0]["lsd"]), rank
         assert (count.view(np.uint32) == ref[1]["count"].view(np.uint32)).all() and (state == ref[3]).all() and (seg == ref[4]).all(), rank
         assert cbs == cbs1 and wv == wv1, rank
+        assert (split["group_rank"], split["group_size"]) == split["expected"] and split["gathered"] == split["members"] and split["parent"] == (rank, world), (rank, split)
+        assert (gcw[0], gcw[1]) == (gbs1, gtot1) and all((gcw[2][k].view(np.uint32) == g1[k][:gtot1].cpu().numpy().view(np.uint32)).all() for k in g1), rank
 
 
 # ---- CanvasPartition -m CBS / -m Wavelets with the chromosomes sharded over the ranks (canvas_cbs_sharded, canvas_wavelets_sharded)
@@ -399,7 +416,15 @@ def test_the_rccl_worker_with_a_one_rank_communicator():
         p.join(60)
         if p.is_alive(): p.kill()
     assert g[1] != "error", g[2]
-    assert len(g) == 7 and sum(len(s) for s in g[5]) >= len(LENGTHS) and len(g[6]) == len(LENGTHS)
+    assert len(g) == 9 and sum(len(s) for s in g[5]) >= len(LENGTHS) and len(g[6]) == len(LENGTHS)
+    split, gcw = g[7], g[8]
+    assert (split["group_rank"], split["group_size"]) == (0, 1) and split["gathered"] == [0] and split["parent"] == (0, 1)      # canvas_comm_split / canvas_comm_restore over a real RCCL communicator
+    from canvas_amd import Canvas
+    cv0 = Canvas(0)
+    gb, gh, gm, gf = _gcw_inputs(cv0.device)
+    g1 = _bins_out(cv0.device)
+    _, _, gtot1, gbs1 = cv0.bin_sample_gcweighted(gb, gm, gh, gf, np.array(GCW_LENGTHS, np.int64), GCW_AUTO, 100, -1, out=g1)
+    assert (gcw[0], gcw[1]) == (gbs1, gtot1) and all((gcw[2][k].view(np.uint32) == g1[k][:gtot1].cpu().numpy().view(np.uint32)).all() for k in g1)
 
 
 # ---- the sample axis: one sample of a trio per rank (canvas_allgather_host, canvas_merge_cleaned_sharded)
