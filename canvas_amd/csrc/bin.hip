@@ -844,18 +844,15 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         const int64_t maxTiles = (maxLen + TILE - 1) / TILE;
         (void)maxTiles; (void)maxLen;
         for (int c = 0; c < nchr; c++) if (((uintptr_t)d_fraglen[c] | (uintptr_t)d_bases[c] | (uintptr_t)d_hits[c]) & 15) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: bases, hits and fragment lengths must be 16-byte aligned");
-        int64_t totWords = 0; for (int c = 0; c < nchr; c++) totWords += (((h_len[c] + 63) >> 6) + 31) & ~31ll;
-        size_t bytes = (size_t)totLen + (size_t)totWords * 9 + 4096 + (size_t)nchr * (16 * NZ_REP + sizeof(GcwChrom) + sizeof(RgChrom)) + (size_t)RG_REP_ALL * 202 * 8 + 101 * 4 + (GCW_HMAX + 1) * 101 * 4 + 8192;
+        size_t bytes = (size_t)totLen + 4096 + (size_t)nchr * (16 * NZ_REP + sizeof(GcwChrom) + sizeof(RgChrom)) + (size_t)RG_REP_ALL * 202 * 8 + 101 * 4 + (GCW_HMAX + 1) * 101 * 4 + 8192;
         if (bytes > ctx->gc_arena_bytes) {
             if (ctx->gc_arena) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->gc_arena)); ctx->gc_arena = nullptr; ctx->gc_arena_bytes = 0; }
             CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->gc_arena, bytes)); ctx->gc_arena_bytes = bytes;
         }
         gcArena = (uint8_t*)ctx->gc_arena;
         uint8_t* p = gcArena;
-        hGch.assign(nchr, GcwChrom{nullptr, nullptr, nullptr}); std::vector<GcwChrom>& gch = hGch;
+        hGch.assign(nchr, GcwChrom{nullptr}); std::vector<GcwChrom>& gch = hGch;
         for (int c = 0; c < nchr; c++) { gch[c].readGc = p; p += (h_len[c] + 255) & ~255ll; }
-        for (int c = 0; c < nchr; c++) { gch[c].wordSum = (double*)p; p += (size_t)((((h_len[c] + 63) >> 6) + 31) & ~31ll) * 8; }      // per 64 positions: exact sum of the weighted terms ...
-        for (int c = 0; c < nchr; c++) { gch[c].wordN = p; p += (size_t)((((h_len[c] + 63) >> 6) + 31) & ~31ll); }                      // ... and how many of them are not zero
         p = (uint8_t*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         unsigned long long* sumCnt = (unsigned long long*)p; p += ((size_t)nchr * NZ_REP * 16 + 255) & ~size_t(255);   // NZ_REP replicas of {sum, count} per chromosome
         unsigned long long* hist = (unsigned long long*)p; p += ((size_t)RG_REP_ALL * 202 * 8 + 255) & ~size_t(255);    // replicas of {expected[101], observed[101]}
@@ -1140,18 +1137,11 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     if (gcw) {
         if (gcwPending) { int32_t rcf = gcw_finish(); if (rcf) return rcf; }       // (single GPU) k_read_gc3 ran beside the kernels above
         ProfScope ps(ctx, "gcw_weighted");
-        // one kernel that computes every position's term once, inside the bin that owns it; CANVAS_GCW_WORDS=1 (the A/B and test hook) takes the two-kernel form of the first half
-        // of the round (per-word sums in memory, then per bin its whole words + the two end words opened again)
-        const bool fused = !getenv("CANVAS_GCW_WORDS");
+        // one kernel that computes every position's term once, inside the bin that owns it
         const int serialOnly = getenv("CANVAS_GCW_SERIAL") ? 1 : 0;      // (test hook: every bin through the reference's own order of additions)
-        static const unsigned gridW = resident_grid((const void*)k_bin_weighted3<false>, 256, ctx->device), gridF = resident_grid((const void*)k_bin_weighted3<true>, 256, ctx->device),
-                              gridS = resident_grid((const void*)k_gcw_words_all, 256, ctx->device);
+        static const unsigned gridF = resident_grid((const void*)k_bin_weighted3, 256, ctx->device);
         hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, dW, dLut);
-        if (fused) hipLaunchKernelGGL(k_bin_weighted3<true>, dim3((unsigned)std::min<int64_t>(gridF, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats, serialOnly, nchr);
-        else {
-            if (!serialOnly) hipLaunchKernelGGL(k_gcw_words_all, dim3((unsigned)std::min<int64_t>(gridS, plan.ntiles)), dim3(256), 0, ctx->stream, dCh, dGch, nchr, (int64_t)plan.ntiles, dW, dLut);
-            hipLaunchKernelGGL(k_bin_weighted3<false>, dim3((unsigned)std::min<int64_t>(gridW, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats, serialOnly, nchr);
-        }
+        hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridF, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats, serialOnly, nchr);
         ctx->gcw_stats_dev = dGcStats; ctx->gcw_total = (long long)total;       // how many bins the interval decided / how many replayed the reference's additions: canvas_bin_gcw_stats
     }
     CANVAS_HIP_TRY(ctx, hipGetLastError());

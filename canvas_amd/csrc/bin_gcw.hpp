@@ -460,13 +460,11 @@ __device__ __forceinline__ float weighted_serial(const BinChrom& C, const uint8_
     }
     return tmp;
 }
-// The weighted count in two steps.  History (80x genome, 6.2 M bins): one wave per bin adding the terms through readlane 19.5 ms (round 3); exact sum in double, one bin per
+// The weighted count.  History (80x genome, 6.2 M bins): one wave per bin adding the terms through readlane 19.5 ms (round 3); exact sum in double, one bin per
 // wave 5.6 ms, 16 lanes per bin 5.2 ms, terms from a table + only the positions with a hit visited 6.8 ms — the SQ counters showed 1.9 ms of VALU time per SIMD (a wave
-// instruction occupies its SIMD for four cycles) on top of a chain of four dependent loads per bin.  Now:
-//   k_gcw_words_all  a streaming sweep like k_tile_summary: per 64-position word the exact sum (double) and the number of the non-zero terms min(10, hit / weight[readGC])
-//                    over its possible positions.  Branch-free: the term comes from a table in LDS indexed by (hit, readGC) — row 0 is 0.0f, so a position without a hit or
-//                    outside the mask costs the same five instructions as any other; hits above GCW_HMAX (a handful per genome) take a division.
-//   k_bin_weighted3  per bin (16 lanes): the sums of its whole words + the two words its ends cut, opened like k_bin_resolve does; then the interval decision.
+// instruction occupies its SIMD for four cycles) on top of a chain of four dependent loads per bin; then per-word sums from a streaming sweep + the two end words of a bin
+// opened again (1.3 terms per position; removed in round 5).  Now k_bin_weighted3 alone: the terms come branch-free from a table in LDS indexed by (hit, readGC) — row 0 is
+// 0.0f, so a position without a hit or outside the mask costs the same five instructions as any other; hits above GCW_HMAX (a handful per genome) take a division.
 #define GCW_HMAX 20
 #define GCW_LONG 64          // whole words between the two end words of a bin beyond which the entire wave sums them
 #define GCW_TAB 64           // chromosomes whose pointers k_bin_weighted3 keeps in LDS (the others are read from the tables in memory)
@@ -512,51 +510,17 @@ __device__ __forceinline__ void gcw_terms16(const uint32_t (&hw)[4], const uint3
     for (int q = 0; q < 4; q++) { const uint32_t x = hw[q]; nz += (uint32_t)__popc((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u); }
     n = nz;
 }
-struct GcwChrom { const uint8_t* readGc; double* wordSum; uint8_t* wordN; };
+struct GcwChrom { const uint8_t* readGc; };
 // one launch over every chromosome's tiles (BinChrom::tileBase numbers them)
 __device__ __forceinline__ int gcw_find_chrom(const BinChrom* __restrict__ ch, int nchr, int64_t tile) {
     int lo = 0, hi = nchr - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ch[mid].tileBase <= tile) lo = mid; else hi = mid - 1; }
     return lo;
 }
-__global__ void __launch_bounds__(256) k_gcw_words_all(const BinChrom* __restrict__ ch, const GcwChrom* __restrict__ gch, int nchr, int64_t ntiles, const float* __restrict__ w, const float* __restrict__ lut) {
-    __shared__ float sW[101];
-    __shared__ double sT[(GCW_HMAX + 1) * 101];
-    if (threadIdx.x < 101) sW[threadIdx.x] = w[threadIdx.x];
-    for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = (double)lut[i];
-    __syncthreads();
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int c = gcw_find_chrom(ch, nchr, tile);
-        const uint64_t* __restrict__ mask = ch[c].mask; const uint8_t* __restrict__ hits = ch[c].hits; const uint8_t* __restrict__ rg = gch[c].readGc;
-        const int64_t len = ch[c].len;
-        const int64_t p = (tile - ch[c].tileBase) * TILE + 16 * (int64_t)threadIdx.x;      // TILE = 256 groups of 16 positions: whole quads (the shuffles below)
-        uint32_t hw[4] = {0, 0, 0, 0}, gw[4] = {0, 0, 0, 0};
-        uint32_t m16 = 0;
-        if (p < len) {
-            m16 = (uint32_t)((mask[p >> 6] >> (p & 63)) & 0xFFFFull);
-            if (p + 16 <= len) {
-                const uint4 h = *reinterpret_cast<const uint4*>(hits + p), gq = *reinterpret_cast<const uint4*>(rg + p);
-                hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w; gw[0] = gq.x; gw[1] = gq.y; gw[2] = gq.z; gw[3] = gq.w;
-            } else {
-                m16 &= 0xFFFFu >> (p + 16 - len);
-                for (int j = 0; j < 16 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); gw[j >> 2] |= (uint32_t)rg[p + j] << (8 * (j & 3)); }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) hw[q] &= expand4(m16 >> (4 * q));       // only possible positions count
-        }
-        double sum; uint32_t n;
-        gcw_terms16(hw, gw, sT, sW, sum, n);
-        sum += __shfl_xor(sum, 1, 64); n += __shfl_xor(n, 1, 64);
-        sum += __shfl_xor(sum, 2, 64); n += __shfl_xor(n, 2, 64);
-        if ((threadIdx.x & 3) == 0 && p < len) { gch[c].wordSum[p >> 6] = sum; gch[c].wordN[p >> 6] = (uint8_t)n; }
-    }
-}
 // 16 lanes per bin: lanes 0-3 open the word the bin starts in, lanes 4-7 the word it ends in (when that is another one), lanes 8-15 add the sums of the words in between
-// FUSED: the bins partition the positions, so the terms of every position can be computed ONCE, by the bin that owns it — no per-word sums in memory, no end words opened a second
-// time (the two-kernel form computes 1.3 terms per position: every word once in k_gcw_words_all, the two words under a bin's ends again here).  16 lanes walk their bin 256 positions
+// The bins partition the positions, so the terms of every position are computed ONCE, by the bin that owns it — no per-word sums in memory.  16 lanes walk their bin 256 positions
 // at a time; a bin that spans more than GCW4_SPAN positions (centromeres, assembly gaps) is scanned by the whole wave, mask words first.
 #define GCW4_SPAN 4096
-template <bool FUSED>
 __global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restrict__ ch, const GcwChrom* __restrict__ gch, long long nbins, const int32_t* __restrict__ oChr,
                                                        const int32_t* __restrict__ oStart, const int32_t* __restrict__ oStop, const float* __restrict__ w, const float* __restrict__ lut,
                                                        float* __restrict__ oCount, unsigned long long* __restrict__ replayed /* [GCW_REP] replicas: bins that replayed the reference's additions */,
@@ -565,13 +529,13 @@ __global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restric
     __shared__ double sT[(GCW_HMAX + 1) * 101];
     // A round was a chain of three dependent trips to memory — the bin's (chromosome, start, stop), that chromosome's pointers, the data under them — and a wave makes some
     // two hundred rounds: 74 % of its cycles waiting (SQ counters), 1.57 ms for 6.2 M bins.  The pointer tables now sit in LDS and the next round's bin is requested while this one works.
-    struct Tab { const uint64_t* mask; const uint8_t* hits; const uint8_t* rg; const double* ws; const uint8_t* wn; int64_t len; };
+    struct Tab { const uint64_t* mask; const uint8_t* hits; const uint8_t* rg; int64_t len; };
     __shared__ Tab sTab[GCW_TAB];
     if (threadIdx.x < 101) sW[threadIdx.x] = w[threadIdx.x];
     for (int i = threadIdx.x; i < (GCW_HMAX + 1) * 101; i += 256) sT[i] = (double)lut[i];
-    for (int i = threadIdx.x; i < nchr && i < GCW_TAB; i += 256) sTab[i] = Tab{ch[i].mask, ch[i].hits, gch[i].readGc, gch[i].wordSum, gch[i].wordN, ch[i].len};
+    for (int i = threadIdx.x; i < nchr && i < GCW_TAB; i += 256) sTab[i] = Tab{ch[i].mask, ch[i].hits, gch[i].readGc, ch[i].len};
     __syncthreads();
-    auto tab = [&](int c) -> Tab { return c < GCW_TAB ? sTab[c] : Tab{ch[c].mask, ch[c].hits, gch[c].readGc, gch[c].wordSum, gch[c].wordN, ch[c].len}; };
+    auto tab = [&](int c) -> Tab { return c < GCW_TAB ? sTab[c] : Tab{ch[c].mask, ch[c].hits, gch[c].readGc, ch[c].len}; };
     const int l = lane_id(), grp = l >> 4, sub = l & 15;
     const long long waveId = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (long long)gridDim.x * 4;
     int cN = 0; int64_t sN = 0, eN = 0;
@@ -583,7 +547,7 @@ __global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restric
         const int64_t s = sN, e = eN;
         { const long long in = i + nwaves * 4; cN = 0; sN = 0; eN = 0; if (in < nbins) { cN = oChr[in]; sN = oStart[in]; eN = oStop[in]; } }
         double sum = 0.0; uint32_t nterms = 0;
-        if constexpr (FUSED) {
+        {
             if (!serialOnly && live && e > s && e - s <= GCW4_SPAN) {
                 const Tab T = tab(c);
                 const gptr<const uint64_t> mask = as_global(T.mask); const gptr<const uint8_t> hits = as_global(T.hits); const gptr<const uint8_t> rg = as_global(T.rg);
@@ -655,61 +619,7 @@ __global__ void __launch_bounds__(256) k_bin_weighted3(const BinChrom* __restric
                 for (int d = 32; d >= 1; d >>= 1) { ls += __shfl_xor(ls, d, 64); ln += __shfl_xor(ln, d, 64); }
                 if (l == src) { sum += ls; nterms += ln; }
             }
-        } else {
-        if (!serialOnly && live && e > s) {
-            const int64_t wS = s >> 6, wE = (e - 1) >> 6;
-            if (sub < 8) {
-                // an end word: positions [max(s, 64 w), min(e, 64 w + 64)) of word w, one 16-position slice per lane
-                const int64_t wq = sub < 4 ? wS : wE;
-                if (sub < 4 || wE != wS) {
-                    const int64_t p = (wq << 6) + 16 * (sub & 3);
-                    const int64_t lo = s > p ? s : p, hi = e < p + 16 ? e : p + 16;
-                    if (lo < hi) {
-                        const Tab T = tab(c);
-                        const gptr<const uint64_t> mask = as_global(T.mask); const gptr<const uint8_t> hits = as_global(T.hits); const gptr<const uint8_t> rg = as_global(T.rg);
-                        const int64_t len = T.len;
-                        uint32_t m16 = (uint32_t)((mask[p >> 6] >> (p & 63)) & 0xFFFFull);
-                        m16 &= (0xFFFFu << (lo - p)) & (0xFFFFu >> (p + 16 - hi));
-                        uint32_t hw[4] = {0, 0, 0, 0}, gw[4] = {0, 0, 0, 0};
-                        if (p + 16 <= len) {
-                            const uint4 h = gload_uint4(hits + p), gq = gload_uint4(rg + p);
-                            hw[0] = h.x; hw[1] = h.y; hw[2] = h.z; hw[3] = h.w; gw[0] = gq.x; gw[1] = gq.y; gw[2] = gq.z; gw[3] = gq.w;
-                        } else {
-                            for (int j = 0; j < 16 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); gw[j >> 2] |= (uint32_t)rg[p + j] << (8 * (j & 3)); }
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; q++) hw[q] &= expand4(m16 >> (4 * q));
-                        gcw_terms16(hw, gw, sT, sW, sum, nterms);
-                    }
-                }
-            } else if (wE - wS - 1 <= GCW_LONG) {
-                const Tab T = tab(c);
-                const gptr<const double> ws = as_global(T.ws); const gptr<const uint8_t> wn = as_global(T.wn);
-                for (int64_t wq = wS + 1 + (sub - 8); wq < wE; wq += 8) { sum += ws[wq]; nterms += wn[wq]; }
-            }
         }
-        // a bin that spans a gap of the mask (centromere, assembly gap: up to megabases for a few hundred possible positions) would keep its eight lanes busy for thousands of
-        // dependent loads while the rest of the device waits for them (measured: 3 of the kernel's 3.9 ms): its whole words are summed by the entire wave, four loads in flight per lane
-        {
-            unsigned long long longBins = __ballot(!serialOnly && live && e > s && sub == 0 && ((e - 1) >> 6) - (s >> 6) - 1 > GCW_LONG);
-            while (longBins) {
-                const int src = __builtin_ctzll(longBins); longBins &= longBins - 1ull;
-                const long long ib = i0 + (src >> 4);
-                const int cb = oChr[ib];
-                const int64_t wS = (int64_t)oStart[ib] >> 6, wE = ((int64_t)oStop[ib] - 1) >> 6;
-                const gptr<const double> ws = as_global(gch[cb].wordSum); const gptr<const uint8_t> wn = as_global(gch[cb].wordN);
-                double s4[4] = {0, 0, 0, 0}; uint32_t n4 = 0;
-                for (int64_t wq = wS + 1 + l; wq < wE; wq += 256) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { const int64_t x = wq + 64 * u; if (x < wE) { s4[u] += ws[x]; n4 += wn[x]; } }
-                }
-                double ls = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) { ls += __shfl_xor(ls, d, 64); n4 += __shfl_xor(n4, d, 64); }
-                if (l == src) { sum += ls; nterms += n4; }
-            }
-        }
-        }   // (!FUSED)
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) { sum += __shfl_xor(sum, d, 64); nterms += __shfl_xor(nterms, d, 64); }      // within the bin's 16 lanes
         // the float32 running sum of the reference differs from the exact sum by at most nterms roundings of half an ulp of a partial sum <= the final sum (+ its own last ulp)

@@ -359,27 +359,6 @@ __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ re
         produced += take; mti += take;
     }
 }
-// data-parallel part, one launch per step: draws [MT_HISTORY + step * MT_WIDTH, + MT_WIDTH) of every request that is long enough
-__global__ void __launch_bounds__(256) k_mt_stride(const PermReq* __restrict__ reqs, int step) {
-    // four consecutive draws per thread: every lag is a multiple of MT_STRIDE (a multiple of 4), so the 134 operands of the four draws are 134 aligned 16-byte loads
-    const PermReq& R = reqs[blockIdx.y];
-    const long long j = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    const long long k = (R.cont ? 0 : MT_HISTORY) + (long long)step * MT_WIDTH + j;
-    if (j >= MT_WIDTH || k >= R.total || R.mtj) return;
-    const uint32_t* __restrict__ d = R.P.draws;
-    if (k + 4 <= R.total && ((reinterpret_cast<uintptr_t>(d + k) & 15) == 0)) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll 8
-        for (int i = 0; i < MT_NLAG; i++) { const uint4 t = *reinterpret_cast<const uint4*>(d + (k - (long long)MT_LAG[i] * MT_STRIDE)); v.x ^= t.x; v.y ^= t.y; v.z ^= t.z; v.w ^= t.w; }
-        *reinterpret_cast<uint4*>(R.P.draws + k) = v;
-    } else {
-        for (int e = 0; e < 4 && k + e < R.total; e++) {
-            uint32_t v = 0;
-            for (int i = 0; i < MT_NLAG; i++) v ^= d[k + e - (long long)MT_LAG[i] * MT_STRIDE];
-            R.P.draws[k + e] = v;
-        }
-    }
-}
 // data-parallel part, one launch for the whole batch.  With every lag a multiple of MT_STRIDE the stream falls apart into MT_STRIDE interleaved sequences (position mod
 // MT_STRIDE) that never read each other: y_r[t] = out[r + MT_STRIDE t] obeys the ORIGINAL 134-term recurrence, y[t] = XOR_i y[t - MT_LAG[i]].  One workgroup owns one
 // sequence and keeps its last 19937 values in a ring in LDS (80 KB), so the 134 operands of a value are LDS reads instead of 134 loads from a 10 MB window in the
@@ -2324,8 +2303,7 @@ struct PermService {
         auto tp0 = std::chrono::steady_clock::now(); double msA = 0, msB = 0;
         auto lap = [&]() { (void)hipStreamSynchronize(stream); auto t = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; return ms; };
         if (dbg) lap();
-        static const bool stepwise = getenv("CANVAS_CBS_MT_STEPWISE") != nullptr;     // the previous generator (one launch per 79 744 outputs), kept for comparison
-        static const bool bootstrap = !stepwise && getenv("CANVAS_CBS_MT_NO_BOOTSTRAP") == nullptr;
+        const bool bootstrap = true;      // (the sequential history is grown by doubling: k_mt_classes with boot = 1)
         bool anyFresh = false; long long maxFresh = 0; int jumpChunks = 0;
         for (int i = 0; i < R; i++) {
             const PermReq& q = batch[i]->r;
@@ -2343,8 +2321,7 @@ struct PermService {
             for (int sd = 1; sd < MT_STRIDE && 19937LL * sd < maxFresh; sd <<= 1) hipLaunchKernelGGL(k_mt_classes, dim3(sd, R), dim3(MTC_T), 0, stream, dReqs, sd, 1);
         if (dbg) msA = lap();
         const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;       // (maxTotal: the requests of the strided generator only)
-        if (stepwise) for (int sidx = 0; sidx < steps; sidx++) hipLaunchKernelGGL(k_mt_stride, dim3((MT_WIDTH / 4 + 255) / 256, R), dim3(256), 0, stream, dReqs, sidx);
-        else if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
+        if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
         if (dbg) msB = lap();
         hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
         bool anyFy = false, anyOld = false, anySmall = false; for (int i = 0; i < R; i++) (batch[i]->r.fy == 2 ? anySmall : batch[i]->r.fy == 1 ? anyFy : batch[i]->r.fy == 0 ? anyOld : anySmall /* (3: below) */) |= batch[i]->r.fy != 3;

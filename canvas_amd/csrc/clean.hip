@@ -665,7 +665,6 @@ static int32_t normalize_by_gc_loess(CleanState& st, int nchr, const uint8_t* h_
 
 #include "quantize.hpp"
 #include "clean_fast.hpp"
-#include "clean_gc_only.hpp"
 
 extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
                                  int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc,
@@ -683,14 +682,6 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     // CANVAS_CLEAN_HOST_DRIVEN=1 forces it (test hook: the two paths must agree bit for bit)
     if (!loessMode && min_bins_per_gc >= 100 && !getenv("CANVAS_CLEAN_HOST_DRIVEN")) {
         bool handled = false;
-        // -g alone in three launches (clean_gc_only.hpp) — measured, and NOT the default: 0.33 ms against 0.11 ms for the general chain on the 30x genome.  The counters per
-        // (GC, count) cost 140 us in atomics even with one replica per XCD (450 us with device-scope atomics) where the general chain's grouped keys count in LDS, and the
-        // register-held in-place compaction 138 us in strided accesses.  CANVAS_CLEAN_GC_ONLY_3K=1 takes it (parity-tested; anything it cannot take leaves the arrays untouched).
-        if (flags == CANVAS_CLEAN_GCNORM && getenv("CANVAS_CLEAN_GC_ONLY_3K")) {
-            int32_t rcg = clean_gc_only(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, h_n_out, h_info, &handled);
-            if (rcg) return rcg;
-            if (handled) { if (h_local_sd_out) *h_local_sd_out = -1.0; return CANVAS_OK; }
-        }
         int32_t rcf = clean_device_driven(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc, h_local_sd_out, h_n_out, h_info, &handled);
         if (rcf) return rcf;
         if (handled) return CANVAS_OK;

@@ -253,12 +253,7 @@ def test_gc_weighted_interval_decisions_equal_the_serial_order(monkeypatch):
         d2 = cv.bin_gcw_stats()
         assert total == total2 == len(ex) and (fast == ex).all() and (serial == ex).all(), (bs, np.nonzero(fast != ex)[0][:5], np.nonzero(serial != ex)[0][:5])
         assert d1[0] > 0 and d2[0] == 0 and d2[1] == total
-        # the two-kernel form of the weighted counts (per-word sums in memory, end words opened again) decides the same bins the same way as the fused kernel
-        monkeypatch.delenv("CANVAS_GCW_SERIAL", raising=False); monkeypatch.setenv("CANVAS_GCW_WORDS", "1")
-        o, per, total3, _ = cv.bin_sample_gcweighted(bases, masks, hits, dfl, lens, [1, 1], 100, bs, out=out)
-        words = out["count"][:total3].cpu().numpy(); d3 = cv.bin_gcw_stats()
-        monkeypatch.delenv("CANVAS_GCW_WORDS", raising=False)
-        assert total3 == total and (words == ex).all() and tuple(d3) == tuple(d1), (bs, d1, d3)
+        monkeypatch.delenv("CANVAS_GCW_SERIAL", raising=False)
 
 
 def test_device_synth_sample_pair_matches_numpy():

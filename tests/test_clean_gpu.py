@@ -304,43 +304,3 @@ def test_clean_counting_selects_taken_and_given_up(clean_path):
     assert info[5] == 0
 
 
-def test_clean_gc_only_three_launch_path(clean_path, monkeypatch):
-    """CanvasClean -g alone on the integer counts of a .binned file (BASELINE configs[1]) through clean_gc_only.hpp (CANVAS_CLEAN_GC_ONLY_3K=1): counters per (GC, count), decisions per bucket, in-place apply +
-    strip — info[6] == 1 says so.  Counts with decimals, GC buckets that are stripped, chromosomes that are not autosomes, inputs whose buckets all fall under the threshold and
-    CANVAS_CLEAN_GENERAL_GC=1 (the general chain) must all give the oracle's bins."""
-    import os
-    monkeypatch.setenv("CANVAS_CLEAN_GC_ONLY_3K", "1")       # (opt-in: the general chain is faster, see clean.hip)
-    cv = get_canvas()
-    rng = np.random.RandomState(17)
-    for n, nchr in ((60_000, 24), (2_600_000, 24), (12_345, 3), (150, 1)):
-        bins = synth.generate_bins(20260927 + 1, n, nchr=nchr)
-        bins["count"] = np.round(bins["count"]).astype(np.float32)                # what CanvasBin writes in modes 0 / 3: whole numbers
-        if n == 60_000:
-            bins["gc"][rng.randint(0, n, 40)] = 3                                   # a bucket of 40 bins: stripped (fewer than 100 autosomal bins)
-            bins["gc"][np.nonzero(bins["chr"] == nchr - 1)[0][:500]] = 97           # 500 bins of a bucket that only a non-autosome fills: counts[97] = 0 -> stripped too
-        info, exp = _run1(cv, bins, CLEAN_GCNORM, nchr=nchr)
-        taken = clean_path != "host_driven"
-        assert info[6] == (1 if taken else 0), (n, info)
-        if n == 60_000:
-            assert len(exp["chr"]) < n - 500
-        if n == 150:
-            assert len(exp["chr"]) == n                                           # no bucket reaches 100 bins: nothing is stripped, nothing normalised (CanvasClean.cs:501-503)
-    # counts with two decimals: the counters cannot hold them, the general chain takes over (the arrays were left untouched)
-    bins = synth.generate_bins(20260927 + 1, 40_000)
-    bins["count"] = _f2(bins["count"] + 0.25)
-    info, _ = _run1(cv, bins, CLEAN_GCNORM)
-    assert info[6] == 0
-    # a count beyond the counters' range
-    bins["count"] = np.round(bins["count"]).astype(np.float32); bins["count"][123] = 5000.0
-    info, _ = _run1(cv, bins, CLEAN_GCNORM)
-    assert info[6] == 0
-
-
-def test_clean_gc_only_equals_the_general_chain(monkeypatch, clean_path):
-    cv = get_canvas()
-    bins = synth.generate_bins(20260927 + 11, 300_000)
-    bins["count"] = np.round(bins["count"]).astype(np.float32)
-    info2, _ = _run1(cv, bins, CLEAN_GCNORM)
-    monkeypatch.setenv("CANVAS_CLEAN_GC_ONLY_3K", "1")
-    info, _ = _run1(cv, bins, CLEAN_GCNORM)
-    assert info2[6] == 0 and info[3] == info2[3] and (info[6] == 1 or clean_path == "host_driven")
