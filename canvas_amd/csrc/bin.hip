@@ -868,7 +868,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         const size_t sidePinBytes = (65536 + 65544) * sizeof(double);
         const size_t offW = (size_t)RG_REP_ALL * 202 * 8, offG = offW + 512;
         if (offG + (size_t)nchr * sizeof(GcwChrom) > sidePinBytes) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: too many chromosomes for the pinned staging buffer");
-        gcwOverlap = !ctx->gcw_reduce && !getenv("CANVAS_GCW_NO_OVERLAP");
+        gcwOverlap = !ctx->gcw_reduce && !cvx_hook("CANVAS_GCW_NO_OVERLAP");
         hipStream_t sp = ctx->stream;
         if (gcwOverlap) {
             CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev, ctx->stream)); CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));      // the inputs are ready with respect to ctx->stream
@@ -903,7 +903,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             const int nWmax = (RG_T + 3 * meanFrag) / 64 + 2;
             // k_read_gc3 follows the default window from position to position, which needs |100 d| < meanFragment; shorter fragments (and CANVAS_GCW_READ_GC2=1, the A/B and test
             // hook) take k_read_gc2, one launch per chromosome
-            const bool rg3 = meanFrag > 100 && !getenv("CANVAS_GCW_READ_GC2");
+            const bool rg3 = meanFrag > 100 && !cvx_hook("CANVAS_GCW_READ_GC2");
             const size_t ldsRg = (size_t)nWmax * (rg3 ? 16 : 12);
             int perCu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, rg3 ? (const void*)k_read_gc3 : (const void*)k_read_gc2, 256, ldsRg) != hipSuccess || perCu <= 0) perCu = 2;
@@ -937,7 +937,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     for (int c = 0; streamed && c < nchr; c++) streamed = ctx->up_bases[c] == d_bases[c] && ctx->up_mask[c] == d_mask[c] && ctx->up_hits[c] == d_hits[c];
     if (ctx->up_active && !streamed) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); }    // other arrays (or mode 5): plain dependency on the whole upload
     ctx->up_active = false;
-    const bool singleRead = packed || streamed || (needRates && !getenv("CANVAS_BIN_TWO_PASS")) || getenv("CANVAS_BIN_SINGLE_READ");
+    const bool singleRead = packed || streamed || (needRates && !cvx_hook("CANVAS_BIN_TWO_PASS")) || cvx_hook("CANVAS_BIN_SINGLE_READ");
     const int nchunks = (int)((plan.ntiles + TS_CHUNK - 1) / TS_CHUNK);
     if (singleRead) { sz.take<uint32_t>(plan.ntiles * 64); sz.take<uint32_t>(plan.ntiles + 8); sz.take<TsPart>(nchunks + 1); sz.take<TsPart>(nchunks + 1); sz.take<unsigned long long>(nchr);
                       sz.take<TsPart>(nchr + 1); sz.take<ChromDev>(nchr); sz.take<uint4>(ub + 1); }
@@ -1138,7 +1138,7 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
         if (gcwPending) { int32_t rcf = gcw_finish(); if (rcf) return rcf; }       // (single GPU) k_read_gc3 ran beside the kernels above
         ProfScope ps(ctx, "gcw_weighted");
         // one kernel that computes every position's term once, inside the bin that owns it
-        const int serialOnly = getenv("CANVAS_GCW_SERIAL") ? 1 : 0;      // (test hook: every bin through the reference's own order of additions)
+        const int serialOnly = cvx_hook("CANVAS_GCW_SERIAL") ? 1 : 0;      // (test hook: every bin through the reference's own order of additions)
         static const unsigned gridF = resident_grid((const void*)k_bin_weighted3, 256, ctx->device);
         hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, dW, dLut);
         hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridF, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats, serialOnly, nchr);

@@ -1649,7 +1649,7 @@ static void eta_boundary_fast(uint32_t nPerm, double eta0, uint32_t n1s, std::ve
 static void compute_boundary_fresh(uint32_t nPerm, double alpha, double eta, std::vector<uint32_t>& sb);
 // CanvasPartition's default parameters take the table that was computed once and compiled in (cbs_boundary_default.hpp); CANVAS_CBS_NO_EMBEDDED_BOUNDARY=1 computes it anew (test hook)
 static void compute_boundary(uint32_t nPerm, double alpha, double eta, std::vector<uint32_t>& sb) {
-    if (nPerm == CBS_DEFAULT_NPERM && alpha == CBS_DEFAULT_ALPHA && eta == 0.05 && sizeof(kCbsDefaultBoundary) > 4 && !getenv("CANVAS_CBS_NO_EMBEDDED_BOUNDARY")) {
+    if (nPerm == CBS_DEFAULT_NPERM && alpha == CBS_DEFAULT_ALPHA && eta == 0.05 && sizeof(kCbsDefaultBoundary) > 4 && !cvx_hook("CANVAS_CBS_NO_EMBEDDED_BOUNDARY")) {
         sb.assign(kCbsDefaultBoundary, kCbsDefaultBoundary + sizeof(kCbsDefaultBoundary) / sizeof(uint32_t));
         return;
     }
@@ -1712,7 +1712,7 @@ template <class F> static void pool_for(int ntasks, F f) {
     std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return left == 0; });
 }
 static void eta_boundary_fast(uint32_t nPerm, double eta0, uint32_t n1s, std::vector<uint32_t>& sb, uint32_t off) {
-    static const bool sequential = getenv("CANVAS_CBS_SEQUENTIAL_BOUNDARY") != nullptr;
+    static const bool sequential = cvx_hook("CANVAS_CBS_SEQUENTIAL_BOUNDARY") != nullptr;
     if (sequential || nPerm < 2000) { eta_boundary(nPerm, eta0, n1s, sb, off); return; }
     const double dn = (double)nPerm - (double)n1s;
     const int K = (int)n1s;                                    // k = 0 .. n1s - 1 can stop the scan (phyper(n1s, n1s, ., i) = 1)
@@ -1957,7 +1957,7 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     q.r.sx = G.dSx; q.r.n = n; q.r.dmax = G.dMax; q.r.firstI = G.dFirst;
     q.p.sx = G.dSx; q.p.n = n; q.p.al0 = al0; q.p.tau = bss0; q.p.bmin = (double*)G.dPr; q.p.bmax = q.p.bmin + nbk; q.p.pairs = (int*)(q.p.bmax + nbk);
     q.p.pairMax = (double*)(q.p.pairs + AP_PAIRCAP); q.p.out = (unsigned long long*)(q.p.pairMax + AP_PAIRCAP); q.p.bpos = (int*)(q.p.out + 8);
-    q.pruned = getenv("CANVAS_CBS_EXHAUSTIVE_ARCS") == nullptr;
+    q.pruned = cvx_hook("CANVAS_CBS_EXHAUSTIVE_ARCS") == nullptr;
     if (q.pruned) {
         rc = service_submit_arc(G.svc, q); if (rc) return rc;
         st.gpu_searches++;
@@ -1980,7 +1980,7 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     q.hMax = hMax; q.hFirst = hFirst; q.r.dmax = G.dMax; q.r.firstI = G.dFirst;
     rc = service_submit_arc(G.svc, q); if (rc) return rc;
     const double* dmax = hMax; const int32_t* firstI = hFirst;
-    if (!getenv("CANVAS_CBS_EXHAUSTIVE_ARCS")) st.gpu_searches--;
+    if (!cvx_hook("CANVAS_CBS_EXHAUSTIVE_ARCS")) st.gpu_searches--;
     st.gpu_searches++; st.gpu_pairs += (long long)n * (n - 1) / 2;
     // arcs of length L in [al0, n - al0] (CBSTStatistic.cs:139-151: alenlo >= al0, alenhi <= n - al0)
     double M = -1.0; int bestL = -1, nbest = 0;
@@ -2079,7 +2079,7 @@ static bool tpermp_device_impl(canvas_ctx* ctx, hipStream_t stream, int n1, int 
     return true;
 }
 static double tpermp(PermGpu& PG, int n1, int n2, int n, const double* gd, int off, double* px, uint32_t nPerm, MT& rnd, Stats& st) {   // CBSTStatistic.cs:947-1024
-    { static const bool onDevice = getenv("CANVAS_CBS_DEVICE_TPERMP") != nullptr; double p; if (onDevice && tpermp_device(PG, n1, n2, n, gd, off, nPerm, rnd, st, p)) return p; }
+    { static const bool onDevice = cvx_hook("CANVAS_CBS_DEVICE_TPERMP") != nullptr; double p; if (onDevice && tpermp_device(PG, n1, n2, n, gd, off, nPerm, rnd, st, p)) return p; }
     double rn1 = (double)n1, rn2 = (double)n2, rn = rn1 + rn2; int nrej;
     if (n1 == 1 || n2 == 1) nrej = (int)nPerm;
     else {
@@ -2178,7 +2178,7 @@ static bool tpermp_device(PermGpu& PG, int n1, int n2, int n, const double* gd, 
 static int32_t tail_p_decide(PermGpu& PG, double b, double delta, int m, double cutoff, uint32_t nPerm, Stats& st, bool& exitNoSplit, int& nrejc) {
     const int nGrid = 100; const double tol = 1E-6;
     auto exact = [&]() { const double p1 = tail_p(b, delta, m, nGrid, tol); st.tailp_host++; exitNoSplit = p1 > cutoff; nrejc = exitNoSplit ? 0 : (int)((cutoff - p1) * nPerm); };
-    if (getenv("CANVAS_CBS_HOST_TAILP")) { exact(); return CANVAS_OK; }
+    if (cvx_hook("CANVAS_CBS_HOST_TAILP")) { exact(); return CANVAS_OK; }
     canvas_ctx* ctx = PG.ctx;
     int32_t rc = PG.ensure_tail(); if (rc) return rc;
     double* hX = (double*)PG.tailPin; double* hNu = hX + 128; int* hFlag = (int*)(hNu + 128);
@@ -2299,7 +2299,7 @@ struct PermService {
             if (batch[i]->drawBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws, batch[i]->hDraws, batch[i]->drawBytes, hipMemcpyHostToDevice, stream));
         }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
-        static const bool dbgEnv = getenv("CANVAS_CBS_DEBUG_BATCHES") != nullptr; const bool dbg = dbgEnv || probeTiming;
+        static const bool dbgEnv = cvx_hook("CANVAS_CBS_DEBUG_BATCHES") != nullptr; const bool dbg = dbgEnv || probeTiming;
         auto tp0 = std::chrono::steady_clock::now(); double msA = 0, msB = 0;
         auto lap = [&]() { (void)hipStreamSynchronize(stream); auto t = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; return ms; };
         if (dbg) lap();
@@ -2372,7 +2372,7 @@ static thread_local ChromClock tlClock;
 #define PERM_RP_SCRATCH_BYTES (size_t(2) << 30)
 #define PERM_RP_MAXB 1024
 static inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
-static inline bool perm_use_rp(int n) { static const bool off = getenv("CANVAS_CBS_NO_RP") != nullptr; static const int minN = getenv("CANVAS_CBS_RP_MIN_N") ? atoi(getenv("CANVAS_CBS_RP_MIN_N")) : PERM_RP_MIN_N; return !off && n >= minN && n <= PERM_RP_MAX_N; }
+static inline bool perm_use_rp(int n) { static const bool off = cvx_hook("CANVAS_CBS_NO_RP") != nullptr; static const int minN = cvx_hook("CANVAS_CBS_RP_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_RP_MIN_N")) : PERM_RP_MIN_N; return !off && n >= minN && n <= PERM_RP_MAX_N; }
 static inline int perm_max_batch(int n) { return perm_use_rp(n) ? (int)std::max<long long>(8, std::min<long long>(PERM_RP_MAXB, PERM_TARGET_ELEMS / n)) : (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n)); }
 static inline int perm_rp_wgs(int n) { PermReq::RpPlan P; rp_plan(n, P); const size_t per = (size_t)P.stride * 4; return (int)std::max<size_t>(64, std::min<size_t>(PERM_RP_GRID, PERM_RP_SCRATCH_BYTES / per)); }
 // device / pinned bytes that serve every segment of up to nMax bins
@@ -2398,7 +2398,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     auto now = []() { return std::chrono::steady_clock::now(); };
     uint32_t* dRpScratch = nullptr; int rpWGs = 0; PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP);
     uint32_t* dMtW0 = nullptr; uint32_t* dMtStates = nullptr;
-    static const bool useJump = getenv("CANVAS_CBS_JUMP") != nullptr;      // (the jump-ahead generator: less device work per draw, more latency per batch than the strided recurrence — see DESIGN.md)
+    static const bool useJump = cvx_hook("CANVAS_CBS_JUMP") != nullptr;      // (the jump-ahead generator: less device work per draw, more latency per batch than the strided recurrence — see DESIGN.md)
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
     auto setup = [&](int mb) -> int32_t {
@@ -2443,7 +2443,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     // first batch: without a single rejection the sequential rule stops at permutation sbdry[k - 1] — known now — and that is what a segment with a real change point
     // does; asking for that many at once saves the 64 / 128 / 256 ramp its two extra launcher round trips (a segment without one leaves after a handful either way)
     int B = std::min(maxB, std::max(64, (int)std::min<uint32_t>(sbdry[k - 1], 4096u)));
-    if (getenv("CANVAS_CBS_B0")) B = std::min(maxB, atoi(getenv("CANVAS_CBS_B0")));
+    if (cvx_hook("CANVAS_CBS_B0")) B = std::min(maxB, atoi(cvx_hook("CANVAS_CBS_B0")));
     outcome = 1;
     while (np < nPerm) {
         const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
@@ -2454,7 +2454,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.r.mtj = (useJump && q.r.total + 1248 <= (long long)MTJ_MAXC * MTJ_C) ? 1 : 0; q.r.mtW0 = dMtW0; q.r.mtStates = dMtStates;      // (every batch starts from its own state: nothing is continued)
         q.r.cont = (!q.r.mtj && np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
-        { static const int fyMin = getenv("CANVAS_CBS_FY_MIN_N") ? atoi(getenv("CANVAS_CBS_FY_MIN_N")) : PERM_FY_MIN_N; q.r.fy = useRp ? 3 : (n >= fyMin ? 1 : 0); }
+        { static const int fyMin = cvx_hook("CANVAS_CBS_FY_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_FY_MIN_N")) : PERM_FY_MIN_N; q.r.fy = useRp ? 3 : (n >= fyMin ? 1 : 0); }
         // persistent workgroups: every one takes the same number of permutations (600 permutations on 512 workgroups would be two rounds with 424 workgroups idle in the second:
         // 300 workgroups with two each take the same time and leave the other CUs to the kernels of the other chromosomes)
         { const int rounds = useRp ? (nb + rpWGs - 1) / rpWGs : 1; q.r.rpWGs = useRp ? (nb + rounds - 1) / rounds : 0; }
@@ -2474,7 +2474,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
             if (contBatch || (long long)(b + 1) * n >= 624) return hSnaps + (size_t)b * 625;
             MT m(0u); m.set_state(cur); for (long long t = 0; t < (long long)(b + 1) * n; t++) (void)m.u32(); m.get_state(tmpState); return tmpState;
         };
-        if (getenv("CANVAS_CBS_TEST_VERIFY")) {      // test hook: every device interval must contain the statistic computed in the reference's order
+        if (cvx_hook("CANVAS_CBS_TEST_VERIFY")) {      // test hook: every device interval must contain the statistic computed in the reference's order
             for (int b = 0; b < nb; b++) {
                 MT m2(0u); m2.set_state(b == 0 ? cur : state_after(b - 1));
                 px.resize(n); sx.resize(n);
@@ -2553,12 +2553,12 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
             np++;
             st.perms++; st.perm_elems += n; st.dev_perms++;
             double pstat = hStat[2 * b];
-            if (!(pstat == pstat) || getenv("CANVAS_CBS_TEST_VERIFY")) {      // a NaN (degenerate extremes) or the test hook: this permutation again on the host, in the reference's order
+            if (!(pstat == pstat) || cvx_hook("CANVAS_CBS_TEST_VERIFY")) {      // a NaN (degenerate extremes) or the test hook: this permutation again on the host, in the reference's order
                 MT m2 = start; for (size_t t = 0; t < (size_t)b * n; t++) (void)m2.u32();
                 px.resize(n); sx.resize(n);
                 xperm(gd, px.data(), n, m2);
                 const double exact = tmaxp_host(tss, px.data(), n, sx.data(), al0);
-                if (getenv("CANVAS_CBS_TEST_VERIFY")) { st.verified++; if (memcmp(&exact, &pstat, 8) != 0 && (exact == exact || pstat == pstat)) st.violations++; }
+                if (cvx_hook("CANVAS_CBS_TEST_VERIFY")) { st.verified++; if (memcmp(&exact, &pstat, 8) != 0 && (exact == exact || pstat == pstat)) st.violations++; }
                 else st.exact_rechecks++;
                 pstat = exact;
             }
@@ -2644,18 +2644,18 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
         int k = nrejc * (nrejc + 1) / 2 + 1;
         auto t0 = std::chrono::steady_clock::now();
         struct Acc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } };
-        static const int permGpuMinN = getenv("CANVAS_CBS_PERM_GPU_MIN_N") ? atoi(getenv("CANVAS_CBS_PERM_GPU_MIN_N")) : PERM_GPU_MIN_N;
-        if (hybrid && n >= permGpuMinN && hk <= PG_MAXK && getenv("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr) {
+        static const int permGpuMinN = cvx_hook("CANVAS_CBS_PERM_GPU_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_PERM_GPU_MIN_N")) : PERM_GPU_MIN_N;
+        if (hybrid && n >= permGpuMinN && hk <= PG_MAXK && cvx_hook("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr) {
             Acc acc{st.ns_dev, t0};
             struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.devLoops++; } } lc{t0};
             int outcome = 1;
             tlClock.loopPerms = 0; tlClock.loopBatches = 0;
             int32_t rc = perm_loop_gpu(PG, gd, n, tss, nPerm, hk, al0, ostat, nrejc, k, sbdry, rnd, st, outcome); if (rc) return rc;
-            { static const bool logLoops = getenv("CANVAS_CBS_TIMING") && atoi(getenv("CANVAS_CBS_TIMING")) >= 2;
+            { static const bool logLoops = cvx_hook("CANVAS_CBS_TIMING") && atoi(cvx_hook("CANVAS_CBS_TIMING")) >= 2;
               if (logLoops) fprintf(stderr, "cbs loop: n %d nrejc %d stop-if-no-rejection %u outcome %d seconds %.4f perms %lld batches %lld\n", n, nrejc, sbdry[(size_t)k - 1], outcome,
                                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), tlClock.loopPerms, tlClock.loopBatches); }
             if (outcome == 0) return CANVAS_OK;
-        } else if (!hybrid && n <= 200 && n >= 4 && PG.svc && getenv("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr && getenv("CANVAS_CBS_HOST_SMALL") == nullptr) {
+        } else if (!hybrid && n <= 200 && n >= 4 && PG.svc && cvx_hook("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr && cvx_hook("CANVAS_CBS_HOST_SMALL") == nullptr) {
             Acc acc{st.ns_dev, t0};
             struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.devLoops++; } } lc{t0};
             int outcome = 1;
@@ -2775,7 +2775,7 @@ struct SpecPool {
             }
         });
     }
-    bool guessAhead = getenv("CANVAS_CBS_NO_GUESSES") == nullptr;
+    bool guessAhead = cvx_hook("CANVAS_CBS_NO_GUESSES") == nullptr;
     // the result of a task: run here if nobody has started it, otherwise wait for the helper
     Phase1& get(const std::shared_ptr<SpecTask>& t, ArcGpu& G, PermGpu& PG) {
         int expect = 0;
@@ -2963,8 +2963,8 @@ extern "C" int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int
     q.r.P.g = (int32_t*)(d + oG); q.r.P.succ = (int32_t*)(d + oSucc); q.r.P.px = (double*)(d + oPx); q.r.P.sx = (double*)(d + oSx);
     q.r.pstat = (double*)(d + oStat); q.r.blockBase = 0; q.r.cont = 0; q.r.fy = kernel == 2 ? 3 : kernel; q.hStat = (double*)(h + pStat); q.hSnaps = (uint32_t*)(h + pSnaps);
     q.r.rpBase = 0; q.r.rpWGs = rpWGs; q.r.rpScratch = (uint32_t*)(d + oScr); q.r.rp = rpP; q.r.rpClk = nullptr;
-    q.r.mtj = (getenv("CANVAS_CBS_JUMP") && q.r.total + 1248 <= (long long)MTJ_MAXC * MTJ_C) ? 1 : 0; q.r.mtW0 = (uint32_t*)(d + oMt); q.r.mtStates = q.r.mtW0 + 33 * 624;
-    long long* dClk = nullptr; const bool wantClk = kernel == 2 && getenv("CANVAS_CBS_PROBE_CLOCKS");
+    q.r.mtj = (cvx_hook("CANVAS_CBS_JUMP") && q.r.total + 1248 <= (long long)MTJ_MAXC * MTJ_C) ? 1 : 0; q.r.mtW0 = (uint32_t*)(d + oMt); q.r.mtStates = q.r.mtW0 + 33 * 624;
+    long long* dClk = nullptr; const bool wantClk = kernel == 2 && cvx_hook("CANVAS_CBS_PROBE_CLOCKS");
     if (wantClk) { CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dClk, 128)); CANVAS_HIP_TRY(ctx, hipMemset(dClk, 0, 128)); q.r.rpClk = dClk; }
     q.hX = (const double*)h; q.dX = (double*)(d + oX); q.xBytes = (size_t)n * 8;
     int32_t rc = svc.submit(q); if (rc) return rc;
@@ -3029,7 +3029,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     std::vector<uint32_t> sbdry;
     { std::lock_guard<std::mutex> lk(bmu); auto tB = std::chrono::steady_clock::now(); const bool fresh = sbN != nperm || sbA != alpha;
       if (fresh) { cbs::compute_boundary(nperm, alpha, 0.05, sb); sbN = nperm; sbA = alpha; } sbdry = sb;
-      if (fresh && getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs: sequential boundary table (GetBoundary.cs) computed in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count()); }
+      if (fresh && cvx_hook("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs: sequential boundary table (GetBoundary.cs) computed in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count()); }
     // per-chromosome seeds in file order (CBSRunner.cs:107-112)
     cbs::MT seeder(0u);
     std::vector<int32_t> seeds(nchr);
@@ -3045,10 +3045,10 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     // launcher threads (own streams): arc searches on one, permutation batches spread over four, so that the device always has several
     // independent kernels in flight (a batch of one chromosome is a chain of latency-bound launches)
     cbs::PermService arcService(ctx), arcService1(ctx), arcService2(ctx), service(ctx), service1(ctx), service2(ctx), service3(ctx);
-    const int nPermSvc = std::max(1, std::min(16, getenv("CANVAS_CBS_PERM_SERVICES") ? atoi(getenv("CANVAS_CBS_PERM_SERVICES")) : 4));
+    const int nPermSvc = std::max(1, std::min(16, cvx_hook("CANVAS_CBS_PERM_SERVICES") ? atoi(cvx_hook("CANVAS_CBS_PERM_SERVICES")) : 4));
     std::vector<std::unique_ptr<cbs::PermService>> moreServices;
     for (int i = 4; i < nPermSvc; i++) moreServices.emplace_back(new cbs::PermService(ctx));
-    const int nArcSvc = std::max(1, std::min(16, getenv("CANVAS_CBS_ARC_SERVICES") ? atoi(getenv("CANVAS_CBS_ARC_SERVICES")) : 3));
+    const int nArcSvc = std::max(1, std::min(16, cvx_hook("CANVAS_CBS_ARC_SERVICES") ? atoi(cvx_hook("CANVAS_CBS_ARC_SERVICES")) : 3));
     std::vector<std::unique_ptr<cbs::PermService>> moreArc;
     for (int i = 3; i < nArcSvc; i++) moreArc.emplace_back(new cbs::PermService(ctx));
     cbs::PermService* arcServices[16] = {&arcService, &arcService1, &arcService2};      // (one launcher synchronises after every round: requests that arrive meanwhile would wait a whole round)
@@ -3058,10 +3058,10 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     for (auto& m : moreServices) permServices.push_back(m.get());
     permServices.resize((size_t)nPermSvc);
     std::atomic_int nextService{0};
-    std::mutex chromMu; double maxChromSec = 0, sumChromSec = 0, slowSec = 0; std::string slowLine; const bool timing = getenv("CANVAS_CBS_TIMING") != nullptr;
+    std::mutex chromMu; double maxChromSec = 0, sumChromSec = 0, slowSec = 0; std::string slowLine; const bool timing = cvx_hook("CANVAS_CBS_TIMING") != nullptr;
     // helper threads for the deterministic front half of every segment on a recursion stack (cbs::SpecPool); CANVAS_CBS_NO_SPECULATION=1: the plain sequential order (test hook)
     std::unique_ptr<cbs::SpecPool> specPool;
-    if (!getenv("CANVAS_CBS_NO_SPECULATION")) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nArcSvc, nperm, alpha, &st}); specPool->start((int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4))); }
+    if (!cvx_hook("CANVAS_CBS_NO_SPECULATION")) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nArcSvc, nperm, alpha, &st}); specPool->start((int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4))); }
     unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
     const int nthreads = (int)std::min<unsigned>(hw, (unsigned)nchr);
     size_t perEngineBudget = ~size_t(0);
@@ -3101,7 +3101,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());
     if (timing) fprintf(stderr, "cbs arc searches whose best admissible arc the reference does not scan (replayed on the host): %lld\n", (long long)st.unscanned_max.load());
     if (timing && specPool) fprintf(stderr, "cbs helpers: %lld segments guessed from a finished phase 1, %lld of them asked for by the recursion\n", (long long)specPool->guessed.load(), (long long)specPool->guessedUsed.load());
-    if (getenv("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: TMaxO on the host %.3f, TailP %.3f (%lld decided from the device series, %lld by the host series)\n", st.ns_tmaxo_host.load() * 1e-9, st.ns_tailp.load() * 1e-9, (long long)st.tailp_dev.load(), (long long)st.tailp_host.load()),
+    if (cvx_hook("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs thread-seconds: TMaxO on the host %.3f, TailP %.3f (%lld decided from the device series, %lld by the host series)\n", st.ns_tmaxo_host.load() * 1e-9, st.ns_tailp.load() * 1e-9, (long long)st.tailp_dev.load(), (long long)st.tailp_host.load()),
                                       fprintf(stderr, "cbs launcher: %lld rounds, %lld arc searches in %.3f s, %lld permutation batches in %.3f s\n", service.rounds + arcService.rounds + arcService1.rounds + arcService2.rounds, arcService.nArc + arcService1.nArc + arcService2.nArc, std::max(arcService.secArc, std::max(arcService1.secArc, arcService2.secArc)), service.nPermReq + service1.nPermReq + service2.nPermReq + service3.nPermReq, std::max(std::max(service.secPerm, service1.secPerm), std::max(service2.secPerm, service3.secPerm))),
                                       fprintf(stderr, "cbs thread-seconds: TMaxO on the device incl. waiting %.3f, edge tests (TPermP) %.3f; per-chromosome wall max %.3f sum %.3f; ", st.ns_tmaxo.load() * 1e-9, st.ns_tpermp.load() * 1e-9, maxChromSec, sumChromSec),
                                       fprintf(stderr, "device permutation loop %.3f (buffers %.3f, uploads %.3f, waiting for the launcher %.3f, stopping rule %.3f), host permutation loop %.3f\n", st.ns_dev.load() * 1e-9, st.ns_ensure.load() * 1e-9, st.ns_upload.load() * 1e-9, st.ns_submit.load() * 1e-9, st.ns_post.load() * 1e-9, st.ns_hostperm.load() * 1e-9);

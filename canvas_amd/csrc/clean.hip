@@ -680,7 +680,7 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     // MedianByGC with the default weighted-median setting: the whole stage is driven from the device (clean_fast.hpp), one synchronisation at the end.  The host-driven
     // path below stays for -m LOESS, -w < 100 (sparse GC buckets take the neighbour-weighted quantiles) and inputs with more than CF_MAXRUN chromosome runs;
     // CANVAS_CLEAN_HOST_DRIVEN=1 forces it (test hook: the two paths must agree bit for bit)
-    if (!loessMode && min_bins_per_gc >= 100 && !getenv("CANVAS_CLEAN_HOST_DRIVEN")) {
+    if (!loessMode && min_bins_per_gc >= 100 && !cvx_hook("CANVAS_CLEAN_HOST_DRIVEN")) {
         bool handled = false;
         int32_t rcf = clean_device_driven(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc, h_local_sd_out, h_n_out, h_info, &handled);
         if (rcf) return rcf;
@@ -934,7 +934,7 @@ extern "C" int32_t canvas_quantize_f2(canvas_ctx* ctx, const float* d_count, int
     if (!ctx) return CANVAS_ERR_INVALID;
     if (n < 0 || (n > 0 && (!d_count || !d_cov))) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_quantize_f2: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (n > 0) hipLaunchKernelGGL(k_quantize_f2, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_count, n, d_cov, getenv("CANVAS_F2_GENERAL") ? 1 : 0);      // (test hook: the general digit arithmetic for every value)
+    if (n > 0) hipLaunchKernelGGL(k_quantize_f2, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_count, n, d_cov, cvx_hook("CANVAS_F2_GENERAL") ? 1 : 0);      // (test hook: the general digit arithmetic for every value)
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
 }
@@ -974,7 +974,7 @@ int32_t cvx_clean_f2_offsets(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t
     if (n < 0 || n >= 0x7FFFFFFFll || nchr <= 0 || nchr > (1 << 20) || !h_chr_is_autosome || !h_n_out || !h_chr_offset || !h_covq_out || !d_cov) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline: bad arguments");
     *h_covq_out = nullptr;
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const bool fused = n > 0 && !(flags & CANVAS_CLEAN_LOESS) && min_bins_per_gc >= 100 && !getenv("CANVAS_CLEAN_HOST_DRIVEN") && !getenv("CANVAS_HMM_RADIX_SELECT") && !getenv("CANVAS_PIPELINE_UNFUSED");
+    const bool fused = n > 0 && !(flags & CANVAS_CLEAN_LOESS) && min_bins_per_gc >= 100 && !cvx_hook("CANVAS_CLEAN_HOST_DRIVEN") && !cvx_hook("CANVAS_HMM_RADIX_SELECT") && !cvx_hook("CANVAS_PIPELINE_UNFUSED");
     bool cleaned = false;
     if (fused) {
         // everything the three stages send back lands in ctx->pin: reserved BEFORE the first copy is enqueued (a later, larger reservation would free the buffer under it)
@@ -1017,7 +1017,7 @@ extern "C" int32_t canvas_clean_batch(canvas_ctx* ctx, int32_t nsamples, const i
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nsamples <= 0 || nsamples > 64 || !h_n || !h_d_chr || !h_d_start || !h_d_stop || !h_d_count || !h_d_gc || !h_chr_is_autosome || !h_n_out) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean_batch: bad arguments (1..64 samples)");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const bool fast = !(flags & CANVAS_CLEAN_LOESS) && min_bins_per_gc >= 100 && !getenv("CANVAS_CLEAN_HOST_DRIVEN");
+    const bool fast = !(flags & CANVAS_CLEAN_LOESS) && min_bins_per_gc >= 100 && !cvx_hook("CANVAS_CLEAN_HOST_DRIVEN");
     int32_t rcAll = CANVAS_OK;
     std::vector<char> done(nsamples, 0);
     if (fast) {

@@ -1469,7 +1469,7 @@ static void cf_gc_medians(canvas_ctx* ctx, const CfArgs* args, int B, unsigned g
 }
 
 // CANVAS_CLEAN_RADIX_SELECT=1 switches the counting selects off (test hook: both ways must agree)
-static inline bool clean_counting_selects() { return getenv("CANVAS_CLEAN_RADIX_SELECT") == nullptr; }
+static inline bool clean_counting_selects() { return cvx_hook("CANVAS_CLEAN_RADIX_SELECT") == nullptr; }
 // Enqueues the whole stage for B samples on ctx->stream (no synchronisation): the CleanDev blocks arrive in ctx->pin.  clean_batch_finish waits for them.
 static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t* const* d_chr, int32_t* const* d_start, int32_t* const* d_stop, float* const* d_count, int32_t* const* d_gc,
                                    int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc, bool useCq) {
@@ -1515,7 +1515,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         gxTcq = std::max(gxTcq, (unsigned)(n / CQ_TILE + NGC + 1));
         A.isAuto = dIsAuto; A.repl = dRepl + (size_t)s * CF_HREP * 3 * NGC; A.szHist = dSz + (size_t)s * CF_SZ_BINS; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
         A.tick = dTick + (size_t)s * 8;
-        { unsigned long long* dbg = ws.take<unsigned long long>(64); A.dbg = getenv("CANVAS_CLEAN_DEBUG_CLOCKS") ? dbg : nullptr; }
+        { unsigned long long* dbg = ws.take<unsigned long long>(64); A.dbg = cvx_hook("CANVAS_CLEAN_DEBUG_CLOCKS") ? dbg : nullptr; }
         gxT = std::max(gxT, tilesUpper);
         anyLsd = anyLsd || A.wantLsd; anyVar = anyVar || (A.wantLsd && n > 500000);
     }
@@ -1560,7 +1560,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     // nothing for the sample and clean_batch_finish enqueues the variance scaling, the second NormalizeByGC and the compaction for it (one more synchronisation, in that case only)
     const int nHist = useCq ? (int)gxTcq : 0, nLsd = anyLsd ? (int)nblk(nMax / 20 + 2, 1024) : 0;
     const int nPick = useCq ? NGC + 1 : 0, nMad = anyLsd ? CF_MADB : 0;
-    if (getenv("CANVAS_CLEAN_SPLIT_ROLES")) {               // profiling hook: every role as a launch of its own (same kernels, same results)
+    if (cvx_hook("CANVAS_CLEAN_SPLIT_ROLES")) {               // profiling hook: every role as a launch of its own (same kernels, same results)
         if (nHist) hipLaunchKernelGGL(k_cf_hist_lsd, dim3(nHist, B), dim3(1024), 0, ctx->stream, dArgs, nHist, 0);
         if (nLsd) hipLaunchKernelGGL(k_cf_hist_lsd, dim3(nLsd, B), dim3(1024), 0, ctx->stream, dArgs, 0, nLsd);
         if (nPick) hipLaunchKernelGGL(k_cf_pick_mad, dim3(nPick, B), dim3(1024), 0, ctx->stream, dArgs, nPick);

@@ -110,6 +110,10 @@ struct ProfScope {
 
 #define CANVAS_FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
 
+// Every CANVAS_* environment switch of the library is a test or diagnostic hook (A/B forms of a kernel, forced fallbacks, timing printouts).  None of them is
+// read unless CANVAS_TEST_HOOKS=1 is set as well (tests/conftest.py and the tools/ scripts set it): a production process cannot be steered off the default path by a stray variable.
+static inline const char* cvx_hook(const char* name) { static const bool on = getenv("CANVAS_TEST_HOOKS") != nullptr; return on ? getenv(name) : nullptr; }
+
 // ---- results a kernel writes STRAIGHT into pinned host memory ("mailboxes": bin size and totals, quartiles, segment count, Wavelets reports).  That a stream or an event has
 // completed does not by itself put such stores in front of the host's reads on this platform: in round 4 a Wavelets report was read before it had arrived about once in eight
 // process starts (gpurun_out/wv_fail_*.log) — silently wrong breakpoints.  So every mailbox carries a sequence word: the kernel stores the payload, fences at system scope, and
@@ -136,7 +140,7 @@ static inline int32_t cvx_mail_await(canvas_ctx* ctx, const volatile unsigned* s
     g_cvx_mail_awaits.fetch_add(1, std::memory_order_relaxed);
     if (*seqWord != expect) {
         g_cvx_mail_waited.fetch_add(1, std::memory_order_relaxed);
-        if (getenv("CANVAS_MAIL_TRACE")) fprintf(stderr, "canvas: %s: the synchronisation returned before the result had arrived in host memory (sequence %u, expected %u): polling\n", what, *seqWord, expect);
+        if (cvx_hook("CANVAS_MAIL_TRACE")) fprintf(stderr, "canvas: %s: the synchronisation returned before the result had arrived in host memory (sequence %u, expected %u): polling\n", what, *seqWord, expect);
         const auto t0 = std::chrono::steady_clock::now();
         while (*seqWord != expect) {
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) { ctx->err = std::string(what) + ": a result written to pinned host memory did not arrive"; return CANVAS_ERR_HIP; }

@@ -1624,7 +1624,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         const double ref = i == j ? P.logA[0][0] : P.logA[0][1];
         if (memcmp(&P.logA[i][j], &ref, sizeof(double)) != 0) twoValuedAll = false;
     }
-    const bool speculative = getenv("CANVAS_HMM_SEQUENTIAL") == nullptr;
+    const bool speculative = cvx_hook("CANVAS_HMM_SEQUENTIAL") == nullptr;
     std::vector<int32_t> redo;
     int32_t* hFail = (int32_t*)ctx->pin; unsigned long long* hSegTot = (unsigned long long*)((char*)ctx->pin + (((size_t)nchr * 4 + 15) & ~size_t(15)));
     bool segEnqueued = false; unsigned* hSegSeq = (unsigned*)(hSegTot + 1); unsigned segSeq = 0;
@@ -1644,7 +1644,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         // How fast the paths merge goes with how well the states are separated, i.e. with the sample's relative dispersion r = IQR / median of the coverage (known on the host:
         // the emission model is built from the same quartiles).  Share of randomised PerSampleHMM calls that needed the second attempt (tools/soak.py, SOAK_DISPERSION=1):
         // r < 0.20: 0 % at 16 steps; 0.20-0.30: 8-34 % at 16, 4-7 % at 32, 0.2 % at 64; r >= 0.30: most at 16 / 32, 5 % (r < 0.4) to 25-90 % at 64 — those keep 128
-        static const int vwEnv = getenv("CANVAS_HMM_LEAD") ? atoi(getenv("CANVAS_HMM_LEAD")) : 0;      // (test hook: the first attempt's cold-start lead-in)
+        static const int vwEnv = cvx_hook("CANVAS_HMM_LEAD") ? atoi(cvx_hook("CANVAS_HMM_LEAD")) : 0;      // (test hook: the first attempt's cold-start lead-in)
         const int vw0 = vwEnv > 0 ? vwEnv : (ctx->hmm_dispersion < 0.20 ? VW0 : (ctx->hmm_dispersion < 0.30 ? 64 : VW));
         const int nAttempts = 5;
         for (int attempt = 0; attempt < nAttempts; attempt++) {
@@ -1660,10 +1660,10 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             else if (twoValued) hipLaunchKernelGGL((k_vit_spec<false, true>), gs, dim3(64), 0, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             else hipLaunchKernelGGL((k_vit_spec<false, false>), gs, dim3(64), 0, ctx->stream, dSBlocks, nblocksS, dChroms, idx, dTab, P, psi, dMapsS, dLast, leadSpec, dTodo, VBS);
             hipLaunchKernelGGL(k_pair_maps, dim3(nblk2(nblocks, 256)), dim3(256), 0, ctx->stream, dVBlocks, nblocks, dChroms, dFirstS, dMapsS, dMaps, dTodo);
-            if (attempt == 0 && getenv("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, chroms[0].begin + chroms[0].T / 2);
+            if (attempt == 0 && cvx_hook("CANVAS_HMM_TEST_CORRUPT")) hipLaunchKernelGGL(k_vit_corrupt, dim3(1), dim3(64), 0, ctx->stream, psi, chroms[0].begin + chroms[0].T / 2);
             backtrack(true);
             hipLaunchKernelGGL(k_vit_increments, dim3(nblk2(N, 256)), dim3(256), 0, ctx->stream, dChroms, nchr, dOffDev, idx, dTab, P, d_state, N, dD);
-            const char* bbMode = getenv("CANVAS_HMM_BACKBONE");      // "chain" | "scan" | default: predicted pieces
+            const char* bbMode = cvx_hook("CANVAS_HMM_BACKBONE");      // "chain" | "scan" | default: predicted pieces
             // (a retry takes the plain chain for its backbone: the predicted pieces below give up on increments they cannot bracket — more binade crossings in a chunk than
             // they keep, exponents that do not behave — and no longer lead-in changes that; the chain is one FP64 add per step, 1.5 ms for a chr1-size chromosome)
             if ((bbMode && !strcmp(bbMode, "chain")) || (attempt > 1 && !bbMode)) hipLaunchKernelGGL(k_vit_backbone, dim3(nchr), dim3(64), 0, ctx->stream, dChroms, dD, dCarry, dTodo);
@@ -1678,7 +1678,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             if (lds) hipLaunchKernelGGL((k_vit_verify<true>), dim3(laneGrid), dim3(64), lds, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail, leadVer, dTodo);
             else hipLaunchKernelGGL((k_vit_verify<false>), dim3(laneGrid), dim3(64), 0, ctx->stream, dVBlocks, nblocks, dChroms, idx, dTab, P, psi, d_state, dD, dCarry, dLast, dFail, leadVer, dTodo);
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFail, dFail, nchr * 4, hipMemcpyDeviceToHost, ctx->stream));
-            if (seg && attempt == 0 && !getenv("CANVAS_HMM_TEST_CORRUPT")) {
+            if (seg && attempt == 0 && !cvx_hook("CANVAS_HMM_TEST_CORRUPT")) {
                 // the states are final unless a chromosome fails its verification (rare): the segment ids are derived now, under the same synchronisation
                 (void)segTot;
                 segSeq = cvx_mail_arm(ctx, hSegSeq);
@@ -1688,8 +1688,8 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             redo.clear();
             for (int c = 0; c < nchr; c++) if (hFail[c] && chroms[c].T > 10) redo.push_back(c);
-            if (!redo.empty() && getenv("CANVAS_HMM_DEBUG_FAIL")) { fprintf(stderr, "viterbi attempt %d (lead-in x%d):", attempt, mult); for (int c : redo) fprintf(stderr, " chr%d(T=%lld, why=0x%x)", c, (long long)chroms[c].T, (unsigned)hFail[c]); fprintf(stderr, "\n"); }
-            if (redo.empty() || getenv("CANVAS_HMM_TEST_CORRUPT") || getenv("CANVAS_HMM_NO_RETRY")) break;
+            if (!redo.empty() && cvx_hook("CANVAS_HMM_DEBUG_FAIL")) { fprintf(stderr, "viterbi attempt %d (lead-in x%d):", attempt, mult); for (int c : redo) fprintf(stderr, " chr%d(T=%lld, why=0x%x)", c, (long long)chroms[c].T, (unsigned)hFail[c]); fprintf(stderr, "\n"); }
+            if (redo.empty() || cvx_hook("CANVAS_HMM_TEST_CORRUPT") || cvx_hook("CANVAS_HMM_NO_RETRY")) break;
             if (attempt < nAttempts - 1) {       // the failed chromosomes become the to-do mask of the next attempt (dRedo doubles as the mask: nchr entries)
                 if (attempt == 0) { ctx->hmm_retry = (int)redo.size(); { ProfScope pr(ctx, "viterbi_retry"); } }     // counted for the tests / bench
                 int32_t rcq = canvas_h2d_small(ctx, dRedo, hFail, nchr * 4); if (rcq) return rcq;
@@ -1706,7 +1706,7 @@ static int32_t hmm_pipeline(canvas_ctx* ctx, int32_t nchr, const int64_t* h_chr_
         // long or empty, runs the same kernel for its few steps under another name: 27 of the 27 'fallbacks' of a noise-40 soak were such calls)
         const bool isFallback = speculative && nblocks > 0;
         ProfScope ps(ctx, isFallback ? "viterbi_sequential" : "viterbi_small");
-        if (getenv("CANVAS_HMM_DEBUG_FAIL")) { fprintf(stderr, "viterbi sequential kernel for %zu chromosomes (speculative %d, blocks %d):", redo.size(), (int)speculative, nblocks); for (size_t i = 0; i < redo.size() && i < 6; i++) fprintf(stderr, " chr%d(T=%lld)", redo[i], (long long)chroms[redo[i]].T); fprintf(stderr, "\n"); }
+        if (cvx_hook("CANVAS_HMM_DEBUG_FAIL")) { fprintf(stderr, "viterbi sequential kernel for %zu chromosomes (speculative %d, blocks %d):", redo.size(), (int)speculative, nblocks); for (size_t i = 0; i < redo.size() && i < 6; i++) fprintf(stderr, " chr%d(T=%lld)", redo[i], (long long)chroms[redo[i]].T); fprintf(stderr, "\n"); }
         rc = canvas_h2d_small(ctx, dRedo, redo.data(), redo.size() * 4); if (rc) return rc;
         hipLaunchKernelGGL(k_viterbi, dim3((unsigned)redo.size()), dim3(64), lds, ctx->stream, dChroms, idx, dTab, P, psi, dLast, dRedo);
         backtrack(false);
@@ -1738,7 +1738,7 @@ static int32_t hmm_per_sample_impl(canvas_ctx* ctx, int32_t nchr, const double* 
     int64_t qidx[6]; int nq;
     quartile_idx(nAll, qidx, nq);
     float v[6], q1, q2, q3;
-    bool radix = getenv("CANVAS_HMM_RADIX_SELECT") != nullptr;
+    bool radix = cvx_hook("CANVAS_HMM_RADIX_SELECT") != nullptr;
     if (!radix && preQ) { rc = cvx_mail_await(ctx, &preQ->pad, ctx->covq_seq, "PerSampleHMM: coverage quartiles"); if (rc) return rc; }      // (preQ is always the context's pinned block: cvx_quant_covq_enqueue)
     if (!radix && preQ && preQ->nq == (uint32_t)nq && preQ->n == nAll) {        // counted while the coverage was quantised (cvx_quantize_f2_covq): the ranks are already on the host
         bool same = true; for (int k = 0; k < nq; k++) same = same && preQ->rank[k] == (unsigned long long)qidx[k];
@@ -1843,7 +1843,7 @@ int32_t cvx_quant_covq_enqueue(canvas_ctx* ctx, const float* d_count, int64_t n,
 int32_t cvx_quantize_f2_covq(canvas_ctx* ctx, const float* d_count, int64_t n, double* d_cov, const void** h_covq_out) {
     if (!ctx) return CANVAS_ERR_INVALID;
     *h_covq_out = nullptr;
-    if (n < 5 || getenv("CANVAS_HMM_RADIX_SELECT")) return canvas_quantize_f2(ctx, d_count, n, d_cov);     // (fewer than 5 bins: PerSampleHMM refuses the sample anyway)
+    if (n < 5 || cvx_hook("CANVAS_HMM_RADIX_SELECT")) return canvas_quantize_f2(ctx, d_count, n, d_cov);     // (fewer than 5 bins: PerSampleHMM refuses the sample anyway)
     return cvx_quant_covq_enqueue(ctx, d_count, n, nullptr, d_cov, h_covq_out);
 }
 

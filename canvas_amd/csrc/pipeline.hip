@@ -16,7 +16,7 @@ static int32_t sample_pipeline_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t
                                     int32_t* h_bin_size, int64_t* h_nbins, int64_t* h_nbins_clean, double* h_local_sd, int64_t* h_chr_offset, int64_t* h_nsegments) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (!d_cov || !d_state || !d_segment_id || !h_chr_offset) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_sample_pipeline: bad arguments");
-    static const bool timing = getenv("CANVAS_PIPELINE_TIMING") != nullptr;      // host wall time of every stage call (each ends in a synchronisation) and of the pause since the previous call returned
+    static const bool timing = cvx_hook("CANVAS_PIPELINE_TIMING") != nullptr;      // host wall time of every stage call (each ends in a synchronisation) and of the pause since the previous call returned
     static thread_local std::chrono::steady_clock::time_point lastReturn; static thread_local bool haveLast = false;
     auto tNow = []() { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };

@@ -234,7 +234,7 @@ static int32_t pipeline_sharded_impl(canvas_ctx* ctx, int32_t nchr, const int32_
         if (localErr) { ctx->err = localMsg; return localErr; }
         CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string("canvas_sample_pipeline_sharded: rank ") + std::to_string(r) + " failed " + where + " (code " + std::to_string(code) + ")");
     };
-    static const bool shTiming = getenv("CANVAS_PIPELINE_TIMING") != nullptr;
+    static const bool shTiming = cvx_hook("CANVAS_PIPELINE_TIMING") != nullptr;
     std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
     auto mark = [&](const char* what) { if (shTiming) { (void)hipStreamSynchronize(ctx->stream); marks.push_back({what, std::chrono::steady_clock::now()}); } };
     mark("start");

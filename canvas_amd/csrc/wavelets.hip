@@ -886,7 +886,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     const int64_t N = h_chr_offset[nchr] - h_chr_offset[0];
     if (N <= 0 || N > 0x7FFFFFF0ll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: bin count out of range");
     const int64_t base = h_chr_offset[0];
-    static const int WV_LONG = [] { const char* e = getenv("CANVAS_WV_LONG"); const int v = e ? atoi(e) : WV_LONG_DEFAULT; return v >= 8 && v <= WV_LONG_MAX ? v : WV_LONG_DEFAULT; }();
+    static const int WV_LONG = [] { const char* e = cvx_hook("CANVAS_WV_LONG"); const int v = e ? atoi(e) : WV_LONG_DEFAULT; return v >= 8 && v <= WV_LONG_MAX ? v : WV_LONG_DEFAULT; }();
     std::vector<int64_t> off(nchr + 1);
     for (int c = 0; c <= nchr; c++) off[c] = h_chr_offset[c] - base;
     const double* dX = d_cov + base;
@@ -914,7 +914,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     // them (levels 12.6 -> 19.2 ms).  CANVAS_WV_CHAIN_CUS = compute units set aside for the chains (an experiment that measured no gain: default 0 = the context's own streams, no masks).
     if (!ctx->wv_streams_tried) {
         ctx->wv_streams_tried = 1;
-        const char* e = getenv("CANVAS_WV_CHAIN_CUS"); int k = e ? atoi(e) : 0;
+        const char* e = cvx_hook("CANVAS_WV_CHAIN_CUS"); int k = e ? atoi(e) : 0;
         hipDeviceProp_t prop;
         if (k > 0 && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount >= 4 * k) {
             const int ncu = prop.multiProcessorCount; std::vector<uint32_t> m((size_t)(ncu + 31) / 32, 0u), inv((size_t)(ncu + 31) / 32, 0u);
@@ -933,18 +933,18 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->wv_fgh_len = WV_LONG;
     }
-    const WvFgh* dFgh = getenv("CANVAS_WV_NO_TABLE") ? nullptr : (const WvFgh*)ctx->wv_fgh; const int fghLen = dFgh ? WV_LONG : 0;
+    const WvFgh* dFgh = cvx_hook("CANVAS_WV_NO_TABLE") ? nullptr : (const WvFgh*)ctx->wv_fgh; const int fghLen = dFgh ? WV_LONG : 0;
     if (!ctx->wv_sub) CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wv_sub, hipStreamNonBlocking));      // the subtree walkers of the roots a batch of levels leaves: next to the following levels and to the chains
     struct StreamSwap { canvas_ctx* c; hipStream_t s0, s1; StreamSwap(canvas_ctx* x) : c(x), s0(x->stream), s1(x->side) { if (x->wv_main && x->wv_chain) { x->stream = x->wv_main; x->side = x->wv_chain; } }
                         ~StreamSwap() { if (c->stream != s0) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->side); } (void)hipStreamSynchronize(c->wv_sub); (void)hipStreamSynchronize(c->wv_sub2); c->stream = s0; c->side = s1; } } streamSwap(ctx);      // (the context's stream is idle: the copy above has been waited for; both are drained on every way out)
-    const bool timing = getenv("CANVAS_WV_TIMING") != nullptr, trace = getenv("CANVAS_WV_TRACE") != nullptr;
+    const bool timing = cvx_hook("CANVAS_WV_TIMING") != nullptr, trace = cvx_hook("CANVAS_WV_TRACE") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     double cv = 0;
     // the factor-of-three CMADs are needed by the healing step only: they are computed on a host thread while the device decomposes
     std::vector<double> f3;
     double f3Seconds = 0;
-    const bool f3OnDevice = nchr <= WV_F3_MAXCHR && !getenv("CANVAS_WV_F3_HOST"), f3Check = getenv("CANVAS_WV_F3_CHECK") != nullptr;
+    const bool f3OnDevice = nchr <= WV_F3_MAXCHR && !cvx_hook("CANVAS_WV_F3_HOST"), f3Check = cvx_hook("CANVAS_WV_F3_CHECK") != nullptr;
     std::thread f3Thread([&]() { if (f3OnDevice && !f3Check) return; const double a = now(); f3 = factor_of_three(nchr, X.data(), off.data()); f3Seconds = now() - a; });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } f3Join{f3Thread};      // joined on every exit path
     // ---- device buffers
@@ -988,7 +988,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     // what does not depend on the thresholds starts now, next to the host's order statistics: counters cleared, the exact prefix sums of the closed-form decisions
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCounts, 0, (size_t)N * sizeof(int32_t), ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dNcand, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    const bool tryClosedForm = !getenv("CANVAS_WV_CHAIN_ONLY");
+    const bool tryClosedForm = !cvx_hook("CANVAS_WV_CHAIN_ONLY");
     if (tryClosedForm) {
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, off.data(), (nchr + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4 * sizeof(int), ctx->stream));
@@ -1023,7 +1023,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     }
     // ---- SegmentationInput.GetCoverageVariability (Segmentation.cs:308-328): the per-window statistics come from the device (CANVAS_WV_VAR_HOST=1: the host threads;
     // CANVAS_WV_VAR_CHECK=1: both, compared), the order statistics over the few hundred windows stay on the host
-    const bool varOnDevice = !getenv("CANVAS_WV_VAR_HOST"), varCheck = getenv("CANVAS_WV_VAR_CHECK") != nullptr;
+    const bool varOnDevice = !cvx_hook("CANVAS_WV_VAR_HOST"), varCheck = cvx_hook("CANVAS_WV_VAR_CHECK") != nullptr;
     std::vector<long long> varStart;
     auto var_enqueue = [&](int window) -> int32_t {          // one workgroup per window, results left in dVarOut
         varStart.clear();
@@ -1057,7 +1057,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         isRoot[(size_t)c] = 1;
     }
     std::vector<double> chromMedian((size_t)nchr, 0.0), chromMad((size_t)nchr, 0.0);
-    const bool medOnDevice = hasCV && varOnDevice && tryClosedForm && !getenv("CANVAS_WV_MEDIAN_HOST");      // (tryClosedForm: dOff is on the device)
+    const bool medOnDevice = hasCV && varOnDevice && tryClosedForm && !cvx_hook("CANVAS_WV_MEDIAN_HOST");      // (tryClosedForm: dOff is on the device)
     if (medOnDevice) {
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dIsRoot, isRoot.data(), (size_t)nchr, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_wv_chrom_median, dim3((unsigned)nchr), dim3(1024), 0, ctx->stream, dX, dOff, dIsRoot, dChromMed);
@@ -1193,7 +1193,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         // the short chromosomes placed above are the first roots of the device-side list
         std::vector<WvRoot> firstRoots(hRoots.begin(), hRoots.end()); hRoots.clear();          // (what flush_roots has launched already stays in front of them)
         size_t rootsLaunched = rootsUsed; unsigned subLaunches = 0;
-        const bool subLate = getenv("CANVAS_WV_SUB_LATE") != nullptr, oneSub = getenv("CANVAS_WV_ONE_SUB") != nullptr;      // (experiments)
+        const bool subLate = cvx_hook("CANVAS_WV_SUB_LATE") != nullptr, oneSub = cvx_hook("CANVAS_WV_ONE_SUB") != nullptr;      // (experiments)
         auto launch_subtrees = [&](unsigned upTo) {             // the roots [rootsLaunched, upTo) of the device's list: written by kernels that have completed
             if (upTo <= rootsLaunched) return;
             const size_t nr = upTo - rootsLaunched;
@@ -1253,7 +1253,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             std::vector<size_t> order(ne);
             for (size_t i = 0; i < ne; i++) order[i] = i;
             std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return hExactIndNew[x] != hExactIndNew[y] ? hExactIndNew[x] > hExactIndNew[y] : x < y; });
-            if (getenv("CANVAS_WV_DEBUG_CHAINS")) ne = std::min<size_t>(ne, (size_t)atoi(getenv("CANVAS_WV_DEBUG_CHAINS")));      // timing experiment: only the longest chains (the result is then wrong)
+            if (cvx_hook("CANVAS_WV_DEBUG_CHAINS")) ne = std::min<size_t>(ne, (size_t)atoi(cvx_hook("CANVAS_WV_DEBUG_CHAINS")));      // timing experiment: only the longest chains (the result is then wrong)
             for (size_t a = 0; a < ne;) {
                 size_t nn = 0; long long used = 0; size_t chunks = 0;
                 while (a + nn < ne && eNodes + nn < maxLong && eBase + nn + 2 <= maxLong + WV_EB) {
@@ -1301,7 +1301,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             exactSeen += k;
             return CANVAS_OK;
         };
-        static const unsigned levelGrid = [] { const char* e = getenv("CANVAS_WV_LEVEL_GRID"); const int v = e ? atoi(e) : 1024; return (unsigned)(v >= 64 && v <= 8192 ? v : 1024); }();
+        static const unsigned levelGrid = [] { const char* e = cvx_hook("CANVAS_WV_LEVEL_GRID"); const int v = e ? atoi(e) : 1024; return (unsigned)(v >= 64 && v <= 8192 ? v : 1024); }();
         while (!hList.empty()) {
             if (hList.size() > maxLong) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: long-node list overflow");
             const int nIn = (int)hList.size();
@@ -1314,7 +1314,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dDev, hdevIn, sizeof hdev, hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(k_wv_list_init, dim3((unsigned)((nIn + 255) / 256)), dim3(256), 0, ctx->stream, dListIn, nIn, dListA, dChA, dDev, (unsigned)maxLong, (unsigned)maxCh);
             hipEvent_t ev[2] = {ctx->side_ev, ctx->side_ev2};
-            static const int firstBatch = [] { const char* e = getenv("CANVAS_WV_FIRST_BATCH"); const int v = e ? atoi(e) : 16; return v >= 2 && v <= 64 && !(v & 1) ? v : 16; }();
+            static const int firstBatch = [] { const char* e = cvx_hook("CANVAS_WV_FIRST_BATCH"); const int v = e ? atoi(e) : 16; return v >= 2 && v <= 64 && !(v & 1) ? v : 16; }();
             int lbOf[2] = {0, 0}, lbNext = firstBatch; unsigned seqOf[2] = {0, 0};       // (16, 32, 64 ... levels.  Smaller first batches start the longest chain earlier but split the chains over several launches of ONE in-order stream, which then run one after the other: 2, 4, 8 ... was 9 ms slower)
             auto enqueue_batch = [&](int slot) -> int32_t {
                 const int lb = lbNext; lbOf[slot] = lb; lbNext = std::min(64, lbNext * 2);
@@ -1433,9 +1433,9 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
         hRedo.clear();
-        for (int32_t i : hLong) if (hOut[i].flag || getenv("CANVAS_WV_TEST_EXACT")) hRedo.push_back(i);
+        for (int32_t i : hLong) if (hOut[i].flag || cvx_hook("CANVAS_WV_TEST_EXACT")) hRedo.push_back(i);
         if (!hRedo.empty()) {                                // a checkpoint of the shortcut chain was not reproduced: IEEE divisions in the chain for those nodes
-            if (!getenv("CANVAS_WV_TEST_EXACT")) redone += (long long)hRedo.size();
+            if (!cvx_hook("CANVAS_WV_TEST_EXACT")) redone += (long long)hRedo.size();
             const int nChunks = upload_long(hRedo);
             rc = long_pass(hRedo.size(), nChunks, false); if (rc) return rc;
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hOut.data(), dOut, nn * sizeof(WvOut), hipMemcpyDeviceToHost, ctx->stream));
@@ -1624,7 +1624,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         }
         segBase[(size_t)nchr] = (int64_t)segs.size();
         bool okLen = true; for (unsigned long long v : segs) if ((v & 0xFFFFFFFFull) == 0) okLen = false;
-        if (!segs.empty() && okLen && segs.size() <= varCap && !getenv("CANVAS_WV_HEAL_HOST")) {
+        if (!segs.empty() && okLen && segs.size() <= varCap && !cvx_hook("CANVAS_WV_HEAL_HOST")) {
             segMed.assign(segs.size(), 0.0);
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVarStart, segs.data(), segs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(k_wv_segment_median, dim3((unsigned)segs.size()), dim3(1024), 0, ctx->stream, dX, (const unsigned long long*)dVarStart, dSegMed);
@@ -1632,7 +1632,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             CANVAS_HIP_TRY(ctx, hipGetLastError());
             segOnDevice = true;
-            if (getenv("CANVAS_WV_VAR_CHECK")) for (size_t k = 0; k < segs.size(); k++) {
+            if (cvx_hook("CANVAS_WV_VAR_CHECK")) for (size_t k = 0; k < segs.size(); k++) {
                 const int64_t a = (int64_t)(segs[k] >> 32), n = (int64_t)(segs[k] & 0xFFFFFFFFull);
                 const double h = median_range(X.data(), a, a + n);
                 if (memcmp(&h, &segMed[k], 8) != 0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's segment medians differ from the host's");

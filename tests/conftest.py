@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("CANVAS_TEST_HOOKS", "1")      # the library reads its CANVAS_* test / diagnostic switches only with this set (common.hpp: cvx_hook)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 

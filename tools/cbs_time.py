@@ -2,6 +2,7 @@
 
 usage: python tools/cbs_time.py [bins] [calls] [seed offset]
 """
+import os as _os; _os.environ.setdefault("CANVAS_TEST_HOOKS", "1")      # (the library reads its CANVAS_* switches only with this set)
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

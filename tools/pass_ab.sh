@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the bench pass on ONE box.  usage: tools/pass_ab.sh "VAR=1" ...   ("" = defaults)
+export CANVAS_TEST_HOOKS=1      # (the library reads its CANVAS_* switches only with this set)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 FLAGS="--no-cpu-baseline --no-cbs --no-wavelets --no-somatic --no-h2d --no-packed --no-executables --no-gc-only --no-pedigree"
 for rep in 1 2; do

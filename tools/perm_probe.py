@@ -1,5 +1,6 @@
 """The device permutation engine on one segment (canvas_cbs_perm_probe): milliseconds of the generator and of the permutation + statistic kernel per batch,
 and the first intervals against the oracle's XPerm + HTMaxP.  usage: python tools/perm_probe.py [kernel ...]"""
+import os as _os; _os.environ.setdefault("CANVAS_TEST_HOOKS", "1")      # (the library reads its CANVAS_* switches only with this set)
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

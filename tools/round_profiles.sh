@@ -2,6 +2,7 @@
 # Collects the per-round evidence under gpurun_out/<tag>/ on a GPU box (copy what is to be judged into profiles/):
 #   kernel summary + timeline of the bench pass, kernel summaries of the somatic flow and of the CBS probe (rocprofv3 --kernel-trace --stats), the five parity soaks.
 # usage: tools/round_profiles.sh <tag> [soak minutes]      (run from the repo root or via gpurun; every step is bounded by `timeout`)
+export CANVAS_TEST_HOOKS=1      # (the library reads its CANVAS_* switches only with this set)
 tag=${1:-rXX}; mins=${2:-6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp

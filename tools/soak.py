@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU (not part of pytest): many seeds / sizes of Clean, F2, PerSampleHMM and segment ids against the oracle.
 usage: tools/soak.py [minutes [seed]]"""
+import os as _os; _os.environ.setdefault("CANVAS_TEST_HOOKS", "1")      # (the library reads its CANVAS_* switches only with this set)
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

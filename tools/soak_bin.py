@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak of CanvasBin on the GPU against the oracle (not part of pytest).  usage: tools/soak_bin.py [minutes [seed]]"""
+import os as _os; _os.environ.setdefault("CANVAS_TEST_HOOKS", "1")      # (the library reads its CANVAS_* switches only with this set)
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 """Randomised parity soak of CanvasBin -m GCContentWeighted on the GPU against the oracle (not part of pytest): fragment-size regimes on both sides of the k_read_gc3 / k_read_gc2
 switch (mean fragment 100), lengths that are no multiple of anything, chromosomes shorter than the window, hits without a length, lengths without a hit, negative / clipped
 lengths, saturated hit counts; every third configuration through the forced kernels (CANVAS_GCW_READ_GC2, CANVAS_GCW_SERIAL).  usage: tools/soak_gcw.py [minutes [seed]]"""
+import os as _os; _os.environ.setdefault("CANVAS_TEST_HOOKS", "1")      # (the library reads its CANVAS_* switches only with this set)
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the tumour / normal flow's CBS time on ONE box under different switches.  usage: tools/somatic_ab.sh "VAR1=1" "VAR2=1 VAR3=1" ...   (an empty string = the defaults)
+export CANVAS_TEST_HOOKS=1      # (the library reads its CANVAS_* switches only with this set)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 for rep in 1 2; do
 for cfg in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # the permutation loops of the tumour / normal flow (BASELINE configs[4]): one line per loop (segment length, permutations, seconds).  usage: tools/somatic_loops.sh <tag>
+export CANVAS_TEST_HOOKS=1      # (the library reads its CANVAS_* switches only with this set)
 tag=${1:-loops}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
 CANVAS_CBS_TIMING=2 timeout 600 python tools/somatic_probe.py > $O/probe.log 2> $O/loops.err; echo "rc $?"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # the Wavelets leg of bench.py alone, with the call's own phase timing, its kernel summary and the timeline of the last call.  usage: tools/wavelets_quick.sh <tag> [ENV=VAL ...]
+export CANVAS_TEST_HOOKS=1      # (the library reads its CANVAS_* switches only with this set)
 tag=${1:-wv}; shift; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 FLAGS="--no-cpu-baseline --no-cbs --no-somatic --no-h2d --no-packed --no-executables --no-gc-only --no-pedigree --steps 1 --warmup 0"

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Repeats the scenario of test_closed_form_decisions_agree_with_the_chains (a chromosome with events, a plain one, a flat one: undecided nodes) and reports every call whose
 breakpoints differ from the first call's.  usage: tools/wv_stress.py [n]"""
+import os as _os; _os.environ.setdefault("CANVAS_TEST_HOOKS", "1")      # (the library reads its CANVAS_* switches only with this set)
 import os, sys
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,3 +1,4 @@
+export CANVAS_TEST_HOOKS=1      # (the library reads its CANVAS_* switches only with this set)
 python -m pytest tests/test_wavelets_gpu.py -x -q -m gpu > gpurun_out/wvt.log 2>&1; tail -2 gpurun_out/wvt.log
 run() { echo "== $*"; env "$@" CANVAS_WV_TIMING=1 python bench.py --no-cbs --no-somatic --no-h2d --no-packed --no-executables --no-gc-only --no-pedigree --no-cpu-baseline --steps 1 --warmup 0 2>&1 | grep "canvas_wavelets\|^{" | tail -7 | python -c "
 import sys, json
