@@ -2365,7 +2365,7 @@ struct PermService {
 };
 static int32_t service_submit_arc(PermService* svc, ArcHostReq& q) { return svc->submit_arc(q); }
 // where the wall time of one chromosome goes (CANVAS_CBS_TIMING): seconds waiting for / running phase 1, in the device and host permutation loops, in the edge tests
-struct ChromClock { double p1 = 0, dev = 0, host = 0, edge = 0; int segments = 0, devLoops = 0, hostLoops = 0; long long loopPerms = 0, loopBatches = 0; };
+struct ChromClock { double p1 = 0, dev = 0, host = 0, edge = 0; int segments = 0, devLoops = 0, hostLoops = 0; long long loopPerms = 0, loopBatches = 0, loopComputed = 0; };
 static thread_local ChromClock tlClock;
 // ---- workspace of a permutation loop.  k_perm_rp (segments of PERM_RP_MIN_N .. PERM_RP_MAX_N bins): the draws of a batch + the scratch of its persistent workgroups;
 // the older kernels (shorter / longer segments): 48 bytes per permuted element.
@@ -2464,7 +2464,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         st.ns_submit += since(tS);
         auto tP = now();
         struct PostAcc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~PostAcc() { a += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } postAcc{st.ns_post, tP};
-        st.dev_batches++; tlClock.loopBatches++;
+        st.dev_batches++; tlClock.loopBatches++; tlClock.loopComputed += nb;
         // generator state behind permutation b of this batch.  The device snapshot is rebuilt from the last 624 outputs in front of that point: fewer than 624 exist when a
         // batch that does not continue another one is cut short inside its first permutations (segments of a few hundred bins) — then the batch's start state is advanced on
         // the host, at most 623 draws.
@@ -2506,7 +2506,21 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
             if (np >= sbdry[k - 1]) { rnd.set_state(state_after(b)); return CANVAS_OK; }
         }
         { const uint32_t* sEnd = state_after(nb - 1); uint32_t keepState[625]; memcpy(keepState, sEnd, sizeof keepState); memcpy(cur, keepState, sizeof cur); }
-        B = std::min(maxB, B * 2);
+        // The next batch: as many permutations as the rule is expected to look at yet (+ 15 %), not simply twice the last one — the permutation kernels are the device's load,
+        // and a loop that stops 20 permutations into a batch of 1024 has computed the other thousand for nothing (with the doubling a third of all permutations computed were never
+        // looked at).  With the rejection rate seen so far, p, the rule stops where np reaches sbdry[k - 1 + p (np' - np)] or where the rejections exceed nrejc, whichever is first.
+        {
+            const double p = (double)nrej / (double)np;
+            long long stopAt = nPerm;
+            if (p > 0.0) stopAt = std::min<long long>(stopAt, (long long)np + (long long)std::ceil((double)(nrejc + 1 - nrej) / p));
+            for (long long t = np; t <= stopAt; t += 16) {      // (the boundary moves up with every expected rejection)
+                const long long kk = (long long)k + (long long)std::floor(p * (double)(t - np));
+                if (kk - 1 >= (long long)sbdry.size()) break;
+                if (t >= (long long)sbdry[(size_t)kk - 1]) { stopAt = t; break; }
+            }
+            const long long want = (long long)std::ceil(1.15 * (double)(stopAt - (long long)np)) + 8;
+            B = (int)std::max<long long>(64, std::min<long long>(maxB, want));
+        }
     }
     rnd.set_state(cur);
     return CANVAS_OK;
@@ -2649,11 +2663,11 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
             Acc acc{st.ns_dev, t0};
             struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.devLoops++; } } lc{t0};
             int outcome = 1;
-            tlClock.loopPerms = 0; tlClock.loopBatches = 0;
+            tlClock.loopPerms = 0; tlClock.loopBatches = 0; tlClock.loopComputed = 0;
             int32_t rc = perm_loop_gpu(PG, gd, n, tss, nPerm, hk, al0, ostat, nrejc, k, sbdry, rnd, st, outcome); if (rc) return rc;
             { static const bool logLoops = cvx_hook("CANVAS_CBS_TIMING") && atoi(cvx_hook("CANVAS_CBS_TIMING")) >= 2;
-              if (logLoops) fprintf(stderr, "cbs loop: n %d nrejc %d stop-if-no-rejection %u outcome %d seconds %.4f perms %lld batches %lld\n", n, nrejc, sbdry[(size_t)k - 1], outcome,
-                                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), tlClock.loopPerms, tlClock.loopBatches); }
+              if (logLoops) fprintf(stderr, "cbs loop: n %d nrejc %d stop-if-no-rejection %u outcome %d seconds %.4f perms %lld batches %lld computed %lld\n", n, nrejc, sbdry[(size_t)k - 1], outcome,
+                                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), tlClock.loopPerms, tlClock.loopBatches, tlClock.loopComputed); }
             if (outcome == 0) return CANVAS_OK;
         } else if (!hybrid && n <= 200 && n >= 4 && PG.svc && cvx_hook("CANVAS_CBS_HOST_PERMUTATIONS") == nullptr && cvx_hook("CANVAS_CBS_HOST_SMALL") == nullptr) {
             Acc acc{st.ns_dev, t0};

@@ -9,10 +9,10 @@ python - <<PY
 import re
 rows=[]
 for l in open("$O/loops.err"):
-    m=re.search(r"cbs loop: n (\d+) nrejc (-?\d+) stop-if-no-rejection (\d+) outcome (\d+) seconds ([\d.]+) perms (\d+) batches (\d+)",l)
+    m=re.search(r"cbs loop: n (\d+) nrejc (-?\d+) stop-if-no-rejection (\d+) outcome (\d+) seconds ([\d.]+) perms (\d+) batches (\d+) computed (\d+)",l)
     if m: rows.append(tuple(float(x) for x in m.groups()))
 rows=rows[len(rows)//2:]   # the second flow
-tot_el=sum(r[0]*r[5] for r in rows); print("loops",len(rows),"elements %.4g"%tot_el,"perms",sum(r[5] for r in rows))
+tot_el=sum(r[0]*r[5] for r in rows); print("loops",len(rows),"elements looked at %.4g"%tot_el,"computed %.4g"%sum(r[0]*r[7] for r in rows),"perms",sum(r[5] for r in rows),"computed",sum(r[7] for r in rows),"batches",sum(r[6] for r in rows))
 bins=[0,1024,4096,16384,32768,65536,131072,262144,1<<30]
 for a,b in zip(bins,bins[1:]):
     rr=[r for r in rows if a<=r[0]<b]
