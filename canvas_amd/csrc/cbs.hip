@@ -959,8 +959,11 @@ __global__ void __launch_bounds__(PG_T) k_perm_fy(const PermReq* __restrict__ re
 // the host evaluates it in the reference's order — as does a block whose ordered steps touch more positions than the table has slots.  The phases are separate functions (not inlined) so that each gets its own register allocation: 128 VGPRs, two workgroups per CU.
 #define RP_R 16384
 #define RP_RSHIFT 14
-#define RP_T PG_T
-#define RP_SPT 4
+#ifndef RP_T
+#define RP_T 512                           // threads of a workgroup (two workgroups per CU by LDS: 128 VGPRs; -DRP_T=256 — four waves with 256 VGPRs, no spills — measured 27 against 34 G elements/s)
+#endif
+#define RP_SPT (2048 / RP_T)
+#define RP_PER (PT_TILE / RP_T)            // consecutive positions of a thread in the statistic
 #define RP_BK (RP_T * RP_SPT)             // 2048 = PT_TILE
 #define RP_TPR (RP_R / RP_BK)
 #define RP_MAXK 32                         // n <= 524 288
@@ -1126,8 +1129,8 @@ __device__ __noinline__ void rp_range_inbox(const PermReq& R, int w, int b, int 
                 more = __syncthreads_or((int)pend);
                 if (round > 4000u) { if (tid == 0) *sOver = 1; break; }
             }
-            sTb[tid] = 0u; sDb[tid] = 0u;
-            if (dirtyChunk) { hKey[tid] = 0xFFFFFFFFu; hKey[tid + RP_T] = 0xFFFFFFFFu; hStamp[tid] = 0u; hStamp[tid + RP_T] = 0u; }
+            for (int z = tid; z < 512; z += RP_T) { sTb[z] = 0u; sDb[z] = 0u; }
+            if (dirtyChunk) { for (int z = tid; z < RP_HASH; z += RP_T) { hKey[z] = 0xFFFFFFFFu; hStamp[z] = 0u; } }
             __syncthreads();
         }
         c0 = c1; tau = tauN; t2 = t2N; c1 = cN1;
@@ -1221,7 +1224,7 @@ __device__ __noinline__ void rp_range_own(const PermReq& R, int w, int b, int k,
         unsigned pend = dm;
         int more = __syncthreads_or((int)dm);                      // (also: every independent step has run, nobody reads the bitmaps any more)
         const int anyOrdered = more;
-        sTb[tid] = 0u; sDb[tid] = 0u;
+        for (int z = tid; z < 512; z += RP_T) { sTb[z] = 0u; sDb[z] = 0u; }
         lapc(2);
         for (uint32_t round = 1; more; round++) {
 #pragma unroll
@@ -1235,7 +1238,7 @@ __device__ __noinline__ void rp_range_own(const PermReq& R, int w, int b, int k,
             more = __syncthreads_or((int)pend);
             if (round > 4000u) { if (tid == 0) *sOver = 1; break; }
         }
-        if (anyOrdered) { hKey[tid] = 0xFFFFFFFFu; hKey[tid + RP_T] = 0xFFFFFFFFu; hStamp[tid] = 0u; hStamp[tid + RP_T] = 0u; }
+        if (anyOrdered) { for (int z = tid; z < RP_HASH; z += RP_T) { hKey[z] = 0xFFFFFFFFu; hStamp[z] = 0u; } }
         else __syncthreads();                                      // (the cleared bitmaps in front of the next block's marks; with ordered steps the rounds' barriers stand there)
         lapc(3);
         // (every step of the block has run behind the last barrier; the next block touches the counters only behind its own first barrier)
@@ -1246,8 +1249,8 @@ __device__ __noinline__ void rp_range_own(const PermReq& R, int w, int b, int k,
     }
     __syncthreads();
     if (k == 0) {
-        static_assert(RP_TAIL * 8 <= RP_HASH * 4 && RP_TAIL == RP_T, "the lane-mask table of the last steps lies over the hash keys, one entry per thread");
-        RP_LDS(unsigned long long, RPL_HKEY)[tid] = 0ull;
+        static_assert(RP_TAIL * 8 <= RP_HASH * 4, "the lane-mask table of the last steps lies over the hash keys");
+        for (int z = tid; z < RP_TAIL; z += RP_T) RP_LDS(unsigned long long, RPL_HKEY)[z] = 0ull;
         __syncthreads();
         if (tid < 64) for (int base = I1; base > 0; base -= 64) { const int i = base - 1 - lane; const bool act = i >= 0; rp_tail_ordered(P, act ? i : -1, act ? rp_target(P.draws, n, i) : -1, act); }
         __syncthreads();
@@ -1326,9 +1329,9 @@ __device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long l
 #pragma unroll
             for (int q = 0; q < RP_SPT; q++) ent[q] = 0xFFFFFFFFu;
         }
-        double v[PT_PER]; double run = 0.0;
+        double v[RP_PER]; double run = 0.0;
 #pragma unroll
-        for (int r = 0; r < PT_PER; r++) { const int i = tid * PT_PER + r; run += i < cnt ? sPx[i] : 0.0; v[r] = run; }
+        for (int r = 0; r < RP_PER; r++) { const int i = tid * RP_PER + r; run += i < cnt ? sPx[i] : 0.0; v[r] = run; }
         const double inc = rp_wave_scan_f64(run);
         if ((tid & 63) == 63) shD[wv] = inc;
         __syncthreads();
@@ -1337,7 +1340,7 @@ __device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long l
         for (int kq = 0; kq < RP_T / 64; kq++) { const double tq = shD[kq]; if (kq < wv) wb += tq; tot += tq; }
         const double before = dcarry + wb + (inc - run);
 #pragma unroll
-        for (int r = 0; r < PT_PER; r++) sT[PT_HALO + tid * PT_PER + r] = before + v[r];
+        for (int r = 0; r < RP_PER; r++) sT[PT_HALO + tid * RP_PER + r] = before + v[r];
         dcarry += tot;
         __syncthreads();
         if (base == 0 && tid < PT_HALO) sEdge[tid] = sT[PT_HALO + tid];
@@ -1345,26 +1348,26 @@ __device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long l
         if (base > 0 && base + PT_TILE < n) {
             // (fmax: one v_max_f64 with the |.| modifier per arc — the ternary compiled to a compare, two selects and an and; all operands are finite)
             // positions u = 4 tid .. 4 tid + 3: arcs of 2 .. 13 from sT[4 tid .. 4 tid + 16], arcs of 14 .. 25 from sT[4 tid + 14 .. 4 tid + 28] — two windows in registers, 96 arcs from 36 reads
-            const double* wp = sT + tid * PT_PER;
-            double w0[PT_PER];
+            const double* wp = sT + tid * RP_PER;
+            double w0[RP_PER];
 #pragma unroll
-            for (int r = 0; r < PT_PER; r++) w0[r] = wp[r];
+            for (int r = 0; r < RP_PER; r++) w0[r] = wp[r];
             {
-                double wa[15];      // wp[2 .. 16]
+                double wa[RP_PER + 11];      // wp[2 .. RP_PER + 12]
 #pragma unroll
-                for (int e = 0; e < 15; e++) wa[e] = wp[2 + e];
+                for (int e = 0; e < RP_PER + 11; e++) wa[e] = wp[2 + e];
 #pragma unroll
-                for (int r = 0; r < PT_PER; r++) {
+                for (int r = 0; r < RP_PER; r++) {
 #pragma unroll
                     for (int j = 2; j <= 13; j++) mx[j - RP_J0] = fmax(mx[j - RP_J0], fabs(wa[r + j - 2] - w0[r]));
                 }
             }
             {
-                double wb2[15];     // wp[14 .. 28]
+                double wb2[RP_PER + 11];     // wp[14 .. RP_PER + 24]
 #pragma unroll
-                for (int e = 0; e < 15; e++) wb2[e] = wp[14 + e];
+                for (int e = 0; e < RP_PER + 11; e++) wb2[e] = wp[14 + e];
 #pragma unroll
-                for (int r = 0; r < PT_PER; r++) {
+                for (int r = 0; r < RP_PER; r++) {
 #pragma unroll
                     for (int j = 14; j <= 25; j++) mx[j - RP_J0] = fmax(mx[j - RP_J0], fabs(wb2[r + j - 14] - w0[r]));
                 }
@@ -1415,7 +1418,7 @@ __device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long l
     }
     __syncthreads();
 }
-__global__ void __launch_bounds__(RP_T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_perm_rp(const PermReq* __restrict__ reqs, int nreq) {
+__global__ void __launch_bounds__(RP_T) __attribute__((amdgpu_waves_per_eu(RP_T / 128, RP_T / 128))) k_perm_rp(const PermReq* __restrict__ reqs, int nreq) {
     int ri = 0;
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].rpBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
     const PermReq& R = reqs[ri];
@@ -1437,8 +1440,8 @@ __global__ void __launch_bounds__(RP_T) __attribute__((amdgpu_waves_per_eu(4, 4)
         for (int k = K - 1; k >= 0; k--) {
             const int lo = k << RP_RSHIFT, hi = n < lo + RP_R ? n : lo + RP_R;
             for (int p = tid; p < hi - lo; p += RP_T) sA[p] = lo + p;
-            sTb[tid] = 0u; sDb[tid] = 0u;
-            hKey[tid] = 0xFFFFFFFFu; hKey[tid + RP_T] = 0xFFFFFFFFu; hStamp[tid] = 0u; hStamp[tid + RP_T] = 0u;
+            for (int z = tid; z < 512; z += RP_T) { sTb[z] = 0u; sDb[z] = 0u; }
+            for (int z = tid; z < RP_HASH; z += RP_T) { hKey[z] = 0xFFFFFFFFu; hStamp[z] = 0u; }
             if (k < K - 1) for (int t = tid; t <= nT; t += RP_T) sRow[t] = P.endsIn[(size_t)k * (nT + 1) + t];
             __syncthreads();
             lapc(0);
