@@ -299,7 +299,6 @@ struct PermReq {
     int fy;                    // 0: k_perm_stat, 1: k_perm_fy, 2: k_perm_small, 3: k_perm_rp evaluates this request's permutations
     // k_perm_rp: rpWGs persistent workgroups (blocks rpBase .. rpBase + rpWGs of its launch), each with its own scratch of rp.stride words behind rpScratch
     int rpBase, rpWGs; uint32_t* rpScratch; long long* rpClk;      // rpClk (probe only): cycles of workgroup 0 per phase
-    int mtj; uint32_t* mtW0; uint32_t* mtStates;      // jump-ahead generator (k_mtj_*): the first words of the sequence behind the start state, the states in front of the chunks
     struct RpPlan { int K, nT; uint32_t inOff[32], inCap[32]; uint32_t oEndsIn, oEndsOwn, oInbox, oOutIn, oOutOwn, stride; } rp;
 };
 // MT19937 is linear over GF(2): every bit of its output stream obeys the recurrence of the characteristic polynomial phi (degree 19937,
@@ -328,7 +327,7 @@ static constexpr int MT_LAG_C[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700
 __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs, int bootstrap) {
     __shared__ uint32_t mtA[624], mtB[624];
     const PermReq& R = reqs[blockIdx.x];
-    if (R.cont || R.fy == 2 || R.mtj) return;
+    if (R.cont || R.fy == 2) return;
     uint32_t* __restrict__ draws = R.P.draws;
     const long long seqMax = bootstrap && R.total >= MT_BOOT_MIN ? 19937LL : MT_HISTORY;     // bootstrap: only the first 19937 outputs come from here (see k_mt_classes)
     const long long total = R.total < seqMax ? R.total : seqMax;
@@ -376,7 +375,7 @@ __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict_
     // index every line was written by 8 different L2s, 4 bytes at a time (PMC: 43 GB of WRITE_SIZE for 4.8 GB of draws).  Sequences r = x * (stride / 8) + k for the k-th
     // workgroup of XCD x: a line's 16 writers share an L2 and run side by side.
     const int bx = (int)blockIdx.x, r = stride >= 8 ? (bx & 7) * (stride >> 3) + (bx >> 3) : bx, tid = (int)threadIdx.x;
-    if (R.fy == 2 || R.mtj || (boot && (R.cont || R.total < MT_BOOT_MIN))) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
+    if (R.fy == 2 || (boot && (R.cont || R.total < MT_BOOT_MIN))) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
     uint32_t* __restrict__ d = R.P.draws;
     const long long start = boot ? 19937LL * stride : (R.cont ? 0 : MT_HISTORY);        // first position to generate; the 19937 * stride positions in front of it are there
     const long long end = boot ? (R.total < 19937LL * 2 * stride ? R.total : 19937LL * 2 * stride) : R.total;
@@ -412,199 +411,6 @@ __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict_
         }
         head += 623;
         __syncthreads();
-    }
-}
-// ---- the generator by JUMP-AHEAD (k_mtj_*; replaces the strided recurrence for batches of up to MTJ_MAXC chunks).  The strided recurrence costs 134 LDS reads per draw: 0.022 ns
-// per draw with half the device busy, a quarter of the device time of a tumour / normal sample's permutation loops.  MT19937's own recurrence costs three reads and a dozen
-// operations per word, but one state is one sequential stream; a batch is therefore cut into chunks of MTJ_C words, and the state in front of chunk c is obtained from the batch's
-// start state by a jump: the state transition A (one word step) is linear over GF(2) with characteristic polynomial chi (degree 19937, the 135 terms of MT_LAG), so
-// A^J = g_J(A) with g_J(x) = x^J mod chi, and with W[0], W[1], ... the untempered word sequence behind the start state (W[0 .. 623] = the state array)
-//     W[J + m] = XOR over the set bits i of g_J of W[i + m]          (m >= 1: every bit of the words behind the first one belongs to the state)
-// — 624 words of a chunk's state from the first 20 561 words of the sequence, ~10 000 XORs each, instead of 134 per DRAW.  The polynomials g_c = x^(c MTJ_C - 1) mod chi do not
-// depend on the batch: they are computed once per context, on the device (k_mtj_table: g_(c + 2^k) = g_c h^(2^k), h = x^MTJ_C, by doubling; polynomial products word by word
-// in LDS, reduction by chi's lags).  Per batch: k_mtj_base writes W[0 .. 20 592) natively, k_mtj_jump forms the states of the chunks c >= 1 (one workgroup each, the sequence in
-// LDS), k_mtj_gen runs every chunk natively from its state (chunk 0 from the start state itself) and writes the tempered draws.  Chunk c covers the words W[624 + c MTJ_C,
-// 624 + (c + 1) MTJ_C) — the draws behind the start state's read index mti are W[mti], W[mti + 1], ... — so the jump distances do not depend on mti.
-#define MTJ_C 131072
-#define MTJ_MAXC 512                       // chunks per batch the table serves (67 M draws)
-#define MTJ_W0 (19937 + 624 + 31)          // words of the sequence the jumps read (rounded up to whole regenerations: 33 x 624 = 20 592)
-#define MTJ_PW 624                         // words of a polynomial (19 968 bits)
-__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b2, uint32_t src) { const uint32_t y = (a & 0x80000000u) | (b2 & 0x7fffffffu); return src ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
-// one regeneration of the 624-word array (three data-parallel phases + the last word), 256 threads
-__device__ __forceinline__ void mt_regen(const uint32_t* cur, uint32_t* nxt, int tid) {
-    if (tid < 227) nxt[tid] = mt_mix(cur[tid], cur[tid + 1], cur[tid + 397]);
-    __syncthreads();
-    if (tid < 227) nxt[227 + tid] = mt_mix(cur[227 + tid], cur[228 + tid], nxt[tid]);
-    __syncthreads();
-    if (tid < 169) nxt[454 + tid] = mt_mix(cur[454 + tid], cur[455 + tid], nxt[227 + tid]);
-    __syncthreads();
-    if (tid == 0) nxt[623] = mt_mix(cur[623], nxt[0], nxt[396]);
-    __syncthreads();
-}
-// c = a * b mod chi for polynomials of MTJ_PW words in LDS (a, b, and prod[2 MTJ_PW] scratch); 640 threads; the result is left in prod[0 .. MTJ_PW)
-__device__ void mtj_mulmod(const uint32_t* a, const uint32_t* b, uint32_t* prod) {
-    const int tid = threadIdx.x;
-    uint32_t acc0 = 0u, acc1 = 0u;
-    const int k0 = tid, k1 = tid + 640;
-    for (int s = 0; s < MTJ_PW; s++) {
-        uint32_t aw = a[s];
-        if (!aw) continue;
-        const int j0 = k0 - s, j1 = k1 - s;
-        const uint32_t b0lo = (j0 >= 0 && j0 < MTJ_PW) ? b[j0] : 0u, b0hi = (j0 - 1 >= 0 && j0 - 1 < MTJ_PW) ? b[j0 - 1] : 0u;
-        const uint32_t b1lo = (j1 >= 0 && j1 < MTJ_PW) ? b[j1] : 0u, b1hi = (j1 - 1 >= 0 && j1 - 1 < MTJ_PW) ? b[j1 - 1] : 0u;
-        while (aw) {
-            const int r = __ffs((int)aw) - 1; aw &= aw - 1u;
-            acc0 ^= r ? (b0lo << r) | (b0hi >> (32 - r)) : b0lo;
-            acc1 ^= r ? (b1lo << r) | (b1hi >> (32 - r)) : b1lo;
-        }
-    }
-    __syncthreads();
-    prod[k0] = acc0; if (k1 < 2 * MTJ_PW) prod[k1] = acc1;
-    __syncthreads();
-    // reduction: a set bit d >= 19937 stands for x^d = sum over the lags L of x^(d - L) (chi = x^19937 + sum x^(19937 - L), the lag 19937 being the constant term).  The smallest
-    // lag is 623, so 19 words (608 bits) from the top reduce without touching one another: 34 groups
-    for (int top = 2 * MTJ_PW - 1; top >= 623; top -= 19) {
-        const int lowW = top - 18 > 623 ? top - 18 : 623;
-        const int nW = top - lowW + 1;
-        for (int e = tid; e < nW * MT_NLAG; e += 640) {
-            const int wI = lowW + e / MT_NLAG, L = MT_LAG[e % MT_NLAG];
-            uint32_t v = prod[wI]; if (wI == 623) v &= ~1u;                 // (bit 19936 = bit 0 of word 623 stays)
-            if (v) {
-                const int bitPos = wI * 32 - L;                              // where bit 0 of the word lands (>= -31: bits that would land below 0 are not set — their d < L cannot be: d >= 19937 >= L)
-                const int tw = bitPos >> 5, r = bitPos & 31;                  // (arithmetic shift: bitPos may be negative only when the low bits of v are clear)
-                if (tw >= 0) atomicXor(&prod[tw], v << r);
-                if (r && tw + 1 >= 0) atomicXor(&prod[tw + 1], v >> (32 - r));
-            }
-        }
-        __syncthreads();
-        for (int wI = lowW + tid; wI <= top; wI += 640) prod[wI] = wI == 623 ? (prod[wI] & 1u) : 0u;
-        __syncthreads();
-    }
-}
-// the table of jump polynomials, level by level: mode 0 (one workgroup): h = x^MTJ_C (squarings), g_1 = h / x, H_0 = h; mode 1 at level k: workgroup w < 2^k: g_(1 + w + 2^k) =
-// g_(1 + w) H_k; workgroup 2^k: H_(k + 1) = H_k^2.  table[c - 1] = g_c; Hbuf[k] = h^(2^k)
-__global__ void __launch_bounds__(640) k_mtj_table(uint32_t* __restrict__ table, uint32_t* __restrict__ Hbuf, int mode, int level) {
-    __shared__ uint32_t sa[MTJ_PW], sb[MTJ_PW], sp[2 * MTJ_PW];
-    const int tid = threadIdx.x;
-    if (mode == 0) {
-        for (int i = tid; i < MTJ_PW; i += 640) sa[i] = i == 0 ? 2u : 0u;      // x
-        __syncthreads();
-        int lg = 0; while ((1 << lg) < MTJ_C) lg++;
-        for (int sq = 0; sq < lg; sq++) {
-            for (int i = tid; i < MTJ_PW; i += 640) sb[i] = sa[i];
-            __syncthreads();
-            mtj_mulmod(sa, sb, sp);
-            for (int i = tid; i < MTJ_PW; i += 640) sa[i] = sp[i];
-            __syncthreads();
-        }
-        for (int i = tid; i < MTJ_PW; i += 640) Hbuf[i] = sa[i];
-        // g_1 = h / x: chi has the constant term 1, so (h + h_0 chi) is divisible by x
-        const uint32_t h0 = sa[0] & 1u;
-        __syncthreads();
-        if (h0) { for (int e = tid; e < MT_NLAG; e += 640) { const int ex = 19937 - MT_LAG[e]; atomicXor(&sa[ex >> 5], 1u << (ex & 31)); } if (tid == 0) atomicXor(&sa[19937 >> 5], 1u << (19937 & 31)); }
-        __syncthreads();
-        for (int i = tid; i < MTJ_PW; i += 640) table[i] = (sa[i] >> 1) | (i + 1 < MTJ_PW ? sa[i + 1] << 31 : 0u);
-        return;
-    }
-    const int w = blockIdx.x, half = 1 << level;
-    const uint32_t* A = w < half ? table + (size_t)w * MTJ_PW : Hbuf + (size_t)level * MTJ_PW;
-    const uint32_t* B = Hbuf + (size_t)level * MTJ_PW;
-    for (int i = tid; i < MTJ_PW; i += 640) { sa[i] = A[i]; sb[i] = B[i]; }
-    __syncthreads();
-    mtj_mulmod(sa, sb, sp);
-    uint32_t* out = w < half ? table + (size_t)(w + half) * MTJ_PW : Hbuf + (size_t)(level + 1) * MTJ_PW;
-    for (int i = tid; i < MTJ_PW; i += 640) out[i] = sp[i];
-}
-// the first MTJ_W0 (rounded up to 33 x 624) untempered words behind the start state of every request that takes the jump generator
-__global__ void __launch_bounds__(256) k_mtj_base(const PermReq* __restrict__ reqs) {
-    __shared__ uint32_t mtA[624], mtB[624];
-    const PermReq& R = reqs[blockIdx.x];
-    if (!R.mtj) return;
-    const int tid = threadIdx.x;
-    uint32_t* cur = mtA; uint32_t* nxt = mtB;
-    for (int i = tid; i < 624; i += 256) { cur[i] = R.state[i]; R.mtW0[i] = R.state[i]; }
-    __syncthreads();
-    for (int g = 1; g < 33; g++) {
-        mt_regen(cur, nxt, tid);
-        for (int i = tid; i < 624; i += 256) R.mtW0[g * 624 + i] = nxt[i];
-        uint32_t* t = cur; cur = nxt; nxt = t;
-    }
-}
-__device__ __forceinline__ int mtj_chunks(const PermReq& R) { const long long last = (long long)R.state[624] + R.total - 1; return last < 624 ? 1 : (int)((last - 624) / MTJ_C) + 1; }
-// the state array in front of chunk c >= 1: words W[c MTJ_C .. c MTJ_C + 623] (grid.x = chunk - 1, grid.y = request).  The polynomial is applied in two halves, each with the
-// 10 608 words of the sequence it reads in LDS (42 KB: the workgroup shares a CU with the permutation kernel's)
-#define MTJ_HALF 9984                      // bits of g per half (312 words)
-__global__ void __launch_bounds__(640) k_mtj_jump(const PermReq* __restrict__ reqs, const uint32_t* __restrict__ table) {
-    __shared__ uint32_t sw[MTJ_HALF + 624];
-    __shared__ uint32_t sg[MTJ_PW];
-    const PermReq& R = reqs[blockIdx.y];
-    const int c = (int)blockIdx.x + 1;
-    if (!R.mtj || c >= mtj_chunks(R)) return;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < MTJ_PW; i += 640) sg[i] = table[(size_t)(c - 1) * MTJ_PW + i];      // (the polynomial: read word by word below, every lane the same word)
-    uint32_t acc = 0u;
-    for (int half = 0; half < 2; half++) {
-        __syncthreads();
-        for (int i = tid; i < MTJ_HALF + 623; i += 640) sw[i] = R.mtW0[half * MTJ_HALF + 1 + i];        // sw[e] = W[half * MTJ_HALF + 1 + e]
-        __syncthreads();
-        if (tid < 624) {
-            const uint32_t* __restrict__ base = sw + tid;
-            for (int s = 0; s < MTJ_HALF / 32; s++) {
-                const uint32_t gw = sg[half * (MTJ_HALF / 32) + s];
-                const uint32_t* __restrict__ p = base + s * 32;
-                // all 32 words are read whether their bit is set or not (about half are): 32 reads with immediate offsets in flight at once instead of one dependent
-                // read per set bit — the loop over the set bits waited out the LDS latency 10 000 times per state (0.5 ms)
-                uint32_t v[32];
-#pragma unroll
-                for (int r = 0; r < 32; r++) v[r] = p[r];
-#pragma unroll
-                for (int r = 0; r < 32; r++) acc ^= v[r] & (0u - ((gw >> r) & 1u));
-            }
-        }
-    }
-    if (tid < 624) R.mtStates[(size_t)c * 624 + tid] = acc;
-}
-// every chunk natively from its state, ONE WAVE per chunk (blockIdx.x * 4 + wave = chunk, grid.y = request): chunk 0 from the start state (its read index included), chunk
-// c >= 1 from the jumped state.  The array is regenerated in place, 64 words at a time in ascending order — word k needs the old words k, k + 1 and k + 397 (k < 227) or the new
-// word k - 227: never a word of its own group, nor of the group before it — so the wave needs no barrier (LDS keeps one wave's accesses in order), the operands of the next
-// group are requested before the current group is written, and a new word is tempered and stored from its register
-__device__ __forceinline__ void mtj_load(const uint32_t* cur, int k, uint32_t& a, uint32_t& b2, uint32_t& sx) {
-    a = 0u; b2 = 0u; sx = 0u;
-    if (k < 623) { a = cur[k]; b2 = cur[k + 1]; sx = k < 227 ? cur[k + 397] : cur[k - 227]; }
-    else if (k == 623) { a = cur[623]; b2 = cur[0]; sx = cur[396]; }      // (cur[0] and cur[396] are new by then: the last group is loaded behind the barrier of the one before it)
-}
-__global__ void __launch_bounds__(256) k_mtj_gen(const PermReq* __restrict__ reqs) {
-    __shared__ uint32_t sm[4][624 + 8];
-    const PermReq& R = reqs[blockIdx.y];
-    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    const int c = (int)blockIdx.x * 4 + wave;
-    if (!R.mtj || c >= mtj_chunks(R)) return;
-    const long long mti = (long long)R.state[624];
-    uint32_t* cur = sm[wave];
-    const uint32_t* src = c == 0 ? R.state : R.mtStates + (size_t)c * 624;
-    for (int i = lane; i < 624; i += 64) cur[i] = src[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t* __restrict__ draws = R.P.draws;
-    // word indices of the sequence: the array holds W[a0, a0 + 624); this chunk emits the draws of W[lo, hi)
-    long long a0 = c == 0 ? 0 : (long long)c * MTJ_C;
-    const long long lo = c == 0 ? mti : 624 + (long long)c * MTJ_C;
-    long long hi = 624 + (long long)(c + 1) * MTJ_C; if (hi > mti + R.total) hi = mti + R.total;
-    if (c == 0) { const long long e = hi < 624 ? hi : 624; for (long long i = lo + lane; i < e; i += 64) draws[i - mti] = mt_temper(cur[i]); }      // (what is left of the start state's own array)
-    while (a0 + 624 < hi) {
-        a0 += 624;
-        uint32_t a, b2, sx;
-        mtj_load(cur, lane, a, b2, sx);
-#pragma unroll
-        for (int g = 0; g < 10; g++) {
-            const int k = g * 64 + lane;
-            uint32_t an = 0u, bn = 0u, sn = 0u;
-            if (g + 1 < 9) mtj_load(cur, k + 64, an, bn, sn);              // (groups 1 .. 8: none of their operands is written by the group in front of them)
-            const uint32_t v = mt_mix(a, b2, sx);
-            if (k < 624) { cur[k] = v; const long long i = a0 + k; if (i >= lo && i < hi) draws[i - mti] = mt_temper(v); }
-            __builtin_amdgcn_wave_barrier();
-            if (g + 1 == 9) mtj_load(cur, k + 64, an, bn, sn);             // (the last group reads the new words 0 and 396: behind the write above; word 349 .. 396 of its k - 227 too)
-            a = an; b2 = bn; sx = sn;
-        }
     }
 }
 // generator state after every permutation of the batch, rebuilt from the outputs: the 624 words behind a position are the untempered
@@ -2220,14 +2026,12 @@ struct PermService {
     canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
     ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
     long long rounds = 0, nArc = 0, nPermReq = 0; double secArc = 0, secPerm = 0;
-    uint32_t* dJumpTable = nullptr;      // k_mtj_table: the jump polynomials (built once per context, kept in its engine cache)
     bool probeTiming = false; double lastMs[3] = {0, 0, 0};      // canvas_cbs_perm_probe: generator (sequential + bootstrap), generator (strided), permutation + statistic of the last launch
     std::mutex mu; std::condition_variable cvWork, cvDone; std::vector<PermHostReq*> pending; bool stop = false; std::thread th; std::string err;
     explicit PermService(canvas_ctx* c) : ctx(c) { th = std::thread([this]() { run(); }); }
     ~PermService() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cvWork.notify_all(); th.join();
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dReqs) (void)hipFree(dReqs); if (hReqs) (void)hipHostFree(hReqs);
         if (dArc) (void)hipFree(dArc); if (hArc) (void)hipHostFree(hArc); if (dArcP) (void)hipFree(dArcP); if (hArcP) (void)hipHostFree(hArcP); }
-    int32_t jump_table();
     int32_t submit(PermHostReq& q) {
         std::unique_lock<std::mutex> lk(mu);
         pending.push_back(&q);
@@ -2295,7 +2099,7 @@ struct PermService {
         int blocks = 0, rpBlocks = 0; long long maxTotal = 0;
         for (int i = 0; i < R; i++) {
             batch[i]->r.rpBase = rpBlocks; if (batch[i]->r.fy == 3) rpBlocks += batch[i]->r.rpWGs; else batch[i]->r.rpWGs = 0;
-            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2 && !batch[i]->r.mtj) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
+            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
             if (batch[i]->r.cont)    // history of this batch = the last MT_HISTORY outputs of the previous one (same buffer, no overlap: prevTotal >= MT_HISTORY)
                 CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws - MT_HISTORY, batch[i]->r.P.draws + (batch[i]->prevTotal - MT_HISTORY), (size_t)MT_HISTORY * 4, hipMemcpyDeviceToDevice, stream));
             if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // pinned source
@@ -2307,23 +2111,13 @@ struct PermService {
         auto lap = [&]() { (void)hipStreamSynchronize(stream); auto t = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; return ms; };
         if (dbg) lap();
         const bool bootstrap = true;      // (the sequential history is grown by doubling: k_mt_classes with boot = 1)
-        bool anyFresh = false; long long maxFresh = 0; int jumpChunks = 0;
-        for (int i = 0; i < R; i++) {
-            const PermReq& q = batch[i]->r;
-            if (q.mtj) { const long long last = (long long)q.state[624] + q.total - 1; jumpChunks = std::max(jumpChunks, last < 624 ? 1 : (int)((last - 624) / MTJ_C) + 1); }
-            else if (!q.cont && q.fy != 2) { anyFresh = true; if (q.total >= MT_BOOT_MIN) maxFresh = std::max(maxFresh, q.total); }
-        }
-        if (jumpChunks) {
-            int32_t rcj = jump_table(); if (rcj) return rcj;
-            hipLaunchKernelGGL(k_mtj_base, dim3(R), dim3(256), 0, stream, dReqs);
-            if (jumpChunks > 1) hipLaunchKernelGGL(k_mtj_jump, dim3(jumpChunks - 1, R), dim3(640), 0, stream, dReqs, dJumpTable);
-            hipLaunchKernelGGL(k_mtj_gen, dim3((jumpChunks + 3) / 4, R), dim3(256), 0, stream, dReqs);
-        }
+        bool anyFresh = false; long long maxFresh = 0;
+        for (int i = 0; i < R; i++) if (!batch[i]->r.cont && batch[i]->r.fy != 2) { anyFresh = true; if (batch[i]->r.total >= MT_BOOT_MIN) maxFresh = std::max(maxFresh, batch[i]->r.total); }
         if (anyFresh) hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs, bootstrap ? 1 : 0);
         if (anyFresh && bootstrap)
             for (int sd = 1; sd < MT_STRIDE && 19937LL * sd < maxFresh; sd <<= 1) hipLaunchKernelGGL(k_mt_classes, dim3(sd, R), dim3(MTC_T), 0, stream, dReqs, sd, 1);
         if (dbg) msA = lap();
-        const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;       // (maxTotal: the requests of the strided generator only)
+        const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;
         if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
         if (dbg) msB = lap();
         hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
@@ -2382,10 +2176,10 @@ static inline int perm_rp_wgs(int n) { PermReq::RpPlan P; rp_plan(n, P); const s
 static void perm_reserve_bytes(size_t nMax, size_t& dev, size_t& pin) {
     const size_t head = al256(nMax * 8) + al256(625 * 4) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
     const size_t elemsRp = std::max<size_t>(PERM_TARGET_ELEMS, 8 * nMax);
-    dev = head + al256((elemsRp + (size_t)MT_HISTORY) * 4) + PERM_RP_SCRATCH_BYTES + (size_t(64) << 20) + al256((size_t)(33 + MTJ_MAXC) * 624 * 4);
+    dev = head + al256((elemsRp + (size_t)MT_HISTORY) * 4) + PERM_RP_SCRATCH_BYTES + (size_t(64) << 20);
     if (nMax > (size_t)PERM_RP_MAX_N || !perm_use_rp((int)std::min<size_t>(nMax, PERM_RP_MAX_N))) {
         const size_t re = (size_t)std::min<long long>((long long)256 * (long long)nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * (long long)nMax));
-        dev = std::max(dev, head + al256((re + (size_t)MT_HISTORY) * 4) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8) + al256((size_t)(33 + MTJ_MAXC) * 624 * 4));
+        dev = std::max(dev, head + al256((re + (size_t)MT_HISTORY) * 4) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
     }
     pin = al256(nMax * 8) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
 }
@@ -2400,8 +2194,6 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     auto now = []() { return std::chrono::steady_clock::now(); };
     uint32_t* dRpScratch = nullptr; int rpWGs = 0; PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP);
-    uint32_t* dMtW0 = nullptr; uint32_t* dMtStates = nullptr;
-    static const bool useJump = cvx_hook("CANVAS_CBS_JUMP") != nullptr;      // (the jump-ahead generator: less device work per draw, more latency per batch than the strided recurrence — see DESIGN.md)
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
     auto setup = [&](int mb) -> int32_t {
@@ -2414,9 +2206,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         // k_perm_rp: the draws and, behind them, the scratch of the persistent workgroups (results travel in streams: no per-element workspace)
         size_t oScratch = 0, totalRp = 0;
         if (useRp) { rp_plan(n, rpP); rpWGs = std::min(perm_rp_wgs(n), mb); oScratch = oDraws + al((e + (size_t)MT_HISTORY) * 4); totalRp = oScratch + al((size_t)rpP.stride * 4 * (size_t)rpWGs); }
-        const size_t mtBytes = al((size_t)(33 + MTJ_MAXC) * 624 * 4);          // jump generator: the first words behind the start state + the chunks' states
-        const size_t oMt = useRp ? totalRp : total;
-        const size_t need = oMt + mtBytes;
+        const size_t need = useRp ? totalRp : total;
         size_t want = need, wantPin = pinTotal;
         if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // the first allocation serves the longest segment this call can meet
         int32_t rc0 = PG.ensure(want, wantPin, need); if (rc0) return rc0;
@@ -2424,7 +2214,6 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         char* d = PG.buf; char* h = PG.pin;
         dX = (double*)(d + oX); dSnaps = (uint32_t*)(d + oSnaps); dStat = (double*)(d + oStat);
         P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY;       // MT_HISTORY outputs of head room for the continuation
-        dMtW0 = (uint32_t*)(d + oMt); dMtStates = dMtW0 + 33 * 624;
         if (useRp) { memset(&P.j, 0, sizeof(PermBuf) - sizeof(uint32_t*)); dRpScratch = (uint32_t*)(d + oScratch); }
         else {
         P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
@@ -2455,8 +2244,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         memcpy(q.r.state, cur, sizeof cur); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
         q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
-        q.r.mtj = (useJump && q.r.total + 1248 <= (long long)MTJ_MAXC * MTJ_C) ? 1 : 0; q.r.mtW0 = dMtW0; q.r.mtStates = dMtStates;      // (every batch starts from its own state: nothing is continued)
-        q.r.cont = (!q.r.mtj && np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
+        q.r.cont = (np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
         { static const int fyMin = cvx_hook("CANVAS_CBS_FY_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_FY_MIN_N")) : PERM_FY_MIN_N; q.r.fy = useRp ? 3 : (n >= fyMin ? 1 : 0); }
         // persistent workgroups: every one takes the same number of permutations (600 permutations on 512 workgroups would be two rounds with 424 workgroups idle in the second:
         // 300 workgroups with two each take the same time and leave the other CUs to the kernels of the other chromosomes)
@@ -2558,7 +2346,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
         PermHostReq q;
         memset(q.r.state, 0, sizeof q.r.state); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = nullptr; q.r.x = dX; q.r.hk = 0; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = 0.0;
         memset(&q.r.P, 0, sizeof q.r.P); q.r.P.draws = dDraws; q.r.pstat = dStat; q.r.blockBase = 0; q.r.cont = 0; q.r.fy = 2; q.hStat = hStat; q.hSnaps = nullptr;
-        q.r.rpBase = 0; q.r.rpWGs = 0; q.r.rpScratch = nullptr; q.r.rpClk = nullptr; memset(&q.r.rp, 0, sizeof q.r.rp); q.r.mtj = 0; q.r.mtW0 = nullptr; q.r.mtStates = nullptr;
+        q.r.rpBase = 0; q.r.rpWGs = 0; q.r.rpScratch = nullptr; q.r.rpClk = nullptr; memset(&q.r.rp, 0, sizeof q.r.rp);
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.hDraws = hDraws; q.drawBytes = (size_t)nb * n * 4;
         auto tS = std::chrono::steady_clock::now();
@@ -2706,8 +2494,6 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
 }
 // the engines' buffers outlive a call: a thread borrows an ArcGpu / PermGpu from the context's cache and hands it back (the buffers only grow)
 struct EngineCache {
-    uint32_t* jumpTable = nullptr; uint32_t* jumpH = nullptr; std::mutex jumpMu;      // the jump polynomials of the generator (k_mtj_table): 1.3 MB, built on first use
-    ~EngineCache() { if (jumpTable) (void)hipFree(jumpTable); if (jumpH) (void)hipFree(jumpH); }
     std::mutex mu; std::vector<std::unique_ptr<ArcGpu>> arcs; std::vector<std::unique_ptr<PermGpu>> perms, tails;      // tails: engines of the helper threads (tail series only: they never grow a permutation workspace and must not take one of those away from a chromosome thread)
     static EngineCache& of(canvas_ctx* ctx) {
         static std::mutex g; std::lock_guard<std::mutex> lk(g);
@@ -2721,23 +2507,6 @@ struct EngineCache {
     void give(std::unique_ptr<ArcGpu> g) { std::lock_guard<std::mutex> lk(mu); arcs.push_back(std::move(g)); }
     void give(std::unique_ptr<PermGpu> g) { std::lock_guard<std::mutex> lk(mu); perms.push_back(std::move(g)); }
 };
-int32_t PermService::jump_table() {
-    if (dJumpTable) return CANVAS_OK;
-    EngineCache& cache = EngineCache::of(ctx);
-    std::lock_guard<std::mutex> lk(cache.jumpMu);
-    if (!cache.jumpTable) {
-        uint32_t* t = nullptr; uint32_t* h = nullptr;
-        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&h, (size_t)12 * MTJ_PW * 4));
-        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&t, (size_t)MTJ_MAXC * MTJ_PW * 4));
-        hipLaunchKernelGGL(k_mtj_table, dim3(1), dim3(640), 0, stream, t, h, 0, 0);
-        for (int level = 0; (1 << level) < MTJ_MAXC; level++) hipLaunchKernelGGL(k_mtj_table, dim3((1 << level) + 1), dim3(640), 0, stream, t, h, 1, level);
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream));       // (other launchers' streams read the table)
-        CANVAS_HIP_TRY(ctx, hipGetLastError());
-        cache.jumpTable = t; cache.jumpH = h;
-    }
-    dJumpTable = cache.jumpTable;
-    return CANVAS_OK;
-}
 // helper threads of phase 1 (own arc-search and tail-series buffers each); a chromosome thread that needs a segment no helper has started yet runs it itself
 #define CBS_SPEC_MIN_N 4
 struct SpecTask { const double* gd; int cn; std::atomic<bool> guess{false}; Phase1 out; std::atomic<int> state{0}; };      // 0 queued, 1 running, 2 done; guess: put there by a helper, not (yet) asked for by the recursion
@@ -2964,7 +2733,7 @@ extern "C" int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int
                  oSx = oPx + al(kernel == 2 ? 0 : e * 8), oScr = oSx + al(kernel == 0 ? e * 8 : 0);
     PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP); int rpWGs = 0;
     if (kernel == 2) { cbs::rp_plan(n, rpP); rpWGs = std::min(cbs::perm_rp_wgs(n), (int)nb); }
-    const size_t oMt = oScr + al((size_t)rpP.stride * 4 * (size_t)rpWGs), total = oMt + al((size_t)(33 + MTJ_MAXC) * 624 * 4);
+    const size_t total = oScr + al((size_t)rpP.stride * 4 * (size_t)rpWGs);
     char* d = nullptr; char* h = nullptr;
     CANVAS_HIP_TRY(ctx, hipMalloc((void**)&d, total));
     struct Free { char*& d; char*& h; ~Free() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); } } fr{d, h};
@@ -2980,7 +2749,6 @@ extern "C" int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int
     q.r.P.g = (int32_t*)(d + oG); q.r.P.succ = (int32_t*)(d + oSucc); q.r.P.px = (double*)(d + oPx); q.r.P.sx = (double*)(d + oSx);
     q.r.pstat = (double*)(d + oStat); q.r.blockBase = 0; q.r.cont = 0; q.r.fy = kernel == 2 ? 3 : kernel; q.hStat = (double*)(h + pStat); q.hSnaps = (uint32_t*)(h + pSnaps);
     q.r.rpBase = 0; q.r.rpWGs = rpWGs; q.r.rpScratch = (uint32_t*)(d + oScr); q.r.rp = rpP; q.r.rpClk = nullptr;
-    q.r.mtj = (cvx_hook("CANVAS_CBS_JUMP") && q.r.total + 1248 <= (long long)MTJ_MAXC * MTJ_C) ? 1 : 0; q.r.mtW0 = (uint32_t*)(d + oMt); q.r.mtStates = q.r.mtW0 + 33 * 624;
     long long* dClk = nullptr; const bool wantClk = kernel == 2 && cvx_hook("CANVAS_CBS_PROBE_CLOCKS");
     if (wantClk) { CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dClk, 128)); CANVAS_HIP_TRY(ctx, hipMemset(dClk, 0, 128)); q.r.rpClk = dClk; }
     q.hX = (const double*)h; q.dX = (double*)(d + oX); q.xBytes = (size_t)n * 8;

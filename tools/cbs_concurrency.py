@@ -31,3 +31,7 @@ for rep in range(2):
     two = [0, 0]; th = [threading.Thread(target=run, args=(cvs[i], two, i)) for i in range(2)]
     t = time.perf_counter(); [x.start() for x in th]; [x.join() for x in th]; wall = time.perf_counter() - t
     print(f"one call {one[0]:.3f} s; two calls at once {wall:.3f} s (each {two[0]:.3f}, {two[1]:.3f}): ratio {wall / one[0]:.2f}", flush=True)
+# ---- the longest chromosome by itself, then the first 2 / 4 / 8: how much of the call's time is chromosome 1's own chain of dependent batches
+for k in (1, 2, 4, 8, 24):
+    offk = np.ascontiguousarray(off[:k + 1]); ck = cov[:int(offk[-1])]
+    cvs[0].cbs(ck, offk, 0.01, 10000); t = time.perf_counter(); cvs[0].cbs(ck, offk, 0.01, 10000); print(f"first {k} chromosomes: {time.perf_counter() - t:.3f} s", flush=True)
