@@ -906,12 +906,12 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
             const bool rg3 = meanFrag > 100 && !cvx_hook("CANVAS_GCW_READ_GC2");
             const size_t ldsRg = (size_t)nWmax * (rg3 ? 16 : 12);
             int perCu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, rg3 ? (const void*)k_read_gc3 : (const void*)k_read_gc2, 256, ldsRg) != hipSuccess || perCu <= 0) perCu = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, rg3 ? (const void*)k_read_gc3<RG3_HE, RG3_HO> : (const void*)k_read_gc2, 256, ldsRg) != hipSuccess || perCu <= 0) perCu = 2;
             const unsigned gridRg = (unsigned)(perCu * cus);
             // x / meanFrag as (x * ceil(2^40 / meanFrag)) >> 40: exact while x < 2^22 and meanFrag < 2^15 (x = 100 * count <= 100 * 32767)
             const unsigned long long mean40 = ((1ull << 40) + (unsigned long long)meanFrag - 1ull) / (unsigned long long)meanFrag;
             ProfScope ps(ctx, "gcw_read_gc", false, sp);
-            if (rg3) hipLaunchKernelGGL(k_read_gc3, dim3((unsigned)std::min<int64_t>(gridRg, ntileAll)), dim3(256), ldsRg, sp, dRg, nchr, ntileAll, meanFrag, mean40, nWmax, hist);
+            if (rg3) hipLaunchKernelGGL((k_read_gc3<RG3_HE, RG3_HO>), dim3((unsigned)std::min<int64_t>(gridRg, ntileAll)), dim3(256), ldsRg, sp, dRg, nchr, ntileAll, meanFrag, mean40, nWmax, hist);
             else for (int c = 0; c < nchr; c++) {
                 const int64_t ntile = (h_len[c] + RG_T - 1) / RG_T;
                 hipLaunchKernelGGL(k_read_gc2, dim3((unsigned)std::min<int64_t>(gridRg, ntile)), dim3(256), ldsRg, sp, d_bases[c], d_fraglen[c], d_hits[c], h_len[c], meanFrag, mean40, nWmax,

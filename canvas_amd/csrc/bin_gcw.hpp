@@ -23,12 +23,13 @@
 #define RG_HALF 4096
 #define RG_LREP 4                      // histogram replicas in LDS
 #define RG_REP 16                      // histogram replicas in global memory (workgroup % RG_REP): a single set of 202 counters would be a serial chain of atomics
-__device__ __forceinline__ uint64_t gc_bits64(const uint8_t* __restrict__ bases, int64_t p, int64_t len) {
+template <class PB>
+__device__ __forceinline__ uint64_t gc_bits64(PB bases, int64_t p, int64_t len) {
     uint64_t g = 0;
     if (p + 64 <= len) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint4 v = *reinterpret_cast<const uint4*>(bases + p + 16 * q);
+            const uint4 v = gload_uint4(bases + p + 16 * q);
             const uint64_t b16 = (uint64_t)(marks_to_bits4(gc_marks4(v.x)) | (marks_to_bits4(gc_marks4(v.y)) << 4) | (marks_to_bits4(gc_marks4(v.z)) << 8) | (marks_to_bits4(gc_marks4(v.w)) << 12));
             g |= b16 << (16 * q);
         }
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(256) k_read_gc2(const uint8_t* __restrict__ ba
         for (int base = 0; base < nW; base += 256) {
             const int w = base + tid;
             uint64_t g = 0;
-            if (w < nW) { const int64_t p = t0 + ((int64_t)w << 6); if (p < len) g = gc_bits64(bases, p, len); sBits[w] = g; }
+            if (w < nW) { const int64_t p = t0 + ((int64_t)w << 6); if (p < len) g = gc_bits64(as_global(bases), p, len); sBits[w] = g; }
             const uint32_t cnt = (uint32_t)__popcll(g);
             const uint32_t inc = wave_inclusive_scan_u32(cnt);
             if ((tid & 63) == 63) sWave[tid >> 6] = inc;
@@ -237,15 +238,24 @@ __global__ void __launch_bounds__(256) k_nonzero_mean_all(const RgChrom* __restr
 // four workgroups per CU do not cover that.  Here the workgroup only builds the tile's GC prefix together; then every WAVE works through its own quarter of the tile in rounds of
 // 512 positions (8 per lane) with no workgroup barrier, the next round's hits and fragment lengths already in flight:
 //   (a) every position as if it carried no fragment length: with x = 100 * count, v = x / meanFragment and r = x % meanFragment the count moves by d in {-1, 0, 1} from one
-//       position to the next, r by 100 d, and |100 d| < meanFragment means at most one step of v either way — no division per position.  32 histogram replicas laid out
-//       [gcContent][lane % 32]: a lane owns its LDS bank, the atomics of a wave never meet, every position simply adds (1, hits) — no run tracking, no branches;
+//       position to the next (round 5: the eight counts of a lane come from one multiplication and v from a float multiply-add; the remainder chain r += 100 d of
+//       round 4 is kept for mean fragments beyond RG3_FAST_M).  32 histogram replicas laid out [gcContent][lane % 32]: a lane owns its LDS bank, the atomics of a
+//       wave never meet; every position adds 1 to the expected histogram, the observed one is fed by step (b) alone;
 //   (b) positions WITH a fragment length are patches of that default: they go on a wave-private list as (offset, length, hits) in one word (wave prefix sum of the lanes'
 //       counts, no atomics), all lanes then work the list off: two lookups in the {32 GC bits, running count} table, a float reciprocal with an exact correction
-//       (quotient <= 100, operands < 2^24), the byte replaced and the histograms corrected by -default +actual (32-bit counters in modular arithmetic, flushed before they can wrap);
+//       (quotient <= 100, operands < 2^24), the byte replaced, the expected histogram corrected by -default +actual (32-bit counters in modular arithmetic, flushed
+//       before they can wrap) and the hits added to the observed one.  Positions with a hit but no length are on the list too (window = the default);
 //   (c) 8-byte stores.
-#define RG3_HR 32
+#define RG3_HE 16                      // histogram replicas in LDS, [gcContent][lane % 16]: measured against 32 / 32 (four workgroups per CU instead of five: 5.5 vs 5.0 ms) and
+#define RG3_HO 16                      // 32 / 8 (same time within the spread between boxes)
 #define RG3_FLUSH_TILES 512            // 512 x 8192 positions x 255 hits < 2^32
 #define RG3_WR 512                     // positions of a wave round
+#define RG3_FAST_M 16384               // largest mean fragment whose default-window values are computed in float (see step (a)); the others carry a remainder along
+__device__ __forceinline__ uint32_t rg3_spread8(uint32_t x) {          // bit j of the low byte -> bit 0 of nibble j
+    uint32_t s = (x | (x << 12)) & 0x000F000Fu;
+    s = (s | (s << 6)) & 0x03030303u;
+    return (s | (s << 3)) & 0x11111111u;
+}
 __device__ __forceinline__ uint32_t rg3_prefix(const uint2* __restrict__ sPre, int a) {      // GC positions in [tile start, tile start + a)
     const uint2 e = sPre[a >> 5];
     return e.y + (uint32_t)__popc(e.x & ((1u << (a & 31)) - 1u));
@@ -257,33 +267,38 @@ __device__ __forceinline__ uint32_t rg3_div100(uint32_t c, uint32_t cur) {      
     if (r < 0) q--; else if ((uint32_t)r >= cur) q++;
     return q;
 }
-__device__ __forceinline__ void rg3_load8(const uint8_t* __restrict__ hits, const int16_t* __restrict__ fl, int64_t p, int64_t len, uint32_t (&hw)[2], uint32_t (&fw)[4]) {
+template <class PH, class PF>
+__device__ __forceinline__ void rg3_load8(PH hits, PF fl, int64_t p, int64_t len, uint32_t (&hw)[2], uint32_t (&fw)[4]) {
     hw[0] = hw[1] = 0; fw[0] = fw[1] = fw[2] = fw[3] = 0;
     if (p + 8 <= len) {
-        const uint2 h = *reinterpret_cast<const uint2*>(hits + p); const uint4 f = *reinterpret_cast<const uint4*>(fl + p);
+        const uint2 h = gload_uint2(hits + p); const uint4 f = gload_uint4(fl + p);
         hw[0] = h.x; hw[1] = h.y; fw[0] = f.x; fw[1] = f.y; fw[2] = f.z; fw[3] = f.w;
     } else {
         for (int j = 0; j < 8 && p + j < len; j++) { hw[j >> 2] |= (uint32_t)hits[p + j] << (8 * (j & 3)); fw[j >> 1] |= (uint32_t)(uint16_t)fl[p + j] << (16 * (j & 1)); }
     }
 }
 // dynamic LDS: uint2 sPre[2 * nWmax]  ({GC bits of 32 positions, GC positions of the tile in front of them})
+template <int HE, int HO>          // replicas of the expected / observed histogram in LDS (RG3_HE, RG3_HO)
 __global__ void __launch_bounds__(256) k_read_gc3(const RgChrom* __restrict__ ch, int nchr, int64_t ntileAll, int meanFrag, unsigned long long mean40, int nWmax,
                                                   unsigned long long* __restrict__ histRep) {
     extern __shared__ __attribute__((aligned(16))) uint2 sPre[];
-    __shared__ unsigned int sHist[2 * 101 * RG3_HR];                    // expected [101][32], observed [101][32]
+    __shared__ unsigned int sHist[101 * HE], sHistO[101 * HO];       // expected [101][HE] (eight atomics per lane and round + the patches), observed [101][HO] (fed by the list only)
     __shared__ uint32_t sWave[4];
     __shared__ __attribute__((aligned(16))) uint8_t sGW[4][RG3_WR];      // gcContent of the wave's round
-    __shared__ uint32_t sListW[4][RG3_WR];                              // the wave's positions with a fragment length: offset in the round << 23 | max(length, 0) << 8 | hits
+    __shared__ uint2 sListW[4][RG3_WR / 2];                             // the wave's positions with a fragment length or a hit, half a round at a time: {length | hits << 16, offset in the round}
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t lane32 = (uint32_t)tid & 31u;
-    for (int i = tid; i < 2 * 101 * RG3_HR; i += 256) sHist[i] = 0;
+    const uint32_t laneR = (uint32_t)tid & (HE - 1u), laneO = (uint32_t)tid & (HO - 1u);
+    for (int i = tid; i < 101 * HE; i += 256) sHist[i] = 0;
+    for (int i = tid; i < 101 * HO; i += 256) sHistO[i] = 0;
     const int M = meanFrag, H = 3 * meanFrag;
+    const bool fastF = M <= RG3_FAST_M;
+    const float rMean = 1.0f / (float)M, c100 = (float)(100.0 / (double)M);        // (both correctly rounded: IEEE division)
     unsigned long long* rep = histRep + (size_t)(blockIdx.x % RG_REP_ALL) * 202;
-    uint8_t* __restrict__ sG = sGW[wv]; uint32_t* __restrict__ sList = sListW[wv];
+    uint8_t* __restrict__ sG = sGW[wv]; uint2* __restrict__ sList = sListW[wv];
     int sinceFlush = 0;
     for (int64_t tile = blockIdx.x; tile < ntileAll; tile += gridDim.x) {
         const int ci = rg_find_chrom(ch, nchr, tile);
-        const uint8_t* __restrict__ bases = ch[ci].bases; const int16_t* __restrict__ fl = ch[ci].fl; const uint8_t* __restrict__ hits = ch[ci].hits; uint8_t* __restrict__ readGc = ch[ci].readGc;
+        const gptr<const uint8_t> bases = as_global(ch[ci].bases); const gptr<const int16_t> fl = as_global(ch[ci].fl); const gptr<const uint8_t> hits = as_global(ch[ci].hits); const gptr<uint8_t> readGc = as_global(ch[ci].readGc);
         const int64_t len = ch[ci].len;
         const int64_t lim = len - (int64_t)H - 1;                  // positions from `lim` on keep gcContent 0 (the loop of CanvasBin.cs:466 stops there)
         const int64_t t0 = (tile - ch[ci].tile0) * RG_T;
@@ -299,7 +314,8 @@ __global__ void __launch_bounds__(256) k_read_gc3(const RgChrom* __restrict__ ch
         if (sinceFlush == RG3_FLUSH_TILES) {
             if (tid < 101) {
                 unsigned int e = 0, o = 0;
-                for (int r = 0; r < RG3_HR; r++) { e += sHist[tid * RG3_HR + r]; o += sHist[(101 + tid) * RG3_HR + r]; sHist[tid * RG3_HR + r] = 0; sHist[(101 + tid) * RG3_HR + r] = 0; }
+                for (int r = 0; r < HE; r++) { e += sHist[tid * HE + r]; sHist[tid * HE + r] = 0; }
+                for (int r = 0; r < HO; r++) { o += sHistO[tid * HO + r]; sHistO[tid * HO + r] = 0; }
                 if (e) atomicAdd(&rep[tid], (unsigned long long)e);
                 if (o) atomicAdd(&rep[101 + tid], (unsigned long long)o);
             }
@@ -344,19 +360,35 @@ __global__ void __launch_bounds__(256) k_read_gc3(const RgChrom* __restrict__ ch
                     const uint2 eB = sPre[b0 >> 5];
                     const uint32_t bitsB = __builtin_amdgcn_alignbit(sPre[(b0 >> 5) + 1].x, eB.x, (uint32_t)(b0 & 31)) & 0xFFu;
                     const uint32_t cnt = (eB.y + (uint32_t)__popc(eB.x & ((1u << (b0 & 31)) - 1u))) - rg3_prefix(sPre, a0);
-                    const uint32_t x = 100u * cnt;
-                    uint32_t v = (uint32_t)(((unsigned long long)x * mean40) >> 40);      // 100 * gcCounter / meanFragmentSize (exact: x < 2^22, see the host)
-                    int32_t r = (int32_t)(x - v * (uint32_t)M);
+                    if (fastF) {
+                        // the eight counts at once: nibble j of `dex` = 8 + (GC positions entering - leaving the window over the j positions in front of position j), from
+                        // the two ends' bits spread to one per nibble, subtracted and summed up by ONE multiplication (the nibbles stay in [1, 15]: no borrow between them);
+                        // v = floor((100 count + 0.5) / meanFragment) in float: the operand is exact (< 2^23), the quotient is off by < 1.8e-5 and 0.5 / meanFragment away
+                        // from the next integer (meanFragment <= RG3_FAST_M; tests/test_gcw_formula.py walks every boundary) — two instructions per position, no carry of
+                        // a remainder from one position to the next
+                        const uint32_t dex = (((rg3_spread8(bitsB) - rg3_spread8(bitsA)) * 0x11111111u + 0x88888888u) << 4) | 8u;
+                        const uint32_t de = dex & 0x0F0F0F0Fu, dod = (dex >> 4) & 0x0F0F0F0Fu;
+                        const float bf = ((float)(int32_t)(100u * cnt) - 799.5f) * rMean;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        out[j >> 2] |= v << (8 * (j & 3));
-                        const uint32_t idx = v * RG3_HR + lane32;
-                        atomicAdd(&sHist[idx], 1u);
-                        atomicAdd(&sHist[101 * RG3_HR + idx], (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-                        r = __mul24(100, (int32_t)((bitsB >> j) & 1u) - (int32_t)((bitsA >> j) & 1u)) + r;
-                        const int32_t adj = (r >> 31) - ((M - 1 - r) >> 31);       // +1: r >= M, -1: r < 0
-                        r -= __mul24(adj, M);
-                        v += (uint32_t)adj;
+                        for (int j = 0; j < 8; j++) {
+                            const float df = (float)((((j & 1) ? dod : de) >> (8 * (j >> 1))) & 0xFFu);
+                            const uint32_t v = (uint32_t)__builtin_fmaf(df, c100, bf);
+                            out[j >> 2] |= v << (8 * (j & 3));
+                            atomicAdd(&sHist[v * HE + laneR], 1u);
+                        }
+                    } else {
+                        const uint32_t x = 100u * cnt;
+                        uint32_t v = (uint32_t)(((unsigned long long)x * mean40) >> 40);      // 100 * gcCounter / meanFragmentSize (exact: x < 2^22, see the host)
+                        int32_t r = (int32_t)(x - v * (uint32_t)M);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            out[j >> 2] |= v << (8 * (j & 3));
+                            atomicAdd(&sHist[v * HE + laneR], 1u);
+                            r = __mul24(100, (int32_t)((bitsB >> j) & 1u) - (int32_t)((bitsA >> j) & 1u)) + r;
+                            const int32_t adj = (r >> 31) - ((M - 1 - r) >> 31);       // +1: r >= M, -1: r < 0
+                            r -= __mul24(adj, M);
+                            v += (uint32_t)adj;
+                        }
                     }
                 } else {
                     // the last groups of the chromosome: positions behind `lim` keep 0, positions behind `len` do not exist
@@ -366,52 +398,60 @@ __global__ void __launch_bounds__(256) k_read_gc3(const RgChrom* __restrict__ ch
                         uint32_t g = 0;
                         if (j < nlim) g = (uint32_t)(((unsigned long long)(100u * (rg3_prefix(sPre, a0 + j + M) - rg3_prefix(sPre, a0 + j))) * mean40) >> 40);
                         out[j >> 2] |= g << (8 * (j & 3));
-                        atomicAdd(&sHist[g * RG3_HR + lane32], 1u);
-                        atomicAdd(&sHist[(101 + g) * RG3_HR + lane32], (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                        atomicAdd(&sHist[g * HE + laneR], 1u);
+                        if (j >= nlim) atomicAdd(&sHistO[g * HO + laneO], (hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);      // (in front of `lim` a hit is a list entry)
                     }
                 }
-                if (nlim < 8) {                                                   // positions from `lim` on are no list entries: their lengths are dropped here
+                if (nlim < 8) {                                                   // positions from `lim` on are no list entries: their lengths and hits are dropped here
 #pragma unroll
-                    for (int j = 0; j < 8; j++) if (j >= nlim) fw[j >> 1] &= ~(0xFFFFu << (16 * (j & 1)));
+                    for (int j = 0; j < 8; j++) if (j >= nlim) { fw[j >> 1] &= ~(0xFFFFu << (16 * (j & 1))); hw[j >> 2] &= ~(0xFFu << (8 * (j & 3))); }
                 }
-            }
-            // the positions that carry a fragment length, position j of every lane at a time: the lanes' ranks come from the comparison's lane mask (no per-lane bit set, no scan)
-            uint32_t nl = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int f = (int)(int16_t)((fw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-                const unsigned long long has = __ballot(f != 0);
-                if (f != 0) {
-                    const uint32_t at = nl + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
-                    sList[at] = ((uint32_t)(8 * lane + j) << 23) | ((uint32_t)(f > 0 ? f : 0) << 8) | ((hw[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-                }
-                nl += (uint32_t)__popcll(has);
             }
             *reinterpret_cast<uint2*>(sG + 8 * lane) = make_uint2(out[0], out[1]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            // (b) the listed positions, all lanes busy: window [pos, pos + min(length, 3 meanFragment)); the default value is replaced, the histograms follow
+            // the positions that carry a fragment length or a hit, position j of every lane at a time: the lanes' ranks come from the comparison's lane mask (no per-lane
+            // bit set, no scan), an entry is {length and hits as they were loaded (one v_perm), offset in the round} — six instructions per position.  The observed histogram
+            // is fed from this list alone (step (b)): a position without a hit adds nothing to it, and four positions in five have neither — step (a) is left with one
+            // atomic per position.  A hit without a fragment length is an entry whose window is the default one.  Two half rounds (positions 0-3 and 4-7 of every lane),
+            // so that the list is 2 KB per wave.
             const int aR = (int)(rBase - t0);
-            for (int k = lane; k < (int)nl; k += 64) {
-                const uint32_t ent = sList[k];
-                const int o = (int)(ent >> 23), f = (int)((ent >> 8) & 0x7FFFu);
-                const uint32_t h = ent & 0xFFu;
-                const int a = aR + o;
-                const int cur = f < H ? f : H;
-                uint32_t g = 0;
-                if (cur > 0) g = rg3_div100(rg3_prefix(sPre, a + cur) - rg3_prefix(sPre, a), (uint32_t)cur);      // (a negative length: an empty window in the reference, gcContent 0)
-                const uint32_t gd = sG[o];
-                if (g != gd) {
-                    sG[o] = (uint8_t)g;
-                    atomicAdd(&sHist[gd * RG3_HR + lane32], 0xFFFFFFFFu);
-                    atomicAdd(&sHist[g * RG3_HR + lane32], 1u);
-                    if (h) { atomicAdd(&sHist[(101 + gd) * RG3_HR + lane32], 0u - h); atomicAdd(&sHist[(101 + g) * RG3_HR + lane32], h); }
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+                uint32_t nl = 0;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int j = 4 * hb + jj;
+                    const uint32_t lo = __builtin_amdgcn_perm(hw[j >> 2], fw[j >> 1], 0x0C000000u | ((4u + (j & 3)) << 16) | ((2u * (j & 1) + 1u) << 8) | (2u * (j & 1)));
+                    const unsigned long long has = __ballot(lo != 0u);
+                    if (lo != 0u) {
+                        const uint32_t at = nl + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
+                        sList[at] = make_uint2(lo, (uint32_t)(8 * lane + j));
+                    }
+                    nl += (uint32_t)__popcll(has);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                // (b) the listed positions, all lanes busy: window [pos, pos + min(length, 3 meanFragment)); the default value is replaced, the histograms follow
+                for (int k = lane; k < (int)nl; k += 64) {
+                    const uint2 ent = sList[k];
+                    const int o = (int)ent.y, f = (int)(int16_t)(ent.x & 0xFFFFu);
+                    const uint32_t h = ent.x >> 16;
+                    const int a = aR + o;
+                    const int cur = f > 0 ? (f < H ? f : H) : (f < 0 ? 0 : M);          // (a negative length: an empty window in the reference, gcContent 0)
+                    uint32_t g = 0;
+                    if (cur > 0) g = rg3_div100(rg3_prefix(sPre, a + cur) - rg3_prefix(sPre, a), (uint32_t)cur);
+                    const uint32_t gd = sG[o];
+                    if (g != gd) {
+                        sG[o] = (uint8_t)g;
+                        atomicAdd(&sHist[gd * HE + laneR], 0xFFFFFFFFu);
+                        atomicAdd(&sHist[g * HE + laneR], 1u);
+                    }
+                    if (h) atomicAdd(&sHistO[g * HO + laneO], h);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             // (c) the store
             if (in) {
                 const uint2 o2 = *reinterpret_cast<const uint2*>(sG + 8 * lane);
-                if (p + 8 <= len) *reinterpret_cast<uint2*>(readGc + p) = o2;
+                if (p + 8 <= len) gstore_uint2(readGc + p, o2);
                 else { const uint32_t o[2] = {o2.x, o2.y}; for (int j = 0; j < 8 && p + j < len; j++) readGc[p + j] = (uint8_t)((o[j >> 2] >> (8 * (j & 3))) & 0xFFu); }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -420,7 +460,8 @@ __global__ void __launch_bounds__(256) k_read_gc3(const RgChrom* __restrict__ ch
     __syncthreads();
     if (tid < 101) {
         unsigned int e = 0, o = 0;
-        for (int r = 0; r < RG3_HR; r++) { e += sHist[tid * RG3_HR + r]; o += sHist[(101 + tid) * RG3_HR + r]; }
+        for (int r = 0; r < HE; r++) e += sHist[tid * HE + r];
+        for (int r = 0; r < HO; r++) o += sHistO[tid * HO + r];
         if (e) atomicAdd(&rep[tid], (unsigned long long)e);
         if (o) atomicAdd(&rep[101 + tid], (unsigned long long)o);
     }

@@ -376,16 +376,16 @@ __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict_
     // workgroup of XCD x: a line's 16 writers share an L2 and run side by side.
     const int bx = (int)blockIdx.x, r = stride >= 8 ? (bx & 7) * (stride >> 3) + (bx >> 3) : bx, tid = (int)threadIdx.x;
     if (R.fy == 2 || (boot && (R.cont || R.total < MT_BOOT_MIN))) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
-    uint32_t* __restrict__ d = R.P.draws;
+    const gptr<uint32_t> d = as_global(R.P.draws);               // (typed global: a flat store in the loop would tie every LDS wait to the store's completion, common.hpp)
     const long long start = boot ? 19937LL * stride : (R.cont ? 0 : MT_HISTORY);        // first position to generate; the 19937 * stride positions in front of it are there
     const long long end = boot ? (R.total < 19937LL * 2 * stride ? R.total : 19937LL * 2 * stride) : R.total;
     const long long left = end - start - r;
     if (left <= 0) return;
     const long long cnt = (left + stride - 1) / stride;              // values of this sequence to generate
-    const uint32_t* __restrict__ hist = d + (start - 19937LL * stride + r);
+    const gptr<const uint32_t> hist = d + (start - 19937LL * stride + r);
     for (int t = tid; t < 19937; t += MTC_T) ring[t] = hist[(long long)t * stride];
     __syncthreads();
-    uint32_t* __restrict__ out = d + (start + r);
+    const gptr<uint32_t> out = d + (start + r);
     int head = 19937;                                                // slot of the next value; the buffer is linear, so every operand sits at a CONSTANT distance below the
                                                                      // value's own slot: 134 ds_read_b32 with immediate offsets, no address arithmetic, issued back to back
                                                                      // (with a ring and a wrap per operand the compiler waited for every single read: 4.5 us per iteration)
@@ -792,7 +792,7 @@ extern __shared__ __align__(16) unsigned char rp_lds[];
 #define RPL_TOTAL (RPL_MISC + 64)
 static_assert(RPL_TOTAL <= 81920, "two workgroups per CU");
 #define RP_LDS(T, off) (reinterpret_cast<T*>(rp_lds + (off)))
-__device__ __forceinline__ int rp_target(const uint32_t* __restrict__ draws, int n, int i) {      // ChangePoint.cs:411-419: the draw of step i is draws[n - 1 - i]
+__device__ __forceinline__ int rp_target(gptr<const uint32_t> draws, int n, int i) {      // ChangePoint.cs:411-419: the draw of step i is draws[n - 1 - i]
     const double cc = (double)draws[n - 1 - i] * (1.0 / 4294967296.0);
     int tt = (int)(cc * (double)(i + 1)); return tt > i ? i : tt;
 }
@@ -825,11 +825,13 @@ __device__ __forceinline__ double rp_wave_scan_f64(double v) {
     v += rp_dpp_f64<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
     return v;
 }
-struct RpPtr { const uint32_t* draws; const double* x; uint32_t* scr; uint32_t* endsIn; uint32_t* endsOwn; uint2* inbox; uint32_t* outIn; uint32_t* outOwn; int n, K, nT; };
-__device__ __forceinline__ RpPtr rp_ptr(const PermReq& R, int w, int b) {
-    RpPtr P; P.n = R.n; P.K = R.rp.K; P.nT = R.rp.nT; P.draws = R.P.draws + (size_t)b * R.n; P.x = R.x;
-    P.scr = R.rpScratch + (size_t)w * R.rp.stride; P.endsIn = P.scr + R.rp.oEndsIn; P.endsOwn = P.scr + R.rp.oEndsOwn; P.inbox = reinterpret_cast<uint2*>(P.scr + R.rp.oInbox);
-    P.outIn = P.scr + R.rp.oOutIn; P.outOwn = P.scr + R.rp.oOutOwn;
+// (typed global pointers: through generic ones every access is a flat instruction, and every LDS wait of these LDS-heavy phases would wait for the stores as well — common.hpp)
+struct RpPtr { gptr<const uint32_t> draws; gptr<const double> x; gptr<uint32_t> scr; gptr<uint32_t> endsIn; gptr<uint32_t> endsOwn; gptr<uint2> inbox; gptr<uint32_t> outIn; gptr<uint32_t> outOwn; int n, K, nT; };
+__device__ __forceinline__ RpPtr rp_ptr(const PermReq& Rq, int w, int b) {
+    const gptr<const PermReq> R = as_global(&Rq);
+    RpPtr P; P.n = R->n; P.K = R->rp.K; P.nT = R->rp.nT; P.draws = as_global((const uint32_t*)R->P.draws) + (size_t)b * R->n; P.x = as_global(R->x);
+    P.scr = as_global(R->rpScratch) + (size_t)w * R->rp.stride; P.endsIn = P.scr + R->rp.oEndsIn; P.endsOwn = P.scr + R->rp.oEndsOwn; P.inbox = reinterpret_cast<gptr<uint2>>(P.scr + R->rp.oInbox);
+    P.outIn = P.scr + R->rp.oOutIn; P.outOwn = P.scr + R->rp.oOutOwn;
     return P;
 }
 // one step, by itself (ordered replay / the last steps)
@@ -838,7 +840,7 @@ __device__ __forceinline__ void rp_exec1(const RpPtr& P, int lo, int i, int tt) 
     const int v = sA[i - lo];
     if (tt < lo) {
         const int d = tt >> RP_RSHIFT; const uint32_t sidx = atomicAdd(&sCnt[d], 1u);
-        if (sidx < RP_LDS(uint32_t, RPL_INCAP)[d]) P.inbox[RP_LDS(uint32_t, RPL_INOFF)[d] + sidx] = make_uint2((uint32_t)v | ((uint32_t)(i & 2047) << 20), (uint32_t)(tt & 16383) | ((uint32_t)(i >> 11) << 14));
+        if (sidx < RP_LDS(uint32_t, RPL_INCAP)[d]) gstore_uint2(P.inbox + (RP_LDS(uint32_t, RPL_INOFF)[d] + sidx), make_uint2((uint32_t)v | ((uint32_t)(i & 2047) << 20), (uint32_t)(tt & 16383) | ((uint32_t)(i >> 11) << 14)));
         else sMisc[1] = 1u;
     } else {
         int old = v; if (tt != i) { old = sA[tt - lo]; sA[tt - lo] = v; }
@@ -877,7 +879,7 @@ __device__ __noinline__ void rp_range_inbox(const PermReq& R, int w, int b, int 
     int32_t* sA = RP_LDS(int32_t, RPL_A); uint32_t* sTb = RP_LDS(uint32_t, RPL_TB); uint32_t* sDb = RP_LDS(uint32_t, RPL_DB);
     uint32_t* hKey = RP_LDS(uint32_t, RPL_HKEY); uint32_t* hStamp = RP_LDS(uint32_t, RPL_HSTAMP); uint32_t* sRow = RP_LDS(uint32_t, RPL_ROW); int* sOver = RP_LDS(int, RPL_MISC) + 1;
     const uint32_t inOff = RP_LDS(uint32_t, RPL_INOFF)[k];
-    const uint2* __restrict__ ib = P.inbox + inOff; uint32_t* __restrict__ ob = P.outIn + inOff;
+    const gptr<uint2> ib = P.inbox + inOff; const gptr<uint32_t> ob = P.outIn + inOff;
     const int tauLo = (k + 1) * RP_TPR;
     int tau = nT - 1; uint32_t c0 = 0u;
     // the chunk [c0, c1) = tiles tau .. t2 (uniform: every thread walks the row in LDS)
@@ -889,7 +891,7 @@ __device__ __noinline__ void rp_range_inbox(const PermReq& R, int w, int b, int 
     if (tau >= tauLo) {
         next_chunk(tau, c0, t2, c1);
 #pragma unroll
-        for (int q = 0; q < RP_SPT; q++) { const uint32_t j = c0 + (uint32_t)(q * RP_T + tid); valid[q] = j < c1; if (valid[q]) m[q] = ib[j]; }
+        for (int q = 0; q < RP_SPT; q++) { const uint32_t j = c0 + (uint32_t)(q * RP_T + tid); valid[q] = j < c1; if (valid[q]) m[q] = gload_uint2(ib + j); }
     }
     while (tau >= tauLo) {
         // the messages of this chunk are in registers; those of the next one are requested before this one is worked on
@@ -900,7 +902,7 @@ __device__ __noinline__ void rp_range_inbox(const PermReq& R, int w, int b, int 
         if (tauN >= tauLo) {
             next_chunk(tauN, cN0, t2N, cN1);
 #pragma unroll
-            for (int q = 0; q < RP_SPT; q++) { const uint32_t j = cN0 + (uint32_t)(q * RP_T + tid); validN[q] = j < cN1; if (validN[q]) mN[q] = ib[j]; }
+            for (int q = 0; q < RP_SPT; q++) { const uint32_t j = cN0 + (uint32_t)(q * RP_T + tid); validN[q] = j < cN1; if (validN[q]) mN[q] = gload_uint2(ib + j); }
         }
         if (c1 > cc0) {
 #pragma unroll
@@ -945,7 +947,7 @@ __device__ __noinline__ void rp_range_inbox(const PermReq& R, int w, int b, int 
     }
 }
 // ---- the own steps of range k, hi - 1 down to lo (range 0: down to RP_TAIL, then the last steps through one wave)
-__device__ __noinline__ void rp_range_own(const PermReq& R, int w, int b, int k, long long* clk) {
+__device__ __noinline__ void rp_range_own(const PermReq& R, int w, int b, int k, gptr<long long> clk) {
     const RpPtr P = rp_ptr(R, w, b);
     const int tid = threadIdx.x, lane = tid & 63, n = P.n, nT = P.nT;
     const int lo = k << RP_RSHIFT, hi = n < lo + RP_R ? n : lo + RP_R;
@@ -1015,7 +1017,7 @@ __device__ __noinline__ void rp_range_own(const PermReq& R, int w, int b, int k,
 #pragma unroll
             for (int q = 0; q < RP_SPT; q++) if (((msgm >> q) & 1u) && (t[q] >> RP_RSHIFT) == d) {
                 const int i = I1 - 1 - (tid * RP_SPT + q);
-                if (sm < cap) P.inbox[off + sm] = make_uint2((uint32_t)vv[q] | ((uint32_t)(i & 2047) << 20), (uint32_t)(t[q] & 16383) | ((uint32_t)tau << 14)); else *sOver = 1;
+                if (sm < cap) gstore_uint2(P.inbox + (off + sm), make_uint2((uint32_t)vv[q] | ((uint32_t)(i & 2047) << 20), (uint32_t)(t[q] & 16383) | ((uint32_t)tau << 14))); else *sOver = 1;
                 sm++;
             }
         }
@@ -1069,7 +1071,7 @@ __device__ __noinline__ void rp_range_own(const PermReq& R, int w, int b, int k,
 #define RP_J0 2
 #define RP_J1 25
 #define RP_NJ (RP_J1 - RP_J0 + 1)
-__device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long long* clk) {
+__device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, gptr<long long> clk) {
     const RpPtr P = rp_ptr(R, w, b);
     const int tid = threadIdx.x, n = P.n, K = P.K, nT = P.nT;
     long long tClk = clk ? clock64() : 0;
@@ -1080,7 +1082,8 @@ __device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long l
     double* shD = reinterpret_cast<double*>(shM + RP_NJ); double* sEdge = shD + (RP_T / 64 + 1);
     int* sSrcOff = reinterpret_cast<int*>(sEdge + 2 * PT_HALO); uint32_t* sSrcBase = reinterpret_cast<uint32_t*>(sSrcOff + 4 * (RP_MAXK + 2));      // four tables each (tile & 3)
     const uint32_t* sInOff = RP_LDS(uint32_t, RPL_INOFF);
-    const double tss = R.tss, errBound = R.errBound;
+    const gptr<const PermReq> Rg = as_global(&R);                      // (the request table lies in global memory: read it through a typed pointer, once)
+    const double tss = Rg->tss, errBound = Rg->errBound; const uint32_t oOutOwn = Rg->rp.oOutOwn, oOutIn = Rg->rp.oOutIn; const gptr<double> pstat = as_global(Rg->pstat);
     for (int t = tid; t <= nT; t += RP_T) sTab[t] = P.endsOwn[t];
     for (int d = 0; d < K - 1; d++) for (int t = tid; t <= nT; t += RP_T) sTab[(size_t)(d + 1) * (nT + 1) + t] = P.endsIn[(size_t)d * (nT + 1) + t];
     __syncthreads();
@@ -1090,7 +1093,7 @@ __device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long l
         const int S = (tau >> 3) + 1; int run = 0;
         for (int sI = 0; sI < S; sI++) {
             const uint32_t beg = sTab[(size_t)sI * (nT + 1) + tau + 1], end = sTab[(size_t)sI * (nT + 1) + tau];
-            so[sI] = run; sb[sI] = (sI == 0 ? R.rp.oOutOwn : R.rp.oOutIn + sInOff[sI - 1]) + beg; run += (int)(end - beg);
+            so[sI] = run; sb[sI] = (sI == 0 ? oOutOwn : oOutIn + sInOff[sI - 1]) + beg; run += (int)(end - beg);
         }
         so[S] = run;
     };
@@ -1219,8 +1222,8 @@ __device__ __noinline__ void rp_statistic(const PermReq& R, int w, int b, long l
             hLo = aa > hLo ? aa : hLo; hHi = bb > hHi ? bb : hHi;
         }
         auto norm = [&](double h) { double tq = tss; if (tq <= h + 0.0001) tq = h + 1.0; return h / ((tq - h) / (rn - 2.0)); };   // CBSTStatistic.cs:334-337
-        if (anyBad || (tss <= hLo + 0.0001) != (tss <= hHi + 0.0001)) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; }
-        else { R.pstat[2 * b] = norm(hLo) * (1.0 - 1e-15); R.pstat[2 * b + 1] = norm(hHi) * (1.0 + 1e-15); }
+        if (anyBad || (tss <= hLo + 0.0001) != (tss <= hHi + 0.0001)) { pstat[2 * b] = -INFINITY; pstat[2 * b + 1] = INFINITY; }
+        else { pstat[2 * b] = norm(hLo) * (1.0 - 1e-15); pstat[2 * b + 1] = norm(hHi) * (1.0 + 1e-15); }
     }
     __syncthreads();
 }
@@ -1235,7 +1238,7 @@ __global__ void __launch_bounds__(RP_T) __attribute__((amdgpu_waves_per_eu(RP_T 
     int32_t* sA = RP_LDS(int32_t, RPL_A); uint32_t* sTb = RP_LDS(uint32_t, RPL_TB); uint32_t* sDb = RP_LDS(uint32_t, RPL_DB);
     uint32_t* hKey = RP_LDS(uint32_t, RPL_HKEY); uint32_t* hStamp = RP_LDS(uint32_t, RPL_HSTAMP); uint32_t* sRow = RP_LDS(uint32_t, RPL_ROW);
     uint32_t* sCnt = RP_LDS(uint32_t, RPL_CNT); uint32_t* sMisc = RP_LDS(uint32_t, RPL_MISC);
-    long long* clk = (w == 0 && tid == 0) ? R.rpClk : nullptr; long long tClk = clk ? clock64() : 0;
+    const gptr<long long> clk = (w == 0 && tid == 0) ? as_global(R.rpClk) : as_global((long long*)nullptr); long long tClk = clk ? clock64() : 0;
     auto lapc = [&](int slot) { if (clk) { const long long t = clock64(); clk[slot] += t - tClk; tClk = t; } };
     for (int b = w; b < R.nb; b += R.rpWGs) {
         const RpPtr P = rp_ptr(R, w, b);
@@ -1257,7 +1260,7 @@ __global__ void __launch_bounds__(RP_T) __attribute__((amdgpu_waves_per_eu(RP_T 
             if (clk) tClk = clock64();
             __syncthreads();
         }
-        if (sMisc[1]) { __syncthreads(); if (tid == 0) { R.pstat[2 * b] = -INFINITY; R.pstat[2 * b + 1] = INFINITY; } continue; }
+        if (sMisc[1]) { __syncthreads(); if (tid == 0) { const gptr<double> pstat = as_global(R.pstat); pstat[2 * b] = -INFINITY; pstat[2 * b + 1] = INFINITY; } continue; }
         rp_statistic(R, w, b, clk);
         if (clk) tClk = clock64();
     }

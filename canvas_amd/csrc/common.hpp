@@ -244,15 +244,23 @@ struct WsSizer {
 
 // ---- device helpers ------------------------------------------------------------------------------------------
 #define WAVE 64
-// A pointer that a kernel reads out of a table in device memory (BinChrom, CfArgs, ...) is a generic pointer to the compiler: every access through it becomes a
-// flat_load / flat_store (address-space check per access, LDS and vector-memory counters both tied up).  Kernel ARGUMENTS are inferred to be global; table entries are
-// not, so the kernels convert them once: gptr<T> is T* in the global address space, and the loads come out as global_load.
+// A pointer that a kernel reads out of a table in device memory (BinChrom, CfArgs, PermReq ...) is a generic pointer to the compiler: every access through it becomes a
+// flat_load / flat_store.  A flat instruction counts on vmcnt AND lgkmcnt, and because LDS and memory answer out of order the only wait the compiler can put behind one is
+// s_waitcnt vmcnt(0) lgkmcnt(0): every LDS read of the kernel then also waits for every load still in flight (a prefetch for the next round is waited for at the first LDS
+// access of this one) and for every store.  Kernel ARGUMENTS are inferred to be global; table entries are not, so the kernels convert them once: gptr<T> is T* in the global
+// address space, and the accesses come out as global_load / global_store with their own counter.  (A cast to the global address space and back is folded away, and
+// __builtin_assume(!__builtin_amdgcn_is_shared(p)) is not picked up by this toolchain, so the TYPE has to be carried to the access.  tools/flat_census.sh lists the kernels
+// that still hold flat instructions.)
 template <class T> using gptr = __attribute__((address_space(1))) T*;
 template <class T> __device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)p; }
 // 16-byte loads through a gptr (uint4 / ulonglong2 are class types whose copy constructors take generic references: the load goes through a builtin vector type)
 typedef unsigned int canvas_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long canvas_u64x2 __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ uint4 gload_uint4(gptr<T> p) { const canvas_u32x4 v = *reinterpret_cast<gptr<const canvas_u32x4>>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+typedef unsigned int canvas_u32x2 __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ uint2 gload_uint2(gptr<T> p) { const canvas_u32x2 v = *reinterpret_cast<gptr<const canvas_u32x2>>(p); return make_uint2(v.x, v.y); }
+template <class T> __device__ __forceinline__ void gstore_uint2(gptr<T> p, uint2 v) { canvas_u32x2 w; w.x = v.x; w.y = v.y; *reinterpret_cast<gptr<canvas_u32x2>>(p) = w; }
+template <class T> __device__ __forceinline__ void gstore_uint4(gptr<T> p, uint4 v) { canvas_u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *reinterpret_cast<gptr<canvas_u32x4>>(p) = w; }
 template <class T> __device__ __forceinline__ ulonglong2 gload_ulonglong2(gptr<T> p) { const canvas_u64x2 v = *reinterpret_cast<gptr<const canvas_u64x2>>(p); return make_ulonglong2(v.x, v.y); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
