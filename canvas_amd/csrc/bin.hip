@@ -788,6 +788,123 @@ int32_t canvas_bin_rates(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_
     return CANVAS_OK;
 }
 
+// ---- mode 5 pre-pass (BinCounts, CanvasBin.cs:427-505): mean fragment size, read-GC profile of EVERY chromosome that has fragment lengths, observed / expected weights.  Shared by
+// the binning call (bin_genome_impl) and the predefined bins (canvas_bin_predefined_gcweighted).  The arena (1 B/base read-GC profile + tables) lives in the context and only grows.
+struct GcwPre {
+    canvas_ctx* ctx = nullptr; int nchr = 0;
+    std::vector<GcwChrom> hGch; float* dW = nullptr; GcwChrom* dGch = nullptr; unsigned long long* dGcStats = nullptr; float* dLut = nullptr;
+    bool overlap = false, pending = false;
+    ~GcwPre() { if (pending && ctx && ctx->side) (void)hipStreamSynchronize(ctx->side); }      // an early return leaves nothing running on the arena
+};
+// the second half of the pre-pass: histograms of the read-GC profile -> observed vs expected weights (CanvasBin.cs:372-391) -> device.  Staging in the side stream's pinned
+// buffer ({replicas of the histograms, the 101 weights, the GcwChrom table}: pinned copies are asynchronous whatever other streams are doing)
+static int32_t gcw_prepass_finish(canvas_ctx* ctx, GcwPre& P) {
+    CANVAS_HIP_TRY(ctx, hipEventSynchronize(ctx->side_ev2));
+    P.pending = false;
+    const unsigned long long* hr = (const unsigned long long*)ctx->side_pin;
+    unsigned long long hh[202];
+    for (int b = 0; b < 202; b++) { hh[b] = 0; for (int r = 0; r < RG_REP_ALL; r++) hh[b] += hr[(size_t)r * 202 + b]; }
+    if (ctx->gcw_reduce) { int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, hh, 202); if (rcr) return rcr; }      // the read-GC profile is the whole genome's (CanvasBin.cs:372-391)
+    long long sumObserved = 0, sumExpected = 0;
+    for (int b = 0; b < 101; b++) { sumExpected += (long long)hh[b]; sumObserved += (long long)hh[101 + b]; }
+    float* w = (float*)((char*)ctx->side_pin + (size_t)RG_REP_ALL * 202 * 8);
+    for (int b = 0; b < 101; b++) {
+        long long e = (long long)hh[b], o = (long long)hh[101 + b];
+        if (e == 0) e = 1;
+        if (o == 0) o = 1;
+        w[b] = ((float)o / (float)e) * ((float)sumExpected / (float)sumObserved);
+    }
+    GcwChrom* hg = (GcwChrom*)((char*)ctx->side_pin + (size_t)RG_REP_ALL * 202 * 8 + 512);
+    for (int c = 0; c < P.nchr; c++) hg[c] = P.hGch[c];
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(P.dW, w, 101 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(P.dGch, hg, P.nchr * sizeof(GcwChrom), hipMemcpyHostToDevice, ctx->stream));
+    return CANVAS_OK;
+}
+static int32_t gcw_prepass_begin(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len, bool mayOverlap, GcwPre& P) {
+    P.ctx = ctx; P.nchr = nchr;
+    int64_t totLen = 0;
+    for (int c = 0; c < nchr; c++) totLen += (h_len[c] + 255) & ~255ll;
+    size_t bytes = (size_t)totLen + 4096 + (size_t)nchr * (16 * NZ_REP + sizeof(GcwChrom) + sizeof(RgChrom)) + (size_t)RG_REP_ALL * 202 * 8 + 101 * 4 + (GCW_HMAX + 1) * 101 * 4 + 8192;
+    if (bytes > ctx->gc_arena_bytes) {
+        if (ctx->gc_arena) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->gc_arena)); ctx->gc_arena = nullptr; ctx->gc_arena_bytes = 0; }
+        CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->gc_arena, bytes)); ctx->gc_arena_bytes = bytes;
+    }
+    uint8_t* gcArena = (uint8_t*)ctx->gc_arena;
+    uint8_t* p = gcArena;
+    P.hGch.assign(nchr, GcwChrom{nullptr}); std::vector<GcwChrom>& gch = P.hGch;
+    for (int c = 0; c < nchr; c++) { gch[c].readGc = p; p += (h_len[c] + 255) & ~255ll; }
+    p = (uint8_t*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    unsigned long long* sumCnt = (unsigned long long*)p; p += ((size_t)nchr * NZ_REP * 16 + 255) & ~size_t(255);   // NZ_REP replicas of {sum, count} per chromosome
+    unsigned long long* hist = (unsigned long long*)p; p += ((size_t)RG_REP_ALL * 202 * 8 + 255) & ~size_t(255);    // replicas of {expected[101], observed[101]}
+    P.dGcStats = (unsigned long long*)p; p += 256;       // GCW_REP counters of replayed bins
+    P.dW = (float*)p; p += 512;
+    P.dLut = (float*)p; p += (((GCW_HMAX + 1) * 101 * 4 + 255) & ~255);
+    P.dGch = (GcwChrom*)p; p += ((size_t)nchr * sizeof(GcwChrom) + 255) & ~size_t(255);
+    RgChrom* dRg = (RgChrom*)p;
+    // Single GPU: the pre-pass runs on the side stream and the binning sweep below (k_tile_summary ... the bin boundaries: HBM-bound, no LDS, independent of the weights) runs
+    // beside k_read_gc3, which is bound by its VALU / LDS work and leaves half of the memory bandwidth idle; the two meet in gcw_finish() in front of the weighted counts.
+    // Sharded (ctx->gcw_reduce: the reductions have their place in the ranks' exchange order) and CANVAS_GCW_NO_OVERLAP=1: everything on ctx->stream, one after the other.
+    int32_t rc0 = canvas_side_init(ctx); if (rc0) return rc0;
+    const size_t sidePinBytes = (65536 + 65544) * sizeof(double);
+    const size_t offW = (size_t)RG_REP_ALL * 202 * 8, offG = offW + 512;
+    if (offG + (size_t)nchr * sizeof(GcwChrom) > sidePinBytes) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: too many chromosomes for the pinned staging buffer");
+    P.overlap = mayOverlap && !ctx->gcw_reduce && !cvx_hook("CANVAS_GCW_NO_OVERLAP");
+    hipStream_t sp = ctx->stream;
+    if (P.overlap) {
+        CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev, ctx->stream)); CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));      // the inputs are ready with respect to ctx->stream
+        sp = ctx->side;
+    }
+    CANVAS_HIP_TRY(ctx, hipMemsetAsync(sumCnt, 0, (size_t)((char*)P.dW - (char*)sumCnt), sp));       // fragment sums, histogram replicas, decision counters: one fill
+    // the chromosome table of the two genome-wide launches: tiles of RG_T positions, numbered through the chromosomes
+    rc0 = canvas_pin_reserve(ctx, (size_t)nchr * (sizeof(RgChrom) + NZ_REP * 16) + 128); if (rc0) return rc0;
+    int64_t ntileAll = 0;
+    {
+        RgChrom* hRg = (RgChrom*)ctx->pin;
+        for (int c = 0; c < nchr; c++) { hRg[c] = RgChrom{d_bases[c], d_fraglen[c], d_hits[c], (uint8_t*)gch[c].readGc, h_len[c], ntileAll}; ntileAll += (h_len[c] + RG_T - 1) / RG_T; }
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRg, hRg, (size_t)nchr * sizeof(RgChrom), hipMemcpyHostToDevice, sp));
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+    hipLaunchKernelGGL(k_nonzero_mean_all, dim3((unsigned)std::min<int64_t>((int64_t)cus * 8, ntileAll)), dim3(256), 0, sp, dRg, nchr, ntileAll, sumCnt);
+    unsigned long long* hs = (unsigned long long*)((char*)ctx->pin + (((size_t)nchr * sizeof(RgChrom) + 63) & ~size_t(63)));      // (behind the table: its upload may still be reading it)
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, sumCnt, (size_t)nchr * NZ_REP * 16, hipMemcpyDeviceToHost, sp));
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(sp));
+    // MeanFragmentSize (CanvasBin.cs:164-174): NonZeroMean of the per-chromosome NonZeroMeans, all in Int16 with integer division
+    long long s2 = 0, c2 = 0;
+    for (int c = 0; c < nchr; c++) {
+        unsigned long long sc = 0, cc = 0;
+        for (int r = 0; r < NZ_REP; r++) { sc += hs[((size_t)c * NZ_REP + r) * 2]; cc += hs[((size_t)c * NZ_REP + r) * 2 + 1]; }
+        int16_t m = cc ? (int16_t)(sc / cc) : 0; if (m > 0) { s2 += m; c2++; }
+    }
+    if (ctx->gcw_reduce) { unsigned long long v[2] = {(unsigned long long)s2, (unsigned long long)c2}; int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, v, 2); if (rcr) return rcr; s2 = (long long)v[0]; c2 = (long long)v[1]; }      // chromosomes of the other ranks (canvas_bin_sample_sharded)
+    const int meanFrag = c2 ? (int)(int16_t)(s2 / c2) : 0;
+    if (meanFrag <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "CNV input error - unable to determine fragment size (CanvasBin.cs:431-434)");
+    {
+        const int nWmax = (RG_T + 3 * meanFrag) / 64 + 2;
+        // k_read_gc3 follows the default window from position to position, which needs |100 d| < meanFragment; shorter fragments (and CANVAS_GCW_READ_GC2=1, the A/B and test
+        // hook) take k_read_gc2, one launch per chromosome
+        const bool rg3 = meanFrag > 100 && !cvx_hook("CANVAS_GCW_READ_GC2");
+        const size_t ldsRg = (size_t)nWmax * (rg3 ? 16 : 12);
+        int perCu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, rg3 ? (const void*)k_read_gc3<RG3_HE, RG3_HO> : (const void*)k_read_gc2, 256, ldsRg) != hipSuccess || perCu <= 0) perCu = 2;
+        const unsigned gridRg = (unsigned)(perCu * cus);
+        // x / meanFrag as (x * ceil(2^40 / meanFrag)) >> 40: exact while x < 2^22 and meanFrag < 2^15 (x = 100 * count <= 100 * 32767)
+        const unsigned long long mean40 = ((1ull << 40) + (unsigned long long)meanFrag - 1ull) / (unsigned long long)meanFrag;
+        ProfScope ps(ctx, "gcw_read_gc", false, sp);
+        if (rg3) hipLaunchKernelGGL((k_read_gc3<RG3_HE, RG3_HO>), dim3((unsigned)std::min<int64_t>(gridRg, ntileAll)), dim3(256), ldsRg, sp, dRg, nchr, ntileAll, meanFrag, mean40, nWmax, hist);
+        else for (int c = 0; c < nchr; c++) {
+            const int64_t ntile = (h_len[c] + RG_T - 1) / RG_T;
+            hipLaunchKernelGGL(k_read_gc2, dim3((unsigned)std::min<int64_t>(gridRg, ntile)), dim3(256), ldsRg, sp, d_bases[c], d_fraglen[c], d_hits[c], h_len[c], meanFrag, mean40, nWmax,
+                               (uint8_t*)gch[c].readGc, hist);
+        }
+    }
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->side_pin, hist, (size_t)RG_REP_ALL * 202 * 8, hipMemcpyDeviceToHost, sp));
+    CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev2, sp));
+    P.pending = true;
+    if (!P.overlap) { rc0 = gcw_prepass_finish(ctx, P); if (rc0) return rc0; }
+    return CANVAS_OK;
+}
+
 static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask,
                                const uint8_t* const* d_hits, const int16_t* const* d_fraglen, const int64_t* h_len, const uint8_t* h_is_auto, int32_t counts_per_bin, int32_t bin_size, int32_t mode,
                                int32_t* d_chr, int32_t* d_start, int32_t* d_stop, int32_t* d_gc, float* d_count, int64_t cap,
@@ -804,124 +921,16 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
     for (int c = 0; c < nchr; c++) if (h_len[c] <= 0 || h_len[c] > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "chromosome length must be in [1, 2^31)");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BinPlan plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len);
-    // ---- mode 5 pre-pass: mean fragment size, read-GC profile, observed/expected weights (kept in a separate allocation)
-    std::vector<GcwChrom> hGch; uint8_t* gcArena = nullptr; float* dW = nullptr; GcwChrom* dGch = nullptr; unsigned long long* dGcStats = nullptr; float* dLut = nullptr; int32_t rc0 = 0;       // the arena (1 B/base read-GC profile + a prefix array) lives in the context and only grows
+    GcwPre gp;
     if (gcw) { ctx->gcw_stats_dev = nullptr; ctx->gcw_total = 0; }       // (set again behind the weighted kernels: a call that fails or returns early in between leaves no pointer into an arena that may have been freed and regrown)
     if (gcw && ctx->up_active) {
         // the pre-pass below reads the per-base arrays on ctx->stream: a pending canvas_upload_genome_begin of them (copy stream) has to have landed first — mode 5 has no
         // per-chromosome overlap (the fence further down, which the other modes rely on, comes after these kernels)
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy)); ctx->up_active = false;
     }
-    // the second half of the pre-pass: histograms of the read-GC profile -> observed vs expected weights (CanvasBin.cs:372-391) -> device.  Staging in the side stream's pinned
-    // buffer ({replicas of the histograms, the 101 weights, the GcwChrom table}: pinned copies are asynchronous whatever other streams are doing)
-    bool gcwOverlap = false, gcwPending = false;
-    struct SideJoin { canvas_ctx* c; bool* pending; ~SideJoin() { if (*pending && c->side) (void)hipStreamSynchronize(c->side); } } sideJoin{ctx, &gcwPending};      // an early return leaves nothing running on the arena
-    auto gcw_finish = [&]() -> int32_t {
-        CANVAS_HIP_TRY(ctx, hipEventSynchronize(ctx->side_ev2));
-        gcwPending = false;
-        const unsigned long long* hr = (const unsigned long long*)ctx->side_pin;
-        unsigned long long hh[202];
-        for (int b = 0; b < 202; b++) { hh[b] = 0; for (int r = 0; r < RG_REP_ALL; r++) hh[b] += hr[(size_t)r * 202 + b]; }
-        if (ctx->gcw_reduce) { int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, hh, 202); if (rcr) return rcr; }      // the read-GC profile is the whole genome's (CanvasBin.cs:372-391)
-        long long sumObserved = 0, sumExpected = 0;
-        for (int b = 0; b < 101; b++) { sumExpected += (long long)hh[b]; sumObserved += (long long)hh[101 + b]; }
-        float* w = (float*)((char*)ctx->side_pin + (size_t)RG_REP_ALL * 202 * 8);
-        for (int b = 0; b < 101; b++) {
-            long long e = (long long)hh[b], o = (long long)hh[101 + b];
-            if (e == 0) e = 1;
-            if (o == 0) o = 1;
-            w[b] = ((float)o / (float)e) * ((float)sumExpected / (float)sumObserved);
-        }
-        GcwChrom* hg = (GcwChrom*)((char*)ctx->side_pin + (size_t)RG_REP_ALL * 202 * 8 + 512);
-        for (int c = 0; c < nchr; c++) hg[c] = hGch[c];
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dW, w, 101 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dGch, hg, nchr * sizeof(GcwChrom), hipMemcpyHostToDevice, ctx->stream));
-        return CANVAS_OK;
-    };
     if (gcw) {
-        int64_t maxLen = 0, totLen = 0;
-        for (int c = 0; c < nchr; c++) { maxLen = std::max(maxLen, h_len[c]); totLen += (h_len[c] + 255) & ~255ll; }
-        const int64_t maxTiles = (maxLen + TILE - 1) / TILE;
-        (void)maxTiles; (void)maxLen;
         for (int c = 0; c < nchr; c++) if (((uintptr_t)d_fraglen[c] | (uintptr_t)d_bases[c] | (uintptr_t)d_hits[c]) & 15) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: bases, hits and fragment lengths must be 16-byte aligned");
-        size_t bytes = (size_t)totLen + 4096 + (size_t)nchr * (16 * NZ_REP + sizeof(GcwChrom) + sizeof(RgChrom)) + (size_t)RG_REP_ALL * 202 * 8 + 101 * 4 + (GCW_HMAX + 1) * 101 * 4 + 8192;
-        if (bytes > ctx->gc_arena_bytes) {
-            if (ctx->gc_arena) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipFree(ctx->gc_arena)); ctx->gc_arena = nullptr; ctx->gc_arena_bytes = 0; }
-            CANVAS_HIP_TRY(ctx, hipMalloc(&ctx->gc_arena, bytes)); ctx->gc_arena_bytes = bytes;
-        }
-        gcArena = (uint8_t*)ctx->gc_arena;
-        uint8_t* p = gcArena;
-        hGch.assign(nchr, GcwChrom{nullptr}); std::vector<GcwChrom>& gch = hGch;
-        for (int c = 0; c < nchr; c++) { gch[c].readGc = p; p += (h_len[c] + 255) & ~255ll; }
-        p = (uint8_t*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-        unsigned long long* sumCnt = (unsigned long long*)p; p += ((size_t)nchr * NZ_REP * 16 + 255) & ~size_t(255);   // NZ_REP replicas of {sum, count} per chromosome
-        unsigned long long* hist = (unsigned long long*)p; p += ((size_t)RG_REP_ALL * 202 * 8 + 255) & ~size_t(255);    // replicas of {expected[101], observed[101]}
-        dGcStats = (unsigned long long*)p; p += 256;       // GCW_REP counters of replayed bins
-        dW = (float*)p; p += 512;
-        dLut = (float*)p; p += (((GCW_HMAX + 1) * 101 * 4 + 255) & ~255);
-        dGch = (GcwChrom*)p; p += ((size_t)nchr * sizeof(GcwChrom) + 255) & ~size_t(255);
-        RgChrom* dRg = (RgChrom*)p;
-        // Single GPU: the pre-pass runs on the side stream and the binning sweep below (k_tile_summary ... the bin boundaries: HBM-bound, no LDS, independent of the weights) runs
-        // beside k_read_gc3, which is bound by its VALU / LDS work and leaves half of the memory bandwidth idle; the two meet in gcw_finish() in front of the weighted counts.
-        // Sharded (ctx->gcw_reduce: the reductions have their place in the ranks' exchange order) and CANVAS_GCW_NO_OVERLAP=1: everything on ctx->stream, one after the other.
-        rc0 = canvas_side_init(ctx); if (rc0) return rc0;
-        const size_t sidePinBytes = (65536 + 65544) * sizeof(double);
-        const size_t offW = (size_t)RG_REP_ALL * 202 * 8, offG = offW + 512;
-        if (offG + (size_t)nchr * sizeof(GcwChrom) > sidePinBytes) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: too many chromosomes for the pinned staging buffer");
-        gcwOverlap = !ctx->gcw_reduce && !cvx_hook("CANVAS_GCW_NO_OVERLAP");
-        hipStream_t sp = ctx->stream;
-        if (gcwOverlap) {
-            CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev, ctx->stream)); CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));      // the inputs are ready with respect to ctx->stream
-            sp = ctx->side;
-        }
-        CANVAS_HIP_TRY(ctx, hipMemsetAsync(sumCnt, 0, (size_t)((char*)dW - (char*)sumCnt), sp));       // fragment sums, histogram replicas, decision counters: one fill
-        // the chromosome table of the two genome-wide launches: tiles of RG_T positions, numbered through the chromosomes
-        rc0 = canvas_pin_reserve(ctx, (size_t)nchr * (sizeof(RgChrom) + NZ_REP * 16) + 128); if (rc0) return rc0;
-        int64_t ntileAll = 0;
-        {
-            RgChrom* hRg = (RgChrom*)ctx->pin;
-            for (int c = 0; c < nchr; c++) { hRg[c] = RgChrom{d_bases[c], d_fraglen[c], d_hits[c], (uint8_t*)gch[c].readGc, h_len[c], ntileAll}; ntileAll += (h_len[c] + RG_T - 1) / RG_T; }
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRg, hRg, (size_t)nchr * sizeof(RgChrom), hipMemcpyHostToDevice, sp));
-        }
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
-        hipLaunchKernelGGL(k_nonzero_mean_all, dim3((unsigned)std::min<int64_t>((int64_t)cus * 8, ntileAll)), dim3(256), 0, sp, dRg, nchr, ntileAll, sumCnt);
-        unsigned long long* hs = (unsigned long long*)((char*)ctx->pin + (((size_t)nchr * sizeof(RgChrom) + 63) & ~size_t(63)));      // (behind the table: its upload may still be reading it)
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, sumCnt, (size_t)nchr * NZ_REP * 16, hipMemcpyDeviceToHost, sp));
-        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(sp));
-        // MeanFragmentSize (CanvasBin.cs:164-174): NonZeroMean of the per-chromosome NonZeroMeans, all in Int16 with integer division
-        long long s2 = 0, c2 = 0;
-        for (int c = 0; c < nchr; c++) {
-            unsigned long long sc = 0, cc = 0;
-            for (int r = 0; r < NZ_REP; r++) { sc += hs[((size_t)c * NZ_REP + r) * 2]; cc += hs[((size_t)c * NZ_REP + r) * 2 + 1]; }
-            int16_t m = cc ? (int16_t)(sc / cc) : 0; if (m > 0) { s2 += m; c2++; }
-        }
-        if (ctx->gcw_reduce) { unsigned long long v[2] = {(unsigned long long)s2, (unsigned long long)c2}; int32_t rcr = ctx->gcw_reduce(ctx->gcw_reduce_user, v, 2); if (rcr) return rcr; s2 = (long long)v[0]; c2 = (long long)v[1]; }      // chromosomes of the other ranks (canvas_bin_sample_sharded)
-        const int meanFrag = c2 ? (int)(int16_t)(s2 / c2) : 0;
-        if (meanFrag <= 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "CNV input error - unable to determine fragment size (CanvasBin.cs:431-434)");
-        {
-            const int nWmax = (RG_T + 3 * meanFrag) / 64 + 2;
-            // k_read_gc3 follows the default window from position to position, which needs |100 d| < meanFragment; shorter fragments (and CANVAS_GCW_READ_GC2=1, the A/B and test
-            // hook) take k_read_gc2, one launch per chromosome
-            const bool rg3 = meanFrag > 100 && !cvx_hook("CANVAS_GCW_READ_GC2");
-            const size_t ldsRg = (size_t)nWmax * (rg3 ? 16 : 12);
-            int perCu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, rg3 ? (const void*)k_read_gc3<RG3_HE, RG3_HO> : (const void*)k_read_gc2, 256, ldsRg) != hipSuccess || perCu <= 0) perCu = 2;
-            const unsigned gridRg = (unsigned)(perCu * cus);
-            // x / meanFrag as (x * ceil(2^40 / meanFrag)) >> 40: exact while x < 2^22 and meanFrag < 2^15 (x = 100 * count <= 100 * 32767)
-            const unsigned long long mean40 = ((1ull << 40) + (unsigned long long)meanFrag - 1ull) / (unsigned long long)meanFrag;
-            ProfScope ps(ctx, "gcw_read_gc", false, sp);
-            if (rg3) hipLaunchKernelGGL((k_read_gc3<RG3_HE, RG3_HO>), dim3((unsigned)std::min<int64_t>(gridRg, ntileAll)), dim3(256), ldsRg, sp, dRg, nchr, ntileAll, meanFrag, mean40, nWmax, hist);
-            else for (int c = 0; c < nchr; c++) {
-                const int64_t ntile = (h_len[c] + RG_T - 1) / RG_T;
-                hipLaunchKernelGGL(k_read_gc2, dim3((unsigned)std::min<int64_t>(gridRg, ntile)), dim3(256), ldsRg, sp, d_bases[c], d_fraglen[c], d_hits[c], h_len[c], meanFrag, mean40, nWmax,
-                                   (uint8_t*)gch[c].readGc, hist);
-            }
-        }
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(ctx->side_pin, hist, (size_t)RG_REP_ALL * 202 * 8, hipMemcpyDeviceToHost, sp));
-        CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->side_ev2, sp));
-        gcwPending = true;
-        if (!gcwOverlap) { rc0 = gcw_finish(); if (rc0) return rc0; }
+        int32_t rc0 = gcw_prepass_begin(ctx, nchr, d_bases, d_hits, d_fraglen, h_len, true, gp); if (rc0) return rc0;
     }
     // the bin arrays are sized by the caller's capacity (the bin size may not be known yet)
     const int64_t ub = cap;
@@ -1135,14 +1144,14 @@ static int32_t bin_genome_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* con
                        tileTotC, tileTotG, d_chr, d_start, d_stop, d_gc, d_count, 0);
     }
     if (gcw) {
-        if (gcwPending) { int32_t rcf = gcw_finish(); if (rcf) return rcf; }       // (single GPU) k_read_gc3 ran beside the kernels above
+        if (gp.pending) { int32_t rcf = gcw_prepass_finish(ctx, gp); if (rcf) return rcf; }       // (single GPU) k_read_gc3 ran beside the kernels above
         ProfScope ps(ctx, "gcw_weighted");
         // one kernel that computes every position's term once, inside the bin that owns it
         const int serialOnly = cvx_hook("CANVAS_GCW_SERIAL") ? 1 : 0;      // (test hook: every bin through the reference's own order of additions)
         static const unsigned gridF = resident_grid((const void*)k_bin_weighted3, 256, ctx->device);
-        hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, dW, dLut);
-        hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridF, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, dGch, (long long)total, d_chr, d_start, d_stop, dW, dLut, d_count, dGcStats, serialOnly, nchr);
-        ctx->gcw_stats_dev = dGcStats; ctx->gcw_total = (long long)total;       // how many bins the interval decided / how many replayed the reference's additions: canvas_bin_gcw_stats
+        hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, gp.dW, gp.dLut);
+        hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridF, (total + 15) / 16)), dim3(256), 0, ctx->stream, dCh, gp.dGch, (long long)total, d_chr, d_start, d_stop, gp.dW, gp.dLut, d_count, gp.dGcStats, serialOnly, nchr);
+        ctx->gcw_stats_dev = gp.dGcStats; ctx->gcw_total = (long long)total;       // how many bins the interval decided / how many replayed the reference's additions: canvas_bin_gcw_stats
     }
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     return CANVAS_OK;
@@ -1451,7 +1460,7 @@ int32_t cvx_bin_sample_hooked(canvas_ctx* ctx, int32_t nchr, const uint8_t* cons
 // except the chromosome's FIRST bin, whose leading 'n' bases are skipped before anything is counted (:582-584).  One wave per bin, 64 positions per step.
 struct PreChrom { const uint8_t* bases; const uint8_t* hits; const uint64_t* mask; long long len; long long binBegin, binEnd; };
 __global__ void __launch_bounds__(256) k_bin_predefined(const PreChrom* __restrict__ ch, int nchr, long long nbins, const int32_t* __restrict__ bStart, const int32_t* __restrict__ bStop, int clampHits,
-                                                        int32_t* __restrict__ oGc, float* __restrict__ oCount, int* __restrict__ err) {
+                                                        int32_t* __restrict__ oGc, float* __restrict__ oCount, int* __restrict__ err, int32_t* __restrict__ oChrIdx, int32_t* __restrict__ oStartUsed) {
     const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= nbins) return;
     int lo = 0, hi = nchr - 1;
@@ -1484,38 +1493,78 @@ __global__ void __launch_bounds__(256) k_bin_predefined(const PreChrom* __restri
         const int nucleotideCount = (int)(e - s);            // every position counts: "!Bases[pos].Equals("n")" compares a char with a string and is always true (:594)
         oGc[b] = (int32_t)(100.0f * (float)(int)gcn / (float)nucleotideCount);
         oCount[b] = (float)(int)obs;
+        if (oChrIdx) { oChrIdx[b] = lo; oStartUsed[b] = (int32_t)s; }      // GCContentWeighted: the range the weighted count runs over (k_bin_weighted3)
     }
 }
 
-extern "C" int32_t canvas_bin_predefined(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
-                                         int32_t mode, const int64_t* h_bin_offset, const int32_t* h_bin_start, const int32_t* h_bin_stop, const int32_t* d_bin_start, const int32_t* d_bin_stop,
-                                         int32_t* d_gc, float* d_count) {
+static int32_t bin_predefined_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int16_t* const* d_fraglen,
+                                   const int64_t* h_len, int32_t mode, const int64_t* h_bin_offset, const int32_t* h_bin_start, const int32_t* h_bin_stop, const int32_t* d_bin_start,
+                                   const int32_t* d_bin_stop, int32_t* d_gc, float* d_count) {
     if (!ctx) return CANVAS_ERR_INVALID;
     if (nchr <= 0 || !d_bases || !d_mask || !d_hits || !h_len || !h_bin_offset || !h_bin_start || !h_bin_stop || !d_bin_start || !d_bin_stop || !d_gc || !d_count)
         CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_predefined: bad arguments");
-    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_bin_predefined: coverage modes 0 and 3");
+    const bool gcw = mode == CANVAS_MODE_GC_CONTENT_WEIGHTED;
+    if (gcw && !d_fraglen) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode needs the fragment-length arrays (canvas_bin_predefined_gcweighted)");
+    if (mode != CANVAS_MODE_BINARY && mode != CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE && !gcw) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_bin_predefined: coverage modes 0, 3 and 5");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int32_t rcf = canvas_upload_fence(ctx); if (rcf) return rcf; }
     const long long nbins = h_bin_offset[nchr];
     std::vector<PreChrom> pc(nchr);
     for (int c = 0; c < nchr; c++) {
+        if (h_len[c] <= 0 || h_len[c] > 0x7FFFFFFFll) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "chromosome length must be in [1, 2^31)");
         pc[c] = PreChrom{d_bases[c], d_hits[c], d_mask[c], (long long)h_len[c], (long long)h_bin_offset[c], (long long)h_bin_offset[c + 1]};
         for (long long b = h_bin_offset[c]; b < h_bin_offset[c + 1]; b++) {
             if (h_bin_start[b] < 0 || h_bin_start[b] >= h_bin_stop[b]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "predefined bin with Start < 0 or Start >= Stop (Utilities.LoadBedFile throws)");
             if (h_bin_stop[b] > h_len[c]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "predefined bin beyond the end of its chromosome (the reference's cursor never closes it)");
         }
     }
+    // GCContentWeighted: the mean fragment size, the read-GC profile and the weights come from EVERY chromosome handed in (BinCounts computes them before it looks at the
+    // predefined bins, CanvasBin.cs:427-505), also when there is no bin to fill — a sample without usable fragment lengths fails as the reference does (:431-434)
+    GcwPre gp;
+    if (gcw) {
+        ctx->gcw_stats_dev = nullptr; ctx->gcw_total = 0;
+        for (int c = 0; c < nchr; c++) if (((uintptr_t)d_fraglen[c] | (uintptr_t)d_bases[c] | (uintptr_t)d_hits[c]) & 15) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: bases, hits and fragment lengths must be 16-byte aligned");
+        int32_t rcp = gcw_prepass_begin(ctx, nchr, d_bases, d_hits, d_fraglen, h_len, false, gp); if (rcp) return rcp;
+    }
     if (nbins == 0) return CANVAS_OK;
-    int32_t rc = canvas_ws_reserve(ctx, (size_t)nchr * sizeof(PreChrom) + 512); if (rc) return rc;
-    PreChrom* dCh = (PreChrom*)ctx->ws; int* dErr = (int*)((char*)ctx->ws + (((size_t)nchr * sizeof(PreChrom) + 255) & ~size_t(255)));
+    WsSizer sz;
+    sz.take<PreChrom>(nchr); sz.take<int>(64); sz.take<BinChrom>(nchr); sz.take<int32_t>(nbins); sz.take<int32_t>(nbins);
+    int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
+    WsCarver cv(ctx->ws);
+    PreChrom* dCh = cv.take<PreChrom>(nchr); int* dErr = cv.take<int>(64); BinChrom* dBc = cv.take<BinChrom>(nchr); int32_t* dChrIdx = cv.take<int32_t>(nbins); int32_t* dStartUsed = cv.take<int32_t>(nbins);
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dCh, pc.data(), (size_t)nchr * sizeof(PreChrom), hipMemcpyHostToDevice, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dErr, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_bin_predefined, dim3((unsigned)((nbins + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, nbins, d_bin_start, d_bin_stop, mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, d_gc, d_count, dErr);
+    BinPlan plan;
+    if (gcw) { plan = make_plan(nchr, d_bases, d_mask, d_hits, h_len); CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dBc, plan.chroms.data(), (size_t)nchr * sizeof(BinChrom), hipMemcpyHostToDevice, ctx->stream)); }
+    hipLaunchKernelGGL(k_bin_predefined, dim3((unsigned)((nbins + 3) / 4)), dim3(256), 0, ctx->stream, dCh, nchr, nbins, d_bin_start, d_bin_stop, mode == CANVAS_MODE_TRUNCATED_DYNAMIC_RANGE ? 1 : 0, d_gc, d_count, dErr,
+                       gcw ? dChrIdx : nullptr, gcw ? dStartUsed : nullptr);
     int err = 0;
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&err, dErr, 4, hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     CANVAS_HIP_TRY(ctx, hipGetLastError());
     if (err) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "the first predefined bin of a chromosome lies entirely in leading 'n' bases (the reference then fills no bin of that chromosome)");
+    if (gcw) {
+        // the weighted count of a bin (CanvasBin.cs:626-636) over [start after the 'n' skip, Stop): the kernel of the binning call, on the predefined ranges
+        const int serialOnly = cvx_hook("CANVAS_GCW_SERIAL") ? 1 : 0;
+        static const unsigned gridF = resident_grid((const void*)k_bin_weighted3, 256, ctx->device);
+        hipLaunchKernelGGL(k_gcw_terms, dim3(1), dim3(256), 0, ctx->stream, gp.dW, gp.dLut);
+        hipLaunchKernelGGL(k_bin_weighted3, dim3((unsigned)std::min<int64_t>(gridF, (nbins + 15) / 16)), dim3(256), 0, ctx->stream, dBc, gp.dGch, nbins, dChrIdx, dStartUsed, d_bin_stop, gp.dW, gp.dLut, d_count,
+                           gp.dGcStats, serialOnly, nchr);
+        ctx->gcw_stats_dev = gp.dGcStats; ctx->gcw_total = nbins;
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // (dChrIdx / dStartUsed live in the workspace)
+        CANVAS_HIP_TRY(ctx, hipGetLastError());
+    }
     return CANVAS_OK;
+}
+extern "C" int32_t canvas_bin_predefined(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
+                                         int32_t mode, const int64_t* h_bin_offset, const int32_t* h_bin_start, const int32_t* h_bin_stop, const int32_t* d_bin_start, const int32_t* d_bin_stop,
+                                         int32_t* d_gc, float* d_count) {
+    if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { if (!ctx) return CANVAS_ERR_INVALID; CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_bin_predefined: GCContentWeighted needs the fragment lengths (canvas_bin_predefined_gcweighted)"); }
+    return bin_predefined_impl(ctx, nchr, d_bases, d_mask, d_hits, nullptr, h_len, mode, h_bin_offset, h_bin_start, h_bin_stop, d_bin_start, d_bin_stop, d_gc, d_count);
+}
+extern "C" int32_t canvas_bin_predefined_gcweighted(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits,
+                                                    const int16_t* const* d_fraglen, const int64_t* h_len, const int64_t* h_bin_offset, const int32_t* h_bin_start, const int32_t* h_bin_stop,
+                                                    const int32_t* d_bin_start, const int32_t* d_bin_stop, int32_t* d_gc, float* d_count) {
+    return bin_predefined_impl(ctx, nchr, d_bases, d_mask, d_hits, d_fraglen, h_len, CANVAS_MODE_GC_CONTENT_WEIGHTED, h_bin_offset, h_bin_start, h_bin_stop, d_bin_start, d_bin_stop, d_gc, d_count);
 }
 

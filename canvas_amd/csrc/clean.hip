@@ -665,6 +665,7 @@ static int32_t normalize_by_gc_loess(CleanState& st, int nchr, const uint8_t* h_
 
 #include "quantize.hpp"
 #include "clean_fast.hpp"
+#include "clean_gc_only.hpp"
 
 extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
                                  int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, const uint8_t* h_chr_is_y, uint32_t flags, int32_t min_bins_per_gc,
@@ -682,6 +683,14 @@ extern "C" int32_t canvas_clean2(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int
     // CANVAS_CLEAN_HOST_DRIVEN=1 forces it (test hook: the two paths must agree bit for bit)
     if (!loessMode && min_bins_per_gc >= 100 && !cvx_hook("CANVAS_CLEAN_HOST_DRIVEN")) {
         bool handled = false;
+        // -g alone on whole-number counts (BASELINE configs[1]): three launches, in place (clean_gc_only.hpp); anything it cannot decide exactly leaves the arrays untouched.
+        // CANVAS_CLEAN_GENERAL_GC=1 (test hook) keeps the general chain
+        if (flags == CANVAS_CLEAN_GCNORM && !cvx_hook("CANVAS_CLEAN_GENERAL_GC")) {
+            char h1 = 0;
+            int32_t rcg = clean_gc_only(ctx, 1, &n, &d_chr, &d_start, &d_stop, &d_count, &d_gc, nchr, h_chr_is_autosome, min_bins_per_gc, h_n_out, h_info, &h1);
+            if (rcg) return rcg;
+            if (h1) { if (h_local_sd_out) *h_local_sd_out = -1.0; return CANVAS_OK; }
+        }
         int32_t rcf = clean_device_driven(ctx, n, d_chr, d_start, d_stop, d_count, d_gc, nchr, h_chr_is_autosome, flags, min_bins_per_gc, h_local_sd_out, h_n_out, h_info, &handled);
         if (rcf) return rcf;
         if (handled) return CANVAS_OK;
@@ -1030,6 +1039,20 @@ extern "C" int32_t canvas_clean_batch(canvas_ctx* ctx, int32_t nsamples, const i
             std::vector<double> lsd(B, -1.0); std::vector<int32_t> info((size_t)8 * B, 0); std::vector<char> handled(B, 0);
             for (int k = 0; k < B; k++) { const int s = idx[k]; n[k] = h_n[s]; c[k] = h_d_chr[s]; st[k] = h_d_start[s]; sp[k] = h_d_stop[s]; g[k] = h_d_gc[s]; cnt[k] = h_d_count[s]; }
             ctx->clean_cq_failed = false;
+            if (flags == CANVAS_CLEAN_GCNORM && B <= CG_MAXB && !cvx_hook("CANVAS_CLEAN_GENERAL_GC")) {
+                // -g alone: the three-launch stage of clean_gc_only.hpp with grid.y = B; samples it hands back go through the general chain one by one below
+                int32_t rcg = clean_gc_only(ctx, B, n.data(), c.data(), st.data(), sp.data(), cnt.data(), g.data(), nchr, h_chr_is_autosome, min_bins_per_gc, nOut.data(), info.data(), handled.data());
+                if (rcg) return rcg;
+                for (int k = 0; k < B; k++) if (handled[k]) { const int s = idx[k]; done[s] = 1; h_n_out[s] = nOut[k]; if (h_local_sd_out) h_local_sd_out[s] = -1.0; if (h_info) memcpy(h_info + 8 * s, info.data() + 8 * k, 8 * sizeof(int32_t)); }
+                std::vector<int> rest; for (int k = 0; k < B; k++) if (!handled[k]) rest.push_back(idx[k]);
+                idx.swap(rest);
+            }
+        }
+        if (!idx.empty()) {
+            const int B = (int)idx.size();
+            std::vector<int64_t> n(B), nOut(B, 0); std::vector<int32_t*> c(B), st(B), sp(B), g(B); std::vector<float*> cnt(B);
+            std::vector<double> lsd(B, -1.0); std::vector<int32_t> info((size_t)8 * B, 0); std::vector<char> handled(B, 0);
+            for (int k = 0; k < B; k++) { const int s = idx[k]; n[k] = h_n[s]; c[k] = h_d_chr[s]; st[k] = h_d_start[s]; sp[k] = h_d_stop[s]; g[k] = h_d_gc[s]; cnt[k] = h_d_count[s]; }
             int32_t rc = clean_batch_enqueue(ctx, B, n.data(), c.data(), st.data(), sp.data(), cnt.data(), g.data(), nchr, h_chr_is_autosome, flags, min_bins_per_gc, clean_counting_selects());
             if (rc == CANVAS_OK) rc = clean_batch_finish(ctx, lsd.data(), nOut.data(), info.data(), handled.data());
             if (rc) return rc;

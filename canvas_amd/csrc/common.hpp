@@ -49,6 +49,7 @@ struct canvas_ctx {
     bool clean_cq_failed = false, clean_cq_skip = false;   // clean_fast.hpp: a sample's counting selects gave up (it is redone with the radix selects)
     std::shared_ptr<void> cbs_cache;     // cbs.hip: device / pinned buffers of the arc-search and permutation engines, kept between calls (a call used to spend tens of ms in hipMalloc / hipHostMalloc)
     std::shared_ptr<void> hmm_pool;      // hmm.hip: helper threads that fill the negative-binomial emission tables of a sample
+    void* cg_state = nullptr; unsigned cg_epoch = 0;     // clean_gc_only.hpp: tickets / genome row / chunk flags of the -g-only stage (zero between calls), call counter
     std::shared_ptr<void> clean_batch;   // clean_fast.hpp: the batch that clean_batch_enqueue queued (consumed by clean_batch_finish)
     void* comm = nullptr;  // ncclComm_t
     int32_t (*gcw_reduce)(void* user, unsigned long long* v, int n) = nullptr; void* gcw_reduce_user = nullptr;      // element-wise sum over the ranks of a sharded GCContentWeighted binning (fragment means, read-GC profile)

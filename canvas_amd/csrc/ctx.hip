@@ -55,6 +55,7 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->covq_dev) (void)hipFree(ctx->covq_dev);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gc_arena) (void)hipFree(ctx->gc_arena);
+    if (ctx->cg_state) (void)hipFree(ctx->cg_state);
     if (ctx->bin_dev) (void)hipFree(ctx->bin_dev);
     if (ctx->bin_ev) (void)hipEventDestroy(ctx->bin_ev);
     if (ctx->shard_ws) (void)hipFree(ctx->shard_ws);

@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "canvas_device_malloc", "canvas_device_free", "canvas_memcpy_h2d", "canvas_memcpy_d2h", "canvas_host_register", "canvas_host_unregister", "canvas_upload_genome_begin", "canvas_upload_genome_wait",
     "canvas_packed_plane_bytes", "canvas_pack_reference_host", "canvas_pack_hits_host", "canvas_pack_genome_device", "canvas_upload_packed_begin", "canvas_bin_sample_packed", "canvas_sample_pipeline_packed", "canvas_pack_hits2_host", "canvas_upload_packed2_begin",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
-    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined",
+    "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined", "canvas_bin_predefined_gcweighted",
     "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_cbs_boundary", "canvas_wavelets", "canvas_wavelets_stats", "canvas_wavelets_decisions", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_allgather_host", "canvas_merge_cleaned_sharded", "canvas_profile_enable", "canvas_profile_get", "canvas_bin_gcw_stats", "canvas_cbs_tpermp_stats", "canvas_comm_split", "canvas_comm_restore", "canvas_comm_rank", "canvas_bin_sample_sharded", "canvas_hmm_per_sample_sharded", "canvas_cbs_perm_probe", "canvas_stale_reads",
 ]
@@ -324,8 +324,9 @@ class Canvas:
         self._check(self.lib.canvas_bin_gcw_stats(self.ctx, _np_ptr(v)))
         return int(v[0]), int(v[1])
 
-    def bin_predefined(self, bases, masks, hits, lens, bin_starts, bin_stops, mode=MODE_TDR):
-        """CanvasBin -n (BinCountsForChromosome with predefined bins): bin_starts / bin_stops = one array per chromosome; returns (gc, count) tensors over the concatenated bins"""
+    def bin_predefined(self, bases, masks, hits, lens, bin_starts, bin_stops, mode=MODE_TDR, fraglens=None):
+        """CanvasBin -n (BinCountsForChromosome with predefined bins): bin_starts / bin_stops = one array per chromosome; returns (gc, count) tensors over the concatenated bins.
+        mode 5 (GCContentWeighted) needs fraglens (int16 per base, per chromosome): canvas_bin_predefined_gcweighted"""
         torch = self.torch
         n = len(bases)
         lens = np.ascontiguousarray(lens, np.int64)
@@ -335,6 +336,10 @@ class Canvas:
         ds = torch.from_numpy(hs if len(hs) else np.zeros(1, np.int32)).to(self.device); de = torch.from_numpy(he if len(he) else np.zeros(1, np.int32)).to(self.device)
         gc = torch.empty(max(1, len(hs)), dtype=torch.int32, device=self.device); cnt = torch.empty(max(1, len(hs)), dtype=torch.float32, device=self.device)
         self.torch.cuda.synchronize()
+        if fraglens is not None:
+            self._check(self.lib.canvas_bin_predefined_gcweighted(self.ctx, n, _ptr_table(bases), _ptr_table(masks), _ptr_table(hits), _ptr_table(fraglens), _np_ptr(lens), _np_ptr(off), _np_ptr(hs),
+                                                                  _np_ptr(he), C.c_void_p(ds.data_ptr()), C.c_void_p(de.data_ptr()), C.c_void_p(gc.data_ptr()), C.c_void_p(cnt.data_ptr())))
+            return gc[:len(hs)], cnt[:len(hs)]
         self._check(self.lib.canvas_bin_predefined(self.ctx, n, _ptr_table(bases), _ptr_table(masks), _ptr_table(hits), _np_ptr(lens), int(mode), _np_ptr(off), _np_ptr(hs), _np_ptr(he),
                                                    C.c_void_p(ds.data_ptr()), C.c_void_p(de.data_ptr()), C.c_void_p(gc.data_ptr()), C.c_void_p(cnt.data_ptr())))
         return gc[:len(hs)], cnt[:len(hs)]

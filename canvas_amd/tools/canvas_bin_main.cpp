@@ -8,7 +8,7 @@
 // protobuf_dat.hpp) including the bit-order quirk of its writer / reader pair, so the C# CanvasBin -c and this CanvasBin -i (or the other way round) can be mixed.
 // BAM flag semantics follow the SAM specification; Isas.SequencingFiles.BamReader is not part of /root/reference (parity unpinned):
 // IsMainAlignment := neither secondary (0x100) nor supplementary (0x800).
-//   CanvasBin -b S.bam -r kmer.fa -i ... -n bins.bed -o S.binned -d 100 [-m 0|3]                       predefined bins (canvas_bin_predefined)
+//   CanvasBin -b S.bam -r kmer.fa -i ... -n bins.bed -o S.binned -d 100 [-m 0|3|5]                     predefined bins (canvas_bin_predefined)
 //   CanvasBin -b S.bam -r genome.fa -n bins.bed -o S.binned -m Fragment -p                              FragmentBinner.Bin (FragmentBinner.cs:26-80): host code
 // Fragment mode is a sequential dictionary algorithm over the BAM stream keyed by read name (the mate confirms or undoes what the first read of the pair did): its cost is
 // BGZF inflation and string hashing, there is no data-parallel part, so it runs on the host exactly as in the reference.
@@ -471,17 +471,20 @@ int main(int argc, char** argv) {
     ph.mark("pack_upload");
     if (a.has("bins") && !a.has("binsizeonly")) {
         // ---- predefined bins (BinCounts with predefinedBins, CanvasBin.cs:506-547): chromosomes in FASTA order that have both an intermediate and bins
-        if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { fprintf(stderr, "CanvasBin (MI355X): -n with -m GCContentWeighted is not built\n"); return 1; }
-        std::vector<const uint8_t*> qB, qH; std::vector<const uint64_t*> qM; std::vector<int64_t> qL, off{0}; std::vector<int32_t> hs, he; std::vector<std::string> qName;
-        for (int c = 0; c < nchr; c++) { auto it = predefined.find(order[c]->name); if (it == predefined.end()) continue;
-            qB.push_back(pBases[c]); qH.push_back(pHits[c]); qM.push_back(pMask[c]); qL.push_back(len[c]); qName.push_back(order[c]->name);
-            for (auto& b : it->second) { hs.push_back(b.start); he.push_back(b.stop); } off.push_back((int64_t)hs.size()); }
+        // -m GCContentWeighted: every chromosome with an intermediate enters the fragment mean, the read-GC profile and the weights (CanvasBin.cs:427-505), whether it has bins or not
+        const bool gcwPre = mode == CANVAS_MODE_GC_CONTENT_WEIGHTED;
+        std::vector<const uint8_t*> qB, qH; std::vector<const uint64_t*> qM; std::vector<const int16_t*> qF; std::vector<int64_t> qL, off{0}; std::vector<int32_t> hs, he; std::vector<std::string> qName;
+        for (int c = 0; c < nchr; c++) { auto it = predefined.find(order[c]->name); if (it == predefined.end() && !gcwPre) continue;
+            qB.push_back(pBases[c]); qH.push_back(pHits[c]); qM.push_back(pMask[c]); qL.push_back(len[c]); qName.push_back(order[c]->name); if (gcwPre) qF.push_back(pFrag[c]);
+            if (it != predefined.end()) for (auto& b : it->second) { hs.push_back(b.start); he.push_back(b.stop); }
+            off.push_back((int64_t)hs.size()); }
         const int64_t nb = (int64_t)hs.size();
         std::vector<int32_t> hGc(nb); std::vector<float> hCount(nb);
         if (nb > 0) {
             Dev dS(ctx, nb * 4), dE(ctx, nb * 4), dG(ctx, nb * 4), dC(ctx, nb * 4);
             TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dS.p, hs.data(), nb * 4)); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dE.p, he.data(), nb * 4));
-            TOOL_TRY(ctx, canvas_bin_predefined(ctx, (int32_t)qL.size(), qB.data(), qM.data(), qH.data(), qL.data(), mode, off.data(), hs.data(), he.data(), dS.as<int32_t>(), dE.as<int32_t>(), dG.as<int32_t>(), dC.as<float>()));
+            if (gcwPre) TOOL_TRY(ctx, canvas_bin_predefined_gcweighted(ctx, (int32_t)qL.size(), qB.data(), qM.data(), qH.data(), qF.data(), qL.data(), off.data(), hs.data(), he.data(), dS.as<int32_t>(), dE.as<int32_t>(), dG.as<int32_t>(), dC.as<float>()));
+            else TOOL_TRY(ctx, canvas_bin_predefined(ctx, (int32_t)qL.size(), qB.data(), qM.data(), qH.data(), qL.data(), mode, off.data(), hs.data(), he.data(), dS.as<int32_t>(), dE.as<int32_t>(), dG.as<int32_t>(), dC.as<float>()));
             TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hGc.data(), dG.p, nb * 4)); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, hCount.data(), dC.p, nb * 4));
         }
         GzWriter wr(out); if (!wr.ok()) { fprintf(stderr, "CanvasBin: cannot write %s\n", out.c_str()); return 1; }

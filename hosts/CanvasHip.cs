@@ -41,6 +41,11 @@ namespace CanvasHipInterop
             int countsPerBin, int binSizeIn, int mode, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, long[] nbinsPerChr, out long nbinsTotal);
         [DllImport(Lib)] public static extern int canvas_bin_sample_gcweighted(IntPtr ctx, int nchr, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, IntPtr[] dFragLen, long[] len,
             byte[] chrIsAutosome, int countsPerBin, int binSizeIn, IntPtr dChr, IntPtr dStart, IntPtr dStop, IntPtr dGc, IntPtr dCount, long cap, out int binSize, long[] nbinsPerChr, out long nbinsTotal);
+        // CanvasBin -n (BinCountsForChromosome with usePredefinedBins, CanvasBin.cs:575-655); the _gcweighted form is -n with -m GCContentWeighted (:617-636)
+        [DllImport(Lib)] public static extern int canvas_bin_predefined(IntPtr ctx, int nchr, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, long[] len, int mode, long[] binOffset,
+            int[] binStart, int[] binStop, IntPtr dBinStart, IntPtr dBinStop, IntPtr dGc, IntPtr dCount);
+        [DllImport(Lib)] public static extern int canvas_bin_predefined_gcweighted(IntPtr ctx, int nchr, IntPtr[] dBases, IntPtr[] dMask, IntPtr[] dHits, IntPtr[] dFragLen, long[] len, long[] binOffset,
+            int[] binStart, int[] binStop, IntPtr dBinStart, IntPtr dBinStop, IntPtr dGc, IntPtr dCount);
 
         // ---- packed per-base inputs (INTEGRATION.md 5b): 0.75 B/base over PCIe instead of 2.125 B/base, same bins
         [DllImport(Lib)] public static extern int canvas_packed_plane_bytes(long len, out long refBytes, out long hitBytes);

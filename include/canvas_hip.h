@@ -165,6 +165,13 @@ int32_t canvas_bin_gcw_stats(canvas_ctx* ctx, int64_t* h_out2);
 int32_t canvas_bin_predefined(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits, const int64_t* h_len,
                               int32_t mode, const int64_t* h_bin_offset, const int32_t* h_bin_start, const int32_t* h_bin_stop, const int32_t* d_bin_start, const int32_t* d_bin_stop,
                               int32_t* d_gc, float* d_count);
+/* The same with -m GCContentWeighted (the predefined-bin close shares the weighted branch, CanvasBin.cs:617-636): d_count = (int)Math.Round of the float32 sum over the bin's
+ * possible positions of Math.Min(10, hit / observedVsExpectedGC[readGC]).  The mean fragment size, the read-GC profile and the weights are the whole call's — every one of the
+ * nchr chromosomes enters them (BinCounts, CanvasBin.cs:427-505), whether it has bins (h_bin_offset[c] < h_bin_offset[c + 1]) or not.  Arrays 16-byte aligned as for
+ * canvas_bin_sample_gcweighted; canvas_bin_gcw_stats reports decided / replayed bins. */
+int32_t canvas_bin_predefined_gcweighted(canvas_ctx* ctx, int32_t nchr, const uint8_t* const* d_bases, const uint64_t* const* d_mask, const uint8_t* const* d_hits,
+                                         const int16_t* const* d_fraglen, const int64_t* h_len, const int64_t* h_bin_offset, const int32_t* h_bin_start, const int32_t* h_bin_stop,
+                                         const int32_t* d_bin_start, const int32_t* d_bin_stop, int32_t* d_gc, float* d_count);
 
 /* ---- CanvasClean --------------------------------------------------------------------------------------------- */
 /* CanvasClean.Main (CanvasClean/CanvasClean.cs:415-533) on the whole-genome SoA in file order, in place; bins that

@@ -14,6 +14,8 @@ int64_t bin_chromosome(const uint8_t* bases, const uint8_t* mask, const uint8_t*
                        int64_t cap, int32_t* start, int32_t* stop, int32_t* gc, int32_t* count);
 int64_t bin_chromosome_predefined(const uint8_t* bases, const uint8_t* mask, const uint8_t* hits, int64_t len, int mode, int64_t nbins, const int32_t* binStart, const int32_t* binStop,
                                   int32_t* gc, int32_t* count);
+int64_t bin_chromosome_predefined_weighted(const uint8_t* bases, const uint8_t* mask, const uint8_t* hits, const uint8_t* readGC, const float* obsVsExp, int64_t len, int64_t nbins,
+                                           const int32_t* binStart, const int32_t* binStop, int32_t* gc, int32_t* count);
 int16_t mean_fragment_size(int nchr, const int16_t* const* fl, const int64_t* len);
 void read_gc_content(const uint8_t* bases, const int16_t* fl, int64_t L, int meanFragmentSize, uint8_t* gcContent);
 void observed_vs_expected_gc(int nchr, const uint8_t* const* readGC, const uint8_t* const* hits, const int64_t* len, float* out101);

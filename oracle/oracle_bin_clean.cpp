@@ -231,6 +231,35 @@ int64_t bin_chromosome_weighted(const uint8_t* bases, const uint8_t* mask, const
     return nb;
 }
 
+// BinCountsForChromosome with predefined bins AND the GCContentWeighted branch (CanvasBin.cs:575-655: the close at :616-617 is shared, the weighted count at :626-636).
+// Same cursor as bin_chromosome_predefined; returns the bins closed or -1.
+int64_t bin_chromosome_predefined_weighted(const uint8_t* bases, const uint8_t* mask, const uint8_t* hits, const uint8_t* readGC, const float* obsVsExp, int64_t len, int64_t nbins,
+                                           const int32_t* binStart, const int32_t* binStop, int32_t* gc, int32_t* count) {
+    if (nbins == 0) return 0;
+    int64_t predefinedBinIndex = 0;
+    int64_t pos = binStart[0];
+    while (true) { if (pos >= len) return -1; if (bases[pos] != 'n') break; pos++; }       // :582-584
+    int NucleotideCount = 0, GCCount = 0;
+    float tmpObservedCount = 0;
+    for (; pos < len; pos++) {
+        NucleotideCount++;
+        switch (bases[pos]) { case 'C': case 'c': case 'G': case 'g': GCCount++; break; default: break; }
+        if ((mask[pos >> 3] >> (pos & 7)) & 1) {                                            // :604-611 binObservations / binPositions, summed at the close in the same order
+            float q = (float)(int)hits[pos] / obsVsExp[readGC[pos]];
+            tmpObservedCount += std::min(10.0f, q);
+        }
+        if (pos == (int64_t)binStop[predefinedBinIndex] - 1) {                              // :616-617
+            float gcf = 100.0f * (float)GCCount; gcf = gcf / (float)NucleotideCount;
+            gc[predefinedBinIndex] = (int)gcf; count[predefinedBinIndex] = (int)round_half_even((double)tmpObservedCount);
+            predefinedBinIndex++;
+            if (predefinedBinIndex >= nbins) break;
+            pos = (int64_t)binStart[predefinedBinIndex] - 1;                                // :646
+            NucleotideCount = GCCount = 0; tmpObservedCount = 0;
+        }
+    }
+    return predefinedBinIndex;
+}
+
 // ------------------------------------------------------------------ CanvasClean
 struct Bins {
     std::vector<int32_t> chr, start, stop, gc;

@@ -58,6 +58,10 @@ int64_t orc_bin_chromosome_predefined(const uint8_t* bases, const uint8_t* mask,
                                       int32_t* gc, int32_t* count) {
     return bin_chromosome_predefined(bases, mask, hits, len, mode, nbins, binStart, binStop, gc, count);
 }
+int64_t orc_bin_chromosome_predefined_weighted(const uint8_t* bases, const uint8_t* mask, const uint8_t* hits, const uint8_t* readGC, const float* obsVsExp, int64_t len, int64_t nbins,
+                                               const int32_t* binStart, const int32_t* binStop, int32_t* gc, int32_t* count) {
+    return bin_chromosome_predefined_weighted(bases, mask, hits, readGC, obsVsExp, len, nbins, binStart, binStop, gc, count);
+}
 // multi-threaded helper for the CPU baseline: one std::thread per chromosome, as Parallel.ForEach in CanvasBin.cs:539
 void orc_bin_genome(int nchr, const uint8_t* const* bases, const uint8_t* const* mask, const uint8_t* const* hits, const int64_t* len,
                     int binSize, int mode, const int64_t* cap, int32_t* const* start, int32_t* const* stop, int32_t* const* gc,

@@ -75,6 +75,29 @@ def bin_predefined(bases, mask, hits, bin_start, bin_stop, mode=3):
     return int(k), gc, cnt
 
 
+def bin_predefined_gc_weighted(bases, masks, hits, fraglens, bin_starts, bin_stops):
+    """CanvasBin -n -m GCContentWeighted: the profile and the weights from every chromosome (BinCounts, CanvasBin.cs:427-505), then the predefined bins of the chromosomes that
+    have any (bin_starts[c] may be empty); returns per chromosome (bins closed, gc, count)"""
+    nchr = len(bases)
+    lens = np.array([len(b) for b in bases], np.int64)
+    m = lib.orc_mean_fragment_size(nchr, _pp(fraglens), _p(lens))
+    rgc = []
+    for c in range(nchr):
+        g = np.zeros(len(bases[c]), np.uint8)
+        lib.orc_read_gc_content(_p(bases[c]), _p(fraglens[c]), C.c_int64(len(bases[c])), m, _p(g))
+        rgc.append(g)
+    w = np.zeros(101, np.float32)
+    lib.orc_observed_vs_expected_gc(nchr, _pp(rgc), _pp(hits), _p(lens), _p(w))
+    lib.orc_bin_chromosome_predefined_weighted.restype = C.c_int64
+    res = []
+    for c in range(nchr):
+        bs = np.ascontiguousarray(bin_starts[c], np.int32); be = np.ascontiguousarray(bin_stops[c], np.int32)
+        gc = np.zeros(len(bs), np.int32); cnt = np.zeros(len(bs), np.int32)
+        k = lib.orc_bin_chromosome_predefined_weighted(_p(bases[c]), _p(masks[c]), _p(hits[c]), _p(rgc[c]), _p(w), C.c_int64(len(bases[c])), C.c_int64(len(bs)), _p(bs), _p(be), _p(gc), _p(cnt))
+        res.append((int(k), gc, cnt))
+    return res
+
+
 def bin_gc_weighted(bases, masks, hits, fraglens, bin_size):
     """GCContentWeighted binning of a genome (CanvasBin.cs:416-506,626-636): returns (per-chromosome [start,stop,gc,count], mean fragment, weights)"""
     nchr = len(bases)

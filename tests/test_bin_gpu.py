@@ -338,3 +338,50 @@ def test_predefined_bins_match_oracle():
         cv.bin_predefined(bases, masks, hits, np.array(lengths, np.int64), [np.array([10], np.int32), np.array([5], np.int32)], [np.array([20], np.int32), np.array([lengths[1] + 1], np.int32)])
     with pytest.raises(CanvasError):                                  # first bin entirely inside the leading n's
         cv.bin_predefined(bases, masks, hits, np.array(lengths, np.int64), [np.array([0], np.int32), np.array([20_000], np.int32)], [np.array([50], np.int32), np.array([21_000], np.int32)])
+
+
+def test_predefined_bins_gc_content_weighted_match_oracle():
+    """CanvasBin -n with -m GCContentWeighted (CanvasBin.cs:617-636: the predefined-bin close shares the weighted branch): canvas_bin_predefined_gcweighted vs the oracle — the
+    profile and the weights come from all three chromosomes, the middle one has no bins; bins of 1 base, touching, overlapping, one spanning megabase-like gaps, the first one
+    starting inside the leading 'n' stretch; CANVAS_GCW_SERIAL=1 (every bin in the reference's own order of additions) gives the same counts"""
+    cv = get_canvas()
+    lengths = [500_000, 90_007, 230_001]
+    data = _chroms(lengths, rate=0.25)
+    rng = np.random.RandomState(41)
+    fl = [np.where(h > 0, np.clip(rng.normal(320, 50, len(h)), 1, 5000), 0).astype(np.int16) for b, h, m in data]
+    bases, hits, masks = _upload(cv, data)
+    dfl = [to_dev(pad16(f), cv.device) for f in fl]
+    starts, stops = [], []
+    for c, L in enumerate(lengths):
+        if c == 1: starts.append(np.zeros(0, np.int32)); stops.append(np.zeros(0, np.int32)); continue
+        s0 = np.sort(rng.choice(L - 3000, 400, replace=False)); e0 = s0 + rng.randint(1, 2500, 400)
+        s0[0] = 0; e0[0] = max(e0[0], 12_000)
+        s0[5] = s0[4]; e0[5] = e0[4] + 1                               # overlapping bins
+        e0[7] = s0[7] + 1                                               # one base
+        e0[200] = s0[200] + 60_000                                      # longer than the 16-lane path's span: the whole wave scans it
+        e0[-1] = L
+        starts.append(s0.astype(np.int32)); stops.append(np.minimum(e0, L).astype(np.int32))
+    exp = O.bin_predefined_gc_weighted([d[0] for d in data], [d[2] for d in data], [d[1] for d in data], fl, starts, stops)
+    lens = np.array(lengths, np.int64)
+    import os
+    for serial in (False, True):
+        if serial: os.environ["CANVAS_GCW_SERIAL"] = "1"
+        try:
+            gc, cnt = cv.bin_predefined(bases, masks, hits, lens, starts, stops, mode=5, fraglens=dfl)
+        finally:
+            os.environ.pop("CANVAS_GCW_SERIAL", None)
+        off = 0
+        for c in range(3):
+            k, eg, ec = exp[c]; n = len(starts[c])
+            assert k == n
+            assert (gc[off:off + n].cpu().numpy() == eg).all()
+            got = cnt[off:off + n].cpu().numpy()
+            assert (got == ec.astype(np.float32)).all(), (serial, c, np.nonzero(got != ec)[0][:5], got[got != ec][:5], ec[got != ec][:5])
+            off += n
+        decided, replayed = cv.bin_gcw_stats()
+        assert decided + replayed == off and (replayed == off if serial else decided > 0.9 * off)
+    from canvas_amd.lib import CanvasError
+    with pytest.raises(CanvasError):                                  # mode 5 through the entry point without fragment lengths
+        cv.bin_predefined(bases, masks, hits, lens, starts, stops, mode=5)
+    with pytest.raises(CanvasError):                                  # no usable fragment length: "Unable to determine fragment size" (CanvasBin.cs:431-434)
+        cv.bin_predefined(bases, masks, hits, lens, starts, stops, mode=5, fraglens=[to_dev(pad16(np.zeros_like(f)), cv.device) for f in fl])

@@ -300,6 +300,18 @@ def test_canvasbin_bam_to_binned(tmp_path):
         exp += [f"{n}\t{a_}\t{b_}\t{O.format_f2(float(cc))}\t{gg}" for (a_, b_), gg, cc in zip(pre_bins[n], g, cnt)]
     with gzip.open(binned, "rt") as f:
         assert f.read().splitlines() == exp
+    # -n with -m GCContentWeighted (CanvasBin.cs:617-636): bins on chrA only — chrB still enters the fragment mean, the read-GC profile and the weights (:427-505)
+    pre5 = str(tmp_path / "predefined5.bed")
+    with open(pre5, "w") as f:
+        for a_, b_ in pre_bins["chrA"]: f.write(f"chrA\t{a_}\t{b_}\n")
+    binned = str(tmp_path / "pre5.binned")
+    r = subprocess.run([BIN, "-b", bam, "-r", fa2, "-o", binned, "-d", "100", "-m", "GCContentWeighted", "-n", pre5] + args, capture_output=True, text=True)      # (args, mk, hk, fk: the mode-5 intermediates)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res5 = O.bin_predefined_gc_weighted([seq2[n] for n in names2], mk, hk, fk, [[b[0] for b in pre_bins["chrA"]], []], [[b[1] for b in pre_bins["chrA"]], []])
+    assert res5[0][0] == len(pre_bins["chrA"])
+    exp = [f"chrA\t{a_}\t{b_}\t{O.format_f2(float(cc))}\t{gg}" for (a_, b_), gg, cc in zip(pre_bins["chrA"], res5[0][1], res5[0][2])]
+    with gzip.open(binned, "rt") as f:
+        assert f.read().splitlines() == exp
     # a truncated file is refused
     bad = str(tmp_path / "bad.dat"); open(bad, "wb").write(_encode_dat("chrA", b"\xff" * 10, b"\x01" * 80, 0)[:-7])
     assert subprocess.run([BIN, "-b", bam, "-r", fa2, "-o", str(tmp_path / "x.binned"), "-d", "100", "-i", bad], capture_output=True).returncode == 1

@@ -304,3 +304,81 @@ def test_clean_counting_selects_taken_and_given_up(clean_path):
     assert info[5] == 0
 
 
+
+
+def test_clean_gc_only_three_launch_path(clean_path):
+    """CanvasClean -g alone on the whole-number counts of a .binned file (BASELINE configs[1]) takes clean_gc_only.hpp by default: per-workgroup (GC, count) counters in LDS, the
+    medians per bucket off the summed rows, in-place apply + strip from registers — info[6] == 1 says so.  Stripped buckets (also at the front of the list, so that every
+    chunk's output reaches back into its predecessors), chromosomes that are not autosomes, inputs whose buckets all fall under the threshold, levels above the window's
+    default start, one bin, and sizes around the chunking boundaries must all give the oracle's bins; counts with decimals, a median outside the counter window and
+    CANVAS_CLEAN_GENERAL_GC=1 hand the sample to the general chain (info[6] == 0), which must agree."""
+    cv = get_canvas()
+    rng = np.random.RandomState(17)
+    taken = clean_path != "host_driven"
+    for n, nchr in ((60_000, 24), (2_600_000, 24), (12_345, 3), (150, 1), (1, 1), (262_144, 24), (262_145, 24), (4_300_000, 24)):
+        bins = synth.generate_bins(20260927 + 1, n, nchr=nchr)
+        bins["count"] = np.round(bins["count"]).astype(np.float32)                # what CanvasBin writes in modes 0 / 3 / 5: whole numbers
+        if n == 60_000:
+            bins["gc"][rng.randint(0, n, 40)] = 3                                   # a bucket of 40 bins: stripped (fewer than 100 autosomal bins)
+            bins["gc"][np.nonzero(bins["chr"] == nchr - 1)[0][:500]] = 97           # 500 bins of a bucket that only a non-autosome fills: counts[97] = 0 -> stripped too
+        if n == 2_600_000:
+            bins["gc"][:30_000:3] = 2                                               # 10 000 bins of the first chunks ...
+            bins["chr"][:30_000:3] = nchr - 1                                       # ... in a bucket without an autosomal bin: stripped, every later chunk moves forward by up to 10 000
+            bins["gc"][rng.randint(0, n, 90)] = 99
+        if n == 4_300_000:
+            bins["count"] += 1000.0                                                 # the level decides where the window starts
+        info, exp = _run1(cv, bins, CLEAN_GCNORM, nchr=nchr)
+        assert info[6] == (1 if taken else 0), (n, info)
+        if n == 60_000:
+            assert len(exp["chr"]) < n - 500
+        if n == 2_600_000:
+            assert len(exp["chr"]) <= n - 10_000
+        if n in (150, 1):
+            assert len(exp["chr"]) == len(bins["chr"])                                           # no bucket reaches 100 bins: nothing is stripped, nothing normalised (CanvasClean.cs:501-503)
+    # counts with two decimals: the counters cannot hold them, the general chain takes over (the arrays were left untouched)
+    bins = synth.generate_bins(20260927 + 1, 40_000)
+    bins["count"] = _f2(bins["count"] + 0.25)
+    info, _ = _run1(cv, bins, CLEAN_GCNORM)
+    assert info[6] == 0
+    # a bucket whose median lies beyond the window (its counts are 400 above the sample's level)
+    bins["count"] = np.round(bins["count"]).astype(np.float32)
+    sel = np.nonzero(bins["gc"] == 45)[0]
+    bins["count"][sel] += 400.0
+    info, _ = _run1(cv, bins, CLEAN_GCNORM)
+    assert info[6] == 0 and len(sel) > 100
+    # single counts far outside the window do not matter (they are counted as "above")
+    bins = synth.generate_bins(20260927 + 5, 40_000)
+    bins["count"] = np.round(bins["count"]).astype(np.float32); bins["count"][123] = 5000.0; bins["count"][7] = 0.0
+    info, _ = _run1(cv, bins, CLEAN_GCNORM)
+    assert info[6] == (1 if taken else 0)
+    # gc outside 0..100: the reference throws
+    from canvas_amd.lib import CanvasError
+    bins["gc"][11] = 101
+    dev = {k: to_dev(v, cv.device) for k, v in bins.items()}
+    with pytest.raises(CanvasError):
+        cv.clean(dev, len(bins["chr"]), synth.IS_AUTOSOME[:24], CLEAN_GCNORM)
+
+
+def test_clean_gc_only_equals_the_general_chain_and_batches(monkeypatch, clean_path):
+    """the same sample through the general chain (CANVAS_CLEAN_GENERAL_GC=1) and through the -g-only stage, alone and as a cohort of 3 (grid.y = 3; one member has decimals and
+    is handed back to the general chain): identical bins"""
+    import torch
+    cv = get_canvas()
+    bins = synth.generate_bins(20260927 + 11, 300_000)
+    bins["count"] = np.round(bins["count"]).astype(np.float32)
+    monkeypatch.setenv("CANVAS_CLEAN_GENERAL_GC", "1")
+    info2, exp = _run1(cv, bins, CLEAN_GCNORM)
+    monkeypatch.delenv("CANVAS_CLEAN_GENERAL_GC")
+    info, _ = _run1(cv, bins, CLEAN_GCNORM)
+    assert info2[6] == 0 and info[3] == info2[3] and (info[6] == 1 or clean_path == "host_driven")
+    other = synth.generate_bins(20260927 + 12, 123_457); other["count"] = np.round(other["count"]).astype(np.float32)
+    frac = synth.generate_bins(20260927 + 13, 50_000); frac["count"] = _f2(frac["count"] + 0.5)
+    samples = [bins, other, frac]
+    devs = [{k: to_dev(v, cv.device) for k, v in b.items()} for b in samples]
+    is_auto = synth.IS_AUTOSOME[:24]
+    n_out, _, infos = cv.clean_batch(devs, [len(b["chr"]) for b in samples], is_auto, CLEAN_GCNORM)
+    is_y = np.zeros(24, np.uint8); is_y[-1] = 1
+    for b, d, no in zip(samples, devs, n_out):
+        ex = O.clean(b["chr"], b["start"], b["stop"], b["count"], b["gc"], is_auto, is_y, CLEAN_GCNORM)
+        assert int(no) == len(ex["chr"])
+        assert (d["count"][:int(no)].cpu().numpy().view(np.uint32) == ex["count"].view(np.uint32)).all() and (d["start"][:int(no)].cpu().numpy() == ex["start"]).all()
