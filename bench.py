@@ -695,8 +695,11 @@ def clean_gc_only_leg(args, cv, torch, seed, bases, masks, lens, is_auto, device
     o = {"workload": "BASELINE configs[1]: whole-genome 30x single sample (rate %.4f), CanvasClean -g only" % (args.rate / 2.0), "bins": int(total), "bin_size": int(bs), "bins_after": int(n_out),
          "avg_ms": round(ms, 4), "achieved_GBs_at_20B_per_bin": round(20.0 * total / (ms * 1e-3) / 1e9, 1), "frac_of_peak_at_20B_per_bin": round(20.0 * total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
          "counting_selects": bool(info[5]),
-         "note": "48 MB of bins: 20 B/bin at the HBM peak is 6 us, less than three kernel boundaries; the stage is 6 dependent launches (flags + GC histogram + decision, compaction + "
-                 "grouping, per-value counters, medians, flags, compaction) and latency-bound at this size — the cohort call below shares them between samples"}
+         "three_launch_stage": bool(info[6]),
+         "note": "clean_gc_only.hpp: three launches, in place (k_cg_count: per-workgroup (GC, count) counters in LDS written as slabs; k_cg_medians: every workgroup takes the "
+                 "strip decision for itself, one workgroup per bucket reads its median off the summed rows; k_cg_apply: register-held apply + strip with a chunk hand-off). "
+                 "It moves 12 B/bin (statistics incl. the chromosome index) + 40 B/bin (all five columns are read and rewritten: the strip shifts every bin behind the first "
+                 "stripped one) + 5 B/bin of slabs against the contract's 20 B/bin, and each launch has a ~2.5 us floor"}
     B = 8
     best = None
     for r in range(3):

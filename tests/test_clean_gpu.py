@@ -371,6 +371,10 @@ def test_clean_gc_only_equals_the_general_chain_and_batches(monkeypatch, clean_p
     monkeypatch.delenv("CANVAS_CLEAN_GENERAL_GC")
     info, _ = _run1(cv, bins, CLEAN_GCNORM)
     assert info2[6] == 0 and info[3] == info2[3] and (info[6] == 1 or clean_path == "host_driven")
+    monkeypatch.setenv("CANVAS_CG_TICKET", "1")                  # chunks of k_cg_apply by ticket (what a grid larger than the device takes) instead of by workgroup index
+    info3, _ = _run1(cv, bins, CLEAN_GCNORM)
+    monkeypatch.delenv("CANVAS_CG_TICKET")
+    assert info3[3] == info[3] and info3[6] == info[6]
     other = synth.generate_bins(20260927 + 12, 123_457); other["count"] = np.round(other["count"]).astype(np.float32)
     frac = synth.generate_bins(20260927 + 13, 50_000); frac["count"] = _f2(frac["count"] + 0.5)
     samples = [bins, other, frac]

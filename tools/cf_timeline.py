@@ -3,7 +3,7 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 rows = [(n.split("(")[0].replace("void ", ""), s, e) for n, s, e in rows]
-idx = [i for i, r in enumerate(rows) if r[0].startswith("k_cf_init")]
+idx = [i for i, r in enumerate(rows) if r[0].startswith("k_cf_init") or r[0].startswith("k_cg_count")]
 a = idx[-1]
 t0 = rows[a][1]; prev = t0
 for n, s, e in rows[a:a + 14]:

@@ -1,4 +1,4 @@
-"""canvas_clean on one WGS-size bin list, repeated (for rocprofv3 / timing): python tools/clean_probe.py [reps] [rate]
+"""canvas_clean on one WGS-size bin list, repeated (for rocprofv3 / timing): python tools/clean_probe.py [reps] [rate] [g]
 prints the hipEvent time of the stage (the library's own clean_total scope) per call"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +21,7 @@ _, per, total, bs = cv.bin_sample(bases, masks, hits, lens, synth.IS_AUTOSOME, 1
 binned = {k: v[:total].clone() for k, v in out.items()}
 del bases, hits, masks
 flags = CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD
+if len(sys.argv) > 3 and sys.argv[3] == "g": flags = CLEAN_GCNORM          # BASELINE configs[1]: -g alone (clean_gc_only.hpp)
 cv.profile_enable(True)
 work = {k: v.clone() for k, v in binned.items()}
 for r in range(reps):
