@@ -207,7 +207,7 @@ def main():
         # collected with rocprofv3 --pmc in separate passes (tools/pmc_summary.py) and are quoted here per launch
         pj = json.load(open(pmc))
         if abs(pj["workload"]["scale"] - args.scale) < 1e-9 and abs(pj["workload"]["rate"] - args.rate) < 1e-9:
-            traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/" + pmc_name + " (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+            traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/" + pmc_name + " (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; git head %s)" % pj.get("git_head", "round 2")
     clean_obj = {"avg_ms": round(clean_ms, 4),
                  "achieved_GBs_at_232B_per_bin": round(232.0 * keep["total"] / max(1e-9, clean_ms * 1e-3) / 1e9, 1),
                  "frac_of_peak_at_232B_per_bin": round(232.0 * keep["total"] / max(1e-9, clean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -222,10 +222,16 @@ def main():
                                   "canvas_clean(all stages)": clean_obj}}
 
     # scalar copies of the figures the review asks about, inside `roofline` (the driver's record keeps this object whole)
-    CLEAN_COUNTER_BYTES_PER_BIN = 86.8      # profiles/r03_pmc_clean_batch.txt: 40.5 B fetched + 46.3 B written per bin (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+    # what the stage really moves per bin (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_round.sh): read from the counter file of this round's code
+    CLEAN_COUNTER_BYTES_PER_BIN, clean_counter_src = 86.8, "profiles/r03_pmc_clean_batch.txt (40.5 B fetched + 46.3 B written per bin)"
+    pcb = os.path.join(ROOT, "profiles", "pmc_clean_batch.json")
+    if os.path.exists(pcb):
+        pj2 = json.load(open(pcb)); CLEAN_COUNTER_BYTES_PER_BIN = float(pj2["bytes_per_bin"])
+        clean_counter_src = "profiles/pmc_clean_batch.json (%.1f B fetched + %.1f B written per bin; git head %s)" % (pj2["fetched_bytes_per_bin"], pj2["written_bytes_per_bin"], pj2.get("git_head", "?"))
     roofline["clean_ms"] = round(clean_ms, 4)
     roofline["clean_frac_232"] = clean_obj["frac_of_peak_at_232B_per_bin"]
     roofline["clean_frac_counter_bytes"] = round(CLEAN_COUNTER_BYTES_PER_BIN * keep["total"] / max(1e-9, clean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    roofline["clean_counter_bytes_source"] = clean_counter_src
     roofline["bin_tail_ms"] = round(ms_close / max(1, k_close) + ms_res / max(1, k_res), 4) if single_read else None
     roofline["viterbi_ms"] = round(ms_vit / max(1, k_vit), 4)
     roofline["stage_scopes_from"] = "%d untimed passes with every scope on, after the timed region (the timed passes carry only the dominant kernel's event pair)" % PROF_PASSES
@@ -238,7 +244,7 @@ def main():
     if os.path.exists(tl):
         tj = json.load(open(tl))
         if abs(tj.get("scale", -1) - args.scale) < 1e-9 and abs(tj.get("rate", -1) - args.rate) < 1e-9:
-            roofline["idle_us_per_pass"] = tj["idle_us"]; roofline["idle_source"] = "profiles/pass_timeline.json (rocprofv3 --kernel-trace of this command: span %.0f us, busy %.0f us)" % (tj["span_us"], tj["busy_us"])
+            roofline["idle_us_per_pass"] = tj["idle_us"]; roofline["idle_source"] = "profiles/pass_timeline.json (rocprofv3 --kernel-trace of this command, git head %s: span %.0f us, busy %.0f us; the run's own figure is hand_over_us_per_pass)" % (tj.get("git_head", "?"), tj["span_us"], tj["busy_us"])
 
     result = {"metric": "genome-bins/sec (bin+clean+partition)", "value": round(value, 1), "unit": "bins/s", "n_gpus": world, "steps": args.steps,
               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -27,4 +27,4 @@ for r in range(reps):
     t0 = time.perf_counter()
     nout, lsd, _ = cv.clean_batch(copies, [total] * B, synth.IS_AUTOSOME, flags)
     dt = time.perf_counter() - t0
-    print(f"B={B}: {dt * 1e3:.3f} ms per batch, {dt / B * 1e3:.4f} ms per sample, n_out {int(nout[0])}")
+    print(f"B={B}: {dt * 1e3:.3f} ms per batch, {dt / B * 1e3:.4f} ms per sample, bins per sample {total}, n_out {int(nout[0])}")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sums the FETCH_SIZE / WRITE_SIZE counters (separate rocprofv3 --pmc passes over `tools/clean_batch_probe.py 8 1`) per CanvasClean kernel.
-usage: tools/pmc_clean_batch.py fetch_counter_collection.csv write_counter_collection.csv bins_per_sample samples > profiles/rNN_pmc_clean_batch.txt"""
+usage: tools/pmc_clean_batch.py fetch_counter_collection.csv write_counter_collection.csv bins_per_sample samples [out.json] > profiles/rNN_pmc_clean_batch.txt
+(out.json: the per-bin totals for bench.py's clean_frac_counter_bytes)"""
 import collections, csv, sys
 
 fetch_csv, write_csv, bins, samples = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
@@ -23,3 +24,8 @@ for k in sorted(set(F) | set(W), key=lambda k: -(sum(F.get(k, [0])) + sum(W.get(
     print("%-26s %6d %16.0f %16.0f" % (k, len(F.get(k, W.get(k, []))), f, w))
 print("%-26s %6s %16.0f %16.0f" % ("total", "", tf, tw))
 print(f"# per bin: {tf / bins / samples:.1f} B fetched + {tw / bins / samples:.1f} B written (SURVEY 8(d) stage-sum figure: 232 B/bin)")
+if len(sys.argv) > 5:
+    import json
+    json.dump({"fetched_bytes_per_bin": round(tf / bins / samples, 2), "written_bytes_per_bin": round(tw / bins / samples, 2), "bytes_per_bin": round((tf + tw) / bins / samples, 2),
+               "samples_in_call": samples, "bins_per_sample": bins, "flags": "-g -s -r --local-sd-metric-file", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/clean_batch_probe.py 8 1"},
+              open(sys.argv[5], "w"), indent=1)
