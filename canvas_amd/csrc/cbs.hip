@@ -1715,29 +1715,59 @@ static double htmaxp_host(int k, double tss, const double* px, int n, double* sx
     return normalise(h, tss, rn);
 }
 
+// (diagnostic, CANVAS_CBS_TIMING: thread-nanoseconds inside the runtime's allocation / stream-creation calls of the engines — what a cold call pays before its first kernel)
+static std::atomic<long long> g_ns_alloc_arc{0}, g_ns_alloc_perm{0}, g_ns_alloc_tail{0}, g_ns_alloc_svc{0};
+struct AllocClock { std::atomic<long long>& a; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now(); explicit AllocClock(std::atomic<long long>& x) : a(x) {}
+                    ~AllocClock() { a += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } };
 struct Stats { std::atomic<long long> unscanned_max{0}; std::atomic<long long> tailp_dev{0}, tailp_host{0}; std::atomic<long long> ns_tmaxo_host{0}, ns_tailp{0}, ns_prep{0}; std::atomic<long long> ns_ensure{0}, ns_upload{0}, ns_submit{0}, ns_post{0}; std::atomic<long long> ns_dev{0}, ns_hostperm{0}, ns_tpermp{0}, ns_tmaxo{0}, ns_mt{0}; std::atomic<long long> dev_perms{0}, dev_batches{0}, exact_rechecks{0}, verified{0}, violations{0}; std::atomic<long long> tmaxo_calls{0}, tmaxo_elems{0}, perms{0}, perm_elems{0}, tpermp_draws{0}, tpermp_device{0}, tailp_exits{0}, big_t{0}, gpu_searches{0}, gpu_pairs{0}, tie_replays{0}; };
 
 // GPU arc search service shared by the chromosome threads
 struct ArcHostReq { ArcReq r; ArcPReq p; bool pruned = true; const void* hSx; void* hMax; void* hFirst; unsigned long long* hOut; bool done = false; int32_t rc = CANVAS_OK; };
 struct PermService;
 static int32_t service_submit_arc(PermService* svc, ArcHostReq& q);
+// One arena per context for what the engines of a call ask for (EngineCache, below): a cold call creates some fifty-six engines from as many threads, and their ~170 small
+// hipMalloc / hipHostMalloc / hipStreamCreate calls queued up behind the runtime's locks — 3.7 thread-seconds in the tail engines alone, 0.13 s of the first call
+// (CANVAS_CBS_TIMING prints the figure).  canvas_cbs sizes the arena for the engines it is about to create: one device slab, one pinned slab, sixteen shared streams.
+struct EngineCache;
+static char* cache_take(EngineCache* ec, bool pinned, size_t bytes);       // nullptr: nothing left (the engine then allocates for itself)
+static hipStream_t cache_tail_stream(EngineCache* ec);                    // nullptr: no pool
+struct SvcRes;
+static SvcRes* cache_svc_take(canvas_ctx* ctx);
+static void cache_svc_give(canvas_ctx* ctx, SvcRes* r);
 struct ArcGpu {       // one per chromosome thread: own buffers; the launches go through the launcher thread (PermService) so that the searches of all chromosomes share one launch
-    canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr;
+    canvas_ctx* ctx = nullptr; PermService* svc = nullptr; hipStream_t stream = nullptr; EngineCache* cache = nullptr;
+    bool owned = true;            // dSx / dPr / pin are allocations of this engine (false: slices of the cache's arena, never freed one by one)
+    int reserveN = 0;             // the call's longest chromosome: the first allocation is made for it (an engine that met a short chromosome first was allocated again later)
     double* dSx = nullptr; double* dMax = nullptr; int32_t* dFirst = nullptr; int cap = 0;
     char* dPr = nullptr;          // pruned search: block minima / maxima, pair list, per-pair maxima, result words
     char* pin = nullptr; size_t pinBytes = 0;
     char* pinEx = nullptr; int capEx = 0;      // the exhaustive search's per-length maxima (device + pinned): only flat data or the test hook ever need them
     // (a cold process creates some fifty engines — chromosome threads and helpers — and paid for 20 pinned bytes and three device arrays per bin of each: 0.3 s of the
     // CanvasPartition -m CBS executable; the pruned search needs the prefix sums and a few result words)
+    int pinCap = 0;               // bins the pinned staging buffer holds: it grows with the segments THIS engine meets (pinning host memory costs ~1.4 ms per MB — sizing all
+                                  // fifty-six buffers for the longest chromosome, 213 MB, was 0.3 s of a cold call; the device side is sized for the longest chromosome at once)
     int32_t ensure(int n) {
-        if (n <= cap) return CANVAS_OK;
-        if (dSx) { (void)hipFree(dSx); (void)hipFree(dPr); (void)hipHostFree(pin); }
-        cap = n + n / 4 + 1024;
-        { const size_t nb = (size_t)cap / AP_BK + 2; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dPr, nb * 24 + AP_PAIRCAP * 12 + 4096)); }
-        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, (size_t)cap * 8));
-        pinBytes = (size_t)cap * 8 + 256; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
+        if (n <= cap && n <= pinCap) return CANVAS_OK;
+        AllocClock ac(g_ns_alloc_arc);
+        if (n > cap) {
+            if (dSx && owned) { (void)hipFree(dSx); (void)hipFree(dPr); }
+            dSx = nullptr; dPr = nullptr;
+            const int want = std::max(n, reserveN);
+            cap = want + want / 4 + 1024;
+            const size_t prBytes = arc_pr_bytes(cap), sxBytes = (size_t)cap * 8;
+            char* d = cache_take(cache, false, ((prBytes + 255) & ~size_t(255)) + sxBytes);
+            if (d) { dPr = d; dSx = (double*)(d + ((prBytes + 255) & ~size_t(255))); owned = false; }
+            else { owned = true; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dPr, prBytes)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, sxBytes)); }
+        }
+        if (n > pinCap) {
+            if (pin) (void)hipHostFree(pin);
+            pin = nullptr; pinCap = n + n / 4 + 1024;
+            pinBytes = (size_t)pinCap * 8 + 256; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
+        }
         return CANVAS_OK;
     }
+    static size_t arc_pr_bytes(int cap) { const size_t nb = (size_t)cap / AP_BK + 2; return nb * 24 + AP_PAIRCAP * 12 + 4096; }
+    static void arena_bytes(int n, size_t& dev, size_t& pin) { const int cap = n + n / 4 + 1024; dev = ((arc_pr_bytes(cap) + 255) & ~size_t(255)) + (size_t)cap * 8 + 256; pin = 0; }
     int32_t ensure_exhaustive() {
         if (capEx >= cap) return CANVAS_OK;
         if (dMax) { (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pinEx); dMax = nullptr; dFirst = nullptr; pinEx = nullptr; }
@@ -1746,7 +1776,7 @@ struct ArcGpu {       // one per chromosome thread: own buffers; the launches go
         capEx = cap;
         return CANVAS_OK;
     }
-    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx) { (void)hipFree(dSx); (void)hipFree(dPr); (void)hipHostFree(pin); }
+    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx && owned) { (void)hipFree(dSx); (void)hipFree(dPr); } if (pin) (void)hipHostFree(pin);
                 if (dMax) { (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pinEx); } }
 };
 
@@ -1762,7 +1792,7 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     canvas_ctx* ctx = G.ctx;
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int32_t rc = G.ensure(n); if (rc) return rc;
-    double* hSx = (double*)G.pin; double* hMax = nullptr; int32_t* hFirst = nullptr; unsigned long long* hOut = (unsigned long long*)(G.pin + (size_t)G.cap * 8);
+    double* hSx = (double*)G.pin; double* hMax = nullptr; int32_t* hFirst = nullptr; unsigned long long* hOut = (unsigned long long*)(G.pin + (size_t)G.pinCap * 8);
     memcpy(hSx, sx, (size_t)n * 8);
     const size_t nbk = (size_t)G.cap / AP_BK + 2;
     ArcHostReq q; q.hSx = hSx; q.hMax = hMax; q.hFirst = hFirst; q.hOut = hOut;
@@ -1957,10 +1987,16 @@ struct PermGpu {
     size_t reserveElems = 0, reserveN = 0;     // the call's longest chromosome: the first allocation is made for it (growing means hipFree + hipMalloc, which stall every stream of the device)
     size_t reserveBytes = 0, reservePin = 0;   // ... in bytes of device / pinned memory (perm_reserve_bytes)
     // analytic tail probability on the device (k_tail_nu): own stream, 3 x 128 values on the device and in pinned memory
-    hipStream_t tailStream = nullptr; char* tailDev = nullptr; char* tailPin = nullptr;
+    hipStream_t tailStream = nullptr; char* tailDev = nullptr; char* tailPin = nullptr; EngineCache* cache = nullptr;
+    bool tailOwned = true;        // false: the stream is one of the cache's shared ones (several engines enqueue their short tail kernels on it; each waits for the stream,
+                                  // i.e. at worst for a few other 10 us kernels) and the buffers are slices of its arena
     int32_t ensure_tail() {
         if (tailStream) return CANVAS_OK;
+        AllocClock ac(g_ns_alloc_tail);
         CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipStream_t sh = cache_tail_stream(cache); char* d = sh ? cache_take(cache, false, 128 * 24) : nullptr; char* p = d ? cache_take(cache, true, 128 * 24) : nullptr;
+        if (sh && d && p) { tailStream = sh; tailDev = d; tailPin = p; tailOwned = false; return CANVAS_OK; }
+        tailOwned = true;
         CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&tailStream, hipStreamNonBlocking));
         CANVAS_HIP_TRY(ctx, hipMalloc((void**)&tailDev, 128 * 24)); CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&tailPin, 128 * 24, hipHostMallocDefault));
         return CANVAS_OK;
@@ -1968,6 +2004,8 @@ struct PermGpu {
     // need: what the reservation asks for (the call's longest chromosome); minNeed: what this request cannot do without — taken when the reservation does not fit the device
     int32_t ensure(size_t need, size_t needPin, size_t minNeed = 0) {
         CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (need <= bytes && needPin <= pinBytes) return CANVAS_OK;
+        AllocClock ac(g_ns_alloc_perm);
         if (need > bytes) {
             if (buf) CANVAS_HIP_TRY(ctx, hipFree(buf));
             buf = nullptr; bytes = 0;
@@ -1980,7 +2018,7 @@ struct PermGpu {
         return CANVAS_OK;
     }
     ~PermGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (buf) (void)hipFree(buf); if (pin) (void)hipHostFree(pin);
-                 if (tailStream) { (void)hipStreamSynchronize(tailStream); (void)hipStreamDestroy(tailStream); } if (tailDev) (void)hipFree(tailDev); if (tailPin) (void)hipHostFree(tailPin); }
+                 if (tailStream && tailOwned) { (void)hipStreamSynchronize(tailStream); (void)hipStreamDestroy(tailStream); } if (tailDev && tailOwned) (void)hipFree(tailDev); if (tailPin && tailOwned) (void)hipHostFree(tailPin); }
 };
 static bool tpermp_device(PermGpu& PG, int n1, int n2, int n, const double* gd, int off, uint32_t nPerm, MT& rnd, Stats& st, double& p) {
     if (PG.ensure_tail() != CANVAS_OK) return false;
@@ -2025,16 +2063,19 @@ static int32_t tail_p_decide(PermGpu& PG, double b, double delta, int m, double 
 struct PermHostReq { PermReq r; long long prevTotal = 0; double* hStat; uint32_t* hSnaps; const double* hX = nullptr; double* dX = nullptr; size_t xBytes = 0;
                      const uint32_t* hDraws = nullptr; size_t drawBytes = 0;      // short segments: the draws of the batch, produced by the host generator
                      bool done = false; int32_t rc = CANVAS_OK; };
+// the device side of a launcher (its stream and request tables): kept by the context between calls — canvas_cbs builds seven launchers per call, and each paid a stream
+// creation and six small allocations on its first round
+struct SvcRes { hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; };
 struct PermService {
-    canvas_ctx* ctx; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
+    canvas_ctx* ctx; SvcRes* res = nullptr; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
     ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
     long long rounds = 0, nArc = 0, nPermReq = 0; double secArc = 0, secPerm = 0;
     bool probeTiming = false; double lastMs[3] = {0, 0, 0};      // canvas_cbs_perm_probe: generator (sequential + bootstrap), generator (strided), permutation + statistic of the last launch
     std::mutex mu; std::condition_variable cvWork, cvDone; std::vector<PermHostReq*> pending; bool stop = false; std::thread th; std::string err;
     explicit PermService(canvas_ctx* c) : ctx(c) { th = std::thread([this]() { run(); }); }
     ~PermService() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cvWork.notify_all(); th.join();
-        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dReqs) (void)hipFree(dReqs); if (hReqs) (void)hipHostFree(hReqs);
-        if (dArc) (void)hipFree(dArc); if (hArc) (void)hipHostFree(hArc); if (dArcP) (void)hipFree(dArcP); if (hArcP) (void)hipHostFree(hArcP); }
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (res) cache_svc_give(ctx, res); }
     int32_t submit(PermHostReq& q) {
         std::unique_lock<std::mutex> lk(mu);
         pending.push_back(&q);
@@ -2054,13 +2095,18 @@ struct PermService {
     int32_t init() {
         CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
         if (!stream) {
-            CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-            CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dReqs, cap * sizeof(PermReq)));
-            CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hReqs, cap * sizeof(PermReq), hipHostMallocDefault));
-            CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dArc, 64 * sizeof(ArcReq)));
-            CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hArc, 64 * sizeof(ArcReq), hipHostMallocDefault));
-            CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dArcP, 64 * sizeof(ArcPReq)));
-            CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&hArcP, 64 * sizeof(ArcPReq), hipHostMallocDefault));
+            AllocClock ac(g_ns_alloc_svc);
+            res = cache_svc_take(ctx);
+            if (!res->stream) {
+                CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking));
+                CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dReqs, cap * sizeof(PermReq)));
+                CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hReqs, cap * sizeof(PermReq), hipHostMallocDefault));
+                CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dArc, 64 * sizeof(ArcReq)));
+                CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hArc, 64 * sizeof(ArcReq), hipHostMallocDefault));
+                CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dArcP, 64 * sizeof(ArcPReq)));
+                CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hArcP, 64 * sizeof(ArcPReq), hipHostMallocDefault));
+            }
+            stream = res->stream; dReqs = res->dReqs; hReqs = res->hReqs; dArc = res->dArc; hArc = res->hArc; dArcP = res->dArcP; hArcP = res->hArcP;
         }
         return CANVAS_OK;
     }
@@ -2497,24 +2543,65 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
 }
 // the engines' buffers outlive a call: a thread borrows an ArcGpu / PermGpu from the context's cache and hands it back (the buffers only grow)
 struct EngineCache {
+    struct Slab { char* base = nullptr; size_t bytes = 0, off = 0; };
+    std::vector<Slab> devSlabs, pinSlabs; std::vector<hipStream_t> tailStreams; size_t nextTail = 0; std::vector<SvcRes*> svcFree, svcAll;
+    ~EngineCache() {
+        arcs.clear(); perms.clear(); tails.clear();           // (the engines first: they may still wait on a shared stream)
+        for (hipStream_t q : tailStreams) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+        for (SvcRes* r : svcAll) { if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); } if (r->dReqs) (void)hipFree(r->dReqs); if (r->hReqs) (void)hipHostFree(r->hReqs);
+                                   if (r->dArc) (void)hipFree(r->dArc); if (r->hArc) (void)hipHostFree(r->hArc); if (r->dArcP) (void)hipFree(r->dArcP); if (r->hArcP) (void)hipHostFree(r->hArcP); delete r; }
+        for (Slab& b : devSlabs) (void)hipFree(b.base);
+        for (Slab& b : pinSlabs) (void)hipHostFree(b.base);
+    }
+    // what the call is about to create: newArc arc engines for chromosomes of up to nMax bins, newTail tail engines.  A failure here only means the engines allocate for themselves.
+    void reserve(canvas_ctx* ctx, int wantArc, int wantTail, int nMax) {
+        std::lock_guard<std::mutex> lk(mu);
+        AllocClock ac(g_ns_alloc_svc);
+        if (hipSetDevice(ctx->device) != hipSuccess) return;
+        // engines in the cache whose buffers are too small for this call will allocate again: count them as new
+        int haveArc = 0; for (auto& a : arcs) if (a->cap >= nMax) haveArc++;
+        int haveTail = 0; for (auto& t : perms) if (t->tailStream) haveTail++; for (auto& t : tails) if (t->tailStream) haveTail++;
+        const int newArc = std::max(0, wantArc - haveArc), newTail = std::max(0, wantTail - haveTail);
+        size_t aDev = 0, aPin = 0; ArcGpu::arena_bytes(nMax, aDev, aPin);
+        const size_t dev = (size_t)newArc * (aDev + 512) + (size_t)newTail * (128 * 24 + 512), pin = (size_t)newArc * (aPin + 512) + (size_t)newTail * (128 * 24 + 512);
+        auto left = [](std::vector<Slab>& v) { return v.empty() ? size_t(0) : v.back().bytes - v.back().off; };
+        if (dev > left(devSlabs)) { Slab b; b.bytes = dev + (1u << 16); if (hipMalloc((void**)&b.base, b.bytes) == hipSuccess) devSlabs.push_back(b); else (void)hipGetLastError(); }
+        if (pin > left(pinSlabs)) { Slab b; b.bytes = pin + (1u << 16); if (hipHostMalloc((void**)&b.base, b.bytes, hipHostMallocDefault) == hipSuccess) pinSlabs.push_back(b); else (void)hipGetLastError(); }
+        while (newTail > 0 && tailStreams.size() < 16) { hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; } tailStreams.push_back(q); }
+    }
+    char* take(bool pinned, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<Slab>& v = pinned ? pinSlabs : devSlabs;
+        if (v.empty()) return nullptr;
+        Slab& b = v.back(); const size_t at = (b.off + 255) & ~size_t(255);
+        if (at + bytes > b.bytes) return nullptr;
+        b.off = at + bytes; return b.base + at;
+    }
+    hipStream_t tail_stream() { std::lock_guard<std::mutex> lk(mu); if (tailStreams.empty()) return nullptr; return tailStreams[nextTail++ % tailStreams.size()]; }
+    SvcRes* svc_take() { std::lock_guard<std::mutex> lk(mu); if (!svcFree.empty()) { SvcRes* r = svcFree.back(); svcFree.pop_back(); return r; } SvcRes* r = new SvcRes(); svcAll.push_back(r); return r; }
+    void svc_give(SvcRes* r) { std::lock_guard<std::mutex> lk(mu); svcFree.push_back(r); }
     std::mutex mu; std::vector<std::unique_ptr<ArcGpu>> arcs; std::vector<std::unique_ptr<PermGpu>> perms, tails;      // tails: engines of the helper threads (tail series only: they never grow a permutation workspace and must not take one of those away from a chromosome thread)
     static EngineCache& of(canvas_ctx* ctx) {
         static std::mutex g; std::lock_guard<std::mutex> lk(g);
         if (!ctx->cbs_cache) ctx->cbs_cache = std::shared_ptr<void>(new EngineCache(), [](void* p) { delete (EngineCache*)p; });
         return *(EngineCache*)ctx->cbs_cache.get();
     }
-    std::unique_ptr<ArcGpu> arc(canvas_ctx* ctx, PermService* svc) { std::unique_ptr<ArcGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!arcs.empty()) { g = std::move(arcs.back()); arcs.pop_back(); } } if (!g) { g.reset(new ArcGpu()); g->ctx = ctx; } g->svc = svc; return g; }
-    std::unique_ptr<PermGpu> perm(canvas_ctx* ctx, PermService* svc) { std::unique_ptr<PermGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!perms.empty()) { g = std::move(perms.back()); perms.pop_back(); } } if (!g) { g.reset(new PermGpu()); g->ctx = ctx; } g->svc = svc; return g; }
-    std::unique_ptr<PermGpu> tail(canvas_ctx* ctx) { std::unique_ptr<PermGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!tails.empty()) { g = std::move(tails.back()); tails.pop_back(); } } if (!g) { g.reset(new PermGpu()); g->ctx = ctx; } g->svc = nullptr; return g; }
+    std::unique_ptr<ArcGpu> arc(canvas_ctx* ctx, PermService* svc) { std::unique_ptr<ArcGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!arcs.empty()) { g = std::move(arcs.back()); arcs.pop_back(); } } if (!g) { g.reset(new ArcGpu()); g->ctx = ctx; } g->svc = svc; g->cache = this; return g; }
+    std::unique_ptr<PermGpu> perm(canvas_ctx* ctx, PermService* svc) { std::unique_ptr<PermGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!perms.empty()) { g = std::move(perms.back()); perms.pop_back(); } } if (!g) { g.reset(new PermGpu()); g->ctx = ctx; } g->svc = svc; g->cache = this; return g; }
+    std::unique_ptr<PermGpu> tail(canvas_ctx* ctx) { std::unique_ptr<PermGpu> g; { std::lock_guard<std::mutex> lk(mu); if (!tails.empty()) { g = std::move(tails.back()); tails.pop_back(); } } if (!g) { g.reset(new PermGpu()); g->ctx = ctx; } g->svc = nullptr; g->cache = this; return g; }
     void give_tail(std::unique_ptr<PermGpu> g) { std::lock_guard<std::mutex> lk(mu); tails.push_back(std::move(g)); }
     void give(std::unique_ptr<ArcGpu> g) { std::lock_guard<std::mutex> lk(mu); arcs.push_back(std::move(g)); }
     void give(std::unique_ptr<PermGpu> g) { std::lock_guard<std::mutex> lk(mu); perms.push_back(std::move(g)); }
 };
+static char* cache_take(EngineCache* ec, bool pinned, size_t bytes) { return ec ? ec->take(pinned, bytes) : nullptr; }
+static hipStream_t cache_tail_stream(EngineCache* ec) { return ec ? ec->tail_stream() : nullptr; }
+static SvcRes* cache_svc_take(canvas_ctx* ctx) { return EngineCache::of(ctx).svc_take(); }
+static void cache_svc_give(canvas_ctx* ctx, SvcRes* r) { EngineCache::of(ctx).svc_give(r); }
 // helper threads of phase 1 (own arc-search and tail-series buffers each); a chromosome thread that needs a segment no helper has started yet runs it itself
 #define CBS_SPEC_MIN_N 4
 struct SpecTask { const double* gd; int cn; std::atomic<bool> guess{false}; Phase1 out; std::atomic<int> state{0}; };      // 0 queued, 1 running, 2 done; guess: put there by a helper, not (yet) asked for by the recursion
 struct SpecPool {
-    canvas_ctx* ctx; PermService** arcSvcs; int nArcSvc; uint32_t nPerm; double cutoff; Stats* st; std::atomic_int nextArc{0};
+    canvas_ctx* ctx; PermService** arcSvcs; int nArcSvc; uint32_t nPerm; double cutoff; Stats* st; std::atomic_int nextArc{0}; int reserveN = 0;      // reserveN: the call's longest chromosome (the helpers' arc engines are allocated for it)
     std::mutex mu; std::condition_variable cvWork, cvDone; std::deque<std::shared_ptr<SpecTask>> queue; bool stopping = false; std::vector<std::thread> workers;
     // every task of the call by (data pointer, length): a segment is looked up here before anything is computed for it.  Helpers put the segments a finished phase 1 makes
     // LIKELY there as well — its two candidate change points are the arc maximiser's (iseg); if the tests of phase 2 keep both, the children are [0, i0), [i0, i1), [i1, n) —
@@ -2550,6 +2637,7 @@ struct SpecPool {
         for (int i = 0; i < n; i++) workers.emplace_back([this]() {
             EngineCache& cache = EngineCache::of(ctx);
             std::unique_ptr<ArcGpu> gp = cache.arc(ctx, arcSvcs[nextArc++ % nArcSvc]); std::unique_ptr<PermGpu> pgp = cache.tail(ctx);
+            gp->reserveN = reserveN;
             struct Back { EngineCache& c; std::unique_ptr<ArcGpu>& a; std::unique_ptr<PermGpu>& p; ~Back() { c.give(std::move(a)); c.give_tail(std::move(p)); } } back{cache, gp, pgp};
             ArcGpu& G = *gp; PermGpu& PG = *pgp;
             for (;;) {
@@ -2849,9 +2937,12 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     std::mutex chromMu; double maxChromSec = 0, sumChromSec = 0, slowSec = 0; std::string slowLine; const bool timing = cvx_hook("CANVAS_CBS_TIMING") != nullptr;
     // helper threads for the deterministic front half of every segment on a recursion stack (cbs::SpecPool); CANVAS_CBS_NO_SPECULATION=1: the plain sequential order (test hook)
     std::unique_ptr<cbs::SpecPool> specPool;
-    if (!cvx_hook("CANVAS_CBS_NO_SPECULATION")) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nArcSvc, nperm, alpha, &st}); specPool->start((int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4))); }
     unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
     const int nthreads = (int)std::min<unsigned>(hw, (unsigned)nchr);
+    const int nHelpers = cvx_hook("CANVAS_CBS_NO_SPECULATION") ? 0 : (int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4));
+    // one device slab, one pinned slab and the shared tail streams for every engine this call is about to create (chromosome threads + helpers): cbs::EngineCache
+    if (!cvx_hook("CANVAS_CBS_NO_ARENA")) cbs::EngineCache::of(ctx).reserve(ctx, nthreads + nHelpers, nthreads + nHelpers, (int)std::min<long long>(nMax, 0x7FFFFFF0ll));
+    if (nHelpers) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nArcSvc, nperm, alpha, &st}); specPool->reserveN = (int)nMax; specPool->start(nHelpers); }
     size_t perEngineBudget = ~size_t(0);
     { size_t freeB = 0, totB = 0; if (hipMemGetInfo(&freeB, &totB) == hipSuccess) perEngineBudget = (freeB / 2) / (size_t)std::max(1, nthreads); }
     auto work = [&]() {
@@ -2859,6 +2950,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
         std::unique_ptr<cbs::PermGpu> pgp = cache.perm(ctx, permServices[(size_t)(nextService++ % nPermSvc)]); std::unique_ptr<cbs::ArcGpu> gp = cache.arc(ctx, arcServices[nextArc++ % nArcSvc]);
         struct Back { cbs::EngineCache& c; std::unique_ptr<cbs::ArcGpu>& a; std::unique_ptr<cbs::PermGpu>& p; ~Back() { c.give(std::move(a)); c.give(std::move(p)); } } back{cache, gp, pgp};
         cbs::PermGpu& PG = *pgp; cbs::ArcGpu& G = *gp;
+        G.reserveN = (int)nMax;
         // the first allocation of an engine is made for the call's longest chromosome (growing later means hipFree + hipMalloc, which stall every stream of the device) —
         // as long as all engines of the call together stay inside half of what the device has free: many contigs on a many-core host, or several contexts on one GPU,
         // would otherwise run out of memory where grow-on-demand engines fit
@@ -2886,6 +2978,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     ctx->cbs_tpermp[0] = st.tpermp_device; ctx->cbs_tpermp[1] = st.tpermp_draws;
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
     ctx->cbs_tailp[0] = st.tailp_dev; ctx->cbs_tailp[1] = st.tailp_host;
+    if (timing) fprintf(stderr, "cbs allocation / stream creation, thread-seconds: arc engines %.3f, permutation engines %.3f, tail engines %.3f, launchers %.3f\n", cbs::g_ns_alloc_arc.exchange(0) * 1e-9, cbs::g_ns_alloc_perm.exchange(0) * 1e-9, cbs::g_ns_alloc_tail.exchange(0) * 1e-9, cbs::g_ns_alloc_svc.exchange(0) * 1e-9);
     if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());
     if (timing) fprintf(stderr, "cbs arc searches whose best admissible arc the reference does not scan (replayed on the host): %lld\n", (long long)st.unscanned_max.load());
     if (timing && specPool) fprintf(stderr, "cbs helpers: %lld segments guessed from a finished phase 1, %lld of them asked for by the recursion\n", (long long)specPool->guessed.load(), (long long)specPool->guessedUsed.load());
