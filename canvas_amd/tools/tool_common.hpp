@@ -12,6 +12,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,6 +31,10 @@ __attribute__((used)) static const char tool_src_hash_marker[] = "CANVAS_SRC_HAS
 // ---- big host buffers (bases, hits, fragment lengths: gigabytes per run) come from 2 MB-aligned anonymous mappings advised to transparent huge pages: the box runs THP
 // in "madvise" mode, and 4 KB pages cost a fault per page while a file is read plus 0.5 s of page freeing when the process leaves.  Everything below 8 MB is malloc's.
 // (each tool is one translation unit: the replaced global operators live here.)  CANVAS_TOOL_NO_HUGEPAGES=1 keeps malloc for everything.
+// This header DEFINES the global operators: it must be part of exactly one translation unit per executable.  A second inclusion is a duplicate-symbol error at link time
+// (the definition below has external linkage on purpose) instead of an ODR violation nobody sees.  Memory released by a library that carries its own allocator never
+// reaches these operators (libcanvas_hip.so hands out no ownership of host memory); blocks of 8 MB and more that such a library allocates for itself are its own business.
+extern "C" { int canvas_tool_common_hpp_is_in_one_translation_unit = 1; }
 namespace tool { struct BigAllocs { std::mutex m; std::map<void*, size_t> len; }; static inline BigAllocs& big_allocs() { static BigAllocs* b = new BigAllocs; return *b; } }
 void* operator new(size_t n) {
     static const bool huge = !getenv("CANVAS_TOOL_NO_HUGEPAGES");
@@ -90,9 +95,10 @@ struct GzReader { gzFile f; explicit GzReader(const std::string& path) { f = gzo
         while (gzgets(f, buf, sizeof buf)) { any = true; out += buf; if (!out.empty() && out.back() == '\n') break; }
         while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
         return any; } };
-struct GzWriter { gzFile f; explicit GzWriter(const std::string& path) { f = gzopen(path.c_str(), "wb"); } ~GzWriter() { if (f) gzclose(f); }
+static std::atomic<int> g_open_writers{0};      // output objects that still hold buffered data: finish() leaves without unwinding only when there is none
+struct GzWriter { gzFile f; explicit GzWriter(const std::string& path) { f = gzopen(path.c_str(), "wb"); if (f) g_open_writers++; } ~GzWriter() { close(); }
     bool ok() const { return f != nullptr; } void line(const std::string& s) { gzwrite(f, s.data(), (unsigned)s.size()); gzputc(f, '\n'); }
-    void close() { if (f) { gzclose(f); f = nullptr; } } };
+    void close() { if (f) { gzclose(f); f = nullptr; g_open_writers--; } } };
 static std::vector<std::string> split_tab(const std::string& s) { std::vector<std::string> r; size_t a = 0; for (;;) { size_t b = s.find('\t', a); r.push_back(s.substr(a, b == std::string::npos ? b : b - a)); if (b == std::string::npos) break; a = b + 1; } return r; }
 static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) { fclose(f); return true; } return false; }
 
@@ -182,6 +188,7 @@ struct AsyncCtx {
 // the HIP runtime's own teardown cost 0.1-0.6 s of wall time and change nothing on disk).  CANVAS_TOOL_FULL_TEARDOWN=1 returns through main instead.
 static inline int finish(Phases& ph, int rc) {
     ph.report(); fflush(stdout); fflush(stderr);
+    if (g_open_writers.load() != 0) return rc;      // (a writer that is still open flushes in its destructor: leave through main)
     if (!getenv("CANVAS_TOOL_FULL_TEARDOWN")) _exit(rc);
     return rc;
 }
