@@ -164,3 +164,24 @@ def test_quartiles_by_counting_fall_back_to_the_radix_select(case, monkeypatch):
     elif case == "negative_zero":
         cov = cov.copy(); cov[5] = -0.0
     _check(cv, bins, cov, off)
+
+
+def test_sample_whose_median_coverage_is_zero_takes_the_sequential_kernel():
+    """The one kind of PerSampleHMM call the speculative attempts give up on, caught in a noise-40 soak and kept as a fixture (tests/golden/viterbi_fallback_median0.npz: the 413
+    bins CanvasClean left of a 600 000-bin sample whose counts were clipped noise; seed 1531490205 of tools/soak.py): three quarters of the coverage are 0, so the sample's
+    median — the model's haploid mean — is 0, every state's emission probability is 0 for every bin with coverage, and the reference's best state is -1 at every position
+    (HMM.cs:100-111).  The speculative passes compare log-likelihoods that are all -inf: every attempt fails its exact comparison (CANVAS_HMM_DEBUG_FAIL: why = 0x19) and the
+    sequential kernel reproduces the reference's all -1 path."""
+    import os, torch
+    cv = get_canvas()
+    cv.profile_enable(True)
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "viterbi_fallback_median0.npz"))
+    cov, off = np.ascontiguousarray(d["cov"], np.float64), np.asarray(d["off"], np.int64)
+    assert np.median(cov) == 0.0 and cov.max() > 100.0
+    per = [np.ascontiguousarray(cov[off[c]:off[c + 1]]) for c in range(len(off) - 1)]
+    paths, ran = O.hmm_genome_per_sample(per, threads=1)
+    assert ran[0] == 1 and (paths[0] == -1).all()
+    cv.profile_get("viterbi_sequential", reset=True)
+    st = cv.hmm_per_sample(torch.from_numpy(cov).to(cv.device), off).cpu().numpy()
+    assert (st == paths[0]).all()
+    assert cv.profile_get("viterbi_sequential")[1] == 1

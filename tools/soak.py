@@ -66,6 +66,8 @@ while time.time() - t0 < budget:
             key = min(20, int(rr / 0.05)); dv = by_disp.setdefault(key, [0, 0]); dv[0] += 1; dv[1] += 1 if r1 else 0
         if f1: fb[(n, nchr, float(noise))] = fb.get((n, nchr, float(noise)), 0) + 1
         hc = cov.cpu().numpy()
+        if f1 and os.environ.get("SOAK_DUMP"):     # a sample whose speculative attempts all failed: the coverage PerSampleHMM saw, for a look at it on the CPU
+            np.savez(os.path.join(os.environ["SOAK_DUMP"], "viterbi_fallback_%d.npz" % int(fallbacks)), cov=hc, off=np.asarray(off), seed=seed, n=n, nchr=nchr, noise=noise)
         per = [np.ascontiguousarray(hc[off[c]:off[c + 1]]) for c in range(nchr)]
         paths, ran = O.hmm_genome_per_sample(per, threads=8)
         for c in range(nchr):
