@@ -179,10 +179,10 @@ int main(int argc, char** argv) {
         const Sample& S0 = samples[0]; const int nchr = (int)S0.chromNames.size(); const int64_t N = S0.off.back();
         for (auto& S : samples) if (S.off != S0.off) { fprintf(stderr, "CanvasPartition: -m HMM needs the same bins in every input\n"); return 1; }
         if (N > 0) {
-            std::vector<Dev> dCovs; dCovs.reserve(samples.size());      // no reallocation: Dev owns device memory
+            std::vector<std::unique_ptr<Dev>> dCovs;
             std::vector<const double*> ptrs;
-            for (auto& S : samples) { dCovs.emplace_back(ctx, N * 8); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCovs.back().p, S.cov.data(), N * 8)); }
-            for (auto& d : dCovs) ptrs.push_back(d.as<double>());
+            for (auto& S : samples) { dCovs.push_back(std::make_unique<Dev>(ctx, N * 8)); TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dCovs.back()->p, S.cov.data(), N * 8)); }
+            for (auto& d : dCovs) ptrs.push_back(d->as<double>());
             Dev dState(ctx, N * 4);
             TOOL_TRY(ctx, canvas_hmm_joint(ctx, (int32_t)samples.size(), nchr, ptrs.data(), S0.off.data(), dState.as<int32_t>()));
             std::vector<int32_t> state(N); TOOL_TRY(ctx, canvas_memcpy_d2h(ctx, state.data(), dState.p, N * 4));

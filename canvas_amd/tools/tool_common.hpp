@@ -13,6 +13,7 @@
 #include <functional>
 #include <map>
 #include <atomic>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -155,6 +156,7 @@ struct Dev {      // tiny RAII around the ABI's device memory
     canvas_ctx* ctx; void* p = nullptr;
     Dev(canvas_ctx* c, int64_t bytes) : ctx(c) { p = canvas_device_malloc(c, bytes > 0 ? bytes : 1); }
     ~Dev() { if (p) canvas_device_free(ctx, p); }
+    Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
     template <class T> T* as() { return (T*)p; }
 };
 // wall-clock phases of a tool run, printed as one JSON line on stderr when CANVAS_TOOL_TIMING is set (bench.py's `executables` leg: what part of a run is file I/O)
@@ -170,8 +172,18 @@ struct Phases {
         reported = true;
         std::string js = std::string("{\"tool\": \"") + tool + "\", \"phases\": {"; double prev = t0;
         for (size_t i = 0; i < v.size(); i++) { char b[96]; snprintf(b, sizeof b, "%s\"%s\": %.4f", i ? ", " : "", v[i].first.c_str(), v[i].second - prev); js += b; prev = v[i].second; }
-        char b[64]; snprintf(b, sizeof b, "}, \"total\": %.4f}", now() - t0); js += b;
+        // (wall-clock stamps of the first and the last statement of main: what lies outside them — the loader in front, the kernel's teardown of the process behind — is the
+        // difference to the caller's own clock around the process, tools/exe_probe.sh)
+        struct timespec tr; clock_gettime(CLOCK_REALTIME, &tr); const double real = (double)tr.tv_sec + 1e-9 * (double)tr.tv_nsec;
+        char b[160]; snprintf(b, sizeof b, "}, \"total\": %.4f, \"main_entered_unix\": %.4f, \"leaving_unix\": %.4f}", now() - t0, real - (now() - t0), real); js += b;
         fprintf(stderr, "%s\n", js.c_str());
+        if (FILE* f = fopen("/proc/self/smaps_rollup", "r")) {      // how much of the process is resident, and how much of that in transparent huge pages (what leaving the process has to give back)
+            char line[256]; std::string rss, thp;
+            while (fgets(line, sizeof line, f)) { if (!strncmp(line, "Rss:", 4)) rss = line + 4; if (!strncmp(line, "AnonHugePages:", 14)) thp = line + 14; }
+            fclose(f);
+            auto trim = [](std::string v) { while (!v.empty() && (v.back() == '\n' || v.back() == ' ')) v.pop_back(); size_t a = v.find_first_not_of(' '); return a == std::string::npos ? std::string() : v.substr(a); };
+            fprintf(stderr, "[memory] resident %s, of it in transparent huge pages %s\n", trim(rss).c_str(), trim(thp).c_str());
+        }
     }
 };
 // The GPU context is created on a helper thread while the main thread reads and parses the input files (HIP initialisation + the context's pinned buffers and streams
@@ -189,6 +201,11 @@ struct AsyncCtx {
 static inline int finish(Phases& ph, int rc) {
     ph.report(); fflush(stdout); fflush(stderr);
     if (g_open_writers.load() != 0) return rc;      // (a writer that is still open flushes in its destructor: leave through main)
+    // Leaving costs CanvasBin as much as its longest phase, and nothing done here changes it (measured, tools/exe_probe.sh + tools/exit_probe.sh: stamps of main's last
+    // statement against the caller's clock): 0.43 s pass between _exit and the caller's wait returning, of which 0.26 s is the kernel giving back 7.6 GB of resident host
+    // pages — 37 ms per GB, with or without a GPU in the process — and 0.07-0.09 s the driver's release of a process that has used the device.  Freeing the device buffers and
+    // destroying the context first (4 ms) leaves the figure where it is, handing the pages to a forked child makes it worse (0.47 s), and unwinding main frees the same pages in
+    // user space for the same price.  What would help is holding less anonymous memory: binning straight from the mapped .dat / FASTA files.
     if (!getenv("CANVAS_TOOL_FULL_TEARDOWN")) _exit(rc);
     return rc;
 }

@@ -16,7 +16,9 @@ root=$(cat /tmp/exe_root.txt); cmd=$(cat $root/bin_cmd.txt)
 export CANVAS_TOOL_TIMING=1
 TIMEFORMAT="wall %R"
 t() { time "$@" > /dev/null; }
-echo "== default"; t $cmd
+stamp() { echo "caller clock: before the spawn $1, after the wait $(date +%s.%N)"; }
+echo "== default"; b=$(date +%s.%N); t $cmd; stamp $b
+echo "== default, again"; b=$(date +%s.%N); t $cmd; stamp $b
 echo "== full teardown"; export CANVAS_TOOL_FULL_TEARDOWN=1; t $cmd; date +%s.%N; unset CANVAS_TOOL_FULL_TEARDOWN
 echo "== help"; t canvas_amd/bin/CanvasBin -h
 grep -i "thp\|AnonHugePages" /proc/meminfo; cat /sys/kernel/mm/transparent_hugepage/enabled /sys/kernel/mm/transparent_hugepage/defrag; nproc; free -g | head -2
