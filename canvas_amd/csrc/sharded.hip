@@ -538,54 +538,87 @@ extern "C" int32_t canvas_cbs_sharded(canvas_ctx* ctx, int32_t nchr, const int32
 static int32_t shard_ws_reserve(canvas_ctx* ctx, size_t need);
 // PerSampleHMM with the chromosomes sharded over the ranks, on a coverage every rank holds (e.g. behind the bin intersection of a pedigree: the step that lies between
 // CanvasClean and CanvasPartition there, so canvas_sample_pipeline_sharded cannot serve it).  The emission parameters come from the quartiles of the WHOLE coverage
-// (HiddenMarkovModelsRunner.cs:36-50); a rank runs the Viterbi passes of its own chromosomes (cvx_hmm_per_sample_subset on a compact copy) and one exchange of the state runs
-// [chromosome, 2 k, (first bin, state) x k] gives every rank every chromosome's path.
+// (HiddenMarkovModelsRunner.cs:36-50); a rank runs the Viterbi passes of its own chromosomes (cvx_hmm_per_sample_subset on a compact copy).  The result never leaves the device
+// (round 5; before, the states went to the host, became run lists there, were gathered, expanded on the host and uploaded again): the state runs are recorded by the kernels
+// of the sharded pipeline (k_sh_flags / k_sh_count / k_sh_scan / k_sh_scatter / k_sh_ends: (chromosome, first bin, last bin, state) per run), gathered by
+// canvas_allgather_boundaries' collective (ncclAllGather on an RCCL communicator) and expanded by k_sh_fill_state into every rank's d_state.  The host sees one count.
 extern "C" int32_t canvas_hmm_per_sample_sharded(canvas_ctx* ctx, int32_t nchr, const int32_t* h_chr_owner, const double* d_cov, const int64_t* h_chr_offset, int32_t* d_state) {
     if (!ctx) return CANVAS_ERR_INVALID;
     const char* what = "canvas_hmm_per_sample_sharded";
     int32_t rc = check_owner_table(ctx, nchr, h_chr_owner, what); if (rc) return rc;
     if (!h_chr_offset || !d_cov || !d_state || h_chr_offset[0] != 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample_sharded: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->nranks;
     const int64_t N = h_chr_offset[nchr];
-    std::vector<int> mine; std::vector<int64_t> loff{0};
+    if (N >= 0x7FFFFFF0ll / 4) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_hmm_per_sample_sharded: too many bins");
+    std::vector<int> mine; std::vector<long long> loff{0};
     for (int c = 0; c < nchr; c++) if (h_chr_owner[c] == ctx->rank) { mine.push_back(c); loff.push_back(loff.back() + (h_chr_offset[c + 1] - h_chr_offset[c])); }
     const int nl = (int)mine.size(); const int64_t nLocal = loff.back();
-    int32_t localErr = CANVAS_OK; std::string localMsg;
-    std::vector<int32_t> hState((size_t)std::max<int64_t>(nLocal, 1));
-    if (nLocal > 0) {
-        auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-        localErr = shard_ws_reserve(ctx, al((size_t)nLocal * 8) + al((size_t)nLocal * 4) + 256);
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    // persistent buffers of this rank (one allocation: growing it frees the old one): compact coverage and states, record flags, block counts, tables
+    const int nb = (int)((nLocal + SH_BLK - 1) / SH_BLK);
+    const size_t oCov = 0, oState = oCov + al((size_t)std::max<int64_t>(nLocal, 1) * 8), oFlags = oState + al((size_t)std::max<int64_t>(nLocal, 1) * 4), oBlk = oFlags + al((size_t)nLocal + 16),
+                 oNrec = oBlk + al((size_t)(nb + 2) * 4), oLoff = oNrec + 256, oL2G = oLoff + al((size_t)(nl + 1) * 8), oOwner = oL2G + al((size_t)(nl + 1) * 4), oChrOff = oOwner + al((size_t)nchr * 4),
+                 oBad = oChrOff + al((size_t)(nchr + 1) * 8), totalB = oBad + 256;
+    int32_t localErr = shard_ws_reserve(ctx, totalB); std::string localMsg;
+    if (localErr) localMsg = ctx->err;
+    char* S = (char*)ctx->shard_ws;
+    double* dCovL = (double*)(S + oCov); int32_t* dStateL = (int32_t*)(S + oState); uint8_t* dFlags = (uint8_t*)(S + oFlags); uint32_t* dBlk = (uint32_t*)(S + oBlk); unsigned int* dNrec = (unsigned int*)(S + oNrec);
+    long long* dLoff = (long long*)(S + oLoff); int32_t* dL2G = (int32_t*)(S + oL2G); int32_t* dOwner = (int32_t*)(S + oOwner); long long* dChrOff = (long long*)(S + oChrOff); int* dBad = (int*)(S + oBad);
+    auto fail_local = [&](int32_t code) { if (!localErr) { localErr = code; localMsg = ctx->err; } };
+    if (!localErr && nLocal > 0) {
+        for (int i = 0; i < nl && !localErr; i++) { const int64_t T = loff[(size_t)i + 1] - loff[(size_t)i];
+            if (T > 0 && hipMemcpyAsync(dCovL + loff[(size_t)i], d_cov + h_chr_offset[mine[(size_t)i]], (size_t)T * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = std::string(what) + ": copy of the owned coverage failed"; fail_local(CANVAS_ERR_HIP); } }
+        if (!localErr) { std::vector<int64_t> loff64(loff.begin(), loff.end()); int32_t rch = cvx_hmm_per_sample_subset(ctx, nl, dCovL, loff64.data(), d_cov, N, dStateL, nullptr); if (rch) fail_local(rch); }
+        std::vector<int32_t> l2g(mine.begin(), mine.end());
+        if (!localErr) { int32_t r2 = canvas_h2d_small(ctx, dLoff, loff.data(), (size_t)(nl + 1) * 8); if (r2) fail_local(r2); }
+        if (!localErr) { int32_t r2 = canvas_h2d_small(ctx, dL2G, l2g.data(), (size_t)nl * 4); if (r2) fail_local(r2); }
         if (!localErr) {
-            double* dCovL = (double*)ctx->shard_ws; int32_t* dStateL = (int32_t*)((char*)ctx->shard_ws + al((size_t)nLocal * 8));
-            for (int i = 0; i < nl && !localErr; i++) { const int64_t T = loff[(size_t)i + 1] - loff[(size_t)i];
-                if (T > 0 && hipMemcpyAsync(dCovL + loff[(size_t)i], d_cov + h_chr_offset[mine[(size_t)i]], (size_t)T * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = std::string(what) + ": copy of the owned coverage failed"; localErr = CANVAS_ERR_HIP; } }
-            if (!localErr) localErr = cvx_hmm_per_sample_subset(ctx, nl, dCovL, loff.data(), d_cov, N, dStateL, nullptr);
-            if (!localErr && (hipMemcpyAsync(hState.data(), dStateL, (size_t)nLocal * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) { ctx->err = std::string(what) + ": copy of the states failed"; localErr = CANVAS_ERR_HIP; }
-        }
-        if (localErr) localMsg = ctx->err;
-    }
-    std::vector<int32_t> list;
-    if (!localErr) for (int i = 0; i < nl; i++) {
-        const int32_t* st = hState.data() + loff[(size_t)i]; const int64_t T = loff[(size_t)i + 1] - loff[(size_t)i];
-        list.push_back(mine[(size_t)i]); const size_t at = list.size(); list.push_back(0);
-        for (int64_t t = 0; t < T; t++) if (t == 0 || st[t] != st[t - 1]) { list.push_back((int32_t)t); list.push_back(st[t]); }
-        list[at] = (int32_t)(list.size() - at - 1);
-    }
-    std::vector<std::vector<int32_t>> all, perChr;
-    rc = exchange_lists(ctx, list, localErr, localMsg, 2 * N + 2 * (int64_t)nchr + 16, what, all); if (rc) return rc;
-    rc = lists_by_chromosome(ctx, nchr, h_chr_owner, all, what, perChr); if (rc) return rc;
-    std::vector<int32_t> flat((size_t)std::max<int64_t>(N, 1), -1);
-    for (int c = 0; c < nchr; c++) {
-        const int64_t b0 = h_chr_offset[c], T = h_chr_offset[c + 1] - b0; const std::vector<int32_t>& r = perChr[(size_t)c];
-        if ((r.size() & 1) || (T > 0 && (r.empty() || r[0] != 0))) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_hmm_per_sample_sharded: the gathered state runs of a chromosome do not start at its first bin");
-        for (size_t k = 0; k + 1 < r.size(); k += 2) {
-            const int64_t a = r[k], e = k + 2 < r.size() ? r[k + 2] : T;
-            if (a < 0 || e > T || e <= a) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "canvas_hmm_per_sample_sharded: the gathered state runs of a chromosome are not increasing");
-            std::fill(flat.begin() + b0 + a, flat.begin() + b0 + e, r[k + 1]);
+            hipLaunchKernelGGL(k_sh_flags, dim3((unsigned)((nLocal + 255) / 256)), dim3(256), 0, ctx->stream, dStateL, dLoff, nl, nLocal, dFlags);
+            hipLaunchKernelGGL(k_sh_count, dim3(nb), dim3(256), 0, ctx->stream, dFlags, nLocal, dBlk);
+            hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(64), 0, ctx->stream, dBlk, nb, dNrec);
         }
     }
-    if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_state, flat.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!localErr) { int32_t r2 = canvas_h2d_small(ctx, dOwner, h_chr_owner, (size_t)nchr * 4); if (r2) fail_local(r2); }
+    // every rank derives the same first bound (a run per 256 bins and two per chromosome: a WGS path has a few hundred runs) and the same hard one (a run per bin)
+    int32_t maxPer = (int32_t)std::min<long long>(4ll * (N / 256 + 2ll * nchr + 64), 0x7FFFFFF0ll);
+    const long long hardMax = std::min<long long>(4ll * (N + nchr + 16), 0x7FFFFFF0ll);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const size_t recBytes = al((size_t)maxPer * 4) + al((size_t)W * (1 + (size_t)maxPer) * 4) + 4096;
+        rc = canvas_ws_reserve(ctx, recBytes + (size_t)(1 + maxPer) * 4 + 4096); if (rc) return rc;      // (the same allocation on every rank)
+        char* wsb = (char*)ctx->ws + al((size_t)(1 + maxPer) * 4 + 256);      // canvas_allgather_boundaries packs into the FRONT of the workspace
+        int32_t* dRec = (int32_t*)wsb; int32_t* dAll = (int32_t*)(wsb + al((size_t)maxPer * 4));
+        unsigned int nrec = 0;
+        if (nLocal > 0 && !localErr) {
+            hipLaunchKernelGGL(k_sh_scatter, dim3(nb), dim3(256), 0, ctx->stream, dFlags, dBlk, dStateL, dLoff, dL2G, nl, nLocal, maxPer / 4, dRec);
+            hipLaunchKernelGGL(k_sh_ends, dim3((unsigned)((maxPer / 4 + 255) / 256)), dim3(256), 0, ctx->stream, dRec, dNrec, maxPer / 4);
+            if (hipMemcpyAsync(&nrec, dNrec, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = std::string(what) + ": the record count did not come back"; fail_local(CANVAS_ERR_HIP); }
+        }
+        const int32_t nrecInts = (int32_t)std::min<long long>((long long)nrec * 4, maxPer);
+        std::vector<int32_t> counts((size_t)W, 0);
+        rc = cvx_allgather_boundaries_status(ctx, dRec, localErr ? (localErr < 0 ? localErr : -localErr) : nrecInts, maxPer, dAll, counts.data()); if (rc) return rc;
+        for (int r = 0; r < W; r++) if (counts[(size_t)r] < 0) {
+            if (localErr) { ctx->err = localMsg; return localErr; }
+            CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string(what) + ": rank " + std::to_string(r) + " failed before the exchange (code " + std::to_string(counts[(size_t)r]) + ")");
+        }
+        bool overflow = (long long)nrec * 4 >= maxPer;
+        for (int r = 0; r < W; r++) if (counts[(size_t)r] >= maxPer) overflow = true;
+        if (overflow && attempt == 0 && maxPer < hardMax) { maxPer = (int32_t)hardMax; continue; }
+        if (overflow) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, std::string(what) + ": the state runs do not fit the exchange");
+        if (N > 0) {
+            std::vector<long long> chrOff64(h_chr_offset, h_chr_offset + nchr + 1);
+            rc = canvas_h2d_small(ctx, dChrOff, chrOff64.data(), (size_t)(nchr + 1) * 8); if (rc) return rc;
+            CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_sh_fill_state, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, dAll, 1 + maxPer, dOwner, dChrOff, nchr, N, d_state, dBad);
+            int bad = 0;
+            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipGetLastError());
+            if (bad) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, std::string(what) + ": the gathered state runs do not cover every bin");
+        }
+        ctx->shard_stats[0] = W; ctx->shard_stats[1] = nl; ctx->shard_stats[4] = nrec; ctx->shard_stats[5] = (long long)(1 + maxPer) * 4;
+        return CANVAS_OK;
+    }
     return CANVAS_OK;
 }
 

@@ -924,3 +924,66 @@ def test_a_trio_on_four_ranks_as_samples_times_chromosome_groups():
         assert (v_.view(np.uint32) == mcnt[s][:k].cpu().numpy().view(np.uint32)).all(), rank
         cov = cv.quantize_f2(mcnt[s], k)
         assert (st_ == cv.hmm_per_sample(cov, off)[:k].cpu().numpy()).all(), rank
+
+
+# ---- PerSampleHMM sharded on its own (canvas_hmm_per_sample_sharded): the state runs are recorded, gathered and expanded on the device
+HMM_LENS = [9_000, 0, 40_000, 3, 700, 15_000, 12]
+
+
+def _hmm_coverage():
+    rng = np.random.default_rng(SEED + 31)
+    parts = []
+    for c, L in enumerate(HMM_LENS):
+        x = rng.normal(60.0, 5.0, L)
+        if L == 40_000:                                          # a state change every fifty bins: 800 runs, more than the exchange's first bound (330 records) holds — every rank retries with the hard bound
+            x = np.where((np.arange(L) // 50) % 2 == 0, 60.0, 120.0) + rng.normal(0, 1.0, L)
+        parts.append(np.round(np.clip(x, 0, None), 2))
+    cov = np.concatenate(parts) if parts else np.zeros(0)
+    off = np.concatenate([[0], np.cumsum(HMM_LENS)]).astype(np.int64)
+    return cov, off
+
+
+def _hmm_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        cov, off = _hmm_coverage()
+        owner = np.array([c % world for c in range(len(HMM_LENS))], np.int32)
+        d = torch.from_numpy(cov).to(cv.device)
+        st = cv.hmm_per_sample_sharded(owner, d, off).cpu().numpy()
+        single = cv.hmm_per_sample(d, off).cpu().numpy()
+        q.put((rank, st.tolist(), bool((st == single).all()), [int(v) for v in cv.sharded_stats()]))
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+
+
+def test_sharded_per_sample_hmm_keeps_its_state_runs_on_the_device():
+    """canvas_hmm_per_sample_sharded on three ranks (host transport, one GPU): chromosomes of 0, 3 and 12 bins, one whose path changes state every fifty bins (the first bound of
+    the record exchange overflows and every rank retries with the hard one); every rank's states equal the single-rank call and the oracle's paths"""
+    import torch.multiprocessing as mp
+    import oracle_lib as O
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hmm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    for g in got:
+        assert g[1] != "error", g[2]
+    cov, off = _hmm_coverage()
+    per = [np.ascontiguousarray(cov[off[c]:off[c + 1]]) for c in range(len(HMM_LENS))]
+    paths, ran = O.hmm_genome_per_sample(per, threads=4)
+    exp = np.concatenate([paths[c] if ran[c] else np.full(len(per[c]), -1, np.int32) for c in range(len(HMM_LENS))])
+    for rank, st, same, stats in got:
+        assert same and (np.array(st, np.int32) == exp).all(), rank
+        assert stats[0] == world
+    assert got[2][3][4] > 500                                    # rank 2 owns the 40 000-bin chromosome: its runs went through the retry
