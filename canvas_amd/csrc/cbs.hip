@@ -295,7 +295,9 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) { y ^= y >> 11; y ^= (
 struct PermReq {
     uint32_t state[625];       // generator state at the start of the batch: mt[624], mti
     long long total; int n; int nb; uint32_t* snaps; const double* x; int hk, al0; double tss, errBound; PermBuf P; double* pstat; int blockBase;
-    int cont;                  // the MT_HISTORY outputs in front of P.draws are the tail of the previous batch: no sequential part needed
+    int cont;                  // this batch continues the previous one of its loop: `hist` = that batch's last MT_HISTORY outputs, no sequential part needed
+    const uint32_t* hist;      // (cont) the MT_HISTORY outputs in front of position 0 of this batch — where they were written: in the OTHER of the loop's two draw buffers (they used to be
+                               // copied in front of P.draws, 10 MB device to device per batch: 7 % of the device time of the tumour / normal flow's CBS went into those copies)
     int fy;                    // 0: k_perm_stat, 1: k_perm_fy, 2: k_perm_small, 3: k_perm_rp evaluates this request's permutations
     // k_perm_rp: rpWGs persistent workgroups (blocks rpBase .. rpBase + rpWGs of its launch), each with its own scratch of rp.stride words behind rpScratch
     int rpBase, rpWGs; uint32_t* rpScratch; long long* rpClk;      // rpClk (probe only): cycles of workgroup 0 per phase
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict_
     const long long left = end - start - r;
     if (left <= 0) return;
     const long long cnt = (left + stride - 1) / stride;              // values of this sequence to generate
-    const gptr<const uint32_t> hist = d + (start - 19937LL * stride + r);
+    const gptr<const uint32_t> hist = (!boot && R.cont) ? as_global(R.hist) + r : (gptr<const uint32_t>)(d + (start - 19937LL * stride + r));
     for (int t = tid; t < 19937; t += MTC_T) ring[t] = hist[(long long)t * stride];
     __syncthreads();
     const gptr<uint32_t> out = d + (start + r);
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(256) k_mt_snapshots(const PermReq* __restrict_
     if (R.fy == 2) return;                                 // (draws of short segments come from the host: perm_loop_small_gpu)
     const long long end = (long long)(b + 1) * R.n;       // (fewer than 624 outputs in front of it in a batch that continues nothing: the host advances the start state instead, perm_loop_gpu)
     uint32_t* s = R.snaps + (size_t)b * 625;
-    for (int i = threadIdx.x; i < 624; i += 256) s[i] = mt_untemper(R.P.draws[end - 624 + i]);
+    for (int i = threadIdx.x; i < 624; i += 256) { const long long at = end - 624 + i; s[i] = mt_untemper(at >= 0 ? R.P.draws[at] : (R.cont ? R.hist[MT_HISTORY + at] : 0u)); }      // (at < 0: a continued batch of a short segment — the words lie in the previous batch; a batch that continues nothing: the snapshot is not used, see above)
     if (threadIdx.x == 0) s[624] = 624u;
 }
 __device__ __forceinline__ int block_excl_scan_i32(int v, int* sh /*PG_T/64 + 1*/, int& total) {
@@ -2149,8 +2151,6 @@ struct PermService {
         for (int i = 0; i < R; i++) {
             batch[i]->r.rpBase = rpBlocks; if (batch[i]->r.fy == 3) rpBlocks += batch[i]->r.rpWGs; else batch[i]->r.rpWGs = 0;
             batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
-            if (batch[i]->r.cont)    // history of this batch = the last MT_HISTORY outputs of the previous one (same buffer, no overlap: prevTotal >= MT_HISTORY)
-                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws - MT_HISTORY, batch[i]->r.P.draws + (batch[i]->prevTotal - MT_HISTORY), (size_t)MT_HISTORY * 4, hipMemcpyDeviceToDevice, stream));
             if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // pinned source
             if (batch[i]->drawBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws, batch[i]->hDraws, batch[i]->drawBytes, hipMemcpyHostToDevice, stream));
         }
@@ -2225,10 +2225,10 @@ static inline int perm_rp_wgs(int n) { PermReq::RpPlan P; rp_plan(n, P); const s
 static void perm_reserve_bytes(size_t nMax, size_t& dev, size_t& pin) {
     const size_t head = al256(nMax * 8) + al256(625 * 4) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
     const size_t elemsRp = std::max<size_t>(PERM_TARGET_ELEMS, 8 * nMax);
-    dev = head + al256((elemsRp + (size_t)MT_HISTORY) * 4) + PERM_RP_SCRATCH_BYTES + (size_t(64) << 20);
+    dev = head + 2 * al256((elemsRp + (size_t)MT_HISTORY) * 4) + PERM_RP_SCRATCH_BYTES + (size_t(64) << 20);
     if (nMax > (size_t)PERM_RP_MAX_N || !perm_use_rp((int)std::min<size_t>(nMax, PERM_RP_MAX_N))) {
         const size_t re = (size_t)std::min<long long>((long long)256 * (long long)nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * (long long)nMax));
-        dev = std::max(dev, head + al256((re + (size_t)MT_HISTORY) * 4) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
+        dev = std::max(dev, head + 2 * al256((re + (size_t)MT_HISTORY) * 4) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
     }
     pin = al256(nMax * 8) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
 }
@@ -2245,16 +2245,17 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     uint32_t* dRpScratch = nullptr; int rpWGs = 0; PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP);
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
+    uint32_t* draws2[2] = {nullptr, nullptr}; int drawBuf = 0;      // the loop's batches alternate between two draw buffers
     auto setup = [&](int mb) -> int32_t {
         const size_t e = (size_t)mb * n, e1 = (size_t)mb * (n + 1);
         const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)mb * 625 * 4), oDraws = oStat + al((size_t)mb * 16),
-                     oJ = oDraws + al((e + (size_t)MT_HISTORY) * 4), oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
+                     oJ = oDraws + 2 * al((e + (size_t)MT_HISTORY) * 4) /* two draw buffers: a batch reads its history where the previous one wrote it */, oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
                      oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
         const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pinTotal = pStat + al((size_t)mb * 16);
         auto tE = now();
         // k_perm_rp: the draws and, behind them, the scratch of the persistent workgroups (results travel in streams: no per-element workspace)
         size_t oScratch = 0, totalRp = 0;
-        if (useRp) { rp_plan(n, rpP); rpWGs = std::min(perm_rp_wgs(n), mb); oScratch = oDraws + al((e + (size_t)MT_HISTORY) * 4); totalRp = oScratch + al((size_t)rpP.stride * 4 * (size_t)rpWGs); }
+        if (useRp) { rp_plan(n, rpP); rpWGs = std::min(perm_rp_wgs(n), mb); oScratch = oDraws + 2 * al((e + (size_t)MT_HISTORY) * 4); totalRp = oScratch + al((size_t)rpP.stride * 4 * (size_t)rpWGs); }
         const size_t need = useRp ? totalRp : total;
         size_t want = need, wantPin = pinTotal;
         if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // the first allocation serves the longest segment this call can meet
@@ -2262,7 +2263,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         st.ns_ensure += since(tE);
         char* d = PG.buf; char* h = PG.pin;
         dX = (double*)(d + oX); dSnaps = (uint32_t*)(d + oSnaps); dStat = (double*)(d + oStat);
-        P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY;       // MT_HISTORY outputs of head room for the continuation
+        P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY; draws2[0] = P.draws; draws2[1] = (uint32_t*)(d + oDraws + al((e + (size_t)MT_HISTORY) * 4)) + MT_HISTORY;
         if (useRp) { memset(&P.j, 0, sizeof(PermBuf) - sizeof(uint32_t*)); dRpScratch = (uint32_t*)(d + oScratch); }
         else {
         P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
@@ -2294,6 +2295,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.r.cont = (np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
+        q.r.P.draws = draws2[drawBuf]; q.r.hist = q.r.cont ? draws2[drawBuf ^ 1] + (prevTotal - MT_HISTORY) : nullptr; drawBuf ^= 1;
         { static const int fyMin = cvx_hook("CANVAS_CBS_FY_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_FY_MIN_N")) : PERM_FY_MIN_N; q.r.fy = useRp ? 3 : (n >= fyMin ? 1 : 0); }
         // persistent workgroups: every one takes the same number of permutations (600 permutations on 512 workgroups would be two rounds with 424 workgroups idle in the second:
         // 300 workgroups with two each take the same time and leave the other CUs to the kernels of the other chromosomes)
@@ -2394,7 +2396,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
         for (size_t t = 0; t < (size_t)nb * n; t++) hDraws[t] = rnd.u32();
         PermHostReq q;
         memset(q.r.state, 0, sizeof q.r.state); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = nullptr; q.r.x = dX; q.r.hk = 0; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = 0.0;
-        memset(&q.r.P, 0, sizeof q.r.P); q.r.P.draws = dDraws; q.r.pstat = dStat; q.r.blockBase = 0; q.r.cont = 0; q.r.fy = 2; q.hStat = hStat; q.hSnaps = nullptr;
+        memset(&q.r.P, 0, sizeof q.r.P); q.r.P.draws = dDraws; q.r.pstat = dStat; q.r.blockBase = 0; q.r.cont = 0; q.r.hist = nullptr; q.r.fy = 2; q.hStat = hStat; q.hSnaps = nullptr;
         q.r.rpBase = 0; q.r.rpWGs = 0; q.r.rpScratch = nullptr; q.r.rpClk = nullptr; memset(&q.r.rp, 0, sizeof q.r.rp);
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.hDraws = hDraws; q.drawBytes = (size_t)nb * n * 4;
@@ -2838,7 +2840,7 @@ extern "C" int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int
     q.r.errBound = 4.04 * (double)(n + 8) * 1.1102230246251565e-16 * absSum;
     q.r.P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY; q.r.P.j = (int32_t*)(d + oJ); q.r.P.off = (int32_t*)(d + oOff); q.r.P.cur = (int32_t*)(d + oCur); q.r.P.items = (int32_t*)(d + oItems);
     q.r.P.g = (int32_t*)(d + oG); q.r.P.succ = (int32_t*)(d + oSucc); q.r.P.px = (double*)(d + oPx); q.r.P.sx = (double*)(d + oSx);
-    q.r.pstat = (double*)(d + oStat); q.r.blockBase = 0; q.r.cont = 0; q.r.fy = kernel == 2 ? 3 : kernel; q.hStat = (double*)(h + pStat); q.hSnaps = (uint32_t*)(h + pSnaps);
+    q.r.pstat = (double*)(d + oStat); q.r.blockBase = 0; q.r.cont = 0; q.r.hist = nullptr; q.r.fy = kernel == 2 ? 3 : kernel; q.hStat = (double*)(h + pStat); q.hSnaps = (uint32_t*)(h + pSnaps);
     q.r.rpBase = 0; q.r.rpWGs = rpWGs; q.r.rpScratch = (uint32_t*)(d + oScr); q.r.rp = rpP; q.r.rpClk = nullptr;
     long long* dClk = nullptr; const bool wantClk = kernel == 2 && cvx_hook("CANVAS_CBS_PROBE_CLOCKS");
     if (wantClk) { CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dClk, 128)); CANVAS_HIP_TRY(ctx, hipMemset(dClk, 0, 128)); q.r.rpClk = dClk; }
