@@ -167,7 +167,10 @@ static int load_bam(const std::string& bam, bool pairedEnd, const std::string& c
 }
 
 // ---------------------------------------------------------------- intermediate file: see protobuf_dat.hpp
-struct Inter { std::string name; int64_t len = 0; std::vector<uint64_t> maskWords; std::vector<uint8_t> hits; std::vector<int16_t> frag; };
+struct Inter { std::string name; int64_t len = 0; std::vector<uint64_t> maskWords; std::vector<uint8_t> hits; std::vector<int16_t> frag;
+               const uint8_t* hitsView = nullptr; size_t hitsViewLen = 0; std::shared_ptr<pbdat::Mapped> keep;      // -i: the observed alignments inside the mapped intermediate file
+               const uint8_t* hits_data() const { return hitsView ? hitsView : hits.data(); }
+               size_t hits_size() const { return hitsView ? hitsViewLen : hits.size(); } };
 
 // ---------------------------------------------------------------- predefined bins: Utilities.LoadBedFile(path, gcIndex: 3) (CanvasCommon/Utilities.cs:793-829)
 struct PreBin { int start, stop, gc; float count; };
@@ -394,14 +397,14 @@ int main(int argc, char** argv) {
         std::vector<pbdat::Data> pds(inters.size()); std::vector<std::string> perr(inters.size()); std::vector<char> okv(inters.size(), 0);
         std::vector<std::vector<std::unique_ptr<Inter>>> made(inters.size()); std::vector<std::string> badEntry(inters.size());
         parallel_for((int64_t)inters.size(), [&](int64_t i) {
-            okv[(size_t)i] = pbdat::read_file(inters[(size_t)i], pds[(size_t)i], perr[(size_t)i]) ? 1 : 0;
+            okv[(size_t)i] = pbdat::read_file(inters[(size_t)i], pds[(size_t)i], perr[(size_t)i], !getenv("CANVAS_TOOL_NO_MAPPED_DAT")) ? 1 : 0;
             if (!okv[(size_t)i]) return;
             for (auto& kv : pds[(size_t)i]) {                                                 // DeserializeCanvasData + IntermediateData.GetData (CanvasBin.cs:725-762,1089-1104)
                 auto d = std::make_unique<Inter>(); d->name = kv.first;
                 d->len = pbdat::unpack_possible_lsb(kv.second.possibleBytes, kv.second.bitsInLastByte, d->maskWords, kv.second.haveBits);      // least significant bit first, as the C# reader (Q2)
                 if (d->len < 0) { badEntry[(size_t)i] = kv.first; return; }
                 std::vector<uint8_t>().swap(kv.second.possibleBytes);
-                d->hits.swap(kv.second.observed); d->frag.swap(kv.second.fragmentLengths);
+                d->hits.swap(kv.second.observed); d->hitsView = kv.second.observedView; d->hitsViewLen = kv.second.observedLen; d->keep = kv.second.keep; d->frag.swap(kv.second.fragmentLengths);
                 made[(size_t)i].push_back(std::move(d));
             }
         });
@@ -410,7 +413,7 @@ int main(int argc, char** argv) {
             if (!okv[i]) { fprintf(stderr, "CanvasBin: %s\n", perr[i].c_str()); return 1; }
             if (!badEntry[i].empty()) { fprintf(stderr, "CanvasBin: %s: %s has no valid count of bits in the last possible-alignment byte (0..7 expected)\n", p.c_str(), badEntry[i].c_str()); return 1; }
             for (auto& d : made[i]) {
-                if ((int64_t)d->hits.size() != d->len) { fprintf(stderr, "CanvasBin: %s: %s has %lld possible-alignment bits but %zu observed-alignment bytes\n", p.c_str(), d->name.c_str(), (long long)d->len, d->hits.size()); return 1; }
+                if ((int64_t)d->hits_size() != d->len) { fprintf(stderr, "CanvasBin: %s: %s has %lld possible-alignment bits but %zu observed-alignment bytes\n", p.c_str(), d->name.c_str(), (long long)d->len, d->hits_size()); return 1; }
                 if (byChrom.count(d->name)) { fprintf(stderr, "CanvasBin: chromosome %s appears in more than one intermediate file (Dictionary.Add throws in the reference)\n", d->name.c_str()); return 1; }
                 const std::string nm = d->name;
                 byChrom[nm] = std::move(d);
@@ -452,7 +455,7 @@ int main(int argc, char** argv) {
             const int s = c & 1; int64_t sat = 0;
             pRef[c] = (const uint64_t*)(base + offR[c]); pPlanes[c] = (const uint64_t*)(base + offH[c]);
             const bool ok = canvas_pack_reference_host((const uint8_t*)order[c]->bases.data(), data[c]->maskWords.data(), len[c], sRef[s].get(), &pos0[c], 0) == 0 &&
-                            canvas_pack_hits_host(data[c]->hits.data(), len[c], sHit[s].get(), &sat, 0) == 0;
+                            canvas_pack_hits_host(data[c]->hits_data(), len[c], sHit[s].get(), &sat, 0) == 0;
             if (up.joinable()) up.join();
             if (!ok) { fprintf(stderr, "CanvasBin: packing %s failed\n", order[c]->name.c_str()); return 1; }
             if (upRc) break;
@@ -464,7 +467,7 @@ int main(int argc, char** argv) {
     for (int c = 0; !usePacked && c < nchr; c++) {
         const int64_t L = data[c]->len, words = (L + 63) / 64; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
         auto up = [&](const void* src, int64_t bytes, int64_t alloc) -> void* { devs.push_back(std::make_unique<Dev>(ctx, alloc)); void* p = devs.back()->p; if (bytes > 0 && canvas_memcpy_h2d(ctx, p, src, bytes) != 0) return nullptr; return p; };
-        pBases[c] = (const uint8_t*)up(order[c]->bases.data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits.data(), L, L + 64); pMask[c] = (const uint64_t*)up(data[c]->maskWords.data(), words * 8, words * 8 + 64);
+        pBases[c] = (const uint8_t*)up(order[c]->bases.data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits_data(), L, L + 64); pMask[c] = (const uint64_t*)up(data[c]->maskWords.data(), words * 8, words * 8 + 64);
         if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { if ((int64_t)data[c]->frag.size() != L) { fprintf(stderr, "CanvasBin: %s has no fragment lengths (was the intermediate written with -m GCContentWeighted?)\n", order[c]->name.c_str()); return 1; } pFrag[c] = (const int16_t*)up(data[c]->frag.data(), L * 2, L * 2 + 64); }
         if (!pBases[c] || !pHits[c] || !pMask[c]) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
     }

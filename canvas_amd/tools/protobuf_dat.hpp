@@ -15,12 +15,23 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <string>
 #include <vector>
 
 namespace pbdat {
 
-struct Chromosome { std::vector<uint8_t> possibleBytes, observed; int bitsInLastByte = 0; bool haveBits = false; std::vector<int16_t> fragmentLengths; };
+// a file mapped read-only: read_file (map = true) leaves the observed-alignment bytes of a chromosome — 1 byte per base, contiguous in the file — where they are
+struct Mapped { const uint8_t* p = nullptr; size_t len = 0; Mapped() = default; Mapped(const Mapped&) = delete; Mapped& operator=(const Mapped&) = delete;
+                ~Mapped() { if (p && len) munmap((void*)p, len); } };
+struct Chromosome { std::vector<uint8_t> possibleBytes, observed; int bitsInLastByte = 0; bool haveBits = false; std::vector<int16_t> fragmentLengths;
+                    const uint8_t* observedView = nullptr; size_t observedLen = 0; std::shared_ptr<Mapped> keep;      // (map = true) the observed alignments inside the mapped file instead of `observed`
+                    const uint8_t* observed_data() const { return observedView ? observedView : observed.data(); }
+                    size_t observed_size() const { return observedView ? observedLen : observed.size(); } };
 typedef std::map<std::string, Chromosome> Data;     // keyed by chromosome name (each file of the pipeline holds one)
 
 // ---- writer
@@ -61,13 +72,30 @@ static bool write_file(const std::string& path, const Data& d, bool withFragment
 struct Cursor { const uint8_t* p; const uint8_t* end; bool ok = true;
     uint64_t varint() { uint64_t v = 0; int sh = 0; while (p < end) { const uint8_t b = *p++; v |= (uint64_t)(b & 0x7F) << sh; if (!(b & 0x80)) return v; sh += 7; if (sh > 63) break; } ok = false; return 0; }
     bool skip(int wire) { if (wire == 0) { varint(); } else if (wire == 1) { p += 8; } else if (wire == 2) { const uint64_t n = varint(); if (!ok || n > (uint64_t)(end - p)) { ok = false; return false; } p += n; } else if (wire == 5) { p += 4; } else ok = false; if (p > end) ok = false; return ok; } };
-static bool read_file(const std::string& path, Data& d, std::string& err) {
-    FILE* f = fopen(path.c_str(), "rb"); if (!f) { err = "cannot open " + path; return false; }
-    fseeko(f, 0, SEEK_END); const int64_t size = ftello(f); fseeko(f, 0, SEEK_SET);
-    std::vector<uint8_t> buf((size_t)size);
-    if (size > 0 && fread(buf.data(), 1, (size_t)size, f) != (size_t)size) { fclose(f); err = "short read on " + path; return false; }
-    fclose(f);
-    Cursor c{buf.data(), buf.data() + buf.size()};
+// map = true: the file is mapped instead of read, and the observed alignments are left in the mapping (Chromosome::observedView) — 3 GB per genome that are neither
+// read into a buffer nor copied out of it (anonymous pages cost a fault when they are first touched and 37 ms per GB when the process gives them back, tools/exit_probe.sh)
+static bool read_file(const std::string& path, Data& d, std::string& err, bool map = false) {
+    std::vector<uint8_t> buf; std::shared_ptr<Mapped> mp; const uint8_t* base = nullptr; size_t total = 0;
+    if (map) {
+        const int fd = open(path.c_str(), O_RDONLY); if (fd < 0) { err = "cannot open " + path; return false; }
+        struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); err = "cannot stat " + path; return false; }
+        total = (size_t)sb.st_size;
+        if (total > 0) {
+            void* m = mmap(nullptr, total, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); err = "cannot map " + path; return false; }
+            (void)madvise(m, total, MADV_WILLNEED);
+            mp = std::make_shared<Mapped>(); mp->p = (const uint8_t*)m; mp->len = total; base = mp->p;
+        }
+        close(fd);
+    } else {
+        FILE* f = fopen(path.c_str(), "rb"); if (!f) { err = "cannot open " + path; return false; }
+        fseeko(f, 0, SEEK_END); const int64_t size = ftello(f); fseeko(f, 0, SEEK_SET);
+        buf.resize((size_t)size);
+        if (size > 0 && fread(buf.data(), 1, (size_t)size, f) != (size_t)size) { fclose(f); err = "short read on " + path; return false; }
+        fclose(f);
+        base = buf.data(); total = buf.size();
+    }
+    Cursor c{base, base + total};
     while (c.ok && c.p < c.end) {
         const uint64_t tag = c.varint(); const int field = (int)(tag >> 3), wire = (int)(tag & 7);
         if (!c.ok) break;
@@ -89,7 +117,7 @@ static bool read_file(const std::string& path, Data& d, std::string& err) {
         if (!e.ok) { c.ok = false; break; }
         Chromosome& ch = d[key];
         if (field == 1) ch.possibleBytes.assign(val, val + nval);
-        else if (field == 2) ch.observed.assign(val, val + nval);
+        else if (field == 2) { if (mp) { ch.observedView = val; ch.observedLen = nval; ch.keep = mp; std::vector<uint8_t>().swap(ch.observed); } else { ch.observed.assign(val, val + nval); ch.observedView = nullptr; ch.observedLen = 0; } }
         else if (field == 3) { ch.bitsInLastByte = (int)ival; ch.haveBits = true; }
         else ch.fragmentLengths.swap(arr);
     }
