@@ -763,6 +763,62 @@ def test_gc_content_weighted_two_restatements():
             assert list(zip(*[a.tolist() for a in res[c]])) == want[c], (it, c)
 
 
+def py_predefined_gc_weighted(bases, possible, observed, read_gc, weights, starts, stops):
+    """BinCountsForChromosome with usePredefinedBins and the GCContentWeighted branch (CanvasBin.cs:575-655), a second reading: the cursor starts at the first bin's Start,
+    skips leading 'n', closes a bin on Stop - 1 and jumps to the next bin's Start; the weighted count is the float32 sum over the bin's possible positions"""
+    f = np.float32
+    out = []
+    if not len(starts):
+        return out
+    k = 0
+    pos = int(starts[0])
+    while bases[pos] == ord("n"):
+        pos += 1
+    nucleotides = gc = 0
+    acc = f(0)
+    while pos < len(bases):
+        nucleotides += 1
+        gc += chr(bases[pos]) in "CcGg"
+        if possible[pos]:
+            acc = f(acc + min(f(10), f(f(int(observed[pos])) / weights[read_gc[pos]])))
+        if pos == int(stops[k]) - 1:
+            out.append((int(f(100.0) * f(gc) / f(nucleotides)), int(np.rint(float(acc)))))
+            k += 1
+            if k >= len(starts):
+                break
+            pos = int(starts[k]) - 1
+            nucleotides = gc = 0
+            acc = f(0)
+        pos += 1
+    return out
+
+
+def test_predefined_bins_gc_content_weighted_two_restatements():
+    """CanvasBin -n with -m GCContentWeighted: the oracle's bin_chromosome_predefined_weighted against the reading above, the profile and the weights from py_gc_weighted
+    (every chromosome enters them, also one without bins)"""
+    rng = np.random.RandomState(777)
+    for it in range(10):
+        nchr = int(rng.randint(2, 4))
+        chroms = [_random_chromosome(rng, int(rng.randint(500, 1400))) for _ in range(nchr)]
+        frag = [np.where(o > 0, rng.randint(20, 140, len(b)), 0).astype(np.int16) for b, p, o in chroms]
+        _, mean_fragment, weights, read_gc = py_gc_weighted([c[0] for c in chroms], [c[1] for c in chroms], [c[2] for c in chroms], frag, 10)
+        starts, stops = [], []
+        for c, (b, p, o) in enumerate(chroms):
+            if c == 1:
+                starts.append(np.zeros(0, np.int32)); stops.append(np.zeros(0, np.int32)); continue
+            L = len(b)
+            s0 = np.sort(rng.choice(L - 60, 12, replace=False)); e0 = np.minimum(s0 + rng.randint(1, 60, 12), L)
+            s0[0] = 0; e0[0] = max(int(e0[0]), 40)                          # the first bin starts inside the leading 'n' stretch (if any) and reaches past it
+            e0[-1] = L
+            starts.append(s0.astype(np.int32)); stops.append(e0.astype(np.int32))
+        res = O.bin_predefined_gc_weighted([c[0] for c in chroms], [_pack_mask(c[1]) for c in chroms], [c[2] for c in chroms], frag, starts, stops)
+        for c, (b, p, o) in enumerate(chroms):
+            want = py_predefined_gc_weighted(b, p, o, read_gc[c], weights, starts[c], stops[c])
+            k, gcs, cnts = res[c]
+            assert k == len(want), (it, c)
+            assert list(zip(gcs.tolist(), cnts.tolist())) == want, (it, c)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # Wavelets: WaveletSegmentation.cs:19-48 (GetInnerProdIter), :54-68 (GetInnerProdMax), :264-383 (FindBestUnbalancedHaarDecomposition),
 # :72-115 (HardThresh), :118-171 (GetUnbalHaarVector, GetReconstructedVector), :174-185 (GetSegments), :194-234 (healing), :237-258
