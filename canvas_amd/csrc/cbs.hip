@@ -424,12 +424,6 @@ __device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
     t = y; t = y ^ (t >> 11); t = y ^ (t >> 11); y = t;
     return y;
 }
-// ONE snapshot, asked for by the host once the stopping rule knows which permutation it ends at (perm_loop_gpu): a batch of 1024 permutations used to send 1024 of them
-// home, 2.5 MB per batch, for the one that is looked at
-__global__ void __launch_bounds__(256) k_mt_snapshot_one(const uint32_t* __restrict__ draws, const uint32_t* __restrict__ hist, int cont, long long end, uint32_t* __restrict__ out) {
-    for (int i = threadIdx.x; i < 624; i += 256) { const long long at = end - 624 + i; out[i] = mt_untemper(at >= 0 ? draws[at] : (cont ? hist[MT_HISTORY + at] : 0u)); }
-    if (threadIdx.x == 0) out[624] = 624u;
-}
 __global__ void __launch_bounds__(256) k_mt_snapshots(const PermReq* __restrict__ reqs, int nreq) {
     int ri = 0;
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
@@ -2175,7 +2169,7 @@ struct PermService {
         const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;
         if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
         if (dbg) msB = lap();
-        { bool anySnaps = false; for (int i = 0; i < R; i++) anySnaps = anySnaps || batch[i]->hSnaps != nullptr; if (anySnaps) hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R); }      // (test hook / probe: every permutation's snapshot)
+        hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
         bool anyFy = false, anyOld = false, anySmall = false; for (int i = 0; i < R; i++) (batch[i]->r.fy == 2 ? anySmall : batch[i]->r.fy == 1 ? anyFy : batch[i]->r.fy == 0 ? anyOld : anySmall /* (3: below) */) |= batch[i]->r.fy != 3;
         if (anyOld) hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         if (anyFy) hipLaunchKernelGGL(k_perm_fy, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
@@ -2236,7 +2230,7 @@ static void perm_reserve_bytes(size_t nMax, size_t& dev, size_t& pin) {
         const size_t re = (size_t)std::min<long long>((long long)256 * (long long)nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * (long long)nMax));
         dev = std::max(dev, head + 2 * al256((re + (size_t)MT_HISTORY) * 4) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
     }
-    pin = al256(nMax * 8) + (cvx_hook("CANVAS_CBS_TEST_VERIFY") ? al256((size_t)PERM_RP_MAXB * 625 * 4) : 0) + al256((size_t)PERM_RP_MAXB * 16);
+    pin = al256(nMax * 8) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
 }
 
 // The sequential stopping rule of FindChangePoints (ChangePoint.cs:337-364) over permutations evaluated in device batches.
@@ -2252,13 +2246,12 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
     uint32_t* draws2[2] = {nullptr, nullptr}; int drawBuf = 0;      // the loop's batches alternate between two draw buffers
-    const bool allSnaps = cvx_hook("CANVAS_CBS_TEST_VERIFY") != nullptr;      // (test hook: every permutation's generator snapshot comes home; otherwise the one the rule asks for is fetched)
     auto setup = [&](int mb) -> int32_t {
         const size_t e = (size_t)mb * n, e1 = (size_t)mb * (n + 1);
         const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)mb * 625 * 4), oDraws = oStat + al((size_t)mb * 16),
                      oJ = oDraws + 2 * al((e + (size_t)MT_HISTORY) * 4) /* two draw buffers: a batch reads its history where the previous one wrote it */, oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
                      oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
-        const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + (allSnaps ? al((size_t)mb * 625 * 4) : 0), pinTotal = pStat + al((size_t)mb * 16);
+        const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pinTotal = pStat + al((size_t)mb * 16);
         auto tE = now();
         // k_perm_rp: the draws and, behind them, the scratch of the persistent workgroups (results travel in streams: no per-element workspace)
         size_t oScratch = 0, totalRp = 0;
@@ -2299,7 +2292,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         auto tS = now();
         PermHostReq q;
         memcpy(q.r.state, cur, sizeof cur); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
-        q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = allSnaps ? hSnaps : nullptr;
+        q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         q.r.cont = (np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
         q.r.P.draws = draws2[drawBuf]; q.r.hist = q.r.cont ? draws2[drawBuf ^ 1] + (prevTotal - MT_HISTORY) : nullptr; drawBuf ^= 1;
@@ -2319,18 +2312,8 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         // the host, at most 623 draws.
         const bool contBatch = q.r.cont != 0;
         uint32_t tmpState[625];
-        int32_t rcFetch = CANVAS_OK;
         auto state_after = [&](int b) -> const uint32_t* {
-            if (contBatch || (long long)(b + 1) * n >= 624) {
-                if (allSnaps) return hSnaps + (size_t)b * 625;
-                // the one snapshot that is needed, rebuilt on the device from the batch's draws (still in place: the next batch is not submitted yet) and fetched through the
-                // engine's small pinned buffer: a kernel of one workgroup + 2.5 KB instead of 2.5 KB per permutation of the batch
-                if (PG.ensure_tail() != CANVAS_OK) { rcFetch = CANVAS_ERR_HIP; return cur; }
-                hipLaunchKernelGGL(k_mt_snapshot_one, dim3(1), dim3(256), 0, PG.tailStream, (const uint32_t*)q.r.P.draws, q.r.hist, q.r.cont, (long long)(b + 1) * n, dSnaps);
-                if (hipMemcpyAsync(PG.tailPin, dSnaps, 625 * 4, hipMemcpyDeviceToHost, PG.tailStream) != hipSuccess || hipStreamSynchronize(PG.tailStream) != hipSuccess) {
-                    ctx->err = "canvas_cbs: the generator snapshot did not come back"; rcFetch = CANVAS_ERR_HIP; return cur; }
-                memcpy(tmpState, PG.tailPin, sizeof tmpState); return tmpState;
-            }
+            if (contBatch || (long long)(b + 1) * n >= 624) return hSnaps + (size_t)b * 625;
             MT m(0u); m.set_state(cur); for (long long t = 0; t < (long long)(b + 1) * n; t++) (void)m.u32(); m.get_state(tmpState); return tmpState;
         };
         if (cvx_hook("CANVAS_CBS_TEST_VERIFY")) {      // test hook: every device interval must contain the statistic computed in the reference's order
@@ -2361,11 +2344,10 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
                 st.exact_rechecks++;
             }
             if (rej) { nrej++; k++; }
-            if (nrej > nrejc) { rnd.set_state(state_after(b)); outcome = 0; return rcFetch; }
-            if (np >= sbdry[k - 1]) { rnd.set_state(state_after(b)); return rcFetch; }
-            if (rcFetch) return rcFetch;
+            if (nrej > nrejc) { rnd.set_state(state_after(b)); outcome = 0; return CANVAS_OK; }
+            if (np >= sbdry[k - 1]) { rnd.set_state(state_after(b)); return CANVAS_OK; }
         }
-        { const uint32_t* sEnd = state_after(nb - 1); if (rcFetch) return rcFetch; uint32_t keepState[625]; memcpy(keepState, sEnd, sizeof keepState); memcpy(cur, keepState, sizeof cur); }
+        { const uint32_t* sEnd = state_after(nb - 1); uint32_t keepState[625]; memcpy(keepState, sEnd, sizeof keepState); memcpy(cur, keepState, sizeof cur); }
         // The next batch: as many permutations as the rule is expected to look at yet (+ 15 %), not simply twice the last one — the permutation kernels are the device's load,
         // and a loop that stops 20 permutations into a batch of 1024 has computed the other thousand for nothing (with the doubling a third of all permutations computed were never
         // looked at).  With the rejection rate seen so far, p, the rule stops where np reaches sbdry[k - 1 + p (np' - np)] or where the rejections exceed nrejc, whichever is first.
