@@ -12,7 +12,7 @@ from canvas_amd import Canvas, synth, CLEAN_GCNORM, CLEAN_FILTSIZE, CLEAN_OUTLIE
 
 cv = Canvas(0); cv.profile_enable(True)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120
-t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}; nbatch = 0; ncount = 0; by_noise = {}; by_disp = {}
+t0 = time.time(); it = 0; fallbacks = 0; retries = 0; fb = {}; nbatch = 0; ncount = 0; ngconly = 0; by_noise = {}; by_disp = {}
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 while time.time() - t0 < budget:
     seed = int(rng.randint(1, 2**31 - 1)); n = int(rng.choice([3_000, 30_000, 120_000, 600_000])); nchr = int(rng.choice([1, 3, 24]))
@@ -24,8 +24,10 @@ while time.time() - t0 < budget:
     if noise: bins["count"] = (bins["count"] + rng.normal(0, noise, len(bins["count"]))).clip(0).astype(np.float32)
     # two thirds of the samples carry two-decimal counts (what CanvasClean reads from a .binned file) at some level: the per-value counters decide their order statistics
     # when the level allows; the rest go through the radix selects
-    shape = rng.choice(["as_is", "f2", "f2_scaled"])
-    if shape != "as_is":
+    shape = rng.choice(["as_is", "f2", "f2_scaled", "whole"])
+    if shape == "whole":      # whole-number counts (what CanvasBin writes): with -g alone they take the three-launch stage of clean_gc_only.hpp
+        bins["count"] = np.round(bins["count"] * float(rng.choice([1.0, 1.0, 3.0, 12.0]))).astype(np.float32)
+    elif shape != "as_is":
         scale = 1.0 if shape == "f2" else float(rng.choice([0.05, 0.4, 1.7, 4.0]))
         bins["count"] = (np.round(bins["count"].astype(np.float64) * scale * 100.0) / 100.0).astype(np.float32)
     flags = int(rng.choice([CLEAN_GCNORM | CLEAN_FILTSIZE | CLEAN_OUTLIERS | CLEAN_LOCALSD, CLEAN_GCNORM, CLEAN_FILTSIZE | CLEAN_OUTLIERS, CLEAN_GCNORM | CLEAN_LOCALSD | CLEAN_FILTSIZE]))
@@ -47,10 +49,10 @@ while time.time() - t0 < budget:
             assert (d["count"][:int(no)].cpu().numpy().view(np.uint32) == e["count"].view(np.uint32)).all() and (d["stop"][:int(no)].cpu().numpy() == e["stop"]).all(), ("batch", seed, n, nchr, flags)
         nbatch += 1
         n_out, lsd = int(nouts[pos]), float(lsds[pos])
-        ncount += int(infos[pos][5])
+        ncount += int(infos[pos][5]); ngconly += int(infos[pos][6])
     else:
         n_out, lsd, info = cv.clean(dev, len(bins["chr"]), is_auto, flags)
-        ncount += int(info[5])
+        ncount += int(info[5]); ngconly += int(info[6])
     assert n_out == len(ex["chr"]) and lsd == ex["local_sd"], (seed, n, nchr, flags)
     got = dev["count"][:n_out].cpu().numpy()
     assert (got.view(np.uint32) == ex["count"].view(np.uint32)).all() and (dev["start"][:n_out].cpu().numpy() == ex["start"]).all(), (seed, n, nchr, flags)
@@ -77,4 +79,4 @@ while time.time() - t0 < budget:
 print("fallback runs by (n, nchr, noise):", sorted(fb.items()))
 print("PerSampleHMM calls that needed a second speculative attempt, by the noise added to the counts:", {k: "%d of %d" % (v[1], v[0]) for k, v in sorted(by_noise.items())})
 if by_disp: print("... by iqr / median of the coverage (bins of 0.05):", {"%.2f" % (k * 0.05): "%d of %d" % (v[1], v[0]) for k, v in sorted(by_disp.items())})
-print(f"soak: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s; {nbatch} of them inside a cohort call; {ncount} decided by the per-value counters; second speculative attempts: {retries}, sequential Viterbi fallbacks: {fallbacks}")
+print(f"soak: {it} random configurations bit-identical to the oracle in {time.time() - t0:.0f} s; {nbatch} of them inside a cohort call; {ncount} decided by the per-value counters; {ngconly} through the -g-only stage (clean_gc_only.hpp); second speculative attempts: {retries}, sequential Viterbi fallbacks: {fallbacks}")
