@@ -26,16 +26,18 @@ int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t 
     if (ctx->comm) { CANVAS_NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream)); return CANVAS_OK; }
     if (!ctx->host_allgather) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "no communicator: call canvas_comm_init or canvas_comm_init_host first");
     const size_t need = bytes * (size_t)(ctx->nranks + 1);
-    if (need > ctx->comm_pin_bytes) {
+    if (need * 2 > ctx->comm_pin_bytes) {      // (two areas of `need` bytes each)
         if (ctx->comm_pin) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); CANVAS_HIP_TRY(ctx, hipHostFree(ctx->comm_pin)); ctx->comm_pin = nullptr; ctx->comm_pin_bytes = 0; }
-        CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->comm_pin, need * 2, hipHostMallocDefault)); ctx->comm_pin_bytes = need * 2;
+        CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->comm_pin, need * 4, hipHostMallocDefault)); ctx->comm_pin_bytes = need * 4;
     }
-    char* hs = (char*)ctx->comm_pin; char* hr = hs + bytes;
+    // two staging areas, used in turn: the upload of this exchange may still be running when the next exchange fills the OTHER area, and that exchange's own
+    // synchronisation (below, same stream) has passed it by the time this area comes round again — one synchronisation per exchange instead of two
+    ctx->comm_pin_flip ^= 1;
+    char* hs = (char*)ctx->comm_pin + (ctx->comm_pin_flip ? ctx->comm_pin_bytes / 2 : 0); char* hr = hs + bytes;
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->host_allgather(ctx->host_allgather_user, hs, (int64_t)bytes, hr) != 0) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "host all-gather callback failed");
     CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_recv, hr, bytes * (size_t)ctx->nranks, hipMemcpyHostToDevice, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the pinned staging area is reused by the next call
     return CANVAS_OK;
 }
 

@@ -58,7 +58,7 @@ struct canvas_ctx {
     // host-callback transport of the collectives (canvas_comm_init_host): used when the ranks cannot form an RCCL communicator
     int32_t (*host_allgather)(void* user, const void* send, int64_t bytes_per_rank, void* recv) = nullptr;
     void* host_allgather_user = nullptr;
-    void* comm_pin = nullptr; size_t comm_pin_bytes = 0;
+    void* comm_pin = nullptr; size_t comm_pin_bytes = 0; int comm_pin_flip = 0;
     // persistent buffers of the chromosome-sharded pipeline (sharded.hip)
     void* shard_ws = nullptr; size_t shard_ws_bytes = 0;
     long long shard_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
