@@ -14,7 +14,8 @@
 // hook below.  Every decision is a function of a few hundred words; recomputing it where it is needed costs less than handing it over.)
 // (Statistics and apply as ONE launch — the first 102 tickets the statistics roles, the others chunk workgroups that load their chunk and then wait for the roles' count — was
 // built and measured: 42.6 us against 12 + 20 for the two launches.  The roles hold 51 CUs that the chunks then get a round later, and their chains of dependent round trips
-// run slower beside 50 MB of streaming loads than alone.)
+// run slower beside 50 MB of streaming loads than alone.  A second form — the roles run BY the first 102 chunk workgroups, behind their own chunk loads, so that nobody holds a CU
+// without a chunk — took 36.3 us: the roles' dependent round trips again, now behind the loads of their own workgroup as well.  The statistics want the device to themselves.)
 // Nothing is written to the caller's arrays unless every decision could be taken exactly: counts that are not whole numbers, an order statistic outside the counter
 // window, a bucket threshold below 100 (the neighbour-weighted medians) raise `fail`, the arrays stay as they were and the general chain takes the sample.
 // Batch-native like clean_fast.hpp: blockIdx.y = sample; the argument blocks travel as a kernel argument.
