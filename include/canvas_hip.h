@@ -180,7 +180,8 @@ int32_t canvas_bin_predefined_gcweighted(canvas_ctx* ctx, int32_t nchr, const ui
  * h_local_sd_out receives the #localSD metric (IO.cs:83-98) or -1.  h_info (may be NULL) gets 8 int32 diagnostics:
  * [0] after size filter, [1] after outlier filter, [2] after GC strip, [3] after local-SD filter, [4] variance-normalised,
  * [5] 1 = the medians / quartiles were read off exact per-value counters (counts that are two-decimal values, as the F2 text
- * of a .binned file always is), 0 = radix selects (any other input; same results). */
+ * of a .binned file always is), 0 = radix selects (any other input; same results), [6] 1 = flags were -g alone (CANVAS_CLEAN_GCNORM) on whole-number counts and
+ * the stage ran as RemoveBinsWithExtremeGC + NormalizeByGC (CanvasClean.cs:163-237,497-505) in three launches, in place (same results as the general chain). */
 int32_t canvas_clean(canvas_ctx* ctx, int64_t n, int32_t* d_chr, int32_t* d_start, int32_t* d_stop, float* d_count,
                      int32_t* d_gc, int32_t nchr, const uint8_t* h_chr_is_autosome, uint32_t flags, int32_t min_bins_per_gc,
                      double* h_local_sd_out, int64_t* h_n_out, int32_t* h_info);
