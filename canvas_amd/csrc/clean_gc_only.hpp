@@ -2,14 +2,15 @@
 // .binned file, in THREE launches and one synchronisation.  (The general chain of clean_fast.hpp serves this configuration in seven launches — two compactions through a
 // scratch copy, grouped keys, a counting sweep — at 0.11 ms for 2.5 M bins; a first three-launch attempt in round 4 counted per (GC, count) with device atomics and lost.)
 //
-//   k_cg_count    every workgroup holds its chunk of the bins (<= 16 384) in registers and counts the autosomal ones per (GC, count) in LDS — 101 rows x 256 counts, 16-bit
-//                 halves, no atomic leaves the CU — and writes the table as a slab of its own (52 KB, coalesced) with the per-GC totals of the chunk beside it.
-//   k_cg_medians  every workgroup sums the chunks' per-GC totals (all of them the same 200 KB, out of the L2) and takes the RemoveBinsWithExtremeGC decision (:207-237) for
+//   k_cg_count    every workgroup holds its chunk of the bins (<= 16 384) in registers and counts the autosomal ones per (GC, count) in LDS — 101 rows x 128 counts, 16-bit
+//                 halves, no atomic leaves the CU — and writes the table as a slab of its own (26 KB, coalesced) with the per-GC totals of the chunk beside it.
+//   k_cg_medians  every workgroup sums the chunks' per-GC totals (all of them the same 210 KB, out of the L2) and takes the RemoveBinsWithExtremeGC decision (:207-237) for
 //                 itself — no workgroup waits for another; one workgroup per GC bucket then sums its row over the slabs, reads the bucket's median off the counters and adds
 //                 the row into the genome row; one more workgroup turns the chunk totals into the chunks' output offsets.
 //   k_cg_apply    IN PLACE: every workgroup loads its whole chunk into registers, says so (a flag per chunk), reads the global median off the genome row while the loads are
 //                 in flight, waits for the chunks its output range reaches back into, and stores the surviving bins — normalised (:189-195) — at their final position.
-//                 Chunks are handed out by a ticket, so a workgroup only ever waits for workgroups that are already running.
+//                 The chunk is the workgroup's index while the grid fits the device (one workgroup per CU: whoever is waited for is running or waits for foreign work
+//                 alone), a ticket otherwise — a workgroup then only ever waits for workgroups that started before it.
 // (A first version took the decisions in the LAST workgroup of k_cg_count / k_cg_medians: 14 + 9 us of tails behind an arrival ticket — measured with CANVAS_CG_CUT, the timing
 // hook below.  Every decision is a function of a few hundred words; recomputing it where it is needed costs less than handing it over.)
 // (Statistics and apply as ONE launch — the first 102 tickets the statistics roles, the others chunk workgroups that load their chunk and then wait for the roles' count — was
