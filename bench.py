@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--no-pedigree", action="store_true", help="skip the trio flow of BASELINE configs[3] that is reported as pedigree_flow")
     ap.add_argument("--no-somatic", action="store_true", help="skip the tumour / normal flow of BASELINE configs[4] that is reported as somatic_flow")
     args = ap.parse_args()
+    launch_ranks_if_asked(args)
 
     import torch
     import torch.distributed as dist
@@ -63,17 +64,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if world != max(1, args.gpus):
+        # the launcher's world and --gpus must say the same thing: a line that claims n_gpus = N must have been measured on N ranks
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher: bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
+    one_gpu = ONE_GPU_HOOK()      # test hook: every rank on GPU 0, exchanges through the library's host transport (gloo) — RCCL refuses two ranks on one device
+    if world > 1 and not one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, this box has %d" % (world, world, torch.cuda.device_count()))
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_sharded = bool(os.environ.get("CANVAS_BENCH_FORCE_SHARDED")) and "RANK" in os.environ      # test hook: the N > 1 code path on a one-rank communicator
     if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     cv = Canvas(local_rank)
     cv.profile_enable(True)
     if world > 1 or force_sharded:
         from canvas_amd import parallel
-        parallel.init_library_comm(cv, rank, world)
+        if one_gpu:
+            parallel.init_host_comm(cv, rank, world)
+        else:
+            parallel.init_library_comm(cv, rank, world)
         if args.multi == "sharded":
             return sharded_main(args, cv, rank, world, device)
 
@@ -407,6 +422,33 @@ def main():
     cv.close()              # streams, engines and workspaces go while the runtime is still up (not from __del__ at interpreter shutdown)
     if world > 1:
         dist.destroy_process_group()
+
+
+def ONE_GPU_HOOK():
+    return os.environ.get("CANVAS_BENCH_ONE_GPU") == "1"
+
+
+def launch_ranks_if_asked(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (one process per GPU under torch.distributed.run, rendezvous on
+    127.0.0.1) and leave with their exit status.  Under a launcher (WORLD_SIZE set) this is a no-op and main() checks that the two agree.  Refuses — non-zero exit,
+    nothing measured — when the box has fewer than N GPUs, so that a line with n_gpus = N can only come from N devices (CANVAS_BENCH_ONE_GPU=1, the tests' hook, puts
+    every rank on GPU 0 over the host transport instead)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    if not ONE_GPU_HOOK():
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print("bench.py: --gpus %d needs %d visible GPUs, this box has %d; nothing was measured" % (args.gpus, args.gpus, have), file=sys.stderr)
+            raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def h2d_region(args, cv, torch, host, bases, masks, hits, lens, is_auto, flags, out, cov_buf, state_buf, seg_buf, keep, total_bases):

@@ -43,7 +43,7 @@ def source_hash(srcs):
     .so that does not correspond to the sources next to it is rebuilt no matter what its mtime says."""
     h = hashlib.sha256()
     h.update(" ".join(FLAGS).encode())
-    deps = sorted(srcs) + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "canvas_hip.h")]
+    deps = sorted(srcs) + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     for d in deps:
         h.update(os.path.basename(d).encode() + b"\0")
         with open(d, "rb") as f:
@@ -196,7 +196,7 @@ def build(force=False, verbose=False):
 
 def _tool_hash(srcs):
     h = hashlib.sha256()
-    for d in list(srcs) + [os.path.join(HERE, "..", "include", "canvas_hip.h")]:
+    for d in list(srcs) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h"))):
         with open(d, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:32]

@@ -23,6 +23,7 @@
 //     stay on the host.  WGS-size run (4.7 M bins, 104 k permutations over 1.27e9 elements): 4.1 s host-only -> 1.5 s.
 #include "common.hpp"
 #include "cbs_boundary_default.hpp"
+#include "../../include/canvas_mathnet.h"
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -1383,7 +1384,7 @@ struct MT {
     double next_double() { return u32() * (1.0 / 4294967296.0); }
     void get_state(uint32_t* s625) const { memcpy(s625, mt, sizeof mt); s625[624] = (uint32_t)mti; }
     void set_state(const uint32_t* s625) { memcpy(mt, s625, sizeof mt); mti = (int)s625[624]; }
-    int32_t next_full_range_int32() { uint32_t v = 0; for (int b = 0; b < 4; b++) v |= (uint32_t)(u32() % 256u) << (8 * b); return (int32_t)v; }
+    int32_t next_full_range_int32() { uint32_t g[4]; for (int b = 0; b < 4; b++) g[b] = u32(); return canvas_mathnet_full_range_int32(g, canvas_mathnet_seed_variant()); }      // (include/canvas_mathnet.h: the switch the oracle shares)
 };
 
 // ---- R nmath subset used by GetBoundary (R.cs:8-160,528-548)
@@ -2810,6 +2811,14 @@ extern "C" int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h
     for (size_t i = 0; i < sb.size(); i++) h_out[i] = sb[i];
     return (int64_t)sb.size();
 }
+// host-only: the per-chromosome seeds in file order (CBSRunner.cs:107-112) under the byte convention of include/canvas_mathnet.h
+static void cbs_chromosome_seeds(int nchr, int32_t* out) { cbs::MT seeder(0u); for (int c = 0; c < nchr; c++) out[c] = seeder.next_full_range_int32(); }
+extern "C" int32_t canvas_cbs_seeds(int32_t nchr, int32_t* h_out, int32_t* h_variant) {
+    if (nchr < 0 || (nchr > 0 && !h_out)) return CANVAS_ERR_INVALID;
+    cbs_chromosome_seeds(nchr, h_out);
+    if (h_variant) *h_variant = canvas_mathnet_seed_variant();
+    return CANVAS_OK;
+}
 // Diagnostic / test entry: ONE batch of nb permutations of the (centred) segment h_x[n] through the device permutation engine, exactly as FindChangePoints' hybrid test
 // runs it (XPerm + HTMaxP with hk = 25, al0 = 2; ChangePoint.cs:337-364,407-421; CBSTStatistic.cs:354-586) from a generator seeded with `seed`.  kernel: 0 = k_perm_stat,
 // 1 = k_perm_fy.  h_lohi[2 nb]: the interval of every permutation's statistic (the exact value lies inside); h_ms3: milliseconds of the generator's sequential part, of its
@@ -2909,9 +2918,8 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
       if (fresh) { cbs::compute_boundary(nperm, alpha, 0.05, sb); sbN = nperm; sbA = alpha; } sbdry = sb;
       if (fresh && cvx_hook("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs: sequential boundary table (GetBoundary.cs) computed in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count()); }
     // per-chromosome seeds in file order (CBSRunner.cs:107-112)
-    cbs::MT seeder(0u);
     std::vector<int32_t> seeds(nchr);
-    for (int c = 0; c < nchr; c++) seeds[c] = seeder.next_full_range_int32();
+    cbs_chromosome_seeds(nchr, seeds.data());
     double trimmedSD = 1.0;
     if (undo == 2 && N > 1) trimmedSD = std::sqrt(cbs::trimmed_variance(cov.data(), h_chr_offset, nchr, 0.025));   // CBSRunner.cs:102
     cbs::Stats st;

@@ -69,10 +69,29 @@ def sample_seed(base_seed, rank):
     return base_seed + 1000 * rank
 
 
+def _gloo():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo"
+
+
+def all_gather_tensor(t):
+    """dist.all_gather of one small tensor on either backend (gloo has no all_gather of device tensors: they travel through host memory); list of tensors on t's device"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return [t]
+    src = t.cpu() if _gloo() else t
+    outs = [torch.zeros_like(src) for _ in range(world)]
+    dist.all_gather(outs, src)
+    return [o.to(t.device) for o in outs]
+
+
 def aggregate_throughput(seconds, units, device=None):
     """(max over ranks of the timed region, sum over ranks of the units processed) -> (seconds, units, units/s)"""
     import torch
     import torch.distributed as dist
+    if _gloo(): device = None
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     u = torch.tensor([float(units)], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -84,6 +103,7 @@ def aggregate_throughput(seconds, units, device=None):
 def max_over_ranks(seconds, device=None):
     import torch
     import torch.distributed as dist
+    if _gloo(): device = None
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -340,7 +360,8 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
     cohort = {"value": round(cbins / (cdt / args.steps), 1), "ms_per_step": round(cdt / args.steps * 1e3, 3), "scaling": "weak", "samples": world,
               "note": "one 60x sample per rank, no data-path collective (python bench.py --multi cohort prints this mode as the headline)"}
     base = {"metric": "genome-bins/sec (bin+clean+partition)", "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
-            "dtype": "u8/int32 (bin), f32/f64 (clean, viterbi)", "data": "synthetic"}
+            "dtype": "u8/int32 (bin), f32/f64 (clean, viterbi)", "data": "synthetic",
+            "transport": "host callback over gloo, every rank on GPU 0 (CANVAS_BENCH_ONE_GPU: the tests' launch, not a scaling measurement)" if _gloo() else "RCCL (ncclAllGather), one GPU per rank"}
 
     def fallback_line(why):
         """the sharded mode did not complete: the cohort mode (already measured) becomes the line of this launch, with the reason"""
@@ -386,8 +407,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
         n = int(r["n_out"])
         dig = torch.stack([seg[:n].to(torch.int64).sum(), (seg[:n].to(torch.int64) * torch.arange(n, device=device) % 1000003).sum(), state[:n].to(torch.int64).sum(),
                            out["count"][:n].view(torch.int32).to(torch.int64).sum()])
-        digs = [torch.zeros_like(dig) for _ in range(world)]
-        dist.all_gather(digs, dig)
+        digs = all_gather_tensor(dig)
         same_on_all_ranks = bool(all((d == digs[0]).all() for d in digs))
         equals_single = None
         if rank == 0:
@@ -453,8 +473,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             else:
                 allbp = np.concatenate([np.asarray(b, np.int64) for b in got] + [np.zeros(1, np.int64)])
                 dig = torch.tensor([int(allbp.sum()), int((allbp * (np.arange(len(allbp)) % 1009)).sum()), len(allbp)], device=device)
-            digs = [torch.zeros_like(dig) for _ in range(world)]
-            dist.all_gather(digs, dig)
+            digs = all_gather_tensor(dig)
             same = bool(all((d == digs[0]).all() for d in digs))
             eq = None; sec1 = None
             if rank == 0:
@@ -494,11 +513,9 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             k = pr["n"]
             dig = torch.stack([pr["start"].to(torch.int64).sum(), pr["stop"].to(torch.int64).sum(), (pr["chr"].to(torch.int64) * (torch.arange(k, device=device) % 1009)).sum(),
                                torch.tensor(k, device=device), torch.tensor(int(pr["bin_size"]), device=device)])
-            digs = [torch.zeros_like(dig) for _ in range(world)]
-            dist.all_gather(digs, dig)
+            digs = all_gather_tensor(dig)
             same = bool(all((d == digs[0]).all() for d in digs))
-            binned = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-            dist.all_gather(binned, torch.tensor([pr["n_binned"]], dtype=torch.int64, device=device))
+            binned = all_gather_tensor(torch.tensor([pr["n_binned"]], dtype=torch.int64, device=device))
             eq = None; sec1 = None
             if rank == 0:
                 t1 = time.perf_counter()
@@ -543,8 +560,13 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
                     else: gb[c], _, gm[c], thr = synth_generate_device(seed, c, lengths[c], args.rate, device, thr)
                     gh[c] = synth_generate_sample_device(seed, seed + 5000 + 31 * gs_, c, int(lengths[c]), thr_g, device)[0]
             torch.cuda.synchronize()
-            enter_world = lambda: restore_library_comm(cv)
-            enter_group = lambda: split_library_comm(cv, gs_, gg_)
+            if _gloo():      # (the tests' one-GPU launch: host transport, one gloo group per sample)
+                ggroups = [dist.new_group(ranks=[r_ for r_ in range(world) if layout[r_][0] == s_], backend="gloo") for s_ in range(3)]
+                enter_world = lambda: init_host_comm(cv, rank, world)
+                enter_group = lambda: init_host_comm(cv, gg_, gn_, group=ggroups[gs_])
+            else:
+                enter_world = lambda: restore_library_comm(cv)
+                enter_group = lambda: split_library_comm(cv, gs_, gg_)
             flow = lambda: pedigree_grid_flow(cv, layout, rank, enter_world, enter_group, gb, gm, gh, lens, is_auto, flags)
             flow(); enter_world(); barrier()
             t0 = time.perf_counter(); gr = flow(); enter_world(); barrier()
@@ -553,8 +575,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             dig = torch.stack([gr["start"].to(torch.int64).sum(), gr["stop"].to(torch.int64).sum(), (gr["chr"].to(torch.int64) * (torch.arange(k, device=device) % 1009)).sum(),
                                torch.tensor(k, device=device), torch.tensor(int(gr["bin_size"]), device=device), gr["count"].view(torch.int32).to(torch.int64).sum(),
                                (gr["state"][:k].to(torch.int64) * (torch.arange(k, device=device) % 1013)).sum()])
-            digs = [torch.zeros_like(dig) for _ in range(world)]
-            dist.all_gather(digs, dig)
+            digs = all_gather_tensor(dig)
             # the bins (first five words) are the pedigree's: the same on every rank; counts and states are the sample's: the same inside a group
             same_bins = bool(all((d[:5] == digs[0][:5]).all() for d in digs))
             same_in_group = bool(all((digs[r_] == digs[rr_]).all() for r_ in range(world) for rr_ in range(world) if layout[r_][0] == layout[rr_][0]))
@@ -588,7 +609,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             barrier()
     except Exception as e:                                        # noqa: BLE001
         grid = {"error": "%s: %s" % (type(e).__name__, e)}
-        try: restore_library_comm(cv)
+        try: enter_world()
         except Exception: pass
     # ---- BASELINE configs[4], chromosomes sharded: tumour 80x (GCContentWeighted) + normal 40x of the owned chromosomes -> canvas_bin_sample_sharded x 2 -> ratio + CanvasClean on
     # every rank -> canvas_cbs_sharded.  Strong scaling (one pair, N ranks); rank 0 repeats the flow on its own GPU and compares.  Untimed for `value`.
@@ -630,8 +651,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             nc = int(sr["n_clean"])
             dig = torch.stack([sr["cov"][:nc].sum().to(torch.float64), sr["seg_len"].to(torch.float64).sum(), torch.tensor(float(nc), device=device, dtype=torch.float64),
                                torch.tensor(float(sr["bin_size"]), device=device, dtype=torch.float64), torch.tensor(float(int(sr["nseg"].sum())), device=device, dtype=torch.float64)])
-            digs = [torch.zeros_like(dig) for _ in range(world)]
-            dist.all_gather(digs, dig)
+            digs = all_gather_tensor(dig)
             same = bool(all((d == digs[0]).all() for d in digs))
             eq = None; sec1 = None
             if rank == 0:

@@ -292,6 +292,10 @@ int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int32_t n, uin
  * CBSRunner passes it: maxOnes (maxOnes + 1) / 2 entries with maxOnes = floor(nperm alpha) + 1.  Returns the number of entries (or a negative error code).  The library
  * evaluates the table's scans on its host thread pool with the scans' own evaluations and comparisons; exposed so that the table can be checked without a device. */
 int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h_out, int64_t cap);
+/* Host-only (no context, no GPU): the seeds of the per-chromosome generators canvas_cbs uses, in file order — new MersenneTwister(0) followed by one NextFullRangeInt32() per
+ * chromosome (CBSRunner.cs:107-112).  h_out[nchr]; h_variant (optional): which reading of MathNet's NextBytes is in force (0 / 1 / 2, include/canvas_mathnet.h: the one
+ * assumption of this path that could not be checked without a .NET SDK; CANVAS_MATHNET_SEED_BYTES selects it at run time).  Returns 0 or a negative error code. */
+int32_t canvas_cbs_seeds(int32_t nchr, int32_t* h_out, int32_t* h_variant);
 
 /* CanvasPartition -m Wavelets, the reference's default method: WaveletsRunner.Run up to the breakpoints (WaveletsRunner.cs:52-150 =
  * SegmentationInput.GetCoverageVariability / FactorOfThreeCoverageVariabilities, Segmentation.cs:297-429, then

@@ -17,6 +17,7 @@
 //   SortedList<T>.Median() (Illumina.Common, not in /root/reference) -> sorted; odd: a[n/2]; even: (a[n/2-1]+a[n/2])/2 in T
 #pragma once
 #include <cstdint>
+#include "../include/canvas_mathnet.h"
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -47,7 +48,7 @@ static inline T median_copy(const std::vector<T>& v) { std::vector<T> c(v); retu
 
 // ---- MT19937 as MathNet.Numerics.Random.MersenneTwister 3.17 is assumed to behave (not in /root/reference;
 // parity unpinned): init_genrand((uint)seed); NextDouble() = genrand_int32() * 2^-32;
-// NextFullRangeInt32() = BitConverter.ToInt32 of 4 bytes, each byte = (byte)(genrand_int32() % 256).
+// NextFullRangeInt32() = BitConverter.ToInt32 of 4 bytes, each byte = (byte)(genrand_int32() % 256) by default — variants 1 / 2: include/canvas_mathnet.h.
 struct MT19937 {
     uint32_t mt[624];
     int mti;
@@ -81,10 +82,10 @@ struct MT19937 {
         return y;
     }
     double next_double() { return next_u32() * (1.0 / 4294967296.0); }
-    int32_t next_full_range_int32() {
-        uint32_t v = 0;
-        for (int b = 0; b < 4; b++) v |= (uint32_t)(next_u32() % 256u) << (8 * b);
-        return (int32_t)v;
+    int32_t next_full_range_int32() {      // which eight bits make a byte: include/canvas_mathnet.h (the one switch the product and this oracle share)
+        uint32_t g[4];
+        for (int b = 0; b < 4; b++) g[b] = next_u32();
+        return canvas_mathnet_full_range_int32(g, canvas_mathnet_seed_variant());
     }
 };
 
