@@ -1526,7 +1526,11 @@ static int32_t bin_predefined_impl(canvas_ctx* ctx, int32_t nchr, const uint8_t*
         for (int c = 0; c < nchr; c++) if (((uintptr_t)d_fraglen[c] | (uintptr_t)d_bases[c] | (uintptr_t)d_hits[c]) & 15) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "GCContentWeighted mode: bases, hits and fragment lengths must be 16-byte aligned");
         int32_t rcp = gcw_prepass_begin(ctx, nchr, d_bases, d_hits, d_fraglen, h_len, false, gp); if (rcp) return rcp;
     }
-    if (nbins == 0) return CANVAS_OK;
+    if (nbins == 0) {
+        // the pre-pass has enqueued copies out of the pinned staging area (weights, chromosome table): they must have left it before the next call refills it
+        if (gcw) CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return CANVAS_OK;
+    }
     WsSizer sz;
     sz.take<PreChrom>(nchr); sz.take<int>(64); sz.take<BinChrom>(nchr); sz.take<int32_t>(nbins); sz.take<int32_t>(nbins);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;

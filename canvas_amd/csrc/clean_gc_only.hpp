@@ -9,8 +9,11 @@
 //                 the row into the genome row; one more workgroup turns the chunk totals into the chunks' output offsets.
 //   k_cg_apply    IN PLACE: every workgroup loads its whole chunk into registers, says so (a flag per chunk), reads the global median off the genome row while the loads are
 //                 in flight, waits for the chunks its output range reaches back into, and stores the surviving bins — normalised (:189-195) — at their final position.
-//                 The chunk is the workgroup's index while the grid fits the device (one workgroup per CU: whoever is waited for is running or waits for foreign work
-//                 alone), a ticket otherwise — a workgroup then only ever waits for workgroups that started before it.
+//                 The chunk is a TICKET, always: a workgroup then only ever waits for workgroups that started before it — each of them is resident and sets its flag
+//                 before it waits for anybody — so the wait chain ends whatever else runs on the device.  (Rounds 4-5 used the workgroup's index while the grid
+//                 fitted the device, 2 us less; that needs every workgroup of the grid resident at once, which another process's kernels, a CU mask or a second
+//                 spinning kernel can break: a hang.  The wait is bounded on top of that: a flag that does not come within ~4 s raises CG_FAIL_STALL and the call
+//                 returns an error instead of never returning.)
 // (A first version took the decisions in the LAST workgroup of k_cg_count / k_cg_medians: 14 + 9 us of tails behind an arrival ticket — measured with CANVAS_CG_CUT, the timing
 // hook below.  Every decision is a function of a few hundred words; recomputing it where it is needed costs less than handing it over.)
 // (Statistics and apply as ONE launch — the first 102 tickets the statistics roles, the others chunk workgroups that load their chunk and then wait for the roles' count — was
@@ -44,6 +47,9 @@
 #define CG_FAIL_VALUE 2u               // a count that is not a whole number in [0, 2^30)
 #define CG_FAIL_THRESHOLD 4u           // buckets with fewer than 100 autosomal bins survive: their medians are neighbour-weighted quantiles (CanvasClean.cs:178-187)
 #define CG_FAIL_WINDOW 8u              // a median lies outside the counter window
+#define CG_FAIL_STALL 16u              // k_cg_apply: a chunk in front of this one never reported its loads (cannot happen in ticket order unless the device stops scheduling a resident
+                                       // workgroup); the arrays are partly rewritten: the call fails with an error, nothing falls back
+#define CG_SPIN_LIMIT (1u << 27)       // s_sleep(1) rounds (64 clocks each, ~30 ns) a workgroup waits for one flag: ~4 s
 
 struct CgDev {
     double medians[NGC]; double globalMedian;
@@ -340,16 +346,12 @@ __global__ void __launch_bounds__(CG_T) k_cg_apply(const CgPack P) {
     __shared__ double sMed[NGC]; __shared__ uint8_t sKeep[NGC + 3];
     __shared__ uint32_t sWc[CG_BPT * CG_NW], sBase[CG_BPT * CG_NW], sPart[4];
     __shared__ unsigned long long sWave[CG_NW];
-    __shared__ int sPick[2];
-    // chunks in the order the workgroups start: a workgroup only ever waits for chunks that are already being worked on
-    // ... which needs a ticket only when the grid has more workgroups than the device has places for them (one per CU: 107 registers x 1024 threads): otherwise every
-    // workgroup that is not running yet waits for foreign work alone, never for one of ours, and the chunk is blockIdx.x without the ticket's round trip
+    __shared__ int sPick[2]; __shared__ int sStall;
+    // chunks in the order the workgroups start: a workgroup only ever waits for chunks that are already being worked on (see the header: always, not only when the grid
+    // exceeds the device)
     if (t == 0) {
-        uint32_t id = blockIdx.x;
-        if (P.ticket) {
-            id = __hip_atomic_fetch_add(&A.S->tick[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((int)id == A.G - 1) __hip_atomic_store(&A.S->tick[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every chunk is handed out: ready for the next call
-        }
+        const uint32_t id = __hip_atomic_fetch_add(&A.S->tick[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)id == A.G - 1) __hip_atomic_store(&A.S->tick[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every chunk is handed out: ready for the next call
         sW = (int)id;
         sPick[0] = -1; sPick[1] = -1;
     }
@@ -408,9 +410,19 @@ __global__ void __launch_bounds__(CG_T) k_cg_apply(const CgPack P) {
     const uint32_t off = D->off[w];
     if (t == 0) {
         const int first = (int)(off / (uint32_t)A.chunk);
-        for (int q = first; q < w; q++) while (__hip_atomic_load(&A.S->ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) __builtin_amdgcn_s_sleep(1);
+        bool stalled = false;
+        for (int q = first; q < w && !stalled; q++) {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&A.S->ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
+                if (++spins > CG_SPIN_LIMIT) { stalled = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (stalled) __hip_atomic_fetch_or(&D->failApply, CG_FAIL_STALL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sStall = stalled ? 1 : 0;
     }
     __syncthreads();
+    if (sStall) return;                                            // never write behind a chunk that may not have been read: the host reports the stall
 #pragma unroll
     for (int j = 0; j < CG_BPT; j++) {
         if (j >= A.bpt) continue;
@@ -440,8 +452,6 @@ static int32_t clean_gc_only(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t
     CgPack pack; memset(&pack, 0, sizeof pack);
     memcpy(pack.isAuto, h_chr_is_autosome, (size_t)nchr); pack.minBinsPerGc = min_bins_per_gc;
     { const char* cut = cvx_hook("CANVAS_CG_CUT"); pack.cut = cut ? atoi(cut) : 0; }
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) cus = 0;
     WsSizer sz; sz.take<CgDev>(B);
     int Gmax = 1;
     for (int s = 0; s < B; s++) {
@@ -455,7 +465,7 @@ static int32_t clean_gc_only(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t
         sz.take<uint32_t>((size_t)G * CG_SLAB); sz.take<uint32_t>((size_t)G * CG_TABW);
         Gmax = std::max(Gmax, G);
     }
-    pack.ticket = ((long long)Gmax * B > (long long)cus || cvx_hook("CANVAS_CG_TICKET")) ? 1 : 0;       // (k_cg_apply; the hook forces the ticket for the tests)
+    pack.ticket = 1;       // (k_cg_apply takes its chunk by ticket, always: see the header)
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     WsCarver ws(ctx->ws);
     CgDev* dD = ws.take<CgDev>(B);
@@ -479,6 +489,7 @@ static int32_t clean_gc_only(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t
     for (int s = 0; s < B; s++) {
         const CgDev& H = *(const CgDev*)((const char*)ctx->pin + (size_t)s * head);
         if (H.fail & CG_FAIL_INDEX) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: a bin has gc outside 0..100 or a chromosome index outside [0, nchr) (the reference throws IndexOutOfRangeException)");
+        if (H.failApply & CG_FAIL_STALL) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_clean: the in-place GC normalisation waited ~4 s for a workgroup that had started and never reported its loads (device not scheduling?); the sample's arrays are partly rewritten and must be reloaded");
     }
     for (int s = 0; s < B; s++) {
         const CgDev& H = *(const CgDev*)((const char*)ctx->pin + (size_t)s * head);

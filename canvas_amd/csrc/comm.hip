@@ -22,7 +22,7 @@ __global__ void k_pack_boundaries(const int32_t* __restrict__ local, int nlocal,
 // they do not (ranks that share a GPU, hosts that bring their own MPI): device -> pinned host -> callback -> device, synchronous.
 int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
     ProfScope ps(ctx, "allgather");                     // (hipEvents on the library's stream around every collective: bench.py --gpus N reports their sum per pass)
-    if (ctx->nranks == 1 && !ctx->comm) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream)); return CANVAS_OK; }
+    if (ctx->nranks == 1 && !ctx->comm) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDefault, ctx->stream)); return CANVAS_OK; }
     if (ctx->comm) { CANVAS_NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream)); return CANVAS_OK; }
     if (!ctx->host_allgather) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "no communicator: call canvas_comm_init or canvas_comm_init_host first");
     const size_t need = bytes * (size_t)(ctx->nranks + 1);
@@ -34,10 +34,11 @@ int32_t cvx_allgather(canvas_ctx* ctx, const void* d_send, void* d_recv, size_t 
     // synchronisation (below, same stream) has passed it by the time this area comes round again — one synchronisation per exchange instead of two
     ctx->comm_pin_flip ^= 1;
     char* hs = (char*)ctx->comm_pin + (ctx->comm_pin_flip ? ctx->comm_pin_bytes / 2 : 0); char* hr = hs + bytes;
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    // (hipMemcpyDefault: a rank that announces a failed device reservation sends from / receives into pinned host memory, sharded.hip)
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hs, d_send, bytes, hipMemcpyDefault, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->host_allgather(ctx->host_allgather_user, hs, (int64_t)bytes, hr) != 0) CANVAS_FAIL(ctx, CANVAS_ERR_COMM, "host all-gather callback failed");
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_recv, hr, bytes * (size_t)ctx->nranks, hipMemcpyHostToDevice, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(d_recv, hr, bytes * (size_t)ctx->nranks, hipMemcpyDefault, ctx->stream));
     return CANVAS_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -145,7 +146,11 @@ static inline int32_t cvx_mail_await(canvas_ctx* ctx, const volatile unsigned* s
         const auto t0 = std::chrono::steady_clock::now();
         while (*seqWord != expect) {
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) { ctx->err = std::string(what) + ": a result written to pinned host memory did not arrive"; return CANVAS_ERR_HIP; }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);

@@ -585,7 +585,23 @@ extern "C" int32_t canvas_hmm_per_sample_sharded(canvas_ctx* ctx, int32_t nchr, 
     const long long hardMax = std::min<long long>(4ll * (N + nchr + 16), 0x7FFFFFF0ll);
     for (int attempt = 0; attempt < 2; attempt++) {
         const size_t recBytes = al((size_t)maxPer * 4) + al((size_t)W * (1 + (size_t)maxPer) * 4) + 4096;
-        rc = canvas_ws_reserve(ctx, recBytes + (size_t)(1 + maxPer) * 4 + 4096); if (rc) return rc;      // (the same allocation on every rank)
+        // (the same allocation on every rank.)  A rank whose reservation fails — on the second attempt it is W x 4 (N + nchr) words — must still ENTER the collective, or its
+        // peers wait in ncclAllGather for ever: it announces the failure from a pinned host area of the same size (device-accessible, so the collective accepts it) and every
+        // rank returns an error.  Only when that allocation fails too is there nothing left to announce with.
+        rc = canvas_ws_reserve(ctx, recBytes + (size_t)(1 + maxPer) * 4 + 4096);
+        { const char* inj = cvx_hook("CANVAS_HMM_SHARDED_FAIL_RESERVE");      // test hook "rank:attempt": that rank's reservation of that attempt fails
+          if (inj && !rc) { int ir = -1, ia = -1; if (sscanf(inj, "%d:%d", &ir, &ia) == 2 && ir == ctx->rank && ia == attempt) { rc = CANVAS_ERR_HIP; ctx->err = std::string(what) + ": workspace reservation failed (injected by CANVAS_HMM_SHARDED_FAIL_RESERVE)"; } } }
+        if (rc) {
+            fail_local(rc);
+            const size_t slot = (size_t)(1 + maxPer) * 4;
+            void* area = nullptr;
+            if (hipHostMalloc(&area, slot * (size_t)(W + 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->err = localMsg; return localErr; }
+            int32_t* hs = (int32_t*)area; memset(hs, 0, slot); hs[0] = localErr < 0 ? localErr : -localErr;
+            const int32_t rcg = cvx_allgather(ctx, hs, (char*)area + slot, slot);
+            (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(area);
+            if (rcg) return rcg;
+            ctx->err = localMsg; return localErr;
+        }
         char* wsb = (char*)ctx->ws + al((size_t)(1 + maxPer) * 4 + 256);      // canvas_allgather_boundaries packs into the FRONT of the workspace
         int32_t* dRec = (int32_t*)wsb; int32_t* dAll = (int32_t*)(wsb + al((size_t)maxPer * 4));
         unsigned int nrec = 0;
@@ -607,6 +623,7 @@ extern "C" int32_t canvas_hmm_per_sample_sharded(canvas_ctx* ctx, int32_t nchr, 
         if (overflow) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, std::string(what) + ": the state runs do not fit the exchange");
         if (N > 0) {
             std::vector<long long> chrOff64(h_chr_offset, h_chr_offset + nchr + 1);
+            // (from here on a failure is local: the function's only collective is behind every rank)
             rc = canvas_h2d_small(ctx, dChrOff, chrOff64.data(), (size_t)(nchr + 1) * 8); if (rc) return rc;
             CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4, ctx->stream));
             hipLaunchKernelGGL(k_sh_fill_state, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, dAll, 1 + maxPer, dOwner, dChrOff, nchr, N, d_state, dBad);

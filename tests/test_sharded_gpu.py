@@ -987,3 +987,53 @@ def test_sharded_per_sample_hmm_keeps_its_state_runs_on_the_device():
         assert same and (np.array(st, np.int32) == exp).all(), rank
         assert stats[0] == world
     assert got[2][3][4] > 500                                    # rank 2 owns the 40 000-bin chromosome: its runs went through the retry
+
+
+def _hmm_fail_worker(rank, world, port, q, inject):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        os.environ["CANVAS_HMM_SHARDED_FAIL_RESERVE"] = inject
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from canvas_amd import Canvas, parallel
+        from canvas_amd.lib import CanvasError
+        cv = Canvas(0)
+        parallel.init_host_comm(cv, rank, world)
+        cov, off = _hmm_coverage()
+        owner = np.array([c % world for c in range(len(HMM_LENS))], np.int32)
+        d = torch.from_numpy(cov).to(cv.device)
+        try:
+            cv.hmm_per_sample_sharded(owner, d, off)
+            q.put((rank, "returned", ""))
+        except CanvasError as e:
+            q.put((rank, "failed", str(e)))
+        dist.destroy_process_group()
+    except Exception:                                           # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("inject", ["1:0", "1:1"])
+def test_sharded_hmm_a_failed_reservation_on_one_rank_fails_every_rank(inject):
+    """ADVICE r05 (sharded.hip:583): rank 1's workspace reservation fails — on the first attempt, or on the retry with the hard bound (W x 4 (N + nchr) words: where an
+    out-of-memory is plausible) — and must be announced THROUGH the collective: every rank returns an error, nobody is left waiting in the all-gather"""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hmm_fail_worker, args=(r, world, port, q, inject)) for r in range(world)]
+    for p in procs: p.start()
+    try:
+        got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])      # a hang shows up as queue.Empty here
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive(): p.kill()
+    for g in got:
+        assert g[1] == "failed", g
+    assert "injected" in got[1][2] and "rank 1 failed" in got[0][2] and "rank 1 failed" in got[2][2]
