@@ -406,6 +406,7 @@ sys.stdin.readline()                                   # all children start thei
 taken = 0
 for it in range(loops):
     dev = {k: v.clone() for k, v in src.items()}
+    torch.cuda.synchronize()                               # (the clones run on torch's stream, the library on its own)
     n_out, _, info = cv.clean(dev, n, is_auto, CLEAN_GCNORM)
     taken += int(info[6])
     if it % 16 == 0 or it == loops - 1:
@@ -416,7 +417,7 @@ print("DONE", taken, flush=True)
 """
 
 
-def test_clean_gc_only_three_processes_share_one_gpu_without_hanging():
+def test_clean_gc_only_three_processes_share_one_gpu_without_hanging(clean_path):
     """VERDICT r05 Weak 8 / ADVICE: k_cg_apply's workgroups wait for one another.  Three processes loop CanvasClean -g on ONE device at the same time — each other's kernels
     hold CUs, so no grid can count on being resident as a whole — under a watchdog: every call must return (chunks are taken by ticket, a workgroup only waits for
     workgroups that have started) with the oracle's bins.  The reference runs CanvasClean one sample after another (Canvas/CanvasRunner.cs:977-993); a shared GPU does not."""
@@ -425,6 +426,8 @@ def test_clean_gc_only_three_processes_share_one_gpu_without_hanging():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    if clean_path == "device_driven_radix":
+        pytest.skip("the -g-only stage does not depend on the select variant")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = [subprocess.Popen([sys.executable, "-c", _CG_CHILD, root, str(20260927 + 40 + i), "300", str(2_500_000 + 100_000 * i)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for i in range(3)]
@@ -441,6 +444,8 @@ def test_clean_gc_only_three_processes_share_one_gpu_without_hanging():
                 pytest.fail("a process looping CanvasClean -g beside two others did not return within 600 s (k_cg_apply stalled?)")
             assert p.returncode == 0, err[-3000:]
             outs.append(out.strip().splitlines()[-1])
+        if clean_path == "host_driven":
+            return                                                 # (that orchestration keeps -g alone on the general chain: the watchdog and the parity checks above are the test)
         assert all(o.startswith("DONE") and int(o.split()[1]) == 300 for o in outs), outs       # every call took the three-launch in-place stage
     finally:
         for p in procs:
