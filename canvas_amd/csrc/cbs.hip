@@ -300,6 +300,7 @@ struct PermReq {
     const uint32_t* hist;      // (cont) the MT_HISTORY outputs in front of position 0 of this batch — where they were written: in the OTHER of the loop's two draw buffers (they used to be
                                // copied in front of P.draws, 10 MB device to device per batch: 7 % of the device time of the tumour / normal flow's CBS went into those copies)
     int fy;                    // 0: k_perm_stat, 1: k_perm_fy, 2: k_perm_small, 3: k_perm_rp evaluates this request's permutations
+    int cached = 0;            // the draws lie in the chromosome's stream cache (MtStreamCache): P.draws points INTO it, nothing is generated or snapshotted for this request
     // k_perm_rp: rpWGs persistent workgroups (blocks rpBase .. rpBase + rpWGs of its launch), each with its own scratch of rp.stride words behind rpScratch
     int rpBase, rpWGs; uint32_t* rpScratch; long long* rpClk;      // rpClk (probe only): cycles of workgroup 0 per phase
     struct RpPlan { int K, nT; uint32_t inOff[32], inCap[32]; uint32_t oEndsIn, oEndsOwn, oInbox, oOutIn, oOutOwn, stride; } rp;
@@ -330,7 +331,7 @@ static constexpr int MT_LAG_C[MT_NLAG] = {623, 850, 1077, 1246, 1304, 1531, 1700
 __global__ void __launch_bounds__(256) k_mt_draws(const PermReq* __restrict__ reqs, int bootstrap) {
     __shared__ uint32_t mtA[624], mtB[624];
     const PermReq& R = reqs[blockIdx.x];
-    if (R.cont || R.fy == 2) return;
+    if (R.cont || R.fy == 2 || R.cached) return;
     uint32_t* __restrict__ draws = R.P.draws;
     const long long seqMax = bootstrap && R.total >= MT_BOOT_MIN ? 19937LL : MT_HISTORY;     // bootstrap: only the first 19937 outputs come from here (see k_mt_classes)
     const long long total = R.total < seqMax ? R.total : seqMax;
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(MTC_T) k_mt_classes(const PermReq* __restrict_
     // index every line was written by 8 different L2s, 4 bytes at a time (PMC: 43 GB of WRITE_SIZE for 4.8 GB of draws).  Sequences r = x * (stride / 8) + k for the k-th
     // workgroup of XCD x: a line's 16 writers share an L2 and run side by side.
     const int bx = (int)blockIdx.x, r = stride >= 8 ? (bx & 7) * (stride >> 3) + (bx >> 3) : bx, tid = (int)threadIdx.x;
-    if (R.fy == 2 || (boot && (R.cont || R.total < MT_BOOT_MIN))) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
+    if (R.fy == 2 || R.cached || (boot && (R.cont || R.total < MT_BOOT_MIN))) return;           // continued from the previous batch: the history is there already; short requests: generated sequentially
     const gptr<uint32_t> d = as_global(R.P.draws);               // (typed global: a flat store in the loop would tie every LDS wait to the store's completion, common.hpp)
     const long long start = boot ? 19937LL * stride : (R.cont ? 0 : MT_HISTORY);        // first position to generate; the 19937 * stride positions in front of it are there
     const long long end = boot ? (R.total < 19937LL * 2 * stride ? R.total : 19937LL * 2 * stride) : R.total;
@@ -430,7 +431,7 @@ __global__ void __launch_bounds__(256) k_mt_snapshots(const PermReq* __restrict_
     { int lo = 0, hi = nreq - 1; while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (reqs[mid].blockBase <= (int)blockIdx.x) lo = mid; else hi = mid - 1; } ri = lo; }
     const PermReq& R = reqs[ri];
     const int b = (int)blockIdx.x - R.blockBase;
-    if (R.fy == 2) return;                                 // (draws of short segments come from the host: perm_loop_small_gpu)
+    if (R.fy == 2 || R.cached) return;                     // (draws of short segments come from the host: perm_loop_small_gpu; cached draws: the host keeps a POSITION, not a state)
     const long long end = (long long)(b + 1) * R.n;       // (fewer than 624 outputs in front of it in a batch that continues nothing: the host advances the start state instead, perm_loop_gpu)
     uint32_t* s = R.snaps + (size_t)b * 625;
     for (int i = threadIdx.x; i < 624; i += 256) { const long long at = end - 624 + i; s[i] = mt_untemper(at >= 0 ? R.P.draws[at] : (R.cont ? R.hist[MT_HISTORY + at] : 0u)); }      // (at < 0: a continued batch of a short segment — the words lie in the previous batch; a batch that continues nothing: the snapshot is not used, see above)
@@ -1367,8 +1368,10 @@ static inline int dn_round(double v) { return (int)std::nearbyint(v); }   // Con
 // MathNet MersenneTwister as assumed in SURVEY §8c (parity unpinned): init_genrand, NextDouble = u32 * 2^-32
 struct MT {
     uint32_t mt[624]; int mti;
+    long long drawn = 0;       // outputs taken since the object was created / adopted a state (Rng: the chromosome's stream position is a base + this)
     explicit MT(uint32_t s) { mt[0] = s; for (mti = 1; mti < 624; mti++) mt[mti] = 1812433253u * (mt[mti - 1] ^ (mt[mti - 1] >> 30)) + (uint32_t)mti; }
     uint32_t u32() {
+        drawn++;
         if (mti >= 624) {
             static const uint32_t mag[2] = {0u, 0x9908b0dfu};
             int k; uint32_t y;
@@ -1918,7 +1921,7 @@ static bool tpermp_device_impl(canvas_ctx* ctx, hipStream_t stream, int n1, int 
     (void)hipFree(d);
     if (!ok) { (void)hipGetLastError(); return false; }
     rnd.set_state(state);
-    if (out[1]) st.tpermp_draws += (long long)nPerm * std::min(n1, n2);
+    if (out[1]) { st.tpermp_draws += (long long)nPerm * std::min(n1, n2); rnd.drawn += (long long)nPerm * std::min(n1, n2); }
     st.tpermp_device++;
     p = (double)out[0] / nPerm;
     return true;
@@ -1978,6 +1981,168 @@ static void rp_plan(int n, PermReq::RpPlan& P) {
 }
 static size_t rp_scratch_bytes(int n, int wgs) { PermReq::RpPlan P; rp_plan(n, P); return (size_t)P.stride * 4 * (size_t)wgs; }
 
+// ================================================================================================ the chromosomes' draw streams, kept in HBM
+// The k-th chromosome's generator is MersenneTwister(seed_k) with seed_k drawn from MersenneTwister(0) in file order (CBSRunner.cs:107-112), and XPerm / TPermP consume it
+// strictly in sequence (ChangePoint.cs:407-421, CBSTStatistic.cs:1009): HOW FAR a call reads depends on the data, the words do not.  So the tempered outputs of every
+// stream are kept per context in device memory — generated once, by the kernels above, in extensions of tens of millions of words that run AHEAD of the permutation loops on a
+// stream of their own — and a permutation batch is handed a pointer into them.  What that removes from every batch of every later call (and from all but the first reader of
+// a position inside a call): the generator launches (k_mt_draws, up to seven bootstrap launches, k_mt_classes: a third of the device time of the tumour / normal flow),
+// k_mt_snapshots and the 2.5 MB of generator states it sent to the host per batch — the host now keeps a POSITION and fetches 624 words only when host code draws (edge
+// tests, re-evaluations).  A stream is one virtual address range (hipMemAddressReserve) into which physical memory is mapped 64 MB at a time as it grows, so positions stay
+// plain offsets and nothing is ever copied; the whole cache is bounded (CANVAS_CBS_CACHE_GB, default 30 % of the device's memory: the 288 GB of an MI355X are there to be
+// used — a 60x germline sample reads 1.6 GB of draws, an 80x / 40x tumour-normal pair 46 GB), and a stream that reaches the bound serves what it holds and hands the rest of
+// the loop to the in-batch generator (the path of rounds 1-5, kept as the fallback).
+#define MTS_GRANULE (size_t(64) << 20)          // physical memory is mapped into a stream in pieces of this size (16 M draws)
+#define MTS_VA_BYTES (size_t(64) << 30)         // address range of a stream: 16 G draws
+#define MTS_FIRST_WORDS (8LL << 20)             // the first extension of a stream (it must leave MT_HISTORY words behind for the strided generator to continue from)
+#define MTS_JOB_MAX_WORDS (256LL << 20)         // ... and the longest one
+struct MtStream {
+    uint32_t seed = 0; char* va = nullptr; size_t mappedBytes = 0; bool plain = false; size_t plainBytes = 0; std::vector<hipMemGenericAllocationHandle_t> handles;
+    long long ready = 0, requested = 0; bool full = false;      // words that are valid / that the producer has been asked for; full: no more memory will be mapped
+    uint32_t* d() const { return (uint32_t*)va; }
+};
+struct MtStreamCache {
+    canvas_ctx* ctx; std::mutex mu; std::condition_variable cvWork, cvReady; std::map<uint32_t, std::unique_ptr<MtStream>> streams;
+    size_t capBytes = 0, usedBytes = 0; bool useVmm = true, stop = false, failed = false, started = false, off = false; std::string err;
+    std::thread th; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr;
+    std::atomic<long long> servedWords{0}, generatedWords{0}, fallbackWords{0}, fetches{0};
+    static constexpr int CAP = 32;
+    explicit MtStreamCache(canvas_ctx* c) : ctx(c) {
+        // CANVAS_CBS_CACHE_GB: the bound of the whole cache in GB (0 switches it off); a configuration switch, read without CANVAS_TEST_HOOKS
+        const char* e = getenv("CANVAS_CBS_CACHE_GB");
+        size_t freeB = 0, totB = 0;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&freeB, &totB) != hipSuccess) { (void)hipGetLastError(); off = true; return; }
+        double gb = e ? atof(e) : 0.30 * (double)totB / 1e9;
+        if (!(gb > 0)) { off = true; return; }
+        capBytes = (size_t)(gb * 1e9);
+        int vmm = 0; if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device) != hipSuccess || !vmm) { (void)hipGetLastError(); useVmm = false; }
+        if (cvx_hook("CANVAS_CBS_CACHE_NO_VMM")) useVmm = false;      // test hook: the fixed-allotment form
+    }
+    ~MtStreamCache() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; } cvWork.notify_all(); cvReady.notify_all();
+        if (th.joinable()) th.join();
+        (void)hipSetDevice(ctx->device);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (dReqs) (void)hipFree(dReqs); if (hReqs) (void)hipHostFree(hReqs);
+        for (auto& kv : streams) {
+            MtStream& S = *kv.second;
+            if (S.plain) { if (S.va) (void)hipFree(S.va); continue; }
+            if (S.va && S.mappedBytes) (void)hipMemUnmap(S.va, S.mappedBytes);
+            for (auto h : S.handles) (void)hipMemRelease(h);
+            if (S.va) (void)hipMemAddressFree(S.va, MTS_VA_BYTES);
+        }
+    }
+    // the stream of a seed (created on first use; nullptr: the cache is off or could not reserve an address range)
+    MtStream* get(uint32_t seed) {
+        if (off) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        if (failed) return nullptr;
+        auto it = streams.find(seed);
+        if (it != streams.end()) return it->second.get();
+        std::unique_ptr<MtStream> S(new MtStream()); S->seed = seed;
+        if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (useVmm) {
+            void* base = nullptr;
+            if (hipMemAddressReserve(&base, MTS_VA_BYTES, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); useVmm = false; }
+            else S->va = (char*)base;
+        }
+        if (!useVmm) {          // no virtual memory management: one fixed allotment per stream (1 / 32 of the bound), served until it is full
+            S->plain = true; S->plainBytes = std::max<size_t>(MTS_GRANULE, (capBytes / 32) & ~(MTS_GRANULE - 1));
+            if (usedBytes + S->plainBytes > capBytes || hipMalloc((void**)&S->va, S->plainBytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            S->mappedBytes = S->plainBytes; usedBytes += S->plainBytes;
+        }
+        MtStream* r = S.get(); streams[seed] = std::move(S);
+        return r;
+    }
+    // ask the producer for [0, upto) without waiting
+    void prefetch(MtStream* S, long long upto) {
+        if (!S) return;
+        { std::lock_guard<std::mutex> lk(mu);
+          upto = std::max(upto, MTS_FIRST_WORDS);
+          if (S->full || failed || upto <= S->requested) return;
+          S->requested = upto; ensure_thread(); }
+        cvWork.notify_one();
+    }
+    // [0, end) must be valid before the caller's kernels read it; ahead: how far beyond `end` the producer should go on.  false: the cache cannot serve `end` (bound reached,
+    // no memory, a HIP error): the caller generates the batch itself
+    bool acquire(MtStream* S, long long end, long long ahead) {
+        if (!S) return false;
+        std::unique_lock<std::mutex> lk(mu);
+        if (S->ready >= end) {
+            if (!S->full && !failed && S->ready < end + ahead / 2 && end + ahead > S->requested) { S->requested = end + ahead; ensure_thread(); lk.unlock(); cvWork.notify_one(); }
+            return true;
+        }
+        if (S->full || failed) return false;
+        if (end + ahead > S->requested) { S->requested = std::max(end + ahead, MTS_FIRST_WORDS); ensure_thread(); cvWork.notify_one(); }
+        cvReady.wait(lk, [&]() { return stop || failed || S->full || S->ready >= end; });
+        return S->ready >= end;
+    }
+    void ensure_thread() { if (!started) { started = true; th = std::thread([this]() { run(); }); } }      // (mu held)
+    // physical memory behind [0, words) of a stream; returns the words that are backed
+    long long back(MtStream& S, long long words) {
+        const size_t need = ((size_t)words * 4 + MTS_GRANULE - 1) & ~(MTS_GRANULE - 1);
+        if (S.plain) return (long long)(S.mappedBytes / 4);
+        while (S.mappedBytes < need && S.mappedBytes + MTS_GRANULE <= MTS_VA_BYTES) {
+            { std::lock_guard<std::mutex> lk(mu); if (usedBytes + MTS_GRANULE > capBytes) break; usedBytes += MTS_GRANULE; }
+            size_t freeB = 0, totB = 0;
+            hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->device;
+            hipMemAccessDesc ad = {}; ad.location.type = hipMemLocationTypeDevice; ad.location.id = ctx->device; ad.flags = hipMemAccessFlagsProtReadWrite;
+            hipMemGenericAllocationHandle_t h;
+            bool ok = hipMemGetInfo(&freeB, &totB) == hipSuccess && freeB > MTS_GRANULE + (size_t(4) << 30)      // (never the device's last 4 GB: the caller's own arrays come first)
+                      && hipMemCreate(&h, MTS_GRANULE, &prop, 0) == hipSuccess;
+            if (ok && hipMemMap(S.va + S.mappedBytes, MTS_GRANULE, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; }
+            if (ok && hipMemSetAccess(S.va + S.mappedBytes, MTS_GRANULE, &ad, 1) != hipSuccess) { (void)hipMemUnmap(S.va + S.mappedBytes, MTS_GRANULE); (void)hipMemRelease(h); ok = false; }
+            if (!ok) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk(mu); usedBytes -= MTS_GRANULE; break; }
+            S.handles.push_back(h); S.mappedBytes += MTS_GRANULE;
+        }
+        return (long long)(S.mappedBytes / 4);
+    }
+    void run() {
+        struct Job { MtStream* S; long long from, to; };
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&dReqs, CAP * sizeof(PermReq)) != hipSuccess
+            || hipHostMalloc((void**)&hReqs, CAP * sizeof(PermReq), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); std::lock_guard<std::mutex> lk(mu); failed = true; err = "the draw-stream cache could not create its stream / request tables"; cvReady.notify_all(); return;
+        }
+        for (;;) {
+            std::vector<Job> jobs;
+            { std::unique_lock<std::mutex> lk(mu);
+              cvWork.wait(lk, [&]() { if (stop) return true; for (auto& kv : streams) if (!kv.second->full && kv.second->requested > kv.second->ready) return true; return false; });
+              if (stop) return;
+              for (auto& kv : streams) { MtStream& S = *kv.second; if (!S.full && S.requested > S.ready && (int)jobs.size() < CAP) jobs.push_back({&S, S.ready, std::min(S.requested, S.ready + MTS_JOB_MAX_WORDS)}); } }
+            std::vector<char> shortJob(jobs.size(), 0);
+            int R = 0; bool anyFresh = false; long long maxFresh = 0, maxTotal = 0;
+            for (size_t i = 0; i < jobs.size(); i++) {
+                Job& j = jobs[i];
+                const long long have = back(*j.S, j.to);
+                if (have < j.to) { j.to = have; shortJob[i] = 1; }
+                if (j.to <= j.from || (j.from == 0 && j.to < MTS_FIRST_WORDS)) { j.to = j.from; continue; }
+                PermReq& q = hReqs[R++];
+                memset((void*)&q, 0, sizeof q);
+                { MT m(j.S->seed); m.get_state(q.state); }
+                q.total = j.to - j.from; q.P.draws = j.S->d() + j.from; q.fy = 0; q.cached = 0;
+                q.cont = j.from > 0 ? 1 : 0; q.hist = q.cont ? j.S->d() + (j.from - MT_HISTORY) : nullptr;
+                if (!q.cont) { anyFresh = true; maxFresh = std::max(maxFresh, q.total); }
+                maxTotal = std::max(maxTotal, q.total + (q.cont ? MT_HISTORY : 0));
+            }
+            bool ok = true;
+            if (R > 0) {
+                ok = hipMemcpyAsync(dReqs, hReqs, (size_t)R * sizeof(PermReq), hipMemcpyHostToDevice, stream) == hipSuccess;
+                if (ok && anyFresh) {
+                    hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs, 1);
+                    for (int sd = 1; sd < MT_STRIDE && 19937LL * sd < maxFresh; sd <<= 1) hipLaunchKernelGGL(k_mt_classes, dim3(sd, R), dim3(MTC_T), 0, stream, dReqs, sd, 1);
+                }
+                if (ok && maxTotal > MT_HISTORY) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
+                ok = ok && hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
+            }
+            { std::lock_guard<std::mutex> lk(mu);
+              if (!ok) { (void)hipGetLastError(); failed = true; err = "the draw-stream cache's generator failed"; }
+              else for (size_t i = 0; i < jobs.size(); i++) { MtStream& S = *jobs[i].S; if (jobs[i].to > S.ready) { generatedWords += jobs[i].to - S.ready; S.ready = jobs[i].to; } if (shortJob[i]) S.full = true; } }
+            cvReady.notify_all();
+            if (!ok) return;
+        }
+    }
+};
+
 // ---- device permutation engine, one instance per chromosome thread (own stream and buffers)
 #define PERM_GPU_MIN_N 201           // every hybrid segment (> 200 bins) takes the device engine (round 2 kept those below 1024 bins on the host: 12 % slower on the device then; with this round's kernels 0.19 vs 0.23 s on the 4.7 M-bin probe); CANVAS_CBS_PERM_GPU_MIN_N overrides
 #define PERM_TARGET_ELEMS (64 << 20) // permuted elements per batch (44 B of workspace each)
@@ -2027,6 +2192,41 @@ static bool tpermp_device(PermGpu& PG, int n1, int n2, int n, const double* gd, 
     if (PG.ensure_tail() != CANVAS_OK) return false;
     return tpermp_device_impl(PG.ctx, PG.tailStream, n1, n2, n, gd, off, nPerm, rnd, st, p);
 }
+// The chromosome's generator as the recursion sees it: a POSITION in the chromosome's stream plus, while host code draws from it (edge tests, re-evaluations, the host's own
+// permutation loops), a real MT19937 at that position.  Device batches served from the stream cache only move the position (jump_to); the state is rebuilt from the 624
+// outputs in front of the position when the host next needs it (host(): one 2.5 KB copy out of the cache).  Without a cache stream (CANVAS_CBS_CACHE_GB=0, no memory) the
+// generator is always real and the batches hand their states over as in rounds 1-5.
+struct Rng {
+    MT mt{0u}; uint32_t seed = 0; MtStreamCache* cache = nullptr; MtStream* S = nullptr; long long pos = 0, base = 0; bool valid = true;
+    void init(uint32_t sd, MtStreamCache* c) { seed = sd; mt = MT(sd); base = 0; pos = 0; valid = true; cache = c; S = c ? c->get(sd) : nullptr; }
+    long long position() const { return valid ? base + mt.drawn : pos; }
+    void jump_to(long long p) { pos = p; valid = false; }                                                      // consumed up to p on the device
+    void adopt(const uint32_t* state625, long long p) { mt.set_state(state625); mt.drawn = 0; base = p; valid = true; }
+    // a generator at stream position p (p <= everything the cache holds, or reachable from the current state): into `out`
+    int32_t at(PermGpu& PG, long long p, MT& out) {
+        if (valid && p >= position() && p - position() <= 4096) { out = mt; while (base + out.drawn < p) (void)out.u32(); return CANVAS_OK; }
+        if (p < 624 || !S) { out = MT(seed); for (long long t = 0; t < p; t++) (void)out.u32(); return CANVAS_OK; }      // (no stream: only reached with small p)
+        canvas_ctx* ctx = PG.ctx;
+        int32_t rc = PG.ensure_tail(); if (rc) return rc;
+        uint32_t* h = (uint32_t*)PG.tailPin;                                                                    // 128 * 24 = 3072 bytes: 624 words fit
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(h, S->d() + (p - 624), 624 * 4, hipMemcpyDeviceToHost, PG.tailStream));
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(PG.tailStream));
+        uint32_t st[625];
+        for (int i = 0; i < 624; i++) { uint32_t y = h[i]; y ^= y >> 18; y ^= (y << 15) & 0xefc60000u; uint32_t t = y; t = y ^ ((t << 7) & 0x9d2c5680u); t = y ^ ((t << 7) & 0x9d2c5680u); t = y ^ ((t << 7) & 0x9d2c5680u); t = y ^ ((t << 7) & 0x9d2c5680u); y = t;
+                                         t = y; t = y ^ (t >> 11); t = y ^ (t >> 11); st[i] = t; }      // (mt_untemper on the host)
+        st[624] = 624u;
+        out.set_state(st); out.drawn = 0;
+        if (cache) cache->fetches++;
+        return CANVAS_OK;
+    }
+    // the real generator at the current position (nullptr: a HIP error, ctx->err set)
+    MT* host(PermGpu& PG) {
+        if (valid) return &mt;
+        MT m(0u); if (at(PG, pos, m) != CANVAS_OK) return nullptr;
+        mt = m; mt.drawn = 0; base = pos; valid = true;
+        return &mt;
+    }
+};
 // TailP for the two decisions of FindChangePoints: device approximation, accepted only when every p1 within 1e-8 relative gives the same decisions; else the exact host series
 static int32_t tail_p_decide(PermGpu& PG, double b, double delta, int m, double cutoff, uint32_t nPerm, Stats& st, bool& exitNoSplit, int& nrejc) {
     const int nGrid = 100; const double tol = 1E-6;
@@ -2151,7 +2351,7 @@ struct PermService {
         int blocks = 0, rpBlocks = 0; long long maxTotal = 0;
         for (int i = 0; i < R; i++) {
             batch[i]->r.rpBase = rpBlocks; if (batch[i]->r.fy == 3) rpBlocks += batch[i]->r.rpWGs; else batch[i]->r.rpWGs = 0;
-            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
+            batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2 && !batch[i]->r.cached) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
             if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // pinned source
             if (batch[i]->drawBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws, batch[i]->hDraws, batch[i]->drawBytes, hipMemcpyHostToDevice, stream));
         }
@@ -2162,7 +2362,9 @@ struct PermService {
         if (dbg) lap();
         const bool bootstrap = true;      // (the sequential history is grown by doubling: k_mt_classes with boot = 1)
         bool anyFresh = false; long long maxFresh = 0;
-        for (int i = 0; i < R; i++) if (!batch[i]->r.cont && batch[i]->r.fy != 2) { anyFresh = true; if (batch[i]->r.total >= MT_BOOT_MIN) maxFresh = std::max(maxFresh, batch[i]->r.total); }
+        bool anyOwn = false;      // requests that generate their own draws (the others read them out of the stream cache: no generator, no snapshots)
+        for (int i = 0; i < R; i++) if (batch[i]->r.fy != 2 && !batch[i]->r.cached) anyOwn = true;
+        for (int i = 0; i < R; i++) if (!batch[i]->r.cont && batch[i]->r.fy != 2 && !batch[i]->r.cached) { anyFresh = true; if (batch[i]->r.total >= MT_BOOT_MIN) maxFresh = std::max(maxFresh, batch[i]->r.total); }
         if (anyFresh) hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs, bootstrap ? 1 : 0);
         if (anyFresh && bootstrap)
             for (int sd = 1; sd < MT_STRIDE && 19937LL * sd < maxFresh; sd <<= 1) hipLaunchKernelGGL(k_mt_classes, dim3(sd, R), dim3(MTC_T), 0, stream, dReqs, sd, 1);
@@ -2170,7 +2372,7 @@ struct PermService {
         const int steps = maxTotal > MT_HISTORY ? (int)((maxTotal - MT_HISTORY + MT_WIDTH - 1) / MT_WIDTH) : 0;
         if (steps > 0) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
         if (dbg) msB = lap();
-        hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
+        if (anyOwn) hipLaunchKernelGGL(k_mt_snapshots, dim3(blocks), dim3(256), 0, stream, dReqs, R);
         bool anyFy = false, anyOld = false, anySmall = false; for (int i = 0; i < R; i++) (batch[i]->r.fy == 2 ? anySmall : batch[i]->r.fy == 1 ? anyFy : batch[i]->r.fy == 0 ? anyOld : anySmall /* (3: below) */) |= batch[i]->r.fy != 3;
         if (anyOld) hipLaunchKernelGGL(k_perm_stat, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
         if (anyFy) hipLaunchKernelGGL(k_perm_fy, dim3(blocks), dim3(PG_T), 0, stream, dReqs, R);
@@ -2214,30 +2416,42 @@ static int32_t service_submit_arc(PermService* svc, ArcHostReq& q) { return svc-
 // where the wall time of one chromosome goes (CANVAS_CBS_TIMING): seconds waiting for / running phase 1, in the device and host permutation loops, in the edge tests
 struct ChromClock { double p1 = 0, dev = 0, host = 0, edge = 0; int segments = 0, devLoops = 0, hostLoops = 0; long long loopPerms = 0, loopBatches = 0, loopComputed = 0; };
 static thread_local ChromClock tlClock;
-// ---- workspace of a permutation loop.  k_perm_rp (segments of PERM_RP_MIN_N .. PERM_RP_MAX_N bins): the draws of a batch + the scratch of its persistent workgroups;
-// the older kernels (shorter / longer segments): 48 bytes per permuted element.
+// ---- workspace of a permutation loop.  k_perm_rp (segments of PERM_RP_MIN_N .. PERM_RP_MAX_N bins): the scratch of its persistent workgroups (+ the draws of two batches
+// when the loop generates its own, i.e. without a cache stream); the older kernels (shorter / longer segments): 48 bytes per permuted element.
 #define PERM_RP_SCRATCH_BYTES (size_t(2) << 30)
 #define PERM_RP_MAXB 1024
 static inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
 static inline bool perm_use_rp(int n) { static const bool off = cvx_hook("CANVAS_CBS_NO_RP") != nullptr; static const int minN = cvx_hook("CANVAS_CBS_RP_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_RP_MIN_N")) : PERM_RP_MIN_N; return !off && n >= minN && n <= PERM_RP_MAX_N; }
 static inline int perm_max_batch(int n) { return perm_use_rp(n) ? (int)std::max<long long>(8, std::min<long long>(PERM_RP_MAXB, PERM_TARGET_ELEMS / n)) : (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n)); }
 static inline int perm_rp_wgs(int n) { PermReq::RpPlan P; rp_plan(n, P); const size_t per = (size_t)P.stride * 4; return (int)std::max<size_t>(64, std::min<size_t>(PERM_RP_GRID, PERM_RP_SCRATCH_BYTES / per)); }
-// device / pinned bytes that serve every segment of up to nMax bins
-static void perm_reserve_bytes(size_t nMax, size_t& dev, size_t& pin) {
+// the scratch of k_perm_rp's workgroups for segments of up to nMax bins: what perm_rp_wgs() workgroups of the LONGEST plan take, never more than PERM_RP_SCRATCH_BYTES — a
+// small genome reserves megabytes, not 2 GiB
+static inline size_t perm_rp_scratch_bytes(size_t nMax) {
+    if (nMax < (size_t)PERM_RP_MIN_N) return 0;
+    const int n = (int)std::min<size_t>(nMax, PERM_RP_MAX_N);
+    if (!perm_use_rp(n)) return 0;
+    PermReq::RpPlan P; rp_plan(n, P);
+    return al256((size_t)P.stride * 4 * (size_t)perm_rp_wgs(n));
+}
+// device / pinned bytes that serve every segment of up to nMax bins; withDraws: the loop generates its own draws (no cache stream): two draw buffers with their history
+static void perm_reserve_bytes(size_t nMax, bool withDraws, size_t& dev, size_t& pin) {
     const size_t head = al256(nMax * 8) + al256(625 * 4) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
     const size_t elemsRp = std::max<size_t>(PERM_TARGET_ELEMS, 8 * nMax);
-    dev = head + 2 * al256((elemsRp + (size_t)MT_HISTORY) * 4) + PERM_RP_SCRATCH_BYTES + (size_t(64) << 20);
+    const size_t drawsB = withDraws ? 2 * al256((elemsRp + (size_t)MT_HISTORY) * 4) : 0;
+    dev = head + drawsB + perm_rp_scratch_bytes(nMax) + (size_t(16) << 20);
     if (nMax > (size_t)PERM_RP_MAX_N || !perm_use_rp((int)std::min<size_t>(nMax, PERM_RP_MAX_N))) {
         const size_t re = (size_t)std::min<long long>((long long)256 * (long long)nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * (long long)nMax));
-        dev = std::max(dev, head + 2 * al256((re + (size_t)MT_HISTORY) * 4) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
+        dev = std::max(dev, head + (withDraws ? 2 * al256((re + (size_t)MT_HISTORY) * 4) : 0) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
     }
     pin = al256(nMax * 8) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
 }
 
 // The sequential stopping rule of FindChangePoints (ChangePoint.cs:337-364) over permutations evaluated in device batches.
 // Returns through `outcome`: 0 = not significant (nrej > nrejc), 1 = continue to the edge tests.  rnd ends exactly where the reference's would.
+// The draws of a batch are read out of the chromosome's cache stream (MtStreamCache: nothing is generated, no state travels; rnd moves by position); when the stream cannot
+// serve a batch (cache off, bound reached) the batch generates its own on the device from the generator's state and hands the state after every permutation back.
 static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int hk, int al0, double ostat, int nrejc, int k,
-                             const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st, int& outcome) {
+                             const std::vector<uint32_t>& sbdry, Rng& rnd, Stats& st, int& outcome) {
     canvas_ctx* ctx = PG.ctx;
     const bool useRp = perm_use_rp(n) && hk == RP_J1 && al0 == RP_J0;      // (k_perm_rp's statistic is written for FindChangePoints' own arc lengths)
     const int maxB = perm_max_batch(n);
@@ -2246,17 +2460,19 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     uint32_t* dRpScratch = nullptr; int rpWGs = 0; PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP);
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
-    uint32_t* draws2[2] = {nullptr, nullptr}; int drawBuf = 0;      // the loop's batches alternate between two draw buffers
-    auto setup = [&](int mb) -> int32_t {
+    uint32_t* draws2[2] = {nullptr, nullptr}; int drawBuf = 0;      // (own draws) the loop's batches alternate between two draw buffers
+    bool haveDraws = false;
+    auto setup = [&](int mb, bool withDraws) -> int32_t {
         const size_t e = (size_t)mb * n, e1 = (size_t)mb * (n + 1);
+        const size_t drawsB = withDraws ? 2 * al((e + (size_t)MT_HISTORY) * 4) : 0;      // two draw buffers: a batch reads its history where the previous one wrote it
         const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)mb * 625 * 4), oDraws = oStat + al((size_t)mb * 16),
-                     oJ = oDraws + 2 * al((e + (size_t)MT_HISTORY) * 4) /* two draw buffers: a batch reads its history where the previous one wrote it */, oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
+                     oJ = oDraws + drawsB, oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
                      oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
         const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pinTotal = pStat + al((size_t)mb * 16);
         auto tE = now();
-        // k_perm_rp: the draws and, behind them, the scratch of the persistent workgroups (results travel in streams: no per-element workspace)
+        // k_perm_rp: behind the draws the scratch of the persistent workgroups (results travel in streams: no per-element workspace)
         size_t oScratch = 0, totalRp = 0;
-        if (useRp) { rp_plan(n, rpP); rpWGs = std::min(perm_rp_wgs(n), mb); oScratch = oDraws + 2 * al((e + (size_t)MT_HISTORY) * 4); totalRp = oScratch + al((size_t)rpP.stride * 4 * (size_t)rpWGs); }
+        if (useRp) { rp_plan(n, rpP); rpWGs = std::min(perm_rp_wgs(n), mb); oScratch = oDraws + drawsB; totalRp = oScratch + al((size_t)rpP.stride * 4 * (size_t)rpWGs); }
         const size_t need = useRp ? totalRp : total;
         size_t want = need, wantPin = pinTotal;
         if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // the first allocation serves the longest segment this call can meet
@@ -2264,25 +2480,29 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         st.ns_ensure += since(tE);
         char* d = PG.buf; char* h = PG.pin;
         dX = (double*)(d + oX); dSnaps = (uint32_t*)(d + oSnaps); dStat = (double*)(d + oStat);
-        P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY; draws2[0] = P.draws; draws2[1] = (uint32_t*)(d + oDraws + al((e + (size_t)MT_HISTORY) * 4)) + MT_HISTORY;
-        if (useRp) { memset(&P.j, 0, sizeof(PermBuf) - sizeof(uint32_t*)); dRpScratch = (uint32_t*)(d + oScratch); }
+        memset(&P, 0, sizeof P);
+        if (withDraws) { P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY; draws2[0] = P.draws; draws2[1] = (uint32_t*)(d + oDraws + al((e + (size_t)MT_HISTORY) * 4)) + MT_HISTORY; }
+        if (useRp) dRpScratch = (uint32_t*)(d + oScratch);
         else {
         P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
         P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx); }
         hX = (double*)(h + pX); hSnaps = (uint32_t*)(h + pSnaps); hStat = (double*)(h + pStat);
+        haveDraws = withDraws;
         return CANVAS_OK;
     };
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int32_t rc = setup(maxB); if (rc) return rc;
+    MtStreamCache* SC = rnd.cache; MtStream* S = rnd.S;
+    int32_t rc = setup(maxB, S == nullptr); if (rc) return rc;
     memcpy(hX, gd, (size_t)n * 8);            // uploaded by the launcher together with the first batch
     bool needUpload = true;
     // worst-case rounding bound of a prefix-sum difference: both orders of summation are within gamma_n * sum|x| of the exact sum
     double absSum = 0.0; for (int i = 0; i < n; i++) absSum += std::fabs(gd[i]);
     const double errBound = 4.04 * (double)(n + 8) * 1.1102230246251565e-16 * absSum;
     std::vector<double> px, sx;
-    uint32_t cur[625]; rnd.get_state(cur);
+    long long pos = rnd.position();            // stream position of the next draw
+    uint32_t cur[625]; bool haveCur = false;   // (own draws) the generator state at `pos`
     int nrej = 0; uint32_t np = 0;
-    long long prevTotal = 0;
+    long long prevTotal = 0; bool prevOwn = false;
     // first batch: without a single rejection the sequential rule stops at permutation sbdry[k - 1] — known now — and that is what a segment with a real change point
     // does; asking for that many at once saves the 64 / 128 / 256 ramp its two extra launcher round trips (a segment without one leaves after a handful either way)
     int B = std::min(maxB, std::max(64, (int)std::min<uint32_t>(sbdry[k - 1], 4096u)));
@@ -2290,25 +2510,40 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     outcome = 1;
     while (np < nPerm) {
         const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
+        const long long need = (long long)nb * n;
         auto tS = now();
+        const bool cached = S && SC->acquire(S, pos + need, std::max<long long>(2 * need, 4LL << 20));
+        if (!cached) {
+            // own draws: the state at pos (a generator that was moved by position is rebuilt from the cache's words in front of it) and the two draw buffers
+            if (!haveCur) { MT m(0u); rc = rnd.at(PG, pos, m); if (rc) return rc; m.get_state(cur); haveCur = true; prevOwn = false; }
+            if (!haveDraws) { rc = setup(maxB, true); if (rc) return rc; memcpy(hX, gd, (size_t)n * 8); needUpload = true; }
+        }
         PermHostReq q;
-        memcpy(q.r.state, cur, sizeof cur); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
-        q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat; q.hSnaps = hSnaps;
+        q.r.total = need; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
+        q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat;
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
-        q.r.cont = (np > 0 && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
-        q.r.P.draws = draws2[drawBuf]; q.r.hist = q.r.cont ? draws2[drawBuf ^ 1] + (prevTotal - MT_HISTORY) : nullptr; drawBuf ^= 1;
+        if (cached) {
+            memset(q.r.state, 0, sizeof q.r.state); q.r.cached = 1; q.r.cont = 0; q.r.hist = nullptr; q.hSnaps = nullptr; q.r.snaps = nullptr;
+            q.r.P.draws = S->d() + pos;
+            SC->servedWords += need;
+        } else {
+            memcpy(q.r.state, cur, sizeof cur); q.r.cached = 0; q.hSnaps = hSnaps;
+            q.r.cont = (prevOwn && prevTotal >= MT_HISTORY) ? 1 : 0; q.prevTotal = prevTotal;
+            q.r.P.draws = draws2[drawBuf]; q.r.hist = q.r.cont ? draws2[drawBuf ^ 1] + (prevTotal - MT_HISTORY) : nullptr; drawBuf ^= 1;
+            if (SC) SC->fallbackWords += need;
+        }
         { static const int fyMin = cvx_hook("CANVAS_CBS_FY_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_FY_MIN_N")) : PERM_FY_MIN_N; q.r.fy = useRp ? 3 : (n >= fyMin ? 1 : 0); }
         // persistent workgroups: every one takes the same number of permutations (600 permutations on 512 workgroups would be two rounds with 424 workgroups idle in the second:
         // 300 workgroups with two each take the same time and leave the other CUs to the kernels of the other chromosomes)
         { const int rounds = useRp ? (nb + rpWGs - 1) / rpWGs : 1; q.r.rpWGs = useRp ? (nb + rounds - 1) / rounds : 0; }
         q.r.rpBase = 0; q.r.rpScratch = dRpScratch; q.r.rp = rpP; q.r.rpClk = nullptr;
-        prevTotal = (long long)nb * n;
+        prevTotal = need; prevOwn = !cached;
         rc = PG.svc->submit(q); if (rc) return rc;
         st.ns_submit += since(tS);
         auto tP = now();
         struct PostAcc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~PostAcc() { a += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } postAcc{st.ns_post, tP};
         st.dev_batches++; tlClock.loopBatches++; tlClock.loopComputed += nb;
-        // generator state behind permutation b of this batch.  The device snapshot is rebuilt from the last 624 outputs in front of that point: fewer than 624 exist when a
+        // (own draws) generator state behind permutation b of this batch.  The device snapshot is rebuilt from the last 624 outputs in front of that point: fewer than 624 exist when a
         // batch that does not continue another one is cut short inside its first permutations (segments of a few hundred bins) — then the batch's start state is advanced on
         // the host, at most 623 draws.
         const bool contBatch = q.r.cont != 0;
@@ -2317,14 +2552,27 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
             if (contBatch || (long long)(b + 1) * n >= 624) return hSnaps + (size_t)b * 625;
             MT m(0u); m.set_state(cur); for (long long t = 0; t < (long long)(b + 1) * n; t++) (void)m.u32(); m.get_state(tmpState); return tmpState;
         };
+        // the rule stops behind permutation b: rnd continues at that position
+        auto stop_behind = [&](int b) { const long long p = pos + (long long)(b + 1) * n; if (cached) rnd.jump_to(p); else rnd.adopt(state_after(b), p); };
+        // a real generator at the start of permutation b (re-evaluations, the test hook)
+        auto gen_before = [&](int b, MT& m) -> int32_t {
+            if (cached) return rnd.at(PG, pos + (long long)b * n, m);
+            m.set_state(b == 0 ? cur : state_after(b - 1)); return CANVAS_OK;
+        };
         if (cvx_hook("CANVAS_CBS_TEST_VERIFY")) {      // test hook: every device interval must contain the statistic computed in the reference's order
+            MT m2(0u); rc = gen_before(0, m2); if (rc) return rc;
+            if (cached) {      // ... and the cached stream must BE the generator's output: the batch's first words against MersenneTwister(seed) advanced to pos
+                const size_t cw = (size_t)std::min<long long>(need, 4096); std::vector<uint32_t> hw(cw);
+                CANVAS_HIP_TRY(ctx, hipMemcpy(hw.data(), S->d() + pos, cw * 4, hipMemcpyDeviceToHost));
+                MT m4 = m2; for (size_t t = 0; t < cw; t++) if (m4.u32() != hw[t]) { st.violations++; break; }
+            }
             for (int b = 0; b < nb; b++) {
-                MT m2(0u); m2.set_state(b == 0 ? cur : state_after(b - 1));
+                if (!cached) { rc = gen_before(b, m2); if (rc) return rc; }      // (cached: m2 runs on from permutation to permutation — the stream is consumed in sequence)
                 px.resize(n); sx.resize(n);
                 xperm(gd, px.data(), n, m2);
                 const double exact = htmaxp_host(hk, tss, px.data(), n, sx.data(), al0);
-                MT m3(0u); m3.set_state(state_after(b));      // the device snapshot must continue the stream exactly where the host generator is
-                bool same = true; for (int t = 0; t < 1400; t++) if (m2.u32() != m3.u32()) { same = false; break; }
+                bool same = true;
+                if (!cached) { MT m3(0u); m3.set_state(state_after(b)); MT m2c = m2; for (int t = 0; t < 1400; t++) if (m2c.u32() != m3.u32()) { same = false; break; } }      // the device snapshot must continue the stream exactly where the host generator is
                 st.verified++;
                 if (!(hStat[2 * b] <= exact && exact <= hStat[2 * b + 1]) || !same ||
                     !(hStat[2 * b + 1] - hStat[2 * b] <= 1e-6 * std::fabs(exact) + 1e-300)) st.violations++;
@@ -2338,17 +2586,19 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
             if (ostat <= lo) rej = true;
             else if (ostat > hi) rej = false;
             else {      // inside the rounding interval: this permutation again, in the reference's order of operations
-                MT m2(0u); m2.set_state(b == 0 ? cur : state_after(b - 1));
+                MT m2(0u); rc = gen_before(b, m2); if (rc) return rc;
                 px.resize(n); sx.resize(n);
                 xperm(gd, px.data(), n, m2);
                 rej = ostat <= htmaxp_host(hk, tss, px.data(), n, sx.data(), al0);
                 st.exact_rechecks++;
             }
             if (rej) { nrej++; k++; }
-            if (nrej > nrejc) { rnd.set_state(state_after(b)); outcome = 0; return CANVAS_OK; }
-            if (np >= sbdry[k - 1]) { rnd.set_state(state_after(b)); return CANVAS_OK; }
+            if (nrej > nrejc) { stop_behind(b); outcome = 0; return CANVAS_OK; }
+            if (np >= sbdry[k - 1]) { stop_behind(b); return CANVAS_OK; }
         }
-        { const uint32_t* sEnd = state_after(nb - 1); uint32_t keepState[625]; memcpy(keepState, sEnd, sizeof keepState); memcpy(cur, keepState, sizeof cur); }
+        if (cached) haveCur = false;
+        else { const uint32_t* sEnd = state_after(nb - 1); uint32_t keepState[625]; memcpy(keepState, sEnd, sizeof keepState); memcpy(cur, keepState, sizeof cur); }
+        pos += need;
         // The next batch: as many permutations as the rule is expected to look at yet (+ 15 %), not simply twice the last one — the permutation kernels are the device's load,
         // and a loop that stops 20 permutations into a batch of 1024 has computed the other thousand for nothing (with the doubling a third of all permutations computed were never
         // looked at).  With the rejection rate seen so far, p, the rule stops where np reaches sbdry[k - 1 + p (np' - np)] or where the rejections exceed nrejc, whichever is first.
@@ -2365,14 +2615,14 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
             B = (int)std::max<long long>(64, std::min<long long>(maxB, want));
         }
     }
-    rnd.set_state(cur);
+    if (haveCur) rnd.adopt(cur, pos); else rnd.jump_to(pos);
     return CANVAS_OK;
 }
 
 // The same stopping rule for the segments of at most 200 bins (the non-hybrid test: XPerm + TMaxP, ChangePoint.cs:337-364): batches of up to 2048 permutations, one wave each
-// (k_perm_small).  The draws of a batch are produced by the chromosome's host generator in the reference's order and travel with the request; the statistic comes back exact, so
-// the comparison ostat <= pstat is the reference's own.  rnd ends behind the last permutation the rule looked at: the batch's start state advanced by that many draws.
-static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int al0, double ostat, int nrejc, int k, const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st, int& outcome) {
+// (k_perm_small).  The draws of a batch come out of the chromosome's cache stream; without one they are produced by the chromosome's host generator in the reference's order
+// and travel with the request.  The statistic comes back exact, so the comparison ostat <= pstat is the reference's own.  rnd ends behind the last permutation the rule looked at.
+static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double tss, uint32_t nPerm, int al0, double ostat, int nrejc, int k, const std::vector<uint32_t>& sbdry, Rng& rnd, Stats& st, int& outcome) {
     canvas_ctx* ctx = PG.ctx;
     const int maxB = 2048;
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -2391,27 +2641,42 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
     int B = 256;
     outcome = 1;
     std::vector<double> px, sx;
+    MtStreamCache* SC = rnd.cache; MtStream* S = rnd.S;
+    long long pos = rnd.position();
     while (np < nPerm) {
         const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
-        const MT start = rnd;                                      // the batch's draws: nb * n outputs of the chromosome's generator, in order
-        for (size_t t = 0; t < (size_t)nb * n; t++) hDraws[t] = rnd.u32();
+        const long long need = (long long)nb * n;
+        const bool cached = S && SC->acquire(S, pos + need, std::max<long long>(2 * need, 4LL << 20));
+        MT start(0u);
+        if (!cached) {      // the batch's draws: nb * n outputs of the chromosome's generator, in order
+            MT* m = rnd.host(PG); if (!m) return CANVAS_ERR_HIP;
+            start = *m;
+            for (size_t t = 0; t < (size_t)need; t++) hDraws[t] = m->u32();
+            if (SC) SC->fallbackWords += need;
+        } else SC->servedWords += need;
         PermHostReq q;
-        memset(q.r.state, 0, sizeof q.r.state); q.r.total = (long long)nb * n; q.r.n = n; q.r.nb = nb; q.r.snaps = nullptr; q.r.x = dX; q.r.hk = 0; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = 0.0;
-        memset(&q.r.P, 0, sizeof q.r.P); q.r.P.draws = dDraws; q.r.pstat = dStat; q.r.blockBase = 0; q.r.cont = 0; q.r.hist = nullptr; q.r.fy = 2; q.hStat = hStat; q.hSnaps = nullptr;
+        memset(q.r.state, 0, sizeof q.r.state); q.r.total = need; q.r.n = n; q.r.nb = nb; q.r.snaps = nullptr; q.r.x = dX; q.r.hk = 0; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = 0.0;
+        memset(&q.r.P, 0, sizeof q.r.P); q.r.P.draws = cached ? S->d() + pos : dDraws; q.r.cached = cached ? 1 : 0; q.r.pstat = dStat; q.r.blockBase = 0; q.r.cont = 0; q.r.hist = nullptr; q.r.fy = 2; q.hStat = hStat; q.hSnaps = nullptr;
         q.r.rpBase = 0; q.r.rpWGs = 0; q.r.rpScratch = nullptr; q.r.rpClk = nullptr; memset(&q.r.rp, 0, sizeof q.r.rp);
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
-        q.hDraws = hDraws; q.drawBytes = (size_t)nb * n * 4;
+        if (!cached) { q.hDraws = hDraws; q.drawBytes = (size_t)need * 4; }
         auto tS = std::chrono::steady_clock::now();
         rc = PG.svc->submit(q); if (rc) return rc;
         st.ns_submit += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tS).count();
         st.dev_batches++;
-        auto stop_at = [&](int b) { rnd = start; for (size_t t = 0; t < (size_t)(b + 1) * n; t++) (void)rnd.u32(); };
+        auto stop_at = [&](int b) {
+            const long long p = pos + (long long)(b + 1) * n;
+            if (cached) rnd.jump_to(p);
+            else { MT m = start; for (size_t t = 0; t < (size_t)(b + 1) * n; t++) (void)m.u32(); uint32_t s625[625]; m.get_state(s625); rnd.adopt(s625, p); }
+        };
         for (int b = 0; b < nb; b++) {
             np++;
             st.perms++; st.perm_elems += n; st.dev_perms++;
             double pstat = hStat[2 * b];
             if (!(pstat == pstat) || cvx_hook("CANVAS_CBS_TEST_VERIFY")) {      // a NaN (degenerate extremes) or the test hook: this permutation again on the host, in the reference's order
-                MT m2 = start; for (size_t t = 0; t < (size_t)b * n; t++) (void)m2.u32();
+                MT m2(0u);
+                if (cached) { rc = rnd.at(PG, pos + (long long)b * n, m2); if (rc) return rc; }
+                else { m2 = start; for (size_t t = 0; t < (size_t)b * n; t++) (void)m2.u32(); }
                 px.resize(n); sx.resize(n);
                 xperm(gd, px.data(), n, m2);
                 const double exact = tmaxp_host(tss, px.data(), n, sx.data(), al0);
@@ -2423,6 +2688,8 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
             if (nrej > nrejc) { stop_at(b); outcome = 0; return CANVAS_OK; }
             if (np >= sbdry[k - 1]) { stop_at(b); return CANVAS_OK; }
         }
+        if (cached) rnd.jump_to(pos + need);      // (own draws: rnd's generator has produced exactly the batch)
+        pos += need;
         B = std::min(maxB, B * 2);
     }
     return CANVAS_OK;
@@ -2485,7 +2752,7 @@ static void phase1_run(ArcGpu& G, PermGpu& PG, const double* gd, int cn, uint32_
         } else P.nrejc = (int)(cutoff * nPerm);
     } else P.bigT = true;
 }
-static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff, int& nCp, int iCp[2], const std::vector<uint32_t>& sbdry, MT& rnd, Stats& st) {
+static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff, int& nCp, int iCp[2], const std::vector<uint32_t>& sbdry, Rng& rnd, Stats& st) {
     const int minWidth = 2, kMax = 25;
     nCp = 0;
     if (P.rc) return P.rc;
@@ -2521,8 +2788,9 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
         } else {
             Acc acc{st.ns_hostperm, t0};
             struct L { std::chrono::steady_clock::time_point t; ~L() { tlClock.host += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); tlClock.hostLoops++; } } lc{t0};
+            MT* hm = rnd.host(PG); if (!hm) return CANVAS_ERR_HIP;
             for (uint32_t np = 1; np <= nPerm; np++) {
-                xperm(gd, px.data(), n, rnd);
+                xperm(gd, px.data(), n, *hm);
                 double pstat = hybrid ? htmaxp_host(hk, tss, px.data(), n, sx.data(), al0) : tmaxp_host(tss, px.data(), n, sx.data(), al0);
                 st.perms++; st.perm_elems += n;
                 if (ostat <= pstat) { nrej++; k++; }
@@ -2537,10 +2805,12 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
     if (iseg[1] == n) { nCp = 1; iCp[0] = iseg[0]; }
     else if (iseg[0] == 0) { nCp = 1; iCp[0] = iseg[1]; }
     else {
+        // the edge tests draw on the host (TPermP: one chain of nPerm x m1 dependent swaps): the real generator at the current position
+        MT* hm = rnd.host(PG); if (!hm) return CANVAS_ERR_HIP;
         int n1 = iseg[0], n12 = iseg[1], n2 = n12 - n1;
-        if (tpermp(PG, n1, n2, n12, gd, 0, px.data(), nPerm, rnd, st) <= cutoff) { nCp = 1; iCp[0] = iseg[0]; }
+        if (tpermp(PG, n1, n2, n12, gd, 0, px.data(), nPerm, *hm, st) <= cutoff) { nCp = 1; iCp[0] = iseg[0]; }
         int off = iseg[0]; n12 = n - iseg[0]; n2 = n - iseg[1]; n1 = n12 - n2;
-        if (tpermp(PG, n1, n2, n12, gd, off, px.data(), nPerm, rnd, st) <= cutoff) { nCp++; iCp[nCp - 1] = iseg[1]; }
+        if (tpermp(PG, n1, n2, n12, gd, off, px.data(), nPerm, *hm, st) <= cutoff) { nCp++; iCp[nCp - 1] = iseg[1]; }
     }
     return CANVAS_OK;
 }
@@ -2548,7 +2818,10 @@ static int32_t phase2_run(PermGpu& PG, Phase1& P, uint32_t nPerm, double cutoff,
 struct EngineCache {
     struct Slab { char* base = nullptr; size_t bytes = 0, off = 0; };
     std::vector<Slab> devSlabs, pinSlabs; std::vector<hipStream_t> tailStreams; size_t nextTail = 0; std::vector<SvcRes*> svcFree, svcAll;
+    std::unique_ptr<MtStreamCache> mts;      // the chromosomes' draw streams (created with the first CBS call / canvas_cbs_prefetch of the context)
+    MtStreamCache* streams(canvas_ctx* ctx) { std::lock_guard<std::mutex> lk(mu); if (!mts) mts.reset(new MtStreamCache(ctx)); return mts->off ? nullptr : mts.get(); }
     ~EngineCache() {
+        mts.reset();                                          // (joins the producer thread, unmaps the streams)
         arcs.clear(); perms.clear(); tails.clear();           // (the engines first: they may still wait on a shared stream)
         for (hipStream_t q : tailStreams) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         for (SvcRes* r : svcAll) { if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); } if (r->dReqs) (void)hipFree(r->dReqs); if (r->hReqs) (void)hipHostFree(r->hReqs);
@@ -2667,7 +2940,7 @@ struct SpecPool {
 };
 
 // ChangePoint.ChangePoints (ChangePoint.cs:44-153), undo = None
-static int32_t change_points(ArcGpu& G, PermGpu& PG, SpecPool* pool, const double* gd, int n, const std::vector<uint32_t>& sbdry, MT& rnd, double alpha, uint32_t nPerm, std::vector<int>& lengthSeg, Stats& st) {
+static int32_t change_points(ArcGpu& G, PermGpu& PG, SpecPool* pool, const double* gd, int n, const std::vector<uint32_t>& sbdry, Rng& rnd, double alpha, uint32_t nPerm, std::vector<int>& lengthSeg, Stats& st) {
     std::vector<int> segEnd = {0, n}, changeLoc;
     int k = 2, nCp = 0, iCp[2] = {0, 0};
     while (k > 1) {
@@ -2863,6 +3136,24 @@ extern "C" int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int
     if (h_ms3) for (int i = 0; i < 3; i++) h_ms3[i] = svc.lastMs[i];
     return CANVAS_OK;
 }
+// the chromosomes' draw streams ahead of the first call: returns at once, the generator runs on its own thread and stream (cbs::MtStreamCache)
+extern "C" int32_t canvas_cbs_prefetch(canvas_ctx* ctx, int32_t nchr, int64_t words_per_chromosome) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (nchr < 0 || nchr > 100000 || words_per_chromosome < 0) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs_prefetch: bad arguments");
+    if (nchr == 0 || cvx_hook("CANVAS_CBS_NO_STREAM_CACHE")) return CANVAS_OK;
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    cbs::MtStreamCache* mts = cbs::EngineCache::of(ctx).streams(ctx);
+    if (!mts) return CANVAS_OK;
+    std::vector<int32_t> seeds((size_t)nchr);
+    cbs_chromosome_seeds(nchr, seeds.data());
+    for (int c = 0; c < nchr; c++) mts->prefetch(mts->get((uint32_t)seeds[(size_t)c]), words_per_chromosome);
+    return CANVAS_OK;
+}
+extern "C" int32_t canvas_cbs_cache_stats(canvas_ctx* ctx, int64_t* h_out6) {
+    if (!ctx || !h_out6) return CANVAS_ERR_INVALID;
+    for (int i = 0; i < 6; i++) h_out6[i] = ctx->cbs_cache_stats[i];
+    return CANVAS_OK;
+}
 extern "C" int32_t canvas_cbs_tailp_stats(canvas_ctx* ctx, int64_t* h_out2) {
     if (!ctx || !h_out2) return CANVAS_ERR_INVALID;
     h_out2[0] = ctx->cbs_tailp[0]; h_out2[1] = ctx->cbs_tailp[1];
@@ -2955,6 +3246,14 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     if (nHelpers) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nArcSvc, nperm, alpha, &st}); specPool->reserveN = (int)nMax; specPool->start(nHelpers); }
     size_t perEngineBudget = ~size_t(0);
     { size_t freeB = 0, totB = 0; if (hipMemGetInfo(&freeB, &totB) == hipSuccess) perEngineBudget = (freeB / 2) / (size_t)std::max(1, nthreads); }
+    // the chromosomes' draw streams: every chromosome that will permute asks for the first extension of its stream NOW, so that the generator runs while the first arc
+    // searches do (in a process that called canvas_cbs_prefetch — the executable does, during its file read — the words are there already)
+    cbs::MtStreamCache* mts = cvx_hook("CANVAS_CBS_NO_STREAM_CACHE") ? nullptr : cbs::EngineCache::of(ctx).streams(ctx);
+    long long mtsBefore[4] = {0, 0, 0, 0};
+    if (mts) {
+        mtsBefore[0] = mts->servedWords; mtsBefore[1] = mts->fallbackWords; mtsBefore[2] = mts->generatedWords; mtsBefore[3] = mts->fetches;
+        for (int c = 0; c < nchr; c++) { const long long n = h_chr_offset[c + 1] - h_chr_offset[c]; if (n >= 4 && (!h_mask || h_mask[c])) mts->prefetch(mts->get((uint32_t)seeds[c]), std::max<long long>(MTS_FIRST_WORDS, 32 * n)); }
+    }
     auto work = [&]() {
         cbs::EngineCache& cache = cbs::EngineCache::of(ctx);                             // per thread: own buffers, borrowed from the context's cache (created on first use)
         std::unique_ptr<cbs::PermGpu> pgp = cache.perm(ctx, permServices[(size_t)(nextService++ % nPermSvc)]); std::unique_ptr<cbs::ArcGpu> gp = cache.arc(ctx, arcServices[nextArc++ % nArcSvc]);
@@ -2964,13 +3263,13 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
         // the first allocation of an engine is made for the call's longest chromosome (growing later means hipFree + hipMalloc, which stall every stream of the device) —
         // as long as all engines of the call together stay inside half of what the device has free: many contigs on a many-core host, or several contexts on one GPU,
         // would otherwise run out of memory where grow-on-demand engines fit
-        PG.reserveN = (size_t)nMax; cbs::perm_reserve_bytes((size_t)nMax, PG.reserveBytes, PG.reservePin);
+        PG.reserveN = (size_t)nMax; cbs::perm_reserve_bytes((size_t)nMax, mts == nullptr, PG.reserveBytes, PG.reservePin);      // (with cache streams no engine holds draw buffers: 0.5 GB each)
         if (PG.reserveBytes > perEngineBudget) { PG.reserveBytes = 0; PG.reservePin = 0; PG.reserveN = 0; }       // the engines then grow on demand
         for (;;) {
             int c = next++; if (c >= nchr) break;
             int n = (int)(h_chr_offset[c + 1] - h_chr_offset[c]);
             if (n <= 0 || (h_mask && !h_mask[c])) continue;
-            cbs::MT rnd((uint32_t)seeds[c]);
+            cbs::Rng rnd; rnd.init((uint32_t)seeds[c], mts);
             auto tC = std::chrono::steady_clock::now();
             struct CAcc { std::mutex& m; double& mx; double& sm; std::chrono::steady_clock::time_point t; ~CAcc() { double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); std::lock_guard<std::mutex> lk(m); mx = std::max(mx, d); sm += d; } } cAcc{chromMu, maxChromSec, sumChromSec, tC};
             cbs::tlClock = cbs::ChromClock();
@@ -2988,6 +3287,13 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     ctx->cbs_tpermp[0] = st.tpermp_device; ctx->cbs_tpermp[1] = st.tpermp_draws;
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
     ctx->cbs_tailp[0] = st.tailp_dev; ctx->cbs_tailp[1] = st.tailp_host;
+    for (int i = 0; i < 6; i++) ctx->cbs_cache_stats[i] = 0;
+    if (mts) {
+        ctx->cbs_cache_stats[0] = mts->servedWords - mtsBefore[0]; ctx->cbs_cache_stats[1] = mts->fallbackWords - mtsBefore[1]; ctx->cbs_cache_stats[2] = mts->generatedWords - mtsBefore[2]; ctx->cbs_cache_stats[3] = mts->fetches - mtsBefore[3];
+        std::lock_guard<std::mutex> lk(mts->mu); ctx->cbs_cache_stats[4] = (long long)mts->usedBytes; long long rdy = 0; for (auto& kv : mts->streams) rdy += kv.second->ready; ctx->cbs_cache_stats[5] = rdy;
+    }
+    if (timing && mts) fprintf(stderr, "cbs draw streams: %lld words read out of the cache, %lld generated inside batches (no stream / bound reached), %lld generated by the cache's producer in this call, %lld states fetched for host code; %.2f GB mapped, %lld words held\n",
+                               ctx->cbs_cache_stats[0], ctx->cbs_cache_stats[1], ctx->cbs_cache_stats[2], ctx->cbs_cache_stats[3], ctx->cbs_cache_stats[4] / 1e9, ctx->cbs_cache_stats[5]);
     if (timing) fprintf(stderr, "cbs allocation / stream creation, thread-seconds: arc engines %.3f, permutation engines %.3f, tail engines %.3f, launchers %.3f\n", cbs::g_ns_alloc_arc.exchange(0) * 1e-9, cbs::g_ns_alloc_perm.exchange(0) * 1e-9, cbs::g_ns_alloc_tail.exchange(0) * 1e-9, cbs::g_ns_alloc_svc.exchange(0) * 1e-9);
     if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());
     if (timing) fprintf(stderr, "cbs arc searches whose best admissible arc the reference does not scan (replayed on the host): %lld\n", (long long)st.unscanned_max.load());

@@ -64,6 +64,7 @@ struct canvas_ctx {
     void* shard_ws = nullptr; size_t shard_ws_bytes = 0;
     long long shard_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long cbs_dev[6] = {0, 0, 0, 0, 0, 0};
+    long long cbs_cache_stats[6] = {0, 0, 0, 0, 0, 0};      // last CBS call: draws read out of the stream cache, generated inside batches, generated by the cache's producer, states fetched for host code; bytes mapped, words held
     long long cbs_tpermp[2] = {0, 0};          // last canvas_cbs call: edge tests (TPermP) run by the device kernel, swaps of all edge tests
     long long cbs_tailp[2] = {0, 0};   // last CBS call: TailP decisions taken from the device series / recomputed by the host series   // counters of the device permutation engine (canvas_cbs_device_stats)
     long long wv_levels = 0, wv_redone = 0;   // last canvas_wavelets call: tree levels processed, nodes recomputed by the exact chain

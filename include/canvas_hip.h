@@ -292,6 +292,15 @@ int32_t canvas_cbs_perm_probe(canvas_ctx* ctx, const double* h_x, int32_t n, uin
  * CBSRunner passes it: maxOnes (maxOnes + 1) / 2 entries with maxOnes = floor(nperm alpha) + 1.  Returns the number of entries (or a negative error code).  The library
  * evaluates the table's scans on its host thread pool with the scans' own evaluations and comparisons; exposed so that the table can be checked without a device. */
 int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h_out, int64_t cap);
+/* The draw streams of canvas_cbs ahead of its first call.  The k-th chromosome's generator is MersenneTwister(seed_k) with seed_k from MersenneTwister(0) in file order
+ * (CBSRunner.cs:107-112) and is consumed strictly in sequence by XPerm / TPermP (ChangePoint.cs:407-421, CBSTStatistic.cs:1009): the words are constants of the method.  The
+ * library keeps them per context in device memory (generated once, extended on demand, bounded by CANVAS_CBS_CACHE_GB — default 30 % of the device's memory, 0 = off) and
+ * canvas_cbs reads its permutations' draws out of them.  canvas_cbs_prefetch starts the generator for the first `words_per_chromosome` draws of the first nchr streams on a
+ * thread and stream of its own and returns at once: a host calls it while it is still reading its input (CanvasPartition does).  Optional — canvas_cbs asks for what it
+ * needs itself.  canvas_cbs_cache_stats: h_out6 = {draws the last canvas_cbs call read out of the cache, draws it generated inside its batches (cache off / bound reached),
+ * draws the cache's generator produced during the call, generator states fetched for host code, bytes of device memory the cache holds, draws it holds}. */
+int32_t canvas_cbs_prefetch(canvas_ctx* ctx, int32_t nchr, int64_t words_per_chromosome);
+int32_t canvas_cbs_cache_stats(canvas_ctx* ctx, int64_t* h_out6);
 /* Host-only (no context, no GPU): the seeds of the per-chromosome generators canvas_cbs uses, in file order — new MersenneTwister(0) followed by one NextFullRangeInt32() per
  * chromosome (CBSRunner.cs:107-112).  h_out[nchr]; h_variant (optional): which reading of MathNet's NextBytes is in force (0 / 1 / 2, include/canvas_mathnet.h: the one
  * assumption of this path that could not be checked without a .NET SDK; CANVAS_MATHNET_SEED_BYTES selects it at run time).  Returns 0 or a negative error code. */
