@@ -44,12 +44,23 @@
 // far below 1e-9); it only feeds two decisions of FindChangePoints (p1 > cutoff; nrejc = (int)((cutoff - p1) nPerm), ChangePoint.cs:318-323), and the host accepts it only when both
 // come out the same for every p1 within 1e-8 relative — otherwise, and whenever a stopping comparison of the series itself is within 1e-6 relative of tol (flag), the call is
 // redone with the host libm in the reference's order.
-__global__ void __launch_bounds__(256) k_tail_nu(const double* __restrict__ xs, int n, double tol, double* __restrict__ nus, int* __restrict__ flags) {
+// The 100 arguments of a call travel as the kernel's argument block and the results are written straight into the engine's pinned mailbox (values, flags, then — by the last
+// workgroup to finish — the call's sequence number with release semantics, common.hpp cvx_mail_*): a call is ONE launch and one synchronisation where it used to be an upload,
+// the launch and two downloads (three of every five copies of a CBS call were these).
+struct TailArgs { double x[100]; };
+__global__ void __launch_bounds__(256) k_tail_nu(const TailArgs A, int n, double tol, double* __restrict__ nus /* pinned host */, int* __restrict__ flags /* pinned host */,
+                                                 unsigned* __restrict__ doneCnt /* device, zero between calls */, unsigned* __restrict__ seqWord /* pinned host */, unsigned seq) {
     __shared__ double sh[4];
     const int g = blockIdx.x; if (g >= n) return;
-    const double x = xs[g];
+    const double x = A.x[g];
     const int t = threadIdx.x;
-    if (!(x > 0.01)) { if (t == 0) { nus[g] = exp(-0.583 * x); flags[g] = 0; } return; }
+    auto finish = [&](double nu, int flag) {      // thread 0 of the workgroup
+        nus[g] = nu; flags[g] = flag;
+        __threadfence_system();
+        const unsigned old = __hip_atomic_fetch_add(doneCnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)n - 1u) { __hip_atomic_store(doneCnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cvx_mail_publish(seqWord, seq); }
+    };
+    if (!(x > 0.01)) { if (t == 0) finish(exp(-0.583 * x), 0); return; }
     double l1 = log(2.0) - 2.0 * log(x), l0 = l1;
     long long dk = 0; long long k = 2; int flag = 0;
     auto block = [&](long long cnt) -> double {           // sum_{i=1..cnt} 2 Phi(-x sqrt(dk + i) / 2) / (dk + i), all threads return the same value
@@ -72,7 +83,7 @@ __global__ void __launch_bounds__(256) k_tail_nu(const double* __restrict__ xs, 
         l1 = l1 - block(k); dk += k;
         k *= 2;
     }
-    if (t == 0) { nus[g] = exp(l1); flags[g] = flag; }
+    if (t == 0) finish(exp(l1), flag);
 }
 
 // ================================================================================================ device: exhaustive arc search
@@ -127,11 +138,13 @@ __global__ void __launch_bounds__(ARC_THREADS) k_arc_search(const ArcReq* __rest
 #define AP_BK 1024
 #define AP_PAIRCAP 8192
 struct ArcPReq { const double* sx; int n; int al0; double tau; double* bmin; double* bmax; int* pairs; unsigned long long* out /* [0] max key, [1] count, [2] min packed arc, [3] npairs, [4] overflow, [5] best block-extreme arc (bits) */; double* pairMax;
-                 int* bpos /* [2 nb]: position of every block's first minimum / first maximum */; };
+                 int* bpos /* [2 nb]: position of every block's first minimum / first maximum */;
+                 unsigned long long* hOut /* pinned host: out[0..4] of the finished search */; unsigned* hSeq /* pinned host: the mailbox's sequence word */; unsigned seq; };
 __global__ void __launch_bounds__(256) k_arcp_blocks(const ArcPReq* __restrict__ reqs) {
     const ArcPReq R = reqs[blockIdx.y];
     const int nb = (R.n + AP_BK - 1) / AP_BK;
     if ((int)blockIdx.x >= nb) return;
+    if (blockIdx.x == 0 && threadIdx.x < 6) R.out[threadIdx.x] = threadIdx.x == 2 ? ~0ull : 0ull;      // the result words of this search (they used to be two memsets per request in front of the launch)
     __shared__ double smn[4], smx[4]; __shared__ int pmn[4], pmx[4];
     double mn = 1.7976931348623157e308, mx = -1.7976931348623157e308; int imn = 0x7fffffff, imx = 0x7fffffff;
     for (int k = threadIdx.x; k < AP_BK; k += 256) { const int i = blockIdx.x * AP_BK + k; if (i < R.n) { const double v = R.sx[i]; if (v < mn) { mn = v; imn = i; } if (v > mx) { mx = v; imx = i; } } }
@@ -148,6 +161,13 @@ __global__ void __launch_bounds__(256) k_arcp_blocks(const ArcPReq* __restrict__
         for (int w = 1; w < 4; w++) { if (smn[w] < mn || (smn[w] == mn && pmn[w] < imn)) { mn = smn[w]; imn = pmn[w]; } if (smx[w] > mx || (smx[w] == mx && pmx[w] < imx)) { mx = smx[w]; imx = pmx[w]; } }
         R.bmin[blockIdx.x] = mn; R.bmax[blockIdx.x] = mx; R.bpos[2 * blockIdx.x] = imn; R.bpos[2 * blockIdx.x + 1] = imx;
     }
+}
+// the finished search's result words into the request's pinned mailbox (one workgroup per request, behind the last k_arcp_eval on the same stream)
+__global__ void __launch_bounds__(64) k_arcp_mail(const ArcPReq* __restrict__ reqs) {
+    const ArcPReq R = reqs[blockIdx.x];
+    if (threadIdx.x < 5) { R.hOut[threadIdx.x] = R.out[threadIdx.x]; __threadfence_system(); }
+    __syncthreads();
+    if (threadIdx.x == 0) cvx_mail_publish(R.hSeq, R.seq);
 }
 __device__ __forceinline__ double arc_c(double rn, int L) { const double rj = (double)L; return rn / (rj * (rn - rj)); }
 // pass 0: a better incumbent than the reference's starting arc — for every block pair the two arcs between the blocks' extremes (real arcs, evaluated exactly as k_arcp_eval
@@ -300,6 +320,7 @@ struct PermReq {
     const uint32_t* hist;      // (cont) the MT_HISTORY outputs in front of position 0 of this batch — where they were written: in the OTHER of the loop's two draw buffers (they used to be
                                // copied in front of P.draws, 10 MB device to device per batch: 7 % of the device time of the tumour / normal flow's CBS went into those copies)
     int fy;                    // 0: k_perm_stat, 1: k_perm_fy, 2: k_perm_small, 3: k_perm_rp evaluates this request's permutations
+    double* mailStat = nullptr; unsigned* mailSeq = nullptr; unsigned seq = 0;      // (pinned host) where k_perm_mail puts the batch's nb intervals, its sequence word and this batch's number; nullptr: pstat is copied by the launcher
     int cached = 0;            // the draws lie in the chromosome's stream cache (MtStreamCache): P.draws points INTO it, nothing is generated or snapshotted for this request
     // k_perm_rp: rpWGs persistent workgroups (blocks rpBase .. rpBase + rpWGs of its launch), each with its own scratch of rp.stride words behind rpScratch
     int rpBase, rpWGs; uint32_t* rpScratch; long long* rpClk;      // rpClk (probe only): cycles of workgroup 0 per phase
@@ -436,6 +457,15 @@ __global__ void __launch_bounds__(256) k_mt_snapshots(const PermReq* __restrict_
     uint32_t* s = R.snaps + (size_t)b * 625;
     for (int i = threadIdx.x; i < 624; i += 256) { const long long at = end - 624 + i; s[i] = mt_untemper(at >= 0 ? R.P.draws[at] : (R.cont ? R.hist[MT_HISTORY + at] : 0u)); }      // (at < 0: a continued batch of a short segment — the words lie in the previous batch; a batch that continues nothing: the snapshot is not used, see above)
     if (threadIdx.x == 0) s[624] = 624u;
+}
+// the intervals of a finished batch into its pinned mailbox: one workgroup per request behind the statistic kernels (instead of one device-to-host copy per request)
+__global__ void __launch_bounds__(256) k_perm_mail(const PermReq* __restrict__ reqs) {
+    const PermReq& R = reqs[blockIdx.x];
+    if (!R.mailStat) return;
+    for (int i = threadIdx.x; i < 2 * R.nb; i += 256) R.mailStat[i] = R.pstat[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) cvx_mail_publish(R.mailSeq, R.seq);
 }
 __device__ __forceinline__ int block_excl_scan_i32(int v, int* sh /*PG_T/64 + 1*/, int& total) {
     int inc = v;
@@ -1799,7 +1829,7 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int32_t rc = G.ensure(n); if (rc) return rc;
     double* hSx = (double*)G.pin; double* hMax = nullptr; int32_t* hFirst = nullptr; unsigned long long* hOut = (unsigned long long*)(G.pin + (size_t)G.pinCap * 8);
-    memcpy(hSx, sx, (size_t)n * 8);
+    memcpy(hSx, sx, (size_t)n * 8);      // (from pageable memory instead — no pinned staging buffers, 0.77 thread-seconds of a cold call — was measured: first call 0.17 against 0.18 s, warm 0.056 against 0.046: not kept)
     const size_t nbk = (size_t)G.cap / AP_BK + 2;
     ArcHostReq q; q.hSx = hSx; q.hMax = hMax; q.hFirst = hFirst; q.hOut = hOut;
     q.r.sx = G.dSx; q.r.n = n; q.r.dmax = G.dMax; q.r.firstI = G.dFirst;
@@ -1995,7 +2025,8 @@ static size_t rp_scratch_bytes(int n, int wgs) { PermReq::RpPlan P; rp_plan(n, P
 #define MTS_GRANULE (size_t(64) << 20)          // physical memory is mapped into a stream in pieces of this size (16 M draws)
 #define MTS_VA_BYTES (size_t(64) << 30)         // address range of a stream: 16 G draws
 #define MTS_FIRST_WORDS (8LL << 20)             // the first extension of a stream (it must leave MT_HISTORY words behind for the strided generator to continue from)
-#define MTS_JOB_MAX_WORDS (256LL << 20)         // ... and the longest one
+#define MTS_JOB_MAX_WORDS (48LL << 20)          // ... and the longest one: a round of the producer serves every stream that is behind and publishes when its LONGEST job is done —
+                                                // short rounds (~1 ms) keep a stream that needs little from waiting behind one that needs much
 struct MtStream {
     uint32_t seed = 0; char* va = nullptr; size_t mappedBytes = 0; bool plain = false; size_t plainBytes = 0; std::vector<hipMemGenericAllocationHandle_t> handles;
     long long ready = 0, requested = 0; bool full = false;      // words that are valid / that the producer has been asked for; full: no more memory will be mapped
@@ -2006,6 +2037,7 @@ struct MtStreamCache {
     size_t capBytes = 0, usedBytes = 0; bool useVmm = true, stop = false, failed = false, started = false, off = false; std::string err;
     std::thread th; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr;
     std::atomic<long long> servedWords{0}, generatedWords{0}, fallbackWords{0}, fetches{0};
+    std::atomic<long long> nsMap{0}, nsGen{0}, rounds{0}, nsWaited{0}, waits{0};      // producer: mapping memory, generating (launch to synchronisation), rounds; consumers: time spent waiting in acquire()
     static constexpr int CAP = 32;
     explicit MtStreamCache(canvas_ctx* c) : ctx(c) {
         // CANVAS_CBS_CACHE_GB: the bound of the whole cache in GB (0 switches it off); a configuration switch, read without CANVAS_TEST_HOOKS
@@ -2074,7 +2106,9 @@ struct MtStreamCache {
         }
         if (S->full || failed) return false;
         if (end + ahead > S->requested) { S->requested = std::max(end + ahead, MTS_FIRST_WORDS); ensure_thread(); cvWork.notify_one(); }
+        const auto tW = std::chrono::steady_clock::now();
         cvReady.wait(lk, [&]() { return stop || failed || S->full || S->ready >= end; });
+        nsWaited += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tW).count(); waits++;
         return S->ready >= end;
     }
     void ensure_thread() { if (!started) { started = true; th = std::thread([this]() { run(); }); } }      // (mu held)
@@ -2111,6 +2145,7 @@ struct MtStreamCache {
               for (auto& kv : streams) { MtStream& S = *kv.second; if (!S.full && S.requested > S.ready && (int)jobs.size() < CAP) jobs.push_back({&S, S.ready, std::min(S.requested, S.ready + MTS_JOB_MAX_WORDS)}); } }
             std::vector<char> shortJob(jobs.size(), 0);
             int R = 0; bool anyFresh = false; long long maxFresh = 0, maxTotal = 0;
+            const auto tM = std::chrono::steady_clock::now();
             for (size_t i = 0; i < jobs.size(); i++) {
                 Job& j = jobs[i];
                 const long long have = back(*j.S, j.to);
@@ -2125,6 +2160,8 @@ struct MtStreamCache {
                 maxTotal = std::max(maxTotal, q.total + (q.cont ? MT_HISTORY : 0));
             }
             bool ok = true;
+            const auto tG = std::chrono::steady_clock::now();
+            nsMap += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(tG - tM).count(); rounds++;
             if (R > 0) {
                 ok = hipMemcpyAsync(dReqs, hReqs, (size_t)R * sizeof(PermReq), hipMemcpyHostToDevice, stream) == hipSuccess;
                 if (ok && anyFresh) {
@@ -2134,6 +2171,7 @@ struct MtStreamCache {
                 if (ok && maxTotal > MT_HISTORY) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
                 ok = ok && hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
             }
+            nsGen += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tG).count();
             { std::lock_guard<std::mutex> lk(mu);
               if (!ok) { (void)hipGetLastError(); failed = true; err = "the draw-stream cache's generator failed"; }
               else for (size_t i = 0; i < jobs.size(); i++) { MtStream& S = *jobs[i].S; if (jobs[i].to > S.ready) { generatedWords += jobs[i].to - S.ready; S.ready = jobs[i].to; } if (shortJob[i]) S.full = true; } }
@@ -2155,7 +2193,8 @@ struct PermGpu {
     size_t reserveElems = 0, reserveN = 0;     // the call's longest chromosome: the first allocation is made for it (growing means hipFree + hipMalloc, which stall every stream of the device)
     size_t reserveBytes = 0, reservePin = 0;   // ... in bytes of device / pinned memory (perm_reserve_bytes)
     // analytic tail probability on the device (k_tail_nu): own stream, 3 x 128 values on the device and in pinned memory
-    hipStream_t tailStream = nullptr; char* tailDev = nullptr; char* tailPin = nullptr; EngineCache* cache = nullptr;
+    hipStream_t tailStream = nullptr; char* tailDev = nullptr; char* tailPin = nullptr; EngineCache* cache = nullptr; unsigned tailSeq = 0;      // tailDev: the completion counter of k_tail_nu; tailPin: its mailbox
+    unsigned mailSeq = 0;         // sequence numbers of the permutation batches' result mailboxes
     bool tailOwned = true;        // false: the stream is one of the cache's shared ones (several engines enqueue their short tail kernels on it; each waits for the stream,
                                   // i.e. at worst for a few other 10 us kernels) and the buffers are slices of its arena
     int32_t ensure_tail() {
@@ -2163,10 +2202,14 @@ struct PermGpu {
         AllocClock ac(g_ns_alloc_tail);
         CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
         hipStream_t sh = cache_tail_stream(cache); char* d = sh ? cache_take(cache, false, 128 * 24) : nullptr; char* p = d ? cache_take(cache, true, 128 * 24) : nullptr;
-        if (sh && d && p) { tailStream = sh; tailDev = d; tailPin = p; tailOwned = false; return CANVAS_OK; }
-        tailOwned = true;
-        CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&tailStream, hipStreamNonBlocking));
-        CANVAS_HIP_TRY(ctx, hipMalloc((void**)&tailDev, 128 * 24)); CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&tailPin, 128 * 24, hipHostMallocDefault));
+        if (sh && d && p) { tailStream = sh; tailDev = d; tailPin = p; tailOwned = false; }
+        else {
+            tailOwned = true;
+            CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&tailStream, hipStreamNonBlocking));
+            CANVAS_HIP_TRY(ctx, hipMalloc((void**)&tailDev, 128 * 24)); CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&tailPin, 128 * 24, hipHostMallocDefault));
+        }
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(tailDev, 0, 256, tailStream));      // the completion counter (every call leaves it at zero again)
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(tailStream));
         return CANVAS_OK;
     }
     // need: what the reservation asks for (the call's longest chromosome); minNeed: what this request cannot do without — taken when the reservation does not fit the device
@@ -2234,16 +2277,17 @@ static int32_t tail_p_decide(PermGpu& PG, double b, double delta, int m, double 
     if (cvx_hook("CANVAS_CBS_HOST_TAILP")) { exact(); return CANVAS_OK; }
     canvas_ctx* ctx = PG.ctx;
     int32_t rc = PG.ensure_tail(); if (rc) return rc;
-    double* hX = (double*)PG.tailPin; double* hNu = hX + 128; int* hFlag = (int*)(hNu + 128);
-    double* dX = (double*)PG.tailDev; double* dNu = dX + 128; int* dFlag = (int*)(dNu + 128);
+    double* hNu = (double*)PG.tailPin; int* hFlag = (int*)(hNu + 128); volatile unsigned* hSeq = (volatile unsigned*)(hFlag + 128);      // the mailbox: 1024 + 512 + 4 bytes of the 3072
     const double dincr = (0.5 - delta) / nGrid, bs = b / std::sqrt((double)m);
     double tl = 0.5 - dincr, t = 0.5 - 0.5 * dincr, tls[128];
-    for (int i = 0; i < nGrid; i++) { tl = tl + dincr; t = t + dincr; hX[i] = bs / std::sqrt(t * (1 - t)); tls[i] = tl; }
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dX, hX, nGrid * 8, hipMemcpyHostToDevice, PG.tailStream));
-    hipLaunchKernelGGL(k_tail_nu, dim3(nGrid), dim3(256), 0, PG.tailStream, dX, nGrid, tol, dNu, dFlag);
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hNu, dNu, nGrid * 8, hipMemcpyDeviceToHost, PG.tailStream));
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hFlag, dFlag, nGrid * 4, hipMemcpyDeviceToHost, PG.tailStream));
+    TailArgs A;
+    for (int i = 0; i < nGrid; i++) { tl = tl + dincr; t = t + dincr; A.x[i] = bs / std::sqrt(t * (1 - t)); tls[i] = tl; }
+    unsigned seq = ++PG.tailSeq; if (seq == 0) seq = ++PG.tailSeq;
+    *hSeq = 0u; std::atomic_thread_fence(std::memory_order_seq_cst);
+    hipLaunchKernelGGL(k_tail_nu, dim3(nGrid), dim3(256), 0, PG.tailStream, A, nGrid, tol, hNu, hFlag, (unsigned*)PG.tailDev, (unsigned*)hSeq, seq);
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(PG.tailStream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    { int32_t rcm = cvx_mail_await(ctx, hSeq, seq, "canvas_cbs (tail series)"); if (rcm) return rcm; }
     bool flagged = false; for (int i = 0; i < nGrid; i++) if (hFlag[i] || !(hNu[i] == hNu[i])) flagged = true;
     if (flagged) { exact(); return CANVAS_OK; }
     double tp = 0.0;
@@ -2268,11 +2312,17 @@ struct PermHostReq { PermReq r; long long prevTotal = 0; double* hStat; uint32_t
                      bool done = false; int32_t rc = CANVAS_OK; };
 // the device side of a launcher (its stream and request tables): kept by the context between calls — canvas_cbs builds seven launchers per call, and each paid a stream
 // creation and six small allocations on its first round
-struct SvcRes { hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; };
+struct SvcRes { hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr;
+                char* rpSlab = nullptr; size_t rpSlabBytes = 0; };      // rpSlab: the scratch of k_perm_rp's persistent workgroups for whatever this launcher has in flight
 struct PermService {
     canvas_ctx* ctx; SvcRes* res = nullptr; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
     ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
-    long long rounds = 0, nArc = 0, nPermReq = 0; double secArc = 0, secPerm = 0;
+    long long rounds = 0, nArc = 0, nPermReq = 0; double secArc = 0, secPerm = 0; unsigned arcSeq = 0;
+    // k_perm_rp's scratch belongs to the LAUNCHER, not to the engines: a launch holds the batches of several chromosomes, the device has 512 workgroup slots for all of them, and
+    // a launcher has one launch in flight — so one slab per launcher (2 GiB for the longest segments) serves what 24 engines used to reserve 2 GiB EACH for (48 GB of
+    // hipMalloc in the first call of a process, which at times took seconds beside the stream cache's mappings: ADVICE r05, profiles/r06_*).  Requests share the slab in
+    // proportion to the workgroups they ask for.
+    size_t rpSlabWant = 0;
     bool probeTiming = false; double lastMs[3] = {0, 0, 0};      // canvas_cbs_perm_probe: generator (sequential + bootstrap), generator (strided), permutation + statistic of the last launch
     std::mutex mu; std::condition_variable cvWork, cvDone; std::vector<PermHostReq*> pending; bool stop = false; std::thread th; std::string err;
     explicit PermService(canvas_ctx* c) : ctx(c) { th = std::thread([this]() { run(); }); }
@@ -2321,7 +2371,9 @@ struct PermService {
         for (auto* q : all) CANVAS_HIP_TRY(ctx, hipMemcpyAsync((void*)q->r.sx, q->hSx, (size_t)q->r.n * 8, hipMemcpyHostToDevice, stream));
         if (!pr.empty()) {
             const int R = (int)pr.size(); int maxN = 0;
-            for (int i = 0; i < R; i++) { hArcP[i] = pr[i]->p; maxN = std::max(maxN, pr[i]->p.n); CANVAS_HIP_TRY(ctx, hipMemsetAsync(pr[i]->p.out, 0, 48, stream)); CANVAS_HIP_TRY(ctx, hipMemsetAsync(pr[i]->p.out + 2, 0xFF, 8, stream)); }
+            for (int i = 0; i < R; i++) { unsigned sq_ = ++arcSeq; if (sq_ == 0) sq_ = ++arcSeq; pr[i]->p.hOut = pr[i]->hOut; pr[i]->p.hSeq = (unsigned*)(pr[i]->hOut + 6); pr[i]->p.seq = sq_; *(volatile unsigned*)pr[i]->p.hSeq = 0u;
+                                          hArcP[i] = pr[i]->p; maxN = std::max(maxN, pr[i]->p.n); }
+            std::atomic_thread_fence(std::memory_order_seq_cst);
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dArcP, hArcP, R * sizeof(ArcPReq), hipMemcpyHostToDevice, stream));
             const int nb = (maxN + AP_BK - 1) / AP_BK;
             hipLaunchKernelGGL(k_arcp_blocks, dim3(nb, R), dim3(256), 0, stream, dArcP);
@@ -2329,7 +2381,7 @@ struct PermService {
             hipLaunchKernelGGL(k_arcp_bounds, dim3((unsigned)(((long long)nb * nb + 255) / 256), R), dim3(256), 0, stream, dArcP, 1);
             hipLaunchKernelGGL(k_arcp_eval, dim3(AP_EVAL_GRID, R), dim3(256), 0, stream, dArcP, 0);
             hipLaunchKernelGGL(k_arcp_eval, dim3(AP_EVAL_GRID, R), dim3(256), 0, stream, dArcP, 1);
-            for (int i = 0; i < R; i++) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(pr[i]->hOut, pr[i]->p.out, 40, hipMemcpyDeviceToHost, stream));
+            hipLaunchKernelGGL(k_arcp_mail, dim3(R), dim3(64), 0, stream, dArcP);
         }
         if (!ex.empty()) {
             const int R = (int)ex.size(); int maxN = 0;
@@ -2343,12 +2395,35 @@ struct PermService {
         }
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
+        for (auto* q : pr) { int32_t rcm = cvx_mail_await(ctx, (volatile unsigned*)q->p.hSeq, q->p.seq, "canvas_cbs (arc search)"); if (rcm) return rcm; }
         return CANVAS_OK;
     }
     int32_t launch(std::vector<PermHostReq*>& batch) {
         { int32_t rc0 = init(); if (rc0) return rc0; }
         const int R = (int)batch.size();
         int blocks = 0, rpBlocks = 0; long long maxTotal = 0;
+        // ---- the launcher's slab shared among the k_perm_rp requests of this launch that bring no scratch of their own (the probe does)
+        auto al256 = [](size_t v) { return (v + 255) & ~size_t(255); };
+        { size_t want = 0; for (int i = 0; i < R; i++) if (batch[i]->r.fy == 3 && !batch[i]->r.rpScratch) want += al256((size_t)batch[i]->r.rp.stride * 4 * (size_t)std::max(1, batch[i]->r.rpWGs));
+          if (want) {
+              if (!res->rpSlab || res->rpSlabBytes < std::min<size_t>(want, std::max<size_t>(rpSlabWant, size_t(64) << 20))) {
+                  AllocClock ac(g_ns_alloc_perm);
+                  if (res->rpSlab) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream)); CANVAS_HIP_TRY(ctx, hipFree(res->rpSlab)); res->rpSlab = nullptr; res->rpSlabBytes = 0; }
+                  size_t bytes = std::max<size_t>(std::max<size_t>(rpSlabWant, size_t(64) << 20), 0);
+                  for (int i = 0; i < R; i++) if (batch[i]->r.fy == 3 && !batch[i]->r.rpScratch) bytes = std::max(bytes, al256((size_t)batch[i]->r.rp.stride * 4) + 256);      // at least one workgroup of the longest plan
+                  CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->rpSlab, bytes)); res->rpSlabBytes = bytes;
+              }
+              const double scale = want > res->rpSlabBytes ? (double)res->rpSlabBytes / (double)want * 0.98 : 1.0;
+              size_t off = 0;
+              for (int i = 0; i < R; i++) if (batch[i]->r.fy == 3 && !batch[i]->r.rpScratch) {
+                  PermReq& q = batch[i]->r; const size_t per = (size_t)q.rp.stride * 4;
+                  int wg = std::max(1, (int)((double)std::max(1, q.rpWGs) * scale));
+                  while (wg > 1 && off + al256(per * (size_t)wg) > res->rpSlabBytes) wg--;
+                  if (off + al256(per * (size_t)wg) > res->rpSlabBytes) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_cbs: the launcher's scratch slab cannot hold one workgroup of every request");
+                  const int rounds = (q.nb + wg - 1) / wg; q.rpWGs = (q.nb + rounds - 1) / rounds;      // (every workgroup the same number of permutations)
+                  q.rpScratch = (uint32_t*)(res->rpSlab + off); off += al256(per * (size_t)q.rpWGs);
+              }
+          } }
         for (int i = 0; i < R; i++) {
             batch[i]->r.rpBase = rpBlocks; if (batch[i]->r.fy == 3) rpBlocks += batch[i]->r.rpWGs; else batch[i]->r.rpWGs = 0;
             batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2 && !batch[i]->r.cached) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
@@ -2385,12 +2460,15 @@ struct PermService {
         if (probeTiming) { lastMs[0] = msA; lastMs[1] = msB; lastMs[2] = lap(); }
         else if (dbg) { const double msC = lap(); int nc = 0, maxN = 0; for (int i = 0; i < R; i++) { nc += batch[i]->r.cont; maxN = std::max(maxN, batch[i]->r.n); }
                    fprintf(stderr, "cbs batch: %d requests (%d continued), %d permutations, longest segment %d, %d stride steps: sequential %.2f ms, strided %.2f ms, statistics %.2f ms\n", R, nc, blocks, maxN, steps, msA, msB, msC); }
+        bool anyMail = false; for (int i = 0; i < R; i++) anyMail |= batch[i]->r.mailStat != nullptr;
+        if (anyMail) hipLaunchKernelGGL(k_perm_mail, dim3(R), dim3(256), 0, stream, dReqs);
         for (int i = 0; i < R; i++) {
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hStat, batch[i]->r.pstat, (size_t)batch[i]->r.nb * 16, hipMemcpyDeviceToHost, stream));
+            if (!batch[i]->r.mailStat) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hStat, batch[i]->r.pstat, (size_t)batch[i]->r.nb * 16, hipMemcpyDeviceToHost, stream));
             if (batch[i]->hSnaps) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->hSnaps, batch[i]->r.snaps, (size_t)batch[i]->r.nb * 625 * 4, hipMemcpyDeviceToHost, stream));
         }
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream));
         CANVAS_HIP_TRY(ctx, hipGetLastError());
+        for (int i = 0; i < R; i++) if (batch[i]->r.mailStat) { int32_t rcm = cvx_mail_await(ctx, (volatile unsigned*)batch[i]->r.mailSeq, batch[i]->r.seq, "canvas_cbs (permutation batch)"); if (rcm) return rcm; }
         return CANVAS_OK;
     }
     void run() {
@@ -2422,7 +2500,11 @@ static thread_local ChromClock tlClock;
 #define PERM_RP_MAXB 1024
 static inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
 static inline bool perm_use_rp(int n) { static const bool off = cvx_hook("CANVAS_CBS_NO_RP") != nullptr; static const int minN = cvx_hook("CANVAS_CBS_RP_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_RP_MIN_N")) : PERM_RP_MIN_N; return !off && n >= minN && n <= PERM_RP_MAX_N; }
-static inline int perm_max_batch(int n) { return perm_use_rp(n) ? (int)std::max<long long>(8, std::min<long long>(PERM_RP_MAXB, PERM_TARGET_ELEMS / n)) : (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n)); }
+// cached: the batch reads its draws out of the chromosome's stream — no draw buffers, so a batch of a long segment could be as large as the stopping rule asks for (a 234 k-bin
+// segment: 1024 permutations instead of 286).  Measured (CANVAS_CBS_TARGET_ELEMS=268435456): the tumour / normal flow's CBS 0.436 against 0.438 s, the germline call 0.061
+// against 0.047 s — the long-running workgroups of the larger batches keep the short arc / tail kernels of the other chromosomes waiting for a CU.  The size stays.
+static inline long long perm_target_elems(bool cached) { static const long long c = cvx_hook("CANVAS_CBS_TARGET_ELEMS") ? atoll(cvx_hook("CANVAS_CBS_TARGET_ELEMS")) : (long long)PERM_TARGET_ELEMS; return cached ? c : (long long)PERM_TARGET_ELEMS; }
+static inline int perm_max_batch(int n, bool cached = false) { return perm_use_rp(n) ? (int)std::max<long long>(8, std::min<long long>(PERM_RP_MAXB, perm_target_elems(cached) / n)) : (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n)); }
 static inline int perm_rp_wgs(int n) { PermReq::RpPlan P; rp_plan(n, P); const size_t per = (size_t)P.stride * 4; return (int)std::max<size_t>(64, std::min<size_t>(PERM_RP_GRID, PERM_RP_SCRATCH_BYTES / per)); }
 // the scratch of k_perm_rp's workgroups for segments of up to nMax bins: what perm_rp_wgs() workgroups of the LONGEST plan take, never more than PERM_RP_SCRATCH_BYTES — a
 // small genome reserves megabytes, not 2 GiB
@@ -2438,12 +2520,12 @@ static void perm_reserve_bytes(size_t nMax, bool withDraws, size_t& dev, size_t&
     const size_t head = al256(nMax * 8) + al256(625 * 4) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
     const size_t elemsRp = std::max<size_t>(PERM_TARGET_ELEMS, 8 * nMax);
     const size_t drawsB = withDraws ? 2 * al256((elemsRp + (size_t)MT_HISTORY) * 4) : 0;
-    dev = head + drawsB + perm_rp_scratch_bytes(nMax) + (size_t(16) << 20);
+    dev = head + drawsB + (size_t(4) << 20);      // (k_perm_rp's scratch is the launcher's: PermService::rpSlabWant)
     if (nMax > (size_t)PERM_RP_MAX_N || !perm_use_rp((int)std::min<size_t>(nMax, PERM_RP_MAX_N))) {
         const size_t re = (size_t)std::min<long long>((long long)256 * (long long)nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * (long long)nMax));
         dev = std::max(dev, head + (withDraws ? 2 * al256((re + (size_t)MT_HISTORY) * 4) : 0) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
     }
-    pin = al256(nMax * 8) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16);
+    pin = al256(nMax * 8) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16) + 256;
 }
 
 // The sequential stopping rule of FindChangePoints (ChangePoint.cs:337-364) over permutations evaluated in device batches.
@@ -2454,25 +2536,25 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
                              const std::vector<uint32_t>& sbdry, Rng& rnd, Stats& st, int& outcome) {
     canvas_ctx* ctx = PG.ctx;
     const bool useRp = perm_use_rp(n) && hk == RP_J1 && al0 == RP_J0;      // (k_perm_rp's statistic is written for FindChangePoints' own arc lengths)
-    const int maxB = perm_max_batch(n);
+    int maxB = perm_max_batch(n, rnd.S != nullptr);
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     auto now = []() { return std::chrono::steady_clock::now(); };
     uint32_t* dRpScratch = nullptr; int rpWGs = 0; PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP);
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
     double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
     uint32_t* draws2[2] = {nullptr, nullptr}; int drawBuf = 0;      // (own draws) the loop's batches alternate between two draw buffers
-    bool haveDraws = false;
+    bool haveDraws = false; volatile unsigned* hMail = nullptr;
     auto setup = [&](int mb, bool withDraws) -> int32_t {
         const size_t e = (size_t)mb * n, e1 = (size_t)mb * (n + 1);
         const size_t drawsB = withDraws ? 2 * al((e + (size_t)MT_HISTORY) * 4) : 0;      // two draw buffers: a batch reads its history where the previous one wrote it
         const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)mb * 625 * 4), oDraws = oStat + al((size_t)mb * 16),
                      oJ = oDraws + drawsB, oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
                      oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
-        const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pinTotal = pStat + al((size_t)mb * 16);
+        const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pMail = pStat + al((size_t)mb * 16), pinTotal = pMail + 256;
         auto tE = now();
         // k_perm_rp: behind the draws the scratch of the persistent workgroups (results travel in streams: no per-element workspace)
-        size_t oScratch = 0, totalRp = 0;
-        if (useRp) { rp_plan(n, rpP); rpWGs = std::min(perm_rp_wgs(n), mb); oScratch = oDraws + drawsB; totalRp = oScratch + al((size_t)rpP.stride * 4 * (size_t)rpWGs); }
+        size_t totalRp = 0;
+        if (useRp) { rp_plan(n, rpP); rpWGs = std::min(perm_rp_wgs(n), mb); totalRp = oDraws + drawsB + 256; }      // (the workgroups' scratch comes out of the launcher's slab at launch time)
         const size_t need = useRp ? totalRp : total;
         size_t want = need, wantPin = pinTotal;
         if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // the first allocation serves the longest segment this call can meet
@@ -2482,11 +2564,10 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         dX = (double*)(d + oX); dSnaps = (uint32_t*)(d + oSnaps); dStat = (double*)(d + oStat);
         memset(&P, 0, sizeof P);
         if (withDraws) { P.draws = (uint32_t*)(d + oDraws) + MT_HISTORY; draws2[0] = P.draws; draws2[1] = (uint32_t*)(d + oDraws + al((e + (size_t)MT_HISTORY) * 4)) + MT_HISTORY; }
-        if (useRp) dRpScratch = (uint32_t*)(d + oScratch);
-        else {
+        if (!useRp) {
         P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
         P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx); }
-        hX = (double*)(h + pX); hSnaps = (uint32_t*)(h + pSnaps); hStat = (double*)(h + pStat);
+        hX = (double*)(h + pX); hSnaps = (uint32_t*)(h + pSnaps); hStat = (double*)(h + pStat); hMail = (volatile unsigned*)(h + pMail);
         haveDraws = withDraws;
         return CANVAS_OK;
     };
@@ -2509,14 +2590,16 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     if (cvx_hook("CANVAS_CBS_B0")) B = std::min(maxB, atoi(cvx_hook("CANVAS_CBS_B0")));
     outcome = 1;
     while (np < nPerm) {
-        const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
-        const long long need = (long long)nb * n;
+        int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
+        long long need = (long long)nb * n;
         auto tS = now();
-        const bool cached = S && SC->acquire(S, pos + need, std::max<long long>(2 * need, 4LL << 20));
+        const bool cached = S && SC->acquire(S, pos + need, std::max<long long>(2 * need, 16LL << 20));
         if (!cached) {
-            // own draws: the state at pos (a generator that was moved by position is rebuilt from the cache's words in front of it) and the two draw buffers
+            // own draws: the state at pos (a generator that was moved by position is rebuilt from the cache's words in front of it) and the two draw buffers (batches of
+            // the size those buffers are reserved for)
             if (!haveCur) { MT m(0u); rc = rnd.at(PG, pos, m); if (rc) return rc; m.get_state(cur); haveCur = true; prevOwn = false; }
-            if (!haveDraws) { rc = setup(maxB, true); if (rc) return rc; memcpy(hX, gd, (size_t)n * 8); needUpload = true; }
+            if (!haveDraws) { maxB = perm_max_batch(n, false); rc = setup(maxB, true); if (rc) return rc; memcpy(hX, gd, (size_t)n * 8); needUpload = true; }
+            if (nb > maxB) { nb = maxB; need = (long long)nb * n; }
         }
         PermHostReq q;
         q.r.total = need; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
@@ -2537,6 +2620,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         // 300 workgroups with two each take the same time and leave the other CUs to the kernels of the other chromosomes)
         { const int rounds = useRp ? (nb + rpWGs - 1) / rpWGs : 1; q.r.rpWGs = useRp ? (nb + rounds - 1) / rounds : 0; }
         q.r.rpBase = 0; q.r.rpScratch = dRpScratch; q.r.rp = rpP; q.r.rpClk = nullptr;
+        { unsigned sq_ = ++PG.mailSeq; if (sq_ == 0) sq_ = ++PG.mailSeq; q.r.mailStat = hStat; q.r.mailSeq = (unsigned*)hMail; q.r.seq = sq_; *hMail = 0u; std::atomic_thread_fence(std::memory_order_seq_cst); }
         prevTotal = need; prevOwn = !cached;
         rc = PG.svc->submit(q); if (rc) return rc;
         st.ns_submit += since(tS);
@@ -2627,14 +2711,14 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
     const int maxB = 2048;
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t oX = 0, oStat = al((size_t)n * 8), oDraws = oStat + al((size_t)maxB * 16), total = oDraws + al(((size_t)maxB * n + (size_t)MT_HISTORY) * 4) + 256;
-    const size_t pX = 0, pStat = al((size_t)n * 8), pDraws = pStat + al((size_t)maxB * 16), pinTotal = pDraws + al((size_t)maxB * n * 4);
+    const size_t pX = 0, pStat = al((size_t)n * 8), pMail = pStat + al((size_t)maxB * 16), pDraws = pMail + 256, pinTotal = pDraws + al((size_t)maxB * n * 4);
     size_t want = total, wantPin = pinTotal;
     if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // never shrink below what perm_loop_gpu will ask for: one allocation per engine
     int32_t rc = PG.ensure(want, wantPin, total); if (rc) return rc;
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     char* d = PG.buf; char* h = PG.pin;
     double* dX = (double*)(d + oX); double* dStat = (double*)(d + oStat); uint32_t* dDraws = (uint32_t*)(d + oDraws) + MT_HISTORY;
-    double* hX = (double*)(h + pX); double* hStat = (double*)(h + pStat); uint32_t* hDraws = (uint32_t*)(h + pDraws);
+    double* hX = (double*)(h + pX); double* hStat = (double*)(h + pStat); uint32_t* hDraws = (uint32_t*)(h + pDraws); volatile unsigned* hMail = (volatile unsigned*)(h + pMail);
     memcpy(hX, gd, (size_t)n * 8);
     bool needUpload = true;
     int nrej = 0; uint32_t np = 0;
@@ -2646,7 +2730,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
     while (np < nPerm) {
         const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
         const long long need = (long long)nb * n;
-        const bool cached = S && SC->acquire(S, pos + need, std::max<long long>(2 * need, 4LL << 20));
+        const bool cached = S && SC->acquire(S, pos + need, std::max<long long>(2 * need, 16LL << 20));
         MT start(0u);
         if (!cached) {      // the batch's draws: nb * n outputs of the chromosome's generator, in order
             MT* m = rnd.host(PG); if (!m) return CANVAS_ERR_HIP;
@@ -2660,6 +2744,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
         q.r.rpBase = 0; q.r.rpWGs = 0; q.r.rpScratch = nullptr; q.r.rpClk = nullptr; memset(&q.r.rp, 0, sizeof q.r.rp);
         if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         if (!cached) { q.hDraws = hDraws; q.drawBytes = (size_t)need * 4; }
+        { unsigned sq_ = ++PG.mailSeq; if (sq_ == 0) sq_ = ++PG.mailSeq; q.r.mailStat = hStat; q.r.mailSeq = (unsigned*)hMail; q.r.seq = sq_; *hMail = 0u; std::atomic_thread_fence(std::memory_order_seq_cst); }
         auto tS = std::chrono::steady_clock::now();
         rc = PG.svc->submit(q); if (rc) return rc;
         st.ns_submit += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tS).count();
@@ -2820,12 +2905,15 @@ struct EngineCache {
     std::vector<Slab> devSlabs, pinSlabs; std::vector<hipStream_t> tailStreams; size_t nextTail = 0; std::vector<SvcRes*> svcFree, svcAll;
     std::unique_ptr<MtStreamCache> mts;      // the chromosomes' draw streams (created with the first CBS call / canvas_cbs_prefetch of the context)
     MtStreamCache* streams(canvas_ctx* ctx) { std::lock_guard<std::mutex> lk(mu); if (!mts) mts.reset(new MtStreamCache(ctx)); return mts->off ? nullptr : mts.get(); }
+    std::thread streamMaker; bool dying = false;
     ~EngineCache() {
+        { std::lock_guard<std::mutex> lk(mu); dying = true; }
+        if (streamMaker.joinable()) streamMaker.join();
         mts.reset();                                          // (joins the producer thread, unmaps the streams)
         arcs.clear(); perms.clear(); tails.clear();           // (the engines first: they may still wait on a shared stream)
         for (hipStream_t q : tailStreams) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         for (SvcRes* r : svcAll) { if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); } if (r->dReqs) (void)hipFree(r->dReqs); if (r->hReqs) (void)hipHostFree(r->hReqs);
-                                   if (r->dArc) (void)hipFree(r->dArc); if (r->hArc) (void)hipHostFree(r->hArc); if (r->dArcP) (void)hipFree(r->dArcP); if (r->hArcP) (void)hipHostFree(r->hArcP); delete r; }
+                                   if (r->dArc) (void)hipFree(r->dArc); if (r->hArc) (void)hipHostFree(r->hArc); if (r->dArcP) (void)hipFree(r->dArcP); if (r->hArcP) (void)hipHostFree(r->hArcP); if (r->rpSlab) (void)hipFree(r->rpSlab); delete r; }
         for (Slab& b : devSlabs) (void)hipFree(b.base);
         for (Slab& b : pinSlabs) (void)hipHostFree(b.base);
     }
@@ -2841,9 +2929,26 @@ struct EngineCache {
         size_t aDev = 0, aPin = 0; ArcGpu::arena_bytes(nMax, aDev, aPin);
         const size_t dev = (size_t)newArc * (aDev + 512) + (size_t)newTail * (128 * 24 + 512), pin = (size_t)newArc * (aPin + 512) + (size_t)newTail * (128 * 24 + 512);
         auto left = [](std::vector<Slab>& v) { return v.empty() ? size_t(0) : v.back().bytes - v.back().off; };
+        auto t0 = std::chrono::steady_clock::now(); auto ms = [&]() { auto t = std::chrono::steady_clock::now(); const double v = std::chrono::duration<double, std::milli>(t - t0).count(); t0 = t; return v; };
         if (dev > left(devSlabs)) { Slab b; b.bytes = dev + (1u << 16); if (hipMalloc((void**)&b.base, b.bytes) == hipSuccess) devSlabs.push_back(b); else (void)hipGetLastError(); }
+        const double msDev = ms();
         if (pin > left(pinSlabs)) { Slab b; b.bytes = pin + (1u << 16); if (hipHostMalloc((void**)&b.base, b.bytes, hipHostMallocDefault) == hipSuccess) pinSlabs.push_back(b); else (void)hipGetLastError(); }
-        while (newTail > 0 && tailStreams.size() < 16) { hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; } tailStreams.push_back(q); }
+        const double msPin = ms();
+        // the shared tail streams: creating one takes ~5 ms on this runtime (sixteen: 77 of the 170 ms of a cold call) — two are made here, the others on a thread of their
+        // own while the chromosome threads start (tail_stream() hands out what exists)
+        while (newTail > 0 && tailStreams.size() < 2) { hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; } tailStreams.push_back(q); }
+        if (newTail > 0 && tailStreams.size() < 12 && !streamMaker.joinable()) {
+            const int dev = ctx->device;
+            streamMaker = std::thread([this, dev]() {
+                if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
+                for (;;) {
+                    { std::lock_guard<std::mutex> lk2(mu); if (tailStreams.size() >= 12 || dying) return; }
+                    hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+                    std::lock_guard<std::mutex> lk2(mu); tailStreams.push_back(q);
+                }
+            });
+        }
+        if (cvx_hook("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs arena: device slab of %.1f MB %.1f ms, pinned slab of %.2f MB %.1f ms, %zu tail streams (the others follow in the background) %.1f ms\n", dev / 1e6, msDev, pin / 1e6, msPin, tailStreams.size(), ms());
     }
     char* take(bool pinned, size_t bytes) {
         std::lock_guard<std::mutex> lk(mu);
@@ -3197,11 +3302,14 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     if (undo != 0 && undo != 1 && undo != 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "undo must be 0 (None), 1 (Prune) or 2 (SDUndo)");
     if (nchr <= 0 || !d_cov || !h_chr_offset || nperm == 0 || !(alpha > 0 && alpha < 1)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs: bad arguments");
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto tEntry = std::chrono::steady_clock::now(); double lapLast = 0; std::string laps;
+    auto lap = [&](const char* name) { const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - tEntry).count(); char b[96]; snprintf(b, sizeof b, "%s %.1f ms, ", name, (t - lapLast) * 1e3); laps += b; lapLast = t; };
     const int64_t N = h_chr_offset[nchr];
     std::vector<double> cov((size_t)N);
     if (N > 0) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(cov.data(), d_cov, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t i = 0; i < N; i++) if (!std::isfinite(cov[i])) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_cbs: non-finite coverage (CBSRunner.cs:63-89 filter) is not built");
+    lap("coverage to the host");
     // sequential stopping boundary (GetBoundary.cs), cached per (nperm, alpha)
     static std::mutex bmu; static std::vector<uint32_t> sb; static uint32_t sbN = 0; static double sbA = 0;
     std::vector<uint32_t> sbdry;
@@ -3235,6 +3343,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     for (auto& m : moreServices) permServices.push_back(m.get());
     permServices.resize((size_t)nPermSvc);
     std::atomic_int nextService{0};
+    for (auto* sv : permServices) sv->rpSlabWant = cbs::perm_rp_scratch_bytes((size_t)std::min<long long>(nMax, 0x7FFFFFF0ll));
     std::mutex chromMu; double maxChromSec = 0, sumChromSec = 0, slowSec = 0; std::string slowLine; const bool timing = cvx_hook("CANVAS_CBS_TIMING") != nullptr;
     // helper threads for the deterministic front half of every segment on a recursion stack (cbs::SpecPool); CANVAS_CBS_NO_SPECULATION=1: the plain sequential order (test hook)
     std::unique_ptr<cbs::SpecPool> specPool;
@@ -3242,7 +3351,9 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     const int nthreads = (int)std::min<unsigned>(hw, (unsigned)nchr);
     const int nHelpers = cvx_hook("CANVAS_CBS_NO_SPECULATION") ? 0 : (int)std::min<unsigned>(32u, std::max(4u, std::thread::hardware_concurrency() / 4));
     // one device slab, one pinned slab and the shared tail streams for every engine this call is about to create (chromosome threads + helpers): cbs::EngineCache
+    lap("launchers");
     if (!cvx_hook("CANVAS_CBS_NO_ARENA")) cbs::EngineCache::of(ctx).reserve(ctx, nthreads + nHelpers, nthreads + nHelpers, (int)std::min<long long>(nMax, 0x7FFFFFF0ll));
+    lap("arena");
     if (nHelpers) { specPool.reset(new cbs::SpecPool{ctx, arcServices, nArcSvc, nperm, alpha, &st}); specPool->reserveN = (int)nMax; specPool->start(nHelpers); }
     size_t perEngineBudget = ~size_t(0);
     { size_t freeB = 0, totB = 0; if (hipMemGetInfo(&freeB, &totB) == hipSuccess) perEngineBudget = (freeB / 2) / (size_t)std::max(1, nthreads); }
@@ -3280,9 +3391,12 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
             if (rcs[c] == 0 && undo == 1 && segs[c].size() > 1) rcs[c] = cbs::prune(cov.data() + h_chr_offset[c], n, segs[c], 0.05, errs[c]);   // undoPrune = 0.05 (CBSRunner.cs:42)
         }
     };
+    lap("helpers + draw streams asked for");
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; t++) th.emplace_back(work);
     for (auto& t : th) t.join();
+    lap("chromosome threads");
+    if (timing) fprintf(stderr, "cbs call phases: %s\n", laps.c_str());
     for (int c = 0; c < nchr; c++) if (rcs[c]) { if (!errs[c].empty()) ctx->err = errs[c]; return rcs[c]; }
     ctx->cbs_tpermp[0] = st.tpermp_device; ctx->cbs_tpermp[1] = st.tpermp_draws;
     ctx->cbs_dev[0] = st.dev_perms; ctx->cbs_dev[1] = st.perms - st.dev_perms; ctx->cbs_dev[2] = st.exact_rechecks; ctx->cbs_dev[3] = st.dev_batches; ctx->cbs_dev[4] = st.verified; ctx->cbs_dev[5] = st.violations;
@@ -3294,6 +3408,8 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     }
     if (timing && mts) fprintf(stderr, "cbs draw streams: %lld words read out of the cache, %lld generated inside batches (no stream / bound reached), %lld generated by the cache's producer in this call, %lld states fetched for host code; %.2f GB mapped, %lld words held\n",
                                ctx->cbs_cache_stats[0], ctx->cbs_cache_stats[1], ctx->cbs_cache_stats[2], ctx->cbs_cache_stats[3], ctx->cbs_cache_stats[4] / 1e9, ctx->cbs_cache_stats[5]);
+    if (timing && mts) fprintf(stderr, "cbs draw streams (since the context was created): producer %lld rounds, %.3f s mapping memory, %.3f s generating; batches waited for the producer %lld times, %.3f thread-seconds\n",
+                               (long long)mts->rounds, mts->nsMap * 1e-9, mts->nsGen * 1e-9, (long long)mts->waits, mts->nsWaited * 1e-9);
     if (timing) fprintf(stderr, "cbs allocation / stream creation, thread-seconds: arc engines %.3f, permutation engines %.3f, tail engines %.3f, launchers %.3f\n", cbs::g_ns_alloc_arc.exchange(0) * 1e-9, cbs::g_ns_alloc_perm.exchange(0) * 1e-9, cbs::g_ns_alloc_tail.exchange(0) * 1e-9, cbs::g_ns_alloc_svc.exchange(0) * 1e-9);
     if (timing) fprintf(stderr, "cbs %s\n", slowLine.c_str());
     if (timing) fprintf(stderr, "cbs arc searches whose best admissible arc the reference does not scan (replayed on the host): %lld\n", (long long)st.unscanned_max.load());
