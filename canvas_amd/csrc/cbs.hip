@@ -3254,9 +3254,29 @@ extern "C" int32_t canvas_cbs_prefetch(canvas_ctx* ctx, int32_t nchr, int64_t wo
     for (int c = 0; c < nchr; c++) mts->prefetch(mts->get((uint32_t)seeds[(size_t)c]), words_per_chromosome);
     return CANVAS_OK;
 }
+// diagnostic / test entry: nwords draws of the chromosome-th stream from `position` on, out of the context's cache (generated now if they are not there yet)
+extern "C" int32_t canvas_cbs_stream_read(canvas_ctx* ctx, int32_t chromosome, int64_t position, int64_t nwords, uint32_t* h_out) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (chromosome < 0 || chromosome > 100000 || position < 0 || nwords < 0 || (nwords > 0 && !h_out)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs_stream_read: bad arguments");
+    if (nwords == 0) return CANVAS_OK;
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    cbs::MtStreamCache* mts = cvx_hook("CANVAS_CBS_NO_STREAM_CACHE") ? nullptr : cbs::EngineCache::of(ctx).streams(ctx);
+    if (!mts) CANVAS_FAIL(ctx, CANVAS_ERR_UNSUPPORTED, "canvas_cbs_stream_read: the draw-stream cache is switched off (CANVAS_CBS_CACHE_GB=0)");
+    std::vector<int32_t> seeds((size_t)chromosome + 1);
+    cbs_chromosome_seeds(chromosome + 1, seeds.data());
+    cbs::MtStream* S = mts->get((uint32_t)seeds[(size_t)chromosome]);
+    if (!S || !mts->acquire(S, position + nwords, 0)) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, "canvas_cbs_stream_read: the cache cannot hold the stream up to that position (CANVAS_CBS_CACHE_GB bounds it)" + (mts->err.empty() ? std::string() : ": " + mts->err));
+    CANVAS_HIP_TRY(ctx, hipMemcpy(h_out, S->d() + position, (size_t)nwords * 4, hipMemcpyDeviceToHost));
+    return CANVAS_OK;
+}
 extern "C" int32_t canvas_cbs_cache_stats(canvas_ctx* ctx, int64_t* h_out6) {
     if (!ctx || !h_out6) return CANVAS_ERR_INVALID;
     for (int i = 0; i < 6; i++) h_out6[i] = ctx->cbs_cache_stats[i];
+    if (ctx->cbs_cache) {      // what the cache holds NOW (the first four are the last canvas_cbs call's)
+        cbs::EngineCache& ec = cbs::EngineCache::of(ctx);
+        std::lock_guard<std::mutex> lk(ec.mu);
+        if (ec.mts && !ec.mts->off) { std::lock_guard<std::mutex> lk2(ec.mts->mu); h_out6[4] = (int64_t)ec.mts->usedBytes; long long rdy = 0; for (auto& kv : ec.mts->streams) rdy += kv.second->ready; h_out6[5] = rdy; }
+    }
     return CANVAS_OK;
 }
 extern "C" int32_t canvas_cbs_tailp_stats(canvas_ctx* ctx, int64_t* h_out2) {

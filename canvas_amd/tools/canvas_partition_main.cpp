@@ -124,6 +124,10 @@ int main(int argc, char** argv) {
     Phases ph("CanvasPartition");
     // the context comes up while the files are read; for -m CBS the helper thread also runs the method once on a toy sample (three chromosomes of 4 000 bins with a step)
     auto warmCbs = [cbsAlpha, undo](canvas_ctx* c) {
+        // the chromosomes' draw streams are constants of the method (MersenneTwister(seed_k), seed_k from MersenneTwister(0) in file order, CBSRunner.cs:107-112): the library's
+        // generator starts on them NOW, on its own thread and stream, while this process is still parsing its input (25 streams: a human reference's chromosomes; a file with more
+        // gets the others when canvas_cbs asks for them)
+        (void)canvas_cbs_prefetch(c, 25, int64_t(16) << 20);
         const int nchr = 3; const int64_t per = 4000, N = nchr * per;
         std::vector<double> cov((size_t)N); std::vector<int64_t> off{0, per, 2 * per, 3 * per};
         uint32_t x = 12345u;

@@ -300,6 +300,9 @@ int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h_out, int64
  * needs itself.  canvas_cbs_cache_stats: h_out6 = {draws the last canvas_cbs call read out of the cache, draws it generated inside its batches (cache off / bound reached),
  * draws the cache's generator produced during the call, generator states fetched for host code, bytes of device memory the cache holds, draws it holds}. */
 int32_t canvas_cbs_prefetch(canvas_ctx* ctx, int32_t nchr, int64_t words_per_chromosome);
+/* Diagnostic / test entry: nwords tempered outputs of the chromosome-th generator (0-based, file order) from output number `position` on, read out of the context's cache
+ * (generated now if they are not there yet; CANVAS_ERR_CAPACITY when the bound of the cache does not reach that far).  What canvas_cbs's permutation kernels read. */
+int32_t canvas_cbs_stream_read(canvas_ctx* ctx, int32_t chromosome, int64_t position, int64_t nwords, uint32_t* h_out);
 int32_t canvas_cbs_cache_stats(canvas_ctx* ctx, int64_t* h_out6);
 /* Host-only (no context, no GPU): the seeds of the per-chromosome generators canvas_cbs uses, in file order — new MersenneTwister(0) followed by one NextFullRangeInt32() per
  * chromosome (CBSRunner.cs:107-112).  h_out[nchr]; h_variant (optional): which reading of MathNet's NextBytes is in force (0 / 1 / 2, include/canvas_mathnet.h: the one
