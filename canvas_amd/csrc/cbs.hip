@@ -2023,7 +2023,8 @@ static size_t rp_scratch_bytes(int n, int wgs) { PermReq::RpPlan P; rp_plan(n, P
 // used — a 60x germline sample reads 1.6 GB of draws, an 80x / 40x tumour-normal pair 46 GB), and a stream that reaches the bound serves what it holds and hands the rest of
 // the loop to the in-batch generator (the path of rounds 1-5, kept as the fallback).
 #define MTS_GRANULE (size_t(64) << 20)          // physical memory is mapped into a stream in pieces of this size (16 M draws)
-#define MTS_VA_BYTES (size_t(64) << 30)         // address range of a stream: 16 G draws
+#define MTS_VA_BYTES (size_t(16) << 30)         // address range of a stream: 4 G draws (the longest chromosome of the 80x / 40x tumour-normal pair reads 2 G; a stream that
+                                                // reaches the end of its range serves what it holds).  (64 GB each: the kernel took 0.3 s longer to take a process with 25 of them apart)
 #define MTS_FIRST_WORDS (8LL << 20)             // the first extension of a stream (it must leave MT_HISTORY words behind for the strided generator to continue from)
 #define MTS_JOB_MAX_WORDS (48LL << 20)          // ... and the longest one: a round of the producer serves every stream that is behind and publishes when its LONGEST job is done —
                                                 // short rounds (~1 ms) keep a stream that needs little from waiting behind one that needs much
@@ -2406,10 +2407,13 @@ struct PermService {
         auto al256 = [](size_t v) { return (v + 255) & ~size_t(255); };
         { size_t want = 0; for (int i = 0; i < R; i++) if (batch[i]->r.fy == 3 && !batch[i]->r.rpScratch) want += al256((size_t)batch[i]->r.rp.stride * 4 * (size_t)std::max(1, batch[i]->r.rpWGs));
           if (want) {
-              if (!res->rpSlab || res->rpSlabBytes < std::min<size_t>(want, std::max<size_t>(rpSlabWant, size_t(64) << 20))) {
+              if (!res->rpSlab || res->rpSlabBytes < std::min<size_t>(want, std::max<size_t>(rpSlabWant, size_t(64) << 20))) {      // (too small for this launch and allowed to grow)
                   AllocClock ac(g_ns_alloc_perm);
                   if (res->rpSlab) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(stream)); CANVAS_HIP_TRY(ctx, hipFree(res->rpSlab)); res->rpSlab = nullptr; res->rpSlabBytes = 0; }
-                  size_t bytes = std::max<size_t>(std::max<size_t>(rpSlabWant, size_t(64) << 20), 0);
+                  // as large as this launch wants (a power of two from 64 MB), never beyond rpSlabWant: a germline call whose loops are short never allocates the 2 GiB a
+                  // tumour / normal call grows to (allocation and, at the end of a one-shot process, release of 4 x 2 GiB were 0.1 s of CanvasPartition -m CBS)
+                  size_t bytes = size_t(64) << 20; while (bytes < want && bytes < std::max<size_t>(rpSlabWant, size_t(64) << 20)) bytes <<= 1;
+                  bytes = std::min(bytes, std::max<size_t>(rpSlabWant, size_t(64) << 20));
                   for (int i = 0; i < R; i++) if (batch[i]->r.fy == 3 && !batch[i]->r.rpScratch) bytes = std::max(bytes, al256((size_t)batch[i]->r.rp.stride * 4) + 256);      // at least one workgroup of the longest plan
                   CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->rpSlab, bytes)); res->rpSlabBytes = bytes;
               }
