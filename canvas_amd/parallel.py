@@ -443,7 +443,9 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
                              "owner_of_chromosome": [int(x) for x in owner], "scale": args.scale, "rate": args.rate},
                   "roofline": rank0_roofline,
                   "sharded": {"collectives_per_pass": int(round(k_ag / max(1, args.steps))), "collectives_ms_per_pass_rank0": round(ms_ag / max(1, args.steps), 4),
-                              "clean_ms_per_pass_rank0": round(ms_cl / max(1, k_cl), 4), "chromosomes_owned_rank0": int(st[1]), "bins_binned_rank0": int(st[2]), "bins_allgather_bytes_per_rank": int(st[3]), "boundary_records_rank0": int(st[4]),
+                              "clean_ms_per_pass_rank0": round(ms_cl / max(1, k_cl), 4), "collective_ms": round(ms_ag / max(1, args.steps), 4), "redundant_clean_ms": round(ms_cl / max(1, k_cl), 4),
+                              "explains": "a pass cannot drop below redundant_clean_ms (CanvasClean's order statistics are genome-wide: every rank runs it on all bins) + collective_ms (rate table, bins, segment boundaries); "
+                                          "what shards is the sweep (k_tile_summary over the owned chromosomes) and the Viterbi passes", "chromosomes_owned_rank0": int(st[1]), "bins_binned_rank0": int(st[2]), "bins_allgather_bytes_per_rank": int(st[3]), "boundary_records_rank0": int(st[4]),
                               "boundary_allgather_bytes_per_rank": int(st[5]), "identical_on_all_ranks": same_on_all_ranks, "equals_single_gpu_result": equals_single,
                               "note": "CanvasClean runs redundantly on every rank (its order statistics are genome-wide): the pass cannot drop below Clean + the collectives"},
                   "cohort_mode": cohort}
@@ -466,8 +468,10 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
         for name, call, single_call in (("cbs", lambda: cv.cbs_sharded(owner, cov, off, 0.01, 10000), lambda: cv.cbs(cov, off, 0.01, 10000)),
                                         ("wavelets", lambda: cv.wavelets_sharded(owner, cov, off), lambda: cv.wavelets(cov, off))):
             call(); barrier()
+            cv.profile_get("allgather", reset=True)
             t0 = time.perf_counter(); got = call(); barrier()
             sec = max_over_ranks(time.perf_counter() - t0, device)
+            ms_coll, k_coll = cv.profile_get("allgather")      # hipEvents around every collective of the call, on the library's stream (rank 0's view)
             if name == "cbs":
                 flat = got[0][:n].to(torch.int64); dig = torch.stack([flat.sum(), (flat * (torch.arange(n, device=device) % 1009)).sum(), torch.tensor(int(got[1].sum()), device=device)])
             else:
@@ -482,7 +486,8 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
                     eq = bool((one[0][:n] == got[0][:n]).all() and (one[1] == got[1]).all())
                 else:
                     eq = bool(len(one) == len(got) and all(np.array_equal(a, b) for a, b in zip(one, got)))
-            part[name] = {"seconds": round(sec, 4), "single_gpu_seconds_rank0": None if sec1 is None else round(sec1, 4), "identical_on_all_ranks": same, "equals_single_gpu_result": eq}
+            part[name] = {"seconds": round(sec, 4), "single_gpu_seconds_rank0": None if sec1 is None else round(sec1, 4), "collectives": int(k_coll), "collective_ms": round(ms_coll, 4),
+                          "identical_on_all_ranks": same, "equals_single_gpu_result": eq}
             barrier()
     except Exception as e:                                        # noqa: BLE001
         part["error"] = "%s: %s" % (type(e).__name__, e)
@@ -506,10 +511,12 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             torch.cuda.synchronize()
             pedigree_sample_flow(cv, rb, rm, my_hits, lens, is_auto, flags)                 # warm
             barrier()
+            cv.profile_get("allgather", reset=True)
             t0 = time.perf_counter()
             pr = pedigree_sample_flow(cv, rb, rm, my_hits, lens, is_auto, flags)
             barrier()
             psec = max_over_ranks(time.perf_counter() - t0, device)
+            ms_coll_p, k_coll_p = cv.profile_get("allgather")
             k = pr["n"]
             dig = torch.stack([pr["start"].to(torch.int64).sum(), pr["stop"].to(torch.int64).sum(), (pr["chr"].to(torch.int64) * (torch.arange(k, device=device) % 1009)).sum(),
                                torch.tensor(k, device=device), torch.tensor(int(pr["bin_size"]), device=device)])
@@ -541,7 +548,7 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
                 eq = bool(all(checks.values()))
                 ped_mismatch = [name for name, ok in checks.items() if not ok] + ([] if k1 == k else ["merged %d vs %d" % (k1, k)])
                 del allh, outs1
-            ped = {"samples": world, "seconds": round(psec, 4), "bins_per_s": round(float(sum(int(b.item()) for b in binned)) / psec, 1), "scaling": "weak", "bin_size": int(pr["bin_size"]),
+            ped = {"samples": world, "seconds": round(psec, 4), "collectives": int(k_coll_p), "collective_ms": round(ms_coll_p, 4), "bins_per_s": round(float(sum(int(b.item()) for b in binned)) / psec, 1), "scaling": "weak", "bin_size": int(pr["bin_size"]),
                    "bins_common_to_all": int(k), "identical_on_all_ranks": same, "equals_single_gpu_flow_rank0": eq, "differs_in": (ped_mismatch if rank == 0 and not eq else None), "single_gpu_seconds_incl_generating_the_other_samples_rank0": None if sec1 is None else round(sec1, 3),
                    "note": "one sample per rank over one reference: rates all-gather -> one bin size, CanvasBin + CanvasClean local, canvas_merge_cleaned_sharded (12 B per bin per rank), F2 + PerSampleHMM local"}
             barrier()
@@ -652,8 +659,10 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
             torch.cuda.synchronize()
             call = lambda: cv.tumor_normal_flow(bb, mm, ht, fl, hn, lens, is_auto, flags, 0.01, 10000, owner=owner, keep=True)
             call(); barrier()
+            cv.profile_get("allgather", reset=True)
             t0 = time.perf_counter(); sr = call(); barrier()
             ssec = max_over_ranks(time.perf_counter() - t0, device)
+            ms_coll_s, k_coll_s = cv.profile_get("allgather")
             nc = int(sr["n_clean"])
             dig = torch.stack([sr["cov"][:nc].sum().to(torch.float64), sr["seg_len"].to(torch.float64).sum(), torch.tensor(float(nc), device=device, dtype=torch.float64),
                                torch.tensor(float(sr["bin_size"]), device=device, dtype=torch.float64), torch.tensor(float(int(sr["nseg"].sum())), device=device, dtype=torch.float64)])
@@ -668,7 +677,8 @@ def bench_sharded(args, cv, rank, world, device, hbm_peak_gbs):
                 eq = bool(one["bin_size"] == sr["bin_size"] and int(one["n_clean"]) == nc and (one["cov"][:nc] == sr["cov"][:nc]).all() and (np.asarray(one["nseg"]) == np.asarray(sr["nseg"])).all()
                           and (one["seg_len"] == sr["seg_len"]).all())
                 del ht1, fl1, hn1
-            som = {"seconds": round(ssec, 4), "single_gpu_seconds_rank0": None if sec1 is None else round(sec1, 4), "scaling": "strong", "bins": int(sr["n_bins"]), "bins_after_clean": nc,
+            som = {"seconds": round(ssec, 4), "single_gpu_seconds_rank0": None if sec1 is None else round(sec1, 4), "collectives": int(k_coll_s), "collective_ms": round(ms_coll_s, 4),
+                   "redundant_clean_ms": (round(sr["stage_seconds"].get("clean", 0.0) * 1e3, 4) if isinstance(sr.get("stage_seconds"), dict) else None), "scaling": "strong", "bins": int(sr["n_bins"]), "bins_after_clean": nc,
                    "segments": int(sr["nseg"].sum()), "stage_seconds_rank0": sr["stage_seconds"] if rank == 0 else None, "identical_on_all_ranks": same, "equals_single_gpu_flow_rank0": eq,
                    "note": "one tumour / normal pair, chromosomes sharded: tumour bins -m GCContentWeighted (two small reductions + rate table + bin all-gather) and the normal's bins "
                            "through canvas_bin_sample_sharded, ratio + CanvasClean redundant, canvas_cbs_sharded"}

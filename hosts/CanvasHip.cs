@@ -71,6 +71,10 @@ namespace CanvasHipInterop
             double madFactor, int variabilityWindow, int minSize, int[] breakpoints, long cap, long[] bpOffset);
         [DllImport(Lib)] public static extern int canvas_cbs_undo(IntPtr ctx, int nchr, IntPtr dCov, long[] chrOffset, double alpha, uint nperm, int undo, double undoSd,
             IntPtr dSegLen, int[] nseg, long[] stats8);
+        // the draw streams of CBS are constants of the method (CBSRunner.cs:107-112): started while CanvasSegment.ReadBedInput is still parsing (CanvasPartitionHipMain.Main)
+        [DllImport(Lib)] public static extern int canvas_cbs_prefetch(IntPtr ctx, int nchr, long wordsPerChromosome);
+        [DllImport(Lib)] public static extern int canvas_cbs_cache_stats(IntPtr ctx, long[] out6);
+        [DllImport(Lib)] public static extern int canvas_cbs_seeds(int nchr, int[] seeds, out int mathNetByteVariant);    // to settle include/canvas_mathnet.h: compare seeds[0] with new MersenneTwister(0).NextFullRangeInt32()
         [DllImport(Lib)] public static extern int canvas_hmm_per_sample(IntPtr ctx, int nchr, IntPtr dCov, long[] chrOffset, IntPtr dState);
         [DllImport(Lib)] public static extern int canvas_hmm_joint(IntPtr ctx, int nsamples, int nchr, IntPtr[] dCovPerSample, long[] chrOffset, IntPtr dState);
         [DllImport(Lib)] public static extern int canvas_segment_ids_ploidy(IntPtr ctx, int nchr, long[] chrOffset, IntPtr dState, IntPtr dStart, IntPtr dStop, int maxInterBinDist,

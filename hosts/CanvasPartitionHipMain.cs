@@ -111,7 +111,9 @@ namespace CanvasPartition
         }
         // In Main's switch (:116-183) the four `new XRunner(...).Run(...)` calls become HipPartition.Wavelets / Cbs / Hmm with one context
         // (`IntPtr ctx = canvas_create(0)`, failure -> message + return 1); `referencePloidy`, SplitOverlappingSegments and PostProcessAndWriteResults
-        // (:114, :138-143, :185-189) stay as they are.  A host that keeps the bins on the device can let the library number the segments as well:
+        // (:114, :138-143, :185-189) stay as they are.  With `-m CBS` the context is created BEFORE the inputs are read (:102-112) and `canvas_cbs_prefetch(ctx, 25, 16 << 20)`
+        // follows it at once: the per-chromosome MersenneTwister streams (CBSRunner.cs:107-112) are constants, and the library generates them on its own thread while
+        // CanvasSegment.ReadBedInput parses the .cleaned files.  A host that keeps the bins on the device can let the library number the segments as well:
         // canvas_segment_ids_ploidy takes the -b intervals and the -p records and returns the id column of the .partitioned file.
     }
 }
