@@ -1782,8 +1782,14 @@ struct ArcGpu {       // one per chromosome thread: own buffers; the launches go
     // CanvasPartition -m CBS executable; the pruned search needs the prefix sums and a few result words)
     int pinCap = 0;               // bins the pinned staging buffer holds: it grows with the segments THIS engine meets (pinning host memory costs ~1.4 ms per MB — sizing all
                                   // fifty-six buffers for the longest chromosome, 213 MB, was 0.3 s of a cold call; the device side is sized for the longest chromosome at once)
+    char* pinSmall = nullptr; bool pinSmallOwned = false;      // the result mailbox (256 bytes) when the prefix sums travel from the caller's pageable array (one-shot hosts)
+    bool pageable() const { return ctx->one_shot != 0; }
     int32_t ensure(int n) {
-        if (n <= cap && n <= pinCap) return CANVAS_OK;
+        if (pageable() && !pinSmall) {
+            pinSmall = cache_take(cache, true, 256);
+            if (!pinSmall) { CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pinSmall, 256, hipHostMallocDefault)); pinSmallOwned = true; }
+        }
+        if (n <= cap && (pageable() || n <= pinCap)) return CANVAS_OK;
         AllocClock ac(g_ns_alloc_arc);
         if (n > cap) {
             if (dSx && owned) { (void)hipFree(dSx); (void)hipFree(dPr); }
@@ -1795,7 +1801,7 @@ struct ArcGpu {       // one per chromosome thread: own buffers; the launches go
             if (d) { dPr = d; dSx = (double*)(d + ((prBytes + 255) & ~size_t(255))); owned = false; }
             else { owned = true; CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dPr, prBytes)); CANVAS_HIP_TRY(ctx, hipMalloc((void**)&dSx, sxBytes)); }
         }
-        if (n > pinCap) {
+        if (n > pinCap && !pageable()) {
             if (pin) (void)hipHostFree(pin);
             pin = nullptr; pinCap = n + n / 4 + 1024;
             pinBytes = (size_t)pinCap * 8 + 256; CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&pin, pinBytes, hipHostMallocDefault));
@@ -1812,7 +1818,7 @@ struct ArcGpu {       // one per chromosome thread: own buffers; the launches go
         capEx = cap;
         return CANVAS_OK;
     }
-    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx && owned) { (void)hipFree(dSx); (void)hipFree(dPr); } if (pin) (void)hipHostFree(pin);
+    ~ArcGpu() { if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } if (dSx && owned) { (void)hipFree(dSx); (void)hipFree(dPr); } if (pin) (void)hipHostFree(pin); if (pinSmall && pinSmallOwned) (void)hipHostFree(pinSmall);
                 if (dMax) { (void)hipFree(dMax); (void)hipFree(dFirst); (void)hipHostFree(pinEx); } }
 };
 
@@ -1829,7 +1835,11 @@ static int32_t tmaxo_gpu(ArcGpu& G, const double* x, int n, double tss, double* 
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int32_t rc = G.ensure(n); if (rc) return rc;
     double* hSx = (double*)G.pin; double* hMax = nullptr; int32_t* hFirst = nullptr; unsigned long long* hOut = (unsigned long long*)(G.pin + (size_t)G.pinCap * 8);
-    memcpy(hSx, sx, (size_t)n * 8);      // (from pageable memory instead — no pinned staging buffers, 0.77 thread-seconds of a cold call — was measured: first call 0.17 against 0.18 s, warm 0.056 against 0.046: not kept)
+    // a host that makes ONE call and exits (canvas_set_one_shot: the CanvasPartition executable) uploads the prefix sums from the caller's pageable array: the pinned staging
+    // buffers of fifty engines are ~100 MB that such a process pins at 1.4 ms per MB and unpins again when it leaves; a host that keeps its context (warm calls: 0.046 against
+    // 0.056 s for the germline sample) keeps the staging buffers
+    if (G.pageable()) { hSx = sx; hOut = (unsigned long long*)G.pinSmall; }
+    else memcpy(hSx, sx, (size_t)n * 8);
     const size_t nbk = (size_t)G.cap / AP_BK + 2;
     ArcHostReq q; q.hSx = hSx; q.hMax = hMax; q.hFirst = hFirst; q.hOut = hOut;
     q.r.sx = G.dSx; q.r.n = n; q.r.dmax = G.dMax; q.r.firstI = G.dFirst;
@@ -2031,6 +2041,7 @@ static size_t rp_scratch_bytes(int n, int wgs) { PermReq::RpPlan P; rp_plan(n, P
 struct MtStream {
     uint32_t seed = 0; char* va = nullptr; size_t mappedBytes = 0; bool plain = false; size_t plainBytes = 0; std::vector<hipMemGenericAllocationHandle_t> handles;
     long long ready = 0, requested = 0; bool full = false;      // words that are valid / that the producer has been asked for; full: no more memory will be mapped
+    long long floorWords = 0;                                   // what canvas_cbs_prefetch / the start of a call asked for: the end of a call does not take THAT back
     uint32_t* d() const { return (uint32_t*)va; }
 };
 struct MtStreamCache {
@@ -2080,7 +2091,7 @@ struct MtStreamCache {
             else S->va = (char*)base;
         }
         if (!useVmm) {          // no virtual memory management: one fixed allotment per stream (1 / 32 of the bound), served until it is full
-            S->plain = true; S->plainBytes = std::max<size_t>(MTS_GRANULE, (capBytes / 32) & ~(MTS_GRANULE - 1));
+            S->plain = true; S->plainBytes = std::max<size_t>(MTS_GRANULE, std::min<size_t>(size_t(512) << 20, capBytes / 32) & ~(MTS_GRANULE - 1));      // (at most 512 MB each: allocating 25 x 2.9 GB took 2 s)
             if (usedBytes + S->plainBytes > capBytes || hipMalloc((void**)&S->va, S->plainBytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
             S->mappedBytes = S->plainBytes; usedBytes += S->plainBytes;
         }
@@ -2092,6 +2103,7 @@ struct MtStreamCache {
         if (!S) return;
         { std::lock_guard<std::mutex> lk(mu);
           upto = std::max(upto, MTS_FIRST_WORDS);
+          S->floorWords = std::max(S->floorWords, upto);
           if (S->full || failed || upto <= S->requested) return;
           S->requested = upto; ensure_thread(); }
         cvWork.notify_one();
@@ -2113,6 +2125,14 @@ struct MtStreamCache {
         return S->ready >= end;
     }
     void ensure_thread() { if (!started) { started = true; th = std::thread([this]() { run(); }); } }      // (mu held)
+    // the end of a call: what was asked for ahead of the permutation loops and has not been generated yet is not needed any more, and nothing of the cache's is left running
+    // on the device when the call returns (a one-shot process that exits with a generator launch in flight pays for it in the driver's teardown: 0.1-0.3 s)
+    bool busy = false;
+    void quiesce() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (auto& kv : streams) if (kv.second->requested > kv.second->ready) kv.second->requested = std::max(kv.second->ready, std::min(kv.second->requested, kv.second->floorWords));
+        cvReady.wait(lk, [&]() { return !busy || stop || failed; });
+    }
     // physical memory behind [0, words) of a stream; returns the words that are backed
     long long back(MtStream& S, long long words) {
         const size_t need = ((size_t)words * 4 + MTS_GRANULE - 1) & ~(MTS_GRANULE - 1);
@@ -2143,7 +2163,8 @@ struct MtStreamCache {
             { std::unique_lock<std::mutex> lk(mu);
               cvWork.wait(lk, [&]() { if (stop) return true; for (auto& kv : streams) if (!kv.second->full && kv.second->requested > kv.second->ready) return true; return false; });
               if (stop) return;
-              for (auto& kv : streams) { MtStream& S = *kv.second; if (!S.full && S.requested > S.ready && (int)jobs.size() < CAP) jobs.push_back({&S, S.ready, std::min(S.requested, S.ready + MTS_JOB_MAX_WORDS)}); } }
+              for (auto& kv : streams) { MtStream& S = *kv.second; if (!S.full && S.requested > S.ready && (int)jobs.size() < CAP) jobs.push_back({&S, S.ready, std::min(S.requested, S.ready + MTS_JOB_MAX_WORDS)}); }
+              busy = true; }
             std::vector<char> shortJob(jobs.size(), 0);
             int R = 0; bool anyFresh = false; long long maxFresh = 0, maxTotal = 0;
             const auto tM = std::chrono::steady_clock::now();
@@ -2175,7 +2196,8 @@ struct MtStreamCache {
             nsGen += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tG).count();
             { std::lock_guard<std::mutex> lk(mu);
               if (!ok) { (void)hipGetLastError(); failed = true; err = "the draw-stream cache's generator failed"; }
-              else for (size_t i = 0; i < jobs.size(); i++) { MtStream& S = *jobs[i].S; if (jobs[i].to > S.ready) { generatedWords += jobs[i].to - S.ready; S.ready = jobs[i].to; } if (shortJob[i]) S.full = true; } }
+              else for (size_t i = 0; i < jobs.size(); i++) { MtStream& S = *jobs[i].S; if (jobs[i].to > S.ready) { generatedWords += jobs[i].to - S.ready; S.ready = jobs[i].to; } if (shortJob[i]) S.full = true; }
+              busy = false; }
             cvReady.notify_all();
             if (!ok) return;
         }
@@ -2431,7 +2453,7 @@ struct PermService {
         for (int i = 0; i < R; i++) {
             batch[i]->r.rpBase = rpBlocks; if (batch[i]->r.fy == 3) rpBlocks += batch[i]->r.rpWGs; else batch[i]->r.rpWGs = 0;
             batch[i]->r.blockBase = blocks; blocks += batch[i]->r.nb; hReqs[i] = batch[i]->r; if (batch[i]->r.fy != 2 && !batch[i]->r.cached) maxTotal = std::max(maxTotal, batch[i]->r.total + (batch[i]->r.cont ? MT_HISTORY : 0));
-            if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // pinned source
+            if (batch[i]->xBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->dX, batch[i]->hX, batch[i]->xBytes, hipMemcpyHostToDevice, stream));     // (the caller's array: it stays valid until the launch has been waited for)
             if (batch[i]->drawBytes) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(batch[i]->r.P.draws, batch[i]->hDraws, batch[i]->drawBytes, hipMemcpyHostToDevice, stream));
         }
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dReqs, hReqs, R * sizeof(PermReq), hipMemcpyHostToDevice, stream));
@@ -2529,7 +2551,7 @@ static void perm_reserve_bytes(size_t nMax, bool withDraws, size_t& dev, size_t&
         const size_t re = (size_t)std::min<long long>((long long)256 * (long long)nMax, std::max<long long>(PERM_TARGET_ELEMS, 8LL * (long long)nMax));
         dev = std::max(dev, head + (withDraws ? 2 * al256((re + (size_t)MT_HISTORY) * 4) : 0) + 5 * al256(re * 4) + 2 * al256((re + 256) * 4) + 2 * al256(re * 8));
     }
-    pin = al256(nMax * 8) + al256((size_t)PERM_RP_MAXB * 625 * 4) + al256((size_t)PERM_RP_MAXB * 16) + 256;
+    pin = (withDraws ? al256((size_t)PERM_RP_MAXB * 625 * 4) : 0) + al256((size_t)PERM_RP_MAXB * 16) + 256 + al256((size_t)2048 * 16);      // (the last term: the small-segment loop's intervals)
 }
 
 // The sequential stopping rule of FindChangePoints (ChangePoint.cs:337-364) over permutations evaluated in device batches.
@@ -2545,7 +2567,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     auto now = []() { return std::chrono::steady_clock::now(); };
     uint32_t* dRpScratch = nullptr; int rpWGs = 0; PermReq::RpPlan rpP; memset(&rpP, 0, sizeof rpP);
     auto since = [](std::chrono::steady_clock::time_point t) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
-    double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; double* hX = nullptr; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
+    double* dX = nullptr; uint32_t* dSnaps = nullptr; double* dStat = nullptr; PermBuf P; uint32_t* hSnaps = nullptr; double* hStat = nullptr;
     uint32_t* draws2[2] = {nullptr, nullptr}; int drawBuf = 0;      // (own draws) the loop's batches alternate between two draw buffers
     bool haveDraws = false; volatile unsigned* hMail = nullptr;
     auto setup = [&](int mb, bool withDraws) -> int32_t {
@@ -2554,7 +2576,10 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         const size_t oX = 0, oState = oX + al((size_t)n * 8), oSnaps = oState + al(625 * 4), oStat = oSnaps + al((size_t)mb * 625 * 4), oDraws = oStat + al((size_t)mb * 16),
                      oJ = oDraws + drawsB, oOff = oJ + al(e * 4), oCur = oOff + al(e1 * 4), oItems = oCur + al(e1 * 4), oG = oItems + al(e * 4), oSucc = oG + al(e * 4),
                      oPx = oSucc + al(e * 4), oSx = oPx + al(e * 8), total = oSx + al(e * 8);
-        const size_t pX = 0, pSnaps = al((size_t)n * 8), pStat = pSnaps + al((size_t)mb * 625 * 4), pMail = pStat + al((size_t)mb * 16), pinTotal = pMail + 256;
+        // pinned: the generator states of a batch (own draws only), its intervals and the mailbox's sequence word.  The segment itself is uploaded from the caller's array, once
+        // per loop (pageable: ~0.4 ms for the longest chromosome, against a loop of milliseconds to seconds) — a pinned staging copy per engine was 3 MB x 24 engines, and with
+        // the states 132 MB that a one-shot process pinned at its start and unpinned at its exit (1.4 ms per MB each way)
+        const size_t pSnaps = 0, pStat = pSnaps + (withDraws ? al((size_t)mb * 625 * 4) : 0), pMail = pStat + al((size_t)mb * 16), pinTotal = pMail + 256;
         auto tE = now();
         // k_perm_rp: behind the draws the scratch of the persistent workgroups (results travel in streams: no per-element workspace)
         size_t totalRp = 0;
@@ -2571,15 +2596,14 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
         if (!useRp) {
         P.j = (int32_t*)(d + oJ); P.off = (int32_t*)(d + oOff); P.cur = (int32_t*)(d + oCur); P.items = (int32_t*)(d + oItems);
         P.g = (int32_t*)(d + oG); P.succ = (int32_t*)(d + oSucc); P.px = (double*)(d + oPx); P.sx = (double*)(d + oSx); }
-        hX = (double*)(h + pX); hSnaps = (uint32_t*)(h + pSnaps); hStat = (double*)(h + pStat); hMail = (volatile unsigned*)(h + pMail);
+        hSnaps = (uint32_t*)(h + pSnaps); hStat = (double*)(h + pStat); hMail = (volatile unsigned*)(h + pMail);
         haveDraws = withDraws;
         return CANVAS_OK;
     };
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     MtStreamCache* SC = rnd.cache; MtStream* S = rnd.S;
     int32_t rc = setup(maxB, S == nullptr); if (rc) return rc;
-    memcpy(hX, gd, (size_t)n * 8);            // uploaded by the launcher together with the first batch
-    bool needUpload = true;
+    bool needUpload = true;                   // the segment is uploaded by the launcher together with the first batch
     // worst-case rounding bound of a prefix-sum difference: both orders of summation are within gamma_n * sum|x| of the exact sum
     double absSum = 0.0; for (int i = 0; i < n; i++) absSum += std::fabs(gd[i]);
     const double errBound = 4.04 * (double)(n + 8) * 1.1102230246251565e-16 * absSum;
@@ -2602,13 +2626,13 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
             // own draws: the state at pos (a generator that was moved by position is rebuilt from the cache's words in front of it) and the two draw buffers (batches of
             // the size those buffers are reserved for)
             if (!haveCur) { MT m(0u); rc = rnd.at(PG, pos, m); if (rc) return rc; m.get_state(cur); haveCur = true; prevOwn = false; }
-            if (!haveDraws) { maxB = perm_max_batch(n, false); rc = setup(maxB, true); if (rc) return rc; memcpy(hX, gd, (size_t)n * 8); needUpload = true; }
+            if (!haveDraws) { maxB = perm_max_batch(n, false); rc = setup(maxB, true); if (rc) return rc; needUpload = true; }
             if (nb > maxB) { nb = maxB; need = (long long)nb * n; }
         }
         PermHostReq q;
         q.r.total = need; q.r.n = n; q.r.nb = nb; q.r.snaps = dSnaps; q.r.x = dX; q.r.hk = hk; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = errBound;
         q.r.P = P; q.r.pstat = dStat; q.r.blockBase = 0; q.hStat = hStat;
-        if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
+        if (needUpload) { q.hX = gd; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         if (cached) {
             memset(q.r.state, 0, sizeof q.r.state); q.r.cached = 1; q.r.cont = 0; q.r.hist = nullptr; q.hSnaps = nullptr; q.r.snaps = nullptr;
             q.r.P.draws = S->d() + pos;
@@ -2715,21 +2739,25 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
     const int maxB = 2048;
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t oX = 0, oStat = al((size_t)n * 8), oDraws = oStat + al((size_t)maxB * 16), total = oDraws + al(((size_t)maxB * n + (size_t)MT_HISTORY) * 4) + 256;
-    const size_t pX = 0, pStat = al((size_t)n * 8), pMail = pStat + al((size_t)maxB * 16), pDraws = pMail + 256, pinTotal = pDraws + al((size_t)maxB * n * 4);
-    size_t want = total, wantPin = pinTotal;
-    if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // never shrink below what perm_loop_gpu will ask for: one allocation per engine
-    int32_t rc = PG.ensure(want, wantPin, total); if (rc) return rc;
+    MtStreamCache* SC = rnd.cache; MtStream* S = rnd.S;
+    const size_t pStat = 0, pMail = pStat + al((size_t)maxB * 16), pDraws = pMail + 256;
+    double* dX = nullptr; double* dStat = nullptr; uint32_t* dDraws = nullptr; double* hStat = nullptr; uint32_t* hDraws = nullptr; volatile unsigned* hMail = nullptr; bool havePinDraws = false;
+    auto setup = [&](bool withDraws) -> int32_t {      // withDraws: the host generator's draws of a batch travel through pinned memory (no cache stream / its bound reached)
+        size_t want = total, wantPin = pDraws + (withDraws ? al((size_t)maxB * n * 4) : 0);
+        if (PG.reserveBytes) { want = std::max(want, PG.reserveBytes); wantPin = std::max(wantPin, PG.reservePin); }      // never shrink below what perm_loop_gpu will ask for: one allocation per engine
+        int32_t rc0 = PG.ensure(want, wantPin, total); if (rc0) return rc0;
+        char* d = PG.buf; char* h = PG.pin;
+        dX = (double*)(d + oX); dStat = (double*)(d + oStat); dDraws = (uint32_t*)(d + oDraws) + MT_HISTORY;
+        hStat = (double*)(h + pStat); hDraws = (uint32_t*)(h + pDraws); hMail = (volatile unsigned*)(h + pMail); havePinDraws = withDraws;
+        return CANVAS_OK;
+    };
     CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    char* d = PG.buf; char* h = PG.pin;
-    double* dX = (double*)(d + oX); double* dStat = (double*)(d + oStat); uint32_t* dDraws = (uint32_t*)(d + oDraws) + MT_HISTORY;
-    double* hX = (double*)(h + pX); double* hStat = (double*)(h + pStat); uint32_t* hDraws = (uint32_t*)(h + pDraws); volatile unsigned* hMail = (volatile unsigned*)(h + pMail);
-    memcpy(hX, gd, (size_t)n * 8);
+    int32_t rc = setup(S == nullptr); if (rc) return rc;
     bool needUpload = true;
     int nrej = 0; uint32_t np = 0;
     int B = 256;
     outcome = 1;
     std::vector<double> px, sx;
-    MtStreamCache* SC = rnd.cache; MtStream* S = rnd.S;
     long long pos = rnd.position();
     while (np < nPerm) {
         const int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);
@@ -2737,6 +2765,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
         const bool cached = S && SC->acquire(S, pos + need, std::max<long long>(2 * need, 16LL << 20));
         MT start(0u);
         if (!cached) {      // the batch's draws: nb * n outputs of the chromosome's generator, in order
+            if (!havePinDraws) { rc = setup(true); if (rc) return rc; needUpload = true; }
             MT* m = rnd.host(PG); if (!m) return CANVAS_ERR_HIP;
             start = *m;
             for (size_t t = 0; t < (size_t)need; t++) hDraws[t] = m->u32();
@@ -2746,7 +2775,7 @@ static int32_t perm_loop_small_gpu(PermGpu& PG, const double* gd, int n, double 
         memset(q.r.state, 0, sizeof q.r.state); q.r.total = need; q.r.n = n; q.r.nb = nb; q.r.snaps = nullptr; q.r.x = dX; q.r.hk = 0; q.r.al0 = al0; q.r.tss = tss; q.r.errBound = 0.0;
         memset(&q.r.P, 0, sizeof q.r.P); q.r.P.draws = cached ? S->d() + pos : dDraws; q.r.cached = cached ? 1 : 0; q.r.pstat = dStat; q.r.blockBase = 0; q.r.cont = 0; q.r.hist = nullptr; q.r.fy = 2; q.hStat = hStat; q.hSnaps = nullptr;
         q.r.rpBase = 0; q.r.rpWGs = 0; q.r.rpScratch = nullptr; q.r.rpClk = nullptr; memset(&q.r.rp, 0, sizeof q.r.rp);
-        if (needUpload) { q.hX = hX; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
+        if (needUpload) { q.hX = gd; q.dX = dX; q.xBytes = (size_t)n * 8; needUpload = false; }
         if (!cached) { q.hDraws = hDraws; q.drawBytes = (size_t)need * 4; }
         { unsigned sq_ = ++PG.mailSeq; if (sq_ == 0) sq_ = ++PG.mailSeq; q.r.mailStat = hStat; q.r.mailSeq = (unsigned*)hMail; q.r.seq = sq_; *hMail = 0u; std::atomic_thread_fence(std::memory_order_seq_cst); }
         auto tS = std::chrono::steady_clock::now();
@@ -2941,12 +2970,14 @@ struct EngineCache {
         // the shared tail streams: creating one takes ~5 ms on this runtime (sixteen: 77 of the 170 ms of a cold call) — two are made here, the others on a thread of their
         // own while the chromosome threads start (tail_stream() hands out what exists)
         while (newTail > 0 && tailStreams.size() < 2) { hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; } tailStreams.push_back(q); }
-        if (newTail > 0 && tailStreams.size() < 12 && !streamMaker.joinable()) {
+        // (a one-shot process pays ~5 ms per stream again when it leaves: four shared tail streams there, twelve for a host that keeps its context)
+        const size_t wantStreams = ctx->one_shot ? 4 : 12;
+        if (newTail > 0 && tailStreams.size() < wantStreams && !streamMaker.joinable()) {
             const int dev = ctx->device;
-            streamMaker = std::thread([this, dev]() {
+            streamMaker = std::thread([this, dev, wantStreams]() {
                 if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
                 for (;;) {
-                    { std::lock_guard<std::mutex> lk2(mu); if (tailStreams.size() >= 12 || dying) return; }
+                    { std::lock_guard<std::mutex> lk2(mu); if (tailStreams.size() >= wantStreams || dying) return; }
                     hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
                     std::lock_guard<std::mutex> lk2(mu); tailStreams.push_back(q);
                 }
@@ -3419,6 +3450,7 @@ int32_t cvx_cbs_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, const
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; t++) th.emplace_back(work);
     for (auto& t : th) t.join();
+    if (mts) mts->quiesce();
     lap("chromosome threads");
     if (timing) fprintf(stderr, "cbs call phases: %s\n", laps.c_str());
     for (int c = 0; c < nchr; c++) if (rcs[c]) { if (!errs[c].empty()) ctx->err = errs[c]; return rcs[c]; }

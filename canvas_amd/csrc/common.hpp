@@ -48,6 +48,7 @@ struct canvas_ctx {
     void* gc_arena = nullptr; size_t gc_arena_bytes = 0;   // GCContentWeighted binning: read-GC profile of every position + GC prefix array (grow-only)
     size_t clean_ws_end = 0;          // clean_fast.hpp: bytes of ctx->ws the last clean_batch_enqueue carved (what is enqueued behind it must not alias them: a second phase may follow)
     bool clean_cq_failed = false, clean_cq_skip = false;   // clean_fast.hpp: a sample's counting selects gave up (it is redone with the radix selects)
+    int one_shot = 0;                   // canvas_set_one_shot: the host makes one call per method and exits — staging through pinned host memory is not worth its pinning
     std::shared_ptr<void> cbs_cache;     // cbs.hip: device / pinned buffers of the arc-search and permutation engines, kept between calls (a call used to spend tens of ms in hipMalloc / hipHostMalloc)
     std::shared_ptr<void> hmm_pool;      // hmm.hip: helper threads that fill the negative-binomial emission tables of a sample
     void* cg_state = nullptr; unsigned cg_epoch = 0;     // clean_gc_only.hpp: tickets / genome row / chunk flags of the -g-only stage (zero between calls), call counter

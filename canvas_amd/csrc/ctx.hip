@@ -71,6 +71,11 @@ void canvas_destroy(canvas_ctx* ctx) {
 
 const char* canvas_last_error(canvas_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context (no usable GPU: this library has no CPU fallback)"; }
 
+int32_t canvas_set_one_shot(canvas_ctx* ctx, int32_t on) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    ctx->one_shot = on ? 1 : 0;
+    return CANVAS_OK;
+}
 int32_t canvas_set_stream(canvas_ctx* ctx, void* hip_stream) {
     if (!ctx) return CANVAS_ERR_INVALID;
     CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -192,7 +192,8 @@ struct AsyncCtx {
     std::thread th; canvas_ctx* ctx = nullptr;
     // warm (optional): run on the helper thread behind canvas_create — e.g. a CBS call on a toy sample, so that the code objects are loaded and the launcher threads, streams
     // and engine buffers of the method exist by the time the real coverage has been read (a cold process paid 0.45 s in the device phase of -m CBS for 0.1 s of work)
-    explicit AsyncCtx(std::function<void(canvas_ctx*)> warm = nullptr) { th = std::thread([this, warm] { ctx = canvas_create(0); if (ctx && warm && !getenv("CANVAS_TOOL_NO_WARMUP")) warm(ctx); }); }
+    explicit AsyncCtx(std::function<void(canvas_ctx*)> warm = nullptr) { th = std::thread([this, warm] { ctx = canvas_create(0); if (ctx && !getenv("CANVAS_TOOL_KEEP_PINNING")) (void)canvas_set_one_shot(ctx, 1);      // (one OS process per sample: nothing amortises pinned staging)
+                                                                                              if (ctx && warm && !getenv("CANVAS_TOOL_NO_WARMUP")) warm(ctx); }); }
     canvas_ctx* get() { if (th.joinable()) th.join(); return ctx; }
     ~AsyncCtx() { if (th.joinable()) th.join(); }
 };

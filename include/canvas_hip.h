@@ -50,6 +50,10 @@ const char* canvas_version(void);
  * a synchronisation that returns early was observed about once in eight process starts in round 4).  No reference counterpart. */
 int32_t canvas_stale_reads(int64_t* h_out2);
 int32_t canvas_set_stream(canvas_ctx* ctx, void* hip_stream); /* run on a caller-owned hipStream_t (NULL = own stream) */
+/* A hint, never a change of results: the host makes ONE call per method with this context and then exits (the reference launches CanvasBin / CanvasClean / CanvasPartition as
+ * one OS process per sample, Canvas/CanvasRunner.cs:123-128).  The library then uploads from the caller's pageable arrays where it would otherwise stage through pinned host
+ * memory of its own: pinning costs ~1.4 ms per MB and the same again when the process leaves, which a second call would amortise and a one-shot process cannot. */
+int32_t canvas_set_one_shot(canvas_ctx* ctx, int32_t on);
 int32_t canvas_synchronize(canvas_ctx* ctx);
 void* canvas_device_malloc(canvas_ctx* ctx, int64_t bytes);
 int32_t canvas_device_free(canvas_ctx* ctx, void* d_ptr);
