@@ -63,15 +63,43 @@ __global__ void __launch_bounds__(256) k_tail_nu(const TailArgs A, int n, double
     if (!(x > 0.01)) { if (t == 0) finish(exp(-0.583 * x), 0); return; }
     double l1 = log(2.0) - 2.0 * log(x), l0 = l1;
     long long dk = 0; long long k = 2; int flag = 0;
-    auto block = [&](long long cnt) -> double {           // sum_{i=1..cnt} 2 Phi(-x sqrt(dk + i) / 2) / (dk + i), all threads return the same value
-        double acc = 0.0;
-        for (long long i = t + 1; i <= cnt; i += 256) { const double d = (double)(dk + i); acc += erfc(x * sqrt(d) / 2.0 / 1.4142135623730951) / d; }     // 2 * (0.5 erfc(-xk / sqrt 2)), xk = -x sqrt(d) / 2
+    // A block of the series is sum_{d = dk + 1}^{dk + cnt} f(d), f(d) = 2 Phi(-x sqrt(d) / 2) / d = erfc(a sqrt(d)) / d with a = x / (2 sqrt 2); from the second block on dk = cnt
+    // = D, i.e. the block is d in (D, 2 D].  Up to D = 256 every term is evaluated (one per thread).  From D = 512 on the block is taken from the Euler-Maclaurin formula in its
+    // midpoint form,  sum = int_{D + 1/2}^{2 D + 1/2} f(t) dt - (f1(2 D + 1/2) - f1(D + 1/2)) / 24 + O(7 / 5760 * 6 / D^4) with f1 the first derivative:  the integral is
+    // 2 int erfc(u) / u du over u = a sqrt(t), i.e. int 2 erfc(e^v) dv over an interval of width ln(2) / 2 — sixteen 16-point Gauss-Legendre panels, one node per thread —
+    // and f1(t) = -erfc(a sqrt t) / t^2 - a e^{-a^2 t} / (sqrt(pi) t^{3/2}).  Against the term-by-term sum the block is off by < 1e-13 at D = 512 and 16 x less with every
+    // doubling (tools/tail_em_check.py; the series itself is ~ 10, the value only feeds decisions the host accepts when they hold for every p1 within 1e-8 relative).  The
+    // long segments of a WGS sample ask for x down to 0.012, i.e. blocks up to D = 2^20: ~2 M erfc evaluations per argument became ~5 000 (k_tail_nu: 9-12 % of the kernel
+    // time of a CBS call, 165-470 us per launch; now tens of us).
+    const double a = x / 2.0 / 1.4142135623730951;
+    auto block_sum = [&](double acc) -> double {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
         __syncthreads();
         if ((t & 63) == 0) sh[t >> 6] = acc;
         __syncthreads();
         return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    };
+    auto block = [&](long long cnt) -> double {           // sum_{i=1..cnt} 2 Phi(-x sqrt(dk + i) / 2) / (dk + i), all threads return the same value
+        if (cnt >= 512 && dk == cnt) {
+            constexpr double GX[16] = {-9.89400934991649939e-01, -9.44575023073232600e-01, -8.65631202387831755e-01, -7.55404408355002999e-01, -6.17876244402643771e-01, -4.58016777657227370e-01, -2.81603550779258915e-01, -9.50125098376374544e-02,
+                                       9.50125098376374544e-02, 2.81603550779258915e-01, 4.58016777657227370e-01, 6.17876244402643771e-01, 7.55404408355002999e-01, 8.65631202387831755e-01, 9.44575023073232600e-01, 9.89400934991649939e-01};
+            constexpr double GW[16] = {2.71524594117540374e-02, 6.22535239386477063e-02, 9.51585116824925914e-02, 1.24628971255534030e-01, 1.49595988816576764e-01, 1.69156519395002619e-01, 1.82603415044923612e-01, 1.89450610455068585e-01,
+                                       1.89450610455068585e-01, 1.82603415044923612e-01, 1.69156519395002619e-01, 1.49595988816576764e-01, 1.24628971255534030e-01, 9.51585116824925914e-02, 6.22535239386477063e-02, 2.71524594117540374e-02};
+            const double t1 = (double)cnt + 0.5, t2 = 2.0 * (double)cnt + 0.5;
+            const double v1 = log(a * sqrt(t1)), v2 = log(a * sqrt(t2)), h = (v2 - v1) / 16.0;
+            const int panel = t >> 4, node = t & 15;
+            double gx = 0.0, gw = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) if (q == node) { gx = GX[q]; gw = GW[q]; }      // (a select chain: a constant array indexed by a lane-dependent value would live in scratch memory)
+            const double v = v1 + ((double)panel + 0.5) * h + 0.5 * h * gx;
+            const double integral = block_sum(0.5 * h * gw * 2.0 * erfc(exp(v)));
+            auto fprime = [&](double tt) { return -erfc(a * sqrt(tt)) / (tt * tt) - a * exp(-a * a * tt) / (1.7724538509055160273 * tt * sqrt(tt)); };
+            return integral - (fprime(t2) - fprime(t1)) / 24.0;
+        }
+        double acc = 0.0;
+        for (long long i = t + 1; i <= cnt; i += 256) { const double d = (double)(dk + i); acc += erfc(a * sqrt(d)) / d; }     // 2 * (0.5 erfc(-xk / sqrt 2)), xk = -x sqrt(d) / 2
+        return block_sum(acc);
     };
     l1 = l1 - block(k); dk += k;
     for (;;) {
@@ -3287,6 +3315,23 @@ extern "C" int32_t canvas_cbs_prefetch(canvas_ctx* ctx, int32_t nchr, int64_t wo
     std::vector<int32_t> seeds((size_t)nchr);
     cbs_chromosome_seeds(nchr, seeds.data());
     for (int c = 0; c < nchr; c++) mts->prefetch(mts->get((uint32_t)seeds[(size_t)c]), words_per_chromosome);
+    return CANVAS_OK;
+}
+// diagnostic / test entry: Nu(x) of TailProbability.cs:52-85 for up to 100 arguments through the device series (k_tail_nu), with the flags that send a call back to the host series
+extern "C" int32_t canvas_cbs_tail_probe(canvas_ctx* ctx, const double* h_x, int32_t n, double tol, double* h_nu, int32_t* h_flag) {
+    if (!ctx) return CANVAS_ERR_INVALID;
+    if (!h_x || !h_nu || !h_flag || n < 1 || n > 100 || !(tol > 0)) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_cbs_tail_probe: 1 .. 100 arguments");
+    CANVAS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    cbs::PermGpu PG; PG.ctx = ctx;
+    int32_t rc = PG.ensure_tail(); if (rc) return rc;
+    double* hNu = (double*)PG.tailPin; int* hFlag = (int*)(hNu + 128); volatile unsigned* hSeq = (volatile unsigned*)(hFlag + 128);
+    TailArgs A; memset(&A, 0, sizeof A); for (int i = 0; i < n; i++) A.x[i] = h_x[i];
+    const unsigned seq = 1u; *hSeq = 0u; std::atomic_thread_fence(std::memory_order_seq_cst);
+    hipLaunchKernelGGL(k_tail_nu, dim3(n), dim3(256), 0, PG.tailStream, A, n, tol, hNu, hFlag, (unsigned*)PG.tailDev, (unsigned*)hSeq, seq);
+    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(PG.tailStream));
+    CANVAS_HIP_TRY(ctx, hipGetLastError());
+    rc = cvx_mail_await(ctx, hSeq, seq, "canvas_cbs_tail_probe"); if (rc) return rc;
+    for (int i = 0; i < n; i++) { h_nu[i] = hNu[i]; h_flag[i] = hFlag[i]; }
     return CANVAS_OK;
 }
 // diagnostic / test entry: nwords draws of the chromosome-th stream from `position` on, out of the context's cache (generated now if they are not there yet)

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "canvas_packed_plane_bytes", "canvas_pack_reference_host", "canvas_pack_hits_host", "canvas_pack_genome_device", "canvas_upload_packed_begin", "canvas_bin_sample_packed", "canvas_sample_pipeline_packed", "canvas_pack_hits2_host", "canvas_upload_packed2_begin",
     "canvas_mask_from_fasta", "canvas_mask_exclude_intervals", "canvas_screen_hits",
     "canvas_bin_rates", "canvas_bin_size_from_rates", "canvas_bin_count_upper_bound", "canvas_bin_genome", "canvas_bin_sample", "canvas_bin_sample_gcweighted", "canvas_bin_predefined", "canvas_bin_predefined_gcweighted",
-    "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_cbs_boundary", "canvas_cbs_seeds", "canvas_cbs_prefetch", "canvas_cbs_stream_read", "canvas_cbs_cache_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_wavelets_decisions", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
+    "canvas_clean", "canvas_clean2", "canvas_clean_batch", "canvas_merge_cleaned", "canvas_chromosome_offsets", "canvas_quantize_f2", "canvas_hmm_per_sample", "canvas_hmm_joint", "canvas_segment_ids", "canvas_segment_ids_filtered", "canvas_segment_ids_ploidy", "canvas_evenness_score", "canvas_split_overlapping", "canvas_cbs", "canvas_cbs_undo", "canvas_cbs_device_stats", "canvas_cbs_tailp_stats", "canvas_cbs_tail_probe", "canvas_cbs_boundary", "canvas_cbs_seeds", "canvas_cbs_prefetch", "canvas_cbs_stream_read", "canvas_cbs_cache_stats", "canvas_wavelets", "canvas_wavelets_stats", "canvas_wavelets_decisions", "canvas_normalize_reference", "canvas_normalize_ratio", "canvas_sample_pipeline",
     "canvas_comm_unique_id", "canvas_comm_init", "canvas_comm_init_host", "canvas_allgather_boundaries", "canvas_sample_pipeline_sharded", "canvas_sample_pipeline_sharded_packed", "canvas_sharded_stats", "canvas_cbs_sharded", "canvas_wavelets_sharded", "canvas_allgather_host", "canvas_merge_cleaned_sharded", "canvas_profile_enable", "canvas_profile_get", "canvas_bin_gcw_stats", "canvas_cbs_tpermp_stats", "canvas_comm_split", "canvas_comm_restore", "canvas_comm_rank", "canvas_bin_sample_sharded", "canvas_hmm_per_sample_sharded", "canvas_cbs_perm_probe", "canvas_stale_reads",
 ]
 
@@ -415,6 +415,12 @@ class Canvas:
         out = np.zeros(6, np.int64)
         self._check(self.lib.canvas_cbs_device_stats(self.ctx, _np_ptr(out)))
         return out
+
+    def cbs_tail_probe(self, xs, tol=1e-6):
+        """TailProbability.Nu of up to 100 arguments through the device series (canvas_cbs_tail_probe): (nu, flags)"""
+        xs = np.ascontiguousarray(xs, np.float64); nu = np.zeros(len(xs), np.float64); fl = np.zeros(len(xs), np.int32)
+        self._check(self.lib.canvas_cbs_tail_probe(self.ctx, _np_ptr(xs), len(xs), C.c_double(tol), _np_ptr(nu), _np_ptr(fl)))
+        return nu, fl
 
     def cbs_cache_stats(self):
         """[draws read out of the stream cache, draws generated inside batches, draws the cache's generator produced, states fetched for host code] of the last cbs() call,

@@ -286,6 +286,10 @@ int32_t canvas_cbs_tpermp_stats(canvas_ctx* ctx, int64_t* h_out2);
  * FindChangePoints (ChangePoint.cs:318-323).  [0] calls decided from the device evaluation of its series (accepted only when every value within 1e-8 relative gives the same
  * decisions), [1] calls recomputed with the host libm in the reference's order. */
 int32_t canvas_cbs_tailp_stats(canvas_ctx* ctx, int64_t* h_out2);
+/* Diagnostic / test entry: TailProbability.Nu (TailProbability.cs:52-85) of n <= 100 arguments through the device series exactly as canvas_cbs evaluates it (k_tail_nu: the
+ * first 512 terms one by one, every later block of the series from the Euler-Maclaurin formula); h_flag[i] != 0: a stopping comparison of the series was too close to call and
+ * canvas_cbs would redo the call with the host series. */
+int32_t canvas_cbs_tail_probe(canvas_ctx* ctx, const double* h_x, int32_t n, double tol, double* h_nu, int32_t* h_flag);
 /* Diagnostic / test entry: ONE batch of nb permutations of the centred segment h_x[n] (n >= 1024, n * nb <= 2^30) through the device permutation engine exactly as the hybrid test of
  * FindChangePoints runs it — XPerm (ChangePoint.cs:407-421) + HTMaxP with k = 25, minimum width 2 (CBSTStatistic.cs:354-586) — from MersenneTwister(seed).  kernel selects the
  * permutation kernel: 0 counting sort + pointer doubling, 1 block-wise simulation of the swaps in global memory, 2 range-partitioned simulation in LDS.  h_lohi[2 nb]: the interval

@@ -244,6 +244,8 @@ void ComputeBoundary(uint32_t nPerm, double alpha, double eta, std::vector<uint3
 
 // ------------------------------------------------------------------ TailProbability.cs
 static double pnorm(double x) { return 0.5 * std::erfc(-x / M_SQRT2); }  // MathNet Normal.CumulativeDistribution (parity unpinned)
+static double Nu(double x, double tol);
+extern "C" double orc_nu(double x, double tol) { return Nu(x, tol); }      // (exported for the test of the device series: tests/test_cbs_gpu.py)
 static double Nu(double x, double tol) {  // TailProbability.cs:45-85
     double lnu1;
     if (x > 0.01) {

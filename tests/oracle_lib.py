@@ -26,6 +26,8 @@ def _load():
     lib.orc_median_f32.restype = C.c_float
     lib.orc_golden_section_square.restype = C.c_double
     lib.orc_golden_section_square.argtypes = [C.c_double, C.c_double]
+    lib.orc_nu.restype = C.c_double
+    lib.orc_nu.argtypes = [C.c_double, C.c_double]
     lib.orc_tailp.restype = C.c_double
     lib.orc_tailp.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.orc_htmaxp.restype = C.c_double

