@@ -2643,6 +2643,11 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     // first batch: without a single rejection the sequential rule stops at permutation sbdry[k - 1] — known now — and that is what a segment with a real change point
     // does; asking for that many at once saves the 64 / 128 / 256 ramp its two extra launcher round trips (a segment without one leaves after a handful either way)
     int B = std::min(maxB, std::max(64, (int)std::min<uint32_t>(sbdry[k - 1], 4096u)));
+    // ... but no more than four times what nrejc + 1 rejections need at a rejection rate of one in four, and no more than one round of the persistent workgroups (a batch of
+    // 1 024 permutations is two rounds of 512 workgroups: two batches of 512 take as long and the second is only computed if the rule is still running).  Three in four loops of
+    // the tumour / normal pair end "not significant" inside their first batch: with sbdry alone 11 % of all permuted elements were never looked at (profiles/r06_loop_waste.txt)
+    { static const bool oldB0 = cvx_hook("CANVAS_CBS_B0_STOP") != nullptr; static const int fac = cvx_hook("CANVAS_CBS_B0_FACTOR") ? atoi(cvx_hook("CANVAS_CBS_B0_FACTOR")) : 4, cap = cvx_hook("CANVAS_CBS_B0_CAP") ? atoi(cvx_hook("CANVAS_CBS_B0_CAP")) : 512;
+      if (!oldB0) B = std::min(B, std::max(64, std::min(cap, fac * (nrejc + 1)))); }
     if (cvx_hook("CANVAS_CBS_B0")) B = std::min(maxB, atoi(cvx_hook("CANVAS_CBS_B0")));
     outcome = 1;
     while (np < nPerm) {
