@@ -27,7 +27,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # read by the HIP runtime at its first call (canvas_amd/__init__.py): CBS keeps more than 4 kernels in flight
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # read by the HIP runtime at its first call: CBS keeps more than 4 kernels in flight.  8, not 16 (round 6): every hardware queue the
+                                                    # runtime creates costs ~5 ms at the first streams and again at exit — 16: first CBS call 0.27-0.32 s, 8: 0.17-0.21, 4: 0.12; the warm tumour / normal CBS 0.39-0.40 / 0.40-0.41 / 0.41 s
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 

@@ -2368,7 +2368,7 @@ struct SvcRes { hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq*
 struct PermService {
     canvas_ctx* ctx; SvcRes* res = nullptr; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
     ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
-    long long rounds = 0, nArc = 0, nPermReq = 0; double secArc = 0, secPerm = 0; unsigned arcSeq = 0;
+    long long rounds = 0, nArc = 0, nPermReq = 0, nArcRounds = 0; double secArc = 0, secPerm = 0; unsigned arcSeq = 0;
     // k_perm_rp's scratch belongs to the LAUNCHER, not to the engines: a launch holds the batches of several chromosomes, the device has 512 workgroup slots for all of them, and
     // a launcher has one launch in flight — so one slab per launcher (2 GiB for the longest segments) serves what 24 engines used to reserve 2 GiB EACH for (48 GB of
     // hipMalloc in the first call of a process, which at times took seconds beside the stream cache's mappings: ADVICE r05, profiles/r06_*).  Requests share the slab in
@@ -2416,7 +2416,10 @@ struct PermService {
     }
     // all waiting arc searches in shared launches (grid.y = request): pruned pipeline, or the exhaustive kernel for requests that ask for it
     int32_t launch_arc(std::vector<ArcHostReq*>& all) {
+        const auto tA0 = std::chrono::steady_clock::now();
         int32_t rc = init(); if (rc) return rc;
+        const double msInit = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tA0).count();
+        struct FirstRounds { PermService* s; double msInit; std::chrono::steady_clock::time_point t0; size_t n; ~FirstRounds() { if (s->nArcRounds++ < 2 && cvx_hook("CANVAS_CBS_TIMING")) fprintf(stderr, "cbs arc launcher %p round %lld: %zu searches, init %.2f ms, copies + kernels + wait %.2f ms\n", (void*)s, s->nArcRounds, n, msInit, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - msInit); } } fr{this, msInit, tA0, all.size()};
         std::vector<ArcHostReq*> pr, ex;
         for (auto* q : all) (q->pruned ? pr : ex).push_back(q);
         for (auto* q : all) CANVAS_HIP_TRY(ctx, hipMemcpyAsync((void*)q->r.sx, q->hSx, (size_t)q->r.n * 8, hipMemcpyHostToDevice, stream));
@@ -3003,8 +3006,8 @@ struct EngineCache {
         // the shared tail streams: creating one takes ~5 ms on this runtime (sixteen: 77 of the 170 ms of a cold call) — two are made here, the others on a thread of their
         // own while the chromosome threads start (tail_stream() hands out what exists)
         while (newTail > 0 && tailStreams.size() < 2) { hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; } tailStreams.push_back(q); }
-        // (a one-shot process pays ~5 ms per stream again when it leaves: four shared tail streams there, twelve for a host that keeps its context)
-        const size_t wantStreams = ctx->one_shot ? 4 : 12;
+        // (a one-shot process pays ~5 ms per stream again when it leaves: four shared tail streams there, eight for a host that keeps its context)
+        const size_t wantStreams = ctx->one_shot ? 4 : 8;
         if (newTail > 0 && tailStreams.size() < wantStreams && !streamMaker.joinable()) {
             const int dev = ctx->device;
             streamMaker = std::thread([this, dev, wantStreams]() {

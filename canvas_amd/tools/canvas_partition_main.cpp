@@ -82,7 +82,7 @@ static int is_uniform_reference_ploidy(const std::vector<PloidyIv>& ivs, int qs,
 }
 
 int main(int argc, char** argv) {
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);      // (read by the HIP runtime at its first call: -m CBS keeps a dozen kernels in flight, the default maps all streams onto 4 hardware queues)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);       // (read by the HIP runtime at its first call: -m CBS keeps a dozen kernels in flight, the default maps all streams onto 4 hardware queues)
     printf(">>>Command-line arguments:\n"); for (int i = 1; i < argc; i++) printf("%s ", argv[i]); printf("\n");
     std::vector<Opt> opts = {{"i", "infile", true}, {"v", "vaffile", true}, {"o", "outfile", true}, {"m", "method", true}, {"r", "reference", true}, {"s", "split", true},
                              {"b", "bedfile", true}, {"c", "commoncnvs", true}, {"g", "germline", false}, {"", "evenness-metric-file", true}, {"p", "ploidyVcfFile", true},
