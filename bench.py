@@ -84,6 +84,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     cv = Canvas(local_rank)
     cv.profile_enable(True)
+    if world == 1 and not (args.no_cbs and args.no_somatic):
+        # what INTEGRATION.md tells a host to do right behind canvas_create (and CanvasPartition -m CBS does during its file read): the draw streams of CBS are constants of
+        # the method — the library starts generating them, and creates its launchers' streams, on a thread of its own while the host is busy with something else
+        cv.cbs_prefetch(len(synth.GRCH38), 16 << 20)
     if world > 1 or force_sharded:
         from canvas_amd import parallel
         if one_gpu:
@@ -321,7 +325,8 @@ def main():
         dstat = cv.cbs_device_stats(); tstat = cv.cbs_tailp_stats()
         cb = {"tailp_decided_on_device": int(tstat[0]), "tailp_recomputed_on_host": int(tstat[1]), "seconds": round(cbs_s, 3), "seconds_of_each_call": [round(x, 3) for x in cbs_runs], "first_call_seconds": round(cbs_first, 3), "bins_per_s": round(int(keep["n_out"]) / cbs_s, 1), "segments": int(sum(nseg_c)), "tmaxo_calls": int(cstats[0]),
               "permutations": int(cstats[2]), "permuted_elements": int(cstats[3]), "device_permutations": int(dstat[0]), "host_permutations": int(dstat[1]),
-              "exact_reevaluations": int(dstat[2]), "note": "CBSRunner.Run (alpha 0.01, 10000 permutations): recursion, stopping rule and the edge tests (TPermP) on the host; TMaxO arc search, TailP series, MT19937 and every "
+              "exact_reevaluations": int(dstat[2]), "prefetch_at_context_creation": True, "draws_read_out_of_the_cache_last_call": int(cv.cbs_cache_stats()[0]), "draws_generated_inside_batches_last_call": int(cv.cbs_cache_stats()[1]),
+              "cache_GB": round(int(cv.cbs_cache_stats()[4]) / 1e9, 2), "note": "first_call_seconds: the first canvas_cbs of the process, in a context that called canvas_cbs_prefetch when it was created (INTEGRATION.md 4: the draw streams and the launchers' streams come up in the background); CBSRunner.Run (alpha 0.01, 10000 permutations): recursion, stopping rule and the edge tests (TPermP) on the host; TMaxO arc search, TailP series, MT19937 and every "
               "permutation of the reference distribution (XPerm + HTMaxP / TMaxP) on the device; seconds = median of three warm calls"}
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

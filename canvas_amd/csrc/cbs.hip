@@ -2365,9 +2365,24 @@ struct PermHostReq { PermReq r; long long prevTotal = 0; double* hStat; uint32_t
 // creation and six small allocations on its first round
 struct SvcRes { hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr;
                 char* rpSlab = nullptr; size_t rpSlabBytes = 0; };      // rpSlab: the scratch of k_perm_rp's persistent workgroups for whatever this launcher has in flight
+#define SVC_REQ_CAP 32
+// the device side of a launcher, created on its first use — or ahead of it by EngineCache::warm (canvas_cbs_prefetch): a stream costs ~5 ms on this runtime, and seven
+// launchers creating theirs at the start of the first call were 60 ms of it
+static int32_t svc_res_create(canvas_ctx* ctx, SvcRes* res) {
+    if (res->stream) return CANVAS_OK;
+    CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking));
+    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dReqs, SVC_REQ_CAP * sizeof(PermReq)));
+    CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hReqs, SVC_REQ_CAP * sizeof(PermReq), hipHostMallocDefault));
+    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dArc, 64 * sizeof(ArcReq)));
+    CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hArc, 64 * sizeof(ArcReq), hipHostMallocDefault));
+    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dArcP, 64 * sizeof(ArcPReq)));
+    CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hArcP, 64 * sizeof(ArcPReq), hipHostMallocDefault));
+    return CANVAS_OK;
+}
 struct PermService {
     canvas_ctx* ctx; SvcRes* res = nullptr; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr; int cap = 32;
     ArcReq* dArc = nullptr; ArcReq* hArc = nullptr; ArcPReq* dArcP = nullptr; ArcPReq* hArcP = nullptr; std::vector<ArcHostReq*> pendingArc;
+    static_assert(SVC_REQ_CAP == 32, "cap below");
     long long rounds = 0, nArc = 0, nPermReq = 0, nArcRounds = 0; double secArc = 0, secPerm = 0; unsigned arcSeq = 0;
     // k_perm_rp's scratch belongs to the LAUNCHER, not to the engines: a launch holds the batches of several chromosomes, the device has 512 workgroup slots for all of them, and
     // a launcher has one launch in flight — so one slab per launcher (2 GiB for the longest segments) serves what 24 engines used to reserve 2 GiB EACH for (48 GB of
@@ -2401,15 +2416,7 @@ struct PermService {
         if (!stream) {
             AllocClock ac(g_ns_alloc_svc);
             res = cache_svc_take(ctx);
-            if (!res->stream) {
-                CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking));
-                CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dReqs, cap * sizeof(PermReq)));
-                CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hReqs, cap * sizeof(PermReq), hipHostMallocDefault));
-                CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dArc, 64 * sizeof(ArcReq)));
-                CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hArc, 64 * sizeof(ArcReq), hipHostMallocDefault));
-                CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dArcP, 64 * sizeof(ArcPReq)));
-                CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hArcP, 64 * sizeof(ArcPReq), hipHostMallocDefault));
-            }
+            { int32_t rcr = svc_res_create(ctx, res); if (rcr) return rcr; }
             stream = res->stream; dReqs = res->dReqs; hReqs = res->hReqs; dArc = res->dArc; hArc = res->hArc; dArcP = res->dArcP; hArcP = res->hArcP;
         }
         return CANVAS_OK;
@@ -2974,10 +2981,34 @@ struct EngineCache {
     std::vector<Slab> devSlabs, pinSlabs; std::vector<hipStream_t> tailStreams; size_t nextTail = 0; std::vector<SvcRes*> svcFree, svcAll;
     std::unique_ptr<MtStreamCache> mts;      // the chromosomes' draw streams (created with the first CBS call / canvas_cbs_prefetch of the context)
     MtStreamCache* streams(canvas_ctx* ctx) { std::lock_guard<std::mutex> lk(mu); if (!mts) mts.reset(new MtStreamCache(ctx)); return mts->off ? nullptr : mts.get(); }
-    std::thread streamMaker; bool dying = false;
+    std::thread streamMaker, warmer; bool dying = false;
+    // ahead of the first call (canvas_cbs_prefetch): the launchers' streams and tables and the shared tail streams, on a thread of their own
+    void warm(canvas_ctx* ctx, int nSvc) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (warmer.joinable()) return;
+        const int dev = ctx->device; const size_t wantStreams = ctx->one_shot ? 4 : 8;
+        warmer = std::thread([this, ctx, dev, nSvc, wantStreams]() {
+            if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
+            std::vector<SvcRes*> made;
+            for (int i = 0; i < nSvc; i++) {
+                { std::lock_guard<std::mutex> lk2(mu); if (dying) break; }
+                SvcRes* r = svc_take();
+                std::string keep = ctx->err;
+                if (svc_res_create(ctx, r) != CANVAS_OK) { (void)hipGetLastError(); ctx->err = keep; }
+                made.push_back(r);
+            }
+            for (SvcRes* r : made) svc_give(r);
+            for (;;) {
+                { std::lock_guard<std::mutex> lk2(mu); if (tailStreams.size() >= wantStreams || dying) return; }
+                hipStream_t q = nullptr; if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+                std::lock_guard<std::mutex> lk2(mu); tailStreams.push_back(q);
+            }
+        });
+    }
     ~EngineCache() {
         { std::lock_guard<std::mutex> lk(mu); dying = true; }
         if (streamMaker.joinable()) streamMaker.join();
+        if (warmer.joinable()) warmer.join();
         mts.reset();                                          // (joins the producer thread, unmaps the streams)
         arcs.clear(); perms.clear(); tails.clear();           // (the engines first: they may still wait on a shared stream)
         for (hipStream_t q : tailStreams) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
@@ -3323,6 +3354,7 @@ extern "C" int32_t canvas_cbs_prefetch(canvas_ctx* ctx, int32_t nchr, int64_t wo
     std::vector<int32_t> seeds((size_t)nchr);
     cbs_chromosome_seeds(nchr, seeds.data());
     for (int c = 0; c < nchr; c++) mts->prefetch(mts->get((uint32_t)seeds[(size_t)c]), words_per_chromosome);
+    cbs::EngineCache::of(ctx).warm(ctx, 7);      // (the seven launchers of a call: their streams and request tables, then the shared tail streams)
     return CANVAS_OK;
 }
 // diagnostic / test entry: Nu(x) of TailProbability.cs:52-85 for up to 100 arguments through the device series (k_tail_nu), with the flags that send a call back to the host series

@@ -304,8 +304,8 @@ int64_t canvas_cbs_boundary(uint32_t nperm, double alpha, uint32_t* h_out, int64
  * (CBSRunner.cs:107-112) and is consumed strictly in sequence by XPerm / TPermP (ChangePoint.cs:407-421, CBSTStatistic.cs:1009): the words are constants of the method.  The
  * library keeps them per context in device memory (generated once, extended on demand, bounded by CANVAS_CBS_CACHE_GB — default 30 % of the device's memory, 0 = off) and
  * canvas_cbs reads its permutations' draws out of them.  canvas_cbs_prefetch starts the generator for the first `words_per_chromosome` draws of the first nchr streams on a
- * thread and stream of its own and returns at once: a host calls it while it is still reading its input (CanvasPartition does).  Optional — canvas_cbs asks for what it
- * needs itself.  canvas_cbs_cache_stats: h_out6 = {draws the last canvas_cbs call read out of the cache, draws it generated inside its batches (cache off / bound reached),
+ * thread and stream of its own — and creates, on another, the streams and request tables of canvas_cbs's launchers (a stream costs ~5 ms on this runtime: 60 ms of a first
+ * call) — and returns at once: a host calls it while it is still reading its input (CanvasPartition does).  Optional — canvas_cbs asks for what it needs itself.  canvas_cbs_cache_stats: h_out6 = {draws the last canvas_cbs call read out of the cache, draws it generated inside its batches (cache off / bound reached),
  * draws the cache's generator produced during the call, generator states fetched for host code, bytes of device memory the cache holds, draws it holds}. */
 int32_t canvas_cbs_prefetch(canvas_ctx* ctx, int32_t nchr, int64_t words_per_chromosome);
 /* Diagnostic / test entry: nwords tempered outputs of the chromosome-th generator (0-based, file order) from output number `position` on, read out of the context's cache
