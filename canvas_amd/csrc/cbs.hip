@@ -23,6 +23,7 @@
 //     stay on the host.  WGS-size run (4.7 M bins, 104 k permutations over 1.27e9 elements): 4.1 s host-only -> 1.5 s.
 #include "common.hpp"
 #include "cbs_boundary_default.hpp"
+#include "cbs_mt_jump.hpp"
 #include "../../include/canvas_mathnet.h"
 #include <algorithm>
 #include <atomic>
@@ -2049,6 +2050,78 @@ static void rp_plan(int n, PermReq::RpPlan& P) {
 }
 static size_t rp_scratch_bytes(int n, int wgs) { PermReq::RpPlan P; rp_plan(n, P); return (size_t)P.stride * 4 * (size_t)wgs; }
 
+// ================================================================================================ the cache's own generator: jump-ahead check points + the plain recurrence
+// A cached stream is CONSUMED in sequence but must be PRODUCED in parallel: one workgroup running the plain recurrence x[n] = x[n - 227] ^ twist(x[n - 624], x[n - 623])
+// makes ~4 G words/s (454 words per barrier), the strided GF(2) form above makes 53 G words/s per stream with 134 LDS reads per word — a third of the kernel time of a cold
+// tumour / normal call.  So a stream is cut into chunks of MT_CHUNK = 2^22 outputs; the generator state a chunk starts from (the 624 untempered outputs in front of it) is
+// obtained from the state of the chunk before it by the jump-ahead polynomial g = x^(2^22) mod phi (cbs_mt_jump.hpp, tools/gen_mt_jump.py: MT19937 is linear over GF(2), so
+// u[k + 2^22] = XOR_{i : g_i} u[k + i] for the untempered outputs u of any seed) — k_mt_jump: one workgroup per stream walks its chunks, generating the 19 937 words behind a
+// state into LDS and XOR-summing 10 024 of them per state word (~0.1 ms per chunk: LDS bandwidth) — and then ALL chunks of ALL streams are generated side by side by k_mt_chunk
+// with the plain recurrence (3 LDS reads per word, stores of 227 consecutive words), which is bound by the HBM writes, not by the generator.
+#define MT_CHUNK (1LL << MT_JUMP_LOG2)
+#define MTJ_T 640
+#define MTJ_W (624 + 19937)
+struct MtJumpJob { uint32_t* cp; int kFrom, kTo; };      // check points cp[k] (624 words each): cp[kFrom] exists, cp[kFrom + 1 .. kTo] are computed
+struct MtChunkJob { const uint32_t* cp; uint32_t* out; long long words; };
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) { const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu); return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+#define MTJ_NIDX ((MT_JUMP_NTERMS + 7) & ~7)
+__global__ void __launch_bounds__(MTJ_T) k_mt_jump(const MtJumpJob* __restrict__ jobs) {
+    __shared__ uint32_t W[MTJ_W + 3];
+    __shared__ __attribute__((aligned(16))) unsigned short sIdx[MTJ_NIDX];      // the polynomial's terms in LDS: read eight at a time as ONE broadcast 16-byte read (from constant memory the
+                                                                                 // scalar loads missed their cache all the way: 0.5 ms per jump instead of 0.1)
+    const MtJumpJob J = jobs[blockIdx.x];
+    const int t = (int)threadIdx.x;
+    for (int i = t; i < MTJ_NIDX; i += MTJ_T) sIdx[i] = i < MT_JUMP_NTERMS ? MT_JUMP_IDX[i] : (unsigned short)0xFFFF;
+    if (t < 624) W[t] = J.cp[(size_t)J.kFrom * 624 + t];
+    __syncthreads();
+    for (int k = J.kFrom; k < J.kTo; k++) {
+        // the 19 937 words behind the state, 227 at a time (each needs words at least 227 behind it)
+        for (int n = 624; n < MTJ_W; n += 227) {
+            if (t < 227 && n + t < MTJ_W) W[n + t] = mt_twist(W[n + t - 624], W[n + t - 623], W[n + t - 227]);
+            __syncthreads();
+        }
+        uint32_t acc = 0;
+        if (t < 624) {
+            const uint32_t* __restrict__ w = W + t;
+            for (int i = 0; i < MTJ_NIDX - 8; i += 8) {           // (the LDS reads of a wave are 64 consecutive words: no bank conflict)
+                const uint4 pk = *reinterpret_cast<const uint4*>(&sIdx[i]);
+                acc ^= w[pk.x & 0xFFFFu] ^ w[pk.x >> 16] ^ w[pk.y & 0xFFFFu] ^ w[pk.y >> 16] ^ w[pk.z & 0xFFFFu] ^ w[pk.z >> 16] ^ w[pk.w & 0xFFFFu] ^ w[pk.w >> 16];
+            }
+            for (int i = MTJ_NIDX - 8; i < MT_JUMP_NTERMS; i++) acc ^= w[sIdx[i]];
+        }
+        __syncthreads();
+        if (t < 624) { W[t] = acc; J.cp[(size_t)(k + 1) * 624 + t] = acc; }
+        __syncthreads();
+    }
+}
+// one workgroup per chunk: the state in an LDS ring, two blocks of 227 words per barrier (the second block of a lane continues its own first word and otherwise reads words
+// that are at least 396 behind: nothing another lane produced in this round)
+__global__ void __launch_bounds__(256) k_mt_chunk(const MtChunkJob* __restrict__ jobs) {
+    __shared__ uint32_t R[2048];
+    const MtChunkJob J = jobs[blockIdx.x];
+    const int t = (int)threadIdx.x;
+    for (int i = t; i < 624; i += 256) R[i] = J.cp[i];
+    __syncthreads();
+    const gptr<uint32_t> out = as_global(J.out);
+    const long long total = J.words;
+    // a round makes the 623 words [n, n + 623): lane t its word n + t, then n + t + 227 (continuing its own first word; the other two operands lie 397 / 396 behind), and — the
+    // lanes below 169 — n + t + 454 (operands 170 / 169 behind the round's start: old).  Every operand that is not the lane's own is older than the round.
+    for (long long n = 624; n - 624 < total; n += 623) {
+        if (t < 227) {
+            const long long m = n + t;
+            const uint32_t a0 = R[(m - 624) & 2047], b0 = R[(m - 623) & 2047], c0 = R[(m - 227) & 2047], a1 = R[(m - 397) & 2047], b1 = R[(m - 396) & 2047];
+            uint32_t a2 = 0, b2 = 0; if (t < 169) { a2 = R[(m - 170) & 2047]; b2 = R[(m - 169) & 2047]; }
+            const uint32_t v0 = mt_twist(a0, b0, c0), v1 = mt_twist(a1, b1, v0);
+            R[m & 2047] = v0; R[(m + 227) & 2047] = v1;
+            if (m - 624 < total) out[m - 624] = mt_temper(v0);
+            if (m - 397 < total) out[m - 397] = mt_temper(v1);
+            if (t < 169) { const uint32_t v2 = mt_twist(a2, b2, v1); R[(m + 454) & 2047] = v2; if (m - 170 < total) out[m - 170] = mt_temper(v2); }
+        }
+        // the round's LDS writes must be visible to the next round's reads; the global stores need not have completed (__syncthreads() would wait for them: vmcnt(0) every 623 words)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
 // ================================================================================================ the chromosomes' draw streams, kept in HBM
 // The k-th chromosome's generator is MersenneTwister(seed_k) with seed_k drawn from MersenneTwister(0) in file order (CBSRunner.cs:107-112), and XPerm / TPermP consume it
 // strictly in sequence (ChangePoint.cs:407-421, CBSTStatistic.cs:1009): HOW FAR a call reads depends on the data, the words do not.  So the tempered outputs of every
@@ -2070,12 +2143,15 @@ struct MtStream {
     uint32_t seed = 0; char* va = nullptr; size_t mappedBytes = 0; bool plain = false; size_t plainBytes = 0; std::vector<hipMemGenericAllocationHandle_t> handles;
     long long ready = 0, requested = 0; bool full = false;      // words that are valid / that the producer has been asked for; full: no more memory will be mapped
     long long floorWords = 0;                                   // what canvas_cbs_prefetch / the start of a call asked for: the end of a call does not take THAT back
+    uint32_t* cp = nullptr; int ncp = 0;                        // the generator states of the stream's chunks (624 untempered words in front of chunk k; cp[0] = init_genrand(seed)), how many exist
     uint32_t* d() const { return (uint32_t*)va; }
 };
 struct MtStreamCache {
     canvas_ctx* ctx; std::mutex mu; std::condition_variable cvWork, cvReady; std::map<uint32_t, std::unique_ptr<MtStream>> streams;
     size_t capBytes = 0, usedBytes = 0; bool useVmm = true, stop = false, failed = false, started = false, off = false; std::string err;
     std::thread th; hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq* hReqs = nullptr;
+    MtJumpJob* dJump = nullptr; MtJumpJob* hJump = nullptr; MtChunkJob* dChunk = nullptr; MtChunkJob* hChunk = nullptr;      // job tables of the cache's own generator (pinned + device)
+    static constexpr int CHUNK_CAP = 2048;
     std::atomic<long long> servedWords{0}, generatedWords{0}, fallbackWords{0}, fetches{0};
     std::atomic<long long> nsMap{0}, nsGen{0}, rounds{0}, nsWaited{0}, waits{0};      // producer: mapping memory, generating (launch to synchronisation), rounds; consumers: time spent waiting in acquire()
     static constexpr int CAP = 32;
@@ -2096,8 +2172,10 @@ struct MtStreamCache {
         (void)hipSetDevice(ctx->device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         if (dReqs) (void)hipFree(dReqs); if (hReqs) (void)hipHostFree(hReqs);
+        if (dJump) (void)hipFree(dJump); if (hJump) (void)hipHostFree(hJump); if (dChunk) (void)hipFree(dChunk); if (hChunk) (void)hipHostFree(hChunk);
         for (auto& kv : streams) {
             MtStream& S = *kv.second;
+            if (S.cp) (void)hipFree(S.cp);
             if (S.plain) { if (S.va) (void)hipFree(S.va); continue; }
             if (S.va && S.mappedBytes) (void)hipMemUnmap(S.va, S.mappedBytes);
             for (auto h : S.handles) (void)hipMemRelease(h);
@@ -2182,8 +2260,17 @@ struct MtStreamCache {
     }
     void run() {
         struct Job { MtStream* S; long long from, to; };
+        // Which generator extends the streams.  Default: the strided one of rounds 3-5 (k_mt_draws + bootstrap + k_mt_classes).  CANVAS_CBS_CACHE_JUMP_GENERATOR=1: jump-ahead check
+        // points + the plain recurrence (k_mt_jump / k_mt_chunk above) — measured in round 6 on the tumour / normal pair: 0.23 s of kernel time per cold call instead of 0.54 s
+        // (profiles/r06_generator_ab.txt), and NO gain in wall time (first call of the flow 0.75-2.1 s against 0.98-1.09 s on the same box, germline first call 0.14 against
+        // 0.10-0.125 s): the cold call waits for allocations and for k_perm_rp, whose persistent workgroups hold 159 of every CU's 160 KB of LDS — k_mt_jump's 100 KB window waits
+        // for a CU exactly as k_mt_classes' 160 KB ring does — and the batches wait for the producer for ~50 ms per chromosome thread either way.  Both are tested (contents of
+        // the cache against the oracle's generator across every seam, CBS parity); the default is the one the six-minute soaks of five rounds have run on.
+        const bool oldGen = cvx_hook("CANVAS_CBS_CACHE_JUMP_GENERATOR") == nullptr;
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&dReqs, CAP * sizeof(PermReq)) != hipSuccess
-            || hipHostMalloc((void**)&hReqs, CAP * sizeof(PermReq), hipHostMallocDefault) != hipSuccess) {
+            || hipHostMalloc((void**)&hReqs, CAP * sizeof(PermReq), hipHostMallocDefault) != hipSuccess
+            || hipMalloc((void**)&dJump, CAP * sizeof(MtJumpJob)) != hipSuccess || hipHostMalloc((void**)&hJump, CAP * sizeof(MtJumpJob), hipHostMallocDefault) != hipSuccess
+            || hipMalloc((void**)&dChunk, CHUNK_CAP * sizeof(MtChunkJob)) != hipSuccess || hipHostMalloc((void**)&hChunk, CHUNK_CAP * sizeof(MtChunkJob), hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError(); std::lock_guard<std::mutex> lk(mu); failed = true; err = "the draw-stream cache could not create its stream / request tables"; cvReady.notify_all(); return;
         }
         for (;;) {
@@ -2194,31 +2281,65 @@ struct MtStreamCache {
               for (auto& kv : streams) { MtStream& S = *kv.second; if (!S.full && S.requested > S.ready && (int)jobs.size() < CAP) jobs.push_back({&S, S.ready, std::min(S.requested, S.ready + MTS_JOB_MAX_WORDS)}); }
               busy = true; }
             std::vector<char> shortJob(jobs.size(), 0);
-            int R = 0; bool anyFresh = false; long long maxFresh = 0, maxTotal = 0;
             const auto tM = std::chrono::steady_clock::now();
             for (size_t i = 0; i < jobs.size(); i++) {
                 Job& j = jobs[i];
-                const long long have = back(*j.S, j.to);
+                if (!oldGen) j.to = (j.to + MT_CHUNK - 1) / MT_CHUNK * MT_CHUNK;                       // whole chunks
+                long long have = back(*j.S, j.to);
+                if (!oldGen) have = have / MT_CHUNK * MT_CHUNK;
                 if (have < j.to) { j.to = have; shortJob[i] = 1; }
-                if (j.to <= j.from || (j.from == 0 && j.to < MTS_FIRST_WORDS)) { j.to = j.from; continue; }
-                PermReq& q = hReqs[R++];
-                memset((void*)&q, 0, sizeof q);
-                { MT m(j.S->seed); m.get_state(q.state); }
-                q.total = j.to - j.from; q.P.draws = j.S->d() + j.from; q.fy = 0; q.cached = 0;
-                q.cont = j.from > 0 ? 1 : 0; q.hist = q.cont ? j.S->d() + (j.from - MT_HISTORY) : nullptr;
-                if (!q.cont) { anyFresh = true; maxFresh = std::max(maxFresh, q.total); }
-                maxTotal = std::max(maxTotal, q.total + (q.cont ? MT_HISTORY : 0));
+                if (j.to <= j.from || (j.from == 0 && j.to < MTS_FIRST_WORDS)) j.to = j.from;
             }
             bool ok = true;
             const auto tG = std::chrono::steady_clock::now();
             nsMap += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(tG - tM).count(); rounds++;
-            if (R > 0) {
-                ok = hipMemcpyAsync(dReqs, hReqs, (size_t)R * sizeof(PermReq), hipMemcpyHostToDevice, stream) == hipSuccess;
-                if (ok && anyFresh) {
-                    hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs, 1);
-                    for (int sd = 1; sd < MT_STRIDE && 19937LL * sd < maxFresh; sd <<= 1) hipLaunchKernelGGL(k_mt_classes, dim3(sd, R), dim3(MTC_T), 0, stream, dReqs, sd, 1);
+            if (oldGen) {
+                int R = 0; bool anyFresh = false; long long maxFresh = 0, maxTotal = 0;
+                for (Job& j : jobs) {
+                    if (j.to <= j.from) continue;
+                    PermReq& q = hReqs[R++];
+                    memset((void*)&q, 0, sizeof q);
+                    { MT m(j.S->seed); m.get_state(q.state); }
+                    q.total = j.to - j.from; q.P.draws = j.S->d() + j.from; q.fy = 0; q.cached = 0;
+                    q.cont = j.from > 0 ? 1 : 0; q.hist = q.cont ? j.S->d() + (j.from - MT_HISTORY) : nullptr;
+                    if (!q.cont) { anyFresh = true; maxFresh = std::max(maxFresh, q.total); }
+                    maxTotal = std::max(maxTotal, q.total + (q.cont ? MT_HISTORY : 0));
                 }
-                if (ok && maxTotal > MT_HISTORY) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
+                if (R > 0) {
+                    ok = hipMemcpyAsync(dReqs, hReqs, (size_t)R * sizeof(PermReq), hipMemcpyHostToDevice, stream) == hipSuccess;
+                    if (ok && anyFresh) {
+                        hipLaunchKernelGGL(k_mt_draws, dim3(R), dim3(256), 0, stream, dReqs, 1);
+                        for (int sd = 1; sd < MT_STRIDE && 19937LL * sd < maxFresh; sd <<= 1) hipLaunchKernelGGL(k_mt_classes, dim3(sd, R), dim3(MTC_T), 0, stream, dReqs, sd, 1);
+                    }
+                    if (ok && maxTotal > MT_HISTORY) hipLaunchKernelGGL(k_mt_classes, dim3(MT_STRIDE, R), dim3(MTC_T), 0, stream, dReqs, MT_STRIDE, 0);
+                    ok = ok && hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
+                }
+            } else {
+                // ---- check points by jump-ahead (one workgroup per stream walks its new chunks), then every chunk of every stream side by side
+                int nJ = 0, nC = 0;
+                std::vector<std::vector<uint32_t>> seeds0;                                         // (initial states on their way to the device: alive until the round has been waited for)
+                const int cpCap = (int)(MTS_VA_BYTES / 4 / MT_CHUNK) + 1;
+                for (Job& j : jobs) {
+                    if (j.to <= j.from || !ok) continue;
+                    MtStream& S = *j.S;
+                    if (!S.cp) { if (hipMalloc((void**)&S.cp, (size_t)cpCap * 624 * 4) != hipSuccess) { ok = false; break; } }
+                    if (S.ncp == 0) {
+                        MT m(S.seed); seeds0.emplace_back(m.mt, m.mt + 624);
+                        ok = hipMemcpyAsync(S.cp, seeds0.back().data(), 624 * 4, hipMemcpyHostToDevice, stream) == hipSuccess; S.ncp = 1;
+                    }
+                    const int c0 = (int)(j.from / MT_CHUNK), c1 = (int)(j.to / MT_CHUNK);              // chunks [c0, c1): their states cp[c0 .. c1 - 1]
+                    if (c1 > cpCap || nC + (c1 - c0) > CHUNK_CAP) { j.to = j.from; continue; }           // (cannot happen: the address range holds cpCap - 1 chunks; a round holds at most CAP x 12)
+                    if (c1 - 1 > S.ncp - 1) { hJump[nJ++] = MtJumpJob{S.cp, S.ncp - 1, c1 - 1}; S.ncp = c1; }
+                    for (int c = c0; c < c1; c++) hChunk[nC++] = MtChunkJob{S.cp + (size_t)c * 624, S.d() + (long long)c * MT_CHUNK, MT_CHUNK};
+                }
+                if (ok && nJ > 0) {
+                    ok = hipMemcpyAsync(dJump, hJump, (size_t)nJ * sizeof(MtJumpJob), hipMemcpyHostToDevice, stream) == hipSuccess;
+                    if (ok) hipLaunchKernelGGL(k_mt_jump, dim3(nJ), dim3(MTJ_T), 0, stream, dJump);
+                }
+                if (ok && nC > 0) {
+                    ok = hipMemcpyAsync(dChunk, hChunk, (size_t)nC * sizeof(MtChunkJob), hipMemcpyHostToDevice, stream) == hipSuccess;
+                    if (ok) hipLaunchKernelGGL(k_mt_chunk, dim3(nC), dim3(256), 0, stream, dChunk);
+                }
                 ok = ok && hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
             }
             nsGen += (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tG).count();

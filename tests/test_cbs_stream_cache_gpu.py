@@ -20,6 +20,7 @@ FIRST = 8 << 20            # MTS_FIRST_WORDS: the first extension of a stream
 HISTORY = 19937 * 128      # MT_HISTORY
 GRANULE = 16 << 20         # words per 64 MB piece of backing memory
 JOB = 48 << 20             # MTS_JOB_MAX_WORDS: the longest extension
+CHUNK = 4 << 20            # MT_CHUNK: a stream is generated chunk by chunk, every chunk from a state obtained by jump-ahead (k_mt_jump) — its seams are where a wrong jump would show
 
 
 def _expected(seed, pos, n):
@@ -34,6 +35,7 @@ def test_cached_stream_is_the_generators_output_at_random_offsets_and_across_ext
     c = 3
     full = O.mt_u32(int(np.uint32(seeds[c])), FIRST + JOB + 3 * GRANULE + 5000)
     spots = [0, 19937 - 50, 2 * 19937 - 7, 64 * 19937 - 300, HISTORY - 400, FIRST - 777, GRANULE - 123, FIRST + JOB - 999, FIRST + JOB + GRANULE - 5]
+    spots += [k * CHUNK - 1000 for k in (1, 2, 3, 5, 9, 14, 17)] + [CHUNK - 1, CHUNK, 19 * CHUNK - 1999]      # straddling chunk seams (2 000 words are read from every spot)
     spots += [int(x) for x in rng.randint(0, FIRST + JOB + 2 * GRANULE, 12)]
     for pos in spots:
         n = 2000
@@ -85,15 +87,40 @@ print("DONE")
 '''
 
 
-@pytest.mark.parametrize("mode,env", [("on", {}), ("on", {"CANVAS_CBS_CACHE_NO_VMM": "1"}), ("off", {"CANVAS_CBS_CACHE_GB": "0"}), ("tiny", {"CANVAS_CBS_CACHE_GB": "0.27"}),
+@pytest.mark.parametrize("mode,env", [("on", {}), ("on", {"CANVAS_CBS_CACHE_NO_VMM": "1"}), ("on", {"CANVAS_CBS_CACHE_JUMP_GENERATOR": "1"}), ("off", {"CANVAS_CBS_CACHE_GB": "0"}), ("tiny", {"CANVAS_CBS_CACHE_GB": "0.27"}),
                                       ("on", {"CANVAS_CBS_TEST_VERIFY": "1"}), ("tiny", {"CANVAS_CBS_CACHE_GB": "0.27", "CANVAS_CBS_TEST_VERIFY": "1"})])
 def test_cbs_equals_the_oracle_however_a_batch_gets_its_draws(mode, env):
-    """cache on (address-range form and fixed-allotment form), cache off, and a bound of four 64 MB pieces for four streams (every stream gets one piece: 16 M draws, less than
+    """cache on (address-range form, fixed-allotment form, and extended by jump-ahead + plain recurrence instead of the strided generator), cache off, and a bound of four 64 MB pieces for four streams (every stream gets one piece: 16 M draws, less than
     the loops read) — each twice in one process; with CANVAS_CBS_TEST_VERIFY every interval the device returns is checked against the statistic computed in the reference's
     order from a host generator at the batch's position, and the batch's first cached words against that generator"""
     e = dict(os.environ, **env)
     p = subprocess.run([sys.executable, "-c", CHILD, ROOT, mode], env=e, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and "DONE" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_cached_stream_from_the_jump_ahead_generator_is_the_generators_output():
+    """the same content check with the streams extended by k_mt_jump + k_mt_chunk (CANVAS_CBS_CACHE_JUMP_GENERATOR=1): chunk seams every 4 M words — where a wrong jump would show"""
+    child = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import oracle_lib as O
+from canvas_amd import Canvas
+cv = Canvas(0)
+seeds = O.cbs_seeds(24)
+CH = 4 << 20
+c = 5
+full = O.mt_u32(int(np.uint32(seeds[c])), 21 * CH + 5000)
+spots = [0, 623, 624, 19937, CH - 1, CH, CH + 1] + [k * CH - 1000 for k in (1, 2, 3, 4, 7, 12, 13, 20)] + [int(x) for x in np.random.RandomState(8).randint(0, 20 * CH, 10)]
+for pos in spots:
+    got = cv.cbs_stream_read(c, pos, 2000)
+    assert (got == full[pos:pos + 2000]).all(), (pos, np.nonzero(got != full[pos:pos + 2000])[0][:5])
+got = cv.cbs_stream_read(11, 0, 9 * CH + 77)
+assert (got == O.mt_u32(int(np.uint32(seeds[11])), 9 * CH + 77)).all()
+print("DONE")
+'''
+    p = subprocess.run([sys.executable, "-c", child, ROOT], env=dict(os.environ, CANVAS_CBS_CACHE_JUMP_GENERATOR="1"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "DONE" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
 
 
 def test_reading_beyond_the_bound_is_refused_not_wrong():
