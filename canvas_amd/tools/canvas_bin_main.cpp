@@ -22,10 +22,17 @@
 using namespace tool;
 
 // ---------------------------------------------------------------- FASTA (kmer.fa: upper case = start of a unique k-mer)
-struct FastaEntry { std::string name, bases; };
+// An entry whose sequence is ONE line (FastaWriter-style kmer.fa files and the samples of bench.py) is a VIEW into the mapped file: nothing is copied and the process holds no
+// anonymous copy of the reference (3.1 GB of a human genome: 0.1 s to copy on the host threads and another 0.11 s for the kernel to take back when the process leaves).  An entry
+// folded into lines is copied with its line ends dropped, as before.
+struct FastaEntry {
+    std::string name, owned; const char* view = nullptr; size_t viewLen = 0; std::shared_ptr<MappedFile> keep;
+    const char* data() const { return view ? view : owned.data(); }
+    size_t size() const { return view ? viewLen : owned.size(); }
+};
 // the file is mapped, the entry headers are located in one scan and the entries are copied (line ends dropped) on several threads
 static bool read_fasta(const std::string& path, const std::string* only, std::vector<FastaEntry>& out) {
-    MappedFile mf; if (!mf.open(path)) return false;
+    std::shared_ptr<MappedFile> mfp = std::make_shared<MappedFile>(); MappedFile& mf = *mfp; if (!mf.open(path)) return false;
     const char* p = mf.p; const size_t n = mf.n;
     struct Ent { size_t hdr, seq, end; std::string name; };
     std::vector<Ent> ents;
@@ -52,11 +59,21 @@ static bool read_fasta(const std::string& path, const std::string* only, std::ve
     out.resize(base + keep.size());
     parallel_for((int64_t)keep.size(), [&](int64_t k) {
         const Ent& e = ents[keep[(size_t)k]]; FastaEntry& fe = out[base + (size_t)k];
-        fe.name = e.name; fe.bases.clear(); fe.bases.reserve(e.end - e.seq);
+        fe.name = e.name; fe.owned.clear(); fe.view = nullptr; fe.viewLen = 0;
+        {   // one line?  (nothing but line ends behind the first line end)
+            const char* le = (const char*)memchr(p + e.seq, '\n', e.end - e.seq); const char* stop = le ? le : p + e.end;
+            bool single = true; for (const char* q = stop; q < p + e.end; q++) if (*q != '\n' && *q != '\r') { single = false; break; }
+            if (single && !getenv("CANVAS_TOOL_COPY_FASTA")) {
+                const char* te = stop; while (te > p + e.seq && te[-1] == '\r') te--;
+                fe.view = p + e.seq; fe.viewLen = (size_t)(te - (p + e.seq)); fe.keep = mfp;
+                return;
+            }
+        }
+        fe.owned.reserve(e.end - e.seq);
         for (const char* q = p + e.seq; q < p + e.end;) {
             const char* le = (const char*)memchr(q, '\n', (size_t)(p + e.end - q)); const char* stop = le ? le : p + e.end;
             const char* te = stop; while (te > q && te[-1] == '\r') te--;
-            fe.bases.append(q, (size_t)(te - q));
+            fe.owned.append(q, (size_t)(te - q));
             q = le ? le + 1 : p + e.end;
         }
     });
@@ -333,8 +350,8 @@ int main(int argc, char** argv) {
             bool gcAvailable = true; for (auto& b : it->second) if (b.gc < 0) gcAvailable = false;
             if (!gcAvailable) {                                                       // PopulateBinGC (:163-181)
                 std::vector<FastaEntry> fa; if (!read_fasta(ref, &chromName, fa) || fa.empty()) { fprintf(stderr, "CanvasBin: chromosome %s not found in %s\n", chromName.c_str(), ref.c_str()); return 1; }
-                const std::string& bases = fa[0].bases;
-                for (auto& b : it->second) { double nt = 0, gcn = 0; for (int p = b.start; p < b.stop && p < (int)bases.size(); p++) { if (bases[p] == 'n') continue; nt++; const char ch = bases[p]; if (ch == 'C' || ch == 'c' || ch == 'G' || ch == 'g') gcn++; }
+                const char* bases = fa[0].data(); const size_t nbases = fa[0].size();
+                for (auto& b : it->second) { double nt = 0, gcn = 0; for (int p = b.start; p < b.stop && p < (int)nbases; p++) { if (bases[p] == 'n') continue; nt++; const char ch = bases[p]; if (ch == 'C' || ch == 'c' || ch == 'G' || ch == 'g') gcn++; }
                     b.gc = nt > 0 ? (int)(100 * gcn / nt) : 0; }
             }
             long u = 0; if (int rc = bin_fragments(bam, chromName, it->second, u)) return rc;
@@ -358,7 +375,7 @@ int main(int argc, char** argv) {
         // ---- phase 1: CalculateSampleHits / BinOneGenomicInterval (CanvasBin.cs:765-792)
         std::vector<FastaEntry> fa;
         if (!read_fasta(ref, &chrom, fa) || fa.empty()) { fprintf(stderr, "CanvasBin: chromosome %s not found in %s\n", chrom.c_str(), ref.c_str()); return 1; }
-        Inter d; d.name = chrom; d.len = (int64_t)fa[0].bases.size();
+        Inter d; d.name = chrom; d.len = (int64_t)fa[0].size();
         const int64_t L = d.len, words = (L + 63) / 64;
         std::vector<uint64_t> mw(words, 0);
         d.hits.assign(L, 0); if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) d.frag.assign(L, 0);
@@ -368,7 +385,7 @@ int main(int argc, char** argv) {
         if (!need_ctx()) return 1;
         if (L > 0) {
             Dev dBases(ctx, L), dHits(ctx, L), dMask(ctx, words * 8);
-            TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dBases.p, fa[0].bases.data(), L));
+            TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dBases.p, fa[0].data(), L));
             TOOL_TRY(ctx, canvas_memcpy_h2d(ctx, dHits.p, d.hits.data(), L));
             TOOL_TRY(ctx, canvas_mask_from_fasta(ctx, dBases.as<uint8_t>(), L, dMask.as<uint64_t>()));
             if (!filter.empty()) {
@@ -427,7 +444,7 @@ int main(int argc, char** argv) {
     ph.mark("read");
     // chromosomes in FASTA order that have an intermediate (CanvasBin.cs:506-540)
     std::vector<const FastaEntry*> order; std::vector<Inter*> data;
-    for (auto& e : fa) { auto it = byChrom.find(e.name); if (it == byChrom.end()) continue; if ((int64_t)e.bases.size() != it->second->len) { fprintf(stderr, "CanvasBin: length of %s differs between the reference and the intermediate file\n", e.name.c_str()); return 1; } order.push_back(&e); data.push_back(it->second.get()); }
+    for (auto& e : fa) { auto it = byChrom.find(e.name); if (it == byChrom.end()) continue; if ((int64_t)e.size() != it->second->len) { fprintf(stderr, "CanvasBin: length of %s differs between the reference and the intermediate file\n", e.name.c_str()); return 1; } order.push_back(&e); data.push_back(it->second.get()); }
     const int nchr = (int)order.size();
     if (nchr == 0) { fprintf(stderr, "CanvasBin: no chromosome to bin\n"); return 1; }
     ExitStamp es3("input planes freed on the device");
@@ -454,7 +471,7 @@ int main(int argc, char** argv) {
         for (int c = 0; c < nchr; c++) {
             const int s = c & 1; int64_t sat = 0;
             pRef[c] = (const uint64_t*)(base + offR[c]); pPlanes[c] = (const uint64_t*)(base + offH[c]);
-            const bool ok = canvas_pack_reference_host((const uint8_t*)order[c]->bases.data(), data[c]->maskWords.data(), len[c], sRef[s].get(), &pos0[c], 0) == 0 &&
+            const bool ok = canvas_pack_reference_host((const uint8_t*)order[c]->data(), data[c]->maskWords.data(), len[c], sRef[s].get(), &pos0[c], 0) == 0 &&
                             canvas_pack_hits_host(data[c]->hits_data(), len[c], sHit[s].get(), &sat, 0) == 0;
             if (up.joinable()) up.join();
             if (!ok) { fprintf(stderr, "CanvasBin: packing %s failed\n", order[c]->name.c_str()); return 1; }
@@ -467,7 +484,7 @@ int main(int argc, char** argv) {
     for (int c = 0; !usePacked && c < nchr; c++) {
         const int64_t L = data[c]->len, words = (L + 63) / 64; len[c] = L; isAuto[c] = is_autosome(order[c]->name) ? 1 : 0;
         auto up = [&](const void* src, int64_t bytes, int64_t alloc) -> void* { devs.push_back(std::make_unique<Dev>(ctx, alloc)); void* p = devs.back()->p; if (bytes > 0 && canvas_memcpy_h2d(ctx, p, src, bytes) != 0) return nullptr; return p; };
-        pBases[c] = (const uint8_t*)up(order[c]->bases.data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits_data(), L, L + 64); pMask[c] = (const uint64_t*)up(data[c]->maskWords.data(), words * 8, words * 8 + 64);
+        pBases[c] = (const uint8_t*)up(order[c]->data(), L, L + 64); pHits[c] = (const uint8_t*)up(data[c]->hits_data(), L, L + 64); pMask[c] = (const uint64_t*)up(data[c]->maskWords.data(), words * 8, words * 8 + 64);
         if (mode == CANVAS_MODE_GC_CONTENT_WEIGHTED) { if ((int64_t)data[c]->frag.size() != L) { fprintf(stderr, "CanvasBin: %s has no fragment lengths (was the intermediate written with -m GCContentWeighted?)\n", order[c]->name.c_str()); return 1; } pFrag[c] = (const int16_t*)up(data[c]->frag.data(), L * 2, L * 2 + 64); }
         if (!pBases[c] || !pHits[c] || !pMask[c]) { fprintf(stderr, "CanvasBin: upload failed: %s\n", canvas_last_error(ctx)); return 1; }
     }
