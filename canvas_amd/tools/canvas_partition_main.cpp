@@ -11,6 +11,7 @@
 // fills for every chromosome of the coverage file when -v is given and leaves empty otherwise (Segmentation.cs:78-79, 158-168).  The allele frequencies themselves
 // never reach the Wavelets method (AdjustBreakpoints gets null, WaveletsRunner.cs:71), so this tool only checks that the -v file exists.
 #include "tool_common.hpp"
+#include <atomic>
 #include <algorithm>
 #include <set>
 using namespace tool;
@@ -259,33 +260,49 @@ int main(int argc, char** argv) {
     for (size_t s = 0; s < samples.size(); s++) {
         Sample& S = samples[s];
         struct OutRow { uint32_t s, e; double cov; int id; int chrom; }; std::vector<OutRow> outRows;
-        int segmentNum = -1;
-        for (size_t c = 0; c < S.chromNames.size(); c++) {
+        // The segment id is a running counter over the whole file (SegmentationResultsProcessor.cs:17-129), but WHERE it advances is decided chromosome by chromosome: every
+        // chromosome is walked on its own host thread with a local counter, the counters are offset in file order afterwards (the walk of 4.7 M bins on one thread was half of
+        // the tool's "write" phase).
+        struct Row { uint32_t s, e; double cov; int id; };
+        const size_t nC = S.chromNames.size();
+        std::vector<std::vector<Row>> rowsC(nC); std::vector<int> incC(nC, 0); std::atomic<int> badChrom(-1);
+        parallel_for((int64_t)nC, [&](int64_t ci) {
+            const size_t c = (size_t)ci;
             const std::string& chrom = S.chromNames[c];
-            std::set<uint32_t> starts; auto mit = merged.find(chrom); if (mit != merged.end()) for (auto& sg : mit->second) starts.insert(sg.first);
+            std::vector<uint32_t> starts; auto mit = merged.find(chrom); if (mit != merged.end()) for (auto& sg : mit->second) starts.push_back(sg.first);
+            std::sort(starts.begin(), starts.end());
             const std::vector<std::pair<int, int>>* ex = nullptr; auto eit = excluded.find(chrom); if (eit != excluded.end()) ex = &eit->second;
             const std::vector<PloidyIv>* pl = nullptr; if (havePloidy) { auto pit = ploidyByChrom.find(chrom); if (pit != ploidyByChrom.end()) pl = &pit->second; }
-            size_t exIdx = 0; uint32_t prevEnd = 0;
-            struct Row { uint32_t s, e; double cov; int id; }; std::vector<Row> rows;
+            size_t exIdx = 0; uint32_t prevEnd = 0; int local = 0;                      // local: advances of the counter inside this chromosome so far
+            std::vector<Row>& rows = rowsC[c]; rows.reserve((size_t)(S.off[c + 1] - S.off[c]));
             for (int64_t b = S.off[c]; b < S.off[c + 1]; b++) {
                 uint32_t st = S.start[b], en = S.end[b];
-                bool newSeg = starts.count(st) > 0;
+                bool newSeg = std::binary_search(starts.begin(), starts.end(), st);
                 if (ex) { while (exIdx < ex->size() && (int64_t)(*ex)[exIdx].second < (int64_t)prevEnd) exIdx++;
                     if (exIdx < ex->size()) { int mid = ((*ex)[exIdx].first + (*ex)[exIdx].second) / 2; if ((int64_t)prevEnd < mid && (int64_t)en >= mid) newSeg = true; } }
                 if (prevEnd > 0 && maxInterBinDist >= 0 && (int64_t)prevEnd + maxInterBinDist < (int64_t)st && !newSeg) newSeg = true;
                 if (!newSeg && pl) {                                          // SegmentationResultsProcessor.cs:117-128
                     const int u = is_uniform_reference_ploidy(*pl, prevEnd > 0 ? (int)prevEnd : 1, (int)en);
-                    if (u < 0) { fprintf(stderr, "CanvasPartition: reference ploidy outside 0..4 on %s (the reference throws IndexOutOfRangeException)\n", chrom.c_str()); return 1; }
+                    if (u < 0) { int expect = -1; badChrom.compare_exchange_strong(expect, (int)c); return; }
                     if (!u) newSeg = true;
                 }
-                if (newSeg) segmentNum++;
-                rows.push_back({st, en, S.cov[b], segmentNum});
+                if (newSeg) local++;
+                rows.push_back({st, en, S.cov[b], local});
                 prevEnd = en;
             }
+            incC[c] = local;
             // bins of a segment are written ordered by start (SegmentWithBins.Bins, Models/SegmentWithBins.cs:11-14); OrderBy is stable
             for (size_t g0 = 0; g0 < rows.size();) { size_t g1 = g0; while (g1 < rows.size() && rows[g1].id == rows[g0].id) g1++;
-                std::stable_sort(rows.begin() + g0, rows.begin() + g1, [](const Row& x, const Row& y) { return x.s < y.s; }); g0 = g1; }
-            for (auto& r : rows) outRows.push_back({r.s, r.e, r.cov, r.id, (int)c});
+                if (!std::is_sorted(rows.begin() + g0, rows.begin() + g1, [](const Row& x, const Row& y) { return x.s < y.s; }))
+                    std::stable_sort(rows.begin() + g0, rows.begin() + g1, [](const Row& x, const Row& y) { return x.s < y.s; });
+                g0 = g1; }
+        });
+        if (badChrom.load() >= 0) { fprintf(stderr, "CanvasPartition: reference ploidy outside 0..4 on %s (the reference throws IndexOutOfRangeException)\n", S.chromNames[(size_t)badChrom.load()].c_str()); return 1; }
+        {
+            std::vector<size_t> at(nC + 1, 0); std::vector<int> base(nC, -1); int segmentNum = -1;
+            for (size_t c = 0; c < nC; c++) { at[c + 1] = at[c] + rowsC[c].size(); base[c] = segmentNum; segmentNum += incC[c]; }
+            outRows.resize(at[nC]);
+            parallel_for((int64_t)nC, [&](int64_t ci) { const size_t c = (size_t)ci; size_t o = at[c]; for (auto& r : rowsC[c]) outRows[o++] = OutRow{r.s, r.e, r.cov, base[c] + r.id, (int)c}; std::vector<Row>().swap(rowsC[c]); });
         }
         if (!write_gz_rows(outFiles[s], (int64_t)outRows.size(), [&](int64_t i, std::string& o) { const OutRow& r = outRows[(size_t)i];
                 o += S.chromNames[(size_t)r.chrom]; o.push_back('\t'); append_uint(o, r.s); o.push_back('\t'); append_uint(o, r.e); o.push_back('\t'); o += format_g(r.cov, 15); o.push_back('\t'); append_int(o, r.id); }))
