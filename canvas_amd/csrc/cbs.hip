@@ -2489,15 +2489,19 @@ struct SvcRes { hipStream_t stream = nullptr; PermReq* dReqs = nullptr; PermReq*
 #define SVC_REQ_CAP 32
 // the device side of a launcher, created on its first use — or ahead of it by EngineCache::warm (canvas_cbs_prefetch): a stream costs ~5 ms on this runtime, and seven
 // launchers creating theirs at the start of the first call were 60 ms of it
-static int32_t svc_res_create(canvas_ctx* ctx, SvcRes* res) {
-    if (res->stream) return CANVAS_OK;
-    CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking));
-    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dReqs, SVC_REQ_CAP * sizeof(PermReq)));
-    CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hReqs, SVC_REQ_CAP * sizeof(PermReq), hipHostMallocDefault));
-    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dArc, 64 * sizeof(ArcReq)));
-    CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hArc, 64 * sizeof(ArcReq), hipHostMallocDefault));
-    CANVAS_HIP_TRY(ctx, hipMalloc((void**)&res->dArcP, 64 * sizeof(ArcPReq)));
-    CANVAS_HIP_TRY(ctx, hipHostMalloc((void**)&res->hArcP, 64 * sizeof(ArcPReq), hipHostMallocDefault));
+// (quiet = the background warmer: it must not write the context's error string, which belongs to the thread that makes the calls)
+static int32_t svc_res_create(canvas_ctx* ctx, SvcRes* res, bool quiet = false) {
+    if (res->stream && res->hArcP) return CANVAS_OK;
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    if (!res->stream) step(hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking));
+    if (e == hipSuccess && !res->dReqs) step(hipMalloc((void**)&res->dReqs, SVC_REQ_CAP * sizeof(PermReq)));
+    if (e == hipSuccess && !res->hReqs) step(hipHostMalloc((void**)&res->hReqs, SVC_REQ_CAP * sizeof(PermReq), hipHostMallocDefault));
+    if (e == hipSuccess && !res->dArc) step(hipMalloc((void**)&res->dArc, 64 * sizeof(ArcReq)));
+    if (e == hipSuccess && !res->hArc) step(hipHostMalloc((void**)&res->hArc, 64 * sizeof(ArcReq), hipHostMallocDefault));
+    if (e == hipSuccess && !res->dArcP) step(hipMalloc((void**)&res->dArcP, 64 * sizeof(ArcPReq)));
+    if (e == hipSuccess && !res->hArcP) step(hipHostMalloc((void**)&res->hArcP, 64 * sizeof(ArcPReq), hipHostMallocDefault));
+    if (e != hipSuccess) { (void)hipGetLastError(); if (!quiet) ctx->err = std::string("canvas_cbs: creating a launcher's stream / request tables: ") + hipGetErrorString(e); return CANVAS_ERR_HIP; }
     return CANVAS_OK;
 }
 struct PermService {
@@ -3114,8 +3118,7 @@ struct EngineCache {
             for (int i = 0; i < nSvc; i++) {
                 { std::lock_guard<std::mutex> lk2(mu); if (dying) break; }
                 SvcRes* r = svc_take();
-                std::string keep = ctx->err;
-                if (svc_res_create(ctx, r) != CANVAS_OK) { (void)hipGetLastError(); ctx->err = keep; }
+                (void)svc_res_create(ctx, r, true);      // (a failure leaves a partly made entry: the launcher that takes it completes it, or reports the error, on its own thread)
                 made.push_back(r);
             }
             for (SvcRes* r : made) svc_give(r);

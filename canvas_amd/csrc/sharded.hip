@@ -454,8 +454,13 @@ extern "C" int32_t canvas_sharded_stats(canvas_ctx* ctx, int64_t* h_out6) {
 static int32_t exchange_lists(canvas_ctx* ctx, const std::vector<int32_t>& mine, int32_t localErr, const std::string& localMsg, int64_t hardMax, const char* what, std::vector<std::vector<int32_t>>& all) {
     const int W = ctx->nranks;
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-    int64_t maxPer = std::min<int64_t>(hardMax, 1 << 16);
-    for (int attempt = 0; attempt < 2; attempt++) {
+    // three sizes: 8 192 words per rank (a WGS sample's segment lists are a few hundred words, its breakpoint lists a few thousand: 32 KB per rank through the collective and
+    // W x 32 KB back to the host, where round 5 moved 256 KB per rank every time), then 2^18, then the hard bound (every rank takes the same step: the counts are the same everywhere)
+    const int64_t first = cvx_hook("CANVAS_SHARDED_LIST_FIRST") ? std::max(4, atoi(cvx_hook("CANVAS_SHARDED_LIST_FIRST"))) : (1 << 13);      // (test hook: a first size the lists overflow)
+    const int64_t sizes[3] = {std::min<int64_t>(hardMax, first), std::min<int64_t>(hardMax, std::max<int64_t>(first * 4, cvx_hook("CANVAS_SHARDED_LIST_FIRST") ? first * 4 : (1 << 18))), hardMax};
+    int64_t maxPer = sizes[0];
+    for (int attempt = 0; attempt < 3; attempt++) {
+        maxPer = sizes[attempt];
         const size_t front = al((size_t)(1 + maxPer) * 4 + 256);
         int32_t rc = canvas_ws_reserve(ctx, front + al((size_t)maxPer * 4) + al((size_t)W * (1 + (size_t)maxPer) * 4) + 4096); if (rc) return rc;
         char* wsb = (char*)ctx->ws + front;
@@ -471,7 +476,7 @@ static int32_t exchange_lists(canvas_ctx* ctx, const std::vector<int32_t>& mine,
         }
         bool overflow = false;
         for (int r = 0; r < W; r++) if (counts[(size_t)r] >= maxPer) overflow = true;
-        if (overflow && attempt == 0 && maxPer < hardMax) { maxPer = hardMax; continue; }
+        if (overflow && attempt < 2 && maxPer < hardMax) continue;
         if (overflow) CANVAS_FAIL(ctx, CANVAS_ERR_CAPACITY, std::string(what) + ": the lists do not fit the exchange");
         std::vector<int32_t> flat((size_t)W * (1 + (size_t)maxPer));
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(flat.data(), dAll, flat.size() * 4, hipMemcpyDeviceToHost, ctx->stream));

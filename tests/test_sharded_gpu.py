@@ -313,9 +313,10 @@ def _partition_coverage():
     return cov, off
 
 
-def _partition_worker(rank, world, port, q, fail):
+def _partition_worker(rank, world, port, q, fail, list_first=None):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        if list_first: os.environ["CANVAS_SHARDED_LIST_FIRST"] = str(list_first)       # the list exchange starts with a size the lists overflow: every rank steps up together
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -345,13 +346,13 @@ def _partition_worker(rank, world, port, q, fail):
         q.put((rank, "error", traceback.format_exc()))
 
 
-def _run_partition(fail):
+def _run_partition(fail, list_first=None):
     import torch.multiprocessing as mp
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_partition_worker, args=(r, world, port, q, fail)) for r in range(world)]
+    procs = [ctx.Process(target=_partition_worker, args=(r, world, port, q, fail, list_first)) for r in range(world)]
     for p in procs: p.start()
     got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs: p.join(60)
@@ -388,6 +389,19 @@ def test_sharded_cbs_and_wavelets_equal_the_single_rank_result_and_the_oracle():
         for rank, _, res in got:
             assert res["wv%d" % int(germ)] == single, (rank, germ)
         assert single[-1] == []                                   # below MinSize: not segmented
+
+
+@pytest.mark.parametrize("first", [4, 24])
+def test_sharded_lists_that_overflow_the_first_exchange_size(first):
+    """the list exchange of canvas_cbs_sharded / canvas_wavelets_sharded takes three sizes (8 192 words per rank, 2^18, the hard bound); with a first size of 4 / 24 words the
+    lists of this sample overflow once / twice and every rank must step up together and end with the lists of the default sizes"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ref = _run_partition(False)
+    got = _run_partition(False, list_first=first)
+    for (r0, _, a), (r1, _, b) in zip(ref, got):
+        assert b["error"] is None and a == b, (r0, r1)
 
 
 def test_sharded_partition_failure_is_collective():
