@@ -9,11 +9,13 @@
 //                 the row into the genome row; one more workgroup turns the chunk totals into the chunks' output offsets.
 //   k_cg_apply    IN PLACE: every workgroup loads its whole chunk into registers, says so (a flag per chunk), reads the global median off the genome row while the loads are
 //                 in flight, waits for the chunks its output range reaches back into, and stores the surviving bins — normalised (:189-195) — at their final position.
-//                 The chunk is a TICKET, always: a workgroup then only ever waits for workgroups that started before it — each of them is resident and sets its flag
-//                 before it waits for anybody — so the wait chain ends whatever else runs on the device.  (Rounds 4-5 used the workgroup's index while the grid
-//                 fitted the device, 2 us less; that needs every workgroup of the grid resident at once, which another process's kernels, a CU mask or a second
-//                 spinning kernel can break: a hang.  The wait is bounded on top of that: a flag that does not come within ~4 s raises CG_FAIL_STALL and the call
-//                 returns an error instead of never returning.)
+//                 No workgroup can wait for ever, whatever else runs on the device: the wait for a chunk in front is BOUNDED (~0.3 ms), and a workgroup whose wait
+//                 runs out puts its bins — they are in its registers — aside in a spill area instead of at their final place, says so (defer[chunk]) and LEAVES, which
+//                 frees its CU for the workgroups it was waiting for; k_cg_fixup moves the spilled chunks to their place when the launch is over (every chunk has been
+//                 read by then).  So the chunk can be the workgroup's index while the grid fits the device (round 5's fast path: on an empty device whoever is waited
+//                 for is running) without the hang that path had when another process's kernels, a CU mask or a second spinning kernel kept part of the grid from
+//                 being resident; a grid larger than the device takes its chunks by ticket (a workgroup then only waits for workgroups that have started).  The ticket
+//                 for every grid cost 3.5 us of 47 (256 atomics on one word); the deferral costs nothing until it is needed.
 // (A first version took the decisions in the LAST workgroup of k_cg_count / k_cg_medians: 14 + 9 us of tails behind an arrival ticket — measured with CANVAS_CG_CUT, the timing
 // hook below.  Every decision is a function of a few hundred words; recomputing it where it is needed costs less than handing it over.)
 // (Statistics and apply as ONE launch — the first 102 tickets the statistics roles, the others chunk workgroups that load their chunk and then wait for the roles' count — was
@@ -47,15 +49,14 @@
 #define CG_FAIL_VALUE 2u               // a count that is not a whole number in [0, 2^30)
 #define CG_FAIL_THRESHOLD 4u           // buckets with fewer than 100 autosomal bins survive: their medians are neighbour-weighted quantiles (CanvasClean.cs:178-187)
 #define CG_FAIL_WINDOW 8u              // a median lies outside the counter window
-#define CG_FAIL_STALL 16u              // k_cg_apply: a chunk in front of this one never reported its loads (cannot happen in ticket order unless the device stops scheduling a resident
-                                       // workgroup); the arrays are partly rewritten: the call fails with an error, nothing falls back
-#define CG_SPIN_LIMIT (1u << 27)       // s_sleep(1) rounds (64 clocks each, ~30 ns) a workgroup waits for one flag: ~4 s
+#define CG_SPIN_LIMIT (1u << 13)       // s_sleep(1) rounds (64 clocks each, ~35 ns with the load) a workgroup waits for the chunks in front of it before it defers: ~0.3 ms
 
 struct CgDev {
     double medians[NGC]; double globalMedian;
     unsigned long long nFinal;         // bins that survive (= n when nothing is stripped)
     unsigned long long nAuto;          // autosomal bins that survive (the list globalMedian is taken from)
     uint32_t fail, failWin, active, threshold; int32_t lo; uint32_t failApply;       // failWin: raised by bucket workgroups of k_cg_medians; failApply: by k_cg_apply (only the host reads it)
+    uint32_t nDeferred, padD;          // chunks k_cg_apply put aside (k_cg_fixup moves them)
     uint8_t keep[NGC + 3];
     uint32_t off[CG_MAXG + 1];         // output offset of every chunk
 };
@@ -70,14 +71,17 @@ struct CgArgs {
     int32_t *chr, *start, *stop, *gc; float* count;
     uint32_t* slab;                    // [G][CG_SLAB]
     uint32_t* tab;                     // [G][CG_TABW]
+    int32_t *spChr, *spStart, *spStop, *spGc; float* spCount;      // spill area of k_cg_apply (n entries per column; a deferred chunk's survivors from b0 on)
+    uint32_t* defer;                   // [G] 0, or 1 + the number of bins the chunk put aside (zeroed by k_cg_count)
     CgDev* D; CgState* S;
 };
-struct CgPack { CgArgs a[CG_MAXB]; uint8_t isAuto[256]; int32_t minBinsPerGc, cut, ticket, pad; };      // cut: timing hook (CANVAS_CG_CUT: the kernels stop early; results are void)
+struct CgPack { CgArgs a[CG_MAXB]; uint8_t isAuto[256]; int32_t minBinsPerGc, cut, ticket; uint32_t spin; };      // cut: timing hook (CANVAS_CG_CUT: the kernels stop early; results are void)
 
 __global__ void __launch_bounds__(CG_T) k_cg_count(const CgPack P) {
     const CgArgs& A = P.a[blockIdx.y];
     const int w = (int)blockIdx.x, t = (int)threadIdx.x;
     if (w >= A.G) return;
+    if (t == 0) A.defer[w] = 0u;
     __shared__ uint32_t sH[NGC * CG_LROW];
     __shared__ uint32_t sOther[NGC], sBelow[NGC], sAbove[NGC], sBad;
     __shared__ uint8_t sAuto[256];
@@ -257,7 +261,7 @@ __global__ void __launch_bounds__(CG_T) k_cg_medians(const CgPack P) {
         if (t < NGC) D->keep[t] = sKeep[t];
         if (t == 0) {
             D->fail = dec.fail; D->active = dec.active ? 1u : 0u; D->threshold = (uint32_t)dec.threshold; D->lo = lo;
-            D->nFinal = dec.active ? dec.kept : (unsigned long long)A.n; D->nAuto = dec.keptAuto; D->globalMedian = 0.0; D->failApply = 0u;
+            D->nFinal = dec.active ? dec.kept : (unsigned long long)A.n; D->nAuto = dec.keptAuto; D->globalMedian = 0.0; D->failApply = 0u; D->nDeferred = 0u;
         }
         if (!live) return;
         const int wv = t >> 6, l = t & 63;
@@ -347,11 +351,13 @@ __global__ void __launch_bounds__(CG_T) k_cg_apply(const CgPack P) {
     __shared__ uint32_t sWc[CG_BPT * CG_NW], sBase[CG_BPT * CG_NW], sPart[4];
     __shared__ unsigned long long sWave[CG_NW];
     __shared__ int sPick[2]; __shared__ int sStall;
-    // chunks in the order the workgroups start: a workgroup only ever waits for chunks that are already being worked on (see the header: always, not only when the grid
-    // exceeds the device)
+    // the chunk: the workgroup's index, or — a grid with more workgroups than the device has places for them — a ticket, i.e. the order in which the workgroups start (see the header)
     if (t == 0) {
-        const uint32_t id = __hip_atomic_fetch_add(&A.S->tick[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)id == A.G - 1) __hip_atomic_store(&A.S->tick[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every chunk is handed out: ready for the next call
+        uint32_t id = blockIdx.x;
+        if (P.ticket) {
+            id = __hip_atomic_fetch_add(&A.S->tick[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)id == A.G - 1) __hip_atomic_store(&A.S->tick[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every chunk is handed out: ready for the next call
+        }
         sW = (int)id;
         sPick[0] = -1; sPick[1] = -1;
     }
@@ -414,15 +420,24 @@ __global__ void __launch_bounds__(CG_T) k_cg_apply(const CgPack P) {
         for (int q = first; q < w && !stalled; q++) {
             uint32_t spins = 0;
             while (__hip_atomic_load(&A.S->ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
-                if (++spins > CG_SPIN_LIMIT) { stalled = true; break; }
+                if (spins++ >= P.spin) { stalled = true; break; }      // (one budget for all the chunks in front)
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        if (stalled) __hip_atomic_fetch_or(&D->failApply, CG_FAIL_STALL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sStall = stalled ? 1 : 0;
     }
     __syncthreads();
-    if (sStall) return;                                            // never write behind a chunk that may not have been read: the host reports the stall
+    // never write behind a chunk that may not have been read: a workgroup whose wait ran out puts its survivors aside (from b0 on in the spill columns, in output order) and
+    // leaves — its CU is free for whoever it was waiting for — and k_cg_fixup moves them when the launch is over
+    const bool deferred = sStall != 0;
+    const gptr<int32_t> oChr = deferred ? as_global(A.spChr) : chr, oStart = deferred ? as_global(A.spStart) : start, oStop = deferred ? as_global(A.spStop) : stop, oGc = deferred ? as_global(A.spGc) : gc;
+    const gptr<float> oCnt = deferred ? as_global(A.spCount) : cnt;
+    const int64_t oBase = deferred ? b0 : (int64_t)off;
+    if (deferred && t == 0) {
+        uint32_t kept = 0; for (int k = 0; k < nslots; k++) kept += sWc[k];
+        A.defer[w] = 1u + kept;
+        __hip_atomic_fetch_add(&D->nDeferred, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int j = 0; j < CG_BPT; j++) {
         if (j >= A.bpt) continue;
@@ -430,12 +445,27 @@ __global__ void __launch_bounds__(CG_T) k_cg_apply(const CgPack P) {
         const bool kp = j * CG_T + t < len && sKeep[gj] != 0;
         const unsigned long long m = __ballot(kp);
         if (kp) {
-            const int64_t o = (int64_t)off + sBase[j * CG_NW + wv] + (uint32_t)__popcll(m & ((1ull << l) - 1ull));
+            const int64_t o = oBase + sBase[j * CG_NW + wv] + (uint32_t)__popcll(m & ((1ull << l) - 1ull));
             const double median = sMed[gj];
             const float y = median > 0.0 ? (float)(gm * (double)x[j] / median) : x[j];          // CanvasClean.cs:189-195
-            chr[o] = cg[j] & 0xFFFF; start[o] = s[j]; stop[o] = e[j]; gc[o] = gj; cnt[o] = y;
+            oChr[o] = cg[j] & 0xFFFF; oStart[o] = s[j]; oStop[o] = e[j]; oGc[o] = gj; oCnt[o] = y;
         }
     }
+}
+
+// the chunks k_cg_apply put aside, moved to their place (launched only when there are any; every chunk of the sample has been read by now)
+__global__ void __launch_bounds__(CG_T) k_cg_fixup(const CgPack P) {
+    const CgArgs& A = P.a[blockIdx.y];
+    const int w = (int)blockIdx.x, t = (int)threadIdx.x;
+    if (w >= A.G) return;
+    const uint32_t d = A.defer[w];
+    if (d == 0) return;
+    const int kept = (int)(d - 1u);
+    const int64_t b0 = (int64_t)w * A.chunk, o0 = (int64_t)A.D->off[w];
+    const gptr<const int32_t> sc = as_global((const int32_t*)A.spChr), ss = as_global((const int32_t*)A.spStart), se = as_global((const int32_t*)A.spStop), sg = as_global((const int32_t*)A.spGc);
+    const gptr<const float> sv = as_global((const float*)A.spCount);
+    const gptr<int32_t> chr = as_global(A.chr), start = as_global(A.start), stop = as_global(A.stop), gc = as_global(A.gc); const gptr<float> cnt = as_global(A.count);
+    for (int i = t; i < kept; i += CG_T) { chr[o0 + i] = sc[b0 + i]; start[o0 + i] = ss[b0 + i]; stop[o0 + i] = se[b0 + i]; gc[o0 + i] = sg[b0 + i]; cnt[o0 + i] = sv[b0 + i]; }
 }
 
 // ---------------------------------------------------------------- host side
@@ -463,9 +493,13 @@ static int32_t clean_gc_only(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t
         a.n = n; a.nchr = nchr; a.G = G; a.chunk = (int32_t)chunk; a.bpt = (int32_t)((chunk + CG_T - 1) / CG_T);
         a.chr = d_chr[s]; a.start = d_start[s]; a.stop = d_stop[s]; a.gc = d_gc[s]; a.count = d_count[s];
         sz.take<uint32_t>((size_t)G * CG_SLAB); sz.take<uint32_t>((size_t)G * CG_TABW);
+        for (int k = 0; k < 5; k++) sz.take<uint32_t>((size_t)n); sz.take<uint32_t>((size_t)G);      // the spill columns and the deferral flags (touched only when a workgroup defers)
         Gmax = std::max(Gmax, G);
     }
-    pack.ticket = 1;       // (k_cg_apply takes its chunk by ticket, always: see the header)
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) cus = 0;
+    pack.ticket = ((long long)Gmax * B > (long long)cus || cvx_hook("CANVAS_CG_TICKET")) ? 1 : 0;       // (the hook forces the ticket for the tests)
+    pack.spin = cvx_hook("CANVAS_CG_SPIN_LIMIT") ? (uint32_t)atoi(cvx_hook("CANVAS_CG_SPIN_LIMIT")) : CG_SPIN_LIMIT;      // (test hook: 0 = every workgroup that finds a chunk in front unread defers at once)
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     WsCarver ws(ctx->ws);
     CgDev* dD = ws.take<CgDev>(B);
@@ -473,6 +507,8 @@ static int32_t clean_gc_only(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t
     for (int s = 0; s < B; s++) {
         CgArgs& a = pack.a[s];
         a.slab = ws.take<uint32_t>((size_t)a.G * CG_SLAB); a.tab = ws.take<uint32_t>((size_t)a.G * CG_TABW);
+        a.spChr = (int32_t*)ws.take<uint32_t>((size_t)a.n); a.spStart = (int32_t*)ws.take<uint32_t>((size_t)a.n); a.spStop = (int32_t*)ws.take<uint32_t>((size_t)a.n); a.spGc = (int32_t*)ws.take<uint32_t>((size_t)a.n);
+        a.spCount = (float*)ws.take<uint32_t>((size_t)a.n); a.defer = ws.take<uint32_t>((size_t)a.G);
         a.D = dD + s; a.S = (CgState*)ctx->cg_state + s; a.epoch = epoch;
     }
     const size_t head = sizeof(CgDev);
@@ -489,13 +525,22 @@ static int32_t clean_gc_only(canvas_ctx* ctx, int B, const int64_t* h_n, int32_t
     for (int s = 0; s < B; s++) {
         const CgDev& H = *(const CgDev*)((const char*)ctx->pin + (size_t)s * head);
         if (H.fail & CG_FAIL_INDEX) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_clean: a bin has gc outside 0..100 or a chromosome index outside [0, nchr) (the reference throws IndexOutOfRangeException)");
-        if (H.failApply & CG_FAIL_STALL) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_clean: the in-place GC normalisation waited ~4 s for a workgroup that had started and never reported its loads (device not scheduling?); the sample's arrays are partly rewritten and must be reloaded");
+    }
+    {   // chunks that were put aside: moved now
+        bool any = false; long long nd = 0;
+        for (int s = 0; s < B; s++) { const CgDev& H = *(const CgDev*)((const char*)ctx->pin + (size_t)s * head); if (!(H.fail || H.failWin || H.failApply) && H.nDeferred) { any = true; nd += H.nDeferred; } }
+        if (any) {
+            hipLaunchKernelGGL(k_cg_fixup, dim3((unsigned)Gmax, (unsigned)B), dim3(CG_T), 0, ctx->stream, pack);
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            CANVAS_HIP_TRY(ctx, hipGetLastError());
+        }
+        ctx->cg_deferred += nd;
     }
     for (int s = 0; s < B; s++) {
         const CgDev& H = *(const CgDev*)((const char*)ctx->pin + (size_t)s * head);
         if (H.fail || H.failWin || H.failApply) continue;
         handled[s] = 1; h_n_out[s] = (int64_t)H.nFinal;
-        if (h_info) { int32_t info[8] = {0}; info[0] = (int32_t)h_n[s]; info[1] = (int32_t)h_n[s]; info[2] = (int32_t)H.nFinal; info[3] = (int32_t)H.nFinal; info[6] = 1; memcpy(h_info + 8 * s, info, sizeof info); }
+        if (h_info) { int32_t info[8] = {0}; info[0] = (int32_t)h_n[s]; info[1] = (int32_t)h_n[s]; info[2] = (int32_t)H.nFinal; info[3] = (int32_t)H.nFinal; info[6] = 1; info[7] = (int32_t)H.nDeferred; memcpy(h_info + 8 * s, info, sizeof info); }      // ([7]: chunks whose wait ran out and that k_cg_fixup moved)
     }
     return CANVAS_OK;
 }

@@ -51,6 +51,7 @@ struct canvas_ctx {
     int one_shot = 0;                   // canvas_set_one_shot: the host makes one call per method and exits — staging through pinned host memory is not worth its pinning
     std::shared_ptr<void> cbs_cache;     // cbs.hip: device / pinned buffers of the arc-search and permutation engines, kept between calls (a call used to spend tens of ms in hipMalloc / hipHostMalloc)
     std::shared_ptr<void> hmm_pool;      // hmm.hip: helper threads that fill the negative-binomial emission tables of a sample
+    long long cg_deferred = 0;           // clean_gc_only.hpp: chunks k_cg_apply has put aside so far (moved by k_cg_fixup): 0 on a device the grid has to itself
     void* cg_state = nullptr; unsigned cg_epoch = 0;     // clean_gc_only.hpp: tickets / genome row / chunk flags of the -g-only stage (zero between calls), call counter
     std::shared_ptr<void> clean_batch;   // clean_fast.hpp: the batch that clean_batch_enqueue queued (consumed by clean_batch_finish)
     void* comm = nullptr;  // ncclComm_t

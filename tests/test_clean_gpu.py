@@ -386,6 +386,41 @@ def test_clean_gc_only_equals_the_general_chain_and_batches(monkeypatch, clean_p
         assert (d["count"][:int(no)].cpu().numpy().view(np.uint32) == ex["count"].view(np.uint32)).all() and (d["start"][:int(no)].cpu().numpy() == ex["start"]).all()
 
 
+def test_clean_gc_only_deferred_chunks_are_moved_to_their_place(monkeypatch, clean_path):
+    """k_cg_apply's wait for the chunks in front of it is bounded: a workgroup whose wait runs out spills its bins and leaves, k_cg_fixup moves them afterwards.  With a budget
+    of zero (CANVAS_CG_SPIN_LIMIT=0) every workgroup that finds a chunk in front of it unread takes that path — the result must be the oracle's all the same, by index and by
+    ticket (CANVAS_CG_TICKET=1: what a grid larger than the device takes)"""
+    if clean_path != "device_driven":
+        pytest.skip("the -g-only stage belongs to the device-driven orchestration")
+    cv = get_canvas()
+    is_auto = synth.IS_AUTOSOME[:24]
+    is_y = np.zeros(24, np.uint8); is_y[-1] = 1
+    deferred_seen = 0
+    for ticket in (False, True):
+        if ticket: monkeypatch.setenv("CANVAS_CG_TICKET", "1")
+        monkeypatch.setenv("CANVAS_CG_SPIN_LIMIT", "0")
+        for seed, n in ((20260927 + 70, 2_600_000), (20260927 + 71, 300_000), (20260927 + 72, 40_000)):
+            bins = synth.generate_bins(seed, n); n = len(bins["chr"])              # (the generator returns a few bins fewer than asked for)
+            bins["count"] = np.round(bins["count"]).astype(np.float32)
+            ex = O.clean(bins["chr"], bins["start"], bins["stop"], bins["count"], bins["gc"], is_auto, is_y, CLEAN_GCNORM)
+            for rep in range(3):
+                dev = {k: to_dev(v, cv.device) for k, v in bins.items()}
+                import torch
+                torch.cuda.synchronize()
+                n_out, _, info = cv.clean(dev, n, is_auto, CLEAN_GCNORM)
+                assert info[6] == 1 and int(n_out) == len(ex["chr"]) < n            # (the sparse GC buckets are stripped: outputs move in front of their inputs, chunk after chunk)
+                for k in ("chr", "start", "stop", "gc"):
+                    assert (dev[k][:int(n_out)].cpu().numpy() == ex[k]).all(), (ticket, n, k)
+                assert (dev["count"][:int(n_out)].cpu().numpy().view(np.uint32) == ex["count"].view(np.uint32)).all()
+                deferred_seen += int(info[7])
+        monkeypatch.delenv("CANVAS_CG_SPIN_LIMIT")
+        # the default budget on a device the grid has to itself: nobody defers
+        dev = {k: to_dev(v, cv.device) for k, v in bins.items()}
+        _, _, info = cv.clean(dev, len(bins["chr"]), is_auto, CLEAN_GCNORM)
+        assert info[6] == 1 and info[7] == 0
+    assert deferred_seen > 0                                          # the spill path really ran
+
+
 _CG_CHILD = r"""
 import os, sys, time
 import numpy as np
@@ -396,6 +431,7 @@ import oracle_lib as O
 seed, loops, n = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 cv = Canvas(0)
 bins = synth.generate_bins(seed, n)
+n = len(bins["chr"])                                   # (the generator returns a few bins fewer than asked for)
 bins["count"] = np.round(bins["count"]).astype(np.float32)
 is_auto = synth.IS_AUTOSOME[:24]
 is_y = np.zeros(24, np.uint8); is_y[-1] = 1
