@@ -130,7 +130,7 @@ struct CfArgs {                      // one sample of the batch
     CfCq* cq; uint32_t* cqHist; SelTile* cqTiles;      // the counting selects (below)
     uint32_t* repl;                  // [CF_HREP][2 * NGC] GC counts of the survivors per replica (k_cf_flags_ab), then [CF_HREP][NGC] write cursors into the grouped keys (its last workgroup -> k_cf_scatter_ab)
     unsigned long long* dbg;         // profiling hook (CANVAS_CLEAN_DEBUG_CLOCKS=1): [64] wall-clock stamps of selected workgroups, else nullptr
-    uint32_t* tick;                  // [8] arrival tickets: 0 k_cf_size, 1 k_cf_flags_ab, 2 window role of k_cf_hist_lsd, 3 / 4 pick and run role of k_cf_pick_mad
+    uint32_t* tick;                  // [8][CF_TICK_WORDS] arrival tickets (cf_arrive_last): 0 k_cf_size, 1 k_cf_flags_ab, 2 window role of k_cf_hist_lsd, 3 / 4 pick and run role of k_cf_pick_mad
 };
 struct CfArgsPack { CfArgs a[CF_BYVAL]; uint8_t isAuto[256]; };
 #define CF_SAMPLE const CfArgs& A = AA[blockIdx.y]
@@ -146,12 +146,24 @@ template <class T> __device__ __forceinline__ T cf_ld(const T* p) { return *p; }
 __device__ __forceinline__ void cf_st_f64(double* p, double v) { cf_st(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v)); }
 __device__ __forceinline__ double cf_ld_f64(const double* p) { return *p; }
 // Arrival ticket (zero at launch): true in the workgroup that arrives last.  Every wave drains its own stores and atomics first, so whatever a workgroup published is
-// in memory before its ticket is.
-__device__ __forceinline__ bool cf_arrive_last(uint32_t* tick, uint32_t expected, int* sFlag) {
+// in memory before its ticket is.  TWO LEVELS: device-scope atomics on one address are performed one after the other at the memory side (~7 ns each), and the
+// workgroups of a streaming kernel all arrive within a few microseconds — 2 339 tickets on one word were 17 of k_cf_flags_ab's 53 us (measured by leaving the
+// ticket out).  So workgroup idx counts on sub-counter idx % CF_TICK_SUB (each on a 128-byte line of its own), and the last arrival of a sub-counter counts on the
+// top word: chains of expected / 32 + 32 instead of expected.
+#define CF_TICK_SUB 32
+#define CF_TICK_WORDS (32 * (1 + CF_TICK_SUB))          // words of one ticket: the top word and the sub-counters, 128 bytes apart
+__device__ __forceinline__ bool cf_arrive_last(uint32_t* tick, uint32_t idx, uint32_t expected, int* sFlag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int last = (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == expected) ? 1 : 0;
+        int last = 0;
+        if (expected <= 2 * CF_TICK_SUB) last = (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == expected) ? 1 : 0;
+        else {
+            const uint32_t r = idx % CF_TICK_SUB, members = (expected - r + CF_TICK_SUB - 1) / CF_TICK_SUB;       // indices below `expected` that are r modulo CF_TICK_SUB
+            // (the returned value is waited for before the top word is touched: every member's stores were drained before its own count)
+            if (__hip_atomic_fetch_add(tick + 32 * (1 + r), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == members)
+                last = (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == CF_TICK_SUB) ? 1 : 0;
+        }
         if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // buffer_inv sc1: this CU's L1 and the XCD's L2 hold nothing stale of what the others published
         *sFlag = last;
     }
@@ -239,7 +251,7 @@ __global__ void __launch_bounds__(1024) k_cf_size(const CfArgs* __restrict__ AA)
     if (lane_id() == 0 && neg) atomicAdd(&A.D->sizeBelow, (unsigned long long)neg);
     __syncthreads();
     for (int i = threadIdx.x; i < CF_SZ_LDS; i += 1024) { const uint32_t v = lh[i]; if (v) atomicAdd(&A.szHist[i], v); }
-    if (!cf_arrive_last(A.tick + 0, CF_SZ_GRID, &sLast)) return;
+    if (!cf_arrive_last(A.tick + 0 * CF_TICK_WORDS, blockIdx.x, CF_SZ_GRID, &sLast)) return;
     // ---- last workgroup: the size with cumulative count > index (the element at `index` of the sorted sizes)
     __shared__ unsigned long long sTot[1024 / 64];
     __shared__ int sFound;
@@ -576,7 +588,7 @@ __global__ void __launch_bounds__(256) k_cf_flags_ab(const CfArgs* __restrict__ 
     if (threadIdx.x == 0) cf_st(&A.dBlk[blockIdx.x], (unsigned long long)(sh[0] + sh[1] + sh[2] + sh[3]) | ((unsigned long long)(sh[4] + sh[5] + sh[6] + sh[7]) << 32));
     if (threadIdx.x < 2 * NGC && lh[threadIdx.x]) atomicAdd(&A.repl[(blockIdx.x % CF_HREP) * (2 * NGC) + threadIdx.x], lh[threadIdx.x]);
     if (blockIdx.x == 0) CF_STAMP(3);
-    const bool last = cf_arrive_last(A.tick + 1, (uint32_t)A.nb, &sLast);
+    const bool last = cf_arrive_last(A.tick + 1 * CF_TICK_WORDS, blockIdx.x, (uint32_t)A.nb, &sLast);
     if (blockIdx.x == 0) CF_STAMP(4);
     if (last) { CF_STAMP(5); cf_decide_gc(A); __syncthreads(); CF_STAMP(6); }
 }
@@ -692,12 +704,15 @@ __global__ void __launch_bounds__(1024) k_cf_hist_lsd(const CfArgs* __restrict__
     CF_SAMPLE;
     __shared__ __attribute__((aligned(16))) uint32_t lw[CQW];       // counters of the sweep role; scratch of the window role's last workgroup (its first 16 KB)
     int* const sLast = reinterpret_cast<int*>(&lw[CQW - 1]);
+    __shared__ uint32_t sBelowW;
+    uint32_t* const sBelow = &sBelowW;
     if ((int)blockIdx.x < nHist) {
         CfCq* __restrict__ C = A.cq;
         if (blockIdx.x >= C->ntiles) return;
         const SelTile T = A.cqTiles[blockIdx.x];
         const long long lo = C->lo;
         for (int i = threadIdx.x; i < CQW / 4; i += 1024) reinterpret_cast<uint4*>(lw)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x == 0) *sBelow = 0;
         __syncthreads();
         const gptr<const uint32_t> keys = as_global(A.keysG);
         uint32_t below = 0, bad = 0;
@@ -715,10 +730,13 @@ __global__ void __launch_bounds__(1024) k_cf_hist_lsd(const CfArgs* __restrict__
             const int64_t i = threadIdx.x < 4 ? T.begin + threadIdx.x : a1 + (threadIdx.x - 4);
             if (threadIdx.x < 4 ? i < a0 : i < T.end) cq_count_key(keys[i], lo, lw, below, bad);
         }
+        // keys under the window: summed over the workgroup first (LDS), ONE pair of device atomics per workgroup — a wave of 2 048 keys nearly always holds one, and
+        // 16 x ntiles atomics on the genome's word are performed one after the other at the memory side
         below = wave_reduce_add_u32(below);
-        if ((threadIdx.x & 63) == 0 && below) { atomicAdd(&C->below[T.seg], below); atomicAdd(&C->below[NGC], below); }
+        if ((threadIdx.x & 63) == 0 && below) atomicAdd(sBelow, below);
         if (bad) C->bad = 1u;
         __syncthreads();
+        if (threadIdx.x == 0 && *sBelow) { atomicAdd(&C->below[T.seg], *sBelow); atomicAdd(&C->below[NGC], *sBelow); }
         uint32_t* __restrict__ row = A.cqHist + (size_t)T.seg * CQW; uint32_t* __restrict__ all = A.cqHist + (size_t)NGC * CQW;
         for (int i = threadIdx.x; i < CQW; i += 1024) { const uint32_t v = lw[i]; if (v) { atomicAdd(&row[i], v); atomicAdd(&all[i], v); } }
         return;
@@ -770,7 +788,7 @@ __global__ void __launch_bounds__(1024) k_cf_hist_lsd(const CfArgs* __restrict__
             prevC = c;
         }
     }
-    if (cf_arrive_last(A.tick + 2, (uint32_t)nLsd, sLast)) cf_runs_build(A, reinterpret_cast<long long*>(lw), reinterpret_cast<long long*>(lw) + CF_MAXRUN);
+    if (cf_arrive_last(A.tick + 2 * CF_TICK_WORDS, blockIdx.x - (uint32_t)nHist, (uint32_t)nLsd, sLast)) cf_runs_build(A, reinterpret_cast<long long*>(lw), reinterpret_cast<long long*>(lw) + CF_MAXRUN);
 }
 
 // ---------------------------------------------------------------- k_cf_pick_mad: order statistics from the counters | median and MAD of the window SDs per chromosome run
@@ -1129,7 +1147,7 @@ __device__ __forceinline__ void cf_role_mad(const CfArgs* __restrict__ AA, uint3
         else cf_run_mad<false>(sd, lo, hi, S, sOut, &A.dRunMad[r], r == 0 ? A.dbg : nullptr);
     }
     if (b == 0) CF_STAMP(35);
-    if (!cf_arrive_last(A.tick + 4, (uint32_t)CF_MADB, sLastP) || t != 0) return;
+    if (!cf_arrive_last(A.tick + 4 * CF_TICK_WORDS, (uint32_t)b, (uint32_t)CF_MADB, sLastP) || t != 0) return;
     if (!D->haveLocalSd) { D->localSd = -1.0; return; }
     double s = 0;
     for (int r = 0; r < nruns; r++) s += cf_ld_f64(&A.dRunMad[r]);               // List<double>.Average(): sequential sum / count
@@ -1211,7 +1229,7 @@ __global__ void __launch_bounds__(1024) k_cf_pick_mad(const CfArgs* __restrict__
         }
         if (g == 41) CF_STAMP(13);
         if (!var) return;
-        const bool lastP = cf_arrive_last(A.tick + 3, (uint32_t)nPick, &sLast);
+        const bool lastP = cf_arrive_last(A.tick + 3 * CF_TICK_WORDS, blockIdx.x, (uint32_t)nPick, &sLast);
         if (g == 41) CF_STAMP(14);
         if (lastP) { CF_STAMP(20); cf_resolve_var(A, lw, swave); __syncthreads(); CF_STAMP(25); }
         return;
@@ -1476,7 +1494,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     useCq = useCq && (flags & CANVAS_CLEAN_GCNORM);
     const size_t cqWords = useCq ? (size_t)B * CQ_ROWS * CQW : 0;
     WsSizer sz;
-    sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<CleanDev>(B); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); sz.take<CfCq>(B); sz.take<uint32_t>((size_t)B * 8); sz.take<uint32_t>(cqWords + 4);
+    sz.take<CfArgs>(B); sz.take<uint8_t>(nchr); sz.take<CleanDev>(B); sz.take<uint32_t>((size_t)B * CF_SZ_BINS); sz.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); sz.take<CfCq>(B); sz.take<uint32_t>((size_t)B * 8 * CF_TICK_WORDS); sz.take<uint32_t>(cqWords + 4);
     int64_t nMax = 0; bool anyLsd = false, anyVar = false;
     for (int s = 0; s < B; s++) {
         const int64_t n = h_n[s], nW0 = n / 20 + 2, nb = nblk(n, CBLK); const size_t tilesUpper = (size_t)(n / SEL_TILE + NGC + 1);
@@ -1496,7 +1514,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
     // two adjacent groups: what the host sends (the argument table) and what starts as zero (k_cf_init)
     CfArgs* dArgs = ws.take<CfArgs>(B); uint8_t* dIsAuto = ws.take<uint8_t>(nchr);
     CleanDev* dD = ws.take<CleanDev>(B); uint32_t* dSz = ws.take<uint32_t>((size_t)B * CF_SZ_BINS); uint32_t* dRepl = ws.take<uint32_t>((size_t)B * CF_HREP * 3 * NGC); CfCq* dCq = ws.take<CfCq>(B);
-    uint32_t* dTick = ws.take<uint32_t>((size_t)B * 8); uint32_t* dCqHist = ws.take<uint32_t>(cqWords + 4);
+    uint32_t* dTick = ws.take<uint32_t>((size_t)B * 8 * CF_TICK_WORDS); uint32_t* dCqHist = ws.take<uint32_t>(cqWords + 4);
     CleanPending pend; pend.useCq = useCq; pend.B = B; pend.dArgs = dArgs; pend.dD = dD; pend.h.resize(B);
     unsigned gxT = 1, gxTcq = 1;
     for (int s = 0; s < B; s++) {
@@ -1514,7 +1532,7 @@ static int32_t clean_batch_enqueue(canvas_ctx* ctx, int B, const int64_t* h_n, i
         A.cqTiles = ws.take<SelTile>((size_t)(n / CQ_TILE + NGC + 1)); A.cq = dCq + s; A.cqHist = dCqHist + (size_t)s * CQ_ROWS * CQW;
         gxTcq = std::max(gxTcq, (unsigned)(n / CQ_TILE + NGC + 1));
         A.isAuto = dIsAuto; A.repl = dRepl + (size_t)s * CF_HREP * 3 * NGC; A.szHist = dSz + (size_t)s * CF_SZ_BINS; A.D = dD + s; A.hist = (uint32_t*)((char*)ctx->sel_hist + histPer * (size_t)s);
-        A.tick = dTick + (size_t)s * 8;
+        A.tick = dTick + (size_t)s * 8 * CF_TICK_WORDS;
         { unsigned long long* dbg = ws.take<unsigned long long>(64); A.dbg = cvx_hook("CANVAS_CLEAN_DEBUG_CLOCKS") ? dbg : nullptr; }
         gxT = std::max(gxT, tilesUpper);
         anyLsd = anyLsd || A.wantLsd; anyVar = anyVar || (A.wantLsd && n > 500000);

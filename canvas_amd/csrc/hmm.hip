@@ -70,9 +70,11 @@ __global__ void __launch_bounds__(1024) k_covq_hist(const double* __restrict__ c
     __shared__ uint32_t lw[CQ_WIN];
     __shared__ long long sv[33];
     __shared__ int sLo;
+    __shared__ uint32_t sBelow;
     // the sample's level: median of 33 strided elements (the same in every workgroup); 33 lanes fetch them, one sorts
     if (threadIdx.x < 33) { const int64_t i = (int64_t)((double)n * (threadIdx.x + 0.5) / 33.0); long long k = -1; if (i < n && !covq_key(cov[i], k)) k = -1; sv[threadIdx.x] = k; }
     for (int i = threadIdx.x; i < CQ_WIN; i += 1024) lw[i] = 0;
+    if (threadIdx.x == 0) sBelow = 0;
     __syncthreads();
     if (threadIdx.x < 33) {                                  // every lane ranks its own sample among the valid ones; the one in the middle sets the window
         const long long mine = sv[threadIdx.x];
@@ -99,10 +101,11 @@ __global__ void __launch_bounds__(1024) k_covq_hist(const double* __restrict__ c
             else if (k - lo < CQ_WIN) atomicAdd(&lw[k - lo], 1u);
         }
     }
-    below = wave_reduce_add_u32(below);
-    if ((threadIdx.x & 63) == 0 && below) atomicAdd(&Q->below, (unsigned long long)below);
+    below = wave_reduce_add_u32(below);                      // (summed over the workgroup first: 4 096 waves adding to ONE word are performed one after the other at the memory side)
+    if ((threadIdx.x & 63) == 0 && below) atomicAdd(&sBelow, below);
     if (bad) Q->bad = 1u;
     __syncthreads();
+    if (threadIdx.x == 0 && sBelow) atomicAdd(&Q->below, (unsigned long long)sBelow);
     for (int i = threadIdx.x; i < CQ_WIN; i += 1024) { const uint32_t v = lw[i]; if (v) atomicAdd(&win[i], v); }
 }
 // Qres == NULL: the ranks were written by the host, the result stays in Q.  Qres != NULL (pipeline): the ranks are derived here from the number of bins (n, or *nDev when the
@@ -158,8 +161,10 @@ __global__ void __launch_bounds__(1024) k_quant_covq(const float* __restrict__ c
     if (nDev) n = (int64_t)*nDev < n ? (int64_t)*nDev : n;        // (enqueued behind CanvasClean: its bin count is still on the device)
     __shared__ long long sv[33];
     __shared__ int sLo;
+    __shared__ uint32_t sBelow;
     if (threadIdx.x < 33) { const int64_t i = (int64_t)((double)n * (threadIdx.x + 0.5) / 33.0); long long k = -1; if (i < n) (void)quantize_f2_one(count[i], &k); sv[threadIdx.x] = k; }
     for (int i = threadIdx.x; i < CQ_WIN; i += 1024) lw[i] = 0;
+    if (threadIdx.x == 0) sBelow = 0;
     __syncthreads();
     if (threadIdx.x < 33) {                                  // every lane ranks its own sample among the valid ones; the one in the middle sets the window
         const long long mine = sv[threadIdx.x];
@@ -188,10 +193,11 @@ __global__ void __launch_bounds__(1024) k_quant_covq(const float* __restrict__ c
             else if (k - lo < CQ_WIN) atomicAdd(&lw[k - lo], 1u);
         }
     }
-    below = wave_reduce_add_u32(below);
-    if ((threadIdx.x & 63) == 0 && below) atomicAdd(&Q->below, (unsigned long long)below);
+    below = wave_reduce_add_u32(below);                      // (summed over the workgroup first: 4 096 waves adding to ONE word are performed one after the other at the memory side)
+    if ((threadIdx.x & 63) == 0 && below) atomicAdd(&sBelow, below);
     if (bad) Q->bad = 1u;
     __syncthreads();
+    if (threadIdx.x == 0 && sBelow) atomicAdd(&Q->below, (unsigned long long)sBelow);
     for (int i = threadIdx.x; i < CQ_WIN; i += 1024) { const uint32_t v = lw[i]; if (v) atomicAdd(&win[i], v); }
 }
 
