@@ -156,12 +156,19 @@ __global__ void __launch_bounds__(1024) k_covq_pick(CovQ* __restrict__ Q, uint32
 
 // The same count inside the sweep that produces the coverage (pipeline.hip): cov[i] = F2(count[i]) is written and counted in one pass — the value is N / 100 by construction,
 // N comes out of the digit arithmetic — so PerSampleHMM starts without a sweep of its own (37 us for a WGS sample) and without its own round trip for the six ranks.
+#define QC_U 8               // counts a thread of k_quant_covq has in flight per round
 __global__ void __launch_bounds__(1024) k_quant_covq(const float* __restrict__ count, int64_t n, double* __restrict__ cov, CovQ* __restrict__ Q, uint32_t* __restrict__ win, const unsigned long long* __restrict__ nDev = nullptr) {
     __shared__ uint32_t lw[CQ_WIN];
     if (nDev) n = (int64_t)*nDev < n ? (int64_t)*nDev : n;        // (enqueued behind CanvasClean: its bin count is still on the device)
     __shared__ long long sv[33];
     __shared__ int sLo;
     __shared__ uint32_t sBelow;
+    // the first round of counts is requested before the level of the sample is worked out (two barriers and a dependent load: the loads travel meanwhile)
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    float c[QC_U];
+#pragma unroll
+    for (int u = 0; u < QC_U; u++) { const int64_t i = i0 + u * stride; c[u] = i < n ? count[i] : 0.0f; }
     if (threadIdx.x < 33) { const int64_t i = (int64_t)((double)n * (threadIdx.x + 0.5) / 33.0); long long k = -1; if (i < n) (void)quantize_f2_one(count[i], &k); sv[threadIdx.x] = k; }
     for (int i = threadIdx.x; i < CQ_WIN; i += 1024) lw[i] = 0;
     if (threadIdx.x == 0) sBelow = 0;
@@ -177,13 +184,13 @@ __global__ void __launch_bounds__(1024) k_quant_covq(const float* __restrict__ c
     if (blockIdx.x == 0 && threadIdx.x == 0) Q->lo = sLo;
     const long long lo = sLo;
     uint32_t below = 0, bad = 0;
-    const int64_t stride = (int64_t)gridDim.x * 1024;
-    for (int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += 4 * stride) {
-        float c[4];
+    while (i0 < n) {
+        const int64_t nx = i0 + QC_U * stride;
+        float cn[QC_U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * stride; c[u] = i < n ? count[i] : 0.0f; }          // four loads in flight
+        for (int u = 0; u < QC_U; u++) { const int64_t i = nx + u * stride; cn[u] = i < n ? count[i] : 0.0f; }      // the next round travels while this one is worked on
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < QC_U; u++) {
             const int64_t i = i0 + u * stride;
             if (i >= n) break;
             long long k;
@@ -192,6 +199,9 @@ __global__ void __launch_bounds__(1024) k_quant_covq(const float* __restrict__ c
             if (k < lo) below++;
             else if (k - lo < CQ_WIN) atomicAdd(&lw[k - lo], 1u);
         }
+#pragma unroll
+        for (int u = 0; u < QC_U; u++) c[u] = cn[u];
+        i0 = nx;
     }
     below = wave_reduce_add_u32(below);                      // (summed over the workgroup first: 4 096 waves adding to ONE word are performed one after the other at the memory side)
     if ((threadIdx.x & 63) == 0 && below) atomicAdd(&sBelow, below);
@@ -1840,7 +1850,7 @@ int32_t cvx_quant_covq_enqueue(canvas_ctx* ctx, const float* d_count, int64_t n,
     if (!ctx->covq_pin) CANVAS_HIP_TRY(ctx, hipHostMalloc(&ctx->covq_pin, 256, hipHostMallocDefault));
     CovQ* dQ = (CovQ*)ctx->covq_dev; CovQ* dQres = (CovQ*)ctx->covq_pin; uint32_t* dWin = (uint32_t*)((char*)ctx->covq_dev + 512);       // (the result goes straight into pinned host memory)
     static_assert(sizeof(CovQ) <= 256, "CovQ");
-    hipLaunchKernelGGL(k_quant_covq, dim3(256), dim3(1024), 0, ctx->stream, d_count, n, d_cov, dQ, dWin, d_n);
+    hipLaunchKernelGGL(k_quant_covq, dim3(256), dim3(1024), 0, ctx->stream, d_count, n, d_cov, dQ, dWin, d_n);      // (128 / 192 / 512 / 1 024 workgroups: 50 / 39 / 46 / 60 us against 35 — the loop shrinks and the flush of the counters grows with the grid)
     ctx->covq_seq = cvx_mail_arm(ctx, &dQres->pad);
     hipLaunchKernelGGL(k_covq_pick, dim3(1), dim3(1024), 0, ctx->stream, dQ, dWin, (long long)n, d_n, dQres, ctx->covq_seq);
     *h_covq_out = ctx->covq_pin;

@@ -30,9 +30,23 @@ __device__ __forceinline__ bool quantize_f2_fast(float v, float af, double& out,
     const int dd = d - 2;                                       // digits dropped by the two-decimal stage (half-up on the decimal digits)
     uint32_t N2;
     if (dd <= 0) N2 = R7 * (dd == 0 ? 1u : (dd == -1 ? 10u : 100u));
-    else { const uint32_t p1 = p / 1000u;                       // 10^(dd - 1)
-           N2 = (R7 / p1 + 5u) / 10u; }
-    const double r = (double)N2 / 100.0;
+    else {
+        // (R7 / 10^(dd-1) + 5) / 10 = (R7 + 5 * 10^(dd-1)) / 10^dd: ONE division of a number below 2^24 by a power of ten — a float estimate (exact operand, reciprocal
+        // and product good to 2^-22: off by one at most) and a correction on the exact remainder, instead of two 32-bit divisions (~40 instructions each)
+        uint32_t P = 10u; float inv = 1.0e-1f;                  // 10^dd, dd = 1..7
+        P = dd >= 2 ? 100u : P; inv = dd >= 2 ? 1.0e-2f : inv; P = dd >= 3 ? 1000u : P; inv = dd >= 3 ? 1.0e-3f : inv; P = dd >= 4 ? 10000u : P; inv = dd >= 4 ? 1.0e-4f : inv;
+        P = dd >= 5 ? 100000u : P; inv = dd >= 5 ? 1.0e-5f : inv; P = dd >= 6 ? 1000000u : P; inv = dd >= 6 ? 1.0e-6f : inv; P = dd >= 7 ? 10000000u : P; inv = dd >= 7 ? 1.0e-7f : inv;
+        const uint32_t x = R7 + (P >> 1);                       // < 1.5e7 < 2^24: exact as a float
+        uint32_t q = (uint32_t)((float)x * inv);
+        int32_t rem = (int32_t)(x - q * P);
+        if (rem < 0) { q--; rem += (int32_t)P; }
+        if (rem >= (int32_t)P) q++;
+        N2 = q;
+    }
+    // N2 / 100.0 correctly rounded without the division sequence: q0 = N2 * RN(1/100) is within an ulp, the fused residual is exact, one correction step rounds correctly
+    // (Markstein); checked against the division for EVERY N2 below 2^30 (tests/test_quantize_division.py restates the check; the fast path only sees N2 < 10^9)
+    const double a2 = (double)N2, q0 = a2 * 0.01, r0 = fma(-100.0, q0, a2);
+    const double r = fma(r0, 0.01, q0);
     if (kOut && !(v < 0) && N2 < (1u << 30)) *kOut = (long long)N2;
     out = v < 0 ? -r : r;
     return true;
