@@ -72,6 +72,7 @@ struct canvas_ctx {
     long long wv_levels = 0, wv_redone = 0;   // last canvas_wavelets call: tree levels processed, nodes recomputed by the exact chain
     void* covq_dev = nullptr; void* covq_pin = nullptr;   // pipeline.hip: counters / result of the genome-wide coverage quartiles counted while the coverage is quantised (hmm.hip)
     hipStream_t wv_main = nullptr, wv_chain = nullptr, wv_sub = nullptr, wv_sub2 = nullptr;
+    hipStream_t wv_copy = nullptr; hipEvent_t wv_ev_in = nullptr, wv_ev_x = nullptr;      // canvas_wavelets: the host copy of the coverage travels next to the first kernels of the call
     void* wv_fgh = nullptr; int wv_fgh_len = 0;          // canvas_wavelets: the step coefficients of every (node length, position) of the short nodes, computed once  // canvas_wavelets: streams confined to disjoint sets of compute units (the exact chains keep theirs to themselves)
     int wv_streams_tried = 0; unsigned wv_calls = 1;
     void* wv_pin = nullptr; size_t wv_pin_bytes = 0;   // pinned arena of canvas_wavelets (host copy of the coverage + staging lists), kept between calls

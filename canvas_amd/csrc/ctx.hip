@@ -50,6 +50,9 @@ void canvas_destroy(canvas_ctx* ctx) {
     if (ctx->wv_chain) (void)hipStreamDestroy(ctx->wv_chain);
     if (ctx->wv_sub) (void)hipStreamDestroy(ctx->wv_sub);
     if (ctx->wv_sub2) (void)hipStreamDestroy(ctx->wv_sub2);
+    if (ctx->wv_copy) (void)hipStreamDestroy(ctx->wv_copy);
+    if (ctx->wv_ev_in) (void)hipEventDestroy(ctx->wv_ev_in);
+    if (ctx->wv_ev_x) (void)hipEventDestroy(ctx->wv_ev_x);
     if (ctx->wv_fgh) (void)hipFree(ctx->wv_fgh);
     if (ctx->covq_pin) (void)hipHostFree(ctx->covq_pin);
     if (ctx->covq_dev) (void)hipFree(ctx->covq_dev);

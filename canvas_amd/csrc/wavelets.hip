@@ -361,29 +361,146 @@ __global__ void __launch_bounds__(256) k_wv_tops(const int32_t* __restrict__ cou
     for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(t, d, 64); t = o > t ? o : t; }
     if ((threadIdx.x & 63) == 0 && t >= 0) atomicMax(&top[blockIdx.y], t);
 }
-// one workgroup per chromosome: k = 100 x as integers (checked bit for bit), P1[i] = k_0 + ... + k_i, P2[i] = P1[0] + ... + P1[i] (both restart at every chromosome)
-__global__ void __launch_bounds__(1024) k_wv_prefix(const double* __restrict__ X, const long long* __restrict__ off, long long* __restrict__ P1, long long* __restrict__ P2, int* __restrict__ bad) {
+// k = 100 x as integers (checked bit for bit), P1[i] = k_0 + ... + k_i, P2[i] = P1[0] + ... + P1[i] (both restart at every chromosome).  TWO launches over tiles of 1 024 bins
+// (a tile belongs to one chromosome; tile0[c] numbers them): k_wv_prefix_tiles leaves the integers (32 bits: the range check keeps them below 2^31) and every tile's
+// {sum of k, sum of its tile-local inclusive sums}; k_wv_prefix_apply takes its carries from the tiles in front of it (all of them full) and writes P1 / P2.
+// (Round 2-5: one workgroup per chromosome walking its tiles one after the other — 1.14 ms for chr1 of a WGS sample in front of everything else of the call.)
+#define WV_PT 1024
+__device__ __forceinline__ int wv_range_of_tile(const int32_t* __restrict__ tile0, int nr, int tile) {      // the range whose tiles contain `tile`: tile0[r] <= tile < tile0[r + 1]
+    int lo = 0, hi = nr - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile0[mid] <= tile) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ void __launch_bounds__(WV_PT) k_wv_prefix_tiles(const double* __restrict__ X, const long long* __restrict__ off, const int32_t* __restrict__ tile0, int nchr,
+                                                           uint32_t* __restrict__ K32, long long* __restrict__ agg /* [tiles][2] */, int* __restrict__ bad) {
     __shared__ long long sh[17];
-    const long long lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
-    long long carry1 = 0, carry2 = 0;
-    int myBad = 0;
-    for (long long base = lo; base < hi; base += 1024) {
-        const long long i = base + threadIdx.x;
-        long long k = 0;
-        if (i < hi) {
-            const double x = X[i];
-            if (!(x >= 0.0 && x < 2.0e7)) myBad = 1;
-            else { k = llrint(x * 100.0); if ((double)k / 100.0 != x) myBad = 1; }
-        }
-        long long t1, t2;
-        const long long l1 = wv_block_scan_i64(k, sh, &t1);                      // tile-local inclusive sums
-        const long long l2 = wv_block_scan_i64(i < hi ? l1 : 0, sh, &t2);
-        const long long cntTile = min<long long>(1024, hi - base);
-        if (i < hi) { P1[i] = carry1 + l1; P2[i] = carry2 + (long long)(threadIdx.x + 1) * carry1 + l2; }
-        carry2 += cntTile * carry1 + t2; carry1 += t1;
-        if (carry2 > (1ll << 61) || (hi - lo) * carry1 > (1ll << 61)) myBad = 1;   // the bound's integer terms stay inside 64 bits
+    const int c = wv_range_of_tile(tile0, nchr, (int)blockIdx.x);
+    const long long hi = off[c + 1], i = off[c] + (long long)((int)blockIdx.x - tile0[c]) * WV_PT + threadIdx.x;
+    long long k = 0; int myBad = 0;
+    if (i < hi) {
+        const double x = X[i];
+        if (!(x >= 0.0 && x < 2.0e7)) { myBad = 1; if (!(fabs(x) <= 1.7976931348623157e308)) myBad = 3; }      // (NaN or an infinity: the call refuses the coverage)
+        else { k = llrint(x * 100.0); if ((double)k / 100.0 != x) myBad = 1; }
+        K32[i] = (uint32_t)k;
     }
-    if (myBad) *bad = 1;
+    long long t1, t2;
+    const long long l1 = wv_block_scan_i64(k, sh, &t1);
+    (void)wv_block_scan_i64(i < hi ? l1 : 0, sh, &t2);
+    if (threadIdx.x == 0) { agg[2 * (size_t)blockIdx.x] = t1; agg[2 * (size_t)blockIdx.x + 1] = t2; }
+    if (myBad) bad[0] = 1;
+    if (myBad == 3) bad[1] = 1;
+}
+__global__ void __launch_bounds__(WV_PT) k_wv_prefix_apply(const uint32_t* __restrict__ K32, const long long* __restrict__ off, const int32_t* __restrict__ tile0, int nchr,
+                                                           const long long* __restrict__ agg, long long* __restrict__ P1, long long* __restrict__ P2, int* __restrict__ bad) {
+    __shared__ long long sh[17];
+    const int c = wv_range_of_tile(tile0, nchr, (int)blockIdx.x);
+    const int first = tile0[c], j = (int)blockIdx.x - first;                   // the tile's number inside its chromosome
+    const long long lo = off[c], hi = off[c + 1], base = lo + (long long)j * WV_PT, i = base + threadIdx.x;
+    // carries: carry1 = sum of the k in front of the tile, carry2 = sum of the P1 in front of it = sum over the tiles T in front of (1 024 x carry1(T) + their local sums)
+    long long carry1 = 0, carry2 = 0;
+    for (int b0 = 0; b0 < j; b0 += WV_PT) {
+        const int T = b0 + (int)threadIdx.x;
+        const long long a1 = T < j ? agg[2 * (size_t)(first + T)] : 0, a2 = T < j ? agg[2 * (size_t)(first + T) + 1] : 0;
+        long long tot1, tot2;
+        const long long inc = wv_block_scan_i64(a1, sh, &tot1);
+        const long long term = T < j ? (long long)WV_PT * (carry1 + inc - a1) + a2 : 0;
+        (void)wv_block_scan_i64(term, sh, &tot2);
+        carry1 += tot1; carry2 += tot2;
+    }
+    const long long k = i < hi ? (long long)K32[i] : 0;
+    long long t1, t2;
+    const long long l1 = wv_block_scan_i64(k, sh, &t1);
+    const long long l2 = wv_block_scan_i64(i < hi ? l1 : 0, sh, &t2);
+    if (i < hi) { P1[i] = carry1 + l1; P2[i] = carry2 + (long long)(threadIdx.x + 1) * carry1 + l2; }
+    const long long cntTile = min<long long>(WV_PT, hi - base);
+    const long long c2 = carry2 + cntTile * carry1 + t2, c1 = carry1 + t1;
+    if (threadIdx.x == 0 && (c2 > (1ll << 61) || (hi - lo) * c1 > (1ll << 61))) *bad = 1;       // the bound's integer terms stay inside 64 bits
+}
+
+// ------------------------------------------------------------------------------------------------ exact medians of many stretches of the coverage at once
+// Median (Utilities.cs:428-443) of every stretch [start, start + len) of a list: the chromosomes (threshold = mad_factor x median x variability, WaveletSegmentation.cs:394-405)
+// or the stretches between preliminary breakpoints (healing step).  The coverage of this path is x = k / 100 with the integers k of k_wv_prefix_tiles, and k -> x is
+// increasing: the median's two middle elements are order statistics of the k.  Three radix passes over the 31 bits (11 + 11 + 9), each ONE launch over tiles of 4 096
+// elements: a workgroup counts its tile's digits in LDS (a wave adds equal digits up with ballots first: in the upper passes every element has the same one), adds
+// them to the stretch's counters, and the LAST workgroup of a stretch (arrival ticket per stretch) picks the digit of both ranks and clears the counters for the next pass.
+// (One workgroup per stretch with 8 passes over doubles: 0.95 ms for the chromosomes and 0.63 ms for the healing step of a WGS sample, chr1 deciding both.)
+#define WV_MT 4096                     // elements of a median tile
+#define WV_MD 2048                     // counters per rank and pass
+#define WV_MED_MAXR 1024               // stretches per call of the multi-stretch median (more: one workgroup per stretch as before)
+struct WvMedState { uint32_t prefix[2]; uint32_t pad[2]; unsigned long long rank[2]; };
+__device__ __forceinline__ void wv_lds_count(uint32_t* h, uint32_t d, bool on) {
+    unsigned long long todo = __ballot(on);
+    const int lane = (int)(threadIdx.x & 63);
+    for (int r = 0; r < 3 && todo; r++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t d0 = (uint32_t)__shfl((int)d, leader, 64);
+        const unsigned long long same = __ballot(on && d == d0);
+        if (lane == leader) atomicAdd(&h[d0], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&h[d], 1u);
+}
+__global__ void __launch_bounds__(1024) k_wv_rmed_pass(const uint32_t* __restrict__ K32, const long long* __restrict__ rStart, const long long* __restrict__ rLen, const int32_t* __restrict__ tile0, int nr,
+                                                       int pass, WvMedState* __restrict__ st, uint32_t* __restrict__ hist /* [nr][2][WV_MD], zero */, uint32_t* __restrict__ tick /* [nr], zero */,
+                                                       double* __restrict__ out) {
+    __shared__ uint32_t lh[2][WV_MD];
+    __shared__ long long sh[17];
+    __shared__ int sLast;
+    const int r = wv_range_of_tile(tile0, nr, (int)blockIdx.x), t = (int)threadIdx.x;
+    const long long n = rLen[r], a = rStart[r] + (long long)((int)blockIdx.x - tile0[r]) * WV_MT, e = min<long long>(rStart[r] + n, a + WV_MT);
+    const int shift = pass == 0 ? 20 : (pass == 1 ? 9 : 0), bits = pass == 2 ? 9 : 11;
+    const uint32_t hiMask = pass == 0 ? 0u : (~0u << (shift + bits)), dMask = (1u << bits) - 1u;
+    uint32_t p0 = 0, p1 = 0;
+    if (pass > 0) { p0 = st[r].prefix[0]; p1 = st[r].prefix[1]; }
+    uint32_t kk[WV_MT / 1024]; bool in[WV_MT / 1024];
+#pragma unroll
+    for (int u = 0; u < WV_MT / 1024; u++) { const long long i = a + u * 1024 + t; in[u] = i < e; kk[u] = in[u] ? K32[i] : 0u; }
+    for (int i = t; i < 2 * WV_MD; i += 1024) (&lh[0][0])[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < WV_MT / 1024; u++) {
+        const uint32_t d = (kk[u] >> shift) & dMask;
+        wv_lds_count(lh[0], d, in[u] && (kk[u] & hiMask) == p0);
+        if (p1 != p0) wv_lds_count(lh[1], d, in[u] && (kk[u] & hiMask) == p1);
+    }
+    __syncthreads();
+    uint32_t* __restrict__ gh = hist + (size_t)r * 2 * WV_MD;
+    for (int i = t; i < 2 * WV_MD; i += 1024) { const uint32_t v = (&lh[0][0])[i]; if (v) atomicAdd(&gh[i], v); }
+    // arrival ticket of the stretch (the idiom of clean_fast.hpp: own atomics drained, one agent-scope acquire in the last workgroup)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t ntiles = (uint32_t)(tile0[r + 1] - tile0[r]);
+        const int last = (__hip_atomic_fetch_add(&tick[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ntiles) ? 1 : 0;
+        if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __hip_atomic_store(&tick[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        sLast = last;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    // ---- the digit of both ranks: two counters per thread, exclusive sums over the workgroup
+    unsigned long long rk[2];
+    if (pass == 0) { rk[0] = (unsigned long long)((n & 1) ? n / 2 : n / 2 - 1); rk[1] = (unsigned long long)(n / 2); }
+    else { rk[0] = st[r].rank[0]; rk[1] = st[r].rank[1]; }
+    __shared__ uint32_t sNp[2];
+    for (int q = 0; q < 2; q++) {
+        const uint32_t* __restrict__ h = gh + ((q == 1 && p0 != p1) ? WV_MD : 0);
+        const uint32_t c0 = h[2 * t], c1 = h[2 * t + 1];
+        long long tot;
+        const long long inc = wv_block_scan_i64((long long)c0 + (long long)c1, sh, &tot);
+        const unsigned long long before = (unsigned long long)(inc - (long long)c0 - (long long)c1), want = rk[q];
+        if (want >= before && want < before + c0 + c1) {
+            const int d = want < before + c0 ? 2 * t : 2 * t + 1;
+            const uint32_t np = (q == 0 ? p0 : p1) | ((uint32_t)d << shift);
+            st[r].prefix[q] = np; sNp[q] = np;
+            st[r].rank[q] = want - before - (d == 2 * t ? 0ull : (unsigned long long)c0);
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < 2 * WV_MD; i += 1024) gh[i] = 0u;                     // (plain stores: nobody else touches the stretch's counters before the next launch)
+    if (pass == 2 && t == 0) {
+        const double lo = (double)sNp[0] / 100.0, hi = (double)sNp[1] / 100.0;      // x = k / 100 bit for bit (k_wv_prefix_tiles checked it)
+        out[r] = (n & 1) ? hi : (lo + hi) / 2;
+    }
 }
 // A node is evaluated in chunks of WV_CH elements, one workgroup per chunk; the last chunk of a node to finish combines the partial results and takes the node's decision
 // (arrival counter per node; partial results are published with write-through stores and read after one agent-scope acquire).  A 380 000-bin chromosome is 186 chunks: its
@@ -902,13 +1019,25 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     struct XView { double* p; double* data() const { return p; } double operator[](size_t i) const { return p[i]; } } X{(double*)ctx->wv_pin};
     char* pinCursor = (char*)ctx->wv_pin + (((size_t)N * sizeof(double) + 255) & ~size_t(255));
     unsigned long long* hF3Keys = (unsigned long long*)pinCursor; unsigned* hF3Seq = (unsigned*)(pinCursor + 128); unsigned f3Seq[8] = {0, 0, 0, 0, 0, 0, 0, 0}; pinCursor += 256;      // the two middle keys of every exponent (factor-of-three statistics on the device)
-    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(X.data(), dX, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    {
+    // The copy travels on a stream of its own behind whatever produced the coverage (37 MB: 1.2 ms) while the first kernels of the call run; the host waits for it
+    // where it first reads X (need_X) — with the default switches that is the reconstruction at the end.  The finiteness check rides on k_wv_prefix_tiles.
+    if (!ctx->wv_copy) CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wv_copy, hipStreamNonBlocking));
+    if (!ctx->wv_ev_in) CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wv_ev_in, hipEventDisableTiming));
+    if (!ctx->wv_ev_x) CANVAS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wv_ev_x, hipEventDisableTiming));
+    CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->wv_ev_in, ctx->stream));
+    CANVAS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->wv_copy, ctx->wv_ev_in, 0));
+    CANVAS_HIP_TRY(ctx, hipMemcpyAsync(X.data(), dX, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->wv_copy));
+    CANVAS_HIP_TRY(ctx, hipEventRecord(ctx->wv_ev_x, ctx->wv_copy));
+    struct CopyDrain { canvas_ctx* c; ~CopyDrain() { (void)hipStreamSynchronize(c->wv_copy); } } copyDrain{ctx};      // (no way out of the call leaves the copy running)
+    bool xHere = false;
+    auto need_X = [&]() -> int32_t { if (!xHere) { CANVAS_HIP_TRY(ctx, hipEventSynchronize(ctx->wv_ev_x)); xHere = true; } return CANVAS_OK; };
+    auto host_finite_check = [&]() -> int32_t {
+        int32_t rcx = need_X(); if (rcx) return rcx;
         std::atomic<int> nonFinite{0};
         host_parallel_for((N + 262143) / 262144, [&](int64_t blk) { const int64_t a = blk * 262144, b = std::min<int64_t>(N, a + 262144); bool ok = true; for (int64_t i = a; i < b; i++) ok &= std::isfinite(X[(size_t)i]); if (!ok) nonFinite = 1; });
         if (nonFinite) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: coverage must be finite");
-    }
+        return CANVAS_OK;
+    };
     // ---- from here on the call runs on two streams of its own, confined to disjoint sets of compute units: the exact chains are single waves of dependent FP64 operations
     // (s_setprio 3), and whatever shares a SIMD with one of them runs at a third of its speed — with a common pool the level kernels paid for the chains started next to
     // them (levels 12.6 -> 19.2 ms).  CANVAS_WV_CHAIN_CUS = compute units set aside for the chains (an experiment that measured no gain: default 0 = the context's own streams, no masks).
@@ -935,8 +1064,9 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     }
     const WvFgh* dFgh = cvx_hook("CANVAS_WV_NO_TABLE") ? nullptr : (const WvFgh*)ctx->wv_fgh; const int fghLen = dFgh ? WV_LONG : 0;
     if (!ctx->wv_sub) CANVAS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wv_sub, hipStreamNonBlocking));      // the subtree walkers of the roots a batch of levels leaves: next to the following levels and to the chains
+    if (ctx->wv_main && ctx->wv_chain) CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (the masked streams start from a finished producer)
     struct StreamSwap { canvas_ctx* c; hipStream_t s0, s1; StreamSwap(canvas_ctx* x) : c(x), s0(x->stream), s1(x->side) { if (x->wv_main && x->wv_chain) { x->stream = x->wv_main; x->side = x->wv_chain; } }
-                        ~StreamSwap() { if (c->stream != s0) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->side); } (void)hipStreamSynchronize(c->wv_sub); (void)hipStreamSynchronize(c->wv_sub2); c->stream = s0; c->side = s1; } } streamSwap(ctx);      // (the context's stream is idle: the copy above has been waited for; both are drained on every way out)
+                        ~StreamSwap() { if (c->stream != s0) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->side); } (void)hipStreamSynchronize(c->wv_sub); (void)hipStreamSynchronize(c->wv_sub2); c->stream = s0; c->side = s1; } } streamSwap(ctx);      // (both are drained on every way out)
     const bool timing = cvx_hook("CANVAS_WV_TIMING") != nullptr, trace = cvx_hook("CANVAS_WV_TRACE") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
@@ -945,7 +1075,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     std::vector<double> f3;
     double f3Seconds = 0;
     const bool f3OnDevice = nchr <= WV_F3_MAXCHR && !cvx_hook("CANVAS_WV_F3_HOST"), f3Check = cvx_hook("CANVAS_WV_F3_CHECK") != nullptr;
-    std::thread f3Thread([&]() { if (f3OnDevice && !f3Check) return; const double a = now(); f3 = factor_of_three(nchr, X.data(), off.data()); f3Seconds = now() - a; });
+    std::thread f3Thread([&]() { if (f3OnDevice && !f3Check) return; (void)hipEventSynchronize(ctx->wv_ev_x); const double a = now(); f3 = factor_of_three(nchr, X.data(), off.data()); f3Seconds = now() - a; });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } f3Join{f3Thread};      // joined on every exit path
     // ---- device buffers
     const size_t maxLong = (size_t)N / WV_LONG + (size_t)nchr + 16, maxChunks = 3 * (size_t)N / WV_CS + maxLong + 16, maxRoots = (size_t)N / 2 + (size_t)nchr + 16;
@@ -966,6 +1096,10 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     const size_t varCap = (size_t)N / (size_t)std::max(1, std::min(variability_window, 10000)) + (size_t)nchr + 16;
     sz.take<long long>(varCap); sz.take<float>(varCap); sz.take<double>(nchr + 1); sz.take<uint8_t>(nchr + 1); sz.take<double>(varCap);
     sz.take<double>(f3Cap); sz.take<double>(f3Cap); sz.take<unsigned long long>(f3Cap); sz.take<WvF3Sel>(1);
+    // the integers of the coverage, the prefix tiles' sums, and the state of the multi-stretch medians (up to WV_MED_MAXR stretches per launch set)
+    const size_t prefTiles = (size_t)N / WV_PT + (size_t)nchr + 1, medR = WV_MED_MAXR;
+    sz.take<uint32_t>((size_t)N); sz.take<long long>(2 * prefTiles); sz.take<int32_t>(nchr + 2); sz.take<long long>(medR); sz.take<long long>(medR); sz.take<int32_t>(medR + 2); sz.take<WvMedState>(medR);
+    sz.take<uint32_t>(medR * 2 * WV_MD); sz.take<uint32_t>(medR);
     int32_t rc = canvas_ws_reserve(ctx, sz.off + 4096); if (rc) return rc;
     rc = canvas_side_init(ctx); if (rc) return rc;
     WsCarver ws(ctx->ws);
@@ -985,18 +1119,123 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     long long* dOpsOffE = ws.take<long long>(maxLong); int32_t* dLimE = ws.take<int32_t>(maxLong);
     double* dF3Med[2] = {ws.take<double>(f3Cap), nullptr}; dF3Med[1] = ws.take<double>(f3Cap); unsigned long long* dF3Key = ws.take<unsigned long long>(f3Cap); WvF3Sel* dF3Sel = ws.take<WvF3Sel>(1);
     long long* dVarStart = ws.take<long long>(varCap); float* dVarOut = ws.take<float>(varCap); double* dChromMed = ws.take<double>(nchr + 1); uint8_t* dIsRoot = ws.take<uint8_t>(nchr + 1); double* dSegMed = ws.take<double>(varCap);
+    uint32_t* dK32 = ws.take<uint32_t>((size_t)N); long long* dAgg = ws.take<long long>(2 * prefTiles); int32_t* dTile0P = ws.take<int32_t>(nchr + 2);
+    long long* dMedStart = ws.take<long long>(medR); long long* dMedLen = ws.take<long long>(medR); int32_t* dMedTile0 = ws.take<int32_t>(medR + 2); WvMedState* dMedState = ws.take<WvMedState>(medR);
+    uint32_t* dMedHist = ws.take<uint32_t>(medR * 2 * WV_MD); uint32_t* dMedTick = ws.take<uint32_t>(medR);
+    // medians of up to WV_MED_MAXR stretches (start, length) of the coverage from its integers, three launches on the main stream; the results stay in `out` (device)
+    auto medians_enqueue = [&](const std::vector<long long>& st, const std::vector<long long>& ln, double* out) -> int32_t {
+        const size_t nr = st.size();
+        std::vector<int32_t> t0(nr + 1, 0);
+        for (size_t r = 0; r < nr; r++) t0[r + 1] = t0[r] + (int32_t)((ln[r] + WV_MT - 1) / WV_MT);
+        if (t0[nr] == 0) return CANVAS_OK;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dMedStart, st.data(), nr * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dMedLen, ln.data(), nr * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dMedTile0, t0.data(), (nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dMedHist, 0, nr * 2 * WV_MD * sizeof(uint32_t), ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dMedTick, 0, nr * sizeof(uint32_t), ctx->stream));
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(out, 0, nr * sizeof(double), ctx->stream));      // (an empty stretch has no tile: its median is 0)
+        for (int pass = 0; pass < 3; pass++)
+            hipLaunchKernelGGL(k_wv_rmed_pass, dim3((unsigned)t0[nr]), dim3(1024), 0, ctx->stream, dK32, dMedStart, dMedLen, dMedTile0, (int)nr, pass, dMedState, dMedHist, dMedTick, out);
+        return CANVAS_OK;
+    };
     // what does not depend on the thresholds starts now, next to the host's order statistics: counters cleared, the exact prefix sums of the closed-form decisions
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCounts, 0, (size_t)N * sizeof(int32_t), ctx->stream));
     CANVAS_HIP_TRY(ctx, hipMemsetAsync(dNcand, 0, 2 * sizeof(unsigned long long), ctx->stream));
     const bool tryClosedForm = !cvx_hook("CANVAS_WV_CHAIN_ONLY");
+    int hBad[2] = {0, 0};
     if (tryClosedForm) {
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dOff, off.data(), (nchr + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipMemsetAsync(dBad, 0, 4 * sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_wv_prefix, dim3(nchr), dim3(1024), 0, ctx->stream, dX, dOff, dP1, dP2, dBad);
+        std::vector<int32_t> t0((size_t)nchr + 1, 0);
+        for (int c = 0; c < nchr; c++) t0[(size_t)c + 1] = t0[(size_t)c] + (int32_t)((off[c + 1] - off[c] + WV_PT - 1) / WV_PT);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dTile0P, t0.data(), ((size_t)nchr + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (t0[(size_t)nchr] > 0) {
+            hipLaunchKernelGGL(k_wv_prefix_tiles, dim3((unsigned)t0[(size_t)nchr]), dim3(WV_PT), 0, ctx->stream, dX, dOff, dTile0P, nchr, dK32, dAgg, dBad);
+            hipLaunchKernelGGL(k_wv_prefix_apply, dim3((unsigned)t0[(size_t)nchr]), dim3(WV_PT), 0, ctx->stream, dK32, dOff, dTile0P, nchr, dAgg, dP1, dP2, dBad);
+        }
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(hBad, dBad, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));      // [0] not two-decimal values, [1] not finite: looked at behind the next synchronisation
+    } else { rc = host_finite_check(); if (rc) return rc; }
+    // ---- SegmentationInput.GetCoverageVariability (Segmentation.cs:308-328): the per-window statistics come from the device (CANVAS_WV_VAR_HOST=1: the host threads;
+    // CANVAS_WV_VAR_CHECK=1: both, compared), the order statistics over the few hundred windows stay on the host
+    const bool varOnDevice = !cvx_hook("CANVAS_WV_VAR_HOST"), varCheck = cvx_hook("CANVAS_WV_VAR_CHECK") != nullptr;
+    std::vector<long long> varStart;
+    auto var_enqueue = [&](int window) -> int32_t {          // one workgroup per window, results left in dVarOut
+        varStart.clear();
+        for (int c = 0; c < nchr; c++) { const int64_t L = off[c + 1] - off[c]; for (int64_t i = 0; i < L - window; i += window) varStart.push_back(off[c] + i); }
+        if (varStart.size() > varCap) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: variability staging");
+        if (varStart.empty()) return CANVAS_OK;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVarStart, varStart.data(), varStart.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_wv_variability, dim3((unsigned)varStart.size()), dim3(1024), 0, ctx->stream, dX, dVarStart, window, dVarOut);
+        return CANVAS_OK;
+    };
+    auto var_collect = [&](int window, std::vector<float>& rv) -> int32_t {
+        rv.assign(varStart.size(), 0.0f);
+        if (!rv.empty()) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(rv.data(), dVarOut, rv.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream)); CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+        if (varCheck) {
+            int32_t rcx = need_X(); if (rcx) return rcx;
+            const std::vector<float> hv = variability_by_window(window, nchr, X.data(), off.data());
+            bool same = hv.size() == rv.size();
+            for (size_t i = 0; same && i < hv.size(); i++) same = memcmp(&hv[i], &rv[i], 4) == 0 || (hv[i] != hv[i] && rv[i] != rv[i]);
+            if (!same) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's window variabilities differ from the host's");
+        }
+        return CANVAS_OK;
+    };
+    const bool hasCV = N >= 10 * (int64_t)variability_window;
+    const int firstWindow = variability_window > 10000 ? 10000 : variability_window;
+    if (hasCV && varOnDevice) { rc = var_enqueue(firstWindow); if (rc) return rc; }
+    // ---- roots: chromosomes longer than MinSize (WaveletsRunner.cs:117-126); their medians (order statistics of whole chromosomes: one host thread each) next to the device
+    std::vector<char> isRoot((size_t)nchr, 0);
+    for (int c = 0; c < nchr; c++) {
+        const int64_t L = off[c + 1] - off[c];
+        if (std::max<int64_t>(L, 1) <= min_size || (h_mask && !h_mask[c])) continue;
+        if (L < 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: a chromosome that passes MinSize needs at least two bins");
+        isRoot[(size_t)c] = 1;
     }
-    // ---- the factor-of-three statistics (needed by the healing step only): enqueued now on a stream of their own, read at the end
-    int f3Levels = 0; long long f3Count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (f3OnDevice) {
+    std::vector<double> chromMedian((size_t)nchr, 0.0), chromMad((size_t)nchr, 0.0);
+    const bool medOnDevice = hasCV && varOnDevice && tryClosedForm && !cvx_hook("CANVAS_WV_MEDIAN_HOST");      // (tryClosedForm: dOff is on the device)
+    const bool medFromIntegers = medOnDevice && (size_t)nchr <= WV_MED_MAXR && !cvx_hook("CANVAS_WV_MEDIAN_PER_WG");      // (needs the integers of k_wv_prefix_tiles: checked below)
+    auto chrom_median_per_wg = [&]() -> int32_t {            // one workgroup per chromosome over the doubles (any finite coverage)
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dIsRoot, isRoot.data(), (size_t)nchr, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_wv_chrom_median, dim3((unsigned)nchr), dim3(1024), 0, ctx->stream, dX, dOff, dIsRoot, dChromMed);
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(chromMedian.data(), dChromMed, (size_t)nchr * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));      // (waited for with the window statistics below)
+        return CANVAS_OK;
+    };
+    if (medFromIntegers) {
+        std::vector<long long> st((size_t)nchr), ln((size_t)nchr);
+        for (int c = 0; c < nchr; c++) { st[(size_t)c] = off[c]; ln[(size_t)c] = isRoot[(size_t)c] ? off[c + 1] - off[c] : 0; }
+        rc = medians_enqueue(st, ln, dChromMed); if (rc) return rc;
+        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(chromMedian.data(), dChromMed, (size_t)nchr * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    } else if (medOnDevice) { rc = chrom_median_per_wg(); if (rc) return rc; }
+    bool medResolved = !medFromIntegers;
+    auto resolve_medians = [&]() -> int32_t {                // behind a synchronisation of the main stream: a coverage that is not made of two-decimal values has no integers
+        if (medResolved) return CANVAS_OK;
+        medResolved = true;
+        if (!hBad[0]) return CANVAS_OK;
+        int32_t rcm = chrom_median_per_wg(); if (rcm) return rcm;
+        CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return CANVAS_OK;
+    };
+    if (!medOnDevice || varCheck) {
+        rc = need_X(); if (rc) return rc;
+        std::vector<double> hostMedian((size_t)nchr, 0.0);
+        host_parallel_for(nchr, [&](int64_t c) {
+            if (!isRoot[(size_t)c]) return;
+            const int64_t L = off[c + 1] - off[c];
+            const double* r = X.data() + off[c];
+            hostMedian[(size_t)c] = median_range(r, 0, L);
+            if (!hasCV) chromMad[(size_t)c] = mad_range(r, 0, L);
+        });
+        if (medOnDevice) {       // CANVAS_WV_VAR_CHECK: both, compared
+            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            rc = resolve_medians(); if (rc) return rc;
+            for (int c = 0; c < nchr; c++) if (isRoot[(size_t)c] && memcmp(&hostMedian[(size_t)c], &chromMedian[(size_t)c], 8) != 0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's chromosome medians differ from the host's");
+        } else chromMedian.swap(hostMedian);
+    }
+    // ---- the factor-of-three statistics (needed by the healing step only): enqueued on a stream of their own, read at the end (144 launches: behind the enqueue of everything the thresholds wait for)
+    int f3Levels = 0; long long f3Count[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool f3Enqueued = false;
+    auto f3_enqueue = [&]() -> int32_t {                     // called where the host would otherwise wait: behind the first two batches of levels (or wherever the call leaves that path)
+        if (f3Enqueued || !f3OnDevice) return CANVAS_OK;
+        f3Enqueued = true;
         const int maxExponent = 8;
         WvF3Level lv; lv.nchr = nchr;
         std::vector<long long> len((size_t)nchr);
@@ -1020,64 +1259,9 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             for (int c = 0; c < nchr; c++) { len[(size_t)c] /= 3; lv.inOff[c] = lv.outOff[c]; }
             lv.inOff[nchr] = lv.outOff[nchr];
         }
-    }
-    // ---- SegmentationInput.GetCoverageVariability (Segmentation.cs:308-328): the per-window statistics come from the device (CANVAS_WV_VAR_HOST=1: the host threads;
-    // CANVAS_WV_VAR_CHECK=1: both, compared), the order statistics over the few hundred windows stay on the host
-    const bool varOnDevice = !cvx_hook("CANVAS_WV_VAR_HOST"), varCheck = cvx_hook("CANVAS_WV_VAR_CHECK") != nullptr;
-    std::vector<long long> varStart;
-    auto var_enqueue = [&](int window) -> int32_t {          // one workgroup per window, results left in dVarOut
-        varStart.clear();
-        for (int c = 0; c < nchr; c++) { const int64_t L = off[c + 1] - off[c]; for (int64_t i = 0; i < L - window; i += window) varStart.push_back(off[c] + i); }
-        if (varStart.size() > varCap) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: variability staging");
-        if (varStart.empty()) return CANVAS_OK;
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVarStart, varStart.data(), varStart.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_wv_variability, dim3((unsigned)varStart.size()), dim3(1024), 0, ctx->stream, dX, dVarStart, window, dVarOut);
         return CANVAS_OK;
     };
-    auto var_collect = [&](int window, std::vector<float>& rv) -> int32_t {
-        rv.assign(varStart.size(), 0.0f);
-        if (!rv.empty()) { CANVAS_HIP_TRY(ctx, hipMemcpyAsync(rv.data(), dVarOut, rv.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream)); CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
-        if (varCheck) {
-            const std::vector<float> hv = variability_by_window(window, nchr, X.data(), off.data());
-            bool same = hv.size() == rv.size();
-            for (size_t i = 0; same && i < hv.size(); i++) same = memcmp(&hv[i], &rv[i], 4) == 0 || (hv[i] != hv[i] && rv[i] != rv[i]);
-            if (!same) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's window variabilities differ from the host's");
-        }
-        return CANVAS_OK;
-    };
-    const bool hasCV = N >= 10 * (int64_t)variability_window;
-    const int firstWindow = variability_window > 10000 ? 10000 : variability_window;
-    if (hasCV && varOnDevice) { rc = var_enqueue(firstWindow); if (rc) return rc; }
-    // ---- roots: chromosomes longer than MinSize (WaveletsRunner.cs:117-126); their medians (order statistics of whole chromosomes: one host thread each) next to the device
-    std::vector<char> isRoot((size_t)nchr, 0);
-    for (int c = 0; c < nchr; c++) {
-        const int64_t L = off[c + 1] - off[c];
-        if (std::max<int64_t>(L, 1) <= min_size || (h_mask && !h_mask[c])) continue;
-        if (L < 2) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: a chromosome that passes MinSize needs at least two bins");
-        isRoot[(size_t)c] = 1;
-    }
-    std::vector<double> chromMedian((size_t)nchr, 0.0), chromMad((size_t)nchr, 0.0);
-    const bool medOnDevice = hasCV && varOnDevice && tryClosedForm && !cvx_hook("CANVAS_WV_MEDIAN_HOST");      // (tryClosedForm: dOff is on the device)
-    if (medOnDevice) {
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dIsRoot, isRoot.data(), (size_t)nchr, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_wv_chrom_median, dim3((unsigned)nchr), dim3(1024), 0, ctx->stream, dX, dOff, dIsRoot, dChromMed);
-        CANVAS_HIP_TRY(ctx, hipMemcpyAsync(chromMedian.data(), dChromMed, (size_t)nchr * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));      // (waited for with the window statistics below)
-    }
-    if (!medOnDevice || varCheck) {
-        std::vector<double> hostMedian((size_t)nchr, 0.0);
-        host_parallel_for(nchr, [&](int64_t c) {
-            if (!isRoot[(size_t)c]) return;
-            const int64_t L = off[c + 1] - off[c];
-            const double* r = X.data() + off[c];
-            hostMedian[(size_t)c] = median_range(r, 0, L);
-            if (!hasCV) chromMad[(size_t)c] = mad_range(r, 0, L);
-        });
-        if (medOnDevice) {       // CANVAS_WV_VAR_CHECK: both, compared
-            CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            for (int c = 0; c < nchr; c++) if (isRoot[(size_t)c] && memcmp(&hostMedian[(size_t)c], &chromMedian[(size_t)c], 8) != 0) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: the device's chromosome medians differ from the host's");
-        } else chromMedian.swap(hostMedian);
-    }
-    if (hasCV && !varOnDevice) { const bool got = coverage_variability(variability_window, nchr, X.data(), off.data(), cv); (void)got; }
+    if (hasCV && !varOnDevice) { rc = need_X(); if (rc) return rc; const bool got = coverage_variability(variability_window, nchr, X.data(), off.data(), cv); (void)got; }
     else if (hasCV) {
         std::vector<float> rv;
         rc = var_collect(firstWindow, rv); if (rc) return rc;
@@ -1090,6 +1274,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         }
     }
 
+    if (!medResolved) { CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); rc = resolve_medians(); if (rc) return rc; }
     const double t1 = now();
     std::vector<ChromTree> trees(nchr);
     std::vector<HNode> cur, nxt;
@@ -1112,6 +1297,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         for (int c = 0; c < nchr; c++) keep[c] = trees[c].keepAbove;
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dKeep, keep.data(), nchr * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the other streams start from initialised buffers
+        if (tryClosedForm && hBad[1]) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: coverage must be finite");      // (k_wv_prefix_tiles looked at every bin)
     }
     PinVec<WvNode> hNodes; PinVec<WvOut> hOut; PinVec<int32_t> hLong, hBase, hRedo; std::vector<WvRoot> hRoots;
     WvNode* hNodesE = nullptr; int32_t *hLongE = nullptr, *hBaseE = nullptr, *hLimE = nullptr; long long* hOpsOffE = nullptr; WvDev *hdevIn = nullptr, *hdevRep[2] = {nullptr, nullptr}; WvDNode* hExactPin[2] = {nullptr, nullptr}; int32_t* hExactIndPin[2] = {nullptr, nullptr};
@@ -1184,6 +1370,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         closedForm = bad == 0;
     }
+    if (!closedForm) { rc = f3_enqueue(); if (rc) return rc; }
     double tcA = now(), tcLevels = 0, tcUndec = 0, tcExact = 0;
     if (closedForm) {
         // ---- FindBestUnbalancedHaarDecomposition (WaveletSegmentation.cs:252-366) on the device: one launch per level, the host reads the counters once per batch of levels
@@ -1301,7 +1488,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             exactSeen += k;
             return CANVAS_OK;
         };
-        static const unsigned levelGrid = [] { const char* e = cvx_hook("CANVAS_WV_LEVEL_GRID"); const int v = e ? atoi(e) : 1024; return (unsigned)(v >= 64 && v <= 8192 ? v : 1024); }();
+        static const unsigned levelGrid = [] { const char* e = cvx_hook("CANVAS_WV_LEVEL_GRID"); const int v = e ? atoi(e) : 2048; return (unsigned)(v >= 64 && v <= 8192 ? v : 2048); }();      // (2 048 workgroups of 256 = eight waves per SIMD: levels 13.6-14.6 -> 13.0-13.2 ms against 1 024; 4 096: 12.7)
         while (!hList.empty()) {
             if (hList.size() > maxLong) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: long-node list overflow");
             const int nIn = (int)hList.size();
@@ -1328,6 +1515,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             };
             rc = enqueue_batch(0); if (rc) return rc;
             rc = enqueue_batch(1); if (rc) return rc;
+            rc = f3_enqueue(); if (rc) return rc;                // (the host would wait for the first batch now)
             for (int k = 0;; k++) {
                 const int slot = k & 1, lb = lbOf[slot];
                 const double tw0 = now();
@@ -1502,6 +1690,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     // ---- per chromosome: HardThresh, reconstruction, healing, refinement (WaveletSegmentation.cs:73-250, 373-425); the chromosomes are independent (the reference runs
     // them under Parallel.ForEach, WaveletsRunner.cs:115-135): one task per chromosome on a few host threads, results concatenated in chromosome order
     if (f3Thread.joinable()) f3Thread.join();
+    rc = f3_enqueue(); if (rc) return rc;                        // (a call that never entered the level loop)
     if (f3OnDevice) {
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->wv_sub2));
         for (int e = 1; e <= f3Levels; e++) { int32_t rcm = cvx_mail_await(ctx, hF3Seq + (e - 1), f3Seq[e - 1], "canvas_wavelets: factor-of-three medians"); if (rcm) return rcm; }
@@ -1614,6 +1803,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         worker();
         for (auto& t : pool) t.join();
     };
+    rc = need_X(); if (rc) return rc;
     run_phase(0);
     {   // the medians between consecutive preliminary breakpoints, all chromosomes in one launch (one workgroup per stretch); CANVAS_WV_HEAL_HOST=1: on the host as before
         std::vector<unsigned long long> segs;
@@ -1626,8 +1816,14 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         bool okLen = true; for (unsigned long long v : segs) if ((v & 0xFFFFFFFFull) == 0) okLen = false;
         if (!segs.empty() && okLen && segs.size() <= varCap && !cvx_hook("CANVAS_WV_HEAL_HOST")) {
             segMed.assign(segs.size(), 0.0);
-            CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVarStart, segs.data(), segs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_wv_segment_median, dim3((unsigned)segs.size()), dim3(1024), 0, ctx->stream, dX, (const unsigned long long*)dVarStart, dSegMed);
+            if (closedForm && segs.size() <= WV_MED_MAXR && !cvx_hook("CANVAS_WV_MEDIAN_PER_WG")) {      // (closedForm: every bin has its integer)
+                std::vector<long long> st(segs.size()), ln(segs.size());
+                for (size_t k = 0; k < segs.size(); k++) { st[k] = (long long)(segs[k] >> 32); ln[k] = (long long)(segs[k] & 0xFFFFFFFFull); }
+                rc = medians_enqueue(st, ln, dSegMed); if (rc) return rc;
+            } else {
+                CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dVarStart, segs.data(), segs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_wv_segment_median, dim3((unsigned)segs.size()), dim3(1024), 0, ctx->stream, dX, (const unsigned long long*)dVarStart, dSegMed);
+            }
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(segMed.data(), dSegMed, segs.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             CANVAS_HIP_TRY(ctx, hipGetLastError());
