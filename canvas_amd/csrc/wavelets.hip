@@ -248,12 +248,15 @@ __global__ void __launch_bounds__(256) k_wv_fgh_table(WvFgh* __restrict__ tab, i
         tab[(size_t)n * (size_t)(L + 1) + (size_t)m] = t;
     }
 }
-__global__ void __launch_bounds__(64) k_wv_subtree(const WvRoot* __restrict__ roots, int nroots, const double* __restrict__ X, const double* __restrict__ keepAbove,
+#define WV_REP 16          // replicas of the level loop's counters (WvCn below)
+struct WvRootSegs { int n; int start[WV_REP + 1], count[WV_REP + 1]; };      // stretches of the root array of one launch: the host's own and one per replica of the level loop
+__global__ void __launch_bounds__(64) k_wv_subtree(const WvRoot* __restrict__ roots, const WvRootSegs segs, const double* __restrict__ X, const double* __restrict__ keepAbove,
                                                    uint32_t* __restrict__ stack, int32_t* __restrict__ counts, WvCand* __restrict__ cands,
                                                    unsigned long long* __restrict__ ncand, unsigned long long capCand, int32_t* __restrict__ overflow, const WvFgh* __restrict__ fgh, int fghLen) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= nroots) return;
-    const WvRoot R = roots[i];
+    int i = blockIdx.x * 64 + threadIdx.x, sg = 0;
+    while (sg < segs.n && i >= segs.count[sg]) { i -= segs.count[sg]; sg++; }
+    if (sg >= segs.n) return;
+    const WvRoot R = roots[(size_t)segs.start[sg] + i];
     const double* __restrict__ xr = X + R.start;
     uint32_t* __restrict__ st = stack + R.start;
     const double keep = keepAbove[R.chrom];
@@ -338,7 +341,14 @@ __global__ void __launch_bounds__(64) k_wv_subtree(const WvRoot* __restrict__ ro
 struct WvDNode { int32_t start, len, chrom, level; };      // start: index into the concatenated coverage
 struct LongBufs { WvNode* nodes; WvOut* out; int32_t *list, *base, *flag; WvHead* head; WvCk* ck; WvBest* best; };      // what one pass of the chain kernels works on
 #define WV_EB 1024        // launches of early exact chains between two harvests (each takes a base entry more than it has nodes)
-struct WvDev { unsigned int cnt[WV_LB + 2], nch[WV_LB + 2]; unsigned int nRoots, nExact, nUndec, overflow, exactReported, seq, pad[2]; };      // seq: number of the batch whose end wrote this report (written last)
+struct WvDev { unsigned int cnt[WV_LB + 2], nch[WV_LB + 2]; unsigned int nRoots, nExact, nUndec, overflow, exactReported, seq, pad[2]; unsigned int nRootsR[WV_REP]; };      // seq: number of the batch whose end wrote this report (written last)
+// The lists of a level are appended to by whichever workgroup finishes a node, and every append used to be two device atomics on the level's two counters (and one on the
+// root counter for a short child): a few thousand per level on ONE line each, performed one after the other at the memory side — and every workgroup's first load (the
+// chunk count of its own level) sat in the same queue.  One more atomic per append cost the level loop 6 of its 13 ms (measured with a dummy).  So the counters are
+// REPLICATED: WV_REP lists per level, each with its own counter line (nodes | chunks << 32: one atomic per append) and its own stretch of the slot / chunk / root arrays;
+// a workgroup appends to replica blockIdx % WV_REP, and a level walks the replicas' chunks as one index space.  cnt[] / nch[] / nRootsR[] of WvDev are the REPORT
+// k_wv_batch_end sums up for the host.
+struct WvCn { unsigned long long cn; unsigned long long pad[15]; };      // one counter on a 128-byte line of its own
 __device__ __forceinline__ long long wv_block_scan_i64(long long v, long long* sh /* [17] */, long long* total) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     long long inc = v;
@@ -510,31 +520,42 @@ struct WvPart { double lw, t, b, u1, u2; int32_t idx, i1; };
 struct WvSlot { WvDNode nd; int32_t chunkBase, arrived; };      // a node of the current level + where its chunks start + how many of them are done
 __device__ __forceinline__ void wv_st_f64(double* p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wv_st_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// appends a long node to the list of iteration `it` (count dev->cnt[it], chunks dev->nch[it]): slot, chunk range, chunk -> slot map
-__device__ __forceinline__ void wv_push_long(WvSlot* __restrict__ list, int32_t* __restrict__ chunkNode, WvDev* __restrict__ dev, int it, unsigned maxList, unsigned maxChunks, const WvDNode& nd) {
-    const unsigned slot = atomicAdd(&dev->cnt[it], 1u);
+// appends a long node to replica r of a level's list: slot, chunk range, chunk -> slot map (global numbers: replica x capacity + local)
+__device__ __forceinline__ void wv_push_long(WvSlot* __restrict__ list, int32_t* __restrict__ chunkNode, WvDev* __restrict__ dev, WvCn* __restrict__ cnLevel /* [WV_REP] of the level */, unsigned r,
+                                             unsigned listCap, unsigned chCap, const WvDNode& nd) {
     const int nch = (int)((nd.len - 1 + WV_CH - 1) / WV_CH);                    // m = 0 .. len - 2
-    const unsigned cb = atomicAdd(&dev->nch[it], (unsigned)nch);
-    if (slot >= maxList || cb + (unsigned)nch > maxChunks) { dev->overflow = 1u; return; }
-    WvSlot sl; sl.nd = nd; sl.chunkBase = (int32_t)cb; sl.arrived = 0;
-    list[slot] = sl;
-    for (int c = 0; c < nch; c++) chunkNode[cb + c] = (int32_t)slot;
+    const unsigned long long old = atomicAdd(&cnLevel[r].cn, ((unsigned long long)(unsigned)nch << 32) | 1ull);
+    const unsigned slot = (unsigned)(old & 0xFFFFFFFFull), cb = (unsigned)(old >> 32);
+    if (slot >= listCap || cb + (unsigned)nch > chCap) { dev->overflow = 1u; return; }
+    WvSlot sl; sl.nd = nd; sl.chunkBase = (int32_t)(r * chCap + cb); sl.arrived = 0;
+    list[(size_t)r * listCap + slot] = sl;
+    for (int c = 0; c < nch; c++) chunkNode[(size_t)r * chCap + cb + c] = (int32_t)(r * listCap + slot);
 }
 // the host's node list (level 0, or the children of nodes the chain decided) becomes the list of iteration 0
-__global__ void __launch_bounds__(256) k_wv_list_init(const WvDNode* __restrict__ in, int n, WvSlot* __restrict__ list, int32_t* __restrict__ chunkNode, WvDev* __restrict__ dev, unsigned maxList, unsigned maxChunks) {
+__global__ void __launch_bounds__(256) k_wv_list_init(const WvDNode* __restrict__ in, int n, WvSlot* __restrict__ list, int32_t* __restrict__ chunkNode, WvDev* __restrict__ dev, WvCn* __restrict__ cn, unsigned listCap, unsigned chCap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) wv_push_long(list, chunkNode, dev, 0, maxList, maxChunks, in[i]);
+    if (i < n) wv_push_long(list, chunkNode, dev, cn, (unsigned)i % WV_REP, listCap, chCap, in[i]);
 }
 // One level of the tree for the long nodes in `cur` (dev->cnt[it] nodes, dev->nch[it] chunks): a workgroup per chunk (grid-stride).
 __global__ void __launch_bounds__(256) k_wv_level(WvSlot* __restrict__ cur, const int32_t* __restrict__ curChunkNode, WvSlot* __restrict__ nxt, int32_t* __restrict__ nxtChunkNode, WvPart* __restrict__ parts,
-                                                  WvDev* __restrict__ dev, int it, unsigned maxList, unsigned maxChunks, unsigned maxList2,
+                                                  WvDev* __restrict__ dev, WvCn* __restrict__ cn /* [levels][WV_REP] */, WvCn* __restrict__ rootCn /* [WV_REP] */, int it, unsigned maxList /* per replica */, unsigned maxChunks /* per replica */, unsigned maxList2,
                                                   const long long* __restrict__ P1, const long long* __restrict__ P2, const long long* __restrict__ off, const double* __restrict__ keepAbove,
                                                   WvRoot* __restrict__ roots, unsigned maxRoots, WvDNode* __restrict__ exactList, int32_t* __restrict__ exactInd, WvDNode* __restrict__ undecList, int32_t* __restrict__ counts, int WV_LONG) {
     __shared__ WvPart sP[4];
     __shared__ int sLast;
-    const unsigned nChunks = min(dev->nch[it], maxChunks);
+    // the replicas' chunks as one index space: replica r holds [pre[r], pre[r + 1])
+    __shared__ unsigned sPre[WV_REP + 1];
+    if (threadIdx.x < WV_REP) sPre[threadIdx.x + 1] = min((unsigned)(cn[(size_t)it * WV_REP + threadIdx.x].cn >> 32), maxChunks);
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned a = 0; sPre[0] = 0; for (int r = 0; r < WV_REP; r++) { a += sPre[r + 1]; sPre[r + 1] = a; } }
+    __syncthreads();
+    const unsigned nChunks = sPre[WV_REP], myRep = blockIdx.x % WV_REP;
+    WvCn* __restrict__ cnNext = cn + (size_t)(it + 1) * WV_REP;
     const double u = 1.1102230246251565e-16;
-    for (unsigned ch = blockIdx.x; ch < nChunks; ch += gridDim.x) {
+    for (unsigned v = blockIdx.x; v < nChunks; v += gridDim.x) {
+        unsigned rr = 0;
+        while (v >= sPre[rr + 1]) rr++;
+        const unsigned ch = rr * maxChunks + (v - sPre[rr]);                  // the chunk's number in the arrays
         const int slot = curChunkNode[ch];
         const WvDNode nd = cur[slot].nd;
         const int cbIdx = cur[slot].chunkBase;
@@ -563,42 +584,56 @@ __global__ void __launch_bounds__(256) k_wv_level(WvSlot* __restrict__ cur, cons
             if (lw > bLw) { bLw = lw; bT = T; bB = B; bIdx = (int32_t)m; }
             if (up > u1) { u2 = u1; u1 = up; i1 = (int32_t)m; } else if (up > u2) u2 = up;
         }
-        // ---- workgroup: best lower bound; the two largest upper bounds
+        // ---- workgroup: best lower bound; the two largest upper bounds (every thread's candidate -> `best` of thread 0; two barriers)
+        WvPart best;
+        auto wg_reduce = [&]() {
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const double oLw = __shfl_xor(bLw, d, 64), oT = __shfl_xor(bT, d, 64), oB = __shfl_xor(bB, d, 64); const int32_t oI = __shfl_xor(bIdx, d, 64);
-            if (oLw > bLw || (oLw == bLw && oI < bIdx)) { bLw = oLw; bT = oT; bB = oB; bIdx = oI; }
-            const double o1 = __shfl_xor(u1, d, 64), o2 = __shfl_xor(u2, d, 64); const int32_t oi1 = __shfl_xor(i1, d, 64);
-            if (o1 > u1) { u2 = fmax(u1, o2); u1 = o1; i1 = oi1; } else u2 = fmax(u2, o1);
-        }
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) { WvPart pk; pk.lw = bLw; pk.t = bT; pk.b = bB; pk.u1 = u1; pk.u2 = u2; pk.idx = bIdx; pk.i1 = i1; sP[threadIdx.x >> 6] = pk; }
-        __syncthreads();
-        const int nch = (int)((n - 1 + WV_CH - 1) / WV_CH);
-        if (threadIdx.x == 0) {
-            WvPart best = sP[0];
-            for (int w = 1; w < 4; w++) {
-                const WvPart o = sP[w];
-                if (o.u1 > best.u1) { best.u2 = fmax(best.u1, o.u2); best.u1 = o.u1; best.i1 = o.i1; } else best.u2 = fmax(best.u2, o.u1);
-                if (o.lw > best.lw || (o.lw == best.lw && o.idx < best.idx)) { best.lw = o.lw; best.t = o.t; best.b = o.b; best.idx = o.idx; }
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double oLw = __shfl_xor(bLw, d, 64), oT = __shfl_xor(bT, d, 64), oB = __shfl_xor(bB, d, 64); const int32_t oI = __shfl_xor(bIdx, d, 64);
+                if (oLw > bLw || (oLw == bLw && oI < bIdx)) { bLw = oLw; bT = oT; bB = oB; bIdx = oI; }
+                const double o1 = __shfl_xor(u1, d, 64), o2 = __shfl_xor(u2, d, 64); const int32_t oi1 = __shfl_xor(i1, d, 64);
+                if (o1 > u1) { u2 = fmax(u1, o2); u1 = o1; i1 = oi1; } else u2 = fmax(u2, o1);
             }
-            int last = 1;
-            if (nch > 1) {
-                // publish the chunk's result (write-through), then the arrival ticket; the last chunk of the node acquires and combines
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) { WvPart pk; pk.lw = bLw; pk.t = bT; pk.b = bB; pk.u1 = u1; pk.u2 = u2; pk.idx = bIdx; pk.i1 = i1; sP[threadIdx.x >> 6] = pk; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                best = sP[0];
+                for (int w = 1; w < 4; w++) {
+                    const WvPart o = sP[w];
+                    if (o.u1 > best.u1) { best.u2 = fmax(best.u1, o.u2); best.u1 = o.u1; best.i1 = o.i1; } else best.u2 = fmax(best.u2, o.u1);
+                    if (o.lw > best.lw || (o.lw == best.lw && o.idx < best.idx)) { best.lw = o.lw; best.t = o.t; best.b = o.b; best.idx = o.idx; }
+                }
+            }
+        };
+        wg_reduce();
+        const int nch = (int)((n - 1 + WV_CH - 1) / WV_CH);
+        bool lastOfNode = true;
+        if (nch > 1) {
+            // publish the chunk's result (write-through), then the arrival ticket; the last chunk of the node acquires and combines — with the whole workgroup: one
+            // thread walking the 186 parts of a 380 000-bin chromosome was 55 us, the floor of every level that still held such a node (the top levels, and every level
+            // of a stretch that keeps shedding short pieces)
+            if (threadIdx.x == 0) {
                 WvPart* pp = parts + ch;
                 wv_st_f64(&pp->lw, best.lw); wv_st_f64(&pp->t, best.t); wv_st_f64(&pp->b, best.b); wv_st_f64(&pp->u1, best.u1); wv_st_f64(&pp->u2, best.u2); wv_st_i32(&pp->idx, best.idx); wv_st_i32(&pp->i1, best.i1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                last = (__hip_atomic_fetch_add(&cur[slot].arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == nch) ? 1 : 0;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    for (int c = 0; c < nch; c++) {
-                        if ((unsigned)(cbIdx + c) == ch) continue;
-                        const WvPart o = parts[cbIdx + c];
-                        if (o.u1 > best.u1) { best.u2 = fmax(best.u1, o.u2); best.u1 = o.u1; best.i1 = o.i1; } else best.u2 = fmax(best.u2, o.u1);
-                        if (o.lw > best.lw || (o.lw == best.lw && o.idx < best.idx)) { best.lw = o.lw; best.t = o.t; best.b = o.b; best.idx = o.idx; }
-                    }
-                }
+                sLast = (__hip_atomic_fetch_add(&cur[slot].arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == nch) ? 1 : 0;
             }
+            __syncthreads();
+            lastOfNode = sLast != 0;
+            if (lastOfNode) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                bLw = -1.0e300; bT = 0.0; bB = 0.0; bIdx = 0x7FFFFFFF; u1 = -1.0e300; u2 = -1.0e300; i1 = -1;
+                for (int c = (int)threadIdx.x; c < nch; c += 256) {
+                    const WvPart o = parts[cbIdx + c];
+                    if (o.u1 > u1) { u2 = fmax(u1, o.u2); u1 = o.u1; i1 = o.i1; } else u2 = fmax(u2, o.u1);
+                    if (o.lw > bLw || (o.lw == bLw && o.idx < bIdx)) { bLw = o.lw; bT = o.t; bB = o.b; bIdx = o.idx; }
+                }
+                wg_reduce();
+            }
+        }
+        if (threadIdx.x == 0) {
+            const int last = lastOfNode ? 1 : 0;
             if (last) {
                 const double others = best.i1 == best.idx ? best.u2 : best.u1;   // the largest upper bound among the OTHER indices
                 const bool decided = best.lw > others;
@@ -611,8 +646,8 @@ __global__ void __launch_bounds__(256) k_wv_level(WvSlot* __restrict__ cur, cons
                     const long long b = s + best.idx, e = s + n - 1;
                     auto place = [&](long long cs, long long ce) {
                         const int32_t len = (int32_t)(ce - cs + 1);
-                        if (len > WV_LONG) wv_push_long(nxt, nxtChunkNode, dev, it + 1, maxList, maxChunks, WvDNode{(int32_t)cs, len, nd.chrom, nd.level + 1});
-                        else { const unsigned k = atomicAdd(&dev->nRoots, 1u); if (k < maxRoots) roots[k] = WvRoot{(int32_t)cs, len, nd.chrom, nd.level + 1, (int32_t)(cs - cbase + 1), (int32_t)cbase}; else dev->overflow = 1u; }
+                        if (len > WV_LONG) wv_push_long(nxt, nxtChunkNode, dev, cnNext, myRep, maxList, maxChunks, WvDNode{(int32_t)cs, len, nd.chrom, nd.level + 1});
+                        else { const unsigned k = (unsigned)atomicAdd(&rootCn[myRep].cn, 1ull); if (k < maxRoots) roots[(size_t)myRep * maxRoots + k] = WvRoot{(int32_t)cs, len, nd.chrom, nd.level + 1, (int32_t)(cs - cbase + 1), (int32_t)cbase}; else dev->overflow = 1u; }
                     };
                     if (b - s >= 1) place(s, b);
                     if (e - b >= 2) place(b + 1, e);
@@ -633,19 +668,32 @@ __global__ void __launch_bounds__(256) k_wv_level(WvSlot* __restrict__ cur, cons
 // End of a batch of `lb` levels, on the device: the counters as they stand and the entries the exact list has gained go straight into pinned host memory (the host waits
 // for an event and reads them: no copy on the stream — one behind a batch of levels stood still until the chain kernel on the OTHER stream had finished, 9 ms), then the pending
 // level becomes level 0 of the next batch.  The next batch is enqueued before this one has been looked at; if nothing is pending its launches find empty lists.
-__global__ void __launch_bounds__(256) k_wv_batch_end(WvDev* __restrict__ dev, int lb, const WvDNode* __restrict__ exactList, const int32_t* __restrict__ exactInd,
+__global__ void __launch_bounds__(256) k_wv_batch_end(WvDev* __restrict__ dev, WvCn* __restrict__ cn, const WvCn* __restrict__ rootCn, int lb, const WvDNode* __restrict__ exactList, const int32_t* __restrict__ exactInd,
                                                       WvDev* __restrict__ pinDev, WvDNode* __restrict__ pinExact, int32_t* __restrict__ pinExactInd, unsigned maxCopy, unsigned seq) {
     const unsigned from = dev->exactReported, nE = dev->nExact;
     const unsigned k = nE > from ? min(nE - from, maxCopy) : 0u;
-    { const unsigned* src = (const unsigned*)dev; unsigned* dst = (unsigned*)pinDev; for (unsigned i = threadIdx.x; i < sizeof(WvDev) / 4; i += 256) if (i != offsetof(WvDev, seq) / 4) dst[i] = src[i]; }
+    // the report: the device's block with the replicas of every level summed up (nodes, chunks) and the replicas' root counts
+    { const unsigned* src = (const unsigned*)dev; unsigned* dst = (unsigned*)pinDev; const unsigned w0 = offsetof(WvDev, nRoots) / 4, w1 = offsetof(WvDev, nRootsR) / 4;
+      for (unsigned i = w0 + threadIdx.x; i < w1; i += 256) if (i != offsetof(WvDev, seq) / 4) dst[i] = src[i]; }
+    for (int lv = threadIdx.x; lv < WV_LB + 2; lv += 256) {             // (levels behind lb + 1 have not been touched since they were cleared)
+        unsigned c = 0, n = 0;
+        if (lv <= lb + 1) for (int r = 0; r < WV_REP; r++) { const unsigned long long q = cn[(size_t)lv * WV_REP + r].cn; c += (unsigned)(q & 0xFFFFFFFFull); n += (unsigned)(q >> 32); }
+        pinDev->cnt[lv] = c; pinDev->nch[lv] = n;
+    }
+    if (threadIdx.x < WV_REP) pinDev->nRootsR[threadIdx.x] = (unsigned)rootCn[threadIdx.x].cn;
     for (unsigned i = threadIdx.x; i < k; i += 256) { pinExact[i] = exactList[from + i]; pinExactInd[i] = exactInd[from + i]; }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_store(&pinDev->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word: everything above is in host memory before it
-        const unsigned c = dev->cnt[lb], n = dev->nch[lb];
-        for (int i = 1; i < WV_LB + 2; i++) { dev->cnt[i] = 0; dev->nch[i] = 0; }
-        dev->cnt[0] = c; dev->nch[0] = n; dev->exactReported = from + k;
+        dev->exactReported = from + k;
+    }
+    // the pending level becomes level 0 of the next batch, replica by replica (a replica's list is where it was: list A / B by the parity of lb, which is even)
+    for (int i = threadIdx.x; i < (lb + 2) * WV_REP; i += 256) {
+        const int lv = i / WV_REP, r = i % WV_REP;
+        if (lv == 0) continue;
+        if (lv == lb) cn[r].cn = cn[i].cn;
+        cn[i].cn = 0ull;
     }
 }
 
@@ -1079,16 +1127,19 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } f3Join{f3Thread};      // joined on every exit path
     // ---- device buffers
     const size_t maxLong = (size_t)N / WV_LONG + (size_t)nchr + 16, maxChunks = 3 * (size_t)N / WV_CS + maxLong + 16, maxRoots = (size_t)N / 2 + (size_t)nchr + 16;
+    const size_t maxCh = (size_t)N / WV_CH + maxLong + 16;
+    // the level loop's lists are WV_REP replicas (see WvCn): a replica takes an eighth of the worst case of the whole level (twice its even share; whoever appends is picked
+    // by the chunk's number, which deals the appends out evenly) — but never less than one node can need
+    const size_t listCap = maxLong / 8 + 1024, chCap = std::max(maxCh / 8, (size_t)N / WV_CH + 16) + 4096, rootCap = maxRoots / 8 + 4096, nCn = (size_t)(WV_LB + 3) * WV_REP;
     const unsigned long long capCand = (unsigned long long)N + 16;
     WsSizer sz;
     const size_t opsCap = 5 * (size_t)N;                                  // the exact chains of nodes of several levels (which overlap in position) run side by side: [N, 5 N); the first N belong to the level loop's own passes
     sz.take<WvOps>(opsCap); sz.take<WvNode>(maxLong); sz.take<WvOut>(maxLong); sz.take<int32_t>(maxLong);
     sz.take<int32_t>(maxLong + 1); sz.take<int32_t>(maxLong); sz.take<WvHead>(maxLong); sz.take<WvCk>(maxChunks); sz.take<WvBest>(maxChunks);
-    sz.take<WvRoot>(maxRoots); sz.take<uint32_t>((size_t)N); sz.take<int32_t>((size_t)N); sz.take<WvCand>((size_t)capCand); sz.take<double>(nchr); sz.take<unsigned long long>(2);
+    sz.take<WvRoot>(maxRoots + WV_REP * rootCap); sz.take<uint32_t>((size_t)N); sz.take<int32_t>((size_t)N); sz.take<WvCand>((size_t)capCand); sz.take<double>(nchr); sz.take<unsigned long long>(2);
     const size_t maxList2 = (size_t)N / 8 + 1024;                          // nodes of ALL levels that wait for the exact chain
-    const size_t maxCh = (size_t)N / WV_CH + maxLong + 16;
-    sz.take<long long>((size_t)N); sz.take<long long>((size_t)N); sz.take<long long>(nchr + 1); sz.take<int>(4); sz.take<WvSlot>(maxLong); sz.take<WvSlot>(maxLong); sz.take<WvDNode>(maxList2); sz.take<int32_t>(maxList2);
-    sz.take<int32_t>(maxCh); sz.take<int32_t>(maxCh); sz.take<WvPart>(maxCh); sz.take<WvDNode>(maxLong);
+    sz.take<long long>((size_t)N); sz.take<long long>((size_t)N); sz.take<long long>(nchr + 1); sz.take<int>(4); sz.take<WvSlot>(WV_REP * listCap); sz.take<WvSlot>(WV_REP * listCap); sz.take<WvCn>(nCn); sz.take<WvDNode>(maxList2); sz.take<int32_t>(maxList2);
+    sz.take<int32_t>(WV_REP * chCap); sz.take<int32_t>(WV_REP * chCap); sz.take<WvPart>(WV_REP * chCap); sz.take<WvDNode>(maxLong);
     sz.take<WvDNode>(maxList2); sz.take<WvDev>(1); sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
     sz.take<WvNode>(maxLong); sz.take<WvOut>(maxLong); sz.take<int32_t>(maxLong); sz.take<int32_t>(maxLong + WV_EB); sz.take<int32_t>(maxLong); sz.take<WvHead>(maxLong); sz.take<WvCk>(maxChunks); sz.take<WvBest>(maxChunks);
     sz.take<long long>(maxLong); sz.take<int32_t>(maxLong);
@@ -1106,12 +1157,12 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     WvOps* dOps = ws.take<WvOps>(opsCap); WvNode* dNodes = ws.take<WvNode>(maxLong); WvOut* dOut = ws.take<WvOut>(maxLong);
     int32_t* dLong = ws.take<int32_t>(maxLong); int32_t* dBase = ws.take<int32_t>(maxLong + 1);
     int32_t* dFlag = ws.take<int32_t>(maxLong); WvHead* dHead = ws.take<WvHead>(maxLong); WvCk* dCk = ws.take<WvCk>(maxChunks); WvBest* dBest = ws.take<WvBest>(maxChunks);
-    WvRoot* dRoots = ws.take<WvRoot>(maxRoots); uint32_t* dStack = ws.take<uint32_t>((size_t)N); int32_t* dCounts = ws.take<int32_t>((size_t)N);
+    WvRoot* dRoots = ws.take<WvRoot>(maxRoots + WV_REP * rootCap); uint32_t* dStack = ws.take<uint32_t>((size_t)N); int32_t* dCounts = ws.take<int32_t>((size_t)N);
     WvCand* dCands = ws.take<WvCand>((size_t)capCand); double* dKeep = ws.take<double>(nchr); unsigned long long* dNcand = ws.take<unsigned long long>(2);
     int32_t* dOverflow = (int32_t*)(dNcand + 1);
     long long* dP1 = ws.take<long long>((size_t)N); long long* dP2 = ws.take<long long>((size_t)N); long long* dOff = ws.take<long long>(nchr + 1); int* dBad = ws.take<int>(4);
-    WvSlot* dListA = ws.take<WvSlot>(maxLong); WvSlot* dListB = ws.take<WvSlot>(maxLong); WvDNode* dExact = ws.take<WvDNode>(maxList2); int32_t* dExactInd = ws.take<int32_t>(maxList2);
-    int32_t* dChA = ws.take<int32_t>(maxCh); int32_t* dChB = ws.take<int32_t>(maxCh); WvPart* dParts = ws.take<WvPart>(maxCh); WvDNode* dListIn = ws.take<WvDNode>(maxLong);
+    WvSlot* dListA = ws.take<WvSlot>(WV_REP * listCap); WvSlot* dListB = ws.take<WvSlot>(WV_REP * listCap); WvCn* dCn = ws.take<WvCn>(nCn); WvCn* dRootCn = dCn + (size_t)(WV_LB + 2) * WV_REP; WvDNode* dExact = ws.take<WvDNode>(maxList2); int32_t* dExactInd = ws.take<int32_t>(maxList2);
+    int32_t* dChA = ws.take<int32_t>(WV_REP * chCap); int32_t* dChB = ws.take<int32_t>(WV_REP * chCap); WvPart* dParts = ws.take<WvPart>(WV_REP * chCap); WvDNode* dListIn = ws.take<WvDNode>(maxLong);
     WvDNode* dUndec = ws.take<WvDNode>(maxList2); WvDev* dDev = ws.take<WvDev>(1); long long* dOpsOff = ws.take<long long>(maxLong); int32_t* dLim = ws.take<int32_t>(maxLong);
     // a second set for the exact chains that start while the level loop is still running (side stream; slices handed out by running offsets, see exact_launch below)
     LongBufs E; E.nodes = ws.take<WvNode>(maxLong); E.out = ws.take<WvOut>(maxLong); E.list = ws.take<int32_t>(maxLong); E.base = ws.take<int32_t>(maxLong + WV_EB); E.flag = ws.take<int32_t>(maxLong);
@@ -1322,8 +1373,8 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         rootBatches.emplace_back(std::move(hRoots)); hRoots.clear();         // the host copy stays alive until the side stream has been drained
         const std::vector<WvRoot>& B = rootBatches.back();
         CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRoots + rootsUsed, B.data(), B.size() * sizeof(WvRoot), hipMemcpyHostToDevice, ctx->side));
-        hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((B.size() + 63) / 64)), dim3(64), 0, ctx->side, dRoots + rootsUsed, (int)B.size(), dX, dKeep, dStack, dCounts,
-                           dCands, dNcand, capCand, dOverflow, dFgh, fghLen);
+        { WvRootSegs sg; memset(&sg, 0, sizeof sg); sg.n = 1; sg.start[0] = (int)rootsUsed; sg.count[0] = (int)B.size();
+          hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((B.size() + 63) / 64)), dim3(64), 0, ctx->side, dRoots, sg, dX, dKeep, dStack, dCounts, dCands, dNcand, capCand, dOverflow, dFgh, fghLen); }
         rootsUsed += B.size();
         return CANVAS_OK;
     };
@@ -1381,15 +1432,21 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         std::vector<WvRoot> firstRoots(hRoots.begin(), hRoots.end()); hRoots.clear();          // (what flush_roots has launched already stays in front of them)
         size_t rootsLaunched = rootsUsed; unsigned subLaunches = 0;
         const bool subLate = cvx_hook("CANVAS_WV_SUB_LATE") != nullptr, oneSub = cvx_hook("CANVAS_WV_ONE_SUB") != nullptr;      // (experiments)
-        auto launch_subtrees = [&](unsigned upTo) {             // the roots [rootsLaunched, upTo) of the device's list: written by kernels that have completed
-            if (upTo <= rootsLaunched) return;
-            const size_t nr = upTo - rootsLaunched;
-            hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, ((subLaunches++ & 1) && !oneSub) ? ctx->wv_sub2 : ctx->wv_sub, dRoots + rootsLaunched, (int)nr, dX, dKeep, dStack, dCounts, dCands, dNcand, capCand, dOverflow, dFgh, fghLen);      // (a launch lasts as long as its slowest lane: two streams take turns)
-            rootsLaunched = upTo;
+        unsigned devRootsLaunched[WV_REP]; for (int r = 0; r < WV_REP; r++) devRootsLaunched[r] = 0;
+        auto launch_subtrees = [&](unsigned upTo, const unsigned* repR) {   // the host's roots [rootsLaunched, upTo) and what the replicas of the level loop have gained: written by kernels that have completed
+            WvRootSegs sg; memset(&sg, 0, sizeof sg); size_t nr = 0;
+            if (upTo > rootsLaunched) { sg.start[sg.n] = (int)rootsLaunched; sg.count[sg.n] = (int)(upTo - rootsLaunched); nr += upTo - rootsLaunched; sg.n++; rootsLaunched = upTo; }
+            for (int r = 0; r < WV_REP && repR; r++) {
+                const unsigned have = std::min<unsigned>(repR[r], (unsigned)rootCap);
+                if (have > devRootsLaunched[r]) { sg.start[sg.n] = (int)(maxRoots + (size_t)r * rootCap + devRootsLaunched[r]); sg.count[sg.n] = (int)(have - devRootsLaunched[r]); nr += have - devRootsLaunched[r]; sg.n++; devRootsLaunched[r] = have; }
+            }
+            if (nr == 0) return;
+            hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, ((subLaunches++ & 1) && !oneSub) ? ctx->wv_sub2 : ctx->wv_sub, dRoots, sg, dX, dKeep, dStack, dCounts, dCands, dNcand, capCand, dOverflow, dFgh, fghLen);      // (a launch lasts as long as its slowest lane: two streams take turns)
         };
         if (firstRoots.size() + rootsUsed > maxRoots) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: root list overflow");
         if (!firstRoots.empty()) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRoots + rootsUsed, firstRoots.data(), firstRoots.size() * sizeof(WvRoot), hipMemcpyHostToDevice, ctx->stream));
         hdev.nRoots = (unsigned)(rootsUsed + firstRoots.size());
+        CANVAS_HIP_TRY(ctx, hipMemsetAsync(dRootCn, 0, WV_REP * sizeof(WvCn), ctx->stream));          // (the replicas' root counters run over all lists of the call)
         std::vector<WvDNode> hUndec;
         // ---- the nodes whose coefficient may survive HardThresh need the exact chain — one wave of dependent FP64 operations per node, 10 ms for the longest of a WGS sample —
         // but nothing waits for its result: the chains of the nodes a batch of levels has found start on the side stream while the next levels run.  Every launch takes slices
@@ -1499,7 +1556,8 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             hdev.exactReported = (unsigned)exactSeen;
             *hdevIn = hdev;
             CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dDev, hdevIn, sizeof hdev, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_wv_list_init, dim3((unsigned)((nIn + 255) / 256)), dim3(256), 0, ctx->stream, dListIn, nIn, dListA, dChA, dDev, (unsigned)maxLong, (unsigned)maxCh);
+            CANVAS_HIP_TRY(ctx, hipMemsetAsync(dCn, 0, (size_t)(WV_LB + 2) * WV_REP * sizeof(WvCn), ctx->stream));
+            hipLaunchKernelGGL(k_wv_list_init, dim3((unsigned)((nIn + 255) / 256)), dim3(256), 0, ctx->stream, dListIn, nIn, dListA, dChA, dDev, dCn, (unsigned)listCap, (unsigned)chCap);
             hipEvent_t ev[2] = {ctx->side_ev, ctx->side_ev2};
             static const int firstBatch = [] { const char* e = cvx_hook("CANVAS_WV_FIRST_BATCH"); const int v = e ? atoi(e) : 16; return v >= 2 && v <= 64 && !(v & 1) ? v : 16; }();
             int lbOf[2] = {0, 0}, lbNext = firstBatch; unsigned seqOf[2] = {0, 0};       // (16, 32, 64 ... levels.  Smaller first batches start the longest chain earlier but split the chains over several launches of ONE in-order stream, which then run one after the other: 2, 4, 8 ... was 9 ms slower)
@@ -1507,8 +1565,8 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
                 const int lb = lbNext; lbOf[slot] = lb; lbNext = std::min(64, lbNext * 2);
                 for (int it = 0; it < lb; it++)
                     hipLaunchKernelGGL(k_wv_level, dim3(levelGrid), dim3(256), 0, ctx->stream, (it & 1) ? dListB : dListA, (it & 1) ? dChB : dChA, (it & 1) ? dListA : dListB, (it & 1) ? dChA : dChB, dParts,
-                                       dDev, it, (unsigned)maxLong, (unsigned)maxCh, (unsigned)maxList2, dP1, dP2, dOff, dKeep, dRoots, (unsigned)maxRoots, dExact, dExactInd, dUndec, dCounts, WV_LONG);
-                hipLaunchKernelGGL(k_wv_batch_end, dim3(1), dim3(256), 0, ctx->stream, dDev, lb, dExact, dExactInd, hdevRep[slot], hExactPin[slot], hExactIndPin[slot], (unsigned)maxLong, ++batchSeq);
+                                       dDev, dCn, dRootCn, it, (unsigned)listCap, (unsigned)chCap, (unsigned)maxList2, dP1, dP2, dOff, dKeep, dRoots + maxRoots, (unsigned)rootCap, dExact, dExactInd, dUndec, dCounts, WV_LONG);
+                hipLaunchKernelGGL(k_wv_batch_end, dim3(1), dim3(256), 0, ctx->stream, dDev, dCn, dRootCn, lb, dExact, dExactInd, hdevRep[slot], hExactPin[slot], hExactIndPin[slot], (unsigned)maxLong, ++batchSeq);
                 seqOf[slot] = batchSeq;
                 CANVAS_HIP_TRY(ctx, hipEventRecord(ev[slot], ctx->stream));
                 return CANVAS_OK;
@@ -1539,7 +1597,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
                 { const size_t cnt = hdev.nExact > hdev.exactReported ? std::min<size_t>(hdev.nExact - hdev.exactReported, maxLong) : 0;
                   hExactNew.assign(hExactPin[slot], hExactPin[slot] + cnt); hExactIndNew.assign(hExactIndPin[slot], hExactIndPin[slot] + cnt); exactSeen += cnt; }
                 if (pending) { rc = enqueue_batch(slot); if (rc) return rc; }                 // (batch k + 2; batch k + 1 is running)
-                if (!subLate) launch_subtrees(std::min<unsigned>(hdev.nRoots, (unsigned)maxRoots));         // (the host's first roots were uploaded on the main stream in front of batch 0: complete as well)
+                if (!subLate) launch_subtrees(std::min<unsigned>(hdev.nRoots, (unsigned)maxRoots), hdev.nRootsR);         // (the host's first roots were uploaded on the main stream in front of batch 0: complete as well)
                 const double tw2 = now(); const size_t nNew = hExactNew.size();
                 if (!hExactNew.empty()) { rc = exact_launch(false); if (rc) return rc; }
                 if (trace && k == 0) fprintf(stderr, "canvas_wavelets: first report: nodes per level %u %u %u %u %u %u, chunks %u %u %u %u, undecided %u, roots %u, exact %u\n", hdev.cnt[0], hdev.cnt[1], hdev.cnt[2], hdev.cnt[3], hdev.cnt[4], hdev.cnt[5], hdev.nch[0], hdev.nch[1], hdev.nch[2], hdev.nch[3], hdev.nUndec, hdev.nRoots, hdev.nExact);
@@ -1597,14 +1655,14 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         // on the main stream (the side stream belongs to the chains); then everything the chains have found
         while (exactSeen < hdev.nExact) { rc = fetch_exact(hdev.nExact); if (rc) return rc; rc = exact_launch(true); if (rc) return rc; }
         if (!hDeferred.empty()) { hExactNew.swap(hDeferred); hExactIndNew.swap(hDeferredInd); rc = exact_launch(true); if (rc) return rc; }
-        launch_subtrees(hdev.nRoots);
+        launch_subtrees(hdev.nRoots, hdev.nRootsR);
         rc = harvest(); if (rc) return rc;
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->wv_sub));
         CANVAS_HIP_TRY(ctx, hipStreamSynchronize(ctx->wv_sub2));
         if (timing) fprintf(stderr, "canvas_wavelets: %lld exact chains, %lld steps in all, longest %lld (device list %u entries, %zu seen)\n", nExactChains, chainSteps, chainLongest, hdev.nExact, exactSeen);
         tcExact = now() - tcA;
-        if (timing) fprintf(stderr, "canvas_wavelets: closed-form levels %.4f s, undecided nodes %.4f s, rest of the exact chains + subtrees %.4f s (%u roots)\n", tcLevels, tcUndec, tcExact, hdev.nRoots);
+        if (timing) fprintf(stderr, "canvas_wavelets: closed-form levels %.4f s, undecided nodes %.4f s, rest of the exact chains + subtrees %.4f s (%u roots)\n", tcLevels, tcUndec, tcExact, [&] { unsigned t = hdev.nRoots; for (int r = 0; r < WV_REP; r++) t += hdev.nRootsR[r]; return t; }());
         rootsUsed = hdev.nRoots;
         cur.clear();
     }
