@@ -130,3 +130,35 @@ def test_factor_of_three_statistics_on_the_device_equal_the_host_thread(monkeypa
             exp = O.wavelets_genome(per, window=window)
             got = _run(cv, per, window=window)
             assert [g.tolist() for g in got] == [e.tolist() for e in exp]
+
+
+def test_tile_edges_of_the_prefix_sums_and_the_stretch_medians(monkeypatch):
+    """Round 6: the prefix sums run over tiles of 1 024 bins (carries from the tiles in front, more than 1 024 of them for a chromosome above a million bins) and the
+    medians of the chromosomes / healing stretches over tiles of 4 096 integers of all stretches at once: chromosome lengths on and around the tile sizes, a chromosome
+    of 1.2 M bins, chromosomes below MinSize between them; the host-comparison hook checks every device median against the host's."""
+    monkeypatch.setenv("CANVAS_TEST_HOOKS", "1"); monkeypatch.setenv("CANVAS_WV_VAR_CHECK", "1")
+    cv = get_canvas()
+    rng = np.random.RandomState(66)
+    lengths = [1_200_000, 1025, 1024, 1, 4096, 2, 4097, 5000, 8192, 9]
+    per = [_coverage(rng, n, mean=100.0, wave=0.03) for n in lengths]
+    exp = O.wavelets_genome(per, is_germline=True, window=1000)
+    got = _run(cv, per, is_germline=True, window=1000)
+    for c in range(len(per)):
+        assert got[c].tolist() == exp[c].tolist(), (c, lengths[c])
+    # the same list through the per-workgroup medians (the path of a coverage that is not two-decimal text)
+    monkeypatch.setenv("CANVAS_WV_MEDIAN_PER_WG", "1")
+    got2 = _run(cv, per, is_germline=True, window=1000)
+    for c in range(len(per)):
+        assert got2[c].tolist() == exp[c].tolist(), (c, lengths[c])
+
+
+def test_a_coverage_without_two_decimal_values_takes_the_other_medians():
+    """x = k / 100 fails for some bins: no integers, so the chromosome medians come from the per-workgroup kernel after the first synchronisation and every long node
+    takes the chain; the result is still the oracle's."""
+    cv = get_canvas()
+    rng = np.random.RandomState(67)
+    per = [_coverage(rng, n) + 0.001 * (np.arange(n) % 7 == 0) for n in (30_000, 4_000)]
+    exp = O.wavelets_genome(per, is_germline=False, window=1000)
+    got = _run(cv, per, is_germline=False, window=1000)
+    for c in range(2):
+        assert got[c].tolist() == exp[c].tolist()
