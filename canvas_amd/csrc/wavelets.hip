@@ -1131,6 +1131,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
     // the level loop's lists are WV_REP replicas (see WvCn): a replica takes an eighth of the worst case of the whole level (twice its even share; whoever appends is picked
     // by the chunk's number, which deals the appends out evenly) — but never less than one node can need
     const size_t listCap = maxLong / 8 + 1024, chCap = std::max(maxCh / 8, (size_t)N / WV_CH + 16) + 4096, rootCap = maxRoots / 8 + 4096, nCn = (size_t)(WV_LB + 3) * WV_REP;
+    if (maxRoots + WV_REP * rootCap > 0x7FFFFFF0ull || WV_REP * chCap > 0x7FFFFFF0ull) CANVAS_FAIL(ctx, CANVAS_ERR_INVALID, "canvas_wavelets: bin count out of range");      // (the replicas' stretches are addressed with 32-bit numbers)
     const unsigned long long capCand = (unsigned long long)N + 16;
     WsSizer sz;
     const size_t opsCap = 5 * (size_t)N;                                  // the exact chains of nodes of several levels (which overlap in position) run side by side: [N, 5 N); the first N belong to the level loop's own passes
