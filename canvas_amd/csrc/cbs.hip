@@ -2690,9 +2690,9 @@ static thread_local ChromClock tlClock;
 static inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
 static inline bool perm_use_rp(int n) { static const bool off = cvx_hook("CANVAS_CBS_NO_RP") != nullptr; static const int minN = cvx_hook("CANVAS_CBS_RP_MIN_N") ? atoi(cvx_hook("CANVAS_CBS_RP_MIN_N")) : PERM_RP_MIN_N; return !off && n >= minN && n <= PERM_RP_MAX_N; }
 // cached: the batch reads its draws out of the chromosome's stream — no draw buffers, so a batch of a long segment could be as large as the stopping rule asks for (a 234 k-bin
-// segment: 1024 permutations instead of 286).  Measured (CANVAS_CBS_TARGET_ELEMS=268435456): the tumour / normal flow's CBS 0.436 against 0.438 s, the germline call 0.061
+// segment: 1024 permutations instead of 286).  Measured with a switch that has been removed again (268 435 456 elements per cached batch): the tumour / normal flow's CBS 0.436 against 0.438 s, the germline call 0.061
 // against 0.047 s — the long-running workgroups of the larger batches keep the short arc / tail kernels of the other chromosomes waiting for a CU.  The size stays.
-static inline long long perm_target_elems(bool cached) { static const long long c = cvx_hook("CANVAS_CBS_TARGET_ELEMS") ? atoll(cvx_hook("CANVAS_CBS_TARGET_ELEMS")) : (long long)PERM_TARGET_ELEMS; return cached ? c : (long long)PERM_TARGET_ELEMS; }
+static inline long long perm_target_elems(bool /*cached*/) { return (long long)PERM_TARGET_ELEMS; }
 static inline int perm_max_batch(int n, bool cached = false) { return perm_use_rp(n) ? (int)std::max<long long>(8, std::min<long long>(PERM_RP_MAXB, perm_target_elems(cached) / n)) : (int)std::max<long long>(8, std::min<long long>(256, PERM_TARGET_ELEMS / n)); }
 static inline int perm_rp_wgs(int n) { PermReq::RpPlan P; rp_plan(n, P); const size_t per = (size_t)P.stride * 4; return (int)std::max<size_t>(64, std::min<size_t>(PERM_RP_GRID, PERM_RP_SCRATCH_BYTES / per)); }
 // the scratch of k_perm_rp's workgroups for segments of up to nMax bins: what perm_rp_wgs() workgroups of the LONGEST plan take, never more than PERM_RP_SCRATCH_BYTES — a
@@ -2781,9 +2781,7 @@ static int32_t perm_loop_gpu(PermGpu& PG, const double* gd, int n, double tss, u
     // ... but no more than four times what nrejc + 1 rejections need at a rejection rate of one in four, and no more than one round of the persistent workgroups (a batch of
     // 1 024 permutations is two rounds of 512 workgroups: two batches of 512 take as long and the second is only computed if the rule is still running).  Three in four loops of
     // the tumour / normal pair end "not significant" inside their first batch: with sbdry alone 11 % of all permuted elements were never looked at (profiles/r06_loop_waste.txt)
-    { static const bool oldB0 = cvx_hook("CANVAS_CBS_B0_STOP") != nullptr; static const int fac = cvx_hook("CANVAS_CBS_B0_FACTOR") ? atoi(cvx_hook("CANVAS_CBS_B0_FACTOR")) : 4, cap = cvx_hook("CANVAS_CBS_B0_CAP") ? atoi(cvx_hook("CANVAS_CBS_B0_CAP")) : 512;
-      if (!oldB0) B = std::min(B, std::max(64, std::min(cap, fac * (nrejc + 1)))); }
-    if (cvx_hook("CANVAS_CBS_B0")) B = std::min(maxB, atoi(cvx_hook("CANVAS_CBS_B0")));
+    B = std::min(B, std::max(64, std::min(512, 4 * (nrejc + 1))));
     outcome = 1;
     while (np < nPerm) {
         int nb = (int)std::min<uint32_t>((uint32_t)B, nPerm - np);

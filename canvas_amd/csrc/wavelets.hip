@@ -1432,7 +1432,6 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
         // the short chromosomes placed above are the first roots of the device-side list
         std::vector<WvRoot> firstRoots(hRoots.begin(), hRoots.end()); hRoots.clear();          // (what flush_roots has launched already stays in front of them)
         size_t rootsLaunched = rootsUsed; unsigned subLaunches = 0;
-        const bool subLate = cvx_hook("CANVAS_WV_SUB_LATE") != nullptr, oneSub = cvx_hook("CANVAS_WV_ONE_SUB") != nullptr;      // (experiments)
         unsigned devRootsLaunched[WV_REP]; for (int r = 0; r < WV_REP; r++) devRootsLaunched[r] = 0;
         auto launch_subtrees = [&](unsigned upTo, const unsigned* repR) {   // the host's roots [rootsLaunched, upTo) and what the replicas of the level loop have gained: written by kernels that have completed
             WvRootSegs sg; memset(&sg, 0, sizeof sg); size_t nr = 0;
@@ -1442,7 +1441,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
                 if (have > devRootsLaunched[r]) { sg.start[sg.n] = (int)(maxRoots + (size_t)r * rootCap + devRootsLaunched[r]); sg.count[sg.n] = (int)(have - devRootsLaunched[r]); nr += have - devRootsLaunched[r]; sg.n++; devRootsLaunched[r] = have; }
             }
             if (nr == 0) return;
-            hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, ((subLaunches++ & 1) && !oneSub) ? ctx->wv_sub2 : ctx->wv_sub, dRoots, sg, dX, dKeep, dStack, dCounts, dCands, dNcand, capCand, dOverflow, dFgh, fghLen);      // (a launch lasts as long as its slowest lane: two streams take turns)
+            hipLaunchKernelGGL(k_wv_subtree, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, (subLaunches++ & 1) ? ctx->wv_sub2 : ctx->wv_sub, dRoots, sg, dX, dKeep, dStack, dCounts, dCands, dNcand, capCand, dOverflow, dFgh, fghLen);      // (a launch lasts as long as its slowest lane: two streams take turns)
         };
         if (firstRoots.size() + rootsUsed > maxRoots) CANVAS_FAIL(ctx, CANVAS_ERR_HIP, "canvas_wavelets: root list overflow");
         if (!firstRoots.empty()) CANVAS_HIP_TRY(ctx, hipMemcpyAsync(dRoots + rootsUsed, firstRoots.data(), firstRoots.size() * sizeof(WvRoot), hipMemcpyHostToDevice, ctx->stream));
@@ -1498,7 +1497,6 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
             std::vector<size_t> order(ne);
             for (size_t i = 0; i < ne; i++) order[i] = i;
             std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return hExactIndNew[x] != hExactIndNew[y] ? hExactIndNew[x] > hExactIndNew[y] : x < y; });
-            if (cvx_hook("CANVAS_WV_DEBUG_CHAINS")) ne = std::min<size_t>(ne, (size_t)atoi(cvx_hook("CANVAS_WV_DEBUG_CHAINS")));      // timing experiment: only the longest chains (the result is then wrong)
             for (size_t a = 0; a < ne;) {
                 size_t nn = 0; long long used = 0; size_t chunks = 0;
                 while (a + nn < ne && eNodes + nn < maxLong && eBase + nn + 2 <= maxLong + WV_EB) {
@@ -1598,7 +1596,7 @@ int32_t cvx_wavelets_masked(canvas_ctx* ctx, int32_t nchr, const double* d_cov, 
                 { const size_t cnt = hdev.nExact > hdev.exactReported ? std::min<size_t>(hdev.nExact - hdev.exactReported, maxLong) : 0;
                   hExactNew.assign(hExactPin[slot], hExactPin[slot] + cnt); hExactIndNew.assign(hExactIndPin[slot], hExactIndPin[slot] + cnt); exactSeen += cnt; }
                 if (pending) { rc = enqueue_batch(slot); if (rc) return rc; }                 // (batch k + 2; batch k + 1 is running)
-                if (!subLate) launch_subtrees(std::min<unsigned>(hdev.nRoots, (unsigned)maxRoots), hdev.nRootsR);         // (the host's first roots were uploaded on the main stream in front of batch 0: complete as well)
+                launch_subtrees(std::min<unsigned>(hdev.nRoots, (unsigned)maxRoots), hdev.nRootsR);         // (the host's first roots were uploaded on the main stream in front of batch 0: complete as well)
                 const double tw2 = now(); const size_t nNew = hExactNew.size();
                 if (!hExactNew.empty()) { rc = exact_launch(false); if (rc) return rc; }
                 if (trace && k == 0) fprintf(stderr, "canvas_wavelets: first report: nodes per level %u %u %u %u %u %u, chunks %u %u %u %u, undecided %u, roots %u, exact %u\n", hdev.cnt[0], hdev.cnt[1], hdev.cnt[2], hdev.cnt[3], hdev.cnt[4], hdev.cnt[5], hdev.nch[0], hdev.nch[1], hdev.nch[2], hdev.nch[3], hdev.nUndec, hdev.nRoots, hdev.nExact);
