@@ -620,6 +620,20 @@ __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict_
     uint32_t f[CBLK / 256], inc[CBLK / 256];
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) { const int64_t i = base + j * 256 + threadIdx.x; f[j] = (i < n) ? flags[i] : 0; }
+    // the five columns of EVERY bin of the block are requested now, whatever its flag (2 % of them are dropped): a load under `if (flag)` is waited for where the condition
+    // ends, one element at a time, and the block offset below (a few thousand counts + two barriers) runs while these travel
+    int32_t lc[CBLK / 256], lg[CBLK / 256], ls[CBLK / 256], le[CBLK / 256]; float lv[CBLK / 256];
+    if (base + CBLK <= n) {
+#pragma unroll
+        for (int j = 0; j < CBLK / 256; j++) { const int64_t i = base + j * 256 + threadIdx.x; lc[j] = src.chr[i]; lg[j] = src.gc[i]; ls[j] = src.start[i]; le[j] = src.stop[i]; lv[j] = src.count[i]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CBLK / 256; j++) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            lc[j] = 0; lg[j] = 0; ls[j] = 0; le[j] = 0; lv[j] = 0.0f;
+            if (i < n) { lc[j] = src.chr[i]; lg[j] = src.gc[i]; ls[j] = src.start[i]; le[j] = src.stop[i]; lv[j] = src.count[i]; }
+        }
+    }
     const uint32_t blockOff = cf_block_offset<true>(A.dBlk, (int)blockIdx.x, sh16);          // (its barriers also publish lcnt / sKeepGc)
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) { inc[j] = wave_inclusive_scan_u32(f[j]); if (lane_id() == 63) shW[j][threadIdx.x >> 6] = inc[j]; }
@@ -634,13 +648,12 @@ __global__ void __launch_bounds__(256) k_cf_scatter_ab(const CfArgs* __restrict_
         for (int k = 0; k < 4; k++) { const uint32_t v = shW[j][k]; if (k < w) woff += v; tot += v; }
         myGc[j] = -1;
         if (f[j]) {
-            const int64_t i = base + j * 256 + threadIdx.x;
             const uint32_t d = running + woff + inc[j] - 1;
             // out-of-range input is reported through D->bad (k_cf_flags_ab) and nothing is returned; the scratch copy holds clamped values so that no later kernel indexes past a table
-            const int32_t c0 = src.chr[i], g0 = src.gc[i];
+            const int32_t c0 = lc[j], g0 = lg[j];
             const int32_t g = (uint32_t)g0 > 100u ? 100 : g0, c = (uint32_t)c0 >= (uint32_t)nchr ? 0 : c0;
-            const float v = src.count[i];
-            dst.chr[d] = c; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = (uint8_t)g; dst.count[d] = v;
+            const float v = lv[j];
+            dst.chr[d] = c; dst.start[d] = ls[j]; dst.stop[d] = le[j]; dst.gc[d] = (uint8_t)g; dst.count[d] = v;
             if (group && isAuto[c] && sKeepGc[g]) { myGc[j] = g; myKey[j] = key_of_float(v); myRank[j] = atomicAdd(&lcnt[g], 1u); }
         }
         running += tot;
@@ -1444,6 +1457,19 @@ __global__ void __launch_bounds__(256) k_cf_scatter_final(const CfArgs* __restri
     uint32_t f[CBLK / 256], inc[CBLK / 256];
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) { const int64_t i = base + j * 256 + threadIdx.x; f[j] = (i < n) ? flags[i] : 0; }
+    // (as in k_cf_scatter_ab: every bin's columns requested at once, in front of the block offset)
+    int32_t lc[CBLK / 256], lg[CBLK / 256], ls[CBLK / 256], le[CBLK / 256]; float lv[CBLK / 256];
+    if (base + CBLK <= n) {
+#pragma unroll
+        for (int j = 0; j < CBLK / 256; j++) { const int64_t i = base + j * 256 + threadIdx.x; lc[j] = src.chr[i]; lg[j] = src.gc[i]; ls[j] = src.start[i]; le[j] = src.stop[i]; lv[j] = src.count[i]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CBLK / 256; j++) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            lc[j] = 0; lg[j] = 0; ls[j] = 0; le[j] = 0; lv[j] = 0.0f;
+            if (i < n) { lc[j] = src.chr[i]; lg[j] = src.gc[i]; ls[j] = src.start[i]; le[j] = src.stop[i]; lv[j] = src.count[i]; }
+        }
+    }
     const uint32_t blockOff = cf_block_offset<false>(A.dBlkF, (int)blockIdx.x, sh16);       // (its barriers also publish sMed)
 #pragma unroll
     for (int j = 0; j < CBLK / 256; j++) { inc[j] = wave_inclusive_scan_u32(f[j]); if (lane_id() == 63) shW[j][threadIdx.x >> 6] = inc[j]; }
@@ -1456,12 +1482,11 @@ __global__ void __launch_bounds__(256) k_cf_scatter_final(const CfArgs* __restri
 #pragma unroll
         for (int k = 0; k < 4; k++) { const uint32_t v = shW[j][k]; if (k < w) woff += v; tot += v; }
         if (f[j]) {
-            const int64_t i = base + j * 256 + threadIdx.x;
             const uint32_t d = running + woff + inc[j] - 1;
-            const int32_t g = src.gc[i];
-            float v = src.count[i];
+            const int32_t g = lg[j];
+            float v = lv[j];
             if (normalise) { const double median = sMed[g]; if (median > 0) v = (float)(globalMedian * (double)v / median); }        // CanvasClean.cs:190-195, applied on the way out
-            dst.chr[d] = src.chr[i]; dst.start[d] = src.start[i]; dst.stop[d] = src.stop[i]; dst.gc[d] = g; dst.count[d] = v;
+            dst.chr[d] = lc[j]; dst.start[d] = ls[j]; dst.stop[d] = le[j]; dst.gc[d] = g; dst.count[d] = v;
         }
         running += tot;
     }
